@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — edge-message updates/sec per sweep on the 10M-edge Gaussian grid (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one full sum-product sweep (every variable→factor message, every factor→variable message,
+every marginal) over the N x N grid held by each rank, i.e. one `update_marginals!` of the reference
+(src/inference_engine.jl:559-632) in the device's flooding order.  Weak scaling: every rank owns one
+1415 x 1415 strip (10,005,465 bipartite edges) of a (1415*N) x 1415 grid; messages on the cut rows are
+exchanged once per sweep (RCCL over xGMI through torch.distributed).  value = message updates of all
+ranks / max-over-ranks time.  Inputs are resident in HBM before the timed region.
+
+Rank 0 prints ONE JSON line carrying `roofline` (dominant kernel, hipEvent-timed on the library's stream)
+and, at N = 1, `cpu_baseline` (the CPU restatement of the reference scheduler on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+BYTES_PER_UPDATE = 32          # read the 16-byte payload once + write it once, f64 scalar Gaussian
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--grid", type=int, default=1415, help="N: each rank holds an N x N grid strip (1415 -> 10,005,465 edges)")
+    ap.add_argument("--schedule", choices=["flooding", "fused"], default=os.environ.get("CX_BENCH_SCHEDULE", "fused"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-grid", type=int, default=768, help="grid side of the bounded CPU sample")
+    ap.add_argument("--seed", type=int, default=1234)
+    return ap.parse_args()
+
+
+def cpu_baseline(sample_n: int, seed: int) -> dict:
+    """The reference's CPU path, restated (oracle/cortex_ref.c): one `update_marginals!` over all variables of a
+    seeded sample grid, single thread (the reference has no threading).  Checker code, timed as a baseline only."""
+    from oracle import ref
+    import cortex.jl_amd as cx
+    from tests.helpers import engine_oracle_from_model
+
+    model = cx.synth.gaussian_grid(sample_n, sample_n, seed=seed)
+    E = engine_oracle_from_model(model)
+    g = ref.FloodGraph(model.edge_var, model.edge_fac, model.factor_ids, model.factor_var)
+    pe = g.partner >= 0
+    E.set_messages_to_variable(g.edge_var[pe], g.edge_fac[pe], np.zeros(int(pe.sum())), np.full(int(pe.sum()), 1e6))
+    total_upd, total_t, reps = 0, 0.0, 0
+    while total_t < 10.0 and reps < 50:
+        if reps > 0:  # a reference user re-sets the priors to make them fresh again before the next iteration
+            E.set_messages_to_variable(model.prior_var, model.prior_fac, model.prior_mean, model.prior_variance)
+        c0 = E.counters()[0]
+        t0 = time.perf_counter()
+        E.update_marginals(model.x_ids)
+        total_t += time.perf_counter() - t0
+        total_upd += E.counters()[0] - c0
+        reps += 1
+    return {"value": total_upd / total_t, "unit": "edge-message updates/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} update_marginals! sweeps of a {sample_n}x{sample_n} Gaussian grid ({model.n_edges} edges), "
+                      f"restated reference scheduler (sequential, readiness bits), {total_t:.1f} s of CPU work"}
+
+
+def main():
+    args = parse()
+    import torch
+    import cortex.jl_amd as cx
+    from cortex.jl_amd import _lib as L
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP sweep has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    N = args.grid
+    schedule = L.SCHED_FUSED if (args.schedule == "fused" and world == 1) else L.SCHED_FLOODING
+    dev = cx.DeviceGraph(device=local_rank, schedule=schedule, marginals_in_sweep=True)
+    stream = torch.cuda.current_stream()
+    dev.set_stream(stream.cuda_stream)
+
+    if world == 1:
+        model = cx.synth.gaussian_grid(N, N, seed=args.seed)
+        cx.synth.load_into_device(model, dev, seed_variance=1e6)
+        exchange = None
+    else:
+        from cortex.jl_amd import partition
+        part = partition.grid_strip(N, N, rank, world, seed=args.seed)
+        cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
+        exchange = partition.HaloExchange(dev, part, dist, torch)
+    st = dev.stats()
+    updates_per_step = st["n_messages_per_sweep"]
+
+    def step():
+        if exchange is None:
+            dev.sweep(1)
+        else:
+            exchange.sweep()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    dev.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        u = torch.tensor([updates_per_step], dtype=torch.float64, device="cuda")
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        total_updates_per_step = float(u.item())
+    else:
+        total_updates_per_step = float(updates_per_step)
+
+    # dominant kernel: hipEvent durations recorded around every launch of the timed region, on the library's stream
+    kern = {}
+    for k in (L.KERNEL_FUSED, L.KERNEL_VAR_TO_FACTOR, L.KERNEL_FACTOR_TO_VAR):
+        ms, n = dev.profile_read(k)
+        if n:
+            kern[dev.kernel_name(k)] = (ms, n, k)
+    res = dev.residual()
+
+    if rank == 0:
+        value = total_updates_per_step * args.steps / elapsed
+        dom = max(kern.items(), key=lambda kv: kv[1][0])
+        dom_name, (dom_ms, dom_n, dom_id) = dom
+        # algorithmic bytes per launch: §8d's 32 B per directed message update x the updates one launch performs
+        if dom_id == L.KERNEL_FUSED:
+            upd_per_launch = updates_per_step
+        else:
+            upd_per_launch = updates_per_step / 2
+        avg_s = dom_ms / dom_n / 1e3
+        achieved = upd_per_launch * BYTES_PER_UPDATE / avg_s / 1e9
+        out = {
+            "metric": "edge-message updates/sec per sweep, 10M-edge Gaussian grid",
+            "value": value, "unit": "edge-message updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C4: {N}x{N} 2-D Gaussian grid loopy BP per GPU ({st['n_edges']} bipartite edges, "
+                                   f"{updates_per_step} directed message updates + {st['n_variables']} marginals per sweep)",
+                       "schedule": args.schedule if world == 1 else "flooding+halo", "partition": f"{world} row strips",
+                       "seed": args.seed},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": dom_ms / dom_n,
+                         "launches": dom_n,
+                         "algorithmic_bytes_per_launch": upd_per_launch * BYTES_PER_UPDATE,
+                         "all_kernels_ms": {k: v[0] / v[1] for k, v in kern.items()}},
+            "hbm_roofline_frac_end_to_end": value * BYTES_PER_UPDATE / 1e9 / (HBM_PEAK_GBS * world),
+            "residual_after_run": res,
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(traffic_file):
+            try:
+                tr = json.load(open(traffic_file))
+                if tr.get("kernel") == dom_name:
+                    out["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_grid, args.seed)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,665 @@
+// cx_api.hip — host side of libcortex_hip.so: the C ABI of include/cortex_hip.h.
+//
+// Flattens the bipartite factor graph once (reference: the accessor loops of
+// src/inference_engine.jl:228-247 and src/dependencies.jl:5-126 over
+// ext/BipartiteFactorGraphsExt/BipartiteFactorGraphsExt.jl:22-48) into a CSR edge table sorted by
+// (variable id, factor id), keeps Gaussian messages resident in HBM, and launches the kernels of
+// cx_kernels.hip.  No exception leaves this file; every entry point returns a status.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <numeric>
+
+#include "cx_internal.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+int32_t fail(cx_handle *h, int32_t code, const std::string &msg) {
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define CX_HIP(h, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(h, e_ == hipErrorOutOfMemory ? CX_ERR_OUT_OF_MEMORY : CX_ERR_DEVICE,     \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                      \
+    } while (0)
+
+#define CX_REQUIRE(h, cond, code, msg) \
+    do { if (!(cond)) return fail(h, code, msg); } while (0)
+
+template <class T>
+int32_t dev_alloc(cx_handle *h, T **p, int64_t count) {
+    *p = nullptr;
+    if (count <= 0) count = 1;
+    CX_HIP(h, hipMalloc((void **)p, (size_t)count * sizeof(T)));
+    h->device_bytes += count * (int64_t)sizeof(T);
+    return CX_OK;
+}
+
+template <class T>
+int32_t dev_upload(cx_handle *h, T **p, const std::vector<T> &v) {
+    int32_t rc = dev_alloc(h, p, (int64_t)v.size());
+    if (rc != CX_OK) return rc;
+    if (!v.empty()) CX_HIP(h, hipMemcpyAsync(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    return CX_OK;
+}
+
+void dev_free_all(cx_handle *h) {
+    void *ptrs[] = {h->d_var_off, h->d_partner, h->d_edge_var, h->d_blk, h->d_big, h->d_big_tmp_off, h->d_big_edges,
+                    h->d_big_tmp, h->d_var_flags, h->d_q, h->d_a, h->d_b, h->d_sq, h->d_sa, h->d_sb, h->d_f2v, h->d_v2f,
+                    h->d_marg, h->d_f2v_alt, h->d_prev, h->d_scratch, h->d_send_edges, h->d_recv_edges, h->d_send_buf,
+                    h->d_recv_buf, h->d_stage};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    h->d_var_off = h->d_partner = h->d_edge_var = h->d_blk = h->d_big = h->d_big_tmp_off = h->d_big_edges = nullptr;
+    h->d_big_tmp = nullptr; h->d_var_flags = nullptr;
+    h->d_q = h->d_a = h->d_b = h->d_sq = h->d_sa = h->d_sb = nullptr;
+    h->d_f2v = h->d_v2f = h->d_marg = h->d_f2v_alt = h->d_prev = nullptr;
+    h->d_scratch = nullptr; h->d_send_edges = h->d_recv_edges = nullptr; h->d_send_buf = h->d_recv_buf = nullptr;
+    h->d_stage = nullptr; h->stage_bytes = 0; h->device_bytes = 0;
+}
+
+int32_t ensure_stage(cx_handle *h, int64_t bytes) {
+    if (bytes <= h->stage_bytes) return CX_OK;
+    if (h->d_stage) { CX_HIP(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_stage); h->d_stage = nullptr; }
+    int64_t want = std::max<int64_t>(bytes, 1 << 20);
+    CX_HIP(h, hipMalloc(&h->d_stage, (size_t)want));
+    h->stage_bytes = want;
+    return CX_OK;
+}
+
+// (variable_id, factor_id) -> edge index; edges are sorted by (variable, factor)
+int64_t find_edge(const cx_handle *h, int64_t var_id, int64_t fac_id) {
+    auto it = std::lower_bound(h->var_ids.begin(), h->var_ids.end(), var_id);
+    if (it == h->var_ids.end() || *it != var_id) return -1;
+    int64_t v = it - h->var_ids.begin();
+    auto b = h->edge_fac_id.begin() + h->var_off[v], e = h->edge_fac_id.begin() + h->var_off[v + 1];
+    auto jt = std::lower_bound(b, e, fac_id);
+    if (jt == e || *jt != fac_id) return -1;
+    return jt - h->edge_fac_id.begin();
+}
+
+int64_t find_var(const cx_handle *h, int64_t var_id) {
+    auto it = std::lower_bound(h->var_ids.begin(), h->var_ids.end(), var_id);
+    if (it == h->var_ids.end() || *it != var_id) return -1;
+    return it - h->var_ids.begin();
+}
+
+const double kNaN = std::numeric_limits<double>::quiet_NaN();
+const double kInf = std::numeric_limits<double>::infinity();
+
+// boundary form -> storage (natural) form
+bool to_natural(int32_t form, const double *p, double2 *out) {
+    switch (form) {
+    case CX_FORM_MOMENT:
+        if (std::isnan(p[1])) { *out = make_double2(kNaN, kNaN); return true; }
+        if (p[1] == 0.0) { *out = make_double2(p[0], kInf); return true; }  // zero variance == point mass
+        out->y = 1.0 / p[1]; out->x = p[0] * out->y; return true;
+    case CX_FORM_POINT: *out = make_double2(p[0], kInf); return true;
+    case CX_FORM_NATURAL: *out = make_double2(p[0], p[1]); return true;
+    }
+    return false;
+}
+
+void from_natural(int32_t form, double2 m, double *out) {
+    if (form == CX_FORM_NATURAL) { out[0] = m.x; out[1] = m.y; return; }
+    if (std::isnan(m.y)) { out[0] = kNaN; if (form == CX_FORM_MOMENT) out[1] = kNaN; return; }
+    if (m.y == kInf) { out[0] = m.x; if (form == CX_FORM_MOMENT) out[1] = 0.0; return; }
+    double var = 1.0 / m.y;
+    out[0] = m.x * var;
+    if (form == CX_FORM_MOMENT) out[1] = var;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t cx_version(void) { return CX_ABI_VERSION; }
+
+const char *cx_last_error(const cx_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int64_t cx_payload_doubles(int32_t dim, int32_t form) {
+    if (dim < 1) return -1;
+    if (form == CX_FORM_POINT) return dim;
+    if (form == CX_FORM_MOMENT || form == CX_FORM_NATURAL) return (int64_t)dim + (int64_t)dim * dim;
+    return -1;
+}
+
+const char *cx_kernel_name(int32_t k) {
+    switch (k) {
+    case CX_KERNEL_VAR_TO_FACTOR: return "k_var_to_factor";
+    case CX_KERNEL_FACTOR_TO_VAR: return "k_factor_to_var";
+    case CX_KERNEL_FUSED: return "k_fused";
+    case CX_KERNEL_BATCH: return "k_batch";
+    case CX_KERNEL_BIG_VAR: return "k_big_var_to_factor";
+    }
+    return "";
+}
+
+int32_t cx_create(const cx_config *config, cx_handle **out) {
+    if (!out) return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: out is NULL");
+    *out = nullptr;
+    if (!config || config->struct_size != (int32_t)sizeof(cx_config))
+        return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: config is NULL or struct_size mismatch");
+    if (config->dim != 1) return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: this build implements dim == 1 (scalar Gaussian) only");
+    if (config->schedule != CX_SCHED_FLOODING && config->schedule != CX_SCHED_FUSED)
+        return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: unknown schedule");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, CX_ERR_NO_DEVICE, "cx_create: no HIP device visible (this library has no CPU fallback)");
+    if (config->device < 0 || config->device >= ndev) return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: bad device ordinal");
+    e = hipSetDevice(config->device);
+    if (e != hipSuccess) return fail(nullptr, CX_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    cx_handle *h = new (std::nothrow) cx_handle();
+    if (!h) return fail(nullptr, CX_ERR_OUT_OF_MEMORY, "cx_create: host allocation failed");
+    h->cfg = *config;
+    h->stream = nullptr;  // default stream until cx_set_stream
+    *out = h;
+    return CX_OK;
+}
+
+int32_t cx_destroy(cx_handle *h) {
+    if (!h) return CX_OK;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipStreamSynchronize(h->stream);
+    for (auto &r : h->recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+    dev_free_all(h);
+    delete h;
+    return CX_OK;
+}
+
+int32_t cx_sync(cx_handle *h) {
+    CX_REQUIRE(h, h, CX_ERR_INVALID_ARGUMENT, "null handle");
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    return CX_OK;
+}
+
+int32_t cx_set_stream(cx_handle *h, void *hip_stream) {
+    CX_REQUIRE(h, h, CX_ERR_INVALID_ARGUMENT, "null handle");
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    h->stream = (hipStream_t)hip_stream;
+    return CX_OK;
+}
+
+int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, const int64_t *edge_fac,
+                        const int32_t *edge_role, int64_t n_factors, const int64_t *factor_ids,
+                        const int32_t *factor_kind, const double *factor_params) {
+    CX_REQUIRE(h, h, CX_ERR_INVALID_ARGUMENT, "null handle");
+    CX_REQUIRE(h, !h->has_graph, CX_ERR_STATE, "cx_graph_create: handle already has a graph");
+    CX_REQUIRE(h, n_edges > 0 && edge_var && edge_fac, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: empty edge list");
+    CX_REQUIRE(h, n_edges < (int64_t)0x7fffffff, CX_ERR_UNSUPPORTED, "cx_graph_create: more than 2^31-1 edges per handle");
+    CX_REQUIRE(h, n_factors > 0 && factor_ids && factor_kind && factor_params, CX_ERR_INVALID_ARGUMENT,
+               "cx_graph_create: factor table missing");
+    try {
+        const int64_t ne = n_edges;
+        // ---- sort edges by (variable id, factor id): ascending-id neighbour order -------------------------------
+        std::vector<int64_t> ord(ne);
+        std::iota(ord.begin(), ord.end(), 0);
+        bool sorted = true;
+        for (int64_t e = 1; e < ne && sorted; e++)
+            sorted = (edge_var[e - 1] < edge_var[e]) || (edge_var[e - 1] == edge_var[e] && edge_fac[e - 1] < edge_fac[e]);
+        if (!sorted)
+            std::sort(ord.begin(), ord.end(), [&](int64_t a, int64_t b) {
+                return edge_var[a] != edge_var[b] ? edge_var[a] < edge_var[b] : edge_fac[a] < edge_fac[b];
+            });
+        for (int64_t e = 1; e < ne; e++)
+            if (edge_var[ord[e]] == edge_var[ord[e - 1]] && edge_fac[ord[e]] == edge_fac[ord[e - 1]])
+                return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: duplicate edge");
+        // ---- variables ---------------------------------------------------------------------------------------------
+        h->var_ids.clear(); h->var_off.clear(); h->edge_var.assign(ne, 0); h->edge_fac_id.assign(ne, 0);
+        for (int64_t e = 0; e < ne; e++) {
+            int64_t v = edge_var[ord[e]];
+            CX_REQUIRE(h, v >= 1, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: ids are 1-based");
+            if (h->var_ids.empty() || h->var_ids.back() != v) { h->var_ids.push_back(v); h->var_off.push_back((int32_t)e); }
+            h->edge_var[e] = (int32_t)h->var_ids.size() - 1;
+            h->edge_fac_id[e] = edge_fac[ord[e]];
+        }
+        h->var_off.push_back((int32_t)ne);
+        h->nv = (int64_t)h->var_ids.size(); h->ne = ne;
+        // ---- factors -----------------------------------------------------------------------------------------------
+        std::vector<int64_t> ford(n_factors);
+        std::iota(ford.begin(), ford.end(), 0);
+        std::sort(ford.begin(), ford.end(), [&](int64_t a, int64_t b) { return factor_ids[a] < factor_ids[b]; });
+        h->fac_ids.resize(n_factors); h->fac_kind.resize(n_factors); h->fac_params.resize(n_factors * CX_NPARAM);
+        for (int64_t f = 0; f < n_factors; f++) {
+            h->fac_ids[f] = factor_ids[ford[f]];
+            if (f > 0 && h->fac_ids[f] == h->fac_ids[f - 1]) return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: duplicate factor id");
+            h->fac_kind[f] = factor_kind[ford[f]];
+            for (int k = 0; k < CX_NPARAM; k++) h->fac_params[f * CX_NPARAM + k] = factor_params[ford[f] * CX_NPARAM + k];
+        }
+        h->nf = n_factors;
+        std::vector<int32_t> edge_fac(ne);
+        for (int64_t e = 0; e < ne; e++) {
+            auto it = std::lower_bound(h->fac_ids.begin(), h->fac_ids.end(), h->edge_fac_id[e]);
+            if (it == h->fac_ids.end() || *it != h->edge_fac_id[e]) return fail(h, CX_ERR_NOT_FOUND, "cx_graph_create: edge names a factor id missing from factor_ids");
+            edge_fac[e] = (int32_t)(it - h->fac_ids.begin());
+        }
+        // factor CSR by counting sort (edges of one factor come out in ascending variable order)
+        std::vector<int32_t> foff(n_factors + 1, 0);
+        for (int64_t e = 0; e < ne; e++) foff[edge_fac[e] + 1]++;
+        for (int64_t f = 0; f < n_factors; f++) foff[f + 1] += foff[f];
+        std::vector<int32_t> fedge(ne), fill(foff.begin(), foff.end() - 1);
+        for (int64_t e = 0; e < ne; e++) fedge[fill[edge_fac[e]]++] = (int32_t)e;
+        // ---- per-edge rule parameters and partners (gather lists of dependencies.jl:17-31) --------------------------
+        h->partner.assign(ne, -1);
+        std::vector<double> q(ne, 0.0), a, b, sq, sa, sb;
+        h->any_linear = false;
+        for (int64_t f = 0; f < n_factors; f++) if (h->fac_kind[f] == CX_FACTOR_GAUSS_LINEAR) h->any_linear = true;
+        if (h->any_linear) { a.assign(ne, 1.0); b.assign(ne, 0.0); sq.assign(ne, 0.0); sa.assign(ne, 1.0); sb.assign(ne, 0.0); }
+        std::vector<int32_t> role(ne, CX_ROLE_OUT);
+        if (edge_role) for (int64_t e = 0; e < ne; e++) role[e] = edge_role[ord[e]];
+        int64_t listened = 0;
+        for (int64_t f = 0; f < n_factors; f++) {
+            const int32_t deg = foff[f + 1] - foff[f], kind = h->fac_kind[f];
+            const double *p = &h->fac_params[f * CX_NPARAM];
+            if (kind == CX_FACTOR_OPAQUE) continue;
+            if (kind != CX_FACTOR_GAUSS_ADDITIVE && kind != CX_FACTOR_GAUSS_LINEAR)
+                return fail(h, CX_ERR_UNSUPPORTED, "cx_graph_create: unknown factor kind");
+            if (deg != 2) return fail(h, CX_ERR_UNSUPPORTED, "cx_graph_create: Gaussian factor kinds need exactly 2 edges (factor id " + std::to_string(h->fac_ids[f]) + ")");
+            if (!(p[0] >= 0.0)) return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: factor variance must be >= 0");
+            const int32_t e1 = fedge[foff[f]], e2 = fedge[foff[f] + 1];
+            h->partner[e1] = e2; h->partner[e2] = e1;
+            q[e1] = q[e2] = p[0];
+            if (kind == CX_FACTOR_GAUSS_LINEAR) {
+                // x_out = a x_in + b + N(0,q): the edge with ROLE_IN carries x_in.  Effective parameters of the
+                // RECEIVING edge: forward (receiver = out) {a, b, q}; backward (receiver = in) {1/a, -b/a, q/a²}.
+                const double A = p[1], B = p[2];
+                if (A == 0.0) return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: GAUSS_LINEAR with a == 0");
+                if (role[e1] == role[e2]) return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: GAUSS_LINEAR needs one ROLE_IN and one ROLE_OUT edge");
+                const int32_t ein = role[e1] == CX_ROLE_IN ? e1 : e2, eout = role[e1] == CX_ROLE_IN ? e2 : e1;
+                a[eout] = A; b[eout] = B; q[eout] = p[0];
+                a[ein] = 1.0 / A; b[ein] = -B / A; q[ein] = p[0] / (A * A);
+            }
+            listened += 2;
+        }
+        if (h->any_linear)
+            for (int64_t e = 0; e < ne; e++)
+                if (h->partner[e] >= 0) { sq[e] = q[h->partner[e]]; sa[e] = a[h->partner[e]]; sb[e] = b[h->partner[e]]; }
+        // ---- workgroup partition of the small-degree variables; list of big ones ----------------------------------
+        h->blk.clear(); h->big_vars.clear(); h->big_tmp_off.clear(); h->big_edges.clear();
+        int64_t big_total = 0;
+        // Simple, robust formulation: consecutive ranges [blk[b], blk[b+1]) covering all variables; a range holds
+        // either only small variables (≤ kBlock of them, ≤ kCapEdges edges) or exactly one big variable.
+        {
+            h->blk.push_back(0);
+            int32_t vars = 0, edges = 0;
+            for (int64_t v = 0; v < h->nv; v++) {
+                const int32_t deg = h->var_off[v + 1] - h->var_off[v];
+                if (deg > cx::kSmallDeg) {
+                    if (vars > 0) { h->blk.push_back((int32_t)v); vars = 0; edges = 0; }
+                    h->blk.push_back((int32_t)v + 1);
+                    h->big_vars.push_back((int32_t)v);
+                    h->big_tmp_off.push_back((int32_t)big_total);
+                    big_total += deg;
+                    for (int32_t e = h->var_off[v]; e < h->var_off[v + 1]; e++) h->big_edges.push_back(e);
+                    continue;
+                }
+                if (vars == cx::kBlock || edges + deg > cx::kCapEdges) { h->blk.push_back((int32_t)v); vars = 0; edges = 0; }
+                vars++; edges += deg;
+            }
+            if (vars > 0) h->blk.push_back((int32_t)h->nv);
+        }
+        CX_REQUIRE(h, big_total < (int64_t)0x7fffffff, CX_ERR_UNSUPPORTED, "too many high-degree edges");
+        // messages with >=1 dependency and >=1 listener: both directions of every 2-edge Gaussian factor, minus the
+        // variable→factor messages of degree-1 variables (no dependencies, dependencies.jl:48-55)
+        int64_t m = 0;
+        for (int64_t e = 0; e < ne; e++) {
+            if (h->partner[e] < 0) continue;
+            m += 1;  // factor→variable on e (its dependency is v2f on the partner)
+            const int32_t v = h->edge_var[e];
+            if (h->var_off[v + 1] - h->var_off[v] >= 2) m += 1;  // variable→factor on e
+        }
+        h->n_messages_per_sweep = m;
+        (void)listened;
+        // ---- upload ------------------------------------------------------------------------------------------------
+        CX_HIP(h, hipSetDevice(h->cfg.device));
+        int32_t rc;
+#define CX_TRY(x) do { rc = (x); if (rc != CX_OK) { dev_free_all(h); return rc; } } while (0)
+        CX_TRY(dev_upload(h, &h->d_var_off, h->var_off));
+        CX_TRY(dev_upload(h, &h->d_partner, h->partner));
+        CX_TRY(dev_upload(h, &h->d_edge_var, h->edge_var));
+        CX_TRY(dev_upload(h, &h->d_blk, h->blk));
+        CX_TRY(dev_upload(h, &h->d_big, h->big_vars));
+        CX_TRY(dev_upload(h, &h->d_big_tmp_off, h->big_tmp_off));
+        CX_TRY(dev_upload(h, &h->d_big_edges, h->big_edges));
+        CX_TRY(dev_alloc(h, &h->d_big_tmp, big_total));
+        CX_TRY(dev_upload(h, &h->d_q, q));
+        if (h->any_linear) {
+            CX_TRY(dev_upload(h, &h->d_a, a)); CX_TRY(dev_upload(h, &h->d_b, b));
+            CX_TRY(dev_upload(h, &h->d_sq, sq)); CX_TRY(dev_upload(h, &h->d_sa, sa)); CX_TRY(dev_upload(h, &h->d_sb, sb));
+        }
+        h->var_flags.assign(h->nv, 0);
+        CX_TRY(dev_upload(h, &h->d_var_flags, h->var_flags));
+        CX_TRY(dev_alloc(h, &h->d_f2v, ne)); CX_TRY(dev_alloc(h, &h->d_v2f, ne)); CX_TRY(dev_alloc(h, &h->d_marg, h->nv));
+        CX_TRY(dev_alloc(h, &h->d_scratch, 4096));
+        // every message starts as UndefValue(): all-ones bytes are a NaN in both halves of each double2
+        CX_HIP(h, hipMemsetAsync(h->d_f2v, 0xff, (size_t)ne * sizeof(double2), h->stream));
+        CX_HIP(h, hipMemsetAsync(h->d_v2f, 0xff, (size_t)ne * sizeof(double2), h->stream));
+        CX_HIP(h, hipMemsetAsync(h->d_marg, 0xff, (size_t)h->nv * sizeof(double2), h->stream));
+        if (h->cfg.schedule == CX_SCHED_FUSED) {
+            CX_TRY(dev_alloc(h, &h->d_f2v_alt, ne));
+            CX_HIP(h, hipMemsetAsync(h->d_f2v_alt, 0xff, (size_t)ne * sizeof(double2), h->stream));
+        }
+#undef CX_TRY
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        h->has_graph = true;
+        return CX_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_graph_create: host allocation failed");
+    } catch (const std::exception &ex) {
+        return fail(h, CX_ERR_INVALID_ARGUMENT, std::string("cx_graph_create: ") + ex.what());
+    }
+}
+
+int32_t cx_graph_stats(const cx_handle *h, cx_stats *out) {
+    if (!h || !out) return CX_ERR_INVALID_ARGUMENT;
+    out->n_variables = h->nv; out->n_factors = h->nf; out->n_edges = h->ne;
+    out->n_messages_per_sweep = h->n_messages_per_sweep;
+    out->n_small_blocks = (int64_t)h->blk.size() - 1; out->n_big_variables = (int64_t)h->big_vars.size();
+    out->device_bytes = h->device_bytes; out->sweeps_done = h->sweeps_done;
+    return CX_OK;
+}
+
+int32_t cx_edge_index(const cx_handle *hc, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, int64_t *out_edge) {
+    cx_handle *h = const_cast<cx_handle *>(hc);
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_edge_index: no graph");
+    CX_REQUIRE(h, n >= 0 && (n == 0 || (variable_ids && factor_ids && out_edge)), CX_ERR_INVALID_ARGUMENT, "cx_edge_index: null argument");
+    for (int64_t i = 0; i < n; i++) {
+        out_edge[i] = find_edge(h, variable_ids[i], factor_ids[i]);
+        if (out_edge[i] < 0)
+            return fail(h, CX_ERR_NOT_FOUND, "no connection between variable " + std::to_string(variable_ids[i]) + " and factor " + std::to_string(factor_ids[i]));
+    }
+    return CX_OK;
+}
+
+static int32_t stage_indices(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, std::vector<int32_t> &idx) {
+    idx.resize(n);
+    for (int64_t i = 0; i < n; i++) {
+        int64_t e = find_edge(h, variable_ids[i], factor_ids[i]);
+        if (e < 0) return fail(h, CX_ERR_NOT_FOUND, "no connection between variable " + std::to_string(variable_ids[i]) + " and factor " + std::to_string(factor_ids[i]));
+        idx[i] = (int32_t)e;
+    }
+    return CX_OK;
+}
+
+int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, int32_t direction,
+                        int32_t form, const double *payload) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_set_messages: no graph");
+    CX_REQUIRE(h, direction == CX_TO_FACTOR || direction == CX_TO_VARIABLE, CX_ERR_INVALID_ARGUMENT, "cx_set_messages: bad direction");
+    CX_REQUIRE(h, form == CX_FORM_MOMENT || form == CX_FORM_POINT || form == CX_FORM_NATURAL, CX_ERR_INVALID_ARGUMENT, "cx_set_messages: bad form");
+    CX_REQUIRE(h, !(form == CX_FORM_POINT && direction == CX_TO_VARIABLE), CX_ERR_UNSUPPORTED, "cx_set_messages: point-mass data is a variable→factor message");
+    if (n == 0) return CX_OK;
+    CX_REQUIRE(h, n > 0 && variable_ids && factor_ids && payload, CX_ERR_INVALID_ARGUMENT, "cx_set_messages: null argument");
+    try {
+        std::vector<int32_t> idx;
+        int32_t rc = stage_indices(h, n, variable_ids, factor_ids, idx);
+        if (rc != CX_OK) return rc;
+        const int64_t stride = form == CX_FORM_POINT ? 1 : 2;
+        std::vector<double2> val(n);
+        for (int64_t i = 0; i < n; i++) to_natural(form, payload + i * stride, &val[i]);
+        const int64_t bytes_idx = ((n * 4 + 15) / 16) * 16, bytes = bytes_idx + n * 16;
+        rc = ensure_stage(h, bytes);
+        if (rc != CX_OK) return rc;
+        int32_t *d_idx = (int32_t *)h->d_stage;
+        double2 *d_val = (double2 *)((char *)h->d_stage + bytes_idx);
+        CX_HIP(h, hipMemcpyAsync(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+        CX_HIP(h, hipMemcpyAsync(d_val, val.data(), n * 16, hipMemcpyHostToDevice, h->stream));
+        if (direction == CX_TO_FACTOR) {
+            cx::launch_scatter(h, h->d_v2f, d_idx, d_val, n);
+            if (form == CX_FORM_POINT) {
+                // a variable that carries a point-mass datum is observed: its messages are never recomputed
+                for (int64_t i = 0; i < n; i++) h->var_flags[h->edge_var[idx[i]]] = 1;
+                CX_HIP(h, hipMemcpyAsync(h->d_var_flags, h->var_flags.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
+            }
+        } else {
+            cx::launch_scatter(h, h->d_f2v, d_idx, d_val, n);
+            if (h->d_f2v_alt) cx::launch_scatter(h, h->d_f2v_alt, d_idx, d_val, n);
+        }
+        CX_HIP(h, hipStreamSynchronize(h->stream));  // host staging vectors die here
+        return CX_OK;
+    } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_set_messages: host allocation failed"); }
+}
+
+int32_t cx_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, int32_t direction,
+                        int32_t form, double *out) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_get_messages: no graph");
+    CX_REQUIRE(h, direction == CX_TO_FACTOR || direction == CX_TO_VARIABLE, CX_ERR_INVALID_ARGUMENT, "cx_get_messages: bad direction");
+    CX_REQUIRE(h, form == CX_FORM_MOMENT || form == CX_FORM_NATURAL, CX_ERR_INVALID_ARGUMENT, "cx_get_messages: bad form");
+    if (n == 0) return CX_OK;
+    CX_REQUIRE(h, n > 0 && variable_ids && factor_ids && out, CX_ERR_INVALID_ARGUMENT, "cx_get_messages: null argument");
+    try {
+        std::vector<int32_t> idx;
+        int32_t rc = stage_indices(h, n, variable_ids, factor_ids, idx);
+        if (rc != CX_OK) return rc;
+        const int64_t bytes_idx = ((n * 4 + 15) / 16) * 16, bytes = bytes_idx + n * 16;
+        rc = ensure_stage(h, bytes);
+        if (rc != CX_OK) return rc;
+        int32_t *d_idx = (int32_t *)h->d_stage;
+        double2 *d_val = (double2 *)((char *)h->d_stage + bytes_idx);
+        CX_HIP(h, hipMemcpyAsync(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+        cx::launch_gather(h, direction == CX_TO_FACTOR ? h->d_v2f : h->d_f2v, d_idx, d_val, n);
+        std::vector<double2> val(n);
+        CX_HIP(h, hipMemcpyAsync(val.data(), d_val, n * 16, hipMemcpyDeviceToHost, h->stream));
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        for (int64_t i = 0; i < n; i++) from_natural(form, val[i], out + 2 * i);
+        return CX_OK;
+    } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_get_messages: host allocation failed"); }
+}
+
+int32_t cx_seed_messages(cx_handle *h, int32_t direction, double mean, double variance) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_seed_messages: no graph");
+    CX_REQUIRE(h, direction == CX_TO_FACTOR || direction == CX_TO_VARIABLE, CX_ERR_INVALID_ARGUMENT, "cx_seed_messages: bad direction");
+    CX_REQUIRE(h, variance > 0.0, CX_ERR_INVALID_ARGUMENT, "cx_seed_messages: variance must be > 0");
+    double2 v = make_double2(mean / variance, 1.0 / variance);
+    if (direction == CX_TO_VARIABLE) {
+        cx::launch_seed(h, h->d_f2v, h->ne, v, h->d_partner);
+        if (h->d_f2v_alt) cx::launch_seed(h, h->d_f2v_alt, h->ne, v, h->d_partner);
+    } else {
+        cx::launch_seed(h, h->d_v2f, h->ne, v, h->d_partner);
+    }
+    CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
+int32_t cx_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, double *out) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_get_marginals: no graph");
+    if (n == 0) return CX_OK;
+    CX_REQUIRE(h, n > 0 && variable_ids && out, CX_ERR_INVALID_ARGUMENT, "cx_get_marginals: null argument");
+    try {
+        std::vector<int32_t> idx(n);
+        for (int64_t i = 0; i < n; i++) {
+            int64_t v = find_var(h, variable_ids[i]);
+            if (v < 0) return fail(h, CX_ERR_NOT_FOUND, "unknown variable id " + std::to_string(variable_ids[i]));
+            idx[i] = (int32_t)v;
+        }
+        const int64_t bytes_idx = ((n * 4 + 15) / 16) * 16, bytes = bytes_idx + n * 16;
+        int32_t rc = ensure_stage(h, bytes);
+        if (rc != CX_OK) return rc;
+        int32_t *d_idx = (int32_t *)h->d_stage;
+        double2 *d_val = (double2 *)((char *)h->d_stage + bytes_idx);
+        CX_HIP(h, hipMemcpyAsync(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+        cx::launch_gather(h, h->d_marg, d_idx, d_val, n);
+        CX_HIP(h, hipMemcpyAsync(out, d_val, n * 16, hipMemcpyDeviceToHost, h->stream));
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        return CX_OK;
+    } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_get_marginals: host allocation failed"); }
+}
+
+int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_update_batch: no graph");
+    if (n == 0) return CX_OK;
+    CX_REQUIRE(h, n > 0 && items, CX_ERR_INVALID_ARGUMENT, "cx_update_batch: null argument");
+    try {
+        std::vector<int32_t> buf(2 * n);
+        for (int64_t i = 0; i < n; i++) {
+            const cx_item &it = items[i];
+            int64_t idx;
+            if (it.kind == CX_ITEM_INDIVIDUAL_MARGINAL) {
+                idx = find_var(h, it.variable_id);
+                if (idx < 0) return fail(h, CX_ERR_NOT_FOUND, "unknown variable id " + std::to_string(it.variable_id));
+            } else if (it.kind == CX_ITEM_MESSAGE_TO_FACTOR || it.kind == CX_ITEM_MESSAGE_TO_VARIABLE) {
+                idx = find_edge(h, it.variable_id, it.factor_id);
+                if (idx < 0) return fail(h, CX_ERR_NOT_FOUND, "no connection between variable " + std::to_string(it.variable_id) + " and factor " + std::to_string(it.factor_id));
+            } else {
+                // ProductOfMessages / JointMarginal have no device rule: the reference's default is error(...)
+                // (src/inference_engine.jl:446,476)
+                return fail(h, CX_ERR_UNSUPPORTED, "cx_update_batch: item kind " + std::to_string(it.kind) + " is not implemented for this processor");
+            }
+            buf[i] = it.kind; buf[n + i] = (int32_t)idx;
+        }
+        int32_t rc = ensure_stage(h, 2 * n * 4);
+        if (rc != CX_OK) return rc;
+        CX_HIP(h, hipMemcpyAsync(h->d_stage, buf.data(), 2 * n * 4, hipMemcpyHostToDevice, h->stream));
+        cx::launch_batch(h, (const int32_t *)h->d_stage, (const int32_t *)h->d_stage + n, n);
+        CX_HIP(h, hipGetLastError());
+        CX_HIP(h, hipStreamSynchronize(h->stream));  // synchronous: the host sets readiness bits next (signal.jl:232-253)
+        return CX_OK;
+    } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_update_batch: host allocation failed"); }
+}
+
+int32_t cx_sweep_phase(cx_handle *h, int32_t phase) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep_phase: no graph");
+    CX_REQUIRE(h, h->cfg.schedule == CX_SCHED_FLOODING, CX_ERR_STATE, "cx_sweep_phase: phases exist only in the flooding schedule");
+    const bool marg = h->cfg.compute_marginals_in_sweep != 0;
+    if (phase == CX_PHASE_VAR_TO_FACTOR) {
+        cx::launch_var_to_factor(h, h->d_f2v, h->d_v2f, marg);
+        cx::launch_big_var_to_factor(h, h->d_f2v, h->d_v2f, marg);
+    } else if (phase == CX_PHASE_FACTOR_TO_VAR) {
+        cx::launch_factor_to_var(h, h->d_v2f, h->d_f2v);
+        h->sweeps_done++;
+    } else {
+        return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_sweep_phase: bad phase");
+    }
+    CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
+int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep: no graph");
+    CX_REQUIRE(h, n_sweeps >= 0, CX_ERR_INVALID_ARGUMENT, "cx_sweep: n_sweeps < 0");
+    const bool marg = h->cfg.compute_marginals_in_sweep != 0;
+    for (int32_t s = 0; s < n_sweeps; s++) {
+        if (h->cfg.schedule == CX_SCHED_FLOODING) {
+            cx::launch_var_to_factor(h, h->d_f2v, h->d_v2f, marg);
+            cx::launch_big_var_to_factor(h, h->d_f2v, h->d_v2f, marg);
+            cx::launch_factor_to_var(h, h->d_v2f, h->d_f2v);
+        } else {
+            cx::launch_fused(h, h->d_f2v, h->d_f2v_alt, h->d_v2f, marg, true);
+            if (!h->big_vars.empty()) {
+                cx::launch_big_var_to_factor(h, h->d_f2v, h->d_v2f, marg);
+                cx::launch_push_edges(h, h->d_big_edges, (int64_t)h->big_edges.size(), h->d_v2f, h->d_f2v_alt);
+            }
+            std::swap(h->d_f2v, h->d_f2v_alt);
+        }
+        h->sweeps_done++;
+    }
+    CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
+int32_t cx_residual(cx_handle *h, double *out) {
+    CX_REQUIRE(h, h && h->has_graph && out, CX_ERR_STATE, "cx_residual: no graph / null out");
+    if (!h->d_prev) {
+        int32_t rc = dev_alloc(h, &h->d_prev, h->ne);
+        if (rc != CX_OK) return rc;
+        CX_HIP(h, hipMemcpyAsync(h->d_prev, h->d_f2v, (size_t)h->ne * 16, hipMemcpyDeviceToDevice, h->stream));
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        *out = std::numeric_limits<double>::infinity();
+        return CX_OK;
+    }
+    cx::launch_residual(h, h->d_f2v, h->d_prev, h->ne, h->d_scratch);
+    std::vector<double> part(1024);
+    CX_HIP(h, hipMemcpyAsync(part.data(), h->d_scratch, 1024 * 8, hipMemcpyDeviceToHost, h->stream));
+    CX_HIP(h, hipMemcpyAsync(h->d_prev, h->d_f2v, (size_t)h->ne * 16, hipMemcpyDeviceToDevice, h->stream));
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    double m = 0.0;
+    for (double p : part) m = std::max(m, p);
+    *out = m;
+    return CX_OK;
+}
+
+// ---- halo -------------------------------------------------------------------------------------------------------
+int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const int64_t *sf, int64_t n_recv,
+                          const int64_t *rv, const int64_t *rf) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_configure: no graph");
+    CX_REQUIRE(h, n_send >= 0 && n_recv >= 0, CX_ERR_INVALID_ARGUMENT, "cx_halo_configure: negative count");
+    CX_REQUIRE(h, (n_send == 0 || (sv && sf)) && (n_recv == 0 || (rv && rf)), CX_ERR_INVALID_ARGUMENT, "cx_halo_configure: null argument");
+    try {
+        int32_t rc = stage_indices(h, n_send, sv, sf, h->send_edges);
+        if (rc != CX_OK) return rc;
+        rc = stage_indices(h, n_recv, rv, rf, h->recv_edges);
+        if (rc != CX_OK) return rc;
+        for (int32_t e : h->recv_edges) {
+            const int32_t v = h->edge_var[e];
+            if (h->var_off[v + 1] - h->var_off[v] != 1)
+                return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_halo_configure: an imported edge must belong to a degree-1 ghost variable");
+        }
+        for (void *p : {(void *)h->d_send_edges, (void *)h->d_recv_edges, (void *)h->d_send_buf, (void *)h->d_recv_buf}) if (p) (void)hipFree(p);
+        h->d_send_edges = h->d_recv_edges = nullptr; h->d_send_buf = h->d_recv_buf = nullptr;
+        rc = dev_upload(h, &h->d_send_edges, h->send_edges); if (rc != CX_OK) return rc;
+        rc = dev_upload(h, &h->d_recv_edges, h->recv_edges); if (rc != CX_OK) return rc;
+        rc = dev_alloc(h, &h->d_send_buf, n_send); if (rc != CX_OK) return rc;
+        rc = dev_alloc(h, &h->d_recv_buf, n_recv); if (rc != CX_OK) return rc;
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        return CX_OK;
+    } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_halo_configure: host allocation failed"); }
+}
+
+int32_t cx_halo_buffers(cx_handle *h, void **send_ptr, int64_t *send_bytes, void **recv_ptr, int64_t *recv_bytes) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_buffers: no graph");
+    if (send_ptr) *send_ptr = h->d_send_buf;
+    if (send_bytes) *send_bytes = (int64_t)h->send_edges.size() * 16;
+    if (recv_ptr) *recv_ptr = h->d_recv_buf;
+    if (recv_bytes) *recv_bytes = (int64_t)h->recv_edges.size() * 16;
+    return CX_OK;
+}
+
+int32_t cx_halo_pack(cx_handle *h) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_pack: no graph");
+    cx::launch_gather(h, h->d_v2f, h->d_send_edges, h->d_send_buf, (int64_t)h->send_edges.size());
+    CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
+int32_t cx_halo_unpack(cx_handle *h) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_unpack: no graph");
+    cx::launch_scatter(h, h->d_v2f, h->d_recv_edges, h->d_recv_buf, (int64_t)h->recv_edges.size());
+    CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
+// ---- profiling ----------------------------------------------------------------------------------------------------
+int32_t cx_profile_enable(cx_handle *h, int32_t on) {
+    CX_REQUIRE(h, h, CX_ERR_INVALID_ARGUMENT, "null handle");
+    h->profiling = on != 0;
+    return CX_OK;
+}
+
+int32_t cx_profile_read(cx_handle *h, int32_t kernel, double *total_ms, int64_t *launches) {
+    CX_REQUIRE(h, h && total_ms && launches, CX_ERR_INVALID_ARGUMENT, "cx_profile_read: null argument");
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    double tot = 0.0; int64_t cnt = 0;
+    std::vector<cx::ProfileRec> keep;
+    for (auto &r : h->recs) {
+        if (r.kernel == kernel) {
+            float ms = 0.f;
+            CX_HIP(h, hipEventElapsedTime(&ms, r.start, r.stop));
+            tot += ms; cnt++;
+            (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop);
+        } else keep.push_back(r);
+    }
+    h->recs.swap(keep);
+    *total_ms = tot; *launches = cnt;
+    return CX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,164 @@
+"""DeviceGraph — thin Python owner of a `cx_handle` (include/cortex_hip.h).
+
+This is plumbing over the C ABI, not an algorithm: every method is one ABI call.  It is what the
+host-side processor (hip_processor.py) and bench.py drive."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+class DeviceGraph:
+    def __init__(self, device: int = 0, dim: int = 1, schedule: int = L.SCHED_FLOODING, marginals_in_sweep: bool = True):
+        self.lib = L.load()
+        cfg = L.Config(C.sizeof(L.Config), device, dim, schedule, int(marginals_in_sweep))
+        h = C.c_void_p()
+        rc = self.lib.cx_create(C.byref(cfg), C.byref(h))
+        if rc != L.OK:
+            raise L.CortexHipError(rc, self.lib.cx_last_error(None).decode())
+        self.h = h
+        self.dim = dim
+        self.schedule = schedule
+
+    # -- status handling ------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != L.OK:
+            raise L.CortexHipError(rc, self.lib.cx_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- graph ----------------------------------------------------------------------------------
+    def graph_create(self, edge_var, edge_fac, factor_ids, factor_kind, factor_params, edge_role=None):
+        edge_var, edge_fac, factor_ids = _i64(edge_var), _i64(edge_fac), _i64(factor_ids)
+        factor_kind = np.ascontiguousarray(factor_kind, dtype=np.int32)
+        fp = np.zeros((len(factor_ids), L.NPARAM), dtype=np.float64)
+        factor_params = np.asarray(factor_params, dtype=np.float64)
+        if factor_params.ndim == 1:
+            fp[:, 0] = factor_params
+        else:
+            fp[:, : factor_params.shape[1]] = factor_params
+        role = None
+        if edge_role is not None:
+            role_arr = np.ascontiguousarray(edge_role, dtype=np.int32)
+            role = _p(role_arr, C.c_int32)
+        self._check(self.lib.cx_graph_create(self.h, len(edge_var), _p(edge_var, C.c_int64), _p(edge_fac, C.c_int64),
+                                             role, len(factor_ids), _p(factor_ids, C.c_int64),
+                                             _p(factor_kind, C.c_int32), _p(fp, C.c_double)))
+
+    def stats(self) -> dict:
+        s = L.Stats()
+        self._check(self.lib.cx_graph_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in L.Stats._fields_}
+
+    def edge_index(self, variable_ids, factor_ids):
+        v, f = _i64(np.atleast_1d(variable_ids)), _i64(np.atleast_1d(factor_ids))
+        out = np.zeros(len(v), dtype=np.int64)
+        self._check(self.lib.cx_edge_index(self.h, len(v), _p(v, C.c_int64), _p(f, C.c_int64), _p(out, C.c_int64)))
+        return out
+
+    # -- data -----------------------------------------------------------------------------------
+    def set_messages(self, variable_ids, factor_ids, direction: int, form: int, payload):
+        v, f = _i64(np.atleast_1d(variable_ids)), _i64(np.atleast_1d(factor_ids))
+        p = _f64(payload)
+        need = len(v) * self.lib.cx_payload_doubles(self.dim, form)
+        if p.size != need:
+            raise ValueError(f"payload has {p.size} doubles, expected {need}")
+        self._check(self.lib.cx_set_messages(self.h, len(v), _p(v, C.c_int64), _p(f, C.c_int64), direction, form,
+                                             _p(p, C.c_double)))
+
+    def get_messages(self, variable_ids, factor_ids, direction: int, form: int = L.FORM_MOMENT):
+        v, f = _i64(np.atleast_1d(variable_ids)), _i64(np.atleast_1d(factor_ids))
+        out = np.zeros((len(v), self.lib.cx_payload_doubles(self.dim, L.FORM_MOMENT)), dtype=np.float64)
+        self._check(self.lib.cx_get_messages(self.h, len(v), _p(v, C.c_int64), _p(f, C.c_int64), direction, form,
+                                             _p(out, C.c_double)))
+        return out
+
+    def seed_messages(self, direction: int, mean: float, variance: float):
+        self._check(self.lib.cx_seed_messages(self.h, direction, float(mean), float(variance)))
+
+    def get_marginals(self, variable_ids):
+        v = _i64(np.atleast_1d(variable_ids))
+        out = np.zeros((len(v), self.lib.cx_payload_doubles(self.dim, L.FORM_MOMENT)), dtype=np.float64)
+        self._check(self.lib.cx_get_marginals(self.h, len(v), _p(v, C.c_int64), _p(out, C.c_double)))
+        return out
+
+    # -- compute --------------------------------------------------------------------------------
+    def update_batch(self, kinds, variable_ids, factor_ids):
+        n = len(kinds)
+        items = (L.Item * n)()
+        for i in range(n):
+            items[i].kind = int(kinds[i])
+            items[i].variable_id = int(variable_ids[i])
+            items[i].factor_id = int(factor_ids[i])
+        self._check(self.lib.cx_update_batch(self.h, items, n))
+
+    def sweep(self, n: int = 1):
+        self._check(self.lib.cx_sweep(self.h, int(n)))
+
+    def sweep_phase(self, phase: int):
+        self._check(self.lib.cx_sweep_phase(self.h, phase))
+
+    def sync(self):
+        self._check(self.lib.cx_sync(self.h))
+
+    def set_stream(self, stream_ptr: Optional[int]):
+        self._check(self.lib.cx_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
+
+    def residual(self) -> float:
+        out = C.c_double()
+        self._check(self.lib.cx_residual(self.h, C.byref(out)))
+        return out.value
+
+    # -- halo -----------------------------------------------------------------------------------
+    def halo_configure(self, send_var, send_fac, recv_var, recv_fac):
+        sv, sf, rv, rf = _i64(send_var), _i64(send_fac), _i64(recv_var), _i64(recv_fac)
+        self._check(self.lib.cx_halo_configure(self.h, len(sv), _p(sv, C.c_int64), _p(sf, C.c_int64), len(rv),
+                                               _p(rv, C.c_int64), _p(rf, C.c_int64)))
+
+    def halo_buffers(self):
+        sp, rp, sb, rb = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_int64()
+        self._check(self.lib.cx_halo_buffers(self.h, C.byref(sp), C.byref(sb), C.byref(rp), C.byref(rb)))
+        return (sp.value or 0, sb.value), (rp.value or 0, rb.value)
+
+    def halo_pack(self):
+        self._check(self.lib.cx_halo_pack(self.h))
+
+    def halo_unpack(self):
+        self._check(self.lib.cx_halo_unpack(self.h))
+
+    # -- measurement ----------------------------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        self._check(self.lib.cx_profile_enable(self.h, int(on)))
+
+    def profile_read(self, kernel: int):
+        ms, n = C.c_double(), C.c_int64()
+        self._check(self.lib.cx_profile_read(self.h, kernel, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def kernel_name(self, kernel: int) -> str:
+        return self.lib.cx_kernel_name(kernel).decode()

@@ -1,0 +1,185 @@
+/*
+ * cortex_hip.h — C ABI of libcortex_hip.so: the MI355X (gfx950) sum-product sweep that sits
+ * behind Cortex.jl's InferenceEngine / AbstractInferenceRequestProcessor plugin API.
+ *
+ * The reference (Cortex.jl v0.3.0, pure Julia) has no FFI; these entry points are what a Julia
+ * `ccall` shim for this path binds (INTEGRATION.md shows the stub).  Each declaration names the
+ * reference interface it replaces (paths relative to the reference checkout):
+ *
+ *   graph ingestion      the 7 model-engine accessors, src/model_engine.jl:329-391, as forwarded by
+ *                        ext/BipartiteFactorGraphsExt/BipartiteFactorGraphsExt.jl:16-48
+ *   cx_set_messages      set_value!(message, data)                         src/signal.jl:232-253
+ *   cx_update_batch      process!(processor, engine, variable_id, signal)  src/inference_engine.jl:479-509
+ *                        → compute_message_to_variable! / compute_message_to_factor! /
+ *                          compute_individual_marginal!                    src/inference_engine.jl:351-419
+ *   cx_sweep             update_marginals!(engine, variable_ids)           src/inference_engine.jl:559-632
+ *                        (device "flooding" schedule over the whole graph)
+ *   cx_get_marginals     get_value(get_variable_marginal(variable))        src/model_engine.jl:60-62
+ *   cx_get_messages      get_value(message_to_variable / message_to_factor) src/model_engine.jl:207-222
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types; every function returns an int32 status
+ *     (CX_OK == 0, negative = error) and never throws or longjmps across the boundary;
+ *     cx_last_error() returns the text a Julia shim passes to error().
+ *   - ids are the reference's ids: 1-based Int64, one id space shared by variables and factors
+ *     (BipartiteFactorGraphs add_variable!/add_factor!).  Neighbour order is ascending id.
+ *   - Gaussian payloads cross the boundary in MOMENT form like the reference's test structs
+ *     (test/runtests.jl:31-34 NormalMeanVariance): dim==1: {mean, variance};
+ *     dim==d: mean[d] then covariance[d*d] row-major.  NaN variance/covariance == UndefValue().
+ *   - the caller owns every pointer it passes; the library copies before returning and owns all
+ *     device memory behind the opaque handle.  One caller thread per handle.
+ *   - calls are asynchronous on the handle's HIP stream unless they return data to the host;
+ *     cx_sync() waits.
+ */
+#ifndef CORTEX_HIP_H
+#define CORTEX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CX_ABI_VERSION 1
+
+/* status codes */
+#define CX_OK 0
+#define CX_ERR_INVALID_ARGUMENT (-1)  /* bad pointer / size / enum */
+#define CX_ERR_NOT_FOUND (-2)         /* unknown variable / factor / edge id */
+#define CX_ERR_UNSUPPORTED (-3)       /* factor arity / kind / dim the device path does not implement */
+#define CX_ERR_STATE (-4)             /* call order (e.g. sweep before graph) */
+#define CX_ERR_DEVICE (-5)            /* HIP runtime error; text in cx_last_error */
+#define CX_ERR_NO_DEVICE (-6)         /* no gfx950 device visible */
+#define CX_ERR_OUT_OF_MEMORY (-7)
+
+/* message direction: which of a Connection's two signals (model_engine.jl:181-186) */
+#define CX_TO_FACTOR 1    /* MessageToFactor(variable_id, factor_id),   inference_signal.jl:29-32 */
+#define CX_TO_VARIABLE 2  /* MessageToVariable(variable_id, factor_id), inference_signal.jl:45-48 */
+
+/* work-item kinds of cx_update_batch == the variants process! dispatches on */
+#define CX_ITEM_MESSAGE_TO_FACTOR 1
+#define CX_ITEM_MESSAGE_TO_VARIABLE 2
+#define CX_ITEM_INDIVIDUAL_MARGINAL 4
+
+/* payload forms */
+#define CX_FORM_MOMENT 0  /* Gaussian (mean, variance|covariance) */
+#define CX_FORM_POINT 1   /* observed datum: the `Real` input of test/inference_engine_tests.jl:424 ; dim values */
+#define CX_FORM_NATURAL 2 /* (xi = precision*mean, w = precision): the library's storage form */
+
+/* factor kinds (what the user rule reads from Factor.functional_form, model_engine.jl:119-122) */
+#define CX_FACTOR_OPAQUE 0          /* messages only ever set by the caller (priors, unary observations) */
+#define CX_FACTOR_GAUSS_ADDITIVE 1  /* 2 edges: x_b = x_a + N(0, q)            params = {q}                */
+#define CX_FACTOR_GAUSS_LINEAR 2    /* 2 edges: x_out = a*x_in + b + N(0, q)   params = {q, a, b}          */
+                                    /* dim>1:   x_out = A x_in + N(0, Q)       params via cx_set_factor_matrices */
+#define CX_NPARAM 4                 /* doubles per factor in factor_params */
+
+/* edge roles for directed factors (Connection.label :out/:in, model_engine.jl:182) */
+#define CX_ROLE_OUT 0
+#define CX_ROLE_IN 1
+
+/* schedules of cx_sweep */
+#define CX_SCHED_FLOODING 0   /* all variable→factor, then all factor→variable, then marginals           */
+#define CX_SCHED_FUSED 1      /* same fixed-point map, one fused kernel on double-buffered messages        */
+
+typedef struct cx_handle cx_handle;
+
+typedef struct cx_config {
+    int32_t struct_size;   /* sizeof(cx_config), for forward compatibility */
+    int32_t device;        /* HIP device ordinal */
+    int32_t dim;           /* message dimension d: 1 (scalar), 4, 64 */
+    int32_t schedule;      /* CX_SCHED_* */
+    int32_t compute_marginals_in_sweep; /* 1: every sweep also refreshes all marginals (update_marginals!) */
+    int32_t reserved[3];
+} cx_config;
+
+typedef struct cx_item {
+    int32_t kind;          /* CX_ITEM_* */
+    int32_t reserved;
+    int64_t variable_id;
+    int64_t factor_id;     /* ignored for CX_ITEM_INDIVIDUAL_MARGINAL */
+} cx_item;
+
+typedef struct cx_stats {
+    int64_t n_variables, n_factors, n_edges;
+    int64_t n_messages_per_sweep;     /* directed messages with >=1 dependency and >=1 listener: the metric's unit */
+    int64_t n_small_blocks, n_big_variables;
+    int64_t device_bytes;
+    int64_t sweeps_done;
+} cx_stats;
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+int32_t cx_version(void);
+int32_t cx_create(const cx_config *config, cx_handle **out);
+int32_t cx_destroy(cx_handle *h);                 /* idempotent on NULL */
+const char *cx_last_error(const cx_handle *h);    /* h may be NULL: last error of a failed cx_create */
+int32_t cx_sync(cx_handle *h);
+int32_t cx_set_stream(cx_handle *h, void *hip_stream); /* run on the caller's hipStream_t (NULL = default) */
+
+/* ---- graph ingestion: BipartiteFactorGraph{Variable,Factor,Connection} flattened once --------
+ * edge_var[e], edge_fac[e]: the (variable_id, factor_id) of every Connection, any order.
+ * factor_ids[f], factor_kind[f], factor_params[f*CX_NPARAM ..]: one row per factor.
+ * edge_role may be NULL (all CX_ROLE_OUT); it is only read for CX_FACTOR_GAUSS_LINEAR.
+ * Replaces get_variable_ids/get_factor_ids/get_connected_*_ids/get_connection
+ * (model_engine.jl:329-391) and fixes the dependency wiring of DefaultDependencyResolver
+ * (dependencies.jl:17-126) into gather lists. */
+int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, const int64_t *edge_fac,
+                        const int32_t *edge_role, int64_t n_factors, const int64_t *factor_ids,
+                        const int32_t *factor_kind, const double *factor_params);
+int32_t cx_graph_stats(const cx_handle *h, cx_stats *out);
+/* position of Connection (variable_id, factor_id) in the flattened edge table (sorted by variable, factor) */
+int32_t cx_edge_index(const cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids,
+                      int64_t *out_edge);
+
+/* ---- data injection / read-back --------------------------------------------------------------
+ * payload: n rows of cx_payload_doubles(dim, form) doubles. */
+int64_t cx_payload_doubles(int32_t dim, int32_t form);
+int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids,
+                        int32_t direction, int32_t form, const double *payload);
+int32_t cx_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids,
+                        int32_t direction, int32_t form, double *out);
+/* give every still-undefined message of `direction` the value N(mean, variance*I): the seeding a user of
+ * the reference does by hand before loopy BP (cf. test/inference_engine_tests.jl:729-736) */
+int32_t cx_seed_messages(cx_handle *h, int32_t direction, double mean, double variance);
+int32_t cx_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, double *out);
+
+/* ---- compute ---------------------------------------------------------------------------------- */
+/* one launch for a batch of mutually independent signals, in the caller's order of enqueue */
+int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n);
+/* n_sweeps passes of the configured device schedule over the whole graph (asynchronous) */
+int32_t cx_sweep(cx_handle *h, int32_t n_sweeps);
+/* max over directed messages of |Δmean|, |Δvariance| between the last two sweeps (host-synchronous) */
+int32_t cx_residual(cx_handle *h, double *out_max_abs_delta);
+
+/* ---- partitioned graphs (one handle per GPU; exchange is the caller's: RCCL/torch.distributed) --
+ * Cut edges appear in this rank's graph as degree-1 "ghost" variables whose variable→factor message is
+ * produced by another rank.  cx_halo_configure names the edges this rank exports / imports; buffers hold
+ * NATURAL-form payloads, 2*dim... doubles per edge, in list order. */
+int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *send_variable_ids,
+                          const int64_t *send_factor_ids, int64_t n_recv, const int64_t *recv_variable_ids,
+                          const int64_t *recv_factor_ids);
+int32_t cx_halo_buffers(cx_handle *h, void **send_device_ptr, int64_t *send_bytes, void **recv_device_ptr,
+                        int64_t *recv_bytes);
+/* phases of one partitioned sweep, so the caller can overlap the exchange:
+ *   cx_sweep_phase(VAR_TO_FACTOR) → cx_halo_pack → [exchange] → cx_halo_unpack → cx_sweep_phase(FACTOR_TO_VAR) */
+#define CX_PHASE_VAR_TO_FACTOR 1
+#define CX_PHASE_FACTOR_TO_VAR 2
+int32_t cx_sweep_phase(cx_handle *h, int32_t phase);
+int32_t cx_halo_pack(cx_handle *h);
+int32_t cx_halo_unpack(cx_handle *h);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+#define CX_KERNEL_VAR_TO_FACTOR 0
+#define CX_KERNEL_FACTOR_TO_VAR 1
+#define CX_KERNEL_FUSED 2
+#define CX_KERNEL_BATCH 3
+#define CX_KERNEL_BIG_VAR 4
+#define CX_KERNEL_COUNT 8
+/* hipEvent pairs around every kernel launch of cx_sweep on the handle's stream */
+int32_t cx_profile_enable(cx_handle *h, int32_t on);
+int32_t cx_profile_read(cx_handle *h, int32_t kernel, double *total_ms, int64_t *launches); /* syncs; resets */
+const char *cx_kernel_name(int32_t kernel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CORTEX_HIP_H */

@@ -1,0 +1,123 @@
+"""oracle/exact.py — exact Gaussian posteriors by direct linear algebra.  TEST INFRASTRUCTURE ONLY.
+
+The reference pins nothing numeric for Gaussian belief propagation (its SSM test asserts only
+signs/monotonicity, test/inference_engine_tests.jl:485-487), so the mathematics does: on a
+tree, sum-product marginals equal the marginals of the joint Gaussian whatever the schedule;
+on a loopy Gaussian graph the converged BP *means* are exact (variances are not).
+These solvers share no code and no formulation with the message-passing paths they check.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def tridiag_posterior(diag, off, h):
+    """Mean and marginal variances of N^{-1}(h, J) with J symmetric tridiagonal
+    (diag[T], off[T-1] = J[t, t+1]).  Schur-complement recursions from both ends:
+        L_t = J_tt - off_{t-1}^2 / L_{t-1},   R_t = J_tt - off_t^2 / R_{t+1},
+        var_t = 1 / (L_t + R_t - J_tt),  mean by the matching forward/backward substitutions."""
+    diag = np.asarray(diag, dtype=np.float64)
+    off = np.asarray(off, dtype=np.float64)
+    h = np.asarray(h, dtype=np.float64)
+    T = len(diag)
+    L = np.empty(T); R = np.empty(T); hl = np.empty(T); hr = np.empty(T)
+    L[0] = diag[0]; hl[0] = h[0]
+    for t in range(1, T):
+        g = off[t - 1] / L[t - 1]
+        L[t] = diag[t] - g * off[t - 1]
+        hl[t] = h[t] - g * hl[t - 1]
+    R[T - 1] = diag[T - 1]; hr[T - 1] = h[T - 1]
+    for t in range(T - 2, -1, -1):
+        g = off[t] / R[t + 1]
+        R[t] = diag[t] - g * off[t]
+        hr[t] = h[t] - g * hr[t + 1]
+    prec = L + R - diag
+    var = 1.0 / prec
+    mean = (hl + hr - h) * var
+    return mean, var
+
+
+def ssm_chain_posterior(y, r, q):
+    """Posterior of the reference's SSM (test/inference_engine_tests.jl:436-453), generalised to
+    per-step variances: y_t ~ N(x_t, r_t), x_{t+1} ~ N(x_t, q_t); no prior on x_1."""
+    y = np.asarray(y, dtype=np.float64)
+    T = len(y)
+    r = np.broadcast_to(np.asarray(r, dtype=np.float64), (T,))
+    q = np.broadcast_to(np.asarray(q, dtype=np.float64), (max(T - 1, 0),))
+    diag = 1.0 / r
+    diag = diag.copy()
+    diag[:-1] += 1.0 / q
+    diag[1:] += 1.0 / q
+    off = -1.0 / q
+    return tridiag_posterior(diag, off, y / r)
+
+
+def grid_precision(n_rows, n_cols, r, qh, qv):
+    """Sparse precision of the grid model: unary y_i ~ N(x_i, r_i) and pairwise
+    difference factors x_i - x_j ~ N(0, q_ij).  qh[i, j] couples (i, j)-(i, j+1); qv[i, j]
+    couples (i, j)-(i+1, j).  Variable index = i * n_cols + j."""
+    import scipy.sparse as sp
+
+    r = np.asarray(r, dtype=np.float64).reshape(n_rows, n_cols)
+    idx = np.arange(n_rows * n_cols).reshape(n_rows, n_cols)
+    rows, cols, vals = [idx.ravel()], [idx.ravel()], [(1.0 / r).ravel()]
+
+    def couple(a, b, q):
+        w = 1.0 / np.asarray(q, dtype=np.float64).ravel()
+        a, b = a.ravel(), b.ravel()
+        rows.extend([a, b, a, b]); cols.extend([a, b, b, a]); vals.extend([w, w, -w, -w])
+
+    if n_cols > 1:
+        couple(idx[:, :-1], idx[:, 1:], np.asarray(qh).reshape(n_rows, n_cols - 1))
+    if n_rows > 1:
+        couple(idx[:-1, :], idx[1:, :], np.asarray(qv).reshape(n_rows - 1, n_cols))
+    J = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                      shape=(n_rows * n_cols,) * 2).tocsc()
+    return J
+
+
+def grid_posterior_mean(n_rows, n_cols, y, r, qh, qv):
+    import scipy.sparse.linalg as spla
+
+    J = grid_precision(n_rows, n_cols, r, qh, qv)
+    h = (np.asarray(y, dtype=np.float64).ravel() / np.asarray(r, dtype=np.float64).ravel())
+    return spla.spsolve(J, h)
+
+
+def block_tridiag_posterior(Jd, Jo, h):
+    """Block-tridiagonal analogue of tridiag_posterior.  Jd[T, d, d] diagonal blocks, Jo[T-1, d, d]
+    = J[t, t+1] blocks, h[T, d].  Returns means [T, d] and marginal covariances [T, d, d]."""
+    Jd = np.asarray(Jd, dtype=np.float64); Jo = np.asarray(Jo, dtype=np.float64); h = np.asarray(h, dtype=np.float64)
+    T, d = h.shape
+    L = np.empty_like(Jd); R = np.empty_like(Jd); hl = np.empty_like(h); hr = np.empty_like(h)
+    L[0] = Jd[0]; hl[0] = h[0]
+    for t in range(1, T):
+        G = np.linalg.solve(L[t - 1], Jo[t - 1]).T  # Jo^T L^{-1}
+        L[t] = Jd[t] - G @ Jo[t - 1]
+        hl[t] = h[t] - G @ hl[t - 1]
+    R[T - 1] = Jd[T - 1]; hr[T - 1] = h[T - 1]
+    for t in range(T - 2, -1, -1):
+        G = np.linalg.solve(R[t + 1].T, Jo[t].T).T  # Jo R^{-1}
+        R[t] = Jd[t] - G @ Jo[t].T
+        hr[t] = h[t] - G @ hr[t + 1]
+    P = L + R - Jd
+    cov = np.linalg.inv(P)
+    mean = np.einsum("tij,tj->ti", cov, hl + hr - h)
+    return mean, cov
+
+
+def lgssm_posterior(y, A, Q, R, H=None):
+    """Posterior of x_{t+1} = A x_t + w, w~N(0,Q);  y_t = H x_t + v, v~N(0,R); no prior on x_1
+    (SURVEY §8d C3/C5 shapes).  y[T, m]."""
+    y = np.asarray(y, dtype=np.float64)
+    T = y.shape[0]
+    d = A.shape[0]
+    H = np.eye(d) if H is None else H
+    Qi = np.linalg.inv(Q); Ri = np.linalg.inv(R)
+    obs = H.T @ Ri @ H
+    Jd = np.tile(obs, (T, 1, 1))
+    Jd[:-1] += A.T @ Qi @ A
+    Jd[1:] += Qi
+    Jo = np.tile(-(A.T @ Qi), (T - 1, 1, 1))
+    h = y @ (Ri @ H)  # rows: H^T R^{-1} y_t
+    return block_tridiag_posterior(Jd, Jo, h)

@@ -1,0 +1,371 @@
+"""oracle/ref.py — ctypes front-end of the CPU checker.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module; the product package never does (tests/test_no_oracle_in_product.py enforces it).
+
+``Engine`` mirrors what a reference test does with ``Cortex.InferenceEngine`` on a
+``BipartiteFactorGraph`` (test/inference_engine_tests.jl), backed by ``cortex_ref.c``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcortex_oracle.so")
+
+UNDEF, REAL, NORMAL, BETA, BOOL = 0, 1, 2, 3, 4
+VAR_UNSPECIFIED, VAR_MSG_TO_FACTOR, VAR_MSG_TO_VARIABLE, VAR_PRODUCT, VAR_MARGINAL, VAR_JOINT = range(6)
+F_OPAQUE, F_GAUSS_ADD, F_BERNOULLI, F_DOUBLE = range(4)
+P_SSM_BP, P_BETA_BERNOULLI, P_TRACING = range(3)
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement with the committed recipe (oracle/Makefile)."""
+    srcs = [os.path.join(_HERE, f) for f in ("cortex_ref.c", "bp_flood.c", "mv_flood.c", "Makefile")]
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libcortex_oracle.so"] + (["-B"] if force else []))
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_SO)
+    i32, i64, dbl, vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
+    pi32, pi64, pd, pu8 = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+
+    def sig(name, res, *args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    sig("cxo_engine_create", vp, i32, i32)
+    sig("cxo_engine_destroy", None, vp)
+    sig("cxo_add_variable", i64, vp)
+    sig("cxo_add_factor", i64, vp, i32, dbl, dbl)
+    sig("cxo_add_edge", i32, vp, i64, i64)
+    sig("cxo_engine_finalize", None, vp, i32)
+    sig("cxo_message_to_variable", i32, vp, i64, i64)
+    sig("cxo_message_to_factor", i32, vp, i64, i64)
+    sig("cxo_marginal", i32, vp, i64)
+    sig("cxo_scan", i64, vp, pi64, i64, pi32, i64)
+    sig("cxo_update_marginals", i32, vp, pi64, i64)
+    sig("cxo_signal_new", i32, vp)
+    sig("cxo_add_dependency", None, vp, i32, i32, i32, i32, i32, i32)
+    sig("cxo_set_value", None, vp, i32, i32, dbl, dbl)
+    sig("cxo_is_pending", i32, vp, i32)
+    sig("cxo_is_computed", i32, vp, i32)
+    sig("cxo_get_value", i32, vp, i32, pd, pd)
+    sig("cxo_num_dependencies", i32, vp, i32)
+    sig("cxo_dependency", i32, vp, i32, i32)
+    sig("cxo_num_listeners", i32, vp, i32)
+    sig("cxo_listener", i32, vp, i32, i32)
+    sig("cxo_num_chunks", i32, vp, i32)
+    sig("cxo_chunk", C.c_uint64, vp, i32, i32)
+    sig("cxo_variant", i32, vp, i32, pi64, pi64, pi32, pi32)
+    sig("cxo_num_signals", i64, vp)
+    sig("cxo_num_warnings", i32, vp)
+    sig("cxo_warning_context", i64, vp, i32)
+    sig("cxo_num_variables", i64, vp)
+    sig("cxo_num_factors", i64, vp)
+    sig("cxo_variable_ids", None, vp, pi64)
+    sig("cxo_factor_ids", None, vp, pi64)
+    sig("cxo_num_neighbors", i32, vp, i64)
+    sig("cxo_neighbor", i64, vp, i64, i32)
+    sig("cxo_trace_len", i64, vp)
+    sig("cxo_trace_rounds", i64, vp)
+    sig("cxo_trace_get", None, vp, i64, pi64, pi64, pi32, pi32, pd, pi32, pd, pd)
+    sig("cxo_counter", i64, vp, i32)
+    sig("cxo_last_error", i32, vp)
+    sig("cxo_process_dependencies", i32, vp, i32, i32, vp, vp)
+    sig("cxo_bulk_set_message_to_factor", None, vp, pi64, pi64, i64, i32, pd, pd)
+    sig("cxo_bulk_set_message_to_variable", None, vp, pi64, pi64, i64, i32, pd, pd)
+    sig("cxo_bulk_get_marginals", None, vp, pi64, i64, pi32, pd, pd)
+    sig("cxo_bulk_get_messages", None, vp, pi64, pi64, i64, i32, pi32, pd, pd)
+    sig("cxo_bulk_build", i32, vp, i64, pi32, pi32, pd, i64, pi64, pi64)
+    sig("cxo_flood_sweep", i64, i64, pi64, i64, pi64, pd, pu8, pd, pd, pd, pd, i32)
+    sig("cxo_flood_marginals", None, i64, pi64, pd, pd, pd, pd, i32)
+    _lib = L
+    return L
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+CALLBACK = C.CFUNCTYPE(C.c_int32, C.c_int32, C.c_void_p)
+
+
+class Engine:
+    """The reference's graph + InferenceEngine, restated (cortex_ref.c)."""
+
+    def __init__(self, processor: int = P_SSM_BP, trace: bool = False):
+        self.L = lib()
+        self.h = self.L.cxo_engine_create(processor, int(trace))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.cxo_engine_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # graph construction (ids follow BipartiteFactorGraphs: one shared 1-based counter)
+    def add_variable(self) -> int:
+        return self.L.cxo_add_variable(self.h)
+
+    def add_factor(self, fkind: int = F_OPAQUE, p0: float = 1.0, p1: float = 0.0) -> int:
+        return self.L.cxo_add_factor(self.h, fkind, p0, p1)
+
+    def add_edge(self, var: int, fac: int) -> int:
+        e = self.L.cxo_add_edge(self.h, var, fac)
+        if e < 0:
+            raise ValueError(f"bad edge ({var}, {fac})")
+        return e
+
+    def bulk_build(self, kind, fkind, p0, evar, efac):
+        kind = np.ascontiguousarray(kind, dtype=np.int32)
+        fkind = np.ascontiguousarray(fkind, dtype=np.int32)
+        p0 = np.ascontiguousarray(p0, dtype=np.float64)
+        evar, efac = _i64(evar), _i64(efac)
+        rc = self.L.cxo_bulk_build(self.h, len(kind), _p(kind, C.c_int32), _p(fkind, C.c_int32), _p(p0, C.c_double),
+                                   len(evar), _p(evar, C.c_int64), _p(efac, C.c_int64))
+        if rc != 0:
+            raise ValueError("bulk_build: bad edge")
+
+    def finalize(self, resolve_dependencies: bool = True):
+        self.L.cxo_engine_finalize(self.h, int(resolve_dependencies))
+
+    # signals
+    def message_to_variable(self, var, fac):
+        return self.L.cxo_message_to_variable(self.h, var, fac)
+
+    def message_to_factor(self, var, fac):
+        return self.L.cxo_message_to_factor(self.h, var, fac)
+
+    def marginal(self, var):
+        return self.L.cxo_marginal(self.h, var)
+
+    def signal(self):
+        return self.L.cxo_signal_new(self.h)
+
+    def add_dependency(self, s, d, weak=False, listen=True, check_computed=True, intermediate=False):
+        self.L.cxo_add_dependency(self.h, s, d, int(weak), int(listen), int(check_computed), int(intermediate))
+
+    def set_value(self, s, value, tag=None, b=0.0):
+        if isinstance(value, tuple):
+            tag, a, b = value
+        elif isinstance(value, bool):
+            tag, a = BOOL, float(value)
+        else:
+            tag, a = (REAL if tag is None else tag), float(value)
+        self.L.cxo_set_value(self.h, s, tag, a, b)
+
+    def is_pending(self, s) -> bool:
+        return bool(self.L.cxo_is_pending(self.h, s))
+
+    def is_computed(self, s) -> bool:
+        return bool(self.L.cxo_is_computed(self.h, s))
+
+    def get_value(self, s):
+        a, b = C.c_double(), C.c_double()
+        tag = self.L.cxo_get_value(self.h, s, C.byref(a), C.byref(b))
+        return tag, a.value, b.value
+
+    def dependencies(self, s):
+        return [self.L.cxo_dependency(self.h, s, i) for i in range(self.L.cxo_num_dependencies(self.h, s))]
+
+    def listeners(self, s):
+        return [self.L.cxo_listener(self.h, s, i) for i in range(self.L.cxo_num_listeners(self.h, s))]
+
+    def chunks(self, s):
+        return [self.L.cxo_chunk(self.h, s, c) for c in range(self.L.cxo_num_chunks(self.h, s))]
+
+    def variant(self, s):
+        v, f, lo, hi = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+        k = self.L.cxo_variant(self.h, s, C.byref(v), C.byref(f), C.byref(lo), C.byref(hi))
+        return k, v.value, f.value, lo.value, hi.value
+
+    def process_dependencies(self, s, fn, retry=False) -> bool:
+        cb = CALLBACK(lambda sig, ctx: int(bool(fn(sig))))
+        return bool(self.L.cxo_process_dependencies(self.h, s, int(retry), C.cast(cb, C.c_void_p), None))
+
+    def warnings(self):
+        return [self.L.cxo_warning_context(self.h, i) for i in range(self.L.cxo_num_warnings(self.h))]
+
+    def variable_ids(self):
+        out = np.zeros(self.L.cxo_num_variables(self.h), dtype=np.int64)
+        self.L.cxo_variable_ids(self.h, _p(out, C.c_int64))
+        return out
+
+    def factor_ids(self):
+        out = np.zeros(self.L.cxo_num_factors(self.h), dtype=np.int64)
+        self.L.cxo_factor_ids(self.h, _p(out, C.c_int64))
+        return out
+
+    def neighbors(self, node_id):
+        return [self.L.cxo_neighbor(self.h, node_id, k) for k in range(self.L.cxo_num_neighbors(self.h, node_id))]
+
+    # scheduler
+    def scan(self, ids):
+        ids = _i64(np.atleast_1d(ids))
+        cap = 1 << 16
+        out = np.zeros(cap, dtype=np.int32)
+        n = self.L.cxo_scan(self.h, _p(ids, C.c_int64), len(ids), _p(out, C.c_int32), cap)
+        return out[:n].tolist()
+
+    def update_marginals(self, ids):
+        ids = _i64(np.atleast_1d(ids))
+        rc = self.L.cxo_update_marginals(self.h, _p(ids, C.c_int64), len(ids))
+        if rc == 1:
+            raise ValueError("Signal is not pending. Cannot compute a non-pending signal.")  # signal.jl:399-405
+        if rc == 2:
+            raise RuntimeError("rule not implemented for this processor / variant")  # inference_engine.jl:358
+        return None
+
+    def trace(self):
+        """[(round, variable_id, signal, value_before, value_after)] of the last update_marginals."""
+        out = []
+        r, v, s = C.c_int64(), C.c_int64(), C.c_int32()
+        tb, ab, ta, aa, ba = C.c_int32(), C.c_double(), C.c_int32(), C.c_double(), C.c_double()
+        for i in range(self.L.cxo_trace_len(self.h)):
+            self.L.cxo_trace_get(self.h, i, C.byref(r), C.byref(v), C.byref(s), C.byref(tb), C.byref(ab),
+                                 C.byref(ta), C.byref(aa), C.byref(ba))
+            out.append((r.value, v.value, s.value, (tb.value, ab.value), (ta.value, aa.value, ba.value)))
+        return out
+
+    def trace_rounds(self):
+        return self.L.cxo_trace_rounds(self.h)
+
+    def counters(self):
+        return self.L.cxo_counter(self.h, 0), self.L.cxo_counter(self.h, 1)
+
+    # bulk
+    def set_messages_to_factor(self, vars_, facs, a, b=None, tag=REAL):
+        vars_, facs = _i64(vars_), _i64(facs)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        bp = None if b is None else _p(np.ascontiguousarray(b, dtype=np.float64), C.c_double)
+        self.L.cxo_bulk_set_message_to_factor(self.h, _p(vars_, C.c_int64), _p(facs, C.c_int64), len(vars_), tag,
+                                              _p(a, C.c_double), bp)
+
+    def set_messages_to_variable(self, vars_, facs, a, b=None, tag=NORMAL):
+        vars_, facs = _i64(vars_), _i64(facs)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = None if b is None else np.ascontiguousarray(b, dtype=np.float64)
+        bp = None if b is None else _p(b, C.c_double)
+        self.L.cxo_bulk_set_message_to_variable(self.h, _p(vars_, C.c_int64), _p(facs, C.c_int64), len(vars_), tag,
+                                                _p(a, C.c_double), bp)
+
+    def get_marginals(self, vars_):
+        vars_ = _i64(vars_)
+        n = len(vars_)
+        tags, a, b = np.zeros(n, np.int32), np.zeros(n), np.zeros(n)
+        self.L.cxo_bulk_get_marginals(self.h, _p(vars_, C.c_int64), n, _p(tags, C.c_int32), _p(a, C.c_double),
+                                      _p(b, C.c_double))
+        return tags, a, b
+
+    def get_messages(self, vars_, facs, to_variable: bool):
+        vars_, facs = _i64(vars_), _i64(facs)
+        n = len(vars_)
+        tags, a, b = np.zeros(n, np.int32), np.zeros(n), np.zeros(n)
+        self.L.cxo_bulk_get_messages(self.h, _p(vars_, C.c_int64), _p(facs, C.c_int64), n, int(to_variable),
+                                     _p(tags, C.c_int32), _p(a, C.c_double), _p(b, C.c_double))
+        return tags, a, b
+
+
+# --------------------------------------------------------------------------- flooding oracle
+
+class FloodGraph:
+    """Flattened edge list for bp_flood.c.  Built here, independently of the product's
+    flattening (cortex.jl_amd/csrc/graph.cpp), from the same (edge_var, edge_fac) lists:
+    edges sorted by (variable id, factor id) — ascending-id neighbour order."""
+
+    def __init__(self, edge_var, edge_fac, factor_ids, factor_var):
+        edge_var, edge_fac = _i64(edge_var), _i64(edge_fac)
+        order = np.lexsort((edge_fac, edge_var))
+        self.order = order
+        self.edge_var = edge_var[order]
+        self.edge_fac = edge_fac[order]
+        self.var_ids = np.unique(self.edge_var)
+        vidx = np.searchsorted(self.var_ids, self.edge_var)
+        self.nv = len(self.var_ids)
+        self.ne = len(edge_var)
+        self.var_off = np.zeros(self.nv + 1, dtype=np.int64)
+        np.add.at(self.var_off, vidx + 1, 1)
+        self.var_off = np.cumsum(self.var_off)
+        # partner: the other edge of a 2-edge factor; -1 for unary; error for >2
+        forder = np.lexsort((self.edge_var, self.edge_fac))
+        fsorted = self.edge_fac[forder]
+        self.partner = np.full(self.ne, -1, dtype=np.int64)
+        starts = np.flatnonzero(np.r_[True, fsorted[1:] != fsorted[:-1]])
+        counts = np.diff(np.r_[starts, self.ne])
+        if np.any(counts > 2):
+            raise ValueError("scalar flooding oracle handles unary and pairwise factors only")
+        two = starts[counts == 2]
+        self.partner[forder[two]] = forder[two + 1]
+        self.partner[forder[two + 1]] = forder[two]
+        fids = _i64(factor_ids)
+        fvar = np.ascontiguousarray(factor_var, dtype=np.float64)
+        srt = np.argsort(fids)
+        pos = np.searchsorted(fids[srt], self.edge_fac)
+        self.q = fvar[srt][pos]
+        self.fixed_v2f = np.zeros(self.ne, dtype=np.uint8)
+        nan = np.full(self.ne, np.nan)
+        self.f2v_m, self.f2v_v = nan.copy(), nan.copy()
+        self.v2f_m, self.v2f_v = nan.copy(), nan.copy()
+
+    def edge_index(self, var, fac):
+        var, fac = _i64(np.atleast_1d(var)), _i64(np.atleast_1d(fac))
+        key = self.edge_var.astype(np.int64) * (int(self.edge_fac.max()) + 1) + self.edge_fac
+        want = var * (int(self.edge_fac.max()) + 1) + fac
+        pos = np.searchsorted(key, want)
+        if np.any(pos >= self.ne) or np.any(key[np.minimum(pos, self.ne - 1)] != want):
+            raise KeyError("edge not found")
+        return pos
+
+    def set_data(self, var, fac, y):
+        """set_value!(message_to_factor(var, fac), y::Real) — clamped data."""
+        e = self.edge_index(var, fac)
+        self.v2f_m[e] = y
+        self.v2f_v[e] = 0.0
+        self.fixed_v2f[e] = 1
+
+    def set_message_to_factor(self, var, fac, mean, variance):
+        e = self.edge_index(var, fac)
+        self.v2f_m[e], self.v2f_v[e] = mean, variance
+
+    def set_message_to_variable(self, var, fac, mean, variance):
+        e = self.edge_index(var, fac)
+        self.f2v_m[e], self.f2v_v[e] = mean, variance
+
+    def sweep(self, n=1, use_omp=False):
+        L = lib()
+        total = 0
+        for _ in range(n):
+            total += L.cxo_flood_sweep(self.nv, _p(self.var_off, C.c_int64), self.ne, _p(self.partner, C.c_int64),
+                                       _p(self.q, C.c_double), _p(self.fixed_v2f, C.c_uint8),
+                                       _p(self.f2v_m, C.c_double), _p(self.f2v_v, C.c_double),
+                                       _p(self.v2f_m, C.c_double), _p(self.v2f_v, C.c_double), int(use_omp))
+        return total
+
+    def marginals(self, use_omp=False):
+        L = lib()
+        m, v = np.zeros(self.nv), np.zeros(self.nv)
+        L.cxo_flood_marginals(self.nv, _p(self.var_off, C.c_int64), _p(self.f2v_m, C.c_double),
+                              _p(self.f2v_v, C.c_double), _p(m, C.c_double), _p(v, C.c_double), int(use_omp))
+        return m, v

@@ -1,0 +1,57 @@
+"""Shared test plumbing: the same Model arrays go to the HIP path and to the CPU checker (oracle/)."""
+import numpy as np
+
+from oracle import ref
+
+
+def flood_oracle_from_model(model, seed_variance=None):
+    """FloodGraph (oracle/bp_flood.c) loaded with the model's data, mirroring synth.load_into_device."""
+    g = ref.FloodGraph(model.edge_var, model.edge_fac, model.factor_ids, model.factor_var)
+    if len(model.data_var):
+        g.set_data(model.data_var, model.data_fac, model.data_y)
+    if len(model.prior_var):
+        g.set_message_to_variable(model.prior_var, model.prior_fac, model.prior_mean, model.prior_variance)
+    if seed_variance is not None:
+        und = np.isnan(g.f2v_v) & (g.partner >= 0)
+        g.f2v_m[und] = 0.0
+        g.f2v_v[und] = seed_variance
+    return g
+
+
+def engine_oracle_from_model(model, trace=False):
+    """The reference's InferenceEngine restated (oracle/cortex_ref.c) on the same graph and data."""
+    n_nodes = int(max(model.edge_var.max(), model.factor_ids.max()))
+    kind = np.zeros(n_nodes, dtype=np.int32)
+    fkind = np.zeros(n_nodes, dtype=np.int32)
+    p0 = np.ones(n_nodes)
+    kind[np.unique(model.edge_var) - 1] = 1
+    kind[model.factor_ids - 1] = 2
+    fkind[model.factor_ids - 1] = np.where(model.factor_kind == 1, ref.F_GAUSS_ADD, ref.F_OPAQUE)
+    p0[model.factor_ids - 1] = model.factor_var
+    assert np.all(kind > 0), "ids must be dense for the restated BipartiteFactorGraph"
+    E = ref.Engine(ref.P_SSM_BP, trace)
+    E.bulk_build(kind, fkind, p0, model.edge_var, model.edge_fac)
+    E.finalize()
+    if len(model.data_var):
+        E.set_messages_to_factor(model.data_var, model.data_fac, model.data_y, tag=ref.REAL)
+    if len(model.prior_var):
+        E.set_messages_to_variable(model.prior_var, model.prior_fac, model.prior_mean, model.prior_variance, tag=ref.NORMAL)
+    return E
+
+
+def assert_close(actual, expected, rtol, what=""):
+    """|a-b| <= rtol * max(|b|, scale) elementwise, scale = typical magnitude of `expected`
+    (means cross zero, so a pure relative test is ill-posed there); NaN patterns must agree."""
+    actual = np.asarray(actual, dtype=np.float64)
+    expected = np.asarray(expected, dtype=np.float64)
+    assert actual.shape == expected.shape, f"{what}: shape {actual.shape} vs {expected.shape}"
+    na, ne = np.isnan(actual), np.isnan(expected)
+    assert np.array_equal(na, ne), f"{what}: undefined-value pattern differs ({na.sum()} vs {ne.sum()} NaN)"
+    ok = ~ne
+    if not ok.any():
+        return 0.0
+    scale = max(float(np.median(np.abs(expected[ok]))), 1e-300)
+    err = np.abs(actual[ok] - expected[ok]) / np.maximum(np.abs(expected[ok]), scale)
+    worst = float(err.max())
+    assert worst <= rtol, f"{what}: max rel err {worst:.3e} > {rtol:.1e}"
+    return worst
