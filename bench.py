@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--grid", type=int, default=1415, help="N: each rank holds an N x N grid strip (1415 -> 10,005,465 edges)")
     ap.add_argument("--schedule", choices=["flooding", "fused"], default=os.environ.get("CX_BENCH_SCHEDULE", "fused"))
+    ap.add_argument("--materialize", action="store_true", help="also store every variable→factor message each sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-grid", type=int, default=768, help="grid side of the bounded CPU sample")
     ap.add_argument("--seed", type=int, default=1234)
@@ -95,7 +96,8 @@ def main():
 
     N = args.grid
     schedule = L.SCHED_FUSED if (args.schedule == "fused" and world == 1) else L.SCHED_FLOODING
-    dev = cx.DeviceGraph(device=local_rank, schedule=schedule, marginals_in_sweep=True)
+    dev = cx.DeviceGraph(device=local_rank, schedule=schedule, marginals_in_sweep=True,
+                         materialize_messages_to_factor=args.materialize)
     stream = torch.cuda.current_stream()
     dev.set_stream(stream.cuda_stream)
 

@@ -21,14 +21,15 @@ FACTOR_OPAQUE, FACTOR_GAUSS_ADDITIVE, FACTOR_GAUSS_LINEAR = 0, 1, 2
 NPARAM = 4
 ROLE_OUT, ROLE_IN = 0, 1
 SCHED_FLOODING, SCHED_FUSED = 0, 1
-PHASE_VAR_TO_FACTOR, PHASE_FACTOR_TO_VAR = 1, 2
 KERNEL_VAR_TO_FACTOR, KERNEL_FACTOR_TO_VAR, KERNEL_FUSED, KERNEL_BATCH, KERNEL_BIG_VAR = 0, 1, 2, 3, 4
+KERNEL_HALO_BEGIN, KERNEL_HALO_END = 5, 6
 KERNEL_COUNT = 8
 
 
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("dim", C.c_int32), ("schedule", C.c_int32),
-                ("compute_marginals_in_sweep", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("compute_marginals_in_sweep", C.c_int32), ("materialize_messages_to_factor", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
 
 
 class Item(C.Structure):
@@ -37,8 +38,8 @@ class Item(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_variables", C.c_int64), ("n_factors", C.c_int64), ("n_edges", C.c_int64),
-                ("n_messages_per_sweep", C.c_int64), ("n_small_blocks", C.c_int64), ("n_big_variables", C.c_int64),
-                ("device_bytes", C.c_int64), ("sweeps_done", C.c_int64)]
+                ("n_messages_per_sweep", C.c_int64), ("n_slices", C.c_int64), ("n_big_variables", C.c_int64),
+                ("n_slots", C.c_int64), ("device_bytes", C.c_int64), ("sweeps_done", C.c_int64)]
 
 
 _i32, _i64, _dbl, _vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
@@ -65,9 +66,10 @@ SIGNATURES = {
     "cx_residual": (_i32, [_vp, _pd]),
     "cx_halo_configure": (_i32, [_vp, _i64, _pi64, _pi64, _i64, _pi64, _pi64]),
     "cx_halo_buffers": (_i32, [_vp, C.POINTER(_vp), _pi64, C.POINTER(_vp), _pi64]),
-    "cx_sweep_phase": (_i32, [_vp, _i32]),
-    "cx_halo_pack": (_i32, [_vp]),
-    "cx_halo_unpack": (_i32, [_vp]),
+    "cx_halo_set_buffers": (_i32, [_vp, _vp, _vp]),
+    "cx_sweep_begin": (_i32, [_vp]),
+    "cx_sweep_main": (_i32, [_vp]),
+    "cx_sweep_end": (_i32, [_vp]),
     "cx_profile_enable": (_i32, [_vp, _i32]),
     "cx_profile_read": (_i32, [_vp, _i32, _pd, _pi64]),
     "cx_kernel_name": (C.c_char_p, [_i32]),

@@ -54,16 +54,18 @@ int32_t dev_upload(cx_handle *h, T **p, const std::vector<T> &v) {
 }
 
 void dev_free_all(cx_handle *h) {
-    void *ptrs[] = {h->d_var_off, h->d_partner, h->d_edge_var, h->d_blk, h->d_big, h->d_big_tmp_off, h->d_big_edges,
-                    h->d_big_tmp, h->d_var_flags, h->d_q, h->d_a, h->d_b, h->d_sq, h->d_sa, h->d_sb, h->d_f2v, h->d_v2f,
-                    h->d_marg, h->d_f2v_alt, h->d_prev, h->d_scratch, h->d_send_edges, h->d_recv_edges, h->d_send_buf,
-                    h->d_recv_buf, h->d_stage};
+    void *ptrs[] = {h->d_slice_off, h->d_partner, h->d_vbase, h->d_var_deg, h->d_big, h->d_big_slots, h->d_big_tmp,
+                    h->d_vinfo, h->d_q, h->d_a, h->d_b, h->d_sq, h->d_sa, h->d_sb, h->d_f2v, h->d_v2f, h->d_marg,
+                    h->d_f2v_alt, h->d_prev, h->d_scratch, h->d_send_slots, h->d_recv_slots, h->d_send_vars,
+                    h->ext_halo_buffers ? nullptr : (void *)h->d_send_buf, h->ext_halo_buffers ? nullptr : (void *)h->d_recv_buf,
+                    h->d_stage};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    h->d_var_off = h->d_partner = h->d_edge_var = h->d_blk = h->d_big = h->d_big_tmp_off = h->d_big_edges = nullptr;
-    h->d_big_tmp = nullptr; h->d_var_flags = nullptr;
+    h->d_slice_off = h->d_partner = h->d_vbase = h->d_var_deg = h->d_big = h->d_big_slots = nullptr;
+    h->d_big_tmp = nullptr; h->d_vinfo = nullptr;
     h->d_q = h->d_a = h->d_b = h->d_sq = h->d_sa = h->d_sb = nullptr;
     h->d_f2v = h->d_v2f = h->d_marg = h->d_f2v_alt = h->d_prev = nullptr;
-    h->d_scratch = nullptr; h->d_send_edges = h->d_recv_edges = nullptr; h->d_send_buf = h->d_recv_buf = nullptr;
+    h->d_scratch = nullptr; h->d_send_slots = h->d_recv_slots = h->d_send_vars = nullptr;
+    h->d_send_buf = h->d_recv_buf = nullptr;
     h->d_stage = nullptr; h->stage_bytes = 0; h->device_bytes = 0;
 }
 
@@ -135,11 +137,13 @@ int64_t cx_payload_doubles(int32_t dim, int32_t form) {
 
 const char *cx_kernel_name(int32_t k) {
     switch (k) {
-    case CX_KERNEL_VAR_TO_FACTOR: return "k_var_to_factor";
+    case CX_KERNEL_VAR_TO_FACTOR: return "k_sweep<var_to_factor>";
     case CX_KERNEL_FACTOR_TO_VAR: return "k_factor_to_var";
-    case CX_KERNEL_FUSED: return "k_fused";
+    case CX_KERNEL_FUSED: return "k_sweep<fused>";
     case CX_KERNEL_BATCH: return "k_batch";
     case CX_KERNEL_BIG_VAR: return "k_big_var_to_factor";
+    case CX_KERNEL_HALO_BEGIN: return "k_v2f_slots<halo>";
+    case CX_KERNEL_HALO_END: return "k_push_slots<halo>";
     }
     return "";
 }
@@ -196,7 +200,7 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
     CX_REQUIRE(h, h, CX_ERR_INVALID_ARGUMENT, "null handle");
     CX_REQUIRE(h, !h->has_graph, CX_ERR_STATE, "cx_graph_create: handle already has a graph");
     CX_REQUIRE(h, n_edges > 0 && edge_var && edge_fac, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: empty edge list");
-    CX_REQUIRE(h, n_edges < (int64_t)0x7fffffff, CX_ERR_UNSUPPORTED, "cx_graph_create: more than 2^31-1 edges per handle");
+    CX_REQUIRE(h, n_edges < (int64_t)0x0fffffff, CX_ERR_UNSUPPORTED, "cx_graph_create: more than 2^28-1 edges per handle");
     CX_REQUIRE(h, n_factors > 0 && factor_ids && factor_kind && factor_params, CX_ERR_INVALID_ARGUMENT,
                "cx_graph_create: factor table missing");
     try {
@@ -214,7 +218,7 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
         for (int64_t e = 1; e < ne; e++)
             if (edge_var[ord[e]] == edge_var[ord[e - 1]] && edge_fac[ord[e]] == edge_fac[ord[e - 1]])
                 return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: duplicate edge");
-        // ---- variables ---------------------------------------------------------------------------------------------
+        // ---- variables (CSR) ----------------------------------------------------------------------------------------
         h->var_ids.clear(); h->var_off.clear(); h->edge_var.assign(ne, 0); h->edge_fac_id.assign(ne, 0);
         for (int64_t e = 0; e < ne; e++) {
             int64_t v = edge_var[ord[e]];
@@ -225,10 +229,43 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
         }
         h->var_off.push_back((int32_t)ne);
         h->nv = (int64_t)h->var_ids.size(); h->ne = ne;
-        // ---- factors -----------------------------------------------------------------------------------------------
+        const int64_t nv = h->nv;
+        // ---- SELL-256 slot layout -----------------------------------------------------------------------------------
+        h->nslices = (nv + cx::kBlock - 1) / cx::kBlock;
+        h->vinfo.assign(nv, 0); h->vbase.assign(nv, 0); h->slice_off.assign(h->nslices + 1, 0);
+        h->big_vars.clear(); h->big_slots.clear();
+        std::vector<int32_t> var_deg(nv);
+        int64_t slots = 0;
+        for (int64_t s = 0; s < h->nslices; s++) {
+            int32_t W = 0;
+            const int64_t v0 = s * cx::kBlock, v1 = std::min<int64_t>(nv, v0 + cx::kBlock);
+            for (int64_t v = v0; v < v1; v++) {
+                const int32_t deg = h->var_off[v + 1] - h->var_off[v];
+                var_deg[v] = deg;
+                if (deg <= cx::kSmallDeg) { W = std::max(W, deg); h->vinfo[v] = (uint8_t)deg; }
+                else { h->vinfo[v] = cx::kBigDeg; h->big_vars.push_back((int32_t)v); }
+            }
+            h->slice_off[s] = (int32_t)slots;
+            for (int64_t v = v0; v < v1; v++) h->vbase[v] = (int32_t)(slots + (v - v0));
+            slots += (int64_t)W * cx::kBlock;
+            CX_REQUIRE(h, slots < (int64_t)0x7fffff00, CX_ERR_UNSUPPORTED, "cx_graph_create: slot space exceeds 2^31");
+        }
+        h->slice_off[h->nslices] = (int32_t)slots;
+        h->big_start = (int32_t)slots;
+        for (int32_t v : h->big_vars) {
+            h->vbase[v] = (int32_t)slots;
+            for (int32_t k = 0; k < var_deg[v]; k++) h->big_slots.push_back((int32_t)slots + k);
+            slots += var_deg[v];
+            CX_REQUIRE(h, slots < (int64_t)0x7fffff00, CX_ERR_UNSUPPORTED, "cx_graph_create: slot space exceeds 2^31");
+        }
+        h->nslots = slots;
+        const int64_t big_total = slots - h->big_start;
+        // ---- factors ------------------------------------------------------------------------------------------------
         std::vector<int64_t> ford(n_factors);
         std::iota(ford.begin(), ford.end(), 0);
-        std::sort(ford.begin(), ford.end(), [&](int64_t a, int64_t b) { return factor_ids[a] < factor_ids[b]; });
+        bool fsorted = true;
+        for (int64_t f = 1; f < n_factors && fsorted; f++) fsorted = factor_ids[f - 1] < factor_ids[f];
+        if (!fsorted) std::sort(ford.begin(), ford.end(), [&](int64_t a, int64_t b) { return factor_ids[a] < factor_ids[b]; });
         h->fac_ids.resize(n_factors); h->fac_kind.resize(n_factors); h->fac_params.resize(n_factors * CX_NPARAM);
         for (int64_t f = 0; f < n_factors; f++) {
             h->fac_ids[f] = factor_ids[ford[f]];
@@ -249,15 +286,12 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
         for (int64_t f = 0; f < n_factors; f++) foff[f + 1] += foff[f];
         std::vector<int32_t> fedge(ne), fill(foff.begin(), foff.end() - 1);
         for (int64_t e = 0; e < ne; e++) fedge[fill[edge_fac[e]]++] = (int32_t)e;
-        // ---- per-edge rule parameters and partners (gather lists of dependencies.jl:17-31) --------------------------
-        h->partner.assign(ne, -1);
-        std::vector<double> q(ne, 0.0), a, b, sq, sa, sb;
+        // ---- per-slot rule parameters and partners (the gather lists of dependencies.jl:17-31) ----------------------
+        h->partner.assign(slots, -1);
+        std::vector<double> q(slots, 0.0), a, b, sq, sa, sb;
         h->any_linear = false;
         for (int64_t f = 0; f < n_factors; f++) if (h->fac_kind[f] == CX_FACTOR_GAUSS_LINEAR) h->any_linear = true;
-        if (h->any_linear) { a.assign(ne, 1.0); b.assign(ne, 0.0); sq.assign(ne, 0.0); sa.assign(ne, 1.0); sb.assign(ne, 0.0); }
-        std::vector<int32_t> role(ne, CX_ROLE_OUT);
-        if (edge_role) for (int64_t e = 0; e < ne; e++) role[e] = edge_role[ord[e]];
-        int64_t listened = 0;
+        if (h->any_linear) { a.assign(slots, 1.0); b.assign(slots, 0.0); sq.assign(slots, 0.0); sa.assign(slots, 1.0); sb.assign(slots, 0.0); }
         for (int64_t f = 0; f < n_factors; f++) {
             const int32_t deg = foff[f + 1] - foff[f], kind = h->fac_kind[f];
             const double *p = &h->fac_params[f * CX_NPARAM];
@@ -267,87 +301,59 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
             if (deg != 2) return fail(h, CX_ERR_UNSUPPORTED, "cx_graph_create: Gaussian factor kinds need exactly 2 edges (factor id " + std::to_string(h->fac_ids[f]) + ")");
             if (!(p[0] >= 0.0)) return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: factor variance must be >= 0");
             const int32_t e1 = fedge[foff[f]], e2 = fedge[foff[f] + 1];
-            h->partner[e1] = e2; h->partner[e2] = e1;
-            q[e1] = q[e2] = p[0];
+            const int32_t s1 = cx::slot_of_edge(h, e1), s2 = cx::slot_of_edge(h, e2);
+            h->partner[s1] = s2; h->partner[s2] = s1;
+            q[s1] = q[s2] = p[0];
             if (kind == CX_FACTOR_GAUSS_LINEAR) {
                 // x_out = a x_in + b + N(0,q): the edge with ROLE_IN carries x_in.  Effective parameters of the
                 // RECEIVING edge: forward (receiver = out) {a, b, q}; backward (receiver = in) {1/a, -b/a, q/a²}.
                 const double A = p[1], B = p[2];
                 if (A == 0.0) return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: GAUSS_LINEAR with a == 0");
-                if (role[e1] == role[e2]) return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: GAUSS_LINEAR needs one ROLE_IN and one ROLE_OUT edge");
-                const int32_t ein = role[e1] == CX_ROLE_IN ? e1 : e2, eout = role[e1] == CX_ROLE_IN ? e2 : e1;
-                a[eout] = A; b[eout] = B; q[eout] = p[0];
-                a[ein] = 1.0 / A; b[ein] = -B / A; q[ein] = p[0] / (A * A);
+                const int32_t r1 = edge_role ? edge_role[ord[e1]] : CX_ROLE_OUT, r2 = edge_role ? edge_role[ord[e2]] : CX_ROLE_OUT;
+                if (r1 == r2) return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: GAUSS_LINEAR needs one ROLE_IN and one ROLE_OUT edge");
+                const int32_t sin = r1 == CX_ROLE_IN ? s1 : s2, sout = r1 == CX_ROLE_IN ? s2 : s1;
+                a[sout] = A; b[sout] = B; q[sout] = p[0];
+                a[sin] = 1.0 / A; b[sin] = -B / A; q[sin] = p[0] / (A * A);
             }
-            listened += 2;
         }
         if (h->any_linear)
-            for (int64_t e = 0; e < ne; e++)
-                if (h->partner[e] >= 0) { sq[e] = q[h->partner[e]]; sa[e] = a[h->partner[e]]; sb[e] = b[h->partner[e]]; }
-        // ---- workgroup partition of the small-degree variables; list of big ones ----------------------------------
-        h->blk.clear(); h->big_vars.clear(); h->big_tmp_off.clear(); h->big_edges.clear();
-        int64_t big_total = 0;
-        // Simple, robust formulation: consecutive ranges [blk[b], blk[b+1]) covering all variables; a range holds
-        // either only small variables (≤ kBlock of them, ≤ kCapEdges edges) or exactly one big variable.
-        {
-            h->blk.push_back(0);
-            int32_t vars = 0, edges = 0;
-            for (int64_t v = 0; v < h->nv; v++) {
-                const int32_t deg = h->var_off[v + 1] - h->var_off[v];
-                if (deg > cx::kSmallDeg) {
-                    if (vars > 0) { h->blk.push_back((int32_t)v); vars = 0; edges = 0; }
-                    h->blk.push_back((int32_t)v + 1);
-                    h->big_vars.push_back((int32_t)v);
-                    h->big_tmp_off.push_back((int32_t)big_total);
-                    big_total += deg;
-                    for (int32_t e = h->var_off[v]; e < h->var_off[v + 1]; e++) h->big_edges.push_back(e);
-                    continue;
-                }
-                if (vars == cx::kBlock || edges + deg > cx::kCapEdges) { h->blk.push_back((int32_t)v); vars = 0; edges = 0; }
-                vars++; edges += deg;
-            }
-            if (vars > 0) h->blk.push_back((int32_t)h->nv);
-        }
-        CX_REQUIRE(h, big_total < (int64_t)0x7fffffff, CX_ERR_UNSUPPORTED, "too many high-degree edges");
-        // messages with >=1 dependency and >=1 listener: both directions of every 2-edge Gaussian factor, minus the
-        // variable→factor messages of degree-1 variables (no dependencies, dependencies.jl:48-55)
+            for (int64_t s = 0; s < slots; s++)
+                if (h->partner[s] >= 0) { sq[s] = q[h->partner[s]]; sa[s] = a[h->partner[s]]; sb[s] = b[h->partner[s]]; }
+        // messages with >=1 dependency and >=1 listener (the metric's unit): both directions of every 2-edge Gaussian
+        // factor, minus variable→factor messages of degree-1 variables (no dependencies, dependencies.jl:48-55)
         int64_t m = 0;
         for (int64_t e = 0; e < ne; e++) {
-            if (h->partner[e] < 0) continue;
-            m += 1;  // factor→variable on e (its dependency is v2f on the partner)
-            const int32_t v = h->edge_var[e];
-            if (h->var_off[v + 1] - h->var_off[v] >= 2) m += 1;  // variable→factor on e
+            if (h->partner[cx::slot_of_edge(h, e)] < 0) continue;
+            m += 1;
+            if (var_deg[h->edge_var[e]] >= 2) m += 1;
         }
         h->n_messages_per_sweep = m;
-        (void)listened;
         // ---- upload ------------------------------------------------------------------------------------------------
         CX_HIP(h, hipSetDevice(h->cfg.device));
         int32_t rc;
 #define CX_TRY(x) do { rc = (x); if (rc != CX_OK) { dev_free_all(h); return rc; } } while (0)
-        CX_TRY(dev_upload(h, &h->d_var_off, h->var_off));
+        CX_TRY(dev_upload(h, &h->d_slice_off, h->slice_off));
         CX_TRY(dev_upload(h, &h->d_partner, h->partner));
-        CX_TRY(dev_upload(h, &h->d_edge_var, h->edge_var));
-        CX_TRY(dev_upload(h, &h->d_blk, h->blk));
+        CX_TRY(dev_upload(h, &h->d_vbase, h->vbase));
+        CX_TRY(dev_upload(h, &h->d_var_deg, var_deg));
+        CX_TRY(dev_upload(h, &h->d_vinfo, h->vinfo));
         CX_TRY(dev_upload(h, &h->d_big, h->big_vars));
-        CX_TRY(dev_upload(h, &h->d_big_tmp_off, h->big_tmp_off));
-        CX_TRY(dev_upload(h, &h->d_big_edges, h->big_edges));
+        CX_TRY(dev_upload(h, &h->d_big_slots, h->big_slots));
         CX_TRY(dev_alloc(h, &h->d_big_tmp, big_total));
         CX_TRY(dev_upload(h, &h->d_q, q));
         if (h->any_linear) {
             CX_TRY(dev_upload(h, &h->d_a, a)); CX_TRY(dev_upload(h, &h->d_b, b));
             CX_TRY(dev_upload(h, &h->d_sq, sq)); CX_TRY(dev_upload(h, &h->d_sa, sa)); CX_TRY(dev_upload(h, &h->d_sb, sb));
         }
-        h->var_flags.assign(h->nv, 0);
-        CX_TRY(dev_upload(h, &h->d_var_flags, h->var_flags));
-        CX_TRY(dev_alloc(h, &h->d_f2v, ne)); CX_TRY(dev_alloc(h, &h->d_v2f, ne)); CX_TRY(dev_alloc(h, &h->d_marg, h->nv));
+        CX_TRY(dev_alloc(h, &h->d_f2v, slots)); CX_TRY(dev_alloc(h, &h->d_v2f, slots)); CX_TRY(dev_alloc(h, &h->d_marg, nv));
         CX_TRY(dev_alloc(h, &h->d_scratch, 4096));
         // every message starts as UndefValue(): all-ones bytes are a NaN in both halves of each double2
-        CX_HIP(h, hipMemsetAsync(h->d_f2v, 0xff, (size_t)ne * sizeof(double2), h->stream));
-        CX_HIP(h, hipMemsetAsync(h->d_v2f, 0xff, (size_t)ne * sizeof(double2), h->stream));
-        CX_HIP(h, hipMemsetAsync(h->d_marg, 0xff, (size_t)h->nv * sizeof(double2), h->stream));
+        CX_HIP(h, hipMemsetAsync(h->d_f2v, 0xff, (size_t)slots * sizeof(double2), h->stream));
+        CX_HIP(h, hipMemsetAsync(h->d_v2f, 0xff, (size_t)slots * sizeof(double2), h->stream));
+        CX_HIP(h, hipMemsetAsync(h->d_marg, 0xff, (size_t)nv * sizeof(double2), h->stream));
         if (h->cfg.schedule == CX_SCHED_FUSED) {
-            CX_TRY(dev_alloc(h, &h->d_f2v_alt, ne));
-            CX_HIP(h, hipMemsetAsync(h->d_f2v_alt, 0xff, (size_t)ne * sizeof(double2), h->stream));
+            CX_TRY(dev_alloc(h, &h->d_f2v_alt, slots));
+            CX_HIP(h, hipMemsetAsync(h->d_f2v_alt, 0xff, (size_t)slots * sizeof(double2), h->stream));
         }
 #undef CX_TRY
         CX_HIP(h, hipStreamSynchronize(h->stream));
@@ -364,7 +370,7 @@ int32_t cx_graph_stats(const cx_handle *h, cx_stats *out) {
     if (!h || !out) return CX_ERR_INVALID_ARGUMENT;
     out->n_variables = h->nv; out->n_factors = h->nf; out->n_edges = h->ne;
     out->n_messages_per_sweep = h->n_messages_per_sweep;
-    out->n_small_blocks = (int64_t)h->blk.size() - 1; out->n_big_variables = (int64_t)h->big_vars.size();
+    out->n_slices = h->nslices; out->n_big_variables = (int64_t)h->big_vars.size(); out->n_slots = h->nslots;
     out->device_bytes = h->device_bytes; out->sweeps_done = h->sweeps_done;
     return CX_OK;
 }
@@ -381,13 +387,29 @@ int32_t cx_edge_index(const cx_handle *hc, int64_t n, const int64_t *variable_id
     return CX_OK;
 }
 
-static int32_t stage_indices(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, std::vector<int32_t> &idx) {
-    idx.resize(n);
+// (variable_id, factor_id) lists -> slots (+ optionally the local variable numbers)
+static int32_t stage_slots(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, std::vector<int32_t> &slots,
+                           std::vector<int32_t> *vars = nullptr) {
+    slots.resize(n);
+    if (vars) vars->resize(n);
     for (int64_t i = 0; i < n; i++) {
         int64_t e = find_edge(h, variable_ids[i], factor_ids[i]);
         if (e < 0) return fail(h, CX_ERR_NOT_FOUND, "no connection between variable " + std::to_string(variable_ids[i]) + " and factor " + std::to_string(factor_ids[i]));
-        idx[i] = (int32_t)e;
+        slots[i] = cx::slot_of_edge(h, e);
+        if (vars) (*vars)[i] = h->edge_var[e];
     }
+    return CX_OK;
+}
+
+// In the fused schedule without materialisation the variable→factor messages of the last sweep exist only as
+// "leave-one-out of the sweep's input buffer", which is retained in d_f2v_alt: recompute them on demand.
+static int32_t ensure_v2f(cx_handle *h) {
+    if (!h->v2f_stale) return CX_OK;
+    const double2 *src = h->d_f2v_alt ? h->d_f2v_alt : h->d_f2v;
+    cx::launch_var_to_factor(h, src, false);
+    cx::launch_big_var_to_factor(h, src, false);
+    CX_HIP(h, hipGetLastError());
+    h->v2f_stale = false;
     return CX_OK;
 }
 
@@ -400,8 +422,8 @@ int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
     if (n == 0) return CX_OK;
     CX_REQUIRE(h, n > 0 && variable_ids && factor_ids && payload, CX_ERR_INVALID_ARGUMENT, "cx_set_messages: null argument");
     try {
-        std::vector<int32_t> idx;
-        int32_t rc = stage_indices(h, n, variable_ids, factor_ids, idx);
+        std::vector<int32_t> idx, vars;
+        int32_t rc = stage_slots(h, n, variable_ids, factor_ids, idx, &vars);
         if (rc != CX_OK) return rc;
         const int64_t stride = form == CX_FORM_POINT ? 1 : 2;
         std::vector<double2> val(n);
@@ -414,16 +436,19 @@ int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
         CX_HIP(h, hipMemcpyAsync(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice, h->stream));
         CX_HIP(h, hipMemcpyAsync(d_val, val.data(), n * 16, hipMemcpyHostToDevice, h->stream));
         if (direction == CX_TO_FACTOR) {
+            rc = ensure_v2f(h);
+            if (rc != CX_OK) return rc;
             cx::launch_scatter(h, h->d_v2f, d_idx, d_val, n);
             if (form == CX_FORM_POINT) {
                 // a variable that carries a point-mass datum is observed: its messages are never recomputed
-                for (int64_t i = 0; i < n; i++) h->var_flags[h->edge_var[idx[i]]] = 1;
-                CX_HIP(h, hipMemcpyAsync(h->d_var_flags, h->var_flags.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
+                for (int64_t i = 0; i < n; i++) h->vinfo[vars[i]] |= cx::kClamped;
+                CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
             }
         } else {
             cx::launch_scatter(h, h->d_f2v, d_idx, d_val, n);
             if (h->d_f2v_alt) cx::launch_scatter(h, h->d_f2v_alt, d_idx, d_val, n);
         }
+        CX_HIP(h, hipGetLastError());
         CX_HIP(h, hipStreamSynchronize(h->stream));  // host staging vectors die here
         return CX_OK;
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_set_messages: host allocation failed"); }
@@ -438,8 +463,9 @@ int32_t cx_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
     CX_REQUIRE(h, n > 0 && variable_ids && factor_ids && out, CX_ERR_INVALID_ARGUMENT, "cx_get_messages: null argument");
     try {
         std::vector<int32_t> idx;
-        int32_t rc = stage_indices(h, n, variable_ids, factor_ids, idx);
+        int32_t rc = stage_slots(h, n, variable_ids, factor_ids, idx);
         if (rc != CX_OK) return rc;
+        if (direction == CX_TO_FACTOR) { rc = ensure_v2f(h); if (rc != CX_OK) return rc; }
         const int64_t bytes_idx = ((n * 4 + 15) / 16) * 16, bytes = bytes_idx + n * 16;
         rc = ensure_stage(h, bytes);
         if (rc != CX_OK) return rc;
@@ -461,10 +487,12 @@ int32_t cx_seed_messages(cx_handle *h, int32_t direction, double mean, double va
     CX_REQUIRE(h, variance > 0.0, CX_ERR_INVALID_ARGUMENT, "cx_seed_messages: variance must be > 0");
     double2 v = make_double2(mean / variance, 1.0 / variance);
     if (direction == CX_TO_VARIABLE) {
-        cx::launch_seed(h, h->d_f2v, h->ne, v, h->d_partner);
-        if (h->d_f2v_alt) cx::launch_seed(h, h->d_f2v_alt, h->ne, v, h->d_partner);
+        cx::launch_seed(h, h->d_f2v, h->nslots, v, h->d_partner);
+        if (h->d_f2v_alt) cx::launch_seed(h, h->d_f2v_alt, h->nslots, v, h->d_partner);
     } else {
-        cx::launch_seed(h, h->d_v2f, h->ne, v, h->d_partner);
+        int32_t rc = ensure_v2f(h);
+        if (rc != CX_OK) return rc;
+        cx::launch_seed(h, h->d_v2f, h->nslots, v, h->d_partner);
     }
     CX_HIP(h, hipGetLastError());
     return CX_OK;
@@ -499,87 +527,117 @@ int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
     if (n == 0) return CX_OK;
     CX_REQUIRE(h, n > 0 && items, CX_ERR_INVALID_ARGUMENT, "cx_update_batch: null argument");
     try {
-        std::vector<int32_t> buf(2 * n);
+        std::vector<int32_t> buf(3 * n);
         for (int64_t i = 0; i < n; i++) {
             const cx_item &it = items[i];
-            int64_t idx;
+            int64_t idx, var;
             if (it.kind == CX_ITEM_INDIVIDUAL_MARGINAL) {
-                idx = find_var(h, it.variable_id);
+                var = idx = find_var(h, it.variable_id);
                 if (idx < 0) return fail(h, CX_ERR_NOT_FOUND, "unknown variable id " + std::to_string(it.variable_id));
             } else if (it.kind == CX_ITEM_MESSAGE_TO_FACTOR || it.kind == CX_ITEM_MESSAGE_TO_VARIABLE) {
-                idx = find_edge(h, it.variable_id, it.factor_id);
-                if (idx < 0) return fail(h, CX_ERR_NOT_FOUND, "no connection between variable " + std::to_string(it.variable_id) + " and factor " + std::to_string(it.factor_id));
+                int64_t e = find_edge(h, it.variable_id, it.factor_id);
+                if (e < 0) return fail(h, CX_ERR_NOT_FOUND, "no connection between variable " + std::to_string(it.variable_id) + " and factor " + std::to_string(it.factor_id));
+                idx = cx::slot_of_edge(h, e); var = h->edge_var[e];
             } else {
                 // ProductOfMessages / JointMarginal have no device rule: the reference's default is error(...)
                 // (src/inference_engine.jl:446,476)
                 return fail(h, CX_ERR_UNSUPPORTED, "cx_update_batch: item kind " + std::to_string(it.kind) + " is not implemented for this processor");
             }
-            buf[i] = it.kind; buf[n + i] = (int32_t)idx;
+            buf[i] = it.kind; buf[n + i] = (int32_t)idx; buf[2 * n + i] = (int32_t)var;
         }
-        int32_t rc = ensure_stage(h, 2 * n * 4);
+        int32_t rc = ensure_v2f(h);
         if (rc != CX_OK) return rc;
-        CX_HIP(h, hipMemcpyAsync(h->d_stage, buf.data(), 2 * n * 4, hipMemcpyHostToDevice, h->stream));
-        cx::launch_batch(h, (const int32_t *)h->d_stage, (const int32_t *)h->d_stage + n, n);
+        rc = ensure_stage(h, 3 * n * 4);
+        if (rc != CX_OK) return rc;
+        CX_HIP(h, hipMemcpyAsync(h->d_stage, buf.data(), 3 * n * 4, hipMemcpyHostToDevice, h->stream));
+        const int32_t *d = (const int32_t *)h->d_stage;
+        cx::launch_batch(h, d, d + n, d + 2 * n, n);
         CX_HIP(h, hipGetLastError());
         CX_HIP(h, hipStreamSynchronize(h->stream));  // synchronous: the host sets readiness bits next (signal.jl:232-253)
         return CX_OK;
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_update_batch: host allocation failed"); }
 }
 
-int32_t cx_sweep_phase(cx_handle *h, int32_t phase) {
-    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep_phase: no graph");
-    CX_REQUIRE(h, h->cfg.schedule == CX_SCHED_FLOODING, CX_ERR_STATE, "cx_sweep_phase: phases exist only in the flooding schedule");
+// ---- the sweep ----------------------------------------------------------------------------------------------------
+static void sweep_main(cx_handle *h, bool skip_ghosts) {
     const bool marg = h->cfg.compute_marginals_in_sweep != 0;
-    if (phase == CX_PHASE_VAR_TO_FACTOR) {
-        cx::launch_var_to_factor(h, h->d_f2v, h->d_v2f, marg);
-        cx::launch_big_var_to_factor(h, h->d_f2v, h->d_v2f, marg);
-    } else if (phase == CX_PHASE_FACTOR_TO_VAR) {
-        cx::launch_factor_to_var(h, h->d_v2f, h->d_f2v);
-        h->sweeps_done++;
+    if (h->cfg.schedule == CX_SCHED_FLOODING) {
+        cx::launch_var_to_factor(h, h->d_f2v, marg);
+        cx::launch_big_var_to_factor(h, h->d_f2v, marg);
     } else {
-        return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_sweep_phase: bad phase");
+        const bool store = h->cfg.materialize_messages_to_factor != 0;
+        cx::launch_fused(h, h->d_f2v, h->d_f2v_alt, marg, store, skip_ghosts);
+        if (!h->big_vars.empty()) {
+            cx::launch_big_var_to_factor(h, h->d_f2v, marg);
+            cx::launch_push_slots(h, h->d_big_slots, (int64_t)h->big_slots.size(), h->d_f2v_alt, CX_KERNEL_BIG_VAR);
+        }
     }
-    CX_HIP(h, hipGetLastError());
-    return CX_OK;
+}
+
+static void sweep_finish(cx_handle *h) {
+    if (h->cfg.schedule == CX_SCHED_FLOODING) {
+        cx::launch_factor_to_var(h, h->d_v2f, h->d_f2v);
+    } else {
+        std::swap(h->d_f2v, h->d_f2v_alt);
+        h->v2f_stale = h->cfg.materialize_messages_to_factor == 0;
+    }
+    h->sweeps_done++;
 }
 
 int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep: no graph");
     CX_REQUIRE(h, n_sweeps >= 0, CX_ERR_INVALID_ARGUMENT, "cx_sweep: n_sweeps < 0");
-    const bool marg = h->cfg.compute_marginals_in_sweep != 0;
-    for (int32_t s = 0; s < n_sweeps; s++) {
-        if (h->cfg.schedule == CX_SCHED_FLOODING) {
-            cx::launch_var_to_factor(h, h->d_f2v, h->d_v2f, marg);
-            cx::launch_big_var_to_factor(h, h->d_f2v, h->d_v2f, marg);
-            cx::launch_factor_to_var(h, h->d_v2f, h->d_f2v);
-        } else {
-            cx::launch_fused(h, h->d_f2v, h->d_f2v_alt, h->d_v2f, marg, true);
-            if (!h->big_vars.empty()) {
-                cx::launch_big_var_to_factor(h, h->d_f2v, h->d_v2f, marg);
-                cx::launch_push_edges(h, h->d_big_edges, (int64_t)h->big_edges.size(), h->d_v2f, h->d_f2v_alt);
-            }
-            std::swap(h->d_f2v, h->d_f2v_alt);
-        }
-        h->sweeps_done++;
-    }
+    CX_REQUIRE(h, h->recv_slots.empty() && h->send_slots.empty(), CX_ERR_STATE,
+               "cx_sweep: this handle holds a partition (halo configured): use cx_sweep_begin / _main / _end");
+    for (int32_t s = 0; s < n_sweeps; s++) { sweep_main(h, false); sweep_finish(h); }
     CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
+int32_t cx_sweep_begin(cx_handle *h) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep_begin: no graph");
+    CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_sweep_begin: previous sweep not ended");
+    const int64_t ns = (int64_t)h->send_slots.size();
+    cx::launch_v2f_slots(h, h->d_send_slots, h->d_send_vars, ns, h->d_f2v, CX_KERNEL_HALO_BEGIN);
+    cx::launch_gather(h, h->d_v2f, h->d_send_slots, h->d_send_buf, ns);
+    CX_HIP(h, hipGetLastError());
+    h->in_sweep = true;
+    return CX_OK;
+}
+
+int32_t cx_sweep_main(cx_handle *h) {
+    CX_REQUIRE(h, h && h->has_graph && h->in_sweep, CX_ERR_STATE, "cx_sweep_main: call cx_sweep_begin first");
+    sweep_main(h, true);
+    CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
+int32_t cx_sweep_end(cx_handle *h) {
+    CX_REQUIRE(h, h && h->has_graph && h->in_sweep, CX_ERR_STATE, "cx_sweep_end: call cx_sweep_begin first");
+    const int64_t nr = (int64_t)h->recv_slots.size();
+    cx::launch_scatter(h, h->d_v2f, h->d_recv_slots, h->d_recv_buf, nr);
+    if (h->cfg.schedule == CX_SCHED_FUSED)
+        cx::launch_push_slots(h, h->d_recv_slots, nr, h->d_f2v_alt, CX_KERNEL_HALO_END);
+    sweep_finish(h);
+    CX_HIP(h, hipGetLastError());
+    h->in_sweep = false;
     return CX_OK;
 }
 
 int32_t cx_residual(cx_handle *h, double *out) {
     CX_REQUIRE(h, h && h->has_graph && out, CX_ERR_STATE, "cx_residual: no graph / null out");
     if (!h->d_prev) {
-        int32_t rc = dev_alloc(h, &h->d_prev, h->ne);
+        int32_t rc = dev_alloc(h, &h->d_prev, h->nslots);
         if (rc != CX_OK) return rc;
-        CX_HIP(h, hipMemcpyAsync(h->d_prev, h->d_f2v, (size_t)h->ne * 16, hipMemcpyDeviceToDevice, h->stream));
+        CX_HIP(h, hipMemcpyAsync(h->d_prev, h->d_f2v, (size_t)h->nslots * 16, hipMemcpyDeviceToDevice, h->stream));
         CX_HIP(h, hipStreamSynchronize(h->stream));
         *out = std::numeric_limits<double>::infinity();
         return CX_OK;
     }
-    cx::launch_residual(h, h->d_f2v, h->d_prev, h->ne, h->d_scratch);
+    cx::launch_residual(h, h->d_f2v, h->d_prev, h->nslots, h->d_scratch);
     std::vector<double> part(1024);
     CX_HIP(h, hipMemcpyAsync(part.data(), h->d_scratch, 1024 * 8, hipMemcpyDeviceToHost, h->stream));
-    CX_HIP(h, hipMemcpyAsync(h->d_prev, h->d_f2v, (size_t)h->ne * 16, hipMemcpyDeviceToDevice, h->stream));
+    CX_HIP(h, hipMemcpyAsync(h->d_prev, h->d_f2v, (size_t)h->nslots * 16, hipMemcpyDeviceToDevice, h->stream));
     CX_HIP(h, hipStreamSynchronize(h->stream));
     double m = 0.0;
     for (double p : part) m = std::max(m, p);
@@ -594,19 +652,24 @@ int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const
     CX_REQUIRE(h, n_send >= 0 && n_recv >= 0, CX_ERR_INVALID_ARGUMENT, "cx_halo_configure: negative count");
     CX_REQUIRE(h, (n_send == 0 || (sv && sf)) && (n_recv == 0 || (rv && rf)), CX_ERR_INVALID_ARGUMENT, "cx_halo_configure: null argument");
     try {
-        int32_t rc = stage_indices(h, n_send, sv, sf, h->send_edges);
+        std::vector<int32_t> send_vars, recv_vars;
+        int32_t rc = stage_slots(h, n_send, sv, sf, h->send_slots, &send_vars);
         if (rc != CX_OK) return rc;
-        rc = stage_indices(h, n_recv, rv, rf, h->recv_edges);
+        rc = stage_slots(h, n_recv, rv, rf, h->recv_slots, &recv_vars);
         if (rc != CX_OK) return rc;
-        for (int32_t e : h->recv_edges) {
-            const int32_t v = h->edge_var[e];
+        for (int32_t v : recv_vars)
             if (h->var_off[v + 1] - h->var_off[v] != 1)
                 return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_halo_configure: an imported edge must belong to a degree-1 ghost variable");
-        }
-        for (void *p : {(void *)h->d_send_edges, (void *)h->d_recv_edges, (void *)h->d_send_buf, (void *)h->d_recv_buf}) if (p) (void)hipFree(p);
-        h->d_send_edges = h->d_recv_edges = nullptr; h->d_send_buf = h->d_recv_buf = nullptr;
-        rc = dev_upload(h, &h->d_send_edges, h->send_edges); if (rc != CX_OK) return rc;
-        rc = dev_upload(h, &h->d_recv_edges, h->recv_edges); if (rc != CX_OK) return rc;
+        for (uint8_t &b : h->vinfo) b &= (uint8_t)~cx::kGhost;
+        for (int32_t v : recv_vars) h->vinfo[v] |= cx::kGhost;
+        CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
+        for (void *p : {(void *)h->d_send_slots, (void *)h->d_recv_slots, (void *)h->d_send_vars}) if (p) (void)hipFree(p);
+        if (!h->ext_halo_buffers) { if (h->d_send_buf) (void)hipFree(h->d_send_buf); if (h->d_recv_buf) (void)hipFree(h->d_recv_buf); }
+        h->d_send_slots = h->d_recv_slots = h->d_send_vars = nullptr; h->d_send_buf = h->d_recv_buf = nullptr;
+        h->ext_halo_buffers = false;
+        rc = dev_upload(h, &h->d_send_slots, h->send_slots); if (rc != CX_OK) return rc;
+        rc = dev_upload(h, &h->d_send_vars, send_vars); if (rc != CX_OK) return rc;
+        rc = dev_upload(h, &h->d_recv_slots, h->recv_slots); if (rc != CX_OK) return rc;
         rc = dev_alloc(h, &h->d_send_buf, n_send); if (rc != CX_OK) return rc;
         rc = dev_alloc(h, &h->d_recv_buf, n_recv); if (rc != CX_OK) return rc;
         CX_HIP(h, hipStreamSynchronize(h->stream));
@@ -617,23 +680,20 @@ int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const
 int32_t cx_halo_buffers(cx_handle *h, void **send_ptr, int64_t *send_bytes, void **recv_ptr, int64_t *recv_bytes) {
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_buffers: no graph");
     if (send_ptr) *send_ptr = h->d_send_buf;
-    if (send_bytes) *send_bytes = (int64_t)h->send_edges.size() * 16;
+    if (send_bytes) *send_bytes = (int64_t)h->send_slots.size() * 16;
     if (recv_ptr) *recv_ptr = h->d_recv_buf;
-    if (recv_bytes) *recv_bytes = (int64_t)h->recv_edges.size() * 16;
+    if (recv_bytes) *recv_bytes = (int64_t)h->recv_slots.size() * 16;
     return CX_OK;
 }
 
-int32_t cx_halo_pack(cx_handle *h) {
-    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_pack: no graph");
-    cx::launch_gather(h, h->d_v2f, h->d_send_edges, h->d_send_buf, (int64_t)h->send_edges.size());
-    CX_HIP(h, hipGetLastError());
-    return CX_OK;
-}
-
-int32_t cx_halo_unpack(cx_handle *h) {
-    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_unpack: no graph");
-    cx::launch_scatter(h, h->d_v2f, h->d_recv_edges, h->d_recv_buf, (int64_t)h->recv_edges.size());
-    CX_HIP(h, hipGetLastError());
+int32_t cx_halo_set_buffers(cx_handle *h, void *send_ptr, void *recv_ptr) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_set_buffers: no graph");
+    CX_REQUIRE(h, (send_ptr || h->send_slots.empty()) && (recv_ptr || h->recv_slots.empty()), CX_ERR_INVALID_ARGUMENT,
+               "cx_halo_set_buffers: null buffer for a non-empty halo list");
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    if (!h->ext_halo_buffers) { if (h->d_send_buf) (void)hipFree(h->d_send_buf); if (h->d_recv_buf) (void)hipFree(h->d_recv_buf); }
+    h->d_send_buf = (double2 *)send_ptr; h->d_recv_buf = (double2 *)recv_ptr;
+    h->ext_halo_buffers = true;
     return CX_OK;
 }
 

@@ -12,9 +12,15 @@
 
 namespace cx {
 
-constexpr int kBlock = 256;        // threads per workgroup = 4 wave64
-constexpr int kCapEdges = 1280;    // edges staged per workgroup: 1280 * 16 B = 20 KiB LDS -> 8 workgroups / CU
-constexpr int kSmallDeg = 8;       // variables up to this degree take the in-register leave-one-out path
+constexpr int kBlock = 256;        // threads per workgroup = 4 wave64 = one SELL slice of 256 variables
+constexpr int kSmallDeg = 8;       // variables up to this degree live in the sliced-ELL region
+constexpr int kSliceShift = 8;     // log2(kBlock)
+
+// vinfo byte per variable
+constexpr uint8_t kDegMask = 0x0f;   // degree 0..8; 15 = "big" variable (CSR region, wave-per-variable kernels)
+constexpr uint8_t kBigDeg = 0x0f;
+constexpr uint8_t kGhost = 0x40;     // degree-1 stand-in for a variable owned by another rank (halo import)
+constexpr uint8_t kClamped = 0x80;   // observed variable: its messages are data, never recomputed
 
 struct ProfileRec {
     int kernel;
@@ -30,41 +36,47 @@ struct cx_handle {
     bool has_graph = false;
 
     // ---- host copy of the flattened graph (lookup + batching) ----
-    int64_t nv = 0, nf = 0, ne = 0;
+    int64_t nv = 0, nf = 0, ne = 0;     // variables, factors, connections
+    int64_t nslots = 0;                 // message slots (SELL region incl. padding + big-variable CSR region)
+    int64_t nslices = 0;
     std::vector<int64_t> var_ids;       // ascending; index = local variable number
     std::vector<int64_t> fac_ids;       // ascending; index = local factor number
     std::vector<int32_t> fac_kind;      // by local factor number
     std::vector<double> fac_params;     // [nf][CX_NPARAM]
-    std::vector<int32_t> var_off;       // [nv+1] into the edge table
-    std::vector<int64_t> edge_fac_id;   // [ne] factor id per edge (edges sorted by variable id, factor id)
-    std::vector<int32_t> edge_var;      // [ne] local variable number per edge
-    std::vector<uint8_t> var_flags;     // [nv] 1 = observed (clamped) variable
-    std::vector<int32_t> partner;       // [ne] the other edge of a 2-edge factor, -1 otherwise
-    std::vector<int32_t> blk;           // [nblk+1] variable ranges of the small-degree workgroups
+    std::vector<int32_t> var_off;       // [nv+1] CSR offsets into the edge table sorted by (variable id, factor id)
+    std::vector<int64_t> edge_fac_id;   // [ne] factor id per CSR edge
+    std::vector<int32_t> edge_var;      // [ne] local variable number per CSR edge
+    std::vector<int32_t> vbase;         // [nv] slot of the variable's first message
+    std::vector<uint8_t> vinfo;         // [nv] degree class + flags
+    std::vector<int32_t> slice_off;     // [nslices+1] first slot of each slice
+    std::vector<int32_t> partner;       // [nslots] slot of the other edge of a 2-edge factor, -1 otherwise
     std::vector<int32_t> big_vars;      // variables with degree > kSmallDeg
-    std::vector<int32_t> big_tmp_off;   // per big variable: offset of its prefix scratch
-    std::vector<int32_t> big_edges;     // all edges of big variables (fused schedule pushes them separately)
+    std::vector<int32_t> big_slots;     // all slots of big variables (the fused schedule pushes them separately)
     int64_t n_messages_per_sweep = 0;
     int64_t sweeps_done = 0;
     bool any_linear = false;
 
     // ---- device buffers ----
-    int32_t *d_var_off = nullptr, *d_partner = nullptr, *d_edge_var = nullptr, *d_blk = nullptr;
-    int32_t *d_big = nullptr, *d_big_tmp_off = nullptr, *d_big_edges = nullptr;
-    double2 *d_big_tmp = nullptr;
-    uint8_t *d_var_flags = nullptr;
-    double *d_q = nullptr, *d_a = nullptr, *d_b = nullptr;  // per receiving edge: effective rule parameters
-    double *d_sq = nullptr, *d_sa = nullptr, *d_sb = nullptr;  // the same, indexed by the SENDING edge (fused push)
+    int32_t *d_slice_off = nullptr, *d_partner = nullptr, *d_vbase = nullptr, *d_var_deg = nullptr;
+    int32_t *d_big = nullptr, *d_big_slots = nullptr;
+    double2 *d_big_tmp = nullptr;   // prefix scratch of the big-variable kernel, one entry per big slot
+    int32_t big_start = 0;          // first slot of the big-variable CSR tail
+    uint8_t *d_vinfo = nullptr;
+    double *d_q = nullptr, *d_a = nullptr, *d_b = nullptr;     // per RECEIVING slot: effective rule parameters
+    double *d_sq = nullptr, *d_sa = nullptr, *d_sb = nullptr;  // the same, indexed by the SENDING slot (push)
     double2 *d_f2v = nullptr, *d_v2f = nullptr, *d_marg = nullptr;  // natural-form messages, moment-form marginals
-    double2 *d_f2v_alt = nullptr;   // second buffer of the fused schedule
+    double2 *d_f2v_alt = nullptr;   // second factor→variable buffer (Jacobi double buffering of the fused sweep)
     double2 *d_prev = nullptr;      // snapshot for cx_residual
     double *d_scratch = nullptr;    // small reduction scratch
     int64_t device_bytes = 0;
 
     // halo
-    std::vector<int32_t> send_edges, recv_edges;
-    int32_t *d_send_edges = nullptr, *d_recv_edges = nullptr;
+    std::vector<int32_t> send_slots, recv_slots;
+    int32_t *d_send_slots = nullptr, *d_recv_slots = nullptr, *d_send_vars = nullptr;
     double2 *d_send_buf = nullptr, *d_recv_buf = nullptr;
+    bool ext_halo_buffers = false;
+    bool in_sweep = false;
+    bool v2f_stale = false;          // fused schedule without materialisation: v2f must be recomputed before use
 
     // staging for set/get/batch
     void *d_stage = nullptr;
@@ -77,16 +89,24 @@ struct cx_handle {
 
 namespace cx {
 
+// slot of CSR edge e (host)
+inline int32_t slot_of_edge(const cx_handle *h, int64_t e) {
+    const int32_t v = h->edge_var[e];
+    const int32_t k = (int32_t)(e - h->var_off[v]);
+    return ((h->vinfo[v] & kDegMask) == kBigDeg) ? h->vbase[v] + k : h->vbase[v] + k * kBlock;
+}
+
 // kernel launchers (cx_kernels.hip)
-void launch_var_to_factor(cx_handle *h, const double2 *f2v, double2 *v2f, bool write_marg);
-void launch_big_var_to_factor(cx_handle *h, const double2 *f2v, double2 *v2f, bool write_marg);
+void launch_fused(cx_handle *h, const double2 *f2v_in, double2 *f2v_out, bool write_marg, bool store_v2f, bool skip_ghosts);
+void launch_var_to_factor(cx_handle *h, const double2 *f2v, bool write_marg);
+void launch_big_var_to_factor(cx_handle *h, const double2 *f2v, bool write_marg);
 void launch_factor_to_var(cx_handle *h, const double2 *v2f, double2 *f2v);
-void launch_fused(cx_handle *h, const double2 *f2v_in, double2 *f2v_out, double2 *v2f, bool write_marg, bool store_v2f);
-void launch_push_edges(cx_handle *h, const int32_t *d_edges, int64_t n, const double2 *v2f, double2 *f2v_out);
-void launch_batch(cx_handle *h, const int32_t *d_kind, const int32_t *d_index, int64_t n);
+void launch_push_slots(cx_handle *h, const int32_t *d_slots, int64_t n, double2 *f2v_out, int kernel_id);
+void launch_v2f_slots(cx_handle *h, const int32_t *d_slots, const int32_t *d_vars, int64_t n, const double2 *f2v, int kernel_id);
+void launch_batch(cx_handle *h, const int32_t *d_kind, const int32_t *d_index, const int32_t *d_var, int64_t n);
 void launch_scatter(cx_handle *h, double2 *dst, const int32_t *d_idx, const double2 *d_val, int64_t n);
 void launch_gather(cx_handle *h, const double2 *src, const int32_t *d_idx, double2 *d_val, int64_t n);
-void launch_seed(cx_handle *h, double2 *buf, int64_t n, double2 value, const int32_t *skip_if_partner_negative);
+void launch_seed(cx_handle *h, double2 *buf, int64_t n, double2 value, const int32_t *partner);
 void launch_residual(cx_handle *h, const double2 *cur, const double2 *prev, int64_t n, double *d_out);
 
 }  // namespace cx

@@ -25,9 +25,11 @@ def _p(a, ct):
 
 
 class DeviceGraph:
-    def __init__(self, device: int = 0, dim: int = 1, schedule: int = L.SCHED_FLOODING, marginals_in_sweep: bool = True):
+    def __init__(self, device: int = 0, dim: int = 1, schedule: int = L.SCHED_FUSED, marginals_in_sweep: bool = True,
+                 materialize_messages_to_factor: bool = False):
         self.lib = L.load()
-        cfg = L.Config(C.sizeof(L.Config), device, dim, schedule, int(marginals_in_sweep))
+        cfg = L.Config(C.sizeof(L.Config), device, dim, schedule, int(marginals_in_sweep),
+                       int(materialize_messages_to_factor))
         h = C.c_void_p()
         rc = self.lib.cx_create(C.byref(cfg), C.byref(h))
         if rc != L.OK:
@@ -120,8 +122,14 @@ class DeviceGraph:
     def sweep(self, n: int = 1):
         self._check(self.lib.cx_sweep(self.h, int(n)))
 
-    def sweep_phase(self, phase: int):
-        self._check(self.lib.cx_sweep_phase(self.h, phase))
+    def sweep_begin(self):
+        self._check(self.lib.cx_sweep_begin(self.h))
+
+    def sweep_main(self):
+        self._check(self.lib.cx_sweep_main(self.h))
+
+    def sweep_end(self):
+        self._check(self.lib.cx_sweep_end(self.h))
 
     def sync(self):
         self._check(self.lib.cx_sync(self.h))
@@ -145,11 +153,8 @@ class DeviceGraph:
         self._check(self.lib.cx_halo_buffers(self.h, C.byref(sp), C.byref(sb), C.byref(rp), C.byref(rb)))
         return (sp.value or 0, sb.value), (rp.value or 0, rb.value)
 
-    def halo_pack(self):
-        self._check(self.lib.cx_halo_pack(self.h))
-
-    def halo_unpack(self):
-        self._check(self.lib.cx_halo_unpack(self.h))
+    def halo_set_buffers(self, send_ptr: int, recv_ptr: int):
+        self._check(self.lib.cx_halo_set_buffers(self.h, C.c_void_p(send_ptr or 0), C.c_void_p(recv_ptr or 0)))
 
     # -- measurement ----------------------------------------------------------------------------
     def profile_enable(self, on: bool = True):

@@ -89,7 +89,11 @@ typedef struct cx_config {
     int32_t dim;           /* message dimension d: 1 (scalar), 4, 64 */
     int32_t schedule;      /* CX_SCHED_* */
     int32_t compute_marginals_in_sweep; /* 1: every sweep also refreshes all marginals (update_marginals!) */
-    int32_t reserved[3];
+    int32_t materialize_messages_to_factor; /* CX_SCHED_FUSED only. 0: variable→factor messages stay in registers
+                                               during a sweep and are recomputed, bit-identically, from the retained
+                                               input buffer when cx_get_messages / cx_update_batch asks for them;
+                                               1: every sweep also stores them */
+    int32_t reserved[2];
 } cx_config;
 
 typedef struct cx_item {
@@ -102,7 +106,7 @@ typedef struct cx_item {
 typedef struct cx_stats {
     int64_t n_variables, n_factors, n_edges;
     int64_t n_messages_per_sweep;     /* directed messages with >=1 dependency and >=1 listener: the metric's unit */
-    int64_t n_small_blocks, n_big_variables;
+    int64_t n_slices, n_big_variables, n_slots; /* SELL-256 slices, CSR-tail variables, message slots incl. padding */
     int64_t device_bytes;
     int64_t sweeps_done;
 } cx_stats;
@@ -153,19 +157,24 @@ int32_t cx_residual(cx_handle *h, double *out_max_abs_delta);
 /* ---- partitioned graphs (one handle per GPU; exchange is the caller's: RCCL/torch.distributed) --
  * Cut edges appear in this rank's graph as degree-1 "ghost" variables whose variable→factor message is
  * produced by another rank.  cx_halo_configure names the edges this rank exports / imports; buffers hold
- * NATURAL-form payloads, 2*dim... doubles per edge, in list order. */
+ * NATURAL-form payloads (2 doubles per edge for dim == 1), in list order. */
 int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *send_variable_ids,
                           const int64_t *send_factor_ids, int64_t n_recv, const int64_t *recv_variable_ids,
                           const int64_t *recv_factor_ids);
 int32_t cx_halo_buffers(cx_handle *h, void **send_device_ptr, int64_t *send_bytes, void **recv_device_ptr,
                         int64_t *recv_bytes);
-/* phases of one partitioned sweep, so the caller can overlap the exchange:
- *   cx_sweep_phase(VAR_TO_FACTOR) → cx_halo_pack → [exchange] → cx_halo_unpack → cx_sweep_phase(FACTOR_TO_VAR) */
-#define CX_PHASE_VAR_TO_FACTOR 1
-#define CX_PHASE_FACTOR_TO_VAR 2
-int32_t cx_sweep_phase(cx_handle *h, int32_t phase);
-int32_t cx_halo_pack(cx_handle *h);
-int32_t cx_halo_unpack(cx_handle *h);
+/* use caller-owned device buffers (e.g. torch tensors handed to torch.distributed) instead of the library's */
+int32_t cx_halo_set_buffers(cx_handle *h, void *send_device_ptr, void *recv_device_ptr);
+/* one partitioned sweep = three asynchronous calls, so the caller can overlap the exchange with the main kernel:
+ *   cx_sweep_begin : compute the exported variable→factor messages and pack them into the send buffer
+ *   [caller starts the exchange of send → peer's recv buffer on its communication stream]
+ *   cx_sweep_main  : the sweep over every variable this rank owns
+ *   [caller makes the handle's stream wait for the exchange]
+ *   cx_sweep_end   : unpack the recv buffer into the ghost variables and push it through the cut factors
+ * The three calls together compute exactly one cx_sweep of the un-partitioned graph. */
+int32_t cx_sweep_begin(cx_handle *h);
+int32_t cx_sweep_main(cx_handle *h);
+int32_t cx_sweep_end(cx_handle *h);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 #define CX_KERNEL_VAR_TO_FACTOR 0
@@ -173,6 +182,8 @@ int32_t cx_halo_unpack(cx_handle *h);
 #define CX_KERNEL_FUSED 2
 #define CX_KERNEL_BATCH 3
 #define CX_KERNEL_BIG_VAR 4
+#define CX_KERNEL_HALO_BEGIN 5
+#define CX_KERNEL_HALO_END 6
 #define CX_KERNEL_COUNT 8
 /* hipEvent pairs around every kernel launch of cx_sweep on the handle's stream */
 int32_t cx_profile_enable(cx_handle *h, int32_t on);

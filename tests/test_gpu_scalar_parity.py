@@ -15,8 +15,8 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-9
 
 
-def _device(model, schedule, seed_variance=None):
-    dev = cx.DeviceGraph(schedule=schedule)
+def _device(model, schedule, seed_variance=None, materialize=False):
+    dev = cx.DeviceGraph(schedule=schedule, materialize_messages_to_factor=materialize)
     cx.synth.load_into_device(model, dev, seed_variance)
     return dev
 
@@ -31,11 +31,14 @@ def _compare_messages(dev, g, what):
     assert_close(v2f[:, 1], g.v2f_v[both], RTOL, what + " v2f variance")
 
 
-@pytest.mark.parametrize("schedule", [L.SCHED_FLOODING, L.SCHED_FUSED])
+SCHEDULES = [(L.SCHED_FLOODING, False), (L.SCHED_FUSED, False), (L.SCHED_FUSED, True)]
+
+
+@pytest.mark.parametrize("schedule,materialize", SCHEDULES)
 @pytest.mark.parametrize("shape", [(1, 2), (2, 2), (3, 7), (16, 16), (37, 23), (64, 300)])
-def test_grid_flooding_sweeps_match_oracle(hip_lib, schedule, shape):
+def test_grid_flooding_sweeps_match_oracle(hip_lib, schedule, materialize, shape):
     model = cx.synth.gaussian_grid(*shape, seed=7)
-    dev = _device(model, schedule, seed_variance=1e6)
+    dev = _device(model, schedule, seed_variance=1e6, materialize=materialize)
     g = flood_oracle_from_model(model, seed_variance=1e6)
     st = dev.stats()
     assert st["n_edges"] == model.n_edges == g.ne
@@ -61,13 +64,13 @@ def test_grid_flooding_sweeps_match_oracle(hip_lib, schedule, shape):
     assert_close(marg[:, 0], mean_exact, 1e-8, f"grid{shape} converged mean vs sparse solve")
 
 
-@pytest.mark.parametrize("schedule", [L.SCHED_FLOODING, L.SCHED_FUSED])
-@pytest.mark.parametrize("T,randvar", [(2, False), (3, False), (50, False), (200, True)])
-def test_chain_flooding_reaches_reference_marginals(hip_lib, schedule, T, randvar):
+@pytest.mark.parametrize("schedule,materialize", SCHEDULES)
+@pytest.mark.parametrize("T,randvar", [(2, False), (3, False), (50, False), (200, True), (700, True)])
+def test_chain_flooding_reaches_reference_marginals(hip_lib, schedule, materialize, T, randvar):
     """On a tree the flooding fixed point equals what the reference's sequential schedule computes in one
     update_marginals! call, and both equal the exact smoother."""
     model = cx.synth.ssm_chain(T, seed=3, random_variances=randvar)
-    dev = _device(model, schedule)
+    dev = _device(model, schedule, materialize=materialize)
     g = flood_oracle_from_model(model)
     for sweep in range(T + 2):
         dev.sweep(1)
