@@ -95,7 +95,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     N = args.grid
-    schedule = L.SCHED_FUSED if (args.schedule == "fused" and world == 1) else L.SCHED_FLOODING
+    schedule = L.SCHED_FUSED if args.schedule == "fused" else L.SCHED_FLOODING
     dev = cx.DeviceGraph(device=local_rank, schedule=schedule, marginals_in_sweep=True,
                          materialize_messages_to_factor=args.materialize)
     stream = torch.cuda.current_stream()
@@ -109,7 +109,8 @@ def main():
         from cortex.jl_amd import partition
         part = partition.grid_strip(N, N, rank, world, seed=args.seed)
         cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
-        exchange = partition.HaloExchange(dev, part, dist, torch)
+        sweeper = partition.DeviceSweeper(dev, part, torch, torch.device("cuda", local_rank))
+        exchange = partition.HaloExchange(sweeper, part, dist)
     st = dev.stats()
     updates_per_step = st["n_messages_per_sweep"]
 
@@ -146,7 +147,7 @@ def main():
 
     # dominant kernel: hipEvent durations recorded around every launch of the timed region, on the library's stream
     kern = {}
-    for k in (L.KERNEL_FUSED, L.KERNEL_VAR_TO_FACTOR, L.KERNEL_FACTOR_TO_VAR):
+    for k in (L.KERNEL_FUSED, L.KERNEL_VAR_TO_FACTOR, L.KERNEL_FACTOR_TO_VAR, L.KERNEL_HALO_BEGIN, L.KERNEL_HALO_END):
         ms, n = dev.profile_read(k)
         if n:
             kern[dev.kernel_name(k)] = (ms, n, k)
@@ -170,7 +171,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"C4: {N}x{N} 2-D Gaussian grid loopy BP per GPU ({st['n_edges']} bipartite edges, "
                                    f"{updates_per_step} directed message updates + {st['n_variables']} marginals per sweep)",
-                       "schedule": args.schedule if world == 1 else "flooding+halo", "partition": f"{world} row strips",
+                       "schedule": args.schedule + ("" if world == 1 else "+halo(send/recv per sweep)"), "partition": f"{world} row strips",
                        "seed": args.seed},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": dom_ms / dom_n,

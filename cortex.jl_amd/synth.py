@@ -58,38 +58,69 @@ def ssm_chain(T: int, seed: int = 1234, q: float = 1.0, r: float = 1.0, random_v
                  meta={"T": T, "r": fvar_lik, "q": fvar_tr, "kind": "ssm_chain"})
 
 
-def gaussian_grid(n_rows: int, n_cols: int, seed: int = 1234, row_offset: int = 0, total_rows: int | None = None) -> Model:
+def _grid_rows(seed: int, total_rows: int, n_cols: int, r0: int, r1: int):
+    """Per-row random streams keyed by (seed, kind, global row): any rank regenerates exactly the rows it needs, and
+    the union over ranks is the same global grid whatever the partition."""
+    nr = r1 - r0
+    yobs = np.empty((nr, n_cols)); r = np.empty((nr, n_cols)); qh = np.empty((nr, max(n_cols - 1, 0)))
+    jj = np.arange(n_cols)
+    for k, i in enumerate(range(r0, r1)):
+        rng = np.random.default_rng([seed, 0, i])
+        field_ = 3.0 * np.sin(2 * np.pi * i / total_rows) * np.cos(2 * np.pi * jj / n_cols) + 0.002 * (i + jj)
+        yobs[k] = field_ + rng.standard_normal(n_cols)
+        r[k] = rng.uniform(0.5, 2.0, n_cols)
+        qh[k] = rng.uniform(0.5, 2.0, max(n_cols - 1, 0))
+    return yobs, r, qh
+
+
+def _grid_qv(seed: int, n_cols: int, i0: int, i1: int):
+    """variances of the vertical factors between global rows i and i+1, for i in [i0, i1)."""
+    qv = np.empty((max(i1 - i0, 0), n_cols))
+    for k, i in enumerate(range(i0, i1)):
+        qv[k] = np.random.default_rng([seed, 1, i]).uniform(0.5, 2.0, n_cols)
+    return qv
+
+
+def gaussian_grid(n_rows: int, n_cols: int, seed: int = 1234, row0: int = 0, row1: int | None = None) -> Model:
     """2-D Gaussian grid, config C4: n_rows*n_cols unary edges + 2*(horizontal+vertical pairwise factors) edges.
-    N = 1415 gives 10,005,465 bipartite edges.  Variable (i, j) has id 1 + i*n_cols + j; unary factor ids follow
-    the variables, then horizontal, then vertical pairwise factors.
+    N = 1415 gives 10,005,465 bipartite edges.  Global numbering (n_rows x n_cols is the WHOLE grid): variable (i, j)
+    has id 1 + i*n_cols + j; unary factor ids follow the variables, then horizontal, then vertical pairwise factors.
+
+    row0/row1 select the strip of rows [row0, row1) owned by one rank; the returned model then also holds the cut
+    vertical factors and, as degree-1 "ghost" variables, the rows row0-1 and row1 they connect to
+    (meta["ghost_rows"]).  With the defaults the model is the whole grid.
 
     Observation field: smooth surface + N(0,1) noise; r_i, q_ij ~ U(0.5, 2) — the precision matrix is strictly
     diagonally dominant, so Gaussian BP converges (Weiss & Freeman 2001)."""
-    rng = np.random.default_rng(seed)
-    nv = n_rows * n_cols
-    idx = np.arange(nv, dtype=np.int64).reshape(n_rows, n_cols)
-    var_id = idx + 1
-    unary = var_id + nv
-    nh, nvert = n_rows * (n_cols - 1), (n_rows - 1) * n_cols
-    hfac = (2 * nv + 1 + np.arange(nh, dtype=np.int64)).reshape(n_rows, max(n_cols - 1, 0))
-    vfac = (2 * nv + nh + 1 + np.arange(nvert, dtype=np.int64)).reshape(max(n_rows - 1, 0), n_cols)
-    edge_var = np.concatenate([var_id.ravel(), var_id[:, :-1].ravel(), var_id[:, 1:].ravel(), var_id[:-1, :].ravel(),
-                               var_id[1:, :].ravel()])
+    row1 = n_rows if row1 is None else row1
+    V = n_rows * n_cols
+    H = n_rows * (n_cols - 1)
+    var_id = lambda i, j: 1 + i * n_cols + j                       # noqa: E731
+    i_own = np.arange(row0, row1, dtype=np.int64)
+    jj = np.arange(n_cols, dtype=np.int64)
+    vid = var_id(i_own[:, None], jj[None, :])                       # [nr, nc]
+    unary = vid + V
+    hfac = 2 * V + 1 + i_own[:, None] * (n_cols - 1) + jj[None, :-1]
+    yobs, r, qh = _grid_rows(seed, n_rows, n_cols, row0, row1)
+    # vertical factors touching owned rows: between rows i and i+1 for i in [max(row0-1,0), min(row1, n_rows-1))
+    v0, v1 = max(row0 - 1, 0), min(row1, n_rows - 1)
+    iv = np.arange(v0, v1, dtype=np.int64)
+    vfac = 2 * V + H + 1 + iv[:, None] * n_cols + jj[None, :]
+    qv = _grid_qv(seed, n_cols, v0, v1)
+    up_var = var_id(iv[:, None], jj[None, :])
+    dn_var = var_id(iv[:, None] + 1, jj[None, :])
+    edge_var = np.concatenate([vid.ravel(), vid[:, :-1].ravel(), vid[:, 1:].ravel(), up_var.ravel(), dn_var.ravel()])
     edge_fac = np.concatenate([unary.ravel(), hfac.ravel(), hfac.ravel(), vfac.ravel(), vfac.ravel()])
-    ii, jj = np.meshgrid(np.arange(n_rows) + row_offset, np.arange(n_cols), indexing="ij")
-    scale = float(total_rows or n_rows)
-    field_ = 3.0 * np.sin(2 * np.pi * ii / scale) * np.cos(2 * np.pi * jj / n_cols) + 0.002 * (ii + jj)
-    yobs = field_ + rng.standard_normal((n_rows, n_cols))
-    r = rng.uniform(0.5, 2.0, (n_rows, n_cols))
-    qh = rng.uniform(0.5, 2.0, (n_rows, max(n_cols - 1, 0)))
-    qv = rng.uniform(0.5, 2.0, (max(n_rows - 1, 0), n_cols))
     factor_ids = np.concatenate([unary.ravel(), hfac.ravel(), vfac.ravel()])
-    factor_kind = np.concatenate([np.full(nv, L.FACTOR_OPAQUE, np.int32), np.full(nh + nvert, L.FACTOR_GAUSS_ADDITIVE, np.int32)])
-    factor_var = np.concatenate([np.ones(nv), qh.ravel(), qv.ravel()])
+    factor_kind = np.concatenate([np.full(unary.size, L.FACTOR_OPAQUE, np.int32),
+                                  np.full(hfac.size + vfac.size, L.FACTOR_GAUSS_ADDITIVE, np.int32)])
+    factor_var = np.concatenate([np.ones(unary.size), qh.ravel(), qv.ravel()])
+    ghost_rows = [i for i in (row0 - 1, row1) if 0 <= i < n_rows and not (row0 <= i < row1)]
     return Model(edge_var=edge_var, edge_fac=edge_fac, factor_ids=factor_ids, factor_kind=factor_kind, factor_var=factor_var,
-                 x_ids=var_id.ravel(), prior_var=var_id.ravel(), prior_fac=unary.ravel(), prior_mean=yobs.ravel(),
+                 x_ids=vid.ravel(), prior_var=vid.ravel(), prior_fac=unary.ravel(), prior_mean=yobs.ravel(),
                  prior_variance=r.ravel(),
-                 meta={"n_rows": n_rows, "n_cols": n_cols, "y": yobs, "r": r, "qh": qh, "qv": qv, "kind": "gaussian_grid"})
+                 meta={"n_rows": n_rows, "n_cols": n_cols, "row0": row0, "row1": row1, "y": yobs, "r": r, "qh": qh,
+                       "qv": qv, "qv_row0": v0, "ghost_rows": ghost_rows, "kind": "gaussian_grid"})
 
 
 def load_into_device(model: Model, dev, seed_variance: float | None = None):

@@ -39,9 +39,12 @@ static inline nmv product(nmv l, nmv r) {
 /* one flooding sweep; returns number of directed messages (re)computed */
 int64_t cxo_flood_sweep(int64_t nv, const int64_t *var_off, int64_t ne, const int64_t *partner, const double *q,
                         const uint8_t *fixed_v2f, double *f2v_m, double *f2v_v, double *v2f_m, double *v2f_v,
-                        int32_t use_omp) {
+                        int32_t use_omp, int32_t phases) {
+    /* phases: bit 0 = phase A (variable -> factor), bit 1 = phase B (factor -> variable); 3 = one full sweep.
+     * A partitioned run does A, exchanges the cut messages, then B. */
     int64_t updates = 0;
     (void)ne;
+    if (phases & 1) {
     /* phase A: variable -> factor */
 #pragma omp parallel for schedule(static) reduction(+ : updates) if (use_omp)
     for (int64_t v = 0; v < nv; v++) {
@@ -62,6 +65,8 @@ int64_t cxo_flood_sweep(int64_t nv, const int64_t *var_off, int64_t ne, const in
             updates++;
         }
     }
+    }
+    if (phases & 2) {
     /* phase B: factor -> variable (pairwise additive-Gaussian factors) */
 #pragma omp parallel for schedule(static) reduction(+ : updates) if (use_omp)
     for (int64_t e = 0; e < ne; e++) {
@@ -71,6 +76,7 @@ int64_t cxo_flood_sweep(int64_t nv, const int64_t *var_off, int64_t ne, const in
         f2v_m[e] = v2f_m[p];
         f2v_v[e] = v2f_v[p] + q[e];
         updates++;
+    }
     }
     return updates;
 }

@@ -93,7 +93,7 @@ def lib():
     sig("cxo_bulk_get_marginals", None, vp, pi64, i64, pi32, pd, pd)
     sig("cxo_bulk_get_messages", None, vp, pi64, pi64, i64, i32, pi32, pd, pd)
     sig("cxo_bulk_build", i32, vp, i64, pi32, pi32, pd, i64, pi64, pi64)
-    sig("cxo_flood_sweep", i64, i64, pi64, i64, pi64, pd, pu8, pd, pd, pd, pd, i32)
+    sig("cxo_flood_sweep", i64, i64, pi64, i64, pi64, pd, pu8, pd, pd, pd, pd, i32, i32)
     sig("cxo_flood_marginals", None, i64, pi64, pd, pd, pd, pd, i32)
     _lib = L
     return L
@@ -353,14 +353,15 @@ class FloodGraph:
         e = self.edge_index(var, fac)
         self.f2v_m[e], self.f2v_v[e] = mean, variance
 
-    def sweep(self, n=1, use_omp=False):
+    def sweep(self, n=1, use_omp=False, phases=3):
+        """phases: 1 = variable→factor only, 2 = factor→variable only, 3 = both (one flooding sweep)."""
         L = lib()
         total = 0
         for _ in range(n):
             total += L.cxo_flood_sweep(self.nv, _p(self.var_off, C.c_int64), self.ne, _p(self.partner, C.c_int64),
                                        _p(self.q, C.c_double), _p(self.fixed_v2f, C.c_uint8),
                                        _p(self.f2v_m, C.c_double), _p(self.f2v_v, C.c_double),
-                                       _p(self.v2f_m, C.c_double), _p(self.v2f_v, C.c_double), int(use_omp))
+                                       _p(self.v2f_m, C.c_double), _p(self.v2f_v, C.c_double), int(use_omp), int(phases))
         return total
 
     def marginals(self, use_omp=False):

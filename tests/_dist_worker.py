@@ -1,0 +1,62 @@
+"""Worker of tests/test_partition_gloo.py: one rank of a world_size-N gloo job on CPU.
+
+Runs the SAME partition + HaloExchange code the GPU bench runs (cortex.jl_amd/partition.py), with the CPU checker
+(oracle/bp_flood.c) standing in for the device sweeper, and writes this rank's messages and marginals to a file."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from cortex.jl_amd import partition  # noqa: E402
+from tests.helpers import flood_oracle_from_model  # noqa: E402
+
+
+class OracleSweeper:
+    def __init__(self, part, seed_variance):
+        self.g = g = flood_oracle_from_model(part.model, seed_variance)
+        self.send_e = g.edge_index(part.send_var, part.send_fac) if len(part.send_var) else np.zeros(0, np.int64)
+        self.recv_e = g.edge_index(part.recv_var, part.recv_fac) if len(part.recv_var) else np.zeros(0, np.int64)
+        g.fixed_v2f[self.recv_e] = 1
+        self.send = torch.zeros((max(len(self.send_e), 1), 2), dtype=torch.float64)
+        self.recv = torch.zeros((max(len(self.recv_e), 1), 2), dtype=torch.float64)
+
+    def sweep_begin(self):
+        self.g.sweep(1, phases=1)
+        n = len(self.send_e)
+        self.send[:n, 0] = torch.from_numpy(self.g.v2f_m[self.send_e])
+        self.send[:n, 1] = torch.from_numpy(self.g.v2f_v[self.send_e])
+
+    def sweep_main(self):
+        pass
+
+    def sweep_end(self):
+        n = len(self.recv_e)
+        self.g.v2f_m[self.recv_e] = self.recv[:n, 0].numpy()
+        self.g.v2f_v[self.recv_e] = self.recv[:n, 1].numpy()
+        self.g.sweep(1, phases=2)
+
+
+def main():
+    rows, cols, sweeps, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    part = partition.grid_strip(rows, cols, rank, world, seed=99)
+    sw = OracleSweeper(part, 1e6)
+    ex = partition.HaloExchange(sw, part, dist)
+    for _ in range(sweeps):
+        ex.sweep()
+    g = sw.g
+    m, v = g.marginals()
+    np.savez(out + f".rank{rank}.npz", edge_var=g.edge_var, edge_fac=g.edge_fac, f2v_m=g.f2v_m, f2v_v=g.f2v_v,
+             v2f_m=g.v2f_m, v2f_v=g.v2f_v, var_ids=g.var_ids, marg_m=m, marg_v=v, owned=part.model.x_ids)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

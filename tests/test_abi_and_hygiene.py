@@ -1,0 +1,79 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/cortex_hip.h
+declares, fails loudly without a GPU, and nothing in the product reaches into oracle/."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import cortex.jl_amd as cx
+from cortex.jl_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cortex_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cx_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(hip_lib):
+    names = _declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(hip_lib, n), f"{n} declared in include/cortex_hip.h but not exported by libcortex_hip.so"
+        assert n in L.SIGNATURES, f"{n} has no ctypes signature in cortex.jl_amd/_lib.py"
+    assert sorted(L.SIGNATURES) == names
+    assert hip_lib.cx_version() == L.ABI_VERSION
+
+
+def test_header_constants_match_binding():
+    text = open(os.path.join(ROOT, "include", "cortex_hip.h")).read()
+    defs = dict(re.findall(r"#define\s+(CX_[A-Z_0-9]+)\s+\(?(-?\d+)\)?", text))
+    for k, v in defs.items():
+        py = k[3:]
+        if hasattr(L, py):
+            assert getattr(L, py) == int(v), k
+    assert C.sizeof(L.Config) == 32 and C.sizeof(L.Item) == 24
+
+
+def test_payload_sizes(hip_lib):
+    assert hip_lib.cx_payload_doubles(1, L.FORM_MOMENT) == 2
+    assert hip_lib.cx_payload_doubles(1, L.FORM_POINT) == 1
+    assert hip_lib.cx_payload_doubles(4, L.FORM_MOMENT) == 20
+    assert hip_lib.cx_payload_doubles(64, L.FORM_MOMENT) == 4160
+    assert hip_lib.cx_payload_doubles(0, L.FORM_MOMENT) == -1
+
+
+def test_no_cpu_fallback_without_gpu(hip_lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(cx.CortexHipError) as e:
+        cx.DeviceGraph()
+    assert e.value.code == L.ERR_NO_DEVICE and "no CPU fallback" in e.value.message
+    bad = L.Config(4, 0, 1, 0, 1, 0)
+    h = C.c_void_p()
+    assert hip_lib.cx_create(C.byref(bad), C.byref(h)) == L.ERR_INVALID_ARGUMENT
+    assert hip_lib.cx_destroy(None) == L.OK  # idempotent on NULL
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/."""
+    offenders = []
+    for base in ("cortex.jl_amd", "cortex", "include", "tools"):
+        for dirpath, _dirs, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cpp", ".c", ".sh")):
+                    src = open(os.path.join(dirpath, f), errors="ignore").read()
+                    if re.search(r"(from|import)\s+oracle\b|libcortex_oracle|oracle/", src):
+                        offenders.append(os.path.join(dirpath, f))
+    assert not offenders, offenders
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle|import oracle|tests\.helpers", bench)]
+    body = bench[bench.index("def cpu_baseline"):bench.index("def main")]
+    assert uses and all(bench.index("def cpu_baseline") < u < bench.index("def main") for u in uses), \
+        "bench.py may use the checker only inside cpu_baseline()"
+    assert "oracle" in body

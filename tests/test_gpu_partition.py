@@ -1,0 +1,122 @@
+"""-m gpu: the partitioned sweep (cx_sweep_begin / _main / _end + halo buffers) on ONE GPU.
+
+Two or three DeviceGraph handles hold neighbouring strips of a grid; an in-process stand-in for torch.distributed
+moves the halo tensors between them (threads + a mailbox).  The result must equal the un-partitioned device sweep
+bit for bit, and the CPU checker within tolerance.  This exercises exactly the code path bench.py runs under
+torch.distributed.run with N > 1, minus RCCL itself."""
+import threading
+
+import numpy as np
+import pytest
+
+import cortex.jl_amd as cx
+from cortex.jl_amd import _lib as L
+from cortex.jl_amd import partition
+from tests.helpers import assert_close, flood_oracle_from_model
+
+pytestmark = pytest.mark.gpu
+
+
+class _Work:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def wait(self):
+        self.fn()
+
+
+class LoopbackDist:
+    """Just enough of torch.distributed's P2P surface for partition.HaloExchange, for ranks living in threads."""
+
+    def __init__(self, world, torch):
+        self.world, self.torch = world, torch
+        self.cv = threading.Condition()
+        self.box = {}
+        self.local = threading.local()
+
+    def bind(self, rank):
+        self.local.rank = rank
+
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    def isend(self, *a):
+        raise NotImplementedError
+
+    def irecv(self, *a):
+        raise NotImplementedError
+
+    def batch_isend_irecv(self, ops):
+        me = self.local.rank
+        works = []
+        for o in ops:
+            if o.op == self.isend:
+                self.torch.cuda.synchronize()  # the pack kernel has finished
+                with self.cv:
+                    self.box[(me, o.peer)] = o.tensor.clone()
+                    self.cv.notify_all()
+            else:
+                def recv(o=o):
+                    with self.cv:
+                        self.cv.wait_for(lambda: (o.peer, me) in self.box, timeout=60)
+                        o.tensor.copy_(self.box.pop((o.peer, me)))
+                works.append(_Work(recv))
+        return works
+
+
+@pytest.mark.parametrize("schedule", [L.SCHED_FUSED, L.SCHED_FLOODING])
+@pytest.mark.parametrize("world,rows,cols", [(2, 5, 9), (3, 40, 300)])
+def test_partitioned_device_sweep_equals_whole_grid(hip_lib, schedule, world, rows, cols):
+    import torch
+
+    sweeps = 7
+    whole_model = cx.synth.gaussian_grid(rows * world, cols, seed=21)
+    whole = cx.DeviceGraph(schedule=schedule)
+    cx.synth.load_into_device(whole_model, whole, seed_variance=1e6)
+    whole.sweep(sweeps)
+
+    ld = LoopbackDist(world, torch)
+    devs, parts, errors = [None] * world, [None] * world, []
+
+    def run(rank):
+        try:
+            ld.bind(rank)
+            part = partition.grid_strip(rows, cols, rank, world, seed=21)
+            dev = cx.DeviceGraph(schedule=schedule)
+            cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
+            sw = partition.DeviceSweeper(dev, part, torch, torch.device("cuda", 0))
+            ex = partition.HaloExchange(sw, part, ld)
+            with pytest.raises(cx.CortexHipError):
+                dev.sweep(1)  # a partition handle refuses the un-partitioned entry point
+            for _ in range(sweeps):
+                ex.sweep()
+            dev.sync()
+            devs[rank], parts[rank] = dev, (part, sw)
+        except Exception as e:  # pragma: no cover
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+
+    g = flood_oracle_from_model(whole_model, 1e6)
+    g.sweep(sweeps)
+    for rank in range(world):
+        part, _sw = parts[rank]
+        m = part.model
+        own = np.isin(m.edge_var, m.x_ids)
+        ev, ef = m.edge_var[own], m.edge_fac[own]
+        got = devs[rank].get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL)
+        ref_ = whole.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL)
+        assert np.array_equal(got, ref_, equal_nan=True), f"rank {rank}: partitioned f2v != whole-grid f2v (bitwise)"
+        gm = devs[rank].get_marginals(m.x_ids)
+        wm = whole.get_marginals(m.x_ids)
+        assert np.array_equal(gm, wm, equal_nan=True)
+        e = g.edge_index(ev, ef)
+        mom = devs[rank].get_messages(ev, ef, L.TO_VARIABLE)
+        assert_close(mom[:, 0], g.f2v_m[e], 1e-9, "f2v mean vs CPU checker")
+        assert_close(mom[:, 1], g.f2v_v[e], 1e-9, "f2v variance vs CPU checker")
