@@ -701,6 +701,8 @@ int32_t cx_halo_set_buffers(cx_handle *h, void *send_ptr, void *recv_ptr) {
 int32_t cx_profile_enable(cx_handle *h, int32_t on) {
     CX_REQUIRE(h, h, CX_ERR_INVALID_ARGUMENT, "null handle");
     h->profiling = on != 0;
+    h->prof_stride = on > 1 ? on : 1;   // on = n > 1: bracket every n-th launch of each kernel only
+    for (auto &c : h->prof_count) c = 0;
     return CX_OK;
 }
 

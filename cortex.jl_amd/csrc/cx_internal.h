@@ -83,7 +83,9 @@ struct cx_handle {
     int64_t stage_bytes = 0;
 
     // profiling
-    bool profiling = false;
+    bool profiling = false, prof_armed = false;
+    int prof_stride = 1;
+    int64_t prof_count[CX_KERNEL_COUNT] = {0};
     std::vector<cx::ProfileRec> recs;
 };
 

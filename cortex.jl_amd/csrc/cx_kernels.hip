@@ -333,8 +333,13 @@ __global__ __launch_bounds__(kBlock) void k_residual(const double2 *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
+// hipEvent pair around a launch.  Every event is a barrier packet on the queue, so with a stride > 1 only every
+// stride-th launch of a kernel is bracketed and the others dispatch back to back.
 static inline void prof_begin(cx_handle *h, int kernel) {
+    h->prof_armed = false;
     if (!h->profiling) return;
+    if ((h->prof_count[kernel]++ % h->prof_stride) != 0) return;
+    h->prof_armed = true;
     ProfileRec r;
     r.kernel = kernel;
     (void)hipEventCreate(&r.start);
@@ -343,7 +348,7 @@ static inline void prof_begin(cx_handle *h, int kernel) {
     h->recs.push_back(r);
 }
 static inline void prof_end(cx_handle *h) {
-    if (!h->profiling) return;
+    if (!h->profiling || !h->prof_armed) return;
     (void)hipEventRecord(h->recs.back().stop, h->stream);
 }
 

@@ -157,7 +157,8 @@ class DeviceGraph:
         self._check(self.lib.cx_halo_set_buffers(self.h, C.c_void_p(send_ptr or 0), C.c_void_p(recv_ptr or 0)))
 
     # -- measurement ----------------------------------------------------------------------------
-    def profile_enable(self, on: bool = True):
+    def profile_enable(self, on=True):
+        """True/1: hipEvents around every launch; n > 1: around every n-th launch; False/0: off."""
         self._check(self.lib.cx_profile_enable(self.h, int(on)))
 
     def profile_read(self, kernel: int):

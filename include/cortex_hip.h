@@ -185,7 +185,8 @@ int32_t cx_sweep_end(cx_handle *h);
 #define CX_KERNEL_HALO_BEGIN 5
 #define CX_KERNEL_HALO_END 6
 #define CX_KERNEL_COUNT 8
-/* hipEvent pairs around every kernel launch of cx_sweep on the handle's stream */
+/* hipEvent pairs around kernel launches on the handle's stream: on == 1 every launch, on == n > 1 every n-th
+ * launch of each kernel (events are barrier packets; a stride keeps the other launches back to back), 0 off */
 int32_t cx_profile_enable(cx_handle *h, int32_t on);
 int32_t cx_profile_read(cx_handle *h, int32_t kernel, double *total_ms, int64_t *launches); /* syncs; resets */
 const char *cx_kernel_name(int32_t kernel);

@@ -15,6 +15,10 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def hip_lib():
     """Build (if stale and hipcc is present) and load libcortex_hip.so."""
+    import torch
+
+    if torch.cuda.is_available():
+        torch.cuda.init()  # torch's HIP context first, in the main thread (tests also hand torch tensors to the library)
     import cortex.jl_amd as cx
     from cortex.jl_amd import build as B
 
