@@ -1,0 +1,195 @@
+"""HipProcessor — the AbstractInferenceRequestProcessor that puts the MI355X sweep behind the reference's plugin API
+(src/inference_engine.jl:331-509).  The host keeps Signals, readiness bits and the scheduler; message values live in
+HBM behind a cx_handle and the rule calls become launches through the C ABI (include/cortex_hip.h).
+
+Modes:
+  "per_signal"  every `process!` is a 1-element cx_update_batch followed by set_value!: the reference's exact
+                execution order, one launch per message (schedule parity; slow by construction).
+  "wavefront"   update_marginals! takes the call over: scan the currently pending signals
+                (scan_inference_request, inference_engine.jl:540-546), compute the whole wavefront in ONE launch,
+                set_value! them in scan order, repeat.  Same results on trees, O(depth) launches.
+  "sweep"       update_marginals! runs `n_sweeps` passes of the device schedule over the whole graph (cx_sweep) and
+                marks the requested marginals computed.  The benchmarked path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Callable, List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib as L
+from .device import DeviceGraph
+from .inference_engine import (AbstractInferenceRequestProcessor, InferenceEngine, request_inference_for,
+                               scan_inference_request)
+from .inference_signal import InferenceSignalVariants as V
+from .model_engine import get_factor_functional_form, get_variable_marginal
+from .signal import Signal, is_pending, set_value as _host_set_value
+
+
+@dataclass(frozen=True)
+class NormalMeanVariance:
+    """The reference's test struct (test/runtests.jl:31-34)."""
+    mean: float
+    variance: float
+
+
+@dataclass(frozen=True)
+class GaussianAdditive:
+    """functional_form of a 2-edge factor x_b = x_a + N(0, variance): the likelihood / transition of
+    test/inference_engine_tests.jl:415-432 (variance 1.0 there)."""
+    variance: float = 1.0
+
+
+@dataclass(frozen=True)
+class GaussianLinear:
+    """x_out = a * x_in + b + N(0, variance); edges labelled :in / :out (Connection.label, model_engine.jl:182)."""
+    a: float
+    b: float
+    variance: float
+
+
+def default_factor_rule(factor) -> Tuple[int, Tuple[float, ...]]:
+    ff = get_factor_functional_form(factor)
+    if isinstance(ff, GaussianAdditive):
+        return L.FACTOR_GAUSS_ADDITIVE, (ff.variance,)
+    if isinstance(ff, GaussianLinear):
+        return L.FACTOR_GAUSS_LINEAR, (ff.variance, ff.a, ff.b)
+    return L.FACTOR_OPAQUE, ()
+
+
+class HipValue:
+    """What a device-computed Signal holds on the host: a handle, not the payload (`Signal.value` only has to differ
+    from UndefValue() for is_computed, signal.jl:162-164).  `.mean` / `.variance` read the device on first use."""
+    __slots__ = ("_proc", "_variant", "_cache")
+
+    def __init__(self, proc, variant):
+        self._proc, self._variant, self._cache = proc, variant, None
+
+    def _fetch(self):
+        if self._cache is None:
+            self._cache = self._proc.read(self._variant)
+        return self._cache
+
+    @property
+    def mean(self):
+        return self._fetch().mean
+
+    @property
+    def variance(self):
+        return self._fetch().variance
+
+    def __repr__(self):
+        return f"HipValue({self._variant!r})"
+
+
+class HipProcessor(AbstractInferenceRequestProcessor):
+    def __init__(self, *, mode: str = "sweep", n_sweeps: int = 1, device: int = 0, schedule: int = L.SCHED_FUSED,
+                 factor_rule: Callable = default_factor_rule):
+        if mode not in ("per_signal", "wavefront", "sweep"):
+            raise ValueError(f"unknown mode {mode!r}")
+        self.mode, self.n_sweeps, self.factor_rule = mode, n_sweeps, factor_rule
+        self.dev = DeviceGraph(device=device, schedule=schedule)   # raises without a GPU: no CPU fallback
+        self.engine: Optional[InferenceEngine] = None
+        self.launches = 0
+        self.execution_log: List[Any] = []   # variants in execution order (schedule-parity checks)
+
+    # ---- build hook: flatten the bipartite graph through the reference's 7 accessors -------------------------
+    def attach(self, engine: InferenceEngine):
+        self.engine = engine
+        ev, ef, role, fids, kinds, params = [], [], [], [], [], []
+        for f in engine.get_factor_ids():
+            kind, p = self.factor_rule(engine.get_factor(f))
+            fids.append(f); kinds.append(kind); params.append(tuple(p) + (0.0,) * (L.NPARAM - len(p)))
+            for v in engine.get_connected_variable_ids(f):
+                ev.append(v); ef.append(f)
+                role.append(L.ROLE_IN if str(engine.get_connection(v, f).label).lstrip(":") == "in" else L.ROLE_OUT)
+        if not ev:
+            return
+        self.dev.graph_create(ev, ef, fids, kinds, np.asarray(params, dtype=np.float64), edge_role=role)
+
+    # ---- data injection: set_value! on a message signal, mirrored to the device ---------------------------------
+    def set_value(self, signal: Signal, value):
+        variant = signal.variant
+        if isinstance(variant, V.MessageToFactor):
+            direction = L.TO_FACTOR
+        elif isinstance(variant, V.MessageToVariable):
+            direction = L.TO_VARIABLE
+        else:
+            raise TypeError("HipProcessor.set_value: only message signals carry device payloads")
+        if isinstance(value, (int, float, np.floating)):
+            self.dev.set_messages([variant.variable_id], [variant.factor_id], direction, L.FORM_POINT, [float(value)])
+        else:
+            self.dev.set_messages([variant.variable_id], [variant.factor_id], direction, L.FORM_MOMENT,
+                                  [float(value.mean), float(value.variance)])
+        _host_set_value(signal, value)
+
+    def read(self, variant) -> NormalMeanVariance:
+        if isinstance(variant, V.IndividualMarginal):
+            m = self.dev.get_marginals([variant.variable_id])[0]
+        elif isinstance(variant, V.MessageToVariable):
+            m = self.dev.get_messages([variant.variable_id], [variant.factor_id], L.TO_VARIABLE)[0]
+        elif isinstance(variant, V.MessageToFactor):
+            m = self.dev.get_messages([variant.variable_id], [variant.factor_id], L.TO_FACTOR)[0]
+        else:
+            raise TypeError(f"no device payload for {variant!r}")
+        return NormalMeanVariance(float(m[0]), float(m[1]))
+
+    # ---- rules: each is a 1-element batch (the scalar fallback of SURVEY §8b) -----------------------------------
+    @staticmethod
+    def _item(variant):
+        if isinstance(variant, V.MessageToVariable):
+            return L.ITEM_MESSAGE_TO_VARIABLE, variant.variable_id, variant.factor_id
+        if isinstance(variant, V.MessageToFactor):
+            return L.ITEM_MESSAGE_TO_FACTOR, variant.variable_id, variant.factor_id
+        if isinstance(variant, V.IndividualMarginal):
+            return L.ITEM_INDIVIDUAL_MARGINAL, variant.variable_id, 0
+        raise NotImplementedError(f"The HIP processor has no rule for {type(variant).__name__}")
+
+    def _launch(self, variants):
+        items = [self._item(v) for v in variants]
+        self.dev.update_batch([i[0] for i in items], [i[1] for i in items], [i[2] for i in items])
+        self.launches += 1
+        self.execution_log.extend(variants)
+
+    def compute_message_to_variable(self, engine, variant, signal, dependencies):
+        self._launch([variant])
+        return HipValue(self, variant)
+
+    compute_message_to_factor = compute_message_to_variable
+    compute_individual_marginal = compute_message_to_variable
+
+    # ---- whole-call takeover (a Julia method of update_marginals! specialised on the processor type) -------------
+    def update_marginals(self, engine, ids) -> bool:
+        if self.mode == "per_signal":
+            return False                       # the generic scheduler drives process! one signal at a time
+        if self.mode == "sweep":
+            self.dev.sweep(self.n_sweeps)
+            self.refresh_marginals(ids)        # marginals of the messages the last sweep produced
+            for vid in ids:
+                m = get_variable_marginal(engine.get_variable(vid))
+                _host_set_value(m, HipValue(self, m.variant))
+            return True
+        # wavefront
+        request = request_inference_for(engine, ids)
+        while True:
+            front = scan_inference_request(request)
+            # a signal may be reachable from several marginals: keep first occurrences, in scan order
+            seen, uniq = set(), []
+            for s in front:
+                if id(s) not in seen:
+                    seen.add(id(s)); uniq.append(s)
+            if not uniq:
+                break
+            self._launch([s.variant for s in uniq])
+            for s in uniq:
+                _host_set_value(s, HipValue(self, s.variant))
+        final = [m for m in request.marginals if is_pending(m)]
+        if final:
+            self._launch([m.variant for m in final])
+            for m in final:
+                _host_set_value(m, HipValue(self, m.variant))
+        return True
+
+    def refresh_marginals(self, ids):
+        self.dev.update_batch([L.ITEM_INDIVIDUAL_MARGINAL] * len(ids), list(ids), [0] * len(ids))

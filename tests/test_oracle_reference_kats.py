@@ -11,9 +11,45 @@ import pytest
 from oracle import exact, ref
 
 
-@pytest.fixture()
-def E():
-    return ref.Engine(ref.P_SSM_BP)
+class MirrorSignals:
+    """The same free-signal surface as ref.Engine, backed by the product's host-side mirror
+    (cortex.jl_amd/signal.py): the reference's known answers pin BOTH restatements."""
+
+    def __init__(self):
+        import cortex.jl_amd as cx
+        self.cx = cx
+
+    def signal(self):
+        return self.cx.Signal()
+
+    def set_value(self, s, value):
+        self.cx.set_value(s, value)
+
+    def add_dependency(self, s, d, weak=False, listen=True, check_computed=True, intermediate=False):
+        self.cx.add_dependency(s, d, weak=weak, listen=listen, check_computed=check_computed, intermediate=intermediate)
+
+    def is_pending(self, s):
+        return self.cx.is_pending(s)
+
+    def is_computed(self, s):
+        return self.cx.is_computed(s)
+
+    def dependencies(self, s):
+        return list(self.cx.get_dependencies(s))
+
+    def listeners(self, s):
+        return list(self.cx.get_listeners(s))
+
+    def chunks(self, s):
+        return list(s.dependencies_props.chunks)
+
+    def process_dependencies(self, s, fn, retry=False):
+        return self.cx.process_dependencies(fn, s, retry=retry)
+
+
+@pytest.fixture(params=["oracle", "mirror"])
+def E(request):
+    return ref.Engine(ref.P_SSM_BP) if request.param == "oracle" else MirrorSignals()
 
 
 def S(E, value=None):
