@@ -20,7 +20,7 @@ FORM_MOMENT, FORM_POINT, FORM_NATURAL = 0, 1, 2
 FACTOR_OPAQUE, FACTOR_GAUSS_ADDITIVE, FACTOR_GAUSS_LINEAR = 0, 1, 2
 NPARAM = 4
 ROLE_OUT, ROLE_IN = 0, 1
-SCHED_FLOODING, SCHED_FUSED = 0, 1
+SCHED_FLOODING, SCHED_FUSED, SCHED_CHAIN_SCAN = 0, 1, 2
 KERNEL_VAR_TO_FACTOR, KERNEL_FACTOR_TO_VAR, KERNEL_FUSED, KERNEL_BATCH, KERNEL_BIG_VAR = 0, 1, 2, 3, 4
 KERNEL_HALO_BEGIN, KERNEL_HALO_END = 5, 6
 KERNEL_COUNT = 8

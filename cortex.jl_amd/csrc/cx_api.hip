@@ -58,8 +58,11 @@ void dev_free_all(cx_handle *h) {
                     h->d_vinfo, h->d_q, h->d_a, h->d_b, h->d_sq, h->d_sa, h->d_sb, h->d_f2v, h->d_v2f, h->d_marg,
                     h->d_f2v_alt, h->d_prev, h->d_scratch, h->d_send_slots, h->d_recv_slots, h->d_send_vars,
                     h->ext_halo_buffers ? nullptr : (void *)h->d_send_buf, h->ext_halo_buffers ? nullptr : (void *)h->d_recv_buf,
-                    h->d_stage};
+                    h->d_stage, h->d_chain_pos_var, h->d_chain_skip0, h->d_chain_skip1, h->d_chain_link_pos, h->d_chain_from,
+                    h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_side, h->d_chain_totals};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    h->d_chain_pos_var = h->d_chain_skip0 = h->d_chain_skip1 = h->d_chain_link_pos = h->d_chain_from = h->d_chain_to = nullptr;
+    h->d_chain_head_fwd = h->d_chain_head_bwd = nullptr; h->d_chain_side = nullptr; h->d_chain_totals = nullptr; h->chains_dirty = true;
     h->d_slice_off = h->d_partner = h->d_vbase = h->d_var_deg = h->d_big = h->d_big_slots = nullptr;
     h->d_big_tmp = nullptr; h->d_vinfo = nullptr;
     h->d_q = h->d_a = h->d_b = h->d_sq = h->d_sa = h->d_sb = nullptr;
@@ -154,7 +157,7 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
     if (!config || config->struct_size != (int32_t)sizeof(cx_config))
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: config is NULL or struct_size mismatch");
     if (config->dim != 1) return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: this build implements dim == 1 (scalar Gaussian) only");
-    if (config->schedule != CX_SCHED_FLOODING && config->schedule != CX_SCHED_FUSED)
+    if (config->schedule != CX_SCHED_FLOODING && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN)
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: unknown schedule");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -442,6 +445,7 @@ int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
             if (form == CX_FORM_POINT) {
                 // a variable that carries a point-mass datum is observed: its messages are never recomputed
                 for (int64_t i = 0; i < n; i++) h->vinfo[vars[i]] |= cx::kClamped;
+                h->chains_dirty = true;
                 CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
             }
         } else {
@@ -558,10 +562,82 @@ int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_update_batch: host allocation failed"); }
 }
 
+// ---- chain decomposition for CX_SCHED_CHAIN_SCAN -------------------------------------------------------------------
+// Free variables (not observed, not ghosts, degree >= 2) linked by 2-edge factors must form disjoint simple paths.
+static int32_t build_chains(cx_handle *h) {
+    if (!h->chains_dirty) return CX_OK;
+    try {
+        const int64_t nv = h->nv;
+        std::vector<int32_t> slot_var(h->nslots, -1);
+        for (int64_t e = 0; e < h->ne; e++) slot_var[cx::slot_of_edge(h, e)] = h->edge_var[e];
+        auto is_free = [&](int32_t v) { return !(h->vinfo[v] & (cx::kClamped | cx::kGhost)) && (h->var_off[v + 1] - h->var_off[v]) >= 2; };
+        std::vector<int32_t> dyn(2 * nv, -1);
+        std::vector<uint8_t> ndyn(nv, 0);
+        for (int64_t e = 0; e < h->ne; e++) {
+            const int32_t v = h->edge_var[e];
+            if (!is_free(v)) continue;
+            const int32_t s = cx::slot_of_edge(h, e), p = h->partner[s];
+            if (p < 0 || !is_free(slot_var[p])) continue;
+            if (ndyn[v] == 2)
+                return fail(h, CX_ERR_UNSUPPORTED, "chain-scan schedule: variable " + std::to_string(h->var_ids[v]) + " has more than two non-observed neighbours (the graph is not a union of chains)");
+            dyn[2 * v + ndyn[v]++] = s;
+        }
+        std::vector<int32_t> pos_var, skip0, skip1, link_pos, from, to;
+        std::vector<uint8_t> head_fwd, head_bwd, visited(nv, 0);
+        for (int64_t v0 = 0; v0 < nv; v0++) {
+            if (!is_free((int32_t)v0) || visited[v0] || ndyn[v0] != 1) continue;
+            int32_t cur = (int32_t)v0, incoming = -1;
+            bool first = true;
+            while (true) {
+                visited[cur] = 1;
+                int32_t out = -1;
+                for (int k = 0; k < ndyn[cur]; k++) if (dyn[2 * cur + k] != incoming) out = dyn[2 * cur + k];
+                pos_var.push_back(cur); skip0.push_back(incoming); skip1.push_back(out);
+                if (out < 0) break;
+                link_pos.push_back((int32_t)pos_var.size() - 1); from.push_back(out); to.push_back(h->partner[out]);
+                head_fwd.push_back(first ? 1 : 0); head_bwd.push_back(0);
+                first = false;
+                incoming = h->partner[out];
+                cur = slot_var[incoming];
+                if (visited[cur]) return fail(h, CX_ERR_UNSUPPORTED, "chain-scan schedule: the graph has a cycle");
+            }
+            if (!head_bwd.empty()) head_bwd.back() = 1;
+        }
+        for (int64_t v = 0; v < nv; v++)
+            if (is_free((int32_t)v) && !visited[v] && ndyn[v] == 2)
+                return fail(h, CX_ERR_UNSUPPORTED, "chain-scan schedule: the graph has a cycle through variable " + std::to_string(h->var_ids[v]));
+        for (void *p : {(void *)h->d_chain_pos_var, (void *)h->d_chain_skip0, (void *)h->d_chain_skip1, (void *)h->d_chain_link_pos,
+                        (void *)h->d_chain_from, (void *)h->d_chain_to, (void *)h->d_chain_head_fwd, (void *)h->d_chain_head_bwd,
+                        (void *)h->d_chain_side, h->d_chain_totals}) if (p) (void)hipFree(p);
+        h->chain_npos = (int64_t)pos_var.size(); h->chain_nlinks = (int64_t)link_pos.size();
+        int32_t rc;
+        if ((rc = dev_upload(h, &h->d_chain_pos_var, pos_var)) != CX_OK) return rc;
+        if ((rc = dev_upload(h, &h->d_chain_skip0, skip0)) != CX_OK) return rc;
+        if ((rc = dev_upload(h, &h->d_chain_skip1, skip1)) != CX_OK) return rc;
+        if ((rc = dev_upload(h, &h->d_chain_link_pos, link_pos)) != CX_OK) return rc;
+        if ((rc = dev_upload(h, &h->d_chain_from, from)) != CX_OK) return rc;
+        if ((rc = dev_upload(h, &h->d_chain_to, to)) != CX_OK) return rc;
+        if ((rc = dev_upload(h, &h->d_chain_head_fwd, head_fwd)) != CX_OK) return rc;
+        if ((rc = dev_upload(h, &h->d_chain_head_bwd, head_bwd)) != CX_OK) return rc;
+        if ((rc = dev_alloc(h, &h->d_chain_side, h->chain_npos)) != CX_OK) return rc;
+        char *tot = nullptr;
+        if ((rc = dev_alloc(h, &tot, (int64_t)cx::chain_total_bytes(h->chain_nlinks))) != CX_OK) return rc;
+        h->d_chain_totals = tot;
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        h->chains_dirty = false;
+        return CX_OK;
+    } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "chain decomposition: host allocation failed"); }
+}
+
 // ---- the sweep ----------------------------------------------------------------------------------------------------
 static void sweep_main(cx_handle *h, bool skip_ghosts) {
     const bool marg = h->cfg.compute_marginals_in_sweep != 0;
-    if (h->cfg.schedule == CX_SCHED_FLOODING) {
+    if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) {
+        cx::launch_factor_to_var(h, h->d_v2f, h->d_f2v);   // messages out of observed leaves (data) into the chains
+        cx::launch_chain_scan(h, h->d_f2v);                // all forward and backward chain messages
+        cx::launch_var_to_factor(h, h->d_f2v, marg);       // every variable→factor message + marginals
+        cx::launch_big_var_to_factor(h, h->d_f2v, marg);
+    } else if (h->cfg.schedule == CX_SCHED_FLOODING) {
         cx::launch_var_to_factor(h, h->d_f2v, marg);
         cx::launch_big_var_to_factor(h, h->d_f2v, marg);
     } else {
@@ -575,7 +651,7 @@ static void sweep_main(cx_handle *h, bool skip_ghosts) {
 }
 
 static void sweep_finish(cx_handle *h) {
-    if (h->cfg.schedule == CX_SCHED_FLOODING) {
+    if (h->cfg.schedule == CX_SCHED_FLOODING || h->cfg.schedule == CX_SCHED_CHAIN_SCAN) {
         cx::launch_factor_to_var(h, h->d_v2f, h->d_f2v);
     } else {
         std::swap(h->d_f2v, h->d_f2v_alt);
@@ -589,6 +665,7 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
     CX_REQUIRE(h, n_sweeps >= 0, CX_ERR_INVALID_ARGUMENT, "cx_sweep: n_sweeps < 0");
     CX_REQUIRE(h, h->recv_slots.empty() && h->send_slots.empty(), CX_ERR_STATE,
                "cx_sweep: this handle holds a partition (halo configured): use cx_sweep_begin / _main / _end");
+    if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) { int32_t rc = build_chains(h); if (rc != CX_OK) return rc; }
     for (int32_t s = 0; s < n_sweeps; s++) { sweep_main(h, false); sweep_finish(h); }
     CX_HIP(h, hipGetLastError());
     return CX_OK;
@@ -597,6 +674,7 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
 int32_t cx_sweep_begin(cx_handle *h) {
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep_begin: no graph");
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_sweep_begin: previous sweep not ended");
+    CX_REQUIRE(h, h->cfg.schedule != CX_SCHED_CHAIN_SCAN, CX_ERR_UNSUPPORTED, "cx_sweep_begin: the chain-scan schedule is not partitioned in this build");
     const int64_t ns = (int64_t)h->send_slots.size();
     cx::launch_v2f_slots(h, h->d_send_slots, h->d_send_vars, ns, h->d_f2v, CX_KERNEL_HALO_BEGIN);
     cx::launch_gather(h, h->d_v2f, h->d_send_slots, h->d_send_buf, ns);
@@ -662,6 +740,7 @@ int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const
                 return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_halo_configure: an imported edge must belong to a degree-1 ghost variable");
         for (uint8_t &b : h->vinfo) b &= (uint8_t)~cx::kGhost;
         for (int32_t v : recv_vars) h->vinfo[v] |= cx::kGhost;
+        h->chains_dirty = true;
         CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
         for (void *p : {(void *)h->d_send_slots, (void *)h->d_recv_slots, (void *)h->d_send_vars}) if (p) (void)hipFree(p);
         if (!h->ext_halo_buffers) { if (h->d_send_buf) (void)hipFree(h->d_send_buf); if (h->d_recv_buf) (void)hipFree(h->d_recv_buf); }

@@ -1,0 +1,226 @@
+// cx_chain.hip — exact sum-product on chain-structured graphs by two associative scans (CX_SCHED_CHAIN_SCAN).
+//
+// What it replaces: on a state-space chain the reference's `update_marginals!` is strictly sequential — a forward
+// pass and a reverse pass of process! calls, 5T−4 message computations (src/inference_engine.jl:575-608; hand trace
+// in SURVEY.md §3.3).  On the device the same messages come from two parallel prefix scans over per-link maps.
+//
+// With messages in natural form m = (xi, w), adding the side information u_t of variable t (the sum of its
+// non-chain incoming messages: likelihoods, priors) and passing through the factor rule
+//     (xi, w) -> ((a (xi+u_xi) + b (w+u_w)) s, (w+u_w) s),   s = 1 / (a² + q (w+u_w))
+// is a projective-linear map on (xi, w, 1):
+//     [xi_num]   [e f g] [xi]
+//     [w_num ] = [0 A B] [w ]      with  e = a, f = b, g = a u_xi + b u_w, A = 1, B = u_w, C = q, D = a² + q u_w
+//     [den   ]   [0 C D] [1 ]
+// Such matrices are closed under multiplication, so the forward messages α_{t+1} = (F_t ∘ … ∘ F_1)(0, 0) and the
+// backward messages β_t = (G_t ∘ … ∘ G_{T-1})(0, 0) are inclusive scans; every product is rescaled to D = 1, which
+// keeps all entries bounded (A, B, C, D ≥ 0 never cancel).  Applied to (0,0) a prefix yields (g, B).
+// Path boundaries are handled by a segmented scan (head flags).  The arithmetic is re-associated relative to the
+// sequential schedule: results agree to rounding (tests hold 1e-9), not bitwise.
+
+#include "cx_internal.h"
+
+namespace cx {
+
+struct Lin {  // projective-linear map with D normalised to 1; seg = 1 marks "starts a new path" (scan does not cross)
+    double e, f, g, A, B, C;
+    int seg;
+};
+
+__device__ __forceinline__ Lin lin_identity() { return Lin{1.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0}; }
+
+// (second ∘ first), segmented: if `second` starts a segment the result is `second` alone
+__device__ __forceinline__ Lin lin_compose(const Lin &first, const Lin &second) {
+    if (second.seg) return second;
+    Lin r;
+    const double D = second.C * first.B + 1.0;
+    const double inv = 1.0 / D;
+    r.A = (second.A * first.A + second.B * first.C) * inv;
+    r.B = (second.A * first.B + second.B) * inv;
+    r.C = (second.C * first.A + first.C) * inv;
+    r.e = (second.e * first.e) * inv;
+    r.f = (second.e * first.f + second.f * first.A + second.g * first.C) * inv;
+    r.g = (second.e * first.g + second.f * first.B + second.g) * inv;
+    r.seg = first.seg;
+    return r;
+}
+
+__device__ __forceinline__ Lin lin_shfl_up(const Lin &x, int d) {
+    Lin r;
+    r.e = __shfl_up(x.e, d, 64); r.f = __shfl_up(x.f, d, 64); r.g = __shfl_up(x.g, d, 64);
+    r.A = __shfl_up(x.A, d, 64); r.B = __shfl_up(x.B, d, 64); r.C = __shfl_up(x.C, d, 64);
+    r.seg = __shfl_up(x.seg, d, 64);
+    return r;
+}
+
+// the map of one link: add side information u, then the factor rule with the receiving slot's (a, b, q)
+__device__ __forceinline__ Lin lin_of_link(double2 u, double q, double a, double b, int seg) {
+    const double D = a * a + q * u.y;
+    const double inv = 1.0 / D;
+    return Lin{a * inv, b * inv, (a * u.x + b * u.y) * inv, inv, u.y * inv, q * inv, seg};
+}
+
+constexpr int kItems = 4;                    // links per thread
+constexpr int kTile = kBlock * kItems;       // links per workgroup
+
+// side information of chain position i: the sum of the variable's incoming messages except its (≤2) chain slots
+__global__ __launch_bounds__(kBlock) void k_chain_side(int npos, const int32_t *__restrict__ pos_var, const int32_t *__restrict__ pos_skip0,
+                                                       const int32_t *__restrict__ pos_skip1, const int32_t *__restrict__ vbase,
+                                                       const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
+                                                       const double2 *__restrict__ f2v, double2 *__restrict__ side) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npos) return;
+    const int v = pos_var[i], s0 = pos_skip0[i], s1 = pos_skip1[i];
+    const int stride = ((vinfo[v] & kDegMask) == kBigDeg) ? 1 : kBlock;
+    const int b = vbase[v], deg = vdeg[v];
+    double2 acc = make_double2(0.0, 0.0);
+    for (int k = 0; k < deg; k++) {
+        const int slot = b + k * stride;
+        if (slot == s0 || slot == s1) continue;
+        const double2 m = f2v[slot];
+        acc.x += m.x; acc.y += m.y;
+    }
+    side[i] = acc;
+}
+
+// Direction dir = +1: link l maps α at position l to α at position l+1 (uses side[l], parameters of to_slot[l]).
+// Direction dir = -1: links are visited in reverse order; link l maps β at position l+1 to β at position l
+// (uses side[l+1], parameters of from_slot[l]).  `pos_of_link[l]` is the chain position of the link's left end.
+struct ChainArgs {
+    int nlinks;
+    const int32_t *link_pos;     // position of the left variable of link l
+    const int32_t *from_slot;    // slot (left variable, factor)
+    const int32_t *to_slot;      // slot (right variable, factor)
+    const uint8_t *head_fwd;     // link l is the first link of its path
+    const uint8_t *head_bwd;     // link l is the last link of its path
+    const double *q, *a, *b;     // rule parameters per RECEIVING slot (a, b may be null: additive)
+    const double2 *side;
+};
+
+__device__ __forceinline__ Lin load_link(const ChainArgs &A, int idx, int dir) {
+    if (idx >= A.nlinks) return lin_identity();
+    const int l = dir > 0 ? idx : A.nlinks - 1 - idx;
+    const int recv = dir > 0 ? A.to_slot[l] : A.from_slot[l];
+    const double2 u = A.side[A.link_pos[l] + (dir > 0 ? 0 : 1)];
+    const int seg = dir > 0 ? A.head_fwd[l] : A.head_bwd[l];
+    return lin_of_link(u, A.q[recv], A.a ? A.a[recv] : 1.0, A.b ? A.b[recv] : 0.0, seg);
+}
+
+// workgroup-wide inclusive scan of kTile links; returns this thread's kItems inclusive prefixes and the tile total
+__device__ __forceinline__ void tile_scan(Lin (&x)[kItems], Lin &tile_total, Lin *wave_tot /* LDS [kBlock/64] */) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 1; k < kItems; k++) x[k] = lin_compose(x[k - 1], x[k]);
+    Lin t = x[kItems - 1];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        Lin o = lin_shfl_up(t, d);
+        if (lane >= d) t = lin_compose(o, t);
+    }
+    if (lane == 63) wave_tot[wid] = t;
+    __syncthreads();
+    Lin excl = lin_shfl_up(t, 1);            // exclusive prefix within the wave
+    if (lane == 0) excl = lin_identity();
+    Lin carry = lin_identity();
+    for (int w = 0; w < wid; w++) carry = lin_compose(carry, wave_tot[w]);
+    excl = lin_compose(carry, excl);
+#pragma unroll
+    for (int k = 0; k < kItems; k++) x[k] = lin_compose(excl, x[k]);
+    tile_total = wave_tot[0];
+    for (int w = 1; w < kBlock / 64; w++) tile_total = lin_compose(tile_total, wave_tot[w]);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kBlock) void k_chain_tile_totals(ChainArgs A, int dir, Lin *__restrict__ totals) {
+    __shared__ Lin wave_tot[kBlock / 64];
+    Lin x[kItems];
+    const int base = blockIdx.x * kTile + threadIdx.x * kItems;
+#pragma unroll
+    for (int k = 0; k < kItems; k++) x[k] = load_link(A, base + k, dir);
+    Lin tot;
+    tile_scan(x, tot, wave_tot);
+    if (threadIdx.x == 0) totals[blockIdx.x] = tot;
+}
+
+// exclusive scan of the tile totals by one workgroup (sequential over chunks of kTile tiles: ≤ 1M links per chunk)
+__global__ __launch_bounds__(kBlock) void k_chain_scan_totals(int ntiles, Lin *__restrict__ totals) {
+    __shared__ Lin wave_tot[kBlock / 64];
+    __shared__ Lin carry_s;
+    if (threadIdx.x == 0) carry_s = lin_identity();
+    __syncthreads();
+    for (int chunk = 0; chunk < ntiles; chunk += kTile) {
+        Lin x[kItems], incl[kItems];
+        const int base = chunk + threadIdx.x * kItems;
+#pragma unroll
+        for (int k = 0; k < kItems; k++) x[k] = (base + k < ntiles) ? totals[base + k] : lin_identity();
+#pragma unroll
+        for (int k = 0; k < kItems; k++) incl[k] = x[k];
+        Lin tot;
+        tile_scan(incl, tot, wave_tot);
+        const Lin carry = carry_s;
+        // exclusive value of element k = carry ∘ (inclusive prefix of the previous element)
+        Lin prev = lin_identity();
+        {
+            // previous thread's last inclusive value
+            Lin lastv = incl[kItems - 1];
+            Lin up = lin_shfl_up(lastv, 1);
+            __shared__ Lin wave_last[kBlock / 64];
+            if ((threadIdx.x & 63) == 63) wave_last[threadIdx.x >> 6] = lastv;
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) prev = (threadIdx.x == 0) ? lin_identity() : wave_last[(threadIdx.x >> 6) - 1];
+            else prev = up;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < kItems; k++) {
+            const Lin ex = lin_compose(carry, k == 0 ? prev : incl[k - 1]);
+            if (base + k < ntiles) totals[base + k] = ex;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = lin_compose(carry, tot);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_chain_apply(ChainArgs A, int dir, const Lin *__restrict__ tile_excl, double2 *__restrict__ f2v) {
+    __shared__ Lin wave_tot[kBlock / 64];
+    Lin x[kItems];
+    const int base = blockIdx.x * kTile + threadIdx.x * kItems;
+#pragma unroll
+    for (int k = 0; k < kItems; k++) x[k] = load_link(A, base + k, dir);
+    Lin tot;
+    tile_scan(x, tot, wave_tot);
+    const Lin carry = tile_excl[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kItems; k++) {
+        const int idx = base + k;
+        if (idx >= A.nlinks) continue;
+        const Lin p = lin_compose(carry, x[k]);
+        const int l = dir > 0 ? idx : A.nlinks - 1 - idx;
+        const int recv = dir > 0 ? A.to_slot[l] : A.from_slot[l];
+        const double2 m = make_double2(p.g, p.B);   // the prefix applied to the empty message (0, 0)
+        if (!__builtin_isnan(m.y)) f2v[recv] = m;
+    }
+}
+
+void launch_chain_scan(cx_handle *h, double2 *f2v) {
+    const int nlinks = (int)h->chain_nlinks, npos = (int)h->chain_npos;
+    if (nlinks == 0) return;
+    hipLaunchKernelGGL(k_chain_side, dim3((npos + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, npos, h->d_chain_pos_var,
+                       h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, f2v, h->d_chain_side);
+    ChainArgs A{nlinks, h->d_chain_link_pos, h->d_chain_from, h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd,
+                h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_chain_side};
+    const int ntiles = (nlinks + kTile - 1) / kTile;
+    Lin *totals = (Lin *)h->d_chain_totals;
+    for (int dir = 1; dir >= -1; dir -= 2) {
+        hipLaunchKernelGGL(k_chain_tile_totals, dim3(ntiles), dim3(kBlock), 0, h->stream, A, dir, totals);
+        hipLaunchKernelGGL(k_chain_scan_totals, dim3(1), dim3(kBlock), 0, h->stream, ntiles, totals);
+        hipLaunchKernelGGL(k_chain_apply, dim3(ntiles), dim3(kBlock), 0, h->stream, A, dir, totals, f2v);
+    }
+}
+
+size_t chain_total_bytes(int64_t nlinks) {
+    const int64_t ntiles = (nlinks + kTile - 1) / kTile;
+    return (size_t)(ntiles + 1) * sizeof(Lin);
+}
+
+}  // namespace cx

@@ -70,6 +70,15 @@ struct cx_handle {
     double *d_scratch = nullptr;    // small reduction scratch
     int64_t device_bytes = 0;
 
+    // chain-scan schedule (cx_chain.hip): paths of free variables, built lazily by build_chains()
+    bool chains_dirty = true;
+    int64_t chain_npos = 0, chain_nlinks = 0;
+    int32_t *d_chain_pos_var = nullptr, *d_chain_skip0 = nullptr, *d_chain_skip1 = nullptr;
+    int32_t *d_chain_link_pos = nullptr, *d_chain_from = nullptr, *d_chain_to = nullptr;
+    uint8_t *d_chain_head_fwd = nullptr, *d_chain_head_bwd = nullptr;
+    double2 *d_chain_side = nullptr;
+    void *d_chain_totals = nullptr;
+
     // halo
     std::vector<int32_t> send_slots, recv_slots;
     int32_t *d_send_slots = nullptr, *d_recv_slots = nullptr, *d_send_vars = nullptr;
@@ -110,5 +119,7 @@ void launch_scatter(cx_handle *h, double2 *dst, const int32_t *d_idx, const doub
 void launch_gather(cx_handle *h, const double2 *src, const int32_t *d_idx, double2 *d_val, int64_t n);
 void launch_seed(cx_handle *h, double2 *buf, int64_t n, double2 value, const int32_t *partner);
 void launch_residual(cx_handle *h, const double2 *cur, const double2 *prev, int64_t n, double *d_out);
+void launch_chain_scan(cx_handle *h, double2 *f2v);
+size_t chain_total_bytes(int64_t nlinks);
 
 }  // namespace cx

@@ -80,6 +80,9 @@ extern "C" {
 /* schedules of cx_sweep */
 #define CX_SCHED_FLOODING 0   /* all variable→factor, then all factor→variable, then marginals           */
 #define CX_SCHED_FUSED 1      /* same fixed-point map, one fused kernel on double-buffered messages        */
+#define CX_SCHED_CHAIN_SCAN 2 /* graphs whose non-observed variables form disjoint chains (state-space models):
+                                 one cx_sweep = the exact forward/backward result of the reference's sequential
+                                 schedule (inference_engine.jl:575-608), by two parallel prefix scans             */
 
 typedef struct cx_handle cx_handle;
 

@@ -1,0 +1,103 @@
+"""-m gpu: CX_SCHED_CHAIN_SCAN — one cx_sweep on a chain-structured graph equals what the reference's sequential
+forward/backward schedule computes in one update_marginals! call (restated scheduler, oracle/cortex_ref.c) and the
+exact Kalman smoother (oracle/exact.py).  Config C2 of BASELINE.json (T = 250,001, 1,000,002 edges) is checked at
+full size against the tridiagonal solve."""
+import numpy as np
+import pytest
+
+import cortex.jl_amd as cx
+from cortex.jl_amd import _lib as L
+from oracle import exact
+from tests.helpers import assert_close, engine_oracle_from_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(model):
+    dev = cx.DeviceGraph(schedule=L.SCHED_CHAIN_SCAN)
+    cx.synth.load_into_device(model, dev)
+    dev.sweep(1)
+    return dev
+
+
+@pytest.mark.parametrize("T,randvar", [(2, False), (3, True), (5, True), (64, True), (257, True), (1027, True), (4100, True), (70001, True)])
+def test_chain_scan_equals_reference_schedule_and_exact_smoother(hip_lib, T, randvar):
+    model = cx.synth.ssm_chain(T, seed=T, random_variances=randvar)
+    dev = _solve(model)
+    marg = dev.get_marginals(model.x_ids)
+    xm, xv = exact.ssm_chain_posterior(model.data_y, model.meta["r"], model.meta["q"])
+    assert_close(marg[:, 0], xm, 1e-9, "marginal mean vs tridiagonal solve")
+    assert_close(marg[:, 1], xv, 1e-9, "marginal variance vs tridiagonal solve")
+    if T <= 5000:
+        E = engine_oracle_from_model(model)
+        E.update_marginals(model.x_ids)
+        _, em, ev = E.get_marginals(model.x_ids)
+        assert_close(marg[:, 0], em, 1e-9, "marginal mean vs restated reference scheduler")
+        assert_close(marg[:, 1], ev, 1e-9, "marginal variance vs restated reference scheduler")
+        tr = model.factor_ids[T:]
+        for to_variable, vs in ((True, model.x_ids[:-1]), (True, model.x_ids[1:]), (False, model.x_ids[:-1]), (False, model.x_ids[1:])):
+            _, mm, mv = E.get_messages(vs, tr, to_variable=to_variable)
+            got = dev.get_messages(vs, tr, L.TO_VARIABLE if to_variable else L.TO_FACTOR)
+            assert_close(got[:, 0], mm, 1e-9, "chain message mean")
+            assert_close(got[:, 1], mv, 1e-9, "chain message variance")
+    # idempotent: a second sweep leaves the fixed point where it is
+    dev.sweep(1)
+    again = dev.get_marginals(model.x_ids)
+    assert_close(again[:, 0], marg[:, 0], 1e-12, "second sweep mean")
+    assert_close(again[:, 1], marg[:, 1], 1e-12, "second sweep variance")
+
+
+def test_config_c2_full_size(hip_lib):
+    """BASELINE.json configs[1]: 1M-edge scalar-Gaussian chain, one full sum-product sweep on one MI355X."""
+    T = 250_001
+    model = cx.synth.ssm_chain(T, seed=1234)
+    assert model.n_edges == 1_000_002
+    dev = _solve(model)
+    assert dev.stats()["n_edges"] == 1_000_002
+    marg = dev.get_marginals(model.x_ids)
+    xm, xv = exact.ssm_chain_posterior(model.data_y, 1.0, 1.0)
+    assert_close(marg[:, 0], xm, 1e-9, "C2 marginal mean")
+    assert_close(marg[:, 1], xv, 1e-9, "C2 marginal variance")
+    # the reference test's own assertions (test/inference_engine_tests.jl:485-487)
+    assert np.all(marg[:, 0] >= 0) and np.all(np.diff(marg[:, 0]) >= 0) and np.all(marg[:, 1] >= 0)
+
+
+def test_several_disjoint_chains_one_scan(hip_lib):
+    """segmented scan: chains of different lengths in one graph, ids interleaved."""
+    lengths = [1, 2, 3, 300, 1, 1500, 7]
+    ev, ef, fids, fq, dv, df, dy, xs_all, chains = [], [], [], [], [], [], [], [], []
+    nid = 0
+    rng = np.random.default_rng(0)
+    for T in lengths:
+        x = list(range(nid + 1, nid + T + 1)); y = list(range(nid + T + 1, nid + 2 * T + 1))
+        lik = list(range(nid + 2 * T + 1, nid + 3 * T + 1)); tr = list(range(nid + 3 * T + 1, nid + 4 * T))
+        nid += 4 * T - 1
+        r, q, data = rng.uniform(0.5, 2, T), rng.uniform(0.5, 2, T - 1), rng.standard_normal(T) * 3
+        for i in range(T):
+            ev += [y[i], x[i]]; ef += [lik[i], lik[i]]
+        for i in range(T - 1):
+            ev += [x[i], x[i + 1]]; ef += [tr[i], tr[i]]
+        fids += lik + tr; fq += list(r) + list(q); dv += y; df += lik; dy += list(data)
+        xs_all += x; chains.append((x, data, r, q))
+    model = cx.synth.Model(edge_var=np.array(ev), edge_fac=np.array(ef), factor_ids=np.array(fids),
+                           factor_kind=np.full(len(fids), L.FACTOR_GAUSS_ADDITIVE, np.int32), factor_var=np.array(fq),
+                           x_ids=np.array(xs_all), data_var=np.array(dv), data_fac=np.array(df), data_y=np.array(dy))
+    dev = _solve(model)
+    for x, data, r, q in chains:
+        marg = dev.get_marginals(x)
+        if len(x) == 1:   # a lone variable: marginal = its likelihood message
+            assert_close(marg[:, 0], data, 1e-12, "lone variable mean")
+            assert_close(marg[:, 1], r, 1e-12, "lone variable variance")
+            continue
+        xm, xv = exact.ssm_chain_posterior(data, r, q)
+        assert_close(marg[:, 0], xm, 1e-9, f"chain of {len(x)} mean")
+        assert_close(marg[:, 1], xv, 1e-9, f"chain of {len(x)} variance")
+
+
+def test_chain_scan_refuses_loopy_graphs(hip_lib):
+    model = cx.synth.gaussian_grid(4, 4, seed=1)
+    dev = cx.DeviceGraph(schedule=L.SCHED_CHAIN_SCAN)
+    cx.synth.load_into_device(model, dev, seed_variance=10.0)
+    with pytest.raises(cx.CortexHipError) as e:
+        dev.sweep(1)
+    assert e.value.code == L.ERR_UNSUPPORTED and "chain" in e.value.message
