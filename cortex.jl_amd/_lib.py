@@ -54,6 +54,7 @@ SIGNATURES = {
     "cx_sync": (_i32, [_vp]),
     "cx_set_stream": (_i32, [_vp, _vp]),
     "cx_graph_create": (_i32, [_vp, _i64, _pi64, _pi64, _pi32, _i64, _pi64, _pi32, _pd]),
+    "cx_set_factor_matrices": (_i32, [_vp, _i64, _pd, _pd]),
     "cx_graph_stats": (_i32, [_vp, C.POINTER(Stats)]),
     "cx_edge_index": (_i32, [_vp, _i64, _pi64, _pi64, _pi64]),
     "cx_payload_doubles": (_i64, [_i32, _i32]),

@@ -58,9 +58,10 @@ void dev_free_all(cx_handle *h) {
                     h->d_vinfo, h->d_q, h->d_a, h->d_b, h->d_sq, h->d_sa, h->d_sb, h->d_f2v, h->d_v2f, h->d_marg,
                     h->d_f2v_alt, h->d_prev, h->d_scratch, h->d_send_slots, h->d_recv_slots, h->d_send_vars,
                     h->ext_halo_buffers ? nullptr : (void *)h->d_send_buf, h->ext_halo_buffers ? nullptr : (void *)h->d_recv_buf,
-                    h->d_stage, h->d_chain_pos_var, h->d_chain_skip0, h->d_chain_skip1, h->d_chain_link_pos, h->d_chain_from,
+                    h->d_stage, h->d_spdir, h->d_ptab, h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prev, h->d_chain_pos_var, h->d_chain_skip0, h->d_chain_skip1, h->d_chain_link_pos, h->d_chain_from,
                     h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_side, h->d_chain_totals};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    h->d_spdir = nullptr; h->d_ptab = nullptr; h->d_mv_f2v = h->d_mv_f2v_alt = h->d_mv_v2f = h->d_mv_marg = h->d_mv_prev = nullptr; h->ptab_sets = 0;
     h->d_chain_pos_var = h->d_chain_skip0 = h->d_chain_skip1 = h->d_chain_link_pos = h->d_chain_from = h->d_chain_to = nullptr;
     h->d_chain_head_fwd = h->d_chain_head_bwd = nullptr; h->d_chain_side = nullptr; h->d_chain_totals = nullptr; h->chains_dirty = true;
     h->d_slice_off = h->d_partner = h->d_vbase = h->d_var_deg = h->d_big = h->d_big_slots = nullptr;
@@ -156,7 +157,10 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
     *out = nullptr;
     if (!config || config->struct_size != (int32_t)sizeof(cx_config))
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: config is NULL or struct_size mismatch");
-    if (config->dim != 1) return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: this build implements dim == 1 (scalar Gaussian) only");
+    if (config->dim != 1 && config->dim != 2 && config->dim != 3 && config->dim != 4)
+        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: this build implements dim in {1, 2, 3, 4}");
+    if (config->dim > 1 && config->schedule != CX_SCHED_FUSED)
+        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: dim > 1 runs the fused schedule only");
     if (config->schedule != CX_SCHED_FLOODING && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN)
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: unknown schedule");
     int ndev = 0;
@@ -169,6 +173,7 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
     cx_handle *h = new (std::nothrow) cx_handle();
     if (!h) return fail(nullptr, CX_ERR_OUT_OF_MEMORY, "cx_create: host allocation failed");
     h->cfg = *config;
+    h->nc = config->dim == 1 ? 2 : config->dim + config->dim * (config->dim + 1) / 2;
     h->stream = nullptr;  // default stream until cx_set_stream
     *out = h;
     return CX_OK;
@@ -195,6 +200,44 @@ int32_t cx_set_stream(cx_handle *h, void *hip_stream) {
     CX_HIP(h, hipStreamSynchronize(h->stream));
     h->stream = (hipStream_t)hip_stream;
     return CX_OK;
+}
+
+// (re)upload the (P, B, C) rule tables of every registered parameter set (dim > 1)
+static int32_t upload_ptab(cx_handle *h) {
+    const int d = h->cfg.dim;
+    const int64_t nsets = std::max<int64_t>((int64_t)h->psets.size(), h->max_pset + 1);
+    if (nsets == 0) return CX_OK;
+    const size_t per = (size_t)6 * d * d;
+    std::vector<double> tab(per * nsets, std::numeric_limits<double>::quiet_NaN());
+    for (int64_t i = 0; i < (int64_t)h->psets.size(); i++) {
+        if (h->psets[i].empty()) continue;
+        if (!cx::mv_rule_tables(d, h->psets[i].data(), h->psets[i].data() + d * d, &tab[per * i]))
+            return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_set_factor_matrices: Q of parameter set " + std::to_string(i) + " is not positive definite");
+    }
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->d_ptab && h->ptab_sets < nsets) { (void)hipFree(h->d_ptab); h->d_ptab = nullptr; }
+    if (!h->d_ptab) { int32_t rc = dev_alloc(h, &h->d_ptab, (int64_t)(per * nsets)); if (rc != CX_OK) return rc; h->ptab_sets = nsets; }
+    CX_HIP(h, hipMemcpy(h->d_ptab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    return CX_OK;
+}
+
+int32_t cx_set_factor_matrices(cx_handle *h, int64_t parameter_set, const double *A, const double *Q) {
+    CX_REQUIRE(h, h, CX_ERR_INVALID_ARGUMENT, "null handle");
+    CX_REQUIRE(h, h->cfg.dim > 1, CX_ERR_STATE, "cx_set_factor_matrices: dim == 1 factors take scalar parameters");
+    CX_REQUIRE(h, parameter_set >= 0 && parameter_set < (1 << 20) && A && Q, CX_ERR_INVALID_ARGUMENT, "cx_set_factor_matrices: bad argument");
+    try {
+        const int d = h->cfg.dim;
+        if ((int64_t)h->psets.size() <= parameter_set) h->psets.resize(parameter_set + 1);
+        auto &ps = h->psets[parameter_set];
+        ps.assign(A, A + d * d);
+        ps.insert(ps.end(), Q, Q + d * d);
+        std::vector<double> chk((size_t)6 * d * d);
+        if (!cx::mv_rule_tables(d, A, Q, chk.data())) {
+            ps.clear();
+            return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_set_factor_matrices: Q is not symmetric positive definite");
+        }
+        return h->has_graph ? upload_ptab(h) : CX_OK;
+    } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_set_factor_matrices: host allocation failed"); }
 }
 
 int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, const int64_t *edge_fac,
@@ -291,7 +334,19 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
         for (int64_t e = 0; e < ne; e++) fedge[fill[edge_fac[e]]++] = (int32_t)e;
         // ---- per-slot rule parameters and partners (the gather lists of dependencies.jl:17-31) ----------------------
         h->partner.assign(slots, -1);
-        std::vector<double> q(slots, 0.0), a, b, sq, sa, sb;
+        const bool mv = h->cfg.dim > 1;
+        std::vector<int32_t> spdir;
+        if (mv) {
+            spdir.assign(slots, 0);
+            if (!h->big_vars.empty())
+                return fail(h, CX_ERR_UNSUPPORTED, "cx_graph_create: dim > 1 handles variables of degree <= 8 only; variable " +
+                            std::to_string(h->var_ids[h->big_vars[0]]) + " has more");
+            for (int64_t v = 0; v < nv; v++)
+                if (var_deg[v] > 4)
+                    return fail(h, CX_ERR_UNSUPPORTED, "cx_graph_create: dim > 1 handles variables of degree <= 4 in this build; variable " +
+                                std::to_string(h->var_ids[v]) + " has degree " + std::to_string(var_deg[v]));
+        }
+        std::vector<double> q(mv ? 1 : slots, 0.0), a, b, sq, sa, sb;
         h->any_linear = false;
         for (int64_t f = 0; f < n_factors; f++) if (h->fac_kind[f] == CX_FACTOR_GAUSS_LINEAR) h->any_linear = true;
         if (h->any_linear) { a.assign(slots, 1.0); b.assign(slots, 0.0); sq.assign(slots, 0.0); sa.assign(slots, 1.0); sb.assign(slots, 0.0); }
@@ -302,10 +357,24 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
             if (kind != CX_FACTOR_GAUSS_ADDITIVE && kind != CX_FACTOR_GAUSS_LINEAR)
                 return fail(h, CX_ERR_UNSUPPORTED, "cx_graph_create: unknown factor kind");
             if (deg != 2) return fail(h, CX_ERR_UNSUPPORTED, "cx_graph_create: Gaussian factor kinds need exactly 2 edges (factor id " + std::to_string(h->fac_ids[f]) + ")");
-            if (!(p[0] >= 0.0)) return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: factor variance must be >= 0");
             const int32_t e1 = fedge[foff[f]], e2 = fedge[foff[f] + 1];
             const int32_t s1 = cx::slot_of_edge(h, e1), s2 = cx::slot_of_edge(h, e2);
             h->partner[s1] = s2; h->partner[s2] = s1;
+            if (mv) {
+                // dim > 1: x_out = A x_in + N(0, Q), (A, Q) = parameter set params[0] (cx_set_factor_matrices).
+                // spdir[sending slot] = 2 * pset + direction of the RECEIVING edge (0: receiver = out, 1: receiver = in)
+                if (kind != CX_FACTOR_GAUSS_LINEAR) return fail(h, CX_ERR_UNSUPPORTED, "cx_graph_create: dim > 1 supports CX_FACTOR_GAUSS_LINEAR (params[0] = parameter set) and CX_FACTOR_OPAQUE");
+                const int64_t pset = (int64_t)p[0];
+                if (pset < 0 || (double)pset != p[0]) return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: params[0] must be a parameter-set index");
+                const int32_t r1 = edge_role ? edge_role[ord[e1]] : CX_ROLE_OUT, r2 = edge_role ? edge_role[ord[e2]] : CX_ROLE_OUT;
+                if (r1 == r2) return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: GAUSS_LINEAR needs one ROLE_IN and one ROLE_OUT edge");
+                const int32_t sin = r1 == CX_ROLE_IN ? s1 : s2, sout = r1 == CX_ROLE_IN ? s2 : s1;
+                spdir[sin] = (int32_t)(2 * pset);       // sent by x_in, received on the out edge: forward
+                spdir[sout] = (int32_t)(2 * pset + 1);  // sent by x_out, received on the in edge: backward
+                h->max_pset = std::max<int64_t>(h->max_pset, pset);
+                continue;
+            }
+            if (!(p[0] >= 0.0)) return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: factor variance must be >= 0");
             q[s1] = q[s2] = p[0];
             if (kind == CX_FACTOR_GAUSS_LINEAR) {
                 // x_out = a x_in + b + N(0,q): the edge with ROLE_IN carries x_in.  Effective parameters of the
@@ -343,13 +412,26 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
         CX_TRY(dev_upload(h, &h->d_big, h->big_vars));
         CX_TRY(dev_upload(h, &h->d_big_slots, h->big_slots));
         CX_TRY(dev_alloc(h, &h->d_big_tmp, big_total));
+        CX_TRY(dev_alloc(h, &h->d_scratch, 4096));
+        if (mv) {
+            const int64_t nc = h->nc;
+            CX_TRY(dev_upload(h, &h->d_spdir, spdir));
+            CX_TRY(dev_alloc(h, &h->d_mv_f2v, nc * slots)); CX_TRY(dev_alloc(h, &h->d_mv_f2v_alt, nc * slots));
+            CX_TRY(dev_alloc(h, &h->d_mv_v2f, nc * slots)); CX_TRY(dev_alloc(h, &h->d_mv_marg, nc * nv));
+            CX_HIP(h, hipMemsetAsync(h->d_mv_f2v, 0xff, (size_t)(nc * slots) * 8, h->stream));
+            CX_HIP(h, hipMemsetAsync(h->d_mv_f2v_alt, 0xff, (size_t)(nc * slots) * 8, h->stream));
+            CX_HIP(h, hipMemsetAsync(h->d_mv_v2f, 0xff, (size_t)(nc * slots) * 8, h->stream));
+            CX_HIP(h, hipMemsetAsync(h->d_mv_marg, 0xff, (size_t)(nc * nv) * 8, h->stream));
+            CX_HIP(h, hipStreamSynchronize(h->stream));
+            h->has_graph = true;
+            return upload_ptab(h);
+        }
         CX_TRY(dev_upload(h, &h->d_q, q));
         if (h->any_linear) {
             CX_TRY(dev_upload(h, &h->d_a, a)); CX_TRY(dev_upload(h, &h->d_b, b));
             CX_TRY(dev_upload(h, &h->d_sq, sq)); CX_TRY(dev_upload(h, &h->d_sa, sa)); CX_TRY(dev_upload(h, &h->d_sb, sb));
         }
         CX_TRY(dev_alloc(h, &h->d_f2v, slots)); CX_TRY(dev_alloc(h, &h->d_v2f, slots)); CX_TRY(dev_alloc(h, &h->d_marg, nv));
-        CX_TRY(dev_alloc(h, &h->d_scratch, 4096));
         // every message starts as UndefValue(): all-ones bytes are a NaN in both halves of each double2
         CX_HIP(h, hipMemsetAsync(h->d_f2v, 0xff, (size_t)slots * sizeof(double2), h->stream));
         CX_HIP(h, hipMemsetAsync(h->d_v2f, 0xff, (size_t)slots * sizeof(double2), h->stream));
@@ -391,8 +473,9 @@ int32_t cx_edge_index(const cx_handle *hc, int64_t n, const int64_t *variable_id
 }
 
 // (variable_id, factor_id) lists -> slots (+ optionally the local variable numbers)
-static int32_t stage_slots(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, std::vector<int32_t> &slots,
-                           std::vector<int32_t> *vars = nullptr) {
+namespace {
+int32_t stage_slots(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, std::vector<int32_t> &slots,
+                std::vector<int32_t> *vars) {
     slots.resize(n);
     if (vars) vars->resize(n);
     for (int64_t i = 0; i < n; i++) {
@@ -403,6 +486,182 @@ static int32_t stage_slots(cx_handle *h, int64_t n, const int64_t *variable_ids,
     }
     return CX_OK;
 }
+}  // namespace
+
+
+// ==================================================================================================================
+// dim > 1 (cx_mv.hip): host side of the data path.  Payload rows at the ABI: MOMENT mean[d] + covariance[d*d];
+// NATURAL eta[d] + Lambda[d*d]; POINT y[d].  Device: eta[d] + packed upper triangle of Lambda, component-major.
+// ==================================================================================================================
+namespace {
+
+void mv_pack(int d, const double *eta, const double *lam_full, double *out) {
+    for (int i = 0; i < d; i++) out[i] = eta[i];
+    int c = d;
+    for (int i = 0; i < d; i++) for (int j = i; j < d; j++) out[c++] = 0.5 * (lam_full[i * d + j] + lam_full[j * d + i]);
+}
+
+void mv_unpack(int d, const double *in, double *eta, double *lam_full) {
+    for (int i = 0; i < d; i++) eta[i] = in[i];
+    int c = d;
+    for (int i = 0; i < d; i++) for (int j = i; j < d; j++) { lam_full[i * d + j] = in[c]; lam_full[j * d + i] = in[c]; c++; }
+}
+
+bool mv_to_natural(int d, int32_t form, const double *p, double *out /* nc */) {
+    const int nc = d + d * (d + 1) / 2;
+    if (form == CX_FORM_POINT) {
+        for (int i = 0; i < nc; i++) out[i] = 0.0;
+        for (int i = 0; i < d; i++) out[i] = p[i];
+        out[d] = kInf;
+        return true;
+    }
+    if (form == CX_FORM_NATURAL) { mv_pack(d, p, p + d, out); return true; }
+    bool undef = false;
+    for (int i = 0; i < d * d; i++) undef = undef || std::isnan(p[d + i]);
+    if (undef) { for (int i = 0; i < nc; i++) out[i] = kNaN; return true; }
+    std::vector<double> lam((size_t)d * d), eta(d);
+    if (!cx::spd_inverse(d, p + d, lam.data())) return false;
+    for (int i = 0; i < d; i++) { double s = 0; for (int j = 0; j < d; j++) s += lam[i * d + j] * p[j]; eta[i] = s; }
+    mv_pack(d, eta.data(), lam.data(), out);
+    return true;
+}
+
+void mv_from_natural(int d, int32_t form, const double *in /* nc */, double *out /* d + d*d */) {
+    std::vector<double> lam((size_t)d * d), eta(d);
+    mv_unpack(d, in, eta.data(), lam.data());
+    if (form == CX_FORM_NATURAL) { for (int i = 0; i < d; i++) out[i] = eta[i]; for (int i = 0; i < d * d; i++) out[d + i] = lam[i]; return; }
+    if (std::isnan(in[d])) { for (int i = 0; i < d + d * d; i++) out[i] = kNaN; return; }
+    if (in[d] == kInf) { for (int i = 0; i < d; i++) out[i] = eta[i]; for (int i = 0; i < d * d; i++) out[d + i] = 0.0; return; }
+    std::vector<double> cov((size_t)d * d);
+    if (!cx::spd_inverse(d, lam.data(), cov.data())) { for (int i = 0; i < d + d * d; i++) out[i] = kNaN; return; }
+    for (int i = 0; i < d; i++) { double s = 0; for (int j = 0; j < d; j++) s += cov[i * d + j] * eta[j]; out[i] = s; }
+    for (int i = 0; i < d * d; i++) out[d + i] = cov[i];
+}
+
+// variable→factor messages are never stored by the dim > 1 sweep: recompute the requested ones from the input buffer
+// the last sweep read (retained in d_mv_f2v_alt after the swap)
+int32_t mv_refresh_v2f(cx_handle *h, const std::vector<int32_t> &slots, const std::vector<int32_t> &vars) {
+    const int64_t n = (int64_t)slots.size();
+    int32_t rc = ensure_stage(h, n * 8);
+    if (rc != CX_OK) return rc;
+    int32_t *d_s = (int32_t *)h->d_stage, *d_v = d_s + n;
+    CX_HIP(h, hipMemcpyAsync(d_s, slots.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+    CX_HIP(h, hipMemcpyAsync(d_v, vars.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+    cx::mv_launch_v2f(h, d_s, d_v, n, h->sweeps_done > 0 ? h->d_mv_f2v_alt : h->d_mv_f2v);
+    CX_HIP(h, hipGetLastError());
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    return CX_OK;
+}
+
+int32_t mv_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, int32_t direction,
+                        int32_t form, const double *payload) {
+    const int d = h->cfg.dim, nc = h->nc;
+    std::vector<int32_t> idx, vars;
+    int32_t rc = stage_slots(h, n, variable_ids, factor_ids, idx, &vars);
+    if (rc != CX_OK) return rc;
+    const int64_t stride = form == CX_FORM_POINT ? d : d + d * d;
+    std::vector<double> val((size_t)n * nc);
+    for (int64_t i = 0; i < n; i++)
+        if (!mv_to_natural(d, form, payload + i * stride, &val[(size_t)i * nc]))
+            return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_set_messages: covariance of row " + std::to_string(i) + " is not positive definite");
+    const int64_t bytes_idx = ((n * 4 + 15) / 16) * 16;
+    rc = ensure_stage(h, bytes_idx + n * nc * 8);
+    if (rc != CX_OK) return rc;
+    int32_t *d_idx = (int32_t *)h->d_stage;
+    double *d_val = (double *)((char *)h->d_stage + bytes_idx);
+    CX_HIP(h, hipMemcpyAsync(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+    CX_HIP(h, hipMemcpyAsync(d_val, val.data(), (size_t)n * nc * 8, hipMemcpyHostToDevice, h->stream));
+    if (direction == CX_TO_FACTOR) {
+        cx::mv_launch_scatter(h, h->d_mv_v2f, h->nslots, nc, d_idx, d_val, n);
+        if (form == CX_FORM_POINT) {
+            for (int64_t i = 0; i < n; i++) h->vinfo[vars[i]] |= cx::kClamped;
+            CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
+        }
+    } else {
+        cx::mv_launch_scatter(h, h->d_mv_f2v, h->nslots, nc, d_idx, d_val, n);
+        cx::mv_launch_scatter(h, h->d_mv_f2v_alt, h->nslots, nc, d_idx, d_val, n);
+    }
+    CX_HIP(h, hipGetLastError());
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    return CX_OK;
+}
+
+int32_t mv_get(cx_handle *h, const double *src, int64_t stride, const std::vector<int32_t> &idx, int32_t form, bool already_moment,
+               double *out) {
+    const int d = h->cfg.dim, nc = h->nc;
+    const int64_t n = (int64_t)idx.size();
+    const int64_t bytes_idx = ((n * 4 + 15) / 16) * 16;
+    int32_t rc = ensure_stage(h, bytes_idx + n * nc * 8);
+    if (rc != CX_OK) return rc;
+    int32_t *d_idx = (int32_t *)h->d_stage;
+    double *d_val = (double *)((char *)h->d_stage + bytes_idx);
+    CX_HIP(h, hipMemcpyAsync(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+    cx::mv_launch_gather(h, src, stride, nc, d_idx, d_val, n);
+    std::vector<double> val((size_t)n * nc);
+    CX_HIP(h, hipMemcpyAsync(val.data(), d_val, (size_t)n * nc * 8, hipMemcpyDeviceToHost, h->stream));
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    for (int64_t i = 0; i < n; i++) {
+        double *o = out + i * (d + d * d);
+        if (already_moment) mv_unpack(d, &val[(size_t)i * nc], o, o + d);
+        else mv_from_natural(d, form, &val[(size_t)i * nc], o);
+    }
+    return CX_OK;
+}
+
+int32_t mv_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, int32_t direction,
+                        int32_t form, double *out) {
+    std::vector<int32_t> idx, vars;
+    int32_t rc = stage_slots(h, n, variable_ids, factor_ids, idx, &vars);
+    if (rc != CX_OK) return rc;
+    if (direction == CX_TO_FACTOR) { rc = mv_refresh_v2f(h, idx, vars); if (rc != CX_OK) return rc; }
+    return mv_get(h, direction == CX_TO_FACTOR ? h->d_mv_v2f : h->d_mv_f2v, h->nslots, idx, form, false, out);
+}
+
+int32_t mv_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, double *out) {
+    std::vector<int32_t> idx(n);
+    for (int64_t i = 0; i < n; i++) {
+        int64_t v = find_var(h, variable_ids[i]);
+        if (v < 0) return fail(h, CX_ERR_NOT_FOUND, "unknown variable id " + std::to_string(variable_ids[i]));
+        idx[i] = (int32_t)v;
+    }
+    return mv_get(h, h->d_mv_marg, h->nv, idx, CX_FORM_MOMENT, true, out);
+}
+
+int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
+    CX_REQUIRE(h, (int64_t)h->psets.size() > h->max_pset, CX_ERR_STATE, "cx_sweep: a factor names a parameter set that was never set (cx_set_factor_matrices)");
+    for (int64_t i = 0; i <= h->max_pset; i++)
+        CX_REQUIRE(h, !h->psets[i].empty(), CX_ERR_STATE, "cx_sweep: parameter set " + std::to_string(i) + " was never set (cx_set_factor_matrices)");
+    for (int32_t s = 0; s < n_sweeps; s++) {
+        cx::mv_launch_sweep(h, h->cfg.compute_marginals_in_sweep != 0);
+        std::swap(h->d_mv_f2v, h->d_mv_f2v_alt);
+        h->sweeps_done++;
+    }
+    CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
+int32_t mv_residual(cx_handle *h, double *out) {
+    const int64_t n = h->nc * h->nslots;
+    if (!h->d_mv_prev) {
+        int32_t rc = dev_alloc(h, &h->d_mv_prev, n);
+        if (rc != CX_OK) return rc;
+        CX_HIP(h, hipMemcpyAsync(h->d_mv_prev, h->d_mv_f2v, (size_t)n * 8, hipMemcpyDeviceToDevice, h->stream));
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        *out = kInf;
+        return CX_OK;
+    }
+    cx::mv_launch_residual(h, h->d_mv_f2v, h->d_mv_prev, n, h->d_scratch);
+    std::vector<double> part(1024);
+    CX_HIP(h, hipMemcpyAsync(part.data(), h->d_scratch, 1024 * 8, hipMemcpyDeviceToHost, h->stream));
+    CX_HIP(h, hipMemcpyAsync(h->d_mv_prev, h->d_mv_f2v, (size_t)n * 8, hipMemcpyDeviceToDevice, h->stream));
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    double m = 0.0;
+    for (double p : part) m = std::max(m, p);
+    *out = m;
+    return CX_OK;
+}
+
+}  // namespace
 
 // In the fused schedule without materialisation the variable→factor messages of the last sweep exist only as
 // "leave-one-out of the sweep's input buffer", which is retained in d_f2v_alt: recompute them on demand.
@@ -424,6 +683,7 @@ int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
     CX_REQUIRE(h, !(form == CX_FORM_POINT && direction == CX_TO_VARIABLE), CX_ERR_UNSUPPORTED, "cx_set_messages: point-mass data is a variable→factor message");
     if (n == 0) return CX_OK;
     CX_REQUIRE(h, n > 0 && variable_ids && factor_ids && payload, CX_ERR_INVALID_ARGUMENT, "cx_set_messages: null argument");
+    if (h->cfg.dim > 1) { try { return mv_set_messages(h, n, variable_ids, factor_ids, direction, form, payload); } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_set_messages: host allocation failed"); } }
     try {
         std::vector<int32_t> idx, vars;
         int32_t rc = stage_slots(h, n, variable_ids, factor_ids, idx, &vars);
@@ -465,9 +725,10 @@ int32_t cx_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
     CX_REQUIRE(h, form == CX_FORM_MOMENT || form == CX_FORM_NATURAL, CX_ERR_INVALID_ARGUMENT, "cx_get_messages: bad form");
     if (n == 0) return CX_OK;
     CX_REQUIRE(h, n > 0 && variable_ids && factor_ids && out, CX_ERR_INVALID_ARGUMENT, "cx_get_messages: null argument");
+    if (h->cfg.dim > 1) { try { return mv_get_messages(h, n, variable_ids, factor_ids, direction, form, out); } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_get_messages: host allocation failed"); } }
     try {
         std::vector<int32_t> idx;
-        int32_t rc = stage_slots(h, n, variable_ids, factor_ids, idx);
+        int32_t rc = stage_slots(h, n, variable_ids, factor_ids, idx, nullptr);
         if (rc != CX_OK) return rc;
         if (direction == CX_TO_FACTOR) { rc = ensure_v2f(h); if (rc != CX_OK) return rc; }
         const int64_t bytes_idx = ((n * 4 + 15) / 16) * 16, bytes = bytes_idx + n * 16;
@@ -489,6 +750,13 @@ int32_t cx_seed_messages(cx_handle *h, int32_t direction, double mean, double va
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_seed_messages: no graph");
     CX_REQUIRE(h, direction == CX_TO_FACTOR || direction == CX_TO_VARIABLE, CX_ERR_INVALID_ARGUMENT, "cx_seed_messages: bad direction");
     CX_REQUIRE(h, variance > 0.0, CX_ERR_INVALID_ARGUMENT, "cx_seed_messages: variance must be > 0");
+    if (h->cfg.dim > 1) {
+        CX_REQUIRE(h, direction == CX_TO_VARIABLE, CX_ERR_UNSUPPORTED, "cx_seed_messages: dim > 1 seeds factor→variable messages only");
+        cx::mv_launch_seed(h, h->d_mv_f2v, mean / variance, 1.0 / variance);
+        cx::mv_launch_seed(h, h->d_mv_f2v_alt, mean / variance, 1.0 / variance);
+        CX_HIP(h, hipGetLastError());
+        return CX_OK;
+    }
     double2 v = make_double2(mean / variance, 1.0 / variance);
     if (direction == CX_TO_VARIABLE) {
         cx::launch_seed(h, h->d_f2v, h->nslots, v, h->d_partner);
@@ -506,6 +774,7 @@ int32_t cx_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, d
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_get_marginals: no graph");
     if (n == 0) return CX_OK;
     CX_REQUIRE(h, n > 0 && variable_ids && out, CX_ERR_INVALID_ARGUMENT, "cx_get_marginals: null argument");
+    if (h->cfg.dim > 1) { try { return mv_get_marginals(h, n, variable_ids, out); } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_get_marginals: host allocation failed"); } }
     try {
         std::vector<int32_t> idx(n);
         for (int64_t i = 0; i < n; i++) {
@@ -530,6 +799,7 @@ int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_update_batch: no graph");
     if (n == 0) return CX_OK;
     CX_REQUIRE(h, n > 0 && items, CX_ERR_INVALID_ARGUMENT, "cx_update_batch: null argument");
+    CX_REQUIRE(h, h->cfg.dim == 1, CX_ERR_UNSUPPORTED, "cx_update_batch: batched mode is implemented for dim == 1 only in this build");
     try {
         std::vector<int32_t> buf(3 * n);
         for (int64_t i = 0; i < n; i++) {
@@ -663,6 +933,7 @@ static void sweep_finish(cx_handle *h) {
 int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep: no graph");
     CX_REQUIRE(h, n_sweeps >= 0, CX_ERR_INVALID_ARGUMENT, "cx_sweep: n_sweeps < 0");
+    if (h->cfg.dim > 1) return mv_sweep(h, n_sweeps);
     CX_REQUIRE(h, h->recv_slots.empty() && h->send_slots.empty(), CX_ERR_STATE,
                "cx_sweep: this handle holds a partition (halo configured): use cx_sweep_begin / _main / _end");
     if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) { int32_t rc = build_chains(h); if (rc != CX_OK) return rc; }
@@ -673,6 +944,7 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
 
 int32_t cx_sweep_begin(cx_handle *h) {
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep_begin: no graph");
+    CX_REQUIRE(h, h->cfg.dim == 1, CX_ERR_UNSUPPORTED, "cx_sweep_begin: partitioned sweeps are implemented for dim == 1 only in this build");
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_sweep_begin: previous sweep not ended");
     CX_REQUIRE(h, h->cfg.schedule != CX_SCHED_CHAIN_SCAN, CX_ERR_UNSUPPORTED, "cx_sweep_begin: the chain-scan schedule is not partitioned in this build");
     const int64_t ns = (int64_t)h->send_slots.size();
@@ -704,6 +976,7 @@ int32_t cx_sweep_end(cx_handle *h) {
 
 int32_t cx_residual(cx_handle *h, double *out) {
     CX_REQUIRE(h, h && h->has_graph && out, CX_ERR_STATE, "cx_residual: no graph / null out");
+    if (h->cfg.dim > 1) return mv_residual(h, out);
     if (!h->d_prev) {
         int32_t rc = dev_alloc(h, &h->d_prev, h->nslots);
         if (rc != CX_OK) return rc;
@@ -727,6 +1000,7 @@ int32_t cx_residual(cx_handle *h, double *out) {
 int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const int64_t *sf, int64_t n_recv,
                           const int64_t *rv, const int64_t *rf) {
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_configure: no graph");
+    CX_REQUIRE(h, h->cfg.dim == 1, CX_ERR_UNSUPPORTED, "cx_halo_configure: partitioned sweeps are implemented for dim == 1 only in this build");
     CX_REQUIRE(h, n_send >= 0 && n_recv >= 0, CX_ERR_INVALID_ARGUMENT, "cx_halo_configure: negative count");
     CX_REQUIRE(h, (n_send == 0 || (sv && sf)) && (n_recv == 0 || (rv && rf)), CX_ERR_INVALID_ARGUMENT, "cx_halo_configure: null argument");
     try {

@@ -70,6 +70,14 @@ struct cx_handle {
     double *d_scratch = nullptr;    // small reduction scratch
     int64_t device_bytes = 0;
 
+    // multivariate path (cx_mv.hip), dim in {2,3,4}: SoA component-major buffers [nc][nslots], packed symmetric Lambda
+    int nc = 2;                                    // stored doubles per message
+    std::vector<std::vector<double>> psets;        // per parameter set: A (d*d) then Q (d*d)
+    int32_t *d_spdir = nullptr;                    // per SENDING slot: 2*pset + direction of the receiving edge
+    double *d_ptab = nullptr;                      // [2*npsets][3][d*d]: (P, B, C) triples
+    int64_t ptab_sets = 0, max_pset = -1;
+    double *d_mv_f2v = nullptr, *d_mv_f2v_alt = nullptr, *d_mv_v2f = nullptr, *d_mv_marg = nullptr, *d_mv_prev = nullptr;
+
     // chain-scan schedule (cx_chain.hip): paths of free variables, built lazily by build_chains()
     bool chains_dirty = true;
     int64_t chain_npos = 0, chain_nlinks = 0;
@@ -120,6 +128,15 @@ void launch_gather(cx_handle *h, const double2 *src, const int32_t *d_idx, doubl
 void launch_seed(cx_handle *h, double2 *buf, int64_t n, double2 value, const int32_t *partner);
 void launch_residual(cx_handle *h, const double2 *cur, const double2 *prev, int64_t n, double *d_out);
 void launch_chain_scan(cx_handle *h, double2 *f2v);
+// multivariate (cx_mv.hip)
+void mv_launch_sweep(cx_handle *h, bool write_marg);
+void mv_launch_v2f(cx_handle *h, const int32_t *d_slots, const int32_t *d_vars, int64_t n, const double *f2v);
+void mv_launch_scatter(cx_handle *h, double *dst, int64_t stride, int nc, const int32_t *d_idx, const double *d_val, int64_t n);
+void mv_launch_gather(cx_handle *h, const double *src, int64_t stride, int nc, const int32_t *d_idx, double *d_val, int64_t n);
+void mv_launch_seed(cx_handle *h, double *buf, double eta, double lam);
+void mv_launch_residual(cx_handle *h, const double *cur, const double *prev, int64_t n, double *d_out);
+bool spd_inverse(int d, const double *S, double *out);
+bool mv_rule_tables(int d, const double *A, const double *Q, double *out);
 size_t chain_total_bytes(int64_t nlinks);
 
 }  // namespace cx

@@ -1,0 +1,421 @@
+// cx_mv.hip — multivariate (d-dimensional) linear-Gaussian messages, small d (2, 4): "batched d×d updates in
+// registers, no MFMA" (BASELINE.json config 3: d = 4 state-space chain).
+//
+// The reference has no d-dimensional rule anywhere (closest: the 2×2 MvNormalMeanPrecision joint of
+// test/inference_engine_tests.jl:949-979); the rules below are the d-dimensional form of its scalar test rules
+// (test/inference_engine_tests.jl:385-432): products of Gaussians and a linear-Gaussian factor
+// x_out = A x_in + N(0, Q).  Parity for dim > 1 is therefore against exact block-tridiagonal solves and the numpy
+// restatement kept with the tests ("parity unpinned" by the reference itself — DESIGN.md §3).
+//
+// Storage: natural form (eta = Lambda mu, Lambda = Sigma^-1), symmetric Lambda packed (upper triangle), component-major
+// SoA over the same SELL-256 slots as the scalar path: component c of slot s at buf[c * nslots + s], so lane <-> variable
+// loads are unit-stride per component.  d = 4: 14 doubles = 112 B per message (the dense 4 + 16 layout would be 160 B).
+//
+// Factor rule with the receiving edge's precomputed triple (P, B, C) — host side, from (A, Q), Qi = Q^-1:
+//   receiver = out (forward):  P = A' Qi A,  B = Qi A,   C = Qi
+//   receiver = in  (backward): P = Qi,       B = A' Qi,  C = A' Qi A
+//   M = Lambda_in + P = L L';   Y = L^-1 B';   Lambda_out = C - Y' Y;   eta_out = Y' (L^-1 eta_in)
+//   point-mass input y (observed variable):  Lambda_out = C,  eta_out = B y.
+// One Cholesky + two triangular solves per message, all in registers, every loop unrolled on the template D.
+
+#include <cmath>
+#include <limits>
+#include <vector>
+
+#include "cx_internal.h"
+
+namespace cx {
+
+template <int D>
+struct Msg {
+    static constexpr int NT = D * (D + 1) / 2;
+    static constexpr int NC = D + NT;
+    double eta[D];
+    double lam[NT];
+};
+
+template <int D>
+__host__ __device__ constexpr int tri(int i, int j) {  // i <= j
+    return i * D - i * (i - 1) / 2 + (j - i);
+}
+
+template <int D>
+__device__ __forceinline__ Msg<D> msg_zero() {
+    Msg<D> m;
+#pragma unroll
+    for (int i = 0; i < D; i++) m.eta[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < Msg<D>::NT; i++) m.lam[i] = 0.0;
+    return m;
+}
+
+template <int D>
+__device__ __forceinline__ Msg<D> msg_load(const double *__restrict__ buf, int64_t nslots, int slot) {
+    Msg<D> m;
+#pragma unroll
+    for (int i = 0; i < D; i++) m.eta[i] = buf[(int64_t)i * nslots + slot];
+#pragma unroll
+    for (int i = 0; i < Msg<D>::NT; i++) m.lam[i] = buf[(int64_t)(D + i) * nslots + slot];
+    return m;
+}
+
+template <int D>
+__device__ __forceinline__ void msg_store(double *__restrict__ buf, int64_t nslots, int slot, const Msg<D> &m) {
+#pragma unroll
+    for (int i = 0; i < D; i++) buf[(int64_t)i * nslots + slot] = m.eta[i];
+#pragma unroll
+    for (int i = 0; i < Msg<D>::NT; i++) buf[(int64_t)(D + i) * nslots + slot] = m.lam[i];
+}
+
+template <int D>
+__device__ __forceinline__ void msg_add(Msg<D> &a, const Msg<D> &b) {
+#pragma unroll
+    for (int i = 0; i < D; i++) a.eta[i] += b.eta[i];
+#pragma unroll
+    for (int i = 0; i < Msg<D>::NT; i++) a.lam[i] += b.lam[i];
+}
+
+// lower Cholesky factor of the packed symmetric matrix S (+ optional full symmetric P): L[i][j], j <= i
+template <int D>
+__device__ __forceinline__ void chol(const double (&S)[Msg<D>::NT], const double *__restrict__ P, double (&Lm)[D][D]) {
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        double d = S[tri<D>(j, j)] + (P ? P[j * D + j] : 0.0);
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= Lm[j][k] * Lm[j][k];
+        const double ljj = sqrt(d);          // non-PD input -> NaN, which marks the message undefined
+        Lm[j][j] = ljj;
+        const double inv = 1.0 / ljj;
+#pragma unroll
+        for (int i = j + 1; i < D; i++) {
+            double s = S[tri<D>(j, i)] + (P ? P[i * D + j] : 0.0);
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= Lm[i][k] * Lm[j][k];
+            Lm[i][j] = s * inv;
+        }
+    }
+}
+
+// x <- L^-1 x
+template <int D>
+__device__ __forceinline__ void fwd_solve(const double (&Lm)[D][D], double (&x)[D]) {
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        double s = x[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= Lm[i][k] * x[k];
+        x[i] = s / Lm[i][i];
+    }
+}
+
+// tab: P (D*D) | B (D*D) | C (D*D), row-major, full
+template <int D>
+__device__ __forceinline__ Msg<D> mv_rule(const Msg<D> &in, const double *__restrict__ tab) {
+    const double *P = tab, *B = tab + D * D, *C = tab + 2 * D * D;
+    Msg<D> out;
+    if (in.lam[0] == __builtin_inf()) {  // observed datum y in eta
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; k++) s += B[i * D + k] * in.eta[k];
+            out.eta[i] = s;
+#pragma unroll
+            for (int j = i; j < D; j++) out.lam[tri<D>(i, j)] = C[i * D + j];
+        }
+        return out;
+    }
+    double Lm[D][D];
+    chol<D>(in.lam, P, Lm);
+    double Y[D][D];  // Y[:, c] = L^-1 (row c of B)'
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+        double col[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) col[k] = B[c * D + k];
+        fwd_solve<D>(Lm, col);
+#pragma unroll
+        for (int k = 0; k < D; k++) Y[k][c] = col[k];
+    }
+    double z[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) z[k] = in.eta[k];
+    fwd_solve<D>(Lm, z);
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; k++) s += Y[k][i] * z[k];
+        out.eta[i] = s;
+#pragma unroll
+        for (int j = i; j < D; j++) {
+            double t = C[i * D + j];
+#pragma unroll
+            for (int k = 0; k < D; k++) t -= Y[k][i] * Y[k][j];
+            out.lam[tri<D>(i, j)] = t;
+        }
+    }
+    return out;
+}
+
+// natural -> moment (mean, packed covariance) for marginals
+template <int D>
+__device__ __forceinline__ Msg<D> mv_to_moment(const Msg<D> &nat) {
+    double Lm[D][D];
+    chol<D>(nat.lam, nullptr, Lm);
+    double Li[D][D];  // columns of L^-1
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+        double e[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) e[k] = (k == c) ? 1.0 : 0.0;
+        fwd_solve<D>(Lm, e);
+#pragma unroll
+        for (int k = 0; k < D; k++) Li[k][c] = e[k];
+    }
+    Msg<D> out;
+#pragma unroll
+    for (int i = 0; i < D; i++)
+#pragma unroll
+        for (int j = i; j < D; j++) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; k++) s += Li[k][i] * Li[k][j];
+            out.lam[tri<D>(i, j)] = s;
+        }
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; j++) s += out.lam[i <= j ? tri<D>(i, j) : tri<D>(j, i)] * nat.eta[j];
+        out.eta[i] = s;
+    }
+    return out;
+}
+
+constexpr int kMvDeg = 4;  // variables of higher degree are refused at graph creation for dim > 1 (this round)
+
+// The fused sweep for small d: thread = variable.  For each outgoing edge the "product of the others" is re-summed
+// from the (L2-resident) input buffer in ascending neighbour order — the reference's left fold order — which keeps
+// the register count flat (one accumulator instead of deg messages).
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_sweep_mv(int nv, int64_t nslots, const int32_t *__restrict__ slice_off,
+                                                     const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
+                                                     const int32_t *__restrict__ spdir, const double *__restrict__ ptab,
+                                                     const double *__restrict__ f2v_in, double *__restrict__ f2v_out,
+                                                     const double *__restrict__ v2f, double *__restrict__ marg, int write_marg) {
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int v = (s << kSliceShift) + tid;
+    if (v >= nv) return;
+    const int info = vinfo[v], deg = info & kDegMask;
+    const int base = slice_off[s] + tid;
+    if (write_marg) {
+        Msg<D> total = msg_zero<D>();
+#pragma unroll
+        for (int k = 0; k < kMvDeg; k++)
+            if (k < deg) msg_add<D>(total, msg_load<D>(f2v_in, nslots, base + k * kBlock));
+        const Msg<D> mo = (deg > 0) ? mv_to_moment<D>(total) : total;
+#pragma unroll
+        for (int i = 0; i < D; i++) marg[(int64_t)i * nv + v] = (deg > 0) ? mo.eta[i] : __builtin_nan("");
+#pragma unroll
+        for (int i = 0; i < Msg<D>::NT; i++) marg[(int64_t)(D + i) * nv + v] = (deg > 0) ? mo.lam[i] : __builtin_nan("");
+    }
+    const bool fixed = (deg < 2) || (info & (kClamped | kGhost));
+#pragma unroll
+    for (int k = 0; k < kMvDeg; k++) {
+        if (k >= deg) continue;
+        const int slot = base + k * kBlock;
+        const int p = partner[slot];
+        if (p < 0) continue;  // nobody listens to this variable→factor message
+        Msg<D> o;
+        if (fixed) {
+            o = msg_load<D>(v2f, nslots, slot);
+        } else {
+            o = msg_zero<D>();
+#pragma unroll
+            for (int j = 0; j < kMvDeg; j++)
+                if (j < deg && j != k) msg_add<D>(o, msg_load<D>(f2v_in, nslots, base + j * kBlock));
+        }
+        if (__builtin_isnan(o.lam[0])) continue;
+        const Msg<D> r = mv_rule<D>(o, ptab + (int64_t)spdir[slot] * 3 * D * D);
+        if (!__builtin_isnan(r.lam[0])) msg_store<D>(f2v_out, nslots, p, r);
+    }
+}
+
+// variable→factor messages of a list of slots, on demand (cx_get_messages): leave-one-out of the retained input buffer
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_v2f_mv(int64_t n, int64_t nslots, const int32_t *__restrict__ slots,
+                                                   const int32_t *__restrict__ vars, const int32_t *__restrict__ vbase,
+                                                   const uint8_t *__restrict__ vinfo, const double *__restrict__ f2v,
+                                                   double *__restrict__ v2f) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int slot = slots[i], v = vars[i];
+    const int info = vinfo[v], deg = info & kDegMask;
+    if (deg < 2 || (info & (kClamped | kGhost))) return;
+    const int b = vbase[v];
+    Msg<D> o = msg_zero<D>();
+    for (int j = 0; j < deg; j++)
+        if (b + j * kBlock != slot) msg_add<D>(o, msg_load<D>(f2v, nslots, b + j * kBlock));
+    if (!__builtin_isnan(o.lam[0])) msg_store<D>(v2f, nslots, slot, o);
+}
+
+__global__ void k_mv_scatter(double *__restrict__ dst, int64_t nslots, int nc, const int32_t *__restrict__ idx,
+                             const double *__restrict__ val, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int c = 0; c < nc; c++) dst[(int64_t)c * nslots + idx[i]] = val[i * nc + c];
+}
+
+__global__ void k_mv_gather(const double *__restrict__ src, int64_t nslots, int nc, const int32_t *__restrict__ idx,
+                            double *__restrict__ val, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int c = 0; c < nc; c++) val[i * nc + c] = src[(int64_t)c * nslots + idx[i]];
+}
+
+__global__ void k_mv_seed(double *__restrict__ buf, int64_t nslots, int dim, int nc, double eta, double lam,
+                          const int32_t *__restrict__ partner) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslots || partner[s] < 0) return;
+    if (!__builtin_isnan(buf[(int64_t)dim * nslots + s])) return;
+    for (int i = 0; i < dim; i++) buf[(int64_t)i * nslots + s] = eta;
+    int c = dim;
+    for (int i = 0; i < dim; i++)
+        for (int j = i; j < dim; j++) buf[(int64_t)(c++) * nslots + s] = (i == j) ? lam : 0.0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_mv_residual(const double *__restrict__ cur, const double *__restrict__ prev, int64_t n,
+                                                        double *__restrict__ out) {
+    __shared__ double red[kBlock / 64];
+    double m = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double a = cur[i], b = prev[i];
+        const bool da = !__builtin_isnan(a), db = !__builtin_isnan(b);
+        if (da != db) m = __builtin_inf();
+        else if (da) m = fmax(m, fabs(a - b));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmax(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kBlock / 64; k++) m = fmax(m, red[k]);
+        out[blockIdx.x] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static void prof_b(cx_handle *h, int kernel) {
+    h->prof_armed = false;
+    if (!h->profiling) return;
+    if ((h->prof_count[kernel]++ % h->prof_stride) != 0) return;
+    h->prof_armed = true;
+    ProfileRec r;
+    r.kernel = kernel;
+    (void)hipEventCreate(&r.start);
+    (void)hipEventCreate(&r.stop);
+    (void)hipEventRecord(r.start, h->stream);
+    h->recs.push_back(r);
+}
+static void prof_e(cx_handle *h) {
+    if (h->profiling && h->prof_armed) (void)hipEventRecord(h->recs.back().stop, h->stream);
+}
+
+void mv_launch_sweep(cx_handle *h, bool write_marg) {
+    if (h->nslices == 0) return;
+    prof_b(h, CX_KERNEL_FUSED);
+    const dim3 g((unsigned)h->nslices), b(kBlock);
+#define CX_MV(DD)                                                                                                          \
+    hipLaunchKernelGGL((k_sweep_mv<DD>), g, b, 0, h->stream, (int)h->nv, h->nslots, h->d_slice_off, h->d_vinfo, h->d_partner, \
+                       h->d_spdir, h->d_ptab, h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg, write_marg ? 1 : 0)
+    if (h->cfg.dim == 2) CX_MV(2);
+    else if (h->cfg.dim == 3) CX_MV(3);
+    else CX_MV(4);
+#undef CX_MV
+    prof_e(h);
+}
+
+void mv_launch_v2f(cx_handle *h, const int32_t *d_slots, const int32_t *d_vars, int64_t n, const double *f2v) {
+    if (n == 0) return;
+    const dim3 g((unsigned)((n + kBlock - 1) / kBlock)), b(kBlock);
+#define CX_MV(DD) hipLaunchKernelGGL((k_v2f_mv<DD>), g, b, 0, h->stream, n, h->nslots, d_slots, d_vars, h->d_vbase, h->d_vinfo, f2v, h->d_mv_v2f)
+    if (h->cfg.dim == 2) CX_MV(2);
+    else if (h->cfg.dim == 3) CX_MV(3);
+    else CX_MV(4);
+#undef CX_MV
+}
+
+void mv_launch_scatter(cx_handle *h, double *dst, int64_t stride, int nc, const int32_t *d_idx, const double *d_val, int64_t n) {
+    if (n) hipLaunchKernelGGL(k_mv_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, dst, stride, nc, d_idx, d_val, n);
+}
+void mv_launch_gather(cx_handle *h, const double *src, int64_t stride, int nc, const int32_t *d_idx, double *d_val, int64_t n) {
+    if (n) hipLaunchKernelGGL(k_mv_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, stride, nc, d_idx, d_val, n);
+}
+void mv_launch_seed(cx_handle *h, double *buf, double eta, double lam) {
+    const int nc = h->cfg.dim + h->cfg.dim * (h->cfg.dim + 1) / 2;
+    hipLaunchKernelGGL(k_mv_seed, dim3((unsigned)((h->nslots + 255) / 256)), dim3(256), 0, h->stream, buf, h->nslots, h->cfg.dim, nc, eta,
+                       lam, h->d_partner);
+}
+void mv_launch_residual(cx_handle *h, const double *cur, const double *prev, int64_t n, double *d_out) {
+    hipLaunchKernelGGL(k_mv_residual, dim3(1024), dim3(kBlock), 0, h->stream, cur, prev, n, d_out);
+}
+
+// ---- small dense helpers (host) -------------------------------------------------------------------------------
+// in-place inverse of an SPD matrix (row-major d x d) by Cholesky; returns false if not positive definite
+bool spd_inverse(int d, const double *S, double *out) {
+    std::vector<double> L((size_t)d * d, 0.0), Li((size_t)d * d, 0.0);
+    for (int j = 0; j < d; j++) {
+        double s = S[j * d + j];
+        for (int k = 0; k < j; k++) s -= L[j * d + k] * L[j * d + k];
+        if (!(s > 0.0)) return false;
+        L[j * d + j] = std::sqrt(s);
+        for (int i = j + 1; i < d; i++) {
+            double t = S[i * d + j];
+            for (int k = 0; k < j; k++) t -= L[i * d + k] * L[j * d + k];
+            L[i * d + j] = t / L[j * d + j];
+        }
+    }
+    for (int c = 0; c < d; c++) {
+        for (int i = 0; i < d; i++) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int k = 0; k < i; k++) s -= L[i * d + k] * Li[k * d + c];
+            Li[i * d + c] = s / L[i * d + i];
+        }
+    }
+    for (int i = 0; i < d; i++)
+        for (int j = 0; j < d; j++) {
+            double s = 0.0;
+            for (int k = 0; k < d; k++) s += Li[k * d + i] * Li[k * d + j];
+            out[i * d + j] = s;
+        }
+    return true;
+}
+
+// (A, Q) -> the two (P, B, C) triples: [forward | backward], each 3*d*d doubles
+bool mv_rule_tables(int d, const double *A, const double *Q, double *out) {
+    std::vector<double> Qi((size_t)d * d), QiA((size_t)d * d), AtQi((size_t)d * d), AtQiA((size_t)d * d);
+    if (!spd_inverse(d, Q, Qi.data())) return false;
+    for (int i = 0; i < d; i++)
+        for (int j = 0; j < d; j++) {
+            double s = 0.0, t = 0.0;
+            for (int k = 0; k < d; k++) { s += Qi[i * d + k] * A[k * d + j]; t += A[k * d + i] * Qi[k * d + j]; }
+            QiA[i * d + j] = s; AtQi[i * d + j] = t;
+        }
+    for (int i = 0; i < d; i++)
+        for (int j = 0; j < d; j++) {
+            double s = 0.0;
+            for (int k = 0; k < d; k++) s += AtQi[i * d + k] * A[k * d + j];
+            AtQiA[i * d + j] = s;
+        }
+    const size_t n = (size_t)d * d;
+    double *fw = out, *bw = out + 3 * n;
+    for (size_t i = 0; i < n; i++) {
+        fw[i] = AtQiA[i]; fw[n + i] = QiA[i]; fw[2 * n + i] = Qi[i];
+        bw[i] = Qi[i];    bw[n + i] = AtQi[i]; bw[2 * n + i] = AtQiA[i];
+    }
+    return true;
+}
+
+}  // namespace cx

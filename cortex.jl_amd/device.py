@@ -72,6 +72,12 @@ class DeviceGraph:
                                              role, len(factor_ids), _p(factor_ids, C.c_int64),
                                              _p(factor_kind, C.c_int32), _p(fp, C.c_double)))
 
+    def set_factor_matrices(self, parameter_set: int, A, Q):
+        A, Q = _f64(A), _f64(Q)
+        if A.shape != (self.dim, self.dim) or Q.shape != (self.dim, self.dim):
+            raise ValueError(f"A and Q must be {self.dim}x{self.dim}")
+        self._check(self.lib.cx_set_factor_matrices(self.h, int(parameter_set), _p(A, C.c_double), _p(Q, C.c_double)))
+
     def stats(self) -> dict:
         s = L.Stats()
         self._check(self.lib.cx_graph_stats(self.h, C.byref(s)))

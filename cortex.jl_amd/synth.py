@@ -34,6 +34,10 @@ class Model:
     prior_mean: np.ndarray = field(default_factory=lambda: np.zeros(0))
     prior_variance: np.ndarray = field(default_factory=lambda: np.zeros(0))
     meta: dict = field(default_factory=dict)
+    # dim > 1 (linear-Gaussian factors x_out = A x_in + N(0, Q)): factor_var holds the parameter-set index
+    dim: int = 1
+    edge_role: np.ndarray | None = None
+    psets: dict = field(default_factory=dict)      # parameter set -> (A, Q)
 
     @property
     def n_edges(self) -> int:
@@ -123,8 +127,51 @@ def gaussian_grid(n_rows: int, n_cols: int, seed: int = 1234, row0: int = 0, row
                        "qv": qv, "qv_row0": v0, "ghost_rows": ghost_rows, "kind": "gaussian_grid"})
 
 
+def lgssm_chain(T: int, d: int = 4, seed: int = 1234) -> Model:
+    """d-dimensional linear-Gaussian state-space chain, configs C3 (d = 4, T = 1e6) / C5 (d = 64, T = 1e5) of
+    SURVEY.md §8d: x_{t+1} = A x_t + w, w ~ N(0, Q);  y_t = x_t + v, v ~ N(0, R);  x_1 ~ N(0, I) for the data only (the
+    graph, like the reference's SSM test, has no prior factor).  d = 4: A = 0.95 * blockdiag(rot(0.1), rot(0.1)),
+    Q = 0.1 I, R = I.  Other d: A = 0.95 * (random orthogonal, seeded).  Same id scheme as ssm_chain."""
+    rng = np.random.default_rng(seed)
+    if d % 2 == 0 and d <= 8:
+        c, s_ = np.cos(0.1), np.sin(0.1)
+        A = np.kron(np.eye(d // 2), np.array([[c, -s_], [s_, c]])) * 0.95
+    else:
+        A = 0.95 * np.linalg.qr(rng.standard_normal((d, d)))[0]
+    Q, R = 0.1 * np.eye(d), np.eye(d)
+    x = np.arange(1, T + 1, dtype=np.int64)
+    y = x + T
+    lik = x + 2 * T
+    tr = np.arange(3 * T + 1, 4 * T, dtype=np.int64)
+    edge_var = np.concatenate([y, x, x[:-1], x[1:]])
+    edge_fac = np.concatenate([lik, lik, tr, tr])
+    edge_role = np.concatenate([np.full(T, L.ROLE_OUT), np.full(T, L.ROLE_IN), np.full(T - 1, L.ROLE_IN),
+                                np.full(T - 1, L.ROLE_OUT)]).astype(np.int32)
+    state = np.empty((T, d))
+    state[0] = rng.standard_normal(d)
+    w = rng.standard_normal((T, d)) * np.sqrt(0.1)
+    for t in range(1, T):
+        state[t] = A @ state[t - 1] + w[t]
+    data = state + rng.standard_normal((T, d))
+    return Model(edge_var=edge_var, edge_fac=edge_fac, factor_ids=np.concatenate([lik, tr]),
+                 factor_kind=np.full(2 * T - 1, L.FACTOR_GAUSS_LINEAR, dtype=np.int32),
+                 factor_var=np.concatenate([np.ones(T), np.zeros(T - 1)]),   # parameter sets: 1 = likelihood, 0 = transition
+                 x_ids=x, data_var=y, data_fac=lik, data_y=data, dim=d, edge_role=edge_role,
+                 psets={0: (A, Q), 1: (np.eye(d), R)}, meta={"T": T, "A": A, "Q": Q, "R": R, "kind": "lgssm_chain"})
+
+
 def load_into_device(model: Model, dev, seed_variance: float | None = None):
     """graph upload + the data injection a user of the reference does with set_value! before update_marginals!."""
+    if model.dim > 1:
+        for k, (A, Q) in model.psets.items():
+            dev.set_factor_matrices(k, A, Q)
+        dev.graph_create(model.edge_var, model.edge_fac, model.factor_ids, model.factor_kind, model.factor_var,
+                         edge_role=model.edge_role)
+        if len(model.data_var):
+            dev.set_messages(model.data_var, model.data_fac, L.TO_FACTOR, L.FORM_POINT, model.data_y)
+        if seed_variance is not None:
+            dev.seed_messages(L.TO_VARIABLE, 0.0, seed_variance)
+        return dev
     dev.graph_create(model.edge_var, model.edge_fac, model.factor_ids, model.factor_kind, model.factor_var)
     if len(model.data_var):
         dev.set_messages(model.data_var, model.data_fac, L.TO_FACTOR, L.FORM_POINT, model.data_y)

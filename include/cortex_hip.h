@@ -89,7 +89,7 @@ typedef struct cx_handle cx_handle;
 typedef struct cx_config {
     int32_t struct_size;   /* sizeof(cx_config), for forward compatibility */
     int32_t device;        /* HIP device ordinal */
-    int32_t dim;           /* message dimension d: 1 (scalar), 4, 64 */
+    int32_t dim;           /* message dimension d: 1 (scalar), 2, 3, 4 (registers); 64 is the MFMA path */
     int32_t schedule;      /* CX_SCHED_* */
     int32_t compute_marginals_in_sweep; /* 1: every sweep also refreshes all marginals (update_marginals!) */
     int32_t materialize_messages_to_factor; /* CX_SCHED_FUSED only. 0: variable→factor messages stay in registers
@@ -132,6 +132,10 @@ int32_t cx_set_stream(cx_handle *h, void *hip_stream); /* run on the caller's hi
 int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, const int64_t *edge_fac,
                         const int32_t *edge_role, int64_t n_factors, const int64_t *factor_ids,
                         const int32_t *factor_kind, const double *factor_params);
+/* dim > 1: parameter set `parameter_set` of the linear-Gaussian factors x_out = A x_in + N(0, Q); A, Q are d x d row-major,
+ * Q symmetric positive definite.  A CX_FACTOR_GAUSS_LINEAR factor names its set in factor_params[0]; its ROLE_IN edge carries
+ * x_in.  (The reference leaves Factor.functional_form opaque, model_engine.jl:119-122; this is what the user rule reads.) */
+int32_t cx_set_factor_matrices(cx_handle *h, int64_t parameter_set, const double *A, const double *Q);
 int32_t cx_graph_stats(const cx_handle *h, cx_stats *out);
 /* position of Connection (variable_id, factor_id) in the flattened edge table (sorted by variable, factor) */
 int32_t cx_edge_index(const cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids,

@@ -39,7 +39,7 @@ def engine_oracle_from_model(model, trace=False):
     return E
 
 
-def assert_close(actual, expected, rtol, what=""):
+def assert_close(actual, expected, rtol, what="", scale_by="median"):
     """|a-b| <= rtol * max(|b|, scale) elementwise, scale = typical magnitude of `expected`
     (means cross zero, so a pure relative test is ill-posed there); NaN patterns must agree."""
     actual = np.asarray(actual, dtype=np.float64)
@@ -50,7 +50,7 @@ def assert_close(actual, expected, rtol, what=""):
     ok = ~ne
     if not ok.any():
         return 0.0
-    scale = max(float(np.median(np.abs(expected[ok]))), 1e-300)
+    scale = max(float((np.median if scale_by == "median" else np.max)(np.abs(expected[ok]))), 1e-300)
     err = np.abs(actual[ok] - expected[ok]) / np.maximum(np.abs(expected[ok]), scale)
     worst = float(err.max())
     assert worst <= rtol, f"{what}: max rel err {worst:.3e} > {rtol:.1e}"

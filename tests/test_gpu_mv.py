@@ -1,0 +1,115 @@
+"""-m gpu: d-dimensional linear-Gaussian messages (dim 2, 3, 4) — BASELINE.json config 3 is the d = 4 chain.
+
+The reference has no d-dimensional rule, so parity here is (i) per sweep against the numpy restatement oracle/mv.py in
+the same flooding order, (ii) at the fixed point against the exact block-tridiagonal smoother, (iii) at the full C3 size
+(T = 1e6, 3,999,998 edges) through a size-independent property: after K sweeps the marginals of a window deep inside
+the chain equal the exact smoother of a slightly larger window (the smoother forgets exponentially)."""
+import numpy as np
+import pytest
+
+import cortex.jl_amd as cx
+from cortex.jl_amd import _lib as L
+from oracle import exact
+from oracle.mv import MvFlood
+from tests.helpers import assert_close as _assert_close
+
+
+def assert_close(a, b, rtol, what=""):
+    # matrices carry numerically-zero entries: measure errors against the largest entry
+    return _assert_close(a, b, rtol, what, scale_by="max")
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def _dev(model, seed_variance=None):
+    dev = cx.DeviceGraph(dim=model.dim, schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(model, dev, seed_variance)
+    return dev
+
+
+@pytest.mark.parametrize("d", [2, 3, 4])
+def test_mv_sweeps_match_numpy_restatement(hip_lib, d):
+    T = 9
+    model = cx.synth.lgssm_chain(T, d=d, seed=3)
+    dev = _dev(model)
+    o = MvFlood(model)
+    g = o.g
+    pe = np.flatnonzero(g.partner >= 0)
+    for sweep in range(T + 2):
+        dev.sweep(1)
+        o.sweep(1)
+        got = dev.get_messages(g.edge_var[pe], g.edge_fac[pe], L.TO_VARIABLE)
+        for row, e in zip(got, pe):
+            if o.f2v[e] is None:
+                assert np.all(np.isnan(row)), f"sweep {sweep} edge {e}: device defined, restatement undefined"
+                continue
+            m, S = o.f2v[e]
+            if not np.all(np.isfinite(S)) or np.linalg.cond(S) > 1e12:
+                continue  # message towards an observed variable before it is proper
+            assert_close(row[:d], m, 1e-8, f"sweep {sweep} f2v mean edge {e}")
+            assert_close(row[d:].reshape(d, d), S, 1e-8, f"sweep {sweep} f2v covariance edge {e}")
+    dev.sweep(1)
+    marg = dev.get_marginals(model.x_ids)
+    em, ecov = exact.lgssm_posterior(model.data_y, model.meta["A"], model.meta["Q"], model.meta["R"])
+    assert_close(marg[:, :d], em, RTOL, "marginal mean vs block-tridiagonal solve")
+    assert_close(marg[:, d:].reshape(T, d, d), ecov, RTOL, "marginal covariance vs block-tridiagonal solve")
+    # variable→factor messages are recomputed on demand from the retained buffer
+    xs = np.searchsorted(g.var_ids, model.x_ids)
+    for t in (1, T // 2):
+        e = [e_ for e_ in range(int(g.var_off[xs[t]]), int(g.var_off[xs[t] + 1]))][-1]
+        got = dev.get_messages([g.edge_var[e]], [g.edge_fac[e]], L.TO_FACTOR)[0]
+        m, S = o.v2f[e]
+        assert_close(got[:d], m, 1e-8, "v2f mean"); assert_close(got[d:].reshape(d, d), S, 1e-8, "v2f covariance")
+
+
+def test_mv_fixed_point_longer_chain(hip_lib):
+    d, T = 4, 120
+    model = cx.synth.lgssm_chain(T, d=d, seed=11)
+    dev = _dev(model)
+    dev.sweep(T + 3)
+    marg = dev.get_marginals(model.x_ids)
+    em, ecov = exact.lgssm_posterior(model.data_y, model.meta["A"], model.meta["Q"], model.meta["R"])
+    assert_close(marg[:, :d], em, RTOL, "marginal mean")
+    assert_close(marg[:, d:].reshape(T, d, d), ecov, RTOL, "marginal covariance")
+    dev.residual()
+    dev.sweep(2)
+    assert dev.residual() < 1e-10
+
+
+def test_config_c3_full_size_window_property(hip_lib):
+    """BASELINE.json configs[2]: d = 4 state-space chain, T = 1e6 (3,999,998 edges)."""
+    d, T, K, W, pad = 4, 1_000_000, 160, 400, 120
+    model = cx.synth.lgssm_chain(T, d=d, seed=1234)
+    assert model.n_edges == 3_999_998
+    # flooding from data alone defines a message only once the wavefront from a chain end has reached it (T sweeps);
+    # like any user of loopy/long-range BP, seed the messages with a vague N(0, 1e6 I) and let them be forgotten
+    dev = _dev(model, seed_variance=1e6)
+    assert dev.stats()["n_edges"] == 3_999_998
+    dev.sweep(K)
+    A, Q, R = model.meta["A"], model.meta["Q"], model.meta["R"]
+    for start in (0, 123_456, 500_000, T - W):
+        lo, hi = max(0, start - pad), min(T, start + W + pad)
+        em, ecov = exact.lgssm_posterior(model.data_y[lo:hi], A, Q, R)
+        ids = model.x_ids[start:start + W]
+        # information from more than `pad` steps away (data, seeds, chain ends) is forgotten to < 1e-12:
+        # the closed-loop factor of this model is ≈ 0.75 per step
+        marg = dev.get_marginals(ids)
+        sl = slice(start - lo, start - lo + W)
+        assert_close(marg[:, :d], em[sl], 1e-8, f"C3 window at {start}: mean")
+        assert_close(marg[:, d:].reshape(W, d, d), ecov[sl], 1e-8, f"C3 window at {start}: covariance")
+
+
+def test_mv_errors(hip_lib):
+    model = cx.synth.lgssm_chain(5, d=4)
+    dev = cx.DeviceGraph(dim=4)
+    dev.graph_create(model.edge_var, model.edge_fac, model.factor_ids, model.factor_kind, model.factor_var, edge_role=model.edge_role)
+    with pytest.raises(cx.CortexHipError) as e:
+        dev.sweep(1)      # parameter sets never supplied
+    assert e.value.code == L.ERR_STATE
+    with pytest.raises(cx.CortexHipError) as e:
+        dev.set_factor_matrices(0, np.eye(4), -np.eye(4))
+    assert e.value.code == L.ERR_INVALID_ARGUMENT
+    with pytest.raises(cx.CortexHipError) as e:
+        cx.DeviceGraph(dim=5)
+    assert e.value.code == L.ERR_UNSUPPORTED
