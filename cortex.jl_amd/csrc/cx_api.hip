@@ -58,9 +58,10 @@ void dev_free_all(cx_handle *h) {
                     h->d_vinfo, h->d_q, h->d_a, h->d_b, h->d_sq, h->d_sa, h->d_sb, h->d_f2v, h->d_v2f, h->d_marg,
                     h->d_f2v_alt, h->d_prev, h->d_scratch, h->d_send_slots, h->d_recv_slots, h->d_send_vars,
                     h->ext_halo_buffers ? nullptr : (void *)h->d_send_buf, h->ext_halo_buffers ? nullptr : (void *)h->d_recv_buf,
-                    h->d_stage, h->d_spdir, h->d_ptab, h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prev, h->d_chain_pos_var, h->d_chain_skip0, h->d_chain_skip1, h->d_chain_link_pos, h->d_chain_from,
+                    h->d_stage, h->d_spdir, h->d_ptab, h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prev, h->d_rule64_slots, h->d_rule64_vars, h->d_rule64_flags, h->d_point64_slots, h->d_chain_pos_var, h->d_chain_skip0, h->d_chain_skip1, h->d_chain_link_pos, h->d_chain_from,
                     h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_side, h->d_chain_totals};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    h->d_rule64_slots = h->d_rule64_vars = h->d_rule64_flags = h->d_point64_slots = nullptr; h->work64_dirty = h->point64_dirty = true;
     h->d_spdir = nullptr; h->d_ptab = nullptr; h->d_mv_f2v = h->d_mv_f2v_alt = h->d_mv_v2f = h->d_mv_marg = h->d_mv_prev = nullptr; h->ptab_sets = 0;
     h->d_chain_pos_var = h->d_chain_skip0 = h->d_chain_skip1 = h->d_chain_link_pos = h->d_chain_from = h->d_chain_to = nullptr;
     h->d_chain_head_fwd = h->d_chain_head_bwd = nullptr; h->d_chain_side = nullptr; h->d_chain_totals = nullptr; h->chains_dirty = true;
@@ -157,8 +158,8 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
     *out = nullptr;
     if (!config || config->struct_size != (int32_t)sizeof(cx_config))
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: config is NULL or struct_size mismatch");
-    if (config->dim != 1 && config->dim != 2 && config->dim != 3 && config->dim != 4)
-        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: this build implements dim in {1, 2, 3, 4}");
+    if (config->dim != 1 && config->dim != 2 && config->dim != 3 && config->dim != 4 && config->dim != 64)
+        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: this build implements dim in {1, 2, 3, 4, 64}");
     if (config->dim > 1 && config->schedule != CX_SCHED_FUSED)
         return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: dim > 1 runs the fused schedule only");
     if (config->schedule != CX_SCHED_FLOODING && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN)
@@ -173,7 +174,7 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
     cx_handle *h = new (std::nothrow) cx_handle();
     if (!h) return fail(nullptr, CX_ERR_OUT_OF_MEMORY, "cx_create: host allocation failed");
     h->cfg = *config;
-    h->nc = config->dim == 1 ? 2 : config->dim + config->dim * (config->dim + 1) / 2;
+    h->nc = config->dim == 1 ? 2 : (config->dim == 64 ? 64 + 64 * 64 : config->dim + config->dim * (config->dim + 1) / 2);
     h->stream = nullptr;  // default stream until cx_set_stream
     *out = h;
     return CX_OK;
@@ -417,11 +418,11 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
             const int64_t nc = h->nc;
             CX_TRY(dev_upload(h, &h->d_spdir, spdir));
             CX_TRY(dev_alloc(h, &h->d_mv_f2v, nc * slots)); CX_TRY(dev_alloc(h, &h->d_mv_f2v_alt, nc * slots));
-            CX_TRY(dev_alloc(h, &h->d_mv_v2f, nc * slots)); CX_TRY(dev_alloc(h, &h->d_mv_marg, nc * nv));
+            CX_TRY(dev_alloc(h, &h->d_mv_v2f, nc * slots)); CX_TRY(dev_alloc(h, &h->d_mv_marg, h->cfg.dim == 64 ? 1 : nc * nv));
             CX_HIP(h, hipMemsetAsync(h->d_mv_f2v, 0xff, (size_t)(nc * slots) * 8, h->stream));
             CX_HIP(h, hipMemsetAsync(h->d_mv_f2v_alt, 0xff, (size_t)(nc * slots) * 8, h->stream));
             CX_HIP(h, hipMemsetAsync(h->d_mv_v2f, 0xff, (size_t)(nc * slots) * 8, h->stream));
-            CX_HIP(h, hipMemsetAsync(h->d_mv_marg, 0xff, (size_t)(nc * nv) * 8, h->stream));
+            if (h->cfg.dim != 64) CX_HIP(h, hipMemsetAsync(h->d_mv_marg, 0xff, (size_t)(nc * nv) * 8, h->stream));
             CX_HIP(h, hipStreamSynchronize(h->stream));
             h->has_graph = true;
             return upload_ptab(h);
@@ -547,7 +548,51 @@ int32_t mv_refresh_v2f(cx_handle *h, const std::vector<int32_t> &slots, const st
     int32_t *d_s = (int32_t *)h->d_stage, *d_v = d_s + n;
     CX_HIP(h, hipMemcpyAsync(d_s, slots.data(), n * 4, hipMemcpyHostToDevice, h->stream));
     CX_HIP(h, hipMemcpyAsync(d_v, vars.data(), n * 4, hipMemcpyHostToDevice, h->stream));
-    cx::mv_launch_v2f(h, d_s, d_v, n, h->sweeps_done > 0 ? h->d_mv_f2v_alt : h->d_mv_f2v);
+    if (h->cfg.dim == 64) cx::mv64_launch_v2f(h, (int)n, d_s, d_v, h->sweeps_done > 0 ? h->d_mv_f2v_alt : h->d_mv_f2v);
+    else cx::mv_launch_v2f(h, d_s, d_v, n, h->sweeps_done > 0 ? h->d_mv_f2v_alt : h->d_mv_f2v);
+    CX_HIP(h, hipGetLastError());
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    return CX_OK;
+}
+
+int32_t mv64_set_messages(cx_handle *h, int64_t n, const std::vector<int32_t> &idx, const std::vector<int32_t> &vars, int32_t direction,
+                          int32_t form, const double *payload) {
+    const int d = 64, nc = h->nc;
+    const int64_t bytes_idx = ((n * 4 + 15) / 16) * 16;
+    int32_t rc;
+    if (form == CX_FORM_POINT) {
+        rc = ensure_stage(h, bytes_idx + n * d * 8);
+        if (rc != CX_OK) return rc;
+        int32_t *d_idx = (int32_t *)h->d_stage;
+        double *d_val = (double *)((char *)h->d_stage + bytes_idx);
+        CX_HIP(h, hipMemcpyAsync(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+        CX_HIP(h, hipMemcpyAsync(d_val, payload, (size_t)n * d * 8, hipMemcpyHostToDevice, h->stream));
+        cx::mv64_set_point(h, h->d_mv_v2f, d_idx, d_val, n);
+        for (int64_t i = 0; i < n; i++) h->vinfo[vars[i]] |= cx::kClamped;
+        CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
+        h->work64_dirty = h->point64_dirty = true;
+    } else {
+        std::vector<double> val((size_t)n * nc);
+        for (int64_t i = 0; i < n; i++) {
+            const double *p = payload + i * (d + d * d);
+            double *o = &val[(size_t)i * nc];
+            if (form == CX_FORM_NATURAL) { std::memcpy(o, p, (size_t)nc * 8); continue; }
+            bool undef = false;
+            for (int k = 0; k < d * d; k++) undef = undef || std::isnan(p[d + k]);
+            if (undef) { for (int k = 0; k < nc; k++) o[k] = kNaN; continue; }
+            if (!cx::spd_inverse(d, p + d, o + d))
+                return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_set_messages: covariance of row " + std::to_string(i) + " is not positive definite");
+            for (int r = 0; r < d; r++) { double s = 0; for (int c = 0; c < d; c++) s += o[d + r * d + c] * p[c]; o[r] = s; }
+        }
+        rc = ensure_stage(h, bytes_idx + n * nc * 8);
+        if (rc != CX_OK) return rc;
+        int32_t *d_idx = (int32_t *)h->d_stage;
+        double *d_val = (double *)((char *)h->d_stage + bytes_idx);
+        CX_HIP(h, hipMemcpyAsync(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+        CX_HIP(h, hipMemcpyAsync(d_val, val.data(), (size_t)n * nc * 8, hipMemcpyHostToDevice, h->stream));
+        if (direction == CX_TO_FACTOR) { cx::mv64_rows_scatter(h, h->d_mv_v2f, d_idx, d_val, n); h->point64_dirty = true; }
+        else { cx::mv64_rows_scatter(h, h->d_mv_f2v, d_idx, d_val, n); cx::mv64_rows_scatter(h, h->d_mv_f2v_alt, d_idx, d_val, n); }
+    }
     CX_HIP(h, hipGetLastError());
     CX_HIP(h, hipStreamSynchronize(h->stream));
     return CX_OK;
@@ -559,6 +604,7 @@ int32_t mv_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
     std::vector<int32_t> idx, vars;
     int32_t rc = stage_slots(h, n, variable_ids, factor_ids, idx, &vars);
     if (rc != CX_OK) return rc;
+    if (d == 64) return mv64_set_messages(h, n, idx, vars, direction, form, payload);
     const int64_t stride = form == CX_FORM_POINT ? d : d + d * d;
     std::vector<double> val((size_t)n * nc);
     for (int64_t i = 0; i < n; i++)
@@ -596,6 +642,24 @@ int32_t mv_get(cx_handle *h, const double *src, int64_t stride, const std::vecto
     int32_t *d_idx = (int32_t *)h->d_stage;
     double *d_val = (double *)((char *)h->d_stage + bytes_idx);
     CX_HIP(h, hipMemcpyAsync(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+    if (d == 64) {
+        if (already_moment) cx::mv64_launch_marginals(h, (int)n, d_idx, h->d_mv_f2v, d_val);   // idx = variables: computed on demand
+        else cx::mv64_rows_gather(h, src, d_idx, d_val, n);
+        CX_HIP(h, hipGetLastError());
+        std::vector<double> val((size_t)n * nc);
+        CX_HIP(h, hipMemcpyAsync(val.data(), d_val, (size_t)n * nc * 8, hipMemcpyDeviceToHost, h->stream));
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        for (int64_t i = 0; i < n; i++) {
+            double *o = out + i * nc;
+            const double *in = &val[(size_t)i * nc];
+            if (already_moment || form == CX_FORM_NATURAL) { std::memcpy(o, in, (size_t)nc * 8); continue; }
+            if (std::isnan(in[d])) { for (int k = 0; k < nc; k++) o[k] = kNaN; continue; }
+            if (in[d] == kInf) { for (int k = 0; k < nc; k++) o[k] = 0.0; for (int k = 0; k < d; k++) o[k] = in[k]; continue; }
+            if (!cx::spd_inverse(d, in + d, o + d)) { for (int k = 0; k < nc; k++) o[k] = kNaN; continue; }
+            for (int r = 0; r < d; r++) { double s = 0; for (int c = 0; c < d; c++) s += o[d + r * d + c] * in[c]; o[r] = s; }
+        }
+        return CX_OK;
+    }
     cx::mv_launch_gather(h, src, stride, nc, d_idx, d_val, n);
     std::vector<double> val((size_t)n * nc);
     CX_HIP(h, hipMemcpyAsync(val.data(), d_val, (size_t)n * nc * 8, hipMemcpyDeviceToHost, h->stream));
@@ -627,12 +691,52 @@ int32_t mv_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, d
     return mv_get(h, h->d_mv_marg, h->nv, idx, CX_FORM_MOMENT, true, out);
 }
 
+// d = 64: which messages need the full MFMA rule, which come from observed variables (constant), which nobody reads
+int32_t build_work64(cx_handle *h) {
+    if (!h->work64_dirty) return CX_OK;
+    std::vector<int32_t> rs, rv, rf, ps, slot_var(h->nslots, -1);
+    for (int64_t e = 0; e < h->ne; e++) slot_var[cx::slot_of_edge(h, e)] = h->edge_var[e];
+    for (int64_t e = 0; e < h->ne; e++) {
+        const int32_t s = cx::slot_of_edge(h, e), p = h->partner[s], v = h->edge_var[e];
+        if (p < 0) continue;
+        const int32_t rvz = slot_var[p];
+        if (h->vinfo[rvz] & cx::kClamped) continue;                 // a message into an observed variable has no reader
+        const int32_t deg = h->var_off[v + 1] - h->var_off[v];
+        if (h->vinfo[v] & cx::kClamped) { ps.push_back(s); continue; }
+        rs.push_back(s); rv.push_back(v); rf.push_back(deg < 2 ? 1 : 0);   // degree-1 leaf: its stored message is the input
+    }
+    for (void *p : {(void *)h->d_rule64_slots, (void *)h->d_rule64_vars, (void *)h->d_rule64_flags, (void *)h->d_point64_slots}) if (p) (void)hipFree(p);
+    h->d_rule64_slots = h->d_rule64_vars = h->d_rule64_flags = h->d_point64_slots = nullptr;
+    h->n_rule64 = (int64_t)rs.size(); h->n_point64 = (int64_t)ps.size();
+    int32_t rc;
+    if ((rc = dev_upload(h, &h->d_rule64_slots, rs)) != CX_OK) return rc;
+    if ((rc = dev_upload(h, &h->d_rule64_vars, rv)) != CX_OK) return rc;
+    if ((rc = dev_upload(h, &h->d_rule64_flags, rf)) != CX_OK) return rc;
+    if ((rc = dev_upload(h, &h->d_point64_slots, ps)) != CX_OK) return rc;
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    h->work64_dirty = false;
+    h->point64_dirty = true;
+    return CX_OK;
+}
+
 int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
     CX_REQUIRE(h, (int64_t)h->psets.size() > h->max_pset, CX_ERR_STATE, "cx_sweep: a factor names a parameter set that was never set (cx_set_factor_matrices)");
     for (int64_t i = 0; i <= h->max_pset; i++)
         CX_REQUIRE(h, !h->psets[i].empty(), CX_ERR_STATE, "cx_sweep: parameter set " + std::to_string(i) + " was never set (cx_set_factor_matrices)");
+    if (h->cfg.dim == 64) {
+        int32_t rc = build_work64(h);
+        if (rc != CX_OK) return rc;
+        if (h->point64_dirty) {   // messages out of observed variables are constant: computed once, into both buffers
+            cx::mv64_launch_point(h, (int)h->n_point64, h->d_point64_slots, h->d_mv_f2v, h->d_mv_f2v_alt);
+            h->point64_dirty = false;
+        }
+    }
     for (int32_t s = 0; s < n_sweeps; s++) {
-        cx::mv_launch_sweep(h, h->cfg.compute_marginals_in_sweep != 0);
+        if (h->cfg.dim == 64)
+            cx::mv64_launch_rule(h, (int)h->n_rule64, h->d_rule64_slots, h->d_rule64_vars, h->d_rule64_flags, h->d_mv_f2v, h->d_mv_f2v_alt,
+                                 CX_KERNEL_FUSED);
+        else
+            cx::mv_launch_sweep(h, h->cfg.compute_marginals_in_sweep != 0);
         std::swap(h->d_mv_f2v, h->d_mv_f2v_alt);
         h->sweeps_done++;
     }
@@ -752,8 +856,13 @@ int32_t cx_seed_messages(cx_handle *h, int32_t direction, double mean, double va
     CX_REQUIRE(h, variance > 0.0, CX_ERR_INVALID_ARGUMENT, "cx_seed_messages: variance must be > 0");
     if (h->cfg.dim > 1) {
         CX_REQUIRE(h, direction == CX_TO_VARIABLE, CX_ERR_UNSUPPORTED, "cx_seed_messages: dim > 1 seeds factor→variable messages only");
-        cx::mv_launch_seed(h, h->d_mv_f2v, mean / variance, 1.0 / variance);
-        cx::mv_launch_seed(h, h->d_mv_f2v_alt, mean / variance, 1.0 / variance);
+        if (h->cfg.dim == 64) {
+            cx::mv64_launch_seed(h, h->d_mv_f2v, mean / variance, 1.0 / variance);
+            cx::mv64_launch_seed(h, h->d_mv_f2v_alt, mean / variance, 1.0 / variance);
+        } else {
+            cx::mv_launch_seed(h, h->d_mv_f2v, mean / variance, 1.0 / variance);
+            cx::mv_launch_seed(h, h->d_mv_f2v_alt, mean / variance, 1.0 / variance);
+        }
         CX_HIP(h, hipGetLastError());
         return CX_OK;
     }

@@ -77,6 +77,10 @@ struct cx_handle {
     double *d_ptab = nullptr;                      // [2*npsets][3][d*d]: (P, B, C) triples
     int64_t ptab_sets = 0, max_pset = -1;
     double *d_mv_f2v = nullptr, *d_mv_f2v_alt = nullptr, *d_mv_v2f = nullptr, *d_mv_marg = nullptr, *d_mv_prev = nullptr;
+    // d = 64 work lists (built lazily: they depend on which variables are observed)
+    bool work64_dirty = true, point64_dirty = true;
+    int64_t n_rule64 = 0, n_point64 = 0;
+    int32_t *d_rule64_slots = nullptr, *d_rule64_vars = nullptr, *d_rule64_flags = nullptr, *d_point64_slots = nullptr;
 
     // chain-scan schedule (cx_chain.hip): paths of free variables, built lazily by build_chains()
     bool chains_dirty = true;
@@ -136,6 +140,16 @@ void mv_launch_gather(cx_handle *h, const double *src, int64_t stride, int nc, c
 void mv_launch_seed(cx_handle *h, double *buf, double eta, double lam);
 void mv_launch_residual(cx_handle *h, const double *cur, const double *prev, int64_t n, double *d_out);
 bool spd_inverse(int d, const double *S, double *out);
+// d = 64 (cx_mv64.hip): message-major layout, MFMA rule kernel
+void mv64_launch_rule(cx_handle *h, int nwork, const int32_t *d_slots, const int32_t *d_vars, const int32_t *d_flags,
+                      const double *f2v_in, double *f2v_out, int kernel_id);
+void mv64_launch_marginals(cx_handle *h, int n, const int32_t *d_vars, const double *f2v, double *out);
+void mv64_launch_point(cx_handle *h, int nwork, const int32_t *d_slots, double *out_a, double *out_b);
+void mv64_launch_v2f(cx_handle *h, int n, const int32_t *d_slots, const int32_t *d_vars, const double *f2v);
+void mv64_launch_seed(cx_handle *h, double *buf, double eta, double lam);
+void mv64_rows_scatter(cx_handle *h, double *dst, const int32_t *d_idx, const double *d_val, int64_t n);
+void mv64_rows_gather(cx_handle *h, const double *src, const int32_t *d_idx, double *d_val, int64_t n);
+void mv64_set_point(cx_handle *h, double *dst, const int32_t *d_idx, const double *d_y, int64_t n);
 bool mv_rule_tables(int d, const double *A, const double *Q, double *out);
 size_t chain_total_bytes(int64_t nlinks);
 

@@ -113,3 +113,76 @@ def test_mv_errors(hip_lib):
     with pytest.raises(cx.CortexHipError) as e:
         cx.DeviceGraph(dim=5)
     assert e.value.code == L.ERR_UNSUPPORTED
+
+
+# ------------------------------------------------------------------------------------------------ d = 64 (MFMA path)
+
+def test_mv64_sweeps_match_numpy_restatement(hip_lib):
+    d, T = 64, 5
+    model = cx.synth.lgssm_chain(T, d=d, seed=3)
+    dev = _dev(model)
+    o = MvFlood(model)
+    g = o.g
+    xs = np.searchsorted(g.var_ids, model.x_ids)
+    # messages into the latent variables (those into observed variables have no reader and are not computed for d = 64)
+    pe = np.array([e for e in np.flatnonzero(g.partner >= 0) if np.searchsorted(g.var_ids, g.edge_var[e]) in set(xs)])
+    # the d = 64 path evaluates the (constant) messages out of observed variables when the data is injected, i.e. one
+    # sweep before the flooding order does: device after k sweeps == restatement after k + 1 sweeps
+    o.sweep(1)
+    for sweep in range(T + 2):
+        dev.sweep(1)
+        o.sweep(1)
+        got = dev.get_messages(g.edge_var[pe], g.edge_fac[pe], L.TO_VARIABLE)
+        for row, e in zip(got, pe):
+            if o.f2v[e] is None:
+                assert np.all(np.isnan(row)), f"sweep {sweep} edge {e}: device defined, restatement undefined"
+                continue
+            m, S = o.f2v[e]
+            assert_close(row[:d], m, 1e-8, f"sweep {sweep} f2v mean edge {e}")
+            assert_close(row[d:].reshape(d, d), S, 1e-8, f"sweep {sweep} f2v covariance edge {e}")
+    marg = dev.get_marginals(model.x_ids)
+    em, ecov = exact.lgssm_posterior(model.data_y, model.meta["A"], model.meta["Q"], model.meta["R"])
+    assert_close(marg[:, :d], em, 1e-8, "d=64 marginal mean vs block-tridiagonal solve")
+    assert_close(marg[:, d:].reshape(T, d, d), ecov, 1e-8, "d=64 marginal covariance vs block-tridiagonal solve")
+    e = int(g.var_off[xs[2] + 1]) - 1
+    got = dev.get_messages([g.edge_var[e]], [g.edge_fac[e]], L.TO_FACTOR)[0]
+    m, S = o.v2f[e]
+    assert_close(got[:d], m, 1e-8, "d=64 v2f mean"); assert_close(got[d:].reshape(d, d), S, 1e-8, "d=64 v2f covariance")
+
+
+def test_mv64_fixed_point_and_user_set_messages(hip_lib):
+    d, T = 64, 24
+    model = cx.synth.lgssm_chain(T, d=d, seed=5)
+    dev = _dev(model)
+    dev.sweep(T + 2)
+    marg = dev.get_marginals(model.x_ids)
+    em, ecov = exact.lgssm_posterior(model.data_y, model.meta["A"], model.meta["Q"], model.meta["R"])
+    assert_close(marg[:, :d], em, 1e-8, "marginal mean")
+    assert_close(marg[:, d:].reshape(T, d, d), ecov, 1e-8, "marginal covariance")
+    dev.residual()
+    dev.sweep(2)
+    assert dev.residual() < 1e-9
+    # a moment-form message set by the caller reads back unchanged
+    rng = np.random.default_rng(0)
+    Sg = rng.standard_normal((d, d)); Sg = Sg @ Sg.T + d * np.eye(d); mg = rng.standard_normal(d)
+    tr0 = model.factor_ids[T]
+    dev.set_messages([model.x_ids[0]], [tr0], L.TO_VARIABLE, L.FORM_MOMENT, np.concatenate([mg, Sg.ravel()]))
+    back = dev.get_messages([model.x_ids[0]], [tr0], L.TO_VARIABLE)[0]
+    assert_close(back[:d], mg, 1e-9, "round-trip mean"); assert_close(back[d:].reshape(d, d), Sg, 1e-9, "round-trip covariance")
+
+
+def test_config_c5_full_size_window_property(hip_lib):
+    """BASELINE.json configs[4]: d = 64 linear-Gaussian factors, 1e5 nodes (399,998 edges), MFMA update path."""
+    d, T, K, W, pad = 64, 100_000, 96, 40, 70
+    model = cx.synth.lgssm_chain(T, d=d, seed=1234)
+    assert model.n_edges == 399_998
+    dev = _dev(model, seed_variance=1e6)
+    dev.sweep(K)
+    A, Q, R = model.meta["A"], model.meta["Q"], model.meta["R"]
+    for start in (0, 50_000, T - W):
+        lo, hi = max(0, start - pad), min(T, start + W + pad)
+        em, ecov = exact.lgssm_posterior(model.data_y[lo:hi], A, Q, R)
+        marg = dev.get_marginals(model.x_ids[start:start + W])
+        sl = slice(start - lo, start - lo + W)
+        assert_close(marg[:, :d], em[sl], 1e-7, f"C5 window at {start}: mean")
+        assert_close(marg[:, d:].reshape(W, d, d), ecov[sl], 1e-7, f"C5 window at {start}: covariance")
