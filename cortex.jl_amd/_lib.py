@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcortex_hip.so")
+LIB_PATH = os.environ.get("CORTEX_HIP_LIB", os.path.join(HERE, "libcortex_hip.so"))  # override: A/B builds of the same ABI
 
 # mirrors of the #defines in include/cortex_hip.h
 ABI_VERSION = 1

@@ -409,6 +409,11 @@ bool mv_rule_tables(int d, const double *A, const double *Q, double *out) {
             for (int k = 0; k < d; k++) s += AtQi[i * d + k] * A[k * d + j];
             AtQiA[i * d + j] = s;
         }
+    for (int i = 0; i < d; i++)      // exactly symmetric P and C tables
+        for (int j = i + 1; j < d; j++) {
+            const double q = 0.5 * (Qi[i * d + j] + Qi[j * d + i]), t = 0.5 * (AtQiA[i * d + j] + AtQiA[j * d + i]);
+            Qi[i * d + j] = Qi[j * d + i] = q; AtQiA[i * d + j] = AtQiA[j * d + i] = t;
+        }
     const size_t n = (size_t)d * d;
     double *fw = out, *bw = out + 3 * n;
     for (size_t i = 0; i < n; i++) {

@@ -29,10 +29,14 @@ constexpr int kMsg = kD + kD * kD;      // doubles per message slot
 
 using d4 = __attribute__((ext_vector_type(4))) double;
 
-__device__ __forceinline__ double readlane_f64(double x, int lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
-    return __hiloint2double(hi, lo);
+// 1/sqrt(x) to double precision: v_rsq_f64 seed (≈ 2^-27) + two Newton steps.  The library's sqrt() and 1.0/x expand to
+// ≈ 40 dependent instructions; inside the 64 pivot steps of a message that chain was the kernel's critical path.
+__device__ __forceinline__ double rsqrt_f64(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * __builtin_fma(-hx * y, y, 1.5);
+    y = y * __builtin_fma(-hx * y, y, 1.5);
+    return y;       // x <= 0 or NaN -> NaN/inf: the message stays undefined
 }
 
 // acc += X[xr0 .. xr0+15][kx0 .. kx0+4*ksteps) * Z[zr0 .. zr0+15][kz0 .. kz0+4*ksteps)'   (16x16 tile of X Z')
@@ -41,6 +45,7 @@ __device__ __forceinline__ d4 mfma_xzt(const double *__restrict__ X, int ldx, in
     const int r = lane & 15, kk = lane >> 4;
     const double *xp = X + (xr0 + r) * ldx + kx0 + kk;
     const double *zp = Z + (zr0 + r) * ldz + kz0 + kk;
+#pragma unroll
     for (int s = 0; s < ksteps; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xp[4 * s], zp[4 * s], acc, 0, 0, 0);
     return acc;
 }
@@ -51,6 +56,14 @@ __device__ __forceinline__ void tile_store(double *__restrict__ T, int ld, int r
     for (int r = 0; r < 4; r++) T[(r0 + rb + 4 * r) * ld + c0 + c] = acc[r];
 }
 
+// store only the first `nrows` rows of a tile (the eta row of Yt is a 1-row "tile")
+__device__ __forceinline__ void tile_store_rows(double *__restrict__ T, int ld, int r0, int c0, d4 acc, int lane, int nrows) {
+    const int c = lane & 15, rb = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        if (rb + 4 * r < nrows) T[(r0 + rb + 4 * r) * ld + c0 + c] = acc[r];
+}
+
 __device__ __forceinline__ d4 tile_load(const double *__restrict__ T, int ld, int r0, int c0, int lane) {
     const int c = lane & 15, rb = lane >> 4;
     d4 a;
@@ -59,43 +72,81 @@ __device__ __forceinline__ d4 tile_load(const double *__restrict__ T, int ld, in
     return a;
 }
 
-// Cholesky of the 16x16 diagonal block at (o, o) of Ms and its inverse into W (row-major, ld kLdw); one wave, lanes 0..15
-// hold one row each, the pivot row is broadcast with v_readlane (its lane index is a compile-time constant).
-__device__ __forceinline__ void diag_block(double *__restrict__ Ms, int o, double *__restrict__ W, int lane) {
-    double a[16], l[16], w[16];
-    const int row = lane & 15;
+// forward substitution with a 4x4 lower factor given by its strict lower part and reciprocal diagonal: x <- L44^-1 x
+__device__ __forceinline__ void sub4(double (&x)[4], double l10, double l20, double l21, double l30, double l31, double l32,
+                                     const double (&ri)[4]) {
+    x[0] = x[0] * ri[0];
+    x[1] = (x[1] - l10 * x[0]) * ri[1];
+    x[2] = (x[2] - l20 * x[0] - l21 * x[1]) * ri[2];
+    x[3] = (x[3] - l30 * x[0] - l31 * x[1] - l32 * x[2]) * ri[3];
+}
+
+// Cholesky of the 16x16 diagonal block at (o, o) of Ms and its inverse into W (row-major, ld kLdw), by the whole
+// workgroup: thread (i, k) = (tid >> 4, tid & 15) keeps A[i][k] and W[i][k] in registers.  Four rounds of four columns,
+// ONE barrier per round: the owners publish the four raw columns and the four rows of W (double-buffered staging), every
+// thread factors the 4x4 pivot block redundantly in registers (the only sqrt chain) and applies the rank-4 update
+//     l_i = raw_i L44^-T;   A[i][k] -= l_i . l_k;   W_J = L44^-1 W_J;   W[i][:] -= l_i W_J.
+// History: a 16-lane v_readlane version took 12.7k cycles per block, a one-column-per-barrier version 11k (each pivot
+// step pays barrier + LDS round trip + rsqrt chain); this one pays that latency 4 times instead of 16.
+__device__ __forceinline__ void diag_block(double *__restrict__ Ms, int o, double *__restrict__ W, double *__restrict__ stage /* 2 x 128 */,
+                                           int tid) {
+    const int i = tid >> 4, k = tid & 15;
+    double a = Ms[(o + i) * kLd + o + k];
+    double w = (i == k) ? 1.0 : 0.0;
 #pragma unroll
-    for (int j = 0; j < 16; j++) a[j] = Ms[(o + row) * kLd + o + j];
-    double rinv_own = 0.0;
+    for (int R = 0; R < 4; R++) {
+        const int j0 = 4 * R;
+        double *col = stage + (R & 1) * 128;     // col[row * 4 + m]: raw A[row][j0 + m]
+        double *wrw = col + 64;                  // wrw[m * 16 + c]:  current W[j0 + m][c]
+        if (k >= j0 && k < j0 + 4) col[i * 4 + (k - j0)] = a;
+        if (i >= j0 && i < j0 + 4) wrw[(i - j0) * 16 + k] = w;
+        __syncthreads();
+        // 4x4 pivot block (rows j0..j0+3 of the staged columns), factored by every thread
+        const double p00 = col[(j0 + 0) * 4 + 0];
+        const double p10 = col[(j0 + 1) * 4 + 0], p11 = col[(j0 + 1) * 4 + 1];
+        const double p20 = col[(j0 + 2) * 4 + 0], p21 = col[(j0 + 2) * 4 + 1], p22 = col[(j0 + 2) * 4 + 2];
+        const double p30 = col[(j0 + 3) * 4 + 0], p31 = col[(j0 + 3) * 4 + 1], p32 = col[(j0 + 3) * 4 + 2], p33 = col[(j0 + 3) * 4 + 3];
+        double ri[4];
+        ri[0] = rsqrt_f64(p00);
+        const double l10 = p10 * ri[0], l20 = p20 * ri[0], l30 = p30 * ri[0];
+        ri[1] = rsqrt_f64(p11 - l10 * l10);
+        const double l21 = (p21 - l20 * l10) * ri[1], l31 = (p31 - l30 * l10) * ri[1];
+        ri[2] = rsqrt_f64(p22 - l20 * l20 - l21 * l21);
+        const double l32 = (p32 - l30 * l20 - l31 * l21) * ri[2];
+        ri[3] = rsqrt_f64(p33 - l30 * l30 - l31 * l31 - l32 * l32);   // not positive definite -> NaN -> message stays undefined
+        double li[4], lk[4], wj[4];
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        double x = a[j];
-#pragma unroll
-        for (int k = 0; k < j; k++) x -= l[k] * readlane_f64(l[k], j);
-        const double d = readlane_f64(x, j);
-        const double rinv = 1.0 / sqrt(d);      // not positive definite -> NaN -> the message stays undefined
-        l[j] = x * rinv;                        // row == j: d / sqrt(d) = sqrt(d)
-        if (row == j) rinv_own = rinv;
+        for (int m = 0; m < 4; m++) { li[m] = col[i * 4 + m]; lk[m] = col[k * 4 + m]; wj[m] = wrw[m * 16 + k]; }
+        sub4(li, l10, l20, l21, l30, l31, l32, ri);
+        sub4(lk, l10, l20, l21, l30, l31, l32, ri);
+        sub4(wj, l10, l20, l21, l30, l31, l32, ri);
+        const int n = k - j0, mi = i - j0;
+        if (i >= j0 && k >= j0) {
+            if (n < 4) {
+                const double lin = n == 0 ? li[0] : n == 1 ? li[1] : n == 2 ? li[2] : li[3];
+                a = (i >= k) ? lin : 0.0;
+            } else {
+                a -= li[0] * lk[0] + li[1] * lk[1] + li[2] * lk[2] + li[3] * lk[3];
+            }
+        }
+        if (mi >= 0 && mi < 4) w = mi == 0 ? wj[0] : mi == 1 ? wj[1] : mi == 2 ? wj[2] : wj[3];
+        else if (mi >= 4) w -= li[0] * wj[0] + li[1] * wj[1] + li[2] * wj[2] + li[3] * wj[3];
     }
-    if (lane < 16) {
-#pragma unroll
-        for (int j = 0; j < 16; j++) Ms[(o + row) * kLd + o + j] = (j <= row) ? l[j] : 0.0;
-    }
-    // inverse: lane c computes column c of W = L^-1 by forward substitution; L[i][k] is broadcast from lane i
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        double s = (row == i) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < i; k++) s -= readlane_f64(l[k], i) * w[k];
-        w[i] = s * readlane_f64(rinv_own, i);
-    }
-    if (lane < 16) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) W[i * kLdw + row] = w[i];
-    }
+    Ms[(o + i) * kLd + o + k] = (k <= i) ? a : 0.0;
+    W[i * kLdw + k] = w;
 }
 
 constexpr int kFlagFixed = 1;     // the sender's message is stored (user-set / observed), not a product of others
+
+// LDS carve (doubles): Ms 64x66 | Yt 65x66 (row 64 carries eta, so z = L^-1 eta and eta_out = Yt z fall out of the same
+// MFMA tiles as Yt and Yt Yt') | Ws 4 x 16x18 | eta_out 64.  The fifth tile row of Yt reads 15 rows past Yt's end: they
+// land in Ws/eta_out (finite or not, they only feed output rows that are never used).
+constexpr int kOffYt = kD * kLd;
+constexpr int kOffWs = kOffYt + (kD + 1) * kLd;
+constexpr int kOffEo = kOffWs + 4 * 16 * kLdw;
+constexpr int kOffSt = kOffEo + kD;                 // 2 x 128 staging doubles of diag_block
+constexpr int kLdsDoubles = kOffSt + 256;
+static_assert((kD + 16) * kLd <= (kD + 1) * kLd + 4 * 16 * kLdw + kD, "fifth tile row must stay inside the LDS block");
 
 // MODE 0: factor→variable message of work item (sender slot, sender variable) into out[partner]
 // MODE 1: marginal (mean | covariance) of variable work_vars[w] into out[w]  (P = 0, B = I, C = 0, sign flipped)
@@ -106,10 +157,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_rule64(int nwork, const int32_t *
                                                       const int32_t *__restrict__ spdir, const double *__restrict__ ptab,
                                                       const double *__restrict__ f2v_in, const double *__restrict__ v2f,
                                                       double *__restrict__ out) {
-    __shared__ double Ms[kD * kLd];
-    __shared__ double Yt[kD * kLd];
-    __shared__ double Ws[4 * 16 * kLdw];
-    __shared__ double eta[kD], zz[kD], tmp[16];
+    __shared__ double lds[kLdsDoubles];
+    double *Ms = lds, *Yt = lds + kOffYt, *Ws = lds + kOffWs, *eo = lds + kOffEo, *stage = lds + kOffSt;
     const int w = blockIdx.x;
     if (w >= nwork) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -120,40 +169,49 @@ __global__ __launch_bounds__(kBlock, 2) void k_rule64(int nwork, const int32_t *
     const int base = vbase[v];
     const double *tab = MODE == 0 ? ptab + (int64_t)spdir[slot] * 3 * kD * kD : nullptr;
 
-    // ---- phase 0: M = P + sum of the other incoming Lambdas; Yt = B; eta = sum of the other etas -------------------
-    for (int e = tid; e < kD * kD; e += kBlock) {
-        const int r = e >> 6, c = e & 63;
-        double acc = MODE == 0 ? tab[e] : 0.0;
+    // ---- phase 0: M = P + sum of the other incoming Lambdas; Yt = [B; eta'] ----------------------------------------------
+    // 16 elements per thread, every message read with 16 independent unit-stride loads in flight per lane
+    {
+        double acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = MODE == 0 ? tab[tid + kBlock * i] : 0.0;
+        double ea = 0.0;
         if (flags & kFlagFixed) {
-            acc += v2f[(int64_t)slot * kMsg + kD + e];
+            const double *src = v2f + (int64_t)slot * kMsg;
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[i] += src[kD + tid + kBlock * i];
+            if (tid < kD) ea = src[tid];
         } else {
-            for (int j = 0; j < deg; j++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {       // all (<= 3) other messages in flight together
                 const int sj = base + j * kBlock;
-                if (sj != slot) acc += f2v_in[(int64_t)sj * kMsg + kD + e];
+                if (j >= deg || sj == slot) continue;
+                const double *src = f2v_in + (int64_t)sj * kMsg;
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[i] += src[kD + tid + kBlock * i];
+                if (tid < kD) ea += src[tid];
             }
         }
-        Ms[r * kLd + c] = acc;
-        Yt[r * kLd + c] = MODE == 0 ? tab[kD * kD + e] : (r == c ? 1.0 : 0.0);
-    }
-    if (tid < kD) {
-        double acc = 0.0;
-        if (flags & kFlagFixed) {
-            acc = v2f[(int64_t)slot * kMsg + tid];
-        } else {
-            for (int j = 0; j < deg; j++) {
-                const int sj = base + j * kBlock;
-                if (sj != slot) acc += f2v_in[(int64_t)sj * kMsg + tid];
-            }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int e = tid + kBlock * i;
+            Ms[(e >> 6) * kLd + (e & 63)] = acc[i];
         }
-        eta[tid] = acc;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int e = tid + kBlock * i;
+            Yt[(e >> 6) * kLd + (e & 63)] = MODE == 0 ? tab[kD * kD + e] : ((e >> 6) == (e & 63) ? 1.0 : 0.0);
+        }
+        if (tid < kD) Yt[kD * kLd + tid] = ea;
     }
     __syncthreads();
     if (__builtin_isnan(Ms[0])) return;   // a dependency is undefined (whole messages are NaN together): not pending
 
     // ---- blocked Cholesky, NB = 16: Ms lower triangle <- L, Ws[kb] <- L_kk^-1 ---------------------------------------
+#pragma unroll
     for (int kb = 0; kb < 4; kb++) {
         const int o = kb * 16;
-        if (wave == 0) diag_block(Ms, o, Ws + kb * 16 * kLdw, lane);
+        diag_block(Ms, o, Ws + kb * 16 * kLdw, stage, tid);
         __syncthreads();
         // panel: L21 = A21 * W', one 16x16 tile per wave
         const int tr = kb + 1 + wave;
@@ -177,63 +235,70 @@ __global__ __launch_bounds__(kBlock, 2) void k_rule64(int nwork, const int32_t *
         __syncthreads();
     }
 
-    // ---- z = L^-1 eta (wave 0, blocked) --------------------------------------------------------------------------------
-    if (wave == 0) {
-        for (int ib = 0; ib < 4; ib++) {
-            const int r = lane & 15;
-            double s = eta[ib * 16 + r];
-            for (int k = 0; k < ib * 16; k++) s -= Ms[(ib * 16 + r) * kLd + k] * zz[k];
-            if (lane < 16) tmp[r] = s;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            double zi = 0.0;
-            for (int c = 0; c < 16; c++) zi += Ws[ib * 16 * kLdw + r * kLdw + c] * tmp[c];
-            if (lane < 16) zz[ib * 16 + r] = zi;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-
-    // ---- Yt = B L^-T, block column by block column; wave = tile row of Yt -------------------------------------------------
-    for (int ib = 0; ib < 4; ib++) {
-        d4 tq = tile_load(Yt, kLd, wave * 16, ib * 16, lane);
-        if (ib > 0) {
-            d4 p = {0.0, 0.0, 0.0, 0.0};
-            p = mfma_xzt(Yt, kLd, wave * 16, 0, Ms, kLd, ib * 16, 0, 4 * ib, p, lane);   // sum_{k < 16 ib} Yt[c][k] L[r][k]
+    // ---- [Yt; z'] = [B; eta'] L^-T, block column by block column; wave w owns tile row w, wave 0 also the eta row ----------
+    const int nrows = wave == 0 ? 2 : 1;          // tile rows of this wave: wave, and 4 for wave 0
 #pragma unroll
-            for (int r = 0; r < 4; r++) tq[r] -= p[r];
+    for (int ib = 0; ib < 4; ib++) {
+        for (int q = 0; q < nrows; q++) {
+            const int tr = q == 0 ? wave : 4;
+            d4 tq = tile_load(Yt, kLd, tr * 16, ib * 16, lane);
+            if (ib > 0) {
+                d4 p = {0.0, 0.0, 0.0, 0.0};
+                p = mfma_xzt(Yt, kLd, tr * 16, 0, Ms, kLd, ib * 16, 0, 4 * ib, p, lane);   // sum_{k < 16 ib} Yt[c][k] L[r][k]
+#pragma unroll
+                for (int r = 0; r < 4; r++) tq[r] -= p[r];
+                tile_store_rows(Yt, kLd, tr * 16, ib * 16, tq, lane, tr == 4 ? 1 : 16);
+            }
         }
-        tile_store(Yt, kLd, wave * 16, ib * 16, tq, lane);
         __syncthreads();
-        d4 y = {0.0, 0.0, 0.0, 0.0};
-        y = mfma_xzt(Yt, kLd, wave * 16, ib * 16, Ws + ib * 16 * kLdw, kLdw, 0, 0, 4, y, lane);   // (rhs tile) * W_ii'
+        d4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+        y0 = mfma_xzt(Yt, kLd, wave * 16, ib * 16, Ws + ib * 16 * kLdw, kLdw, 0, 0, 4, y0, lane);   // (rhs tile) * W_ii'
+        if (wave == 0) y1 = mfma_xzt(Yt, kLd, 4 * 16, ib * 16, Ws + ib * 16 * kLdw, kLdw, 0, 0, 4, y1, lane);
         __syncthreads();
-        tile_store(Yt, kLd, wave * 16, ib * 16, y, lane);
+        tile_store_rows(Yt, kLd, wave * 16, ib * 16, y0, lane, 16);
+        if (wave == 0) tile_store_rows(Yt, kLd, 4 * 16, ib * 16, y1, lane, 1);
         __syncthreads();
     }
 
-    // ---- G = Yt Yt' into Ms (free now); eta_out = Yt z --------------------------------------------------------------------
-    for (int tj = 0; tj < 4; tj++) {
-        d4 g = {0.0, 0.0, 0.0, 0.0};
-        g = mfma_xzt(Yt, kLd, wave * 16, 0, Yt, kLd, tj * 16, 0, 16, g, lane);
-        tile_store(Ms, kLd, wave * 16, tj * 16, g, lane);
-    }
-    if (tid < kD) {
-        double s = 0.0;
-        for (int k = 0; k < kD; k++) s += Yt[tid * kLd + k] * zz[k];
-        eta[tid] = s;
+    // ---- G = Yt Yt' into Ms (free now); eta_out = Yt z is the 65th column of the same product --------------------------------
+    // C is fetched now, before the MFMA phase: on gfx950 vmcnt retires loads and stores in issue order, so a load issued
+    // after this kernel's own output stores would wait for them (that mistake cost 40 % of the kernel's time).
+    double creg[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) creg[i] = MODE == 0 ? tab[2 * kD * kD + tid + kBlock * i] : 0.0;
+    {
+        // five accumulators share the A operand (this wave's 16 rows of Yt): 6 LDS reads per 5 MFMA, independent chains
+        d4 g[5];
+#pragma unroll
+        for (int tj = 0; tj < 5; tj++) g[tj] = d4{0.0, 0.0, 0.0, 0.0};
+        const int r = lane & 15, kk = lane >> 4;
+#pragma unroll
+        for (int s4 = 0; s4 < 16; s4++) {
+            const double av = Yt[(wave * 16 + r) * kLd + 4 * s4 + kk];
+#pragma unroll
+            for (int tj = 0; tj < 5; tj++)
+                g[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Yt[(tj * 16 + r) * kLd + 4 * s4 + kk], g[tj], 0, 0, 0);
+        }
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++) tile_store(Ms, kLd, wave * 16, tj * 16, g[tj], lane);
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) eo[wave * 16 + (lane >> 4) + 4 * rr] = g[4][rr];
+        }
     }
     __syncthreads();
-    if (__builtin_isnan(Ms[0]) || __builtin_isnan(eta[0])) return;   // not positive definite: leave the old value
+    if (__builtin_isnan(Ms[0]) || __builtin_isnan(eo[0])) return;   // not positive definite: leave the old value
 
     // ---- store --------------------------------------------------------------------------------------------------------------
     const int64_t dst = MODE == 0 ? (int64_t)partner[slot] * kMsg : (int64_t)w * kMsg;
-    for (int e = tid; e < kD * kD; e += kBlock) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int e = tid + kBlock * i;
         const int r = e >> 6, c = e & 63;
-        const double g = 0.5 * (Ms[r * kLd + c] + Ms[c * kLd + r]);
-        out[dst + kD + e] = MODE == 0 ? tab[2 * kD * kD + e] - g : g;
+        const double g = Ms[r * kLd + c];   // Yt Yt' is bitwise symmetric: (i,j) and (j,i) sum the same products in the same order
+        out[dst + kD + e] = MODE == 0 ? creg[i] - g : g;
     }
-    if (tid < kD) out[dst + tid] = eta[tid];
+    if (tid < kD) out[dst + tid] = eo[tid];
 }
 
 // observed senders: Lambda_out = C, eta_out = B y  (one workgroup per message; pure streaming)
