@@ -130,3 +130,97 @@ def test_errors_are_statuses_not_crashes(hip_lib):
     with pytest.raises(cx.CortexHipError) as e:
         dev.update_batch([3], [1], [1])  # ProductOfMessages: no device rule (reference default: error(...))
     assert e.value.code == L.ERR_UNSUPPORTED
+
+
+def _random_pairwise_graph(rng, n_var, n_pair, hubs=()):
+    """variables 1..n_var with a unary prior each, random pairwise factors, plus hub variables of given degrees."""
+    ev, ef, fids, kinds, fq = [], [], [], [], []
+    nid = n_var
+    prior_var, prior_fac = [], []
+    for v in range(1, n_var + 1):
+        nid += 1
+        ev.append(v); ef.append(nid); fids.append(nid); kinds.append(L.FACTOR_OPAQUE); fq.append(1.0)
+        prior_var.append(v); prior_fac.append(nid)
+    pairs = set()
+    while len(pairs) < n_pair:
+        a, b = rng.integers(1, n_var + 1, 2)
+        if a != b:
+            pairs.add((int(min(a, b)), int(max(a, b))))
+    for hub, deg in hubs:
+        others = rng.choice(np.setdiff1d(np.arange(1, n_var + 1), [hub]), size=deg, replace=False)
+        for o in others:
+            pairs.add((int(min(hub, o)), int(max(hub, o))))
+    for a, b in sorted(pairs):
+        nid += 1
+        ev += [a, b]; ef += [nid, nid]; fids.append(nid); kinds.append(L.FACTOR_GAUSS_ADDITIVE); fq.append(float(rng.uniform(0.5, 2.0)))
+    pm, pv = rng.standard_normal(n_var), rng.uniform(0.5, 2.0, n_var)
+    return cx.synth.Model(edge_var=np.array(ev), edge_fac=np.array(ef), factor_ids=np.array(fids),
+                          factor_kind=np.array(kinds, dtype=np.int32), factor_var=np.array(fq), x_ids=np.arange(1, n_var + 1),
+                          prior_var=np.array(prior_var), prior_fac=np.array(prior_fac), prior_mean=pm, prior_variance=pv)
+
+
+@pytest.mark.parametrize("schedule,materialize", SCHEDULES)
+def test_ragged_degrees_and_high_degree_variables(hip_lib, schedule, materialize):
+    """degrees 1..8 take the SELL path, hubs of degree 9, 40, 300 and 1500 the wave-per-variable scans
+    (the device analogue of the reference's segment tree, dependencies.jl:90-173)."""
+    rng = np.random.default_rng(42)
+    model = _random_pairwise_graph(rng, 2000, 2500, hubs=[(7, 9), (300, 40), (999, 300), (1500, 1500)])
+    dev = _device(model, schedule, seed_variance=50.0, materialize=materialize)
+    g = flood_oracle_from_model(model, seed_variance=50.0)
+    assert dev.stats()["n_big_variables"] >= 4
+    for sweep in range(5):
+        dev.sweep(1)
+        assert g.sweep(1) == dev.stats()["n_messages_per_sweep"]
+        _compare_messages(dev, g, f"ragged sweep {sweep}")
+    dev.sweep(1)
+    marg = dev.get_marginals(model.x_ids)
+    m, v = g.marginals()
+    assert_close(marg[:, 0], m, RTOL, "ragged marginal mean")
+    assert_close(marg[:, 1], v, RTOL, "ragged marginal variance")
+
+
+def test_empty_batches_and_lists_are_noops(hip_lib):
+    model = cx.synth.ssm_chain(6)
+    dev = _device(model, L.SCHED_FUSED)
+    dev.update_batch([], [], [])
+    dev.set_messages([], [], L.TO_FACTOR, L.FORM_POINT, [])
+    assert dev.get_messages([], [], L.TO_VARIABLE).shape == (0, 2)
+    assert dev.get_marginals([]).shape == (0, 2)
+    dev.sweep(0)
+    assert dev.stats()["sweeps_done"] == 0
+
+
+def test_config_c4_full_size(hip_lib):
+    """BASELINE.json's metric config: the 10,005,465-edge Gaussian grid, at full size.
+    (i) three sweeps against the CPU checker on 300k sampled messages and all marginals;
+    (ii) size-independent property: at convergence the BP means solve J m = h of the grid's precision matrix."""
+    N = 1415
+    model = cx.synth.gaussian_grid(N, N, seed=1234)
+    assert model.n_edges == 10_005_465
+    dev = _device(model, L.SCHED_FUSED, seed_variance=1e6)
+    st = dev.stats()
+    assert st["n_edges"] == 10_005_465 and st["n_messages_per_sweep"] == 16_006_480
+    g = flood_oracle_from_model(model, seed_variance=1e6)
+    dev.sweep(3)
+    assert g.sweep(3, use_omp=True) == 3 * 16_006_480
+    rng = np.random.default_rng(0)
+    pick = rng.choice(np.flatnonzero(g.partner >= 0), size=300_000, replace=False)
+    got = dev.get_messages(g.edge_var[pick], g.edge_fac[pick], L.TO_VARIABLE)
+    assert_close(got[:, 0], g.f2v_m[pick], RTOL, "C4 f2v mean (sampled)")
+    assert_close(got[:, 1], g.f2v_v[pick], RTOL, "C4 f2v variance (sampled)")
+    dev.sweep(1)
+    marg = dev.get_marginals(model.x_ids)
+    m, v = g.marginals(use_omp=True)
+    assert_close(marg[:, 0], m, RTOL, "C4 marginal mean")
+    assert_close(marg[:, 1], v, RTOL, "C4 marginal variance")
+    dev.residual()
+    for _ in range(12):
+        dev.sweep(100)
+        if dev.residual() < 1e-12:
+            break
+    dev.sweep(1)
+    marg = dev.get_marginals(model.x_ids)
+    J = exact.grid_precision(N, N, model.meta["r"], model.meta["qh"], model.meta["qv"])
+    h = (model.meta["y"] / model.meta["r"]).ravel()
+    resid = np.abs(J @ marg[:, 0] - h).max() / np.abs(h).max()
+    assert resid < 1e-9, f"converged BP means do not solve the normal equations: relative residual {resid:.2e}"
