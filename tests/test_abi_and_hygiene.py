@@ -77,3 +77,37 @@ def test_product_never_touches_the_oracle():
     assert uses and all(bench.index("def cpu_baseline") < u < bench.index("def main") for u in uses), \
         "bench.py may use the checker only inside cpu_baseline()"
     assert "oracle" in body
+
+
+def test_header_compiles_as_plain_c_and_the_c_client_links(hip_lib, tmp_path):
+    """include/cortex_hip.h is a C header (no C++/torch types) and the C client of tests/c links against the library."""
+    import subprocess
+
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(ROOT, "cortex.jl_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", exe, "-L" + libdir, "-lcortex_hip",
+                           "-Wl,-rpath," + libdir])
+    import torch
+    if not torch.cuda.is_available():
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 77 and "no CPU fallback" in out.stderr   # fails loudly without a GPU
+
+
+def test_oracle_under_address_and_ub_sanitizers(tmp_path):
+    """CPU sanitizers on the checker (GPU ASan is not available on this pool): rebuild oracle/*.c with
+    -fsanitize=address,undefined and run a representative slice of the known-answer tests against that build."""
+    import subprocess
+    import sys
+
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "asan"])
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    env = dict(os.environ, LD_PRELOAD=asan, CXO_LIB=os.path.join(ROOT, "oracle", "libcortex_oracle_asan.so"),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    code = ("import sys; sys.path.insert(0, %r); import pytest; "
+            "sys.exit(pytest.main(['-x', '-q', '-p', 'no:cacheprovider', %r, '-k', "
+            "'oracle and (beta or ssm or tracing or nibble or scan or chain)']))") % (
+        ROOT, os.path.join(ROOT, "tests", "test_oracle_reference_kats.py"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr
