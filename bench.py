@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--grid", type=int, default=1415, help="N: each rank holds an N x N grid strip (1415 -> 10,005,465 edges)")
     ap.add_argument("--schedule", choices=["flooding", "fused"], default=os.environ.get("CX_BENCH_SCHEDULE", "fused"))
     ap.add_argument("--materialize", action="store_true", help="also store every variable→factor message each sweep")
+    ap.add_argument("--halo", choices=["rccl", "torch"], default=os.environ.get("CX_HALO", "rccl"),
+                    help="N > 1: exchange issued by the library on RCCL (default) or by torch.distributed isend/irecv")
+    ap.add_argument("--self-halo", action="store_true",
+                    help="N = 1 experiment: a cylinder whose wrap-around cut makes rank 0 its own halo neighbour")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-grid", type=int, default=768, help="grid side of the bounded CPU sample")
     ap.add_argument("--seed", type=int, default=1234)
@@ -102,16 +106,30 @@ def main():
     stream = torch.cuda.current_stream()
     dev.set_stream(stream.cuda_stream)
 
-    if world == 1:
+    halo_kind = None
+    if world == 1 and not args.self_halo:
         model = cx.synth.gaussian_grid(N, N, seed=args.seed)
         cx.synth.load_into_device(model, dev, seed_variance=1e6)
         exchange = None
     else:
         from cortex.jl_amd import partition
-        part = partition.grid_strip(N, N, rank, world, seed=args.seed)
+        if world == 1:
+            part, _wrap = partition.cylinder_self(N, N, seed=args.seed)
+        else:
+            part = partition.grid_strip(N, N, rank, world, seed=args.seed)
         cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
-        sweeper = partition.DeviceSweeper(dev, part, torch, torch.device("cuda", local_rank))
-        exchange = partition.HaloExchange(sweeper, part, dist)
+        exchange = None
+        if args.halo == "rccl":
+            try:
+                exchange = partition.RcclExchange(dev, part, dist, torch, torch.device("cuda", local_rank))
+                halo_kind = "rccl send/recv issued by the library"
+            except cx.CortexHipError as e:   # e.g. librccl not loadable: fall back to torch.distributed
+                if rank == 0:
+                    print(f"[bench] RCCL exchange unavailable ({e}); falling back to torch.distributed", file=sys.stderr)
+        if exchange is None:
+            sweeper = partition.DeviceSweeper(dev, part, torch, torch.device("cuda", local_rank))
+            exchange = partition.HaloExchange(sweeper, part, dist)
+            halo_kind = "torch.distributed isend/irecv"
     st = dev.stats()
     updates_per_step = st["n_messages_per_sweep"]
 
@@ -173,7 +191,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"C4: {N}x{N} 2-D Gaussian grid loopy BP per GPU ({st['n_edges']} bipartite edges, "
                                    f"{updates_per_step} directed message updates + {st['n_variables']} marginals per sweep)",
-                       "schedule": args.schedule + ("" if world == 1 else "+halo(send/recv per sweep)"), "partition": f"{world} row strips",
+                       "schedule": args.schedule + ("" if halo_kind is None else f" + halo per sweep ({halo_kind})"), "partition": f"{world} row strips",
                        "seed": args.seed},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": dom_ms / dom_n,

@@ -71,6 +71,10 @@ SIGNATURES = {
     "cx_sweep_begin": (_i32, [_vp]),
     "cx_sweep_main": (_i32, [_vp]),
     "cx_sweep_end": (_i32, [_vp]),
+    "cx_comm_unique_id": (_i32, [_vp]),
+    "cx_comm_init": (_i32, [_vp, _i32, _i32, _vp]),
+    "cx_halo_peers": (_i32, [_vp, _i32, _pi32, _pi64, _pi64, _pi64, _pi64]),
+    "cx_sweep_exchange": (_i32, [_vp, _i32]),
     "cx_profile_enable": (_i32, [_vp, _i32]),
     "cx_profile_read": (_i32, [_vp, _i32, _pd, _pi64]),
     "cx_kernel_name": (C.c_char_p, [_i32]),

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcortex_hip.so")
-SOURCES = ["cx_api.hip", "cx_kernels.hip", "cx_chain.hip", "cx_mv.hip", "cx_mv64.hip"]
+SOURCES = ["cx_api.hip", "cx_kernels.hip", "cx_chain.hip", "cx_mv.hip", "cx_mv64.hip", "cx_comm.hip"]
 HEADERS = [os.path.join(CSRC, "cx_internal.h"), os.path.join(ROOT, "include", "cortex_hip.h")]
 
 
@@ -36,7 +36,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-I/opt/rocm/include", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -185,6 +185,7 @@ int32_t cx_destroy(cx_handle *h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     for (auto &r : h->recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+    cx::comm_destroy(h);
     dev_free_all(h);
     delete h;
     return CX_OK;
@@ -1056,9 +1057,7 @@ int32_t cx_sweep_begin(cx_handle *h) {
     CX_REQUIRE(h, h->cfg.dim == 1, CX_ERR_UNSUPPORTED, "cx_sweep_begin: partitioned sweeps are implemented for dim == 1 only in this build");
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_sweep_begin: previous sweep not ended");
     CX_REQUIRE(h, h->cfg.schedule != CX_SCHED_CHAIN_SCAN, CX_ERR_UNSUPPORTED, "cx_sweep_begin: the chain-scan schedule is not partitioned in this build");
-    const int64_t ns = (int64_t)h->send_slots.size();
-    cx::launch_v2f_slots(h, h->d_send_slots, h->d_send_vars, ns, h->d_f2v, CX_KERNEL_HALO_BEGIN);
-    cx::launch_gather(h, h->d_v2f, h->d_send_slots, h->d_send_buf, ns);
+    cx::launch_halo_export(h, h->d_f2v, h->stream);
     CX_HIP(h, hipGetLastError());
     h->in_sweep = true;
     return CX_OK;
@@ -1073,10 +1072,7 @@ int32_t cx_sweep_main(cx_handle *h) {
 
 int32_t cx_sweep_end(cx_handle *h) {
     CX_REQUIRE(h, h && h->has_graph && h->in_sweep, CX_ERR_STATE, "cx_sweep_end: call cx_sweep_begin first");
-    const int64_t nr = (int64_t)h->recv_slots.size();
-    cx::launch_scatter(h, h->d_v2f, h->d_recv_slots, h->d_recv_buf, nr);
-    if (h->cfg.schedule == CX_SCHED_FUSED)
-        cx::launch_push_slots(h, h->d_recv_slots, nr, h->d_f2v_alt, CX_KERNEL_HALO_END);
+    cx::launch_halo_import(h, h->d_f2v_alt, h->cfg.schedule == CX_SCHED_FUSED);
     sweep_finish(h);
     CX_HIP(h, hipGetLastError());
     h->in_sweep = false;
@@ -1156,6 +1152,70 @@ int32_t cx_halo_set_buffers(cx_handle *h, void *send_ptr, void *recv_ptr) {
     if (!h->ext_halo_buffers) { if (h->d_send_buf) (void)hipFree(h->d_send_buf); if (h->d_recv_buf) (void)hipFree(h->d_recv_buf); }
     h->d_send_buf = (double2 *)send_ptr; h->d_recv_buf = (double2 *)recv_ptr;
     h->ext_halo_buffers = true;
+    return CX_OK;
+}
+
+// ---- RCCL exchange issued by the library ----------------------------------------------------------------------------
+int32_t cx_comm_unique_id(void *out128) {
+    if (!out128) return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_comm_unique_id: null buffer");
+    std::string err;
+    if (!cx::comm_unique_id(out128, err)) return fail(nullptr, CX_ERR_DEVICE, "cx_comm_unique_id: " + err);
+    return CX_OK;
+}
+
+int32_t cx_comm_init(cx_handle *h, int32_t world, int32_t rank, const void *id128) {
+    CX_REQUIRE(h, h, CX_ERR_INVALID_ARGUMENT, "null handle");
+    CX_REQUIRE(h, id128 && world >= 1 && rank >= 0 && rank < world, CX_ERR_INVALID_ARGUMENT, "cx_comm_init: bad world / rank / id");
+    CX_REQUIRE(h, !h->comm, CX_ERR_STATE, "cx_comm_init: communicator already initialised");
+    CX_HIP(h, hipSetDevice(h->cfg.device));
+    std::string err;
+    if (!cx::comm_init(h, world, rank, id128, err)) return fail(h, CX_ERR_DEVICE, "cx_comm_init: " + err);
+    return CX_OK;
+}
+
+int32_t cx_halo_peers(cx_handle *h, int32_t n_peers, const int32_t *peer_rank, const int64_t *send_offset, const int64_t *send_count,
+                      const int64_t *recv_offset, const int64_t *recv_count) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_peers: no graph");
+    CX_REQUIRE(h, n_peers >= 0 && (n_peers == 0 || (peer_rank && send_offset && send_count && recv_offset && recv_count)),
+               CX_ERR_INVALID_ARGUMENT, "cx_halo_peers: null argument");
+    std::vector<cx_handle::Peer> peers;
+    for (int32_t i = 0; i < n_peers; i++) {
+        cx_handle::Peer p{peer_rank[i], send_offset[i], send_count[i], recv_offset[i], recv_count[i]};
+        if (p.send_off < 0 || p.send_count < 0 || p.send_off + p.send_count > (int64_t)h->send_slots.size() || p.recv_off < 0 ||
+            p.recv_count < 0 || p.recv_off + p.recv_count > (int64_t)h->recv_slots.size())
+            return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_halo_peers: segment outside the halo lists of cx_halo_configure");
+        peers.push_back(p);
+    }
+    h->peers.swap(peers);
+    return CX_OK;
+}
+
+int32_t cx_sweep_exchange(cx_handle *h, int32_t n_sweeps) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep_exchange: no graph");
+    CX_REQUIRE(h, n_sweeps >= 0, CX_ERR_INVALID_ARGUMENT, "cx_sweep_exchange: n_sweeps < 0");
+    CX_REQUIRE(h, h->comm || h->peers.empty(), CX_ERR_STATE, "cx_sweep_exchange: call cx_comm_init first");
+    for (auto &p : h->peers)
+        CX_REQUIRE(h, p.rank >= 0 && p.rank < h->comm_world, CX_ERR_INVALID_ARGUMENT, "cx_sweep_exchange: bad peer rank");   // a rank may be its own neighbour (periodic cut)
+    CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_sweep_exchange: a cx_sweep_begin is still open");
+    CX_REQUIRE(h, h->cfg.dim == 1 && h->cfg.schedule != CX_SCHED_CHAIN_SCAN, CX_ERR_UNSUPPORTED, "cx_sweep_exchange: scalar fused / flooding schedules only");
+    const bool overlap = !h->peers.empty();
+    for (int32_t s = 0; s < n_sweeps; s++) {
+        // The export reads the same input buffer as the main kernel and writes only the send buffer, so it runs on the
+        // communication stream, beside the main kernel:   comm: [wait swept] export, group{send, recv}, record recv
+        //                                                  main: main kernel, [wait recv] import+push, record swept
+        if (overlap) {
+            CX_HIP(h, hipEventRecord(h->ev_swept, h->stream));
+            CX_HIP(h, hipStreamWaitEvent(h->comm_stream, h->ev_swept, 0));
+            cx::launch_halo_export(h, h->d_f2v, h->comm_stream);
+            std::string err;
+            if (!cx::comm_exchange(h, err, true)) return fail(h, CX_ERR_DEVICE, "cx_sweep_exchange: " + err);
+        }
+        sweep_main(h, true);
+        if (overlap) CX_HIP(h, hipStreamWaitEvent(h->stream, h->ev_recv, 0));
+        cx::launch_halo_import(h, h->d_f2v_alt, h->cfg.schedule == CX_SCHED_FUSED);
+        sweep_finish(h);
+        CX_HIP(h, hipGetLastError());
+    }
     return CX_OK;
 }
 

@@ -96,6 +96,13 @@ struct cx_handle {
     int32_t *d_send_slots = nullptr, *d_recv_slots = nullptr, *d_send_vars = nullptr;
     double2 *d_send_buf = nullptr, *d_recv_buf = nullptr;
     bool ext_halo_buffers = false;
+    // RCCL exchange issued by the library (cx_comm.hip)
+    struct Peer { int rank; int64_t send_off, send_count, recv_off, recv_count; };
+    std::vector<Peer> peers;
+    void *comm = nullptr;            // ncclComm_t
+    int comm_world = 0, comm_rank = -1;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_recv = nullptr, ev_swept = nullptr;
     bool in_sweep = false;
     bool v2f_stale = false;          // fused schedule without materialisation: v2f must be recomputed before use
 
@@ -105,6 +112,7 @@ struct cx_handle {
 
     // profiling
     bool profiling = false, prof_armed = false;
+    hipStream_t prof_stream = nullptr;
     int prof_stride = 1;
     int64_t prof_count[CX_KERNEL_COUNT] = {0};
     std::vector<cx::ProfileRec> recs;
@@ -126,6 +134,8 @@ void launch_big_var_to_factor(cx_handle *h, const double2 *f2v, bool write_marg)
 void launch_factor_to_var(cx_handle *h, const double2 *v2f, double2 *f2v);
 void launch_push_slots(cx_handle *h, const int32_t *d_slots, int64_t n, double2 *f2v_out, int kernel_id);
 void launch_v2f_slots(cx_handle *h, const int32_t *d_slots, const int32_t *d_vars, int64_t n, const double2 *f2v, int kernel_id);
+void launch_halo_export(cx_handle *h, const double2 *f2v, hipStream_t stream);
+void launch_halo_import(cx_handle *h, double2 *f2v_out, bool push);
 void launch_batch(cx_handle *h, const int32_t *d_kind, const int32_t *d_index, const int32_t *d_var, int64_t n);
 void launch_scatter(cx_handle *h, double2 *dst, const int32_t *d_idx, const double2 *d_val, int64_t n);
 void launch_gather(cx_handle *h, const double2 *src, const int32_t *d_idx, double2 *d_val, int64_t n);
@@ -152,5 +162,10 @@ void mv64_rows_gather(cx_handle *h, const double *src, const int32_t *d_idx, dou
 void mv64_set_point(cx_handle *h, double *dst, const int32_t *d_idx, const double *d_y, int64_t n);
 bool mv_rule_tables(int d, const double *A, const double *Q, double *out);
 size_t chain_total_bytes(int64_t nlinks);
+// RCCL halo exchange (cx_comm.hip)
+bool comm_unique_id(void *out128, std::string &err);
+bool comm_init(cx_handle *h, int world, int rank, const void *id128, std::string &err);
+void comm_destroy(cx_handle *h);
+bool comm_exchange(cx_handle *h, std::string &err, bool packed_on_comm_stream);
 
 }  // namespace cx

@@ -258,6 +258,35 @@ __global__ __launch_bounds__(kBlock) void k_v2f_slots(const int32_t *__restrict_
     m2f_one(slots[i], vars[i], vbase, vdeg, vinfo, f2v, v2f);
 }
 
+// halo export: variable→factor of the exported slots, computed straight into the send buffer (and into v2f)
+__global__ __launch_bounds__(kBlock) void k_halo_export(const int32_t *__restrict__ slots, const int32_t *__restrict__ vars, int64_t n,
+                                                        const int32_t *__restrict__ vbase, const int32_t *__restrict__ vdeg,
+                                                        const uint8_t *__restrict__ vinfo, const double2 *__restrict__ f2v,
+                                                        double2 *__restrict__ v2f, double2 *__restrict__ send) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int slot = slots[i];
+    m2f_one(slot, vars[i], vbase, vdeg, vinfo, f2v, v2f);
+    send[i] = v2f[slot];   // same thread wrote it (or it keeps its stored value: fixed / not yet defined)
+}
+
+// halo import: received messages become the ghost variables' variable→factor messages and go through the cut factors
+template <bool LINEAR, bool PUSH>
+__global__ __launch_bounds__(kBlock) void k_halo_import(const int32_t *__restrict__ slots, int64_t n, const double2 *__restrict__ recv,
+                                                        const int32_t *__restrict__ partner, const double *__restrict__ sq,
+                                                        const double *__restrict__ sa, const double *__restrict__ sb,
+                                                        double2 *__restrict__ v2f, double2 *__restrict__ f2v_out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int e = slots[i];
+    const double2 o = recv[i];
+    v2f[e] = o;
+    if (!PUSH) return;
+    const int p = partner[e];
+    if (p < 0 || __builtin_isnan(o.y)) return;
+    f2v_out[p] = factor_rule<LINEAR>(o, sq[e], LINEAR ? sa[e] : 1.0, LINEAR ? sb[e] : 0.0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Batched mode: one thread per enqueued signal (the processor's `process!` override flushes a batch of
 // mutually independent pending signals; inference_engine.jl:528-537 is the precedent for collecting).
@@ -335,7 +364,9 @@ __global__ __launch_bounds__(kBlock) void k_residual(const double2 *__restrict__
 // ------------------------------------------------------------------------------------------------ launchers
 // hipEvent pair around a launch.  Every event is a barrier packet on the queue, so with a stride > 1 only every
 // stride-th launch of a kernel is bracketed and the others dispatch back to back.
-static inline void prof_begin(cx_handle *h, int kernel) {
+static inline void prof_begin(cx_handle *h, int kernel, hipStream_t stream = nullptr) {
+    if (!stream) stream = h->stream;
+    h->prof_stream = stream;
     h->prof_armed = false;
     if (!h->profiling) return;
     if ((h->prof_count[kernel]++ % h->prof_stride) != 0) return;
@@ -344,12 +375,12 @@ static inline void prof_begin(cx_handle *h, int kernel) {
     r.kernel = kernel;
     (void)hipEventCreate(&r.start);
     (void)hipEventCreate(&r.stop);
-    (void)hipEventRecord(r.start, h->stream);
+    (void)hipEventRecord(r.start, stream);
     h->recs.push_back(r);
 }
 static inline void prof_end(cx_handle *h) {
     if (!h->profiling || !h->prof_armed) return;
-    (void)hipEventRecord(h->recs.back().stop, h->stream);
+    (void)hipEventRecord(h->recs.back().stop, h->prof_stream);
 }
 
 template <bool LINEAR, bool STORE, bool PUSH>
@@ -424,6 +455,28 @@ void launch_v2f_slots(cx_handle *h, const int32_t *d_slots, const int32_t *d_var
     prof_begin(h, kernel_id);
     hipLaunchKernelGGL(k_v2f_slots, dim3(nb), dim3(kBlock), 0, h->stream, d_slots, d_vars, n, h->d_vbase, h->d_var_deg, h->d_vinfo,
                        f2v, h->d_v2f);
+    prof_end(h);
+}
+
+void launch_halo_export(cx_handle *h, const double2 *f2v, hipStream_t stream) {
+    const int64_t n = (int64_t)h->send_slots.size();
+    if (n == 0) return;
+    prof_begin(h, CX_KERNEL_HALO_BEGIN, stream);
+    hipLaunchKernelGGL(k_halo_export, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, h->d_send_slots, h->d_send_vars, n,
+                       h->d_vbase, h->d_var_deg, h->d_vinfo, f2v, h->d_v2f, h->d_send_buf);
+    prof_end(h);
+}
+
+void launch_halo_import(cx_handle *h, double2 *f2v_out, bool push) {
+    const int64_t n = (int64_t)h->recv_slots.size();
+    if (n == 0) return;
+    const double *sq = h->any_linear ? h->d_sq : h->d_q;
+    const dim3 g((unsigned)((n + kBlock - 1) / kBlock)), b(kBlock);
+    prof_begin(h, CX_KERNEL_HALO_END);
+#define CX_IMP(LIN, PU) hipLaunchKernelGGL((k_halo_import<LIN, PU>), g, b, 0, h->stream, h->d_recv_slots, n, h->d_recv_buf, h->d_partner, sq, h->d_sa, h->d_sb, h->d_v2f, f2v_out)
+    if (h->any_linear) { if (push) CX_IMP(true, true); else CX_IMP(true, false); }
+    else { if (push) CX_IMP(false, true); else CX_IMP(false, false); }
+#undef CX_IMP
     prof_end(h);
 }
 

@@ -162,6 +162,28 @@ class DeviceGraph:
     def halo_set_buffers(self, send_ptr: int, recv_ptr: int):
         self._check(self.lib.cx_halo_set_buffers(self.h, C.c_void_p(send_ptr or 0), C.c_void_p(recv_ptr or 0)))
 
+    # -- RCCL exchange issued by the library -------------------------------------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = self.lib.cx_comm_unique_id(buf)
+        if rc != L.OK:
+            raise L.CortexHipError(rc, self.lib.cx_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, world: int, rank: int, unique_id: bytes):
+        assert len(unique_id) == 128
+        self._check(self.lib.cx_comm_init(self.h, world, rank, C.c_char_p(unique_id)))
+
+    def halo_peers(self, peers):
+        """peers: iterable of (rank, send_offset, send_count, recv_offset, recv_count), in messages."""
+        peers = list(peers)
+        r = np.ascontiguousarray([p[0] for p in peers], dtype=np.int32)
+        cols = [np.ascontiguousarray([p[k] for p in peers], dtype=np.int64) for k in (1, 2, 3, 4)]
+        self._check(self.lib.cx_halo_peers(self.h, len(peers), _p(r, C.c_int32), *[_p(c, C.c_int64) for c in cols]))
+
+    def sweep_exchange(self, n: int = 1):
+        self._check(self.lib.cx_sweep_exchange(self.h, int(n)))
+
     # -- measurement ----------------------------------------------------------------------------
     def profile_enable(self, on=True):
         """True/1: hipEvents around every launch; n > 1: around every n-th launch; False/0: off."""

@@ -63,6 +63,60 @@ def grid_strip(rows_per_rank: int, n_cols: int, rank: int, world: int, seed: int
                      recv_fac=cat(rf), peers=peers)
 
 
+def cylinder_self(n_rows: int, n_cols: int, seed: int = 1234):
+    """A grid whose last row is also coupled to its first row (a cylinder), held by ONE rank that is its own halo
+    neighbour: every wrap-around factor is cut, each side sees the other through a ghost variable, and the exported
+    messages travel rank 0 -> rank 0.  Exercises the whole exchange machinery (pack, RCCL send/recv to self, events,
+    unpack, ghost push) on a single GPU.  Returns (Partition, wrap) where wrap = (top variable ids, bottom variable ids,
+    variances) describes the wrap factors for building the un-partitioned cylinder."""
+    base = synth.gaussian_grid(n_rows, n_cols, seed=seed)
+    rng = np.random.default_rng([seed, 7])
+    qw = rng.uniform(0.5, 2.0, n_cols)
+    top = 1 + np.arange(n_cols, dtype=np.int64)                          # row 0
+    bot = 1 + (n_rows - 1) * n_cols + np.arange(n_cols, dtype=np.int64)  # row n_rows-1
+    nid = int(max(base.factor_ids.max(), base.edge_var.max()))
+    f_bot = nid + 1 + np.arange(n_cols, dtype=np.int64)                  # wrap factor as seen from the bottom row
+    f_top = f_bot + n_cols                                               # ... and from the top row
+    g_for_top = f_top + n_cols                                           # ghost of top[j], attached to f_bot[j]
+    g_for_bot = g_for_top + n_cols                                       # ghost of bot[j], attached to f_top[j]
+    m = synth.Model(
+        edge_var=np.concatenate([base.edge_var, bot, g_for_top, top, g_for_bot]),
+        edge_fac=np.concatenate([base.edge_fac, f_bot, f_bot, f_top, f_top]),
+        factor_ids=np.concatenate([base.factor_ids, f_bot, f_top]),
+        factor_kind=np.concatenate([base.factor_kind, np.full(2 * n_cols, 1, np.int32)]),
+        factor_var=np.concatenate([base.factor_var, qw, qw]),
+        x_ids=base.x_ids, prior_var=base.prior_var, prior_fac=base.prior_fac, prior_mean=base.prior_mean,
+        prior_variance=base.prior_variance, meta=dict(base.meta))
+    part = Partition(model=m, rank=0, world=1,
+                     send_var=np.concatenate([top, bot]), send_fac=np.concatenate([f_top, f_bot]),
+                     recv_var=np.concatenate([g_for_top, g_for_bot]), recv_fac=np.concatenate([f_bot, f_top]),
+                     peers=[Peer(0, slice(0, 2 * n_cols), slice(0, 2 * n_cols))])
+    return part, (top, bot, qw)
+
+
+class RcclExchange:
+    """The partitioned sweep with the exchange issued by the library on RCCL (cx_sweep_exchange): Python only hands
+    over the peer table and the ncclUniqueId (broadcast through torch.distributed when there is more than one rank)."""
+
+    def __init__(self, dev, part: Partition, dist=None, torch=None, device=None):
+        self.dev = dev
+        dev.halo_configure(part.send_var, part.send_fac, part.recv_var, part.recv_fac)
+        dev.halo_peers([(p.rank, p.send.start, p.send.stop - p.send.start, p.recv.start, p.recv.stop - p.recv.start)
+                        for p in part.peers])
+        if part.world > 1:
+            idt = torch.zeros(128, dtype=torch.uint8, device=device)
+            if part.rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(dev.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            uid = bytes(idt.cpu().numpy().tobytes())
+        else:
+            uid = dev.comm_unique_id()
+        dev.comm_init(part.world, part.rank, uid)
+
+    def sweep(self, n: int = 1):
+        self.dev.sweep_exchange(n)
+
+
 class DeviceSweeper:
     """Adapter: a DeviceGraph whose halo buffers are torch tensors (so torch.distributed can move them)."""
 

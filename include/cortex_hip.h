@@ -183,6 +183,18 @@ int32_t cx_sweep_begin(cx_handle *h);
 int32_t cx_sweep_main(cx_handle *h);
 int32_t cx_sweep_end(cx_handle *h);
 
+/* The same three steps with the exchange issued by the library itself on RCCL (grouped ncclSend/ncclRecv with the
+ * partition neighbours on a dedicated stream, overlapped with the main kernel) — no host language in the per-sweep loop.
+ *   cx_comm_unique_id : rank 0 obtains the 128-byte ncclUniqueId and distributes it by any means
+ *   cx_comm_init      : every rank joins (one communicator per handle)
+ *   cx_halo_peers     : which segments (in messages) of the send / recv lists of cx_halo_configure belong to which rank
+ *   cx_sweep_exchange : n_sweeps x { begin, exchange, main, end }, asynchronous on the handle's stream */
+int32_t cx_comm_unique_id(void *out128);
+int32_t cx_comm_init(cx_handle *h, int32_t world, int32_t rank, const void *id128);
+int32_t cx_halo_peers(cx_handle *h, int32_t n_peers, const int32_t *peer_rank, const int64_t *send_offset,
+                      const int64_t *send_count, const int64_t *recv_offset, const int64_t *recv_count);
+int32_t cx_sweep_exchange(cx_handle *h, int32_t n_sweeps);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 #define CX_KERNEL_VAR_TO_FACTOR 0
 #define CX_KERNEL_FACTOR_TO_VAR 1

@@ -120,3 +120,44 @@ def test_partitioned_device_sweep_equals_whole_grid(hip_lib, schedule, world, ro
         mom = devs[rank].get_messages(ev, ef, L.TO_VARIABLE)
         assert_close(mom[:, 0], g.f2v_m[e], 1e-9, "f2v mean vs CPU checker")
         assert_close(mom[:, 1], g.f2v_v[e], 1e-9, "f2v variance vs CPU checker")
+
+
+@pytest.mark.parametrize("schedule", [L.SCHED_FUSED, L.SCHED_FLOODING])
+def test_rccl_exchange_issued_by_the_library_self_neighbour(hip_lib, schedule):
+    """cx_comm_init + cx_halo_peers + cx_sweep_exchange on one GPU: a cylinder whose wrap-around factors are cut and
+    whose only halo neighbour is the rank itself (RCCL send/recv to self inside one group).  Must equal the sweep of
+    the un-partitioned cylinder (CPU checker)."""
+    from oracle import ref
+
+    rows, cols, sweeps = 9, 40, 8
+    part, (top, bot, qw) = partition.cylinder_self(rows, cols, seed=5)
+    dev = cx.DeviceGraph(schedule=schedule)
+    cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
+    ex = partition.RcclExchange(dev, part)
+    ex.sweep(sweeps)
+    dev.sync()
+    # the un-partitioned cylinder: base grid + one wrap factor per column
+    base = cx.synth.gaussian_grid(rows, cols, seed=5)
+    wf = int(max(base.factor_ids.max(), base.edge_var.max())) + 1 + np.arange(cols)
+    g = ref.FloodGraph(np.concatenate([base.edge_var, bot, top]), np.concatenate([base.edge_fac, wf, wf]),
+                       np.concatenate([base.factor_ids, wf]), np.concatenate([base.factor_var, qw]))
+    g.set_message_to_variable(base.prior_var, base.prior_fac, base.prior_mean, base.prior_variance)
+    und = np.isnan(g.f2v_v) & (g.partner >= 0)
+    g.f2v_m[und] = 0.0; g.f2v_v[und] = 1e6
+    g.sweep(sweeps)
+    # messages on the base grid's edges
+    pe = np.flatnonzero(g.partner[: len(base.edge_var)] >= 0) if False else None
+    ev, ef = base.edge_var, base.edge_fac
+    e = g.edge_index(ev, ef)
+    got = dev.get_messages(ev, ef, L.TO_VARIABLE)
+    keep = g.partner[e] >= 0
+    assert_close(got[keep, 0], g.f2v_m[e][keep], 1e-9, "cylinder f2v mean (grid edges)")
+    assert_close(got[keep, 1], g.f2v_v[e][keep], 1e-9, "cylinder f2v variance (grid edges)")
+    # messages that crossed the halo: factor→variable on the wrap factors, both sides
+    nid = int(max(base.factor_ids.max(), base.edge_var.max()))
+    f_bot = nid + 1 + np.arange(cols); f_top = f_bot + cols
+    for vs, fs_dev in ((bot, f_bot), (top, f_top)):
+        got = dev.get_messages(vs, fs_dev, L.TO_VARIABLE)
+        e = g.edge_index(vs, wf)
+        assert_close(got[:, 0], g.f2v_m[e], 1e-9, "wrap-factor message mean")
+        assert_close(got[:, 1], g.f2v_v[e], 1e-9, "wrap-factor message variance")
