@@ -78,6 +78,22 @@ def cpu_baseline(sample_n: int, seed: int) -> dict:
                       f"restated reference scheduler (sequential, readiness bits), {total_t:.1f} s of CPU work"}
 
 
+def _watchdog(seconds: float):
+    """A multi-rank run that stops making progress (a peer died, a collective never matched) must fail fast instead of
+    sitting on the node until the driver's limit."""
+    import threading
+
+    def fire():
+        sys.stderr.write(f"[bench] no completion after {seconds:.0f} s: aborting\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def main():
     args = parse()
     import torch
@@ -99,6 +115,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    dog = _watchdog(900.0)
     N = args.grid
     schedule = L.SCHED_FUSED if args.schedule == "fused" else L.SCHED_FLOODING
     dev = cx.DeviceGraph(device=local_rank, schedule=schedule, marginals_in_sweep=True,
@@ -212,6 +229,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_grid, args.seed)
         print(json.dumps(out))
+    dog.cancel()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
