@@ -417,6 +417,7 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
         CX_TRY(dev_alloc(h, &h->d_scratch, 4096));
         if (mv) {
             const int64_t nc = h->nc;
+            h->spdir = spdir; h->spdir_dirty = true;
             CX_TRY(dev_upload(h, &h->d_spdir, spdir));
             CX_TRY(dev_alloc(h, &h->d_mv_f2v, nc * slots)); CX_TRY(dev_alloc(h, &h->d_mv_f2v_alt, nc * slots));
             CX_TRY(dev_alloc(h, &h->d_mv_v2f, nc * slots)); CX_TRY(dev_alloc(h, &h->d_mv_marg, h->cfg.dim == 64 ? 1 : nc * nv));
@@ -623,6 +624,7 @@ int32_t mv_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
         if (form == CX_FORM_POINT) {
             for (int64_t i = 0; i < n; i++) h->vinfo[vars[i]] |= cx::kClamped;
             CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
+            h->spdir_dirty = true;
         }
     } else {
         cx::mv_launch_scatter(h, h->d_mv_f2v, h->nslots, nc, d_idx, d_val, n);
@@ -731,6 +733,16 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
             cx::mv64_launch_point(h, (int)h->n_point64, h->d_point64_slots, h->d_mv_f2v, h->d_mv_f2v_alt);
             h->point64_dirty = false;
         }
+    }
+    if (h->cfg.dim != 64 && h->spdir_dirty) {   // mask the rules whose receiver is an observed variable
+        std::vector<int32_t> eff(h->spdir), slot_var(h->nslots, -1);
+        for (int64_t e = 0; e < h->ne; e++) slot_var[cx::slot_of_edge(h, e)] = h->edge_var[e];
+        for (int64_t sl = 0; sl < h->nslots; sl++) {
+            const int32_t p = h->partner[sl];
+            if (p >= 0 && (h->vinfo[slot_var[p]] & cx::kClamped)) eff[sl] = -1;
+        }
+        CX_HIP(h, hipMemcpy(h->d_spdir, eff.data(), eff.size() * 4, hipMemcpyHostToDevice));
+        h->spdir_dirty = false;
     }
     for (int32_t s = 0; s < n_sweeps; s++) {
         if (h->cfg.dim == 64)

@@ -73,7 +73,9 @@ struct cx_handle {
     // multivariate path (cx_mv.hip), dim in {2,3,4}: SoA component-major buffers [nc][nslots], packed symmetric Lambda
     int nc = 2;                                    // stored doubles per message
     std::vector<std::vector<double>> psets;        // per parameter set: A (d*d) then Q (d*d)
-    int32_t *d_spdir = nullptr;                    // per SENDING slot: 2*pset + direction of the receiving edge
+    int32_t *d_spdir = nullptr;                    // per SENDING slot: 2*pset + direction of the receiving edge; -1: receiver observed
+    std::vector<int32_t> spdir;                    // host copy without the observed-receiver mask
+    bool spdir_dirty = true;
     double *d_ptab = nullptr;                      // [2*npsets][3][d*d]: (P, B, C) triples
     int64_t ptab_sets = 0, max_pset = -1;
     double *d_mv_f2v = nullptr, *d_mv_f2v_alt = nullptr, *d_mv_v2f = nullptr, *d_mv_marg = nullptr, *d_mv_prev = nullptr;

@@ -217,9 +217,11 @@ __global__ __launch_bounds__(kBlock) void k_sweep_mv(int nv, int64_t nslots, con
             if (k < deg) msg_add<D>(total, msg_load<D>(f2v_in, nslots, base + k * kBlock));
         const Msg<D> mo = (deg > 0) ? mv_to_moment<D>(total) : total;
 #pragma unroll
-        for (int i = 0; i < D; i++) marg[(int64_t)i * nv + v] = (deg > 0) ? mo.eta[i] : __builtin_nan("");
+        // marginals are written once and not re-read by the sweep: nontemporal stores (C3: -2 %; nontemporal message
+        // LOADS are +18 % here, unlike the scalar kernel, because every message is re-read for the leave-one-out sums)
+        for (int i = 0; i < D; i++) __builtin_nontemporal_store((deg > 0) ? mo.eta[i] : __builtin_nan(""), &marg[(int64_t)i * nv + v]);
 #pragma unroll
-        for (int i = 0; i < Msg<D>::NT; i++) marg[(int64_t)(D + i) * nv + v] = (deg > 0) ? mo.lam[i] : __builtin_nan("");
+        for (int i = 0; i < Msg<D>::NT; i++) __builtin_nontemporal_store((deg > 0) ? mo.lam[i] : __builtin_nan(""), &marg[(int64_t)(D + i) * nv + v]);
     }
     const bool fixed = (deg < 2) || (info & (kClamped | kGhost));
 #pragma unroll
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_mv(int nv, int64_t nslots, con
         if (k >= deg) continue;
         const int slot = base + k * kBlock;
         const int p = partner[slot];
-        if (p < 0) continue;  // nobody listens to this variable→factor message
+        if (p < 0 || spdir[slot] < 0) continue;  // nobody listens to this variable→factor message
         Msg<D> o;
         if (fixed) {
             o = msg_load<D>(v2f, nslots, slot);
@@ -237,8 +239,10 @@ __global__ __launch_bounds__(kBlock) void k_sweep_mv(int nv, int64_t nslots, con
             for (int j = 0; j < kMvDeg; j++)
                 if (j < deg && j != k) msg_add<D>(o, msg_load<D>(f2v_in, nslots, base + j * kBlock));
         }
+        const int pd = spdir[slot];
+        if (pd < 0) continue;  // the receiver is an observed variable: nobody reads that message (lazy, like the reference)
         if (__builtin_isnan(o.lam[0])) continue;
-        const Msg<D> r = mv_rule<D>(o, ptab + (int64_t)spdir[slot] * 3 * D * D);
+        const Msg<D> r = mv_rule<D>(o, ptab + (int64_t)pd * 3 * D * D);
         if (!__builtin_isnan(r.lam[0])) msg_store<D>(f2v_out, nslots, p, r);
     }
 }
