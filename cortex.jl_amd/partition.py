@@ -63,6 +63,87 @@ def grid_strip(rows_per_rank: int, n_cols: int, rank: int, world: int, seed: int
                      recv_fac=cat(rf), peers=peers)
 
 
+def by_assignment(model: synth.Model, owner_of_variable, rank: int, world: int) -> Partition:
+    """Generic vertex partition: `owner_of_variable(ids) -> ranks` assigns every variable to a rank.
+    Rank r keeps its variables, every factor touching one of them and, for pairwise factors whose other variable lives
+    elsewhere, that variable as a degree-1 ghost.  Exports / imports are ordered by (peer, factor id), which both sides
+    of a cut compute identically, so the k-th exported message of rank a towards rank b is the k-th imported message of
+    b from a.  Scalar models with unary and pairwise factors."""
+    ev, ef = np.asarray(model.edge_var, np.int64), np.asarray(model.edge_fac, np.int64)
+    own_e = np.asarray(owner_of_variable(ev), np.int64)
+    # pairwise factors: the two edges of each factor
+    order = np.lexsort((ev, ef))
+    fs, vs, os_ = ef[order], ev[order], own_e[order]
+    first = np.flatnonzero(np.r_[True, fs[1:] != fs[:-1]])
+    counts = np.diff(np.r_[first, len(fs)])
+    if np.any(counts > 2):
+        raise ValueError("by_assignment handles unary and pairwise factors")
+    two = first[counts == 2]
+    a_v, b_v, a_o, b_o, f2 = vs[two], vs[two + 1], os_[two], os_[two + 1], fs[two]
+    one = first[counts == 1]
+    keep_unary = one[os_[one] == rank]
+    mine_a, mine_b = a_o == rank, b_o == rank
+    inner = mine_a & mine_b
+    cut_a = mine_a & ~mine_b          # I own a, b is remote
+    cut_b = mine_b & ~mine_a
+    # local edges: unary + inner pairs (both edges) + cut pairs (own edge + ghost edge)
+    loc_var = np.concatenate([vs[keep_unary], a_v[inner], b_v[inner], a_v[cut_a], b_v[cut_a], a_v[cut_b], b_v[cut_b]])
+    loc_fac = np.concatenate([fs[keep_unary], f2[inner], f2[inner], f2[cut_a], f2[cut_a], f2[cut_b], f2[cut_b]])
+    fid = np.asarray(model.factor_ids, np.int64)
+    keep_f = np.isin(fid, np.unique(loc_fac))
+    x_own = np.asarray(model.x_ids, np.int64)
+    x_own = x_own[np.asarray(owner_of_variable(x_own)) == rank]
+
+    def sel(var_arr, *cols):
+        var_arr = np.asarray(var_arr, np.int64)
+        m = np.asarray(owner_of_variable(var_arr)) == rank if len(var_arr) else np.zeros(0, bool)
+        return [np.asarray(c)[m] for c in (var_arr,) + cols]
+
+    dv, df, dy = sel(model.data_var, model.data_fac, model.data_y) if len(model.data_var) else (np.zeros(0, np.int64),) * 2 + (np.zeros(0),)
+    if len(model.prior_var):
+        pv, pf, pm, pvv = sel(model.prior_var, model.prior_fac, model.prior_mean, model.prior_variance)
+    else:
+        pv = pf = np.zeros(0, np.int64); pm = pvv = np.zeros(0)
+    local = synth.Model(edge_var=loc_var, edge_fac=loc_fac, factor_ids=fid[keep_f], factor_kind=np.asarray(model.factor_kind)[keep_f],
+                        factor_var=np.asarray(model.factor_var)[keep_f], x_ids=x_own, data_var=dv, data_fac=df, data_y=dy,
+                        prior_var=pv, prior_fac=pf, prior_mean=pm, prior_variance=pvv, meta=dict(model.meta))
+    # halo lists grouped by peer, ordered by factor id within a peer
+    my_v = np.concatenate([a_v[cut_a], b_v[cut_b]]); gh_v = np.concatenate([b_v[cut_a], a_v[cut_b]])
+    cf = np.concatenate([f2[cut_a], f2[cut_b]]); peer = np.concatenate([b_o[cut_a], a_o[cut_b]])
+    o = np.lexsort((cf, peer))
+    my_v, gh_v, cf, peer = my_v[o], gh_v[o], cf[o], peer[o]
+    peers, pos = [], 0
+    for pr in np.unique(peer):
+        n = int((peer == pr).sum())
+        peers.append(Peer(int(pr), slice(pos, pos + n), slice(pos, pos + n)))
+        pos += n
+    return Partition(model=local, rank=rank, world=world, send_var=my_v, send_fac=cf, recv_var=gh_v, recv_fac=cf, peers=peers)
+
+
+def contiguous_blocks(model: synth.Model, rank: int, world: int) -> Partition:
+    """Equal contiguous id-blocks of the latent variables (time blocks of a chain, row blocks of a grid); every other
+    variable (observations) goes with its first neighbour among the latent variables."""
+    x = np.sort(np.asarray(model.x_ids, np.int64))
+    bounds = x[(np.arange(1, world) * len(x)) // world] if world > 1 else np.zeros(0, np.int64)
+    ev, ef = np.asarray(model.edge_var, np.int64), np.asarray(model.edge_fac, np.int64)
+    is_x = np.isin(ev, x)
+    # an observation's owner = owner of the latent variable sharing its factor
+    order = np.argsort(ef, kind="stable")
+    fs, vs, xs = ef[order], ev[order], is_x[order]
+    fac_latent = {}
+    lat_f, lat_v = fs[xs], vs[xs]
+    first = np.flatnonzero(np.r_[True, lat_f[1:] != lat_f[:-1]]) if len(lat_f) else np.zeros(0, np.int64)
+    fac_latent = dict(zip(lat_f[first].tolist(), lat_v[first].tolist()))
+    obs_owner_var = {int(v): fac_latent[int(f)] for v, f in zip(ev[~is_x], ef[~is_x]) if int(f) in fac_latent}
+
+    def owner(ids):
+        ids = np.asarray(ids, np.int64)
+        rep = np.array([obs_owner_var.get(int(i), int(i)) for i in ids], dtype=np.int64) if len(ids) else ids
+        return np.searchsorted(bounds, rep, side="right")
+
+    return by_assignment(model, owner, rank, world)
+
+
 def cylinder_self(n_rows: int, n_cols: int, seed: int = 1234):
     """A grid whose last row is also coupled to its first row (a cylinder), held by ONE rank that is its own halo
     neighbour: every wrap-around factor is cut, each side sees the other through a ghost variable, and the exported

@@ -161,3 +161,42 @@ def test_rccl_exchange_issued_by_the_library_self_neighbour(hip_lib, schedule):
         e = g.edge_index(vs, wf)
         assert_close(got[:, 0], g.f2v_m[e], 1e-9, "wrap-factor message mean")
         assert_close(got[:, 1], g.f2v_v[e], 1e-9, "wrap-factor message variance")
+
+
+def test_generic_partition_of_a_chain_on_device(hip_lib):
+    """time blocks of a state-space chain (partition.contiguous_blocks), three handles on one GPU, in-process exchange:
+    bitwise equal to the un-partitioned flooding sweeps."""
+    import torch
+
+    T, world, sweeps = 90, 3, 25
+    whole_model = cx.synth.ssm_chain(T, seed=4, random_variances=True)
+    whole = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(whole_model, whole)
+    whole.sweep(sweeps)
+    ld = LoopbackDist(world, torch)
+    devs, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            ld.bind(rank)
+            part = partition.contiguous_blocks(whole_model, rank, world)
+            dev = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+            cx.synth.load_into_device(part.model, dev)
+            sw = partition.DeviceSweeper(dev, part, torch, torch.device("cuda", 0))
+            ex = partition.HaloExchange(sw, part, ld)
+            for _ in range(sweeps):
+                ex.sweep()
+            dev.sync()
+            devs[rank] = (dev, part)
+        except Exception as e:  # pragma: no cover
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    for dev, part in devs:
+        ids = part.model.x_ids
+        assert np.array_equal(dev.get_marginals(ids), whole.get_marginals(ids), equal_nan=True)

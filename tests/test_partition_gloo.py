@@ -82,3 +82,57 @@ def test_gloo_halo_exchange_matches_single_process(tmp_path, world):
         assert np.array_equal(d["marg_m"][li], gm[vi]) and np.array_equal(d["marg_v"][li], gv[vi])
         seen += own.sum()
     assert seen == g.ne
+
+
+def _union_check(whole, parts):
+    owned = np.concatenate([p.model.x_ids for p in parts])
+    assert np.array_equal(np.sort(owned), np.sort(whole.x_ids))
+    for p in parts:
+        for peer in p.peers:
+            q = parts[peer.rank]
+            back = [pp for pp in q.peers if pp.rank == p.rank][0]
+            assert np.array_equal(p.send_var[peer.send], q.recv_var[back.recv])
+            assert np.array_equal(p.send_fac[peer.send], q.recv_fac[back.recv])
+            assert np.array_equal(q.send_var[back.send], p.recv_var[peer.recv])
+
+
+def test_generic_partitioner_reproduces_the_strip_partition():
+    rows, cols, world = 4, 6, 3
+    whole = cx.synth.gaussian_grid(rows * world, cols, seed=99)
+    parts = [partition.contiguous_blocks(whole, r, world) for r in range(world)]
+    _union_check(whole, parts)
+    for r in range(world):
+        s = partition.grid_strip(rows, cols, r, world, seed=99)
+        g = parts[r]
+        key = lambda m: sorted(zip(m.edge_var.tolist(), m.edge_fac.tolist()))  # noqa: E731
+        assert key(g.model) == key(s.model)
+        assert sorted(zip(g.send_var.tolist(), g.send_fac.tolist())) == sorted(zip(s.send_var.tolist(), s.send_fac.tolist()))
+
+
+def test_generic_partitioner_on_a_chain_matches_single_process():
+    """time blocks of a state-space chain: 1 cut factor per boundary; flooding sweeps with the exchange equal the
+    un-partitioned sweeps bit for bit (in-process exchange through numpy, same code path as _dist_worker)."""
+    from tests._dist_worker import OracleSweeper
+
+    T, world, sweeps = 40, 4, 30
+    whole = cx.synth.ssm_chain(T, seed=8, random_variances=True)
+    parts = [partition.contiguous_blocks(whole, r, world) for r in range(world)]
+    _union_check(whole, parts)
+    assert all(len(p.send_var) == (1 if r in (0, world - 1) else 2) for r, p in enumerate(parts))
+    sws = [OracleSweeper(p, None) for p in parts]
+    for _ in range(sweeps):
+        for sw in sws:
+            sw.sweep_begin()
+        for r, p in enumerate(parts):
+            for peer in p.peers:
+                back = [pp for pp in parts[peer.rank].peers if pp.rank == r][0]
+                sws[peer.rank].recv[back.recv] = sws[r].send[peer.send]
+        for sw in sws:
+            sw.sweep_main(); sw.sweep_end()
+    g = flood_oracle_from_model(whole)
+    g.sweep(sweeps)
+    gm, gv = g.marginals()
+    for p, sw in zip(parts, sws):
+        m, v = sw.g.marginals()
+        li = np.searchsorted(sw.g.var_ids, p.model.x_ids); wi = np.searchsorted(g.var_ids, p.model.x_ids)
+        assert np.array_equal(m[li], gm[wi], equal_nan=True) and np.array_equal(v[li], gv[wi], equal_nan=True)
