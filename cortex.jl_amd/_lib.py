@@ -21,6 +21,7 @@ FACTOR_OPAQUE, FACTOR_GAUSS_ADDITIVE, FACTOR_GAUSS_LINEAR = 0, 1, 2
 NPARAM = 4
 ROLE_OUT, ROLE_IN = 0, 1
 SCHED_FLOODING, SCHED_FUSED, SCHED_CHAIN_SCAN = 0, 1, 2
+FAMILY_GAUSSIAN, FAMILY_NATURAL2 = 0, 1
 KERNEL_VAR_TO_FACTOR, KERNEL_FACTOR_TO_VAR, KERNEL_FUSED, KERNEL_BATCH, KERNEL_BIG_VAR = 0, 1, 2, 3, 4
 KERNEL_HALO_BEGIN, KERNEL_HALO_END = 5, 6
 KERNEL_COUNT = 8
@@ -29,7 +30,7 @@ KERNEL_COUNT = 8
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("dim", C.c_int32), ("schedule", C.c_int32),
                 ("compute_marginals_in_sweep", C.c_int32), ("materialize_messages_to_factor", C.c_int32),
-                ("reserved", C.c_int32 * 2)]
+                ("family", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class Item(C.Structure):

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep(int nv, const int32_t *__restr
 #pragma unroll
     for (int k = kSmallDeg - 1; k >= 0; k--) { out[k] = add2(out[k], acc); acc = add2(acc, in[k]); }
 
-    if (write_marg) store_stream(&marg[v], to_moment(total));
+    if (write_marg) store_stream(&marg[v], write_marg == 2 ? total : to_moment(total));   // 2: natural-parameter marginals
 
     // a variable with <2 factors has no dependencies on its message to the factor (dependencies.jl:48-55): never
     // computed; observed variables keep the data the caller set.  Their stored message still feeds the factor.
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void k_big_var_to_factor(const int32_t *__r
         if (i < t) pre[i] = add2(carry, exc);
         carry = add2(carry, make_double2(__shfl(inc.x, 63, 64), __shfl(inc.y, 63, 64)));
     }
-    if (write_marg && lane == 0) marg[v] = to_moment(carry);
+    if (write_marg && lane == 0) marg[v] = write_marg == 2 ? carry : to_moment(carry);
     if (vinfo[v] & (kClamped | kGhost)) return;
     // backward: exclusive suffix; lanes walk each chunk from its end
     const int nchunk = (t - s + 63) >> 6;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void k_batch(int64_t n, const int32_t *__re
                                                   const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
                                                   const int32_t *__restrict__ partner, const double *__restrict__ q,
                                                   const double *__restrict__ pa, const double *__restrict__ pb,
-                                                  double2 *__restrict__ f2v, double2 *__restrict__ v2f, double2 *__restrict__ marg) {
+                                                  double2 *__restrict__ f2v, double2 *__restrict__ v2f, double2 *__restrict__ marg, int nat_marg) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const int k = kind[i], idx = index[i], v = var[i];
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void k_batch(int64_t n, const int32_t *__re
         const int b = vbase[v];
         double2 acc = zero2();
         for (int j = 0; j < deg; j++) acc = add2(acc, f2v[b + j * stride]);
-        marg[v] = (deg > 0) ? to_moment(acc) : nan2();
+        marg[v] = (deg > 0) ? (nat_marg ? acc : to_moment(acc)) : nan2();
     }
 }
 
@@ -405,7 +405,7 @@ static void launch_sweep_t(cx_handle *h, const double2 *f2v_in, double2 *f2v_out
     const double *sq = h->any_linear ? h->d_sq : h->d_q;  // additive factors: q is symmetric in the two edges
     hipLaunchKernelGGL((k_sweep<LINEAR, STORE, PUSH>), dim3((unsigned)h->nslices), dim3(kBlock), 0, h->stream, (int)h->nv,
                        h->d_slice_off, h->d_vinfo, h->d_partner, sq, h->d_sa, h->d_sb, f2v_in, f2v_out, h->d_v2f, h->d_marg,
-                       write_marg ? 1 : 0, skip_ghosts ? 1 : 0);
+                       write_marg ? (h->cfg.family == CX_FAMILY_NATURAL2 ? 2 : 1) : 0, skip_ghosts ? 1 : 0);
 }
 
 void launch_fused(cx_handle *h, const double2 *f2v_in, double2 *f2v_out, bool write_marg, bool store_v2f, bool skip_ghosts) {
@@ -435,7 +435,7 @@ void launch_big_var_to_factor(cx_handle *h, const double2 *f2v, bool write_marg)
     const int waves_per_block = kBlock / 64;
     const int nb = (nbig + waves_per_block - 1) / waves_per_block;
     hipLaunchKernelGGL(k_big_var_to_factor, dim3(nb), dim3(kBlock), 0, h->stream, h->d_big, nbig, h->d_vbase, h->d_var_deg,
-                       h->d_vinfo, f2v, h->d_v2f, h->d_big_tmp, h->big_start, h->d_marg, write_marg ? 1 : 0);
+                       h->d_vinfo, f2v, h->d_v2f, h->d_big_tmp, h->big_start, h->d_marg, write_marg ? (h->cfg.family == CX_FAMILY_NATURAL2 ? 2 : 1) : 0);
     prof_end(h);
 }
 
@@ -503,11 +503,11 @@ void launch_batch(cx_handle *h, const int32_t *d_kind, const int32_t *d_index, c
     prof_begin(h, CX_KERNEL_BATCH);
     if (h->any_linear)
         hipLaunchKernelGGL(k_batch<true>, dim3(nb), dim3(kBlock), 0, h->stream, n, d_kind, d_index, d_var, h->d_vbase, h->d_var_deg,
-                           h->d_vinfo, h->d_partner, h->d_q, h->d_a, h->d_b, h->d_f2v, h->d_v2f, h->d_marg);
+                           h->d_vinfo, h->d_partner, h->d_q, h->d_a, h->d_b, h->d_f2v, h->d_v2f, h->d_marg, h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0);
     else
         hipLaunchKernelGGL(k_batch<false>, dim3(nb), dim3(kBlock), 0, h->stream, n, d_kind, d_index, d_var, h->d_vbase, h->d_var_deg,
                            h->d_vinfo, h->d_partner, h->d_q, (const double *)nullptr, (const double *)nullptr, h->d_f2v, h->d_v2f,
-                           h->d_marg);
+                           h->d_marg, h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0);
     prof_end(h);
 }
 

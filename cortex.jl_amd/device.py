@@ -26,10 +26,10 @@ def _p(a, ct):
 
 class DeviceGraph:
     def __init__(self, device: int = 0, dim: int = 1, schedule: int = L.SCHED_FUSED, marginals_in_sweep: bool = True,
-                 materialize_messages_to_factor: bool = False):
+                 materialize_messages_to_factor: bool = False, family: int = L.FAMILY_GAUSSIAN):
         self.lib = L.load()
         cfg = L.Config(C.sizeof(L.Config), device, dim, schedule, int(marginals_in_sweep),
-                       int(materialize_messages_to_factor))
+                       int(materialize_messages_to_factor), int(family))
         h = C.c_void_p()
         rc = self.lib.cx_create(C.byref(cfg), C.byref(h))
         if rc != L.OK:

@@ -77,6 +77,14 @@ extern "C" {
 #define CX_ROLE_OUT 0
 #define CX_ROLE_IN 1
 
+/* message families for dim == 1.  The sweep's products are sums of natural parameters for ANY exponential family; only
+ * the factor rules, the moment conversions at the ABI and the marginal read-out are Gaussian-specific. */
+#define CX_FAMILY_GAUSSIAN 0  /* (xi, w); marginals and MOMENT payloads are (mean, variance) */
+#define CX_FAMILY_NATURAL2 1  /* any 2-parameter family in natural coordinates, e.g. Beta(a, b) as (a-1, b-1): the
+                                 Beta-Bernoulli model of test/inference_engine_tests.jl:241-377.  Payloads are NATURAL only,
+                                 factors are CX_FACTOR_OPAQUE (their messages are set by the caller), marginals come back as
+                                 the natural-parameter sums. */
+
 /* schedules of cx_sweep */
 #define CX_SCHED_FLOODING 0   /* all variable→factor, then all factor→variable, then marginals           */
 #define CX_SCHED_FUSED 1      /* same fixed-point map, one fused kernel on double-buffered messages        */
@@ -96,7 +104,8 @@ typedef struct cx_config {
                                                during a sweep and are recomputed, bit-identically, from the retained
                                                input buffer when cx_get_messages / cx_update_batch asks for them;
                                                1: every sweep also stores them */
-    int32_t reserved[2];
+    int32_t family;        /* CX_FAMILY_*: what a scalar (dim == 1) message's two numbers mean */
+    int32_t reserved[1];
 } cx_config;
 
 typedef struct cx_item {

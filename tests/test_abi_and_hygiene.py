@@ -54,7 +54,7 @@ def test_no_cpu_fallback_without_gpu(hip_lib):
     with pytest.raises(cx.CortexHipError) as e:
         cx.DeviceGraph()
     assert e.value.code == L.ERR_NO_DEVICE and "no CPU fallback" in e.value.message
-    bad = L.Config(4, 0, 1, 0, 1, 0)
+    bad = L.Config(4, 0, 1, 0, 1, 0, 0)
     h = C.c_void_p()
     assert hip_lib.cx_create(C.byref(bad), C.byref(h)) == L.ERR_INVALID_ARGUMENT
     assert hip_lib.cx_destroy(None) == L.OK  # idempotent on NULL

@@ -224,3 +224,34 @@ def test_config_c4_full_size(hip_lib):
     h = (model.meta["y"] / model.meta["r"]).ravel()
     resid = np.abs(J @ marg[:, 0] - h).max() / np.abs(h).max()
     assert resid < 1e-9, f"converged BP means do not solve the normal equations: relative residual {resid:.2e}"
+
+
+@pytest.mark.parametrize("schedule", [L.SCHED_FLOODING, L.SCHED_FUSED])
+@pytest.mark.parametrize("n", [1, 3, 5, 8, 9, 100, 3000])
+def test_beta_bernoulli_known_answer_on_device(hip_lib, schedule, n):
+    """The reference's conjugate known answer (test/inference_engine_tests.jl:360-376): posterior Beta(1 + Σ, 1 + n − Σ)
+    of the star-shaped Beta-Bernoulli model, computed by the device's product-of-messages path (SELL leave-one-out for
+    n ≤ 8, wave-scan "segment tree" for n > 8) on messages of the generic 2-parameter family: Beta(a, b) travels as its
+    natural parameters (a − 1, b − 1), so the reference's Beta product (a + a' − 1, b + b' − 1) is a plain sum."""
+    rng = np.random.default_rng(n)
+    data = rng.random(n) < 0.5
+    p = 1
+    o = 2 * np.arange(1, n + 1)          # ids as make_beta_bernoulli_model hands them out: o_i, f_i alternate (:311-327)
+    f = o + 1
+    dev = cx.DeviceGraph(schedule=schedule, family=L.FAMILY_NATURAL2)
+    dev.graph_create(np.concatenate([np.full(n, p), o]), np.concatenate([f, f]), f, np.full(n, L.FACTOR_OPAQUE, np.int32), np.ones(n))
+    # compute_message_to_variable! of the reference's processor: Beta(1 + r, 2 − r) (:256-258) → natural (r, 1 − r)
+    r = data.astype(float)
+    dev.set_messages(np.full(n, p), f, L.TO_VARIABLE, L.FORM_NATURAL, np.stack([r, 1.0 - r], axis=1))
+    dev.sweep(1)
+    nat = dev.get_marginals([p])[0]
+    assert (1.0 + nat[0], 1.0 + nat[1]) == (1.0 + data.sum(), 1.0 + n - data.sum())   # exact: small integers in f64
+    dev.update_batch([L.ITEM_INDIVIDUAL_MARGINAL], [p], [0])
+    nat = dev.get_marginals([p])[0]
+    assert (1.0 + nat[0], 1.0 + nat[1]) == (1.0 + data.sum(), 1.0 + n - data.sum())
+    if n >= 2:   # "product of all but me": the message towards factor f_1 is the sum of the others
+        dev.update_batch([L.ITEM_MESSAGE_TO_FACTOR], [p], [int(f[0])])
+        m = dev.get_messages([p], [int(f[0])], L.TO_FACTOR, L.FORM_NATURAL)[0]
+        assert (m[0], m[1]) == (r[1:].sum(), (1.0 - r[1:]).sum())
+    with pytest.raises(cx.CortexHipError):
+        dev.get_messages([p], [int(f[0])], L.TO_VARIABLE, L.FORM_MOMENT)   # moment form is Gaussian-only
