@@ -108,12 +108,21 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP sweep has no CPU fallback")
+    # rehearsal knobs (never set by the driver): CX_DIST_BACKEND=gloo + CX_SINGLE_DEVICE=1 run N ranks against ONE GPU with
+    # host-staged halos, to exercise the multi-rank control flow on a one-GPU box
+    backend = os.environ.get("CX_DIST_BACKEND", "nccl")
+    if os.environ.get("CX_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     dog = _watchdog(900.0)
     N = args.grid
@@ -136,7 +145,11 @@ def main():
             part = partition.grid_strip(N, N, rank, world, seed=args.seed)
         cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
         exchange = None
-        if args.halo == "rccl":
+        if backend != "nccl" and world > 1:
+            sweeper = partition.HostStagedSweeper(dev, part, torch, torch.device("cuda", local_rank))
+            exchange = partition.HaloExchange(sweeper, part, dist)
+            halo_kind = f"REHEARSAL: host-staged over {backend}"
+        elif args.halo == "rccl":
             try:
                 exchange = partition.RcclExchange(dev, part, dist, torch, torch.device("cuda", local_rank))
                 halo_kind = "rccl send/recv issued by the library"
@@ -173,10 +186,10 @@ def main():
     elapsed = time.perf_counter() - t0
     dev.profile_enable(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        u = torch.tensor([updates_per_step], dtype=torch.float64, device="cuda")
+        u = torch.tensor([updates_per_step], dtype=torch.float64, device=red_dev)
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
         total_updates_per_step = float(u.item())
     else:
@@ -219,7 +232,7 @@ def main():
             "max_message_change_over_run": res,
         }
         traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(traffic_file):
+        if os.path.exists(traffic_file) and N == 1415 and args.schedule == "fused" and not args.materialize:   # measured for that workload only
             try:
                 tr = json.load(open(traffic_file))
                 if tr.get("kernel") == dom_name:

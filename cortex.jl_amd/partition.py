@@ -218,6 +218,27 @@ class DeviceSweeper:
         self.dev.sweep_end()
 
 
+class HostStagedSweeper(DeviceSweeper):
+    """Rehearsal transport: the halo tensors live on the host (gloo cannot move device memory); every sweep copies the
+    packed messages device -> host before the exchange and host -> device after it.  Only for exercising the multi-rank
+    control flow on a box with fewer GPUs than ranks — never a measured configuration."""
+
+    def __init__(self, dev, part: Partition, torch, device):
+        super().__init__(dev, part, torch, device)
+        self.dsend, self.drecv = self.send, self.recv
+        self.send = torch.zeros_like(self.dsend, device="cpu")
+        self.recv = torch.zeros_like(self.drecv, device="cpu")
+
+    def sweep_begin(self):
+        self.dev.sweep_begin()
+        self.dev.sync()
+        self.send.copy_(self.dsend)
+
+    def sweep_end(self):
+        self.drecv.copy_(self.recv)
+        self.dev.sweep_end()
+
+
 class HaloExchange:
     """One partitioned sweep = begin (pack the exported messages) → start send/recv with the partition neighbours →
     main sweep (overlaps the exchange) → wait → end (unpack + push the imported messages through the cut factors).
