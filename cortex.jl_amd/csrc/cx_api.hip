@@ -147,8 +147,8 @@ const char *cx_kernel_name(int32_t k) {
     case CX_KERNEL_FUSED: return "k_sweep<fused>";
     case CX_KERNEL_BATCH: return "k_batch";
     case CX_KERNEL_BIG_VAR: return "k_big_var_to_factor";
-    case CX_KERNEL_HALO_BEGIN: return "k_v2f_slots<halo>";
-    case CX_KERNEL_HALO_END: return "k_push_slots<halo>";
+    case CX_KERNEL_HALO_BEGIN: return "k_halo_export";
+    case CX_KERNEL_HALO_END: return "k_halo_import";
     }
     return "";
 }

@@ -135,7 +135,6 @@ void launch_var_to_factor(cx_handle *h, const double2 *f2v, bool write_marg);
 void launch_big_var_to_factor(cx_handle *h, const double2 *f2v, bool write_marg);
 void launch_factor_to_var(cx_handle *h, const double2 *v2f, double2 *f2v);
 void launch_push_slots(cx_handle *h, const int32_t *d_slots, int64_t n, double2 *f2v_out, int kernel_id);
-void launch_v2f_slots(cx_handle *h, const int32_t *d_slots, const int32_t *d_vars, int64_t n, const double2 *f2v, int kernel_id);
 void launch_halo_export(cx_handle *h, const double2 *f2v, hipStream_t stream);
 void launch_halo_import(cx_handle *h, double2 *f2v_out, bool push);
 void launch_batch(cx_handle *h, const int32_t *d_kind, const int32_t *d_index, const int32_t *d_var, int64_t n);

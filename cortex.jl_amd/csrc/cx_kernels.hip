@@ -265,16 +265,6 @@ __device__ __forceinline__ void m2f_one(int slot, int v, const int32_t *vbase, c
     if (!__builtin_isnan(o.y)) v2f[slot] = o;
 }
 
-// variable→factor for a list of (slot, variable): the messages a rank exports before the main sweep
-__global__ __launch_bounds__(kBlock) void k_v2f_slots(const int32_t *__restrict__ slots, const int32_t *__restrict__ vars, int64_t n,
-                                                      const int32_t *__restrict__ vbase, const int32_t *__restrict__ vdeg,
-                                                      const uint8_t *__restrict__ vinfo, const double2 *__restrict__ f2v,
-                                                      double2 *__restrict__ v2f) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    m2f_one(slots[i], vars[i], vbase, vdeg, vinfo, f2v, v2f);
-}
-
 // halo export: variable→factor of the exported slots, computed straight into the send buffer (and into v2f)
 __global__ __launch_bounds__(kBlock) void k_halo_export(const int32_t *__restrict__ slots, const int32_t *__restrict__ vars, int64_t n,
                                                         const int32_t *__restrict__ vbase, const int32_t *__restrict__ vdeg,
@@ -463,15 +453,6 @@ void launch_push_slots(cx_handle *h, const int32_t *d_slots, int64_t n, double2 
     else
         hipLaunchKernelGGL(k_push_slots<false>, dim3(nb), dim3(kBlock), 0, h->stream, d_slots, n, h->d_partner, sq,
                            (const double *)nullptr, (const double *)nullptr, h->d_v2f, f2v_out);
-    prof_end(h);
-}
-
-void launch_v2f_slots(cx_handle *h, const int32_t *d_slots, const int32_t *d_vars, int64_t n, const double2 *f2v, int kernel_id) {
-    if (n == 0) return;
-    const int nb = (int)((n + kBlock - 1) / kBlock);
-    prof_begin(h, kernel_id);
-    hipLaunchKernelGGL(k_v2f_slots, dim3(nb), dim3(kBlock), 0, h->stream, d_slots, d_vars, n, h->d_vbase, h->d_var_deg, h->d_vinfo,
-                       f2v, h->d_v2f);
     prof_end(h);
 }
 
