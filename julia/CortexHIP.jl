@@ -1,0 +1,85 @@
+# julia/CortexHIP.jl — the reference-side binding of libcortex_hip.so (SURVEY.md §8f1).
+#
+# NOT EXECUTED in the authoring container (no Julia toolchain, no network): shipped as source for a maintainer to try
+# against Cortex.jl v0.3.0.  It uses only the C ABI of include/cortex_hip.h; the identical call sequence is exercised
+# through Python ctypes by every `-m gpu` test of this repository (cortex.jl_amd/hip_processor.py is the tested twin).
+# The text below is the same as the stub in INTEGRATION.md.
+
+module CortexHIP
+using Cortex
+const lib = "libcortex_hip.so"
+
+struct CxConfig            # mirrors cx_config
+    struct_size::Int32; device::Int32; dim::Int32; schedule::Int32
+    compute_marginals_in_sweep::Int32; materialize_messages_to_factor::Int32; reserved::NTuple{2,Int32}
+end
+struct CxItem              # mirrors cx_item
+    kind::Int32; reserved::Int32; variable_id::Int64; factor_id::Int64
+end
+
+mutable struct HipProcessor <: Cortex.AbstractInferenceRequestProcessor
+    handle::Ptr{Cvoid}
+    queue::Vector{CxItem}
+    signals::Vector{Cortex.InferenceSignal}
+end
+
+check(h, rc) = rc == 0 ? nothing : error(unsafe_string(ccall((:cx_last_error, lib), Cstring, (Ptr{Cvoid},), h)))
+
+function HipProcessor(; device = 0, dim = 1, schedule = 1)
+    cfg = Ref(CxConfig(sizeof(CxConfig), device, dim, schedule, 1, 0, (0, 0)))
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:cx_create, lib), Int32, (Ref{CxConfig}, Ref{Ptr{Cvoid}}), cfg, out)
+    rc == 0 || error(unsafe_string(ccall((:cx_last_error, lib), Cstring, (Ptr{Cvoid},), C_NULL)))
+    p = HipProcessor(out[], CxItem[], Cortex.InferenceSignal[])
+    finalizer(q -> ccall((:cx_destroy, lib), Int32, (Ptr{Cvoid},), q.handle), p)
+    return p
+end
+
+# graph ingestion through the reference's own accessors (model_engine.jl:329-391)
+function upload!(p::HipProcessor, engine::Cortex.InferenceEngine, kind_of, params_of)
+    ev, ef = Int64[], Int64[]
+    fids = collect(Int64, Cortex.get_factor_ids(engine))
+    for f in fids, v in Cortex.get_connected_variable_ids(engine, f)
+        push!(ev, v); push!(ef, f)
+    end
+    kinds = Int32[kind_of(Cortex.get_factor(engine, f)) for f in fids]          # CX_FACTOR_*
+    params = reduce(vcat, [collect(Float64, params_of(Cortex.get_factor(engine, f))) for f in fids])  # 4 per factor
+    check(p.handle, ccall((:cx_graph_create, lib), Int32,
+        (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int32}, Int64, Ptr{Int64}, Ptr{Int32}, Ptr{Float64}),
+        p.handle, length(ev), ev, ef, C_NULL, length(fids), fids, kinds, params))
+end
+
+# batched mode: collect like InferenceRequestScanner (inference_engine.jl:528-537), compute on flush
+function Cortex.process!(p::HipProcessor, engine::Cortex.InferenceEngine, variable_id, signal::Cortex.InferenceSignal)
+    v = Cortex.get_variant(signal)
+    item = v isa Cortex.InferenceSignalVariants.MessageToVariable ? CxItem(2, 0, v.variable_id, v.factor_id) :
+           v isa Cortex.InferenceSignalVariants.MessageToFactor   ? CxItem(1, 0, v.variable_id, v.factor_id) :
+           v isa Cortex.InferenceSignalVariants.IndividualMarginal ? CxItem(4, 0, v.variable_id, 0) :
+           error("The HIP processor has no rule for $(typeof(v))")
+    push!(p.queue, item); push!(p.signals, signal)
+    flush!(p)                       # or defer: flush once per scan wavefront
+end
+
+function flush!(p::HipProcessor)
+    isempty(p.queue) && return
+    check(p.handle, ccall((:cx_update_batch, lib), Int32, (Ptr{Cvoid}, Ptr{CxItem}, Int64), p.handle, p.queue, length(p.queue)))
+    for s in p.signals
+        Cortex.set_value!(s, HipValue())     # any non-UndefValue(): readiness bits evolve as in the reference (signal.jl:232-253)
+    end
+    empty!(p.queue); empty!(p.signals)
+end
+struct HipValue end                           # the payload stays in HBM; read it back with cx_get_messages / cx_get_marginals
+
+# whole-sweep mode
+function Cortex.update_marginals!(engine::Cortex.InferenceEngine{M,D,HipProcessor}, ids::Union{AbstractVector,Tuple}) where {M,D}
+    p = Cortex.get_inference_request_processor(engine)
+    check(p.handle, ccall((:cx_sweep, lib), Int32, (Ptr{Cvoid}, Int32), p.handle, 1))
+    out = Matrix{Float64}(undef, 2, length(ids))
+    check(p.handle, ccall((:cx_get_marginals, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Float64}),
+                          p.handle, length(ids), collect(Int64, ids), out))
+    for (i, id) in enumerate(ids)   # make the values visible as the reference's test structs (runtests.jl:31-34)
+        Cortex.set_value!(Cortex.get_variable_marginal(Cortex.get_variable(engine, id)), (mean = out[1, i], variance = out[2, i]))
+    end
+    return nothing
+end
+end
