@@ -11,7 +11,7 @@ const lib = "libcortex_hip.so"
 
 struct CxConfig            # mirrors cx_config
     struct_size::Int32; device::Int32; dim::Int32; schedule::Int32
-    compute_marginals_in_sweep::Int32; materialize_messages_to_factor::Int32; reserved::NTuple{2,Int32}
+    compute_marginals_in_sweep::Int32; materialize_messages_to_factor::Int32; family::Int32; reserved::Int32
 end
 struct CxItem              # mirrors cx_item
     kind::Int32; reserved::Int32; variable_id::Int64; factor_id::Int64
@@ -26,7 +26,7 @@ end
 check(h, rc) = rc == 0 ? nothing : error(unsafe_string(ccall((:cx_last_error, lib), Cstring, (Ptr{Cvoid},), h)))
 
 function HipProcessor(; device = 0, dim = 1, schedule = 1)
-    cfg = Ref(CxConfig(sizeof(CxConfig), device, dim, schedule, 1, 0, (0, 0)))
+    cfg = Ref(CxConfig(sizeof(CxConfig), device, dim, schedule, 1, 0, 0, 0))
     out = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:cx_create, lib), Int32, (Ref{CxConfig}, Ref{Ptr{Cvoid}}), cfg, out)
     rc == 0 || error(unsafe_string(ccall((:cx_last_error, lib), Cstring, (Ptr{Cvoid},), C_NULL)))
