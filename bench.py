@@ -136,6 +136,7 @@ def main():
     dev.set_stream(stream.cuda_stream)
 
     halo_kind = None
+    halo_tensors = None
     if world == 1 and not args.self_halo:
         model = cx.synth.gaussian_grid(N, N, seed=args.seed)
         cx.synth.load_into_device(model, dev, seed_variance=1e6)
@@ -154,17 +155,27 @@ def main():
             sweeper = partition.HostStagedSweeper(dev, part, torch, torch.device("cuda", local_rank))
             exchange = partition.HaloExchange(sweeper, part, dist)
             halo_kind = f"REHEARSAL: host-staged over {backend}"
+            halo_tensors = (sweeper.send, sweeper.recv)
         elif args.halo == "rccl":
+            err = None
             try:
                 exchange = partition.RcclExchange(dev, part, dist, torch, torch.device("cuda", local_rank))
                 halo_kind = "rccl send/recv issued by the library"
+                halo_tensors = (exchange.send, exchange.recv)
             except cx.CortexHipError as e:   # e.g. librccl not loadable: fall back to torch.distributed
-                if rank == 0:
-                    print(f"[bench] RCCL exchange unavailable ({e}); falling back to torch.distributed", file=sys.stderr)
+                err = e
+            if dist is not None:             # all ranks take the same path
+                okf = torch.tensor([0 if err else 1], dtype=torch.int32, device=red_dev)
+                dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+                if okf.item() == 0:
+                    exchange = None
+            if exchange is None and rank == 0:
+                print(f"[bench] RCCL exchange unavailable ({err}); falling back to torch.distributed", file=sys.stderr)
         if exchange is None:
             sweeper = partition.DeviceSweeper(dev, part, torch, torch.device("cuda", local_rank))
             exchange = partition.HaloExchange(sweeper, part, dist)
             halo_kind = "torch.distributed isend/irecv"
+            halo_tensors = (sweeper.send, sweeper.recv)
     st = dev.stats()
     updates_per_step = st["n_messages_per_sweep"]
 
@@ -207,6 +218,13 @@ def main():
         if n:
             kern[dev.kernel_name(k)] = (ms, n, k)
     res = dev.residual()
+    # audit of the last exchange of the run (outside the timed region): what each rank imported == what its neighbour packed
+    halo_check = None
+    if halo_tensors is not None:
+        from cortex.jl_amd import partition
+        dev.sync()
+        torch.cuda.synchronize()
+        halo_check = partition.verify_last_exchange(part, halo_tensors[0], halo_tensors[1], dist, torch)
 
     if rank == 0:
         value = total_updates_per_step * args.steps / elapsed
@@ -238,6 +256,8 @@ def main():
             "hbm_roofline_frac_end_to_end": value * BYTES_PER_UPDATE / 1e9 / (HBM_PEAK_GBS * world),
             "max_message_change_over_run": res,
         }
+        if halo_check is not None:
+            out["halo_check"] = "ok: last imported halo == neighbours' packed messages, bit for bit" if halo_check else "FAILED"
         traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(traffic_file) and N == 1415 and args.schedule == "fused" and not args.materialize:   # measured for that workload only
             try:

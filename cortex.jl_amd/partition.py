@@ -184,6 +184,13 @@ class RcclExchange:
         dev.halo_configure(part.send_var, part.send_fac, part.recv_var, part.recv_fac)
         dev.halo_peers([(p.rank, p.send.start, p.send.stop - p.send.start, p.recv.start, p.recv.stop - p.recv.start)
                         for p in part.peers])
+        self.send = self.recv = None
+        if torch is not None and device is not None:
+            # caller-visible halo buffers (the library packs into / unpacks from them), so that a driver can audit what
+            # the library-issued exchange moved (verify_last_exchange)
+            self.send = torch.zeros((max(len(part.send_var), 1), 2), dtype=torch.float64, device=device)
+            self.recv = torch.zeros((max(len(part.recv_var), 1), 2), dtype=torch.float64, device=device)
+            dev.halo_set_buffers(self.send.data_ptr(), self.recv.data_ptr())
         if part.world > 1:
             idt = torch.zeros(128, dtype=torch.uint8, device=device)
             if part.rank == 0:
@@ -259,3 +266,28 @@ class HaloExchange:
         for w in works:
             w.wait()
         sw.sweep_end()
+
+
+def verify_last_exchange(part: Partition, send, recv, dist, torch) -> bool:
+    """Audit of the most recent halo exchange, whatever transport made it: every rank re-sends the slices of its packed
+    send buffer to its partition neighbours over torch.distributed and compares what arrives, bit for bit, with the
+    slices its recv buffer holds.  Collective over the partition's ranks; call it only when no sweep is in flight."""
+    ok = True
+    if part.world == 1:
+        for p in part.peers:           # a rank that is its own neighbour (periodic cut)
+            ok = ok and bool(torch.equal(recv[p.recv.start:p.recv.stop], send[p.send.start:p.send.stop]))
+        return ok
+    ops, got = [], []
+    for p in part.peers:
+        tmp = torch.empty_like(recv[p.recv.start:p.recv.stop])
+        got.append((p, tmp))
+        ops.append(dist.P2POp(dist.isend, send[p.send.start:p.send.stop].contiguous(), p.rank))
+        ops.append(dist.P2POp(dist.irecv, tmp, p.rank))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for p, tmp in got:
+        ok = ok and bool(torch.equal(tmp, recv[p.recv.start:p.recv.stop]))
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=send.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item() == 1)

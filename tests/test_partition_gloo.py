@@ -71,6 +71,7 @@ def test_gloo_halo_exchange_matches_single_process(tmp_path, world):
     seen = 0
     for r in range(world):
         d = np.load(out + f".rank{r}.npz")
+        assert bool(d["audit_ok"]) and not bool(d["audit_bad"])     # partition.verify_last_exchange, as bench.py runs it
         own = np.isin(d["edge_var"], d["owned"])
         pos = order[np.searchsorted(gkey[order], key(d["edge_var"][own], d["edge_fac"][own]))]
         for name in ("f2v_m", "f2v_v", "v2f_m", "v2f_v"):
