@@ -76,6 +76,9 @@ SIGNATURES = {
     "cx_comm_init": (_i32, [_vp, _i32, _i32, _vp]),
     "cx_halo_peers": (_i32, [_vp, _i32, _pi32, _pi64, _pi64, _pi64, _pi64]),
     "cx_sweep_exchange": (_i32, [_vp, _i32]),
+    "cx_state_bytes": (_i32, [_vp, _pi64]),
+    "cx_state_export": (_i32, [_vp, _vp, C.c_int64]),
+    "cx_state_import": (_i32, [_vp, _vp, C.c_int64]),
     "cx_profile_enable": (_i32, [_vp, _i32]),
     "cx_profile_read": (_i32, [_vp, _i32, _pd, _pi64]),
     "cx_kernel_name": (C.c_char_p, [_i32]),

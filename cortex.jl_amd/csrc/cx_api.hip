@@ -1239,6 +1239,134 @@ int32_t cx_sweep_exchange(cx_handle *h, int32_t n_sweeps) {
     return CX_OK;
 }
 
+// ---- checkpoint: the mutable state of a handle as one relocatable blob ------------------------------
+// The reference keeps no persistent state (nothing to mirror); with all messages resident in HBM a long loopy run needs
+// a way to stop and resume.  The blob holds the message buffers, marginals and observed-variable flags bit for bit, plus
+// a fingerprint of the flattened graph so that it can only be restored into a handle built from the same graph.
+namespace {
+
+struct StateHeader {
+    char magic[8];
+    int32_t abi, dim, family, schedule;
+    int64_t nv, ne, nslots, nc, sweeps_done;
+    int32_t v2f_stale, n_sections;
+    uint64_t fingerprint;
+};
+struct StateSection { int32_t id, reserved; int64_t bytes; };
+struct StatePart { int32_t id; void *dev; int64_t bytes; };
+const char kStateMagic[8] = {'C', 'X', 'S', 'T', 'A', 'T', 'E', '1'};
+
+uint64_t fnv1a(uint64_t hsh, const void *p, size_t n) {
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < n; i++) { hsh ^= b[i]; hsh *= 1099511628211ull; }
+    return hsh;
+}
+
+uint64_t graph_fingerprint(const cx_handle *h) {
+    uint64_t f = 1469598103934665603ull;
+    f = fnv1a(f, h->var_ids.data(), h->var_ids.size() * 8);
+    f = fnv1a(f, h->var_off.data(), h->var_off.size() * 4);
+    f = fnv1a(f, h->edge_fac_id.data(), h->edge_fac_id.size() * 8);
+    f = fnv1a(f, h->fac_kind.data(), h->fac_kind.size() * 4);
+    return f;
+}
+
+std::vector<StatePart> state_parts(cx_handle *h) {
+    std::vector<StatePart> parts;
+    const int64_t slots = h->nslots, nv = h->nv;
+    parts.push_back({1, h->d_vinfo, nv});
+    if (h->cfg.dim == 1) {
+        parts.push_back({2, h->d_f2v, slots * 16});
+        if (h->d_f2v_alt) parts.push_back({3, h->d_f2v_alt, slots * 16});
+        parts.push_back({4, h->d_v2f, slots * 16});
+        parts.push_back({5, h->d_marg, nv * 16});
+    } else {
+        const int64_t nc = h->nc;
+        parts.push_back({2, h->d_mv_f2v, nc * slots * 8});
+        parts.push_back({3, h->d_mv_f2v_alt, nc * slots * 8});
+        parts.push_back({4, h->d_mv_v2f, nc * slots * 8});
+        if (h->cfg.dim != 64) parts.push_back({5, h->d_mv_marg, nc * nv * 8});
+    }
+    return parts;
+}
+
+}  // namespace
+
+int32_t cx_state_bytes(const cx_handle *hc, int64_t *bytes) {
+    cx_handle *h = const_cast<cx_handle *>(hc);
+    CX_REQUIRE(h, h && h->has_graph && bytes, CX_ERR_STATE, "cx_state_bytes: no graph or null argument");
+    int64_t n = (int64_t)sizeof(StateHeader);
+    for (auto &p : state_parts(h)) n += (int64_t)sizeof(StateSection) + p.bytes;
+    *bytes = n;
+    return CX_OK;
+}
+
+int32_t cx_state_export(cx_handle *h, void *buf, int64_t bytes) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_state_export: no graph");
+    CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_state_export: a cx_sweep_begin is still open");
+    int64_t need = 0;
+    (void)cx_state_bytes(h, &need);
+    CX_REQUIRE(h, buf && bytes >= need, CX_ERR_INVALID_ARGUMENT, "cx_state_export: buffer smaller than cx_state_bytes");
+    CX_HIP(h, hipSetDevice(h->cfg.device));
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    auto parts = state_parts(h);
+    StateHeader hd{};
+    std::memcpy(hd.magic, kStateMagic, 8);
+    hd.abi = CX_ABI_VERSION; hd.dim = h->cfg.dim; hd.family = h->cfg.family; hd.schedule = h->cfg.schedule;
+    hd.nv = h->nv; hd.ne = h->ne; hd.nslots = h->nslots; hd.nc = h->nc; hd.sweeps_done = h->sweeps_done;
+    hd.v2f_stale = h->v2f_stale ? 1 : 0; hd.n_sections = (int32_t)parts.size();
+    hd.fingerprint = graph_fingerprint(h);
+    char *o = (char *)buf;
+    std::memcpy(o, &hd, sizeof hd); o += sizeof hd;
+    for (auto &p : parts) {
+        StateSection sc{p.id, 0, p.bytes};
+        std::memcpy(o, &sc, sizeof sc); o += sizeof sc;
+        if (p.bytes) CX_HIP(h, hipMemcpy(o, p.dev, (size_t)p.bytes, hipMemcpyDeviceToHost));
+        o += p.bytes;
+    }
+    return CX_OK;
+}
+
+int32_t cx_state_import(cx_handle *h, const void *buf, int64_t bytes) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_state_import: no graph");
+    CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_state_import: a cx_sweep_begin is still open");
+    CX_REQUIRE(h, buf && bytes >= (int64_t)sizeof(StateHeader), CX_ERR_INVALID_ARGUMENT, "cx_state_import: blob too short");
+    StateHeader hd;
+    std::memcpy(&hd, buf, sizeof hd);
+    CX_REQUIRE(h, std::memcmp(hd.magic, kStateMagic, 8) == 0 && hd.abi == CX_ABI_VERSION, CX_ERR_INVALID_ARGUMENT,
+               "cx_state_import: not a state blob of this ABI version");
+    CX_REQUIRE(h, hd.dim == h->cfg.dim && hd.family == h->cfg.family && hd.schedule == h->cfg.schedule, CX_ERR_INVALID_ARGUMENT,
+               "cx_state_import: the blob was exported with a different dim / family / schedule");
+    CX_REQUIRE(h, hd.nv == h->nv && hd.ne == h->ne && hd.nslots == h->nslots && hd.nc == h->nc && hd.fingerprint == graph_fingerprint(h),
+               CX_ERR_INVALID_ARGUMENT, "cx_state_import: the blob belongs to a different graph");
+    auto parts = state_parts(h);
+    CX_REQUIRE(h, hd.n_sections == (int32_t)parts.size(), CX_ERR_INVALID_ARGUMENT, "cx_state_import: section count mismatch");
+    // validate the whole layout before touching the device
+    const char *o = (const char *)buf + sizeof hd, *end = (const char *)buf + bytes;
+    for (auto &p : parts) {
+        CX_REQUIRE(h, end - o >= (int64_t)sizeof(StateSection), CX_ERR_INVALID_ARGUMENT, "cx_state_import: truncated blob");
+        StateSection sc;
+        std::memcpy(&sc, o, sizeof sc); o += sizeof sc;
+        CX_REQUIRE(h, sc.id == p.id && sc.bytes == p.bytes && end - o >= sc.bytes, CX_ERR_INVALID_ARGUMENT, "cx_state_import: truncated or foreign blob");
+        o += sc.bytes;
+    }
+    CX_HIP(h, hipSetDevice(h->cfg.device));
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    o = (const char *)buf + sizeof hd;
+    for (auto &p : parts) {
+        o += sizeof(StateSection);
+        if (p.id == 1) std::memcpy(h->vinfo.data(), o, (size_t)p.bytes);
+        if (p.bytes) CX_HIP(h, hipMemcpy(p.dev, o, (size_t)p.bytes, hipMemcpyHostToDevice));
+        o += p.bytes;
+    }
+    h->sweeps_done = hd.sweeps_done;
+    h->v2f_stale = hd.v2f_stale != 0;
+    h->spdir_dirty = h->work64_dirty = h->point64_dirty = h->chains_dirty = true;   // derived from the observed flags
+    if (h->d_prev) { (void)hipFree(h->d_prev); h->d_prev = nullptr; }               // residual snapshots restart
+    if (h->d_mv_prev) { (void)hipFree(h->d_mv_prev); h->d_mv_prev = nullptr; }
+    return CX_OK;
+}
+
 // ---- profiling ----------------------------------------------------------------------------------------------------
 int32_t cx_profile_enable(cx_handle *h, int32_t on) {
     CX_REQUIRE(h, h, CX_ERR_INVALID_ARGUMENT, "null handle");

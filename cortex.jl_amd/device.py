@@ -184,6 +184,25 @@ class DeviceGraph:
     def sweep_exchange(self, n: int = 1):
         self._check(self.lib.cx_sweep_exchange(self.h, int(n)))
 
+    # -- checkpoint (cx_state_*) -----------------------------------------------------------------
+    def export_state(self) -> np.ndarray:
+        """The handle's mutable state (messages, marginals, observed flags, sweep counter) as a uint8 array."""
+        n = C.c_int64()
+        self._check(self.lib.cx_state_bytes(self.h, C.byref(n)))
+        blob = np.empty(n.value, dtype=np.uint8)
+        self._check(self.lib.cx_state_export(self.h, blob.ctypes.data_as(C.c_void_p), n.value))
+        return blob
+
+    def import_state(self, blob) -> None:
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self._check(self.lib.cx_state_import(self.h, blob.ctypes.data_as(C.c_void_p), blob.size))
+
+    def save_state(self, path: str) -> None:
+        self.export_state().tofile(path)
+
+    def load_state(self, path: str) -> None:
+        self.import_state(np.fromfile(path, dtype=np.uint8))
+
     # -- measurement ----------------------------------------------------------------------------
     def profile_enable(self, on=True):
         """True/1: hipEvents around every launch; n > 1: around every n-th launch; False/0: off."""

@@ -204,6 +204,16 @@ int32_t cx_halo_peers(cx_handle *h, int32_t n_peers, const int32_t *peer_rank, c
                       const int64_t *send_count, const int64_t *recv_offset, const int64_t *recv_count);
 int32_t cx_sweep_exchange(cx_handle *h, int32_t n_sweeps);
 
+/* ---- checkpoint (the reference keeps no persistent state — src/ has no serialisation at all) ----
+ * The mutable state of a handle (every message buffer, the marginals, the observed-variable flags, the sweep counter)
+ * as one relocatable host blob.  A blob restores only into a handle created with the same dim / family / schedule and
+ * the same graph (a fingerprint of the flattened graph is checked); after cx_state_import the handle continues exactly
+ * where the exporting one stood: the following sweeps reproduce its results bit for bit.  Halo buffers are not part
+ * of the state (the next partitioned sweep exchanges them again). */
+int32_t cx_state_bytes(const cx_handle *h, int64_t *bytes);
+int32_t cx_state_export(cx_handle *h, void *buf, int64_t bytes);        /* synchronises the handle's stream */
+int32_t cx_state_import(cx_handle *h, const void *buf, int64_t bytes);  /* validates everything before writing */
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 #define CX_KERNEL_VAR_TO_FACTOR 0
 #define CX_KERNEL_FACTOR_TO_VAR 1
