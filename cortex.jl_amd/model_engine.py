@@ -48,6 +48,14 @@ def get_factor_functional_form(f: Factor):
     return f.functional_form
 
 
+def get_factor_local_marginals(f: Factor):          # model_engine.jl:141-143
+    return f.local_marginals
+
+
+def add_local_marginal_to_factor(f: Factor, local_marginal: Signal):   # model_engine.jl:150-153
+    f.local_marginals.append(local_marginal)
+
+
 def get_connection_message_to_variable(c: Connection) -> Signal:
     return c.message_to_variable
 

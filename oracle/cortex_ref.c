@@ -30,12 +30,17 @@
 
 /* ---------------------------------------------------------------- values -- */
 
-enum { CXO_UNDEF = 0, CXO_REAL = 1, CXO_NORMAL = 2, CXO_BETA = 3, CXO_BOOL = 4 };
+enum { CXO_UNDEF = 0, CXO_REAL = 1, CXO_NORMAL = 2, CXO_BETA = 3, CXO_BOOL = 4,
+       /* value kinds only the callback processor produces (test/runtests.jl:48-76): */
+       CXO_NORMAL_MP = 5,   /* NormalMeanPrecision: a = mean, b = precision */
+       CXO_GAMMA = 6,       /* Gamma: a = shape, b = scale */
+       CXO_MVNORMAL2 = 7 }; /* MvNormalMeanPrecision, 2-D: a, b = mean; x = precision row-major */
 
 typedef struct {
     int32_t tag;   /* CXO_UNDEF ≙ UndefValue() (signal.jl:7) */
     double a;      /* REAL: value; NORMAL: mean; BETA: a; BOOL: 0/1 */
     double b;      /* NORMAL: variance; BETA: b */
+    double x[4];   /* extra payload of the wider value kinds */
 } cxo_value;
 
 /* InferenceSignalVariants (inference_signal.jl:8-97) */
@@ -82,13 +87,19 @@ enum {
     CXO_F_DOUBLE = 3      /* :likelihood1/2 of the tracing test (returns 2*dep) :1155-1171 */
 };
 
-enum { CXO_P_SSM_BP = 0, CXO_P_BETA_BERNOULLI = 1, CXO_P_TRACING = 2 };
+enum { CXO_P_SSM_BP = 0, CXO_P_BETA_BERNOULLI = 1, CXO_P_TRACING = 2,
+       CXO_P_CALLBACK = 3 }; /* rules supplied by the test as a callback (the reference's processors are user code) */
+
+/* rule callback: fills out7 = {a, b, x0..x3} and *tag for signal `sig`; returns 1 on success, 0 for "no rule" */
+typedef int32_t (*cxo_rule_cb)(void *ctx, int32_t sig, int32_t *tag, double *out6);
 
 typedef struct {
     int32_t kind; /* 0 none, 1 variable, 2 factor */
     int32_t fkind;
     double p0, p1;
     int32_t marginal; /* signal id (variables) */
+    int32_t nlinked, caplinked;
+    int32_t *linked;  /* Variable.linked_signals (model_engine.jl:30-35,75-83) */
     int32_t nnb, capnb;
     int64_t *nb;      /* neighbour ids, ascending after finalize */
     int32_t *nbedge;  /* edge index per neighbour */
@@ -130,6 +141,8 @@ typedef struct {
     int32_t *scan_out;
     int64_t nscan, capscan;
     int32_t scanning;
+    cxo_rule_cb rule_cb;
+    void *rule_ctx;
 } cxo_engine;
 
 /* ---------------------------------------------------------------- signals -- */
@@ -256,7 +269,7 @@ static cxo_value normal_product(cxo_value l, cxo_value r) {
     double w = 1 / l.b + 1 / r.b;
     double variance = 1 / w;
     double mean = variance * xi;
-    cxo_value o = { CXO_NORMAL, mean, variance };
+    cxo_value o = { CXO_NORMAL, mean, variance, { 0, 0, 0, 0 } };
     return o;
 }
 
@@ -295,6 +308,15 @@ static int fold_beta(cxo_engine *E, cxo_signal *s, cxo_value *out) {
 static int apply_rule(cxo_engine *E, int32_t id, cxo_value *out) {
     cxo_signal *s = &E->sig[id];
     switch (E->processor) {
+    case CXO_P_CALLBACK: {
+        if (!E->rule_cb) return 0;
+        double six[6] = { 0, 0, 0, 0, 0, 0 };
+        int32_t tag = CXO_UNDEF;
+        if (!E->rule_cb(E->rule_ctx, id, &tag, six) || tag == CXO_UNDEF) return 0;
+        out->tag = tag; out->a = six[0]; out->b = six[1];
+        for (int k = 0; k < 4; k++) out->x[k] = six[2 + k];
+        return 1;
+    }
     case CXO_P_SSM_BP: /* test/inference_engine_tests.jl:383-432 */
         if (s->variant == CXO_VAR_MSG_TO_VARIABLE) {
             if (s->ndeps != 1) return 0; /* @assert length(dependencies) == 1 */
@@ -577,12 +599,16 @@ void cxo_engine_finalize(cxo_engine *E, int32_t resolve_dependencies) {
 
 /* ------------------------------------------------------------- scheduler -- */
 
-/* request_inference_for, inference_engine.jl:298-323 (no linked signals in this restatement's graphs) */
+/* request_inference_for, inference_engine.jl:298-323 */
 static void request_inference(cxo_engine *E, const int64_t *ids, int64_t n) {
     for (int64_t i = 0; i < n; i++) {
         cxo_signal *m = &E->sig[E->nodes[ids[i]].marginal];
         for (int32_t k = 0; k < m->ndeps; k++) {
             cxo_signal *d = &E->sig[m->deps[k]];
+            d->potentially_pending = 1; d->pending = 0;
+        }
+        for (int32_t k = 0; k < E->nodes[ids[i]].nlinked; k++) { /* :313-317 */
+            cxo_signal *d = &E->sig[E->nodes[ids[i]].linked[k]];
             d->potentially_pending = 1; d->pending = 0;
         }
     }
@@ -627,6 +653,12 @@ int32_t cxo_update_marginals(cxo_engine *E, const int64_t *ids, int64_t n) {
         int32_t marg = E->nodes[ids[i]].marginal;
         if (sig_is_pending(E, marg)) process(E, ids[i], marg);
         if (E->error) { free(ready); return E->error; }
+        for (int32_t k = 0; k < E->nodes[ids[i]].nlinked; k++) { /* linked signals, :618-626 */
+            int32_t ls = E->nodes[ids[i]].linked[k];
+            if (!sig_is_pending(E, ls)) continue;
+            process(E, ids[i], ls);
+            if (E->error) { free(ready); return E->error; }
+        }
     }
     round_end(E);
     free(ready);
@@ -637,7 +669,36 @@ int32_t cxo_update_marginals(cxo_engine *E, const int64_t *ids, int64_t n) {
 
 int32_t cxo_signal_new(cxo_engine *E) { return sig_new(E); }
 void cxo_add_dependency(cxo_engine *E, int32_t s, int32_t d, int32_t weak, int32_t listen, int32_t check_computed, int32_t intermediate) { sig_add_dependency(E, s, d, weak, listen, check_computed, intermediate); }
-void cxo_set_value(cxo_engine *E, int32_t s, int32_t tag, double a, double b) { cxo_value v = { tag, a, b }; sig_set_value(E, s, v); }
+void cxo_set_value(cxo_engine *E, int32_t s, int32_t tag, double a, double b) { cxo_value v = { tag, a, b, { 0, 0, 0, 0 } }; sig_set_value(E, s, v); }
+void cxo_set_value_ex(cxo_engine *E, int32_t s, int32_t tag, const double *six) {
+    cxo_value v = { tag, six[0], six[1], { six[2], six[3], six[4], six[5] } };
+    sig_set_value(E, s, v);
+}
+int32_t cxo_get_value_ex(cxo_engine *E, int32_t s, double *six) {
+    cxo_value v = E->sig[s].value;
+    six[0] = v.a; six[1] = v.b;
+    for (int k = 0; k < 4; k++) six[2 + k] = v.x[k];
+    return v.tag;
+}
+/* resolve_variable_dependencies!(DefaultDependencyResolver(), ...) for one variable: what a custom resolver delegates to
+ * (test/inference_engine_tests.jl:812-814) */
+void cxo_resolve_variable_default(cxo_engine *E, int64_t var) { resolve_variable(E, var); }
+void cxo_set_rule_callback(cxo_engine *E, cxo_rule_cb cb, void *ctx) { E->rule_cb = cb; E->rule_ctx = ctx; }
+/* link_signal_to_variable!, model_engine.jl:75-83 */
+void cxo_link_signal_to_variable(cxo_engine *E, int64_t var, int32_t s) {
+    cxo_node *n = &E->nodes[var];
+    if (n->nlinked == n->caplinked) {
+        n->caplinked = n->caplinked ? n->caplinked * 2 : 4;
+        n->linked = (int32_t *)realloc(n->linked, (size_t)n->caplinked * sizeof(int32_t));
+    }
+    n->linked[n->nlinked++] = s;
+}
+/* set_variant! for signals the resolver creates itself (JointMarginal(factor_id, variable_ids), inference_signal.jl:93-96):
+ * variable_id carries the first variable of the cluster, range_lo/hi the first and last */
+void cxo_set_variant(cxo_engine *E, int32_t s, int32_t variant, int64_t variable_id, int64_t factor_id, int32_t lo, int32_t hi) {
+    cxo_signal *g = &E->sig[s];
+    g->variant = variant; g->variable_id = variable_id; g->factor_id = factor_id; g->range_lo = lo; g->range_hi = hi;
+}
 int32_t cxo_is_pending(cxo_engine *E, int32_t s) { return sig_is_pending(E, s); }
 int32_t cxo_is_computed(cxo_engine *E, int32_t s) { return sig_is_computed(E, s); }
 int32_t cxo_get_value(cxo_engine *E, int32_t s, double *a, double *b) { *a = E->sig[s].value.a; *b = E->sig[s].value.b; return E->sig[s].value.tag; }
@@ -690,10 +751,10 @@ int32_t cxo_process_dependencies(cxo_engine *E, int32_t s, int32_t retry, cxo_cb
 
 /* bulk helpers so Python never loops over 1e6 signals */
 void cxo_bulk_set_message_to_factor(cxo_engine *E, const int64_t *vars, const int64_t *facs, int64_t n, int32_t tag, const double *a, const double *b) {
-    for (int64_t i = 0; i < n; i++) { cxo_value v = { tag, a[i], b ? b[i] : 0.0 }; sig_set_value(E, cxo_message_to_factor(E, vars[i], facs[i]), v); }
+    for (int64_t i = 0; i < n; i++) { cxo_value v = { tag, a[i], b ? b[i] : 0.0, { 0, 0, 0, 0 } }; sig_set_value(E, cxo_message_to_factor(E, vars[i], facs[i]), v); }
 }
 void cxo_bulk_set_message_to_variable(cxo_engine *E, const int64_t *vars, const int64_t *facs, int64_t n, int32_t tag, const double *a, const double *b) {
-    for (int64_t i = 0; i < n; i++) { cxo_value v = { tag, a[i], b ? b[i] : 0.0 }; sig_set_value(E, cxo_message_to_variable(E, vars[i], facs[i]), v); }
+    for (int64_t i = 0; i < n; i++) { cxo_value v = { tag, a[i], b ? b[i] : 0.0, { 0, 0, 0, 0 } }; sig_set_value(E, cxo_message_to_variable(E, vars[i], facs[i]), v); }
 }
 void cxo_bulk_get_marginals(cxo_engine *E, const int64_t *vars, int64_t n, int32_t *tags, double *a, double *b) {
     for (int64_t i = 0; i < n; i++) { cxo_value v = E->sig[E->nodes[vars[i]].marginal].value; tags[i] = v.tag; a[i] = v.a; b[i] = v.b; }
@@ -717,7 +778,7 @@ int32_t cxo_bulk_build(cxo_engine *E, int64_t n_nodes, const int32_t *kind, cons
 void cxo_engine_destroy(cxo_engine *E) {
     if (!E) return;
     for (int64_t i = 0; i < E->nsig; i++) { free(E->sig[i].deps); free(E->sig[i].xchunks); free(E->sig[i].listeners); free(E->sig[i].listenmask); }
-    for (int64_t i = 1; i <= E->nnodes; i++) { free(E->nodes[i].nb); free(E->nodes[i].nbedge); }
+    for (int64_t i = 1; i <= E->nnodes; i++) { free(E->nodes[i].nb); free(E->nodes[i].nbedge); free(E->nodes[i].linked); }
     free(E->sig); free(E->nodes); free(E->edges); free(E->var_ids); free(E->fac_ids); free(E->warn_ctx); free(E->trace); free(E->scan_out);
     free(E);
 }

@@ -17,10 +17,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("CXO_LIB", os.path.join(_HERE, "libcortex_oracle.so"))   # CXO_LIB: the sanitizer build
 
-UNDEF, REAL, NORMAL, BETA, BOOL = 0, 1, 2, 3, 4
+UNDEF, REAL, NORMAL, BETA, BOOL, NORMAL_MP, GAMMA, MVNORMAL2 = 0, 1, 2, 3, 4, 5, 6, 7
 VAR_UNSPECIFIED, VAR_MSG_TO_FACTOR, VAR_MSG_TO_VARIABLE, VAR_PRODUCT, VAR_MARGINAL, VAR_JOINT = range(6)
 F_OPAQUE, F_GAUSS_ADD, F_BERNOULLI, F_DOUBLE = range(4)
-P_SSM_BP, P_BETA_BERNOULLI, P_TRACING = range(3)
+P_SSM_BP, P_BETA_BERNOULLI, P_TRACING, P_CALLBACK = range(4)
 
 
 def build(force: bool = False) -> str:
@@ -65,6 +65,12 @@ def lib():
     sig("cxo_signal_new", i32, vp)
     sig("cxo_add_dependency", None, vp, i32, i32, i32, i32, i32, i32)
     sig("cxo_set_value", None, vp, i32, i32, dbl, dbl)
+    sig("cxo_set_value_ex", None, vp, i32, i32, pd)
+    sig("cxo_get_value_ex", i32, vp, i32, pd)
+    sig("cxo_set_rule_callback", None, vp, vp, vp)
+    sig("cxo_resolve_variable_default", None, vp, i64)
+    sig("cxo_link_signal_to_variable", None, vp, i64, i32)
+    sig("cxo_set_variant", None, vp, i32, i32, i64, i64, i32, i32)
     sig("cxo_is_pending", i32, vp, i32)
     sig("cxo_is_computed", i32, vp, i32)
     sig("cxo_get_value", i32, vp, i32, pd, pd)
@@ -110,6 +116,7 @@ def _i64(a):
 
 
 CALLBACK = C.CFUNCTYPE(C.c_int32, C.c_int32, C.c_void_p)
+RULE_CALLBACK = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double))
 
 
 class Engine:
@@ -178,6 +185,44 @@ class Engine:
             tag, a = (REAL if tag is None else tag), float(value)
         self.L.cxo_set_value(self.h, s, tag, a, b)
 
+    # wider values + user rules (P_CALLBACK): a value is (tag, [up to 6 doubles])
+    def set_value_ex(self, s, tag, payload):
+        six = (C.c_double * 6)(*(list(payload) + [0.0] * (6 - len(payload))))
+        self.L.cxo_set_value_ex(self.h, s, tag, six)
+
+    def get_value_ex(self, s):
+        six = (C.c_double * 6)()
+        tag = self.L.cxo_get_value_ex(self.h, s, six)
+        return tag, list(six)
+
+    def set_rule(self, fn):
+        """fn(signal_id) -> (tag, payload) or None; called by the restated compute! for every pending signal."""
+        def thunk(ctx, sig, tag_out, out6):
+            try:
+                r = fn(sig)
+            except Exception as ex:           # an exception must not unwind through C
+                self.rule_error = ex
+                return 0
+            if r is None:
+                return 0
+            tag, payload = r
+            tag_out[0] = tag
+            for k, x in enumerate(payload):
+                out6[k] = x
+            return 1
+        self.rule_error = None
+        self._rule_cb = RULE_CALLBACK(thunk)   # keep alive
+        self.L.cxo_set_rule_callback(self.h, C.cast(self._rule_cb, C.c_void_p), None)
+
+    def resolve_variable_default(self, var):
+        self.L.cxo_resolve_variable_default(self.h, var)
+
+    def link_signal_to_variable(self, var, s):
+        self.L.cxo_link_signal_to_variable(self.h, var, s)
+
+    def set_variant(self, s, variant, variable_id=0, factor_id=0, lo=0, hi=0):
+        self.L.cxo_set_variant(self.h, s, variant, variable_id, factor_id, lo, hi)
+
     def is_pending(self, s) -> bool:
         return bool(self.L.cxo_is_pending(self.h, s))
 
@@ -237,6 +282,8 @@ class Engine:
         if rc == 1:
             raise ValueError("Signal is not pending. Cannot compute a non-pending signal.")  # signal.jl:399-405
         if rc == 2:
+            if getattr(self, "rule_error", None) is not None:
+                raise self.rule_error
             raise RuntimeError("rule not implemented for this processor / variant")  # inference_engine.jl:358
         return None
 
