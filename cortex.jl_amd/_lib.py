@@ -16,12 +16,13 @@ ERR_INVALID_ARGUMENT, ERR_NOT_FOUND, ERR_UNSUPPORTED, ERR_STATE, ERR_DEVICE, ERR
     -1, -2, -3, -4, -5, -6, -7)
 TO_FACTOR, TO_VARIABLE = 1, 2
 ITEM_MESSAGE_TO_FACTOR, ITEM_MESSAGE_TO_VARIABLE, ITEM_INDIVIDUAL_MARGINAL = 1, 2, 4
-FORM_MOMENT, FORM_POINT, FORM_NATURAL = 0, 1, 2
-FACTOR_OPAQUE, FACTOR_GAUSS_ADDITIVE, FACTOR_GAUSS_LINEAR = 0, 1, 2
+FORM_MOMENT, FORM_POINT, FORM_NATURAL, FORM_MEAN_PRECISION, FORM_GAMMA = 0, 1, 2, 3, 4
+FACTOR_OPAQUE, FACTOR_GAUSS_ADDITIVE, FACTOR_GAUSS_LINEAR, FACTOR_NORMAL_PRECISION = 0, 1, 2, 3
 NPARAM = 4
-ROLE_OUT, ROLE_IN = 0, 1
+ROLE_OUT, ROLE_IN, ROLE_PRECISION = 0, 1, 2
 SCHED_FLOODING, SCHED_FUSED, SCHED_CHAIN_SCAN = 0, 1, 2
-FAMILY_GAUSSIAN, FAMILY_NATURAL2 = 0, 1
+FAMILY_GAUSSIAN, FAMILY_NATURAL2, FAMILY_VMP_MEAN_FIELD, FAMILY_VMP_STRUCTURED = 0, 1, 2, 3
+VMP_ALL_NORMAL, VMP_ALL_PRECISION = -1, -2
 KERNEL_VAR_TO_FACTOR, KERNEL_FACTOR_TO_VAR, KERNEL_FUSED, KERNEL_BATCH, KERNEL_BIG_VAR = 0, 1, 2, 3, 4
 KERNEL_HALO_BEGIN, KERNEL_HALO_END = 5, 6
 KERNEL_COUNT = 8
@@ -76,6 +77,8 @@ SIGNATURES = {
     "cx_comm_init": (_i32, [_vp, _i32, _i32, _vp]),
     "cx_halo_peers": (_i32, [_vp, _i32, _pi32, _pi64, _pi64, _pi64, _pi64]),
     "cx_sweep_exchange": (_i32, [_vp, _i32]),
+    "cx_set_marginals": (_i32, [_vp, _i64, _pi64, _i32, _pd]),
+    "cx_update_marginals": (_i32, [_vp, _i64, _pi64]),
     "cx_state_bytes": (_i32, [_vp, _pi64]),
     "cx_state_export": (_i32, [_vp, _vp, C.c_int64]),
     "cx_state_import": (_i32, [_vp, _vp, C.c_int64]),

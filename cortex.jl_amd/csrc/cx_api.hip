@@ -137,6 +137,7 @@ int64_t cx_payload_doubles(int32_t dim, int32_t form) {
     if (dim < 1) return -1;
     if (form == CX_FORM_POINT) return dim;
     if (form == CX_FORM_MOMENT || form == CX_FORM_NATURAL) return (int64_t)dim + (int64_t)dim * dim;
+    if ((form == CX_FORM_MEAN_PRECISION || form == CX_FORM_GAMMA) && dim == 1) return 2;
     return -1;
 }
 
@@ -160,8 +161,11 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: config is NULL or struct_size mismatch");
     if (config->dim != 1 && config->dim != 2 && config->dim != 3 && config->dim != 4 && config->dim != 64)
         return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: this build implements dim in {1, 2, 3, 4, 64}");
-    if (config->family != CX_FAMILY_GAUSSIAN && config->family != CX_FAMILY_NATURAL2)
+    const bool is_vmp = config->family == CX_FAMILY_VMP_MEAN_FIELD || config->family == CX_FAMILY_VMP_STRUCTURED;
+    if (config->family != CX_FAMILY_GAUSSIAN && config->family != CX_FAMILY_NATURAL2 && !is_vmp)
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: unknown family");
+    if (is_vmp && config->dim != 1)
+        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: the variational families need dim == 1");
     if (config->family == CX_FAMILY_NATURAL2 && (config->dim != 1 || config->schedule == CX_SCHED_CHAIN_SCAN))
         return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: CX_FAMILY_NATURAL2 needs dim == 1 and the flooding or fused schedule");
     if (config->dim > 1 && config->schedule != CX_SCHED_FUSED)
@@ -190,6 +194,7 @@ int32_t cx_destroy(cx_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     for (auto &r : h->recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     cx::comm_destroy(h);
+    cx::vmp_free(h);
     dev_free_all(h);
     delete h;
     return CX_OK;
@@ -205,7 +210,7 @@ int32_t cx_set_stream(cx_handle *h, void *hip_stream) {
     CX_REQUIRE(h, h, CX_ERR_INVALID_ARGUMENT, "null handle");
     CX_HIP(h, hipStreamSynchronize(h->stream));
     h->stream = (hipStream_t)hip_stream;
-    return CX_OK;
+    return cx::vmp_set_stream(h);
 }
 
 // (re)upload the (P, B, C) rule tables of every registered parameter set (dim > 1)
@@ -246,6 +251,11 @@ int32_t cx_set_factor_matrices(cx_handle *h, int64_t parameter_set, const double
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_set_factor_matrices: host allocation failed"); }
 }
 
+static inline bool is_vmp(const cx_handle *h) {
+    return h->cfg.family == CX_FAMILY_VMP_MEAN_FIELD || h->cfg.family == CX_FAMILY_VMP_STRUCTURED;
+}
+#define CX_NOT_VMP(h, name) CX_REQUIRE(h, !(h) || !is_vmp(h), CX_ERR_UNSUPPORTED, name ": not available for the variational families (their state is the set of marginals: cx_set_marginals / cx_update_marginals)")
+
 int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, const int64_t *edge_fac,
                         const int32_t *edge_role, int64_t n_factors, const int64_t *factor_ids,
                         const int32_t *factor_kind, const double *factor_params) {
@@ -253,6 +263,12 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
     CX_REQUIRE(h, !h->has_graph, CX_ERR_STATE, "cx_graph_create: handle already has a graph");
     CX_REQUIRE(h, n_edges > 0 && edge_var && edge_fac, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: empty edge list");
     CX_REQUIRE(h, n_edges < (int64_t)0x0fffffff, CX_ERR_UNSUPPORTED, "cx_graph_create: more than 2^28-1 edges per handle");
+    if (is_vmp(h)) {
+        CX_REQUIRE(h, n_factors > 0 && factor_ids && factor_kind, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: factor table missing");
+        int32_t rc = cx::vmp_graph_create(h, n_edges, edge_var, edge_fac, edge_role, n_factors, factor_ids, factor_kind);
+        if (rc != CX_OK) cx::vmp_free(h);
+        return rc;
+    }
     CX_REQUIRE(h, n_factors > 0 && factor_ids && factor_kind && factor_params, CX_ERR_INVALID_ARGUMENT,
                "cx_graph_create: factor table missing");
     try {
@@ -800,6 +816,7 @@ static int32_t ensure_v2f(cx_handle *h) {
 
 int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, int32_t direction,
                         int32_t form, const double *payload) {
+    CX_NOT_VMP(h, "cx_set_messages");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_set_messages: no graph");
     CX_REQUIRE(h, direction == CX_TO_FACTOR || direction == CX_TO_VARIABLE, CX_ERR_INVALID_ARGUMENT, "cx_set_messages: bad direction");
     CX_REQUIRE(h, form == CX_FORM_MOMENT || form == CX_FORM_POINT || form == CX_FORM_NATURAL, CX_ERR_INVALID_ARGUMENT, "cx_set_messages: bad form");
@@ -844,6 +861,7 @@ int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
 
 int32_t cx_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, int32_t direction,
                         int32_t form, double *out) {
+    CX_NOT_VMP(h, "cx_get_messages");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_get_messages: no graph");
     CX_REQUIRE(h, direction == CX_TO_FACTOR || direction == CX_TO_VARIABLE, CX_ERR_INVALID_ARGUMENT, "cx_get_messages: bad direction");
     CX_REQUIRE(h, form == CX_FORM_MOMENT || form == CX_FORM_NATURAL, CX_ERR_INVALID_ARGUMENT, "cx_get_messages: bad form");
@@ -872,6 +890,7 @@ int32_t cx_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
 }
 
 int32_t cx_seed_messages(cx_handle *h, int32_t direction, double mean, double variance) {
+    CX_NOT_VMP(h, "cx_seed_messages");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_seed_messages: no graph");
     CX_REQUIRE(h, direction == CX_TO_FACTOR || direction == CX_TO_VARIABLE, CX_ERR_INVALID_ARGUMENT, "cx_seed_messages: bad direction");
     CX_REQUIRE(h, variance > 0.0, CX_ERR_INVALID_ARGUMENT, "cx_seed_messages: variance must be > 0");
@@ -904,6 +923,7 @@ int32_t cx_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, d
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_get_marginals: no graph");
     if (n == 0) return CX_OK;
     CX_REQUIRE(h, n > 0 && variable_ids && out, CX_ERR_INVALID_ARGUMENT, "cx_get_marginals: null argument");
+    if (is_vmp(h)) return cx::vmp_get_marginals(h, n, variable_ids, out);
     if (h->cfg.dim > 1) { try { return mv_get_marginals(h, n, variable_ids, out); } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_get_marginals: host allocation failed"); } }
     try {
         std::vector<int32_t> idx(n);
@@ -926,6 +946,7 @@ int32_t cx_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, d
 }
 
 int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
+    CX_NOT_VMP(h, "cx_update_batch");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_update_batch: no graph");
     if (n == 0) return CX_OK;
     CX_REQUIRE(h, n > 0 && items, CX_ERR_INVALID_ARGUMENT, "cx_update_batch: null argument");
@@ -1061,6 +1082,7 @@ static void sweep_finish(cx_handle *h) {
 }
 
 int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
+    CX_NOT_VMP(h, "cx_sweep");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep: no graph");
     CX_REQUIRE(h, n_sweeps >= 0, CX_ERR_INVALID_ARGUMENT, "cx_sweep: n_sweeps < 0");
     if (h->cfg.dim > 1) return mv_sweep(h, n_sweeps);
@@ -1073,6 +1095,7 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
 }
 
 int32_t cx_sweep_begin(cx_handle *h) {
+    CX_NOT_VMP(h, "cx_sweep_begin");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep_begin: no graph");
     CX_REQUIRE(h, h->cfg.dim == 1, CX_ERR_UNSUPPORTED, "cx_sweep_begin: partitioned sweeps are implemented for dim == 1 only in this build");
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_sweep_begin: previous sweep not ended");
@@ -1100,6 +1123,7 @@ int32_t cx_sweep_end(cx_handle *h) {
 }
 
 int32_t cx_residual(cx_handle *h, double *out) {
+    CX_NOT_VMP(h, "cx_residual");
     CX_REQUIRE(h, h && h->has_graph && out, CX_ERR_STATE, "cx_residual: no graph / null out");
     if (h->cfg.dim > 1) return mv_residual(h, out);
     if (!h->d_prev) {
@@ -1124,6 +1148,7 @@ int32_t cx_residual(cx_handle *h, double *out) {
 // ---- halo -------------------------------------------------------------------------------------------------------
 int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const int64_t *sf, int64_t n_recv,
                           const int64_t *rv, const int64_t *rf) {
+    CX_NOT_VMP(h, "cx_halo_configure");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_configure: no graph");
     CX_REQUIRE(h, h->cfg.dim == 1, CX_ERR_UNSUPPORTED, "cx_halo_configure: partitioned sweeps are implemented for dim == 1 only in this build");
     CX_REQUIRE(h, n_send >= 0 && n_recv >= 0, CX_ERR_INVALID_ARGUMENT, "cx_halo_configure: negative count");
@@ -1239,10 +1264,27 @@ int32_t cx_sweep_exchange(cx_handle *h, int32_t n_sweeps) {
     return CX_OK;
 }
 
+// ---- variational families (cx_vmp.hip) --------------------------------------------------------------------------------
+int32_t cx_set_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, int32_t form, const double *payload) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_set_marginals: no graph");
+    CX_REQUIRE(h, is_vmp(h), CX_ERR_UNSUPPORTED, "cx_set_marginals: only the variational families keep settable marginals (sum-product marginals are products of messages: cx_set_messages)");
+    if (n == 0) return CX_OK;
+    CX_REQUIRE(h, n > 0 && variable_ids && payload, CX_ERR_INVALID_ARGUMENT, "cx_set_marginals: null argument");
+    return cx::vmp_set_marginals(h, n, variable_ids, form, payload);
+}
+
+int32_t cx_update_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids) {
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_update_marginals: no graph");
+    CX_REQUIRE(h, is_vmp(h), CX_ERR_UNSUPPORTED, "cx_update_marginals: variational families only (sum-product handles run cx_sweep / cx_update_batch)");
+    if (n == 0) return CX_OK;
+    return cx::vmp_update_marginals(h, n, variable_ids);
+}
+
 // ---- checkpoint: the mutable state of a handle as one relocatable blob ------------------------------
 // The reference keeps no persistent state (nothing to mirror); with all messages resident in HBM a long loopy run needs
 // a way to stop and resume.  The blob holds the message buffers, marginals and observed-variable flags bit for bit, plus
 // a fingerprint of the flattened graph so that it can only be restored into a handle built from the same graph.
+extern "C++" {
 namespace {
 
 struct StateHeader {
@@ -1291,10 +1333,12 @@ std::vector<StatePart> state_parts(cx_handle *h) {
 }
 
 }  // namespace
+}  // extern "C++"
 
 int32_t cx_state_bytes(const cx_handle *hc, int64_t *bytes) {
     cx_handle *h = const_cast<cx_handle *>(hc);
     CX_REQUIRE(h, h && h->has_graph && bytes, CX_ERR_STATE, "cx_state_bytes: no graph or null argument");
+    CX_NOT_VMP(h, "cx_state_bytes");
     int64_t n = (int64_t)sizeof(StateHeader);
     for (auto &p : state_parts(h)) n += (int64_t)sizeof(StateSection) + p.bytes;
     *bytes = n;
@@ -1302,6 +1346,7 @@ int32_t cx_state_bytes(const cx_handle *hc, int64_t *bytes) {
 }
 
 int32_t cx_state_export(cx_handle *h, void *buf, int64_t bytes) {
+    CX_NOT_VMP(h, "cx_state_export");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_state_export: no graph");
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_state_export: a cx_sweep_begin is still open");
     int64_t need = 0;
@@ -1328,6 +1373,7 @@ int32_t cx_state_export(cx_handle *h, void *buf, int64_t bytes) {
 }
 
 int32_t cx_state_import(cx_handle *h, const void *buf, int64_t bytes) {
+    CX_NOT_VMP(h, "cx_state_import");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_state_import: no graph");
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_state_import: a cx_sweep_begin is still open");
     CX_REQUIRE(h, buf && bytes >= (int64_t)sizeof(StateHeader), CX_ERR_INVALID_ARGUMENT, "cx_state_import: blob too short");

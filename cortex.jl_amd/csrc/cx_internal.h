@@ -108,6 +108,9 @@ struct cx_handle {
     bool in_sweep = false;
     bool v2f_stale = false;          // fused schedule without materialisation: v2f must be recomputed before use
 
+    // variational families (cx_vmp.hip): opaque state
+    void *vmp = nullptr;
+
     // staging for set/get/batch
     void *d_stage = nullptr;
     int64_t stage_bytes = 0;
@@ -163,6 +166,14 @@ void mv64_rows_gather(cx_handle *h, const double *src, const int32_t *d_idx, dou
 void mv64_set_point(cx_handle *h, double *dst, const int32_t *d_idx, const double *d_y, int64_t n);
 bool mv_rule_tables(int d, const double *A, const double *Q, double *out);
 size_t chain_total_bytes(int64_t nlinks);
+// variational families (cx_vmp.hip)
+int32_t vmp_graph_create(cx_handle *h, int64_t ne, const int64_t *edge_var, const int64_t *edge_fac, const int32_t *edge_role,
+                         int64_t nf, const int64_t *factor_ids, const int32_t *factor_kind);
+int32_t vmp_set_marginals(cx_handle *h, int64_t n, const int64_t *ids, int32_t form, const double *payload);
+int32_t vmp_get_marginals(cx_handle *h, int64_t n, const int64_t *ids, double *out);
+int32_t vmp_update_marginals(cx_handle *h, int64_t n, const int64_t *ids);
+int32_t vmp_set_stream(cx_handle *h);
+void vmp_free(cx_handle *h);
 // RCCL halo exchange (cx_comm.hip)
 bool comm_unique_id(void *out128, std::string &err);
 bool comm_init(cx_handle *h, int world, int rank, const void *id128, std::string &err);

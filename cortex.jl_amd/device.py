@@ -184,6 +184,23 @@ class DeviceGraph:
     def sweep_exchange(self, n: int = 1):
         self._check(self.lib.cx_sweep_exchange(self.h, int(n)))
 
+    # -- variational families (cx_set_marginals / cx_update_marginals) ----------------------------
+    def set_marginals(self, variable_ids, form: int, payload):
+        v = _i64(np.atleast_1d(variable_ids))
+        p = _f64(payload)
+        need = len(v) * (1 if form == L.FORM_POINT else 2)
+        if p.size != need:
+            raise ValueError(f"payload has {p.size} doubles, expected {need}")
+        self._check(self.lib.cx_set_marginals(self.h, len(v), _p(v, C.c_int64), form, _p(p, C.c_double)))
+
+    def update_marginals(self, variable_ids):
+        """One `update_marginals!(engine, ids)`; `variable_ids` may be L.VMP_ALL_NORMAL / L.VMP_ALL_PRECISION."""
+        if isinstance(variable_ids, (int, np.integer)) and variable_ids < 0:
+            self._check(self.lib.cx_update_marginals(self.h, int(variable_ids), None))
+            return
+        v = _i64(np.atleast_1d(variable_ids))
+        self._check(self.lib.cx_update_marginals(self.h, len(v), _p(v, C.c_int64)))
+
     # -- checkpoint (cx_state_*) -----------------------------------------------------------------
     def export_state(self) -> np.ndarray:
         """The handle's mutable state (messages, marginals, observed flags, sweep counter) as a uint8 array."""

@@ -181,3 +181,52 @@ def load_into_device(model: Model, dev, seed_variance: float | None = None):
     if seed_variance is not None:
         dev.seed_messages(L.TO_VARIABLE, 0.0, seed_variance)
     return dev
+
+
+# ---- variational state-space model ----------------------------------------------------------------
+@dataclass
+class VmpModel:
+    """The graph of test/inference_engine_tests.jl:691-715 / :1032-1056: ssnoise (id 1), obsnoise (2), x_1..x_n,
+    y_1..y_n, n likelihood factors (y_i, x_i, obsnoise) and n - 1 transition factors (x_i, x_{i+1}, ssnoise)."""
+    n: int
+    edge_var: np.ndarray
+    edge_fac: np.ndarray
+    edge_role: np.ndarray
+    factor_ids: np.ndarray
+    x_ids: np.ndarray
+    y_ids: np.ndarray
+    ssnoise: int
+    obsnoise: int
+    data_y: np.ndarray
+
+
+def vmp_ssm(n: int, seed: int = 1234, ssnoise_real: float = 100.0, obsnoise_real: float = 100.0) -> VmpModel:
+    """Random walk with transition precision `ssnoise_real`, observed with precision `obsnoise_real` (:775-785)."""
+    rng = np.random.default_rng(seed)
+    steps = rng.standard_normal(n) / np.sqrt(ssnoise_real)
+    steps[0] = 0.0
+    walk = np.cumsum(steps)
+    y = walk + rng.standard_normal(n) / np.sqrt(obsnoise_real)
+    ss, obs = 1, 2
+    x = np.arange(3, 3 + n, dtype=np.int64)
+    yv = np.arange(3 + n, 3 + 2 * n, dtype=np.int64)
+    lik = np.arange(3 + 2 * n, 3 + 3 * n, dtype=np.int64)
+    tr = np.arange(3 + 3 * n, 3 + 4 * n - 1, dtype=np.int64)
+    one = np.ones(n, dtype=np.int64)
+    ev = np.concatenate([yv, x, obs * one, x[:-1], x[1:], ss * one[:-1]])
+    ef = np.concatenate([lik, lik, lik, tr, tr, tr])
+    role = np.concatenate([np.full(n, L.ROLE_OUT), np.full(n, L.ROLE_IN), np.full(n, L.ROLE_PRECISION),
+                           np.full(n - 1, L.ROLE_IN), np.full(n - 1, L.ROLE_OUT), np.full(n - 1, L.ROLE_PRECISION)]).astype(np.int32)
+    return VmpModel(n=n, edge_var=ev, edge_fac=ef, edge_role=role, factor_ids=np.concatenate([lik, tr]), x_ids=x, y_ids=yv,
+                    ssnoise=ss, obsnoise=obs, data_y=y)
+
+
+def load_vmp_into_device(model: VmpModel, dev):
+    """graph upload + the initial marginals and the data of :717-736"""
+    nf = len(model.factor_ids)
+    dev.graph_create(model.edge_var, model.edge_fac, model.factor_ids, np.full(nf, L.FACTOR_NORMAL_PRECISION, dtype=np.int32),
+                     np.zeros(nf), edge_role=model.edge_role)
+    dev.set_marginals([model.ssnoise, model.obsnoise], L.FORM_GAMMA, [1.0, 1.0, 1.0, 1.0])
+    dev.set_marginals(model.x_ids, L.FORM_MEAN_PRECISION, np.tile([0.0, 1.0], model.n))
+    dev.set_marginals(model.y_ids, L.FORM_POINT, model.data_y)
+    return dev

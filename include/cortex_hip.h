@@ -65,17 +65,23 @@ extern "C" {
 #define CX_FORM_MOMENT 0  /* Gaussian (mean, variance|covariance) */
 #define CX_FORM_POINT 1   /* observed datum: the `Real` input of test/inference_engine_tests.jl:424 ; dim values */
 #define CX_FORM_NATURAL 2 /* (xi = precision*mean, w = precision): the library's storage form */
+#define CX_FORM_MEAN_PRECISION 3 /* NormalMeanPrecision(mean, precision), test/runtests.jl:48-56 (variational families) */
+#define CX_FORM_GAMMA 4          /* Gamma(shape, scale), test/runtests.jl:60-67 (variational families) */
 
 /* factor kinds (what the user rule reads from Factor.functional_form, model_engine.jl:119-122) */
 #define CX_FACTOR_OPAQUE 0          /* messages only ever set by the caller (priors, unary observations) */
 #define CX_FACTOR_GAUSS_ADDITIVE 1  /* 2 edges: x_b = x_a + N(0, q)            params = {q}                */
 #define CX_FACTOR_GAUSS_LINEAR 2    /* 2 edges: x_out = a*x_in + b + N(0, q)   params = {q, a, b}          */
                                     /* dim>1:   x_out = A x_in + N(0, Q)       params via cx_set_factor_matrices */
+#define CX_FACTOR_NORMAL_PRECISION 3 /* 3 edges (variational families): x_out ~ N(x_in, 1 / precision); roles OUT, IN,
+                                       PRECISION — the :likelihood and :transition factors of
+                                       test/inference_engine_tests.jl:691-715 */
 #define CX_NPARAM 4                 /* doubles per factor in factor_params */
 
 /* edge roles for directed factors (Connection.label :out/:in, model_engine.jl:182) */
 #define CX_ROLE_OUT 0
 #define CX_ROLE_IN 1
+#define CX_ROLE_PRECISION 2   /* the Gamma-distributed precision of a CX_FACTOR_NORMAL_PRECISION factor */
 
 /* message families for dim == 1.  The sweep's products are sums of natural parameters for ANY exponential family; only
  * the factor rules, the moment conversions at the ABI and the marginal read-out are Gaussian-specific. */
@@ -84,6 +90,14 @@ extern "C" {
                                  Beta-Bernoulli model of test/inference_engine_tests.jl:241-377.  Payloads are NATURAL only,
                                  factors are CX_FACTOR_OPAQUE (their messages are set by the caller), marginals come back as
                                  the natural-parameter sums. */
+/* Variational message passing: messages depend WEAKLY on marginals (add_dependency!(...; weak = true), signal.jl:36-45).
+ * The state is the set of marginals (cx_set_marginals / cx_update_marginals / cx_get_marginals); cx_sweep, cx_update_batch
+ * and the message accessors do not apply.  Factors are CX_FACTOR_NORMAL_PRECISION, dim == 1. */
+#define CX_FAMILY_VMP_MEAN_FIELD 2  /* fully factorised posterior: the MeanFieldResolver + SSMMeanFieldInferenceRequestProcessor
+                                       of test/inference_engine_tests.jl:599-689 */
+#define CX_FAMILY_VMP_STRUCTURED 3  /* Normal variables jointly (belief propagation with E[precision], run with cfg.schedule —
+                                       CX_SCHED_CHAIN_SCAN gives the exact forward/backward pass per update), precisions from
+                                       the joint marginals: StructuredResolver + SSMStructuredInferenceRequestProcessor, :810-1030 */
 
 /* schedules of cx_sweep */
 #define CX_SCHED_FLOODING 0   /* all variable→factor, then all factor→variable, then marginals           */
@@ -157,6 +171,23 @@ int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
                         int32_t direction, int32_t form, const double *payload);
 int32_t cx_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids,
                         int32_t direction, int32_t form, double *out);
+/* ---- variational families: the marginals are the state -------------------------------------------------------------
+ * cx_set_marginals    : the user's set_value!(get_variable_marginal(...), value) (test/inference_engine_tests.jl:717-727,
+ *                       :734-736): CX_FORM_POINT observes a Normal variable (1 double), CX_FORM_MEAN_PRECISION /
+ *                       CX_FORM_MOMENT initialise a latent Normal variable, CX_FORM_GAMMA a precision variable (2 doubles).
+ * cx_update_marginals : one update_marginals!(engine, variable_ids) (src/inference_engine.jl:559-632) under the weak
+ *                       wiring: the messages into the requested variables are computed from the marginals as they stand
+ *                       before the call, then the requested marginals are stored.  n may be CX_VMP_ALL_NORMAL or
+ *                       CX_VMP_ALL_PRECISION (variable_ids ignored) to name a whole class without an id list.
+ *                       CX_FAMILY_VMP_STRUCTURED updates the latent Normal variables together and refuses requests that
+ *                       mix them with precision variables (in the reference the evaluation order of such a request is
+ *                       an artefact of the lazy readiness flags).  Asynchronous on the handle's stream.
+ * cx_get_marginals    : (mean, precision) for Normal variables ((datum, +inf) when observed), (shape, scale) for precisions. */
+#define CX_VMP_ALL_NORMAL (-1)
+#define CX_VMP_ALL_PRECISION (-2)
+int32_t cx_set_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, int32_t form, const double *payload);
+int32_t cx_update_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids);
+
 /* give every still-undefined message of `direction` the value N(mean, variance*I): the seeding a user of
  * the reference does by hand before loopy BP (cf. test/inference_engine_tests.jl:729-736) */
 int32_t cx_seed_messages(cx_handle *h, int32_t direction, double mean, double variance);

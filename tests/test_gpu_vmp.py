@@ -1,0 +1,145 @@
+"""-m gpu: the variational families (cx_set_marginals / cx_update_marginals) against the array form of the reference's
+update_marginals! on its two variational SSM test models (oracle/vmp.py, itself pinned call by call against the restated
+engine in tests/test_vmp_restatement.py) and against the engine restatement directly.
+
+Tolerance: the device sums natural parameters (Normal) and rates (Gamma) in a fixed tree; the reference folds
+mean/precision and shape/scale pairs left to right or through its segment tree — identical up to rounding, RTOL 1e-10."""
+import numpy as np
+import pytest
+
+import cortex.jl_amd as cx
+from cortex.jl_amd import _lib as L
+from oracle import vmp
+from tests import vmp_support as S
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+
+
+def _device(model, family, schedule=L.SCHED_CHAIN_SCAN):
+    dev = cx.DeviceGraph(family=family, schedule=schedule)
+    cx.synth.load_vmp_into_device(model, dev)
+    return dev
+
+
+def _state(dev, model):
+    xs = dev.get_marginals(model.x_ids)
+    g = dev.get_marginals([model.ssnoise, model.obsnoise])
+    return np.concatenate([xs[:, 0], xs[:, 1], g[0], g[1]])
+
+
+def _array_state(arr):
+    return np.concatenate([arr.xm, arr.xw, arr.ss, arr.obs])
+
+
+def _ids_of(model, which):
+    out = []
+    for w in which:
+        out += list(model.x_ids) if w == "x" else [model.ssnoise if w == "ssnoise" else model.obsnoise]
+    return out
+
+
+MF_SEQ = [["x"], ["ssnoise"], ["obsnoise"], ["obsnoise"], ["ssnoise"], ["ssnoise", "obsnoise"], ["x"], ["x", "ssnoise", "obsnoise"],
+          ["obsnoise", "x"]]
+ST_SEQ = [["obsnoise"], ["ssnoise"], ["x"], ["ssnoise"], ["ssnoise"], ["ssnoise"], ["x"], ["x"], ["obsnoise"], ["obsnoise"],
+          ["ssnoise", "obsnoise"]]
+
+
+@pytest.mark.parametrize("n", [2, 3, 8, 100, 5000])
+def test_mean_field_calls_match_the_array_form(hip_lib, n):
+    model = cx.synth.vmp_ssm(n, seed=11)
+    dev = _device(model, L.FAMILY_VMP_MEAN_FIELD)
+    arr = vmp.MeanFieldVMP(model.data_y)
+    for it in range(4):
+        for which in MF_SEQ:
+            dev.update_marginals(_ids_of(model, which))
+            arr.update(which)
+            np.testing.assert_allclose(_state(dev, model), _array_state(arr), rtol=RTOL, atol=0, err_msg=f"n={n} it={it} {which}")
+
+
+@pytest.mark.parametrize("schedule", [L.SCHED_CHAIN_SCAN])
+@pytest.mark.parametrize("n", [7, 8, 100, 5000])
+def test_structured_calls_match_the_array_form(hip_lib, n, schedule):
+    model = cx.synth.vmp_ssm(n, seed=12)
+    dev = _device(model, L.FAMILY_VMP_STRUCTURED, schedule)
+    arr = vmp.StructuredVMP(model.data_y)
+    for it in range(4):
+        for which in ST_SEQ:
+            dev.update_marginals(_ids_of(model, which))
+            arr.update(which)
+            np.testing.assert_allclose(_state(dev, model), _array_state(arr), rtol=1e-9, atol=0, err_msg=f"n={n} it={it} {which}")
+
+
+@pytest.mark.parametrize("kind,family,rule", [("mean_field", L.FAMILY_VMP_MEAN_FIELD, S.mean_field_rule),
+                                              ("structured", L.FAMILY_VMP_STRUCTURED, S.structured_rule)])
+def test_reference_experiment_against_the_restated_engine(hip_lib, kind, family, rule):
+    """The reference's own experiment (n = 100, its sequence of update_marginals! calls, class by class) on the device and
+    on the C restatement of the engine driven through the transcribed resolvers and rules."""
+    n, iters = 100, 30
+    model = cx.synth.vmp_ssm(n, seed=1234)
+    dev = _device(model, family)
+    be = S.OracleBackend(rule)
+    calls_of = S.mean_field_calls if kind == "mean_field" else S.structured_calls_by_class
+    checked = [0]
+
+    def on_call(it, ids):
+        dev.update_marginals(ids)
+        if it in (1, 2, iters):
+            got = _state(dev, model)
+            xs = np.array([be.get_marginal(int(v))[1][:2] for v in model.x_ids])
+            want = np.concatenate([xs[:, 0], xs[:, 1], be.get_marginal(1)[1][:2], be.get_marginal(2)[1][:2]])
+            np.testing.assert_allclose(got, want, rtol=1e-8, atol=0, err_msg=f"{kind}: iteration {it}, request {ids[:3]}")
+            checked[0] += 1
+
+    ans = S.run_experiment(be, kind, list(model.data_y), iters, on_call=on_call, calls_of=calls_of)
+    assert checked[0] > 20
+    g = dev.get_marginals([model.ssnoise, model.obsnoise])
+    assert g[0, 0] * g[0, 1] == pytest.approx(S.mean(ans["ssnoise"]), rel=1e-8)
+    assert g[1, 0] * g[1, 1] == pytest.approx(S.mean(ans["obsnoise"]), rel=1e-8)
+
+
+def test_class_selectors_equal_id_lists(hip_lib):
+    model = cx.synth.vmp_ssm(300, seed=5)
+    a, b = _device(model, L.FAMILY_VMP_STRUCTURED), _device(model, L.FAMILY_VMP_STRUCTURED)
+    for _ in range(3):
+        a.update_marginals(model.x_ids); b.update_marginals(L.VMP_ALL_NORMAL)
+        a.update_marginals([model.ssnoise, model.obsnoise]); b.update_marginals(L.VMP_ALL_PRECISION)
+    assert np.array_equal(_state(a, model), _state(b, model))
+
+
+def test_vmp_recovers_the_noise_precisions_at_scale(hip_lib):
+    """n = 200,000: structured VMP to convergence; the posterior means of both precisions land on the true value 100."""
+    model = cx.synth.vmp_ssm(200_000, seed=3)
+    dev = _device(model, L.FAMILY_VMP_STRUCTURED)
+    for _ in range(60):
+        dev.update_marginals(L.VMP_ALL_NORMAL)
+        dev.update_marginals(L.VMP_ALL_PRECISION)
+    g = dev.get_marginals([model.ssnoise, model.obsnoise])
+    assert g[0, 0] * g[0, 1] == pytest.approx(100.0, rel=0.03)
+    assert g[1, 0] * g[1, 1] == pytest.approx(100.0, rel=0.03)
+
+
+def test_vmp_errors(hip_lib):
+    model = cx.synth.vmp_ssm(10, seed=1)
+    dev = _device(model, L.FAMILY_VMP_STRUCTURED)
+    with pytest.raises(cx.CortexHipError, match="separate calls"):
+        dev.update_marginals([model.ssnoise] + list(model.x_ids))
+    with pytest.raises(cx.CortexHipError, match="together"):
+        dev.update_marginals(model.x_ids[:3])
+    with pytest.raises(cx.CortexHipError, match="unknown variable id"):
+        dev.update_marginals([10_000])
+    with pytest.raises(cx.CortexHipError, match="not available for the variational families"):
+        dev.sweep(1)
+    with pytest.raises(cx.CortexHipError, match="precision variable"):
+        dev.set_marginals([model.ssnoise], L.FORM_MEAN_PRECISION, [0.0, 1.0])
+    with pytest.raises(cx.CortexHipError, match="shape > 0"):
+        dev.set_marginals([model.ssnoise], L.FORM_GAMMA, [-1.0, 1.0])
+    with pytest.raises(cx.CortexHipError, match="is observed"):
+        dev.set_marginals([model.y_ids[0]], L.FORM_MEAN_PRECISION, [0.0, 1.0])
+    plain = cx.DeviceGraph()
+    cx.synth.load_into_device(cx.synth.ssm_chain(5), plain)
+    with pytest.raises(cx.CortexHipError, match="variational families only"):
+        plain.update_marginals([1])
+    bad = cx.DeviceGraph(family=L.FAMILY_VMP_MEAN_FIELD)
+    with pytest.raises(cx.CortexHipError, match="edge_role"):
+        bad.graph_create(model.edge_var, model.edge_fac, model.factor_ids, np.full(len(model.factor_ids), L.FACTOR_NORMAL_PRECISION), np.zeros(len(model.factor_ids)))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/bench_configs.py — timings of the non-headline configs of BASELINE.json (C2 chain scan, C3 d=4, C5 d=64).
 Not the driver's bench (bench.py measures C4); prints one JSON line per config for DESIGN.md / profiles/.
-    python tools/bench_configs.py [c2] [c3] [c5]"""
+    python tools/bench_configs.py [c2] [c3] [c5] [vmp]"""
 import json
 import os
 import sys
@@ -65,9 +65,41 @@ def mv(d, T, steps):
     return out
 
 
+def vmp(n=1_000_000):
+    """one variational iteration (all latent states, then both precisions) of the reference's SSM with
+    unknown noise precisions, n states: 2n - 1 three-way factors, 6n - 3 edges."""
+    model = cx.synth.vmp_ssm(n, seed=1234)
+    out = []
+    for name, fam in (("structured", L.FAMILY_VMP_STRUCTURED), ("mean_field", L.FAMILY_VMP_MEAN_FIELD)):
+        dev = cx.DeviceGraph(family=fam, schedule=L.SCHED_CHAIN_SCAN)
+        cx.synth.load_vmp_into_device(model, dev)
+
+        def it():
+            dev.update_marginals(L.VMP_ALL_NORMAL)
+            dev.update_marginals(L.VMP_ALL_PRECISION)
+        dt = timed(dev, it, 50, 10)
+        g = dev.get_marginals([model.ssnoise, model.obsnoise])
+        st = dev.stats()
+        # CPU figure beside it: the array form of the same two calls (numpy, one core) — test infrastructure, timed only
+        from oracle import vmp as ovmp
+        arr = (ovmp.StructuredVMP if name == "structured" else ovmp.MeanFieldVMP)(model.data_y[:200_000])
+        t0 = time.perf_counter()
+        arr._store_x(arr._x())
+        cpu_x = (time.perf_counter() - t0) * (n / 200_000)
+        out.append({"config": "VMP", "workload": f"{name} VMP, SSM with unknown precisions, n={n} states ({st['n_edges']} edges, {st['n_factors']} factors)",
+                    "ms_per_iteration": dt * 1e3, "messages_per_iteration": st["n_messages_per_sweep"],
+                    "messages_per_s": st["n_messages_per_sweep"] / dt, "E_ssnoise": g[0, 0] * g[0, 1], "E_obsnoise": g[1, 0] * g[1, 1],
+                    "cpu_numpy_state_update_ms_scaled": cpu_x * 1e3})
+    return out
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c2", "c3", "c5"]
     torch.cuda.init()
     for w in which:
+        if w == "vmp":
+            for r in vmp():
+                print(json.dumps(r), flush=True)
+            continue
         r = c2() if w == "c2" else (mv(4, 1_000_000, 30) if w == "c3" else mv(64, 100_000, 20))
         print(json.dumps(r), flush=True)
