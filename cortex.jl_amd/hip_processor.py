@@ -193,3 +193,111 @@ class HipProcessor(AbstractInferenceRequestProcessor):
 
     def refresh_marginals(self, ids):
         self.dev.update_batch([L.ITEM_INDIVIDUAL_MARGINAL] * len(ids), list(ids), [0] * len(ids))
+
+
+# ---- variational families --------------------------------------------------------------------------
+@dataclass(frozen=True)
+class NormalMeanPrecision:
+    """test/runtests.jl:48-56"""
+    mean: float
+    precision: float
+
+
+@dataclass(frozen=True)
+class Gamma:
+    """test/runtests.jl:60-67"""
+    shape: float
+    scale: float
+
+
+@dataclass(frozen=True)
+class NormalPrecisionFactor:
+    """functional_form of a 3-edge factor out ~ N(mean, 1 / precision): the :likelihood and :transition factors of
+    test/inference_engine_tests.jl:691-715.  `roles` maps a connected variable's *name* to its role
+    ("out" | "mean" | "precision"); with two variables of one name (x_i, x_{i+1}) the lower id is the mean."""
+    roles: Tuple[Tuple[str, str], ...]
+
+
+class HipVmpValue:
+    """Host-side handle of a device-held marginal of the variational families (`.mean`, `.precision` / `.shape`,
+    `.scale` read the device on first use)."""
+    __slots__ = ("_proc", "_vid", "_cache")
+
+    def __init__(self, proc, vid):
+        self._proc, self._vid, self._cache = proc, vid, None
+
+    def get(self):
+        if self._cache is None:
+            self._cache = self._proc.read_marginal(self._vid)
+        return self._cache
+
+    def __getattr__(self, name):
+        return getattr(self.get(), name)
+
+    def __repr__(self):
+        return f"HipVmpValue(variable {self._vid})"
+
+
+class HipVmpProcessor(AbstractInferenceRequestProcessor):
+    """The variational families behind the reference's plugin API.  With weak dependencies every `update_marginals!`
+    is a whole-call takeover (cx_update_marginals); initial marginals and data enter through `set_value` on the
+    marginal signals, exactly where the reference's tests call `set_value!(get_variable_marginal(...), ...)`.
+
+    family = "mean_field" (MeanFieldResolver wiring) or "structured" (StructuredResolver wiring); the engine is built
+    with `resolve_dependencies=False`: the dependency wiring these resolvers would create is what the device path
+    implements, the host keeps only the marginal signals."""
+
+    def __init__(self, *, family: str = "structured", device: int = 0, schedule: int = L.SCHED_CHAIN_SCAN):
+        if family not in ("mean_field", "structured"):
+            raise ValueError(f"unknown family {family!r}")
+        fam = L.FAMILY_VMP_MEAN_FIELD if family == "mean_field" else L.FAMILY_VMP_STRUCTURED
+        self.dev = DeviceGraph(device=device, schedule=schedule, family=fam)
+        self.engine: Optional[InferenceEngine] = None
+        self.kind = {}
+
+    def attach(self, engine: InferenceEngine):
+        self.engine = engine
+        ev, ef, role, fids = [], [], [], []
+        for f in engine.get_factor_ids():
+            ff = get_factor_functional_form(engine.get_factor(f))
+            if not isinstance(ff, NormalPrecisionFactor):
+                raise NotImplementedError(f"The HIP VMP processor has no rule for a factor with functional form {ff!r}")
+            roles = dict(ff.roles)
+            seen_mean = False
+            fids.append(f)
+            for v in engine.get_connected_variable_ids(f):          # ascending ids
+                name = str(engine.get_variable(v).name).lstrip(":")
+                r = roles[name]
+                if r == "both":                                      # two variables of one name: lower id = mean
+                    r = "out" if seen_mean else "mean"
+                    seen_mean = True
+                ev.append(v); ef.append(f)
+                role.append({"out": L.ROLE_OUT, "mean": L.ROLE_IN, "precision": L.ROLE_PRECISION}[r])
+                self.kind[v] = "gamma" if r == "precision" else "normal"
+        self.dev.graph_create(ev, ef, fids, [L.FACTOR_NORMAL_PRECISION] * len(fids), np.zeros(len(fids)), edge_role=role)
+
+    def set_value(self, signal: Signal, value):
+        variant = signal.variant
+        if not isinstance(variant, V.IndividualMarginal):
+            raise TypeError("HipVmpProcessor.set_value: the state of the variational families is the set of marginals")
+        vid = variant.variable_id
+        if isinstance(value, Gamma):
+            self.dev.set_marginals([vid], L.FORM_GAMMA, [value.shape, value.scale])
+        elif isinstance(value, NormalMeanPrecision):
+            self.dev.set_marginals([vid], L.FORM_MEAN_PRECISION, [value.mean, value.precision])
+        elif isinstance(value, (int, float, np.floating)):
+            self.dev.set_marginals([vid], L.FORM_POINT, [float(value)])
+        else:
+            raise TypeError(f"HipVmpProcessor.set_value: no device form for {type(value).__name__}")
+        _host_set_value(signal, value)
+
+    def read_marginal(self, vid):
+        a, b = self.dev.get_marginals([vid])[0]
+        return Gamma(float(a), float(b)) if self.kind[vid] == "gamma" else NormalMeanPrecision(float(a), float(b))
+
+    def update_marginals(self, engine, ids) -> bool:
+        self.dev.update_marginals(list(ids))
+        for vid in ids:
+            m = get_variable_marginal(engine.get_variable(vid))
+            _host_set_value(m, HipVmpValue(self, vid))
+        return True

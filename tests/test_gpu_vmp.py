@@ -143,3 +143,50 @@ def test_vmp_errors(hip_lib):
     bad = cx.DeviceGraph(family=L.FAMILY_VMP_MEAN_FIELD)
     with pytest.raises(cx.CortexHipError, match="edge_role"):
         bad.graph_create(model.edge_var, model.edge_fac, model.factor_ids, np.full(len(model.factor_ids), L.FACTOR_NORMAL_PRECISION), np.zeros(len(model.factor_ids)))
+
+
+@pytest.mark.parametrize("family,rule,kind", [("mean_field", S.mean_field_rule, "mean_field"), ("structured", S.structured_rule, "structured")])
+def test_vmp_processor_behind_the_engine_api(hip_lib, family, rule, kind):
+    """The reference's experiment written against the engine API (make_ssm_model + experiment,
+    test/inference_engine_tests.jl:691-770) with the HIP processor plugged in, beside the restated engine."""
+    n, iters = 40, 8
+    data = S.dataset(n, seed=9)
+    graph = cx.BipartiteFactorGraph()
+    ssnoise = graph.add_variable(cx.Variable(name="ssnoise"))
+    obsnoise = graph.add_variable(cx.Variable(name="obsnoise"))
+    x = [graph.add_variable(cx.Variable(name="x", index=(i,))) for i in range(n)]
+    y = [graph.add_variable(cx.Variable(name="y", index=(i,))) for i in range(n)]
+    lik_form = cx.NormalPrecisionFactor(roles=(("y", "out"), ("x", "mean"), ("obsnoise", "precision")))
+    tr_form = cx.NormalPrecisionFactor(roles=(("x", "both"), ("ssnoise", "precision")))
+    likelihood = [graph.add_factor(cx.Factor(functional_form=lik_form)) for _ in range(n)]
+    transition = [graph.add_factor(cx.Factor(functional_form=tr_form)) for _ in range(n - 1)]
+    for i in range(n):
+        graph.add_edge(y[i], likelihood[i], cx.Connection(label="out"))
+        graph.add_edge(x[i], likelihood[i], cx.Connection(label="out"))
+        graph.add_edge(obsnoise, likelihood[i], cx.Connection(label="out"))
+    for i in range(n - 1):
+        graph.add_edge(x[i], transition[i], cx.Connection(label="out"))
+        graph.add_edge(x[i + 1], transition[i], cx.Connection(label="in"))
+        graph.add_edge(ssnoise, transition[i], cx.Connection(label="out"))
+    proc = cx.HipVmpProcessor(family=family)
+    engine = cx.InferenceEngine(model_engine=graph, inference_request_processor=proc, resolve_dependencies=False)
+    marginal = lambda v: cx.get_variable_marginal(engine.get_variable(v))  # noqa: E731
+    proc.set_value(marginal(ssnoise), cx.Gamma(1.0, 1.0))
+    proc.set_value(marginal(obsnoise), cx.Gamma(1.0, 1.0))
+    for v in x:
+        proc.set_value(marginal(v), cx.NormalMeanPrecision(0.0, 1.0))
+    for v, d in zip(y, data):
+        proc.set_value(marginal(v), d)
+    be = S.OracleBackend(rule)
+    calls_of = S.mean_field_calls if kind == "mean_field" else S.structured_calls_by_class
+
+    def on_call(it, ids):
+        cx.update_marginals(engine, ids)
+
+    ans = S.run_experiment(be, kind, data, iters, on_call=on_call, calls_of=calls_of)
+    got_ss, got_obs = cx.get_value(marginal(ssnoise)), cx.get_value(marginal(obsnoise))
+    assert got_ss.shape * got_ss.scale == pytest.approx(S.mean(ans["ssnoise"]), rel=1e-8)
+    assert got_obs.shape * got_obs.scale == pytest.approx(S.mean(ans["obsnoise"]), rel=1e-8)
+    for v, want in zip(x, ans["x"]):
+        got = cx.get_value(marginal(v))
+        assert got.mean == pytest.approx(want[1][0], rel=1e-8, abs=1e-12) and got.precision == pytest.approx(want[1][1], rel=1e-8)

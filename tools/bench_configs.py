@@ -80,16 +80,9 @@ def vmp(n=1_000_000):
         dt = timed(dev, it, 50, 10)
         g = dev.get_marginals([model.ssnoise, model.obsnoise])
         st = dev.stats()
-        # CPU figure beside it: the array form of the same two calls (numpy, one core) — test infrastructure, timed only
-        from oracle import vmp as ovmp
-        arr = (ovmp.StructuredVMP if name == "structured" else ovmp.MeanFieldVMP)(model.data_y[:200_000])
-        t0 = time.perf_counter()
-        arr._store_x(arr._x())
-        cpu_x = (time.perf_counter() - t0) * (n / 200_000)
         out.append({"config": "VMP", "workload": f"{name} VMP, SSM with unknown precisions, n={n} states ({st['n_edges']} edges, {st['n_factors']} factors)",
                     "ms_per_iteration": dt * 1e3, "messages_per_iteration": st["n_messages_per_sweep"],
-                    "messages_per_s": st["n_messages_per_sweep"] / dt, "E_ssnoise": g[0, 0] * g[0, 1], "E_obsnoise": g[1, 0] * g[1, 1],
-                    "cpu_numpy_state_update_ms_scaled": cpu_x * 1e3})
+                    "messages_per_s": st["n_messages_per_sweep"] / dt, "E_ssnoise": g[0, 0] * g[0, 1], "E_obsnoise": g[1, 0] * g[1, 1]})
     return out
 
 
