@@ -1072,8 +1072,11 @@ static void sweep_main(cx_handle *h, bool skip_ghosts) {
 }
 
 static void sweep_finish(cx_handle *h) {
-    if (h->cfg.schedule == CX_SCHED_FLOODING || h->cfg.schedule == CX_SCHED_CHAIN_SCAN) {
+    if (h->cfg.schedule == CX_SCHED_FLOODING) {
         cx::launch_factor_to_var(h, h->d_v2f, h->d_f2v);
+    } else if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) {
+        // nothing: the scans already produced every factor→variable message a free variable reads, from the same
+        // variable→factor messages the variable phase just wrote (a factor phase here would only re-derive them)
     } else {
         std::swap(h->d_f2v, h->d_f2v_alt);
         h->v2f_stale = h->cfg.materialize_messages_to_factor == 0;

@@ -130,7 +130,11 @@ __device__ __forceinline__ void tile_scan(Lin (&x)[kItems], Lin &tile_total, Lin
     __syncthreads();
 }
 
-__global__ __launch_bounds__(kBlock) void k_chain_tile_totals(ChainArgs A, int dir, Lin *__restrict__ totals) {
+// The forward and the backward scan are independent: every stage runs both in one launch, blockIdx.y = 0 forward,
+// 1 backward, with the backward direction's tile totals stored after the forward ones (stride ntiles + 1).
+__global__ __launch_bounds__(kBlock) void k_chain_tile_totals(ChainArgs A, Lin *__restrict__ totals) {
+    const int dir = blockIdx.y == 0 ? 1 : -1;
+    totals += (size_t)blockIdx.y * (gridDim.x + 1);
     __shared__ Lin wave_tot[kBlock / 64];
     Lin x[kItems];
     const int base = blockIdx.x * kTile + threadIdx.x * kItems;
@@ -143,6 +147,7 @@ __global__ __launch_bounds__(kBlock) void k_chain_tile_totals(ChainArgs A, int d
 
 // exclusive scan of the tile totals by one workgroup (sequential over chunks of kTile tiles: ≤ 1M links per chunk)
 __global__ __launch_bounds__(kBlock) void k_chain_scan_totals(int ntiles, Lin *__restrict__ totals) {
+    totals += (size_t)blockIdx.x * (ntiles + 1);     // one workgroup per direction
     __shared__ Lin wave_tot[kBlock / 64];
     __shared__ Lin carry_s;
     if (threadIdx.x == 0) carry_s = lin_identity();
@@ -181,7 +186,9 @@ __global__ __launch_bounds__(kBlock) void k_chain_scan_totals(int ntiles, Lin *_
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_chain_apply(ChainArgs A, int dir, const Lin *__restrict__ tile_excl, double2 *__restrict__ f2v) {
+__global__ __launch_bounds__(kBlock) void k_chain_apply(ChainArgs A, const Lin *__restrict__ tile_excl, double2 *__restrict__ f2v) {
+    const int dir = blockIdx.y == 0 ? 1 : -1;
+    tile_excl += (size_t)blockIdx.y * (gridDim.x + 1);
     __shared__ Lin wave_tot[kBlock / 64];
     Lin x[kItems];
     const int base = blockIdx.x * kTile + threadIdx.x * kItems;
@@ -211,16 +218,14 @@ void launch_chain_scan(cx_handle *h, double2 *f2v) {
                 h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_chain_side};
     const int ntiles = (nlinks + kTile - 1) / kTile;
     Lin *totals = (Lin *)h->d_chain_totals;
-    for (int dir = 1; dir >= -1; dir -= 2) {
-        hipLaunchKernelGGL(k_chain_tile_totals, dim3(ntiles), dim3(kBlock), 0, h->stream, A, dir, totals);
-        hipLaunchKernelGGL(k_chain_scan_totals, dim3(1), dim3(kBlock), 0, h->stream, ntiles, totals);
-        hipLaunchKernelGGL(k_chain_apply, dim3(ntiles), dim3(kBlock), 0, h->stream, A, dir, totals, f2v);
-    }
+    hipLaunchKernelGGL(k_chain_tile_totals, dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, totals);
+    hipLaunchKernelGGL(k_chain_scan_totals, dim3(2), dim3(kBlock), 0, h->stream, ntiles, totals);
+    hipLaunchKernelGGL(k_chain_apply, dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, totals, f2v);
 }
 
 size_t chain_total_bytes(int64_t nlinks) {
     const int64_t ntiles = (nlinks + kTile - 1) / kTile;
-    return (size_t)(ntiles + 1) * sizeof(Lin);
+    return (size_t)2 * (ntiles + 1) * sizeof(Lin);     // forward and backward tile totals
 }
 
 }  // namespace cx
