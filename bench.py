@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): every rank owns an N x N strip of an (N*ranks) x N grid; strong: the ONE N x N grid "
                          "(BASELINE config 4: 10M edges, 8-way cut) is split into row blocks over the ranks")
+    ap.add_argument("--halo-depth", type=int, default=int(os.environ.get("CX_HALO_DEPTH", "8")),
+                    help="deep halo: each rank keeps this many redundant rows of its neighbours and exchanges their state once "
+                         "per that many sweeps (bit-identical to the un-partitioned sweep); 0 = one message halo per sweep")
     ap.add_argument("--self-halo", action="store_true",
                     help="N = 1 experiment: a cylinder whose wrap-around cut makes rank 0 its own halo neighbour")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -157,23 +160,32 @@ def main():
         exchange = None
     else:
         from cortex.jl_amd import partition
+        depth = args.halo_depth if args.scaling == "weak" else 0     # the generic (strong-scaling) cut uses message halos
+        depth = min(depth, N)
         if world == 1:
-            part, _wrap = partition.cylinder_self(N, N, seed=args.seed)
+            part = partition.deep_self(N, N, depth, seed=args.seed) if depth else partition.cylinder_self(N, N, seed=args.seed)[0]
         elif args.scaling == "strong":
             part = partition.contiguous_blocks(cx.synth.gaussian_grid(N, N, seed=args.seed), rank, world)
+        elif depth:
+            part = partition.grid_strip_deep(N, N, rank, world, depth, seed=args.seed)
         else:
             part = partition.grid_strip(N, N, rank, world, seed=args.seed)
         cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
         exchange = None
+        tdev = torch.device("cuda", local_rank)
         if backend != "nccl" and world > 1:
-            sweeper = partition.HostStagedSweeper(dev, part, torch, torch.device("cuda", local_rank))
-            exchange = partition.HaloExchange(sweeper, part, dist)
+            if depth:
+                sweeper = partition.HostStagedStateSweeper(dev, part, torch, tdev)
+                exchange = partition.DeepHaloExchange(sweeper, part, dist)
+            else:
+                sweeper = partition.HostStagedSweeper(dev, part, torch, tdev)
+                exchange = partition.HaloExchange(sweeper, part, dist)
             halo_kind = f"REHEARSAL: host-staged over {backend}"
             halo_tensors = (sweeper.send, sweeper.recv)
         elif args.halo == "rccl":
             err = None
             try:
-                exchange = partition.RcclExchange(dev, part, dist, torch, torch.device("cuda", local_rank))
+                exchange = (partition.DeepHaloRccl if depth else partition.RcclExchange)(dev, part, dist, torch, tdev)
                 halo_kind = "rccl send/recv issued by the library"
                 halo_tensors = (exchange.send, exchange.recv)
             except cx.CortexHipError as e:   # e.g. librccl not loadable: fall back to torch.distributed
@@ -186,12 +198,25 @@ def main():
             if exchange is None and rank == 0:
                 print(f"[bench] RCCL exchange unavailable ({err}); falling back to torch.distributed", file=sys.stderr)
         if exchange is None:
-            sweeper = partition.DeviceSweeper(dev, part, torch, torch.device("cuda", local_rank))
-            exchange = partition.HaloExchange(sweeper, part, dist)
+            if depth:
+                sweeper = partition.DeviceStateSweeper(dev, part, torch, tdev)
+                exchange = partition.DeepHaloExchange(sweeper, part, dist)
+            else:
+                sweeper = partition.DeviceSweeper(dev, part, torch, tdev)
+                exchange = partition.HaloExchange(sweeper, part, dist)
             halo_kind = "torch.distributed isend/irecv"
             halo_tensors = (sweeper.send, sweeper.recv)
+        if depth:
+            halo_kind = f"deep halo, {depth} redundant rows per side, state exchanged every {depth} sweeps; " + halo_kind
+        else:
+            halo_kind = "message halo per sweep; " + halo_kind
     st = dev.stats()
-    updates_per_step = st["n_messages_per_sweep"]
+    local_updates_per_step = st["n_messages_per_sweep"]      # what one launch computes (redundant rows included)
+    updates_per_step = local_updates_per_step
+    if exchange is not None and getattr(part, "depth", 0) and world > 1:
+        # the metric counts OWNED updates only: 4 directed messages per pairwise factor, a factor belongs to the rank of its
+        # lower-id variable: R (C - 1) horizontal + R C vertical factors, the last rank one row fewer
+        updates_per_step = 4 * (N * (N - 1) + (N if rank < world - 1 else N - 1) * N)
 
     def step():
         if exchange is None:
@@ -246,9 +271,9 @@ def main():
         dom_name, (dom_ms, dom_n, dom_id) = dom
         # algorithmic bytes per launch: §8d's 32 B per directed message update x the updates one launch performs
         if dom_id == L.KERNEL_FUSED:
-            upd_per_launch = updates_per_step
+            upd_per_launch = local_updates_per_step
         else:
-            upd_per_launch = updates_per_step / 2
+            upd_per_launch = local_updates_per_step / 2
         avg_s = dom_ms / dom_n / 1e3
         achieved = upd_per_launch * BYTES_PER_UPDATE / avg_s / 1e9
         out = {
@@ -260,7 +285,7 @@ def main():
                                     f"C4: ONE {N}x{N} 2-D Gaussian grid loopy BP cut into {world} row blocks; rank 0 holds") +
                                    f" ({st['n_edges']} bipartite edges, {updates_per_step} directed message updates + "
                                    f"{st['n_variables']} marginals per sweep)",
-                       "schedule": args.schedule + ("" if halo_kind is None else f" + halo per sweep ({halo_kind})"), "partition": f"{world} row strips",
+                       "schedule": args.schedule + ("" if halo_kind is None else f" + {halo_kind}"), "partition": f"{world} row strips",
                        "seed": args.seed},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": dom_ms / dom_n,
@@ -268,7 +293,7 @@ def main():
                          "algorithmic_bytes_per_launch": upd_per_launch * BYTES_PER_UPDATE,
                          "all_kernels_ms": {k: v[0] / v[1] for k, v in kern.items()}},
             "hbm_roofline_frac_end_to_end": value * BYTES_PER_UPDATE / 1e9 / (HBM_PEAK_GBS * world),
-            "marginals_per_s": st["n_variables"] * world * args.steps / elapsed,   # computed inside the same kernel, not counted in `value`
+            "marginals_per_s": (N * N if exchange is not None and getattr(part, "depth", 0) else st["n_variables"]) * world * args.steps / elapsed,   # computed inside the same kernel, not counted in `value`
             "max_message_change_over_run": res,
         }
         if halo_check is not None:

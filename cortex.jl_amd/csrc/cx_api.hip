@@ -1089,7 +1089,7 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep: no graph");
     CX_REQUIRE(h, n_sweeps >= 0, CX_ERR_INVALID_ARGUMENT, "cx_sweep: n_sweeps < 0");
     if (h->cfg.dim > 1) return mv_sweep(h, n_sweeps);
-    CX_REQUIRE(h, h->recv_slots.empty() && h->send_slots.empty(), CX_ERR_STATE,
+    CX_REQUIRE(h, h->halo_state || (h->recv_slots.empty() && h->send_slots.empty()), CX_ERR_STATE,
                "cx_sweep: this handle holds a partition (halo configured): use cx_sweep_begin / _main / _end");
     if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) { int32_t rc = build_chains(h); if (rc != CX_OK) return rc; }
     for (int32_t s = 0; s < n_sweeps; s++) { sweep_main(h, false); sweep_finish(h); }
@@ -1102,6 +1102,7 @@ int32_t cx_sweep_begin(cx_handle *h) {
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep_begin: no graph");
     CX_REQUIRE(h, h->cfg.dim == 1, CX_ERR_UNSUPPORTED, "cx_sweep_begin: partitioned sweeps are implemented for dim == 1 only in this build");
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_sweep_begin: previous sweep not ended");
+    CX_REQUIRE(h, !h->halo_state, CX_ERR_STATE, "cx_sweep_begin: the handle is configured for state halos (cx_halo_configure_state): use cx_sweep + cx_halo_state_exchange");
     CX_REQUIRE(h, h->cfg.schedule != CX_SCHED_CHAIN_SCAN, CX_ERR_UNSUPPORTED, "cx_sweep_begin: the chain-scan schedule is not partitioned in this build");
     cx::launch_halo_export(h, h->d_f2v, h->stream);
     CX_HIP(h, hipGetLastError());
@@ -1167,6 +1168,7 @@ int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const
                 return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_halo_configure: an imported edge must belong to a degree-1 ghost variable");
         for (uint8_t &b : h->vinfo) b &= (uint8_t)~cx::kGhost;
         for (int32_t v : recv_vars) h->vinfo[v] |= cx::kGhost;
+        h->halo_state = false;
         h->chains_dirty = true;
         CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
         for (void *p : {(void *)h->d_send_slots, (void *)h->d_recv_slots, (void *)h->d_send_vars}) if (p) (void)hipFree(p);
@@ -1181,6 +1183,56 @@ int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const
         CX_HIP(h, hipStreamSynchronize(h->stream));
         return CX_OK;
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_halo_configure: host allocation failed"); }
+}
+
+// ---- state halos (deep halo): the partition keeps `depth` redundant rows of its neighbours' variables; between exchanges
+// the handle runs plain sweeps, an exchange overwrites the factor→variable messages of the redundant variables with the
+// owner's values.  After k <= depth sweeps every message of an owned variable equals the un-partitioned sweep's bit for bit
+// (the error of the frozen outer edge advances one row per sweep).
+int32_t cx_halo_configure_state(cx_handle *h, int64_t n_send, const int64_t *sv, const int64_t *sf, int64_t n_recv,
+                                const int64_t *rv, const int64_t *rf) {
+    CX_NOT_VMP(h, "cx_halo_configure_state");
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_configure_state: no graph");
+    CX_REQUIRE(h, h->cfg.dim == 1 && h->cfg.schedule != CX_SCHED_CHAIN_SCAN, CX_ERR_UNSUPPORTED,
+               "cx_halo_configure_state: scalar fused / flooding schedules only");
+    CX_REQUIRE(h, n_send >= 0 && n_recv >= 0, CX_ERR_INVALID_ARGUMENT, "cx_halo_configure_state: negative count");
+    CX_REQUIRE(h, (n_send == 0 || (sv && sf)) && (n_recv == 0 || (rv && rf)), CX_ERR_INVALID_ARGUMENT, "cx_halo_configure_state: null argument");
+    CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_halo_configure_state: a cx_sweep_begin is still open");
+    try {
+        int32_t rc = stage_slots(h, n_send, sv, sf, h->send_slots, nullptr);
+        if (rc != CX_OK) return rc;
+        rc = stage_slots(h, n_recv, rv, rf, h->recv_slots, nullptr);
+        if (rc != CX_OK) return rc;
+        if (std::any_of(h->vinfo.begin(), h->vinfo.end(), [](uint8_t b) { return (b & cx::kGhost) != 0; })) {
+            for (uint8_t &b : h->vinfo) b &= (uint8_t)~cx::kGhost;
+            CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
+        }
+        for (void *p : {(void *)h->d_send_slots, (void *)h->d_recv_slots, (void *)h->d_send_vars}) if (p) (void)hipFree(p);
+        if (!h->ext_halo_buffers) { if (h->d_send_buf) (void)hipFree(h->d_send_buf); if (h->d_recv_buf) (void)hipFree(h->d_recv_buf); }
+        h->d_send_slots = h->d_recv_slots = h->d_send_vars = nullptr; h->d_send_buf = h->d_recv_buf = nullptr;
+        h->ext_halo_buffers = false;
+        rc = dev_upload(h, &h->d_send_slots, h->send_slots); if (rc != CX_OK) return rc;
+        rc = dev_upload(h, &h->d_recv_slots, h->recv_slots); if (rc != CX_OK) return rc;
+        rc = dev_alloc(h, &h->d_send_buf, n_send); if (rc != CX_OK) return rc;
+        rc = dev_alloc(h, &h->d_recv_buf, n_recv); if (rc != CX_OK) return rc;
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        h->halo_state = true;
+        return CX_OK;
+    } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_halo_configure_state: host allocation failed"); }
+}
+
+int32_t cx_halo_state_pack(cx_handle *h) {
+    CX_REQUIRE(h, h && h->has_graph && h->halo_state, CX_ERR_STATE, "cx_halo_state_pack: call cx_halo_configure_state first");
+    cx::launch_gather(h, h->d_f2v, h->d_send_slots, h->d_send_buf, (int64_t)h->send_slots.size());
+    CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
+int32_t cx_halo_state_unpack(cx_handle *h) {
+    CX_REQUIRE(h, h && h->has_graph && h->halo_state, CX_ERR_STATE, "cx_halo_state_unpack: call cx_halo_configure_state first");
+    cx::launch_scatter(h, h->d_f2v, h->d_recv_slots, h->d_recv_buf, (int64_t)h->recv_slots.size());
+    CX_HIP(h, hipGetLastError());
+    return CX_OK;
 }
 
 int32_t cx_halo_buffers(cx_handle *h, void **send_ptr, int64_t *send_bytes, void **recv_ptr, int64_t *recv_bytes) {
@@ -1245,6 +1297,7 @@ int32_t cx_sweep_exchange(cx_handle *h, int32_t n_sweeps) {
     for (auto &p : h->peers)
         CX_REQUIRE(h, p.rank >= 0 && p.rank < h->comm_world, CX_ERR_INVALID_ARGUMENT, "cx_sweep_exchange: bad peer rank");   // a rank may be its own neighbour (periodic cut)
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_sweep_exchange: a cx_sweep_begin is still open");
+    CX_REQUIRE(h, !h->halo_state, CX_ERR_STATE, "cx_sweep_exchange: the handle is configured for state halos: use cx_sweep + cx_halo_state_exchange");
     CX_REQUIRE(h, h->cfg.dim == 1 && h->cfg.schedule != CX_SCHED_CHAIN_SCAN, CX_ERR_UNSUPPORTED, "cx_sweep_exchange: scalar fused / flooding schedules only");
     const bool overlap = !h->peers.empty();
     for (int32_t s = 0; s < n_sweeps; s++) {
@@ -1264,6 +1317,22 @@ int32_t cx_sweep_exchange(cx_handle *h, int32_t n_sweeps) {
         sweep_finish(h);
         CX_HIP(h, hipGetLastError());
     }
+    return CX_OK;
+}
+
+int32_t cx_halo_state_exchange(cx_handle *h) {
+    CX_REQUIRE(h, h && h->has_graph && h->halo_state, CX_ERR_STATE, "cx_halo_state_exchange: call cx_halo_configure_state first");
+    CX_REQUIRE(h, h->comm || h->peers.empty(), CX_ERR_STATE, "cx_halo_state_exchange: call cx_comm_init first");
+    for (auto &p : h->peers)
+        CX_REQUIRE(h, p.rank >= 0 && p.rank < h->comm_world, CX_ERR_INVALID_ARGUMENT, "cx_halo_state_exchange: bad peer rank");
+    if (h->peers.empty()) return CX_OK;
+    // pack, send/recv and unpack in stream order on the handle's own stream: no cross-stream hand-off at all (each one
+    // costs ≈6 µs on this stack); the exchange happens once per `depth` sweeps, so it need not hide behind a kernel
+    cx::launch_gather(h, h->d_f2v, h->d_send_slots, h->d_send_buf, (int64_t)h->send_slots.size());
+    std::string err;
+    if (!cx::comm_exchange_on(h, h->stream, err)) return fail(h, CX_ERR_DEVICE, "cx_halo_state_exchange: " + err);
+    cx::launch_scatter(h, h->d_f2v, h->d_recv_slots, h->d_recv_buf, (int64_t)h->recv_slots.size());
+    CX_HIP(h, hipGetLastError());
     return CX_OK;
 }
 

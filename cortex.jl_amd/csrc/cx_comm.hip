@@ -85,24 +85,31 @@ void comm_destroy(cx_handle *h) {
     h->comm_stream = nullptr; h->ev_packed = h->ev_recv = h->ev_swept = nullptr;
 }
 
-// grouped send/recv with every peer on the comm stream; returns false with err set on an RCCL error
-bool comm_exchange(cx_handle *h, std::string &err, bool packed_on_comm_stream) {
+// grouped send/recv with every peer, issued on `stream`; returns false with err set on an RCCL error
+bool comm_exchange_on(cx_handle *h, hipStream_t stream, std::string &err) {
     if (h->peers.empty()) return true;
     ncclComm_t comm = (ncclComm_t)h->comm;
-    if (!packed_on_comm_stream) {   // the send buffer was packed on the main stream
-        (void)hipEventRecord(h->ev_packed, h->stream);
-        (void)hipStreamWaitEvent(h->comm_stream, h->ev_packed, 0);
-    }
     ncclResult_t r = g_nccl.GroupStart();
     for (const auto &p : h->peers) {
         if (r == ncclSuccess && p.send_count)
-            r = g_nccl.Send((const double *)h->d_send_buf + 2 * p.send_off, (size_t)(2 * p.send_count), ncclDouble, p.rank, comm, h->comm_stream);
+            r = g_nccl.Send((const double *)h->d_send_buf + 2 * p.send_off, (size_t)(2 * p.send_count), ncclDouble, p.rank, comm, stream);
         if (r == ncclSuccess && p.recv_count)
-            r = g_nccl.Recv((double *)h->d_recv_buf + 2 * p.recv_off, (size_t)(2 * p.recv_count), ncclDouble, p.rank, comm, h->comm_stream);
+            r = g_nccl.Recv((double *)h->d_recv_buf + 2 * p.recv_off, (size_t)(2 * p.recv_count), ncclDouble, p.rank, comm, stream);
     }
     ncclResult_t r2 = g_nccl.GroupEnd();
     if (r == ncclSuccess) r = r2;
     if (r != ncclSuccess) { err = std::string("RCCL send/recv: ") + g_nccl.GetErrorString(r); return false; }
+    return true;
+}
+
+// the per-sweep message halo: on the comm stream, beside the main kernel
+bool comm_exchange(cx_handle *h, std::string &err, bool packed_on_comm_stream) {
+    if (h->peers.empty()) return true;
+    if (!packed_on_comm_stream) {   // the send buffer was packed on the main stream
+        (void)hipEventRecord(h->ev_packed, h->stream);
+        (void)hipStreamWaitEvent(h->comm_stream, h->ev_packed, 0);
+    }
+    if (!comm_exchange_on(h, h->comm_stream, err)) return false;
     (void)hipEventRecord(h->ev_recv, h->comm_stream);
     return true;
 }

@@ -98,6 +98,7 @@ struct cx_handle {
     int32_t *d_send_slots = nullptr, *d_recv_slots = nullptr, *d_send_vars = nullptr;
     double2 *d_send_buf = nullptr, *d_recv_buf = nullptr;
     bool ext_halo_buffers = false;
+    bool halo_state = false;         // halo lists name factor→variable messages of redundant variables (deep halo)
     // RCCL exchange issued by the library (cx_comm.hip)
     struct Peer { int rank; int64_t send_off, send_count, recv_off, recv_count; };
     std::vector<Peer> peers;
@@ -179,5 +180,6 @@ bool comm_unique_id(void *out128, std::string &err);
 bool comm_init(cx_handle *h, int world, int rank, const void *id128, std::string &err);
 void comm_destroy(cx_handle *h);
 bool comm_exchange(cx_handle *h, std::string &err, bool packed_on_comm_stream);
+bool comm_exchange_on(cx_handle *h, hipStream_t stream, std::string &err);
 
 }  // namespace cx

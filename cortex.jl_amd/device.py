@@ -154,6 +154,21 @@ class DeviceGraph:
         self._check(self.lib.cx_halo_configure(self.h, len(sv), _p(sv, C.c_int64), _p(sf, C.c_int64), len(rv),
                                                _p(rv, C.c_int64), _p(rf, C.c_int64)))
 
+    def halo_configure_state(self, send_var, send_fac, recv_var, recv_fac):
+        """Deep halo: the lists name factor→variable messages of redundant variables (cx_halo_configure_state)."""
+        sv, sf, rv, rf = _i64(send_var), _i64(send_fac), _i64(recv_var), _i64(recv_fac)
+        self._check(self.lib.cx_halo_configure_state(self.h, len(sv), _p(sv, C.c_int64), _p(sf, C.c_int64), len(rv),
+                                                     _p(rv, C.c_int64), _p(rf, C.c_int64)))
+
+    def halo_state_pack(self):
+        self._check(self.lib.cx_halo_state_pack(self.h))
+
+    def halo_state_unpack(self):
+        self._check(self.lib.cx_halo_state_unpack(self.h))
+
+    def halo_state_exchange(self):
+        self._check(self.lib.cx_halo_state_exchange(self.h))
+
     def halo_buffers(self):
         sp, rp, sb, rb = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_int64()
         self._check(self.lib.cx_halo_buffers(self.h, C.byref(sp), C.byref(sb), C.byref(rp), C.byref(rb)))

@@ -35,6 +35,8 @@ class Partition:
     recv_var: np.ndarray     # (ghost variable_id, factor_id) of imported messages, grouped by peer
     recv_fac: np.ndarray
     peers: List[Peer] = field(default_factory=list)
+    depth: int = 0                 # 0: per-sweep message halo; w > 0: state ("deep") halo exchanged every w sweeps
+    owned_x: np.ndarray = None     # deep halo: the latent variables this rank owns (model.x_ids also lists the redundant ones)
 
 
 def grid_strip(rows_per_rank: int, n_cols: int, rank: int, world: int, seed: int = 1234) -> Partition:
@@ -61,6 +63,44 @@ def grid_strip(rows_per_rank: int, n_cols: int, rank: int, world: int, seed: int
     cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.int64)  # noqa: E731
     return Partition(model=model, rank=rank, world=world, send_var=cat(sv), send_fac=cat(sf), recv_var=cat(rv),
                      recv_fac=cat(rf), peers=peers)
+
+
+def grid_strip_deep(rows_per_rank: int, n_cols: int, rank: int, world: int, depth: int, seed: int = 1234) -> Partition:
+    """Row strips with a deep halo: besides its own rows [r0, r1) the rank holds `depth` redundant rows of each neighbour
+    (all their factors included; beyond them the usual degree-1 stand-ins of the next row).  Halo lists = every
+    factor→variable message of the redundant rows, ordered by (variable id, factor id) — both sides of a cut build the
+    same list.  One exchange per `depth` plain sweeps keeps every message of an owned variable bit-identical to the
+    un-partitioned sweep (the error of the frozen outer edge advances one row per sweep)."""
+    if not 1 <= depth <= rows_per_rank:
+        raise ValueError("depth must be in [1, rows_per_rank]: redundant rows come from the direct neighbours only")
+    total = rows_per_rank * world
+    r0, r1 = rank * rows_per_rank, (rank + 1) * rows_per_rank
+    lo, hi = max(r0 - depth, 0), min(r1 + depth, total)
+    model = synth.gaussian_grid(total, n_cols, seed=seed, row0=lo, row1=hi)
+    ev, ef = np.asarray(model.edge_var, np.int64), np.asarray(model.edge_fac, np.int64)
+    row = (ev - 1) // n_cols                              # global row of the edge's variable (ghost rows: lo-1, hi)
+
+    def edges_of_rows(a, b):
+        m = (row >= a) & (row < b)
+        v, f = ev[m], ef[m]
+        o = np.lexsort((f, v))
+        return v[o], f[o]
+
+    sv, sf, rv, rf, peers = [], [], [], [], []
+    ps = pr = 0
+    for peer, send_rows, recv_rows in ((rank - 1, (r0, min(r0 + depth, r1)), (lo, r0)), (rank + 1, (max(r1 - depth, r0), r1), (r1, hi))):
+        if peer < 0 or peer >= world:
+            continue
+        a, b = edges_of_rows(*send_rows)
+        c, d = edges_of_rows(*recv_rows)
+        sv.append(a); sf.append(b); rv.append(c); rf.append(d)
+        peers.append(Peer(peer, slice(ps, ps + len(a)), slice(pr, pr + len(c))))
+        ps += len(a); pr += len(c)
+    cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.int64)  # noqa: E731
+    jj = np.arange(n_cols, dtype=np.int64)
+    owned = (1 + np.arange(r0, r1, dtype=np.int64)[:, None] * n_cols + jj[None, :]).ravel()
+    return Partition(model=model, rank=rank, world=world, send_var=cat(sv), send_fac=cat(sf), recv_var=cat(rv), recv_fac=cat(rf),
+                     peers=peers, depth=depth, owned_x=owned)
 
 
 def by_assignment(model: synth.Model, owner_of_variable, rank: int, world: int) -> Partition:
@@ -175,6 +215,22 @@ def cylinder_self(n_rows: int, n_cols: int, seed: int = 1234):
     return part, (top, bot, qw)
 
 
+def deep_self(n_rows: int, n_cols: int, depth: int, seed: int = 1234) -> Partition:
+    """One rank that is its own deep-halo neighbour: the whole grid, whose first and last `depth` rows are both exported
+    and imported (send list == recv list, peer = rank 0).  The exchange then rewrites those messages with their own
+    values: the sweeps must equal the un-partitioned ones bit for bit, while pack, RCCL send/recv and unpack move exactly
+    the volume a middle rank of a strip partition moves.  For exercising and timing the deep-halo path on one GPU."""
+    model = synth.gaussian_grid(n_rows, n_cols, seed=seed)
+    ev, ef = np.asarray(model.edge_var, np.int64), np.asarray(model.edge_fac, np.int64)
+    row = (ev - 1) // n_cols
+    m = (row < depth) | (row >= n_rows - depth)
+    v, f = ev[m], ef[m]
+    o = np.lexsort((f, v))
+    v, f = v[o], f[o]
+    return Partition(model=model, rank=0, world=1, send_var=v, send_fac=f, recv_var=v, recv_fac=f,
+                     peers=[Peer(0, slice(0, len(v)), slice(0, len(v)))], depth=depth, owned_x=np.asarray(model.x_ids))
+
+
 class RcclExchange:
     """The partitioned sweep with the exchange issued by the library on RCCL (cx_sweep_exchange): Python only hands
     over the peer table and the ncclUniqueId (broadcast through torch.distributed when there is more than one rank)."""
@@ -203,6 +259,100 @@ class RcclExchange:
 
     def sweep(self, n: int = 1):
         self.dev.sweep_exchange(n)
+
+
+class DeepHaloRccl:
+    """Deep-halo partition driven by the library: one cx_halo_state_exchange (pack, grouped RCCL send/recv, unpack, all on
+    the handle's stream) before every `depth` plain sweeps."""
+
+    def __init__(self, dev, part: Partition, dist=None, torch=None, device=None):
+        self.dev, self.depth, self.k = dev, part.depth, 0
+        dev.halo_configure_state(part.send_var, part.send_fac, part.recv_var, part.recv_fac)
+        dev.halo_peers([(p.rank, p.send.start, p.send.stop - p.send.start, p.recv.start, p.recv.stop - p.recv.start)
+                        for p in part.peers])
+        self.send = self.recv = None
+        if torch is not None and device is not None:
+            self.send = torch.zeros((max(len(part.send_var), 1), 2), dtype=torch.float64, device=device)
+            self.recv = torch.zeros((max(len(part.recv_var), 1), 2), dtype=torch.float64, device=device)
+            dev.halo_set_buffers(self.send.data_ptr(), self.recv.data_ptr())
+        if part.world > 1:
+            idt = torch.zeros(128, dtype=torch.uint8, device=device)
+            if part.rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(dev.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            uid = bytes(idt.cpu().numpy().tobytes())
+        else:
+            uid = dev.comm_unique_id()
+        dev.comm_init(part.world, part.rank, uid)
+
+    def sweep(self, n: int = 1):
+        for _ in range(n):
+            if self.k % self.depth == 0:
+                self.dev.halo_state_exchange()
+            self.dev.sweep(1)
+            self.k += 1
+
+
+class DeviceStateSweeper:
+    """Adapter for a caller-owned transport of the deep halo: pack / unpack around torch tensors."""
+
+    def __init__(self, dev, part: Partition, torch, device):
+        self.dev = dev
+        dev.halo_configure_state(part.send_var, part.send_fac, part.recv_var, part.recv_fac)
+        self.send = torch.zeros((max(len(part.send_var), 1), 2), dtype=torch.float64, device=device)
+        self.recv = torch.zeros((max(len(part.recv_var), 1), 2), dtype=torch.float64, device=device)
+        dev.halo_set_buffers(self.send.data_ptr(), self.recv.data_ptr())
+
+    def pack(self):
+        self.dev.halo_state_pack()
+        self.dev.sync()
+
+    def unpack(self):
+        self.dev.halo_state_unpack()
+
+    def sweep(self):
+        self.dev.sweep(1)
+
+
+class HostStagedStateSweeper(DeviceStateSweeper):
+    """Rehearsal transport (gloo cannot move device memory): the halo tensors are staged through the host."""
+
+    def __init__(self, dev, part: Partition, torch, device):
+        super().__init__(dev, part, torch, device)
+        self.dsend, self.drecv = self.send, self.recv
+        self.send = torch.zeros_like(self.dsend, device="cpu")
+        self.recv = torch.zeros_like(self.drecv, device="cpu")
+
+    def pack(self):
+        super().pack()
+        self.send.copy_(self.dsend)
+
+    def unpack(self):
+        self.drecv.copy_(self.recv)
+        super().unpack()
+
+
+class DeepHaloExchange:
+    """Deep halo over torch.distributed: before every `depth` sweeps pack → isend/irecv with the partition neighbours →
+    unpack.  `sweeper` provides pack / unpack / sweep and the `send` / `recv` tensors."""
+
+    def __init__(self, sweeper, part: Partition, dist):
+        self.sw, self.part, self.dist, self.k = sweeper, part, dist, 0
+
+    def sweep(self, n: int = 1):
+        dist, sw = self.dist, self.sw
+        for _ in range(n):
+            if self.k % self.part.depth == 0:
+                sw.pack()
+                ops = []
+                for p in self.part.peers:
+                    ops.append(dist.P2POp(dist.isend, sw.send[p.send], p.rank))
+                    ops.append(dist.P2POp(dist.irecv, sw.recv[p.recv], p.rank))
+                for w in (dist.batch_isend_irecv(ops) if ops else []):
+                    w.wait()
+                sw.unpack()
+            sw.sweep()
+            self.k += 1
 
 
 class DeviceSweeper:

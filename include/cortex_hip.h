@@ -235,6 +235,23 @@ int32_t cx_halo_peers(cx_handle *h, int32_t n_peers, const int32_t *peer_rank, c
                       const int64_t *send_count, const int64_t *recv_offset, const int64_t *recv_count);
 int32_t cx_sweep_exchange(cx_handle *h, int32_t n_sweeps);
 
+/* ---- state halos ("deep halo"): exchange once per `depth` sweeps instead of once per sweep ---------------------------
+ * The local graph of a rank additionally holds `depth` layers of its neighbours' variables (redundant copies, with all
+ * their factors; beyond them a degree-1 stand-in per cut factor).  Between exchanges the handle runs plain cx_sweep calls;
+ * an exchange overwrites every factor→variable message of the redundant variables with the values their owner holds.
+ * After k <= depth sweeps every message of an OWNED variable equals the un-partitioned sweep's bit for bit: the error of
+ * the frozen outer edge advances one layer per sweep and is wiped by the next exchange.  The redundant work is
+ * 2*depth layers per rank; the per-sweep cost of the halo falls by the factor depth.
+ *   cx_halo_configure_state : (variable, factor) of the messages exported to / imported from the neighbours, grouped by
+ *                             peer like cx_halo_configure (cx_halo_peers, cx_halo_buffers, cx_halo_set_buffers apply)
+ *   cx_halo_state_pack / _unpack : gather into the send buffer / scatter from the recv buffer (caller-owned transport)
+ *   cx_halo_state_exchange  : pack, grouped ncclSend/ncclRecv, unpack — all on the handle's stream (cx_comm_init first) */
+int32_t cx_halo_configure_state(cx_handle *h, int64_t n_send, const int64_t *send_var, const int64_t *send_fac,
+                                int64_t n_recv, const int64_t *recv_var, const int64_t *recv_fac);
+int32_t cx_halo_state_pack(cx_handle *h);
+int32_t cx_halo_state_unpack(cx_handle *h);
+int32_t cx_halo_state_exchange(cx_handle *h);
+
 /* ---- checkpoint (the reference keeps no persistent state — src/ has no serialisation at all) ----
  * The mutable state of a handle (every message buffer, the marginals, the observed-variable flags, the sweep counter)
  * as one relocatable host blob.  A blob restores only into a handle created with the same dim / family / schedule and

@@ -41,15 +41,46 @@ class OracleSweeper:
         self.g.sweep(1, phases=2)
 
 
+class OracleStateSweeper:
+    """Deep halo with the CPU checker as the sweeper: the exchanged state is the factor→variable messages."""
+
+    def __init__(self, part, seed_variance):
+        self.g = g = flood_oracle_from_model(part.model, seed_variance)
+        self.send_e = g.edge_index(part.send_var, part.send_fac) if len(part.send_var) else np.zeros(0, np.int64)
+        self.recv_e = g.edge_index(part.recv_var, part.recv_fac) if len(part.recv_var) else np.zeros(0, np.int64)
+        self.send = torch.zeros((max(len(self.send_e), 1), 2), dtype=torch.float64)
+        self.recv = torch.zeros((max(len(self.recv_e), 1), 2), dtype=torch.float64)
+
+    def pack(self):
+        n = len(self.send_e)
+        self.send[:n, 0] = torch.from_numpy(self.g.f2v_m[self.send_e])
+        self.send[:n, 1] = torch.from_numpy(self.g.f2v_v[self.send_e])
+
+    def unpack(self):
+        n = len(self.recv_e)
+        self.g.f2v_m[self.recv_e] = self.recv[:n, 0].numpy()
+        self.g.f2v_v[self.recv_e] = self.recv[:n, 1].numpy()
+
+    def sweep(self):
+        self.g.sweep(1)
+
+
 def main():
     rows, cols, sweeps, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    depth = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    part = partition.grid_strip(rows, cols, rank, world, seed=99)
-    sw = OracleSweeper(part, 1e6)
-    ex = partition.HaloExchange(sw, part, dist)
-    for _ in range(sweeps):
-        ex.sweep()
+    if depth:
+        part = partition.grid_strip_deep(rows, cols, rank, world, depth, seed=99)
+        sw = OracleStateSweeper(part, 1e6)
+        ex = partition.DeepHaloExchange(sw, part, dist)
+        ex.sweep(sweeps)
+    else:
+        part = partition.grid_strip(rows, cols, rank, world, seed=99)
+        sw = OracleSweeper(part, 1e6)
+        ex = partition.HaloExchange(sw, part, dist)
+        for _ in range(sweeps):
+            ex.sweep()
     # the audit bench.py runs after its timed region: must pass on a correct exchange and fail on a corrupted buffer
     audit_ok = partition.verify_last_exchange(part, sw.send, sw.recv, dist, torch)
     if rank == 0:
@@ -60,7 +91,7 @@ def main():
     g = sw.g
     m, v = g.marginals()
     np.savez(out + f".rank{rank}.npz", edge_var=g.edge_var, edge_fac=g.edge_fac, f2v_m=g.f2v_m, f2v_v=g.f2v_v,
-             v2f_m=g.v2f_m, v2f_v=g.v2f_v, var_ids=g.var_ids, marg_m=m, marg_v=v, owned=part.model.x_ids,
+             v2f_m=g.v2f_m, v2f_v=g.v2f_v, var_ids=g.var_ids, marg_m=m, marg_v=v, owned=part.model.x_ids if part.owned_x is None else part.owned_x,
              audit_ok=audit_ok, audit_bad=audit_bad)
     dist.barrier()
     dist.destroy_process_group()

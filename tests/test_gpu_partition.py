@@ -200,3 +200,71 @@ def test_generic_partition_of_a_chain_on_device(hip_lib):
     for dev, part in devs:
         ids = part.model.x_ids
         assert np.array_equal(dev.get_marginals(ids), whole.get_marginals(ids), equal_nan=True)
+
+
+@pytest.mark.parametrize("schedule", [L.SCHED_FUSED, L.SCHED_FLOODING])
+@pytest.mark.parametrize("world,rows,cols,depth", [(2, 5, 9, 1), (3, 6, 40, 3), (3, 40, 300, 8)])
+def test_deep_halo_equals_whole_grid(hip_lib, schedule, world, rows, cols, depth):
+    """Deep halo (cx_halo_configure_state, pack / unpack, plain cx_sweep between exchanges): three handles on one GPU with
+    an in-process transport.  Messages and marginals of every owned variable equal the un-partitioned device sweep bit
+    for bit, whatever the number of sweeps since the last exchange."""
+    import torch
+
+    sweeps = 2 * depth + 3
+    whole_model = cx.synth.gaussian_grid(rows * world, cols, seed=21)
+    whole = cx.DeviceGraph(schedule=schedule)
+    cx.synth.load_into_device(whole_model, whole, seed_variance=1e6)
+    whole.sweep(sweeps)
+    ld = LoopbackDist(world, torch)
+    devs, parts, errors = [None] * world, [None] * world, []
+
+    def run(rank):
+        try:
+            ld.bind(rank)
+            part = partition.grid_strip_deep(rows, cols, rank, world, depth, seed=21)
+            dev = cx.DeviceGraph(schedule=schedule)
+            cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
+            sw = partition.DeviceStateSweeper(dev, part, torch, torch.device("cuda", 0))
+            ex = partition.DeepHaloExchange(sw, part, ld)
+            with pytest.raises(cx.CortexHipError, match="state halos"):
+                dev.sweep_begin()
+            ex.sweep(sweeps)
+            dev.sync()
+            devs[rank], parts[rank] = dev, part
+        except Exception as e:  # pragma: no cover
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    for rank in range(world):
+        part = parts[rank]
+        m = part.model
+        own = np.isin(m.edge_var, part.owned_x)
+        ev, ef = m.edge_var[own], m.edge_fac[own]
+        for direction in (L.TO_VARIABLE, L.TO_FACTOR):
+            got = devs[rank].get_messages(ev, ef, direction, L.FORM_NATURAL)
+            ref_ = whole.get_messages(ev, ef, direction, L.FORM_NATURAL)
+            assert np.array_equal(got, ref_, equal_nan=True), f"rank {rank}: deep-halo messages != whole-grid messages (bitwise)"
+        assert np.array_equal(devs[rank].get_marginals(part.owned_x), whole.get_marginals(part.owned_x), equal_nan=True)
+
+
+def test_deep_halo_exchange_issued_by_the_library(hip_lib):
+    """cx_halo_state_exchange with real RCCL on one GPU: rank 0 exports and imports the same boundary rows (its own
+    neighbour), so the sweeps must stay bit-identical to the plain handle while pack / send / recv / unpack run."""
+    rows, cols, depth, sweeps = 30, 64, 4, 11
+    part = partition.deep_self(rows, cols, depth, seed=8)
+    dev = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
+    ex = partition.DeepHaloRccl(dev, part)
+    ex.sweep(sweeps)
+    plain = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(part.model, plain, seed_variance=1e6)
+    plain.sweep(sweeps)
+    m = part.model
+    assert np.array_equal(dev.get_messages(m.edge_var, m.edge_fac, L.TO_VARIABLE, L.FORM_NATURAL),
+                          plain.get_messages(m.edge_var, m.edge_fac, L.TO_VARIABLE, L.FORM_NATURAL), equal_nan=True)
+    assert np.array_equal(dev.get_marginals(m.x_ids), plain.get_marginals(m.x_ids), equal_nan=True)

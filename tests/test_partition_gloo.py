@@ -43,8 +43,10 @@ def test_strip_partition_covers_the_grid_exactly_once():
     assert all(wf[f] == q for f, (_k, q) in factors.items())
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_gloo_halo_exchange_matches_single_process(tmp_path, world):
+@pytest.mark.parametrize("world,depth", [(2, 0), (3, 0), (2, 1), (3, 2), (3, 3), (2, 4)])
+def test_gloo_halo_exchange_matches_single_process(tmp_path, world, depth):
+    """depth 0: one message halo per sweep; depth w: deep halo, the redundant rows' state exchanged every w sweeps.  Either
+    way every message and marginal of an owned variable equals the single-process sweep bit for bit."""
     rows, cols, sweeps = 4, 7, 9
     out = str(tmp_path / "res")
     port = _free_port()
@@ -53,7 +55,7 @@ def test_gloo_halo_exchange_matches_single_process(tmp_path, world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(rows), str(cols),
-                                       str(sweeps), out], env=env, cwd=ROOT))
+                                       str(sweeps), out] + ([str(depth)] if depth else []), env=env, cwd=ROOT))
     try:
         for p in procs:
             assert p.wait(timeout=240) == 0
