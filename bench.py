@@ -160,12 +160,11 @@ def main():
         exchange = None
     else:
         from cortex.jl_amd import partition
-        depth = args.halo_depth if args.scaling == "weak" else 0     # the generic (strong-scaling) cut uses message halos
-        depth = min(depth, N)
+        depth = min(args.halo_depth, N if args.scaling == "weak" else max(N // max(world, 1), 1))
         if world == 1:
             part = partition.deep_self(N, N, depth, seed=args.seed) if depth else partition.cylinder_self(N, N, seed=args.seed)[0]
         elif args.scaling == "strong":
-            part = partition.contiguous_blocks(cx.synth.gaussian_grid(N, N, seed=args.seed), rank, world)
+            part = partition.contiguous_blocks(cx.synth.gaussian_grid(N, N, seed=args.seed), rank, world, depth=depth)
         elif depth:
             part = partition.grid_strip_deep(N, N, rank, world, depth, seed=args.seed)
         else:
@@ -216,7 +215,11 @@ def main():
     if exchange is not None and getattr(part, "depth", 0) and world > 1:
         # the metric counts OWNED updates only: 4 directed messages per pairwise factor, a factor belongs to the rank of its
         # lower-id variable: R (C - 1) horizontal + R C vertical factors, the last rank one row fewer
-        updates_per_step = 4 * (N * (N - 1) + (N if rank < world - 1 else N - 1) * N)
+        if args.scaling == "weak":
+            updates_per_step = 4 * (N * (N - 1) + (N if rank < world - 1 else N - 1) * N)
+        else:   # one N x N grid in total: 8 N (N - 1) directed updates, split evenly for the sum over ranks
+            total = 8 * N * (N - 1)
+            updates_per_step = total // world + (total % world if rank == 0 else 0)
 
     def step():
         if exchange is None:

@@ -160,7 +160,105 @@ def by_assignment(model: synth.Model, owner_of_variable, rank: int, world: int) 
     return Partition(model=local, rank=rank, world=world, send_var=my_v, send_fac=cf, recv_var=gh_v, recv_fac=cf, peers=peers)
 
 
-def contiguous_blocks(model: synth.Model, rank: int, world: int) -> Partition:
+def by_assignment_deep(model: synth.Model, owner_of_variable, rank: int, world: int, depth: int) -> Partition:
+    """Generic vertex partition with a deep halo (the scheme of grid_strip_deep for any unary + pairwise model): rank r
+    keeps its variables, `depth` breadth-first layers of redundant variables around them with ALL their factors, and the
+    next layer as degree-1 stand-ins.  Halo lists: every factor→variable message of a redundant variable, imported from its
+    owner; ordered by (variable id, factor id), which both sides compute identically from the global model."""
+    import scipy.sparse as sp
+
+    if depth < 1:
+        raise ValueError("depth >= 1")
+    ev, ef = np.asarray(model.edge_var, np.int64), np.asarray(model.edge_fac, np.int64)
+    vids = np.unique(ev)
+    vix = np.searchsorted(vids, ev)
+    nv = len(vids)
+    own = np.asarray(owner_of_variable(vids), np.int64)
+    # variable adjacency through the pairwise factors
+    order = np.lexsort((ev, ef))
+    fs, vx = ef[order], vix[order]
+    first = np.flatnonzero(np.r_[True, fs[1:] != fs[:-1]])
+    counts = np.diff(np.r_[first, len(fs)])
+    if np.any(counts > 2):
+        raise ValueError("by_assignment_deep handles unary and pairwise factors")
+    two = first[counts == 2]
+    a, b = vx[two], vx[two + 1]
+    A = sp.coo_matrix((np.ones(2 * len(a), np.int8), (np.r_[a, b], np.r_[b, a])), shape=(nv, nv)).tocsr()
+
+    def layers(r):
+        """distance (0 = owned by r) of every variable within depth + 1 of rank r's variables, -1 beyond"""
+        dist = np.full(nv, -1, np.int64)
+        seen = own == r
+        dist[seen] = 0
+        frontier = seen.copy()
+        for d in range(1, depth + 2):
+            reach = (A @ frontier.astype(np.int8)) > 0
+            frontier = reach & ~seen
+            dist[frontier] = d
+            seen |= frontier
+        return dist
+
+    dist_me = layers(rank)
+    full = (dist_me >= 0) & (dist_me <= depth)           # owned + redundant: all their factors are kept
+    local_v = dist_me >= 0                                # plus the stand-in layer
+    # factors: unary ones of `full` variables, pairwise ones with at least one `full` end (the other end is local by construction)
+    fac_of_edge_full = full[vix]
+    keep_fac = np.unique(ef[fac_of_edge_full])
+    e_keep = np.isin(ef, keep_fac) & local_v[vix]
+    loc_var, loc_fac = ev[e_keep], ef[e_keep]
+    fid = np.asarray(model.factor_ids, np.int64)
+    keep_f = np.isin(fid, keep_fac)
+    x_all = np.asarray(model.x_ids, np.int64)
+    x_loc = x_all[full[np.searchsorted(vids, x_all)]]
+    x_own = x_all[dist_me[np.searchsorted(vids, x_all)] == 0]
+    local_ids = vids[local_v]
+
+    def sel(var_arr, *cols):
+        var_arr = np.asarray(var_arr, np.int64)
+        m = np.isin(var_arr, local_ids) if len(var_arr) else np.zeros(0, bool)
+        return [np.asarray(c)[m] for c in (var_arr,) + cols]
+
+    dv, df, dy = sel(model.data_var, model.data_fac, model.data_y) if len(model.data_var) else (np.zeros(0, np.int64),) * 2 + (np.zeros(0),)
+    if len(dv):     # a datum enters through an edge that must exist locally
+        m = np.isin(df, keep_fac)
+        dv, df, dy = dv[m], df[m], dy[m]
+    if len(model.prior_var):
+        pv, pf, pm, pvv = sel(model.prior_var, model.prior_fac, model.prior_mean, model.prior_variance)
+        m = np.isin(pf, keep_fac)
+        pv, pf, pm, pvv = pv[m], pf[m], pm[m], pvv[m]
+    else:
+        pv = pf = np.zeros(0, np.int64); pm = pvv = np.zeros(0)
+    local = synth.Model(edge_var=loc_var, edge_fac=loc_fac, factor_ids=fid[keep_f], factor_kind=np.asarray(model.factor_kind)[keep_f],
+                        factor_var=np.asarray(model.factor_var)[keep_f], x_ids=x_loc, data_var=dv, data_fac=df, data_y=dy,
+                        prior_var=pv, prior_fac=pf, prior_mean=pm, prior_variance=pvv, meta=dict(model.meta))
+
+    def edges_of(mask_v):
+        m = mask_v[vix]
+        v, f = ev[m], ef[m]
+        o = np.lexsort((f, v))
+        return v[o], f[o]
+
+    sv, sf, rv, rf, peers = [], [], [], [], []
+    ps = pr = 0
+    for q in range(world):
+        if q == rank:
+            continue
+        recv_mask = (own == q) & full                       # q's variables that are redundant here
+        dist_q = layers(q)
+        send_mask = (own == rank) & (dist_q >= 1) & (dist_q <= depth)   # my variables that are redundant on q
+        if not recv_mask.any() and not send_mask.any():
+            continue
+        a_, b_ = edges_of(send_mask)
+        c_, d_ = edges_of(recv_mask)
+        sv.append(a_); sf.append(b_); rv.append(c_); rf.append(d_)
+        peers.append(Peer(q, slice(ps, ps + len(a_)), slice(pr, pr + len(c_))))
+        ps += len(a_); pr += len(c_)
+    cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.int64)  # noqa: E731
+    return Partition(model=local, rank=rank, world=world, send_var=cat(sv), send_fac=cat(sf), recv_var=cat(rv), recv_fac=cat(rf),
+                     peers=peers, depth=depth, owned_x=x_own)
+
+
+def contiguous_blocks(model: synth.Model, rank: int, world: int, depth: int = 0) -> Partition:
     """Equal contiguous id-blocks of the latent variables (time blocks of a chain, row blocks of a grid); every other
     variable (observations) goes with its first neighbour among the latent variables."""
     x = np.sort(np.asarray(model.x_ids, np.int64))
@@ -181,7 +279,7 @@ def contiguous_blocks(model: synth.Model, rank: int, world: int) -> Partition:
         rep = np.array([obs_owner_var.get(int(i), int(i)) for i in ids], dtype=np.int64) if len(ids) else ids
         return np.searchsorted(bounds, rep, side="right")
 
-    return by_assignment(model, owner, rank, world)
+    return by_assignment_deep(model, owner, rank, world, depth) if depth else by_assignment(model, owner, rank, world)
 
 
 def cylinder_self(n_rows: int, n_cols: int, seed: int = 1234):

@@ -163,9 +163,10 @@ def test_rccl_exchange_issued_by_the_library_self_neighbour(hip_lib, schedule):
         assert_close(got[:, 1], g.f2v_v[e], 1e-9, "wrap-factor message variance")
 
 
-def test_generic_partition_of_a_chain_on_device(hip_lib):
+@pytest.mark.parametrize("depth", [0, 2])
+def test_generic_partition_of_a_chain_on_device(hip_lib, depth):
     """time blocks of a state-space chain (partition.contiguous_blocks), three handles on one GPU, in-process exchange:
-    bitwise equal to the un-partitioned flooding sweeps."""
+    bitwise equal to the un-partitioned flooding sweeps — with one message halo per sweep (depth 0) or a deep halo."""
     import torch
 
     T, world, sweeps = 90, 3, 25
@@ -179,13 +180,18 @@ def test_generic_partition_of_a_chain_on_device(hip_lib):
     def run(rank):
         try:
             ld.bind(rank)
-            part = partition.contiguous_blocks(whole_model, rank, world)
+            part = partition.contiguous_blocks(whole_model, rank, world, depth=depth)
             dev = cx.DeviceGraph(schedule=L.SCHED_FUSED)
             cx.synth.load_into_device(part.model, dev)
-            sw = partition.DeviceSweeper(dev, part, torch, torch.device("cuda", 0))
-            ex = partition.HaloExchange(sw, part, ld)
-            for _ in range(sweeps):
-                ex.sweep()
+            if depth:
+                sw = partition.DeviceStateSweeper(dev, part, torch, torch.device("cuda", 0))
+                ex = partition.DeepHaloExchange(sw, part, ld)
+                ex.sweep(sweeps)
+            else:
+                sw = partition.DeviceSweeper(dev, part, torch, torch.device("cuda", 0))
+                ex = partition.HaloExchange(sw, part, ld)
+                for _ in range(sweeps):
+                    ex.sweep()
             dev.sync()
             devs[rank] = (dev, part)
         except Exception as e:  # pragma: no cover
@@ -198,7 +204,7 @@ def test_generic_partition_of_a_chain_on_device(hip_lib):
         t.join(timeout=120)
     assert not errors, errors
     for dev, part in devs:
-        ids = part.model.x_ids
+        ids = part.model.x_ids if part.owned_x is None else part.owned_x
         assert np.array_equal(dev.get_marginals(ids), whole.get_marginals(ids), equal_nan=True)
 
 

@@ -139,3 +139,54 @@ def test_generic_partitioner_on_a_chain_matches_single_process():
         m, v = sw.g.marginals()
         li = np.searchsorted(sw.g.var_ids, p.model.x_ids); wi = np.searchsorted(g.var_ids, p.model.x_ids)
         assert np.array_equal(m[li], gm[wi], equal_nan=True) and np.array_equal(v[li], gv[wi], equal_nan=True)
+
+
+def test_generic_deep_partitioner_reproduces_the_deep_strips():
+    rows, cols, world, depth = 5, 6, 3, 2
+    whole = cx.synth.gaussian_grid(rows * world, cols, seed=99)
+    for r in range(world):
+        s = partition.grid_strip_deep(rows, cols, r, world, depth, seed=99)
+        g = partition.contiguous_blocks(whole, r, world, depth=depth)
+        key = lambda m: sorted(zip(m.edge_var.tolist(), m.edge_fac.tolist()))  # noqa: E731
+        assert key(g.model) == key(s.model)
+        for name in ("send_var", "send_fac", "recv_var", "recv_fac"):
+            assert np.array_equal(getattr(g, name), getattr(s, name)), name
+        assert [p.rank for p in g.peers] == [p.rank for p in s.peers]
+        assert np.array_equal(np.sort(g.owned_x), np.sort(s.owned_x))
+
+
+@pytest.mark.parametrize("depth", [1, 3])
+def test_generic_deep_partition_of_a_chain_matches_single_process(depth):
+    """time blocks of a state-space chain with a deep halo (observations are variables of their own here): flooding sweeps
+    with one state exchange per `depth` sweeps equal the un-partitioned sweeps bit for bit on every owned variable."""
+    from tests._dist_worker import OracleStateSweeper
+
+    T, world, sweeps = 40, 4, 2 * depth + 5
+    whole = cx.synth.ssm_chain(T, seed=8, random_variances=True)
+    parts = [partition.contiguous_blocks(whole, r, world, depth=depth) for r in range(world)]
+    assert np.array_equal(np.sort(np.concatenate([p.owned_x for p in parts])), np.sort(whole.x_ids))
+    sws = [OracleStateSweeper(p, None) for p in parts]
+    for k in range(sweeps):
+        if k % depth == 0:
+            for sw in sws:
+                sw.pack()
+            for r, p in enumerate(parts):
+                for peer in p.peers:
+                    back = [pp for pp in parts[peer.rank].peers if pp.rank == r][0]
+                    assert back.recv.stop - back.recv.start == peer.send.stop - peer.send.start
+                    sws[peer.rank].recv[back.recv] = sws[r].send[peer.send]
+            for sw in sws:
+                sw.unpack()
+        for sw in sws:
+            sw.sweep()
+    g = flood_oracle_from_model(whole)
+    g.sweep(sweeps)
+    gm, gv = g.marginals()
+    for p, sw in zip(parts, sws):
+        m, v = sw.g.marginals()
+        li = np.searchsorted(sw.g.var_ids, p.owned_x); wi = np.searchsorted(g.var_ids, p.owned_x)
+        assert np.array_equal(m[li], gm[wi], equal_nan=True) and np.array_equal(v[li], gv[wi], equal_nan=True)
+        own = np.isin(sw.g.edge_var, p.owned_x)
+        e = g.edge_index(sw.g.edge_var[own], sw.g.edge_fac[own])
+        for name in ("f2v_m", "f2v_v", "v2f_m", "v2f_v"):
+            assert np.array_equal(getattr(sw.g, name)[own], getattr(g, name)[e], equal_nan=True), name
