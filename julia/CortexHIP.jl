@@ -82,4 +82,71 @@ function Cortex.update_marginals!(engine::Cortex.InferenceEngine{M,D,HipProcesso
     end
     return nothing
 end
+
+# ---- variational families (weak dependencies): the marginals are the state ------------------------------------------------
+# A processor for the models of test/inference_engine_tests.jl:593-805 ("Mean Field", family = 2) and :807-1147
+# ("Structured", family = 3).  The dependency wiring those tests' resolvers create is what the device implements, so the
+# engine is built with `resolve_dependencies = false`; the host keeps only the marginal signals.
+mutable struct HipVmpProcessor <: Cortex.AbstractInferenceRequestProcessor
+    handle::Ptr{Cvoid}
+end
+
+function HipVmpProcessor(; device = 0, family = 3, schedule = 2)          # CX_FAMILY_VMP_STRUCTURED, CX_SCHED_CHAIN_SCAN
+    cfg = Ref(CxConfig(sizeof(CxConfig), device, 1, schedule, 1, 0, family, 0))
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:cx_create, lib), Int32, (Ref{CxConfig}, Ref{Ptr{Cvoid}}), cfg, out)
+    rc == 0 || error(unsafe_string(ccall((:cx_last_error, lib), Cstring, (Ptr{Cvoid},), C_NULL)))
+    p = HipVmpProcessor(out[])
+    finalizer(q -> ccall((:cx_destroy, lib), Int32, (Ptr{Cvoid},), q.handle), p)
+    return p
+end
+
+# role_of(engine, variable_id, factor_id) -> 0 (out) | 1 (mean) | 2 (precision); all factors are CX_FACTOR_NORMAL_PRECISION (3)
+function upload!(p::HipVmpProcessor, engine::Cortex.InferenceEngine, role_of)
+    ev, ef, er = Int64[], Int64[], Int32[]
+    fids = collect(Int64, Cortex.get_factor_ids(engine))
+    for f in fids, v in Cortex.get_connected_variable_ids(engine, f)
+        push!(ev, v); push!(ef, f); push!(er, role_of(engine, v, f))
+    end
+    kinds = fill(Int32(3), length(fids))
+    check(p.handle, ccall((:cx_graph_create, lib), Int32,
+        (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int32}, Int64, Ptr{Int64}, Ptr{Int32}, Ptr{Float64}),
+        p.handle, length(ev), ev, ef, er, length(fids), fids, kinds, C_NULL))
+end
+
+# where the tests call set_value!(get_variable_marginal(...), value): form 1 = datum, 3 = (mean, precision), 4 = Gamma(shape, scale)
+function set_marginal!(p::HipVmpProcessor, variable_id, form, payload::Vector{Float64})
+    check(p.handle, ccall((:cx_set_marginals, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}, Int32, Ptr{Float64}),
+                          p.handle, 1, Int64[variable_id], form, payload))
+end
+
+function Cortex.update_marginals!(engine::Cortex.InferenceEngine{M,D,HipVmpProcessor}, ids::Union{AbstractVector,Tuple}) where {M,D}
+    p = Cortex.get_inference_request_processor(engine)
+    v = collect(Int64, ids)
+    check(p.handle, ccall((:cx_update_marginals, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}), p.handle, length(v), v))
+    out = Matrix{Float64}(undef, 2, length(v))      # (mean, precision) or (shape, scale) per column
+    check(p.handle, ccall((:cx_get_marginals, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Float64}), p.handle, length(v), v, out))
+    for (i, id) in enumerate(v)
+        Cortex.set_value!(Cortex.get_variable_marginal(Cortex.get_variable(engine, id)), (out[1, i], out[2, i]))
+    end
+    return nothing
+end
+
+# ---- checkpoint and multi-GPU (one Julia process per GPU) ---------------------------------------------------------------
+function save_state(p, path)
+    n = Ref{Int64}(0)
+    check(p.handle, ccall((:cx_state_bytes, lib), Int32, (Ptr{Cvoid}, Ref{Int64}), p.handle, n))
+    buf = Vector{UInt8}(undef, n[])
+    check(p.handle, ccall((:cx_state_export, lib), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int64), p.handle, buf, n[]))
+    write(path, buf)
+end
+load_state!(p, path) = (buf = read(path); check(p.handle, ccall((:cx_state_import, lib), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int64), p.handle, buf, length(buf))))
+
+# deep halo: `exchange_every` plain sweeps between two state exchanges issued by the library over RCCL
+function sweep_partitioned!(p, n_sweeps, exchange_every)
+    for k in 0:(n_sweeps - 1)
+        k % exchange_every == 0 && check(p.handle, ccall((:cx_halo_state_exchange, lib), Int32, (Ptr{Cvoid},), p.handle))
+        check(p.handle, ccall((:cx_sweep, lib), Int32, (Ptr{Cvoid}, Int32), p.handle, 1))
+    end
+end
 end
