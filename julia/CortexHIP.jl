@@ -3,7 +3,8 @@
 # NOT EXECUTED in the authoring container (no Julia toolchain, no network): shipped as source for a maintainer to try
 # against Cortex.jl v0.3.0.  It uses only the C ABI of include/cortex_hip.h; the identical call sequence is exercised
 # through Python ctypes by every `-m gpu` test of this repository (cortex.jl_amd/hip_processor.py is the tested twin).
-# The text below is the same as the stub in INTEGRATION.md.
+# The HipProcessor part is the same text as the stub in INTEGRATION.md; the variational, checkpoint and multi-GPU parts
+# follow the entry-point table there.
 
 module CortexHIP
 using Cortex
