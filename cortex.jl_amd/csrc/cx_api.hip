@@ -1031,6 +1031,9 @@ static int32_t build_chains(cx_handle *h) {
                         (void *)h->d_chain_from, (void *)h->d_chain_to, (void *)h->d_chain_head_fwd, (void *)h->d_chain_head_bwd,
                         (void *)h->d_chain_side, h->d_chain_totals}) if (p) (void)hipFree(p);
         h->chain_npos = (int64_t)pos_var.size(); h->chain_nlinks = (int64_t)link_pos.size();
+        int64_t n_readers = 0;   // variables that read factor→variable messages: everything but observed variables and ghosts
+        for (int64_t v = 0; v < nv; v++) n_readers += (h->vinfo[v] & (cx::kClamped | cx::kGhost)) ? 0 : 1;
+        h->chain_covers_all = n_readers == h->chain_npos;
         int32_t rc;
         if ((rc = dev_upload(h, &h->d_chain_pos_var, pos_var)) != CX_OK) return rc;
         if ((rc = dev_upload(h, &h->d_chain_skip0, skip0)) != CX_OK) return rc;
@@ -1054,8 +1057,10 @@ static int32_t build_chains(cx_handle *h) {
 static void sweep_main(cx_handle *h, bool skip_ghosts) {
     const bool marg = h->cfg.compute_marginals_in_sweep != 0;
     if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) {
-        cx::launch_factor_to_var(h, h->d_v2f, h->d_f2v);   // messages out of observed leaves (data) into the chains
-        cx::launch_chain_scan(h, h->d_f2v);                // all forward and backward chain messages
+        // messages out of observed leaves (data) into the chains: by the scan's side pass when every free variable is on a
+        // chain, by a factor phase over all slots otherwise (free variables off the chains need theirs too)
+        if (!h->chain_covers_all) cx::launch_factor_to_var(h, h->d_v2f, h->d_f2v);
+        cx::launch_chain_scan(h, h->d_f2v, h->chain_covers_all);   // all forward and backward chain messages
         cx::launch_var_to_factor(h, h->d_f2v, marg);       // every variable→factor message + marginals
         cx::launch_big_var_to_factor(h, h->d_f2v, marg);
     } else if (h->cfg.schedule == CX_SCHED_FLOODING) {

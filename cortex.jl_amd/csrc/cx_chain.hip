@@ -62,11 +62,32 @@ __device__ __forceinline__ Lin lin_of_link(double2 u, double q, double a, double
 constexpr int kItems = 4;                    // links per thread
 constexpr int kTile = kBlock * kItems;       // links per workgroup
 
-// side information of chain position i: the sum of the variable's incoming messages except its (≤2) chain slots
+// the factor→variable rule of cx_kernels.hip (receiving edge's parameters); a = 1, b = 0 for additive factors
+__device__ __forceinline__ double2 chain_factor_rule(double2 m, double q, double a, double b) {
+    double2 o;
+    if (m.y == __builtin_inf()) {
+        o.y = 1.0 / q;
+        o.x = (a * m.x + b) * o.y;
+    } else {
+        const double s = 1.0 / (a * a + q * m.y);
+        o.y = m.y * s;
+        o.x = (a * m.x + b * m.y) * s;
+    }
+    return o;
+}
+
+// side information of chain position i: the sum of the variable's incoming messages except its (≤2) chain slots.
+// FUSED_LEAVES: those messages are first recomputed from the variable→factor messages of their senders (observed leaves,
+// priors keep their stored value) and stored — the factor phase of the flooding schedule restricted to the slots the
+// scans do not produce, so that no separate pass over all slots is needed.
+template <bool FUSED_LEAVES>
 __global__ __launch_bounds__(kBlock) void k_chain_side(int npos, const int32_t *__restrict__ pos_var, const int32_t *__restrict__ pos_skip0,
                                                        const int32_t *__restrict__ pos_skip1, const int32_t *__restrict__ vbase,
                                                        const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
-                                                       const double2 *__restrict__ f2v, double2 *__restrict__ side) {
+                                                       const int32_t *__restrict__ partner, const double *__restrict__ q,
+                                                       const double *__restrict__ pa, const double *__restrict__ pb,
+                                                       const double2 *__restrict__ v2f, double2 *__restrict__ f2v,
+                                                       double2 *__restrict__ side) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= npos) return;
     const int v = pos_var[i], s0 = pos_skip0[i], s1 = pos_skip1[i];
@@ -76,7 +97,17 @@ __global__ __launch_bounds__(kBlock) void k_chain_side(int npos, const int32_t *
     for (int k = 0; k < deg; k++) {
         const int slot = b + k * stride;
         if (slot == s0 || slot == s1) continue;
-        const double2 m = f2v[slot];
+        double2 m = f2v[slot];
+        if (FUSED_LEAVES) {
+            const int p = partner[slot];
+            if (p >= 0) {
+                const double2 in = v2f[p];
+                if (!__builtin_isnan(in.y)) {
+                    m = chain_factor_rule(in, q[slot], pa ? pa[slot] : 1.0, pb ? pb[slot] : 0.0);
+                    f2v[slot] = m;
+                }
+            }
+        }
         acc.x += m.x; acc.y += m.y;
     }
     side[i] = acc;
@@ -209,11 +240,18 @@ __global__ __launch_bounds__(kBlock) void k_chain_apply(ChainArgs A, const Lin *
     }
 }
 
-void launch_chain_scan(cx_handle *h, double2 *f2v) {
+void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves) {
     const int nlinks = (int)h->chain_nlinks, npos = (int)h->chain_npos;
     if (nlinks == 0) return;
-    hipLaunchKernelGGL(k_chain_side, dim3((npos + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, npos, h->d_chain_pos_var,
-                       h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, f2v, h->d_chain_side);
+    const double *pa = h->any_linear ? h->d_a : nullptr, *pb = h->any_linear ? h->d_b : nullptr;
+    if (fused_leaves)
+        hipLaunchKernelGGL(k_chain_side<true>, dim3((npos + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, npos, h->d_chain_pos_var,
+                           h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, pa, pb,
+                           h->d_v2f, f2v, h->d_chain_side);
+    else
+        hipLaunchKernelGGL(k_chain_side<false>, dim3((npos + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, npos, h->d_chain_pos_var,
+                           h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, pa, pb,
+                           h->d_v2f, f2v, h->d_chain_side);
     ChainArgs A{nlinks, h->d_chain_link_pos, h->d_chain_from, h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd,
                 h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_chain_side};
     const int ntiles = (nlinks + kTile - 1) / kTile;

@@ -87,6 +87,7 @@ struct cx_handle {
     // chain-scan schedule (cx_chain.hip): paths of free variables, built lazily by build_chains()
     bool chains_dirty = true;
     int64_t chain_npos = 0, chain_nlinks = 0;
+    bool chain_covers_all = false;   // every variable that reads messages is a chain position: the scan's side pass produces all leaf messages
     int32_t *d_chain_pos_var = nullptr, *d_chain_skip0 = nullptr, *d_chain_skip1 = nullptr;
     int32_t *d_chain_link_pos = nullptr, *d_chain_from = nullptr, *d_chain_to = nullptr;
     uint8_t *d_chain_head_fwd = nullptr, *d_chain_head_bwd = nullptr;
@@ -146,7 +147,7 @@ void launch_scatter(cx_handle *h, double2 *dst, const int32_t *d_idx, const doub
 void launch_gather(cx_handle *h, const double2 *src, const int32_t *d_idx, double2 *d_val, int64_t n);
 void launch_seed(cx_handle *h, double2 *buf, int64_t n, double2 value, const int32_t *partner);
 void launch_residual(cx_handle *h, const double2 *cur, const double2 *prev, int64_t n, double *d_out);
-void launch_chain_scan(cx_handle *h, double2 *f2v);
+void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves);
 // multivariate (cx_mv.hip)
 void mv_launch_sweep(cx_handle *h, bool write_marg);
 void mv_launch_v2f(cx_handle *h, const int32_t *d_slots, const int32_t *d_vars, int64_t n, const double *f2v);
