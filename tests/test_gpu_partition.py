@@ -274,3 +274,46 @@ def test_deep_halo_exchange_issued_by_the_library(hip_lib):
     assert np.array_equal(dev.get_messages(m.edge_var, m.edge_fac, L.TO_VARIABLE, L.FORM_NATURAL),
                           plain.get_messages(m.edge_var, m.edge_fac, L.TO_VARIABLE, L.FORM_NATURAL), equal_nan=True)
     assert np.array_equal(dev.get_marginals(m.x_ids), plain.get_marginals(m.x_ids), equal_nan=True)
+
+
+def test_config_c4_full_size_deep_halo(hip_lib):
+    """BASELINE config C4 at full size: the 1415 x 1415 grid (10,005,465 edges) cut into 5 strips of 283 rows with an
+    8-row deep halo, five handles on one GPU.  After 19 sweeps (two full exchange periods + 3) every marginal equals the
+    un-partitioned device sweep bit for bit."""
+    import torch
+
+    N, world, depth, sweeps = 1415, 5, 8, 19
+    rows = N // world
+    whole_model = cx.synth.gaussian_grid(N, N, seed=1234)
+    whole = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(whole_model, whole, seed_variance=1e6)
+    assert whole.stats()["n_edges"] == 10_005_465
+    whole.sweep(sweeps)
+    ld = LoopbackDist(world, torch)
+    devs, parts, errors = [None] * world, [None] * world, []
+
+    def run(rank):
+        try:
+            ld.bind(rank)
+            part = partition.grid_strip_deep(rows, N, rank, world, depth, seed=1234)
+            dev = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+            cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
+            ex = partition.DeepHaloExchange(partition.DeviceStateSweeper(dev, part, torch, torch.device("cuda", 0)), part, ld)
+            ex.sweep(sweeps)
+            dev.sync()
+            devs[rank], parts[rank] = dev, part
+        except Exception as e:  # pragma: no cover
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    total = 0
+    for rank in range(world):
+        ids = parts[rank].owned_x
+        assert np.array_equal(devs[rank].get_marginals(ids), whole.get_marginals(ids), equal_nan=True), f"rank {rank}"
+        total += len(ids)
+    assert total == N * N
