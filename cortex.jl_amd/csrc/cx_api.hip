@@ -643,6 +643,7 @@ int32_t mv_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
     CX_HIP(h, hipMemcpyAsync(d_val, val.data(), (size_t)n * nc * 8, hipMemcpyHostToDevice, h->stream));
     if (direction == CX_TO_FACTOR) {
         cx::mv_launch_scatter(h, h->d_mv_v2f, h->nslots, nc, d_idx, d_val, n);
+        h->observed_passes_due = 2;   // a stored variable→factor message changed: observed senders are refreshed
         if (form == CX_FORM_POINT) {
             for (int64_t i = 0; i < n; i++) h->vinfo[vars[i]] |= cx::kClamped;
             CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
@@ -765,13 +766,16 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
         }
         CX_HIP(h, hipMemcpy(h->d_spdir, eff.data(), eff.size() * 4, hipMemcpyHostToDevice));
         h->spdir_dirty = false;
+        h->observed_passes_due = 2;   // the data (or the set of observed variables) changed: refresh both buffers
     }
     for (int32_t s = 0; s < n_sweeps; s++) {
         if (h->cfg.dim == 64)
             cx::mv64_launch_rule(h, (int)h->n_rule64, h->d_rule64_slots, h->d_rule64_vars, h->d_rule64_flags, h->d_mv_f2v, h->d_mv_f2v_alt,
                                  CX_KERNEL_FUSED);
-        else
-            cx::mv_launch_sweep(h, h->cfg.compute_marginals_in_sweep != 0);
+        else {
+            if (h->observed_passes_due > 0) { cx::mv_launch_sweep(h, false, true); h->observed_passes_due--; }
+            cx::mv_launch_sweep(h, h->cfg.compute_marginals_in_sweep != 0, false);
+        }
         std::swap(h->d_mv_f2v, h->d_mv_f2v_alt);
         h->sweeps_done++;
     }

@@ -76,6 +76,7 @@ struct cx_handle {
     int32_t *d_spdir = nullptr;                    // per SENDING slot: 2*pset + direction of the receiving edge; -1: receiver observed
     std::vector<int32_t> spdir;                    // host copy without the observed-receiver mask
     bool spdir_dirty = true;
+    int observed_passes_due = 2;                   // sweeps that still have to write the messages out of observed variables
     double *d_ptab = nullptr;                      // [2*npsets][3][d*d]: (P, B, C) triples
     int64_t ptab_sets = 0, max_pset = -1;
     double *d_mv_f2v = nullptr, *d_mv_f2v_alt = nullptr, *d_mv_v2f = nullptr, *d_mv_marg = nullptr, *d_mv_prev = nullptr;
@@ -149,7 +150,7 @@ void launch_seed(cx_handle *h, double2 *buf, int64_t n, double2 value, const int
 void launch_residual(cx_handle *h, const double2 *cur, const double2 *prev, int64_t n, double *d_out);
 void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves);
 // multivariate (cx_mv.hip)
-void mv_launch_sweep(cx_handle *h, bool write_marg);
+void mv_launch_sweep(cx_handle *h, bool write_marg, bool observed_only);
 void mv_launch_v2f(cx_handle *h, const int32_t *d_slots, const int32_t *d_vars, int64_t n, const double *f2v);
 void mv_launch_scatter(cx_handle *h, double *dst, int64_t stride, int nc, const int32_t *d_idx, const double *d_val, int64_t n);
 void mv_launch_gather(cx_handle *h, const double *src, int64_t stride, int nc, const int32_t *d_idx, double *d_val, int64_t n);

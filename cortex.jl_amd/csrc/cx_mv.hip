@@ -203,12 +203,17 @@ __global__ __launch_bounds__(kBlock) void k_sweep_mv(int nv, int64_t nslots, con
                                                      const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
                                                      const int32_t *__restrict__ spdir, const double *__restrict__ ptab,
                                                      const double *__restrict__ f2v_in, double *__restrict__ f2v_out,
-                                                     const double *__restrict__ v2f, double *__restrict__ marg, int write_marg) {
+                                                     const double *__restrict__ v2f, double *__restrict__ marg, int write_marg,
+                                                     int observed_only) {
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
     const int v = (s << kSliceShift) + tid;
     if (v >= nv) return;
     const int info = vinfo[v], deg = info & kDegMask;
+    // Messages out of observed variables are constants of the data: the regular sweep skips those variables (on a
+    // state-space chain a third of all rule evaluations and stores); the host runs an `observed_only` pass into the output
+    // buffer for the first two sweeps after the data changed, which leaves them in both buffers of the Jacobi pair.
+    if (((info & kClamped) != 0) != (observed_only != 0)) return;
     const int base = slice_off[s] + tid;
     if (write_marg) {
         Msg<D> total = msg_zero<D>();
@@ -327,18 +332,19 @@ static void prof_e(cx_handle *h) {
     if (h->profiling && h->prof_armed) (void)hipEventRecord(h->recs.back().stop, h->stream);
 }
 
-void mv_launch_sweep(cx_handle *h, bool write_marg) {
+void mv_launch_sweep(cx_handle *h, bool write_marg, bool observed_only) {
     if (h->nslices == 0) return;
-    prof_b(h, CX_KERNEL_FUSED);
+    if (!observed_only) prof_b(h, CX_KERNEL_FUSED);
     const dim3 g((unsigned)h->nslices), b(kBlock);
 #define CX_MV(DD)                                                                                                          \
     hipLaunchKernelGGL((k_sweep_mv<DD>), g, b, 0, h->stream, (int)h->nv, h->nslots, h->d_slice_off, h->d_vinfo, h->d_partner, \
-                       h->d_spdir, h->d_ptab, h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg, write_marg ? 1 : 0)
+                       h->d_spdir, h->d_ptab, h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg,                        \
+                       (write_marg && !observed_only) ? 1 : 0, observed_only ? 1 : 0)
     if (h->cfg.dim == 2) CX_MV(2);
     else if (h->cfg.dim == 3) CX_MV(3);
     else CX_MV(4);
 #undef CX_MV
-    prof_e(h);
+    if (!observed_only) prof_e(h);
 }
 
 void mv_launch_v2f(cx_handle *h, const int32_t *d_slots, const int32_t *d_vars, int64_t n, const double *f2v) {
