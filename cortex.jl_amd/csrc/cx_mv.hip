@@ -75,17 +75,28 @@ __device__ __forceinline__ void msg_add(Msg<D> &a, const Msg<D> &b) {
     for (int i = 0; i < Msg<D>::NT; i++) a.lam[i] += b.lam[i];
 }
 
+// 1/sqrt(x) to double precision: v_rsq_f64 seed + two Newton steps.  sqrt(), 1.0/x and x/y each expand to 30-40 dependent
+// instructions; a d = 4 rule had 28 of them (4 sqrt, 4 reciprocals, 20 divisions in the triangular solves) — with the
+// reciprocal diagonal kept from the factorisation it is 4 rsqrt and no division.
+__device__ __forceinline__ double rsqrt_f64(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * __builtin_fma(-hx * y, y, 1.5);
+    y = y * __builtin_fma(-hx * y, y, 1.5);
+    return y;
+}
+
 // lower Cholesky factor of the packed symmetric matrix S (+ optional full symmetric P): L[i][j], j <= i
 template <int D>
-__device__ __forceinline__ void chol(const double (&S)[Msg<D>::NT], const double *__restrict__ P, double (&Lm)[D][D]) {
+__device__ __forceinline__ void chol(const double (&S)[Msg<D>::NT], const double *__restrict__ P, double (&Lm)[D][D], double (&ri)[D]) {
 #pragma unroll
     for (int j = 0; j < D; j++) {
         double d = S[tri<D>(j, j)] + (P ? P[j * D + j] : 0.0);
 #pragma unroll
         for (int k = 0; k < j; k++) d -= Lm[j][k] * Lm[j][k];
-        const double ljj = sqrt(d);          // non-PD input -> NaN, which marks the message undefined
-        Lm[j][j] = ljj;
-        const double inv = 1.0 / ljj;
+        const double inv = rsqrt_f64(d);     // non-PD input -> NaN, which marks the message undefined
+        ri[j] = inv;
+        Lm[j][j] = d * inv;
 #pragma unroll
         for (int i = j + 1; i < D; i++) {
             double s = S[tri<D>(j, i)] + (P ? P[i * D + j] : 0.0);
@@ -96,15 +107,15 @@ __device__ __forceinline__ void chol(const double (&S)[Msg<D>::NT], const double
     }
 }
 
-// x <- L^-1 x
+// x <- L^-1 x   (ri = reciprocal diagonal of L)
 template <int D>
-__device__ __forceinline__ void fwd_solve(const double (&Lm)[D][D], double (&x)[D]) {
+__device__ __forceinline__ void fwd_solve(const double (&Lm)[D][D], const double (&ri)[D], double (&x)[D]) {
 #pragma unroll
     for (int i = 0; i < D; i++) {
         double s = x[i];
 #pragma unroll
         for (int k = 0; k < i; k++) s -= Lm[i][k] * x[k];
-        x[i] = s / Lm[i][i];
+        x[i] = s * ri[i];
     }
 }
 
@@ -125,22 +136,22 @@ __device__ __forceinline__ Msg<D> mv_rule(const Msg<D> &in, const double *__rest
         }
         return out;
     }
-    double Lm[D][D];
-    chol<D>(in.lam, P, Lm);
+    double Lm[D][D], ri[D];
+    chol<D>(in.lam, P, Lm, ri);
     double Y[D][D];  // Y[:, c] = L^-1 (row c of B)'
 #pragma unroll
     for (int c = 0; c < D; c++) {
         double col[D];
 #pragma unroll
         for (int k = 0; k < D; k++) col[k] = B[c * D + k];
-        fwd_solve<D>(Lm, col);
+        fwd_solve<D>(Lm, ri, col);
 #pragma unroll
         for (int k = 0; k < D; k++) Y[k][c] = col[k];
     }
     double z[D];
 #pragma unroll
     for (int k = 0; k < D; k++) z[k] = in.eta[k];
-    fwd_solve<D>(Lm, z);
+    fwd_solve<D>(Lm, ri, z);
 #pragma unroll
     for (int i = 0; i < D; i++) {
         double s = 0.0;
@@ -161,15 +172,15 @@ __device__ __forceinline__ Msg<D> mv_rule(const Msg<D> &in, const double *__rest
 // natural -> moment (mean, packed covariance) for marginals
 template <int D>
 __device__ __forceinline__ Msg<D> mv_to_moment(const Msg<D> &nat) {
-    double Lm[D][D];
-    chol<D>(nat.lam, nullptr, Lm);
+    double Lm[D][D], ri[D];
+    chol<D>(nat.lam, nullptr, Lm, ri);
     double Li[D][D];  // columns of L^-1
 #pragma unroll
     for (int c = 0; c < D; c++) {
         double e[D];
 #pragma unroll
         for (int k = 0; k < D; k++) e[k] = (k == c) ? 1.0 : 0.0;
-        fwd_solve<D>(Lm, e);
+        fwd_solve<D>(Lm, ri, e);
 #pragma unroll
         for (int k = 0; k < D; k++) Li[k][c] = e[k];
     }
@@ -195,35 +206,58 @@ __device__ __forceinline__ Msg<D> mv_to_moment(const Msg<D> &nat) {
 
 constexpr int kMvDeg = 4;  // variables of higher degree are refused at graph creation for dim > 1 (this round)
 
-// The fused sweep for small d: thread = variable.  For each outgoing edge the "product of the others" is re-summed
-// from the (L2-resident) input buffer in ascending neighbour order — the reference's left fold order — which keeps
-// the register count flat (one accumulator instead of deg messages).
+// The fused sweep for small d: thread = variable.
+// Latency: a wave first issues EVERY load it will need — all incoming messages, the partner and rule-selector words of all
+// its edges — under workgroup-uniform branches (k < slice width), and only then waits; the (P, B, C) rule tables of up to
+// kTabLds parameter-set/direction pairs sit in LDS.  The earlier form loaded partner[], then spdir[], then the 48 table
+// doubles, one dependent round trip after the other and per edge: ≈10 serialised memory latencies per wave (C3: 0.19 ms
+// per sweep; PMC: VALU busy 6 %, waves waiting on memory 65 % of their cycles).
+// The leave-one-out sums add the messages in ascending neighbour order, the reference's left fold order.
+constexpr int kTabLds = 8;   // parameter-set/direction pairs kept in LDS (3 d*d matrices each); more fall back to global memory
+
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_sweep_mv(int nv, int64_t nslots, const int32_t *__restrict__ slice_off,
                                                      const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
-                                                     const int32_t *__restrict__ spdir, const double *__restrict__ ptab,
+                                                     const int32_t *__restrict__ spdir, const double *__restrict__ ptab, int ntab,
                                                      const double *__restrict__ f2v_in, double *__restrict__ f2v_out,
                                                      const double *__restrict__ v2f, double *__restrict__ marg, int write_marg,
                                                      int observed_only) {
+    __shared__ double tab_s[kTabLds * 3 * D * D];
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
     const int v = (s << kSliceShift) + tid;
-    if (v >= nv) return;
-    const int info = vinfo[v], deg = info & kDegMask;
+    const int off = slice_off[s];
+    const int W = (slice_off[s + 1] - off) >> kSliceShift;   // slice width: workgroup-uniform
+    const int nt = ntab < kTabLds ? ntab : kTabLds;
+    for (int i = tid; i < nt * 3 * D * D; i += kBlock) tab_s[i] = ptab[i];
+    const int info = v < nv ? vinfo[v] : 0, deg = info & kDegMask;
     // Messages out of observed variables are constants of the data: the regular sweep skips those variables (on a
     // state-space chain a third of all rule evaluations and stores); the host runs an `observed_only` pass into the output
     // buffer for the first two sweeps after the data changed, which leaves them in both buffers of the Jacobi pair.
-    if (((info & kClamped) != 0) != (observed_only != 0)) return;
-    const int base = slice_off[s] + tid;
+    const bool active = v < nv && (((info & kClamped) != 0) == (observed_only != 0));
+    const int base = off + tid;
+    Msg<D> in[kMvDeg];
+    int pk[kMvDeg], sd[kMvDeg];
+#pragma unroll
+    for (int k = 0; k < kMvDeg; k++) {
+        in[k] = msg_zero<D>();
+        pk[k] = -1; sd[k] = -1;
+        if (k < W && active) {   // k < W is uniform; lanes with deg <= k read a padding slot of their own slice and drop it
+            const Msg<D> x = msg_load<D>(f2v_in, nslots, base + k * kBlock);
+            const int p = partner[base + k * kBlock], d = spdir[base + k * kBlock];
+            if (k < deg) { in[k] = x; pk[k] = p; sd[k] = d; }
+        }
+    }
+    __syncthreads();   // rule tables are in LDS (every thread of the workgroup reaches this point)
+    if (!active) return;
     if (write_marg) {
         Msg<D> total = msg_zero<D>();
 #pragma unroll
         for (int k = 0; k < kMvDeg; k++)
-            if (k < deg) msg_add<D>(total, msg_load<D>(f2v_in, nslots, base + k * kBlock));
+            if (k < deg) msg_add<D>(total, in[k]);
         const Msg<D> mo = (deg > 0) ? mv_to_moment<D>(total) : total;
+        // marginals are written once and not re-read by the sweep: nontemporal stores
 #pragma unroll
-        // marginals are written once and not re-read by the sweep: nontemporal stores (C3: -2 %; nontemporal message
-        // LOADS are +18 % here, unlike the scalar kernel, because every message is re-read for the leave-one-out sums)
         for (int i = 0; i < D; i++) __builtin_nontemporal_store((deg > 0) ? mo.eta[i] : __builtin_nan(""), &marg[(int64_t)i * nv + v]);
 #pragma unroll
         for (int i = 0; i < Msg<D>::NT; i++) __builtin_nontemporal_store((deg > 0) ? mo.lam[i] : __builtin_nan(""), &marg[(int64_t)(D + i) * nv + v]);
@@ -233,8 +267,10 @@ __global__ __launch_bounds__(kBlock) void k_sweep_mv(int nv, int64_t nslots, con
     for (int k = 0; k < kMvDeg; k++) {
         if (k >= deg) continue;
         const int slot = base + k * kBlock;
-        const int p = partner[slot];
-        if (p < 0 || spdir[slot] < 0) continue;  // nobody listens to this variable→factor message
+        const int p = pk[k], pd = sd[k];
+        // p < 0: nobody listens to this variable→factor message; pd < 0: the receiver is an observed variable, nobody reads
+        // the message into it (lazy, like the reference)
+        if (p < 0 || pd < 0) continue;
         Msg<D> o;
         if (fixed) {
             o = msg_load<D>(v2f, nslots, slot);
@@ -242,12 +278,10 @@ __global__ __launch_bounds__(kBlock) void k_sweep_mv(int nv, int64_t nslots, con
             o = msg_zero<D>();
 #pragma unroll
             for (int j = 0; j < kMvDeg; j++)
-                if (j < deg && j != k) msg_add<D>(o, msg_load<D>(f2v_in, nslots, base + j * kBlock));
+                if (j < deg && j != k) msg_add<D>(o, in[j]);
         }
-        const int pd = spdir[slot];
-        if (pd < 0) continue;  // the receiver is an observed variable: nobody reads that message (lazy, like the reference)
         if (__builtin_isnan(o.lam[0])) continue;
-        const Msg<D> r = mv_rule<D>(o, ptab + (int64_t)pd * 3 * D * D);
+        const Msg<D> r = pd < nt ? mv_rule<D>(o, tab_s + pd * 3 * D * D) : mv_rule<D>(o, ptab + (int64_t)pd * 3 * D * D);
         if (!__builtin_isnan(r.lam[0])) msg_store<D>(f2v_out, nslots, p, r);
     }
 }
@@ -338,7 +372,7 @@ void mv_launch_sweep(cx_handle *h, bool write_marg, bool observed_only) {
     const dim3 g((unsigned)h->nslices), b(kBlock);
 #define CX_MV(DD)                                                                                                          \
     hipLaunchKernelGGL((k_sweep_mv<DD>), g, b, 0, h->stream, (int)h->nv, h->nslots, h->d_slice_off, h->d_vinfo, h->d_partner, \
-                       h->d_spdir, h->d_ptab, h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg,                        \
+                       h->d_spdir, h->d_ptab, (int)(2 * h->ptab_sets), h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg, \
                        (write_marg && !observed_only) ? 1 : 0, observed_only ? 1 : 0)
     if (h->cfg.dim == 2) CX_MV(2);
     else if (h->cfg.dim == 3) CX_MV(3);
