@@ -1419,7 +1419,7 @@ std::vector<StatePart> state_parts(cx_handle *h) {
 int32_t cx_state_bytes(const cx_handle *hc, int64_t *bytes) {
     cx_handle *h = const_cast<cx_handle *>(hc);
     CX_REQUIRE(h, h && h->has_graph && bytes, CX_ERR_STATE, "cx_state_bytes: no graph or null argument");
-    CX_NOT_VMP(h, "cx_state_bytes");
+    if (is_vmp(h)) return cx::vmp_state_bytes(h, bytes);
     int64_t n = (int64_t)sizeof(StateHeader);
     for (auto &p : state_parts(h)) n += (int64_t)sizeof(StateSection) + p.bytes;
     *bytes = n;
@@ -1427,8 +1427,8 @@ int32_t cx_state_bytes(const cx_handle *hc, int64_t *bytes) {
 }
 
 int32_t cx_state_export(cx_handle *h, void *buf, int64_t bytes) {
-    CX_NOT_VMP(h, "cx_state_export");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_state_export: no graph");
+    if (is_vmp(h)) return cx::vmp_state_export(h, buf, bytes);
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_state_export: a cx_sweep_begin is still open");
     int64_t need = 0;
     (void)cx_state_bytes(h, &need);
@@ -1454,8 +1454,8 @@ int32_t cx_state_export(cx_handle *h, void *buf, int64_t bytes) {
 }
 
 int32_t cx_state_import(cx_handle *h, const void *buf, int64_t bytes) {
-    CX_NOT_VMP(h, "cx_state_import");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_state_import: no graph");
+    if (is_vmp(h)) return cx::vmp_state_import(h, buf, bytes);
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_state_import: a cx_sweep_begin is still open");
     CX_REQUIRE(h, buf && bytes >= (int64_t)sizeof(StateHeader), CX_ERR_INVALID_ARGUMENT, "cx_state_import: blob too short");
     StateHeader hd;

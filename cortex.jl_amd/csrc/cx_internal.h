@@ -176,6 +176,9 @@ int32_t vmp_set_marginals(cx_handle *h, int64_t n, const int64_t *ids, int32_t f
 int32_t vmp_get_marginals(cx_handle *h, int64_t n, const int64_t *ids, double *out);
 int32_t vmp_update_marginals(cx_handle *h, int64_t n, const int64_t *ids);
 int32_t vmp_set_stream(cx_handle *h);
+int32_t vmp_state_bytes(cx_handle *h, int64_t *bytes);
+int32_t vmp_state_export(cx_handle *h, void *buf, int64_t bytes);
+int32_t vmp_state_import(cx_handle *h, const void *buf, int64_t bytes);
 void vmp_free(cx_handle *h);
 // RCCL halo exchange (cx_comm.hip)
 bool comm_unique_id(void *out128, std::string &err);

@@ -595,3 +595,93 @@ int32_t vmp_update_marginals(cx_handle *h, int64_t n, const int64_t *ids) {
 }
 
 }  // namespace cx
+
+// ---- checkpoint (cx_state_*): marginals, observed flags, and — structured family — the inner handle's own blob -------------
+namespace {
+struct VmpStateHeader {
+    char magic[8];
+    int32_t abi, family, schedule, chain_ready;
+    int64_t nN, nG, nF, n_latent, sweeps_done, n_messages, inner_bytes;
+    uint64_t fingerprint;
+};
+const char kVmpMagic[8] = {'C', 'X', 'V', 'M', 'P', 'S', 'T', '1'};
+
+uint64_t vmp_fingerprint(const Vmp *s) {
+    uint64_t f = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { f ^= b[i]; f *= 1099511628211ull; } };
+    mix(s->var_ids.data(), s->var_ids.size() * 8); mix(s->var_kind.data(), s->var_kind.size() * 4);
+    mix(s->fac_ids.data(), s->fac_ids.size() * 8); mix(s->f_out.data(), s->f_out.size() * 4);
+    mix(s->f_mean.data(), s->f_mean.size() * 4); mix(s->f_gamma.data(), s->f_gamma.size() * 4);
+    return f;
+}
+int64_t vmp_own_bytes(const Vmp *s) { return (int64_t)sizeof(VmpStateHeader) + s->nN * 17 + s->nG * 24; }
+}  // namespace
+
+namespace cx {
+
+int32_t vmp_state_bytes(cx_handle *h, int64_t *bytes) {
+    Vmp *s = (Vmp *)h->vmp;
+    int64_t inner = 0;
+    if (s->chain) { int32_t rc = cx_state_bytes(s->chain, &inner); VMP_REQUIRE(h, rc == CX_OK, rc, std::string("cx_state_bytes (inner handle): ") + cx_last_error(s->chain)); }
+    *bytes = vmp_own_bytes(s) + inner;
+    return CX_OK;
+}
+
+int32_t vmp_state_export(cx_handle *h, void *buf, int64_t bytes) {
+    Vmp *s = (Vmp *)h->vmp;
+    int64_t need = 0, inner = 0;
+    int32_t rc = vmp_state_bytes(h, &need);
+    if (rc != CX_OK) return rc;
+    VMP_REQUIRE(h, buf && bytes >= need, CX_ERR_INVALID_ARGUMENT, "cx_state_export: buffer smaller than cx_state_bytes");
+    if (s->chain) (void)cx_state_bytes(s->chain, &inner);
+    VMP_HIP(h, hipSetDevice(h->cfg.device));
+    VMP_HIP(h, hipStreamSynchronize(h->stream));
+    VmpStateHeader hd{};
+    std::memcpy(hd.magic, kVmpMagic, 8);
+    hd.abi = CX_ABI_VERSION; hd.family = h->cfg.family; hd.schedule = h->cfg.schedule; hd.chain_ready = s->chain_ready ? 1 : 0;
+    hd.nN = s->nN; hd.nG = s->nG; hd.nF = s->nF; hd.n_latent = s->n_latent; hd.sweeps_done = h->sweeps_done;
+    hd.n_messages = h->n_messages_per_sweep; hd.inner_bytes = inner; hd.fingerprint = vmp_fingerprint(s);
+    char *o = (char *)buf;
+    std::memcpy(o, &hd, sizeof hd); o += sizeof hd;
+    VMP_HIP(h, hipMemcpy(o, s->n_mean, (size_t)s->nN * 8, hipMemcpyDeviceToHost)); o += s->nN * 8;
+    VMP_HIP(h, hipMemcpy(o, s->n_prec, (size_t)s->nN * 8, hipMemcpyDeviceToHost)); o += s->nN * 8;
+    std::memcpy(o, s->n_observed.data(), (size_t)s->nN); o += s->nN;
+    VMP_HIP(h, hipMemcpy(o, s->g_shape, (size_t)s->nG * 8, hipMemcpyDeviceToHost)); o += s->nG * 8;
+    VMP_HIP(h, hipMemcpy(o, s->g_scale, (size_t)s->nG * 8, hipMemcpyDeviceToHost)); o += s->nG * 8;
+    VMP_HIP(h, hipMemcpy(o, s->g_mean, (size_t)s->nG * 8, hipMemcpyDeviceToHost)); o += s->nG * 8;
+    if (s->chain) {
+        rc = cx_state_export(s->chain, o, inner);
+        VMP_REQUIRE(h, rc == CX_OK, rc, std::string("cx_state_export (inner handle): ") + cx_last_error(s->chain));
+    }
+    return CX_OK;
+}
+
+int32_t vmp_state_import(cx_handle *h, const void *buf, int64_t bytes) {
+    Vmp *s = (Vmp *)h->vmp;
+    VMP_REQUIRE(h, buf && bytes >= (int64_t)sizeof(VmpStateHeader), CX_ERR_INVALID_ARGUMENT, "cx_state_import: blob too short");
+    VmpStateHeader hd;
+    std::memcpy(&hd, buf, sizeof hd);
+    VMP_REQUIRE(h, std::memcmp(hd.magic, kVmpMagic, 8) == 0 && hd.abi == CX_ABI_VERSION, CX_ERR_INVALID_ARGUMENT, "cx_state_import: not a state blob of a variational handle of this ABI version");
+    VMP_REQUIRE(h, hd.family == h->cfg.family && hd.schedule == h->cfg.schedule, CX_ERR_INVALID_ARGUMENT, "cx_state_import: the blob was exported with a different family / schedule");
+    VMP_REQUIRE(h, hd.nN == s->nN && hd.nG == s->nG && hd.nF == s->nF && hd.fingerprint == vmp_fingerprint(s), CX_ERR_INVALID_ARGUMENT, "cx_state_import: the blob belongs to a different graph");
+    VMP_REQUIRE(h, bytes >= vmp_own_bytes(s) + hd.inner_bytes && (hd.inner_bytes > 0) == (s->chain != nullptr), CX_ERR_INVALID_ARGUMENT, "cx_state_import: truncated or foreign blob");
+    VMP_HIP(h, hipSetDevice(h->cfg.device));
+    VMP_HIP(h, hipStreamSynchronize(h->stream));
+    const char *o = (const char *)buf + sizeof hd;
+    if (s->chain) {   // the inner handle validates its own part before anything is written
+        int32_t rc = cx_state_import(s->chain, o + s->nN * 17 + s->nG * 24, hd.inner_bytes);
+        VMP_REQUIRE(h, rc == CX_OK, rc, std::string("cx_state_import (inner handle): ") + cx_last_error(s->chain));
+    }
+    VMP_HIP(h, hipMemcpy(s->n_mean, o, (size_t)s->nN * 8, hipMemcpyHostToDevice)); o += s->nN * 8;
+    VMP_HIP(h, hipMemcpy(s->n_prec, o, (size_t)s->nN * 8, hipMemcpyHostToDevice)); o += s->nN * 8;
+    std::memcpy(s->n_observed.data(), o, (size_t)s->nN);
+    VMP_HIP(h, hipMemcpy(s->d_observed, o, (size_t)s->nN, hipMemcpyHostToDevice)); o += s->nN;
+    VMP_HIP(h, hipMemcpy(s->g_shape, o, (size_t)s->nG * 8, hipMemcpyHostToDevice)); o += s->nG * 8;
+    VMP_HIP(h, hipMemcpy(s->g_scale, o, (size_t)s->nG * 8, hipMemcpyHostToDevice)); o += s->nG * 8;
+    VMP_HIP(h, hipMemcpy(s->g_mean, o, (size_t)s->nG * 8, hipMemcpyHostToDevice)); o += s->nG * 8;
+    s->n_latent = hd.n_latent; s->chain_ready = hd.chain_ready != 0;
+    h->sweeps_done = hd.sweeps_done; h->n_messages_per_sweep = hd.n_messages;
+    return CX_OK;
+}
+
+}  // namespace cx

@@ -257,7 +257,8 @@ int32_t cx_halo_state_exchange(cx_handle *h);
  * as one relocatable host blob.  A blob restores only into a handle created with the same dim / family / schedule and
  * the same graph (a fingerprint of the flattened graph is checked); after cx_state_import the handle continues exactly
  * where the exporting one stood: the following sweeps reproduce its results bit for bit.  Halo buffers are not part
- * of the state (the next partitioned sweep exchanges them again). */
+ * of the state (the next partitioned sweep exchanges them again).  Variational handles export their marginals and observed
+ * flags (the structured family also the inner chain handle's state, inside the same blob). */
 int32_t cx_state_bytes(const cx_handle *h, int64_t *bytes);
 int32_t cx_state_export(cx_handle *h, void *buf, int64_t bytes);        /* synchronises the handle's stream */
 int32_t cx_state_import(cx_handle *h, const void *buf, int64_t bytes);  /* validates everything before writing */

@@ -190,3 +190,32 @@ def test_vmp_processor_behind_the_engine_api(hip_lib, family, rule, kind):
     for v, want in zip(x, ans["x"]):
         got = cx.get_value(marginal(v))
         assert got.mean == pytest.approx(want[1][0], rel=1e-8, abs=1e-12) and got.precision == pytest.approx(want[1][1], rel=1e-8)
+
+
+@pytest.mark.parametrize("family", [L.FAMILY_VMP_MEAN_FIELD, L.FAMILY_VMP_STRUCTURED])
+def test_vmp_checkpoint_continues_bit_for_bit(hip_lib, family):
+    """cx_state_export / cx_state_import on a variational handle (structured: the inner chain handle's state travels inside
+    the blob): a restored handle continues exactly where the exporter stood; a blob of another graph is refused."""
+    ma, mb = cx.synth.vmp_ssm(400, seed=1), cx.synth.vmp_ssm(400, seed=2)
+    a, b = _device(ma, family), _device(mb, family)
+
+    def iterate(dev, k):
+        for _ in range(k):
+            dev.update_marginals(L.VMP_ALL_NORMAL)
+            dev.update_marginals(L.VMP_ALL_PRECISION)
+
+    iterate(a, 3)
+    blob = a.export_state()
+    iterate(a, 4)
+    iterate(b, 2)                       # other data, other state
+    b.import_state(blob)                # ... replaced: observations, marginals, chain messages, counters
+    iterate(b, 4)
+    assert np.array_equal(_state(a, ma), _state(b, ma))
+    assert a.stats()["sweeps_done"] == b.stats()["sweeps_done"]
+    other = _device(cx.synth.vmp_ssm(401, seed=1), family)
+    with pytest.raises(cx.CortexHipError, match="different graph"):
+        other.import_state(blob)
+    plain = cx.DeviceGraph()
+    cx.synth.load_into_device(cx.synth.ssm_chain(5), plain)
+    with pytest.raises(cx.CortexHipError, match="not a state blob"):
+        plain.import_state(blob)
