@@ -246,8 +246,22 @@ def update_marginals(engine: InferenceEngine, variable_id_or_ids):
     ids = _as_ids(variable_id_or_ids)
     processor = engine.get_inference_request_processor()
     takeover = getattr(processor, "update_marginals", None)
-    if takeover is not None and takeover(engine, ids):
-        return None
+    if takeover is not None:
+        if engine.tracer is None:
+            if takeover(engine, ids):
+                return None
+        else:
+            # a whole-call takeover still leaves a trace: one request, one round, the requested marginals in request order
+            # with the values they held before and after (the reference's per-signal records, inference_engine.jl:650-700,
+            # have no counterpart when a launch computes every message at once)
+            marginals = [get_variable_marginal(engine.get_variable(v)) for v in ids]
+            before = [get_value(m) for m in marginals]
+            if takeover(engine, ids):
+                req = TracedInferenceRequest(ids)
+                rnd = TracedInferenceRound([TracedInferenceExecution(v, m, b, get_value(m)) for v, m, b in zip(ids, marginals, before)])
+                req.rounds.append(rnd)
+                engine.tracer.inference_requests.append(req)
+                return None
     request = request_inference_for(engine, ids)
     req_trace = None
     if engine.tracer is not None:

@@ -72,6 +72,15 @@ def test_sweep_mode_reaches_the_same_marginals(hip_lib):
     # messages are readable through the same accessors a reference user would use
     m = proc.read(V.MessageToVariable(x[3], engine.get_connected_factor_ids(x[3])[-1]))
     assert np.isfinite(m.mean) and m.variance > 0
+    # the engine was built with trace = true: a whole-call takeover leaves one request with one round holding the
+    # requested marginals in request order, undefined before and device-held after
+    tr = engine.get_trace().inference_requests
+    assert len(tr) == 1 and len(tr[0].rounds) == 1
+    ex = tr[0].rounds[0].executions
+    assert [e.variable_id for e in ex] == list(x)
+    assert all(isinstance(e.value_before_execution, cx.UndefValue) for e in ex)
+    assert all(isinstance(e.value_after_execution, cx.HipValue) for e in ex)
+    assert ex[7].value_after_execution.mean == pytest.approx(em[7], rel=1e-9)
 
 
 def test_linear_gaussian_factor_rule(hip_lib):
