@@ -94,6 +94,22 @@ def test_header_compiles_as_plain_c_and_the_c_client_links(hip_lib, tmp_path):
         assert out.returncode == 77 and "no CPU fallback" in out.stderr   # fails loudly without a GPU
 
 
+def test_cpp_host_classes_compile_against_the_abi(tmp_path):
+    """include/cortex_hip.hpp (cortex::Handle / HipProcessor / VmpProcessor, SURVEY.md §8b's "equivalent C++ host class")
+    builds with g++ -Wall -Wextra -Werror against the C ABI alone and fails loudly without a GPU."""
+    import subprocess
+
+    exe = str(tmp_path / "host_class_demo")
+    libdir = os.path.join(ROOT, "cortex.jl_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "host_class_demo.cpp"), "-o", exe, "-L" + libdir, "-lcortex_hip",
+                           "-Wl,-rpath," + libdir])
+    import torch
+    if not torch.cuda.is_available():
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 77 and "no CPU fallback" in out.stderr
+
+
 def test_oracle_under_address_and_ub_sanitizers(tmp_path):
     """CPU sanitizers on the checker (GPU ASan is not available on this pool): rebuild oracle/*.c with
     -fsanitize=address,undefined and run a representative slice of the known-answer tests against that build."""
