@@ -258,6 +258,56 @@ def by_assignment_deep(model: synth.Model, owner_of_variable, rank: int, world: 
                      peers=peers, depth=depth, owned_x=x_own)
 
 
+def metis_assignment(model: synth.Model, world: int):
+    """Variable → rank map from METIS_PartGraphKway, if a libmetis with 32-bit idx_t / 32-bit real_t can be loaded
+    (BASELINE's config names a METIS 8-way cut; neither libmetis nor pymetis is in this image, so this path is untested
+    here and every caller falls back to contiguous blocks when it returns None).  Graph = latent variables and the other
+    variables, adjacent through the pairwise factors; returns (sorted variable ids, owner per id) or None."""
+    import ctypes
+    import ctypes.util
+
+    name = ctypes.util.find_library("metis")
+    if not name:
+        return None
+    try:
+        lib = ctypes.CDLL(name)
+        fn = lib.METIS_PartGraphKway
+    except (OSError, AttributeError):
+        return None
+    import scipy.sparse as sp
+
+    ev, ef = np.asarray(model.edge_var, np.int64), np.asarray(model.edge_fac, np.int64)
+    vids = np.unique(ev)
+    vix = np.searchsorted(vids, ev)
+    order = np.lexsort((ev, ef))
+    fs, vx = ef[order], vix[order]
+    first = np.flatnonzero(np.r_[True, fs[1:] != fs[:-1]])
+    two = first[np.diff(np.r_[first, len(fs)]) == 2]
+    a, b = vx[two], vx[two + 1]
+    nv = len(vids)
+    A = sp.coo_matrix((np.ones(2 * len(a), np.int8), (np.r_[a, b], np.r_[b, a])), shape=(nv, nv)).tocsr()
+    xadj, adjncy = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    i32 = ctypes.c_int32
+    n, ncon, nparts, objval = i32(nv), i32(1), i32(world), i32(0)
+    part = np.zeros(nv, np.int32)
+    p32 = ctypes.POINTER(ctypes.c_int32)
+    rc = fn(ctypes.byref(n), ctypes.byref(ncon), xadj.ctypes.data_as(p32), adjncy.ctypes.data_as(p32), None, None, None,
+            ctypes.byref(nparts), None, None, None, ctypes.byref(objval), part.ctypes.data_as(p32))
+    if rc != 1 or part.min() < 0 or part.max() >= world:     # METIS_OK == 1
+        return None
+    return vids, part.astype(np.int64)
+
+
+def auto_partition(model: synth.Model, rank: int, world: int, depth: int = 0) -> Partition:
+    """METIS k-way cut when libmetis is present, contiguous blocks otherwise; deep halo when depth > 0."""
+    got = metis_assignment(model, world) if world > 1 else None
+    if got is None:
+        return contiguous_blocks(model, rank, world, depth=depth)
+    vids, part = got
+    owner = lambda ids: part[np.searchsorted(vids, np.asarray(ids, np.int64))]  # noqa: E731
+    return by_assignment_deep(model, owner, rank, world, depth) if depth else by_assignment(model, owner, rank, world)
+
+
 def contiguous_blocks(model: synth.Model, rank: int, world: int, depth: int = 0) -> Partition:
     """Equal contiguous id-blocks of the latent variables (time blocks of a chain, row blocks of a grid); every other
     variable (observations) goes with its first neighbour among the latent variables."""

@@ -190,3 +190,14 @@ def test_generic_deep_partition_of_a_chain_matches_single_process(depth):
         e = g.edge_index(sw.g.edge_var[own], sw.g.edge_fac[own])
         for name in ("f2v_m", "f2v_v", "v2f_m", "v2f_v"):
             assert np.array_equal(getattr(sw.g, name)[own], getattr(g, name)[e], equal_nan=True), name
+
+
+def test_auto_partition_falls_back_to_blocks_without_metis():
+    """libmetis is not in this image: metis_assignment reports that, auto_partition cuts contiguous blocks."""
+    whole = cx.synth.gaussian_grid(8, 5, seed=3)
+    if partition.metis_assignment(whole, 2) is None:
+        a, b = partition.auto_partition(whole, 1, 2, depth=2), partition.contiguous_blocks(whole, 1, 2, depth=2)
+        assert np.array_equal(a.send_var, b.send_var) and np.array_equal(a.recv_fac, b.recv_fac)
+    else:   # a box with METIS: the cut must still cover every latent variable exactly once
+        parts = [partition.auto_partition(whole, r, 2, depth=1) for r in range(2)]
+        assert np.array_equal(np.sort(np.concatenate([p.owned_x for p in parts])), np.sort(whole.x_ids))
