@@ -57,9 +57,30 @@ def parse():
     return ap.parse_args()
 
 
+def _usable_cores() -> int:
+    """cores this process may actually use: the affinity mask, capped by the cgroup CPU quota if there is one"""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def cpu_baseline(sample_n: int, seed: int) -> dict:
     """The reference's CPU path, restated (oracle/cortex_ref.c): one `update_marginals!` over all variables of a
     seeded sample grid, single thread (the reference has no threading).  Checker code, timed as a baseline only."""
+    cores = _usable_cores()
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))     # read by libgomp when the checker library is first loaded
     from oracle import ref
     import cortex.jl_amd as cx
     from tests.helpers import engine_oracle_from_model
@@ -85,7 +106,7 @@ def cpu_baseline(sample_n: int, seed: int) -> dict:
     # second figure: the same arithmetic as a flooding sweep over flat arrays on ALL host cores (OpenMP):
     # what a CPU gets once the reference's per-signal bookkeeping is taken away
     from tests.helpers import flood_oracle_from_model
-    cores = len(os.sched_getaffinity(0))
+    cores = int(os.environ.get("OMP_NUM_THREADS", cores))
     fg = flood_oracle_from_model(model, 1e6)
     fg.sweep(2, use_omp=True)
     t0, n_upd, sw = time.perf_counter(), 0, 0
