@@ -58,10 +58,10 @@ void dev_free_all(cx_handle *h) {
                     h->d_vinfo, h->d_q, h->d_a, h->d_b, h->d_sq, h->d_sa, h->d_sb, h->d_f2v, h->d_v2f, h->d_marg,
                     h->d_f2v_alt, h->d_prev, h->d_scratch, h->d_send_slots, h->d_recv_slots, h->d_send_vars,
                     h->ext_halo_buffers ? nullptr : (void *)h->d_send_buf, h->ext_halo_buffers ? nullptr : (void *)h->d_recv_buf,
-                    h->d_stage, h->d_spdir, h->d_ptab, h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prev, h->d_rule64_slots, h->d_rule64_vars, h->d_rule64_flags, h->d_point64_slots, h->d_chain_pos_var, h->d_chain_skip0, h->d_chain_skip1, h->d_chain_link_pos, h->d_chain_from,
+                    h->d_stage, h->d_spdir, h->d_ptab, h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prev, h->d_rule64_slots, h->d_rule64_vars, h->d_rule64_flags, h->d_point64_slots, h->d_rule64_rec, h->d_chain_pos_var, h->d_chain_skip0, h->d_chain_skip1, h->d_chain_link_pos, h->d_chain_from,
                     h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_side, h->d_chain_totals};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    h->d_rule64_slots = h->d_rule64_vars = h->d_rule64_flags = h->d_point64_slots = nullptr; h->work64_dirty = h->point64_dirty = true;
+    h->d_rule64_slots = h->d_rule64_vars = h->d_rule64_flags = h->d_point64_slots = h->d_rule64_rec = nullptr; h->work64_dirty = h->point64_dirty = true;
     h->d_spdir = nullptr; h->d_ptab = nullptr; h->d_mv_f2v = h->d_mv_f2v_alt = h->d_mv_v2f = h->d_mv_marg = h->d_mv_prev = nullptr; h->ptab_sets = 0;
     h->d_chain_pos_var = h->d_chain_skip0 = h->d_chain_skip1 = h->d_chain_link_pos = h->d_chain_from = h->d_chain_to = nullptr;
     h->d_chain_head_fwd = h->d_chain_head_bwd = nullptr; h->d_chain_side = nullptr; h->d_chain_totals = nullptr; h->chains_dirty = true;
@@ -720,7 +720,7 @@ int32_t mv_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, d
 // d = 64: which messages need the full MFMA rule, which come from observed variables (constant), which nobody reads
 int32_t build_work64(cx_handle *h) {
     if (!h->work64_dirty) return CX_OK;
-    std::vector<int32_t> rs, rv, rf, ps, slot_var(h->nslots, -1);
+    std::vector<int32_t> rs, rv, rf, ps, rec, slot_var(h->nslots, -1);
     for (int64_t e = 0; e < h->ne; e++) slot_var[cx::slot_of_edge(h, e)] = h->edge_var[e];
     for (int64_t e = 0; e < h->ne; e++) {
         const int32_t s = cx::slot_of_edge(h, e), p = h->partner[s], v = h->edge_var[e];
@@ -730,15 +730,25 @@ int32_t build_work64(cx_handle *h) {
         const int32_t deg = h->var_off[v + 1] - h->var_off[v];
         if (h->vinfo[v] & cx::kClamped) { ps.push_back(s); continue; }
         rs.push_back(s); rv.push_back(v); rf.push_back(deg < 2 ? 1 : 0);   // degree-1 leaf: its stored message is the input
+        // the record the rule kernel reads: sender slot, the other incoming slots in ascending neighbour order (the fold
+        // order), rule-table index, destination slot, flags
+        int32_t others[3] = {-1, -1, -1};
+        int n_others = 0;
+        for (int32_t j = 0; j < deg; j++) {
+            const int32_t sj = h->vbase[v] + j * cx::kBlock;
+            if (sj != s && n_others < 3) others[n_others++] = sj;
+        }
+        rec.insert(rec.end(), {s, others[0], others[1], others[2], h->spdir[s], p, deg < 2 ? 1 : 0, 0});
     }
-    for (void *p : {(void *)h->d_rule64_slots, (void *)h->d_rule64_vars, (void *)h->d_rule64_flags, (void *)h->d_point64_slots}) if (p) (void)hipFree(p);
-    h->d_rule64_slots = h->d_rule64_vars = h->d_rule64_flags = h->d_point64_slots = nullptr;
+    for (void *p : {(void *)h->d_rule64_slots, (void *)h->d_rule64_vars, (void *)h->d_rule64_flags, (void *)h->d_point64_slots, (void *)h->d_rule64_rec}) if (p) (void)hipFree(p);
+    h->d_rule64_slots = h->d_rule64_vars = h->d_rule64_flags = h->d_point64_slots = h->d_rule64_rec = nullptr;
     h->n_rule64 = (int64_t)rs.size(); h->n_point64 = (int64_t)ps.size();
     int32_t rc;
     if ((rc = dev_upload(h, &h->d_rule64_slots, rs)) != CX_OK) return rc;
     if ((rc = dev_upload(h, &h->d_rule64_vars, rv)) != CX_OK) return rc;
     if ((rc = dev_upload(h, &h->d_rule64_flags, rf)) != CX_OK) return rc;
     if ((rc = dev_upload(h, &h->d_point64_slots, ps)) != CX_OK) return rc;
+    if ((rc = dev_upload(h, &h->d_rule64_rec, rec)) != CX_OK) return rc;
     CX_HIP(h, hipStreamSynchronize(h->stream));
     h->work64_dirty = false;
     h->point64_dirty = true;
@@ -770,8 +780,7 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
     }
     for (int32_t s = 0; s < n_sweeps; s++) {
         if (h->cfg.dim == 64)
-            cx::mv64_launch_rule(h, (int)h->n_rule64, h->d_rule64_slots, h->d_rule64_vars, h->d_rule64_flags, h->d_mv_f2v, h->d_mv_f2v_alt,
-                                 CX_KERNEL_FUSED);
+            cx::mv64_launch_rule(h, (int)h->n_rule64, h->d_rule64_rec, h->d_mv_f2v, h->d_mv_f2v_alt, CX_KERNEL_FUSED);
         else {
             if (h->observed_passes_due > 0) { cx::mv_launch_sweep(h, false, true); h->observed_passes_due--; }
             cx::mv_launch_sweep(h, h->cfg.compute_marginals_in_sweep != 0, false);

@@ -84,6 +84,7 @@ struct cx_handle {
     bool work64_dirty = true, point64_dirty = true;
     int64_t n_rule64 = 0, n_point64 = 0;
     int32_t *d_rule64_slots = nullptr, *d_rule64_vars = nullptr, *d_rule64_flags = nullptr, *d_point64_slots = nullptr;
+    int32_t *d_rule64_rec = nullptr;               // 8 words per work item (see k_rule64)
 
     // chain-scan schedule (cx_chain.hip): paths of free variables, built lazily by build_chains()
     bool chains_dirty = true;
@@ -158,8 +159,7 @@ void mv_launch_seed(cx_handle *h, double *buf, double eta, double lam);
 void mv_launch_residual(cx_handle *h, const double *cur, const double *prev, int64_t n, double *d_out);
 bool spd_inverse(int d, const double *S, double *out);
 // d = 64 (cx_mv64.hip): message-major layout, MFMA rule kernel
-void mv64_launch_rule(cx_handle *h, int nwork, const int32_t *d_slots, const int32_t *d_vars, const int32_t *d_flags,
-                      const double *f2v_in, double *f2v_out, int kernel_id);
+void mv64_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const double *f2v_in, double *f2v_out, int kernel_id);
 void mv64_launch_marginals(cx_handle *h, int n, const int32_t *d_vars, const double *f2v, double *out);
 void mv64_launch_point(cx_handle *h, int nwork, const int32_t *d_slots, double *out_a, double *out_b);
 void mv64_launch_v2f(cx_handle *h, int n, const int32_t *d_slots, const int32_t *d_vars, const double *f2v);

@@ -150,11 +150,13 @@ static_assert((kD + 16) * kLd <= (kD + 1) * kLd + 4 * 16 * kLdw + kD, "fifth til
 
 // MODE 0: factor→variable message of work item (sender slot, sender variable) into out[partner]
 // MODE 1: marginal (mean | covariance) of variable work_vars[w] into out[w]  (P = 0, B = I, C = 0, sign flipped)
+// MODE 0 reads its work item from an 8-word record built on the host (cx_api.hip, build_work64):
+//   {sender slot, up to three source slots (-1: none), rule-table index, destination slot, flags, 0}
+// — one scalar round trip instead of the chain work list → vinfo / vbase / spdir / partner → loads.
 template <int MODE>
-__global__ __launch_bounds__(kBlock, 2) void k_rule64(int nwork, const int32_t *__restrict__ work_slots, const int32_t *__restrict__ work_vars,
-                                                      const int32_t *__restrict__ work_flags, const int32_t *__restrict__ vbase,
-                                                      const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
-                                                      const int32_t *__restrict__ spdir, const double *__restrict__ ptab,
+__global__ __launch_bounds__(kBlock, 2) void k_rule64(int nwork, const int32_t *__restrict__ work_rec, const int32_t *__restrict__ work_vars,
+                                                      const int32_t *__restrict__ vbase, const uint8_t *__restrict__ vinfo,
+                                                      const double *__restrict__ ptab,
                                                       const double *__restrict__ f2v_in, const double *__restrict__ v2f,
                                                       double *__restrict__ out) {
     __shared__ double lds[kLdsDoubles];
@@ -162,45 +164,74 @@ __global__ __launch_bounds__(kBlock, 2) void k_rule64(int nwork, const int32_t *
     const int w = blockIdx.x;
     if (w >= nwork) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int v = work_vars[w];
-    const int slot = MODE == 0 ? work_slots[w] : -1;
-    const int flags = MODE == 0 ? work_flags[w] : 0;
-    const int deg = vinfo[v] & kDegMask;
-    const int base = vbase[v];
-    const double *tab = MODE == 0 ? ptab + (int64_t)spdir[slot] * 3 * kD * kD : nullptr;
+    int slot = -1, flags = 0, dst_slot = 0, s0 = -1, s1 = -1, s2 = -1;
+    const double *tab = nullptr;
+    if (MODE == 0) {
+        const int32_t *rec = work_rec + 8 * (int64_t)w;
+        slot = rec[0]; s0 = rec[1]; s1 = rec[2]; s2 = rec[3];
+        tab = ptab + (int64_t)rec[4] * 3 * kD * kD;
+        dst_slot = rec[5]; flags = rec[6];
+    }
 
     // ---- phase 0: M = P + sum of the other incoming Lambdas; Yt = [B; eta'] ----------------------------------------------
-    // 16 elements per thread, every message read with 16 independent unit-stride loads in flight per lane
-    {
+    // In-kernel stamps put HALF of a workgroup's lifetime here when the groups of loads were issued one after the other
+    // (P, then each message, then B: four dependent round trips at two workgroups per CU).  Now every load of the phase —
+    // 16 doubles of P, of B and of each source message per thread — is in flight before the first use.
+    if (MODE == 0) {
+        double pa[16], pb[16], m0[16], m1[16], m2[16];
+        const double *src0 = (flags & kFlagFixed) ? v2f + (int64_t)slot * kMsg : (s0 >= 0 ? f2v_in + (int64_t)s0 * kMsg : nullptr);
+        const double *src1 = (!(flags & kFlagFixed) && s1 >= 0) ? f2v_in + (int64_t)s1 * kMsg : nullptr;
+        const double *src2 = (!(flags & kFlagFixed) && s2 >= 0) ? f2v_in + (int64_t)s2 * kMsg : nullptr;
+#pragma unroll
+        for (int i = 0; i < 16; i++) pa[i] = tab[tid + kBlock * i];
+#pragma unroll
+        for (int i = 0; i < 16; i++) m0[i] = src0 ? src0[kD + tid + kBlock * i] : 0.0;      // workgroup-uniform branches
+#pragma unroll
+        for (int i = 0; i < 16; i++) m1[i] = src1 ? src1[kD + tid + kBlock * i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) m2[i] = src2 ? src2[kD + tid + kBlock * i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) pb[i] = tab[kD * kD + tid + kBlock * i];
+        double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+        if (tid < kD) { e0 = src0 ? src0[tid] : 0.0; e1 = src1 ? src1[tid] : 0.0; e2 = src2 ? src2[tid] : 0.0; }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int e = tid + kBlock * i;
+            double a = pa[i];
+            if (src0) a += m0[i];
+            if (src1) a += m1[i];
+            if (src2) a += m2[i];
+            Ms[(e >> 6) * kLd + (e & 63)] = a;
+            Yt[(e >> 6) * kLd + (e & 63)] = pb[i];
+        }
+        if (tid < kD) {
+            double ea = 0.0;
+            if (src0) ea += e0;
+            if (src1) ea += e1;
+            if (src2) ea += e2;
+            Yt[kD * kLd + tid] = ea;
+        }
+    } else {
+        const int v = work_vars[w];
+        const int deg = vinfo[v] & kDegMask;
+        const int base = vbase[v];
         double acc[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) acc[i] = MODE == 0 ? tab[tid + kBlock * i] : 0.0;
+        for (int i = 0; i < 16; i++) acc[i] = 0.0;
         double ea = 0.0;
-        if (flags & kFlagFixed) {
-            const double *src = v2f + (int64_t)slot * kMsg;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (j >= deg) continue;
+            const double *src = f2v_in + (int64_t)(base + j * kBlock) * kMsg;
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[i] += src[kD + tid + kBlock * i];
-            if (tid < kD) ea = src[tid];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {       // all (<= 3) other messages in flight together
-                const int sj = base + j * kBlock;
-                if (j >= deg || sj == slot) continue;
-                const double *src = f2v_in + (int64_t)sj * kMsg;
-#pragma unroll
-                for (int i = 0; i < 16; i++) acc[i] += src[kD + tid + kBlock * i];
-                if (tid < kD) ea += src[tid];
-            }
+            if (tid < kD) ea += src[tid];
         }
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int e = tid + kBlock * i;
             Ms[(e >> 6) * kLd + (e & 63)] = acc[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int e = tid + kBlock * i;
-            Yt[(e >> 6) * kLd + (e & 63)] = MODE == 0 ? tab[kD * kD + e] : ((e >> 6) == (e & 63) ? 1.0 : 0.0);
+            Yt[(e >> 6) * kLd + (e & 63)] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
         }
         if (tid < kD) Yt[kD * kLd + tid] = ea;
     }
@@ -290,7 +321,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_rule64(int nwork, const int32_t *
     if (__builtin_isnan(Ms[0]) || __builtin_isnan(eo[0])) return;   // not positive definite: leave the old value
 
     // ---- store --------------------------------------------------------------------------------------------------------------
-    const int64_t dst = MODE == 0 ? (int64_t)partner[slot] * kMsg : (int64_t)w * kMsg;
+    const int64_t dst = MODE == 0 ? (int64_t)dst_slot * kMsg : (int64_t)w * kMsg;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const int e = tid + kBlock * i;
@@ -388,8 +419,7 @@ void mv64_set_point(cx_handle *h, double *dst, const int32_t *d_idx, const doubl
     if (n) hipLaunchKernelGGL(k_set_point64, dim3((unsigned)n), dim3(128), 0, h->stream, dst, d_idx, d_y, n);
 }
 
-void mv64_launch_rule(cx_handle *h, int nwork, const int32_t *d_slots, const int32_t *d_vars, const int32_t *d_flags,
-                      const double *f2v_in, double *f2v_out, int kernel_id) {
+void mv64_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const double *f2v_in, double *f2v_out, int kernel_id) {
     if (nwork == 0) return;
     h->prof_armed = false;
     if (h->profiling && (h->prof_count[kernel_id]++ % h->prof_stride) == 0) {
@@ -398,15 +428,15 @@ void mv64_launch_rule(cx_handle *h, int nwork, const int32_t *d_slots, const int
         (void)hipEventCreate(&r.start); (void)hipEventCreate(&r.stop); (void)hipEventRecord(r.start, h->stream);
         h->recs.push_back(r);
     }
-    hipLaunchKernelGGL((k_rule64<0>), dim3(nwork), dim3(kBlock), 0, h->stream, nwork, d_slots, d_vars, d_flags, h->d_vbase, h->d_vinfo,
-                       h->d_partner, h->d_spdir, h->d_ptab, f2v_in, h->d_mv_v2f, f2v_out);
+    hipLaunchKernelGGL((k_rule64<0>), dim3(nwork), dim3(kBlock), 0, h->stream, nwork, d_rec, (const int32_t *)nullptr, h->d_vbase, h->d_vinfo,
+                       h->d_ptab, f2v_in, h->d_mv_v2f, f2v_out);
     if (h->profiling && h->prof_armed) (void)hipEventRecord(h->recs.back().stop, h->stream);
 }
 
 void mv64_launch_marginals(cx_handle *h, int n, const int32_t *d_vars, const double *f2v, double *out) {
     if (n == 0) return;
-    hipLaunchKernelGGL((k_rule64<1>), dim3(n), dim3(kBlock), 0, h->stream, n, (const int32_t *)nullptr, d_vars, (const int32_t *)nullptr,
-                       h->d_vbase, h->d_vinfo, h->d_partner, h->d_spdir, h->d_ptab, f2v, h->d_mv_v2f, out);
+    hipLaunchKernelGGL((k_rule64<1>), dim3(n), dim3(kBlock), 0, h->stream, n, (const int32_t *)nullptr, d_vars,
+                       h->d_vbase, h->d_vinfo, h->d_ptab, f2v, h->d_mv_v2f, out);
 }
 
 void mv64_launch_point(cx_handle *h, int nwork, const int32_t *d_slots, double *out_a, double *out_b) {
