@@ -219,3 +219,57 @@ def test_vmp_checkpoint_continues_bit_for_bit(hip_lib, family):
     cx.synth.load_into_device(cx.synth.ssm_chain(5), plain)
     with pytest.raises(cx.CortexHipError, match="not a state blob"):
         plain.import_state(blob)
+
+
+def test_structured_vmp_on_a_tree_with_the_fused_schedule(hip_lib):
+    """Beyond chains: a random tree of latent states with one shared edge precision and one observation precision, the inner
+    handle on the fused flooding schedule (one sweep per update call; `depth` calls settle the tree).  Belief propagation is
+    exact on a tree, so the variational fixed point must equal the one computed with dense linear algebra."""
+    rng = np.random.default_rng(4)
+    n = 40
+    parent = [-1] + [int(rng.integers(0, i)) for i in range(1, n)]
+    edges = [(parent[i], i) for i in range(1, n)]
+    truth = np.cumsum(rng.standard_normal(n)) * 0.3
+    y = truth + rng.standard_normal(n) * 0.5
+    ss, obs = 1, 2
+    x = np.arange(3, 3 + n); yv = np.arange(3 + n, 3 + 2 * n)
+    lik = np.arange(3 + 2 * n, 3 + 3 * n); tr = np.arange(3 + 3 * n, 3 + 3 * n + len(edges))
+    ev, ef, role = [], [], []
+    for i in range(n):
+        ev += [yv[i], x[i], obs]; ef += [lik[i]] * 3; role += [L.ROLE_OUT, L.ROLE_IN, L.ROLE_PRECISION]
+    for k, (a, b) in enumerate(edges):
+        ev += [x[a], x[b], ss]; ef += [tr[k]] * 3; role += [L.ROLE_IN, L.ROLE_OUT, L.ROLE_PRECISION]
+    fids = np.concatenate([lik, tr])
+    dev = cx.DeviceGraph(family=L.FAMILY_VMP_STRUCTURED, schedule=L.SCHED_FUSED)
+    dev.graph_create(ev, ef, fids, np.full(len(fids), L.FACTOR_NORMAL_PRECISION, np.int32), np.zeros(len(fids)), edge_role=role)
+    dev.set_marginals([ss, obs], L.FORM_GAMMA, [1.0, 1.0, 1.0, 1.0])
+    dev.set_marginals(x, L.FORM_MEAN_PRECISION, np.tile([0.0, 1.0], n))
+    dev.set_marginals(yv, L.FORM_POINT, y)
+    # dense reference of the same coordinate ascent
+    ts, to = 1.0, 1.0
+    for _ in range(60):
+        J = np.eye(n) * to
+        for a, b in edges:
+            J[a, a] += ts; J[b, b] += ts; J[a, b] -= ts; J[b, a] -= ts
+        S = np.linalg.inv(J)
+        mu = S @ (to * y)
+        spread_s = sum(S[a, a] + S[b, b] - 2 * S[a, b] + (mu[a] - mu[b]) ** 2 for a, b in edges)
+        spread_o = float(np.sum(np.diag(S) + (y - mu) ** 2))
+        ts = (1 + 0.5 * len(edges)) / (0.5 * spread_s)
+        to = (1 + 0.5 * n) / (0.5 * spread_o)
+    for _ in range(60):
+        for _ in range(n):                 # the tree's depth is < n: more than enough flooding sweeps to settle it
+            dev.update_marginals(L.VMP_ALL_NORMAL)
+        dev.update_marginals(L.VMP_ALL_PRECISION)
+    g = dev.get_marginals([ss, obs])
+    assert g[0, 0] * g[0, 1] == pytest.approx(ts, rel=1e-6)
+    assert g[1, 0] * g[1, 1] == pytest.approx(to, rel=1e-6)
+    for _ in range(n):
+        dev.update_marginals(L.VMP_ALL_NORMAL)
+    q = dev.get_marginals(x)
+    J = np.eye(n) * to
+    for a, b in edges:
+        J[a, a] += ts; J[b, b] += ts; J[a, b] -= ts; J[b, a] -= ts
+    S = np.linalg.inv(J)
+    np.testing.assert_allclose(q[:, 0], S @ (to * y), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(1 / q[:, 1], np.diag(S), rtol=1e-5)
