@@ -18,6 +18,8 @@
 // messages with unit-stride 8 B/lane loads; LDS per workgroup 78 KiB -> 2 workgroups per CU, so one workgroup's serial
 // diagonal-block phase overlaps the other's MFMA phase.
 
+#include <cstdlib>
+
 #include "cx_internal.h"
 
 namespace cx {
@@ -332,6 +334,181 @@ __global__ __launch_bounds__(kBlock, 2) void k_rule64(int nwork, const int32_t *
     if (tid < kD) out[dst + tid] = eo[tid];
 }
 
+// ---- the MODE 0 rule with THREE workgroups per CU ------------------------------------------------------------------------
+// Stamps and PMC of k_rule64<0>: with 80 KB of LDS two workgroups fit on a CU and each spends 40 % of its
+// life waiting for its own source messages at the miss parallelism of one loader per CU.  This form needs 53 KB:
+//   * Yt lives where M / L lived.  After the factorisation wave i keeps the row panel L[16 i .. 16 i + 15][0 .. 16 i) as
+//     accumulator tiles in registers (<= 3 tiles = 12 doubles per lane) and publishes it through a 16-row LDS panel when
+//     solve step i needs it; only then is the region overwritten with [B; eta'].
+//   * the 16-row panel shares its LDS with the staging area of the diagonal blocks (used in disjoint phases).
+// A third workgroup per CU overlaps one workgroup's load phase with two others' compute.
+constexpr int kOffLp_s = (kD + 1) * kLd;                 // after the [M | Yt] region (65 x 66)
+constexpr int kOffWs_s = kOffLp_s + 16 * kLd;            // 16 x 66 panel / diag staging
+constexpr int kOffEo_s = kOffWs_s + 4 * 16 * kLdw;
+constexpr int kOffEt_s = kOffEo_s + kD;
+constexpr int kLdsDoubles_s = kOffEt_s + kD;
+static_assert(kLdsDoubles_s * 8 * 3 <= 160 * 1024, "three workgroups per CU");
+static_assert(16 * kLd >= 256, "diag_block staging fits in the panel");
+
+__global__ __launch_bounds__(kBlock, 3) void k_rule64s(int nwork, const int32_t *__restrict__ work_rec, const double *__restrict__ ptab,
+                                                       const double *__restrict__ f2v_in, const double *__restrict__ v2f,
+                                                       double *__restrict__ out) {
+    __shared__ double lds[kLdsDoubles_s];
+    double *Ms = lds, *Yt = lds, *Lp = lds + kOffLp_s, *Ws = lds + kOffWs_s, *eo = lds + kOffEo_s, *et = lds + kOffEt_s;
+    double *stage = Lp;
+    const int w = blockIdx.x;
+    if (w >= nwork) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t *rec = work_rec + 8 * (int64_t)w;
+    const int slot = rec[0], s0 = rec[1], s1 = rec[2], s2 = rec[3], dst_slot = rec[5], flags = rec[6];
+    const double *tab = ptab + (int64_t)rec[4] * 3 * kD * kD;
+
+    // ---- phase 0: M = P + sum of the other incoming Lambdas (ascending neighbour order); eta aside --------------------------
+    {
+        const double *src0 = (flags & kFlagFixed) ? v2f + (int64_t)slot * kMsg : (s0 >= 0 ? f2v_in + (int64_t)s0 * kMsg : nullptr);
+        const double *src1 = (!(flags & kFlagFixed) && s1 >= 0) ? f2v_in + (int64_t)s1 * kMsg : nullptr;
+        const double *src2 = (!(flags & kFlagFixed) && s2 >= 0) ? f2v_in + (int64_t)s2 * kMsg : nullptr;
+        double pa[16], m0[16], m1[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) pa[i] = tab[tid + kBlock * i];
+#pragma unroll
+        for (int i = 0; i < 16; i++) m0[i] = src0 ? src0[kD + tid + kBlock * i] : 0.0;      // workgroup-uniform branches
+#pragma unroll
+        for (int i = 0; i < 16; i++) m1[i] = src1 ? src1[kD + tid + kBlock * i] : 0.0;
+        double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+        if (tid < kD) { e0 = src0 ? src0[tid] : 0.0; e1 = src1 ? src1[tid] : 0.0; e2 = src2 ? src2[tid] : 0.0; }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int e = tid + kBlock * i;
+            double a = pa[i];
+            if (src0) a += m0[i];
+            if (src1) a += m1[i];
+            if (src2) a += src2[kD + e];           // a third source (degree 4) is rare: loaded in place
+            Ms[(e >> 6) * kLd + (e & 63)] = a;
+        }
+        if (tid < kD) {
+            double ea = 0.0;
+            if (src0) ea += e0;
+            if (src1) ea += e1;
+            if (src2) ea += e2;
+            et[tid] = ea;
+        }
+    }
+    __syncthreads();
+    if (__builtin_isnan(Ms[0])) return;   // a dependency is undefined (whole messages are NaN together): not pending
+
+    // ---- blocked Cholesky, NB = 16: Ms lower triangle <- L, Ws[kb] <- L_kk^-1 ---------------------------------------
+    double pb[16];                         // B, fetched during the last block step, stored once L has left the region
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) {
+        const int o = kb * 16;
+        if (kb == 3) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) pb[i] = tab[kD * kD + tid + kBlock * i];
+        }
+        diag_block(Ms, o, Ws + kb * 16 * kLdw, stage, tid);
+        __syncthreads();
+        const int tr = kb + 1 + wave;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        if (tr < 4) acc = mfma_xzt(Ms, kLd, tr * 16, o, Ws + kb * 16 * kLdw, kLdw, 0, 0, 4, acc, lane);
+        __syncthreads();                       // every lane has read its A21 tile before the tile is overwritten
+        if (tr < 4) tile_store(Ms, kLd, tr * 16, o, acc, lane);
+        __syncthreads();
+        int t = 0;
+        for (int ti = kb + 1; ti < 4; ti++)
+            for (int tj = kb + 1; tj <= ti; tj++, t++) {
+                if ((t & 3) != wave) continue;
+                d4 c = tile_load(Ms, kLd, ti * 16, tj * 16, lane);
+                d4 p = {0.0, 0.0, 0.0, 0.0};
+                p = mfma_xzt(Ms, kLd, ti * 16, o, Ms, kLd, tj * 16, o, 4, p, lane);
+#pragma unroll
+                for (int r = 0; r < 4; r++) c[r] -= p[r];
+                tile_store(Ms, kLd, ti * 16, tj * 16, c, lane);
+            }
+        __syncthreads();
+    }
+
+    // ---- L leaves the region: wave i keeps row panel i (tiles (i, 0 .. i-1)); then the region becomes [B; eta'] ---------------
+    d4 lt[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) lt[j] = (j < wave) ? tile_load(Ms, kLd, wave * 16, j * 16, lane) : d4{0.0, 0.0, 0.0, 0.0};
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int e = tid + kBlock * i;
+        Yt[(e >> 6) * kLd + (e & 63)] = pb[i];
+    }
+    if (tid < kD) Yt[kD * kLd + tid] = et[tid];
+    __syncthreads();
+
+    // ---- [Yt; z'] = [B; eta'] L^-T, block column by block column; wave w owns tile row w, wave 0 also the eta row ----------
+    const int nrows = wave == 0 ? 2 : 1;
+#pragma unroll
+    for (int ib = 0; ib < 4; ib++) {
+        if (ib > 0) {
+            if (wave == ib) {
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    if (j < ib) tile_store(Lp, kLd, 0, j * 16, lt[j], lane);      // L[16 ib .. +15][0 .. 16 ib)
+            }
+            __syncthreads();
+            for (int q = 0; q < nrows; q++) {
+                const int tr = q == 0 ? wave : 4;
+                d4 tq = tile_load(Yt, kLd, tr * 16, ib * 16, lane);
+                d4 p = {0.0, 0.0, 0.0, 0.0};
+                p = mfma_xzt(Yt, kLd, tr * 16, 0, Lp, kLd, 0, 0, 4 * ib, p, lane);   // sum_{k < 16 ib} Yt[c][k] L[r][k]
+#pragma unroll
+                for (int r = 0; r < 4; r++) tq[r] -= p[r];
+                tile_store_rows(Yt, kLd, tr * 16, ib * 16, tq, lane, tr == 4 ? 1 : 16);
+            }
+        }
+        __syncthreads();
+        d4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+        y0 = mfma_xzt(Yt, kLd, wave * 16, ib * 16, Ws + ib * 16 * kLdw, kLdw, 0, 0, 4, y0, lane);   // (rhs tile) * W_ii'
+        if (wave == 0) y1 = mfma_xzt(Yt, kLd, 4 * 16, ib * 16, Ws + ib * 16 * kLdw, kLdw, 0, 0, 4, y1, lane);
+        __syncthreads();
+        tile_store_rows(Yt, kLd, wave * 16, ib * 16, y0, lane, 16);
+        if (wave == 0) tile_store_rows(Yt, kLd, 4 * 16, ib * 16, y1, lane, 1);
+        __syncthreads();
+    }
+
+    // ---- G = Yt Yt'; eta_out = Yt z is the 65th column of the same product ---------------------------------------------------
+    double creg[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) creg[i] = tab[2 * kD * kD + tid + kBlock * i];
+    {
+        d4 g[5];
+#pragma unroll
+        for (int tj = 0; tj < 5; tj++) g[tj] = d4{0.0, 0.0, 0.0, 0.0};
+        const int r = lane & 15, kk = lane >> 4;
+#pragma unroll
+        for (int s4 = 0; s4 < 16; s4++) {
+            const double av = Yt[(wave * 16 + r) * kLd + 4 * s4 + kk];
+#pragma unroll
+            for (int tj = 0; tj < 5; tj++)
+                g[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Yt[(tj * 16 + r) * kLd + 4 * s4 + kk], g[tj], 0, 0, 0);
+        }
+        __syncthreads();                    // every wave has read Yt before G is written over it
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++) tile_store(Ms, kLd, wave * 16, tj * 16, g[tj], lane);
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) eo[wave * 16 + (lane >> 4) + 4 * rr] = g[4][rr];
+        }
+    }
+    __syncthreads();
+    if (__builtin_isnan(Ms[0]) || __builtin_isnan(eo[0])) return;   // not positive definite: leave the old value
+
+    const int64_t dst = (int64_t)dst_slot * kMsg;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int e = tid + kBlock * i;
+        const double g = Ms[(e >> 6) * kLd + (e & 63)];
+        out[dst + kD + e] = creg[i] - g;
+    }
+    if (tid < kD) out[dst + tid] = eo[tid];
+}
+
 // observed senders: Lambda_out = C, eta_out = B y  (one workgroup per message; pure streaming)
 __global__ __launch_bounds__(kBlock) void k_point64(int nwork, const int32_t *__restrict__ work_slots, const int32_t *__restrict__ partner,
                                                     const int32_t *__restrict__ spdir, const double *__restrict__ ptab,
@@ -428,8 +605,12 @@ void mv64_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const doubl
         (void)hipEventCreate(&r.start); (void)hipEventCreate(&r.stop); (void)hipEventRecord(r.start, h->stream);
         h->recs.push_back(r);
     }
-    hipLaunchKernelGGL((k_rule64<0>), dim3(nwork), dim3(kBlock), 0, h->stream, nwork, d_rec, (const int32_t *)nullptr, h->d_vbase, h->d_vinfo,
-                       h->d_ptab, f2v_in, h->d_mv_v2f, f2v_out);
+    static const bool classic = getenv("CX_RULE64_CLASSIC") != nullptr;   // A/B switch: the 80 KB form, two workgroups per CU
+    if (classic)
+        hipLaunchKernelGGL((k_rule64<0>), dim3(nwork), dim3(kBlock), 0, h->stream, nwork, d_rec, (const int32_t *)nullptr, h->d_vbase, h->d_vinfo,
+                           h->d_ptab, f2v_in, h->d_mv_v2f, f2v_out);
+    else
+        hipLaunchKernelGGL(k_rule64s, dim3(nwork), dim3(kBlock), 0, h->stream, nwork, d_rec, h->d_ptab, f2v_in, h->d_mv_v2f, f2v_out);
     if (h->profiling && h->prof_armed) (void)hipEventRecord(h->recs.back().stop, h->stream);
 }
 
