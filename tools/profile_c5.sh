@@ -26,10 +26,10 @@ for sub in ("mfma","mfma2"):
     cnt=collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(O+f"/{sub}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_rule64" in r["Kernel_Name"] and "Li0" not in r["Kernel_Name"] or "k_rule64<0>" in r["Kernel_Name"]:
+            if "k_rule64s" in r["Kernel_Name"]:
                 cnt[r["Counter_Name"]]["v"].append(float(r["Counter_Value"]))
     if cnt:
-        lines+=["",f"## PMC on k_rule64<0> ({sub} pass, per launch median)","","| counter | value |","|---|---|"]
+        lines+=["",f"## PMC on k_rule64s ({sub} pass, per launch median)","","| counter | value |","|---|---|"]
         for c,d in cnt.items():
             v=sorted(d["v"])[len(d["v"])//2]; out[c]=v; lines.append(f"| {c} | {v:.4g} |")
 if "SQ_VALU_MFMA_BUSY_CYCLES" in out and "GRBM_GUI_ACTIVE" in out:
