@@ -68,6 +68,8 @@ struct Vmp {
     int32_t *d_slot_out = nullptr, *d_slot_mean = nullptr;   // slot (inner handle) of the factor's OUT / IN edge
     int32_t *d_slot_gamma = nullptr;                         // per inner slot: Gamma variable of its factor, -1 for padding
     std::vector<void *> owned;
+    // staging for set / get marginals (grown on demand, freed with the rest)
+    int32_t *st_idx = nullptr; double *st_a = nullptr, *st_b = nullptr; int64_t st_cap = 0;
 };
 
 int32_t vfail(cx_handle *h, int32_t code, const std::string &msg) { h->err = msg; return code; }
@@ -95,6 +97,21 @@ int32_t alloc(cx_handle *h, Vmp *s, T **p, int64_t n) {
     VMP_HIP(h, hipMalloc((void **)p, (size_t)n * sizeof(T)));
     s->owned.push_back(*p);
     h->device_bytes += n * (int64_t)sizeof(T);
+    return CX_OK;
+}
+
+
+// device staging of n indices + 2n doubles, reused across calls
+int32_t stage(cx_handle *h, Vmp *s, int64_t n) {
+    if (n <= s->st_cap) return CX_OK;
+    VMP_HIP(h, hipStreamSynchronize(h->stream));
+    for (void *p : {(void *)s->st_idx, (void *)s->st_a, (void *)s->st_b}) if (p) (void)hipFree(p);
+    s->st_idx = nullptr; s->st_a = s->st_b = nullptr; s->st_cap = 0;
+    const int64_t cap = std::max<int64_t>(n, 4096);
+    VMP_HIP(h, hipMalloc((void **)&s->st_idx, (size_t)cap * 4));
+    VMP_HIP(h, hipMalloc((void **)&s->st_a, (size_t)cap * 16));
+    VMP_HIP(h, hipMalloc((void **)&s->st_b, (size_t)cap * 8));
+    s->st_cap = cap;
     return CX_OK;
 }
 
@@ -247,6 +264,7 @@ void vmp_free(cx_handle *h) {
     Vmp *s = (Vmp *)h->vmp;
     if (!s) return;
     for (void *p : s->owned) (void)hipFree(p);
+    for (void *p : {(void *)s->st_idx, (void *)s->st_a, (void *)s->st_b}) if (p) (void)hipFree(p);
     if (s->chain) (void)cx_destroy(s->chain);
     delete s;
     h->vmp = nullptr;
@@ -454,8 +472,8 @@ int32_t vmp_set_marginals(cx_handle *h, int64_t n, const int64_t *ids, int32_t f
             }
         }
         VMP_HIP(h, hipSetDevice(h->cfg.device));
-        int32_t *d_idx; double *d_a, *d_b;
-        VMP_HIP(h, hipMalloc((void **)&d_idx, (size_t)n * 4)); VMP_HIP(h, hipMalloc((void **)&d_a, (size_t)n * 8)); VMP_HIP(h, hipMalloc((void **)&d_b, (size_t)n * 8));
+        { int32_t rc = stage(h, s, n); if (rc != CX_OK) return rc; }
+        int32_t *d_idx = s->st_idx; double *d_a = s->st_a, *d_b = s->st_b;
         VMP_HIP(h, hipMemcpyAsync(d_idx, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
         VMP_HIP(h, hipMemcpyAsync(d_a, a.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
         VMP_HIP(h, hipMemcpyAsync(d_b, b.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
@@ -463,8 +481,7 @@ int32_t vmp_set_marginals(cx_handle *h, int64_t n, const int64_t *ids, int32_t f
         else hipLaunchKernelGGL(k_scatter2, dim3(blocks(n)), dim3(256), 0, h->stream, (int)n, d_idx, d_a, d_b, s->n_mean, s->n_prec, (double *)nullptr);
         if (form == CX_FORM_POINT)
             VMP_HIP(h, hipMemcpyAsync(s->d_observed, s->n_observed.data(), (size_t)s->nN, hipMemcpyHostToDevice, h->stream));
-        VMP_HIP(h, hipStreamSynchronize(h->stream));
-        (void)hipFree(d_idx); (void)hipFree(d_a); (void)hipFree(d_b);
+        VMP_HIP(h, hipStreamSynchronize(h->stream));     // the host vectors above go out of scope
         if (s->structured && !obs_ids.empty()) {
             // an observed variable is data for the inner handle: its messages into every factor are the datum
             std::vector<int64_t> ev, ef;
@@ -498,15 +515,14 @@ int32_t vmp_get_marginals(cx_handle *h, int64_t n, const int64_t *ids, double *o
             const std::vector<int64_t> &where = pass == 0 ? pn : pg;
             const int64_t m = (int64_t)idx.size();
             if (m == 0) continue;
-            int32_t *d_idx; double *d_out;
-            VMP_HIP(h, hipMalloc((void **)&d_idx, (size_t)m * 4)); VMP_HIP(h, hipMalloc((void **)&d_out, (size_t)m * 16));
+            { int32_t rc = stage(h, s, m); if (rc != CX_OK) return rc; }
+            int32_t *d_idx = s->st_idx; double *d_out = s->st_a;      // st_a holds 2 doubles per entry
             VMP_HIP(h, hipMemcpyAsync(d_idx, idx.data(), (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
             if (pass == 0) hipLaunchKernelGGL(k_gather2, dim3(blocks(m)), dim3(256), 0, h->stream, (int)m, d_idx, s->n_mean, s->n_prec, d_out);
             else hipLaunchKernelGGL(k_gather2, dim3(blocks(m)), dim3(256), 0, h->stream, (int)m, d_idx, s->g_shape, s->g_scale, d_out);
             std::vector<double> tmp(2 * m);
             VMP_HIP(h, hipMemcpyAsync(tmp.data(), d_out, (size_t)m * 16, hipMemcpyDeviceToHost, h->stream));
             VMP_HIP(h, hipStreamSynchronize(h->stream));
-            (void)hipFree(d_idx); (void)hipFree(d_out);
             for (int64_t k = 0; k < m; k++) { out[2 * where[k]] = tmp[2 * k]; out[2 * where[k] + 1] = tmp[2 * k + 1]; }
         }
         return CX_OK;
