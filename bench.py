@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--halo-depth", type=int, default=int(os.environ.get("CX_HALO_DEPTH", "8")),
                     help="deep halo: each rank keeps this many redundant rows of its neighbours and exchanges their state once "
                          "per that many sweeps (bit-identical to the un-partitioned sweep); 0 = one message halo per sweep")
+    ap.add_argument("--cpu-configs", action="store_true", help="CPU baselines of configs C1, C2 and the C4 sample only (no GPU needed)")
     ap.add_argument("--self-halo", action="store_true",
                     help="N = 1 experiment: a cylinder whose wrap-around cut makes rank 0 its own halo neighbour")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -114,9 +115,40 @@ def cpu_baseline(sample_n: int, seed: int) -> dict:
         n_upd += fg.sweep(4, use_omp=True)
         sw += 4
     dt = time.perf_counter() - t0
+    import shutil
+    out["reference_julia"] = shutil.which("julia") or "not on this box (BASELINE.md §3.1: the real reference is timed only where Julia is installed)"
     out["flooding_all_cores"] = {"value": n_upd / dt, "unit": "edge-message updates/s", "cores": cores, "kind": "port",
                                  "sample": f"{sw} flooding sweeps of the same grid, flat arrays + OpenMP over {cores} cores, {dt:.1f} s"}
     return out
+
+
+def cpu_config_table(seed: int):
+    """the restated reference scheduler (one core) on configs C1 and C2 and on the C4 sample, one JSON line
+    per config.  CPU only; `python bench.py --cpu-configs`."""
+    from tests.helpers import engine_oracle_from_model
+    import cortex.jl_amd as cx
+
+    rows = []
+    for name, T in (("C1", 1_000), ("C2", 250_001)):
+        model = cx.synth.ssm_chain(T, seed=seed)
+        E = engine_oracle_from_model(model)
+        E.set_messages_to_factor(model.data_var, model.data_fac, model.data_y)
+        c0 = E.counters()[0]
+        t0 = time.perf_counter()
+        E.update_marginals(model.x_ids)
+        dt = time.perf_counter() - t0
+        upd = E.counters()[0] - c0
+        rows.append({"config": name, "schedule": "reference update_marginals! (restated, sequential)", "device": "cpu", "cores": 1,
+                     "updates_per_sweep": upd, "ms_per_sweep": dt * 1e3, "updates_per_s": upd / dt,
+                     "algorithmic_GBps": upd * BYTES_PER_UPDATE / dt / 1e9})
+    c4 = cpu_baseline(768, seed)
+    rows.append({"config": "C4 sample (768x768)", "schedule": "reference update_marginals! (restated, sequential)", "device": "cpu",
+                 "cores": 1, "updates_per_s": c4["value"], "sample": c4["sample"]})
+    fa = c4["flooding_all_cores"]
+    rows.append({"config": "C4 sample (768x768)", "schedule": "flooding, flat arrays + OpenMP", "device": "cpu", "cores": fa["cores"],
+                 "updates_per_s": fa["value"], "sample": fa["sample"]})
+    for r in rows:
+        print(json.dumps(r), flush=True)
 
 
 def _watchdog(seconds: float):
@@ -137,6 +169,9 @@ def _watchdog(seconds: float):
 
 def main():
     args = parse()
+    if args.cpu_configs:
+        cpu_config_table(args.seed)
+        return
     import torch
     import cortex.jl_amd as cx
     from cortex.jl_amd import _lib as L
