@@ -25,8 +25,10 @@
 namespace cx {
 
 constexpr int kD = 64;
-constexpr int kLd = 66;                 // leading dimension of the 64x64 LDS matrices (doubles)
-constexpr int kLdw = 18;                // leading dimension of the 16x16 inverse blocks
+constexpr int kLd = 65;                 // leading dimension of the 64x64 LDS matrices (doubles): odd, so that the 16 rows an MFMA
+                                        // operand read touches per quarter-wave fall into 16 different bank pairs (with 66 rows r and
+                                        // r + 8 collided: PMC counted 30 % of the LDS cycles as bank conflicts)
+constexpr int kLdw = 17;                // leading dimension of the 16x16 inverse blocks (odd, as above)
 constexpr int kMsg = kD + kD * kD;      // doubles per message slot
 
 using d4 = __attribute__((ext_vector_type(4))) double;
