@@ -412,9 +412,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_rule64s(int nwork, const int32_t 
         __syncthreads();
         const int tr = kb + 1 + wave;
         d4 acc = {0.0, 0.0, 0.0, 0.0};
-        if (tr < 4) acc = mfma_xzt(Ms, kLd, tr * 16, o, Ws + kb * 16 * kLdw, kLdw, 0, 0, 4, acc, lane);
-        __syncthreads();                       // every lane has read its A21 tile before the tile is overwritten
-        if (tr < 4) tile_store(Ms, kLd, tr * 16, o, acc, lane);
+        // each wave rewrites the tile it alone read (LDS operations of one wave execute in order): no barrier in between
+        if (tr < 4) { acc = mfma_xzt(Ms, kLd, tr * 16, o, Ws + kb * 16 * kLdw, kLdw, 0, 0, 4, acc, lane); tile_store(Ms, kLd, tr * 16, o, acc, lane); }
         __syncthreads();
         int t = 0;
         for (int ti = kb + 1; ti < 4; ti++)
@@ -444,6 +443,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_rule64s(int nwork, const int32_t 
     __syncthreads();
 
     // ---- [Yt; z'] = [B; eta'] L^-T, block column by block column; wave w owns tile row w, wave 0 also the eta row ----------
+    // The rows of Yt are independent: a wave reads and writes only its own tile row(s); the only data shared between waves
+    // is the L panel, so a step needs two barriers (panel published / panel no longer read), the first step none.
     const int nrows = wave == 0 ? 2 : 1;
 #pragma unroll
     for (int ib = 0; ib < 4; ib++) {
@@ -463,16 +464,15 @@ __global__ __launch_bounds__(kBlock, 3) void k_rule64s(int nwork, const int32_t 
                 for (int r = 0; r < 4; r++) tq[r] -= p[r];
                 tile_store_rows(Yt, kLd, tr * 16, ib * 16, tq, lane, tr == 4 ? 1 : 16);
             }
+            if (ib < 3) __syncthreads();          // the panel may be overwritten by the next step's owner
         }
-        __syncthreads();
         d4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
         y0 = mfma_xzt(Yt, kLd, wave * 16, ib * 16, Ws + ib * 16 * kLdw, kLdw, 0, 0, 4, y0, lane);   // (rhs tile) * W_ii'
         if (wave == 0) y1 = mfma_xzt(Yt, kLd, 4 * 16, ib * 16, Ws + ib * 16 * kLdw, kLdw, 0, 0, 4, y1, lane);
-        __syncthreads();
         tile_store_rows(Yt, kLd, wave * 16, ib * 16, y0, lane, 16);
         if (wave == 0) tile_store_rows(Yt, kLd, 4 * 16, ib * 16, y1, lane, 1);
-        __syncthreads();
     }
+    __syncthreads();                              // G reads every row of Yt
 
     // ---- G = Yt Yt'; eta_out = Yt z is the 65th column of the same product ---------------------------------------------------
     double creg[16];
