@@ -201,3 +201,63 @@ def test_auto_partition_falls_back_to_blocks_without_metis():
     else:   # a box with METIS: the cut must still cover every latent variable exactly once
         parts = [partition.auto_partition(whole, r, 2, depth=1) for r in range(2)]
         assert np.array_equal(np.sort(np.concatenate([p.owned_x for p in parts])), np.sort(whole.x_ids))
+
+
+@pytest.mark.parametrize("seed,world,depth", [(0, 2, 1), (1, 3, 2), (2, 4, 3), (3, 3, 1)])
+def test_generic_deep_partition_of_random_sparse_graphs(seed, world, depth):
+    """Random loopy models (unary priors + random pairwise factors), random variable→rank maps, deep halo of depth 1–3:
+    in-process exchange with the CPU checker as the sweeper, every owned message and marginal bit-identical to the
+    single-process flooding sweeps."""
+    from tests._dist_worker import OracleStateSweeper
+
+    rng = np.random.default_rng(seed)
+    nv = 60
+    pairs = set()
+    for v in range(1, nv):                       # a spanning tree keeps the graph connected, extra edges make it loopy
+        pairs.add((int(rng.integers(0, v)), v))
+    while len(pairs) < nv + 25:
+        a, b = sorted(int(t) for t in rng.integers(0, nv, 2))
+        if a != b:
+            pairs.add((a, b))
+    pairs = sorted(pairs)
+    x = np.arange(1, nv + 1, dtype=np.int64)
+    unary = nv + x
+    pf = 2 * nv + 1 + np.arange(len(pairs), dtype=np.int64)
+    pa = np.array([p[0] for p in pairs]) + 1; pb = np.array([p[1] for p in pairs]) + 1
+    whole = cx.synth.Model(edge_var=np.concatenate([x, pa, pb]), edge_fac=np.concatenate([unary, pf, pf]),
+                           factor_ids=np.concatenate([unary, pf]),
+                           factor_kind=np.concatenate([np.zeros(nv, np.int32), np.ones(len(pairs), np.int32)]),
+                           factor_var=np.concatenate([np.ones(nv), rng.uniform(0.5, 2.0, len(pairs))]), x_ids=x,
+                           prior_var=x, prior_fac=unary, prior_mean=rng.standard_normal(nv) * 2, prior_variance=rng.uniform(0.5, 2.0, nv))
+    owner_map = rng.integers(0, world, nv)
+    owner = lambda ids: owner_map[np.asarray(ids, np.int64) - 1]  # noqa: E731
+    parts = [partition.by_assignment_deep(whole, owner, r, world, depth) for r in range(world)]
+    assert np.array_equal(np.sort(np.concatenate([p.owned_x for p in parts])), x)
+    sws = [OracleStateSweeper(p, 1e6) for p in parts]
+    sweeps = 3 * depth + 2
+    for k in range(sweeps):
+        if k % depth == 0:
+            for sw in sws:
+                sw.pack()
+            for r, p in enumerate(parts):
+                for peer in p.peers:
+                    back = [pp for pp in parts[peer.rank].peers if pp.rank == r][0]
+                    assert back.recv.stop - back.recv.start == peer.send.stop - peer.send.start
+                    sws[peer.rank].recv[back.recv] = sws[r].send[peer.send]
+            for sw in sws:
+                sw.unpack()
+        for sw in sws:
+            sw.sweep()
+    g = flood_oracle_from_model(whole, 1e6)
+    g.sweep(sweeps)
+    gm, gv = g.marginals()
+    for p, sw in zip(parts, sws):
+        if len(p.owned_x) == 0:
+            continue
+        m, v = sw.g.marginals()
+        li = np.searchsorted(sw.g.var_ids, p.owned_x); wi = np.searchsorted(g.var_ids, p.owned_x)
+        assert np.array_equal(m[li], gm[wi], equal_nan=True) and np.array_equal(v[li], gv[wi], equal_nan=True)
+        own = np.isin(sw.g.edge_var, p.owned_x)
+        e = g.edge_index(sw.g.edge_var[own], sw.g.edge_fac[own])
+        for name in ("f2v_m", "f2v_v"):
+            assert np.array_equal(getattr(sw.g, name)[own], getattr(g, name)[e], equal_nan=True), name
