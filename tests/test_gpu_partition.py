@@ -317,3 +317,48 @@ def test_config_c4_full_size_deep_halo(hip_lib):
         assert np.array_equal(devs[rank].get_marginals(ids), whole.get_marginals(ids), equal_nan=True), f"rank {rank}"
         total += len(ids)
     assert total == N * N
+
+
+@pytest.mark.parametrize("seed,world,depth", [(0, 2, 1), (1, 3, 2), (2, 4, 3)])
+def test_generic_deep_partition_of_random_sparse_graphs_on_device(hip_lib, seed, world, depth):
+    """Random loopy models, random variable→rank maps (partition.by_assignment_deep), handles on one GPU with an in-process
+    transport: owned messages and marginals bit-identical to the un-partitioned device sweeps."""
+    import torch
+    from tests.helpers import random_loopy_model
+
+    whole_model, owner = random_loopy_model(seed, world)
+    sweeps = 3 * depth + 2
+    whole = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(whole_model, whole, seed_variance=1e6)
+    whole.sweep(sweeps)
+    ld = LoopbackDist(world, torch)
+    devs, parts, errors = [None] * world, [None] * world, []
+
+    def run(rank):
+        try:
+            ld.bind(rank)
+            part = partition.by_assignment_deep(whole_model, owner, rank, world, depth)
+            dev = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+            cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
+            ex = partition.DeepHaloExchange(partition.DeviceStateSweeper(dev, part, torch, torch.device("cuda", 0)), part, ld)
+            ex.sweep(sweeps)
+            dev.sync()
+            devs[rank], parts[rank] = dev, part
+        except Exception as e:  # pragma: no cover
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    for rank in range(world):
+        part = parts[rank]
+        if len(part.owned_x) == 0:
+            continue
+        own = np.isin(part.model.edge_var, part.owned_x)
+        ev, ef = part.model.edge_var[own], part.model.edge_fac[own]
+        assert np.array_equal(devs[rank].get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL),
+                              whole.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL), equal_nan=True)
+        assert np.array_equal(devs[rank].get_marginals(part.owned_x), whole.get_marginals(part.owned_x), equal_nan=True)

@@ -210,27 +210,10 @@ def test_generic_deep_partition_of_random_sparse_graphs(seed, world, depth):
     single-process flooding sweeps."""
     from tests._dist_worker import OracleStateSweeper
 
-    rng = np.random.default_rng(seed)
-    nv = 60
-    pairs = set()
-    for v in range(1, nv):                       # a spanning tree keeps the graph connected, extra edges make it loopy
-        pairs.add((int(rng.integers(0, v)), v))
-    while len(pairs) < nv + 25:
-        a, b = sorted(int(t) for t in rng.integers(0, nv, 2))
-        if a != b:
-            pairs.add((a, b))
-    pairs = sorted(pairs)
-    x = np.arange(1, nv + 1, dtype=np.int64)
-    unary = nv + x
-    pf = 2 * nv + 1 + np.arange(len(pairs), dtype=np.int64)
-    pa = np.array([p[0] for p in pairs]) + 1; pb = np.array([p[1] for p in pairs]) + 1
-    whole = cx.synth.Model(edge_var=np.concatenate([x, pa, pb]), edge_fac=np.concatenate([unary, pf, pf]),
-                           factor_ids=np.concatenate([unary, pf]),
-                           factor_kind=np.concatenate([np.zeros(nv, np.int32), np.ones(len(pairs), np.int32)]),
-                           factor_var=np.concatenate([np.ones(nv), rng.uniform(0.5, 2.0, len(pairs))]), x_ids=x,
-                           prior_var=x, prior_fac=unary, prior_mean=rng.standard_normal(nv) * 2, prior_variance=rng.uniform(0.5, 2.0, nv))
-    owner_map = rng.integers(0, world, nv)
-    owner = lambda ids: owner_map[np.asarray(ids, np.int64) - 1]  # noqa: E731
+    from tests.helpers import random_loopy_model
+
+    whole, owner = random_loopy_model(seed, world)
+    x = whole.x_ids
     parts = [partition.by_assignment_deep(whole, owner, r, world, depth) for r in range(world)]
     assert np.array_equal(np.sort(np.concatenate([p.owned_x for p in parts])), x)
     sws = [OracleStateSweeper(p, 1e6) for p in parts]
