@@ -1,0 +1,128 @@
+"""The committed golden vectors (tests/golden/*.json, generator: tests/golden/make_golden.py).
+
+CPU half: the checker code still reproduces them (they pin the oracle against drift) and the two independent routes they
+hold agree with each other — the restated engine against the Thomas solve, converged loopy BP against the dense solve.
+GPU half: the HIP path through the C ABI against the same files."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cortex.jl_amd as cx
+from cortex.jl_amd import _lib as L
+from oracle import exact, vmp
+from tests.helpers import engine_oracle_from_model, flood_oracle_from_model
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    with open(os.path.join(G, name)) as f:
+        return {k: (np.asarray(v) if isinstance(v, list) else v) for k, v in json.load(f).items()}
+
+
+# ---------------------------------------------------------------------------------------------------------------- CPU
+def test_chain_vector_engine_and_exact_solver_agree():
+    d = load("chain16.json")
+    m = cx.synth.ssm_chain(16, seed=1234)
+    assert np.array_equal(m.data_y, d["data_y"])                         # the seeded generator has not drifted
+    np.testing.assert_allclose(d["engine_mean"], d["exact_mean"], rtol=1e-12)
+    np.testing.assert_allclose(d["engine_variance"], d["exact_variance"], rtol=1e-12)
+    E = engine_oracle_from_model(m)
+    E.set_messages_to_factor(m.data_var, m.data_fac, m.data_y)
+    E.update_marginals(m.x_ids)
+    _t, em, ev = E.get_marginals(m.x_ids)
+    assert np.array_equal(em, d["engine_mean"]) and np.array_equal(ev, d["engine_variance"])
+    # the reference test's own assertions on its chain (test/inference_engine_tests.jl:485-487)
+    assert np.all(np.diff(d["engine_mean"]) >= 0) and np.all(d["engine_variance"] >= 0)
+
+
+def test_grid_vector_flooding_checker_and_dense_solve_agree():
+    d = load("grid8x8.json")
+    m = cx.synth.gaussian_grid(8, 8, seed=1234)
+    g = flood_oracle_from_model(m, 1e6)
+    assert np.array_equal(g.edge_var, d["edge_var"]) and np.array_equal(g.edge_fac, d["edge_fac"])
+    g.sweep(5)
+    assert np.array_equal(g.f2v_m, d["f2v_mean_after_5"], equal_nan=True) and np.array_equal(g.f2v_v, d["f2v_variance_after_5"], equal_nan=True)
+    np.testing.assert_allclose(d["bp_mean_converged"], d["exact_mean"], rtol=1e-10)   # loopy Gaussian BP means are exact
+
+
+def test_block_chain_and_variational_vectors_reproduce():
+    d = load("lgssm_d4.json")
+    em, ecov = exact.lgssm_posterior(d["data_y"], d["A"], d["Q"], d["R"])
+    np.testing.assert_allclose(em, d["posterior_mean"], rtol=1e-13)
+    np.testing.assert_allclose(ecov, d["posterior_covariance"], rtol=1e-13)
+    v = load("vmp_n8.json")
+    for name, cls in (("mean_field", vmp.MeanFieldVMP), ("structured", vmp.StructuredVMP)):
+        a = cls(v["data_y"])
+        for _ in range(5):
+            a.update(["x"]); a.update(["ssnoise", "obsnoise"])
+        np.testing.assert_allclose(a.xm, v[name]["x_mean"], rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(list(a.ss) + list(a.obs), v[name]["ssnoise_shape_scale"] + v[name]["obsnoise_shape_scale"], rtol=1e-13)
+
+
+def test_reference_known_answer_constants():
+    k = load("kats.json")
+    t = k["tracing"]
+    assert [2 * x for x in t["data"]] == t["message_values"] and sum(t["message_values"]) + t["prior"] == t["marginal"]
+    assert k["beta_bernoulli"]["prior"] == [1.0, 1.0]
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_device_chain_against_the_golden_vector(hip_lib):
+    d = load("chain16.json")
+    for schedule, sweeps in ((L.SCHED_CHAIN_SCAN, 1), (L.SCHED_FUSED, 18), (L.SCHED_FLOODING, 18)):
+        dev = cx.DeviceGraph(schedule=schedule)
+        cx.synth.load_into_device(cx.synth.ssm_chain(16, seed=1234), dev)
+        dev.sweep(sweeps)
+        if schedule != L.SCHED_CHAIN_SCAN:
+            dev.update_batch([L.ITEM_INDIVIDUAL_MARGINAL] * 16, d["x_ids"], [0] * 16)
+        m = dev.get_marginals(d["x_ids"])
+        np.testing.assert_allclose(m[:, 0], d["engine_mean"], rtol=1e-10)
+        np.testing.assert_allclose(m[:, 1], d["engine_variance"], rtol=1e-10)
+
+
+@pytest.mark.gpu
+def test_device_grid_against_the_golden_vector(hip_lib):
+    d = load("grid8x8.json")
+    model = cx.synth.gaussian_grid(8, 8, seed=1234)
+    for schedule in (L.SCHED_FUSED, L.SCHED_FLOODING):
+        dev = cx.DeviceGraph(schedule=schedule)
+        cx.synth.load_into_device(model, dev, seed_variance=1e6)
+        dev.sweep(5)
+        got = dev.get_messages(d["edge_var"], d["edge_fac"], L.TO_VARIABLE)
+        keep = ~np.isnan(d["f2v_variance_after_5"])
+        np.testing.assert_allclose(got[keep, 0], d["f2v_mean_after_5"][keep], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(got[keep, 1], d["f2v_variance_after_5"][keep], rtol=1e-9)
+        dev.sweep(400)
+        dev.update_batch([L.ITEM_INDIVIDUAL_MARGINAL] * 64, d["x_ids"], [0] * 64)
+        m = dev.get_marginals(d["x_ids"])
+        np.testing.assert_allclose(m[:, 0], d["exact_mean"], rtol=1e-9)
+        np.testing.assert_allclose(m[:, 1], d["bp_variance_converged"], rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_device_block_chain_and_vmp_against_the_golden_vectors(hip_lib):
+    d = load("lgssm_d4.json")
+    model = cx.synth.lgssm_chain(8, d=4, seed=1234)
+    assert np.array_equal(model.data_y, d["data_y"])
+    dev = cx.DeviceGraph(dim=4, schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(model, dev)
+    dev.sweep(10)
+    marg = dev.get_marginals(d["x_ids"])
+    np.testing.assert_allclose(marg[:, :4], d["posterior_mean"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(marg[:, 4:].reshape(8, 4, 4), d["posterior_covariance"], rtol=1e-9, atol=1e-12)
+    v = load("vmp_n8.json")
+    vm = cx.synth.vmp_ssm(8, seed=1234)
+    for name, fam in (("mean_field", L.FAMILY_VMP_MEAN_FIELD), ("structured", L.FAMILY_VMP_STRUCTURED)):
+        h = cx.DeviceGraph(family=fam, schedule=L.SCHED_CHAIN_SCAN)
+        cx.synth.load_vmp_into_device(vm, h)
+        for _ in range(5):
+            h.update_marginals(vm.x_ids); h.update_marginals([vm.ssnoise, vm.obsnoise])
+        q = h.get_marginals(vm.x_ids)
+        g = h.get_marginals([vm.ssnoise, vm.obsnoise])
+        np.testing.assert_allclose(q[:, 0], v[name]["x_mean"], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(q[:, 1], v[name]["x_precision"], rtol=1e-9)
+        np.testing.assert_allclose(g.ravel(), v[name]["ssnoise_shape_scale"] + v[name]["obsnoise_shape_scale"], rtol=1e-9)
