@@ -1115,6 +1115,29 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
     return CX_OK;
 }
 
+// Loopy graphs: sweep until the largest change of a factor→variable message over `check_every` sweeps falls below tol
+// (the stopping rule a user of the reference writes around update_marginals!; the reference itself has none).
+int32_t cx_sweep_until(cx_handle *h, double tol, int32_t max_sweeps, int32_t check_every, int32_t *sweeps_run, double *residual) {
+    CX_NOT_VMP(h, "cx_sweep_until");
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep_until: no graph");
+    CX_REQUIRE(h, tol >= 0 && max_sweeps >= 0 && check_every >= 1, CX_ERR_INVALID_ARGUMENT, "cx_sweep_until: tol >= 0, max_sweeps >= 0, check_every >= 1");
+    double r = std::numeric_limits<double>::infinity();
+    int32_t rc = cx_residual(h, &r);            // snapshot of the starting point
+    if (rc != CX_OK) return rc;
+    int32_t done = 0;
+    r = std::numeric_limits<double>::infinity();
+    while (done < max_sweeps) {
+        const int32_t k = std::min(check_every, max_sweeps - done);
+        if ((rc = cx_sweep(h, k)) != CX_OK) return rc;
+        done += k;
+        if ((rc = cx_residual(h, &r)) != CX_OK) return rc;
+        if (r <= tol) break;
+    }
+    if (sweeps_run) *sweeps_run = done;
+    if (residual) *residual = r;
+    return CX_OK;
+}
+
 int32_t cx_sweep_begin(cx_handle *h) {
     CX_NOT_VMP(h, "cx_sweep_begin");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep_begin: no graph");

@@ -154,6 +154,12 @@ class DeviceGraph:
         self._check(self.lib.cx_halo_configure(self.h, len(sv), _p(sv, C.c_int64), _p(sf, C.c_int64), len(rv),
                                                _p(rv, C.c_int64), _p(rf, C.c_int64)))
 
+    def sweep_until(self, tol: float, max_sweeps: int, check_every: int = 10):
+        """(sweeps run, last residual): cx_sweep_until"""
+        n, r = C.c_int32(), C.c_double()
+        self._check(self.lib.cx_sweep_until(self.h, float(tol), int(max_sweeps), int(check_every), C.byref(n), C.byref(r)))
+        return n.value, r.value
+
     def halo_configure_state(self, send_var, send_fac, recv_var, recv_fac):
         """Deep halo: the lists name factor→variable messages of redundant variables (cx_halo_configure_state)."""
         sv, sf, rv, rf = _i64(send_var), _i64(send_fac), _i64(recv_var), _i64(recv_fac)

@@ -200,6 +200,9 @@ int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n);
 int32_t cx_sweep(cx_handle *h, int32_t n_sweeps);
 /* max over directed messages of |Δmean|, |Δvariance| between the last two sweeps (host-synchronous) */
 int32_t cx_residual(cx_handle *h, double *out_max_abs_delta);
+/* sweep until cx_residual over `check_every` sweeps is <= tol, or max_sweeps have run (stopping rule for loopy graphs; the
+ * reference leaves it to the caller of update_marginals!).  A NaN residual (undefined messages) never satisfies tol. */
+int32_t cx_sweep_until(cx_handle *h, double tol, int32_t max_sweeps, int32_t check_every, int32_t *sweeps_run, double *residual);
 
 /* ---- partitioned graphs (one handle per GPU; exchange is the caller's: RCCL/torch.distributed) --
  * Cut edges appear in this rank's graph as degree-1 "ghost" variables whose variable→factor message is

@@ -100,6 +100,11 @@ class Handle {
     void update_batch(const std::vector<cx_item> &items) { check(cx_update_batch(h_, items.data(), (int64_t)items.size())); }
     void sweep(int32_t n = 1) { check(cx_sweep(h_, n)); }
     double residual() { double r = 0; check(cx_residual(h_, &r)); return r; }
+    std::pair<int32_t, double> sweep_until(double tol, int32_t max_sweeps, int32_t check_every = 10) {
+        int32_t n = 0; double r = 0;
+        check(cx_sweep_until(h_, tol, max_sweeps, check_every, &n, &r));
+        return {n, r};
+    }
     void sync() { check(cx_sync(h_)); }
     void set_stream(void *hip_stream) { check(cx_set_stream(h_, hip_stream)); }
 

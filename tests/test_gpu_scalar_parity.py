@@ -255,3 +255,20 @@ def test_beta_bernoulli_known_answer_on_device(hip_lib, schedule, n):
         assert (m[0], m[1]) == (r[1:].sum(), (1.0 - r[1:]).sum())
     with pytest.raises(cx.CortexHipError):
         dev.get_messages([p], [int(f[0])], L.TO_VARIABLE, L.FORM_MOMENT)   # moment form is Gaussian-only
+
+
+def test_sweep_until_stops_at_the_requested_residual(hip_lib):
+    """cx_sweep_until on a loopy grid: stops once the largest message change over `check_every` sweeps is below tol, well
+    before max_sweeps; the marginal means then equal the dense solve (loopy Gaussian BP means are exact at convergence)."""
+    model = cx.synth.gaussian_grid(24, 31, seed=2)
+    dev = _device(model, L.SCHED_FUSED, seed_variance=1e6)
+    n, r = dev.sweep_until(1e-12, 5000, check_every=20)
+    assert n % 20 == 0 and 20 <= n < 5000 and r <= 1e-12
+    dev.update_batch([L.ITEM_INDIVIDUAL_MARGINAL] * len(model.x_ids), model.x_ids, [0] * len(model.x_ids))
+    m = dev.get_marginals(model.x_ids)
+    mean = exact.grid_posterior_mean(24, 31, model.meta["y"], model.meta["r"], model.meta["qh"], model.meta["qv"])
+    assert_close(m[:, 0], mean, 1e-9, "converged BP mean vs dense solve")
+    n2, r2 = dev.sweep_until(1e-12, 7, check_every=3)          # max_sweeps caps the run: 3 + 3 + 1
+    assert n2 in (3, 7) and r2 <= 1e-12 or n2 == 7
+    with pytest.raises(cx.CortexHipError):
+        dev.sweep_until(-1.0, 10)
