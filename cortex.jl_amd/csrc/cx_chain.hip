@@ -217,17 +217,37 @@ __global__ __launch_bounds__(kBlock) void k_chain_scan_totals(int ntiles, Lin *_
     }
 }
 
+// OWN_CARRY: the tile totals are NOT pre-scanned; every workgroup composes the totals of the tiles before it itself (a few
+// KB from L2, one more tile scan) — for up to kOwnCarryTiles tiles that is cheaper than the one-workgroup scan kernel's
+// launch (≈6 us on a 1M-edge chain, where the whole sweep is launch-bound).
+constexpr int kOwnCarryTiles = 8 * kTile;
+template <bool OWN_CARRY>
 __global__ __launch_bounds__(kBlock) void k_chain_apply(ChainArgs A, const Lin *__restrict__ tile_excl, double2 *__restrict__ f2v) {
     const int dir = blockIdx.y == 0 ? 1 : -1;
     tile_excl += (size_t)blockIdx.y * (gridDim.x + 1);
     __shared__ Lin wave_tot[kBlock / 64];
+    Lin own = lin_identity();
+    if (OWN_CARRY) {
+        const int t = blockIdx.x;                       // totals[0 .. t) precede this tile
+        for (int chunk = 0; chunk < t; chunk += kTile) {
+            Lin c[kItems];
+#pragma unroll
+            for (int k = 0; k < kItems; k++) {
+                const int j = chunk + threadIdx.x * kItems + k;
+                c[k] = j < t ? tile_excl[j] : lin_identity();
+            }
+            Lin tot;
+            tile_scan(c, tot, wave_tot);
+            own = lin_compose(own, tot);
+        }
+    }
     Lin x[kItems];
     const int base = blockIdx.x * kTile + threadIdx.x * kItems;
 #pragma unroll
     for (int k = 0; k < kItems; k++) x[k] = load_link(A, base + k, dir);
     Lin tot;
     tile_scan(x, tot, wave_tot);
-    const Lin carry = tile_excl[blockIdx.x];
+    const Lin carry = OWN_CARRY ? own : tile_excl[blockIdx.x];
 #pragma unroll
     for (int k = 0; k < kItems; k++) {
         const int idx = base + k;
@@ -257,8 +277,12 @@ void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves) {
     const int ntiles = (nlinks + kTile - 1) / kTile;
     Lin *totals = (Lin *)h->d_chain_totals;
     hipLaunchKernelGGL(k_chain_tile_totals, dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, totals);
-    hipLaunchKernelGGL(k_chain_scan_totals, dim3(2), dim3(kBlock), 0, h->stream, ntiles, totals);
-    hipLaunchKernelGGL(k_chain_apply, dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, totals, f2v);
+    if (ntiles <= kOwnCarryTiles) {
+        hipLaunchKernelGGL(k_chain_apply<true>, dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, totals, f2v);
+    } else {
+        hipLaunchKernelGGL(k_chain_scan_totals, dim3(2), dim3(kBlock), 0, h->stream, ntiles, totals);
+        hipLaunchKernelGGL(k_chain_apply<false>, dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, totals, f2v);
+    }
 }
 
 size_t chain_total_bytes(int64_t nlinks) {

@@ -101,3 +101,15 @@ def test_chain_scan_refuses_loopy_graphs(hip_lib):
     with pytest.raises(cx.CortexHipError) as e:
         dev.sweep(1)
     assert e.value.code == L.ERR_UNSUPPORTED and "chain" in e.value.message
+
+
+def test_chain_longer_than_one_chunk_of_tile_totals(hip_lib):
+    """T = 1,100,000: 1075 tiles per direction, i.e. the apply kernel composes its carry from TWO chunks of tile totals."""
+    T = 1_100_000
+    model = cx.synth.ssm_chain(T, seed=5)
+    dev = _solve(model)
+    idx = np.concatenate([np.arange(0, 1500), np.arange(T // 2 - 750, T // 2 + 750), np.arange(T - 1500, T)])
+    marg = dev.get_marginals(model.x_ids[idx])
+    xm, xv = exact.ssm_chain_posterior(model.data_y, 1.0, 1.0)
+    assert_close(marg[:, 0], xm[idx], 1e-9, "long chain marginal mean")
+    assert_close(marg[:, 1], xv[idx], 1e-9, "long chain marginal variance")
