@@ -589,3 +589,24 @@ def verify_last_exchange(part: Partition, send, recv, dist, torch) -> bool:
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=send.device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     return bool(flag.item() == 1)
+
+
+def converge(exchange, local_residual, dist, torch, tol: float, max_sweeps: int, check_every: int, device="cpu"):
+    """Partitioned sweeps until the largest message change over `check_every` sweeps, maximised over all ranks, is <= tol.
+    The one collective on this path: an 8-byte MAX all-reduce every `check_every` sweeps; every rank takes the
+    same decision, so the halo exchanges stay matched.  `local_residual()` returns this rank's max change since its last call
+    (DeviceGraph.residual).  Returns (sweeps run, global residual)."""
+    local_residual()                       # snapshot of the starting point
+    done, r = 0, float("inf")
+    while done < max_sweeps:
+        k = min(check_every, max_sweeps - done)
+        exchange.sweep(k)
+        done += k
+        r = float(local_residual())
+        if dist is not None:
+            t = torch.tensor([r if r == r else float("inf")], dtype=torch.float64, device=device)   # NaN (undefined messages) never converges
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            r = float(t.item())
+        if r <= tol:
+            break
+    return done, r

@@ -64,6 +64,16 @@ class OracleStateSweeper:
     def sweep(self):
         self.g.sweep(1)
 
+    def residual(self):
+        """max |change| of the factor→variable messages (mean and variance) since the last call"""
+        cur = np.concatenate([self.g.f2v_m, self.g.f2v_v])
+        prev = getattr(self, "_prev", None)
+        self._prev = cur.copy()
+        if prev is None:
+            return float("inf")
+        both = ~np.isnan(cur) & ~np.isnan(prev)
+        return float(np.max(np.abs(cur[both] - prev[both]))) if both.any() else float("inf")
+
 
 def main():
     rows, cols, sweeps, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
@@ -74,7 +84,11 @@ def main():
         part = partition.grid_strip_deep(rows, cols, rank, world, depth, seed=99)
         sw = OracleStateSweeper(part, 1e6)
         ex = partition.DeepHaloExchange(sw, part, dist)
-        ex.sweep(sweeps)
+        if sweeps < 0:        # convergence mode: sweep to a global residual instead of a fixed count
+            n_run, res = partition.converge(ex, sw.residual, dist, torch, 1e-12, 4000, 2 * depth)
+            np.save(out + f".rank{rank}.conv.npy", np.array([n_run, res]))
+        else:
+            ex.sweep(sweeps)
     else:
         part = partition.grid_strip(rows, cols, rank, world, seed=99)
         sw = OracleSweeper(part, 1e6)

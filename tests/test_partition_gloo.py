@@ -244,3 +244,38 @@ def test_generic_deep_partition_of_random_sparse_graphs(seed, world, depth):
         e = g.edge_index(sw.g.edge_var[own], sw.g.edge_fac[own])
         for name in ("f2v_m", "f2v_v"):
             assert np.array_equal(getattr(sw.g, name)[own], getattr(g, name)[e], equal_nan=True), name
+
+
+def test_gloo_partitioned_convergence_with_the_residual_all_reduce(tmp_path):
+    """partition.converge over gloo: three ranks with a deep halo sweep until the globally reduced residual is below 1e-12 —
+    all ranks stop after the same number of sweeps — and the owned marginal means then equal the dense solve of the whole
+    grid (loopy Gaussian BP means are exact at convergence)."""
+    from oracle import exact
+
+    rows, cols, world, depth = 4, 7, 3, 2
+    out = str(tmp_path / "res")
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(rows), str(cols),
+                                       "-1", out, str(depth)], env=env, cwd=ROOT))
+    try:
+        for p in procs:
+            assert p.wait(timeout=240) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    whole = cx.synth.gaussian_grid(rows * world, cols, seed=99)
+    mean = exact.grid_posterior_mean(rows * world, cols, whole.meta["y"], whole.meta["r"], whole.meta["qh"], whole.meta["qv"]).ravel()
+    runs = set()
+    for r in range(world):
+        n_run, res = np.load(out + f".rank{r}.conv.npy")
+        runs.add(int(n_run))
+        assert res <= 1e-12 and 0 < n_run < 4000
+        d = np.load(out + f".rank{r}.npz")
+        li = np.searchsorted(d["var_ids"], d["owned"])
+        np.testing.assert_allclose(d["marg_m"][li], mean[d["owned"] - 1], rtol=1e-9)
+    assert len(runs) == 1          # the all-reduce makes the decision common
