@@ -829,6 +829,7 @@ static int32_t ensure_v2f(cx_handle *h) {
 
 int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, int32_t direction,
                         int32_t form, const double *payload) {
+    if (h) h->chain_side_dirty = true;
     CX_NOT_VMP(h, "cx_set_messages");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_set_messages: no graph");
     CX_REQUIRE(h, direction == CX_TO_FACTOR || direction == CX_TO_VARIABLE, CX_ERR_INVALID_ARGUMENT, "cx_set_messages: bad direction");
@@ -903,6 +904,7 @@ int32_t cx_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
 }
 
 int32_t cx_seed_messages(cx_handle *h, int32_t direction, double mean, double variance) {
+    if (h) h->chain_side_dirty = true;
     CX_NOT_VMP(h, "cx_seed_messages");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_seed_messages: no graph");
     CX_REQUIRE(h, direction == CX_TO_FACTOR || direction == CX_TO_VARIABLE, CX_ERR_INVALID_ARGUMENT, "cx_seed_messages: bad direction");
@@ -959,6 +961,7 @@ int32_t cx_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, d
 }
 
 int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
+    if (h) h->chain_side_dirty = true;
     CX_NOT_VMP(h, "cx_update_batch");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_update_batch: no graph");
     if (n == 0) return CX_OK;
@@ -1044,6 +1047,7 @@ static int32_t build_chains(cx_handle *h) {
                         (void *)h->d_chain_from, (void *)h->d_chain_to, (void *)h->d_chain_head_fwd, (void *)h->d_chain_head_bwd,
                         (void *)h->d_chain_side, h->d_chain_totals}) if (p) (void)hipFree(p);
         h->chain_npos = (int64_t)pos_var.size(); h->chain_nlinks = (int64_t)link_pos.size();
+        h->chain_side_dirty = true;
         int64_t n_readers = 0;   // variables that read factor→variable messages: everything but observed variables and ghosts
         for (int64_t v = 0; v < nv; v++) n_readers += (h->vinfo[v] & (cx::kClamped | cx::kGhost)) ? 0 : 1;
         h->chain_covers_all = n_readers == h->chain_npos;
@@ -1486,6 +1490,7 @@ int32_t cx_state_export(cx_handle *h, void *buf, int64_t bytes) {
 }
 
 int32_t cx_state_import(cx_handle *h, const void *buf, int64_t bytes) {
+    if (h) h->chain_side_dirty = true;
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_state_import: no graph");
     if (is_vmp(h)) return cx::vmp_state_import(h, buf, bytes);
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_state_import: a cx_sweep_begin is still open");

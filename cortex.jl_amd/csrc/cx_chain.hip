@@ -264,7 +264,12 @@ void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves) {
     const int nlinks = (int)h->chain_nlinks, npos = (int)h->chain_npos;
     if (nlinks == 0) return;
     const double *pa = h->any_linear ? h->d_a : nullptr, *pb = h->any_linear ? h->d_b : nullptr;
-    if (fused_leaves)
+    // With fused leaves the side sums depend only on stored messages of fixed senders (data, priors) and on the rule
+    // parameters: they are recomputed when one of those changed (cx_set_messages, cx_seed_messages, cx_update_batch, a state
+    // import, a new q table), not on every sweep.
+    if (fused_leaves && !h->chain_side_dirty) {
+        // nothing
+    } else if (fused_leaves)
         hipLaunchKernelGGL(k_chain_side<true>, dim3((npos + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, npos, h->d_chain_pos_var,
                            h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, pa, pb,
                            h->d_v2f, f2v, h->d_chain_side);
@@ -272,6 +277,7 @@ void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves) {
         hipLaunchKernelGGL(k_chain_side<false>, dim3((npos + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, npos, h->d_chain_pos_var,
                            h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, pa, pb,
                            h->d_v2f, f2v, h->d_chain_side);
+    h->chain_side_dirty = false;
     ChainArgs A{nlinks, h->d_chain_link_pos, h->d_chain_from, h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd,
                 h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_chain_side};
     const int ntiles = (nlinks + kTile - 1) / kTile;

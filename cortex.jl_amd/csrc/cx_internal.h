@@ -89,6 +89,7 @@ struct cx_handle {
     // chain-scan schedule (cx_chain.hip): paths of free variables, built lazily by build_chains()
     bool chains_dirty = true;
     int64_t chain_npos = 0, chain_nlinks = 0;
+    bool chain_side_dirty = true;    // the leaf messages / side sums of the chain positions must be recomputed (data or rule parameters changed)
     bool chain_covers_all = false;   // every variable that reads messages is a chain position: the scan's side pass produces all leaf messages
     int32_t *d_chain_pos_var = nullptr, *d_chain_skip0 = nullptr, *d_chain_skip1 = nullptr;
     int32_t *d_chain_link_pos = nullptr, *d_chain_from = nullptr, *d_chain_to = nullptr;

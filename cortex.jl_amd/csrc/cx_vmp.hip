@@ -597,6 +597,7 @@ int32_t vmp_update_marginals(cx_handle *h, int64_t n, const int64_t *ids) {
         if (do_normal && s->structured) {
             cx_handle *c = s->chain;
             hipLaunchKernelGGL(k_set_q, dim3(blocks(c->nslots)), dim3(256), 0, h->stream, (int)c->nslots, s->d_slot_gamma, s->g_mean, c->d_q);
+            c->chain_side_dirty = true;      // the leaf messages N(y, q) change with q
             int32_t rc = cx_sweep(c, 1);
             VMP_REQUIRE(h, rc == CX_OK, rc, std::string("cx_update_marginals (inner handle): ") + cx_last_error(c));
             hipLaunchKernelGGL(k_pull_marginals, dim3(blocks(s->nN)), dim3(256), 0, h->stream, (int)s->nN, c->d_marg, s->d_observed, s->n_mean, s->n_prec);
