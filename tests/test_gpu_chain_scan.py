@@ -113,3 +113,21 @@ def test_chain_longer_than_one_chunk_of_tile_totals(hip_lib):
     xm, xv = exact.ssm_chain_posterior(model.data_y, 1.0, 1.0)
     assert_close(marg[:, 0], xm[idx], 1e-9, "long chain marginal mean")
     assert_close(marg[:, 1], xv[idx], 1e-9, "long chain marginal variance")
+
+
+def test_chain_scan_sees_data_changes_between_sweeps(hip_lib):
+    """The side sums / leaf messages are cached between sweeps: new observations (cx_set_messages) must invalidate them."""
+    T = 300
+    model = cx.synth.ssm_chain(T, seed=3)
+    dev = _solve(model)
+    first = dev.get_marginals(model.x_ids)
+    dev.sweep(1)                                                      # cached side sums: same answer
+    assert np.array_equal(dev.get_marginals(model.x_ids), first)
+    y2 = model.data_y + np.linspace(-3, 3, T)
+    dev.set_messages(model.data_var, model.data_fac, L.TO_FACTOR, L.FORM_POINT, y2)
+    dev.sweep(1)
+    xm, xv = exact.ssm_chain_posterior(y2, 1.0, 1.0)
+    marg = dev.get_marginals(model.x_ids)
+    assert_close(marg[:, 0], xm, 1e-9, "posterior mean after new data")
+    assert_close(marg[:, 1], xv, 1e-9, "posterior variance after new data")
+    assert not np.allclose(marg[:, 0], first[:, 0])
