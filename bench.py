@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py — edge-message updates/sec per sweep on the 10M-edge Gaussian grid (BASELINE.json).
+"""bench.py — edge-message updates/sec per sweep on the 10M-edge Gaussian grid (BASELINE.json, config 4).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            # N > 1: this process only spawns and supervises N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step = one full sum-product sweep (every variable→factor message, every factor→variable message,
-every marginal) over the N x N grid held by each rank, i.e. one `update_marginals!` of the reference
-(src/inference_engine.jl:559-632) in the device's flooding order.  Weak scaling: every rank owns one
-1415 x 1415 strip (10,005,465 bipartite edges) of a (1415*N) x 1415 grid; messages on the cut rows are
-exchanged once per sweep (RCCL over xGMI through torch.distributed).  value = message updates of all
-ranks / max-over-ranks time.  Inputs are resident in HBM before the timed region.
+A step = one full sum-product sweep (every variable→factor message, every factor→variable message, every
+marginal), i.e. one `update_marginals!` of the reference (src/inference_engine.jl:559-632) in the device's
+flooding order.  The workload is BASELINE config 4: ONE 1415 x 1415 Gaussian grid (10,005,465 bipartite edges,
+16,006,480 directed message updates per sweep).  N > 1 cuts that one grid into N row blocks (strong scaling,
+the "8-way cut" of the config) with a deep halo: the redundant rows' state travels once per `--halo-depth`
+sweeps (RCCL over xGMI, issued by the library); a weak-scaling figure (one 1415 x 1415 strip per rank) is
+measured afterwards and printed as the `weak_scaling` field.  value = owned message updates of all ranks /
+max-over-ranks time.  Inputs are resident in HBM before the timed region.
 
-Rank 0 prints ONE JSON line carrying `roofline` (dominant kernel, hipEvent-timed on the library's stream)
-and, at N = 1, `cpu_baseline` (the CPU restatement of the reference scheduler on a bounded sample).
+Rank 0 prints ONE JSON line carrying `roofline` (dominant kernel: device time of the timed region on the
+library's stream / launches; counter traffic from profiles/) and, at N = 1, `cpu_baseline` (the CPU restatement
+of the reference scheduler on a bounded sample).
 """
 from __future__ import annotations
 
@@ -32,21 +35,25 @@ HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARC
 BYTES_PER_UPDATE = 32          # read the 16-byte payload once + write it once, f64 scalar Gaussian
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--event-stride", type=int, default=8, help="hipEvent-time every n-th launch of the timed region")
-    ap.add_argument("--grid", type=int, default=1415, help="N: each rank holds an N x N grid strip (1415 -> 10,005,465 edges)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of exactly --steps steps each (barrier + synchronize on both sides); the median is reported")
+    ap.add_argument("--event-stride", type=int, default=1,
+                    help="per-launch hipEvent pairs in the extra, untimed sampling region (every n-th launch)")
+    ap.add_argument("--grid", type=int, default=1415, help="N: the N x N grid (1415 -> 10,005,465 edges)")
     ap.add_argument("--schedule", choices=["flooding", "fused"], default=os.environ.get("CX_BENCH_SCHEDULE", "fused"))
     ap.add_argument("--materialize", action="store_true", help="also store every variable→factor message each sweep")
     ap.add_argument("--halo", choices=["rccl", "torch"], default=os.environ.get("CX_HALO", "rccl"),
                     help="N > 1: exchange issued by the library on RCCL (default) or by torch.distributed isend/irecv")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak (default): every rank owns an N x N strip of an (N*ranks) x N grid; strong: the ONE N x N grid "
-                         "(BASELINE config 4: 10M edges, 8-way cut) is split into row blocks over the ranks")
-    ap.add_argument("--halo-depth", type=int, default=int(os.environ.get("CX_HALO_DEPTH", "8")),
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="strong (default, BASELINE config 4): the ONE N x N grid is cut into row blocks over the ranks; "
+                         "weak: every rank owns an N x N strip of an (N*ranks) x N grid")
+    ap.add_argument("--no-weak-figure", action="store_true", help="N > 1, strong scaling: skip the second (weak-scaling) measurement")
+    ap.add_argument("--halo-depth", type=int, default=int(os.environ.get("CX_HALO_DEPTH", "16")),
                     help="deep halo: each rank keeps this many redundant rows of its neighbours and exchanges their state once "
                          "per that many sweeps (bit-identical to the un-partitioned sweep); 0 = one message halo per sweep")
     ap.add_argument("--cpu-configs", action="store_true", help="CPU baselines of configs C1, C2 and the C4 sample only (no GPU needed)")
@@ -55,7 +62,97 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-grid", type=int, default=768, help="grid side of the bounded CPU sample")
     ap.add_argument("--seed", type=int, default=1234)
-    return ap.parse_args()
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous of the spawned ranks only (gloo all-reduce, no GPU): what the CPU test of the launcher runs")
+    return ap.parse_args(argv)
+
+
+# ---- launcher: `python bench.py --gpus N` by itself ---------------------------------------------------------------------
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv, timeout_s: float = 1500.0) -> int:
+    """Spawn one child per rank (this file, same arguments) with the torch.distributed environment set, relay rank 0's
+    stdout, wait.  The parent never imports torch nor touches a GPU; nothing is exec'd from a process that has.  A child
+    that fails takes the others down and the exit code is non-zero."""
+    import signal
+    import subprocess
+
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CX_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, start_new_session=True))
+    deadline = time.time() + timeout_s
+    rc, out0 = 0, b""
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if r == 0:
+                    out0 = procs[0].stdout.read()
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write(f"[bench] rank {r} exited with {code}: stopping the other ranks\n")
+            if rc != 0 or time.time() > deadline:
+                if rc == 0:
+                    rc = 3
+                    sys.stderr.write(f"[bench] no completion after {timeout_s:.0f} s: stopping the ranks\n")
+                break
+            if pending:
+                time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)   # the child's own session: exactly the processes started here
+                except ProcessLookupError:
+                    pass
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+    if not out0 and procs[0].stdout is not None:
+        try:
+            out0 = procs[0].stdout.read() or b""
+        except ValueError:
+            out0 = b""
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
+
+def launch_check():
+    """what a spawned rank does under --launch-check: join the rendezvous, all-reduce the ranks, report (CPU only)"""
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if os.environ.get("CX_BENCH_FAIL_RANK") == str(rank):
+        os._exit(7)                          # the launcher test's "a child dies" case
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launcher": "ok", "world": world, "sum_of_ranks_plus_one": int(t.item())}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def _usable_cores() -> int:
@@ -151,6 +248,8 @@ def cpu_config_table(seed: int):
         print(json.dumps(r), flush=True)
 
 
+
+
 def _watchdog(seconds: float):
     """A multi-rank run that stops making progress (a peer died, a collective never matched) must fail fast instead of
     sitting on the node until the driver's limit."""
@@ -167,11 +266,134 @@ def _watchdog(seconds: float):
     return t
 
 
-def main():
-    args = parse()
-    if args.cpu_configs:
-        cpu_config_table(args.seed)
-        return
+class Workload:
+    """one DeviceGraph loaded with this rank's part of the grid + the object that runs n sweeps of it"""
+
+    def __init__(self, args, scaling, rank, world, local_rank, backend, dist, torch, cx, L):
+        from cortex.jl_amd import partition
+
+        N = args.grid
+        self.args, self.scaling, self.world, self.rank = args, scaling, world, rank
+        schedule = L.SCHED_FUSED if args.schedule == "fused" else L.SCHED_FLOODING
+        self.dev = dev = cx.DeviceGraph(device=local_rank, schedule=schedule, marginals_in_sweep=True,
+                                        materialize_messages_to_factor=args.materialize)
+        dev.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.halo_kind, self.halo_tensors, self.part, self.exchange = None, None, None, None
+        red_dev = "cuda" if backend == "nccl" else "cpu"
+        if world == 1 and not args.self_halo:
+            model = cx.synth.gaussian_grid(N, N, seed=args.seed)
+            cx.synth.load_into_device(model, dev, seed_variance=1e6)
+        else:
+            rows_min = N if scaling == "weak" else N // world
+            depth = self.depth = max(0, min(args.halo_depth, rows_min))
+            if world == 1:
+                part = partition.deep_self(N, N, depth, seed=args.seed) if depth else partition.cylinder_self(N, N, seed=args.seed)[0]
+            elif scaling == "strong":
+                part = (partition.grid_rows_deep(N, N, rank, world, depth, seed=args.seed) if depth
+                        else partition.grid_rows(N, N, rank, world, seed=args.seed))
+            elif depth:
+                part = partition.grid_strip_deep(N, N, rank, world, depth, seed=args.seed)
+            else:
+                part = partition.grid_strip(N, N, rank, world, seed=args.seed)
+            self.part = part
+            cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
+            exchange = None
+            tdev = torch.device("cuda", local_rank)
+            if backend != "nccl" and world > 1:
+                if depth:
+                    sweeper = partition.HostStagedStateSweeper(dev, part, torch, tdev)
+                    exchange = partition.DeepHaloExchange(sweeper, part, dist)
+                else:
+                    sweeper = partition.HostStagedSweeper(dev, part, torch, tdev)
+                    exchange = partition.HaloExchange(sweeper, part, dist)
+                self.halo_kind = f"REHEARSAL: host-staged over {backend}"
+                self.halo_tensors = (sweeper.send, sweeper.recv)
+            elif args.halo == "rccl":
+                err = None
+                try:
+                    exchange = (partition.DeepHaloRccl if depth else partition.RcclExchange)(dev, part, dist, torch, tdev)
+                    self.halo_kind = "rccl send/recv issued by the library"
+                    self.halo_tensors = (exchange.send, exchange.recv)
+                except cx.CortexHipError as e:   # e.g. librccl not loadable: fall back to torch.distributed
+                    err = e
+                if dist is not None:             # all ranks take the same path
+                    okf = torch.tensor([0 if err else 1], dtype=torch.int32, device=red_dev)
+                    dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+                    if okf.item() == 0:
+                        exchange = None
+                if exchange is None and rank == 0:
+                    print(f"[bench] RCCL exchange unavailable ({err}); falling back to torch.distributed", file=sys.stderr)
+            if exchange is None:
+                if depth:
+                    sweeper = partition.DeviceStateSweeper(dev, part, torch, tdev)
+                    exchange = partition.DeepHaloExchange(sweeper, part, dist)
+                else:
+                    sweeper = partition.DeviceSweeper(dev, part, torch, tdev)
+                    exchange = partition.HaloExchange(sweeper, part, dist)
+                self.halo_kind = "torch.distributed isend/irecv"
+                self.halo_tensors = (sweeper.send, sweeper.recv)
+            if depth:
+                self.halo_kind = f"deep halo, {depth} redundant rows per side, state exchanged every {depth} sweeps; " + self.halo_kind
+            else:
+                self.halo_kind = "message halo per sweep; " + self.halo_kind
+            self.exchange = exchange
+        self.st = st = dev.stats()
+        self.local_updates_per_step = st["n_messages_per_sweep"]      # what one launch computes (redundant rows included)
+        self.updates_per_step = self.local_updates_per_step
+        self.owned_variables = st["n_variables"]
+        if self.exchange is not None and getattr(self.part, "depth", 0):
+            # the metric counts OWNED updates only: 4 directed messages per pairwise factor; a factor belongs to the rank of
+            # its lower-id variable (SURVEY.md §8e): R (C - 1) horizontal + R C vertical factors, the last block one row fewer
+            if world == 1:
+                rows, last = N, True
+            elif scaling == "weak":
+                rows, last = N, rank == world - 1
+            else:
+                b = partition._row_bounds(N, world)
+                rows, last = int(b[rank + 1] - b[rank]), rank == world - 1
+            self.updates_per_step = 4 * (rows * (N - 1) + (rows - 1 if last else rows) * N)
+            self.owned_variables = rows * N
+
+    def run(self, n: int):
+        if self.exchange is None:
+            self.dev.sweep(n)
+        else:
+            self.exchange.sweep(n)
+
+    def close(self):
+        self.exchange = None
+        self.dev.close()
+
+
+def timed_regions(w: Workload, steps: int, repeats: int, dist, torch, red_dev):
+    """`repeats` regions of exactly `steps` steps, each between barrier + synchronize; per region the wall time (max over
+    ranks) and the device time between two events on the library's stream.  Returns the lists."""
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    walls, devs = [], []
+    for _ in range(max(1, repeats)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        e0.record()
+        w.run(steps)
+        e1.record()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        dev_ms = e0.elapsed_time(e1)
+        if dist is not None:
+            t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, dev_ms = float(t[0].item()), float(t[1].item())
+        walls.append(elapsed)
+        devs.append(dev_ms)
+    return walls, devs
+
+
+def run_rank(args):
     import torch
     import cortex.jl_amd as cx
     from cortex.jl_amd import _lib as L
@@ -180,8 +402,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP sweep has no CPU fallback")
     # rehearsal knobs (never set by the driver): CX_DIST_BACKEND=gloo + CX_SINGLE_DEVICE=1 run N ranks against ONE GPU with
@@ -200,179 +421,151 @@ def main():
             dist.init_process_group(backend)
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
-    dog = _watchdog(900.0)
+    dog = _watchdog(1200.0)
     N = args.grid
-    schedule = L.SCHED_FUSED if args.schedule == "fused" else L.SCHED_FLOODING
-    dev = cx.DeviceGraph(device=local_rank, schedule=schedule, marginals_in_sweep=True,
-                         materialize_messages_to_factor=args.materialize)
-    stream = torch.cuda.current_stream()
-    dev.set_stream(stream.cuda_stream)
+    w = Workload(args, args.scaling, rank, world, local_rank, backend, dist, torch, cx, L)
+    dev = w.dev
 
-    halo_kind = None
-    halo_tensors = None
-    if world == 1 and not args.self_halo:
-        model = cx.synth.gaussian_grid(N, N, seed=args.seed)
-        cx.synth.load_into_device(model, dev, seed_variance=1e6)
-        exchange = None
-    else:
-        from cortex.jl_amd import partition
-        depth = min(args.halo_depth, N if args.scaling == "weak" else max(N // max(world, 1), 1))
-        if world == 1:
-            part = partition.deep_self(N, N, depth, seed=args.seed) if depth else partition.cylinder_self(N, N, seed=args.seed)[0]
-        elif args.scaling == "strong":
-            part = partition.contiguous_blocks(cx.synth.gaussian_grid(N, N, seed=args.seed), rank, world, depth=depth)
-        elif depth:
-            part = partition.grid_strip_deep(N, N, rank, world, depth, seed=args.seed)
-        else:
-            part = partition.grid_strip(N, N, rank, world, seed=args.seed)
-        cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
-        exchange = None
-        tdev = torch.device("cuda", local_rank)
-        if backend != "nccl" and world > 1:
-            if depth:
-                sweeper = partition.HostStagedStateSweeper(dev, part, torch, tdev)
-                exchange = partition.DeepHaloExchange(sweeper, part, dist)
-            else:
-                sweeper = partition.HostStagedSweeper(dev, part, torch, tdev)
-                exchange = partition.HaloExchange(sweeper, part, dist)
-            halo_kind = f"REHEARSAL: host-staged over {backend}"
-            halo_tensors = (sweeper.send, sweeper.recv)
-        elif args.halo == "rccl":
-            err = None
-            try:
-                exchange = (partition.DeepHaloRccl if depth else partition.RcclExchange)(dev, part, dist, torch, tdev)
-                halo_kind = "rccl send/recv issued by the library"
-                halo_tensors = (exchange.send, exchange.recv)
-            except cx.CortexHipError as e:   # e.g. librccl not loadable: fall back to torch.distributed
-                err = e
-            if dist is not None:             # all ranks take the same path
-                okf = torch.tensor([0 if err else 1], dtype=torch.int32, device=red_dev)
-                dist.all_reduce(okf, op=dist.ReduceOp.MIN)
-                if okf.item() == 0:
-                    exchange = None
-            if exchange is None and rank == 0:
-                print(f"[bench] RCCL exchange unavailable ({err}); falling back to torch.distributed", file=sys.stderr)
-        if exchange is None:
-            if depth:
-                sweeper = partition.DeviceStateSweeper(dev, part, torch, tdev)
-                exchange = partition.DeepHaloExchange(sweeper, part, dist)
-            else:
-                sweeper = partition.DeviceSweeper(dev, part, torch, tdev)
-                exchange = partition.HaloExchange(sweeper, part, dist)
-            halo_kind = "torch.distributed isend/irecv"
-            halo_tensors = (sweeper.send, sweeper.recv)
-        if depth:
-            halo_kind = f"deep halo, {depth} redundant rows per side, state exchanged every {depth} sweeps; " + halo_kind
-        else:
-            halo_kind = "message halo per sweep; " + halo_kind
-    st = dev.stats()
-    local_updates_per_step = st["n_messages_per_sweep"]      # what one launch computes (redundant rows included)
-    updates_per_step = local_updates_per_step
-    if exchange is not None and getattr(part, "depth", 0) and world > 1:
-        # the metric counts OWNED updates only: 4 directed messages per pairwise factor, a factor belongs to the rank of its
-        # lower-id variable: R (C - 1) horizontal + R C vertical factors, the last rank one row fewer
-        if args.scaling == "weak":
-            updates_per_step = 4 * (N * (N - 1) + (N if rank < world - 1 else N - 1) * N)
-        else:   # one N x N grid in total: 8 N (N - 1) directed updates, split evenly for the sum over ranks
-            total = 8 * N * (N - 1)
-            updates_per_step = total // world + (total % world if rank == 0 else 0)
+    w.run(args.warmup)
+    dev.residual()   # snapshot: the residual reported below is the change over the timed regions
+    walls, devs = timed_regions(w, args.steps, args.repeats, dist, torch, red_dev)
+    order = sorted(range(len(walls)), key=lambda i: walls[i])
+    mid = order[len(order) // 2]
+    elapsed, dev_ms = walls[mid], devs[mid]
+    res = dev.residual()
 
-    def step():
-        if exchange is None:
-            dev.sweep(1)
-        else:
-            exchange.sweep()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    dev.residual()   # snapshot: the residual reported below is the change over the timed region
-    barrier()
+    # one more, UNTIMED region with a hipEvent pair around every launch (each pair is a barrier packet on the queue, which
+    # is why it stays out of the timed regions): per-launch durations of every kernel
     dev.profile_enable(max(1, args.event_stride))
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    w.run(min(args.steps, 400))
+    dev.sync()
     dev.profile_enable(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        u = torch.tensor([updates_per_step], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(u, op=dist.ReduceOp.SUM)
-        total_updates_per_step = float(u.item())
-    else:
-        total_updates_per_step = float(updates_per_step)
-
-    # dominant kernel: hipEvent durations recorded around every launch of the timed region, on the library's stream
     kern = {}
     for k in (L.KERNEL_FUSED, L.KERNEL_VAR_TO_FACTOR, L.KERNEL_FACTOR_TO_VAR, L.KERNEL_HALO_BEGIN, L.KERNEL_HALO_END):
         ms, n = dev.profile_read(k)
         if n:
             kern[dev.kernel_name(k)] = (ms, n, k)
-    res = dev.residual()
+
+    if dist is not None:
+        u = torch.tensor([w.updates_per_step, w.owned_variables], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        total_updates_per_step, total_variables = float(u[0].item()), float(u[1].item())
+    else:
+        total_updates_per_step, total_variables = float(w.updates_per_step), float(w.owned_variables)
+
     # audit of the last exchange of the run (outside the timed region): what each rank imported == what its neighbour packed
     halo_check = None
-    if halo_tensors is not None:
+    if w.halo_tensors is not None:
         from cortex.jl_amd import partition
         dev.sync()
         torch.cuda.synchronize()
-        halo_check = partition.verify_last_exchange(part, halo_tensors[0], halo_tensors[1], dist, torch)
+        halo_check = partition.verify_last_exchange(w.part, w.halo_tensors[0], w.halo_tensors[1], dist, torch)
+
+    # second figure at N > 1: weak scaling (every rank one N x N strip of an (N * ranks) x N grid)
+    weak = None
+    if world > 1 and args.scaling == "strong" and not args.no_weak_figure:
+        st_strong, halo_kind_strong = dict(w.st), w.halo_kind
+        w2 = Workload(args, "weak", rank, world, local_rank, backend, dist, torch, cx, L)
+        w2.run(args.warmup)
+        wl, _ = timed_regions(w2, args.steps, min(args.repeats, 3), dist, torch, red_dev)
+        wl.sort()
+        u = torch.tensor([w2.updates_per_step], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        t_w = wl[len(wl) // 2]
+        weak = {"value": float(u.item()) * args.steps / t_w, "unit": "edge-message updates/s", "ms_per_step": t_w / args.steps * 1e3,
+                "workload": f"every rank one {N}x{N} strip of a {N * world}x{N} grid ({w2.st['n_edges']} bipartite edges per rank)",
+                "schedule": args.schedule + f" + {w2.halo_kind}"}
+        w2.close()
 
     if rank == 0:
+        st = w.st
         value = total_updates_per_step * args.steps / elapsed
-        dom = max(kern.items(), key=lambda kv: kv[1][0])
-        dom_name, (dom_ms, dom_n, dom_id) = dom
-        # algorithmic bytes per launch: §8d's 32 B per directed message update x the updates one launch performs
-        if dom_id == L.KERNEL_FUSED:
-            upd_per_launch = local_updates_per_step
+        launches_per_step = 1 if args.schedule == "fused" else 2
+        if kern:
+            dom_name, (dom_ms, dom_n, dom_id) = max(kern.items(), key=lambda kv: kv[1][0])
         else:
-            upd_per_launch = local_updates_per_step / 2
-        avg_s = dom_ms / dom_n / 1e3
-        achieved = upd_per_launch * BYTES_PER_UPDATE / avg_s / 1e9
+            dom_name, (dom_ms, dom_n, dom_id) = "k_sweep<fused>", (0.0, 0, L.KERNEL_FUSED)
+        # algorithmic bytes per launch: §8d's 32 B per directed message update x the updates one launch performs
+        upd_per_launch = w.local_updates_per_step if dom_id == L.KERNEL_FUSED else w.local_updates_per_step / 2
+        alg_bytes = upd_per_launch * BYTES_PER_UPDATE
+        # average launch duration: device time of the median timed region (events on the library's stream around the whole
+        # region, launches back to back) / launches.  It contains the inter-launch gaps, so it can only over-state the
+        # kernel; the per-launch event pairs of the sampling region are printed beside it.
+        region_ms_per_launch = dev_ms / args.steps / launches_per_step if args.schedule == "fused" else None
+        sampled_ms = dom_ms / dom_n if dom_n else None
+        avg_ms = region_ms_per_launch if region_ms_per_launch is not None else sampled_ms
+        # counter traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections: profiles/): measured on
+        # the full 1415 x 1415 launch, carried to other launch sizes per message update
+        traffic, traffic_src = None, None
+        traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(traffic_file) and args.schedule == "fused" and not args.materialize:
+            try:
+                tr = json.load(open(traffic_file))
+                if tr.get("kernel") == dom_name:
+                    per_update = tr["hbm_bytes_per_launch"] / tr.get("updates_per_launch", 16006480)
+                    traffic = per_update * upd_per_launch
+                    traffic_src = tr.get("source")
+            except Exception:
+                pass
+        achieved_alg = alg_bytes / (avg_ms * 1e-3) / 1e9
+        achieved = (traffic / (avg_ms * 1e-3) / 1e9) if traffic else achieved_alg
+        strong = args.scaling == "strong"
         out = {
             "metric": "edge-message updates/sec per sweep, 10M-edge Gaussian grid",
             "value": value, "unit": "edge-message updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"C4: {N}x{N} 2-D Gaussian grid loopy BP per GPU" if args.scaling == "weak" else
-                                    f"C4: ONE {N}x{N} 2-D Gaussian grid loopy BP cut into {world} row blocks; rank 0 holds") +
-                                   f" ({st['n_edges']} bipartite edges, {updates_per_step} directed message updates + "
-                                   f"{st['n_variables']} marginals per sweep)",
-                       "schedule": args.schedule + ("" if halo_kind is None else f" + {halo_kind}"), "partition": f"{world} row strips",
-                       "seed": args.seed},
+            "config": {"workload": ((f"C4: ONE {N}x{N} 2-D Gaussian grid loopy BP" +
+                                     (f" cut into {world} row blocks (strong scaling); rank 0 holds" if world > 1 else ";")) if strong else
+                                    f"C4 weak scaling: one {N}x{N} strip per GPU of a {N * world}x{N} grid; rank 0 holds") +
+                                   f" {st['n_edges']} bipartite edges, {w.updates_per_step} owned directed message updates + "
+                                   f"{w.owned_variables} marginals per sweep; whole job {int(total_updates_per_step)} updates per sweep",
+                       "schedule": args.schedule + ("" if w.halo_kind is None else f" + {w.halo_kind}"),
+                       "partition": f"{world} row blocks", "seed": args.seed},
+            "timed_regions": {"count": len(walls), "reported": "median", "ms_per_step_each": [x / args.steps * 1e3 for x in walls],
+                              "device_ms_per_step_each": [x / args.steps for x in devs]},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": dom_ms / dom_n,
-                         "launches": dom_n,
-                         "algorithmic_bytes_per_launch": upd_per_launch * BYTES_PER_UPDATE,
-                         "all_kernels_ms": {k: v[0] / v[1] for k, v in kern.items()}},
-            "hbm_roofline_frac_end_to_end": value * BYTES_PER_UPDATE / 1e9 / (HBM_PEAK_GBS * world),
-            "marginals_per_s": (N * N if exchange is not None and getattr(part, "depth", 0) else st["n_variables"]) * world * args.steps / elapsed,   # computed inside the same kernel, not counted in `value`
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "basis": ("counter traffic (FETCH_SIZE x2 + WRITE_SIZE at the L2-fabric side, Infinity-Cache hits included) / avg launch duration"
+                                   if traffic else "algorithmic bytes / avg launch duration (no counter traffic on file for this kernel)"),
+                         "traffic_source": traffic_src,
+                         "avg_kernel_ms": avg_ms,
+                         "avg_kernel_basis": "device time of the median timed region (events on the library's stream) / launches",
+                         "sampled_kernel_ms": sampled_ms, "sampled_launches": dom_n,
+                         "algorithmic_bytes_per_launch": alg_bytes, "achieved_algorithmic": achieved_alg,
+                         "frac_algorithmic": achieved_alg / HBM_PEAK_GBS,
+                         "frac_algorithmic_note": "SURVEY §8d convention (32 B per directed update); the fused kernel never stores "
+                                                  "variable→factor messages, so it moves fewer bytes than this convention counts",
+                         "all_kernels_sampled_ms": {k: v[0] / v[1] for k, v in kern.items()}},
+            "marginals_per_s": total_variables * args.steps / elapsed,   # computed inside the same kernel, not counted in `value`
             "max_message_change_over_run": res,
         }
         if halo_check is not None:
             out["halo_check"] = "ok: last imported halo == neighbours' packed messages, bit for bit" if halo_check else "FAILED"
-        traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(traffic_file) and N == 1415 and args.schedule == "fused" and not args.materialize:   # measured for that workload only
-            try:
-                tr = json.load(open(traffic_file))
-                if tr.get("kernel") == dom_name:
-                    out["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
-            except Exception:
-                pass
+        if weak is not None:
+            out["weak_scaling"] = weak
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_grid, args.seed)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     dog.cancel()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def main():
+    args = parse()
+    if args.cpu_configs:
+        cpu_config_table(args.seed)
+        return 0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])
+    if args.launch_check:
+        launch_check()
+        return 0
+    run_rank(args)
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

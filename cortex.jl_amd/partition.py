@@ -39,13 +39,14 @@ class Partition:
     owned_x: np.ndarray = None     # deep halo: the latent variables this rank owns (model.x_ids also lists the redundant ones)
 
 
-def grid_strip(rows_per_rank: int, n_cols: int, rank: int, world: int, seed: int = 1234) -> Partition:
-    """Row-strip partition of the (rows_per_rank*world) x n_cols Gaussian grid: rank r owns rows
-    [r*rows_per_rank, (r+1)*rows_per_rank).  Cut = the vertical factors between neighbouring strips
-    (n_cols factors per boundary).  METIS is not available in this image; for a regular grid strips minimise the
-    number of neighbours (2) and give perfectly balanced parts."""
-    total = rows_per_rank * world
-    r0, r1 = rank * rows_per_rank, (rank + 1) * rows_per_rank
+def _row_bounds(n_rows: int, world: int) -> np.ndarray:
+    """near-equal contiguous row blocks of ONE n_rows-row grid: rank r owns rows [b[r], b[r+1])"""
+    return (np.arange(world + 1, dtype=np.int64) * n_rows) // world
+
+
+def _grid_cut(total: int, n_cols: int, bounds, rank: int, seed: int) -> Partition:
+    world = len(bounds) - 1
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
     model = synth.gaussian_grid(total, n_cols, seed=seed, row0=r0, row1=r1)
     V, H = total * n_cols, total * (n_cols - 1)
     jj = np.arange(n_cols, dtype=np.int64)
@@ -65,16 +66,25 @@ def grid_strip(rows_per_rank: int, n_cols: int, rank: int, world: int, seed: int
                      recv_fac=cat(rf), peers=peers)
 
 
-def grid_strip_deep(rows_per_rank: int, n_cols: int, rank: int, world: int, depth: int, seed: int = 1234) -> Partition:
-    """Row strips with a deep halo: besides its own rows [r0, r1) the rank holds `depth` redundant rows of each neighbour
-    (all their factors included; beyond them the usual degree-1 stand-ins of the next row).  Halo lists = every
-    factor→variable message of the redundant rows, ordered by (variable id, factor id) — both sides of a cut build the
-    same list.  One exchange per `depth` plain sweeps keeps every message of an owned variable bit-identical to the
-    un-partitioned sweep (the error of the frozen outer edge advances one row per sweep)."""
-    if not 1 <= depth <= rows_per_rank:
-        raise ValueError("depth must be in [1, rows_per_rank]: redundant rows come from the direct neighbours only")
-    total = rows_per_rank * world
-    r0, r1 = rank * rows_per_rank, (rank + 1) * rows_per_rank
+def grid_strip(rows_per_rank: int, n_cols: int, rank: int, world: int, seed: int = 1234) -> Partition:
+    """Row-strip partition of the (rows_per_rank*world) x n_cols Gaussian grid (weak scaling): rank r owns rows
+    [r*rows_per_rank, (r+1)*rows_per_rank).  Cut = the vertical factors between neighbouring strips
+    (n_cols factors per boundary).  METIS is not available in this image; for a regular grid strips minimise the
+    number of neighbours (2) and give perfectly balanced parts."""
+    return _grid_cut(rows_per_rank * world, n_cols, np.arange(world + 1, dtype=np.int64) * rows_per_rank, rank, seed)
+
+
+def grid_rows(n_rows: int, n_cols: int, rank: int, world: int, seed: int = 1234) -> Partition:
+    """ONE n_rows x n_cols grid cut into `world` near-equal row blocks (strong scaling; BASELINE config 4 is the
+    1415 x 1415 grid cut 8 ways), one message halo per sweep."""
+    return _grid_cut(n_rows, n_cols, _row_bounds(n_rows, world), rank, seed)
+
+
+def _grid_cut_deep(total: int, n_cols: int, bounds, rank: int, depth: int, seed: int) -> Partition:
+    world = len(bounds) - 1
+    if depth < 1 or depth > int(np.min(np.diff(bounds))):
+        raise ValueError("depth must be in [1, rows of the smallest block]: redundant rows come from the direct neighbours only")
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
     lo, hi = max(r0 - depth, 0), min(r1 + depth, total)
     model = synth.gaussian_grid(total, n_cols, seed=seed, row0=lo, row1=hi)
     ev, ef = np.asarray(model.edge_var, np.int64), np.asarray(model.edge_fac, np.int64)
@@ -101,6 +111,21 @@ def grid_strip_deep(rows_per_rank: int, n_cols: int, rank: int, world: int, dept
     owned = (1 + np.arange(r0, r1, dtype=np.int64)[:, None] * n_cols + jj[None, :]).ravel()
     return Partition(model=model, rank=rank, world=world, send_var=cat(sv), send_fac=cat(sf), recv_var=cat(rv), recv_fac=cat(rf),
                      peers=peers, depth=depth, owned_x=owned)
+
+
+def grid_strip_deep(rows_per_rank: int, n_cols: int, rank: int, world: int, depth: int, seed: int = 1234) -> Partition:
+    """Row strips with a deep halo (weak scaling): besides its own rows [r0, r1) the rank holds `depth` redundant rows of
+    each neighbour (all their factors included; beyond them the usual degree-1 stand-ins of the next row).  Halo lists =
+    every factor→variable message of the redundant rows, ordered by (variable id, factor id) — both sides of a cut build
+    the same list.  One exchange per `depth` plain sweeps keeps every message of an owned variable bit-identical to the
+    un-partitioned sweep (the error of the frozen outer edge advances one row per sweep)."""
+    return _grid_cut_deep(rows_per_rank * world, n_cols, np.arange(world + 1, dtype=np.int64) * rows_per_rank, rank, depth, seed)
+
+
+def grid_rows_deep(n_rows: int, n_cols: int, rank: int, world: int, depth: int, seed: int = 1234) -> Partition:
+    """ONE n_rows x n_cols grid cut into `world` near-equal row blocks, each with `depth` redundant rows per side
+    (strong scaling: BASELINE config 4 = the 1415 x 1415 grid, 8 blocks of 176 / 177 rows)."""
+    return _grid_cut_deep(n_rows, n_cols, _row_bounds(n_rows, world), rank, depth, seed)
 
 
 def by_assignment(model: synth.Model, owner_of_variable, rank: int, world: int) -> Partition:
@@ -434,11 +459,15 @@ class DeepHaloRccl:
         dev.comm_init(part.world, part.rank, uid)
 
     def sweep(self, n: int = 1):
-        for _ in range(n):
+        """n sweeps; the sweeps between two exchanges go to the library as ONE cx_sweep call (at 1/8 of the C4 grid a sweep is
+        a few microseconds of kernel: a Python call per sweep would be the bound)"""
+        while n > 0:
             if self.k % self.depth == 0:
                 self.dev.halo_state_exchange()
-            self.dev.sweep(1)
-            self.k += 1
+            run = min(n, self.depth - self.k % self.depth)
+            self.dev.sweep(run)
+            self.k += run
+            n -= run
 
 
 class DeviceStateSweeper:
@@ -458,8 +487,8 @@ class DeviceStateSweeper:
     def unpack(self):
         self.dev.halo_state_unpack()
 
-    def sweep(self):
-        self.dev.sweep(1)
+    def sweep(self, n: int = 1):
+        self.dev.sweep(n)
 
 
 class HostStagedStateSweeper(DeviceStateSweeper):
@@ -488,9 +517,9 @@ class DeepHaloExchange:
         self.sw, self.part, self.dist, self.k = sweeper, part, dist, 0
 
     def sweep(self, n: int = 1):
-        dist, sw = self.dist, self.sw
-        for _ in range(n):
-            if self.k % self.part.depth == 0:
+        dist, sw, depth = self.dist, self.sw, self.part.depth
+        while n > 0:
+            if self.k % depth == 0:
                 sw.pack()
                 ops = []
                 for p in self.part.peers:
@@ -499,8 +528,10 @@ class DeepHaloExchange:
                 for w in (dist.batch_isend_irecv(ops) if ops else []):
                     w.wait()
                 sw.unpack()
-            sw.sweep()
-            self.k += 1
+            run = min(n, depth - self.k % depth)
+            sw.sweep(run)
+            self.k += run
+            n -= run
 
 
 class DeviceSweeper:
@@ -552,18 +583,19 @@ class HaloExchange:
     def __init__(self, sweeper, part: Partition, dist):
         self.sw, self.part, self.dist = sweeper, part, dist
 
-    def sweep(self):
+    def sweep(self, n: int = 1):
         dist, sw = self.dist, self.sw
-        sw.sweep_begin()
-        ops = []
-        for p in self.part.peers:
-            ops.append(dist.P2POp(dist.isend, sw.send[p.send], p.rank))
-            ops.append(dist.P2POp(dist.irecv, sw.recv[p.recv], p.rank))
-        works = dist.batch_isend_irecv(ops) if ops else []
-        sw.sweep_main()
-        for w in works:
-            w.wait()
-        sw.sweep_end()
+        for _ in range(n):
+            sw.sweep_begin()
+            ops = []
+            for p in self.part.peers:
+                ops.append(dist.P2POp(dist.isend, sw.send[p.send], p.rank))
+                ops.append(dist.P2POp(dist.irecv, sw.recv[p.recv], p.rank))
+            works = dist.batch_isend_irecv(ops) if ops else []
+            sw.sweep_main()
+            for w in works:
+                w.wait()
+            sw.sweep_end()
 
 
 def verify_last_exchange(part: Partition, send, recv, dist, torch) -> bool:

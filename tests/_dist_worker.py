@@ -16,6 +16,17 @@ from cortex.jl_amd import partition  # noqa: E402
 from tests.helpers import flood_oracle_from_model  # noqa: E402
 
 
+def _residual(sw):
+    """max |change| of the factor→variable messages (mean and variance) since the last call"""
+    cur = np.concatenate([sw.g.f2v_m, sw.g.f2v_v])
+    prev = getattr(sw, "_prev", None)
+    sw._prev = cur.copy()
+    if prev is None:
+        return float("inf")
+    both = ~np.isnan(cur) & ~np.isnan(prev)
+    return float(np.max(np.abs(cur[both] - prev[both]))) if both.any() else float("inf")
+
+
 class OracleSweeper:
     def __init__(self, part, seed_variance):
         self.g = g = flood_oracle_from_model(part.model, seed_variance)
@@ -40,6 +51,9 @@ class OracleSweeper:
         self.g.v2f_v[self.recv_e] = self.recv[:n, 1].numpy()
         self.g.sweep(1, phases=2)
 
+    def residual(self):
+        return _residual(self)
+
 
 class OracleStateSweeper:
     """Deep halo with the CPU checker as the sweeper: the exchanged state is the factor→variable messages."""
@@ -61,27 +75,21 @@ class OracleStateSweeper:
         self.g.f2v_m[self.recv_e] = self.recv[:n, 0].numpy()
         self.g.f2v_v[self.recv_e] = self.recv[:n, 1].numpy()
 
-    def sweep(self):
-        self.g.sweep(1)
+    def sweep(self, n=1):
+        self.g.sweep(n)
 
     def residual(self):
-        """max |change| of the factor→variable messages (mean and variance) since the last call"""
-        cur = np.concatenate([self.g.f2v_m, self.g.f2v_v])
-        prev = getattr(self, "_prev", None)
-        self._prev = cur.copy()
-        if prev is None:
-            return float("inf")
-        both = ~np.isnan(cur) & ~np.isnan(prev)
-        return float(np.max(np.abs(cur[both] - prev[both]))) if both.any() else float("inf")
+        return _residual(self)
 
 
 def main():
     rows, cols, sweeps, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     depth = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    strong = len(sys.argv) > 6 and sys.argv[6] == "strong"    # `rows` is then the whole grid's row count (uneven blocks)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     if depth:
-        part = partition.grid_strip_deep(rows, cols, rank, world, depth, seed=99)
+        part = (partition.grid_rows_deep if strong else partition.grid_strip_deep)(rows, cols, rank, world, depth, seed=99)
         sw = OracleStateSweeper(part, 1e6)
         ex = partition.DeepHaloExchange(sw, part, dist)
         if sweeps < 0:        # convergence mode: sweep to a global residual instead of a fixed count
@@ -90,11 +98,14 @@ def main():
         else:
             ex.sweep(sweeps)
     else:
-        part = partition.grid_strip(rows, cols, rank, world, seed=99)
+        part = (partition.grid_rows if strong else partition.grid_strip)(rows, cols, rank, world, seed=99)
         sw = OracleSweeper(part, 1e6)
         ex = partition.HaloExchange(sw, part, dist)
-        for _ in range(sweeps):
-            ex.sweep()
+        if sweeps < 0:        # the per-sweep message halo under the convergence loop (HaloExchange.sweep(k))
+            n_run, res = partition.converge(ex, sw.residual, dist, torch, 1e-12, 4000, 5)
+            np.save(out + f".rank{rank}.conv.npy", np.array([n_run, res]))
+        else:
+            ex.sweep(sweeps)
     # the audit bench.py runs after its timed region: must pass on a correct exchange and fail on a corrupted buffer
     audit_ok = partition.verify_last_exchange(part, sw.send, sw.recv, dist, torch)
     if rank == 0:

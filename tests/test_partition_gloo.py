@@ -246,13 +246,15 @@ def test_generic_deep_partition_of_random_sparse_graphs(seed, world, depth):
             assert np.array_equal(getattr(sw.g, name)[own], getattr(g, name)[e], equal_nan=True), name
 
 
-def test_gloo_partitioned_convergence_with_the_residual_all_reduce(tmp_path):
-    """partition.converge over gloo: three ranks with a deep halo sweep until the globally reduced residual is below 1e-12 —
-    all ranks stop after the same number of sweeps — and the owned marginal means then equal the dense solve of the whole
-    grid (loopy Gaussian BP means are exact at convergence)."""
+@pytest.mark.parametrize("depth", [2, 0])
+def test_gloo_partitioned_convergence_with_the_residual_all_reduce(tmp_path, depth):
+    """partition.converge over gloo: three ranks — deep halo (depth 2) or one message halo per sweep (depth 0, the
+    HaloExchange.sweep(k) path) — sweep until the globally reduced residual is below 1e-12; all ranks stop after the same
+    number of sweeps, and the owned marginal means then equal the dense solve of the whole grid (loopy Gaussian BP means
+    are exact at convergence)."""
     from oracle import exact
 
-    rows, cols, world, depth = 4, 7, 3, 2
+    rows, cols, world = 4, 7, 3
     out = str(tmp_path / "res")
     port = _free_port()
     procs = []
@@ -260,7 +262,7 @@ def test_gloo_partitioned_convergence_with_the_residual_all_reduce(tmp_path):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(rows), str(cols),
-                                       "-1", out, str(depth)], env=env, cwd=ROOT))
+                                       "-1", out, str(depth)], env=env, cwd=ROOT))   # depth 0 is parsed as "no deep halo"
     try:
         for p in procs:
             assert p.wait(timeout=240) == 0
@@ -279,3 +281,69 @@ def test_gloo_partitioned_convergence_with_the_residual_all_reduce(tmp_path):
         li = np.searchsorted(d["var_ids"], d["owned"])
         np.testing.assert_allclose(d["marg_m"][li], mean[d["owned"] - 1], rtol=1e-9)
     assert len(runs) == 1          # the all-reduce makes the decision common
+
+
+@pytest.mark.parametrize("world,depth", [(3, 0), (3, 2), (2, 3)])
+def test_gloo_strong_scaling_cut_of_one_grid(tmp_path, world, depth):
+    """BASELINE config 4's shape: ONE grid cut into `world` near-equal row blocks (10 rows over 3 ranks: 3 / 3 / 4), as
+    bench.py --gpus N does by default (partition.grid_rows / grid_rows_deep).  Owned messages and marginals equal the
+    single-process sweep bit for bit."""
+    rows, cols, sweeps = 10 if world == 3 else 7, 6, 8
+    out = str(tmp_path / "res")
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(rows), str(cols),
+                                       str(sweeps), out, str(depth), "strong"], env=env, cwd=ROOT))
+    try:
+        for p in procs:
+            assert p.wait(timeout=240) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    whole = cx.synth.gaussian_grid(rows, cols, seed=99)
+    g = flood_oracle_from_model(whole, 1e6)
+    g.sweep(sweeps)
+    gm, gv = g.marginals()
+    key = lambda v, f: v.astype(np.int64) * (1 << 32) + f  # noqa: E731
+    gkey = key(g.edge_var, g.edge_fac)
+    order = np.argsort(gkey)
+    owned_all = []
+    for r in range(world):
+        d = np.load(out + f".rank{r}.npz")
+        assert bool(d["audit_ok"]) and not bool(d["audit_bad"])
+        own = np.isin(d["edge_var"], d["owned"])
+        pos = order[np.searchsorted(gkey[order], key(d["edge_var"][own], d["edge_fac"][own]))]
+        for name in ("f2v_m", "f2v_v"):
+            a, b = d[name][own], getattr(g, name)[pos]
+            assert np.array_equal(a, b, equal_nan=True), f"{name} differs on rank {r}"
+        vi = np.searchsorted(g.var_ids, d["owned"])
+        li = np.searchsorted(d["var_ids"], d["owned"])
+        assert np.array_equal(d["marg_m"][li], gm[vi]) and np.array_equal(d["marg_v"][li], gv[vi])
+        owned_all.append(d["owned"])
+    assert np.array_equal(np.sort(np.concatenate(owned_all)), np.sort(whole.x_ids))
+    b = partition._row_bounds(rows, world)
+    assert [len(o) // cols for o in owned_all] == np.diff(b).tolist()
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher around it: the parent spawns N ranks (before importing torch or touching
+    a GPU), relays rank 0's line and returns 0; a rank that dies makes the whole run fail with its code.  --launch-check
+    stops after the rendezvous, so this runs without a GPU."""
+    import json
+
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-check"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    got = json.loads(line)
+    assert got == {"launcher": "ok", "world": 3, "sum_of_ranks_plus_one": 6}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-check"],
+                       env=dict(env, CX_BENCH_FAIL_RANK="2"), cwd=ROOT, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 7
+    assert "rank 2 exited with 7" in r.stderr
