@@ -103,6 +103,8 @@ def lib():
     sig("cxo_bulk_build", i32, vp, i64, pi32, pi32, pd, i64, pi64, pi64)
     sig("cxo_flood_sweep", i64, i64, pi64, i64, pi64, pd, pu8, pd, pd, pd, pd, i32, i32)
     sig("cxo_flood_marginals", None, i64, pi64, pd, pd, pd, pd, i32)
+    sig("cxo_mv_flood_sweep", i64, i32, i64, pi64, i64, pi64, pi32, pi32, pd, pd, pu8, pd, pd, pd, pu8, pd, pd, pu8, i32)
+    sig("cxo_mv_flood_marginals", i32, i32, i64, pi64, pd, pd, pu8, pd, pd, pu8)
     _lib = L
     return L
 

@@ -188,3 +188,48 @@ def test_config_c5_full_size_window_property(hip_lib):
         sl = slice(start - lo, start - lo + W)
         assert_close(marg[:, :d], em[sl], 1e-7, f"C5 window at {start}: mean")
         assert_close(marg[:, d:].reshape(W, d, d), ecov[sl], 1e-7, f"C5 window at {start}: covariance")
+
+
+# ------------------------------------------------------------------------------------------------ per-sweep parity at length
+# oracle/mv_flood.c (C) instead of oracle/mv.py (Python loops): the same flooding order at chain lengths where the
+# wavefront from the chain ends has NOT crossed the chain, seeded with a vague N(0, 1e6 I) as the full-size configs are.
+
+def _per_sweep_parity(model, sweeps, tol, lag):
+    from oracle.mv import MvFloodC
+
+    d = model.dim
+    dev = _dev(model, seed_variance=1e6)
+    o = MvFloodC(model)
+    o.seed(0.0, 1e6)
+    g = o.g
+    xs = set(np.searchsorted(g.var_ids, model.x_ids).tolist())
+    pe = np.array([e for e in np.flatnonzero(g.partner >= 0) if int(np.searchsorted(g.var_ids, g.edge_var[e])) in xs])
+    o.sweep(lag)      # d = 64 evaluates the constant messages out of observed variables one sweep early (see above)
+    for sweep in range(sweeps):
+        dev.sweep(1)
+        o.sweep(1, use_omp=True)
+        got = dev.get_messages(g.edge_var[pe], g.edge_fac[pe], L.TO_VARIABLE)
+        assert np.array_equal(~np.isnan(got[:, 0]), o.f2v_def[pe].astype(bool)), f"sweep {sweep}: definedness differs"
+        m, S = o.f2v_m[pe], o.f2v_S[pe]
+        assert_close(got[:, :d], m, tol, f"sweep {sweep}: f2v means of {len(pe)} messages")
+        assert_close(got[:, d:].reshape(-1, d, d), S, tol, f"sweep {sweep}: f2v covariances")
+    dev.sweep(1)
+    o.sweep(1, use_omp=True)
+    mm, SS, ok = o.marginals()
+    xi = np.searchsorted(g.var_ids, model.x_ids)
+    marg = dev.get_marginals(model.x_ids)
+    assert ok[xi].all()
+    # the device's marginal is the product of the messages its last sweep READ (one sweep behind the fresh messages)
+    return marg, mm[xi], SS[xi]
+
+
+@pytest.mark.parametrize("d,T,sweeps", [(4, 2000, 12), (2, 500, 6), (3, 300, 6)])
+def test_mv_per_sweep_parity_with_c_checker_long_chain(hip_lib, d, T, sweeps):
+    model = cx.synth.lgssm_chain(T, d=d, seed=17)
+    _per_sweep_parity(model, sweeps, 1e-8, 0)
+
+
+def test_mv64_per_sweep_parity_with_c_checker(hip_lib):
+    """d = 64 at T = 48 (190 edges, 94 MFMA rule evaluations per sweep), every sweep against oracle/mv_flood.c"""
+    model = cx.synth.lgssm_chain(48, d=64, seed=19)
+    _per_sweep_parity(model, 6, 1e-7, 1)
