@@ -247,7 +247,11 @@ int32_t cx_set_factor_matrices(cx_handle *h, int64_t parameter_set, const double
             ps.clear();
             return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_set_factor_matrices: Q is not symmetric positive definite");
         }
-        return h->has_graph ? upload_ptab(h) : CX_OK;
+        if (!h->has_graph) return CX_OK;
+        // the messages out of observed variables, N(A y, Q), are cached in both Jacobi buffers: new (A, Q) invalidates them
+        h->observed_passes_due = 2;
+        h->point64_dirty = true;
+        return upload_ptab(h);
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_set_factor_matrices: host allocation failed"); }
 }
 
@@ -808,7 +812,7 @@ int32_t mv_residual(cx_handle *h, double *out) {
     CX_HIP(h, hipMemcpyAsync(h->d_mv_prev, h->d_mv_f2v, (size_t)n * 8, hipMemcpyDeviceToDevice, h->stream));
     CX_HIP(h, hipStreamSynchronize(h->stream));
     double m = 0.0;
-    for (double p : part) m = std::max(m, p);
+    for (double p : part) m = (p != p) ? kInf : std::max(m, p);
     *out = m;
     return CX_OK;
 }
@@ -1189,7 +1193,7 @@ int32_t cx_residual(cx_handle *h, double *out) {
     CX_HIP(h, hipMemcpyAsync(h->d_prev, h->d_f2v, (size_t)h->nslots * 16, hipMemcpyDeviceToDevice, h->stream));
     CX_HIP(h, hipStreamSynchronize(h->stream));
     double m = 0.0;
-    for (double p : part) m = std::max(m, p);
+    for (double p : part) m = (p != p) ? kInf : std::max(m, p);
     *out = m;
     return CX_OK;
 }
@@ -1427,6 +1431,10 @@ uint64_t graph_fingerprint(const cx_handle *h) {
     f = fnv1a(f, h->var_off.data(), h->var_off.size() * 4);
     f = fnv1a(f, h->edge_fac_id.data(), h->edge_fac_id.size() * 8);
     f = fnv1a(f, h->fac_kind.data(), h->fac_kind.size() * 4);
+    // the rule parameters: a blob continues under the parameters it was exported with, or not at all
+    f = fnv1a(f, h->fac_params.data(), h->fac_params.size() * 8);
+    f = fnv1a(f, h->spdir.data(), h->spdir.size() * 4);
+    for (const auto &ps : h->psets) { const uint64_t n = ps.size(); f = fnv1a(f, &n, 8); f = fnv1a(f, ps.data(), ps.size() * 8); }
     return f;
 }
 
@@ -1513,6 +1521,13 @@ int32_t cx_state_import(cx_handle *h, const void *buf, int64_t bytes) {
         std::memcpy(&sc, o, sizeof sc); o += sizeof sc;
         CX_REQUIRE(h, sc.id == p.id && sc.bytes == p.bytes && end - o >= sc.bytes, CX_ERR_INVALID_ARGUMENT, "cx_state_import: truncated or foreign blob");
         o += sc.bytes;
+    }
+    // the vinfo section: only the observed flag is state; degree class and ghost flag are structure the kernels index by
+    {
+        const unsigned char *vi = (const unsigned char *)buf + sizeof hd + sizeof(StateSection);
+        for (int64_t v = 0; v < h->nv; v++)
+            CX_REQUIRE(h, (vi[v] & (uint8_t)~cx::kClamped) == (h->vinfo[v] & (uint8_t)~cx::kClamped), CX_ERR_INVALID_ARGUMENT,
+                       "cx_state_import: the blob's variable table does not match this handle's graph");
     }
     CX_HIP(h, hipSetDevice(h->cfg.device));
     CX_HIP(h, hipStreamSynchronize(h->stream));

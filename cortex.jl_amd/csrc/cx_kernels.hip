@@ -354,8 +354,10 @@ __global__ __launch_bounds__(kBlock) void k_residual(const double2 *__restrict__
         const bool da = !__builtin_isnan(a.y), db = !__builtin_isnan(b.y);
         if (da != db) m = __builtin_inf();
         else if (da) {
+            // a NaN difference (a mean that became inf - inf, a divergent loopy run) must not vanish in fmax: it never converges
             double2 ma = to_moment(a), mb = to_moment(b);
-            m = fmax(m, fmax(fabs(ma.x - mb.x), fabs(ma.y - mb.y)));
+            const double d = fmax(fabs(ma.x - mb.x), fabs(ma.y - mb.y));
+            m = (d != d || ma.x != ma.x || mb.x != mb.x) ? __builtin_inf() : fmax(m, d);
         }
     }
 #pragma unroll

@@ -337,7 +337,8 @@ __global__ __launch_bounds__(kBlock) void k_mv_residual(const double *__restrict
         const double a = cur[i], b = prev[i];
         const bool da = !__builtin_isnan(a), db = !__builtin_isnan(b);
         if (da != db) m = __builtin_inf();
-        else if (da) m = fmax(m, fabs(a - b));
+        else if (da) m = fmax(m, fabs(a - b));   // a, b defined: the difference is NaN only for inf - inf, caught below
+        if (da && db && (a - b) != (a - b) && a != b) m = __builtin_inf();
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmax(m, __shfl_xor(m, d, 64));

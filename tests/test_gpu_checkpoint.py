@@ -102,3 +102,38 @@ def test_foreign_and_damaged_blobs_are_refused(hip_lib):
     empty = cx.DeviceGraph()
     with pytest.raises(cx.CortexHipError):
         empty.export_state()
+
+
+def test_blob_of_other_rule_parameters_or_a_doctored_variable_table_is_refused(hip_lib):
+    """the fingerprint covers the factor parameters (same topology, other variances: refused) and the
+    imported variable table may differ from the handle's only in the observed flags."""
+    import dataclasses
+
+    model = cx.synth.gaussian_grid(8, 8, seed=5)
+    a = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(model, a, 1e6)
+    a.sweep(2)
+    blob = a.export_state()
+    other = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(dataclasses.replace(model, factor_var=model.factor_var * 1.5), other, 1e6)
+    with pytest.raises(cx.CortexHipError, match="different graph"):
+        other.import_state(blob)
+    # dim > 1: same chain, other (A, Q)
+    m4 = cx.synth.lgssm_chain(6, d=4, seed=3)
+    b = cx.DeviceGraph(dim=4)
+    cx.synth.load_into_device(m4, b)
+    b.sweep(2)
+    blob4 = b.export_state()
+    c = cx.DeviceGraph(dim=4)
+    A, Q = m4.psets[0]
+    cx.synth.load_into_device(dataclasses.replace(m4, psets={0: (A, 2.0 * Q), 1: m4.psets[1]}), c)
+    with pytest.raises(cx.CortexHipError, match="different graph"):
+        c.import_state(blob4)
+    # a blob whose variable table carries another degree nibble: refused before anything reaches the device
+    hdr = 8 + 4 * 4 + 5 * 8 + 2 * 4 + 8      # StateHeader (cx_api.hip), then one 16-byte section header, then vinfo
+    bad = blob.copy()
+    bad[hdr + 16] = (int(bad[hdr + 16]) & 0xF0) | ((int(bad[hdr + 16]) + 1) & 0x0F)
+    before = _all_messages(a, model, L.TO_VARIABLE)
+    with pytest.raises(cx.CortexHipError, match="variable table"):
+        a.import_state(bad)
+    assert _same(before, _all_messages(a, model, L.TO_VARIABLE))

@@ -233,3 +233,36 @@ def test_mv64_per_sweep_parity_with_c_checker(hip_lib):
     """d = 64 at T = 48 (190 edges, 94 MFMA rule evaluations per sweep), every sweep against oracle/mv_flood.c"""
     model = cx.synth.lgssm_chain(48, d=64, seed=19)
     _per_sweep_parity(model, 6, 1e-7, 1)
+
+
+@pytest.mark.parametrize("d,T", [(4, 40), (64, 6)])
+def test_new_rule_matrices_between_sweeps_refresh_the_cached_leaf_messages(hip_lib, d, T):
+    """ADVICE r01 (parameter learning / EM): cx_set_factor_matrices on a live handle.  The messages out of observed
+    variables, N(A y, Q), are cached in both Jacobi buffers; after new (A, Q) the handle must converge to the posterior
+    of the NEW parameters — the same marginals as a fresh handle built with them."""
+    import dataclasses
+
+    model = cx.synth.lgssm_chain(T, d=d, seed=23)
+    A1, R1 = model.psets[1]
+    R2 = 2.5 * R1
+    dev = _dev(model)
+    dev.sweep(T + 3)
+    dev.set_factor_matrices(1, A1, R2)       # the likelihood's noise changes: every leaf message N(y, R) is stale
+    dev.sweep(T + 3)
+    fresh = _dev(dataclasses.replace(model, psets={0: model.psets[0], 1: (A1, R2)}))
+    fresh.sweep(T + 3)
+    got, want = dev.get_marginals(model.x_ids), fresh.get_marginals(model.x_ids)
+    assert_close(got, want, 1e-10, "marginals after a parameter change vs a fresh handle")
+    em, ecov = exact.lgssm_posterior(model.data_y, model.meta["A"], model.meta["Q"], R2)
+    assert_close(got[:, :d], em, 1e-8 if d < 64 else 1e-7, "mean vs the exact smoother of the new parameters")
+
+
+def test_observed_variables_have_no_marginal_for_dim_gt_1(hip_lib):
+    """dim > 1 never computes the messages INTO observed variables (nobody reads them: lazy, like the reference), so the
+    product of incoming messages — the marginal — of an observed variable stays UndefValue().  (The scalar sweep computes
+    every message of the graph and therefore also those marginals.)"""
+    model = cx.synth.lgssm_chain(12, d=4, seed=2)
+    dev = _dev(model)
+    dev.sweep(15)
+    assert np.all(np.isnan(dev.get_marginals(model.data_var)))
+    assert not np.any(np.isnan(dev.get_marginals(model.x_ids)))

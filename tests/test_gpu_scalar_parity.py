@@ -272,3 +272,21 @@ def test_sweep_until_stops_at_the_requested_residual(hip_lib):
     assert n2 in (3, 7) and r2 <= 1e-12 or n2 == 7
     with pytest.raises(cx.CortexHipError):
         dev.sweep_until(-1.0, 10)
+
+
+def test_residual_of_a_numerically_broken_state_is_infinite(hip_lib):
+    """a message whose precision is defined but whose mean became NaN (inf - inf, a divergent run) must not
+    vanish in the max-reduction: cx_residual reports +inf, so cx_sweep_until / partition.converge never call it converged."""
+    model = cx.synth.gaussian_grid(12, 12, seed=3)
+    dev = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(model, dev, seed_variance=1e6)
+    dev.sweep(400)
+    dev.residual()
+    dev.sweep(2)
+    assert dev.residual() < 1e-9
+    # poison ONE pairwise message: natural form (xi = NaN, w = 1)
+    e = int(np.flatnonzero(model.factor_kind[np.searchsorted(model.factor_ids, model.edge_fac)] == L.FACTOR_GAUSS_ADDITIVE)[0])
+    dev.set_messages([model.edge_var[e]], [model.edge_fac[e]], L.TO_VARIABLE, L.FORM_NATURAL, [float("nan"), 1.0])
+    assert dev.residual() == float("inf")
+    n, r = dev.sweep_until(1e-9, 6, 2)
+    assert n == 6 and not (r <= 1e-9)     # the NaN spreads; never "converged"
