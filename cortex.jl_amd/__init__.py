@@ -19,7 +19,7 @@ from .dependencies import (AbstractDependencyResolver, DefaultDependencyResolver
                            resolve_dependencies)
 from .inference_engine import (AbstractInferenceRequestProcessor, InferenceEngine, InferenceRequestScanner,
                                request_inference_for, scan_inference_request, update_marginals)
-from .hip_processor import (Gamma, GaussianAdditive, GaussianLinear, HipProcessor, HipValue, HipVmpProcessor, HipVmpValue,
+from .hip_processor import (Beta, Gamma, GaussianAdditive, GaussianLinear, HipProcessor, HipValue, HipVmpProcessor, HipVmpValue,
                             NormalMeanPrecision, NormalMeanVariance, NormalPrecisionFactor)
 
 __all__ = [n for n in dir() if not n.startswith("__")]

@@ -16,8 +16,9 @@ ERR_INVALID_ARGUMENT, ERR_NOT_FOUND, ERR_UNSUPPORTED, ERR_STATE, ERR_DEVICE, ERR
     -1, -2, -3, -4, -5, -6, -7)
 TO_FACTOR, TO_VARIABLE = 1, 2
 ITEM_MESSAGE_TO_FACTOR, ITEM_MESSAGE_TO_VARIABLE, ITEM_INDIVIDUAL_MARGINAL = 1, 2, 4
+ITEM_PRODUCT_OF_MESSAGES, ITEM_JOINT_MARGINAL = 8, 16
 FORM_MOMENT, FORM_POINT, FORM_NATURAL, FORM_MEAN_PRECISION, FORM_GAMMA = 0, 1, 2, 3, 4
-FACTOR_OPAQUE, FACTOR_GAUSS_ADDITIVE, FACTOR_GAUSS_LINEAR, FACTOR_NORMAL_PRECISION = 0, 1, 2, 3
+FACTOR_OPAQUE, FACTOR_GAUSS_ADDITIVE, FACTOR_GAUSS_LINEAR, FACTOR_NORMAL_PRECISION, FACTOR_BERNOULLI = 0, 1, 2, 3, 4
 NPARAM = 4
 ROLE_OUT, ROLE_IN, ROLE_PRECISION = 0, 1, 2
 SCHED_FLOODING, SCHED_FUSED, SCHED_CHAIN_SCAN = 0, 1, 2
@@ -65,6 +66,8 @@ SIGNATURES = {
     "cx_seed_messages": (_i32, [_vp, _i32, _dbl, _dbl]),
     "cx_get_marginals": (_i32, [_vp, _i64, _pi64, _pd]),
     "cx_update_batch": (_i32, [_vp, C.POINTER(Item), _i64]),
+    "cx_get_products": (_i32, [_vp, _i64, _pi64, _pi32, _pi32, _i32, _pd]),
+    "cx_get_joint_marginals": (_i32, [_vp, _i64, _pi64, _pd]),
     "cx_sweep": (_i32, [_vp, _i32]),
     "cx_residual": (_i32, [_vp, _pd]),
     "cx_halo_configure": (_i32, [_vp, _i64, _pi64, _pi64, _i64, _pi64, _pi64]),
@@ -91,6 +94,11 @@ SIGNATURES = {
     "cx_profile_read": (_i32, [_vp, _i32, _pd, _pi64]),
     "cx_kernel_name": (C.c_char_p, [_i32]),
 }
+
+def item_range(lo: int, hi: int) -> int:
+    """CX_ITEM_RANGE(lo, hi): the 1-based inclusive range of a ProductOfMessages item, as it travels in cx_item.factor_id"""
+    return (int(lo) << 32) | int(hi)
+
 
 _lib = None
 

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <map>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -113,6 +115,15 @@ struct cx_handle {
     bool in_sweep = false;
     bool v2f_stale = false;          // fused schedule without materialisation: v2f must be recomputed before use
 
+    // stores of the batched API's intermediates: ProductOfMessages nodes (variable, lo, hi) and JointMarginal nodes (factor)
+    std::map<std::tuple<int32_t, int32_t, int32_t>, int32_t> prod_index;
+    std::map<int32_t, int32_t> joint_index;
+    std::vector<uint8_t> lin_out_is_second;   // per factor (GAUSS_LINEAR): the OUT edge is the edge of the higher variable id
+    std::vector<int32_t> fac_edges;           // [2 nf] CSR edges of each (≤ 2-edge) factor, built on first use
+    double2 *d_prod = nullptr;
+    double *d_joint = nullptr;
+    int64_t prod_cap = 0, joint_cap = 0;
+
     // variational families (cx_vmp.hip): opaque state
     void *vmp = nullptr;
 
@@ -145,7 +156,7 @@ void launch_factor_to_var(cx_handle *h, const double2 *v2f, double2 *f2v);
 void launch_push_slots(cx_handle *h, const int32_t *d_slots, int64_t n, double2 *f2v_out, int kernel_id);
 void launch_halo_export(cx_handle *h, const double2 *f2v, hipStream_t stream);
 void launch_halo_import(cx_handle *h, double2 *f2v_out, bool push);
-void launch_batch(cx_handle *h, const int32_t *d_kind, const int32_t *d_index, const int32_t *d_var, int64_t n);
+void launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n);   // 5 int32 per item: kind, index, var, lo, hi
 void launch_scatter(cx_handle *h, double2 *dst, const int32_t *d_idx, const double2 *d_val, int64_t n);
 void launch_gather(cx_handle *h, const double2 *src, const int32_t *d_idx, double2 *d_val, int64_t n);
 void launch_seed(cx_handle *h, double2 *buf, int64_t n, double2 value, const int32_t *partner);

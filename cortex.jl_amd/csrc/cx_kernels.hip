@@ -61,9 +61,19 @@ __device__ __forceinline__ double2 nan2() { return make_double2(__builtin_nan(""
 //   moment form:  N(a m + b, a² v + q)        [a=1, b=0: test/inference_engine_tests.jl:426-427]
 //   natural form: s = 1/(a² + q w);  w' = w s;  xi' = (a xi + b w) s
 //   point mass y: N(a y + b, q)               [:424-425]
-template <bool LINEAR>
+//   MODE 2 (CX_FAMILY_NATURAL2, CX_FACTOR_BERNOULLI): the other edge carries an observed Bool r as a point mass; the message
+//   is Beta(1 + r, 2 - r) (test/inference_engine_tests.jl:256-258) = natural parameters (r, 1 - r).  Without a datum the
+//   reference's rule is error("Unreachable reached"): the output stays undefined.
+constexpr int kRuleAdditive = 0, kRuleLinear = 1, kRuleBernoulli = 2;
+template <int MODE>
 __device__ __forceinline__ double2 factor_rule(double2 m, double q, double a, double b) {
+    constexpr bool LINEAR = MODE == kRuleLinear;
     double2 o;
+    if (MODE == kRuleBernoulli) {
+        if (m.y == __builtin_inf()) { o.x = m.x; o.y = 1.0 - m.x; }
+        else o = make_double2(__builtin_nan(""), __builtin_nan(""));
+        return o;
+    }
     if (m.y == __builtin_inf()) {
         double mean = LINEAR ? (a * m.x + b) : m.x;
         o.y = 1.0 / q;
@@ -82,7 +92,7 @@ __device__ __forceinline__ double2 to_moment(double2 nat) {
 }
 
 // store one fresh variable→factor message and/or push it through its factor to the partner slot
-template <bool LINEAR, bool STORE_V2F, bool PUSH>
+template <int MODE, bool STORE_V2F, bool PUSH>
 __device__ __forceinline__ void emit(int slot, double2 o, const int32_t *__restrict__ partner, const double *__restrict__ sq,
                                      const double *__restrict__ sa, const double *__restrict__ sb, double2 *__restrict__ f2v_out,
                                      double2 *__restrict__ v2f) {
@@ -90,7 +100,10 @@ __device__ __forceinline__ void emit(int slot, double2 o, const int32_t *__restr
     if (STORE_V2F) v2f[slot] = o;
     if (PUSH) {
         const int p = partner[slot];
-        if (p >= 0) f2v_out[p] = factor_rule<LINEAR>(o, sq[slot], LINEAR ? sa[slot] : 1.0, LINEAR ? sb[slot] : 0.0);
+        if (p >= 0) {
+            const double2 r = factor_rule<MODE>(o, sq[slot], MODE == kRuleLinear ? sa[slot] : 1.0, MODE == kRuleLinear ? sb[slot] : 0.0);
+            if (MODE != kRuleBernoulli || !__builtin_isnan(r.y)) f2v_out[p] = r;
+        }
     }
 }
 
@@ -107,7 +120,7 @@ __device__ __forceinline__ void emit(int slot, double2 o, const int32_t *__restr
 // OTHER factor→variable buffer (Jacobi double buffering): the whole sweep is this one launch.
 // !PUSH: phase A of the two-phase flooding schedule (stores variable→factor messages only).
 // ------------------------------------------------------------------------------------------------
-template <bool LINEAR, bool STORE_V2F, bool PUSH>
+template <int MODE, bool STORE_V2F, bool PUSH>
 __global__ __launch_bounds__(kBlock) void k_sweep(int nv, const int32_t *__restrict__ slice_off, const uint8_t *__restrict__ vinfo,
                                                   const int32_t *__restrict__ partner, const double *__restrict__ sq,
                                                   const double *__restrict__ sa, const double *__restrict__ sb,
@@ -152,19 +165,19 @@ __global__ __launch_bounds__(kBlock) void k_sweep(int nv, const int32_t *__restr
     if (!fixed) {
 #pragma unroll
         for (int k = 0; k < kSmallDeg; k++)
-            if (k < deg) emit<LINEAR, STORE_V2F, PUSH>(base + k * kBlock, out[k], partner, sq, sa, sb, f2v_out, v2f);
+            if (k < deg) emit<MODE, STORE_V2F, PUSH>(base + k * kBlock, out[k], partner, sq, sa, sb, f2v_out, v2f);
     } else if (PUSH) {
         // separate path (not a select on the message) so that out[] never has its address taken
 #pragma unroll
         for (int k = 0; k < kSmallDeg; k++)
-            if (k < deg) emit<LINEAR, false, true>(base + k * kBlock, v2f[base + k * kBlock], partner, sq, sa, sb, f2v_out, v2f);
+            if (k < deg) emit<MODE, false, true>(base + k * kBlock, v2f[base + k * kBlock], partner, sq, sa, sb, f2v_out, v2f);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Phase B of the two-phase flooding schedule: factor → variable by pulling from the partner slot.
 // ------------------------------------------------------------------------------------------------
-template <bool LINEAR>
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_factor_to_var(int nslots, const int32_t *__restrict__ partner,
                                                           const double *__restrict__ q, const double *__restrict__ pa,
                                                           const double *__restrict__ pb, const double2 *__restrict__ v2f,
@@ -175,7 +188,8 @@ __global__ __launch_bounds__(kBlock) void k_factor_to_var(int nslots, const int3
     if (p < 0) return;
     const double2 m = v2f[p];
     if (__builtin_isnan(m.y)) return;  // dependency not computed: not pending, keep the old value
-    f2v[e] = factor_rule<LINEAR>(m, q[e], LINEAR ? pa[e] : 1.0, LINEAR ? pb[e] : 0.0);
+    const double2 r = factor_rule<MODE>(m, q[e], MODE == kRuleLinear ? pa[e] : 1.0, MODE == kRuleLinear ? pb[e] : 0.0);
+    if (MODE != kRuleBernoulli || !__builtin_isnan(r.y)) f2v[e] = r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void k_big_var_to_factor(const int32_t *__r
 
 // push the stored variable→factor messages of a list of slots through their factors
 // (big variables in the fused schedule; ghost variables once the halo has arrived)
-template <bool LINEAR>
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_push_slots(const int32_t *__restrict__ slots, int64_t n, const int32_t *__restrict__ partner,
                                                        const double *__restrict__ sq, const double *__restrict__ sa,
                                                        const double *__restrict__ sb, const double2 *__restrict__ v2f,
@@ -246,7 +260,8 @@ __global__ __launch_bounds__(kBlock) void k_push_slots(const int32_t *__restrict
     if (p < 0) return;
     const double2 o = v2f[e];
     if (__builtin_isnan(o.y)) return;
-    f2v_out[p] = factor_rule<LINEAR>(o, sq[e], LINEAR ? sa[e] : 1.0, LINEAR ? sb[e] : 0.0);
+    const double2 r = factor_rule<MODE>(o, sq[e], MODE == kRuleLinear ? sa[e] : 1.0, MODE == kRuleLinear ? sb[e] : 0.0);
+    if (MODE != kRuleBernoulli || !__builtin_isnan(r.y)) f2v_out[p] = r;
 }
 
 // variable→factor for one slot of variable v (sequential sums in the order of the sweep kernel)
@@ -278,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void k_halo_export(const int32_t *__restric
 }
 
 // halo import: received messages become the ghost variables' variable→factor messages and go through the cut factors
-template <bool LINEAR, bool PUSH>
+template <int MODE, bool PUSH>
 __global__ __launch_bounds__(kBlock) void k_halo_import(const int32_t *__restrict__ slots, int64_t n, const double2 *__restrict__ recv,
                                                         const int32_t *__restrict__ partner, const double *__restrict__ sq,
                                                         const double *__restrict__ sa, const double *__restrict__ sb,
@@ -291,23 +306,36 @@ __global__ __launch_bounds__(kBlock) void k_halo_import(const int32_t *__restric
     if (!PUSH) return;
     const int p = partner[e];
     if (p < 0 || __builtin_isnan(o.y)) return;
-    f2v_out[p] = factor_rule<LINEAR>(o, sq[e], LINEAR ? sa[e] : 1.0, LINEAR ? sb[e] : 0.0);
+    const double2 r = factor_rule<MODE>(o, sq[e], MODE == kRuleLinear ? sa[e] : 1.0, MODE == kRuleLinear ? sb[e] : 0.0);
+    if (MODE != kRuleBernoulli || !__builtin_isnan(r.y)) f2v_out[p] = r;
 }
 
 // ------------------------------------------------------------------------------------------------
 // Batched mode: one thread per enqueued signal (the processor's `process!` override flushes a batch of
 // mutually independent pending signals; inference_engine.jl:528-537 is the precedent for collecting).
 // ------------------------------------------------------------------------------------------------
-template <bool LINEAR>
-__global__ __launch_bounds__(kBlock) void k_batch(int64_t n, const int32_t *__restrict__ kind, const int32_t *__restrict__ index,
-                                                  const int32_t *__restrict__ var, const int32_t *__restrict__ vbase,
+// Item record (5 int32): kind, index, var, lo, hi.
+//   MESSAGE_TO_FACTOR / MESSAGE_TO_VARIABLE: index = slot, var = local variable
+//   INDIVIDUAL_MARGINAL:                     index = var = local variable
+//   PRODUCT_OF_MESSAGES (compute_product_of_messages!, inference_engine.jl:439-449; the segment-tree intermediates of
+//                        dependencies.jl:128-173): index = node in the product store, var = local variable, [lo, hi] = 1-based
+//                        inclusive range over the variable's neighbours (ascending factor id); value = product of those
+//                        factor→variable messages (natural form: their sum, left to right like the reference's fold)
+//   JOINT_MARGINAL (compute_joint_marginal!, :469-477): index = node in the joint store, var = slot of the factor's edge whose
+//                        rule parameters describe x_out = a x_in + b + N(0, q) (the OUT edge; either edge of an additive
+//                        factor), lo = slot of the other edge, hi = 1 when the OUT edge's variable has the LOWER id (output
+//                        order is ascending variable id).  Value: the 2-d Gaussian proportional to factor x the two
+//                        variable→factor messages, as mean[2] + covariance[4].
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_batch(int64_t n, const int32_t *__restrict__ rec, const int32_t *__restrict__ vbase,
                                                   const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
                                                   const int32_t *__restrict__ partner, const double *__restrict__ q,
                                                   const double *__restrict__ pa, const double *__restrict__ pb,
-                                                  double2 *__restrict__ f2v, double2 *__restrict__ v2f, double2 *__restrict__ marg, int nat_marg) {
+                                                  double2 *__restrict__ f2v, double2 *__restrict__ v2f, double2 *__restrict__ marg, int nat_marg,
+                                                  double2 *__restrict__ prod, double *__restrict__ joint) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const int k = kind[i], idx = index[i], v = var[i];
+    const int k = rec[5 * i], idx = rec[5 * i + 1], v = rec[5 * i + 2], lo = rec[5 * i + 3], hi = rec[5 * i + 4];
     if (k == CX_ITEM_MESSAGE_TO_FACTOR) {
         m2f_one(idx, v, vbase, vdeg, vinfo, f2v, v2f);
     } else if (k == CX_ITEM_MESSAGE_TO_VARIABLE) {
@@ -315,7 +343,8 @@ __global__ __launch_bounds__(kBlock) void k_batch(int64_t n, const int32_t *__re
         if (p < 0) return;
         const double2 m = v2f[p];
         if (__builtin_isnan(m.y)) return;
-        f2v[idx] = factor_rule<LINEAR>(m, q[idx], LINEAR ? pa[idx] : 1.0, LINEAR ? pb[idx] : 0.0);
+        const double2 r = factor_rule<MODE>(m, q[idx], MODE == kRuleLinear ? pa[idx] : 1.0, MODE == kRuleLinear ? pb[idx] : 0.0);
+        if (MODE != kRuleBernoulli || !__builtin_isnan(r.y)) f2v[idx] = r;
     } else if (k == CX_ITEM_INDIVIDUAL_MARGINAL) {
         const int deg = vdeg[v];
         const int stride = ((vinfo[v] & kDegMask) == kBigDeg) ? 1 : kBlock;
@@ -323,6 +352,38 @@ __global__ __launch_bounds__(kBlock) void k_batch(int64_t n, const int32_t *__re
         double2 acc = zero2();
         for (int j = 0; j < deg; j++) acc = add2(acc, f2v[b + j * stride]);
         marg[v] = (deg > 0) ? (nat_marg ? acc : to_moment(acc)) : nan2();
+    } else if (k == CX_ITEM_PRODUCT_OF_MESSAGES) {
+        const int stride = ((vinfo[v] & kDegMask) == kBigDeg) ? 1 : kBlock;
+        const int b = vbase[v];
+        double2 acc = zero2();
+        for (int j = lo - 1; j < hi; j++) acc = add2(acc, f2v[b + j * stride]);
+        if (!__builtin_isnan(acc.y)) prod[idx] = acc;     // a dependency is undefined: not pending, keep the stored value
+    } else if (k == CX_ITEM_JOINT_MARGINAL) {
+        if (MODE == kRuleBernoulli) return;
+        const int s_out = v, s_in = lo;
+        const double2 m_in = v2f[s_in], m_out = v2f[s_out];
+        double *o = joint + 6 * (int64_t)idx;
+        if (__builtin_isnan(m_in.y) || __builtin_isnan(m_out.y)) return;
+        const double a = MODE == kRuleLinear ? pa[s_out] : 1.0, b = MODE == kRuleLinear ? pb[s_out] : 0.0, iq = 1.0 / q[s_out];
+        double mi, mo, cii, cio, coo;
+        const double inf = __builtin_inf();
+        if (m_in.y == inf && m_out.y == inf) { mi = m_in.x; mo = m_out.x; cii = cio = coo = 0.0; }
+        else if (m_in.y == inf) {          // x_in observed: x_out | x_in
+            mi = m_in.x; cii = cio = 0.0;
+            coo = 1.0 / (m_out.y + iq); mo = coo * (m_out.x + (a * mi + b) * iq);
+        } else if (m_out.y == inf) {       // x_out observed
+            mo = m_out.x; coo = cio = 0.0;
+            cii = 1.0 / (m_in.y + a * a * iq); mi = cii * (m_in.x + a * (mo - b) * iq);
+        } else {
+            // precision [[w_in + a²/q, -a/q], [-a/q, w_out + 1/q]], potential [xi_in - a b/q, xi_out + b/q]
+            const double l11 = m_in.y + a * a * iq, l12 = -a * iq, l22 = m_out.y + iq;
+            const double e1 = m_in.x - a * b * iq, e2 = m_out.x + b * iq;
+            const double idet = 1.0 / (l11 * l22 - l12 * l12);
+            cii = l22 * idet; cio = -l12 * idet; coo = l11 * idet;
+            mi = cii * e1 + cio * e2; mo = cio * e1 + coo * e2;
+        }
+        if (hi) { o[0] = mo; o[1] = mi; o[2] = coo; o[3] = cio; o[4] = cio; o[5] = cii; }
+        else    { o[0] = mi; o[1] = mo; o[2] = cii; o[3] = cio; o[4] = cio; o[5] = coo; }
     }
 }
 
@@ -392,7 +453,11 @@ static inline void prof_end(cx_handle *h) {
     (void)hipEventRecord(h->recs.back().stop, h->prof_stream);
 }
 
-template <bool LINEAR, bool STORE, bool PUSH>
+static inline int rule_mode(const cx_handle *h) {
+    return h->cfg.family == CX_FAMILY_NATURAL2 ? kRuleBernoulli : (h->any_linear ? kRuleLinear : kRuleAdditive);
+}
+
+template <int LINEAR, bool STORE, bool PUSH>
 static void launch_sweep_t(cx_handle *h, const double2 *f2v_in, double2 *f2v_out, bool write_marg, bool skip_ghosts) {
     const double *sq = h->any_linear ? h->d_sq : h->d_q;  // additive factors: q is symmetric in the two edges
     hipLaunchKernelGGL((k_sweep<LINEAR, STORE, PUSH>), dim3((unsigned)h->nslices), dim3(kBlock), 0, h->stream, (int)h->nv,
@@ -403,20 +468,18 @@ static void launch_sweep_t(cx_handle *h, const double2 *f2v_in, double2 *f2v_out
 void launch_fused(cx_handle *h, const double2 *f2v_in, double2 *f2v_out, bool write_marg, bool store_v2f, bool skip_ghosts) {
     if (h->nslices == 0) return;
     prof_begin(h, CX_KERNEL_FUSED);
-    if (h->any_linear) {
-        if (store_v2f) launch_sweep_t<true, true, true>(h, f2v_in, f2v_out, write_marg, skip_ghosts);
-        else launch_sweep_t<true, false, true>(h, f2v_in, f2v_out, write_marg, skip_ghosts);
-    } else {
-        if (store_v2f) launch_sweep_t<false, true, true>(h, f2v_in, f2v_out, write_marg, skip_ghosts);
-        else launch_sweep_t<false, false, true>(h, f2v_in, f2v_out, write_marg, skip_ghosts);
-    }
+    const int mode = rule_mode(h);
+#define CX_F(M) do { if (store_v2f) launch_sweep_t<M, true, true>(h, f2v_in, f2v_out, write_marg, skip_ghosts); \
+                     else launch_sweep_t<M, false, true>(h, f2v_in, f2v_out, write_marg, skip_ghosts); } while (0)
+    if (mode == kRuleLinear) CX_F(kRuleLinear); else if (mode == kRuleBernoulli) CX_F(kRuleBernoulli); else CX_F(kRuleAdditive);
+#undef CX_F
     prof_end(h);
 }
 
 void launch_var_to_factor(cx_handle *h, const double2 *f2v, bool write_marg) {
     if (h->nslices == 0) return;
     prof_begin(h, CX_KERNEL_VAR_TO_FACTOR);
-    launch_sweep_t<false, true, false>(h, f2v, nullptr, write_marg, false);
+    launch_sweep_t<kRuleAdditive, true, false>(h, f2v, nullptr, write_marg, false);   // no factor rule in this phase
     prof_end(h);
 }
 
@@ -436,10 +499,14 @@ void launch_factor_to_var(cx_handle *h, const double2 *v2f, double2 *f2v) {
     if (n == 0) return;
     const int nb = (n + kBlock - 1) / kBlock;
     prof_begin(h, CX_KERNEL_FACTOR_TO_VAR);
-    if (h->any_linear)
-        hipLaunchKernelGGL(k_factor_to_var<true>, dim3(nb), dim3(kBlock), 0, h->stream, n, h->d_partner, h->d_q, h->d_a, h->d_b, v2f, f2v);
+    const int mode = rule_mode(h);
+    if (mode == kRuleLinear)
+        hipLaunchKernelGGL(k_factor_to_var<kRuleLinear>, dim3(nb), dim3(kBlock), 0, h->stream, n, h->d_partner, h->d_q, h->d_a, h->d_b, v2f, f2v);
+    else if (mode == kRuleBernoulli)
+        hipLaunchKernelGGL(k_factor_to_var<kRuleBernoulli>, dim3(nb), dim3(kBlock), 0, h->stream, n, h->d_partner, h->d_q,
+                           (const double *)nullptr, (const double *)nullptr, v2f, f2v);
     else
-        hipLaunchKernelGGL(k_factor_to_var<false>, dim3(nb), dim3(kBlock), 0, h->stream, n, h->d_partner, h->d_q,
+        hipLaunchKernelGGL(k_factor_to_var<kRuleAdditive>, dim3(nb), dim3(kBlock), 0, h->stream, n, h->d_partner, h->d_q,
                            (const double *)nullptr, (const double *)nullptr, v2f, f2v);
     prof_end(h);
 }
@@ -449,11 +516,15 @@ void launch_push_slots(cx_handle *h, const int32_t *d_slots, int64_t n, double2 
     const double *sq = h->any_linear ? h->d_sq : h->d_q;
     const int nb = (int)((n + kBlock - 1) / kBlock);
     prof_begin(h, kernel_id);
-    if (h->any_linear)
-        hipLaunchKernelGGL(k_push_slots<true>, dim3(nb), dim3(kBlock), 0, h->stream, d_slots, n, h->d_partner, sq, h->d_sa, h->d_sb,
+    const int mode = rule_mode(h);
+    if (mode == kRuleLinear)
+        hipLaunchKernelGGL(k_push_slots<kRuleLinear>, dim3(nb), dim3(kBlock), 0, h->stream, d_slots, n, h->d_partner, sq, h->d_sa, h->d_sb,
                            h->d_v2f, f2v_out);
+    else if (mode == kRuleBernoulli)
+        hipLaunchKernelGGL(k_push_slots<kRuleBernoulli>, dim3(nb), dim3(kBlock), 0, h->stream, d_slots, n, h->d_partner, sq,
+                           (const double *)nullptr, (const double *)nullptr, h->d_v2f, f2v_out);
     else
-        hipLaunchKernelGGL(k_push_slots<false>, dim3(nb), dim3(kBlock), 0, h->stream, d_slots, n, h->d_partner, sq,
+        hipLaunchKernelGGL(k_push_slots<kRuleAdditive>, dim3(nb), dim3(kBlock), 0, h->stream, d_slots, n, h->d_partner, sq,
                            (const double *)nullptr, (const double *)nullptr, h->d_v2f, f2v_out);
     prof_end(h);
 }
@@ -474,23 +545,23 @@ void launch_halo_import(cx_handle *h, double2 *f2v_out, bool push) {
     const dim3 g((unsigned)((n + kBlock - 1) / kBlock)), b(kBlock);
     prof_begin(h, CX_KERNEL_HALO_END);
 #define CX_IMP(LIN, PU) hipLaunchKernelGGL((k_halo_import<LIN, PU>), g, b, 0, h->stream, h->d_recv_slots, n, h->d_recv_buf, h->d_partner, sq, h->d_sa, h->d_sb, h->d_v2f, f2v_out)
-    if (h->any_linear) { if (push) CX_IMP(true, true); else CX_IMP(true, false); }
-    else { if (push) CX_IMP(false, true); else CX_IMP(false, false); }
+    if (h->any_linear) { if (push) CX_IMP(kRuleLinear, true); else CX_IMP(kRuleLinear, false); }
+    else { if (push) CX_IMP(kRuleAdditive, true); else CX_IMP(kRuleAdditive, false); }
 #undef CX_IMP
     prof_end(h);
 }
 
-void launch_batch(cx_handle *h, const int32_t *d_kind, const int32_t *d_index, const int32_t *d_var, int64_t n) {
+void launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n) {
     if (n == 0) return;
     const int nb = (int)((n + kBlock - 1) / kBlock);
     prof_begin(h, CX_KERNEL_BATCH);
-    if (h->any_linear)
-        hipLaunchKernelGGL(k_batch<true>, dim3(nb), dim3(kBlock), 0, h->stream, n, d_kind, d_index, d_var, h->d_vbase, h->d_var_deg,
-                           h->d_vinfo, h->d_partner, h->d_q, h->d_a, h->d_b, h->d_f2v, h->d_v2f, h->d_marg, h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0);
-    else
-        hipLaunchKernelGGL(k_batch<false>, dim3(nb), dim3(kBlock), 0, h->stream, n, d_kind, d_index, d_var, h->d_vbase, h->d_var_deg,
-                           h->d_vinfo, h->d_partner, h->d_q, (const double *)nullptr, (const double *)nullptr, h->d_f2v, h->d_v2f,
-                           h->d_marg, h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0);
+    const int mode = rule_mode(h), nat = h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0;
+#define CX_B(M, PA, PB) hipLaunchKernelGGL(k_batch<M>, dim3(nb), dim3(kBlock), 0, h->stream, n, d_rec, h->d_vbase, h->d_var_deg, h->d_vinfo, \
+                                           h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint)
+    if (mode == kRuleLinear) CX_B(kRuleLinear, h->d_a, h->d_b);
+    else if (mode == kRuleBernoulli) CX_B(kRuleBernoulli, (const double *)nullptr, (const double *)nullptr);
+    else CX_B(kRuleAdditive, (const double *)nullptr, (const double *)nullptr);
+#undef CX_B
     prof_end(h);
 }
 

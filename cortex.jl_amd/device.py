@@ -125,6 +125,23 @@ class DeviceGraph:
             items[i].factor_id = int(factor_ids[i])
         self._check(self.lib.cx_update_batch(self.h, items, n))
 
+    def get_products(self, variable_ids, range_lo, range_hi, form: int = L.FORM_MOMENT):
+        """stored ProductOfMessages(variable, lo:hi) values, [n, 2]"""
+        v = _i64(np.atleast_1d(variable_ids))
+        lo = np.ascontiguousarray(np.atleast_1d(range_lo), dtype=np.int32)
+        hi = np.ascontiguousarray(np.atleast_1d(range_hi), dtype=np.int32)
+        out = np.zeros((len(v), 2), dtype=np.float64)
+        self._check(self.lib.cx_get_products(self.h, len(v), _p(v, C.c_int64), _p(lo, C.c_int32), _p(hi, C.c_int32), form,
+                                             _p(out, C.c_double)))
+        return out
+
+    def get_joint_marginals(self, factor_ids):
+        """stored JointMarginal(factor) values: (mean [n, 2], covariance [n, 2, 2]), variables in ascending id order"""
+        f = _i64(np.atleast_1d(factor_ids))
+        out = np.zeros((len(f), 6), dtype=np.float64)
+        self._check(self.lib.cx_get_joint_marginals(self.h, len(f), _p(f, C.c_int64), _p(out, C.c_double)))
+        return out[:, :2], out[:, 2:].reshape(-1, 2, 2)
+
     def sweep(self, n: int = 1):
         self._check(self.lib.cx_sweep(self.h, int(n)))
 

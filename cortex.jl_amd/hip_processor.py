@@ -49,8 +49,19 @@ class GaussianLinear:
     variance: float
 
 
+@dataclass(frozen=True)
+class Beta:
+    """The reference's test struct of the Beta-Bernoulli model (test/runtests.jl; `Beta(a, b)`).  On the device a Beta
+    travels as its natural parameters (a - 1, b - 1) in the generic 2-parameter family, so the reference's product
+    Beta(a + a' - 1, b + b' - 1) (test/inference_engine_tests.jl:270-277) is a plain sum."""
+    a: float
+    b: float
+
+
 def default_factor_rule(factor) -> Tuple[int, Tuple[float, ...]]:
     ff = get_factor_functional_form(factor)
+    if isinstance(ff, str) and ff.lstrip(":") == "bernoulli":     # functional_form = :bernoulli, test/...:323
+        return L.FACTOR_BERNOULLI, ()
     if isinstance(ff, GaussianAdditive):
         return L.FACTOR_GAUSS_ADDITIVE, (ff.variance,)
     if isinstance(ff, GaussianLinear):
@@ -79,17 +90,29 @@ class HipValue:
     def variance(self):
         return self._fetch().variance
 
+    @property
+    def a(self):
+        return self._fetch().a
+
+    @property
+    def b(self):
+        return self._fetch().b
+
     def __repr__(self):
         return f"HipValue({self._variant!r})"
 
 
 class HipProcessor(AbstractInferenceRequestProcessor):
     def __init__(self, *, mode: str = "sweep", n_sweeps: int = 1, device: int = 0, schedule: int = L.SCHED_FUSED,
-                 factor_rule: Callable = default_factor_rule):
+                 factor_rule: Callable = default_factor_rule, family: str = "gaussian"):
         if mode not in ("per_signal", "wavefront", "sweep"):
             raise ValueError(f"unknown mode {mode!r}")
-        self.mode, self.n_sweeps, self.factor_rule = mode, n_sweeps, factor_rule
-        self.dev = DeviceGraph(device=device, schedule=schedule)   # raises without a GPU: no CPU fallback
+        if family not in ("gaussian", "beta"):
+            raise ValueError(f"unknown family {family!r}")
+        self.mode, self.n_sweeps, self.factor_rule, self.family = mode, n_sweeps, factor_rule, family
+        # raises without a GPU: no CPU fallback
+        self.dev = DeviceGraph(device=device, schedule=schedule,
+                               family=L.FAMILY_GAUSSIAN if family == "gaussian" else L.FAMILY_NATURAL2)
         self.engine: Optional[InferenceEngine] = None
         self.launches = 0
         self.execution_log: List[Any] = []   # variants in execution order (schedule-parity checks)
@@ -117,22 +140,32 @@ class HipProcessor(AbstractInferenceRequestProcessor):
             direction = L.TO_VARIABLE
         else:
             raise TypeError("HipProcessor.set_value: only message signals carry device payloads")
-        if isinstance(value, (int, float, np.floating)):
+        if isinstance(value, (bool, int, float, np.floating, np.bool_)):
             self.dev.set_messages([variant.variable_id], [variant.factor_id], direction, L.FORM_POINT, [float(value)])
+        elif isinstance(value, Beta):
+            self.dev.set_messages([variant.variable_id], [variant.factor_id], direction, L.FORM_NATURAL, [value.a - 1.0, value.b - 1.0])
         else:
             self.dev.set_messages([variant.variable_id], [variant.factor_id], direction, L.FORM_MOMENT,
                                   [float(value.mean), float(value.variance)])
         _host_set_value(signal, value)
 
-    def read(self, variant) -> NormalMeanVariance:
+    def read(self, variant):
+        form = L.FORM_MOMENT if self.family == "gaussian" else L.FORM_NATURAL
+        if isinstance(variant, V.JointMarginal):
+            mean, cov = self.dev.get_joint_marginals([variant.factor_id])
+            return mean[0], cov[0]
         if isinstance(variant, V.IndividualMarginal):
             m = self.dev.get_marginals([variant.variable_id])[0]
         elif isinstance(variant, V.MessageToVariable):
-            m = self.dev.get_messages([variant.variable_id], [variant.factor_id], L.TO_VARIABLE)[0]
+            m = self.dev.get_messages([variant.variable_id], [variant.factor_id], L.TO_VARIABLE, form)[0]
         elif isinstance(variant, V.MessageToFactor):
-            m = self.dev.get_messages([variant.variable_id], [variant.factor_id], L.TO_FACTOR)[0]
+            m = self.dev.get_messages([variant.variable_id], [variant.factor_id], L.TO_FACTOR, form)[0]
+        elif isinstance(variant, V.ProductOfMessages):
+            m = self.dev.get_products([variant.variable_id], [variant.range[0]], [variant.range[1]], form)[0]
         else:
             raise TypeError(f"no device payload for {variant!r}")
+        if self.family == "beta":
+            return Beta(float(m[0]) + 1.0, float(m[1]) + 1.0)
         return NormalMeanVariance(float(m[0]), float(m[1]))
 
     # ---- rules: each is a 1-element batch (the scalar fallback of SURVEY §8b) -----------------------------------
@@ -144,6 +177,10 @@ class HipProcessor(AbstractInferenceRequestProcessor):
             return L.ITEM_MESSAGE_TO_FACTOR, variant.variable_id, variant.factor_id
         if isinstance(variant, V.IndividualMarginal):
             return L.ITEM_INDIVIDUAL_MARGINAL, variant.variable_id, 0
+        if isinstance(variant, V.ProductOfMessages):      # 1-based inclusive range, as in Julia (inference_signal.jl:62-66)
+            return L.ITEM_PRODUCT_OF_MESSAGES, variant.variable_id, L.item_range(variant.range[0], variant.range[1])
+        if isinstance(variant, V.JointMarginal):
+            return L.ITEM_JOINT_MARGINAL, 0, variant.factor_id
         raise NotImplementedError(f"The HIP processor has no rule for {type(variant).__name__}")
 
     def _launch(self, variants):
@@ -158,6 +195,8 @@ class HipProcessor(AbstractInferenceRequestProcessor):
 
     compute_message_to_factor = compute_message_to_variable
     compute_individual_marginal = compute_message_to_variable
+    compute_product_of_messages = compute_message_to_variable     # inference_engine.jl:439-449
+    compute_joint_marginal = compute_message_to_variable          # inference_engine.jl:469-477
 
     # ---- whole-call takeover (a Julia method of update_marginals! specialised on the processor type) -------------
     def update_marginals(self, engine, ids) -> bool:

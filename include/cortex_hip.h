@@ -11,7 +11,8 @@
  *   cx_set_messages      set_value!(message, data)                         src/signal.jl:232-253
  *   cx_update_batch      process!(processor, engine, variable_id, signal)  src/inference_engine.jl:479-509
  *                        → compute_message_to_variable! / compute_message_to_factor! /
- *                          compute_individual_marginal!                    src/inference_engine.jl:351-419
+ *                          compute_individual_marginal! / compute_product_of_messages! /
+ *                          compute_joint_marginal!                         src/inference_engine.jl:351-477
  *   cx_sweep             update_marginals!(engine, variable_ids)           src/inference_engine.jl:559-632
  *                        (device "flooding" schedule over the whole graph)
  *   cx_get_marginals     get_value(get_variable_marginal(variable))        src/model_engine.jl:60-62
@@ -60,6 +61,17 @@ extern "C" {
 #define CX_ITEM_MESSAGE_TO_FACTOR 1
 #define CX_ITEM_MESSAGE_TO_VARIABLE 2
 #define CX_ITEM_INDIVIDUAL_MARGINAL 4
+#define CX_ITEM_PRODUCT_OF_MESSAGES 8  /* ProductOfMessages(variable_id, range, factors), inference_signal.jl:62-66: the product of
+                                          the factor→variable messages number lo..hi (1-based, inclusive, ascending factor id:
+                                          the reference's `range` over factors_connected_to_variable) of variable_id — the
+                                          segment-tree intermediates of dependencies.jl:128-173.  The range travels in
+                                          cx_item.factor_id as CX_ITEM_RANGE(lo, hi); the value is kept in a device store
+                                          (cx_get_products) */
+#define CX_ITEM_JOINT_MARGINAL 16      /* JointMarginal(factor_id, variable_ids), inference_signal.jl:93-96, for a pairwise
+                                          Gaussian factor: the 2-d Gaussian ∝ factor x the two variable→factor messages
+                                          (compute_joint_marginal!, inference_engine.jl:469-477); variable_id is ignored, the
+                                          value is kept in a device store (cx_get_joint_marginals) */
+#define CX_ITEM_RANGE(lo, hi) ((int64_t)(((uint64_t)(uint32_t)(lo) << 32) | (uint64_t)(uint32_t)(hi)))
 
 /* payload forms */
 #define CX_FORM_MOMENT 0  /* Gaussian (mean, variance|covariance) */
@@ -76,6 +88,10 @@ extern "C" {
 #define CX_FACTOR_NORMAL_PRECISION 3 /* 3 edges (variational families): x_out ~ N(x_in, 1 / precision); roles OUT, IN,
                                        PRECISION — the :likelihood and :transition factors of
                                        test/inference_engine_tests.jl:691-715 */
+#define CX_FACTOR_BERNOULLI 4        /* CX_FAMILY_NATURAL2, 2 edges: one variable carries an observed Bool r (a CX_FORM_POINT datum),
+                                       the message to the other is Beta(1 + r, 2 - r) = natural (r, 1 - r): the :bernoulli
+                                       factor of test/inference_engine_tests.jl:250-262.  Without a datum the reference's rule
+                                       is error(...): the message stays undefined */
 #define CX_NPARAM 4                 /* doubles per factor in factor_params */
 
 /* edge roles for directed factors (Connection.label :out/:in, model_engine.jl:182) */
@@ -87,9 +103,9 @@ extern "C" {
  * the factor rules, the moment conversions at the ABI and the marginal read-out are Gaussian-specific. */
 #define CX_FAMILY_GAUSSIAN 0  /* (xi, w); marginals and MOMENT payloads are (mean, variance) */
 #define CX_FAMILY_NATURAL2 1  /* any 2-parameter family in natural coordinates, e.g. Beta(a, b) as (a-1, b-1): the
-                                 Beta-Bernoulli model of test/inference_engine_tests.jl:241-377.  Payloads are NATURAL only,
-                                 factors are CX_FACTOR_OPAQUE (their messages are set by the caller), marginals come back as
-                                 the natural-parameter sums. */
+                                 Beta-Bernoulli model of test/inference_engine_tests.jl:241-377.  Payloads are NATURAL (data:
+                                 POINT), factors are CX_FACTOR_OPAQUE (their messages are set by the caller) or
+                                 CX_FACTOR_BERNOULLI, marginals come back as the natural-parameter sums. */
 /* Variational message passing: messages depend WEAKLY on marginals (add_dependency!(...; weak = true), signal.jl:36-45).
  * The state is the set of marginals (cx_set_marginals / cx_update_marginals / cx_get_marginals); cx_sweep, cx_update_batch
  * and the message accessors do not apply.  Factors are CX_FACTOR_NORMAL_PRECISION, dim == 1. */
@@ -126,7 +142,7 @@ typedef struct cx_item {
     int32_t kind;          /* CX_ITEM_* */
     int32_t reserved;
     int64_t variable_id;
-    int64_t factor_id;     /* ignored for CX_ITEM_INDIVIDUAL_MARGINAL */
+    int64_t factor_id;     /* ignored for CX_ITEM_INDIVIDUAL_MARGINAL; CX_ITEM_RANGE(lo, hi) for CX_ITEM_PRODUCT_OF_MESSAGES */
 } cx_item;
 
 typedef struct cx_stats {
@@ -196,6 +212,12 @@ int32_t cx_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, d
 /* ---- compute ---------------------------------------------------------------------------------- */
 /* one launch for a batch of mutually independent signals, in the caller's order of enqueue */
 int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n);
+/* values of the intermediates cx_update_batch keeps on the device: ProductOfMessages nodes (2 doubles each, `form`
+ * CX_FORM_MOMENT or CX_FORM_NATURAL) and JointMarginal nodes (6 doubles each: mean[2], covariance[4] row-major, variables in
+ * ascending id order).  A node never computed reads as NaN (UndefValue()). */
+int32_t cx_get_products(cx_handle *h, int64_t n, const int64_t *variable_ids, const int32_t *range_lo, const int32_t *range_hi,
+                        int32_t form, double *out);
+int32_t cx_get_joint_marginals(cx_handle *h, int64_t n, const int64_t *factor_ids, double *out);
 /* n_sweeps passes of the configured device schedule over the whole graph (asynchronous) */
 int32_t cx_sweep(cx_handle *h, int32_t n_sweeps);
 /* max over directed messages of |Δmean|, |Δvariance| between the last two sweeps (host-synchronous) */

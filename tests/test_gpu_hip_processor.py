@@ -119,4 +119,177 @@ def test_linear_gaussian_factor_rule(hip_lib):
 def test_unsupported_variant_is_an_error_not_a_crash(hip_lib):
     proc = cx.HipProcessor(mode="per_signal")
     with pytest.raises(NotImplementedError):
-        proc._item(V.JointMarginal(1, (1, 2)))
+        proc._item(V.Unspecified())
+
+
+# ------------------------------------------------------------------------------------------------ a15: ProductOfMessages
+class BetaBernoulliProcessor(cx.AbstractInferenceRequestProcessor):
+    """test/inference_engine_tests.jl:245-309, on the host (the CPU arm of the comparison)"""
+
+    def compute_message_to_variable(self, engine, variant, signal, dependencies):
+        assert engine.get_factor(variant.factor_id).functional_form == "bernoulli"
+        r = float(bool(get_value(dependencies[0])))
+        return cx.Beta(1.0 + r, 2.0 - r)
+
+    def _fold(self, engine, variant, signal, dependencies):
+        acc = get_value(dependencies[0])
+        for d in dependencies[1:]:
+            nxt = get_value(d)
+            acc = cx.Beta(acc.a + nxt.a - 1, acc.b + nxt.b - 1)
+        return acc
+
+    compute_individual_marginal = _fold
+    compute_product_of_messages = _fold
+
+
+def make_beta_bernoulli(n, processor, trace=True):
+    """make_beta_bernoulli_model, test/inference_engine_tests.jl:311-337"""
+    graph = cx.BipartiteFactorGraph()
+    p = graph.add_variable(cx.Variable(name="p"))
+    o, f = [], []
+    for i in range(1, n + 1):
+        oi = graph.add_variable(cx.Variable(name="o", index=(i,)))
+        fi = graph.add_factor(cx.Factor(functional_form="bernoulli"))
+        o.append(oi); f.append(fi)
+        graph.add_edge(p, fi, cx.Connection(label="out"))
+        graph.add_edge(oi, fi, cx.Connection(label="out"))
+    engine = cx.InferenceEngine(model_engine=graph, dependency_resolver=cx.DefaultDependencyResolver(),
+                                inference_request_processor=processor, trace=trace)
+    return engine, p, o, f
+
+
+def _beta_experiment(n, processor, data):
+    engine, p, o, f = make_beta_bernoulli(n, processor)
+    for i in range(n):
+        sig = engine.get_connection_message_to_factor(o[i], f[i])
+        if isinstance(processor, cx.HipProcessor):
+            processor.set_value(sig, bool(data[i]))
+        else:
+            cx.set_value(sig, bool(data[i]))
+    update_marginals(engine, [p])
+    return engine, p, get_value(get_variable_marginal(engine.get_variable(p)))
+
+
+@pytest.mark.parametrize("mode", ["per_signal", "wavefront"])
+@pytest.mark.parametrize("n", [100, 6, 13])
+def test_beta_bernoulli_model_through_the_plugin(hip_lib, mode, n):
+    """The reference's Beta-Bernoulli test (test/inference_engine_tests.jl:241-377, n = 100) under DefaultDependencyResolver:
+    the variable p has degree n > 5, so its marginal hangs off the segment tree of ProductOfMessages signals
+    (dependencies.jl:90-173).  Every process! — MessageToVariable through the :bernoulli rule, ProductOfMessages,
+    IndividualMarginal — is a device computation (CX_ITEM_*); the posterior is the exact Beta(1 + Σ, 1 + n − Σ)."""
+    rng = np.random.default_rng(1234 + n)
+    data = rng.random(n) < 0.5
+    proc = cx.HipProcessor(mode=mode, family="beta", schedule=cx._lib.SCHED_FLOODING)
+    engine, p, answer = _beta_experiment(n, proc, data)
+    assert (answer.a, answer.b) == (1.0 + data.sum(), 1.0 + n - data.sum())          # known answer, exact (:360-376)
+    engine_cpu, _, answer_cpu = _beta_experiment(n, BetaBernoulliProcessor(), data)
+    assert (answer_cpu.a, answer_cpu.b) == (answer.a, answer.b)
+    order_cpu = [e.signal.variant for r in engine_cpu.get_trace().inference_requests[0].rounds for e in r.executions]
+    kinds = {type(v).__name__ for v in order_cpu}
+    assert kinds == {"MessageToVariable", "ProductOfMessages", "IndividualMarginal"}
+    if mode == "per_signal":
+        assert proc.execution_log == order_cpu and proc.launches == len(order_cpu)     # the reference's execution order
+    else:
+        assert sorted(map(repr, proc.execution_log)) == sorted(map(repr, order_cpu))   # same signals, each exactly once
+        assert proc.launches <= 2 + int(np.ceil(np.log2(n))) + 2                       # O(tree depth) launches
+    # every segment-tree intermediate holds on the device what the CPU processor computed for the same signal
+    prods_cpu = {(e.signal.variant.range): get_value(e.signal) for r in engine_cpu.get_trace().inference_requests[0].rounds
+                 for e in r.executions if isinstance(e.signal.variant, V.ProductOfMessages)}
+    assert len(prods_cpu) >= 2
+    for (lo, hi), want in prods_cpu.items():
+        got = proc.read(V.ProductOfMessages(p, (lo, hi), ()))
+        assert (got.a, got.b) == (want.a, want.b), f"ProductOfMessages {lo}:{hi}"
+    nat = proc.dev.get_products([p], [1], [n], cx._lib.FORM_NATURAL)      # a node nobody computed is UndefValue()
+    assert np.all(np.isnan(nat))
+
+
+def test_product_of_messages_and_joint_marginal_items_gaussian(hip_lib):
+    """CX_ITEM_PRODUCT_OF_MESSAGES / CX_ITEM_JOINT_MARGINAL straight through the C ABI on a Gaussian model: a hub variable
+    observed through 12 noisy factors (degree 13 with its chain link: the segment-tree case) on a short chain.
+    Products = precision-weighted products of the named message ranges; the joint marginal of a transition factor's two
+    variables = the 2 x 2 block of the exact posterior."""
+    L = cx._lib
+    T, m = 6, 12
+    rng = np.random.default_rng(3)
+    x = np.arange(1, T + 1)                       # chain x_1..x_T
+    tr = 100 + np.arange(T - 1)                   # transition factors
+    yv = 200 + np.arange(T)                       # one observation per state ...
+    lk = 300 + np.arange(T)
+    hub_obs = 400 + np.arange(m)                  # ... and 12 more of x_3
+    hub_lk = 500 + np.arange(m)
+    ev = np.concatenate([x[:-1], x[1:], yv, x, hub_obs, np.full(m, x[2])])
+    ef = np.concatenate([tr, tr, lk, lk, hub_lk, hub_lk])
+    fids = np.concatenate([tr, lk, hub_lk])
+    q = np.concatenate([rng.uniform(0.5, 2, T - 1), rng.uniform(0.5, 2, T), rng.uniform(0.5, 2, m)])
+    dev = cx.DeviceGraph(schedule=L.SCHED_FLOODING)
+    dev.graph_create(ev, ef, fids, np.full(len(fids), L.FACTOR_GAUSS_ADDITIVE, np.int32), q)
+    ys, hub_y = rng.standard_normal(T) * 2, rng.standard_normal(m) + 1.0
+    dev.set_messages(np.concatenate([yv, hub_obs]), np.concatenate([lk, hub_lk]), L.TO_FACTOR, L.FORM_POINT, np.concatenate([ys, hub_y]))
+    dev.sweep(T + 2)                               # a tree: converged
+    hub = int(x[2])
+    facs = np.sort(ef[ev == hub])                  # neighbour order = ascending factor id
+    assert len(facs) == m + 3
+    msgs = dev.get_messages(np.full(len(facs), hub), facs, L.TO_VARIABLE)
+    ranges = [(1, 7), (8, 15), (1, 3), (4, 7), (5, 5), (1, 15)]
+    dev.update_batch([L.ITEM_PRODUCT_OF_MESSAGES] * len(ranges), [hub] * len(ranges), [L.item_range(a, b) for a, b in ranges])
+    got = dev.get_products([hub] * len(ranges), [a for a, _ in ranges], [b for _, b in ranges])
+    for (a, b), g in zip(ranges, got):
+        w = (1.0 / msgs[a - 1:b, 1]).sum()
+        xi = (msgs[a - 1:b, 0] / msgs[a - 1:b, 1]).sum()
+        assert g[0] == pytest.approx(xi / w, rel=1e-12) and g[1] == pytest.approx(1.0 / w, rel=1e-12), (a, b)
+    marg = dev.get_marginals([hub])[0]
+    assert got[-1][0] == pytest.approx(marg[0], rel=1e-12) and got[-1][1] == pytest.approx(marg[1], rel=1e-12)   # 1:deg == marginal
+    with pytest.raises(cx.CortexHipError):
+        dev.update_batch([L.ITEM_PRODUCT_OF_MESSAGES], [hub], [L.item_range(3, 16)])       # range outside 1:15
+    # joint marginals of every transition factor vs the exact posterior covariance blocks
+    dev.update_batch([L.ITEM_JOINT_MARGINAL] * (T - 1), [0] * (T - 1), tr)
+    jm, jc = dev.get_joint_marginals(tr)
+    J = np.zeros((T, T)); h = np.zeros(T)
+    for i in range(T):
+        J[i, i] += 1 / q[T - 1 + i]; h[i] += ys[i] / q[T - 1 + i]
+    for k in range(m):
+        J[2, 2] += 1 / q[2 * T - 1 + k]; h[2] += hub_y[k] / q[2 * T - 1 + k]
+    for i in range(T - 1):
+        J[i, i] += 1 / q[i]; J[i + 1, i + 1] += 1 / q[i]; J[i, i + 1] -= 1 / q[i]; J[i + 1, i] -= 1 / q[i]
+    S = np.linalg.inv(J); mu = S @ h
+    for i in range(T - 1):
+        np.testing.assert_allclose(jm[i], mu[i:i + 2], rtol=1e-10)
+        np.testing.assert_allclose(jc[i], S[i:i + 2, i:i + 2], rtol=1e-10)
+    # a likelihood factor: one variable observed -> degenerate joint (datum, 0 variance) x the latent's posterior given it
+    dev.update_batch([L.ITEM_JOINT_MARGINAL], [0], [int(lk[0])])
+    jm1, jc1 = dev.get_joint_marginals([int(lk[0])])
+    assert jm1[0][1] == ys[0] and jc1[0][1, 1] == 0.0 and jc1[0][0, 1] == 0.0            # x_1 (id 1) first, y (id 200) second
+    assert jm1[0][0] == pytest.approx(mu[0], rel=1e-10) and jc1[0][0, 0] == pytest.approx(S[0, 0], rel=1e-10)
+    assert np.all(np.isnan(dev.get_joint_marginals([int(lk[1])])[0]))                      # never computed: UndefValue()
+
+
+def test_unknown_item_kind_is_an_error_not_a_crash(hip_lib):
+    dev = cx.DeviceGraph()
+    m = cx.synth.ssm_chain(4)
+    cx.synth.load_into_device(m, dev)
+    with pytest.raises(cx.CortexHipError) as e:
+        dev.update_batch([32], [int(m.x_ids[0])], [0])
+    assert e.value.code == cx._lib.ERR_UNSUPPORTED
+
+
+# ------------------------------------------------------------------------------------------------ config C1 at its stated size
+@pytest.mark.parametrize("mode", ["per_signal", "wavefront"])
+def test_config_c1_T1000_through_the_plugin(hip_lib, mode):
+    """BASELINE.json configs[0]: the scalar-Gaussian chain (Kalman smoother) at T = 1,000 (3,998 edges) through the
+    processor plug-in: the host keeps the reference's scheduler and readiness bits, every process! is a device computation.
+    Execution order == the same scheduler driving the reference-arithmetic CPU processor; marginals == Thomas solve."""
+    n = 1000
+    proc = cx.HipProcessor(mode=mode)
+    engine, x, mean, var, dataset = _run(n, proc)
+    em, ev = exact.ssm_chain_posterior(dataset, 1.0, 1.0)
+    assert_close(mean, em, 1e-9, "C1 marginal mean vs exact smoother")
+    assert_close(var, ev, 1e-9, "C1 marginal variance vs exact smoother")
+    assert np.all(mean >= 0) and np.all(np.diff(mean) >= 0) and np.all(var >= 0)        # the reference's own assertions (:485-487)
+    engine_cpu = _run(n, SSMBeliefPropagationProcessor())[0]
+    order_cpu = [e.signal.variant for r in engine_cpu.get_trace().inference_requests[0].rounds for e in r.executions]
+    assert len(order_cpu) == 5 * n - 4 + n                                                 # 4,996 messages + 1,000 marginals
+    if mode == "per_signal":
+        assert proc.execution_log == order_cpu and proc.launches == len(order_cpu)
+    else:
+        assert sorted(map(repr, proc.execution_log)) == sorted(map(repr, order_cpu))
+        assert proc.launches <= 2 * n + 4
