@@ -17,6 +17,32 @@ import torch  # noqa: E402
 import cortex.jl_amd as cx  # noqa: E402
 from cortex.jl_amd import _lib as L  # noqa: E402
 
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+F64_MATRIX_PEAK_TF = 78.6  # f64 matrix peak (AMD public spec)
+
+
+def counter_traffic(kernel_substr):
+    """HBM bytes per launch of a kernel from the newest profiles/*_configs_rocprof.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    separate passes, FETCH x2 on gfx950: tools/profile_configs.sh); None when no summary is on file"""
+    import glob
+    subs = [kernel_substr] if isinstance(kernel_substr, str) else list(kernel_substr)
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_configs_rocprof.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        tot = sum(v["hbm_bytes_per_launch"] for k, v in d.get("traffic", {}).items() if any(x in k for x in subs))
+        if tot:
+            best = (tot, os.path.relpath(f, ROOT))     # several kernels (one launch of each per sweep): their sum
+    return best
+
+
+def roofline(bound, achieved, peak, unit, traffic, **extra):
+    r = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak, "traffic": traffic}
+    r.update(extra)
+    return r
+
 
 def timed(dev, fn, steps, warmup):
     for _ in range(warmup):
@@ -43,9 +69,16 @@ def c2():
     fl.sweep(3)
     dtf = timed(fl, lambda: fl.sweep(1), 200, 20)
     nf = fl.stats()["n_messages_per_sweep"]
+    tr = counter_traffic(["k_chain_tile_totals", "k_chain_apply", "k_chain_scan_totals", "true, false>"])   # the steady-state launches of one sweep
+    alg = (5 * T - 4) * 32
+    achieved = (tr[0] if tr else alg) / dt / 1e9
     return {"config": "C2", "workload": f"scalar chain T={T} ({st['n_edges']} edges), chain-scan schedule: exact forward/backward in one sweep",
             "ms_per_sweep": dt * 1e3, "reference_updates_per_sweep": 5 * T - 4, "updates_per_s": (5 * T - 4) / dt,
-            "algorithmic_GBps": (5 * T - 4) * 32 / dt / 1e9,
+            "algorithmic_GBps": alg / dt / 1e9,
+            # three launches at their fixed cost: the sweep is LAUNCH-LATENCY bound, far from the HBM roofline it is priced against
+            "roofline": roofline("hbm", achieved, HBM_PEAK_GBS, "GB/s", tr[0] if tr else None, limited_by="launch latency (3 kernels per sweep)",
+                                 basis="counter traffic of the sweep's kernels / sweep time" if tr else "algorithmic bytes / sweep time",
+                                 traffic_source=tr[1] if tr else None, algorithmic_bytes_per_sweep=alg, frac_algorithmic=alg / dt / 1e9 / HBM_PEAK_GBS),
             "flooding": {"ms_per_sweep": dtf * 1e3, "updates_per_sweep": nf, "updates_per_s": nf / dtf, "algorithmic_GBps": nf * 32 / dtf / 1e9}}
 
 
@@ -63,12 +96,26 @@ def mv(d, T, steps):
     out = {"config": "C3" if d == 4 else "C5", "workload": f"d={d} linear-Gaussian chain T={T} ({st['n_edges']} edges), fused flooding sweep",
            "ms_per_sweep": dt * 1e3, "kernel_ms": ms / max(n, 1), "updates_per_sweep": upd, "updates_per_s": upd / dt,
            "algorithmic_GBps": upd * 2 * payload / dt / 1e9, "payload_bytes": payload}
+    kern_s = ms / max(n, 1) / 1e3
+    tr = counter_traffic("k_rule64s" if d == 64 else f"k_sweep_mv<{d}>")
+    alg = upd * 2 * payload
     if d == 64:
-        # MFMA work per factor→variable message: panel 24 + trailing 40 + Yt updates 96 + Yt*W' 64 + Yt Yt' 256 = 480
-        # v_mfma_f64_16x16x4_f64, 2*16*16*4 flop each
+        # v_mfma_f64_16x16x4_f64 per factor→variable message, as the counters see them (SQ_INSTS_MFMA / messages,
+        # profiles/r01_c5_rocprof.json): 584, 2*16*16*4 flop each
         nmsg = 2 * (T - 1)
-        out["mfma_TFLOPs"] = nmsg * 480 * 2048 / (ms / max(n, 1) / 1e3) / 1e12
-        out["f64_matrix_peak_TFLOPs"] = 78.6
+        tf = nmsg * 584 * 2048 / kern_s / 1e12
+        out["mfma_TFLOPs"] = tf
+        out["roofline"] = roofline("mfma", tf, F64_MATRIX_PEAK_TF, "TFLOP/s", tr[0] if tr else None, kernel="k_rule64s",
+                                   mfma_per_message=584, messages_per_launch=nmsg, avg_kernel_ms=kern_s * 1e3,
+                                   traffic_source=tr[1] if tr else None, hbm_GBps=(tr[0] / kern_s / 1e9) if tr else None)
+    else:
+        achieved = (tr[0] if tr else alg) / kern_s / 1e9
+        out["roofline"] = roofline("hbm", achieved, HBM_PEAK_GBS, "GB/s", tr[0] if tr else None, kernel=f"k_sweep_mv<{d}>", avg_kernel_ms=kern_s * 1e3,
+                                   basis="counter traffic / avg launch duration" if tr else "algorithmic bytes / avg launch duration",
+                                   traffic_source=tr[1] if tr else None, algorithmic_bytes_per_launch=alg,
+                                   frac_algorithmic=alg / kern_s / 1e9 / HBM_PEAK_GBS,
+                                   frac_algorithmic_note="SURVEY §8d convention: 2 x 160 B per update over ALL directed updates; the kernel skips the constant "
+                                                         "messages out of observed variables and stores packed-symmetric 112 B, so it moves fewer bytes")
     return out
 
 
