@@ -46,6 +46,8 @@ def parse(argv=None):
                     help="per-launch hipEvent pairs in the extra, untimed sampling region (every n-th launch)")
     ap.add_argument("--grid", type=int, default=1415, help="N: the N x N grid (1415 -> 10,005,465 edges)")
     ap.add_argument("--schedule", choices=["flooding", "fused"], default=os.environ.get("CX_BENCH_SCHEDULE", "fused"))
+    ap.add_argument("--sweeps-per-launch", type=int, default=1, choices=[1, 2],
+                    help="2: the two-sweeps-per-launch experiment (cx_tiles.hip; bit-identical, measured slower: DESIGN.md §4c)")
     ap.add_argument("--materialize", action="store_true", help="also store every variable→factor message each sweep")
     ap.add_argument("--halo", choices=["rccl", "torch"], default=os.environ.get("CX_HALO", "rccl"),
                     help="N > 1: exchange issued by the library on RCCL (default) or by torch.distributed isend/irecv")
@@ -276,7 +278,7 @@ class Workload:
         self.args, self.scaling, self.world, self.rank = args, scaling, world, rank
         schedule = L.SCHED_FUSED if args.schedule == "fused" else L.SCHED_FLOODING
         self.dev = dev = cx.DeviceGraph(device=local_rank, schedule=schedule, marginals_in_sweep=True,
-                                        materialize_messages_to_factor=args.materialize)
+                                        materialize_messages_to_factor=args.materialize, sweeps_per_launch=args.sweeps_per_launch)
         dev.set_stream(torch.cuda.current_stream().cuda_stream)
         self.halo_kind, self.halo_tensors, self.part, self.exchange = None, None, None, None
         red_dev = "cuda" if backend == "nccl" else "cpu"
@@ -441,7 +443,7 @@ def run_rank(args):
     dev.sync()
     dev.profile_enable(False)
     kern = {}
-    for k in (L.KERNEL_FUSED, L.KERNEL_VAR_TO_FACTOR, L.KERNEL_FACTOR_TO_VAR, L.KERNEL_HALO_BEGIN, L.KERNEL_HALO_END):
+    for k in (L.KERNEL_TILED, L.KERNEL_FUSED, L.KERNEL_VAR_TO_FACTOR, L.KERNEL_FACTOR_TO_VAR, L.KERNEL_HALO_BEGIN, L.KERNEL_HALO_END):
         ms, n = dev.profile_read(k)
         if n:
             kern[dev.kernel_name(k)] = (ms, n, k)
@@ -480,18 +482,20 @@ def run_rank(args):
     if rank == 0:
         st = w.st
         value = total_updates_per_step * args.steps / elapsed
-        launches_per_step = 1 if args.schedule == "fused" else 2
         if kern:
             dom_name, (dom_ms, dom_n, dom_id) = max(kern.items(), key=lambda kv: kv[1][0])
         else:
             dom_name, (dom_ms, dom_n, dom_id) = "k_sweep<fused>", (0.0, 0, L.KERNEL_FUSED)
+        tiles = dev.tile_stats()
+        # launches per step: the two-sweep kernel covers two steps per launch; the flooding schedule needs two launches per step
+        steps_per_launch = 2.0 if dom_id == L.KERNEL_TILED else (1.0 if args.schedule == "fused" else 0.5)
         # algorithmic bytes per launch: §8d's 32 B per directed message update x the updates one launch performs
-        upd_per_launch = w.local_updates_per_step if dom_id == L.KERNEL_FUSED else w.local_updates_per_step / 2
+        upd_per_launch = w.local_updates_per_step * steps_per_launch
         alg_bytes = upd_per_launch * BYTES_PER_UPDATE
         # average launch duration: device time of the median timed region (events on the library's stream around the whole
         # region, launches back to back) / launches.  It contains the inter-launch gaps, so it can only over-state the
         # kernel; the per-launch event pairs of the sampling region are printed beside it.
-        region_ms_per_launch = dev_ms / args.steps / launches_per_step if args.schedule == "fused" else None
+        region_ms_per_launch = dev_ms / args.steps * steps_per_launch if args.schedule == "fused" else None
         sampled_ms = dom_ms / dom_n if dom_n else None
         avg_ms = region_ms_per_launch if region_ms_per_launch is not None else sampled_ms
         # counter traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections: profiles/): measured on
@@ -520,7 +524,10 @@ def run_rank(args):
                                     f"C4 weak scaling: one {N}x{N} strip per GPU of a {N * world}x{N} grid; rank 0 holds") +
                                    f" {st['n_edges']} bipartite edges, {w.updates_per_step} owned directed message updates + "
                                    f"{w.owned_variables} marginals per sweep; whole job {int(total_updates_per_step)} updates per sweep",
-                       "schedule": args.schedule + ("" if w.halo_kind is None else f" + {w.halo_kind}"),
+                       "schedule": args.schedule + (f", two sweeps per launch ({tiles['n_tiles']} tiles, {tiles['variables_loaded_per_owned']:.2f} variables "
+                                                    f"loaded per owned one, {tiles['lds_bytes_per_workgroup']} B LDS per workgroup; marginals written by the "
+                                                    f"second sweep of each launch)" if dom_id == L.KERNEL_TILED else "") +
+                                   ("" if w.halo_kind is None else f" + {w.halo_kind}"),
                        "partition": f"{world} row blocks", "seed": args.seed},
             "timed_regions": {"count": len(walls), "reported": "median", "ms_per_step_each": [x / args.steps * 1e3 for x in walls],
                               "device_ms_per_step_each": [x / args.steps for x in devs]},
@@ -537,7 +544,8 @@ def run_rank(args):
                          "frac_algorithmic_note": "SURVEY §8d convention (32 B per directed update); the fused kernel never stores "
                                                   "variable→factor messages, so it moves fewer bytes than this convention counts",
                          "all_kernels_sampled_ms": {k: v[0] / v[1] for k, v in kern.items()}},
-            "marginals_per_s": total_variables * args.steps / elapsed,   # computed inside the same kernel, not counted in `value`
+            # computed inside the same kernel, not counted in `value`; a two-sweep launch writes them once (its second sweep's)
+            "marginals_per_s": total_variables * args.steps / elapsed / (2.0 if dom_id == L.KERNEL_TILED else 1.0),
             "max_message_change_over_run": res,
         }
         if halo_check is not None:

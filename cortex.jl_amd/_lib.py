@@ -25,14 +25,14 @@ SCHED_FLOODING, SCHED_FUSED, SCHED_CHAIN_SCAN = 0, 1, 2
 FAMILY_GAUSSIAN, FAMILY_NATURAL2, FAMILY_VMP_MEAN_FIELD, FAMILY_VMP_STRUCTURED = 0, 1, 2, 3
 VMP_ALL_NORMAL, VMP_ALL_PRECISION = -1, -2
 KERNEL_VAR_TO_FACTOR, KERNEL_FACTOR_TO_VAR, KERNEL_FUSED, KERNEL_BATCH, KERNEL_BIG_VAR = 0, 1, 2, 3, 4
-KERNEL_HALO_BEGIN, KERNEL_HALO_END = 5, 6
+KERNEL_HALO_BEGIN, KERNEL_HALO_END, KERNEL_TILED = 5, 6, 7
 KERNEL_COUNT = 8
 
 
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("dim", C.c_int32), ("schedule", C.c_int32),
                 ("compute_marginals_in_sweep", C.c_int32), ("materialize_messages_to_factor", C.c_int32),
-                ("family", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("family", C.c_int32), ("sweeps_per_launch", C.c_int32)]
 
 
 class Item(C.Structure):
@@ -59,6 +59,7 @@ SIGNATURES = {
     "cx_graph_create": (_i32, [_vp, _i64, _pi64, _pi64, _pi32, _i64, _pi64, _pi32, _pd]),
     "cx_set_factor_matrices": (_i32, [_vp, _i64, _pd, _pd]),
     "cx_graph_stats": (_i32, [_vp, C.POINTER(Stats)]),
+    "cx_tile_stats": (_i32, [_vp, _pi64, _pd, _pi64]),
     "cx_edge_index": (_i32, [_vp, _i64, _pi64, _pi64, _pi64]),
     "cx_payload_doubles": (_i64, [_i32, _i32]),
     "cx_set_messages": (_i32, [_vp, _i64, _pi64, _pi64, _i32, _i32, _pd]),

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -61,6 +62,9 @@ void dev_free_all(cx_handle *h) {
                     h->d_stage, h->d_spdir, h->d_ptab, h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prev, h->d_rule64_slots, h->d_rule64_vars, h->d_rule64_flags, h->d_point64_slots, h->d_rule64_rec, h->d_chain_pos_var, h->d_chain_skip0, h->d_chain_skip1, h->d_chain_link_pos, h->d_chain_from,
                     h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_side, h->d_chain_totals};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    cx::tiles_free(h);
+    if (h->d_f2v_tmp) (void)hipFree(h->d_f2v_tmp);
+    h->d_f2v_tmp = nullptr; h->alt_two_back = false;
     if (h->d_prod) (void)hipFree(h->d_prod);
     if (h->d_joint) (void)hipFree(h->d_joint);
     h->d_prod = nullptr; h->d_joint = nullptr; h->prod_cap = h->joint_cap = 0; h->prod_index.clear(); h->joint_index.clear();
@@ -153,6 +157,7 @@ const char *cx_kernel_name(int32_t k) {
     case CX_KERNEL_BIG_VAR: return "k_big_var_to_factor";
     case CX_KERNEL_HALO_BEGIN: return "k_halo_export";
     case CX_KERNEL_HALO_END: return "k_halo_import";
+    case CX_KERNEL_TILED: return "k_sweep2<two sweeps per launch>";
     }
     return "";
 }
@@ -175,6 +180,8 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
         return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: dim > 1 runs the fused schedule only");
     if (config->schedule != CX_SCHED_FLOODING && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN)
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: unknown schedule");
+    if (config->sweeps_per_launch < 0 || config->sweeps_per_launch > 2)
+        return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: sweeps_per_launch must be 0 (automatic), 1 or 2");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -501,6 +508,15 @@ int32_t cx_graph_stats(const cx_handle *h, cx_stats *out) {
     return CX_OK;
 }
 
+// tiles of the two-sweep launches (built on the first cx_sweep(n >= 2) of a fused scalar handle)
+int32_t cx_tile_stats(const cx_handle *h, int64_t *n_tiles, double *variables_loaded_per_owned, int64_t *lds_bytes_per_workgroup) {
+    if (!h) return CX_ERR_INVALID_ARGUMENT;
+    if (n_tiles) *n_tiles = h->tiles_state > 0 ? h->n_tiles : 0;
+    if (variables_loaded_per_owned) *variables_loaded_per_owned = h->tiles_state > 0 ? h->tile_redundancy : 0.0;
+    if (lds_bytes_per_workgroup) *lds_bytes_per_workgroup = h->tiles_state > 0 ? h->tile_lds : 0;
+    return CX_OK;
+}
+
 int32_t cx_edge_index(const cx_handle *hc, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, int64_t *out_edge) {
     cx_handle *h = const_cast<cx_handle *>(hc);
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_edge_index: no graph");
@@ -609,7 +625,7 @@ int32_t mv64_set_messages(cx_handle *h, int64_t n, const std::vector<int32_t> &i
         CX_HIP(h, hipMemcpyAsync(d_val, payload, (size_t)n * d * 8, hipMemcpyHostToDevice, h->stream));
         cx::mv64_set_point(h, h->d_mv_v2f, d_idx, d_val, n);
         for (int64_t i = 0; i < n; i++) h->vinfo[vars[i]] |= cx::kClamped;
-        CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
+        CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
         h->work64_dirty = h->point64_dirty = true;
     } else {
         std::vector<double> val((size_t)n * nc);
@@ -662,7 +678,7 @@ int32_t mv_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
         h->observed_passes_due = 2;   // a stored variable→factor message changed: observed senders are refreshed
         if (form == CX_FORM_POINT) {
             for (int64_t i = 0; i < n; i++) h->vinfo[vars[i]] |= cx::kClamped;
-            CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
+            CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
             h->spdir_dirty = true;
         }
     } else {
@@ -833,8 +849,27 @@ int32_t mv_residual(cx_handle *h, double *out) {
 
 // In the fused schedule without materialisation the variable→factor messages of the last sweep exist only as
 // "leave-one-out of the sweep's input buffer", which is retained in d_f2v_alt: recompute them on demand.
+// After a two-sweep launch (cx_tiles.hip) the retained buffer d_f2v_alt holds time t while d_f2v holds t+2: the buffer of
+// time t+1 — the input of the last sweep, which is what variable→factor messages and checkpoints are defined from — never
+// existed.  Regenerate it with one plain sweep from time t into a third buffer and make that the retained buffer.
+static int32_t normalize_alt(cx_handle *h) {
+    if (!h->alt_two_back) return CX_OK;
+    if (!h->d_f2v_tmp) { int32_t rc = dev_alloc(h, &h->d_f2v_tmp, h->nslots); if (rc != CX_OK) return rc; }
+    // slots no sweep writes (priors of unary factors, padding) are equal in every buffer: start from a copy
+    CX_HIP(h, hipMemcpyAsync(h->d_f2v_tmp, h->d_f2v_alt, (size_t)h->nslots * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
+    const bool prof = h->profiling;
+    h->profiling = false;
+    cx::launch_fused(h, h->d_f2v_alt, h->d_f2v_tmp, false, false, false);
+    h->profiling = prof;
+    CX_HIP(h, hipGetLastError());
+    std::swap(h->d_f2v_alt, h->d_f2v_tmp);
+    h->alt_two_back = false;
+    return CX_OK;
+}
+
 static int32_t ensure_v2f(cx_handle *h) {
     if (!h->v2f_stale) return CX_OK;
+    { int32_t rc = normalize_alt(h); if (rc != CX_OK) return rc; }
     const double2 *src = h->d_f2v_alt ? h->d_f2v_alt : h->d_f2v;
     cx::launch_var_to_factor(h, src, false);
     cx::launch_big_var_to_factor(h, src, false);
@@ -878,7 +913,7 @@ int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
                 // a variable that carries a point-mass datum is observed: its messages are never recomputed
                 for (int64_t i = 0; i < n; i++) h->vinfo[vars[i]] |= cx::kClamped;
                 h->chains_dirty = true;
-                CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
+                CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
             }
         } else {
             cx::launch_scatter(h, h->d_f2v, d_idx, d_val, n);
@@ -1207,6 +1242,12 @@ static int32_t build_chains(cx_handle *h) {
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "chain decomposition: host allocation failed"); }
 }
 
+// CX_TILED=0 in the environment turns the two-sweep launches off (A/B measurements)
+static bool tiled_env_enabled() {
+    static const int on = [] { const char *e = std::getenv("CX_TILED"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0;
+}
+
 // ---- the sweep ----------------------------------------------------------------------------------------------------
 static void sweep_main(cx_handle *h, bool skip_ghosts) {
     const bool marg = h->cfg.compute_marginals_in_sweep != 0;
@@ -1251,7 +1292,26 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
     CX_REQUIRE(h, h->halo_state || (h->recv_slots.empty() && h->send_slots.empty()), CX_ERR_STATE,
                "cx_sweep: this handle holds a partition (halo configured): use cx_sweep_begin / _main / _end");
     if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) { int32_t rc = build_chains(h); if (rc != CX_OK) return rc; }
-    for (int32_t s = 0; s < n_sweeps; s++) { sweep_main(h, false); sweep_finish(h); }
+    int32_t s = 0;
+    // pairs of sweeps as ONE launch each (cx_tiles.hip), when the schedule and the graph allow it
+    // (opt-in: measured SLOWER than single sweeps on MI355X, see DESIGN.md §4c — kept as a tested experiment, not the default)
+    const bool want_pairs = n_sweeps >= 2 && h->cfg.schedule == CX_SCHED_FUSED && h->cfg.sweeps_per_launch == 2 &&
+                            h->cfg.family == CX_FAMILY_GAUSSIAN && h->cfg.materialize_messages_to_factor == 0 && tiled_env_enabled();
+    if (want_pairs && h->tiles_state == 0) {
+        std::string why;
+        if (cx::tiles_build(h, why) && !cx::tiles_prepare_kernel(h)) { cx::tiles_free(h); h->tiles_state = -1; }
+    }
+    if (want_pairs && h->tiles_state > 0) {
+        const bool marg = h->cfg.compute_marginals_in_sweep != 0;
+        for (; s + 2 <= n_sweeps; s += 2) {
+            cx::launch_tiled2(h, h->d_f2v, h->d_f2v_alt, marg);
+            std::swap(h->d_f2v, h->d_f2v_alt);     // d_f2v: time t+2; d_f2v_alt: time t
+            h->alt_two_back = true;
+            h->v2f_stale = true;
+            h->sweeps_done += 2;
+        }
+    }
+    for (; s < n_sweeps; s++) { sweep_main(h, false); sweep_finish(h); h->alt_two_back = false; }
     CX_HIP(h, hipGetLastError());
     return CX_OK;
 }
@@ -1352,7 +1412,7 @@ int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const
         for (int32_t v : recv_vars) h->vinfo[v] |= cx::kGhost;
         h->halo_state = false;
         h->chains_dirty = true;
-        CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
+        CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
         for (void *p : {(void *)h->d_send_slots, (void *)h->d_recv_slots, (void *)h->d_send_vars}) if (p) (void)hipFree(p);
         if (!h->ext_halo_buffers) { if (h->d_send_buf) (void)hipFree(h->d_send_buf); if (h->d_recv_buf) (void)hipFree(h->d_recv_buf); }
         h->d_send_slots = h->d_recv_slots = h->d_send_vars = nullptr; h->d_send_buf = h->d_recv_buf = nullptr;
@@ -1387,7 +1447,7 @@ int32_t cx_halo_configure_state(cx_handle *h, int64_t n_send, const int64_t *sv,
         if (rc != CX_OK) return rc;
         if (std::any_of(h->vinfo.begin(), h->vinfo.end(), [](uint8_t b) { return (b & cx::kGhost) != 0; })) {
             for (uint8_t &b : h->vinfo) b &= (uint8_t)~cx::kGhost;
-            CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
+            CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
         }
         for (void *p : {(void *)h->d_send_slots, (void *)h->d_recv_slots, (void *)h->d_send_vars}) if (p) (void)hipFree(p);
         if (!h->ext_halo_buffers) { if (h->d_send_buf) (void)hipFree(h->d_send_buf); if (h->d_recv_buf) (void)hipFree(h->d_recv_buf); }
@@ -1611,6 +1671,7 @@ int32_t cx_state_export(cx_handle *h, void *buf, int64_t bytes) {
     (void)cx_state_bytes(h, &need);
     CX_REQUIRE(h, buf && bytes >= need, CX_ERR_INVALID_ARGUMENT, "cx_state_export: buffer smaller than cx_state_bytes");
     CX_HIP(h, hipSetDevice(h->cfg.device));
+    { int32_t rc = normalize_alt(h); if (rc != CX_OK) return rc; }   // the blob holds the buffers of time n and n - 1
     CX_HIP(h, hipStreamSynchronize(h->stream));
     auto parts = state_parts(h);
     StateHeader hd{};
@@ -1673,6 +1734,7 @@ int32_t cx_state_import(cx_handle *h, const void *buf, int64_t bytes) {
     }
     h->sweeps_done = hd.sweeps_done;
     h->v2f_stale = hd.v2f_stale != 0;
+    h->alt_two_back = false; h->tile_info_dirty = true;
     h->spdir_dirty = h->work64_dirty = h->point64_dirty = h->chains_dirty = true;   // derived from the observed flags
     if (h->d_prev) { (void)hipFree(h->d_prev); h->d_prev = nullptr; }               // residual snapshots restart
     if (h->d_mv_prev) { (void)hipFree(h->d_mv_prev); h->d_mv_prev = nullptr; }

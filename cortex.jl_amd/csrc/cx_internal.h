@@ -124,6 +124,17 @@ struct cx_handle {
     double *d_joint = nullptr;
     int64_t prod_cap = 0, joint_cap = 0;
 
+    // two sweeps per launch (cx_tiles.hip): tile tables built once per graph
+    int tiles_state = 0;             // 0: not built yet, 1: ready, -1: this graph is outside the tiled kernel
+    void *d_tile_hdr = nullptr, *d_tile_recs = nullptr, *d_tile_pl = nullptr, *d_tile_var = nullptr, *d_tile_info = nullptr;
+    int32_t n_tiles = 0, tile_max_slots = 0, tile_pl_stride = 0, tile_max_deg = 8, tile_grid = 256;
+    int64_t n_tile_recs = 0;
+    bool tile_info_dirty = true;     // d_vinfo changed since the tiles' copy of the observed / stand-in flags was refreshed
+    int64_t tile_lds = 0;
+    double tile_redundancy = 0.0;    // (own + ring) variables loaded per own variable
+    bool alt_two_back = false;       // after a two-sweep launch d_f2v_alt holds time t, not t+1 (see normalize_alt in cx_api.hip)
+    double2 *d_f2v_tmp = nullptr;
+
     // variational families (cx_vmp.hip): opaque state
     void *vmp = nullptr;
 
@@ -162,6 +173,11 @@ void launch_gather(cx_handle *h, const double2 *src, const int32_t *d_idx, doubl
 void launch_seed(cx_handle *h, double2 *buf, int64_t n, double2 value, const int32_t *partner);
 void launch_residual(cx_handle *h, const double2 *cur, const double2 *prev, int64_t n, double *d_out);
 void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves);
+// two sweeps per launch (cx_tiles.hip)
+bool tiles_build(cx_handle *h, std::string &why);
+bool tiles_prepare_kernel(cx_handle *h);
+void tiles_free(cx_handle *h);
+void launch_tiled2(cx_handle *h, const double2 *f2v_in, double2 *f2v_out, bool write_marg);
 // multivariate (cx_mv.hip)
 void mv_launch_sweep(cx_handle *h, bool write_marg, bool observed_only);
 void mv_launch_v2f(cx_handle *h, const int32_t *d_slots, const int32_t *d_vars, int64_t n, const double *f2v);
