@@ -23,6 +23,8 @@
 //
 // Roofline: HBM bytes (≈12 flop per 32 payload bytes).
 
+#include <cstdlib>
+
 #include "cx_internal.h"
 
 namespace cx {
@@ -95,14 +97,14 @@ __device__ __forceinline__ double2 to_moment(double2 nat) {
 template <int MODE, bool STORE_V2F, bool PUSH>
 __device__ __forceinline__ void emit(int slot, double2 o, const int32_t *__restrict__ partner, const double *__restrict__ sq,
                                      const double *__restrict__ sa, const double *__restrict__ sb, double2 *__restrict__ f2v_out,
-                                     double2 *__restrict__ v2f) {
+                                     double2 *__restrict__ v2f, int nt_out = 0) {
     if (__builtin_isnan(o.y)) return;  // a dependency is undefined: the signal is not pending, keep stored values
     if (STORE_V2F) v2f[slot] = o;
     if (PUSH) {
         const int p = partner[slot];
         if (p >= 0) {
             const double2 r = factor_rule<MODE>(o, sq[slot], MODE == kRuleLinear ? sa[slot] : 1.0, MODE == kRuleLinear ? sb[slot] : 0.0);
-            if (MODE != kRuleBernoulli || !__builtin_isnan(r.y)) f2v_out[p] = r;
+            if (MODE != kRuleBernoulli || !__builtin_isnan(r.y)) { if (nt_out) store_stream(&f2v_out[p], r); else f2v_out[p] = r; }
         }
     }
 }
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep(int nv, const int32_t *__restr
                                                   const double *__restrict__ sa, const double *__restrict__ sb,
                                                   const double2 *__restrict__ f2v_in, double2 *__restrict__ f2v_out,
                                                   double2 *__restrict__ v2f, double2 *__restrict__ marg, int write_marg,
-                                                  int skip_ghosts) {
+                                                  int skip_ghosts, int nt_out) {
     const int s = xcd_slab(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x;
     const int v = (s << kSliceShift) + tid;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep(int nv, const int32_t *__restr
     if (!fixed) {
 #pragma unroll
         for (int k = 0; k < kSmallDeg; k++)
-            if (k < deg) emit<MODE, STORE_V2F, PUSH>(base + k * kBlock, out[k], partner, sq, sa, sb, f2v_out, v2f);
+            if (k < deg) emit<MODE, STORE_V2F, PUSH>(base + k * kBlock, out[k], partner, sq, sa, sb, f2v_out, v2f, nt_out);
     } else if (PUSH) {
         // separate path (not a select on the message) so that out[] never has its address taken
 #pragma unroll
@@ -453,6 +455,17 @@ static inline void prof_end(cx_handle *h) {
     (void)hipEventRecord(h->recs.back().stop, h->prof_stream);
 }
 
+// Scatter stores of the fused sweep.  On the 10M-edge grid plain stores win (nt: +2 us, the lines are re-touched by the
+// neighbouring rows' stores).  On a graph whose written bytes FIT the L2s (a 1/8 strip: 22 MB against 8 x 4 MB) plain stores
+// stay dirty in L2 until the kernel ends and are written back in its tail; CX_NT_SCATTER=1/0 forces either form, default: by size.
+static inline int nt_scatter(const cx_handle *h) {
+    static const int forced = [] { const char *e = std::getenv("CX_NT_SCATTER"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    if (forced >= 0) return forced;
+    // measured on MI355X: 1/8 strip of the C4 grid (25 MB of message slots) 10.97 -> 9.75 us per sweep with nt stores; the whole grid
+    // (160 MB) 63.4 -> 64.3 us.  The L2s hold 32 MB in all.
+    return (h->nslots * (int64_t)sizeof(double2) <= (int64_t)40 << 20) ? 1 : 0;
+}
+
 static inline int rule_mode(const cx_handle *h) {
     return h->cfg.family == CX_FAMILY_NATURAL2 ? kRuleBernoulli : (h->any_linear ? kRuleLinear : kRuleAdditive);
 }
@@ -462,7 +475,7 @@ static void launch_sweep_t(cx_handle *h, const double2 *f2v_in, double2 *f2v_out
     const double *sq = h->any_linear ? h->d_sq : h->d_q;  // additive factors: q is symmetric in the two edges
     hipLaunchKernelGGL((k_sweep<LINEAR, STORE, PUSH>), dim3((unsigned)h->nslices), dim3(kBlock), 0, h->stream, (int)h->nv,
                        h->d_slice_off, h->d_vinfo, h->d_partner, sq, h->d_sa, h->d_sb, f2v_in, f2v_out, h->d_v2f, h->d_marg,
-                       write_marg ? (h->cfg.family == CX_FAMILY_NATURAL2 ? 2 : 1) : 0, skip_ghosts ? 1 : 0);
+                       write_marg ? (h->cfg.family == CX_FAMILY_NATURAL2 ? 2 : 1) : 0, skip_ghosts ? 1 : 0, nt_scatter(h));
 }
 
 void launch_fused(cx_handle *h, const double2 *f2v_in, double2 *f2v_out, bool write_marg, bool store_v2f, bool skip_ghosts) {
