@@ -1248,6 +1248,67 @@ static bool tiled_env_enabled() {
     return on != 0;
 }
 
+// ---- chain-scan partitions: the composed maps of a time block -------------------------------------------
+// Host copy of cx_chain.hip's map algebra (projective-linear maps on (xi, w, 1), D normalised to 1)
+extern "C++" {
+namespace {
+struct HLin { double e, f, g, A, B, C; int seg, pad; };
+HLin hlin_compose(const HLin &first, const HLin &second) {
+    if (second.seg) return second;
+    HLin r;
+    const double inv = 1.0 / (second.C * first.B + 1.0);
+    r.A = (second.A * first.A + second.B * first.C) * inv;
+    r.B = (second.A * first.B + second.B) * inv;
+    r.C = (second.C * first.A + first.C) * inv;
+    r.e = (second.e * first.e) * inv;
+    r.f = (second.e * first.f + second.f * first.A + second.g * first.C) * inv;
+    r.g = (second.e * first.g + second.f * first.B + second.g) * inv;
+    r.seg = first.seg; r.pad = 0;
+    return r;
+}
+}  // namespace
+}  // extern "C++"
+
+int32_t cx_chain_block_maps(cx_handle *h, double *fwd6, double *bwd6, double *side_first2, double *side_last2,
+                            int64_t *first_variable_id, int64_t *last_variable_id, int64_t *n_links) {
+    CX_NOT_VMP(h, "cx_chain_block_maps");
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_chain_block_maps: no graph");
+    CX_REQUIRE(h, h->cfg.dim == 1 && h->cfg.schedule == CX_SCHED_CHAIN_SCAN, CX_ERR_STATE, "cx_chain_block_maps: scalar chain-scan handles only");
+    CX_REQUIRE(h, fwd6 && bwd6 && side_first2 && side_last2, CX_ERR_INVALID_ARGUMENT, "cx_chain_block_maps: null argument");
+    CX_REQUIRE(h, !h->any_linear, CX_ERR_UNSUPPORTED, "cx_chain_block_maps: additive factors only in this build");
+    int32_t rc = build_chains(h);
+    if (rc != CX_OK) return rc;
+    CX_REQUIRE(h, h->chain_npos >= 1 && h->chain_nlinks == h->chain_npos - 1, CX_ERR_UNSUPPORTED,
+               "cx_chain_block_maps: the non-observed variables of this handle must form ONE path (a time block of a chain)");
+    try {
+        // side sums + tile totals only (no apply): the same kernels a sweep starts with
+        h->chain_partition = true;
+        int64_t ntiles = 0;
+        cx::launch_chain_totals(h, h->d_f2v, h->chain_covers_all, &ntiles);
+        CX_HIP(h, hipGetLastError());
+        std::vector<HLin> tot((size_t)2 * (ntiles + 1));
+        if (ntiles) CX_HIP(h, hipMemcpyAsync(tot.data(), h->d_chain_totals, tot.size() * sizeof(HLin), hipMemcpyDeviceToHost, h->stream));
+        double2 sf, sl;
+        CX_HIP(h, hipMemcpyAsync(&sf, h->d_chain_side, 16, hipMemcpyDeviceToHost, h->stream));
+        CX_HIP(h, hipMemcpyAsync(&sl, h->d_chain_side + (h->chain_npos - 1), 16, hipMemcpyDeviceToHost, h->stream));
+        int32_t pv[2] = {0, 0};
+        CX_HIP(h, hipMemcpyAsync(&pv[0], h->d_chain_pos_var, 4, hipMemcpyDeviceToHost, h->stream));
+        CX_HIP(h, hipMemcpyAsync(&pv[1], h->d_chain_pos_var + (h->chain_npos - 1), 4, hipMemcpyDeviceToHost, h->stream));
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        for (int dir = 0; dir < 2; dir++) {
+            HLin t{1.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0, 0};      // identity: a block of one variable has no link
+            for (int64_t i = 0; i < ntiles; i++) t = (i == 0) ? tot[(size_t)dir * (ntiles + 1)] : hlin_compose(t, tot[(size_t)dir * (ntiles + 1) + i]);
+            double *o = dir == 0 ? fwd6 : bwd6;
+            o[0] = t.e; o[1] = t.f; o[2] = t.g; o[3] = t.A; o[4] = t.B; o[5] = t.C;
+        }
+        side_first2[0] = sf.x; side_first2[1] = sf.y; side_last2[0] = sl.x; side_last2[1] = sl.y;
+        if (first_variable_id) *first_variable_id = h->var_ids[pv[0]];
+        if (last_variable_id) *last_variable_id = h->var_ids[pv[1]];
+        if (n_links) *n_links = h->chain_nlinks;
+        return CX_OK;
+    } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_chain_block_maps: host allocation failed"); }
+}
+
 // ---- the sweep ----------------------------------------------------------------------------------------------------
 static void sweep_main(cx_handle *h, bool skip_ghosts) {
     const bool marg = h->cfg.compute_marginals_in_sweep != 0;
@@ -1289,7 +1350,7 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep: no graph");
     CX_REQUIRE(h, n_sweeps >= 0, CX_ERR_INVALID_ARGUMENT, "cx_sweep: n_sweeps < 0");
     if (h->cfg.dim > 1) return mv_sweep(h, n_sweeps);
-    CX_REQUIRE(h, h->halo_state || (h->recv_slots.empty() && h->send_slots.empty()), CX_ERR_STATE,
+    CX_REQUIRE(h, h->halo_state || h->chain_partition || (h->recv_slots.empty() && h->send_slots.empty()), CX_ERR_STATE,
                "cx_sweep: this handle holds a partition (halo configured): use cx_sweep_begin / _main / _end");
     if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) { int32_t rc = build_chains(h); if (rc != CX_OK) return rc; }
     int32_t s = 0;
@@ -1392,6 +1453,9 @@ int32_t cx_residual(cx_handle *h, double *out) {
 }
 
 // ---- halo -------------------------------------------------------------------------------------------------------
+// doubles per message in the halo buffers: the storage form (natural): 2 | d + d(d+1)/2 (packed symmetric) | 64 + 64*64
+static inline int64_t halo_doubles(const cx_handle *h) { return h->cfg.dim == 1 ? 2 : h->nc; }
+
 int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const int64_t *sf, int64_t n_recv,
                           const int64_t *rv, const int64_t *rf) {
     CX_NOT_VMP(h, "cx_halo_configure");
@@ -1435,8 +1499,8 @@ int32_t cx_halo_configure_state(cx_handle *h, int64_t n_send, const int64_t *sv,
                                 const int64_t *rv, const int64_t *rf) {
     CX_NOT_VMP(h, "cx_halo_configure_state");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_configure_state: no graph");
-    CX_REQUIRE(h, h->cfg.dim == 1 && h->cfg.schedule != CX_SCHED_CHAIN_SCAN, CX_ERR_UNSUPPORTED,
-               "cx_halo_configure_state: scalar fused / flooding schedules only");
+    CX_REQUIRE(h, h->cfg.schedule != CX_SCHED_CHAIN_SCAN, CX_ERR_UNSUPPORTED,
+               "cx_halo_configure_state: fused / flooding schedules (a chain-scan partition exchanges block maps: cx_chain_block_maps)");
     CX_REQUIRE(h, n_send >= 0 && n_recv >= 0, CX_ERR_INVALID_ARGUMENT, "cx_halo_configure_state: negative count");
     CX_REQUIRE(h, (n_send == 0 || (sv && sf)) && (n_recv == 0 || (rv && rf)), CX_ERR_INVALID_ARGUMENT, "cx_halo_configure_state: null argument");
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_halo_configure_state: a cx_sweep_begin is still open");
@@ -1455,24 +1519,38 @@ int32_t cx_halo_configure_state(cx_handle *h, int64_t n_send, const int64_t *sv,
         h->ext_halo_buffers = false;
         rc = dev_upload(h, &h->d_send_slots, h->send_slots); if (rc != CX_OK) return rc;
         rc = dev_upload(h, &h->d_recv_slots, h->recv_slots); if (rc != CX_OK) return rc;
-        rc = dev_alloc(h, &h->d_send_buf, n_send); if (rc != CX_OK) return rc;
-        rc = dev_alloc(h, &h->d_recv_buf, n_recv); if (rc != CX_OK) return rc;
+        const int64_t per = halo_doubles(h);     // doubles per message: 2 (scalar), packed natural form for dim 2..4, 4160 for dim 64
+        rc = dev_alloc(h, &h->d_send_buf, (n_send * per + 1) / 2); if (rc != CX_OK) return rc;
+        rc = dev_alloc(h, &h->d_recv_buf, (n_recv * per + 1) / 2); if (rc != CX_OK) return rc;
         CX_HIP(h, hipStreamSynchronize(h->stream));
         h->halo_state = true;
         return CX_OK;
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_halo_configure_state: host allocation failed"); }
 }
 
+static void state_pack(cx_handle *h) {
+    const int64_t n = (int64_t)h->send_slots.size();
+    if (h->cfg.dim == 1) cx::launch_gather(h, h->d_f2v, h->d_send_slots, h->d_send_buf, n);
+    else if (h->cfg.dim == 64) cx::mv64_rows_gather(h, h->d_mv_f2v, h->d_send_slots, (double *)h->d_send_buf, n);
+    else cx::mv_launch_gather(h, h->d_mv_f2v, h->nslots, h->nc, h->d_send_slots, (double *)h->d_send_buf, n);
+}
+static void state_unpack(cx_handle *h) {
+    const int64_t n = (int64_t)h->recv_slots.size();
+    if (h->cfg.dim == 1) cx::launch_scatter(h, h->d_f2v, h->d_recv_slots, h->d_recv_buf, n);
+    else if (h->cfg.dim == 64) cx::mv64_rows_scatter(h, h->d_mv_f2v, h->d_recv_slots, (const double *)h->d_recv_buf, n);
+    else cx::mv_launch_scatter(h, h->d_mv_f2v, h->nslots, h->nc, h->d_recv_slots, (const double *)h->d_recv_buf, n);
+}
+
 int32_t cx_halo_state_pack(cx_handle *h) {
     CX_REQUIRE(h, h && h->has_graph && h->halo_state, CX_ERR_STATE, "cx_halo_state_pack: call cx_halo_configure_state first");
-    cx::launch_gather(h, h->d_f2v, h->d_send_slots, h->d_send_buf, (int64_t)h->send_slots.size());
+    state_pack(h);
     CX_HIP(h, hipGetLastError());
     return CX_OK;
 }
 
 int32_t cx_halo_state_unpack(cx_handle *h) {
     CX_REQUIRE(h, h && h->has_graph && h->halo_state, CX_ERR_STATE, "cx_halo_state_unpack: call cx_halo_configure_state first");
-    cx::launch_scatter(h, h->d_f2v, h->d_recv_slots, h->d_recv_buf, (int64_t)h->recv_slots.size());
+    state_unpack(h);
     CX_HIP(h, hipGetLastError());
     return CX_OK;
 }
@@ -1480,9 +1558,9 @@ int32_t cx_halo_state_unpack(cx_handle *h) {
 int32_t cx_halo_buffers(cx_handle *h, void **send_ptr, int64_t *send_bytes, void **recv_ptr, int64_t *recv_bytes) {
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_buffers: no graph");
     if (send_ptr) *send_ptr = h->d_send_buf;
-    if (send_bytes) *send_bytes = (int64_t)h->send_slots.size() * 16;
+    if (send_bytes) *send_bytes = (int64_t)h->send_slots.size() * 8 * halo_doubles(h);
     if (recv_ptr) *recv_ptr = h->d_recv_buf;
-    if (recv_bytes) *recv_bytes = (int64_t)h->recv_slots.size() * 16;
+    if (recv_bytes) *recv_bytes = (int64_t)h->recv_slots.size() * 8 * halo_doubles(h);
     return CX_OK;
 }
 
@@ -1570,10 +1648,10 @@ int32_t cx_halo_state_exchange(cx_handle *h) {
     if (h->peers.empty()) return CX_OK;
     // pack, send/recv and unpack in stream order on the handle's own stream: no cross-stream hand-off at all (each one
     // costs ≈6 µs on this stack); the exchange happens once per `depth` sweeps, so it need not hide behind a kernel
-    cx::launch_gather(h, h->d_f2v, h->d_send_slots, h->d_send_buf, (int64_t)h->send_slots.size());
+    state_pack(h);
     std::string err;
     if (!cx::comm_exchange_on(h, h->stream, err)) return fail(h, CX_ERR_DEVICE, "cx_halo_state_exchange: " + err);
-    cx::launch_scatter(h, h->d_f2v, h->d_recv_slots, h->d_recv_buf, (int64_t)h->recv_slots.size());
+    state_unpack(h);
     CX_HIP(h, hipGetLastError());
     return CX_OK;
 }

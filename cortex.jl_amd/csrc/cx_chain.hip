@@ -291,6 +291,27 @@ void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves) {
     }
 }
 
+// side sums + tile totals only (the first two stages of a sweep), for cx_chain_block_maps; totals stay un-scanned
+void launch_chain_totals(cx_handle *h, double2 *f2v, bool fused_leaves, int64_t *ntiles_out) {
+    const int nlinks = (int)h->chain_nlinks, npos = (int)h->chain_npos;
+    const double *pa = h->any_linear ? h->d_a : nullptr, *pb = h->any_linear ? h->d_b : nullptr;
+    if (fused_leaves)
+        hipLaunchKernelGGL(k_chain_side<true>, dim3((npos + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, npos, h->d_chain_pos_var,
+                           h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, pa, pb,
+                           h->d_v2f, f2v, h->d_chain_side);
+    else
+        hipLaunchKernelGGL(k_chain_side<false>, dim3((npos + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, npos, h->d_chain_pos_var,
+                           h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, pa, pb,
+                           h->d_v2f, f2v, h->d_chain_side);
+    h->chain_side_dirty = true;     // the boundary messages will change before the sweep proper
+    const int ntiles = (nlinks + kTile - 1) / kTile;
+    *ntiles_out = ntiles;
+    if (nlinks == 0) return;
+    ChainArgs A{nlinks, h->d_chain_link_pos, h->d_chain_from, h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd,
+                h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_chain_side};
+    hipLaunchKernelGGL(k_chain_tile_totals, dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, (Lin *)h->d_chain_totals);
+}
+
 size_t chain_total_bytes(int64_t nlinks) {
     const int64_t ntiles = (nlinks + kTile - 1) / kTile;
     return (size_t)2 * (ntiles + 1) * sizeof(Lin);     // forward and backward tile totals

@@ -91,10 +91,11 @@ bool comm_exchange_on(cx_handle *h, hipStream_t stream, std::string &err) {
     ncclComm_t comm = (ncclComm_t)h->comm;
     ncclResult_t r = g_nccl.GroupStart();
     for (const auto &p : h->peers) {
+        const int64_t per = h->cfg.dim == 1 ? 2 : h->nc;     // doubles per message (storage form)
         if (r == ncclSuccess && p.send_count)
-            r = g_nccl.Send((const double *)h->d_send_buf + 2 * p.send_off, (size_t)(2 * p.send_count), ncclDouble, p.rank, comm, stream);
+            r = g_nccl.Send((const double *)h->d_send_buf + per * p.send_off, (size_t)(per * p.send_count), ncclDouble, p.rank, comm, stream);
         if (r == ncclSuccess && p.recv_count)
-            r = g_nccl.Recv((double *)h->d_recv_buf + 2 * p.recv_off, (size_t)(2 * p.recv_count), ncclDouble, p.rank, comm, stream);
+            r = g_nccl.Recv((double *)h->d_recv_buf + per * p.recv_off, (size_t)(per * p.recv_count), ncclDouble, p.rank, comm, stream);
     }
     ncclResult_t r2 = g_nccl.GroupEnd();
     if (r == ncclSuccess) r = r2;

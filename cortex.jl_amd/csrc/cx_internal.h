@@ -92,6 +92,7 @@ struct cx_handle {
     bool chains_dirty = true;
     int64_t chain_npos = 0, chain_nlinks = 0;
     bool chain_side_dirty = true;    // the leaf messages / side sums of the chain positions must be recomputed (data or rule parameters changed)
+    bool chain_partition = false;    // the handle holds a time block of a partitioned chain (cx_chain_block_maps was called)
     bool chain_covers_all = false;   // every variable that reads messages is a chain position: the scan's side pass produces all leaf messages
     int32_t *d_chain_pos_var = nullptr, *d_chain_skip0 = nullptr, *d_chain_skip1 = nullptr;
     int32_t *d_chain_link_pos = nullptr, *d_chain_from = nullptr, *d_chain_to = nullptr;
@@ -173,6 +174,7 @@ void launch_gather(cx_handle *h, const double2 *src, const int32_t *d_idx, doubl
 void launch_seed(cx_handle *h, double2 *buf, int64_t n, double2 value, const int32_t *partner);
 void launch_residual(cx_handle *h, const double2 *cur, const double2 *prev, int64_t n, double *d_out);
 void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves);
+void launch_chain_totals(cx_handle *h, double2 *f2v, bool fused_leaves, int64_t *ntiles_out);
 // two sweeps per launch (cx_tiles.hip)
 bool tiles_build(cx_handle *h, std::string &why);
 bool tiles_prepare_kernel(cx_handle *h);

@@ -197,6 +197,21 @@ class DeviceGraph:
     def halo_state_exchange(self):
         self._check(self.lib.cx_halo_state_exchange(self.h))
 
+    @property
+    def halo_doubles(self) -> int:
+        """doubles per message in the halo buffers (the storage form)"""
+        d = self.dim
+        return 2 if d == 1 else (d + d * d if d == 64 else d + d * (d + 1) // 2)
+
+    def chain_block_maps(self):
+        """cx_chain_block_maps: (forward map [6], backward map [6], side of the first variable [2], side of the last [2],
+        first variable id, last variable id, links)"""
+        f, b, sf, sl = np.zeros(6), np.zeros(6), np.zeros(2), np.zeros(2)
+        v0, v1, nl = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self.lib.cx_chain_block_maps(self.h, _p(f, C.c_double), _p(b, C.c_double), _p(sf, C.c_double), _p(sl, C.c_double),
+                                                 C.byref(v0), C.byref(v1), C.byref(nl)))
+        return f, b, sf, sl, v0.value, v1.value, nl.value
+
     def halo_buffers(self):
         sp, rp, sb, rb = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_int64()
         self._check(self.lib.cx_halo_buffers(self.h, C.byref(sp), C.byref(sb), C.byref(rp), C.byref(rb)))

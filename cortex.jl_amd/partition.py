@@ -154,6 +154,11 @@ def by_assignment(model: synth.Model, owner_of_variable, rank: int, world: int) 
     # local edges: unary + inner pairs (both edges) + cut pairs (own edge + ghost edge)
     loc_var = np.concatenate([vs[keep_unary], a_v[inner], b_v[inner], a_v[cut_a], b_v[cut_a], a_v[cut_b], b_v[cut_b]])
     loc_fac = np.concatenate([fs[keep_unary], f2[inner], f2[inner], f2[cut_a], f2[cut_a], f2[cut_b], f2[cut_b]])
+    loc_role = None
+    if model.edge_role is not None:      # directed factors (x_out = A x_in + noise): the role travels with the edge
+        ro = np.asarray(model.edge_role)[order]
+        ra, rb = ro[two], ro[two + 1]
+        loc_role = np.concatenate([ro[keep_unary], ra[inner], rb[inner], ra[cut_a], rb[cut_a], ra[cut_b], rb[cut_b]]).astype(np.int32)
     fid = np.asarray(model.factor_ids, np.int64)
     keep_f = np.isin(fid, np.unique(loc_fac))
     x_own = np.asarray(model.x_ids, np.int64)
@@ -171,7 +176,8 @@ def by_assignment(model: synth.Model, owner_of_variable, rank: int, world: int) 
         pv = pf = np.zeros(0, np.int64); pm = pvv = np.zeros(0)
     local = synth.Model(edge_var=loc_var, edge_fac=loc_fac, factor_ids=fid[keep_f], factor_kind=np.asarray(model.factor_kind)[keep_f],
                         factor_var=np.asarray(model.factor_var)[keep_f], x_ids=x_own, data_var=dv, data_fac=df, data_y=dy,
-                        prior_var=pv, prior_fac=pf, prior_mean=pm, prior_variance=pvv, meta=dict(model.meta))
+                        prior_var=pv, prior_fac=pf, prior_mean=pm, prior_variance=pvv, meta=dict(model.meta),
+                        dim=model.dim, edge_role=loc_role, psets=dict(model.psets))
     # halo lists grouped by peer, ordered by factor id within a peer
     my_v = np.concatenate([a_v[cut_a], b_v[cut_b]]); gh_v = np.concatenate([b_v[cut_a], a_v[cut_b]])
     cf = np.concatenate([f2[cut_a], f2[cut_b]]); peer = np.concatenate([b_o[cut_a], a_o[cut_b]])
@@ -231,6 +237,7 @@ def by_assignment_deep(model: synth.Model, owner_of_variable, rank: int, world: 
     keep_fac = np.unique(ef[fac_of_edge_full])
     e_keep = np.isin(ef, keep_fac) & local_v[vix]
     loc_var, loc_fac = ev[e_keep], ef[e_keep]
+    loc_role = None if model.edge_role is None else np.asarray(model.edge_role)[e_keep].astype(np.int32)
     fid = np.asarray(model.factor_ids, np.int64)
     keep_f = np.isin(fid, keep_fac)
     x_all = np.asarray(model.x_ids, np.int64)
@@ -255,7 +262,8 @@ def by_assignment_deep(model: synth.Model, owner_of_variable, rank: int, world: 
         pv = pf = np.zeros(0, np.int64); pm = pvv = np.zeros(0)
     local = synth.Model(edge_var=loc_var, edge_fac=loc_fac, factor_ids=fid[keep_f], factor_kind=np.asarray(model.factor_kind)[keep_f],
                         factor_var=np.asarray(model.factor_var)[keep_f], x_ids=x_loc, data_var=dv, data_fac=df, data_y=dy,
-                        prior_var=pv, prior_fac=pf, prior_mean=pm, prior_variance=pvv, meta=dict(model.meta))
+                        prior_var=pv, prior_fac=pf, prior_mean=pm, prior_variance=pvv, meta=dict(model.meta),
+                        dim=model.dim, edge_role=loc_role, psets=dict(model.psets))
 
     def edges_of(mask_v):
         m = mask_v[vix]
@@ -445,8 +453,9 @@ class DeepHaloRccl:
                         for p in part.peers])
         self.send = self.recv = None
         if torch is not None and device is not None:
-            self.send = torch.zeros((max(len(part.send_var), 1), 2), dtype=torch.float64, device=device)
-            self.recv = torch.zeros((max(len(part.recv_var), 1), 2), dtype=torch.float64, device=device)
+            w = getattr(dev, "halo_doubles", 2)
+            self.send = torch.zeros((max(len(part.send_var), 1), w), dtype=torch.float64, device=device)
+            self.recv = torch.zeros((max(len(part.recv_var), 1), w), dtype=torch.float64, device=device)
             dev.halo_set_buffers(self.send.data_ptr(), self.recv.data_ptr())
         if part.world > 1:
             idt = torch.zeros(128, dtype=torch.uint8, device=device)
@@ -476,8 +485,9 @@ class DeviceStateSweeper:
     def __init__(self, dev, part: Partition, torch, device):
         self.dev = dev
         dev.halo_configure_state(part.send_var, part.send_fac, part.recv_var, part.recv_fac)
-        self.send = torch.zeros((max(len(part.send_var), 1), 2), dtype=torch.float64, device=device)
-        self.recv = torch.zeros((max(len(part.recv_var), 1), 2), dtype=torch.float64, device=device)
+        w = getattr(dev, "halo_doubles", 2)      # doubles per message: the storage form of the handle's dim
+        self.send = torch.zeros((max(len(part.send_var), 1), w), dtype=torch.float64, device=device)
+        self.recv = torch.zeros((max(len(part.recv_var), 1), w), dtype=torch.float64, device=device)
         dev.halo_set_buffers(self.send.data_ptr(), self.recv.data_ptr())
 
     def pack(self):
@@ -596,6 +606,89 @@ class HaloExchange:
             for w in works:
                 w.wait()
             sw.sweep_end()
+
+
+# ---- chain-scan partition (contiguous time blocks + one composed map per block) ------------------------------
+def _lin_apply(M, m):
+    """the projective-linear map (e f g A B C; D = 1) of csrc/cx_chain.hip applied to a natural-form message (xi, w)"""
+    e, f, g, A, B, Cc = M
+    den = Cc * m[1] + 1.0
+    return np.array([(e * m[0] + f * m[1] + g) / den, (A * m[1] + B) / den])
+
+
+def _rule_additive(q, m):
+    """factor→variable rule of an additive factor on a natural-form message (test/inference_engine_tests.jl:426-427)"""
+    s = 1.0 / (1.0 + q * m[1])
+    return np.array([m[0] * s, m[1] * s])
+
+
+class ChainScanExchange:
+    """A state-space chain cut into contiguous time blocks, one chain-scan handle per rank (`partition.contiguous_blocks(model,
+    rank, world)`: the block's variables, the cut transition factors, the remote end of each as a degree-1 stand-in).
+
+    One `update()` = the exact forward/backward result of the WHOLE chain on every rank's block:
+      1. every rank asks its handle for the block's composed forward and backward maps and the side sums of its end variables
+         (`cx_chain_block_maps`: the scan's first two kernels), with the cut messages out of the picture;
+      2. ONE all-gather of 18 doubles per rank (the only collective);
+      3. every rank applies the maps of the blocks before it (after it) to the empty message and obtains the one message that
+         enters its block from the left (right): the stand-ins' variable→factor messages;
+      4. one local `cx_sweep(1)`.
+    `block` provides chain_block_maps / set_messages / sweep (a DeviceGraph, or the CPU stand-in of the tests); `dist` is
+    torch.distributed (or None for world 1)."""
+
+    def __init__(self, block, part: Partition, dist, torch, device="cpu"):
+        self.block, self.part, self.dist, self.torch, self.device = block, part, dist, torch, device
+        fv = dict(zip(np.asarray(part.model.factor_ids).tolist(), np.asarray(part.model.factor_var).tolist()))
+        self.left = self.right = None        # (stand-in variable, cut factor, own end variable, factor variance)
+        for p in part.peers:
+            assert p.send.stop - p.send.start == 1 and p.recv.stop - p.recv.start == 1, "a chain block has one cut factor per neighbour"
+            cut = int(part.recv_fac[p.recv.start])
+            rec = (int(part.recv_var[p.recv.start]), cut, int(part.send_var[p.send.start]), float(fv[cut]))
+            if p.rank < part.rank:
+                self.left = rec
+            else:
+                self.right = rec
+
+    def update(self):
+        from . import _lib as L
+
+        blk, nan2, zero2 = self.block, [float("nan")] * 2, [0.0, 0.0]
+        for rec in (self.left, self.right):
+            if rec is not None:      # the cut messages out of the picture: nothing enters, nothing is known about the stand-in
+                blk.set_messages([rec[2]], [rec[1]], L.TO_VARIABLE, L.FORM_NATURAL, zero2)
+                blk.set_messages([rec[0]], [rec[1]], L.TO_FACTOR, L.FORM_NATURAL, nan2)
+        fwd, bwd, s_first, s_last, _v0, _v1, _nl = blk.chain_block_maps()
+        mine = np.concatenate([fwd, bwd, s_first, s_last, [self.left[3] if self.left else 0.0, self.right[3] if self.right else 0.0]])
+        world, rank = self.part.world, self.part.rank
+        if world > 1:
+            t = self.torch.from_numpy(mine.copy()).to(self.device)
+            got = [self.torch.zeros_like(t) for _ in range(world)]
+            self.dist.all_gather(got, t)
+            rows = np.stack([g.cpu().numpy() for g in got])
+        else:
+            rows = mine[None, :]
+        # message that leaves block r on its right end towards the cut factor, given what entered it from the left
+        out = np.zeros(2)
+        left_in = None
+        for r in range(world):
+            F, sl, qL = rows[r, 0:6], rows[r, 14:16], rows[r, 16]
+            if r == rank:
+                left_in = out.copy() if r > 0 else None
+            enter = _rule_additive(qL, out) if r > 0 else np.zeros(2)     # through the cut factor; block 0 starts from the empty message
+            out = _lin_apply(F, enter) + sl
+        out = np.zeros(2)
+        right_in = None
+        for r in range(world - 1, -1, -1):
+            B, sf, qR = rows[r, 6:12], rows[r, 12:14], rows[r, 17]
+            if r == rank:
+                right_in = out.copy() if r < world - 1 else None
+            enter = _rule_additive(qR, out) if r < world - 1 else np.zeros(2)
+            out = _lin_apply(B, enter) + sf
+        if self.left is not None:
+            blk.set_messages([self.left[0]], [self.left[1]], L.TO_FACTOR, L.FORM_NATURAL, left_in)
+        if self.right is not None:
+            blk.set_messages([self.right[0]], [self.right[1]], L.TO_FACTOR, L.FORM_NATURAL, right_in)
+        blk.sweep(1)
 
 
 def verify_last_exchange(part: Partition, send, recv, dist, torch) -> bool:

@@ -276,7 +276,9 @@ int32_t cx_sweep_exchange(cx_handle *h, int32_t n_sweeps);
  * the frozen outer edge advances one layer per sweep and is wiped by the next exchange.  The redundant work is
  * 2*depth layers per rank; the per-sweep cost of the halo falls by the factor depth.
  *   cx_halo_configure_state : (variable, factor) of the messages exported to / imported from the neighbours, grouped by
- *                             peer like cx_halo_configure (cx_halo_peers, cx_halo_buffers, cx_halo_set_buffers apply)
+ *                             peer like cx_halo_configure (cx_halo_peers, cx_halo_buffers, cx_halo_set_buffers apply).  Any dim:
+ *                             a message travels in its storage form — 2 doubles (dim 1), d + d(d+1)/2 (dim 2..4: natural
+ *                             parameters, packed symmetric), 64 + 64*64 (dim 64)
  *   cx_halo_state_pack / _unpack : gather into the send buffer / scatter from the recv buffer (caller-owned transport)
  *   cx_halo_state_exchange  : pack, grouped ncclSend/ncclRecv, unpack — all on the handle's stream (cx_comm_init first) */
 int32_t cx_halo_configure_state(cx_handle *h, int64_t n_send, const int64_t *send_var, const int64_t *send_fac,
@@ -284,6 +286,20 @@ int32_t cx_halo_configure_state(cx_handle *h, int64_t n_send, const int64_t *sen
 int32_t cx_halo_state_pack(cx_handle *h);
 int32_t cx_halo_state_unpack(cx_handle *h);
 int32_t cx_halo_state_exchange(cx_handle *h);
+
+/* ---- partitioned chain scan (CX_SCHED_CHAIN_SCAN; SURVEY.md §8e: "contiguous time blocks + one composed map per block") ----
+ * A rank holds a time block of a chain (its own variables, the cut transition factors, the remote end of each as a degree-1
+ * stand-in named in cx_halo_configure).  The exact forward / backward messages of a block are a projective-linear function of
+ * the ONE message that enters it at either end, so the ranks exchange maps, not sweeps:
+ *   cx_chain_block_maps : the block's composed forward and backward maps over its links — 6 doubles each, (e f g A B C) of
+ *                         [xi' w' 1] ~ [[e f g] [0 A B] [0 C 1]] [xi w 1] — and the side sums (all non-chain messages) of its
+ *                         first and last variable, from the data currently on the device.  Before the call the caller sets the
+ *                         factor→variable messages of the cut factors into the block's end variables to natural (0, 0), so that
+ *                         the maps exclude them.
+ *   [caller all-gathers the maps (16 doubles per rank), composes the prefixes and sets the stand-ins' variable→factor messages]
+ *   cx_sweep(h, 1)      : the block's exact messages and marginals (cortex.jl_amd/partition.py: ChainScanExchange). */
+int32_t cx_chain_block_maps(cx_handle *h, double *forward6, double *backward6, double *side_first2, double *side_last2,
+                            int64_t *first_variable_id, int64_t *last_variable_id, int64_t *n_links);
 
 /* ---- checkpoint (the reference keeps no persistent state — src/ has no serialisation at all) ----
  * The mutable state of a handle (every message buffer, the marginals, the observed-variable flags, the sweep counter)

@@ -82,7 +82,166 @@ class OracleStateSweeper:
         return _residual(self)
 
 
+class OracleMvStateSweeper:
+    """Deep halo for d-dimensional messages with the C flooding checker (oracle/mv_flood.c) as the sweeper: the exchanged state
+    is every factor→variable message of the redundant variables, as (mean, covariance, defined) rows."""
+
+    def __init__(self, part):
+        from oracle.mv import MvFloodC
+
+        self.o = o = MvFloodC(part.model)
+        g, d = o.g, o.d
+        self.send_e = g.edge_index(part.send_var, part.send_fac) if len(part.send_var) else np.zeros(0, np.int64)
+        self.recv_e = g.edge_index(part.recv_var, part.recv_fac) if len(part.recv_var) else np.zeros(0, np.int64)
+        w = d + d * d + 1
+        self.send = torch.zeros((max(len(self.send_e), 1), w), dtype=torch.float64)
+        self.recv = torch.zeros((max(len(self.recv_e), 1), w), dtype=torch.float64)
+
+    def pack(self):
+        o, n, d = self.o, len(self.send_e), self.o.d
+        self.send[:n, :d] = torch.from_numpy(o.f2v_m[self.send_e])
+        self.send[:n, d:d + d * d] = torch.from_numpy(o.f2v_S[self.send_e].reshape(n, d * d))
+        self.send[:n, -1] = torch.from_numpy(o.f2v_def[self.send_e].astype(np.float64))
+
+    def unpack(self):
+        o, n, d = self.o, len(self.recv_e), self.o.d
+        r = self.recv[:n].numpy()
+        o.f2v_m[self.recv_e] = r[:, :d]
+        o.f2v_S[self.recv_e] = r[:, d:d + d * d].reshape(n, d, d)
+        o.f2v_def[self.recv_e] = r[:, -1].astype(np.uint8)
+
+    def sweep(self, n=1):
+        self.o.sweep(n)
+
+
+class OracleChainBlock:
+    """CPU stand-in for a chain-scan DeviceGraph holding ONE time block (what partition.ChainScanExchange drives): the same
+    three entry points — chain_block_maps, set_messages, sweep — in numpy, natural form, with the map algebra of
+    csrc/cx_chain.hip."""
+
+    def __init__(self, part):
+        m = part.model
+        self.x = np.sort(np.asarray(m.x_ids))
+        fv = dict(zip(np.asarray(m.factor_ids).tolist(), np.asarray(m.factor_var).tolist()))
+        ev, ef = np.asarray(m.edge_var), np.asarray(m.edge_fac)
+        fac_of = {}
+        for v, f in zip(ev.tolist(), ef.tolist()):
+            fac_of.setdefault(f, []).append(v)
+        own = set(self.x.tolist())
+        pos = {int(v): i for i, v in enumerate(self.x)}
+        n = len(self.x)
+        self.q = np.zeros(max(n - 1, 0))
+        self.side = np.zeros((n, 2))
+        y = dict(zip(np.asarray(m.data_var).tolist(), np.asarray(m.data_y).tolist()))
+        for f, vs in fac_of.items():
+            a, b = sorted(vs)
+            if a in own and b in own:
+                self.q[pos[a]] = fv[f]                       # transition x_a -> x_b, consecutive in the block
+            elif (a in y) != (b in y):                       # likelihood: datum on one side
+                xv, yv = (b, a) if a in y else (a, b)
+                self.side[pos[xv]] += [y[yv] / fv[f], 1.0 / fv[f]]
+        self.boundary = {}
+        self.ends = {}                                       # cut factor -> (own end variable, variance)
+        for f, vs in fac_of.items():
+            a, b = sorted(vs)
+            if (a in own) != (b in own) and a not in y and b not in y:
+                self.ends[f] = (a if a in own else b, fv[f])
+
+    @staticmethod
+    def _link(u, q):
+        D = 1.0 + q * u[1]
+        return np.array([1.0 / D, 0.0, u[0] / D, 1.0 / D, u[1] / D, q / D])
+
+    @staticmethod
+    def _compose(first, second):
+        e1, f1, g1, A1, B1, C1 = first
+        e2, f2, g2, A2, B2, C2 = second
+        inv = 1.0 / (C2 * B1 + 1.0)
+        return np.array([e2 * e1, e2 * f1 + f2 * A1 + g2 * C1, e2 * g1 + f2 * B1 + g2, A2 * A1 + B2 * C1, A2 * B1 + B2, C2 * A1 + C1]) * inv
+
+    def chain_block_maps(self):
+        n = len(self.x)
+        ident = np.array([1.0, 0.0, 0.0, 1.0, 0.0, 0.0])
+        F, B = ident.copy(), ident.copy()
+        for l in range(n - 1):
+            F = self._link(self.side[l], self.q[l]) if l == 0 else self._compose(F, self._link(self.side[l], self.q[l]))
+        for l in range(n - 2, -1, -1):
+            Lk = self._link(self.side[l + 1], self.q[l])
+            B = Lk if l == n - 2 else self._compose(B, Lk)
+        return F, B, self.side[0].copy(), self.side[-1].copy(), int(self.x[0]), int(self.x[-1]), n - 1
+
+    def set_messages(self, var, fac, direction, form, payload):
+        from cortex.jl_amd import _lib as L
+
+        if direction == L.TO_FACTOR:                         # a stand-in's message into its cut factor: the block's boundary input
+            self.boundary[int(fac[0])] = np.asarray(payload, dtype=float)
+
+    def sweep(self, n=1):
+        from cortex.jl_amd.partition import _lin_apply, _rule_additive
+
+        nx = len(self.x)
+        alpha, beta = np.zeros((nx, 2)), np.zeros((nx, 2))
+        for f, (end, q) in self.ends.items():
+            b = self.boundary.get(f)
+            if b is None or np.isnan(b[1]):
+                continue
+            if end == self.x[0] and not (nx == 1 and f == max(self.ends)):
+                alpha[0] = _rule_additive(q, b)
+            else:
+                beta[-1] = _rule_additive(q, b)
+        if nx == 1 and len(self.ends) == 2:                  # a one-variable block: lower cut factor id is the left one
+            fl, fr = sorted(self.ends)
+            alpha[0] = _rule_additive(self.ends[fl][1], self.boundary[fl]); beta[0] = _rule_additive(self.ends[fr][1], self.boundary[fr])
+        for l in range(nx - 1):
+            alpha[l + 1] = _rule_additive(self.q[l], alpha[l] + self.side[l])
+        for l in range(nx - 2, -1, -1):
+            beta[l] = _rule_additive(self.q[l], beta[l + 1] + self.side[l + 1])
+        nat = alpha + beta + self.side
+        self.marg_mean, self.marg_var = nat[:, 0] / nat[:, 1], 1.0 / nat[:, 1]
+
+
+def main_chain():
+    """argv: chain T out — time blocks of a scalar state-space chain, ChainScanExchange over gloo"""
+    import cortex.jl_amd as cx
+
+    T, out = int(sys.argv[2]), sys.argv[3]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    whole = cx.synth.ssm_chain(T, seed=8, random_variances=True)
+    part = partition.contiguous_blocks(whole, rank, world)
+    blk = OracleChainBlock(part)
+    ex = partition.ChainScanExchange(blk, part, dist, torch)
+    ex.update()
+    np.savez(out + f".rank{rank}.npz", x=blk.x, mean=blk.marg_mean, var=blk.marg_var)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main_mv():
+    """argv: mv d T sweeps depth out — time blocks of a d-dimensional chain with a deep halo over gloo"""
+    import cortex.jl_amd as cx
+
+    d, T, sweeps, depth, out = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    whole = cx.synth.lgssm_chain(T, d=d, seed=6)
+    part = partition.contiguous_blocks(whole, rank, world, depth=depth)
+    sw = OracleMvStateSweeper(part)
+    sw.o.seed(0.0, 1e6)
+    ex = partition.DeepHaloExchange(sw, part, dist)
+    ex.sweep(sweeps)
+    m, S, ok = sw.o.marginals()
+    li = np.searchsorted(sw.o.g.var_ids, part.owned_x)
+    np.savez(out + f".rank{rank}.npz", owned=part.owned_x, mean=m[li], cov=S[li], ok=ok[li])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
+    if sys.argv[1] == "chain":
+        return main_chain()
+    if sys.argv[1] == "mv":
+        return main_mv()
     rows, cols, sweeps, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     depth = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     strong = len(sys.argv) > 6 and sys.argv[6] == "strong"    # `rows` is then the whole grid's row count (uneven blocks)

@@ -47,6 +47,18 @@ class LoopbackDist:
     def irecv(self, *a):
         raise NotImplementedError
 
+    def all_gather(self, out_list, tensor):
+        """every rank contributes one tensor per call, in call order (a per-rank round counter)"""
+        me = self.local.rank
+        rnd = getattr(self.local, "round", 0)
+        self.local.round = rnd + 1
+        with self.cv:
+            self.box[("ag", rnd, me)] = tensor.clone()
+            self.cv.notify_all()
+            assert self.cv.wait_for(lambda: all(("ag", rnd, r) in self.box for r in range(self.world)), timeout=60), "all_gather never completed"
+            for r in range(self.world):
+                out_list[r].copy_(self.box[("ag", rnd, r)])
+
     def batch_isend_irecv(self, ops):
         me = self.local.rank
         works = []
@@ -362,3 +374,127 @@ def test_generic_deep_partition_of_random_sparse_graphs_on_device(hip_lib, seed,
         assert np.array_equal(devs[rank].get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL),
                               whole.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL), equal_nan=True)
         assert np.array_equal(devs[rank].get_marginals(part.owned_x), whole.get_marginals(part.owned_x), equal_nan=True)
+
+
+@pytest.mark.parametrize("d,T,world,depth", [(4, 300, 3, 3), (2, 64, 2, 2), (64, 14, 2, 2)])
+def test_deep_halo_for_d_dimensional_messages_on_device(hip_lib, d, T, world, depth):
+    """dim > 1 partitions: time blocks of a d-dimensional linear-Gaussian chain with a deep halo — the state
+    halo carries messages in their storage form (packed natural parameters for d <= 4, 4160 doubles for d = 64).  `world`
+    handles on one GPU, in-process transport; owned marginals equal the un-partitioned device sweeps bit for bit."""
+    import torch
+
+    sweeps = 3 * depth + 2
+    whole_model = cx.synth.lgssm_chain(T, d=d, seed=9)
+    whole = cx.DeviceGraph(dim=d, schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(whole_model, whole, seed_variance=1e6)
+    whole.sweep(sweeps)
+    ld = LoopbackDist(world, torch)
+    devs, parts, errors = [None] * world, [None] * world, []
+
+    def run(rank):
+        try:
+            ld.bind(rank)
+            part = partition.contiguous_blocks(whole_model, rank, world, depth=depth)
+            dev = cx.DeviceGraph(dim=d, schedule=L.SCHED_FUSED)
+            cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
+            sw = partition.DeviceStateSweeper(dev, part, torch, torch.device("cuda", 0))
+            assert sw.send.shape[1] == dev.halo_doubles
+            ex = partition.DeepHaloExchange(sw, part, ld)
+            ex.sweep(sweeps)
+            dev.sync()
+            devs[rank], parts[rank] = dev, part
+        except Exception as e:  # pragma: no cover
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=180)
+    assert not errors, errors
+    total = 0
+    for rank in range(world):
+        ids = parts[rank].owned_x
+        assert np.array_equal(devs[rank].get_marginals(ids), whole.get_marginals(ids), equal_nan=True), f"rank {rank}"
+        m = parts[rank].model
+        own = np.isin(m.edge_var, ids)
+        assert np.array_equal(devs[rank].get_messages(m.edge_var[own], m.edge_fac[own], L.TO_VARIABLE, L.FORM_NATURAL),
+                              whole.get_messages(m.edge_var[own], m.edge_fac[own], L.TO_VARIABLE, L.FORM_NATURAL), equal_nan=True)
+        total += len(ids)
+    assert total == T
+
+
+@pytest.mark.parametrize("T,world", [(90, 3), (17, 4), (250_001, 8)])
+def test_chain_scan_partition_on_device(hip_lib, T, world):
+    """The chain-scan schedule cut into time blocks: one chain-scan handle per block, ONE all-gather
+    of the blocks' composed maps (cx_chain_block_maps), one local sweep — every block then holds the exact posterior of the
+    WHOLE chain.  T = 250,001 over 8 blocks is BASELINE config C2 (1,000,002 edges) in the 8-way cut."""
+    import torch
+
+    from oracle import exact
+
+    whole_model = cx.synth.ssm_chain(T, seed=1234, random_variances=T < 1000)
+    whole = cx.DeviceGraph(schedule=L.SCHED_CHAIN_SCAN)
+    cx.synth.load_into_device(whole_model, whole)
+    whole.sweep(1)
+    ld = LoopbackDist(world, torch)
+    devs, parts, errors = [None] * world, [None] * world, []
+
+    def run(rank):
+        try:
+            ld.bind(rank)
+            part = partition.contiguous_blocks(whole_model, rank, world)
+            dev = cx.DeviceGraph(schedule=L.SCHED_CHAIN_SCAN)
+            cx.synth.load_into_device(part.model, dev)
+            ex = partition.ChainScanExchange(dev, part, ld, torch)
+            ex.update()
+            dev.sync()
+            devs[rank], parts[rank] = (dev, ex), part
+        except Exception as e:  # pragma: no cover
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    em, ev = exact.ssm_chain_posterior(whole_model.data_y, whole_model.meta["r"], whole_model.meta["q"])
+    total = 0
+    for rank in range(world):
+        ids = parts[rank].model.x_ids
+        got, ref_ = devs[rank][0].get_marginals(ids), whole.get_marginals(ids)
+        assert_close(got[:, 0], ref_[:, 0], 1e-10, f"rank {rank}: mean vs the un-partitioned chain scan")
+        assert_close(got[:, 1], ref_[:, 1], 1e-10, f"rank {rank}: variance vs the un-partitioned chain scan")
+        assert_close(got[:, 0], em[ids - 1], 1e-9, f"rank {rank}: mean vs Thomas solve")
+        assert_close(got[:, 1], ev[ids - 1], 1e-9, f"rank {rank}: variance vs Thomas solve")
+        total += len(ids)
+    assert total == T
+    # new data: the exchange repeats (maps recomputed from the new side sums) and tracks the new posterior
+    rng = np.random.default_rng(5)
+    y2 = whole_model.data_y + rng.standard_normal(T)
+    for rank in range(world):
+        dev, ex = devs[rank]
+        m = parts[rank].model
+        sel = np.searchsorted(whole_model.data_var, m.data_var)
+        dev.set_messages(m.data_var, m.data_fac, L.TO_FACTOR, L.FORM_POINT, y2[sel])
+
+    def again(rank):
+        try:
+            ld.bind(rank)
+            ld.local.round = 1
+            devs[rank][1].update()
+        except Exception as e:  # pragma: no cover
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=again, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    em2, ev2 = exact.ssm_chain_posterior(y2, whole_model.meta["r"], whole_model.meta["q"])
+    for rank in range(world):
+        ids = parts[rank].model.x_ids
+        got = devs[rank][0].get_marginals(ids)
+        assert_close(got[:, 0], em2[ids - 1], 1e-9, f"rank {rank}: mean after new data")

@@ -347,3 +347,65 @@ def test_bench_launches_its_own_ranks():
                        env=dict(env, CX_BENCH_FAIL_RANK="2"), cwd=ROOT, capture_output=True, text=True, timeout=240)
     assert r.returncode == 7
     assert "rank 2 exited with 7" in r.stderr
+
+
+def _spawn(world, args):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py")] + [str(a) for a in args], env=env, cwd=ROOT))
+    try:
+        for p in procs:
+            assert p.wait(timeout=240) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+
+
+@pytest.mark.parametrize("world,T", [(2, 40), (3, 41), (4, 9)])
+def test_gloo_chain_scan_partition_is_the_exact_smoother(tmp_path, world, T):
+    """SURVEY §8e for chains: contiguous time blocks, ONE all-gather of the blocks' composed maps, a local pass
+    (partition.ChainScanExchange over gloo, a numpy block standing in for the chain-scan handle): every rank's marginals are
+    the exact posterior of the WHOLE chain (Thomas solve)."""
+    from oracle import exact
+
+    out = str(tmp_path / "res")
+    _spawn(world, ["chain", T, out])
+    whole = cx.synth.ssm_chain(T, seed=8, random_variances=True)
+    em, ev = exact.ssm_chain_posterior(whole.data_y, whole.meta["r"], whole.meta["q"])
+    seen = []
+    for r in range(world):
+        d = np.load(out + f".rank{r}.npz")
+        idx = d["x"] - 1
+        np.testing.assert_allclose(d["mean"], em[idx], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(d["var"], ev[idx], rtol=1e-10)
+        seen.append(d["x"])
+    assert np.array_equal(np.sort(np.concatenate(seen)), whole.x_ids)
+
+
+@pytest.mark.parametrize("world,d,depth", [(2, 4, 2), (3, 2, 3)])
+def test_gloo_deep_halo_for_d_dimensional_messages(tmp_path, world, d, depth):
+    """dim > 1 partitions: time blocks of a d-dimensional chain with a deep halo (partition.contiguous_blocks(..., depth) carries
+    edge roles and parameter sets; DeepHaloExchange moves (mean, covariance) rows), the C checker as the sweeper: owned marginals
+    equal the single-process flooding sweeps bit for bit."""
+    from oracle.mv import MvFloodC
+
+    T, sweeps = 24, 3 * depth + 1
+    out = str(tmp_path / "res")
+    _spawn(world, ["mv", d, T, sweeps, depth, out])
+    whole = cx.synth.lgssm_chain(T, d=d, seed=6)
+    o = MvFloodC(whole)
+    o.seed(0.0, 1e6)
+    o.sweep(sweeps)
+    m, S, ok = o.marginals()
+    seen = []
+    for r in range(world):
+        g = np.load(out + f".rank{r}.npz")
+        li = np.searchsorted(o.g.var_ids, g["owned"])
+        assert ok[li].all() and g["ok"].all()
+        assert np.array_equal(g["mean"], m[li]) and np.array_equal(g["cov"], S[li])
+        seen.append(g["owned"])
+    assert np.array_equal(np.sort(np.concatenate(seen)), np.sort(whole.x_ids))
