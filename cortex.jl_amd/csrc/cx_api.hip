@@ -1284,6 +1284,9 @@ int32_t cx_chain_block_maps(cx_handle *h, double *fwd6, double *bwd6, double *si
         // side sums + tile totals only (no apply): the same kernels a sweep starts with
         h->chain_partition = true;
         int64_t ntiles = 0;
+        // as in sweep_main: when variables off the chain read messages too (the stand-ins do), the leaf messages come from a
+        // factor phase over all slots, otherwise from the side pass itself
+        if (!h->chain_covers_all) cx::launch_factor_to_var(h, h->d_v2f, h->d_f2v);
         cx::launch_chain_totals(h, h->d_f2v, h->chain_covers_all, &ntiles);
         CX_HIP(h, hipGetLastError());
         std::vector<HLin> tot((size_t)2 * (ntiles + 1));
