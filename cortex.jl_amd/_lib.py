@@ -83,6 +83,7 @@ SIGNATURES = {
     "cx_sweep_exchange": (_i32, [_vp, _i32]),
     "cx_sweep_until": (_i32, [_vp, _dbl, _i32, _i32, _pi32, _pd]),
     "cx_halo_configure_state": (_i32, [_vp, _i64, _pi64, _pi64, _i64, _pi64, _pi64]),
+    "cx_halo_set_layers": (_i32, [_vp, _i64, _pi64, _pi32, _i32]),
     "cx_halo_state_pack": (_i32, [_vp]),
     "cx_halo_state_unpack": (_i32, [_vp]),
     "cx_halo_state_exchange": (_i32, [_vp]),

@@ -1375,7 +1375,17 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
             h->sweeps_done += 2;
         }
     }
-    for (; s < n_sweeps; s++) { sweep_main(h, false); sweep_finish(h); h->alt_two_back = false; }
+    for (; s < n_sweeps; s++) {
+        h->run_slice0 = 0; h->run_nslices = 0;
+        if (h->halo_state && h->halo_depth > 0 && h->cfg.schedule == CX_SCHED_FUSED && h->big_vars.empty()) {
+            const int j = std::min(h->sweeps_since_exchange + 1, h->halo_depth);     // this is sweep j after the exchange
+            const int L = h->halo_depth - j + 1;                                       // layers that have to run
+            if (h->trim_hi[L] >= h->trim_lo[L]) { h->run_slice0 = h->trim_lo[L]; h->run_nslices = h->trim_hi[L] - h->trim_lo[L] + 1; }
+        }
+        sweep_main(h, false); sweep_finish(h); h->alt_two_back = false;
+        h->run_slice0 = 0; h->run_nslices = 0;
+        h->sweeps_since_exchange++;
+    }
     CX_HIP(h, hipGetLastError());
     return CX_OK;
 }
@@ -1527,6 +1537,7 @@ int32_t cx_halo_configure_state(cx_handle *h, int64_t n_send, const int64_t *sv,
         rc = dev_alloc(h, &h->d_recv_buf, (n_recv * per + 1) / 2); if (rc != CX_OK) return rc;
         CX_HIP(h, hipStreamSynchronize(h->stream));
         h->halo_state = true;
+        h->halo_depth = 0; h->trim_lo.clear(); h->trim_hi.clear(); h->sweeps_since_exchange = 0;
         return CX_OK;
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_halo_configure_state: host allocation failed"); }
 }
@@ -1544,6 +1555,35 @@ static void state_unpack(cx_handle *h) {
     else cx::mv_launch_scatter(h, h->d_mv_f2v, h->nslots, h->nc, h->d_recv_slots, (const double *)h->d_recv_buf, n);
 }
 
+// Deep halo, trimmed sweeps.  `layer` = distance of a redundant variable from the owned set (1 .. depth; the stand-ins beyond are
+// depth + 1; owned variables 0 and need not be listed).  After an exchange every layer is valid; sweep j (1-based) leaves layers
+// <= depth - j valid and, to do so, has to RUN the variables of layers <= depth - j + 1 (a variable's new messages are pushed by
+// its neighbours' threads).  cx_sweep therefore launches only the slices that hold such variables: on row strips of a grid
+// (depth + 1) / 2 redundant rows per side per sweep on average instead of depth.  Results of owned variables are unchanged.
+int32_t cx_halo_set_layers(cx_handle *h, int64_t n, const int64_t *variable_ids, const int32_t *layer, int32_t depth) {
+    CX_REQUIRE(h, h && h->has_graph && h->halo_state, CX_ERR_STATE, "cx_halo_set_layers: call cx_halo_configure_state first");
+    CX_REQUIRE(h, depth >= 1 && n >= 0 && (n == 0 || (variable_ids && layer)), CX_ERR_INVALID_ARGUMENT, "cx_halo_set_layers: bad argument");
+    try {
+        std::vector<int32_t> lay(h->nv, 0);
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t v = find_var(h, variable_ids[i]);
+            if (v < 0) return fail(h, CX_ERR_NOT_FOUND, "unknown variable id " + std::to_string(variable_ids[i]));
+            if (layer[i] < 0) return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_halo_set_layers: negative layer");
+            lay[v] = layer[i];
+        }
+        h->trim_lo.assign(depth + 1, (int32_t)h->nslices); h->trim_hi.assign(depth + 1, -1);
+        for (int64_t v = 0; v < h->nv; v++) {
+            const int32_t s = (int32_t)(v >> cx::kSliceShift);
+            for (int32_t L = std::min<int32_t>(lay[v], depth + 1); L <= depth; L++) {   // a variable of layer l belongs to every set "layer <= L", L >= l
+                h->trim_lo[L] = std::min(h->trim_lo[L], s); h->trim_hi[L] = std::max(h->trim_hi[L], s);
+            }
+        }
+        h->halo_depth = depth;
+        h->sweeps_since_exchange = 0;
+        return CX_OK;
+    } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_halo_set_layers: host allocation failed"); }
+}
+
 int32_t cx_halo_state_pack(cx_handle *h) {
     CX_REQUIRE(h, h && h->has_graph && h->halo_state, CX_ERR_STATE, "cx_halo_state_pack: call cx_halo_configure_state first");
     state_pack(h);
@@ -1554,6 +1594,7 @@ int32_t cx_halo_state_pack(cx_handle *h) {
 int32_t cx_halo_state_unpack(cx_handle *h) {
     CX_REQUIRE(h, h && h->has_graph && h->halo_state, CX_ERR_STATE, "cx_halo_state_unpack: call cx_halo_configure_state first");
     state_unpack(h);
+    h->sweeps_since_exchange = 0;
     CX_HIP(h, hipGetLastError());
     return CX_OK;
 }
@@ -1655,6 +1696,7 @@ int32_t cx_halo_state_exchange(cx_handle *h) {
     std::string err;
     if (!cx::comm_exchange_on(h, h->stream, err)) return fail(h, CX_ERR_DEVICE, "cx_halo_state_exchange: " + err);
     state_unpack(h);
+    h->sweeps_since_exchange = 0;
     CX_HIP(h, hipGetLastError());
     return CX_OK;
 }

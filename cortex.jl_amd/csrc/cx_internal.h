@@ -106,6 +106,10 @@ struct cx_handle {
     double2 *d_send_buf = nullptr, *d_recv_buf = nullptr;
     bool ext_halo_buffers = false;
     bool halo_state = false;         // halo lists name factor→variable messages of redundant variables (deep halo)
+    // deep halo: redundant layer of each variable (cx_halo_set_layers) -> slice range that sweep j after an exchange has to run
+    int halo_depth = 0, sweeps_since_exchange = 0;
+    std::vector<int32_t> trim_lo, trim_hi;   // [depth + 1]: first / last slice holding a variable of layer <= L
+    int run_slice0 = 0, run_nslices = 0;     // what launch_fused covers (0 slices: everything)
     // RCCL exchange issued by the library (cx_comm.hip)
     struct Peer { int rank; int64_t send_off, send_count, recv_off, recv_count; };
     std::vector<Peer> peers;

@@ -188,6 +188,11 @@ class DeviceGraph:
         self._check(self.lib.cx_halo_configure_state(self.h, len(sv), _p(sv, C.c_int64), _p(sf, C.c_int64), len(rv),
                                                      _p(rv, C.c_int64), _p(rf, C.c_int64)))
 
+    def halo_set_layers(self, variable_ids, layers, depth: int):
+        v = _i64(np.atleast_1d(variable_ids))
+        lay = np.ascontiguousarray(np.atleast_1d(layers), dtype=np.int32)
+        self._check(self.lib.cx_halo_set_layers(self.h, len(v), _p(v, C.c_int64), _p(lay, C.c_int32), int(depth)))
+
     def halo_state_pack(self):
         self._check(self.lib.cx_halo_state_pack(self.h))
 

@@ -37,6 +37,8 @@ class Partition:
     peers: List[Peer] = field(default_factory=list)
     depth: int = 0                 # 0: per-sweep message halo; w > 0: state ("deep") halo exchanged every w sweeps
     owned_x: np.ndarray = None     # deep halo: the latent variables this rank owns (model.x_ids also lists the redundant ones)
+    layer_var: np.ndarray = None   # deep halo: ids of the redundant variables and stand-ins ...
+    layer: np.ndarray = None       # ... and their distance from the owned set (1 .. depth, stand-ins depth + 1): cx_halo_set_layers
 
 
 def _row_bounds(n_rows: int, world: int) -> np.ndarray:
@@ -109,8 +111,12 @@ def _grid_cut_deep(total: int, n_cols: int, bounds, rank: int, depth: int, seed:
     cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.int64)  # noqa: E731
     jj = np.arange(n_cols, dtype=np.int64)
     owned = (1 + np.arange(r0, r1, dtype=np.int64)[:, None] * n_cols + jj[None, :]).ravel()
+    vids = np.unique(ev)
+    vrow = (vids - 1) // n_cols
+    lay = np.where(vrow < r0, r0 - vrow, np.where(vrow >= r1, vrow - r1 + 1, 0))
+    red = lay > 0
     return Partition(model=model, rank=rank, world=world, send_var=cat(sv), send_fac=cat(sf), recv_var=cat(rv), recv_fac=cat(rf),
-                     peers=peers, depth=depth, owned_x=owned)
+                     peers=peers, depth=depth, owned_x=owned, layer_var=vids[red], layer=lay[red].astype(np.int32))
 
 
 def grid_strip_deep(rows_per_rank: int, n_cols: int, rank: int, world: int, depth: int, seed: int = 1234) -> Partition:
@@ -287,8 +293,9 @@ def by_assignment_deep(model: synth.Model, owner_of_variable, rank: int, world: 
         peers.append(Peer(q, slice(ps, ps + len(a_)), slice(pr, pr + len(c_))))
         ps += len(a_); pr += len(c_)
     cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.int64)  # noqa: E731
+    red = dist_me > 0
     return Partition(model=local, rank=rank, world=world, send_var=cat(sv), send_fac=cat(sf), recv_var=cat(rv), recv_fac=cat(rf),
-                     peers=peers, depth=depth, owned_x=x_own)
+                     peers=peers, depth=depth, owned_x=x_own, layer_var=vids[red], layer=dist_me[red].astype(np.int32))
 
 
 def metis_assignment(model: synth.Model, world: int):
@@ -449,6 +456,8 @@ class DeepHaloRccl:
     def __init__(self, dev, part: Partition, dist=None, torch=None, device=None):
         self.dev, self.depth, self.k = dev, part.depth, 0
         dev.halo_configure_state(part.send_var, part.send_fac, part.recv_var, part.recv_fac)
+        if part.layer_var is not None and part.depth and dev.dim == 1:
+            dev.halo_set_layers(part.layer_var, part.layer, part.depth)    # trimmed sweeps between exchanges
         dev.halo_peers([(p.rank, p.send.start, p.send.stop - p.send.start, p.recv.start, p.recv.stop - p.recv.start)
                         for p in part.peers])
         self.send = self.recv = None
@@ -485,6 +494,8 @@ class DeviceStateSweeper:
     def __init__(self, dev, part: Partition, torch, device):
         self.dev = dev
         dev.halo_configure_state(part.send_var, part.send_fac, part.recv_var, part.recv_fac)
+        if part.layer_var is not None and part.depth and dev.dim == 1:
+            dev.halo_set_layers(part.layer_var, part.layer, part.depth)    # trimmed sweeps between exchanges
         w = getattr(dev, "halo_doubles", 2)      # doubles per message: the storage form of the handle's dim
         self.send = torch.zeros((max(len(part.send_var), 1), w), dtype=torch.float64, device=device)
         self.recv = torch.zeros((max(len(part.recv_var), 1), w), dtype=torch.float64, device=device)

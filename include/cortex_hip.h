@@ -283,6 +283,11 @@ int32_t cx_sweep_exchange(cx_handle *h, int32_t n_sweeps);
  *   cx_halo_state_exchange  : pack, grouped ncclSend/ncclRecv, unpack — all on the handle's stream (cx_comm_init first) */
 int32_t cx_halo_configure_state(cx_handle *h, int64_t n_send, const int64_t *send_var, const int64_t *send_fac,
                                 int64_t n_recv, const int64_t *recv_var, const int64_t *recv_fac);
+/*   cx_halo_set_layers      : optional.  layer[i] = distance (1 .. depth; stand-ins depth + 1) of redundant variable_ids[i] from the
+ *                             owned set.  cx_sweep then runs, in the j-th sweep after an exchange, only the slices that hold
+ *                             variables of layer <= depth - j + 1 — the layers that can still be valid — instead of the whole local
+ *                             graph (fused schedule).  Owned results are unchanged bit for bit. */
+int32_t cx_halo_set_layers(cx_handle *h, int64_t n, const int64_t *variable_ids, const int32_t *layer, int32_t depth);
 int32_t cx_halo_state_pack(cx_handle *h);
 int32_t cx_halo_state_unpack(cx_handle *h);
 int32_t cx_halo_state_exchange(cx_handle *h);

@@ -33,7 +33,7 @@ def self_exchange(part):
     n = [min(p.send.stop - p.send.start, p.recv.stop - p.recv.start) for p in ps]
     peers = [partition.Peer(0, slice(p.send.start, p.send.start + k), slice(p.recv.start, p.recv.start + k)) for p, k in zip(ps, n)]
     return partition.Partition(model=part.model, rank=0, world=1, send_var=part.send_var, send_fac=part.send_fac, recv_var=part.recv_var,
-                               recv_fac=part.recv_fac, peers=peers, depth=part.depth, owned_x=part.owned_x)
+                               recv_fac=part.recv_fac, peers=peers, depth=part.depth, owned_x=part.owned_x, layer_var=part.layer_var, layer=part.layer)
 
 
 def main():
@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--sweeps", type=int, default=4000)
     ap.add_argument("--exchange", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="sweeps per cx_sweep call (default: depth)")
+    ap.add_argument("--no-trim", action="store_true", help="run every redundant row in every sweep (no cx_halo_set_layers)")
     a = ap.parse_args()
     torch.cuda.init()
     N = a.grid
@@ -61,6 +62,8 @@ def main():
     whole.close()
     for depth in a.depth:
         part = partition.grid_rows_deep(N, N, a.rank, a.world, depth, seed=1234)
+        if a.no_trim:
+            part.layer_var = part.layer = None
         dev = cx.DeviceGraph(schedule=L.SCHED_FUSED)
         dev.set_stream(torch.cuda.current_stream().cuda_stream)
         cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
@@ -68,6 +71,9 @@ def main():
         ex = None
         if a.exchange:
             ex = partition.DeepHaloRccl(dev, self_exchange(part), None, torch, torch.device("cuda", 0))
+        elif not a.no_trim:     # no exchange: the trimming schedule restarts every `depth` sweeps as if one had happened
+            dev.halo_configure_state([], [], [], [])
+            dev.halo_set_layers(part.layer_var, part.layer, depth)
         batch = a.batch or depth
 
         def run(n):
@@ -76,6 +82,8 @@ def main():
             else:
                 while n > 0:
                     k = min(n, batch)
+                    if not a.no_trim:
+                        dev.halo_state_unpack()      # empty lists: only restarts the count of sweeps since the last exchange
                     dev.sweep(k)
                     n -= k
         run(400)
