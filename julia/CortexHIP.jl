@@ -12,7 +12,7 @@ const lib = "libcortex_hip.so"
 
 struct CxConfig            # mirrors cx_config
     struct_size::Int32; device::Int32; dim::Int32; schedule::Int32
-    compute_marginals_in_sweep::Int32; materialize_messages_to_factor::Int32; family::Int32; reserved::Int32
+    compute_marginals_in_sweep::Int32; materialize_messages_to_factor::Int32; family::Int32; sweeps_per_launch::Int32
 end
 struct CxItem              # mirrors cx_item
     kind::Int32; reserved::Int32; variable_id::Int64; factor_id::Int64
@@ -56,6 +56,8 @@ function Cortex.process!(p::HipProcessor, engine::Cortex.InferenceEngine, variab
     item = v isa Cortex.InferenceSignalVariants.MessageToVariable ? CxItem(2, 0, v.variable_id, v.factor_id) :
            v isa Cortex.InferenceSignalVariants.MessageToFactor   ? CxItem(1, 0, v.variable_id, v.factor_id) :
            v isa Cortex.InferenceSignalVariants.IndividualMarginal ? CxItem(4, 0, v.variable_id, 0) :
+           v isa Cortex.InferenceSignalVariants.ProductOfMessages  ? CxItem(8, 0, v.variable_id, (Int64(first(v.range)) << 32) | Int64(last(v.range))) :   # CX_ITEM_RANGE
+           v isa Cortex.InferenceSignalVariants.JointMarginal      ? CxItem(16, 0, 0, v.factor_id) :
            error("The HIP processor has no rule for $(typeof(v))")
     push!(p.queue, item); push!(p.signals, signal)
     flush!(p)                       # or defer: flush once per scan wavefront

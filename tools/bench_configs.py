@@ -39,7 +39,13 @@ def counter_traffic(kernel_substr):
 
 
 def roofline(bound, achieved, peak, unit, traffic, **extra):
-    r = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak, "traffic": traffic}
+    frac = achieved / peak
+    r = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": frac, "traffic": traffic}
+    if traffic is None and frac > 1.0:
+        # without counter traffic only the SURVEY §8d convention is available, and a kernel that moves fewer bytes than the
+        # convention counts would read above 1: not a physical fraction, so none is printed
+        r["frac"] = None
+        r["frac_note"] = "no counter traffic on file (tools/profile_configs.sh); the algorithmic convention over-counts this kernel's bytes"
     r.update(extra)
     return r
 
