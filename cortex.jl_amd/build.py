@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcortex_hip.so")
-SOURCES = ["cx_api.hip", "cx_kernels.hip", "cx_tiles.hip", "cx_chain.hip", "cx_mv.hip", "cx_mv64.hip", "cx_comm.hip", "cx_vmp.hip"]
+SOURCES = ["cx_api.hip", "cx_kernels.hip", "cx_tiles.hip", "cx_chain.hip", "cx_mv.hip", "cx_mv64.hip", "cx_mv64w.hip", "cx_comm.hip", "cx_vmp.hip"]
 HEADERS = [os.path.join(CSRC, "cx_internal.h"), os.path.join(ROOT, "include", "cortex_hip.h")]
 
 

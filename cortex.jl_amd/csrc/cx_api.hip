@@ -59,7 +59,7 @@ void dev_free_all(cx_handle *h) {
                     h->d_vinfo, h->d_q, h->d_a, h->d_b, h->d_sq, h->d_sa, h->d_sb, h->d_f2v, h->d_v2f, h->d_marg,
                     h->d_f2v_alt, h->d_prev, h->d_scratch, h->d_send_slots, h->d_recv_slots, h->d_send_vars,
                     h->ext_halo_buffers ? nullptr : (void *)h->d_send_buf, h->ext_halo_buffers ? nullptr : (void *)h->d_recv_buf,
-                    h->d_stage, h->d_spdir, h->d_ptab, h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prev, h->d_rule64_slots, h->d_rule64_vars, h->d_rule64_flags, h->d_point64_slots, h->d_rule64_rec, h->d_chain_pos_var, h->d_chain_skip0, h->d_chain_skip1, h->d_chain_link_pos, h->d_chain_from,
+                    h->d_stage, h->d_spdir, h->d_ptab, h->d_ptab_bt, h->d_zero_msg, h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prev, h->d_rule64_slots, h->d_rule64_vars, h->d_rule64_flags, h->d_point64_slots, h->d_rule64_rec, h->d_chain_pos_var, h->d_chain_skip0, h->d_chain_skip1, h->d_chain_link_pos, h->d_chain_from,
                     h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_side, h->d_chain_totals};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     cx::tiles_free(h);
@@ -69,7 +69,7 @@ void dev_free_all(cx_handle *h) {
     if (h->d_joint) (void)hipFree(h->d_joint);
     h->d_prod = nullptr; h->d_joint = nullptr; h->prod_cap = h->joint_cap = 0; h->prod_index.clear(); h->joint_index.clear();
     h->d_rule64_slots = h->d_rule64_vars = h->d_rule64_flags = h->d_point64_slots = h->d_rule64_rec = nullptr; h->work64_dirty = h->point64_dirty = true;
-    h->d_spdir = nullptr; h->d_ptab = nullptr; h->d_mv_f2v = h->d_mv_f2v_alt = h->d_mv_v2f = h->d_mv_marg = h->d_mv_prev = nullptr; h->ptab_sets = 0;
+    h->d_spdir = nullptr; h->d_ptab = nullptr; h->d_ptab_bt = nullptr; h->d_zero_msg = nullptr; h->d_mv_f2v = h->d_mv_f2v_alt = h->d_mv_v2f = h->d_mv_marg = h->d_mv_prev = nullptr; h->ptab_sets = 0;
     h->d_chain_pos_var = h->d_chain_skip0 = h->d_chain_skip1 = h->d_chain_link_pos = h->d_chain_from = h->d_chain_to = nullptr;
     h->d_chain_head_fwd = h->d_chain_head_bwd = nullptr; h->d_chain_side = nullptr; h->d_chain_totals = nullptr; h->chains_dirty = true;
     h->d_slice_off = h->d_partner = h->d_vbase = h->d_var_deg = h->d_big = h->d_big_slots = nullptr;
@@ -239,6 +239,23 @@ static int32_t upload_ptab(cx_handle *h) {
     if (h->d_ptab && h->ptab_sets < nsets) { (void)hipFree(h->d_ptab); h->d_ptab = nullptr; }
     if (!h->d_ptab) { int32_t rc = dev_alloc(h, &h->d_ptab, (int64_t)(per * nsets)); if (rc != CX_OK) return rc; h->ptab_sets = nsets; }
     CX_HIP(h, hipMemcpy(h->d_ptab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    if (d == 64) {   // the wave-per-message rule kernel reads B transposed (tile rows are its contraction index)
+        const size_t dd = (size_t)d * d;
+        std::vector<double> bt(2 * (size_t)nsets * dd);
+        for (int64_t t = 0; t < 2 * nsets; t++) {
+            const double *B = &tab[(size_t)t * 3 * dd + dd];
+            for (int r = 0; r < d; r++) for (int c = 0; c < d; c++) bt[(size_t)t * dd + (size_t)r * d + c] = B[(size_t)c * d + r];
+        }
+        if (!h->d_zero_msg) {
+            int32_t rc0 = dev_alloc(h, &h->d_zero_msg, (int64_t)(d + d * d));
+            if (rc0 != CX_OK) return rc0;
+            CX_HIP(h, hipMemset(h->d_zero_msg, 0, (size_t)(d + d * d) * 8));
+        }
+        if (h->d_ptab_bt) { (void)hipFree(h->d_ptab_bt); h->d_ptab_bt = nullptr; }
+        int32_t rc = dev_alloc(h, &h->d_ptab_bt, (int64_t)bt.size());
+        if (rc != CX_OK) return rc;
+        CX_HIP(h, hipMemcpy(h->d_ptab_bt, bt.data(), bt.size() * 8, hipMemcpyHostToDevice));
+    }
     return CX_OK;
 }
 

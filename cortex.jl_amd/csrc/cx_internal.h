@@ -80,6 +80,8 @@ struct cx_handle {
     bool spdir_dirty = true;
     int observed_passes_due = 2;                   // sweeps that still have to write the messages out of observed variables
     double *d_ptab = nullptr;                      // [2*npsets][3][d*d]: (P, B, C) triples
+    double *d_zero_msg = nullptr;                  // d = 64: one message of zeros (what an absent source reads)
+    double *d_ptab_bt = nullptr;                   // d = 64: [2*npsets][d*d], the transposes of the B tables (cx_mv64w.hip)
     int64_t ptab_sets = 0, max_pset = -1;
     double *d_mv_f2v = nullptr, *d_mv_f2v_alt = nullptr, *d_mv_v2f = nullptr, *d_mv_marg = nullptr, *d_mv_prev = nullptr;
     // d = 64 work lists (built lazily: they depend on which variables are observed)
@@ -194,6 +196,7 @@ void mv_launch_residual(cx_handle *h, const double *cur, const double *prev, int
 bool spd_inverse(int d, const double *S, double *out);
 // d = 64 (cx_mv64.hip): message-major layout, MFMA rule kernel
 void mv64_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const double *f2v_in, double *f2v_out, int kernel_id);
+void mv64w_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const double *f2v_in, double *f2v_out);   // cx_mv64w.hip
 void mv64_launch_marginals(cx_handle *h, int n, const int32_t *d_vars, const double *f2v, double *out);
 void mv64_launch_point(cx_handle *h, int nwork, const int32_t *d_slots, double *out_a, double *out_b);
 void mv64_launch_v2f(cx_handle *h, int n, const int32_t *d_slots, const int32_t *d_vars, const double *f2v);

@@ -608,7 +608,13 @@ void mv64_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const doubl
         h->recs.push_back(r);
     }
     static const bool classic = getenv("CX_RULE64_CLASSIC") != nullptr;   // A/B switch: the 80 KB form, two workgroups per CU
-    if (classic)
+    // CX_RULE64=w: the wave-per-message form (cx_mv64w.hip; correct, measured slower: DESIGN.md §4); read per launch so that a
+    // test can switch forms inside one process
+    const char *form_env = getenv("CX_RULE64");
+    const int wave_form = (form_env && form_env[0] == 'w') ? 1 : 0;
+    if (wave_form && !classic)
+        mv64w_launch_rule(h, nwork, d_rec, f2v_in, f2v_out);
+    else if (classic)
         hipLaunchKernelGGL((k_rule64<0>), dim3(nwork), dim3(kBlock), 0, h->stream, nwork, d_rec, (const int32_t *)nullptr, h->d_vbase, h->d_vinfo,
                            h->d_ptab, f2v_in, h->d_mv_v2f, f2v_out);
     else

@@ -1,0 +1,187 @@
+// cx_mv64w.hip — the d = 64 factor→variable rule with ONE WAVE PER MESSAGE and the matrices resident in registers.
+//
+// Why (issue-slot budget of k_rule64s): in the workgroup-per-message form the f64 vector pipe carries as many
+// SIMD cycles as the 584 matrix instructions — 77 % of them the 4 x 4 pivot factorisations that all four waves repeat — and
+// the ≈ 40 barrier-separated phases of a message leave issue slots empty.  Here a message belongs to one wave: no workgroup
+// barrier, every pivot computed once, and no operand ever goes through LDS for a matrix product.
+//
+// The rule (same as cx_mv64.hip; P, B, C the receiving edge's tables, M = Lambda_in + P):
+//     Lambda_out = C - B M^-1 B',      eta_out = B M^-1 eta_in.
+// With the UPPER factor M = U'U and Yt = U^-T [B' | eta_in] this is  [Lambda_out | eta_out] = [C | 0] -/+ Yt(:, 0:64)' Yt.
+//
+// Accumulators as operands.  A 16 x 16 tile T lives in the layout v_mfma_f64_16x16x4_f64 returns: lane l = (g, c) =
+// (l >> 4, l & 15) holds T[g + 4 r][c] in register r = 0..3.  For that instruction lane l supplies A[i = l & 15][k = l >> 4] and
+// B[k = l >> 4][j = l & 15]; so register s of a tile T IS the A operand of T' and register s of a tile S the B operand of S, for
+// the k-step that covers rows 4s..4s+3:        T' S  =  sum_{s = 0..3} mfma(T.reg[s], S.reg[s]).
+// Every product of the upper-factor formulation contracts over tile ROWS — panel  U[k][j] = V_k' M[k][j]  (V_k = U_kk^-1),
+// trailing update  M[i][j] -= U[k][i]' U[k][j],  solve  Yt[j] = V_j' R[j],  R[j'] -= U[j][j']' Yt[j],  Gram  G[a][b] += Yt[j][a]' Yt[j][b]
+// — so all 584 matrix instructions read their operands straight from the registers the previous ones wrote.
+//
+// The only work outside the matrix pipe is the 16 x 16 diagonal tile: it goes through a 2 KB LDS transpose into "lane c holds
+// column c", is factored and inverted there with constant-lane v_readlane broadcasts (pivot i: one rsqrt chain, 15 - i
+// independent FMAs), and comes back as V_k in tile layout.  One wave per SIMD (≈ 430 VGPRs); four messages per CU in flight.
+//
+// The reference has no such rule (parity unpinned for d > 1); the kernel is checked against the numpy / C
+// restatements every sweep, the exact block-tridiagonal smoother, and the workgroup-per-message kernel (same results to
+// rounding: the factorisation order differs, upper instead of lower).
+
+#include <cstdlib>
+
+#include "cx_internal.h"
+#include "cx_mv64w_core.h"
+
+namespace cx {
+
+using namespace w64;
+
+// work record (8 int32, built by build_work64 in cx_api.hip): {sender slot, three source slots (-1: none), rule-table index,
+// destination slot, flags, 0}.  ptab: per table index (P, B, C); btab: per table index B' (the transpose of B).
+//
+// Register plan for TWO waves per SIMD (<= 256 registers each), so that one wave's diagonal-tile chains and memory round trips
+// hide behind the other's matrix instructions:
+//   factorisation   M upper tiles (80) + the column-layout temporaries of diag_factor (~100); V_k go to LDS (2 KB each)
+//   solve           U off-diagonal (48) + Yt column blocks as they are finished (<= 160) + one V tile / negated U tile (16)
+//   Gram + store    Yt (160) + one G tile, one C tile; every G tile leaves for HBM as soon as its 16 instructions are done
+template <int WAVES_PER_SIMD>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES_PER_SIMD, WAVES_PER_SIMD)))
+void k_rule64w(int nwork, const int32_t *__restrict__ work_rec, const double *__restrict__ ptab, const double *__restrict__ btab,
+               const double *__restrict__ zero_msg, const double *__restrict__ f2v_in, const double *__restrict__ v2f,
+               double *__restrict__ out) {
+    __shared__ double S[16 * kLdT];
+    __shared__ double Vs[4][16 * kLdT];
+    const int w = blockIdx.x;
+    if (w >= nwork) return;
+    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    const int32_t *rec = work_rec + 8 * (int64_t)w;
+    const int slot = rec[0], s0 = rec[1], s1 = rec[2], s2 = rec[3], dst_slot = rec[5], flags = rec[6];
+    const double *tab = ptab + (int64_t)rec[4] * 3 * kD * kD;
+    const double *bt = btab + (int64_t)rec[4] * kD * kD;
+    const bool fixed = (flags & kFlagFixed) != 0;
+    // an absent source reads a message of zeros: a "load or skip" choice per element — even a wave-uniform one — makes hipcc
+    // branch around every load and wait for it alone (336 dependent round trips per message in the first version of this kernel)
+    const double *src0 = fixed ? v2f + (int64_t)slot * kMsg : (s0 >= 0 ? f2v_in + (int64_t)s0 * kMsg : zero_msg);
+    const double *src1 = (!fixed && s1 >= 0) ? f2v_in + (int64_t)s1 * kMsg : zero_msg;
+    const bool has2 = !fixed && s2 >= 0;
+    const double *src2 = has2 ? f2v_in + (int64_t)s2 * kMsg : zero_msg;
+
+    // ---- M = P + sum of the other incoming Lambdas (ascending neighbour order), upper tiles only ------------------------------
+    d4 M[10];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = a; b < 4; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int o = tile_off(a, b, r, g, c);
+                M[ut(a, b)][r] = (tab[o] + src0[kD + o]) + src1[kD + o];
+            }
+    if (has2) {      // a third source (a sender of degree 4) is rare: ONE branch around the whole block of loads
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = a; b < 4; b++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) M[ut(a, b)][r] += src2[kD + tile_off(a, b, r, g, c)];
+    }
+    // a dependency is undefined (whole messages are NaN together): the signal is not pending
+    if (__builtin_isnan(bcast(M[0][0], 0))) return;
+
+    // ---- blocked upper Cholesky, NB = 16: off-diagonal tiles of M become U, V_k = U_kk^-1 goes to LDS -------------------------
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const d4 Vk = diag_factor(M[ut(k, k)], S, g, c);
+#pragma unroll
+        for (int r = 0; r < 4; r++) Vs[k][(g + 4 * r) * kLdT + c] = Vk[r];
+#pragma unroll
+        for (int j = k + 1; j < 4; j++) M[ut(k, j)] = tts(Vk, M[ut(k, j)], d4{0.0, 0.0, 0.0, 0.0});        // U[k][j] = V_k' M[k][j]
+#pragma unroll
+        for (int i = k + 1; i < 4; i++) {
+            const d4 nu = neg(M[ut(k, i)]);
+#pragma unroll
+            for (int j = i; j < 4; j++) M[ut(i, j)] = tts(nu, M[ut(k, j)], M[ut(i, j)]);                       // M[i][j] -= U[k][i]' U[k][j]
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // ---- Yt = U^-T [B' | eta_in], one block COLUMN at a time (forward substitution over its four row blocks) -------------------
+    d4 Y[4][5];
+#pragma unroll
+    for (int b = 0; b < 5; b++) {
+        if (b < 4) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) Y[j][b][r] = bt[tile_off(j, b, r, g, c)];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int e = 16 * j + g + 4 * r;
+                    double x = src0[e] + src1[e];
+                    if (has2) x += src2[e];
+                    Y[j][4][r] = (c == 0) ? x : 0.0;       // the fifth block column carries eta in its column 0
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            d4 Vj;
+#pragma unroll
+            for (int r = 0; r < 4; r++) Vj[r] = Vs[j][(g + 4 * r) * kLdT + c];
+            Y[j][b] = tts(Vj, Y[j][b], d4{0.0, 0.0, 0.0, 0.0});                                                  // Yt[j] = V_j' R[j]
+#pragma unroll
+            for (int jj = j + 1; jj < 4; jj++) Y[jj][b] = tts(neg(M[ut(j, jj)]), Y[j][b], Y[jj][b]);           // R[jj] -= U[j][jj]' Yt[j]
+        }
+    }
+    // not positive definite somewhere: NaN everywhere downstream — leave the old message
+    if (__builtin_isnan(bcast(Y[3][0][0], 0)) || __builtin_isnan(bcast(Y[3][4][0], 0))) return;
+
+    // ---- Gram tile by tile: G[a][b] = sum_j Yt[j][a]' Yt[j][b];  Lambda_out = C - G (C symmetric: the lower tiles are the
+    //      transposes of the same differences, turned through LDS);  eta_out = column 0 of G[a][4] -------------------------------
+    double *dst = out + (int64_t)dst_slot * kMsg;
+    const double *C = tab + 2 * kD * kD;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+#pragma unroll
+        for (int b = a; b < 4; b++) {
+            d4 Ct;
+#pragma unroll
+            for (int r = 0; r < 4; r++) Ct[r] = C[tile_off(a, b, r, g, c)];
+            d4 G = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < 4; j++) G = tts(Y[j][a], Y[j][b], G);
+            d4 D;
+#pragma unroll
+            for (int r = 0; r < 4; r++) D[r] = Ct[r] - G[r];
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[kD + tile_off(a, b, r, g, c)] = D[r];
+            if (b > a) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the previous tile's reads have returned
+#pragma unroll
+                for (int r = 0; r < 4; r++) S[(g + 4 * r) * kLdT + c] = D[r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 4; r++) dst[kD + tile_off(b, a, r, g, c)] = S[c * kLdT + g + 4 * r];
+            }
+        }
+        d4 E = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < 4; j++) E = tts(Y[j][a], Y[j][4], E);
+        if (c == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[16 * a + g + 4 * r] = E[r];
+        }
+    }
+}
+
+void mv64w_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const double *f2v_in, double *f2v_out) {
+    static const int one = [] { const char *e = getenv("CX_RULE64_WAVES"); return (e && e[0] == '1') ? 1 : 0; }();
+    if (one)
+        hipLaunchKernelGGL(k_rule64w<1>, dim3(nwork), dim3(64), 0, h->stream, nwork, d_rec, h->d_ptab, h->d_ptab_bt, h->d_zero_msg, f2v_in,
+                           h->d_mv_v2f, f2v_out);
+    else
+        hipLaunchKernelGGL(k_rule64w<2>, dim3(nwork), dim3(64), 0, h->stream, nwork, d_rec, h->d_ptab, h->d_ptab_bt, h->d_zero_msg, f2v_in,
+                           h->d_mv_v2f, f2v_out);
+}
+
+}  // namespace cx

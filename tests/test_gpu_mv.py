@@ -268,3 +268,30 @@ def test_observed_variables_have_no_marginal_for_dim_gt_1(hip_lib):
     dev.sweep(15)
     assert np.all(np.isnan(dev.get_marginals(model.data_var)))
     assert not np.any(np.isnan(dev.get_marginals(model.x_ids)))
+
+
+def test_mv64_wave_per_message_form_matches_the_workgroup_form(hip_lib, monkeypatch):
+    """The experimental d = 64 rule kernel (csrc/cx_mv64w.hip: one wave per message, matrices resident in registers, upper
+    Cholesky with accumulators as MFMA operands; selected by CX_RULE64=w) against the shipped workgroup form:
+    same messages and marginals to rounding (the factorisation order differs), the same UndefValue() pattern, every sweep."""
+    d, T = 64, 9
+    model = cx.synth.lgssm_chain(T, d=d, seed=13)
+    xe = np.isin(model.edge_var, model.x_ids)
+    ev, ef = model.edge_var[xe], model.edge_fac[xe]
+    a, b = _dev(model), _dev(model)
+    for sweep in range(T + 2):
+        monkeypatch.delenv("CX_RULE64", raising=False)
+        a.sweep(1)
+        monkeypatch.setenv("CX_RULE64", "w")
+        b.sweep(1)
+        x = a.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL)
+        y = b.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL)
+        assert np.array_equal(np.isnan(x), np.isnan(y)), f"sweep {sweep}: definedness differs"
+        ok = ~np.isnan(x[:, 0])
+        if ok.any():
+            assert_close(y[ok], x[ok], 1e-9, f"sweep {sweep}: natural-form messages, wave form vs workgroup form")
+    monkeypatch.delenv("CX_RULE64", raising=False)
+    em, ecov = exact.lgssm_posterior(model.data_y, model.meta["A"], model.meta["Q"], model.meta["R"])
+    marg = b.get_marginals(model.x_ids)
+    assert_close(marg[:, :d], em, 1e-8, "wave form: marginal mean vs block-tridiagonal solve")
+    assert_close(marg[:, d:].reshape(T, d, d), ecov, 1e-8, "wave form: marginal covariance vs block-tridiagonal solve")
