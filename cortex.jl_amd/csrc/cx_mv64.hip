@@ -608,10 +608,10 @@ void mv64_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const doubl
         h->recs.push_back(r);
     }
     static const bool classic = getenv("CX_RULE64_CLASSIC") != nullptr;   // A/B switch: the 80 KB form, two workgroups per CU
-    // CX_RULE64=w: the wave-per-message form (cx_mv64w.hip; correct, measured slower: DESIGN.md §4); read per launch so that a
-    // test can switch forms inside one process
+    // default: the wave-per-message form (cx_mv64w.hip, 5.1 ms per C5 sweep); CX_RULE64=g selects the workgroup-per-message
+    // form below (8.8 ms).  Read per launch so that a test can switch forms inside one process.
     const char *form_env = getenv("CX_RULE64");
-    const int wave_form = (form_env && form_env[0] == 'w') ? 1 : 0;
+    const int wave_form = (form_env && form_env[0] == 'g') ? 0 : 1;
     if (wave_form && !classic)
         mv64w_launch_rule(h, nwork, d_rec, f2v_in, f2v_out);
     else if (classic)

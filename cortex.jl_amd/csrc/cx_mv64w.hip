@@ -176,6 +176,8 @@ void k_rule64w(int nwork, const int32_t *__restrict__ work_rec, const double *__
 
 void mv64w_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const double *f2v_in, double *f2v_out) {
     static const int one = [] { const char *e = getenv("CX_RULE64_WAVES"); return (e && e[0] == '1') ? 1 : 0; }();
+    // (holding back the odd wave slot of every SIMD's first pair by half a message, so that the two waves would not run their
+    // vector and matrix phases in lockstep, was measured in tools/ab_c5.py: no difference at 2, 3, 4 or 6 x 8k cycles)
     if (one)
         hipLaunchKernelGGL(k_rule64w<1>, dim3(nwork), dim3(64), 0, h->stream, nwork, d_rec, h->d_ptab, h->d_ptab_bt, h->d_zero_msg, f2v_in,
                            h->d_mv_v2f, f2v_out);

@@ -40,42 +40,40 @@ __device__ __forceinline__ d4 neg(const d4 &T) { return d4{-T[0], -T[1], -T[2], 
 __device__ __forceinline__ constexpr int ut(int a, int b) { return a * 4 - a * (a - 1) / 2 + (b - a); }
 
 // Upper Cholesky of a symmetric 16 x 16 tile and the inverse of its factor: T = U'U, returns V = U^-1 (tile layout).
-// S: 16 x 17 doubles of LDS private to this wave.
+// S: 16 x 17 doubles of LDS private to this wave.  Lane c holds column c of the tile (all four lane groups hold a copy).
+// Pivot k: d = 1 / sqrt(pivot) from lane k; u = U[k][.] = m[k] d; every later row i gets  m[i] -= U[k][i] u  with U[k][i]
+// broadcast from lane i.  The SAME broadcast builds W = (U')^-1 by forward substitution, W[i][c] = d_i ([i == c] - sum_{k < i}
+// U[k][i] W[k][c]), so each of the 120 off-diagonal entries is broadcast once; lane c ends with column c of W = row c of V.
 __device__ __forceinline__ d4 diag_factor(const d4 &T, double *__restrict__ S, int g, int c, double *dbg_u = nullptr) {
 #pragma unroll
     for (int r = 0; r < 4; r++) S[(g + 4 * r) * kLdT + c] = T[r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    double m[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) m[i] = S[i * kLdT + c];      // column c (all four lane groups hold a copy)
-    double d[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        d[i] = rsqrt_f64(bcast(m[i], i));                      // lane i holds column i: its m[i] is the pivot
-        const double ui = m[i] * d[i];                         // U[i][c] (meaningful for c >= i)
-        m[i] = ui;
-#pragma unroll
-        for (int k = i + 1; k < 16; k++) m[k] -= bcast(ui, k) * ui;   // U[i][k] lives in lane k
-    }
     // hipcc (ROCm 7.2) was seen to move LDS accesses of this wave-private tile across each other without these compiler
-    // barriers (tools/lab/t64.hip: |V U - I| = 78 without, 2e-16 with any one of them); they cost no instruction
-    asm volatile("" ::: "memory");
+    // barriers (tools/lab/t64.hip: |V U - I| = 78 without, 2e-16 with); the waits are what the hardware needs anyway
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double m[16], aw[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { m[i] = S[i * kLdT + c]; aw[i] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const double dk = rsqrt_f64(bcast(m[k], k));           // lane k holds column k: its m[k] is the pivot
+        const double uk = m[k] * dk;                           // U[k][c] (meaningful for c >= k)
+        const double wk = dk * (((k == c) ? 1.0 : 0.0) - aw[k]);   // W[k][c] (zero for c > k by construction)
+        m[k] = uk; aw[k] = wk;
+#pragma unroll
+        for (int i = k + 1; i < 16; i++) {
+            const double s = bcast(uk, i);                     // U[k][i] lives in lane i
+            m[i] -= s * uk;
+            aw[i] += s * wk;
+        }
+    }
     if (dbg_u && g == 0) {
 #pragma unroll
         for (int i = 0; i < 16; i++) dbg_u[i * 16 + c] = m[i];
     }
-    // column c of V = U^-1 by back substitution: V[c][c] = 1 / U[c][c], V[i][c] = -(1 / U[i][i]) sum_{k > i} U[i][k] V[k][c], 0 below
-    double v[16];
-#pragma unroll
-    for (int i = 15; i >= 0; i--) {
-        double acc = 0.0;
-#pragma unroll
-        for (int k = i + 1; k < 16; k++) acc += bcast(m[i], k) * v[k];
-        v[i] = (i == c) ? d[i] : ((i < c) ? -d[i] * acc : 0.0);
-    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (g == 0) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) S[i * kLdT + c] = v[i];
+        for (int i = 0; i < 16; i++) S[c * kLdT + i] = aw[i];   // V[c][i] = W[i][c]
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     d4 V;

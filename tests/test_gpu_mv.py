@@ -271,8 +271,8 @@ def test_observed_variables_have_no_marginal_for_dim_gt_1(hip_lib):
 
 
 def test_mv64_wave_per_message_form_matches_the_workgroup_form(hip_lib, monkeypatch):
-    """The experimental d = 64 rule kernel (csrc/cx_mv64w.hip: one wave per message, matrices resident in registers, upper
-    Cholesky with accumulators as MFMA operands; selected by CX_RULE64=w) against the shipped workgroup form:
+    """The d = 64 rule kernel (csrc/cx_mv64w.hip: one wave per message, matrices resident in registers, upper Cholesky with
+    accumulators as MFMA operands; the default since round 2) against round 1's workgroup-per-message form (CX_RULE64=g):
     same messages and marginals to rounding (the factorisation order differs), the same UndefValue() pattern, every sweep."""
     d, T = 64, 9
     model = cx.synth.lgssm_chain(T, d=d, seed=13)
@@ -280,7 +280,7 @@ def test_mv64_wave_per_message_form_matches_the_workgroup_form(hip_lib, monkeypa
     ev, ef = model.edge_var[xe], model.edge_fac[xe]
     a, b = _dev(model), _dev(model)
     for sweep in range(T + 2):
-        monkeypatch.delenv("CX_RULE64", raising=False)
+        monkeypatch.setenv("CX_RULE64", "g")
         a.sweep(1)
         monkeypatch.setenv("CX_RULE64", "w")
         b.sweep(1)

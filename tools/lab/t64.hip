@@ -15,7 +15,7 @@ __global__ __launch_bounds__(64) void k_test(const double *Tin, const double *Si
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
     d4 T, X;
     for (int r = 0; r < 4; r++) { T[r] = Tin[(g + 4 * r) * 16 + c]; X[r] = Sin[(g + 4 * r) * 16 + c]; }
-    d4 V = diag_factor(T, S, g, c, (double *)nullptr); (void)Uout;
+    d4 V = diag_factor(T, S, g, c, Uout);
     d4 P = tts(T, X, d4{0.0, 0.0, 0.0, 0.0});
     for (int r = 0; r < 4; r++) { Vout[(g + 4 * r) * 16 + c] = V[r]; Pout[(g + 4 * r) * 16 + c] = P[r]; }
 }
