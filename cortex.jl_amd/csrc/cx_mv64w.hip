@@ -103,26 +103,39 @@ void k_rule64w(int nwork, const int32_t *__restrict__ work_rec, const double *__
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-    // ---- Yt = U^-T [B' | eta_in], one block COLUMN at a time (forward substitution over its four row blocks) -------------------
-    d4 Y[4][5];
+    // ---- z = U^-T eta_in on the vector pipe (as a fifth block column of the matrix solve it cost 104 of 488 matrix
+    //      instructions, on tiles that are 15/16 zeros).  Two vector layouts: RV — lane (g, c) holds x[g + 4 r] in register r
+    //      (indexed like tile rows); CV — lane (g, c) holds y[c] (indexed like tile columns).  T' x for a tile T: four FMAs per lane
+    //      and a sum over the four lane groups gives CV; CV -> RV is four lane reads. -----------------------------------------------
+    double zrv[4][4];
 #pragma unroll
-    for (int b = 0; b < 5; b++) {
-        if (b < 4) {
+    for (int j = 0; j < 4; j++) {
+        const int e = 16 * j + c;
+        double wcv = src0[e] + src1[e];
+        if (has2) wcv += src2[e];
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+        for (int k = 0; k < j; k++) {
+            double p = 0.0;
 #pragma unroll
-                for (int r = 0; r < 4; r++) Y[j][b][r] = bt[tile_off(j, b, r, g, c)];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int e = 16 * j + g + 4 * r;
-                    double x = src0[e] + src1[e];
-                    if (has2) x += src2[e];
-                    Y[j][4][r] = (c == 0) ? x : 0.0;       // the fifth block column carries eta in its column 0
-                }
+            for (int r = 0; r < 4; r++) p += M[ut(k, j)][r] * zrv[k][r];
+            wcv -= sum_groups(p);                                                      // eta_j - sum_k U[k][j]' z_k
         }
+        double p = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) p += Vs[j][(g + 4 * r) * kLdT + c] * cv_to_rv(wcv, g, r);
+        const double zcv = sum_groups(p);                                              // z_j = V_j' w_j
+#pragma unroll
+        for (int r = 0; r < 4; r++) zrv[j][r] = cv_to_rv(zcv, g, r);
+    }
+
+    // ---- Yt = U^-T B', one block COLUMN at a time (forward substitution over its four row blocks) ------------------------------
+    d4 Y[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) Y[j][b][r] = bt[tile_off(j, b, r, g, c)];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             d4 Vj;
@@ -134,10 +147,10 @@ void k_rule64w(int nwork, const int32_t *__restrict__ work_rec, const double *__
         }
     }
     // not positive definite somewhere: NaN everywhere downstream — leave the old message
-    if (__builtin_isnan(bcast(Y[3][0][0], 0)) || __builtin_isnan(bcast(Y[3][4][0], 0))) return;
+    if (__builtin_isnan(bcast(Y[3][0][0], 0)) || __builtin_isnan(bcast(zrv[3][0], 0))) return;
 
     // ---- Gram tile by tile: G[a][b] = sum_j Yt[j][a]' Yt[j][b];  Lambda_out = C - G (C symmetric: the lower tiles are the
-    //      transposes of the same differences, turned through LDS);  eta_out = column 0 of G[a][4] -------------------------------
+    //      transposes of the same differences, turned through LDS);  eta_out = Yt' z on the vector pipe ---------------------------
     double *dst = out + (int64_t)dst_slot * kMsg;
     const double *C = tab + 2 * kD * kD;
 #pragma unroll
@@ -164,13 +177,13 @@ void k_rule64w(int nwork, const int32_t *__restrict__ work_rec, const double *__
                 for (int r = 0; r < 4; r++) dst[kD + tile_off(b, a, r, g, c)] = S[c * kLdT + g + 4 * r];
             }
         }
-        d4 E = d4{0.0, 0.0, 0.0, 0.0};
+        double p = 0.0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) E = tts(Y[j][a], Y[j][4], E);
-        if (c == 0) {
+        for (int j = 0; j < 4; j++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) dst[16 * a + g + 4 * r] = E[r];
-        }
+            for (int r = 0; r < 4; r++) p += Y[j][a][r] * zrv[j][r];
+        const double ecv = sum_groups(p);                                              // (Yt' z)[16 a + c]
+        if (g == 0) dst[16 * a + c] = ecv;
     }
 }
 

@@ -27,6 +27,15 @@ __device__ __forceinline__ double bcast(double x, int src) {
     return __hiloint2double(hi, lo);
 }
 
+// sum of a per-lane value over the four lane groups (lanes c, c + 16, c + 32, c + 48): every lane ends with the total
+__device__ __forceinline__ double sum_groups(double p) {
+    p += __shfl_xor(p, 16, 64);
+    p += __shfl_xor(p, 32, 64);
+    return p;
+}
+// CV -> RV: lane (g, c) reads the value that the lanes of column g + 4 r hold
+__device__ __forceinline__ double cv_to_rv(double cv, int g, int r) { return __shfl(cv, g + 4 * r, 64); }
+
 // T' S accumulated into acc (contraction over the 16 tile rows)
 __device__ __forceinline__ d4 tts(const d4 &T, const d4 &S, d4 acc) {
 #pragma unroll

@@ -19,6 +19,9 @@ from cortex.jl_amd import _lib as L  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 F64_MATRIX_PEAK_TF = 78.6  # f64 matrix peak (AMD public spec)
+F64_MATRIX_SUSTAINED_TF = 49.3   # what a bare v_mfma_f64_16x16x4_f64 loop sustains on this chip (4 accumulators, 4 waves per SIMD:
+                                 # tools/lab/mfma64_peak.hip, profiles/r02_f64_mfma_sustained.txt)
+MFMA_PER_MESSAGE = {"wave": 384, "workgroup": 584}    # matrix instructions per factor→variable message of the two d = 64 kernel forms
 
 
 def counter_traffic(kernel_substr):
@@ -103,16 +106,24 @@ def mv(d, T, steps):
            "ms_per_sweep": dt * 1e3, "kernel_ms": ms / max(n, 1), "updates_per_sweep": upd, "updates_per_s": upd / dt,
            "algorithmic_GBps": upd * 2 * payload / dt / 1e9, "payload_bytes": payload}
     kern_s = ms / max(n, 1) / 1e3
-    tr = counter_traffic("k_rule64s" if d == 64 else f"k_sweep_mv<{d}>")
+    tr = counter_traffic("k_rule64" if d == 64 else f"k_sweep_mv<{d}>")
     alg = upd * 2 * payload
     if d == 64:
-        # v_mfma_f64_16x16x4_f64 per factor→variable message, as the counters see them (SQ_INSTS_MFMA / messages,
-        # profiles/r01_c5_rocprof.json): 584, 2*16*16*4 flop each
+        # v_mfma_f64_16x16x4_f64 per factor→variable message, 2*16*16*4 flop each: 384 in the wave-per-message kernel
+        # (Cholesky 64, solve 160, Gram 160), 584 in round 1's workgroup form (CX_RULE64=g) for the same arithmetic
+        form = "workgroup" if os.environ.get("CX_RULE64", "") == "g" else "wave"
         nmsg = 2 * (T - 1)
-        tf = nmsg * 584 * 2048 / kern_s / 1e12
+        per = MFMA_PER_MESSAGE[form]
+        tf = nmsg * per * 2048 / kern_s / 1e12
         out["mfma_TFLOPs"] = tf
-        out["roofline"] = roofline("mfma", tf, F64_MATRIX_PEAK_TF, "TFLOP/s", tr[0] if tr else None, kernel="k_rule64s",
-                                   mfma_per_message=584, messages_per_launch=nmsg, avg_kernel_ms=kern_s * 1e3,
+        out["roofline"] = roofline("mfma", tf, F64_MATRIX_PEAK_TF, "TFLOP/s", tr[0] if tr else None,
+                                   kernel="k_rule64w" if form == "wave" else "k_rule64s",
+                                   mfma_per_message=per, messages_per_launch=nmsg, avg_kernel_ms=kern_s * 1e3,
+                                   peak_sustained=F64_MATRIX_SUSTAINED_TF, frac_of_sustained=tf / F64_MATRIX_SUSTAINED_TF,
+                                   peak_note="78.6 is the spec figure; a bare MFMA loop on this chip sustains 49.3 (profiles/r02_f64_mfma_sustained.txt)",
+                                   round1_equivalent_TFLOPs=nmsg * 584 * 2048 / kern_s / 1e12,
+                                   round1_equivalent_note="the same messages priced at round 1's 584 matrix instructions each: what the earlier kernel "
+                                                          "would have had to sustain for this time",
                                    traffic_source=tr[1] if tr else None, hbm_GBps=(tr[0] / kern_s / 1e9) if tr else None)
     else:
         achieved = (tr[0] if tr else alg) / kern_s / 1e9
