@@ -34,6 +34,20 @@ namespace cx {
 
 using namespace w64;
 
+// lab only (tools/lab/w64_phases.hip defines CX_W64_STAMPS and the counters): shader-clock cycles per phase and wave
+#ifdef CX_W64_STAMPS
+#define W64_STAMP(i)                                                                                  \
+    do {                                                                                              \
+        const uint64_t t_ = __builtin_amdgcn_s_memtime();                                             \
+        if (lane == 0) cx_w64_stamps[8 * (size_t)blockIdx.x + i] += (unsigned long long)(t_ - t_prev); \
+        t_prev = t_;                                                                                  \
+    } while (0)
+#define W64_STAMP_INIT uint64_t t_prev = __builtin_amdgcn_s_memtime()
+#else
+#define W64_STAMP(i)
+#define W64_STAMP_INIT
+#endif
+
 // work record (8 int32, built by build_work64 in cx_api.hip): {sender slot, three source slots (-1: none), rule-table index,
 // destination slot, flags, 0}.  ptab: per table index (P, B, C); btab: per table index B' (the transpose of B).
 //
@@ -52,6 +66,7 @@ void k_rule64w(int nwork, const int32_t *__restrict__ work_rec, const double *__
     const int w = blockIdx.x;
     if (w >= nwork) return;
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    W64_STAMP_INIT;
     const int32_t *rec = work_rec + 8 * (int64_t)w;
     const int slot = rec[0], s0 = rec[1], s1 = rec[2], s2 = rec[3], dst_slot = rec[5], flags = rec[6];
     const double *tab = ptab + (int64_t)rec[4] * 3 * kD * kD;
@@ -85,11 +100,13 @@ void k_rule64w(int nwork, const int32_t *__restrict__ work_rec, const double *__
     }
     // a dependency is undefined (whole messages are NaN together): the signal is not pending
     if (__builtin_isnan(bcast(M[0][0], 0))) return;
+    W64_STAMP(0);
 
     // ---- blocked upper Cholesky, NB = 16: off-diagonal tiles of M become U, V_k = U_kk^-1 goes to LDS -------------------------
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const d4 Vk = diag_factor(M[ut(k, k)], S, g, c);
+        W64_STAMP(1);
 #pragma unroll
         for (int r = 0; r < 4; r++) Vs[k][(g + 4 * r) * kLdT + c] = Vk[r];
 #pragma unroll
@@ -100,6 +117,7 @@ void k_rule64w(int nwork, const int32_t *__restrict__ work_rec, const double *__
 #pragma unroll
             for (int j = i; j < 4; j++) M[ut(i, j)] = tts(nu, M[ut(k, j)], M[ut(i, j)]);                       // M[i][j] -= U[k][i]' U[k][j]
         }
+        W64_STAMP(2);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -128,6 +146,7 @@ void k_rule64w(int nwork, const int32_t *__restrict__ work_rec, const double *__
         for (int r = 0; r < 4; r++) zrv[j][r] = cv_to_rv(zcv, g, r);
     }
 
+    W64_STAMP(3);
     // ---- Yt = U^-T B', one block COLUMN at a time (forward substitution over its four row blocks) ------------------------------
     d4 Y[4][4];
 #pragma unroll
@@ -148,6 +167,7 @@ void k_rule64w(int nwork, const int32_t *__restrict__ work_rec, const double *__
     }
     // not positive definite somewhere: NaN everywhere downstream — leave the old message
     if (__builtin_isnan(bcast(Y[3][0][0], 0)) || __builtin_isnan(bcast(zrv[3][0], 0))) return;
+    W64_STAMP(4);
 
     // ---- Gram tile by tile: G[a][b] = sum_j Yt[j][a]' Yt[j][b];  Lambda_out = C - G (C symmetric: the lower tiles are the
     //      transposes of the same differences, turned through LDS);  eta_out = Yt' z on the vector pipe ---------------------------
@@ -185,6 +205,7 @@ void k_rule64w(int nwork, const int32_t *__restrict__ work_rec, const double *__
         const double ecv = sum_groups(p);                                              // (Yt' z)[16 a + c]
         if (g == 0) dst[16 * a + c] = ecv;
     }
+    W64_STAMP(5);
 }
 
 void mv64w_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const double *f2v_in, double *f2v_out) {

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 namespace cx {
 namespace w64 {
 
@@ -48,6 +50,36 @@ __device__ __forceinline__ d4 neg(const d4 &T) { return d4{-T[0], -T[1], -T[2], 
 // index of the upper tile (a, b), a <= b, in a 10-entry array
 __device__ __forceinline__ constexpr int ut(int a, int b) { return a * 4 - a * (a - 1) / 2 + (b - a); }
 
+// acc += (lane I of this lane's 16-lane row).row_val * mul — v_fmac_f64 with the DPP control row_newbcast (gfx90a and later: the only
+// DPP control 64-bit vector instructions take).  A VGPR written by a vector instruction needs two wait states before a DPP read
+// and the compiler's hazard pass does not look inside inline assembly: dpp_ready() puts them right after the value is made.
+template <int I>
+__device__ __forceinline__ void fmac_rowbcast(double &acc, double row_val, double mul) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(row_val), "v"(mul), "n"(I));
+}
+__device__ __forceinline__ void dpp_ready(double &x) { asm("s_nop 1" : "+v"(x)); }
+template <int I>
+__device__ __forceinline__ double rowbcast(double x) { return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + I, 0xf, 0xf, false); }
+
+template <int K, int... Is>
+__device__ __forceinline__ void diag_eliminate(double (&m)[16], double (&aw)[16], double uk, double nuk, double wk, std::integer_sequence<int, Is...>) {
+    ((fmac_rowbcast<K + 1 + Is>(m[K + 1 + Is], uk, nuk), fmac_rowbcast<K + 1 + Is>(aw[K + 1 + Is], uk, wk)), ...);
+}
+template <int K>
+__device__ __forceinline__ void diag_step(double (&m)[16], double (&aw)[16], int c) {
+    const double dk = rsqrt_f64(rowbcast<K>(m[K]));             // lane K of the row holds column K: its m[K] is the pivot
+    const double uk = m[K] * dk;                                // U[K][c] (meaningful for c >= K)
+    const double wk = dk * (((K == c) ? 1.0 : 0.0) - aw[K]);    // W[K][c] (zero for c > K by construction)
+    double ur = uk;
+    dpp_ready(ur);
+    m[K] = uk; aw[K] = wk;
+    diag_eliminate<K>(m, aw, ur, -uk, wk, std::make_integer_sequence<int, 15 - K>{});      // m[i] -= U[K][i] uk;  aw[i] += U[K][i] wk
+}
+template <int... Ks>
+__device__ __forceinline__ void diag_steps(double (&m)[16], double (&aw)[16], int c, std::integer_sequence<int, Ks...>) {
+    (diag_step<Ks>(m, aw, c), ...);
+}
+
 // Upper Cholesky of a symmetric 16 x 16 tile and the inverse of its factor: T = U'U, returns V = U^-1 (tile layout).
 // S: 16 x 17 doubles of LDS private to this wave.  Lane c holds column c of the tile (all four lane groups hold a copy).
 // Pivot k: d = 1 / sqrt(pivot) from lane k; u = U[k][.] = m[k] d; every later row i gets  m[i] -= U[k][i] u  with U[k][i]
@@ -59,22 +91,14 @@ __device__ __forceinline__ d4 diag_factor(const d4 &T, double *__restrict__ S, i
     // hipcc (ROCm 7.2) was seen to move LDS accesses of this wave-private tile across each other without these compiler
     // barriers (tools/lab/t64.hip: |V U - I| = 78 without, 2e-16 with); the waits are what the hardware needs anyway
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // Every lane group holds column c of both U (m) and W (aw).  The multiplier U[k][i] of row i sits in lane i of each 16-lane
+    // row: v_fmac_f64 with the DPP control row_newbcast:i reads it from there, so an elimination step costs one instruction
+    // per (k, i) and array and nothing goes through SGPRs.  (v_readlane broadcasts: three instructions per (k, i), and hipcc
+    // kept each for a second use and spilled it to VGPR lanes — 612 v_writelane + as many reloads + ~1000 s_nop per message.)
     double m[16], aw[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) { m[i] = S[i * kLdT + c]; aw[i] = 0.0; }
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const double dk = rsqrt_f64(bcast(m[k], k));           // lane k holds column k: its m[k] is the pivot
-        const double uk = m[k] * dk;                           // U[k][c] (meaningful for c >= k)
-        const double wk = dk * (((k == c) ? 1.0 : 0.0) - aw[k]);   // W[k][c] (zero for c > k by construction)
-        m[k] = uk; aw[k] = wk;
-#pragma unroll
-        for (int i = k + 1; i < 16; i++) {
-            const double s = bcast(uk, i);                     // U[k][i] lives in lane i
-            m[i] -= s * uk;
-            aw[i] += s * wk;
-        }
-    }
+    diag_steps(m, aw, c, std::make_integer_sequence<int, 16>{});
     if (dbg_u && g == 0) {
 #pragma unroll
         for (int i = 0; i < 16; i++) dbg_u[i * 16 + c] = m[i];
