@@ -1,13 +1,13 @@
 // cx_mv64w.hip — the d = 64 factor→variable rule with ONE WAVE PER MESSAGE and the matrices resident in registers.
 //
-// Why (issue-slot budget of k_rule64s): in the workgroup-per-message form the f64 vector pipe carries as many
-// SIMD cycles as the 584 matrix instructions — 77 % of them the 4 x 4 pivot factorisations that all four waves repeat — and
-// the ≈ 40 barrier-separated phases of a message leave issue slots empty.  Here a message belongs to one wave: no workgroup
+// Why: in the workgroup-per-message form (cx_mv64.hip, k_rule64s) the f64 vector pipe carries as many SIMD
+// cycles as its 584 matrix instructions — 77 % of them the 4 x 4 pivot factorisations that all four waves repeat — and the
+// ≈ 40 barrier-separated phases of a message leave issue slots empty.  Here a message belongs to one wave: no workgroup
 // barrier, every pivot computed once, and no operand ever goes through LDS for a matrix product.
 //
 // The rule (same as cx_mv64.hip; P, B, C the receiving edge's tables, M = Lambda_in + P):
 //     Lambda_out = C - B M^-1 B',      eta_out = B M^-1 eta_in.
-// With the UPPER factor M = U'U and Yt = U^-T [B' | eta_in] this is  [Lambda_out | eta_out] = [C | 0] -/+ Yt(:, 0:64)' Yt.
+// With the UPPER factor M = U'U, Yt = U^-T B' and z = U^-T eta_in this is  Lambda_out = C - Yt' Yt,  eta_out = Yt' z.
 //
 // Accumulators as operands.  A 16 x 16 tile T lives in the layout v_mfma_f64_16x16x4_f64 returns: lane l = (g, c) =
 // (l >> 4, l & 15) holds T[g + 4 r][c] in register r = 0..3.  For that instruction lane l supplies A[i = l & 15][k = l >> 4] and
@@ -15,11 +15,12 @@
 // the k-step that covers rows 4s..4s+3:        T' S  =  sum_{s = 0..3} mfma(T.reg[s], S.reg[s]).
 // Every product of the upper-factor formulation contracts over tile ROWS — panel  U[k][j] = V_k' M[k][j]  (V_k = U_kk^-1),
 // trailing update  M[i][j] -= U[k][i]' U[k][j],  solve  Yt[j] = V_j' R[j],  R[j'] -= U[j][j']' Yt[j],  Gram  G[a][b] += Yt[j][a]' Yt[j][b]
-// — so all 584 matrix instructions read their operands straight from the registers the previous ones wrote.
+// — so all 384 matrix instructions (Cholesky 64, solve 160, Gram 160) read their operands straight from the registers the
+// previous ones wrote.  eta rides on the vector pipe (z = U^-T eta, eta_out = Yt' z).
 //
 // The only work outside the matrix pipe is the 16 x 16 diagonal tile: it goes through a 2 KB LDS transpose into "lane c holds
-// column c", is factored and inverted there with constant-lane v_readlane broadcasts (pivot i: one rsqrt chain, 15 - i
-// independent FMAs), and comes back as V_k in tile layout.  One wave per SIMD (≈ 430 VGPRs); four messages per CU in flight.
+// column c", is factored and inverted there with DPP row broadcasts (pivot i: one rsqrt chain, 15 - i independent
+// v_fmac_f64_dpp per array), and comes back as V_k in tile layout.  255 VGPRs: two waves per SIMD, eight messages per CU in flight.
 //
 // The reference has no such rule (parity unpinned for d > 1); the kernel is checked against the numpy / C
 // restatements every sweep, the exact block-tridiagonal smoother, and the workgroup-per-message kernel (same results to

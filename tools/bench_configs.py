@@ -19,8 +19,8 @@ from cortex.jl_amd import _lib as L  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 F64_MATRIX_PEAK_TF = 78.6  # f64 matrix peak (AMD public spec)
-F64_MATRIX_SUSTAINED_TF = 49.3   # what a bare v_mfma_f64_16x16x4_f64 loop sustains on this chip (4 accumulators, 4 waves per SIMD:
-                                 # tools/lab/mfma64_peak.hip, profiles/r02_f64_mfma_sustained.txt)
+F64_MATRIX_SUSTAINED_TF = 77.3   # what a bare v_mfma_f64_16x16x4_f64 loop sustains on this chip with the same number of waves on every
+                                 # SIMD (tools/lab/mfma64_peak.hip, profiles/r02_f64_mfma_sustained.txt): the spec figure is reachable
 MFMA_PER_MESSAGE = {"wave": 384, "workgroup": 584}    # matrix instructions per factor→variable message of the two d = 64 kernel forms
 
 
@@ -120,7 +120,7 @@ def mv(d, T, steps):
                                    kernel="k_rule64w" if form == "wave" else "k_rule64s",
                                    mfma_per_message=per, messages_per_launch=nmsg, avg_kernel_ms=kern_s * 1e3,
                                    peak_sustained=F64_MATRIX_SUSTAINED_TF, frac_of_sustained=tf / F64_MATRIX_SUSTAINED_TF,
-                                   peak_note="78.6 is the spec figure; a bare MFMA loop on this chip sustains 49.3 (profiles/r02_f64_mfma_sustained.txt)",
+                                   peak_note="78.6 is the spec figure; a bare MFMA loop on this chip sustains 77.3 (profiles/r02_f64_mfma_sustained.txt)",
                                    round1_equivalent_TFLOPs=nmsg * 584 * 2048 / kern_s / 1e12,
                                    round1_equivalent_note="the same messages priced at round 1's 584 matrix instructions each: what the earlier kernel "
                                                           "would have had to sustain for this time",

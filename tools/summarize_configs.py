@@ -75,7 +75,7 @@ def main():
             tf = pm["SQ_INSTS_MFMA"] * 2048 / t / 1e12
             pm["mfma_TFLOPs"] = tf
             lines += [f"SQ_INSTS_MFMA x 2048 flop / median launch = **{tf:.1f} TFLOP/s** = {tf/78.6:.3f} of the 78.6 TFLOP/s f64 matrix peak (spec), "
-                      f"{tf/49.3:.3f} of the 49.3 TFLOP/s a bare MFMA loop sustains on this chip (profiles/r02_f64_mfma_sustained.txt)"]
+                      f"{tf/77.3:.3f} of the 77.3 TFLOP/s a bare MFMA loop sustains on this chip (profiles/r02_f64_mfma_sustained.txt)"]
         res["pmc_rule64"] = pm
     open(os.path.join(a.out, f"{a.tag}_configs_rocprof.md"), "w").write("\n".join(lines) + "\n")
     json.dump(res, open(os.path.join(a.out, f"{a.tag}_configs_rocprof.json"), "w"), indent=1)
