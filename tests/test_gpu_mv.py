@@ -295,3 +295,73 @@ def test_mv64_wave_per_message_form_matches_the_workgroup_form(hip_lib, monkeypa
     marg = b.get_marginals(model.x_ids)
     assert_close(marg[:, :d], em, 1e-8, "wave form: marginal mean vs block-tridiagonal solve")
     assert_close(marg[:, d:].reshape(T, d, d), ecov, 1e-8, "wave form: marginal covariance vs block-tridiagonal solve")
+
+
+# ------------------------------------------------------------------------------- degree-4 variables (three sources)
+
+def _branching_lgssm(n, d, seed):
+    """a binary TREE of states (node i has children 2i+1, 2i+2), every state observed: inner nodes have degree 4 (parent,
+    two children, likelihood), so a message out of them sums THREE incoming ones — the branch a chain never takes"""
+    rng = np.random.default_rng(seed)
+    A = 0.9 * np.linalg.qr(rng.standard_normal((d, d)))[0]
+    Q, R = 0.2 * np.eye(d), np.eye(d)
+    x = np.arange(1, n + 1, dtype=np.int64)
+    y, lik = x + n, x + 2 * n
+    pairs = [(p, c) for p in range(n) for c in (2 * p + 1, 2 * p + 2) if c < n]
+    tr = 3 * n + 1 + np.arange(len(pairs), dtype=np.int64)
+    par = np.array([x[p] for p, _ in pairs]); chi = np.array([x[c] for _, c in pairs])
+    edge_var = np.concatenate([y, x, par, chi])
+    edge_fac = np.concatenate([lik, lik, tr, tr])
+    role = np.concatenate([np.full(n, L.ROLE_OUT), np.full(n, L.ROLE_IN), np.full(len(pairs), L.ROLE_IN), np.full(len(pairs), L.ROLE_OUT)]).astype(np.int32)
+    state = np.zeros((n, d)); state[0] = rng.standard_normal(d)
+    for p, c in pairs:
+        state[c] = A @ state[p] + np.sqrt(0.2) * rng.standard_normal(d)
+    data = state + rng.standard_normal((n, d))
+    model = cx.synth.Model(edge_var=edge_var, edge_fac=edge_fac, factor_ids=np.concatenate([lik, tr]),
+                           factor_kind=np.full(n + len(pairs), L.FACTOR_GAUSS_LINEAR, dtype=np.int32),
+                           factor_var=np.concatenate([np.ones(n), np.zeros(len(pairs))]), x_ids=x, data_var=y, data_fac=lik, data_y=data,
+                           dim=d, edge_role=role, psets={0: (A, Q), 1: (np.eye(d), R)}, meta={"pairs": pairs})
+    # exact posterior of the tree: joint information matrix (no prior on the root, like the chain models)
+    Qi, Ri = np.linalg.inv(Q), np.linalg.inv(R)
+    J = np.zeros((n * d, n * d)); hvec = np.zeros(n * d)
+    for i in range(n):
+        J[i*d:(i+1)*d, i*d:(i+1)*d] += Ri; hvec[i*d:(i+1)*d] += Ri @ data[i]
+    for p, c in pairs:
+        P, C = slice(p*d, (p+1)*d), slice(c*d, (c+1)*d)
+        J[P, P] += A.T @ Qi @ A; J[C, C] += Qi; J[P, C] -= A.T @ Qi; J[C, P] -= Qi @ A
+    S = np.linalg.inv(J); mean = S @ hvec
+    return model, mean.reshape(n, d), np.stack([S[i*d:(i+1)*d, i*d:(i+1)*d] for i in range(n)])
+
+
+@pytest.mark.parametrize("d,form", [(3, ""), (4, ""), (64, ""), (64, "g")])
+def test_mv_tree_with_degree_4_variables(hip_lib, monkeypatch, d, form):
+    if form:
+        monkeypatch.setenv("CX_RULE64", form)      # the workgroup-per-message form of the d = 64 rule
+    n = 15 if d < 64 else 7
+    model, emean, ecov = _branching_lgssm(n, d, seed=5)
+    dev = _dev(model)
+    o = MvFlood(model)
+    g = o.g
+    xs_set = set(np.searchsorted(g.var_ids, model.x_ids).tolist())
+    pe = np.array([e for e in np.flatnonzero(g.partner >= 0) if int(np.searchsorted(g.var_ids, g.edge_var[e])) in xs_set])
+    deg = np.diff(g.var_off)
+    assert deg.max() == 4
+    if d == 64:
+        o.sweep(1)        # the d = 64 path evaluates the messages out of observed variables at data injection (see above)
+    for sweep in range(10):
+        dev.sweep(1)
+        o.sweep(1)
+        got = dev.get_messages(g.edge_var[pe], g.edge_fac[pe], L.TO_VARIABLE)
+        for row, e in zip(got, pe):
+            if o.f2v[e] is None:
+                assert np.all(np.isnan(row)), f"sweep {sweep} edge {e}: device defined, restatement undefined"
+                continue
+            m, S = o.f2v[e]
+            if not np.all(np.isfinite(S)) or np.linalg.cond(S) > 1e12:
+                continue
+            assert_close(row[:d], m, 1e-8, f"sweep {sweep} f2v mean edge {e}")
+            assert_close(row[d:].reshape(d, d), S, 1e-8, f"sweep {sweep} f2v covariance edge {e}")
+    dev.sweep(1)
+    marg = dev.get_marginals(model.x_ids)
+    assert_close(marg[:, :d], emean, 1e-8, "tree marginal mean vs the joint solve")
+    assert_close(marg[:, d:].reshape(n, d, d), ecov, 1e-8, "tree marginal covariance vs the joint solve")
