@@ -1037,12 +1037,13 @@ static int32_t grow_store(cx_handle *h, T **buf, int64_t *cap, int64_t need, int
     int64_t ncap = std::max<int64_t>(need, std::max<int64_t>(256, *cap * 2));
     T *nb = nullptr;
     CX_HIP(h, hipMalloc((void **)&nb, (size_t)(ncap * per_record) * sizeof(T)));
-    CX_HIP(h, hipMemsetAsync(nb, 0xff, (size_t)(ncap * per_record) * sizeof(T), h->stream));
-    if (*buf) {
-        CX_HIP(h, hipMemcpyAsync(nb, *buf, (size_t)(*cap * per_record) * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
-        CX_HIP(h, hipStreamSynchronize(h->stream));
-        (void)hipFree(*buf);
+    hipError_t e = hipMemsetAsync(nb, 0xff, (size_t)(ncap * per_record) * sizeof(T), h->stream);
+    if (e == hipSuccess && *buf) {
+        e = hipMemcpyAsync(nb, *buf, (size_t)(*cap * per_record) * sizeof(T), hipMemcpyDeviceToDevice, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     }
+    if (e != hipSuccess) { (void)hipFree(nb); CX_HIP(h, e); }
+    if (*buf) (void)hipFree(*buf);
     *buf = nb; *cap = ncap;
     return CX_OK;
 }
@@ -1150,7 +1151,8 @@ int32_t cx_get_products(cx_handle *h, int64_t n, const int64_t *variable_ids, co
     if (n == 0) return CX_OK;
     CX_REQUIRE(h, n > 0 && variable_ids && range_lo && range_hi && out, CX_ERR_INVALID_ARGUMENT, "cx_get_products: null argument");
     try {
-        std::vector<double2> store((size_t)h->prod_index.size());
+        // a batch that failed half-way may have indexed nodes the store was never grown for: they read as UndefValue()
+        std::vector<double2> store((size_t)std::min<int64_t>((int64_t)h->prod_index.size(), h->prod_cap));
         if (!store.empty()) {
             CX_HIP(h, hipMemcpyAsync(store.data(), h->d_prod, store.size() * 16, hipMemcpyDeviceToHost, h->stream));
             CX_HIP(h, hipStreamSynchronize(h->stream));
@@ -1159,7 +1161,7 @@ int32_t cx_get_products(cx_handle *h, int64_t n, const int64_t *variable_ids, co
             const int64_t v = find_var(h, variable_ids[i]);
             if (v < 0) return fail(h, CX_ERR_NOT_FOUND, "unknown variable id " + std::to_string(variable_ids[i]));
             auto it = h->prod_index.find(std::make_tuple((int32_t)v, range_lo[i], range_hi[i]));
-            const double2 m = it == h->prod_index.end() ? make_double2(kNaN, kNaN) : store[it->second];
+            const double2 m = (it == h->prod_index.end() || (size_t)it->second >= store.size()) ? make_double2(kNaN, kNaN) : store[it->second];
             from_natural(form, m, out + 2 * i);
         }
         return CX_OK;
@@ -1173,7 +1175,7 @@ int32_t cx_get_joint_marginals(cx_handle *h, int64_t n, const int64_t *factor_id
     if (n == 0) return CX_OK;
     CX_REQUIRE(h, n > 0 && factor_ids && out, CX_ERR_INVALID_ARGUMENT, "cx_get_joint_marginals: null argument");
     try {
-        std::vector<double> store((size_t)6 * h->joint_index.size());
+        std::vector<double> store((size_t)6 * std::min<int64_t>((int64_t)h->joint_index.size(), h->joint_cap));
         if (!store.empty()) {
             CX_HIP(h, hipMemcpyAsync(store.data(), h->d_joint, store.size() * 8, hipMemcpyDeviceToHost, h->stream));
             CX_HIP(h, hipStreamSynchronize(h->stream));
@@ -1182,7 +1184,8 @@ int32_t cx_get_joint_marginals(cx_handle *h, int64_t n, const int64_t *factor_id
             auto ft = std::lower_bound(h->fac_ids.begin(), h->fac_ids.end(), factor_ids[i]);
             if (ft == h->fac_ids.end() || *ft != factor_ids[i]) return fail(h, CX_ERR_NOT_FOUND, "unknown factor id " + std::to_string(factor_ids[i]));
             auto it = h->joint_index.find((int32_t)(ft - h->fac_ids.begin()));
-            for (int k = 0; k < 6; k++) out[6 * i + k] = it == h->joint_index.end() ? kNaN : store[(size_t)6 * it->second + k];
+            const bool have = it != h->joint_index.end() && (size_t)6 * it->second + 5 < store.size();
+            for (int k = 0; k < 6; k++) out[6 * i + k] = have ? store[(size_t)6 * it->second + k] : kNaN;
         }
         return CX_OK;
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_get_joint_marginals: host allocation failed"); }

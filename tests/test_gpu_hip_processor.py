@@ -263,6 +263,25 @@ def test_product_of_messages_and_joint_marginal_items_gaussian(hip_lib):
     assert np.all(np.isnan(dev.get_joint_marginals([int(lk[1])])[0]))                      # never computed: UndefValue()
 
 
+def test_a_batch_that_fails_half_way_leaves_readable_stores(hip_lib):
+    """the first items of a failing batch are indexed before the error is found; nothing was computed, so reading them
+    back gives UndefValue() (this used to read past the end of a store that was never grown)"""
+    L = cx._lib
+    dev = cx.DeviceGraph(schedule=L.SCHED_FLOODING)
+    m = cx.synth.ssm_chain(40)
+    cx.synth.load_into_device(m, dev)
+    dev.sweep(45)                                  # a chain without priors: defined everywhere after T sweeps
+    v = int(m.x_ids[5])
+    fac = int(np.sort(m.edge_fac[m.edge_var == v])[-1])
+    with pytest.raises(cx.CortexHipError):
+        dev.update_batch([L.ITEM_PRODUCT_OF_MESSAGES, L.ITEM_JOINT_MARGINAL, L.ITEM_MESSAGE_TO_FACTOR], [v, 0, v], [L.item_range(1, 2), fac, 987654321])
+    assert np.all(np.isnan(dev.get_products([v], [1], [2])))
+    assert np.all(np.isnan(dev.get_joint_marginals([fac])[0]))
+    dev.update_batch([L.ITEM_PRODUCT_OF_MESSAGES, L.ITEM_JOINT_MARGINAL], [v, 0], [L.item_range(1, 2), fac])    # and the next good batch works
+    assert np.all(np.isfinite(dev.get_products([v], [1], [2])))
+    assert np.all(np.isfinite(dev.get_joint_marginals([fac])[0]))
+
+
 def test_unknown_item_kind_is_an_error_not_a_crash(hip_lib):
     dev = cx.DeviceGraph()
     m = cx.synth.ssm_chain(4)
