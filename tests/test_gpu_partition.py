@@ -288,14 +288,15 @@ def test_deep_halo_exchange_issued_by_the_library(hip_lib):
     assert np.array_equal(dev.get_marginals(m.x_ids), plain.get_marginals(m.x_ids), equal_nan=True)
 
 
-def test_config_c4_full_size_deep_halo(hip_lib):
-    """BASELINE config C4 at full size: the 1415 x 1415 grid (10,005,465 edges) cut into 5 strips of 283 rows with an
-    8-row deep halo, five handles on one GPU.  After 19 sweeps (two full exchange periods + 3) every marginal equals the
-    un-partitioned device sweep bit for bit."""
+@pytest.mark.parametrize("world,depth,sweeps", [(5, 8, 19), (8, 16, 35)])
+def test_config_c4_full_size_deep_halo(hip_lib, world, depth, sweeps):
+    """BASELINE config C4 at full size: the 1415 x 1415 grid (10,005,465 edges) cut into row blocks with a deep halo, one
+    handle per block on one GPU — 5 strips of 283 rows with 8 redundant rows, and the cut `bench.py --gpus 8` runs (8 blocks
+    of 177 / 176 rows, 16 redundant rows, partition.grid_rows_deep).  After two full exchange periods + 3 sweeps every
+    marginal equals the un-partitioned device sweep bit for bit."""
     import torch
 
-    N, world, depth, sweeps = 1415, 5, 8, 19
-    rows = N // world
+    N = 1415
     whole_model = cx.synth.gaussian_grid(N, N, seed=1234)
     whole = cx.DeviceGraph(schedule=L.SCHED_FUSED)
     cx.synth.load_into_device(whole_model, whole, seed_variance=1e6)
@@ -307,7 +308,7 @@ def test_config_c4_full_size_deep_halo(hip_lib):
     def run(rank):
         try:
             ld.bind(rank)
-            part = partition.grid_strip_deep(rows, N, rank, world, depth, seed=1234)
+            part = partition.grid_rows_deep(N, N, rank, world, depth, seed=1234)
             dev = cx.DeviceGraph(schedule=L.SCHED_FUSED)
             cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
             ex = partition.DeepHaloExchange(partition.DeviceStateSweeper(dev, part, torch, torch.device("cuda", 0)), part, ld)
