@@ -136,12 +136,14 @@ def mv(d, T, steps):
     return out
 
 
-def vmp(n=1_000_000):
+def vmp(n=1_000_000, only=None):
     """one variational iteration (all latent states, then both precisions) of the reference's SSM with
     unknown noise precisions, n states: 2n - 1 three-way factors, 6n - 3 edges."""
     model = cx.synth.vmp_ssm(n, seed=1234)
     out = []
     for name, fam in (("structured", L.FAMILY_VMP_STRUCTURED), ("mean_field", L.FAMILY_VMP_MEAN_FIELD)):
+        if only and name != only:
+            continue
         dev = cx.DeviceGraph(family=fam, schedule=L.SCHED_CHAIN_SCAN)
         cx.synth.load_vmp_into_device(model, dev)
 
@@ -161,8 +163,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["c2", "c3", "c5"]
     torch.cuda.init()
     for w in which:
-        if w == "vmp":
-            for r in vmp():
+        if w.startswith("vmp"):
+            for r in vmp(only=w[4:] or None):          # vmp | vmp_structured | vmp_mean_field
                 print(json.dumps(r), flush=True)
             continue
         r = c2() if w == "c2" else (mv(4, 1_000_000, 30) if w == "c3" else mv(64, 100_000, 20))
