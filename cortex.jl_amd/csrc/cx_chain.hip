@@ -127,9 +127,18 @@ struct ChainArgs {
     const double2 *side;
 };
 
-__device__ __forceinline__ Lin load_link(const ChainArgs &A, int idx, int dir) {
-    if (idx >= A.nlinks) return lin_identity();
-    const int l = dir > 0 ? idx : A.nlinks - 1 - idx;
+// Tiles are blocks of kTile consecutive links in BOTH directions: the tile at position p of the forward scan is block p, of the
+// backward scan block ntiles - 1 - p, visited from its last link to its first (the ragged block comes first there; identity
+// maps pad it).  One workgroup holds the same block for both directions, so the side sums and rule parameters of a link cross
+// the fabric once (with separate forward / backward workgroups — on different XCDs, behind different L2s — the two scan kernels
+// of a 1M-link chain fetched 184 + 88 MB: profiles/r02_vmp_rocprof.md).
+__device__ __forceinline__ Lin load_link(const ChainArgs &A, int tile_pos, int j, int dir, int ntiles, int *link_out = nullptr) {
+    const int block = dir > 0 ? tile_pos : ntiles - 1 - tile_pos;
+    const int lo = block * kTile, hi = min(lo + kTile, A.nlinks);
+    if (link_out) *link_out = -1;
+    if (j >= hi - lo) return lin_identity();
+    const int l = dir > 0 ? lo + j : hi - 1 - j;
+    if (link_out) *link_out = l;
     const int recv = dir > 0 ? A.to_slot[l] : A.from_slot[l];
     const double2 u = A.side[A.link_pos[l] + (dir > 0 ? 0 : 1)];
     const int seg = dir > 0 ? A.head_fwd[l] : A.head_bwd[l];
@@ -137,8 +146,10 @@ __device__ __forceinline__ Lin load_link(const ChainArgs &A, int idx, int dir) {
 }
 
 // workgroup-wide inclusive scan of kTile links; returns this thread's kItems inclusive prefixes and the tile total
-__device__ __forceinline__ void tile_scan(Lin (&x)[kItems], Lin &tile_total, Lin *wave_tot /* LDS [kBlock/64] */) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+// (tid: thread within its group of kBlock; a workgroup of 2 * kBlock threads runs two such scans side by side, each on its own
+// LDS array — every thread of the workgroup has to make the call: __syncthreads)
+__device__ __forceinline__ void tile_scan(Lin (&x)[kItems], Lin &tile_total, Lin *wave_tot /* LDS [kBlock/64] */, int tid) {
+    const int lane = tid & 63, wid = tid >> 6;
 #pragma unroll
     for (int k = 1; k < kItems; k++) x[k] = lin_compose(x[k - 1], x[k]);
     Lin t = x[kItems - 1];
@@ -161,19 +172,21 @@ __device__ __forceinline__ void tile_scan(Lin (&x)[kItems], Lin &tile_total, Lin
     __syncthreads();
 }
 
-// The forward and the backward scan are independent: every stage runs both in one launch, blockIdx.y = 0 forward,
-// 1 backward, with the backward direction's tile totals stored after the forward ones (stride ntiles + 1).
-__global__ __launch_bounds__(kBlock) void k_chain_tile_totals(ChainArgs A, Lin *__restrict__ totals) {
-    const int dir = blockIdx.y == 0 ? 1 : -1;
-    totals += (size_t)blockIdx.y * (gridDim.x + 1);
-    __shared__ Lin wave_tot[kBlock / 64];
+// The forward and the backward scan are independent: every stage runs both in one launch, threads 0..kBlock-1 of a workgroup
+// forward, the other kBlock backward over the same block of links, with the backward direction's tile totals stored after the
+// forward ones (stride ntiles + 1) in scan order.
+constexpr int kChainThreads = 2 * kBlock;
+__global__ __launch_bounds__(kChainThreads) void k_chain_tile_totals(ChainArgs A, Lin *__restrict__ totals) {
+    const int half = threadIdx.x / kBlock, tid = threadIdx.x % kBlock, dir = half == 0 ? 1 : -1, ntiles = gridDim.x;
+    const int pos = half == 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;       // this block's place in the direction's scan order
+    totals += (size_t)half * (ntiles + 1);
+    __shared__ Lin wave_tot[2][kBlock / 64];
     Lin x[kItems];
-    const int base = blockIdx.x * kTile + threadIdx.x * kItems;
 #pragma unroll
-    for (int k = 0; k < kItems; k++) x[k] = load_link(A, base + k, dir);
+    for (int k = 0; k < kItems; k++) x[k] = load_link(A, pos, tid * kItems + k, dir, ntiles);
     Lin tot;
-    tile_scan(x, tot, wave_tot);
-    if (threadIdx.x == 0) totals[blockIdx.x] = tot;
+    tile_scan(x, tot, wave_tot[half], tid);
+    if (tid == 0) totals[pos] = tot;
 }
 
 // exclusive scan of the tile totals by one workgroup (sequential over chunks of kTile tiles: ≤ 1M links per chunk)
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(kBlock) void k_chain_scan_totals(int ntiles, Lin *_
 #pragma unroll
         for (int k = 0; k < kItems; k++) incl[k] = x[k];
         Lin tot;
-        tile_scan(incl, tot, wave_tot);
+        tile_scan(incl, tot, wave_tot, threadIdx.x);
         const Lin carry = carry_s;
         // exclusive value of element k = carry ∘ (inclusive prefix of the previous element)
         Lin prev = lin_identity();
@@ -222,38 +235,39 @@ __global__ __launch_bounds__(kBlock) void k_chain_scan_totals(int ntiles, Lin *_
 // launch (≈6 us on a 1M-edge chain, where the whole sweep is launch-bound).
 constexpr int kOwnCarryTiles = 8 * kTile;
 template <bool OWN_CARRY>
-__global__ __launch_bounds__(kBlock) void k_chain_apply(ChainArgs A, const Lin *__restrict__ tile_excl, double2 *__restrict__ f2v) {
-    const int dir = blockIdx.y == 0 ? 1 : -1;
-    tile_excl += (size_t)blockIdx.y * (gridDim.x + 1);
-    __shared__ Lin wave_tot[kBlock / 64];
+__global__ __launch_bounds__(kChainThreads) void k_chain_apply(ChainArgs A, const Lin *__restrict__ tile_excl, double2 *__restrict__ f2v) {
+    const int half = threadIdx.x / kBlock, tid = threadIdx.x % kBlock, dir = half == 0 ? 1 : -1, ntiles = gridDim.x;
+    const int pos = half == 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;
+    tile_excl += (size_t)half * (ntiles + 1);
+    __shared__ Lin wave_tot[2][kBlock / 64];
     Lin own = lin_identity();
     if (OWN_CARRY) {
-        const int t = blockIdx.x;                       // totals[0 .. t) precede this tile
-        for (int chunk = 0; chunk < t; chunk += kTile) {
+        // totals[0 .. pos) precede this tile in its direction; both halves make the same number of scans (the barrier inside)
+        const int most = max(blockIdx.x, ntiles - 1 - (int)blockIdx.x);
+        for (int chunk = 0; chunk < most; chunk += kTile) {
             Lin c[kItems];
 #pragma unroll
             for (int k = 0; k < kItems; k++) {
-                const int j = chunk + threadIdx.x * kItems + k;
-                c[k] = j < t ? tile_excl[j] : lin_identity();
+                const int j = chunk + tid * kItems + k;
+                c[k] = j < pos ? tile_excl[j] : lin_identity();
             }
             Lin tot;
-            tile_scan(c, tot, wave_tot);
+            tile_scan(c, tot, wave_tot[half], tid);
             own = lin_compose(own, tot);
         }
     }
     Lin x[kItems];
-    const int base = blockIdx.x * kTile + threadIdx.x * kItems;
+    int link[kItems];
 #pragma unroll
-    for (int k = 0; k < kItems; k++) x[k] = load_link(A, base + k, dir);
+    for (int k = 0; k < kItems; k++) x[k] = load_link(A, pos, tid * kItems + k, dir, ntiles, &link[k]);
     Lin tot;
-    tile_scan(x, tot, wave_tot);
-    const Lin carry = OWN_CARRY ? own : tile_excl[blockIdx.x];
+    tile_scan(x, tot, wave_tot[half], tid);
+    const Lin carry = OWN_CARRY ? own : tile_excl[pos];
 #pragma unroll
     for (int k = 0; k < kItems; k++) {
-        const int idx = base + k;
-        if (idx >= A.nlinks) continue;
+        const int l = link[k];
+        if (l < 0) continue;
         const Lin p = lin_compose(carry, x[k]);
-        const int l = dir > 0 ? idx : A.nlinks - 1 - idx;
         const int recv = dir > 0 ? A.to_slot[l] : A.from_slot[l];
         const double2 m = make_double2(p.g, p.B);   // the prefix applied to the empty message (0, 0)
         if (!__builtin_isnan(m.y)) f2v[recv] = m;
@@ -282,12 +296,12 @@ void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves) {
                 h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_chain_side};
     const int ntiles = (nlinks + kTile - 1) / kTile;
     Lin *totals = (Lin *)h->d_chain_totals;
-    hipLaunchKernelGGL(k_chain_tile_totals, dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, totals);
+    hipLaunchKernelGGL(k_chain_tile_totals, dim3(ntiles), dim3(kChainThreads), 0, h->stream, A, totals);
     if (ntiles <= kOwnCarryTiles) {
-        hipLaunchKernelGGL(k_chain_apply<true>, dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, totals, f2v);
+        hipLaunchKernelGGL(k_chain_apply<true>, dim3(ntiles), dim3(kChainThreads), 0, h->stream, A, totals, f2v);
     } else {
         hipLaunchKernelGGL(k_chain_scan_totals, dim3(2), dim3(kBlock), 0, h->stream, ntiles, totals);
-        hipLaunchKernelGGL(k_chain_apply<false>, dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, totals, f2v);
+        hipLaunchKernelGGL(k_chain_apply<false>, dim3(ntiles), dim3(kChainThreads), 0, h->stream, A, totals, f2v);
     }
 }
 
@@ -309,7 +323,7 @@ void launch_chain_totals(cx_handle *h, double2 *f2v, bool fused_leaves, int64_t 
     if (nlinks == 0) return;
     ChainArgs A{nlinks, h->d_chain_link_pos, h->d_chain_from, h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd,
                 h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_chain_side};
-    hipLaunchKernelGGL(k_chain_tile_totals, dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, (Lin *)h->d_chain_totals);
+    hipLaunchKernelGGL(k_chain_tile_totals, dim3(ntiles), dim3(kChainThreads), 0, h->stream, A, (Lin *)h->d_chain_totals);
 }
 
 size_t chain_total_bytes(int64_t nlinks) {
