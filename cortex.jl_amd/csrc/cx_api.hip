@@ -507,7 +507,7 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
         }
 #undef CX_TRY
         CX_HIP(h, hipStreamSynchronize(h->stream));
-        h->has_graph = true;
+        h->has_graph = true; h->offchain_marg_dirty = true;
         return CX_OK;
     } catch (const std::bad_alloc &) {
         return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_graph_create: host allocation failed");
@@ -897,7 +897,9 @@ static int32_t ensure_v2f(cx_handle *h) {
 
 int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, int32_t direction,
                         int32_t form, const double *payload) {
-    if (h) h->chain_side_dirty = true;
+    // data injection (variable→factor messages of observed variables) changes the chains' leaf messages but no marginal of a
+    // variable off the chains: those depend on stored factor→variable messages only
+    if (h) { h->chain_side_dirty = true; if (direction != CX_TO_FACTOR) h->offchain_marg_dirty = true; }
     CX_NOT_VMP(h, "cx_set_messages");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_set_messages: no graph");
     CX_REQUIRE(h, direction == CX_TO_FACTOR || direction == CX_TO_VARIABLE, CX_ERR_INVALID_ARGUMENT, "cx_set_messages: bad direction");
@@ -927,10 +929,15 @@ int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
             if (rc != CX_OK) return rc;
             cx::launch_scatter(h, h->d_v2f, d_idx, d_val, n);
             if (form == CX_FORM_POINT) {
-                // a variable that carries a point-mass datum is observed: its messages are never recomputed
-                for (int64_t i = 0; i < n; i++) h->vinfo[vars[i]] |= cx::kClamped;
-                h->chains_dirty = true;
-                CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
+                // a variable that carries a point-mass datum is observed: its messages are never recomputed.  New data for variables
+                // that were observed already leaves the structure (chains, tiles) as it is.
+                bool newly = false;
+                for (int64_t i = 0; i < n; i++)
+                    if (!(h->vinfo[vars[i]] & cx::kClamped)) { h->vinfo[vars[i]] |= cx::kClamped; newly = true; }
+                if (newly) {
+                    h->chains_dirty = true; h->offchain_marg_dirty = true;
+                    CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
+                }
             }
         } else {
             cx::launch_scatter(h, h->d_f2v, d_idx, d_val, n);
@@ -973,7 +980,7 @@ int32_t cx_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
 }
 
 int32_t cx_seed_messages(cx_handle *h, int32_t direction, double mean, double variance) {
-    if (h) h->chain_side_dirty = true;
+    if (h) { h->chain_side_dirty = true; h->offchain_marg_dirty = true; }
     CX_NOT_VMP(h, "cx_seed_messages");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_seed_messages: no graph");
     CX_REQUIRE(h, direction == CX_TO_FACTOR || direction == CX_TO_VARIABLE, CX_ERR_INVALID_ARGUMENT, "cx_seed_messages: bad direction");
@@ -1080,7 +1087,7 @@ static int32_t joint_slots(cx_handle *h, int64_t factor_id, int32_t *s_out, int3
 }
 
 int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
-    if (h) h->chain_side_dirty = true;
+    if (h) { h->chain_side_dirty = true; h->offchain_marg_dirty = true; }
     CX_NOT_VMP(h, "cx_update_batch");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_update_batch: no graph");
     if (n == 0) return CX_OK;
@@ -1339,9 +1346,21 @@ static void sweep_main(cx_handle *h, bool skip_ghosts) {
         // messages out of observed leaves (data) into the chains: by the scan's side pass when every free variable is on a
         // chain, by a factor phase over all slots otherwise (free variables off the chains need theirs too)
         if (!h->chain_covers_all) cx::launch_factor_to_var(h, h->d_v2f, h->d_f2v);
-        cx::launch_chain_scan(h, h->d_f2v, h->chain_covers_all);   // all forward and backward chain messages
-        cx::launch_var_to_factor(h, h->d_f2v, marg);       // every variable→factor message + marginals
-        cx::launch_big_var_to_factor(h, h->d_f2v, marg);
+        // When every reader of factor→variable messages sits on a chain and nobody asked for stored variable→factor messages,
+        // the scan's second kernel writes the marginals itself and the variable phase is not launched (variable→factor messages
+        // are recomputed from the stored messages on demand: ensure_v2f).  Variables off the chains — observed ones, stand-ins —
+        // have marginals that depend on stored messages only: a full variable phase after those were set, none otherwise.
+        const bool fast = h->chain_covers_all && h->big_vars.empty() && h->cfg.materialize_messages_to_factor == 0 && !h->offchain_marg_dirty;
+        const int form = marg ? (h->cfg.family == CX_FAMILY_NATURAL2 ? 2 : 1) : 0;
+        cx::launch_chain_scan(h, h->d_f2v, h->chain_covers_all, fast ? form : 0);   // all forward and backward chain messages
+        if (fast && marg) {
+            h->v2f_stale = true;
+        } else {
+            cx::launch_var_to_factor(h, h->d_f2v, marg);       // every variable→factor message + marginals
+            cx::launch_big_var_to_factor(h, h->d_f2v, marg);
+            h->v2f_stale = false;
+            if (marg) h->offchain_marg_dirty = false;
+        }
     } else if (h->cfg.schedule == CX_SCHED_FLOODING) {
         cx::launch_var_to_factor(h, h->d_f2v, marg);
         cx::launch_big_var_to_factor(h, h->d_f2v, marg);
@@ -1821,7 +1840,8 @@ int32_t cx_state_export(cx_handle *h, void *buf, int64_t bytes) {
     std::memcpy(hd.magic, kStateMagic, 8);
     hd.abi = CX_ABI_VERSION; hd.dim = h->cfg.dim; hd.family = h->cfg.family; hd.schedule = h->cfg.schedule;
     hd.nv = h->nv; hd.ne = h->ne; hd.nslots = h->nslots; hd.nc = h->nc; hd.sweeps_done = h->sweeps_done;
-    hd.v2f_stale = h->v2f_stale ? 1 : 0; hd.n_sections = (int32_t)parts.size();
+    hd.v2f_stale = (h->v2f_stale ? 1 : 0) | (h->offchain_marg_dirty ? 2 : 0);      // bit 1: marginals off the chains are due
+    hd.n_sections = (int32_t)parts.size();
     hd.fingerprint = graph_fingerprint(h);
     char *o = (char *)buf;
     std::memcpy(o, &hd, sizeof hd); o += sizeof hd;
@@ -1835,7 +1855,7 @@ int32_t cx_state_export(cx_handle *h, void *buf, int64_t bytes) {
 }
 
 int32_t cx_state_import(cx_handle *h, const void *buf, int64_t bytes) {
-    if (h) h->chain_side_dirty = true;
+    if (h) { h->chain_side_dirty = true; h->offchain_marg_dirty = true; }
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_state_import: no graph");
     if (is_vmp(h)) return cx::vmp_state_import(h, buf, bytes);
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_state_import: a cx_sweep_begin is still open");
@@ -1876,7 +1896,8 @@ int32_t cx_state_import(cx_handle *h, const void *buf, int64_t bytes) {
         o += p.bytes;
     }
     h->sweeps_done = hd.sweeps_done;
-    h->v2f_stale = hd.v2f_stale != 0;
+    h->v2f_stale = (hd.v2f_stale & 1) != 0;
+    h->offchain_marg_dirty = (hd.v2f_stale & 2) != 0;     // the marginals themselves travelled in section 5
     h->alt_two_back = false; h->tile_info_dirty = true;
     h->spdir_dirty = h->work64_dirty = h->point64_dirty = h->chains_dirty = true;   // derived from the observed flags
     if (h->d_prev) { (void)hipFree(h->d_prev); h->d_prev = nullptr; }               // residual snapshots restart

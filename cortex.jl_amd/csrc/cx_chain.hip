@@ -125,6 +125,7 @@ struct ChainArgs {
     const uint8_t *head_bwd;     // link l is the last link of its path
     const double *q, *a, *b;     // rule parameters per RECEIVING slot (a, b may be null: additive)
     const double2 *side;
+    const int32_t *pos_var;      // variable at a chain position (for the marginals k_chain_apply<.., true> writes)
 };
 
 // Tiles are blocks of kTile consecutive links in BOTH directions: the tile at position p of the forward scan is block p, of the
@@ -234,12 +235,26 @@ __global__ __launch_bounds__(kBlock) void k_chain_scan_totals(int ntiles, Lin *_
 // KB from L2, one more tile scan) — for up to kOwnCarryTiles tiles that is cheaper than the one-workgroup scan kernel's
 // launch (≈6 us on a 1M-edge chain, where the whole sweep is launch-bound).
 constexpr int kOwnCarryTiles = 8 * kTile;
-template <bool OWN_CARRY>
-__global__ __launch_bounds__(kChainThreads) void k_chain_apply(ChainArgs A, const Lin *__restrict__ tile_excl, double2 *__restrict__ f2v) {
+__device__ __forceinline__ double2 chain_to_moment(double2 nat) {      // as cx_kernels.hip's to_moment
+    const double var = 1.0 / nat.y;
+    return make_double2(nat.x * var, var);
+}
+
+// MARG: the workgroup also writes the marginals of its block's chain variables.  It holds alpha (the forward message into the
+// right end of every link of the block) and beta (the backward message into the left end): the marginal of a link's LEFT variable
+// is side + beta(this link) + alpha(previous link) — across a block seam the forward carry applied to the empty message, none
+// at the head of a path — and the last link of a path also owns its RIGHT variable (side + alpha).  With every reader of
+// factor→variable messages on a chain this replaces the variable phase of the sweep (one launch less; variable→factor messages
+// are then recomputed from the stored messages when somebody asks for them, like in the fused schedule).
+template <bool OWN_CARRY, bool MARG>
+__global__ __launch_bounds__(kChainThreads) void k_chain_apply(ChainArgs A, const Lin *__restrict__ tile_excl, double2 *__restrict__ f2v,
+                                                               double2 *__restrict__ marg, int marg_form) {
     const int half = threadIdx.x / kBlock, tid = threadIdx.x % kBlock, dir = half == 0 ? 1 : -1, ntiles = gridDim.x;
     const int pos = half == 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;
     tile_excl += (size_t)half * (ntiles + 1);
     __shared__ Lin wave_tot[2][kBlock / 64];
+    __shared__ double2 msg_s[MARG ? 2 : 1][MARG ? kTile : 1];      // [0]: alpha by link of the block, [1]: beta
+    __shared__ double2 seam_alpha;
     Lin own = lin_identity();
     if (OWN_CARRY) {
         // totals[0 .. pos) precede this tile in its direction; both halves make the same number of scans (the barrier inside)
@@ -263,6 +278,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_apply(ChainArgs A, cons
     Lin tot;
     tile_scan(x, tot, wave_tot[half], tid);
     const Lin carry = OWN_CARRY ? own : tile_excl[pos];
+    const int lo = blockIdx.x * kTile;
 #pragma unroll
     for (int k = 0; k < kItems; k++) {
         const int l = link[k];
@@ -270,11 +286,30 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_apply(ChainArgs A, cons
         const Lin p = lin_compose(carry, x[k]);
         const int recv = dir > 0 ? A.to_slot[l] : A.from_slot[l];
         const double2 m = make_double2(p.g, p.B);   // the prefix applied to the empty message (0, 0)
+        if (MARG) msg_s[half][l - lo] = m;
         if (!__builtin_isnan(m.y)) f2v[recv] = m;
+    }
+    if (MARG) {
+        if (threadIdx.x == 0) seam_alpha = make_double2(carry.g, carry.B);      // alpha into the left end of the block's first link
+        __syncthreads();
+        const int cnt = min(kTile, A.nlinks - lo);
+        for (int j = threadIdx.x; j < cnt; j += kChainThreads) {
+            const int l = lo + j, p = A.link_pos[l];
+            const double2 sd = A.side[p], be = msg_s[1][j];
+            double2 t = make_double2(sd.x + be.x, sd.y + be.y);
+            if (!A.head_fwd[l]) { const double2 al = j > 0 ? msg_s[0][j - 1] : seam_alpha; t.x += al.x; t.y += al.y; }
+            marg[A.pos_var[p]] = marg_form == 2 ? t : chain_to_moment(t);
+            if (A.head_bwd[l]) {
+                const double2 s1 = A.side[p + 1], al = msg_s[0][j];
+                const double2 u = make_double2(s1.x + al.x, s1.y + al.y);
+                marg[A.pos_var[p + 1]] = marg_form == 2 ? u : chain_to_moment(u);
+            }
+        }
     }
 }
 
-void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves) {
+void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_form) {
+    // marg_form: 0 — messages only (the caller runs the variable phase); 1 / 2 — also the chain variables' marginals, moment / natural
     const int nlinks = (int)h->chain_nlinks, npos = (int)h->chain_npos;
     if (nlinks == 0) return;
     const double *pa = h->any_linear ? h->d_a : nullptr, *pb = h->any_linear ? h->d_b : nullptr;
@@ -293,15 +328,18 @@ void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves) {
                            h->d_v2f, f2v, h->d_chain_side);
     h->chain_side_dirty = false;
     ChainArgs A{nlinks, h->d_chain_link_pos, h->d_chain_from, h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd,
-                h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_chain_side};
+                h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_chain_side, h->d_chain_pos_var};
     const int ntiles = (nlinks + kTile - 1) / kTile;
     Lin *totals = (Lin *)h->d_chain_totals;
     hipLaunchKernelGGL(k_chain_tile_totals, dim3(ntiles), dim3(kChainThreads), 0, h->stream, A, totals);
+    const dim3 g(ntiles), b(kChainThreads);
+    if (ntiles > kOwnCarryTiles) hipLaunchKernelGGL(k_chain_scan_totals, dim3(2), dim3(kBlock), 0, h->stream, ntiles, totals);
     if (ntiles <= kOwnCarryTiles) {
-        hipLaunchKernelGGL(k_chain_apply<true>, dim3(ntiles), dim3(kChainThreads), 0, h->stream, A, totals, f2v);
+        if (marg_form) hipLaunchKernelGGL((k_chain_apply<true, true>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, marg_form);
+        else hipLaunchKernelGGL((k_chain_apply<true, false>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, 0);
     } else {
-        hipLaunchKernelGGL(k_chain_scan_totals, dim3(2), dim3(kBlock), 0, h->stream, ntiles, totals);
-        hipLaunchKernelGGL(k_chain_apply<false>, dim3(ntiles), dim3(kChainThreads), 0, h->stream, A, totals, f2v);
+        if (marg_form) hipLaunchKernelGGL((k_chain_apply<false, true>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, marg_form);
+        else hipLaunchKernelGGL((k_chain_apply<false, false>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, 0);
     }
 }
 
@@ -322,7 +360,7 @@ void launch_chain_totals(cx_handle *h, double2 *f2v, bool fused_leaves, int64_t 
     *ntiles_out = ntiles;
     if (nlinks == 0) return;
     ChainArgs A{nlinks, h->d_chain_link_pos, h->d_chain_from, h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd,
-                h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_chain_side};
+                h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_chain_side, h->d_chain_pos_var};
     hipLaunchKernelGGL(k_chain_tile_totals, dim3(ntiles), dim3(kChainThreads), 0, h->stream, A, (Lin *)h->d_chain_totals);
 }
 
