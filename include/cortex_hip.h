@@ -120,7 +120,10 @@ extern "C" {
 #define CX_SCHED_FUSED 1      /* same fixed-point map, one fused kernel on double-buffered messages        */
 #define CX_SCHED_CHAIN_SCAN 2 /* graphs whose non-observed variables form disjoint chains (state-space models):
                                  one cx_sweep = the exact forward/backward result of the reference's sequential
-                                 schedule (inference_engine.jl:575-608), by two parallel prefix scans             */
+                                 schedule (inference_engine.jl:575-608), by two parallel prefix scans.  When every
+                                 non-observed variable is on a chain and materialize_messages_to_factor is 0, the
+                                 scan writes the marginals itself and variable→factor messages are recomputed from
+                                 the stored messages when cx_get_messages / cx_update_batch ask for them          */
 
 typedef struct cx_handle cx_handle;
 
