@@ -145,6 +145,57 @@ def test_marginals_written_by_the_scan_on_segmented_chains_and_messages_on_deman
         assert_close(b[:, 0], a[:, 0], 1e-12, "variable→factor mean on demand"); assert_close(b[:, 1], a[:, 1], 1e-12, "variable→factor variance on demand")
 
 
+@pytest.mark.parametrize("n,extra", [(7, 0), (1500, 2), (2300, 5)])
+def test_chain_scan_with_linear_factors_and_several_side_factors(hip_lib, n, extra):
+    """x_{t+1} = a_t x_t + b_t + N(0, q_t) with per-factor parameters, and `extra` more observations per state (side sums of
+    several messages): the exact posterior from the joint precision matrix, on the sweep that runs the variable phase and on
+    the following ones (marginals written by the scan), and again after new data."""
+    rng = np.random.default_rng(n + extra)
+    m = 1 + extra                                           # observations per state
+    x = np.arange(1, n + 1)
+    yv = (n + 1 + np.arange(n * m)).reshape(n, m); lk = (n + n * m + 1 + np.arange(n * m)).reshape(n, m)
+    tr = n + 2 * n * m + 1 + np.arange(n - 1)
+    ev = np.concatenate([yv.ravel(), np.repeat(x, m), x[:-1], x[1:]]); ef = np.concatenate([lk.ravel(), lk.ravel(), tr, tr])
+    role = np.concatenate([np.full(n * m, L.ROLE_OUT), np.full(n * m, L.ROLE_IN), np.full(n - 1, L.ROLE_IN), np.full(n - 1, L.ROLE_OUT)]).astype(np.int32)
+    fids = np.concatenate([lk.ravel(), tr])
+    kinds = np.concatenate([np.full(n * m, L.FACTOR_GAUSS_ADDITIVE), np.full(n - 1, L.FACTOR_GAUSS_LINEAR)]).astype(np.int32)
+    r = rng.uniform(0.5, 2.0, (n, m)); q = rng.uniform(0.3, 1.5, n - 1); a = rng.uniform(0.6, 1.1, n - 1); b = rng.uniform(-0.5, 0.5, n - 1)
+    params = np.zeros((n * m + n - 1, L.NPARAM)); params[:n * m, 0] = r.ravel(); params[n * m:, 0] = q; params[n * m:, 1] = a; params[n * m:, 2] = b
+
+    def exact_posterior(ys):
+        from scipy.linalg import solveh_banded
+        d0 = (1.0 / r).sum(axis=1); h = (ys / r).sum(axis=1); d1 = np.zeros(n - 1)
+        d0[:-1] += a * a / q; d0[1:] += 1.0 / q; d1 -= a / q
+        h[:-1] -= a * b / q; h[1:] += b / q
+        ab = np.zeros((2, n)); ab[1] = d0; ab[0, 1:] = d1
+        mean = solveh_banded(ab, h)
+        # diagonal of the inverse of a tridiagonal matrix by the two-sided recursion
+        fw = np.zeros(n); bw = np.zeros(n)
+        fw[0] = d0[0]
+        for i in range(1, n):
+            fw[i] = d0[i] - d1[i - 1] ** 2 / fw[i - 1]
+        bw[-1] = d0[-1]
+        for i in range(n - 2, -1, -1):
+            bw[i] = d0[i] - d1[i] ** 2 / bw[i + 1]
+        return mean, 1.0 / (fw + bw - d0)
+
+    dev = cx.DeviceGraph(schedule=L.SCHED_CHAIN_SCAN)
+    dev.graph_create(ev, ef, fids, kinds, params, edge_role=role)
+    ys = rng.standard_normal((n, m)) * 2
+    dev.set_messages(yv.ravel(), lk.ravel(), L.TO_FACTOR, L.FORM_POINT, ys.ravel())
+    em, evar = exact_posterior(ys)
+    for sweep in range(3):
+        dev.sweep(1)
+        marg = dev.get_marginals(x)
+        assert_close(marg[:, 0], em, 1e-9, f"sweep {sweep}: mean"); assert_close(marg[:, 1], evar, 1e-9, f"sweep {sweep}: variance")
+    ys2 = ys + rng.standard_normal((n, m))
+    dev.set_messages(yv.ravel(), lk.ravel(), L.TO_FACTOR, L.FORM_POINT, ys2.ravel())
+    dev.sweep(1)
+    em2, _ = exact_posterior(ys2)
+    marg = dev.get_marginals(x)
+    assert_close(marg[:, 0], em2, 1e-9, "after new data: mean"); assert_close(marg[:, 1], evar, 1e-9, "after new data: variance")
+
+
 def test_chain_scan_refuses_loopy_graphs(hip_lib):
     model = cx.synth.gaussian_grid(4, 4, seed=1)
     dev = cx.DeviceGraph(schedule=L.SCHED_CHAIN_SCAN)
