@@ -1352,7 +1352,7 @@ static void sweep_main(cx_handle *h, bool skip_ghosts) {
         // have marginals that depend on stored messages only: a full variable phase after those were set, none otherwise.
         const bool fast = h->chain_covers_all && h->big_vars.empty() && h->cfg.materialize_messages_to_factor == 0 && !h->offchain_marg_dirty;
         const int form = marg ? (h->cfg.family == CX_FAMILY_NATURAL2 ? 2 : 1) : 0;
-        cx::launch_chain_scan(h, h->d_f2v, h->chain_covers_all, fast ? form : 0);   // all forward and backward chain messages
+        cx::launch_chain_scan(h, h->d_f2v, h->chain_covers_all, fast ? form : 0, h->chain_v2f_from_scan);   // all forward and backward chain messages
         if (fast && marg) {
             h->v2f_stale = true;
         } else {

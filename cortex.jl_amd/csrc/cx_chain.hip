@@ -248,13 +248,13 @@ __device__ __forceinline__ double2 chain_to_moment(double2 nat) {      // as cx_
 // are then recomputed from the stored messages when somebody asks for them, like in the fused schedule).
 template <bool OWN_CARRY, bool MARG>
 __global__ __launch_bounds__(kChainThreads) void k_chain_apply(ChainArgs A, const Lin *__restrict__ tile_excl, double2 *__restrict__ f2v,
-                                                               double2 *__restrict__ marg, int marg_form) {
+                                                               double2 *__restrict__ marg, int marg_form, double2 *__restrict__ chain_v2f) {
     const int half = threadIdx.x / kBlock, tid = threadIdx.x % kBlock, dir = half == 0 ? 1 : -1, ntiles = gridDim.x;
     const int pos = half == 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;
     tile_excl += (size_t)half * (ntiles + 1);
     __shared__ Lin wave_tot[2][kBlock / 64];
     __shared__ double2 msg_s[MARG ? 2 : 1][MARG ? kTile : 1];      // [0]: alpha by link of the block, [1]: beta
-    __shared__ double2 seam_alpha;
+    __shared__ double2 seam_alpha, seam_beta;
     Lin own = lin_identity();
     if (OWN_CARRY) {
         // totals[0 .. pos) precede this tile in its direction; both halves make the same number of scans (the barrier inside)
@@ -291,25 +291,36 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_apply(ChainArgs A, cons
     }
     if (MARG) {
         if (threadIdx.x == 0) seam_alpha = make_double2(carry.g, carry.B);      // alpha into the left end of the block's first link
+        if (threadIdx.x == kBlock) seam_beta = make_double2(carry.g, carry.B);  // beta into the right end of the block's last link
         __syncthreads();
         const int cnt = min(kTile, A.nlinks - lo);
         for (int j = threadIdx.x; j < cnt; j += kChainThreads) {
             const int l = lo + j, p = A.link_pos[l];
             const double2 sd = A.side[p], be = msg_s[1][j];
-            double2 t = make_double2(sd.x + be.x, sd.y + be.y);
-            if (!A.head_fwd[l]) { const double2 al = j > 0 ? msg_s[0][j - 1] : seam_alpha; t.x += al.x; t.y += al.y; }
+            double2 lx = sd;                                                  // everything the left variable hears except this link
+            if (!A.head_fwd[l]) { const double2 al = j > 0 ? msg_s[0][j - 1] : seam_alpha; lx.x += al.x; lx.y += al.y; }
+            const double2 t = make_double2(lx.x + be.x, lx.y + be.y);
             marg[A.pos_var[p]] = marg_form == 2 ? t : chain_to_moment(t);
+            const double2 s1 = A.side[p + 1], al1 = msg_s[0][j];
             if (A.head_bwd[l]) {
-                const double2 s1 = A.side[p + 1], al = msg_s[0][j];
-                const double2 u = make_double2(s1.x + al.x, s1.y + al.y);
+                const double2 u = make_double2(s1.x + al1.x, s1.y + al1.y);
                 marg[A.pos_var[p + 1]] = marg_form == 2 ? u : chain_to_moment(u);
+            }
+            if (chain_v2f) {
+                // the two variable→factor messages of the link (the variational families read them: cx_vmp.hip, k_rate): what each
+                // end hears from everybody else.  Undefined ones keep their stored value, like the variable phase does.
+                if (!__builtin_isnan(lx.y)) chain_v2f[A.from_slot[l]] = lx;
+                double2 rx = s1;
+                if (!A.head_bwd[l]) { const double2 bn = j + 1 < cnt ? msg_s[1][j + 1] : seam_beta; rx.x += bn.x; rx.y += bn.y; }
+                if (!__builtin_isnan(rx.y)) chain_v2f[A.to_slot[l]] = rx;
             }
         }
     }
 }
 
-void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_form) {
-    // marg_form: 0 — messages only (the caller runs the variable phase); 1 / 2 — also the chain variables' marginals, moment / natural
+void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_form, bool chain_v2f) {
+    // marg_form: 0 — messages only (the caller runs the variable phase); 1 / 2 — also the chain variables' marginals, moment / natural;
+    // chain_v2f (with marg_form != 0): also the variable→factor messages of the chain links
     const int nlinks = (int)h->chain_nlinks, npos = (int)h->chain_npos;
     if (nlinks == 0) return;
     const double *pa = h->any_linear ? h->d_a : nullptr, *pb = h->any_linear ? h->d_b : nullptr;
@@ -335,11 +346,11 @@ void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_f
     const dim3 g(ntiles), b(kChainThreads);
     if (ntiles > kOwnCarryTiles) hipLaunchKernelGGL(k_chain_scan_totals, dim3(2), dim3(kBlock), 0, h->stream, ntiles, totals);
     if (ntiles <= kOwnCarryTiles) {
-        if (marg_form) hipLaunchKernelGGL((k_chain_apply<true, true>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, marg_form);
-        else hipLaunchKernelGGL((k_chain_apply<true, false>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, 0);
+        if (marg_form) hipLaunchKernelGGL((k_chain_apply<true, true>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, marg_form, chain_v2f ? h->d_v2f : nullptr);
+        else hipLaunchKernelGGL((k_chain_apply<true, false>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, 0, (double2 *)nullptr);
     } else {
-        if (marg_form) hipLaunchKernelGGL((k_chain_apply<false, true>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, marg_form);
-        else hipLaunchKernelGGL((k_chain_apply<false, false>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, 0);
+        if (marg_form) hipLaunchKernelGGL((k_chain_apply<false, true>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, marg_form, chain_v2f ? h->d_v2f : nullptr);
+        else hipLaunchKernelGGL((k_chain_apply<false, false>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, 0, (double2 *)nullptr);
     }
 }
 

@@ -121,6 +121,7 @@ struct cx_handle {
     hipEvent_t ev_packed = nullptr, ev_recv = nullptr, ev_swept = nullptr;
     bool in_sweep = false;
     bool v2f_stale = false;          // fused schedule without materialisation: v2f must be recomputed before use
+    bool chain_v2f_from_scan = false; // the scan also stores the variable→factor messages of the chain links (set by cx_vmp.hip on its inner handle)
     bool offchain_marg_dirty = true; // chain scan: marginals of variables OFF the chains (observed, stand-ins) are due — they depend on
                                      // stored factor→variable messages only, so a full variable phase runs after those were set
 
@@ -181,7 +182,7 @@ void launch_scatter(cx_handle *h, double2 *dst, const int32_t *d_idx, const doub
 void launch_gather(cx_handle *h, const double2 *src, const int32_t *d_idx, double2 *d_val, int64_t n);
 void launch_seed(cx_handle *h, double2 *buf, int64_t n, double2 value, const int32_t *partner);
 void launch_residual(cx_handle *h, const double2 *cur, const double2 *prev, int64_t n, double *d_out);
-void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_form);
+void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_form, bool chain_v2f);
 void launch_chain_totals(cx_handle *h, double2 *f2v, bool fused_leaves, int64_t *ntiles_out);
 // two sweeps per launch (cx_tiles.hip)
 bool tiles_build(cx_handle *h, std::string &why);

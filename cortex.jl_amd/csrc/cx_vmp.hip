@@ -399,9 +399,14 @@ int32_t vmp_graph_create(cx_handle *h, int64_t ne, const int64_t *edge_var, cons
         } else {
             // inner scalar handle over the Normal variables: the same factors as additive-noise links x_out = x_mean + N(0, q)
             cx_config cc = h->cfg;
-            cc.family = CX_FAMILY_GAUSSIAN; cc.dim = 1; cc.compute_marginals_in_sweep = 1; cc.materialize_messages_to_factor = 1;
+            // k_rate reads the two variable→factor messages of every latent-latent factor from the inner handle: with the chain
+            // scan the scan's own kernel stores exactly those (and the marginals), so no variable phase runs per iteration;
+            // any other schedule materialises every variable→factor message
+            const bool scan = cc.schedule == CX_SCHED_CHAIN_SCAN;
+            cc.family = CX_FAMILY_GAUSSIAN; cc.dim = 1; cc.compute_marginals_in_sweep = 1; cc.materialize_messages_to_factor = scan ? 0 : 1;
             rc = cx_create(&cc, &s->chain);
             VMP_REQUIRE(h, rc == CX_OK, rc, std::string("cx_graph_create (inner handle): ") + cx_last_error(nullptr));
+            s->chain->chain_v2f_from_scan = scan;
             std::vector<int64_t> cev(2 * nf), cef(2 * nf);
             std::vector<int32_t> ckind(nf, CX_FACTOR_GAUSS_ADDITIVE);
             std::vector<double> cpar((size_t)nf * CX_NPARAM, 0.0);

@@ -42,7 +42,7 @@ for fam in ("structured", "mean_field"):
     t_us = b_tot = 0.0
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
         per = len(v) / ITER
-        if per < 1: continue
+        if per < 0.9: continue
         v2 = sorted(v); avg = sum(v2[: max(1, len(v2) - 2)]) / max(1, len(v2) - 2)
         rd = (sorted(fe[k])[len(fe[k]) // 2] * 2048) if k in fe else 0.0
         ww = (sorted(wr[k])[len(wr[k]) // 2] * 1024) if k in wr else 0.0
