@@ -286,8 +286,8 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_apply(ChainArgs A, cons
         const Lin p = lin_compose(carry, x[k]);
         const int recv = dir > 0 ? A.to_slot[l] : A.from_slot[l];
         const double2 m = make_double2(p.g, p.B);   // the prefix applied to the empty message (0, 0)
-        if (MARG) msg_s[half][l - lo] = m;
-        if (!__builtin_isnan(m.y)) f2v[recv] = m;
+        if (MARG) msg_s[half][l - lo] = m;      // stored below, in link order across the lanes (a thread's own four links are 64 B apart)
+        else if (!__builtin_isnan(m.y)) f2v[recv] = m;
     }
     if (MARG) {
         if (threadIdx.x == 0) seam_alpha = make_double2(carry.g, carry.B);      // alpha into the left end of the block's first link
@@ -297,6 +297,8 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_apply(ChainArgs A, cons
         for (int j = threadIdx.x; j < cnt; j += kChainThreads) {
             const int l = lo + j, p = A.link_pos[l];
             const double2 sd = A.side[p], be = msg_s[1][j];
+            { const double2 al = msg_s[0][j]; if (!__builtin_isnan(al.y)) f2v[A.to_slot[l]] = al; }
+            if (!__builtin_isnan(be.y)) f2v[A.from_slot[l]] = be;
             double2 lx = sd;                                                  // everything the left variable hears except this link
             if (!A.head_fwd[l]) { const double2 al = j > 0 ? msg_s[0][j - 1] : seam_alpha; lx.x += al.x; lx.y += al.y; }
             const double2 t = make_double2(lx.x + be.x, lx.y + be.y);
