@@ -14,7 +14,9 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcortex_hip.so")
 SOURCES = ["cx_api.hip", "cx_kernels.hip", "cx_tiles.hip", "cx_chain.hip", "cx_mv.hip", "cx_mv64.hip", "cx_mv64w.hip", "cx_comm.hip", "cx_vmp.hip"]
-HEADERS = [os.path.join(CSRC, "cx_internal.h"), os.path.join(ROOT, "include", "cortex_hip.h")]
+# every header a source may include: a change in any of them rebuilds everything (cx_mv64w_core.h and cx_tiling.h were missing
+# from this list for a while — an edit there alone left the library as it was)
+HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(ROOT, "include", "cortex_hip.h")]
 
 
 def _hipcc() -> str:
