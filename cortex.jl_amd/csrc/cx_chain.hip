@@ -17,6 +17,8 @@
 // Path boundaries are handled by a segmented scan (head flags).  The arithmetic is re-associated relative to the
 // sequential schedule: results agree to rounding (tests hold 1e-9), not bitwise.
 
+#include <cstdlib>
+
 #include "cx_internal.h"
 
 namespace cx {
@@ -346,8 +348,11 @@ void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_f
     Lin *totals = (Lin *)h->d_chain_totals;
     hipLaunchKernelGGL(k_chain_tile_totals, dim3(ntiles), dim3(kChainThreads), 0, h->stream, A, totals);
     const dim3 g(ntiles), b(kChainThreads);
-    if (ntiles > kOwnCarryTiles) hipLaunchKernelGGL(k_chain_scan_totals, dim3(2), dim3(kBlock), 0, h->stream, ntiles, totals);
-    if (ntiles <= kOwnCarryTiles) {
+    // CX_CHAIN_OWN_CARRY_TILES: the tile count up to which the apply workgroups compose their own carry (tests set it low to run the
+    // one-workgroup scan of the totals on small chains)
+    static const int own_carry_tiles = [] { const char *e = getenv("CX_CHAIN_OWN_CARRY_TILES"); return e ? atoi(e) : kOwnCarryTiles; }();
+    if (ntiles > own_carry_tiles) hipLaunchKernelGGL(k_chain_scan_totals, dim3(2), dim3(kBlock), 0, h->stream, ntiles, totals);
+    if (ntiles <= own_carry_tiles) {
         if (marg_form) hipLaunchKernelGGL((k_chain_apply<true, true>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, marg_form, chain_v2f ? h->d_v2f : nullptr);
         else hipLaunchKernelGGL((k_chain_apply<true, false>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, 0, (double2 *)nullptr);
     } else {

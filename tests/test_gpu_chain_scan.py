@@ -196,6 +196,34 @@ def test_chain_scan_with_linear_factors_and_several_side_factors(hip_lib, n, ext
     assert_close(marg[:, 0], em2, 1e-9, "after new data: mean"); assert_close(marg[:, 1], evar, 1e-9, "after new data: variance")
 
 
+def test_prescanned_tile_totals_path(hip_lib):
+    """chains of more than 8192 tiles (8.4 M links) pre-scan the tile totals with a one-workgroup kernel instead of composing the
+    carry in every apply workgroup; CX_CHAIN_OWN_CARRY_TILES lowers that threshold so the path runs at T = 70,001 (69 tiles) —
+    in a child process, the library reads the variable once"""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent("""
+        import numpy as np
+        import cortex.jl_amd as cx
+        from cortex.jl_amd import _lib as L
+        from oracle import exact
+        T = 70001
+        model = cx.synth.ssm_chain(T, seed=11, random_variances=True)
+        dev = cx.DeviceGraph(schedule=L.SCHED_CHAIN_SCAN)
+        cx.synth.load_into_device(model, dev)
+        xm, xv = exact.ssm_chain_posterior(model.data_y, model.meta["r"], model.meta["q"])
+        for sweep in range(3):          # variable phase first, then the marginals the scan writes
+            dev.sweep(1)
+            m = dev.get_marginals(model.x_ids)
+            assert np.max(np.abs(m[:, 0] - xm) / (1e-300 + np.abs(xm).max())) < 1e-9, sweep
+            assert np.max(np.abs(m[:, 1] - xv) / xv) < 1e-9, sweep
+        print("ok")
+    """)
+    env = dict(os.environ, CX_CHAIN_OWN_CARRY_TILES="8")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_chain_scan_refuses_loopy_graphs(hip_lib):
     model = cx.synth.gaussian_grid(4, 4, seed=1)
     dev = cx.DeviceGraph(schedule=L.SCHED_CHAIN_SCAN)
