@@ -121,6 +121,7 @@ struct cx_handle {
     hipEvent_t ev_packed = nullptr, ev_recv = nullptr, ev_swept = nullptr;
     bool in_sweep = false;
     bool v2f_stale = false;          // fused schedule without materialisation: v2f must be recomputed before use
+    int mv_max_deg = 0;              // dim 2..4: widest slice of the graph (0: not computed yet)
     bool chain_v2f_from_scan = false; // the scan also stores the variable→factor messages of the chain links (set by cx_vmp.hip on its inner handle)
     bool offchain_marg_dirty = true; // chain scan: marginals of variables OFF the chains (observed, stand-ins) are due — they depend on
                                      // stored factor→variable messages only, so a full variable phase runs after those were set

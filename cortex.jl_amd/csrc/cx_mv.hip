@@ -215,8 +215,11 @@ constexpr int kMvDeg = 4;  // variables of higher degree are refused at graph cr
 // The leave-one-out sums add the messages in ascending neighbour order, the reference's left fold order.
 constexpr int kTabLds = 8;   // parameter-set/direction pairs kept in LDS (3 d*d matrices each); more fall back to global memory
 
-template <int D>
-__global__ __launch_bounds__(kBlock) void k_sweep_mv(int nv, int64_t nslots, const int32_t *__restrict__ slice_off,
+// DEG: the largest variable degree of the graph (3 or 4).  A state-space chain has degree 3: three incoming messages instead of four
+// are 28 registers less for d = 4 — 168 VGPRs, THREE waves per SIMD instead of two (no scratch), which is what this kernel's
+// load / compute lock-step was short of.
+template <int D, int DEG>
+__global__ __launch_bounds__(kBlock, DEG == 3 ? 3 : 2) void k_sweep_mv(int nv, int64_t nslots, const int32_t *__restrict__ slice_off,
                                                      const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
                                                      const int32_t *__restrict__ spdir, const double *__restrict__ ptab, int ntab,
                                                      const double *__restrict__ f2v_in, double *__restrict__ f2v_out,
@@ -236,10 +239,10 @@ __global__ __launch_bounds__(kBlock) void k_sweep_mv(int nv, int64_t nslots, con
     // buffer for the first two sweeps after the data changed, which leaves them in both buffers of the Jacobi pair.
     const bool active = v < nv && (((info & kClamped) != 0) == (observed_only != 0));
     const int base = off + tid;
-    Msg<D> in[kMvDeg];
-    int pk[kMvDeg], sd[kMvDeg];
+    Msg<D> in[DEG];
+    int pk[DEG], sd[DEG];
 #pragma unroll
-    for (int k = 0; k < kMvDeg; k++) {
+    for (int k = 0; k < DEG; k++) {
         in[k] = msg_zero<D>();
         pk[k] = -1; sd[k] = -1;
         if (k < W && active) {   // k < W is uniform; lanes with deg <= k read a padding slot of their own slice and drop it
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_mv(int nv, int64_t nslots, con
     if (write_marg) {
         Msg<D> total = msg_zero<D>();
 #pragma unroll
-        for (int k = 0; k < kMvDeg; k++)
+        for (int k = 0; k < DEG; k++)
             if (k < deg) msg_add<D>(total, in[k]);
         const Msg<D> mo = (deg > 0) ? mv_to_moment<D>(total) : total;
         // marginals are written once and not re-read by the sweep: nontemporal stores
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_mv(int nv, int64_t nslots, con
     }
     const bool fixed = (deg < 2) || (info & (kClamped | kGhost));
 #pragma unroll
-    for (int k = 0; k < kMvDeg; k++) {
+    for (int k = 0; k < DEG; k++) {
         if (k >= deg) continue;
         const int slot = base + k * kBlock;
         const int p = pk[k], pd = sd[k];
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_mv(int nv, int64_t nslots, con
         } else {
             o = msg_zero<D>();
 #pragma unroll
-            for (int j = 0; j < kMvDeg; j++)
+            for (int j = 0; j < DEG; j++)
                 if (j < deg && j != k) msg_add<D>(o, in[j]);
         }
         if (__builtin_isnan(o.lam[0])) continue;
@@ -371,13 +374,23 @@ void mv_launch_sweep(cx_handle *h, bool write_marg, bool observed_only) {
     if (h->nslices == 0) return;
     if (!observed_only) prof_b(h, CX_KERNEL_FUSED);
     const dim3 g((unsigned)h->nslices), b(kBlock);
-#define CX_MV(DD)                                                                                                          \
-    hipLaunchKernelGGL((k_sweep_mv<DD>), g, b, 0, h->stream, (int)h->nv, h->nslots, h->d_slice_off, h->d_vinfo, h->d_partner, \
-                       h->d_spdir, h->d_ptab, (int)(2 * h->ptab_sets), h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg, \
-                       (write_marg && !observed_only) ? 1 : 0, observed_only ? 1 : 0)
+    // widest slice = largest variable degree (computed once per graph); CX_MV_DEG4=1 forces the four-message instantiation (A/B)
+    if (h->mv_max_deg == 0) {
+        int w = 0;
+        for (int64_t sl = 0; sl < h->nslices; sl++) w = std::max<int>(w, (h->slice_off[sl + 1] - h->slice_off[sl]) >> kSliceShift);
+        h->mv_max_deg = std::max(w, 1);
+    }
+    static const bool force4 = [] { const char *e = getenv("CX_MV_DEG4"); return e && e[0] == '1'; }();
+    const bool deg3 = h->mv_max_deg <= 3 && !force4;
+#define CX_MV_ARGS g, b, 0, h->stream, (int)h->nv, h->nslots, h->d_slice_off, h->d_vinfo, h->d_partner, h->d_spdir, h->d_ptab, (int)(2 * h->ptab_sets), \
+                   h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg, (write_marg && !observed_only) ? 1 : 0, observed_only ? 1 : 0
+#define CX_MV(DD)                                                          \
+    if (deg3) hipLaunchKernelGGL((k_sweep_mv<DD, 3>), CX_MV_ARGS);         \
+    else hipLaunchKernelGGL((k_sweep_mv<DD, 4>), CX_MV_ARGS)
     if (h->cfg.dim == 2) CX_MV(2);
     else if (h->cfg.dim == 3) CX_MV(3);
     else CX_MV(4);
+#undef CX_MV_ARGS
 #undef CX_MV
     if (!observed_only) prof_e(h);
 }
