@@ -749,6 +749,19 @@ static int pd_cb(cxo_engine *E, int32_t id, int retry, cxo_cb f, void *ctx) {
 }
 int32_t cxo_process_dependencies(cxo_engine *E, int32_t s, int32_t retry, cxo_cb f, void *ctx) { return pd_cb(E, s, retry, f, ctx); }
 
+/* compute!(strategy, signal; force, skip_if_no_listeners) on a free signal, signal.jl:392-410.  The strategy sees the signal and its
+ * dependencies and returns a value.  0: computed and stored (set_value!), 3: skipped — no listeners, 1: the ArgumentError of a
+ * non-pending signal without force, 2: the strategy failed. */
+typedef int32_t (*cxo_strategy_cb)(void *ctx, int32_t sig, int32_t ndeps, const int32_t *deps, int32_t *tag_out, double *a_out, double *b_out);
+int32_t cxo_compute(cxo_engine *E, int32_t s, int32_t force, int32_t skip_if_no_listeners, cxo_strategy_cb strategy, void *ctx) {
+    if (skip_if_no_listeners && E->sig[s].nlist == 0) return 3;
+    if (!force && !sig_is_pending(E, s)) return 1;
+    cxo_value v = { CXO_UNDEF, 0.0, 0.0, { 0, 0, 0, 0 } };
+    if (!strategy(ctx, s, E->sig[s].ndeps, E->sig[s].deps, &v.tag, &v.a, &v.b)) return 2;
+    sig_set_value(E, s, v);
+    return 0;
+}
+
 /* bulk helpers so Python never loops over 1e6 signals */
 void cxo_bulk_set_message_to_factor(cxo_engine *E, const int64_t *vars, const int64_t *facs, int64_t n, int32_t tag, const double *a, const double *b) {
     for (int64_t i = 0; i < n; i++) { cxo_value v = { tag, a[i], b ? b[i] : 0.0, { 0, 0, 0, 0 } }; sig_set_value(E, cxo_message_to_factor(E, vars[i], facs[i]), v); }

@@ -96,6 +96,7 @@ def lib():
     sig("cxo_counter", i64, vp, i32)
     sig("cxo_last_error", i32, vp)
     sig("cxo_process_dependencies", i32, vp, i32, i32, vp, vp)
+    sig("cxo_compute", i32, vp, i32, i32, i32, vp, vp)
     sig("cxo_bulk_set_message_to_factor", None, vp, pi64, pi64, i64, i32, pd, pd)
     sig("cxo_bulk_set_message_to_variable", None, vp, pi64, pi64, i64, i32, pd, pd)
     sig("cxo_bulk_get_marginals", None, vp, pi64, i64, pi32, pd, pd)
@@ -118,6 +119,8 @@ def _i64(a):
 
 
 CALLBACK = C.CFUNCTYPE(C.c_int32, C.c_int32, C.c_void_p)
+STRATEGY_CALLBACK = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                                C.POINTER(C.c_double))
 RULE_CALLBACK = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double))
 
 
@@ -253,6 +256,23 @@ class Engine:
     def process_dependencies(self, s, fn, retry=False) -> bool:
         cb = CALLBACK(lambda sig, ctx: int(bool(fn(sig))))
         return bool(self.L.cxo_process_dependencies(self.h, s, int(retry), C.cast(cb, C.c_void_p), None))
+
+    def compute(self, s, strategy, force=False, skip_if_no_listeners=False):
+        """compute!(strategy, signal; force, skip_if_no_listeners) (signal.jl:392-410); strategy(signal, deps) -> number"""
+        def thunk(ctx, sig, ndeps, deps, tag_out, a_out, b_out):
+            try:
+                r = strategy(sig, [deps[i] for i in range(ndeps)])
+            except Exception as ex:           # must not unwind through C
+                self.rule_error = ex
+                return 0
+            tag_out[0] = REAL; a_out[0] = float(r); b_out[0] = 0.0
+            return 1
+        cb = STRATEGY_CALLBACK(thunk)
+        rc = self.L.cxo_compute(self.h, s, int(force), int(skip_if_no_listeners), C.cast(cb, C.c_void_p), None)
+        if rc == 1:
+            raise ValueError("Signal is not pending. Cannot compute a non-pending signal.")  # signal.jl:399-405
+        if rc == 2:
+            raise RuntimeError(f"strategy failed: {getattr(self, 'rule_error', None)!r}")
 
     def warnings(self):
         return [self.L.cxo_warning_context(self.h, i) for i in range(self.L.cxo_num_warnings(self.h))]

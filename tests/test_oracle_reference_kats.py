@@ -46,10 +46,25 @@ class MirrorSignals:
     def process_dependencies(self, s, fn, retry=False):
         return self.cx.process_dependencies(fn, s, retry=retry)
 
+    def compute(self, s, strategy, force=False, skip_if_no_listeners=False):
+        self.cx.compute(strategy, s, force=force, skip_if_no_listeners=skip_if_no_listeners)
+
+    def value(self, s):
+        v = self.cx.get_value(s)
+        return None if isinstance(v, self.cx.UndefValue) else v
+
 
 @pytest.fixture(params=["oracle", "mirror"])
 def E(request):
     return ref.Engine(ref.P_SSM_BP) if request.param == "oracle" else MirrorSignals()
+
+
+def val(E, s):
+    """get_value as a plain number, None for UndefValue() — on either restatement"""
+    if hasattr(E, "value"):
+        return E.value(s)
+    tag, a, _ = E.get_value(s)
+    return None if tag == ref.UNDEF else a
 
 
 def S(E, value=None):
@@ -61,6 +76,100 @@ def S(E, value=None):
 
 
 # ------------------------------------------------------------------ test/signal_tests.jl
+
+def test_basic_signal_operations(E):
+    """signal_tests.jl:1-21 "Basic Signal Operations" (the untyped half: typed Signals are Julia's type system)."""
+    s = S(E, 42)
+    assert val(E, s) == 42
+    E.set_value(s, 100)
+    assert val(E, s) == 100
+
+
+def test_empty_signal_creation(E):
+    """signal_tests.jl:69-88."""
+    s = S(E)
+    assert val(E, s) is None                       # UndefValue()
+    assert E.dependencies(s) == [] and E.listeners(s) == []
+    assert not E.is_pending(s) and not E.is_computed(s)
+
+
+def test_signal_creation_with_value_sets_computed(E):
+    """signal_tests.jl:90-97."""
+    s = S(E, 10)
+    assert val(E, s) == 10 and E.is_computed(s) and not E.is_pending(s)
+
+
+def test_signal_computed_with_a_strategy(E):
+    """signal_tests.jl:834-871 "A Signal Can Be Computed With A Lambda Function", basic case."""
+    s1, s2, s3 = S(E, 1), S(E, 2), S(E)
+    E.add_dependency(s3, s1); E.add_dependency(s3, s2)
+    assert E.is_pending(s3) and not E.is_computed(s3)
+    strategy = lambda _, deps: sum(val(E, d) for d in deps)
+    E.compute(s3, strategy)
+    assert E.is_computed(s3) and not E.is_pending(s3) and val(E, s3) == 3
+    with pytest.raises(ValueError):                # ArgumentError: no longer pending
+        E.compute(s3, strategy)
+    E.compute(s3, strategy, force=True)
+    assert val(E, s3) == 3 and not E.is_pending(s3)
+    E.set_value(s1, 10); E.set_value(s2, 20)
+    assert E.is_pending(s3)
+    E.compute(s3, strategy)
+    assert E.is_computed(s3) and not E.is_pending(s3) and val(E, s3) == 30
+
+
+def test_pyramid_of_signals(E):
+    """signal_tests.jl:873-916."""
+    s01, s02, s11, s12 = S(E, 1), S(E, 2), S(E, 3), S(E, 4)
+    s21, s22, s3 = S(E), S(E), S(E)
+    E.add_dependency(s21, s01); E.add_dependency(s21, s02)
+    E.add_dependency(s22, s11); E.add_dependency(s22, s12)
+    E.add_dependency(s3, s21); E.add_dependency(s3, s22)
+    assert E.is_pending(s21) and E.is_pending(s22) and not E.is_computed(s21) and not E.is_computed(s22)
+    assert not E.is_pending(s3) and not E.is_computed(s3)
+    strategy = lambda _, deps: sum(val(E, d) for d in deps)
+    E.compute(s21, strategy); E.compute(s22, strategy)
+    assert not E.is_pending(s21) and not E.is_pending(s22)
+    assert E.is_pending(s3) and not E.is_computed(s3)          # pending once its dependencies are computed
+    E.compute(s3, strategy)
+    assert E.is_computed(s3) and not E.is_pending(s3) and val(E, s3) == 10
+
+
+def test_intermediate_dependencies_are_listed(E):
+    """signal_tests.jl:919-931."""
+    source, intermediate, derived = S(E), S(E), S(E)
+    E.add_dependency(intermediate, source)
+    E.add_dependency(derived, intermediate, intermediate=True)
+    assert E.dependencies(derived) == [intermediate] and E.dependencies(intermediate) == [source]
+
+
+@pytest.mark.parametrize("retry", [False, True])
+def test_process_dependencies_reports_that_something_was_processed(E, retry):
+    """signal_tests.jl:1061-1082."""
+    source, intermediate, derived = S(E), S(E), S(E)
+    E.add_dependency(intermediate, source)
+    E.add_dependency(derived, intermediate, intermediate=True)
+    attempted = []
+
+    def f(dep):
+        attempted.append(dep)
+        return dep is source or dep == source
+    assert E.process_dependencies(derived, f, retry=retry)
+    assert len(attempted) >= 1
+
+
+def test_compute_skips_a_signal_without_listeners_unless_told_otherwise(E):
+    """signal_tests.jl:1116-1133."""
+    s = S(E, 1)
+    E.compute(s, lambda sig, deps: 2, skip_if_no_listeners=True)
+    assert val(E, s) == 1
+    seen = []
+
+    def strategy(sig, deps):
+        seen.append(len(deps))
+        return 2
+    E.compute(s, strategy, force=True, skip_if_no_listeners=False)
+    assert seen == [0] and val(E, s) == 2
+
 
 def test_add_dependency_basic(E):
     """signal_tests.jl:99-135 "Add Dependency Basic"."""
