@@ -279,3 +279,59 @@ def test_wiring_and_execution_order_equal_the_c_restatement(seed, loopy):
                 assert t == ref.UNDEF
             else:
                 assert (m.mean, m.variance) == (a, b)   # bit-identical: same arithmetic, same order
+
+
+# ---- test/model_engine_tests.jl:1-112 and test/ext/bipartite_factor_graphs_ext_tests.jl: the graph data structures and the
+#      accessors HipProcessor.attach ingests a model through — assertions transcribed, on the host mirror
+def test_variable_factor_connection_data_structures():
+    from cortex.jl_amd.model_engine import (add_local_marginal_to_factor, get_connection_message_to_factor,
+                                           get_connection_message_to_variable, get_factor_functional_form, get_factor_local_marginals,
+                                           get_variable_linked_signals, link_signal_to_variable)
+    for name in ("v", "v1", "v2", "v3"):                                  # model_engine_tests.jl:1-21
+        v = Variable(name=name)
+        assert v.name == name and v.index is None
+        assert isinstance(get_variable_marginal(v), cx.Signal) and isinstance(get_variable_linked_signals(v), list)
+    for index in (1, 2, 3):
+        v = Variable(name="v", index=index)
+        assert v.name == "v" and v.index == index and isinstance(get_variable_marginal(v), cx.Signal)
+    assert get_variable_linked_signals(Variable(name="v")) == []          # :23-29
+    external = cx.create_inference_signal()                               # :31-39
+    assert get_variable_marginal(Variable(name="v", marginal=external)) is external
+    v1, other = Variable(name="v1"), cx.create_inference_signal()         # :41-52
+    link_signal_to_variable(v1, other)
+    assert any(s is other for s in get_variable_linked_signals(v1))
+    for form in ("f", "g", "h"):                                          # :54-63
+        f = Factor(functional_form=form)
+        assert get_factor_functional_form(f) == form and isinstance(get_factor_local_marginals(f), list)
+    f = Factor(functional_form="f")                                       # :65-84
+    assert get_factor_local_marginals(f) == []
+    lm = cx.create_inference_signal()
+    add_local_marginal_to_factor(f, lm)
+    assert any(s is lm for s in get_factor_local_marginals(f))
+    for label in ("c", "d", "e"):                                         # :86-104
+        for index in (1, 2, 3):
+            c = Connection(label=label, index=index)
+            assert c.label == label and c.index == index
+            assert isinstance(get_connection_message_to_variable(c), cx.Signal) and isinstance(get_connection_message_to_factor(c), cx.Signal)
+    assert Connection(label="c").index == 0                               # :106-112
+
+
+def test_bipartite_factor_graph_backend_accessors():
+    """test/ext/bipartite_factor_graphs_ext_tests.jl:1-93"""
+    from cortex.jl_amd.model_engine import get_connection_message_to_factor, get_connection_message_to_variable, get_factor_functional_form
+    for kw in ({}, {"resolve_dependencies": False}, {"prepare_signals_metadata": False}):
+        assert isinstance(InferenceEngine(model_engine=BipartiteFactorGraph(), **kw), InferenceEngine)
+    graph = BipartiteFactorGraph()
+    a = graph.add_variable(Variable(name="a")); b = graph.add_variable(Variable(name="b", index=(1,))); c = graph.add_variable(Variable(name="c", index=(2, 3)))
+    f1 = graph.add_factor(Factor(functional_form="f1")); f2 = graph.add_factor(Factor(functional_form="f2"))
+    graph.add_edge(a, f1, Connection(label="out")); graph.add_edge(b, f2, Connection(label="theta"))
+    engine = InferenceEngine(model_engine=graph)
+    assert [engine.get_variable(v).name for v in (a, b, c)] == ["a", "b", "c"]
+    assert [engine.get_variable(v).index for v in (a, b, c)] == [None, (1,), (2, 3)]
+    assert all(isinstance(get_variable_marginal(engine.get_variable(v)), cx.Signal) for v in (a, b, c))
+    assert get_factor_functional_form(engine.get_factor(f1)) == "f1" and get_factor_functional_form(engine.get_factor(f2)) == "f2"
+    for v, f, label in ((a, f1, "out"), (b, f2, "theta")):
+        conn = engine.get_connection(v, f)
+        assert isinstance(conn, Connection) and conn.label == label
+        assert engine.get_connection_message_to_variable(v, f) is get_connection_message_to_variable(conn)
+        assert engine.get_connection_message_to_factor(v, f) is get_connection_message_to_factor(conn)
