@@ -335,3 +335,9 @@ def test_bipartite_factor_graph_backend_accessors():
         assert isinstance(conn, Connection) and conn.label == label
         assert engine.get_connection_message_to_variable(v, f) is get_connection_message_to_variable(conn)
         assert engine.get_connection_message_to_factor(v, f) is get_connection_message_to_factor(conn)
+    for v, f in ((a, f2), (b, f1)):                                       # :84-86: no such connection
+        with pytest.raises(Exception):
+            engine.get_connection(v, f)
+    assert set(engine.get_variable_ids()) == {a, b, c} and set(engine.get_factor_ids()) == {f1, f2}
+    assert set(engine.get_connected_variable_ids(f1)) == {a} and set(engine.get_connected_variable_ids(f2)) == {b}
+    assert set(engine.get_connected_factor_ids(a)) == {f1} and set(engine.get_connected_factor_ids(b)) == {f2} and set(engine.get_connected_factor_ids(c)) == set()
