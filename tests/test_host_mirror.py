@@ -341,3 +341,14 @@ def test_bipartite_factor_graph_backend_accessors():
     assert set(engine.get_variable_ids()) == {a, b, c} and set(engine.get_factor_ids()) == {f1, f2}
     assert set(engine.get_connected_variable_ids(f1)) == {a} and set(engine.get_connected_variable_ids(f2)) == {b}
     assert set(engine.get_connected_factor_ids(a)) == {f1} and set(engine.get_connected_factor_ids(b)) == {f2} and set(engine.get_connected_factor_ids(c)) == set()
+
+
+def test_isa_variant_with_inference_signal_variants():
+    """test/inference_engine_tests.jl:10-31 (the JET / allocation lines are Julia's)"""
+    V = cx.InferenceSignalVariants
+    c = cx.create_inference_signal()
+    assert cx.isa_variant(c, V.Unspecified)
+    cx.set_variant(c, V.MessageToVariable(1, 2))
+    assert cx.isa_variant(c, V.MessageToVariable) and not cx.isa_variant(c, V.MessageToFactor)
+    cx.set_variant(c, V.MessageToFactor(1, 2))
+    assert cx.isa_variant(c, V.MessageToFactor) and not cx.isa_variant(c, V.MessageToVariable)
