@@ -352,3 +352,26 @@ def test_isa_variant_with_inference_signal_variants():
     assert cx.isa_variant(c, V.MessageToVariable) and not cx.isa_variant(c, V.MessageToFactor)
     cx.set_variant(c, V.MessageToFactor(1, 2))
     assert cx.isa_variant(c, V.MessageToFactor) and not cx.isa_variant(c, V.MessageToVariable)
+
+
+def test_resolve_dependencies_visits_every_variable_and_factor():
+    """test/dependencies_tests.jl:1-37: a custom resolver sees all of them"""
+    from cortex.jl_amd.dependencies import resolve_dependencies
+
+    class Recording(cx.AbstractDependencyResolver):
+        def __init__(self):
+            self.variables, self.factors = set(), set()
+
+        def resolve_variable_dependencies(self, engine, variable_id):
+            self.variables.add(variable_id)
+
+        def resolve_factor_dependencies(self, engine, factor_id):
+            self.factors.add(factor_id)
+
+    graph = BipartiteFactorGraph()
+    x, y, z = (graph.add_variable(Variable(name=n)) for n in "xyz")
+    f1, f2 = graph.add_factor(Factor(functional_form="f1")), graph.add_factor(Factor(functional_form="f2"))
+    engine = InferenceEngine(model_engine=graph)
+    r = Recording()
+    resolve_dependencies(r, engine)
+    assert r.variables == {x, y, z} and r.factors == {f1, f2}
