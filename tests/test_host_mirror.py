@@ -375,3 +375,17 @@ def test_resolve_dependencies_visits_every_variable_and_factor():
     r = Recording()
     resolve_dependencies(r, engine)
     assert r.variables == {x, y, z} and r.factors == {f1, f2}
+
+
+def test_signal_variant_defaults_and_updates():
+    """test/signal_tests.jl:23-52 "Signal Variant" (default values, custom variant; the typed-Signal testset is Julia's type system)"""
+    s = cx.Signal(42)
+    assert isinstance(cx.get_variant(s), cx.UndefVariant) and isinstance(cx.get_variant(cx.Signal()), cx.UndefVariant)
+    cx.set_variant(s, 1)
+    assert cx.get_variant(s) == 1 and cx.isa_variant(s, int) and not cx.isa_variant(s, str)
+    cx.set_variant(s, "2")
+    assert cx.get_variant(s) == "2" and cx.isa_variant(s, str) and not cx.isa_variant(s, int)
+    s = cx.Signal(42, variant=1)
+    assert cx.get_variant(s) == 1
+    cx.set_variant(s, 2); assert cx.get_variant(s) == 2
+    cx.set_variant(s, "3"); assert cx.get_variant(s) == "3"
