@@ -11,6 +11,9 @@ one, by an independent exact solver:
   grid8x8.json    8 x 8 Gaussian grid: priors, factor variances, the flooding checker's messages after 5 sweeps and its
                   marginals at convergence, the dense-solve posterior means
   lgssm_d4.json   d = 4 linear-Gaussian chain, T = 8: A, Q, R, data, block-tridiagonal posterior means and covariances
+  lgssm_d64.json  d = 64 linear-Gaussian chain, T = 3 (the MFMA path's rule): data, posterior means, the posterior covariance of the
+                  middle state and the diagonals of all three (A is regenerated from the seed by cx.synth.lgssm_chain; its first
+                  row is stored as a guard)
   vmp_n8.json     variational SSM of :691-770 / :1032-1120, n = 8: data, posteriors after 5 x (x; ssnoise, obsnoise) for the
                   mean-field and the structured family (array form, oracle/vmp.py)
   kats.json       constants of the reference's own known answers: Beta-Bernoulli posterior (:360-376), tracing values 2, 4, 9
@@ -77,6 +80,14 @@ def lgssm_d4():
                            "x_ids": m.x_ids, "posterior_mean": em, "posterior_covariance": ecov})
 
 
+def lgssm_d64():
+    m = cx.synth.lgssm_chain(3, d=64, seed=1234)
+    em, ecov = exact.lgssm_posterior(m.data_y, m.meta["A"], m.meta["Q"], m.meta["R"])
+    dump("lgssm_d64.json", {"T": 3, "d": 64, "seed": 1234, "A_row0": m.meta["A"][0], "q": 0.1, "r": 1.0, "data_y": m.data_y, "x_ids": m.x_ids,
+                            "posterior_mean": em, "posterior_covariance_middle": ecov[1],
+                            "posterior_variances": np.stack([np.diag(c) for c in ecov])})
+
+
 def vmp_n8():
     m = cx.synth.vmp_ssm(8, seed=1234)
     out = {"n": 8, "seed": 1234, "data_y": m.data_y, "iterations": 5, "calls": "5 x (update x; update [ssnoise, obsnoise])"}
@@ -97,5 +108,5 @@ def kats():
 
 
 if __name__ == "__main__":
-    chain16(); grid8x8(); lgssm_d4(); vmp_n8(); kats()
+    chain16(); grid8x8(); lgssm_d4(); lgssm_d64(); vmp_n8(); kats()
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".json")))

@@ -53,6 +53,21 @@ def test_block_chain_and_variational_vectors_reproduce():
     em, ecov = exact.lgssm_posterior(d["data_y"], d["A"], d["Q"], d["R"])
     np.testing.assert_allclose(em, d["posterior_mean"], rtol=1e-13)
     np.testing.assert_allclose(ecov, d["posterior_covariance"], rtol=1e-13)
+    d64 = load("lgssm_d64.json")
+    m64 = cx.synth.lgssm_chain(3, d=64, seed=1234)                 # A comes from the seed: its first row guards the generator
+    np.testing.assert_allclose(m64.meta["A"][0], d64["A_row0"], rtol=0, atol=0)
+    assert np.array_equal(m64.data_y, d64["data_y"])
+    em, ecov = exact.lgssm_posterior(m64.data_y, m64.meta["A"], m64.meta["Q"], m64.meta["R"])
+    np.testing.assert_allclose(em, d64["posterior_mean"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(ecov[1], d64["posterior_covariance_middle"], rtol=1e-12, atol=1e-14)
+    # the numpy flooding restatement (what the d = 64 kernel is checked against sweep by sweep) reaches the same posterior
+    from oracle.mv import MvFlood
+    o = MvFlood(m64)
+    o.sweep(6)
+    for t, xi in enumerate(np.searchsorted(o.g.var_ids, m64.x_ids)):
+        mu, S = o.marginal(int(xi))
+        np.testing.assert_allclose(mu, d64["posterior_mean"][t], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(np.diag(S), d64["posterior_variances"][t], rtol=1e-9)
     v = load("vmp_n8.json")
     for name, cls in (("mean_field", vmp.MeanFieldVMP), ("structured", vmp.StructuredVMP)):
         a = cls(v["data_y"])
@@ -114,6 +129,16 @@ def test_device_block_chain_and_vmp_against_the_golden_vectors(hip_lib):
     marg = dev.get_marginals(d["x_ids"])
     np.testing.assert_allclose(marg[:, :4], d["posterior_mean"], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(marg[:, 4:].reshape(8, 4, 4), d["posterior_covariance"], rtol=1e-9, atol=1e-12)
+    d64 = load("lgssm_d64.json")
+    m64 = cx.synth.lgssm_chain(3, d=64, seed=1234)
+    h64 = cx.DeviceGraph(dim=64, schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(m64, h64)
+    h64.sweep(6)
+    q64 = h64.get_marginals(d64["x_ids"])
+    np.testing.assert_allclose(q64[:, :64], d64["posterior_mean"], rtol=1e-8, atol=1e-11)
+    cov = q64[:, 64:].reshape(3, 64, 64)
+    np.testing.assert_allclose(cov[1], d64["posterior_covariance_middle"], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(np.stack([np.diag(c) for c in cov]), d64["posterior_variances"], rtol=1e-8)
     v = load("vmp_n8.json")
     vm = cx.synth.vmp_ssm(8, seed=1234)
     for name, fam in (("mean_field", L.FAMILY_VMP_MEAN_FIELD), ("structured", L.FAMILY_VMP_STRUCTURED)):
