@@ -283,12 +283,12 @@ def test_gloo_partitioned_convergence_with_the_residual_all_reduce(tmp_path, dep
     assert len(runs) == 1          # the all-reduce makes the decision common
 
 
-@pytest.mark.parametrize("world,depth", [(3, 0), (3, 2), (2, 3)])
+@pytest.mark.parametrize("world,depth", [(3, 0), (3, 2), (2, 3), (8, 2)])
 def test_gloo_strong_scaling_cut_of_one_grid(tmp_path, world, depth):
     """BASELINE config 4's shape: ONE grid cut into `world` near-equal row blocks (10 rows over 3 ranks: 3 / 3 / 4), as
     bench.py --gpus N does by default (partition.grid_rows / grid_rows_deep).  Owned messages and marginals equal the
     single-process sweep bit for bit."""
-    rows, cols, sweeps = 10 if world == 3 else 7, 6, 8
+    rows, cols, sweeps = {3: 10, 2: 7, 8: 43}[world], 6, 8        # 8 ranks (what bench.py --gpus 8 runs): blocks of 5 / 6 rows, two-neighbour middle ranks
     out = str(tmp_path / "res")
     port = _free_port()
     procs = []
