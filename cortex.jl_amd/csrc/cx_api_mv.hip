@@ -1,0 +1,304 @@
+// ==================================================================================================================
+// dim > 1 (cx_mv.hip): host side of the data path.  Payload rows at the ABI: MOMENT mean[d] + covariance[d*d];
+// NATURAL eta[d] + Lambda[d*d]; POINT y[d].  Device: eta[d] + packed upper triangle of Lambda, component-major.
+// ==================================================================================================================
+#include "cx_host.h"
+
+using namespace cxh;
+
+namespace cxh {
+
+void mv_pack(int d, const double *eta, const double *lam_full, double *out) {
+    for (int i = 0; i < d; i++) out[i] = eta[i];
+    int c = d;
+    for (int i = 0; i < d; i++) for (int j = i; j < d; j++) out[c++] = 0.5 * (lam_full[i * d + j] + lam_full[j * d + i]);
+}
+
+void mv_unpack(int d, const double *in, double *eta, double *lam_full) {
+    for (int i = 0; i < d; i++) eta[i] = in[i];
+    int c = d;
+    for (int i = 0; i < d; i++) for (int j = i; j < d; j++) { lam_full[i * d + j] = in[c]; lam_full[j * d + i] = in[c]; c++; }
+}
+
+bool mv_to_natural(int d, int32_t form, const double *p, double *out /* nc */) {
+    const int nc = d + d * (d + 1) / 2;
+    if (form == CX_FORM_POINT) {
+        for (int i = 0; i < nc; i++) out[i] = 0.0;
+        for (int i = 0; i < d; i++) out[i] = p[i];
+        out[d] = kInf;
+        return true;
+    }
+    if (form == CX_FORM_NATURAL) { mv_pack(d, p, p + d, out); return true; }
+    bool undef = false;
+    for (int i = 0; i < d * d; i++) undef = undef || std::isnan(p[d + i]);
+    if (undef) { for (int i = 0; i < nc; i++) out[i] = kNaN; return true; }
+    std::vector<double> lam((size_t)d * d), eta(d);
+    if (!cx::spd_inverse(d, p + d, lam.data())) return false;
+    for (int i = 0; i < d; i++) { double s = 0; for (int j = 0; j < d; j++) s += lam[i * d + j] * p[j]; eta[i] = s; }
+    mv_pack(d, eta.data(), lam.data(), out);
+    return true;
+}
+
+void mv_from_natural(int d, int32_t form, const double *in /* nc */, double *out /* d + d*d */) {
+    std::vector<double> lam((size_t)d * d), eta(d);
+    mv_unpack(d, in, eta.data(), lam.data());
+    if (form == CX_FORM_NATURAL) { for (int i = 0; i < d; i++) out[i] = eta[i]; for (int i = 0; i < d * d; i++) out[d + i] = lam[i]; return; }
+    if (std::isnan(in[d])) { for (int i = 0; i < d + d * d; i++) out[i] = kNaN; return; }
+    if (in[d] == kInf) { for (int i = 0; i < d; i++) out[i] = eta[i]; for (int i = 0; i < d * d; i++) out[d + i] = 0.0; return; }
+    std::vector<double> cov((size_t)d * d);
+    if (!cx::spd_inverse(d, lam.data(), cov.data())) { for (int i = 0; i < d + d * d; i++) out[i] = kNaN; return; }
+    for (int i = 0; i < d; i++) { double s = 0; for (int j = 0; j < d; j++) s += cov[i * d + j] * eta[j]; out[i] = s; }
+    for (int i = 0; i < d * d; i++) out[d + i] = cov[i];
+}
+
+// variable→factor messages are never stored by the dim > 1 sweep: recompute the requested ones from the input buffer
+// the last sweep read (retained in d_mv_f2v_alt after the swap)
+int32_t mv_refresh_v2f(cx_handle *h, const std::vector<int32_t> &slots, const std::vector<int32_t> &vars) {
+    const int64_t n = (int64_t)slots.size();
+    int32_t rc = ensure_stage(h, n * 8);
+    if (rc != CX_OK) return rc;
+    int32_t *d_s = (int32_t *)h->d_stage, *d_v = d_s + n;
+    CX_HIP(h, hipMemcpyAsync(d_s, slots.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+    CX_HIP(h, hipMemcpyAsync(d_v, vars.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+    if (h->cfg.dim == 64) cx::mv64_launch_v2f(h, (int)n, d_s, d_v, h->sweeps_done > 0 ? h->d_mv_f2v_alt : h->d_mv_f2v);
+    else cx::mv_launch_v2f(h, d_s, d_v, n, h->sweeps_done > 0 ? h->d_mv_f2v_alt : h->d_mv_f2v);
+    CX_HIP(h, hipGetLastError());
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    return CX_OK;
+}
+
+int32_t mv64_set_messages(cx_handle *h, int64_t n, const std::vector<int32_t> &idx, const std::vector<int32_t> &vars, int32_t direction,
+                          int32_t form, const double *payload) {
+    const int d = 64, nc = h->nc;
+    const int64_t bytes_idx = ((n * 4 + 15) / 16) * 16;
+    int32_t rc;
+    if (form == CX_FORM_POINT) {
+        rc = ensure_stage(h, bytes_idx + n * d * 8);
+        if (rc != CX_OK) return rc;
+        int32_t *d_idx = (int32_t *)h->d_stage;
+        double *d_val = (double *)((char *)h->d_stage + bytes_idx);
+        CX_HIP(h, hipMemcpyAsync(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+        CX_HIP(h, hipMemcpyAsync(d_val, payload, (size_t)n * d * 8, hipMemcpyHostToDevice, h->stream));
+        cx::mv64_set_point(h, h->d_mv_v2f, d_idx, d_val, n);
+        for (int64_t i = 0; i < n; i++) h->vinfo[vars[i]] |= cx::kClamped;
+        CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
+        h->work64_dirty = h->point64_dirty = true;
+    } else {
+        std::vector<double> val((size_t)n * nc);
+        for (int64_t i = 0; i < n; i++) {
+            const double *p = payload + i * (d + d * d);
+            double *o = &val[(size_t)i * nc];
+            if (form == CX_FORM_NATURAL) { std::memcpy(o, p, (size_t)nc * 8); continue; }
+            bool undef = false;
+            for (int k = 0; k < d * d; k++) undef = undef || std::isnan(p[d + k]);
+            if (undef) { for (int k = 0; k < nc; k++) o[k] = kNaN; continue; }
+            if (!cx::spd_inverse(d, p + d, o + d))
+                return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_set_messages: covariance of row " + std::to_string(i) + " is not positive definite");
+            for (int r = 0; r < d; r++) { double s = 0; for (int c = 0; c < d; c++) s += o[d + r * d + c] * p[c]; o[r] = s; }
+        }
+        rc = ensure_stage(h, bytes_idx + n * nc * 8);
+        if (rc != CX_OK) return rc;
+        int32_t *d_idx = (int32_t *)h->d_stage;
+        double *d_val = (double *)((char *)h->d_stage + bytes_idx);
+        CX_HIP(h, hipMemcpyAsync(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+        CX_HIP(h, hipMemcpyAsync(d_val, val.data(), (size_t)n * nc * 8, hipMemcpyHostToDevice, h->stream));
+        if (direction == CX_TO_FACTOR) { cx::mv64_rows_scatter(h, h->d_mv_v2f, d_idx, d_val, n); h->point64_dirty = true; }
+        else { cx::mv64_rows_scatter(h, h->d_mv_f2v, d_idx, d_val, n); cx::mv64_rows_scatter(h, h->d_mv_f2v_alt, d_idx, d_val, n); }
+    }
+    CX_HIP(h, hipGetLastError());
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    return CX_OK;
+}
+
+int32_t mv_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, int32_t direction,
+                        int32_t form, const double *payload) {
+    const int d = h->cfg.dim, nc = h->nc;
+    std::vector<int32_t> idx, vars;
+    int32_t rc = stage_slots(h, n, variable_ids, factor_ids, idx, &vars);
+    if (rc != CX_OK) return rc;
+    if (d == 64) return mv64_set_messages(h, n, idx, vars, direction, form, payload);
+    const int64_t stride = form == CX_FORM_POINT ? d : d + d * d;
+    std::vector<double> val((size_t)n * nc);
+    for (int64_t i = 0; i < n; i++)
+        if (!mv_to_natural(d, form, payload + i * stride, &val[(size_t)i * nc]))
+            return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_set_messages: covariance of row " + std::to_string(i) + " is not positive definite");
+    const int64_t bytes_idx = ((n * 4 + 15) / 16) * 16;
+    rc = ensure_stage(h, bytes_idx + n * nc * 8);
+    if (rc != CX_OK) return rc;
+    int32_t *d_idx = (int32_t *)h->d_stage;
+    double *d_val = (double *)((char *)h->d_stage + bytes_idx);
+    CX_HIP(h, hipMemcpyAsync(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+    CX_HIP(h, hipMemcpyAsync(d_val, val.data(), (size_t)n * nc * 8, hipMemcpyHostToDevice, h->stream));
+    if (direction == CX_TO_FACTOR) {
+        cx::mv_launch_scatter(h, h->d_mv_v2f, h->nslots, nc, d_idx, d_val, n);
+        h->observed_passes_due = 2;   // a stored variable→factor message changed: observed senders are refreshed
+        if (form == CX_FORM_POINT) {
+            for (int64_t i = 0; i < n; i++) h->vinfo[vars[i]] |= cx::kClamped;
+            CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
+            h->spdir_dirty = true;
+        }
+    } else {
+        cx::mv_launch_scatter(h, h->d_mv_f2v, h->nslots, nc, d_idx, d_val, n);
+        cx::mv_launch_scatter(h, h->d_mv_f2v_alt, h->nslots, nc, d_idx, d_val, n);
+    }
+    CX_HIP(h, hipGetLastError());
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    return CX_OK;
+}
+
+int32_t mv_get(cx_handle *h, const double *src, int64_t stride, const std::vector<int32_t> &idx, int32_t form, bool already_moment,
+               double *out) {
+    const int d = h->cfg.dim, nc = h->nc;
+    const int64_t n = (int64_t)idx.size();
+    const int64_t bytes_idx = ((n * 4 + 15) / 16) * 16;
+    int32_t rc = ensure_stage(h, bytes_idx + n * nc * 8);
+    if (rc != CX_OK) return rc;
+    int32_t *d_idx = (int32_t *)h->d_stage;
+    double *d_val = (double *)((char *)h->d_stage + bytes_idx);
+    CX_HIP(h, hipMemcpyAsync(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+    if (d == 64) {
+        if (already_moment) cx::mv64_launch_marginals(h, (int)n, d_idx, h->d_mv_f2v, d_val);   // idx = variables: computed on demand
+        else cx::mv64_rows_gather(h, src, d_idx, d_val, n);
+        CX_HIP(h, hipGetLastError());
+        std::vector<double> val((size_t)n * nc);
+        CX_HIP(h, hipMemcpyAsync(val.data(), d_val, (size_t)n * nc * 8, hipMemcpyDeviceToHost, h->stream));
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        for (int64_t i = 0; i < n; i++) {
+            double *o = out + i * nc;
+            const double *in = &val[(size_t)i * nc];
+            if (already_moment || form == CX_FORM_NATURAL) { std::memcpy(o, in, (size_t)nc * 8); continue; }
+            if (std::isnan(in[d])) { for (int k = 0; k < nc; k++) o[k] = kNaN; continue; }
+            if (in[d] == kInf) { for (int k = 0; k < nc; k++) o[k] = 0.0; for (int k = 0; k < d; k++) o[k] = in[k]; continue; }
+            if (!cx::spd_inverse(d, in + d, o + d)) { for (int k = 0; k < nc; k++) o[k] = kNaN; continue; }
+            for (int r = 0; r < d; r++) { double s = 0; for (int c = 0; c < d; c++) s += o[d + r * d + c] * in[c]; o[r] = s; }
+        }
+        return CX_OK;
+    }
+    cx::mv_launch_gather(h, src, stride, nc, d_idx, d_val, n);
+    std::vector<double> val((size_t)n * nc);
+    CX_HIP(h, hipMemcpyAsync(val.data(), d_val, (size_t)n * nc * 8, hipMemcpyDeviceToHost, h->stream));
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    for (int64_t i = 0; i < n; i++) {
+        double *o = out + i * (d + d * d);
+        if (already_moment) mv_unpack(d, &val[(size_t)i * nc], o, o + d);
+        else mv_from_natural(d, form, &val[(size_t)i * nc], o);
+    }
+    return CX_OK;
+}
+
+int32_t mv_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, int32_t direction,
+                        int32_t form, double *out) {
+    std::vector<int32_t> idx, vars;
+    int32_t rc = stage_slots(h, n, variable_ids, factor_ids, idx, &vars);
+    if (rc != CX_OK) return rc;
+    if (direction == CX_TO_FACTOR) { rc = mv_refresh_v2f(h, idx, vars); if (rc != CX_OK) return rc; }
+    return mv_get(h, direction == CX_TO_FACTOR ? h->d_mv_v2f : h->d_mv_f2v, h->nslots, idx, form, false, out);
+}
+
+int32_t mv_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, double *out) {
+    std::vector<int32_t> idx(n);
+    for (int64_t i = 0; i < n; i++) {
+        int64_t v = find_var(h, variable_ids[i]);
+        if (v < 0) return fail(h, CX_ERR_NOT_FOUND, "unknown variable id " + std::to_string(variable_ids[i]));
+        idx[i] = (int32_t)v;
+    }
+    return mv_get(h, h->d_mv_marg, h->nv, idx, CX_FORM_MOMENT, true, out);
+}
+
+// d = 64: which messages need the full MFMA rule, which come from observed variables (constant), which nobody reads
+int32_t build_work64(cx_handle *h) {
+    if (!h->work64_dirty) return CX_OK;
+    std::vector<int32_t> rs, rv, rf, ps, rec, slot_var(h->nslots, -1);
+    for (int64_t e = 0; e < h->ne; e++) slot_var[cx::slot_of_edge(h, e)] = h->edge_var[e];
+    for (int64_t e = 0; e < h->ne; e++) {
+        const int32_t s = cx::slot_of_edge(h, e), p = h->partner[s], v = h->edge_var[e];
+        if (p < 0) continue;
+        const int32_t rvz = slot_var[p];
+        if (h->vinfo[rvz] & cx::kClamped) continue;                 // a message into an observed variable has no reader
+        const int32_t deg = h->var_off[v + 1] - h->var_off[v];
+        if (h->vinfo[v] & cx::kClamped) { ps.push_back(s); continue; }
+        rs.push_back(s); rv.push_back(v); rf.push_back(deg < 2 ? 1 : 0);   // degree-1 leaf: its stored message is the input
+        // the record the rule kernel reads: sender slot, the other incoming slots in ascending neighbour order (the fold
+        // order), rule-table index, destination slot, flags
+        int32_t others[3] = {-1, -1, -1};
+        int n_others = 0;
+        for (int32_t j = 0; j < deg; j++) {
+            const int32_t sj = h->vbase[v] + j * cx::kBlock;
+            if (sj != s && n_others < 3) others[n_others++] = sj;
+        }
+        rec.insert(rec.end(), {s, others[0], others[1], others[2], h->spdir[s], p, deg < 2 ? 1 : 0, 0});
+    }
+    for (void *p : {(void *)h->d_rule64_slots, (void *)h->d_rule64_vars, (void *)h->d_rule64_flags, (void *)h->d_point64_slots, (void *)h->d_rule64_rec}) if (p) (void)hipFree(p);
+    h->d_rule64_slots = h->d_rule64_vars = h->d_rule64_flags = h->d_point64_slots = h->d_rule64_rec = nullptr;
+    h->n_rule64 = (int64_t)rs.size(); h->n_point64 = (int64_t)ps.size();
+    int32_t rc;
+    if ((rc = dev_upload(h, &h->d_rule64_slots, rs)) != CX_OK) return rc;
+    if ((rc = dev_upload(h, &h->d_rule64_vars, rv)) != CX_OK) return rc;
+    if ((rc = dev_upload(h, &h->d_rule64_flags, rf)) != CX_OK) return rc;
+    if ((rc = dev_upload(h, &h->d_point64_slots, ps)) != CX_OK) return rc;
+    if ((rc = dev_upload(h, &h->d_rule64_rec, rec)) != CX_OK) return rc;
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    h->work64_dirty = false;
+    h->point64_dirty = true;
+    return CX_OK;
+}
+
+int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
+    CX_REQUIRE(h, (int64_t)h->psets.size() > h->max_pset, CX_ERR_STATE, "cx_sweep: a factor names a parameter set that was never set (cx_set_factor_matrices)");
+    for (int64_t i = 0; i <= h->max_pset; i++)
+        CX_REQUIRE(h, !h->psets[i].empty(), CX_ERR_STATE, "cx_sweep: parameter set " + std::to_string(i) + " was never set (cx_set_factor_matrices)");
+    if (h->cfg.dim == 64) {
+        int32_t rc = build_work64(h);
+        if (rc != CX_OK) return rc;
+        if (h->point64_dirty) {   // messages out of observed variables are constant: computed once, into both buffers
+            cx::mv64_launch_point(h, (int)h->n_point64, h->d_point64_slots, h->d_mv_f2v, h->d_mv_f2v_alt);
+            h->point64_dirty = false;
+        }
+    }
+    if (h->cfg.dim != 64 && h->spdir_dirty) {   // mask the rules whose receiver is an observed variable
+        std::vector<int32_t> eff(h->spdir), slot_var(h->nslots, -1);
+        for (int64_t e = 0; e < h->ne; e++) slot_var[cx::slot_of_edge(h, e)] = h->edge_var[e];
+        for (int64_t sl = 0; sl < h->nslots; sl++) {
+            const int32_t p = h->partner[sl];
+            if (p >= 0 && (h->vinfo[slot_var[p]] & cx::kClamped)) eff[sl] = -1;
+        }
+        CX_HIP(h, hipMemcpy(h->d_spdir, eff.data(), eff.size() * 4, hipMemcpyHostToDevice));
+        h->spdir_dirty = false;
+        h->observed_passes_due = 2;   // the data (or the set of observed variables) changed: refresh both buffers
+    }
+    for (int32_t s = 0; s < n_sweeps; s++) {
+        if (h->cfg.dim == 64)
+            cx::mv64_launch_rule(h, (int)h->n_rule64, h->d_rule64_rec, h->d_mv_f2v, h->d_mv_f2v_alt, CX_KERNEL_FUSED);
+        else {
+            if (h->observed_passes_due > 0) { cx::mv_launch_sweep(h, false, true); h->observed_passes_due--; }
+            cx::mv_launch_sweep(h, h->cfg.compute_marginals_in_sweep != 0, false);
+        }
+        std::swap(h->d_mv_f2v, h->d_mv_f2v_alt);
+        h->sweeps_done++;
+    }
+    CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
+int32_t mv_residual(cx_handle *h, double *out) {
+    const int64_t n = h->nc * h->nslots;
+    if (!h->d_mv_prev) {
+        int32_t rc = dev_alloc(h, &h->d_mv_prev, n);
+        if (rc != CX_OK) return rc;
+        CX_HIP(h, hipMemcpyAsync(h->d_mv_prev, h->d_mv_f2v, (size_t)n * 8, hipMemcpyDeviceToDevice, h->stream));
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        *out = kInf;
+        return CX_OK;
+    }
+    cx::mv_launch_residual(h, h->d_mv_f2v, h->d_mv_prev, n, h->d_scratch);
+    std::vector<double> part(1024);
+    CX_HIP(h, hipMemcpyAsync(part.data(), h->d_scratch, 1024 * 8, hipMemcpyDeviceToHost, h->stream));
+    CX_HIP(h, hipMemcpyAsync(h->d_mv_prev, h->d_mv_f2v, (size_t)n * 8, hipMemcpyDeviceToDevice, h->stream));
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    double m = 0.0;
+    for (double p : part) m = (p != p) ? kInf : std::max(m, p);
+    *out = m;
+    return CX_OK;
+}
+
+}  // namespace cxh

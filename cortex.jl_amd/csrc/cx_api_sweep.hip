@@ -1,0 +1,352 @@
+// cx_api_sweep.hip — cx_sweep and what it needs: the chain decomposition of CX_SCHED_CHAIN_SCAN, the composed maps of a
+// chain partition, the schedules' launch sequences, residuals.
+
+#include "cx_host.h"
+
+using namespace cxh;
+
+namespace cxh {
+
+// In the fused schedule without materialisation the variable→factor messages of the last sweep exist only as
+// "leave-one-out of the sweep's input buffer", which is retained in d_f2v_alt: recompute them on demand.
+// After a two-sweep launch (cx_tiles.hip) the retained buffer d_f2v_alt holds time t while d_f2v holds t+2: the buffer of
+// time t+1 — the input of the last sweep, which is what variable→factor messages and checkpoints are defined from — never
+// existed.  Regenerate it with one plain sweep from time t into a third buffer and make that the retained buffer.
+int32_t normalize_alt(cx_handle *h) {
+    if (!h->alt_two_back) return CX_OK;
+    if (!h->d_f2v_tmp) { int32_t rc = dev_alloc(h, &h->d_f2v_tmp, h->nslots); if (rc != CX_OK) return rc; }
+    // slots no sweep writes (priors of unary factors, padding) are equal in every buffer: start from a copy
+    CX_HIP(h, hipMemcpyAsync(h->d_f2v_tmp, h->d_f2v_alt, (size_t)h->nslots * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
+    const bool prof = h->profiling;
+    h->profiling = false;
+    cx::launch_fused(h, h->d_f2v_alt, h->d_f2v_tmp, false, false, false);
+    h->profiling = prof;
+    CX_HIP(h, hipGetLastError());
+    std::swap(h->d_f2v_alt, h->d_f2v_tmp);
+    h->alt_two_back = false;
+    return CX_OK;
+}
+
+int32_t ensure_v2f(cx_handle *h) {
+    if (!h->v2f_stale) return CX_OK;
+    { int32_t rc = normalize_alt(h); if (rc != CX_OK) return rc; }
+    const double2 *src = h->d_f2v_alt ? h->d_f2v_alt : h->d_f2v;
+    cx::launch_var_to_factor(h, src, false);
+    cx::launch_big_var_to_factor(h, src, false);
+    CX_HIP(h, hipGetLastError());
+    h->v2f_stale = false;
+    return CX_OK;
+}
+
+// ---- chain decomposition for CX_SCHED_CHAIN_SCAN -------------------------------------------------------------------
+// Free variables (not observed, not ghosts, degree >= 2) linked by 2-edge factors must form disjoint simple paths.
+int32_t build_chains(cx_handle *h) {
+    if (!h->chains_dirty) return CX_OK;
+    try {
+        const int64_t nv = h->nv;
+        std::vector<int32_t> slot_var(h->nslots, -1);
+        for (int64_t e = 0; e < h->ne; e++) slot_var[cx::slot_of_edge(h, e)] = h->edge_var[e];
+        auto is_free = [&](int32_t v) { return !(h->vinfo[v] & (cx::kClamped | cx::kGhost)) && (h->var_off[v + 1] - h->var_off[v]) >= 2; };
+        std::vector<int32_t> dyn(2 * nv, -1);
+        std::vector<uint8_t> ndyn(nv, 0);
+        for (int64_t e = 0; e < h->ne; e++) {
+            const int32_t v = h->edge_var[e];
+            if (!is_free(v)) continue;
+            const int32_t s = cx::slot_of_edge(h, e), p = h->partner[s];
+            if (p < 0 || !is_free(slot_var[p])) continue;
+            if (ndyn[v] == 2)
+                return fail(h, CX_ERR_UNSUPPORTED, "chain-scan schedule: variable " + std::to_string(h->var_ids[v]) + " has more than two non-observed neighbours (the graph is not a union of chains)");
+            dyn[2 * v + ndyn[v]++] = s;
+        }
+        std::vector<int32_t> pos_var, skip0, skip1, link_pos, from, to;
+        std::vector<uint8_t> head_fwd, head_bwd, visited(nv, 0);
+        for (int64_t v0 = 0; v0 < nv; v0++) {
+            if (!is_free((int32_t)v0) || visited[v0] || ndyn[v0] != 1) continue;
+            int32_t cur = (int32_t)v0, incoming = -1;
+            bool first = true;
+            while (true) {
+                visited[cur] = 1;
+                int32_t out = -1;
+                for (int k = 0; k < ndyn[cur]; k++) if (dyn[2 * cur + k] != incoming) out = dyn[2 * cur + k];
+                pos_var.push_back(cur); skip0.push_back(incoming); skip1.push_back(out);
+                if (out < 0) break;
+                link_pos.push_back((int32_t)pos_var.size() - 1); from.push_back(out); to.push_back(h->partner[out]);
+                head_fwd.push_back(first ? 1 : 0); head_bwd.push_back(0);
+                first = false;
+                incoming = h->partner[out];
+                cur = slot_var[incoming];
+                if (visited[cur]) return fail(h, CX_ERR_UNSUPPORTED, "chain-scan schedule: the graph has a cycle");
+            }
+            if (!head_bwd.empty()) head_bwd.back() = 1;
+        }
+        for (int64_t v = 0; v < nv; v++)
+            if (is_free((int32_t)v) && !visited[v] && ndyn[v] == 2)
+                return fail(h, CX_ERR_UNSUPPORTED, "chain-scan schedule: the graph has a cycle through variable " + std::to_string(h->var_ids[v]));
+        for (void *p : {(void *)h->d_chain_pos_var, (void *)h->d_chain_skip0, (void *)h->d_chain_skip1, (void *)h->d_chain_link_pos,
+                        (void *)h->d_chain_from, (void *)h->d_chain_to, (void *)h->d_chain_head_fwd, (void *)h->d_chain_head_bwd,
+                        (void *)h->d_chain_side, h->d_chain_totals}) if (p) (void)hipFree(p);
+        h->chain_npos = (int64_t)pos_var.size(); h->chain_nlinks = (int64_t)link_pos.size();
+        h->chain_side_dirty = true;
+        int64_t n_readers = 0;   // variables that read factor→variable messages: everything but observed variables and ghosts
+        for (int64_t v = 0; v < nv; v++) n_readers += (h->vinfo[v] & (cx::kClamped | cx::kGhost)) ? 0 : 1;
+        h->chain_covers_all = n_readers == h->chain_npos;
+        int32_t rc;
+        if ((rc = dev_upload(h, &h->d_chain_pos_var, pos_var)) != CX_OK) return rc;
+        if ((rc = dev_upload(h, &h->d_chain_skip0, skip0)) != CX_OK) return rc;
+        if ((rc = dev_upload(h, &h->d_chain_skip1, skip1)) != CX_OK) return rc;
+        if ((rc = dev_upload(h, &h->d_chain_link_pos, link_pos)) != CX_OK) return rc;
+        if ((rc = dev_upload(h, &h->d_chain_from, from)) != CX_OK) return rc;
+        if ((rc = dev_upload(h, &h->d_chain_to, to)) != CX_OK) return rc;
+        if ((rc = dev_upload(h, &h->d_chain_head_fwd, head_fwd)) != CX_OK) return rc;
+        if ((rc = dev_upload(h, &h->d_chain_head_bwd, head_bwd)) != CX_OK) return rc;
+        if ((rc = dev_alloc(h, &h->d_chain_side, h->chain_npos)) != CX_OK) return rc;
+        char *tot = nullptr;
+        if ((rc = dev_alloc(h, &tot, (int64_t)cx::chain_total_bytes(h->chain_nlinks))) != CX_OK) return rc;
+        h->d_chain_totals = tot;
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        h->chains_dirty = false;
+        return CX_OK;
+    } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "chain decomposition: host allocation failed"); }
+}
+
+
+// ---- the sweep ----------------------------------------------------------------------------------------------------
+void sweep_main(cx_handle *h, bool skip_ghosts) {
+    const bool marg = h->cfg.compute_marginals_in_sweep != 0;
+    if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) {
+        // messages out of observed leaves (data) into the chains: by the scan's side pass when every free variable is on a
+        // chain, by a factor phase over all slots otherwise (free variables off the chains need theirs too)
+        if (!h->chain_covers_all) cx::launch_factor_to_var(h, h->d_v2f, h->d_f2v);
+        // When every reader of factor→variable messages sits on a chain and nobody asked for stored variable→factor messages,
+        // the scan's second kernel writes the marginals itself and the variable phase is not launched (variable→factor messages
+        // are recomputed from the stored messages on demand: ensure_v2f).  Variables off the chains — observed ones, stand-ins —
+        // have marginals that depend on stored messages only: a full variable phase after those were set, none otherwise.
+        const bool fast = h->chain_covers_all && h->big_vars.empty() && h->cfg.materialize_messages_to_factor == 0 && !h->offchain_marg_dirty;
+        const int form = marg ? (h->cfg.family == CX_FAMILY_NATURAL2 ? 2 : 1) : 0;
+        cx::launch_chain_scan(h, h->d_f2v, h->chain_covers_all, fast ? form : 0, h->chain_v2f_from_scan);   // all forward and backward chain messages
+        if (fast && marg) {
+            h->v2f_stale = true;
+        } else {
+            cx::launch_var_to_factor(h, h->d_f2v, marg);       // every variable→factor message + marginals
+            cx::launch_big_var_to_factor(h, h->d_f2v, marg);
+            h->v2f_stale = false;
+            if (marg) h->offchain_marg_dirty = false;
+        }
+    } else if (h->cfg.schedule == CX_SCHED_FLOODING) {
+        cx::launch_var_to_factor(h, h->d_f2v, marg);
+        cx::launch_big_var_to_factor(h, h->d_f2v, marg);
+    } else {
+        const bool store = h->cfg.materialize_messages_to_factor != 0;
+        cx::launch_fused(h, h->d_f2v, h->d_f2v_alt, marg, store, skip_ghosts);
+        if (!h->big_vars.empty()) {
+            cx::launch_big_var_to_factor(h, h->d_f2v, marg);
+            cx::launch_push_slots(h, h->d_big_slots, (int64_t)h->big_slots.size(), h->d_f2v_alt, CX_KERNEL_BIG_VAR);
+        }
+    }
+}
+
+void sweep_finish(cx_handle *h) {
+    if (h->cfg.schedule == CX_SCHED_FLOODING) {
+        cx::launch_factor_to_var(h, h->d_v2f, h->d_f2v);
+    } else if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) {
+        // nothing: the scans already produced every factor→variable message a free variable reads, from the same
+        // variable→factor messages the variable phase just wrote (a factor phase here would only re-derive them)
+    } else {
+        std::swap(h->d_f2v, h->d_f2v_alt);
+        h->v2f_stale = h->cfg.materialize_messages_to_factor == 0;
+    }
+    h->sweeps_done++;
+}
+
+}  // namespace cxh
+
+// CX_TILED=0 in the environment turns the two-sweep launches off (A/B measurements)
+static bool tiled_env_enabled() {
+    static const int on = [] { const char *e = std::getenv("CX_TILED"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0;
+}
+
+
+// ---- chain-scan partitions: the composed maps of a time block -------------------------------------------
+// Host copy of cx_chain.hip's map algebra (projective-linear maps on (xi, w, 1), D normalised to 1)
+namespace {
+struct HLin { double e, f, g, A, B, C; int seg, pad; };
+HLin hlin_compose(const HLin &first, const HLin &second) {
+    if (second.seg) return second;
+    HLin r;
+    const double inv = 1.0 / (second.C * first.B + 1.0);
+    r.A = (second.A * first.A + second.B * first.C) * inv;
+    r.B = (second.A * first.B + second.B) * inv;
+    r.C = (second.C * first.A + first.C) * inv;
+    r.e = (second.e * first.e) * inv;
+    r.f = (second.e * first.f + second.f * first.A + second.g * first.C) * inv;
+    r.g = (second.e * first.g + second.f * first.B + second.g) * inv;
+    r.seg = first.seg; r.pad = 0;
+    return r;
+}
+}  // namespace
+
+
+extern "C" {
+
+int32_t cx_chain_block_maps(cx_handle *h, double *fwd6, double *bwd6, double *side_first2, double *side_last2,
+                            int64_t *first_variable_id, int64_t *last_variable_id, int64_t *n_links) {
+    CX_NOT_VMP(h, "cx_chain_block_maps");
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_chain_block_maps: no graph");
+    CX_REQUIRE(h, h->cfg.dim == 1 && h->cfg.schedule == CX_SCHED_CHAIN_SCAN, CX_ERR_STATE, "cx_chain_block_maps: scalar chain-scan handles only");
+    CX_REQUIRE(h, fwd6 && bwd6 && side_first2 && side_last2, CX_ERR_INVALID_ARGUMENT, "cx_chain_block_maps: null argument");
+    CX_REQUIRE(h, !h->any_linear, CX_ERR_UNSUPPORTED, "cx_chain_block_maps: additive factors only in this build");
+    int32_t rc = build_chains(h);
+    if (rc != CX_OK) return rc;
+    CX_REQUIRE(h, h->chain_npos >= 1 && h->chain_nlinks == h->chain_npos - 1, CX_ERR_UNSUPPORTED,
+               "cx_chain_block_maps: the non-observed variables of this handle must form ONE path (a time block of a chain)");
+    try {
+        // side sums + tile totals only (no apply): the same kernels a sweep starts with
+        h->chain_partition = true;
+        int64_t ntiles = 0;
+        // as in sweep_main: when variables off the chain read messages too (the stand-ins do), the leaf messages come from a
+        // factor phase over all slots, otherwise from the side pass itself
+        if (!h->chain_covers_all) cx::launch_factor_to_var(h, h->d_v2f, h->d_f2v);
+        cx::launch_chain_totals(h, h->d_f2v, h->chain_covers_all, &ntiles);
+        CX_HIP(h, hipGetLastError());
+        std::vector<HLin> tot((size_t)2 * (ntiles + 1));
+        if (ntiles) CX_HIP(h, hipMemcpyAsync(tot.data(), h->d_chain_totals, tot.size() * sizeof(HLin), hipMemcpyDeviceToHost, h->stream));
+        double2 sf, sl;
+        CX_HIP(h, hipMemcpyAsync(&sf, h->d_chain_side, 16, hipMemcpyDeviceToHost, h->stream));
+        CX_HIP(h, hipMemcpyAsync(&sl, h->d_chain_side + (h->chain_npos - 1), 16, hipMemcpyDeviceToHost, h->stream));
+        int32_t pv[2] = {0, 0};
+        CX_HIP(h, hipMemcpyAsync(&pv[0], h->d_chain_pos_var, 4, hipMemcpyDeviceToHost, h->stream));
+        CX_HIP(h, hipMemcpyAsync(&pv[1], h->d_chain_pos_var + (h->chain_npos - 1), 4, hipMemcpyDeviceToHost, h->stream));
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        for (int dir = 0; dir < 2; dir++) {
+            HLin t{1.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0, 0};      // identity: a block of one variable has no link
+            for (int64_t i = 0; i < ntiles; i++) t = (i == 0) ? tot[(size_t)dir * (ntiles + 1)] : hlin_compose(t, tot[(size_t)dir * (ntiles + 1) + i]);
+            double *o = dir == 0 ? fwd6 : bwd6;
+            o[0] = t.e; o[1] = t.f; o[2] = t.g; o[3] = t.A; o[4] = t.B; o[5] = t.C;
+        }
+        side_first2[0] = sf.x; side_first2[1] = sf.y; side_last2[0] = sl.x; side_last2[1] = sl.y;
+        if (first_variable_id) *first_variable_id = h->var_ids[pv[0]];
+        if (last_variable_id) *last_variable_id = h->var_ids[pv[1]];
+        if (n_links) *n_links = h->chain_nlinks;
+        return CX_OK;
+    } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_chain_block_maps: host allocation failed"); }
+}
+
+int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
+    CX_NOT_VMP(h, "cx_sweep");
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep: no graph");
+    CX_REQUIRE(h, n_sweeps >= 0, CX_ERR_INVALID_ARGUMENT, "cx_sweep: n_sweeps < 0");
+    if (h->cfg.dim > 1) return mv_sweep(h, n_sweeps);
+    CX_REQUIRE(h, h->halo_state || h->chain_partition || (h->recv_slots.empty() && h->send_slots.empty()), CX_ERR_STATE,
+               "cx_sweep: this handle holds a partition (halo configured): use cx_sweep_begin / _main / _end");
+    if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) { int32_t rc = build_chains(h); if (rc != CX_OK) return rc; }
+    int32_t s = 0;
+    // pairs of sweeps as ONE launch each (cx_tiles.hip), when the schedule and the graph allow it
+    // (opt-in: measured SLOWER than single sweeps on MI355X, see DESIGN.md §4c — kept as a tested experiment, not the default)
+    const bool want_pairs = n_sweeps >= 2 && h->cfg.schedule == CX_SCHED_FUSED && h->cfg.sweeps_per_launch == 2 &&
+                            h->cfg.family == CX_FAMILY_GAUSSIAN && h->cfg.materialize_messages_to_factor == 0 && tiled_env_enabled();
+    if (want_pairs && h->tiles_state == 0) {
+        std::string why;
+        if (cx::tiles_build(h, why) && !cx::tiles_prepare_kernel(h)) { cx::tiles_free(h); h->tiles_state = -1; }
+    }
+    if (want_pairs && h->tiles_state > 0) {
+        const bool marg = h->cfg.compute_marginals_in_sweep != 0;
+        for (; s + 2 <= n_sweeps; s += 2) {
+            cx::launch_tiled2(h, h->d_f2v, h->d_f2v_alt, marg);
+            std::swap(h->d_f2v, h->d_f2v_alt);     // d_f2v: time t+2; d_f2v_alt: time t
+            h->alt_two_back = true;
+            h->v2f_stale = true;
+            h->sweeps_done += 2;
+        }
+    }
+    for (; s < n_sweeps; s++) {
+        h->run_slice0 = 0; h->run_nslices = 0;
+        if (h->halo_state && h->halo_depth > 0 && h->cfg.schedule == CX_SCHED_FUSED && h->big_vars.empty()) {
+            const int j = std::min(h->sweeps_since_exchange + 1, h->halo_depth);     // this is sweep j after the exchange
+            const int L = h->halo_depth - j + 1;                                       // layers that have to run
+            if (h->trim_hi[L] >= h->trim_lo[L]) { h->run_slice0 = h->trim_lo[L]; h->run_nslices = h->trim_hi[L] - h->trim_lo[L] + 1; }
+        }
+        sweep_main(h, false); sweep_finish(h); h->alt_two_back = false;
+        h->run_slice0 = 0; h->run_nslices = 0;
+        h->sweeps_since_exchange++;
+    }
+    CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
+// Loopy graphs: sweep until the largest change of a factor→variable message over `check_every` sweeps falls below tol
+// (the stopping rule a user of the reference writes around update_marginals!; the reference itself has none).
+int32_t cx_sweep_until(cx_handle *h, double tol, int32_t max_sweeps, int32_t check_every, int32_t *sweeps_run, double *residual) {
+    CX_NOT_VMP(h, "cx_sweep_until");
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep_until: no graph");
+    CX_REQUIRE(h, tol >= 0 && max_sweeps >= 0 && check_every >= 1, CX_ERR_INVALID_ARGUMENT, "cx_sweep_until: tol >= 0, max_sweeps >= 0, check_every >= 1");
+    double r = std::numeric_limits<double>::infinity();
+    int32_t rc = cx_residual(h, &r);            // snapshot of the starting point
+    if (rc != CX_OK) return rc;
+    int32_t done = 0;
+    r = std::numeric_limits<double>::infinity();
+    while (done < max_sweeps) {
+        const int32_t k = std::min(check_every, max_sweeps - done);
+        if ((rc = cx_sweep(h, k)) != CX_OK) return rc;
+        done += k;
+        if ((rc = cx_residual(h, &r)) != CX_OK) return rc;
+        if (r <= tol) break;
+    }
+    if (sweeps_run) *sweeps_run = done;
+    if (residual) *residual = r;
+    return CX_OK;
+}
+
+int32_t cx_sweep_begin(cx_handle *h) {
+    CX_NOT_VMP(h, "cx_sweep_begin");
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep_begin: no graph");
+    CX_REQUIRE(h, h->cfg.dim == 1, CX_ERR_UNSUPPORTED, "cx_sweep_begin: partitioned sweeps are implemented for dim == 1 only in this build");
+    CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_sweep_begin: previous sweep not ended");
+    CX_REQUIRE(h, !h->halo_state, CX_ERR_STATE, "cx_sweep_begin: the handle is configured for state halos (cx_halo_configure_state): use cx_sweep + cx_halo_state_exchange");
+    CX_REQUIRE(h, h->cfg.schedule != CX_SCHED_CHAIN_SCAN, CX_ERR_UNSUPPORTED, "cx_sweep_begin: the chain-scan schedule is not partitioned in this build");
+    cx::launch_halo_export(h, h->d_f2v, h->stream);
+    CX_HIP(h, hipGetLastError());
+    h->in_sweep = true;
+    return CX_OK;
+}
+
+int32_t cx_sweep_main(cx_handle *h) {
+    CX_REQUIRE(h, h && h->has_graph && h->in_sweep, CX_ERR_STATE, "cx_sweep_main: call cx_sweep_begin first");
+    sweep_main(h, true);
+    CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
+int32_t cx_sweep_end(cx_handle *h) {
+    CX_REQUIRE(h, h && h->has_graph && h->in_sweep, CX_ERR_STATE, "cx_sweep_end: call cx_sweep_begin first");
+    cx::launch_halo_import(h, h->d_f2v_alt, h->cfg.schedule == CX_SCHED_FUSED);
+    sweep_finish(h);
+    CX_HIP(h, hipGetLastError());
+    h->in_sweep = false;
+    return CX_OK;
+}
+
+int32_t cx_residual(cx_handle *h, double *out) {
+    CX_NOT_VMP(h, "cx_residual");
+    CX_REQUIRE(h, h && h->has_graph && out, CX_ERR_STATE, "cx_residual: no graph / null out");
+    if (h->cfg.dim > 1) return mv_residual(h, out);
+    if (!h->d_prev) {
+        int32_t rc = dev_alloc(h, &h->d_prev, h->nslots);
+        if (rc != CX_OK) return rc;
+        CX_HIP(h, hipMemcpyAsync(h->d_prev, h->d_f2v, (size_t)h->nslots * 16, hipMemcpyDeviceToDevice, h->stream));
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        *out = std::numeric_limits<double>::infinity();
+        return CX_OK;
+    }
+    cx::launch_residual(h, h->d_f2v, h->d_prev, h->nslots, h->d_scratch);
+    std::vector<double> part(1024);
+    CX_HIP(h, hipMemcpyAsync(part.data(), h->d_scratch, 1024 * 8, hipMemcpyDeviceToHost, h->stream));
+    CX_HIP(h, hipMemcpyAsync(h->d_prev, h->d_f2v, (size_t)h->nslots * 16, hipMemcpyDeviceToDevice, h->stream));
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    double m = 0.0;
+    for (double p : part) m = (p != p) ? kInf : std::max(m, p);
+    *out = m;
+    return CX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,148 @@
+// cx_host.h — what the host-side translation units of libcortex_hip.so share (cx_api*.hip): status helpers, device
+// allocation, id lookup, payload conversion, and the few functions one section calls in another.
+// No exception leaves an entry point; every one returns a status (include/cortex_hip.h).
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <numeric>
+
+#include "cx_internal.h"
+
+namespace cxh {
+
+inline thread_local std::string g_create_error;
+
+inline int32_t fail(cx_handle *h, int32_t code, const std::string &msg) {
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define CX_HIP(h, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return cxh::fail(h, e_ == hipErrorOutOfMemory ? CX_ERR_OUT_OF_MEMORY : CX_ERR_DEVICE, \
+                             std::string(#call) + ": " + hipGetErrorString(e_));                 \
+    } while (0)
+
+#define CX_REQUIRE(h, cond, code, msg) \
+    do { if (!(cond)) return cxh::fail(h, code, msg); } while (0)
+
+template <class T>
+int32_t dev_alloc(cx_handle *h, T **p, int64_t count) {
+    *p = nullptr;
+    if (count <= 0) count = 1;
+    CX_HIP(h, hipMalloc((void **)p, (size_t)count * sizeof(T)));
+    h->device_bytes += count * (int64_t)sizeof(T);
+    return CX_OK;
+}
+
+template <class T>
+int32_t dev_upload(cx_handle *h, T **p, const std::vector<T> &v) {
+    int32_t rc = dev_alloc(h, p, (int64_t)v.size());
+    if (rc != CX_OK) return rc;
+    if (!v.empty()) CX_HIP(h, hipMemcpyAsync(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    return CX_OK;
+}
+
+inline int32_t ensure_stage(cx_handle *h, int64_t bytes) {
+    if (bytes <= h->stage_bytes) return CX_OK;
+    if (h->d_stage) { CX_HIP(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_stage); h->d_stage = nullptr; }
+    int64_t want = std::max<int64_t>(bytes, 1 << 20);
+    CX_HIP(h, hipMalloc(&h->d_stage, (size_t)want));
+    h->stage_bytes = want;
+    return CX_OK;
+}
+
+// (variable_id, factor_id) -> edge index; edges are sorted by (variable, factor)
+inline int64_t find_edge(const cx_handle *h, int64_t var_id, int64_t fac_id) {
+    auto it = std::lower_bound(h->var_ids.begin(), h->var_ids.end(), var_id);
+    if (it == h->var_ids.end() || *it != var_id) return -1;
+    int64_t v = it - h->var_ids.begin();
+    auto b = h->edge_fac_id.begin() + h->var_off[v], e = h->edge_fac_id.begin() + h->var_off[v + 1];
+    auto jt = std::lower_bound(b, e, fac_id);
+    if (jt == e || *jt != fac_id) return -1;
+    return jt - h->edge_fac_id.begin();
+}
+
+inline int64_t find_var(const cx_handle *h, int64_t var_id) {
+    auto it = std::lower_bound(h->var_ids.begin(), h->var_ids.end(), var_id);
+    if (it == h->var_ids.end() || *it != var_id) return -1;
+    return it - h->var_ids.begin();
+}
+
+inline int64_t find_factor(const cx_handle *h, int64_t fac_id) {
+    auto it = std::lower_bound(h->fac_ids.begin(), h->fac_ids.end(), fac_id);
+    if (it == h->fac_ids.end() || *it != fac_id) return -1;
+    return it - h->fac_ids.begin();
+}
+
+const double kNaN = std::numeric_limits<double>::quiet_NaN();
+const double kInf = std::numeric_limits<double>::infinity();
+
+// boundary form -> storage (natural) form
+inline bool to_natural(int32_t form, const double *p, double2 *out) {
+    switch (form) {
+    case CX_FORM_MOMENT:
+        if (std::isnan(p[1])) { *out = make_double2(kNaN, kNaN); return true; }
+        if (p[1] == 0.0) { *out = make_double2(p[0], kInf); return true; }  // zero variance == point mass
+        out->y = 1.0 / p[1]; out->x = p[0] * out->y; return true;
+    case CX_FORM_POINT: *out = make_double2(p[0], kInf); return true;
+    case CX_FORM_NATURAL: *out = make_double2(p[0], p[1]); return true;
+    }
+    return false;
+}
+
+inline void from_natural(int32_t form, double2 m, double *out) {
+    if (form == CX_FORM_NATURAL) { out[0] = m.x; out[1] = m.y; return; }
+    if (std::isnan(m.y)) { out[0] = kNaN; if (form == CX_FORM_MOMENT) out[1] = kNaN; return; }
+    if (m.y == kInf) { out[0] = m.x; if (form == CX_FORM_MOMENT) out[1] = 0.0; return; }
+    double var = 1.0 / m.y;
+    out[0] = m.x * var;
+    if (form == CX_FORM_MOMENT) out[1] = var;
+}
+
+inline bool is_vmp(const cx_handle *h) {
+    return h->cfg.family == CX_FAMILY_VMP_MEAN_FIELD || h->cfg.family == CX_FAMILY_VMP_STRUCTURED;
+}
+#define CX_NOT_VMP(h, name) CX_REQUIRE(h, !(h) || !cxh::is_vmp(h), CX_ERR_UNSUPPORTED, name ": not available for the variational families (their state is the set of marginals: cx_set_marginals / cx_update_marginals)")
+
+// (variable_id, factor_id) lists -> slots (+ optionally the local variable numbers)
+inline int32_t stage_slots(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, std::vector<int32_t> &slots,
+                           std::vector<int32_t> *vars) {
+    slots.resize(n);
+    if (vars) vars->resize(n);
+    for (int64_t i = 0; i < n; i++) {
+        int64_t e = find_edge(h, variable_ids[i], factor_ids[i]);
+        if (e < 0) return fail(h, CX_ERR_NOT_FOUND, "no connection between variable " + std::to_string(variable_ids[i]) + " and factor " + std::to_string(factor_ids[i]));
+        slots[i] = cx::slot_of_edge(h, e);
+        if (vars) (*vars)[i] = h->edge_var[e];
+    }
+    return CX_OK;
+}
+
+// ---- cx_api.hip -----------------------------------------------------------------------------------------------------
+void dev_free_all(cx_handle *h);
+// ---- cx_api_mv.hip: host side of dim > 1 ----------------------------------------------------------------------------
+int32_t mv_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, int32_t direction,
+                        int32_t form, const double *payload);
+int32_t mv_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, int32_t direction,
+                        int32_t form, double *out);
+int32_t mv_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, double *out);
+int32_t mv_sweep(cx_handle *h, int32_t n_sweeps);
+int32_t mv_residual(cx_handle *h, double *out);
+int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n);
+// ---- cx_api_sweep.hip -----------------------------------------------------------------------------------------------
+int32_t normalize_alt(cx_handle *h);
+int32_t ensure_v2f(cx_handle *h);
+int32_t build_chains(cx_handle *h);
+void sweep_main(cx_handle *h, bool skip_ghosts);
+void sweep_finish(cx_handle *h);
+
+}  // namespace cxh

@@ -143,7 +143,7 @@ struct cx_handle {
     bool tile_info_dirty = true;     // d_vinfo changed since the tiles' copy of the observed / stand-in flags was refreshed
     int64_t tile_lds = 0;
     double tile_redundancy = 0.0;    // (own + ring) variables loaded per own variable
-    bool alt_two_back = false;       // after a two-sweep launch d_f2v_alt holds time t, not t+1 (see normalize_alt in cx_api.hip)
+    bool alt_two_back = false;       // after a two-sweep launch d_f2v_alt holds time t, not t+1 (see normalize_alt in cx_api_sweep.hip)
     double2 *d_f2v_tmp = nullptr;
 
     // variational families (cx_vmp.hip): opaque state

@@ -1,0 +1,189 @@
+// cx_mv_core.h — device arithmetic of small d-dimensional Gaussian messages (d = 2, 3, 4), shared by the fused flooding
+// sweep (cx_mv.hip), the chain scan (cx_mvchain.hip) and the batched per-signal kernels (cx_mvbatch.hip).
+// Natural form (eta = Lambda mu, Lambda = Sigma^-1), symmetric matrices packed (upper triangle); every loop unrolled on D,
+// everything in registers.  Rules and their derivation: cx_mv.hip's header.
+#pragma once
+
+#include "cx_internal.h"
+
+namespace cx {
+
+template <int D>
+struct Msg {
+    static constexpr int NT = D * (D + 1) / 2;
+    static constexpr int NC = D + NT;
+    double eta[D];
+    double lam[NT];
+};
+
+template <int D>
+__host__ __device__ constexpr int tri(int i, int j) {  // i <= j
+    return i * D - i * (i - 1) / 2 + (j - i);
+}
+
+template <int D>
+__device__ __forceinline__ Msg<D> msg_zero() {
+    Msg<D> m;
+#pragma unroll
+    for (int i = 0; i < D; i++) m.eta[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < Msg<D>::NT; i++) m.lam[i] = 0.0;
+    return m;
+}
+
+template <int D>
+__device__ __forceinline__ Msg<D> msg_load(const double *__restrict__ buf, int64_t nslots, int slot) {
+    Msg<D> m;
+#pragma unroll
+    for (int i = 0; i < D; i++) m.eta[i] = buf[(int64_t)i * nslots + slot];
+#pragma unroll
+    for (int i = 0; i < Msg<D>::NT; i++) m.lam[i] = buf[(int64_t)(D + i) * nslots + slot];
+    return m;
+}
+
+template <int D>
+__device__ __forceinline__ void msg_store(double *__restrict__ buf, int64_t nslots, int slot, const Msg<D> &m) {
+#pragma unroll
+    for (int i = 0; i < D; i++) buf[(int64_t)i * nslots + slot] = m.eta[i];
+#pragma unroll
+    for (int i = 0; i < Msg<D>::NT; i++) buf[(int64_t)(D + i) * nslots + slot] = m.lam[i];
+}
+
+template <int D>
+__device__ __forceinline__ void msg_add(Msg<D> &a, const Msg<D> &b) {
+#pragma unroll
+    for (int i = 0; i < D; i++) a.eta[i] += b.eta[i];
+#pragma unroll
+    for (int i = 0; i < Msg<D>::NT; i++) a.lam[i] += b.lam[i];
+}
+
+// 1/sqrt(x) to double precision: v_rsq_f64 seed + two Newton steps.  sqrt(), 1.0/x and x/y each expand to 30-40 dependent
+// instructions; a d = 4 rule had 28 of them (4 sqrt, 4 reciprocals, 20 divisions in the triangular solves) — with the
+// reciprocal diagonal kept from the factorisation it is 4 rsqrt and no division.
+__device__ __forceinline__ double rsqrt_f64(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * __builtin_fma(-hx * y, y, 1.5);
+    y = y * __builtin_fma(-hx * y, y, 1.5);
+    return y;
+}
+
+// lower Cholesky factor of the packed symmetric matrix S (+ optional full symmetric P): L[i][j], j <= i
+template <int D>
+__device__ __forceinline__ void chol(const double (&S)[Msg<D>::NT], const double *__restrict__ P, double (&Lm)[D][D], double (&ri)[D]) {
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        double d = S[tri<D>(j, j)] + (P ? P[j * D + j] : 0.0);
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= Lm[j][k] * Lm[j][k];
+        const double inv = rsqrt_f64(d);     // non-PD input -> NaN, which marks the message undefined
+        ri[j] = inv;
+        Lm[j][j] = d * inv;
+#pragma unroll
+        for (int i = j + 1; i < D; i++) {
+            double s = S[tri<D>(j, i)] + (P ? P[i * D + j] : 0.0);
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= Lm[i][k] * Lm[j][k];
+            Lm[i][j] = s * inv;
+        }
+    }
+}
+
+// x <- L^-1 x   (ri = reciprocal diagonal of L)
+template <int D>
+__device__ __forceinline__ void fwd_solve(const double (&Lm)[D][D], const double (&ri)[D], double (&x)[D]) {
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        double s = x[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= Lm[i][k] * x[k];
+        x[i] = s * ri[i];
+    }
+}
+
+// tab: P (D*D) | B (D*D) | C (D*D), row-major, full
+template <int D>
+__device__ __forceinline__ Msg<D> mv_rule(const Msg<D> &in, const double *__restrict__ tab) {
+    const double *P = tab, *B = tab + D * D, *C = tab + 2 * D * D;
+    Msg<D> out;
+    if (in.lam[0] == __builtin_inf()) {  // observed datum y in eta
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; k++) s += B[i * D + k] * in.eta[k];
+            out.eta[i] = s;
+#pragma unroll
+            for (int j = i; j < D; j++) out.lam[tri<D>(i, j)] = C[i * D + j];
+        }
+        return out;
+    }
+    double Lm[D][D], ri[D];
+    chol<D>(in.lam, P, Lm, ri);
+    double Y[D][D];  // Y[:, c] = L^-1 (row c of B)'
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+        double col[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) col[k] = B[c * D + k];
+        fwd_solve<D>(Lm, ri, col);
+#pragma unroll
+        for (int k = 0; k < D; k++) Y[k][c] = col[k];
+    }
+    double z[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) z[k] = in.eta[k];
+    fwd_solve<D>(Lm, ri, z);
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; k++) s += Y[k][i] * z[k];
+        out.eta[i] = s;
+#pragma unroll
+        for (int j = i; j < D; j++) {
+            double t = C[i * D + j];
+#pragma unroll
+            for (int k = 0; k < D; k++) t -= Y[k][i] * Y[k][j];
+            out.lam[tri<D>(i, j)] = t;
+        }
+    }
+    return out;
+}
+
+// natural -> moment (mean, packed covariance) for marginals
+template <int D>
+__device__ __forceinline__ Msg<D> mv_to_moment(const Msg<D> &nat) {
+    double Lm[D][D], ri[D];
+    chol<D>(nat.lam, nullptr, Lm, ri);
+    double Li[D][D];  // columns of L^-1
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+        double e[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) e[k] = (k == c) ? 1.0 : 0.0;
+        fwd_solve<D>(Lm, ri, e);
+#pragma unroll
+        for (int k = 0; k < D; k++) Li[k][c] = e[k];
+    }
+    Msg<D> out;
+#pragma unroll
+    for (int i = 0; i < D; i++)
+#pragma unroll
+        for (int j = i; j < D; j++) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; k++) s += Li[k][i] * Li[k][j];
+            out.lam[tri<D>(i, j)] = s;
+        }
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; j++) s += out.lam[i <= j ? tri<D>(i, j) : tri<D>(j, i)] * nat.eta[j];
+        out.eta[i] = s;
+    }
+    return out;
+}
+
+}  // namespace cx

@@ -130,7 +130,7 @@ def test_blob_of_other_rule_parameters_or_a_doctored_variable_table_is_refused(h
     with pytest.raises(cx.CortexHipError, match="different graph"):
         c.import_state(blob4)
     # a blob whose variable table carries another degree nibble: refused before anything reaches the device
-    hdr = 8 + 4 * 4 + 5 * 8 + 2 * 4 + 8      # StateHeader (cx_api.hip), then one 16-byte section header, then vinfo
+    hdr = 8 + 4 * 4 + 5 * 8 + 2 * 4 + 8      # StateHeader (cx_api_state.hip), then one 16-byte section header, then vinfo
     bad = blob.copy()
     bad[hdr + 16] = (int(bad[hdr + 16]) & 0xF0) | ((int(bad[hdr + 16]) + 1) & 0x0F)
     before = _all_messages(a, model, L.TO_VARIABLE)
