@@ -60,8 +60,10 @@ int32_t mv_refresh_v2f(cx_handle *h, const std::vector<int32_t> &slots, const st
     int32_t *d_s = (int32_t *)h->d_stage, *d_v = d_s + n;
     CX_HIP(h, hipMemcpyAsync(d_s, slots.data(), n * 4, hipMemcpyHostToDevice, h->stream));
     CX_HIP(h, hipMemcpyAsync(d_v, vars.data(), n * 4, hipMemcpyHostToDevice, h->stream));
-    if (h->cfg.dim == 64) cx::mv64_launch_v2f(h, (int)n, d_s, d_v, h->sweeps_done > 0 ? h->d_mv_f2v_alt : h->d_mv_f2v);
-    else cx::mv_launch_v2f(h, d_s, d_v, n, h->sweeps_done > 0 ? h->d_mv_f2v_alt : h->d_mv_f2v);
+    // fused schedule: the input buffer of the last sweep; chain scan: the one buffer there is (its messages are the fixed point)
+    const double *src = (h->sweeps_done > 0 && h->cfg.schedule != CX_SCHED_CHAIN_SCAN) ? h->d_mv_f2v_alt : h->d_mv_f2v;
+    if (h->cfg.dim == 64) cx::mv64_launch_v2f(h, (int)n, d_s, d_v, src);
+    else cx::mv_launch_v2f(h, d_s, d_v, n, src);
     CX_HIP(h, hipGetLastError());
     CX_HIP(h, hipStreamSynchronize(h->stream));
     return CX_OK;
@@ -133,7 +135,8 @@ int32_t mv_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
         cx::mv_launch_scatter(h, h->d_mv_v2f, h->nslots, nc, d_idx, d_val, n);
         h->observed_passes_due = 2;   // a stored variable→factor message changed: observed senders are refreshed
         if (form == CX_FORM_POINT) {
-            for (int64_t i = 0; i < n; i++) h->vinfo[vars[i]] |= cx::kClamped;
+            for (int64_t i = 0; i < n; i++)
+                if (!(h->vinfo[vars[i]] & cx::kClamped)) { h->vinfo[vars[i]] |= cx::kClamped; h->chains_dirty = true; }   // a newly observed variable leaves the chains
             CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
             h->spdir_dirty = true;
         }
@@ -243,10 +246,52 @@ int32_t build_work64(cx_handle *h) {
     return CX_OK;
 }
 
+// mask the rules whose receiver is an observed variable (nobody reads a message into it)
+static int32_t mv_refresh_spdir(cx_handle *h) {
+    if (!h->spdir_dirty) return CX_OK;
+    std::vector<int32_t> eff(h->spdir), slot_var(h->nslots, -1);
+    for (int64_t e = 0; e < h->ne; e++) slot_var[cx::slot_of_edge(h, e)] = h->edge_var[e];
+    for (int64_t sl = 0; sl < h->nslots; sl++) {
+        const int32_t p = h->partner[sl];
+        if (p >= 0 && (h->vinfo[slot_var[p]] & cx::kClamped)) eff[sl] = -1;
+    }
+    CX_HIP(h, hipMemcpy(h->d_spdir, eff.data(), eff.size() * 4, hipMemcpyHostToDevice));
+    h->spdir_dirty = false;
+    h->observed_passes_due = 2;   // the data (or the set of observed variables) changed: refresh both buffers
+    return CX_OK;
+}
+
+// CX_SCHED_CHAIN_SCAN for dim 2..4 (cx_mvchain.hip): one sweep = the exact forward/backward pass along every chain.
+// There is ONE message buffer (d_mv_f2v): the scan overwrites the chain messages with their exact values.
+static int32_t mv_chain_sweep(cx_handle *h, int32_t n_sweeps) {
+    int32_t rc = build_chains(h);
+    if (rc != CX_OK) return rc;
+    CX_REQUIRE(h, h->chain_covers_all, CX_ERR_UNSUPPORTED,
+               "cx_sweep: the chain-scan schedule for dim > 1 needs every non-observed variable on a chain (a non-observed variable of degree 1 "
+               "or a stand-in reads messages the scan does not produce): use the fused schedule for this graph");
+    if ((rc = mv_refresh_spdir(h)) != CX_OK) return rc;
+    const bool marg = h->cfg.compute_marginals_in_sweep != 0;
+    for (int32_t s = 0; s < n_sweeps; s++) {
+        if (h->observed_passes_due > 0 || h->chain_side_dirty) {
+            // the constant messages into the chains: out of observed variables (data through the likelihood rule) and out of
+            // other senders of stored messages, then the side sums — only after data, stored messages or rule tables changed
+            cx::mv_launch_sweep(h, false, 1, h->d_mv_f2v);
+            cx::mv_launch_sweep(h, false, 2, h->d_mv_f2v);
+            cx::mvc_launch_side(h, marg);
+            h->observed_passes_due = 0; h->chain_side_dirty = false;
+        }
+        cx::mvc_launch_scan(h, marg);
+        h->sweeps_done++;
+    }
+    CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
 int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
     CX_REQUIRE(h, (int64_t)h->psets.size() > h->max_pset, CX_ERR_STATE, "cx_sweep: a factor names a parameter set that was never set (cx_set_factor_matrices)");
     for (int64_t i = 0; i <= h->max_pset; i++)
         CX_REQUIRE(h, !h->psets[i].empty(), CX_ERR_STATE, "cx_sweep: parameter set " + std::to_string(i) + " was never set (cx_set_factor_matrices)");
+    if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) return mv_chain_sweep(h, n_sweeps);
     if (h->cfg.dim == 64) {
         int32_t rc = build_work64(h);
         if (rc != CX_OK) return rc;
@@ -255,23 +300,13 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
             h->point64_dirty = false;
         }
     }
-    if (h->cfg.dim != 64 && h->spdir_dirty) {   // mask the rules whose receiver is an observed variable
-        std::vector<int32_t> eff(h->spdir), slot_var(h->nslots, -1);
-        for (int64_t e = 0; e < h->ne; e++) slot_var[cx::slot_of_edge(h, e)] = h->edge_var[e];
-        for (int64_t sl = 0; sl < h->nslots; sl++) {
-            const int32_t p = h->partner[sl];
-            if (p >= 0 && (h->vinfo[slot_var[p]] & cx::kClamped)) eff[sl] = -1;
-        }
-        CX_HIP(h, hipMemcpy(h->d_spdir, eff.data(), eff.size() * 4, hipMemcpyHostToDevice));
-        h->spdir_dirty = false;
-        h->observed_passes_due = 2;   // the data (or the set of observed variables) changed: refresh both buffers
-    }
+    if (h->cfg.dim != 64) { int32_t rc = mv_refresh_spdir(h); if (rc != CX_OK) return rc; }
     for (int32_t s = 0; s < n_sweeps; s++) {
         if (h->cfg.dim == 64)
             cx::mv64_launch_rule(h, (int)h->n_rule64, h->d_rule64_rec, h->d_mv_f2v, h->d_mv_f2v_alt, CX_KERNEL_FUSED);
         else {
-            if (h->observed_passes_due > 0) { cx::mv_launch_sweep(h, false, true); h->observed_passes_due--; }
-            cx::mv_launch_sweep(h, h->cfg.compute_marginals_in_sweep != 0, false);
+            if (h->observed_passes_due > 0) { cx::mv_launch_sweep(h, false, 1); h->observed_passes_due--; }
+            cx::mv_launch_sweep(h, h->cfg.compute_marginals_in_sweep != 0, 0);
         }
         std::swap(h->d_mv_f2v, h->d_mv_f2v_alt);
         h->sweeps_done++;

@@ -82,9 +82,29 @@ int32_t build_chains(cx_handle *h) {
         for (int64_t v = 0; v < nv; v++)
             if (is_free((int32_t)v) && !visited[v] && ndyn[v] == 2)
                 return fail(h, CX_ERR_UNSUPPORTED, "chain-scan schedule: the graph has a cycle through variable " + std::to_string(h->var_ids[v]));
+        std::vector<int32_t> tab_fwd, tab_bwd;
+        if (h->cfg.dim > 1) {
+            // a non-observed variable with no non-observed neighbour is a path of one position and no link: the side pass of
+            // cx_mvchain.hip writes its marginal (the scalar path leaves such variables to its general variable phase)
+            // (so is a non-observed variable of degree 1 whose one factor leads to no chain variable: a chain of one state)
+            for (int64_t v = 0; v < nv; v++) {
+                if (visited[v] || (h->vinfo[v] & (cx::kClamped | cx::kGhost))) continue;
+                const int32_t deg = h->var_off[v + 1] - h->var_off[v];
+                bool alone = is_free((int32_t)v) && ndyn[v] == 0;
+                if (deg == 1) {
+                    const int32_t pp = h->partner[cx::slot_of_edge(h, h->var_off[v])];
+                    alone = pp < 0 || !is_free(slot_var[pp]);
+                }
+                if (alone) { visited[v] = 1; pos_var.push_back((int32_t)v); skip0.push_back(-1); skip1.push_back(-1); }
+            }
+            // rule-table index of each link's two messages: spdir of the SENDING slot (2 * parameter set + direction)
+            for (size_t l = 0; l < from.size(); l++) { tab_fwd.push_back(h->spdir[from[l]]); tab_bwd.push_back(h->spdir[to[l]]); }
+        }
         for (void *p : {(void *)h->d_chain_pos_var, (void *)h->d_chain_skip0, (void *)h->d_chain_skip1, (void *)h->d_chain_link_pos,
                         (void *)h->d_chain_from, (void *)h->d_chain_to, (void *)h->d_chain_head_fwd, (void *)h->d_chain_head_bwd,
-                        (void *)h->d_chain_side, h->d_chain_totals}) if (p) (void)hipFree(p);
+                        (void *)h->d_chain_side, h->d_chain_totals, (void *)h->d_chain_tab_fwd, (void *)h->d_chain_tab_bwd, (void *)h->d_mvc_side,
+                        (void *)h->d_mvc_totals}) if (p) (void)hipFree(p);
+        h->d_chain_tab_fwd = h->d_chain_tab_bwd = nullptr; h->d_mvc_side = h->d_mvc_totals = nullptr;
         h->chain_npos = (int64_t)pos_var.size(); h->chain_nlinks = (int64_t)link_pos.size();
         h->chain_side_dirty = true;
         int64_t n_readers = 0;   // variables that read factor→variable messages: everything but observed variables and ghosts
@@ -99,10 +119,18 @@ int32_t build_chains(cx_handle *h) {
         if ((rc = dev_upload(h, &h->d_chain_to, to)) != CX_OK) return rc;
         if ((rc = dev_upload(h, &h->d_chain_head_fwd, head_fwd)) != CX_OK) return rc;
         if ((rc = dev_upload(h, &h->d_chain_head_bwd, head_bwd)) != CX_OK) return rc;
-        if ((rc = dev_alloc(h, &h->d_chain_side, h->chain_npos)) != CX_OK) return rc;
-        char *tot = nullptr;
-        if ((rc = dev_alloc(h, &tot, (int64_t)cx::chain_total_bytes(h->chain_nlinks))) != CX_OK) return rc;
-        h->d_chain_totals = tot;
+        if (h->cfg.dim > 1) {
+            h->d_chain_side = nullptr; h->d_chain_totals = nullptr;
+            if ((rc = dev_upload(h, &h->d_chain_tab_fwd, tab_fwd)) != CX_OK) return rc;
+            if ((rc = dev_upload(h, &h->d_chain_tab_bwd, tab_bwd)) != CX_OK) return rc;
+            if ((rc = dev_alloc(h, &h->d_mvc_side, h->nc * h->chain_npos)) != CX_OK) return rc;
+            if ((rc = dev_alloc(h, &h->d_mvc_totals, (int64_t)cx::mvc_totals_doubles(h->cfg.dim, h->chain_nlinks))) != CX_OK) return rc;
+        } else {
+            if ((rc = dev_alloc(h, &h->d_chain_side, h->chain_npos)) != CX_OK) return rc;
+            char *tot = nullptr;
+            if ((rc = dev_alloc(h, &tot, (int64_t)cx::chain_total_bytes(h->chain_nlinks))) != CX_OK) return rc;
+            h->d_chain_totals = tot;
+        }
         CX_HIP(h, hipStreamSynchronize(h->stream));
         h->chains_dirty = false;
         return CX_OK;

@@ -101,6 +101,9 @@ struct cx_handle {
     uint8_t *d_chain_head_fwd = nullptr, *d_chain_head_bwd = nullptr;
     double2 *d_chain_side = nullptr;
     void *d_chain_totals = nullptr;
+    // dim 2..4 (cx_mvchain.hip): rule-table index of each link's two messages, side sums [nc][npos], tile totals of the map scan
+    int32_t *d_chain_tab_fwd = nullptr, *d_chain_tab_bwd = nullptr;
+    double *d_mvc_side = nullptr, *d_mvc_totals = nullptr;
 
     // halo
     std::vector<int32_t> send_slots, recv_slots;
@@ -191,7 +194,7 @@ bool tiles_prepare_kernel(cx_handle *h);
 void tiles_free(cx_handle *h);
 void launch_tiled2(cx_handle *h, const double2 *f2v_in, double2 *f2v_out, bool write_marg);
 // multivariate (cx_mv.hip)
-void mv_launch_sweep(cx_handle *h, bool write_marg, bool observed_only);
+void mv_launch_sweep(cx_handle *h, bool write_marg, int only, double *f2v_out = nullptr);   // only: 0 regular, 1 observed variables, 2 other fixed senders (degree 1, stand-ins)
 void mv_launch_v2f(cx_handle *h, const int32_t *d_slots, const int32_t *d_vars, int64_t n, const double *f2v);
 void mv_launch_scatter(cx_handle *h, double *dst, int64_t stride, int nc, const int32_t *d_idx, const double *d_val, int64_t n);
 void mv_launch_gather(cx_handle *h, const double *src, int64_t stride, int nc, const int32_t *d_idx, double *d_val, int64_t n);
@@ -210,6 +213,10 @@ void mv64_rows_gather(cx_handle *h, const double *src, const int32_t *d_idx, dou
 void mv64_set_point(cx_handle *h, double *dst, const int32_t *d_idx, const double *d_y, int64_t n);
 bool mv_rule_tables(int d, const double *A, const double *Q, double *out);
 size_t chain_total_bytes(int64_t nlinks);
+// chain scan for dim 2..4 (cx_mvchain.hip)
+size_t mvc_totals_doubles(int dim, int64_t nlinks);
+void mvc_launch_side(cx_handle *h, bool write_marg);
+void mvc_launch_scan(cx_handle *h, bool write_marg);
 // variational families (cx_vmp.hip)
 int32_t vmp_graph_create(cx_handle *h, int64_t ne, const int64_t *edge_var, const int64_t *edge_fac, const int32_t *edge_role,
                          int64_t nf, const int64_t *factor_ids, const int32_t *factor_kind);

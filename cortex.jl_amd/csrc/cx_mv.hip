@@ -63,7 +63,11 @@ __global__ __launch_bounds__(kBlock, DEG == 3 ? 3 : 2) void k_sweep_mv(int nv, i
     // Messages out of observed variables are constants of the data: the regular sweep skips those variables (on a
     // state-space chain a third of all rule evaluations and stores); the host runs an `observed_only` pass into the output
     // buffer for the first two sweeps after the data changed, which leaves them in both buffers of the Jacobi pair.
-    const bool active = v < nv && (((info & kClamped) != 0) == (observed_only != 0));
+    // observed_only == 2: the other senders of constant messages — free variables of degree 1 and stand-ins, whose stored
+    // variable→factor message goes through the rule (the chain scan's leaf pass; the regular sweep handles them itself)
+    const bool is_fixed = (info & kGhost) || deg < 2;
+    const bool active = v < nv && (observed_only == 2 ? (!(info & kClamped) && is_fixed && deg > 0)
+                                                      : (((info & kClamped) != 0) == (observed_only != 0)));
     const int base = off + tid;
     Msg<D> in[DEG];
     int pk[DEG], sd[DEG];
@@ -196,7 +200,8 @@ static void prof_e(cx_handle *h) {
     if (h->profiling && h->prof_armed) (void)hipEventRecord(h->recs.back().stop, h->stream);
 }
 
-void mv_launch_sweep(cx_handle *h, bool write_marg, bool observed_only) {
+void mv_launch_sweep(cx_handle *h, bool write_marg, int observed_only, double *f2v_out) {
+    if (!f2v_out) f2v_out = h->d_mv_f2v_alt;
     if (h->nslices == 0) return;
     if (!observed_only) prof_b(h, CX_KERNEL_FUSED);
     const dim3 g((unsigned)h->nslices), b(kBlock);
@@ -209,7 +214,7 @@ void mv_launch_sweep(cx_handle *h, bool write_marg, bool observed_only) {
     static const bool force4 = [] { const char *e = getenv("CX_MV_DEG4"); return e && e[0] == '1'; }();
     const bool deg3 = h->mv_max_deg <= 3 && !force4;
 #define CX_MV_ARGS g, b, 0, h->stream, (int)h->nv, h->nslots, h->d_slice_off, h->d_vinfo, h->d_partner, h->d_spdir, h->d_ptab, (int)(2 * h->ptab_sets), \
-                   h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg, (write_marg && !observed_only) ? 1 : 0, observed_only ? 1 : 0
+                   h->d_mv_f2v, f2v_out, h->d_mv_v2f, h->d_mv_marg, (write_marg && !observed_only) ? 1 : 0, observed_only
 #define CX_MV(DD)                                                          \
     if (deg3) hipLaunchKernelGGL((k_sweep_mv<DD, 3>), CX_MV_ARGS);         \
     else hipLaunchKernelGGL((k_sweep_mv<DD, 4>), CX_MV_ARGS)

@@ -101,12 +101,13 @@ __device__ __forceinline__ void fwd_solve(const double (&Lm)[D][D], const double
     }
 }
 
-// tab: P (D*D) | B (D*D) | C (D*D), row-major, full
-template <int D>
+// tab: P (D*D) | B (D*D) | C (D*D), row-major, full.  POINT = false: the caller knows the input is no point mass (a sum of
+// factor→variable messages: the chain scan's walks)
+template <int D, bool POINT = true>
 __device__ __forceinline__ Msg<D> mv_rule(const Msg<D> &in, const double *__restrict__ tab) {
     const double *P = tab, *B = tab + D * D, *C = tab + 2 * D * D;
     Msg<D> out;
-    if (in.lam[0] == __builtin_inf()) {  // observed datum y in eta
+    if (POINT && in.lam[0] == __builtin_inf()) {  // observed datum y in eta
 #pragma unroll
         for (int i = 0; i < D; i++) {
             double s = 0.0;

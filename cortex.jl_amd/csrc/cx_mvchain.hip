@@ -1,0 +1,436 @@
+// cx_mvchain.hip — CX_SCHED_CHAIN_SCAN for d-dimensional messages (d = 2, 3, 4): ONE cx_sweep on a state-space chain is the
+// exact forward/backward smoother, i.e. what ONE update_marginals! of the reference computes on such a graph
+// (src/inference_engine.jl:575-608: a forward pass and a reverse pass of process! calls, 5T-4 message computations; SURVEY.md
+// §3.3 hand trace; the SSM of test/inference_engine_tests.jl:436-487) — here by parallel prefix scans over per-link maps
+// instead of a walk that is sequential in t.  (The flooding sweep of cx_mv.hip moves information one link per sweep.)
+//
+// The map of a link.  With messages in natural form m = (eta, Lambda), "add the side information u of the sending variable
+// (the sum of its non-chain incoming messages: likelihoods, priors), then apply the factor rule with the receiving edge's triple
+// (P, B, C)" (cx_mv.hip) is
+//     f(eta, Lambda) = ( c + B (Lambda + P~)^-1 (eta + h),   C - B (Lambda + P~)^-1 B' ),    P~ = P + U,  h = u_eta,  c = 0.
+// Maps of this form are closed under composition (Woodbury): for f2 after f1, with S = (C1 + P2)^-1 and g = c1 + h2,
+//     P12 = P1 - B1' S B1,   B12 = B2 S B1,   C12 = C2 - B2 S B2',   h12 = h1 + B1' S g,   c12 = c2 + B2 S g
+// — one d x d Cholesky and five small products per combine, all in registers.  (The scalar scan of cx_chain.hip is the d = 1
+// case written as a projective 3 x 3 matrix; the (P, B, C, h, c) form is the information-form element of the parallel Kalman
+// smoother.)  The first link of a path receives nothing from the chain: its map is the CONSTANT map "rule applied to u alone"
+// (B = 0), so every prefix of a path is a constant map and yields the message (c, C) directly; a constant second operand also
+// ends a segment of the segmented scan.
+//
+// Work decomposition.  A thread owns K consecutive links: it composes their K maps (thread total), the workgroup scans the
+// thread totals (wave shuffles + LDS across waves), a one-workgroup kernel scans the tile totals; the apply kernels recompute
+// the thread totals, obtain every thread's incoming message from its exclusive prefix and then WALK the K links with the
+// ordinary rule of the flooding sweep (one Cholesky per message) — map composition is only paid per thread, not per link.
+// Forward walk: alpha into the right end of every link.  Backward walk (second launch, reads the alphas back): beta into the
+// left end, and the marginal of every chain variable = side + alpha + beta, in moment form.
+// Results are re-associated relative to the sequential schedule: they agree with it to rounding, not bitwise.
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "cx_internal.h"
+#include "cx_mv_core.h"
+
+namespace cx {
+
+constexpr int kMapSeg = 1;     // constant map: the first link of a path (the scan does not cross it)
+constexpr int kMapIdent = 2;   // identity (padding, exclusive prefix of the first element)
+
+template <int D>
+struct CMap {
+    static constexpr int NT = D * (D + 1) / 2;
+    static constexpr int oB = NT, oC = NT + D * D, oH = oC + NT, oS = oH + D, ND = oS + D;   // P | B | C | h | c
+    double v[ND];
+    int flags;
+};
+
+template <int D>
+__device__ __forceinline__ CMap<D> cmap_identity() {
+    CMap<D> r;
+#pragma unroll
+    for (int i = 0; i < CMap<D>::ND; i++) r.v[i] = 0.0;
+    r.flags = kMapIdent;
+    return r;
+}
+
+// second ∘ first
+template <int D>
+__device__ __forceinline__ CMap<D> cmap_compose(const CMap<D> &f, const CMap<D> &s) {
+    using M = CMap<D>;
+    if (s.flags & (kMapSeg | kMapIdent)) return (s.flags & kMapSeg) ? s : f;
+    if (f.flags & kMapIdent) return s;
+    double Kp[M::NT];
+#pragma unroll
+    for (int i = 0; i < M::NT; i++) Kp[i] = f.v[M::oC + i] + s.v[i];
+    double Lm[D][D], ri[D];
+    chol<D>(Kp, nullptr, Lm, ri);
+    double X1[D][D], X2[D][D];      // X1 = L^-1 B1,  X2 = L^-1 B2'
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        double col[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) col[k] = f.v[M::oB + k * D + j];
+        fwd_solve<D>(Lm, ri, col);
+#pragma unroll
+        for (int k = 0; k < D; k++) X1[k][j] = col[k];
+#pragma unroll
+        for (int k = 0; k < D; k++) col[k] = s.v[M::oB + j * D + k];
+        fwd_solve<D>(Lm, ri, col);
+#pragma unroll
+        for (int k = 0; k < D; k++) X2[k][j] = col[k];
+    }
+    double g[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) g[k] = f.v[M::oS + k] + s.v[M::oH + k];
+    fwd_solve<D>(Lm, ri, g);
+    M r;
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        double hh = f.v[M::oH + i], cc = s.v[M::oS + i];
+#pragma unroll
+        for (int k = 0; k < D; k++) { hh += X1[k][i] * g[k]; cc += X2[k][i] * g[k]; }
+        r.v[M::oH + i] = hh; r.v[M::oS + i] = cc;
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            double b = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; k++) b += X2[k][i] * X1[k][j];
+            r.v[M::oB + i * D + j] = b;
+        }
+#pragma unroll
+        for (int j = i; j < D; j++) {
+            double p = f.v[tri<D>(i, j)], c = s.v[M::oC + tri<D>(i, j)];
+#pragma unroll
+            for (int k = 0; k < D; k++) { p -= X1[k][i] * X1[k][j]; c -= X2[k][i] * X2[k][j]; }
+            r.v[tri<D>(i, j)] = p; r.v[M::oC + tri<D>(i, j)] = c;
+        }
+    }
+    r.flags = f.flags;
+    return r;
+}
+
+template <int D>
+__device__ __forceinline__ CMap<D> cmap_shfl(const CMap<D> &x, int src) {
+    CMap<D> r;
+    src = src < 0 ? 0 : (src > 63 ? 63 : src);
+#pragma unroll
+    for (int i = 0; i < CMap<D>::ND; i++) r.v[i] = __shfl(x.v[i], src, 64);
+    r.flags = __shfl(x.flags, src, 64);
+    return r;
+}
+
+template <int D>
+__device__ __forceinline__ void cmap_store(double *p, const CMap<D> &x) {      // ND + 1 doubles
+#pragma unroll
+    for (int i = 0; i < CMap<D>::ND; i++) p[i] = x.v[i];
+    p[CMap<D>::ND] = (double)x.flags;
+}
+template <int D>
+__device__ __forceinline__ CMap<D> cmap_load(const double *p) {
+    CMap<D> r;
+#pragma unroll
+    for (int i = 0; i < CMap<D>::ND; i++) r.v[i] = p[i];
+    r.flags = (int)p[CMap<D>::ND];
+    return r;
+}
+
+// the map of one link from the side information u of its sending variable and the receiving edge's (P | B | C) tables
+template <int D>
+__device__ __forceinline__ CMap<D> cmap_of_link(const Msg<D> &u, const double *__restrict__ tab, bool head) {
+    using M = CMap<D>;
+    M r;
+    if (head) {
+        const Msg<D> o = mv_rule<D, false>(u, tab);
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            r.v[M::oH + i] = 0.0; r.v[M::oS + i] = o.eta[i];
+#pragma unroll
+            for (int j = 0; j < D; j++) r.v[M::oB + i * D + j] = 0.0;
+#pragma unroll
+            for (int j = i; j < D; j++) { r.v[tri<D>(i, j)] = i == j ? 1.0 : 0.0; r.v[M::oC + tri<D>(i, j)] = o.lam[tri<D>(i, j)]; }
+        }
+        r.flags = kMapSeg;
+        return r;
+    }
+    const double *P = tab, *B = tab + D * D, *C = tab + 2 * D * D;
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        r.v[M::oH + i] = u.eta[i]; r.v[M::oS + i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; j++) r.v[M::oB + i * D + j] = B[i * D + j];
+#pragma unroll
+        for (int j = i; j < D; j++) { r.v[tri<D>(i, j)] = P[i * D + j] + u.lam[tri<D>(i, j)]; r.v[M::oC + tri<D>(i, j)] = C[i * D + j]; }
+    }
+    r.flags = 0;
+    return r;
+}
+
+struct MvcArgs {
+    int nlinks, npos, nv, ntab;
+    int64_t nslots;
+    const int32_t *link_pos;             // chain position of the link's left variable
+    const int32_t *from_slot, *to_slot;  // slot (left variable, factor), slot (right variable, factor)
+    const int32_t *tab_fwd, *tab_bwd;    // rule-table index of the message left → right / right → left
+    const uint8_t *head_fwd, *head_bwd;  // first / last link of its path
+    const int32_t *pos_var;
+    const double *side;                  // [nc][npos]: sum of the non-chain messages into each chain variable
+    const double *ptab;                  // [ntab][3][D*D]
+};
+
+constexpr int kMvcTabLds = 16;           // rule tables (parameter set x direction) kept in LDS; graphs with more read them from memory
+
+template <int D, bool GT>
+__device__ __forceinline__ const double *mvc_tab(const MvcArgs &A, const double *tab_s, int t) {
+    return (GT ? A.ptab : tab_s) + (size_t)t * 3 * D * D;
+}
+
+// dir = +1: link l maps alpha at its left variable to alpha at its right variable; dir = -1: beta at the right to beta at the left
+template <int D, bool GT>
+__device__ __forceinline__ CMap<D> mvc_link(const MvcArgs &A, const double *tab_s, int l, int dir) {
+    const int p = A.link_pos[l] + (dir > 0 ? 0 : 1);
+    const bool head = (dir > 0 ? A.head_fwd[l] : A.head_bwd[l]) != 0;
+    const int t = dir > 0 ? A.tab_fwd[l] : A.tab_bwd[l];
+    const Msg<D> u = msg_load<D>(A.side, A.npos, p);
+    return cmap_of_link<D>(u, mvc_tab<D, GT>(A, tab_s, t), head);
+}
+
+// the composed map of a thread's K consecutive links, in the direction's order
+template <int D, bool GT>
+__device__ __forceinline__ CMap<D> mvc_thread_total(const MvcArgs &A, const double *tab_s, int l0, int K, int dir) {
+    CMap<D> tot = cmap_identity<D>();
+#pragma unroll 1
+    for (int k = 0; k < K; k++) {
+        const int l = dir > 0 ? l0 + k : l0 + K - 1 - k;
+        if (l < A.nlinks) tot = cmap_compose<D>(tot, mvc_link<D, GT>(A, tab_s, l, dir));
+    }
+    return tot;
+}
+
+// Workgroup scan in the direction's logical order (dir = -1: thread 255 first).  In: every thread's total.  Out: t = the
+// exclusive prefix of the thread within the workgroup; total (WANT_TOTAL) = the workgroup's total, valid in the logically
+// LAST thread only.  wt: LDS, kBlock/64 elements of ND + 1 doubles.
+template <int D, bool WANT_TOTAL>
+__device__ __forceinline__ void mvc_wg_scan(CMap<D> &t, CMap<D> &total, double *wt, int tid, int dir) {
+    constexpr int E = CMap<D>::ND + 1, NW = kBlock / 64;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int li = dir > 0 ? lane : 63 - lane, wl = dir > 0 ? wid : NW - 1 - wid;
+#pragma unroll 1
+    for (int d = 1; d < 64; d <<= 1) {
+        const CMap<D> o = cmap_shfl<D>(t, dir > 0 ? lane - d : lane + d);
+        if (li >= d) t = cmap_compose<D>(o, t);
+    }
+    if (li == 63) cmap_store<D>(wt + wid * E, t);
+    __syncthreads();
+    CMap<D> ex = cmap_shfl<D>(t, dir > 0 ? lane - 1 : lane + 1);
+    if (li == 0) ex = cmap_identity<D>();
+    CMap<D> carry = cmap_identity<D>();
+#pragma unroll 1
+    for (int w = 0; w < wl; w++) carry = cmap_compose<D>(carry, cmap_load<D>(wt + (dir > 0 ? w : NW - 1 - w) * E));
+    if (WANT_TOTAL && wl == NW - 1 && li == 63) total = cmap_compose<D>(carry, t);
+    t = cmap_compose<D>(carry, ex);
+    __syncthreads();
+}
+
+template <int D>
+__device__ __forceinline__ void mvc_load_tabs(const MvcArgs &A, double *tab_s, int tid) {
+    const int n = (A.ntab < kMvcTabLds ? A.ntab : kMvcTabLds) * 3 * D * D;
+    for (int i = tid; i < n; i += kBlock) tab_s[i] = A.ptab[i];
+    __syncthreads();
+}
+
+// grid (ntiles, 2): blockIdx.y = 0 forward, 1 backward.  totals[dir][pos] in the direction's scan order (backward: tile ntiles-1 first)
+template <int D, bool GT>
+__global__ __launch_bounds__(kBlock) void k_mvc_totals(MvcArgs A, int K, double *__restrict__ totals) {
+    constexpr int E = CMap<D>::ND + 1;
+    __shared__ double tab_s[GT ? 1 : kMvcTabLds * 3 * D * D];
+    __shared__ double wt[(kBlock / 64) * E];
+    const int tid = threadIdx.x, dir = blockIdx.y ? -1 : 1, ntiles = gridDim.x;
+    if (!GT) mvc_load_tabs<D>(A, tab_s, tid);
+    CMap<D> t = mvc_thread_total<D, GT>(A, tab_s, (blockIdx.x * kBlock + tid) * K, K, dir);
+    CMap<D> total = cmap_identity<D>();
+    mvc_wg_scan<D, true>(t, total, wt, tid, dir);
+    const int pos = dir > 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;
+    if (tid == (dir > 0 ? kBlock - 1 : 0)) cmap_store<D>(totals + ((size_t)blockIdx.y * ntiles + pos) * E, total);
+}
+
+// exclusive scan of the tile totals, in place: one workgroup per direction, chunks of kBlock tiles
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_mvc_scan_totals(int ntiles, double *__restrict__ totals) {
+    constexpr int E = CMap<D>::ND + 1;
+    __shared__ double wt[(kBlock / 64) * E];
+    __shared__ double carry_s[E];
+    const int tid = threadIdx.x;
+    totals += (size_t)blockIdx.x * ntiles * E;
+    if (tid == 0) cmap_store<D>(carry_s, cmap_identity<D>());
+    __syncthreads();
+#pragma unroll 1
+    for (int chunk = 0; chunk < ntiles; chunk += kBlock) {
+        const int j = chunk + tid;
+        CMap<D> t = j < ntiles ? cmap_load<D>(totals + (size_t)j * E) : cmap_identity<D>();
+        CMap<D> total = cmap_identity<D>();
+        mvc_wg_scan<D, true>(t, total, wt, tid, 1);
+        const CMap<D> carry = cmap_load<D>(carry_s);
+        if (j < ntiles) cmap_store<D>(totals + (size_t)j * E, cmap_compose<D>(carry, t));
+        __syncthreads();
+        if (tid == kBlock - 1) cmap_store<D>(carry_s, cmap_compose<D>(carry, total));
+        __syncthreads();
+    }
+}
+
+template <int D>
+__device__ __forceinline__ Msg<D> msg_nan() {
+    Msg<D> m;
+#pragma unroll
+    for (int i = 0; i < D; i++) m.eta[i] = __builtin_nan("");
+#pragma unroll
+    for (int i = 0; i < Msg<D>::NT; i++) m.lam[i] = __builtin_nan("");
+    return m;
+}
+
+template <int D>
+__device__ __forceinline__ void marg_store(double *__restrict__ marg, int nv, int v, const Msg<D> &nat) {
+    const Msg<D> mo = mv_to_moment<D>(nat);
+#pragma unroll
+    for (int i = 0; i < D; i++) __builtin_nontemporal_store(mo.eta[i], &marg[(int64_t)i * nv + v]);
+#pragma unroll
+    for (int i = 0; i < Msg<D>::NT; i++) __builtin_nontemporal_store(mo.lam[i], &marg[(int64_t)(D + i) * nv + v]);
+}
+
+// One direction per launch (dir = +1 first: the backward launch reads the alphas it stored).
+// Forward: f2v[to_slot[l]] = alpha_l.  Backward: f2v[from_slot[l]] = beta_l and, with write_marg, the marginal of the right
+// variable of every link (side + alpha_l + beta of the next link) and of the left variable of a path's first link.
+template <int D, bool GT>
+__global__ __launch_bounds__(kBlock) void k_mvc_apply(MvcArgs A, int K, int dir, const double *__restrict__ excl, double *__restrict__ f2v,
+                                                      double *__restrict__ marg, int write_marg) {
+    constexpr int E = CMap<D>::ND + 1;
+    using M = CMap<D>;
+    __shared__ double tab_s[GT ? 1 : kMvcTabLds * 3 * D * D];
+    __shared__ double wt[(kBlock / 64) * E];
+    const int tid = threadIdx.x, ntiles = gridDim.x;
+    if (!GT) mvc_load_tabs<D>(A, tab_s, tid);
+    const int l0 = (blockIdx.x * kBlock + tid) * K;
+    CMap<D> t = mvc_thread_total<D, GT>(A, tab_s, l0, K, dir);
+    CMap<D> unused;
+    mvc_wg_scan<D, false>(t, unused, wt, tid, dir);
+    const int pos = dir > 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;
+    const CMap<D> inc = cmap_compose<D>(cmap_load<D>(excl + ((size_t)(dir > 0 ? 0 : 1) * ntiles + pos) * E), t);
+    // every prefix that reaches back to the first link of a path is a constant map: the message it produces from nothing
+    Msg<D> cur = msg_nan<D>();
+    if (inc.flags & kMapSeg) {
+#pragma unroll
+        for (int i = 0; i < D; i++) cur.eta[i] = inc.v[M::oS + i];
+#pragma unroll
+        for (int i = 0; i < Msg<D>::NT; i++) cur.lam[i] = inc.v[M::oC + i];
+    }
+    if (l0 >= A.nlinks) return;
+    if (dir > 0) {
+#pragma unroll 1
+        for (int k = 0; k < K; k++) {
+            const int l = l0 + k;
+            if (l >= A.nlinks) break;
+            Msg<D> in = msg_load<D>(A.side, A.npos, A.link_pos[l]);
+            if (!A.head_fwd[l]) msg_add<D>(in, cur);
+            cur = mv_rule<D, false>(in, mvc_tab<D, GT>(A, tab_s, A.tab_fwd[l]));
+            if (!__builtin_isnan(cur.lam[0])) msg_store<D>(f2v, A.nslots, A.to_slot[l], cur);
+        }
+    } else {
+#pragma unroll 1
+        for (int k = K - 1; k >= 0; k--) {
+            const int l = l0 + k;
+            if (l >= A.nlinks) continue;
+            const int p = A.link_pos[l];
+            Msg<D> in = msg_load<D>(A.side, A.npos, p + 1);      // what the right variable hears from everybody but this link
+            if (!A.head_bwd[l]) msg_add<D>(in, cur);
+            if (write_marg) {
+                Msg<D> tot = msg_load<D>(f2v, A.nslots, A.to_slot[l]);   // alpha_l, stored by the forward launch
+                msg_add<D>(tot, in);
+                marg_store<D>(marg, A.nv, A.pos_var[p + 1], tot);
+            }
+            cur = mv_rule<D, false>(in, mvc_tab<D, GT>(A, tab_s, A.tab_bwd[l]));
+            if (!__builtin_isnan(cur.lam[0])) msg_store<D>(f2v, A.nslots, A.from_slot[l], cur);
+            if (write_marg && A.head_fwd[l]) {
+                Msg<D> tot = msg_load<D>(A.side, A.npos, p);
+                msg_add<D>(tot, cur);
+                marg_store<D>(marg, A.nv, A.pos_var[p], tot);
+            }
+        }
+    }
+}
+
+// side information of every chain position (runs after data, stored messages or rule parameters changed); a position without
+// links (an isolated non-observed variable) gets its marginal here: the product of everything it hears
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_mvc_side(int npos, int64_t nslots, int nv, const int32_t *__restrict__ pos_var,
+                                                     const int32_t *__restrict__ skip0, const int32_t *__restrict__ skip1,
+                                                     const int32_t *__restrict__ vbase, const uint8_t *__restrict__ vinfo,
+                                                     const double *__restrict__ f2v, double *__restrict__ side,
+                                                     double *__restrict__ marg, int write_marg) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npos) return;
+    const int v = pos_var[i], s0 = skip0[i], s1 = skip1[i], b = vbase[v], deg = vinfo[v] & kDegMask;
+    Msg<D> acc = msg_zero<D>();
+    for (int k = 0; k < deg; k++) {
+        const int slot = b + k * kBlock;
+        if (slot == s0 || slot == s1) continue;
+        msg_add<D>(acc, msg_load<D>(f2v, nslots, slot));
+    }
+    msg_store<D>(side, npos, i, acc);
+    if (write_marg && s0 < 0 && s1 < 0) marg_store<D>(marg, nv, v, acc);
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+// links per thread of the scan; CX_MVC_K overrides (read per sweep: the tests run several values in one process)
+int mvc_links_per_thread() {
+    const char *e = getenv("CX_MVC_K");
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 && v <= 64 ? v : 2;
+}
+
+static int64_t mvc_ntiles(int64_t nlinks, int K) {
+    const int64_t per = (int64_t)kBlock * K;
+    return (nlinks + per - 1) / per;
+}
+
+// tile totals of both directions, sized for one link per thread (the most tiles any K needs)
+size_t mvc_totals_doubles(int dim, int64_t nlinks) {
+    const int nd = 2 * (dim * (dim + 1) / 2) + dim * dim + 2 * dim + 1;
+    return (size_t)2 * (size_t)std::max<int64_t>(mvc_ntiles(nlinks, 1), 1) * nd;
+}
+
+void mvc_launch_side(cx_handle *h, bool write_marg) {
+    const int npos = (int)h->chain_npos;
+    if (npos == 0) return;
+    const dim3 g((npos + kBlock - 1) / kBlock), b(kBlock);
+#define CX_MVC(DD) hipLaunchKernelGGL((k_mvc_side<DD>), g, b, 0, h->stream, npos, h->nslots, (int)h->nv, h->d_chain_pos_var, h->d_chain_skip0, \
+                                      h->d_chain_skip1, h->d_vbase, h->d_vinfo, h->d_mv_f2v, h->d_mvc_side, h->d_mv_marg, write_marg ? 1 : 0)
+    if (h->cfg.dim == 2) CX_MVC(2);
+    else if (h->cfg.dim == 3) CX_MVC(3);
+    else CX_MVC(4);
+#undef CX_MVC
+}
+
+template <int D, bool GT>
+static void mvc_launch_t(cx_handle *h, const MvcArgs &A, bool write_marg) {
+    const int K = mvc_links_per_thread();
+    const int ntiles = (int)mvc_ntiles(A.nlinks, K);
+    hipLaunchKernelGGL((k_mvc_totals<D, GT>), dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, K, h->d_mvc_totals);
+    hipLaunchKernelGGL((k_mvc_scan_totals<D>), dim3(2), dim3(kBlock), 0, h->stream, ntiles, h->d_mvc_totals);
+    hipLaunchKernelGGL((k_mvc_apply<D, GT>), dim3(ntiles), dim3(kBlock), 0, h->stream, A, K, 1, h->d_mvc_totals, h->d_mv_f2v, h->d_mv_marg, 0);
+    hipLaunchKernelGGL((k_mvc_apply<D, GT>), dim3(ntiles), dim3(kBlock), 0, h->stream, A, K, -1, h->d_mvc_totals, h->d_mv_f2v, h->d_mv_marg,
+                       write_marg ? 1 : 0);
+}
+
+// all forward and backward chain messages (into d_mv_f2v) and, with write_marg, the chain variables' marginals
+void mvc_launch_scan(cx_handle *h, bool write_marg) {
+    if (h->chain_nlinks == 0) return;
+    MvcArgs A{(int)h->chain_nlinks, (int)h->chain_npos, (int)h->nv, (int)(2 * h->ptab_sets), h->nslots, h->d_chain_link_pos, h->d_chain_from,
+              h->d_chain_to, h->d_chain_tab_fwd, h->d_chain_tab_bwd, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_pos_var,
+              h->d_mvc_side, h->d_ptab};
+    const bool gt = A.ntab > kMvcTabLds;
+#define CX_MVC(DD) do { if (gt) mvc_launch_t<DD, true>(h, A, write_marg); else mvc_launch_t<DD, false>(h, A, write_marg); } while (0)
+    if (h->cfg.dim == 2) CX_MVC(2);
+    else if (h->cfg.dim == 3) CX_MVC(3);
+    else CX_MVC(4);
+#undef CX_MVC
+}
+
+}  // namespace cx

@@ -127,7 +127,7 @@ def gaussian_grid(n_rows: int, n_cols: int, seed: int = 1234, row0: int = 0, row
                        "qv": qv, "qv_row0": v0, "ghost_rows": ghost_rows, "kind": "gaussian_grid"})
 
 
-def lgssm_chain(T: int, d: int = 4, seed: int = 1234) -> Model:
+def lgssm_chain(T: int, d: int = 4, seed: int = 1234, A=None, Q=None, R=None) -> Model:
     """d-dimensional linear-Gaussian state-space chain, configs C3 (d = 4, T = 1e6) / C5 (d = 64, T = 1e5) of
     SURVEY.md §8d: x_{t+1} = A x_t + w, w ~ N(0, Q);  y_t = x_t + v, v ~ N(0, R);  x_1 ~ N(0, I) for the data only (the
     graph, like the reference's SSM test, has no prior factor).  d = 4: A = 0.95 * blockdiag(rot(0.1), rot(0.1)),
@@ -135,10 +135,15 @@ def lgssm_chain(T: int, d: int = 4, seed: int = 1234) -> Model:
     rng = np.random.default_rng(seed)
     if d % 2 == 0 and d <= 8:
         c, s_ = np.cos(0.1), np.sin(0.1)
-        A = np.kron(np.eye(d // 2), np.array([[c, -s_], [s_, c]])) * 0.95
+        A_default = np.kron(np.eye(d // 2), np.array([[c, -s_], [s_, c]])) * 0.95
     else:
-        A = 0.95 * np.linalg.qr(rng.standard_normal((d, d)))[0]
-    Q, R = 0.1 * np.eye(d), np.eye(d)
+        A_default = 0.95 * np.linalg.qr(rng.standard_normal((d, d)))[0]
+    # A, Q, R given: another model of the same shape (e.g. the slow-mixing A = 0.999 I, Q = 1e-4 I, R = 10 I, or ill-conditioned noise)
+    A = A if A is None else np.asarray(A, dtype=np.float64)
+    if A is None:
+        A = A_default
+    Q = 0.1 * np.eye(d) if Q is None else np.asarray(Q, dtype=np.float64)
+    R = np.eye(d) if R is None else np.asarray(R, dtype=np.float64)
     x = np.arange(1, T + 1, dtype=np.int64)
     y = x + T
     lik = x + 2 * T
@@ -149,15 +154,33 @@ def lgssm_chain(T: int, d: int = 4, seed: int = 1234) -> Model:
                                 np.full(T - 1, L.ROLE_OUT)]).astype(np.int32)
     state = np.empty((T, d))
     state[0] = rng.standard_normal(d)
-    w = rng.standard_normal((T, d)) * np.sqrt(0.1)
+    Lq, Lr = np.linalg.cholesky(Q), np.linalg.cholesky(R)     # (defaults: sqrt(0.1) I and I — the streams of the round-1 models)
+    w = rng.standard_normal((T, d)) @ Lq.T
     for t in range(1, T):
         state[t] = A @ state[t - 1] + w[t]
-    data = state + rng.standard_normal((T, d))
+    data = state + rng.standard_normal((T, d)) @ Lr.T
     return Model(edge_var=edge_var, edge_fac=edge_fac, factor_ids=np.concatenate([lik, tr]),
                  factor_kind=np.full(2 * T - 1, L.FACTOR_GAUSS_LINEAR, dtype=np.int32),
                  factor_var=np.concatenate([np.ones(T), np.zeros(T - 1)]),   # parameter sets: 1 = likelihood, 0 = transition
                  x_ids=x, data_var=y, data_fac=lik, data_y=data, dim=d, edge_role=edge_role,
                  psets={0: (A, Q), 1: (np.eye(d), R)}, meta={"T": T, "A": A, "Q": Q, "R": R, "kind": "lgssm_chain"})
+
+
+def concat_models(models) -> Model:
+    """several dim > 1 models as ONE graph of disjoint components (ids shifted past each other): chains of different lengths,
+    isolated variables — what the segmented chain scan has to keep apart"""
+    off, parts = 0, []
+    for m in models:
+        parts.append((m, off))
+        off += int(max(m.edge_var.max(), m.edge_fac.max()))
+    cat = lambda f: np.concatenate([f(m, o) for m, o in parts])
+    first = models[0]
+    return Model(edge_var=cat(lambda m, o: m.edge_var + o), edge_fac=cat(lambda m, o: m.edge_fac + o),
+                 factor_ids=cat(lambda m, o: m.factor_ids + o), factor_kind=cat(lambda m, o: m.factor_kind),
+                 factor_var=cat(lambda m, o: m.factor_var), x_ids=cat(lambda m, o: m.x_ids + o),
+                 data_var=cat(lambda m, o: m.data_var + o), data_fac=cat(lambda m, o: m.data_fac + o),
+                 data_y=np.concatenate([m.data_y for m in models]), dim=first.dim, edge_role=cat(lambda m, o: m.edge_role),
+                 psets=first.psets, meta={"parts": [(len(m.x_ids), o) for m, o in parts], "kind": "concat"})
 
 
 def load_into_device(model: Model, dev, seed_variance: float | None = None):

@@ -121,3 +121,21 @@ def lgssm_posterior(y, A, Q, R, H=None):
     Jo = np.tile(-(A.T @ Qi), (T - 1, 1, 1))
     h = y @ (Ri @ H)  # rows: H^T R^{-1} y_t
     return block_tridiag_posterior(Jd, Jo, h)
+
+
+def lgssm_posterior_c(y, A, Q, R):
+    """lgssm_posterior (H = I) by oracle/blocktri.c: the same block-tridiagonal statement with pivoted LU solves in C, for the
+    full-size chains (T = 1e6) where the numpy loop above would take minutes.  Pinned against it in tests/test_blocktri_checker.py."""
+    import ctypes as C
+
+    from .ref import lib
+
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    T, d = y.shape
+    A = np.ascontiguousarray(A, dtype=np.float64); Q = np.ascontiguousarray(Q, dtype=np.float64); R = np.ascontiguousarray(R, dtype=np.float64)
+    mean = np.empty((T, d)); cov = np.empty((T, d, d))
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    rc = lib().cxo_lgssm_posterior(d, T, p(y), p(A), p(Q), p(R), p(mean), p(cov))
+    if rc != 0:
+        raise RuntimeError(f"cxo_lgssm_posterior: status {rc}")
+    return mean, cov

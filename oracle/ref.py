@@ -25,7 +25,7 @@ P_SSM_BP, P_BETA_BERNOULLI, P_TRACING, P_CALLBACK = range(4)
 
 def build(force: bool = False) -> str:
     """Compile the C restatement with the committed recipe (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("cortex_ref.c", "bp_flood.c", "mv_flood.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("cortex_ref.c", "bp_flood.c", "mv_flood.c", "blocktri.c", "Makefile")]
     if "CXO_LIB" in os.environ:
         return _SO
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
@@ -105,6 +105,7 @@ def lib():
     sig("cxo_flood_sweep", i64, i64, pi64, i64, pi64, pd, pu8, pd, pd, pd, pd, i32, i32)
     sig("cxo_flood_marginals", None, i64, pi64, pd, pd, pd, pd, i32)
     sig("cxo_mv_flood_sweep", i64, i32, i64, pi64, i64, pi64, pi32, pi32, pd, pd, pu8, pd, pd, pd, pu8, pd, pd, pu8, i32)
+    sig("cxo_lgssm_posterior", i32, i32, i64, pd, pd, pd, pd, pd, pd)
     sig("cxo_mv_flood_marginals", i32, i32, i64, pi64, pd, pd, pu8, pd, pd, pu8)
     _lib = L
     return L
