@@ -194,6 +194,7 @@ int32_t mv_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
     std::vector<int32_t> idx, vars;
     int32_t rc = stage_slots(h, n, variable_ids, factor_ids, idx, &vars);
     if (rc != CX_OK) return rc;
+    if ((rc = mv_ensure_chain_msgs(h)) != CX_OK) return rc;
     if (direction == CX_TO_FACTOR) { rc = mv_refresh_v2f(h, idx, vars); if (rc != CX_OK) return rc; }
     return mv_get(h, direction == CX_TO_FACTOR ? h->d_mv_v2f : h->d_mv_f2v, h->nslots, idx, form, false, out);
 }
@@ -280,10 +281,25 @@ static int32_t mv_chain_sweep(cx_handle *h, int32_t n_sweeps) {
             cx::mvc_launch_side(h, marg);
             h->observed_passes_due = 0; h->chain_side_dirty = false;
         }
-        cx::mvc_launch_scan(h, marg);
+        cx::mvc_launch_scan(h, marg, false, true);
+        h->chain_msgs_stale = true;      // the chain messages live in the scan's own buffers until somebody asks for them
         h->sweeps_done++;
     }
     CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
+// dim 2..4 under the chain-scan schedule: bring the chain messages in d_mv_f2v up to date (the tile carries of the last sweep are
+// still on the device: two apply launches).  Every reader of d_mv_f2v calls this first.
+int32_t mv_ensure_chain_msgs(cx_handle *h) {
+    if (!h->chain_msgs_stale) return CX_OK;
+    // side sums, alphas and tile carries of the last sweep are untouched until the next sweep (or a rebuild of the chains, which
+    // calls this first): the two walks reproduce exactly the messages of that sweep
+    if (h->d_mvc_alpha && h->chain_nlinks > 0) {
+        cx::mvc_launch_scan(h, false, true, false);
+        CX_HIP(h, hipGetLastError());
+    }
+    h->chain_msgs_stale = false;
     return CX_OK;
 }
 
@@ -317,6 +333,7 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
 
 int32_t mv_residual(cx_handle *h, double *out) {
     const int64_t n = h->nc * h->nslots;
+    { int32_t rc = mv_ensure_chain_msgs(h); if (rc != CX_OK) return rc; }
     if (!h->d_mv_prev) {
         int32_t rc = dev_alloc(h, &h->d_mv_prev, n);
         if (rc != CX_OK) return rc;

@@ -23,6 +23,13 @@
 // Forward walk: alpha into the right end of every link.  Backward walk (second launch, reads the alphas back): beta into the
 // left end, and the marginal of every chain variable = side + alpha + beta, in moment form.
 // Results are re-associated relative to the sequential schedule: they agree with it to rounding, not bitwise.
+//
+// Memory layout.  "Thread owns K consecutive links" would make every access to a chain-ordered array a stride-K access.  The
+// arrays the sweep streams — the side sums of a link's two ends and the alphas — are therefore kept in a thread-interleaved
+// order IL(l) = tile * 256 K + (l mod K) * 256 + thread: what the 256 threads of a workgroup touch in step k of their walks is
+// one contiguous run of 2 KB per component.  Messages go to the SELL slots of cx_mv.hip only on demand (cx_get_messages, a
+// checkpoint, a residual: mvc_launch_scan(..., store_msgs)), like the variable→factor messages of the fused sweep; the
+// marginals are written every sweep.
 
 #include <algorithm>
 #include <cstdlib>
@@ -172,9 +179,19 @@ struct MvcArgs {
     const int32_t *tab_fwd, *tab_bwd;    // rule-table index of the message left → right / right → left
     const uint8_t *head_fwd, *head_bwd;  // first / last link of its path
     const int32_t *pos_var;
-    const double *side;                  // [nc][npos]: sum of the non-chain messages into each chain variable
+    const double *side;                  // [nc][npos]: sum of the non-chain messages into each chain variable, by position
+    const double *side_l, *side_r;       // [nc][il_stride]: the same for the left / right variable of link l, at IL(l)
+    double *alpha;                       // [nc][il_stride]: the forward message link l produces, at IL(l)
+    double *marg_il;                     // [nc][il_stride]: the marginal of link l's right variable (moment form), at IL(l)
+    int64_t il_stride;                   // ntiles * 256 * K
     const double *ptab;                  // [ntab][3][D*D]
 };
+
+// thread-interleaved index of link l = (tile * 256 + thread) * K + k
+__device__ __forceinline__ int64_t mvc_il(int l, int K) {
+    const int th = l / K, k = l - th * K;
+    return (int64_t)(th / kBlock) * kBlock * K + (int64_t)k * kBlock + (th % kBlock);
+}
 
 constexpr int kMvcTabLds = 16;           // rule tables (parameter set x direction) kept in LDS; graphs with more read them from memory
 
@@ -185,22 +202,21 @@ __device__ __forceinline__ const double *mvc_tab(const MvcArgs &A, const double 
 
 // dir = +1: link l maps alpha at its left variable to alpha at its right variable; dir = -1: beta at the right to beta at the left
 template <int D, bool GT>
-__device__ __forceinline__ CMap<D> mvc_link(const MvcArgs &A, const double *tab_s, int l, int dir) {
-    const int p = A.link_pos[l] + (dir > 0 ? 0 : 1);
+__device__ __forceinline__ CMap<D> mvc_link(const MvcArgs &A, const double *tab_s, int l, int64_t il, int dir) {
     const bool head = (dir > 0 ? A.head_fwd[l] : A.head_bwd[l]) != 0;
     const int t = dir > 0 ? A.tab_fwd[l] : A.tab_bwd[l];
-    const Msg<D> u = msg_load<D>(A.side, A.npos, p);
+    const Msg<D> u = msg_load<D>(dir > 0 ? A.side_l : A.side_r, A.il_stride, il);
     return cmap_of_link<D>(u, mvc_tab<D, GT>(A, tab_s, t), head);
 }
 
 // the composed map of a thread's K consecutive links, in the direction's order
 template <int D, bool GT>
-__device__ __forceinline__ CMap<D> mvc_thread_total(const MvcArgs &A, const double *tab_s, int l0, int K, int dir) {
+__device__ __forceinline__ CMap<D> mvc_thread_total(const MvcArgs &A, const double *tab_s, int l0, int64_t il0, int K, int dir) {
     CMap<D> tot = cmap_identity<D>();
 #pragma unroll 1
     for (int k = 0; k < K; k++) {
-        const int l = dir > 0 ? l0 + k : l0 + K - 1 - k;
-        if (l < A.nlinks) tot = cmap_compose<D>(tot, mvc_link<D, GT>(A, tab_s, l, dir));
+        const int kk = dir > 0 ? k : K - 1 - k;
+        if (l0 + kk < A.nlinks) tot = cmap_compose<D>(tot, mvc_link<D, GT>(A, tab_s, l0 + kk, il0 + (int64_t)kk * kBlock, dir));
     }
     return tot;
 }
@@ -245,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void k_mvc_totals(MvcArgs A, int K, double 
     __shared__ double wt[(kBlock / 64) * E];
     const int tid = threadIdx.x, dir = blockIdx.y ? -1 : 1, ntiles = gridDim.x;
     if (!GT) mvc_load_tabs<D>(A, tab_s, tid);
-    CMap<D> t = mvc_thread_total<D, GT>(A, tab_s, (blockIdx.x * kBlock + tid) * K, K, dir);
+    CMap<D> t = mvc_thread_total<D, GT>(A, tab_s, (blockIdx.x * kBlock + tid) * K, (int64_t)blockIdx.x * kBlock * K + tid, K, dir);
     CMap<D> total = cmap_identity<D>();
     mvc_wg_scan<D, true>(t, total, wt, tid, dir);
     const int pos = dir > 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;
@@ -287,7 +303,7 @@ __device__ __forceinline__ Msg<D> msg_nan() {
 }
 
 template <int D>
-__device__ __forceinline__ void marg_store(double *__restrict__ marg, int nv, int v, const Msg<D> &nat) {
+__device__ __forceinline__ void marg_store(double *__restrict__ marg, int64_t nv, int64_t v, const Msg<D> &nat) {
     const Msg<D> mo = mv_to_moment<D>(nat);
 #pragma unroll
     for (int i = 0; i < D; i++) __builtin_nontemporal_store(mo.eta[i], &marg[(int64_t)i * nv + v]);
@@ -296,11 +312,12 @@ __device__ __forceinline__ void marg_store(double *__restrict__ marg, int nv, in
 }
 
 // One direction per launch (dir = +1 first: the backward launch reads the alphas it stored).
-// Forward: f2v[to_slot[l]] = alpha_l.  Backward: f2v[from_slot[l]] = beta_l and, with write_marg, the marginal of the right
-// variable of every link (side + alpha_l + beta of the next link) and of the left variable of a path's first link.
+// Forward: alpha_l into the interleaved buffer.  Backward: the marginal of the right variable of every link (side + alpha_l +
+// beta of the next link) and of the left variable of a path's first link.  flags & 2: alpha_l / beta_l also go to their SELL
+// slots f2v[to_slot[l]] / f2v[from_slot[l]].
 template <int D, bool GT>
 __global__ __launch_bounds__(kBlock) void k_mvc_apply(MvcArgs A, int K, int dir, const double *__restrict__ excl, double *__restrict__ f2v,
-                                                      double *__restrict__ marg, int write_marg) {
+                                                      double *__restrict__ marg, int flags /* 1: marginals, 2: messages into f2v */) {
     constexpr int E = CMap<D>::ND + 1;
     using M = CMap<D>;
     __shared__ double tab_s[GT ? 1 : kMvcTabLds * 3 * D * D];
@@ -308,7 +325,8 @@ __global__ __launch_bounds__(kBlock) void k_mvc_apply(MvcArgs A, int K, int dir,
     const int tid = threadIdx.x, ntiles = gridDim.x;
     if (!GT) mvc_load_tabs<D>(A, tab_s, tid);
     const int l0 = (blockIdx.x * kBlock + tid) * K;
-    CMap<D> t = mvc_thread_total<D, GT>(A, tab_s, l0, K, dir);
+    const int64_t il0 = (int64_t)blockIdx.x * kBlock * K + tid;
+    CMap<D> t = mvc_thread_total<D, GT>(A, tab_s, l0, il0, K, dir);
     CMap<D> unused;
     mvc_wg_scan<D, false>(t, unused, wt, tid, dir);
     const int pos = dir > 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;
@@ -322,31 +340,35 @@ __global__ __launch_bounds__(kBlock) void k_mvc_apply(MvcArgs A, int K, int dir,
         for (int i = 0; i < Msg<D>::NT; i++) cur.lam[i] = inc.v[M::oC + i];
     }
     if (l0 >= A.nlinks) return;
+    const bool store_msgs = (flags & 2) != 0, write_marg = (flags & 1) != 0;
     if (dir > 0) {
 #pragma unroll 1
         for (int k = 0; k < K; k++) {
             const int l = l0 + k;
             if (l >= A.nlinks) break;
-            Msg<D> in = msg_load<D>(A.side, A.npos, A.link_pos[l]);
+            const int64_t il = il0 + (int64_t)k * kBlock;
+            Msg<D> in = msg_load<D>(A.side_l, A.il_stride, il);
             if (!A.head_fwd[l]) msg_add<D>(in, cur);
             cur = mv_rule<D, false>(in, mvc_tab<D, GT>(A, tab_s, A.tab_fwd[l]));
-            if (!__builtin_isnan(cur.lam[0])) msg_store<D>(f2v, A.nslots, A.to_slot[l], cur);
+            msg_store<D>(A.alpha, A.il_stride, il, cur);
+            if (store_msgs && !__builtin_isnan(cur.lam[0])) msg_store<D>(f2v, A.nslots, A.to_slot[l], cur);
         }
     } else {
 #pragma unroll 1
         for (int k = K - 1; k >= 0; k--) {
             const int l = l0 + k;
             if (l >= A.nlinks) continue;
+            const int64_t il = il0 + (int64_t)k * kBlock;
             const int p = A.link_pos[l];
-            Msg<D> in = msg_load<D>(A.side, A.npos, p + 1);      // what the right variable hears from everybody but this link
+            Msg<D> in = msg_load<D>(A.side_r, A.il_stride, il);      // what the right variable hears from everybody but this link
             if (!A.head_bwd[l]) msg_add<D>(in, cur);
             if (write_marg) {
-                Msg<D> tot = msg_load<D>(f2v, A.nslots, A.to_slot[l]);   // alpha_l, stored by the forward launch
+                Msg<D> tot = msg_load<D>(A.alpha, A.il_stride, il);   // alpha_l, stored by the forward launch
                 msg_add<D>(tot, in);
-                marg_store<D>(marg, A.nv, A.pos_var[p + 1], tot);
+                marg_store<D>(A.marg_il, A.il_stride, il, tot);       // interleaved: k_mvc_marg_out moves it to the variable's place
             }
             cur = mv_rule<D, false>(in, mvc_tab<D, GT>(A, tab_s, A.tab_bwd[l]));
-            if (!__builtin_isnan(cur.lam[0])) msg_store<D>(f2v, A.nslots, A.from_slot[l], cur);
+            if (store_msgs && !__builtin_isnan(cur.lam[0])) msg_store<D>(f2v, A.nslots, A.from_slot[l], cur);
             if (write_marg && A.head_fwd[l]) {
                 Msg<D> tot = msg_load<D>(A.side, A.npos, p);
                 msg_add<D>(tot, cur);
@@ -377,31 +399,70 @@ __global__ __launch_bounds__(kBlock) void k_mvc_side(int npos, int64_t nslots, i
     if (write_marg && s0 < 0 && s1 < 0) marg_store<D>(marg, nv, v, acc);
 }
 
+// marginals from the interleaved buffer of the backward walk to marg[c][variable]: a transpose through LDS, one component at a
+// time, so that both the reads (interleaved order) and the writes (variable order) are contiguous runs
+__global__ __launch_bounds__(kBlock) void k_mvc_marg_out(int nlinks, int nc, int K, int64_t il_stride, int nv, const int32_t *__restrict__ link_pos,
+                                                         const int32_t *__restrict__ pos_var, const double *__restrict__ marg_il,
+                                                         double *__restrict__ marg) {
+    extern __shared__ double buf[];          // [K][kBlock + 1]
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * kBlock * K;
+    for (int c = 0; c < nc; c++) {
+        for (int k = 0; k < K; k++) buf[k * (kBlock + 1) + tid] = marg_il[(int64_t)c * il_stride + base + (int64_t)k * kBlock + tid];
+        __syncthreads();
+        for (int e = tid; e < kBlock * K; e += kBlock) {
+            const int64_t l = base + e;      // link number: thread e / K, step e % K
+            if (l < nlinks) __builtin_nontemporal_store(buf[(e % K) * (kBlock + 1) + e / K], &marg[(int64_t)c * nv + pos_var[link_pos[l] + 1]]);
+        }
+        __syncthreads();
+    }
+}
+
+// the side sums of each link's two end variables, in the interleaved order the scan kernels read
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_mvc_side_links(int nlinks, int npos, int K, int64_t il_stride, const int32_t *__restrict__ link_pos,
+                                                           const double *__restrict__ side, double *__restrict__ side_l, double *__restrict__ side_r) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // interleaved index: consecutive threads write consecutive addresses
+    const int tile = (int)(i / ((int64_t)kBlock * K)), r = (int)(i % ((int64_t)kBlock * K)), k = r / kBlock, th = r % kBlock;
+    const int l = (tile * kBlock + th) * K + k;
+    if (l >= nlinks) return;
+    const int p = link_pos[l];
+    msg_store<D>(side_l, il_stride, (int)i, msg_load<D>(side, npos, p));
+    msg_store<D>(side_r, il_stride, (int)i, msg_load<D>(side, npos, p + 1));
+}
+
 // ------------------------------------------------------------------------------------------------ host side
-// links per thread of the scan; CX_MVC_K overrides (read per sweep: the tests run several values in one process)
+// links per thread of the scan; CX_MVC_K overrides.  Read when the chains are (re)built: the interleaved buffers are laid out for it.
 int mvc_links_per_thread() {
     const char *e = getenv("CX_MVC_K");
     const int v = e ? atoi(e) : 0;
-    return v >= 1 && v <= 64 ? v : 2;
+    return v >= 1 && v <= 64 ? v : 4;
 }
 
-static int64_t mvc_ntiles(int64_t nlinks, int K) {
+int64_t mvc_ntiles(int64_t nlinks, int K) {
     const int64_t per = (int64_t)kBlock * K;
-    return (nlinks + per - 1) / per;
+    return std::max<int64_t>((nlinks + per - 1) / per, 1);
 }
 
-// tile totals of both directions, sized for one link per thread (the most tiles any K needs)
-size_t mvc_totals_doubles(int dim, int64_t nlinks) {
+size_t mvc_totals_doubles(int dim, int64_t nlinks, int K) {
     const int nd = 2 * (dim * (dim + 1) / 2) + dim * dim + 2 * dim + 1;
-    return (size_t)2 * (size_t)std::max<int64_t>(mvc_ntiles(nlinks, 1), 1) * nd;
+    return (size_t)2 * (size_t)mvc_ntiles(nlinks, K) * nd;
 }
 
+// side sums by position, then by link in the interleaved order (after data, stored messages or rule tables changed)
 void mvc_launch_side(cx_handle *h, bool write_marg) {
-    const int npos = (int)h->chain_npos;
+    const int npos = (int)h->chain_npos, nlinks = (int)h->chain_nlinks, K = h->mvc_K;
     if (npos == 0) return;
     const dim3 g((npos + kBlock - 1) / kBlock), b(kBlock);
-#define CX_MVC(DD) hipLaunchKernelGGL((k_mvc_side<DD>), g, b, 0, h->stream, npos, h->nslots, (int)h->nv, h->d_chain_pos_var, h->d_chain_skip0, \
-                                      h->d_chain_skip1, h->d_vbase, h->d_vinfo, h->d_mv_f2v, h->d_mvc_side, h->d_mv_marg, write_marg ? 1 : 0)
+    const int64_t S = mvc_ntiles(nlinks, K) * kBlock * K;
+    const dim3 gl((unsigned)(S / kBlock));
+#define CX_MVC(DD)                                                                                                                           \
+    do {                                                                                                                                     \
+        hipLaunchKernelGGL((k_mvc_side<DD>), g, b, 0, h->stream, npos, h->nslots, (int)h->nv, h->d_chain_pos_var, h->d_chain_skip0,          \
+                           h->d_chain_skip1, h->d_vbase, h->d_vinfo, h->d_mv_f2v, h->d_mvc_side, h->d_mv_marg, write_marg ? 1 : 0);          \
+        if (nlinks) hipLaunchKernelGGL((k_mvc_side_links<DD>), gl, b, 0, h->stream, nlinks, npos, K, S, h->d_chain_link_pos, h->d_mvc_side,  \
+                                       h->d_mvc_side_l, h->d_mvc_side_r);                                                                    \
+    } while (0)
     if (h->cfg.dim == 2) CX_MVC(2);
     else if (h->cfg.dim == 3) CX_MVC(3);
     else CX_MVC(4);
@@ -409,24 +470,31 @@ void mvc_launch_side(cx_handle *h, bool write_marg) {
 }
 
 template <int D, bool GT>
-static void mvc_launch_t(cx_handle *h, const MvcArgs &A, bool write_marg) {
-    const int K = mvc_links_per_thread();
+static void mvc_launch_t(cx_handle *h, const MvcArgs &A, int K, int flags, bool scan) {
     const int ntiles = (int)mvc_ntiles(A.nlinks, K);
-    hipLaunchKernelGGL((k_mvc_totals<D, GT>), dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, K, h->d_mvc_totals);
-    hipLaunchKernelGGL((k_mvc_scan_totals<D>), dim3(2), dim3(kBlock), 0, h->stream, ntiles, h->d_mvc_totals);
-    hipLaunchKernelGGL((k_mvc_apply<D, GT>), dim3(ntiles), dim3(kBlock), 0, h->stream, A, K, 1, h->d_mvc_totals, h->d_mv_f2v, h->d_mv_marg, 0);
-    hipLaunchKernelGGL((k_mvc_apply<D, GT>), dim3(ntiles), dim3(kBlock), 0, h->stream, A, K, -1, h->d_mvc_totals, h->d_mv_f2v, h->d_mv_marg,
-                       write_marg ? 1 : 0);
+    if (scan) {
+        hipLaunchKernelGGL((k_mvc_totals<D, GT>), dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, K, h->d_mvc_totals);
+        hipLaunchKernelGGL((k_mvc_scan_totals<D>), dim3(2), dim3(kBlock), 0, h->stream, ntiles, h->d_mvc_totals);
+    }
+    hipLaunchKernelGGL((k_mvc_apply<D, GT>), dim3(ntiles), dim3(kBlock), 0, h->stream, A, K, 1, h->d_mvc_totals, h->d_mv_f2v, h->d_mv_marg, flags & 2);
+    hipLaunchKernelGGL((k_mvc_apply<D, GT>), dim3(ntiles), dim3(kBlock), 0, h->stream, A, K, -1, h->d_mvc_totals, h->d_mv_f2v, h->d_mv_marg, flags);
+    if (flags & 1)
+        hipLaunchKernelGGL(k_mvc_marg_out, dim3(ntiles), dim3(kBlock), (size_t)K * (kBlock + 1) * sizeof(double), h->stream, A.nlinks, D + D * (D + 1) / 2, K,
+                           A.il_stride, A.nv, A.link_pos, A.pos_var, A.marg_il, h->d_mv_marg);
 }
 
-// all forward and backward chain messages (into d_mv_f2v) and, with write_marg, the chain variables' marginals
-void mvc_launch_scan(cx_handle *h, bool write_marg) {
+// One sweep: all forward and backward chain messages and, with write_marg, the chain variables' marginals.
+// store_msgs: the messages also go to their slots of d_mv_f2v.  scan = false: the tile carries of the last sweep are still valid
+// (nothing changed since): only the two apply launches run — how the messages are materialised on demand.
+void mvc_launch_scan(cx_handle *h, bool write_marg, bool store_msgs, bool scan) {
     if (h->chain_nlinks == 0) return;
+    const int K = h->mvc_K;
     MvcArgs A{(int)h->chain_nlinks, (int)h->chain_npos, (int)h->nv, (int)(2 * h->ptab_sets), h->nslots, h->d_chain_link_pos, h->d_chain_from,
               h->d_chain_to, h->d_chain_tab_fwd, h->d_chain_tab_bwd, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_pos_var,
-              h->d_mvc_side, h->d_ptab};
+              h->d_mvc_side, h->d_mvc_side_l, h->d_mvc_side_r, h->d_mvc_alpha, h->d_mvc_marg_il, mvc_ntiles(h->chain_nlinks, K) * kBlock * K, h->d_ptab};
     const bool gt = A.ntab > kMvcTabLds;
-#define CX_MVC(DD) do { if (gt) mvc_launch_t<DD, true>(h, A, write_marg); else mvc_launch_t<DD, false>(h, A, write_marg); } while (0)
+    const int flags = (write_marg ? 1 : 0) | (store_msgs ? 2 : 0);
+#define CX_MVC(DD) do { if (gt) mvc_launch_t<DD, true>(h, A, K, flags, scan); else mvc_launch_t<DD, false>(h, A, K, flags, scan); } while (0)
     if (h->cfg.dim == 2) CX_MVC(2);
     else if (h->cfg.dim == 3) CX_MVC(3);
     else CX_MVC(4);

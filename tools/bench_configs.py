@@ -136,6 +136,37 @@ def mv(d, T, steps):
     return out
 
 
+def mv_scan(d, T, steps, ks=(None,)):
+    """the chain-scan schedule for dim 2..4 (cx_mvchain.hip): ONE sweep = the exact smoother = one reference update_marginals!
+    (5T-4 message computations + T marginals).  ks: values of CX_MVC_K (links per thread) to time; None = the default."""
+    model = cx.synth.lgssm_chain(T, d=d, seed=1234)
+    dev = cx.DeviceGraph(dim=d, schedule=L.SCHED_CHAIN_SCAN)
+    cx.synth.load_into_device(model, dev)
+    st = dev.stats()
+    payload = (d + d * d) * 8
+    ref_upd = 5 * T - 4
+    out = []
+    for k in ks:
+        if k is None:
+            os.environ.pop("CX_MVC_K", None)
+        else:
+            os.environ["CX_MVC_K"] = str(k)
+        dev.sweep(2)
+        dt = timed(dev, lambda: dev.sweep(1), steps, 3)
+        tr = counter_traffic(["k_mvc_totals", "k_mvc_scan_totals", "k_mvc_apply"]) if k is None else None
+        alg = ref_upd * 2 * payload
+        achieved = (tr[0] if tr else alg) / dt / 1e9
+        out.append({"config": "C3-scan" if d == 4 else f"d{d}-scan", "links_per_thread": k,
+                    "workload": f"d={d} linear-Gaussian chain T={T} ({st['n_edges']} edges), chain-scan schedule: exact forward/backward in one sweep",
+                    "ms_per_sweep": dt * 1e3, "reference_updates_per_sweep": ref_upd, "updates_per_s": ref_upd / dt,
+                    "roofline": roofline("hbm", achieved, HBM_PEAK_GBS, "GB/s", tr[0] if tr else None, kernel="k_mvc_totals + k_mvc_scan_totals + 2 x k_mvc_apply",
+                                         basis="counter traffic of the sweep's four launches / sweep time" if tr else "algorithmic bytes / sweep time",
+                                         traffic_source=tr[1] if tr else None, algorithmic_bytes_per_sweep=alg,
+                                         frac_algorithmic=alg / dt / 1e9 / HBM_PEAK_GBS)})
+    os.environ.pop("CX_MVC_K", None)
+    return out
+
+
 def vmp(n=1_000_000, only=None):
     """one variational iteration (all latent states, then both precisions) of the reference's SSM with
     unknown noise precisions, n states: 2n - 1 three-way factors, 6n - 3 edges."""
@@ -165,6 +196,11 @@ if __name__ == "__main__":
     for w in which:
         if w.startswith("vmp"):
             for r in vmp(only=w[4:] or None):          # vmp | vmp_structured | vmp_mean_field
+                print(json.dumps(r), flush=True)
+            continue
+        if w.startswith("c3scan"):                       # c3scan | c3scan:1,2,4,8 (links per thread)
+            ks = tuple(int(x) for x in w.split(":")[1].split(",")) if ":" in w else (None,)
+            for r in mv_scan(4, 1_000_000, 30, ks):
                 print(json.dumps(r), flush=True)
             continue
         r = c2() if w == "c2" else (mv(4, 1_000_000, 30) if w == "c3" else mv(64, 100_000, 20))
