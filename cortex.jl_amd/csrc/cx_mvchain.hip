@@ -16,16 +16,20 @@
 // (B = 0), so every prefix of a path is a constant map and yields the message (c, C) directly; a constant second operand also
 // ends a segment of the segmented scan.
 //
-// Work decomposition.  A thread owns K consecutive links: it composes their K maps (thread total), the workgroup scans the
-// thread totals (wave shuffles + LDS across waves), a one-workgroup kernel scans the tile totals; the apply kernels recompute
-// the thread totals, obtain every thread's incoming message from its exclusive prefix and then WALK the K links with the
-// ordinary rule of the flooding sweep (one Cholesky per message) — map composition is only paid per thread, not per link.
-// Forward walk: alpha into the right end of every link.  Backward walk (second launch, reads the alphas back): beta into the
-// left end, and the marginal of every chain variable = side + alpha + beta, in moment form.
+// Work decomposition (four launches per sweep).  A thread owns K consecutive links.
+//   k_mvc_totals      composes the K maps of every thread (thread total), scans the thread totals over the workgroup (wave shuffles
+//                     + LDS across waves) and stores each thread's exclusive prefix within its tile, and the tile total;
+//                     forward and backward direction in one grid
+//   k_mvc_scan_totals one workgroup per direction: exclusive scan of the tile totals
+//   k_mvc_apply       tile carry ∘ thread prefix = the message entering the thread's first link; then the thread WALKS its K links
+//                     with the ordinary rule of the flooding sweep (one Cholesky per message) — map composition is paid once per
+//                     thread and scan step, not per link.  The forward walk leaves alpha (into the right end of every link), the
+//                     backward walk gamma (what the right end hears from everybody but the link); both directions in one grid
+//   k_mvc_marg_out    marginal of a link's right variable = alpha + gamma, to moment form, transposed through LDS into marg[c][v]
 // Results are re-associated relative to the sequential schedule: they agree with it to rounding, not bitwise.
 //
 // Memory layout.  "Thread owns K consecutive links" would make every access to a chain-ordered array a stride-K access.  The
-// arrays the sweep streams — the side sums of a link's two ends and the alphas — are therefore kept in a thread-interleaved
+// arrays the sweep streams — the side sums of a link's two ends, alpha and gamma — are therefore kept in a thread-interleaved
 // order IL(l) = tile * 256 K + (l mod K) * 256 + thread: what the 256 threads of a workgroup touch in step k of their walks is
 // one contiguous run of 2 KB per component.  Messages go to the SELL slots of cx_mv.hip only on demand (cx_get_messages, a
 // checkpoint, a residual: mvc_launch_scan(..., store_msgs)), like the variable→factor messages of the fused sweep; the
@@ -181,17 +185,12 @@ struct MvcArgs {
     const int32_t *pos_var;
     const double *side;                  // [nc][npos]: sum of the non-chain messages into each chain variable, by position
     const double *side_l, *side_r;       // [nc][il_stride]: the same for the left / right variable of link l, at IL(l)
-    double *alpha;                       // [nc][il_stride]: the forward message link l produces, at IL(l)
-    double *marg_il;                     // [nc][il_stride]: the marginal of link l's right variable (moment form), at IL(l)
-    int64_t il_stride;                   // ntiles * 256 * K
+    double *alpha, *gamma;               // [nc][il_stride] at IL(l): the forward message link l produces; what its right variable hears
+                                         // from everybody but the link (side + the backward message of the next link)
+    double *prefix;                      // [2][ND + 1][nthreads]: every thread's exclusive prefix within its tile, per direction
+    int64_t il_stride;                   // ntiles * 256 * K = K * nthreads
     const double *ptab;                  // [ntab][3][D*D]
 };
-
-// thread-interleaved index of link l = (tile * 256 + thread) * K + k
-__device__ __forceinline__ int64_t mvc_il(int l, int K) {
-    const int th = l / K, k = l - th * K;
-    return (int64_t)(th / kBlock) * kBlock * K + (int64_t)k * kBlock + (th % kBlock);
-}
 
 constexpr int kMvcTabLds = 16;           // rule tables (parameter set x direction) kept in LDS; graphs with more read them from memory
 
@@ -253,6 +252,22 @@ __device__ __forceinline__ void mvc_load_tabs(const MvcArgs &A, double *tab_s, i
     __syncthreads();
 }
 
+// a thread's map to / from the prefix array: component-major over the threads of the grid, so that a wave's access is contiguous
+template <int D>
+__device__ __forceinline__ void prefix_store(double *__restrict__ p, int64_t nthreads, int64_t gid, const CMap<D> &x) {
+#pragma unroll
+    for (int i = 0; i < CMap<D>::ND; i++) p[(int64_t)i * nthreads + gid] = x.v[i];
+    p[(int64_t)CMap<D>::ND * nthreads + gid] = (double)x.flags;
+}
+template <int D>
+__device__ __forceinline__ CMap<D> prefix_load(const double *__restrict__ p, int64_t nthreads, int64_t gid) {
+    CMap<D> r;
+#pragma unroll
+    for (int i = 0; i < CMap<D>::ND; i++) r.v[i] = p[(int64_t)i * nthreads + gid];
+    r.flags = (int)p[(int64_t)CMap<D>::ND * nthreads + gid];
+    return r;
+}
+
 // grid (ntiles, 2): blockIdx.y = 0 forward, 1 backward.  totals[dir][pos] in the direction's scan order (backward: tile ntiles-1 first)
 template <int D, bool GT>
 __global__ __launch_bounds__(kBlock) void k_mvc_totals(MvcArgs A, int K, double *__restrict__ totals) {
@@ -261,9 +276,11 @@ __global__ __launch_bounds__(kBlock) void k_mvc_totals(MvcArgs A, int K, double 
     __shared__ double wt[(kBlock / 64) * E];
     const int tid = threadIdx.x, dir = blockIdx.y ? -1 : 1, ntiles = gridDim.x;
     if (!GT) mvc_load_tabs<D>(A, tab_s, tid);
-    CMap<D> t = mvc_thread_total<D, GT>(A, tab_s, (blockIdx.x * kBlock + tid) * K, (int64_t)blockIdx.x * kBlock * K + tid, K, dir);
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + tid, nthreads = (int64_t)ntiles * kBlock;
+    CMap<D> t = mvc_thread_total<D, GT>(A, tab_s, (int)gid * K, (int64_t)blockIdx.x * kBlock * K + tid, K, dir);
     CMap<D> total = cmap_identity<D>();
     mvc_wg_scan<D, true>(t, total, wt, tid, dir);
+    prefix_store<D>(A.prefix + (size_t)blockIdx.y * E * nthreads, nthreads, gid, t);
     const int pos = dir > 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;
     if (tid == (dir > 0 ? kBlock - 1 : 0)) cmap_store<D>(totals + ((size_t)blockIdx.y * ntiles + pos) * E, total);
 }
@@ -311,26 +328,24 @@ __device__ __forceinline__ void marg_store(double *__restrict__ marg, int64_t nv
     for (int i = 0; i < Msg<D>::NT; i++) __builtin_nontemporal_store(mo.lam[i], &marg[(int64_t)(D + i) * nv + v]);
 }
 
-// One direction per launch (dir = +1 first: the backward launch reads the alphas it stored).
-// Forward: alpha_l into the interleaved buffer.  Backward: the marginal of the right variable of every link (side + alpha_l +
-// beta of the next link) and of the left variable of a path's first link.  flags & 2: alpha_l / beta_l also go to their SELL
-// slots f2v[to_slot[l]] / f2v[from_slot[l]].
+// grid (ntiles, 2): the forward and the backward walks are independent of each other.
+// flags & 1: marginals are wanted (the backward walk writes those of the first variable of every path itself; all others come
+// from alpha + gamma in k_mvc_marg_out).  flags & 2: alpha_l / beta_l also go to their SELL slots f2v[to_slot[l]] / f2v[from_slot[l]].
 template <int D, bool GT>
-__global__ __launch_bounds__(kBlock) void k_mvc_apply(MvcArgs A, int K, int dir, const double *__restrict__ excl, double *__restrict__ f2v,
-                                                      double *__restrict__ marg, int flags /* 1: marginals, 2: messages into f2v */) {
+__global__ __launch_bounds__(kBlock) void k_mvc_apply(MvcArgs A, int K, const double *__restrict__ excl, double *__restrict__ f2v,
+                                                      double *__restrict__ marg, int flags) {
     constexpr int E = CMap<D>::ND + 1;
     using M = CMap<D>;
     __shared__ double tab_s[GT ? 1 : kMvcTabLds * 3 * D * D];
-    __shared__ double wt[(kBlock / 64) * E];
-    const int tid = threadIdx.x, ntiles = gridDim.x;
+    const int tid = threadIdx.x, ntiles = gridDim.x, dir = blockIdx.y ? -1 : 1;
     if (!GT) mvc_load_tabs<D>(A, tab_s, tid);
-    const int l0 = (blockIdx.x * kBlock + tid) * K;
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + tid, nthreads = (int64_t)ntiles * kBlock;
+    const int l0 = (int)gid * K;
+    if (l0 >= A.nlinks) return;
     const int64_t il0 = (int64_t)blockIdx.x * kBlock * K + tid;
-    CMap<D> t = mvc_thread_total<D, GT>(A, tab_s, l0, il0, K, dir);
-    CMap<D> unused;
-    mvc_wg_scan<D, false>(t, unused, wt, tid, dir);
     const int pos = dir > 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;
-    const CMap<D> inc = cmap_compose<D>(cmap_load<D>(excl + ((size_t)(dir > 0 ? 0 : 1) * ntiles + pos) * E), t);
+    const CMap<D> inc = cmap_compose<D>(cmap_load<D>(excl + ((size_t)blockIdx.y * ntiles + pos) * E),
+                                        prefix_load<D>(A.prefix + (size_t)blockIdx.y * E * nthreads, nthreads, gid));
     // every prefix that reaches back to the first link of a path is a constant map: the message it produces from nothing
     Msg<D> cur = msg_nan<D>();
     if (inc.flags & kMapSeg) {
@@ -339,7 +354,6 @@ __global__ __launch_bounds__(kBlock) void k_mvc_apply(MvcArgs A, int K, int dir,
 #pragma unroll
         for (int i = 0; i < Msg<D>::NT; i++) cur.lam[i] = inc.v[M::oC + i];
     }
-    if (l0 >= A.nlinks) return;
     const bool store_msgs = (flags & 2) != 0, write_marg = (flags & 1) != 0;
     if (dir > 0) {
 #pragma unroll 1
@@ -359,22 +373,59 @@ __global__ __launch_bounds__(kBlock) void k_mvc_apply(MvcArgs A, int K, int dir,
             const int l = l0 + k;
             if (l >= A.nlinks) continue;
             const int64_t il = il0 + (int64_t)k * kBlock;
-            const int p = A.link_pos[l];
             Msg<D> in = msg_load<D>(A.side_r, A.il_stride, il);      // what the right variable hears from everybody but this link
             if (!A.head_bwd[l]) msg_add<D>(in, cur);
-            if (write_marg) {
-                Msg<D> tot = msg_load<D>(A.alpha, A.il_stride, il);   // alpha_l, stored by the forward launch
-                msg_add<D>(tot, in);
-                marg_store<D>(A.marg_il, A.il_stride, il, tot);       // interleaved: k_mvc_marg_out moves it to the variable's place
-            }
+            msg_store<D>(A.gamma, A.il_stride, il, in);
             cur = mv_rule<D, false>(in, mvc_tab<D, GT>(A, tab_s, A.tab_bwd[l]));
             if (store_msgs && !__builtin_isnan(cur.lam[0])) msg_store<D>(f2v, A.nslots, A.from_slot[l], cur);
-            if (write_marg && A.head_fwd[l]) {
+            if (write_marg && A.head_fwd[l]) {                        // the first variable of a path hears no alpha
+                const int p = A.link_pos[l];
                 Msg<D> tot = msg_load<D>(A.side, A.npos, p);
                 msg_add<D>(tot, cur);
                 marg_store<D>(marg, A.nv, A.pos_var[p], tot);
             }
         }
+    }
+}
+
+// Marginal of every link's right variable: (alpha + gamma) to moment form, then from the interleaved order of the walks to
+// marg[c][variable] through LDS.  A tile goes through in slabs of W = 512 / K threads (all K steps of each: <= 512 links, 57 KB
+// for d = 4): the reads are runs of W doubles per step and component, the writes runs of W K variables per component.
+__host__ __device__ inline int mvc_slab_threads(int K) { return K >= 512 ? 1 : (512 / K > kBlock ? kBlock : 512 / K); }
+__host__ __device__ inline int mvc_slab_pitch(int K) { return mvc_slab_threads(K) + (((K & (K - 1)) == 0 && K <= 32) ? 32 / K : 1); }   // conflict-free column reads for K | 32
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_mvc_marg_out(int nlinks, int K, int64_t il_stride, int nv, const int32_t *__restrict__ link_pos,
+                                                         const int32_t *__restrict__ pos_var, const double *__restrict__ alpha,
+                                                         const double *__restrict__ gamma, double *__restrict__ marg) {
+    constexpr int NC = Msg<D>::NC;
+    extern __shared__ double buf[];          // [NC][K][Wp]
+    const int tid = threadIdx.x, W = mvc_slab_threads(K), Wp = mvc_slab_pitch(K);
+    const int64_t base = (int64_t)blockIdx.x * kBlock * K;      // first link of the tile == its first interleaved index
+    for (int t0 = 0; t0 < kBlock; t0 += W) {
+        const int wn = min(W, kBlock - t0), nitems = wn * K;
+        for (int i = tid; i < nitems; i += kBlock) {
+            const int k = i / wn, tt = i - k * wn;
+            if (base + (int64_t)(t0 + tt) * K + k >= nlinks) continue;
+            const int64_t il = base + (int64_t)k * kBlock + t0 + tt;
+            Msg<D> tot = msg_load<D>(alpha, il_stride, il);
+            msg_add<D>(tot, msg_load<D>(gamma, il_stride, il));
+            const Msg<D> mo = mv_to_moment<D>(tot);
+#pragma unroll
+            for (int c = 0; c < D; c++) buf[(c * K + k) * Wp + tt] = mo.eta[c];
+#pragma unroll
+            for (int c = 0; c < Msg<D>::NT; c++) buf[((D + c) * K + k) * Wp + tt] = mo.lam[c];
+        }
+        __syncthreads();
+        for (int e = tid; e < nitems; e += kBlock) {
+            const int64_t l = base + (int64_t)t0 * K + e;       // links in chain order: thread t0 + e / K, step e % K
+            if (l >= nlinks) break;
+            const int64_t v = pos_var[link_pos[l] + 1];
+            const int src = (e % K) * Wp + e / K;
+#pragma unroll
+            for (int c = 0; c < NC; c++) __builtin_nontemporal_store(buf[c * K * Wp + src], &marg[(int64_t)c * nv + v]);
+        }
+        __syncthreads();
     }
 }
 
@@ -399,25 +450,6 @@ __global__ __launch_bounds__(kBlock) void k_mvc_side(int npos, int64_t nslots, i
     if (write_marg && s0 < 0 && s1 < 0) marg_store<D>(marg, nv, v, acc);
 }
 
-// marginals from the interleaved buffer of the backward walk to marg[c][variable]: a transpose through LDS, one component at a
-// time, so that both the reads (interleaved order) and the writes (variable order) are contiguous runs
-__global__ __launch_bounds__(kBlock) void k_mvc_marg_out(int nlinks, int nc, int K, int64_t il_stride, int nv, const int32_t *__restrict__ link_pos,
-                                                         const int32_t *__restrict__ pos_var, const double *__restrict__ marg_il,
-                                                         double *__restrict__ marg) {
-    extern __shared__ double buf[];          // [K][kBlock + 1]
-    const int tid = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * kBlock * K;
-    for (int c = 0; c < nc; c++) {
-        for (int k = 0; k < K; k++) buf[k * (kBlock + 1) + tid] = marg_il[(int64_t)c * il_stride + base + (int64_t)k * kBlock + tid];
-        __syncthreads();
-        for (int e = tid; e < kBlock * K; e += kBlock) {
-            const int64_t l = base + e;      // link number: thread e / K, step e % K
-            if (l < nlinks) __builtin_nontemporal_store(buf[(e % K) * (kBlock + 1) + e / K], &marg[(int64_t)c * nv + pos_var[link_pos[l] + 1]]);
-        }
-        __syncthreads();
-    }
-}
-
 // the side sums of each link's two end variables, in the interleaved order the scan kernels read
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_mvc_side_links(int nlinks, int npos, int K, int64_t il_stride, const int32_t *__restrict__ link_pos,
@@ -432,11 +464,16 @@ __global__ __launch_bounds__(kBlock) void k_mvc_side_links(int nlinks, int npos,
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-// links per thread of the scan; CX_MVC_K overrides.  Read when the chains are (re)built: the interleaved buffers are laid out for it.
-int mvc_links_per_thread() {
+// links per thread of the scan; CX_MVC_K overrides.  Chosen when the chains are (re)built: the interleaved buffers are laid out for it.
+// Long chains: 16 (map compositions per link fall as 1 + 9 / K; the walks are one rule per link whatever K); short chains fewer,
+// so that the grid still has a few workgroups per compute unit.
+int mvc_links_per_thread(int64_t nlinks) {
     const char *e = getenv("CX_MVC_K");
     const int v = e ? atoi(e) : 0;
-    return v >= 1 && v <= 64 ? v : 4;
+    if (v >= 1 && v <= 32) return v;
+    int64_t k = 1;
+    while (k < 16 && 2 * k <= nlinks / ((int64_t)kBlock * 128)) k *= 2;      // a power of two (the marginal transpose's LDS reads are conflict-free then)
+    return (int)k;
 }
 
 int64_t mvc_ntiles(int64_t nlinks, int K) {
@@ -444,10 +481,10 @@ int64_t mvc_ntiles(int64_t nlinks, int K) {
     return std::max<int64_t>((nlinks + per - 1) / per, 1);
 }
 
-size_t mvc_totals_doubles(int dim, int64_t nlinks, int K) {
-    const int nd = 2 * (dim * (dim + 1) / 2) + dim * dim + 2 * dim + 1;
-    return (size_t)2 * (size_t)mvc_ntiles(nlinks, K) * nd;
-}
+static int mvc_map_doubles(int dim) { return 2 * (dim * (dim + 1) / 2) + dim * dim + 2 * dim + 1; }
+
+size_t mvc_totals_doubles(int dim, int64_t nlinks, int K) { return (size_t)2 * (size_t)mvc_ntiles(nlinks, K) * mvc_map_doubles(dim); }
+size_t mvc_prefix_doubles(int dim, int64_t nlinks, int K) { return (size_t)2 * (size_t)mvc_ntiles(nlinks, K) * kBlock * mvc_map_doubles(dim); }
 
 // side sums by position, then by link in the interleaved order (after data, stored messages or rule tables changed)
 void mvc_launch_side(cx_handle *h, bool write_marg) {
@@ -476,22 +513,23 @@ static void mvc_launch_t(cx_handle *h, const MvcArgs &A, int K, int flags, bool 
         hipLaunchKernelGGL((k_mvc_totals<D, GT>), dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, K, h->d_mvc_totals);
         hipLaunchKernelGGL((k_mvc_scan_totals<D>), dim3(2), dim3(kBlock), 0, h->stream, ntiles, h->d_mvc_totals);
     }
-    hipLaunchKernelGGL((k_mvc_apply<D, GT>), dim3(ntiles), dim3(kBlock), 0, h->stream, A, K, 1, h->d_mvc_totals, h->d_mv_f2v, h->d_mv_marg, flags & 2);
-    hipLaunchKernelGGL((k_mvc_apply<D, GT>), dim3(ntiles), dim3(kBlock), 0, h->stream, A, K, -1, h->d_mvc_totals, h->d_mv_f2v, h->d_mv_marg, flags);
-    if (flags & 1)
-        hipLaunchKernelGGL(k_mvc_marg_out, dim3(ntiles), dim3(kBlock), (size_t)K * (kBlock + 1) * sizeof(double), h->stream, A.nlinks, D + D * (D + 1) / 2, K,
-                           A.il_stride, A.nv, A.link_pos, A.pos_var, A.marg_il, h->d_mv_marg);
+    hipLaunchKernelGGL((k_mvc_apply<D, GT>), dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, K, h->d_mvc_totals, h->d_mv_f2v, h->d_mv_marg, flags);
+    if (flags & 1) {
+        hipLaunchKernelGGL((k_mvc_marg_out<D>), dim3(ntiles), dim3(kBlock), (size_t)Msg<D>::NC * K * mvc_slab_pitch(K) * sizeof(double), h->stream, A.nlinks, K,
+                           A.il_stride, A.nv, A.link_pos, A.pos_var, A.alpha, A.gamma, h->d_mv_marg);
+    }
 }
 
 // One sweep: all forward and backward chain messages and, with write_marg, the chain variables' marginals.
-// store_msgs: the messages also go to their slots of d_mv_f2v.  scan = false: the tile carries of the last sweep are still valid
-// (nothing changed since): only the two apply launches run — how the messages are materialised on demand.
+// store_msgs: the messages also go to their slots of d_mv_f2v.  scan = false: the thread prefixes and tile carries of the last sweep
+// are still valid (nothing changed since): only the walks run — how the messages are materialised on demand.
 void mvc_launch_scan(cx_handle *h, bool write_marg, bool store_msgs, bool scan) {
     if (h->chain_nlinks == 0) return;
     const int K = h->mvc_K;
     MvcArgs A{(int)h->chain_nlinks, (int)h->chain_npos, (int)h->nv, (int)(2 * h->ptab_sets), h->nslots, h->d_chain_link_pos, h->d_chain_from,
               h->d_chain_to, h->d_chain_tab_fwd, h->d_chain_tab_bwd, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_pos_var,
-              h->d_mvc_side, h->d_mvc_side_l, h->d_mvc_side_r, h->d_mvc_alpha, h->d_mvc_marg_il, mvc_ntiles(h->chain_nlinks, K) * kBlock * K, h->d_ptab};
+              h->d_mvc_side, h->d_mvc_side_l, h->d_mvc_side_r, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix,
+              mvc_ntiles(h->chain_nlinks, K) * kBlock * K, h->d_ptab};
     const bool gt = A.ntab > kMvcTabLds;
     const int flags = (write_marg ? 1 : 0) | (store_msgs ? 2 : 0);
 #define CX_MVC(DD) do { if (gt) mvc_launch_t<DD, true>(h, A, K, flags, scan); else mvc_launch_t<DD, false>(h, A, K, flags, scan); } while (0)
