@@ -20,6 +20,7 @@ from .dependencies import (AbstractDependencyResolver, DefaultDependencyResolver
 from .inference_engine import (AbstractInferenceRequestProcessor, InferenceEngine, InferenceRequestScanner,
                                request_inference_for, scan_inference_request, update_marginals)
 from .hip_processor import (Beta, Gamma, GaussianAdditive, GaussianLinear, HipProcessor, HipValue, HipVmpProcessor, HipVmpValue,
-                            NormalMeanPrecision, NormalMeanVariance, NormalPrecisionFactor)
+                            MvGaussianLinear, MvNormalMeanCovariance, MvNormalMeanPrecision, NormalMeanPrecision, NormalMeanVariance,
+                            NormalPrecisionFactor)
 
 __all__ = [n for n in dir() if not n.startswith("__")]

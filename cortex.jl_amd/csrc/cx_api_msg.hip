@@ -203,7 +203,7 @@ int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_update_batch: no graph");
     if (n == 0) return CX_OK;
     CX_REQUIRE(h, n > 0 && items, CX_ERR_INVALID_ARGUMENT, "cx_update_batch: null argument");
-    CX_REQUIRE(h, h->cfg.dim == 1, CX_ERR_UNSUPPORTED, "cx_update_batch: batched mode is implemented for dim == 1 only in this build");
+    if (h->cfg.dim > 1) { try { return mv_update_batch(h, items, n); } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_update_batch: host allocation failed"); } }
     try {
         std::vector<int32_t> buf(5 * n, 0);
         for (int64_t i = 0; i < n; i++) {

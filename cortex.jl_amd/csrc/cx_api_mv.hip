@@ -303,6 +303,78 @@ int32_t mv_ensure_chain_msgs(cx_handle *h) {
     return CX_OK;
 }
 
+// cx_update_batch for dim > 1: MessageToFactor / MessageToVariable / IndividualMarginal items (process!'s dispatch,
+// src/inference_engine.jl:479-509, on the three variants a linear-Gaussian model uses).  dim 2..4: one launch of k_batch_mv
+// (cx_mvbatch.hip).  dim 64: the items are sorted into the three kernels the sweep is made of — variable→factor sums (k_v2f64), the
+// MFMA rule on a stored variable→factor message (k_rule64w with the "stored input" flag), the point-mass rule (k_point64);
+// marginals of dim 64 are computed from the stored messages when they are read (cx_get_marginals), so a marginal item only
+// checks its variable.
+int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
+    CX_REQUIRE(h, (int64_t)h->psets.size() > h->max_pset, CX_ERR_STATE, "cx_update_batch: a factor names a parameter set that was never set (cx_set_factor_matrices)");
+    for (int64_t i = 0; i <= h->max_pset; i++)
+        CX_REQUIRE(h, !h->psets[i].empty(), CX_ERR_STATE, "cx_update_batch: parameter set " + std::to_string(i) + " was never set (cx_set_factor_matrices)");
+    int32_t rc = mv_ensure_chain_msgs(h);
+    if (rc != CX_OK) return rc;
+    const bool d64 = h->cfg.dim == 64;
+    std::vector<int32_t> rec, v2f_slots, v2f_vars, point_slots, rule_rec, slot_var;
+    if (d64) {
+        slot_var.assign(h->nslots, -1);
+        for (int64_t e = 0; e < h->ne; e++) slot_var[cx::slot_of_edge(h, e)] = h->edge_var[e];
+    } else {
+        rec.assign(5 * n, 0);
+    }
+    for (int64_t i = 0; i < n; i++) {
+        const cx_item &it = items[i];
+        int64_t idx, var, tab = 0;
+        if (it.kind == CX_ITEM_INDIVIDUAL_MARGINAL) {
+            var = idx = find_var(h, it.variable_id);
+            if (idx < 0) return fail(h, CX_ERR_NOT_FOUND, "unknown variable id " + std::to_string(it.variable_id));
+            if (d64) continue;
+        } else if (it.kind == CX_ITEM_MESSAGE_TO_FACTOR || it.kind == CX_ITEM_MESSAGE_TO_VARIABLE) {
+            const int64_t e = find_edge(h, it.variable_id, it.factor_id);
+            if (e < 0) return fail(h, CX_ERR_NOT_FOUND, "no connection between variable " + std::to_string(it.variable_id) + " and factor " + std::to_string(it.factor_id));
+            idx = cx::slot_of_edge(h, e); var = h->edge_var[e];
+            const int32_t p = h->partner[idx];
+            if (it.kind == CX_ITEM_MESSAGE_TO_VARIABLE && p >= 0) tab = h->spdir[p];      // the rule table of the SENDING slot (unmasked: any message can be asked for)
+            if (d64) {
+                if (it.kind == CX_ITEM_MESSAGE_TO_FACTOR) { v2f_slots.push_back((int32_t)idx); v2f_vars.push_back((int32_t)var); continue; }
+                if (p < 0) continue;                                                            // an opaque factor's message is the caller's to set
+                if (h->vinfo[slot_var[p]] & cx::kClamped) {
+                    if (h->vinfo[var] & cx::kClamped)
+                        return fail(h, CX_ERR_UNSUPPORTED, "cx_update_batch: dim 64 does not compute a message between two observed variables (factor " + std::to_string(it.factor_id) + ")");
+                    point_slots.push_back(p);
+                } else {
+                    rule_rec.insert(rule_rec.end(), {p, -1, -1, -1, (int32_t)tab, (int32_t)idx, 1, 0});      // flag 1: the stored variable→factor message of slot p is the input
+                }
+                continue;
+            }
+        } else {
+            return fail(h, CX_ERR_UNSUPPORTED, "cx_update_batch: dim > 1 implements MessageToFactor, MessageToVariable and IndividualMarginal items (kind " + std::to_string(it.kind) + ")");
+        }
+        rec[5 * i] = it.kind; rec[5 * i + 1] = (int32_t)idx; rec[5 * i + 2] = (int32_t)var; rec[5 * i + 3] = (int32_t)tab;
+    }
+    if (!d64) {
+        if ((rc = ensure_stage(h, 5 * n * 4)) != CX_OK) return rc;
+        CX_HIP(h, hipMemcpyAsync(h->d_stage, rec.data(), 5 * n * 4, hipMemcpyHostToDevice, h->stream));
+        cx::mv_launch_batch(h, (const int32_t *)h->d_stage, n);
+    } else {
+        const int64_t n1 = (int64_t)v2f_slots.size(), n2 = (int64_t)point_slots.size(), n3 = (int64_t)rule_rec.size() / 8;
+        if ((rc = ensure_stage(h, (2 * n1 + n2 + 8 * n3 + 4) * 4)) != CX_OK) return rc;
+        int32_t *d = (int32_t *)h->d_stage;
+        int32_t *d_s = d, *d_v = d + n1, *d_p = d + 2 * n1, *d_r = d + 2 * n1 + n2;
+        if (n1) { CX_HIP(h, hipMemcpyAsync(d_s, v2f_slots.data(), n1 * 4, hipMemcpyHostToDevice, h->stream)); CX_HIP(h, hipMemcpyAsync(d_v, v2f_vars.data(), n1 * 4, hipMemcpyHostToDevice, h->stream)); }
+        if (n2) CX_HIP(h, hipMemcpyAsync(d_p, point_slots.data(), n2 * 4, hipMemcpyHostToDevice, h->stream));
+        if (n3) CX_HIP(h, hipMemcpyAsync(d_r, rule_rec.data(), n3 * 32, hipMemcpyHostToDevice, h->stream));
+        cx::mv64_launch_v2f(h, (int)n1, d_s, d_v, h->d_mv_f2v);
+        cx::mv64_launch_point(h, (int)n2, d_p, h->d_mv_f2v, h->d_mv_f2v);
+        cx::mv64_launch_rule(h, (int)n3, d_r, h->d_mv_f2v, h->d_mv_f2v, CX_KERNEL_BATCH);
+        h->point64_dirty = true;      // a sweep recomputes the constant messages into both of its buffers
+    }
+    CX_HIP(h, hipGetLastError());
+    CX_HIP(h, hipStreamSynchronize(h->stream));      // synchronous: the host sets readiness bits next (signal.jl:232-253)
+    return CX_OK;
+}
+
 int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
     CX_REQUIRE(h, (int64_t)h->psets.size() > h->max_pset, CX_ERR_STATE, "cx_sweep: a factor names a parameter set that was never set (cx_set_factor_matrices)");
     for (int64_t i = 0; i <= h->max_pset; i++)

@@ -202,6 +202,7 @@ void mv_launch_v2f(cx_handle *h, const int32_t *d_slots, const int32_t *d_vars, 
 void mv_launch_scatter(cx_handle *h, double *dst, int64_t stride, int nc, const int32_t *d_idx, const double *d_val, int64_t n);
 void mv_launch_gather(cx_handle *h, const double *src, int64_t stride, int nc, const int32_t *d_idx, double *d_val, int64_t n);
 void mv_launch_seed(cx_handle *h, double *buf, double eta, double lam);
+void mv_launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n);   // cx_mvbatch.hip: 5 int32 per item (kind, index, variable, rule table, 0)
 void mv_launch_residual(cx_handle *h, const double *cur, const double *prev, int64_t n, double *d_out);
 bool spd_inverse(int d, const double *S, double *out);
 // d = 64 (cx_mv64.hip): message-major layout, MFMA rule kernel

@@ -1,0 +1,66 @@
+// cx_mvbatch.hip — cx_update_batch for d-dimensional messages (d = 2, 3, 4): the per-signal / per-wavefront granularity of the
+// plug-in boundary.  One work item is one process!(processor, engine, variable_id, signal) of the reference
+// (src/inference_engine.jl:479-509) on a signal whose variant is
+//   MessageToFactor      compute_message_to_factor!     (:381-389): the product of the variable's OTHER incoming factor→variable
+//                        messages, left fold in neighbour order (ascending factor id) — a sum in natural form
+//   MessageToVariable    compute_message_to_variable!   (:351-361): the linear-Gaussian factor rule on the message the factor's other
+//                        variable sent (cx_mv.hip: Cholesky + two triangular solves; a point-mass datum gives N(A y, Q) / its backward form)
+//   IndividualMarginal   compute_individual_marginal!   (:409-419): the product of ALL incoming messages, stored in moment form
+// A batch holds mutually independent signals (the host's scheduler guarantees it: one wavefront of pending signals), so the items
+// of a launch never read what another item of the same launch writes.  A result with an undefined dependency (NaN) is not stored:
+// the signal was not pending.
+// d = 64 goes through the kernels of cx_mv64.hip / cx_mv64w.hip instead (cx_api_mv.hip: mv_update_batch).
+
+#include "cx_internal.h"
+#include "cx_mv_core.h"
+
+namespace cx {
+
+// rec: 5 int32 per item — kind, index (slot of the signal's edge | local variable), local variable, rule table of the sending slot, 0
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_batch_mv(int64_t n, const int32_t *__restrict__ rec, int64_t nslots, int nv, const int32_t *__restrict__ vbase,
+                                                     const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
+                                                     const double *__restrict__ ptab, double *__restrict__ f2v, double *__restrict__ v2f,
+                                                     double *__restrict__ marg) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int kind = rec[5 * i], idx = rec[5 * i + 1], v = rec[5 * i + 2], tab = rec[5 * i + 3];
+    const int info = vinfo[v], deg = info & kDegMask, b = vbase[v];
+    if (kind == CX_ITEM_MESSAGE_TO_FACTOR) {
+        // variables of degree 1, observed variables and stand-ins have no dependencies: their message is what the caller stored
+        if (deg < 2 || (info & (kClamped | kGhost))) return;
+        Msg<D> o = msg_zero<D>();
+        for (int j = 0; j < deg; j++)
+            if (b + j * kBlock != idx) msg_add<D>(o, msg_load<D>(f2v, nslots, b + j * kBlock));
+        if (!__builtin_isnan(o.lam[0])) msg_store<D>(v2f, nslots, idx, o);
+    } else if (kind == CX_ITEM_MESSAGE_TO_VARIABLE) {
+        const int p = partner[idx];
+        if (p < 0) return;                                  // an opaque factor's message is the caller's to set
+        const Msg<D> in = msg_load<D>(v2f, nslots, p);
+        if (__builtin_isnan(in.lam[0])) return;
+        const Msg<D> r = mv_rule<D>(in, ptab + (int64_t)tab * 3 * D * D);
+        if (!__builtin_isnan(r.lam[0])) msg_store<D>(f2v, nslots, idx, r);
+    } else if (kind == CX_ITEM_INDIVIDUAL_MARGINAL) {
+        Msg<D> total = msg_zero<D>();
+        for (int j = 0; j < deg; j++) msg_add<D>(total, msg_load<D>(f2v, nslots, b + j * kBlock));
+        const bool ok = deg > 0 && !__builtin_isnan(total.lam[0]);
+        const Msg<D> mo = ok ? mv_to_moment<D>(total) : total;
+#pragma unroll
+        for (int c = 0; c < D; c++) marg[(int64_t)c * nv + v] = ok ? mo.eta[c] : __builtin_nan("");
+#pragma unroll
+        for (int c = 0; c < Msg<D>::NT; c++) marg[(int64_t)(D + c) * nv + v] = ok ? mo.lam[c] : __builtin_nan("");
+    }
+}
+
+void mv_launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n) {
+    if (n == 0) return;
+    const dim3 g((unsigned)((n + kBlock - 1) / kBlock)), b(kBlock);
+#define CX_MVB(DD) hipLaunchKernelGGL((k_batch_mv<DD>), g, b, 0, h->stream, n, d_rec, h->nslots, (int)h->nv, h->d_vbase, h->d_vinfo, h->d_partner, \
+                                      h->d_ptab, h->d_mv_f2v, h->d_mv_v2f, h->d_mv_marg)
+    if (h->cfg.dim == 2) CX_MVB(2);
+    else if (h->cfg.dim == 3) CX_MVB(3);
+    else CX_MVB(4);
+#undef CX_MVB
+}
+
+}  // namespace cx

@@ -49,6 +49,28 @@ class GaussianLinear:
     variance: float
 
 
+@dataclass(frozen=True, eq=False)
+class MvNormalMeanCovariance:
+    """d-dimensional Gaussian in moment form — what a device-computed message or marginal of a dim > 1 processor reads as."""
+    mean: Any
+    covariance: Any
+
+
+@dataclass(frozen=True, eq=False)
+class MvNormalMeanPrecision:
+    """The reference's test struct (test/runtests.jl:70-77, `MvNormalMeanPrecision(mean, precision)`); accepted by set_value."""
+    mean: Any
+    precision: Any
+
+
+@dataclass(frozen=True, eq=False)
+class MvGaussianLinear:
+    """functional_form of a 2-edge factor x_out = A x_in + N(0, Q) between d-dimensional variables; edges labelled :in / :out
+    (Connection.label, model_engine.jl:182).  Factors that share one (A, Q) object share one parameter set on the device."""
+    A: Any
+    Q: Any
+
+
 @dataclass(frozen=True)
 class Beta:
     """The reference's test struct of the Beta-Bernoulli model (test/runtests.jl; `Beta(a, b)`).  On the device a Beta
@@ -66,6 +88,8 @@ def default_factor_rule(factor) -> Tuple[int, Tuple[float, ...]]:
         return L.FACTOR_GAUSS_ADDITIVE, (ff.variance,)
     if isinstance(ff, GaussianLinear):
         return L.FACTOR_GAUSS_LINEAR, (ff.variance, ff.a, ff.b)
+    if isinstance(ff, MvGaussianLinear):
+        return L.FACTOR_GAUSS_LINEAR, ff          # dim > 1: attach() turns the (A, Q) object into a parameter-set index
     return L.FACTOR_OPAQUE, ()
 
 
@@ -91,6 +115,10 @@ class HipValue:
         return self._fetch().variance
 
     @property
+    def covariance(self):
+        return self._fetch().covariance
+
+    @property
     def a(self):
         return self._fetch().a
 
@@ -104,14 +132,18 @@ class HipValue:
 
 class HipProcessor(AbstractInferenceRequestProcessor):
     def __init__(self, *, mode: str = "sweep", n_sweeps: int = 1, device: int = 0, schedule: int = L.SCHED_FUSED,
-                 factor_rule: Callable = default_factor_rule, family: str = "gaussian"):
+                 factor_rule: Callable = default_factor_rule, family: str = "gaussian", dim: int = 1):
+        """dim: the dimension of every variable (1: scalars; 2, 3, 4: small matrices in registers; 64: the MFMA path).  With
+        dim > 1 the factors are MvGaussianLinear, data are length-d arrays and messages MvNormalMeanCovariance."""
         if mode not in ("per_signal", "wavefront", "sweep"):
             raise ValueError(f"unknown mode {mode!r}")
         if family not in ("gaussian", "beta"):
             raise ValueError(f"unknown family {family!r}")
-        self.mode, self.n_sweeps, self.factor_rule, self.family = mode, n_sweeps, factor_rule, family
+        if dim != 1 and family != "gaussian":
+            raise ValueError("dim > 1 is Gaussian")
+        self.mode, self.n_sweeps, self.factor_rule, self.family, self.dim = mode, n_sweeps, factor_rule, family, dim
         # raises without a GPU: no CPU fallback
-        self.dev = DeviceGraph(device=device, schedule=schedule,
+        self.dev = DeviceGraph(device=device, dim=dim, schedule=schedule,
                                family=L.FAMILY_GAUSSIAN if family == "gaussian" else L.FAMILY_NATURAL2)
         self.engine: Optional[InferenceEngine] = None
         self.launches = 0
@@ -121,8 +153,18 @@ class HipProcessor(AbstractInferenceRequestProcessor):
     def attach(self, engine: InferenceEngine):
         self.engine = engine
         ev, ef, role, fids, kinds, params = [], [], [], [], [], []
+        psets = {}                             # id(functional_form) -> parameter-set index (dim > 1)
         for f in engine.get_factor_ids():
             kind, p = self.factor_rule(engine.get_factor(f))
+            if isinstance(p, MvGaussianLinear):
+                if self.dim == 1:
+                    raise TypeError("MvGaussianLinear factors need HipProcessor(dim=d)")
+                if id(p) not in psets:
+                    psets[id(p)] = len(psets)
+                    self.dev.set_factor_matrices(psets[id(p)], np.asarray(p.A, dtype=np.float64), np.asarray(p.Q, dtype=np.float64))
+                p = (float(psets[id(p)]),)
+            elif self.dim > 1 and kind != L.FACTOR_OPAQUE:
+                raise TypeError(f"HipProcessor(dim={self.dim}): factor {f} needs an MvGaussianLinear functional form")
             fids.append(f); kinds.append(kind); params.append(tuple(p) + (0.0,) * (L.NPARAM - len(p)))
             for v in engine.get_connected_variable_ids(f):
                 ev.append(v); ef.append(f)
@@ -140,7 +182,17 @@ class HipProcessor(AbstractInferenceRequestProcessor):
             direction = L.TO_VARIABLE
         else:
             raise TypeError("HipProcessor.set_value: only message signals carry device payloads")
-        if isinstance(value, (bool, int, float, np.floating, np.bool_)):
+        if self.dim > 1:
+            d = self.dim
+            if isinstance(value, MvNormalMeanCovariance):
+                form, payload = L.FORM_MOMENT, np.concatenate([np.asarray(value.mean, dtype=np.float64).reshape(d), np.asarray(value.covariance, dtype=np.float64).reshape(d * d)])
+            elif isinstance(value, MvNormalMeanPrecision):
+                W = np.asarray(value.precision, dtype=np.float64).reshape(d, d)
+                form, payload = L.FORM_NATURAL, np.concatenate([W @ np.asarray(value.mean, dtype=np.float64).reshape(d), W.reshape(d * d)])
+            else:                              # an observed datum: the `Real` branch of the reference's rule, d-dimensional
+                form, payload = L.FORM_POINT, np.asarray(value, dtype=np.float64).reshape(d)
+            self.dev.set_messages([variant.variable_id], [variant.factor_id], direction, form, payload)
+        elif isinstance(value, (bool, int, float, np.floating, np.bool_)):
             self.dev.set_messages([variant.variable_id], [variant.factor_id], direction, L.FORM_POINT, [float(value)])
         elif isinstance(value, Beta):
             self.dev.set_messages([variant.variable_id], [variant.factor_id], direction, L.FORM_NATURAL, [value.a - 1.0, value.b - 1.0])
@@ -164,6 +216,9 @@ class HipProcessor(AbstractInferenceRequestProcessor):
             m = self.dev.get_products([variant.variable_id], [variant.range[0]], [variant.range[1]], form)[0]
         else:
             raise TypeError(f"no device payload for {variant!r}")
+        if self.dim > 1:
+            d = self.dim
+            return MvNormalMeanCovariance(np.array(m[:d]), np.array(m[d:]).reshape(d, d))
         if self.family == "beta":
             return Beta(float(m[0]) + 1.0, float(m[1]) + 1.0)
         return NormalMeanVariance(float(m[0]), float(m[1]))

@@ -123,7 +123,11 @@ extern "C" {
                                  schedule (inference_engine.jl:575-608), by two parallel prefix scans.  When every
                                  non-observed variable is on a chain and materialize_messages_to_factor is 0, the
                                  scan writes the marginals itself and variable→factor messages are recomputed from
-                                 the stored messages when cx_get_messages / cx_update_batch ask for them          */
+                                 the stored messages when cx_get_messages / cx_update_batch ask for them.
+                                 dim 1, 2, 3, 4.  For dim 2..4 (scan over composed linear-Gaussian maps) every
+                                 non-observed variable must sit on a chain; a sweep writes the marginals, the chain
+                                 messages reach their slots when cx_get_messages / cx_update_batch / cx_residual /
+                                 cx_state_export ask for them                                                     */
 
 typedef struct cx_handle cx_handle;
 
@@ -131,7 +135,7 @@ typedef struct cx_config {
     int32_t struct_size;   /* sizeof(cx_config), for forward compatibility */
     int32_t device;        /* HIP device ordinal */
     int32_t dim;           /* message dimension d: 1 (scalar), 2, 3, 4 (registers); 64 is the MFMA path */
-    int32_t schedule;      /* CX_SCHED_* */
+    int32_t schedule;      /* CX_SCHED_*: dim 1 all three; dim 2..4 CX_SCHED_FUSED or CX_SCHED_CHAIN_SCAN; dim 64 CX_SCHED_FUSED */
     int32_t compute_marginals_in_sweep; /* 1: every sweep also refreshes all marginals (update_marginals!) */
     int32_t materialize_messages_to_factor; /* CX_SCHED_FUSED only. 0: variable→factor messages stay in registers
                                                during a sweep and are recomputed, bit-identically, from the retained
@@ -221,7 +225,10 @@ int32_t cx_seed_messages(cx_handle *h, int32_t direction, double mean, double va
 int32_t cx_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, double *out);
 
 /* ---- compute ---------------------------------------------------------------------------------- */
-/* one launch for a batch of mutually independent signals, in the caller's order of enqueue */
+/* one launch for a batch of mutually independent signals, in the caller's order of enqueue.  dim == 1: all five item kinds;
+ * dim 2, 3, 4, 64: CX_ITEM_MESSAGE_TO_FACTOR, CX_ITEM_MESSAGE_TO_VARIABLE, CX_ITEM_INDIVIDUAL_MARGINAL (for dim 64 a marginal is
+ * computed from the stored messages when cx_get_marginals reads it: the item only checks its variable).  A result with an undefined
+ * dependency is not stored (the signal was not pending, src/signal.jl:668-730).  Synchronous at return. */
 int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n);
 /* values of the intermediates cx_update_batch keeps on the device: ProductOfMessages nodes (2 doubles each, `form`
  * CX_FORM_MOMENT or CX_FORM_NATURAL) and JointMarginal nodes (6 doubles each: mean[2], covariance[4] row-major, variables in

@@ -20,6 +20,7 @@ end
 
 mutable struct HipProcessor <: Cortex.AbstractInferenceRequestProcessor
     handle::Ptr{Cvoid}
+    dim::Int                   # 1: scalar messages; 2, 3, 4, 64: d-dimensional linear-Gaussian messages
     queue::Vector{CxItem}
     signals::Vector{Cortex.InferenceSignal}
 end
@@ -31,26 +32,43 @@ function HipProcessor(; device = 0, dim = 1, schedule = 1)
     out = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:cx_create, lib), Int32, (Ref{CxConfig}, Ref{Ptr{Cvoid}}), cfg, out)
     rc == 0 || error(unsafe_string(ccall((:cx_last_error, lib), Cstring, (Ptr{Cvoid},), C_NULL)))
-    p = HipProcessor(out[], CxItem[], Cortex.InferenceSignal[])
+    p = HipProcessor(out[], dim, CxItem[], Cortex.InferenceSignal[])
     finalizer(q -> ccall((:cx_destroy, lib), Int32, (Ptr{Cvoid},), q.handle), p)
     return p
 end
 
-# graph ingestion through the reference's own accessors (model_engine.jl:329-391)
-function upload!(p::HipProcessor, engine::Cortex.InferenceEngine, kind_of, params_of)
-    ev, ef = Int64[], Int64[]
+# graph ingestion through the reference's own accessors (model_engine.jl:329-391).  Directed factors (CX_FACTOR_GAUSS_LINEAR:
+# x_out = a x_in + b + N(0, q), or x_out = A x_in + N(0, Q) for dim > 1) read the edge roles from Connection.label:
+# role_of(engine, v, f) -> 0 (:out) | 1 (:in).  For dim > 1 params_of returns (parameter_set, 0, 0, 0) and the matrices of
+# every set are supplied with set_factor_matrices! BEFORE the first sweep / batch.
+function upload!(p::HipProcessor, engine::Cortex.InferenceEngine, kind_of, params_of; role_of = (engine, v, f) -> 0)
+    ev, ef, er = Int64[], Int64[], Int32[]
     fids = collect(Int64, Cortex.get_factor_ids(engine))
     for f in fids, v in Cortex.get_connected_variable_ids(engine, f)
-        push!(ev, v); push!(ef, f)
+        push!(ev, v); push!(ef, f); push!(er, role_of(engine, v, f))
     end
     kinds = Int32[kind_of(Cortex.get_factor(engine, f)) for f in fids]          # CX_FACTOR_*
     params = reduce(vcat, [collect(Float64, params_of(Cortex.get_factor(engine, f))) for f in fids])  # 4 per factor
     check(p.handle, ccall((:cx_graph_create, lib), Int32,
         (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int32}, Int64, Ptr{Int64}, Ptr{Int32}, Ptr{Float64}),
-        p.handle, length(ev), ev, ef, C_NULL, length(fids), fids, kinds, params))
+        p.handle, length(ev), ev, ef, er, length(fids), fids, kinds, params))
 end
 
-# batched mode: collect like InferenceRequestScanner (inference_engine.jl:528-537), compute on flush
+# dim > 1: (A, Q) of parameter set `set` (0-based), d x d each; the ABI is row-major, Julia column-major: pass the transposes
+set_factor_matrices!(p::HipProcessor, set, A::Matrix{Float64}, Q::Matrix{Float64}) =
+    check(p.handle, ccall((:cx_set_factor_matrices, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}),
+                          p.handle, set, collect(transpose(A)), collect(transpose(Q))))
+
+# where the user calls set_value!(message_to_factor(y, likelihood), datum): a Real for dim == 1, a length-d vector for dim > 1
+function set_datum!(p::HipProcessor, signal::Cortex.InferenceSignal, datum)
+    v = Cortex.get_variant(signal)
+    check(p.handle, ccall((:cx_set_messages, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Int32, Int32, Ptr{Float64}),
+                          p.handle, 1, Int64[v.variable_id], Int64[v.factor_id], 1, 1, collect(Float64, datum)))   # CX_TO_FACTOR, CX_FORM_POINT
+    Cortex.set_value!(signal, datum)
+end
+
+# batched mode: collect like InferenceRequestScanner (inference_engine.jl:528-537), compute on flush.
+# Every dim takes MessageToVariable / MessageToFactor / IndividualMarginal items; ProductOfMessages and JointMarginal are dim == 1.
 function Cortex.process!(p::HipProcessor, engine::Cortex.InferenceEngine, variable_id, signal::Cortex.InferenceSignal)
     v = Cortex.get_variant(signal)
     item = v isa Cortex.InferenceSignalVariants.MessageToVariable ? CxItem(2, 0, v.variable_id, v.factor_id) :
@@ -77,11 +95,13 @@ struct HipValue end                           # the payload stays in HBM; read i
 function Cortex.update_marginals!(engine::Cortex.InferenceEngine{M,D,HipProcessor}, ids::Union{AbstractVector,Tuple}) where {M,D}
     p = Cortex.get_inference_request_processor(engine)
     check(p.handle, ccall((:cx_sweep, lib), Int32, (Ptr{Cvoid}, Int32), p.handle, 1))
-    out = Matrix{Float64}(undef, 2, length(ids))
+    d = p.dim
+    out = Matrix{Float64}(undef, d == 1 ? 2 : d + d * d, length(ids))           # per marginal: mean[d] then covariance[d*d]
     check(p.handle, ccall((:cx_get_marginals, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Float64}),
                           p.handle, length(ids), collect(Int64, ids), out))
-    for (i, id) in enumerate(ids)   # make the values visible as the reference's test structs (runtests.jl:31-34)
-        Cortex.set_value!(Cortex.get_variable_marginal(Cortex.get_variable(engine, id)), (mean = out[1, i], variance = out[2, i]))
+    for (i, id) in enumerate(ids)   # make the values visible as the reference's test structs (runtests.jl:31-34, :70-77)
+        value = d == 1 ? (mean = out[1, i], variance = out[2, i]) : (mean = out[1:d, i], covariance = reshape(out[d+1:end, i], d, d))
+        Cortex.set_value!(Cortex.get_variable_marginal(Cortex.get_variable(engine, id)), value)
     end
     return nothing
 end

@@ -15,6 +15,60 @@
         if (rc_ != CX_OK) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, cx_last_error(h)); return 1; } \
     } while (0)
 
+/* dim = 4 through the batched entry point: the reference's schedule on a 3-step state-space chain (SURVEY.md §3.3 hand trace:
+ * lik_t->x_t, x1->tr1, tr1->x2, x2->tr2, tr2->x3 | x3->tr2, tr2->x2, x2->tr1, tr1->x1 | marginals), one cx_update_batch per
+ * wavefront of independent signals, as a processor whose process! enqueues and flushes would issue them. */
+#define D 4
+#define T3 3
+static int mv_batches(void) {
+    cx_handle *h = NULL;
+    cx_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = (int32_t)sizeof cfg;
+    cfg.device = 0; cfg.dim = D; cfg.schedule = CX_SCHED_FUSED; cfg.compute_marginals_in_sweep = 1;
+    int32_t rc = cx_create(&cfg, &h);
+    if (rc != CX_OK) { fprintf(stderr, "cx_create(dim 4) -> %d: %s\n", rc, cx_last_error(NULL)); return 1; }
+    double A[D * D], Q[D * D], I4[D * D], R[D * D];
+    for (int i = 0; i < D; i++)
+        for (int j = 0; j < D; j++) {
+            A[i * D + j] = i == j ? 0.9 : (j == i + 1 ? 0.1 : 0.0);
+            Q[i * D + j] = i == j ? 0.1 : 0.0; I4[i * D + j] = i == j ? 1.0 : 0.0; R[i * D + j] = i == j ? 1.0 : 0.0;
+        }
+    CHECK(cx_set_factor_matrices(h, 0, A, Q));      /* transitions */
+    CHECK(cx_set_factor_matrices(h, 1, I4, R));     /* likelihoods */
+    /* x 1..3, y 4..6, likelihood 7..9, transition 10..11 */
+    int64_t ev[4 * T3 - 2], ef[4 * T3 - 2], fid[2 * T3 - 1];
+    int32_t role[4 * T3 - 2], fkind[2 * T3 - 1];
+    double fpar[(2 * T3 - 1) * CX_NPARAM];
+    int n = 0;
+    memset(fpar, 0, sizeof fpar);
+    for (int i = 0; i < T3; i++) { ev[n] = T3 + 1 + i; ef[n] = 2 * T3 + 1 + i; role[n++] = CX_ROLE_OUT; ev[n] = 1 + i; ef[n] = 2 * T3 + 1 + i; role[n++] = CX_ROLE_IN; }
+    for (int i = 0; i < T3 - 1; i++) { ev[n] = 1 + i; ef[n] = 3 * T3 + 1 + i; role[n++] = CX_ROLE_IN; ev[n] = 2 + i; ef[n] = 3 * T3 + 1 + i; role[n++] = CX_ROLE_OUT; }
+    for (int f = 0; f < 2 * T3 - 1; f++) { fid[f] = 2 * T3 + 1 + f; fkind[f] = CX_FACTOR_GAUSS_LINEAR; fpar[f * CX_NPARAM] = f < T3 ? 1.0 : 0.0; }
+    CHECK(cx_graph_create(h, n, ev, ef, role, 2 * T3 - 1, fid, fkind, fpar));
+    int64_t yv[T3] = {4, 5, 6}, yf[T3] = {7, 8, 9}, xv[T3] = {1, 2, 3};
+    double y[T3 * D] = {0.5, -1.0, 2.0, 0.25, 1.5, -0.5, 1.0, 0.75, 2.5, 0.5, 0.0, 1.25};
+    CHECK(cx_set_messages(h, T3, yv, yf, CX_TO_FACTOR, CX_FORM_POINT, y));
+#define ITEM(k, v, f) {k, 0, v, f}
+    const cx_item w0[] = {ITEM(CX_ITEM_MESSAGE_TO_VARIABLE, 1, 7), ITEM(CX_ITEM_MESSAGE_TO_VARIABLE, 2, 8), ITEM(CX_ITEM_MESSAGE_TO_VARIABLE, 3, 9)};
+    const cx_item seq[] = {ITEM(CX_ITEM_MESSAGE_TO_FACTOR, 1, 10), ITEM(CX_ITEM_MESSAGE_TO_VARIABLE, 2, 10), ITEM(CX_ITEM_MESSAGE_TO_FACTOR, 2, 11),
+                           ITEM(CX_ITEM_MESSAGE_TO_VARIABLE, 3, 11), ITEM(CX_ITEM_MESSAGE_TO_FACTOR, 3, 11), ITEM(CX_ITEM_MESSAGE_TO_VARIABLE, 2, 11),
+                           ITEM(CX_ITEM_MESSAGE_TO_FACTOR, 2, 10), ITEM(CX_ITEM_MESSAGE_TO_VARIABLE, 1, 10)};
+    const cx_item wm[] = {ITEM(CX_ITEM_INDIVIDUAL_MARGINAL, 1, 0), ITEM(CX_ITEM_INDIVIDUAL_MARGINAL, 2, 0), ITEM(CX_ITEM_INDIVIDUAL_MARGINAL, 3, 0)};
+    CHECK(cx_update_batch(h, w0, 3));
+    for (int i = 0; i < 8; i++) CHECK(cx_update_batch(h, &seq[i], 1));    /* the sequential part of the schedule: one signal per wavefront */
+    CHECK(cx_update_batch(h, wm, 3));
+    double marg[T3 * (D + D * D)];
+    CHECK(cx_get_marginals(h, T3, xv, marg));
+    for (int t = 0; t < T3; t++) {
+        printf("m4 %d", t + 1);
+        for (int k = 0; k < D + D * D; k++) printf(" %.15g", marg[t * (D + D * D) + k]);
+        printf("\n");
+    }
+    CHECK(cx_destroy(h));
+    return 0;
+}
+
 int main(void) {
     cx_handle *h = NULL;
     cx_config cfg;
@@ -48,5 +102,5 @@ int main(void) {
     rc = cx_get_messages(h, 1, &bad_v, &bad_f, CX_TO_VARIABLE, CX_FORM_MOMENT, tmp);
     printf("unknown-edge status %d: %s\n", rc, cx_last_error(h));
     CHECK(cx_destroy(h));
-    return 0;
+    return mv_batches();
 }

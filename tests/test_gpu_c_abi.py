@@ -26,3 +26,12 @@ def test_c_program_drives_the_abi(hip_lib, tmp_path):
     np.testing.assert_allclose(got[:, 0], m, rtol=1e-12)
     np.testing.assert_allclose(got[:, 1], v, rtol=1e-12)
     assert "unknown-edge status -2" in out.stdout and "12345" in out.stdout
+    # the dim = 4 chain driven batch by batch in the reference's schedule (abi_smoke.c: mv_batches)
+    d = 4
+    rows4 = np.array([[float(x) for x in l.split()[2:]] for l in out.stdout.splitlines() if l.startswith("m4 ")])
+    assert rows4.shape == (3, d + d * d)
+    A = 0.9 * np.eye(d) + 0.1 * np.eye(d, k=1)
+    y = np.array([[0.5, -1.0, 2.0, 0.25], [1.5, -0.5, 1.0, 0.75], [2.5, 0.5, 0.0, 1.25]])
+    em, ecov = exact.lgssm_posterior(y, A, 0.1 * np.eye(d), np.eye(d))
+    np.testing.assert_allclose(rows4[:, :d], em, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(rows4[:, d:].reshape(3, d, d), ecov, rtol=1e-10, atol=1e-12)

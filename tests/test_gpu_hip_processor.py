@@ -312,3 +312,83 @@ def test_config_c1_T1000_through_the_plugin(hip_lib, mode):
     else:
         assert sorted(map(repr, proc.execution_log)) == sorted(map(repr, order_cpu))
         assert proc.launches <= 2 * n + 4
+
+
+# ------------------------------------------------------------------------------------------------ dim > 1 behind the plug-in
+def _make_mv_ssm(n, d, processor, A, Q, R, trace=True):
+    """the graph of make_ssm_model (test/inference_engine_tests.jl:436-462) with d-dimensional variables and linear-Gaussian
+    factors: likelihood y_t = x_t + N(0, R), transition x_{t+1} = A x_t + N(0, Q)"""
+    graph = cx.BipartiteFactorGraph()
+    x = [graph.add_variable(cx.Variable(name="x", index=(i,))) for i in range(1, n + 1)]
+    y = [graph.add_variable(cx.Variable(name="y", index=(i,))) for i in range(1, n + 1)]
+    lik_form, tr_form = cx.MvGaussianLinear(np.eye(d), R), cx.MvGaussianLinear(A, Q)
+    likelihood = [graph.add_factor(cx.Factor(functional_form=lik_form)) for _ in range(n)]
+    transition = [graph.add_factor(cx.Factor(functional_form=tr_form)) for _ in range(n - 1)]
+    for i in range(n):
+        graph.add_edge(y[i], likelihood[i], cx.Connection(label="out"))
+        graph.add_edge(x[i], likelihood[i], cx.Connection(label="in"))
+    for i in range(n - 1):
+        graph.add_edge(x[i], transition[i], cx.Connection(label="in"))
+        graph.add_edge(x[i + 1], transition[i], cx.Connection(label="out"))
+    engine = cx.InferenceEngine(model_engine=graph, dependency_resolver=cx.DefaultDependencyResolver(),
+                                inference_request_processor=processor, trace=trace)
+    return engine, x, y, likelihood, transition
+
+
+@pytest.mark.parametrize("d,n,mode,tol", [(4, 50, "per_signal", 1e-9), (4, 50, "wavefront", 1e-9), (2, 7, "per_signal", 1e-9),
+                                          (64, 6, "per_signal", 1e-8), (64, 6, "wavefront", 1e-8)])
+def test_d_dimensional_chain_through_the_plugin(hip_lib, d, n, mode, tol):
+    """dim > 1 behind the plug-in boundary.  The host mirror's scheduler (readiness bits and all) drives the device
+    one signal (or one wavefront) at a time through cx_update_batch; execution order == the same scheduler on the same graph shape
+    with the scalar reference-arithmetic processor (the order depends on the graph only); marginals == the exact smoother; the
+    messages == oracle/mv.py at its fixed point."""
+    from oracle.mv import MvFlood
+
+    model = cx.synth.lgssm_chain(n, d=d, seed=9)
+    A, Q, R = model.meta["A"], model.meta["Q"], model.meta["R"]
+    proc = cx.HipProcessor(mode=mode, dim=d)
+    engine, x, y, lik, tr = _make_mv_ssm(n, d, proc, A, Q, R)
+    for i in range(n):
+        proc.set_value(engine.get_connection_message_to_factor(y[i], lik[i]), model.data_y[i])
+    update_marginals(engine, x)
+    vals = [get_value(get_variable_marginal(engine.get_variable(v))) for v in x]
+    mean = np.stack([v.mean for v in vals]); cov = np.stack([v.covariance for v in vals])
+    em, ecov = exact.lgssm_posterior(model.data_y, A, Q, R)
+    assert_close(mean, em, tol, f"d={d} {mode}: marginal means vs exact smoother", scale_by="max")
+    assert_close(cov, ecov, tol, f"d={d} {mode}: marginal covariances vs exact smoother", scale_by="max")
+    # the schedule: the same signals, and in per-signal mode the same ORDER, as the scalar SSM under the CPU processor
+    engine_cpu, xs, *_ = _run(n, SSMBeliefPropagationProcessor())
+    order_cpu = [e.signal.variant for r in engine_cpu.get_trace().inference_requests[0].rounds for e in r.executions]
+    if mode == "per_signal":
+        assert proc.execution_log == order_cpu and proc.launches == 5 * n - 4 + n
+    else:
+        assert sorted(map(repr, proc.execution_log)) == sorted(map(repr, order_cpu)) and proc.launches <= 2 * n + 4
+    # messages into the latent variables vs the numpy restatement at its fixed point (ids coincide: same construction order)
+    o = MvFlood(model)
+    o.sweep(n + 2)
+    g = o.g
+    xi = set(np.searchsorted(g.var_ids, model.x_ids).tolist())
+    for e in np.flatnonzero(g.partner >= 0):
+        if int(np.searchsorted(g.var_ids, g.edge_var[e])) not in xi:
+            continue
+        got = proc.read(V.MessageToVariable(int(g.edge_var[e]), int(g.edge_fac[e])))
+        m, S = o.f2v[e]
+        assert_close(got.mean, m, tol, f"f2v mean edge {e}", scale_by="max"); assert_close(got.covariance, S, tol, f"f2v covariance edge {e}", scale_by="max")
+
+
+def test_d_dimensional_batch_errors(hip_lib):
+    d = 4
+    model = cx.synth.lgssm_chain(5, d=d, seed=2)
+    dev = cx.DeviceGraph(dim=d)
+    cx.synth.load_into_device(model, dev)
+    L = cx._lib
+    with pytest.raises(cx.CortexHipError) as e:        # a ProductOfMessages item has no dim > 1 form
+        dev.update_batch([L.ITEM_PRODUCT_OF_MESSAGES], [int(model.x_ids[0])], [L.item_range(1, 2)])
+    assert e.value.code == L.ERR_UNSUPPORTED
+    with pytest.raises(cx.CortexHipError) as e:
+        dev.update_batch([L.ITEM_MESSAGE_TO_VARIABLE], [int(model.x_ids[0])], [int(model.factor_ids[-1]) + 99])
+    assert e.value.code == L.ERR_NOT_FOUND
+    # a message whose dependency is undefined is not stored (the signal is not pending): x_2 -> transition needs alpha_1 first
+    tr0 = int(model.factor_ids[5])
+    dev.update_batch([L.ITEM_MESSAGE_TO_FACTOR], [int(model.x_ids[1])], [tr0])
+    assert np.all(np.isnan(dev.get_messages([model.x_ids[1]], [tr0], L.TO_FACTOR)))
