@@ -84,15 +84,20 @@ def launch_ranks(n: int, argv, timeout_s: float = 1500.0) -> int:
     import signal
     import subprocess
 
+    import tempfile
+
     port = _free_port()
     procs = []
+    # rank 0's stdout goes to a temporary file, relayed after it exits: a pipe that nobody reads while the child runs would block
+    # the child once it holds 64 KB (verbose JSON, warnings) — and look like a hung GPU to whoever waits for us
+    out_file = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CX_BENCH_SPAWNED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, cwd=ROOT,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, start_new_session=True))
+                                      stdout=out_file if r == 0 else subprocess.DEVNULL, start_new_session=True))
     deadline = time.time() + timeout_s
     rc, out0 = 0, b""
     try:
@@ -103,8 +108,6 @@ def launch_ranks(n: int, argv, timeout_s: float = 1500.0) -> int:
                 if code is None:
                     continue
                 pending.discard(r)
-                if r == 0:
-                    out0 = procs[0].stdout.read()
                 if code != 0 and rc == 0:
                     rc = code if code > 0 else 1
                     sys.stderr.write(f"[bench] rank {r} exited with {code}: stopping the other ranks\n")
@@ -130,11 +133,9 @@ def launch_ranks(n: int, argv, timeout_s: float = 1500.0) -> int:
                     os.killpg(p.pid, signal.SIGKILL)
                 except ProcessLookupError:
                     pass
-    if not out0 and procs[0].stdout is not None:
-        try:
-            out0 = procs[0].stdout.read() or b""
-        except ValueError:
-            out0 = b""
+    out_file.seek(0)
+    out0 = out_file.read()
+    out_file.close()
     sys.stdout.write(out0.decode(errors="replace"))
     sys.stdout.flush()
     return rc

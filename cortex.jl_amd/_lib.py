@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CORTEX_HIP_LIB", os.path.join(HERE, "libcortex_hip.so"))  # override: A/B builds of the same ABI
 
 # mirrors of the #defines in include/cortex_hip.h
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NOT_FOUND, ERR_UNSUPPORTED, ERR_STATE, ERR_DEVICE, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY = (
     -1, -2, -3, -4, -5, -6, -7)

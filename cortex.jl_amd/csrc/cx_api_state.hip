@@ -38,7 +38,8 @@ struct StateHeader {
 };
 struct StateSection { int32_t id, reserved; int64_t bytes; };
 struct StatePart { int32_t id; void *dev; int64_t bytes; };
-const char kStateMagic[8] = {'C', 'X', 'S', 'T', 'A', 'T', 'E', '1'};
+const char kStateMagic[8] = {'C', 'X', 'S', 'T', 'A', 'T', 'E', '2'};   // '2': the fingerprint covers rule parameters, v2f_stale is a bit-field
+const char kStateMagicV1[8] = {'C', 'X', 'S', 'T', 'A', 'T', 'E', '1'};
 
 uint64_t fnv1a(uint64_t hsh, const void *p, size_t n) {
     const unsigned char *b = (const unsigned char *)p;
@@ -129,6 +130,8 @@ int32_t cx_state_import(cx_handle *h, const void *buf, int64_t bytes) {
     CX_REQUIRE(h, buf && bytes >= (int64_t)sizeof(StateHeader), CX_ERR_INVALID_ARGUMENT, "cx_state_import: blob too short");
     StateHeader hd;
     std::memcpy(&hd, buf, sizeof hd);
+    CX_REQUIRE(h, std::memcmp(hd.magic, kStateMagicV1, 8) != 0, CX_ERR_INVALID_ARGUMENT,
+               "cx_state_import: the blob was written by an earlier build (state format 1); this build reads format 2");
     CX_REQUIRE(h, std::memcmp(hd.magic, kStateMagic, 8) == 0 && hd.abi == CX_ABI_VERSION, CX_ERR_INVALID_ARGUMENT,
                "cx_state_import: not a state blob of this ABI version");
     CX_REQUIRE(h, hd.dim == h->cfg.dim && hd.family == h->cfg.family && hd.schedule == h->cfg.schedule, CX_ERR_INVALID_ARGUMENT,

@@ -412,7 +412,7 @@ __global__ void k_seed(double2 *__restrict__ buf, int64_t n, double2 value, cons
 
 // max |Δmean|, |Δvariance| per workgroup (moment form), reduced on the host from 1024 partials
 __global__ __launch_bounds__(kBlock) void k_residual(const double2 *__restrict__ cur, const double2 *__restrict__ prev, int64_t n,
-                                                     double *__restrict__ out) {
+                                                     double *__restrict__ out, int natural) {
     __shared__ double red[kBlock / 64];
     double m = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
@@ -420,10 +420,20 @@ __global__ __launch_bounds__(kBlock) void k_residual(const double2 *__restrict__
         const bool da = !__builtin_isnan(a.y), db = !__builtin_isnan(b.y);
         if (da != db) m = __builtin_inf();
         else if (da) {
-            // a NaN difference (a mean that became inf - inf, a divergent loopy run) must not vanish in fmax: it never converges
-            double2 ma = to_moment(a), mb = to_moment(b);
-            const double d = fmax(fabs(ma.x - mb.x), fabs(ma.y - mb.y));
-            m = (d != d || ma.x != ma.x || mb.x != mb.x) ? __builtin_inf() : fmax(m, d);
+            // Two snapshots of one message that are bitwise equal have not moved, whatever they hold — a zero-precision message
+            // (0, 0) (moment form 0 * inf), a Beta(1 + r, 2 - r) with a zero natural parameter: both legitimate and constant.
+            if (a.x == b.x && a.y == b.y) continue;
+            double d;
+            if (natural) {
+                // any 2-parameter family in natural coordinates (CX_FAMILY_NATURAL2): the moment form below is Gaussian-only
+                d = fmax(fabs(a.x - b.x), fabs(a.y - b.y));
+            } else {
+                const double2 ma = to_moment(a), mb = to_moment(b);
+                const double dm = (ma.x == mb.x) ? 0.0 : fabs(ma.x - mb.x), dv = (ma.y == mb.y) ? 0.0 : fabs(ma.y - mb.y);   // equal infinities: no change
+                d = fmax(dm, dv);
+                if (dm != dm || dv != dv) d = __builtin_inf();      // a difference that is NaN (inf - inf, 0 * inf on one side only): never converged
+            }
+            m = (d != d) ? __builtin_inf() : fmax(m, d);
         }
     }
 #pragma unroll
@@ -599,7 +609,7 @@ void launch_seed(cx_handle *h, double2 *buf, int64_t n, double2 value, const int
 }
 
 void launch_residual(cx_handle *h, const double2 *cur, const double2 *prev, int64_t n, double *d_out) {
-    hipLaunchKernelGGL(k_residual, dim3(1024), dim3(kBlock), 0, h->stream, cur, prev, n, d_out);
+    hipLaunchKernelGGL(k_residual, dim3(1024), dim3(kBlock), 0, h->stream, cur, prev, n, d_out, h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0);
 }
 
 }  // namespace cx

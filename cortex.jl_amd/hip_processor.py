@@ -233,6 +233,13 @@ class HipProcessor(AbstractInferenceRequestProcessor):
         if isinstance(variant, V.IndividualMarginal):
             return L.ITEM_INDIVIDUAL_MARGINAL, variant.variable_id, 0
         if isinstance(variant, V.ProductOfMessages):      # 1-based inclusive range, as in Julia (inference_signal.jl:62-66)
+            # the reference's range indexes `factors_connected_to_variable` (dependencies.jl:128-173), i.e. whatever order the model
+            # engine's get_connected_factor_ids returns; the device resolves it over ASCENDING factor ids (cortex_hip.h).  An engine
+            # that lists factors in another order would multiply the wrong subsets without any error: refuse it here.
+            fs = tuple(variant.factors_connected_to_variable)
+            if any(a >= b for a, b in zip(fs, fs[1:])):
+                raise ValueError(f"ProductOfMessages of variable {variant.variable_id}: factors_connected_to_variable is not in ascending id order "
+                                 "(the device resolves ranges over ascending factor ids)")
             return L.ITEM_PRODUCT_OF_MESSAGES, variant.variable_id, L.item_range(variant.range[0], variant.range[1])
         if isinstance(variant, V.JointMarginal):
             return L.ITEM_JOINT_MARGINAL, 0, variant.factor_id

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CX_ABI_VERSION 1
+#define CX_ABI_VERSION 2   /* 2: cx_config.reserved became sweeps_per_launch (validated), five new item / factor kinds, state blobs "CXSTATE2" */
 
 /* status codes */
 #define CX_OK 0
@@ -64,7 +64,10 @@ extern "C" {
 #define CX_ITEM_PRODUCT_OF_MESSAGES 8  /* ProductOfMessages(variable_id, range, factors), inference_signal.jl:62-66: the product of
                                           the factor→variable messages number lo..hi (1-based, inclusive, ascending factor id:
                                           the reference's `range` over factors_connected_to_variable) of variable_id — the
-                                          segment-tree intermediates of dependencies.jl:128-173.  The range travels in
+                                          segment-tree intermediates of dependencies.jl:128-173.  ORDERING ASSUMPTION: the range is
+                                          resolved over the variable's factors in ascending id order; a plug-in whose model engine
+                                          lists factors_connected_to_variable in another order must refuse or translate (the Python
+                                          and Julia plug-ins check it).  The range travels in
                                           cx_item.factor_id as CX_ITEM_RANGE(lo, hi); the value is kept in a device store
                                           (cx_get_products) */
 #define CX_ITEM_JOINT_MARGINAL 16      /* JointMarginal(factor_id, variable_ids), inference_signal.jl:93-96, for a pairwise
@@ -319,7 +322,9 @@ int32_t cx_chain_block_maps(cx_handle *h, double *forward6, double *backward6, d
 /* ---- checkpoint (the reference keeps no persistent state — src/ has no serialisation at all) ----
  * The mutable state of a handle (every message buffer, the marginals, the observed-variable flags, the sweep counter)
  * as one relocatable host blob.  A blob restores only into a handle created with the same dim / family / schedule and
- * the same graph (a fingerprint of the flattened graph is checked); after cx_state_import the handle continues exactly
+ * the same graph AND the same rule parameters (a fingerprint of the flattened graph, the factor parameters and the (A, Q) sets is
+ * checked: a blob continues under the parameters it was exported with, or not at all; blobs of an earlier format are refused with
+ * a version error); after cx_state_import the handle continues exactly
  * where the exporting one stood: the following sweeps reproduce its results bit for bit.  Halo buffers are not part
  * of the state (the next partitioned sweep exchanges them again).  Variational handles export their marginals and observed
  * flags (the structured family also the inner chain handle's state, inside the same blob). */

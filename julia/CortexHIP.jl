@@ -74,7 +74,8 @@ function Cortex.process!(p::HipProcessor, engine::Cortex.InferenceEngine, variab
     item = v isa Cortex.InferenceSignalVariants.MessageToVariable ? CxItem(2, 0, v.variable_id, v.factor_id) :
            v isa Cortex.InferenceSignalVariants.MessageToFactor   ? CxItem(1, 0, v.variable_id, v.factor_id) :
            v isa Cortex.InferenceSignalVariants.IndividualMarginal ? CxItem(4, 0, v.variable_id, 0) :
-           v isa Cortex.InferenceSignalVariants.ProductOfMessages  ? CxItem(8, 0, v.variable_id, (Int64(first(v.range)) << 32) | Int64(last(v.range))) :   # CX_ITEM_RANGE
+           v isa Cortex.InferenceSignalVariants.ProductOfMessages  ? (issorted(v.factors_connected_to_variable) || error("ProductOfMessages: the device resolves ranges over ascending factor ids");
+                                                                      CxItem(8, 0, v.variable_id, (Int64(first(v.range)) << 32) | Int64(last(v.range)))) :   # CX_ITEM_RANGE
            v isa Cortex.InferenceSignalVariants.JointMarginal      ? CxItem(16, 0, 0, v.factor_id) :
            error("The HIP processor has no rule for $(typeof(v))")
     push!(p.queue, item); push!(p.signals, signal)

@@ -137,3 +137,19 @@ def test_blob_of_other_rule_parameters_or_a_doctored_variable_table_is_refused(h
     with pytest.raises(cx.CortexHipError, match="variable table"):
         a.import_state(bad)
     assert _same(before, _all_messages(a, model, L.TO_VARIABLE))
+
+
+def test_blob_of_an_earlier_state_format_is_refused_with_a_version_error(hip_lib):
+    """the fingerprint now covers rule parameters and v2f_stale became a bit-field — blobs written before that carry
+    magic "CXSTATE1" and must fail as an old FORMAT, not as "a different graph"."""
+    model = cx.synth.ssm_chain(20, seed=3)
+    dev = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(model, dev, seed_variance=1e6)
+    dev.sweep(3)
+    blob = dev.export_state()
+    assert bytes(blob[:8]) == b"CXSTATE2"
+    old = blob.copy()
+    old[7] = ord("1")
+    with pytest.raises(cx.CortexHipError, match="earlier build"):
+        dev.import_state(old)
+    dev.import_state(blob)

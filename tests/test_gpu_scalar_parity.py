@@ -290,3 +290,27 @@ def test_residual_of_a_numerically_broken_state_is_infinite(hip_lib):
     assert dev.residual() == float("inf")
     n, r = dev.sweep_until(1e-9, 6, 2)
     assert n == 6 and not (r <= 1e-9)     # the NaN spreads; never "converged"
+
+
+def test_residual_on_constant_zero_precision_and_beta_messages(hip_lib):
+    """messages that are legitimately degenerate in MOMENT form — the Beta-Bernoulli family's natural (r, 1 - r) with a
+    zero component, a Gaussian empty message (0, 0) — are constants of the model, not divergence: the residual compares snapshots
+    bitwise first and the generic 2-parameter family in natural coordinates, so cx_sweep_until stops when nothing moves."""
+    n = 40
+    data = (np.arange(n) % 3 == 0).astype(np.float64)         # r = 1 for every third outcome: Beta(2, 1) = natural (1, 0)
+    p, o, f = 1, 2 + np.arange(n), 100 + np.arange(n)
+    dev = cx.DeviceGraph(schedule=L.SCHED_FLOODING, family=L.FAMILY_NATURAL2)
+    dev.graph_create(np.concatenate([np.full(n, p), o]), np.concatenate([f, f]), f, np.full(n, L.FACTOR_BERNOULLI, np.int32), np.zeros(n))
+    dev.set_messages(o, f, L.TO_FACTOR, L.FORM_POINT, data)
+    ran, res = dev.sweep_until(1e-12, 60, 2)
+    assert ran <= 6 and res == 0.0, (ran, res)
+    a, b = dev.get_marginals([p])[0]
+    assert (a + 1, b + 1) == (1 + data.sum(), 1 + n - data.sum())          # the exact posterior, natural parameters
+    # Gaussian grid: one prior replaced by the empty (zero-precision) message (0, 0) — "no prior on this variable" — which no sweep
+    # rewrites: the same value in both snapshots; its moment form is (0 * inf, inf)
+    model = cx.synth.gaussian_grid(10, 10, seed=5)
+    dev = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(model, dev, seed_variance=1e6)
+    dev.set_messages([model.prior_var[0]], [model.prior_fac[0]], L.TO_VARIABLE, L.FORM_NATURAL, [0.0, 0.0])
+    ran, res = dev.sweep_until(1e-12, 3000, 10)
+    assert ran < 3000 and res <= 1e-12, (ran, res)
