@@ -21,6 +21,6 @@ from .inference_engine import (AbstractInferenceRequestProcessor, InferenceEngin
                                request_inference_for, scan_inference_request, update_marginals)
 from .hip_processor import (Beta, Gamma, GaussianAdditive, GaussianLinear, HipProcessor, HipValue, HipVmpProcessor, HipVmpValue,
                             MvGaussianLinear, MvNormalMeanCovariance, MvNormalMeanPrecision, NormalMeanPrecision, NormalMeanVariance,
-                            NormalPrecisionFactor)
+                            NormalPrecisionFactor, run_wavefronts)
 
 __all__ = [n for n in dir() if not n.startswith("__")]

@@ -93,6 +93,71 @@ def default_factor_rule(factor) -> Tuple[int, Tuple[float, ...]]:
     return L.FACTOR_OPAQUE, ()
 
 
+def _unique(signals):
+    """first occurrences, in order (a signal may be reachable from several marginals)"""
+    seen, uniq = set(), []
+    for s in signals:
+        if id(s) not in seen:
+            seen.add(id(s)); uniq.append(s)
+    return uniq
+
+
+def request_scope(request):
+    """ids of the signals a scan of this request can ever visit: every dependency of a visited signal, visiting (as
+    process_dependencies! does, signal.jl:466-490) only through dependencies flagged intermediate"""
+    from .signal import IS_INTERMEDIATE
+
+    scope, visited, stack = set(), set(), list(request.marginals)
+    while stack:
+        node = stack.pop()
+        props = node.dependencies_props
+        for i, dep in enumerate(node.dependencies):
+            scope.add(id(dep))
+            if props.get(i, IS_INTERMEDIATE) and id(dep) not in visited:
+                visited.add(id(dep)); stack.append(dep)
+    return scope
+
+
+def run_wavefronts(request, launch, stats: Optional[dict] = None):
+    """The batched mode between per-signal dispatch and the whole-call takeover: `launch(front)` computes one set of mutually
+    independent pending signals and set_value!s them (one device launch), repeated until nothing is pending, then the requested
+    marginals.
+
+    The first frontier comes from a full scan of the request (scan_inference_request, inference_engine.jl:540-546: O(request)).
+    After that a signal can only BECOME pending because one of its dependencies was just set — set_value! notifies exactly its
+    listeners (signal.jl:232-253) — so the next frontier is looked for among the listeners of the signals of this one:
+    O(frontier) per wavefront instead of O(request) (a chain of T states is 2T wavefronts: O(T²) host work with a scan each).
+    When that set runs dry a full scan confirms that nothing is pending any more.  On trees the frontiers are those of the
+    repeated full scan; stats (if given) counts wavefronts and full scans."""
+    scope = request_scope(request)
+    marginal_ids = {id(m) for m in request.marginals}
+    front = _unique(scan_inference_request(request))
+    deferred: List[Signal] = []
+    n_fronts, n_scans = 0, 1
+    while True:
+        if not front:
+            front = _unique(scan_inference_request(request))
+            n_scans += 1
+            if not front:
+                break
+        launch(front)
+        n_fronts += 1
+        cand = _unique(deferred + [l for s in front for on, l in zip(s.listenmask, s.listeners) if on])
+        pend = [l for l in cand if id(l) in scope and id(l) not in marginal_ids and is_pending(l)]
+        # a batch holds mutually independent signals: a pending signal that is a direct dependency of another pending one waits a
+        # round (the scan hides it behind its listener in the same way, signal.jl:476-482)
+        pid = {id(l) for l in pend}
+        hidden = {id(d) for l in pend for d in l.dependencies if id(d) in pid}
+        front = [l for l in pend if id(l) not in hidden]
+        deferred = [l for l in pend if id(l) in hidden]
+    final = [m for m in request.marginals if is_pending(m)]
+    if final:
+        launch(final)
+        n_fronts += 1
+    if stats is not None:
+        stats["wavefronts"], stats["full_scans"] = n_fronts, n_scans
+
+
 class HipValue:
     """What a device-computed Signal holds on the host: a handle, not the payload (`Signal.value` only has to differ
     from UndefValue() for is_computed, signal.jl:162-164).  `.mean` / `.variance` read the device on first use."""
@@ -271,25 +336,12 @@ class HipProcessor(AbstractInferenceRequestProcessor):
                 m = get_variable_marginal(engine.get_variable(vid))
                 _host_set_value(m, HipValue(self, m.variant))
             return True
-        # wavefront
-        request = request_inference_for(engine, ids)
-        while True:
-            front = scan_inference_request(request)
-            # a signal may be reachable from several marginals: keep first occurrences, in scan order
-            seen, uniq = set(), []
+        def launch(front):
+            self._launch([s.variant for s in front])
             for s in front:
-                if id(s) not in seen:
-                    seen.add(id(s)); uniq.append(s)
-            if not uniq:
-                break
-            self._launch([s.variant for s in uniq])
-            for s in uniq:
                 _host_set_value(s, HipValue(self, s.variant))
-        final = [m for m in request.marginals if is_pending(m)]
-        if final:
-            self._launch([m.variant for m in final])
-            for m in final:
-                _host_set_value(m, HipValue(self, m.variant))
+
+        run_wavefronts(request_inference_for(engine, ids), launch)
         return True
 
     def refresh_marginals(self, ids):

@@ -35,7 +35,49 @@ def run(n, processor):
     return dt, m
 
 
+def grid_wavefront(N=256):
+    """a loopy N x N Gaussian grid (the C4 model at 1/30 of its size) through the wavefront mode: after seeding, one
+    update_marginals! is three wavefronts — every variable→factor message, every factor→variable message, the marginals"""
+    from cortex.jl_amd.signal import set_value as host_set
+
+    model = cx.synth.gaussian_grid(N, N, seed=1234)
+    proc = cx.HipProcessor(mode="wavefront")
+    graph = cx.BipartiteFactorGraph()
+    t0 = time.perf_counter()
+    # ids in the order synth.gaussian_grid hands them out: variables first, then the factors in factor_ids order
+    for _ in range(N * N):
+        graph.add_variable(cx.Variable(name="x"))
+    kinds, var = model.factor_kind, model.factor_var
+    for k, q in zip(kinds, var):
+        graph.add_factor(cx.Factor(functional_form=cx.GaussianAdditive(float(q)) if k == L.FACTOR_GAUSS_ADDITIVE else "prior"))
+    for v, f in zip(model.edge_var, model.edge_fac):
+        graph.add_edge(int(v), int(f), cx.Connection(label="out"))
+    engine = cx.InferenceEngine(model_engine=graph, inference_request_processor=proc)
+    build_s = time.perf_counter() - t0
+    # priors and seeds: the host signals one by one (readiness bits), the device in two calls
+    prior_of = dict(zip(model.prior_fac.tolist(), zip(model.prior_mean.tolist(), model.prior_variance.tolist())))
+    proc.dev.set_messages(model.prior_var, model.prior_fac, L.TO_VARIABLE, L.FORM_MOMENT, np.stack([model.prior_mean, model.prior_variance], axis=1))
+    proc.dev.seed_messages(L.TO_VARIABLE, 0.0, 1e6)
+    for v, f in zip(model.edge_var.tolist(), model.edge_fac.tolist()):
+        m, s2 = prior_of.get(f, (0.0, 1e6))
+        host_set(engine.get_connection_message_to_variable(v, f), cx.NormalMeanVariance(m, s2))
+    ids = [int(v) for v in model.x_ids]
+    out = []
+    for it in range(3):
+        l0 = proc.launches
+        t0 = time.perf_counter()
+        update_marginals(engine, ids)
+        dt = time.perf_counter() - t0
+        out.append((dt, proc.launches - l0))
+    st = proc.dev.stats()
+    print(json.dumps({"config": "grid", "N": N, "path": "HipProcessor(mode='wavefront') behind the host scheduler, loopy grid",
+                      "edges": st["n_edges"], "signals_per_update_marginals": st["n_messages_per_sweep"] + N * N, "engine_build_s": build_s,
+                      "launches_per_update_marginals": [o[1] for o in out], "ms_per_update_marginals": [o[0] * 1e3 for o in out]}), flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "grid":
+        return grid_wavefront(int(sys.argv[2]) if len(sys.argv) > 2 else 256)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     signals = 5 * n - 4 + n
     run(50, cx.HipProcessor(mode="wavefront"))          # warm the library
