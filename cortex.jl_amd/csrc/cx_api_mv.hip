@@ -160,7 +160,12 @@ int32_t mv_get(cx_handle *h, const double *src, int64_t stride, const std::vecto
     double *d_val = (double *)((char *)h->d_stage + bytes_idx);
     CX_HIP(h, hipMemcpyAsync(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice, h->stream));
     if (d == 64) {
-        if (already_moment) cx::mv64_launch_marginals(h, (int)n, d_idx, h->d_mv_f2v, d_val);   // idx = variables: computed on demand
+        if (already_moment) {
+            // idx = variables: computed on demand.  A marginal the kernel cannot form (an incoming message undefined, a total precision
+            // that is not positive definite) is not stored: the staging rows start as UndefValue()
+            CX_HIP(h, hipMemsetAsync(d_val, 0xff, (size_t)n * nc * 8, h->stream));
+            cx::mv64_launch_marginals(h, (int)n, d_idx, h->d_mv_f2v, d_val);
+        }
         else cx::mv64_rows_gather(h, src, d_idx, d_val, n);
         CX_HIP(h, hipGetLastError());
         std::vector<double> val((size_t)n * nc);

@@ -139,3 +139,50 @@ def lgssm_posterior_c(y, A, Q, R):
     if rc != 0:
         raise RuntimeError(f"cxo_lgssm_posterior: status {rc}")
     return mean, cov
+
+
+# ---- extended precision (x86 long double, 64-bit mantissa): the reference for ill-conditioned models, where two f64 solvers of
+# ---- the same system already disagree at cond(Q) * 1e-16 -----------------------------------------------------------------------
+def _ld_solve(M, B):
+    """M X = B by Gaussian elimination with partial pivoting in np.longdouble (numpy.linalg has no long double path)"""
+    M = np.array(M, dtype=np.longdouble); B = np.array(B, dtype=np.longdouble)
+    d = M.shape[0]
+    for c in range(d):
+        p = c + int(np.argmax(np.abs(M[c:, c])))
+        if p != c:
+            M[[c, p]] = M[[p, c]]; B[[c, p]] = B[[p, c]]
+        f = M[c + 1:, c] / M[c, c]
+        M[c + 1:] -= f[:, None] * M[c]
+        B[c + 1:] -= f[:, None] * B[c]
+    for r in range(d - 1, -1, -1):
+        B[r] = (B[r] - M[r, r + 1:] @ B[r + 1:]) / M[r, r]
+    return B
+
+
+def lgssm_posterior_longdouble(y, A, Q, R):
+    """lgssm_posterior (H = I) with every operation in np.longdouble: the same Schur-complement recursions from both ends"""
+    ld = np.longdouble
+    y = np.asarray(y, dtype=ld); A = np.asarray(A, dtype=ld); Q = np.asarray(Q, dtype=ld); R = np.asarray(R, dtype=ld)
+    T, d = y.shape
+    I = np.eye(d, dtype=ld)
+    Qi, Ri = _ld_solve(Q, I), _ld_solve(R, I)
+    AtQi = A.T @ Qi
+    AtQiA = AtQi @ A
+    Jo = -AtQi
+    Jd = [Ri + (AtQiA if t < T - 1 else 0) + (Qi if t > 0 else 0) for t in range(T)]
+    h = [Ri @ y[t] for t in range(T)]
+    L, hl = [Jd[0]], [h[0]]
+    for t in range(1, T):
+        W = _ld_solve(L[t - 1], np.concatenate([Jo, hl[t - 1][:, None]], axis=1))      # L^-1 [Jo | hl]
+        L.append(Jd[t] - Jo.T @ W[:, :d]); hl.append(h[t] - Jo.T @ W[:, d])
+    Rr, hr = [None] * T, [None] * T
+    Rr[T - 1], hr[T - 1] = Jd[T - 1], h[T - 1]
+    for t in range(T - 2, -1, -1):
+        W = _ld_solve(Rr[t + 1], np.concatenate([Jo.T, hr[t + 1][:, None]], axis=1))
+        Rr[t] = Jd[t] - Jo @ W[:, :d]; hr[t] = h[t] - Jo @ W[:, d]
+    mean, cov = np.empty((T, d)), np.empty((T, d, d))
+    for t in range(T):
+        P = L[t] + Rr[t] - Jd[t]
+        X = _ld_solve(P, np.concatenate([I, (hl[t] + hr[t] - h[t])[:, None]], axis=1))
+        cov[t] = X[:, :d].astype(np.float64); mean[t] = X[:, d].astype(np.float64)
+    return mean, cov
