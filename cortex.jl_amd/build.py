@@ -19,6 +19,33 @@ SOURCES = ["cx_api.hip", "cx_api_mv.hip", "cx_api_msg.hip", "cx_api_sweep.hip", 
 HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(ROOT, "include", "cortex_hip.h")]
 
 
+# which sources a kernel's code comes from: a counter-traffic figure kept under profiles/ is only as good as the kernel it was
+# measured on, so the summaries store a hash of these files and bench.py refuses a figure whose kernel has changed since
+KERNEL_SOURCES = (("k_sweep_mv", ("cx_mv.hip", "cx_mv_core.h")), ("k_mvc_", ("cx_mvchain.hip", "cx_mv_core.h")),
+                  ("k_chain_", ("cx_chain.hip",)), ("k_rule64w", ("cx_mv64w.hip", "cx_mv64w_core.h")), ("k_rule64", ("cx_mv64.hip",)),
+                  ("k_sweep", ("cx_kernels.hip",)), ("k_mf_", ("cx_vmp.hip",)), ("k_rate", ("cx_vmp.hip",)), ("k_gamma", ("cx_vmp.hip",)),
+                  ("k_set_q", ("cx_vmp.hip",)), ("k_pull", ("cx_vmp.hip",)), ("k_reduce", ("cx_vmp.hip",)))
+
+
+def sources_sha16(kernel_name: str) -> str:
+    """16 hex digits over the sources of `kernel_name`; unknown kernels hash every file of csrc/"""
+    import hashlib
+
+    name = kernel_name.replace("cx::", "").replace("void ", "")
+    files = None
+    for prefix, fs in KERNEL_SOURCES:
+        if name.startswith(prefix):
+            files = list(fs)          # (cx_internal.h holds the host's handle struct, which changes for reasons no kernel sees)
+            break
+    if files is None:
+        files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""tools/lab/conditioning.py — what tolerance the d > 1 kernels actually hold on ill-conditioned models (cond(Q) = 1e6, |A| near 1):
+"""tests/lab_conditioning.py — what tolerance the d > 1 kernels actually hold on ill-conditioned models (cond(Q) = 1e6, |A| near 1):
 device vs the exact smoother, with the two exact solvers' disagreement (numpy LU vs C LU) beside it as the oracle's own error."""
 import os, sys, json
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import cortex.jl_amd as cx
 from cortex.jl_amd import _lib as L

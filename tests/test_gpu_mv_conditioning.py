@@ -4,7 +4,7 @@ Both small-d and d = 64 rules factor M = Lambda + P with an UN-PIVOTED Cholesky 
 (csrc/cx_mv_core.h: chol, csrc/cx_mv64w_core.h).  Round 2 tested them on well-conditioned models only (A = 0.95 * orthogonal,
 Q = 0.1 I, R = I).  Here: cond(Q) = 1e6 and |A| = 0.99, against the exact smoother in x86 extended precision
 (oracle/exact.py:lgssm_posterior_longdouble) — two f64 solvers of these systems already disagree at ~cond(Q) * 1e-15, so an f64
-oracle cannot tell a device error from its own.  What is asserted is what was measured (tools/lab/conditioning.py):
+oracle cannot tell a device error from its own.  What is asserted is what was measured (tests/lab_conditioning.py):
 the device is as accurate as numpy's pivoted f64 solve of the same posterior; and non-PD inputs leave the affected results
 UNDEFINED or unchanged — never a half-written or NaN-poisoned message that spreads."""
 import numpy as np

@@ -8,7 +8,7 @@ O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $R/bench.py --no-cpu-baseline"
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-other-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $BENCH --steps 200 --warmup 20 > $O/trace.log 2>&1 || { tail -5 $O/trace.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $BENCH --steps 20 --warmup 3 > $O/fetch.log 2>&1 || { tail -5 $O/fetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $BENCH --steps 20 --warmup 3 > $O/write.log 2>&1 || { tail -5 $O/write.log; exit 1; }

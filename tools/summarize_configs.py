@@ -9,6 +9,12 @@ import json
 import os
 
 
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from importlib import import_module
+sources_sha16 = import_module("cortex.jl_amd.build").sources_sha16      # the figure is refused once the kernel's sources change
+
+
 def short(name):
     return name.split("(")[0].replace("void ", "")[:90]
 
@@ -51,7 +57,7 @@ def main():
         rd = med(fetch[k]) * 1024 * 2 if k in fetch else None
         wr = med(write[k]) * 1024 if k in write else None
         if rd is not None and wr is not None:
-            res["traffic"][k] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
+            res["traffic"][k] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr, "sources_sha16": sources_sha16(k)}
             lines.append(f"| `{k}` | {len(v)} | {sum(v)/len(v):.1f} | {med(v):.1f} | {rd/1e6:.2f} | {wr/1e6:.2f} | {(rd+wr)/med(v)/1e3:.0f} |")
         else:
             lines.append(f"| `{k}` | {len(v)} | {sum(v)/len(v):.1f} | {med(v):.1f} | - | - | - |")

@@ -116,7 +116,13 @@ def main():
                                "write_corrected": t["write_raw_bytes"] * wcorr, "correction": note}
             lines += [f"**dominant kernel** `{k}`: corrected HBM bytes per launch = **{hbm:.4g}** "
                       f"(reads {t['fetch_raw_bytes']*corr:.4g} + writes {t['write_raw_bytes']*wcorr:.4g}); {note}", ""]
-            json.dump({"kernel": "k_sweep<fused>", "hbm_bytes_per_launch": hbm, "source": f"profiles/{a.tag}_rocprof.md"},
+            import sys
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from importlib import import_module
+            sha = import_module("cortex.jl_amd.build").sources_sha16("k_sweep")
+            json.dump({"kernel": "k_sweep<fused>", "hbm_bytes_per_launch": hbm, "updates_per_launch": 16006480, "source": f"profiles/{a.tag}_rocprof.md",
+                       "sources_sha16": sha, "sources_note": "sha256[:16] of the kernel's sources (cortex.jl_amd/build.py: sources_sha16): bench.py "
+                                                             "refuses this figure once they change"},
                       open(os.path.join(a.out, "traffic_latest.json"), "w"))
     open(os.path.join(a.out, f"{a.tag}_rocprof.md"), "w").write("\n".join(lines) + "\n")
     json.dump(res, open(os.path.join(a.out, f"{a.tag}_rocprof.json"), "w"), indent=1)
