@@ -649,6 +649,12 @@ class ChainScanExchange:
 
     def __init__(self, block, part: Partition, dist, torch, device="cpu"):
         self.block, self.part, self.dist, self.torch, self.device = block, part, dist, torch, device
+        # cx_chain_block_maps composes the maps of a block's LINKS: a block of one latent variable has none (the library refuses it
+        # with "must form ONE path").  Say so here, where the cause is visible: more ranks than the chain has pairs of states.
+        owned = np.setdiff1d(np.intersect1d(np.asarray(part.model.x_ids), np.asarray(part.model.edge_var)), np.asarray(part.recv_var))
+        if len(owned) < 2:
+            raise ValueError(f"ChainScanExchange: rank {part.rank} of {part.world} holds {len(owned)} latent variable(s); a time block needs at "
+                             "least two (one link) — use fewer ranks for a chain this short")
         fv = dict(zip(np.asarray(part.model.factor_ids).tolist(), np.asarray(part.model.factor_var).tolist()))
         self.left = self.right = None        # (stand-in variable, cut factor, own end variable, factor variance)
         for p in part.peers:

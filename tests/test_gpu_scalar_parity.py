@@ -128,7 +128,7 @@ def test_errors_are_statuses_not_crashes(hip_lib):
         dev.get_messages([1], [999], L.TO_VARIABLE)
     assert e.value.code == L.ERR_NOT_FOUND and "999" in e.value.message
     with pytest.raises(cx.CortexHipError) as e:
-        dev.update_batch([3], [1], [1])  # ProductOfMessages: no device rule (reference default: error(...))
+        dev.update_batch([3], [1], [1])  # 3 is no item kind (CX_ITEM_* are 1, 2, 4, 8, 16): the reference's error("...no rule...") branch
     assert e.value.code == L.ERR_UNSUPPORTED
 
 

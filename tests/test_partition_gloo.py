@@ -409,3 +409,14 @@ def test_gloo_deep_halo_for_d_dimensional_messages(tmp_path, world, d, depth):
         assert np.array_equal(g["mean"], m[li]) and np.array_equal(g["cov"], S[li])
         seen.append(g["owned"])
     assert np.array_equal(np.sort(np.concatenate(seen)), np.sort(whole.x_ids))
+
+
+def test_chain_scan_exchange_refuses_a_block_of_one_state():
+    """world large relative to T leaves a rank with a single latent variable — no link, no block map: a clear error"""
+    from cortex.jl_amd import partition
+
+    model = cx.synth.ssm_chain(5, seed=1)
+    part = partition.contiguous_blocks(model, 1, 4)
+    with pytest.raises(ValueError, match="at least two"):
+        partition.ChainScanExchange(None, part, None, None)
+    partition.ChainScanExchange(None, partition.contiguous_blocks(model, 0, 2), None, None)     # 2 or 3 states per block: fine
