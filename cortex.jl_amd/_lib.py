@@ -87,6 +87,7 @@ SIGNATURES = {
     "cx_halo_state_pack": (_i32, [_vp]),
     "cx_halo_state_unpack": (_i32, [_vp]),
     "cx_halo_state_exchange": (_i32, [_vp]),
+    "cx_halo_exchange_sweep": (_i32, [_vp, _i32]),
     "cx_chain_block_maps": (_i32, [_vp, _pd, _pd, _pd, _pd, _pi64, _pi64, _pi64]),
     "cx_set_marginals": (_i32, [_vp, _i64, _pi64, _i32, _pd]),
     "cx_update_marginals": (_i32, [_vp, _i64, _pi64]),

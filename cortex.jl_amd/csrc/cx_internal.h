@@ -118,6 +118,8 @@ struct cx_handle {
     int halo_depth = 0, sweeps_since_exchange = 0;
     std::vector<int32_t> trim_lo, trim_hi;   // [depth + 1]: first / last slice holding a variable of layer <= L
     int run_slice0 = 0, run_nslices = 0;     // what launch_fused covers (0 slices: everything)
+    int run_excl_lo = 1, run_excl_hi = 0;    // ... minus this slice range (empty by default)
+    int own_slice_lo = 1, own_slice_hi = 0;  // deep halo: the run of slices that hold OWNED variables only (cx_halo_set_layers); empty: none
     // RCCL exchange issued by the library (cx_comm.hip)
     struct Peer { int rank; int64_t send_off, send_count, recv_off, recv_count; };
     std::vector<Peer> peers;

@@ -128,11 +128,12 @@ __global__ __launch_bounds__(kBlock) void k_sweep(int nv, const int32_t *__restr
                                                   const double *__restrict__ sa, const double *__restrict__ sb,
                                                   const double2 *__restrict__ f2v_in, double2 *__restrict__ f2v_out,
                                                   double2 *__restrict__ v2f, double2 *__restrict__ marg, int write_marg,
-                                                  int skip_ghosts, int nt_out, int slice_lo, int slice_hi) {
+                                                  int skip_ghosts, int nt_out, int slice_lo, int slice_hi, int excl_lo, int excl_hi) {
     // the slice -> XCD mapping stays the same from sweep to sweep (a strip's messages largely live in the L2s between sweeps:
-    // launching only the active slice range re-deals the slices over the XCDs and measured 10 % SLOWER); idle slices exit here
+    // launching only the active slice range re-deals the slices over the XCDs and measured 10 % SLOWER); idle slices exit here.
+    // [excl_lo, excl_hi]: slices another launch of the same sweep covers (the owned interior, run beside the halo exchange)
     const int s = xcd_slab(blockIdx.x, gridDim.x);
-    if (s < slice_lo || s > slice_hi) return;
+    if (s < slice_lo || s > slice_hi || (s >= excl_lo && s <= excl_hi)) return;
     const int tid = threadIdx.x;
     const int v = (s << kSliceShift) + tid;
     const int off = slice_off[s];
@@ -488,9 +489,10 @@ static void launch_sweep_t(cx_handle *h, const double2 *f2v_in, double2 *f2v_out
     const double *sq = h->any_linear ? h->d_sq : h->d_q;  // additive factors: q is symmetric in the two edges
     // deep-halo partitions: k sweeps after an exchange only the redundant layers that can still be valid are run (slice range)
     const int lo = (PUSH && h->run_nslices > 0) ? h->run_slice0 : 0, hi = (PUSH && h->run_nslices > 0) ? h->run_slice0 + h->run_nslices - 1 : (int)h->nslices;
+    const int xlo = PUSH ? h->run_excl_lo : 1, xhi = PUSH ? h->run_excl_hi : 0;
     hipLaunchKernelGGL((k_sweep<LINEAR, STORE, PUSH>), dim3((unsigned)h->nslices), dim3(kBlock), 0, h->stream, (int)h->nv,
                        h->d_slice_off, h->d_vinfo, h->d_partner, sq, h->d_sa, h->d_sb, f2v_in, f2v_out, h->d_v2f, h->d_marg,
-                       write_marg ? (h->cfg.family == CX_FAMILY_NATURAL2 ? 2 : 1) : 0, skip_ghosts ? 1 : 0, nt_scatter(h), lo, hi);
+                       write_marg ? (h->cfg.family == CX_FAMILY_NATURAL2 ? 2 : 1) : 0, skip_ghosts ? 1 : 0, nt_scatter(h), lo, hi, xlo, xhi);
 }
 
 void launch_fused(cx_handle *h, const double2 *f2v_in, double2 *f2v_out, bool write_marg, bool store_v2f, bool skip_ghosts) {

@@ -202,6 +202,10 @@ class DeviceGraph:
     def halo_state_exchange(self):
         self._check(self.lib.cx_halo_state_exchange(self.h))
 
+    def halo_exchange_sweep(self, n: int):
+        """the exchange and n sweeps, the exchange overlapped with the owned part of the first sweep"""
+        self._check(self.lib.cx_halo_exchange_sweep(self.h, int(n)))
+
     @property
     def halo_doubles(self) -> int:
         """doubles per message in the halo buffers (the storage form)"""

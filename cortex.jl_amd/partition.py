@@ -415,8 +415,15 @@ def deep_self(n_rows: int, n_cols: int, depth: int, seed: int = 1234) -> Partiti
     v, f = ev[m], ef[m]
     o = np.lexsort((f, v))
     v, f = v[o], f[o]
+    # the exchanged rows count as layer 1 — "rewritten by an exchange" — whatever their distance from the edge, so that every
+    # sweep of a batch still runs them (they are real rows here: trimming must not drop them) while cx_halo_exchange_sweep sees
+    # which slices hold no exchanged variable and can run beside the exchange
+    xs = np.asarray(model.x_ids, np.int64)
+    xrow = (xs - 1) // n_cols
+    lv = xs[(xrow < depth) | (xrow >= n_rows - depth)]
     return Partition(model=model, rank=0, world=1, send_var=v, send_fac=f, recv_var=v, recv_fac=f,
-                     peers=[Peer(0, slice(0, len(v)), slice(0, len(v)))], depth=depth, owned_x=np.asarray(model.x_ids))
+                     peers=[Peer(0, slice(0, len(v)), slice(0, len(v)))], depth=depth, owned_x=np.asarray(model.x_ids),
+                     layer_var=lv, layer=np.ones(len(lv), np.int32))
 
 
 class RcclExchange:
@@ -453,8 +460,12 @@ class DeepHaloRccl:
     """Deep-halo partition driven by the library: one cx_halo_state_exchange (pack, grouped RCCL send/recv, unpack, all on
     the handle's stream) before every `depth` plain sweeps."""
 
-    def __init__(self, dev, part: Partition, dist=None, torch=None, device=None):
-        self.dev, self.depth, self.k = dev, part.depth, 0
+    def __init__(self, dev, part: Partition, dist=None, torch=None, device=None, overlap: bool = False):
+        """overlap: cx_halo_exchange_sweep (the exchange on a second stream beside the owned part of the batch's first sweep) instead
+        of cx_halo_state_exchange + cx_sweep.  Bit-identical; measured SLOWER on one MI355X (13.2 against 11.1-11.5 us per sweep for
+        a 1/8 strip of C4 at depth 16: the two cross-stream hand-offs and the split sweep cost more than the 9 us of sweep the
+        exchange hides behind), hence off by default."""
+        self.dev, self.depth, self.k, self.overlap = dev, part.depth, 0, overlap
         dev.halo_configure_state(part.send_var, part.send_fac, part.recv_var, part.recv_fac)
         if part.layer_var is not None and part.depth and dev.dim == 1:
             dev.halo_set_layers(part.layer_var, part.layer, part.depth)    # trimmed sweeps between exchanges
@@ -480,10 +491,13 @@ class DeepHaloRccl:
         """n sweeps; the sweeps between two exchanges go to the library as ONE cx_sweep call (at 1/8 of the C4 grid a sweep is
         a few microseconds of kernel: a Python call per sweep would be the bound)"""
         while n > 0:
-            if self.k % self.depth == 0:
-                self.dev.halo_state_exchange()
             run = min(n, self.depth - self.k % self.depth)
-            self.dev.sweep(run)
+            if self.k % self.depth == 0 and self.overlap:
+                self.dev.halo_exchange_sweep(run)       # the exchange rides beside the owned part of the batch's first sweep
+            else:
+                if self.k % self.depth == 0:
+                    self.dev.halo_state_exchange()
+                self.dev.sweep(run)
             self.k += run
             n -= run
 

@@ -304,6 +304,12 @@ int32_t cx_halo_set_layers(cx_handle *h, int64_t n, const int64_t *variable_ids,
 int32_t cx_halo_state_pack(cx_handle *h);
 int32_t cx_halo_state_unpack(cx_handle *h);
 int32_t cx_halo_state_exchange(cx_handle *h);
+/*   cx_halo_exchange_sweep  : one batch = the exchange AND n_sweeps sweeps, the exchange overlapped with the first sweep: the slices
+ *                             that hold owned variables only (known from cx_halo_set_layers) run on the handle's stream while a
+ *                             second stream packs, sends / receives and unpacks; the redundant rows' part of that sweep follows the
+ *                             unpack.  Bit-identical to cx_halo_state_exchange + cx_sweep(n_sweeps), and falls back to exactly that
+ *                             when the handle cannot split a sweep (no layers, dim > 1, another schedule). */
+int32_t cx_halo_exchange_sweep(cx_handle *h, int32_t n_sweeps);
 
 /* ---- partitioned chain scan (CX_SCHED_CHAIN_SCAN; SURVEY.md §8e: "contiguous time blocks + one composed map per block") ----
  * A rank holds a time block of a chain (its own variables, the cut transition factors, the remote end of each as a degree-1

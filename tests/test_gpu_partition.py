@@ -270,15 +270,23 @@ def test_deep_halo_equals_whole_grid(hip_lib, schedule, world, rows, cols, depth
         assert np.array_equal(devs[rank].get_marginals(part.owned_x), whole.get_marginals(part.owned_x), equal_nan=True)
 
 
-def test_deep_halo_exchange_issued_by_the_library(hip_lib):
-    """cx_halo_state_exchange with real RCCL on one GPU: rank 0 exports and imports the same boundary rows (its own
-    neighbour), so the sweeps must stay bit-identical to the plain handle while pack / send / recv / unpack run."""
-    rows, cols, depth, sweeps = 30, 64, 4, 11
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("rows,cols,depth,sweeps", [(30, 64, 4, 11), (120, 300, 8, 27), (64, 256, 16, 33)])
+def test_deep_halo_exchange_issued_by_the_library(hip_lib, rows, cols, depth, sweeps, overlap):
+    """cx_halo_state_exchange / cx_halo_exchange_sweep with real RCCL on one GPU: rank 0 exports and imports the same boundary rows
+    (its own neighbour), so the sweeps must stay bit-identical to the plain handle while pack / send / recv / unpack run.
+    overlap: the exchange on the communication stream beside the owned part of the batch's first sweep (two launches for that
+    sweep: the slices of owned variables only, then — after the unpack — everything else)."""
     part = partition.deep_self(rows, cols, depth, seed=8)
     dev = cx.DeviceGraph(schedule=L.SCHED_FUSED)
     cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
-    ex = partition.DeepHaloRccl(dev, part)
+    ex = partition.DeepHaloRccl(dev, part, overlap=overlap)
+    dev.profile_enable(1)
     ex.sweep(sweeps)
+    _ms, launches = dev.profile_read(L.KERNEL_FUSED)
+    dev.profile_enable(0)
+    exchanges = -(-sweeps // depth)
+    assert launches == sweeps + (exchanges if overlap else 0), "the overlapped batch splits its first sweep into two launches"
     plain = cx.DeviceGraph(schedule=L.SCHED_FUSED)
     cx.synth.load_into_device(part.model, plain, seed_variance=1e6)
     plain.sweep(sweeps)
