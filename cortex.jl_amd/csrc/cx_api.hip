@@ -104,6 +104,7 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
     if (!h) return fail(nullptr, CX_ERR_OUT_OF_MEMORY, "cx_create: host allocation failed");
     h->cfg = *config;
     h->nc = config->dim == 1 ? 2 : (config->dim == 64 ? 64 + 64 * 64 : config->dim + config->dim * (config->dim + 1) / 2);
+    h->ncs = (config->dim >= 2 && config->dim <= 4) ? 2 * ((h->nc + 1) / 2) : h->nc;
     h->stream = nullptr;  // default stream until cx_set_stream
     *out = h;
     return CX_OK;
@@ -387,14 +388,14 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
         CX_TRY(dev_alloc(h, &h->d_big_tmp, big_total));
         CX_TRY(dev_alloc(h, &h->d_scratch, 4096));
         if (mv) {
-            const int64_t nc = h->nc;
+            const int64_t nc = h->nc, ncs = h->ncs;
             h->spdir = spdir; h->spdir_dirty = true;
             CX_TRY(dev_upload(h, &h->d_spdir, spdir));
-            CX_TRY(dev_alloc(h, &h->d_mv_f2v, nc * slots)); CX_TRY(dev_alloc(h, &h->d_mv_f2v_alt, nc * slots));
-            CX_TRY(dev_alloc(h, &h->d_mv_v2f, nc * slots)); CX_TRY(dev_alloc(h, &h->d_mv_marg, h->cfg.dim == 64 ? 1 : nc * nv));
-            CX_HIP(h, hipMemsetAsync(h->d_mv_f2v, 0xff, (size_t)(nc * slots) * 8, h->stream));
-            CX_HIP(h, hipMemsetAsync(h->d_mv_f2v_alt, 0xff, (size_t)(nc * slots) * 8, h->stream));
-            CX_HIP(h, hipMemsetAsync(h->d_mv_v2f, 0xff, (size_t)(nc * slots) * 8, h->stream));
+            CX_TRY(dev_alloc(h, &h->d_mv_f2v, ncs * slots)); CX_TRY(dev_alloc(h, &h->d_mv_f2v_alt, ncs * slots));
+            CX_TRY(dev_alloc(h, &h->d_mv_v2f, ncs * slots)); CX_TRY(dev_alloc(h, &h->d_mv_marg, h->cfg.dim == 64 ? 1 : nc * nv));
+            CX_HIP(h, hipMemsetAsync(h->d_mv_f2v, 0xff, (size_t)(ncs * slots) * 8, h->stream));
+            CX_HIP(h, hipMemsetAsync(h->d_mv_f2v_alt, 0xff, (size_t)(ncs * slots) * 8, h->stream));
+            CX_HIP(h, hipMemsetAsync(h->d_mv_v2f, 0xff, (size_t)(ncs * slots) * 8, h->stream));
             if (h->cfg.dim != 64) CX_HIP(h, hipMemsetAsync(h->d_mv_marg, 0xff, (size_t)(nc * nv) * 8, h->stream));
             CX_HIP(h, hipStreamSynchronize(h->stream));
             h->has_graph = true;

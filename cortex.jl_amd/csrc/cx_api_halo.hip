@@ -87,13 +87,13 @@ static void state_pack(cx_handle *h) {
     const int64_t n = (int64_t)h->send_slots.size();
     if (h->cfg.dim == 1) cx::launch_gather(h, h->d_f2v, h->d_send_slots, h->d_send_buf, n);
     else if (h->cfg.dim == 64) cx::mv64_rows_gather(h, h->d_mv_f2v, h->d_send_slots, (double *)h->d_send_buf, n);
-    else cx::mv_launch_gather(h, h->d_mv_f2v, h->nslots, h->nc, h->d_send_slots, (double *)h->d_send_buf, n);
+    else cx::mv_launch_gather(h, h->d_mv_f2v, h->nslots, h->nc, h->ncs, h->d_send_slots, (double *)h->d_send_buf, n);
 }
 static void state_unpack(cx_handle *h) {
     const int64_t n = (int64_t)h->recv_slots.size();
     if (h->cfg.dim == 1) cx::launch_scatter(h, h->d_f2v, h->d_recv_slots, h->d_recv_buf, n);
     else if (h->cfg.dim == 64) cx::mv64_rows_scatter(h, h->d_mv_f2v, h->d_recv_slots, (const double *)h->d_recv_buf, n);
-    else cx::mv_launch_scatter(h, h->d_mv_f2v, h->nslots, h->nc, h->d_recv_slots, (const double *)h->d_recv_buf, n);
+    else cx::mv_launch_scatter(h, h->d_mv_f2v, h->nslots, h->nc, h->ncs, h->d_recv_slots, (const double *)h->d_recv_buf, n);
 }
 
 // Deep halo, trimmed sweeps.  `layer` = distance of a redundant variable from the owned set (1 .. depth; the stand-ins beyond are

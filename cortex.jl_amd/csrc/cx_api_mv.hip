@@ -132,7 +132,7 @@ int32_t mv_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
     CX_HIP(h, hipMemcpyAsync(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice, h->stream));
     CX_HIP(h, hipMemcpyAsync(d_val, val.data(), (size_t)n * nc * 8, hipMemcpyHostToDevice, h->stream));
     if (direction == CX_TO_FACTOR) {
-        cx::mv_launch_scatter(h, h->d_mv_v2f, h->nslots, nc, d_idx, d_val, n);
+        cx::mv_launch_scatter(h, h->d_mv_v2f, h->nslots, nc, h->ncs, d_idx, d_val, n);
         h->observed_passes_due = 2;   // a stored variable→factor message changed: observed senders are refreshed
         if (form == CX_FORM_POINT) {
             for (int64_t i = 0; i < n; i++)
@@ -141,8 +141,8 @@ int32_t mv_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
             h->spdir_dirty = true;
         }
     } else {
-        cx::mv_launch_scatter(h, h->d_mv_f2v, h->nslots, nc, d_idx, d_val, n);
-        cx::mv_launch_scatter(h, h->d_mv_f2v_alt, h->nslots, nc, d_idx, d_val, n);
+        cx::mv_launch_scatter(h, h->d_mv_f2v, h->nslots, nc, h->ncs, d_idx, d_val, n);
+        cx::mv_launch_scatter(h, h->d_mv_f2v_alt, h->nslots, nc, h->ncs, d_idx, d_val, n);
     }
     CX_HIP(h, hipGetLastError());
     CX_HIP(h, hipStreamSynchronize(h->stream));
@@ -182,7 +182,7 @@ int32_t mv_get(cx_handle *h, const double *src, int64_t stride, const std::vecto
         }
         return CX_OK;
     }
-    cx::mv_launch_gather(h, src, stride, nc, d_idx, d_val, n);
+    cx::mv_launch_gather(h, src, stride, nc, already_moment ? 0 : h->ncs, d_idx, d_val, n);      // the marginals are a plain component-major array
     std::vector<double> val((size_t)n * nc);
     CX_HIP(h, hipMemcpyAsync(val.data(), d_val, (size_t)n * nc * 8, hipMemcpyDeviceToHost, h->stream));
     CX_HIP(h, hipStreamSynchronize(h->stream));
@@ -409,7 +409,7 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
 }
 
 int32_t mv_residual(cx_handle *h, double *out) {
-    const int64_t n = h->nc * h->nslots;
+    const int64_t n = h->ncs * h->nslots;      // every stored double (the padding of d = 2, 3 is equal in both snapshots)
     { int32_t rc = mv_ensure_chain_msgs(h); if (rc != CX_OK) return rc; }
     if (!h->d_mv_prev) {
         int32_t rc = dev_alloc(h, &h->d_mv_prev, n);

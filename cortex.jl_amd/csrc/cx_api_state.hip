@@ -70,10 +70,10 @@ std::vector<StatePart> state_parts(cx_handle *h) {
         parts.push_back({4, h->d_v2f, slots * 16});
         parts.push_back({5, h->d_marg, nv * 16});
     } else {
-        const int64_t nc = h->nc;
-        parts.push_back({2, h->d_mv_f2v, nc * slots * 8});
-        parts.push_back({3, h->d_mv_f2v_alt, nc * slots * 8});
-        parts.push_back({4, h->d_mv_v2f, nc * slots * 8});
+        const int64_t nc = h->nc, ncs = h->ncs;
+        parts.push_back({2, h->d_mv_f2v, ncs * slots * 8});
+        parts.push_back({3, h->d_mv_f2v_alt, ncs * slots * 8});
+        parts.push_back({4, h->d_mv_v2f, ncs * slots * 8});
         if (h->cfg.dim != 64) parts.push_back({5, h->d_mv_marg, nc * nv * 8});
     }
     return parts;

@@ -128,10 +128,10 @@ int32_t build_chains(cx_handle *h) {
             h->mvc_K = cx::mvc_links_per_thread(h->chain_nlinks);
             const int64_t il = cx::mvc_ntiles(h->chain_nlinks, h->mvc_K) * cx::kBlock * h->mvc_K;     // interleaved arrays, padded to whole tiles
             if ((rc = dev_alloc(h, &h->d_mvc_side, h->nc * h->chain_npos)) != CX_OK) return rc;
-            if ((rc = dev_alloc(h, &h->d_mvc_side_l, h->nc * il)) != CX_OK) return rc;
-            if ((rc = dev_alloc(h, &h->d_mvc_side_r, h->nc * il)) != CX_OK) return rc;
-            if ((rc = dev_alloc(h, &h->d_mvc_alpha, h->nc * il)) != CX_OK) return rc;
-            if ((rc = dev_alloc(h, &h->d_mvc_gamma, h->nc * il)) != CX_OK) return rc;
+            if ((rc = dev_alloc(h, &h->d_mvc_side_l, h->ncs * il)) != CX_OK) return rc;
+            if ((rc = dev_alloc(h, &h->d_mvc_side_r, h->ncs * il)) != CX_OK) return rc;
+            if ((rc = dev_alloc(h, &h->d_mvc_alpha, h->ncs * il)) != CX_OK) return rc;
+            if ((rc = dev_alloc(h, &h->d_mvc_gamma, h->ncs * il)) != CX_OK) return rc;
             if ((rc = dev_alloc(h, &h->d_mvc_prefix, (int64_t)cx::mvc_prefix_doubles(h->cfg.dim, h->chain_nlinks, h->mvc_K))) != CX_OK) return rc;
             if ((rc = dev_alloc(h, &h->d_mvc_totals, (int64_t)cx::mvc_totals_doubles(h->cfg.dim, h->chain_nlinks, h->mvc_K))) != CX_OK) return rc;
         } else {

@@ -73,7 +73,8 @@ struct cx_handle {
     int64_t device_bytes = 0;
 
     // multivariate path (cx_mv.hip), dim in {2,3,4}: SoA component-major buffers [nc][nslots], packed symmetric Lambda
-    int nc = 2;                                    // stored doubles per message
+    int nc = 2;                                    // doubles per message (eta + packed Lambda; 64 + 64*64 for dim 64)
+    int ncs = 2;                                   // STORED doubles per message slot: dim 2..4 pad nc to whole 16-byte pairs (cx_mv_core.h)
     std::vector<std::vector<double>> psets;        // per parameter set: A (d*d) then Q (d*d)
     int32_t *d_spdir = nullptr;                    // per SENDING slot: 2*pset + direction of the receiving edge; -1: receiver observed
     std::vector<int32_t> spdir;                    // host copy without the observed-receiver mask
@@ -201,8 +202,8 @@ void launch_tiled2(cx_handle *h, const double2 *f2v_in, double2 *f2v_out, bool w
 // multivariate (cx_mv.hip)
 void mv_launch_sweep(cx_handle *h, bool write_marg, int only, double *f2v_out = nullptr);   // only: 0 regular, 1 observed variables, 2 other fixed senders (degree 1, stand-ins)
 void mv_launch_v2f(cx_handle *h, const int32_t *d_slots, const int32_t *d_vars, int64_t n, const double *f2v);
-void mv_launch_scatter(cx_handle *h, double *dst, int64_t stride, int nc, const int32_t *d_idx, const double *d_val, int64_t n);
-void mv_launch_gather(cx_handle *h, const double *src, int64_t stride, int nc, const int32_t *d_idx, double *d_val, int64_t n);
+void mv_launch_scatter(cx_handle *h, double *dst, int64_t stride, int nc, int ncs, const int32_t *d_idx, const double *d_val, int64_t n);
+void mv_launch_gather(cx_handle *h, const double *src, int64_t stride, int nc, int ncs, const int32_t *d_idx, double *d_val, int64_t n);
 void mv_launch_seed(cx_handle *h, double *buf, double eta, double lam);
 void mv_launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n);   // cx_mvbatch.hip: 5 int32 per item (kind, index, variable, rule table, 0)
 void mv_launch_residual(cx_handle *h, const double *cur, const double *prev, int64_t n, double *d_out);

@@ -7,9 +7,9 @@
 // x_out = A x_in + N(0, Q).  Parity for dim > 1 is therefore against exact block-tridiagonal solves and the numpy
 // restatement kept with the tests ("parity unpinned" by the reference itself — DESIGN.md §3).
 //
-// Storage: natural form (eta = Lambda mu, Lambda = Sigma^-1), symmetric Lambda packed (upper triangle), component-major
-// SoA over the same SELL-256 slots as the scalar path: component c of slot s at buf[c * nslots + s], so lane <-> variable
-// loads are unit-stride per component.  d = 4: 14 doubles = 112 B per message (the dense 4 + 16 layout would be 160 B).
+// Storage: natural form (eta = Lambda mu, Lambda = Sigma^-1), symmetric Lambda packed (upper triangle), over the same SELL-256
+// slots as the scalar path, block-major in 16-byte pairs (cx_mv_core.h: slot_load / slot_store): lane <-> variable accesses are
+// one contiguous kilobyte per wave and plane.  d = 4: 14 doubles = 112 B per message (the dense 4 + 16 layout would be 160 B).
 //
 // Factor rule with the receiving edge's precomputed triple (P, B, C) — host side, from (A, Q), Qi = Q^-1:
 //   receiver = out (forward):  P = A' Qi A,  B = Qi A,   C = Qi
@@ -44,7 +44,7 @@ constexpr int kTabLds = 8;   // parameter-set/direction pairs kept in LDS (3 d*d
 // DEG: the largest variable degree of the graph (3 or 4).  A state-space chain has degree 3: three incoming messages instead of four
 // are 28 registers less for d = 4 — 168 VGPRs, THREE waves per SIMD instead of two (no scratch), which is what this kernel's
 // load / compute lock-step was short of.
-template <int D, int DEG>
+template <int D, int DEG, bool NT_LOADS>
 __global__ __launch_bounds__(kBlock, DEG == 3 ? 3 : 2) void k_sweep_mv(int nv, int64_t nslots, const int32_t *__restrict__ slice_off,
                                                      const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
                                                      const int32_t *__restrict__ spdir, const double *__restrict__ ptab, int ntab,
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kBlock, DEG == 3 ? 3 : 2) void k_sweep_mv(int nv, i
         in[k] = msg_zero<D>();
         pk[k] = -1; sd[k] = -1;
         if (k < W && active) {   // k < W is uniform; lanes with deg <= k read a padding slot of their own slice and drop it
-            const Msg<D> x = msg_load<D>(f2v_in, nslots, base + k * kBlock);
+            const Msg<D> x = NT_LOADS ? slot_load<D, true>(f2v_in, base + k * kBlock) : slot_load<D, false>(f2v_in, base + k * kBlock);
             const int p = partner[base + k * kBlock], d = spdir[base + k * kBlock];
             if (k < deg) { in[k] = x; pk[k] = p; sd[k] = d; }
         }
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kBlock, DEG == 3 ? 3 : 2) void k_sweep_mv(int nv, i
         if (p < 0 || pd < 0) continue;
         Msg<D> o;
         if (fixed) {
-            o = msg_load<D>(v2f, nslots, slot);
+            o = slot_load<D>(v2f, slot);
         } else {
             o = msg_zero<D>();
 #pragma unroll
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kBlock, DEG == 3 ? 3 : 2) void k_sweep_mv(int nv, i
         }
         if (__builtin_isnan(o.lam[0])) continue;
         const Msg<D> r = pd < nt ? mv_rule<D>(o, tab_s + pd * 3 * D * D) : mv_rule<D>(o, ptab + (int64_t)pd * 3 * D * D);
-        if (!__builtin_isnan(r.lam[0])) msg_store<D>(f2v_out, nslots, p, r);
+        if (!__builtin_isnan(r.lam[0])) slot_store<D>(f2v_out, p, r);
     }
 }
 
@@ -133,33 +133,42 @@ __global__ __launch_bounds__(kBlock) void k_v2f_mv(int64_t n, int64_t nslots, co
     const int b = vbase[v];
     Msg<D> o = msg_zero<D>();
     for (int j = 0; j < deg; j++)
-        if (b + j * kBlock != slot) msg_add<D>(o, msg_load<D>(f2v, nslots, b + j * kBlock));
-    if (!__builtin_isnan(o.lam[0])) msg_store<D>(v2f, nslots, slot, o);
+        if (b + j * kBlock != slot) msg_add<D>(o, slot_load<D>(f2v, b + j * kBlock));
+    if (!__builtin_isnan(o.lam[0])) slot_store<D>(v2f, slot, o);
 }
 
-__global__ void k_mv_scatter(double *__restrict__ dst, int64_t nslots, int nc, const int32_t *__restrict__ idx,
+// host staging <-> device.  ncs > 0: a MESSAGE buffer (block-major pairs, ncs stored doubles per slot: cx_mv_core.h);
+// ncs == 0: a plain component-major array of `stride` entries (the marginals).  Staging rows are nc doubles, compact.
+__device__ __forceinline__ int64_t mv_addr(int64_t stride, int ncs, int c, int idx) {
+    return ncs ? (int64_t)(idx >> kSliceShift) * kBlock * ncs + (int64_t)(c >> 1) * 2 * kBlock + (int64_t)(idx & (kBlock - 1)) * 2 + (c & 1)
+               : (int64_t)c * stride + idx;
+}
+
+__global__ void k_mv_scatter(double *__restrict__ dst, int64_t stride, int nc, int ncs, const int32_t *__restrict__ idx,
                              const double *__restrict__ val, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    for (int c = 0; c < nc; c++) dst[(int64_t)c * nslots + idx[i]] = val[i * nc + c];
+    for (int c = 0; c < nc; c++) dst[mv_addr(stride, ncs, c, idx[i])] = val[i * nc + c];
+    for (int c = nc; c < ncs; c++) dst[mv_addr(stride, ncs, c, idx[i])] = 0.0;      // padding of the last pair
 }
 
-__global__ void k_mv_gather(const double *__restrict__ src, int64_t nslots, int nc, const int32_t *__restrict__ idx,
+__global__ void k_mv_gather(const double *__restrict__ src, int64_t stride, int nc, int ncs, const int32_t *__restrict__ idx,
                             double *__restrict__ val, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    for (int c = 0; c < nc; c++) val[i * nc + c] = src[(int64_t)c * nslots + idx[i]];
+    for (int c = 0; c < nc; c++) val[i * nc + c] = src[mv_addr(stride, ncs, c, idx[i])];
 }
 
-__global__ void k_mv_seed(double *__restrict__ buf, int64_t nslots, int dim, int nc, double eta, double lam,
+__global__ void k_mv_seed(double *__restrict__ buf, int64_t nslots, int dim, int nc, int ncs, double eta, double lam,
                           const int32_t *__restrict__ partner) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nslots || partner[s] < 0) return;
-    if (!__builtin_isnan(buf[(int64_t)dim * nslots + s])) return;
-    for (int i = 0; i < dim; i++) buf[(int64_t)i * nslots + s] = eta;
+    if (!__builtin_isnan(buf[mv_addr(nslots, ncs, dim, (int)s)])) return;
+    for (int i = 0; i < dim; i++) buf[mv_addr(nslots, ncs, i, (int)s)] = eta;
     int c = dim;
     for (int i = 0; i < dim; i++)
-        for (int j = i; j < dim; j++) buf[(int64_t)(c++) * nslots + s] = (i == j) ? lam : 0.0;
+        for (int j = i; j < dim; j++) buf[mv_addr(nslots, ncs, c++, (int)s)] = (i == j) ? lam : 0.0;
+    for (; c < ncs; c++) buf[mv_addr(nslots, ncs, c, (int)s)] = 0.0;
 }
 
 __global__ __launch_bounds__(kBlock) void k_mv_residual(const double *__restrict__ cur, const double *__restrict__ prev, int64_t n,
@@ -215,9 +224,13 @@ void mv_launch_sweep(cx_handle *h, bool write_marg, int observed_only, double *f
     const bool deg3 = h->mv_max_deg <= 3 && !force4;
 #define CX_MV_ARGS g, b, 0, h->stream, (int)h->nv, h->nslots, h->d_slice_off, h->d_vinfo, h->d_partner, h->d_spdir, h->d_ptab, (int)(2 * h->ptab_sets), \
                    h->d_mv_f2v, f2v_out, h->d_mv_v2f, h->d_mv_marg, (write_marg && !observed_only) ? 1 : 0, observed_only
-#define CX_MV(DD)                                                          \
-    if (deg3) hipLaunchKernelGGL((k_sweep_mv<DD, 3>), CX_MV_ARGS);         \
-    else hipLaunchKernelGGL((k_sweep_mv<DD, 4>), CX_MV_ARGS)
+    // CX_MV_NT=0/1: nontemporal loads of the incoming messages off / on (A/B; default on: every message is read once per sweep)
+    static const bool nt = [] { const char *e = getenv("CX_MV_NT"); return !(e && e[0] == '0'); }();
+#define CX_MV(DD)                                                                      \
+    if (deg3 && nt) hipLaunchKernelGGL((k_sweep_mv<DD, 3, true>), CX_MV_ARGS);         \
+    else if (deg3) hipLaunchKernelGGL((k_sweep_mv<DD, 3, false>), CX_MV_ARGS);         \
+    else if (nt) hipLaunchKernelGGL((k_sweep_mv<DD, 4, true>), CX_MV_ARGS);            \
+    else hipLaunchKernelGGL((k_sweep_mv<DD, 4, false>), CX_MV_ARGS)
     if (h->cfg.dim == 2) CX_MV(2);
     else if (h->cfg.dim == 3) CX_MV(3);
     else CX_MV(4);
@@ -236,15 +249,15 @@ void mv_launch_v2f(cx_handle *h, const int32_t *d_slots, const int32_t *d_vars, 
 #undef CX_MV
 }
 
-void mv_launch_scatter(cx_handle *h, double *dst, int64_t stride, int nc, const int32_t *d_idx, const double *d_val, int64_t n) {
-    if (n) hipLaunchKernelGGL(k_mv_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, dst, stride, nc, d_idx, d_val, n);
+// ncs: h->ncs for a message buffer (f2v, v2f), 0 for the component-major marginals
+void mv_launch_scatter(cx_handle *h, double *dst, int64_t stride, int nc, int ncs, const int32_t *d_idx, const double *d_val, int64_t n) {
+    if (n) hipLaunchKernelGGL(k_mv_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, dst, stride, nc, ncs, d_idx, d_val, n);
 }
-void mv_launch_gather(cx_handle *h, const double *src, int64_t stride, int nc, const int32_t *d_idx, double *d_val, int64_t n) {
-    if (n) hipLaunchKernelGGL(k_mv_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, stride, nc, d_idx, d_val, n);
+void mv_launch_gather(cx_handle *h, const double *src, int64_t stride, int nc, int ncs, const int32_t *d_idx, double *d_val, int64_t n) {
+    if (n) hipLaunchKernelGGL(k_mv_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, stride, nc, ncs, d_idx, d_val, n);
 }
 void mv_launch_seed(cx_handle *h, double *buf, double eta, double lam) {
-    const int nc = h->cfg.dim + h->cfg.dim * (h->cfg.dim + 1) / 2;
-    hipLaunchKernelGGL(k_mv_seed, dim3((unsigned)((h->nslots + 255) / 256)), dim3(256), 0, h->stream, buf, h->nslots, h->cfg.dim, nc, eta,
+    hipLaunchKernelGGL(k_mv_seed, dim3((unsigned)((h->nslots + 255) / 256)), dim3(256), 0, h->stream, buf, h->nslots, h->cfg.dim, h->nc, h->ncs, eta,
                        lam, h->d_partner);
 }
 void mv_launch_residual(cx_handle *h, const double *cur, const double *prev, int64_t n, double *d_out) {

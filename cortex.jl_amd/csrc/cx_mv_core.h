@@ -49,6 +49,56 @@ __device__ __forceinline__ void msg_store(double *__restrict__ buf, int64_t nslo
     for (int i = 0; i < Msg<D>::NT; i++) buf[(int64_t)(D + i) * nslots + slot] = m.lam[i];
 }
 
+// ---- message buffers (factor→variable, variable→factor): block-major pairs, 16 bytes per lane ------------------------------------
+// The NC doubles of a message are stored as NCP = ceil(NC / 2) double2 "planes"; the planes of the 256 slots of one SELL block
+// sit next to each other:  address(slot, plane p) = (slot / 256) * (256 * 2 * NCP) + p * 512 + (slot % 256) * 2.
+// Lane <-> slot, so a wave's access to one plane is ONE contiguous kilobyte of 16-byte pieces (global_load_dwordx4), like the
+// scalar path's double2 messages.  (Round 2 stored NC component planes over all slots and read them 8 bytes per lane: a pure copy
+// of that shape reaches 5.3 TB/s on this part, this one 5.9: tools/lab/soa_streams.hip.)  d = 2 and 3 pad the last plane.
+template <int D>
+struct MsgStore {
+    static constexpr int NCP = (Msg<D>::NC + 1) / 2;      // planes
+    static constexpr int NCS = 2 * NCP;                   // stored doubles per slot
+    static constexpr int BLOCK = kBlock * NCS;            // doubles per 256-slot block
+};
+
+template <int D>
+__device__ __forceinline__ int64_t slot_offset(int slot) {
+    return (int64_t)(slot >> kSliceShift) * MsgStore<D>::BLOCK + (int64_t)(slot & (kBlock - 1)) * 2;
+}
+
+// NT: the message is read once by this launch and not again before it is overwritten (the streaming reads of a sweep)
+template <int D, bool NT = false>
+__device__ __forceinline__ Msg<D> slot_load(const double *__restrict__ buf, int slot) {
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const d2v *p = reinterpret_cast<const d2v *>(buf + slot_offset<D>(slot));
+    Msg<D> m;
+    double c[MsgStore<D>::NCS];
+#pragma unroll
+    for (int q = 0; q < MsgStore<D>::NCP; q++) {
+        const d2v t = NT ? __builtin_nontemporal_load(p + q * kBlock) : p[q * kBlock];
+        c[2 * q] = t.x; c[2 * q + 1] = t.y;
+    }
+#pragma unroll
+    for (int i = 0; i < D; i++) m.eta[i] = c[i];
+#pragma unroll
+    for (int i = 0; i < Msg<D>::NT; i++) m.lam[i] = c[D + i];
+    return m;
+}
+
+template <int D>
+__device__ __forceinline__ void slot_store(double *__restrict__ buf, int slot, const Msg<D> &m) {
+    double2 *p = reinterpret_cast<double2 *>(buf + slot_offset<D>(slot));
+    double c[MsgStore<D>::NCS];
+#pragma unroll
+    for (int i = 0; i < D; i++) c[i] = m.eta[i];
+#pragma unroll
+    for (int i = 0; i < Msg<D>::NT; i++) c[D + i] = m.lam[i];
+    if (MsgStore<D>::NCS > Msg<D>::NC) c[MsgStore<D>::NCS - 1] = 0.0;
+#pragma unroll
+    for (int q = 0; q < MsgStore<D>::NCP; q++) p[q * kBlock] = make_double2(c[2 * q], c[2 * q + 1]);
+}
+
 template <int D>
 __device__ __forceinline__ void msg_add(Msg<D> &a, const Msg<D> &b) {
 #pragma unroll

@@ -31,18 +31,18 @@ __global__ __launch_bounds__(kBlock) void k_batch_mv(int64_t n, const int32_t *_
         if (deg < 2 || (info & (kClamped | kGhost))) return;
         Msg<D> o = msg_zero<D>();
         for (int j = 0; j < deg; j++)
-            if (b + j * kBlock != idx) msg_add<D>(o, msg_load<D>(f2v, nslots, b + j * kBlock));
-        if (!__builtin_isnan(o.lam[0])) msg_store<D>(v2f, nslots, idx, o);
+            if (b + j * kBlock != idx) msg_add<D>(o, slot_load<D>(f2v, b + j * kBlock));
+        if (!__builtin_isnan(o.lam[0])) slot_store<D>(v2f, idx, o);
     } else if (kind == CX_ITEM_MESSAGE_TO_VARIABLE) {
         const int p = partner[idx];
         if (p < 0) return;                                  // an opaque factor's message is the caller's to set
-        const Msg<D> in = msg_load<D>(v2f, nslots, p);
+        const Msg<D> in = slot_load<D>(v2f, p);
         if (__builtin_isnan(in.lam[0])) return;
         const Msg<D> r = mv_rule<D>(in, ptab + (int64_t)tab * 3 * D * D);
-        if (!__builtin_isnan(r.lam[0])) msg_store<D>(f2v, nslots, idx, r);
+        if (!__builtin_isnan(r.lam[0])) slot_store<D>(f2v, idx, r);
     } else if (kind == CX_ITEM_INDIVIDUAL_MARGINAL) {
         Msg<D> total = msg_zero<D>();
-        for (int j = 0; j < deg; j++) msg_add<D>(total, msg_load<D>(f2v, nslots, b + j * kBlock));
+        for (int j = 0; j < deg; j++) msg_add<D>(total, slot_load<D>(f2v, b + j * kBlock));
         const bool ok = deg > 0 && !__builtin_isnan(total.lam[0]);
         const Msg<D> mo = ok ? mv_to_moment<D>(total) : total;
 #pragma unroll

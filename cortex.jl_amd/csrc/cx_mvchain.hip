@@ -184,8 +184,9 @@ struct MvcArgs {
     const uint8_t *head_fwd, *head_bwd;  // first / last link of its path
     const int32_t *pos_var;
     const double *side;                  // [nc][npos]: sum of the non-chain messages into each chain variable, by position
-    const double *side_l, *side_r;       // [nc][il_stride]: the same for the left / right variable of link l, at IL(l)
-    double *alpha, *gamma;               // [nc][il_stride] at IL(l): the forward message link l produces; what its right variable hears
+    const double *side_l, *side_r;       // the same for the left / right variable of link l, at IL(l); block-major pairs like the message
+                                         // buffers (cx_mv_core.h: slot_load): a block = the 256 threads of a workgroup at one step k
+    double *alpha, *gamma;               // at IL(l), same form: the forward message link l produces; what its right variable hears
                                          // from everybody but the link (side + the backward message of the next link)
     double *prefix;                      // [2][ND + 1][nthreads]: every thread's exclusive prefix within its tile, per direction
     int64_t il_stride;                   // ntiles * 256 * K = K * nthreads
@@ -204,7 +205,7 @@ template <int D, bool GT>
 __device__ __forceinline__ CMap<D> mvc_link(const MvcArgs &A, const double *tab_s, int l, int64_t il, int dir) {
     const bool head = (dir > 0 ? A.head_fwd[l] : A.head_bwd[l]) != 0;
     const int t = dir > 0 ? A.tab_fwd[l] : A.tab_bwd[l];
-    const Msg<D> u = msg_load<D>(dir > 0 ? A.side_l : A.side_r, A.il_stride, il);
+    const Msg<D> u = slot_load<D, true>(dir > 0 ? A.side_l : A.side_r, (int)il);
     return cmap_of_link<D>(u, mvc_tab<D, GT>(A, tab_s, t), head);
 }
 
@@ -361,11 +362,11 @@ __global__ __launch_bounds__(kBlock) void k_mvc_apply(MvcArgs A, int K, const do
             const int l = l0 + k;
             if (l >= A.nlinks) break;
             const int64_t il = il0 + (int64_t)k * kBlock;
-            Msg<D> in = msg_load<D>(A.side_l, A.il_stride, il);
+            Msg<D> in = slot_load<D, true>(A.side_l, (int)il);
             if (!A.head_fwd[l]) msg_add<D>(in, cur);
             cur = mv_rule<D, false>(in, mvc_tab<D, GT>(A, tab_s, A.tab_fwd[l]));
-            msg_store<D>(A.alpha, A.il_stride, il, cur);
-            if (store_msgs && !__builtin_isnan(cur.lam[0])) msg_store<D>(f2v, A.nslots, A.to_slot[l], cur);
+            slot_store<D>(A.alpha, (int)il, cur);
+            if (store_msgs && !__builtin_isnan(cur.lam[0])) slot_store<D>(f2v, A.to_slot[l], cur);
         }
     } else {
 #pragma unroll 1
@@ -373,11 +374,11 @@ __global__ __launch_bounds__(kBlock) void k_mvc_apply(MvcArgs A, int K, const do
             const int l = l0 + k;
             if (l >= A.nlinks) continue;
             const int64_t il = il0 + (int64_t)k * kBlock;
-            Msg<D> in = msg_load<D>(A.side_r, A.il_stride, il);      // what the right variable hears from everybody but this link
+            Msg<D> in = slot_load<D, true>(A.side_r, (int)il);      // what the right variable hears from everybody but this link
             if (!A.head_bwd[l]) msg_add<D>(in, cur);
-            msg_store<D>(A.gamma, A.il_stride, il, in);
+            slot_store<D>(A.gamma, (int)il, in);
             cur = mv_rule<D, false>(in, mvc_tab<D, GT>(A, tab_s, A.tab_bwd[l]));
-            if (store_msgs && !__builtin_isnan(cur.lam[0])) msg_store<D>(f2v, A.nslots, A.from_slot[l], cur);
+            if (store_msgs && !__builtin_isnan(cur.lam[0])) slot_store<D>(f2v, A.from_slot[l], cur);
             if (write_marg && A.head_fwd[l]) {                        // the first variable of a path hears no alpha
                 const int p = A.link_pos[l];
                 Msg<D> tot = msg_load<D>(A.side, A.npos, p);
@@ -408,8 +409,8 @@ __global__ __launch_bounds__(kBlock) void k_mvc_marg_out(int nlinks, int K, int6
             const int k = i / wn, tt = i - k * wn;
             if (base + (int64_t)(t0 + tt) * K + k >= nlinks) continue;
             const int64_t il = base + (int64_t)k * kBlock + t0 + tt;
-            Msg<D> tot = msg_load<D>(alpha, il_stride, il);
-            msg_add<D>(tot, msg_load<D>(gamma, il_stride, il));
+            Msg<D> tot = slot_load<D, true>(alpha, (int)il);
+            msg_add<D>(tot, slot_load<D, true>(gamma, (int)il));
             const Msg<D> mo = mv_to_moment<D>(tot);
 #pragma unroll
             for (int c = 0; c < D; c++) buf[(c * K + k) * Wp + tt] = mo.eta[c];
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void k_mvc_side(int npos, int64_t nslots, i
     for (int k = 0; k < deg; k++) {
         const int slot = b + k * kBlock;
         if (slot == s0 || slot == s1) continue;
-        msg_add<D>(acc, msg_load<D>(f2v, nslots, slot));
+        msg_add<D>(acc, slot_load<D>(f2v, slot));
     }
     msg_store<D>(side, npos, i, acc);
     if (write_marg && s0 < 0 && s1 < 0) marg_store<D>(marg, nv, v, acc);
@@ -459,8 +460,8 @@ __global__ __launch_bounds__(kBlock) void k_mvc_side_links(int nlinks, int npos,
     const int l = (tile * kBlock + th) * K + k;
     if (l >= nlinks) return;
     const int p = link_pos[l];
-    msg_store<D>(side_l, il_stride, (int)i, msg_load<D>(side, npos, p));
-    msg_store<D>(side_r, il_stride, (int)i, msg_load<D>(side, npos, p + 1));
+    slot_store<D>(side_l, (int)i, msg_load<D>(side, npos, p));
+    slot_store<D>(side_r, (int)i, msg_load<D>(side, npos, p + 1));
 }
 
 // ------------------------------------------------------------------------------------------------ host side
