@@ -175,6 +175,225 @@ __device__ __forceinline__ CMap<D> cmap_of_link(const Msg<D> &u, const double *_
     return r;
 }
 
+// ---- in-place forms (round 3, second pass): the generic cmap_compose above keeps both operands and the result in registers —
+// 360 of them for d = 4, one wave per SIMD.  The forms below overwrite the accumulator field by field and fetch the other
+// operand's fields when they are consumed (from registers, LDS / global memory, the link's tables, or another lane): ≈ 250
+// registers, two waves per SIMD for the kernel that is bound by these compositions' dependent chains (k_mvc_totals).
+
+// operand sources: P(a, b) / C(a, b) for a <= b, B(a, b), h(a), c(a), flags()
+template <int D>
+struct SrcMem {            // ND + 1 doubles at p (cmap_store's form)
+    using M = CMap<D>;
+    const double *p;
+    __device__ __forceinline__ double P(int a, int b) const { return p[tri<D>(a, b)]; }
+    __device__ __forceinline__ double B(int a, int b) const { return p[M::oB + a * D + b]; }
+    __device__ __forceinline__ double C(int a, int b) const { return p[M::oC + tri<D>(a, b)]; }
+    __device__ __forceinline__ double h(int a) const { return p[M::oH + a]; }
+    __device__ __forceinline__ double c(int a) const { return p[M::oS + a]; }
+    __device__ __forceinline__ int flags() const { return (int)p[M::ND]; }
+};
+template <int D>
+struct SrcStrided {        // component i of the map at p[i * stride] (prefix_store's form)
+    using M = CMap<D>;
+    const double *p; int64_t stride;
+    __device__ __forceinline__ double at(int i) const { return p[(int64_t)i * stride]; }
+    __device__ __forceinline__ double P(int a, int b) const { return at(tri<D>(a, b)); }
+    __device__ __forceinline__ double B(int a, int b) const { return at(M::oB + a * D + b); }
+    __device__ __forceinline__ double C(int a, int b) const { return at(M::oC + tri<D>(a, b)); }
+    __device__ __forceinline__ double h(int a) const { return at(M::oH + a); }
+    __device__ __forceinline__ double c(int a) const { return at(M::oS + a); }
+    __device__ __forceinline__ int flags() const { return (int)at(M::ND); }
+};
+template <int D>
+struct SrcLink {           // the (non-constant) map of a link: side information u, the receiving edge's (P | B | C) tables
+    const Msg<D> &u; const double *tab;
+    __device__ __forceinline__ double P(int a, int b) const { return tab[a * D + b] + u.lam[tri<D>(a, b)]; }
+    __device__ __forceinline__ double B(int a, int b) const { return tab[D * D + a * D + b]; }
+    __device__ __forceinline__ double C(int a, int b) const { return tab[2 * D * D + a * D + b]; }
+    __device__ __forceinline__ double h(int a) const { return u.eta[a]; }
+    __device__ __forceinline__ double c(int) const { return 0.0; }
+    __device__ __forceinline__ int flags() const { return 0; }
+};
+
+template <int D, class S>
+__device__ __forceinline__ void cmap_assign(CMap<D> &f, const S &s) {
+    using M = CMap<D>;
+#pragma unroll
+    for (int a = 0; a < D; a++) {
+        f.v[M::oH + a] = s.h(a); f.v[M::oS + a] = s.c(a);
+#pragma unroll
+        for (int b = 0; b < D; b++) f.v[M::oB + a * D + b] = s.B(a, b);
+#pragma unroll
+        for (int b = a; b < D; b++) { f.v[tri<D>(a, b)] = s.P(a, b); f.v[M::oC + tri<D>(a, b)] = s.C(a, b); }
+    }
+    f.flags = s.flags();
+}
+
+// f <- s ∘ f, both general (no flag logic); f is overwritten field by field
+template <int D, class S>
+__device__ __forceinline__ void cmap_append(CMap<D> &f, const S &s) {
+    using M = CMap<D>;
+    double Lm[D][D], ri[D];
+    {
+        double Kp[M::NT];
+#pragma unroll
+        for (int a = 0; a < D; a++)
+#pragma unroll
+            for (int b = a; b < D; b++) Kp[tri<D>(a, b)] = f.v[M::oC + tri<D>(a, b)] + s.P(a, b);
+        chol<D>(Kp, nullptr, Lm, ri);
+    }
+    double X1[D][D], X2[D][D], g[D];      // X1 = L^-1 B1,  X2 = L^-1 B2'
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        double col[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) col[k] = f.v[M::oB + k * D + j];
+        fwd_solve<D>(Lm, ri, col);
+#pragma unroll
+        for (int k = 0; k < D; k++) X1[k][j] = col[k];
+#pragma unroll
+        for (int k = 0; k < D; k++) col[k] = s.B(j, k);
+        fwd_solve<D>(Lm, ri, col);
+#pragma unroll
+        for (int k = 0; k < D; k++) X2[k][j] = col[k];
+    }
+#pragma unroll
+    for (int k = 0; k < D; k++) g[k] = f.v[M::oS + k] + s.h(k);
+    fwd_solve<D>(Lm, ri, g);
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        double hh = f.v[M::oH + i], cc = s.c(i);
+#pragma unroll
+        for (int k = 0; k < D; k++) { hh += X1[k][i] * g[k]; cc += X2[k][i] * g[k]; }
+        f.v[M::oH + i] = hh; f.v[M::oS + i] = cc;
+#pragma unroll
+        for (int j = i; j < D; j++) {
+            double p = f.v[tri<D>(i, j)], c = s.C(i, j);
+#pragma unroll
+            for (int k = 0; k < D; k++) { p -= X1[k][i] * X1[k][j]; c -= X2[k][i] * X2[k][j]; }
+            f.v[tri<D>(i, j)] = p; f.v[M::oC + tri<D>(i, j)] = c;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; i++)
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            double b = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; k++) b += X2[k][i] * X1[k][j];
+            f.v[M::oB + i * D + j] = b;
+        }
+}
+
+// f <- s ∘ f with the segment / identity rules of cmap_compose
+template <int D, class S>
+__device__ __forceinline__ void cmap_append_any(CMap<D> &f, const S &s) {
+    const int sf = s.flags();
+    if (sf & kMapIdent) return;
+    if ((sf & kMapSeg) || (f.flags & kMapIdent)) { cmap_assign<D>(f, s); return; }
+    cmap_append<D>(f, s);
+}
+
+// One step of the wave scan, in place: t <- t ∘ (the map of lane src) where `active`, t unchanged elsewhere.  Every field of the
+// other lane's map is fetched exactly once, BEFORE this lane (and, in lock step, every lane) overwrites its own copy of that
+// field; the lane's own old fields are consumed before they are overwritten.
+template <int D>
+__device__ __forceinline__ void cmap_scan_step(CMap<D> &t, int src, bool active) {
+    using M = CMap<D>;
+    src = src < 0 ? 0 : (src > 63 ? 63 : src);
+    const int ff = __shfl(t.flags, src, 64);
+    const bool keep = !active || (t.flags & kMapSeg) || (ff & kMapIdent);
+    const bool copy = !keep && (t.flags & kMapIdent);          // own map is the identity: the result is the other lane's map
+    const bool gen = !keep && !copy;
+    double Lm[D][D], ri[D], X2[D][D], g[D];
+    {
+        double fC[M::NT], Kp[M::NT];
+#pragma unroll
+        for (int a = 0; a < D; a++)
+#pragma unroll
+            for (int b = a; b < D; b++) {
+                const int i = tri<D>(a, b);
+                fC[i] = __shfl(t.v[M::oC + i], src, 64);
+                Kp[i] = gen ? fC[i] + t.v[i] : (a == b ? 1.0 : 0.0);
+            }
+        chol<D>(Kp, nullptr, Lm, ri);          // lanes that do not compose factor the identity: no NaN, no exception, result unused
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            double col[D];
+#pragma unroll
+            for (int k = 0; k < D; k++) col[k] = t.v[M::oB + j * D + k];
+            fwd_solve<D>(Lm, ri, col);
+#pragma unroll
+            for (int k = 0; k < D; k++) X2[k][j] = col[k];
+        }
+#pragma unroll
+        for (int i = 0; i < D; i++)
+#pragma unroll
+            for (int j = i; j < D; j++) {
+                double c = t.v[M::oC + tri<D>(i, j)];
+#pragma unroll
+                for (int k = 0; k < D; k++) c -= X2[k][i] * X2[k][j];
+                t.v[M::oC + tri<D>(i, j)] = copy ? fC[tri<D>(i, j)] : (gen ? c : t.v[M::oC + tri<D>(i, j)]);
+            }
+    }
+    {
+        double fcv[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) { fcv[k] = __shfl(t.v[M::oS + k], src, 64); g[k] = fcv[k] + t.v[M::oH + k]; }
+        fwd_solve<D>(Lm, ri, g);
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            double cc = t.v[M::oS + i];
+#pragma unroll
+            for (int k = 0; k < D; k++) cc += X2[k][i] * g[k];
+            t.v[M::oS + i] = copy ? fcv[i] : (gen ? cc : t.v[M::oS + i]);
+        }
+    }
+    double X1[D][D];
+    {
+        double fB[D * D];
+#pragma unroll
+        for (int i = 0; i < D * D; i++) fB[i] = __shfl(t.v[M::oB + i], src, 64);
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            double col[D];
+#pragma unroll
+            for (int k = 0; k < D; k++) col[k] = fB[k * D + j];
+            fwd_solve<D>(Lm, ri, col);
+#pragma unroll
+            for (int k = 0; k < D; k++) X1[k][j] = col[k];
+        }
+#pragma unroll
+        for (int i = 0; i < D; i++)
+#pragma unroll
+            for (int j = 0; j < D; j++) {
+                double b = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; k++) b += X2[k][i] * X1[k][j];
+                t.v[M::oB + i * D + j] = copy ? fB[i * D + j] : (gen ? b : t.v[M::oB + i * D + j]);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < D; i++)
+#pragma unroll
+        for (int j = i; j < D; j++) {
+            const double fP = __shfl(t.v[tri<D>(i, j)], src, 64);
+            double p = fP;
+#pragma unroll
+            for (int k = 0; k < D; k++) p -= X1[k][i] * X1[k][j];
+            t.v[tri<D>(i, j)] = copy ? fP : (gen ? p : t.v[tri<D>(i, j)]);
+        }
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        const double fh = __shfl(t.v[M::oH + i], src, 64);
+        double hh = fh;
+#pragma unroll
+        for (int k = 0; k < D; k++) hh += X1[k][i] * g[k];
+        t.v[M::oH + i] = copy ? fh : (gen ? hh : t.v[M::oH + i]);
+    }
+    t.flags = keep ? t.flags : ff;
+}
+
 struct MvcArgs {
     int nlinks, npos, nv, ntab;
     int64_t nslots;
@@ -188,7 +407,8 @@ struct MvcArgs {
                                          // buffers (cx_mv_core.h: slot_load): a block = the 256 threads of a workgroup at one step k
     double *alpha, *gamma;               // at IL(l), same form: the forward message link l produces; what its right variable hears
                                          // from everybody but the link (side + the backward message of the next link)
-    double *prefix;                      // [2][ND + 1][nthreads]: every thread's exclusive prefix within its tile, per direction
+    double *prefix;                      // [2][ND + 1][nthreads]: every thread's inclusive prefix within its WAVE, per direction
+    double *wave_carry;                  // [2][ntiles][4][ND + 1]: the carry into each wave of each tile
     int64_t il_stride;                   // ntiles * 256 * K = K * nthreads
     const double *ptab;                  // [ntab][3][D*D]
 };
@@ -209,16 +429,36 @@ __device__ __forceinline__ CMap<D> mvc_link(const MvcArgs &A, const double *tab_
     return cmap_of_link<D>(u, mvc_tab<D, GT>(A, tab_s, t), head);
 }
 
-// the composed map of a thread's K consecutive links, in the direction's order
+// the composed map of a thread's K consecutive links, in the direction's order, accumulated in place: the link's own map is
+// never materialised (its B and C are the LDS tables, its P and h the tables plus the side information)
 template <int D, bool GT>
-__device__ __forceinline__ CMap<D> mvc_thread_total(const MvcArgs &A, const double *tab_s, int l0, int64_t il0, int K, int dir) {
-    CMap<D> tot = cmap_identity<D>();
+__device__ __forceinline__ void mvc_thread_total(CMap<D> &tot, const MvcArgs &A, const double *tab_s, int l0, int64_t il0, int K, int dir) {
+    using M = CMap<D>;
+    tot = cmap_identity<D>();
 #pragma unroll 1
     for (int k = 0; k < K; k++) {
-        const int kk = dir > 0 ? k : K - 1 - k;
-        if (l0 + kk < A.nlinks) tot = cmap_compose<D>(tot, mvc_link<D, GT>(A, tab_s, l0 + kk, il0 + (int64_t)kk * kBlock, dir));
+        const int kk = dir > 0 ? k : K - 1 - k, l = l0 + kk;
+        if (l >= A.nlinks) continue;
+        const bool head = (dir > 0 ? A.head_fwd[l] : A.head_bwd[l]) != 0;
+        const double *tab = mvc_tab<D, GT>(A, tab_s, dir > 0 ? A.tab_fwd[l] : A.tab_bwd[l]);
+        const Msg<D> u = slot_load<D, true>(dir > 0 ? A.side_l : A.side_r, (int)(il0 + (int64_t)kk * kBlock));
+        if (head) {                          // the first link of a path: the constant map "rule applied to u alone"
+            const Msg<D> o = mv_rule<D, false>(u, tab);
+#pragma unroll
+            for (int i = 0; i < D; i++) {
+                tot.v[M::oH + i] = 0.0; tot.v[M::oS + i] = o.eta[i];
+#pragma unroll
+                for (int j = 0; j < D; j++) tot.v[M::oB + i * D + j] = 0.0;
+#pragma unroll
+                for (int j = i; j < D; j++) { tot.v[tri<D>(i, j)] = i == j ? 1.0 : 0.0; tot.v[M::oC + tri<D>(i, j)] = o.lam[tri<D>(i, j)]; }
+            }
+            tot.flags = kMapSeg;
+        } else {
+            const SrcLink<D> link{u, tab};
+            if (tot.flags & kMapIdent) cmap_assign<D>(tot, link);
+            else cmap_append<D>(tot, link);
+        }
     }
-    return tot;
 }
 
 // Workgroup scan in the direction's logical order (dir = -1: thread 255 first).  In: every thread's total.  Out: t = the
@@ -269,21 +509,38 @@ __device__ __forceinline__ CMap<D> prefix_load(const double *__restrict__ p, int
     return r;
 }
 
-// grid (ntiles, 2): blockIdx.y = 0 forward, 1 backward.  totals[dir][pos] in the direction's scan order (backward: tile ntiles-1 first)
+// grid (ntiles, 2): blockIdx.y = 0 forward, 1 backward.  Per thread: the composed map of its K links, then the INCLUSIVE scan
+// over its wave (in place, by shuffles) — stored as the thread's prefix.  Per wave: the carry into it (the waves logically before
+// it in the workgroup, composed) — stored per wave; the logically last wave also stores the tile total = its carry ∘ its total,
+// at totals[dir][pos], pos in the direction's scan order (backward: tile ntiles - 1 first).  The walks put the pieces together
+// (k_mvc_apply): tile carry ∘ wave carry ∘ prefix of the previous lane.
 template <int D, bool GT>
-__global__ __launch_bounds__(kBlock) void k_mvc_totals(MvcArgs A, int K, double *__restrict__ totals) {
-    constexpr int E = CMap<D>::ND + 1;
+__global__ __launch_bounds__(kBlock, 2) void k_mvc_totals(MvcArgs A, int K, double *__restrict__ totals) {
+    constexpr int E = CMap<D>::ND + 1, NW = kBlock / 64;
     __shared__ double tab_s[GT ? 1 : kMvcTabLds * 3 * D * D];
-    __shared__ double wt[(kBlock / 64) * E];
+    __shared__ double wt[NW * E];
     const int tid = threadIdx.x, dir = blockIdx.y ? -1 : 1, ntiles = gridDim.x;
     if (!GT) mvc_load_tabs<D>(A, tab_s, tid);
     const int64_t gid = (int64_t)blockIdx.x * kBlock + tid, nthreads = (int64_t)ntiles * kBlock;
-    CMap<D> t = mvc_thread_total<D, GT>(A, tab_s, (int)gid * K, (int64_t)blockIdx.x * kBlock * K + tid, K, dir);
-    CMap<D> total = cmap_identity<D>();
-    mvc_wg_scan<D, true>(t, total, wt, tid, dir);
+    const int lane = tid & 63, wid = tid >> 6;
+    const int li = dir > 0 ? lane : 63 - lane, wl = dir > 0 ? wid : NW - 1 - wid;
+    CMap<D> t;
+    mvc_thread_total<D, GT>(t, A, tab_s, (int)gid * K, (int64_t)blockIdx.x * kBlock * K + tid, K, dir);
+#pragma unroll 1
+    for (int d = 1; d < 64; d <<= 1) cmap_scan_step<D>(t, dir > 0 ? lane - d : lane + d, li >= d);
     prefix_store<D>(A.prefix + (size_t)blockIdx.y * E * nthreads, nthreads, gid, t);
-    const int pos = dir > 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;
-    if (tid == (dir > 0 ? kBlock - 1 : 0)) cmap_store<D>(totals + ((size_t)blockIdx.y * ntiles + pos) * E, total);
+    if (li == 63) cmap_store<D>(wt + wid * E, t);
+    __syncthreads();
+    // wave-uniform from here on: every lane of a wave composes the same carry
+    CMap<D> carry = cmap_identity<D>();
+#pragma unroll 1
+    for (int w = 0; w < wl; w++) cmap_append_any<D>(carry, SrcMem<D>{wt + (dir > 0 ? w : NW - 1 - w) * E});
+    if (li == 0) cmap_store<D>(A.wave_carry + (((size_t)blockIdx.y * ntiles + blockIdx.x) * NW + wid) * E, carry);
+    if (wl == NW - 1) {
+        cmap_append_any<D>(carry, SrcMem<D>{wt + wid * E});
+        const int pos = dir > 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;
+        if (li == 0) cmap_store<D>(totals + ((size_t)blockIdx.y * ntiles + pos) * E, carry);
+    }
 }
 
 // exclusive scan of the tile totals, in place: one workgroup per direction, chunks of kBlock tiles
@@ -345,8 +602,13 @@ __global__ __launch_bounds__(kBlock) void k_mvc_apply(MvcArgs A, int K, const do
     if (l0 >= A.nlinks) return;
     const int64_t il0 = (int64_t)blockIdx.x * kBlock * K + tid;
     const int pos = dir > 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;
-    const CMap<D> inc = cmap_compose<D>(cmap_load<D>(excl + ((size_t)blockIdx.y * ntiles + pos) * E),
-                                        prefix_load<D>(A.prefix + (size_t)blockIdx.y * E * nthreads, nthreads, gid));
+    // the map from the start of the scan to this thread's first link: tile carry, then the carry into the thread's wave, then the
+    // inclusive prefix of the logically previous lane of the wave (none for the wave's first lane)
+    constexpr int NW = kBlock / 64;
+    const int lane = tid & 63, wid = tid >> 6, li = dir > 0 ? lane : 63 - lane;
+    CMap<D> inc = cmap_load<D>(excl + ((size_t)blockIdx.y * ntiles + pos) * E);
+    cmap_append_any<D>(inc, SrcMem<D>{A.wave_carry + (((size_t)blockIdx.y * ntiles + blockIdx.x) * NW + wid) * E});
+    if (li > 0) cmap_append_any<D>(inc, SrcStrided<D>{A.prefix + (size_t)blockIdx.y * E * nthreads + (gid - dir), nthreads});
     // every prefix that reaches back to the first link of a path is a constant map: the message it produces from nothing
     Msg<D> cur = msg_nan<D>();
     if (inc.flags & kMapSeg) {
@@ -486,6 +748,7 @@ static int mvc_map_doubles(int dim) { return 2 * (dim * (dim + 1) / 2) + dim * d
 
 size_t mvc_totals_doubles(int dim, int64_t nlinks, int K) { return (size_t)2 * (size_t)mvc_ntiles(nlinks, K) * mvc_map_doubles(dim); }
 size_t mvc_prefix_doubles(int dim, int64_t nlinks, int K) { return (size_t)2 * (size_t)mvc_ntiles(nlinks, K) * kBlock * mvc_map_doubles(dim); }
+size_t mvc_wave_carry_doubles(int dim, int64_t nlinks, int K) { return (size_t)2 * (size_t)mvc_ntiles(nlinks, K) * (kBlock / 64) * mvc_map_doubles(dim); }
 
 // side sums by position, then by link in the interleaved order (after data, stored messages or rule tables changed)
 void mvc_launch_side(cx_handle *h, bool write_marg) {
@@ -529,7 +792,7 @@ void mvc_launch_scan(cx_handle *h, bool write_marg, bool store_msgs, bool scan) 
     const int K = h->mvc_K;
     MvcArgs A{(int)h->chain_nlinks, (int)h->chain_npos, (int)h->nv, (int)(2 * h->ptab_sets), h->nslots, h->d_chain_link_pos, h->d_chain_from,
               h->d_chain_to, h->d_chain_tab_fwd, h->d_chain_tab_bwd, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_pos_var,
-              h->d_mvc_side, h->d_mvc_side_l, h->d_mvc_side_r, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix,
+              h->d_mvc_side, h->d_mvc_side_l, h->d_mvc_side_r, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix, h->d_mvc_wave_carry,
               mvc_ntiles(h->chain_nlinks, K) * kBlock * K, h->d_ptab};
     const bool gt = A.ntab > kMvcTabLds;
     const int flags = (write_marg ? 1 : 0) | (store_msgs ? 2 : 0);
