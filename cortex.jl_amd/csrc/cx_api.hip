@@ -392,11 +392,11 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
             h->spdir = spdir; h->spdir_dirty = true;
             CX_TRY(dev_upload(h, &h->d_spdir, spdir));
             CX_TRY(dev_alloc(h, &h->d_mv_f2v, ncs * slots)); CX_TRY(dev_alloc(h, &h->d_mv_f2v_alt, ncs * slots));
-            CX_TRY(dev_alloc(h, &h->d_mv_v2f, ncs * slots)); CX_TRY(dev_alloc(h, &h->d_mv_marg, h->cfg.dim == 64 ? 1 : nc * nv));
+            CX_TRY(dev_alloc(h, &h->d_mv_v2f, ncs * slots)); CX_TRY(dev_alloc(h, &h->d_mv_marg, h->cfg.dim == 64 ? 1 : ncs * h->nslices * cx::kBlock));      // pair form by variable, whole 256-blocks
             CX_HIP(h, hipMemsetAsync(h->d_mv_f2v, 0xff, (size_t)(ncs * slots) * 8, h->stream));
             CX_HIP(h, hipMemsetAsync(h->d_mv_f2v_alt, 0xff, (size_t)(ncs * slots) * 8, h->stream));
             CX_HIP(h, hipMemsetAsync(h->d_mv_v2f, 0xff, (size_t)(ncs * slots) * 8, h->stream));
-            if (h->cfg.dim != 64) CX_HIP(h, hipMemsetAsync(h->d_mv_marg, 0xff, (size_t)(nc * nv) * 8, h->stream));
+            if (h->cfg.dim != 64) CX_HIP(h, hipMemsetAsync(h->d_mv_marg, 0xff, (size_t)(ncs * h->nslices * cx::kBlock) * 8, h->stream));
             CX_HIP(h, hipStreamSynchronize(h->stream));
             h->has_graph = true;
             return upload_ptab(h);

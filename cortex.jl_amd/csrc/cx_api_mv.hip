@@ -182,7 +182,7 @@ int32_t mv_get(cx_handle *h, const double *src, int64_t stride, const std::vecto
         }
         return CX_OK;
     }
-    cx::mv_launch_gather(h, src, stride, nc, already_moment ? 0 : h->ncs, d_idx, d_val, n);      // the marginals are a plain component-major array
+    cx::mv_launch_gather(h, src, stride, nc, h->ncs, d_idx, d_val, n);      // messages by slot, marginals by variable: the same pair form
     std::vector<double> val((size_t)n * nc);
     CX_HIP(h, hipMemcpyAsync(val.data(), d_val, (size_t)n * nc * 8, hipMemcpyDeviceToHost, h->stream));
     CX_HIP(h, hipStreamSynchronize(h->stream));

@@ -74,7 +74,7 @@ std::vector<StatePart> state_parts(cx_handle *h) {
         parts.push_back({2, h->d_mv_f2v, ncs * slots * 8});
         parts.push_back({3, h->d_mv_f2v_alt, ncs * slots * 8});
         parts.push_back({4, h->d_mv_v2f, ncs * slots * 8});
-        if (h->cfg.dim != 64) parts.push_back({5, h->d_mv_marg, nc * nv * 8});
+        if (h->cfg.dim != 64) parts.push_back({5, h->d_mv_marg, ncs * h->nslices * cx::kBlock * 8});
     }
     return parts;
 }

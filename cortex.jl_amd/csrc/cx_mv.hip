@@ -89,11 +89,8 @@ __global__ __launch_bounds__(kBlock, DEG == 3 ? 3 : 2) void k_sweep_mv(int nv, i
         for (int k = 0; k < DEG; k++)
             if (k < deg) msg_add<D>(total, in[k]);
         const Msg<D> mo = (deg > 0) ? mv_to_moment<D>(total) : total;
-        // marginals are written once and not re-read by the sweep: nontemporal stores
-#pragma unroll
-        for (int i = 0; i < D; i++) __builtin_nontemporal_store((deg > 0) ? mo.eta[i] : __builtin_nan(""), &marg[(int64_t)i * nv + v]);
-#pragma unroll
-        for (int i = 0; i < Msg<D>::NT; i++) __builtin_nontemporal_store((deg > 0) ? mo.lam[i] : __builtin_nan(""), &marg[(int64_t)(D + i) * nv + v]);
+        // marginals are written once and not re-read by the sweep: nontemporal 16-byte stores, the pair form of the messages
+        slot_store_nt<D>(marg, v, (deg > 0) ? mo : msg_all_nan<D>());
     }
     const bool fixed = (deg < 2) || (info & (kClamped | kGhost));
 #pragma unroll

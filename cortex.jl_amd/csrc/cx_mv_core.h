@@ -99,6 +99,32 @@ __device__ __forceinline__ void slot_store(double *__restrict__ buf, int slot, c
     for (int q = 0; q < MsgStore<D>::NCP; q++) p[q * kBlock] = make_double2(c[2 * q], c[2 * q + 1]);
 }
 
+// the same with nontemporal stores: marginals (written once per sweep, read by nobody on the device) use the pair form too,
+// indexed by the local variable number
+template <int D>
+__device__ __forceinline__ void slot_store_nt(double *__restrict__ buf, int slot, const Msg<D> &m) {
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    d2v *p = reinterpret_cast<d2v *>(buf + slot_offset<D>(slot));
+    double c[MsgStore<D>::NCS];
+#pragma unroll
+    for (int i = 0; i < D; i++) c[i] = m.eta[i];
+#pragma unroll
+    for (int i = 0; i < Msg<D>::NT; i++) c[D + i] = m.lam[i];
+    if (MsgStore<D>::NCS > Msg<D>::NC) c[MsgStore<D>::NCS - 1] = 0.0;
+#pragma unroll
+    for (int q = 0; q < MsgStore<D>::NCP; q++) { d2v t; t.x = c[2 * q]; t.y = c[2 * q + 1]; __builtin_nontemporal_store(t, p + q * kBlock); }
+}
+
+template <int D>
+__device__ __forceinline__ Msg<D> msg_all_nan() {
+    Msg<D> m;
+#pragma unroll
+    for (int i = 0; i < D; i++) m.eta[i] = __builtin_nan("");
+#pragma unroll
+    for (int i = 0; i < Msg<D>::NT; i++) m.lam[i] = __builtin_nan("");
+    return m;
+}
+
 template <int D>
 __device__ __forceinline__ void msg_add(Msg<D> &a, const Msg<D> &b) {
 #pragma unroll

@@ -44,11 +44,7 @@ __global__ __launch_bounds__(kBlock) void k_batch_mv(int64_t n, const int32_t *_
         Msg<D> total = msg_zero<D>();
         for (int j = 0; j < deg; j++) msg_add<D>(total, slot_load<D>(f2v, b + j * kBlock));
         const bool ok = deg > 0 && !__builtin_isnan(total.lam[0]);
-        const Msg<D> mo = ok ? mv_to_moment<D>(total) : total;
-#pragma unroll
-        for (int c = 0; c < D; c++) marg[(int64_t)c * nv + v] = ok ? mo.eta[c] : __builtin_nan("");
-#pragma unroll
-        for (int c = 0; c < Msg<D>::NT; c++) marg[(int64_t)(D + c) * nv + v] = ok ? mo.lam[c] : __builtin_nan("");
+        slot_store<D>(marg, v, ok ? mv_to_moment<D>(total) : msg_all_nan<D>());
     }
 }
 

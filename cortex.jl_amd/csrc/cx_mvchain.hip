@@ -25,7 +25,7 @@
 //                     with the ordinary rule of the flooding sweep (one Cholesky per message) — map composition is paid once per
 //                     thread and scan step, not per link.  The forward walk leaves alpha (into the right end of every link), the
 //                     backward walk gamma (what the right end hears from everybody but the link); both directions in one grid
-//   k_mvc_marg_out    marginal of a link's right variable = alpha + gamma, to moment form, transposed through LDS into marg[c][v]
+//   k_mvc_marg_out    marginal of a link's right variable = alpha + gamma, to moment form, transposed through LDS into the marginals (pair form by variable)
 // Results are re-associated relative to the sequential schedule: they agree with it to rounding, not bitwise.
 //
 // Memory layout.  "Thread owns K consecutive links" would make every access to a chain-ordered array a stride-K access.  The
@@ -578,12 +578,8 @@ __device__ __forceinline__ Msg<D> msg_nan() {
 }
 
 template <int D>
-__device__ __forceinline__ void marg_store(double *__restrict__ marg, int64_t nv, int64_t v, const Msg<D> &nat) {
-    const Msg<D> mo = mv_to_moment<D>(nat);
-#pragma unroll
-    for (int i = 0; i < D; i++) __builtin_nontemporal_store(mo.eta[i], &marg[(int64_t)i * nv + v]);
-#pragma unroll
-    for (int i = 0; i < Msg<D>::NT; i++) __builtin_nontemporal_store(mo.lam[i], &marg[(int64_t)(D + i) * nv + v]);
+__device__ __forceinline__ void marg_store(double *__restrict__ marg, int64_t, int64_t v, const Msg<D> &nat) {
+    slot_store_nt<D>(marg, (int)v, mv_to_moment<D>(nat));      // marginals: the messages' pair form, indexed by the variable
 }
 
 // grid (ntiles, 2): the forward and the backward walks are independent of each other.
@@ -652,7 +648,7 @@ __global__ __launch_bounds__(kBlock) void k_mvc_apply(MvcArgs A, int K, const do
 }
 
 // Marginal of every link's right variable: (alpha + gamma) to moment form, then from the interleaved order of the walks to
-// marg[c][variable] through LDS.  A tile goes through in slabs of W = 512 / K threads (all K steps of each: <= 512 links, 57 KB
+// the marginals' place (pair form by variable) through LDS.  A tile goes through in slabs of W = 512 / K threads (all K steps of each: <= 512 links, 57 KB
 // for d = 4): the reads are runs of W doubles per step and component, the writes runs of W K variables per component.
 __host__ __device__ inline int mvc_slab_threads(int K) { return K >= 512 ? 1 : (512 / K > kBlock ? kBlock : 512 / K); }
 __host__ __device__ inline int mvc_slab_pitch(int K) { return mvc_slab_threads(K) + (((K & (K - 1)) == 0 && K <= 32) ? 32 / K : 1); }   // conflict-free column reads for K | 32
@@ -685,8 +681,15 @@ __global__ __launch_bounds__(kBlock) void k_mvc_marg_out(int nlinks, int K, int6
             if (l >= nlinks) break;
             const int64_t v = pos_var[link_pos[l] + 1];
             const int src = (e % K) * Wp + e / K;
+            typedef double d2v __attribute__((ext_vector_type(2)));
+            d2v *dst = reinterpret_cast<d2v *>(marg + slot_offset<D>((int)v));
 #pragma unroll
-            for (int c = 0; c < NC; c++) __builtin_nontemporal_store(buf[c * K * Wp + src], &marg[(int64_t)c * nv + v]);
+            for (int q = 0; q < MsgStore<D>::NCP; q++) {
+                d2v t2;
+                t2.x = buf[(2 * q) * K * Wp + src];
+                t2.y = (2 * q + 1 < NC) ? buf[(2 * q + 1) * K * Wp + src] : 0.0;
+                __builtin_nontemporal_store(t2, dst + q * kBlock);
+            }
         }
         __syncthreads();
     }
