@@ -82,9 +82,14 @@ int32_t mv64_set_messages(cx_handle *h, int64_t n, const std::vector<int32_t> &i
         CX_HIP(h, hipMemcpyAsync(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice, h->stream));
         CX_HIP(h, hipMemcpyAsync(d_val, payload, (size_t)n * d * 8, hipMemcpyHostToDevice, h->stream));
         cx::mv64_set_point(h, h->d_mv_v2f, d_idx, d_val, n);
-        for (int64_t i = 0; i < n; i++) h->vinfo[vars[i]] |= cx::kClamped;
-        CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
-        h->work64_dirty = h->point64_dirty = true;
+        bool newly = false;
+        for (int64_t i = 0; i < n; i++)
+            if (!(h->vinfo[vars[i]] & cx::kClamped)) { h->vinfo[vars[i]] |= cx::kClamped; newly = true; }
+        if (newly) {     // the work lists depend on WHICH variables are observed, not on their data
+            CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
+            h->work64_dirty = true;
+        }
+        h->point64_dirty = true;      // the constant messages out of the observed variables are due again
     } else {
         std::vector<double> val((size_t)n * nc);
         for (int64_t i = 0; i < n; i++) {
@@ -135,10 +140,16 @@ int32_t mv_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
         cx::mv_launch_scatter(h, h->d_mv_v2f, h->nslots, nc, h->ncs, d_idx, d_val, n);
         h->observed_passes_due = 2;   // a stored variable→factor message changed: observed senders are refreshed
         if (form == CX_FORM_POINT) {
+            // New data for variables that were observed already leaves the structure (observed flags, rule masks, chains) as it is:
+            // only the constant messages out of them are due again (observed_passes_due above).
+            bool newly = false;
             for (int64_t i = 0; i < n; i++)
-                if (!(h->vinfo[vars[i]] & cx::kClamped)) { h->vinfo[vars[i]] |= cx::kClamped; h->chains_dirty = true; }   // a newly observed variable leaves the chains
-            CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
-            h->spdir_dirty = true;
+                if (!(h->vinfo[vars[i]] & cx::kClamped)) { h->vinfo[vars[i]] |= cx::kClamped; newly = true; }
+            if (newly) {
+                h->chains_dirty = true;      // a newly observed variable leaves the chains
+                CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
+                h->spdir_dirty = true;
+            }
         }
     } else {
         cx::mv_launch_scatter(h, h->d_mv_f2v, h->nslots, nc, h->ncs, d_idx, d_val, n);

@@ -716,17 +716,46 @@ __global__ __launch_bounds__(kBlock) void k_mvc_side(int npos, int64_t nslots, i
     if (write_marg && s0 < 0 && s1 < 0) marg_store<D>(marg, nv, v, acc);
 }
 
-// the side sums of each link's two end variables, in the interleaved order the scan kernels read
+// The side sums of each link's two end variables, in the interleaved order the scan kernels read.  The inverse of k_mvc_marg_out:
+// a tile goes through LDS in slabs of W = 512 / K threads (all K links of each), read from the by-position array as contiguous
+// runs and written as contiguous runs of the interleaved arrays.  Links of one thread are consecutive and link_pos grows by one per
+// link (by two across a path boundary), so a slab's positions are one range; a slab with so many path boundaries that its range
+// overflows the buffer reads the overflow from memory directly.
 template <int D>
-__global__ __launch_bounds__(kBlock) void k_mvc_side_links(int nlinks, int npos, int K, int64_t il_stride, const int32_t *__restrict__ link_pos,
+__global__ __launch_bounds__(kBlock) void k_mvc_side_links(int nlinks, int npos, int K, const int32_t *__restrict__ link_pos,
                                                            const double *__restrict__ side, double *__restrict__ side_l, double *__restrict__ side_r) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // interleaved index: consecutive threads write consecutive addresses
-    const int tile = (int)(i / ((int64_t)kBlock * K)), r = (int)(i % ((int64_t)kBlock * K)), k = r / kBlock, th = r % kBlock;
-    const int l = (tile * kBlock + th) * K + k;
-    if (l >= nlinks) return;
-    const int p = link_pos[l];
-    slot_store<D>(side_l, (int)i, msg_load<D>(side, npos, p));
-    slot_store<D>(side_r, (int)i, msg_load<D>(side, npos, p + 1));
+    constexpr int NC = Msg<D>::NC;
+    extern __shared__ double buf[];          // [NC][span + span / 32 + 1]: position j of the slab at j + j / 32 (stride-K reads spread over the banks)
+    const int tid = threadIdx.x, W = mvc_slab_threads(K);
+    const int span = W * K + 8, pitch = span + span / 32 + 1;
+    const int nslab = (kBlock + W - 1) / W;                 // grid: one workgroup per (tile, slab) — a tile alone would leave the chip under one wave per SIMD
+    const int64_t base = (int64_t)(blockIdx.x / nslab) * kBlock * K;
+    {
+        const int t0 = (blockIdx.x % nslab) * W;
+        const int wn = min(W, kBlock - t0), nitems = wn * K;
+        const int64_t L0 = base + (int64_t)t0 * K;
+        if (L0 >= nlinks) return;
+        const int p0 = link_pos[L0];
+        for (int c = 0; c < NC; c++)
+            for (int j = tid; j < span; j += kBlock) buf[c * pitch + j + j / 32] = (p0 + j < npos) ? side[(int64_t)c * npos + p0 + j] : 0.0;
+        __syncthreads();
+        for (int i = tid; i < nitems; i += kBlock) {
+            const int k = i / wn, tt = i - k * wn;
+            const int64_t l = L0 + (int64_t)tt * K + k;
+            if (l >= nlinks) continue;
+            const int p = link_pos[l], q = p - p0;
+            Msg<D> a, b;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const double va = (q < span) ? buf[c * pitch + q + q / 32] : side[(int64_t)c * npos + p];
+                const double vb = (q + 1 < span) ? buf[c * pitch + (q + 1) + (q + 1) / 32] : side[(int64_t)c * npos + p + 1];
+                if (c < D) { a.eta[c] = va; b.eta[c] = vb; } else { a.lam[c - D] = va; b.lam[c - D] = vb; }
+            }
+            const int il = (int)(base + (int64_t)k * kBlock + t0 + tt);
+            slot_store<D>(side_l, il, a);
+            slot_store<D>(side_r, il, b);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -758,13 +787,14 @@ void mvc_launch_side(cx_handle *h, bool write_marg) {
     const int npos = (int)h->chain_npos, nlinks = (int)h->chain_nlinks, K = h->mvc_K;
     if (npos == 0) return;
     const dim3 g((npos + kBlock - 1) / kBlock), b(kBlock);
-    const int64_t S = mvc_ntiles(nlinks, K) * kBlock * K;
-    const dim3 gl((unsigned)(S / kBlock));
+    const dim3 gl((unsigned)(mvc_ntiles(nlinks, K) * ((kBlock + mvc_slab_threads(K) - 1) / mvc_slab_threads(K))));
+    const int span = mvc_slab_threads(K) * K + 8;
+    const size_t lds = (size_t)h->nc * (span + span / 32 + 1) * sizeof(double);
 #define CX_MVC(DD)                                                                                                                           \
     do {                                                                                                                                     \
         hipLaunchKernelGGL((k_mvc_side<DD>), g, b, 0, h->stream, npos, h->nslots, (int)h->nv, h->d_chain_pos_var, h->d_chain_skip0,          \
                            h->d_chain_skip1, h->d_vbase, h->d_vinfo, h->d_mv_f2v, h->d_mvc_side, h->d_mv_marg, write_marg ? 1 : 0);          \
-        if (nlinks) hipLaunchKernelGGL((k_mvc_side_links<DD>), gl, b, 0, h->stream, nlinks, npos, K, S, h->d_chain_link_pos, h->d_mvc_side,  \
+        if (nlinks) hipLaunchKernelGGL((k_mvc_side_links<DD>), gl, b, lds, h->stream, nlinks, npos, K, h->d_chain_link_pos, h->d_mvc_side,   \
                                        h->d_mvc_side_l, h->d_mvc_side_r);                                                                    \
     } while (0)
     if (h->cfg.dim == 2) CX_MVC(2);
