@@ -139,7 +139,10 @@ def launch_ranks(n: int, argv, timeout_s: float = 1500.0) -> int:
     out_file.seek(0)
     out0 = out_file.read()
     out_file.close()
-    sys.stdout.write(out0.decode(errors="replace"))
+    # stdout carries the ONE JSON line; whatever else a library printed there (gloo's "[Gloo] Rank 0 is connected ..." in the one-GPU
+    # rehearsal) goes to stderr
+    for line in out0.decode(errors="replace").splitlines(keepends=True):
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
     sys.stdout.flush()
     return rc
 
