@@ -305,6 +305,45 @@ static int32_t mv_chain_sweep(cx_handle *h, int32_t n_sweeps) {
     return CX_OK;
 }
 
+// cx_chain_block_maps for dim 2..4: the composed forward / backward maps of the handle's ONE path (a time block of a partitioned
+// chain) as functions of the message that enters the block at either end, and the side sums of its end variables.
+// Map layout (ND = 2 d(d+1)/2 + d^2 + 2 d doubles): P packed upper | B row-major | C packed upper | h | c, of
+//     f(eta, Lambda) = ( c + B (Lambda + P)^-1 (eta + h),  C - B (Lambda + P)^-1 B' );   sides: eta[d] | Lambda packed upper.
+int32_t mv_chain_block_maps(cx_handle *h, double *fwd, double *bwd, double *side_first, double *side_last, int64_t *first_variable_id,
+                            int64_t *last_variable_id, int64_t *n_links) {
+    CX_REQUIRE(h, h->cfg.dim <= 4, CX_ERR_UNSUPPORTED, "cx_chain_block_maps: dim 1..4");
+    CX_REQUIRE(h, (int64_t)h->psets.size() > h->max_pset, CX_ERR_STATE, "cx_chain_block_maps: a parameter set was never set (cx_set_factor_matrices)");
+    int32_t rc = build_chains(h);
+    if (rc != CX_OK) return rc;
+    CX_REQUIRE(h, h->chain_nlinks >= 1 && h->chain_nlinks == h->chain_npos - 1, CX_ERR_UNSUPPORTED,
+               "cx_chain_block_maps: the non-observed variables of this handle must form ONE path of at least two variables (a time block of a chain)");
+    if ((rc = mv_ensure_chain_msgs(h)) != CX_OK) return rc;      // the maps overwrite the stored prefixes of the last sweep
+    if ((rc = mv_refresh_spdir(h)) != CX_OK) return rc;
+    // the leaf messages and side sums from the data currently on the device (the caller has zeroed the cut messages)
+    cx::mv_launch_sweep(h, false, 1, h->d_mv_f2v);
+    cx::mv_launch_sweep(h, false, 2, h->d_mv_f2v);
+    cx::mvc_launch_side(h, false);
+    cx::mvc_launch_block_maps(h);
+    CX_HIP(h, hipGetLastError());
+    h->observed_passes_due = 0;
+    h->chain_side_dirty = true;          // the boundary messages change before the sweep proper
+    const int d = h->cfg.dim, nc = h->nc, nd = 2 * (d * (d + 1) / 2) + d * d + 2 * d;
+    std::vector<double> maps((size_t)2 * (nd + 1)), side((size_t)nc * h->chain_npos);
+    CX_HIP(h, hipMemcpyAsync(maps.data(), h->d_mvc_block, maps.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    CX_HIP(h, hipMemcpyAsync(side.data(), h->d_mvc_side, side.size() * 8, hipMemcpyDeviceToHost, h->stream));     // [nc][npos]: small blocks only travel whole
+    int32_t pv[2] = {0, 0};
+    CX_HIP(h, hipMemcpyAsync(&pv[0], h->d_chain_pos_var, 4, hipMemcpyDeviceToHost, h->stream));
+    CX_HIP(h, hipMemcpyAsync(&pv[1], h->d_chain_pos_var + (h->chain_npos - 1), 4, hipMemcpyDeviceToHost, h->stream));
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    std::memcpy(fwd, maps.data(), (size_t)nd * 8);
+    std::memcpy(bwd, maps.data() + nd + 1, (size_t)nd * 8);
+    for (int c = 0; c < nc; c++) { side_first[c] = side[(size_t)c * h->chain_npos]; side_last[c] = side[(size_t)c * h->chain_npos + h->chain_npos - 1]; }
+    if (first_variable_id) *first_variable_id = h->var_ids[pv[0]];
+    if (last_variable_id) *last_variable_id = h->var_ids[pv[1]];
+    if (n_links) *n_links = h->chain_nlinks;
+    return CX_OK;
+}
+
 // dim 2..4 under the chain-scan schedule: bring the chain messages in d_mv_f2v up to date (the tile carries of the last sweep are
 // still on the device: two apply launches).  Every reader of d_mv_f2v calls this first.
 int32_t mv_ensure_chain_msgs(cx_handle *h) {

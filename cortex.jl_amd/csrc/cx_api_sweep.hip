@@ -104,9 +104,9 @@ int32_t build_chains(cx_handle *h) {
         for (void *p : {(void *)h->d_chain_pos_var, (void *)h->d_chain_skip0, (void *)h->d_chain_skip1, (void *)h->d_chain_link_pos,
                         (void *)h->d_chain_from, (void *)h->d_chain_to, (void *)h->d_chain_head_fwd, (void *)h->d_chain_head_bwd,
                         (void *)h->d_chain_side, h->d_chain_totals, (void *)h->d_chain_tab_fwd, (void *)h->d_chain_tab_bwd, (void *)h->d_mvc_side,
-                        (void *)h->d_mvc_totals, (void *)h->d_mvc_side_l, (void *)h->d_mvc_side_r, (void *)h->d_mvc_alpha, (void *)h->d_mvc_gamma, (void *)h->d_mvc_prefix, (void *)h->d_mvc_wave_carry}) if (p) (void)hipFree(p);
+                        (void *)h->d_mvc_totals, (void *)h->d_mvc_side_l, (void *)h->d_mvc_side_r, (void *)h->d_mvc_alpha, (void *)h->d_mvc_gamma, (void *)h->d_mvc_prefix, (void *)h->d_mvc_wave_carry, (void *)h->d_mvc_block}) if (p) (void)hipFree(p);
         h->d_chain_tab_fwd = h->d_chain_tab_bwd = nullptr; h->d_mvc_side = h->d_mvc_totals = nullptr;
-        h->d_mvc_side_l = h->d_mvc_side_r = h->d_mvc_alpha = h->d_mvc_gamma = h->d_mvc_prefix = h->d_mvc_wave_carry = nullptr;
+        h->d_mvc_side_l = h->d_mvc_side_r = h->d_mvc_alpha = h->d_mvc_gamma = h->d_mvc_prefix = h->d_mvc_wave_carry = h->d_mvc_block = nullptr;
         h->chain_npos = (int64_t)pos_var.size(); h->chain_nlinks = (int64_t)link_pos.size();
         h->chain_side_dirty = true;
         int64_t n_readers = 0;   // variables that read factor→variable messages: everything but observed variables and ghosts
@@ -134,6 +134,7 @@ int32_t build_chains(cx_handle *h) {
             if ((rc = dev_alloc(h, &h->d_mvc_gamma, h->ncs * il)) != CX_OK) return rc;
             if ((rc = dev_alloc(h, &h->d_mvc_prefix, (int64_t)cx::mvc_prefix_doubles(h->cfg.dim, h->chain_nlinks, h->mvc_K))) != CX_OK) return rc;
             if ((rc = dev_alloc(h, &h->d_mvc_wave_carry, (int64_t)cx::mvc_wave_carry_doubles(h->cfg.dim, h->chain_nlinks, h->mvc_K))) != CX_OK) return rc;
+            if ((rc = dev_alloc(h, &h->d_mvc_block, (int64_t)cx::mvc_totals_doubles(h->cfg.dim, 1, 1))) != CX_OK) return rc;      // two maps
             if ((rc = dev_alloc(h, &h->d_mvc_totals, (int64_t)cx::mvc_totals_doubles(h->cfg.dim, h->chain_nlinks, h->mvc_K))) != CX_OK) return rc;
         } else {
             if ((rc = dev_alloc(h, &h->d_chain_side, h->chain_npos)) != CX_OK) return rc;
@@ -231,8 +232,12 @@ int32_t cx_chain_block_maps(cx_handle *h, double *fwd6, double *bwd6, double *si
                             int64_t *first_variable_id, int64_t *last_variable_id, int64_t *n_links) {
     CX_NOT_VMP(h, "cx_chain_block_maps");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_chain_block_maps: no graph");
-    CX_REQUIRE(h, h->cfg.dim == 1 && h->cfg.schedule == CX_SCHED_CHAIN_SCAN, CX_ERR_STATE, "cx_chain_block_maps: scalar chain-scan handles only");
+    CX_REQUIRE(h, h->cfg.schedule == CX_SCHED_CHAIN_SCAN, CX_ERR_STATE, "cx_chain_block_maps: chain-scan handles only");
     CX_REQUIRE(h, fwd6 && bwd6 && side_first2 && side_last2, CX_ERR_INVALID_ARGUMENT, "cx_chain_block_maps: null argument");
+    if (h->cfg.dim > 1) {
+        try { h->chain_partition = true; return mv_chain_block_maps(h, fwd6, bwd6, side_first2, side_last2, first_variable_id, last_variable_id, n_links); }
+        catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_chain_block_maps: host allocation failed"); }
+    }
     CX_REQUIRE(h, !h->any_linear, CX_ERR_UNSUPPORTED, "cx_chain_block_maps: additive factors only in this build");
     int32_t rc = build_chains(h);
     if (rc != CX_OK) return rc;

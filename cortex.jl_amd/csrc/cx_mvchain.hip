@@ -410,6 +410,8 @@ struct MvcArgs {
     double *prefix;                      // [2][ND + 1][nthreads]: every thread's inclusive prefix within its WAVE, per direction
     double *wave_carry;                  // [2][ntiles][4][ND + 1]: the carry into each wave of each tile
     int64_t il_stride;                   // ntiles * 256 * K = K * nthreads
+    int collapse_heads;                  // 1 (a sweep): the first link of a path is the constant map "rule applied to the side information";
+                                         // 0 (cx_chain_block_maps): it stays a general map of the message that enters the block
     const double *ptab;                  // [ntab][3][D*D]
 };
 
@@ -442,7 +444,7 @@ __device__ __forceinline__ void mvc_thread_total(CMap<D> &tot, const MvcArgs &A,
         const bool head = (dir > 0 ? A.head_fwd[l] : A.head_bwd[l]) != 0;
         const double *tab = mvc_tab<D, GT>(A, tab_s, dir > 0 ? A.tab_fwd[l] : A.tab_bwd[l]);
         const Msg<D> u = slot_load<D, true>(dir > 0 ? A.side_l : A.side_r, (int)(il0 + (int64_t)kk * kBlock));
-        if (head) {                          // the first link of a path: the constant map "rule applied to u alone"
+        if (head && A.collapse_heads) {      // the first link of a path: the constant map "rule applied to u alone"
             const Msg<D> o = mv_rule<D, false>(u, tab);
 #pragma unroll
             for (int i = 0; i < D; i++) {
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mvc_totals(MvcArgs A, int K, doub
 
 // exclusive scan of the tile totals, in place: one workgroup per direction, chunks of kBlock tiles
 template <int D>
-__global__ __launch_bounds__(kBlock) void k_mvc_scan_totals(int ntiles, double *__restrict__ totals) {
+__global__ __launch_bounds__(kBlock) void k_mvc_scan_totals(int ntiles, double *__restrict__ totals, double *__restrict__ block_total) {
     constexpr int E = CMap<D>::ND + 1;
     __shared__ double wt[(kBlock / 64) * E];
     __shared__ double carry_s[E];
@@ -565,6 +567,8 @@ __global__ __launch_bounds__(kBlock) void k_mvc_scan_totals(int ntiles, double *
         if (tid == kBlock - 1) cmap_store<D>(carry_s, cmap_compose<D>(carry, total));
         __syncthreads();
     }
+    // the composed map of the whole direction (what a partition exchanges: cx_chain_block_maps)
+    if (block_total && tid < E) block_total[(size_t)blockIdx.x * E + tid] = carry_s[tid];
 }
 
 template <int D>
@@ -808,7 +812,7 @@ static void mvc_launch_t(cx_handle *h, const MvcArgs &A, int K, int flags, bool 
     const int ntiles = (int)mvc_ntiles(A.nlinks, K);
     if (scan) {
         hipLaunchKernelGGL((k_mvc_totals<D, GT>), dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, K, h->d_mvc_totals);
-        hipLaunchKernelGGL((k_mvc_scan_totals<D>), dim3(2), dim3(kBlock), 0, h->stream, ntiles, h->d_mvc_totals);
+        hipLaunchKernelGGL((k_mvc_scan_totals<D>), dim3(2), dim3(kBlock), 0, h->stream, ntiles, h->d_mvc_totals, h->d_mvc_block);
     }
     hipLaunchKernelGGL((k_mvc_apply<D, GT>), dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, K, h->d_mvc_totals, h->d_mv_f2v, h->d_mv_marg, flags);
     if (flags & 1) {
@@ -826,10 +830,36 @@ void mvc_launch_scan(cx_handle *h, bool write_marg, bool store_msgs, bool scan) 
     MvcArgs A{(int)h->chain_nlinks, (int)h->chain_npos, (int)h->nv, (int)(2 * h->ptab_sets), h->nslots, h->d_chain_link_pos, h->d_chain_from,
               h->d_chain_to, h->d_chain_tab_fwd, h->d_chain_tab_bwd, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_pos_var,
               h->d_mvc_side, h->d_mvc_side_l, h->d_mvc_side_r, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix, h->d_mvc_wave_carry,
-              mvc_ntiles(h->chain_nlinks, K) * kBlock * K, h->d_ptab};
+              mvc_ntiles(h->chain_nlinks, K) * kBlock * K, 1, h->d_ptab};
     const bool gt = A.ntab > kMvcTabLds;
     const int flags = (write_marg ? 1 : 0) | (store_msgs ? 2 : 0);
 #define CX_MVC(DD) do { if (gt) mvc_launch_t<DD, true>(h, A, K, flags, scan); else mvc_launch_t<DD, false>(h, A, K, flags, scan); } while (0)
+    if (h->cfg.dim == 2) CX_MVC(2);
+    else if (h->cfg.dim == 3) CX_MVC(3);
+    else CX_MVC(4);
+#undef CX_MVC
+}
+
+// The composed forward and backward maps of the handle's one path, heads NOT collapsed: totals + scan of the totals only, the
+// two maps end up in h->d_mvc_block (2 x (ND + 1) doubles).  The stored thread prefixes are overwritten: the caller materialises
+// the last sweep's messages first (mv_ensure_chain_msgs) and marks the side sums dirty.
+template <int D, bool GT>
+static void mvc_block_maps_t(cx_handle *h, MvcArgs A, int K) {
+    A.collapse_heads = 0;
+    const int ntiles = (int)mvc_ntiles(A.nlinks, K);
+    hipLaunchKernelGGL((k_mvc_totals<D, GT>), dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, K, h->d_mvc_totals);
+    hipLaunchKernelGGL((k_mvc_scan_totals<D>), dim3(2), dim3(kBlock), 0, h->stream, ntiles, h->d_mvc_totals, h->d_mvc_block);
+}
+
+void mvc_launch_block_maps(cx_handle *h) {
+    if (h->chain_nlinks == 0) return;
+    const int K = h->mvc_K;
+    MvcArgs A{(int)h->chain_nlinks, (int)h->chain_npos, (int)h->nv, (int)(2 * h->ptab_sets), h->nslots, h->d_chain_link_pos, h->d_chain_from,
+              h->d_chain_to, h->d_chain_tab_fwd, h->d_chain_tab_bwd, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_pos_var,
+              h->d_mvc_side, h->d_mvc_side_l, h->d_mvc_side_r, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix, h->d_mvc_wave_carry,
+              mvc_ntiles(h->chain_nlinks, K) * kBlock * K, 0, h->d_ptab};
+    const bool gt = A.ntab > kMvcTabLds;
+#define CX_MVC(DD) do { if (gt) mvc_block_maps_t<DD, true>(h, A, K); else mvc_block_maps_t<DD, false>(h, A, K); } while (0)
     if (h->cfg.dim == 2) CX_MVC(2);
     else if (h->cfg.dim == 3) CX_MVC(3);
     else CX_MVC(4);

@@ -215,7 +215,9 @@ class DeviceGraph:
     def chain_block_maps(self):
         """cx_chain_block_maps: (forward map [6], backward map [6], side of the first variable [2], side of the last [2],
         first variable id, last variable id, links)"""
-        f, b, sf, sl = np.zeros(6), np.zeros(6), np.zeros(2), np.zeros(2)
+        d = self.dim
+        nd, ns = (6, 2) if d == 1 else (d * (d + 1) + d * d + 2 * d, d + d * (d + 1) // 2)     # dim > 1: P | B | C | h | c;  eta | Lambda packed
+        f, b, sf, sl = np.zeros(nd), np.zeros(nd), np.zeros(ns), np.zeros(ns)
         v0, v1, nl = C.c_int64(), C.c_int64(), C.c_int64()
         self._check(self.lib.cx_chain_block_maps(self.h, _p(f, C.c_double), _p(b, C.c_double), _p(sf, C.c_double), _p(sl, C.c_double),
                                                  C.byref(v0), C.byref(v1), C.byref(nl)))

@@ -647,6 +647,31 @@ def _rule_additive(q, m):
     return np.array([m[0] * s, m[1] * s])
 
 
+# ---- d-dimensional blocks (dim 2..4): the maps of csrc/cx_mvchain.hip on the host (what the all-gathered rows are put together with)
+def _mv_sym(p, d):
+    """packed upper triangle (row by row) -> symmetric d x d"""
+    S = np.zeros((d, d))
+    S[np.triu_indices(d)] = p
+    return S + np.triu(S, 1).T
+
+
+def _mv_map_apply(M, d, eta, lam):
+    """f(eta, Lambda) = (c + B (Lambda + P)^-1 (eta + h), C - B (Lambda + P)^-1 B') for the map M = P | B | C | h | c"""
+    nt = d * (d + 1) // 2
+    P, B, Cm = _mv_sym(M[:nt], d), M[nt:nt + d * d].reshape(d, d), _mv_sym(M[nt + d * d:2 * nt + d * d], d)
+    h, c = M[2 * nt + d * d:2 * nt + d * d + d], M[2 * nt + d * d + d:]
+    W = np.linalg.inv(lam + P)
+    return c + B @ W @ (eta + h), Cm - B @ W @ B.T
+
+
+def _mv_rule(eta, lam, A, Q, forward):
+    """factor→variable rule of x_out = A x_in + N(0, Q) on a natural-form message (cx_mv.hip): forward = the receiver is the OUT edge"""
+    Qi = np.linalg.inv(Q)
+    P, B, Cm = (A.T @ Qi @ A, Qi @ A, Qi) if forward else (Qi, A.T @ Qi, A.T @ Qi @ A)
+    W = np.linalg.inv(lam + P)
+    return B @ W @ eta, Cm - B @ W @ B.T
+
+
 class ChainScanExchange:
     """A state-space chain cut into contiguous time blocks, one chain-scan handle per rank (`partition.contiguous_blocks(model,
     rank, world)`: the block's variables, the cut transition factors, the remote end of each as a degree-1 stand-in).
@@ -659,7 +684,10 @@ class ChainScanExchange:
          enters its block from the left (right): the stand-ins' variable→factor messages;
       4. one local `cx_sweep(1)`.
     `block` provides chain_block_maps / set_messages / sweep (a DeviceGraph, or the CPU stand-in of the tests); `dist` is
-    torch.distributed (or None for world 1)."""
+    torch.distributed (or None for world 1).
+
+    Scalar chains (additive factors) and, since round 3, d-dimensional chains (dim 2..4: the maps (P, B, C, h, c) of
+    csrc/cx_mvchain.hip, 2 ND + 2 nc + 4 doubles per rank in the all-gather: 120 for d = 4)."""
 
     def __init__(self, block, part: Partition, dist, torch, device="cpu"):
         self.block, self.part, self.dist, self.torch, self.device = block, part, dist, torch, device
@@ -670,17 +698,27 @@ class ChainScanExchange:
             raise ValueError(f"ChainScanExchange: rank {part.rank} of {part.world} holds {len(owned)} latent variable(s); a time block needs at "
                              "least two (one link) — use fewer ranks for a chain this short")
         fv = dict(zip(np.asarray(part.model.factor_ids).tolist(), np.asarray(part.model.factor_var).tolist()))
-        self.left = self.right = None        # (stand-in variable, cut factor, own end variable, factor variance)
+        self.dim = int(getattr(part.model, "dim", 1))
+        role = {}
+        if self.dim > 1:
+            role = {(int(v), int(f)): int(r) for v, f, r in zip(part.model.edge_var, part.model.edge_fac, part.model.edge_role)}
+        # (stand-in variable, cut factor, own end variable, factor variance | parameter set, own end variable is the OUT edge)
+        self.left = self.right = None
         for p in part.peers:
             assert p.send.stop - p.send.start == 1 and p.recv.stop - p.recv.start == 1, "a chain block has one cut factor per neighbour"
             cut = int(part.recv_fac[p.recv.start])
-            rec = (int(part.recv_var[p.recv.start]), cut, int(part.send_var[p.send.start]), float(fv[cut]))
+            own = int(part.send_var[p.send.start])
+            rec = (int(part.recv_var[p.recv.start]), cut, own, float(fv[cut]), role.get((own, cut), 0) == 0)      # ROLE_OUT == 0
             if p.rank < part.rank:
                 self.left = rec
             else:
                 self.right = rec
+        if self.dim > 1:      # the library has to know which variables are stand-ins (they are not observed, and not part of the chain)
+            block.halo_configure(part.send_var, part.send_fac, part.recv_var, part.recv_fac)
 
     def update(self):
+        if self.dim > 1:
+            return self._update_mv()
         from . import _lib as L
 
         blk, nan2, zero2 = self.block, [float("nan")] * 2, [0.0, 0.0]
@@ -720,6 +758,65 @@ class ChainScanExchange:
         if self.right is not None:
             blk.set_messages([self.right[0]], [self.right[1]], L.TO_FACTOR, L.FORM_NATURAL, right_in)
         blk.sweep(1)
+
+
+def _chain_scan_exchange_update_mv(self):
+    """ChainScanExchange.update for dim 2..4"""
+    from . import _lib as L
+
+    blk, d, psets = self.block, self.dim, self.part.model.psets
+    nt = d * (d + 1) // 2
+    nd, ns = 2 * nt + d * d + 2 * d, d + nt
+    zero, nan = np.zeros(d + d * d), np.full(d + d * d, np.nan)
+    for rec in (self.left, self.right):
+        if rec is not None:      # the cut messages out of the picture: nothing enters, nothing is known about the stand-in
+            blk.set_messages([rec[2]], [rec[1]], L.TO_VARIABLE, L.FORM_NATURAL, zero)
+            blk.set_messages([rec[0]], [rec[1]], L.TO_FACTOR, L.FORM_NATURAL, nan)
+    fwd, bwd, s_first, s_last, _v0, _v1, _nl = blk.chain_block_maps()
+    cuts = [(-1.0, 0.0) if r is None else (float(int(r[3])), 1.0 if r[4] else 0.0) for r in (self.left, self.right)]
+    mine = np.concatenate([fwd, bwd, s_first, s_last, cuts[0], cuts[1]])
+    world, rank = self.part.world, self.part.rank
+    if world > 1:
+        t = self.torch.from_numpy(mine.copy()).to(self.device)
+        got = [self.torch.zeros_like(t) for _ in range(world)]
+        self.dist.all_gather(got, t)
+        rows = np.stack([g.cpu().numpy() for g in got])
+    else:
+        rows = mine[None, :]
+    side = lambda p: (p[:d].copy(), _mv_sym(p[d:], d))       # noqa: E731
+    o = 2 * nd + 2 * ns
+    # what leaves block r on its right end towards the cut factor, given what entered it from the left
+    out, left_in = None, None
+    for r in range(world):
+        if r == rank:
+            left_in = out
+        if r > 0:         # through the cut factor into block r's first variable (receiver: that variable)
+            A, Q = psets[int(rows[r, o])]
+            enter = _mv_rule(out[0], out[1], np.asarray(A, float), np.asarray(Q, float), rows[r, o + 1] == 1.0)
+        else:
+            enter = (np.zeros(d), np.zeros((d, d)))          # block 0 starts from the empty message
+        e, lam = _mv_map_apply(rows[r, :nd], d, *enter)
+        se, sl = side(rows[r, 2 * nd + ns:2 * nd + 2 * ns])
+        out = (e + se, lam + sl)
+    out, right_in = None, None
+    for r in range(world - 1, -1, -1):
+        if r == rank:
+            right_in = out
+        if r < world - 1:
+            A, Q = psets[int(rows[r, o + 2])]
+            enter = _mv_rule(out[0], out[1], np.asarray(A, float), np.asarray(Q, float), rows[r, o + 3] == 1.0)
+        else:
+            enter = (np.zeros(d), np.zeros((d, d)))
+        e, lam = _mv_map_apply(rows[r, nd:2 * nd], d, *enter)
+        se, sl = side(rows[r, 2 * nd:2 * nd + ns])
+        out = (e + se, lam + sl)
+    for rec, m in ((self.left, left_in), (self.right, right_in)):
+        if rec is not None:
+            blk.set_messages([rec[0]], [rec[1]], L.TO_FACTOR, L.FORM_NATURAL, np.concatenate([m[0], m[1].ravel()]))
+    blk.sweep(1)
+
+
+ChainScanExchange._update_mv = _chain_scan_exchange_update_mv
 
 
 def verify_last_exchange(part: Partition, send, recv, dist, torch) -> bool:

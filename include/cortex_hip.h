@@ -321,7 +321,11 @@ int32_t cx_halo_exchange_sweep(cx_handle *h, int32_t n_sweeps);
  *                         factor→variable messages of the cut factors into the block's end variables to natural (0, 0), so that
  *                         the maps exclude them.
  *   [caller all-gathers the maps (16 doubles per rank), composes the prefixes and sets the stand-ins' variable→factor messages]
- *   cx_sweep(h, 1)      : the block's exact messages and marginals (cortex.jl_amd/partition.py: ChainScanExchange). */
+ *   cx_sweep(h, 1)      : the block's exact messages and marginals (cortex.jl_amd/partition.py: ChainScanExchange).
+ * dim 2, 3, 4 (round 3): the same protocol with the maps of csrc/cx_mvchain.hip.  A map is ND = 2 d(d+1)/2 + d^2 + 2 d doubles —
+ *   P (packed upper) | B (row-major) | C (packed upper) | h | c  of  f(eta, Lambda) = (c + B (Lambda + P)^-1 (eta + h), C - B (Lambda + P)^-1 B')
+ *   — in forward6 / backward6 (ND doubles each); the side sums are eta[d] | Lambda (packed upper) in side_first2 / side_last2.  The
+ *   stand-ins of a dim > 1 block are named with cx_halo_configure (recv lists only matter: they mark the stand-in variables). */
 int32_t cx_chain_block_maps(cx_handle *h, double *forward6, double *backward6, double *side_first2, double *side_last2,
                             int64_t *first_variable_id, int64_t *last_variable_id, int64_t *n_links);
 

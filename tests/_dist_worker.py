@@ -200,6 +200,123 @@ class OracleChainBlock:
         self.marg_mean, self.marg_var = nat[:, 0] / nat[:, 1], 1.0 / nat[:, 1]
 
 
+class OracleMvChainBlock:
+    """CPU stand-in for a dim 2..4 chain-scan DeviceGraph holding ONE time block (what partition.ChainScanExchange drives for
+    d-dimensional chains): halo_configure, chain_block_maps, set_messages, sweep in numpy — the map algebra of csrc/cx_mvchain.hip
+    (f(eta, Lambda) = (c + B (Lambda + P)^-1 (eta + h), C - B (Lambda + P)^-1 B') and its composition) written independently."""
+
+    def __init__(self, part):
+        m = part.model
+        self.d = d = m.dim
+        self.A, self.Q = (np.asarray(z, float) for z in m.psets[0])
+        R = np.asarray(m.psets[1][1], float)
+        Qi, Ri = np.linalg.inv(self.Q), np.linalg.inv(R)
+        A = self.A
+        self.tab_f = (A.T @ Qi @ A, Qi @ A, Qi)              # receiver = out (the later state)
+        self.tab_b = (Qi, A.T @ Qi, A.T @ Qi @ A)            # receiver = in
+        ghosts = set(np.asarray(part.recv_var).tolist())
+        self.x = np.array(sorted(v for v in np.asarray(m.x_ids).tolist() if v not in ghosts))
+        y = dict(zip(np.asarray(m.data_var).tolist(), np.asarray(m.data_y)))
+        pos = {int(v): i for i, v in enumerate(self.x)}
+        n = len(self.x)
+        self.side = [(np.zeros(d), np.zeros((d, d))) for _ in range(n)]
+        fac_of = {}
+        for v, f in zip(np.asarray(m.edge_var).tolist(), np.asarray(m.edge_fac).tolist()):
+            fac_of.setdefault(f, []).append(v)
+        self.cuts = {}                                       # cut factor -> "left" | "right"
+        for f, vs in fac_of.items():
+            a, b = sorted(vs)
+            if a in pos and b in y:
+                self.side[pos[a]] = (Ri @ y[b], Ri.copy())
+            elif (a in ghosts) != (b in ghosts):
+                own = b if a in ghosts else a
+                self.cuts[f] = "left" if own == self.x[0] and (n > 1 or a in ghosts) else "right"
+        self.boundary = {}
+
+    def halo_configure(self, *a):
+        pass
+
+    @staticmethod
+    def _rule(m, tab):
+        P, B, C = tab
+        W = np.linalg.inv(m[1] + P)
+        return B @ W @ m[0], C - B @ W @ B.T
+
+    @staticmethod
+    def _compose(m1, m2):
+        P1, B1, C1, h1, c1 = m1
+        P2, B2, C2, h2, c2 = m2
+        S = np.linalg.inv(C1 + P2)
+        g = c1 + h2
+        return (P1 - B1.T @ S @ B1, B2 @ S @ B1, C2 - B2 @ S @ B2.T, h1 + B1.T @ S @ g, c2 + B2 @ S @ g)
+
+    def _pack(self, m):
+        iu = np.triu_indices(self.d)
+        P, B, C, h, c = m
+        return np.concatenate([P[iu], B.ravel(), C[iu], h, c])
+
+    def chain_block_maps(self):
+        n, d = len(self.x), self.d
+        link = lambda u, tab: (tab[0] + u[1], tab[1], tab[2], u[0], np.zeros(d))      # noqa: E731
+        F = B = None
+        for l in range(n - 1):
+            e = link(self.side[l], self.tab_f)
+            F = e if F is None else self._compose(F, e)
+        for l in range(n - 2, -1, -1):
+            e = link(self.side[l + 1], self.tab_b)
+            B = e if B is None else self._compose(B, e)
+        iu = np.triu_indices(d)
+        ps = lambda u: np.concatenate([u[0], u[1][iu]])     # noqa: E731
+        return self._pack(F), self._pack(B), ps(self.side[0]), ps(self.side[-1]), int(self.x[0]), int(self.x[-1]), n - 1
+
+    def set_messages(self, var, fac, direction, form, payload):
+        from cortex.jl_amd import _lib as L
+
+        if direction == L.TO_FACTOR:                         # a stand-in's message into its cut factor: the block's boundary input
+            p = np.asarray(payload, dtype=float)
+            self.boundary[int(fac[0])] = (p[:self.d], p[self.d:].reshape(self.d, self.d))
+
+    def sweep(self, n=1):
+        nx, d = len(self.x), self.d
+        zero = (np.zeros(d), np.zeros((d, d)))
+        add = lambda a, b: (a[0] + b[0], a[1] + b[1])        # noqa: E731
+        alpha, beta = [zero] * nx, [zero] * nx
+        for f, where in self.cuts.items():
+            b = self.boundary.get(f)
+            if b is None or np.isnan(b[1]).any():
+                continue
+            if where == "left":
+                alpha[0] = self._rule(b, self.tab_f)
+            else:
+                beta[-1] = self._rule(b, self.tab_b)
+        for l in range(nx - 1):
+            alpha[l + 1] = self._rule(add(alpha[l], self.side[l]), self.tab_f)
+        for l in range(nx - 2, -1, -1):
+            beta[l] = self._rule(add(beta[l + 1], self.side[l + 1]), self.tab_b)
+        self.mean, self.cov = np.zeros((nx, d)), np.zeros((nx, d, d))
+        for t in range(nx):
+            e, lam = add(add(alpha[t], beta[t]), self.side[t])
+            self.cov[t] = np.linalg.inv(lam)
+            self.mean[t] = self.cov[t] @ e
+
+
+def main_mvchain():
+    """argv: mvchain d T out — time blocks of a d-dimensional chain, ChainScanExchange over gloo (one all-gather of the blocks' maps)"""
+    import cortex.jl_amd as cx
+
+    d, T, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    whole = cx.synth.lgssm_chain(T, d=d, seed=12)
+    part = partition.contiguous_blocks(whole, rank, world)
+    blk = OracleMvChainBlock(part)
+    ex = partition.ChainScanExchange(blk, part, dist, torch)
+    ex.update()
+    np.savez(out + f".rank{rank}.npz", x=blk.x, mean=blk.mean, cov=blk.cov)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main_chain():
     """argv: chain T out — time blocks of a scalar state-space chain, ChainScanExchange over gloo"""
     import cortex.jl_amd as cx
@@ -240,6 +357,8 @@ def main_mv():
 def main():
     if sys.argv[1] == "chain":
         return main_chain()
+    if sys.argv[1] == "mvchain":
+        return main_mvchain()
     if sys.argv[1] == "mv":
         return main_mv()
     rows, cols, sweeps, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]

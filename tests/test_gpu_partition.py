@@ -507,3 +507,73 @@ def test_chain_scan_partition_on_device(hip_lib, T, world):
         ids = parts[rank].model.x_ids
         got = devs[rank][0].get_marginals(ids)
         assert_close(got[:, 0], em2[ids - 1], 1e-9, f"rank {rank}: mean after new data")
+
+
+@pytest.mark.parametrize("d,T,world", [(2, 64, 3), (4, 500, 4), (4, 100_003, 8)])
+def test_chain_scan_partition_for_d_dimensional_chains_on_device(hip_lib, d, T, world):
+    """The dim 2..4 chain scan cut into time blocks (round 3; SURVEY §8e "exchange one composed map per block"): one chain-scan handle
+    per block, ONE all-gather of the blocks' composed linear-Gaussian maps (cx_chain_block_maps: P | B | C | h | c), one local sweep —
+    every block then holds the exact posterior of the WHOLE chain, also after new data."""
+    import torch
+
+    from oracle import exact
+
+    whole_model = cx.synth.lgssm_chain(T, d=d, seed=77)
+    A, Q, R = whole_model.meta["A"], whole_model.meta["Q"], whole_model.meta["R"]
+    ld = LoopbackDist(world, torch)
+    devs, parts, errors = [None] * world, [None] * world, []
+
+    def run(rank):
+        try:
+            ld.bind(rank)
+            part = partition.contiguous_blocks(whole_model, rank, world)
+            dev = cx.DeviceGraph(dim=d, schedule=L.SCHED_CHAIN_SCAN)
+            cx.synth.load_into_device(part.model, dev)
+            ex = partition.ChainScanExchange(dev, part, ld, torch)
+            ex.update()
+            dev.sync()
+            devs[rank], parts[rank] = (dev, ex), part
+        except Exception as e:  # pragma: no cover
+            errors.append((rank, repr(e)))
+
+    def everyone(fn):
+        threads = [threading.Thread(target=fn, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not errors, errors
+
+    everyone(run)
+    solve = exact.lgssm_posterior_c if T > 5000 else exact.lgssm_posterior
+
+    def check(y, what):
+        em, ecov = solve(y, A, Q, R)
+        total = 0
+        for rank in range(world):
+            own = np.setdiff1d(parts[rank].model.x_ids, parts[rank].recv_var)      # the stand-ins are listed among x_ids too
+            got = devs[rank][0].get_marginals(own)
+            assert_close(got[:, :d], em[own - 1], 1e-8, f"{what}, rank {rank}: means", scale_by="max")
+            assert_close(got[:, d:].reshape(len(own), d, d), ecov[own - 1], 1e-8, f"{what}, rank {rank}: covariances", scale_by="max")
+            total += len(own)
+        assert total == T
+
+    check(whole_model.data_y, "first exchange")
+    rng = np.random.default_rng(5)
+    y2 = whole_model.data_y + rng.standard_normal((T, d))
+    for rank in range(world):
+        dev, ex = devs[rank]
+        m = parts[rank].model
+        sel = np.searchsorted(whole_model.data_var, m.data_var)
+        dev.set_messages(m.data_var, m.data_fac, L.TO_FACTOR, L.FORM_POINT, y2[sel])
+
+    def again(rank):
+        try:
+            ld.bind(rank)
+            ld.local.round = 1
+            devs[rank][1].update()
+        except Exception as e:  # pragma: no cover
+            errors.append((rank, repr(e)))
+
+    everyone(again)
+    check(y2, "after new data")

@@ -411,6 +411,27 @@ def test_gloo_deep_halo_for_d_dimensional_messages(tmp_path, world, d, depth):
     assert np.array_equal(np.sort(np.concatenate(seen)), np.sort(whole.x_ids))
 
 
+@pytest.mark.parametrize("world,d,T", [(2, 2, 9), (3, 4, 31)])
+def test_gloo_chain_scan_partition_for_d_dimensional_chains(tmp_path, world, d, T):
+    """SURVEY §8e for d-dimensional chains (round 3): contiguous time blocks, ONE all-gather of the blocks' composed linear-Gaussian
+    maps, a local pass (partition.ChainScanExchange over gloo, a numpy block standing in for the dim > 1 chain-scan handle): every
+    rank's marginals are the exact posterior of the WHOLE chain (block-tridiagonal solve)."""
+    from oracle import exact
+
+    out = str(tmp_path / "res")
+    _spawn(world, ["mvchain", d, T, out])
+    whole = cx.synth.lgssm_chain(T, d=d, seed=12)
+    em, ecov = exact.lgssm_posterior(whole.data_y, whole.meta["A"], whole.meta["Q"], whole.meta["R"])
+    seen = []
+    for r in range(world):
+        g = np.load(out + f".rank{r}.npz")
+        idx = g["x"] - 1
+        np.testing.assert_allclose(g["mean"], em[idx], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(g["cov"], ecov[idx], rtol=1e-9, atol=1e-12)
+        seen.append(g["x"])
+    assert np.array_equal(np.sort(np.concatenate(seen)), whole.x_ids)
+
+
 def test_chain_scan_exchange_refuses_a_block_of_one_state():
     """world large relative to T leaves a rank with a single latent variable — no link, no block map: a clear error"""
     from cortex.jl_amd import partition
