@@ -69,7 +69,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+    dbg = ["-gline-tables-only"] if os.environ.get("CX_BUILD_DEBUG") else []      # line numbers in host backtraces (rocgdb)
+    flags = dbg + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-I/opt/rocm/include"]
     hdr_t = max(os.path.getmtime(h) for h in HEADERS)
 

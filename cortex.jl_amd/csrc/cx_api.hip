@@ -312,7 +312,10 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
         }
         std::vector<double> q(mv ? 1 : slots, 0.0), a, b, sq, sa, sb;
         h->any_linear = false;
-        for (int64_t f = 0; f < n_factors; f++) if (h->fac_kind[f] == CX_FACTOR_GAUSS_LINEAR) h->any_linear = true;
+        // (dim > 1: every factor is "linear" but its parameters are matrices in the rule tables — the per-slot scalar arrays below do
+        // not exist; q has ONE element there, and reading q[partner] for every slot ran off its end: a latent out-of-bounds read
+        // since round 1 that depended on what the heap held next to it)
+        for (int64_t f = 0; f < n_factors && !mv; f++) if (h->fac_kind[f] == CX_FACTOR_GAUSS_LINEAR) h->any_linear = true;
         if (h->any_linear) { a.assign(slots, 1.0); b.assign(slots, 0.0); sq.assign(slots, 0.0); sa.assign(slots, 1.0); sb.assign(slots, 0.0); }
         for (int64_t f = 0; f < n_factors; f++) {
             const int32_t deg = foff[f + 1] - foff[f], kind = h->fac_kind[f];

@@ -238,7 +238,6 @@ int32_t cx_chain_block_maps(cx_handle *h, double *fwd6, double *bwd6, double *si
         try { h->chain_partition = true; return mv_chain_block_maps(h, fwd6, bwd6, side_first2, side_last2, first_variable_id, last_variable_id, n_links); }
         catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_chain_block_maps: host allocation failed"); }
     }
-    CX_REQUIRE(h, !h->any_linear, CX_ERR_UNSUPPORTED, "cx_chain_block_maps: additive factors only in this build");
     int32_t rc = build_chains(h);
     if (rc != CX_OK) return rc;
     CX_REQUIRE(h, h->chain_npos >= 1 && h->chain_nlinks == h->chain_npos - 1, CX_ERR_UNSUPPORTED,

@@ -672,6 +672,22 @@ def _mv_rule(eta, lam, A, Q, forward):
     return B @ W @ eta, Cm - B @ W @ B.T
 
 
+def _rule_linear(abq, m):
+    """factor→variable rule with the RECEIVING edge's effective (a, b, q) on a natural-form message (csrc/cx_kernels.hip:
+    factor_rule): s = 1 / (a² + q w);  (xi, w) -> ((a xi + b w) s, w s).  Additive factors are (1, 0, q)."""
+    a, b, q = abq
+    s = 1.0 / (a * a + q * m[1])
+    return np.array([(a * m[0] + b * m[1]) * s, m[1] * s])
+
+
+def _effective_abq(params, receiver_is_out):
+    """x_out = a x_in + b + N(0, q): the parameters the receiving edge applies — forward (receiver = out) {a, b, q}, backward
+    (receiver = in) {1/a, -b/a, q/a²} (cx_graph_create)"""
+    p = np.atleast_1d(np.asarray(params, float))
+    q, a, b = (p[0], 1.0, 0.0) if len(p) < 3 or p[1] == 0.0 else (p[0], p[1], p[2])
+    return (a, b, q) if receiver_is_out else (1.0 / a, -b / a, q / (a * a))
+
+
 class ChainScanExchange:
     """A state-space chain cut into contiguous time blocks, one chain-scan handle per rank (`partition.contiguous_blocks(model,
     rank, world)`: the block's variables, the cut transition factors, the remote end of each as a degree-1 stand-in).
@@ -679,14 +695,14 @@ class ChainScanExchange:
     One `update()` = the exact forward/backward result of the WHOLE chain on every rank's block:
       1. every rank asks its handle for the block's composed forward and backward maps and the side sums of its end variables
          (`cx_chain_block_maps`: the scan's first two kernels), with the cut messages out of the picture;
-      2. ONE all-gather of 18 doubles per rank (the only collective);
+      2. ONE all-gather of 22 doubles per rank (the only collective);
       3. every rank applies the maps of the blocks before it (after it) to the empty message and obtains the one message that
          enters its block from the left (right): the stand-ins' variable→factor messages;
       4. one local `cx_sweep(1)`.
     `block` provides chain_block_maps / set_messages / sweep (a DeviceGraph, or the CPU stand-in of the tests); `dist` is
     torch.distributed (or None for world 1).
 
-    Scalar chains (additive factors) and, since round 3, d-dimensional chains (dim 2..4: the maps (P, B, C, h, c) of
+    Scalar chains (additive and — round 3 — linear factors x_out = a x_in + b + noise) and, since round 3, d-dimensional chains (dim 2..4: the maps (P, B, C, h, c) of
     csrc/cx_mvchain.hip, 2 ND + 2 nc + 4 doubles per rank in the all-gather: 120 for d = 4)."""
 
     def __init__(self, block, part: Partition, dist, torch, device="cpu"):
@@ -700,7 +716,7 @@ class ChainScanExchange:
         fv = dict(zip(np.asarray(part.model.factor_ids).tolist(), np.asarray(part.model.factor_var).tolist()))
         self.dim = int(getattr(part.model, "dim", 1))
         role = {}
-        if self.dim > 1:
+        if part.model.edge_role is not None:
             role = {(int(v), int(f)): int(r) for v, f, r in zip(part.model.edge_var, part.model.edge_fac, part.model.edge_role)}
         # (stand-in variable, cut factor, own end variable, factor variance | parameter set, own end variable is the OUT edge)
         self.left = self.right = None
@@ -708,7 +724,7 @@ class ChainScanExchange:
             assert p.send.stop - p.send.start == 1 and p.recv.stop - p.recv.start == 1, "a chain block has one cut factor per neighbour"
             cut = int(part.recv_fac[p.recv.start])
             own = int(part.send_var[p.send.start])
-            rec = (int(part.recv_var[p.recv.start]), cut, own, float(fv[cut]), role.get((own, cut), 0) == 0)      # ROLE_OUT == 0
+            rec = (int(part.recv_var[p.recv.start]), cut, own, fv[cut], role.get((own, cut), 0) == 0)      # ROLE_OUT == 0
             if p.rank < part.rank:
                 self.left = rec
             else:
@@ -727,7 +743,9 @@ class ChainScanExchange:
                 blk.set_messages([rec[2]], [rec[1]], L.TO_VARIABLE, L.FORM_NATURAL, zero2)
                 blk.set_messages([rec[0]], [rec[1]], L.TO_FACTOR, L.FORM_NATURAL, nan2)
         fwd, bwd, s_first, s_last, _v0, _v1, _nl = blk.chain_block_maps()
-        mine = np.concatenate([fwd, bwd, s_first, s_last, [self.left[3] if self.left else 0.0, self.right[3] if self.right else 0.0]])
+        # the rule a message goes through when it ENTERS this block over a cut factor: the effective (a, b, q) of the own end's edge
+        eff = [(1.0, 0.0, 0.0) if r is None else _effective_abq(r[3], r[4]) for r in (self.left, self.right)]
+        mine = np.concatenate([fwd, bwd, s_first, s_last, eff[0], eff[1]])
         world, rank = self.part.world, self.part.rank
         if world > 1:
             t = self.torch.from_numpy(mine.copy()).to(self.device)
@@ -740,18 +758,18 @@ class ChainScanExchange:
         out = np.zeros(2)
         left_in = None
         for r in range(world):
-            F, sl, qL = rows[r, 0:6], rows[r, 14:16], rows[r, 16]
+            F, sl, abqL = rows[r, 0:6], rows[r, 14:16], rows[r, 16:19]
             if r == rank:
                 left_in = out.copy() if r > 0 else None
-            enter = _rule_additive(qL, out) if r > 0 else np.zeros(2)     # through the cut factor; block 0 starts from the empty message
+            enter = _rule_linear(abqL, out) if r > 0 else np.zeros(2)     # through the cut factor; block 0 starts from the empty message
             out = _lin_apply(F, enter) + sl
         out = np.zeros(2)
         right_in = None
         for r in range(world - 1, -1, -1):
-            B, sf, qR = rows[r, 6:12], rows[r, 12:14], rows[r, 17]
+            B, sf, abqR = rows[r, 6:12], rows[r, 12:14], rows[r, 19:22]
             if r == rank:
                 right_in = out.copy() if r < world - 1 else None
-            enter = _rule_additive(qR, out) if r < world - 1 else np.zeros(2)
+            enter = _rule_linear(abqR, out) if r < world - 1 else np.zeros(2)
             out = _lin_apply(B, enter) + sf
         if self.left is not None:
             blk.set_messages([self.left[0]], [self.left[1]], L.TO_FACTOR, L.FORM_NATURAL, left_in)

@@ -62,6 +62,34 @@ def ssm_chain(T: int, seed: int = 1234, q: float = 1.0, r: float = 1.0, random_v
                  meta={"T": T, "r": fvar_lik, "q": fvar_tr, "kind": "ssm_chain"})
 
 
+def ssm_chain_linear(T: int, seed: int = 1234, a: float = 0.9, b: float = 0.3, q: float = 0.5, r: float = 0.7) -> Model:
+    """The same chain with LINEAR transitions x_{t+1} = a_t x_t + b_t + N(0, q_t) (CX_FACTOR_GAUSS_LINEAR; a_t, b_t, q_t jittered around
+    the arguments) and additive likelihoods of variance r: factor_var holds one (q, a, b) row per factor, edge_role the :in / :out ends."""
+    rng = np.random.default_rng(seed)
+    x = np.arange(1, T + 1, dtype=np.int64)
+    y = x + T
+    lik = x + 2 * T
+    tr = np.arange(3 * T + 1, 4 * T, dtype=np.int64)
+    edge_var = np.concatenate([y, x, x[:-1], x[1:]])
+    edge_fac = np.concatenate([lik, lik, tr, tr])
+    edge_role = np.concatenate([np.full(2 * T, L.ROLE_OUT), np.full(T - 1, L.ROLE_IN), np.full(T - 1, L.ROLE_OUT)]).astype(np.int32)
+    at = a * rng.uniform(0.8, 1.2, T - 1) * rng.choice([1.0, -1.0], T - 1, p=[0.8, 0.2])
+    bt = b * rng.standard_normal(T - 1)
+    qt = q * rng.uniform(0.5, 2.0, T - 1)
+    params = np.zeros((2 * T - 1, 3))
+    params[:T, 0] = r
+    params[T:, 0], params[T:, 1], params[T:, 2] = qt, at, bt
+    state = np.empty(T)
+    state[0] = rng.standard_normal()
+    for t in range(1, T):
+        state[t] = at[t - 1] * state[t - 1] + bt[t - 1] + np.sqrt(qt[t - 1]) * rng.standard_normal()
+    data = state + np.sqrt(r) * rng.standard_normal(T)
+    kind = np.concatenate([np.full(T, L.FACTOR_GAUSS_ADDITIVE), np.full(T - 1, L.FACTOR_GAUSS_LINEAR)]).astype(np.int32)
+    return Model(edge_var=edge_var, edge_fac=edge_fac, factor_ids=np.concatenate([lik, tr]), factor_kind=kind, factor_var=params,
+                 x_ids=x, data_var=y, data_fac=lik, data_y=data, edge_role=edge_role,
+                 meta={"T": T, "r": r, "q": qt, "a": at, "b": bt, "kind": "ssm_chain_linear"})
+
+
 def _grid_rows(seed: int, total_rows: int, n_cols: int, r0: int, r1: int):
     """Per-row random streams keyed by (seed, kind, global row): any rank regenerates exactly the rows it needs, and
     the union over ranks is the same global grid whatever the partition."""
@@ -195,7 +223,7 @@ def load_into_device(model: Model, dev, seed_variance: float | None = None):
         if seed_variance is not None:
             dev.seed_messages(L.TO_VARIABLE, 0.0, seed_variance)
         return dev
-    dev.graph_create(model.edge_var, model.edge_fac, model.factor_ids, model.factor_kind, model.factor_var)
+    dev.graph_create(model.edge_var, model.edge_fac, model.factor_ids, model.factor_kind, model.factor_var, edge_role=model.edge_role)
     if len(model.data_var):
         dev.set_messages(model.data_var, model.data_fac, L.TO_FACTOR, L.FORM_POINT, model.data_y)
     if len(model.prior_var):
