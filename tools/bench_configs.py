@@ -111,7 +111,7 @@ def mv(d, T, steps):
            "ms_per_sweep": dt * 1e3, "kernel_ms": ms / max(n, 1), "updates_per_sweep": upd, "updates_per_s": upd / dt,
            "algorithmic_GBps": upd * 2 * payload / dt / 1e9, "payload_bytes": payload}
     kern_s = ms / max(n, 1) / 1e3
-    tr = counter_traffic("k_rule64" if d == 64 else f"k_sweep_mv<{d}>")
+    tr = counter_traffic("k_rule64" if d == 64 else f"k_sweep_mv<{d},")
     alg = upd * 2 * payload
     if d == 64:
         # v_mfma_f64_16x16x4_f64 per factor→variable message, 2*16*16*4 flop each: 384 in the wave-per-message kernel
