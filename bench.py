@@ -50,7 +50,7 @@ def parse(argv=None):
     ap.add_argument("--sweeps-per-launch", type=int, default=1, choices=[1, 2],
                     help="2: the two-sweeps-per-launch experiment (cx_tiles.hip; bit-identical, measured slower: DESIGN.md §4c)")
     ap.add_argument("--materialize", action="store_true", help="also store every variable→factor message each sweep")
-    ap.add_argument("--halo", choices=["rccl", "torch"], default=os.environ.get("CX_HALO", "rccl"),
+    ap.add_argument("--halo", choices=["ipc", "rccl", "torch"], default=os.environ.get("CX_HALO", "ipc"),
                     help="N > 1: exchange issued by the library on RCCL (default) or by torch.distributed isend/irecv")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
                     help="strong (default, BASELINE config 4): the ONE N x N grid is cut into row blocks over the ranks; "
@@ -339,7 +339,7 @@ class Workload:
         self.dev = dev = cx.DeviceGraph(device=local_rank, schedule=schedule, marginals_in_sweep=True,
                                         materialize_messages_to_factor=args.materialize, sweeps_per_launch=args.sweeps_per_launch)
         dev.set_stream(torch.cuda.current_stream().cuda_stream)
-        self.halo_kind, self.halo_tensors, self.part, self.exchange = None, None, None, None
+        self.halo_kind, self.halo_tensors, self.part, self.exchange, self.ipc = None, None, None, None, None
         red_dev = "cuda" if backend == "nccl" else "cpu"
         if world == 1 and not args.self_halo:
             model = cx.synth.gaussian_grid(N, N, seed=args.seed)
@@ -360,7 +360,42 @@ class Workload:
             cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
             exchange = None
             tdev = torch.device("cuda", local_rank)
-            if backend != "nccl" and world > 1:
+            err = None
+            if args.halo == "ipc" and depth:
+                # the library pushes into the neighbours' IPC-mapped receive areas (one launch per exchange, no collective
+                # library on the data path).  Audited on this very topology before it is used: the first exchange must put
+                # the owners' values into the redundant rows bit for bit (second copy over torch.distributed); anything
+                # else — allocation, handle import, a neighbour that does not arrive, a mismatch — and ALL ranks fall back
+                # to the RCCL exchange below
+                def agreed(e):              # every rank takes the same path: one rank's failure is everybody's
+                    if dist is None:
+                        return e
+                    okf = torch.tensor([0 if e else 1], dtype=torch.int32, device=red_dev)
+                    dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+                    return e if e or okf.item() == 1 else "another rank failed"
+                ex = None
+                try:
+                    ex = partition.DeepHaloIpc(dev, part, dist, torch, tdev)
+                    dev.halo_ipc_set_timeout(30.0)
+                except (cx.CortexHipError, RuntimeError, ValueError) as e:
+                    err = e
+                err = agreed(err)
+                if err is None:             # the audit is collective: entered by all ranks or by none
+                    try:
+                        if not ex.audit(dist, torch, tdev if backend == "nccl" or dist is None else torch.device("cpu")):
+                            err = "audit of the first exchange failed"
+                    except (cx.CortexHipError, RuntimeError, ValueError) as e:
+                        err = e
+                    err = agreed(err)
+                if err is None:
+                    exchange = self.ipc = ex
+                    self.halo_kind = "pushed into the neighbours' IPC-mapped receive areas behind an epoch flag, one launch per exchange (audited at start)"
+                elif rank == 0:
+                    print(f"[bench] IPC exchange unavailable ({err}); falling back", file=sys.stderr)
+                err = None
+            if exchange is not None:
+                pass
+            elif backend != "nccl" and world > 1:
                 if depth:
                     sweeper = partition.HostStagedStateSweeper(dev, part, torch, tdev)
                     exchange = partition.DeepHaloExchange(sweeper, part, dist)
@@ -369,8 +404,7 @@ class Workload:
                     exchange = partition.HaloExchange(sweeper, part, dist)
                 self.halo_kind = f"REHEARSAL: host-staged over {backend}"
                 self.halo_tensors = (sweeper.send, sweeper.recv)
-            elif args.halo == "rccl":
-                err = None
+            elif args.halo in ("ipc", "rccl"):
                 try:
                     exchange = (partition.DeepHaloRccl if depth else partition.RcclExchange)(dev, part, dist, torch, tdev)
                     self.halo_kind = "rccl send/recv issued by the library"
@@ -521,6 +555,12 @@ def run_rank(args):
         dev.sync()
         torch.cuda.synchronize()
         halo_check = partition.verify_last_exchange(w.part, w.halo_tensors[0], w.halo_tensors[1], dist, torch)
+    elif w.ipc is not None:
+        # one more exchange, audited (the run ends between batches only when its sweeps are a multiple of the depth: top up)
+        w.ipc.check()
+        if w.ipc.k % w.ipc.depth:
+            w.run(w.ipc.depth - w.ipc.k % w.ipc.depth)
+        halo_check = w.ipc.audit(dist, torch, torch.device("cuda", local_rank) if backend == "nccl" or dist is None else torch.device("cpu"))
 
     # second figure at N > 1: weak scaling (every rank one N x N strip of an (N * ranks) x N grid)
     weak = None

@@ -88,6 +88,13 @@ SIGNATURES = {
     "cx_halo_state_unpack": (_i32, [_vp]),
     "cx_halo_state_exchange": (_i32, [_vp]),
     "cx_halo_exchange_sweep": (_i32, [_vp, _i32]),
+    "cx_halo_ipc_alloc": (_i32, [_vp, C.c_char_p, C.POINTER(C.c_void_p), _pi64]),
+    "cx_halo_ipc_connect": (_i32, [_vp, _i32, C.c_char_p, C.c_void_p, _i32, _i64, _i64]),
+    "cx_halo_ipc_exchange": (_i32, [_vp]),
+    "cx_halo_ipc_push": (_i32, [_vp]),
+    "cx_halo_ipc_unpack": (_i32, [_vp]),
+    "cx_halo_ipc_status": (_i32, [_vp, _pi32, _pi64]),
+    "cx_halo_ipc_set_timeout": (_i32, [_vp, C.c_double]),
     "cx_chain_block_maps": (_i32, [_vp, _pd, _pd, _pd, _pd, _pi64, _pi64, _pi64]),
     "cx_set_marginals": (_i32, [_vp, _i64, _pi64, _i32, _pd]),
     "cx_update_marginals": (_i32, [_vp, _i64, _pi64]),

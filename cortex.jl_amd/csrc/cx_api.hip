@@ -116,6 +116,7 @@ int32_t cx_destroy(cx_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     for (auto &r : h->recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     cx::comm_destroy(h);
+    cx::ipc_destroy(h);
     cx::vmp_free(h);
     dev_free_all(h);
     delete h;

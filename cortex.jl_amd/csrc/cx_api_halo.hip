@@ -34,6 +34,7 @@ int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const
         h->halo_state = false;
         h->chains_dirty = true;
         CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
+        cx::ipc_destroy(h);          // the receive areas are sized by the halo lists
         for (void *p : {(void *)h->d_send_slots, (void *)h->d_recv_slots, (void *)h->d_send_vars}) if (p) (void)hipFree(p);
         if (!h->ext_halo_buffers) { if (h->d_send_buf) (void)hipFree(h->d_send_buf); if (h->d_recv_buf) (void)hipFree(h->d_recv_buf); }
         h->d_send_slots = h->d_recv_slots = h->d_send_vars = nullptr; h->d_send_buf = h->d_recv_buf = nullptr;
@@ -76,6 +77,7 @@ int32_t cx_halo_configure_state(cx_handle *h, int64_t n_send, const int64_t *sv,
             for (uint8_t &b : h->vinfo) b &= (uint8_t)~cx::kGhost;
             CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
         }
+        cx::ipc_destroy(h);          // the receive areas are sized by the halo lists
         for (void *p : {(void *)h->d_send_slots, (void *)h->d_recv_slots, (void *)h->d_send_vars}) if (p) (void)hipFree(p);
         if (!h->ext_halo_buffers) { if (h->d_send_buf) (void)hipFree(h->d_send_buf); if (h->d_recv_buf) (void)hipFree(h->d_recv_buf); }
         h->d_send_slots = h->d_recv_slots = h->d_send_vars = nullptr; h->d_send_buf = h->d_recv_buf = nullptr;

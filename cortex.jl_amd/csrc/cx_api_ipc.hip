@@ -1,0 +1,330 @@
+// cx_api_ipc.hip — deep-halo state exchange WITHOUT a collective library: every rank pushes the state of its boundary rows
+// straight into a receive area of its neighbour (device memory the neighbour exported with hipIpcGetMemHandle, mapped over xGMI)
+// and raises an epoch flag there; the neighbour's unpack kernel waits for the flag and scatters the area into its redundant rows.
+// Two launches on the handle's own stream per exchange — push, wait + unpack — against pack, RCCL send/recv kernel, unpack of
+// cx_halo_state_exchange (cx_api_halo.hip), which stays the audited fallback.  (SURVEY.md §5 names this form as the alternative;
+// the reference itself is single-process: the partition is this library's, docs/src/index.md "not implemented: parallel".)
+//
+// Memory.  One block per rank, allocated fine-grained (every access coherent between agents while kernels run):
+//     [ flags: 64 B per peer entry ]  [ receive area, parity 0 ]  [ receive area, parity 1 ]
+// A receive area has the layout of the handle's halo receive buffer (segment of peer entry i at recv_off[i] messages).  Exchange
+// e (1, 2, ...) uses parity e & 1.  Why two parities suffice without an acknowledgement: a neighbour can only push exchange e + 2
+// after it has unpacked exchange e + 1 from me, which I push after my sweeps of batch e + 1, which follow my unpack of exchange e
+// on my stream.
+// Ordering.  push: every thread stores its messages (system scope, write-through), waits for the acknowledgements, the workgroup
+// counts itself done; the LAST workgroup stores the epoch into the neighbours' flags.  unpack: one thread per workgroup polls the
+// rank's own flags (system scope, past the caches), bounded by a wall-clock limit — a neighbour that never arrives sets the
+// error word that cx_halo_ipc_status reports, the grid drains either way; then the area is read past the caches.
+
+#include "cx_host.h"
+
+using namespace cxh;
+
+namespace {
+
+constexpr int kMaxPeers = 8;
+constexpr int64_t kFlagStride = 64;              // bytes between two flags: one per cache line
+constexpr int64_t kFlagBytes = 4096;
+
+struct PushArgs {
+    int n_peers;
+    int64_t send_off[kMaxPeers], send_count[kMaxPeers];
+    double2 *remote_area[kMaxPeers];             // the neighbour's receive area of this exchange's parity, at my segment
+    unsigned long long *remote_flag[kMaxPeers];
+};
+
+struct WaitArgs {
+    int n_peers;
+    const unsigned long long *flag[kMaxPeers];
+};
+
+// Accesses to the exchanged memory carry their own scope (relaxed atomics at system scope: write-through stores, cache-bypassing
+// loads) instead of release / acquire FENCES: a fence at agent or system scope writes back / invalidates the whole L2 of the XCD,
+// once per wave that executes it — measured: + 100 us per exchange and the sweeps that follow start from a cold L2.  What a
+// fence would order is ordered here by completion: a wave waits until its stores have been acknowledged (s_waitcnt vmcnt(0)),
+// then the workgroup counts itself done; the flags are stored after the last count.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_sys(double2 *p, double2 v) {      // one 16-byte write-through store (sc0 sc1 = system scope)
+    u32x4 r;
+    __builtin_memcpy(&r, &v, 16);
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(r) : "memory");
+}
+// four 16-byte loads past the caches, in flight together; the wait is part of the statement (the compiler does not know that an
+// asm load completes later and would read its destination at once)
+__device__ __forceinline__ void load_sys4(const double2 *p0, const double2 *p1, const double2 *p2, const double2 *p3, u32x4 (&r)[4]) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+                 : "memory");
+}
+
+constexpr int kIpcBlock = 1024, kIpcItems = 4;   // few, fat workgroups: the completion counter is one same-address atomic per workgroup
+                                                 // (884 of them cost more than the copy itself: 14 us per push)
+
+__device__ __forceinline__ void ipc_push_block(int64_t block, unsigned int nblocks, const double2 *__restrict__ f2v, const int32_t *__restrict__ send_slots,
+                                               int64_t n, const PushArgs &a, unsigned long long epoch, unsigned int *__restrict__ done) {
+    const int64_t base = block * (kIpcBlock * kIpcItems) + threadIdx.x;
+    int32_t slot[kIpcItems];
+    double2 m[kIpcItems];
+#pragma unroll
+    for (int k = 0; k < kIpcItems; k++) { const int64_t i = base + k * kIpcBlock; slot[k] = i < n ? send_slots[i] : -1; }
+#pragma unroll
+    for (int k = 0; k < kIpcItems; k++) if (slot[k] >= 0) m[k] = f2v[slot[k]];
+    __builtin_amdgcn_s_waitcnt(0);                           // the messages are in registers: no wait is left to be placed between the stores
+    for (int p = 0; p < a.n_peers; p++) {                    // a message may go to several neighbours
+        const int64_t off = a.send_off[p], cnt = a.send_count[p];
+        double2 *dst = a.remote_area[p];
+#pragma unroll
+        for (int k = 0; k < kIpcItems; k++) {                // the stores of a neighbour go out back to back
+            const int64_t j = base + k * kIpcBlock - off;
+            if (slot[k] >= 0 && j >= 0 && j < cnt) store_sys(dst + j, m[k]);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);                           // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int before = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == nblocks - 1) {                         // every workgroup's stores are complete: raise the flags
+            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int p = 0; p < a.n_peers; p++) __hip_atomic_store(a.remote_flag[p], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+__device__ __forceinline__ void ipc_unpack_block(int64_t block, double2 *__restrict__ f2v, const int32_t *__restrict__ recv_slots,
+                                                 const double2 *__restrict__ area, int64_t n, const WaitArgs &w, unsigned long long epoch,
+                                                 unsigned long long limit_ticks, int *__restrict__ err) {
+    __shared__ int ok;
+    const int64_t base = block * (kIpcBlock * kIpcItems) + threadIdx.x;
+    int32_t slot[kIpcItems];
+#pragma unroll
+    for (int k = 0; k < kIpcItems; k++) { const int64_t i = base + k * kIpcBlock; slot[k] = i < n ? recv_slots[i] : -1; }   // while thread 0 waits
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();
+        int good = 1;
+        for (int p = 0; p < w.n_peers && good; p++)
+            while (__hip_atomic_load(w.flag[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+                if (wall_clock64() - t0 > limit_ticks) { good = 0; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        if (!good) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = good;
+    }
+    __syncthreads();                                         // the loads below are issued after the flag has been seen
+    if (!ok) return;
+    static_assert(kIpcItems == 4, "load_sys4");
+    if (n == 0) return;
+    u32x4 r[kIpcItems];
+    const double2 *src[kIpcItems];
+#pragma unroll
+    for (int k = 0; k < kIpcItems; k++) src[k] = area + std::min<int64_t>(base + k * kIpcBlock, n - 1);   // every lane loads; the tail re-reads the last message
+    load_sys4(src[0], src[1], src[2], src[3], r);
+#pragma unroll
+    for (int k = 0; k < kIpcItems; k++)
+        if (slot[k] >= 0) { double2 v; __builtin_memcpy(&v, &r[k], 16); f2v[slot[k]] = v; }
+}
+
+__global__ __launch_bounds__(kIpcBlock) void k_ipc_push(const double2 *__restrict__ f2v, const int32_t *__restrict__ send_slots, int64_t n, PushArgs a,
+                                                        unsigned long long epoch, unsigned int *__restrict__ done) {
+    ipc_push_block(blockIdx.x, gridDim.x, f2v, send_slots, n, a, epoch, done);
+}
+
+__global__ __launch_bounds__(kIpcBlock) void k_ipc_unpack(double2 *__restrict__ f2v, const int32_t *__restrict__ recv_slots, const double2 *__restrict__ area,
+                                                          int64_t n, WaitArgs w, unsigned long long epoch, unsigned long long limit_ticks,
+                                                          int *__restrict__ err) {
+    ipc_unpack_block(blockIdx.x, f2v, recv_slots, area, n, w, epoch, limit_ticks, err);
+}
+
+// push and unpack of one exchange in ONE launch: they touch disjoint messages (what a rank sends belongs to owned variables, what it
+// receives to redundant ones).  The first n_push workgroups push — they are dispatched first and never wait — the others wait for
+// the neighbours' flags and unpack.
+__global__ __launch_bounds__(kIpcBlock) void k_ipc_exchange(double2 *__restrict__ f2v, const int32_t *__restrict__ send_slots, int64_t n_send, PushArgs a,
+                                                            unsigned int n_push, unsigned int *__restrict__ done, const int32_t *__restrict__ recv_slots,
+                                                            const double2 *__restrict__ area, int64_t n_recv, WaitArgs w, unsigned long long epoch,
+                                                            unsigned long long limit_ticks, int *__restrict__ err) {
+    if (blockIdx.x < n_push) ipc_push_block(blockIdx.x, n_push, f2v, send_slots, n_send, a, epoch, done);
+    else ipc_unpack_block(blockIdx.x - n_push, f2v, recv_slots, area, n_recv, w, epoch, limit_ticks, err);
+}
+
+}  // namespace
+
+namespace cx {
+
+void ipc_destroy(cx_handle *h) {
+    for (auto &c : h->ipc_conn)
+        if (c.opened) (void)hipIpcCloseMemHandle(c.opened);
+    h->ipc_conn.clear();
+    if (h->d_ipc_block) (void)hipFree(h->d_ipc_block);
+    if (h->d_ipc_local) (void)hipFree(h->d_ipc_local);
+    h->d_ipc_block = nullptr; h->d_ipc_local = nullptr; h->ipc_area_bytes = 0; h->ipc_epoch = h->ipc_pushed = 0;
+}
+
+}  // namespace cx
+
+extern "C" {
+
+int32_t cx_halo_ipc_alloc(cx_handle *h, void *handle64, void **local_base, int64_t *area_bytes) {
+    CX_REQUIRE(h, h && h->has_graph && h->halo_state, CX_ERR_STATE, "cx_halo_ipc_alloc: call cx_halo_configure_state first");
+    CX_REQUIRE(h, h->cfg.dim == 1, CX_ERR_UNSUPPORTED, "cx_halo_ipc_alloc: scalar messages (dim 1); dim > 1 partitions exchange through cx_halo_state_exchange");
+    CX_REQUIRE(h, handle64 && local_base && area_bytes, CX_ERR_INVALID_ARGUMENT, "cx_halo_ipc_alloc: null argument");
+    CX_REQUIRE(h, !h->peers.empty() && (int)h->peers.size() <= kMaxPeers, CX_ERR_STATE, "cx_halo_ipc_alloc: call cx_halo_peers first (1 to 8 neighbours)");
+    CX_HIP(h, hipSetDevice(h->cfg.device));
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    cx::ipc_destroy(h);
+    const int64_t area = (((int64_t)h->recv_slots.size() * 16 + 4095) / 4096 + 1) * 4096;
+    const size_t total = (size_t)(kFlagBytes + 2 * area);
+    // fine-grained: coherent between agents while kernels run (what a flag protocol needs); plain hipMalloc memory is only
+    // coherent at kernel boundaries
+    hipError_t e = hipExtMallocWithFlags(&h->d_ipc_block, total, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) return fail(h, e == hipErrorOutOfMemory ? CX_ERR_OUT_OF_MEMORY : CX_ERR_DEVICE,
+                                     std::string("cx_halo_ipc_alloc: hipExtMallocWithFlags(fine-grained): ") + hipGetErrorString(e));
+    CX_HIP(h, hipMemset(h->d_ipc_block, 0, total));
+    CX_HIP(h, hipMalloc(&h->d_ipc_local, 64));               // [0] workgroups done (push), [1] error word (unpack)
+    CX_HIP(h, hipMemset(h->d_ipc_local, 0, 64));
+    hipIpcMemHandle_t hd;
+    static_assert(sizeof(hd) == 64, "hipIpcMemHandle_t is 64 bytes");
+    CX_HIP(h, hipIpcGetMemHandle(&hd, h->d_ipc_block));
+    std::memcpy(handle64, &hd, 64);
+    h->ipc_area_bytes = area;
+    h->ipc_conn.assign(h->peers.size(), cx_handle::IpcConn{});
+    *local_base = h->d_ipc_block;
+    *area_bytes = area;
+    return CX_OK;
+}
+
+// Peer entry `peer_index` of this handle sends to the neighbour's block: `handle64` as the neighbour's cx_halo_ipc_alloc returned
+// it (another process), or `same_process_base` when the neighbour is a handle of THIS process (a block cannot be opened by the
+// process that exported it).  remote_entry = index of the neighbour's peer entry that receives from this rank (its flag and its
+// segment: remote_recv_off messages into the neighbour's receive area), remote_area_bytes = the neighbour's area size.
+int32_t cx_halo_ipc_connect(cx_handle *h, int32_t peer_index, const void *handle64, void *same_process_base, int32_t remote_entry,
+                            int64_t remote_recv_off, int64_t remote_area_bytes) {
+    CX_REQUIRE(h, h && h->d_ipc_block, CX_ERR_STATE, "cx_halo_ipc_connect: call cx_halo_ipc_alloc first");
+    CX_REQUIRE(h, peer_index >= 0 && peer_index < (int)h->ipc_conn.size(), CX_ERR_INVALID_ARGUMENT, "cx_halo_ipc_connect: no such peer entry");
+    CX_REQUIRE(h, (handle64 != nullptr) != (same_process_base != nullptr), CX_ERR_INVALID_ARGUMENT, "cx_halo_ipc_connect: exactly one of handle64 / same_process_base");
+    CX_REQUIRE(h, remote_entry >= 0 && remote_entry < kMaxPeers && remote_recv_off >= 0 && remote_area_bytes > 0 && remote_area_bytes % 4096 == 0 &&
+                  (remote_recv_off + h->peers[peer_index].send_count) * 16 <= remote_area_bytes,
+               CX_ERR_INVALID_ARGUMENT, "cx_halo_ipc_connect: segment outside the neighbour's receive area");
+    CX_HIP(h, hipSetDevice(h->cfg.device));
+    auto &c = h->ipc_conn[peer_index];
+    if (c.opened) { (void)hipIpcCloseMemHandle(c.opened); c.opened = nullptr; }
+    char *base = (char *)same_process_base;
+    if (handle64) {
+        hipIpcMemHandle_t hd;
+        std::memcpy(&hd, handle64, 64);
+        void *p = nullptr;
+        CX_HIP(h, hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess));
+        c.opened = p;
+        base = (char *)p;
+    }
+    c.flag = (unsigned long long *)(base + (int64_t)remote_entry * kFlagStride);
+    c.area[0] = (double2 *)(base + kFlagBytes) + remote_recv_off;
+    c.area[1] = (double2 *)(base + kFlagBytes + remote_area_bytes) + remote_recv_off;
+    c.connected = true;
+    return CX_OK;
+}
+
+// The two halves of an exchange.  cx_halo_ipc_push: store this rank's boundary state into the neighbours' receive areas of the next
+// epoch and raise their flags.  cx_halo_ipc_unpack: wait for the flags of the epoch last pushed and scatter the receive area into
+// the redundant rows.  cx_halo_ipc_exchange = both in ONE launch.  (Handles of ONE process whose streams may share a hardware queue call
+// every push before any unpack, so that no waiting unpack sits in front of the push it waits for.)
+static int32_t ipc_push(cx_handle *h, const char *who) {
+    CX_REQUIRE(h, h && h->has_graph && h->halo_state && h->d_ipc_block, CX_ERR_STATE, std::string(who) + ": call cx_halo_ipc_alloc first");
+    CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, std::string(who) + ": a cx_sweep_begin is still open");
+    CX_REQUIRE(h, h->ipc_pushed == h->ipc_epoch, CX_ERR_STATE, std::string(who) + ": the previous push has not been followed by its unpack");
+    PushArgs a{};
+    a.n_peers = (int)h->peers.size();
+    for (int p = 0; p < a.n_peers; p++)
+        CX_REQUIRE(h, h->ipc_conn[p].connected, CX_ERR_STATE, std::string(who) + ": a peer entry is not connected (cx_halo_ipc_connect)");
+    const unsigned long long epoch = (unsigned long long)(h->ipc_epoch + 1);
+    const int par = (int)(epoch & 1);
+    for (int p = 0; p < a.n_peers; p++) {
+        a.send_off[p] = h->peers[p].send_off; a.send_count[p] = h->peers[p].send_count;
+        a.remote_area[p] = h->ipc_conn[p].area[par];
+        a.remote_flag[p] = h->ipc_conn[p].flag;
+    }
+    const int64_t ns = (int64_t)h->send_slots.size();
+    // the push runs even with nothing to send: its last workgroup raises the flags the neighbours wait for
+    hipLaunchKernelGGL(k_ipc_push, dim3((unsigned)std::max<int64_t>((ns + kIpcBlock * kIpcItems - 1) / (kIpcBlock * kIpcItems), 1)), dim3(kIpcBlock), 0, h->stream, (const double2 *)h->d_f2v,
+                       (const int32_t *)h->d_send_slots, ns, a, epoch, (unsigned int *)h->d_ipc_local);
+    h->ipc_pushed = (int64_t)epoch;
+    CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
+static int32_t ipc_unpack(cx_handle *h, const char *who) {
+    CX_REQUIRE(h, h && h->has_graph && h->halo_state && h->d_ipc_block, CX_ERR_STATE, std::string(who) + ": call cx_halo_ipc_alloc first");
+    CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, std::string(who) + ": a cx_sweep_begin is still open");
+    CX_REQUIRE(h, h->ipc_pushed == h->ipc_epoch + 1, CX_ERR_STATE, std::string(who) + ": no push is waiting for its unpack (cx_halo_ipc_push)");
+    WaitArgs w{};
+    w.n_peers = (int)h->peers.size();
+    const unsigned long long epoch = (unsigned long long)h->ipc_pushed;
+    const int par = (int)(epoch & 1);
+    for (int p = 0; p < w.n_peers; p++) w.flag[p] = (const unsigned long long *)((char *)h->d_ipc_block + (int64_t)p * kFlagStride);
+    const int64_t nr = (int64_t)h->recv_slots.size();
+    const double2 *area = (const double2 *)((char *)h->d_ipc_block + kFlagBytes + (int64_t)par * h->ipc_area_bytes);
+    const unsigned long long limit = (unsigned long long)(h->ipc_timeout_s * 1e8);       // wall_clock64: 100 MHz
+    hipLaunchKernelGGL(k_ipc_unpack, dim3((unsigned)std::max<int64_t>((nr + kIpcBlock * kIpcItems - 1) / (kIpcBlock * kIpcItems), 1)), dim3(kIpcBlock), 0, h->stream, (double2 *)h->d_f2v,
+                       (const int32_t *)h->d_recv_slots, area, nr, w, epoch, limit, (int *)h->d_ipc_local + 1);
+    h->ipc_epoch = (int64_t)epoch;
+    h->sweeps_since_exchange = 0;
+    CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
+int32_t cx_halo_ipc_push(cx_handle *h) { return ipc_push(h, "cx_halo_ipc_push"); }
+int32_t cx_halo_ipc_unpack(cx_handle *h) { return ipc_unpack(h, "cx_halo_ipc_unpack"); }
+int32_t cx_halo_ipc_exchange(cx_handle *h) {
+    const char *who = "cx_halo_ipc_exchange";
+    CX_REQUIRE(h, h && h->has_graph && h->halo_state && h->d_ipc_block, CX_ERR_STATE, std::string(who) + ": call cx_halo_ipc_alloc first");
+    CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, std::string(who) + ": a cx_sweep_begin is still open");
+    CX_REQUIRE(h, h->ipc_pushed == h->ipc_epoch, CX_ERR_STATE, std::string(who) + ": a push is waiting for its unpack (cx_halo_ipc_unpack)");
+    PushArgs a{};
+    WaitArgs w{};
+    a.n_peers = w.n_peers = (int)h->peers.size();
+    for (int p = 0; p < a.n_peers; p++)
+        CX_REQUIRE(h, h->ipc_conn[p].connected, CX_ERR_STATE, std::string(who) + ": a peer entry is not connected (cx_halo_ipc_connect)");
+    const unsigned long long epoch = (unsigned long long)(h->ipc_epoch + 1);
+    const int par = (int)(epoch & 1);
+    for (int p = 0; p < a.n_peers; p++) {
+        a.send_off[p] = h->peers[p].send_off; a.send_count[p] = h->peers[p].send_count;
+        a.remote_area[p] = h->ipc_conn[p].area[par];
+        a.remote_flag[p] = h->ipc_conn[p].flag;
+        w.flag[p] = (const unsigned long long *)((char *)h->d_ipc_block + (int64_t)p * kFlagStride);
+    }
+    const int64_t ns = (int64_t)h->send_slots.size(), nr = (int64_t)h->recv_slots.size(), per = kIpcBlock * kIpcItems;
+    const unsigned int n_push = (unsigned)std::max<int64_t>((ns + per - 1) / per, 1), n_unpack = (unsigned)std::max<int64_t>((nr + per - 1) / per, 1);
+    const double2 *area = (const double2 *)((char *)h->d_ipc_block + kFlagBytes + (int64_t)par * h->ipc_area_bytes);
+    const unsigned long long limit = (unsigned long long)(h->ipc_timeout_s * 1e8);       // wall_clock64: 100 MHz
+    hipLaunchKernelGGL(k_ipc_exchange, dim3(n_push + n_unpack), dim3(kIpcBlock), 0, h->stream, (double2 *)h->d_f2v, (const int32_t *)h->d_send_slots, ns, a,
+                       n_push, (unsigned int *)h->d_ipc_local, (const int32_t *)h->d_recv_slots, area, nr, w, epoch, limit, (int *)h->d_ipc_local + 1);
+    h->ipc_epoch = h->ipc_pushed = (int64_t)epoch;
+    h->sweeps_since_exchange = 0;
+    CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
+// Waits for the stream and reports whether any unpack gave up waiting for a neighbour (then its redundant rows are stale and
+// every result since is void).
+int32_t cx_halo_ipc_status(cx_handle *h, int32_t *timed_out, int64_t *exchanges) {
+    CX_REQUIRE(h, h && h->d_ipc_block, CX_ERR_STATE, "cx_halo_ipc_status: call cx_halo_ipc_alloc first");
+    CX_REQUIRE(h, timed_out && exchanges, CX_ERR_INVALID_ARGUMENT, "cx_halo_ipc_status: null argument");
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    int32_t e[2] = {0, 0};
+    CX_HIP(h, hipMemcpy(e, h->d_ipc_local, 8, hipMemcpyDeviceToHost));
+    *timed_out = e[1];
+    *exchanges = h->ipc_epoch;
+    return CX_OK;
+}
+
+int32_t cx_halo_ipc_set_timeout(cx_handle *h, double seconds) {
+    CX_REQUIRE(h, h, CX_ERR_INVALID_ARGUMENT, "cx_halo_ipc_set_timeout: null handle");
+    CX_REQUIRE(h, seconds > 0 && seconds <= 600, CX_ERR_INVALID_ARGUMENT, "cx_halo_ipc_set_timeout: 0 < seconds <= 600");
+    h->ipc_timeout_s = seconds;
+    return CX_OK;
+}
+
+}  // extern "C"

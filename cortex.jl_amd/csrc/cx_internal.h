@@ -128,6 +128,13 @@ struct cx_handle {
     int comm_world = 0, comm_rank = -1;
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_packed = nullptr, ev_recv = nullptr, ev_swept = nullptr;
+    // deep-halo exchange through IPC-mapped receive areas and epoch flags (cx_api_ipc.hip)
+    struct IpcConn { void *opened = nullptr; unsigned long long *flag = nullptr; double2 *area[2] = {nullptr, nullptr}; bool connected = false; };
+    std::vector<IpcConn> ipc_conn;   // one per peer entry: where this rank pushes
+    void *d_ipc_block = nullptr;     // this rank's flags + two receive areas (fine-grained, exported)
+    void *d_ipc_local = nullptr;     // push completion counter, error word
+    int64_t ipc_area_bytes = 0, ipc_epoch = 0, ipc_pushed = 0;   // epochs unpacked / pushed
+    double ipc_timeout_s = 20.0;
     bool in_sweep = false;
     bool v2f_stale = false;          // fused schedule without materialisation: v2f must be recomputed before use
     int mv_max_deg = 0;              // dim 2..4: widest slice of the graph (0: not computed yet)
@@ -246,5 +253,6 @@ bool comm_init(cx_handle *h, int world, int rank, const void *id128, std::string
 void comm_destroy(cx_handle *h);
 bool comm_exchange(cx_handle *h, std::string &err, bool packed_on_comm_stream);
 bool comm_exchange_on(cx_handle *h, hipStream_t stream, std::string &err);
+void ipc_destroy(cx_handle *h);  // cx_api_ipc.hip
 
 }  // namespace cx

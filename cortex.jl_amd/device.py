@@ -243,6 +243,39 @@ class DeviceGraph:
         assert len(unique_id) == 128
         self._check(self.lib.cx_comm_init(self.h, world, rank, C.c_char_p(unique_id)))
 
+    # -- deep-halo exchange through IPC-mapped receive areas (cx_api_ipc.hip) -----------------------
+    def halo_ipc_alloc(self):
+        """-> (64-byte IPC handle, device address of the block, bytes of one receive area)"""
+        buf = C.create_string_buffer(64)
+        base, area = C.c_void_p(), C.c_int64()
+        self._check(self.lib.cx_halo_ipc_alloc(self.h, buf, C.byref(base), C.byref(area)))
+        return buf.raw, int(base.value), int(area.value)
+
+    def halo_ipc_connect(self, peer_index: int, remote_entry: int, remote_recv_off: int, remote_area_bytes: int, handle: bytes = None,
+                         same_process_base: int = None):
+        assert (handle is None) != (same_process_base is None)
+        self._check(self.lib.cx_halo_ipc_connect(self.h, int(peer_index), C.c_char_p(handle) if handle is not None else None,
+                                                 C.c_void_p(same_process_base) if same_process_base is not None else None,
+                                                 int(remote_entry), int(remote_recv_off), int(remote_area_bytes)))
+
+    def halo_ipc_exchange(self):
+        self._check(self.lib.cx_halo_ipc_exchange(self.h))
+
+    def halo_ipc_push(self):
+        self._check(self.lib.cx_halo_ipc_push(self.h))
+
+    def halo_ipc_unpack(self):
+        self._check(self.lib.cx_halo_ipc_unpack(self.h))
+
+    def halo_ipc_status(self):
+        """synchronises -> (timed_out, exchanges)"""
+        t, n = C.c_int32(), C.c_int64()
+        self._check(self.lib.cx_halo_ipc_status(self.h, C.byref(t), C.byref(n)))
+        return bool(t.value), int(n.value)
+
+    def halo_ipc_set_timeout(self, seconds: float):
+        self._check(self.lib.cx_halo_ipc_set_timeout(self.h, float(seconds)))
+
     def halo_peers(self, peers):
         """peers: iterable of (rank, send_offset, send_count, recv_offset, recv_count), in messages."""
         peers = list(peers)

@@ -13,6 +13,7 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import List, Tuple
 
+import os
 import numpy as np
 
 from . import synth
@@ -500,6 +501,106 @@ class DeepHaloRccl:
                 self.dev.sweep(run)
             self.k += run
             n -= run
+
+
+class DeepHaloIpc:
+    """Deep-halo partition with the exchange done by the library WITHOUT a collective: every rank pushes its boundary state
+    straight into its neighbours' IPC-mapped receive areas and raises an epoch flag there (cx_api_ipc.hip) — ONE launch per
+    exchange on the handle's stream.  Bit-identical to DeepHaloRccl.  `dist` is only used once, to carry the 64-byte memory
+    handles between the ranks (all_gather_object) — and by `audit`; a rank that is its own neighbour, and handles of the same
+    process (`connect=False`, then `connect({rank: info})`), connect by device address.  A rank whose allocation or connection
+    fails raises on EVERY rank after the handles have been gathered, so that all ranks can fall back together."""
+
+    def __init__(self, dev, part: Partition, dist=None, torch=None, device=None, connect=True):
+        self.dev, self.depth, self.k, self.part, self.fresh = dev, part.depth, 0, part, False
+        dev.halo_configure_state(part.send_var, part.send_fac, part.recv_var, part.recv_fac)
+        if part.layer_var is not None and part.depth and dev.dim == 1:
+            dev.halo_set_layers(part.layer_var, part.layer, part.depth)    # trimmed sweeps between exchanges
+        dev.halo_peers([(p.rank, p.send.start, p.send.stop - p.send.start, p.recv.start, p.recv.stop - p.recv.start)
+                        for p in part.peers])
+        self.send = self.recv = None
+        self.info, err = None, None
+        try:
+            self.handle, self.base, self.area_bytes = dev.halo_ipc_alloc()
+            # what a neighbour needs to push to me: my peer entries (index, sending rank, recv offset, count)
+            self.info = {"rank": part.rank, "handle": self.handle, "base": self.base, "area_bytes": self.area_bytes, "pid": os.getpid(),
+                         "entries": [(i, p.rank, p.recv.start, p.recv.stop - p.recv.start) for i, p in enumerate(part.peers)]}
+        except Exception as e:
+            if not (connect and part.world > 1):
+                raise
+            err = e
+        if connect:
+            if part.world > 1:
+                infos = [None] * part.world
+                dist.all_gather_object(infos, self.info)
+                bad = [r for r, x in enumerate(infos) if x is None]
+                if bad:
+                    raise RuntimeError(f"IPC halo: rank(s) {bad} could not allocate / export their receive area" + (f" ({err})" if err else ""))
+            else:
+                infos = {part.rank: self.info}
+            self.connect(infos)
+
+    def connect(self, infos):
+        """infos[rank] = the `info` of that rank's DeepHaloIpc.  The k-th peer entry of mine for rank q pairs with the k-th peer
+        entry of q for me (the order in which a grouped send/recv would match them)."""
+        part, seen = self.part, {}
+        for i, p in enumerate(part.peers):
+            k = seen.get(p.rank, 0)
+            seen[p.rank] = k + 1
+            theirs = infos[p.rank]
+            match = [e for e in theirs["entries"] if e[1] == part.rank]
+            if k >= len(match):
+                raise ValueError(f"rank {p.rank} has no peer entry {k} for rank {part.rank}")
+            entry, _, recv_off, recv_count = match[k]
+            if recv_count != p.send.stop - p.send.start:
+                raise ValueError(f"rank {part.rank} sends {p.send.stop - p.send.start} messages to rank {p.rank}, which expects {recv_count}")
+            same = theirs["pid"] == os.getpid()
+            self.dev.halo_ipc_connect(i, entry, recv_off, theirs["area_bytes"], handle=None if same else theirs["handle"],
+                                      same_process_base=theirs["base"] if same else None)
+
+    def sweep(self, n: int = 1):
+        while n > 0:
+            run = min(n, self.depth - self.k % self.depth)
+            if self.k % self.depth == 0:
+                if self.fresh:
+                    self.fresh = False              # `audit` has just made this exchange
+                else:
+                    self.dev.halo_ipc_exchange()
+            self.dev.sweep(run)
+            self.k += run
+            n -= run
+
+    def check(self):
+        """synchronises; raises when an unpack gave up waiting for a neighbour"""
+        timed_out, n = self.dev.halo_ipc_status()
+        if timed_out:
+            raise RuntimeError(f"rank {self.part.rank}: a neighbour did not arrive at one of {n} IPC halo exchanges (stale redundant rows)")
+        return n
+
+    def audit(self, dist, torch, device) -> bool:
+        """An exchange NOW (only between batches: the sweeps so far a multiple of the depth), then the comparison a caller-owned
+        transport gets from verify_last_exchange: what this rank's redundant rows hold == what their owners hold, the owners'
+        values carried a second time over torch.distributed.  Collective; False on any rank means False on all."""
+        from . import _lib as L
+        if self.k % self.depth != 0:
+            raise RuntimeError("DeepHaloIpc.audit: between batches only")
+        ok = True
+        try:
+            if not self.fresh:
+                self.dev.halo_ipc_exchange()
+            self.check()
+        except Exception:
+            ok = False
+        self.fresh = True
+        part = self.part
+        send = torch.from_numpy(self.dev.get_messages(part.send_var, part.send_fac, L.TO_VARIABLE, L.FORM_NATURAL)).to(device)
+        recv = torch.from_numpy(self.dev.get_messages(part.recv_var, part.recv_fac, L.TO_VARIABLE, L.FORM_NATURAL)).to(device)
+        same = verify_last_exchange(part, send, recv, dist, torch)
+        if dist is not None and part.world > 1:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item() == 1)
+        return bool(same and ok)
 
 
 class DeviceStateSweeper:

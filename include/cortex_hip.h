@@ -310,6 +310,31 @@ int32_t cx_halo_state_exchange(cx_handle *h);
  *                             unpack.  Bit-identical to cx_halo_state_exchange + cx_sweep(n_sweeps), and falls back to exactly that
  *                             when the handle cannot split a sweep (no layers, dim > 1, another schedule). */
 int32_t cx_halo_exchange_sweep(cx_handle *h, int32_t n_sweeps);
+/* The same exchange WITHOUT a collective library (dim 1): every rank pushes its boundary state straight into a receive area of
+ * the neighbour — device memory the neighbour exported with hipIpcGetMemHandle — and raises an epoch flag there; the neighbour's
+ * unpack kernel waits for the flag.  Two launches on the handle's stream per exchange (push; wait + unpack) instead of pack,
+ * RCCL kernel, unpack.  Results are bit-identical to cx_halo_state_exchange.
+ *   cx_halo_ipc_alloc     : after cx_halo_configure_state + cx_halo_peers.  Allocates this rank's block (flags + two receive areas)
+ *                           and returns its 64-byte hipIpcMemHandle_t, its device address (for a neighbour in the SAME process,
+ *                           which cannot open the handle) and the size of one receive area.  The caller carries the three to the
+ *                           neighbours (torch.distributed.all_gather_object, MPI, a file).
+ *   cx_halo_ipc_connect   : peer entry peer_index (order of cx_halo_peers) sends to the neighbour's block: handle64 XOR
+ *                           same_process_base; remote_entry = the neighbour's peer entry that receives from this rank,
+ *                           remote_recv_off = that entry's recv_offset (messages), remote_area_bytes = the neighbour's area size.
+ *   cx_halo_ipc_push      : store the boundary state into the neighbours' receive areas of the next epoch, raise their flags
+ *   cx_halo_ipc_unpack    : wait for this rank's flags of the epoch last pushed, scatter the receive area into the redundant rows
+ *   cx_halo_ipc_exchange  : push, then unpack; asynchronous like cx_sweep.  Every neighbour has to call it the same number of
+ *                           times.  A neighbour that does not arrive within the timeout (default 20 s) is NOT waited for for
+ *                           ever: the unpack gives up, the grid drains and cx_halo_ipc_status reports it.
+ *   cx_halo_ipc_status    : synchronises; *timed_out != 0 when an unpack gave up (results since are void), *exchanges = count */
+int32_t cx_halo_ipc_alloc(cx_handle *h, void *handle64, void **local_base, int64_t *area_bytes);
+int32_t cx_halo_ipc_connect(cx_handle *h, int32_t peer_index, const void *handle64, void *same_process_base, int32_t remote_entry,
+                            int64_t remote_recv_off, int64_t remote_area_bytes);
+int32_t cx_halo_ipc_push(cx_handle *h);
+int32_t cx_halo_ipc_unpack(cx_handle *h);
+int32_t cx_halo_ipc_exchange(cx_handle *h);
+int32_t cx_halo_ipc_status(cx_handle *h, int32_t *timed_out, int64_t *exchanges);
+int32_t cx_halo_ipc_set_timeout(cx_handle *h, double seconds);
 
 /* ---- partitioned chain scan (CX_SCHED_CHAIN_SCAN; SURVEY.md §8e: "contiguous time blocks + one composed map per block") ----
  * A rank holds a time block of a chain (its own variables, the cut transition factors, the remote end of each as a degree-1

@@ -140,6 +140,7 @@ class Handle {
     void comm_init(int32_t world, int32_t rank, const void *id128) { check(cx_comm_init(h_, world, rank, id128)); }
     void halo_state_exchange() { check(cx_halo_state_exchange(h_)); }
     void halo_exchange_sweep(int n_sweeps) { check(cx_halo_exchange_sweep(h_, n_sweeps)); }
+    void halo_ipc_exchange() { check(cx_halo_ipc_exchange(h_)); }
     void sweep_exchange(int32_t n = 1) { check(cx_sweep_exchange(h_, n)); }
 
   private:

@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--exchange", action="store_true")
     ap.add_argument("--overlap-exchange", action="store_true", help="with --exchange: cx_halo_exchange_sweep (pack, send/recv, unpack on a second stream beside "
                                                                     "the owned part of the batch's first sweep) instead of serially on the compute stream")
+    ap.add_argument("--ipc", action="store_true", help="with --exchange: push into the neighbour's IPC receive area + epoch flag (cx_halo_ipc_exchange: "
+                                                       "two launches) instead of pack, RCCL send/recv, unpack")
     ap.add_argument("--batch", type=int, default=0, help="sweeps per cx_sweep call (default: depth)")
     ap.add_argument("--no-trim", action="store_true", help="run every redundant row in every sweep (no cx_halo_set_layers)")
     a = ap.parse_args()
@@ -72,7 +74,10 @@ def main():
         st = dev.stats()
         ex = None
         if a.exchange:
-            ex = partition.DeepHaloRccl(dev, self_exchange(part), None, torch, torch.device("cuda", 0), overlap=a.overlap_exchange)
+            if a.ipc:
+                ex = partition.DeepHaloIpc(dev, self_exchange(part))
+            else:
+                ex = partition.DeepHaloRccl(dev, self_exchange(part), None, torch, torch.device("cuda", 0), overlap=a.overlap_exchange)
         elif not a.no_trim:     # no exchange: the trimming schedule restarts every `depth` sweeps as if one had happened
             dev.halo_configure_state([], [], [], [])
             dev.halo_set_layers(part.layer_var, part.layer, depth)
@@ -104,10 +109,12 @@ def main():
         rows_owned = len(part.owned_x) // N
         rows_held = st["n_variables"] // N
         print(json.dumps({"strip": f"rank {a.rank} of {a.world}, {rows_owned} owned rows + 2 x {depth} redundant ({rows_held} rows held incl. stand-ins)",
-                          "depth": depth, "exchange": ("overlapped with the owned part of the first sweep" if a.overlap_exchange else "serial on the compute stream") if a.exchange else False, "us_per_sweep_wall": best[0], "us_per_sweep_device": best[1],
+                          "depth": depth, "exchange": ("IPC push + flag, on the compute stream" if a.ipc else "overlapped with the owned part of the first sweep" if a.overlap_exchange else "RCCL, serial on the compute stream") if a.exchange else False, "us_per_sweep_wall": best[0], "us_per_sweep_device": best[1],
                           "whole_grid_us_per_sweep": whole_us, "ideal_us": whole_us / a.world,
                           "ratio_to_ideal": best[0] / (whole_us / a.world), "speedup_if_all_ranks_like_this": whole_us / best[0],
                           "slices": st["n_slices"], "halo_messages": int(len(part.recv_var))}), flush=True)
+        if ex is not None and a.ipc:
+            ex.check()
         dev.close()
 
 
