@@ -248,12 +248,22 @@ int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
         if (rc != CX_OK) return rc;
         rc = ensure_v2f(h);
         if (rc != CX_OK) return rc;
+        if (n <= cx::kSmallBatch) {
+            // a per-signal process! or a wavefront of a few signals: the records ride in the kernel arguments and the call returns
+            // as soon as the launch is queued.  What the host does next — setting readiness bits (signal.jl:232-253) — does not read
+            // the device; whatever does (cx_get_*, cx_residual, ...) waits for the stream first.
+            cx::SmallBatch sb{};
+            std::memcpy(sb.r, buf.data(), (size_t)(5 * n) * 4);
+            cx::launch_batch_small(h, sb, (int)n);
+            CX_HIP(h, hipGetLastError());
+            return CX_OK;
+        }
         rc = ensure_stage(h, 5 * n * 4);
         if (rc != CX_OK) return rc;
         CX_HIP(h, hipMemcpyAsync(h->d_stage, buf.data(), 5 * n * 4, hipMemcpyHostToDevice, h->stream));
         cx::launch_batch(h, (const int32_t *)h->d_stage, n);
         CX_HIP(h, hipGetLastError());
-        CX_HIP(h, hipStreamSynchronize(h->stream));  // synchronous: the host sets readiness bits next (signal.jl:232-253)
+        CX_HIP(h, hipStreamSynchronize(h->stream));  // the staging buffer is the handle's: the next call may overwrite it
         return CX_OK;
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_update_batch: host allocation failed"); }
 }

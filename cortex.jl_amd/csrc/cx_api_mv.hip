@@ -408,6 +408,13 @@ int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
         }
         rec[5 * i] = it.kind; rec[5 * i + 1] = (int32_t)idx; rec[5 * i + 2] = (int32_t)var; rec[5 * i + 3] = (int32_t)tab;
     }
+    if (!d64 && n <= cx::kSmallBatch) {          // records in the kernel arguments, no wait (cx_api_msg.hip: cx_update_batch)
+        cx::SmallBatch sb{};
+        std::memcpy(sb.r, rec.data(), (size_t)(5 * n) * 4);
+        cx::mv_launch_batch_small(h, sb, (int)n);
+        CX_HIP(h, hipGetLastError());
+        return CX_OK;
+    }
     if (!d64) {
         if ((rc = ensure_stage(h, 5 * n * 4)) != CX_OK) return rc;
         CX_HIP(h, hipMemcpyAsync(h->d_stage, rec.data(), 5 * n * 4, hipMemcpyHostToDevice, h->stream));

@@ -194,7 +194,10 @@ void launch_factor_to_var(cx_handle *h, const double2 *v2f, double2 *f2v);
 void launch_push_slots(cx_handle *h, const int32_t *d_slots, int64_t n, double2 *f2v_out, int kernel_id);
 void launch_halo_export(cx_handle *h, const double2 *f2v, hipStream_t stream);
 void launch_halo_import(cx_handle *h, double2 *f2v_out, bool push);
-void launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n);   // 5 int32 per item: kind, index, var, lo, hi
+void launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n);
+constexpr int kSmallBatch = 48;                        // items whose records (5 int32 each) ride in the kernel arguments
+struct SmallBatch { int32_t r[5 * kSmallBatch]; };
+void launch_batch_small(cx_handle *h, const SmallBatch &recs, int n);   // 5 int32 per item: kind, index, var, lo, hi
 void launch_scatter(cx_handle *h, double2 *dst, const int32_t *d_idx, const double2 *d_val, int64_t n);
 void launch_gather(cx_handle *h, const double2 *src, const int32_t *d_idx, double2 *d_val, int64_t n);
 void launch_seed(cx_handle *h, double2 *buf, int64_t n, double2 value, const int32_t *partner);
@@ -212,6 +215,7 @@ void mv_launch_v2f(cx_handle *h, const int32_t *d_slots, const int32_t *d_vars, 
 void mv_launch_scatter(cx_handle *h, double *dst, int64_t stride, int nc, int ncs, const int32_t *d_idx, const double *d_val, int64_t n);
 void mv_launch_gather(cx_handle *h, const double *src, int64_t stride, int nc, int ncs, const int32_t *d_idx, double *d_val, int64_t n);
 void mv_launch_seed(cx_handle *h, double *buf, double eta, double lam);
+void mv_launch_batch_small(cx_handle *h, const SmallBatch &recs, int n);
 void mv_launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n);   // cx_mvbatch.hip: 5 int32 per item (kind, index, variable, rule table, 0)
 void mv_launch_residual(cx_handle *h, const double *cur, const double *prev, int64_t n, double *d_out);
 bool spd_inverse(int d, const double *S, double *out);

@@ -333,15 +333,12 @@ __global__ __launch_bounds__(kBlock) void k_halo_import(const int32_t *__restric
 //                        order is ascending variable id).  Value: the 2-d Gaussian proportional to factor x the two
 //                        variable→factor messages, as mean[2] + covariance[4].
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_batch(int64_t n, const int32_t *__restrict__ rec, const int32_t *__restrict__ vbase,
-                                                  const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
-                                                  const int32_t *__restrict__ partner, const double *__restrict__ q,
-                                                  const double *__restrict__ pa, const double *__restrict__ pb,
-                                                  double2 *__restrict__ f2v, double2 *__restrict__ v2f, double2 *__restrict__ marg, int nat_marg,
-                                                  double2 *__restrict__ prod, double *__restrict__ joint) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const int k = rec[5 * i], idx = rec[5 * i + 1], v = rec[5 * i + 2], lo = rec[5 * i + 3], hi = rec[5 * i + 4];
+__device__ __forceinline__ void batch_item(int k, int idx, int v, int lo, int hi, const int32_t *__restrict__ vbase,
+                                           const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
+                                           const int32_t *__restrict__ partner, const double *__restrict__ q,
+                                           const double *__restrict__ pa, const double *__restrict__ pb,
+                                           double2 *__restrict__ f2v, double2 *__restrict__ v2f, double2 *__restrict__ marg, int nat_marg,
+                                           double2 *__restrict__ prod, double *__restrict__ joint) {
     if (k == CX_ITEM_MESSAGE_TO_FACTOR) {
         m2f_one(idx, v, vbase, vdeg, vinfo, f2v, v2f);
     } else if (k == CX_ITEM_MESSAGE_TO_VARIABLE) {
@@ -391,6 +388,36 @@ __global__ __launch_bounds__(kBlock) void k_batch(int64_t n, const int32_t *__re
         if (hi) { o[0] = mo; o[1] = mi; o[2] = coo; o[3] = cio; o[4] = cio; o[5] = cii; }
         else    { o[0] = mi; o[1] = mo; o[2] = cii; o[3] = cio; o[4] = cio; o[5] = coo; }
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_batch(int64_t n, const int32_t *__restrict__ rec, const int32_t *__restrict__ vbase,
+                                                  const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
+                                                  const int32_t *__restrict__ partner, const double *__restrict__ q,
+                                                  const double *__restrict__ pa, const double *__restrict__ pb,
+                                                  double2 *__restrict__ f2v, double2 *__restrict__ v2f, double2 *__restrict__ marg, int nat_marg,
+                                                  double2 *__restrict__ prod, double *__restrict__ joint) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    batch_item<MODE>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg,
+                     nat_marg, prod, joint);
+}
+
+// A batch of at most kSmallBatch items travels IN the kernel arguments: no staging copy, nothing for the host to wait for before
+// it reuses its buffer — the launch is all a per-signal `process!` or a wavefront of a few signals costs.  The records are the
+// first parameter, i.e. the start of the kernarg segment, which every thread reads like any other constant memory.
+template <int MODE>
+__global__ __launch_bounds__(64) void k_batch_small(SmallBatch recs, int n, const int32_t *__restrict__ vbase, const int32_t *__restrict__ vdeg,
+                                                    const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
+                                                    const double *__restrict__ q, const double *__restrict__ pa, const double *__restrict__ pb,
+                                                    double2 *__restrict__ f2v, double2 *__restrict__ v2f, double2 *__restrict__ marg, int nat_marg,
+                                                    double2 *__restrict__ prod, double *__restrict__ joint) {
+    const int i = threadIdx.x;
+    if (i >= n) return;
+    const __attribute__((address_space(4))) int32_t *rec = (const __attribute__((address_space(4))) int32_t *)__builtin_amdgcn_kernarg_segment_ptr();
+    batch_item<MODE>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg,
+                     nat_marg, prod, joint);
+    (void)recs;
 }
 
 // ------------------------------------------------------------------------------------------------ utilities
@@ -587,6 +614,19 @@ void launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n) {
     prof_begin(h, CX_KERNEL_BATCH);
     const int mode = rule_mode(h), nat = h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0;
 #define CX_B(M, PA, PB) hipLaunchKernelGGL(k_batch<M>, dim3(nb), dim3(kBlock), 0, h->stream, n, d_rec, h->d_vbase, h->d_var_deg, h->d_vinfo, \
+                                           h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint)
+    if (mode == kRuleLinear) CX_B(kRuleLinear, h->d_a, h->d_b);
+    else if (mode == kRuleBernoulli) CX_B(kRuleBernoulli, (const double *)nullptr, (const double *)nullptr);
+    else CX_B(kRuleAdditive, (const double *)nullptr, (const double *)nullptr);
+#undef CX_B
+    prof_end(h);
+}
+
+void launch_batch_small(cx_handle *h, const SmallBatch &recs, int n) {
+    if (n == 0) return;
+    prof_begin(h, CX_KERNEL_BATCH);
+    const int mode = rule_mode(h), nat = h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0;
+#define CX_B(M, PA, PB) hipLaunchKernelGGL(k_batch_small<M>, dim3(1), dim3(64), 0, h->stream, recs, n, h->d_vbase, h->d_var_deg, h->d_vinfo, \
                                            h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint)
     if (mode == kRuleLinear) CX_B(kRuleLinear, h->d_a, h->d_b);
     else if (mode == kRuleBernoulli) CX_B(kRuleBernoulli, (const double *)nullptr, (const double *)nullptr);

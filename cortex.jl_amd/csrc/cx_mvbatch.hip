@@ -18,13 +18,9 @@ namespace cx {
 
 // rec: 5 int32 per item — kind, index (slot of the signal's edge | local variable), local variable, rule table of the sending slot, 0
 template <int D>
-__global__ __launch_bounds__(kBlock) void k_batch_mv(int64_t n, const int32_t *__restrict__ rec, int64_t nslots, int nv, const int32_t *__restrict__ vbase,
-                                                     const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
-                                                     const double *__restrict__ ptab, double *__restrict__ f2v, double *__restrict__ v2f,
-                                                     double *__restrict__ marg) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const int kind = rec[5 * i], idx = rec[5 * i + 1], v = rec[5 * i + 2], tab = rec[5 * i + 3];
+__device__ __forceinline__ void batch_item_mv(int kind, int idx, int v, int tab, const int32_t *__restrict__ vbase, const uint8_t *__restrict__ vinfo,
+                                              const int32_t *__restrict__ partner, const double *__restrict__ ptab, double *__restrict__ f2v,
+                                              double *__restrict__ v2f, double *__restrict__ marg) {
     const int info = vinfo[v], deg = info & kDegMask, b = vbase[v];
     if (kind == CX_ITEM_MESSAGE_TO_FACTOR) {
         // variables of degree 1, observed variables and stand-ins have no dependencies: their message is what the caller stored
@@ -48,11 +44,43 @@ __global__ __launch_bounds__(kBlock) void k_batch_mv(int64_t n, const int32_t *_
     }
 }
 
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_batch_mv(int64_t n, const int32_t *__restrict__ rec, int64_t nslots, int nv, const int32_t *__restrict__ vbase,
+                                                     const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
+                                                     const double *__restrict__ ptab, double *__restrict__ f2v, double *__restrict__ v2f,
+                                                     double *__restrict__ marg) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    batch_item_mv<D>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], vbase, vinfo, partner, ptab, f2v, v2f, marg);
+}
+
+// at most kSmallBatch items: the records are the first kernel argument (cx_kernels.hip: k_batch_small)
+template <int D>
+__global__ __launch_bounds__(64) void k_batch_mv_small(SmallBatch recs, int n, const int32_t *__restrict__ vbase, const uint8_t *__restrict__ vinfo,
+                                                       const int32_t *__restrict__ partner, const double *__restrict__ ptab, double *__restrict__ f2v,
+                                                       double *__restrict__ v2f, double *__restrict__ marg) {
+    const int i = threadIdx.x;
+    if (i >= n) return;
+    const __attribute__((address_space(4))) int32_t *rec = (const __attribute__((address_space(4))) int32_t *)__builtin_amdgcn_kernarg_segment_ptr();
+    batch_item_mv<D>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], vbase, vinfo, partner, ptab, f2v, v2f, marg);
+    (void)recs;
+}
+
 void mv_launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n) {
     if (n == 0) return;
     const dim3 g((unsigned)((n + kBlock - 1) / kBlock)), b(kBlock);
 #define CX_MVB(DD) hipLaunchKernelGGL((k_batch_mv<DD>), g, b, 0, h->stream, n, d_rec, h->nslots, (int)h->nv, h->d_vbase, h->d_vinfo, h->d_partner, \
                                       h->d_ptab, h->d_mv_f2v, h->d_mv_v2f, h->d_mv_marg)
+    if (h->cfg.dim == 2) CX_MVB(2);
+    else if (h->cfg.dim == 3) CX_MVB(3);
+    else CX_MVB(4);
+#undef CX_MVB
+}
+
+void mv_launch_batch_small(cx_handle *h, const SmallBatch &recs, int n) {
+    if (n == 0) return;
+#define CX_MVB(DD) hipLaunchKernelGGL((k_batch_mv_small<DD>), dim3(1), dim3(64), 0, h->stream, recs, n, h->d_vbase, h->d_vinfo, h->d_partner, h->d_ptab, \
+                                      h->d_mv_f2v, h->d_mv_v2f, h->d_mv_marg)
     if (h->cfg.dim == 2) CX_MVB(2);
     else if (h->cfg.dim == 3) CX_MVB(3);
     else CX_MVB(4);

@@ -28,6 +28,7 @@ class DeviceGraph:
     def __init__(self, device: int = 0, dim: int = 1, schedule: int = L.SCHED_FUSED, marginals_in_sweep: bool = True,
                  materialize_messages_to_factor: bool = False, family: int = L.FAMILY_GAUSSIAN, sweeps_per_launch: int = 0):
         self.lib = L.load()
+        self._batch_raw = None
         cfg = L.Config(C.sizeof(L.Config), device, dim, schedule, int(marginals_in_sweep),
                        int(materialize_messages_to_factor), int(family), int(sweeps_per_launch))
         h = C.c_void_p()
@@ -129,6 +130,16 @@ class DeviceGraph:
             items[i].variable_id = int(variable_ids[i])
             items[i].factor_id = int(factor_ids[i])
         self._check(self.lib.cx_update_batch(self.h, items, n))
+
+    def update_batch_packed(self, records: bytes, n: int):
+        """the same call with the items already packed (`struct.pack("<iiqq", kind, 0, variable_id, factor_id)` each, concatenated):
+        a scheduler that launches thousands of small batches packs every signal's record once"""
+        if self._batch_raw is None:
+            proto = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_char_p, C.c_int64)
+            self._batch_raw = proto(("cx_update_batch", self.lib))
+        rc = self._batch_raw(self.h, records, n)
+        if rc != L.OK:
+            self._check(rc)
 
     def get_products(self, variable_ids, range_lo, range_hi, form: int = L.FORM_MOMENT):
         """stored ProductOfMessages(variable, lo:hi) values, [n, 2]"""

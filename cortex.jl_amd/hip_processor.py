@@ -16,6 +16,7 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Any, Callable, List, Optional, Tuple
 
+import struct
 import numpy as np
 
 from . import _lib as L
@@ -212,6 +213,8 @@ class HipProcessor(AbstractInferenceRequestProcessor):
                                family=L.FAMILY_GAUSSIAN if family == "gaussian" else L.FAMILY_NATURAL2)
         self.engine: Optional[InferenceEngine] = None
         self.launches = 0
+        self._records: dict = {}
+        self._record_owners: list = []
         self.execution_log: List[Any] = []   # variants in execution order (schedule-parity checks)
 
     # ---- build hook: flatten the bipartite graph through the reference's 7 accessors -------------------------
@@ -311,8 +314,19 @@ class HipProcessor(AbstractInferenceRequestProcessor):
         raise NotImplementedError(f"The HIP processor has no rule for {type(variant).__name__}")
 
     def _launch(self, variants):
-        items = [self._item(v) for v in variants]
-        self.dev.update_batch([i[0] for i in items], [i[1] for i in items], [i[2] for i in items])
+        # every signal's record (cx_item: kind, 0, variable_id, factor_id) is packed once, at its first launch: a chain of T states is
+        # 2T wavefronts of three signals, and building ctypes items per launch cost as much as the launch itself
+        recs = self._records
+        try:
+            buf = b"".join([recs[id(v)] for v in variants])
+        except KeyError:
+            for v in variants:
+                if id(v) not in recs:
+                    k, var, fac = self._item(v)
+                    recs[id(v)] = struct.pack("<iiqq", int(k), 0, int(var), int(fac))
+                    self._record_owners.append(v)            # keeps id(v) unique for the processor's lifetime
+            buf = b"".join([recs[id(v)] for v in variants])
+        self.dev.update_batch_packed(buf, len(variants))
         self.launches += 1
         self.execution_log.extend(variants)
 
