@@ -67,6 +67,7 @@ SIGNATURES = {
     "cx_seed_messages": (_i32, [_vp, _i32, _dbl, _dbl]),
     "cx_get_marginals": (_i32, [_vp, _i64, _pi64, _pd]),
     "cx_update_batch": (_i32, [_vp, C.POINTER(Item), _i64]),
+    "cx_update_batch_async": (_i32, [_vp, C.POINTER(Item), _i64]),
     "cx_get_products": (_i32, [_vp, _i64, _pi64, _pi32, _pi32, _i32, _pd]),
     "cx_get_joint_marginals": (_i32, [_vp, _i64, _pi64, _pd]),
     "cx_sweep": (_i32, [_vp, _i32]),

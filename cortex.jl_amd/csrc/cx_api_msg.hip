@@ -197,7 +197,7 @@ static int32_t joint_slots(cx_handle *h, int64_t factor_id, int32_t *s_out, int3
     return CX_OK;
 }
 
-int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
+static int32_t update_batch(cx_handle *h, const cx_item *items, int64_t n) {
     if (h) { h->chain_side_dirty = true; h->offchain_marg_dirty = true; }
     CX_NOT_VMP(h, "cx_update_batch");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_update_batch: no graph");
@@ -266,6 +266,16 @@ int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
         CX_HIP(h, hipStreamSynchronize(h->stream));  // the staging buffer is the handle's: the next call may overwrite it
         return CX_OK;
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_update_batch: host allocation failed"); }
+}
+
+// cx_update_batch: complete at return.  cx_update_batch_async: a batch of up to kSmallBatch items (dim 1 - 4) returns when its launch
+// is queued — the form a scheduler uses between two set_value!s; larger batches and dim 64 are complete at return either way.
+int32_t cx_update_batch_async(cx_handle *h, const cx_item *items, int64_t n) { return update_batch(h, items, n); }
+int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
+    const int32_t rc = update_batch(h, items, n);
+    if (rc != CX_OK || n == 0) return rc;
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    return CX_OK;
 }
 
 // stored ProductOfMessages values (natural form for CX_FORM_NATURAL, (mean, variance) for CX_FORM_MOMENT); a node that was

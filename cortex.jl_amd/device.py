@@ -132,11 +132,11 @@ class DeviceGraph:
         self._check(self.lib.cx_update_batch(self.h, items, n))
 
     def update_batch_packed(self, records: bytes, n: int):
-        """the same call with the items already packed (`struct.pack("<iiqq", kind, 0, variable_id, factor_id)` each, concatenated):
+        """cx_update_batch_async (small batches return when their launch is queued) with the items already packed (`struct.pack("<iiqq", kind, 0, variable_id, factor_id)` each, concatenated):
         a scheduler that launches thousands of small batches packs every signal's record once"""
         if self._batch_raw is None:
             proto = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_char_p, C.c_int64)
-            self._batch_raw = proto(("cx_update_batch", self.lib))
+            self._batch_raw = proto(("cx_update_batch_async", self.lib))
         rc = self._batch_raw(self.h, records, n)
         if rc != L.OK:
             self._check(rc)

@@ -232,11 +232,13 @@ int32_t cx_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, d
  * dim 2, 3, 4, 64: CX_ITEM_MESSAGE_TO_FACTOR, CX_ITEM_MESSAGE_TO_VARIABLE, CX_ITEM_INDIVIDUAL_MARGINAL (for dim 64 a marginal is
  * computed from the stored messages when cx_get_marginals reads it: the item only checks its variable).  A result with an undefined
  * dependency is not stored (the signal was not pending, src/signal.jl:668-730).
- * Completion: batches of up to 48 items (dim 1 - 4) carry their records in the kernel arguments and return as soon as the launch is
- * queued, like cx_sweep — what a scheduler does next (setting readiness bits, signal.jl:232-253) does not read the device, and
- * every cx_get_* / cx_residual / cx_sync waits for the stream; larger batches and dim 64 stage their records through a buffer of
- * the handle and have completed at return. */
+ * cx_update_batch is complete at return.  cx_update_batch_async is the same call without the wait for batches of up to 48 items
+ * (dim 1 - 4): their records travel in the kernel arguments and the call returns when the launch is queued, like cx_sweep — what
+ * a scheduler does next (set_value!, readiness bits: signal.jl:232-253) does not read the device, and every cx_get_* /
+ * cx_residual / cx_sync waits for the stream.  Larger batches and dim 64 stage their records through a buffer of the handle and
+ * are complete at return in both forms. */
 int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n);
+int32_t cx_update_batch_async(cx_handle *h, const cx_item *items, int64_t n);
 /* values of the intermediates cx_update_batch keeps on the device: ProductOfMessages nodes (2 doubles each, `form`
  * CX_FORM_MOMENT or CX_FORM_NATURAL) and JointMarginal nodes (6 doubles each: mean[2], covariance[4] row-major, variables in
  * ascending id order).  A node never computed reads as NaN (UndefValue()). */

@@ -98,6 +98,7 @@ class Handle {
 
     // compute
     void update_batch(const std::vector<cx_item> &items) { check(cx_update_batch(h_, items.data(), (int64_t)items.size())); }
+    void update_batch_async(const std::vector<cx_item> &items) { check(cx_update_batch_async(h_, items.data(), (int64_t)items.size())); }
     void sweep(int32_t n = 1) { check(cx_sweep(h_, n)); }
     double residual() { double r = 0; check(cx_residual(h_, &r)); return r; }
     std::pair<int32_t, double> sweep_until(double tol, int32_t max_sweeps, int32_t check_every = 10) {

@@ -84,7 +84,7 @@ end
 
 function flush!(p::HipProcessor)
     isempty(p.queue) && return
-    check(p.handle, ccall((:cx_update_batch, lib), Int32, (Ptr{Cvoid}, Ptr{CxItem}, Int64), p.handle, p.queue, length(p.queue)))
+    check(p.handle, ccall((:cx_update_batch_async, lib), Int32, (Ptr{Cvoid}, Ptr{CxItem}, Int64), p.handle, p.queue, length(p.queue)))
     for s in p.signals
         Cortex.set_value!(s, HipValue())     # any non-UndefValue(): readiness bits evolve as in the reference (signal.jl:232-253)
     end

@@ -392,3 +392,38 @@ def test_d_dimensional_batch_errors(hip_lib):
     tr0 = int(model.factor_ids[5])
     dev.update_batch([L.ITEM_MESSAGE_TO_FACTOR], [int(model.x_ids[1])], [tr0])
     assert np.all(np.isnan(dev.get_messages([model.x_ids[1]], [tr0], L.TO_FACTOR)))
+
+
+@pytest.mark.parametrize("dim", [1, 4])
+@pytest.mark.parametrize("n_items", [1, 48, 49, 130])
+def test_batches_in_the_kernel_arguments_and_staged_batches_agree(hip_lib, dim, n_items):
+    """Up to 48 items travel in the kernel arguments (cx_update_batch_async returns when the launch is queued), more go through the
+    handle's staging buffer: the same wavefront of variable→factor messages either way, equal to the leave-one-out sums of the stored messages."""
+    import struct
+
+    from cortex.jl_amd import _lib as L
+
+    T = 140
+    model = cx.synth.lgssm_chain(T, dim, seed=5) if dim > 1 else cx.synth.ssm_chain(T, seed=5)
+    sched = L.SCHED_FLOODING if dim == 1 else L.SCHED_FUSED
+    dev = cx.DeviceGraph(dim=dim, schedule=sched)
+    cx.synth.load_into_device(model, dev, seed_variance=100.0)     # every factor→variable message defined from the start
+    # the variable→factor messages of the first n_items (state, transition) pairs, as ONE batch
+    pairs = [(int(v), int(f)) for v, f in zip(model.edge_var, model.edge_fac) if int(v) in set(model.x_ids.tolist())][: n_items]
+    assert len(pairs) == n_items
+    recs = b"".join(struct.pack("<iiqq", L.ITEM_MESSAGE_TO_FACTOR, 0, v, f) for v, f in pairs)
+    dev.update_batch_packed(recs, n_items)        # asynchronous for n_items <= 48
+    got = dev.get_messages([p[0] for p in pairs], [p[1] for p in pairs], L.TO_FACTOR, L.FORM_NATURAL)      # waits for the stream
+    dev2 = cx.DeviceGraph(dim=dim, schedule=sched)
+    cx.synth.load_into_device(model, dev2, seed_variance=100.0)
+    dev2.update_batch([L.ITEM_MESSAGE_TO_FACTOR] * n_items, [p[0] for p in pairs], [p[1] for p in pairs])  # complete at return
+    want = dev2.get_messages([p[0] for p in pairs], [p[1] for p in pairs], L.TO_FACTOR, L.FORM_NATURAL)
+    assert np.array_equal(got, want, equal_nan=True)
+    # independent of both: the sum (natural form) of the OTHER factor→variable messages of the variable, from the stored messages
+    inc = dev.get_messages(model.edge_var, model.edge_fac, L.TO_VARIABLE, L.FORM_NATURAL)
+    by_var = {}
+    for (v, f), m in zip(zip(model.edge_var.tolist(), model.edge_fac.tolist()), inc):
+        by_var.setdefault(v, []).append((f, m))
+    want2 = np.array([sum(m for f2, m in by_var[v] if f2 != f) for v, f in pairs])
+    assert not np.isnan(got).any()
+    np.testing.assert_allclose(got, want2, rtol=1e-12, atol=1e-300)
