@@ -11,6 +11,8 @@ sys.path.insert(0, ROOT)
 
 def main():
     rows, cols, depth, sweeps, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    skew = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
+    import time
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -29,7 +31,21 @@ def main():
         ex = partition.DeepHaloIpc(dev, part, dist, torch, torch.device("cuda", 0))
         dev.halo_ipc_set_timeout(30.0)
         res["audit_start"] = ex.audit(dist, torch, torch.device("cpu"))       # gloo carries the second copy
-        ex.sweep(sweeps)
+        if skew > 0:
+            # ranks drift apart: every rank idles at batches of its own (rank r before batches r, r + world, ...), the device drained,
+            # so that a neighbour's push of the NEXT exchange arrives while this rank still holds the previous one unread or is
+            # about to read it — what the two parities of the receive area and the epoch flags are for
+            done, batch = 0, 0
+            while done < sweeps:
+                run = min(depth, sweeps - done)
+                if batch % world == rank:
+                    dev.sync()
+                    time.sleep(skew)
+                ex.sweep(run)
+                done += run
+                batch += 1
+        else:
+            ex.sweep(sweeps)
         res["exchanges"] = ex.check()
         whole = cx.DeviceGraph(schedule=L.SCHED_FUSED)
         cx.synth.load_into_device(cx.synth.gaussian_grid(rows, cols, seed=5), whole, seed_variance=1e6)

@@ -125,24 +125,26 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("rows,cols,depth,sweeps", [(64, 128, 4, 19), (354, 1415, 16, 35)])
-def test_two_processes_on_one_gpu(hip_lib, tmp_path, rows, cols, depth, sweeps):
-    """Two ranks, two processes, both on cuda:0: each opens the other's hipIpcMemHandle and pushes into it.  (354 x 1415 at depth 16
-    is the volume of two neighbouring ranks of bench.py --gpus 8.)"""
+@pytest.mark.parametrize("world,rows,cols,depth,sweeps,skew", [(2, 64, 128, 4, 19, 0.0), (2, 354, 1415, 16, 35, 0.0), (3, 96, 128, 4, 27, 0.15),
+                                                              (2, 64, 128, 2, 21, 0.1)])
+def test_processes_on_one_gpu(hip_lib, tmp_path, world, rows, cols, depth, sweeps, skew):
+    """Two or three ranks, one PROCESS each, all on cuda:0: each opens its neighbours' hipIpcMemHandles and pushes into them.
+    (354 x 1415 at depth 16 is the volume of two neighbouring ranks of bench.py --gpus 8; three ranks give the middle one two
+    neighbours.)  skew > 0: the ranks take turns idling between batches, so pushes arrive early and late relative to the reader."""
     out, port, procs = str(tmp_path / "res"), _free_port(), []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ipc_worker.py"), str(rows), str(cols), str(depth),
-                                       str(sweeps), out], env=env, cwd=ROOT))
+                                       str(sweeps), out, str(skew)], env=env, cwd=ROOT))
     try:
         for p in procs:
-            assert p.wait(timeout=240) == 0
+            assert p.wait(timeout=300) == 0
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    for r in range(2):
+    for r in range(world):
         res = json.load(open(f"{out}.{r}.json"))
         assert res.get("ok") and res.get("audit_start"), res
         assert res["exchanges"] == -(-sweeps // depth)
