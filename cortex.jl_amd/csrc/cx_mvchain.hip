@@ -655,8 +655,13 @@ __global__ __launch_bounds__(kBlock) void k_mvc_apply(MvcArgs A, int K, const do
 // the marginals' place (pair form by variable) through LDS.  A tile goes through in slabs of W = 512 / K threads (all K steps of each: <= 512 links, 57 KB
 // for d = 4): the reads are runs of W doubles per step and component, the writes runs of W K variables per component.
 __host__ __device__ inline int mvc_slab_threads(int K) { return K >= 512 ? 1 : (512 / K > kBlock ? kBlock : 512 / K); }
+// k_mvc_side_links takes half-size slabs: 30 KB of LDS per workgroup instead of 60 — five workgroups per compute unit in flight
+__host__ __device__ inline int mvc_side_slab_threads(int K) { return K >= 256 ? 1 : 256 / K; }
 __host__ __device__ inline int mvc_slab_pitch(int K) { return mvc_slab_threads(K) + (((K & (K - 1)) == 0 && K <= 32) ? 32 / K : 1); }   // conflict-free column reads for K | 32
 
+// One workgroup per SLAB of a tile: the W threads t0 .. t0 + W - 1 of the tile (W * K <= 512 links, contiguous in chain order) —
+// grid = tiles x slabs, so the pass has thousands of small workgroups in flight instead of one per tile looping over its slabs
+// behind barriers (244 workgroups on 256 compute units: 83 us for 348 MB).
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_mvc_marg_out(int nlinks, int K, int64_t il_stride, int nv, const int32_t *__restrict__ link_pos,
                                                          const int32_t *__restrict__ pos_var, const double *__restrict__ alpha,
@@ -664,38 +669,36 @@ __global__ __launch_bounds__(kBlock) void k_mvc_marg_out(int nlinks, int K, int6
     constexpr int NC = Msg<D>::NC;
     extern __shared__ double buf[];          // [NC][K][Wp]
     const int tid = threadIdx.x, W = mvc_slab_threads(K), Wp = mvc_slab_pitch(K);
-    const int64_t base = (int64_t)blockIdx.x * kBlock * K;      // first link of the tile == its first interleaved index
-    for (int t0 = 0; t0 < kBlock; t0 += W) {
-        const int wn = min(W, kBlock - t0), nitems = wn * K;
-        for (int i = tid; i < nitems; i += kBlock) {
-            const int k = i / wn, tt = i - k * wn;
-            if (base + (int64_t)(t0 + tt) * K + k >= nlinks) continue;
-            const int64_t il = base + (int64_t)k * kBlock + t0 + tt;
-            Msg<D> tot = slot_load<D, true>(alpha, (int)il);
-            msg_add<D>(tot, slot_load<D, true>(gamma, (int)il));
-            const Msg<D> mo = mv_to_moment<D>(tot);
+    const int slabs = (kBlock + W - 1) / W, tile = blockIdx.x / slabs, t0 = (blockIdx.x - tile * slabs) * W;
+    const int64_t base = (int64_t)tile * kBlock * K;      // first link of the tile == its first interleaved index
+    const int wn = min(W, kBlock - t0), nitems = wn * K;
+    for (int i = tid; i < nitems; i += kBlock) {
+        const int k = i / wn, tt = i - k * wn;
+        if (base + (int64_t)(t0 + tt) * K + k >= nlinks) continue;
+        const int64_t il = base + (int64_t)k * kBlock + t0 + tt;
+        Msg<D> tot = slot_load<D, true>(alpha, (int)il);
+        msg_add<D>(tot, slot_load<D, true>(gamma, (int)il));
+        const Msg<D> mo = mv_to_moment<D>(tot);
 #pragma unroll
-            for (int c = 0; c < D; c++) buf[(c * K + k) * Wp + tt] = mo.eta[c];
+        for (int c = 0; c < D; c++) buf[(c * K + k) * Wp + tt] = mo.eta[c];
 #pragma unroll
-            for (int c = 0; c < Msg<D>::NT; c++) buf[((D + c) * K + k) * Wp + tt] = mo.lam[c];
+        for (int c = 0; c < Msg<D>::NT; c++) buf[((D + c) * K + k) * Wp + tt] = mo.lam[c];
+    }
+    __syncthreads();
+    for (int e = tid; e < nitems; e += kBlock) {
+        const int64_t l = base + (int64_t)t0 * K + e;       // links in chain order: thread t0 + e / K, step e % K
+        if (l >= nlinks) break;
+        const int64_t v = pos_var[link_pos[l] + 1];
+        const int src = (e % K) * Wp + e / K;
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        d2v *dst = reinterpret_cast<d2v *>(marg + slot_offset<D>((int)v));
+#pragma unroll
+        for (int q = 0; q < MsgStore<D>::NCP; q++) {
+            d2v t2;
+            t2.x = buf[(2 * q) * K * Wp + src];
+            t2.y = (2 * q + 1 < NC) ? buf[(2 * q + 1) * K * Wp + src] : 0.0;
+            __builtin_nontemporal_store(t2, dst + q * kBlock);
         }
-        __syncthreads();
-        for (int e = tid; e < nitems; e += kBlock) {
-            const int64_t l = base + (int64_t)t0 * K + e;       // links in chain order: thread t0 + e / K, step e % K
-            if (l >= nlinks) break;
-            const int64_t v = pos_var[link_pos[l] + 1];
-            const int src = (e % K) * Wp + e / K;
-            typedef double d2v __attribute__((ext_vector_type(2)));
-            d2v *dst = reinterpret_cast<d2v *>(marg + slot_offset<D>((int)v));
-#pragma unroll
-            for (int q = 0; q < MsgStore<D>::NCP; q++) {
-                d2v t2;
-                t2.x = buf[(2 * q) * K * Wp + src];
-                t2.y = (2 * q + 1 < NC) ? buf[(2 * q + 1) * K * Wp + src] : 0.0;
-                __builtin_nontemporal_store(t2, dst + q * kBlock);
-            }
-        }
-        __syncthreads();
     }
 }
 
@@ -721,7 +724,7 @@ __global__ __launch_bounds__(kBlock) void k_mvc_side(int npos, int64_t nslots, i
 }
 
 // The side sums of each link's two end variables, in the interleaved order the scan kernels read.  The inverse of k_mvc_marg_out:
-// a tile goes through LDS in slabs of W = 512 / K threads (all K links of each), read from the by-position array as contiguous
+// a tile goes through LDS in slabs of W = 256 / K threads (all K links of each), read from the by-position array as contiguous
 // runs and written as contiguous runs of the interleaved arrays.  Links of one thread are consecutive and link_pos grows by one per
 // link (by two across a path boundary), so a slab's positions are one range; a slab with so many path boundaries that its range
 // overflows the buffer reads the overflow from memory directly.
@@ -730,7 +733,7 @@ __global__ __launch_bounds__(kBlock) void k_mvc_side_links(int nlinks, int npos,
                                                            const double *__restrict__ side, double *__restrict__ side_l, double *__restrict__ side_r) {
     constexpr int NC = Msg<D>::NC;
     extern __shared__ double buf[];          // [NC][span + span / 32 + 1]: position j of the slab at j + j / 32 (stride-K reads spread over the banks)
-    const int tid = threadIdx.x, W = mvc_slab_threads(K);
+    const int tid = threadIdx.x, W = mvc_side_slab_threads(K);
     const int span = W * K + 8, pitch = span + span / 32 + 1;
     const int nslab = (kBlock + W - 1) / W;                 // grid: one workgroup per (tile, slab) — a tile alone would leave the chip under one wave per SIMD
     const int64_t base = (int64_t)(blockIdx.x / nslab) * kBlock * K;
@@ -791,8 +794,8 @@ void mvc_launch_side(cx_handle *h, bool write_marg) {
     const int npos = (int)h->chain_npos, nlinks = (int)h->chain_nlinks, K = h->mvc_K;
     if (npos == 0) return;
     const dim3 g((npos + kBlock - 1) / kBlock), b(kBlock);
-    const dim3 gl((unsigned)(mvc_ntiles(nlinks, K) * ((kBlock + mvc_slab_threads(K) - 1) / mvc_slab_threads(K))));
-    const int span = mvc_slab_threads(K) * K + 8;
+    const dim3 gl((unsigned)(mvc_ntiles(nlinks, K) * ((kBlock + mvc_side_slab_threads(K) - 1) / mvc_side_slab_threads(K))));
+    const int span = mvc_side_slab_threads(K) * K + 8;
     const size_t lds = (size_t)h->nc * (span + span / 32 + 1) * sizeof(double);
 #define CX_MVC(DD)                                                                                                                           \
     do {                                                                                                                                     \
@@ -816,7 +819,7 @@ static void mvc_launch_t(cx_handle *h, const MvcArgs &A, int K, int flags, bool 
     }
     hipLaunchKernelGGL((k_mvc_apply<D, GT>), dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, K, h->d_mvc_totals, h->d_mv_f2v, h->d_mv_marg, flags);
     if (flags & 1) {
-        hipLaunchKernelGGL((k_mvc_marg_out<D>), dim3(ntiles), dim3(kBlock), (size_t)Msg<D>::NC * K * mvc_slab_pitch(K) * sizeof(double), h->stream, A.nlinks, K,
+        hipLaunchKernelGGL((k_mvc_marg_out<D>), dim3((unsigned)(ntiles * ((kBlock + mvc_slab_threads(K) - 1) / mvc_slab_threads(K)))), dim3(kBlock), (size_t)Msg<D>::NC * K * mvc_slab_pitch(K) * sizeof(double), h->stream, A.nlinks, K,
                            A.il_stride, A.nv, A.link_pos, A.pos_var, A.alpha, A.gamma, h->d_mv_marg);
     }
 }
