@@ -88,6 +88,7 @@ int32_t build_chains(cx_handle *h) {
             // a non-observed variable with no non-observed neighbour is a path of one position and no link: the side pass of
             // cx_mvchain.hip writes its marginal (the scalar path leaves such variables to its general variable phase)
             // (so is a non-observed variable of degree 1 whose one factor leads to no chain variable: a chain of one state)
+            h->chain_npos_linked = (int64_t)pos_var.size();
             for (int64_t v = 0; v < nv; v++) {
                 if (visited[v] || (h->vinfo[v] & (cx::kClamped | cx::kGhost))) continue;
                 const int32_t deg = h->var_off[v + 1] - h->var_off[v];

@@ -94,6 +94,7 @@ struct cx_handle {
     // chain-scan schedule (cx_chain.hip): paths of free variables, built lazily by build_chains()
     bool chains_dirty = true;
     int64_t chain_npos = 0, chain_nlinks = 0;
+    int64_t chain_npos_linked = 0;   // dim > 1: positions [0, this) belong to paths with links; the isolated ones follow
     bool chain_side_dirty = true;    // the leaf messages / side sums of the chain positions must be recomputed (data or rule parameters changed)
     bool chain_partition = false;    // the handle holds a time block of a partitioned chain (cx_chain_block_maps was called)
     bool chain_covers_all = false;   // every variable that reads messages is a chain position: the scan's side pass produces all leaf messages

@@ -705,63 +705,93 @@ __global__ __launch_bounds__(kBlock) void k_mvc_marg_out(int nlinks, int K, int6
 // side information of every chain position (runs after data, stored messages or rule parameters changed); a position without
 // links (an isolated non-observed variable) gets its marginal here: the product of everything it hears
 template <int D>
-__global__ __launch_bounds__(kBlock) void k_mvc_side(int npos, int64_t nslots, int nv, const int32_t *__restrict__ pos_var,
-                                                     const int32_t *__restrict__ skip0, const int32_t *__restrict__ skip1,
-                                                     const int32_t *__restrict__ vbase, const uint8_t *__restrict__ vinfo,
-                                                     const double *__restrict__ f2v, double *__restrict__ side,
-                                                     double *__restrict__ marg, int write_marg) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= npos) return;
-    const int v = pos_var[i], s0 = skip0[i], s1 = skip1[i], b = vbase[v], deg = vinfo[v] & kDegMask;
+__device__ __forceinline__ Msg<D> mvc_side_sum(int v, int s0, int s1, const int32_t *__restrict__ vbase, const uint8_t *__restrict__ vinfo,
+                                               const double *__restrict__ f2v) {
+    const int b = vbase[v], deg = vinfo[v] & kDegMask;
     Msg<D> acc = msg_zero<D>();
     for (int k = 0; k < deg; k++) {
         const int slot = b + k * kBlock;
         if (slot == s0 || slot == s1) continue;
         msg_add<D>(acc, slot_load<D>(f2v, slot));
     }
+    return acc;
+}
+
+// positions first .. npos - 1 (the positions WITHOUT links — isolated non-observed variables — sit behind the paths' positions;
+// those of the paths get their side sums from k_mvc_side_links)
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_mvc_side(int first, int npos, int64_t nslots, int nv, const int32_t *__restrict__ pos_var,
+                                                     const int32_t *__restrict__ skip0, const int32_t *__restrict__ skip1,
+                                                     const int32_t *__restrict__ vbase, const uint8_t *__restrict__ vinfo,
+                                                     const double *__restrict__ f2v, double *__restrict__ side,
+                                                     double *__restrict__ marg, int write_marg) {
+    const int i = first + blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npos) return;
+    const int v = pos_var[i], s0 = skip0[i], s1 = skip1[i];
+    const Msg<D> acc = mvc_side_sum<D>(v, s0, s1, vbase, vinfo, f2v);
     msg_store<D>(side, npos, i, acc);
     if (write_marg && s0 < 0 && s1 < 0) marg_store<D>(marg, nv, v, acc);
 }
 
-// The side sums of each link's two end variables, in the interleaved order the scan kernels read.  The inverse of k_mvc_marg_out:
-// a tile goes through LDS in slabs of W = 256 / K threads (all K links of each), read from the by-position array as contiguous
-// runs and written as contiguous runs of the interleaved arrays.  Links of one thread are consecutive and link_pos grows by one per
-// link (by two across a path boundary), so a slab's positions are one range; a slab with so many path boundaries that its range
-// overflows the buffer reads the overflow from memory directly.
+// The side sums of the paths' positions — what a chain variable hears from everybody who is not on the chain — computed, stored by
+// position, and stored a second time as each link's two ends in the interleaved order the scan kernels read.  One workgroup per
+// (tile, slab): a slab is W = 256 / K threads with all K links of each; its links are consecutive and link_pos grows by one per link
+// (by two across a path boundary), so its positions are one range.  Phase 1 sums the range's positions into LDS (and into the
+// by-position array: contiguous runs per component); phase 2 reads the two ends of every link from LDS and writes contiguous runs
+// of the interleaved arrays.  A slab with so many path boundaries that its range overflows the buffer sums the overflow on the spot.
+// (Until the end of round 3 the sums were a kernel of their own and this one re-read them: 40 + 100 us for a 1M-state chain.)
 template <int D>
-__global__ __launch_bounds__(kBlock) void k_mvc_side_links(int nlinks, int npos, int K, const int32_t *__restrict__ link_pos,
-                                                           const double *__restrict__ side, double *__restrict__ side_l, double *__restrict__ side_r) {
+__global__ __launch_bounds__(kBlock) void k_mvc_side_links(int nlinks, int npos, int npos_linked, int K, const int32_t *__restrict__ link_pos,
+                                                           const int32_t *__restrict__ pos_var, const int32_t *__restrict__ skip0,
+                                                           const int32_t *__restrict__ skip1, const int32_t *__restrict__ vbase,
+                                                           const uint8_t *__restrict__ vinfo, const double *__restrict__ f2v,
+                                                           double *__restrict__ side, double *__restrict__ side_l, double *__restrict__ side_r) {
     constexpr int NC = Msg<D>::NC;
     extern __shared__ double buf[];          // [NC][span + span / 32 + 1]: position j of the slab at j + j / 32 (stride-K reads spread over the banks)
     const int tid = threadIdx.x, W = mvc_side_slab_threads(K);
     const int span = W * K + 8, pitch = span + span / 32 + 1;
     const int nslab = (kBlock + W - 1) / W;                 // grid: one workgroup per (tile, slab) — a tile alone would leave the chip under one wave per SIMD
     const int64_t base = (int64_t)(blockIdx.x / nslab) * kBlock * K;
-    {
-        const int t0 = (blockIdx.x % nslab) * W;
-        const int wn = min(W, kBlock - t0), nitems = wn * K;
-        const int64_t L0 = base + (int64_t)t0 * K;
-        if (L0 >= nlinks) return;
-        const int p0 = link_pos[L0];
-        for (int c = 0; c < NC; c++)
-            for (int j = tid; j < span; j += kBlock) buf[c * pitch + j + j / 32] = (p0 + j < npos) ? side[(int64_t)c * npos + p0 + j] : 0.0;
-        __syncthreads();
-        for (int i = tid; i < nitems; i += kBlock) {
-            const int k = i / wn, tt = i - k * wn;
-            const int64_t l = L0 + (int64_t)tt * K + k;
-            if (l >= nlinks) continue;
-            const int p = link_pos[l], q = p - p0;
-            Msg<D> a, b;
+    const int t0 = (blockIdx.x % nslab) * W;
+    const int wn = min(W, kBlock - t0), nitems = wn * K;
+    const int64_t L0 = base + (int64_t)t0 * K;
+    if (L0 >= nlinks) return;
+    const int p0 = link_pos[L0];
+    for (int j = tid; j < span; j += kBlock) {
+        const int p = p0 + j;
+        Msg<D> acc = msg_zero<D>();
+        if (p < npos_linked) {
+            acc = mvc_side_sum<D>(pos_var[p], skip0[p], skip1[p], vbase, vinfo, f2v);
+            msg_store<D>(side, npos, p, acc);               // neighbouring slabs overlap by a few positions: the same value twice
+        }
+        const int jj = j + j / 32;
+#pragma unroll
+        for (int c = 0; c < D; c++) buf[c * pitch + jj] = acc.eta[c];
+#pragma unroll
+        for (int c = 0; c < Msg<D>::NT; c++) buf[(D + c) * pitch + jj] = acc.lam[c];
+    }
+    __syncthreads();
+    for (int i = tid; i < nitems; i += kBlock) {
+        const int k = i / wn, tt = i - k * wn;
+        const int64_t l = L0 + (int64_t)tt * K + k;
+        if (l >= nlinks) continue;
+        const int p = link_pos[l], q = p - p0;
+        Msg<D> a, b;
+        if (q + 1 < span) {
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                const double va = (q < span) ? buf[c * pitch + q + q / 32] : side[(int64_t)c * npos + p];
-                const double vb = (q + 1 < span) ? buf[c * pitch + (q + 1) + (q + 1) / 32] : side[(int64_t)c * npos + p + 1];
+                const double va = buf[c * pitch + q + q / 32], vb = buf[c * pitch + (q + 1) + (q + 1) / 32];
                 if (c < D) { a.eta[c] = va; b.eta[c] = vb; } else { a.lam[c - D] = va; b.lam[c - D] = vb; }
             }
-            const int il = (int)(base + (int64_t)k * kBlock + t0 + tt);
-            slot_store<D>(side_l, il, a);
-            slot_store<D>(side_r, il, b);
+        } else {                                            // beyond the buffer: nobody else is sure to cover these positions
+            a = mvc_side_sum<D>(pos_var[p], skip0[p], skip1[p], vbase, vinfo, f2v);
+            b = mvc_side_sum<D>(pos_var[p + 1], skip0[p + 1], skip1[p + 1], vbase, vinfo, f2v);
+            msg_store<D>(side, npos, p, a);
+            msg_store<D>(side, npos, p + 1, b);
         }
+        const int il = (int)(base + (int64_t)k * kBlock + t0 + tt);
+        slot_store<D>(side_l, il, a);
+        slot_store<D>(side_r, il, b);
     }
 }
 
@@ -793,16 +823,20 @@ size_t mvc_wave_carry_doubles(int dim, int64_t nlinks, int K) { return (size_t)2
 void mvc_launch_side(cx_handle *h, bool write_marg) {
     const int npos = (int)h->chain_npos, nlinks = (int)h->chain_nlinks, K = h->mvc_K;
     if (npos == 0) return;
-    const dim3 g((npos + kBlock - 1) / kBlock), b(kBlock);
+    const int linked = nlinks ? (int)h->chain_npos_linked : 0, alone = npos - linked;
+    const dim3 g((unsigned)std::max((alone + kBlock - 1) / kBlock, 1)), b(kBlock);
     const dim3 gl((unsigned)(mvc_ntiles(nlinks, K) * ((kBlock + mvc_side_slab_threads(K) - 1) / mvc_side_slab_threads(K))));
     const int span = mvc_side_slab_threads(K) * K + 8;
     const size_t lds = (size_t)h->nc * (span + span / 32 + 1) * sizeof(double);
 #define CX_MVC(DD)                                                                                                                           \
     do {                                                                                                                                     \
-        hipLaunchKernelGGL((k_mvc_side<DD>), g, b, 0, h->stream, npos, h->nslots, (int)h->nv, h->d_chain_pos_var, h->d_chain_skip0,          \
-                           h->d_chain_skip1, h->d_vbase, h->d_vinfo, h->d_mv_f2v, h->d_mvc_side, h->d_mv_marg, write_marg ? 1 : 0);          \
-        if (nlinks) hipLaunchKernelGGL((k_mvc_side_links<DD>), gl, b, lds, h->stream, nlinks, npos, K, h->d_chain_link_pos, h->d_mvc_side,   \
-                                       h->d_mvc_side_l, h->d_mvc_side_r);                                                                    \
+        if (alone > 0)                                                                                                                       \
+            hipLaunchKernelGGL((k_mvc_side<DD>), g, b, 0, h->stream, linked, npos, h->nslots, (int)h->nv, h->d_chain_pos_var,                \
+                               h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_vinfo, h->d_mv_f2v, h->d_mvc_side, h->d_mv_marg,         \
+                               write_marg ? 1 : 0);                                                                                          \
+        if (nlinks) hipLaunchKernelGGL((k_mvc_side_links<DD>), gl, b, lds, h->stream, nlinks, npos, linked, K, h->d_chain_link_pos,          \
+                                       h->d_chain_pos_var, h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_vinfo, h->d_mv_f2v,          \
+                                       h->d_mvc_side, h->d_mvc_side_l, h->d_mvc_side_r);                                                    \
     } while (0)
     if (h->cfg.dim == 2) CX_MVC(2);
     else if (h->cfg.dim == 3) CX_MVC(3);
