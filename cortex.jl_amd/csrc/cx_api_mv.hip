@@ -292,8 +292,7 @@ static int32_t mv_chain_sweep(cx_handle *h, int32_t n_sweeps) {
         if (h->observed_passes_due > 0 || h->chain_side_dirty) {
             // the constant messages into the chains: out of observed variables (data through the likelihood rule) and out of
             // other senders of stored messages, then the side sums — only after data, stored messages or rule tables changed
-            cx::mv_launch_sweep(h, false, 1, h->d_mv_f2v);
-            cx::mv_launch_sweep(h, false, 2, h->d_mv_f2v);
+            cx::mv_launch_sweep(h, false, 3, h->d_mv_f2v);
             cx::mvc_launch_side(h, marg);
             h->observed_passes_due = 0; h->chain_side_dirty = false;
         }
@@ -320,8 +319,7 @@ int32_t mv_chain_block_maps(cx_handle *h, double *fwd, double *bwd, double *side
     if ((rc = mv_ensure_chain_msgs(h)) != CX_OK) return rc;      // the maps overwrite the stored prefixes of the last sweep
     if ((rc = mv_refresh_spdir(h)) != CX_OK) return rc;
     // the leaf messages and side sums from the data currently on the device (the caller has zeroed the cut messages)
-    cx::mv_launch_sweep(h, false, 1, h->d_mv_f2v);
-    cx::mv_launch_sweep(h, false, 2, h->d_mv_f2v);
+    cx::mv_launch_sweep(h, false, 3, h->d_mv_f2v);
     cx::mvc_launch_side(h, false);
     cx::mvc_launch_block_maps(h);
     CX_HIP(h, hipGetLastError());

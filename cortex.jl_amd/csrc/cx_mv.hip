@@ -66,8 +66,10 @@ __global__ __launch_bounds__(kBlock, DEG == 3 ? 3 : 2) void k_sweep_mv(int nv, i
     // observed_only == 2: the other senders of constant messages — free variables of degree 1 and stand-ins, whose stored
     // variable→factor message goes through the rule (the chain scan's leaf pass; the regular sweep handles them itself)
     const bool is_fixed = (info & kGhost) || deg < 2;
-    const bool active = v < nv && (observed_only == 2 ? (!(info & kClamped) && is_fixed && deg > 0)
-                                                      : (((info & kClamped) != 0) == (observed_only != 0)));
+    // observed_only == 3: both kinds of constant senders in one pass (what the chain scan's leaf pass launches)
+    const bool active = v < nv && (observed_only == 3 ? ((info & kClamped) || (is_fixed && deg > 0))
+                                   : observed_only == 2 ? (!(info & kClamped) && is_fixed && deg > 0)
+                                                        : (((info & kClamped) != 0) == (observed_only != 0)));
     const int base = off + tid;
     Msg<D> in[DEG];
     int pk[DEG], sd[DEG];

@@ -736,8 +736,8 @@ __global__ __launch_bounds__(kBlock) void k_mvc_side(int first, int npos, int64_
 // The side sums of the paths' positions — what a chain variable hears from everybody who is not on the chain — computed, stored by
 // position, and stored a second time as each link's two ends in the interleaved order the scan kernels read.  One workgroup per
 // (tile, slab): a slab is W = 256 / K threads with all K links of each; its links are consecutive and link_pos grows by one per link
-// (by two across a path boundary), so its positions are one range.  Phase 1 sums the range's positions into LDS (and into the
-// by-position array: contiguous runs per component); phase 2 reads the two ends of every link from LDS and writes contiguous runs
+// (by two across a path boundary), so its positions are one range.  Phase 1 sums the range's positions into LDS (and, for the ends
+// of the paths, into the by-position array); phase 2 reads the two ends of every link from LDS and writes contiguous runs
 // of the interleaved arrays.  A slab with so many path boundaries that its range overflows the buffer sums the overflow on the spot.
 // (Until the end of round 3 the sums were a kernel of their own and this one re-read them: 40 + 100 us for a 1M-state chain.)
 template <int D>
@@ -761,8 +761,11 @@ __global__ __launch_bounds__(kBlock) void k_mvc_side_links(int nlinks, int npos,
         const int p = p0 + j;
         Msg<D> acc = msg_zero<D>();
         if (p < npos_linked) {
-            acc = mvc_side_sum<D>(pos_var[p], skip0[p], skip1[p], vbase, vinfo, f2v);
-            msg_store<D>(side, npos, p, acc);               // neighbouring slabs overlap by a few positions: the same value twice
+            const int s0 = skip0[p], s1 = skip1[p];
+            acc = mvc_side_sum<D>(pos_var[p], s0, s1, vbase, vinfo, f2v);
+            // by position only where somebody reads it that way: the ends of the paths (the marginal of a path's first variable in
+            // k_mvc_apply, the end variables' side sums of cx_chain_block_maps) — a position inside a path lacks no chain neighbour
+            if (s0 < 0 || s1 < 0) msg_store<D>(side, npos, p, acc);
         }
         const int jj = j + j / 32;
 #pragma unroll
@@ -786,8 +789,8 @@ __global__ __launch_bounds__(kBlock) void k_mvc_side_links(int nlinks, int npos,
         } else {                                            // beyond the buffer: nobody else is sure to cover these positions
             a = mvc_side_sum<D>(pos_var[p], skip0[p], skip1[p], vbase, vinfo, f2v);
             b = mvc_side_sum<D>(pos_var[p + 1], skip0[p + 1], skip1[p + 1], vbase, vinfo, f2v);
-            msg_store<D>(side, npos, p, a);
-            msg_store<D>(side, npos, p + 1, b);
+            if (skip0[p] < 0 || skip1[p] < 0) msg_store<D>(side, npos, p, a);
+            if (skip0[p + 1] < 0 || skip1[p + 1] < 0) msg_store<D>(side, npos, p + 1, b);
         }
         const int il = (int)(base + (int64_t)k * kBlock + t0 + tt);
         slot_store<D>(side_l, il, a);
