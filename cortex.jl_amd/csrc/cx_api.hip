@@ -20,7 +20,7 @@ void dev_free_all(cx_handle *h) {
                     h->ext_halo_buffers ? nullptr : (void *)h->d_send_buf, h->ext_halo_buffers ? nullptr : (void *)h->d_recv_buf,
                     h->d_stage, h->d_spdir, h->d_ptab, h->d_ptab_bt, h->d_zero_msg, h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prev, h->d_rule64_slots, h->d_rule64_vars, h->d_rule64_flags, h->d_point64_slots, h->d_rule64_rec, h->d_chain_pos_var, h->d_chain_skip0, h->d_chain_skip1, h->d_chain_link_pos, h->d_chain_from,
                     h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_side, h->d_chain_totals, h->d_chain_tab_fwd, h->d_chain_tab_bwd,
-                    h->d_mvc_side, h->d_mvc_totals, h->d_mvc_side_l, h->d_mvc_side_r, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix, h->d_mvc_wave_carry, h->d_mvc_block};
+                    h->d_mvc_side, h->d_mvc_totals, h->d_mvc_side_l, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix, h->d_mvc_wave_carry, h->d_mvc_block};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     cx::tiles_free(h);
     if (h->d_f2v_tmp) (void)hipFree(h->d_f2v_tmp);
@@ -32,7 +32,7 @@ void dev_free_all(cx_handle *h) {
     h->d_spdir = nullptr; h->d_ptab = nullptr; h->d_ptab_bt = nullptr; h->d_zero_msg = nullptr; h->d_mv_f2v = h->d_mv_f2v_alt = h->d_mv_v2f = h->d_mv_marg = h->d_mv_prev = nullptr; h->ptab_sets = 0;
     h->d_chain_pos_var = h->d_chain_skip0 = h->d_chain_skip1 = h->d_chain_link_pos = h->d_chain_from = h->d_chain_to = nullptr;
     h->d_chain_head_fwd = h->d_chain_head_bwd = nullptr; h->d_chain_side = nullptr; h->d_chain_totals = nullptr; h->chains_dirty = true;
-    h->d_chain_tab_fwd = h->d_chain_tab_bwd = nullptr; h->d_mvc_side = h->d_mvc_totals = nullptr; h->d_mvc_side_l = h->d_mvc_side_r = h->d_mvc_alpha = h->d_mvc_gamma = h->d_mvc_prefix = h->d_mvc_wave_carry = h->d_mvc_block = nullptr;
+    h->d_chain_tab_fwd = h->d_chain_tab_bwd = nullptr; h->d_mvc_side = h->d_mvc_totals = nullptr; h->d_mvc_side_l = h->d_mvc_alpha = h->d_mvc_gamma = h->d_mvc_prefix = h->d_mvc_wave_carry = h->d_mvc_block = nullptr;
     h->d_slice_off = h->d_partner = h->d_vbase = h->d_var_deg = h->d_big = h->d_big_slots = nullptr;
     h->d_big_tmp = nullptr; h->d_vinfo = nullptr;
     h->d_q = h->d_a = h->d_b = h->d_sq = h->d_sa = h->d_sb = nullptr;

@@ -105,9 +105,9 @@ int32_t build_chains(cx_handle *h) {
         for (void *p : {(void *)h->d_chain_pos_var, (void *)h->d_chain_skip0, (void *)h->d_chain_skip1, (void *)h->d_chain_link_pos,
                         (void *)h->d_chain_from, (void *)h->d_chain_to, (void *)h->d_chain_head_fwd, (void *)h->d_chain_head_bwd,
                         (void *)h->d_chain_side, h->d_chain_totals, (void *)h->d_chain_tab_fwd, (void *)h->d_chain_tab_bwd, (void *)h->d_mvc_side,
-                        (void *)h->d_mvc_totals, (void *)h->d_mvc_side_l, (void *)h->d_mvc_side_r, (void *)h->d_mvc_alpha, (void *)h->d_mvc_gamma, (void *)h->d_mvc_prefix, (void *)h->d_mvc_wave_carry, (void *)h->d_mvc_block}) if (p) (void)hipFree(p);
+                        (void *)h->d_mvc_totals, (void *)h->d_mvc_side_l, (void *)h->d_mvc_alpha, (void *)h->d_mvc_gamma, (void *)h->d_mvc_prefix, (void *)h->d_mvc_wave_carry, (void *)h->d_mvc_block}) if (p) (void)hipFree(p);
         h->d_chain_tab_fwd = h->d_chain_tab_bwd = nullptr; h->d_mvc_side = h->d_mvc_totals = nullptr;
-        h->d_mvc_side_l = h->d_mvc_side_r = h->d_mvc_alpha = h->d_mvc_gamma = h->d_mvc_prefix = h->d_mvc_wave_carry = h->d_mvc_block = nullptr;
+        h->d_mvc_side_l = h->d_mvc_alpha = h->d_mvc_gamma = h->d_mvc_prefix = h->d_mvc_wave_carry = h->d_mvc_block = nullptr;
         h->chain_npos = (int64_t)pos_var.size(); h->chain_nlinks = (int64_t)link_pos.size();
         h->chain_side_dirty = true;
         int64_t n_readers = 0;   // variables that read factor→variable messages: everything but observed variables and ghosts
@@ -130,7 +130,6 @@ int32_t build_chains(cx_handle *h) {
             const int64_t il = cx::mvc_ntiles(h->chain_nlinks, h->mvc_K) * cx::kBlock * h->mvc_K;     // interleaved arrays, padded to whole tiles
             if ((rc = dev_alloc(h, &h->d_mvc_side, h->nc * h->chain_npos)) != CX_OK) return rc;
             if ((rc = dev_alloc(h, &h->d_mvc_side_l, h->ncs * il)) != CX_OK) return rc;
-            if ((rc = dev_alloc(h, &h->d_mvc_side_r, h->ncs * il)) != CX_OK) return rc;
             if ((rc = dev_alloc(h, &h->d_mvc_alpha, h->ncs * il)) != CX_OK) return rc;
             if ((rc = dev_alloc(h, &h->d_mvc_gamma, h->ncs * il)) != CX_OK) return rc;
             if ((rc = dev_alloc(h, &h->d_mvc_prefix, (int64_t)cx::mvc_prefix_doubles(h->cfg.dim, h->chain_nlinks, h->mvc_K))) != CX_OK) return rc;

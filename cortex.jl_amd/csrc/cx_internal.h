@@ -106,7 +106,7 @@ struct cx_handle {
     // dim 2..4 (cx_mvchain.hip): rule-table index of each link's two messages, side sums [nc][npos], tile totals of the map scan
     int32_t *d_chain_tab_fwd = nullptr, *d_chain_tab_bwd = nullptr;
     double *d_mvc_side = nullptr, *d_mvc_totals = nullptr;
-    double *d_mvc_side_l = nullptr, *d_mvc_side_r = nullptr, *d_mvc_alpha = nullptr, *d_mvc_gamma = nullptr, *d_mvc_prefix = nullptr, *d_mvc_wave_carry = nullptr, *d_mvc_block = nullptr;   // thread-interleaved by link, [nc][ntiles * 256 * K]
+    double *d_mvc_side_l = nullptr, *d_mvc_alpha = nullptr, *d_mvc_gamma = nullptr, *d_mvc_prefix = nullptr, *d_mvc_wave_carry = nullptr, *d_mvc_block = nullptr;   // thread-interleaved by link, [nc][ntiles * 256 * K]
     int mvc_K = 4;                   // links per thread of the scan (fixed when the chains are built)
     bool chain_msgs_stale = false;   // dim 2..4 chain scan: the chain messages in d_mv_f2v are older than the last sweep (refreshed on demand)
 

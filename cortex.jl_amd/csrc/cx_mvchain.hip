@@ -403,8 +403,9 @@ struct MvcArgs {
     const uint8_t *head_fwd, *head_bwd;  // first / last link of its path
     const int32_t *pos_var;
     const double *side;                  // [nc][npos]: sum of the non-chain messages into each chain variable, by position
-    const double *side_l, *side_r;       // the same for the left / right variable of link l, at IL(l); block-major pairs like the message
-                                         // buffers (cx_mv_core.h: slot_load): a block = the 256 threads of a workgroup at one step k
+    const double *side_l;                // the same for the LEFT variable of link l, at IL(l); block-major pairs like the message buffers
+                                         // (cx_mv_core.h: slot_load): a block = the 256 threads of a workgroup at one step k.  The right
+                                         // variable of a link is the left variable of the next one: mvc_side_right
     double *alpha, *gamma;               // at IL(l), same form: the forward message link l produces; what its right variable hears
                                          // from everybody but the link (side + the backward message of the next link)
     double *prefix;                      // [2][ND + 1][nthreads]: every thread's inclusive prefix within its WAVE, per direction
@@ -415,20 +416,25 @@ struct MvcArgs {
     const double *ptab;                  // [ntab][3][D*D]
 };
 
+// What the RIGHT variable of link l hears from off the chain.  Inside a path that is the side sum of the next link's left variable —
+// IL(l + 1): the same thread's next step, or the first step of the next thread (of the next tile) — and for the last link of a path
+// the by-position entry of the path's last variable.  (A copy at IL(l) used to be kept: a third of what the side pass wrote.)
+template <int D>
+__device__ __forceinline__ Msg<D> mvc_side_right(const MvcArgs &A, int l, int64_t il, int K) {
+    int64_t iln = il + kBlock;
+    if ((l + 1) % K == 0) { const int64_t g = (int64_t)(l + 1) / K; iln = (g / kBlock) * (int64_t)kBlock * K + (g % kBlock); }
+    // the load goes out before the path-end flag is known (a dependent round trip per step of the backward walk otherwise); the
+    // last link of the last tile would point one past the array
+    Msg<D> u = slot_load<D, true>(A.side_l, (int)(iln < A.il_stride ? iln : il));
+    if (A.head_bwd[l]) u = msg_load<D>(A.side, A.npos, A.link_pos[l] + 1);
+    return u;
+}
+
 constexpr int kMvcTabLds = 16;           // rule tables (parameter set x direction) kept in LDS; graphs with more read them from memory
 
 template <int D, bool GT>
 __device__ __forceinline__ const double *mvc_tab(const MvcArgs &A, const double *tab_s, int t) {
     return (GT ? A.ptab : tab_s) + (size_t)t * 3 * D * D;
-}
-
-// dir = +1: link l maps alpha at its left variable to alpha at its right variable; dir = -1: beta at the right to beta at the left
-template <int D, bool GT>
-__device__ __forceinline__ CMap<D> mvc_link(const MvcArgs &A, const double *tab_s, int l, int64_t il, int dir) {
-    const bool head = (dir > 0 ? A.head_fwd[l] : A.head_bwd[l]) != 0;
-    const int t = dir > 0 ? A.tab_fwd[l] : A.tab_bwd[l];
-    const Msg<D> u = slot_load<D, true>(dir > 0 ? A.side_l : A.side_r, (int)il);
-    return cmap_of_link<D>(u, mvc_tab<D, GT>(A, tab_s, t), head);
 }
 
 // the composed map of a thread's K consecutive links, in the direction's order, accumulated in place: the link's own map is
@@ -443,7 +449,7 @@ __device__ __forceinline__ void mvc_thread_total(CMap<D> &tot, const MvcArgs &A,
         if (l >= A.nlinks) continue;
         const bool head = (dir > 0 ? A.head_fwd[l] : A.head_bwd[l]) != 0;
         const double *tab = mvc_tab<D, GT>(A, tab_s, dir > 0 ? A.tab_fwd[l] : A.tab_bwd[l]);
-        const Msg<D> u = slot_load<D, true>(dir > 0 ? A.side_l : A.side_r, (int)(il0 + (int64_t)kk * kBlock));
+        const Msg<D> u = dir > 0 ? slot_load<D, true>(A.side_l, (int)(il0 + (int64_t)kk * kBlock)) : mvc_side_right<D>(A, l, il0 + (int64_t)kk * kBlock, K);
         if (head && A.collapse_heads) {      // the first link of a path: the constant map "rule applied to u alone"
             const Msg<D> o = mv_rule<D, false>(u, tab);
 #pragma unroll
@@ -590,7 +596,7 @@ __device__ __forceinline__ void marg_store(double *__restrict__ marg, int64_t, i
 // flags & 1: marginals are wanted (the backward walk writes those of the first variable of every path itself; all others come
 // from alpha + gamma in k_mvc_marg_out).  flags & 2: alpha_l / beta_l also go to their SELL slots f2v[to_slot[l]] / f2v[from_slot[l]].
 template <int D, bool GT>
-__global__ __launch_bounds__(kBlock) void k_mvc_apply(MvcArgs A, int K, const double *__restrict__ excl, double *__restrict__ f2v,
+__global__ __launch_bounds__(kBlock, 4) void k_mvc_apply(MvcArgs A, int K, const double *__restrict__ excl, double *__restrict__ f2v,
                                                       double *__restrict__ marg, int flags) {
     constexpr int E = CMap<D>::ND + 1;
     using M = CMap<D>;
@@ -636,7 +642,7 @@ __global__ __launch_bounds__(kBlock) void k_mvc_apply(MvcArgs A, int K, const do
             const int l = l0 + k;
             if (l >= A.nlinks) continue;
             const int64_t il = il0 + (int64_t)k * kBlock;
-            Msg<D> in = slot_load<D, true>(A.side_r, (int)il);      // what the right variable hears from everybody but this link
+            Msg<D> in = mvc_side_right<D>(A, l, il, K);             // what the right variable hears from everybody but this link
             if (!A.head_bwd[l]) msg_add<D>(in, cur);
             slot_store<D>(A.gamma, (int)il, in);
             cur = mv_rule<D, false>(in, mvc_tab<D, GT>(A, tab_s, A.tab_bwd[l]));
@@ -734,18 +740,18 @@ __global__ __launch_bounds__(kBlock) void k_mvc_side(int first, int npos, int64_
 }
 
 // The side sums of the paths' positions — what a chain variable hears from everybody who is not on the chain — computed, stored by
-// position, and stored a second time as each link's two ends in the interleaved order the scan kernels read.  One workgroup per
+// position (ends of paths), and stored as each link's LEFT end in the interleaved order the scan kernels read.  One workgroup per
 // (tile, slab): a slab is W = 256 / K threads with all K links of each; its links are consecutive and link_pos grows by one per link
 // (by two across a path boundary), so its positions are one range.  Phase 1 sums the range's positions into LDS (and, for the ends
-// of the paths, into the by-position array); phase 2 reads the two ends of every link from LDS and writes contiguous runs
-// of the interleaved arrays.  A slab with so many path boundaries that its range overflows the buffer sums the overflow on the spot.
+// of the paths, into the by-position array); phase 2 reads the left end of every link from LDS and writes contiguous runs
+// of the interleaved array.  A slab with so many path boundaries that its range overflows the buffer sums the overflow on the spot.
 // (Until the end of round 3 the sums were a kernel of their own and this one re-read them: 40 + 100 us for a 1M-state chain.)
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_mvc_side_links(int nlinks, int npos, int npos_linked, int K, const int32_t *__restrict__ link_pos,
                                                            const int32_t *__restrict__ pos_var, const int32_t *__restrict__ skip0,
                                                            const int32_t *__restrict__ skip1, const int32_t *__restrict__ vbase,
                                                            const uint8_t *__restrict__ vinfo, const double *__restrict__ f2v,
-                                                           double *__restrict__ side, double *__restrict__ side_l, double *__restrict__ side_r) {
+                                                           double *__restrict__ side, double *__restrict__ side_l) {
     constexpr int NC = Msg<D>::NC;
     extern __shared__ double buf[];          // [NC][span + span / 32 + 1]: position j of the slab at j + j / 32 (stride-K reads spread over the banks)
     const int tid = threadIdx.x, W = mvc_side_slab_threads(K);
@@ -779,22 +785,21 @@ __global__ __launch_bounds__(kBlock) void k_mvc_side_links(int nlinks, int npos,
         const int64_t l = L0 + (int64_t)tt * K + k;
         if (l >= nlinks) continue;
         const int p = link_pos[l], q = p - p0;
-        Msg<D> a, b;
-        if (q + 1 < span) {
+        Msg<D> a;
+        if (q < span) {
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                const double va = buf[c * pitch + q + q / 32], vb = buf[c * pitch + (q + 1) + (q + 1) / 32];
-                if (c < D) { a.eta[c] = va; b.eta[c] = vb; } else { a.lam[c - D] = va; b.lam[c - D] = vb; }
+                const double va = buf[c * pitch + q + q / 32];
+                if (c < D) a.eta[c] = va; else a.lam[c - D] = va;
             }
-        } else {                                            // beyond the buffer: nobody else is sure to cover these positions
+        } else {                                            // beyond the buffer: nobody else is sure to cover this position
             a = mvc_side_sum<D>(pos_var[p], skip0[p], skip1[p], vbase, vinfo, f2v);
-            b = mvc_side_sum<D>(pos_var[p + 1], skip0[p + 1], skip1[p + 1], vbase, vinfo, f2v);
-            if (skip0[p] < 0 || skip1[p] < 0) msg_store<D>(side, npos, p, a);
-            if (skip0[p + 1] < 0 || skip1[p + 1] < 0) msg_store<D>(side, npos, p + 1, b);
+            if (skip0[p] < 0) msg_store<D>(side, npos, p, a);
         }
+        if (q + 1 >= span && skip1[p + 1] < 0)              // ... nor the last position of a path that ends out there
+            msg_store<D>(side, npos, p + 1, mvc_side_sum<D>(pos_var[p + 1], skip0[p + 1], skip1[p + 1], vbase, vinfo, f2v));
         const int il = (int)(base + (int64_t)k * kBlock + t0 + tt);
         slot_store<D>(side_l, il, a);
-        slot_store<D>(side_r, il, b);
     }
 }
 
@@ -839,7 +844,7 @@ void mvc_launch_side(cx_handle *h, bool write_marg) {
                                write_marg ? 1 : 0);                                                                                          \
         if (nlinks) hipLaunchKernelGGL((k_mvc_side_links<DD>), gl, b, lds, h->stream, nlinks, npos, linked, K, h->d_chain_link_pos,          \
                                        h->d_chain_pos_var, h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_vinfo, h->d_mv_f2v,          \
-                                       h->d_mvc_side, h->d_mvc_side_l, h->d_mvc_side_r);                                                    \
+                                       h->d_mvc_side, h->d_mvc_side_l);                                                    \
     } while (0)
     if (h->cfg.dim == 2) CX_MVC(2);
     else if (h->cfg.dim == 3) CX_MVC(3);
@@ -869,7 +874,7 @@ void mvc_launch_scan(cx_handle *h, bool write_marg, bool store_msgs, bool scan) 
     const int K = h->mvc_K;
     MvcArgs A{(int)h->chain_nlinks, (int)h->chain_npos, (int)h->nv, (int)(2 * h->ptab_sets), h->nslots, h->d_chain_link_pos, h->d_chain_from,
               h->d_chain_to, h->d_chain_tab_fwd, h->d_chain_tab_bwd, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_pos_var,
-              h->d_mvc_side, h->d_mvc_side_l, h->d_mvc_side_r, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix, h->d_mvc_wave_carry,
+              h->d_mvc_side, h->d_mvc_side_l, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix, h->d_mvc_wave_carry,
               mvc_ntiles(h->chain_nlinks, K) * kBlock * K, 1, h->d_ptab};
     const bool gt = A.ntab > kMvcTabLds;
     const int flags = (write_marg ? 1 : 0) | (store_msgs ? 2 : 0);
@@ -896,7 +901,7 @@ void mvc_launch_block_maps(cx_handle *h) {
     const int K = h->mvc_K;
     MvcArgs A{(int)h->chain_nlinks, (int)h->chain_npos, (int)h->nv, (int)(2 * h->ptab_sets), h->nslots, h->d_chain_link_pos, h->d_chain_from,
               h->d_chain_to, h->d_chain_tab_fwd, h->d_chain_tab_bwd, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_pos_var,
-              h->d_mvc_side, h->d_mvc_side_l, h->d_mvc_side_r, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix, h->d_mvc_wave_carry,
+              h->d_mvc_side, h->d_mvc_side_l, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix, h->d_mvc_wave_carry,
               mvc_ntiles(h->chain_nlinks, K) * kBlock * K, 0, h->d_ptab};
     const bool gt = A.ntab > kMvcTabLds;
 #define CX_MVC(DD) do { if (gt) mvc_block_maps_t<DD, true>(h, A, K); else mvc_block_maps_t<DD, false>(h, A, K); } while (0)
