@@ -377,6 +377,8 @@ class Workload:
                 try:
                     ex = partition.DeepHaloIpc(dev, part, dist, torch, tdev)
                     dev.halo_ipc_set_timeout(30.0)
+                    if os.environ.get("CX_BENCH_IPC_FAIL") == str(rank):      # rehearsal knob: one rank fails, ALL must fall back
+                        raise RuntimeError("injected failure (CX_BENCH_IPC_FAIL)")
                 except (cx.CortexHipError, RuntimeError, ValueError) as e:
                     err = e
                 err = agreed(err)
