@@ -62,6 +62,7 @@ struct Vmp {
     int32_t *d_nb_off = nullptr, *d_nb_other = nullptr, *d_nb_gamma = nullptr;            // mean field: CSR per Normal variable
     int32_t *d_chunk_begin = nullptr, *d_chunk_end = nullptr, *d_g_chunk_off = nullptr, *d_g_deg = nullptr;
     int32_t *d_req = nullptr;                                                               // requested Gamma indices
+    std::vector<int32_t> req_on_device;                                                     // ... as last uploaded
     double *d_rate = nullptr, *d_partial = nullptr;
     // structured: inner scalar handle over the Normal variables
     cx_handle *chain = nullptr;
@@ -191,28 +192,22 @@ __global__ __launch_bounds__(256) void k_reduce_chunks(const int32_t *__restrict
     if (threadIdx.x == 0) partial[c] = s;
 }
 
-// one workgroup per requested Gamma variable: sum its chunk partials; stage (shape, scale)
+// one workgroup per requested Gamma variable: sum its chunk partials and store (shape, scale, mean).  Every reader of the OLD
+// means in this round (k_mf_normal, k_rate) was launched before this kernel on the same stream, so the Jacobi round needs no
+// staging copy and no commit launch of its own.
 __global__ __launch_bounds__(256) void k_gamma_finish(const int32_t *__restrict__ req, const int32_t *__restrict__ g_chunk_off,
                                                       const int32_t *__restrict__ g_deg, const double *__restrict__ partial,
-                                                      double *__restrict__ staged, int ng) {
+                                                      double *__restrict__ shape, double *__restrict__ scale, double *__restrict__ mean) {
     __shared__ double sh[4];
     const int g = req[blockIdx.x];
     double acc = 0.0;
     for (int c = g_chunk_off[g] + threadIdx.x; c < g_chunk_off[g + 1]; c += blockDim.x) acc += partial[c];
     const double s = block_sum(acc, sh);
     if (threadIdx.x == 0) {
-        staged[g] = 1.0 + 0.5 * (double)g_deg[g];   // product of deg Gamma(3/2, .): shape 3/2 deg - (deg - 1)
-        staged[ng + g] = 1.0 / s;
+        const double a = 1.0 + 0.5 * (double)g_deg[g];     // product of deg Gamma(3/2, .): shape 3/2 deg - (deg - 1)
+        const double th = 1.0 / s;
+        shape[g] = a; scale[g] = th; mean[g] = a * th;
     }
-}
-
-__global__ void k_gamma_commit(int nreq, const int32_t *__restrict__ req, const double *__restrict__ staged, int ng,
-                               double *__restrict__ shape, double *__restrict__ scale, double *__restrict__ mean) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nreq) return;
-    const int g = req[i];
-    const double a = staged[g], th = staged[ng + g];
-    shape[g] = a; scale[g] = th; mean[g] = a * th;
 }
 
 // structured: the inner handle's factor variance q = 1 / E[precision], for both slots of every factor
@@ -584,7 +579,11 @@ int32_t vmp_update_marginals(cx_handle *h, int64_t n, const int64_t *ids) {
                                s->n_mean, s->n_prec, s->d_observed, all ? (const uint8_t *)nullptr : s->d_mask, s->g_mean, s->n_mean_alt, s->n_prec_alt);
         }
         if (!req.empty()) {
-            VMP_HIP(h, hipMemcpyAsync(s->d_req, req.data(), req.size() * 4, hipMemcpyHostToDevice, h->stream));
+            if (req != s->req_on_device) {      // the same request round after round (the usual case): the list is already there
+                VMP_HIP(h, hipMemcpyAsync(s->d_req, req.data(), req.size() * 4, hipMemcpyHostToDevice, h->stream));
+                VMP_HIP(h, hipStreamSynchronize(h->stream));      // `req` is a local: the copy has to have read it
+                s->req_on_device = req;
+            }
             if (s->structured)
                 hipLaunchKernelGGL(k_rate<true>, dim3(blocks(s->nF)), dim3(256), 0, h->stream, (int)s->nF, s->d_f_out, s->d_f_mean, s->d_f_gamma, s->d_f_pos,
                                    s->n_mean, s->n_prec, s->d_observed, s->g_mean, s->d_slot_out, s->d_slot_mean, s->chain->d_v2f, s->d_rate);
@@ -592,13 +591,11 @@ int32_t vmp_update_marginals(cx_handle *h, int64_t n, const int64_t *ids) {
                 hipLaunchKernelGGL(k_rate<false>, dim3(blocks(s->nF)), dim3(256), 0, h->stream, (int)s->nF, s->d_f_out, s->d_f_mean, s->d_f_gamma, s->d_f_pos,
                                    s->n_mean, s->n_prec, s->d_observed, s->g_mean, (const int32_t *)nullptr, (const int32_t *)nullptr, (const double2 *)nullptr, s->d_rate);
             hipLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)s->nChunks), dim3(256), 0, h->stream, s->d_chunk_begin, s->d_chunk_end, s->d_rate, s->d_partial);
-            hipLaunchKernelGGL(k_gamma_finish, dim3((unsigned)req.size()), dim3(256), 0, h->stream, s->d_req, s->d_g_chunk_off, s->d_g_deg, s->d_partial, s->g_new, (int)s->nG);
+            hipLaunchKernelGGL(k_gamma_finish, dim3((unsigned)req.size()), dim3(256), 0, h->stream, s->d_req, s->d_g_chunk_off, s->d_g_deg, s->d_partial,
+                               s->g_shape, s->g_scale, s->g_mean);
         }
         // the final round: store
         if (do_normal && !s->structured) { std::swap(s->n_mean, s->n_mean_alt); std::swap(s->n_prec, s->n_prec_alt); }
-        if (!req.empty())
-            hipLaunchKernelGGL(k_gamma_commit, dim3(blocks((int64_t)req.size())), dim3(256), 0, h->stream, (int)req.size(), s->d_req, s->g_new, (int)s->nG,
-                               s->g_shape, s->g_scale, s->g_mean);
         if (do_normal && s->structured) {
             cx_handle *c = s->chain;
             hipLaunchKernelGGL(k_set_q, dim3(blocks(c->nslots)), dim3(256), 0, h->stream, (int)c->nslots, s->d_slot_gamma, s->g_mean, c->d_q);
