@@ -49,11 +49,11 @@ def counter_traffic(kernel_substr):
 def roofline(bound, achieved, peak, unit, traffic, **extra):
     frac = achieved / peak
     r = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": frac, "traffic": traffic}
-    if traffic is None and frac > 1.0:
-        # without counter traffic only the SURVEY §8d convention is available, and a kernel that moves fewer bytes than the
-        # convention counts would read above 1: not a physical fraction, so none is printed
+    if traffic is None and bound == "hbm":
+        # without counter traffic (none on file, or measured on another version of the kernel's sources) only the SURVEY §8d
+        # convention is available, which counts bytes these kernels do not move: not a physical fraction, so none is printed
         r["frac"] = None
-        r["frac_note"] = "no counter traffic on file (tools/profile_configs.sh); the algorithmic convention over-counts this kernel's bytes"
+        r["frac_note"] = "no counter traffic on file for this version of the kernel (tools/profile_configs.sh); the algorithmic convention over-counts its bytes"
     r.update(extra)
     return r
 
