@@ -214,6 +214,7 @@ int32_t cx_halo_peers(cx_handle *h, int32_t n_peers, const int32_t *peer_rank, c
             return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_halo_peers: segment outside the halo lists of cx_halo_configure");
         peers.push_back(p);
     }
+    cx::ipc_destroy(h);              // the receive block's flags and connections are per peer entry
     h->peers.swap(peers);
     return CX_OK;
 }

@@ -210,15 +210,27 @@ int32_t cx_halo_ipc_connect(cx_handle *h, int32_t peer_index, const void *handle
                CX_ERR_INVALID_ARGUMENT, "cx_halo_ipc_connect: segment outside the neighbour's receive area");
     CX_HIP(h, hipSetDevice(h->cfg.device));
     auto &c = h->ipc_conn[peer_index];
-    if (c.opened) { (void)hipIpcCloseMemHandle(c.opened); c.opened = nullptr; }
+    if (c.opened) {          // re-connecting an entry: nobody else may still point into the mapping it opened
+        for (const auto &o : h->ipc_conn)
+            CX_REQUIRE(h, &o == &c || o.mapped != c.opened, CX_ERR_STATE, "cx_halo_ipc_connect: another peer entry uses the mapping this one opened; call cx_halo_ipc_alloc again");
+        (void)hipIpcCloseMemHandle(c.opened); c.opened = nullptr;
+    }
     char *base = (char *)same_process_base;
+    c.mapped = nullptr;
     if (handle64) {
-        hipIpcMemHandle_t hd;
-        std::memcpy(&hd, handle64, 64);
-        void *p = nullptr;
-        CX_HIP(h, hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess));
-        c.opened = p;
-        base = (char *)p;
+        // two peer entries may lead to the same neighbour (a ring of two ranks): a block is opened once per process
+        for (const auto &o : h->ipc_conn)
+            if (o.mapped && std::memcmp(o.handle, handle64, 64) == 0) { c.mapped = o.mapped; break; }
+        if (!c.mapped) {
+            hipIpcMemHandle_t hd;
+            std::memcpy(&hd, handle64, 64);
+            void *p = nullptr;
+            CX_HIP(h, hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess));
+            c.opened = p;
+            c.mapped = p;
+        }
+        std::memcpy(c.handle, handle64, 64);
+        base = (char *)c.mapped;
     }
     c.flag = (unsigned long long *)(base + (int64_t)remote_entry * kFlagStride);
     c.area[0] = (double2 *)(base + kFlagBytes) + remote_recv_off;

@@ -130,7 +130,7 @@ struct cx_handle {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_packed = nullptr, ev_recv = nullptr, ev_swept = nullptr;
     // deep-halo exchange through IPC-mapped receive areas and epoch flags (cx_api_ipc.hip)
-    struct IpcConn { void *opened = nullptr; unsigned long long *flag = nullptr; double2 *area[2] = {nullptr, nullptr}; bool connected = false; };
+    struct IpcConn { void *opened = nullptr; void *mapped = nullptr; char handle[64] = {0}; unsigned long long *flag = nullptr; double2 *area[2] = {nullptr, nullptr}; bool connected = false; };
     std::vector<IpcConn> ipc_conn;   // one per peer entry: where this rank pushes
     void *d_ipc_block = nullptr;     // this rank's flags + two receive areas (fine-grained, exported)
     void *d_ipc_local = nullptr;     // push completion counter, error word
