@@ -65,15 +65,20 @@ __device__ __forceinline__ void load_sys4(const double2 *p0, const double2 *p1, 
 constexpr int kIpcBlock = 1024, kIpcItems = 4;   // few, fat workgroups: the completion counter is one same-address atomic per workgroup
                                                  // (884 of them cost more than the copy itself: 14 us per push)
 
+// What travels is 16-byte UNITS: a scalar message is one (its double2), a message of dim 2 - 4 is ncp of them — the pairs of its
+// block-major storage form (cx_mv_core.h: slot_offset; pair q of slot s is unit ((s >> 8) ncp + q) 256 + (s & 255) of the buffer).
+// Unit u of a halo list is pair u % ncp of its message u / ncp; send / receive offsets and counts are in units.
+__device__ __forceinline__ int64_t ipc_unit(int32_t slot, int q, int ncp) { return ((int64_t)(slot >> 8) * ncp + q) * 256 + (slot & 255); }
+
 __device__ __forceinline__ void ipc_push_block(int64_t block, unsigned int nblocks, const double2 *__restrict__ f2v, const int32_t *__restrict__ send_slots,
-                                               int64_t n, const PushArgs &a, unsigned long long epoch, unsigned int *__restrict__ done) {
+                                               int64_t n, int ncp, const PushArgs &a, unsigned long long epoch, unsigned int *__restrict__ done) {
     const int64_t base = block * (kIpcBlock * kIpcItems) + threadIdx.x;
     int32_t slot[kIpcItems];
     double2 m[kIpcItems];
 #pragma unroll
-    for (int k = 0; k < kIpcItems; k++) { const int64_t i = base + k * kIpcBlock; slot[k] = i < n ? send_slots[i] : -1; }
+    for (int k = 0; k < kIpcItems; k++) { const int64_t i = base + k * kIpcBlock; slot[k] = i < n ? send_slots[i / ncp] : -1; }
 #pragma unroll
-    for (int k = 0; k < kIpcItems; k++) if (slot[k] >= 0) m[k] = f2v[slot[k]];
+    for (int k = 0; k < kIpcItems; k++) if (slot[k] >= 0) m[k] = f2v[ipc_unit(slot[k], (int)((base + k * kIpcBlock) % ncp), ncp)];
     __builtin_amdgcn_s_waitcnt(0);                           // the messages are in registers: no wait is left to be placed between the stores
     for (int p = 0; p < a.n_peers; p++) {                    // a message may go to several neighbours
         const int64_t off = a.send_off[p], cnt = a.send_count[p];
@@ -96,13 +101,13 @@ __device__ __forceinline__ void ipc_push_block(int64_t block, unsigned int nbloc
 }
 
 __device__ __forceinline__ void ipc_unpack_block(int64_t block, double2 *__restrict__ f2v, const int32_t *__restrict__ recv_slots,
-                                                 const double2 *__restrict__ area, int64_t n, const WaitArgs &w, unsigned long long epoch,
+                                                 const double2 *__restrict__ area, int64_t n, int ncp, const WaitArgs &w, unsigned long long epoch,
                                                  unsigned long long limit_ticks, int *__restrict__ err) {
     __shared__ int ok;
     const int64_t base = block * (kIpcBlock * kIpcItems) + threadIdx.x;
     int32_t slot[kIpcItems];
 #pragma unroll
-    for (int k = 0; k < kIpcItems; k++) { const int64_t i = base + k * kIpcBlock; slot[k] = i < n ? recv_slots[i] : -1; }   // while thread 0 waits
+    for (int k = 0; k < kIpcItems; k++) { const int64_t i = base + k * kIpcBlock; slot[k] = i < n ? recv_slots[i / ncp] : -1; }   // while thread 0 waits
     if (threadIdx.x == 0) {
         const unsigned long long t0 = wall_clock64();
         int good = 1;
@@ -125,34 +130,38 @@ __device__ __forceinline__ void ipc_unpack_block(int64_t block, double2 *__restr
     load_sys4(src[0], src[1], src[2], src[3], r);
 #pragma unroll
     for (int k = 0; k < kIpcItems; k++)
-        if (slot[k] >= 0) { double2 v; __builtin_memcpy(&v, &r[k], 16); f2v[slot[k]] = v; }
+        if (slot[k] >= 0) { double2 v; __builtin_memcpy(&v, &r[k], 16); f2v[ipc_unit(slot[k], (int)((base + k * kIpcBlock) % ncp), ncp)] = v; }
 }
 
-__global__ __launch_bounds__(kIpcBlock) void k_ipc_push(const double2 *__restrict__ f2v, const int32_t *__restrict__ send_slots, int64_t n, PushArgs a,
-                                                        unsigned long long epoch, unsigned int *__restrict__ done) {
-    ipc_push_block(blockIdx.x, gridDim.x, f2v, send_slots, n, a, epoch, done);
+__global__ __launch_bounds__(kIpcBlock) void k_ipc_push(const double2 *__restrict__ f2v, const int32_t *__restrict__ send_slots, int64_t n, int ncp,
+                                                        PushArgs a, unsigned long long epoch, unsigned int *__restrict__ done) {
+    ipc_push_block(blockIdx.x, gridDim.x, f2v, send_slots, n, ncp, a, epoch, done);
 }
 
 __global__ __launch_bounds__(kIpcBlock) void k_ipc_unpack(double2 *__restrict__ f2v, const int32_t *__restrict__ recv_slots, const double2 *__restrict__ area,
-                                                          int64_t n, WaitArgs w, unsigned long long epoch, unsigned long long limit_ticks,
+                                                          int64_t n, int ncp, WaitArgs w, unsigned long long epoch, unsigned long long limit_ticks,
                                                           int *__restrict__ err) {
-    ipc_unpack_block(blockIdx.x, f2v, recv_slots, area, n, w, epoch, limit_ticks, err);
+    ipc_unpack_block(blockIdx.x, f2v, recv_slots, area, n, ncp, w, epoch, limit_ticks, err);
 }
 
 // push and unpack of one exchange in ONE launch: they touch disjoint messages (what a rank sends belongs to owned variables, what it
 // receives to redundant ones).  The first n_push workgroups push — they are dispatched first and never wait — the others wait for
 // the neighbours' flags and unpack.
-__global__ __launch_bounds__(kIpcBlock) void k_ipc_exchange(double2 *__restrict__ f2v, const int32_t *__restrict__ send_slots, int64_t n_send, PushArgs a,
-                                                            unsigned int n_push, unsigned int *__restrict__ done, const int32_t *__restrict__ recv_slots,
-                                                            const double2 *__restrict__ area, int64_t n_recv, WaitArgs w, unsigned long long epoch,
-                                                            unsigned long long limit_ticks, int *__restrict__ err) {
-    if (blockIdx.x < n_push) ipc_push_block(blockIdx.x, n_push, f2v, send_slots, n_send, a, epoch, done);
-    else ipc_unpack_block(blockIdx.x - n_push, f2v, recv_slots, area, n_recv, w, epoch, limit_ticks, err);
+__global__ __launch_bounds__(kIpcBlock) void k_ipc_exchange(double2 *__restrict__ f2v, const int32_t *__restrict__ send_slots, int64_t n_send, int ncp,
+                                                            PushArgs a, unsigned int n_push, unsigned int *__restrict__ done,
+                                                            const int32_t *__restrict__ recv_slots, const double2 *__restrict__ area, int64_t n_recv,
+                                                            WaitArgs w, unsigned long long epoch, unsigned long long limit_ticks, int *__restrict__ err) {
+    if (blockIdx.x < n_push) ipc_push_block(blockIdx.x, n_push, f2v, send_slots, n_send, ncp, a, epoch, done);
+    else ipc_unpack_block(blockIdx.x - n_push, f2v, recv_slots, area, n_recv, ncp, w, epoch, limit_ticks, err);
 }
 
 }  // namespace
 
 namespace cx {
+
+// 16-byte units per message (scalar: 1; dim 2 - 4: the pairs of the storage form) and the buffer they live in
+static inline int ipc_ncp(const cx_handle *h) { return h->cfg.dim == 1 ? 1 : (int)(h->ncs / 2); }
+static inline double2 *ipc_messages(cx_handle *h) { return h->cfg.dim == 1 ? (double2 *)h->d_f2v : (double2 *)h->d_mv_f2v; }
 
 void ipc_destroy(cx_handle *h) {
     for (auto &c : h->ipc_conn)
@@ -169,13 +178,13 @@ extern "C" {
 
 int32_t cx_halo_ipc_alloc(cx_handle *h, void *handle64, void **local_base, int64_t *area_bytes) {
     CX_REQUIRE(h, h && h->has_graph && h->halo_state, CX_ERR_STATE, "cx_halo_ipc_alloc: call cx_halo_configure_state first");
-    CX_REQUIRE(h, h->cfg.dim == 1, CX_ERR_UNSUPPORTED, "cx_halo_ipc_alloc: scalar messages (dim 1); dim > 1 partitions exchange through cx_halo_state_exchange");
+    CX_REQUIRE(h, h->cfg.dim >= 1 && h->cfg.dim <= 4, CX_ERR_UNSUPPORTED, "cx_halo_ipc_alloc: dim 1 - 4; dim 64 partitions exchange through cx_halo_state_exchange");
     CX_REQUIRE(h, handle64 && local_base && area_bytes, CX_ERR_INVALID_ARGUMENT, "cx_halo_ipc_alloc: null argument");
     CX_REQUIRE(h, !h->peers.empty() && (int)h->peers.size() <= kMaxPeers, CX_ERR_STATE, "cx_halo_ipc_alloc: call cx_halo_peers first (1 to 8 neighbours)");
     CX_HIP(h, hipSetDevice(h->cfg.device));
     CX_HIP(h, hipStreamSynchronize(h->stream));
     cx::ipc_destroy(h);
-    const int64_t area = (((int64_t)h->recv_slots.size() * 16 + 4095) / 4096 + 1) * 4096;
+    const int64_t area = (((int64_t)h->recv_slots.size() * cx::ipc_ncp(h) * 16 + 4095) / 4096 + 1) * 4096;
     const size_t total = (size_t)(kFlagBytes + 2 * area);
     // fine-grained: coherent between agents while kernels run (what a flag protocol needs); plain hipMalloc memory is only
     // coherent at kernel boundaries
@@ -206,7 +215,7 @@ int32_t cx_halo_ipc_connect(cx_handle *h, int32_t peer_index, const void *handle
     CX_REQUIRE(h, peer_index >= 0 && peer_index < (int)h->ipc_conn.size(), CX_ERR_INVALID_ARGUMENT, "cx_halo_ipc_connect: no such peer entry");
     CX_REQUIRE(h, (handle64 != nullptr) != (same_process_base != nullptr), CX_ERR_INVALID_ARGUMENT, "cx_halo_ipc_connect: exactly one of handle64 / same_process_base");
     CX_REQUIRE(h, remote_entry >= 0 && remote_entry < kMaxPeers && remote_recv_off >= 0 && remote_area_bytes > 0 && remote_area_bytes % 4096 == 0 &&
-                  (remote_recv_off + h->peers[peer_index].send_count) * 16 <= remote_area_bytes,
+                  (remote_recv_off + h->peers[peer_index].send_count) * cx::ipc_ncp(h) * 16 <= remote_area_bytes,
                CX_ERR_INVALID_ARGUMENT, "cx_halo_ipc_connect: segment outside the neighbour's receive area");
     CX_HIP(h, hipSetDevice(h->cfg.device));
     auto &c = h->ipc_conn[peer_index];
@@ -233,8 +242,8 @@ int32_t cx_halo_ipc_connect(cx_handle *h, int32_t peer_index, const void *handle
         base = (char *)c.mapped;
     }
     c.flag = (unsigned long long *)(base + (int64_t)remote_entry * kFlagStride);
-    c.area[0] = (double2 *)(base + kFlagBytes) + remote_recv_off;
-    c.area[1] = (double2 *)(base + kFlagBytes + remote_area_bytes) + remote_recv_off;
+    c.area[0] = (double2 *)(base + kFlagBytes) + remote_recv_off * cx::ipc_ncp(h);
+    c.area[1] = (double2 *)(base + kFlagBytes + remote_area_bytes) + remote_recv_off * cx::ipc_ncp(h);
     c.connected = true;
     return CX_OK;
 }
@@ -249,19 +258,20 @@ static int32_t ipc_push(cx_handle *h, const char *who) {
     CX_REQUIRE(h, h->ipc_pushed == h->ipc_epoch, CX_ERR_STATE, std::string(who) + ": the previous push has not been followed by its unpack");
     PushArgs a{};
     a.n_peers = (int)h->peers.size();
+    const int ncp = cx::ipc_ncp(h);
     for (int p = 0; p < a.n_peers; p++)
         CX_REQUIRE(h, h->ipc_conn[p].connected, CX_ERR_STATE, std::string(who) + ": a peer entry is not connected (cx_halo_ipc_connect)");
     const unsigned long long epoch = (unsigned long long)(h->ipc_epoch + 1);
     const int par = (int)(epoch & 1);
     for (int p = 0; p < a.n_peers; p++) {
-        a.send_off[p] = h->peers[p].send_off; a.send_count[p] = h->peers[p].send_count;
+        a.send_off[p] = h->peers[p].send_off * ncp; a.send_count[p] = h->peers[p].send_count * ncp;
         a.remote_area[p] = h->ipc_conn[p].area[par];
         a.remote_flag[p] = h->ipc_conn[p].flag;
     }
-    const int64_t ns = (int64_t)h->send_slots.size();
+    const int64_t ns = (int64_t)h->send_slots.size() * ncp;
     // the push runs even with nothing to send: its last workgroup raises the flags the neighbours wait for
-    hipLaunchKernelGGL(k_ipc_push, dim3((unsigned)std::max<int64_t>((ns + kIpcBlock * kIpcItems - 1) / (kIpcBlock * kIpcItems), 1)), dim3(kIpcBlock), 0, h->stream, (const double2 *)h->d_f2v,
-                       (const int32_t *)h->d_send_slots, ns, a, epoch, (unsigned int *)h->d_ipc_local);
+    hipLaunchKernelGGL(k_ipc_push, dim3((unsigned)std::max<int64_t>((ns + kIpcBlock * kIpcItems - 1) / (kIpcBlock * kIpcItems), 1)), dim3(kIpcBlock), 0, h->stream,
+                       (const double2 *)cx::ipc_messages(h), (const int32_t *)h->d_send_slots, ns, ncp, a, epoch, (unsigned int *)h->d_ipc_local);
     h->ipc_pushed = (int64_t)epoch;
     CX_HIP(h, hipGetLastError());
     return CX_OK;
@@ -276,11 +286,12 @@ static int32_t ipc_unpack(cx_handle *h, const char *who) {
     const unsigned long long epoch = (unsigned long long)h->ipc_pushed;
     const int par = (int)(epoch & 1);
     for (int p = 0; p < w.n_peers; p++) w.flag[p] = (const unsigned long long *)((char *)h->d_ipc_block + (int64_t)p * kFlagStride);
-    const int64_t nr = (int64_t)h->recv_slots.size();
+    const int ncp = cx::ipc_ncp(h);
+    const int64_t nr = (int64_t)h->recv_slots.size() * ncp;
     const double2 *area = (const double2 *)((char *)h->d_ipc_block + kFlagBytes + (int64_t)par * h->ipc_area_bytes);
     const unsigned long long limit = (unsigned long long)(h->ipc_timeout_s * 1e8);       // wall_clock64: 100 MHz
-    hipLaunchKernelGGL(k_ipc_unpack, dim3((unsigned)std::max<int64_t>((nr + kIpcBlock * kIpcItems - 1) / (kIpcBlock * kIpcItems), 1)), dim3(kIpcBlock), 0, h->stream, (double2 *)h->d_f2v,
-                       (const int32_t *)h->d_recv_slots, area, nr, w, epoch, limit, (int *)h->d_ipc_local + 1);
+    hipLaunchKernelGGL(k_ipc_unpack, dim3((unsigned)std::max<int64_t>((nr + kIpcBlock * kIpcItems - 1) / (kIpcBlock * kIpcItems), 1)), dim3(kIpcBlock), 0, h->stream,
+                       cx::ipc_messages(h), (const int32_t *)h->d_recv_slots, area, nr, ncp, w, epoch, limit, (int *)h->d_ipc_local + 1);
     h->ipc_epoch = (int64_t)epoch;
     h->sweeps_since_exchange = 0;
     CX_HIP(h, hipGetLastError());
@@ -297,21 +308,22 @@ int32_t cx_halo_ipc_exchange(cx_handle *h) {
     PushArgs a{};
     WaitArgs w{};
     a.n_peers = w.n_peers = (int)h->peers.size();
+    const int ncp = cx::ipc_ncp(h);
     for (int p = 0; p < a.n_peers; p++)
         CX_REQUIRE(h, h->ipc_conn[p].connected, CX_ERR_STATE, std::string(who) + ": a peer entry is not connected (cx_halo_ipc_connect)");
     const unsigned long long epoch = (unsigned long long)(h->ipc_epoch + 1);
     const int par = (int)(epoch & 1);
     for (int p = 0; p < a.n_peers; p++) {
-        a.send_off[p] = h->peers[p].send_off; a.send_count[p] = h->peers[p].send_count;
+        a.send_off[p] = h->peers[p].send_off * ncp; a.send_count[p] = h->peers[p].send_count * ncp;
         a.remote_area[p] = h->ipc_conn[p].area[par];
         a.remote_flag[p] = h->ipc_conn[p].flag;
         w.flag[p] = (const unsigned long long *)((char *)h->d_ipc_block + (int64_t)p * kFlagStride);
     }
-    const int64_t ns = (int64_t)h->send_slots.size(), nr = (int64_t)h->recv_slots.size(), per = kIpcBlock * kIpcItems;
+    const int64_t ns = (int64_t)h->send_slots.size() * ncp, nr = (int64_t)h->recv_slots.size() * ncp, per = kIpcBlock * kIpcItems;
     const unsigned int n_push = (unsigned)std::max<int64_t>((ns + per - 1) / per, 1), n_unpack = (unsigned)std::max<int64_t>((nr + per - 1) / per, 1);
     const double2 *area = (const double2 *)((char *)h->d_ipc_block + kFlagBytes + (int64_t)par * h->ipc_area_bytes);
     const unsigned long long limit = (unsigned long long)(h->ipc_timeout_s * 1e8);       // wall_clock64: 100 MHz
-    hipLaunchKernelGGL(k_ipc_exchange, dim3(n_push + n_unpack), dim3(kIpcBlock), 0, h->stream, (double2 *)h->d_f2v, (const int32_t *)h->d_send_slots, ns, a,
+    hipLaunchKernelGGL(k_ipc_exchange, dim3(n_push + n_unpack), dim3(kIpcBlock), 0, h->stream, cx::ipc_messages(h), (const int32_t *)h->d_send_slots, ns, ncp, a,
                        n_push, (unsigned int *)h->d_ipc_local, (const int32_t *)h->d_recv_slots, area, nr, w, epoch, limit, (int *)h->d_ipc_local + 1);
     h->ipc_epoch = h->ipc_pushed = (int64_t)epoch;
     h->sweeps_since_exchange = 0;

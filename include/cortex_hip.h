@@ -316,7 +316,7 @@ int32_t cx_halo_state_exchange(cx_handle *h);
  *                             unpack.  Bit-identical to cx_halo_state_exchange + cx_sweep(n_sweeps), and falls back to exactly that
  *                             when the handle cannot split a sweep (no layers, dim > 1, another schedule). */
 int32_t cx_halo_exchange_sweep(cx_handle *h, int32_t n_sweeps);
-/* The same exchange WITHOUT a collective library (dim 1): every rank pushes its boundary state straight into a receive area of
+/* The same exchange WITHOUT a collective library (dim 1 - 4): every rank pushes its boundary state straight into a receive area of
  * the neighbour — device memory the neighbour exported with hipIpcGetMemHandle — and raises an epoch flag there; the neighbour's
  * unpack kernel waits for the flag.  Two launches on the handle's stream per exchange (push; wait + unpack) instead of pack,
  * RCCL kernel, unpack.  Results are bit-identical to cx_halo_state_exchange.
