@@ -56,7 +56,9 @@ static int mv_batches(void) {
                            ITEM(CX_ITEM_MESSAGE_TO_FACTOR, 2, 10), ITEM(CX_ITEM_MESSAGE_TO_VARIABLE, 1, 10)};
     const cx_item wm[] = {ITEM(CX_ITEM_INDIVIDUAL_MARGINAL, 1, 0), ITEM(CX_ITEM_INDIVIDUAL_MARGINAL, 2, 0), ITEM(CX_ITEM_INDIVIDUAL_MARGINAL, 3, 0)};
     CHECK(cx_update_batch(h, w0, 3));
-    for (int i = 0; i < 8; i++) CHECK(cx_update_batch(h, &seq[i], 1));    /* the sequential part of the schedule: one signal per wavefront */
+    /* the sequential part of the schedule, one signal per wavefront, without waiting between the launches (what a scheduler does
+     * between two of them does not read the device); cx_get_marginals below waits for the stream */
+    for (int i = 0; i < 8; i++) CHECK(cx_update_batch_async(h, &seq[i], 1));
     CHECK(cx_update_batch(h, wm, 3));
     double marg[T3 * (D + D * D)];
     CHECK(cx_get_marginals(h, T3, xv, marg));
