@@ -75,10 +75,16 @@ __device__ __forceinline__ void ipc_push_block(int64_t block, unsigned int nbloc
     const int64_t base = block * (kIpcBlock * kIpcItems) + threadIdx.x;
     int32_t slot[kIpcItems];
     double2 m[kIpcItems];
+    int q[kIpcItems];                                        // unit -> (message, pair): 32-bit division, none at all for scalar messages
 #pragma unroll
-    for (int k = 0; k < kIpcItems; k++) { const int64_t i = base + k * kIpcBlock; slot[k] = i < n ? send_slots[i / ncp] : -1; }
+    for (int k = 0; k < kIpcItems; k++) {
+        const int64_t i = base + k * kIpcBlock;
+        const unsigned int u = (unsigned int)i, mi = ncp == 1 ? u : u / (unsigned int)ncp;
+        q[k] = ncp == 1 ? 0 : (int)(u - mi * (unsigned int)ncp);
+        slot[k] = i < n ? send_slots[mi] : -1;
+    }
 #pragma unroll
-    for (int k = 0; k < kIpcItems; k++) if (slot[k] >= 0) m[k] = f2v[ipc_unit(slot[k], (int)((base + k * kIpcBlock) % ncp), ncp)];
+    for (int k = 0; k < kIpcItems; k++) if (slot[k] >= 0) m[k] = f2v[ipc_unit(slot[k], q[k], ncp)];
     __builtin_amdgcn_s_waitcnt(0);                           // the messages are in registers: no wait is left to be placed between the stores
     for (int p = 0; p < a.n_peers; p++) {                    // a message may go to several neighbours
         const int64_t off = a.send_off[p], cnt = a.send_count[p];
@@ -106,8 +112,14 @@ __device__ __forceinline__ void ipc_unpack_block(int64_t block, double2 *__restr
     __shared__ int ok;
     const int64_t base = block * (kIpcBlock * kIpcItems) + threadIdx.x;
     int32_t slot[kIpcItems];
+    int q[kIpcItems];
 #pragma unroll
-    for (int k = 0; k < kIpcItems; k++) { const int64_t i = base + k * kIpcBlock; slot[k] = i < n ? recv_slots[i / ncp] : -1; }   // while thread 0 waits
+    for (int k = 0; k < kIpcItems; k++) {                    // while thread 0 waits
+        const int64_t i = base + k * kIpcBlock;
+        const unsigned int u = (unsigned int)i, mi = ncp == 1 ? u : u / (unsigned int)ncp;
+        q[k] = ncp == 1 ? 0 : (int)(u - mi * (unsigned int)ncp);
+        slot[k] = i < n ? recv_slots[mi] : -1;
+    }
     if (threadIdx.x == 0) {
         const unsigned long long t0 = wall_clock64();
         int good = 1;
@@ -130,7 +142,7 @@ __device__ __forceinline__ void ipc_unpack_block(int64_t block, double2 *__restr
     load_sys4(src[0], src[1], src[2], src[3], r);
 #pragma unroll
     for (int k = 0; k < kIpcItems; k++)
-        if (slot[k] >= 0) { double2 v; __builtin_memcpy(&v, &r[k], 16); f2v[ipc_unit(slot[k], (int)((base + k * kIpcBlock) % ncp), ncp)] = v; }
+        if (slot[k] >= 0) { double2 v; __builtin_memcpy(&v, &r[k], 16); f2v[ipc_unit(slot[k], q[k], ncp)] = v; }
 }
 
 __global__ __launch_bounds__(kIpcBlock) void k_ipc_push(const double2 *__restrict__ f2v, const int32_t *__restrict__ send_slots, int64_t n, int ncp,
@@ -181,6 +193,8 @@ int32_t cx_halo_ipc_alloc(cx_handle *h, void *handle64, void **local_base, int64
     CX_REQUIRE(h, h->cfg.dim >= 1 && h->cfg.dim <= 4, CX_ERR_UNSUPPORTED, "cx_halo_ipc_alloc: dim 1 - 4; dim 64 partitions exchange through cx_halo_state_exchange");
     CX_REQUIRE(h, handle64 && local_base && area_bytes, CX_ERR_INVALID_ARGUMENT, "cx_halo_ipc_alloc: null argument");
     CX_REQUIRE(h, !h->peers.empty() && (int)h->peers.size() <= kMaxPeers, CX_ERR_STATE, "cx_halo_ipc_alloc: call cx_halo_peers first (1 to 8 neighbours)");
+    CX_REQUIRE(h, (int64_t)std::max(h->send_slots.size(), h->recv_slots.size()) * cx::ipc_ncp(h) < (1ll << 31), CX_ERR_UNSUPPORTED,
+               "cx_halo_ipc_alloc: a halo list of 2^31 or more 16-byte units");
     CX_HIP(h, hipSetDevice(h->cfg.device));
     CX_HIP(h, hipStreamSynchronize(h->stream));
     cx::ipc_destroy(h);
