@@ -56,9 +56,12 @@ def parse(argv=None):
                     help="strong (default, BASELINE config 4): the ONE N x N grid is cut into row blocks over the ranks; "
                          "weak: every rank owns an N x N strip of an (N*ranks) x N grid")
     ap.add_argument("--no-weak-figure", action="store_true", help="N > 1, strong scaling: skip the second (weak-scaling) measurement")
-    ap.add_argument("--halo-depth", type=int, default=int(os.environ.get("CX_HALO_DEPTH", "16")),
+    ap.add_argument("--halo-depth", default=os.environ.get("CX_HALO_DEPTH", "auto"),
                     help="deep halo: each rank keeps this many redundant rows of its neighbours and exchanges their state once "
-                         "per that many sweeps (bit-identical to the un-partitioned sweep); 0 = one message halo per sweep")
+                         "per that many sweeps (bit-identical to the un-partitioned sweep); 0 = one message halo per sweep; "
+                         "auto (default): N > 1 times a few batches at depths 12, 16, 24 and 32 before the warm-up and keeps the fastest "
+                         "— what an exchange costs depends on the links between the GPUs, which this program cannot know beforehand "
+                         "(on one GPU, the rank as its own neighbour: 16)")
     ap.add_argument("--cpu-configs", action="store_true", help="CPU baselines of configs C1, C2 and the C4 sample only (no GPU needed)")
     ap.add_argument("--self-halo", action="store_true",
                     help="N = 1 experiment: a cylinder whose wrap-around cut makes rank 0 its own halo neighbour")
@@ -520,6 +523,33 @@ def run_rank(args):
 
     dog = _watchdog(1200.0)
     N = args.grid
+    depth_trials = None
+    if str(args.halo_depth) == "auto":
+        args.halo_depth = 16
+        if world > 1:
+            # the depth of the halo trades redundant rows (more per sweep) against exchanges (fewer): which wins depends on what an
+            # exchange costs between THESE GPUs.  A few batches at each candidate, every rank timing the same region; all ranks see
+            # the same maxima and take the same decision.  Not part of the warm-up or of the timed regions.
+            rows_min = N if args.scaling == "weak" else N // world
+            depth_trials = {}
+            for cand in (12, 16, 24, 32):
+                if cand > rows_min:
+                    continue
+                args.halo_depth = cand
+                try:
+                    wt = Workload(args, args.scaling, rank, world, local_rank, backend, dist, torch, cx, L)
+                    wt.run(2 * cand)
+                    tw, _ = timed_regions(wt, 384, 3, dist, torch, red_dev)       # 384 = 4 x 96 sweeps: whole batches at every candidate
+                    depth_trials[cand] = min(tw) / 384 * 1e3
+                    wt.close()
+                except Exception as e:      # a candidate that cannot be built is no candidate (all ranks build the same cuts)
+                    if rank == 0:
+                        print(f"[bench] halo depth {cand}: {e!r}", file=sys.stderr)
+            args.halo_depth = min(depth_trials, key=depth_trials.get) if depth_trials else 16
+            if rank == 0:
+                print(f"[bench] halo depth trials (ms per sweep): {depth_trials} -> {args.halo_depth}", file=sys.stderr)
+    else:
+        args.halo_depth = int(args.halo_depth)
     w = Workload(args, args.scaling, rank, world, local_rank, backend, dist, torch, cx, L)
     dev = w.dev
 
@@ -632,7 +662,8 @@ def run_rank(args):
                                                     f"loaded per owned one, {tiles['lds_bytes_per_workgroup']} B LDS per workgroup; marginals written by the "
                                                     f"second sweep of each launch)" if dom_id == L.KERNEL_TILED else "") +
                                    ("" if w.halo_kind is None else f" + {w.halo_kind}"),
-                       "partition": f"{world} row blocks", "seed": args.seed},
+                       "partition": f"{world} row blocks", "seed": args.seed,
+                       **({"halo_depth": args.halo_depth, "halo_depth_trials_ms_per_sweep": depth_trials} if depth_trials else {})},
             "timed_regions": {"count": len(walls), "reported": "median", "ms_per_step_each": [x / args.steps * 1e3 for x in walls],
                               "device_ms_per_step_each": [x / args.steps for x in devs]},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
