@@ -51,7 +51,11 @@ def parse(argv=None):
                     help="2: the two-sweeps-per-launch experiment (cx_tiles.hip; bit-identical, measured slower: DESIGN.md §4c)")
     ap.add_argument("--materialize", action="store_true", help="also store every variable→factor message each sweep")
     ap.add_argument("--halo", choices=["ipc", "rccl", "torch"], default=os.environ.get("CX_HALO", "ipc"),
-                    help="N > 1: exchange issued by the library on RCCL (default) or by torch.distributed isend/irecv")
+                    help="N > 1: the exchange pushed by the library into the neighbours' IPC-mapped receive areas (default; audited, "
+                         "RCCL as the fallback), issued by the library on RCCL, or by torch.distributed isend/irecv")
+    ap.add_argument("--ipc-overlap", action="store_true",
+                    help="--halo ipc: the owned part of a batch's first sweep between push and unpack (cx_halo_ipc_exchange_sweep); "
+                         "with --halo-depth auto the two forms are timed and the faster is kept")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
                     help="strong (default, BASELINE config 4): the ONE N x N grid is cut into row blocks over the ranks; "
                          "weak: every rank owns an N x N strip of an (N*ranks) x N grid")
@@ -378,7 +382,7 @@ class Workload:
                     return e if e or okf.item() == 1 else "another rank failed"
                 ex = None
                 try:
-                    ex = partition.DeepHaloIpc(dev, part, dist, torch, tdev)
+                    ex = partition.DeepHaloIpc(dev, part, dist, torch, tdev, overlap=bool(getattr(args, "ipc_overlap", False)))
                     dev.halo_ipc_set_timeout(30.0)
                     if os.environ.get("CX_BENCH_IPC_FAIL") == str(rank):      # rehearsal knob: one rank fails, ALL must fall back
                         raise RuntimeError("injected failure (CX_BENCH_IPC_FAIL)")
@@ -394,7 +398,9 @@ class Workload:
                     err = agreed(err)
                 if err is None:
                     exchange = self.ipc = ex
-                    self.halo_kind = "pushed into the neighbours' IPC-mapped receive areas behind an epoch flag, one launch per exchange (audited at start)"
+                    self.halo_kind = ("pushed into the neighbours' IPC-mapped receive areas behind an epoch flag" +
+                                      (", the owned part of a batch's first sweep between push and unpack" if getattr(args, "ipc_overlap", False)
+                                       else ", one launch per exchange") + " (audited at start)")
                 elif rank == 0:
                     print(f"[bench] IPC exchange unavailable ({err}); falling back", file=sys.stderr)
                 err = None
@@ -546,8 +552,28 @@ def run_rank(args):
                     if rank == 0:
                         print(f"[bench] halo depth {cand}: {e!r}", file=sys.stderr)
             args.halo_depth = min(depth_trials, key=depth_trials.get) if depth_trials else 16
+            # ... and, at that depth, the exchange AROUND the owned part of the first sweep (cx_halo_ipc_exchange_sweep): the same
+            # results; whether hiding the neighbours' pushes behind one interior sweep pays for the extra launch is a property of
+            # the links as well (on one GPU it does not)
+            if depth_trials and args.halo == "ipc":
+                try:
+                    args.ipc_overlap = True
+                    wt = Workload(args, args.scaling, rank, world, local_rank, backend, dist, torch, cx, L)
+                    if wt.ipc is not None:
+                        wt.run(2 * args.halo_depth)
+                        tw, _ = timed_regions(wt, 384, 3, dist, torch, red_dev)
+                        depth_trials["%d, exchange around the owned part of sweep 1" % args.halo_depth] = min(tw) / 384 * 1e3
+                        args.ipc_overlap = min(tw) / 384 * 1e3 < depth_trials[args.halo_depth]
+                    else:
+                        args.ipc_overlap = False
+                    wt.close()
+                except Exception as e:
+                    args.ipc_overlap = False
+                    if rank == 0:
+                        print(f"[bench] overlapped IPC exchange: {e!r}", file=sys.stderr)
             if rank == 0:
-                print(f"[bench] halo depth trials (ms per sweep): {depth_trials} -> {args.halo_depth}", file=sys.stderr)
+                print(f"[bench] halo trials (ms per sweep): {depth_trials} -> depth {args.halo_depth}" +
+                      (", exchange around the owned part of sweep 1" if getattr(args, "ipc_overlap", False) else ""), file=sys.stderr)
     else:
         args.halo_depth = int(args.halo_depth)
     w = Workload(args, args.scaling, rank, world, local_rank, backend, dist, torch, cx, L)

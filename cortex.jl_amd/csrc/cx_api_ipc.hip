@@ -345,6 +345,41 @@ int32_t cx_halo_ipc_exchange(cx_handle *h) {
     return CX_OK;
 }
 
+// One batch with the exchange AROUND the owned part of the first sweep, all on the handle's stream:
+//     push  |  first sweep, slices of owned variables only  |  wait + unpack  |  rest of the first sweep  |  sweeps 2 .. n
+// What the unpack rewrites are messages INTO redundant variables, which the slices of owned variables never read; so while this
+// rank computes its interior the neighbours' pushes travel, and the wait in front of the unpack is shorter by one interior sweep.
+// Bit-identical to cx_halo_ipc_exchange + cx_sweep(n) (every message is written by the same thread from the same inputs), which is
+// also what runs when the sweep cannot be split (no layers set, dim > 1, another schedule).  On ONE GPU (a rank as its own neighbour)
+// the flags are up before the unpack starts either way and the split only costs a launch: whether it pays between GPUs is for a
+// measurement there to say (bench.py times both forms at N > 1).
+int32_t cx_halo_ipc_exchange_sweep(cx_handle *h, int32_t n_sweeps) {
+    CX_REQUIRE(h, h && h->has_graph && h->halo_state && h->d_ipc_block, CX_ERR_STATE, "cx_halo_ipc_exchange_sweep: call cx_halo_ipc_alloc first");
+    CX_REQUIRE(h, n_sweeps >= 1, CX_ERR_INVALID_ARGUMENT, "cx_halo_ipc_exchange_sweep: n_sweeps < 1");
+    const bool split = h->cfg.dim == 1 && h->cfg.schedule == CX_SCHED_FUSED && h->halo_depth > 0 && h->big_vars.empty() && !h->peers.empty() &&
+                       h->own_slice_hi >= h->own_slice_lo && h->cfg.sweeps_per_launch != 2;
+    if (!split) {
+        const int32_t rc = cx_halo_ipc_exchange(h);
+        return rc != CX_OK ? rc : cx_sweep(h, n_sweeps);
+    }
+    int32_t rc = ipc_push(h, "cx_halo_ipc_exchange_sweep");
+    if (rc != CX_OK) return rc;
+    const int L = h->halo_depth;         // sweep 1 after an exchange runs every layer <= depth
+    const int lo = h->trim_hi[L] >= h->trim_lo[L] ? h->trim_lo[L] : 0, hi = h->trim_hi[L] >= h->trim_lo[L] ? h->trim_hi[L] : (int)h->nslices - 1;
+    h->run_slice0 = h->own_slice_lo; h->run_nslices = h->own_slice_hi - h->own_slice_lo + 1;
+    sweep_main(h, false);
+    rc = ipc_unpack(h, "cx_halo_ipc_exchange_sweep");
+    if (rc != CX_OK) { h->run_slice0 = 0; h->run_nslices = 0; return rc; }
+    h->run_slice0 = lo; h->run_nslices = hi - lo + 1; h->run_excl_lo = h->own_slice_lo; h->run_excl_hi = h->own_slice_hi;
+    sweep_main(h, false);
+    h->run_excl_lo = 1; h->run_excl_hi = 0; h->run_slice0 = 0; h->run_nslices = 0;
+    sweep_finish(h);
+    h->alt_two_back = false;
+    h->sweeps_since_exchange = 1;
+    CX_HIP(h, hipGetLastError());
+    return n_sweeps > 1 ? cx_sweep(h, n_sweeps - 1) : CX_OK;
+}
+
 // Waits for the stream and reports whether any unpack gave up waiting for a neighbour (then its redundant rows are stale and
 // every result since is void).
 int32_t cx_halo_ipc_status(cx_handle *h, int32_t *timed_out, int64_t *exchanges) {

@@ -272,6 +272,10 @@ class DeviceGraph:
     def halo_ipc_exchange(self):
         self._check(self.lib.cx_halo_ipc_exchange(self.h))
 
+    def halo_ipc_exchange_sweep(self, n: int):
+        """the exchange around the owned part of the first of n sweeps"""
+        self._check(self.lib.cx_halo_ipc_exchange_sweep(self.h, int(n)))
+
     def halo_ipc_push(self):
         self._check(self.lib.cx_halo_ipc_push(self.h))
 

@@ -511,8 +511,10 @@ class DeepHaloIpc:
     process (`connect=False`, then `connect({rank: info})`), connect by device address.  A rank whose allocation or connection
     fails raises on EVERY rank after the handles have been gathered, so that all ranks can fall back together."""
 
-    def __init__(self, dev, part: Partition, dist=None, torch=None, device=None, connect=True):
-        self.dev, self.depth, self.k, self.part, self.fresh = dev, part.depth, 0, part, False
+    def __init__(self, dev, part: Partition, dist=None, torch=None, device=None, connect=True, overlap: bool = False):
+        """overlap: cx_halo_ipc_exchange_sweep — the owned part of a batch's first sweep between the push and the unpack (the
+        neighbours' pushes travel meanwhile).  Bit-identical; costs a launch where nothing travels (one GPU)."""
+        self.dev, self.depth, self.k, self.part, self.fresh, self.overlap = dev, part.depth, 0, part, False, overlap
         dev.halo_configure_state(part.send_var, part.send_fac, part.recv_var, part.recv_fac)
         if part.layer_var is not None and part.depth and dev.dim == 1:
             dev.halo_set_layers(part.layer_var, part.layer, part.depth)    # trimmed sweeps between exchanges
@@ -561,12 +563,15 @@ class DeepHaloIpc:
     def sweep(self, n: int = 1):
         while n > 0:
             run = min(n, self.depth - self.k % self.depth)
-            if self.k % self.depth == 0:
-                if self.fresh:
-                    self.fresh = False              # `audit` has just made this exchange
-                else:
-                    self.dev.halo_ipc_exchange()
-            self.dev.sweep(run)
+            if self.k % self.depth == 0 and not self.fresh and self.overlap:
+                self.dev.halo_ipc_exchange_sweep(run)
+            else:
+                if self.k % self.depth == 0:
+                    if self.fresh:
+                        self.fresh = False          # `audit` has just made this exchange
+                    else:
+                        self.dev.halo_ipc_exchange()
+                self.dev.sweep(run)
             self.k += run
             n -= run
 

@@ -339,6 +339,11 @@ int32_t cx_halo_ipc_connect(cx_handle *h, int32_t peer_index, const void *handle
 int32_t cx_halo_ipc_push(cx_handle *h);
 int32_t cx_halo_ipc_unpack(cx_handle *h);
 int32_t cx_halo_ipc_exchange(cx_handle *h);
+/*   cx_halo_ipc_exchange_sweep : one batch = push | the owned part of the first sweep | wait + unpack | the rest of that sweep |
+ *                           sweeps 2 .. n, all on the handle's stream: the neighbours' pushes travel while this rank computes
+ *                           its interior.  Bit-identical to cx_halo_ipc_exchange + cx_sweep(n), and exactly that when the sweep
+ *                           cannot be split (no cx_halo_set_layers, dim > 1, another schedule). */
+int32_t cx_halo_ipc_exchange_sweep(cx_handle *h, int32_t n_sweeps);
 int32_t cx_halo_ipc_status(cx_handle *h, int32_t *timed_out, int64_t *exchanges);
 int32_t cx_halo_ipc_set_timeout(cx_handle *h, double seconds);
 

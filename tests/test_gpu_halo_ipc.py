@@ -19,18 +19,27 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("rows,cols,depth,sweeps", [(30, 64, 4, 11), (120, 300, 8, 27), (64, 256, 16, 33)])
-def test_ipc_exchange_self_neighbour(hip_lib, rows, cols, depth, sweeps):
+def test_ipc_exchange_self_neighbour(hip_lib, rows, cols, depth, sweeps, overlap):
+    """overlap: cx_halo_ipc_exchange_sweep — push, the slices of owned variables only, wait + unpack, the rest of the first sweep
+    (two launches of the sweep kernel for that sweep)."""
     part = partition.deep_self(rows, cols, depth, seed=8)
     dev = cx.DeviceGraph(schedule=L.SCHED_FUSED)
     cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
-    ex = partition.DeepHaloIpc(dev, part)
+    ex = partition.DeepHaloIpc(dev, part, overlap=overlap)
     dev.halo_ipc_set_timeout(5.0)
     import torch
 
     assert ex.audit(None, torch, torch.device("cuda", 0))      # the exchange of the first batch, audited
+    dev.profile_enable(1)
     ex.sweep(sweeps)
-    assert ex.check() == -(-sweeps // depth)
+    _ms, launches = dev.profile_read(L.KERNEL_FUSED)
+    dev.profile_enable(0)
+    exchanges = -(-sweeps // depth)
+    assert ex.check() == exchanges
+    # the audited first exchange was made on its own; every later batch of the overlapped form splits its first sweep
+    assert launches == sweeps + (exchanges - 1 if overlap else 0)
     plain = cx.DeviceGraph(schedule=L.SCHED_FUSED)
     cx.synth.load_into_device(part.model, plain, seed_variance=1e6)
     plain.sweep(sweeps)
@@ -176,18 +185,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,rows,cols,depth,sweeps,skew", [(2, 64, 128, 4, 19, 0.0), (2, 354, 1415, 16, 35, 0.0), (3, 96, 128, 4, 27, 0.15),
-                                                              (2, 64, 128, 2, 21, 0.1)])
-def test_processes_on_one_gpu(hip_lib, tmp_path, world, rows, cols, depth, sweeps, skew):
+@pytest.mark.parametrize("world,rows,cols,depth,sweeps,skew,overlap", [(2, 64, 128, 4, 19, 0.0, 0), (2, 354, 1415, 16, 35, 0.0, 0), (3, 96, 128, 4, 27, 0.15, 0),
+                                                                      (2, 64, 128, 2, 21, 0.1, 0), (2, 354, 1415, 16, 51, 0.0, 1), (3, 96, 128, 4, 27, 0.15, 1)])
+def test_processes_on_one_gpu(hip_lib, tmp_path, world, rows, cols, depth, sweeps, skew, overlap):
     """Two or three ranks, one PROCESS each, all on cuda:0: each opens its neighbours' hipIpcMemHandles and pushes into them.
     (354 x 1415 at depth 16 is the volume of two neighbouring ranks of bench.py --gpus 8; three ranks give the middle one two
-    neighbours.)  skew > 0: the ranks take turns idling between batches, so pushes arrive early and late relative to the reader."""
+    neighbours.)  skew > 0: the ranks take turns idling between batches, so pushes arrive early and late relative to the reader.
+    overlap: cx_halo_ipc_exchange_sweep (the owned part of the first sweep between push and unpack)."""
     out, port, procs = str(tmp_path / "res"), _free_port(), []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ipc_worker.py"), str(rows), str(cols), str(depth),
-                                       str(sweeps), out, str(skew)], env=env, cwd=ROOT))
+                                       str(sweeps), out, str(skew), str(overlap)], env=env, cwd=ROOT))
     try:
         for p in procs:
             assert p.wait(timeout=300) == 0

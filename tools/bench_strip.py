@@ -75,7 +75,7 @@ def main():
         ex = None
         if a.exchange:
             if a.ipc:
-                ex = partition.DeepHaloIpc(dev, self_exchange(part))
+                ex = partition.DeepHaloIpc(dev, self_exchange(part), overlap=a.overlap_exchange)
             else:
                 ex = partition.DeepHaloRccl(dev, self_exchange(part), None, torch, torch.device("cuda", 0), overlap=a.overlap_exchange)
         elif not a.no_trim:     # no exchange: the trimming schedule restarts every `depth` sweeps as if one had happened
@@ -109,7 +109,7 @@ def main():
         rows_owned = len(part.owned_x) // N
         rows_held = st["n_variables"] // N
         print(json.dumps({"strip": f"rank {a.rank} of {a.world}, {rows_owned} owned rows + 2 x {depth} redundant ({rows_held} rows held incl. stand-ins)",
-                          "depth": depth, "exchange": ("IPC push + flag, on the compute stream" if a.ipc else "overlapped with the owned part of the first sweep" if a.overlap_exchange else "RCCL, serial on the compute stream") if a.exchange else False, "us_per_sweep_wall": best[0], "us_per_sweep_device": best[1],
+                          "depth": depth, "exchange": (("IPC push, owned part of sweep 1, unpack, rest: one stream" if a.overlap_exchange else "IPC push + flag, on the compute stream") if a.ipc else "overlapped with the owned part of the first sweep" if a.overlap_exchange else "RCCL, serial on the compute stream") if a.exchange else False, "us_per_sweep_wall": best[0], "us_per_sweep_device": best[1],
                           "whole_grid_us_per_sweep": whole_us, "ideal_us": whole_us / a.world,
                           "ratio_to_ideal": best[0] / (whole_us / a.world), "speedup_if_all_ranks_like_this": whole_us / best[0],
                           "slices": st["n_slices"], "halo_messages": int(len(part.recv_var))}), flush=True)
