@@ -142,6 +142,7 @@ class Handle {
     void halo_state_exchange() { check(cx_halo_state_exchange(h_)); }
     void halo_exchange_sweep(int n_sweeps) { check(cx_halo_exchange_sweep(h_, n_sweeps)); }
     void halo_ipc_exchange() { check(cx_halo_ipc_exchange(h_)); }
+    void halo_ipc_exchange_sweep(int n_sweeps) { check(cx_halo_ipc_exchange_sweep(h_, n_sweeps)); }
     void sweep_exchange(int32_t n = 1) { check(cx_sweep_exchange(h_, n)); }
 
   private:
