@@ -200,7 +200,33 @@ def vmp(n=1_000_000, only=None):
         out.append({"config": "VMP", "workload": f"{name} VMP, SSM with unknown precisions, n={n} states ({st['n_edges']} edges, {st['n_factors']} factors)",
                     "ms_per_iteration": dt * 1e3, "messages_per_iteration": st["n_messages_per_sweep"],
                     "messages_per_s": st["n_messages_per_sweep"] / dt, "E_ssnoise": g[0, 0] * g[0, 1], "E_obsnoise": g[1, 0] * g[1, 1]})
+        tr = vmp_traffic(name) if n == 1_000_000 else None
+        if tr:
+            out[-1]["roofline"] = roofline("hbm", tr[0] / dt / 1e9, HBM_PEAK_GBS, "GB/s", tr[0],
+                                           kernel="all kernels of one iteration (state pass + both precisions)",
+                                           basis="counter traffic of one iteration / iteration time", traffic_source=tr[1])
+        else:
+            out[-1]["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                                   "frac_note": "no counter traffic on file for this version of the kernels (tools/profile_vmp.sh)"}
     return out
+
+
+def vmp_traffic(family):
+    """HBM bytes of one iteration of a variational family from the newest profiles/r*_vmp_rocprof.json (tools/profile_vmp.sh) whose
+    kernel sources are the current ones; None otherwise"""
+    import glob
+    from importlib import import_module
+    sha = import_module("cortex.jl_amd.build").sources_sha16
+    want = sha("k_mf_normal") + sha("k_chain_apply")
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_vmp_rocprof.json"))):
+        try:
+            d = json.load(open(f)).get(family, {})
+        except Exception:
+            continue
+        if d.get("sources_sha16") == want and d.get("hbm_bytes_per_iteration"):
+            best = (float(d["hbm_bytes_per_iteration"]), os.path.relpath(f, ROOT))
+    return best
 
 
 if __name__ == "__main__":

@@ -20,6 +20,11 @@ done
 R=$R TAG=$TAG python3 - <<'PY'
 import csv, glob, collections, json, os
 R = os.environ["R"]; TAG = os.environ["TAG"]
+import sys
+sys.path.insert(0, R)
+from importlib import import_module
+_sha = import_module("cortex.jl_amd.build").sources_sha16
+SHA = _sha("k_mf_normal") + _sha("k_chain_apply")       # the families' own kernels + the chain scan the structured one runs
 ITER = 60      # bench_configs.vmp: 10 warm-up + 50 timed iterations
 def per_kernel(d, counter=None):
     out = collections.defaultdict(list)
@@ -50,7 +55,8 @@ for fam in ("structured", "mean_field"):
         t_us += n * avg; b_tot += n * (rd + ww)
         lines.append(f"| `{k}` | {n} | {avg:.1f} | {rd/1e6:.2f} | {ww/1e6:.2f} |")
     t_us = t_us or float("nan")
-    res[fam] = {"kernel_us_per_iteration": t_us, "hbm_bytes_per_iteration": b_tot, "GBps": b_tot / t_us / 1e3}
+    res[fam] = {"kernel_us_per_iteration": t_us, "hbm_bytes_per_iteration": b_tot, "GBps": b_tot / t_us / 1e3,
+                "sources_sha16": SHA, "sources_note": "sha256[:16] over cx_vmp.hip and the chain-scan kernels' sources: the figure is refused once they change"}
     lines += ["", f"per iteration: {t_us:.1f} us of kernels, {b_tot/1e6:.1f} MB of HBM traffic = {b_tot/t_us/1e3:.0f} GB/s = **{b_tot/t_us/1e3/8000:.2f}** of the 8 TB/s peak", ""]
 open(f"{R}/gpurun_out/profiles_{TAG}/{TAG}_vmp_rocprof.md", "w").write("\n".join(lines) + "\n")
 json.dump(res, open(f"{R}/gpurun_out/profiles_{TAG}/{TAG}_vmp_rocprof.json", "w"), indent=1)
