@@ -98,6 +98,7 @@ SIGNATURES = {
     "cx_halo_ipc_status": (_i32, [_vp, _pi32, _pi64]),
     "cx_halo_ipc_set_timeout": (_i32, [_vp, C.c_double]),
     "cx_chain_block_maps": (_i32, [_vp, _pd, _pd, _pd, _pd, _pi64, _pi64, _pi64]),
+    "cx_chain_plan_stats": (_i32, [_vp, _pi64]),
     "cx_set_marginals": (_i32, [_vp, _i64, _pi64, _i32, _pd]),
     "cx_update_marginals": (_i32, [_vp, _i64, _pi64]),
     "cx_state_bytes": (_i32, [_vp, _pi64]),

@@ -22,6 +22,7 @@ void dev_free_all(cx_handle *h) {
                     h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_side, h->d_chain_totals, h->d_chain_tab_fwd, h->d_chain_tab_bwd,
                     h->d_mvc_side, h->d_mvc_totals, h->d_mvc_side_l, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix, h->d_mvc_wave_carry, h->d_mvc_block};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    cx::chain64_free(h);
     cx::tiles_free(h);
     if (h->d_f2v_tmp) (void)hipFree(h->d_f2v_tmp);
     h->d_f2v_tmp = nullptr; h->alt_two_back = false;
@@ -87,8 +88,8 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
         return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: the variational families need dim == 1");
     if (config->family == CX_FAMILY_NATURAL2 && (config->dim != 1 || config->schedule == CX_SCHED_CHAIN_SCAN))
         return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: CX_FAMILY_NATURAL2 needs dim == 1 and the flooding or fused schedule");
-    if (config->dim > 1 && config->schedule != CX_SCHED_FUSED && !(config->schedule == CX_SCHED_CHAIN_SCAN && config->dim <= 4))
-        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: dim > 1 runs the fused schedule, dim 2..4 also the chain-scan schedule");
+    if (config->dim > 1 && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN)
+        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: dim > 1 runs the fused and the chain-scan schedule");
     if (config->schedule != CX_SCHED_FLOODING && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN)
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: unknown schedule");
     if (config->sweeps_per_launch < 0 || config->sweeps_per_launch > 2)

@@ -88,6 +88,7 @@ int32_t mv64_set_messages(cx_handle *h, int64_t n, const std::vector<int32_t> &i
         if (newly) {     // the work lists depend on WHICH variables are observed, not on their data
             CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
             h->work64_dirty = true;
+            h->chains_dirty = true;      // a newly observed variable leaves the chains
         }
         h->point64_dirty = true;      // the constant messages out of the observed variables are due again
     } else {
@@ -286,6 +287,22 @@ static int32_t mv_chain_sweep(cx_handle *h, int32_t n_sweeps) {
     CX_REQUIRE(h, h->chain_covers_all, CX_ERR_UNSUPPORTED,
                "cx_sweep: the chain-scan schedule for dim > 1 needs every non-observed variable on a chain (a non-observed variable of degree 1 "
                "or a stand-in reads messages the scan does not produce): use the fused schedule for this graph");
+    if (h->cfg.dim == 64) {
+        // dim 64 (cx_mv64chain.hip): the messages out of observed variables are constants (k_point64, once per change of data or rule
+        // tables); a sweep composes the blocks' potentials and walks every path in both directions, writing the exact messages into
+        // the ONE message buffer.  Marginals of dim 64 are formed from the stored messages when they are read.
+        if ((rc = build_work64(h)) != CX_OK) return rc;
+        if (h->point64_dirty) {
+            cx::mv64_launch_point(h, (int)h->n_point64, h->d_point64_slots, h->d_mv_f2v, h->d_mv_f2v_alt);
+            h->point64_dirty = false;
+        }
+        for (int32_t s = 0; s < n_sweeps; s++) {
+            if ((rc = cx::chain64_sweep(h)) != CX_OK) return rc;
+            h->sweeps_done++;
+        }
+        CX_HIP(h, hipGetLastError());
+        return CX_OK;
+    }
     if ((rc = mv_refresh_spdir(h)) != CX_OK) return rc;
     const bool marg = h->cfg.compute_marginals_in_sweep != 0;
     for (int32_t s = 0; s < n_sweeps; s++) {

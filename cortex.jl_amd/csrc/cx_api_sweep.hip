@@ -122,7 +122,11 @@ int32_t build_chains(cx_handle *h) {
         if ((rc = dev_upload(h, &h->d_chain_to, to)) != CX_OK) return rc;
         if ((rc = dev_upload(h, &h->d_chain_head_fwd, head_fwd)) != CX_OK) return rc;
         if ((rc = dev_upload(h, &h->d_chain_head_bwd, head_bwd)) != CX_OK) return rc;
-        if (h->cfg.dim > 1) {
+        if (h->cfg.dim == 64) {
+            // wide messages: a plan of compositions and walks (cx_chain64_plan.h) instead of the per-thread scan of dim 2..4
+            h->d_chain_side = nullptr; h->d_chain_totals = nullptr;
+            if ((rc = cx::chain64_build(h, pos_var, skip0, skip1, link_pos, from, to, head_fwd, head_bwd, tab_fwd, tab_bwd)) != CX_OK) return rc;
+        } else if (h->cfg.dim > 1) {
             h->d_chain_side = nullptr; h->d_chain_totals = nullptr;
             if ((rc = dev_upload(h, &h->d_chain_tab_fwd, tab_fwd)) != CX_OK) return rc;
             if ((rc = dev_upload(h, &h->d_chain_tab_bwd, tab_bwd)) != CX_OK) return rc;
@@ -272,6 +276,12 @@ int32_t cx_chain_block_maps(cx_handle *h, double *fwd6, double *bwd6, double *si
         if (n_links) *n_links = h->chain_nlinks;
         return CX_OK;
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_chain_block_maps: host allocation failed"); }
+}
+
+int32_t cx_chain_plan_stats(const cx_handle *h, int64_t *out8) {
+    if (!h || !out8) return CX_ERR_INVALID_ARGUMENT;
+    cx::chain64_stats(h, out8);
+    return CX_OK;
 }
 
 int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {

@@ -108,6 +108,7 @@ struct cx_handle {
     double *d_mvc_side = nullptr, *d_mvc_totals = nullptr;
     double *d_mvc_side_l = nullptr, *d_mvc_alpha = nullptr, *d_mvc_gamma = nullptr, *d_mvc_prefix = nullptr, *d_mvc_wave_carry = nullptr, *d_mvc_block = nullptr;   // thread-interleaved by link, [nc][ntiles * 256 * K]
     int mvc_K = 4;                   // links per thread of the scan (fixed when the chains are built)
+    void *chain64 = nullptr;         // dim 64 chain scan (cx_mv64chain.hip): the plan's records, potential and entry arenas on the device
     bool chain_msgs_stale = false;   // dim 2..4 chain scan: the chain messages in d_mv_f2v are older than the last sweep (refreshed on demand)
 
     // halo
@@ -241,6 +242,14 @@ size_t mvc_totals_doubles(int dim, int64_t nlinks, int K);
 void mvc_launch_side(cx_handle *h, bool write_marg);
 void mvc_launch_scan(cx_handle *h, bool write_marg, bool store_msgs, bool scan);
 void mvc_launch_block_maps(cx_handle *h);
+// chain scan for dim 64 (cx_mv64chain.hip; the plan: cx_chain64_plan.h)
+int32_t chain64_build(cx_handle *h, const std::vector<int32_t> &pos_var, const std::vector<int32_t> &skip0, const std::vector<int32_t> &skip1,
+                      const std::vector<int32_t> &link_pos, const std::vector<int32_t> &from, const std::vector<int32_t> &to,
+                      const std::vector<uint8_t> &head_fwd, const std::vector<uint8_t> &head_bwd, const std::vector<int32_t> &tab_fwd,
+                      const std::vector<int32_t> &tab_bwd);
+int32_t chain64_sweep(cx_handle *h);
+void chain64_free(cx_handle *h);
+void chain64_stats(const cx_handle *h, int64_t *out8);
 // variational families (cx_vmp.hip)
 int32_t vmp_graph_create(cx_handle *h, int64_t ne, const int64_t *edge_var, const int64_t *edge_fac, const int32_t *edge_role,
                          int64_t nf, const int64_t *factor_ids, const int32_t *factor_kind);

@@ -35,20 +35,6 @@ namespace cx {
 
 using namespace w64;
 
-// lab only (tools/lab/w64_phases.hip defines CX_W64_STAMPS and the counters): shader-clock cycles per phase and wave
-#ifdef CX_W64_STAMPS
-#define W64_STAMP(i)                                                                                  \
-    do {                                                                                              \
-        const uint64_t t_ = __builtin_amdgcn_s_memtime();                                             \
-        if (lane == 0) cx_w64_stamps[8 * (size_t)blockIdx.x + i] += (unsigned long long)(t_ - t_prev); \
-        t_prev = t_;                                                                                  \
-    } while (0)
-#define W64_STAMP_INIT uint64_t t_prev = __builtin_amdgcn_s_memtime()
-#else
-#define W64_STAMP(i)
-#define W64_STAMP_INIT
-#endif
-
 // work record (8 int32, built by build_work64 in cx_api.hip): {sender slot, three source slots (-1: none), rule-table index,
 // destination slot, flags, 0}.  ptab: per table index (P, B, C); btab: per table index B' (the transpose of B).
 //
@@ -67,7 +53,6 @@ void k_rule64w(int nwork, const int32_t *__restrict__ work_rec, const double *__
     const int w = blockIdx.x;
     if (w >= nwork) return;
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-    W64_STAMP_INIT;
     const int32_t *rec = work_rec + 8 * (int64_t)w;
     const int slot = rec[0], s0 = rec[1], s1 = rec[2], s2 = rec[3], dst_slot = rec[5], flags = rec[6];
     const double *tab = ptab + (int64_t)rec[4] * 3 * kD * kD;
@@ -80,133 +65,7 @@ void k_rule64w(int nwork, const int32_t *__restrict__ work_rec, const double *__
     const bool has2 = !fixed && s2 >= 0;
     const double *src2 = has2 ? f2v_in + (int64_t)s2 * kMsg : zero_msg;
 
-    // ---- M = P + sum of the other incoming Lambdas (ascending neighbour order), upper tiles only ------------------------------
-    d4 M[10];
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = a; b < 4; b++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int o = tile_off(a, b, r, g, c);
-                M[ut(a, b)][r] = (tab[o] + src0[kD + o]) + src1[kD + o];
-            }
-    if (has2) {      // a third source (a sender of degree 4) is rare: ONE branch around the whole block of loads
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = a; b < 4; b++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) M[ut(a, b)][r] += src2[kD + tile_off(a, b, r, g, c)];
-    }
-    // a dependency is undefined (whole messages are NaN together): the signal is not pending
-    if (__builtin_isnan(bcast(M[0][0], 0))) return;
-    W64_STAMP(0);
-
-    // ---- blocked upper Cholesky, NB = 16: off-diagonal tiles of M become U, V_k = U_kk^-1 goes to LDS -------------------------
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const d4 Vk = diag_factor(M[ut(k, k)], S, g, c);
-        W64_STAMP(1);
-#pragma unroll
-        for (int r = 0; r < 4; r++) Vs[k][(g + 4 * r) * kLdT + c] = Vk[r];
-#pragma unroll
-        for (int j = k + 1; j < 4; j++) M[ut(k, j)] = tts(Vk, M[ut(k, j)], d4{0.0, 0.0, 0.0, 0.0});        // U[k][j] = V_k' M[k][j]
-#pragma unroll
-        for (int i = k + 1; i < 4; i++) {
-            const d4 nu = neg(M[ut(k, i)]);
-#pragma unroll
-            for (int j = i; j < 4; j++) M[ut(i, j)] = tts(nu, M[ut(k, j)], M[ut(i, j)]);                       // M[i][j] -= U[k][i]' U[k][j]
-        }
-        W64_STAMP(2);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-
-    // ---- z = U^-T eta_in on the vector pipe (as a fifth block column of the matrix solve it cost 104 of 488 matrix
-    //      instructions, on tiles that are 15/16 zeros).  Two vector layouts: RV — lane (g, c) holds x[g + 4 r] in register r
-    //      (indexed like tile rows); CV — lane (g, c) holds y[c] (indexed like tile columns).  T' x for a tile T: four FMAs per lane
-    //      and a sum over the four lane groups gives CV; CV -> RV is four lane reads. -----------------------------------------------
-    double zrv[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int e = 16 * j + c;
-        double wcv = src0[e] + src1[e];
-        if (has2) wcv += src2[e];
-#pragma unroll
-        for (int k = 0; k < j; k++) {
-            double p = 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) p += M[ut(k, j)][r] * zrv[k][r];
-            wcv -= sum_groups(p);                                                      // eta_j - sum_k U[k][j]' z_k
-        }
-        double p = 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; r++) p += Vs[j][(g + 4 * r) * kLdT + c] * cv_to_rv(wcv, g, r);
-        const double zcv = sum_groups(p);                                              // z_j = V_j' w_j
-#pragma unroll
-        for (int r = 0; r < 4; r++) zrv[j][r] = cv_to_rv(zcv, g, r);
-    }
-
-    W64_STAMP(3);
-    // ---- Yt = U^-T B', one block COLUMN at a time (forward substitution over its four row blocks) ------------------------------
-    d4 Y[4][4];
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) Y[j][b][r] = bt[tile_off(j, b, r, g, c)];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            d4 Vj;
-#pragma unroll
-            for (int r = 0; r < 4; r++) Vj[r] = Vs[j][(g + 4 * r) * kLdT + c];
-            Y[j][b] = tts(Vj, Y[j][b], d4{0.0, 0.0, 0.0, 0.0});                                                  // Yt[j] = V_j' R[j]
-#pragma unroll
-            for (int jj = j + 1; jj < 4; jj++) Y[jj][b] = tts(neg(M[ut(j, jj)]), Y[j][b], Y[jj][b]);           // R[jj] -= U[j][jj]' Yt[j]
-        }
-    }
-    // not positive definite somewhere: NaN everywhere downstream — leave the old message
-    if (__builtin_isnan(bcast(Y[3][0][0], 0)) || __builtin_isnan(bcast(zrv[3][0], 0))) return;
-    W64_STAMP(4);
-
-    // ---- Gram tile by tile: G[a][b] = sum_j Yt[j][a]' Yt[j][b];  Lambda_out = C - G (C symmetric: the lower tiles are the
-    //      transposes of the same differences, turned through LDS);  eta_out = Yt' z on the vector pipe ---------------------------
-    double *dst = out + (int64_t)dst_slot * kMsg;
-    const double *C = tab + 2 * kD * kD;
-#pragma unroll
-    for (int a = 0; a < 4; a++) {
-#pragma unroll
-        for (int b = a; b < 4; b++) {
-            d4 Ct;
-#pragma unroll
-            for (int r = 0; r < 4; r++) Ct[r] = C[tile_off(a, b, r, g, c)];
-            d4 G = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int j = 0; j < 4; j++) G = tts(Y[j][a], Y[j][b], G);
-            d4 D;
-#pragma unroll
-            for (int r = 0; r < 4; r++) D[r] = Ct[r] - G[r];
-#pragma unroll
-            for (int r = 0; r < 4; r++) dst[kD + tile_off(a, b, r, g, c)] = D[r];
-            if (b > a) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the previous tile's reads have returned
-#pragma unroll
-                for (int r = 0; r < 4; r++) S[(g + 4 * r) * kLdT + c] = D[r];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int r = 0; r < 4; r++) dst[kD + tile_off(b, a, r, g, c)] = S[c * kLdT + g + 4 * r];
-            }
-        }
-        double p = 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) p += Y[j][a][r] * zrv[j][r];
-        const double ecv = sum_groups(p);                                              // (Yt' z)[16 a + c]
-        if (g == 0) dst[16 * a + c] = ecv;
-    }
-    W64_STAMP(5);
+    (void)rule64w_apply<false>(tab, bt, tab + 2 * kD * kD, nullptr, nullptr, src0, src1, src2, has2, out + (int64_t)dst_slot * kMsg, S, Vs, lane, g, c);
 }
 
 void mv64w_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const double *f2v_in, double *f2v_out) {

@@ -89,6 +89,13 @@ class DeviceGraph:
         self._check(self.lib.cx_tile_stats(self.h, C.byref(n), C.byref(r), C.byref(b)))
         return {"n_tiles": n.value, "variables_loaded_per_owned": r.value, "lds_bytes_per_workgroup": b.value}
 
+    def chain_plan_stats(self):
+        """cx_chain_plan_stats: the composition / walk plan of the dim 64 chain-scan schedule (zeros for other handles)"""
+        out = (C.c_int64 * 8)()
+        self._check(self.lib.cx_chain_plan_stats(self.h, out))
+        keys = ("links_per_block", "fan", "levels", "potentials", "compositions", "rules", "launches", "device_bytes")
+        return dict(zip(keys, (int(x) for x in out)))
+
     def edge_index(self, variable_ids, factor_ids):
         v, f = _i64(np.atleast_1d(variable_ids)), _i64(np.atleast_1d(factor_ids))
         out = np.zeros(len(v), dtype=np.int64)

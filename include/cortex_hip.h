@@ -365,6 +365,14 @@ int32_t cx_halo_ipc_set_timeout(cx_handle *h, double seconds);
 int32_t cx_chain_block_maps(cx_handle *h, double *forward6, double *backward6, double *side_first2, double *side_last2,
                             int64_t *first_variable_id, int64_t *last_variable_id, int64_t *n_links);
 
+/* ---- the chain-scan schedule for dim 64 (csrc/cx_mv64chain.hip) ----
+ * One cx_sweep composes pairwise potentials of blocks of links bottom-up and walks them top-down (the plan: csrc/cx_chain64_plan.h),
+ * so that ONE call is the reference's one update_marginals! on a chain (src/inference_engine.jl:575-608).  cx_chain_plan_stats
+ * reports the plan the last cx_sweep used, for the work count of a measurement: out8 = {links per level-0 block, potentials per
+ * group, levels, potentials, pairwise compositions per sweep (960 matrix instructions each), rule applications per sweep (384
+ * each), kernel launches per sweep, device bytes of the plan}.  All zeros before the first sweep and for any other handle. */
+int32_t cx_chain_plan_stats(const cx_handle *h, int64_t *out8);
+
 /* ---- checkpoint (the reference keeps no persistent state — src/ has no serialisation at all) ----
  * The mutable state of a handle (every message buffer, the marginals, the observed-variable flags, the sweep counter)
  * as one relocatable host blob.  A blob restores only into a handle created with the same dim / family / schedule and

@@ -176,10 +176,6 @@ def test_unsupported_graphs_are_refused_not_approximated(hip_lib):
     with pytest.raises(cx.CortexHipError) as e:
         dev.sweep(1)
     assert e.value.code == L.ERR_UNSUPPORTED
-    # dim 64 has no chain scan in this build
-    with pytest.raises(cx.CortexHipError) as e:
-        cx.DeviceGraph(dim=64, schedule=L.SCHED_CHAIN_SCAN)
-    assert e.value.code == L.ERR_UNSUPPORTED
 
 
 def test_checkpoint_round_trip_under_the_chain_schedule(hip_lib):

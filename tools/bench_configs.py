@@ -180,6 +180,41 @@ def mv_scan(d, T, steps, ks=(None,)):
     return out
 
 
+def mv64_scan(T, steps, ks=(None,)):
+    """the chain-scan schedule for dim 64 (cx_mv64chain.hip): ONE sweep = the exact smoother = one reference update_marginals!
+    (5T-4 message computations).  Matrix work per sweep from the plan: 960 v_mfma_f64_16x16x4_f64 per pairwise composition
+    of potentials + 384 per rule application (2048 flop each).  ks: values of CX_MVC64_K (links per level-0 block); None = the default."""
+    model = cx.synth.lgssm_chain(T, d=64, seed=1234)
+    out = []
+    for k in ks:
+        if k is None:
+            os.environ.pop("CX_MVC64_K", None)
+        else:
+            os.environ["CX_MVC64_K"] = str(k)
+        dev = cx.DeviceGraph(dim=64, schedule=L.SCHED_CHAIN_SCAN)
+        cx.synth.load_into_device(model, dev)
+        st = dev.stats()
+        dev.sweep(2)
+        dt = timed(dev, lambda: dev.sweep(1), steps, 2)
+        ps = dev.chain_plan_stats()
+        n_mfma = 960 * ps["compositions"] + 384 * ps["rules"]
+        tf = n_mfma * 2048 / dt / 1e12
+        ref_upd = 5 * T - 4
+        out.append({"config": "C5-scan", "links_per_block": ps["links_per_block"],
+                    "workload": f"d=64 linear-Gaussian chain T={T} ({st['n_edges']} edges), chain-scan schedule: exact forward/backward in one sweep",
+                    "ms_per_sweep": dt * 1e3, "reference_updates_per_sweep": ref_upd, "updates_per_s": ref_upd / dt, "plan": ps,
+                    "mfma_TFLOPs": tf,
+                    "roofline": roofline("mfma", tf, F64_MATRIX_PEAK_TF, "TFLOP/s", None, kernel="k_compose64 + k_walk64 (all launches of one sweep)",
+                                         mfma_per_sweep=n_mfma, mfma_per_composition=960, mfma_per_rule=384, compositions=ps["compositions"],
+                                         rules=ps["rules"], launches_per_sweep=ps["launches"],
+                                         basis="matrix instructions of the plan x 2048 flop / sweep time (launch gaps and the serial top of the tree included)",
+                                         minimum_note="the sequential smoother needs 2(T-1) rules = 384 x 2(T-1) matrix instructions; the tree costs "
+                                                      f"{n_mfma / (384 * 2 * (T - 1)):.2f}x that for its parallelism")})
+        dev.close()
+    os.environ.pop("CX_MVC64_K", None)
+    return out
+
+
 def vmp(n=1_000_000, only=None):
     """one variational iteration (all latent states, then both precisions) of the reference's SSM with
     unknown noise precisions, n states: 2n - 1 three-way factors, 6n - 3 edges."""
@@ -235,6 +270,11 @@ if __name__ == "__main__":
     for w in which:
         if w.startswith("vmp"):
             for r in vmp(only=w[4:] or None):          # vmp | vmp_structured | vmp_mean_field
+                print(json.dumps(r), flush=True)
+            continue
+        if w.startswith("c5scan"):                       # c5scan | c5scan:49,98,196 (links per level-0 block)
+            ks = tuple(int(x) for x in w.split(":")[1].split(",")) if ":" in w else (None,)
+            for r in mv64_scan(100_000, 10, ks):
                 print(json.dumps(r), flush=True)
             continue
         if w.startswith("c3scan"):                       # c3scan | c3scan:1,2,4,8 (links per thread)
