@@ -269,21 +269,148 @@ def parity_check(sample_n: int, seed: int, sweeps: int, device: int = 0) -> dict
             "checker": "oracle/bp_flood.c: the reference's rules (test/inference_engine_tests.jl:385-432) in moment form, in the device's sweep order"}
 
 
-def other_configs() -> list:
+def _rel_err(a, b):
+    """largest |a - b| relative to the largest |b| (means cross zero: a purely relative test is ill-posed there); inf on a NaN mismatch"""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    if np.any(np.isnan(a)) or np.any(np.isnan(b)):
+        return float("inf")
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-300))
+
+
+def config_parity(device: int = 0) -> dict:
+    """Parity of the non-headline configs, in the same run as their timings (part of the cpu_baseline leg: checker code).  Returns
+    {"hooks": callbacks that bench_configs' recipes run on their TIMED devices at full size, "standalone": rows computed here on small
+    devices}.  What each figure is measured against is named in its `checker`; the reference pins none of these numbers:
+    trees are pinned by exact solves, flooding sweeps by the C restatement of the same sweep, the variational families by the array
+    form of the reference's update_marginals! (oracle/vmp.py)."""
+    import cortex.jl_amd as cx
+    from cortex.jl_amd import _lib as L
+    from oracle import exact
+
+    def c2(dev, model):          # full size: all T marginals against the Thomas solve of the tridiagonal posterior
+        em, ev = exact.ssm_chain_posterior(model.data_y, 1.0, 1.0)
+        marg = dev.get_marginals(model.x_ids)
+        return {"max_rel_err": max(_rel_err(marg[:, 0], em), _rel_err(marg[:, 1], ev)), "tolerance": 1e-6,
+                "checker": "oracle/exact.py: Thomas solve of the chain's tridiagonal posterior", "sample": f"all {len(model.x_ids)} marginals (full size), one sweep"}
+
+    def c3_scan(dev, model):     # full size: all T marginals against the exact block-tridiagonal smoother in C
+        d, T = model.dim, len(model.x_ids)
+        em, ecov = exact.lgssm_posterior_c(model.data_y, model.meta["A"], model.meta["Q"], model.meta["R"])
+        marg = dev.get_marginals(model.x_ids)
+        return {"max_rel_err": max(_rel_err(marg[:, :d], em), _rel_err(marg[:, d:].reshape(T, d, d), ecov)), "tolerance": 1e-6,
+                "checker": "oracle/blocktri.c: exact smoother by pivoted block elimination", "sample": f"all {T} marginals (full size), one sweep, no seeding"}
+
+    def c5_scan(dev, model):     # full size: eight windows of 40 marginals against the exact smoother of the window + 300 steps either side
+        d, T, W, pad = model.dim, len(model.x_ids), 40, 300
+        A, Q, R = model.meta["A"], model.meta["Q"], model.meta["R"]
+        worst = 0.0
+        starts = [0, T - W] + [int(x) for x in np.linspace(T // 7, T - T // 7, 6)]
+        for start in starts:
+            lo, hi = max(0, start - pad), min(T, start + W + pad)
+            em, ecov = exact.lgssm_posterior_c(model.data_y[lo:hi], A, Q, R)
+            marg = dev.get_marginals(model.x_ids[start:start + W])
+            sl = slice(start - lo, start - lo + W)
+            worst = max(worst, _rel_err(marg[:, :d], em[sl]), _rel_err(marg[:, d:].reshape(W, d, d), ecov[sl]))
+        return {"max_rel_err": worst, "tolerance": 1e-6, "checker": "oracle/blocktri.c on windows (the model forgets a boundary within ~100 steps: 300 steps of "
+                "padding make the window's posterior the chain's to rounding); every one of the 1e5 marginals against the whole-chain solve: "
+                "tests/test_gpu_mv64_chain.py::test_config_c5_full_size_one_sweep_every_marginal", "sample": f"{len(starts)} windows of {W} marginals at full size, one sweep, no seeding"}
+
+    rows = {}
+
+    def flooding(d, T, sweeps, lag):      # per-sweep parity of the fused flooding kernels against the C restatement of the same sweep
+        from oracle.mv import MvFloodC
+        model = cx.synth.lgssm_chain(T, d=d, seed=17)
+        dev = cx.DeviceGraph(device=device, dim=d, schedule=L.SCHED_FUSED)
+        cx.synth.load_into_device(model, dev, seed_variance=1e6)
+        o = MvFloodC(model)
+        o.sweep(lag)
+        o.seed(0.0, 1e6)
+        g = o.g
+        xs = set(np.searchsorted(g.var_ids, model.x_ids).tolist())
+        pe = np.array([e for e in np.flatnonzero(g.partner >= 0) if int(np.searchsorted(g.var_ids, g.edge_var[e])) in xs])
+        worst = 0.0
+        for _ in range(sweeps):
+            dev.sweep(1)
+            o.sweep(1, use_omp=True)
+            got = dev.get_messages(g.edge_var[pe], g.edge_fac[pe], L.TO_VARIABLE)
+            worst = max(worst, _rel_err(got[:, :d], o.f2v_m[pe]), _rel_err(got[:, d:].reshape(-1, d, d), o.f2v_S[pe]))
+        dev.close()
+        return {"max_rel_err": worst, "tolerance": 1e-6, "checker": "oracle/mv_flood.c: the same flooding sweep in moment form",
+                "sample": f"T={T}, every factor→variable message of the latent variables after each of {sweeps} sweeps"}
+
+    def c5_fixed_point():                 # the d = 64 rule to its fixed point on a short chain against the exact smoother
+        d, T = 64, 48
+        model = cx.synth.lgssm_chain(T, d=d, seed=19)
+        dev = cx.DeviceGraph(device=device, dim=d, schedule=L.SCHED_FUSED)
+        cx.synth.load_into_device(model, dev, seed_variance=1e6)
+        dev.sweep(T + 2)
+        em, ecov = exact.lgssm_posterior(model.data_y, model.meta["A"], model.meta["Q"], model.meta["R"])
+        marg = dev.get_marginals(model.x_ids)
+        dev.close()
+        return {"max_rel_err": max(_rel_err(marg[:, :d], em), _rel_err(marg[:, d:].reshape(T, d, d), ecov)), "tolerance": 1e-6,
+                "checker": "oracle/exact.py: block-tridiagonal posterior", "sample": f"T={T} chain swept to its fixed point ({T + 2} sweeps), all marginals"}
+
+    def vmp_family(name, fam):
+        from oracle import vmp
+        n = 64
+        model = cx.synth.vmp_ssm(n, seed=12)
+        dev = cx.DeviceGraph(device=device, family=fam, schedule=L.SCHED_CHAIN_SCAN)
+        cx.synth.load_vmp_into_device(model, dev)
+        arr = (vmp.StructuredVMP if name == "structured" else vmp.MeanFieldVMP)(model.data_y)
+        worst = 0.0
+        for _ in range(6):
+            for which, ids in ((["x"], L.VMP_ALL_NORMAL), (["ssnoise", "obsnoise"], L.VMP_ALL_PRECISION)):
+                dev.update_marginals(ids)
+                arr.update(which)
+                xs = dev.get_marginals(model.x_ids)
+                gm = dev.get_marginals([model.ssnoise, model.obsnoise])
+                got = np.concatenate([xs[:, 0], xs[:, 1], gm[0], gm[1]])
+                want = np.concatenate([arr.xm, arr.xw, arr.ss, arr.obs])
+                worst = max(worst, float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-300))))
+        dev.close()
+        return {"max_rel_err": worst, "tolerance": 1e-6, "checker": "oracle/vmp.py: the array form of the reference's update_marginals! on its variational SSM "
+                "(test/inference_engine_tests.jl:593-1147), pinned call by call against the restated engine",
+                "sample": f"n={n} states, 6 iterations (states, then both precisions), every marginal after every call"}
+
+    for key, fn in (("C3", lambda: flooding(4, 2000, 8, 0)), ("C5", c5_fixed_point),
+                    ("VMP structured", lambda: vmp_family("structured", L.FAMILY_VMP_STRUCTURED)),
+                    ("VMP mean_field", lambda: vmp_family("mean_field", L.FAMILY_VMP_MEAN_FIELD))):
+        try:
+            rows[key] = fn()
+        except Exception as e:
+            rows[key] = {"error": f"{type(e).__name__}: {e}"}
+    return {"hooks": {"C2": c2, "C3-scan": c3_scan, "C5-scan": c5_scan}, "standalone": rows}
+
+
+def other_configs(parity=None) -> list:
     """The other configs of BASELINE.json on this GPU, a few seconds each (tools/bench_configs.py holds the recipes): C2 (chain scan),
-    C3 (d = 4: fused flooding sweep and the exact chain-scan sweep), C5 (d = 64, MFMA), both variational families.  Each row carries
-    ms per sweep, updates per second and its own roofline object (counter traffic from profiles/ when the kernel is unchanged)."""
+    C3 (d = 4: fused flooding sweep and the exact chain-scan sweep), C5 (d = 64, MFMA: flooding sweep and the exact chain-scan sweep),
+    both variational families.  Each row carries ms per sweep, updates per second, its own roofline object (counter traffic from
+    profiles/ when the kernel is unchanged) and — with `parity` = config_parity()'s result — a parity object {max_rel_err, tolerance,
+    ok, checker, sample} measured in this run."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_configs as bc
 
+    hooks = (parity or {}).get("hooks", {})
+    alone = (parity or {}).get("standalone", {})
     rows = []
-    for name, fn in (("C2", bc.c2), ("C3", lambda: bc.mv(4, 1_000_000, 30)), ("C3-scan", lambda: bc.mv_scan(4, 1_000_000, 30)[0]),
-                     ("C5", lambda: bc.mv(64, 100_000, 12)), ("VMP", lambda: bc.vmp())):
+    for name, fn in (("C2", lambda: bc.c2(check=hooks.get("C2"))), ("C3", lambda: bc.mv(4, 1_000_000, 30)),
+                     ("C3-scan", lambda: bc.mv_scan(4, 1_000_000, 30, check=hooks.get("C3-scan"))[0]),
+                     ("C5", lambda: bc.mv(64, 100_000, 12)), ("C5-scan", lambda: bc.mv64_scan(100_000, 8, check=hooks.get("C5-scan"))[0]),
+                     ("VMP", lambda: bc.vmp())):
         try:
             r = fn()
             rows.extend(r if isinstance(r, list) else [r])
         except Exception as e:      # one config failing must not take the headline line with it
             rows.append({"config": name, "error": f"{type(e).__name__}: {e}"})
+    for r in rows:
+        key = r.get("config")
+        if key == "VMP":
+            key = "VMP structured" if "structured" in r.get("workload", "") else "VMP mean_field"
+        if "parity" not in r and key in alone:
+            r["parity"] = alone[key]
+        if "parity" in r and "max_rel_err" in r["parity"]:
+            r["parity"]["ok"] = bool(r["parity"]["max_rel_err"] <= r["parity"]["tolerance"])
     return rows
 
 
@@ -723,7 +850,7 @@ def run_rank(args):
             out["parity"] = parity_check(args.cpu_sample_grid, args.seed, args.parity_sweeps, local_rank)
         if world == 1 and not args.no_other_configs and not args.self_halo:
             w.close()                                  # free the headline grid before the other configs allocate theirs
-            out["other_configs"] = other_configs()
+            out["other_configs"] = other_configs(config_parity(local_rank) if not args.no_cpu_baseline else None)
         print(json.dumps(out), flush=True)
     dog.cancel()
     if dist is not None:

@@ -17,9 +17,10 @@
 //
 // Plan: level 0 = blocks of K0 consecutive links; level j + 1 = groups of FAN level-j potentials, while a level has more than
 // FAN of them.  Launches, in order: compose level 0, 1, ... (a wave per potential, its children composed left to right);
-// then walks (a wave per job, its steps in sequence, every step one rule application): the top level of every path from
-// its two ends, the groups of each lower level (each walk hands every child the message that enters it), and finally every
-// level-0 block along its links, forwards and backwards, writing the messages into their factor→variable slots.
+// then walks (a wave per job, its steps in sequence, every step one rule application — the device runs step s of all jobs of a
+// walk launch as one kernel launch): the top level of every path from its two ends, the groups of each lower level (each walk
+// hands every child the message that enters it), and finally every level-0 block along its links, forwards and backwards,
+// writing the messages into their factor→variable slots.
 //
 // Records name their operands by HANDLES (space << 56 | offset in doubles); the device resolves them against the base
 // pointers of the moment, so a plan survives reallocation and can be executed anywhere.
@@ -59,7 +60,7 @@ struct Input {
     // per position: up to three slots of side information, -1 = none
     const int32_t *side = nullptr;      // [npos][3]
     int K0 = 0;                         // links per level-0 block (0: chosen from the chain length and `lanes`)
-    int fan = 4;                        // potentials per group of the upper levels
+    int fan = 2;                        // potentials per group of the upper levels
     int64_t lanes = 1024;               // waves the composition launch should fill (SIMDs of the device)
 };
 

@@ -9,9 +9,9 @@
 //             = 64 (Cholesky) + 2 x 160 (solves) + 2 x 160 (Grams) + 256 (product) = 960 v_mfma_f64_16x16x4_f64, all on
 //             register-resident tiles in the accumulator layout of cx_mv64w_core.h.  The SAME potential serves the forward and the
 //             backward pass (read from its other end it is (C, B', P, c, h)): one tree for both directions.
-//   walk      a wave applies rules in sequence (rule64w_apply, the body of k_rule64w): the potentials of a group, to hand every
-//             child the message that enters it, and finally the links of a level-0 block, which writes the exact
-//             factor→variable messages into their slots.
+//   walk      a wave applies rules in sequence (rule64w_apply, the body of k_rule64w), ONE LAUNCH PER STEP (k_step64): the potentials
+//             of a group, to hand every child the message that enters it, and finally the links of a level-0 block, which writes the
+//             exact factor→variable messages into their slots.
 // Registers: a composition keeps B1 -> Y1 -> B (128), C1 -> M -> U (80) and Y2 (128) resident and updates P1 in its output record:
 // one wave per SIMD (512 registers).  The walks run two waves per SIMD like the flooding rule.
 //
@@ -23,6 +23,23 @@
 
 #include "cx_host.h"
 #include "cx_chain64_plan.h"
+// lab build (CX_BUILD_STAMPS=1 python -m cortex.jl_amd.build): shader-clock stamps at the phase boundaries of both kernels, summed per
+// launch and printed to stderr after every launch — where a wave's cycles go (never defined in the shipped library)
+#ifdef CX_C64_STAMPS
+__device__ unsigned long long *cx_w64_stamps;      // the rule body's phases: 8 counters per workgroup (cx_mv64w_core.h)
+__device__ unsigned long long *cx_c64_stamps;      // the composition's phases: 16 counters per workgroup
+#define CX_W64_STAMPS 1
+#define C64_STAMP(i)                                                                                   \
+    do {                                                                                               \
+        const uint64_t t_ = __builtin_amdgcn_s_memtime();                                              \
+        if (lane == 0) cx_c64_stamps[16 * (size_t)blockIdx.x + i] += (unsigned long long)(t_ - t_prev); \
+        t_prev = t_;                                                                                   \
+    } while (0)
+#define C64_STAMP_INIT uint64_t t_prev = __builtin_amdgcn_s_memtime()
+#else
+#define C64_STAMP(i)
+#define C64_STAMP_INIT
+#endif
 #include "cx_mv64w_core.h"
 
 namespace cx {
@@ -30,39 +47,45 @@ namespace cx {
 using namespace w64;
 namespace p64 = plan64;
 
-// The six base pointers travel as six KERNEL ARGUMENTS and a handle selects among them: pointers read from memory (a table of
-// bases) are generic to hipcc and every access through them becomes a flat_load / flat_store; selected kernel arguments stay global.
-#define CX_BASES_PARAMS double *__restrict__ b_zero, double *__restrict__ b_f2v, double *__restrict__ b_ptab, double *__restrict__ b_btab, double *__restrict__ b_pot, double *__restrict__ b_ent
-#define CX_RESOLVE(h) resolve64(b_zero, b_f2v, b_ptab, b_btab, b_pot, b_ent, (h))
-__device__ __forceinline__ double *resolve64(double *b_zero, double *b_f2v, double *b_ptab, double *b_btab, double *b_pot, double *b_ent, int64_t h) {
-    const int sp = (int)(h >> 56);
-    double *base = sp == p64::kF2V ? b_f2v : sp == p64::kPtab ? b_ptab : sp == p64::kBtab ? b_btab : sp == p64::kPot ? b_pot : sp == p64::kEnt ? b_ent : b_zero;
-    return base + (h & p64::kOffMask);
+// Device records: the plan's handles resolved to pointers (chain64_resolve, host) — ten 64-bit words each, like the plan's.
+struct DStep { gcdp src[3], P, Bt, C, h, c; gdp dst; int64_t has2; };
+struct DChild { gcdp P, B, Bt, C, h, c, side[3]; int64_t pad; };
+struct DJob { gdp out; int32_t first, n; };
+static_assert(sizeof(DStep) == sizeof(p64::Step) && sizeof(DChild) == sizeof(p64::Child) && sizeof(DJob) == sizeof(p64::Job), "records mirror the plan's");
+
+// A record is read ONCE per step by the whole wave.  Behind the stores of the loop body hipcc no longer treats such a load as
+// uniform-and-unclobbered: it becomes a vector load, every pointer derived from it lives in two VGPRs per lane and every access gets
+// its own 64-bit address arithmetic.  Reading the records through the constant address space keeps them scalar loads and the
+// pointers in SGPRs (base SGPR + one lane offset per access, as in k_rule64w).  The first version resolved handles against six base
+// pointers on the device: selects of pointers ended up on the vector pipe, the loop body's address arithmetic was hoisted and
+// spilled, and at two waves per SIMD the M loads of a step were serialised into one memory round trip each (52 k cycles per step).
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T *as_const(const T *p) {
+    return (const __attribute__((address_space(4))) T *)(uintptr_t)p;
 }
 
-// AFFINE: the steps apply composed potentials (offsets h, c); the walks along the links of a block apply plain factor rules
+// One step of every walk of a launch: wave w applies step `s` of its job (nothing once the job is shorter, or dead).  The walks are
+// sequences of dependent rules, but as a LOOP inside one kernel the same body compiles badly: loop-invariant per-lane values (tile
+// offsets, LDS addresses, the unit-vector constants of the diagonal tiles) are hoisted and stay live, the body goes over 256
+// registers, and hipcc then un-clusters its loads — one memory round trip per load, 52 k cycles per step in the in-kernel stamps,
+// 7.1 ms for the link walks of C5.  One launch per step keeps the straight-line code of k_rule64w (no scratch, 48 loads in flight);
+// a launch boundary costs ≈ 2 us against ≈ 40 us of step.
+// AFFINE: the steps apply composed potentials (offsets h, c); the walks along the links of a block apply plain factor rules.
+// dead[w] != 0: an earlier step of job w found an undefined input or a matrix that is not positive definite — nothing downstream of
+// it is recomputed (the reference would not find those signals pending either).
 template <int WAVES_PER_SIMD, bool AFFINE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES_PER_SIMD, WAVES_PER_SIMD)))
-void k_walk64(int njobs, const p64::Job *__restrict__ jobs, const p64::Step *__restrict__ steps, CX_BASES_PARAMS) {
+void k_step64(int njobs, const DJob *__restrict__ jobs, const DStep *__restrict__ steps, const int s, int32_t *__restrict__ dead) {
     __shared__ double S[16 * kLdT];
     __shared__ double Vs[4][16 * kLdT];
     const int w = blockIdx.x;
     if (w >= njobs) return;
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
     const int first = jobs[w].first, n = jobs[w].n;
-    // (the body inlined into this loop needs 184 bytes of scratch per lane at two waves per SIMD where k_rule64w needs none; a real
-    // call per step — the callee with its own register allocation — needs 540, opaque lane offsets per step 372: measured, kept inline)
-    for (int s = 0; s < n; s++) {
-        const p64::Step *st = steps + (first + s);
-        const int64_t h2 = st->src[2];
-        const bool has2 = (h2 >> 56) != p64::kZero;
-        if (!rule64w_apply<AFFINE>(CX_RESOLVE(st->P), CX_RESOLVE(st->Bt), CX_RESOLVE(st->C), AFFINE ? CX_RESOLVE(st->h) : nullptr,
-                                   AFFINE ? CX_RESOLVE(st->c) : nullptr, CX_RESOLVE(st->src[0]), CX_RESOLVE(st->src[1]),
-                                   CX_RESOLVE(h2), has2, CX_RESOLVE(st->dst), S, Vs, lane, g, c))
-            return;      // undefined input or not positive definite: nothing stored, and nothing downstream of it is defined either
-        // the next step reads what this one stored (same wave, same CU: its stores must have left the wave first)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (s >= n || dead[w] != 0) return;
+    const DStep *st = steps + (first + s);
+    if (!rule64w_apply<AFFINE>(st->P, st->Bt, st->C, st->h, st->c, st->src[0], st->src[1], st->src[2], st->has2 != 0, st->dst, S, Vs, lane, g, c))
+        if (lane == 0) dead[w] = 1;
 }
 
 // Yt = U^-T R for the four tiles of block column b of R (in place): forward substitution over the row blocks
@@ -79,25 +102,25 @@ __device__ __forceinline__ void solve_col(d4 (&R)[4][4], const int b, const d4 (
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_compose64(int njobs, const p64::Job *__restrict__ jobs, const p64::Child *__restrict__ children, CX_BASES_PARAMS) {
+void k_compose64(int njobs, const DJob *__restrict__ jobs, const DChild *__restrict__ children) {
     __shared__ double S[16 * kLdT];
     __shared__ double Vs[4][16 * kLdT];
     const int w = blockIdx.x;
     if (w >= njobs) return;
-    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-    const int first = jobs[w].first, n = jobs[w].n;
-    double *out = CX_RESOLVE(jobs[w].out);
+    int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    const int first = as_const(jobs)[w].first, n = as_const(jobs)[w].n;
+    gdp out = as_const(jobs)[w].out;
+    C64_STAMP_INIT;
 
     // ---- the accumulated potential starts as the first child -------------------------------------------------------------------
     // (P1 does not stay in registers: it is only ever updated tile by tile, so it lives in the output record — 940 bytes of scratch
     // per lane with it resident)
     d4 C1[10], B1[4][4];
     double h1[4], c1[4];         // CV layout: lane (g, c) holds x[16 a + c]
-    double *oP = out;
+    gdp oP = out;
     {
-        const p64::Child *ch = children + first;
-        const double *P = CX_RESOLVE(ch->P), *B = CX_RESOLVE(ch->B), *C = CX_RESOLVE(ch->C);
-        const double *hh = CX_RESOLVE(ch->h), *cc = CX_RESOLVE(ch->c);
+        const auto *ch = as_const(children) + first;
+        gcdp P = ch->P, B = ch->B, C = ch->C, hh = ch->h, cc = ch->c;
 #pragma unroll
         for (int a = 0; a < 4; a++) {
 #pragma unroll
@@ -113,11 +136,14 @@ void k_compose64(int njobs, const p64::Job *__restrict__ jobs, const p64::Child 
         }
     }
 
+    C64_STAMP(0);
     for (int k = 1; k < n; k++) {
-        const p64::Child *ch = children + (first + k);
-        const double *P2 = CX_RESOLVE(ch->P), *Bt2 = CX_RESOLVE(ch->Bt), *C2 = CX_RESOLVE(ch->C);
-        const double *h2 = CX_RESOLVE(ch->h), *c2 = CX_RESOLVE(ch->c);
-        const double *s0 = CX_RESOLVE(ch->side[0]), *s1 = CX_RESOLVE(ch->side[1]), *s2 = CX_RESOLVE(ch->side[2]);
+        const auto *ch = as_const(children) + (first + k);
+        // (the lane id opaque per step, its range restated: see k_step64)
+        asm volatile("" : "+v"(lane));
+        lane &= 63;
+        g = lane >> 4; c = lane & 15;
+        gcdp P2 = ch->P, Bt2 = ch->Bt, C2 = ch->C, h2 = ch->h, c2 = ch->c, s0 = ch->side[0], s1 = ch->side[1], s2 = ch->side[2];
         // ---- M = C1 + side information of the joint + P2 (upper tiles; C1's registers become M, then U) ------------------------------
 #pragma unroll
         for (int a = 0; a < 4; a++)
@@ -131,10 +157,12 @@ void k_compose64(int njobs, const p64::Job *__restrict__ jobs, const p64::Child 
         double gv[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) { const int e = 16 * j + c; gv[j] = c1[j] + (s0[e] + s1[e]) + (s2[e] + h2[e]); }
+        C64_STAMP(1);
         // ---- blocked upper Cholesky (as in rule64w_apply) ---------------------------------------------------------------------------
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
             const d4 Vk = diag_factor(C1[ut(kk, kk)], S, g, c);
+            C64_STAMP(2);
 #pragma unroll
             for (int r = 0; r < 4; r++) Vs[kk][(g + 4 * r) * kLdT + c] = Vk[r];
 #pragma unroll
@@ -145,6 +173,7 @@ void k_compose64(int njobs, const p64::Job *__restrict__ jobs, const p64::Child 
 #pragma unroll
                 for (int j = i; j < 4; j++) C1[ut(i, j)] = tts(nu, C1[ut(kk, j)], C1[ut(i, j)]);
             }
+            C64_STAMP(3);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // ---- z = U^-T g on the vector pipe ----------------------------------------------------------------------------------------------
@@ -166,9 +195,11 @@ void k_compose64(int njobs, const p64::Job *__restrict__ jobs, const p64::Child 
 #pragma unroll
             for (int r = 0; r < 4; r++) zrv[j][r] = cv_to_rv(zcv, g, r);
         }
+        C64_STAMP(4);
         // ---- Y1 = U^-T B1 in place;  P1 -= Y1'Y1;  h1 += Y1'z --------------------------------------------------------------------------
 #pragma unroll
         for (int b = 0; b < 4; b++) solve_col(B1, b, C1, Vs, g, c);
+        C64_STAMP(5);
 #pragma unroll
         for (int a = 0; a < 4; a++) {
 #pragma unroll
@@ -187,6 +218,7 @@ void k_compose64(int njobs, const p64::Job *__restrict__ jobs, const p64::Child 
                 for (int r = 0; r < 4; r++) p += B1[j][a][r] * zrv[j][r];
             h1[a] += sum_groups(p);
         }
+        C64_STAMP(6);
         // ---- Y2 = U^-T B2';  C1 = C2 - Y2'Y2;  c1 = c2 + Y2'z -------------------------------------------------------------------------
         d4 Y2[4][4];
 #pragma unroll
@@ -197,6 +229,7 @@ void k_compose64(int njobs, const p64::Job *__restrict__ jobs, const p64::Child 
                 for (int r = 0; r < 4; r++) Y2[j][b][r] = Bt2[tile_off(j, b, r, g, c)];
             solve_col(Y2, b, C1, Vs, g, c);
         }
+        C64_STAMP(7);
 #pragma unroll
         for (int a = 0; a < 4; a++) {
 #pragma unroll
@@ -214,6 +247,7 @@ void k_compose64(int njobs, const p64::Job *__restrict__ jobs, const p64::Child 
                 for (int r = 0; r < 4; r++) p += Y2[j][a][r] * zrv[j][r];
             c1[a] = c2[16 * a + c] + sum_groups(p);
         }
+        C64_STAMP(8);
         // ---- B = Y2'Y1, one block column of Y1 at a time, in place ------------------------------------------------------------------------
 #pragma unroll
         for (int b = 0; b < 4; b++) {
@@ -227,10 +261,11 @@ void k_compose64(int njobs, const p64::Job *__restrict__ jobs, const p64::Child 
 #pragma unroll
             for (int a = 0; a < 4; a++) B1[a][b] = T[a];
         }
+        C64_STAMP(9);
     }
 
     // ---- the potential record: P | B | B' | C | h | c (P, C: upper tiles only — every reader takes the upper tiles) ------------------------
-    double *oB = out + kD * kD, *oBt = out + 2 * kD * kD, *oC = out + 3 * kD * kD, *oh = out + 4 * kD * kD, *oc = oh + kD;
+    gdp oB = out + kD * kD, oBt = out + 2 * kD * kD, oC = out + 3 * kD * kD, oh = out + 4 * kD * kD, oc = oh + kD;
 #pragma unroll
     for (int a = 0; a < 4; a++) {
 #pragma unroll
@@ -250,15 +285,21 @@ void k_compose64(int njobs, const p64::Job *__restrict__ jobs, const p64::Child 
         }
         if (g == 0) { oh[16 * a + c] = h1[a]; oc[16 * a + c] = c1[a]; }
     }
+    C64_STAMP(10);
 }
 
 // ---- host: the plan on the device -----------------------------------------------------------------------------------------------
 struct Chain64 {
-    p64::Job *d_jobs = nullptr;
-    p64::Child *d_children = nullptr;
-    p64::Step *d_steps = nullptr;
+    DJob *d_jobs = nullptr;
+    DChild *d_children = nullptr;
+    DStep *d_steps = nullptr;
+    std::vector<p64::Job> jobs;            // the plan's records (handles), kept to be resolved again when a base pointer moves
+    std::vector<p64::Child> children;
+    std::vector<p64::Step> steps;
+    double *bases[p64::kSpaces] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // what the device records were resolved against
     double *d_pot = nullptr, *d_ent = nullptr;
-    struct Launch { int kind; int64_t first; int n; };      // kind 0: compose, 1: walk over potentials, 2: walk along links
+    struct Launch { int kind; int64_t first; int n; int steps; };      // kind 0: compose, 1: walk over potentials, 2: walk along links; steps: longest job
+    int32_t *d_dead = nullptr;             // per job of the widest walk launch: an earlier step failed
     std::vector<Launch> launches;
     int64_t n_pot = 0, n_ent = 0, n_compositions = 0, n_rules = 0;
     int K0 = 0, fan = 0, levels = 0;
@@ -268,7 +309,7 @@ struct Chain64 {
 void chain64_free(cx_handle *h) {
     Chain64 *c = (Chain64 *)h->chain64;
     if (!c) return;
-    for (void *p : {(void *)c->d_jobs, (void *)c->d_children, (void *)c->d_steps, (void *)c->d_pot, (void *)c->d_ent}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)c->d_jobs, (void *)c->d_children, (void *)c->d_steps, (void *)c->d_pot, (void *)c->d_ent, (void *)c->d_dead}) if (p) (void)hipFree(p);
     h->device_bytes -= c->bytes;
     delete c;
     h->chain64 = nullptr;
@@ -305,7 +346,7 @@ int32_t chain64_build(cx_handle *h, const std::vector<int32_t> &pos_var, const s
     in.link_pos = link_pos.data(); in.from = from.data(); in.to = to.data(); in.tab_fwd = tab_fwd.data(); in.tab_bwd = tab_bwd.data();
     in.head_fwd = head_fwd.data(); in.head_bwd = head_bwd.data(); in.side = side.data();
     in.K0 = env_int("CX_MVC64_K", 0);            // links per level-0 block (default: one block per SIMD)
-    in.fan = std::max(2, env_int("CX_MVC64_FAN", 4));
+    in.fan = std::max(2, env_int("CX_MVC64_FAN", 2));      // binary tree: the shortest dependent chain above level 0 (fan 2 / 4 / 8: 14.19 / 14.37 / 15.08 ms on C5)
     in.lanes = 4 * (int64_t)ncu;                 // a composition is one wave per SIMD
     p64::Plan plan;
     try { plan = p64::build(in); }
@@ -316,21 +357,27 @@ int32_t chain64_build(cx_handle *h, const std::vector<int32_t> &pos_var, const s
     h->chain64 = c;
     c->n_pot = plan.n_pot; c->n_ent = plan.n_ent; c->K0 = plan.K0; c->fan = plan.fan; c->levels = plan.levels;
     c->n_compositions = plan.n_compositions; c->n_rules = plan.n_rules;
-    std::vector<p64::Job> jobs;
-    for (const auto &L : plan.compose_launches) if (!L.empty()) { c->launches.push_back({0, (int64_t)jobs.size(), (int)L.size()}); jobs.insert(jobs.end(), L.begin(), L.end()); }
+    auto &jobs = c->jobs;
+    auto longest = [](const std::vector<p64::Job> &L) { int m = 0; for (const auto &j : L) m = std::max(m, (int)j.n); return m; };
+    int widest = 1;
+    for (const auto &L : plan.compose_launches) if (!L.empty()) { c->launches.push_back({0, (int64_t)jobs.size(), (int)L.size(), longest(L)}); jobs.insert(jobs.end(), L.begin(), L.end()); }
     for (size_t i = 0; i < plan.walk_launches.size(); i++) {      // the last walk launch is the one along the links (plain rules, h = c = 0)
         const auto &L = plan.walk_launches[i];
         if (L.empty()) continue;
-        c->launches.push_back({i + 1 == plan.walk_launches.size() ? 2 : 1, (int64_t)jobs.size(), (int)L.size()});
+        c->launches.push_back({i + 1 == plan.walk_launches.size() ? 2 : 1, (int64_t)jobs.size(), (int)L.size(), longest(L)});
         jobs.insert(jobs.end(), L.begin(), L.end());
+        widest = std::max(widest, (int)L.size());
     }
+    c->children = std::move(plan.children);
+    c->steps = std::move(plan.steps);
     const int64_t before = h->device_bytes;
     int32_t rc;
-    if ((rc = cxh::dev_upload(h, &c->d_jobs, jobs)) != CX_OK) return rc;
-    if ((rc = cxh::dev_upload(h, &c->d_children, plan.children)) != CX_OK) return rc;
-    if ((rc = cxh::dev_upload(h, &c->d_steps, plan.steps)) != CX_OK) return rc;
+    if ((rc = cxh::dev_alloc(h, &c->d_jobs, (int64_t)jobs.size())) != CX_OK) return rc;
+    if ((rc = cxh::dev_alloc(h, &c->d_children, (int64_t)c->children.size())) != CX_OK) return rc;
+    if ((rc = cxh::dev_alloc(h, &c->d_steps, (int64_t)c->steps.size())) != CX_OK) return rc;
     if ((rc = cxh::dev_alloc(h, &c->d_pot, plan.n_pot * plan.pot)) != CX_OK) return rc;
     if ((rc = cxh::dev_alloc(h, &c->d_ent, plan.n_ent * plan.msg)) != CX_OK) return rc;
+    if ((rc = cxh::dev_alloc(h, &c->d_dead, (int64_t)widest)) != CX_OK) return rc;
     // a potential or entry message that was never computed reads as UndefValue()
     CX_HIP(h, hipMemsetAsync(c->d_pot, 0xff, (size_t)std::max<int64_t>(1, plan.n_pot * plan.pot) * 8, h->stream));
     CX_HIP(h, hipMemsetAsync(c->d_ent, 0xff, (size_t)std::max<int64_t>(1, plan.n_ent * plan.msg) * 8, h->stream));
@@ -338,21 +385,84 @@ int32_t chain64_build(cx_handle *h, const std::vector<int32_t> &pos_var, const s
     return CX_OK;
 }
 
+// The device records hold POINTERS: the plan's handles resolved against the six base pointers of the moment.  Redone (host loop +
+// one upload per array) only when a base has moved: new rule tables (cx_set_factor_matrices) or a new plan.
+static int32_t chain64_resolve(cx_handle *h, Chain64 *c) {
+    double *bases[p64::kSpaces] = {h->d_zero_msg, h->d_mv_f2v, h->d_ptab, h->d_ptab_bt, c->d_pot, c->d_ent};
+    if (std::memcmp(bases, c->bases, sizeof bases) == 0) return CX_OK;
+    try {
+        auto ptr = [&](int64_t hd) { return (uint64_t)(uintptr_t)(bases[hd >> 56] + (hd & p64::kOffMask)); };
+        std::vector<uint64_t> w;
+        w.resize(c->jobs.size() * 2);
+        for (size_t i = 0; i < c->jobs.size(); i++) {
+            w[2 * i] = ptr(c->jobs[i].out);
+            w[2 * i + 1] = (uint64_t)(uint32_t)c->jobs[i].first | ((uint64_t)(uint32_t)c->jobs[i].n << 32);
+        }
+        CX_HIP(h, hipMemcpy(c->d_jobs, w.data(), w.size() * 8, hipMemcpyHostToDevice));
+        w.resize(c->children.size() * 10);
+        for (size_t i = 0; i < c->children.size(); i++) {
+            const p64::Child &r = c->children[i];
+            const int64_t hs[9] = {r.P, r.B, r.Bt, r.C, r.h, r.c, r.side[0], r.side[1], r.side[2]};
+            for (int k = 0; k < 9; k++) w[10 * i + k] = ptr(hs[k]);
+            w[10 * i + 9] = 0;
+        }
+        if (!w.empty()) CX_HIP(h, hipMemcpy(c->d_children, w.data(), w.size() * 8, hipMemcpyHostToDevice));
+        w.resize(c->steps.size() * 10);
+        for (size_t i = 0; i < c->steps.size(); i++) {
+            const p64::Step &r = c->steps[i];
+            const int64_t hs[9] = {r.src[0], r.src[1], r.src[2], r.P, r.Bt, r.C, r.h, r.c, r.dst};
+            for (int k = 0; k < 9; k++) w[10 * i + k] = ptr(hs[k]);
+            w[10 * i + 9] = (r.src[2] >> 56) != p64::kZero ? 1 : 0;      // a third source: one extra block of loads in the rule
+        }
+        if (!w.empty()) CX_HIP(h, hipMemcpy(c->d_steps, w.data(), w.size() * 8, hipMemcpyHostToDevice));
+    } catch (const std::bad_alloc &) { return cxh::fail(h, CX_ERR_OUT_OF_MEMORY, "chain-scan schedule, dim 64: host allocation failed"); }
+    std::memcpy(c->bases, bases, sizeof bases);
+    return CX_OK;
+}
+
 // one exact sweep: every launch of the plan, in order, on the handle's stream
 int32_t chain64_sweep(cx_handle *h) {
     Chain64 *c = (Chain64 *)h->chain64;
     if (!c) return cxh::fail(h, CX_ERR_STATE, "chain-scan schedule, dim 64: no plan");
-    double *b0 = h->d_zero_msg, *b1 = h->d_mv_f2v, *b2 = h->d_ptab, *b3 = h->d_ptab_bt, *b4 = c->d_pot, *b5 = c->d_ent;
+    { int32_t rc = chain64_resolve(h, c); if (rc != CX_OK) return rc; }
     static const int walk_waves = env_int("CX_MVC64_WALK_WAVES", 2);
+#ifdef CX_C64_STAMPS
+    static unsigned long long *d_st = nullptr;
+    const size_t st_n = (size_t)16 * 8192;
+    if (!d_st) {
+        (void)hipMalloc(&d_st, st_n * 8);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(cx_w64_stamps), &d_st, sizeof d_st);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(cx_c64_stamps), &d_st, sizeof d_st);
+    }
+    std::vector<unsigned long long> hs(st_n);
+#endif
     for (const auto &L : c->launches) {
-        if (L.kind == 0)
-            hipLaunchKernelGGL(k_compose64, dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_children, b0, b1, b2, b3, b4, b5);
-        else if (L.kind == 1)      // few jobs, long dependent chains: a wave alone on its SIMD
-            hipLaunchKernelGGL((k_walk64<1, true>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps, b0, b1, b2, b3, b4, b5);
-        else if (walk_waves == 1)
-            hipLaunchKernelGGL((k_walk64<1, false>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps, b0, b1, b2, b3, b4, b5);
-        else
-            hipLaunchKernelGGL((k_walk64<2, false>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps, b0, b1, b2, b3, b4, b5);
+#ifdef CX_C64_STAMPS
+        (void)hipMemsetAsync(d_st, 0, st_n * 8, h->stream);
+#endif
+        if (L.kind == 0) {
+            hipLaunchKernelGGL(k_compose64, dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_children);
+        } else {
+            CX_HIP(h, hipMemsetAsync(c->d_dead, 0, (size_t)L.n * 4, h->stream));
+            for (int s = 0; s < L.steps; s++) {
+                if (L.kind == 1)           // few jobs: a wave alone on its SIMD
+                    hipLaunchKernelGGL((k_step64<1, true>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps, s, c->d_dead);
+                else if (walk_waves == 1)
+                    hipLaunchKernelGGL((k_step64<1, false>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps, s, c->d_dead);
+                else
+                    hipLaunchKernelGGL((k_step64<2, false>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps, s, c->d_dead);
+            }
+        }
+#ifdef CX_C64_STAMPS
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipMemcpy(hs.data(), d_st, st_n * 8, hipMemcpyDeviceToHost);
+        const int per = L.kind == 0 ? 16 : 8, nph = L.kind == 0 ? 11 : 6;
+        double tot[16] = {0};
+        for (int wg = 0; wg < std::min(L.n, (int)(st_n / per)); wg++) for (int i = 0; i < nph; i++) tot[i] += (double)hs[(size_t)per * wg + i];
+        fprintf(stderr, "[c64 stamps] kind %d, %d jobs: cycles per job and phase:", L.kind, L.n);
+        for (int i = 0; i < nph; i++) fprintf(stderr, " %.0f", tot[i] / L.n);
+        fprintf(stderr, "\n");
+#endif
     }
     CX_HIP(h, hipGetLastError());
     return CX_OK;
@@ -363,7 +473,8 @@ void chain64_stats(const cx_handle *h, int64_t *out8) {
     for (int i = 0; i < 8; i++) out8[i] = 0;
     if (!c) return;
     out8[0] = c->K0; out8[1] = c->fan; out8[2] = c->levels; out8[3] = c->n_pot; out8[4] = c->n_compositions; out8[5] = c->n_rules;
-    out8[6] = (int64_t)c->launches.size(); out8[7] = c->bytes;
+    for (const auto &L : c->launches) out8[6] += L.kind == 0 ? 1 : L.steps;
+    out8[7] = c->bytes;
 }
 
 }  // namespace cx

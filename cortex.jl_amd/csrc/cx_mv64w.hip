@@ -65,7 +65,8 @@ void k_rule64w(int nwork, const int32_t *__restrict__ work_rec, const double *__
     const bool has2 = !fixed && s2 >= 0;
     const double *src2 = has2 ? f2v_in + (int64_t)s2 * kMsg : zero_msg;
 
-    (void)rule64w_apply<false>(tab, bt, tab + 2 * kD * kD, nullptr, nullptr, src0, src1, src2, has2, out + (int64_t)dst_slot * kMsg, S, Vs, lane, g, c);
+    (void)rule64w_apply<false>((gcdp)tab, (gcdp)bt, (gcdp)(tab + 2 * kD * kD), nullptr, nullptr, (gcdp)src0, (gcdp)src1, (gcdp)src2, has2,
+                               (gdp)(out + (int64_t)dst_slot * kMsg), S, Vs, lane, g, c);
 }
 
 void mv64w_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const double *f2v_in, double *f2v_out) {

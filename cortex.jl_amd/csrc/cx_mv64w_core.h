@@ -13,6 +13,10 @@ constexpr int kLdT = 17;                // leading dimension of the 16 x 16 LDS 
 constexpr int kFlagFixed = 1;
 
 using d4 = __attribute__((ext_vector_type(4))) double;
+// pointers into device memory, typed as such: a pointer that a kernel READS from a record (cx_mv64chain.hip) is generic to hipcc
+// unless it says so, and every access through a generic pointer is a flat_load / flat_store
+using gdp = __attribute__((address_space(1))) double *;
+using gcdp = const __attribute__((address_space(1))) double *;
 
 // 1 / sqrt(x): v_rsq_f64 (2^-24 relative, measured) and ONE third-order step y (1 + h/2 + 3 h^2/8), h = 1 - x y^2:
 // 0.62 ulp at worst over 2^20 arguments (tools/lab/rsq_acc.hip; two Newton steps: 1.06 ulp and two more dependent operations)
@@ -146,12 +150,12 @@ __device__ __forceinline__ int tile_off(int tr, int tc, int r, int g, int c) { r
 // AFFINE: the rule of a composed potential carries the offsets hv, cv (a single factor's rule has none).
 // S: 16 x 17 doubles, Vs: 4 x 16 x 17 doubles of LDS private to this wave.  Returns false — and stores nothing — when an input is
 // undefined (NaN) or M is not positive definite.
-template <bool AFFINE>
-__device__ __forceinline__ bool rule64w_apply(const double *tabP, const double *bt, const double *tabC,
-                                              const double *hv, const double *cv, const double *src0,
-                                              const double *src1, const double *src2, const bool has2,
-                                              double *dst, double *S, double (*Vs)[16 * kLdT],
-                                              const int lane, const int g, const int c) {
+// ZS (optional): 64 doubles of LDS private to this wave.  With it z = U^-T eta_in waits there between its solve and its use (eta_out =
+// Yt' z) instead of in 32 registers across the matrix solve — what the loops of cx_mv64chain.hip need to stay under 256 registers at two
+// waves per SIMD without spilling (over the limit hipcc also un-clusters the loads: one memory round trip per load).
+template <bool AFFINE, bool Z_IN_LDS = false>
+__device__ __forceinline__ bool rule64w_apply(gcdp tabP, gcdp bt, gcdp tabC, gcdp hv, gcdp cv, gcdp src0, gcdp src1, gcdp src2, const bool has2, gdp dst,
+                                              double *S, double (*Vs)[16 * kLdT], const int lane, const int g, const int c, double *ZS = nullptr) {
     W64_STAMP_INIT;
     (void)lane;
     // ---- M = P + sum of the other incoming Lambdas (ascending neighbour order), upper tiles only ------------------------------
@@ -220,7 +224,9 @@ __device__ __forceinline__ bool rule64w_apply(const double *tabP, const double *
         const double zcv = sum_groups(p);                                              // z_j = V_j' w_j
 #pragma unroll
         for (int r = 0; r < 4; r++) zrv[j][r] = cv_to_rv(zcv, g, r);
+        if (Z_IN_LDS && g == 0) ZS[16 * j + c] = zcv;
     }
+    const bool z_undefined = __builtin_isnan(bcast(zrv[3][0], 0));
 
     W64_STAMP(3);
     // ---- Yt = U^-T B', one block COLUMN at a time (forward substitution over its four row blocks) ------------------------------
@@ -242,7 +248,7 @@ __device__ __forceinline__ bool rule64w_apply(const double *tabP, const double *
         }
     }
     // not positive definite somewhere: NaN everywhere downstream — leave the old message
-    if (__builtin_isnan(bcast(Y[3][0][0], 0)) || __builtin_isnan(bcast(zrv[3][0], 0))) return false;
+    if (__builtin_isnan(bcast(Y[3][0][0], 0)) || z_undefined) return false;
     W64_STAMP(4);
 
     // ---- Gram tile by tile: G[a][b] = sum_j Yt[j][a]' Yt[j][b];  Lambda_out = C - G (C symmetric: the lower tiles are the
@@ -275,7 +281,7 @@ __device__ __forceinline__ bool rule64w_apply(const double *tabP, const double *
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) p += Y[j][a][r] * zrv[j][r];
+            for (int r = 0; r < 4; r++) p += Y[j][a][r] * (Z_IN_LDS ? ZS[16 * j + g + 4 * r] : zrv[j][r]);
         double ecv = sum_groups(p);                                                    // (Yt' z)[16 a + c]
         if (AFFINE) ecv += cv[16 * a + c];
         if (g == 0) dst[16 * a + c] = ecv;

@@ -69,12 +69,15 @@ def timed(dev, fn, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
-def c2():
+def c2(check=None):
+    """check(dev, model) -> dict: an optional parity callback run on the timed device (bench.py passes one that uses the CPU checker;
+    nothing under tools/ reaches into the checker)"""
     T = 250_001
     model = cx.synth.ssm_chain(T, seed=1234)
     dev = cx.DeviceGraph(schedule=L.SCHED_CHAIN_SCAN)
     cx.synth.load_into_device(model, dev)
     dt = timed(dev, lambda: dev.sweep(1), 50, 5)
+    parity = check(dev, model) if check else None
     st = dev.stats()
     # one reference update_marginals! on this chain is 5T-4 message computations + T marginals (SURVEY §3.3)
     # the same chain under the fused flooding schedule: ONE parallel sweep (information moves one step; T sweeps converge)
@@ -93,7 +96,8 @@ def c2():
             "roofline": roofline("hbm", achieved, HBM_PEAK_GBS, "GB/s", tr[0] if tr else None, limited_by="launch latency (2 kernels per sweep)",
                                  basis="counter traffic of the sweep's kernels / sweep time" if tr else "algorithmic bytes / sweep time",
                                  traffic_source=tr[1] if tr else None, algorithmic_bytes_per_sweep=alg, frac_algorithmic=alg / dt / 1e9 / HBM_PEAK_GBS),
-            "flooding": {"ms_per_sweep": dtf * 1e3, "updates_per_sweep": nf, "updates_per_s": nf / dtf, "algorithmic_GBps": nf * 32 / dtf / 1e9}}
+            "flooding": {"ms_per_sweep": dtf * 1e3, "updates_per_sweep": nf, "updates_per_s": nf / dtf, "algorithmic_GBps": nf * 32 / dtf / 1e9},
+            **({"parity": parity} if parity else {})}
 
 
 def mv(d, T, steps):
@@ -141,7 +145,7 @@ def mv(d, T, steps):
     return out
 
 
-def mv_scan(d, T, steps, ks=(None,)):
+def mv_scan(d, T, steps, ks=(None,), check=None):
     """the chain-scan schedule for dim 2..4 (cx_mvchain.hip): ONE sweep = the exact smoother = one reference update_marginals!
     (5T-4 message computations + T marginals).  ks: values of CX_MVC_K (links per thread) to time; None = the default."""
     model = cx.synth.lgssm_chain(T, d=d, seed=1234)
@@ -165,6 +169,7 @@ def mv_scan(d, T, steps, ks=(None,)):
             dev.sweep(1)
         dt_fresh = timed(dev, fresh, max(steps // 3, 3), 2)
         tr = counter_traffic(["k_mvc_totals", "k_mvc_scan_totals", "k_mvc_apply", "k_mvc_marg_out"]) if k is None else None
+        parity = check(dev, model) if (check and k is None) else None
         alg = ref_upd * 2 * payload
         achieved = (tr[0] if tr else alg) / dt / 1e9
         out.append({"config": "C3-scan" if d == 4 else f"d{d}-scan", "links_per_thread": k,
@@ -175,12 +180,13 @@ def mv_scan(d, T, steps, ks=(None,)):
                     "roofline": roofline("hbm", achieved, HBM_PEAK_GBS, "GB/s", tr[0] if tr else None, kernel="k_mvc_totals + k_mvc_scan_totals + k_mvc_apply + k_mvc_marg_out",
                                          basis="counter traffic of the sweep's four launches / sweep time" if tr else "algorithmic bytes / sweep time",
                                          traffic_source=tr[1] if tr else None, algorithmic_bytes_per_sweep=alg,
-                                         frac_algorithmic=alg / dt / 1e9 / HBM_PEAK_GBS)})
+                                         frac_algorithmic=alg / dt / 1e9 / HBM_PEAK_GBS),
+                    **({"parity": parity} if parity else {})})
     os.environ.pop("CX_MVC_K", None)
     return out
 
 
-def mv64_scan(T, steps, ks=(None,)):
+def mv64_scan(T, steps, ks=(None,), check=None):
     """the chain-scan schedule for dim 64 (cx_mv64chain.hip): ONE sweep = the exact smoother = one reference update_marginals!
     (5T-4 message computations).  Matrix work per sweep from the plan: 960 v_mfma_f64_16x16x4_f64 per pairwise composition
     of potentials + 384 per rule application (2048 flop each).  ks: values of CX_MVC64_K (links per level-0 block); None = the default."""
@@ -200,7 +206,8 @@ def mv64_scan(T, steps, ks=(None,)):
         n_mfma = 960 * ps["compositions"] + 384 * ps["rules"]
         tf = n_mfma * 2048 / dt / 1e12
         ref_upd = 5 * T - 4
-        out.append({"config": "C5-scan", "links_per_block": ps["links_per_block"],
+        parity = check(dev, model) if (check and k is None) else None
+        out.append({"config": "C5-scan", "links_per_block": ps["links_per_block"], **({"parity": parity} if parity else {}),
                     "workload": f"d=64 linear-Gaussian chain T={T} ({st['n_edges']} edges), chain-scan schedule: exact forward/backward in one sweep",
                     "ms_per_sweep": dt * 1e3, "reference_updates_per_sweep": ref_upd, "updates_per_s": ref_upd / dt, "plan": ps,
                     "mfma_TFLOPs": tf,
