@@ -165,7 +165,8 @@ void sweep_main(cx_handle *h, bool skip_ghosts) {
         // are recomputed from the stored messages on demand: ensure_v2f).  Variables off the chains — observed ones, stand-ins —
         // have marginals that depend on stored messages only: a full variable phase after those were set, none otherwise.
         const bool fast = h->chain_covers_all && h->big_vars.empty() && h->cfg.materialize_messages_to_factor == 0 && !h->offchain_marg_dirty;
-        const int form = marg ? (h->cfg.family == CX_FAMILY_NATURAL2 ? 2 : 1) : 0;
+        const int form = marg ? (h->d_split_mean ? 3 : (h->cfg.family == CX_FAMILY_NATURAL2 ? 2 : 1)) : 0;
+        h->split_marg_written = fast && form == 3;
         cx::launch_chain_scan(h, h->d_f2v, h->chain_covers_all, fast ? form : 0, h->chain_v2f_from_scan);   // all forward and backward chain messages
         if (fast && marg) {
             h->v2f_stale = true;

@@ -78,6 +78,13 @@ __device__ __forceinline__ double2 chain_factor_rule(double2 m, double q, double
     return o;
 }
 
+// the factor variance of a receiving slot: the per-slot table, or — when an owner of this handle names precision variables
+// (cx_vmp.hip: q = 1 / E[precision], the same for every factor of one precision variable) — read through the slot's index
+__device__ __forceinline__ double slot_q(const double *__restrict__ q, const int32_t *__restrict__ qg, const double *__restrict__ gm, int slot) {
+    if (qg) { const int g = qg[slot]; if (g >= 0) return 1.0 / gm[g]; }
+    return q[slot];
+}
+
 // side information of chain position i: the sum of the variable's incoming messages except its (≤2) chain slots.
 // FUSED_LEAVES: those messages are first recomputed from the variable→factor messages of their senders (observed leaves,
 // priors keep their stored value) and stored — the factor phase of the flooding schedule restricted to the slots the
@@ -87,6 +94,7 @@ __global__ __launch_bounds__(kBlock) void k_chain_side(int npos, const int32_t *
                                                        const int32_t *__restrict__ pos_skip1, const int32_t *__restrict__ vbase,
                                                        const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
                                                        const int32_t *__restrict__ partner, const double *__restrict__ q,
+                                                       const int32_t *__restrict__ qg, const double *__restrict__ gm,
                                                        const double *__restrict__ pa, const double *__restrict__ pb,
                                                        const double2 *__restrict__ v2f, double2 *__restrict__ f2v,
                                                        double2 *__restrict__ side) {
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void k_chain_side(int npos, const int32_t *
             if (p >= 0) {
                 const double2 in = v2f[p];
                 if (!__builtin_isnan(in.y)) {
-                    m = chain_factor_rule(in, q[slot], pa ? pa[slot] : 1.0, pb ? pb[slot] : 0.0);
+                    m = chain_factor_rule(in, slot_q(q, qg, gm, slot), pa ? pa[slot] : 1.0, pb ? pb[slot] : 0.0);
                     f2v[slot] = m;
                 }
             }
@@ -126,6 +134,8 @@ struct ChainArgs {
     const uint8_t *head_fwd;     // link l is the first link of its path
     const uint8_t *head_bwd;     // link l is the last link of its path
     const double *q, *a, *b;     // rule parameters per RECEIVING slot (a, b may be null: additive)
+    const int32_t *qg;           // slot_q: optional indirection of q through a precision variable's mean
+    const double *gm;
     const double2 *side;
     const int32_t *pos_var;      // variable at a chain position (for the marginals k_chain_apply<.., true> writes)
 };
@@ -145,7 +155,7 @@ __device__ __forceinline__ Lin load_link(const ChainArgs &A, int tile_pos, int j
     const int recv = dir > 0 ? A.to_slot[l] : A.from_slot[l];
     const double2 u = A.side[A.link_pos[l] + (dir > 0 ? 0 : 1)];
     const int seg = dir > 0 ? A.head_fwd[l] : A.head_bwd[l];
-    return lin_of_link(u, A.q[recv], A.a ? A.a[recv] : 1.0, A.b ? A.b[recv] : 0.0, seg);
+    return lin_of_link(u, slot_q(A.q, A.qg, A.gm, recv), A.a ? A.a[recv] : 1.0, A.b ? A.b[recv] : 0.0, seg);
 }
 
 // workgroup-wide inclusive scan of kTile links; returns this thread's kItems inclusive prefixes and the tile total
@@ -250,7 +260,8 @@ __device__ __forceinline__ double2 chain_to_moment(double2 nat) {      // as cx_
 // are then recomputed from the stored messages when somebody asks for them, like in the fused schedule).
 template <bool OWN_CARRY, bool MARG>
 __global__ __launch_bounds__(kChainThreads) void k_chain_apply(ChainArgs A, const Lin *__restrict__ tile_excl, double2 *__restrict__ f2v,
-                                                               double2 *__restrict__ marg, int marg_form, double2 *__restrict__ chain_v2f) {
+                                                               double2 *__restrict__ marg, int marg_form, double2 *__restrict__ chain_v2f,
+                                                               double *__restrict__ split_mean, double *__restrict__ split_prec, const bool store_msgs) {
     const int half = threadIdx.x / kBlock, tid = threadIdx.x % kBlock, dir = half == 0 ? 1 : -1, ntiles = gridDim.x;
     const int pos = half == 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;
     tile_excl += (size_t)half * (ntiles + 1);
@@ -299,16 +310,22 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_apply(ChainArgs A, cons
         for (int j = threadIdx.x; j < cnt; j += kChainThreads) {
             const int l = lo + j, p = A.link_pos[l];
             const double2 sd = A.side[p], be = msg_s[1][j];
-            { const double2 al = msg_s[0][j]; if (!__builtin_isnan(al.y)) f2v[A.to_slot[l]] = al; }
-            if (!__builtin_isnan(be.y)) f2v[A.from_slot[l]] = be;
+            if (store_msgs) {
+                const double2 al = msg_s[0][j];
+                if (!__builtin_isnan(al.y)) f2v[A.to_slot[l]] = al;
+                if (!__builtin_isnan(be.y)) f2v[A.from_slot[l]] = be;
+            }
             double2 lx = sd;                                                  // everything the left variable hears except this link
             if (!A.head_fwd[l]) { const double2 al = j > 0 ? msg_s[0][j - 1] : seam_alpha; lx.x += al.x; lx.y += al.y; }
             const double2 t = make_double2(lx.x + be.x, lx.y + be.y);
-            marg[A.pos_var[p]] = marg_form == 2 ? t : chain_to_moment(t);
+            // marg_form 3: (mean, precision) into two arrays of the handle's owner (cx_vmp.hip keeps its marginals that way: no copy pass)
+            if (marg_form == 3) { const int v = A.pos_var[p]; split_mean[v] = t.x / t.y; split_prec[v] = t.y; }
+            else marg[A.pos_var[p]] = marg_form == 2 ? t : chain_to_moment(t);
             const double2 s1 = A.side[p + 1], al1 = msg_s[0][j];
             if (A.head_bwd[l]) {
                 const double2 u = make_double2(s1.x + al1.x, s1.y + al1.y);
-                marg[A.pos_var[p + 1]] = marg_form == 2 ? u : chain_to_moment(u);
+                if (marg_form == 3) { const int v = A.pos_var[p + 1]; split_mean[v] = u.x / u.y; split_prec[v] = u.y; }
+                else marg[A.pos_var[p + 1]] = marg_form == 2 ? u : chain_to_moment(u);
             }
             if (chain_v2f) {
                 // the two variable→factor messages of the link (the variational families read them: cx_vmp.hip, k_rate): what each
@@ -324,6 +341,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_apply(ChainArgs A, cons
 
 void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_form, bool chain_v2f) {
     // marg_form: 0 — messages only (the caller runs the variable phase); 1 / 2 — also the chain variables' marginals, moment / natural;
+    // 3 — as (mean, precision) into h->d_split_mean / d_split_prec;
     // chain_v2f (with marg_form != 0): also the variable→factor messages of the chain links
     const int nlinks = (int)h->chain_nlinks, npos = (int)h->chain_npos;
     if (nlinks == 0) return;
@@ -335,15 +353,15 @@ void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_f
         // nothing
     } else if (fused_leaves)
         hipLaunchKernelGGL(k_chain_side<true>, dim3((npos + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, npos, h->d_chain_pos_var,
-                           h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, pa, pb,
+                           h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, h->d_q_gamma, h->d_q_gmean, pa, pb,
                            h->d_v2f, f2v, h->d_chain_side);
     else
         hipLaunchKernelGGL(k_chain_side<false>, dim3((npos + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, npos, h->d_chain_pos_var,
-                           h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, pa, pb,
+                           h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, h->d_q_gamma, h->d_q_gmean, pa, pb,
                            h->d_v2f, f2v, h->d_chain_side);
     h->chain_side_dirty = false;
     ChainArgs A{nlinks, h->d_chain_link_pos, h->d_chain_from, h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd,
-                h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_chain_side, h->d_chain_pos_var};
+                h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_q_gamma, h->d_q_gmean, h->d_chain_side, h->d_chain_pos_var};
     const int ntiles = (nlinks + kTile - 1) / kTile;
     Lin *totals = (Lin *)h->d_chain_totals;
     hipLaunchKernelGGL(k_chain_tile_totals, dim3(ntiles), dim3(kChainThreads), 0, h->stream, A, totals);
@@ -353,11 +371,11 @@ void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_f
     static const int own_carry_tiles = [] { const char *e = getenv("CX_CHAIN_OWN_CARRY_TILES"); return e ? atoi(e) : kOwnCarryTiles; }();
     if (ntiles > own_carry_tiles) hipLaunchKernelGGL(k_chain_scan_totals, dim3(2), dim3(kBlock), 0, h->stream, ntiles, totals);
     if (ntiles <= own_carry_tiles) {
-        if (marg_form) hipLaunchKernelGGL((k_chain_apply<true, true>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, marg_form, chain_v2f ? h->d_v2f : nullptr);
-        else hipLaunchKernelGGL((k_chain_apply<true, false>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, 0, (double2 *)nullptr);
+        if (marg_form) hipLaunchKernelGGL((k_chain_apply<true, true>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, marg_form, chain_v2f ? h->d_v2f : nullptr, h->d_split_mean, h->d_split_prec, !(h->chain_msgs_unread && marg_form == 3 && chain_v2f));
+        else hipLaunchKernelGGL((k_chain_apply<true, false>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, 0, (double2 *)nullptr, (double *)nullptr, (double *)nullptr, true);
     } else {
-        if (marg_form) hipLaunchKernelGGL((k_chain_apply<false, true>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, marg_form, chain_v2f ? h->d_v2f : nullptr);
-        else hipLaunchKernelGGL((k_chain_apply<false, false>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, 0, (double2 *)nullptr);
+        if (marg_form) hipLaunchKernelGGL((k_chain_apply<false, true>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, marg_form, chain_v2f ? h->d_v2f : nullptr, h->d_split_mean, h->d_split_prec, !(h->chain_msgs_unread && marg_form == 3 && chain_v2f));
+        else hipLaunchKernelGGL((k_chain_apply<false, false>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, 0, (double2 *)nullptr, (double *)nullptr, (double *)nullptr, true);
     }
 }
 
@@ -367,18 +385,18 @@ void launch_chain_totals(cx_handle *h, double2 *f2v, bool fused_leaves, int64_t 
     const double *pa = h->any_linear ? h->d_a : nullptr, *pb = h->any_linear ? h->d_b : nullptr;
     if (fused_leaves)
         hipLaunchKernelGGL(k_chain_side<true>, dim3((npos + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, npos, h->d_chain_pos_var,
-                           h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, pa, pb,
+                           h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, h->d_q_gamma, h->d_q_gmean, pa, pb,
                            h->d_v2f, f2v, h->d_chain_side);
     else
         hipLaunchKernelGGL(k_chain_side<false>, dim3((npos + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, npos, h->d_chain_pos_var,
-                           h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, pa, pb,
+                           h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, h->d_q_gamma, h->d_q_gmean, pa, pb,
                            h->d_v2f, f2v, h->d_chain_side);
     h->chain_side_dirty = true;     // the boundary messages will change before the sweep proper
     const int ntiles = (nlinks + kTile - 1) / kTile;
     *ntiles_out = ntiles;
     if (nlinks == 0) return;
     ChainArgs A{nlinks, h->d_chain_link_pos, h->d_chain_from, h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd,
-                h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_chain_side, h->d_chain_pos_var};
+                h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_q_gamma, h->d_q_gmean, h->d_chain_side, h->d_chain_pos_var};
     hipLaunchKernelGGL(k_chain_tile_totals, dim3(ntiles), dim3(kChainThreads), 0, h->stream, A, (Lin *)h->d_chain_totals);
 }
 

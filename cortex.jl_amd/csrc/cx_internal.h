@@ -66,6 +66,13 @@ struct cx_handle {
     uint8_t *d_vinfo = nullptr;
     double *d_q = nullptr, *d_a = nullptr, *d_b = nullptr;     // per RECEIVING slot: effective rule parameters
     double *d_sq = nullptr, *d_sa = nullptr, *d_sb = nullptr;  // the same, indexed by the SENDING slot (push)
+    // chain scan, set by an owner that drives this handle (cx_vmp.hip's inner handle; never owned here):
+    const int32_t *d_q_gamma = nullptr;   // per slot: index into d_q_gmean of the precision variable whose mean sets this factor's variance
+    const double *d_q_gmean = nullptr;    //   q = 1 / d_q_gmean[d_q_gamma[slot]] read in place of d_q[slot] (no per-slot table to rewrite per call)
+    double *d_split_mean = nullptr, *d_split_prec = nullptr;   // the scan writes (mean, precision) of the chain variables here instead of d_marg
+    bool split_marg_written = false;      // ... and did so in the last sweep
+    bool chain_msgs_unread = false;       // the owner reads the chain links' variable→factor messages and marginals only: the scan need not store
+                                          // the factor→variable messages of the links (nothing of this handle is asked for them)
     double2 *d_f2v = nullptr, *d_v2f = nullptr, *d_marg = nullptr;  // natural-form messages, moment-form marginals
     double2 *d_f2v_alt = nullptr;   // second factor→variable buffer (Jacobi double buffering of the fused sweep)
     double2 *d_prev = nullptr;      // snapshot for cx_residual

@@ -31,7 +31,7 @@
 #include <string>
 #include <vector>
 
-#include "cx_internal.h"
+#include "cx_host.h"
 
 namespace {
 
@@ -598,11 +598,27 @@ int32_t vmp_update_marginals(cx_handle *h, int64_t n, const int64_t *ids) {
         if (do_normal && !s->structured) { std::swap(s->n_mean, s->n_mean_alt); std::swap(s->n_prec, s->n_prec_alt); }
         if (do_normal && s->structured) {
             cx_handle *c = s->chain;
-            hipLaunchKernelGGL(k_set_q, dim3(blocks(c->nslots)), dim3(256), 0, h->stream, (int)c->nslots, s->d_slot_gamma, s->g_mean, c->d_q);
+            // The factor variance q = 1 / E[precision] is one number per precision variable: under the chain-scan schedule the inner
+            // handle's kernels read it through the slot's precision index (slot_q, cx_chain.hip) instead of from a per-slot table that
+            // k_set_q rewrote on every call (13 us, 48 MB at n = 1e6: profiles/r03_vmp_rocprof.md), and the scan's second kernel stores
+            // the states' (mean, precision) straight into this family's arrays instead of k_pull_marginals copying them (8 us, 34 MB).
+            // Any other schedule, and a sweep that has to run the general variable phase, keep the two kernels.
+            bool scan = c->cfg.schedule == CX_SCHED_CHAIN_SCAN;
+            if (scan) {      // a reader of messages off the chains would get its leaf messages from the general factor phase, which reads the table
+                int32_t rcb = cxh::build_chains(c);
+                VMP_REQUIRE(h, rcb == CX_OK, rcb, std::string("cx_update_marginals (inner handle): ") + cx_last_error(c));
+                scan = c->chain_covers_all;
+            }
+            c->d_q_gamma = scan ? s->d_slot_gamma : nullptr; c->d_q_gmean = scan ? s->g_mean : nullptr;
+            c->d_split_mean = scan ? s->n_mean : nullptr; c->d_split_prec = scan ? s->n_prec : nullptr;
+            c->chain_msgs_unread = scan;     // k_rate reads the links' variable→factor messages, nobody the factor→variable ones (32 MB of stores)
+            if (!scan) hipLaunchKernelGGL(k_set_q, dim3(blocks(c->nslots)), dim3(256), 0, h->stream, (int)c->nslots, s->d_slot_gamma, s->g_mean, c->d_q);
             c->chain_side_dirty = true;      // the leaf messages N(y, q) change with q
+            c->split_marg_written = false;
             int32_t rc = cx_sweep(c, 1);
             VMP_REQUIRE(h, rc == CX_OK, rc, std::string("cx_update_marginals (inner handle): ") + cx_last_error(c));
-            hipLaunchKernelGGL(k_pull_marginals, dim3(blocks(s->nN)), dim3(256), 0, h->stream, (int)s->nN, c->d_marg, s->d_observed, s->n_mean, s->n_prec);
+            if (!c->split_marg_written)
+                hipLaunchKernelGGL(k_pull_marginals, dim3(blocks(s->nN)), dim3(256), 0, h->stream, (int)s->nN, c->d_marg, s->d_observed, s->n_mean, s->n_prec);
             s->chain_ready = true;
         }
         VMP_HIP(h, hipGetLastError());
