@@ -55,7 +55,14 @@ def parse(argv=None):
                          "RCCL as the fallback), issued by the library on RCCL, or by torch.distributed isend/irecv")
     ap.add_argument("--ipc-overlap", action="store_true",
                     help="--halo ipc: the owned part of a batch's first sweep between push and unpack (cx_halo_ipc_exchange_sweep); "
-                         "with --halo-depth auto the two forms are timed and the faster is kept")
+                         "with --halo-depth auto the forms are timed and the fastest is kept")
+    ap.add_argument("--ipc-early-push", action="store_true",
+                    help="--halo ipc: additionally the NEXT exchange is pushed inside the last sweep of every batch (cx_halo_ipc_batch): "
+                         "two partial sweeps of compute between a push and the wait for it")
+    ap.add_argument("--ipc-soak", type=int, default=24,
+                    help="--halo ipc, N > 1: before anything is timed, this many batches are run with an audit after EVERY exchange (the "
+                         "owners' values carried a second time over torch.distributed must equal the redundant rows bit for bit, ranks "
+                         "skewed against each other); one mismatch and all ranks fall back to the RCCL exchange")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
                     help="strong (default, BASELINE config 4): the ONE N x N grid is cut into row blocks over the ranks; "
                          "weak: every rank owns an N x N strip of an (N*ranks) x N grid")
@@ -509,7 +516,10 @@ class Workload:
                     return e if e or okf.item() == 1 else "another rank failed"
                 ex = None
                 try:
-                    ex = partition.DeepHaloIpc(dev, part, dist, torch, tdev, overlap=bool(getattr(args, "ipc_overlap", False)))
+                    # one launch per exchange only when every rank has a GPU of its own (cx_halo_ipc_set_fused)
+                    on_own_gpus = world > 1 and os.environ.get("CX_SINGLE_DEVICE") != "1"
+                    ex = partition.DeepHaloIpc(dev, part, dist, torch, tdev, overlap=bool(getattr(args, "ipc_overlap", False)),
+                                               early_push=bool(getattr(args, "ipc_early_push", False)), peers_on_other_devices=on_own_gpus)
                     dev.halo_ipc_set_timeout(30.0)
                     if os.environ.get("CX_BENCH_IPC_FAIL") == str(rank):      # rehearsal knob: one rank fails, ALL must fall back
                         raise RuntimeError("injected failure (CX_BENCH_IPC_FAIL)")
@@ -523,11 +533,34 @@ class Workload:
                     except (cx.CortexHipError, RuntimeError, ValueError) as e:
                         err = e
                     err = agreed(err)
+                soak = int(getattr(args, "ipc_soak", 0)) if world > 1 else 0
+                if err is None and soak > 0 and not getattr(args, "_ipc_soaked", False):
+                    # The protocol orders a flag behind its data by completion, not by fences (cx_api_ipc.hip) — an argument that only
+                    # means something between GPUs.  So it is shown to hold HERE before it is used: `soak` batches, every rank idling
+                    # at batches of its own so that pushes arrive early and late, and after EVERY exchange the redundant rows are
+                    # compared with the owners' values carried a second time by torch.distributed.  (Once per run: the depth trials
+                    # and the timed workload share the verdict.)
+                    adev = tdev if backend == "nccl" or dist is None else torch.device("cpu")
+                    try:
+                        for b in range(soak):
+                            if b % world == rank:
+                                dev.sync()
+                                time.sleep(0.002)
+                            ex.sweep(depth)
+                            if not ex.audit(dist, torch, adev):
+                                err = f"soak: exchange {b + 2} left a redundant row that differs from its owner's"
+                                break
+                    except (cx.CortexHipError, RuntimeError, ValueError) as e:
+                        err = e
+                    err = agreed(err)
+                    if err is None:
+                        args._ipc_soaked = True
                 if err is None:
                     exchange = self.ipc = ex
                     self.halo_kind = ("pushed into the neighbours' IPC-mapped receive areas behind an epoch flag" +
-                                      (", the owned part of a batch's first sweep between push and unpack" if getattr(args, "ipc_overlap", False)
-                                       else ", one launch per exchange") + " (audited at start)")
+                                      (", the next exchange pushed inside the last sweep of a batch, unpacked after the owned part of the first" if getattr(args, "ipc_early_push", False)
+                                       else ", the owned part of a batch's first sweep between push and unpack" if getattr(args, "ipc_overlap", False)
+                                       else "") + (f" (audited after each of {soak} exchanges before the timing, and at start and end)" if soak else " (audited at start)"))
                 elif rank == 0:
                     print(f"[bench] IPC exchange unavailable ({err}); falling back", file=sys.stderr)
                 err = None
@@ -665,42 +698,61 @@ def run_rank(args):
             # the same maxima and take the same decision.  Not part of the warm-up or of the timed regions.
             rows_min = N if args.scaling == "weak" else N // world
             depth_trials = {}
+            def trial(label):
+                """one candidate configuration (args as set by the caller): ms per sweep, or None — on EVERY rank — when any rank
+                failed; the workload is closed whatever happens (its receive area is mapped by the neighbours)"""
+                wt, ms, bad = None, None, 0
+                try:
+                    wt = Workload(args, args.scaling, rank, world, local_rank, backend, dist, torch, cx, L)
+                    wt.run(2 * args.halo_depth)
+                    tw, _ = timed_regions(wt, 384, 3, dist, torch, red_dev)       # 384 = 4 x 96 sweeps: whole batches at every candidate
+                    ms = min(tw) / 384 * 1e3
+                    if wt.ipc is not None:
+                        wt.ipc.check()
+                except Exception as e:      # a candidate that cannot be built or run is no candidate
+                    bad = 1
+                    if rank == 0:
+                        print(f"[bench] halo trial {label}: {e!r}", file=sys.stderr)
+                finally:
+                    if wt is not None:
+                        try:
+                            wt.close()
+                        except Exception:
+                            pass
+                if dist is not None:
+                    f = torch.tensor([bad], dtype=torch.int32, device=red_dev)
+                    dist.all_reduce(f, op=dist.ReduceOp.MAX)
+                    bad = int(f.item())
+                return (None if bad else ms), (wt is not None and wt.ipc is not None)
+
             for cand in (12, 16, 24, 32):
                 if cand > rows_min:
                     continue
                 args.halo_depth = cand
-                try:
-                    wt = Workload(args, args.scaling, rank, world, local_rank, backend, dist, torch, cx, L)
-                    wt.run(2 * cand)
-                    tw, _ = timed_regions(wt, 384, 3, dist, torch, red_dev)       # 384 = 4 x 96 sweeps: whole batches at every candidate
-                    depth_trials[cand] = min(tw) / 384 * 1e3
-                    wt.close()
-                except Exception as e:      # a candidate that cannot be built is no candidate (all ranks build the same cuts)
-                    if rank == 0:
-                        print(f"[bench] halo depth {cand}: {e!r}", file=sys.stderr)
+                ms, _ = trial(f"depth {cand}")
+                if ms is not None:
+                    depth_trials[cand] = ms
             args.halo_depth = min(depth_trials, key=depth_trials.get) if depth_trials else 16
-            # ... and, at that depth, the exchange AROUND the owned part of the first sweep (cx_halo_ipc_exchange_sweep): the same
-            # results; whether hiding the neighbours' pushes behind one interior sweep pays for the extra launch is a property of
-            # the links as well (on one GPU it does not)
+            # ... and, at that depth, the two forms that put compute between a push and the wait for it: the exchange AROUND the owned
+            # part of the first sweep (cx_halo_ipc_exchange_sweep) and, on top of that, the next exchange pushed inside the last sweep of
+            # a batch (cx_halo_ipc_batch).  The same results; whether hiding the transfer pays for the extra launches is a property of
+            # the links (on one GPU, where nothing travels, it does not)
             if depth_trials and args.halo == "ipc":
-                try:
-                    args.ipc_overlap = True
-                    wt = Workload(args, args.scaling, rank, world, local_rank, backend, dist, torch, cx, L)
-                    if wt.ipc is not None:
-                        wt.run(2 * args.halo_depth)
-                        tw, _ = timed_regions(wt, 384, 3, dist, torch, red_dev)
-                        depth_trials["%d, exchange around the owned part of sweep 1" % args.halo_depth] = min(tw) / 384 * 1e3
-                        args.ipc_overlap = min(tw) / 384 * 1e3 < depth_trials[args.halo_depth]
-                    else:
-                        args.ipc_overlap = False
-                    wt.close()
-                except Exception as e:
-                    args.ipc_overlap = False
-                    if rank == 0:
-                        print(f"[bench] overlapped IPC exchange: {e!r}", file=sys.stderr)
+                best = depth_trials[args.halo_depth]
+                choice = (False, False)
+                for label, ov, ep in (("exchange around the owned part of sweep 1", True, False),
+                                      ("next exchange pushed inside the last sweep of a batch", False, True)):
+                    args.ipc_overlap, args.ipc_early_push = ov, ep
+                    ms, was_ipc = trial(label)
+                    if ms is not None and was_ipc:
+                        depth_trials["%d, %s" % (args.halo_depth, label)] = ms
+                        if ms < best:
+                            best, choice = ms, (ov, ep)
+                args.ipc_overlap, args.ipc_early_push = choice
             if rank == 0:
                 print(f"[bench] halo trials (ms per sweep): {depth_trials} -> depth {args.halo_depth}" +
-                      (", exchange around the owned part of sweep 1" if getattr(args, "ipc_overlap", False) else ""), file=sys.stderr)
+                      (", next exchange pushed inside the last sweep of a batch" if getattr(args, "ipc_early_push", False) else
+                       ", exchange around the owned part of sweep 1" if getattr(args, "ipc_overlap", False) else ""), file=sys.stderr)
     else:
         args.halo_depth = int(args.halo_depth)
     w = Workload(args, args.scaling, rank, world, local_rank, backend, dist, torch, cx, L)

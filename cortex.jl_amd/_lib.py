@@ -93,6 +93,8 @@ SIGNATURES = {
     "cx_halo_ipc_connect": (_i32, [_vp, _i32, C.c_char_p, C.c_void_p, _i32, _i64, _i64]),
     "cx_halo_ipc_exchange": (_i32, [_vp]),
     "cx_halo_ipc_exchange_sweep": (_i32, [_vp, _i32]),
+    "cx_halo_ipc_batch": (_i32, [_vp, _i32]),
+    "cx_halo_ipc_set_fused": (_i32, [_vp, _i32]),
     "cx_halo_ipc_push": (_i32, [_vp]),
     "cx_halo_ipc_unpack": (_i32, [_vp]),
     "cx_halo_ipc_status": (_i32, [_vp, _pi32, _pi64]),

@@ -122,7 +122,9 @@ __device__ __forceinline__ void ipc_unpack_block(int64_t block, double2 *__restr
     }
     if (threadIdx.x == 0) {
         const unsigned long long t0 = wall_clock64();
-        int good = 1;
+        // a neighbour that did not arrive once is not waited for again: every later exchange would spin for the full limit (the host
+        // reads the error word only at the end of a region) — the grid drains at once and the results stay void
+        int good = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 ? 1 : 0;
         for (int p = 0; p < w.n_peers && good; p++)
             while (__hip_atomic_load(w.flag[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
                 if (wall_clock64() - t0 > limit_ticks) { good = 0; break; }
@@ -157,8 +159,11 @@ __global__ __launch_bounds__(kIpcBlock) void k_ipc_unpack(double2 *__restrict__ 
 }
 
 // push and unpack of one exchange in ONE launch: they touch disjoint messages (what a rank sends belongs to owned variables, what it
-// receives to redundant ones).  The first n_push workgroups push — they are dispatched first and never wait — the others wait for
-// the neighbours' flags and unpack.
+// receives to redundant ones).  The first n_push workgroups push and never wait, the others wait for the neighbours' flags and unpack.
+// REQUIREMENT: no waiting workgroup may keep a workgroup it waits for off the device.  Neither dispatch order nor residency is
+// promised by the runtime, so this form is used only when (a) the caller has said that every neighbour pushes from ANOTHER device
+// (cx_halo_ipc_set_fused) — a rank that is its own neighbour, handles of one process and processes that share a GPU take the two
+// launches, which have no dependency inside a kernel — and (b) the whole grid fits the device at one workgroup per compute unit.
 __global__ __launch_bounds__(kIpcBlock) void k_ipc_exchange(double2 *__restrict__ f2v, const int32_t *__restrict__ send_slots, int64_t n_send, int ncp,
                                                             PushArgs a, unsigned int n_push, unsigned int *__restrict__ done,
                                                             const int32_t *__restrict__ recv_slots, const double2 *__restrict__ area, int64_t n_recv,
@@ -205,15 +210,42 @@ int32_t cx_halo_ipc_alloc(cx_handle *h, void *handle64, void **local_base, int64
     hipError_t e = hipExtMallocWithFlags(&h->d_ipc_block, total, hipDeviceMallocFinegrained);
     if (e != hipSuccess) return fail(h, e == hipErrorOutOfMemory ? CX_ERR_OUT_OF_MEMORY : CX_ERR_DEVICE,
                                      std::string("cx_halo_ipc_alloc: hipExtMallocWithFlags(fine-grained): ") + hipGetErrorString(e));
-    CX_HIP(h, hipMemset(h->d_ipc_block, 0, total));
-    CX_HIP(h, hipMalloc(&h->d_ipc_local, 64));               // [0] workgroups done (push), [1] error word (unpack)
-    CX_HIP(h, hipMemset(h->d_ipc_local, 0, 64));
+    // any failure from here on leaves NO half-built state behind (a block without connections would pass the later checks)
+#define CX_IPC_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cx::ipc_destroy(h); \
+        return fail(h, e_ == hipErrorOutOfMemory ? CX_ERR_OUT_OF_MEMORY : CX_ERR_DEVICE, std::string("cx_halo_ipc_alloc: " #call ": ") + hipGetErrorString(e_)); } } while (0)
+    CX_IPC_TRY(hipMemset(h->d_ipc_block, 0, total));
+    CX_IPC_TRY(hipMalloc(&h->d_ipc_local, 64));               // [0] workgroups done (push), [1] error word (unpack)
+    CX_IPC_TRY(hipMemset(h->d_ipc_local, 0, 64));
     hipIpcMemHandle_t hd;
     static_assert(sizeof(hd) == 64, "hipIpcMemHandle_t is 64 bytes");
-    CX_HIP(h, hipIpcGetMemHandle(&hd, h->d_ipc_block));
+    CX_IPC_TRY(hipIpcGetMemHandle(&hd, h->d_ipc_block));
+#undef CX_IPC_TRY
     std::memcpy(handle64, &hd, 64);
     h->ipc_area_bytes = area;
     h->ipc_conn.assign(h->peers.size(), cx_handle::IpcConn{});
+    // the last sweep of a batch can run in two parts around an early push (cx_halo_ipc_batch): which slices hold no WRITER of a message
+    // of the send list (the thread of the partner slot's variable writes it), and of those the longest run inside the owned-only slices
+    h->ipc_quiet_lo = 1; h->ipc_quiet_hi = 0;
+    if (h->cfg.dim == 1 && h->own_slice_hi >= h->own_slice_lo) {
+        try {
+            std::vector<int32_t> slot_var(h->nslots, -1);
+            for (int64_t e = 0; e < h->ne; e++) slot_var[cx::slot_of_edge(h, e)] = h->edge_var[e];
+            std::vector<uint8_t> writer(h->nslices, 0);
+            for (int32_t sl : h->send_slots) {
+                const int32_t p = sl >= 0 && sl < (int32_t)h->nslots ? h->partner[sl] : -1;
+                if (p >= 0 && slot_var[p] >= 0) writer[slot_var[p] >> cx::kSliceShift] = 1;
+            }
+            int run0 = -1;
+            for (int sl = h->own_slice_lo; sl <= h->own_slice_hi + 1; sl++) {
+                const bool quiet = sl <= h->own_slice_hi && !writer[sl];
+                if (quiet && run0 < 0) run0 = sl;
+                if (!quiet && run0 >= 0) {
+                    if (sl - run0 > h->ipc_quiet_hi - h->ipc_quiet_lo + 1) { h->ipc_quiet_lo = run0; h->ipc_quiet_hi = sl - 1; }
+                    run0 = -1;
+                }
+            }
+        } catch (const std::bad_alloc &) { cx::ipc_destroy(h); return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_halo_ipc_alloc: host allocation failed"); }
+    }
     *local_base = h->d_ipc_block;
     *area_bytes = area;
     return CX_OK;
@@ -266,8 +298,9 @@ int32_t cx_halo_ipc_connect(cx_handle *h, int32_t peer_index, const void *handle
 // epoch and raise their flags.  cx_halo_ipc_unpack: wait for the flags of the epoch last pushed and scatter the receive area into
 // the redundant rows.  cx_halo_ipc_exchange = both in ONE launch.  (Handles of ONE process whose streams may share a hardware queue call
 // every push before any unpack, so that no waiting unpack sits in front of the push it waits for.)
-static int32_t ipc_push(cx_handle *h, const char *who) {
+static int32_t ipc_push(cx_handle *h, const char *who, const double2 *src = nullptr) {
     CX_REQUIRE(h, h && h->has_graph && h->halo_state && h->d_ipc_block, CX_ERR_STATE, std::string(who) + ": call cx_halo_ipc_alloc first");
+    CX_REQUIRE(h, h->ipc_conn.size() == h->peers.size(), CX_ERR_STATE, std::string(who) + ": the peer list changed after cx_halo_ipc_alloc");
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, std::string(who) + ": a cx_sweep_begin is still open");
     CX_REQUIRE(h, h->ipc_pushed == h->ipc_epoch, CX_ERR_STATE, std::string(who) + ": the previous push has not been followed by its unpack");
     PushArgs a{};
@@ -285,7 +318,7 @@ static int32_t ipc_push(cx_handle *h, const char *who) {
     const int64_t ns = (int64_t)h->send_slots.size() * ncp;
     // the push runs even with nothing to send: its last workgroup raises the flags the neighbours wait for
     hipLaunchKernelGGL(k_ipc_push, dim3((unsigned)std::max<int64_t>((ns + kIpcBlock * kIpcItems - 1) / (kIpcBlock * kIpcItems), 1)), dim3(kIpcBlock), 0, h->stream,
-                       (const double2 *)cx::ipc_messages(h), (const int32_t *)h->d_send_slots, ns, ncp, a, epoch, (unsigned int *)h->d_ipc_local);
+                       src ? src : (const double2 *)cx::ipc_messages(h), (const int32_t *)h->d_send_slots, ns, ncp, a, epoch, (unsigned int *)h->d_ipc_local);
     h->ipc_pushed = (int64_t)epoch;
     CX_HIP(h, hipGetLastError());
     return CX_OK;
@@ -293,6 +326,7 @@ static int32_t ipc_push(cx_handle *h, const char *who) {
 
 static int32_t ipc_unpack(cx_handle *h, const char *who) {
     CX_REQUIRE(h, h && h->has_graph && h->halo_state && h->d_ipc_block, CX_ERR_STATE, std::string(who) + ": call cx_halo_ipc_alloc first");
+    CX_REQUIRE(h, h->ipc_conn.size() == h->peers.size(), CX_ERR_STATE, std::string(who) + ": the peer list changed after cx_halo_ipc_alloc");
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, std::string(who) + ": a cx_sweep_begin is still open");
     CX_REQUIRE(h, h->ipc_pushed == h->ipc_epoch + 1, CX_ERR_STATE, std::string(who) + ": no push is waiting for its unpack (cx_halo_ipc_push)");
     WaitArgs w{};
@@ -318,7 +352,20 @@ int32_t cx_halo_ipc_exchange(cx_handle *h) {
     const char *who = "cx_halo_ipc_exchange";
     CX_REQUIRE(h, h && h->has_graph && h->halo_state && h->d_ipc_block, CX_ERR_STATE, std::string(who) + ": call cx_halo_ipc_alloc first");
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, std::string(who) + ": a cx_sweep_begin is still open");
-    CX_REQUIRE(h, h->ipc_pushed == h->ipc_epoch, CX_ERR_STATE, std::string(who) + ": a push is waiting for its unpack (cx_halo_ipc_unpack)");
+    CX_REQUIRE(h, h->ipc_conn.size() == h->peers.size(), CX_ERR_STATE, std::string(who) + ": the peer list changed after cx_halo_ipc_alloc");
+    // a push made early (cx_halo_ipc_batch: during the last sweep of the batch before) already carries the state of this moment
+    if (h->ipc_pushed == h->ipc_epoch + 1) return ipc_unpack(h, who);
+    CX_REQUIRE(h, h->ipc_pushed == h->ipc_epoch, CX_ERR_STATE, std::string(who) + ": push / unpack out of step");
+    {
+        const int64_t per_ = kIpcBlock * kIpcItems, ncp_ = cx::ipc_ncp(h);
+        const int64_t wgs = std::max<int64_t>(((int64_t)h->send_slots.size() * ncp_ + per_ - 1) / per_, 1) + std::max<int64_t>(((int64_t)h->recv_slots.size() * ncp_ + per_ - 1) / per_, 1);
+        int ncu = 0;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->cfg.device);
+        if (!h->ipc_fused || wgs > std::max(ncu, 1)) {      // two launches: no workgroup waits for another one of its own kernel
+            const int32_t rc = ipc_push(h, who);
+            return rc != CX_OK ? rc : ipc_unpack(h, who);
+        }
+    }
     PushArgs a{};
     WaitArgs w{};
     a.n_peers = w.n_peers = (int)h->peers.size();
@@ -362,7 +409,8 @@ int32_t cx_halo_ipc_exchange_sweep(cx_handle *h, int32_t n_sweeps) {
         const int32_t rc = cx_halo_ipc_exchange(h);
         return rc != CX_OK ? rc : cx_sweep(h, n_sweeps);
     }
-    int32_t rc = ipc_push(h, "cx_halo_ipc_exchange_sweep");
+    int32_t rc = CX_OK;
+    if (h->ipc_pushed == h->ipc_epoch) rc = ipc_push(h, "cx_halo_ipc_exchange_sweep");      // (not when cx_halo_ipc_batch pushed it already)
     if (rc != CX_OK) return rc;
     const int L = h->halo_depth;         // sweep 1 after an exchange runs every layer <= depth
     const int lo = h->trim_hi[L] >= h->trim_lo[L] ? h->trim_lo[L] : 0, hi = h->trim_hi[L] >= h->trim_lo[L] ? h->trim_hi[L] : (int)h->nslices - 1;
@@ -378,6 +426,75 @@ int32_t cx_halo_ipc_exchange_sweep(cx_handle *h, int32_t n_sweeps) {
     h->sweeps_since_exchange = 1;
     CX_HIP(h, hipGetLastError());
     return n_sweeps > 1 ? cx_sweep(h, n_sweeps - 1) : CX_OK;
+}
+
+// One batch with the NEXT exchange's push inside its last sweep (the wire hidden behind compute):
+//     [push, unless the batch before made it]  |  sweep 1, owned slices  |  wait + unpack  |  rest of sweep 1  |  sweeps 2 .. n - 1  |
+//     last sweep: every slice that holds a writer of the send list  |  PUSH of the next exchange  |  the quiet run of that sweep
+// so that between a push and the wait for it lie the quiet part of a sweep and the owned part of the next one (≈ 16 us of compute on
+// a 1/8 strip of C4 where cx_halo_ipc_exchange_sweep has ≈ 9 and cx_halo_ipc_exchange none).  The push reads the buffer the running
+// sweep WRITES (the Jacobi output), in which every message of the send list is final once its writers have run; a sweep computed in
+// parts is bit-identical to one launch (every message is written by the same thread from the same inputs).  The state after the call:
+// the next exchange is pushed but not unpacked — cx_halo_ipc_exchange / _exchange_sweep / _batch pick that up.  Falls back to
+// cx_halo_ipc_exchange_sweep when the sweep cannot be split, there is no quiet run, or n_sweeps < 2.
+int32_t cx_halo_ipc_batch(cx_handle *h, int32_t n_sweeps) {
+    const char *who = "cx_halo_ipc_batch";
+    CX_REQUIRE(h, h && h->has_graph && h->halo_state && h->d_ipc_block, CX_ERR_STATE, std::string(who) + ": call cx_halo_ipc_alloc first");
+    CX_REQUIRE(h, n_sweeps >= 1, CX_ERR_INVALID_ARGUMENT, std::string(who) + ": n_sweeps < 1");
+    const bool split = h->cfg.dim == 1 && h->cfg.schedule == CX_SCHED_FUSED && h->halo_depth > 0 && h->big_vars.empty() && !h->peers.empty() &&
+                       h->own_slice_hi >= h->own_slice_lo && h->cfg.sweeps_per_launch != 2 && h->ipc_quiet_hi >= h->ipc_quiet_lo &&
+                       h->cfg.materialize_messages_to_factor == 0 && n_sweeps >= 2 && n_sweeps <= h->halo_depth;
+    if (!split) return cx_halo_ipc_exchange_sweep(h, n_sweeps);
+    int32_t rc;
+    if (h->ipc_pushed == h->ipc_epoch) { if ((rc = ipc_push(h, who)) != CX_OK) return rc; }
+    auto range_of = [&](int j, int &lo, int &hi) {      // slices sweep j after the exchange has to run (cx_sweep's trimming)
+        const int L = h->halo_depth - std::min(j, h->halo_depth) + 1;
+        if (h->trim_hi[L] >= h->trim_lo[L]) { lo = h->trim_lo[L]; hi = h->trim_hi[L]; } else { lo = 0; hi = (int)h->nslices - 1; }
+    };
+    auto reset = [&]() { h->run_excl_lo = 1; h->run_excl_hi = 0; h->run_slice0 = 0; h->run_nslices = 0; };
+    // ---- sweep 1 around the unpack -----------------------------------------------------------------------------------------------
+    int lo, hi;
+    range_of(1, lo, hi);
+    h->run_slice0 = h->own_slice_lo; h->run_nslices = h->own_slice_hi - h->own_slice_lo + 1;
+    sweep_main(h, false);
+    rc = ipc_unpack(h, who);
+    if (rc != CX_OK) { reset(); return rc; }
+    h->run_slice0 = lo; h->run_nslices = hi - lo + 1; h->run_excl_lo = h->own_slice_lo; h->run_excl_hi = h->own_slice_hi;
+    sweep_main(h, false);
+    reset();
+    sweep_finish(h);
+    h->alt_two_back = false;
+    h->sweeps_since_exchange = 1;
+    // ---- sweeps 2 .. n - 1 ---------------------------------------------------------------------------------------------------------
+    if (n_sweeps > 2 && (rc = cx_sweep(h, n_sweeps - 2)) != CX_OK) return rc;
+    // ---- the last sweep around the push of the NEXT exchange ------------------------------------------------------------------------
+    range_of(n_sweeps, lo, hi);
+    const int qlo = std::max(h->ipc_quiet_lo, lo), qhi = std::min(h->ipc_quiet_hi, hi);
+    if (qhi < qlo) {                                       // nothing quiet inside what this sweep runs
+        if ((rc = cx_sweep(h, 1)) != CX_OK) return rc;
+        return ipc_push(h, who);
+    }
+    h->run_slice0 = lo; h->run_nslices = hi - lo + 1; h->run_excl_lo = qlo; h->run_excl_hi = qhi;
+    sweep_main(h, false);
+    reset();
+    rc = ipc_push(h, who, h->d_f2v_alt);                   // the running sweep's output buffer: sweep_finish swaps it in
+    if (rc != CX_OK) return rc;
+    h->run_slice0 = qlo; h->run_nslices = qhi - qlo + 1;
+    sweep_main(h, false);
+    reset();
+    sweep_finish(h);
+    h->alt_two_back = false;
+    h->sweeps_since_exchange++;
+    CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
+// on != 0: the caller asserts that every neighbour of this handle pushes from ANOTHER device, so that push and unpack of an exchange may
+// share one launch (k_ipc_exchange's requirement); default off: two launches
+int32_t cx_halo_ipc_set_fused(cx_handle *h, int32_t on) {
+    CX_REQUIRE(h, h, CX_ERR_INVALID_ARGUMENT, "cx_halo_ipc_set_fused: null handle");
+    h->ipc_fused = on != 0;
+    return CX_OK;
 }
 
 // Waits for the stream and reports whether any unpack gave up waiting for a neighbour (then its redundant rows are stale and

@@ -144,6 +144,9 @@ struct cx_handle {
     void *d_ipc_local = nullptr;     // push completion counter, error word
     int64_t ipc_area_bytes = 0, ipc_epoch = 0, ipc_pushed = 0;   // epochs unpacked / pushed
     double ipc_timeout_s = 20.0;
+    bool ipc_fused = false;          // cx_halo_ipc_set_fused: push and unpack of an exchange as ONE launch (every neighbour pushes from another device)
+    int ipc_quiet_lo = 1, ipc_quiet_hi = 0;   // the longest run of owned-only slices none of whose variables WRITES a message of the send list
+                                              // (cx_halo_ipc_batch: that run of the last sweep is computed after the push); empty: none
     bool in_sweep = false;
     bool v2f_stale = false;          // fused schedule without materialisation: v2f must be recomputed before use
     int mv_max_deg = 0;              // dim 2..4: widest slice of the graph (0: not computed yet)

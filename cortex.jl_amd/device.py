@@ -283,6 +283,14 @@ class DeviceGraph:
         """the exchange around the owned part of the first of n sweeps"""
         self._check(self.lib.cx_halo_ipc_exchange_sweep(self.h, int(n)))
 
+    def halo_ipc_batch(self, n: int):
+        """cx_halo_ipc_batch: n sweeps with the next exchange pushed inside the last one (bit-identical to exchange + sweep(n))"""
+        self._check(self.lib.cx_halo_ipc_batch(self.h, int(n)))
+
+    def halo_ipc_set_fused(self, on: bool):
+        """cx_halo_ipc_set_fused: every neighbour pushes from another device -> one launch per exchange"""
+        self._check(self.lib.cx_halo_ipc_set_fused(self.h, 1 if on else 0))
+
     def halo_ipc_push(self):
         self._check(self.lib.cx_halo_ipc_push(self.h))
 

@@ -511,10 +511,15 @@ class DeepHaloIpc:
     process (`connect=False`, then `connect({rank: info})`), connect by device address.  A rank whose allocation or connection
     fails raises on EVERY rank after the handles have been gathered, so that all ranks can fall back together."""
 
-    def __init__(self, dev, part: Partition, dist=None, torch=None, device=None, connect=True, overlap: bool = False):
+    def __init__(self, dev, part: Partition, dist=None, torch=None, device=None, connect=True, overlap: bool = False, early_push: bool = False,
+                 peers_on_other_devices: bool = False):
         """overlap: cx_halo_ipc_exchange_sweep — the owned part of a batch's first sweep between the push and the unpack (the
-        neighbours' pushes travel meanwhile).  Bit-identical; costs a launch where nothing travels (one GPU)."""
-        self.dev, self.depth, self.k, self.part, self.fresh, self.overlap = dev, part.depth, 0, part, False, overlap
+        neighbours' pushes travel meanwhile).  early_push: cx_halo_ipc_batch — additionally the NEXT exchange is pushed inside the
+        last sweep of every full batch, as soon as the slices that write the boundary state have run (two partial sweeps of compute
+        between a push and the wait for it).  Both bit-identical; both cost launches where nothing travels (one GPU).
+        peers_on_other_devices: the caller's assertion that every neighbour pushes from another GPU — only then do push and unpack of
+        an exchange share one launch (cx_halo_ipc_set_fused)."""
+        self.dev, self.depth, self.k, self.part, self.fresh, self.overlap, self.early_push = dev, part.depth, 0, part, False, overlap, early_push
         dev.halo_configure_state(part.send_var, part.send_fac, part.recv_var, part.recv_fac)
         if part.layer_var is not None and part.depth and dev.dim == 1:
             dev.halo_set_layers(part.layer_var, part.layer, part.depth)    # trimmed sweeps between exchanges
@@ -524,6 +529,7 @@ class DeepHaloIpc:
         self.info, err = None, None
         try:
             self.handle, self.base, self.area_bytes = dev.halo_ipc_alloc()
+            dev.halo_ipc_set_fused(bool(peers_on_other_devices))
             # what a neighbour needs to push to me: my peer entries (index, sending rank, recv offset, count)
             self.info = {"rank": part.rank, "handle": self.handle, "base": self.base, "area_bytes": self.area_bytes, "pid": os.getpid(),
                          "entries": [(i, p.rank, p.recv.start, p.recv.stop - p.recv.start) for i, p in enumerate(part.peers)]}
@@ -563,7 +569,9 @@ class DeepHaloIpc:
     def sweep(self, n: int = 1):
         while n > 0:
             run = min(n, self.depth - self.k % self.depth)
-            if self.k % self.depth == 0 and not self.fresh and self.overlap:
+            if self.k % self.depth == 0 and not self.fresh and self.early_push and run == self.depth and run >= 2:
+                self.dev.halo_ipc_batch(run)         # a full batch: its last sweep carries the push of the next exchange
+            elif self.k % self.depth == 0 and not self.fresh and (self.overlap or self.early_push):
                 self.dev.halo_ipc_exchange_sweep(run)
             else:
                 if self.k % self.depth == 0:

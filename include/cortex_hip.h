@@ -344,6 +344,18 @@ int32_t cx_halo_ipc_exchange(cx_handle *h);
  *                           its interior.  Bit-identical to cx_halo_ipc_exchange + cx_sweep(n), and exactly that when the sweep
  *                           cannot be split (no cx_halo_set_layers, dim > 1, another schedule). */
 int32_t cx_halo_ipc_exchange_sweep(cx_handle *h, int32_t n_sweeps);
+/*   cx_halo_ipc_batch     : one batch of n sweeps (2 <= n <= depth) with the push of the NEXT exchange inside its last sweep: that
+ *                           sweep runs the slices that write the boundary state first, pushes, then runs the rest; the batch's own
+ *                           exchange is unpacked after the owned part of its first sweep.  Between a push and the wait for it then
+ *                           lie two partial sweeps of compute for the transfer to hide behind.  Bit-identical to
+ *                           cx_halo_ipc_exchange + cx_sweep(n); afterwards the next exchange is pushed but not unpacked, which
+ *                           cx_halo_ipc_exchange / _exchange_sweep / _batch pick up.  Falls back to cx_halo_ipc_exchange_sweep.
+ *   cx_halo_ipc_set_fused : on != 0 — the caller asserts that every neighbour pushes from ANOTHER device: push and unpack of an
+ *                           exchange may then share one launch.  Default off (two launches): a rank that is its own neighbour,
+ *                           handles of one process and processes sharing a GPU must not wait inside a kernel for workgroups of the
+ *                           same or a co-scheduled kernel. */
+int32_t cx_halo_ipc_batch(cx_handle *h, int32_t n_sweeps);
+int32_t cx_halo_ipc_set_fused(cx_handle *h, int32_t on);
 int32_t cx_halo_ipc_status(cx_handle *h, int32_t *timed_out, int64_t *exchanges);
 int32_t cx_halo_ipc_set_timeout(cx_handle *h, double seconds);
 

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 def main():
     rows, cols, depth, sweeps, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     skew = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
-    overlap = bool(int(sys.argv[7])) if len(sys.argv) > 7 else False
+    mode = int(sys.argv[7]) if len(sys.argv) > 7 else 0          # 0 plain, 1 the exchange around the owned part of sweep 1, 2 + the early push
     import time
     import numpy as np
     import torch
@@ -29,7 +29,7 @@ def main():
         part = partition.grid_rows_deep(rows, cols, rank, world, depth, seed=5)
         dev = cx.DeviceGraph(schedule=L.SCHED_FUSED)
         cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
-        ex = partition.DeepHaloIpc(dev, part, dist, torch, torch.device("cuda", 0), overlap=overlap)
+        ex = partition.DeepHaloIpc(dev, part, dist, torch, torch.device("cuda", 0), overlap=mode == 1, early_push=mode == 2)
         dev.halo_ipc_set_timeout(30.0)
         res["audit_start"] = ex.audit(dist, torch, torch.device("cpu"))       # gloo carries the second copy
         if skew > 0:

@@ -19,15 +19,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-@pytest.mark.parametrize("rows,cols,depth,sweeps", [(30, 64, 4, 11), (120, 300, 8, 27), (64, 256, 16, 33)])
+@pytest.mark.parametrize("overlap", [0, 1, 2])
+@pytest.mark.parametrize("rows,cols,depth,sweeps", [(30, 64, 4, 11), (120, 300, 8, 27), (64, 256, 16, 33), (354, 1415, 16, 50), (90, 300, 2, 9)])
 def test_ipc_exchange_self_neighbour(hip_lib, rows, cols, depth, sweeps, overlap):
-    """overlap: cx_halo_ipc_exchange_sweep — push, the slices of owned variables only, wait + unpack, the rest of the first sweep
-    (two launches of the sweep kernel for that sweep)."""
+    """overlap 1: cx_halo_ipc_exchange_sweep — push, the slices of owned variables only, wait + unpack, the rest of the first sweep
+    (two launches of the sweep kernel for that sweep).  overlap 2: cx_halo_ipc_batch — also the NEXT exchange's push inside the last
+    sweep of every full batch, between the slices that write the boundary state and the quiet rest."""
     part = partition.deep_self(rows, cols, depth, seed=8)
     dev = cx.DeviceGraph(schedule=L.SCHED_FUSED)
     cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
-    ex = partition.DeepHaloIpc(dev, part, overlap=overlap)
+    ex = partition.DeepHaloIpc(dev, part, overlap=overlap == 1, early_push=overlap == 2)
     dev.halo_ipc_set_timeout(5.0)
     import torch
 
@@ -39,7 +40,13 @@ def test_ipc_exchange_self_neighbour(hip_lib, rows, cols, depth, sweeps, overlap
     exchanges = -(-sweeps // depth)
     assert ex.check() == exchanges
     # the audited first exchange was made on its own; every later batch of the overlapped form splits its first sweep
-    assert launches == sweeps + (exchanges - 1 if overlap else 0)
+    if overlap < 2:
+        assert launches == sweeps + (exchanges - 1 if overlap else 0)
+    else:
+        # full batches after the audited one: first AND last sweep in two parts (where the strip has a quiet run); never fewer launches than sweeps
+        assert sweeps <= launches <= sweeps + 2 * exchanges
+        if rows >= 300:
+            assert launches >= sweeps + 2 * ((sweeps - depth) // depth), "the big strip has a quiet run: the last sweeps were split"
     plain = cx.DeviceGraph(schedule=L.SCHED_FUSED)
     cx.synth.load_into_device(part.model, plain, seed_variance=1e6)
     plain.sweep(sweeps)
@@ -186,12 +193,14 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,rows,cols,depth,sweeps,skew,overlap", [(2, 64, 128, 4, 19, 0.0, 0), (2, 354, 1415, 16, 35, 0.0, 0), (3, 96, 128, 4, 27, 0.15, 0),
-                                                                      (2, 64, 128, 2, 21, 0.1, 0), (2, 354, 1415, 16, 51, 0.0, 1), (3, 96, 128, 4, 27, 0.15, 1)])
+                                                                      (2, 64, 128, 2, 21, 0.1, 0), (2, 354, 1415, 16, 51, 0.0, 1), (3, 96, 128, 4, 27, 0.15, 1),
+                                                                      (2, 354, 1415, 16, 67, 0.0, 2), (3, 300, 256, 4, 31, 0.15, 2), (2, 64, 128, 2, 21, 0.1, 2)])
 def test_processes_on_one_gpu(hip_lib, tmp_path, world, rows, cols, depth, sweeps, skew, overlap):
     """Two or three ranks, one PROCESS each, all on cuda:0: each opens its neighbours' hipIpcMemHandles and pushes into them.
     (354 x 1415 at depth 16 is the volume of two neighbouring ranks of bench.py --gpus 8; three ranks give the middle one two
     neighbours.)  skew > 0: the ranks take turns idling between batches, so pushes arrive early and late relative to the reader.
-    overlap: cx_halo_ipc_exchange_sweep (the owned part of the first sweep between push and unpack)."""
+    overlap 1: cx_halo_ipc_exchange_sweep (the owned part of the first sweep between push and unpack); 2: cx_halo_ipc_batch (also the
+    next exchange's push inside the last sweep of a batch)."""
     out, port, procs = str(tmp_path / "res"), _free_port(), []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),

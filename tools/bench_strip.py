@@ -48,6 +48,10 @@ def main():
                                                                     "the owned part of the batch's first sweep) instead of serially on the compute stream")
     ap.add_argument("--ipc", action="store_true", help="with --exchange: push into the neighbour's IPC receive area + epoch flag (cx_halo_ipc_exchange: "
                                                        "two launches) instead of pack, RCCL send/recv, unpack")
+    ap.add_argument("--ipc-form", choices=["two", "one", "overlap", "early"], default="two",
+                    help="with --ipc: two launches per exchange (the default wherever neighbours may share a device); ONE launch (what "
+                         "ranks on GPUs of their own run: cx_halo_ipc_set_fused; with the rank as its own neighbour this is a timing rig only); "
+                         "overlap = cx_halo_ipc_exchange_sweep; early = cx_halo_ipc_batch (the next exchange pushed inside the last sweep of a batch)")
     ap.add_argument("--batch", type=int, default=0, help="sweeps per cx_sweep call (default: depth)")
     ap.add_argument("--no-trim", action="store_true", help="run every redundant row in every sweep (no cx_halo_set_layers)")
     a = ap.parse_args()
@@ -75,7 +79,9 @@ def main():
         ex = None
         if a.exchange:
             if a.ipc:
-                ex = partition.DeepHaloIpc(dev, self_exchange(part), overlap=a.overlap_exchange)
+                form = "overlap" if a.overlap_exchange else a.ipc_form
+                ex = partition.DeepHaloIpc(dev, self_exchange(part), overlap=form == "overlap", early_push=form == "early",
+                                           peers_on_other_devices=form == "one")
             else:
                 ex = partition.DeepHaloRccl(dev, self_exchange(part), None, torch, torch.device("cuda", 0), overlap=a.overlap_exchange)
         elif not a.no_trim:     # no exchange: the trimming schedule restarts every `depth` sweeps as if one had happened
@@ -109,7 +115,7 @@ def main():
         rows_owned = len(part.owned_x) // N
         rows_held = st["n_variables"] // N
         print(json.dumps({"strip": f"rank {a.rank} of {a.world}, {rows_owned} owned rows + 2 x {depth} redundant ({rows_held} rows held incl. stand-ins)",
-                          "depth": depth, "exchange": (("IPC push, owned part of sweep 1, unpack, rest: one stream" if a.overlap_exchange else "IPC push + flag, on the compute stream") if a.ipc else "overlapped with the owned part of the first sweep" if a.overlap_exchange else "RCCL, serial on the compute stream") if a.exchange else False, "us_per_sweep_wall": best[0], "us_per_sweep_device": best[1],
+                          "depth": depth, "exchange": (("IPC push, owned part of sweep 1, unpack, rest: one stream" if (a.overlap_exchange or a.ipc_form == "overlap") else "IPC, next exchange pushed inside the last sweep of a batch, unpacked after the owned part of the first" if a.ipc_form == "early" else "IPC push + flag, ONE launch" if a.ipc_form == "one" else "IPC push + flag, two launches") if a.ipc else "overlapped with the owned part of the first sweep" if a.overlap_exchange else "RCCL, serial on the compute stream") if a.exchange else False, "us_per_sweep_wall": best[0], "us_per_sweep_device": best[1],
                           "whole_grid_us_per_sweep": whole_us, "ideal_us": whole_us / a.world,
                           "ratio_to_ideal": best[0] / (whole_us / a.world), "speedup_if_all_ranks_like_this": whole_us / best[0],
                           "slices": st["n_slices"], "halo_messages": int(len(part.recv_var))}), flush=True)
