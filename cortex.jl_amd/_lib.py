@@ -18,7 +18,7 @@ TO_FACTOR, TO_VARIABLE = 1, 2
 ITEM_MESSAGE_TO_FACTOR, ITEM_MESSAGE_TO_VARIABLE, ITEM_INDIVIDUAL_MARGINAL = 1, 2, 4
 ITEM_PRODUCT_OF_MESSAGES, ITEM_JOINT_MARGINAL = 8, 16
 FORM_MOMENT, FORM_POINT, FORM_NATURAL, FORM_MEAN_PRECISION, FORM_GAMMA = 0, 1, 2, 3, 4
-FACTOR_OPAQUE, FACTOR_GAUSS_ADDITIVE, FACTOR_GAUSS_LINEAR, FACTOR_NORMAL_PRECISION, FACTOR_BERNOULLI = 0, 1, 2, 3, 4
+FACTOR_OPAQUE, FACTOR_GAUSS_ADDITIVE, FACTOR_GAUSS_LINEAR, FACTOR_NORMAL_PRECISION, FACTOR_BERNOULLI, FACTOR_GAUSS_LINEAR_N = 0, 1, 2, 3, 4, 5
 NPARAM = 4
 ROLE_OUT, ROLE_IN, ROLE_PRECISION = 0, 1, 2
 SCHED_FLOODING, SCHED_FUSED, SCHED_CHAIN_SCAN = 0, 1, 2
@@ -60,6 +60,7 @@ SIGNATURES = {
     "cx_set_factor_matrices": (_i32, [_vp, _i64, _pd, _pd]),
     "cx_graph_stats": (_i32, [_vp, C.POINTER(Stats)]),
     "cx_tile_stats": (_i32, [_vp, _pi64, _pd, _pi64]),
+    "cx_set_factor_coefficients": (_i32, [_vp, _i64, _pi64, _pi64, _pd]),
     "cx_edge_index": (_i32, [_vp, _i64, _pi64, _pi64, _pi64]),
     "cx_payload_doubles": (_i64, [_i32, _i32]),
     "cx_set_messages": (_i32, [_vp, _i64, _pi64, _pi64, _i32, _i32, _pd]),

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcortex_hip.so")
-SOURCES = ["cx_api.hip", "cx_api_mv.hip", "cx_api_msg.hip", "cx_api_sweep.hip", "cx_api_halo.hip", "cx_api_ipc.hip", "cx_api_state.hip", "cx_kernels.hip", "cx_tiles.hip", "cx_chain.hip", "cx_mv.hip", "cx_mvchain.hip", "cx_mv64chain.hip", "cx_mvbatch.hip", "cx_mv64.hip", "cx_mv64w.hip", "cx_comm.hip", "cx_vmp.hip"]
+SOURCES = ["cx_api.hip", "cx_api_mv.hip", "cx_api_msg.hip", "cx_api_sweep.hip", "cx_api_halo.hip", "cx_api_ipc.hip", "cx_api_state.hip", "cx_kernels.hip", "cx_kary.hip", "cx_tiles.hip", "cx_chain.hip", "cx_mv.hip", "cx_mvchain.hip", "cx_mv64chain.hip", "cx_mvbatch.hip", "cx_mv64.hip", "cx_mv64w.hip", "cx_comm.hip", "cx_vmp.hip"]
 # every header a source may include: a change in any of them rebuilds everything (cx_mv64w_core.h and cx_tiling.h were missing
 # from this list for a while — an edit there alone left the library as it was)
 HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(ROOT, "include", "cortex_hip.h")]

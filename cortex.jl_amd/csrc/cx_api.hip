@@ -23,6 +23,7 @@ void dev_free_all(cx_handle *h) {
                     h->d_mvc_side, h->d_mvc_totals, h->d_mvc_side_l, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix, h->d_mvc_wave_carry, h->d_mvc_block};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     cx::chain64_free(h);
+    cx::kary_free(h);
     cx::tiles_free(h);
     if (h->d_f2v_tmp) (void)hipFree(h->d_f2v_tmp);
     h->d_f2v_tmp = nullptr; h->alt_two_back = false;
@@ -286,6 +287,7 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
         }
         h->nf = n_factors;
         h->lin_out_is_second.assign(n_factors, 0); h->fac_edges.clear();
+        h->n_kary = 0; h->kary_slot.clear(); h->kary_coef.clear(); h->kary_qb.clear(); h->slot_kary.clear(); h->kary_dirty = true;
         std::vector<int32_t> edge_fac(ne);
         for (int64_t e = 0; e < ne; e++) {
             auto it = std::lower_bound(h->fac_ids.begin(), h->fac_ids.end(), h->edge_fac_id[e]);
@@ -332,6 +334,33 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
                 h->partner[b1] = b2; h->partner[b2] = b1;
                 continue;
             }
+            if (kind == CX_FACTOR_GAUSS_LINEAR_N) {
+                // more than two edges (cx_kary.hip): every edge's message reads all the others' (dependencies.jl:17-31).  Entry order: the OUT
+                // edge, then the IN edges by ascending variable id; coefficients start at a_i = 1 (cx_set_factor_coefficients)
+                const std::string who = "cx_graph_create: CX_FACTOR_GAUSS_LINEAR_N (factor id " + std::to_string(h->fac_ids[f]) + ")";
+                if (mv) return fail(h, CX_ERR_UNSUPPORTED, who + " needs dim == 1");
+                if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) return fail(h, CX_ERR_UNSUPPORTED, who + ": a factor of three or more variables is not a link of a chain (use the fused or the flooding schedule)");
+                if (deg < 3 || deg > 7) return fail(h, CX_ERR_UNSUPPORTED, who + " takes 2 to 6 inputs and one output (3 to 7 edges), not " + std::to_string(deg) + " edges");
+                if (!(p[0] >= 0.0)) return fail(h, CX_ERR_INVALID_ARGUMENT, who + ": the variance q must be >= 0");
+                if (!edge_role) return fail(h, CX_ERR_INVALID_ARGUMENT, who + " needs edge roles (one CX_ROLE_OUT, the rest CX_ROLE_IN)");
+                const size_t row = (size_t)h->n_kary++;
+                h->kary_slot.resize(8 * (row + 1), -1); h->kary_coef.resize(8 * (row + 1), 0.0);
+                h->kary_qb.push_back(p[0]); h->kary_qb.push_back(p[1]);
+                if (h->slot_kary.empty()) h->slot_kary.assign(slots, -1);
+                int n_in = 0, n_out = 0;
+                for (int32_t k = 0; k < deg; k++) {
+                    const int32_t e = fedge[foff[f] + k], sl = cx::slot_of_edge(h, e), role = edge_role[ord[e]];
+                    if (role != CX_ROLE_OUT && role != CX_ROLE_IN) return fail(h, CX_ERR_INVALID_ARGUMENT, who + ": edge roles are CX_ROLE_OUT or CX_ROLE_IN");
+                    const int pos = role == CX_ROLE_OUT ? 0 : 1 + n_in++;
+                    if (role == CX_ROLE_OUT && n_out++) return fail(h, CX_ERR_INVALID_ARGUMENT, who + " has more than one CX_ROLE_OUT edge");
+                    if (pos > 7) return fail(h, CX_ERR_INVALID_ARGUMENT, who + " has no CX_ROLE_OUT edge");
+                    h->kary_slot[8 * row + pos] = sl;
+                    h->kary_coef[8 * row + pos] = role == CX_ROLE_OUT ? 1.0 : -1.0;
+                    h->slot_kary[sl] = (int32_t)(8 * row + pos);
+                }
+                if (n_out != 1) return fail(h, CX_ERR_INVALID_ARGUMENT, who + " needs exactly one CX_ROLE_OUT edge");
+                continue;
+            }
             if (kind != CX_FACTOR_GAUSS_ADDITIVE && kind != CX_FACTOR_GAUSS_LINEAR)
                 return fail(h, CX_ERR_UNSUPPORTED, "cx_graph_create: unknown factor kind");
             if (deg != 2) return fail(h, CX_ERR_UNSUPPORTED, "cx_graph_create: Gaussian factor kinds need exactly 2 edges (factor id " + std::to_string(h->fac_ids[f]) + ")");
@@ -374,7 +403,8 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
         // factor, minus variable→factor messages of degree-1 variables (no dependencies, dependencies.jl:48-55)
         int64_t m = 0;
         for (int64_t e = 0; e < ne; e++) {
-            if (h->partner[cx::slot_of_edge(h, e)] < 0) continue;
+            const int32_t sl_ = cx::slot_of_edge(h, e);
+            if (h->partner[sl_] < 0 && (h->slot_kary.empty() || h->slot_kary[sl_] < 0)) continue;
             m += 1;
             if (var_deg[h->edge_var[e]] >= 2) m += 1;
         }
@@ -421,7 +451,9 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
             CX_HIP(h, hipMemsetAsync(h->d_f2v_alt, 0xff, (size_t)slots * sizeof(double2), h->stream));
         }
 #undef CX_TRY
+#define CX_TRY2(x) do { int32_t rc2_ = (x); if (rc2_ != CX_OK) { dev_free_all(h); return rc2_; } } while (0)
         CX_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->n_kary) { if (h->slot_kary.empty()) h->slot_kary.assign(slots, -1); CX_TRY2(cx::kary_upload(h)); }
         h->has_graph = true; h->offchain_marg_dirty = true;
         return CX_OK;
     } catch (const std::bad_alloc &) {

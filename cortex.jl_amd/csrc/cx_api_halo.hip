@@ -12,6 +12,7 @@ static inline int64_t halo_doubles(const cx_handle *h) { return h->cfg.dim == 1 
 
 int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const int64_t *sf, int64_t n_recv,
                           const int64_t *rv, const int64_t *rf) {
+    CX_REQUIRE(h, !h || h->n_kary == 0, CX_ERR_UNSUPPORTED, "halo configuration: partitions are implemented for unary and pairwise factors (this graph has CX_FACTOR_GAUSS_LINEAR_N factors)");
     CX_NOT_VMP(h, "cx_halo_configure");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_configure: no graph");
     // dim 2..4 under the chain-scan schedule: the lists only name the stand-ins of a time block (cx_chain_block_maps exchanges maps,
@@ -61,6 +62,7 @@ int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const
 // (the error of the frozen outer edge advances one row per sweep).
 int32_t cx_halo_configure_state(cx_handle *h, int64_t n_send, const int64_t *sv, const int64_t *sf, int64_t n_recv,
                                 const int64_t *rv, const int64_t *rf) {
+    CX_REQUIRE(h, !h || h->n_kary == 0, CX_ERR_UNSUPPORTED, "halo configuration: partitions are implemented for unary and pairwise factors (this graph has CX_FACTOR_GAUSS_LINEAR_N factors)");
     CX_NOT_VMP(h, "cx_halo_configure_state");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_configure_state: no graph");
     CX_REQUIRE(h, h->cfg.schedule != CX_SCHED_CHAIN_SCAN, CX_ERR_UNSUPPORTED,

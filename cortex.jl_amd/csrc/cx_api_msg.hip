@@ -205,7 +205,7 @@ static int32_t update_batch(cx_handle *h, const cx_item *items, int64_t n) {
     CX_REQUIRE(h, n > 0 && items, CX_ERR_INVALID_ARGUMENT, "cx_update_batch: null argument");
     if (h->cfg.dim > 1) { try { return mv_update_batch(h, items, n); } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_update_batch: host allocation failed"); } }
     try {
-        std::vector<int32_t> buf(5 * n, 0);
+        std::vector<int32_t> buf(5 * n, 0), kary_entries;
         for (int64_t i = 0; i < n; i++) {
             const cx_item &it = items[i];
             int64_t idx, var, lo = 0, hi = 0;
@@ -216,6 +216,9 @@ static int32_t update_batch(cx_handle *h, const cx_item *items, int64_t n) {
                 int64_t e = find_edge(h, it.variable_id, it.factor_id);
                 if (e < 0) return fail(h, CX_ERR_NOT_FOUND, "no connection between variable " + std::to_string(it.variable_id) + " and factor " + std::to_string(it.factor_id));
                 idx = cx::slot_of_edge(h, e); var = h->edge_var[e];
+                // a message out of a factor with more than two edges: computed from ALL its other stored variable→factor messages
+                // (cx_kary.hip) behind the batch's other items; the pairwise path sees a slot without a partner and leaves it alone
+                if (it.kind == CX_ITEM_MESSAGE_TO_VARIABLE && !h->slot_kary.empty() && h->slot_kary[idx] >= 0) kary_entries.push_back(h->slot_kary[idx]);
             } else if (it.kind == CX_ITEM_PRODUCT_OF_MESSAGES) {
                 // ProductOfMessages(variable_id, range, ...), inference_signal.jl:62-66: the range travels in factor_id
                 var = find_var(h, it.variable_id);
@@ -248,6 +251,16 @@ static int32_t update_batch(cx_handle *h, const cx_item *items, int64_t n) {
         if (rc != CX_OK) return rc;
         rc = ensure_v2f(h);
         if (rc != CX_OK) return rc;
+        if (!kary_entries.empty()) {
+            if ((rc = cx::kary_upload(h)) != CX_OK) return rc;
+            const int64_t nk = (int64_t)kary_entries.size();
+            int32_t *d_en = nullptr;
+            CX_HIP(h, hipMalloc((void **)&d_en, (size_t)nk * 4));
+            hipError_t ce = hipMemcpyAsync(d_en, kary_entries.data(), (size_t)nk * 4, hipMemcpyHostToDevice, h->stream);
+            if (ce == hipSuccess) { cx::launch_kary_items(h, d_en, nk); ce = hipStreamSynchronize(h->stream); }
+            (void)hipFree(d_en);
+            CX_HIP(h, ce);
+        }
         if (n <= cx::kSmallBatch) {
             // a per-signal process! or a wavefront of a few signals: the records ride in the kernel arguments and the call returns
             // as soon as the launch is queued.  What the host does next — setting readiness bits (signal.jl:232-253) — does not read

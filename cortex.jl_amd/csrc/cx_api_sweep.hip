@@ -180,24 +180,28 @@ void sweep_main(cx_handle *h, bool skip_ghosts) {
         cx::launch_var_to_factor(h, h->d_f2v, marg);
         cx::launch_big_var_to_factor(h, h->d_f2v, marg);
     } else {
-        const bool store = h->cfg.materialize_messages_to_factor != 0;
+        // a factor with more than two edges reads variable→factor messages that other threads compute: such a graph stores them
+        // every sweep and runs the factors' own kernel behind the variable phase, into the same output buffer (cx_kary.hip)
+        const bool store = h->cfg.materialize_messages_to_factor != 0 || h->n_kary > 0;
         cx::launch_fused(h, h->d_f2v, h->d_f2v_alt, marg, store, skip_ghosts);
         if (!h->big_vars.empty()) {
             cx::launch_big_var_to_factor(h, h->d_f2v, marg);
             cx::launch_push_slots(h, h->d_big_slots, (int64_t)h->big_slots.size(), h->d_f2v_alt, CX_KERNEL_BIG_VAR);
         }
+        cx::launch_kary(h, h->d_v2f, h->d_f2v_alt);
     }
 }
 
 void sweep_finish(cx_handle *h) {
     if (h->cfg.schedule == CX_SCHED_FLOODING) {
         cx::launch_factor_to_var(h, h->d_v2f, h->d_f2v);
+        cx::launch_kary(h, h->d_v2f, h->d_f2v);
     } else if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) {
         // nothing: the scans already produced every factor→variable message a free variable reads, from the same
         // variable→factor messages the variable phase just wrote (a factor phase here would only re-derive them)
     } else {
         std::swap(h->d_f2v, h->d_f2v_alt);
-        h->v2f_stale = h->cfg.materialize_messages_to_factor == 0;
+        h->v2f_stale = h->cfg.materialize_messages_to_factor == 0 && h->n_kary == 0;
     }
     h->sweeps_done++;
 }
@@ -293,11 +297,12 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
     CX_REQUIRE(h, h->halo_state || h->chain_partition || (h->recv_slots.empty() && h->send_slots.empty()), CX_ERR_STATE,
                "cx_sweep: this handle holds a partition (halo configured): use cx_sweep_begin / _main / _end");
     if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) { int32_t rc = build_chains(h); if (rc != CX_OK) return rc; }
+    { int32_t rc = cx::kary_upload(h); if (rc != CX_OK) return rc; }      // coefficients set since the last sweep
     int32_t s = 0;
     // pairs of sweeps as ONE launch each (cx_tiles.hip), when the schedule and the graph allow it
     // (opt-in: measured SLOWER than single sweeps on MI355X, see DESIGN.md §4c — kept as a tested experiment, not the default)
     const bool want_pairs = n_sweeps >= 2 && h->cfg.schedule == CX_SCHED_FUSED && h->cfg.sweeps_per_launch == 2 &&
-                            h->cfg.family == CX_FAMILY_GAUSSIAN && h->cfg.materialize_messages_to_factor == 0 && tiled_env_enabled();
+                            h->cfg.family == CX_FAMILY_GAUSSIAN && h->cfg.materialize_messages_to_factor == 0 && h->n_kary == 0 && tiled_env_enabled();
     if (want_pairs && h->tiles_state == 0) {
         std::string why;
         if (cx::tiles_build(h, why) && !cx::tiles_prepare_kernel(h)) { cx::tiles_free(h); h->tiles_state = -1; }

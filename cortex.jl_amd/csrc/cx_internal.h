@@ -79,6 +79,15 @@ struct cx_handle {
     double *d_scratch = nullptr;    // small reduction scratch
     int64_t device_bytes = 0;
 
+    // factors with more than two edges (cx_kary.hip, CX_FACTOR_GAUSS_LINEAR_N): entry = 8 * row + edge position (OUT first, then IN by
+    // ascending variable id); coefficient c_e = +1 (OUT) / -a_i (IN); their slots have partner -1 (no pairwise rule touches them)
+    int64_t n_kary = 0;
+    std::vector<int32_t> kary_slot, slot_kary;      // [8 n_kary] slot per entry (-1 padding); [nslots] entry of a slot, -1 otherwise
+    std::vector<double> kary_coef, kary_qb;         // [8 n_kary] c_e; [2 n_kary] q, b
+    int32_t *d_kary_slot = nullptr, *d_slot_kary = nullptr;
+    double *d_kary_coef = nullptr, *d_kary_qb = nullptr;
+    bool kary_dirty = true;
+
     // multivariate path (cx_mv.hip), dim in {2,3,4}: SoA component-major buffers [nc][nslots], packed symmetric Lambda
     int nc = 2;                                    // doubles per message (eta + packed Lambda; 64 + 64*64 for dim 64)
     int ncs = 2;                                   // STORED doubles per message slot: dim 2..4 pad nc to whole 16-byte pairs (cx_mv_core.h)
@@ -213,6 +222,11 @@ void launch_batch_small(cx_handle *h, const SmallBatch &recs, int n);   // 5 int
 void launch_scatter(cx_handle *h, double2 *dst, const int32_t *d_idx, const double2 *d_val, int64_t n);
 void launch_gather(cx_handle *h, const double2 *src, const int32_t *d_idx, double2 *d_val, int64_t n);
 void launch_seed(cx_handle *h, double2 *buf, int64_t n, double2 value, const int32_t *partner);
+// factors with more than two edges (cx_kary.hip)
+int32_t kary_upload(cx_handle *h);
+void kary_free(cx_handle *h);
+void launch_kary(cx_handle *h, const double2 *v2f, double2 *f2v_out);
+void launch_kary_items(cx_handle *h, const int32_t *d_entries, int64_t n);
 void launch_residual(cx_handle *h, const double2 *cur, const double2 *prev, int64_t n, double *d_out);
 void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_form, bool chain_v2f);
 void launch_chain_totals(cx_handle *h, double2 *f2v, bool fused_leaves, int64_t *ntiles_out);

@@ -431,10 +431,10 @@ __global__ void k_gather(const double2 *__restrict__ src, const int32_t *__restr
     if (i < n) val[i] = src[idx[i]];
 }
 
-__global__ void k_seed(double2 *__restrict__ buf, int64_t n, double2 value, const int32_t *__restrict__ partner) {
+__global__ void k_seed(double2 *__restrict__ buf, int64_t n, double2 value, const int32_t *__restrict__ partner, const int32_t *__restrict__ slot_kary) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (partner[i] < 0) return;  // padding slots and messages nobody computes are the caller's to set
+    if (partner[i] < 0 && !(slot_kary && slot_kary[i] >= 0)) return;  // padding slots and messages nobody computes are the caller's to set
     if (__builtin_isnan(buf[i].y)) buf[i] = value;
 }
 
@@ -647,7 +647,7 @@ void launch_gather(cx_handle *h, const double2 *src, const int32_t *d_idx, doubl
 
 void launch_seed(cx_handle *h, double2 *buf, int64_t n, double2 value, const int32_t *partner) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_seed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, buf, n, value, partner);
+    hipLaunchKernelGGL(k_seed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, buf, n, value, partner, (const int32_t *)h->d_slot_kary);
 }
 
 void launch_residual(cx_handle *h, const double2 *cur, const double2 *prev, int64_t n, double *d_out) {

@@ -73,6 +73,11 @@ class DeviceGraph:
                                              role, len(factor_ids), _p(factor_ids, C.c_int64),
                                              _p(factor_kind, C.c_int32), _p(fp, C.c_double)))
 
+    def set_factor_coefficients(self, variable_ids, factor_ids, a):
+        """cx_set_factor_coefficients: a_i of the ROLE_IN edges of CX_FACTOR_GAUSS_LINEAR_N factors (default 1)"""
+        v, f, a = _i64(np.atleast_1d(variable_ids)), _i64(np.atleast_1d(factor_ids)), _f64(np.atleast_1d(a))
+        self._check(self.lib.cx_set_factor_coefficients(self.h, len(v), _p(v, C.c_int64), _p(f, C.c_int64), _p(a, C.c_double)))
+
     def set_factor_matrices(self, parameter_set: int, A, Q):
         A, Q = _f64(A), _f64(Q)
         if A.shape != (self.dim, self.dim) or Q.shape != (self.dim, self.dim):

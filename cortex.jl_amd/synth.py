@@ -211,6 +211,68 @@ def concat_models(models) -> Model:
                  psets=first.psets, meta={"parts": [(len(m.x_ids), o) for m, o in parts], "kind": "concat"})
 
 
+def kary_model(n_factors: int, seed: int = 1234, tree: bool = True, k_choices=(2, 3, 4, 5, 6), observe: float = 0.0) -> Model:
+    """Scalar model with linear-Gaussian factors of MORE than two edges (CX_FACTOR_GAUSS_LINEAR_N): x_out = sum_i a_i x_i + b + N(0, q),
+    k in `k_choices` inputs each, plus a unary prior factor on every latent variable (message set by the caller, as the prior of
+    test/inference_engine_tests.jl:1224).  tree: every new factor hangs off ONE existing variable and brings its other k variables along
+    (a bipartite tree: sum-product is exact); otherwise the variables of a factor are drawn from a pool (loopy).  observe: the share of
+    leaf variables that carry a point-mass datum instead of a prior.  meta: the coefficient per edge (`coef_var`, `coef_fac`, `coef`),
+    `q`, `b`, `out_var` per factor."""
+    rng = np.random.default_rng(seed)
+    fac_vars, nvar = [], 1
+    for f in range(n_factors):
+        k = int(rng.choice(k_choices))
+        if tree:
+            anchor = int(rng.integers(1, nvar + 1))
+            vs = [anchor] + list(range(nvar + 1, nvar + k + 1))
+            nvar += k
+        else:
+            pool = max(nvar, k + 2, int(1.6 * (f + 2)))
+            vs = sorted(int(v) for v in rng.choice(np.arange(1, pool + 1), size=k + 1, replace=False))
+            nvar = max(nvar, pool)
+        fac_vars.append(vs)
+    x = np.arange(1, nvar + 1, dtype=np.int64)
+    used = np.unique(np.concatenate([np.asarray(v) for v in fac_vars]))
+    prior_fac_of = {int(v): nvar + 1 + i for i, v in enumerate(used)}           # one unary factor per variable that occurs
+    kf_id0 = nvar + len(used) + 1
+    ev, ef, er, coef_var, coef_fac, coef, out_var = [], [], [], [], [], [], []
+    q, b = rng.uniform(0.3, 1.5, n_factors), rng.standard_normal(n_factors)
+    for f, vs in enumerate(fac_vars):
+        fid = kf_id0 + f
+        o = int(rng.integers(0, len(vs)))
+        out_var.append(vs[o])
+        for j, v in enumerate(vs):
+            ev.append(v); ef.append(fid); er.append(L.ROLE_OUT if j == o else L.ROLE_IN)
+            if j != o:
+                coef_var.append(v); coef_fac.append(fid)
+                coef.append(float(rng.uniform(0.4, 1.3) * rng.choice([1.0, -1.0], p=[0.75, 0.25])))
+    # leaves that are observed carry data on their unary factor's edge instead of a prior message
+    deg = np.bincount(np.asarray(ev), minlength=nvar + 1)
+    is_obs = np.zeros(nvar + 1, dtype=bool)
+    if observe > 0:
+        leaves = [int(v) for v in used if deg[v] == 1]
+        is_obs[[v for v in leaves if rng.random() < observe]] = True
+    pv = np.array([v for v in used if not is_obs[v]], dtype=np.int64)
+    for v in used:                                   # every occurring variable has its unary factor (observed ones: the datum's factor is the k-ary one itself)
+        if not is_obs[v]:
+            ev.append(int(v)); ef.append(prior_fac_of[int(v)]); er.append(L.ROLE_OUT)
+    data_var = np.array([v for v in used if is_obs[v]], dtype=np.int64)
+    data_fac = np.array([ef[[i for i in range(len(ev)) if ev[i] == int(v)][0]] for v in data_var], dtype=np.int64)
+    prior_ids = np.array([prior_fac_of[int(v)] for v in pv], dtype=np.int64)
+    kf_ids = kf_id0 + np.arange(n_factors, dtype=np.int64)
+    params = np.zeros((len(prior_ids) + n_factors, 2))
+    params[len(prior_ids):, 0] = q
+    params[len(prior_ids):, 1] = b
+    return Model(edge_var=np.asarray(ev, dtype=np.int64), edge_fac=np.asarray(ef, dtype=np.int64), factor_ids=np.concatenate([prior_ids, kf_ids]),
+                 factor_kind=np.concatenate([np.full(len(prior_ids), L.FACTOR_OPAQUE), np.full(n_factors, L.FACTOR_GAUSS_LINEAR_N)]).astype(np.int32),
+                 factor_var=params, x_ids=pv, data_var=data_var, data_fac=data_fac, data_y=rng.standard_normal(len(data_var)) * 2,
+                 prior_var=pv, prior_fac=prior_ids, prior_mean=rng.standard_normal(len(pv)) * 2, prior_variance=rng.uniform(0.5, 2.0, len(pv)),
+                 edge_role=np.asarray(er, dtype=np.int32),
+                 meta={"kind": "kary", "coef_var": np.asarray(coef_var, dtype=np.int64), "coef_fac": np.asarray(coef_fac, dtype=np.int64),
+                       "coef": np.asarray(coef), "q": q, "b": b, "out_var": np.asarray(out_var, dtype=np.int64), "kary_ids": kf_ids,
+                       "fac_vars": fac_vars, "used": used})
+
+
 def load_into_device(model: Model, dev, seed_variance: float | None = None):
     """graph upload + the data injection a user of the reference does with set_value! before update_marginals!."""
     if model.dim > 1:
@@ -224,6 +286,8 @@ def load_into_device(model: Model, dev, seed_variance: float | None = None):
             dev.seed_messages(L.TO_VARIABLE, 0.0, seed_variance)
         return dev
     dev.graph_create(model.edge_var, model.edge_fac, model.factor_ids, model.factor_kind, model.factor_var, edge_role=model.edge_role)
+    if model.meta.get("kind") == "kary":
+        dev.set_factor_coefficients(model.meta["coef_var"], model.meta["coef_fac"], model.meta["coef"])
     if len(model.data_var):
         dev.set_messages(model.data_var, model.data_fac, L.TO_FACTOR, L.FORM_POINT, model.data_y)
     if len(model.prior_var):

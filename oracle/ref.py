@@ -25,7 +25,7 @@ P_SSM_BP, P_BETA_BERNOULLI, P_TRACING, P_CALLBACK = range(4)
 
 def build(force: bool = False) -> str:
     """Compile the C restatement with the committed recipe (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("cortex_ref.c", "bp_flood.c", "mv_flood.c", "blocktri.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("cortex_ref.c", "bp_flood.c", "bp_kary.c", "mv_flood.c", "blocktri.c", "Makefile")]
     if "CXO_LIB" in os.environ:
         return _SO
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
@@ -51,6 +51,7 @@ def lib():
         f.restype = res
         f.argtypes = list(args)
 
+    sig("cxo_kary_factor_phase", i64, i64, pi64, pi64, pd, pd, pd, pd, pd, pd, pd)
     sig("cxo_engine_create", vp, i32, i32)
     sig("cxo_engine_destroy", None, vp)
     sig("cxo_add_variable", i64, vp)
@@ -386,8 +387,9 @@ class FloodGraph:
         self.partner = np.full(self.ne, -1, dtype=np.int64)
         starts = np.flatnonzero(np.r_[True, fsorted[1:] != fsorted[:-1]])
         counts = np.diff(np.r_[starts, self.ne])
-        if np.any(counts > 2):
+        if np.any(counts > 2) and not getattr(self, "allow_kary", False):
             raise ValueError("scalar flooding oracle handles unary and pairwise factors only")
+        self._fstarts, self._fcounts, self._forder = starts, counts, forder
         two = starts[counts == 2]
         self.partner[forder[two]] = forder[two + 1]
         self.partner[forder[two + 1]] = forder[two]
@@ -442,3 +444,46 @@ class FloodGraph:
         L.cxo_flood_marginals(self.nv, _p(self.var_off, C.c_int64), _p(self.f2v_m, C.c_double),
                               _p(self.f2v_v, C.c_double), _p(m, C.c_double), _p(v, C.c_double), int(use_omp))
         return m, v
+
+
+class KaryFloodGraph(FloodGraph):
+    """FloodGraph + linear-Gaussian factors with more than two edges (oracle/bp_kary.c): one flooding sweep = the variable phase
+    (bp_flood.c, phase A: every message to a factor = the product of the variable's OTHER incoming messages), the pairwise factor
+    phase (none in these models) and the k-ary factor phase.  Built from a synth.kary_model."""
+    allow_kary = True
+
+    def __init__(self, model):
+        fvar = np.zeros(len(model.factor_ids))
+        super().__init__(model.edge_var, model.edge_fac, model.factor_ids, fvar)
+        # phase A computes a message to a factor for every edge "with a listener": to bp_flood.c that is partner >= 0.  The k-ary
+        # edges get a self-partner mark for phase A only; phase B of bp_flood.c (pairwise) is never run here.
+        meta = model.meta
+        kids = set(int(f) for f in meta["kary_ids"])
+        self.kary_edge = np.array([int(f) in kids for f in self.edge_fac])
+        self.partner_a = np.where(self.kary_edge, np.arange(self.ne), -1).astype(np.int64)
+        role = np.asarray(model.edge_role)[self.order]
+        coef = {(int(v), int(f)): float(a) for v, f, a in zip(meta["coef_var"], meta["coef_fac"], meta["coef"])}
+        foff, fedge, acoef = [0], [], []
+        for fid in meta["kary_ids"]:
+            es = np.flatnonzero(self.edge_fac == fid)
+            out = [e for e in es if role[e] == 0]
+            ins = [e for e in es if role[e] != 0]
+            assert len(out) == 1
+            for e in out + ins:
+                fedge.append(int(e))
+                acoef.append(coef.get((int(self.edge_var[e]), int(fid)), 1.0))
+            foff.append(len(fedge))
+        self.foff, self.fedge, self.acoef = np.array(foff, dtype=np.int64), np.array(fedge, dtype=np.int64), np.array(acoef)
+        self.kq, self.kb = np.ascontiguousarray(meta["q"], dtype=np.float64), np.ascontiguousarray(meta["b"], dtype=np.float64)
+
+    def sweep(self, n=1, use_omp=False, phases=3):
+        L = lib()
+        total = 0
+        for _ in range(n):
+            total += L.cxo_flood_sweep(self.nv, _p(self.var_off, C.c_int64), self.ne, _p(self.partner_a, C.c_int64), _p(self.q, C.c_double),
+                                       _p(self.fixed_v2f, C.c_uint8), _p(self.f2v_m, C.c_double), _p(self.f2v_v, C.c_double),
+                                       _p(self.v2f_m, C.c_double), _p(self.v2f_v, C.c_double), int(use_omp), 1)
+            total += L.cxo_kary_factor_phase(len(self.kq), _p(self.foff, C.c_int64), _p(self.fedge, C.c_int64), _p(self.acoef, C.c_double),
+                                             _p(self.kq, C.c_double), _p(self.kb, C.c_double), _p(self.v2f_m, C.c_double), _p(self.v2f_v, C.c_double),
+                                             _p(self.f2v_m, C.c_double), _p(self.f2v_v, C.c_double))
+        return total
