@@ -1,6 +1,7 @@
 // cx_api_halo.hip — partitioned graphs: message halos per sweep, state halos ("deep halo"), the RCCL exchange.
 
 #include "cx_host.h"
+#include "cx_halo_plan.h"
 
 using namespace cxh;
 
@@ -125,26 +126,7 @@ int32_t cx_halo_set_layers(cx_handle *h, int64_t n, const int64_t *variable_ids,
             if (layer[i] < 0) return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_halo_set_layers: negative layer");
             lay[v] = layer[i];
         }
-        h->trim_lo.assign(depth + 1, (int32_t)h->nslices); h->trim_hi.assign(depth + 1, -1);
-        for (int64_t v = 0; v < h->nv; v++) {
-            const int32_t s = (int32_t)(v >> cx::kSliceShift);
-            for (int32_t L = std::min<int32_t>(lay[v], depth + 1); L <= depth; L++) {   // a variable of layer l belongs to every set "layer <= L", L >= l
-                h->trim_lo[L] = std::min(h->trim_lo[L], s); h->trim_hi[L] = std::max(h->trim_hi[L], s);
-            }
-        }
-        // the longest run of slices whose variables are all owned (layer 0): what a sweep can run while an exchange is in flight
-        h->own_slice_lo = 1; h->own_slice_hi = 0;
-        int run0 = -1;
-        for (int64_t sl = 0; sl <= h->nslices; sl++) {
-            bool owned = sl < h->nslices;
-            for (int64_t v = sl * cx::kBlock; owned && v < std::min<int64_t>(h->nv, (sl + 1) * cx::kBlock); v++) owned = lay[v] == 0;
-            if (owned && run0 < 0) run0 = (int)sl;
-            if (!owned && run0 >= 0) {
-                if ((int)sl - run0 > h->own_slice_hi - h->own_slice_lo + 1) { h->own_slice_lo = run0; h->own_slice_hi = (int)sl - 1; }
-                run0 = -1;
-            }
-        }
-        h->halo_depth = depth;
+        cx::haloplan::layers(h, lay, depth);      // cx_halo_plan.h (GPU-free: also built and tested on the CPU under sanitizers)
         h->sweeps_since_exchange = 0;
         return CX_OK;
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_halo_set_layers: host allocation failed"); }

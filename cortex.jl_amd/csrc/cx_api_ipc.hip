@@ -17,6 +17,7 @@
 // error word that cx_halo_ipc_status reports, the grid drains either way; then the area is read past the caches.
 
 #include "cx_host.h"
+#include "cx_halo_plan.h"
 
 using namespace cxh;
 
@@ -226,25 +227,9 @@ int32_t cx_halo_ipc_alloc(cx_handle *h, void *handle64, void **local_base, int64
     // the last sweep of a batch can run in two parts around an early push (cx_halo_ipc_batch): which slices hold no WRITER of a message
     // of the send list (the thread of the partner slot's variable writes it), and of those the longest run inside the owned-only slices
     h->ipc_quiet_lo = 1; h->ipc_quiet_hi = 0;
-    if (h->cfg.dim == 1 && h->own_slice_hi >= h->own_slice_lo) {
-        try {
-            std::vector<int32_t> slot_var(h->nslots, -1);
-            for (int64_t e = 0; e < h->ne; e++) slot_var[cx::slot_of_edge(h, e)] = h->edge_var[e];
-            std::vector<uint8_t> writer(h->nslices, 0);
-            for (int32_t sl : h->send_slots) {
-                const int32_t p = sl >= 0 && sl < (int32_t)h->nslots ? h->partner[sl] : -1;
-                if (p >= 0 && slot_var[p] >= 0) writer[slot_var[p] >> cx::kSliceShift] = 1;
-            }
-            int run0 = -1;
-            for (int sl = h->own_slice_lo; sl <= h->own_slice_hi + 1; sl++) {
-                const bool quiet = sl <= h->own_slice_hi && !writer[sl];
-                if (quiet && run0 < 0) run0 = sl;
-                if (!quiet && run0 >= 0) {
-                    if (sl - run0 > h->ipc_quiet_hi - h->ipc_quiet_lo + 1) { h->ipc_quiet_lo = run0; h->ipc_quiet_hi = sl - 1; }
-                    run0 = -1;
-                }
-            }
-        } catch (const std::bad_alloc &) { cx::ipc_destroy(h); return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_halo_ipc_alloc: host allocation failed"); }
+    if (h->cfg.dim == 1) {
+        try { cx::haloplan::quiet_run(h); }      // cx_halo_plan.h
+        catch (const std::bad_alloc &) { cx::ipc_destroy(h); return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_halo_ipc_alloc: host allocation failed"); }
     }
     *local_base = h->d_ipc_block;
     *area_bytes = area;

@@ -11,6 +11,7 @@
 
 #include "cx_chain64_plan.h"
 #include "cx_chains.h"
+#include "cx_halo_plan.h"
 
 using cx::plan64::Plan;
 
@@ -87,6 +88,9 @@ struct HostGraph {                       // the host fields of cx_handle that cx
     std::vector<int32_t> kary_slot, slot_kary;
     std::vector<double> kary_coef, kary_qb;
     bool kary_dirty = true;
+    // deep halo (cx_halo_plan.h)
+    std::vector<int32_t> trim_lo, trim_hi, send_slots;
+    int own_slice_lo = 1, own_slice_hi = 0, halo_depth = 0, ipc_quiet_lo = 1, ipc_quiet_hi = 0;
     cx::flat::Out fo;
     cx::chains::Out co;
     std::string err;
@@ -126,10 +130,25 @@ int32_t cxh_flat_chains(void *p, char *err, int32_t errlen) {
     return rc;
 }
 
+// deep halo: layers by variable id (others 0), then the send list as slots; fills trim_lo / trim_hi / own and quiet runs
+int32_t cxh_flat_halo(void *p, int64_t n, const int64_t *variable_ids, const int32_t *layer, int32_t depth, int64_t n_send, const int32_t *send_slots) {
+    HostGraph *g = (HostGraph *)p;
+    std::vector<int32_t> lay(g->nv, 0);
+    for (int64_t i = 0; i < n; i++) {
+        auto it = std::lower_bound(g->var_ids.begin(), g->var_ids.end(), variable_ids[i]);
+        if (it == g->var_ids.end() || *it != variable_ids[i]) return CX_ERR_NOT_FOUND;
+        lay[it - g->var_ids.begin()] = layer[i];
+    }
+    cx::haloplan::layers(g, lay, depth);
+    g->send_slots.assign(send_slots, send_slots + n_send);
+    cx::haloplan::quiet_run(g);
+    return CX_OK;
+}
+
 // array `which` of the graph: returns its length, copies it as int64 (or as doubles for the floating-point ones) when out != NULL
 //   0 var_ids 1 var_off 2 edge_var 3 edge_fac_id 4 vbase 5 vinfo 6 slice_off 7 partner 8 big_vars 9 spdir 10 var_deg
 //   20 q 21 a 22 b 23 sq 24 sa 25 sb 26 kary_coef 27 kary_qb          30 kary_slot 31 slot_kary
-//   40 pos_var 41 skip0 42 skip1 43 link_pos 44 from 45 to 46 head_fwd 47 head_bwd 48 tab_fwd 49 tab_bwd
+//   40 pos_var 41 skip0 42 skip1 43 link_pos 44 from 45 to 46 head_fwd 47 head_bwd 48 tab_fwd 49 tab_bwd 50 trim_lo 51 trim_hi
 int64_t cxh_flat_array(const void *p, int32_t which, void *out) {
     const HostGraph *g = (const HostGraph *)p;
     auto ints = [&](const auto &v) { if (out) for (size_t i = 0; i < v.size(); i++) ((int64_t *)out)[i] = (int64_t)v[i]; return (int64_t)v.size(); };
@@ -144,15 +163,18 @@ int64_t cxh_flat_array(const void *p, int32_t which, void *out) {
     case 40: return ints(g->co.pos_var); case 41: return ints(g->co.skip0); case 42: return ints(g->co.skip1); case 43: return ints(g->co.link_pos);
     case 44: return ints(g->co.from); case 45: return ints(g->co.to); case 46: return ints(g->co.head_fwd); case 47: return ints(g->co.head_bwd);
     case 48: return ints(g->co.tab_fwd); case 49: return ints(g->co.tab_bwd);
+    case 50: return ints(g->trim_lo); case 51: return ints(g->trim_hi);
     }
     return -1;
 }
 
-// scalars: 0 nv 1 nf 2 ne 3 nslots 4 nslices 5 n_messages_per_sweep 6 any_linear 7 n_kary 8 big_start 9 npos_linked
+// scalars: 0 nv 1 nf 2 ne 3 nslots 4 nslices 5 n_messages_per_sweep 6 any_linear 7 n_kary 8 big_start 9 npos_linked 10 own_slice_lo 11 own_slice_hi
+//          12 ipc_quiet_lo 13 ipc_quiet_hi
 int64_t cxh_flat_scalar(const void *p, int32_t which) {
     const HostGraph *g = (const HostGraph *)p;
-    const int64_t v[] = {g->nv, g->nf, g->ne, g->nslots, g->nslices, g->n_messages_per_sweep, g->any_linear ? 1 : 0, g->n_kary, g->big_start, g->co.npos_linked};
-    return which >= 0 && which < 10 ? v[which] : -1;
+    const int64_t v[] = {g->nv, g->nf, g->ne, g->nslots, g->nslices, g->n_messages_per_sweep, g->any_linear ? 1 : 0, g->n_kary, g->big_start, g->co.npos_linked,
+                         g->own_slice_lo, g->own_slice_hi, g->ipc_quiet_lo, g->ipc_quiet_hi};
+    return which >= 0 && which < 14 ? v[which] : -1;
 }
 
 }  // extern "C"

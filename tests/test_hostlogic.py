@@ -39,7 +39,7 @@ def check_layout(g, model):
     # SELL-256: slice s holds variables 256 s .. 256 s + 255, as wide as its widest variable of degree <= 8; bigger ones go to a CSR tail
     nv, ns = len(var_ids), -(-len(var_ids) // 256)
     small = np.where(deg <= 8, deg, 0)
-    width = np.array([small[s * 256:(s + 1) * 256].max(initial=0) for s in range(ns)])
+    width = np.maximum.reduceat(np.r_[small, np.zeros(ns * 256 - nv, dtype=small.dtype)], np.arange(0, ns * 256, 256)) if nv else np.zeros(0, dtype=np.int64)
     slice_off = np.r_[0, np.cumsum(width * 256)]
     assert np.array_equal(g.arr("slice_off"), slice_off)
     vinfo = g.arr("vinfo")
@@ -54,16 +54,21 @@ def check_layout(g, model):
     slot = np.where(deg[vidx] <= 8, vbase[vidx] + 256 * k, vbase[vidx] + k)
     assert len(np.unique(slot)) == len(slot) and slot.max() < g.scalar("nslots")
     # partners: the two edges of every 2-edge factor that has a rule; everything else -1
-    kind_of = dict(zip(np.asarray(model.factor_ids).tolist(), np.asarray(model.factor_kind).tolist()))
-    partner = np.full(g.scalar("nslots"), -1, dtype=np.int64)
+    fids = np.asarray(model.factor_ids); fkinds = np.asarray(model.factor_kind)
+    fsrt = np.argsort(fids)
     fs = ef[order]
-    for f in np.unique(fs):
-        es = np.flatnonzero(fs == f)
-        if len(es) == 2 and kind_of[int(f)] in (L.FACTOR_GAUSS_ADDITIVE, L.FACTOR_GAUSS_LINEAR, L.FACTOR_BERNOULLI):
-            partner[slot[es[0]]], partner[slot[es[1]]] = slot[es[1]], slot[es[0]]
+    kind_e = fkinds[fsrt][np.searchsorted(fids[fsrt], fs)]          # factor kind per edge
+    partner = np.full(g.scalar("nslots"), -1, dtype=np.int64)
+    by_f = np.argsort(fs, kind="stable")
+    starts = np.flatnonzero(np.r_[True, fs[by_f][1:] != fs[by_f][:-1]])
+    counts = np.diff(np.r_[starts, len(fs)])
+    has_rule = np.isin(kind_e[by_f][starts], (L.FACTOR_GAUSS_ADDITIVE, L.FACTOR_GAUSS_LINEAR, L.FACTOR_BERNOULLI))
+    two = starts[(counts == 2) & has_rule]
+    e0, e1 = by_f[two], by_f[two + 1]
+    partner[slot[e0]], partner[slot[e1]] = slot[e1], slot[e0]
     assert np.array_equal(g.arr("partner"), partner)
     # the metric's unit: directed messages with a dependency and a listener
-    in_kary = np.array([kind_of[int(f)] == L.FACTOR_GAUSS_LINEAR_N for f in fs])
+    in_kary = kind_e == L.FACTOR_GAUSS_LINEAR_N
     live = (partner[slot] >= 0) | in_kary
     assert g.scalar("n_messages_per_sweep") == int(live.sum() + (live & (deg[vidx] >= 2)).sum())
     return slot, order, vidx
@@ -80,7 +85,7 @@ def test_scalar_graphs(make):
         assert g.scalar("any_linear") == 1 and len(g.arr("a")) == g.scalar("nslots")
         # effective parameters of the RECEIVING edge: forward (receiver = out) {a, b, q}; backward {1/a, -b/a, q/a^2}
         role = np.asarray(m.edge_role)[order]
-        par = {int(f): p for f, p in zip(m.factor_ids, np.atleast_2d(m.factor_var))}
+        par = {int(f): p for f, p in zip(m.factor_ids, np.atleast_2d(m.factor_var) if np.ndim(m.factor_var) > 1 else np.asarray(m.factor_var)[:, None])}
         a, b, q = g.arr("a"), g.arr("b"), g.arr("q")
         for e in np.flatnonzero(np.isin(np.asarray(m.edge_fac)[order], [f for f, k in zip(m.factor_ids, m.factor_kind) if k == L.FACTOR_GAUSS_LINEAR]))[:400]:
             qq, aa, bb = par[int(np.asarray(m.edge_fac)[order][e])][:3]
@@ -166,6 +171,46 @@ def test_factors_with_more_than_two_edges():
         assert coef[row, 0] == 1.0 and np.all(coef[row, 1:len(want)] == -1.0) and np.all(coef[row, len(want):] == 0.0)     # a_i = 1 until set
         assert [sk[s] for s in want] == [8 * row + j for j in range(len(want))]
     assert np.array_equal(g.arr("kary_qb").reshape(-1, 2), np.stack([m.meta["q"], m.meta["b"]], axis=1))
+
+
+@pytest.mark.parametrize("rows,cols,rank,world,depth", [(40, 30, 1, 3, 4), (354, 1415, 1, 2, 16), (1415 // 8 * 3, 1415, 1, 3, 16), (12, 9, 0, 2, 2)])
+def test_deep_halo_slice_ranges(rows, cols, rank, world, depth):
+    """cx_halo_set_layers' trimmed ranges, the owned-only run, and cx_halo_ipc_batch's quiet run (csrc/cx_halo_plan.h) against their
+    definitions, on the strips the partition tests and bench.py --gpus 8 cut"""
+    part = partition.grid_rows_deep(rows, cols, rank, world, depth, seed=5)
+    m = part.model
+    g = flat_of(m)
+    slot, order, vidx = check_layout(g, m)
+    var_ids = g.arr("var_ids")
+    big = int(np.asarray(m.edge_fac).max()) + 1
+    ekey = np.asarray(m.edge_var)[order].astype(np.int64) * big + np.asarray(m.edge_fac)[order]          # sorted by construction
+    send = slot[np.searchsorted(ekey, np.asarray(part.send_var, dtype=np.int64) * big + np.asarray(part.send_fac))].astype(np.int32)
+    assert g.halo(part.layer_var, part.layer, depth, send) == L.OK
+    lay = np.zeros(len(var_ids), dtype=np.int64)
+    lay[np.searchsorted(var_ids, part.layer_var)] = part.layer
+    sl_of = np.arange(len(var_ids)) // 256
+    lo, hi = g.arr("trim_lo"), g.arr("trim_hi")
+    for Lr in range(depth + 1):
+        in_set = sl_of[lay <= Lr]
+        assert (lo[Lr], hi[Lr]) == ((in_set.min(), in_set.max()) if len(in_set) else (g.scalar("nslices"), -1))
+    olo, ohi = g.scalar("own_slice_lo"), g.scalar("own_slice_hi")
+    ns_ = g.scalar("nslices")
+    owned_only = np.maximum.reduceat(np.r_[lay, np.zeros(ns_ * 256 - len(lay), dtype=lay.dtype)], np.arange(0, ns_ * 256, 256)) == 0
+    if ohi >= olo:
+        assert owned_only[olo:ohi + 1].all() and (olo == 0 or not owned_only[olo - 1]) and (ohi + 1 == len(owned_only) or not owned_only[ohi + 1])
+    else:
+        assert not owned_only.any()
+    # the quiet run: inside the owned-only run, and no variable in it writes a message of the send list
+    qlo, qhi = g.scalar("ipc_quiet_lo"), g.scalar("ipc_quiet_hi")
+    partner = g.arr("partner")
+    slot_var = np.full(g.scalar("nslots"), -1, dtype=np.int64)
+    slot_var[slot] = vidx
+    writers = set((slot_var[partner[send[partner[send] >= 0]]] // 256).tolist())
+    if qhi >= qlo:
+        assert olo <= qlo and qhi <= ohi and not (writers & set(range(qlo, qhi + 1)))
+        assert (qlo == olo or (qlo - 1) in writers) and (qhi == ohi or (qhi + 1) in writers)
+    if rows >= 300:
+        assert qhi - qlo + 1 >= 0.5 * (ohi - olo + 1), "a strip of C4 has a long quiet run"
 
 
 def test_error_paths_leave_nothing_out_of_bounds():

@@ -29,6 +29,9 @@ class FakeDev:
         area = ((self.n_recv * 16 + 4095) // 4096 + 1) * 4096
         return bytes([self.rank]) * 64, 0x1000_0000 * (self.rank + 1), area
 
+    def halo_ipc_set_fused(self, on):
+        self.fused = bool(on)
+
     def halo_ipc_connect(self, peer_index, remote_entry, remote_recv_off, remote_area_bytes, handle=None, same_process_base=None):
         assert (handle is None) != (same_process_base is None)
         self.connected[peer_index] = (remote_entry, remote_recv_off, remote_area_bytes, handle, same_process_base)
