@@ -250,53 +250,16 @@ int32_t cx_halo_state_exchange(cx_handle *h) {
     return CX_OK;
 }
 
-// One batch of a deep-halo partition: the state exchange and n_sweeps sweeps, with the exchange OVERLAPPED with the first sweep.
-// What the exchange rewrites are factor→variable messages INTO redundant variables; a sweep's work for an owned variable reads
-// only that variable's own incoming messages.  So the slices that hold owned variables only run at once on the handle's stream
-// while the communication stream packs, sends / receives and unpacks; the rest of the first sweep (the redundant rows and the
-// slices they share with owned rows) follows when the unpack has finished; sweeps 2..n are plain.  Every message is written by
-// exactly one thread of exactly one of the two launches, from the same inputs as in the un-split sweep: results are bit-identical
-// to cx_halo_state_exchange + cx_sweep(n_sweeps), which is also what runs when the handle cannot split a sweep (no layers set,
-// dim > 1, another schedule than the fused one).
+// One batch of a deep-halo partition: the state exchange, then n_sweeps sweeps.  Rounds 2 - 3 ran the exchange on a second stream
+// beside the owned part of the first sweep here; it was bit-identical and measured SLOWER on every depth (13.2 against 11.1 - 11.5 us
+// per sweep at depth 16: two cross-stream hand-offs and a split sweep cost more than the 9 us of sweep the exchange could hide behind;
+// HISTORY.md, profiles/r03_strip.md) and was removed in round 4.  The entry point stays (ABI); the forms that do put compute between
+// a push and the wait for it are cx_halo_ipc_exchange_sweep and cx_halo_ipc_batch (cx_api_ipc.hip), on ONE stream.
 int32_t cx_halo_exchange_sweep(cx_handle *h, int32_t n_sweeps) {
     CX_REQUIRE(h, h && h->has_graph && h->halo_state, CX_ERR_STATE, "cx_halo_exchange_sweep: call cx_halo_configure_state first");
     CX_REQUIRE(h, n_sweeps >= 1, CX_ERR_INVALID_ARGUMENT, "cx_halo_exchange_sweep: n_sweeps < 1");
-    const bool split = h->cfg.dim == 1 && h->cfg.schedule == CX_SCHED_FUSED && h->halo_depth > 0 && h->big_vars.empty() && !h->peers.empty() &&
-                       h->own_slice_hi >= h->own_slice_lo && h->cfg.sweeps_per_launch != 2 && h->comm_stream;
-    if (!split) {
-        int32_t rc = cx_halo_state_exchange(h);
-        return rc != CX_OK ? rc : cx_sweep(h, n_sweeps);
-    }
-    CX_REQUIRE(h, h->comm, CX_ERR_STATE, "cx_halo_exchange_sweep: call cx_comm_init first");
-    for (auto &p : h->peers)
-        CX_REQUIRE(h, p.rank >= 0 && p.rank < h->comm_world, CX_ERR_INVALID_ARGUMENT, "cx_halo_exchange_sweep: bad peer rank");
-    // communication stream: after everything the handle's stream has queued (the last sweep of the previous batch wrote d_f2v)
-    CX_HIP(h, hipEventRecord(h->ev_swept, h->stream));
-    CX_HIP(h, hipStreamWaitEvent(h->comm_stream, h->ev_swept, 0));
-    hipStream_t main_stream = h->stream;
-    h->stream = h->comm_stream;          // pack / unpack launch on h->stream
-    state_pack(h);
-    std::string err;
-    const bool ok = cx::comm_exchange_on(h, h->comm_stream, err);
-    if (ok) state_unpack(h);
-    h->stream = main_stream;
-    if (!ok) return fail(h, CX_ERR_DEVICE, "cx_halo_exchange_sweep: " + err);
-    CX_HIP(h, hipEventRecord(h->ev_recv, h->comm_stream));
-    // first sweep, part 1: the owned interior, beside the exchange
-    const int L = h->halo_depth;         // sweep 1 after an exchange runs every layer <= depth
-    const int lo = h->trim_hi[L] >= h->trim_lo[L] ? h->trim_lo[L] : 0, hi = h->trim_hi[L] >= h->trim_lo[L] ? h->trim_hi[L] : (int)h->nslices - 1;
-    h->run_slice0 = h->own_slice_lo; h->run_nslices = h->own_slice_hi - h->own_slice_lo + 1;
-    sweep_main(h, false);
-    // part 2: everything else of the same sweep, once the redundant rows hold the owners' messages
-    CX_HIP(h, hipStreamWaitEvent(h->stream, h->ev_recv, 0));
-    h->run_slice0 = lo; h->run_nslices = hi - lo + 1; h->run_excl_lo = h->own_slice_lo; h->run_excl_hi = h->own_slice_hi;
-    sweep_main(h, false);
-    h->run_excl_lo = 1; h->run_excl_hi = 0; h->run_slice0 = 0; h->run_nslices = 0;
-    sweep_finish(h);
-    h->alt_two_back = false;
-    h->sweeps_since_exchange = 1;
-    CX_HIP(h, hipGetLastError());
-    return n_sweeps > 1 ? cx_sweep(h, n_sweeps - 1) : CX_OK;
+    const int32_t rc = cx_halo_state_exchange(h);
+    return rc != CX_OK ? rc : cx_sweep(h, n_sweeps);
 }
 
 }  // extern "C"

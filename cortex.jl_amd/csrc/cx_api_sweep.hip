@@ -161,6 +161,17 @@ void sweep_finish(cx_handle *h) {
 
 }  // namespace cxh
 
+#ifndef CX_WITH_TILED2
+// cx_tiles.hip is not part of the default build (two sweeps per launch: bit-identical, measured slower — HISTORY.md; built with
+// CX_BUILD_TILED2=1): cx_config.sweeps_per_launch = 2 then runs single sweeps, exactly as it does for a graph the tiler refuses
+namespace cx {
+bool tiles_build(cx_handle *, std::string &why) { why = "two sweeps per launch is not built into this library (CX_BUILD_TILED2)"; return false; }
+bool tiles_prepare_kernel(cx_handle *) { return false; }
+void tiles_free(cx_handle *) {}
+void launch_tiled2(cx_handle *, const double2 *, double2 *, bool) {}
+}  // namespace cx
+#endif
+
 // CX_TILED=0 in the environment turns the two-sweep launches off (A/B measurements)
 static bool tiled_env_enabled() {
     static const int on = [] { const char *e = std::getenv("CX_TILED"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -258,7 +269,8 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
                             h->cfg.family == CX_FAMILY_GAUSSIAN && h->cfg.materialize_messages_to_factor == 0 && h->n_kary == 0 && tiled_env_enabled();
     if (want_pairs && h->tiles_state == 0) {
         std::string why;
-        if (cx::tiles_build(h, why) && !cx::tiles_prepare_kernel(h)) { cx::tiles_free(h); h->tiles_state = -1; }
+        if (!cx::tiles_build(h, why)) h->tiles_state = -1;
+        else if (!cx::tiles_prepare_kernel(h)) { cx::tiles_free(h); h->tiles_state = -1; }
     }
     if (want_pairs && h->tiles_state > 0) {
         const bool marg = h->cfg.compute_marginals_in_sweep != 0;
