@@ -164,6 +164,18 @@ function save_state(p, path)
     check(p.handle, ccall((:cx_state_export, lib), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int64), p.handle, buf, n[]))
     write(path, buf)
 end
+# factors of more than two variables (CX_FACTOR_GAUSS_LINEAR_N = 5: x_out = sum a_i x_i + b + N(0, q)): coefficients of the ROLE_IN edges
+set_factor_coefficients!(p, variable_ids::Vector{Int64}, factor_ids::Vector{Int64}, a::Vector{Float64}) =
+    check(p.handle, ccall((:cx_set_factor_coefficients, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}),
+                          p.handle, length(a), variable_ids, factor_ids, a))
+
+# the plan of the dim 64 chain-scan schedule: (links per block, fan, levels, potentials, compositions, rules, launches, device bytes)
+function chain_plan_stats(p)
+    out = zeros(Int64, 8)
+    check(p.handle, ccall((:cx_chain_plan_stats, lib), Int32, (Ptr{Cvoid}, Ptr{Int64}), p.handle, out))
+    out
+end
+
 load_state!(p, path) = (buf = read(path); check(p.handle, ccall((:cx_state_import, lib), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int64), p.handle, buf, length(buf))))
 
 # deep halo: `exchange_every` plain sweeps between two state exchanges issued by the library over RCCL
