@@ -49,7 +49,7 @@ namespace p64 = plan64;
 
 // Device records: the plan's handles resolved to pointers (chain64_resolve, host) — ten 64-bit words each, like the plan's.
 struct DStep { gcdp src[3], P, Bt, C, h, c; gdp dst; int64_t has2; };
-struct DChild { gcdp P, B, Bt, C, h, c, side[3]; int64_t pad; };
+struct DChild { gcdp P, B, Bt, C, h, c, side[3]; int64_t nside; };      // nside: sides that are not the zero page (they come first)
 struct DJob { gdp out; int32_t first, n; };
 static_assert(sizeof(DStep) == sizeof(p64::Step) && sizeof(DChild) == sizeof(p64::Child) && sizeof(DJob) == sizeof(p64::Job), "records mirror the plan's");
 
@@ -288,6 +288,388 @@ void k_compose64(int njobs, const DJob *__restrict__ jobs, const DChild *__restr
     C64_STAMP(10);
 }
 
+// ---- the composition as a PAIR of waves ------------------------------------------------------------------------------------------
+// k_compose64 above keeps B1, U and Y2 (336 registers of matrices) in ONE wave: they need the accumulator half of the register file,
+// hipcc shuffles them back and forth (≈ 1,000 v_accvgpr_read and 330 scratch accesses per step), and with one wave per SIMD every
+// memory round trip of a step is exposed: 0.26 of the matrix pipe, 8.6 ms for the 99,995 compositions of C5.
+// Here a composition is split between the two waves of a 128-thread workgroup so that each stays under 256 registers (two waves per
+// SIMD) with nothing spilled:
+//   wave A (the RULE part: what k_rule64w does)   M = C1 + side + P2 = U'U,  z = U^-T g;  hands -U, V = U_kk^-1 and z over (LDS);
+//                                                 Y2 = U^-T B2' -> hands it over (32 KB per workgroup in global memory: the "ring");
+//                                                 C1 <- C2 - Y2'Y2,  c1 <- c2 + Y2'z                       384 MFMA + the diagonal tiles
+//   wave B (the EXTENSION)                        Y1 = U^-T B1 in place,  P1 -= Y1'Y1 (in the output record),  h1 += Y1'z;
+//                                                 B1 <- Y2'Y1, one block column at a time, Y2 streamed from the ring     576 MFMA
+// Both waves read U tile by tile from LDS while they solve (A's 80 registers of M are free once U is published; B never holds U).
+// Two workgroup barriers per step: (1) U, V, z are in LDS;  (2) Y2 is in the ring — and both waves have finished with U, V, z.  A is
+// already factoring the next joint while B forms the cross product; A's next write of the ring comes after barrier (1) of the next
+// step, which B only reaches with the cross product done.  Tiles travel in the accumulator layout (element r of lane l at
+// tile * 256 + r * 64 + l): both waves use the same lane <-> element map, nothing is transposed.  The waves of a workgroup share
+// their CU's vector cache, so the ring needs a workgroup-scope release / acquire around barrier (2) and nothing wider.
+constexpr int kTileD = 256;      // doubles per 16 x 16 tile
+
+__device__ __forceinline__ void tile_put(double *dst, int t, const d4 &T, int lane) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) dst[t * kTileD + r * 64 + lane] = T[r];
+}
+__device__ __forceinline__ d4 tile_get(const double *src, int t, int lane) {
+    d4 T;
+#pragma unroll
+    for (int r = 0; r < 4; r++) T[r] = src[t * kTileD + r * 64 + lane];
+    return T;
+}
+__device__ __forceinline__ d4 tile_get_g(gcdp src, int t, int lane) {
+    d4 T;
+#pragma unroll
+    for (int r = 0; r < 4; r++) T[r] = src[t * kTileD + r * 64 + lane];
+    return T;
+}
+__device__ __forceinline__ constexpr int uo(int a, int b) { return ut(a, b) - a - 1; }      // the off-diagonal upper tile (a < b) among the six
+
+// solve_col with -U read from LDS (nU: six tiles, accumulator layout)
+__device__ __forceinline__ void solve_col_lds(d4 (&R)[4][4], const int b, const double *nU, const double (*Vs)[16 * kLdT], const int lane, const int g, const int c) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        d4 Vj;
+#pragma unroll
+        for (int r = 0; r < 4; r++) Vj[r] = Vs[j][(g + 4 * r) * kLdT + c];
+        R[j][b] = tts(Vj, R[j][b], d4{0.0, 0.0, 0.0, 0.0});
+#pragma unroll
+        for (int jj = j + 1; jj < 4; jj++) R[jj][b] = tts(tile_get(nU, uo(j, jj), lane), R[j][b], R[jj][b]);
+    }
+}
+
+__device__ __forceinline__ void wg_barrier_acquire() {
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void wg_barrier_release_acquire() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Buffer addressing for this kernel: address = base (four scalar registers) + ONE per-lane byte offset + a compile-time constant
+// (scalar).  With plain pointers hipcc keeps a 64-bit per-lane address or a separate 32-bit offset for every tile row that is out
+// of reach of the 13-bit immediate — dozens of registers of addresses, which at 256 registers per wave were spilled (1.2 KB of
+// scratch per lane).  Reads past the end of a buffer return zero; nothing here relies on that.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t buf(const double __attribute__((address_space(1))) *p) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)p, 0, 0x7fffffff, 0x00020000);
+}
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double bld(rsrc_t r, int lane_bytes, int const_bytes) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, const_bytes, 0));
+}
+__device__ __forceinline__ void bst(rsrc_t r, int lane_bytes, int const_bytes, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, lane_bytes, const_bytes, 0);
+}
+// element r of tile (a, b) of a row-major 64 x 64 matrix: lane part (g * 64 + c) * 8, the rest is a constant
+__device__ __forceinline__ constexpr int mconst(int a, int b, int r) { return ((16 * a + 4 * r) * kD + 16 * b) * 8; }
+
+// M += P2 + (the first NS sides), tile by tile in chunks: the loads of a chunk are all in flight together (one memory round trip per
+// chunk), the sums are pinned where they are made — hipcc otherwise sinks the additions below the factorisation of the first diagonal
+// tile (the first use of the other tiles) and keeps, that is spills, the loaded operands of every element instead of their sum.
+// Chunks are sized for ≈ 100 registers of operands in flight beside the 80 of M.
+template <int NS>
+__device__ __forceinline__ void add_joint(d4 (&M)[10], double (&gv)[4], const rsrc_t P2, const rsrc_t h2, const rsrc_t s0, const rsrc_t s1, const rsrc_t s2,
+                                          const int mo, const int vo) {
+    constexpr int kChunk = NS == 0 ? 10 : NS == 1 ? 5 : NS == 2 ? 4 : 3;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        double v = bld(h2, vo, 128 * j);
+        if (NS > 0) v += bld(s0, vo, 128 * j);
+        if (NS > 1) v += bld(s1, vo, 128 * j);
+        if (NS > 2) v += bld(s2, vo, 128 * j);
+        gv[j] += v;
+    }
+#pragma unroll
+    for (int t0 = 0; t0 < 10; t0 += kChunk) {
+        d4 X[kChunk];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = a; b < 4; b++) {
+                const int t = ut(a, b);
+                if (t < t0 || t >= t0 + kChunk) continue;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int o = mconst(a, b, r);
+                    double v = bld(P2, mo, o);
+                    if (NS > 0) v += bld(s0, mo, kD * 8 + o);
+                    if (NS > 1) v += bld(s1, mo, kD * 8 + o);
+                    if (NS > 2) v += bld(s2, mo, kD * 8 + o);
+                    X[t - t0][r] = v;
+                }
+            }
+#pragma unroll
+        for (int t = t0; t < t0 + kChunk && t < 10; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                M[t][r] += X[t - t0][r];
+                asm volatile("" : "+v"(M[t][r]));
+            }
+        asm volatile("" ::: "memory");
+    }
+}
+
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_compose64p(int njobs, const DJob *__restrict__ jobs, const DChild *__restrict__ children, double *__restrict__ ring_base) {
+    __shared__ double Us[6 * kTileD];           // -U off the diagonal, accumulator layout
+    __shared__ double Vs[4][16 * kLdT];         // V_k = U_kk^-1, row-major with pitch (what the solves read)
+    __shared__ double SA[16 * kLdT], SB[16 * kLdT];
+    __shared__ double zs[kD];
+    const int w = blockIdx.x;
+    if (w >= njobs) return;
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // uniform: each wave takes ONE side of the branch below
+    int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int first = as_const(jobs)[w].first, n = as_const(jobs)[w].n;
+    gdp out = as_const(jobs)[w].out;
+    const rsrc_t ring = buf((gdp)(ring_base + (size_t)w * 16 * kTileD));
+    const rsrc_t oP = buf(out), oB = buf(out + kD * kD), oBt = buf(out + 2 * kD * kD), oC = buf(out + 3 * kD * kD), ohc = buf(out + 4 * kD * kD);
+
+    if (role == 0) {
+        // ================================================================ wave A: the rule part =========================================
+        d4 C1[10];
+        double c1[4];
+        C64_STAMP_INIT;
+        {
+            const auto *ch = as_const(children) + first;
+            const rsrc_t C = buf(ch->C), cc = buf(ch->c);
+            const int mo = (g * kD + c) * 8;
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+#pragma unroll
+                for (int b = a; b < 4; b++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) C1[ut(a, b)][r] = bld(C, mo, mconst(a, b, r));
+                c1[a] = bld(cc, c * 8, 128 * a);
+            }
+        }
+        for (int k = 1; k < n; k++) {
+            const auto *ch = as_const(children) + (first + k);
+            asm volatile("" : "+v"(lane));      // (opaque per step, range restated: nothing lane-derived is hoisted out of the loop)
+            lane &= 63;
+            g = lane >> 4; c = lane & 15;
+            const int mo = (g * kD + c) * 8, vo = c * 8, to = lane * 8;
+            const rsrc_t P2 = buf(ch->P), Bt2 = buf(ch->Bt), C2 = buf(ch->C), h2 = buf(ch->h), c2 = buf(ch->c), s0 = buf(ch->side[0]), s1 = buf(ch->side[1]), s2 = buf(ch->side[2]);
+            double gv[4] = {c1[0], c1[1], c1[2], c1[3]};
+            switch ((int)ch->nside) {       // uniform
+            case 0: add_joint<0>(C1, gv, P2, h2, s0, s1, s2, mo, vo); break;
+            case 1: add_joint<1>(C1, gv, P2, h2, s0, s1, s2, mo, vo); break;
+            case 2: add_joint<2>(C1, gv, P2, h2, s0, s1, s2, mo, vo); break;
+            default: add_joint<3>(C1, gv, P2, h2, s0, s1, s2, mo, vo); break;
+            }
+            C64_STAMP(0);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const d4 Vk = diag_factor(C1[ut(kk, kk)], SA, g, c);
+#pragma unroll
+                for (int r = 0; r < 4; r++) Vs[kk][(g + 4 * r) * kLdT + c] = Vk[r];
+#pragma unroll
+                for (int j = kk + 1; j < 4; j++) C1[ut(kk, j)] = tts(Vk, C1[ut(kk, j)], d4{0.0, 0.0, 0.0, 0.0});
+#pragma unroll
+                for (int i = kk + 1; i < 4; i++) {
+                    const d4 nu = neg(C1[ut(kk, i)]);
+#pragma unroll
+                    for (int j = i; j < 4; j++) C1[ut(i, j)] = tts(nu, C1[ut(kk, j)], C1[ut(i, j)]);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // z = U^-T g (vector pipe), left in LDS in column order for both waves
+            {
+                double zrv[4][4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    double wcv = gv[j];
+#pragma unroll
+                    for (int q = 0; q < j; q++) {
+                        double p = 0.0;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) p += C1[ut(q, j)][r] * zrv[q][r];
+                        wcv -= sum_groups(p);
+                    }
+                    double p = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) p += Vs[j][(g + 4 * r) * kLdT + c] * cv_to_rv(wcv, g, r);
+                    const double zcv = sum_groups(p);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) zrv[j][r] = cv_to_rv(zcv, g, r);
+                    if (g == 0) zs[16 * j + c] = zcv;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = a + 1; b < 4; b++) tile_put(Us, uo(a, b), neg(C1[ut(a, b)]), lane);
+            C64_STAMP(1);
+            wg_barrier_release_acquire();                      // (1) -U, V, z are in LDS (this wave's M is dead from here)
+            C64_STAMP(2);
+            // Y2 = U^-T B2' -> the ring
+            d4 Y2[4][4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) Y2[j][b][r] = bld(Bt2, mo, mconst(j, b, r));
+                solve_col_lds(Y2, b, Us, Vs, lane, g, c);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) bst(ring, to, ((4 * j + b) * kTileD + r * 64) * 8, Y2[j][b][r]);
+            }
+            // c1 <- c2 + Y2'z (z is rewritten after barrier (2))
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                double p = 0.0;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) p += Y2[j][a][r] * zs[16 * j + g + 4 * r];
+                c1[a] = bld(c2, vo, 128 * a) + sum_groups(p);
+            }
+            C64_STAMP(3);
+            wg_barrier_release_acquire();                      // (2) Y2 is in the ring; both waves are done with -U, V, z
+            C64_STAMP(4);
+            // C1 <- C2 - Y2'Y2, last block column first: a column of Y2 is dead once its Gram tiles exist
+#pragma unroll
+            for (int b = 3; b >= 0; b--)
+#pragma unroll
+                for (int a = 0; a <= b; a++) {
+                    d4 G = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) G = tts(Y2[j][a], Y2[j][b], G);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) C1[ut(a, b)][r] = bld(C2, mo, mconst(a, b, r)) - G[r];
+                }
+            C64_STAMP(5);
+        }
+        {
+            const int mo = (g * kD + c) * 8;
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+#pragma unroll
+                for (int b = a; b < 4; b++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) bst(oC, mo, mconst(a, b, r), C1[ut(a, b)][r]);
+                if (g == 0) bst(ohc, c * 8, (kD + 16 * a) * 8, c1[a]);
+            }
+        }
+    } else {
+        // ================================================================ wave B: the extension =========================================
+        d4 B1[4][4];
+        double h1[4];
+        C64_STAMP_INIT;
+        {
+            const auto *ch = as_const(children) + first;
+            const rsrc_t P = buf(ch->P), B = buf(ch->B), hh = buf(ch->h);
+            const int mo = (g * kD + c) * 8;
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        B1[a][b][r] = bld(B, mo, mconst(a, b, r));
+                        if (b >= a) bst(oP, mo, mconst(a, b, r), bld(P, mo, mconst(a, b, r)));
+                    }
+                h1[a] = bld(hh, c * 8, 128 * a);
+            }
+        }
+        for (int k = 1; k < n; k++) {
+            asm volatile("" : "+v"(lane));
+            lane &= 63;
+            g = lane >> 4; c = lane & 15;
+            const int mo = (g * kD + c) * 8, to = lane * 8;
+            // P1's tiles, for the update below: fetched while this wave waits for the factorisation anyway
+            d4 Pt[10];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = a; b < 4; b++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) Pt[ut(a, b)][r] = bld(oP, mo, mconst(a, b, r));
+            wg_barrier_acquire();                              // (1) (this wave has published nothing: no release, the fetches stay in flight)
+            C64_STAMP(8);
+#pragma unroll
+            for (int b = 0; b < 4; b++) solve_col_lds(B1, b, Us, Vs, lane, g, c);        // Y1 = U^-T B1 in place
+            C64_STAMP(9);
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+#pragma unroll
+                for (int b = a; b < 4; b++) {
+                    d4 G = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) G = tts(B1[j][a], B1[j][b], G);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) bst(oP, mo, mconst(a, b, r), Pt[ut(a, b)][r] - G[r]);
+                }
+                double p = 0.0;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) p += B1[j][a][r] * zs[16 * j + g + 4 * r];
+                h1[a] += sum_groups(p);
+            }
+            C64_STAMP(10);
+            wg_barrier_release_acquire();                      // (2)
+            C64_STAMP(11);
+            // B1 <- Y2'Y1, one block column of Y1 at a time; block column a of Y2 (four tiles) is fetched from the ring while the
+            // products with the previous one run (the memory clobber keeps hipcc from fetching further ahead and spilling B1 for it)
+            {
+                d4 Yc[4], Yn[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) Yc[j][r] = bld(ring, to, ((4 * j + 0) * kTileD + r * 64) * 8);
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    d4 T[4];
+#pragma unroll
+                    for (int a = 0; a < 4; a++) {
+                        const int an = (a + 1) & 3;
+                        if (!(b == 3 && a == 3)) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+#pragma unroll
+                                for (int r = 0; r < 4; r++) Yn[j][r] = bld(ring, to, ((4 * j + an) * kTileD + r * 64) * 8);
+                        }
+                        T[a] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int j = 0; j < 4; j++) T[a] = tts(Yc[j], B1[j][b], T[a]);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) asm volatile("" : "+v"(T[a][r]));
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int j = 0; j < 4; j++) Yc[j] = Yn[j];
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; a++) B1[a][b] = T[a];
+                }
+            }
+            C64_STAMP(12);
+        }
+        {
+            const int mo = (g * kD + c) * 8;
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) bst(oB, mo, mconst(a, b, r), B1[a][b][r]);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int r = 0; r < 4; r++) SB[(g + 4 * r) * kLdT + c] = B1[a][b][r];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int r = 0; r < 4; r++) bst(oBt, mo, mconst(b, a, r), SB[c * kLdT + g + 4 * r]);
+                }
+                if (g == 0) bst(ohc, c * 8, 16 * a * 8, h1[a]);
+            }
+        }
+    }
+}
+
 // ---- host: the plan on the device -----------------------------------------------------------------------------------------------
 struct Chain64 {
     DJob *d_jobs = nullptr;
@@ -297,7 +679,7 @@ struct Chain64 {
     std::vector<p64::Child> children;
     std::vector<p64::Step> steps;
     double *bases[p64::kSpaces] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // what the device records were resolved against
-    double *d_pot = nullptr, *d_ent = nullptr;
+    double *d_pot = nullptr, *d_ent = nullptr, *d_ring = nullptr;      // d_ring: the Y2 hand-off of k_compose64p, 32 KB per job of the widest launch
     struct Launch { int kind; int64_t first; int n; int steps; };      // kind 0: compose, 1: walk over potentials, 2: walk along links; steps: longest job
     int32_t *d_dead = nullptr;             // per job of the widest walk launch: an earlier step failed
     std::vector<Launch> launches;
@@ -309,7 +691,7 @@ struct Chain64 {
 void chain64_free(cx_handle *h) {
     Chain64 *c = (Chain64 *)h->chain64;
     if (!c) return;
-    for (void *p : {(void *)c->d_jobs, (void *)c->d_children, (void *)c->d_steps, (void *)c->d_pot, (void *)c->d_ent, (void *)c->d_dead}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)c->d_jobs, (void *)c->d_children, (void *)c->d_steps, (void *)c->d_pot, (void *)c->d_ent, (void *)c->d_dead, (void *)c->d_ring}) if (p) (void)hipFree(p);
     h->device_bytes -= c->bytes;
     delete c;
     h->chain64 = nullptr;
@@ -359,7 +741,8 @@ int32_t chain64_build(cx_handle *h, const std::vector<int32_t> &pos_var, const s
     c->n_compositions = plan.n_compositions; c->n_rules = plan.n_rules;
     auto &jobs = c->jobs;
     auto longest = [](const std::vector<p64::Job> &L) { int m = 0; for (const auto &j : L) m = std::max(m, (int)j.n); return m; };
-    int widest = 1;
+    int widest = 1, widest_compose = 1;
+    for (const auto &L : plan.compose_launches) widest_compose = std::max(widest_compose, (int)L.size());
     for (const auto &L : plan.compose_launches) if (!L.empty()) { c->launches.push_back({0, (int64_t)jobs.size(), (int)L.size(), longest(L)}); jobs.insert(jobs.end(), L.begin(), L.end()); }
     for (size_t i = 0; i < plan.walk_launches.size(); i++) {      // the last walk launch is the one along the links (plain rules, h = c = 0)
         const auto &L = plan.walk_launches[i];
@@ -378,6 +761,7 @@ int32_t chain64_build(cx_handle *h, const std::vector<int32_t> &pos_var, const s
     if ((rc = cxh::dev_alloc(h, &c->d_pot, plan.n_pot * plan.pot)) != CX_OK) return rc;
     if ((rc = cxh::dev_alloc(h, &c->d_ent, plan.n_ent * plan.msg)) != CX_OK) return rc;
     if ((rc = cxh::dev_alloc(h, &c->d_dead, (int64_t)widest)) != CX_OK) return rc;
+    if (plan.n_pot > 0 && (rc = cxh::dev_alloc(h, &c->d_ring, (int64_t)widest_compose * 16 * kTileD)) != CX_OK) return rc;
     // a potential or entry message that was never computed reads as UndefValue()
     CX_HIP(h, hipMemsetAsync(c->d_pot, 0xff, (size_t)std::max<int64_t>(1, plan.n_pot * plan.pot) * 8, h->stream));
     CX_HIP(h, hipMemsetAsync(c->d_ent, 0xff, (size_t)std::max<int64_t>(1, plan.n_ent * plan.msg) * 8, h->stream));
@@ -404,7 +788,9 @@ static int32_t chain64_resolve(cx_handle *h, Chain64 *c) {
             const p64::Child &r = c->children[i];
             const int64_t hs[9] = {r.P, r.B, r.Bt, r.C, r.h, r.c, r.side[0], r.side[1], r.side[2]};
             for (int k = 0; k < 9; k++) w[10 * i + k] = ptr(hs[k]);
-            w[10 * i + 9] = 0;
+            uint64_t ns = 0;
+            for (int k = 0; k < 3; k++) ns += (r.side[k] >> 56) != p64::kZero;
+            w[10 * i + 9] = ns;
         }
         if (!w.empty()) CX_HIP(h, hipMemcpy(c->d_children, w.data(), w.size() * 8, hipMemcpyHostToDevice));
         w.resize(c->steps.size() * 10);
@@ -441,7 +827,10 @@ int32_t chain64_sweep(cx_handle *h) {
         (void)hipMemsetAsync(d_st, 0, st_n * 8, h->stream);
 #endif
         if (L.kind == 0) {
-            hipLaunchKernelGGL(k_compose64, dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_children);
+            // CX_MVC64_COMPOSE=1: the one-wave composition (one wave per SIMD, 512 registers) for A/B; default: the paired form
+            static const int one_wave = env_int("CX_MVC64_COMPOSE", 2) == 1;
+            if (one_wave) hipLaunchKernelGGL(k_compose64, dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_children);
+            else hipLaunchKernelGGL(k_compose64p, dim3(L.n), dim3(128), 0, h->stream, L.n, c->d_jobs + L.first, c->d_children, c->d_ring);
         } else {
             CX_HIP(h, hipMemsetAsync(c->d_dead, 0, (size_t)L.n * 4, h->stream));
             for (int s = 0; s < L.steps; s++) {
@@ -456,7 +845,7 @@ int32_t chain64_sweep(cx_handle *h) {
 #ifdef CX_C64_STAMPS
         (void)hipStreamSynchronize(h->stream);
         (void)hipMemcpy(hs.data(), d_st, st_n * 8, hipMemcpyDeviceToHost);
-        const int per = L.kind == 0 ? 16 : 8, nph = L.kind == 0 ? 11 : 6;
+        const int per = L.kind == 0 ? 16 : 8, nph = L.kind == 0 ? 13 : 6;
         double tot[16] = {0};
         for (int wg = 0; wg < std::min(L.n, (int)(st_n / per)); wg++) for (int i = 0; i < nph; i++) tot[i] += (double)hs[(size_t)per * wg + i];
         fprintf(stderr, "[c64 stamps] kind %d, %d jobs: cycles per job and phase:", L.kind, L.n);
