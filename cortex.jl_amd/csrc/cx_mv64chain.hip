@@ -88,6 +88,33 @@ void k_step64(int njobs, const DJob *__restrict__ jobs, const DStep *__restrict_
         if (lane == 0) dead[w] = 1;
 }
 
+// The walks as a LOOP inside one kernel after all (k_walk64b): what made the loop compile badly were per-lane values kept across
+// iterations.  With buffer addressing (BufAcc: one per-lane offset for every access) and the lane index made opaque at the top of
+// every step there is nothing per-lane left to hoist, and the body keeps the allocation of the straight-line kernel.  What the loop
+// buys: the waves of a launch drift apart, so one wave's loads (its side information comes from HBM, once per sweep) run beside its
+// SIMD neighbour's arithmetic — per-step launches start every wave of a step together, and all of them wait for memory together —
+// and ≈ 100 launch boundaries per sweep go.
+template <int WAVES_PER_SIMD, bool AFFINE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES_PER_SIMD, WAVES_PER_SIMD)))
+void k_walk64b(int njobs, const DJob *__restrict__ jobs, const DStep *__restrict__ steps) {
+    __shared__ double S[16 * kLdT];
+    __shared__ double Vs[4][16 * kLdT];
+    const int w = blockIdx.x;
+    if (w >= njobs) return;
+    int lane = threadIdx.x;
+    const int first = as_const(jobs)[w].first, n = as_const(jobs)[w].n;
+    for (int s = 0; s < n; s++) {
+        const auto *st = as_const(steps) + (first + s);
+        asm volatile("" : "+v"(lane));
+        lane &= 63;
+        const int g = lane >> 4, c = lane & 15;
+        if (!rule64b_apply<AFFINE>(st->P, st->Bt, st->C, st->h, st->c, st->src[0], st->src[1], st->src[2], st->has2 != 0, st->dst, S, Vs, lane, g, c)) break;
+        // the next step reads what this one stored (its entering message): the stores have to have left the wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
 // Yt = U^-T R for the four tiles of block column b of R (in place): forward substitution over the row blocks
 __device__ __forceinline__ void solve_col(d4 (&R)[4][4], const int b, const d4 (&M)[10], const double (*Vs)[16 * kLdT], const int g, const int c) {
 #pragma unroll
@@ -352,16 +379,12 @@ __device__ __forceinline__ void wg_barrier_release_acquire() {
 // (scalar).  With plain pointers hipcc keeps a 64-bit per-lane address or a separate 32-bit offset for every tile row that is out
 // of reach of the 13-bit immediate — dozens of registers of addresses, which at 256 registers per wave were spilled (1.2 KB of
 // scratch per lane).  Reads past the end of a buffer return zero; nothing here relies on that.
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-__device__ __forceinline__ rsrc_t buf(const double __attribute__((address_space(1))) *p) {
-    return __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)p, 0, 0x7fffffff, 0x00020000);
-}
-typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rsrc_t buf(const double __attribute__((address_space(1))) *p) { return buf_of(p).r; }
 __device__ __forceinline__ double bld(rsrc_t r, int lane_bytes, int const_bytes) {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, const_bytes, 0));
 }
 __device__ __forceinline__ void bst(rsrc_t r, int lane_bytes, int const_bytes, double v) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, lane_bytes, const_bytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), r, lane_bytes, const_bytes, 0);
 }
 // element r of tile (a, b) of a row-major 64 x 64 matrix: lane part (g * 64 + c) * 8, the rest is a constant
 __device__ __forceinline__ constexpr int mconst(int a, int b, int r) { return ((16 * a + 4 * r) * kD + 16 * b) * 8; }
@@ -832,6 +855,14 @@ int32_t chain64_sweep(cx_handle *h) {
             if (one_wave) hipLaunchKernelGGL(k_compose64, dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_children);
             else hipLaunchKernelGGL(k_compose64p, dim3(L.n), dim3(128), 0, h->stream, L.n, c->d_jobs + L.first, c->d_children, c->d_ring);
         } else {
+            // CX_MVC64_WALK=1: one launch per step (k_step64) for A/B; default: the walk loops inside one launch
+            static const int per_step = env_int("CX_MVC64_WALK", 2) == 1;
+            if (!per_step) {
+                if (L.kind == 1) hipLaunchKernelGGL((k_walk64b<1, true>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps);
+                else if (walk_waves == 1) hipLaunchKernelGGL((k_walk64b<1, false>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps);
+                else hipLaunchKernelGGL((k_walk64b<2, false>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps);
+                continue;
+            }
             CX_HIP(h, hipMemsetAsync(c->d_dead, 0, (size_t)L.n * 4, h->stream));
             for (int s = 0; s < L.steps; s++) {
                 if (L.kind == 1)           // few jobs: a wave alone on its SIMD

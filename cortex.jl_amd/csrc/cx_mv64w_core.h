@@ -129,6 +129,34 @@ __device__ __forceinline__ d4 diag_factor(const d4 &T, double *__restrict__ S, i
 // element (row, col) of a row-major 64 x 64 matrix for tile (tr, tc), register r, this lane
 __device__ __forceinline__ int tile_off(int tr, int tc, int r, int g, int c) { return (16 * tr + g + 4 * r) * kD + 16 * tc + c; }
 
+// ---- how the rule body addresses memory: element = base + a PER-LANE part (one register for every access of a kind) + a constant ----
+//   tile (a, b), register r of a row-major 64 x 64 matrix:  lane part g * 64 + c,  constant tile_const(a, b, r)
+//   element 16 j + c of a vector:                           lane part c,           constant 16 j
+// PtrAcc: plain global pointers (k_rule64w, k_step64: straight-line kernels, hipcc folds the constants into its own addressing).
+// BufAcc: buffer descriptors — base in four scalar registers, the constant in a scalar register or the instruction: NOTHING per
+// lane but the one offset, which is what a kernel that LOOPS over rules needs to stay under 256 registers (with pointers hipcc
+// keeps a 64-bit address or a 32-bit offset per tile row that is out of reach of the 13-bit immediate, hoists them out of the
+// loop and spills: cx_mv64chain.hip).  Reads past the end of a buffer return zero; nothing relies on that.
+__device__ __forceinline__ constexpr int tile_const(int a, int b, int r) { return (16 * a + 4 * r) * kD + 16 * b; }
+struct PtrAcc {
+    gdp p;
+    __device__ __forceinline__ double ld(int lane_part, int cst) const { return p[lane_part + cst]; }
+    __device__ __forceinline__ void st(int lane_part, int cst, double v) const { p[lane_part + cst] = v; }
+};
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+struct BufAcc {
+    rsrc_t r;
+    __device__ __forceinline__ double ld(int lane_part, int cst) const {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, lane_part * 8, cst * 8, 0));
+    }
+    __device__ __forceinline__ void st(int lane_part, int cst, double v) const {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), r, lane_part * 8, cst * 8, 0);
+    }
+};
+__device__ __forceinline__ PtrAcc acc_of(gcdp p) { return PtrAcc{(gdp)p}; }
+__device__ __forceinline__ BufAcc buf_of(gcdp p) { return BufAcc{__builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)p, 0, 0x7fffffff, 0x00020000)}; }
+
 // lab only (tools/lab/w64_phases.hip defines CX_W64_STAMPS and the counters): shader-clock cycles per phase and wave
 #ifdef CX_W64_STAMPS
 #define W64_STAMP(i)                                                                                  \
@@ -153,21 +181,75 @@ __device__ __forceinline__ int tile_off(int tr, int tc, int r, int g, int c) { r
 // ZS (optional): 64 doubles of LDS private to this wave.  With it z = U^-T eta_in waits there between its solve and its use (eta_out =
 // Yt' z) instead of in 32 registers across the matrix solve — what the loops of cx_mv64chain.hip need to stay under 256 registers at two
 // waves per SIMD without spilling (over the limit hipcc also un-clusters the loads: one memory round trip per load).
-template <bool AFFINE, bool Z_IN_LDS = false>
-__device__ __forceinline__ bool rule64w_apply(gcdp tabP, gcdp bt, gcdp tabC, gcdp hv, gcdp cv, gcdp src0, gcdp src1, gcdp src2, const bool has2, gdp dst,
-                                              double *S, double (*Vs)[16 * kLdT], const int lane, const int g, const int c, double *ZS = nullptr) {
+template <bool AFFINE, bool Z_IN_LDS, bool CHUNKED, class A>
+__device__ __forceinline__ bool rule64_body(const A tabP, const A bt, const A tabC, const A hv, const A cv, const A src0, const A src1, const A src2, const bool has2,
+                                            const A dst, double *S, double (*Vs)[16 * kLdT], const int lane, const int g, const int c, double *ZS = nullptr) {
     W64_STAMP_INIT;
     (void)lane;
+    const int mo = g * kD + c;          // the per-lane part of every matrix access
     // ---- M = P + sum of the other incoming Lambdas (ascending neighbour order), upper tiles only ------------------------------
     d4 M[10];
+    if constexpr (CHUNKED) {
+        // a kernel that loops over rules: four tiles' worth of operands in flight at a time, each sum pinned where it is made.
+        // Left to itself hipcc, at 256 registers, falls back to its minimum-pressure schedule for this block: one memory round trip
+        // per element (load, load, wait, add, load, wait, add), 120 of them per rule.
+#pragma unroll
+        for (int t0 = 0; t0 < 10; t0 += 4) {
+            d4 X0[4], X1[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = a; b < 4; b++) {
+                    const int t = ut(a, b);
+                    if (t < t0 || t >= t0 + 4) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int o = tile_const(a, b, r);
+                        M[t][r] = tabP.ld(mo, o); X0[t - t0][r] = src0.ld(mo, kD + o); X1[t - t0][r] = src1.ld(mo, kD + o);
+                    }
+                }
+            // (the loads above are written first and the additions after them: under register pressure hipcc keeps source order)
+#pragma unroll
+            for (int t = t0; t < t0 + 4 && t < 10; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    M[t][r] = (M[t][r] + X0[t - t0][r]) + X1[t - t0][r];
+                    asm volatile("" : "+v"(M[t][r]));
+                }
+            asm volatile("" ::: "memory");
+        }
+        if (has2) {
+#pragma unroll
+            for (int t0 = 0; t0 < 10; t0 += 5) {
+                d4 X2[5];
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = a; b < 4; b++) {
+                        const int t = ut(a, b);
+                        if (t < t0 || t >= t0 + 5) continue;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) X2[t - t0][r] = src2.ld(mo, kD + tile_const(a, b, r));
+                    }
+#pragma unroll
+                for (int t = t0; t < t0 + 5; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        M[t][r] += X2[t - t0][r];
+                        asm volatile("" : "+v"(M[t][r]));
+                    }
+                asm volatile("" ::: "memory");
+            }
+        }
+    } else {
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = a; b < 4; b++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int o = tile_off(a, b, r, g, c);
-                M[ut(a, b)][r] = (tabP[o] + src0[kD + o]) + src1[kD + o];
+                const int o = tile_const(a, b, r);
+                M[ut(a, b)][r] = (tabP.ld(mo, o) + src0.ld(mo, kD + o)) + src1.ld(mo, kD + o);
             }
     if (has2) {      // a third source (a sender of degree 4) is rare: ONE branch around the whole block of loads
 #pragma unroll
@@ -175,7 +257,8 @@ __device__ __forceinline__ bool rule64w_apply(gcdp tabP, gcdp bt, gcdp tabC, gcd
 #pragma unroll
             for (int b = a; b < 4; b++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) M[ut(a, b)][r] += src2[kD + tile_off(a, b, r, g, c)];
+                for (int r = 0; r < 4; r++) M[ut(a, b)][r] += src2.ld(mo, kD + tile_const(a, b, r));
+    }
     }
     // a dependency is undefined (whole messages are NaN together): the signal is not pending
     if (__builtin_isnan(bcast(M[0][0], 0))) return false;
@@ -207,10 +290,9 @@ __device__ __forceinline__ bool rule64w_apply(gcdp tabP, gcdp bt, gcdp tabC, gcd
     double zrv[4][4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int e = 16 * j + c;
-        double wcv = src0[e] + src1[e];
-        if (has2) wcv += src2[e];
-        if (AFFINE) wcv += hv[e];
+        double wcv = src0.ld(c, 16 * j) + src1.ld(c, 16 * j);
+        if (has2) wcv += src2.ld(c, 16 * j);
+        if (AFFINE) wcv += hv.ld(c, 16 * j);
 #pragma unroll
         for (int k = 0; k < j; k++) {
             double p = 0.0;
@@ -236,7 +318,7 @@ __device__ __forceinline__ bool rule64w_apply(gcdp tabP, gcdp bt, gcdp tabC, gcd
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) Y[j][b][r] = bt[tile_off(j, b, r, g, c)];
+            for (int r = 0; r < 4; r++) Y[j][b][r] = bt.ld(mo, tile_const(j, b, r));
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             d4 Vj;
@@ -259,7 +341,7 @@ __device__ __forceinline__ bool rule64w_apply(gcdp tabP, gcdp bt, gcdp tabC, gcd
         for (int b = a; b < 4; b++) {
             d4 Ct;
 #pragma unroll
-            for (int r = 0; r < 4; r++) Ct[r] = tabC[tile_off(a, b, r, g, c)];
+            for (int r = 0; r < 4; r++) Ct[r] = tabC.ld(mo, tile_const(a, b, r));
             d4 G = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int j = 0; j < 4; j++) G = tts(Y[j][a], Y[j][b], G);
@@ -267,14 +349,14 @@ __device__ __forceinline__ bool rule64w_apply(gcdp tabP, gcdp bt, gcdp tabC, gcd
 #pragma unroll
             for (int r = 0; r < 4; r++) D[r] = Ct[r] - G[r];
 #pragma unroll
-            for (int r = 0; r < 4; r++) dst[kD + tile_off(a, b, r, g, c)] = D[r];
+            for (int r = 0; r < 4; r++) dst.st(mo, kD + tile_const(a, b, r), D[r]);
             if (b > a) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the previous tile's reads have returned
 #pragma unroll
                 for (int r = 0; r < 4; r++) S[(g + 4 * r) * kLdT + c] = D[r];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int r = 0; r < 4; r++) dst[kD + tile_off(b, a, r, g, c)] = S[c * kLdT + g + 4 * r];
+                for (int r = 0; r < 4; r++) dst.st(mo, kD + tile_const(b, a, r), S[c * kLdT + g + 4 * r]);
             }
         }
         double p = 0.0;
@@ -283,13 +365,29 @@ __device__ __forceinline__ bool rule64w_apply(gcdp tabP, gcdp bt, gcdp tabC, gcd
 #pragma unroll
             for (int r = 0; r < 4; r++) p += Y[j][a][r] * (Z_IN_LDS ? ZS[16 * j + g + 4 * r] : zrv[j][r]);
         double ecv = sum_groups(p);                                                    // (Yt' z)[16 a + c]
-        if (AFFINE) ecv += cv[16 * a + c];
-        if (g == 0) dst[16 * a + c] = ecv;
+        if (AFFINE) ecv += cv.ld(c, 16 * a);
+        if (g == 0) dst.st(c, 16 * a, ecv);
     }
     W64_STAMP(5);
     return true;
 }
 
+
+
+// the rule on plain pointers (k_rule64w, k_step64)
+template <bool AFFINE, bool Z_IN_LDS = false>
+__device__ __forceinline__ bool rule64w_apply(gcdp tabP, gcdp bt, gcdp tabC, gcdp hv, gcdp cv, gcdp src0, gcdp src1, gcdp src2, const bool has2, gdp dst,
+                                              double *S, double (*Vs)[16 * kLdT], const int lane, const int g, const int c, double *ZS = nullptr) {
+    return rule64_body<AFFINE, Z_IN_LDS, false, PtrAcc>(acc_of(tabP), acc_of(bt), acc_of(tabC), acc_of(hv), acc_of(cv), acc_of(src0), acc_of(src1), acc_of(src2), has2,
+                                                 acc_of((gcdp)dst), S, Vs, lane, g, c, ZS);
+}
+// the rule on buffer descriptors (the walks that loop inside a kernel: cx_mv64chain.hip)
+template <bool AFFINE, bool Z_IN_LDS = false>
+__device__ __forceinline__ bool rule64b_apply(gcdp tabP, gcdp bt, gcdp tabC, gcdp hv, gcdp cv, gcdp src0, gcdp src1, gcdp src2, const bool has2, gdp dst,
+                                              double *S, double (*Vs)[16 * kLdT], const int lane, const int g, const int c, double *ZS = nullptr) {
+    return rule64_body<AFFINE, Z_IN_LDS, true, BufAcc>(buf_of(tabP), buf_of(bt), buf_of(tabC), buf_of(hv), buf_of(cv), buf_of(src0), buf_of(src1), buf_of(src2), has2,
+                                                 buf_of((gcdp)dst), S, Vs, lane, g, c, ZS);
+}
 
 }  // namespace w64
 }  // namespace cx
