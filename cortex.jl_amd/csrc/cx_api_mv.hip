@@ -223,6 +223,7 @@ int32_t mv_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, d
         if (v < 0) return fail(h, CX_ERR_NOT_FOUND, "unknown variable id " + std::to_string(variable_ids[i]));
         idx[i] = (int32_t)v;
     }
+    { int32_t rc = mv_ensure_marginals(h); if (rc != CX_OK) return rc; }
     return mv_get(h, h->d_mv_marg, h->nv, idx, CX_FORM_MOMENT, true, out);
 }
 
@@ -313,7 +314,11 @@ static int32_t mv_chain_sweep(cx_handle *h, int32_t n_sweeps) {
             cx::mvc_launch_side(h, marg);
             h->observed_passes_due = 0; h->chain_side_dirty = false;
         }
-        cx::mvc_launch_scan(h, marg, false, true);
+        // compute_marginals_in_sweep == 2: the marginals on demand, like the chain messages (and like dim 64): the sweep leaves alpha and
+        // gamma in the walks' order, the pass that turns them into marginals runs before the first reader (mv_ensure_marginals)
+        const bool defer = h->cfg.compute_marginals_in_sweep == 2;
+        cx::mvc_launch_scan(h, marg, false, true, defer);
+        h->mvc_marg_pending = marg && defer;
         h->chain_msgs_stale = true;      // the chain messages live in the scan's own buffers until somebody asks for them
         h->sweeps_done++;
     }
@@ -361,7 +366,19 @@ int32_t mv_chain_block_maps(cx_handle *h, double *fwd, double *bwd, double *side
 
 // dim 2..4 under the chain-scan schedule: bring the chain messages in d_mv_f2v up to date (the tile carries of the last sweep are
 // still on the device: two apply launches).  Every reader of d_mv_f2v calls this first.
+int32_t mv_ensure_marginals(cx_handle *h) {
+    if (!h->mvc_marg_pending) return CX_OK;
+    h->mvc_marg_pending = false;
+    if (h->d_mvc_alpha && h->chain_nlinks > 0) {
+        cx::mvc_launch_marg_out(h);
+        CX_HIP(h, hipGetLastError());
+    }
+    return CX_OK;
+}
+
 int32_t mv_ensure_chain_msgs(cx_handle *h) {
+    // (every caller is about to read or to change state the deferred marginals depend on: they are formed first)
+    { int32_t rc = mv_ensure_marginals(h); if (rc != CX_OK) return rc; }
     if (!h->chain_msgs_stale) return CX_OK;
     // side sums, alphas and tile carries of the last sweep are untouched until the next sweep (or a rebuild of the chains, which
     // calls this first): the two walks reproduce exactly the messages of that sweep

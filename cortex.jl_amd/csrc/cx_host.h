@@ -140,6 +140,7 @@ int32_t mv_residual(cx_handle *h, double *out);
 int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n);
 int32_t mv_chain_block_maps(cx_handle *h, double *fwd, double *bwd, double *side_first, double *side_last, int64_t *first_variable_id,
                             int64_t *last_variable_id, int64_t *n_links);
+int32_t mv_ensure_marginals(cx_handle *h);    // chain scan, dim 2..4, marginals on demand: form them from the last sweep's alpha and gamma
 int32_t mv_ensure_chain_msgs(cx_handle *h);   // chain scan, dim 2..4: materialise the chain messages in d_mv_f2v (every reader of it calls this)
 // ---- cx_api_sweep.hip -----------------------------------------------------------------------------------------------
 int32_t normalize_alt(cx_handle *h);

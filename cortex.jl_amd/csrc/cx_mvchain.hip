@@ -852,6 +852,13 @@ void mvc_launch_side(cx_handle *h, bool write_marg) {
 #undef CX_MVC
 }
 
+template <int D>
+static void mvc_marg_out_t(cx_handle *h, const MvcArgs &A, int K) {
+    const int ntiles = (int)mvc_ntiles(A.nlinks, K);
+    hipLaunchKernelGGL((k_mvc_marg_out<D>), dim3((unsigned)(ntiles * ((kBlock + mvc_slab_threads(K) - 1) / mvc_slab_threads(K)))), dim3(kBlock), (size_t)Msg<D>::NC * K * mvc_slab_pitch(K) * sizeof(double), h->stream, A.nlinks, K,
+                       A.il_stride, A.nv, A.link_pos, A.pos_var, A.alpha, A.gamma, h->d_mv_marg);
+}
+
 template <int D, bool GT>
 static void mvc_launch_t(cx_handle *h, const MvcArgs &A, int K, int flags, bool scan) {
     const int ntiles = (int)mvc_ntiles(A.nlinks, K);
@@ -860,16 +867,31 @@ static void mvc_launch_t(cx_handle *h, const MvcArgs &A, int K, int flags, bool 
         hipLaunchKernelGGL((k_mvc_scan_totals<D>), dim3(2), dim3(kBlock), 0, h->stream, ntiles, h->d_mvc_totals, h->d_mvc_block);
     }
     hipLaunchKernelGGL((k_mvc_apply<D, GT>), dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, K, h->d_mvc_totals, h->d_mv_f2v, h->d_mv_marg, flags);
-    if (flags & 1) {
-        hipLaunchKernelGGL((k_mvc_marg_out<D>), dim3((unsigned)(ntiles * ((kBlock + mvc_slab_threads(K) - 1) / mvc_slab_threads(K)))), dim3(kBlock), (size_t)Msg<D>::NC * K * mvc_slab_pitch(K) * sizeof(double), h->stream, A.nlinks, K,
-                           A.il_stride, A.nv, A.link_pos, A.pos_var, A.alpha, A.gamma, h->d_mv_marg);
-    }
+    if ((flags & 1) && !(flags & 4)) mvc_marg_out_t<D>(h, A, K);
 }
 
 // One sweep: all forward and backward chain messages and, with write_marg, the chain variables' marginals.
 // store_msgs: the messages also go to their slots of d_mv_f2v.  scan = false: the thread prefixes and tile carries of the last sweep
 // are still valid (nothing changed since): only the walks run — how the messages are materialised on demand.
-void mvc_launch_scan(cx_handle *h, bool write_marg, bool store_msgs, bool scan) {
+// defer_marg (with write_marg): the walks leave alpha and gamma — and write the marginal of every path's first variable, which hears no
+// alpha — but the pass that adds them up, converts to moment form and moves them to the marginals' place is left to mvc_launch_marg_out.
+static MvcArgs mvc_args(cx_handle *h, int collapse_heads) {
+    const int K = h->mvc_K;
+    return MvcArgs{(int)h->chain_nlinks, (int)h->chain_npos, (int)h->nv, (int)(2 * h->ptab_sets), h->nslots, h->d_chain_link_pos, h->d_chain_from,
+                   h->d_chain_to, h->d_chain_tab_fwd, h->d_chain_tab_bwd, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_pos_var,
+                   h->d_mvc_side, h->d_mvc_side_l, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix, h->d_mvc_wave_carry,
+                   mvc_ntiles(h->chain_nlinks, K) * kBlock * K, collapse_heads, h->d_ptab};
+}
+
+void mvc_launch_marg_out(cx_handle *h) {
+    if (h->chain_nlinks == 0) return;
+    const MvcArgs A = mvc_args(h, 1);
+    if (h->cfg.dim == 2) mvc_marg_out_t<2>(h, A, h->mvc_K);
+    else if (h->cfg.dim == 3) mvc_marg_out_t<3>(h, A, h->mvc_K);
+    else mvc_marg_out_t<4>(h, A, h->mvc_K);
+}
+
+void mvc_launch_scan(cx_handle *h, bool write_marg, bool store_msgs, bool scan, bool defer_marg) {
     if (h->chain_nlinks == 0) return;
     const int K = h->mvc_K;
     MvcArgs A{(int)h->chain_nlinks, (int)h->chain_npos, (int)h->nv, (int)(2 * h->ptab_sets), h->nslots, h->d_chain_link_pos, h->d_chain_from,
@@ -877,7 +899,7 @@ void mvc_launch_scan(cx_handle *h, bool write_marg, bool store_msgs, bool scan) 
               h->d_mvc_side, h->d_mvc_side_l, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix, h->d_mvc_wave_carry,
               mvc_ntiles(h->chain_nlinks, K) * kBlock * K, 1, h->d_ptab};
     const bool gt = A.ntab > kMvcTabLds;
-    const int flags = (write_marg ? 1 : 0) | (store_msgs ? 2 : 0);
+    const int flags = (write_marg ? 1 : 0) | (store_msgs ? 2 : 0) | (defer_marg ? 4 : 0);
 #define CX_MVC(DD) do { if (gt) mvc_launch_t<DD, true>(h, A, K, flags, scan); else mvc_launch_t<DD, false>(h, A, K, flags, scan); } while (0)
     if (h->cfg.dim == 2) CX_MVC(2);
     else if (h->cfg.dim == 3) CX_MVC(3);

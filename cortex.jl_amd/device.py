@@ -29,7 +29,7 @@ class DeviceGraph:
                  materialize_messages_to_factor: bool = False, family: int = L.FAMILY_GAUSSIAN, sweeps_per_launch: int = 0):
         self.lib = L.load()
         self._batch_raw = None
-        cfg = L.Config(C.sizeof(L.Config), device, dim, schedule, int(marginals_in_sweep),
+        cfg = L.Config(C.sizeof(L.Config), device, dim, schedule, int(marginals_in_sweep),      # True/1: every sweep; 2: on demand (chain scan, dim 2..4)
                        int(materialize_messages_to_factor), int(family), int(sweeps_per_launch))
         h = C.c_void_p()
         rc = self.lib.cx_create(C.byref(cfg), C.byref(h))

@@ -143,7 +143,12 @@ typedef struct cx_config {
     int32_t device;        /* HIP device ordinal */
     int32_t dim;           /* message dimension d: 1 (scalar), 2, 3, 4 (registers); 64 is the MFMA path */
     int32_t schedule;      /* CX_SCHED_*: dim 1 all three; dim 2..4 CX_SCHED_FUSED or CX_SCHED_CHAIN_SCAN; dim 64 CX_SCHED_FUSED */
-    int32_t compute_marginals_in_sweep; /* 1: every sweep also refreshes all marginals (update_marginals!) */
+    int32_t compute_marginals_in_sweep; /* 1: every sweep also refreshes all marginals (update_marginals!).
+                                           2 (CX_SCHED_CHAIN_SCAN, dim 2..4; elsewhere the same as 1): on demand — a sweep leaves
+                                           the chain's forward and backward sums in the order of its walks, and the pass that
+                                           adds them up, converts to moment form and moves them to the marginals' place runs
+                                           before the first cx_get_marginals / cx_state_export / cx_update_batch after it
+                                           (the same values; dim 64 always works this way)                                  */
     int32_t materialize_messages_to_factor; /* CX_SCHED_FUSED only. 0: variable→factor messages stay in registers
                                                during a sweep and are recomputed, bit-identically, from the retained
                                                input buffer when cx_get_messages / cx_update_batch asks for them;

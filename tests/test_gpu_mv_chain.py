@@ -190,3 +190,41 @@ def test_checkpoint_round_trip_under_the_chain_schedule(hip_lib):
     assert np.array_equal(other.get_marginals(model.x_ids), want)
     other.sweep(1)
     assert_close(other.get_marginals(model.x_ids), want, 1e-12, "a sweep after the import")
+
+
+def test_marginals_on_demand_are_the_same_marginals(hip_lib, monkeypatch):
+    """compute_marginals_in_sweep = 2: a sweep leaves the forward and backward sums, the marginal pass runs before the first reader.
+    Bit for bit the marginals of the default mode — after a sweep, after reads of other state in between (messages, a checkpoint,
+    a batch of items), after new data, over several components, for every K"""
+    d = 3
+    for K in (1, 4, 16):
+        monkeypatch.setenv("CX_MVC_K", str(K))
+        A = cx.synth.lgssm_chain(2, d=d, seed=70).meta["A"]
+        parts = [cx.synth.lgssm_chain(T, d=d, seed=70 + T, A=A) for T in (1, 2, 700, 9)]
+        model = cx.synth.concat_models(parts)
+        eager = _dev(model)
+        lazy = cx.DeviceGraph(dim=d, schedule=L.SCHED_CHAIN_SCAN, marginals_in_sweep=2)
+        cx.synth.load_into_device(model, lazy)
+        eager.sweep(1); lazy.sweep(1)
+        assert np.array_equal(eager.get_marginals(model.x_ids), lazy.get_marginals(model.x_ids)), f"K={K}: first read"
+        assert np.array_equal(eager.get_marginals(model.x_ids[:3]), lazy.get_marginals(model.x_ids[:3])), f"K={K}: second read"
+        # two sweeps without a read in between, then messages first (their walks rewrite the same sums), then the marginals
+        eager.sweep(2); lazy.sweep(2)
+        ev, ef = model.edge_var[:40], model.edge_fac[:40]
+        assert np.array_equal(eager.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL), lazy.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL), equal_nan=True)
+        assert np.array_equal(eager.get_marginals(model.x_ids), lazy.get_marginals(model.x_ids)), f"K={K}: after get_messages"
+        # a checkpoint taken while the marginals are still owed carries them
+        lazy.sweep(1); eager.sweep(1)
+        blob = lazy.export_state()
+        other = cx.DeviceGraph(dim=d, schedule=L.SCHED_CHAIN_SCAN, marginals_in_sweep=2)
+        cx.synth.load_into_device(model, other)
+        other.import_state(blob)
+        assert np.array_equal(other.get_marginals(model.x_ids), eager.get_marginals(model.x_ids)), f"K={K}: through a checkpoint"
+        # new data, sweep, read
+        y2 = model.data_y - 0.25
+        for dev in (eager, lazy):
+            dev.set_messages(model.data_var, model.data_fac, L.TO_FACTOR, L.FORM_POINT, y2)
+            dev.sweep(1)
+        assert np.array_equal(eager.get_marginals(model.x_ids), lazy.get_marginals(model.x_ids)), f"K={K}: after new data"
+        for dev in (eager, lazy, other):
+            dev.close()
