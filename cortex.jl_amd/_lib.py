@@ -21,7 +21,7 @@ FORM_MOMENT, FORM_POINT, FORM_NATURAL, FORM_MEAN_PRECISION, FORM_GAMMA = 0, 1, 2
 FACTOR_OPAQUE, FACTOR_GAUSS_ADDITIVE, FACTOR_GAUSS_LINEAR, FACTOR_NORMAL_PRECISION, FACTOR_BERNOULLI, FACTOR_GAUSS_LINEAR_N = 0, 1, 2, 3, 4, 5
 NPARAM = 4
 ROLE_OUT, ROLE_IN, ROLE_PRECISION = 0, 1, 2
-SCHED_FLOODING, SCHED_FUSED, SCHED_CHAIN_SCAN = 0, 1, 2
+SCHED_FLOODING, SCHED_FUSED, SCHED_CHAIN_SCAN, SCHED_TREE = 0, 1, 2, 3
 FAMILY_GAUSSIAN, FAMILY_NATURAL2, FAMILY_VMP_MEAN_FIELD, FAMILY_VMP_STRUCTURED = 0, 1, 2, 3
 VMP_ALL_NORMAL, VMP_ALL_PRECISION = -1, -2
 KERNEL_VAR_TO_FACTOR, KERNEL_FACTOR_TO_VAR, KERNEL_FUSED, KERNEL_BATCH, KERNEL_BIG_VAR = 0, 1, 2, 3, 4
@@ -102,6 +102,7 @@ SIGNATURES = {
     "cx_halo_ipc_set_timeout": (_i32, [_vp, C.c_double]),
     "cx_chain_block_maps": (_i32, [_vp, _pd, _pd, _pd, _pd, _pi64, _pi64, _pi64]),
     "cx_chain_plan_stats": (_i32, [_vp, _pi64]),
+    "cx_tree_plan_stats": (_i32, [_vp, _pi64]),
     "cx_set_marginals": (_i32, [_vp, _i64, _pi64, _i32, _pd]),
     "cx_update_marginals": (_i32, [_vp, _i64, _pi64]),
     "cx_state_bytes": (_i32, [_vp, _pi64]),

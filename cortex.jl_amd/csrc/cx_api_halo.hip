@@ -34,7 +34,7 @@ int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const
         for (uint8_t &b : h->vinfo) b &= (uint8_t)~cx::kGhost;
         for (int32_t v : recv_vars) h->vinfo[v] |= cx::kGhost;
         h->halo_state = false;
-        h->chains_dirty = true;
+        h->chains_dirty = true; h->tree_dirty = true;
         CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
         cx::ipc_destroy(h);          // the receive areas are sized by the halo lists
         for (void *p : {(void *)h->d_send_slots, (void *)h->d_recv_slots, (void *)h->d_send_vars}) if (p) (void)hipFree(p);

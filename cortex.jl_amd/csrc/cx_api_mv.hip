@@ -88,7 +88,7 @@ int32_t mv64_set_messages(cx_handle *h, int64_t n, const std::vector<int32_t> &i
         if (newly) {     // the work lists depend on WHICH variables are observed, not on their data
             CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
             h->work64_dirty = true;
-            h->chains_dirty = true;      // a newly observed variable leaves the chains
+            h->chains_dirty = true; h->tree_dirty = true;      // a newly observed variable leaves the chains
         }
         h->point64_dirty = true;      // the constant messages out of the observed variables are due again
     } else {
@@ -147,7 +147,7 @@ int32_t mv_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
             for (int64_t i = 0; i < n; i++)
                 if (!(h->vinfo[vars[i]] & cx::kClamped)) { h->vinfo[vars[i]] |= cx::kClamped; newly = true; }
             if (newly) {
-                h->chains_dirty = true;      // a newly observed variable leaves the chains
+                h->chains_dirty = true; h->tree_dirty = true;      // a newly observed variable leaves the chains
                 CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
                 h->spdir_dirty = true;
             }

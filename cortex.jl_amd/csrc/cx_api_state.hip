@@ -170,7 +170,7 @@ int32_t cx_state_import(cx_handle *h, const void *buf, int64_t bytes) {
     h->v2f_stale = (hd.v2f_stale & 1) != 0;
     h->offchain_marg_dirty = (hd.v2f_stale & 2) != 0;     // the marginals themselves travelled in section 5
     h->alt_two_back = false; h->tile_info_dirty = true; h->chain_msgs_stale = false; h->mvc_marg_pending = false;     // (the imported marginals are final)
-    h->spdir_dirty = h->work64_dirty = h->point64_dirty = h->chains_dirty = true;   // derived from the observed flags
+    h->spdir_dirty = h->work64_dirty = h->point64_dirty = h->chains_dirty = true; h->tree_dirty = true;   // derived from the observed flags
     if (h->d_prev) { (void)hipFree(h->d_prev); h->d_prev = nullptr; }               // residual snapshots restart
     if (h->d_mv_prev) { (void)hipFree(h->d_mv_prev); h->d_mv_prev = nullptr; }
     return CX_OK;

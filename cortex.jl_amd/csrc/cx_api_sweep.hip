@@ -3,6 +3,7 @@
 
 #include "cx_host.h"
 #include "cx_chains.h"
+#include "cx_tree_plan.h"
 
 using namespace cxh;
 
@@ -105,6 +106,40 @@ int32_t build_chains(cx_handle *h) {
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "chain decomposition: host allocation failed"); }
 }
 
+
+// ---- CX_SCHED_TREE: the stages of cx_tree_plan.h, built once per set of observed variables ----------------------------
+int32_t build_tree(cx_handle *h) {
+    if (!h->tree_dirty) return CX_OK;
+    try {
+        cx::treeplan::Out plan;
+        std::string terr;
+        const int32_t rc = cx::treeplan::build(h, plan, terr);
+        if (rc != CX_OK) return fail(h, rc, terr);
+        for (void *p : {(void *)h->d_tree_rec, (void *)h->d_tree_kary}) if (p) (void)hipFree(p);
+        h->d_tree_rec = h->d_tree_kary = nullptr;
+        int32_t rc2;
+        if (!plan.rec.empty() && (rc2 = dev_upload(h, &h->d_tree_rec, plan.rec)) != CX_OK) return rc2;
+        if (!plan.kary.empty() && (rc2 = dev_upload(h, &h->d_tree_kary, plan.kary)) != CX_OK) return rc2;
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        h->tree_stage_off = plan.stage_off; h->tree_kary_off = plan.kary_off;
+        const int64_t st[8] = {plan.depth, (int64_t)plan.stage_off.size() - 1, (int64_t)plan.rec.size() / 5, (int64_t)plan.kary.size(), plan.n_components,
+                               plan.n_up, plan.n_down, plan.n_marginals};
+        std::memcpy(h->tree_stats, st, sizeof st);
+        h->tree_dirty = false;
+        return CX_OK;
+    } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "tree schedule: host allocation failed"); }
+}
+
+// one exact sweep: every stage in order, on the handle's stream, in place (a stage's items are independent; a stage reads what
+// earlier stages of this sweep and the stored constants left)
+static void tree_sweep(cx_handle *h) {
+    const size_t ns = h->tree_stage_off.empty() ? 0 : h->tree_stage_off.size() - 1;
+    for (size_t s = 0; s < ns; s++) {
+        const int64_t n = h->tree_stage_off[s + 1] - h->tree_stage_off[s], nk = h->tree_kary_off[s + 1] - h->tree_kary_off[s];
+        if (n > 0) cx::launch_batch(h, h->d_tree_rec + 5 * h->tree_stage_off[s], n);
+        if (nk > 0) cx::launch_kary_items(h, h->d_tree_kary + h->tree_kary_off[s], nk);
+    }
+}
 
 // ---- the sweep ----------------------------------------------------------------------------------------------------
 void sweep_main(cx_handle *h, bool skip_ghosts) {
@@ -247,6 +282,12 @@ int32_t cx_chain_block_maps(cx_handle *h, double *fwd6, double *bwd6, double *si
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_chain_block_maps: host allocation failed"); }
 }
 
+int32_t cx_tree_plan_stats(const cx_handle *h, int64_t *out8) {
+    CX_REQUIRE(const_cast<cx_handle *>(h), h && out8, CX_ERR_INVALID_ARGUMENT, "cx_tree_plan_stats: null argument");
+    for (int i = 0; i < 8; i++) out8[i] = h->tree_dirty ? 0 : h->tree_stats[i];
+    return CX_OK;
+}
+
 int32_t cx_chain_plan_stats(const cx_handle *h, int64_t *out8) {
     if (!h || !out8) return CX_ERR_INVALID_ARGUMENT;
     cx::chain64_stats(h, out8);
@@ -262,6 +303,15 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
                "cx_sweep: this handle holds a partition (halo configured): use cx_sweep_begin / _main / _end");
     if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) { int32_t rc = build_chains(h); if (rc != CX_OK) return rc; }
     { int32_t rc = cx::kary_upload(h); if (rc != CX_OK) return rc; }      // coefficients set since the last sweep
+    if (h->cfg.schedule == CX_SCHED_TREE) {
+        CX_REQUIRE(h, h->recv_slots.empty() && h->send_slots.empty(), CX_ERR_UNSUPPORTED, "cx_sweep: the tree schedule is not partitioned in this build");
+        int32_t rc = build_tree(h);
+        if (rc != CX_OK) return rc;
+        for (int32_t s = 0; s < n_sweeps; s++) { tree_sweep(h); h->sweeps_done++; }
+        h->v2f_stale = false;            // every variable→factor message somebody reads was stored by its stage
+        CX_HIP(h, hipGetLastError());
+        return CX_OK;
+    }
     int32_t s = 0;
     // pairs of sweeps as ONE launch each (cx_tiles.hip), when the schedule and the graph allow it
     // (opt-in: measured SLOWER than single sweeps on MI355X, see DESIGN.md §4c — kept as a tested experiment, not the default)
@@ -326,7 +376,7 @@ int32_t cx_sweep_begin(cx_handle *h) {
     CX_REQUIRE(h, h->cfg.dim == 1, CX_ERR_UNSUPPORTED, "cx_sweep_begin: partitioned sweeps are implemented for dim == 1 only in this build");
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_sweep_begin: previous sweep not ended");
     CX_REQUIRE(h, !h->halo_state, CX_ERR_STATE, "cx_sweep_begin: the handle is configured for state halos (cx_halo_configure_state): use cx_sweep + cx_halo_state_exchange");
-    CX_REQUIRE(h, h->cfg.schedule != CX_SCHED_CHAIN_SCAN, CX_ERR_UNSUPPORTED, "cx_sweep_begin: the chain-scan schedule is not partitioned in this build");
+    CX_REQUIRE(h, h->cfg.schedule != CX_SCHED_CHAIN_SCAN && h->cfg.schedule != CX_SCHED_TREE, CX_ERR_UNSUPPORTED, "cx_sweep_begin: the chain-scan and tree schedules are not partitioned in this build");
     cx::launch_halo_export(h, h->d_f2v, h->stream);
     CX_HIP(h, hipGetLastError());
     h->in_sweep = true;

@@ -100,6 +100,11 @@ struct cx_handle {
 
     // chain-scan schedule (cx_chain.hip): paths of free variables, built lazily by build_chains()
     bool chains_dirty = true;
+    // CX_SCHED_TREE (cx_tree_plan.h): the stages' items and k-ary entries on the device, their offsets on the host
+    bool tree_dirty = true;
+    int32_t *d_tree_rec = nullptr, *d_tree_kary = nullptr;
+    std::vector<int64_t> tree_stage_off, tree_kary_off;
+    int64_t tree_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // depth, stages, items, k-ary entries, components, up, down, marginals
     int64_t chain_npos = 0, chain_nlinks = 0;
     int64_t chain_npos_linked = 0;   // dim > 1: positions [0, this) belong to paths with links; the isolated ones follow
     bool chain_side_dirty = true;    // the leaf messages / side sums of the chain positions must be recomputed (data or rule parameters changed)

@@ -94,6 +94,13 @@ class DeviceGraph:
         self._check(self.lib.cx_tile_stats(self.h, C.byref(n), C.byref(r), C.byref(b)))
         return {"n_tiles": n.value, "variables_loaded_per_owned": r.value, "lds_bytes_per_workgroup": b.value}
 
+    def tree_plan_stats(self):
+        """cx_tree_plan_stats: the stages of the tree schedule's last sweep (zeros before it and for other schedules)"""
+        out = (C.c_int64 * 8)()
+        self._check(self.lib.cx_tree_plan_stats(self.h, out))
+        keys = ("depth", "stages", "items", "kary_entries", "components", "messages_up", "messages_down", "marginals")
+        return dict(zip(keys, [int(x) for x in out]))
+
     def chain_plan_stats(self):
         """cx_chain_plan_stats: the composition / walk plan of the dim 64 chain-scan schedule (zeros for other handles)"""
         out = (C.c_int64 * 8)()

@@ -273,6 +273,81 @@ def kary_model(n_factors: int, seed: int = 1234, tree: bool = True, k_choices=(2
                        "fac_vars": fac_vars, "used": used})
 
 
+def tree_model(n_factors: int, seed: int = 1234, k_choices=(1, 1, 2, 3, 5), observe: float = 0.25, shape: str = "random", components: int = 1) -> Model:
+    """A scalar Gaussian model whose factor graph is a FOREST with factors of every arity: pairwise linear factors x_out = a x_in + b +
+    N(0, q) (CX_FACTOR_GAUSS_LINEAR, k = 1 input) next to factors of k >= 2 inputs (CX_FACTOR_GAUSS_LINEAR_N), a unary prior on every
+    latent variable and point-mass data on a share `observe` of the leaves.  shape: where a new factor hangs — "random" (any existing
+    variable: bushy, depth ~ log n), "deep" (a recent variable: long paths with side branches), "star" (the first variable: one hub of
+    degree n_factors + 1).  components: that many disjoint trees.  meta as synth.kary_model's (coefficients of the k-ary factors only, for
+    cx_set_factor_coefficients) plus `all_coef_*`: the input coefficient of EVERY factor edge, for a dense solve."""
+    rng = np.random.default_rng(seed)
+    fac_vars, nvar, roots = [], components, list(range(1, components + 1))
+    comp_vars = [[r] for r in roots]
+    for f in range(n_factors):
+        k = int(rng.choice(k_choices))
+        cv = comp_vars[f % components]
+        if shape == "star":
+            anchor = cv[0]
+        elif shape == "deep":
+            anchor = cv[-1 - int(rng.integers(0, min(3, len(cv))))]
+        else:
+            anchor = cv[int(rng.integers(0, len(cv)))]
+        new = list(range(nvar + 1, nvar + k + 1))
+        nvar += k
+        cv.extend(new)
+        fac_vars.append([anchor] + new)
+    used = np.arange(1, nvar + 1, dtype=np.int64)
+    prior_fac_of = {int(v): nvar + 1 + i for i, v in enumerate(used)}
+    kf_id0 = 2 * nvar + 1
+    ev, ef, er, cvr, cfc, cf, acv, acf, ac, out_var = [], [], [], [], [], [], [], [], [], []
+    q, b = rng.uniform(0.3, 1.5, n_factors), rng.standard_normal(n_factors)
+    kinds, params = [], []
+    for f, vs in enumerate(fac_vars):
+        fid = kf_id0 + f
+        o = int(rng.integers(0, len(vs)))
+        out_var.append(vs[o])
+        pair_a = 0.0
+        for j, v in enumerate(vs):
+            ev.append(v); ef.append(fid); er.append(L.ROLE_OUT if j == o else L.ROLE_IN)
+            if j != o:
+                a = float(rng.uniform(0.4, 1.3) * rng.choice([1.0, -1.0], p=[0.75, 0.25]))
+                acv.append(v); acf.append(fid); ac.append(a)
+                if len(vs) > 2:
+                    cvr.append(v); cfc.append(fid); cf.append(a)
+                else:
+                    pair_a = a
+        if len(vs) > 2:
+            kinds.append(L.FACTOR_GAUSS_LINEAR_N); params.append([q[f], b[f], 0.0])
+        else:
+            kinds.append(L.FACTOR_GAUSS_LINEAR); params.append([q[f], pair_a, b[f]])
+    deg = np.bincount(np.asarray(ev), minlength=nvar + 1)
+    is_obs = np.zeros(nvar + 1, dtype=bool)
+    if observe > 0:
+        is_obs[[int(v) for v in used if deg[v] == 1 and v not in roots and rng.random() < observe]] = True
+    pv = np.array([v for v in used if not is_obs[v]], dtype=np.int64)
+    for v in pv:
+        ev.append(int(v)); ef.append(prior_fac_of[int(v)]); er.append(L.ROLE_OUT)
+    data_var = np.array([v for v in used if is_obs[v]], dtype=np.int64)
+    first_fac = {}
+    for v, f in zip(ev, ef):
+        first_fac.setdefault(int(v), int(f))
+    data_fac = np.array([first_fac[int(v)] for v in data_var], dtype=np.int64)
+    prior_ids = np.array([prior_fac_of[int(v)] for v in pv], dtype=np.int64)
+    kf_ids = kf_id0 + np.arange(n_factors, dtype=np.int64)
+    fp = np.zeros((len(prior_ids) + n_factors, 3))
+    fp[len(prior_ids):] = np.asarray(params).reshape(n_factors, 3)
+    is_kary = np.asarray(kinds) == L.FACTOR_GAUSS_LINEAR_N
+    return Model(edge_var=np.asarray(ev, dtype=np.int64), edge_fac=np.asarray(ef, dtype=np.int64), factor_ids=np.concatenate([prior_ids, kf_ids]),
+                 factor_kind=np.concatenate([np.full(len(prior_ids), L.FACTOR_OPAQUE), np.asarray(kinds)]).astype(np.int32),
+                 factor_var=fp, x_ids=pv, data_var=data_var, data_fac=data_fac, data_y=rng.standard_normal(len(data_var)) * 2,
+                 prior_var=pv, prior_fac=prior_ids, prior_mean=rng.standard_normal(len(pv)) * 2, prior_variance=rng.uniform(0.5, 2.0, len(pv)),
+                 edge_role=np.asarray(er, dtype=np.int32),
+                 meta={"kind": "kary" if is_kary.any() else "tree", "coef_var": np.asarray(cvr, dtype=np.int64), "coef_fac": np.asarray(cfc, dtype=np.int64),
+                       "coef": np.asarray(cf), "all_coef_var": np.asarray(acv, dtype=np.int64), "all_coef_fac": np.asarray(acf, dtype=np.int64),
+                       "all_coef": np.asarray(ac), "q": q, "b": b, "out_var": np.asarray(out_var, dtype=np.int64), "kary_ids": kf_ids,
+                       "fac_vars": fac_vars, "used": used, "is_kary": is_kary})
+
+
 def load_into_device(model: Model, dev, seed_variance: float | None = None):
     """graph upload + the data injection a user of the reference does with set_value! before update_marginals!."""
     if model.dim > 1:

@@ -135,6 +135,14 @@ extern "C" {
                                  non-observed variable must sit on a chain; a sweep writes the marginals, the chain
                                  messages reach their slots when cx_get_messages / cx_update_batch / cx_residual /
                                  cx_state_export ask for them                                                     */
+#define CX_SCHED_TREE 3       /* graphs whose non-observed part is a forest (any degrees, factors of two or more variables):
+                                 one cx_sweep = the reference's one update_marginals! there — every message once, from
+                                 final inputs, leaves to root and back (inference_engine.jl:575-608), level by level:
+                                 2 x depth + 1 launches over item lists built once (depth = half the longest path of a
+                                 component, counted in variables and factors).  A cycle among the non-observed variables
+                                 is refused (CX_ERR_UNSUPPORTED).  Lazy like the reference: nothing into observed
+                                 variables.  dim 1, Gaussian and natural-pair families.                                  */
+
 
 typedef struct cx_handle cx_handle;
 
@@ -395,6 +403,10 @@ int32_t cx_chain_block_maps(cx_handle *h, double *forward6, double *backward6, d
  * group, levels, potentials, pairwise compositions per sweep (960 matrix instructions each), rule applications per sweep (384
  * each), kernel launches per sweep, device bytes of the plan}.  All zeros before the first sweep and for any other handle. */
 int32_t cx_chain_plan_stats(const cx_handle *h, int64_t *out8);
+
+/* CX_SCHED_TREE: the plan of the last sweep (zeros before the first one and for other schedules).
+ * out8 = { depth, stages, items, k-ary entries, components, messages upwards, messages downwards, marginals }. */
+int32_t cx_tree_plan_stats(const cx_handle *h, int64_t *out8);
 
 /* ---- checkpoint (the reference keeps no persistent state — src/ has no serialisation at all) ----
  * The mutable state of a handle (every message buffer, the marginals, the observed-variable flags, the sweep counter)

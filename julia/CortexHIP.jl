@@ -170,6 +170,12 @@ set_factor_coefficients!(p, variable_ids::Vector{Int64}, factor_ids::Vector{Int6
                           p.handle, length(a), variable_ids, factor_ids, a))
 
 # the plan of the dim 64 chain-scan schedule: (links per block, fan, levels, potentials, compositions, rules, launches, device bytes)
+function tree_plan_stats(p)            # CX_SCHED_TREE (schedule = 3): depth, stages, items, k-ary entries, components, up, down, marginals
+    out = zeros(Int64, 8)
+    check(p.handle, ccall((:cx_tree_plan_stats, lib), Int32, (Ptr{Cvoid}, Ptr{Int64}), p.handle, out))
+    return out
+end
+
 function chain_plan_stats(p)
     out = zeros(Int64, 8)
     check(p.handle, ccall((:cx_chain_plan_stats, lib), Int32, (Ptr{Cvoid}, Ptr{Int64}), p.handle, out))

@@ -15,7 +15,8 @@ def dense_posterior(model):
     for v, m, s in zip(model.prior_var, model.prior_mean, model.prior_variance):
         J[pos[int(v)], pos[int(v)]] += 1.0 / s
         h[pos[int(v)]] += m / s
-    coef = {(int(v), int(f)): float(a) for v, f, a in zip(meta["coef_var"], meta["coef_fac"], meta["coef"])}
+    cv, cf, ca = (meta["all_coef_var"], meta["all_coef_fac"], meta["all_coef"]) if "all_coef" in meta else (meta["coef_var"], meta["coef_fac"], meta["coef"])
+    coef = {(int(v), int(f)): float(a) for v, f, a in zip(cv, cf, ca)}
     for fi, fid in enumerate(meta["kary_ids"]):
         vs = meta["fac_vars"][fi]
         c = {v: (1.0 if v == int(meta["out_var"][fi]) else -coef[(v, int(fid))]) for v in vs}

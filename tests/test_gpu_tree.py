@@ -1,0 +1,163 @@
+"""-m gpu: CX_SCHED_TREE — ONE cx_sweep on a graph whose non-observed part is a forest is what ONE update_marginals! of the
+reference leaves there (src/inference_engine.jl:575-608: the forward and the reverse pass; on a tree every message is then final),
+for factors of any arity and variables of any degree.
+
+Pinned by: the dense solve of the joint Gaussian (tests/kary_support.py); the flooding schedule run to its fixed point on the same
+device (message by message); the restated reference scheduler on the reference's own state-space model
+(test/inference_engine_tests.jl:436-487) — and the plan itself by its numpy execution on the CPU (tests/test_tree_plan.py)."""
+import numpy as np
+import pytest
+
+import cortex.jl_amd as cx
+from cortex.jl_amd import _lib as L
+from tests.helpers import assert_close, engine_oracle_from_model
+from tests.kary_support import dense_posterior
+
+pytestmark = pytest.mark.gpu
+
+
+def _tree_dev(m):
+    dev = cx.DeviceGraph(schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(m, dev)
+    return dev
+
+
+@pytest.mark.parametrize("shape", ["random", "deep", "star"])
+@pytest.mark.parametrize("n_factors,components,seed", [(1, 1, 1), (40, 1, 2), (40, 4, 3), (3000, 2, 4)])
+def test_one_sweep_is_the_exact_posterior(hip_lib, shape, n_factors, components, seed):
+    m = cx.synth.tree_model(n_factors, seed=seed, shape=shape, components=components, observe=0.3)
+    dev = _tree_dev(m)
+    dev.sweep(1)
+    ids, em, ev = dense_posterior(m)
+    marg = dev.get_marginals(ids)
+    assert not np.any(np.isnan(marg)), "undefined marginals after one sweep"
+    assert_close(marg[:, 0], em, 1e-9, f"{shape}: marginal means vs the dense solve")
+    assert_close(marg[:, 1], ev, 1e-9, f"{shape}: marginal variances vs the dense solve")
+    st = dev.tree_plan_stats()
+    assert st["components"] == components and st["marginals"] == len(ids) and st["stages"] == 2 * st["depth"] + 1
+    # a second sweep recomputes the same messages from the same inputs
+    before = dev.get_marginals(ids)
+    dev.sweep(1)
+    assert np.array_equal(before, dev.get_marginals(ids))
+
+
+def test_messages_equal_the_flooding_fixed_point(hip_lib):
+    """every factor→variable message into a non-observed variable and every variable→factor message that has a reader: one tree sweep
+    == the flooding schedule after diameter-many sweeps on the same device"""
+    m = cx.synth.tree_model(120, seed=9, shape="random", components=2, observe=0.25)
+    tree = _tree_dev(m)
+    tree.sweep(1)
+    flood = cx.DeviceGraph(schedule=L.SCHED_FLOODING)
+    cx.synth.load_into_device(m, flood)
+    flood.sweep(2 * tree.tree_plan_stats()["depth"] + 4)
+    obs = set(int(v) for v in m.data_var)
+    keep = np.array([int(v) not in obs for v in m.edge_var])
+    ev, ef = m.edge_var[keep], m.edge_fac[keep]
+    a, b = tree.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL), flood.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL)
+    assert not np.any(np.isnan(a))
+    assert_close(a, b, 1e-9, "factor→variable messages, natural form")
+    a, b = tree.get_messages(ev, ef, L.TO_FACTOR, L.FORM_NATURAL), flood.get_messages(ev, ef, L.TO_FACTOR, L.FORM_NATURAL)
+    has = ~np.isnan(a[:, 1])          # lazy: no message towards a factor whose other variables are all observed, none out of a degree-1 variable
+    assert has.sum() > len(ev) // 3
+    assert_close(a[has], b[has], 1e-9, "variable→factor messages that the tree schedule computes")
+
+
+def test_the_reference_state_space_model(hip_lib):
+    """the SSM of test/inference_engine_tests.jl:436-487 (a path is a tree): one sweep == the restated reference scheduler's one
+    update_marginals! == the chain-scan schedule"""
+    m = cx.synth.ssm_chain(200, seed=5, random_variances=True)
+    dev = _tree_dev(m)
+    dev.sweep(1)
+    eng = engine_oracle_from_model(m)
+    eng.update_marginals(m.x_ids)
+    _, em, ev = eng.get_marginals(m.x_ids)
+    got = dev.get_marginals(m.x_ids)
+    assert_close(got[:, 0], em, 1e-9, "means vs the restated scheduler")
+    assert_close(got[:, 1], ev, 1e-9, "variances vs the restated scheduler")
+    scan = cx.DeviceGraph(schedule=L.SCHED_CHAIN_SCAN)
+    cx.synth.load_into_device(m, scan)
+    scan.sweep(1)
+    assert_close(got, scan.get_marginals(m.x_ids), 1e-10, "tree schedule vs chain scan")
+    assert dev.tree_plan_stats()["depth"] <= 200 + 1      # rooted at the middle of the path
+
+
+def test_a_hub_of_degree_two_thousand(hip_lib):
+    """the star: one variable in 2,000 factors (the segment-tree case of src/dependencies.jl:128-173) — two levels"""
+    m = cx.synth.tree_model(2000, seed=12, shape="star", k_choices=(1, 2), observe=0.2)
+    dev = _tree_dev(m)
+    dev.sweep(1)
+    ids, em, ev = dense_posterior(m)
+    marg = dev.get_marginals(ids)
+    assert_close(marg[:, 0], em, 1e-9, "means")
+    assert_close(marg[:, 1], ev, 1e-9, "variances")
+    assert dev.tree_plan_stats()["depth"] <= 4
+
+
+def test_new_data_and_newly_observed_variables(hip_lib):
+    """data changes keep the plan; observing a latent variable cuts the tree there (the plan is rebuilt)"""
+    import dataclasses
+    m = cx.synth.tree_model(80, seed=21, shape="deep", observe=0.3)
+    dev = _tree_dev(m)
+    dev.sweep(1)
+    y2 = m.data_y + 1.0
+    dev.set_messages(m.data_var, m.data_fac, L.TO_FACTOR, L.FORM_POINT, y2)
+    dev.sweep(1)
+    m2 = dataclasses.replace(m, data_y=y2)
+    ids, em, ev = dense_posterior(m2)
+    marg = dev.get_marginals(ids)
+    assert_close(marg[:, 0], em, 1e-9, "after new data: means")
+    assert_close(marg[:, 1], ev, 1e-9, "after new data: variances")
+    # observe an inner variable through one of its factors: everything it separates becomes independent
+    fac_of = {}
+    for v, f in zip(m.edge_var, m.edge_fac):
+        if int(f) in set(int(x) for x in m.meta["kary_ids"]):
+            fac_of.setdefault(int(v), int(f))
+    deg = np.bincount(m.edge_var)
+    inner = next(int(v) for v in m.x_ids if deg[v] >= 3 and int(v) in fac_of)
+    before = dev.tree_plan_stats()
+    inner_facs = m.edge_fac[m.edge_var == inner]          # the datum travels on every edge of the variable (a message is per edge)
+    dev.set_messages(np.full(len(inner_facs), inner), inner_facs, L.TO_FACTOR, L.FORM_POINT, np.full(len(inner_facs), 0.7))
+    assert dev.tree_plan_stats()["stages"] == 0, "a newly observed variable invalidates the plan"
+    dev.sweep(1)
+    after = dev.tree_plan_stats()
+    assert after["marginals"] == before["marginals"] - 1 and after["components"] >= before["components"]
+    # dense solve with the extra datum: the observed variable's prior no longer counts (its messages are never read)
+    keep = m.prior_var != inner
+    m3 = dataclasses.replace(m2, data_var=np.r_[m.data_var, inner], data_fac=np.r_[m.data_fac, fac_of[inner]], data_y=np.r_[y2, 0.7],
+                             prior_var=m.prior_var[keep], prior_fac=m.prior_fac[keep], prior_mean=m.prior_mean[keep], prior_variance=m.prior_variance[keep])
+    ids, em, ev = dense_posterior(m3)
+    marg = dev.get_marginals(ids)
+    assert_close(marg[:, 0], em, 1e-9, "after observing an inner variable: means")
+    assert_close(marg[:, 1], ev, 1e-9, "after observing an inner variable: variances")
+
+
+def test_cycles_are_refused_not_approximated(hip_lib):
+    m = cx.synth.gaussian_grid(5, 5, seed=3)
+    dev = cx.DeviceGraph(schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(m, dev)
+    with pytest.raises(cx.CortexHipError) as e:
+        dev.sweep(1)
+    assert e.value.code == L.ERR_UNSUPPORTED and "cycle" in str(e.value)
+    loopy = cx.synth.kary_model(50, seed=4, tree=False)
+    dev2 = cx.DeviceGraph(schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(loopy, dev2)
+    with pytest.raises(cx.CortexHipError) as e:
+        dev2.sweep(1)
+    assert e.value.code == L.ERR_UNSUPPORTED
+
+
+def test_a_large_bushy_tree_one_sweep(hip_lib):
+    """200,000 factors, ~10^6 edges: the depth stays logarithmic, one sweep is a few dozen launches; checked against the flooding
+    schedule at its fixed point on a sample of the marginals"""
+    m = cx.synth.tree_model(200_000, seed=31, shape="random", observe=0.2)
+    dev = _tree_dev(m)
+    dev.sweep(1)
+    st = dev.tree_plan_stats()
+    assert st["depth"] < 120, st
+    flood = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(m, flood)
+    flood.sweep(2 * st["depth"] + 6)
+    ids = m.x_ids[:: max(len(m.x_ids) // 50_000, 1)]
+    a, b = dev.get_marginals(ids), flood.get_marginals(ids)
+    assert not np.any(np.isnan(a))
+    assert_close(a, b, 1e-9, "marginals vs the fused schedule at its fixed point")

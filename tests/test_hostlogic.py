@@ -234,18 +234,21 @@ def test_error_paths_leave_nothing_out_of_bounds():
     assert norole.status == L.ERR_INVALID_ARGUMENT and "edge roles" in norole.error
 
 
-def _run_under_asan(lib, select):
+def _run_under_asan(lib, select, files=None):
     pre = " ".join(subprocess.check_output(["gcc", "-print-file-name=" + n], text=True).strip() for n in ("libasan.so", "libstdc++.so.6"))
     env = dict(os.environ, LD_PRELOAD=pre, CXH_LIB=lib, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
-    code = ("import sys; sys.path.insert(0, %r); import pytest; sys.exit(pytest.main(['-x', '-q', '-s', '-p', 'no:cacheprovider', %r, '-k', %r]))"
-            % (ROOT, os.path.abspath(__file__), select))
+    files = files or [os.path.abspath(__file__)]
+    code = ("import sys; sys.path.insert(0, %r); import pytest; sys.exit(pytest.main(['-x', '-q', '-s', '-p', 'no:cacheprovider'] + %r + ['-k', %r]))"
+            % (ROOT, files, select))
     return subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
 
 
 def test_host_logic_under_address_and_ub_sanitizers():
     from cortex.jl_amd import build as B
 
-    out = _run_under_asan(B.build_hostlogic(asan=True), "not sanitizers and not reintroduced")
+    # this file and the plan of the tree schedule (tests/test_tree_plan.py: cx_tree_plan.h over forests, cycles, observed cuts)
+    out = _run_under_asan(B.build_hostlogic(asan=True), "not sanitizers and not reintroduced",
+                          [os.path.abspath(__file__), os.path.join(ROOT, "tests", "test_tree_plan.py")])
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr
 

@@ -1,0 +1,170 @@
+"""CPU: the plan of CX_SCHED_TREE (csrc/cx_tree_plan.h, compiled without HIP by csrc/cx_hostlogic.cpp) EXECUTED in numpy.
+
+Every stage's items are applied to message tables that start undefined except for what the caller set (priors, data), with the
+reference's rules for a linear-Gaussian factor of any arity (test/inference_engine_tests.jl:415-432 generalised; one
+variable→factor message = the product of the OTHER factor→variable messages, src/dependencies.jl:60-88).  An item that reads an
+undefined input fails the test — so a plan that passes has every dependency produced by an earlier stage — each message is
+produced once, and the marginals of the one pass must equal a dense solve of the joint Gaussian."""
+import numpy as np
+import pytest
+
+import cortex.jl_amd as cx
+from cortex.jl_amd import _lib as L
+from tests.hostlogic import FlatGraph
+from tests.kary_support import dense_posterior
+
+ITEM_M2F, ITEM_M2V, ITEM_MARG = L.ITEM_MESSAGE_TO_FACTOR, L.ITEM_MESSAGE_TO_VARIABLE, L.ITEM_INDIVIDUAL_MARGINAL
+
+
+def flat_of(model):
+    g = FlatGraph(model.edge_var, model.edge_fac, model.factor_ids, model.factor_kind, model.factor_var, edge_role=model.edge_role, dim=1, schedule=L.SCHED_TREE)
+    assert g.status == L.OK, g.error
+    if len(model.data_var):
+        g.clamp(model.data_var)
+    return g
+
+
+class PlanRun:
+    """message tables by slot + the model's rules, driven by the plan's items"""
+
+    def __init__(self, g, model):
+        self.g, self.m = g, model
+        self.var_ids, self.var_off = g.arr("var_ids"), g.arr("var_off")
+        self.edge_var, self.edge_fac = g.arr("edge_var"), g.arr("edge_fac_id")
+        vbase, deg = g.arr("vbase"), g.arr("var_deg")
+        k = np.arange(len(self.edge_var)) - self.var_off[self.edge_var]
+        self.slot_of_edge = np.where(deg[self.edge_var] <= 8, vbase[self.edge_var] + 256 * k, vbase[self.edge_var] + k)
+        self.edge_of_slot = {int(s): e for e, s in enumerate(self.slot_of_edge)}
+        ns = g.scalar("nslots")
+        self.f2v = np.full((ns, 2), np.nan)     # natural form (xi, w)
+        self.v2f = np.full((ns, 2), np.nan)
+        self.clamped = (g.arr("vinfo") & 16) != 0
+        meta = model.meta
+        self.fac_edges = {}
+        for e, f in enumerate(self.edge_fac):
+            self.fac_edges.setdefault(int(f), []).append(e)
+        self.coef = {}                          # (factor id, variable id) -> c: sum_e c_e x_e = b + N(0, q)
+        for fi, fid in enumerate(meta["kary_ids"]):
+            for v in meta["fac_vars"][fi]:
+                self.coef[(int(fid), int(v))] = 1.0
+        for v, f, a in zip(meta["all_coef_var"], meta["all_coef_fac"], meta["all_coef"]):
+            self.coef[(int(f), int(v))] = -float(a)
+        self.qb = {int(fid): (float(meta["q"][fi]), float(meta["b"][fi])) for fi, fid in enumerate(meta["kary_ids"])}
+        self.written = set()
+        eidx = {(int(self.var_ids[v]), int(f)): e for e, (v, f) in enumerate(zip(self.edge_var, self.edge_fac))}
+        for v, f, mu, s2 in zip(model.prior_var, model.prior_fac, model.prior_mean, model.prior_variance):
+            self.f2v[self.slot_of_edge[eidx[(int(v), int(f))]]] = (mu / s2, 1.0 / s2)
+        for v, f, y in zip(model.data_var, model.data_fac, model.data_y):
+            self.v2f[self.slot_of_edge[eidx[(int(v), int(f))]]] = (y, np.inf)
+
+    def moments(self, nat):
+        return (nat[0], 0.0) if np.isinf(nat[1]) else (nat[0] / nat[1], 1.0 / nat[1])
+
+    def m2f(self, slot, v):
+        e = self.edge_of_slot[slot]
+        assert self.edge_var[e] == v and not self.clamped[v]
+        others = [self.slot_of_edge[x] for x in range(self.var_off[v], self.var_off[v + 1]) if x != e]
+        assert others, "a variable of degree 1 has no variable→factor item"
+        tot = self.f2v[others].sum(axis=0)
+        assert not np.any(np.isnan(tot)), f"variable {self.var_ids[v]} → factor {self.edge_fac[e]}: an input is undefined at this stage"
+        self._store(("v2f", slot), self.v2f, slot, tot)
+
+    def m2v(self, slot):
+        e = self.edge_of_slot[slot]
+        f, v = int(self.edge_fac[e]), int(self.var_ids[self.edge_var[e]])
+        assert not self.clamped[self.edge_var[e]], "no message into an observed variable"
+        q, b = self.qb[f]
+        cj = self.coef[(f, v)]
+        mean, var = b, q
+        for x in self.fac_edges[f]:
+            if x == e:
+                continue
+            nat = self.v2f[self.slot_of_edge[x]]
+            assert not np.any(np.isnan(nat)), f"factor {f} → variable {v}: the message of variable {self.var_ids[self.edge_var[x]]} is undefined at this stage"
+            mx, vx = self.moments(nat)
+            c = self.coef[(f, int(self.var_ids[self.edge_var[x]]))]
+            mean -= c * mx
+            var += c * c * vx
+        mean /= cj
+        var /= cj * cj
+        self._store(("f2v", slot), self.f2v, slot, (mean / var, 1.0 / var))
+
+    def _store(self, key, table, slot, value):
+        assert key not in self.written, f"{key} is produced twice in one sweep"
+        self.written.add(key)
+        table[slot] = value
+
+    def run(self):
+        g = self.g
+        rec = g.arr("tree_rec").reshape(-1, 5)
+        off, kary, koff = g.arr("tree_stage_off"), g.arr("tree_kary"), g.arr("tree_kary_off")
+        kslot = g.arr("kary_slot_all")
+        marg = {}
+        for s in range(len(off) - 1):
+            items, ents = rec[off[s]:off[s + 1]], kary[koff[s]:koff[s + 1]]
+            kinds = set(int(k) for k in items[:, 0]) | ({ITEM_M2V} if len(ents) else set())
+            # a stage is of ONE kind: variable→factor items read factor→variable messages and write the other table (and the other way
+            # round), so the items of a stage cannot read what another item of the same stage writes
+            assert len(kinds) <= 1, f"stage {s} mixes item kinds {kinds}"
+            for kind, slot, var, _, _ in items:
+                if kind == ITEM_M2F:
+                    self.m2f(int(slot), int(var))
+                elif kind == ITEM_M2V:
+                    self.m2v(int(slot))
+                else:
+                    assert kind == ITEM_MARG and s == len(off) - 2, "marginals belong to the last stage"
+                    v = int(var)
+                    tot = self.f2v[[self.slot_of_edge[x] for x in range(self.var_off[v], self.var_off[v + 1])]].sum(axis=0)
+                    assert not np.any(np.isnan(tot)), f"marginal of {self.var_ids[v]}: an input is undefined"
+                    marg[int(self.var_ids[v])] = (tot[0] / tot[1], 1.0 / tot[1])
+            for ent in ents:
+                self.m2v(int(kslot[ent]))
+        return marg
+
+
+@pytest.mark.parametrize("shape", ["random", "deep", "star"])
+@pytest.mark.parametrize("n_factors,components,seed", [(1, 1, 1), (7, 1, 2), (60, 1, 3), (60, 3, 4), (300, 2, 5)])
+def test_one_pass_of_the_plan_is_the_exact_posterior(shape, n_factors, components, seed):
+    m = cx.synth.tree_model(n_factors, seed=seed, shape=shape, components=components, observe=0.3)
+    g = flat_of(m)
+    rc, err = g.tree()
+    assert rc == L.OK, err
+    run = PlanRun(g, m)
+    marg = run.run()
+    ids, em, ev = dense_posterior(m)
+    assert sorted(marg) == sorted(int(i) for i in ids), "a marginal for every non-observed variable and no other"
+    got = np.array([marg[int(i)] for i in ids])
+    assert np.allclose(got[:, 0], em, rtol=1e-9, atol=1e-12) and np.allclose(got[:, 1], ev, rtol=1e-9, atol=1e-12)
+    assert g.scalar("tree_components") == components and g.scalar("tree_marginals") == len(ids)
+    # stages: 2 x depth + 1; the depth is half the longest path of the deepest component, rounded up to a variable
+    assert len(g.arr("tree_stage_off")) - 1 == 2 * g.scalar("tree_depth") + 1
+
+
+def test_depth_is_half_the_diameter():
+    """a path of T variables: rooted at its middle, the plan is T - 1 levels deep at most (variables and factors alternate), not 2 T"""
+    for T in (2, 3, 10, 31):
+        m = cx.synth.ssm_chain_linear(T, seed=T)
+        m.meta.update(kary_ids=np.zeros(0, dtype=np.int64))
+        g = FlatGraph(m.edge_var, m.edge_fac, m.factor_ids, m.factor_kind, m.factor_var, edge_role=m.edge_role, schedule=L.SCHED_TREE)
+        g.clamp(m.data_var)
+        rc, err = g.tree()
+        assert rc == L.OK, err
+        # longest path of the free part: likelihood factor - x_1 - ... - x_T - likelihood factor = 2 T nodes + ... edges: 2 (T - 1) + 2 hops
+        assert g.scalar("tree_depth") in (T, T + 1), (T, g.scalar("tree_depth"))
+
+
+def test_cycles_are_refused_and_observed_variables_cut_them():
+    m = cx.synth.gaussian_grid(4, 4, seed=3)
+    g = FlatGraph(m.edge_var, m.edge_fac, m.factor_ids, m.factor_kind, m.factor_var, edge_role=m.edge_role, schedule=L.SCHED_TREE)
+    g.clamp(m.data_var)
+    rc, err = g.tree()
+    assert rc == L.ERR_UNSUPPORTED and "cycle" in err
+    # a 2 x N ladder is loopy; observing one rail leaves a path
+    lad = cx.synth.gaussian_grid(2, 6, seed=4)
+    g2 = FlatGraph(lad.edge_var, lad.edge_fac, lad.factor_ids, lad.factor_kind, lad.factor_var, edge_role=lad.edge_role, schedule=L.SCHED_TREE)
+    g2.clamp(lad.data_var)
+    assert g2.tree()[0] == L.ERR_UNSUPPORTED
+    g2.clamp(np.r_[lad.data_var, lad.x_ids[:6]])
+    rc, err = g2.tree()
+    assert rc == L.OK, err
+    assert g2.scalar("tree_components") == 1 and g2.scalar("tree_marginals") == 6

@@ -110,9 +110,13 @@ def test_host_cost_is_linear_in_the_chain_length():
     """2T wavefronts of O(1) host work each, not O(T) each.  (Python on a shared box: a loose bound.)"""
     times = {}
     for n in (250, 1000):
-        engine, proc, x, *_ = _ssm(n)
-        t0 = time.perf_counter()
-        cx.run_wavefronts(request_inference_for(engine, x), _launcher(engine, proc, []))
-        times[n] = time.perf_counter() - t0
+        best = None
+        for _ in range(3):                  # the best of three: a loaded box stretches single runs, not the scaling
+            engine, proc, x, *_ = _ssm(n)
+            t0 = time.perf_counter()
+            cx.run_wavefronts(request_inference_for(engine, x), _launcher(engine, proc, []))
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        times[n] = best
     assert times[1000] < 8 * times[250] + 0.05, times          # quadratic would be 16x
     assert times[1000] < 1.5, times
