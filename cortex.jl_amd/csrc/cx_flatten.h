@@ -135,10 +135,13 @@ int32_t flatten(H *h, int64_t n_edges, const int64_t *edge_var, const int64_t *e
         if (!h->big_vars.empty())
             return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_create: dim > 1 handles variables of degree <= 8 only; variable " +
                         std::to_string(h->var_ids[h->big_vars[0]]) + " has more");
+        // dim 2..4: a variable's incoming messages live in registers (k_sweep_mv<D, DEG>: DEG = 3, 4 or 8 by the graph's widest
+        // variable); dim 64: a rule sums at most three sources (k_rule64w)
+        const int max_deg = h->cfg.dim == 64 ? 4 : 8;
         for (int64_t v = 0; v < nv; v++)
-            if (var_deg[v] > 4)
-                return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_create: dim > 1 handles variables of degree <= 4 in this build; variable " +
-                            std::to_string(h->var_ids[v]) + " has degree " + std::to_string(var_deg[v]));
+            if (var_deg[v] > max_deg)
+                return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_create: dim " + std::to_string(h->cfg.dim) + " handles variables of degree <= " + std::to_string(max_deg) +
+                            " in this build; variable " + std::to_string(h->var_ids[v]) + " has degree " + std::to_string(var_deg[v]));
     }
     std::vector<double> q(mv ? 1 : slots, 0.0), a, b, sq, sa, sb;
     h->any_linear = false;

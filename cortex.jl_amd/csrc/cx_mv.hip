@@ -41,11 +41,12 @@ constexpr int kMvDeg = 4;  // variables of higher degree are refused at graph cr
 // The leave-one-out sums add the messages in ascending neighbour order, the reference's left fold order.
 constexpr int kTabLds = 8;   // parameter-set/direction pairs kept in LDS (3 d*d matrices each); more fall back to global memory
 
-// DEG: the largest variable degree of the graph (3 or 4).  A state-space chain has degree 3: three incoming messages instead of four
+// DEG: the largest variable degree of the graph (3, 4, or 8 for anything wider: eight messages in registers is one wave per SIMD and some
+// scratch for d = 4 — the instance exists so that such graphs run, not to be fast).  A state-space chain has degree 3: three incoming messages instead of four
 // are 28 registers less for d = 4 — 168 VGPRs, THREE waves per SIMD instead of two (no scratch), which is what this kernel's
 // load / compute lock-step was short of.
 template <int D, int DEG, bool NT_LOADS>
-__global__ __launch_bounds__(kBlock, DEG == 3 ? 3 : 2) void k_sweep_mv(int nv, int64_t nslots, const int32_t *__restrict__ slice_off,
+__global__ __launch_bounds__(kBlock, DEG == 3 ? 3 : DEG == 4 ? 2 : 1) void k_sweep_mv(int nv, int64_t nslots, const int32_t *__restrict__ slice_off,
                                                      const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
                                                      const int32_t *__restrict__ spdir, const double *__restrict__ ptab, int ntab,
                                                      const double *__restrict__ f2v_in, double *__restrict__ f2v_out,
@@ -220,13 +221,14 @@ void mv_launch_sweep(cx_handle *h, bool write_marg, int observed_only, double *f
         h->mv_max_deg = std::max(w, 1);
     }
     static const bool force4 = [] { const char *e = getenv("CX_MV_DEG4"); return e && e[0] == '1'; }();
-    const bool deg3 = h->mv_max_deg <= 3 && !force4;
+    const bool deg3 = h->mv_max_deg <= 3 && !force4, deg8 = h->mv_max_deg > 4;
 #define CX_MV_ARGS g, b, 0, h->stream, (int)h->nv, h->nslots, h->d_slice_off, h->d_vinfo, h->d_partner, h->d_spdir, h->d_ptab, (int)(2 * h->ptab_sets), \
                    h->d_mv_f2v, f2v_out, h->d_mv_v2f, h->d_mv_marg, (write_marg && !observed_only) ? 1 : 0, observed_only
     // CX_MV_NT=0/1: nontemporal loads of the incoming messages off / on (A/B; default on: every message is read once per sweep)
     static const bool nt = [] { const char *e = getenv("CX_MV_NT"); return !(e && e[0] == '0'); }();
 #define CX_MV(DD)                                                                      \
-    if (deg3 && nt) hipLaunchKernelGGL((k_sweep_mv<DD, 3, true>), CX_MV_ARGS);         \
+    if (deg8) hipLaunchKernelGGL((k_sweep_mv<DD, 8, true>), CX_MV_ARGS);               \
+    else if (deg3 && nt) hipLaunchKernelGGL((k_sweep_mv<DD, 3, true>), CX_MV_ARGS);    \
     else if (deg3) hipLaunchKernelGGL((k_sweep_mv<DD, 3, false>), CX_MV_ARGS);         \
     else if (nt) hipLaunchKernelGGL((k_sweep_mv<DD, 4, true>), CX_MV_ARGS);            \
     else hipLaunchKernelGGL((k_sweep_mv<DD, 4, false>), CX_MV_ARGS)

@@ -299,15 +299,15 @@ def test_mv64_wave_per_message_form_matches_the_workgroup_form(hip_lib, monkeypa
 
 # ------------------------------------------------------------------------------- degree-4 variables (three sources)
 
-def _branching_lgssm(n, d, seed):
-    """a binary TREE of states (node i has children 2i+1, 2i+2), every state observed: inner nodes have degree 4 (parent,
-    two children, likelihood), so a message out of them sums THREE incoming ones — the branch a chain never takes"""
+def _branching_lgssm(n, d, seed, b=2):
+    """a TREE of states with b children per node (node i has children b i + 1 .. b i + b), every state observed: inner nodes have degree
+    b + 2 (parent, children, likelihood); b = 2: degree 4, a message out of them sums THREE incoming ones — the branch a chain never takes"""
     rng = np.random.default_rng(seed)
     A = 0.9 * np.linalg.qr(rng.standard_normal((d, d)))[0]
     Q, R = 0.2 * np.eye(d), np.eye(d)
     x = np.arange(1, n + 1, dtype=np.int64)
     y, lik = x + n, x + 2 * n
-    pairs = [(p, c) for p in range(n) for c in (2 * p + 1, 2 * p + 2) if c < n]
+    pairs = [(p, c) for p in range(n) for c in range(b * p + 1, b * p + b + 1) if c < n]
     tr = 3 * n + 1 + np.arange(len(pairs), dtype=np.int64)
     par = np.array([x[p] for p, _ in pairs]); chi = np.array([x[c] for _, c in pairs])
     edge_var = np.concatenate([y, x, par, chi])
@@ -365,3 +365,36 @@ def test_mv_tree_with_degree_4_variables(hip_lib, monkeypatch, d, form):
     marg = dev.get_marginals(model.x_ids)
     assert_close(marg[:, :d], emean, 1e-8, "tree marginal mean vs the joint solve")
     assert_close(marg[:, d:].reshape(n, d, d), ecov, 1e-8, "tree marginal covariance vs the joint solve")
+
+
+@pytest.mark.parametrize("d,b", [(2, 3), (3, 5), (4, 4), (4, 6)])
+def test_mv_tree_with_variables_of_degree_up_to_eight(hip_lib, d, b):
+    """dim 2..4: more than four edges per variable (the reference's resolver takes any degree, src/dependencies.jl:60-125): the sweep
+    keeps up to eight incoming messages in registers (k_sweep_mv<D, 8>).  Per sweep against the numpy restatement, then the joint solve."""
+    n = 1 + b + b * b
+    model, emean, ecov = _branching_lgssm(n, d, seed=6 + b, b=b)
+    dev = _dev(model)
+    o = MvFlood(model)
+    g = o.g
+    assert np.diff(g.var_off).max() == b + 2
+    xs_set = set(np.searchsorted(g.var_ids, model.x_ids).tolist())
+    pe = np.array([e for e in np.flatnonzero(g.partner >= 0) if int(np.searchsorted(g.var_ids, g.edge_var[e])) in xs_set])
+    for sweep in range(6):
+        dev.sweep(1)
+        o.sweep(1)
+        got = dev.get_messages(g.edge_var[pe], g.edge_fac[pe], L.TO_VARIABLE)
+        for row, e in zip(got, pe):
+            if o.f2v[e] is None:
+                assert np.all(np.isnan(row)), f"sweep {sweep} edge {e}: device defined, restatement undefined"
+                continue
+            m, S = o.f2v[e]
+            if not np.all(np.isfinite(S)) or np.linalg.cond(S) > 1e12:
+                continue
+            assert_close(row[:d], m, 1e-8, f"sweep {sweep} f2v mean edge {e}")
+            assert_close(row[d:].reshape(d, d), S, 1e-8, f"sweep {sweep} f2v covariance edge {e}")
+    marg = dev.get_marginals(model.x_ids)
+    assert_close(marg[:, :d], emean, 1e-8, "marginal mean vs the joint solve")
+    assert_close(marg[:, d:].reshape(n, d, d), ecov, 1e-8, "marginal covariance vs the joint solve")
+    # variable→factor messages on demand and item by item through the boundary see the same degrees
+    vm = dev.get_messages(g.edge_var[pe], g.edge_fac[pe], L.TO_FACTOR)
+    assert not np.all(np.isnan(vm))
