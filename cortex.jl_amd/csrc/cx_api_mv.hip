@@ -61,7 +61,7 @@ int32_t mv_refresh_v2f(cx_handle *h, const std::vector<int32_t> &slots, const st
     CX_HIP(h, hipMemcpyAsync(d_s, slots.data(), n * 4, hipMemcpyHostToDevice, h->stream));
     CX_HIP(h, hipMemcpyAsync(d_v, vars.data(), n * 4, hipMemcpyHostToDevice, h->stream));
     // fused schedule: the input buffer of the last sweep; chain scan: the one buffer there is (its messages are the fixed point)
-    const double *src = (h->sweeps_done > 0 && h->cfg.schedule != CX_SCHED_CHAIN_SCAN) ? h->d_mv_f2v_alt : h->d_mv_f2v;
+    const double *src = (h->sweeps_done > 0 && h->cfg.schedule != CX_SCHED_CHAIN_SCAN && h->cfg.schedule != CX_SCHED_TREE) ? h->d_mv_f2v_alt : h->d_mv_f2v;
     if (h->cfg.dim == 64) cx::mv64_launch_v2f(h, (int)n, d_s, d_v, src);
     else cx::mv_launch_v2f(h, d_s, d_v, n, src);
     CX_HIP(h, hipGetLastError());
@@ -474,6 +474,22 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
     for (int64_t i = 0; i <= h->max_pset; i++)
         CX_REQUIRE(h, !h->psets[i].empty(), CX_ERR_STATE, "cx_sweep: parameter set " + std::to_string(i) + " was never set (cx_set_factor_matrices)");
     if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) return mv_chain_sweep(h, n_sweeps);
+    if (h->cfg.schedule == CX_SCHED_TREE) {
+        // dim 2..4 on a forest (cx_tree_plan.h): the stages' items through k_batch_mv, in place in the one message buffer; the items
+        // carry the rule table of the sending slot as the plan found it (the plan is rebuilt when a variable becomes observed)
+        int32_t rc = build_tree(h);
+        if (rc != CX_OK) return rc;
+        const size_t ns = h->tree_stage_off.empty() ? 0 : h->tree_stage_off.size() - 1;
+        for (int32_t s = 0; s < n_sweeps; s++) {
+            for (size_t st = 0; st < ns; st++) {
+                const int64_t n = h->tree_stage_off[st + 1] - h->tree_stage_off[st];
+                if (n > 0) cx::mv_launch_batch(h, h->d_tree_rec + 5 * h->tree_stage_off[st], n);
+            }
+            h->sweeps_done++;
+        }
+        CX_HIP(h, hipGetLastError());
+        return CX_OK;
+    }
     if (h->cfg.dim == 64) {
         int32_t rc = build_work64(h);
         if (rc != CX_OK) return rc;

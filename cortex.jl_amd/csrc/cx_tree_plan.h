@@ -8,7 +8,8 @@
 //            variable→factor message, factors (odd levels) their factor→variable message
 //   down     stages from level 0 to the last but one: the nodes of a level send to their children
 //   last     the marginal of every non-observed variable
-// A stage is a list of batch items (5 int32 each: kind, slot, variable, 0, 0 — what cx_update_batch stages, cx_kernels.hip) plus,
+// A stage is a list of batch items (5 int32 each: kind, slot, variable, rule table (dim > 1), 0 — what cx_update_batch stages,
+// cx_kernels.hip / cx_mvbatch.hip) plus,
 // for factors with more than two edges, a list of entries of the k-ary table (cx_kary.hip).  Items of a stage are independent.
 // Lazy like the reference: no message into an observed variable or a stand-in, no variable→factor message towards a factor whose
 // other variables are all observed, nothing out of a variable of degree 1 (its stored message has no dependencies,
@@ -127,7 +128,10 @@ int32_t build(const H *h, Out &out, std::string &err) {
     auto m2v = [&](int32_t stage, int32_t e) {                 // the message of edge e's factor into edge e's variable
         const int32_t sl = flat::slot_of_edge_t(h, e);
         if (!h->slot_kary.empty() && h->slot_kary[sl] >= 0) kents[stage].push_back(h->slot_kary[sl]);
-        else if (h->partner[sl] >= 0) push_item(stage, CX_ITEM_MESSAGE_TO_VARIABLE, sl, h->edge_var[e]);
+        else if (h->partner[sl] >= 0) {
+            push_item(stage, CX_ITEM_MESSAGE_TO_VARIABLE, sl, h->edge_var[e]);
+            if (h->cfg.dim > 1) items[stage][items[stage].size() - 2] = h->spdir[h->partner[sl]];      // dim > 1: the rule table of the SENDING slot travels in the item
+        }
         // (a factor with one edge: its message is a stored constant)
     };
     auto m2f = [&](int32_t stage, int32_t e) {                 // the message of edge e's variable into edge e's factor

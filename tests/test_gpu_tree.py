@@ -161,3 +161,44 @@ def test_a_large_bushy_tree_one_sweep(hip_lib):
     a, b = dev.get_marginals(ids), flood.get_marginals(ids)
     assert not np.any(np.isnan(a))
     assert_close(a, b, 1e-9, "marginals vs the fused schedule at its fixed point")
+
+
+@pytest.mark.parametrize("d,b,n", [(2, 2, 31), (3, 4, 85), (4, 3, 121), (4, 6, 259)])
+def test_d_dimensional_trees_one_sweep(hip_lib, d, b, n):
+    """dim 2..4: a tree of states with b children each (degree b + 2 <= 8), every state observed through a likelihood factor: one sweep of
+    the tree schedule == the joint solve == the fused schedule at its fixed point, message by message"""
+    from tests.test_gpu_mv import _branching_lgssm
+
+    model, emean, ecov = _branching_lgssm(n, d, seed=40 + b, b=b)
+    dev = cx.DeviceGraph(dim=d, schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(model, dev)
+    dev.sweep(1)
+    marg = dev.get_marginals(model.x_ids)
+    assert not np.any(np.isnan(marg))
+    assert_close(marg[:, :d], emean, 1e-8, "marginal mean vs the joint solve", scale_by="max")
+    assert_close(marg[:, d:].reshape(n, d, d), ecov, 1e-8, "marginal covariance vs the joint solve", scale_by="max")      # (covariances ∝ I here: the median entry is ~ 0)
+    st = dev.tree_plan_stats()
+    assert st["components"] == 1 and st["marginals"] == n and st["kary_entries"] == 0
+    fused = cx.DeviceGraph(dim=d, schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(model, fused)
+    fused.sweep(2 * st["depth"] + 6)
+    xs = set(int(v) for v in model.x_ids)
+    keep = np.array([int(v) in xs for v in model.edge_var])
+    ev, ef = model.edge_var[keep], model.edge_fac[keep]
+    a, bb = dev.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL), fused.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL)
+    assert not np.any(np.isnan(a))
+    assert_close(a, bb, 1e-8, "factor→variable messages vs the fused schedule at its fixed point", scale_by="max")
+    before = dev.get_marginals(model.x_ids)
+    dev.sweep(1)
+    assert np.array_equal(before, dev.get_marginals(model.x_ids))
+
+
+def test_d_dimensional_chain_is_a_tree_too(hip_lib):
+    m = cx.synth.lgssm_chain(300, d=4, seed=8)
+    tree = cx.DeviceGraph(dim=4, schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(m, tree)
+    tree.sweep(1)
+    scan = cx.DeviceGraph(dim=4, schedule=L.SCHED_CHAIN_SCAN)
+    cx.synth.load_into_device(m, scan)
+    scan.sweep(1)
+    assert_close(tree.get_marginals(m.x_ids), scan.get_marginals(m.x_ids), 1e-9, "tree schedule vs chain scan on a d = 4 chain", scale_by="max")
