@@ -83,6 +83,18 @@ def test_sweep_mode_reaches_the_same_marginals(hip_lib):
     assert ex[7].value_after_execution.mean == pytest.approx(em[7], rel=1e-9)
 
 
+@pytest.mark.parametrize("schedule", ["tree", "chain_scan"])
+def test_sweep_mode_with_an_exact_schedule_needs_one_sweep(hip_lib, schedule):
+    """update_marginals! taken over whole: with CX_SCHED_TREE (any forest) or CX_SCHED_CHAIN_SCAN (paths) ONE device sweep is the
+    reference's result — the fused schedule above needs n + 2"""
+    n = 300
+    proc = cx.HipProcessor(mode="sweep", n_sweeps=1, schedule=cx._lib.SCHED_TREE if schedule == "tree" else cx._lib.SCHED_CHAIN_SCAN)
+    engine, x, mean, var, dataset = _run(n, proc)
+    em, ev = exact.ssm_chain_posterior(dataset, 1.0, 1.0)
+    assert_close(mean, em, 1e-9, f"{schedule}: marginal mean after one sweep")
+    assert_close(var, ev, 1e-9, f"{schedule}: marginal variance after one sweep")
+
+
 def test_linear_gaussian_factor_rule(hip_lib):
     """x_{t+1} = a x_t + b + N(0, q): the device's GAUSS_LINEAR rule against the exact posterior."""
     n, a, b, q, r = 30, 0.9, 0.3, 0.5, 0.7

@@ -290,6 +290,32 @@ def vmp_traffic(family):
     return best
 
 
+def tree(n_factors=200_000, steps=20, shape="random"):
+    """the tree schedule (CX_SCHED_TREE): ONE sweep on a forest = the reference's one update_marginals! there, level by level.  Not a
+    BASELINE config: a bushy tree with factors of 2..6 variables and ~10^6 edges, timed per exact sweep, beside the number of fused
+    sweeps the fixed-point schedule needs for the same result on the same graph."""
+    model = cx.synth.tree_model(n_factors, seed=31, shape=shape, observe=0.2)
+    dev = cx.DeviceGraph(schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(model, dev)
+    dev.sweep(2)
+    dt = timed(dev, lambda: dev.sweep(1), steps, 3)
+    st = dev.tree_plan_stats()
+    fused = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(model, fused)
+    need = 2 * st["depth"] + 2
+    fused.sweep(need)
+    dtf = timed(fused, lambda: fused.sweep(1), steps, 3)
+    ids = model.x_ids[:: max(len(model.x_ids) // 100_000, 1)]
+    a, b = dev.get_marginals(ids), fused.get_marginals(ids)
+    err = float(np.nanmax(np.abs(a - b) / np.maximum(np.abs(b), np.median(np.abs(b)))))
+    n_msgs = st["messages_up"] + st["messages_down"]
+    return {"config": "tree", "workload": f"scalar Gaussian forest, {n_factors} factors of 2..6 variables + a prior per variable ({len(model.edge_var)} edges, shape {shape})",
+            "ms_per_sweep": dt * 1e3, "plan": st, "launches_per_sweep": st["stages"], "messages_per_sweep": n_msgs, "messages_per_s": n_msgs / dt,
+            "fused_schedule": {"ms_per_sweep": dtf * 1e3, "sweeps_to_the_same_result": need, "ms_to_the_same_result": need * dtf * 1e3},
+            "parity": {"max_rel_err_marginals": err, "ok": bool(err < 1e-9), "checker": "the fused schedule at its fixed point on the same device (the tree "
+                       "schedule against a dense solve: tests/test_gpu_tree.py)", "sample": f"{len(ids)} marginals"}}
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c2", "c3", "c5"]
     torch.cuda.init()
@@ -297,6 +323,9 @@ if __name__ == "__main__":
         if w.startswith("vmp"):
             for r in vmp(only=w[4:] or None):          # vmp | vmp_structured | vmp_mean_field
                 print(json.dumps(r), flush=True)
+            continue
+        if w.startswith("tree"):                         # tree | tree:deep
+            print(json.dumps(tree(shape=w.split(":")[1] if ":" in w else "random")), flush=True)
             continue
         if w.startswith("c5scan"):                       # c5scan | c5scan:49,98,196 (links per level-0 block)
             ks = tuple(int(x) for x in w.split(":")[1].split(",")) if ":" in w else (None,)
