@@ -443,7 +443,11 @@ void k_compose64p(int njobs, const DJob *__restrict__ jobs, const DChild *__rest
     __shared__ double zs[kD];
     const int w = blockIdx.x;
     if (w >= njobs) return;
-    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // uniform: each wave takes ONE side of the branch below
+    // uniform: each wave takes ONE side of the branch below.  (Alternating the parts with the workgroup's parity, so that the
+    // factorisations do not all land on the SIMDs of first waves: measured 10.50 against 10.10 ms per C5 sweep — not kept.  Neither is
+    // the variant with wave A ONE STEP AHEAD of wave B (one barrier fewer to wait at, the ring doubled): both waves then compete for
+    // the SIMD's one f64 pipe all the time and the joint's loads stretch from 12 k to 49 k cycles per step: 10.67 ms.)
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const int first = as_const(jobs)[w].first, n = as_const(jobs)[w].n;
     gdp out = as_const(jobs)[w].out;
@@ -587,17 +591,29 @@ void k_compose64p(int njobs, const DJob *__restrict__ jobs, const DChild *__rest
             const auto *ch = as_const(children) + first;
             const rsrc_t P = buf(ch->P), B = buf(ch->B), hh = buf(ch->h);
             const int mo = (g * kD + c) * 8;
+            // (all fetches first, then the copy of P into the output record: written as load, store, load, store hipcc waits for every
+            // element — 40 round trips before the first step, most of what a launch of the tree's upper levels took)
 #pragma unroll
             for (int a = 0; a < 4; a++) {
 #pragma unroll
                 for (int b = 0; b < 4; b++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        B1[a][b][r] = bld(B, mo, mconst(a, b, r));
-                        if (b >= a) bst(oP, mo, mconst(a, b, r), bld(P, mo, mconst(a, b, r)));
-                    }
+                    for (int r = 0; r < 4; r++) B1[a][b][r] = bld(B, mo, mconst(a, b, r));
                 h1[a] = bld(hh, c * 8, 128 * a);
             }
+            d4 Pc[10];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = a; b < 4; b++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) Pc[ut(a, b)][r] = bld(P, mo, mconst(a, b, r));
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = a; b < 4; b++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) bst(oP, mo, mconst(a, b, r), Pc[ut(a, b)][r]);
         }
         for (int k = 1; k < n; k++) {
             asm volatile("" : "+v"(lane));
@@ -850,6 +866,7 @@ int32_t chain64_sweep(cx_handle *h) {
         (void)hipMemsetAsync(d_st, 0, st_n * 8, h->stream);
 #endif
         if (L.kind == 0) {
+            // CX_MVC64_COMPOSE=1: the one-wave composition (one wave per SIMD, 512 registers) for A/B; default: the paired form
             // CX_MVC64_COMPOSE=1: the one-wave composition (one wave per SIMD, 512 registers) for A/B; default: the paired form
             static const int one_wave = env_int("CX_MVC64_COMPOSE", 2) == 1;
             if (one_wave) hipLaunchKernelGGL(k_compose64, dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_children);
