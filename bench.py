@@ -404,7 +404,10 @@ def other_configs(parity=None) -> list:
     for name, fn in (("C2", lambda: bc.c2(check=hooks.get("C2"))), ("C3", lambda: bc.mv(4, 1_000_000, 30)),
                      ("C3-scan", lambda: bc.mv_scan(4, 1_000_000, 30, check=hooks.get("C3-scan"))[0]),
                      ("C5", lambda: bc.mv(64, 100_000, 12)), ("C5-scan", lambda: bc.mv64_scan(100_000, 8, check=hooks.get("C5-scan"))[0]),
-                     ("VMP", lambda: bc.vmp())):
+                     ("VMP", lambda: bc.vmp()),
+                     # not a BASELINE config: the tree schedule (one sweep = the reference's one-call result on any forest), on a tree small
+                     # enough to generate in a second
+                     ("tree", lambda: bc.tree(n_factors=30_000, steps=20))):
         try:
             r = fn()
             rows.extend(r if isinstance(r, list) else [r])

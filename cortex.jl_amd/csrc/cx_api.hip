@@ -83,8 +83,14 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
     *out = nullptr;
     if (!config || config->struct_size != (int32_t)sizeof(cx_config))
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: config is NULL or struct_size mismatch");
-    if (config->dim != 1 && config->dim != 2 && config->dim != 3 && config->dim != 4 && config->dim != 64)
-        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: this build implements dim in {1, 2, 3, 4, 64}");
+    if (config->dim < 1 || config->dim > 64)
+        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: this build implements dim 1 .. 64");
+    // dim 5 .. 63 run on the dim 64 path, embedded: x -> (x, u) with u a 64 - d dimensional unit random walk observed nowhere — every
+    // rule matrix, message and datum block-diagonal (real block, identity block), so the real block of every result is exact and the
+    // identity block keeps every joint positive definite.  The price is the arithmetic of dim 64 whatever d is.
+    const int user_dim = (config->dim > 4 && config->dim < 64) ? config->dim : 0;
+    cx_config padded;
+    if (user_dim) { padded = *config; padded.dim = 64; config = &padded; }
     const bool is_vmp = config->family == CX_FAMILY_VMP_MEAN_FIELD || config->family == CX_FAMILY_VMP_STRUCTURED;
     if (config->family != CX_FAMILY_GAUSSIAN && config->family != CX_FAMILY_NATURAL2 && !is_vmp)
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: unknown family");
@@ -110,6 +116,7 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
     cx_handle *h = new (std::nothrow) cx_handle();
     if (!h) return fail(nullptr, CX_ERR_OUT_OF_MEMORY, "cx_create: host allocation failed");
     h->cfg = *config;
+    h->user_dim = user_dim;
     h->nc = config->dim == 1 ? 2 : (config->dim == 64 ? 64 + 64 * 64 : config->dim + config->dim * (config->dim + 1) / 2);
     h->ncs = (config->dim >= 2 && config->dim <= 4) ? 2 * ((h->nc + 1) / 2) : h->nc;
     h->stream = nullptr;  // default stream until cx_set_stream
@@ -185,6 +192,14 @@ int32_t cx_set_factor_matrices(cx_handle *h, int64_t parameter_set, const double
     CX_REQUIRE(h, parameter_set >= 0 && parameter_set < (1 << 20) && A && Q, CX_ERR_INVALID_ARGUMENT, "cx_set_factor_matrices: bad argument");
     try {
         const int d = h->cfg.dim;
+        std::vector<double> Ap, Qp;
+        if (h->user_dim) {      // blockdiag(A, I), blockdiag(Q, I)
+            const int u = h->user_dim;
+            Ap.assign((size_t)d * d, 0.0); Qp.assign((size_t)d * d, 0.0);
+            for (int r = 0; r < d; r++) { Ap[(size_t)r * d + r] = 1.0; Qp[(size_t)r * d + r] = 1.0; }
+            for (int r = 0; r < u; r++) for (int c = 0; c < u; c++) { Ap[(size_t)r * d + c] = A[(size_t)r * u + c]; Qp[(size_t)r * d + c] = Q[(size_t)r * u + c]; }
+            A = Ap.data(); Q = Qp.data();
+        }
         if ((int64_t)h->psets.size() <= parameter_set) h->psets.resize(parameter_set + 1);
         auto &ps = h->psets[parameter_set];
         ps.assign(A, A + d * d);

@@ -1,10 +1,34 @@
 // cx_api_msg.hip — data injection / read-back and the batched per-signal entry point (cx_update_batch) of the C ABI.
 
+#include <limits>
+#include <cmath>
+
 #include "cx_host.h"
 
 using namespace cxh;
 
 extern "C" {
+
+// ---- dim 5 .. 63 embedded in dim 64 (cx_create): payloads in, block-diagonal with an identity block; results out, their real block ----
+namespace {
+// vector[u] (+ matrix[u][u]) -> vector[64] (+ matrix[64][64] = blockdiag(matrix, I)); a NaN matrix (UndefValue) stays all NaN
+void pad_payload(int u, bool with_matrix, const double *in, double *out) {
+    const int d = 64;
+    for (int k = 0; k < d; k++) out[k] = k < u ? in[k] : 0.0;
+    if (!with_matrix) return;
+    bool undef = false;
+    for (int k = 0; k < u * u; k++) undef = undef || std::isnan(in[u + k]);
+    for (int r = 0; r < d; r++)
+        for (int c = 0; c < d; c++)
+            out[d + r * d + c] = undef ? std::numeric_limits<double>::quiet_NaN() : (r < u && c < u) ? in[u + r * u + c] : (r == c ? 1.0 : 0.0);
+    if (undef) for (int k = 0; k < d; k++) out[k] = std::numeric_limits<double>::quiet_NaN();
+}
+void unpad_payload(int u, const double *in, double *out) {
+    const int d = 64;
+    for (int k = 0; k < u; k++) out[k] = in[k];
+    for (int r = 0; r < u; r++) for (int c = 0; c < u; c++) out[u + r * u + c] = in[d + r * d + c];
+}
+}  // namespace
 
 int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, int32_t direction,
                         int32_t form, const double *payload) {
@@ -20,6 +44,16 @@ int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
                "cx_set_messages: CX_FAMILY_NATURAL2 takes CX_FORM_NATURAL payloads (and CX_FORM_POINT data)");
     if (n == 0) return CX_OK;
     CX_REQUIRE(h, n > 0 && variable_ids && factor_ids && payload, CX_ERR_INVALID_ARGUMENT, "cx_set_messages: null argument");
+    if (h->user_dim) {
+        try {
+            const int u = h->user_dim, d = 64;
+            const bool mat = form != CX_FORM_POINT;
+            const size_t si = mat ? (size_t)u + (size_t)u * u : (size_t)u, so = mat ? (size_t)d + (size_t)d * d : (size_t)d;
+            std::vector<double> big((size_t)n * so);
+            for (int64_t i = 0; i < n; i++) pad_payload(u, mat, payload + (size_t)i * si, &big[(size_t)i * so]);
+            return mv_set_messages(h, n, variable_ids, factor_ids, direction, form, big.data());
+        } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_set_messages: host allocation failed"); }
+    }
     if (h->cfg.dim > 1) { try { return mv_set_messages(h, n, variable_ids, factor_ids, direction, form, payload); } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_set_messages: host allocation failed"); } }
     try {
         std::vector<int32_t> idx, vars;
@@ -69,6 +103,17 @@ int32_t cx_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
     CX_REQUIRE(h, h->cfg.family == CX_FAMILY_GAUSSIAN || form == CX_FORM_NATURAL, CX_ERR_UNSUPPORTED, "cx_get_messages: CX_FAMILY_NATURAL2 returns CX_FORM_NATURAL payloads only");
     if (n == 0) return CX_OK;
     CX_REQUIRE(h, n > 0 && variable_ids && factor_ids && out, CX_ERR_INVALID_ARGUMENT, "cx_get_messages: null argument");
+    if (h->user_dim) {
+        try {
+            const int u = h->user_dim, d = 64;
+            const size_t so = (size_t)u + (size_t)u * u, sb = (size_t)d + (size_t)d * d;
+            std::vector<double> big((size_t)n * sb);
+            const int32_t rc = mv_get_messages(h, n, variable_ids, factor_ids, direction, form, big.data());
+            if (rc != CX_OK) return rc;
+            for (int64_t i = 0; i < n; i++) unpad_payload(u, &big[(size_t)i * sb], out + (size_t)i * so);
+            return CX_OK;
+        } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_get_messages: host allocation failed"); }
+    }
     if (h->cfg.dim > 1) { try { return mv_get_messages(h, n, variable_ids, factor_ids, direction, form, out); } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_get_messages: host allocation failed"); } }
     try {
         std::vector<int32_t> idx;
@@ -126,6 +171,17 @@ int32_t cx_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, d
     if (n == 0) return CX_OK;
     CX_REQUIRE(h, n > 0 && variable_ids && out, CX_ERR_INVALID_ARGUMENT, "cx_get_marginals: null argument");
     if (is_vmp(h)) return cx::vmp_get_marginals(h, n, variable_ids, out);
+    if (h->user_dim) {
+        try {
+            const int u = h->user_dim, d = 64;
+            const size_t so = (size_t)u + (size_t)u * u, sb = (size_t)d + (size_t)d * d;
+            std::vector<double> big((size_t)n * sb);
+            const int32_t rc = mv_get_marginals(h, n, variable_ids, big.data());
+            if (rc != CX_OK) return rc;
+            for (int64_t i = 0; i < n; i++) unpad_payload(u, &big[(size_t)i * sb], out + (size_t)i * so);
+            return CX_OK;
+        } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_get_marginals: host allocation failed"); }
+    }
     if (h->cfg.dim > 1) { try { return mv_get_marginals(h, n, variable_ids, out); } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_get_marginals: host allocation failed"); } }
     try {
         std::vector<int32_t> idx(n);

@@ -99,6 +99,9 @@ struct cx_handle {
     int32_t *d_rule64_rec = nullptr;               // 8 words per work item (see k_rule64)
 
     // chain-scan schedule (cx_chain.hip): paths of free variables, built lazily by build_chains()
+    // cfg.dim of 5 .. 63 as the caller gave it (0 otherwise): such a handle runs as dim 64 with every message, datum and rule matrix
+    // embedded block-diagonally (cx_api.hip: pad_* helpers); cfg.dim holds 64
+    int user_dim = 0;
     bool chains_dirty = true;
     // CX_SCHED_TREE (cx_tree_plan.h): the stages' items and k-ary entries on the device, their offsets on the host
     bool tree_dirty = true;

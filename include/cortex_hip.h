@@ -149,7 +149,9 @@ typedef struct cx_handle cx_handle;
 typedef struct cx_config {
     int32_t struct_size;   /* sizeof(cx_config), for forward compatibility */
     int32_t device;        /* HIP device ordinal */
-    int32_t dim;           /* message dimension d: 1 (scalar), 2, 3, 4 (registers); 64 is the MFMA path */
+    int32_t dim;           /* message dimension d: 1 (scalar), 2, 3, 4 (registers); 64 is the MFMA path; 5 .. 63 run ON the dim 64 path,
+                              embedded block-diagonally (x, u) with u a unit random walk nobody observes: exact results for the d x d
+                              blocks, payloads of d and d + d*d doubles as for any d, at the cost of dim 64 whatever d is           */
     int32_t schedule;      /* CX_SCHED_*: dim 1 all three; dim 2..4 CX_SCHED_FUSED or CX_SCHED_CHAIN_SCAN; dim 64 CX_SCHED_FUSED */
     int32_t compute_marginals_in_sweep; /* 1: every sweep also refreshes all marginals (update_marginals!).
                                            2 (CX_SCHED_CHAIN_SCAN, dim 2..4; elsewhere the same as 1): on demand — a sweep leaves

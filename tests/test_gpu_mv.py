@@ -398,3 +398,53 @@ def test_mv_tree_with_variables_of_degree_up_to_eight(hip_lib, d, b):
     # variable→factor messages on demand and item by item through the boundary see the same degrees
     vm = dev.get_messages(g.edge_var[pe], g.edge_fac[pe], L.TO_FACTOR)
     assert not np.all(np.isnan(vm))
+
+
+# ------------------------------------------------------------------------------- dim 5 .. 63: embedded in the dim 64 path
+
+@pytest.mark.parametrize("d", [5, 6, 16, 33, 63])
+def test_dimensions_between_4_and_64_run_embedded_in_the_mfma_path(hip_lib, d):
+    """cfg.dim of 5 .. 63 (a constant-velocity model has d = 6, ...): the handle runs as dim 64 with every rule matrix, message and
+    datum block-diagonal (real block, identity block) — payloads stay d and d + d*d doubles.  Per sweep against the numpy restatement in
+    dimension d, then the block-tridiagonal solve; the chain-scan schedule gives the same marginals in ONE sweep."""
+    T = 7
+    model = cx.synth.lgssm_chain(T, d=d, seed=30 + d)
+    dev = _dev(model)
+    o = MvFlood(model)
+    g = o.g
+    xs_set = set(np.searchsorted(g.var_ids, model.x_ids).tolist())
+    pe = np.array([e for e in np.flatnonzero(g.partner >= 0) if int(np.searchsorted(g.var_ids, g.edge_var[e])) in xs_set])
+    o.sweep(1)            # the dim 64 path evaluates the messages out of observed variables at data injection
+    for sweep in range(T + 1):
+        dev.sweep(1)
+        o.sweep(1)
+        got = dev.get_messages(g.edge_var[pe], g.edge_fac[pe], L.TO_VARIABLE)
+        assert got.shape == (len(pe), d + d * d)
+        for row, e in zip(got, pe):
+            if o.f2v[e] is None:
+                assert np.all(np.isnan(row)), f"sweep {sweep} edge {e}: device defined, restatement undefined"
+                continue
+            m, S = o.f2v[e]
+            if not np.all(np.isfinite(S)) or np.linalg.cond(S) > 1e10:
+                continue
+            assert_close(row[:d], m, 1e-7, f"d={d} sweep {sweep} f2v mean edge {e}")
+            assert_close(row[d:].reshape(d, d), S, 1e-7, f"d={d} sweep {sweep} f2v covariance edge {e}")
+    dev.sweep(2)
+    em, ecov = exact.lgssm_posterior(model.data_y, model.meta["A"], model.meta["Q"], model.meta["R"])
+    marg = dev.get_marginals(model.x_ids)
+    assert marg.shape == (T, d + d * d)
+    assert_close(marg[:, :d], em, 1e-8, f"d={d}: marginal mean vs block-tridiagonal solve")
+    assert_close(marg[:, d:].reshape(T, d, d), ecov, 1e-8, f"d={d}: marginal covariance vs block-tridiagonal solve")
+    scan = cx.DeviceGraph(dim=d, schedule=L.SCHED_CHAIN_SCAN)
+    cx.synth.load_into_device(model, scan)
+    scan.sweep(1)
+    ms = scan.get_marginals(model.x_ids)
+    assert_close(ms[:, :d], em, 1e-8, f"d={d}: chain scan, one sweep: means")
+    assert_close(ms[:, d:].reshape(T, d, d), ecov, 1e-8, f"d={d}: chain scan, one sweep: covariances")
+    # a message the caller sets in moment form (a prior on the first state through its likelihood edge's partner direction is not
+    # needed here: natural-form round trip of a stored message is the identity on the real block)
+    e0 = pe[0]
+    nat = dev.get_messages([g.edge_var[e0]], [g.edge_fac[e0]], L.TO_VARIABLE, L.FORM_NATURAL)
+    dev.set_messages([g.edge_var[e0]], [g.edge_fac[e0]], L.TO_VARIABLE, L.FORM_NATURAL, nat)
+    back = dev.get_messages([g.edge_var[e0]], [g.edge_fac[e0]], L.TO_VARIABLE, L.FORM_NATURAL)
+    assert np.array_equal(nat, back)
