@@ -113,7 +113,10 @@ def test_mv_errors(hip_lib):
         dev.set_factor_matrices(0, np.eye(4), -np.eye(4))
     assert e.value.code == L.ERR_INVALID_ARGUMENT
     with pytest.raises(cx.CortexHipError) as e:
-        cx.DeviceGraph(dim=5)
+        cx.DeviceGraph(dim=65)          # (5 .. 63 run embedded in the dim 64 path: see below)
+    assert e.value.code == L.ERR_UNSUPPORTED
+    with pytest.raises(cx.CortexHipError) as e:
+        cx.DeviceGraph(dim=0)
     assert e.value.code == L.ERR_UNSUPPORTED
 
 
