@@ -22,9 +22,9 @@ void dev_free_all(cx_handle *h) {
                     h->d_stage, h->d_spdir, h->d_ptab, h->d_ptab_bt, h->d_zero_msg, h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prev, h->d_rule64_slots, h->d_rule64_vars, h->d_rule64_flags, h->d_point64_slots, h->d_rule64_rec, h->d_chain_pos_var, h->d_chain_skip0, h->d_chain_skip1, h->d_chain_link_pos, h->d_chain_from,
                     h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_side, h->d_chain_totals, h->d_chain_tab_fwd, h->d_chain_tab_bwd,
                     h->d_mvc_side, h->d_mvc_totals, h->d_mvc_side_l, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix, h->d_mvc_wave_carry, h->d_mvc_block,
-                    h->d_tree_rec, h->d_tree_kary};
+                    h->d_tree_rec, h->d_tree_kary, h->d_partner16};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    h->d_tree_rec = h->d_tree_kary = nullptr; h->tree_dirty = true;
+    h->d_tree_rec = h->d_tree_kary = nullptr; h->tree_dirty = true; h->d_partner16 = nullptr;
     cx::chain64_free(h);
     cx::kary_free(h);
     cx::tiles_free(h);
@@ -253,6 +253,17 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
 #define CX_TRY(x) do { rc = (x); if (rc != CX_OK) { dev_free_all(h); return rc; } } while (0)
         CX_TRY(dev_upload(h, &h->d_slice_off, h->slice_off));
         CX_TRY(dev_upload(h, &h->d_partner, h->partner));
+        {   // the partners as 16-bit differences, where they all fit (grids, chains, banded graphs: the fused sweep then reads 2 bytes per slot)
+            std::vector<int16_t> p16(h->partner.size());
+            bool fits = !h->partner.empty();
+            for (size_t sl = 0; sl < h->partner.size() && fits; sl++) {
+                const int64_t pp = h->partner[sl], dl = pp - (int64_t)sl;
+                if (pp < 0) p16[sl] = -32768;
+                else if (dl < -32767 || dl > 32767) fits = false;
+                else p16[sl] = (int16_t)dl;
+            }
+            if (fits) CX_TRY(dev_upload(h, &h->d_partner16, p16));
+        }
         CX_TRY(dev_upload(h, &h->d_vbase, h->vbase));
         CX_TRY(dev_upload(h, &h->d_var_deg, var_deg));
         CX_TRY(dev_upload(h, &h->d_vinfo, h->vinfo));

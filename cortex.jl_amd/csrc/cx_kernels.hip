@@ -94,16 +94,25 @@ __device__ __forceinline__ double2 to_moment(double2 nat) {
 }
 
 // store one fresh variable→factor message and/or push it through its factor to the partner slot
-template <int MODE, bool STORE_V2F, bool PUSH>
+// PACK (the fused sweep of graphs that allow it; 104 of the 427 MB a C4 sweep moves were indices and parameters):
+//   bit 0  the partner comes as a 16-bit difference to the slot (kNoPartner16: none) — graphs whose partners are all within 32 k slots
+//   bit 1  q is read at the LOWER slot of the factor's two: additive factors have one q for both directions, so only the lines of
+//          the lower slots are ever fetched (a line holds the k-th neighbour of 16 consecutive variables: all lower or all higher on
+//          grid-like graphs)
+constexpr int kPackPartner16 = 1, kPackQLow = 2;
+constexpr int16_t kNoPartner16 = -32768;
+template <int MODE, bool STORE_V2F, bool PUSH, int PACK = 0>
 __device__ __forceinline__ void emit(int slot, double2 o, const int32_t *__restrict__ partner, const double *__restrict__ sq,
                                      const double *__restrict__ sa, const double *__restrict__ sb, double2 *__restrict__ f2v_out,
-                                     double2 *__restrict__ v2f, int nt_out = 0) {
+                                     double2 *__restrict__ v2f, int nt_out = 0, const int16_t *__restrict__ partner16 = nullptr) {
     if (__builtin_isnan(o.y)) return;  // a dependency is undefined: the signal is not pending, keep stored values
     if (STORE_V2F) v2f[slot] = o;
     if (PUSH) {
-        const int p = partner[slot];
+        int p;
+        if (PACK & kPackPartner16) { const int dlt = partner16[slot]; p = dlt == kNoPartner16 ? -1 : slot + dlt; }
+        else p = partner[slot];
         if (p >= 0) {
-            const double2 r = factor_rule<MODE>(o, sq[slot], MODE == kRuleLinear ? sa[slot] : 1.0, MODE == kRuleLinear ? sb[slot] : 0.0);
+            const double2 r = factor_rule<MODE>(o, sq[(PACK & kPackQLow) ? (p < slot ? p : slot) : slot], MODE == kRuleLinear ? sa[slot] : 1.0, MODE == kRuleLinear ? sb[slot] : 0.0);
             if (MODE != kRuleBernoulli || !__builtin_isnan(r.y)) { if (nt_out) store_stream(&f2v_out[p], r); else f2v_out[p] = r; }
         }
     }
@@ -122,13 +131,14 @@ __device__ __forceinline__ void emit(int slot, double2 o, const int32_t *__restr
 // OTHER factor→variable buffer (Jacobi double buffering): the whole sweep is this one launch.
 // !PUSH: phase A of the two-phase flooding schedule (stores variable→factor messages only).
 // ------------------------------------------------------------------------------------------------
-template <int MODE, bool STORE_V2F, bool PUSH>
+template <int MODE, bool STORE_V2F, bool PUSH, int PACK = 0>
 __global__ __launch_bounds__(kBlock) void k_sweep(int nv, const int32_t *__restrict__ slice_off, const uint8_t *__restrict__ vinfo,
                                                   const int32_t *__restrict__ partner, const double *__restrict__ sq,
                                                   const double *__restrict__ sa, const double *__restrict__ sb,
                                                   const double2 *__restrict__ f2v_in, double2 *__restrict__ f2v_out,
                                                   double2 *__restrict__ v2f, double2 *__restrict__ marg, int write_marg,
-                                                  int skip_ghosts, int nt_out, int slice_lo, int slice_hi, int excl_lo, int excl_hi) {
+                                                  int skip_ghosts, int nt_out, int slice_lo, int slice_hi, int excl_lo, int excl_hi,
+                                                  const int16_t *__restrict__ partner16) {
     // the slice -> XCD mapping stays the same from sweep to sweep (a strip's messages largely live in the L2s between sweeps:
     // launching only the active slice range re-deals the slices over the XCDs and measured 10 % SLOWER); idle slices exit here.
     // [excl_lo, excl_hi]: slices another launch of the same sweep covers (the owned interior, run beside the halo exchange)
@@ -171,12 +181,12 @@ __global__ __launch_bounds__(kBlock) void k_sweep(int nv, const int32_t *__restr
     if (!fixed) {
 #pragma unroll
         for (int k = 0; k < kSmallDeg; k++)
-            if (k < deg) emit<MODE, STORE_V2F, PUSH>(base + k * kBlock, out[k], partner, sq, sa, sb, f2v_out, v2f, nt_out);
+            if (k < deg) emit<MODE, STORE_V2F, PUSH, PACK>(base + k * kBlock, out[k], partner, sq, sa, sb, f2v_out, v2f, nt_out, partner16);
     } else if (PUSH) {
         // separate path (not a select on the message) so that out[] never has its address taken
 #pragma unroll
         for (int k = 0; k < kSmallDeg; k++)
-            if (k < deg) emit<MODE, false, true>(base + k * kBlock, v2f[base + k * kBlock], partner, sq, sa, sb, f2v_out, v2f);
+            if (k < deg) emit<MODE, false, true, PACK>(base + k * kBlock, v2f[base + k * kBlock], partner, sq, sa, sb, f2v_out, v2f, 0, partner16);
     }
 }
 
@@ -517,9 +527,17 @@ static void launch_sweep_t(cx_handle *h, const double2 *f2v_in, double2 *f2v_out
     // deep-halo partitions: k sweeps after an exchange only the redundant layers that can still be valid are run (slice range)
     const int lo = (PUSH && h->run_nslices > 0) ? h->run_slice0 : 0, hi = (PUSH && h->run_nslices > 0) ? h->run_slice0 + h->run_nslices - 1 : (int)h->nslices;
     const int xlo = PUSH ? h->run_excl_lo : 1, xhi = PUSH ? h->run_excl_hi : 0;
-    hipLaunchKernelGGL((k_sweep<LINEAR, STORE, PUSH>), dim3((unsigned)h->nslices), dim3(kBlock), 0, h->stream, (int)h->nv,
-                       h->d_slice_off, h->d_vinfo, h->d_partner, sq, h->d_sa, h->d_sb, f2v_in, f2v_out, h->d_v2f, h->d_marg,
-                       write_marg ? (h->cfg.family == CX_FAMILY_NATURAL2 ? 2 : 1) : 0, skip_ghosts ? 1 : 0, nt_scatter(h), lo, hi, xlo, xhi);
+    // CX_PACK=0 in the environment: the unpacked kernel (A/B); otherwise the packed form wherever the graph allows it (additive
+    // Gaussian factors, every partner within 32 k slots) — bit-identical results: the same values travel, fewer bytes
+    static const bool pack_on = [] { const char *e = std::getenv("CX_PACK"); return !(e && e[0] == '0'); }();
+#define CX_SWEEP_ARGS dim3((unsigned)h->nslices), dim3(kBlock), 0, h->stream, (int)h->nv, h->d_slice_off, h->d_vinfo, h->d_partner, sq, h->d_sa, \
+                      h->d_sb, f2v_in, f2v_out, h->d_v2f, h->d_marg, write_marg ? (h->cfg.family == CX_FAMILY_NATURAL2 ? 2 : 1) : 0,             \
+                      skip_ghosts ? 1 : 0, nt_scatter(h), lo, hi, xlo, xhi, h->d_partner16
+    if (PUSH && LINEAR == kRuleAdditive && pack_on && h->d_partner16)
+        hipLaunchKernelGGL((k_sweep<LINEAR, STORE, PUSH, kPackPartner16 | kPackQLow>), CX_SWEEP_ARGS);
+    else
+        hipLaunchKernelGGL((k_sweep<LINEAR, STORE, PUSH, 0>), CX_SWEEP_ARGS);
+#undef CX_SWEEP_ARGS
 }
 
 void launch_fused(cx_handle *h, const double2 *f2v_in, double2 *f2v_out, bool write_marg, bool store_v2f, bool skip_ghosts) {

@@ -16,6 +16,6 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/cfetch -- $R/tools/hbm_cali
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/cwrite -- $R/tools/hbm_calib > $O/cwrite.log 2>&1 || { tail -5 $O/cwrite.log; exit 1; }
 cd $R
 python3 tools/summarize_rocprof.py --tag $TAG --trace $O/trace --fetch $O/fetch --write $O/write --calib-fetch $O/cfetch --calib-write $O/cwrite \
-   --reads 16:160087440,8:64025920,4:40021860,1:2002225 --out $R/gpurun_out/profiles_$TAG
+   --reads 16:160087440,8:32012960,2:20010930,1:2002225 --out $R/gpurun_out/profiles_$TAG
 # keep the small CSV stats next to the summary
 find $O/trace -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/profiles_$TAG/${TAG}_kernel_stats.csv \;
