@@ -202,3 +202,24 @@ def test_d_dimensional_chain_is_a_tree_too(hip_lib):
     cx.synth.load_into_device(m, scan)
     scan.sweep(1)
     assert_close(tree.get_marginals(m.x_ids), scan.get_marginals(m.x_ids), 1e-9, "tree schedule vs chain scan on a d = 4 chain", scale_by="max")
+
+
+def test_many_small_random_forests(hip_lib):
+    """forty small forests of every shape (factor arities, hubs, long paths, several components, a random share of observed leaves): one
+    sweep == the dense solve, and the plan's bookkeeping adds up"""
+    rng = np.random.default_rng(99)
+    for trial in range(40):
+        n_factors = int(rng.integers(1, 40))
+        shape = ["random", "deep", "star"][trial % 3]
+        comps = int(rng.integers(1, 4))
+        m = cx.synth.tree_model(n_factors, seed=1000 + trial, shape=shape, components=comps, observe=float(rng.uniform(0, 0.6)),
+                                k_choices=tuple(int(k) for k in rng.integers(1, 7, size=3)))
+        dev = _tree_dev(m)
+        dev.sweep(1)
+        ids, em, ev = dense_posterior(m)
+        marg = dev.get_marginals(ids)
+        assert_close(marg[:, 0], em, 1e-9, f"trial {trial} ({shape}, {n_factors} factors, {comps} components): means")
+        assert_close(marg[:, 1], ev, 1e-9, f"trial {trial}: variances")
+        st = dev.tree_plan_stats()
+        assert st["marginals"] == len(ids) and st["messages_up"] == st["messages_down"]
+        dev.close()
