@@ -16,6 +16,9 @@ one, by an independent exact solver:
                   row is stored as a guard)
   vmp_n8.json     variational SSM of :691-770 / :1032-1120, n = 8: data, posteriors after 5 x (x; ssnoise, obsnoise) for the
                   mean-field and the structured family (array form, oracle/vmp.py)
+  tree24.json     a forest of 24 factors with two to six variables each (synth.tree_model, two components, observed leaves): the graph,
+                  every parameter, priors and data, and the dense-solve posterior (tests/kary_support.py) — what ONE sweep of the tree
+                  schedule has to return; the numpy execution of the schedule's plan (tests/test_tree_plan.py) reproduces it on the CPU
   kats.json       constants of the reference's own known answers: Beta-Bernoulli posterior (:360-376), tracing values 2, 4, 9
                   (:1226-1261)
 
@@ -99,6 +102,18 @@ def vmp_n8():
     dump("vmp_n8.json", out)
 
 
+def tree24():
+    from tests.kary_support import dense_posterior
+    m = cx.synth.tree_model(24, seed=77, shape="random", components=2, observe=0.3)
+    ids, em, ev = dense_posterior(m)
+    dump("tree24.json", {"n_factors": 24, "seed": 77, "shape": "random", "components": 2, "observe": 0.3,
+                         "edge_var": m.edge_var, "edge_fac": m.edge_fac, "edge_role": m.edge_role, "factor_ids": m.factor_ids, "factor_kind": m.factor_kind,
+                         "factor_params": m.factor_var, "coef_var": m.meta["coef_var"], "coef_fac": m.meta["coef_fac"], "coef": m.meta["coef"],
+                         "prior_var": m.prior_var, "prior_fac": m.prior_fac, "prior_mean": m.prior_mean, "prior_variance": m.prior_variance,
+                         "data_var": m.data_var, "data_fac": m.data_fac, "data_y": m.data_y,
+                         "x_ids": ids, "posterior_mean": em, "posterior_variance": ev})
+
+
 def kats():
     dump("kats.json", {"beta_bernoulli": {"source": "test/inference_engine_tests.jl:360-376", "prior": [1.0, 1.0],
                                           "rule": "posterior = Beta(1 + #true, 1 + #false)"},
@@ -108,5 +123,5 @@ def kats():
 
 
 if __name__ == "__main__":
-    chain16(); grid8x8(); lgssm_d4(); lgssm_d64(); vmp_n8(); kats()
+    chain16(); grid8x8(); lgssm_d4(); lgssm_d64(); vmp_n8(); tree24(); kats()
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".json")))

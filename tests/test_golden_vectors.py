@@ -151,3 +151,43 @@ def test_device_block_chain_and_vmp_against_the_golden_vectors(hip_lib):
         np.testing.assert_allclose(q[:, 0], v[name]["x_mean"], rtol=1e-8, atol=1e-12)
         np.testing.assert_allclose(q[:, 1], v[name]["x_precision"], rtol=1e-9)
         np.testing.assert_allclose(g.ravel(), v[name]["ssnoise_shape_scale"] + v[name]["obsnoise_shape_scale"], rtol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------------------- the tree schedule
+def _tree24_model(d):
+    m = cx.synth.tree_model(int(d["n_factors"]), seed=int(d["seed"]), shape=d["shape"], components=int(d["components"]), observe=float(d["observe"]))
+    # the seeded generator has not drifted: graph, parameters, priors and data are the file's
+    for key, have in (("edge_var", m.edge_var), ("edge_fac", m.edge_fac), ("edge_role", m.edge_role), ("factor_ids", m.factor_ids), ("factor_kind", m.factor_kind),
+                      ("factor_params", m.factor_var), ("coef", m.meta["coef"]), ("prior_mean", m.prior_mean), ("prior_variance", m.prior_variance),
+                      ("data_var", m.data_var), ("data_y", m.data_y)):
+        assert np.array_equal(np.asarray(have), d[key]), key
+    return m
+
+
+def test_tree_vector_plan_execution_and_dense_solve_agree():
+    """CPU: the plan of CX_SCHED_TREE (the product's cx_tree_plan.h, compiled without HIP) executed in numpy on the file's model == the
+    file's dense-solve posterior"""
+    from tests.hostlogic import FlatGraph
+    from tests.test_tree_plan import PlanRun, flat_of
+
+    d = load("tree24.json")
+    m = _tree24_model(d)
+    g = flat_of(m)
+    rc, err = g.tree()
+    assert rc == L.OK, err
+    marg = PlanRun(g, m).run()
+    got = np.array([marg[int(i)] for i in d["x_ids"]])
+    np.testing.assert_allclose(got[:, 0], d["posterior_mean"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(got[:, 1], d["posterior_variance"], rtol=1e-10)
+
+
+@pytest.mark.gpu
+def test_device_tree_against_the_golden_vector(hip_lib):
+    d = load("tree24.json")
+    m = _tree24_model(d)
+    dev = cx.DeviceGraph(schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(m, dev)
+    dev.sweep(1)
+    got = dev.get_marginals(d["x_ids"])
+    np.testing.assert_allclose(got[:, 0], d["posterior_mean"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(got[:, 1], d["posterior_variance"], rtol=1e-10)
