@@ -59,9 +59,9 @@ int32_t build_chains(cx_handle *h) {
         for (void *p : {(void *)h->d_chain_pos_var, (void *)h->d_chain_skip0, (void *)h->d_chain_skip1, (void *)h->d_chain_link_pos,
                         (void *)h->d_chain_from, (void *)h->d_chain_to, (void *)h->d_chain_head_fwd, (void *)h->d_chain_head_bwd,
                         (void *)h->d_chain_side, h->d_chain_totals, (void *)h->d_chain_tab_fwd, (void *)h->d_chain_tab_bwd, (void *)h->d_mvc_side,
-                        (void *)h->d_mvc_totals, (void *)h->d_mvc_side_l, (void *)h->d_mvc_alpha, (void *)h->d_mvc_gamma, (void *)h->d_mvc_prefix, (void *)h->d_mvc_wave_carry, (void *)h->d_mvc_block}) if (p) (void)hipFree(p);
+                        (void *)h->d_mvc_totals, (void *)h->d_mvc_side_l, (void *)h->d_mvc_alpha, (void *)h->d_mvc_gamma, (void *)h->d_mvc_prefix, (void *)h->d_mvc_wave_carry, (void *)h->d_mvc_block, (void *)h->d_mvc_var_link}) if (p) (void)hipFree(p);
         h->d_chain_tab_fwd = h->d_chain_tab_bwd = nullptr; h->d_mvc_side = h->d_mvc_totals = nullptr;
-        h->d_mvc_side_l = h->d_mvc_alpha = h->d_mvc_gamma = h->d_mvc_prefix = h->d_mvc_wave_carry = h->d_mvc_block = nullptr;
+        h->d_mvc_side_l = h->d_mvc_alpha = h->d_mvc_gamma = h->d_mvc_prefix = h->d_mvc_wave_carry = h->d_mvc_block = nullptr; h->d_mvc_var_link = nullptr;
         h->chain_npos = (int64_t)pos_var.size(); h->chain_nlinks = (int64_t)link_pos.size();
         h->chain_side_dirty = true;
         int64_t n_readers = 0;   // variables that read factor→variable messages: everything but observed variables and ghosts
@@ -94,6 +94,11 @@ int32_t build_chains(cx_handle *h) {
             if ((rc = dev_alloc(h, &h->d_mvc_wave_carry, (int64_t)cx::mvc_wave_carry_doubles(h->cfg.dim, h->chain_nlinks, h->mvc_K))) != CX_OK) return rc;
             if ((rc = dev_alloc(h, &h->d_mvc_block, (int64_t)cx::mvc_totals_doubles(h->cfg.dim, 1, 1))) != CX_OK) return rc;      // two maps
             if ((rc = dev_alloc(h, &h->d_mvc_totals, (int64_t)cx::mvc_totals_doubles(h->cfg.dim, h->chain_nlinks, h->mvc_K))) != CX_OK) return rc;
+            {   // which link ends (on its right) in a variable: what a marginal on demand is formed from (cx_mvchain.hip: k_mvc_marg_gather)
+                std::vector<int32_t> var_link(nv, -1);
+                for (size_t l = 0; l < link_pos.size(); l++) var_link[pos_var[link_pos[l] + 1]] = (int32_t)l;
+                if ((rc = dev_upload(h, &h->d_mvc_var_link, var_link)) != CX_OK) return rc;
+            }
         } else {
             if ((rc = dev_alloc(h, &h->d_chain_side, h->chain_npos)) != CX_OK) return rc;
             char *tot = nullptr;

@@ -122,6 +122,7 @@ struct cx_handle {
     // dim 2..4 (cx_mvchain.hip): rule-table index of each link's two messages, side sums [nc][npos], tile totals of the map scan
     int32_t *d_chain_tab_fwd = nullptr, *d_chain_tab_bwd = nullptr;
     double *d_mvc_side = nullptr, *d_mvc_totals = nullptr;
+    int32_t *d_mvc_var_link = nullptr;     // per variable: the chain link whose RIGHT end it is, -1 otherwise (dim 2..4; marginals on demand)
     bool mvc_marg_pending = false;      // dim 2..4 chain scan, compute_marginals_in_sweep == 2: the last sweep left alpha and gamma, the marginals are formed when read
     double *d_mvc_side_l = nullptr, *d_mvc_alpha = nullptr, *d_mvc_gamma = nullptr, *d_mvc_prefix = nullptr, *d_mvc_wave_carry = nullptr, *d_mvc_block = nullptr;   // thread-interleaved by link, [nc][ntiles * 256 * K]
     int mvc_K = 4;                   // links per thread of the scan (fixed when the chains are built)
@@ -266,7 +267,8 @@ int64_t mvc_ntiles(int64_t nlinks, int K);
 size_t mvc_totals_doubles(int dim, int64_t nlinks, int K);
 void mvc_launch_side(cx_handle *h, bool write_marg);
 void mvc_launch_scan(cx_handle *h, bool write_marg, bool store_msgs, bool scan, bool defer_marg = false);
-void mvc_launch_marg_out(cx_handle *h);      // alpha + gamma of the last sweep -> the marginals (what a sweep with defer_marg left undone)
+void mvc_launch_marg_out(cx_handle *h);
+void mvc_launch_marg_gather(cx_handle *h, const int32_t *d_vars, int64_t n, double *d_val);   // a few marginals from alpha + gamma (rows of nc doubles, moment form, packed)      // alpha + gamma of the last sweep -> the marginals (what a sweep with defer_marg left undone)
 void mvc_launch_block_maps(cx_handle *h);
 // chain scan for dim 64 (cx_mv64chain.hip; the plan: cx_chain64_plan.h)
 int32_t chain64_build(cx_handle *h, const std::vector<int32_t> &pos_var, const std::vector<int32_t> &skip0, const std::vector<int32_t> &skip1,

@@ -708,6 +708,33 @@ __global__ __launch_bounds__(kBlock) void k_mvc_marg_out(int nlinks, int K, int6
     }
 }
 
+// Marginals ON DEMAND for a few variables (compute_marginals_in_sweep == 2, cx_get_marginals of less than the whole chain): the
+// marginal of the right variable of link l is alpha_l + gamma_l, both still in the walks' order; a variable that is not the right end
+// of a link (the first of a path, an isolated one) had its marginal written by the sweep itself.  Rows come out as k_mv_gather's.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_mvc_marg_gather(int64_t n, const int32_t *__restrict__ vars, const int32_t *__restrict__ var_link, int K,
+                                                            const double *__restrict__ alpha, const double *__restrict__ gamma,
+                                                            const double *__restrict__ marg, int64_t marg_stride, int ncs, double *__restrict__ val) {
+    constexpr int NC = Msg<D>::NC;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int v = vars[i], l = var_link[v];
+    (void)marg_stride; (void)ncs;
+    Msg<D> mo;
+    if (l < 0) {
+        mo = slot_load<D, false>(marg, v);          // written by the sweep itself, in the marginals' pair form by variable
+    } else {
+        const int64_t g = (int64_t)l / K, il = (g / kBlock) * (int64_t)kBlock * K + (int64_t)(l % K) * kBlock + (g % kBlock);
+        Msg<D> tot = slot_load<D, true>(alpha, (int)il);
+        msg_add<D>(tot, slot_load<D, true>(gamma, (int)il));
+        mo = mv_to_moment<D>(tot);
+    }
+#pragma unroll
+    for (int c = 0; c < D; c++) val[i * NC + c] = mo.eta[c];
+#pragma unroll
+    for (int c = 0; c < Msg<D>::NT; c++) val[i * NC + D + c] = mo.lam[c];
+}
+
 // side information of every chain position (runs after data, stored messages or rule parameters changed); a position without
 // links (an isolated non-observed variable) gets its marginal here: the product of everything it hears
 template <int D>
@@ -881,6 +908,18 @@ static MvcArgs mvc_args(cx_handle *h, int collapse_heads) {
                    h->d_chain_to, h->d_chain_tab_fwd, h->d_chain_tab_bwd, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_pos_var,
                    h->d_mvc_side, h->d_mvc_side_l, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix, h->d_mvc_wave_carry,
                    mvc_ntiles(h->chain_nlinks, K) * kBlock * K, collapse_heads, h->d_ptab};
+}
+
+void mvc_launch_marg_gather(cx_handle *h, const int32_t *d_vars, int64_t n, double *d_val) {
+    if (n == 0) return;
+    const dim3 g((unsigned)((n + kBlock - 1) / kBlock)), b(kBlock);
+    const int64_t stride = h->nslices * kBlock;
+#define CX_MG(DD) hipLaunchKernelGGL((k_mvc_marg_gather<DD>), g, b, 0, h->stream, n, d_vars, h->d_mvc_var_link, h->mvc_K, h->d_mvc_alpha, h->d_mvc_gamma, \
+                                     h->d_mv_marg, stride, (int)h->ncs, d_val)
+    if (h->cfg.dim == 2) CX_MG(2);
+    else if (h->cfg.dim == 3) CX_MG(3);
+    else CX_MG(4);
+#undef CX_MG
 }
 
 void mvc_launch_marg_out(cx_handle *h) {

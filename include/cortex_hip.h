@@ -157,7 +157,8 @@ typedef struct cx_config {
                                            2 (CX_SCHED_CHAIN_SCAN, dim 2..4; elsewhere the same as 1): on demand — a sweep leaves
                                            the chain's forward and backward sums in the order of its walks, and the pass that
                                            adds them up, converts to moment form and moves them to the marginals' place runs
-                                           before the first cx_get_marginals / cx_state_export / cx_update_batch after it
+                                           before the first cx_state_export / cx_update_batch / cx_get_marginals of an eighth of
+                                           the variables or more after it; a cx_get_marginals for fewer forms just those
                                            (the same values; dim 64 always works this way)                                  */
     int32_t materialize_messages_to_factor; /* CX_SCHED_FUSED only. 0: variable→factor messages stay in registers
                                                during a sweep and are recomputed, bit-identically, from the retained

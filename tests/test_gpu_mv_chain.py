@@ -208,8 +208,14 @@ def test_marginals_on_demand_are_the_same_marginals(hip_lib, monkeypatch):
         eager.sweep(1); lazy.sweep(1)
         assert np.array_equal(eager.get_marginals(model.x_ids), lazy.get_marginals(model.x_ids)), f"K={K}: first read"
         assert np.array_equal(eager.get_marginals(model.x_ids[:3]), lazy.get_marginals(model.x_ids[:3])), f"K={K}: second read"
-        # two sweeps without a read in between, then messages first (their walks rewrite the same sums), then the marginals
+        # two sweeps without a read in between; a FEW marginals first (formed from the walks' sums for just those variables, the pass
+        # for all of them still owed: first and last variable of every component, isolated ones, scattered inner ones), then messages
+        # (their walks rewrite the same sums), then all marginals
         eager.sweep(2); lazy.sweep(2)
+        few = np.unique(np.r_[model.x_ids[:4], model.x_ids[-3:], model.x_ids[[5, 350, 351, 699, 700, 701, 702]]])
+        assert len(few) * 8 < 2 * len(model.x_ids)
+        assert np.array_equal(eager.get_marginals(few), lazy.get_marginals(few)), f"K={K}: a few marginals on demand"
+        assert np.array_equal(eager.get_marginals(few[::-1]), lazy.get_marginals(few[::-1])), f"K={K}: again, another order"
         ev, ef = model.edge_var[:40], model.edge_fac[:40]
         assert np.array_equal(eager.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL), lazy.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL), equal_nan=True)
         assert np.array_equal(eager.get_marginals(model.x_ids), lazy.get_marginals(model.x_ids)), f"K={K}: after get_messages"

@@ -184,9 +184,10 @@ def mv_scan(d, T, steps, ks=(None,), check=None):
                 dev2.get_marginals(one)
             dt3 = timed(dev2, sweep_and_read, max(steps // 3, 3), 2)
             lazy = {"ms_per_sweep": dt2 * 1e3, "ms_per_sweep_then_one_marginal_read": dt3 * 1e3,
-                    "note": "compute_marginals_in_sweep = 2: a sweep = every chain message (forward and backward sums in the walks' order); k_mvc_marg_out "
-                            "(all marginals to moment form, in place) runs before the first cx_get_marginals after it — the second figure includes that "
-                            "pass, one gather and the host round trip",
+                    "note": "compute_marginals_in_sweep = 2: a sweep = every chain message (forward and backward sums in the walks' order); a "
+                            "cx_get_marginals for a few variables forms just those from the sums (k_mvc_marg_gather), one for an eighth of the chain or "
+                            "more runs k_mvc_marg_out once (all marginals to moment form, in place) — the second figure is a sweep followed by the read "
+                            "of one marginal, host round trip included",
                     **({"parity": check(dev2, model)} if check else {})}
             dev2.close()
         alg = ref_upd * 2 * payload
