@@ -26,7 +26,7 @@ HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith("
 # which sources a kernel's code comes from: a counter-traffic figure kept under profiles/ is only as good as the kernel it was
 # measured on, so the summaries store a hash of these files and bench.py refuses a figure whose kernel has changed since
 KERNEL_SOURCES = (("k_sweep_mv", ("cx_mv.hip", "cx_mv_core.h")), ("k_mvc_", ("cx_mvchain.hip", "cx_mv_core.h")),
-                  ("k_chain_", ("cx_chain.hip",)), ("k_rule64w", ("cx_mv64w.hip", "cx_mv64w_core.h")), ("k_compose64", ("cx_mv64chain.hip", "cx_mv64w_core.h")), ("k_step64", ("cx_mv64chain.hip", "cx_mv64w_core.h")), ("k_rule64", ("cx_mv64.hip",)),
+                  ("k_chain_", ("cx_chain.hip",)), ("k_rule64w", ("cx_mv64w.hip", "cx_mv64w_core.h")), ("k_compose64", ("cx_mv64chain.hip", "cx_mv64w_core.h")), ("k_walk64b", ("cx_mv64chain.hip", "cx_mv64w_core.h")), ("k_rule64", ("cx_mv64.hip",)),
                   ("k_sweep", ("cx_kernels.hip",)), ("k_mf_", ("cx_vmp.hip",)), ("k_rate", ("cx_vmp.hip",)), ("k_gamma", ("cx_vmp.hip",)),
                   ("k_set_q", ("cx_vmp.hip",)), ("k_pull", ("cx_vmp.hip",)), ("k_reduce", ("cx_vmp.hip",)))
 

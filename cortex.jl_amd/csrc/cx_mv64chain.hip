@@ -3,17 +3,16 @@
 // of test/inference_engine_tests.jl:436-487) — with no seeding and at every time step.
 //
 // The plan (cx_chain64_plan.h, host, GPU-free) cuts every path into blocks and names two kinds of work:
-//   compose   a wave folds its children — links of a block, or the potentials of the level below — into ONE pairwise potential
-//             (P, B, C, h, c) of the segment's two end variables.  Per pair of children (M = C1 + side + P2 = U'U):
+//   compose   a PAIR of waves (k_compose64p) folds its children — links of a block, or the potentials of the level below — into ONE
+//             pairwise potential (P, B, C, h, c) of the segment's two end variables.  Per pair of children (M = C1 + side + P2 = U'U):
 //                 Y1 = U^-T B1,  Y2 = U^-T B2',  P = P1 - Y1'Y1,  C = C2 - Y2'Y2,  B = Y2'Y1,  h = h1 + Y1'z,  c = c2 + Y2'z,  z = U^-T g
-//             = 64 (Cholesky) + 2 x 160 (solves) + 2 x 160 (Grams) + 256 (product) = 960 v_mfma_f64_16x16x4_f64, all on
-//             register-resident tiles in the accumulator layout of cx_mv64w_core.h.  The SAME potential serves the forward and the
-//             backward pass (read from its other end it is (C, B', P, c, h)): one tree for both directions.
-//   walk      a wave applies rules in sequence (rule64w_apply, the body of k_rule64w), ONE LAUNCH PER STEP (k_step64): the potentials
-//             of a group, to hand every child the message that enters it, and finally the links of a level-0 block, which writes the
-//             exact factor→variable messages into their slots.
-// Registers: a composition keeps B1 -> Y1 -> B (128), C1 -> M -> U (80) and Y2 (128) resident and updates P1 in its output record:
-// one wave per SIMD (512 registers).  The walks run two waves per SIMD like the flooding rule.
+//             = 64 (Cholesky) + 2 x 160 (solves) + 2 x 160 (Grams) + 256 (product) = 960 v_mfma_f64_16x16x4_f64, on register-resident
+//             tiles in the accumulator layout of cx_mv64w_core.h.  The SAME potential serves the forward and the backward pass (read
+//             from its other end it is (C, B', P, c, h)): one tree for both directions.
+//   walk      a wave applies rules in sequence (k_walk64b: the body of k_rule64w on buffer descriptors, looping inside one launch): the
+//             potentials of a group, to hand every child the message that enters it, and finally the links of a level-0 block, which
+//             writes the exact factor→variable messages into their slots.
+// Every kernel here runs two waves per SIMD under 256 registers (the walks of the tree's thin upper levels: one).
 //
 // Records name operands by handle (space << 56 | offset), resolved against the six base pointers of the moment (kernel arguments).
 // The reference has no d-dimensional rule (parity unpinned for d > 1); pinned by the exact block-tridiagonal
@@ -64,31 +63,8 @@ __device__ __forceinline__ const __attribute__((address_space(4))) T *as_const(c
     return (const __attribute__((address_space(4))) T *)(uintptr_t)p;
 }
 
-// One step of every walk of a launch: wave w applies step `s` of its job (nothing once the job is shorter, or dead).  The walks are
-// sequences of dependent rules, but as a LOOP inside one kernel the same body compiles badly: loop-invariant per-lane values (tile
-// offsets, LDS addresses, the unit-vector constants of the diagonal tiles) are hoisted and stay live, the body goes over 256
-// registers, and hipcc then un-clusters its loads — one memory round trip per load, 52 k cycles per step in the in-kernel stamps,
-// 7.1 ms for the link walks of C5.  One launch per step keeps the straight-line code of k_rule64w (no scratch, 48 loads in flight);
-// a launch boundary costs ≈ 2 us against ≈ 40 us of step.
-// AFFINE: the steps apply composed potentials (offsets h, c); the walks along the links of a block apply plain factor rules.
-// dead[w] != 0: an earlier step of job w found an undefined input or a matrix that is not positive definite — nothing downstream of
-// it is recomputed (the reference would not find those signals pending either).
-template <int WAVES_PER_SIMD, bool AFFINE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES_PER_SIMD, WAVES_PER_SIMD)))
-void k_step64(int njobs, const DJob *__restrict__ jobs, const DStep *__restrict__ steps, const int s, int32_t *__restrict__ dead) {
-    __shared__ double S[16 * kLdT];
-    __shared__ double Vs[4][16 * kLdT];
-    const int w = blockIdx.x;
-    if (w >= njobs) return;
-    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-    const int first = jobs[w].first, n = jobs[w].n;
-    if (s >= n || dead[w] != 0) return;
-    const DStep *st = steps + (first + s);
-    if (!rule64w_apply<AFFINE>(st->P, st->Bt, st->C, st->h, st->c, st->src[0], st->src[1], st->src[2], st->has2 != 0, st->dst, S, Vs, lane, g, c))
-        if (lane == 0) dead[w] = 1;
-}
-
-// The walks as a LOOP inside one kernel after all (k_walk64b): what made the loop compile badly were per-lane values kept across
+// The walks LOOP inside one kernel (k_walk64b; the first version launched every step — k_step64, 98 launches per level — because
+// the loop compiled badly: DESIGN.md §4): what made the loop compile badly were per-lane values kept across
 // iterations.  With buffer addressing (BufAcc: one per-lane offset for every access) and the lane index made opaque at the top of
 // every step there is nothing per-lane left to hoist, and the body keeps the allocation of the straight-line kernel.  What the loop
 // buys: the waves of a launch drift apart, so one wave's loads (its side information comes from HBM, once per sweep) run beside its
@@ -128,197 +104,11 @@ __device__ __forceinline__ void solve_col(d4 (&R)[4][4], const int b, const d4 (
     }
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_compose64(int njobs, const DJob *__restrict__ jobs, const DChild *__restrict__ children) {
-    __shared__ double S[16 * kLdT];
-    __shared__ double Vs[4][16 * kLdT];
-    const int w = blockIdx.x;
-    if (w >= njobs) return;
-    int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-    const int first = as_const(jobs)[w].first, n = as_const(jobs)[w].n;
-    gdp out = as_const(jobs)[w].out;
-    C64_STAMP_INIT;
-
-    // ---- the accumulated potential starts as the first child -------------------------------------------------------------------
-    // (P1 does not stay in registers: it is only ever updated tile by tile, so it lives in the output record — 940 bytes of scratch
-    // per lane with it resident)
-    d4 C1[10], B1[4][4];
-    double h1[4], c1[4];         // CV layout: lane (g, c) holds x[16 a + c]
-    gdp oP = out;
-    {
-        const auto *ch = as_const(children) + first;
-        gcdp P = ch->P, B = ch->B, C = ch->C, hh = ch->h, cc = ch->c;
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-#pragma unroll
-            for (int b = 0; b < 4; b++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int o = tile_off(a, b, r, g, c);
-                    B1[a][b][r] = B[o];
-                    if (b >= a) { oP[o] = P[o]; C1[ut(a, b)][r] = C[o]; }
-                }
-            h1[a] = hh[16 * a + c];
-            c1[a] = cc[16 * a + c];
-        }
-    }
-
-    C64_STAMP(0);
-    for (int k = 1; k < n; k++) {
-        const auto *ch = as_const(children) + (first + k);
-        // (the lane id opaque per step, its range restated: see k_step64)
-        asm volatile("" : "+v"(lane));
-        lane &= 63;
-        g = lane >> 4; c = lane & 15;
-        gcdp P2 = ch->P, Bt2 = ch->Bt, C2 = ch->C, h2 = ch->h, c2 = ch->c, s0 = ch->side[0], s1 = ch->side[1], s2 = ch->side[2];
-        // ---- M = C1 + side information of the joint + P2 (upper tiles; C1's registers become M, then U) ------------------------------
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = a; b < 4; b++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int o = tile_off(a, b, r, g, c);
-                    C1[ut(a, b)][r] += (P2[o] + s0[kD + o]) + (s1[kD + o] + s2[kD + o]);
-                }
-        double gv[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) { const int e = 16 * j + c; gv[j] = c1[j] + (s0[e] + s1[e]) + (s2[e] + h2[e]); }
-        C64_STAMP(1);
-        // ---- blocked upper Cholesky (as in rule64w_apply) ---------------------------------------------------------------------------
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            const d4 Vk = diag_factor(C1[ut(kk, kk)], S, g, c);
-            C64_STAMP(2);
-#pragma unroll
-            for (int r = 0; r < 4; r++) Vs[kk][(g + 4 * r) * kLdT + c] = Vk[r];
-#pragma unroll
-            for (int j = kk + 1; j < 4; j++) C1[ut(kk, j)] = tts(Vk, C1[ut(kk, j)], d4{0.0, 0.0, 0.0, 0.0});
-#pragma unroll
-            for (int i = kk + 1; i < 4; i++) {
-                const d4 nu = neg(C1[ut(kk, i)]);
-#pragma unroll
-                for (int j = i; j < 4; j++) C1[ut(i, j)] = tts(nu, C1[ut(kk, j)], C1[ut(i, j)]);
-            }
-            C64_STAMP(3);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // ---- z = U^-T g on the vector pipe ----------------------------------------------------------------------------------------------
-        double zrv[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            double wcv = gv[j];
-#pragma unroll
-            for (int q = 0; q < j; q++) {
-                double p = 0.0;
-#pragma unroll
-                for (int r = 0; r < 4; r++) p += C1[ut(q, j)][r] * zrv[q][r];
-                wcv -= sum_groups(p);
-            }
-            double p = 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) p += Vs[j][(g + 4 * r) * kLdT + c] * cv_to_rv(wcv, g, r);
-            const double zcv = sum_groups(p);
-#pragma unroll
-            for (int r = 0; r < 4; r++) zrv[j][r] = cv_to_rv(zcv, g, r);
-        }
-        C64_STAMP(4);
-        // ---- Y1 = U^-T B1 in place;  P1 -= Y1'Y1;  h1 += Y1'z --------------------------------------------------------------------------
-#pragma unroll
-        for (int b = 0; b < 4; b++) solve_col(B1, b, C1, Vs, g, c);
-        C64_STAMP(5);
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-#pragma unroll
-            for (int b = a; b < 4; b++) {
-                d4 G = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int j = 0; j < 4; j++) G = tts(B1[j][a], B1[j][b], G);
-                // same lane, same address as the store that wrote it: in order behind it
-#pragma unroll
-                for (int r = 0; r < 4; r++) { const int o = tile_off(a, b, r, g, c); oP[o] = oP[o] - G[r]; }
-            }
-            double p = 0.0;
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) p += B1[j][a][r] * zrv[j][r];
-            h1[a] += sum_groups(p);
-        }
-        C64_STAMP(6);
-        // ---- Y2 = U^-T B2';  C1 = C2 - Y2'Y2;  c1 = c2 + Y2'z -------------------------------------------------------------------------
-        d4 Y2[4][4];
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) Y2[j][b][r] = Bt2[tile_off(j, b, r, g, c)];
-            solve_col(Y2, b, C1, Vs, g, c);
-        }
-        C64_STAMP(7);
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-#pragma unroll
-            for (int b = a; b < 4; b++) {
-                d4 G = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int j = 0; j < 4; j++) G = tts(Y2[j][a], Y2[j][b], G);
-#pragma unroll
-                for (int r = 0; r < 4; r++) C1[ut(a, b)][r] = C2[tile_off(a, b, r, g, c)] - G[r];      // (U is dead: every solve is done)
-            }
-            double p = 0.0;
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) p += Y2[j][a][r] * zrv[j][r];
-            c1[a] = c2[16 * a + c] + sum_groups(p);
-        }
-        C64_STAMP(8);
-        // ---- B = Y2'Y1, one block column of Y1 at a time, in place ------------------------------------------------------------------------
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            d4 T[4];
-#pragma unroll
-            for (int a = 0; a < 4; a++) {
-                T[a] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int j = 0; j < 4; j++) T[a] = tts(Y2[j][a], B1[j][b], T[a]);
-            }
-#pragma unroll
-            for (int a = 0; a < 4; a++) B1[a][b] = T[a];
-        }
-        C64_STAMP(9);
-    }
-
-    // ---- the potential record: P | B | B' | C | h | c (P, C: upper tiles only — every reader takes the upper tiles) ------------------------
-    gdp oB = out + kD * kD, oBt = out + 2 * kD * kD, oC = out + 3 * kD * kD, oh = out + 4 * kD * kD, oc = oh + kD;
-#pragma unroll
-    for (int a = 0; a < 4; a++) {
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int o = tile_off(a, b, r, g, c);
-                oB[o] = B1[a][b][r];
-                if (b >= a) oC[o] = C1[ut(a, b)][r];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int r = 0; r < 4; r++) S[(g + 4 * r) * kLdT + c] = B1[a][b][r];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int r = 0; r < 4; r++) oBt[tile_off(b, a, r, g, c)] = S[c * kLdT + g + 4 * r];
-        }
-        if (g == 0) { oh[16 * a + c] = h1[a]; oc[16 * a + c] = c1[a]; }
-    }
-    C64_STAMP(10);
-}
-
 // ---- the composition as a PAIR of waves ------------------------------------------------------------------------------------------
-// k_compose64 above keeps B1, U and Y2 (336 registers of matrices) in ONE wave: they need the accumulator half of the register file,
-// hipcc shuffles them back and forth (≈ 1,000 v_accvgpr_read and 330 scratch accesses per step), and with one wave per SIMD every
-// memory round trip of a step is exposed: 0.26 of the matrix pipe, 8.6 ms for the 99,995 compositions of C5.
+// The first version (one wave per composition, removed) kept B1, U and Y2 — 336 registers of matrices — in ONE wave: they need the
+// accumulator half of the register file, hipcc shuffles them back and forth (≈ 1,000 v_accvgpr_read and 330 scratch accesses per
+// step), and with one wave per SIMD every memory round trip of a step is exposed: 0.26 of the matrix pipe, 8.6 ms for the 99,995
+// compositions of C5.
 // Here a composition is split between the two waves of a 128-thread workgroup so that each stays under 256 registers (two waves per
 // SIMD) with nothing spilled:
 //   wave A (the RULE part: what k_rule64w does)   M = C1 + side + P2 = U'U,  z = U^-T g;  hands -U, V = U_kk^-1 and z over (LDS);
@@ -720,7 +510,6 @@ struct Chain64 {
     double *bases[p64::kSpaces] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // what the device records were resolved against
     double *d_pot = nullptr, *d_ent = nullptr, *d_ring = nullptr;      // d_ring: the Y2 hand-off of k_compose64p, 32 KB per job of the widest launch
     struct Launch { int kind; int64_t first; int n; int steps; };      // kind 0: compose, 1: walk over potentials, 2: walk along links; steps: longest job
-    int32_t *d_dead = nullptr;             // per job of the widest walk launch: an earlier step failed
     std::vector<Launch> launches;
     int64_t n_pot = 0, n_ent = 0, n_compositions = 0, n_rules = 0;
     int K0 = 0, fan = 0, levels = 0;
@@ -730,7 +519,7 @@ struct Chain64 {
 void chain64_free(cx_handle *h) {
     Chain64 *c = (Chain64 *)h->chain64;
     if (!c) return;
-    for (void *p : {(void *)c->d_jobs, (void *)c->d_children, (void *)c->d_steps, (void *)c->d_pot, (void *)c->d_ent, (void *)c->d_dead, (void *)c->d_ring}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)c->d_jobs, (void *)c->d_children, (void *)c->d_steps, (void *)c->d_pot, (void *)c->d_ent, (void *)c->d_ring}) if (p) (void)hipFree(p);
     h->device_bytes -= c->bytes;
     delete c;
     h->chain64 = nullptr;
@@ -780,7 +569,7 @@ int32_t chain64_build(cx_handle *h, const std::vector<int32_t> &pos_var, const s
     c->n_compositions = plan.n_compositions; c->n_rules = plan.n_rules;
     auto &jobs = c->jobs;
     auto longest = [](const std::vector<p64::Job> &L) { int m = 0; for (const auto &j : L) m = std::max(m, (int)j.n); return m; };
-    int widest = 1, widest_compose = 1;
+    int widest_compose = 1;
     for (const auto &L : plan.compose_launches) widest_compose = std::max(widest_compose, (int)L.size());
     for (const auto &L : plan.compose_launches) if (!L.empty()) { c->launches.push_back({0, (int64_t)jobs.size(), (int)L.size(), longest(L)}); jobs.insert(jobs.end(), L.begin(), L.end()); }
     for (size_t i = 0; i < plan.walk_launches.size(); i++) {      // the last walk launch is the one along the links (plain rules, h = c = 0)
@@ -788,7 +577,6 @@ int32_t chain64_build(cx_handle *h, const std::vector<int32_t> &pos_var, const s
         if (L.empty()) continue;
         c->launches.push_back({i + 1 == plan.walk_launches.size() ? 2 : 1, (int64_t)jobs.size(), (int)L.size(), longest(L)});
         jobs.insert(jobs.end(), L.begin(), L.end());
-        widest = std::max(widest, (int)L.size());
     }
     c->children = std::move(plan.children);
     c->steps = std::move(plan.steps);
@@ -799,7 +587,6 @@ int32_t chain64_build(cx_handle *h, const std::vector<int32_t> &pos_var, const s
     if ((rc = cxh::dev_alloc(h, &c->d_steps, (int64_t)c->steps.size())) != CX_OK) return rc;
     if ((rc = cxh::dev_alloc(h, &c->d_pot, plan.n_pot * plan.pot)) != CX_OK) return rc;
     if ((rc = cxh::dev_alloc(h, &c->d_ent, plan.n_ent * plan.msg)) != CX_OK) return rc;
-    if ((rc = cxh::dev_alloc(h, &c->d_dead, (int64_t)widest)) != CX_OK) return rc;
     if (plan.n_pot > 0 && (rc = cxh::dev_alloc(h, &c->d_ring, (int64_t)widest_compose * 16 * kTileD)) != CX_OK) return rc;
     // a potential or entry message that was never computed reads as UndefValue()
     CX_HIP(h, hipMemsetAsync(c->d_pot, 0xff, (size_t)std::max<int64_t>(1, plan.n_pot * plan.pot) * 8, h->stream));
@@ -866,29 +653,13 @@ int32_t chain64_sweep(cx_handle *h) {
         (void)hipMemsetAsync(d_st, 0, st_n * 8, h->stream);
 #endif
         if (L.kind == 0) {
-            // CX_MVC64_COMPOSE=1: the one-wave composition (one wave per SIMD, 512 registers) for A/B; default: the paired form
-            // CX_MVC64_COMPOSE=1: the one-wave composition (one wave per SIMD, 512 registers) for A/B; default: the paired form
-            static const int one_wave = env_int("CX_MVC64_COMPOSE", 2) == 1;
-            if (one_wave) hipLaunchKernelGGL(k_compose64, dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_children);
-            else hipLaunchKernelGGL(k_compose64p, dim3(L.n), dim3(128), 0, h->stream, L.n, c->d_jobs + L.first, c->d_children, c->d_ring);
+            hipLaunchKernelGGL(k_compose64p, dim3(L.n), dim3(128), 0, h->stream, L.n, c->d_jobs + L.first, c->d_children, c->d_ring);
+        } else if (L.kind == 1) {          // few jobs: a wave alone on its SIMD
+            hipLaunchKernelGGL((k_walk64b<1, true>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps);
+        } else if (walk_waves == 1) {
+            hipLaunchKernelGGL((k_walk64b<1, false>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps);
         } else {
-            // CX_MVC64_WALK=1: one launch per step (k_step64) for A/B; default: the walk loops inside one launch
-            static const int per_step = env_int("CX_MVC64_WALK", 2) == 1;
-            if (!per_step) {
-                if (L.kind == 1) hipLaunchKernelGGL((k_walk64b<1, true>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps);
-                else if (walk_waves == 1) hipLaunchKernelGGL((k_walk64b<1, false>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps);
-                else hipLaunchKernelGGL((k_walk64b<2, false>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps);
-                continue;
-            }
-            CX_HIP(h, hipMemsetAsync(c->d_dead, 0, (size_t)L.n * 4, h->stream));
-            for (int s = 0; s < L.steps; s++) {
-                if (L.kind == 1)           // few jobs: a wave alone on its SIMD
-                    hipLaunchKernelGGL((k_step64<1, true>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps, s, c->d_dead);
-                else if (walk_waves == 1)
-                    hipLaunchKernelGGL((k_step64<1, false>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps, s, c->d_dead);
-                else
-                    hipLaunchKernelGGL((k_step64<2, false>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps, s, c->d_dead);
-            }
+            hipLaunchKernelGGL((k_walk64b<2, false>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps);
         }
 #ifdef CX_C64_STAMPS
         (void)hipStreamSynchronize(h->stream);

@@ -231,7 +231,7 @@ def mv64_scan(T, steps, ks=(None,), check=None):
                     "workload": f"d=64 linear-Gaussian chain T={T} ({st['n_edges']} edges), chain-scan schedule: exact forward/backward in one sweep",
                     "ms_per_sweep": dt * 1e3, "reference_updates_per_sweep": ref_upd, "updates_per_s": ref_upd / dt, "plan": ps,
                     "mfma_TFLOPs": tf,
-                    "roofline": roofline("mfma", tf, F64_MATRIX_PEAK_TF, "TFLOP/s", None, kernel="k_compose64 + k_walk64 (all launches of one sweep)",
+                    "roofline": roofline("mfma", tf, F64_MATRIX_PEAK_TF, "TFLOP/s", None, kernel="k_compose64p + k_walk64b (all launches of one sweep)",
                                          mfma_per_sweep=n_mfma, mfma_per_composition=960, mfma_per_rule=384, compositions=ps["compositions"],
                                          rules=ps["rules"], launches_per_sweep=ps["launches"],
                                          basis="matrix instructions of the plan x 2048 flop / sweep time (launch gaps and the serial top of the tree included)",
