@@ -25,6 +25,7 @@ void dev_free_all(cx_handle *h) {
                     h->d_tree_rec, h->d_tree_kary, h->d_partner16, h->d_mvc_var_link};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     h->d_tree_rec = h->d_tree_kary = nullptr; h->tree_dirty = true; h->d_partner16 = nullptr; h->d_mvc_var_link = nullptr;
+    tree_graph_drop(h); h->tree_graph_failed = false;
     cx::chain64_free(h);
     cx::kary_free(h);
     cx::tiles_free(h);
@@ -131,6 +132,8 @@ int32_t cx_destroy(cx_handle *h) {
     for (auto &r : h->recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     cx::comm_destroy(h);
     cx::ipc_destroy(h);
+    tree_graph_drop(h);
+    if (h->tree_capture_stream) { (void)hipStreamDestroy(h->tree_capture_stream); h->tree_capture_stream = nullptr; }
     cx::vmp_free(h);
     dev_free_all(h);
     delete h;

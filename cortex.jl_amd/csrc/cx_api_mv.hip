@@ -497,14 +497,7 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
         // carry the rule table of the sending slot as the plan found it (the plan is rebuilt when a variable becomes observed)
         int32_t rc = build_tree(h);
         if (rc != CX_OK) return rc;
-        const size_t ns = h->tree_stage_off.empty() ? 0 : h->tree_stage_off.size() - 1;
-        for (int32_t s = 0; s < n_sweeps; s++) {
-            for (size_t st = 0; st < ns; st++) {
-                const int64_t n = h->tree_stage_off[st + 1] - h->tree_stage_off[st];
-                if (n > 0) cx::mv_launch_batch(h, h->d_tree_rec + 5 * h->tree_stage_off[st], n);
-            }
-            h->sweeps_done++;
-        }
+        for (int32_t s = 0; s < n_sweeps; s++) { tree_sweep(h); h->sweeps_done++; }
         CX_HIP(h, hipGetLastError());
         return CX_OK;
     }

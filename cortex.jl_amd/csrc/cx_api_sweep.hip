@@ -113,6 +113,10 @@ int32_t build_chains(cx_handle *h) {
 
 
 // ---- CX_SCHED_TREE: the stages of cx_tree_plan.h, built once per set of observed variables ----------------------------
+void tree_graph_drop(cx_handle *h) {
+    if (h->tree_exec) { (void)hipGraphExecDestroy(h->tree_exec); h->tree_exec = nullptr; }
+}
+
 int32_t build_tree(cx_handle *h) {
     if (!h->tree_dirty) return CX_OK;
     try {
@@ -122,11 +126,21 @@ int32_t build_tree(cx_handle *h) {
         if (rc != CX_OK) return fail(h, rc, terr);
         for (void *p : {(void *)h->d_tree_rec, (void *)h->d_tree_kary}) if (p) (void)hipFree(p);
         h->d_tree_rec = h->d_tree_kary = nullptr;
+        tree_graph_drop(h);
         int32_t rc2;
-        if (!plan.rec.empty() && (rc2 = dev_upload(h, &h->d_tree_rec, plan.rec)) != CX_OK) return rc2;
-        if (!plan.kary.empty() && (rc2 = dev_upload(h, &h->d_tree_kary, plan.kary)) != CX_OK) return rc2;
+        // a stage's messages out of factors with more than two edges ride in the same list as its other items (cx_kernels.hip:
+        // kItemKaryEntry): one launch per stage
+        std::vector<int32_t> rec;
+        std::vector<int64_t> off(1, 0), koff(plan.kary_off.size(), 0);
+        rec.reserve(plan.rec.size() + 5 * plan.kary.size());
+        for (size_t st = 0; st + 1 < plan.stage_off.size(); st++) {
+            rec.insert(rec.end(), plan.rec.begin() + 5 * plan.stage_off[st], plan.rec.begin() + 5 * plan.stage_off[st + 1]);
+            for (int64_t k = plan.kary_off[st]; k < plan.kary_off[st + 1]; k++) rec.insert(rec.end(), {32, plan.kary[k], 0, 0, 0});
+            off.push_back((int64_t)rec.size() / 5);
+        }
+        if (!rec.empty() && (rc2 = dev_upload(h, &h->d_tree_rec, rec)) != CX_OK) return rc2;
         CX_HIP(h, hipStreamSynchronize(h->stream));
-        h->tree_stage_off = plan.stage_off; h->tree_kary_off = plan.kary_off;
+        h->tree_stage_off = off; h->tree_kary_off = koff;
         const int64_t st[8] = {plan.depth, (int64_t)plan.stage_off.size() - 1, (int64_t)plan.rec.size() / 5, (int64_t)plan.kary.size(), plan.n_components,
                                plan.n_up, plan.n_down, plan.n_marginals};
         std::memcpy(h->tree_stats, st, sizeof st);
@@ -137,13 +151,46 @@ int32_t build_tree(cx_handle *h) {
 
 // one exact sweep: every stage in order, on the handle's stream, in place (a stage's items are independent; a stage reads what
 // earlier stages of this sweep and the stored constants left)
-static void tree_sweep(cx_handle *h) {
+static void tree_issue(cx_handle *h) {
     const size_t ns = h->tree_stage_off.empty() ? 0 : h->tree_stage_off.size() - 1;
     for (size_t s = 0; s < ns; s++) {
         const int64_t n = h->tree_stage_off[s + 1] - h->tree_stage_off[s], nk = h->tree_kary_off[s + 1] - h->tree_kary_off[s];
+        if (h->cfg.dim > 1) { if (n > 0) cx::mv_launch_batch(h, h->d_tree_rec + 5 * h->tree_stage_off[s], n); continue; }
         if (n > 0) cx::launch_batch(h, h->d_tree_rec + 5 * h->tree_stage_off[s], n);
         if (nk > 0) cx::launch_kary_items(h, h->d_tree_kary + h->tree_kary_off[s], nk);
     }
+}
+
+// The stages are hundreds of small launches whose arguments never change between sweeps (device-resident lists, the handle's
+// buffers): they are captured ONCE into a HIP graph — on a stream of the handle's own, so that the caller's stream may be the null
+// stream — and a sweep is one hipGraphLaunch on the caller's stream.  Measured on the 1.09 M-edge forest of tools/bench_configs.py
+// (206 launches): the sweep was bound by the host's launch rate.  CX_TREE_GRAPH=0: plain launches (A/B); a refused capture or
+// instantiation also falls back to them, for good.
+void tree_sweep(cx_handle *h) {
+    static const bool graphs = [] { const char *e = std::getenv("CX_TREE_GRAPH"); return !(e && e[0] == '0'); }();
+    if (graphs && !h->tree_graph_failed && !h->profiling && !h->tree_exec) {
+        hipError_t e = hipSuccess;
+        if (!h->tree_capture_stream) e = hipStreamCreateWithFlags(&h->tree_capture_stream, hipStreamNonBlocking);
+        hipGraph_t g = nullptr;
+        if (e == hipSuccess) e = hipStreamBeginCapture(h->tree_capture_stream, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            hipStream_t user = h->stream;
+            h->stream = h->tree_capture_stream;
+            tree_issue(h);
+            h->stream = user;
+            e = hipStreamEndCapture(h->tree_capture_stream, &g);
+        }
+        if (e == hipSuccess && g) e = hipGraphInstantiate(&h->tree_exec, g, nullptr, nullptr, 0);
+        if (g) (void)hipGraphDestroy(g);
+        if (e != hipSuccess || !h->tree_exec) { (void)hipGetLastError(); h->tree_exec = nullptr; h->tree_graph_failed = true; }
+    }
+    if (h->tree_exec && !h->profiling) {
+        if (hipGraphLaunch(h->tree_exec, h->stream) == hipSuccess) return;
+        (void)hipGetLastError();
+        tree_graph_drop(h);
+        h->tree_graph_failed = true;
+    }
+    tree_issue(h);
 }
 
 // ---- the sweep ----------------------------------------------------------------------------------------------------

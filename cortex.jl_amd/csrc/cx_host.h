@@ -146,7 +146,9 @@ int32_t mv_ensure_chain_msgs(cx_handle *h);   // chain scan, dim 2..4: materiali
 int32_t normalize_alt(cx_handle *h);
 int32_t ensure_v2f(cx_handle *h);
 int32_t build_chains(cx_handle *h);
-int32_t build_tree(cx_handle *h);        // CX_SCHED_TREE: the stages of cx_tree_plan.h on the device (rebuilt when the set of observed variables changed)
+int32_t build_tree(cx_handle *h);
+void tree_sweep(cx_handle *h);           // every stage of the plan on the handle's stream (one graph launch when the runtime allows it)
+void tree_graph_drop(cx_handle *h);        // CX_SCHED_TREE: the stages of cx_tree_plan.h on the device (rebuilt when the set of observed variables changed)
 void sweep_main(cx_handle *h, bool skip_ghosts);
 void sweep_finish(cx_handle *h);
 

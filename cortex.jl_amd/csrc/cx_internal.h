@@ -108,6 +108,9 @@ struct cx_handle {
     bool tree_dirty = true;
     int32_t *d_tree_rec = nullptr, *d_tree_kary = nullptr;
     std::vector<int64_t> tree_stage_off, tree_kary_off;
+    hipGraphExec_t tree_exec = nullptr;    // the stages of one sweep as ONE graph launch (hundreds of small launches otherwise: the sweep was bound by
+    hipStream_t tree_capture_stream = nullptr;      //  the host's launch rate); captured on a stream of the handle's own, launched on the caller's
+    bool tree_graph_failed = false;        // capture or instantiation refused once: plain launches from then on
     int64_t tree_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // depth, stages, items, k-ary entries, components, up, down, marginals
     int64_t chain_npos = 0, chain_nlinks = 0;
     int64_t chain_npos_linked = 0;   // dim > 1: positions [0, this) belong to paths with links; the isolated ones follow

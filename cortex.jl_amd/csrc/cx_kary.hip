@@ -21,24 +21,11 @@
 // joint Gaussian (tests/test_gpu_kary.py, tests/test_kary_checker.py).
 
 #include "cx_host.h"
+#include "cx_kary_core.h"
 
 namespace cx {
 
 namespace {
-
-// natural (xi, w) -> (mean, variance); point mass (y, +inf) -> (y, 0); flat (0, 0) -> (0, +inf); undefined stays NaN
-__device__ __forceinline__ double2 kary_moment(double2 n) {
-    if (n.y == __builtin_inf()) return make_double2(n.x, 0.0);
-    if (n.y == 0.0) return make_double2(0.0, __builtin_inf());
-    const double v = 1.0 / n.y;
-    return make_double2(n.x * v, v);
-}
-__device__ __forceinline__ double2 kary_natural(double mean, double var) {
-    if (var == 0.0) return make_double2(mean, __builtin_inf());
-    if (var == __builtin_inf()) return make_double2(0.0, 0.0);
-    const double w = 1.0 / var;
-    return make_double2(mean * w, w);
-}
 
 __global__ __launch_bounds__(kBlock) void k_factor_kary(int nrows, const int32_t *__restrict__ kslot, const double *__restrict__ kcoef,
                                                         const double *__restrict__ kqb, const double2 *__restrict__ v2f, double2 *__restrict__ f2v) {
@@ -70,19 +57,7 @@ __global__ void k_kary_items(int n, const int32_t *__restrict__ entries, const i
                              const double *__restrict__ kqb, const double2 *__restrict__ v2f, double2 *__restrict__ f2v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int en = entries[i], row = en >> 3, e = en & 7;
-    double sm = 0.0, sv = 0.0;
-    for (int r = 1; r < 8; r++) {
-        const int o = 8 * row + ((e + r) & 7), s = kslot[o];
-        if (s < 0) continue;
-        const double2 in = kary_moment(v2f[s]);
-        sm += kcoef[o] * in.x;
-        sv += kcoef[o] * kcoef[o] * in.y;
-    }
-    const double c = kcoef[en];
-    const double mean = (kqb[2 * row + 1] - sm) / c, var = (kqb[2 * row] + sv) / (c * c);
-    if (__builtin_isnan(mean) || __builtin_isnan(var)) return;
-    f2v[kslot[en]] = kary_natural(mean, var);
+    kary_item(entries[i], kslot, kcoef, kqb, v2f, f2v);
 }
 
 }  // namespace

@@ -26,6 +26,7 @@
 #include <cstdlib>
 
 #include "cx_internal.h"
+#include "cx_kary_core.h"
 
 namespace cx {
 
@@ -342,14 +343,20 @@ __global__ __launch_bounds__(kBlock) void k_halo_import(const int32_t *__restric
 //                        factor), lo = slot of the other edge, hi = 1 when the OUT edge's variable has the LOWER id (output
 //                        order is ascending variable id).  Value: the 2-d Gaussian proportional to factor x the two
 //                        variable→factor messages, as mean[2] + covariance[4].
+// a message out of a factor with more than two edges as a batch item (cx_kary_core.h): not a kind of the public interface —
+// cx_update_batch refuses kinds it does not know and routes such messages itself
+constexpr int kItemKaryEntry = 32;
+struct KaryTab { const int32_t *slot; const double *coef, *qb; };
 template <int MODE>
 __device__ __forceinline__ void batch_item(int k, int idx, int v, int lo, int hi, const int32_t *__restrict__ vbase,
                                            const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
                                            const int32_t *__restrict__ partner, const double *__restrict__ q,
                                            const double *__restrict__ pa, const double *__restrict__ pb,
                                            double2 *__restrict__ f2v, double2 *__restrict__ v2f, double2 *__restrict__ marg, int nat_marg,
-                                           double2 *__restrict__ prod, double *__restrict__ joint) {
-    if (k == CX_ITEM_MESSAGE_TO_FACTOR) {
+                                           double2 *__restrict__ prod, double *__restrict__ joint, const KaryTab kt) {
+    if (k == kItemKaryEntry) {            // internal (the tree schedule's stage lists): index = entry of the k-ary table
+        kary_item(idx, kt.slot, kt.coef, kt.qb, v2f, f2v);
+    } else if (k == CX_ITEM_MESSAGE_TO_FACTOR) {
         m2f_one(idx, v, vbase, vdeg, vinfo, f2v, v2f);
     } else if (k == CX_ITEM_MESSAGE_TO_VARIABLE) {
         const int p = partner[idx];
@@ -406,11 +413,11 @@ __global__ __launch_bounds__(kBlock) void k_batch(int64_t n, const int32_t *__re
                                                   const int32_t *__restrict__ partner, const double *__restrict__ q,
                                                   const double *__restrict__ pa, const double *__restrict__ pb,
                                                   double2 *__restrict__ f2v, double2 *__restrict__ v2f, double2 *__restrict__ marg, int nat_marg,
-                                                  double2 *__restrict__ prod, double *__restrict__ joint) {
+                                                  double2 *__restrict__ prod, double *__restrict__ joint, const KaryTab kt) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     batch_item<MODE>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg,
-                     nat_marg, prod, joint);
+                     nat_marg, prod, joint, kt);
 }
 
 // A batch of at most kSmallBatch items travels IN the kernel arguments: no staging copy, nothing for the host to wait for before
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(64) void k_batch_small(SmallBatch recs, int n, cons
     if (i >= n) return;
     const __attribute__((address_space(4))) int32_t *rec = (const __attribute__((address_space(4))) int32_t *)__builtin_amdgcn_kernarg_segment_ptr();
     batch_item<MODE>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg,
-                     nat_marg, prod, joint);
+                     nat_marg, prod, joint, KaryTab{nullptr, nullptr, nullptr});
     (void)recs;
 }
 
@@ -631,8 +638,9 @@ void launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n) {
     const int nb = (int)((n + kBlock - 1) / kBlock);
     prof_begin(h, CX_KERNEL_BATCH);
     const int mode = rule_mode(h), nat = h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0;
+    const KaryTab kt{h->d_kary_slot, h->d_kary_coef, h->d_kary_qb};
 #define CX_B(M, PA, PB) hipLaunchKernelGGL(k_batch<M>, dim3(nb), dim3(kBlock), 0, h->stream, n, d_rec, h->d_vbase, h->d_var_deg, h->d_vinfo, \
-                                           h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint)
+                                           h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint, kt)
     if (mode == kRuleLinear) CX_B(kRuleLinear, h->d_a, h->d_b);
     else if (mode == kRuleBernoulli) CX_B(kRuleBernoulli, (const double *)nullptr, (const double *)nullptr);
     else CX_B(kRuleAdditive, (const double *)nullptr, (const double *)nullptr);
