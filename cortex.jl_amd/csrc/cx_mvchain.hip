@@ -16,12 +16,12 @@
 // (B = 0), so every prefix of a path is a constant map and yields the message (c, C) directly; a constant second operand also
 // ends a segment of the segmented scan.
 //
-// Work decomposition (four launches per sweep).  A thread owns K consecutive links.
+// Work decomposition (three launches per sweep; two when the marginals are formed on demand).  A thread owns K consecutive links.
 //   k_mvc_totals      composes the K maps of every thread (thread total), scans the thread totals over the workgroup (wave shuffles
 //                     + LDS across waves) and stores each thread's exclusive prefix within its tile, and the tile total;
 //                     forward and backward direction in one grid
-//   k_mvc_scan_totals one workgroup per direction: exclusive scan of the tile totals
-//   k_mvc_apply       tile carry ∘ thread prefix = the message entering the thread's first link; then the thread WALKS its K links
+//   k_mvc_apply       the tile carry (composed by the workgroup's first wave from the tile totals before it: no scan launch in between),
+//                     tile carry ∘ thread prefix = the message entering the thread's first link; then the thread WALKS its K links
 //                     with the ordinary rule of the flooding sweep (one Cholesky per message) — map composition is paid once per
 //                     thread and scan step, not per link.  The forward walk leaves alpha (into the right end of every link), the
 //                     backward walk gamma (what the right end hears from everybody but the link); both directions in one grid
@@ -601,18 +601,40 @@ __global__ __launch_bounds__(kBlock, 4) void k_mvc_apply(MvcArgs A, int K, const
     constexpr int E = CMap<D>::ND + 1;
     using M = CMap<D>;
     __shared__ double tab_s[GT ? 1 : kMvcTabLds * 3 * D * D];
+    __shared__ double red_s[64 * E];          // the tile carry's reduction: one partial product per lane of the first wave
     const int tid = threadIdx.x, ntiles = gridDim.x, dir = blockIdx.y ? -1 : 1;
     if (!GT) mvc_load_tabs<D>(A, tab_s, tid);
     const int64_t gid = (int64_t)blockIdx.x * kBlock + tid, nthreads = (int64_t)ntiles * kBlock;
     const int l0 = (int)gid * K;
-    if (l0 >= A.nlinks) return;
     const int64_t il0 = (int64_t)blockIdx.x * kBlock * K + tid;
     const int pos = dir > 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;
+    // ---- the tile carry: the composition of the tile totals before this tile in the direction's scan order, by the workgroup's FIRST
+    // WAVE (a launch of one workgroup per direction used to scan them, 25 us of pure latency): every lane
+    // composes its run of consecutive totals straight from memory, then the 64 partial products are reduced in order through LDS —
+    // the operand of a composition is always read from memory, so nothing but the accumulator lives in registers
+    if (tid < 64) {
+        const double *T = excl + (size_t)blockIdx.y * ntiles * E;
+        const int per = (pos + 63) / 64, j0 = tid * per, j1 = min(pos, j0 + per);
+        CMap<D> acc = cmap_identity<D>();
+#pragma unroll 1
+        for (int j = j0; j < j1; j++) cmap_append_any<D>(acc, SrcMem<D>{T + (size_t)j * E});
+        cmap_store<D>(red_s + tid * E, acc);
+#pragma unroll 1
+        for (int st = 1; st < 64; st <<= 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its LDS accesses complete in order; hipcc must not move them)
+            if ((tid & (2 * st - 1)) == 0 && tid + st < 64) {
+                cmap_append_any<D>(acc, SrcMem<D>{red_s + (tid + st) * E});
+                cmap_store<D>(red_s + tid * E, acc);
+            }
+        }
+    }
+    __syncthreads();
+    if (l0 >= A.nlinks) return;
     // the map from the start of the scan to this thread's first link: tile carry, then the carry into the thread's wave, then the
     // inclusive prefix of the logically previous lane of the wave (none for the wave's first lane)
     constexpr int NW = kBlock / 64;
     const int lane = tid & 63, wid = tid >> 6, li = dir > 0 ? lane : 63 - lane;
-    CMap<D> inc = cmap_load<D>(excl + ((size_t)blockIdx.y * ntiles + pos) * E);
+    CMap<D> inc = cmap_load<D>(red_s);
     cmap_append_any<D>(inc, SrcMem<D>{A.wave_carry + (((size_t)blockIdx.y * ntiles + blockIdx.x) * NW + wid) * E});
     if (li > 0) cmap_append_any<D>(inc, SrcStrided<D>{A.prefix + (size_t)blockIdx.y * E * nthreads + (gid - dir), nthreads});
     // every prefix that reaches back to the first link of a path is a constant map: the message it produces from nothing
@@ -889,10 +911,9 @@ static void mvc_marg_out_t(cx_handle *h, const MvcArgs &A, int K) {
 template <int D, bool GT>
 static void mvc_launch_t(cx_handle *h, const MvcArgs &A, int K, int flags, bool scan) {
     const int ntiles = (int)mvc_ntiles(A.nlinks, K);
-    if (scan) {
-        hipLaunchKernelGGL((k_mvc_totals<D, GT>), dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, K, h->d_mvc_totals);
-        hipLaunchKernelGGL((k_mvc_scan_totals<D>), dim3(2), dim3(kBlock), 0, h->stream, ntiles, h->d_mvc_totals, h->d_mvc_block);
-    }
+    // (the tile totals stay as k_mvc_totals left them: the walks' workgroups compose their own carry from them — also when only the
+    // walks run again, scan == false)
+    if (scan) hipLaunchKernelGGL((k_mvc_totals<D, GT>), dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, K, h->d_mvc_totals);
     hipLaunchKernelGGL((k_mvc_apply<D, GT>), dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, K, h->d_mvc_totals, h->d_mv_f2v, h->d_mv_marg, flags);
     if ((flags & 1) && !(flags & 4)) mvc_marg_out_t<D>(h, A, K);
 }
