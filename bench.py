@@ -27,6 +27,10 @@ import time
 
 import numpy as np
 
+# dmabuf IPC (the only form this pool's host driver supports) has to be chosen before anything initialises HIP: set here, at import, not
+# next to the process group (torch.cuda.is_available() already is a HIP call)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
