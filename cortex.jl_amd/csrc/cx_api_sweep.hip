@@ -152,7 +152,8 @@ int32_t build_tree(cx_handle *h) {
 // one exact sweep: every stage in order, on the handle's stream, in place (a stage's items are independent; a stage reads what
 // earlier stages of this sweep and the stored constants left)
 static void tree_issue(cx_handle *h) {
-    const size_t ns = h->tree_stage_off.empty() ? 0 : h->tree_stage_off.size() - 1;
+    size_t ns = h->tree_stage_off.empty() ? 0 : h->tree_stage_off.size() - 1;
+    if (ns > 0 && h->cfg.compute_marginals_in_sweep == 0) ns--;      // the last stage is the marginals (the flag is fixed per handle)
     for (size_t s = 0; s < ns; s++) {
         const int64_t n = h->tree_stage_off[s + 1] - h->tree_stage_off[s], nk = h->tree_kary_off[s + 1] - h->tree_kary_off[s];
         if (h->cfg.dim > 1) { if (n > 0) cx::mv_launch_batch(h, h->d_tree_rec + 5 * h->tree_stage_off[s], n); continue; }

@@ -223,3 +223,19 @@ def test_many_small_random_forests(hip_lib):
         st = dev.tree_plan_stats()
         assert st["marginals"] == len(ids) and st["messages_up"] == st["messages_down"]
         dev.close()
+
+
+def test_without_marginals_in_the_sweep_the_last_stage_is_left_out(hip_lib):
+    """compute_marginals_in_sweep = 0: the messages of one sweep are the same, the marginals are the caller's to ask for item by item"""
+    m = cx.synth.tree_model(60, seed=5, shape="random", observe=0.3)
+    a, b = _tree_dev(m), cx.DeviceGraph(schedule=L.SCHED_TREE, marginals_in_sweep=0)
+    cx.synth.load_into_device(m, b)
+    a.sweep(1); b.sweep(1)
+    obs = set(int(v) for v in m.data_var)
+    keep = np.array([int(v) not in obs for v in m.edge_var])
+    ev, ef = m.edge_var[keep], m.edge_fac[keep]
+    assert np.array_equal(a.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL), b.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL), equal_nan=True)
+    ids, em, ev_ = dense_posterior(m)
+    assert np.all(np.isnan(b.get_marginals(ids)))
+    b.update_batch([L.ITEM_INDIVIDUAL_MARGINAL] * len(ids), ids, [0] * len(ids))
+    assert np.array_equal(a.get_marginals(ids), b.get_marginals(ids))
