@@ -20,15 +20,17 @@ end
 
 mutable struct HipProcessor <: Cortex.AbstractInferenceRequestProcessor
     handle::Ptr{Cvoid}
-    dim::Int                   # 1: scalar messages; 2, 3, 4, 64: d-dimensional linear-Gaussian messages
+    dim::Int                   # 1: scalar messages; 2 .. 64: d-dimensional linear-Gaussian messages (2, 3, 4 in registers, 64 on the matrix cores, 5 .. 63 embedded in the dim 64 path)
     queue::Vector{CxItem}
     signals::Vector{Cortex.InferenceSignal}
 end
 
 check(h, rc) = rc == 0 ? nothing : error(unsafe_string(ccall((:cx_last_error, lib), Cstring, (Ptr{Cvoid},), h)))
 
-function HipProcessor(; device = 0, dim = 1, schedule = 1)
-    cfg = Ref(CxConfig(sizeof(CxConfig), device, dim, schedule, 1, 0, 0, 0))
+# schedule: 0 flooding, 1 fused (default), 2 chain scan (paths: one cx_sweep = one update_marginals!), 3 tree (any forest: the same)
+# marginals: 1 every sweep writes every marginal; 2 (chain scan, dim 2 .. 4) on demand — formed when get_marginals asks
+function HipProcessor(; device = 0, dim = 1, schedule = 1, marginals = 1)
+    cfg = Ref(CxConfig(sizeof(CxConfig), device, dim, schedule, marginals, 0, 0, 0))
     out = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:cx_create, lib), Int32, (Ref{CxConfig}, Ref{Ptr{Cvoid}}), cfg, out)
     rc == 0 || error(unsafe_string(ccall((:cx_last_error, lib), Cstring, (Ptr{Cvoid},), C_NULL)))
