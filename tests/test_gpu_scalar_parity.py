@@ -226,7 +226,7 @@ def test_config_c4_full_size(hip_lib):
     assert resid < 1e-9, f"converged BP means do not solve the normal equations: relative residual {resid:.2e}"
 
 
-@pytest.mark.parametrize("schedule", [L.SCHED_FLOODING, L.SCHED_FUSED])
+@pytest.mark.parametrize("schedule", [L.SCHED_FLOODING, L.SCHED_FUSED, L.SCHED_TREE])
 @pytest.mark.parametrize("n", [1, 3, 5, 8, 9, 100, 3000])
 def test_beta_bernoulli_known_answer_on_device(hip_lib, schedule, n):
     """The reference's conjugate known answer (test/inference_engine_tests.jl:360-376): posterior Beta(1 + Σ, 1 + n − Σ)
