@@ -11,6 +11,8 @@ one, by an independent exact solver:
   grid8x8.json    8 x 8 Gaussian grid: priors, factor variances, the flooding checker's messages after 5 sweeps and its
                   marginals at convergence, the dense-solve posterior means
   lgssm_d4.json   d = 4 linear-Gaussian chain, T = 8: A, Q, R, data, block-tridiagonal posterior means and covariances
+  lgssm_d8.json   d = 8 linear-Gaussian chain, T = 6 (SURVEY §8c "d in {4, 8} blocks"; on the device a dimension between 4 and 64 runs
+                  embedded in the d = 64 path): A, Q, R, data, block-tridiagonal posterior
   lgssm_d64.json  d = 64 linear-Gaussian chain, T = 3 (the MFMA path's rule): data, posterior means, the posterior covariance of the
                   middle state and the diagonals of all three (A is regenerated from the seed by cx.synth.lgssm_chain; its first
                   row is stored as a guard)
@@ -83,6 +85,13 @@ def lgssm_d4():
                            "x_ids": m.x_ids, "posterior_mean": em, "posterior_covariance": ecov})
 
 
+def lgssm_d8():
+    m = cx.synth.lgssm_chain(6, d=8, seed=1234)
+    em, ecov = exact.lgssm_posterior(m.data_y, m.meta["A"], m.meta["Q"], m.meta["R"])
+    dump("lgssm_d8.json", {"T": 6, "d": 8, "seed": 1234, "A": m.meta["A"], "Q": m.meta["Q"], "R": m.meta["R"], "data_y": m.data_y,
+                           "x_ids": m.x_ids, "posterior_mean": em, "posterior_covariance": ecov})
+
+
 def lgssm_d64():
     m = cx.synth.lgssm_chain(3, d=64, seed=1234)
     em, ecov = exact.lgssm_posterior(m.data_y, m.meta["A"], m.meta["Q"], m.meta["R"])
@@ -123,5 +132,5 @@ def kats():
 
 
 if __name__ == "__main__":
-    chain16(); grid8x8(); lgssm_d4(); lgssm_d64(); vmp_n8(); tree24(); kats()
+    chain16(); grid8x8(); lgssm_d4(); lgssm_d8(); lgssm_d64(); vmp_n8(); tree24(); kats()
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".json")))

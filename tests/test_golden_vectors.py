@@ -191,3 +191,26 @@ def test_device_tree_against_the_golden_vector(hip_lib):
     got = dev.get_marginals(d["x_ids"])
     np.testing.assert_allclose(got[:, 0], d["posterior_mean"], rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(got[:, 1], d["posterior_variance"], rtol=1e-10)
+
+
+# ---------------------------------------------------------------------------------------------------------------- d = 8
+def test_d8_vector_is_what_the_block_solver_returns():
+    d = load("lgssm_d8.json")
+    m = cx.synth.lgssm_chain(6, d=8, seed=1234)
+    assert np.array_equal(m.data_y, d["data_y"]) and np.array_equal(m.meta["A"], d["A"])
+    em, ecov = exact.lgssm_posterior(m.data_y, m.meta["A"], m.meta["Q"], m.meta["R"])
+    assert np.array_equal(em, d["posterior_mean"]) and np.array_equal(ecov, d["posterior_covariance"])
+
+
+@pytest.mark.gpu
+def test_device_d8_chain_against_the_golden_vector(hip_lib):
+    """a dimension between 4 and 64 (embedded in the dim 64 path): flooding to its fixed point and ONE chain-scan sweep"""
+    d = load("lgssm_d8.json")
+    m = cx.synth.lgssm_chain(6, d=8, seed=1234)
+    for schedule, sweeps in ((L.SCHED_FUSED, 10), (L.SCHED_CHAIN_SCAN, 1)):
+        dev = cx.DeviceGraph(dim=8, schedule=schedule)
+        cx.synth.load_into_device(m, dev)
+        dev.sweep(sweeps)
+        marg = dev.get_marginals(d["x_ids"])
+        np.testing.assert_allclose(marg[:, :8], d["posterior_mean"], rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(marg[:, 8:].reshape(6, 8, 8), d["posterior_covariance"], rtol=1e-8, atol=1e-11)
