@@ -313,6 +313,10 @@ def tree(n_factors=200_000, steps=20, shape="random"):
     return {"config": "tree", "workload": f"scalar Gaussian forest, {n_factors} factors of 2..6 variables + a prior per variable ({len(model.edge_var)} edges, shape {shape})",
             "ms_per_sweep": dt * 1e3, "plan": st, "launches_per_sweep": st["stages"], "messages_per_sweep": n_msgs, "messages_per_s": n_msgs / dt,
             "fused_schedule": {"ms_per_sweep": dtf * 1e3, "sweeps_to_the_same_result": need, "ms_to_the_same_result": need * dtf * 1e3},
+            "roofline": roofline("hbm", n_msgs * 32 / dt / 1e9, HBM_PEAK_GBS, "GB/s", None, kernel="k_batch, one launch per stage",
+                                 basis="algorithmic bytes (32 B per message, SURVEY §8d) / sweep time",
+                                 bound_detail=f"not a bandwidth-bound schedule: {st['stages']} dependent stages, each a launch of its own (≈ {dt / max(st['stages'], 1) * 1e6:.1f} us "
+                                              "per stage at this size): the time is depth x per-kernel time"),
             "parity": {"max_rel_err_marginals": err, "ok": bool(err < 1e-9), "checker": "the fused schedule at its fixed point on the same device (the tree "
                        "schedule against a dense solve: tests/test_gpu_tree.py)", "sample": f"{len(ids)} marginals"}}
 
