@@ -139,6 +139,8 @@ int32_t build_tree(cx_handle *h) {
             off.push_back((int64_t)rec.size() / 5);
         }
         if (!rec.empty() && (rc2 = dev_upload(h, &h->d_tree_rec, rec)) != CX_OK) return rc2;
+        if (h->d_tree_stage_off) { (void)hipFree(h->d_tree_stage_off); h->d_tree_stage_off = nullptr; }
+        if ((rc2 = dev_upload(h, &h->d_tree_stage_off, off)) != CX_OK) return rc2;
         CX_HIP(h, hipStreamSynchronize(h->stream));
         h->tree_stage_off = off; h->tree_kary_off = koff;
         const int64_t st[8] = {plan.depth, (int64_t)plan.stage_off.size() - 1, (int64_t)plan.rec.size() / 5, (int64_t)plan.kary.size(), plan.n_components,
@@ -154,11 +156,18 @@ int32_t build_tree(cx_handle *h) {
 static void tree_issue(cx_handle *h) {
     size_t ns = h->tree_stage_off.empty() ? 0 : h->tree_stage_off.size() - 1;
     if (ns > 0 && h->cfg.compute_marginals_in_sweep == 0) ns--;      // the last stage is the marginals (the flag is fixed per handle)
-    for (size_t s = 0; s < ns; s++) {
+    // CX_TREE_RUNS=0: every stage a launch of its own (A/B)
+    static const bool runs = [] { const char *e = std::getenv("CX_TREE_RUNS"); return !(e && e[0] == '0'); }();
+    for (size_t s = 0; s < ns;) {
         const int64_t n = h->tree_stage_off[s + 1] - h->tree_stage_off[s], nk = h->tree_kary_off[s + 1] - h->tree_kary_off[s];
-        if (h->cfg.dim > 1) { if (n > 0) cx::mv_launch_batch(h, h->d_tree_rec + 5 * h->tree_stage_off[s], n); continue; }
+        if (h->cfg.dim > 1) { if (n > 0) cx::mv_launch_batch(h, h->d_tree_rec + 5 * h->tree_stage_off[s], n); s++; continue; }
+        // dim 1: consecutive thin stages (the levels next to the roots) leave as ONE launch of one workgroup (cx_kernels.hip: k_batch_run)
+        size_t e = s;
+        while (runs && e < ns && h->tree_stage_off[e + 1] - h->tree_stage_off[e] <= 1024) e++;
+        if (e >= s + 2) { cx::launch_batch_run(h, h->d_tree_rec, h->d_tree_stage_off, (int)s, (int)e); s = e; continue; }
         if (n > 0) cx::launch_batch(h, h->d_tree_rec + 5 * h->tree_stage_off[s], n);
         if (nk > 0) cx::launch_kary_items(h, h->d_tree_kary + h->tree_kary_off[s], nk);
+        s++;
     }
 }
 

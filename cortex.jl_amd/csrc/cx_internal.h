@@ -107,6 +107,7 @@ struct cx_handle {
     // CX_SCHED_TREE (cx_tree_plan.h): the stages' items and k-ary entries on the device, their offsets on the host
     bool tree_dirty = true;
     int32_t *d_tree_rec = nullptr, *d_tree_kary = nullptr;
+    int64_t *d_tree_stage_off = nullptr;      // the stage table on the device (runs of thin stages go out as one launch)
     std::vector<int64_t> tree_stage_off, tree_kary_off;
     hipGraphExec_t tree_exec = nullptr;    // the stages of one sweep as ONE graph launch (hundreds of small launches otherwise: the sweep was bound by
     hipStream_t tree_capture_stream = nullptr;      //  the host's launch rate); captured on a stream of the handle's own, launched on the caller's
@@ -221,6 +222,7 @@ void launch_push_slots(cx_handle *h, const int32_t *d_slots, int64_t n, double2 
 void launch_halo_export(cx_handle *h, const double2 *f2v, hipStream_t stream);
 void launch_halo_import(cx_handle *h, double2 *f2v_out, bool push);
 void launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n);
+void launch_batch_run(cx_handle *h, const int32_t *d_rec, const int64_t *d_stage_off, int s0, int s1);   // consecutive thin stages (<= 1024 items each) in one launch
 constexpr int kSmallBatch = 48;                        // items whose records (5 int32 each) ride in the kernel arguments
 struct SmallBatch { int32_t r[5 * kSmallBatch]; };
 void launch_batch_small(cx_handle *h, const SmallBatch &recs, int n);   // 5 int32 per item: kind, index, var, lo, hi

@@ -420,6 +420,29 @@ __global__ __launch_bounds__(kBlock) void k_batch(int64_t n, const int32_t *__re
                      nat_marg, prod, joint, kt);
 }
 
+// A RUN of consecutive thin stages of the tree schedule (each at most kRunBlock items) in ONE launch of ONE workgroup: the stages of a
+// run depend on each other, so the workgroup takes them one after the other with a barrier (and a workgroup-scope fence: the threads of
+// a workgroup share their compute unit's vector cache) in between — instead of a launch of ≈ 5 us per stage of a few items.  The thin
+// stages are the levels next to the roots, on the way up and again on the way down.
+constexpr int kRunBlock = 1024;
+template <int MODE>
+__global__ __launch_bounds__(kRunBlock) void k_batch_run(const int64_t *__restrict__ stage_off, int s0, int s1, const int32_t *__restrict__ rec,
+                                                         const int32_t *__restrict__ vbase, const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
+                                                         const int32_t *__restrict__ partner, const double *__restrict__ q, const double *__restrict__ pa,
+                                                         const double *__restrict__ pb, double2 *__restrict__ f2v, double2 *__restrict__ v2f,
+                                                         double2 *__restrict__ marg, int nat_marg, double2 *__restrict__ prod, double *__restrict__ joint,
+                                                         const KaryTab kt) {
+    for (int st = s0; st < s1; st++) {
+        const int64_t i = stage_off[st] + threadIdx.x;
+        if (i < stage_off[st + 1])
+            batch_item<MODE>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg,
+                             nat_marg, prod, joint, kt);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
 // A batch of at most kSmallBatch items travels IN the kernel arguments: no staging copy, nothing for the host to wait for before
 // it reuses its buffer — the launch is all a per-signal `process!` or a wavefront of a few signals costs.  The records are the
 // first parameter, i.e. the start of the kernarg segment, which every thread reads like any other constant memory.
@@ -646,6 +669,19 @@ void launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n) {
     else CX_B(kRuleAdditive, (const double *)nullptr, (const double *)nullptr);
 #undef CX_B
     prof_end(h);
+}
+
+// stages [s0, s1) of a device-resident stage table, each of at most kRunBlock items, in one launch (cx_api_sweep.hip: the tree schedule)
+void launch_batch_run(cx_handle *h, const int32_t *d_rec, const int64_t *d_stage_off, int s0, int s1) {
+    if (s1 <= s0) return;
+    const int mode = rule_mode(h), nat = h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0;
+    const KaryTab kt{h->d_kary_slot, h->d_kary_coef, h->d_kary_qb};
+#define CX_B(M, PA, PB) hipLaunchKernelGGL(k_batch_run<M>, dim3(1), dim3(kRunBlock), 0, h->stream, d_stage_off, s0, s1, d_rec, h->d_vbase, h->d_var_deg, h->d_vinfo, \
+                                           h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint, kt)
+    if (mode == kRuleLinear) CX_B(kRuleLinear, h->d_a, h->d_b);
+    else if (mode == kRuleBernoulli) CX_B(kRuleBernoulli, (const double *)nullptr, (const double *)nullptr);
+    else CX_B(kRuleAdditive, (const double *)nullptr, (const double *)nullptr);
+#undef CX_B
 }
 
 void launch_batch_small(cx_handle *h, const SmallBatch &recs, int n) {
