@@ -99,8 +99,8 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
         return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: the variational families need dim == 1");
     if (config->family == CX_FAMILY_NATURAL2 && (config->dim != 1 || config->schedule == CX_SCHED_CHAIN_SCAN))
         return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: CX_FAMILY_NATURAL2 needs dim == 1 and the flooding or fused schedule");
-    if (config->dim > 1 && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN && !(config->schedule == CX_SCHED_TREE && config->dim <= 4))
-        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: dim > 1 runs the fused and the chain-scan schedule (dim 2..4 also the tree schedule)");
+    if (config->dim > 1 && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN && config->schedule != CX_SCHED_TREE)
+        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: dim > 1 runs the fused, the chain-scan and the tree schedule");
     if (config->schedule != CX_SCHED_FLOODING && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN && config->schedule != CX_SCHED_TREE)
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: unknown schedule");
     if (config->schedule == CX_SCHED_TREE && is_vmp)

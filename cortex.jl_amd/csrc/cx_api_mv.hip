@@ -497,6 +497,13 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
         // carry the rule table of the sending slot as the plan found it (the plan is rebuilt when a variable becomes observed)
         int32_t rc = build_tree(h);
         if (rc != CX_OK) return rc;
+        if (h->cfg.dim == 64) {       // the constant messages out of observed variables (as the other dim 64 schedules do)
+            if ((rc = build_work64(h)) != CX_OK) return rc;
+            if (h->point64_dirty) {
+                cx::mv64_launch_point(h, (int)h->n_point64, h->d_point64_slots, h->d_mv_f2v, h->d_mv_f2v_alt);
+                h->point64_dirty = false;
+            }
+        }
         for (int32_t s = 0; s < n_sweeps; s++) { tree_sweep(h); h->sweeps_done++; }
         CX_HIP(h, hipGetLastError());
         return CX_OK;

@@ -133,6 +133,32 @@ int32_t build_tree(cx_handle *h) {
         std::vector<int32_t> rec;
         std::vector<int64_t> off(1, 0), koff(plan.kary_off.size(), 0);
         rec.reserve(plan.rec.size() + 5 * plan.kary.size());
+        if (h->cfg.dim == 64) {
+            // dim 64: a factor→variable message is ONE rule record of cx_mv64w.hip — the sending slot, the other slots of the sending
+            // variable (the rule sums them itself: no stored variable→factor message), the rule table, the destination — so only the
+            // plan's factor→variable items become work; messages out of observed variables are constants (k_point64 at data injection),
+            // marginals of dim 64 are formed when read
+            std::vector<int32_t> slot_var(h->nslots, -1);
+            for (int64_t e = 0; e < h->ne; e++) slot_var[cx::slot_of_edge(h, e)] = h->edge_var[e];
+            for (size_t st = 0; st + 1 < plan.stage_off.size(); st++) {
+                for (int64_t i = plan.stage_off[st]; i < plan.stage_off[st + 1]; i++) {
+                    if (plan.rec[5 * i] != CX_ITEM_MESSAGE_TO_VARIABLE) continue;
+                    const int32_t dst = plan.rec[5 * i + 1], sl = h->partner[dst];
+                    if (sl < 0) continue;
+                    const int32_t u = slot_var[sl];
+                    if (h->vinfo[u] & cx::kClamped) continue;
+                    const int32_t deg = h->var_off[u + 1] - h->var_off[u];
+                    int32_t others[3] = {-1, -1, -1};
+                    int n_others = 0;
+                    for (int32_t j = 0; j < deg; j++) {
+                        const int32_t sj = h->vbase[u] + j * cx::kBlock;
+                        if (sj != sl && n_others < 3) others[n_others++] = sj;
+                    }
+                    rec.insert(rec.end(), {sl, others[0], others[1], others[2], h->spdir[sl], dst, deg < 2 ? 1 : 0, 0});
+                }
+                off.push_back((int64_t)rec.size() / 8);
+            }
+        } else
         for (size_t st = 0; st + 1 < plan.stage_off.size(); st++) {
             rec.insert(rec.end(), plan.rec.begin() + 5 * plan.stage_off[st], plan.rec.begin() + 5 * plan.stage_off[st + 1]);
             for (int64_t k = plan.kary_off[st]; k < plan.kary_off[st + 1]; k++) rec.insert(rec.end(), {32, plan.kary[k], 0, 0, 0});
@@ -155,11 +181,12 @@ int32_t build_tree(cx_handle *h) {
 // earlier stages of this sweep and the stored constants left)
 static void tree_issue(cx_handle *h) {
     size_t ns = h->tree_stage_off.empty() ? 0 : h->tree_stage_off.size() - 1;
-    if (ns > 0 && h->cfg.compute_marginals_in_sweep == 0) ns--;      // the last stage is the marginals (the flag is fixed per handle)
+    if (ns > 0 && h->cfg.compute_marginals_in_sweep == 0 && h->cfg.dim != 64) ns--;      // the last stage is the marginals (the flag is fixed per handle)
     // CX_TREE_RUNS=0: every stage a launch of its own (A/B)
     static const bool runs = [] { const char *e = std::getenv("CX_TREE_RUNS"); return !(e && e[0] == '0'); }();
     for (size_t s = 0; s < ns;) {
         const int64_t n = h->tree_stage_off[s + 1] - h->tree_stage_off[s], nk = h->tree_kary_off[s + 1] - h->tree_kary_off[s];
+        if (h->cfg.dim == 64) { if (n > 0) cx::mv64_launch_rule(h, (int)n, h->d_tree_rec + 8 * h->tree_stage_off[s], h->d_mv_f2v, h->d_mv_f2v, CX_KERNEL_BATCH); s++; continue; }
         if (h->cfg.dim > 1) { if (n > 0) cx::mv_launch_batch(h, h->d_tree_rec + 5 * h->tree_stage_off[s], n); s++; continue; }
         // dim 1: consecutive thin stages (the levels next to the roots) leave as ONE launch of one workgroup (cx_kernels.hip: k_batch_run)
         size_t e = s;

@@ -141,7 +141,7 @@ extern "C" {
                                  2 x depth + 1 launches over item lists built once (depth = half the longest path of a
                                  component, counted in variables and factors).  A cycle among the non-observed variables
                                  is refused (CX_ERR_UNSUPPORTED).  Lazy like the reference: nothing into observed
-                                 variables.  dim 1 (Gaussian and natural-pair families) and dim 2, 3, 4.                    */
+                                 variables.  dim 1 (Gaussian and natural-pair families), 2, 3, 4 and 64 (5 .. 63 with it).  */
 
 
 typedef struct cx_handle cx_handle;

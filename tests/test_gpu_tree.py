@@ -239,3 +239,44 @@ def test_without_marginals_in_the_sweep_the_last_stage_is_left_out(hip_lib):
     assert np.all(np.isnan(b.get_marginals(ids)))
     b.update_batch([L.ITEM_INDIVIDUAL_MARGINAL] * len(ids), ids, [0] * len(ids))
     assert np.array_equal(a.get_marginals(ids), b.get_marginals(ids))
+
+
+@pytest.mark.parametrize("d,b,n", [(64, 2, 7), (64, 2, 15), (6, 2, 15), (33, 1, 9)])
+def test_dim_64_trees_one_sweep(hip_lib, d, b, n):
+    """dim 64 (and 5 .. 63 embedded in it): a tree of states with b children each (degree b + 2 <= 4: a dim 64 rule sums at most three
+    sources), every state observed: ONE sweep of the tree schedule — a stage is one launch of the MFMA rule kernel over its records —
+    == the joint solve; the fused schedule needs depth-many sweeps for the same messages"""
+    from tests.test_gpu_mv import _branching_lgssm
+
+    model, emean, ecov = _branching_lgssm(n, d, seed=60 + n, b=b)
+    dev = cx.DeviceGraph(dim=d, schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(model, dev)
+    dev.sweep(1)
+    marg = dev.get_marginals(model.x_ids)
+    assert not np.any(np.isnan(marg))
+    assert_close(marg[:, :d], emean, 1e-8, f"d={d}: marginal mean vs the joint solve", scale_by="max")
+    assert_close(marg[:, d:].reshape(n, d, d), ecov, 1e-8, f"d={d}: marginal covariance vs the joint solve", scale_by="max")
+    st = dev.tree_plan_stats()
+    fused = cx.DeviceGraph(dim=d, schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(model, fused)
+    fused.sweep(2 * st["depth"] + 4)
+    xs = set(int(v) for v in model.x_ids)
+    keep = np.array([int(v) in xs for v in model.edge_var])
+    ev, ef = model.edge_var[keep], model.edge_fac[keep]
+    a, bb = dev.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL), fused.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL)
+    assert not np.any(np.isnan(a))
+    assert_close(a, bb, 1e-8, "factor→variable messages vs the fused schedule at its fixed point", scale_by="max")
+    before = dev.get_marginals(model.x_ids)
+    dev.sweep(1)
+    assert np.array_equal(before, dev.get_marginals(model.x_ids))
+
+
+def test_dim_64_chain_under_the_tree_schedule_equals_the_chain_scan(hip_lib):
+    m = cx.synth.lgssm_chain(40, d=64, seed=9)
+    tree = cx.DeviceGraph(dim=64, schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(m, tree)
+    tree.sweep(1)
+    scan = cx.DeviceGraph(dim=64, schedule=L.SCHED_CHAIN_SCAN)
+    cx.synth.load_into_device(m, scan)
+    scan.sweep(1)
+    assert_close(tree.get_marginals(m.x_ids), scan.get_marginals(m.x_ids), 1e-8, "tree schedule vs chain scan on a d = 64 chain", scale_by="max")
