@@ -43,7 +43,7 @@ void dev_free_all(cx_handle *h) {
     h->d_big_tmp = nullptr; h->d_vinfo = nullptr;
     h->d_q = h->d_a = h->d_b = h->d_sq = h->d_sa = h->d_sb = nullptr;
     h->d_f2v = h->d_v2f = h->d_marg = h->d_f2v_alt = h->d_prev = nullptr;
-    h->mv_max_deg = 0;
+    h->mv_max_deg = 0; h->sweep_max_w = 0;
     h->d_scratch = nullptr; h->d_send_slots = h->d_recv_slots = h->d_send_vars = nullptr;
     h->d_send_buf = h->d_recv_buf = nullptr;
     h->d_stage = nullptr; h->stage_bytes = 0; h->device_bytes = 0;

@@ -102,6 +102,7 @@ struct cx_handle {
     // cfg.dim of 5 .. 63 as the caller gave it (0 otherwise): such a handle runs as dim 64 with every message, datum and rule matrix
     // embedded block-diagonally (cx_api.hip: pad_* helpers); cfg.dim holds 64
     int user_dim = 0;
+    int sweep_max_w = 0;                 // the widest SELL slice (0: not yet computed): picks the register footprint of the fused sweep
     int16_t *d_partner16 = nullptr;      // partner[s] - s where every difference fits (kNoPartner16: none); null otherwise (cx_kernels.hip: PACK)
     bool chains_dirty = true;
     // CX_SCHED_TREE (cx_tree_plan.h): the stages' items and k-ary entries on the device, their offsets on the host

@@ -132,7 +132,10 @@ __device__ __forceinline__ void emit(int slot, double2 o, const int32_t *__restr
 // OTHER factor→variable buffer (Jacobi double buffering): the whole sweep is this one launch.
 // !PUSH: phase A of the two-phase flooding schedule (stores variable→factor messages only).
 // ------------------------------------------------------------------------------------------------
-template <int MODE, bool STORE_V2F, bool PUSH, int PACK = 0>
+// MAXW: the widest slice of the graph rounded up to 5 or 8 (a 2-D grid with one observation per variable has degree 5): the incoming and
+// the outgoing messages of a variable live in 2 x MAXW register pairs, and with five instead of eight the kernel fits 64 registers —
+// eight waves per SIMD instead of six.
+template <int MODE, bool STORE_V2F, bool PUSH, int PACK = 0, int MAXW = kSmallDeg>
 __global__ __launch_bounds__(kBlock) void k_sweep(int nv, const int32_t *__restrict__ slice_off, const uint8_t *__restrict__ vinfo,
                                                   const int32_t *__restrict__ partner, const double *__restrict__ sq,
                                                   const double *__restrict__ sa, const double *__restrict__ sb,
@@ -156,23 +159,23 @@ __global__ __launch_bounds__(kBlock) void k_sweep(int nv, const int32_t *__restr
     if (skip_ghosts && (info & kGhost)) return;       // pushed by cx_sweep_end once the halo has arrived
     const int base = off + tid;
 
-    double2 in[kSmallDeg];
+    double2 in[MAXW];
 #pragma unroll
-    for (int k = 0; k < kSmallDeg; k++) {
+    for (int k = 0; k < MAXW; k++) {
         in[k] = zero2();
         if (k < W) {  // uniform branch
             double2 x = load_stream(&f2v_in[base + k * kBlock]);
             if (k < deg) in[k] = x;
         }
     }
-    double2 out[kSmallDeg];
+    double2 out[MAXW];
     double2 acc = zero2();
 #pragma unroll
-    for (int k = 0; k < kSmallDeg; k++) { out[k] = acc; acc = add2(acc, in[k]); }
+    for (int k = 0; k < MAXW; k++) { out[k] = acc; acc = add2(acc, in[k]); }
     const double2 total = acc;
     acc = zero2();
 #pragma unroll
-    for (int k = kSmallDeg - 1; k >= 0; k--) { out[k] = add2(out[k], acc); acc = add2(acc, in[k]); }
+    for (int k = MAXW - 1; k >= 0; k--) { out[k] = add2(out[k], acc); acc = add2(acc, in[k]); }
 
     if (write_marg) store_stream(&marg[v], write_marg == 2 ? total : to_moment(total));   // 2: natural-parameter marginals
 
@@ -181,12 +184,12 @@ __global__ __launch_bounds__(kBlock) void k_sweep(int nv, const int32_t *__restr
     const bool fixed = (deg < 2) || (info & (kClamped | kGhost));
     if (!fixed) {
 #pragma unroll
-        for (int k = 0; k < kSmallDeg; k++)
+        for (int k = 0; k < MAXW; k++)
             if (k < deg) emit<MODE, STORE_V2F, PUSH, PACK>(base + k * kBlock, out[k], partner, sq, sa, sb, f2v_out, v2f, nt_out, partner16);
     } else if (PUSH) {
         // separate path (not a select on the message) so that out[] never has its address taken
 #pragma unroll
-        for (int k = 0; k < kSmallDeg; k++)
+        for (int k = 0; k < MAXW; k++)
             if (k < deg) emit<MODE, false, true, PACK>(base + k * kBlock, v2f[base + k * kBlock], partner, sq, sa, sb, f2v_out, v2f, 0, partner16);
     }
 }
@@ -563,10 +566,19 @@ static void launch_sweep_t(cx_handle *h, const double2 *f2v_in, double2 *f2v_out
 #define CX_SWEEP_ARGS dim3((unsigned)h->nslices), dim3(kBlock), 0, h->stream, (int)h->nv, h->d_slice_off, h->d_vinfo, h->d_partner, sq, h->d_sa, \
                       h->d_sb, f2v_in, f2v_out, h->d_v2f, h->d_marg, write_marg ? (h->cfg.family == CX_FAMILY_NATURAL2 ? 2 : 1) : 0,             \
                       skip_ghosts ? 1 : 0, nt_scatter(h), lo, hi, xlo, xhi, h->d_partner16
-    if (PUSH && LINEAR == kRuleAdditive && pack_on && h->d_partner16)
-        hipLaunchKernelGGL((k_sweep<LINEAR, STORE, PUSH, kPackPartner16 | kPackQLow>), CX_SWEEP_ARGS);
-    else
-        hipLaunchKernelGGL((k_sweep<LINEAR, STORE, PUSH, 0>), CX_SWEEP_ARGS);
+    // the widest slice, once per graph (CX_MAXW8=1: the eight-message instance for every graph, A/B)
+    if (h->sweep_max_w == 0) {
+        int w = 1;
+        for (int64_t sl = 0; sl < h->nslices; sl++) w = std::max<int>(w, (h->slice_off[sl + 1] - h->slice_off[sl]) >> kSliceShift);
+        h->sweep_max_w = w;
+    }
+    static const bool force8 = [] { const char *e = std::getenv("CX_MAXW8"); return e && e[0] == '1'; }();
+    const bool w5 = h->sweep_max_w <= 5 && !force8;
+    if (PUSH && LINEAR == kRuleAdditive && pack_on && h->d_partner16) {
+        if (w5) hipLaunchKernelGGL((k_sweep<LINEAR, STORE, PUSH, kPackPartner16 | kPackQLow, 5>), CX_SWEEP_ARGS);
+        else hipLaunchKernelGGL((k_sweep<LINEAR, STORE, PUSH, kPackPartner16 | kPackQLow, kSmallDeg>), CX_SWEEP_ARGS);
+    } else
+        hipLaunchKernelGGL((k_sweep<LINEAR, STORE, PUSH, 0, kSmallDeg>), CX_SWEEP_ARGS);
 #undef CX_SWEEP_ARGS
 }
 
