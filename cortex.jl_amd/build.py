@@ -117,7 +117,7 @@ def build_hostlogic(asan: bool = False, verbose: bool = False, defines=(), suffi
     return lib
 
 
-HOSTLOGIC_HEADERS = ("cx_chain64_plan.h", "cx_flatten.h", "cx_chains.h", "cx_halo_plan.h", "cx_const.h", "cortex_hip.h")
+HOSTLOGIC_HEADERS = ("cx_chain64_plan.h", "cx_tree_plan.h", "cx_flatten.h", "cx_chains.h", "cx_halo_plan.h", "cx_const.h", "cortex_hip.h")
 
 
 if __name__ == "__main__":

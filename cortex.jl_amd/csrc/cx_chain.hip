@@ -140,22 +140,45 @@ struct ChainArgs {
     const int32_t *pos_var;      // variable at a chain position (for the marginals k_chain_apply<.., true> writes)
 };
 
-// Tiles are blocks of kTile consecutive links in BOTH directions: the tile at position p of the forward scan is block p, of the
-// backward scan block ntiles - 1 - p, visited from its last link to its first (the ragged block comes first there; identity
-// maps pad it).  One workgroup holds the same block for both directions, so the side sums and rule parameters of a link cross
-// the fabric once (with separate forward / backward workgroups — on different XCDs, behind different L2s — the two scan kernels
+// Tiles are blocks of K * T consecutive links in BOTH directions (K links per thread, T threads per direction): the tile at position p
+// of the forward scan is block p, of the backward scan block ntiles - 1 - p, visited from its last link to its first (the ragged
+// block comes first there).  One workgroup holds the same block for both directions, so the side sums and rule parameters of a link
+// cross the fabric once (with separate forward / backward workgroups — on different XCDs, behind different L2s — the two scan kernels
 // of a 1M-link chain fetched 184 + 88 MB: profiles/r02_vmp_rocprof.md).
-__device__ __forceinline__ Lin load_link(const ChainArgs &A, int tile_pos, int j, int dir, int ntiles, int *link_out = nullptr) {
-    const int block = dir > 0 ? tile_pos : ntiles - 1 - tile_pos;
-    const int lo = block * kTile, hi = min(lo + kTile, A.nlinks);
-    if (link_out) *link_out = -1;
-    if (j >= hi - lo) return lin_identity();
-    const int l = dir > 0 ? lo + j : hi - 1 - j;
-    if (link_out) *link_out = l;
-    const int recv = dir > 0 ? A.to_slot[l] : A.from_slot[l];
-    const double2 u = A.side[A.link_pos[l] + (dir > 0 ? 0 : 1)];
-    const int seg = dir > 0 ? A.head_fwd[l] : A.head_bwd[l];
-    return lin_of_link(u, slot_q(A.q, A.qg, A.gm, recv), A.a ? A.a[recv] : 1.0, A.b ? A.b[recv] : 0.0, seg);
+//
+// Round 4, second form.  The first form gave every thread four links, scanned the 1024 maps of a tile with a workgroup scan (twice: once
+// for the tile totals, once in the apply kernel, which composed carry ∘ prefix for every link) and composed the tile carries with a
+// third one: ≈ 14 instructions per link and direction.  Now a thread owns a RUN of K consecutive links: the totals kernel composes the
+// run's maps in order, scans the run totals of a wave, and stores each thread's exclusive prefix within its tile; the apply kernel
+// turns that prefix and the tile's entering message into the message at the head of the run and WALKS the run with the message rule
+// itself (one division and six multiply-adds per link instead of a 30-flop composition): ≈ 7 instructions per link and direction.
+// What that bought is less than the count suggests (C2 23.5 -> 21.5 us, the structured family unchanged): the counters show the vector
+// pipe ≈ 30 % busy and the waves 55 - 73 % of their life in s_waitcnt — the kernels are bound by their dependent loads (link -> position
+// -> side sum; link -> slot -> precision index -> mean) at four waves per SIMD, not by instruction issue.
+struct LinkIn {       // what the rule of one link needs
+    double2 u;        // side sum of the variable the link leaves
+    double q, a, b;
+    int recv, seg, link;
+};
+
+template <int K, int T>
+__device__ __forceinline__ int run_link(const ChainArgs &A, int block, int j, int dir) {      // the link at place j of the tile's scan order, -1 past its end
+    const int lo = block * (K * T), hi = min(lo + K * T, A.nlinks);
+    if (j >= hi - lo) return -1;
+    return dir > 0 ? lo + j : hi - 1 - j;
+}
+
+__device__ __forceinline__ LinkIn load_link_in(const ChainArgs &A, int l, int dir) {
+    LinkIn in;
+    in.link = l;
+    if (l < 0) { in.u = make_double2(0.0, 0.0); in.q = 0.0; in.a = 1.0; in.b = 0.0; in.recv = -1; in.seg = 0; return in; }
+    in.recv = dir > 0 ? A.to_slot[l] : A.from_slot[l];
+    in.u = A.side[A.link_pos[l] + (dir > 0 ? 0 : 1)];
+    in.seg = dir > 0 ? A.head_fwd[l] : A.head_bwd[l];
+    in.q = slot_q(A.q, A.qg, A.gm, in.recv);
+    in.a = A.a ? A.a[in.recv] : 1.0;
+    in.b = A.b ? A.b[in.recv] : 0.0;
+    return in;
 }
 
 // workgroup-wide inclusive scan of kTile links; returns this thread's kItems inclusive prefixes and the tile total
@@ -185,21 +208,46 @@ __device__ __forceinline__ void tile_scan(Lin (&x)[kItems], Lin &tile_total, Lin
     __syncthreads();
 }
 
-// The forward and the backward scan are independent: every stage runs both in one launch, threads 0..kBlock-1 of a workgroup
-// forward, the other kBlock backward over the same block of links, with the backward direction's tile totals stored after the
-// forward ones (stride ntiles + 1) in scan order.
-constexpr int kChainThreads = 2 * kBlock;
-__global__ __launch_bounds__(kChainThreads) void k_chain_tile_totals(ChainArgs A, Lin *__restrict__ totals) {
-    const int half = threadIdx.x / kBlock, tid = threadIdx.x % kBlock, dir = half == 0 ? 1 : -1, ntiles = gridDim.x;
+// The forward and the backward scan are independent: every stage runs both in one launch, threads 0..T-1 of a workgroup forward, the
+// other T backward over the same block of links, with the backward direction's tile totals stored after the forward ones (stride
+// ntiles + 1) in scan order.  `run_excl`: per direction, tile (scan order) and thread, the composition of the runs before the thread's
+// own within its tile.
+template <int K, int T>
+__global__ __launch_bounds__(2 * T) void k_chain_run_totals(ChainArgs A, Lin *__restrict__ totals, Lin *__restrict__ run_excl) {
+    const int half = threadIdx.x / T, tid = threadIdx.x % T, dir = half == 0 ? 1 : -1, ntiles = gridDim.x;
     const int pos = half == 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;       // this block's place in the direction's scan order
-    totals += (size_t)half * (ntiles + 1);
-    __shared__ Lin wave_tot[2][kBlock / 64];
-    Lin x[kItems];
+    const int lane = tid & 63, wid = tid >> 6;
+    __shared__ Lin wave_tot[2][T / 64];
+    LinkIn in[K];
 #pragma unroll
-    for (int k = 0; k < kItems; k++) x[k] = load_link(A, pos, tid * kItems + k, dir, ntiles);
-    Lin tot;
-    tile_scan(x, tot, wave_tot[half], tid);
-    if (tid == 0) totals[pos] = tot;
+    for (int k = 0; k < K; k++) in[k] = load_link_in(A, run_link<K, T>(A, blockIdx.x, tid * K + k, dir), dir);
+    Lin t = lin_identity();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if (in[k].link < 0) continue;
+        const Lin m = lin_of_link(in[k].u, in[k].q, in[k].a, in[k].b, in[k].seg);
+        t = k == 0 ? m : lin_compose(t, m);
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        Lin o = lin_shfl_up(t, d);
+        if (lane >= d) t = lin_compose(o, t);
+    }
+    if (lane == 63) wave_tot[half][wid] = t;
+    __syncthreads();
+    Lin excl = lin_shfl_up(t, 1);            // exclusive prefix within the wave
+    if (lane == 0) excl = lin_identity();
+    if (wid > 0) {
+        Lin carry = wave_tot[half][0];
+        for (int w = 1; w < wid; w++) carry = lin_compose(carry, wave_tot[half][w]);
+        excl = lin_compose(carry, excl);
+    }
+    run_excl[((size_t)half * ntiles + pos) * T + tid] = excl;
+    if (tid == 0) {
+        Lin tot = wave_tot[half][0];
+        for (int w = 1; w < T / 64; w++) tot = lin_compose(tot, wave_tot[half][w]);
+        totals[(size_t)half * (ntiles + 1) + pos] = tot;
+    }
 }
 
 // exclusive scan of the tile totals by one workgroup (sequential over chunks of kTile tiles: ≤ 1M links per chunk)
@@ -243,71 +291,89 @@ __global__ __launch_bounds__(kBlock) void k_chain_scan_totals(int ntiles, Lin *_
     }
 }
 
-// OWN_CARRY: the tile totals are NOT pre-scanned; every workgroup composes the totals of the tiles before it itself (a few
-// KB from L2, one more tile scan) — for up to kOwnCarryTiles tiles that is cheaper than the one-workgroup scan kernel's
-// launch (≈6 us on a 1M-edge chain, where the whole sweep is launch-bound).
-constexpr int kOwnCarryTiles = 8 * kTile;
+// OWN_CARRY: the tile totals are NOT pre-scanned; every workgroup composes the totals of the tiles before it itself (each thread a
+// run of them in order, a wave scan, the wave totals by one thread) — up to kOwnCarryTiles tiles that is cheaper than the
+// one-workgroup scan kernel and its launch.
+constexpr int kOwnCarryTiles = 2048;
 __device__ __forceinline__ double2 chain_to_moment(double2 nat) {      // as cx_kernels.hip's to_moment
     const double var = 1.0 / nat.y;
     return make_double2(nat.x * var, var);
 }
 
+// a map applied to a message (D = 1); a map that starts a path ignores what comes in
+__device__ __forceinline__ double2 lin_apply(const Lin &p, double2 m) {
+    if (p.seg) return make_double2(p.g, p.B);
+    const double inv = 1.0 / (p.C * m.y + 1.0);
+    return make_double2((p.e * m.x + p.f * m.y + p.g) * inv, (p.A * m.y + p.B) * inv);
+}
+
 // MARG: the workgroup also writes the marginals of its block's chain variables.  It holds alpha (the forward message into the
 // right end of every link of the block) and beta (the backward message into the left end): the marginal of a link's LEFT variable
-// is side + beta(this link) + alpha(previous link) — across a block seam the forward carry applied to the empty message, none
-// at the head of a path — and the last link of a path also owns its RIGHT variable (side + alpha).  With every reader of
-// factor→variable messages on a chain this replaces the variable phase of the sweep (one launch less; variable→factor messages
-// are then recomputed from the stored messages when somebody asks for them, like in the fused schedule).
-template <bool OWN_CARRY, bool MARG>
-__global__ __launch_bounds__(kChainThreads) void k_chain_apply(ChainArgs A, const Lin *__restrict__ tile_excl, double2 *__restrict__ f2v,
-                                                               double2 *__restrict__ marg, int marg_form, double2 *__restrict__ chain_v2f,
-                                                               double *__restrict__ split_mean, double *__restrict__ split_prec, const bool store_msgs) {
-    const int half = threadIdx.x / kBlock, tid = threadIdx.x % kBlock, dir = half == 0 ? 1 : -1, ntiles = gridDim.x;
+// is side + beta(this link) + alpha(previous link) — across a block seam the message that enters the tile, none at the head of a
+// path — and the last link of a path also owns its RIGHT variable (side + alpha).  With every reader of factor→variable messages
+// on a chain this replaces the variable phase of the sweep (one launch less; variable→factor messages are then recomputed from
+// the stored messages when somebody asks for them, like in the fused schedule).
+template <int K, int T, bool OWN_CARRY, bool MARG>
+__global__ __launch_bounds__(2 * T) void k_chain_run_apply(ChainArgs A, const Lin *__restrict__ tile_excl, const Lin *__restrict__ run_excl,
+                                                           double2 *__restrict__ f2v, double2 *__restrict__ marg, int marg_form,
+                                                           double2 *__restrict__ chain_v2f, double *__restrict__ split_mean,
+                                                           double *__restrict__ split_prec, const bool store_msgs) {
+    constexpr int kRunTile = K * T;
+    const int half = threadIdx.x / T, tid = threadIdx.x % T, dir = half == 0 ? 1 : -1, ntiles = gridDim.x;
     const int pos = half == 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
     tile_excl += (size_t)half * (ntiles + 1);
-    __shared__ Lin wave_tot[2][kBlock / 64];
-    __shared__ double2 msg_s[MARG ? 2 : 1][MARG ? kTile : 1];      // [0]: alpha by link of the block, [1]: beta
-    __shared__ double2 seam_alpha, seam_beta;
-    Lin own = lin_identity();
+    __shared__ Lin wave_tot[2][T / 64];
+    __shared__ double2 msg_s[MARG ? 2 : 1][MARG ? kRunTile : 1];      // [0]: alpha by link of the block, [1]: beta
+    __shared__ double2 seam[2];                                       // the message that enters the tile: [0] alpha from the left, [1] beta from the right
+    // this thread's run and its prefix within the tile: issued before the carry is worked out
+    LinkIn in[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) in[k] = load_link_in(A, run_link<K, T>(A, blockIdx.x, tid * K + k, dir), dir);
+    const Lin ex = run_excl[((size_t)half * ntiles + pos) * T + tid];
     if (OWN_CARRY) {
-        // totals[0 .. pos) precede this tile in its direction; both halves make the same number of scans (the barrier inside)
-        const int most = max(blockIdx.x, ntiles - 1 - (int)blockIdx.x);
-        for (int chunk = 0; chunk < most; chunk += kTile) {
-            Lin c[kItems];
+        // totals[0 .. pos) precede this tile in its direction: thread t composes the run [t * per, (t + 1) * per) of them in order
+        const int per = (pos + T - 1) / T;
+        if (wid * 64 * per < pos) {            // (a wave whose runs are all empty has nothing to add)
+            const int b = tid * per, e = min(b + per, pos);
+            Lin c = lin_identity();
+            for (int j = b; j < e; j++) c = j == b ? tile_excl[j] : lin_compose(c, tile_excl[j]);
 #pragma unroll
-            for (int k = 0; k < kItems; k++) {
-                const int j = chunk + tid * kItems + k;
-                c[k] = j < pos ? tile_excl[j] : lin_identity();
+            for (int d = 1; d < 64; d <<= 1) {
+                Lin o = lin_shfl_up(c, d);
+                if (lane >= d) c = lin_compose(o, c);
             }
-            Lin tot;
-            tile_scan(c, tot, wave_tot[half], tid);
-            own = lin_compose(own, tot);
+            if (lane == 63) wave_tot[half][wid] = c;
+        } else if (lane == 63) wave_tot[half][wid] = lin_identity();
+        __syncthreads();
+        if (tid == 0) {
+            Lin c = wave_tot[half][0];
+            for (int w = 1; w < T / 64; w++) c = lin_compose(c, wave_tot[half][w]);
+            seam[half] = make_double2(c.g, c.B);      // the carry applied to the empty message
         }
+    } else if (tid == 0) {
+        const Lin c = tile_excl[pos];
+        seam[half] = make_double2(c.g, c.B);
     }
-    Lin x[kItems];
-    int link[kItems];
+    __syncthreads();
+    const int lo = blockIdx.x * kRunTile;
+    double2 m = lin_apply(ex, seam[half]);          // the message into the variable this thread's run starts at
 #pragma unroll
-    for (int k = 0; k < kItems; k++) x[k] = load_link(A, pos, tid * kItems + k, dir, ntiles, &link[k]);
-    Lin tot;
-    tile_scan(x, tot, wave_tot[half], tid);
-    const Lin carry = OWN_CARRY ? own : tile_excl[pos];
-    const int lo = blockIdx.x * kTile;
-#pragma unroll
-    for (int k = 0; k < kItems; k++) {
-        const int l = link[k];
+    for (int k = 0; k < K; k++) {
+        const int l = in[k].link;
         if (l < 0) continue;
-        const Lin p = lin_compose(carry, x[k]);
-        const int recv = dir > 0 ? A.to_slot[l] : A.from_slot[l];
-        const double2 m = make_double2(p.g, p.B);   // the prefix applied to the empty message (0, 0)
-        if (MARG) msg_s[half][l - lo] = m;      // stored below, in link order across the lanes (a thread's own four links are 64 B apart)
-        else if (!__builtin_isnan(m.y)) f2v[recv] = m;
+        if (in[k].seg) m = make_double2(0.0, 0.0);
+        const double2 v = make_double2(m.x + in[k].u.x, m.y + in[k].u.y);
+        const double s = 1.0 / (in[k].a * in[k].a + in[k].q * v.y);
+        m = make_double2((in[k].a * v.x + in[k].b * v.y) * s, v.y * s);
+        if (MARG) msg_s[half][l - lo] = m;      // stored below, in link order across the lanes
+        else if (!__builtin_isnan(m.y)) f2v[in[k].recv] = m;
     }
     if (MARG) {
-        if (threadIdx.x == 0) seam_alpha = make_double2(carry.g, carry.B);      // alpha into the left end of the block's first link
-        if (threadIdx.x == kBlock) seam_beta = make_double2(carry.g, carry.B);  // beta into the right end of the block's last link
         __syncthreads();
-        const int cnt = min(kTile, A.nlinks - lo);
-        for (int j = threadIdx.x; j < cnt; j += kChainThreads) {
+        const double2 seam_alpha = seam[0], seam_beta = seam[1];
+        const int cnt = min(kRunTile, A.nlinks - lo);
+        for (int j = threadIdx.x; j < cnt; j += 2 * T) {
             const int l = lo + j, p = A.link_pos[l];
             const double2 sd = A.side[p], be = msg_s[1][j];
             if (store_msgs) {
@@ -339,49 +405,44 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_apply(ChainArgs A, cons
     }
 }
 
-void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_form, bool chain_v2f) {
-    // marg_form: 0 — messages only (the caller runs the variable phase); 1 / 2 — also the chain variables' marginals, moment / natural;
-    // 3 — as (mean, precision) into h->d_split_mean / d_split_prec;
-    // chain_v2f (with marg_form != 0): also the variable→factor messages of the chain links
-    const int nlinks = (int)h->chain_nlinks, npos = (int)h->chain_npos;
-    if (nlinks == 0) return;
-    const double *pa = h->any_linear ? h->d_a : nullptr, *pb = h->any_linear ? h->d_b : nullptr;
-    // With fused leaves the side sums depend only on stored messages of fixed senders (data, priors) and on the rule
-    // parameters: they are recomputed when one of those changed (cx_set_messages, cx_seed_messages, cx_update_batch, a state
-    // import, a new q table), not on every sweep.
-    if (fused_leaves && !h->chain_side_dirty) {
-        // nothing
-    } else if (fused_leaves)
-        hipLaunchKernelGGL(k_chain_side<true>, dim3((npos + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, npos, h->d_chain_pos_var,
-                           h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, h->d_q_gamma, h->d_q_gmean, pa, pb,
-                           h->d_v2f, f2v, h->d_chain_side);
-    else
-        hipLaunchKernelGGL(k_chain_side<false>, dim3((npos + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, npos, h->d_chain_pos_var,
-                           h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, h->d_q_gamma, h->d_q_gmean, pa, pb,
-                           h->d_v2f, f2v, h->d_chain_side);
-    h->chain_side_dirty = false;
-    ChainArgs A{nlinks, h->d_chain_link_pos, h->d_chain_from, h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd,
-                h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_q_gamma, h->d_q_gmean, h->d_chain_side, h->d_chain_pos_var};
-    const int ntiles = (nlinks + kTile - 1) / kTile;
-    Lin *totals = (Lin *)h->d_chain_totals;
-    hipLaunchKernelGGL(k_chain_tile_totals, dim3(ntiles), dim3(kChainThreads), 0, h->stream, A, totals);
-    const dim3 g(ntiles), b(kChainThreads);
+// the shape of a tile: K links per thread, T threads per direction (CX_CHAIN_SHAPE picks among the instances: lab switch)
+constexpr int kRunTileLinks = 512;        // every instance below has K * T = 512 or a multiple of it
+static int chain_shape() {
+    static const int v = [] { const char *e = getenv("CX_CHAIN_SHAPE"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
+template <int K, int T>
+static void launch_run_totals(cx_handle *h, const ChainArgs &A, int *ntiles_out) {
+    const int ntiles = (A.nlinks + K * T - 1) / (K * T);
+    Lin *totals = (Lin *)h->d_chain_totals, *run_excl = totals + (size_t)2 * (ntiles + 1);
+    hipLaunchKernelGGL((k_chain_run_totals<K, T>), dim3(ntiles), dim3(2 * T), 0, h->stream, A, totals, run_excl);
+    *ntiles_out = ntiles;
+}
+
+template <int K, int T>
+static void launch_run_scan(cx_handle *h, const ChainArgs &A, double2 *f2v, int marg_form, bool chain_v2f) {
+    int ntiles = 0;
+    launch_run_totals<K, T>(h, A, &ntiles);
+    Lin *totals = (Lin *)h->d_chain_totals, *run_excl = totals + (size_t)2 * (ntiles + 1);
+    const dim3 g(ntiles), b(2 * T);
     // CX_CHAIN_OWN_CARRY_TILES: the tile count up to which the apply workgroups compose their own carry (tests set it low to run the
     // one-workgroup scan of the totals on small chains)
     static const int own_carry_tiles = [] { const char *e = getenv("CX_CHAIN_OWN_CARRY_TILES"); return e ? atoi(e) : kOwnCarryTiles; }();
-    if (ntiles > own_carry_tiles) hipLaunchKernelGGL(k_chain_scan_totals, dim3(2), dim3(kBlock), 0, h->stream, ntiles, totals);
+    const bool store = !(h->chain_msgs_unread && marg_form == 3 && chain_v2f);
+    double2 *v2f = chain_v2f ? h->d_v2f : nullptr;
     if (ntiles <= own_carry_tiles) {
-        if (marg_form) hipLaunchKernelGGL((k_chain_apply<true, true>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, marg_form, chain_v2f ? h->d_v2f : nullptr, h->d_split_mean, h->d_split_prec, !(h->chain_msgs_unread && marg_form == 3 && chain_v2f));
-        else hipLaunchKernelGGL((k_chain_apply<true, false>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, 0, (double2 *)nullptr, (double *)nullptr, (double *)nullptr, true);
+        if (marg_form) hipLaunchKernelGGL((k_chain_run_apply<K, T, true, true>), g, b, 0, h->stream, A, totals, run_excl, f2v, h->d_marg, marg_form, v2f, h->d_split_mean, h->d_split_prec, store);
+        else hipLaunchKernelGGL((k_chain_run_apply<K, T, true, false>), g, b, 0, h->stream, A, totals, run_excl, f2v, h->d_marg, 0, (double2 *)nullptr, (double *)nullptr, (double *)nullptr, true);
     } else {
-        if (marg_form) hipLaunchKernelGGL((k_chain_apply<false, true>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, marg_form, chain_v2f ? h->d_v2f : nullptr, h->d_split_mean, h->d_split_prec, !(h->chain_msgs_unread && marg_form == 3 && chain_v2f));
-        else hipLaunchKernelGGL((k_chain_apply<false, false>), g, b, 0, h->stream, A, totals, f2v, h->d_marg, 0, (double2 *)nullptr, (double *)nullptr, (double *)nullptr, true);
+        hipLaunchKernelGGL(k_chain_scan_totals, dim3(2), dim3(kBlock), 0, h->stream, ntiles, totals);
+        if (marg_form) hipLaunchKernelGGL((k_chain_run_apply<K, T, false, true>), g, b, 0, h->stream, A, totals, run_excl, f2v, h->d_marg, marg_form, v2f, h->d_split_mean, h->d_split_prec, store);
+        else hipLaunchKernelGGL((k_chain_run_apply<K, T, false, false>), g, b, 0, h->stream, A, totals, run_excl, f2v, h->d_marg, 0, (double2 *)nullptr, (double *)nullptr, (double *)nullptr, true);
     }
 }
 
-// side sums + tile totals only (the first two stages of a sweep), for cx_chain_block_maps; totals stay un-scanned
-void launch_chain_totals(cx_handle *h, double2 *f2v, bool fused_leaves, int64_t *ntiles_out) {
-    const int nlinks = (int)h->chain_nlinks, npos = (int)h->chain_npos;
+static void launch_chain_side(cx_handle *h, double2 *f2v, bool fused_leaves) {
+    const int npos = (int)h->chain_npos;
     const double *pa = h->any_linear ? h->d_a : nullptr, *pb = h->any_linear ? h->d_b : nullptr;
     if (fused_leaves)
         hipLaunchKernelGGL(k_chain_side<true>, dim3((npos + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, npos, h->d_chain_pos_var,
@@ -391,18 +452,60 @@ void launch_chain_totals(cx_handle *h, double2 *f2v, bool fused_leaves, int64_t 
         hipLaunchKernelGGL(k_chain_side<false>, dim3((npos + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, npos, h->d_chain_pos_var,
                            h->d_chain_skip0, h->d_chain_skip1, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, h->d_q_gamma, h->d_q_gmean, pa, pb,
                            h->d_v2f, f2v, h->d_chain_side);
+}
+
+static ChainArgs chain_args(cx_handle *h) {
+    return ChainArgs{(int)h->chain_nlinks, h->d_chain_link_pos, h->d_chain_from, h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd,
+                     h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_q_gamma, h->d_q_gmean, h->d_chain_side, h->d_chain_pos_var};
+}
+
+// CX_CHAIN_SHAPE, measured on one box (C2 / structured family, us per sweep / iteration): 1 = <4, 256>: 21.0 / 119.7 (the default);
+// 0 = <8, 128>: 23.8 / 144.8; 2 = <8, 256>: 32.7 / 135.3; 3 = <2, 256>: 24.8 / 153.3; 4 = <4, 128>: 21.8 / 148.1 (smaller tiles: more
+// totals for every workgroup's own carry)
+#define CX_CHAIN_SHAPES(CALL)                      \
+    switch (chain_shape()) {                       \
+    case 0: CALL(8, 128); break;                   \
+    case 2: CALL(8, 256); break;                   \
+    case 3: CALL(2, 256); break;                   \
+    case 4: CALL(4, 128); break;                   \
+    default: CALL(4, 256); break;                  \
+    }
+
+void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_form, bool chain_v2f) {
+    // marg_form: 0 — messages only (the caller runs the variable phase); 1 / 2 — also the chain variables' marginals, moment / natural;
+    // 3 — as (mean, precision) into h->d_split_mean / d_split_prec;
+    // chain_v2f (with marg_form != 0): also the variable→factor messages of the chain links
+    if (h->chain_nlinks == 0) return;
+    // With fused leaves the side sums depend only on stored messages of fixed senders (data, priors) and on the rule
+    // parameters: they are recomputed when one of those changed (cx_set_messages, cx_seed_messages, cx_update_batch, a state
+    // import, a new q table), not on every sweep.
+    if (!fused_leaves || h->chain_side_dirty) launch_chain_side(h, f2v, fused_leaves);
+    h->chain_side_dirty = false;
+    const ChainArgs A = chain_args(h);
+#define CX_CALL(K, T) launch_run_scan<K, T>(h, A, f2v, marg_form, chain_v2f)
+    CX_CHAIN_SHAPES(CX_CALL)
+#undef CX_CALL
+}
+
+// side sums + tile totals only (the first two stages of a sweep), for cx_chain_block_maps; totals stay un-scanned
+void launch_chain_totals(cx_handle *h, double2 *f2v, bool fused_leaves, int64_t *ntiles_out) {
+    launch_chain_side(h, f2v, fused_leaves);
     h->chain_side_dirty = true;     // the boundary messages will change before the sweep proper
-    const int ntiles = (nlinks + kTile - 1) / kTile;
+    int ntiles = 0;
+    if (h->chain_nlinks) {
+        const ChainArgs A = chain_args(h);
+#define CX_CALL(K, T) launch_run_totals<K, T>(h, A, &ntiles)
+        CX_CHAIN_SHAPES(CX_CALL)
+#undef CX_CALL
+    }
     *ntiles_out = ntiles;
-    if (nlinks == 0) return;
-    ChainArgs A{nlinks, h->d_chain_link_pos, h->d_chain_from, h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd,
-                h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_q_gamma, h->d_q_gmean, h->d_chain_side, h->d_chain_pos_var};
-    hipLaunchKernelGGL(k_chain_tile_totals, dim3(ntiles), dim3(kChainThreads), 0, h->stream, A, (Lin *)h->d_chain_totals);
 }
 
 size_t chain_total_bytes(int64_t nlinks) {
-    const int64_t ntiles = (nlinks + kTile - 1) / kTile;
-    return (size_t)2 * (ntiles + 1) * sizeof(Lin);     // forward and backward tile totals
+    // forward and backward tile totals, then every thread's exclusive prefix within its tile (sized for the smallest tile and the
+    // widest workgroup of the instances above)
+    const int64_t ntiles = (nlinks + kRunTileLinks - 1) / kRunTileLinks;
+    return (size_t)(2 * (ntiles + 1) + 2 * ntiles * 256) * sizeof(Lin);
 }
 
 }  // namespace cx
