@@ -169,6 +169,7 @@ static int32_t upload_ptab(cx_handle *h) {
     if (h->d_ptab && h->ptab_sets < nsets) { (void)hipFree(h->d_ptab); h->d_ptab = nullptr; }
     if (!h->d_ptab) { int32_t rc = dev_alloc(h, &h->d_ptab, (int64_t)(per * nsets)); if (rc != CX_OK) return rc; h->ptab_sets = nsets; }
     CX_HIP(h, hipMemcpy(h->d_ptab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    h->pot64_fresh = false;
     if (d == 64) {   // the wave-per-message rule kernel reads B transposed (tile rows are its contraction index)
         const size_t dd = (size_t)d * d;
         std::vector<double> bt(2 * (size_t)nsets * dd);

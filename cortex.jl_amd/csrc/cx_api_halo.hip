@@ -16,9 +16,9 @@ int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const
     CX_REQUIRE(h, !h || h->n_kary == 0, CX_ERR_UNSUPPORTED, "halo configuration: partitions are implemented for unary and pairwise factors (this graph has CX_FACTOR_GAUSS_LINEAR_N factors)");
     CX_NOT_VMP(h, "cx_halo_configure");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_configure: no graph");
-    // dim 2..4 under the chain-scan schedule: the lists only name the stand-ins of a time block (cx_chain_block_maps exchanges maps,
+    // dim 2..4 and 64 under the chain-scan schedule: the lists only name the stand-ins of a time block (cx_chain_block_maps exchanges maps,
     // not messages); every other dim > 1 partition uses state halos (cx_halo_configure_state)
-    const bool mv_chain_block = h->cfg.dim >= 2 && h->cfg.dim <= 4 && h->cfg.schedule == CX_SCHED_CHAIN_SCAN;
+    const bool mv_chain_block = ((h->cfg.dim >= 2 && h->cfg.dim <= 4) || h->cfg.dim == 64) && h->cfg.schedule == CX_SCHED_CHAIN_SCAN;
     CX_REQUIRE(h, h->cfg.dim == 1 || mv_chain_block, CX_ERR_UNSUPPORTED, "cx_halo_configure: message halos are implemented for dim == 1 (dim > 1: cx_halo_configure_state, or a chain-scan time block)");
     CX_REQUIRE(h, n_send >= 0 && n_recv >= 0, CX_ERR_INVALID_ARGUMENT, "cx_halo_configure: negative count");
     CX_REQUIRE(h, (n_send == 0 || (sv && sf)) && (n_recv == 0 || (rv && rf)), CX_ERR_INVALID_ARGUMENT, "cx_halo_configure: null argument");
@@ -43,7 +43,7 @@ int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const
         h->ext_halo_buffers = false;
         if (mv_chain_block) {      // no message buffers: the stand-ins are marked, nothing else
             h->send_slots.clear(); h->recv_slots.clear();
-            h->spdir_dirty = true; h->chain_partition = true;
+            h->spdir_dirty = true; h->chain_partition = true; h->work64_dirty = true;
             CX_HIP(h, hipStreamSynchronize(h->stream));
             return CX_OK;
         }

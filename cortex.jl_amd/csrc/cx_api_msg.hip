@@ -144,6 +144,7 @@ int32_t cx_seed_messages(cx_handle *h, int32_t direction, double mean, double va
     if (h->cfg.dim > 1) {
         CX_REQUIRE(h, direction == CX_TO_VARIABLE, CX_ERR_UNSUPPORTED, "cx_seed_messages: dim > 1 seeds factor→variable messages only");
         if (h->cfg.dim == 64) {
+            h->pot64_fresh = false;
             cx::mv64_launch_seed(h, h->d_mv_f2v, mean / variance, 1.0 / variance);
             cx::mv64_launch_seed(h, h->d_mv_f2v_alt, mean / variance, 1.0 / variance);
         } else {

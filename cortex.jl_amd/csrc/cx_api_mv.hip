@@ -74,6 +74,9 @@ int32_t mv64_set_messages(cx_handle *h, int64_t n, const std::vector<int32_t> &i
     const int d = 64, nc = h->nc;
     const int64_t bytes_idx = ((n * 4 + 15) / 16) * 16;
     int32_t rc;
+    // (a partition's time block: the messages that enter it at its two ends are the only ones the fresh potentials do not depend on)
+    for (int64_t i = 0; i < n && h->pot64_fresh; i++)
+        h->pot64_fresh = direction == CX_TO_VARIABLE && std::find(h->pot64_end_slots, h->pot64_end_slots + 6, idx[i]) != h->pot64_end_slots + 6;
     if (form == CX_FORM_POINT) {
         rc = ensure_stage(h, bytes_idx + n * d * 8);
         if (rc != CX_OK) return rc;
@@ -314,6 +317,7 @@ static int32_t mv_chain_sweep(cx_handle *h, int32_t n_sweeps) {
         if (h->point64_dirty) {
             cx::mv64_launch_point(h, (int)h->n_point64, h->d_point64_slots, h->d_mv_f2v, h->d_mv_f2v_alt);
             h->point64_dirty = false;
+            h->pot64_fresh = false;
         }
         for (int32_t s = 0; s < n_sweeps; s++) {
             if ((rc = cx::chain64_sweep(h)) != CX_OK) return rc;
@@ -350,12 +354,70 @@ static int32_t mv_chain_sweep(cx_handle *h, int32_t n_sweeps) {
 //     f(eta, Lambda) = ( c + B (Lambda + P)^-1 (eta + h),  C - B (Lambda + P)^-1 B' );   sides: eta[d] | Lambda packed upper.
 int32_t mv_chain_block_maps(cx_handle *h, double *fwd, double *bwd, double *side_first, double *side_last, int64_t *first_variable_id,
                             int64_t *last_variable_id, int64_t *n_links) {
-    CX_REQUIRE(h, h->cfg.dim <= 4, CX_ERR_UNSUPPORTED, "cx_chain_block_maps: dim 1..4");
+    CX_REQUIRE(h, h->cfg.dim <= 4 || h->cfg.dim == 64, CX_ERR_UNSUPPORTED, "cx_chain_block_maps: dim 1..4 and 64");
     CX_REQUIRE(h, (int64_t)h->psets.size() > h->max_pset, CX_ERR_STATE, "cx_chain_block_maps: a parameter set was never set (cx_set_factor_matrices)");
     int32_t rc = build_chains(h);
     if (rc != CX_OK) return rc;
     CX_REQUIRE(h, h->chain_nlinks >= 1 && h->chain_nlinks == h->chain_npos - 1, CX_ERR_UNSUPPORTED,
                "cx_chain_block_maps: the non-observed variables of this handle must form ONE path of at least two variables (a time block of a chain)");
+    if (h->cfg.dim == 64) {
+        // dim 64 (round 4): the plan of cx_chain64_plan.h with a root — the compose launches leave the ONE potential of the block's two
+        // end variables; forwards it is the map (P + side_first, B, C, h + side_first, c), backwards (C + side_last, B', P, c + side_last, h)
+        // (the same convention as dim 2..4: a direction's map includes the side information of the end it is entered at)
+        const int d = 64, dd = d * d, nt = d * (d + 1) / 2, msg = d + dd;
+        if ((rc = build_work64(h)) != CX_OK) return rc;
+        if (h->point64_dirty) {
+            cx::mv64_launch_point(h, (int)h->n_point64, h->d_point64_slots, h->d_mv_f2v, h->d_mv_f2v_alt);
+            h->point64_dirty = false;
+        }
+        std::vector<double> pot((size_t)4 * dd + 2 * d);
+        int32_t sf[3], sl[3];
+        bool no_root = false;
+        if ((rc = cx::chain64_block_potential(h, pot.data(), sf, sl, &no_root)) != CX_OK) return rc;
+        if (no_root) {      // the plan was built before the handle became a partition's: once more, with a root
+            h->chains_dirty = true;
+            if ((rc = build_chains(h)) != CX_OK) return rc;
+            if ((rc = cx::chain64_block_potential(h, pot.data(), sf, sl, &no_root)) != CX_OK) return rc;
+            CX_REQUIRE(h, !no_root, CX_ERR_STATE, "cx_chain_block_maps: the plan has no root potential");
+        }
+        std::vector<int32_t> idx;
+        for (int k = 0; k < 3; k++) if (sf[k] >= 0) idx.push_back(sf[k]);
+        const size_t nf = idx.size();
+        for (int k = 0; k < 3; k++) if (sl[k] >= 0) idx.push_back(sl[k]);
+        std::vector<double> sm(idx.size() * (size_t)msg), sum((size_t)2 * msg, 0.0);
+        if (!idx.empty() && (rc = mv_get(h, h->d_mv_f2v, h->nslots, idx, CX_FORM_NATURAL, false, sm.data())) != CX_OK) return rc;
+        for (size_t i = 0; i < idx.size(); i++)
+            for (int k = 0; k < msg; k++) sum[(i < nf ? 0 : msg) + k] += sm[i * msg + k];
+        // symmetric matrices travel as their upper 16 x 16 tile blocks (potentials) or whole (messages): read the upper triangle
+        auto up = [&](const double *M, int r, int c) { return r <= c ? M[r * d + c] : M[c * d + r]; };
+        auto pack = [&](double *o, const double *P, const double *B, const double *Cm, const double *hh, const double *cc, const double *side) {
+            int k = 0;
+            for (int r = 0; r < d; r++) for (int c = r; c < d; c++) o[k++] = up(P, r, c) + up(side + d, r, c);
+            std::memcpy(o + nt, B, (size_t)dd * 8);
+            k = nt + dd;
+            for (int r = 0; r < d; r++) for (int c = r; c < d; c++) o[k++] = up(Cm, r, c);
+            for (int r = 0; r < d; r++) o[2 * nt + dd + r] = hh[r] + side[r];
+            std::memcpy(o + 2 * nt + dd + d, cc, (size_t)d * 8);
+        };
+        const double *P = pot.data(), *B = P + dd, *Bt = P + 2 * dd, *Cm = P + 3 * dd, *hh = P + 4 * dd, *cc = hh + d;
+        pack(fwd, P, B, Cm, hh, cc, sum.data());
+        pack(bwd, Cm, Bt, P, cc, hh, sum.data() + msg);
+        for (int e = 0; e < 2; e++) {
+            double *o = e == 0 ? side_first : side_last;
+            const double *sd = sum.data() + (size_t)e * msg;
+            std::memcpy(o, sd, (size_t)d * 8);
+            int k = d;
+            for (int r = 0; r < d; r++) for (int c = r; c < d; c++) o[k++] = up(sd + d, r, c);
+        }
+        int32_t pv[2] = {0, 0};
+        CX_HIP(h, hipMemcpyAsync(&pv[0], h->d_chain_pos_var, 4, hipMemcpyDeviceToHost, h->stream));
+        CX_HIP(h, hipMemcpyAsync(&pv[1], h->d_chain_pos_var + (h->chain_npos - 1), 4, hipMemcpyDeviceToHost, h->stream));
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        if (first_variable_id) *first_variable_id = h->var_ids[pv[0]];
+        if (last_variable_id) *last_variable_id = h->var_ids[pv[1]];
+        if (n_links) *n_links = h->chain_nlinks;
+        return CX_OK;
+    }
     if ((rc = mv_ensure_chain_msgs(h)) != CX_OK) return rc;      // the maps overwrite the stored prefixes of the last sweep
     if ((rc = mv_refresh_spdir(h)) != CX_OK) return rc;
     // the leaf messages and side sums from the data currently on the device (the caller has zeroed the cut messages)
@@ -415,6 +477,7 @@ int32_t mv_ensure_chain_msgs(cx_handle *h) {
 // marginals of dim 64 are computed from the stored messages when they are read (cx_get_marginals), so a marginal item only
 // checks its variable.
 int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
+    h->pot64_fresh = false;
     CX_REQUIRE(h, (int64_t)h->psets.size() > h->max_pset, CX_ERR_STATE, "cx_update_batch: a factor names a parameter set that was never set (cx_set_factor_matrices)");
     for (int64_t i = 0; i <= h->max_pset; i++)
         CX_REQUIRE(h, !h->psets[i].empty(), CX_ERR_STATE, "cx_update_batch: parameter set " + std::to_string(i) + " was never set (cx_set_factor_matrices)");

@@ -125,7 +125,7 @@ int32_t cx_state_export(cx_handle *h, void *buf, int64_t bytes) {
 }
 
 int32_t cx_state_import(cx_handle *h, const void *buf, int64_t bytes) {
-    if (h) { h->chain_side_dirty = true; h->offchain_marg_dirty = true; }
+    if (h) { h->chain_side_dirty = true; h->offchain_marg_dirty = true; h->pot64_fresh = false; }
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_state_import: no graph");
     if (is_vmp(h)) return cx::vmp_state_import(h, buf, bytes);
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_state_import: a cx_sweep_begin is still open");

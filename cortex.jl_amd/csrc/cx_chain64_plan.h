@@ -62,6 +62,8 @@ struct Input {
     int K0 = 0;                         // links per level-0 block (0: chosen from the chain length and `lanes`)
     int fan = 2;                        // potentials per group of the upper levels
     int64_t lanes = 1024;               // waves the composition launch should fill (SIMDs of the device)
+    bool root = false;                  // every path also gets the ONE potential of its two end variables (a time block of a partitioned
+                                        // chain hands it to the other blocks: cx_chain_block_maps); the tree then has a single top segment
 };
 
 struct Plan {
@@ -73,6 +75,8 @@ struct Plan {
     std::vector<Step> steps;
     std::vector<std::vector<Job>> compose_launches, walk_launches;
     int64_t n_compositions = 0, n_rules = 0;     // pairwise compositions / rule applications per sweep (the MFMA work count)
+    std::vector<int64_t> root_pot;               // Input.root: per path, the handle of its whole potential (P part)
+    std::vector<int64_t> end_pos;                // Input.root: per path, its first and last position
 };
 
 namespace detail {
@@ -133,7 +137,7 @@ inline Plan build(const Input &in) {
             const int64_t a = i * p.K0, b = std::min<int64_t>(n, a + p.K0);
             lev[0].push_back(Seg{p0 + a, p0 + b, -1, -1, -1, zero, zero, l0 + a, b - a});
         }
-        while ((int64_t)lev.back().size() > in.fan) {
+        while ((int64_t)lev.back().size() > (in.root ? 1 : in.fan)) {
             const auto &lo = lev.back();
             std::vector<Seg> up;
             for (int64_t i = 0; i < (int64_t)lo.size(); i += in.fan) {
@@ -144,7 +148,7 @@ inline Plan build(const Input &in) {
         }
         const int top = (int)lev.size() - 1;
         max_levels = std::max(max_levels, top + 1);
-        const bool composed = lev[0].size() >= 2;       // a path of ONE block needs no potential at all
+        const bool composed = in.root || lev[0].size() >= 2;       // a path of ONE block needs no potential at all (unless it is asked for)
         if (composed)
             for (auto &L : lev) for (auto &s : L) { s.pot = p.n_pot++; s.ent_f = p.n_ent++; s.ent_b = p.n_ent++; }
         // ---- compose jobs -------------------------------------------------------------------------------------------
@@ -174,6 +178,7 @@ inline Plan build(const Input &in) {
                     p.compose_launches[lv].push_back(j);
                 }
         }
+        if (in.root) { p.root_pot.push_back(pot_part(lev[top][0].pot, 0)); p.end_pos.push_back(p0); p.end_pos.push_back(p0 + n); }
         // ---- walks over potentials: step k applies child k to the message that enters it --------------------------------
         auto fwd_step = [&](const Seg &ch, int64_t dst) {
             Step st{{zero, zero, zero}, pot_part(ch.pot, 0), pot_part(ch.pot, 2), pot_part(ch.pot, 3), pot_part(ch.pot, 4), pot_part(ch.pot, 5), dst, 0};

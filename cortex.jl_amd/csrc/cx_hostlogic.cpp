@@ -20,12 +20,12 @@ extern "C" {
 
 void *cxh_plan64_create(int32_t d, int64_t npos, int64_t nlinks, const int32_t *link_pos, const int32_t *from, const int32_t *to,
                         const int32_t *tab_fwd, const int32_t *tab_bwd, const uint8_t *head_fwd, const uint8_t *head_bwd,
-                        const int32_t *side, int32_t K0, int32_t fan, int64_t lanes, char *err, int32_t errlen) {
+                        const int32_t *side, int32_t K0, int32_t fan, int64_t lanes, int32_t root, char *err, int32_t errlen) {
     try {
         cx::plan64::Input in;
         in.d = d; in.npos = npos; in.nlinks = nlinks; in.link_pos = link_pos; in.from = from; in.to = to;
         in.tab_fwd = tab_fwd; in.tab_bwd = tab_bwd; in.head_fwd = head_fwd; in.head_bwd = head_bwd; in.side = side;
-        in.K0 = K0; in.fan = fan; in.lanes = lanes;
+        in.K0 = K0; in.fan = fan; in.lanes = lanes; in.root = root != 0;
         return new Plan(cx::plan64::build(in));
     } catch (const std::exception &e) {
         if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", e.what());
@@ -36,7 +36,7 @@ void *cxh_plan64_create(int32_t d, int64_t npos, int64_t nlinks, const int32_t *
 void cxh_plan64_destroy(void *p) { delete (Plan *)p; }
 
 // what: 0 n_pot, 1 n_ent, 2 children, 3 steps, 4 compose launches, 5 walk launches, 6 msg, 7 pot, 8 K0, 9 levels,
-//       10 compositions per sweep, 11 rule applications per sweep
+//       10 compositions per sweep, 11 rule applications per sweep, 12 paths with a root potential, 100 + i: root potential of path i
 int64_t cxh_plan64_info(const void *pv, int32_t what) {
     const Plan *p = (const Plan *)pv;
     switch (what) {
@@ -52,7 +52,9 @@ int64_t cxh_plan64_info(const void *pv, int32_t what) {
     case 9: return p->levels;
     case 10: return p->n_compositions;
     case 11: return p->n_rules;
+    case 12: return (int64_t)p->root_pot.size();
     }
+    if (what >= 100 && what - 100 < (int32_t)p->root_pot.size()) return p->root_pot[what - 100];
     return -1;
 }
 

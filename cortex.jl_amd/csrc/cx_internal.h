@@ -62,6 +62,9 @@ struct cx_handle {
     const double *d_q_gmean = nullptr;    //   q = 1 / d_q_gmean[d_q_gamma[slot]] read in place of d_q[slot] (no per-slot table to rewrite per call)
     double *d_split_mean = nullptr, *d_split_prec = nullptr;   // the scan writes (mean, precision) of the chain variables here instead of d_marg
     bool split_marg_written = false;      // ... and did so in the last sweep
+    bool pot64_fresh = false;             // dim 64, a partition's time block: the potentials of the composition tree are those of the data on the device
+                                          // (cx_chain_block_maps just composed them and nothing they read has changed): the next sweep starts at its walks
+    int32_t pot64_end_slots[6] = {-1, -1, -1, -1, -1, -1};      // side slots of the path's two END positions: no composition reads them
     bool chain_msgs_unread = false;       // the owner reads the chain links' variable→factor messages and marginals only: the scan need not store
                                           // the factor→variable messages of the links (nothing of this handle is asked for them)
     double2 *d_f2v = nullptr, *d_v2f = nullptr, *d_marg = nullptr;  // natural-form messages, moment-form marginals
@@ -284,6 +287,7 @@ int32_t chain64_build(cx_handle *h, const std::vector<int32_t> &pos_var, const s
 int32_t chain64_sweep(cx_handle *h);
 void chain64_free(cx_handle *h);
 void chain64_stats(const cx_handle *h, int64_t *out8);
+int32_t chain64_block_potential(cx_handle *h, double *pot, int32_t *side_first3, int32_t *side_last3, bool *no_root);
 // variational families (cx_vmp.hip)
 int32_t vmp_graph_create(cx_handle *h, int64_t ne, const int64_t *edge_var, const int64_t *edge_fac, const int32_t *edge_role,
                          int64_t nf, const int64_t *factor_ids, const int32_t *factor_kind);

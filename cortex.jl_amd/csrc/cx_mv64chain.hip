@@ -514,6 +514,10 @@ struct Chain64 {
     int64_t n_pot = 0, n_ent = 0, n_compositions = 0, n_rules = 0;
     int K0 = 0, fan = 0, levels = 0;
     int64_t bytes = 0;
+    // a time block of a partitioned chain (cx_chain_block_maps): the plan also composes ONE potential per path
+    int n_roots = 0;
+    int64_t root_off = -1;                 // path 0's potential, in doubles from d_pot
+    int32_t side_ends[6] = {-1, -1, -1, -1, -1, -1};      // side slots of path 0's first / last position
 };
 
 void chain64_free(cx_handle *h) {
@@ -537,6 +541,7 @@ int32_t chain64_build(cx_handle *h, const std::vector<int32_t> &pos_var, const s
                       const std::vector<int32_t> &tab_bwd) {
     using cxh::fail;
     chain64_free(h);
+    h->pot64_fresh = false;
     const int64_t npos = (int64_t)pos_var.size(), nlinks = (int64_t)link_pos.size();
     std::vector<int32_t> side((size_t)3 * npos, -1);
     for (int64_t p = 0; p < npos; p++) {
@@ -558,6 +563,7 @@ int32_t chain64_build(cx_handle *h, const std::vector<int32_t> &pos_var, const s
     in.K0 = env_int("CX_MVC64_K", 0);            // links per level-0 block (default: one block per SIMD)
     in.fan = std::max(2, env_int("CX_MVC64_FAN", 2));      // binary tree: the shortest dependent chain above level 0 (fan 2 / 4 / 8: 14.19 / 14.37 / 15.08 ms on C5)
     in.lanes = 4 * (int64_t)ncu;                 // a composition is one wave per SIMD
+    in.root = h->chain_partition;                // a time block hands its whole potential to the other blocks
     p64::Plan plan;
     try { plan = p64::build(in); }
     catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "chain-scan schedule, dim 64: host allocation failed"); }
@@ -567,6 +573,11 @@ int32_t chain64_build(cx_handle *h, const std::vector<int32_t> &pos_var, const s
     h->chain64 = c;
     c->n_pot = plan.n_pot; c->n_ent = plan.n_ent; c->K0 = plan.K0; c->fan = plan.fan; c->levels = plan.levels;
     c->n_compositions = plan.n_compositions; c->n_rules = plan.n_rules;
+    c->n_roots = (int)plan.root_pot.size();
+    if (c->n_roots > 0) {
+        c->root_off = plan.root_pot[0] & p64::kOffMask;
+        for (int k = 0; k < 3; k++) { c->side_ends[k] = side[3 * plan.end_pos[0] + k]; c->side_ends[3 + k] = side[3 * plan.end_pos[1] + k]; }
+    }
     auto &jobs = c->jobs;
     auto longest = [](const std::vector<p64::Job> &L) { int m = 0; for (const auto &j : L) m = std::max(m, (int)j.n); return m; };
     int widest_compose = 1;
@@ -648,10 +659,15 @@ int32_t chain64_sweep(cx_handle *h) {
     }
     std::vector<unsigned long long> hs(st_n);
 #endif
+    // a time block right after cx_chain_block_maps: the potentials are on the device already (what changed since — the messages that
+    // enter the block at its two ends — is side information of END positions, which no composition reads)
+    const bool skip_compose = h->pot64_fresh;
+    h->pot64_fresh = false;
     for (const auto &L : c->launches) {
 #ifdef CX_C64_STAMPS
         (void)hipMemsetAsync(d_st, 0, st_n * 8, h->stream);
 #endif
+        if (L.kind == 0 && skip_compose) continue;
         if (L.kind == 0) {
             hipLaunchKernelGGL(k_compose64p, dim3(L.n), dim3(128), 0, h->stream, L.n, c->d_jobs + L.first, c->d_children, c->d_ring);
         } else if (L.kind == 1) {          // few jobs: a wave alone on its SIMD
@@ -673,6 +689,27 @@ int32_t chain64_sweep(cx_handle *h) {
 #endif
     }
     CX_HIP(h, hipGetLastError());
+    return CX_OK;
+}
+
+// cx_chain_block_maps, dim 64: the compose launches of the plan (no walks), then the ONE potential of the handle's path
+// (P | B | B' | C row-major 64 x 64 — P and C hold their upper 16 x 16 tile blocks only — | h | c) and the side slots of its two ends.
+// *no_root: the plan was built without a root (the caller rebuilds it as a partition's and asks again).
+int32_t chain64_block_potential(cx_handle *h, double *pot, int32_t *side_first3, int32_t *side_last3, bool *no_root) {
+    Chain64 *c = (Chain64 *)h->chain64;
+    if (!c) return cxh::fail(h, CX_ERR_STATE, "chain-scan schedule, dim 64: no plan");
+    *no_root = c->n_roots < 1;
+    if (*no_root) return CX_OK;
+    if (c->n_roots != 1) return cxh::fail(h, CX_ERR_UNSUPPORTED, "cx_chain_block_maps: the non-observed variables of this handle must form ONE path (a time block of a chain)");
+    { int32_t rc = chain64_resolve(h, c); if (rc != CX_OK) return rc; }
+    for (const auto &L : c->launches)
+        if (L.kind == 0) hipLaunchKernelGGL(k_compose64p, dim3(L.n), dim3(128), 0, h->stream, L.n, c->d_jobs + L.first, c->d_children, c->d_ring);
+    CX_HIP(h, hipGetLastError());
+    CX_HIP(h, hipMemcpyAsync(pot, c->d_pot + c->root_off, (size_t)(4 * kD * kD + 2 * kD) * 8, hipMemcpyDeviceToHost, h->stream));
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    for (int k = 0; k < 3; k++) { side_first3[k] = c->side_ends[k]; side_last3[k] = c->side_ends[3 + k]; }
+    for (int k = 0; k < 6; k++) h->pot64_end_slots[k] = c->side_ends[k];
+    h->pot64_fresh = true;
     return CX_OK;
 }
 

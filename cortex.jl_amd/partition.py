@@ -774,16 +774,31 @@ def _mv_map_apply(M, d, eta, lam):
     nt = d * (d + 1) // 2
     P, B, Cm = _mv_sym(M[:nt], d), M[nt:nt + d * d].reshape(d, d), _mv_sym(M[nt + d * d:2 * nt + d * d], d)
     h, c = M[2 * nt + d * d:2 * nt + d * d + d], M[2 * nt + d * d + d:]
-    W = np.linalg.inv(lam + P)
-    return c + B @ W @ (eta + h), Cm - B @ W @ B.T
+    BW = np.linalg.solve(lam + P, B.T).T          # B (Lambda + P)^-1 (the matrix is symmetric)
+    return c + BW @ (eta + h), Cm - BW @ B.T
+
+
+_MV_TABLES = {}
+
+
+def _mv_rule_tables(A, Q, forward):
+    """(P, B, C) of x_out = A x_in + N(0, Q) for the receiving end (csrc/cx_mv_core.h: mv_rule_tables), cached per matrix pair"""
+    key = (A.ctypes.data, Q.ctypes.data, A.shape, bool(forward), float(A[0, 0]), float(Q[0, 0]), float(A[-1, -1]), float(Q[-1, -1]))
+    tab = _MV_TABLES.get(key)
+    if tab is None:
+        Qi = np.linalg.inv(Q)
+        tab = (A.T @ Qi @ A, Qi @ A, Qi) if forward else (Qi, A.T @ Qi, A.T @ Qi @ A)
+        if len(_MV_TABLES) > 64:
+            _MV_TABLES.clear()
+        _MV_TABLES[key] = tab
+    return tab
 
 
 def _mv_rule(eta, lam, A, Q, forward):
     """factor→variable rule of x_out = A x_in + N(0, Q) on a natural-form message (cx_mv.hip): forward = the receiver is the OUT edge"""
-    Qi = np.linalg.inv(Q)
-    P, B, Cm = (A.T @ Qi @ A, Qi @ A, Qi) if forward else (Qi, A.T @ Qi, A.T @ Qi @ A)
-    W = np.linalg.inv(lam + P)
-    return B @ W @ eta, Cm - B @ W @ B.T
+    P, B, Cm = _mv_rule_tables(A, Q, forward)
+    BW = np.linalg.solve(lam + P, B.T).T          # B (Lambda + P)^-1 (the matrix is symmetric)
+    return BW @ eta, Cm - BW @ B.T
 
 
 def _rule_linear(abq, m):
@@ -817,7 +832,8 @@ class ChainScanExchange:
     torch.distributed (or None for world 1).
 
     Scalar chains (additive and — round 3 — linear factors x_out = a x_in + b + noise) and, since round 3, d-dimensional chains (dim 2..4: the maps (P, B, C, h, c) of
-    csrc/cx_mvchain.hip, 2 ND + 2 nc + 4 doubles per rank in the all-gather: 120 for d = 4)."""
+    csrc/cx_mvchain.hip, 2 ND + 2 nc + 4 doubles per rank in the all-gather: 120 for d = 4) and — round 4 — dim 64 (the ONE potential of a
+    block's two end variables out of the composition tree of csrc/cx_mv64chain.hip: 21,060 doubles per rank)."""
 
     def __init__(self, block, part: Partition, dist, torch, device="cpu"):
         self.block, self.part, self.dist, self.torch, self.device = block, part, dist, torch, device
@@ -900,10 +916,15 @@ def _chain_scan_exchange_update_mv(self):
     nt = d * (d + 1) // 2
     nd, ns = 2 * nt + d * d + 2 * d, d + nt
     zero, nan = np.zeros(d + d * d), np.full(d + d * d, np.nan)
+    # dim 64 keeps ONE message buffer and no stored variable→factor messages: what enters a block is handed over as the cut factor's
+    # message INTO the block's end variable (the rule through the cut factor applied here, on the host); dim 2..4 hand over the
+    # stand-in's message into the cut factor and let the device apply the rule
+    after_cut = d == 64
     for rec in (self.left, self.right):
         if rec is not None:      # the cut messages out of the picture: nothing enters, nothing is known about the stand-in
             blk.set_messages([rec[2]], [rec[1]], L.TO_VARIABLE, L.FORM_NATURAL, zero)
-            blk.set_messages([rec[0]], [rec[1]], L.TO_FACTOR, L.FORM_NATURAL, nan)
+            if not after_cut:
+                blk.set_messages([rec[0]], [rec[1]], L.TO_FACTOR, L.FORM_NATURAL, nan)
     fwd, bwd, s_first, s_last, _v0, _v1, _nl = blk.chain_block_maps()
     cuts = [(-1.0, 0.0) if r is None else (float(int(r[3])), 1.0 if r[4] else 0.0) for r in (self.left, self.right)]
     mine = np.concatenate([fwd, bwd, s_first, s_last, cuts[0], cuts[1]])
@@ -943,7 +964,13 @@ def _chain_scan_exchange_update_mv(self):
         se, sl = side(rows[r, 2 * nd:2 * nd + ns])
         out = (e + se, lam + sl)
     for rec, m in ((self.left, left_in), (self.right, right_in)):
-        if rec is not None:
+        if rec is None:
+            continue
+        if after_cut:
+            A, Q = psets[int(rec[3])]
+            m = _mv_rule(m[0], m[1], np.asarray(A, float), np.asarray(Q, float), bool(rec[4]))
+            blk.set_messages([rec[2]], [rec[1]], L.TO_VARIABLE, L.FORM_NATURAL, np.concatenate([m[0], m[1].ravel()]))
+        else:
             blk.set_messages([rec[0]], [rec[1]], L.TO_FACTOR, L.FORM_NATURAL, np.concatenate([m[0], m[1].ravel()]))
     blk.sweep(1)
 

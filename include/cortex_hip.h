@@ -395,7 +395,12 @@ int32_t cx_halo_ipc_set_timeout(cx_handle *h, double seconds);
  * dim 2, 3, 4 (round 3): the same protocol with the maps of csrc/cx_mvchain.hip.  A map is ND = 2 d(d+1)/2 + d^2 + 2 d doubles —
  *   P (packed upper) | B (row-major) | C (packed upper) | h | c  of  f(eta, Lambda) = (c + B (Lambda + P)^-1 (eta + h), C - B (Lambda + P)^-1 B')
  *   — in forward6 / backward6 (ND doubles each); the side sums are eta[d] | Lambda (packed upper) in side_first2 / side_last2.  The
- *   stand-ins of a dim > 1 block are named with cx_halo_configure (recv lists only matter: they mark the stand-in variables). */
+ *   stand-ins of a dim > 1 block are named with cx_halo_configure (recv lists only matter: they mark the stand-in variables).
+ * dim 64 (round 4): the same layout (ND = 8,384, sides 2,144 doubles).  The block's composition tree (csrc/cx_mv64chain.hip) ends in
+ *   ONE potential of its two end variables; the call runs the compose launches and returns it as the two directions' maps.  dim 64
+ *   keeps one message buffer and no variable→factor messages, so the caller hands the boundary over AFTER the cut factor's rule: as
+ *   the cut factor's factor→variable message into the block's end variable (cx_set_messages, CX_TO_VARIABLE).  A cx_sweep that
+ *   follows with nothing but those two messages changed starts from the potentials that are on the device already (its walks only). */
 int32_t cx_chain_block_maps(cx_handle *h, double *forward6, double *backward6, double *side_first2, double *side_last2,
                             int64_t *first_variable_id, int64_t *last_variable_id, int64_t *n_links);
 

@@ -231,7 +231,7 @@ class OracleMvChainBlock:
             elif (a in ghosts) != (b in ghosts):
                 own = b if a in ghosts else a
                 self.cuts[f] = "left" if own == self.x[0] and (n > 1 or a in ghosts) else "right"
-        self.boundary = {}
+        self.boundary, self.after_cut = {}, {}
 
     def halo_configure(self, *a):
         pass
@@ -272,9 +272,11 @@ class OracleMvChainBlock:
     def set_messages(self, var, fac, direction, form, payload):
         from cortex.jl_amd import _lib as L
 
+        p = np.asarray(payload, dtype=float)
         if direction == L.TO_FACTOR:                         # a stand-in's message into its cut factor: the block's boundary input
-            p = np.asarray(payload, dtype=float)
             self.boundary[int(fac[0])] = (p[:self.d], p[self.d:].reshape(self.d, self.d))
+        elif int(fac[0]) in self.cuts:                       # dim 64: the cut factor's message into the block's end variable, rule applied by the sender
+            self.after_cut[int(fac[0])] = (p[:self.d], p[self.d:].reshape(self.d, self.d))
 
     def sweep(self, n=1):
         nx, d = len(self.x), self.d
@@ -282,7 +284,13 @@ class OracleMvChainBlock:
         add = lambda a, b: (a[0] + b[0], a[1] + b[1])        # noqa: E731
         alpha, beta = [zero] * nx, [zero] * nx
         for f, where in self.cuts.items():
-            b = self.boundary.get(f)
+            b, a = self.boundary.get(f), self.after_cut.get(f)
+            if a is not None and (b is None or np.isnan(b[1]).any()):
+                if where == "left":
+                    alpha[0] = a
+                else:
+                    beta[-1] = a
+                continue
             if b is None or np.isnan(b[1]).any():
                 continue
             if where == "left":

@@ -18,7 +18,7 @@ def lib():
         path = os.environ.get("CXH_LIB") or B.build_hostlogic()
         _lib = C.CDLL(path)
         _lib.cxh_plan64_create.restype = C.c_void_p
-        _lib.cxh_plan64_create.argtypes = [C.c_int32, C.c_int64, C.c_int64] + [C.c_void_p] * 8 + [C.c_int32, C.c_int32, C.c_int64, C.c_char_p, C.c_int32]
+        _lib.cxh_plan64_create.argtypes = [C.c_int32, C.c_int64, C.c_int64] + [C.c_void_p] * 8 + [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_char_p, C.c_int32]
         _lib.cxh_plan64_destroy.argtypes = [C.c_void_p]
         _lib.cxh_plan64_info.restype = C.c_int64
         _lib.cxh_plan64_info.argtypes = [C.c_void_p, C.c_int32]
@@ -34,7 +34,7 @@ SPACES = ("zero", "f2v", "ptab", "btab", "pot", "ent")
 class Plan64:
     """the plan of cx_chain64_plan.h as numpy arrays"""
 
-    def __init__(self, d, link_pos, frm, to, tab_fwd, tab_bwd, head_fwd, head_bwd, side, K0=0, fan=4, lanes=1024):
+    def __init__(self, d, link_pos, frm, to, tab_fwd, tab_bwd, head_fwd, head_bwd, side, K0=0, fan=4, lanes=1024, root=False):
         L = lib()
         a32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)
         a8 = lambda x: np.ascontiguousarray(x, dtype=np.uint8)
@@ -43,12 +43,13 @@ class Plan64:
         npos = side.shape[0]
         err = C.create_string_buffer(512)
         p = L.cxh_plan64_create(d, npos, len(link_pos), link_pos.ctypes.data, frm.ctypes.data, to.ctypes.data, tab_fwd.ctypes.data,
-                                tab_bwd.ctypes.data, head_fwd.ctypes.data, head_bwd.ctypes.data, side.ctypes.data, K0, fan, lanes, err, 512)
+                                tab_bwd.ctypes.data, head_fwd.ctypes.data, head_bwd.ctypes.data, side.ctypes.data, K0, fan, lanes, 1 if root else 0, err, 512)
         if not p:
             raise RuntimeError(err.value.decode())
         try:
             info = lambda w: int(L.cxh_plan64_info(p, w))
             self.n_pot, self.n_ent, nch, nst, ncl, nwl, self.msg, self.pot, self.K0, self.levels, self.n_compositions, self.n_rules = (info(w) for w in range(12))
+            self.root_pot = [info(100 + i) for i in range(info(12))]
             self.children = np.zeros((nch, 10), dtype=np.int64)
             self.steps = np.zeros((nst, 10), dtype=np.int64)
             if nch:

@@ -119,9 +119,9 @@ def chain_inputs(lengths, d, seed, extra_side=False):
                 ptab=ptab, btab=btab, y=y, Ri=Ri, prior_prec=prior_prec, prior_eta=prior_eta)
 
 
-def check(lengths, d, K0, fan, seed=1, extra_side=False, lanes=1024):
+def check(lengths, d, K0, fan, seed=1, extra_side=False, lanes=1024, root=False):
     g = chain_inputs(lengths, d, seed, extra_side)
-    plan = Plan64(d, g["link_pos"], g["frm"], g["to"], g["tab_fwd"], g["tab_bwd"], g["head_f"], g["head_b"], g["side"], K0=K0, fan=fan, lanes=lanes)
+    plan = Plan64(d, g["link_pos"], g["frm"], g["to"], g["tab_fwd"], g["tab_bwd"], g["head_f"], g["head_b"], g["side"], K0=K0, fan=fan, lanes=lanes, root=root)
     ar = Arena(plan, g["nslots"], g["ptab"], g["btab"], d)
     f2v = ar.mem["f2v"].reshape(g["nslots"], plan.msg)
     npos, nlinks = g["npos"], g["nlinks"]
@@ -131,6 +131,7 @@ def check(lengths, d, K0, fan, seed=1, extra_side=False, lanes=1024):
     f2v[pr:pr + npos, :d] = g["prior_eta"]
     f2v[pr:pr + npos, d:] = g["prior_prec"].reshape(npos, -1)
     run_plan(plan, ar, np.random.default_rng(seed))
+    plan.arena, plan.inputs = ar, g
     # marginal of every position = its side information + the two chain messages into it
     p = 0
     link = 0
@@ -176,6 +177,50 @@ def test_one_path_every_marginal_exact(T, K0, fan, d):
     assert plan.n_rules >= 2 * n
     if n <= K0:
         assert plan.n_pot == 0 and not any(len(j) for j in plan.compose_launches)      # one block: nothing to compose
+
+
+@pytest.mark.parametrize("T,K0,fan", [(2, 4, 2), (3, 4, 2), (9, 2, 2), (33, 4, 4), (64, 1, 2), (200, 3, 3)])
+def test_root_potential_of_a_time_block(T, K0, fan):
+    """Input.root (cx_chain_block_maps for dim 64: a time block of a partitioned chain): every path also gets the ONE potential of its
+    two end variables with everything between them summed out (interior side information included, the ends' excluded) — checked
+    against the Schur complement of the dense joint precision — and every marginal is still exact."""
+    d = 3
+    plan = check([T, 5], d, K0, fan, seed=T, root=True)
+    g, ar = plan.inputs, plan.arena
+    assert len(plan.root_pot) == 2
+    p0 = 0
+    for i, Tn in enumerate((T, 5)):
+        sp, off = Plan64.split(plan.root_pot[i])
+        assert sp == "pot"
+        rec = ar.mem["pot"][off:off + plan.pot]
+        dd = d * d
+        P, B, Bt, Cm = (rec[k * dd:(k + 1) * dd].reshape(d, d) for k in range(4))
+        h, c = rec[4 * dd:4 * dd + d], rec[4 * dd + d:]
+        # dense joint over the path's variables: transitions + the side information of the INTERIOR positions
+        A, Qi, Ri = g["A"], np.linalg.inv(g["Q"]), g["Ri"]
+        n = Tn * d
+        J, hv = np.zeros((n, n)), np.zeros(n)
+        for t in range(Tn):
+            sl = slice(t * d, (t + 1) * d)
+            if 0 < t < Tn - 1:
+                J[sl, sl] += Ri
+                hv[sl] += Ri @ g["y"][p0 + t]
+            if t + 1 < Tn:
+                s2 = slice((t + 1) * d, (t + 2) * d)
+                J[sl, sl] += A.T @ Qi @ A; J[s2, s2] += Qi; J[s2, sl] -= Qi @ A; J[sl, s2] -= (Qi @ A).T
+        ends = np.r_[0:d, n - d:n]
+        mid = np.arange(d, n - d)
+        if len(mid):
+            W = np.linalg.inv(J[np.ix_(mid, mid)])
+            Je = J[np.ix_(ends, ends)] - J[np.ix_(ends, mid)] @ W @ J[np.ix_(mid, ends)]
+            he = hv[ends] - J[np.ix_(ends, mid)] @ W @ hv[mid]
+        else:
+            Je, he = J, hv
+        # psi = exp(-1/2 xa'P xa - 1/2 xb'C xb + xb'B xa + h'xa + c'xb): the joint precision is [[P, -B'], [-B, C]]
+        assert np.allclose(P, Je[:d, :d], rtol=1e-9, atol=1e-11) and np.allclose(Cm, Je[d:, d:], rtol=1e-9, atol=1e-11)
+        assert np.allclose(B, -Je[d:, :d], rtol=1e-9, atol=1e-11) and np.array_equal(Bt, B.T)
+        assert np.allclose(h, he[:d], rtol=1e-9, atol=1e-11) and np.allclose(c, he[d:], rtol=1e-9, atol=1e-11)
+        p0 += Tn
 
 
 def test_several_paths_of_different_depths_share_the_launches():

@@ -176,11 +176,37 @@ def test_undefined_inputs_leave_the_messages_undefined_and_unsupported_graphs_ar
     with pytest.raises(cx.CortexHipError) as e:
         dev.sweep(1)
     assert e.value.code == L.ERR_UNSUPPORTED
-    # the composed maps of a partitioned chain exist for dim 1..4 only
-    dev2 = _dev(cx.synth.lgssm_chain(5, d=D, seed=3))
-    with pytest.raises(cx.CortexHipError) as e:
-        dev2.chain_block_maps()
-    assert e.value.code == L.ERR_UNSUPPORTED
+
+
+def test_block_potential_of_a_whole_chain(hip_lib):
+    """cx_chain_block_maps for dim 64 (round 4; what a partition's time blocks exchange: tests/test_gpu_partition.py): on a chain that
+    is not cut at all, the forward map applied to the empty message, plus the side information of the last variable, IS that
+    variable's marginal — and the backward map gives the first variable's — in natural form."""
+    from cortex.jl_amd import partition
+
+    T = 9
+    model = cx.synth.lgssm_chain(T, d=D, seed=3)
+    dev = _dev(model)
+    fwd, bwd, s_first, s_last, v0, v1, nl = dev.chain_block_maps()
+    assert (v0, v1, nl) == (int(model.x_ids[0]), int(model.x_ids[-1]), T - 1)
+    em, ecov = exact.lgssm_posterior(model.data_y, model.meta["A"], model.meta["Q"], model.meta["R"])
+    zero = (np.zeros(D), np.zeros((D, D)))
+    for M, side, t in ((fwd, s_last, T - 1), (bwd, s_first, 0)):
+        e, lam = partition._mv_map_apply(M, D, *zero)
+        e, lam = e + side[:D], lam + partition._mv_sym(side[D:], D)
+        cov = np.linalg.inv(lam)
+        assert_close(cov, ecov[t], 1e-9, f"covariance of state {t} from the block potential")
+        assert_close(cov @ e, em[t], 1e-9, f"mean of state {t} from the block potential")
+    dev.sweep(1)          # the sweep after it starts from the potentials that are on the device already
+    _check_exact(dev, model, 1e-9, "sweep after cx_chain_block_maps")
+    dev.set_messages(model.data_var, model.data_fac, L.TO_FACTOR, L.FORM_POINT, model.data_y + 1.0)
+    dev.chain_block_maps()
+    dev.set_messages(model.data_var[:1], model.data_fac[:1], L.TO_FACTOR, L.FORM_POINT, model.data_y[:1])      # ... unless data changed in between
+    dev.sweep(1)
+    y2 = model.data_y + 1.0
+    y2[0] = model.data_y[0]
+    em2, _ = exact.lgssm_posterior(y2, model.meta["A"], model.meta["Q"], model.meta["R"])
+    assert_close(dev.get_marginals(model.x_ids)[:, :D], em2, 1e-9, "new data between the block maps and the sweep")
 
 
 def test_checkpoint_round_trip_under_the_chain_schedule(hip_lib):

@@ -411,11 +411,12 @@ def test_gloo_deep_halo_for_d_dimensional_messages(tmp_path, world, d, depth):
     assert np.array_equal(np.sort(np.concatenate(seen)), np.sort(whole.x_ids))
 
 
-@pytest.mark.parametrize("world,d,T", [(2, 2, 9), (3, 4, 31)])
+@pytest.mark.parametrize("world,d,T", [(2, 2, 9), (3, 4, 31), (2, 64, 7)])
 def test_gloo_chain_scan_partition_for_d_dimensional_chains(tmp_path, world, d, T):
     """SURVEY §8e for d-dimensional chains (round 3): contiguous time blocks, ONE all-gather of the blocks' composed linear-Gaussian
     maps, a local pass (partition.ChainScanExchange over gloo, a numpy block standing in for the dim > 1 chain-scan handle): every
-    rank's marginals are the exact posterior of the WHOLE chain (block-tridiagonal solve)."""
+    rank's marginals are the exact posterior of the WHOLE chain (block-tridiagonal solve).  d = 64 (round 4): the boundary messages are
+    handed over AFTER the cut factor's rule, as the dim 64 handle takes them."""
     from oracle import exact
 
     out = str(tmp_path / "res")
