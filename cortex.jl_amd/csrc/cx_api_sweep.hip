@@ -128,6 +128,46 @@ int32_t build_tree(cx_handle *h) {
         h->d_tree_rec = h->d_tree_kary = nullptr;
         tree_graph_drop(h);
         int32_t rc2;
+        // Heavy paths (cx_tree_plan.h: build_hp; scalar messages): the same exact sweep as O(log n) rounds of scans and item stages.  Taken
+        // when it needs fewer launches than the level schedule's 2 x depth + 1 — chains with side branches, not bushy trees.
+        // CX_TREE_HP=0 / 1: never / whenever the graph allows (A/B, tests).
+        h->tree_hp = false;
+        if (h->cfg.dim == 1 && h->cfg.family != CX_FAMILY_NATURAL2) {
+            const char *hp_e = std::getenv("CX_TREE_HP");
+            const int hp_env = hp_e ? std::atoi(hp_e) : -1;
+            cx::treeplan::HP hp;
+            if (hp_env != 0) {
+                const int32_t rch = cx::treeplan::build_hp(h, hp, terr);
+                if (rch != CX_OK) return fail(h, rch, terr);
+            }
+            if (hp_env != 0 && !hp.link_pos.empty() && (hp_env > 0 || hp.launches < 2 * (int64_t)plan.depth + 1)) {
+                for (void *p : {(void *)h->d_chain_pos_var, (void *)h->d_chain_skip0, (void *)h->d_chain_skip1, (void *)h->d_tree_skip1_down, (void *)h->d_chain_link_pos,
+                                (void *)h->d_chain_from, (void *)h->d_chain_to, (void *)h->d_chain_head_fwd, (void *)h->d_chain_head_bwd, (void *)h->d_chain_side,
+                                h->d_chain_totals}) if (p) (void)hipFree(p);
+                h->d_chain_pos_var = h->d_chain_skip0 = h->d_chain_skip1 = h->d_tree_skip1_down = h->d_chain_link_pos = h->d_chain_from = h->d_chain_to = nullptr;
+                h->d_chain_head_fwd = h->d_chain_head_bwd = nullptr; h->d_chain_side = nullptr; h->d_chain_totals = nullptr;
+                if ((rc2 = dev_upload(h, &h->d_chain_pos_var, hp.pos_var)) != CX_OK) return rc2;
+                if ((rc2 = dev_upload(h, &h->d_chain_skip0, hp.skip0)) != CX_OK) return rc2;
+                if ((rc2 = dev_upload(h, &h->d_chain_skip1, hp.skip1_up)) != CX_OK) return rc2;
+                if ((rc2 = dev_upload(h, &h->d_tree_skip1_down, hp.skip1_down)) != CX_OK) return rc2;
+                if ((rc2 = dev_upload(h, &h->d_chain_link_pos, hp.link_pos)) != CX_OK) return rc2;
+                if ((rc2 = dev_upload(h, &h->d_chain_from, hp.from)) != CX_OK) return rc2;
+                if ((rc2 = dev_upload(h, &h->d_chain_to, hp.to)) != CX_OK) return rc2;
+                if ((rc2 = dev_upload(h, &h->d_chain_head_fwd, hp.head_fwd)) != CX_OK) return rc2;
+                if ((rc2 = dev_upload(h, &h->d_chain_head_bwd, hp.head_bwd)) != CX_OK) return rc2;
+                if ((rc2 = dev_alloc(h, &h->d_chain_side, (int64_t)hp.pos_var.size())) != CX_OK) return rc2;
+                char *tot = nullptr;
+                if ((rc2 = dev_alloc(h, &tot, (int64_t)cx::chain_total_bytes((int64_t)hp.link_pos.size()))) != CX_OK) return rc2;
+                h->d_chain_totals = tot;
+                h->tree_hp = true;
+                h->tree_hp_steps = hp.steps; h->tree_hp_pos_off = hp.pos_off; h->tree_hp_link_off = hp.link_off; h->tree_hp_marginal_stage = hp.marginal_stage;
+                const int64_t hs[4] = {hp.levels, hp.n_paths, hp.n_single, hp.launches};
+                std::memcpy(h->tree_hp_stats, hs, sizeof hs);
+                // the item stages of the heavy-path plan take the place of the level schedule's
+                plan.rec = std::move(hp.rec); plan.stage_off = std::move(hp.stage_off); plan.kary = std::move(hp.kary); plan.kary_off = std::move(hp.kary_off);
+            }
+        }
+        if (!h->tree_hp) std::memset(h->tree_hp_stats, 0, sizeof h->tree_hp_stats);
         // a stage's messages out of factors with more than two edges ride in the same list as its other items (cx_kernels.hip:
         // kItemKaryEntry): one launch per stage
         std::vector<int32_t> rec;
@@ -180,6 +220,24 @@ int32_t build_tree(cx_handle *h) {
 // one exact sweep: every stage in order, on the handle's stream, in place (a stage's items are independent; a stage reads what
 // earlier stages of this sweep and the stored constants left)
 static void tree_issue(cx_handle *h) {
+    if (h->tree_hp) {
+        // heavy paths: item stages and scans in the plan's order.  (The final scans always write marginals — and the links'
+        // variable→factor messages, which no item produces — whatever compute_marginals_in_sweep says; only the stage of the single
+        // variables' marginals is left out then.)
+        for (size_t i = 0; i + 1 < h->tree_hp_steps.size(); i += 2) {
+            const int32_t kind = h->tree_hp_steps[i], idx = h->tree_hp_steps[i + 1];
+            if (kind == 0) {
+                if (idx == h->tree_hp_marginal_stage && h->cfg.compute_marginals_in_sweep == 0) continue;
+                const int64_t n = h->tree_stage_off[idx + 1] - h->tree_stage_off[idx];
+                if (n > 0) cx::launch_batch(h, h->d_tree_rec + 5 * h->tree_stage_off[idx], n);
+            } else {
+                const int64_t p0 = h->tree_hp_pos_off[idx], l0 = h->tree_hp_link_off[idx];
+                cx::launch_chain_scan_range(h, h->d_f2v, p0, h->tree_hp_pos_off[idx + 1] - p0, l0, h->tree_hp_link_off[idx + 1] - l0,
+                                            kind == 1 ? h->d_chain_skip1 : h->d_tree_skip1_down, kind == 2);
+            }
+        }
+        return;
+    }
     size_t ns = h->tree_stage_off.empty() ? 0 : h->tree_stage_off.size() - 1;
     if (ns > 0 && h->cfg.compute_marginals_in_sweep == 0 && h->cfg.dim != 64) ns--;      // the last stage is the marginals (the flag is fixed per handle)
     // CX_TREE_RUNS=0: every stage a launch of its own (A/B)
@@ -374,6 +432,12 @@ int32_t cx_chain_block_maps(cx_handle *h, double *fwd6, double *bwd6, double *si
 int32_t cx_tree_plan_stats(const cx_handle *h, int64_t *out8) {
     CX_REQUIRE(const_cast<cx_handle *>(h), h && out8, CX_ERR_INVALID_ARGUMENT, "cx_tree_plan_stats: null argument");
     for (int i = 0; i < 8; i++) out8[i] = h->tree_dirty ? 0 : h->tree_stats[i];
+    return CX_OK;
+}
+
+int32_t cx_tree_heavy_path_stats(const cx_handle *h, int64_t *out4) {
+    CX_REQUIRE(const_cast<cx_handle *>(h), h && out4, CX_ERR_INVALID_ARGUMENT, "cx_tree_heavy_path_stats: null argument");
+    for (int i = 0; i < 4; i++) out4[i] = (h->tree_dirty || !h->tree_hp) ? 0 : h->tree_hp_stats[i];
     return CX_OK;
 }
 

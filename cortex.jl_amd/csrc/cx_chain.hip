@@ -487,6 +487,25 @@ void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_f
 #undef CX_CALL
 }
 
+// CX_SCHED_TREE over heavy paths (cx_tree_plan.h: build_hp): the scan of ONE light depth — positions [pos_lo, pos_lo + npos) and links
+// [link_lo, link_lo + nlinks) of the plan's arrays, which live in the handle's chain fields.  `skip1`: the second skipped slot of every
+// position (on the way up a head also skips its slot towards its parent).  final: both directions are exact — marginals of the
+// positions and the variable→factor messages of the links are written as well; otherwise messages only.
+void launch_chain_scan_range(cx_handle *h, double2 *f2v, int64_t pos_lo, int64_t npos, int64_t link_lo, int64_t nlinks, const int32_t *skip1, bool final) {
+    if (nlinks <= 0 || npos <= 0) return;
+    const double *pa = h->any_linear ? h->d_a : nullptr, *pb = h->any_linear ? h->d_b : nullptr;
+    hipLaunchKernelGGL(k_chain_side<false>, dim3((unsigned)((npos + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, (int)npos, h->d_chain_pos_var + pos_lo,
+                       h->d_chain_skip0 + pos_lo, skip1 + pos_lo, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, h->d_q_gamma, h->d_q_gmean, pa, pb,
+                       h->d_v2f, f2v, h->d_chain_side + pos_lo);
+    // the link arrays start at this depth's first link; positions stay global (link_pos, side and pos_var are indexed by them)
+    const ChainArgs A{(int)nlinks, h->d_chain_link_pos + link_lo, h->d_chain_from + link_lo, h->d_chain_to + link_lo, h->d_chain_head_fwd + link_lo,
+                      h->d_chain_head_bwd + link_lo, h->d_q, pa, pb, h->d_q_gamma, h->d_q_gmean, h->d_chain_side, h->d_chain_pos_var};
+    const int form = final ? (h->cfg.family == CX_FAMILY_NATURAL2 ? 2 : 1) : 0;
+#define CX_CALL(K, T) launch_run_scan<K, T>(h, A, f2v, form, final)
+    CX_CHAIN_SHAPES(CX_CALL)
+#undef CX_CALL
+}
+
 // side sums + tile totals only (the first two stages of a sweep), for cx_chain_block_maps; totals stay un-scanned
 void launch_chain_totals(cx_handle *h, double2 *f2v, bool fused_leaves, int64_t *ntiles_out) {
     launch_chain_side(h, f2v, fused_leaves);

@@ -97,6 +97,7 @@ struct HostGraph {                       // the host fields of cx_handle that cx
     cx::flat::Out fo;
     cx::chains::Out co;
     cx::treeplan::Out to;
+    cx::treeplan::HP hp;
     std::string err;
 };
 
@@ -144,6 +145,16 @@ int32_t cxh_flat_tree(void *p, char *err, int32_t errlen) {
     return rc;
 }
 
+// the same sweep over heavy paths (cx_tree_plan.h: build_hp)
+int32_t cxh_flat_tree_hp(void *p, char *err, int32_t errlen) {
+    HostGraph *g = (HostGraph *)p;
+    std::string e;
+    int32_t rc;
+    try { rc = cx::treeplan::build_hp(g, g->hp, e); } catch (const std::exception &x) { rc = CX_ERR_INVALID_ARGUMENT; e = x.what(); }
+    if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", e.c_str());
+    return rc;
+}
+
 // deep halo: layers by variable id (others 0), then the send list as slots; fills trim_lo / trim_hi / own and quiet runs
 int32_t cxh_flat_halo(void *p, int64_t n, const int64_t *variable_ids, const int32_t *layer, int32_t depth, int64_t n_send, const int32_t *send_slots) {
     HostGraph *g = (HostGraph *)p;
@@ -163,6 +174,8 @@ int32_t cxh_flat_halo(void *p, int64_t n, const int64_t *variable_ids, const int
 //   0 var_ids 1 var_off 2 edge_var 3 edge_fac_id 4 vbase 5 vinfo 6 slice_off 7 partner 8 big_vars 9 spdir 10 var_deg
 //   20 q 21 a 22 b 23 sq 24 sa 25 sb 26 kary_coef 27 kary_qb          30 kary_slot 31 slot_kary
 //   60 tree items (5 per item) 61 tree stage offsets 62 tree k-ary entries 63 their stage offsets 64 partner 65 slot_kary 66 kary_slot
+//   70.. heavy-path plan: 70 items 71 stage offsets 72 k-ary entries 73 their offsets 74 pos_var 75 skip0 76 skip1_up 77 skip1_down 78 link_pos 79 from 80 to
+//        81 head_fwd 82 head_bwd 83 pos_off 84 link_off 85 steps
 //   40 pos_var 41 skip0 42 skip1 43 link_pos 44 from 45 to 46 head_fwd 47 head_bwd 48 tab_fwd 49 tab_bwd 50 trim_lo 51 trim_hi
 int64_t cxh_flat_array(const void *p, int32_t which, void *out) {
     const HostGraph *g = (const HostGraph *)p;
@@ -181,17 +194,23 @@ int64_t cxh_flat_array(const void *p, int32_t which, void *out) {
     case 50: return ints(g->trim_lo); case 51: return ints(g->trim_hi);
     case 60: return ints(g->to.rec); case 61: return ints(g->to.stage_off); case 62: return ints(g->to.kary); case 63: return ints(g->to.kary_off);
     case 64: return ints(g->partner); case 65: return ints(g->slot_kary); case 66: return ints(g->kary_slot);
+    case 70: return ints(g->hp.rec); case 71: return ints(g->hp.stage_off); case 72: return ints(g->hp.kary); case 73: return ints(g->hp.kary_off);
+    case 74: return ints(g->hp.pos_var); case 75: return ints(g->hp.skip0); case 76: return ints(g->hp.skip1_up); case 77: return ints(g->hp.skip1_down);
+    case 78: return ints(g->hp.link_pos); case 79: return ints(g->hp.from); case 80: return ints(g->hp.to); case 81: return ints(g->hp.head_fwd);
+    case 82: return ints(g->hp.head_bwd); case 83: return ints(g->hp.pos_off); case 84: return ints(g->hp.link_off); case 85: return ints(g->hp.steps);
     }
     return -1;
 }
 
 // scalars: 0 nv 1 nf 2 ne 3 nslots 4 nslices 5 n_messages_per_sweep 6 any_linear 7 n_kary 8 big_start 9 npos_linked 10 own_slice_lo 11 own_slice_hi
 //          12 ipc_quiet_lo 13 ipc_quiet_hi 14 tree depth 15 tree components 16 messages up 17 messages down 18 marginals
+//          19 heavy-path plan: light depths 20 paths 21 variables on no path 22 launches per sweep 23 the marginal stage
 int64_t cxh_flat_scalar(const void *p, int32_t which) {
     const HostGraph *g = (const HostGraph *)p;
     const int64_t v[] = {g->nv, g->nf, g->ne, g->nslots, g->nslices, g->n_messages_per_sweep, g->any_linear ? 1 : 0, g->n_kary, g->big_start, g->co.npos_linked,
-                         g->own_slice_lo, g->own_slice_hi, g->ipc_quiet_lo, g->ipc_quiet_hi, g->to.depth, g->to.n_components, g->to.n_up, g->to.n_down, g->to.n_marginals};
-    return which >= 0 && which < 19 ? v[which] : -1;
+                         g->own_slice_lo, g->own_slice_hi, g->ipc_quiet_lo, g->ipc_quiet_hi, g->to.depth, g->to.n_components, g->to.n_up, g->to.n_down, g->to.n_marginals,
+                         g->hp.levels, g->hp.n_paths, g->hp.n_single, g->hp.launches, g->hp.marginal_stage};
+    return which >= 0 && which < 24 ? v[which] : -1;
 }
 
 }  // extern "C"

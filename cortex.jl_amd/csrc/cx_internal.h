@@ -117,6 +117,14 @@ struct cx_handle {
     hipStream_t tree_capture_stream = nullptr;      //  the host's launch rate); captured on a stream of the handle's own, launched on the caller's
     bool tree_graph_failed = false;        // capture or instantiation refused once: plain launches from then on
     int64_t tree_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // depth, stages, items, k-ary entries, components, up, down, marginals
+    // the same sweep over heavy paths (cx_tree_plan.h: build_hp), chosen when it takes fewer launches: the paths' arrays live in the chain
+    // fields (d_chain_pos_var .. d_chain_totals; d_chain_skip1 is the way up's), item stages in d_tree_rec as before
+    bool tree_hp = false;
+    int32_t *d_tree_skip1_down = nullptr;
+    std::vector<int32_t> tree_hp_steps;            // pairs (kind, index): 0 item stage, 1 scan of a light depth on the way up, 2 its final scan
+    std::vector<int64_t> tree_hp_pos_off, tree_hp_link_off;
+    int32_t tree_hp_marginal_stage = -1;
+    int64_t tree_hp_stats[4] = {0, 0, 0, 0};       // light depths, paths of two or more, variables on no such path, launches per sweep
     int64_t chain_npos = 0, chain_nlinks = 0;
     int64_t chain_npos_linked = 0;   // dim > 1: positions [0, this) belong to paths with links; the isolated ones follow
     bool chain_side_dirty = true;    // the leaf messages / side sums of the chain positions must be recomputed (data or rule parameters changed)
@@ -241,6 +249,7 @@ void launch_kary_items(cx_handle *h, const int32_t *d_entries, int64_t n);
 void launch_residual(cx_handle *h, const double2 *cur, const double2 *prev, int64_t n, double *d_out);
 void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_form, bool chain_v2f);
 void launch_chain_totals(cx_handle *h, double2 *f2v, bool fused_leaves, int64_t *ntiles_out);
+void launch_chain_scan_range(cx_handle *h, double2 *f2v, int64_t pos_lo, int64_t npos, int64_t link_lo, int64_t nlinks, const int32_t *skip1, bool final);
 // two sweeps per launch (cx_tiles.hip)
 bool tiles_build(cx_handle *h, std::string &why);
 bool tiles_prepare_kernel(cx_handle *h);

@@ -35,27 +35,39 @@ struct Out {
 
 using flat::fail_;
 
+// the forest of non-observed variables, rooted: shared by the level schedule below and the heavy-path schedule further down
+struct Rooted {
+    std::vector<int32_t> efac, foff, fedge;          // factor index of every edge; factor -> its edges
+    std::vector<int32_t> level, parent_edge;         // per node (variable v -> v, factor f -> nv + f): -1 = not in the forest; the edge that leads to the parent (-1: root)
+    std::vector<int32_t> members;                    // nodes of all components in breadth-first order (parents before children)
+    std::vector<int32_t> ffree;                      // free variables a factor touches
+    int32_t depth = 0;
+    int64_t n_components = 0;
+};
+
 template <class H>
-int32_t build(const H *h, Out &out, std::string &err) {
+int32_t root_forest(const H *h, Rooted &R, std::string &err) {
     const int64_t nv = h->nv, nf = h->nf, ne = h->ne;
-    out = Out();
+    R = Rooted();
+    auto &efac = R.efac; auto &foff = R.foff; auto &fedge = R.fedge; auto &level = R.level; auto &parent_edge = R.parent_edge; auto &members = R.members;
     // factor index of every edge, factor CSR
-    std::vector<int32_t> efac(ne);
+    efac.resize(ne);
     for (int64_t e = 0; e < ne; e++) {
         auto it = std::lower_bound(h->fac_ids.begin(), h->fac_ids.end(), h->edge_fac_id[e]);
         if (it == h->fac_ids.end() || *it != h->edge_fac_id[e]) return fail_(err, CX_ERR_STATE, "tree schedule: edge names an unknown factor");
         efac[e] = (int32_t)(it - h->fac_ids.begin());
     }
-    std::vector<int32_t> foff(nf + 1, 0);
+    foff.assign(nf + 1, 0);
     for (int64_t e = 0; e < ne; e++) foff[efac[e] + 1]++;
     for (int64_t f = 0; f < nf; f++) foff[f + 1] += foff[f];
-    std::vector<int32_t> fedge(ne), fill(foff.begin(), foff.end() - 1);
+    fedge.resize(ne);
+    std::vector<int32_t> fill(foff.begin(), foff.end() - 1);
     for (int64_t e = 0; e < ne; e++) fedge[fill[efac[e]]++] = (int32_t)e;
     auto is_free = [&](int32_t v) { return !(h->vinfo[v] & (kClamped | kGhost)); };
     auto vdeg = [&](int32_t v) { return h->var_off[v + 1] - h->var_off[v]; };
     // nodes: variable v -> v, factor f -> nv + f.  Only free variables and the factors they touch take part.
     const int64_t nn = nv + nf;
-    std::vector<int32_t> level(nn, -1), parent_edge(nn, -1), comp_of;      // parent_edge: the edge that leads to the parent (-1: root)
+    level.assign(nn, -1); parent_edge.assign(nn, -1);
     std::vector<int32_t> queue;
     queue.reserve(nn);
     // breadth-first search from `start` over the free part; fills level / parent_edge for the nodes it reaches when `keep`, returns
@@ -95,7 +107,6 @@ int32_t build(const H *h, Out &out, std::string &err) {
         }
         return last;
     };
-    std::vector<int32_t> members;       // nodes of all components, in final breadth-first order (parents before children)
     members.reserve(nn);
     for (int64_t v0 = 0; v0 < nv; v0++) {
         if (!is_free((int32_t)v0) || level[v0] >= 0 || vdeg((int32_t)v0) == 0) continue;
@@ -112,12 +123,27 @@ int32_t build(const H *h, Out &out, std::string &err) {
         }
         if (c >= nv) { const int32_t e = tmp_parent[c]; c = e >= 0 ? h->edge_var[e] : (int32_t)v0; }
         (void)bfs(c, cycle);
-        for (int32_t n : queue) { level[n] = tmp_level[n]; parent_edge[n] = tmp_parent[n]; members.push_back(n); out.depth = std::max(out.depth, tmp_level[n]); }
-        out.n_components++;
+        for (int32_t n : queue) { level[n] = tmp_level[n]; parent_edge[n] = tmp_parent[n]; members.push_back(n); R.depth = std::max(R.depth, tmp_level[n]); }
+        R.n_components++;
     }
     // how many free variables a factor touches (a variable→factor message towards a factor with a single free variable has no reader)
-    std::vector<int32_t> ffree(nf, 0);
-    for (int64_t e = 0; e < ne; e++) if (is_free(h->edge_var[e])) ffree[efac[e]]++;
+    R.ffree.assign(nf, 0);
+    for (int64_t e = 0; e < ne; e++) if (is_free(h->edge_var[e])) R.ffree[efac[e]]++;
+    return CX_OK;
+}
+
+template <class H>
+int32_t build(const H *h, Out &out, std::string &err) {
+    const int64_t nv = h->nv, nf = h->nf;
+    out = Out();
+    Rooted R;
+    { const int32_t rc = root_forest(h, R, err); if (rc != CX_OK) return rc; }
+    const auto &efac = R.efac; const auto &foff = R.foff; const auto &fedge = R.fedge; const auto &level = R.level; const auto &parent_edge = R.parent_edge;
+    const auto &members = R.members; const auto &ffree = R.ffree;
+    out.depth = R.depth; out.n_components = R.n_components;
+    auto is_free = [&](int32_t v) { return !(h->vinfo[v] & (kClamped | kGhost)); };
+    auto vdeg = [&](int32_t v) { return h->var_off[v + 1] - h->var_off[v]; };
+    (void)nf;
     // stages: up (levels depth .. 1), down (levels 0 .. depth - 1), marginals
     const int32_t D = out.depth, nstages = 2 * D + 1;
     std::vector<std::vector<int32_t>> items(nstages), kents(nstages);
@@ -167,6 +193,186 @@ int32_t build(const H *h, Out &out, std::string &err) {
         out.stage_off.push_back((int64_t)out.rec.size() / 5);
         out.kary_off.push_back((int64_t)out.kary.size());
     }
+    return CX_OK;
+}
+
+// ---- heavy paths: the same exact sweep in O(log n) rounds of launches instead of one per level -------------------------------------
+// The level schedule pays two launches per level of the tree: a chain with side branches (a state-space model whose states carry a
+// latent layer of their own: depth ~ T) costs ~ 2 T launches.  Here every variable picks its HEAVY child — the child with the largest
+// subtree among those it reaches through a two-edge factor — and the heavy edges form disjoint paths; any root-to-leaf walk leaves a
+// path (takes a LIGHT edge) at most log2(n) times.  The paths of one light depth are independent of each other and are what the
+// chain-scan schedule handles: ONE segmented scan per light depth and direction (cx_chain.hip: side sums, tile totals, walks) computes
+// every message along them, whatever their length; the light edges — from a path's head to the variable above it, factors with more
+// than two edges, paths of a single variable — stay batch items as in the level schedule.  A sweep, with Lmax the largest light depth:
+//   up    for l = Lmax + 1 .. 1:   [scan of the paths of depth l towards their heads: the message that leaves each head upwards is
+//                                   complete because everything below the path is]
+//                                  [items A: head (or single variable) of depth l -> its parent factor]
+//                                  [items B: light factors below the variables of depth l - 1 -> those variables]
+//   down  for l = 0 .. Lmax:       [items C: variables of depth l - 1 -> their light factors]   [items D: those factors -> the heads of depth l]
+//                                  [scan of the paths of depth l, final: both directions exact, marginals written]
+//   last  marginals of the variables that are on no path of two or more
+// Exactness: every message is computed once from final inputs, as in the level schedule (the up scan's messages AWAY from the heads lack
+// what comes from above and are overwritten by the down scan before anything reads them).
+struct HP {
+    std::vector<int32_t> rec;            // item stages, as in Out
+    std::vector<int64_t> stage_off;
+    std::vector<int32_t> kary;
+    std::vector<int64_t> kary_off;
+    // every path of two or more variables, the light depths one after the other; positions run from the head (nearest the root) to the
+    // tail, links likewise — the arrays of cx_chains.h, with the head's slot towards its parent as a second skipped slot on the way up
+    std::vector<int32_t> pos_var, skip0, skip1_up, skip1_down, link_pos, from, to;
+    std::vector<uint8_t> head_fwd, head_bwd;
+    std::vector<int64_t> pos_off, link_off;      // per light depth, levels + 1 entries
+    std::vector<int32_t> steps;                  // pairs (kind, index): 0 item stage, 1 scan of depth `index` on the way up (messages only), 2 the final scan of depth `index`
+    int32_t levels = 0, depth = 0, marginal_stage = -1;
+    int64_t n_components = 0, n_paths = 0, n_single = 0, launches = 0;
+};
+
+template <class H>
+int32_t build_hp(const H *h, HP &out, std::string &err) {
+    const int64_t nv = h->nv;
+    out = HP();
+    Rooted R;
+    { const int32_t rc = root_forest(h, R, err); if (rc != CX_OK) return rc; }
+    const auto &efac = R.efac; const auto &foff = R.foff; const auto &fedge = R.fedge; const auto &level = R.level; const auto &parent_edge = R.parent_edge;
+    const auto &members = R.members; const auto &ffree = R.ffree;
+    out.depth = R.depth; out.n_components = R.n_components;
+    auto is_free = [&](int32_t v) { return !(h->vinfo[v] & (kClamped | kGhost)); };
+    auto vdeg = [&](int32_t v) { return h->var_off[v + 1] - h->var_off[v]; };
+    auto parent_of = [&](int32_t n) { const int32_t e = parent_edge[n]; return e < 0 ? -1 : (n < nv ? (int32_t)nv + efac[e] : h->edge_var[e]); };
+    auto slot = [&](int32_t e) { return flat::slot_of_edge_t(h, e); };
+    const int64_t nn = nv + h->nf;
+    // subtree sizes (free variables), children before parents
+    std::vector<int64_t> sz(nn, 0);
+    for (int32_t n : members) if (n < nv) sz[n] = 1;
+    for (size_t i = members.size(); i-- > 0;) { const int32_t n = members[i], p = parent_of(n); if (p >= 0) sz[p] += sz[n]; }
+    // heavy child: through a two-edge factor with a rule of its own (partner slot), into a variable that sends (degree >= 2)
+    std::vector<int32_t> heavy(nv, -1), hfac(nv, -1);
+    for (int32_t n : members) {
+        if (n < nv) continue;
+        const int32_t f = n - (int32_t)nv, ev = parent_edge[n];
+        if (ev < 0 || foff[f + 1] - foff[f] != 2) continue;
+        const int32_t ec = fedge[foff[f]] == ev ? fedge[foff[f] + 1] : fedge[foff[f]];
+        const int32_t v = h->edge_var[ev], c = h->edge_var[ec];
+        if (!is_free(c) || vdeg(c) < 2 || level[c] != level[n] + 1 || parent_edge[c] != ec) continue;
+        if (h->partner[slot(ev)] < 0 || (!h->slot_kary.empty() && h->slot_kary[slot(ev)] >= 0)) continue;
+        if (heavy[v] < 0 || sz[c] > sz[heavy[v]]) { heavy[v] = c; hfac[v] = f; }
+    }
+    // light depth of every variable; heads
+    std::vector<int32_t> ld(nv, -1);
+    std::vector<uint8_t> is_head(nv, 0);
+    int32_t lmax = 0;
+    for (int32_t n : members) {
+        if (n >= nv) continue;
+        const int32_t pf = parent_of(n);
+        if (pf < 0) { ld[n] = 0; is_head[n] = 1; continue; }
+        const int32_t v = parent_of(pf);
+        const bool on = heavy[v] == n;
+        ld[n] = ld[v] + (on ? 0 : 1);
+        is_head[n] = on ? 0 : 1;
+        lmax = std::max(lmax, ld[n]);
+    }
+    out.levels = lmax + 1;
+    // paths by light depth
+    std::vector<std::vector<int32_t>> heads(lmax + 1);
+    std::vector<uint8_t> on_path(nv, 0);
+    for (int32_t n : members) if (n < nv && is_head[n] && heavy[n] >= 0) heads[ld[n]].push_back(n);
+    out.pos_off.assign(1, 0); out.link_off.assign(1, 0);
+    for (int32_t L = 0; L <= lmax; L++) {
+        for (int32_t hd : heads[L]) {
+            out.n_paths++;
+            int32_t v = hd, prev_to = -1;
+            while (true) {
+                on_path[v] = 1;
+                const int32_t c = heavy[v];
+                const int32_t s_next = c >= 0 ? slot(parent_edge[nv + hfac[v]]) : -1;
+                out.pos_var.push_back(v);
+                if (v == hd) {
+                    out.skip0.push_back(s_next);
+                    out.skip1_down.push_back(-1);
+                    out.skip1_up.push_back(parent_edge[v] >= 0 ? slot(parent_edge[v]) : -1);
+                } else {
+                    out.skip0.push_back(prev_to);
+                    out.skip1_down.push_back(s_next);
+                    out.skip1_up.push_back(s_next);
+                }
+                if (c < 0) break;
+                out.link_pos.push_back((int32_t)out.pos_var.size() - 1);
+                out.from.push_back(s_next);
+                prev_to = slot(parent_edge[c]);
+                out.to.push_back(prev_to);
+                out.head_fwd.push_back(v == hd ? 1 : 0);
+                out.head_bwd.push_back(heavy[c] < 0 ? 1 : 0);
+                v = c;
+            }
+        }
+        out.pos_off.push_back((int64_t)out.pos_var.size());
+        out.link_off.push_back((int64_t)out.link_pos.size());
+    }
+    // light factors by the depth of what hangs below them (= depth of the variable above + 1)
+    std::vector<std::vector<int32_t>> lfac(lmax + 2);
+    for (int32_t n : members) {
+        if (n < nv) continue;
+        const int32_t f = n - (int32_t)nv, v = parent_of(n);
+        if (v < 0 || hfac[v] == f) continue;
+        lfac[ld[v] + 1].push_back(f);
+    }
+    std::vector<std::vector<int32_t>> hv(lmax + 1);      // heads and single variables by depth (those with a parent)
+    for (int32_t n : members) if (n < nv && is_head[n] && parent_edge[n] >= 0) hv[ld[n]].push_back(n);
+    // ---- stages -------------------------------------------------------------------------------------------------------------------
+    std::vector<int32_t> cur, curk;
+    auto push_item = [&](int32_t kind, int32_t sl, int32_t var) { cur.push_back(kind); cur.push_back(sl); cur.push_back(var); cur.push_back(0); cur.push_back(0); };
+    auto m2v = [&](int32_t e) {
+        const int32_t sl = slot(e);
+        if (!h->slot_kary.empty() && h->slot_kary[sl] >= 0) curk.push_back(h->slot_kary[sl]);
+        else if (h->partner[sl] >= 0) push_item(CX_ITEM_MESSAGE_TO_VARIABLE, sl, h->edge_var[e]);
+    };
+    auto m2f = [&](int32_t e) {
+        const int32_t v = h->edge_var[e];
+        if (vdeg(v) < 2 || ffree[efac[e]] < 2) return;
+        push_item(CX_ITEM_MESSAGE_TO_FACTOR, slot(e), v);
+    };
+    out.stage_off.assign(1, 0); out.kary_off.assign(1, 0);
+    auto close_stage = [&]() -> bool {
+        if (cur.empty() && curk.empty()) return false;
+        out.rec.insert(out.rec.end(), cur.begin(), cur.end());
+        out.kary.insert(out.kary.end(), curk.begin(), curk.end());
+        out.stage_off.push_back((int64_t)out.rec.size() / 5);
+        out.kary_off.push_back((int64_t)out.kary.size());
+        out.steps.push_back(0); out.steps.push_back((int32_t)out.stage_off.size() - 2);
+        out.launches += 1 + (curk.empty() || cur.empty() ? 0 : 1);
+        cur.clear(); curk.clear();
+        return true;
+    };
+    auto scan = [&](int32_t kind, int32_t L) {
+        if (out.link_off[L + 1] == out.link_off[L]) return;
+        out.steps.push_back(kind); out.steps.push_back(L);
+        out.launches += 3;
+    };
+    for (int32_t l = lmax + 1; l >= 1; l--) {
+        if (l <= lmax) {
+            scan(1, l);
+            for (int32_t c : hv[l]) m2f(parent_edge[c]);
+            close_stage();
+        }
+        for (int32_t f : lfac[l]) m2v(parent_edge[nv + f]);
+        close_stage();
+    }
+    for (int32_t l = 0; l <= lmax; l++) {
+        if (l >= 1) {
+            for (int32_t f : lfac[l]) m2f(parent_edge[nv + f]);
+            close_stage();
+            for (int32_t f : lfac[l])
+                for (int32_t k = foff[f]; k < foff[f + 1]; k++) {
+                    const int32_t e = fedge[k];
+                    if (e != parent_edge[nv + f] && is_free(h->edge_var[e])) m2v(e);
+                }
+            close_stage();
+        }
+        scan(2, l);
+    }
+    for (int32_t n : members) if (n < nv && !on_path[n]) { push_item(CX_ITEM_INDIVIDUAL_MARGINAL, n, n); out.n_single++; }
+    if (close_stage()) out.marginal_stage = (int32_t)out.stage_off.size() - 2;
     return CX_OK;
 }
 

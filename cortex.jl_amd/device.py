@@ -101,6 +101,12 @@ class DeviceGraph:
         keys = ("depth", "stages", "items", "kary_entries", "components", "messages_up", "messages_down", "marginals")
         return dict(zip(keys, [int(x) for x in out]))
 
+    def tree_heavy_path_stats(self):
+        """cx_tree_heavy_path_stats: zeros unless the tree schedule's last sweep ran over heavy paths"""
+        out = (C.c_int64 * 4)()
+        self._check(self.lib.cx_tree_heavy_path_stats(self.h, out))
+        return dict(zip(("light_depths", "paths", "single_variables", "launches"), [int(x) for x in out]))
+
     def chain_plan_stats(self):
         """cx_chain_plan_stats: the composition / walk plan of the dim 64 chain-scan schedule (zeros for other handles)"""
         out = (C.c_int64 * 8)()

@@ -278,15 +278,23 @@ def tree_model(n_factors: int, seed: int = 1234, k_choices=(1, 1, 2, 3, 5), obse
     N(0, q) (CX_FACTOR_GAUSS_LINEAR, k = 1 input) next to factors of k >= 2 inputs (CX_FACTOR_GAUSS_LINEAR_N), a unary prior on every
     latent variable and point-mass data on a share `observe` of the leaves.  shape: where a new factor hangs — "random" (any existing
     variable: bushy, depth ~ log n), "deep" (a recent variable: long paths with side branches), "star" (the first variable: one hub of
-    degree n_factors + 1).  components: that many disjoint trees.  meta as synth.kary_model's (coefficients of the k-ary factors only, for
+    degree n_factors + 1), "comb" (pairwise factors only: a spine of states, a tooth of two variables below each — a state-space model
+    with a latent layer; depth ~ n_factors / 3).  components: that many disjoint trees.  meta as synth.kary_model's (coefficients of the k-ary factors only, for
     cx_set_factor_coefficients) plus `all_coef_*`: the input coefficient of EVERY factor edge, for a dense solve."""
     rng = np.random.default_rng(seed)
     fac_vars, nvar, roots = [], components, list(range(1, components + 1))
     comp_vars = [[r] for r in roots]
+    spine = [[r] for r in roots]
     for f in range(n_factors):
-        k = int(rng.choice(k_choices))
+        k = 1 if shape == "comb" else int(rng.choice(k_choices))
         cv = comp_vars[f % components]
-        if shape == "star":
+        if shape == "comb":
+            # a spine of states, each with a tooth of two more variables (a latent layer below every state): depth ~ n / 3, two light depths
+            sp, r = spine[f % components], (f // components) % 3
+            anchor = sp[-1] if r < 2 else cv[-1]
+            if r == 0:
+                sp.append(nvar + 1)
+        elif shape == "star":
             anchor = cv[0]
         elif shape == "deep":
             anchor = cv[-1 - int(rng.integers(0, min(3, len(cv))))]

@@ -415,6 +415,13 @@ int32_t cx_chain_plan_stats(const cx_handle *h, int64_t *out8);
 /* CX_SCHED_TREE: the plan of the last sweep (zeros before the first one and for other schedules).
  * out8 = { depth, stages, items, k-ary entries, components, messages upwards, messages downwards, marginals }. */
 int32_t cx_tree_plan_stats(const cx_handle *h, int64_t *out8);
+/* CX_SCHED_TREE, scalar messages: when the sweep takes fewer launches that way, the plan runs over HEAVY PATHS — every variable's
+ * heaviest child through a two-edge factor continues its path; the paths of one light depth (light edges above them) are ONE segmented
+ * scan per direction, whatever their length, the light edges stay items: O(log n) rounds of launches instead of 2 x depth + 1 (a
+ * chain of T states with a latent layer below each: ~ 25 launches instead of ~ 2 T).  The same messages, every marginal exact.
+ * out4 = { light depths, paths of two or more variables, variables on no such path, launches per sweep }; zeros when the level
+ * schedule is in use (then cx_tree_plan_stats's "stages" are its launches).  With heavy paths "stages" / "items" count the item stages. */
+int32_t cx_tree_heavy_path_stats(const cx_handle *h, int64_t *out4);
 
 /* ---- checkpoint (the reference keeps no persistent state — src/ has no serialisation at all) ----
  * The mutable state of a handle (every message buffer, the marginals, the observed-variable flags, the sweep counter)

@@ -79,6 +79,7 @@ class Handle {
     cx_stats stats() const { cx_stats s{}; check(cx_graph_stats(h_, &s)); return s; }
     // CX_SCHED_TREE: { depth, stages, items, k-ary entries, components, messages up, messages down, marginals } of the last sweep's plan
     std::array<int64_t, 8> tree_plan_stats() const { std::array<int64_t, 8> o{}; check(cx_tree_plan_stats(h_, o.data())); return o; }
+    std::array<int64_t, 4> tree_heavy_path_stats() const { std::array<int64_t, 4> o{}; check(cx_tree_heavy_path_stats(h_, o.data())); return o; }
 
     // data injection / read-back: the user's set_value! on message signals (signal.jl:232-253)
     void set_messages(const std::vector<int64_t> &variable_ids, const std::vector<int64_t> &factor_ids, int32_t direction, int32_t form,

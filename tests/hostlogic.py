@@ -80,11 +80,13 @@ class Plan64:
 _ARR = {"var_ids": 0, "var_off": 1, "edge_var": 2, "edge_fac_id": 3, "vbase": 4, "vinfo": 5, "slice_off": 6, "partner": 7, "big_vars": 8, "spdir": 9,
         "var_deg": 10, "q": 20, "a": 21, "b": 22, "sq": 23, "sa": 24, "sb": 25, "kary_coef": 26, "kary_qb": 27, "kary_slot": 30, "slot_kary": 31,
         "pos_var": 40, "skip0": 41, "skip1": 42, "link_pos": 43, "from": 44, "to": 45, "head_fwd": 46, "head_bwd": 47, "tab_fwd": 48, "tab_bwd": 49,
-        "trim_lo": 50, "trim_hi": 51, "tree_rec": 60, "tree_stage_off": 61, "tree_kary": 62, "tree_kary_off": 63, "partner": 64, "slot_kary_all": 65,
+        "trim_lo": 50, "trim_hi": 51, "hp_rec": 70, "hp_stage_off": 71, "hp_kary": 72, "hp_kary_off": 73, "hp_pos_var": 74, "hp_skip0": 75, "hp_skip1_up": 76, "hp_skip1_down": 77,
+        "hp_link_pos": 78, "hp_from": 79, "hp_to": 80, "hp_head_fwd": 81, "hp_head_bwd": 82, "hp_pos_off": 83, "hp_link_off": 84, "hp_steps": 85,
+        "tree_rec": 60, "tree_stage_off": 61, "tree_kary": 62, "tree_kary_off": 63, "partner": 64, "slot_kary_all": 65,
         "kary_slot_all": 66}
 _SCA = {"nv": 0, "nf": 1, "ne": 2, "nslots": 3, "nslices": 4, "n_messages_per_sweep": 5, "any_linear": 6, "n_kary": 7, "big_start": 8, "npos_linked": 9,
         "own_slice_lo": 10, "own_slice_hi": 11, "ipc_quiet_lo": 12, "ipc_quiet_hi": 13, "tree_depth": 14, "tree_components": 15, "tree_up": 16,
-        "tree_down": 17, "tree_marginals": 18}
+        "tree_down": 17, "tree_marginals": 18, "hp_levels": 19, "hp_paths": 20, "hp_single": 21, "hp_launches": 22, "hp_marginal_stage": 23}
 
 
 class FlatGraph:
@@ -106,6 +108,8 @@ class FlatGraph:
             L.cxh_flat_scalar.argtypes = [C.c_void_p, C.c_int32]
             L.cxh_flat_tree.restype = C.c_int32
             L.cxh_flat_tree.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+            L.cxh_flat_tree_hp.restype = C.c_int32
+            L.cxh_flat_tree_hp.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
             L.cxh_flat_halo.restype = C.c_int32
             L.cxh_flat_halo.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
             L._flat_ready = True
@@ -151,6 +155,11 @@ class FlatGraph:
     def tree(self):
         err = C.create_string_buffer(512)
         rc = int(self.L.cxh_flat_tree(self.p, err, 512))
+        return rc, err.value.decode()
+
+    def tree_hp(self):
+        err = C.create_string_buffer(512)
+        rc = int(self.L.cxh_flat_tree_hp(self.p, err, 512))
         return rc, err.value.decode()
 
     def halo(self, layer_var, layer, depth, send_slots):

@@ -34,11 +34,72 @@ def test_one_sweep_is_the_exact_posterior(hip_lib, shape, n_factors, components,
     assert_close(marg[:, 0], em, 1e-9, f"{shape}: marginal means vs the dense solve")
     assert_close(marg[:, 1], ev, 1e-9, f"{shape}: marginal variances vs the dense solve")
     st = dev.tree_plan_stats()
-    assert st["components"] == components and st["marginals"] == len(ids) and st["stages"] == 2 * st["depth"] + 1
+    assert st["components"] == components and st["marginals"] == len(ids)
+    hp = dev.tree_heavy_path_stats()
+    assert st["stages"] == 2 * st["depth"] + 1 or 0 < hp["launches"] < 2 * st["depth"] + 1      # level by level, or over heavy paths where that takes fewer launches
     # a second sweep recomputes the same messages from the same inputs
     before = dev.get_marginals(ids)
     dev.sweep(1)
     assert np.array_equal(before, dev.get_marginals(ids))
+
+
+@pytest.mark.parametrize("shape", ["random", "deep", "star", "comb"])
+@pytest.mark.parametrize("n_factors,components,seed", [(1, 1, 1), (40, 1, 2), (40, 4, 3), (3000, 2, 4)])
+def test_one_sweep_over_heavy_paths_is_the_exact_posterior(hip_lib, monkeypatch, shape, n_factors, components, seed):
+    """the same sweep over HEAVY PATHS (cx_tree_plan.h: build_hp; forced here, chosen by launch count otherwise): the paths of one
+    light depth are one segmented scan per direction (csrc/cx_chain.hip), light edges and factors of more than two edges stay items"""
+    monkeypatch.setenv("CX_TREE_HP", "1")
+    m = cx.synth.tree_model(n_factors, seed=seed, shape=shape, components=components, observe=0.3)
+    dev = _tree_dev(m)
+    dev.sweep(1)
+    ids, em, ev = dense_posterior(m)
+    marg = dev.get_marginals(ids)
+    assert not np.any(np.isnan(marg)), "undefined marginals after one sweep"
+    assert_close(marg[:, 0], em, 1e-9, f"{shape}: marginal means vs the dense solve")
+    assert_close(marg[:, 1], ev, 1e-9, f"{shape}: marginal variances vs the dense solve")
+    hp = dev.tree_heavy_path_stats()
+    if hp["launches"]:            # (a graph without a single two-edge link between sending variables has no path: level by level then)
+        assert hp["paths"] >= 1 and len(ids) >= hp["single_variables"] + 2 * hp["paths"]
+    before = dev.get_marginals(ids)
+    dev.sweep(1)
+    assert np.array_equal(before, dev.get_marginals(ids))
+    # message by message against the level schedule on the same device
+    monkeypatch.setenv("CX_TREE_HP", "0")
+    lv = _tree_dev(m)
+    lv.sweep(1)
+    assert lv.tree_heavy_path_stats()["launches"] == 0
+    obs = set(int(v) for v in m.data_var)
+    keep = np.array([int(v) not in obs for v in m.edge_var])
+    evv, eff = m.edge_var[keep], m.edge_fac[keep]
+    for direction in (L.TO_VARIABLE, L.TO_FACTOR):
+        a, b = dev.get_messages(evv, eff, direction, L.FORM_NATURAL), lv.get_messages(evv, eff, direction, L.FORM_NATURAL)
+        assert np.array_equal(np.isnan(a), np.isnan(b)), "the same messages are defined"
+        assert_close(a[~np.isnan(a)], b[~np.isnan(b)], 1e-9, f"{shape}: messages, direction {direction}")
+
+
+def test_a_state_space_model_with_a_latent_layer_takes_a_constant_number_of_launches(hip_lib, monkeypatch):
+    """a spine of 20,000 states with a tooth of two variables below each (depth ~ 10,000 levels): by default the sweep runs over heavy
+    paths — three light depths, a few dozen launches — and leaves what the level schedule leaves after its ~ 20,000 stages"""
+    m = cx.synth.tree_model(60_000, seed=5, shape="comb", observe=0.3)
+    dev = _tree_dev(m)
+    dev.sweep(1)
+    st, hp = dev.tree_plan_stats(), dev.tree_heavy_path_stats()
+    assert st["depth"] >= 19_000 and 0 < hp["launches"] <= 30 and hp["light_depths"] <= 3
+    monkeypatch.setenv("CX_TREE_HP", "0")
+    lv = _tree_dev(m)
+    lv.sweep(1)
+    assert lv.tree_heavy_path_stats()["launches"] == 0 and lv.tree_plan_stats()["stages"] == 2 * st["depth"] + 1
+    ids = m.x_ids
+    a, b = dev.get_marginals(ids), lv.get_marginals(ids)
+    assert not np.any(np.isnan(a))
+    assert_close(a, b, 1e-9, "heavy paths vs level by level: marginals")
+    # new data: the plan stays, the sweep follows
+    rng = np.random.default_rng(2)
+    y2 = m.data_y + rng.standard_normal(len(m.data_y))
+    for d_ in (dev, lv):
+        d_.set_messages(m.data_var, m.data_fac, L.TO_FACTOR, L.FORM_POINT, y2)
+        d_.sweep(1)
+    assert_close(dev.get_marginals(ids), lv.get_marginals(ids), 1e-9, "after new data")
 
 
 def test_messages_equal_the_flooding_fixed_point(hip_lib):

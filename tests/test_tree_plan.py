@@ -122,6 +122,149 @@ class PlanRun:
         return marg
 
 
+class HpRun(PlanRun):
+    """the heavy-path plan (cx_tree_plan.h: build_hp): item stages as above, and scans — here a plain walk along every path of the
+    scanned depth in both directions, reading the side sums (everything a position hears except its skipped slots) the way
+    cx_chain.hip's side kernel forms them"""
+
+    def pair_rule(self, recv_slot, m):
+        """the message into `recv_slot` through its two-edge factor, given the sender's variable→factor message m (natural form)"""
+        e = self.edge_of_slot[recv_slot]
+        f, v = int(self.edge_fac[e]), int(self.var_ids[self.edge_var[e]])
+        (x,) = [x for x in self.fac_edges[f] if x != e]
+        q, b = self.qb[f]
+        cj, c = self.coef[(f, v)], self.coef[(f, int(self.var_ids[self.edge_var[x]]))]
+        mx, vx = self.moments(m)
+        mean, var = (b - c * mx) / cj, (q + c * c * vx) / (cj * cj)
+        return np.array([mean / var, 1.0 / var])
+
+    def scan(self, L, final, marg):
+        g = self.g
+        pos_var, skip0 = g.arr("hp_pos_var"), g.arr("hp_skip0")
+        skip1 = g.arr("hp_skip1_down" if final else "hp_skip1_up")
+        link_pos, frm, to = g.arr("hp_link_pos"), g.arr("hp_from"), g.arr("hp_to")
+        hf, hb = g.arr("hp_head_fwd"), g.arr("hp_head_bwd")
+        p0, p1 = g.arr("hp_pos_off")[L:L + 2]
+        l0, l1 = g.arr("hp_link_off")[L:L + 2]
+        side = {}
+        for p in range(p0, p1):
+            v = int(pos_var[p])
+            sl = [self.slot_of_edge[x] for x in range(self.var_off[v], self.var_off[v + 1])]
+            keep = [x for x in sl if x != skip0[p] and x != skip1[p]]
+            assert {int(skip0[p]), int(skip1[p])} - {-1} <= set(int(x) for x in sl), "skipped slots belong to the position's variable"
+            tot = self.f2v[keep].sum(axis=0) if keep else np.zeros(2)
+            assert not np.any(np.isnan(tot)), f"scan of depth {L}: a side input of variable {self.var_ids[v]} is undefined"
+            side[p] = tot
+        alpha = np.zeros(2)
+        for l in range(l0, l1):                       # head -> tail
+            if hf[l]:
+                alpha = np.zeros(2)
+            alpha = self.pair_rule(int(to[l]), alpha + side[int(link_pos[l])])
+            if final:
+                self._store(("f2v", int(to[l])), self.f2v, int(to[l]), alpha)
+        beta = np.zeros(2)
+        for l in range(l1 - 1, l0 - 1, -1):           # tail -> head
+            if hb[l]:
+                beta = np.zeros(2)
+            beta = self.pair_rule(int(frm[l]), beta + side[int(link_pos[l]) + 1])
+            if final:
+                self._store(("f2v", int(frm[l])), self.f2v, int(frm[l]), beta)
+            else:
+                self.f2v[int(frm[l])] = beta         # the way up: overwritten by the final scan
+        if final:
+            for p in range(p0, p1):
+                v = int(pos_var[p])
+                tot = self.f2v[[self.slot_of_edge[x] for x in range(self.var_off[v], self.var_off[v + 1])]].sum(axis=0)
+                assert int(self.var_ids[v]) not in marg
+                marg[int(self.var_ids[v])] = (tot[0] / tot[1], 1.0 / tot[1])
+
+    def run(self):
+        g = self.g
+        rec = g.arr("hp_rec").reshape(-1, 5)
+        off, kary, koff = g.arr("hp_stage_off"), g.arr("hp_kary"), g.arr("hp_kary_off")
+        kslot = g.arr("kary_slot_all")
+        steps = g.arr("hp_steps").reshape(-1, 2)
+        marg = {}
+        up_written = set()
+        for kind, idx in steps:
+            if kind != 0:
+                self.scan(int(idx), kind == 2, marg)
+                continue
+            s = int(idx)
+            items, ents = rec[off[s]:off[s + 1]], kary[koff[s]:koff[s + 1]]
+            kinds = set(int(k) for k in items[:, 0]) | ({ITEM_M2V} if len(ents) else set())
+            assert len(kinds) == 1, f"stage {s} mixes item kinds {kinds} (or is empty)"
+            for k, slot, var, _, _ in items:
+                if k == ITEM_M2F:
+                    self.m2f(int(slot), int(var))
+                elif k == ITEM_M2V:
+                    self.m2v(int(slot))
+                else:
+                    assert k == ITEM_MARG and s == g.scalar("hp_marginal_stage")
+                    v = int(var)
+                    tot = self.f2v[[self.slot_of_edge[x] for x in range(self.var_off[v], self.var_off[v + 1])]].sum(axis=0)
+                    assert not np.any(np.isnan(tot)), f"marginal of {self.var_ids[v]}: an input is undefined"
+                    assert int(self.var_ids[v]) not in marg
+                    marg[int(self.var_ids[v])] = (tot[0] / tot[1], 1.0 / tot[1])
+            for ent in ents:
+                self.m2v(int(kslot[ent]))
+        del up_written
+        return marg
+
+
+@pytest.mark.parametrize("shape", ["random", "deep", "star"])
+@pytest.mark.parametrize("n_factors,components,seed", [(1, 1, 1), (7, 1, 2), (60, 1, 3), (60, 3, 4), (300, 2, 5), (1500, 1, 6)])
+def test_heavy_path_plan_is_the_exact_posterior(shape, n_factors, components, seed):
+    """cx_tree_plan.h: build_hp — heavy paths by scans, light edges by items: every marginal of the dense solve, each message produced
+    once, every input defined when it is read; the number of light depths is logarithmic where the level schedule's depth is not"""
+    m = cx.synth.tree_model(n_factors, seed=seed, shape=shape, components=components, observe=0.3)
+    g = flat_of(m)
+    rc, err = g.tree_hp()
+    assert rc == L.OK, err
+    marg = HpRun(g, m).run()
+    ids, em, ev = dense_posterior(m)
+    assert sorted(marg) == sorted(int(i) for i in ids), "a marginal for every non-observed variable and no other"
+    got = np.array([marg[int(i)] for i in ids])
+    assert np.allclose(got[:, 0], em, rtol=1e-9, atol=1e-12) and np.allclose(got[:, 1], ev, rtol=1e-9, atol=1e-12)
+    n_free = len(ids)
+    assert g.tree()[0] == L.OK
+    assert g.scalar("hp_levels") <= g.scalar("tree_depth") // 2 + 1, "never more light depths than the tree has levels of variables"
+    assert len(g.arr("hp_pos_var")) + g.scalar("hp_single") == n_free, "every free variable is on exactly one path or single"
+
+
+@pytest.mark.parametrize("n_factors,components,observe", [(3, 1, 0.0), (30, 1, 0.5), (301, 2, 0.3), (3000, 1, 0.3)])
+def test_heavy_paths_of_a_comb_need_three_light_depths(n_factors, components, observe):
+    """a spine of states with a tooth of two variables below each (synth.tree_model(shape="comb")): the level schedule is ~ n / 3 levels
+    deep, the heavy-path plan has the spine at light depths 0 and 1 and the teeth one below — a constant number of launches"""
+    m = cx.synth.tree_model(n_factors, seed=n_factors, shape="comb", components=components, observe=observe)
+    g = flat_of(m)
+    rc, err = g.tree_hp()
+    assert rc == L.OK, err
+    assert g.tree()[0] == L.OK
+    # (the root is the middle of the spine: one half of it is the root's heavy path, the other half starts one light edge down)
+    assert g.scalar("hp_levels") <= 3 and g.scalar("hp_launches") <= 30
+    if n_factors >= 300:
+        assert g.scalar("tree_depth") >= n_factors // (3 * components) and 2 * g.scalar("tree_depth") + 1 > 3 * g.scalar("hp_launches")
+    marg = HpRun(g, m).run()
+    ids, em, ev = dense_posterior(m)
+    assert sorted(marg) == sorted(int(i) for i in ids)
+    got = np.array([marg[int(i)] for i in ids])
+    assert np.allclose(got[:, 0], em, rtol=1e-9, atol=1e-12) and np.allclose(got[:, 1], ev, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_heavy_paths_of_pairwise_trees_are_logarithmic(seed):
+    m = cx.synth.tree_model(2000, seed=seed, k_choices=(1,), shape="deep", observe=0.3)
+    g = flat_of(m)
+    assert g.tree_hp()[0] == L.OK
+    n_free = len(g.arr("hp_pos_var")) + g.scalar("hp_single")
+    assert g.scalar("hp_levels") <= int(np.log2(n_free)) + 1
+    marg = HpRun(g, m).run()
+    ids, em, ev = dense_posterior(m)
+    got = np.array([marg[int(i)] for i in ids])
+    assert np.allclose(got[:, 0], em, rtol=1e-9, atol=1e-12) and np.allclose(got[:, 1], ev, rtol=1e-9, atol=1e-12)
+
+
 @pytest.mark.parametrize("shape", ["random", "deep", "star"])
 @pytest.mark.parametrize("n_factors,components,seed", [(1, 1, 1), (7, 1, 2), (60, 1, 3), (60, 3, 4), (300, 2, 5)])
 def test_one_pass_of_the_plan_is_the_exact_posterior(shape, n_factors, components, seed):
