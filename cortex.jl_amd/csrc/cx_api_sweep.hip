@@ -159,6 +159,14 @@ int32_t build_tree(cx_handle *h) {
                 char *tot = nullptr;
                 if ((rc2 = dev_alloc(h, &tot, (int64_t)cx::chain_total_bytes((int64_t)hp.link_pos.size()))) != CX_OK) return rc2;
                 h->d_chain_totals = tot;
+                for (void *p : {(void *)h->d_tree_a, (void *)h->d_tree_b}) if (p) (void)hipFree(p);
+                h->d_tree_a = h->d_tree_b = nullptr;
+                h->tree_hp_kary_links = hp.n_kary_links;
+                if (hp.n_kary_links > 0 && !h->any_linear) {      // no (a, b) per slot on this graph: the links' own, 1 and 0 everywhere else
+                    const std::vector<double> one((size_t)h->nslots, 1.0), zero((size_t)h->nslots, 0.0);
+                    if ((rc2 = dev_upload(h, &h->d_tree_a, one)) != CX_OK) return rc2;
+                    if ((rc2 = dev_upload(h, &h->d_tree_b, zero)) != CX_OK) return rc2;
+                }
                 h->tree_hp = true;
                 h->tree_hp_steps = hp.steps; h->tree_hp_pos_off = hp.pos_off; h->tree_hp_link_off = hp.link_off; h->tree_hp_marginal_stage = hp.marginal_stage;
                 const int64_t hs[4] = {hp.levels, hp.n_paths, hp.n_single, hp.launches};
@@ -230,6 +238,9 @@ static void tree_issue(cx_handle *h) {
                 if (idx == h->tree_hp_marginal_stage && h->cfg.compute_marginals_in_sweep == 0) continue;
                 const int64_t n = h->tree_stage_off[idx + 1] - h->tree_stage_off[idx];
                 if (n > 0) cx::launch_batch(h, h->d_tree_rec + 5 * h->tree_stage_off[idx], n);
+            } else if (kind == 3) {
+                const int64_t l0 = h->tree_hp_link_off[idx];
+                cx::launch_kary_link_params(h, l0, h->tree_hp_link_off[idx + 1] - l0, h->d_tree_a ? h->d_tree_a : h->d_a, h->d_tree_b ? h->d_tree_b : h->d_b);
             } else {
                 const int64_t p0 = h->tree_hp_pos_off[idx], l0 = h->tree_hp_link_off[idx];
                 cx::launch_chain_scan_range(h, h->d_f2v, p0, h->tree_hp_pos_off[idx + 1] - p0, l0, h->tree_hp_link_off[idx + 1] - l0,

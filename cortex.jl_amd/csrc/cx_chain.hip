@@ -493,7 +493,8 @@ void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_f
 // positions and the variable→factor messages of the links are written as well; otherwise messages only.
 void launch_chain_scan_range(cx_handle *h, double2 *f2v, int64_t pos_lo, int64_t npos, int64_t link_lo, int64_t nlinks, const int32_t *skip1, bool final) {
     if (nlinks <= 0 || npos <= 0) return;
-    const double *pa = h->any_linear ? h->d_a : nullptr, *pb = h->any_linear ? h->d_b : nullptr;
+    // (paths through factors with more than two edges: their links' (a, b) live in the tree's own arrays on a graph that has none)
+    const double *pa = h->d_tree_a ? h->d_tree_a : (h->any_linear ? h->d_a : nullptr), *pb = h->d_tree_b ? h->d_tree_b : (h->any_linear ? h->d_b : nullptr);
     hipLaunchKernelGGL(k_chain_side<false>, dim3((unsigned)((npos + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, (int)npos, h->d_chain_pos_var + pos_lo,
                        h->d_chain_skip0 + pos_lo, skip1 + pos_lo, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, h->d_q_gamma, h->d_q_gmean, pa, pb,
                        h->d_v2f, f2v, h->d_chain_side + pos_lo);

@@ -204,13 +204,13 @@ int64_t cxh_flat_array(const void *p, int32_t which, void *out) {
 
 // scalars: 0 nv 1 nf 2 ne 3 nslots 4 nslices 5 n_messages_per_sweep 6 any_linear 7 n_kary 8 big_start 9 npos_linked 10 own_slice_lo 11 own_slice_hi
 //          12 ipc_quiet_lo 13 ipc_quiet_hi 14 tree depth 15 tree components 16 messages up 17 messages down 18 marginals
-//          19 heavy-path plan: light depths 20 paths 21 variables on no path 22 launches per sweep 23 the marginal stage
+//          19 heavy-path plan: light depths 20 paths 21 variables on no path 22 launches per sweep 23 the marginal stage 24 links through factors of more than two edges
 int64_t cxh_flat_scalar(const void *p, int32_t which) {
     const HostGraph *g = (const HostGraph *)p;
     const int64_t v[] = {g->nv, g->nf, g->ne, g->nslots, g->nslices, g->n_messages_per_sweep, g->any_linear ? 1 : 0, g->n_kary, g->big_start, g->co.npos_linked,
                          g->own_slice_lo, g->own_slice_hi, g->ipc_quiet_lo, g->ipc_quiet_hi, g->to.depth, g->to.n_components, g->to.n_up, g->to.n_down, g->to.n_marginals,
-                         g->hp.levels, g->hp.n_paths, g->hp.n_single, g->hp.launches, g->hp.marginal_stage};
-    return which >= 0 && which < 24 ? v[which] : -1;
+                         g->hp.levels, g->hp.n_paths, g->hp.n_single, g->hp.launches, g->hp.marginal_stage, g->hp.n_kary_links};
+    return which >= 0 && which < 25 ? v[which] : -1;
 }
 
 }  // extern "C"

@@ -125,6 +125,10 @@ struct cx_handle {
     std::vector<int64_t> tree_hp_pos_off, tree_hp_link_off;
     int32_t tree_hp_marginal_stage = -1;
     int64_t tree_hp_stats[4] = {0, 0, 0, 0};       // light depths, paths of two or more, variables on no such path, launches per sweep
+    // heavy paths through factors with more than two edges: their pairwise parameters per receiving slot are written every sweep
+    // (cx_kary.hip: k_kary_link_params) into d_q and into d_a / d_b — or, on a graph without pairwise linear factors, into these
+    double *d_tree_a = nullptr, *d_tree_b = nullptr;
+    int64_t tree_hp_kary_links = 0;
     int64_t chain_npos = 0, chain_nlinks = 0;
     int64_t chain_npos_linked = 0;   // dim > 1: positions [0, this) belong to paths with links; the isolated ones follow
     bool chain_side_dirty = true;    // the leaf messages / side sums of the chain positions must be recomputed (data or rule parameters changed)
@@ -246,6 +250,7 @@ int32_t kary_upload(cx_handle *h);
 void kary_free(cx_handle *h);
 void launch_kary(cx_handle *h, const double2 *v2f, double2 *f2v_out);
 void launch_kary_items(cx_handle *h, const int32_t *d_entries, int64_t n);
+void launch_kary_link_params(cx_handle *h, int64_t link_lo, int64_t nlinks, double *a, double *b);
 void launch_residual(cx_handle *h, const double2 *cur, const double2 *prev, int64_t n, double *d_out);
 void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_form, bool chain_v2f);
 void launch_chain_totals(cx_handle *h, double2 *f2v, bool fused_leaves, int64_t *ntiles_out);

@@ -60,6 +60,35 @@ __global__ void k_kary_items(int n, const int32_t *__restrict__ entries, const i
     kary_item(entries[i], kslot, kcoef, kqb, v2f, f2v);
 }
 
+// CX_SCHED_TREE over heavy paths (cx_tree_plan.h): a link of a path that runs through a factor of this table.  With the messages of the
+// factor's OTHER variables fixed (its light children — final once everything below the path is — and its observed variables) the
+// factor is a pairwise rule between the link's two variables: from  sum_e c_e x_e = b + eps  and the others' moments (m_j, v_j),
+//     x_r = (-c_s / c_r) x_s + (b - sum_j c_j m_j) / c_r + N(0, (q + sum_j c_j^2 v_j) / c_r^2)
+// for receiver r and sender s — written as the (a, b, q) of the RECEIVING slot, the form cx_chain.hip's scans read, for both directions.
+// One thread per link; links through two-edge factors keep the parameters of the graph.  A vague input (variance inf) makes the
+// rule's variance the largest finite number instead of inf (inf x 0 in the scans' maps); an undefined input leaves NaN parameters:
+// the messages that depend on the link stay what they were, like everything that reads an undefined signal.
+__global__ void k_kary_link_params(int n, const int32_t *__restrict__ from, const int32_t *__restrict__ to, const int32_t *__restrict__ slot_kary,
+                                   const int32_t *__restrict__ kslot, const double *__restrict__ kcoef, const double *__restrict__ kqb,
+                                   const double2 *__restrict__ v2f, double *__restrict__ q, double *__restrict__ a, double *__restrict__ b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int sf = from[i], st = to[i], ef = slot_kary[sf];
+    if (ef < 0) return;
+    const int et = slot_kary[st], row = ef >> 3;
+    double sm = 0.0, sv = 0.0;
+    for (int r = 0; r < 8; r++) {
+        const int o = 8 * row + r, s = kslot[o];
+        if (s < 0 || o == ef || o == et) continue;
+        const double2 in = kary_moment(v2f[s]);
+        sm += kcoef[o] * in.x;
+        sv += kcoef[o] * kcoef[o] * in.y;
+    }
+    const double cf = kcoef[ef], ct = kcoef[et], rest = kqb[2 * row + 1] - sm, var = fmin(kqb[2 * row] + sv, 1.7976931348623157e308);
+    a[st] = -cf / ct; b[st] = rest / ct; q[st] = fmin(var / (ct * ct), 1.7976931348623157e308);
+    a[sf] = -ct / cf; b[sf] = rest / cf; q[sf] = fmin(var / (cf * cf), 1.7976931348623157e308);
+}
+
 }  // namespace
 
 int32_t kary_upload(cx_handle *h) {
@@ -93,6 +122,12 @@ void launch_kary(cx_handle *h, const double2 *v2f, double2 *f2v_out) {
     const int64_t threads = 8 * h->n_kary;
     hipLaunchKernelGGL(k_factor_kary, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, (int)h->n_kary, h->d_kary_slot,
                        h->d_kary_coef, h->d_kary_qb, v2f, f2v_out);
+}
+
+void launch_kary_link_params(cx_handle *h, int64_t link_lo, int64_t nlinks, double *a, double *b) {
+    if (nlinks <= 0 || h->n_kary == 0) return;
+    hipLaunchKernelGGL(k_kary_link_params, dim3((unsigned)((nlinks + 255) / 256)), dim3(256), 0, h->stream, (int)nlinks, h->d_chain_from + link_lo,
+                       h->d_chain_to + link_lo, h->d_slot_kary, h->d_kary_slot, h->d_kary_coef, h->d_kary_qb, (const double2 *)h->d_v2f, h->d_q, a, b);
 }
 
 void launch_kary_items(cx_handle *h, const int32_t *d_entries, int64_t n) {

@@ -213,6 +213,10 @@ int32_t build(const H *h, Out &out, std::string &err) {
 //   last  marginals of the variables that are on no path of two or more
 // Exactness: every message is computed once from final inputs, as in the level schedule (the up scan's messages AWAY from the heads lack
 // what comes from above and are overwritten by the down scan before anything reads them).
+// A heavy edge may also run through a factor with MORE than two edges: given the messages of the factor's other variables — its light
+// children, final once the depth below has been scanned, and its observed variables — the factor is a pairwise linear rule between the
+// path's two variables (cx_kary.hip: k_kary_link_params forms its (a, b, q) per direction before the depth's first scan: step kind 3);
+// on the way down the factor's messages to its light children are items that read the two variable→factor messages the final scan left.
 struct HP {
     std::vector<int32_t> rec;            // item stages, as in Out
     std::vector<int64_t> stage_off;
@@ -223,9 +227,10 @@ struct HP {
     std::vector<int32_t> pos_var, skip0, skip1_up, skip1_down, link_pos, from, to;
     std::vector<uint8_t> head_fwd, head_bwd;
     std::vector<int64_t> pos_off, link_off;      // per light depth, levels + 1 entries
-    std::vector<int32_t> steps;                  // pairs (kind, index): 0 item stage, 1 scan of depth `index` on the way up (messages only), 2 the final scan of depth `index`
+    std::vector<int32_t> steps;                  // pairs (kind, index): 0 item stage, 1 scan of depth `index` on the way up (messages only), 2 the final scan of depth `index`,
+                                                 // 3 the pairwise parameters of the links of depth `index` that run through factors with more than two edges
     int32_t levels = 0, depth = 0, marginal_stage = -1;
-    int64_t n_components = 0, n_paths = 0, n_single = 0, launches = 0;
+    int64_t n_components = 0, n_paths = 0, n_single = 0, launches = 0, n_kary_links = 0;
 };
 
 template <class H>
@@ -246,17 +251,25 @@ int32_t build_hp(const H *h, HP &out, std::string &err) {
     std::vector<int64_t> sz(nn, 0);
     for (int32_t n : members) if (n < nv) sz[n] = 1;
     for (size_t i = members.size(); i-- > 0;) { const int32_t n = members[i], p = parent_of(n); if (p >= 0) sz[p] += sz[n]; }
-    // heavy child: through a two-edge factor with a rule of its own (partner slot), into a variable that sends (degree >= 2)
+    // heavy child: through a two-edge factor with a rule of its own (partner slot) or a factor of the k-ary table, into a variable
+    // that sends (degree >= 2)
     std::vector<int32_t> heavy(nv, -1), hfac(nv, -1);
+    std::vector<uint8_t> fkary(h->nf, 0);                 // the factor is in the k-ary table (more than two edges)
     for (int32_t n : members) {
         if (n < nv) continue;
         const int32_t f = n - (int32_t)nv, ev = parent_edge[n];
-        if (ev < 0 || foff[f + 1] - foff[f] != 2) continue;
-        const int32_t ec = fedge[foff[f]] == ev ? fedge[foff[f] + 1] : fedge[foff[f]];
-        const int32_t v = h->edge_var[ev], c = h->edge_var[ec];
-        if (!is_free(c) || vdeg(c) < 2 || level[c] != level[n] + 1 || parent_edge[c] != ec) continue;
-        if (h->partner[slot(ev)] < 0 || (!h->slot_kary.empty() && h->slot_kary[slot(ev)] >= 0)) continue;
-        if (heavy[v] < 0 || sz[c] > sz[heavy[v]]) { heavy[v] = c; hfac[v] = f; }
+        if (ev < 0) continue;
+        const int32_t v = h->edge_var[ev];
+        const bool kary = !h->slot_kary.empty() && h->slot_kary[slot(ev)] >= 0;
+        if (!kary && (foff[f + 1] - foff[f] != 2 || h->partner[slot(ev)] < 0)) continue;
+        fkary[f] = kary ? 1 : 0;
+        for (int32_t k = foff[f]; k < foff[f + 1]; k++) {
+            const int32_t ec = fedge[k];
+            if (ec == ev) continue;
+            const int32_t c = h->edge_var[ec];
+            if (!is_free(c) || vdeg(c) < 2 || level[c] != level[n] + 1 || parent_edge[c] != ec) continue;
+            if (heavy[v] < 0 || sz[c] > sz[heavy[v]]) { heavy[v] = c; hfac[v] = f; }
+        }
     }
     // light depth of every variable; heads
     std::vector<int32_t> ld(nv, -1);
@@ -278,7 +291,9 @@ int32_t build_hp(const H *h, HP &out, std::string &err) {
     std::vector<uint8_t> on_path(nv, 0);
     for (int32_t n : members) if (n < nv && is_head[n] && heavy[n] >= 0) heads[ld[n]].push_back(n);
     out.pos_off.assign(1, 0); out.link_off.assign(1, 0);
+    std::vector<uint8_t> kary_depth(lmax + 1, 0);         // the depth has links through factors with more than two edges
     for (int32_t L = 0; L <= lmax; L++) {
+        bool depth_has_kary = false;
         for (int32_t hd : heads[L]) {
             out.n_paths++;
             int32_t v = hd, prev_to = -1;
@@ -303,18 +318,22 @@ int32_t build_hp(const H *h, HP &out, std::string &err) {
                 out.to.push_back(prev_to);
                 out.head_fwd.push_back(v == hd ? 1 : 0);
                 out.head_bwd.push_back(heavy[c] < 0 ? 1 : 0);
+                if (fkary[hfac[v]]) { out.n_kary_links++; depth_has_kary = true; }
                 v = c;
             }
         }
         out.pos_off.push_back((int64_t)out.pos_var.size());
         out.link_off.push_back((int64_t)out.link_pos.size());
+        kary_depth[L] = depth_has_kary ? 1 : 0;
     }
-    // light factors by the depth of what hangs below them (= depth of the variable above + 1)
-    std::vector<std::vector<int32_t>> lfac(lmax + 2);
+    // light factors by the depth of what hangs below them (= depth of the variable above + 1); heavy factors with more than two edges
+    // likewise: their other children are light
+    std::vector<std::vector<int32_t>> lfac(lmax + 2), hkfac(lmax + 2);
     for (int32_t n : members) {
         if (n < nv) continue;
         const int32_t f = n - (int32_t)nv, v = parent_of(n);
-        if (v < 0 || hfac[v] == f) continue;
+        if (v < 0) continue;
+        if (hfac[v] == f) { if (fkary[f]) hkfac[ld[v] + 1].push_back(f); continue; }
         lfac[ld[v] + 1].push_back(f);
     }
     std::vector<std::vector<int32_t>> hv(lmax + 1);      // heads and single variables by depth (those with a parent)
@@ -344,8 +363,14 @@ int32_t build_hp(const H *h, HP &out, std::string &err) {
         cur.clear(); curk.clear();
         return true;
     };
+    std::vector<uint8_t> params_done(lmax + 1, 0);
     auto scan = [&](int32_t kind, int32_t L) {
         if (out.link_off[L + 1] == out.link_off[L]) return;
+        if (kary_depth[L] && !params_done[L]) {      // before the depth's first scan: everything below it is final
+            out.steps.push_back(3); out.steps.push_back(L);
+            out.launches += 1;
+            params_done[L] = 1;
+        }
         out.steps.push_back(kind); out.steps.push_back(L);
         out.launches += 3;
     };
@@ -367,6 +392,13 @@ int32_t build_hp(const H *h, HP &out, std::string &err) {
                     const int32_t e = fedge[k];
                     if (e != parent_edge[nv + f] && is_free(h->edge_var[e])) m2v(e);
                 }
+            for (int32_t f : hkfac[l]) {                 // the light children of a heavy factor: the final scan of depth l - 1 left both of its path variables' messages
+                const int32_t v = h->edge_var[parent_edge[nv + f]], ec = parent_edge[heavy[v]];
+                for (int32_t k = foff[f]; k < foff[f + 1]; k++) {
+                    const int32_t e = fedge[k];
+                    if (e != parent_edge[nv + f] && e != ec && is_free(h->edge_var[e])) m2v(e);
+                }
+            }
             close_stage();
         }
         scan(2, l);

@@ -86,7 +86,7 @@ _ARR = {"var_ids": 0, "var_off": 1, "edge_var": 2, "edge_fac_id": 3, "vbase": 4,
         "kary_slot_all": 66}
 _SCA = {"nv": 0, "nf": 1, "ne": 2, "nslots": 3, "nslices": 4, "n_messages_per_sweep": 5, "any_linear": 6, "n_kary": 7, "big_start": 8, "npos_linked": 9,
         "own_slice_lo": 10, "own_slice_hi": 11, "ipc_quiet_lo": 12, "ipc_quiet_hi": 13, "tree_depth": 14, "tree_components": 15, "tree_up": 16,
-        "tree_down": 17, "tree_marginals": 18, "hp_levels": 19, "hp_paths": 20, "hp_single": 21, "hp_launches": 22, "hp_marginal_stage": 23}
+        "tree_down": 17, "tree_marginals": 18, "hp_levels": 19, "hp_paths": 20, "hp_single": 21, "hp_launches": 22, "hp_marginal_stage": 23, "hp_kary_links": 24}
 
 
 class FlatGraph:

@@ -102,6 +102,62 @@ def test_a_state_space_model_with_a_latent_layer_takes_a_constant_number_of_laun
     assert_close(dev.get_marginals(ids), lv.get_marginals(ids), 1e-9, "after new data")
 
 
+def test_heavy_paths_run_through_factors_of_more_than_two_edges(hip_lib, monkeypatch):
+    """long paths with side branches and factors of 2..6 variables (depth ~ 0.7 n levels): a heavy edge also runs through a factor with
+    more than two edges — given its light children's messages such a factor is a pairwise rule between the path's two variables
+    (csrc/cx_kary.hip: k_kary_link_params) — so the sweep takes a few dozen launches, not two per level, and leaves the level
+    schedule's messages and marginals"""
+    m = cx.synth.tree_model(20_000, seed=7, shape="deep", observe=0.3)
+    dev = _tree_dev(m)
+    dev.sweep(1)
+    st, hp = dev.tree_plan_stats(), dev.tree_heavy_path_stats()
+    assert st["depth"] >= 10_000 and 0 < hp["launches"] <= 80 and hp["light_depths"] <= 6, (st, hp)
+    monkeypatch.setenv("CX_TREE_HP", "0")
+    lv = _tree_dev(m)
+    lv.sweep(1)
+    assert lv.tree_heavy_path_stats()["launches"] == 0 and lv.tree_plan_stats()["stages"] == 2 * st["depth"] + 1
+    ids = m.x_ids
+    a, b = dev.get_marginals(ids), lv.get_marginals(ids)
+    assert not np.any(np.isnan(a))
+    assert_close(a, b, 1e-9, "heavy paths through k-ary factors vs level by level: marginals")
+    obs = set(int(v) for v in m.data_var)
+    keep = np.array([int(v) not in obs for v in m.edge_var])
+    evv, eff = m.edge_var[keep], m.edge_fac[keep]
+    for direction in (L.TO_VARIABLE, L.TO_FACTOR):
+        x, y = dev.get_messages(evv, eff, direction, L.FORM_NATURAL), lv.get_messages(evv, eff, direction, L.FORM_NATURAL)
+        assert np.array_equal(np.isnan(x), np.isnan(y)), "the same messages are defined"
+        assert_close(x[~np.isnan(x)], y[~np.isnan(y)], 1e-9, f"messages, direction {direction}")
+    # new coefficients and new data: the plan stays, the links' pairwise parameters follow (they are formed every sweep)
+    rng = np.random.default_rng(3)
+    coef2 = m.meta["coef"] * rng.uniform(0.8, 1.2, len(m.meta["coef"]))
+    y2 = m.data_y + rng.standard_normal(len(m.data_y))
+    for d_ in (dev, lv):
+        d_.set_factor_coefficients(m.meta["coef_var"], m.meta["coef_fac"], coef2)
+        d_.set_messages(m.data_var, m.data_fac, L.TO_FACTOR, L.FORM_POINT, y2)
+        d_.sweep(1)
+    assert_close(dev.get_marginals(ids), lv.get_marginals(ids), 1e-9, "after new coefficients and data")
+
+
+@pytest.mark.parametrize("n_factors,seed", [(1, 1), (30, 2), (400, 3)])
+def test_heavy_paths_on_a_graph_of_k_ary_factors_only(hip_lib, monkeypatch, n_factors, seed):
+    """no pairwise factor at all (synth.kary_model: factors of 3..7 variables and unary priors — the handle keeps no per-slot (a, b)):
+    every link of every path runs through a k-ary factor; the dense solve's marginals"""
+    monkeypatch.setenv("CX_TREE_HP", "1")
+    m = cx.synth.kary_model(n_factors, seed=seed, tree=True, observe=0.25)
+    dev = _tree_dev(m)
+    dev.sweep(1)
+    hp = dev.tree_heavy_path_stats()
+    assert hp["launches"] > 0 and hp["paths"] >= 1
+    ids, em, ev = dense_posterior(m)
+    marg = dev.get_marginals(ids)
+    assert not np.any(np.isnan(marg))
+    assert_close(marg[:, 0], em, 1e-9, "k-ary only: marginal means vs the dense solve")
+    assert_close(marg[:, 1], ev, 1e-9, "k-ary only: marginal variances vs the dense solve")
+    before = dev.get_marginals(ids)
+    dev.sweep(1)
+    assert np.array_equal(before, dev.get_marginals(ids))
+
+
 def test_messages_equal_the_flooding_fixed_point(hip_lib):
     """every factor→variable message into a non-observed variable and every variable→factor message that has a reader: one tree sweep
     == the flooding schedule after diameter-many sweeps on the same device"""

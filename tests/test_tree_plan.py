@@ -127,14 +127,50 @@ class HpRun(PlanRun):
     scanned depth in both directions, reading the side sums (everything a position hears except its skipped slots) the way
     cx_chain.hip's side kernel forms them"""
 
+    def link_params(self, L):
+        """step kind 3: a factor with more than two edges on a path of depth L is, given the messages of its OTHER variables (its light
+        children and its observed variables: all of them must be defined by now), a pairwise rule x_recv = a x_send + b + N(0, q) between
+        the path's two variables — per direction, as cx_kary.hip: k_kary_link_params forms it"""
+        g = self.g
+        frm, to = g.arr("hp_from"), g.arr("hp_to")
+        l0, l1 = g.arr("hp_link_off")[L:L + 2]
+        n = 0
+        for l in range(l0, l1):
+            ef, et = self.edge_of_slot[int(frm[l])], self.edge_of_slot[int(to[l])]
+            f = int(self.edge_fac[ef])
+            assert f == int(self.edge_fac[et]), "a link's two slots belong to one factor"
+            if len(self.fac_edges[f]) == 2:
+                continue
+            n += 1
+            q, b = self.qb[f]
+            sm = sv = 0.0
+            for x in self.fac_edges[f]:
+                if x in (ef, et):
+                    continue
+                nat = self.v2f[self.slot_of_edge[x]]
+                assert not np.any(np.isnan(nat)), f"link through factor {f}: the message of variable {self.var_ids[self.edge_var[x]]} is undefined at this step"
+                mx, vx = self.moments(nat)
+                c = self.coef[(f, int(self.var_ids[self.edge_var[x]]))]
+                sm += c * mx
+                sv += c * c * vx
+            cf, ct = self.coef[(f, int(self.var_ids[self.edge_var[ef]]))], self.coef[(f, int(self.var_ids[self.edge_var[et]]))]
+            self.eff[int(to[l])] = (-cf / ct, (b - sm) / ct, (q + sv) / (ct * ct))
+            self.eff[int(frm[l])] = (-ct / cf, (b - sm) / cf, (q + sv) / (cf * cf))
+        assert n > 0, "a parameter step for a depth without such links"
+
     def pair_rule(self, recv_slot, m):
-        """the message into `recv_slot` through its two-edge factor, given the sender's variable→factor message m (natural form)"""
+        """the message into `recv_slot` through its factor, given the sender's variable→factor message m (natural form): a two-edge
+        factor's own rule, or the pairwise parameters link_params left for this slot"""
         e = self.edge_of_slot[recv_slot]
         f, v = int(self.edge_fac[e]), int(self.var_ids[self.edge_var[e]])
+        mx, vx = self.moments(m)
+        if len(self.fac_edges[f]) > 2:
+            a, b, q = self.eff[recv_slot]
+            mean, var = a * mx + b, a * a * vx + q
+            return np.array([mean / var, 1.0 / var])
         (x,) = [x for x in self.fac_edges[f] if x != e]
         q, b = self.qb[f]
         cj, c = self.coef[(f, v)], self.coef[(f, int(self.var_ids[self.edge_var[x]]))]
-        mx, vx = self.moments(m)
         mean, var = (b - c * mx) / cj, (q + c * c * vx) / (cj * cj)
         return np.array([mean / var, 1.0 / var])
 
@@ -177,6 +213,13 @@ class HpRun(PlanRun):
                 tot = self.f2v[[self.slot_of_edge[x] for x in range(self.var_off[v], self.var_off[v + 1])]].sum(axis=0)
                 assert int(self.var_ids[v]) not in marg
                 marg[int(self.var_ids[v])] = (tot[0] / tot[1], 1.0 / tot[1])
+            # the final scan also leaves the links' two variable→factor messages (what each end hears from everybody else): the
+            # messages of a heavy factor with more than two edges to its light children read them
+            for l in range(l0, l1):
+                for slot_, p in ((int(frm[l]), int(link_pos[l])), (int(to[l]), int(link_pos[l]) + 1)):
+                    v = int(pos_var[p])
+                    others = [self.slot_of_edge[x] for x in range(self.var_off[v], self.var_off[v + 1]) if self.slot_of_edge[x] != slot_]
+                    self._store(("v2f", slot_), self.v2f, slot_, self.f2v[others].sum(axis=0))
 
     def run(self):
         g = self.g
@@ -186,8 +229,15 @@ class HpRun(PlanRun):
         steps = g.arr("hp_steps").reshape(-1, 2)
         marg = {}
         up_written = set()
+        self.eff = {}
+        scanned = set()
         for kind, idx in steps:
+            if kind == 3:
+                assert int(idx) not in scanned, "the parameters of a depth's links are formed before its first scan"
+                self.link_params(int(idx))
+                continue
             if kind != 0:
+                scanned.add(int(idx))
                 self.scan(int(idx), kind == 2, marg)
                 continue
             s = int(idx)
@@ -245,6 +295,28 @@ def test_heavy_paths_of_a_comb_need_three_light_depths(n_factors, components, ob
     assert g.scalar("hp_levels") <= 3 and g.scalar("hp_launches") <= 30
     if n_factors >= 300:
         assert g.scalar("tree_depth") >= n_factors // (3 * components) and 2 * g.scalar("tree_depth") + 1 > 3 * g.scalar("hp_launches")
+    marg = HpRun(g, m).run()
+    ids, em, ev = dense_posterior(m)
+    assert sorted(marg) == sorted(int(i) for i in ids)
+    got = np.array([marg[int(i)] for i in ids])
+    assert np.allclose(got[:, 0], em, rtol=1e-9, atol=1e-12) and np.allclose(got[:, 1], ev, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("k_choices,n_factors,seed", [((1, 1, 2, 3, 5), 1500, 1), ((2, 3, 5), 400, 2), ((2,), 300, 3), ((5,), 200, 4)])
+def test_heavy_paths_run_through_factors_of_more_than_two_edges(k_choices, n_factors, seed):
+    """long paths with side branches whose factors have 3..6 variables: the links through such factors get their pairwise parameters in a
+    step of their own before the depth's first scan (every light child's message defined by then — the executor fails otherwise), the
+    factor's messages to its light children are items after the final scan; a few dozen launches where the level schedule has two per
+    level, the dense solve's marginals"""
+    m = cx.synth.tree_model(n_factors, seed=seed, k_choices=k_choices, shape="deep", observe=0.3)
+    g = flat_of(m)
+    rc, err = g.tree_hp()
+    assert rc == L.OK, err
+    assert g.tree()[0] == L.OK
+    assert g.scalar("hp_kary_links") > 0.3 * len(g.arr("hp_link_pos"))
+    assert g.scalar("hp_launches") <= 80 < 2 * g.scalar("tree_depth") + 1 and g.scalar("hp_levels") <= 6
+    steps = g.arr("hp_steps").reshape(-1, 2)
+    assert 1 <= int((steps[:, 0] == 3).sum()) <= g.scalar("hp_levels")
     marg = HpRun(g, m).run()
     ids, em, ev = dense_posterior(m)
     assert sorted(marg) == sorted(int(i) for i in ids)

@@ -301,6 +301,8 @@ def tree(n_factors=200_000, steps=20, shape="random"):
     dev.sweep(2)
     dt = timed(dev, lambda: dev.sweep(1), steps, 3)
     st = dev.tree_plan_stats()
+    hp = dev.tree_heavy_path_stats()       # zeros when the sweep runs level by level
+    launches = hp["launches"] or st["stages"]
     fused = cx.DeviceGraph(schedule=L.SCHED_FUSED)
     cx.synth.load_into_device(model, fused)
     need = 2 * st["depth"] + 2
@@ -311,12 +313,13 @@ def tree(n_factors=200_000, steps=20, shape="random"):
     err = float(np.nanmax(np.abs(a - b) / np.maximum(np.abs(b), np.median(np.abs(b)))))
     n_msgs = st["messages_up"] + st["messages_down"]
     return {"config": "tree", "workload": f"scalar Gaussian forest, {n_factors} factors of 2..6 variables + a prior per variable ({len(model.edge_var)} edges, shape {shape})",
-            "ms_per_sweep": dt * 1e3, "plan": st, "launches_per_sweep": st["stages"], "messages_per_sweep": n_msgs, "messages_per_s": n_msgs / dt,
+            "ms_per_sweep": dt * 1e3, "plan": st, "heavy_paths": hp, "launches_per_sweep": launches, "messages_per_sweep": n_msgs, "messages_per_s": n_msgs / dt,
             "fused_schedule": {"ms_per_sweep": dtf * 1e3, "sweeps_to_the_same_result": need, "ms_to_the_same_result": need * dtf * 1e3},
-            "roofline": roofline("hbm", n_msgs * 32 / dt / 1e9, HBM_PEAK_GBS, "GB/s", None, kernel="k_batch, one launch per stage",
+            "roofline": roofline("hbm", n_msgs * 32 / dt / 1e9, HBM_PEAK_GBS, "GB/s", None,
+                                 kernel="k_chain_* scans of the heavy paths + k_batch item stages" if hp["launches"] else "k_batch, one launch per stage",
                                  basis="algorithmic bytes (32 B per message, SURVEY §8d) / sweep time",
-                                 bound_detail=f"not a bandwidth-bound schedule: {st['stages']} dependent stages, each a launch of its own (≈ {dt / max(st['stages'], 1) * 1e6:.1f} us "
-                                              "per stage at this size): the time is depth x per-kernel time"),
+                                 bound_detail=f"not a bandwidth-bound schedule: {launches} dependent launches (≈ {dt / max(launches, 1) * 1e6:.1f} us "
+                                              "each at this size): the time is the number of dependent launches x per-kernel time"),
             "parity": {"max_rel_err_marginals": err, "ok": bool(err < 1e-9), "checker": "the fused schedule at its fixed point on the same device (the tree "
                        "schedule against a dense solve: tests/test_gpu_tree.py)", "sample": f"{len(ids)} marginals"}}
 
