@@ -430,6 +430,16 @@ __device__ __forceinline__ Msg<D> mvc_side_right(const MvcArgs &A, int l, int64_
     return u;
 }
 
+template <int D>
+__device__ __forceinline__ Msg<D> msg_nan() {
+    Msg<D> m;
+#pragma unroll
+    for (int i = 0; i < D; i++) m.eta[i] = __builtin_nan("");
+#pragma unroll
+    for (int i = 0; i < Msg<D>::NT; i++) m.lam[i] = __builtin_nan("");
+    return m;
+}
+
 constexpr int kMvcTabLds = 16;           // rule tables (parameter set x direction) kept in LDS; graphs with more read them from memory
 
 template <int D, bool GT>
@@ -443,6 +453,7 @@ template <int D, bool GT>
 __device__ __forceinline__ void mvc_thread_total(CMap<D> &tot, const MvcArgs &A, const double *tab_s, int l0, int64_t il0, int K, int dir) {
     using M = CMap<D>;
     tot = cmap_identity<D>();
+    // (the next link's loads in flight while this link's map is appended — what the walks do — measured: no gain here, 0.243 vs 0.241 ms)
 #pragma unroll 1
     for (int k = 0; k < K; k++) {
         const int kk = dir > 0 ? k : K - 1 - k, l = l0 + kk;
@@ -578,16 +589,6 @@ __global__ __launch_bounds__(kBlock) void k_mvc_scan_totals(int ntiles, double *
 }
 
 template <int D>
-__device__ __forceinline__ Msg<D> msg_nan() {
-    Msg<D> m;
-#pragma unroll
-    for (int i = 0; i < D; i++) m.eta[i] = __builtin_nan("");
-#pragma unroll
-    for (int i = 0; i < Msg<D>::NT; i++) m.lam[i] = __builtin_nan("");
-    return m;
-}
-
-template <int D>
 __device__ __forceinline__ void marg_store(double *__restrict__ marg, int64_t, int64_t v, const Msg<D> &nat) {
     slot_store_nt<D>(marg, (int)v, mv_to_moment<D>(nat));      // marginals: the messages' pair form, indexed by the variable
 }
@@ -595,9 +596,12 @@ __device__ __forceinline__ void marg_store(double *__restrict__ marg, int64_t, i
 // grid (ntiles, 2): the forward and the backward walks are independent of each other.
 // flags & 1: marginals are wanted (the backward walk writes those of the first variable of every path itself; all others come
 // from alpha + gamma in k_mvc_marg_out).  flags & 2: alpha_l / beta_l also go to their SELL slots f2v[to_slot[l]] / f2v[from_slot[l]].
-template <int D, bool GT>
-__global__ __launch_bounds__(kBlock, 4) void k_mvc_apply(MvcArgs A, int K, const double *__restrict__ excl, double *__restrict__ f2v,
-                                                      double *__restrict__ marg, int flags) {
+// PF (round 4): the walks fetch the NEXT step's side information, head flag and table index while the current step's rule runs — and
+// the first step's before the tile carry is composed; a step of the plain form is a memory round trip, then the rule, then the
+// stores, at the two waves per SIMD a chain of 1e6 links fills (the registers are held to two waves per SIMD then, not four).
+template <int D, bool GT, bool PF>
+__global__ __launch_bounds__(kBlock, PF ? 2 : 4) void k_mvc_apply(MvcArgs A, int K, const double *__restrict__ excl, double *__restrict__ f2v,
+                                                               double *__restrict__ marg, int flags) {
     constexpr int E = CMap<D>::ND + 1;
     using M = CMap<D>;
     __shared__ double tab_s[GT ? 1 : kMvcTabLds * 3 * D * D];
@@ -608,6 +612,19 @@ __global__ __launch_bounds__(kBlock, 4) void k_mvc_apply(MvcArgs A, int K, const
     const int l0 = (int)gid * K;
     const int64_t il0 = (int64_t)blockIdx.x * kBlock * K + tid;
     const int pos = dir > 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;
+    // PF: what the first step of the walk reads, issued before the carry
+    Msg<D> nx = msg_nan<D>();
+    int nx_head = 0, nx_tab = 0;
+    if (PF) {
+        const int k = dir > 0 ? 0 : K - 1, l = l0 + k;
+        // (backward: a thread whose run is ragged starts at its last existing link — found below; prefetch only the common case)
+        if (l < A.nlinks) {
+            const int64_t il = il0 + (int64_t)k * kBlock;
+            nx = dir > 0 ? slot_load<D, true>(A.side_l, (int)il) : mvc_side_right<D>(A, l, il, K);
+            nx_head = dir > 0 ? A.head_fwd[l] : A.head_bwd[l];
+            nx_tab = dir > 0 ? A.tab_fwd[l] : A.tab_bwd[l];
+        }
+    }
     // ---- the tile carry: the composition of the tile totals before this tile in the direction's scan order, by the workgroup's FIRST
     // WAVE (a launch of one workgroup per direction used to scan them, 25 us of pure latency): every lane
     // composes its run of consecutive totals straight from memory, then the 64 partial products are reduced in order through LDS —
@@ -652,22 +669,44 @@ __global__ __launch_bounds__(kBlock, 4) void k_mvc_apply(MvcArgs A, int K, const
             const int l = l0 + k;
             if (l >= A.nlinks) break;
             const int64_t il = il0 + (int64_t)k * kBlock;
-            Msg<D> in = slot_load<D, true>(A.side_l, (int)il);
-            if (!A.head_fwd[l]) msg_add<D>(in, cur);
-            cur = mv_rule<D, false>(in, mvc_tab<D, GT>(A, tab_s, A.tab_fwd[l]));
+            Msg<D> in;
+            int head, tab;
+            if (PF) {
+                in = nx; head = nx_head; tab = nx_tab;
+                if (k + 1 < K && l + 1 < A.nlinks) {
+                    nx = slot_load<D, true>(A.side_l, (int)(il + kBlock));
+                    nx_head = A.head_fwd[l + 1]; nx_tab = A.tab_fwd[l + 1];
+                }
+            } else {
+                in = slot_load<D, true>(A.side_l, (int)il);
+                head = A.head_fwd[l]; tab = A.tab_fwd[l];
+            }
+            if (!head) msg_add<D>(in, cur);
+            cur = mv_rule<D, false>(in, mvc_tab<D, GT>(A, tab_s, tab));
             slot_store<D>(A.alpha, (int)il, cur);
             if (store_msgs && !__builtin_isnan(cur.lam[0])) slot_store<D>(f2v, A.to_slot[l], cur);
         }
     } else {
+        bool have = PF && l0 + K - 1 < A.nlinks;        // the prefetch at the top was for step K - 1
 #pragma unroll 1
         for (int k = K - 1; k >= 0; k--) {
             const int l = l0 + k;
             if (l >= A.nlinks) continue;
             const int64_t il = il0 + (int64_t)k * kBlock;
-            Msg<D> in = mvc_side_right<D>(A, l, il, K);             // what the right variable hears from everybody but this link
-            if (!A.head_bwd[l]) msg_add<D>(in, cur);
+            Msg<D> in;                                               // what the right variable hears from everybody but this link
+            int head, tab;
+            if (PF) {
+                if (!have) { nx = mvc_side_right<D>(A, l, il, K); nx_head = A.head_bwd[l]; nx_tab = A.tab_bwd[l]; }
+                in = nx; head = nx_head; tab = nx_tab;
+                have = k > 0;
+                if (have) { nx = mvc_side_right<D>(A, l - 1, il - kBlock, K); nx_head = A.head_bwd[l - 1]; nx_tab = A.tab_bwd[l - 1]; }
+            } else {
+                in = mvc_side_right<D>(A, l, il, K);
+                head = A.head_bwd[l]; tab = A.tab_bwd[l];
+            }
+            if (!head) msg_add<D>(in, cur);
             slot_store<D>(A.gamma, (int)il, in);
-            cur = mv_rule<D, false>(in, mvc_tab<D, GT>(A, tab_s, A.tab_bwd[l]));
+            cur = mv_rule<D, false>(in, mvc_tab<D, GT>(A, tab_s, tab));
             if (store_msgs && !__builtin_isnan(cur.lam[0])) slot_store<D>(f2v, A.from_slot[l], cur);
             if (write_marg && A.head_fwd[l]) {                        // the first variable of a path hears no alpha
                 const int p = A.link_pos[l];
@@ -914,7 +953,10 @@ static void mvc_launch_t(cx_handle *h, const MvcArgs &A, int K, int flags, bool 
     // (the tile totals stay as k_mvc_totals left them: the walks' workgroups compose their own carry from them — also when only the
     // walks run again, scan == false)
     if (scan) hipLaunchKernelGGL((k_mvc_totals<D, GT>), dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, K, h->d_mvc_totals);
-    hipLaunchKernelGGL((k_mvc_apply<D, GT>), dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, K, h->d_mvc_totals, h->d_mv_f2v, h->d_mv_marg, flags);
+    // CX_MVC_PREFETCH=0: the walks without the next step's loads in flight (A/B)
+    static const bool pf = [] { const char *e = getenv("CX_MVC_PREFETCH"); return !(e && e[0] == '0'); }();
+    if (pf) hipLaunchKernelGGL((k_mvc_apply<D, GT, true>), dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, K, h->d_mvc_totals, h->d_mv_f2v, h->d_mv_marg, flags);
+    else hipLaunchKernelGGL((k_mvc_apply<D, GT, false>), dim3(ntiles, 2), dim3(kBlock), 0, h->stream, A, K, h->d_mvc_totals, h->d_mv_f2v, h->d_mv_marg, flags);
     if ((flags & 1) && !(flags & 4)) mvc_marg_out_t<D>(h, A, K);
 }
 

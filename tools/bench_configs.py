@@ -86,7 +86,7 @@ def c2(check=None):
     fl.sweep(3)
     dtf = timed(fl, lambda: fl.sweep(1), 200, 20)
     nf = fl.stats()["n_messages_per_sweep"]
-    tr = counter_traffic(["k_chain_tile_totals", "k_chain_apply<true, true>"])   # the steady-state launches of one sweep (245 tiles: no scan-of-totals kernel)
+    tr = counter_traffic(["k_chain_run_totals", "k_chain_run_apply"])   # the steady-state launches of one sweep (245 tiles: no scan-of-totals kernel)
     alg = (5 * T - 4) * 32
     achieved = (tr[0] if tr else alg) / dt / 1e9
     return {"config": "C2", "workload": f"scalar chain T={T} ({st['n_edges']} edges), chain-scan schedule: exact forward/backward in one sweep",
