@@ -54,6 +54,8 @@ struct Vmp {
     std::vector<int32_t> nb_off, nb_fac;        // CSR: factors of every Normal variable, ascending factor id
     int64_t n_latent = 0;
     bool chain_ready = false;                   // structured: the inner handle has swept at least once
+    std::vector<uint8_t> g_fresh;               // structured: the precision variable was updated since the states last were (what a request that
+                                                // names states and precisions together depends on: vmp_update_marginals)
     // device
     double *n_mean = nullptr, *n_prec = nullptr, *n_mean_alt = nullptr, *n_prec_alt = nullptr;
     uint8_t *d_observed = nullptr, *d_mask = nullptr;
@@ -349,6 +351,7 @@ int32_t vmp_graph_create(cx_handle *h, int64_t ne, const int64_t *edge_var, cons
         s->g_chunk_off[s->nG] = (int32_t)chunk_begin.size();
         s->nChunks = (int64_t)chunk_begin.size();
         s->g_needs_chain.assign(s->nG, 0);
+        s->g_fresh.assign(s->nG, 0);
 
         VMP_HIP(h, hipSetDevice(h->cfg.device));
         int32_t rc;
@@ -556,11 +559,48 @@ int32_t vmp_update_marginals(cx_handle *h, int64_t n, const int64_t *ids) {
         VMP_HIP(h, hipSetDevice(h->cfg.device));
         const bool do_normal = n_normal > 0, do_gamma = !req.empty();
         if (s->structured) {
-            VMP_REQUIRE(h, !(do_normal && do_gamma), CX_ERR_UNSUPPORTED,
-                        "cx_update_marginals (structured): request the Normal variables and the precision variables in separate calls "
-                        "(in the reference the order of evaluation of such a mixed request emerges from the lazy readiness flags)");
             VMP_REQUIRE(h, !do_normal || n_normal == n_latent, CX_ERR_UNSUPPORTED,
                         "cx_update_marginals (structured): the latent Normal variables are updated together (one belief-propagation pass)");
+            if (do_normal && do_gamma) {
+                // A request that names states AND precisions (the last call of the reference's own experiment,
+                // test/inference_engine_tests.jl:1113).  In the reference its order of evaluation emerges from the lazy readiness flags
+                // (src/inference_engine.jl:575-608); pinned against the restated engine (tests/test_vmp_restatement.py) it is, whenever
+                //   (a) the states have been updated before (the joint marginals exist) and the chain precisions have degree > 5,
+                //   (b) every precision of a factor between two latent states (a "chain" precision) is named BEFORE the first state,
+                //   (c) every other requested precision was updated since the states last were,
+                // exactly three calls, class by class: the chain precisions (found pending by the first chain message and computed on
+                // the fly), the states, the other precisions (in the final round, from the new states).  Anything else interleaves per
+                // variable in the reference (some messages read the old expectation, some the new one): refused, as before.
+                const char *why = "cx_update_marginals (structured): a request that names states and precisions together is accepted when the states "
+                                  "were updated before, every precision of a transition factor (degree > 5) comes before the first state in the "
+                                  "request and every other requested precision was updated since the last state update — otherwise the reference's "
+                                  "order of evaluation interleaves per variable: request the classes in separate calls";
+                VMP_REQUIRE(h, s->chain_ready && n >= 0, CX_ERR_UNSUPPORTED, why);
+                std::vector<uint8_t> chain_g(s->nG, 0);
+                for (int64_t f = 0; f < s->nF; f++)
+                    if (!s->n_observed[s->f_out[f]] && !s->n_observed[s->f_mean[f]]) chain_g[s->f_gamma[f]] = 1;
+                std::vector<int64_t> ids_chain, ids_state, ids_other;
+                bool seen_state = false;
+                for (int64_t i = 0; i < n; i++) {
+                    const int64_t v = find_var(s, ids[i]);
+                    if (s->var_kind[v] != 1) { if (!s->n_observed[s->var_local[v]]) { seen_state = true; ids_state.push_back(ids[i]); } continue; }
+                    const int32_t g = s->var_local[v];
+                    if (chain_g[g]) {
+                        VMP_REQUIRE(h, !seen_state && s->g_deg[g] > 5, CX_ERR_UNSUPPORTED, why);
+                        ids_chain.push_back(ids[i]);
+                    } else {
+                        VMP_REQUIRE(h, s->g_fresh[g], CX_ERR_UNSUPPORTED, why);
+                        ids_other.push_back(ids[i]);
+                    }
+                }
+                const int64_t before = h->sweeps_done;
+                int32_t rc = CX_OK;
+                if (!ids_chain.empty()) rc = vmp_update_marginals(h, (int64_t)ids_chain.size(), ids_chain.data());
+                if (rc == CX_OK) rc = vmp_update_marginals(h, (int64_t)ids_state.size(), ids_state.data());
+                if (rc == CX_OK && !ids_other.empty()) rc = vmp_update_marginals(h, (int64_t)ids_other.size(), ids_other.data());
+                if (rc == CX_OK) h->sweeps_done = before + 1;      // one call of the caller's
+                return rc;
+            }
         }
         if (do_gamma) {
             // which precision variables need the chain messages (a factor with two latent Normal variables)
@@ -620,6 +660,10 @@ int32_t vmp_update_marginals(cx_handle *h, int64_t n, const int64_t *ids) {
             if (!c->split_marg_written)
                 hipLaunchKernelGGL(k_pull_marginals, dim3(blocks(s->nN)), dim3(256), 0, h->stream, (int)s->nN, c->d_marg, s->d_observed, s->n_mean, s->n_prec);
             s->chain_ready = true;
+        }
+        if (s->structured) {
+            if (do_normal) std::fill(s->g_fresh.begin(), s->g_fresh.end(), 0);
+            for (int32_t g : req) s->g_fresh[g] = 1;
         }
         VMP_HIP(h, hipGetLastError());
         h->sweeps_done++;
@@ -715,6 +759,7 @@ int32_t vmp_state_import(cx_handle *h, const void *buf, int64_t bytes) {
     VMP_HIP(h, hipMemcpy(s->g_scale, o, (size_t)s->nG * 8, hipMemcpyHostToDevice)); o += s->nG * 8;
     VMP_HIP(h, hipMemcpy(s->g_mean, o, (size_t)s->nG * 8, hipMemcpyHostToDevice)); o += s->nG * 8;
     s->n_latent = hd.n_latent; s->chain_ready = hd.chain_ready != 0;
+    std::fill(s->g_fresh.begin(), s->g_fresh.end(), 0);      // (not in the blob: a request of states and precisions together waits for the precisions' next update)
     h->sweeps_done = hd.sweeps_done; h->n_messages_per_sweep = hd.n_messages;
     return CX_OK;
 }

@@ -235,9 +235,13 @@ int32_t cx_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
  *                       wiring: the messages into the requested variables are computed from the marginals as they stand
  *                       before the call, then the requested marginals are stored.  n may be CX_VMP_ALL_NORMAL or
  *                       CX_VMP_ALL_PRECISION (variable_ids ignored) to name a whole class without an id list.
- *                       CX_FAMILY_VMP_STRUCTURED updates the latent Normal variables together and refuses requests that
- *                       mix them with precision variables (in the reference the evaluation order of such a request is
- *                       an artefact of the lazy readiness flags).  Asynchronous on the handle's stream.
+ *                       CX_FAMILY_VMP_STRUCTURED updates the latent Normal variables together.  A request that names them TOGETHER
+ *                       with precision variables (the last call of the reference's experiment, test/inference_engine_tests.jl:1113)
+ *                       is evaluated by the reference in an order that emerges from its lazy readiness flags; it is accepted where
+ *                       that order is class by class — transition precisions, states, other precisions — i.e. when the states were
+ *                       updated before, every precision of a transition factor (degree > 5) precedes the first state in the list and
+ *                       every other requested precision was updated since the states last were; CX_ERR_UNSUPPORTED otherwise (the
+ *                       reference then interleaves per variable).  Asynchronous on the handle's stream.
  * cx_get_marginals    : (mean, precision) for Normal variables ((datum, +inf) when observed), (shape, scale) for precisions. */
 #define CX_VMP_ALL_NORMAL (-1)
 #define CX_VMP_ALL_PRECISION (-2)

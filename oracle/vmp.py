@@ -110,6 +110,32 @@ class StructuredVMP(_Base):
         super().__init__(y)
         self.joint = None          # (mu1, mu2, W11, W12, W22) arrays of the n-1 joint marginals, undefined before update(x)
         self.to_f = None           # the chain messages into the transition factors, as the last update(x) left them
+        self.obs_fresh = False     # q(obsnoise) was updated since the states last were
+
+    def update(self, which):
+        """One update_marginals! call.  A request of ONE class, or of the two precisions, is the base class's Jacobi step.  A request
+        that names the states TOGETHER with precisions (the last call of the reference's experiment, :1113) is evaluated in an order
+        that emerges from the lazy readiness flags (src/inference_engine.jl:575-608); pinned against the restated engine
+        (tests/test_vmp_restatement.py) it is three calls, class by class — q(ssnoise) (found pending by the first chain message and
+        computed on the fly), the states, q(obsnoise) (final round, from the new states) — whenever the states were updated before,
+        n - 1 > 5, "ssnoise" comes before "x" in the request and q(obsnoise) was updated since the states last were.  Outside these
+        conditions the reference interleaves per variable (some messages read the old expectation, some the new one): no array form."""
+        which = list(which)
+        if "x" in which and len(which) > 1:
+            ok = self.joint is not None and self.n - 1 > 5
+            ok = ok and ("ssnoise" not in which or which.index("ssnoise") < which.index("x"))
+            ok = ok and ("obsnoise" not in which or self.obs_fresh)
+            if not ok:
+                raise NotImplementedError("a request of states and precisions together outside the conditions of StructuredVMP.update")
+            for w in ("ssnoise", "x", "obsnoise"):
+                if w in which:
+                    self.update([w])
+            return
+        super().update(which)
+        if "x" in which:
+            self.obs_fresh = False
+        if "obsnoise" in which:
+            self.obs_fresh = True
 
     def _x(self):
         n, tau_s, tau_o = self.n, self.gmean(self.ss), self.gmean(self.obs)

@@ -41,8 +41,11 @@ def _ids_of(model, which):
 
 MF_SEQ = [["x"], ["ssnoise"], ["obsnoise"], ["obsnoise"], ["ssnoise"], ["ssnoise", "obsnoise"], ["x"], ["x", "ssnoise", "obsnoise"],
           ["obsnoise", "x"]]
+# (the last three: states TOGETHER with precisions, as the reference's experiment ends an iteration, test/inference_engine_tests.jl:1113;
+# accepted where the reference's emergent order is class by class — oracle/vmp.py: StructuredVMP.update — n - 1 > 5)
 ST_SEQ = [["obsnoise"], ["ssnoise"], ["x"], ["ssnoise"], ["ssnoise"], ["ssnoise"], ["x"], ["x"], ["obsnoise"], ["obsnoise"],
           ["ssnoise", "obsnoise"]]
+ST_TOGETHER = [["ssnoise", "obsnoise", "x"], ["obsnoise"], ["ssnoise", "x"], ["obsnoise"], ["obsnoise", "x"]]
 
 
 @pytest.mark.parametrize("n", [2, 3, 8, 100, 5000])
@@ -64,7 +67,7 @@ def test_structured_calls_match_the_array_form(hip_lib, n, schedule):
     dev = _device(model, L.FAMILY_VMP_STRUCTURED, schedule)
     arr = vmp.StructuredVMP(model.data_y)
     for it in range(4):
-        for which in ST_SEQ:
+        for which in ST_SEQ + (ST_TOGETHER if n - 1 > 5 else []):
             dev.update_marginals(_ids_of(model, which))
             arr.update(which)
             np.testing.assert_allclose(_state(dev, model), _array_state(arr), rtol=1e-9, atol=0, err_msg=f"n={n} it={it} {which}")
@@ -79,7 +82,7 @@ def test_reference_experiment_against_the_restated_engine(hip_lib, kind, family,
     model = cx.synth.vmp_ssm(n, seed=1234)
     dev = _device(model, family)
     be = S.OracleBackend(rule)
-    calls_of = S.mean_field_calls if kind == "mean_field" else S.structured_calls_by_class
+    calls_of = S.mean_field_calls if kind == "mean_field" else S.structured_calls      # every call of the reference's experiment, the last one (:1113) included
     checked = [0]
 
     def on_call(it, ids):
@@ -122,8 +125,20 @@ def test_vmp_recovers_the_noise_precisions_at_scale(hip_lib):
 def test_vmp_errors(hip_lib):
     model = cx.synth.vmp_ssm(10, seed=1)
     dev = _device(model, L.FAMILY_VMP_STRUCTURED)
-    with pytest.raises(cx.CortexHipError, match="separate calls"):
+    with pytest.raises(cx.CortexHipError, match="separate calls"):      # no state update yet
         dev.update_marginals([model.ssnoise] + list(model.x_ids))
+    dev.update_marginals(model.x_ids)
+    with pytest.raises(cx.CortexHipError, match="separate calls"):      # the transition precision after the first state
+        dev.update_marginals(list(model.x_ids) + [model.ssnoise])
+    with pytest.raises(cx.CortexHipError, match="separate calls"):      # q(obsnoise) not updated since the states were
+        dev.update_marginals([model.obsnoise] + list(model.x_ids))
+    before = _state(dev, model)
+    dev.update_marginals([model.ssnoise] + list(model.x_ids))            # accepted: the precision first, nothing stale
+    assert not np.array_equal(before, _state(dev, model))
+    small = _device(cx.synth.vmp_ssm(5, seed=1), L.FAMILY_VMP_STRUCTURED)
+    small.update_marginals(cx.synth.vmp_ssm(5, seed=1).x_ids)
+    with pytest.raises(cx.CortexHipError, match="separate calls"):      # degree <= 5: the joints are read as the last state update left them
+        small.update_marginals([1] + list(cx.synth.vmp_ssm(5, seed=1).x_ids))
     with pytest.raises(cx.CortexHipError, match="together"):
         dev.update_marginals(model.x_ids[:3])
     with pytest.raises(cx.CortexHipError, match="unknown variable id"):
@@ -178,7 +193,7 @@ def test_vmp_processor_behind_the_engine_api(hip_lib, family, rule, kind):
     for v, d in zip(y, data):
         proc.set_value(marginal(v), d)
     be = S.OracleBackend(rule)
-    calls_of = S.mean_field_calls if kind == "mean_field" else S.structured_calls_by_class
+    calls_of = S.mean_field_calls if kind == "mean_field" else S.structured_calls      # the last call of an iteration names states and precisions together (:1113)
 
     def on_call(it, ids):
         cx.update_marginals(engine, ids)
