@@ -132,7 +132,8 @@ int32_t build_tree(cx_handle *h) {
         // when it needs fewer launches than the level schedule's 2 x depth + 1 — chains with side branches, not bushy trees.
         // CX_TREE_HP=0 / 1: never / whenever the graph allows (A/B, tests).
         h->tree_hp = false;
-        if (h->cfg.dim == 1 && h->cfg.family != CX_FAMILY_NATURAL2) {
+        const bool hp_mv = h->cfg.dim >= 2 && h->cfg.dim <= 4;      // (dim 2 .. 4: the scans of cx_mvchain.hip per light depth)
+        if ((h->cfg.dim == 1 && h->cfg.family != CX_FAMILY_NATURAL2) || hp_mv) {
             const char *hp_e = std::getenv("CX_TREE_HP");
             const int hp_env = hp_e ? std::atoi(hp_e) : -1;
             cx::treeplan::HP hp;
@@ -155,10 +156,39 @@ int32_t build_tree(cx_handle *h) {
                 if ((rc2 = dev_upload(h, &h->d_chain_to, hp.to)) != CX_OK) return rc2;
                 if ((rc2 = dev_upload(h, &h->d_chain_head_fwd, hp.head_fwd)) != CX_OK) return rc2;
                 if ((rc2 = dev_upload(h, &h->d_chain_head_bwd, hp.head_bwd)) != CX_OK) return rc2;
-                if ((rc2 = dev_alloc(h, &h->d_chain_side, (int64_t)hp.pos_var.size())) != CX_OK) return rc2;
-                char *tot = nullptr;
-                if ((rc2 = dev_alloc(h, &tot, (int64_t)cx::chain_total_bytes((int64_t)hp.link_pos.size()))) != CX_OK) return rc2;
-                h->d_chain_totals = tot;
+                h->tree_hp_K.clear(); h->tree_hp_npos = (int64_t)hp.pos_var.size();
+                if (!hp_mv) {
+                    if ((rc2 = dev_alloc(h, &h->d_chain_side, (int64_t)hp.pos_var.size())) != CX_OK) return rc2;
+                    char *tot = nullptr;
+                    if ((rc2 = dev_alloc(h, &tot, (int64_t)cx::chain_total_bytes((int64_t)hp.link_pos.size()))) != CX_OK) return rc2;
+                    h->d_chain_totals = tot;
+                } else {
+                    for (void *p : {(void *)h->d_chain_tab_fwd, (void *)h->d_chain_tab_bwd, (void *)h->d_mvc_side, (void *)h->d_mvc_totals, (void *)h->d_mvc_side_l,
+                                    (void *)h->d_mvc_alpha, (void *)h->d_mvc_gamma, (void *)h->d_mvc_prefix, (void *)h->d_mvc_wave_carry}) if (p) (void)hipFree(p);
+                    h->d_chain_tab_fwd = h->d_chain_tab_bwd = nullptr; h->d_mvc_side = h->d_mvc_totals = nullptr;
+                    h->d_mvc_side_l = h->d_mvc_alpha = h->d_mvc_gamma = h->d_mvc_prefix = h->d_mvc_wave_carry = nullptr;
+                    std::vector<int32_t> tab_fwd(hp.from.size()), tab_bwd(hp.from.size());
+                    for (size_t l = 0; l < hp.from.size(); l++) { tab_fwd[l] = h->spdir[hp.from[l]]; tab_bwd[l] = h->spdir[hp.to[l]]; }      // the SENDING slot's table (cx_chains.h)
+                    if ((rc2 = dev_upload(h, &h->d_chain_tab_fwd, tab_fwd)) != CX_OK) return rc2;
+                    if ((rc2 = dev_upload(h, &h->d_chain_tab_bwd, tab_bwd)) != CX_OK) return rc2;
+                    int64_t il = 0, pre = 0, wc = 0, tot = 0;
+                    for (int32_t L = 0; L < hp.levels; L++) {
+                        const int64_t nl = hp.link_off[L + 1] - hp.link_off[L];
+                        const int K = cx::mvc_links_per_thread(nl);
+                        h->tree_hp_K.push_back(K);
+                        il = std::max<int64_t>(il, cx::mvc_ntiles(nl, K) * cx::kBlock * K);
+                        pre = std::max<int64_t>(pre, (int64_t)cx::mvc_prefix_doubles(h->cfg.dim, nl, K));
+                        wc = std::max<int64_t>(wc, (int64_t)cx::mvc_wave_carry_doubles(h->cfg.dim, nl, K));
+                        tot = std::max<int64_t>(tot, (int64_t)cx::mvc_totals_doubles(h->cfg.dim, nl, K));
+                    }
+                    if ((rc2 = dev_alloc(h, &h->d_mvc_side, h->nc * (int64_t)hp.pos_var.size())) != CX_OK) return rc2;
+                    if ((rc2 = dev_alloc(h, &h->d_mvc_side_l, h->ncs * il)) != CX_OK) return rc2;
+                    if ((rc2 = dev_alloc(h, &h->d_mvc_alpha, h->ncs * il)) != CX_OK) return rc2;
+                    if ((rc2 = dev_alloc(h, &h->d_mvc_gamma, h->ncs * il)) != CX_OK) return rc2;
+                    if ((rc2 = dev_alloc(h, &h->d_mvc_prefix, pre)) != CX_OK) return rc2;
+                    if ((rc2 = dev_alloc(h, &h->d_mvc_wave_carry, wc)) != CX_OK) return rc2;
+                    if ((rc2 = dev_alloc(h, &h->d_mvc_totals, tot)) != CX_OK) return rc2;
+                }
                 for (void *p : {(void *)h->d_tree_a, (void *)h->d_tree_b}) if (p) (void)hipFree(p);
                 h->d_tree_a = h->d_tree_b = nullptr;
                 h->tree_hp_kary_links = hp.n_kary_links;
@@ -237,7 +267,12 @@ static void tree_issue(cx_handle *h) {
             if (kind == 0) {
                 if (idx == h->tree_hp_marginal_stage && h->cfg.compute_marginals_in_sweep == 0) continue;
                 const int64_t n = h->tree_stage_off[idx + 1] - h->tree_stage_off[idx];
-                if (n > 0) cx::launch_batch(h, h->d_tree_rec + 5 * h->tree_stage_off[idx], n);
+                if (n > 0 && h->cfg.dim > 1) cx::mv_launch_batch(h, h->d_tree_rec + 5 * h->tree_stage_off[idx], n);
+                else if (n > 0) cx::launch_batch(h, h->d_tree_rec + 5 * h->tree_stage_off[idx], n);
+            } else if (h->cfg.dim > 1) {
+                const int64_t l0 = h->tree_hp_link_off[idx];
+                cx::mvc_launch_scan_range(h, h->tree_hp_npos, h->tree_hp_pos_off[idx + 1], l0, h->tree_hp_link_off[idx + 1] - l0, h->tree_hp_K[idx],
+                                          kind == 1 ? h->d_chain_skip1 : h->d_tree_skip1_down, kind == 2);
             } else if (kind == 3) {
                 const int64_t l0 = h->tree_hp_link_off[idx];
                 cx::launch_kary_link_params(h, l0, h->tree_hp_link_off[idx + 1] - l0, h->d_tree_a ? h->d_tree_a : h->d_a, h->d_tree_b ? h->d_tree_b : h->d_b);

@@ -129,6 +129,10 @@ struct cx_handle {
     // (cx_kary.hip: k_kary_link_params) into d_q and into d_a / d_b — or, on a graph without pairwise linear factors, into these
     double *d_tree_a = nullptr, *d_tree_b = nullptr;
     int64_t tree_hp_kary_links = 0;
+    // dim 2 .. 4 over heavy paths: the scans of cx_mvchain.hip on a light depth's range; links per thread chosen per depth, the
+    // interleaved buffers (d_mvc_*) sized for the largest depth and shared by all of them
+    std::vector<int32_t> tree_hp_K;
+    int64_t tree_hp_npos = 0;
     int64_t chain_npos = 0, chain_nlinks = 0;
     int64_t chain_npos_linked = 0;   // dim > 1: positions [0, this) belong to paths with links; the isolated ones follow
     bool chain_side_dirty = true;    // the leaf messages / side sums of the chain positions must be recomputed (data or rule parameters changed)
@@ -290,6 +294,7 @@ int64_t mvc_ntiles(int64_t nlinks, int K);
 size_t mvc_totals_doubles(int dim, int64_t nlinks, int K);
 void mvc_launch_side(cx_handle *h, bool write_marg);
 void mvc_launch_scan(cx_handle *h, bool write_marg, bool store_msgs, bool scan, bool defer_marg = false);
+void mvc_launch_scan_range(cx_handle *h, int64_t npos_total, int64_t pos_hi, int64_t link_lo, int64_t nlinks, int K, const int32_t *skip1, bool final);
 void mvc_launch_marg_out(cx_handle *h);
 void mvc_launch_marg_gather(cx_handle *h, const int32_t *d_vars, int64_t n, double *d_val);   // a few marginals from alpha + gamma (rows of nc doubles, moment form, packed)      // alpha + gamma of the last sweep -> the marginals (what a sweep with defer_marg left undone)
 void mvc_launch_block_maps(cx_handle *h);

@@ -1009,6 +1009,36 @@ void mvc_launch_scan(cx_handle *h, bool write_marg, bool store_msgs, bool scan, 
 #undef CX_MVC
 }
 
+// CX_SCHED_TREE over heavy paths, dim 2 .. 4 (cx_tree_plan.h: build_hp): the scan of ONE light depth — links [link_lo, link_lo + nlinks)
+// of the plan's arrays (positions stay global: link_pos, the by-position side sums and pos_var are indexed by them; pos_hi = one past the
+// depth's last position).  `skip1`: the second skipped slot of every position (on the way up a head also skips its slot towards its
+// parent).  final: both directions are exact — the messages go to their slots and the marginals of the paths' variables are written;
+// otherwise the messages only (the way up reads those towards the heads).  The interleaved buffers are scratch shared by all depths.
+void mvc_launch_scan_range(cx_handle *h, int64_t npos_total, int64_t pos_hi, int64_t link_lo, int64_t nlinks, int K, const int32_t *skip1, bool final) {
+    if (nlinks <= 0) return;
+    const dim3 b(kBlock);
+    const dim3 gl((unsigned)(mvc_ntiles(nlinks, K) * ((kBlock + mvc_side_slab_threads(K) - 1) / mvc_side_slab_threads(K))));
+    const int span = mvc_side_slab_threads(K) * K + 8;
+    const size_t lds = (size_t)h->nc * (span + span / 32 + 1) * sizeof(double);
+#define CX_MVC(DD) hipLaunchKernelGGL((k_mvc_side_links<DD>), gl, b, lds, h->stream, (int)nlinks, (int)npos_total, (int)pos_hi, K, h->d_chain_link_pos + link_lo, \
+                                      h->d_chain_pos_var, h->d_chain_skip0, skip1, h->d_vbase, h->d_vinfo, h->d_mv_f2v, h->d_mvc_side, h->d_mvc_side_l)
+    if (h->cfg.dim == 2) CX_MVC(2);
+    else if (h->cfg.dim == 3) CX_MVC(3);
+    else CX_MVC(4);
+#undef CX_MVC
+    MvcArgs A{(int)nlinks, (int)npos_total, (int)h->nv, (int)(2 * h->ptab_sets), h->nslots, h->d_chain_link_pos + link_lo, h->d_chain_from + link_lo,
+              h->d_chain_to + link_lo, h->d_chain_tab_fwd + link_lo, h->d_chain_tab_bwd + link_lo, h->d_chain_head_fwd + link_lo, h->d_chain_head_bwd + link_lo,
+              h->d_chain_pos_var, h->d_mvc_side, h->d_mvc_side_l, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix, h->d_mvc_wave_carry,
+              mvc_ntiles(nlinks, K) * kBlock * K, 1, h->d_ptab};
+    const bool gt = A.ntab > kMvcTabLds;
+    const int flags = final ? 3 : 2;
+#define CX_MVC(DD) do { if (gt) mvc_launch_t<DD, true>(h, A, K, flags, true); else mvc_launch_t<DD, false>(h, A, K, flags, true); } while (0)
+    if (h->cfg.dim == 2) CX_MVC(2);
+    else if (h->cfg.dim == 3) CX_MVC(3);
+    else CX_MVC(4);
+#undef CX_MVC
+}
+
 // The composed forward and backward maps of the handle's one path, heads NOT collapsed: totals + scan of the totals only, the
 // two maps end up in h->d_mvc_block (2 x (ND + 1) doubles).  The stored thread prefixes are overwritten: the caller materialises
 // the last sweep's messages first (mv_ensure_chain_msgs) and marks the side sums dirty.

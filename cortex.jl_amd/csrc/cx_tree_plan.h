@@ -196,7 +196,7 @@ int32_t build(const H *h, Out &out, std::string &err) {
     return CX_OK;
 }
 
-// ---- heavy paths: the same exact sweep in O(log n) rounds of launches instead of one per level -------------------------------------
+// ---- heavy paths (scalar messages and dim 2 .. 4): the same exact sweep in O(log n) rounds of launches instead of one per level -------
 // The level schedule pays two launches per level of the tree: a chain with side branches (a state-space model whose states carry a
 // latent layer of their own: depth ~ T) costs ~ 2 T launches.  Here every variable picks its HEAVY child — the child with the largest
 // subtree among those it reaches through a two-edge factor — and the heavy edges form disjoint paths; any root-to-leaf walk leaves a
@@ -344,7 +344,10 @@ int32_t build_hp(const H *h, HP &out, std::string &err) {
     auto m2v = [&](int32_t e) {
         const int32_t sl = slot(e);
         if (!h->slot_kary.empty() && h->slot_kary[sl] >= 0) curk.push_back(h->slot_kary[sl]);
-        else if (h->partner[sl] >= 0) push_item(CX_ITEM_MESSAGE_TO_VARIABLE, sl, h->edge_var[e]);
+        else if (h->partner[sl] >= 0) {
+            push_item(CX_ITEM_MESSAGE_TO_VARIABLE, sl, h->edge_var[e]);
+            if (h->cfg.dim > 1) cur[cur.size() - 2] = h->spdir[h->partner[sl]];      // dim > 1: the rule table of the SENDING slot travels in the item
+        }
     };
     auto m2f = [&](int32_t e) {
         const int32_t v = h->edge_var[e];
@@ -372,7 +375,7 @@ int32_t build_hp(const H *h, HP &out, std::string &err) {
             params_done[L] = 1;
         }
         out.steps.push_back(kind); out.steps.push_back(L);
-        out.launches += 3;
+        out.launches += (h->cfg.dim > 1 && kind == 2) ? 4 : 3;      // side sums, thread totals, walks (+ the marginal pass of dim 2 .. 4)
     };
     for (int32_t l = lmax + 1; l >= 1; l--) {
         if (l <= lmax) {

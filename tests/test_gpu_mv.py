@@ -302,15 +302,17 @@ def test_mv64_wave_per_message_form_matches_the_workgroup_form(hip_lib, monkeypa
 
 # ------------------------------------------------------------------------------- degree-4 variables (three sources)
 
-def _branching_lgssm(n, d, seed, b=2):
+def _branching_lgssm(n, d, seed, b=2, pairs=None, solve=True):
     """a TREE of states with b children per node (node i has children b i + 1 .. b i + b), every state observed: inner nodes have degree
-    b + 2 (parent, children, likelihood); b = 2: degree 4, a message out of them sums THREE incoming ones — the branch a chain never takes"""
+    b + 2 (parent, children, likelihood); b = 2: degree 4, a message out of them sums THREE incoming ones — the branch a chain never takes.
+    pairs: any other tree as (parent, child) index pairs, parents before children.  solve = False: no dense solve (large n)."""
     rng = np.random.default_rng(seed)
     A = 0.9 * np.linalg.qr(rng.standard_normal((d, d)))[0]
     Q, R = 0.2 * np.eye(d), np.eye(d)
     x = np.arange(1, n + 1, dtype=np.int64)
     y, lik = x + n, x + 2 * n
-    pairs = [(p, c) for p in range(n) for c in range(b * p + 1, b * p + b + 1) if c < n]
+    if pairs is None:
+        pairs = [(p, c) for p in range(n) for c in range(b * p + 1, b * p + b + 1) if c < n]
     tr = 3 * n + 1 + np.arange(len(pairs), dtype=np.int64)
     par = np.array([x[p] for p, _ in pairs]); chi = np.array([x[c] for _, c in pairs])
     edge_var = np.concatenate([y, x, par, chi])
@@ -324,6 +326,8 @@ def _branching_lgssm(n, d, seed, b=2):
                            factor_kind=np.full(n + len(pairs), L.FACTOR_GAUSS_LINEAR, dtype=np.int32),
                            factor_var=np.concatenate([np.ones(n), np.zeros(len(pairs))]), x_ids=x, data_var=y, data_fac=lik, data_y=data,
                            dim=d, edge_role=role, psets={0: (A, Q), 1: (np.eye(d), R)}, meta={"pairs": pairs})
+    if not solve:
+        return model, None, None
     # exact posterior of the tree: joint information matrix (no prior on the root, like the chain models)
     Qi, Ri = np.linalg.inv(Q), np.linalg.inv(R)
     J = np.zeros((n * d, n * d)); hvec = np.zeros(n * d)

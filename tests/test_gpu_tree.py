@@ -310,11 +310,103 @@ def test_d_dimensional_trees_one_sweep(hip_lib, d, b, n):
     assert np.array_equal(before, dev.get_marginals(model.x_ids))
 
 
+def _comb_pairs(n_spine, teeth=1):
+    """a spine of states 0 .. n_spine - 1, below every state a path of `teeth` more states (a latent layer): (parent, child) pairs, parents first"""
+    pairs, nxt = [], n_spine
+    for i in range(n_spine):
+        if i + 1 < n_spine:
+            pairs.append((i, i + 1))
+        up = i
+        for _ in range(teeth):
+            pairs.append((up, nxt)); up = nxt; nxt += 1
+    return sorted(pairs), nxt
+
+
+@pytest.mark.parametrize("d", [2, 3, 4])
+@pytest.mark.parametrize("n_spine,teeth", [(2, 1), (60, 1), (150, 2)])
+def test_d_dimensional_heavy_paths(hip_lib, monkeypatch, d, n_spine, teeth):
+    """dim 2..4 over heavy paths (the scans of csrc/cx_mvchain.hip per light depth, light edges as items): a chain of states with a latent
+    layer below each — the joint solve's marginals, the level schedule's messages"""
+    from tests.test_gpu_mv import _branching_lgssm
+
+    pairs, n = _comb_pairs(n_spine, teeth)
+    model, emean, ecov = _branching_lgssm(n, d, seed=70 + d, pairs=pairs)
+    monkeypatch.setenv("CX_TREE_HP", "1")
+    dev = cx.DeviceGraph(dim=d, schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(model, dev)
+    dev.sweep(1)
+    hp = dev.tree_heavy_path_stats()
+    assert hp["launches"] > 0 and hp["paths"] >= 1 and hp["light_depths"] <= 3
+    marg = dev.get_marginals(model.x_ids)
+    assert not np.any(np.isnan(marg))
+    assert_close(marg[:, :d], emean, 1e-8, "marginal mean vs the joint solve", scale_by="max")
+    assert_close(marg[:, d:].reshape(n, d, d), ecov, 1e-8, "marginal covariance vs the joint solve", scale_by="max")
+    monkeypatch.setenv("CX_TREE_HP", "0")
+    lv = cx.DeviceGraph(dim=d, schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(model, lv)
+    lv.sweep(1)
+    assert lv.tree_heavy_path_stats()["launches"] == 0
+    xs = set(int(v) for v in model.x_ids)
+    keep = np.array([int(v) in xs for v in model.edge_var])
+    ev, ef = model.edge_var[keep], model.edge_fac[keep]
+    a, b = dev.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL), lv.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL)
+    assert np.array_equal(np.isnan(a), np.isnan(b)), "the same messages are defined"
+    assert_close(a[~np.isnan(a)], b[~np.isnan(b)], 1e-8, "factor→variable messages vs the level schedule", scale_by="max")
+    before = dev.get_marginals(model.x_ids)
+    dev.sweep(1)
+    assert np.array_equal(before, dev.get_marginals(model.x_ids))
+
+
+@pytest.mark.parametrize("d,b,n", [(2, 2, 40), (4, 3, 60), (3, 6, 80)])
+def test_d_dimensional_bushy_trees_over_heavy_paths(hip_lib, monkeypatch, d, b, n):
+    """forced over heavy paths where the level schedule would be chosen: many light depths, short paths, variables of degree up to 8"""
+    from tests.test_gpu_mv import _branching_lgssm
+
+    model, emean, ecov = _branching_lgssm(n, d, seed=90 + b, b=b)
+    monkeypatch.setenv("CX_TREE_HP", "1")
+    dev = cx.DeviceGraph(dim=d, schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(model, dev)
+    dev.sweep(1)
+    assert dev.tree_heavy_path_stats()["launches"] > 0
+    marg = dev.get_marginals(model.x_ids)
+    assert not np.any(np.isnan(marg))
+    assert_close(marg[:, :d], emean, 1e-8, "marginal mean vs the joint solve", scale_by="max")
+    assert_close(marg[:, d:].reshape(n, d, d), ecov, 1e-8, "marginal covariance vs the joint solve", scale_by="max")
+
+
+def test_a_d_dimensional_state_space_model_with_a_latent_layer(hip_lib, monkeypatch):
+    """d = 4, 20,000 states on the spine and a latent state below each (depth ~ 20,000 levels): by default over heavy paths — two light
+    depths, a dozen launches — and the level schedule's marginals; new data under the standing plan"""
+    from tests.test_gpu_mv import _branching_lgssm
+
+    pairs, n = _comb_pairs(20_000, 1)
+    model, _, _ = _branching_lgssm(n, 4, seed=77, pairs=pairs, solve=False)
+    dev = cx.DeviceGraph(dim=4, schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(model, dev)
+    dev.sweep(1)
+    st, hp = dev.tree_plan_stats(), dev.tree_heavy_path_stats()
+    assert st["depth"] >= 19_000 and 0 < hp["launches"] <= 30 and hp["light_depths"] <= 3, (st, hp)
+    monkeypatch.setenv("CX_TREE_HP", "0")
+    lv = cx.DeviceGraph(dim=4, schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(model, lv)
+    lv.sweep(1)
+    a, b = dev.get_marginals(model.x_ids), lv.get_marginals(model.x_ids)
+    assert not np.any(np.isnan(a))
+    assert_close(a, b, 1e-8, "heavy paths vs level by level: marginals", scale_by="max")
+    rng = np.random.default_rng(4)
+    y2 = model.data_y + rng.standard_normal(model.data_y.shape)
+    for d_ in (dev, lv):
+        d_.set_messages(model.data_var, model.data_fac, L.TO_FACTOR, L.FORM_POINT, y2)
+        d_.sweep(1)
+    assert_close(dev.get_marginals(model.x_ids), lv.get_marginals(model.x_ids), 1e-8, "after new data", scale_by="max")
+
+
 def test_d_dimensional_chain_is_a_tree_too(hip_lib):
     m = cx.synth.lgssm_chain(300, d=4, seed=8)
     tree = cx.DeviceGraph(dim=4, schedule=L.SCHED_TREE)
     cx.synth.load_into_device(m, tree)
     tree.sweep(1)
+    assert 0 < tree.tree_heavy_path_stats()["launches"] <= 20      # rooted in the middle: one half is the root's heavy path, the other starts one light edge down
     scan = cx.DeviceGraph(dim=4, schedule=L.SCHED_CHAIN_SCAN)
     cx.synth.load_into_device(m, scan)
     scan.sweep(1)
