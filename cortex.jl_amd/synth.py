@@ -194,6 +194,36 @@ def lgssm_chain(T: int, d: int = 4, seed: int = 1234, A=None, Q=None, R=None) ->
                  psets={0: (A, Q), 1: (np.eye(d), R)}, meta={"T": T, "A": A, "Q": Q, "R": R, "kind": "lgssm_chain"})
 
 
+def lgssm_comb(n_spine: int, d: int = 4, teeth: int = 1, seed: int = 1234) -> Model:
+    """d-dimensional linear-Gaussian TREE: a spine of n_spine states x_{t+1} = A x_t + w and, below every state, a path of `teeth` more
+    states of the same dynamics (a latent layer); every state observed, y = x + v.  A = 0.9 * (random orthogonal), Q = 0.2 I, R = I.
+    The level schedule of such a tree has ~ n_spine levels; over heavy paths it is two or three light depths."""
+    rng = np.random.default_rng(seed)
+    A = 0.9 * np.linalg.qr(rng.standard_normal((d, d)))[0]
+    Q, R = 0.2 * np.eye(d), np.eye(d)
+    spine = np.arange(n_spine, dtype=np.int64)
+    par = [spine[:-1]]
+    chi = [spine[1:]]
+    up, nxt = spine, n_spine
+    for _ in range(teeth):
+        c = np.arange(nxt, nxt + n_spine, dtype=np.int64)
+        par.append(up); chi.append(c)
+        up, nxt = c, nxt + n_spine
+    par, chi = np.concatenate(par), np.concatenate(chi)
+    n = int(nxt)
+    x = np.arange(1, n + 1, dtype=np.int64)
+    y, lik = x + n, x + 2 * n
+    tr = 3 * n + 1 + np.arange(len(par), dtype=np.int64)
+    edge_var = np.concatenate([y, x, x[par], x[chi]])
+    edge_fac = np.concatenate([lik, lik, tr, tr])
+    role = np.concatenate([np.full(n, L.ROLE_OUT), np.full(n, L.ROLE_IN), np.full(len(par), L.ROLE_IN), np.full(len(par), L.ROLE_OUT)]).astype(np.int32)
+    data = rng.standard_normal((n, d)) * 1.5            # (synthetic data of the model's scale: the timing does not depend on it)
+    return Model(edge_var=edge_var, edge_fac=edge_fac, factor_ids=np.concatenate([lik, tr]),
+                 factor_kind=np.full(n + len(par), L.FACTOR_GAUSS_LINEAR, dtype=np.int32),
+                 factor_var=np.concatenate([np.ones(n), np.zeros(len(par))]), x_ids=x, data_var=y, data_fac=lik, data_y=data,
+                 dim=d, edge_role=role, psets={0: (A, Q), 1: (np.eye(d), R)}, meta={"kind": "lgssm_comb", "n_spine": n_spine, "teeth": teeth})
+
+
 def concat_models(models) -> Model:
     """several dim > 1 models as ONE graph of disjoint components (ids shifted past each other): chains of different lengths,
     isolated variables — what the segmented chain scan has to keep apart"""

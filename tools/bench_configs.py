@@ -324,6 +324,41 @@ def tree(n_factors=200_000, steps=20, shape="random"):
                        "schedule against a dense solve: tests/test_gpu_tree.py)", "sample": f"{len(ids)} marginals"}}
 
 
+def tree_mv(d=4, n_spine=200_000):
+    """the tree schedule for dim 2..4 over heavy paths: a d-dimensional chain of n_spine states with a latent state below each (depth
+    ~ n_spine levels), ONE exact sweep; beside it the level schedule on a tenth of the model (its time is launches x per-launch time)"""
+    import os
+    model = cx.synth.lgssm_comb(n_spine, d=d, teeth=1, seed=5)
+    dev = cx.DeviceGraph(dim=d, schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(model, dev)
+    dev.sweep(2)
+    dt = timed(dev, lambda: dev.sweep(1), 20, 3)
+    st, hp = dev.tree_plan_stats(), dev.tree_heavy_path_stats()
+    n_msgs = st["messages_up"] + st["messages_down"]
+    small = cx.synth.lgssm_comb(n_spine // 10, d=d, teeth=1, seed=5)
+    os.environ["CX_TREE_HP"] = "0"
+    lv = cx.DeviceGraph(dim=d, schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(small, lv)
+    lv.sweep(1)
+    dtl = timed(lv, lambda: lv.sweep(1), 3, 1)
+    os.environ["CX_TREE_HP"] = "1"
+    hs = cx.DeviceGraph(dim=d, schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(small, hs)
+    hs.sweep(1)
+    del os.environ["CX_TREE_HP"]
+    ids = small.x_ids[:: max(len(small.x_ids) // 50_000, 1)]
+    a, b = hs.get_marginals(ids), lv.get_marginals(ids)
+    err = float(np.nanmax(np.abs(a - b)) / np.nanmax(np.abs(b)))
+    S = (d + d * d) * 8
+    return {"config": "tree-mv", "workload": f"d={d} linear-Gaussian chain of {n_spine} states with a latent state below each ({len(model.edge_var)} edges), tree schedule over heavy paths",
+            "ms_per_sweep": dt * 1e3, "plan": st, "heavy_paths": hp, "launches_per_sweep": hp["launches"] or st["stages"], "messages_per_sweep": n_msgs, "messages_per_s": n_msgs / dt,
+            "level_schedule_on_a_tenth": {"ms_per_sweep": dtl * 1e3, "stages": lv.tree_plan_stats()["stages"]},
+            "roofline": roofline("hbm", n_msgs * 2 * S / dt / 1e9, HBM_PEAK_GBS, "GB/s", None, kernel="k_mvc_* scans of the heavy paths + k_batch_mv item stages",
+                                 basis=f"algorithmic bytes ({2 * S} B per message, SURVEY §8d) / sweep time"),
+            "parity": {"max_rel_err_marginals": err, "ok": bool(err < 1e-8), "checker": "the level schedule on the same device, a tenth of the model (joint solves: tests/test_gpu_tree.py)",
+                       "sample": f"{len(ids)} marginals"}}
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c2", "c3", "c5"]
     torch.cuda.init()
@@ -331,6 +366,9 @@ if __name__ == "__main__":
         if w.startswith("vmp"):
             for r in vmp(only=w[4:] or None):          # vmp | vmp_structured | vmp_mean_field
                 print(json.dumps(r), flush=True)
+            continue
+        if w.startswith("treemv"):                       # treemv | treemv:2
+            print(json.dumps(tree_mv(d=int(w.split(":")[1]) if ":" in w else 4)), flush=True)
             continue
         if w.startswith("tree"):                         # tree | tree:deep
             print(json.dumps(tree(shape=w.split(":")[1] if ":" in w else "random")), flush=True)
