@@ -411,7 +411,11 @@ def other_configs(parity=None) -> list:
                      ("VMP", lambda: bc.vmp()),
                      # not a BASELINE config: the tree schedule (one sweep = the reference's one-call result on any forest), on a tree small
                      # enough to generate in a second
-                     ("tree", lambda: bc.tree(n_factors=30_000, steps=20))):
+                     ("tree", lambda: bc.tree(n_factors=30_000, steps=20)),
+                     # the same schedule where the level-by-level form would take two launches per level: long paths with side branches and
+                     # factors of 2..6 variables (scalar; heavy paths through factors of any arity), and a d = 4 chain with a latent layer
+                     ("tree-deep", lambda: bc.tree(n_factors=20_000, steps=20, shape="deep")),
+                     ("tree-mv", lambda: bc.tree_mv(d=4, n_spine=50_000))):
         try:
             r = fn()
             rows.extend(r if isinstance(r, list) else [r])

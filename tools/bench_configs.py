@@ -312,7 +312,7 @@ def tree(n_factors=200_000, steps=20, shape="random"):
     a, b = dev.get_marginals(ids), fused.get_marginals(ids)
     err = float(np.nanmax(np.abs(a - b) / np.maximum(np.abs(b), np.median(np.abs(b)))))
     n_msgs = st["messages_up"] + st["messages_down"]
-    return {"config": "tree", "workload": f"scalar Gaussian forest, {n_factors} factors of 2..6 variables + a prior per variable ({len(model.edge_var)} edges, shape {shape})",
+    return {"config": "tree" if shape == "random" else f"tree-{shape}", "workload": f"scalar Gaussian forest, {n_factors} factors of 2..6 variables + a prior per variable ({len(model.edge_var)} edges, shape {shape})",
             "ms_per_sweep": dt * 1e3, "plan": st, "heavy_paths": hp, "launches_per_sweep": launches, "messages_per_sweep": n_msgs, "messages_per_s": n_msgs / dt,
             "fused_schedule": {"ms_per_sweep": dtf * 1e3, "sweeps_to_the_same_result": need, "ms_to_the_same_result": need * dtf * 1e3},
             "roofline": roofline("hbm", n_msgs * 32 / dt / 1e9, HBM_PEAK_GBS, "GB/s", None,
