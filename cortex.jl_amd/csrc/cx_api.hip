@@ -22,9 +22,9 @@ void dev_free_all(cx_handle *h) {
                     h->d_stage, h->d_spdir, h->d_ptab, h->d_ptab_bt, h->d_zero_msg, h->d_mv_f2v, h->d_mv_f2v_alt, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prev, h->d_rule64_slots, h->d_rule64_vars, h->d_rule64_flags, h->d_point64_slots, h->d_rule64_rec, h->d_chain_pos_var, h->d_chain_skip0, h->d_chain_skip1, h->d_chain_link_pos, h->d_chain_from,
                     h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd, h->d_chain_side, h->d_chain_totals, h->d_chain_tab_fwd, h->d_chain_tab_bwd,
                     h->d_mvc_side, h->d_mvc_totals, h->d_mvc_side_l, h->d_mvc_alpha, h->d_mvc_gamma, h->d_mvc_prefix, h->d_mvc_wave_carry, h->d_mvc_block,
-                    h->d_tree_rec, h->d_tree_kary, h->d_partner16, h->d_mvc_var_link, h->d_tree_stage_off, h->d_tree_skip1_down, h->d_tree_a, h->d_tree_b};
+                    h->d_tree_rec, h->d_tree_kary, h->d_partner16, h->d_mvc_var_link, h->d_tree_stage_off, h->d_tree_skip1_down, h->d_tree_a, h->d_tree_b, h->d_pre64_slots, h->d_pre64_vars, h->d_tree_pre_slots, h->d_tree_pre_vars};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    h->d_tree_rec = h->d_tree_kary = nullptr; h->d_tree_skip1_down = nullptr; h->d_tree_a = h->d_tree_b = nullptr; h->tree_hp = false; h->tree_dirty = true; h->d_partner16 = nullptr; h->d_mvc_var_link = nullptr; h->d_tree_stage_off = nullptr;
+    h->d_tree_rec = h->d_tree_kary = nullptr; h->d_tree_skip1_down = nullptr; h->d_tree_a = h->d_tree_b = nullptr; h->d_pre64_slots = h->d_pre64_vars = h->d_tree_pre_slots = h->d_tree_pre_vars = nullptr; h->n_pre64 = 0; h->tree_hp = false; h->tree_dirty = true; h->d_partner16 = nullptr; h->d_mvc_var_link = nullptr; h->d_tree_stage_off = nullptr;
     tree_graph_drop(h); h->tree_graph_failed = false;
     cx::chain64_free(h);
     cx::kary_free(h);

@@ -251,7 +251,7 @@ int32_t mv_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, d
 // d = 64: which messages need the full MFMA rule, which come from observed variables (constant), which nobody reads
 int32_t build_work64(cx_handle *h) {
     if (!h->work64_dirty) return CX_OK;
-    std::vector<int32_t> rs, rv, rf, ps, rec, slot_var(h->nslots, -1);
+    std::vector<int32_t> rs, rv, rf, ps, rec, pre_s, pre_v, slot_var(h->nslots, -1);
     for (int64_t e = 0; e < h->ne; e++) slot_var[cx::slot_of_edge(h, e)] = h->edge_var[e];
     for (int64_t e = 0; e < h->ne; e++) {
         const int32_t s = cx::slot_of_edge(h, e), p = h->partner[s], v = h->edge_var[e];
@@ -269,12 +269,19 @@ int32_t build_work64(cx_handle *h) {
             const int32_t sj = h->vbase[v] + j * cx::kBlock;
             if (sj != s && n_others < 3) others[n_others++] = sj;
         }
+        if (deg > 4) {      // more than three other messages: k_v2f64 sums them into the stored variable→factor message, the rule reads that
+            pre_s.push_back(s); pre_v.push_back(v);
+            rec.insert(rec.end(), {s, -1, -1, -1, h->spdir[s], p, 1, 0});
+        } else
         rec.insert(rec.end(), {s, others[0], others[1], others[2], h->spdir[s], p, deg < 2 ? 1 : 0, 0});
     }
-    for (void *p : {(void *)h->d_rule64_slots, (void *)h->d_rule64_vars, (void *)h->d_rule64_flags, (void *)h->d_point64_slots, (void *)h->d_rule64_rec}) if (p) (void)hipFree(p);
-    h->d_rule64_slots = h->d_rule64_vars = h->d_rule64_flags = h->d_point64_slots = h->d_rule64_rec = nullptr;
-    h->n_rule64 = (int64_t)rs.size(); h->n_point64 = (int64_t)ps.size();
+    for (void *p : {(void *)h->d_rule64_slots, (void *)h->d_rule64_vars, (void *)h->d_rule64_flags, (void *)h->d_point64_slots, (void *)h->d_rule64_rec,
+                    (void *)h->d_pre64_slots, (void *)h->d_pre64_vars}) if (p) (void)hipFree(p);
+    h->d_rule64_slots = h->d_rule64_vars = h->d_rule64_flags = h->d_point64_slots = h->d_rule64_rec = h->d_pre64_slots = h->d_pre64_vars = nullptr;
+    h->n_rule64 = (int64_t)rs.size(); h->n_point64 = (int64_t)ps.size(); h->n_pre64 = (int64_t)pre_s.size();
     int32_t rc;
+    if ((rc = dev_upload(h, &h->d_pre64_slots, pre_s)) != CX_OK) return rc;
+    if ((rc = dev_upload(h, &h->d_pre64_vars, pre_v)) != CX_OK) return rc;
     if ((rc = dev_upload(h, &h->d_rule64_slots, rs)) != CX_OK) return rc;
     if ((rc = dev_upload(h, &h->d_rule64_vars, rv)) != CX_OK) return rc;
     if ((rc = dev_upload(h, &h->d_rule64_flags, rf)) != CX_OK) return rc;
@@ -581,9 +588,10 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
     }
     if (h->cfg.dim != 64) { int32_t rc = mv_refresh_spdir(h); if (rc != CX_OK) return rc; }
     for (int32_t s = 0; s < n_sweeps; s++) {
-        if (h->cfg.dim == 64)
+        if (h->cfg.dim == 64) {
+            cx::mv64_launch_v2f(h, (int)h->n_pre64, h->d_pre64_slots, h->d_pre64_vars, h->d_mv_f2v);      // senders of degree 5 .. 8
             cx::mv64_launch_rule(h, (int)h->n_rule64, h->d_rule64_rec, h->d_mv_f2v, h->d_mv_f2v_alt, CX_KERNEL_FUSED);
-        else {
+        } else {
             if (h->observed_passes_due > 0) { cx::mv_launch_sweep(h, false, 1); h->observed_passes_due--; }
             cx::mv_launch_sweep(h, h->cfg.compute_marginals_in_sweep != 0, 0);
         }

@@ -216,7 +216,8 @@ int32_t build_tree(cx_handle *h) {
             // variable (the rule sums them itself: no stored variable→factor message), the rule table, the destination — so only the
             // plan's factor→variable items become work; messages out of observed variables are constants (k_point64 at data injection),
             // marginals of dim 64 are formed when read
-            std::vector<int32_t> slot_var(h->nslots, -1);
+            std::vector<int32_t> slot_var(h->nslots, -1), pre_s, pre_v;
+            h->tree_pre_off.assign(1, 0);
             for (int64_t e = 0; e < h->ne; e++) slot_var[cx::slot_of_edge(h, e)] = h->edge_var[e];
             for (size_t st = 0; st + 1 < plan.stage_off.size(); st++) {
                 for (int64_t i = plan.stage_off[st]; i < plan.stage_off[st + 1]; i++) {
@@ -232,10 +233,19 @@ int32_t build_tree(cx_handle *h) {
                         const int32_t sj = h->vbase[u] + j * cx::kBlock;
                         if (sj != sl && n_others < 3) others[n_others++] = sj;
                     }
+                    if (deg > 4) {      // a sender of degree 5 .. 8: its other messages (final by now) are summed by k_v2f64 first, the rule reads the sum
+                        pre_s.push_back(sl); pre_v.push_back(u);
+                        rec.insert(rec.end(), {sl, -1, -1, -1, h->spdir[sl], dst, 1, 0});
+                    } else
                     rec.insert(rec.end(), {sl, others[0], others[1], others[2], h->spdir[sl], dst, deg < 2 ? 1 : 0, 0});
                 }
                 off.push_back((int64_t)rec.size() / 8);
+                h->tree_pre_off.push_back((int64_t)pre_s.size());
             }
+            for (void *p : {(void *)h->d_tree_pre_slots, (void *)h->d_tree_pre_vars}) if (p) (void)hipFree(p);
+            h->d_tree_pre_slots = h->d_tree_pre_vars = nullptr;
+            if ((rc2 = dev_upload(h, &h->d_tree_pre_slots, pre_s)) != CX_OK) return rc2;
+            if ((rc2 = dev_upload(h, &h->d_tree_pre_vars, pre_v)) != CX_OK) return rc2;
         } else
         for (size_t st = 0; st + 1 < plan.stage_off.size(); st++) {
             rec.insert(rec.end(), plan.rec.begin() + 5 * plan.stage_off[st], plan.rec.begin() + 5 * plan.stage_off[st + 1]);
@@ -290,7 +300,12 @@ static void tree_issue(cx_handle *h) {
     static const bool runs = [] { const char *e = std::getenv("CX_TREE_RUNS"); return !(e && e[0] == '0'); }();
     for (size_t s = 0; s < ns;) {
         const int64_t n = h->tree_stage_off[s + 1] - h->tree_stage_off[s], nk = h->tree_kary_off[s + 1] - h->tree_kary_off[s];
-        if (h->cfg.dim == 64) { if (n > 0) cx::mv64_launch_rule(h, (int)n, h->d_tree_rec + 8 * h->tree_stage_off[s], h->d_mv_f2v, h->d_mv_f2v, CX_KERNEL_BATCH); s++; continue; }
+        if (h->cfg.dim == 64) {
+            const int64_t np = h->tree_pre_off[s + 1] - h->tree_pre_off[s];
+            if (np > 0) cx::mv64_launch_v2f(h, (int)np, h->d_tree_pre_slots + h->tree_pre_off[s], h->d_tree_pre_vars + h->tree_pre_off[s], h->d_mv_f2v);
+            if (n > 0) cx::mv64_launch_rule(h, (int)n, h->d_tree_rec + 8 * h->tree_stage_off[s], h->d_mv_f2v, h->d_mv_f2v, CX_KERNEL_BATCH);
+            s++; continue;
+        }
         if (h->cfg.dim > 1) { if (n > 0) cx::mv_launch_batch(h, h->d_tree_rec + 5 * h->tree_stage_off[s], n); s++; continue; }
         // dim 1: consecutive thin stages (the levels next to the roots) leave as ONE launch of one workgroup (cx_kernels.hip: k_batch_run)
         size_t e = s;

@@ -136,8 +136,10 @@ int32_t flatten(H *h, int64_t n_edges, const int64_t *edge_var, const int64_t *e
             return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_create: dim > 1 handles variables of degree <= 8 only; variable " +
                         std::to_string(h->var_ids[h->big_vars[0]]) + " has more");
         // dim 2..4: a variable's incoming messages live in registers (k_sweep_mv<D, DEG>: DEG = 3, 4 or 8 by the graph's widest
-        // variable); dim 64: a rule sums at most three sources (k_rule64w)
-        const int max_deg = h->cfg.dim == 64 ? 4 : 8;
+        // variable); dim 64: a rule sums at most three sources itself (k_rule64w) — a sender of degree 5 .. 8 has its other messages summed
+        // into its stored variable→factor message first (k_v2f64; flooding and tree schedules, batch items).  The chain-scan schedule
+        // of dim 64 keeps to degree <= 4 (cx_chain64_plan.h: three inputs per joint).
+        const int max_deg = 8;
         for (int64_t v = 0; v < nv; v++)
             if (var_deg[v] > max_deg)
                 return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_create: dim " + std::to_string(h->cfg.dim) + " handles variables of degree <= " + std::to_string(max_deg) +

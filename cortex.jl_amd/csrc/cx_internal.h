@@ -100,6 +100,11 @@ struct cx_handle {
     int64_t n_rule64 = 0, n_point64 = 0;
     int32_t *d_rule64_slots = nullptr, *d_rule64_vars = nullptr, *d_rule64_flags = nullptr, *d_point64_slots = nullptr;
     int32_t *d_rule64_rec = nullptr;               // 8 words per work item (see k_rule64)
+    // senders of degree 5 .. 8 (a rule sums at most three sources): their variable→factor messages are summed first (k_v2f64) and the
+    // rule reads the stored message; the same per stage of the tree schedule
+    int64_t n_pre64 = 0;
+    int32_t *d_pre64_slots = nullptr, *d_pre64_vars = nullptr, *d_tree_pre_slots = nullptr, *d_tree_pre_vars = nullptr;
+    std::vector<int64_t> tree_pre_off;
 
     // chain-scan schedule (cx_chain.hip): paths of free variables, built lazily by build_chains()
     // cfg.dim of 5 .. 63 as the caller gave it (0 otherwise): such a handle runs as dim 64 with every message, datum and rule matrix

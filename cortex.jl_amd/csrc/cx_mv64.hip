@@ -223,9 +223,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_rule64(int nwork, const int32_t *
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[i] = 0.0;
         double ea = 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (j >= deg) continue;
+#pragma unroll 4
+        for (int j = 0; j < 8; j++) {      // (degree <= 8: the SELL width)
+            if (j >= deg) break;
             const double *src = f2v_in + (int64_t)(base + j * kBlock) * kMsg;
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[i] += src[kD + tid + kBlock * i];

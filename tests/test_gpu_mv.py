@@ -340,19 +340,20 @@ def _branching_lgssm(n, d, seed, b=2, pairs=None, solve=True):
     return model, mean.reshape(n, d), np.stack([S[i*d:(i+1)*d, i*d:(i+1)*d] for i in range(n)])
 
 
-@pytest.mark.parametrize("d,form", [(3, ""), (4, ""), (64, ""), (64, "g")])
-def test_mv_tree_with_degree_4_variables(hip_lib, monkeypatch, d, form):
+@pytest.mark.parametrize("d,form,b", [(3, "", 2), (4, "", 2), (64, "", 2), (64, "g", 2), (64, "", 4), (64, "g", 5)])
+def test_mv_tree_with_degree_4_variables(hip_lib, monkeypatch, d, form, b):
+    """(b > 2 at dim 64: variables of degree 6 and 7 — more than the three sources a rule sums itself: k_v2f64 sums them first)"""
     if form:
         monkeypatch.setenv("CX_RULE64", form)      # the workgroup-per-message form of the d = 64 rule
-    n = 15 if d < 64 else 7
-    model, emean, ecov = _branching_lgssm(n, d, seed=5)
+    n = 15 if d < 64 else (7 if b == 2 else 11)
+    model, emean, ecov = _branching_lgssm(n, d, seed=5, b=b)
     dev = _dev(model)
     o = MvFlood(model)
     g = o.g
     xs_set = set(np.searchsorted(g.var_ids, model.x_ids).tolist())
     pe = np.array([e for e in np.flatnonzero(g.partner >= 0) if int(np.searchsorted(g.var_ids, g.edge_var[e])) in xs_set])
     deg = np.diff(g.var_off)
-    assert deg.max() == 4
+    assert deg.max() == b + 2
     if d == 64:
         o.sweep(1)        # the d = 64 path evaluates the messages out of observed variables at data injection (see above)
     for sweep in range(10):

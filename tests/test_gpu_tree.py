@@ -450,11 +450,12 @@ def test_without_marginals_in_the_sweep_the_last_stage_is_left_out(hip_lib):
     assert np.array_equal(a.get_marginals(ids), b.get_marginals(ids))
 
 
-@pytest.mark.parametrize("d,b,n", [(64, 2, 7), (64, 2, 15), (6, 2, 15), (33, 1, 9)])
+@pytest.mark.parametrize("d,b,n", [(64, 2, 7), (64, 2, 15), (6, 2, 15), (33, 1, 9), (64, 3, 13), (64, 6, 15), (6, 4, 21)])
 def test_dim_64_trees_one_sweep(hip_lib, d, b, n):
-    """dim 64 (and 5 .. 63 embedded in it): a tree of states with b children each (degree b + 2 <= 4: a dim 64 rule sums at most three
-    sources), every state observed: ONE sweep of the tree schedule — a stage is one launch of the MFMA rule kernel over its records —
-    == the joint solve; the fused schedule needs depth-many sweeps for the same messages"""
+    """dim 64 (and 5 .. 63 embedded in it): a tree of states with b children each (degree b + 2 <= 8; a dim 64 rule sums at most three
+    sources itself: a sender of degree 5 .. 8 has its other messages summed by k_v2f64 first), every state observed: ONE sweep of the tree
+    schedule — a stage is one launch of the MFMA rule kernel over its records — == the joint solve; the fused schedule needs depth-many
+    sweeps for the same messages"""
     from tests.test_gpu_mv import _branching_lgssm
 
     model, emean, ecov = _branching_lgssm(n, d, seed=60 + n, b=b)

@@ -229,8 +229,7 @@ def test_error_paths_leave_nothing_out_of_bounds():
     hub = lambda dim: FlatGraph(hub_v, hub_f, np.r_[wide.factor_ids, 9000 + np.arange(5)], np.r_[wide.factor_kind, np.zeros(5, np.int32)],
                                 np.r_[wide.factor_var, np.zeros(5)], edge_role=np.r_[wide.edge_role, np.zeros(5, np.int32)], dim=dim)
     assert hub(4).status == L.OK                                           # degree 7: dim 2..4 keep up to eight messages in registers
-    big = hub(64)
-    assert big.status == L.ERR_UNSUPPORTED and "degree <= 4" in big.error     # a dim 64 rule sums at most three sources
+    assert hub(64).status == L.OK                                          # degree 7 at dim 64: the other messages are summed before the rule (k_v2f64)
     hub_v9, hub_f9 = np.r_[wide.edge_var, np.full(7, wide.x_ids[0])], np.r_[wide.edge_fac, 9000 + np.arange(7)]
     big9 = FlatGraph(hub_v9, hub_f9, np.r_[wide.factor_ids, 9000 + np.arange(7)], np.r_[wide.factor_kind, np.zeros(7, np.int32)], np.r_[wide.factor_var, np.zeros(7)],
                      edge_role=np.r_[wide.edge_role, np.zeros(7, np.int32)], dim=4)
