@@ -318,6 +318,8 @@ def tree(n_factors=200_000, steps=20, shape="random"):
             "roofline": roofline("hbm", n_msgs * 32 / dt / 1e9, HBM_PEAK_GBS, "GB/s", None,
                                  kernel="k_chain_* scans of the heavy paths + k_batch item stages" if hp["launches"] else "k_batch, one launch per stage",
                                  basis="algorithmic bytes (32 B per message, SURVEY §8d) / sweep time",
+                                 frac_algorithmic=n_msgs * 32 / dt / 1e9 / HBM_PEAK_GBS,
+                                 frac_note="a latency-bound schedule: the fraction of HBM on algorithmic bytes is frac_algorithmic, no counter traffic was collected",
                                  bound_detail=f"not a bandwidth-bound schedule: {launches} dependent launches (≈ {dt / max(launches, 1) * 1e6:.1f} us "
                                               "each at this size): the time is the number of dependent launches x per-kernel time"),
             "parity": {"max_rel_err_marginals": err, "ok": bool(err < 1e-9), "checker": "the fused schedule at its fixed point on the same device (the tree "
@@ -354,7 +356,8 @@ def tree_mv(d=4, n_spine=200_000):
             "ms_per_sweep": dt * 1e3, "plan": st, "heavy_paths": hp, "launches_per_sweep": hp["launches"] or st["stages"], "messages_per_sweep": n_msgs, "messages_per_s": n_msgs / dt,
             "level_schedule_on_a_tenth": {"ms_per_sweep": dtl * 1e3, "stages": lv.tree_plan_stats()["stages"]},
             "roofline": roofline("hbm", n_msgs * 2 * S / dt / 1e9, HBM_PEAK_GBS, "GB/s", None, kernel="k_mvc_* scans of the heavy paths + k_batch_mv item stages",
-                                 basis=f"algorithmic bytes ({2 * S} B per message, SURVEY §8d) / sweep time"),
+                                 basis=f"algorithmic bytes ({2 * S} B per message, SURVEY §8d) / sweep time", frac_algorithmic=n_msgs * 2 * S / dt / 1e9 / HBM_PEAK_GBS,
+                                 frac_note="a latency-bound schedule: the fraction of HBM on algorithmic bytes is frac_algorithmic, no counter traffic was collected"),
             "parity": {"max_rel_err_marginals": err, "ok": bool(err < 1e-8), "checker": "the level schedule on the same device, a tenth of the model (joint solves: tests/test_gpu_tree.py)",
                        "sample": f"{len(ids)} marginals"}}
 
