@@ -251,7 +251,7 @@ int32_t mv_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, d
 // d = 64: which messages need the full MFMA rule, which come from observed variables (constant), which nobody reads
 int32_t build_work64(cx_handle *h) {
     if (!h->work64_dirty) return CX_OK;
-    std::vector<int32_t> rs, rv, rf, ps, rec, pre_s, pre_v, slot_var(h->nslots, -1);
+    std::vector<int32_t> ps, rec, pre_s, pre_v, slot_var(h->nslots, -1);
     for (int64_t e = 0; e < h->ne; e++) slot_var[cx::slot_of_edge(h, e)] = h->edge_var[e];
     for (int64_t e = 0; e < h->ne; e++) {
         const int32_t s = cx::slot_of_edge(h, e), p = h->partner[s], v = h->edge_var[e];
@@ -260,7 +260,6 @@ int32_t build_work64(cx_handle *h) {
         if (h->vinfo[rvz] & cx::kClamped) continue;                 // a message into an observed variable has no reader
         const int32_t deg = h->var_off[v + 1] - h->var_off[v];
         if (h->vinfo[v] & cx::kClamped) { ps.push_back(s); continue; }
-        rs.push_back(s); rv.push_back(v); rf.push_back(deg < 2 ? 1 : 0);   // degree-1 leaf: its stored message is the input
         // the record the rule kernel reads: sender slot, the other incoming slots in ascending neighbour order (the fold
         // order), rule-table index, destination slot, flags
         int32_t others[3] = {-1, -1, -1};
@@ -273,18 +272,14 @@ int32_t build_work64(cx_handle *h) {
             pre_s.push_back(s); pre_v.push_back(v);
             rec.insert(rec.end(), {s, -1, -1, -1, h->spdir[s], p, 1, 0});
         } else
-        rec.insert(rec.end(), {s, others[0], others[1], others[2], h->spdir[s], p, deg < 2 ? 1 : 0, 0});
+        rec.insert(rec.end(), {s, others[0], others[1], others[2], h->spdir[s], p, deg < 2 ? 1 : 0, 0});      // (flag 1, degree-1 leaf: its stored message is the input)
     }
-    for (void *p : {(void *)h->d_rule64_slots, (void *)h->d_rule64_vars, (void *)h->d_rule64_flags, (void *)h->d_point64_slots, (void *)h->d_rule64_rec,
-                    (void *)h->d_pre64_slots, (void *)h->d_pre64_vars}) if (p) (void)hipFree(p);
-    h->d_rule64_slots = h->d_rule64_vars = h->d_rule64_flags = h->d_point64_slots = h->d_rule64_rec = h->d_pre64_slots = h->d_pre64_vars = nullptr;
-    h->n_rule64 = (int64_t)rs.size(); h->n_point64 = (int64_t)ps.size(); h->n_pre64 = (int64_t)pre_s.size();
+    for (void *p : {(void *)h->d_point64_slots, (void *)h->d_rule64_rec, (void *)h->d_pre64_slots, (void *)h->d_pre64_vars}) if (p) (void)hipFree(p);
+    h->d_point64_slots = h->d_rule64_rec = h->d_pre64_slots = h->d_pre64_vars = nullptr;
+    h->n_rule64 = (int64_t)rec.size() / 8; h->n_point64 = (int64_t)ps.size(); h->n_pre64 = (int64_t)pre_s.size();
     int32_t rc;
     if ((rc = dev_upload(h, &h->d_pre64_slots, pre_s)) != CX_OK) return rc;
     if ((rc = dev_upload(h, &h->d_pre64_vars, pre_v)) != CX_OK) return rc;
-    if ((rc = dev_upload(h, &h->d_rule64_slots, rs)) != CX_OK) return rc;
-    if ((rc = dev_upload(h, &h->d_rule64_vars, rv)) != CX_OK) return rc;
-    if ((rc = dev_upload(h, &h->d_rule64_flags, rf)) != CX_OK) return rc;
     if ((rc = dev_upload(h, &h->d_point64_slots, ps)) != CX_OK) return rc;
     if ((rc = dev_upload(h, &h->d_rule64_rec, rec)) != CX_OK) return rc;
     CX_HIP(h, hipStreamSynchronize(h->stream));

@@ -98,7 +98,7 @@ struct cx_handle {
     // d = 64 work lists (built lazily: they depend on which variables are observed)
     bool work64_dirty = true, point64_dirty = true;
     int64_t n_rule64 = 0, n_point64 = 0;
-    int32_t *d_rule64_slots = nullptr, *d_rule64_vars = nullptr, *d_rule64_flags = nullptr, *d_point64_slots = nullptr;
+    int32_t *d_point64_slots = nullptr;
     int32_t *d_rule64_rec = nullptr;               // 8 words per work item (see k_rule64)
     // senders of degree 5 .. 8 (a rule sums at most three sources): their variable→factor messages are summed first (k_v2f64) and the
     // rule reads the stored message; the same per stage of the tree schedule
