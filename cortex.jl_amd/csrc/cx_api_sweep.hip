@@ -133,7 +133,10 @@ int32_t build_tree(cx_handle *h) {
         // CX_TREE_HP=0 / 1: never / whenever the graph allows (A/B, tests).
         h->tree_hp = false;
         const bool hp_mv = h->cfg.dim >= 2 && h->cfg.dim <= 4;      // (dim 2 .. 4: the scans of cx_mvchain.hip per light depth)
-        if ((h->cfg.dim == 1 && h->cfg.family != CX_FAMILY_NATURAL2) || hp_mv) {
+        const bool hp64 = h->cfg.dim == 64;                          // (dim 64: a plan of compositions and walks per light depth, cx_mv64chain.hip)
+        cx::chain64_tree_free(h);
+        h->tree_c64_up.clear(); h->tree_c64_final.clear();
+        if ((h->cfg.dim == 1 && h->cfg.family != CX_FAMILY_NATURAL2) || hp_mv || hp64) {
             const char *hp_e = std::getenv("CX_TREE_HP");
             const int hp_env = hp_e ? std::atoi(hp_e) : -1;
             cx::treeplan::HP hp;
@@ -141,7 +144,39 @@ int32_t build_tree(cx_handle *h) {
                 const int32_t rch = cx::treeplan::build_hp(h, hp, terr);
                 if (rch != CX_OK) return fail(h, rch, terr);
             }
-            if (hp_env != 0 && !hp.link_pos.empty() && (hp_env > 0 || hp.launches < 2 * (int64_t)plan.depth + 1)) {
+            bool take = hp_env != 0 && !hp.link_pos.empty() && (hp_env > 0 || hp.launches < 2 * (int64_t)plan.depth + 1);
+            if (take && hp64) {
+                // the scans' launches are known once the plans exist; a variable with more than three inputs besides its links
+                // (cx_chain64_plan.h) leaves the tree to the level schedule
+                h->tree_c64_up.assign(hp.levels, -1); h->tree_c64_final.assign(hp.levels, -1);
+                int64_t launches = 0;
+                for (size_t i = 0; i + 1 < hp.steps.size() && take; i += 2) {
+                    const int32_t kind = hp.steps[i], L = hp.steps[i + 1];
+                    if (kind == 0) { launches++; continue; }
+                    const int64_t p0 = hp.pos_off[L], p1 = hp.pos_off[L + 1], l0 = hp.link_off[L], l1 = hp.link_off[L + 1];
+                    auto cut = [](const auto &v, int64_t a, int64_t b) { return std::decay_t<decltype(v)>(v.begin() + a, v.begin() + b); };
+                    std::vector<int32_t> lp = cut(hp.link_pos, l0, l1), tf(l1 - l0), tb(l1 - l0);
+                    for (auto &x : lp) x -= (int32_t)p0;
+                    for (int64_t l = l0; l < l1; l++) { tf[l - l0] = h->spdir[hp.from[l]]; tb[l - l0] = h->spdir[hp.to[l]]; }
+                    int idx = -1;
+                    const int32_t rcb = cx::chain64_tree_build(h, &idx, cut(hp.pos_var, p0, p1), cut(hp.skip0, p0, p1), cut(kind == 1 ? hp.skip1_up : hp.skip1_down, p0, p1),
+                                                               lp, cut(hp.from, l0, l1), cut(hp.to, l0, l1), cut(hp.head_fwd, l0, l1), cut(hp.head_bwd, l0, l1), tf, tb);
+                    if (rcb == CX_ERR_UNSUPPORTED) { take = false; break; }
+                    if (rcb != CX_OK) return rcb;
+                    (kind == 1 ? h->tree_c64_up : h->tree_c64_final)[L] = idx;
+                    launches += cx::chain64_tree_launches(h, idx);
+                }
+                if (take && hp_env <= 0 && launches >= 2 * (int64_t)plan.depth + 1) take = false;
+                if (!take) { cx::chain64_tree_free(h); h->tree_c64_up.clear(); h->tree_c64_final.clear(); }
+                else hp.launches = launches;
+            }
+            if (take && hp64) {
+                h->tree_hp = true;
+                h->tree_hp_steps = hp.steps; h->tree_hp_pos_off = hp.pos_off; h->tree_hp_link_off = hp.link_off; h->tree_hp_marginal_stage = hp.marginal_stage;
+                const int64_t hs[4] = {hp.levels, hp.n_paths, hp.n_single, hp.launches};
+                std::memcpy(h->tree_hp_stats, hs, sizeof hs);
+                plan.rec = std::move(hp.rec); plan.stage_off = std::move(hp.stage_off); plan.kary = std::move(hp.kary); plan.kary_off = std::move(hp.kary_off);
+            } else if (take) {
                 for (void *p : {(void *)h->d_chain_pos_var, (void *)h->d_chain_skip0, (void *)h->d_chain_skip1, (void *)h->d_tree_skip1_down, (void *)h->d_chain_link_pos,
                                 (void *)h->d_chain_from, (void *)h->d_chain_to, (void *)h->d_chain_head_fwd, (void *)h->d_chain_head_bwd, (void *)h->d_chain_side,
                                 h->d_chain_totals}) if (p) (void)hipFree(p);
@@ -274,7 +309,14 @@ static void tree_issue(cx_handle *h) {
         // variables' marginals is left out then.)
         for (size_t i = 0; i + 1 < h->tree_hp_steps.size(); i += 2) {
             const int32_t kind = h->tree_hp_steps[i], idx = h->tree_hp_steps[i + 1];
-            if (kind == 0) {
+            if (kind == 0 && h->cfg.dim == 64) {      // a stage of dim 64: one launch of the rule kernel over its records (marginals are formed when read)
+                const int64_t n = h->tree_stage_off[idx + 1] - h->tree_stage_off[idx], np = h->tree_pre_off[idx + 1] - h->tree_pre_off[idx];
+                if (np > 0) cx::mv64_launch_v2f(h, (int)np, h->d_tree_pre_slots + h->tree_pre_off[idx], h->d_tree_pre_vars + h->tree_pre_off[idx], h->d_mv_f2v);
+                if (n > 0) cx::mv64_launch_rule(h, (int)n, h->d_tree_rec + 8 * h->tree_stage_off[idx], h->d_mv_f2v, h->d_mv_f2v, CX_KERNEL_BATCH);
+            } else if (h->cfg.dim == 64) {
+                const int32_t pi = (kind == 1 ? h->tree_c64_up : h->tree_c64_final)[idx];
+                if (pi >= 0) (void)cx::chain64_tree_sweep(h, pi);
+            } else if (kind == 0) {
                 if (idx == h->tree_hp_marginal_stage && h->cfg.compute_marginals_in_sweep == 0) continue;
                 const int64_t n = h->tree_stage_off[idx + 1] - h->tree_stage_off[idx];
                 if (n > 0 && h->cfg.dim > 1) cx::mv_launch_batch(h, h->d_tree_rec + 5 * h->tree_stage_off[idx], n);
@@ -324,6 +366,7 @@ static void tree_issue(cx_handle *h) {
 // instantiation also falls back to them, for good.
 void tree_sweep(cx_handle *h) {
     static const bool graphs = [] { const char *e = std::getenv("CX_TREE_GRAPH"); return !(e && e[0] == '0'); }();
+    if (!h->tree_c64.empty()) (void)cx::chain64_tree_resolve(h);      // host copies when a base pointer moved: never inside the capture below
     if (graphs && !h->tree_graph_failed && !h->profiling && !h->tree_exec) {
         hipError_t e = hipSuccess;
         if (!h->tree_capture_stream) e = hipStreamCreateWithFlags(&h->tree_capture_stream, hipStreamNonBlocking);

@@ -138,6 +138,9 @@ struct cx_handle {
     // interleaved buffers (d_mvc_*) sized for the largest depth and shared by all of them
     std::vector<int32_t> tree_hp_K;
     int64_t tree_hp_npos = 0;
+    // dim 64 over heavy paths: a plan of compositions and walks (cx_chain64_plan.h) per light depth and direction of travel
+    std::vector<void *> tree_c64;
+    std::vector<int32_t> tree_c64_up, tree_c64_final;      // per light depth: index into tree_c64, -1 = no such scan
     int64_t chain_npos = 0, chain_nlinks = 0;
     int64_t chain_npos_linked = 0;   // dim > 1: positions [0, this) belong to paths with links; the isolated ones follow
     bool chain_side_dirty = true;    // the leaf messages / side sums of the chain positions must be recomputed (data or rule parameters changed)
@@ -310,6 +313,14 @@ int32_t chain64_build(cx_handle *h, const std::vector<int32_t> &pos_var, const s
                       const std::vector<int32_t> &tab_bwd);
 int32_t chain64_sweep(cx_handle *h);
 void chain64_free(cx_handle *h);
+int32_t chain64_tree_build(cx_handle *h, int *index, const std::vector<int32_t> &pos_var, const std::vector<int32_t> &skip0, const std::vector<int32_t> &skip1,
+                           const std::vector<int32_t> &link_pos, const std::vector<int32_t> &from, const std::vector<int32_t> &to,
+                           const std::vector<uint8_t> &head_fwd, const std::vector<uint8_t> &head_bwd, const std::vector<int32_t> &tab_fwd,
+                           const std::vector<int32_t> &tab_bwd);
+int32_t chain64_tree_resolve(cx_handle *h);
+int64_t chain64_tree_launches(const cx_handle *h, int index);
+int32_t chain64_tree_sweep(cx_handle *h, int index);
+void chain64_tree_free(cx_handle *h);
 void chain64_stats(const cx_handle *h, int64_t *out8);
 int32_t chain64_block_potential(cx_handle *h, double *pot, int32_t *side_first3, int32_t *side_last3, bool *no_root);
 // variational families (cx_vmp.hip)

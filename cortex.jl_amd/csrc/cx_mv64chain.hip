@@ -520,13 +520,22 @@ struct Chain64 {
     int32_t side_ends[6] = {-1, -1, -1, -1, -1, -1};      // side slots of path 0's first / last position
 };
 
-void chain64_free(cx_handle *h) {
-    Chain64 *c = (Chain64 *)h->chain64;
+static void chain64_drop(cx_handle *h, Chain64 *c) {
     if (!c) return;
     for (void *p : {(void *)c->d_jobs, (void *)c->d_children, (void *)c->d_steps, (void *)c->d_pot, (void *)c->d_ent, (void *)c->d_ring}) if (p) (void)hipFree(p);
     h->device_bytes -= c->bytes;
     delete c;
+}
+
+void chain64_free(cx_handle *h) {
+    chain64_drop(h, (Chain64 *)h->chain64);
     h->chain64 = nullptr;
+}
+
+// CX_SCHED_TREE over heavy paths (cx_tree_plan.h): one plan per light depth and direction of travel
+void chain64_tree_free(cx_handle *h) {
+    for (void *p : h->tree_c64) chain64_drop(h, (Chain64 *)p);
+    h->tree_c64.clear();
 }
 
 static int env_int(const char *name, int dflt) {
@@ -535,13 +544,42 @@ static int env_int(const char *name, int dflt) {
 }
 
 // Build the plan from the chain decomposition (host arrays of build_chains) and upload it.
+static int32_t chain64_make(cx_handle *h, Chain64 **out, bool root, const std::vector<int32_t> &pos_var, const std::vector<int32_t> &skip0,
+                            const std::vector<int32_t> &skip1, const std::vector<int32_t> &link_pos, const std::vector<int32_t> &from,
+                            const std::vector<int32_t> &to, const std::vector<uint8_t> &head_fwd, const std::vector<uint8_t> &head_bwd,
+                            const std::vector<int32_t> &tab_fwd, const std::vector<int32_t> &tab_bwd);
+
 int32_t chain64_build(cx_handle *h, const std::vector<int32_t> &pos_var, const std::vector<int32_t> &skip0, const std::vector<int32_t> &skip1,
                       const std::vector<int32_t> &link_pos, const std::vector<int32_t> &from, const std::vector<int32_t> &to,
                       const std::vector<uint8_t> &head_fwd, const std::vector<uint8_t> &head_bwd, const std::vector<int32_t> &tab_fwd,
                       const std::vector<int32_t> &tab_bwd) {
-    using cxh::fail;
     chain64_free(h);
     h->pot64_fresh = false;
+    Chain64 *c = nullptr;
+    const int32_t rc = chain64_make(h, &c, h->chain_partition, pos_var, skip0, skip1, link_pos, from, to, head_fwd, head_bwd, tab_fwd, tab_bwd);
+    h->chain64 = c;      // (a plan that failed half-way is freed with the handle's)
+    return rc;
+}
+
+// the plan of ONE light depth of the tree schedule's heavy paths, for one direction of travel (the way up skips a head's slot towards
+// its parent: other side information); appended to h->tree_c64, *index = its place there
+int32_t chain64_tree_build(cx_handle *h, int *index, const std::vector<int32_t> &pos_var, const std::vector<int32_t> &skip0, const std::vector<int32_t> &skip1,
+                           const std::vector<int32_t> &link_pos, const std::vector<int32_t> &from, const std::vector<int32_t> &to,
+                           const std::vector<uint8_t> &head_fwd, const std::vector<uint8_t> &head_bwd, const std::vector<int32_t> &tab_fwd,
+                           const std::vector<int32_t> &tab_bwd) {
+    Chain64 *c = nullptr;
+    const int32_t rc = chain64_make(h, &c, false, pos_var, skip0, skip1, link_pos, from, to, head_fwd, head_bwd, tab_fwd, tab_bwd);
+    if (rc != CX_OK) { chain64_drop(h, c); return rc; }
+    *index = (int)h->tree_c64.size();
+    h->tree_c64.push_back(c);
+    return CX_OK;
+}
+
+static int32_t chain64_make(cx_handle *h, Chain64 **out, bool root, const std::vector<int32_t> &pos_var, const std::vector<int32_t> &skip0,
+                            const std::vector<int32_t> &skip1, const std::vector<int32_t> &link_pos, const std::vector<int32_t> &from,
+                            const std::vector<int32_t> &to, const std::vector<uint8_t> &head_fwd, const std::vector<uint8_t> &head_bwd,
+                            const std::vector<int32_t> &tab_fwd, const std::vector<int32_t> &tab_bwd) {
+    using cxh::fail;
     const int64_t npos = (int64_t)pos_var.size(), nlinks = (int64_t)link_pos.size();
     std::vector<int32_t> side((size_t)3 * npos, -1);
     for (int64_t p = 0; p < npos; p++) {
@@ -563,14 +601,14 @@ int32_t chain64_build(cx_handle *h, const std::vector<int32_t> &pos_var, const s
     in.K0 = env_int("CX_MVC64_K", 0);            // links per level-0 block (default: one block per SIMD)
     in.fan = std::max(2, env_int("CX_MVC64_FAN", 2));      // binary tree: the shortest dependent chain above level 0 (fan 2 / 4 / 8: 14.19 / 14.37 / 15.08 ms on C5)
     in.lanes = 4 * (int64_t)ncu;                 // a composition is one wave per SIMD
-    in.root = h->chain_partition;                // a time block hands its whole potential to the other blocks
+    in.root = root;                              // a time block hands its whole potential to the other blocks
     p64::Plan plan;
     try { plan = p64::build(in); }
     catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "chain-scan schedule, dim 64: host allocation failed"); }
     catch (const std::exception &e) { return fail(h, CX_ERR_UNSUPPORTED, std::string("chain-scan schedule, dim 64: ") + e.what()); }
     Chain64 *c = new (std::nothrow) Chain64();
     if (!c) return fail(h, CX_ERR_OUT_OF_MEMORY, "chain-scan schedule, dim 64: host allocation failed");
-    h->chain64 = c;
+    *out = c;
     c->n_pot = plan.n_pot; c->n_ent = plan.n_ent; c->K0 = plan.K0; c->fan = plan.fan; c->levels = plan.levels;
     c->n_compositions = plan.n_compositions; c->n_rules = plan.n_rules;
     c->n_roots = (int)plan.root_pot.size();
@@ -644,9 +682,28 @@ static int32_t chain64_resolve(cx_handle *h, Chain64 *c) {
 }
 
 // one exact sweep: every launch of the plan, in order, on the handle's stream
+static int32_t chain64_run(cx_handle *h, Chain64 *c, bool skip_compose);
+
 int32_t chain64_sweep(cx_handle *h) {
     Chain64 *c = (Chain64 *)h->chain64;
     if (!c) return cxh::fail(h, CX_ERR_STATE, "chain-scan schedule, dim 64: no plan");
+    // a time block right after cx_chain_block_maps: the potentials are on the device already (what changed since — the messages that
+    // enter the block at its two ends — is side information of END positions, which no composition reads)
+    const bool skip_compose = h->pot64_fresh;
+    h->pot64_fresh = false;
+    return chain64_run(h, c, skip_compose);
+}
+
+// the tree schedule's plans: their device records resolved against the current base pointers (host copies: NOT inside a stream capture),
+// their launches, and one of them run
+int32_t chain64_tree_resolve(cx_handle *h) {
+    for (void *p : h->tree_c64) { const int32_t rc = chain64_resolve(h, (Chain64 *)p); if (rc != CX_OK) return rc; }
+    return CX_OK;
+}
+int64_t chain64_tree_launches(const cx_handle *h, int index) { return (int64_t)((const Chain64 *)h->tree_c64[index])->launches.size(); }
+int32_t chain64_tree_sweep(cx_handle *h, int index) { return chain64_run(h, (Chain64 *)h->tree_c64[index], false); }
+
+static int32_t chain64_run(cx_handle *h, Chain64 *c, bool skip_compose) {
     { int32_t rc = chain64_resolve(h, c); if (rc != CX_OK) return rc; }
     static const int walk_waves = env_int("CX_MVC64_WALK_WAVES", 2);
 #ifdef CX_C64_STAMPS
@@ -659,10 +716,6 @@ int32_t chain64_sweep(cx_handle *h) {
     }
     std::vector<unsigned long long> hs(st_n);
 #endif
-    // a time block right after cx_chain_block_maps: the potentials are on the device already (what changed since — the messages that
-    // enter the block at its two ends — is side information of END positions, which no composition reads)
-    const bool skip_compose = h->pot64_fresh;
-    h->pot64_fresh = false;
     for (const auto &L : c->launches) {
 #ifdef CX_C64_STAMPS
         (void)hipMemsetAsync(d_st, 0, st_n * 8, h->stream);

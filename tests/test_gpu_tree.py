@@ -322,11 +322,12 @@ def _comb_pairs(n_spine, teeth=1):
     return sorted(pairs), nxt
 
 
-@pytest.mark.parametrize("d", [2, 3, 4])
-@pytest.mark.parametrize("n_spine,teeth", [(2, 1), (60, 1), (150, 2)])
+@pytest.mark.parametrize("d,n_spine,teeth", [(2, 2, 1), (2, 60, 1), (2, 150, 2), (3, 2, 1), (3, 60, 1), (3, 150, 2), (4, 2, 1), (4, 60, 1), (4, 150, 2),
+                                             (64, 2, 1), (64, 7, 1), (64, 12, 2), (6, 20, 1), (33, 9, 2)])
 def test_d_dimensional_heavy_paths(hip_lib, monkeypatch, d, n_spine, teeth):
-    """dim 2..4 over heavy paths (the scans of csrc/cx_mvchain.hip per light depth, light edges as items): a chain of states with a latent
-    layer below each — the joint solve's marginals, the level schedule's messages"""
+    """dim 2..4 over heavy paths (the scans of csrc/cx_mvchain.hip per light depth, light edges as items) and dim 64 — with 5..63 embedded
+    in it — (a plan of compositions and walks per light depth, csrc/cx_mv64chain.hip): a chain of states with a latent layer below each —
+    the joint solve's marginals, the level schedule's messages"""
     from tests.test_gpu_mv import _branching_lgssm
 
     pairs, n = _comb_pairs(n_spine, teeth)
@@ -476,6 +477,31 @@ def test_dim_64_trees_one_sweep(hip_lib, d, b, n):
     a, bb = dev.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL), fused.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL)
     assert not np.any(np.isnan(a))
     assert_close(a, bb, 1e-8, "factor→variable messages vs the fused schedule at its fixed point", scale_by="max")
+    before = dev.get_marginals(model.x_ids)
+    dev.sweep(1)
+    assert np.array_equal(before, dev.get_marginals(model.x_ids))
+
+
+def test_a_dim_64_state_space_model_with_a_latent_layer(hip_lib, monkeypatch):
+    """d = 64, 400 states on the spine and a latent state below each (depth ~ 400 levels, 801 stages level by level): by default over
+    heavy paths — fewer launches — and the level schedule's marginals"""
+    from tests.test_gpu_mv import _branching_lgssm
+
+    pairs, n = _comb_pairs(400, 1)
+    model, _, _ = _branching_lgssm(n, 64, seed=78, pairs=pairs, solve=False)
+    dev = cx.DeviceGraph(dim=64, schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(model, dev)
+    dev.sweep(1)
+    st, hp = dev.tree_plan_stats(), dev.tree_heavy_path_stats()
+    assert st["depth"] >= 390 and 0 < hp["launches"] < 2 * st["depth"] + 1 and hp["light_depths"] <= 3, (st, hp)
+    monkeypatch.setenv("CX_TREE_HP", "0")
+    lv = cx.DeviceGraph(dim=64, schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(model, lv)
+    lv.sweep(1)
+    assert lv.tree_heavy_path_stats()["launches"] == 0
+    a, b = dev.get_marginals(model.x_ids), lv.get_marginals(model.x_ids)
+    assert not np.any(np.isnan(a))
+    assert_close(a, b, 1e-7, "heavy paths vs level by level: marginals", scale_by="max")
     before = dev.get_marginals(model.x_ids)
     dev.sweep(1)
     assert np.array_equal(before, dev.get_marginals(model.x_ids))

@@ -370,8 +370,9 @@ if __name__ == "__main__":
             for r in vmp(only=w[4:] or None):          # vmp | vmp_structured | vmp_mean_field
                 print(json.dumps(r), flush=True)
             continue
-        if w.startswith("treemv"):                       # treemv | treemv:2
-            print(json.dumps(tree_mv(d=int(w.split(":")[1]) if ":" in w else 4)), flush=True)
+        if w.startswith("treemv"):                       # treemv | treemv:2 | treemv:64 (5,000 states on the spine)
+            dd = int(w.split(":")[1]) if ":" in w else 4
+            print(json.dumps(tree_mv(d=dd, n_spine=200_000 if dd <= 4 else 5_000)), flush=True)
             continue
         if w.startswith("tree"):                         # tree | tree:deep
             print(json.dumps(tree(shape=w.split(":")[1] if ":" in w else "random")), flush=True)
