@@ -419,7 +419,7 @@ int32_t cx_chain_plan_stats(const cx_handle *h, int64_t *out8);
 /* CX_SCHED_TREE: the plan of the last sweep (zeros before the first one and for other schedules).
  * out8 = { depth, stages, items, k-ary entries, components, messages upwards, messages downwards, marginals }. */
 int32_t cx_tree_plan_stats(const cx_handle *h, int64_t *out8);
-/* CX_SCHED_TREE, scalar messages and dim 2 .. 4: when the sweep takes fewer launches that way, the plan runs over HEAVY PATHS — every variable's
+/* CX_SCHED_TREE: when the sweep takes fewer launches that way, the plan runs over HEAVY PATHS — every variable's
  * heaviest child continues its path, through a two-edge factor or through a factor of more edges (which, given the messages of its
  * other variables, is a pairwise rule between the two: formed on the device before the depth's first scan); the paths of one light
  * depth (light edges above them) are ONE segmented scan per direction, whatever their length, the light edges stay items: O(log n)

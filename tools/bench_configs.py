@@ -355,7 +355,7 @@ def tree_mv(d=4, n_spine=200_000):
     return {"config": "tree-mv", "workload": f"d={d} linear-Gaussian chain of {n_spine} states with a latent state below each ({len(model.edge_var)} edges), tree schedule over heavy paths",
             "ms_per_sweep": dt * 1e3, "plan": st, "heavy_paths": hp, "launches_per_sweep": hp["launches"] or st["stages"], "messages_per_sweep": n_msgs, "messages_per_s": n_msgs / dt,
             "level_schedule_on_a_tenth": {"ms_per_sweep": dtl * 1e3, "stages": lv.tree_plan_stats()["stages"]},
-            "roofline": roofline("hbm", n_msgs * 2 * S / dt / 1e9, HBM_PEAK_GBS, "GB/s", None, kernel="k_mvc_* scans of the heavy paths + k_batch_mv item stages",
+            "roofline": roofline("hbm", n_msgs * 2 * S / dt / 1e9, HBM_PEAK_GBS, "GB/s", None, kernel="k_mvc_* scans of the heavy paths + k_batch_mv item stages" if d <= 4 else "k_compose64p / k_walk64b plans of the heavy paths + k_rule64w item stages",
                                  basis=f"algorithmic bytes ({2 * S} B per message, SURVEY §8d) / sweep time", frac_algorithmic=n_msgs * 2 * S / dt / 1e9 / HBM_PEAK_GBS,
                                  frac_note="a latency-bound schedule: the fraction of HBM on algorithmic bytes is frac_algorithmic, no counter traffic was collected"),
             "parity": {"max_rel_err_marginals": err, "ok": bool(err < 1e-8), "checker": "the level schedule on the same device, a tenth of the model (joint solves: tests/test_gpu_tree.py)",
