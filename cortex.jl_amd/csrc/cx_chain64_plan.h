@@ -34,7 +34,7 @@
 namespace cx {
 namespace plan64 {
 
-enum Space : int64_t { kZero = 0, kF2V = 1, kPtab = 2, kBtab = 3, kPot = 4, kEnt = 5, kSpaces = 6 };
+enum Space : int64_t { kZero = 0, kF2V = 1, kPtab = 2, kBtab = 3, kPot = 4, kEnt = 5, kAux = 6, kSpaces = 7 };
 constexpr int64_t kOffMask = ((int64_t)1 << 56) - 1;
 inline int64_t H(Space s, int64_t off) { return ((int64_t)s << 56) | off; }
 
@@ -59,6 +59,9 @@ struct Input {
     const uint8_t *head_fwd = nullptr, *head_bwd = nullptr;     // first / last link of its path
     // per position: up to three slots of side information, -1 = none
     const int32_t *side = nullptr;      // [npos][3]
+    // per position (optional): the index of a message in the "aux" arena that holds the position's side information already summed (the
+    // caller sums it before every sweep: a position with three or more side slots), -1: the slots of `side` as they are
+    const int32_t *side_aux = nullptr;  // [npos]
     int K0 = 0;                         // links per level-0 block (0: chosen from the chain length and `lanes`)
     int fan = 2;                        // potentials per group of the upper levels
     int64_t lanes = 1024;               // waves the composition launch should fill (SIMDs of the device)
@@ -107,6 +110,8 @@ inline Plan build(const Input &in) {
     auto slot = [&](int32_t s) { return H(kF2V, (int64_t)s * p.msg); };
     auto sides_of = [&](int64_t pos, int64_t out[3]) {
         int n = 0;
+        if (in.side_aux && in.side_aux[pos] >= 0) out[n++] = H(kAux, (int64_t)in.side_aux[pos] * p.msg);
+        else
         for (int k = 0; k < 3; k++) { const int32_t s = in.side[3 * pos + k]; if (s >= 0) out[n++] = slot(s); }
         for (int k = n; k < 3; k++) out[k] = zero;
         return n;

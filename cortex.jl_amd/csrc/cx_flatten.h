@@ -137,8 +137,8 @@ int32_t flatten(H *h, int64_t n_edges, const int64_t *edge_var, const int64_t *e
                         std::to_string(h->var_ids[h->big_vars[0]]) + " has more");
         // dim 2..4: a variable's incoming messages live in registers (k_sweep_mv<D, DEG>: DEG = 3, 4 or 8 by the graph's widest
         // variable); dim 64: a rule sums at most three sources itself (k_rule64w) — a sender of degree 5 .. 8 has its other messages summed
-        // into its stored variable→factor message first (k_v2f64; flooding and tree schedules, batch items).  The chain-scan schedule
-        // of dim 64 keeps to degree <= 4 (cx_chain64_plan.h: three inputs per joint).
+        // into its stored variable→factor message first (k_v2f64; flooding and tree schedules, batch items); the chain-scan plans sum the
+        // side information of such a path variable into one message of their own first (k_side64, cx_mv64chain.hip).
         const int max_deg = 8;
         for (int64_t v = 0; v < nv; v++)
             if (var_deg[v] > max_deg)

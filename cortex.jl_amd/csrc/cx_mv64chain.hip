@@ -507,8 +507,13 @@ struct Chain64 {
     std::vector<p64::Job> jobs;            // the plan's records (handles), kept to be resolved again when a base pointer moves
     std::vector<p64::Child> children;
     std::vector<p64::Step> steps;
-    double *bases[p64::kSpaces] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // what the device records were resolved against
+    double *bases[p64::kSpaces] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // what the device records were resolved against
     double *d_pot = nullptr, *d_ent = nullptr, *d_ring = nullptr;      // d_ring: the Y2 hand-off of k_compose64p, 32 KB per job of the widest launch
+    // positions with three or more side slots (a path variable of degree 5 .. 8): their side information is summed into one message of
+    // this arena at the head of every sweep (k_side64), and the plan reads that one
+    double *d_aux = nullptr;
+    int32_t *d_aux_src = nullptr;          // 8 slots per arena message, -1 = none
+    int64_t n_aux = 0;
     struct Launch { int kind; int64_t first; int n; int steps; };      // kind 0: compose, 1: walk over potentials, 2: walk along links; steps: longest job
     std::vector<Launch> launches;
     int64_t n_pot = 0, n_ent = 0, n_compositions = 0, n_rules = 0;
@@ -522,9 +527,24 @@ struct Chain64 {
 
 static void chain64_drop(cx_handle *h, Chain64 *c) {
     if (!c) return;
-    for (void *p : {(void *)c->d_jobs, (void *)c->d_children, (void *)c->d_steps, (void *)c->d_pot, (void *)c->d_ent, (void *)c->d_ring}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)c->d_jobs, (void *)c->d_children, (void *)c->d_steps, (void *)c->d_pot, (void *)c->d_ent, (void *)c->d_ring, (void *)c->d_aux, (void *)c->d_aux_src}) if (p) (void)hipFree(p);
     h->device_bytes -= c->bytes;
     delete c;
+}
+
+// the side information of a position with three or more side slots, summed: one workgroup per arena message
+__global__ __launch_bounds__(256) void k_side64(int n, const int32_t *__restrict__ src, const double *__restrict__ f2v, double *__restrict__ aux) {
+    const int w = blockIdx.x;
+    if (w >= n) return;
+    int s[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s[j] = src[8 * w + j];
+    for (int e = threadIdx.x; e < kMsg; e += 256) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (s[j] >= 0) acc += f2v[(int64_t)s[j] * kMsg + e];
+        aux[(int64_t)w * kMsg + e] = acc;
+    }
 }
 
 void chain64_free(cx_handle *h) {
@@ -581,23 +601,28 @@ static int32_t chain64_make(cx_handle *h, Chain64 **out, bool root, const std::v
                             const std::vector<int32_t> &tab_fwd, const std::vector<int32_t> &tab_bwd) {
     using cxh::fail;
     const int64_t npos = (int64_t)pos_var.size(), nlinks = (int64_t)link_pos.size();
-    std::vector<int32_t> side((size_t)3 * npos, -1);
+    std::vector<int32_t> side((size_t)3 * npos, -1), side_aux((size_t)npos, -1), aux_src;
     for (int64_t p = 0; p < npos; p++) {
         const int32_t v = pos_var[p], deg = h->var_off[v + 1] - h->var_off[v];
+        int32_t all[8];
         int n = 0;
-        for (int32_t j = 0; j < deg; j++) {
+        for (int32_t j = 0; j < deg && j < 8; j++) {
             const int32_t sj = h->vbase[v] + j * kBlock;
             if (sj == skip0[p] || sj == skip1[p]) continue;
-            if (n == 3) return fail(h, CX_ERR_UNSUPPORTED, "chain-scan schedule, dim 64: variable " + std::to_string(h->var_ids[v]) + " has more than three inputs besides its chain links");
-            side[3 * p + n++] = sj;
+            all[n++] = sj;
         }
+        if (n <= 2 || (root && n == 3)) { for (int k = 0; k < n; k++) side[3 * p + k] = all[k]; continue; }      // (a time block's end variables hand their side slots to the caller as they are)
+        // three or more side slots (with the entering message: more than the three sources a rule or a joint sums): summed first
+        if (root) return fail(h, CX_ERR_UNSUPPORTED, "cx_chain_block_maps, dim 64: variable " + std::to_string(h->var_ids[v]) + " has more than three inputs besides its chain links");
+        side_aux[p] = (int32_t)(aux_src.size() / 8);
+        for (int k = 0; k < 8; k++) aux_src.push_back(k < n ? all[k] : -1);
     }
     int ncu = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, h->cfg.device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
     p64::Input in;
     in.d = 64; in.npos = npos; in.nlinks = nlinks;
     in.link_pos = link_pos.data(); in.from = from.data(); in.to = to.data(); in.tab_fwd = tab_fwd.data(); in.tab_bwd = tab_bwd.data();
-    in.head_fwd = head_fwd.data(); in.head_bwd = head_bwd.data(); in.side = side.data();
+    in.head_fwd = head_fwd.data(); in.head_bwd = head_bwd.data(); in.side = side.data(); in.side_aux = side_aux.data();
     in.K0 = env_int("CX_MVC64_K", 0);            // links per level-0 block (default: one block per SIMD)
     in.fan = std::max(2, env_int("CX_MVC64_FAN", 2));      // binary tree: the shortest dependent chain above level 0 (fan 2 / 4 / 8: 14.19 / 14.37 / 15.08 ms on C5)
     in.lanes = 4 * (int64_t)ncu;                 // a composition is one wave per SIMD
@@ -637,6 +662,12 @@ static int32_t chain64_make(cx_handle *h, Chain64 **out, bool root, const std::v
     if ((rc = cxh::dev_alloc(h, &c->d_pot, plan.n_pot * plan.pot)) != CX_OK) return rc;
     if ((rc = cxh::dev_alloc(h, &c->d_ent, plan.n_ent * plan.msg)) != CX_OK) return rc;
     if (plan.n_pot > 0 && (rc = cxh::dev_alloc(h, &c->d_ring, (int64_t)widest_compose * 16 * kTileD)) != CX_OK) return rc;
+    c->n_aux = (int64_t)aux_src.size() / 8;
+    if (c->n_aux > 0) {
+        if ((rc = cxh::dev_alloc(h, &c->d_aux, c->n_aux * (int64_t)kMsg)) != CX_OK) return rc;
+        if ((rc = cxh::dev_upload(h, &c->d_aux_src, aux_src)) != CX_OK) return rc;
+        CX_HIP(h, hipStreamSynchronize(h->stream));      // (aux_src is a local)
+    }
     // a potential or entry message that was never computed reads as UndefValue()
     CX_HIP(h, hipMemsetAsync(c->d_pot, 0xff, (size_t)std::max<int64_t>(1, plan.n_pot * plan.pot) * 8, h->stream));
     CX_HIP(h, hipMemsetAsync(c->d_ent, 0xff, (size_t)std::max<int64_t>(1, plan.n_ent * plan.msg) * 8, h->stream));
@@ -647,7 +678,7 @@ static int32_t chain64_make(cx_handle *h, Chain64 **out, bool root, const std::v
 // The device records hold POINTERS: the plan's handles resolved against the six base pointers of the moment.  Redone (host loop +
 // one upload per array) only when a base has moved: new rule tables (cx_set_factor_matrices) or a new plan.
 static int32_t chain64_resolve(cx_handle *h, Chain64 *c) {
-    double *bases[p64::kSpaces] = {h->d_zero_msg, h->d_mv_f2v, h->d_ptab, h->d_ptab_bt, c->d_pot, c->d_ent};
+    double *bases[p64::kSpaces] = {h->d_zero_msg, h->d_mv_f2v, h->d_ptab, h->d_ptab_bt, c->d_pot, c->d_ent, c->d_aux};
     if (std::memcmp(bases, c->bases, sizeof bases) == 0) return CX_OK;
     try {
         auto ptr = [&](int64_t hd) { return (uint64_t)(uintptr_t)(bases[hd >> 56] + (hd & p64::kOffMask)); };
@@ -716,6 +747,7 @@ static int32_t chain64_run(cx_handle *h, Chain64 *c, bool skip_compose) {
     }
     std::vector<unsigned long long> hs(st_n);
 #endif
+    if (c->n_aux > 0) hipLaunchKernelGGL(k_side64, dim3((unsigned)c->n_aux), dim3(256), 0, h->stream, (int)c->n_aux, c->d_aux_src, h->d_mv_f2v, c->d_aux);
     for (const auto &L : c->launches) {
 #ifdef CX_C64_STAMPS
         (void)hipMemsetAsync(d_st, 0, st_n * 8, h->stream);

@@ -302,6 +302,43 @@ def test_mv64_wave_per_message_form_matches_the_workgroup_form(hip_lib, monkeypa
 
 # ------------------------------------------------------------------------------- degree-4 variables (three sources)
 
+def _multi_sensor_lgssm(n, d, seed, sensors=3, pairs=None):
+    """states x_1 .. x_n linked as `pairs` (default: a chain), every state observed by `sensors` independent sensors y = x + N(0, R):
+    a chain variable of degree 2 + sensors.  Returns the model and the exact posterior (mean, covariance per state) of the joint solve."""
+    rng = np.random.default_rng(seed)
+    A = 0.9 * np.linalg.qr(rng.standard_normal((d, d)))[0]
+    Q, R = 0.2 * np.eye(d), np.eye(d)
+    x = np.arange(1, n + 1, dtype=np.int64)
+    if pairs is None:
+        pairs = [(i, i + 1) for i in range(n - 1)]
+    ys = [x + n * (k + 1) for k in range(sensors)]
+    liks = [x + n * (sensors + 1 + k) for k in range(sensors)]
+    tr = n * (2 * sensors + 1) + 1 + np.arange(len(pairs), dtype=np.int64)
+    par = np.array([x[p] for p, _ in pairs]); chi = np.array([x[c] for _, c in pairs])
+    edge_var = np.concatenate(ys + [x] * sensors + [par, chi])
+    edge_fac = np.concatenate(liks + liks + [tr, tr])
+    role = np.concatenate([np.full(n * sensors, L.ROLE_OUT), np.full(n * sensors, L.ROLE_IN), np.full(len(pairs), L.ROLE_IN), np.full(len(pairs), L.ROLE_OUT)]).astype(np.int32)
+    state = np.zeros((n, d)); state[0] = rng.standard_normal(d)
+    for p, c in pairs:
+        state[c] = A @ state[p] + np.sqrt(0.2) * rng.standard_normal(d)
+    data = [state + rng.standard_normal((n, d)) for _ in range(sensors)]
+    model = cx.synth.Model(edge_var=edge_var, edge_fac=edge_fac, factor_ids=np.concatenate(liks + [tr]),
+                           factor_kind=np.full(n * sensors + len(pairs), L.FACTOR_GAUSS_LINEAR, dtype=np.int32),
+                           factor_var=np.concatenate([np.ones(n * sensors), np.zeros(len(pairs))]), x_ids=x, data_var=np.concatenate(ys),
+                           data_fac=np.concatenate(liks), data_y=np.concatenate(data), dim=d, edge_role=role, psets={0: (A, Q), 1: (np.eye(d), R)},
+                           meta={"pairs": pairs})
+    Qi, Ri = np.linalg.inv(Q), np.linalg.inv(R)
+    J = np.zeros((n * d, n * d)); hvec = np.zeros(n * d)
+    for i in range(n):
+        for k in range(sensors):
+            J[i*d:(i+1)*d, i*d:(i+1)*d] += Ri; hvec[i*d:(i+1)*d] += Ri @ data[k][i]
+    for p, c in pairs:
+        P, C = slice(p*d, (p+1)*d), slice(c*d, (c+1)*d)
+        J[P, P] += A.T @ Qi @ A; J[C, C] += Qi; J[P, C] -= A.T @ Qi; J[C, P] -= Qi @ A
+    S = np.linalg.inv(J); mean = S @ hvec
+    return model, mean.reshape(n, d), np.stack([S[i*d:(i+1)*d, i*d:(i+1)*d] for i in range(n)])
+
+
 def _branching_lgssm(n, d, seed, b=2, pairs=None, solve=True):
     """a TREE of states with b children per node (node i has children b i + 1 .. b i + b), every state observed: inner nodes have degree
     b + 2 (parent, children, likelihood); b = 2: degree 4, a message out of them sums THREE incoming ones — the branch a chain never takes.

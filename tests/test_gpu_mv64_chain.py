@@ -221,3 +221,22 @@ def test_checkpoint_round_trip_under_the_chain_schedule(hip_lib):
     assert np.array_equal(other.get_marginals(model.x_ids), want)
     other.sweep(1)
     assert_close(other.get_marginals(model.x_ids), want, 1e-12, "a sweep after the import")
+
+
+@pytest.mark.parametrize("d,sensors,T", [(64, 3, 9), (64, 6, 7), (6, 4, 30)])
+def test_chain_variables_of_degree_up_to_eight(hip_lib, d, sensors, T):
+    """a chain whose states are observed by several sensors each (degree 2 + sensors, up to 8): a rule or a joint of the plan sums three
+    sources — the side information of such a position is summed into one message first (k_side64) — ONE sweep == the joint solve"""
+    from tests.test_gpu_mv import _multi_sensor_lgssm
+
+    model, emean, ecov = _multi_sensor_lgssm(T, d, seed=11 + sensors, sensors=sensors)
+    dev = cx.DeviceGraph(dim=d, schedule=L.SCHED_CHAIN_SCAN)
+    cx.synth.load_into_device(model, dev)
+    dev.sweep(1)
+    marg = dev.get_marginals(model.x_ids)
+    assert not np.any(np.isnan(marg))
+    assert_close(marg[:, :d], emean, 1e-8, "marginal mean vs the joint solve")
+    assert_close(marg[:, d:].reshape(T, d, d), ecov, 1e-8, "marginal covariance vs the joint solve")
+    before = dev.get_marginals(model.x_ids)
+    dev.sweep(1)
+    assert np.array_equal(before, dev.get_marginals(model.x_ids))
