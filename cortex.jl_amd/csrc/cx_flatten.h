@@ -174,7 +174,7 @@ int32_t flatten(H *h, int64_t n_edges, const int64_t *edge_var, const int64_t *e
             // edge, then the IN edges by ascending variable id; coefficients start at a_i = 1 (cx_set_factor_coefficients)
             const std::string who = "cx_graph_create: CX_FACTOR_GAUSS_LINEAR_N (factor id " + std::to_string(h->fac_ids[f]) + ")";
             if (mv) return fail_(err, CX_ERR_UNSUPPORTED, who + " needs dim == 1");
-            if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) return fail_(err, CX_ERR_UNSUPPORTED, who + ": a factor of three or more variables is not a link of a chain (use the fused or the flooding schedule)");
+            if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) return fail_(err, CX_ERR_UNSUPPORTED, who + ": a factor of three or more variables is not a link of a chain (use the tree, the fused or the flooding schedule)");
             if (deg < 3 || deg > 7) return fail_(err, CX_ERR_UNSUPPORTED, who + " takes 2 to 6 inputs and one output (3 to 7 edges), not " + std::to_string(deg) + " edges");
             if (!(p[0] >= 0.0)) return fail_(err, CX_ERR_INVALID_ARGUMENT, who + ": the variance q must be >= 0");
             if (!edge_role) return fail_(err, CX_ERR_INVALID_ARGUMENT, who + " needs edge roles (one CX_ROLE_OUT, the rest CX_ROLE_IN)");

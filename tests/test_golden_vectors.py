@@ -181,13 +181,32 @@ def test_tree_vector_plan_execution_and_dense_solve_agree():
     np.testing.assert_allclose(got[:, 1], d["posterior_variance"], rtol=1e-10)
 
 
+def test_tree_vector_heavy_path_plan_execution_agrees_too():
+    """CPU: the same file under the heavy-path plan (cx_tree_plan.h: build_hp — scans along heavy paths, through the file's factors of
+    three to six variables where a path runs through them, light edges as items)"""
+    from tests.test_tree_plan import HpRun, flat_of
+
+    d = load("tree24.json")
+    m = _tree24_model(d)
+    g = flat_of(m)
+    rc, err = g.tree_hp()
+    assert rc == L.OK, err
+    marg = HpRun(g, m).run()
+    got = np.array([marg[int(i)] for i in d["x_ids"]])
+    np.testing.assert_allclose(got[:, 0], d["posterior_mean"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(got[:, 1], d["posterior_variance"], rtol=1e-10)
+
+
 @pytest.mark.gpu
-def test_device_tree_against_the_golden_vector(hip_lib):
+@pytest.mark.parametrize("heavy_paths", ["0", "1"])
+def test_device_tree_against_the_golden_vector(hip_lib, monkeypatch, heavy_paths):
+    monkeypatch.setenv("CX_TREE_HP", heavy_paths)      # level by level / over heavy paths
     d = load("tree24.json")
     m = _tree24_model(d)
     dev = cx.DeviceGraph(schedule=L.SCHED_TREE)
     cx.synth.load_into_device(m, dev)
     dev.sweep(1)
+    assert (dev.tree_heavy_path_stats()["launches"] > 0) == (heavy_paths == "1")
     got = dev.get_marginals(d["x_ids"])
     np.testing.assert_allclose(got[:, 0], d["posterior_mean"], rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(got[:, 1], d["posterior_variance"], rtol=1e-10)
