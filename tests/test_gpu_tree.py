@@ -414,9 +414,12 @@ def test_d_dimensional_chain_is_a_tree_too(hip_lib):
     assert_close(tree.get_marginals(m.x_ids), scan.get_marginals(m.x_ids), 1e-9, "tree schedule vs chain scan on a d = 4 chain", scale_by="max")
 
 
-def test_many_small_random_forests(hip_lib):
+@pytest.mark.parametrize("heavy_paths", ["", "1"])
+def test_many_small_random_forests(hip_lib, monkeypatch, heavy_paths):
     """forty small forests of every shape (factor arities, hubs, long paths, several components, a random share of observed leaves): one
-    sweep == the dense solve, and the plan's bookkeeping adds up"""
+    sweep == the dense solve, and the plan's bookkeeping adds up — as the library chooses, and forced over heavy paths"""
+    if heavy_paths:
+        monkeypatch.setenv("CX_TREE_HP", heavy_paths)
     rng = np.random.default_rng(99)
     for trial in range(40):
         n_factors = int(rng.integers(1, 40))
