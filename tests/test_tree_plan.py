@@ -324,6 +324,26 @@ def test_heavy_paths_run_through_factors_of_more_than_two_edges(k_choices, n_fac
     assert np.allclose(got[:, 0], em, rtol=1e-9, atol=1e-12) and np.allclose(got[:, 1], ev, rtol=1e-9, atol=1e-12)
 
 
+def test_sixty_small_random_forests_under_both_plans():
+    """every shape, arity mix, number of components and share of observed leaves a seed produces: the level plan and the heavy-path plan,
+    both executed in numpy, both the dense solve's marginals (an undefined input at any step fails inside the executor)"""
+    rng = np.random.default_rng(2024)
+    for trial in range(60):
+        n_factors = int(rng.integers(1, 50))
+        shape = ["random", "deep", "star", "comb"][trial % 4]
+        m = cx.synth.tree_model(n_factors, seed=3000 + trial, shape=shape, components=int(rng.integers(1, 4)), observe=float(rng.uniform(0, 0.6)),
+                                k_choices=tuple(int(k) for k in rng.integers(1, 7, size=3)))
+        ids, em, ev = dense_posterior(m)
+        for plan in ("level", "heavy paths"):
+            g = flat_of(m)
+            rc, err = g.tree() if plan == "level" else g.tree_hp()
+            assert rc == L.OK, err
+            marg = (PlanRun if plan == "level" else HpRun)(g, m).run()
+            assert sorted(marg) == sorted(int(i) for i in ids), f"trial {trial} ({shape}), {plan}: a marginal for every non-observed variable"
+            got = np.array([marg[int(i)] for i in ids])
+            assert np.allclose(got[:, 0], em, rtol=1e-9, atol=1e-12) and np.allclose(got[:, 1], ev, rtol=1e-9, atol=1e-12), f"trial {trial} ({shape}), {plan}"
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_heavy_paths_of_pairwise_trees_are_logarithmic(seed):
     m = cx.synth.tree_model(2000, seed=seed, k_choices=(1,), shape="deep", observe=0.3)
