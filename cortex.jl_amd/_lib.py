@@ -73,6 +73,7 @@ SIGNATURES = {
     "cx_get_joint_marginals": (_i32, [_vp, _i64, _pi64, _pd]),
     "cx_sweep": (_i32, [_vp, _i32]),
     "cx_residual": (_i32, [_vp, _pd]),
+    "cx_message_health": (_i32, [_vp, _pi64]),
     "cx_halo_configure": (_i32, [_vp, _i64, _pi64, _pi64, _i64, _pi64, _pi64]),
     "cx_halo_buffers": (_i32, [_vp, C.POINTER(_vp), _pi64, C.POINTER(_vp), _pi64]),
     "cx_halo_set_buffers": (_i32, [_vp, _vp, _vp]),

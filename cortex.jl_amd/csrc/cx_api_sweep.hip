@@ -366,7 +366,6 @@ static void tree_issue(cx_handle *h) {
 // instantiation also falls back to them, for good.
 void tree_sweep(cx_handle *h) {
     static const bool graphs = [] { const char *e = std::getenv("CX_TREE_GRAPH"); return !(e && e[0] == '0'); }();
-    if (!h->tree_c64.empty()) (void)cx::chain64_tree_resolve(h);      // host copies when a base pointer moved: never inside the capture below
     if (graphs && !h->tree_graph_failed && !h->profiling && !h->tree_exec) {
         hipError_t e = hipSuccess;
         if (!h->tree_capture_stream) e = hipStreamCreateWithFlags(&h->tree_capture_stream, hipStreamNonBlocking);

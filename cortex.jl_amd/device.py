@@ -206,6 +206,12 @@ class DeviceGraph:
         self._check(self.lib.cx_residual(self.h, C.byref(out)))
         return out.value
 
+    def message_health(self):
+        """cx_message_health: the stored factor→variable messages into non-observed variables, counted on the device by state"""
+        out = (C.c_int64 * 4)()
+        self._check(self.lib.cx_message_health(self.h, out))
+        return dict(zip(("defined", "undefined", "negative_precision", "non_finite"), [int(x) for x in out]))
+
     # -- halo -----------------------------------------------------------------------------------
     def halo_configure(self, send_var, send_fac, recv_var, recv_fac):
         sv, sf, rv, rf = _i64(send_var), _i64(send_fac), _i64(recv_var), _i64(recv_fac)

@@ -429,6 +429,15 @@ int32_t cx_tree_plan_stats(const cx_handle *h, int64_t *out8);
  * schedule is in use (then cx_tree_plan_stats's "stages" are its launches).  With heavy paths "stages" / "items" count the item stages. */
 int32_t cx_tree_heavy_path_stats(const cx_handle *h, int64_t *out4);
 
+/* ---- numerical guards as counters (non-finite values, variances <= 0 and matrices that are not positive definite are
+ * reported through status codes and counters, never by an abort; the reference has nothing to mirror here — a rule that divides by
+ * zero throws in the user's Julia code).  An undefined value is NaN and propagates by itself, a rule whose input is not positive
+ * definite leaves its output undefined or unchanged; this call counts, on the device, the stored factor→variable messages INTO
+ * NON-OBSERVED variables:  out4 = { defined, undefined (UndefValue: never computed, or a dependency was undefined), defined with a
+ * negative precision (dim > 1: a negative diagonal entry of the precision matrix), defined with a non-finite entry (a point mass
+ * (y, +inf) of dim 1 is a value, not counted) }.  Synchronous. */
+int32_t cx_message_health(cx_handle *h, int64_t *out4);
+
 /* ---- checkpoint (the reference keeps no persistent state — src/ has no serialisation at all) ----
  * The mutable state of a handle (every message buffer, the marginals, the observed-variable flags, the sweep counter)
  * as one relocatable host blob.  A blob restores only into a handle created with the same dim / family / schedule and

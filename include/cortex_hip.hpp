@@ -105,6 +105,7 @@ class Handle {
     void update_batch_async(const std::vector<cx_item> &items) { check(cx_update_batch_async(h_, items.data(), (int64_t)items.size())); }
     void sweep(int32_t n = 1) { check(cx_sweep(h_, n)); }
     double residual() { double r = 0; check(cx_residual(h_, &r)); return r; }
+    std::array<int64_t, 4> message_health() { std::array<int64_t, 4> o{}; check(cx_message_health(h_, o.data())); return o; }      // defined, undefined, negative precision, non-finite
     std::pair<int32_t, double> sweep_until(double tol, int32_t max_sweeps, int32_t check_every = 10) {
         int32_t n = 0; double r = 0;
         check(cx_sweep_until(h_, tol, max_sweeps, check_every, &n, &r));

@@ -178,6 +178,12 @@ function tree_plan_stats(p)            # CX_SCHED_TREE (schedule = 3): depth, st
     return out
 end
 
+function message_health(p)             # numerical guards as counters: defined, undefined, negative precision, non-finite (messages into non-observed variables)
+    out = zeros(Int64, 4)
+    check(p.handle, ccall((:cx_message_health, lib), Int32, (Ptr{Cvoid}, Ptr{Int64}), p.handle, out))
+    return out
+end
+
 function tree_heavy_path_stats(p)      # light depths, paths, variables on no path, launches per sweep (zeros: the level schedule is in use)
     out = zeros(Int64, 4)
     check(p.handle, ccall((:cx_tree_heavy_path_stats, lib), Int32, (Ptr{Cvoid}, Ptr{Int64}), p.handle, out))
