@@ -98,6 +98,9 @@ int main(void) {
     CHECK(cx_sweep(h, 1));                                                  /* update_marginals!(engine, x) */
     CHECK(cx_get_marginals(h, T, xv, marg));
     for (int i = 0; i < T; i++) printf("x%d %.15g %.15g\n", i + 1, marg[2 * i], marg[2 * i + 1]);
+    int64_t health[4];
+    CHECK(cx_message_health(h, health));                                    /* the numerical guards as counters: nothing undefined after the sweep */
+    printf("health %lld %lld %lld %lld\n", (long long)health[0], (long long)health[1], (long long)health[2], (long long)health[3]);
 
     int64_t bad_v = 1, bad_f = 12345;
     double tmp[2];

@@ -26,6 +26,8 @@ def test_c_program_drives_the_abi(hip_lib, tmp_path):
     np.testing.assert_allclose(got[:, 0], m, rtol=1e-12)
     np.testing.assert_allclose(got[:, 1], v, rtol=1e-12)
     assert "unknown-edge status -2" in out.stdout and "12345" in out.stdout
+    (health,) = [l.split()[1:] for l in out.stdout.splitlines() if l.startswith("health ")]
+    assert int(health[0]) > 0 and [int(x) for x in health[1:]] == [0, 0, 0]      # cx_message_health: every message into a state is defined, none is broken
     # the dim = 4 chain driven batch by batch in the reference's schedule (abi_smoke.c: mv_batches)
     d = 4
     rows4 = np.array([[float(x) for x in l.split()[2:]] for l in out.stdout.splitlines() if l.startswith("m4 ")])
