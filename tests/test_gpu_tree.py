@@ -375,6 +375,35 @@ def test_d_dimensional_bushy_trees_over_heavy_paths(hip_lib, monkeypatch, d, b, 
     assert_close(marg[:, d:].reshape(n, d, d), ecov, 1e-8, "marginal covariance vs the joint solve", scale_by="max")
 
 
+@pytest.mark.parametrize("d,n_spine", [(4, 90), (2, 40), (64, 10)])
+def test_observing_a_state_rebuilds_the_heavy_paths_of_dim_greater_one(hip_lib, monkeypatch, d, n_spine):
+    """a standing heavy-path plan of dim 2..4 / 64, then a state in the middle of the spine becomes observed (a point mass on every one
+    of its edges): the plan is rebuilt — the spine is two paths now — and the sweep leaves what the level schedule leaves"""
+    from tests.test_gpu_mv import _branching_lgssm
+
+    pairs, n = _comb_pairs(n_spine, 1)
+    model, _, _ = _branching_lgssm(n, d, seed=81, pairs=pairs, solve=False)
+    mid = int(model.x_ids[n_spine // 2])
+    mid_facs = model.edge_fac[model.edge_var == mid]
+    value = np.tile(np.linspace(-0.5, 0.5, d), (len(mid_facs), 1))
+    free = np.array([v for v in model.x_ids if int(v) != mid])
+    got = {}
+    for hp_env in ("1", "0"):
+        monkeypatch.setenv("CX_TREE_HP", hp_env)
+        dev = cx.DeviceGraph(dim=d, schedule=L.SCHED_TREE)
+        cx.synth.load_into_device(model, dev)
+        dev.sweep(1)
+        paths_before = dev.tree_heavy_path_stats()["paths"]
+        dev.set_messages(np.full(len(mid_facs), mid), mid_facs, L.TO_FACTOR, L.FORM_POINT, value)
+        assert dev.tree_plan_stats()["stages"] == 0, "a newly observed variable invalidates the plan"
+        dev.sweep(1)
+        if hp_env == "1":
+            assert dev.tree_heavy_path_stats()["paths"] >= paths_before and dev.tree_heavy_path_stats()["launches"] > 0
+        got[hp_env] = dev.get_marginals(free)
+        assert not np.any(np.isnan(got[hp_env]))
+    assert_close(got["1"], got["0"], 1e-8, "after observing a state: heavy paths vs level by level", scale_by="max")
+
+
 def test_a_d_dimensional_state_space_model_with_a_latent_layer(hip_lib, monkeypatch):
     """d = 4, 20,000 states on the spine and a latent state below each (depth ~ 20,000 levels): by default over heavy paths — two light
     depths, a dozen launches — and the level schedule's marginals; new data under the standing plan"""
