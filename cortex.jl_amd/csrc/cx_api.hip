@@ -104,8 +104,9 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
         return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: dim > 1 runs the fused, the chain-scan and the tree schedule");
     if (config->schedule != CX_SCHED_FLOODING && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN && config->schedule != CX_SCHED_TREE)
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: unknown schedule");
-    if (config->schedule == CX_SCHED_TREE && is_vmp)
-        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: the variational families run the flooding, fused or chain-scan schedule");
+    if (config->schedule == CX_SCHED_TREE && config->family == CX_FAMILY_VMP_MEAN_FIELD)
+        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: the mean-field family has no inner sweep to schedule (flooding, fused or chain-scan are accepted and ignored; "
+                                                 "the tree schedule is the structured family's, for state variables that form a forest)");
     if (config->sweeps_per_launch < 0 || config->sweeps_per_launch > 2)
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: sweeps_per_launch must be 0 (automatic), 1 or 2");
     int ndev = 0;

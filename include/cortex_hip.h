@@ -119,8 +119,9 @@ extern "C" {
 #define CX_FAMILY_VMP_MEAN_FIELD 2  /* fully factorised posterior: the MeanFieldResolver + SSMMeanFieldInferenceRequestProcessor
                                        of test/inference_engine_tests.jl:599-689 */
 #define CX_FAMILY_VMP_STRUCTURED 3  /* Normal variables jointly (belief propagation with E[precision], run with cfg.schedule —
-                                       CX_SCHED_CHAIN_SCAN gives the exact forward/backward pass per update), precisions from
-                                       the joint marginals: StructuredResolver + SSMStructuredInferenceRequestProcessor, :810-1030 */
+                                       CX_SCHED_CHAIN_SCAN gives the exact forward/backward pass per update, CX_SCHED_TREE the exact
+                                       two passes when the states form any forest), precisions from the joint marginals:
+                                       StructuredResolver + SSMStructuredInferenceRequestProcessor, :810-1030 */
 
 /* schedules of cx_sweep */
 #define CX_SCHED_FLOODING 0   /* all variable→factor, then all factor→variable, then marginals           */

@@ -60,7 +60,7 @@ def test_mean_field_calls_match_the_array_form(hip_lib, n):
             np.testing.assert_allclose(_state(dev, model), _array_state(arr), rtol=RTOL, atol=0, err_msg=f"n={n} it={it} {which}")
 
 
-@pytest.mark.parametrize("schedule", [L.SCHED_CHAIN_SCAN])
+@pytest.mark.parametrize("schedule", [L.SCHED_CHAIN_SCAN, L.SCHED_TREE])      # (a chain is a tree: level by level for the short ones, over its heavy path for n = 5000)
 @pytest.mark.parametrize("n", [7, 8, 100, 5000])
 def test_structured_calls_match_the_array_form(hip_lib, n, schedule):
     model = cx.synth.vmp_ssm(n, seed=12)
@@ -236,10 +236,13 @@ def test_vmp_checkpoint_continues_bit_for_bit(hip_lib, family):
         plain.import_state(blob)
 
 
-def test_structured_vmp_on_a_tree_with_the_fused_schedule(hip_lib):
+@pytest.mark.parametrize("schedule", [L.SCHED_FUSED, L.SCHED_TREE])
+def test_structured_vmp_on_a_tree_with_the_fused_schedule(hip_lib, schedule):
     """Beyond chains: a random tree of latent states with one shared edge precision and one observation precision, the inner
-    handle on the fused flooding schedule (one sweep per update call; `depth` calls settle the tree).  Belief propagation is
-    exact on a tree, so the variational fixed point must equal the one computed with dense linear algebra."""
+    handle on the fused flooding schedule (one sweep per update call; `depth` calls settle the tree) or on the tree schedule
+    (ONE call is the exact two passes).  Belief propagation is exact on a tree, so the variational fixed point must equal the
+    one computed with dense linear algebra."""
+    calls_per_state_update = 1 if schedule == L.SCHED_TREE else None
     rng = np.random.default_rng(4)
     n = 40
     parent = [-1] + [int(rng.integers(0, i)) for i in range(1, n)]
@@ -255,7 +258,7 @@ def test_structured_vmp_on_a_tree_with_the_fused_schedule(hip_lib):
     for k, (a, b) in enumerate(edges):
         ev += [x[a], x[b], ss]; ef += [tr[k]] * 3; role += [L.ROLE_IN, L.ROLE_OUT, L.ROLE_PRECISION]
     fids = np.concatenate([lik, tr])
-    dev = cx.DeviceGraph(family=L.FAMILY_VMP_STRUCTURED, schedule=L.SCHED_FUSED)
+    dev = cx.DeviceGraph(family=L.FAMILY_VMP_STRUCTURED, schedule=schedule)
     dev.graph_create(ev, ef, fids, np.full(len(fids), L.FACTOR_NORMAL_PRECISION, np.int32), np.zeros(len(fids)), edge_role=role)
     dev.set_marginals([ss, obs], L.FORM_GAMMA, [1.0, 1.0, 1.0, 1.0])
     dev.set_marginals(x, L.FORM_MEAN_PRECISION, np.tile([0.0, 1.0], n))
@@ -273,13 +276,13 @@ def test_structured_vmp_on_a_tree_with_the_fused_schedule(hip_lib):
         ts = (1 + 0.5 * len(edges)) / (0.5 * spread_s)
         to = (1 + 0.5 * n) / (0.5 * spread_o)
     for _ in range(60):
-        for _ in range(n):                 # the tree's depth is < n: more than enough flooding sweeps to settle it
+        for _ in range(calls_per_state_update or n):                 # the tree's depth is < n: more than enough flooding sweeps to settle it
             dev.update_marginals(L.VMP_ALL_NORMAL)
         dev.update_marginals(L.VMP_ALL_PRECISION)
     g = dev.get_marginals([ss, obs])
     assert g[0, 0] * g[0, 1] == pytest.approx(ts, rel=1e-6)
     assert g[1, 0] * g[1, 1] == pytest.approx(to, rel=1e-6)
-    for _ in range(n):
+    for _ in range(calls_per_state_update or n):
         dev.update_marginals(L.VMP_ALL_NORMAL)
     q = dev.get_marginals(x)
     J = np.eye(n) * to
