@@ -349,6 +349,71 @@ def auto_partition(model: synth.Model, rank: int, world: int, depth: int = 0) ->
     return by_assignment_deep(model, owner, rank, world, depth) if depth else by_assignment(model, owner, rank, world)
 
 
+def by_components(model: synth.Model, rank: int, world: int) -> synth.Model:
+    """Independent objects ("shards naturally"): the connected components of the NON-OBSERVED part of a model — the trees
+    of a forest, the chains of a batch of state-space models — dealt to the ranks, largest first onto the least loaded; no exchange of
+    any kind follows: every rank runs its exact schedule (CX_SCHED_TREE, CX_SCHED_CHAIN_SCAN) on the sub-model this returns.  An
+    observed variable belongs to no component: it travels with every factor that touches it (each rank sets its datum on its own copy).
+    The sub-model keeps the model's ids."""
+    ev, ef = np.asarray(model.edge_var, np.int64), np.asarray(model.edge_fac, np.int64)
+    obs = np.isin(ev, np.asarray(model.data_var, np.int64))
+    # union-find over factors: two factors that share a non-observed variable are one component
+    fids, finv = np.unique(ef, return_inverse=True)
+    parent = np.arange(len(fids))
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+    order = np.argsort(ev, kind="stable")
+    evs, fis, obs_s = ev[order], finv[order], obs[order]
+    for i in range(1, len(evs)):
+        if evs[i] == evs[i - 1] and not obs_s[i]:
+            a, b = find(fis[i]), find(fis[i - 1])
+            if a != b:
+                parent[a] = b
+    root = np.array([find(i) for i in range(len(fids))])
+    comp_ids, comp_of_fac = np.unique(root, return_inverse=True)
+    load = np.bincount(comp_of_fac[finv], minlength=len(comp_ids))          # edges per component
+    owner_of_comp = np.zeros(len(comp_ids), np.int64)
+    totals = np.zeros(world, np.int64)
+    for c in np.argsort(-load, kind="stable"):
+        r = int(np.argmin(totals))
+        owner_of_comp[c] = r
+        totals[r] += load[c]
+    fac_mine = owner_of_comp[comp_of_fac] == rank                            # per unique factor id
+    keep_e = fac_mine[finv]
+    my_f = set(fids[fac_mine].tolist())
+    fmask = np.array([int(f) in my_f for f in np.asarray(model.factor_ids, np.int64)], dtype=bool)
+    my_v = set(ev[keep_e].tolist())
+
+    def pick(mask_src, *arrs):
+        return tuple(np.asarray(a)[mask_src] for a in arrs)
+    dm = np.array([int(v) in my_v and int(f) in my_f for v, f in zip(model.data_var, model.data_fac)], dtype=bool) if len(model.data_var) else np.zeros(0, bool)
+    pm = np.array([int(f) in my_f for f in model.prior_fac], dtype=bool) if len(model.prior_var) else np.zeros(0, bool)
+    meta = dict(model.meta)
+    if "kary_ids" in meta:                                                   # synth.kary_model / tree_model: per-factor and per-edge tables follow
+        km = np.array([int(f) in my_f for f in meta["kary_ids"]], dtype=bool)
+        meta["kary_ids"] = np.asarray(meta["kary_ids"])[km]
+        meta["fac_vars"] = [fv for fv, k in zip(meta["fac_vars"], km) if k]
+        for key in ("q", "b", "out_var"):
+            meta[key] = np.asarray(meta[key])[km]
+        if "is_kary" in meta:
+            meta["is_kary"] = np.asarray(meta["is_kary"])[km]
+        for pre in ("coef", "all_coef"):
+            if pre + "_fac" in meta:
+                cm = np.array([int(f) in my_f for f in meta[pre + "_fac"]], dtype=bool)
+                meta[pre + "_var"], meta[pre + "_fac"], meta[pre] = np.asarray(meta[pre + "_var"])[cm], np.asarray(meta[pre + "_fac"])[cm], np.asarray(meta[pre])[cm]
+        meta["used"] = np.array(sorted(my_v), dtype=np.int64)
+    return synth.Model(edge_var=ev[keep_e], edge_fac=ef[keep_e], factor_ids=np.asarray(model.factor_ids)[fmask], factor_kind=np.asarray(model.factor_kind)[fmask],
+                       factor_var=np.asarray(model.factor_var)[fmask], x_ids=np.array([v for v in model.x_ids if int(v) in my_v], dtype=np.int64),
+                       data_var=np.asarray(model.data_var)[dm], data_fac=np.asarray(model.data_fac)[dm], data_y=np.asarray(model.data_y)[dm],
+                       prior_var=np.asarray(model.prior_var)[pm], prior_fac=np.asarray(model.prior_fac)[pm], prior_mean=np.asarray(model.prior_mean)[pm],
+                       prior_variance=np.asarray(model.prior_variance)[pm], meta=meta, dim=model.dim,
+                       edge_role=None if model.edge_role is None else np.asarray(model.edge_role)[keep_e], psets=model.psets)
+
+
 def contiguous_blocks(model: synth.Model, rank: int, world: int, depth: int = 0) -> Partition:
     """Equal contiguous id-blocks of the latent variables (time blocks of a chain, row blocks of a grid); every other
     variable (observations) goes with its first neighbour among the latent variables."""

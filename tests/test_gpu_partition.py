@@ -707,3 +707,44 @@ def test_chain_scan_partition_with_linear_factors_on_device(hip_lib, T, world):
         assert_close(got[:, 1], ref_[ids - 1, 1], 1e-9, f"rank {rank}: variance vs the un-partitioned chain scan")
         total += len(ids)
     assert total == T
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_forest_components_dealt_to_ranks_need_no_exchange(hip_lib, world):
+    """partition.by_components (independent objects): the trees of a forest on `world` handles — one per rank on a multi-GPU
+    node, here all on one device — each ONE exact sweep of the tree schedule, nothing exchanged: every rank's marginals are the single
+    handle's marginals of its variables, bit for bit where the plans coincide and to rounding otherwise"""
+    m = cx.synth.tree_model(900, seed=23, shape="deep", components=9, observe=0.3)
+    whole = cx.DeviceGraph(schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(m, whole)
+    whole.sweep(1)
+    ref = dict(zip((int(v) for v in m.x_ids), whole.get_marginals(m.x_ids)))
+    seen = 0
+    for r in range(world):
+        sub = partition.by_components(m, r, world)
+        dev = cx.DeviceGraph(schedule=L.SCHED_TREE)
+        cx.synth.load_into_device(sub, dev)
+        dev.sweep(1)
+        got = dev.get_marginals(sub.x_ids)
+        want = np.array([ref[int(v)] for v in sub.x_ids])
+        assert_close(got, want, 1e-10, f"rank {r} of {world}: marginals vs the single handle")
+        seen += len(sub.x_ids)
+        dev.close()
+    assert seen == len(m.x_ids)
+
+
+def test_a_batch_of_d_dimensional_chains_dealt_to_ranks(hip_lib):
+    chains = [cx.synth.lgssm_chain(T, d=4, seed=40 + T) for T in (60, 9, 130, 41, 17, 80)]
+    m = cx.synth.concat_models(chains)
+    whole = cx.DeviceGraph(dim=4, schedule=L.SCHED_CHAIN_SCAN)
+    cx.synth.load_into_device(m, whole)
+    whole.sweep(1)
+    ref = dict(zip((int(v) for v in m.x_ids), whole.get_marginals(m.x_ids)))
+    for r in range(2):
+        sub = partition.by_components(m, r, 2)
+        dev = cx.DeviceGraph(dim=4, schedule=L.SCHED_CHAIN_SCAN)
+        cx.synth.load_into_device(sub, dev)
+        dev.sweep(1)
+        assert_close(dev.get_marginals(sub.x_ids), np.array([ref[int(v)] for v in sub.x_ids]), 1e-9, f"rank {r}: marginals vs the single handle",
+                     scale_by="max")      # (most covariance entries are ~ 0: the median is no scale)
+        dev.close()
