@@ -353,11 +353,37 @@ int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
 int32_t cx_get_products(cx_handle *h, int64_t n, const int64_t *variable_ids, const int32_t *range_lo, const int32_t *range_hi,
                         int32_t form, double *out) {
     CX_NOT_VMP(h, "cx_get_products");
-    CX_REQUIRE(h, h && h->has_graph && h->cfg.dim == 1, CX_ERR_STATE, "cx_get_products: no scalar graph");
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_get_products: no graph");
     CX_REQUIRE(h, form == CX_FORM_MOMENT || form == CX_FORM_NATURAL, CX_ERR_INVALID_ARGUMENT, "cx_get_products: bad form");
     CX_REQUIRE(h, h->cfg.family == CX_FAMILY_GAUSSIAN || form == CX_FORM_NATURAL, CX_ERR_UNSUPPORTED, "cx_get_products: CX_FAMILY_NATURAL2 returns CX_FORM_NATURAL payloads only");
     if (n == 0) return CX_OK;
     CX_REQUIRE(h, n > 0 && variable_ids && range_lo && range_hi && out, CX_ERR_INVALID_ARGUMENT, "cx_get_products: null argument");
+    if (h->cfg.dim > 1) {
+        // dim > 1: rows of the device table (a node that was never computed reads as UndefValue(): the table's spare entry 0 .. cap - 1 are
+        // NaN until written; an unknown node gets a NaN row)
+        try {
+            const int d = h->cfg.dim, u = h->user_dim ? h->user_dim : d;
+            const size_t sb = (size_t)d + (size_t)d * d, so = (size_t)u + (size_t)u * u;
+            std::vector<int32_t> idx;
+            std::vector<int64_t> where;
+            for (int64_t i = 0; i < n; i++) {
+                const int64_t v = find_var(h, variable_ids[i]);
+                if (v < 0) return fail(h, CX_ERR_NOT_FOUND, "unknown variable id " + std::to_string(variable_ids[i]));
+                auto it = h->prod_index.find(std::make_tuple((int32_t)v, range_lo[i], range_hi[i]));
+                if (it != h->prod_index.end() && it->second < h->mv_prod_cap) { idx.push_back(it->second); where.push_back(i); }
+                for (size_t k = 0; k < so; k++) out[(size_t)i * so + k] = kNaN;
+            }
+            if (idx.empty()) return CX_OK;
+            std::vector<double> rows(idx.size() * sb);
+            const int32_t rc = mv_get(h, h->d_mv_prod, h->mv_prod_cap, idx, form, false, rows.data());
+            if (rc != CX_OK) return rc;
+            for (size_t k = 0; k < idx.size(); k++) {
+                if (h->user_dim) unpad_payload(u, &rows[k * sb], out + (size_t)where[k] * so);
+                else std::memcpy(out + (size_t)where[k] * so, &rows[k * sb], sb * 8);
+            }
+            return CX_OK;
+        } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_get_products: host allocation failed"); }
+    }
     try {
         // a batch that failed half-way may have indexed nodes the store was never grown for: they read as UndefValue()
         std::vector<double2> store((size_t)std::min<int64_t>((int64_t)h->prod_index.size(), h->prod_cap));

@@ -486,7 +486,7 @@ int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
     int32_t rc = mv_ensure_chain_msgs(h);
     if (rc != CX_OK) return rc;
     const bool d64 = h->cfg.dim == 64;
-    std::vector<int32_t> rec, v2f_slots, v2f_vars, point_slots, rule_rec, slot_var;
+    std::vector<int32_t> rec, v2f_slots, v2f_vars, point_slots, rule_rec, slot_var, prod_rec;
     if (d64) {
         slot_var.assign(h->nslots, -1);
         for (int64_t e = 0; e < h->ne; e++) slot_var[cx::slot_of_edge(h, e)] = h->edge_var[e];
@@ -518,10 +518,44 @@ int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
                 }
                 continue;
             }
+        } else if (it.kind == CX_ITEM_PRODUCT_OF_MESSAGES) {
+            // ProductOfMessages(variable_id, range, ...), inference_signal.jl:62-66 (the range travels in factor_id): what the reference's
+            // default resolver creates for a variable of degree > 5 (src/dependencies.jl:90-173) — dim > 1 takes degrees up to 8
+            var = find_var(h, it.variable_id);
+            if (var < 0) return fail(h, CX_ERR_NOT_FOUND, "unknown variable id " + std::to_string(it.variable_id));
+            const int64_t lo = (int64_t)((uint64_t)it.factor_id >> 32), hi = (int64_t)((uint64_t)it.factor_id & 0xffffffffu);
+            const int64_t deg = h->var_off[var + 1] - h->var_off[var];
+            if (lo < 1 || hi < lo || hi > deg)
+                return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_update_batch: ProductOfMessages range " + std::to_string(lo) + ":" + std::to_string(hi) +
+                            " outside 1:" + std::to_string(deg) + " (variable " + std::to_string(it.variable_id) + ")");
+            auto key = std::make_tuple((int32_t)var, (int32_t)lo, (int32_t)hi);
+            auto pit = h->prod_index.find(key);
+            if (pit == h->prod_index.end()) pit = h->prod_index.emplace(key, (int32_t)h->prod_index.size()).first;
+            idx = pit->second; tab = lo;
+            if (d64) {
+                prod_rec.insert(prod_rec.end(), {(int32_t)idx, (int32_t)(hi - lo + 1)});
+                for (int64_t j = lo - 1; j < lo - 1 + 8; j++) prod_rec.push_back(j < hi ? h->vbase[var] + (int32_t)j * cx::kBlock : -1);
+                continue;
+            }
+            rec[5 * i + 4] = (int32_t)hi;
         } else {
-            return fail(h, CX_ERR_UNSUPPORTED, "cx_update_batch: dim > 1 implements MessageToFactor, MessageToVariable and IndividualMarginal items (kind " + std::to_string(it.kind) + ")");
+            return fail(h, CX_ERR_UNSUPPORTED, "cx_update_batch: dim > 1 implements MessageToFactor, MessageToVariable, IndividualMarginal and ProductOfMessages items (kind " + std::to_string(it.kind) + ")");
         }
         rec[5 * i] = it.kind; rec[5 * i + 1] = (int32_t)idx; rec[5 * i + 2] = (int32_t)var; rec[5 * i + 3] = (int32_t)tab;
+    }
+    // the ProductOfMessages table grows with the signals that name it (whole blocks of 256 entries; new entries read as UndefValue())
+    if ((int64_t)h->prod_index.size() > h->mv_prod_cap) {
+        const int64_t cap = std::max<int64_t>(2 * h->mv_prod_cap, (((int64_t)h->prod_index.size() + 255) / 256) * 256);
+        const int64_t per = d64 ? h->nc : h->ncs;
+        double *bigger = nullptr;
+        if ((rc = dev_alloc(h, &bigger, cap * per)) != CX_OK) return rc;
+        CX_HIP(h, hipMemsetAsync(bigger, 0xff, (size_t)(cap * per) * 8, h->stream));
+        if (h->d_mv_prod) {
+            CX_HIP(h, hipMemcpyAsync(bigger, h->d_mv_prod, (size_t)(h->mv_prod_cap * per) * 8, hipMemcpyDeviceToDevice, h->stream));
+            CX_HIP(h, hipStreamSynchronize(h->stream));
+            (void)hipFree(h->d_mv_prod);
+        }
+        h->d_mv_prod = bigger; h->mv_prod_cap = cap;
     }
     if (!d64 && n <= cx::kSmallBatch) {          // records in the kernel arguments, no wait (cx_api_msg.hip: cx_update_batch)
         cx::SmallBatch sb{};
@@ -535,10 +569,14 @@ int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
         CX_HIP(h, hipMemcpyAsync(h->d_stage, rec.data(), 5 * n * 4, hipMemcpyHostToDevice, h->stream));
         cx::mv_launch_batch(h, (const int32_t *)h->d_stage, n);
     } else {
-        const int64_t n1 = (int64_t)v2f_slots.size(), n2 = (int64_t)point_slots.size(), n3 = (int64_t)rule_rec.size() / 8;
-        if ((rc = ensure_stage(h, (2 * n1 + n2 + 8 * n3 + 4) * 4)) != CX_OK) return rc;
+        const int64_t n1 = (int64_t)v2f_slots.size(), n2 = (int64_t)point_slots.size(), n3 = (int64_t)rule_rec.size() / 8, n4 = (int64_t)prod_rec.size() / 10;
+        if ((rc = ensure_stage(h, (2 * n1 + n2 + 8 * n3 + 10 * n4 + 4) * 4)) != CX_OK) return rc;
         int32_t *d = (int32_t *)h->d_stage;
-        int32_t *d_s = d, *d_v = d + n1, *d_p = d + 2 * n1, *d_r = d + 2 * n1 + n2;
+        int32_t *d_s = d, *d_v = d + n1, *d_p = d + 2 * n1, *d_r = d + 2 * n1 + n2, *d_q = d + 2 * n1 + n2 + 8 * n3;
+        if (n4) {
+            CX_HIP(h, hipMemcpyAsync(d_q, prod_rec.data(), n4 * 40, hipMemcpyHostToDevice, h->stream));
+            cx::mv64_launch_range_sums(h, (int)n4, d_q, h->d_mv_f2v, h->d_mv_prod);
+        }
         if (n1) { CX_HIP(h, hipMemcpyAsync(d_s, v2f_slots.data(), n1 * 4, hipMemcpyHostToDevice, h->stream)); CX_HIP(h, hipMemcpyAsync(d_v, v2f_vars.data(), n1 * 4, hipMemcpyHostToDevice, h->stream)); }
         if (n2) CX_HIP(h, hipMemcpyAsync(d_p, point_slots.data(), n2 * 4, hipMemcpyHostToDevice, h->stream));
         if (n3) CX_HIP(h, hipMemcpyAsync(d_r, rule_rec.data(), n3 * 32, hipMemcpyHostToDevice, h->stream));

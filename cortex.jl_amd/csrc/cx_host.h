@@ -132,6 +132,7 @@ void dev_free_all(cx_handle *h);
 // ---- cx_api_mv.hip: host side of dim > 1 ----------------------------------------------------------------------------
 int32_t mv_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, int32_t direction,
                         int32_t form, const double *payload);
+int32_t mv_get(cx_handle *h, const double *src, int64_t stride, const std::vector<int32_t> &idx, int32_t form, bool already_moment, double *out);      // rows of a message-form buffer by index
 int32_t mv_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, int32_t direction,
                         int32_t form, double *out);
 int32_t mv_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, double *out);

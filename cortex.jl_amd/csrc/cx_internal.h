@@ -205,6 +205,8 @@ struct cx_handle {
     double2 *d_prod = nullptr;
     double *d_joint = nullptr;
     int64_t prod_cap = 0, joint_cap = 0;
+    double *d_mv_prod = nullptr;         // dim > 1: the ProductOfMessages table (natural form; dim 2..4 in the messages' pair form, dim 64 one row of 4,160 doubles each)
+    int64_t mv_prod_cap = 0;             // entries it holds (a multiple of 256)
 
     // two sweeps per launch (cx_tiles.hip): tile tables built once per graph
     int tiles_state = 0;             // 0: not built yet, 1: ready, -1: this graph is outside the tiled kernel
@@ -288,6 +290,7 @@ void mv64w_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const doub
 void mv64_launch_marginals(cx_handle *h, int n, const int32_t *d_vars, const double *f2v, double *out);
 void mv64_launch_point(cx_handle *h, int nwork, const int32_t *d_slots, double *out_a, double *out_b);
 void mv64_launch_v2f(cx_handle *h, int n, const int32_t *d_slots, const int32_t *d_vars, const double *f2v);
+void mv64_launch_range_sums(cx_handle *h, int n, const int32_t *d_rec10, const double *f2v, double *out);      // rec: destination row, n sources, 8 source slots
 void mv64_launch_seed(cx_handle *h, double *buf, double eta, double lam);
 void mv64_rows_scatter(cx_handle *h, double *dst, const int32_t *d_idx, const double *d_val, int64_t n);
 void mv64_rows_gather(cx_handle *h, const double *src, const int32_t *d_idx, double *d_val, int64_t n);

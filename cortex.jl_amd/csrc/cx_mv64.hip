@@ -557,6 +557,21 @@ __global__ __launch_bounds__(kBlock) void k_v2f64(int n, const int32_t *__restri
     }
 }
 
+// ProductOfMessages of dim 64: the sum of up to eight messages of a variable into a row of the product table; nothing is stored when one
+// of them is undefined (the signal is not pending)
+__global__ __launch_bounds__(kBlock) void k_range_sum64(int n, const int32_t *__restrict__ rec, const double *__restrict__ f2v, double *__restrict__ out) {
+    const int w = blockIdx.x;
+    if (w >= n) return;
+    const int32_t *r = rec + 10 * (int64_t)w;
+    const int dst = r[0], ns = r[1];
+    for (int j = 0; j < ns; j++) if (__builtin_isnan(f2v[(int64_t)r[2 + j] * kMsg + kD])) return;      // (whole messages are NaN together)
+    for (int e = threadIdx.x; e < kMsg; e += kBlock) {
+        double acc = 0.0;
+        for (int j = 0; j < ns; j++) acc += f2v[(int64_t)r[2 + j] * kMsg + e];
+        out[(int64_t)dst * kMsg + e] = acc;
+    }
+}
+
 __global__ void k_fill64(double *__restrict__ buf, int64_t nslots, double eta, double lam, const int32_t *__restrict__ partner) {
     const int64_t s = blockIdx.x;
     if (s >= nslots || partner[s] < 0) return;
@@ -637,6 +652,11 @@ void mv64_launch_point(cx_handle *h, int nwork, const int32_t *d_slots, double *
 void mv64_launch_v2f(cx_handle *h, int n, const int32_t *d_slots, const int32_t *d_vars, const double *f2v) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_v2f64, dim3(n), dim3(kBlock), 0, h->stream, n, d_slots, d_vars, h->d_vbase, h->d_vinfo, f2v, h->d_mv_v2f);
+}
+
+void mv64_launch_range_sums(cx_handle *h, int n, const int32_t *d_rec10, const double *f2v, double *out) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_range_sum64, dim3(n), dim3(kBlock), 0, h->stream, n, d_rec10, f2v, out);
 }
 
 void mv64_launch_seed(cx_handle *h, double *buf, double eta, double lam) {

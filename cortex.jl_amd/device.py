@@ -167,11 +167,11 @@ class DeviceGraph:
             self._check(rc)
 
     def get_products(self, variable_ids, range_lo, range_hi, form: int = L.FORM_MOMENT):
-        """stored ProductOfMessages(variable, lo:hi) values, [n, 2]"""
+        """stored ProductOfMessages(variable, lo:hi) values, [n, 2] (dim > 1: [n, d + d * d], as messages)"""
         v = _i64(np.atleast_1d(variable_ids))
         lo = np.ascontiguousarray(np.atleast_1d(range_lo), dtype=np.int32)
         hi = np.ascontiguousarray(np.atleast_1d(range_hi), dtype=np.int32)
-        out = np.zeros((len(v), 2), dtype=np.float64)
+        out = np.zeros((len(v), self.lib.cx_payload_doubles(self.dim, L.FORM_MOMENT) if self.dim > 1 else 2), dtype=np.float64)
         self._check(self.lib.cx_get_products(self.h, len(v), _p(v, C.c_int64), _p(lo, C.c_int32), _p(hi, C.c_int32), form,
                                              _p(out, C.c_double)))
         return out

@@ -388,15 +388,65 @@ def test_d_dimensional_chain_through_the_plugin(hip_lib, d, n, mode, tol):
         assert_close(got.mean, m, tol, f"f2v mean edge {e}", scale_by="max"); assert_close(got.covariance, S, tol, f"f2v covariance edge {e}", scale_by="max")
 
 
+@pytest.mark.parametrize("d,children,mode", [(4, 5, "per_signal"), (3, 7, "wavefront"), (64, 5, "per_signal")])
+def test_a_d_dimensional_hub_through_the_plugin(hip_lib, d, children, mode):
+    """a state with `children` child states, everybody observed: the hub has degree children + 1 > 5, so the reference's default
+    resolver hangs its messages and its marginal off a segment tree of ProductOfMessages signals (src/dependencies.jl:90-173).  The host
+    mirror's scheduler drives all of them — the product nodes included — through cx_update_batch; the marginals are the joint solve's"""
+    rng = np.random.default_rng(17)
+    A = 0.9 * np.linalg.qr(rng.standard_normal((d, d)))[0]
+    Q, R = 0.2 * np.eye(d), np.eye(d)
+    n = children + 1
+    proc = cx.HipProcessor(mode=mode, dim=d)
+    graph = cx.BipartiteFactorGraph()
+    x = [graph.add_variable(cx.Variable(name="x", index=(i,))) for i in range(1, n + 1)]
+    y = [graph.add_variable(cx.Variable(name="y", index=(i,))) for i in range(1, n + 1)]
+    lik_form, tr_form = cx.MvGaussianLinear(np.eye(d), R), cx.MvGaussianLinear(A, Q)
+    lik = [graph.add_factor(cx.Factor(functional_form=lik_form)) for _ in range(n)]
+    tr = [graph.add_factor(cx.Factor(functional_form=tr_form)) for _ in range(children)]
+    for i in range(n):
+        graph.add_edge(y[i], lik[i], cx.Connection(label="out"))
+        graph.add_edge(x[i], lik[i], cx.Connection(label="in"))
+    for c in range(children):
+        graph.add_edge(x[0], tr[c], cx.Connection(label="in"))
+        graph.add_edge(x[c + 1], tr[c], cx.Connection(label="out"))
+    engine = cx.InferenceEngine(model_engine=graph, dependency_resolver=cx.DefaultDependencyResolver(), inference_request_processor=proc, trace=True)
+    data = rng.standard_normal((n, d))
+    for i in range(n):
+        proc.set_value(engine.get_connection_message_to_factor(y[i], lik[i]), data[i])
+    update_marginals(engine, x)
+    assert any(isinstance(v, V.ProductOfMessages) for v in proc.execution_log), "the segment tree's nodes were processed on the device"
+    vals = [get_value(get_variable_marginal(engine.get_variable(v))) for v in x]
+    # joint solve
+    Qi, Ri = np.linalg.inv(Q), np.linalg.inv(R)
+    J = np.zeros((n * d, n * d)); hv = np.zeros(n * d)
+    for i in range(n):
+        J[i*d:(i+1)*d, i*d:(i+1)*d] += Ri; hv[i*d:(i+1)*d] += Ri @ data[i]
+    for c in range(1, n):
+        P, C = slice(0, d), slice(c * d, (c + 1) * d)
+        J[P, P] += A.T @ Qi @ A; J[C, C] += Qi; J[P, C] -= A.T @ Qi; J[C, P] -= Qi @ A
+    S = np.linalg.inv(J); mean = (S @ hv).reshape(n, d)
+    assert_close(np.stack([v.mean for v in vals]), mean, 1e-8, f"d={d} {mode}: marginal means vs the joint solve", scale_by="max")
+    assert_close(np.stack([v.covariance for v in vals]), np.stack([S[i*d:(i+1)*d, i*d:(i+1)*d] for i in range(n)]), 1e-8,
+                 f"d={d} {mode}: marginal covariances vs the joint solve", scale_by="max")
+    # a product node reads back as the product of its range
+    node = next(v for v in proc.execution_log if isinstance(v, V.ProductOfMessages))
+    got = proc.read(node)
+    assert got.mean.shape == (d,) and np.all(np.isfinite(got.covariance))
+
+
 def test_d_dimensional_batch_errors(hip_lib):
     d = 4
     model = cx.synth.lgssm_chain(5, d=d, seed=2)
     dev = cx.DeviceGraph(dim=d)
     cx.synth.load_into_device(model, dev)
     L = cx._lib
-    with pytest.raises(cx.CortexHipError) as e:        # a ProductOfMessages item has no dim > 1 form
-        dev.update_batch([L.ITEM_PRODUCT_OF_MESSAGES], [int(model.x_ids[0])], [L.item_range(1, 2)])
+    with pytest.raises(cx.CortexHipError) as e:        # a JointMarginal item has no dim > 1 form (ProductOfMessages has one: tests/test_gpu_mv.py)
+        dev.update_batch([L.ITEM_JOINT_MARGINAL], [0], [int(model.factor_ids[-1])])
     assert e.value.code == L.ERR_UNSUPPORTED
+    with pytest.raises(cx.CortexHipError) as e:        # a range beyond the variable's degree
+        dev.update_batch([L.ITEM_PRODUCT_OF_MESSAGES], [int(model.x_ids[0])], [L.item_range(1, 3)])
+    assert e.value.code == L.ERR_INVALID_ARGUMENT
     with pytest.raises(cx.CortexHipError) as e:
         dev.update_batch([L.ITEM_MESSAGE_TO_VARIABLE], [int(model.x_ids[0])], [int(model.factor_ids[-1]) + 99])
     assert e.value.code == L.ERR_NOT_FOUND

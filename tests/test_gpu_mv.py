@@ -493,3 +493,34 @@ def test_dimensions_between_4_and_64_run_embedded_in_the_mfma_path(hip_lib, d):
     dev.set_messages([g.edge_var[e0]], [g.edge_fac[e0]], L.TO_VARIABLE, L.FORM_NATURAL, nat)
     back = dev.get_messages([g.edge_var[e0]], [g.edge_fac[e0]], L.TO_VARIABLE, L.FORM_NATURAL)
     assert np.array_equal(nat, back)
+
+
+@pytest.mark.parametrize("d,b", [(3, 5), (4, 6), (64, 5), (6, 4)])
+def test_product_of_messages_items_for_variables_of_degree_above_five(hip_lib, d, b):
+    """the reference's default resolver hangs the marginal of a variable of degree > 5 off a segment tree of ProductOfMessages signals
+    (src/dependencies.jl:90-173; inference_signal.jl:62-66): for dim > 1 — degrees up to 8 — cx_update_batch takes those items too and
+    cx_get_products reads them back: the product of messages lo..hi of the variable, i.e. the sum of their natural parameters"""
+    n = 1 + b + 2
+    model, _, _ = _branching_lgssm(n, d, seed=33, b=b, solve=False)
+    dev = _dev(model)
+    dev.sweep(6)                                       # a few flooding sweeps: every message defined
+    root = int(model.x_ids[0])                         # degree b + 1 (children + likelihood)
+    ev, ef = model.edge_var, model.edge_fac
+    facs = np.sort(ef[ev == root])                     # ascending factor id: the order the ranges are resolved over
+    deg = len(facs)
+    assert deg == b + 1 >= 5
+    ranges = [(1, deg // 2), (deg // 2 + 1, deg), (1, deg), (2, 2)]
+    kinds = [L.ITEM_PRODUCT_OF_MESSAGES] * len(ranges)
+    dev.update_batch(kinds, [root] * len(ranges), [L.item_range(lo, hi) for lo, hi in ranges])
+    nat = dev.get_messages(np.full(deg, root), facs, L.TO_VARIABLE, L.FORM_NATURAL)
+    got = dev.get_products([root] * len(ranges), [lo for lo, _ in ranges], [hi for _, hi in ranges], L.FORM_NATURAL)
+    for (lo, hi), row in zip(ranges, got):
+        assert_close(row, nat[lo - 1:hi].sum(axis=0), 1e-12, f"d={d}: ProductOfMessages {lo}:{hi} == the sum of the natural parameters")
+    # moment form, and a node nobody computed reads as UndefValue()
+    mom = dev.get_products([root, root], [1, 1], [deg, 1], L.FORM_MOMENT)
+    tot = nat.sum(axis=0)
+    cov = np.linalg.inv(tot[d:].reshape(d, d))
+    assert_close(mom[0, :d], cov @ tot[:d], 1e-9, "moment form: mean")
+    assert np.all(np.isnan(mom[1]))
+    with pytest.raises(cx.CortexHipError, match="outside 1:"):
+        dev.update_batch([L.ITEM_PRODUCT_OF_MESSAGES], [root], [L.item_range(1, deg + 1)])
