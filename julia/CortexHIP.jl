@@ -70,7 +70,7 @@ function set_datum!(p::HipProcessor, signal::Cortex.InferenceSignal, datum)
 end
 
 # batched mode: collect like InferenceRequestScanner (inference_engine.jl:528-537), compute on flush.
-# Every dim takes MessageToVariable / MessageToFactor / IndividualMarginal items; ProductOfMessages and JointMarginal are dim == 1.
+# Every dim takes MessageToVariable / MessageToFactor / IndividualMarginal / ProductOfMessages items; JointMarginal is dim == 1.
 function Cortex.process!(p::HipProcessor, engine::Cortex.InferenceEngine, variable_id, signal::Cortex.InferenceSignal)
     v = Cortex.get_variant(signal)
     item = v isa Cortex.InferenceSignalVariants.MessageToVariable ? CxItem(2, 0, v.variable_id, v.factor_id) :
