@@ -882,7 +882,7 @@ __global__ __launch_bounds__(kBlock) void k_mvc_side_links(int nlinks, int npos,
             }
         } else {                                            // beyond the buffer: nobody else is sure to cover this position
             a = mvc_side_sum<D>(pos_var[p], skip0[p], skip1[p], vbase, vinfo, f2v);
-            if (skip0[p] < 0) msg_store<D>(side, npos, p, a);
+            if (skip0[p] < 0 || skip1[p] < 0) msg_store<D>(side, npos, p, a);      // an end of a path (the heavy-path plan keeps a head's next slot in skip0, -1 in skip1)
         }
         if (q + 1 >= span && skip1[p + 1] < 0)              // ... nor the last position of a path that ends out there
             msg_store<D>(side, npos, p + 1, mvc_side_sum<D>(pos_var[p + 1], skip0[p + 1], skip1[p + 1], vbase, vinfo, f2v));

@@ -45,8 +45,11 @@ struct Rooted {
     int64_t n_components = 0;
 };
 
+// at_end: root every component at an END of its longest path instead of its centre — the level schedule wants the centre (half the
+// depth: half the stages), the heavy-path schedule the end: the longest path is then ONE heavy path from the root instead of two halves
+// on two light depths (a chain: one scan per direction instead of two)
 template <class H>
-int32_t root_forest(const H *h, Rooted &R, std::string &err) {
+int32_t root_forest(const H *h, Rooted &R, std::string &err, bool at_end = false) {
     const int64_t nv = h->nv, nf = h->nf, ne = h->ne;
     R = Rooted();
     auto &efac = R.efac; auto &foff = R.foff; auto &fedge = R.fedge; auto &level = R.level; auto &parent_edge = R.parent_edge; auto &members = R.members;
@@ -117,7 +120,7 @@ int32_t root_forest(const H *h, Rooted &R, std::string &err) {
         const int32_t b = bfs(a, cycle);
         // walk back from b half of the distance; the root is a variable (step one further when the middle is a factor)
         int32_t c = b;
-        for (int32_t s = 0; s < tmp_level[b] / 2; s++) {
+        for (int32_t s = 0; s < (at_end ? 0 : tmp_level[b] / 2); s++) {
             const int32_t e = tmp_parent[c];
             c = c < nv ? (int32_t)nv + efac[e] : h->edge_var[e];
         }
@@ -238,7 +241,7 @@ int32_t build_hp(const H *h, HP &out, std::string &err) {
     const int64_t nv = h->nv;
     out = HP();
     Rooted R;
-    { const int32_t rc = root_forest(h, R, err); if (rc != CX_OK) return rc; }
+    { const int32_t rc = root_forest(h, R, err, true); if (rc != CX_OK) return rc; }
     const auto &efac = R.efac; const auto &foff = R.foff; const auto &fedge = R.fedge; const auto &level = R.level; const auto &parent_edge = R.parent_edge;
     const auto &members = R.members; const auto &ffree = R.ffree;
     out.depth = R.depth; out.n_components = R.n_components;

@@ -426,7 +426,7 @@ int32_t cx_tree_plan_stats(const cx_handle *h, int64_t *out8);
  * other variables, is a pairwise rule between the two: formed on the device before the depth's first scan); the paths of one light
  * depth (light edges above them) are ONE segmented scan per direction, whatever their length, the light edges stay items: O(log n)
  * rounds of launches instead of 2 x depth + 1 (a chain of T states with a latent layer below each: ~ 25 launches instead of ~ 2 T; a
- * tree of 1.1 M edges and 144,559 levels: 45).  The same messages, every marginal exact.
+ * tree of 1.1 M edges and 144,559 levels: 32).  The same messages, every marginal exact.
  * out4 = { light depths, paths of two or more variables, variables on no such path, launches per sweep }; zeros when the level
  * schedule is in use (then cx_tree_plan_stats's "stages" are its launches).  With heavy paths "stages" / "items" count the item stages. */
 int32_t cx_tree_heavy_path_stats(const cx_handle *h, int64_t *out4);
