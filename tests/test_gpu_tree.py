@@ -436,7 +436,7 @@ def test_d_dimensional_chain_is_a_tree_too(hip_lib):
     tree = cx.DeviceGraph(dim=4, schedule=L.SCHED_TREE)
     cx.synth.load_into_device(m, tree)
     tree.sweep(1)
-    assert 0 < tree.tree_heavy_path_stats()["launches"] <= 20      # rooted in the middle: one half is the root's heavy path, the other starts one light edge down
+    assert 0 < tree.tree_heavy_path_stats()["launches"] <= 8       # the heavy-path plan roots a chain at one of its ends: ONE path, one final scan
     scan = cx.DeviceGraph(dim=4, schedule=L.SCHED_CHAIN_SCAN)
     cx.synth.load_into_device(m, scan)
     scan.sweep(1)
