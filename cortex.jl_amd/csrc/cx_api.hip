@@ -36,7 +36,7 @@ void dev_free_all(cx_handle *h) {
     if (h->d_joint) (void)hipFree(h->d_joint);
     h->d_prod = nullptr; h->d_joint = nullptr; h->prod_cap = h->joint_cap = 0; h->prod_index.clear(); h->joint_index.clear();
     h->d_point64_slots = h->d_rule64_rec = nullptr; h->work64_dirty = h->point64_dirty = true;
-    h->d_spdir = nullptr; h->d_ptab = nullptr; h->d_ptab_bt = nullptr; h->d_zero_msg = nullptr; h->d_mv_f2v = h->d_mv_f2v_alt = h->d_mv_v2f = h->d_mv_marg = h->d_mv_prev = nullptr; h->d_mv_prod = nullptr; h->mv_prod_cap = 0; h->ptab_sets = 0;
+    h->d_spdir = nullptr; h->d_ptab = nullptr; h->d_ptab_bt = nullptr; h->d_zero_msg = nullptr; h->d_mv_f2v = h->d_mv_f2v_alt = h->d_mv_v2f = h->d_mv_marg = h->d_mv_prev = nullptr; h->d_mv_prod = nullptr; h->mv_prod_cap = 0; h->ptab_sets = 0; h->ptab_bt_sets = 0;
     h->d_chain_pos_var = h->d_chain_skip0 = h->d_chain_skip1 = h->d_chain_link_pos = h->d_chain_from = h->d_chain_to = nullptr;
     h->d_chain_head_fwd = h->d_chain_head_bwd = nullptr; h->d_chain_side = nullptr; h->d_chain_totals = nullptr; h->chains_dirty = true; h->tree_dirty = true;
     h->d_chain_tab_fwd = h->d_chain_tab_bwd = nullptr; h->d_mvc_side = h->d_mvc_totals = nullptr; h->d_mvc_side_l = h->d_mvc_alpha = h->d_mvc_gamma = h->d_mvc_prefix = h->d_mvc_wave_carry = h->d_mvc_block = nullptr;
@@ -168,7 +168,10 @@ static int32_t upload_ptab(cx_handle *h) {
             return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_set_factor_matrices: Q of parameter set " + std::to_string(i) + " is not positive definite");
     }
     CX_HIP(h, hipStreamSynchronize(h->stream));
-    if (h->d_ptab && h->ptab_sets < nsets) { (void)hipFree(h->d_ptab); h->d_ptab = nullptr; }
+    // The tree schedule's stages are captured into a HIP graph with the table pointers baked in by value (cx_api_sweep.hip:
+    // tree_sweep): the tables are rewritten IN PLACE while their size holds, and a graph captured over a table that has to move is
+    // dropped before the old allocation goes (the next sweep captures again).
+    if (h->d_ptab && h->ptab_sets < nsets) { tree_graph_drop(h); (void)hipFree(h->d_ptab); h->d_ptab = nullptr; }
     if (!h->d_ptab) { int32_t rc = dev_alloc(h, &h->d_ptab, (int64_t)(per * nsets)); if (rc != CX_OK) return rc; h->ptab_sets = nsets; }
     CX_HIP(h, hipMemcpy(h->d_ptab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
     h->pot64_fresh = false;
@@ -184,9 +187,12 @@ static int32_t upload_ptab(cx_handle *h) {
             if (rc0 != CX_OK) return rc0;
             CX_HIP(h, hipMemset(h->d_zero_msg, 0, (size_t)(d + d * d) * 8));
         }
-        if (h->d_ptab_bt) { (void)hipFree(h->d_ptab_bt); h->d_ptab_bt = nullptr; }
-        int32_t rc = dev_alloc(h, &h->d_ptab_bt, (int64_t)bt.size());
-        if (rc != CX_OK) return rc;
+        if (h->d_ptab_bt && h->ptab_bt_sets < nsets) { tree_graph_drop(h); (void)hipFree(h->d_ptab_bt); h->d_ptab_bt = nullptr; }
+        if (!h->d_ptab_bt) {
+            int32_t rc = dev_alloc(h, &h->d_ptab_bt, (int64_t)bt.size());
+            if (rc != CX_OK) return rc;
+            h->ptab_bt_sets = nsets;
+        }
         CX_HIP(h, hipMemcpy(h->d_ptab_bt, bt.data(), bt.size() * 8, hipMemcpyHostToDevice));
     }
     return CX_OK;

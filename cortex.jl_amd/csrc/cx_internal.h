@@ -93,7 +93,7 @@ struct cx_handle {
     double *d_ptab = nullptr;                      // [2*npsets][3][d*d]: (P, B, C) triples
     double *d_zero_msg = nullptr;                  // d = 64: one message of zeros (what an absent source reads)
     double *d_ptab_bt = nullptr;                   // d = 64: [2*npsets][d*d], the transposes of the B tables (cx_mv64w.hip)
-    int64_t ptab_sets = 0, max_pset = -1;
+    int64_t ptab_sets = 0, ptab_bt_sets = 0, max_pset = -1;     // parameter sets the device tables have room for (rewritten in place while that holds)
     double *d_mv_f2v = nullptr, *d_mv_f2v_alt = nullptr, *d_mv_v2f = nullptr, *d_mv_marg = nullptr, *d_mv_prev = nullptr;
     // d = 64 work lists (built lazily: they depend on which variables are observed)
     bool work64_dirty = true, point64_dirty = true;

@@ -7,7 +7,9 @@ Modes:
                 execution order, one launch per message (schedule parity; slow by construction).
   "wavefront"   update_marginals! takes the call over: scan the currently pending signals
                 (scan_inference_request, inference_engine.jl:540-546), compute the whole wavefront in ONE launch,
-                set_value! them in scan order, repeat.  Same results on trees, O(depth) launches.
+                set_value! them in scan order, repeat.  Same results on trees, O(depth) launches.  A request whose
+                dependency graph has a cycle (a loopy factor graph) is handed back to the host scheduler and runs per
+                signal: a wavefront there would be a Jacobi step the reference never takes.
   "sweep"       update_marginals! runs `n_sweeps` passes of the device schedule over the whole graph (cx_sweep) and
                 marks the requested marginals computed.  The benchmarked path.
 """
@@ -119,10 +121,47 @@ def request_scope(request):
     return scope
 
 
+def request_has_cycle(request) -> bool:
+    """Does the dependency graph a request can reach hold a directed cycle?  Followed through EVERY dependency (a pending signal's
+    inputs are recomputed by the scheduler whether or not the edge is flagged intermediate, once they become pending themselves).
+    With the default resolver's wiring (dependencies.jl:17-126) this is exactly "the factor graph has a loop": a variable→factor
+    message depends on the other factor→variable messages of its variable, those on the other variable→factor messages of their
+    factor, and so on around the loop.  Iterative three-colour depth-first search, O(signals + dependencies)."""
+    colour = {}
+    for root in request.marginals:
+        if id(root) in colour:
+            continue
+        colour[id(root)] = 1
+        stack = [(root, 0)]
+        while stack:
+            node, i = stack[-1]
+            deps = node.dependencies
+            if i == len(deps):
+                colour[id(node)] = 2
+                stack.pop()
+                continue
+            stack[-1] = (node, i + 1)
+            d = deps[i]
+            c = colour.get(id(d), 0)
+            if c == 1:
+                return True
+            if c == 0:
+                colour[id(d)] = 1
+                stack.append((d, 0))
+    return False
+
+
 def run_wavefronts(request, launch, stats: Optional[dict] = None):
     """The batched mode between per-signal dispatch and the whole-call takeover: `launch(front)` computes one set of mutually
     independent pending signals and set_value!s them (one device launch), repeated until nothing is pending, then the requested
     marginals.
+
+    ONLY for requests whose dependency graph is acyclic (trees; `request_has_cycle`).  There a pending signal's inputs are all fresh,
+    i.e. final for this call, so computing a whole frontier at once leaves what the reference's one-signal-at-a-time order leaves.
+    On a graph with a loop every signal of a frontier would read the values its neighbours held BEFORE the frontier — a Jacobi step —
+    where the reference's sequential pass (inference_engine.jl:575-608) reads the newest ones: a result the reference never computes.
+    HipProcessor.update_marginals therefore checks the request first and hands a cyclic one back to the host scheduler, which runs
+    it per signal in the reference's order (tests/test_gpu_loopy_plugin.py).
 
     The first frontier comes from a full scan of the request (scan_inference_request, inference_engine.jl:540-546: O(request)).
     After that a signal can only BECOME pending because one of its dependencies was just set — set_value! notifies exactly its
@@ -216,6 +255,8 @@ class HipProcessor(AbstractInferenceRequestProcessor):
         self._records: dict = {}
         self._record_owners: list = []
         self.execution_log: List[Any] = []   # variants in execution order (schedule-parity checks)
+        self._cycle_key, self._cycle = None, False
+        self.cyclic_requests = 0             # wavefront mode: calls handed back to the host scheduler because the request's graph has a loop
 
     # ---- build hook: flatten the bipartite graph through the reference's 7 accessors -------------------------
     def attach(self, engine: InferenceEngine):
@@ -355,7 +396,16 @@ class HipProcessor(AbstractInferenceRequestProcessor):
             for s in front:
                 _host_set_value(s, HipValue(self, s.variant))
 
-        run_wavefronts(request_inference_for(engine, ids), launch)
+        request = request_inference_for(engine, ids)
+        key = tuple(ids)
+        if self._cycle_key != key:                 # the wiring is fixed at construction: one search per distinct request
+            self._cycle_key, self._cycle = key, request_has_cycle(request)
+        if self._cycle:
+            # a loopy request: the generic scheduler runs it, one process! per signal in the reference's order (request_inference_for
+            # only flags potentially-pending signals, which the scheduler's own call repeats: handing back is free of side effects)
+            self.cyclic_requests += 1
+            return False
+        run_wavefronts(request, launch)
         return True
 
     def refresh_marginals(self, ids):

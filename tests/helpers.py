@@ -83,3 +83,25 @@ def random_loopy_model(seed, world, nv=60, extra=25):
                            prior_variance=rng.uniform(0.5, 2.0, nv))
     owner_map = rng.integers(0, world, nv)
     return whole, (lambda ids: owner_map[np.asarray(ids, np.int64) - 1])
+
+
+def mirror_engine_from_model(model, processor, trace=False):
+    """The host mirror's InferenceEngine (cortex.jl_amd: the reference's Signals, resolver and scheduler, which the host keeps) on the
+    graph of a scalar Model, ids as in the model (one dense 1-based id space shared by variables and factors)."""
+    import cortex.jl_amd as cx
+
+    n_nodes = int(max(model.edge_var.max(), model.factor_ids.max()))
+    is_var = np.zeros(n_nodes + 1, bool)
+    is_var[np.unique(model.edge_var)] = True
+    fvar = {int(f): (int(k), float(q)) for f, k, q in zip(model.factor_ids, model.factor_kind, np.asarray(model.factor_var).reshape(len(model.factor_ids), -1)[:, 0])}
+    graph = cx.BipartiteFactorGraph()
+    for i in range(1, n_nodes + 1):
+        if is_var[i]:
+            got = graph.add_variable(cx.Variable(name="x", index=(i,)))
+        else:
+            kind, q = fvar[i]
+            got = graph.add_factor(cx.Factor(functional_form=cx.GaussianAdditive(q) if kind == 1 else "prior"))
+        assert got == i, "ids must be dense for the mirrored BipartiteFactorGraph"
+    for v, f in zip(model.edge_var, model.edge_fac):
+        graph.add_edge(int(v), int(f), cx.Connection(label="out"))
+    return cx.InferenceEngine(model_engine=graph, inference_request_processor=processor, trace=trace)

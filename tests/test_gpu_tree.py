@@ -548,3 +548,44 @@ def test_dim_64_chain_under_the_tree_schedule_equals_the_chain_scan(hip_lib):
     cx.synth.load_into_device(m, scan)
     scan.sweep(1)
     assert_close(tree.get_marginals(m.x_ids), scan.get_marginals(m.x_ids), 1e-8, "tree schedule vs chain scan on a d = 64 chain", scale_by="max")
+
+
+@pytest.mark.parametrize("d,b,n,heavy", [(4, 3, 40, "0"), (4, 3, 40, "1"), (64, 2, 7, "0"), (64, 2, 9, "1"), (6, 2, 7, "0")])
+def test_new_rule_matrices_under_a_standing_tree_plan(hip_lib, monkeypatch, d, b, n, heavy):
+    """cx_set_factor_matrices between two sweeps of the tree schedule (the parameter-learning flow): the stages of a sweep are a captured
+    HIP graph with the rule tables' addresses baked in, so the tables are rewritten in place and a graph over a table that has to move
+    (one more parameter set) is dropped — the second sweep is the exact posterior under the NEW (A, Q), equal to a fresh handle's."""
+    import copy
+
+    from tests.test_gpu_mv import _branching_lgssm
+
+    monkeypatch.setenv("CX_TREE_HP", heavy)
+    model, emean, ecov = _branching_lgssm(n, d, seed=31, b=b)
+    rng = np.random.default_rng(7)
+    A_old = 0.7 * np.linalg.qr(rng.standard_normal((d, d)))[0]
+    old = copy.copy(model)
+    old.psets = {0: (A_old, 0.5 * np.eye(d)), 1: model.psets[1]}
+    dev = cx.DeviceGraph(dim=d, schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(old, dev)
+    dev.sweep(1)
+    stale = dev.get_marginals(model.x_ids)
+    assert not np.any(np.isnan(stale))
+    dev.set_factor_matrices(0, *model.psets[0])                     # same size: rewritten in place
+    dev.sweep(1)
+    fresh = cx.DeviceGraph(dim=d, schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(model, fresh)
+    fresh.sweep(1)
+    want = fresh.get_marginals(model.x_ids)
+    got = dev.get_marginals(model.x_ids)
+    assert np.max(np.abs(stale - want)) > 1e-3, "the two parameter sets must give different posteriors for this test to mean anything"
+    assert_close(got, want, 1e-10, "marginals after new matrices vs a fresh handle", scale_by="max")
+    assert_close(got[:, :d], emean, 1e-8, "marginal mean vs the joint solve", scale_by="max")
+    assert_close(got[:, d:].reshape(n, d, d), ecov, 1e-8, "marginal covariance vs the joint solve", scale_by="max")
+    dev.set_factor_matrices(2, np.eye(d), np.eye(d))                # one more set: the tables move, the captured graph goes
+    dev.set_factor_matrices(0, A_old, 0.5 * np.eye(d))
+    dev.sweep(1)
+    assert_close(dev.get_marginals(model.x_ids), stale, 1e-10, "back to the first parameters after the tables moved", scale_by="max")
+    dev.set_factor_matrices(0, *model.psets[0])
+    dev.sweep(2)
+    assert_close(dev.get_marginals(model.x_ids), want, 1e-10, "and to the second", scale_by="max")
+    dev.close(); fresh.close()
