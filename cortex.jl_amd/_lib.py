@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CORTEX_HIP_LIB", os.path.join(HERE, "libcortex_hip.so"))  # override: A/B builds of the same ABI
 
 # mirrors of the #defines in include/cortex_hip.h
-ABI_VERSION = 2
+ABI_VERSION = 3
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NOT_FOUND, ERR_UNSUPPORTED, ERR_STATE, ERR_DEVICE, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY = (
     -1, -2, -3, -4, -5, -6, -7)
@@ -21,7 +21,7 @@ FORM_MOMENT, FORM_POINT, FORM_NATURAL, FORM_MEAN_PRECISION, FORM_GAMMA = 0, 1, 2
 FACTOR_OPAQUE, FACTOR_GAUSS_ADDITIVE, FACTOR_GAUSS_LINEAR, FACTOR_NORMAL_PRECISION, FACTOR_BERNOULLI, FACTOR_GAUSS_LINEAR_N = 0, 1, 2, 3, 4, 5
 NPARAM = 4
 ROLE_OUT, ROLE_IN, ROLE_PRECISION = 0, 1, 2
-SCHED_FLOODING, SCHED_FUSED, SCHED_CHAIN_SCAN, SCHED_TREE = 0, 1, 2, 3
+SCHED_FLOODING, SCHED_FUSED, SCHED_CHAIN_SCAN, SCHED_TREE, SCHED_REFERENCE = 0, 1, 2, 3, 4
 FAMILY_GAUSSIAN, FAMILY_NATURAL2, FAMILY_VMP_MEAN_FIELD, FAMILY_VMP_STRUCTURED = 0, 1, 2, 3
 VMP_ALL_NORMAL, VMP_ALL_PRECISION = -1, -2
 KERNEL_VAR_TO_FACTOR, KERNEL_FACTOR_TO_VAR, KERNEL_FUSED, KERNEL_BATCH, KERNEL_BIG_VAR = 0, 1, 2, 3, 4
@@ -72,6 +72,9 @@ SIGNATURES = {
     "cx_get_products": (_i32, [_vp, _i64, _pi64, _pi32, _pi32, _i32, _pd]),
     "cx_get_joint_marginals": (_i32, [_vp, _i64, _pi64, _pd]),
     "cx_sweep": (_i32, [_vp, _i32]),
+    "cx_sweep_for": (_i32, [_vp, _i64, _pi64]),
+    "cx_ref_plan_stats": (_i32, [_vp, _pi64]),
+    "cx_ref_trace": (_i32, [_vp, _i64, C.POINTER(Item), _pi64]),
     "cx_residual": (_i32, [_vp, _pd]),
     "cx_message_health": (_i32, [_vp, _pi64]),
     "cx_halo_configure": (_i32, [_vp, _i64, _pi64, _pi64, _i64, _pi64, _pi64]),

@@ -26,6 +26,7 @@ void dev_free_all(cx_handle *h) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     h->d_tree_rec = h->d_tree_kary = nullptr; h->d_tree_skip1_down = nullptr; h->d_tree_a = h->d_tree_b = nullptr; h->d_pre64_slots = h->d_pre64_vars = h->d_tree_pre_slots = h->d_tree_pre_vars = nullptr; h->n_pre64 = 0; h->tree_hp = false; h->tree_dirty = true; h->d_partner16 = nullptr; h->d_mvc_var_link = nullptr; h->d_tree_stage_off = nullptr;
     tree_graph_drop(h); h->tree_graph_failed = false;
+    ref_free(h);
     cx::chain64_free(h);
     cx::chain64_tree_free(h);
     cx::kary_free(h);
@@ -99,10 +100,12 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
     if (is_vmp && config->dim != 1)
         return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: the variational families need dim == 1");
     if (config->family == CX_FAMILY_NATURAL2 && (config->dim != 1 || config->schedule == CX_SCHED_CHAIN_SCAN))
-        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: CX_FAMILY_NATURAL2 needs dim == 1 and the flooding or fused schedule");
+        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: CX_FAMILY_NATURAL2 needs dim == 1 and the flooding, fused, tree or reference schedule");
+    if (config->schedule == CX_SCHED_REFERENCE && (config->dim != 1 || is_vmp))
+        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: CX_SCHED_REFERENCE replays the reference's execution order for scalar messages (dim == 1, Gaussian or natural-pair family)");
     if (config->dim > 1 && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN && config->schedule != CX_SCHED_TREE)
         return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: dim > 1 runs the fused, the chain-scan and the tree schedule");
-    if (config->schedule != CX_SCHED_FLOODING && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN && config->schedule != CX_SCHED_TREE)
+    if (config->schedule != CX_SCHED_FLOODING && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN && config->schedule != CX_SCHED_TREE && config->schedule != CX_SCHED_REFERENCE)
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: unknown schedule");
     if (config->schedule == CX_SCHED_TREE && config->family == CX_FAMILY_VMP_MEAN_FIELD)
         return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: the mean-field family has no inner sweep to schedule (flooding, fused or chain-scan are accepted and ignored; "
@@ -315,6 +318,7 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
 #define CX_TRY2(x) do { int32_t rc2_ = (x); if (rc2_ != CX_OK) { dev_free_all(h); return rc2_; } } while (0)
         CX_HIP(h, hipStreamSynchronize(h->stream));
         if (h->n_kary) { if (h->slot_kary.empty()) h->slot_kary.assign(slots, -1); CX_TRY2(cx::kary_upload(h)); }
+        if (h->cfg.schedule == CX_SCHED_REFERENCE) CX_TRY2(ref_build(h));      // the default resolver's wiring + the shadow of the readiness state
         h->has_graph = true; h->offchain_marg_dirty = true;
         return CX_OK;
     } catch (const std::bad_alloc &) {

@@ -16,6 +16,7 @@ int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const
     CX_REQUIRE(h, !h || h->n_kary == 0, CX_ERR_UNSUPPORTED, "halo configuration: partitions are implemented for unary and pairwise factors (this graph has CX_FACTOR_GAUSS_LINEAR_N factors)");
     CX_NOT_VMP(h, "cx_halo_configure");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_configure: no graph");
+    CX_REQUIRE(h, h->cfg.schedule != CX_SCHED_REFERENCE, CX_ERR_UNSUPPORTED, "cx_halo_configure: the reference-order schedule is sequential by definition and is not partitioned");
     // dim 2..4 and 64 under the chain-scan schedule: the lists only name the stand-ins of a time block (cx_chain_block_maps exchanges maps,
     // not messages); every other dim > 1 partition uses state halos (cx_halo_configure_state)
     const bool mv_chain_block = ((h->cfg.dim >= 2 && h->cfg.dim <= 4) || h->cfg.dim == 64) && h->cfg.schedule == CX_SCHED_CHAIN_SCAN;
@@ -66,8 +67,8 @@ int32_t cx_halo_configure_state(cx_handle *h, int64_t n_send, const int64_t *sv,
     CX_REQUIRE(h, !h || h->n_kary == 0, CX_ERR_UNSUPPORTED, "halo configuration: partitions are implemented for unary and pairwise factors (this graph has CX_FACTOR_GAUSS_LINEAR_N factors)");
     CX_NOT_VMP(h, "cx_halo_configure_state");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_configure_state: no graph");
-    CX_REQUIRE(h, h->cfg.schedule != CX_SCHED_CHAIN_SCAN, CX_ERR_UNSUPPORTED,
-               "cx_halo_configure_state: fused / flooding schedules (a chain-scan partition exchanges block maps: cx_chain_block_maps)");
+    CX_REQUIRE(h, h->cfg.schedule != CX_SCHED_CHAIN_SCAN && h->cfg.schedule != CX_SCHED_REFERENCE, CX_ERR_UNSUPPORTED,
+               "cx_halo_configure_state: fused / flooding schedules (a chain-scan partition exchanges block maps: cx_chain_block_maps; the reference-order schedule is not partitioned)");
     CX_REQUIRE(h, n_send >= 0 && n_recv >= 0, CX_ERR_INVALID_ARGUMENT, "cx_halo_configure_state: negative count");
     CX_REQUIRE(h, (n_send == 0 || (sv && sf)) && (n_recv == 0 || (rv && rf)), CX_ERR_INVALID_ARGUMENT, "cx_halo_configure_state: null argument");
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_halo_configure_state: a cx_sweep_begin is still open");

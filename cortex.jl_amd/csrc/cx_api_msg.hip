@@ -90,6 +90,11 @@ int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
         }
         CX_HIP(h, hipGetLastError());
         CX_HIP(h, hipStreamSynchronize(h->stream));  // host staging vectors die here
+        if (h->ref) {      // CX_SCHED_REFERENCE: the user's set_value! on the shadow of the readiness state, in list order
+            std::vector<int64_t> edges((size_t)n);
+            for (int64_t i = 0; i < n; i++) edges[i] = find_edge(h, variable_ids[i], factor_ids[i]);
+            ref_on_set(h, n, edges.data(), direction);
+        }
         return CX_OK;
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_set_messages: host allocation failed"); }
 }
@@ -164,6 +169,7 @@ int32_t cx_seed_messages(cx_handle *h, int32_t direction, double mean, double va
         cx::launch_seed(h, h->d_v2f, h->nslots, v, h->d_partner);
     }
     CX_HIP(h, hipGetLastError());
+    try { ref_on_seed(h, direction); } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_seed_messages: host allocation failed"); }
     return CX_OK;
 }
 
@@ -222,6 +228,17 @@ static int32_t grow_store(cx_handle *h, T **buf, int64_t *cap, int64_t need, int
     *buf = nb; *cap = ncap;
     return CX_OK;
 }
+}  // extern "C++"
+
+extern "C++" {
+namespace cxh {
+int32_t ensure_prod_store(cx_handle *h) {
+    const double2 *before = h->d_prod;
+    const int32_t rc = grow_store(h, &h->d_prod, &h->prod_cap, (int64_t)h->prod_index.size(), 1);
+    if (before && h->d_prod != before) { tree_graph_drop(h); ref_graphs_drop(h); }      // captured launches hold the store's address by value
+    return rc;
+}
+}  // namespace cxh
 }  // extern "C++"
 
 // JointMarginal(factor): the two slots of a pairwise Gaussian factor, the OUT edge first (its per-slot parameters are the
@@ -302,7 +319,7 @@ static int32_t update_batch(cx_handle *h, const cx_item *items, int64_t n) {
             }
             buf[5 * i] = it.kind; buf[5 * i + 1] = (int32_t)idx; buf[5 * i + 2] = (int32_t)var; buf[5 * i + 3] = (int32_t)lo; buf[5 * i + 4] = (int32_t)hi;
         }
-        int32_t rc = grow_store(h, &h->d_prod, &h->prod_cap, (int64_t)h->prod_index.size(), 1);
+        int32_t rc = ensure_prod_store(h);
         if (rc != CX_OK) return rc;
         rc = grow_store(h, &h->d_joint, &h->joint_cap, (int64_t)h->joint_index.size(), 6);
         if (rc != CX_OK) return rc;
@@ -326,6 +343,7 @@ static int32_t update_batch(cx_handle *h, const cx_item *items, int64_t n) {
             std::memcpy(sb.r, buf.data(), (size_t)(5 * n) * 4);
             cx::launch_batch_small(h, sb, (int)n);
             CX_HIP(h, hipGetLastError());
+            ref_on_batch(h, items, n);
             return CX_OK;
         }
         rc = ensure_stage(h, 5 * n * 4);
@@ -334,6 +352,7 @@ static int32_t update_batch(cx_handle *h, const cx_item *items, int64_t n) {
         cx::launch_batch(h, (const int32_t *)h->d_stage, n);
         CX_HIP(h, hipGetLastError());
         CX_HIP(h, hipStreamSynchronize(h->stream));  // the staging buffer is the handle's: the next call may overwrite it
+        ref_on_batch(h, items, n);
         return CX_OK;
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_update_batch: host allocation failed"); }
 }

@@ -1,0 +1,342 @@
+// cx_api_ref.hip — CX_SCHED_REFERENCE: one cx_sweep / cx_sweep_for is ONE update_marginals! of the reference on any graph, loops
+// included (/root/reference/src/inference_engine.jl:559-632).  The order of a call is found on a shadow of the readiness state
+// (cx_refsched.h), levelled into stages of independent items, and replayed on the device as ONE graph launch; plans are kept per
+// (readiness state at the start of the call, request), so the steady state of an iteration — set the priors, call, set the priors,
+// call — replays a standing plan and costs the host a hash lookup.
+
+#include <memory>
+
+#include "cx_host.h"
+#include "cx_refsched.h"
+
+using namespace cxh;
+namespace rs = cx::refsched;
+
+namespace {
+
+struct PlanEntry {
+    uint64_t key = 0, req_key = 0;
+    int32_t *d_rec = nullptr, *d_list = nullptr;
+    int64_t *d_stage_off = nullptr;
+    std::vector<int64_t> stage_off;
+    hipGraphExec_t exec = nullptr;
+    bool graph_failed = false;
+    std::shared_ptr<const rs::State> post;      // the readiness state the call leaves
+    std::vector<int32_t> order;                 // the executions, in the reference's order (cx_ref_trace)
+    int64_t n_messages = 0, n_marginals = 0, n_products = 0, rounds = 0, launches = 0, list_entries = 0;
+    uint64_t last_used = 0;
+    int64_t device_bytes = 0;
+};
+
+struct RefSched {
+    rs::Wiring W;
+    std::shared_ptr<rs::State> S;               // copy-on-write: a cache hit adopts the entry's post state without copying it
+    std::vector<PlanEntry> cache;
+    std::vector<int32_t> prod_slot;             // segment-tree node -> index in the handle's product store
+    int64_t hits = 0, misses = 0;
+    uint64_t tick = 0;
+    int last = -1;
+    int max_entries = 4, run_max = 4096;
+};
+
+RefSched *ref_of(cx_handle *h) { return (RefSched *)h->ref; }
+
+void entry_free(cx_handle *h, PlanEntry &e) {
+    if (e.exec) { (void)hipGraphExecDestroy(e.exec); e.exec = nullptr; }
+    for (void *p : {(void *)e.d_rec, (void *)e.d_list, (void *)e.d_stage_off}) if (p) (void)hipFree(p);
+    e.d_rec = e.d_list = nullptr; e.d_stage_off = nullptr;
+    h->device_bytes -= e.device_bytes; e.device_bytes = 0;
+}
+
+rs::State &writable(RefSched *R) {
+    if (R->S.use_count() > 1) R->S = std::make_shared<rs::State>(*R->S);      // a cached plan still names this state as its result
+    return *R->S;
+}
+
+// the stages of a plan on the handle's stream: runs of stages of at most run_max items as ONE launch of one workgroup (a barrier
+// between the stages instead of a kernel boundary), the wide ones a launch each
+int64_t issue(cx_handle *h, RefSched *R, const PlanEntry &e, bool count_only) {
+    const size_t ns = e.stage_off.empty() ? 0 : e.stage_off.size() - 1;
+    int64_t launches = 0;
+    if (!count_only) h->d_ref_list = e.d_list;
+    for (size_t s = 0; s < ns;) {
+        size_t t = s;
+        while (t < ns && e.stage_off[t + 1] - e.stage_off[t] <= R->run_max) t++;
+        if (t >= s + 2) { if (!count_only) cx::launch_batch_run(h, e.d_rec, e.d_stage_off, (int)s, (int)t); launches++; s = t; continue; }
+        const int64_t n = e.stage_off[s + 1] - e.stage_off[s];
+        if (n > 0) { if (!count_only) cx::launch_batch(h, e.d_rec + 5 * e.stage_off[s], n); launches++; }
+        s++;
+    }
+    return launches;
+}
+
+void run_entry(cx_handle *h, RefSched *R, PlanEntry &e) {
+    static const bool graphs = [] { const char *v = std::getenv("CX_REF_GRAPH"); return !(v && v[0] == '0'); }();
+    if (graphs && !e.graph_failed && !h->profiling && !e.exec && e.launches > 1) {
+        hipError_t er = hipSuccess;
+        if (!h->tree_capture_stream) er = hipStreamCreateWithFlags(&h->tree_capture_stream, hipStreamNonBlocking);
+        hipGraph_t g = nullptr;
+        if (er == hipSuccess) er = hipStreamBeginCapture(h->tree_capture_stream, hipStreamCaptureModeThreadLocal);
+        if (er == hipSuccess) {
+            hipStream_t user = h->stream;
+            h->stream = h->tree_capture_stream;
+            (void)issue(h, R, e, false);
+            h->stream = user;
+            er = hipStreamEndCapture(h->tree_capture_stream, &g);
+        }
+        if (er == hipSuccess && g) er = hipGraphInstantiate(&e.exec, g, nullptr, nullptr, 0);
+        if (g) (void)hipGraphDestroy(g);
+        if (er != hipSuccess || !e.exec) { (void)hipGetLastError(); e.exec = nullptr; e.graph_failed = true; }
+    }
+    if (e.exec && !h->profiling) {
+        if (hipGraphLaunch(e.exec, h->stream) == hipSuccess) return;
+        (void)hipGetLastError();
+        (void)hipGraphExecDestroy(e.exec); e.exec = nullptr; e.graph_failed = true;
+    }
+    (void)issue(h, R, e, false);
+}
+
+}  // namespace
+
+namespace cxh {
+
+void ref_free(cx_handle *h) {
+    RefSched *R = ref_of(h);
+    if (!R) return;
+    for (auto &e : R->cache) entry_free(h, e);
+    delete R;
+    h->ref = nullptr; h->d_ref_list = nullptr;
+}
+
+// the captured graphs hold the product store's address by value: dropped when the store moves
+void ref_graphs_drop(cx_handle *h) {
+    RefSched *R = ref_of(h);
+    if (!R) return;
+    for (auto &e : R->cache) if (e.exec) { (void)hipGraphExecDestroy(e.exec); e.exec = nullptr; }
+}
+
+// the wiring and the shadow state, built with the graph (everything starts as UndefValue(): nothing computed, nothing fresh)
+int32_t ref_build(cx_handle *h) {
+    if (h->ref) return CX_OK;
+    std::unique_ptr<RefSched> R(new RefSched());
+    std::string err;
+    const int32_t rc = rs::build_wiring(h, R->W, err);
+    if (rc != CX_OK) return fail(h, rc, err);
+    R->S = std::make_shared<rs::State>();
+    rs::init_state(R->W, *R->S);
+    // the segment-tree nodes of the variables of degree > 5 live in the handle's product store, under the keys cx_update_batch's
+    // ProductOfMessages items and cx_get_products use
+    R->prod_slot.resize(R->W.prods.size());
+    for (size_t i = 0; i < R->W.prods.size(); i++) {
+        const auto &p = R->W.prods[i];
+        auto key = std::make_tuple(p.var, p.lo, p.hi);
+        auto it = h->prod_index.find(key);
+        if (it == h->prod_index.end()) it = h->prod_index.emplace(key, (int32_t)h->prod_index.size()).first;
+        R->prod_slot[i] = it->second;
+    }
+    { const int32_t rp = ensure_prod_store(h); if (rp != CX_OK) return rp; }
+    if (const char *v = std::getenv("CX_REF_CACHE")) R->max_entries = std::max(1, std::atoi(v));
+    if (const char *v = std::getenv("CX_REF_RUN_MAX")) R->run_max = std::max(0, std::atoi(v));
+    h->ref = R.release();
+    return CX_OK;
+}
+
+// set_value! of message signals through the ABI (cx_set_messages): edges as CSR indices
+void ref_on_set(cx_handle *h, int64_t n, const int64_t *edges, int32_t direction) {
+    RefSched *R = ref_of(h);
+    if (!R || n == 0) return;
+    rs::State &S = writable(R);
+    for (int64_t i = 0; i < n; i++) rs::set_value(R->W, S, direction == CX_TO_FACTOR ? R->W.sig_v2f(edges[i]) : R->W.sig_f2v(edges[i]));
+}
+
+// cx_seed_messages: every message of `direction` that a rule computes (its slot has a partner or sits in a factor of more edges) and
+// that is still undefined gets a value — the user's set_value! over those signals, in edge order
+void ref_on_seed(cx_handle *h, int32_t direction) {
+    RefSched *R = ref_of(h);
+    if (!R) return;
+    rs::State &S = writable(R);
+    for (int64_t e = 0; e < h->ne; e++) {
+        const int32_t slot = cx::slot_of_edge(h, e);
+        if (h->partner[slot] < 0 && (h->slot_kary.empty() || h->slot_kary[slot] < 0)) continue;
+        const int64_t s = direction == CX_TO_FACTOR ? R->W.sig_v2f(e) : R->W.sig_f2v(e);
+        if (!(S.flags[s] & rs::kComputed)) rs::set_value(R->W, S, s);
+    }
+}
+
+// cx_update_batch: a plug-in's process! of each item's signal (compute! = rule + set_value!, signal.jl:392-410)
+void ref_on_batch(cx_handle *h, const cx_item *items, int64_t n) {
+    RefSched *R = ref_of(h);
+    if (!R) return;
+    rs::State &S = writable(R);
+    for (int64_t i = 0; i < n; i++) {
+        const cx_item &it = items[i];
+        int64_t s = -1;
+        if (it.kind == CX_ITEM_MESSAGE_TO_FACTOR || it.kind == CX_ITEM_MESSAGE_TO_VARIABLE) {
+            const int64_t e = find_edge(h, it.variable_id, it.factor_id);
+            if (e >= 0) s = it.kind == CX_ITEM_MESSAGE_TO_FACTOR ? R->W.sig_v2f(e) : R->W.sig_f2v(e);
+        } else if (it.kind == CX_ITEM_INDIVIDUAL_MARGINAL) {
+            const int64_t v = find_var(h, it.variable_id);
+            if (v >= 0) s = R->W.sig_marg(v);
+        } else if (it.kind == CX_ITEM_PRODUCT_OF_MESSAGES) {
+            const int64_t v = find_var(h, it.variable_id);
+            if (v >= 0) s = rs::find_prod(R->W, (int32_t)v, (int32_t)((uint64_t)it.factor_id >> 32), (int32_t)((uint64_t)it.factor_id & 0xffffffffu));
+        }
+        if (s >= 0) rs::set_value(R->W, S, s);
+    }
+}
+
+// ONE update_marginals!(engine, request): req = local variable numbers in request order
+int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n) {
+    RefSched *R = ref_of(h);
+    CX_REQUIRE(h, R, CX_ERR_STATE, "reference schedule: no wiring (cx_graph_create builds it)");
+    uint64_t rk = rs::mix64((uint64_t)n);
+    for (int64_t i = 0; i < n; i++) rk = rs::mix64(rk ^ (uint64_t)(uint32_t)req[i]);
+    const uint64_t key = R->S->hash;
+    int hit = -1;
+    for (size_t i = 0; i < R->cache.size(); i++) if (R->cache[i].key == key && R->cache[i].req_key == rk) { hit = (int)i; break; }
+    if (hit < 0) {
+        try {
+            // the scheduler runs on a copy: a call the device cannot replay leaves the shadow where it was
+            auto T = std::make_shared<rs::State>(*R->S);
+            rs::Call call;
+            const int32_t bad = rs::update_marginals(R->W, *T, req, n, call);
+            (void)bad;      // reported by level() with the message's ids
+            rs::Plan P;
+            std::string err;
+            const int32_t rc = rs::level(h, R->W, call, [&](int64_t i) { return R->prod_slot[i]; }, P, err);
+            if (rc != CX_OK) return fail(h, rc, err);
+            if ((int)R->cache.size() >= R->max_entries) {      // least recently used out
+                size_t lru = 0;
+                for (size_t i = 1; i < R->cache.size(); i++) if (R->cache[i].last_used < R->cache[lru].last_used) lru = i;
+                CX_HIP(h, hipStreamSynchronize(h->stream));
+                entry_free(h, R->cache[lru]);
+                R->cache.erase(R->cache.begin() + lru);
+            }
+            PlanEntry e;
+            e.key = key; e.req_key = rk;
+            e.stage_off = P.stage_off;
+            e.n_messages = P.n_messages; e.n_marginals = P.n_marginals; e.n_products = P.n_products; e.rounds = P.rounds; e.list_entries = (int64_t)P.list.size();
+            const int64_t before = h->device_bytes;
+            int32_t rc2;
+            if ((rc2 = dev_upload(h, &e.d_rec, P.rec)) != CX_OK || (rc2 = dev_upload(h, &e.d_list, P.list)) != CX_OK || (rc2 = dev_upload(h, &e.d_stage_off, P.stage_off)) != CX_OK) {
+                e.device_bytes = h->device_bytes - before; entry_free(h, e); return rc2;
+            }
+            e.device_bytes = h->device_bytes - before;
+            CX_HIP(h, hipStreamSynchronize(h->stream));      // the plan's host vectors die here
+            e.post = T;
+            e.order = std::move(call.order);
+            e.launches = issue(h, R, e, true);
+            R->cache.push_back(std::move(e));
+            hit = (int)R->cache.size() - 1;
+            R->misses++;
+        } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "reference schedule: host allocation failed"); }
+    } else R->hits++;
+    PlanEntry &e = R->cache[hit];
+    e.last_used = ++R->tick;
+    R->last = hit;
+    { const int32_t rc = cx::kary_upload(h); if (rc != CX_OK) return rc; }
+    run_entry(h, R, e);
+    CX_HIP(h, hipGetLastError());
+    R->S = std::const_pointer_cast<rs::State>(e.post);      // shared: the next writer copies
+    h->sweeps_done++;
+    h->v2f_stale = false;
+    return CX_OK;
+}
+
+// the request of a plain cx_sweep: every variable that is neither observed nor a stand-in, ascending id
+int32_t ref_sweep_all(cx_handle *h, int32_t n_sweeps) {
+    std::vector<int32_t> req;
+    for (int64_t v = 0; v < h->nv; v++) if (!(h->vinfo[v] & (cx::kClamped | cx::kGhost))) req.push_back((int32_t)v);
+    for (int32_t s = 0; s < n_sweeps; s++) { const int32_t rc = ref_sweep(h, req.data(), (int64_t)req.size()); if (rc != CX_OK) return rc; }
+    return CX_OK;
+}
+
+// checkpoint: the shadow as one host section (hash | flags | chunks)
+int64_t ref_state_bytes(cx_handle *h) {
+    RefSched *R = ref_of(h);
+    return R ? 8 + (int64_t)R->S->flags.size() + 8 * (int64_t)R->S->chunks.size() : 0;
+}
+void ref_state_write(cx_handle *h, char *out) {
+    RefSched *R = ref_of(h);
+    if (!R) return;
+    std::memcpy(out, &R->S->hash, 8);
+    std::memcpy(out + 8, R->S->flags.data(), R->S->flags.size());
+    std::memcpy(out + 8 + R->S->flags.size(), R->S->chunks.data(), 8 * R->S->chunks.size());
+}
+bool ref_state_read(cx_handle *h, const char *in, int64_t bytes) {
+    RefSched *R = ref_of(h);
+    if (!R || bytes != ref_state_bytes(h)) return false;
+    auto T = std::make_shared<rs::State>(*R->S);
+    std::memcpy(T->flags.data(), in + 8, T->flags.size());
+    std::memcpy(T->chunks.data(), in + 8 + T->flags.size(), 8 * T->chunks.size());
+    // the fingerprint is recomputed, not trusted
+    T->hash = 0;
+    for (int64_t c = 0; c < (int64_t)T->chunks.size(); c++) T->hash ^= rs::zob_chunk(c, T->chunks[c]);
+    for (int64_t s = 0; s < (int64_t)T->flags.size(); s++) T->hash ^= rs::zob_flag(s, T->flags[s]);
+    R->S = T;
+    return true;
+}
+
+}  // namespace cxh
+
+extern "C" {
+
+int32_t cx_sweep_for(cx_handle *h, int64_t n, const int64_t *variable_ids) {
+    CX_NOT_VMP(h, "cx_sweep_for");
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep_for: no graph");
+    CX_REQUIRE(h, h->cfg.schedule == CX_SCHED_REFERENCE, CX_ERR_UNSUPPORTED,
+               "cx_sweep_for: a request for some variables, in the caller's order, is served by CX_SCHED_REFERENCE (on a forest it computes exactly the "
+               "messages those marginals need, level by level); the other schedules compute every message: cx_sweep");
+    CX_REQUIRE(h, n >= 0 && (n == 0 || variable_ids), CX_ERR_INVALID_ARGUMENT, "cx_sweep_for: null argument");
+    try {
+        std::vector<int32_t> req((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t v = find_var(h, variable_ids[i]);
+            if (v < 0) return fail(h, CX_ERR_NOT_FOUND, "unknown variable id " + std::to_string(variable_ids[i]));
+            req[i] = (int32_t)v;
+        }
+        return ref_sweep(h, req.data(), n);
+    } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_sweep_for: host allocation failed"); }
+}
+
+int32_t cx_ref_plan_stats(const cx_handle *hc, int64_t *out8) {
+    cx_handle *h = const_cast<cx_handle *>(hc);
+    CX_REQUIRE(h, h && out8, CX_ERR_INVALID_ARGUMENT, "cx_ref_plan_stats: null argument");
+    for (int i = 0; i < 8; i++) out8[i] = 0;
+    RefSched *R = ref_of(h);
+    if (!R || R->last < 0 || R->last >= (int)R->cache.size()) return CX_OK;
+    const PlanEntry &e = R->cache[R->last];
+    out8[0] = e.stage_off.empty() ? 0 : (int64_t)e.stage_off.size() - 1; out8[1] = e.launches; out8[2] = (int64_t)e.order.size(); out8[3] = e.n_messages;
+    out8[4] = e.rounds; out8[5] = (int64_t)R->cache.size(); out8[6] = R->hits; out8[7] = R->misses;
+    return CX_OK;
+}
+
+int32_t cx_ref_trace(const cx_handle *hc, int64_t capacity, cx_item *out, int64_t *n_executions) {
+    cx_handle *h = const_cast<cx_handle *>(hc);
+    CX_REQUIRE(h, h && n_executions, CX_ERR_INVALID_ARGUMENT, "cx_ref_trace: null argument");
+    *n_executions = 0;
+    RefSched *R = ref_of(h);
+    if (!R || R->last < 0 || R->last >= (int)R->cache.size()) return CX_OK;
+    const PlanEntry &e = R->cache[R->last];
+    *n_executions = (int64_t)e.order.size();
+    if (!out) return CX_OK;
+    const int64_t ne = R->W.ne, nv = R->W.nv;
+    for (int64_t i = 0; i < std::min<int64_t>(capacity, (int64_t)e.order.size()); i++) {
+        const int64_t s = e.order[i];
+        cx_item it{};
+        if (s < 2 * ne) {
+            const int64_t ed = s < ne ? s : s - ne;
+            it.kind = s < ne ? CX_ITEM_MESSAGE_TO_FACTOR : CX_ITEM_MESSAGE_TO_VARIABLE;
+            it.variable_id = h->var_ids[h->edge_var[ed]]; it.factor_id = h->edge_fac_id[ed];
+        } else if (s < 2 * ne + nv) {
+            it.kind = CX_ITEM_INDIVIDUAL_MARGINAL; it.variable_id = h->var_ids[s - 2 * ne];
+        } else {
+            const auto &p = R->W.prods[s - 2 * ne - nv];
+            it.kind = CX_ITEM_PRODUCT_OF_MESSAGES; it.variable_id = h->var_ids[p.var]; it.factor_id = CX_ITEM_RANGE(p.lo, p.hi);
+        }
+        out[i] = it;
+    }
+    return CX_OK;
+}
+
+}  // extern "C"

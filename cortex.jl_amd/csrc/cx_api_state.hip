@@ -37,7 +37,7 @@ struct StateHeader {
     uint64_t fingerprint;
 };
 struct StateSection { int32_t id, reserved; int64_t bytes; };
-struct StatePart { int32_t id; void *dev; int64_t bytes; };
+struct StatePart { int32_t id; void *dev; int64_t bytes; };      // dev == nullptr: a host section (id 7: the reference schedule's readiness shadow)
 const char kStateMagic[8] = {'C', 'X', 'S', 'T', 'A', 'T', 'E', '2'};   // '2': the fingerprint covers rule parameters, v2f_stale is a bit-field
 const char kStateMagicV1[8] = {'C', 'X', 'S', 'T', 'A', 'T', 'E', '1'};
 
@@ -71,6 +71,10 @@ std::vector<StatePart> state_parts(cx_handle *h) {
         if (h->d_f2v_alt) parts.push_back({3, h->d_f2v_alt, slots * 16});
         parts.push_back({4, h->d_v2f, slots * 16});
         parts.push_back({5, h->d_marg, nv * 16});
+        if (h->ref) {      // CX_SCHED_REFERENCE: the segment-tree nodes are values the next call may read; the shadow decides what it computes
+            parts.push_back({6, h->d_prod, (int64_t)h->prod_index.size() * 16});
+            parts.push_back({7, nullptr, ref_state_bytes(h)});
+        }
     } else {
         const int64_t nc = h->nc, ncs = h->ncs;
         parts.push_back({2, h->d_mv_f2v, ncs * slots * 8});
@@ -118,7 +122,8 @@ int32_t cx_state_export(cx_handle *h, void *buf, int64_t bytes) {
     for (auto &p : parts) {
         StateSection sc{p.id, 0, p.bytes};
         std::memcpy(o, &sc, sizeof sc); o += sizeof sc;
-        if (p.bytes) CX_HIP(h, hipMemcpy(o, p.dev, (size_t)p.bytes, hipMemcpyDeviceToHost));
+        if (p.bytes && p.dev) CX_HIP(h, hipMemcpy(o, p.dev, (size_t)p.bytes, hipMemcpyDeviceToHost));
+        else if (p.bytes && p.id == 7) ref_state_write(h, o);
         o += p.bytes;
     }
     return CX_OK;
@@ -164,7 +169,8 @@ int32_t cx_state_import(cx_handle *h, const void *buf, int64_t bytes) {
     for (auto &p : parts) {
         o += sizeof(StateSection);
         if (p.id == 1) std::memcpy(h->vinfo.data(), o, (size_t)p.bytes);
-        if (p.bytes) CX_HIP(h, hipMemcpy(p.dev, o, (size_t)p.bytes, hipMemcpyHostToDevice));
+        if (p.bytes && p.dev) CX_HIP(h, hipMemcpy(p.dev, o, (size_t)p.bytes, hipMemcpyHostToDevice));
+        else if (p.bytes && p.id == 7) CX_REQUIRE(h, ref_state_read(h, o, p.bytes), CX_ERR_INVALID_ARGUMENT, "cx_state_import: the readiness section does not fit this handle's wiring");
         o += p.bytes;
     }
     h->sweeps_done = hd.sweeps_done;

@@ -559,6 +559,10 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
                "cx_sweep: this handle holds a partition (halo configured): use cx_sweep_begin / _main / _end");
     if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) { int32_t rc = build_chains(h); if (rc != CX_OK) return rc; }
     { int32_t rc = cx::kary_upload(h); if (rc != CX_OK) return rc; }      // coefficients set since the last sweep
+    if (h->cfg.schedule == CX_SCHED_REFERENCE) {
+        CX_REQUIRE(h, h->recv_slots.empty() && h->send_slots.empty(), CX_ERR_UNSUPPORTED, "cx_sweep: the reference-order schedule is not partitioned");
+        return ref_sweep_all(h, n_sweeps);
+    }
     if (h->cfg.schedule == CX_SCHED_TREE) {
         CX_REQUIRE(h, h->recv_slots.empty() && h->send_slots.empty(), CX_ERR_UNSUPPORTED, "cx_sweep: the tree schedule is not partitioned in this build");
         int32_t rc = build_tree(h);
@@ -632,7 +636,7 @@ int32_t cx_sweep_begin(cx_handle *h) {
     CX_REQUIRE(h, h->cfg.dim == 1, CX_ERR_UNSUPPORTED, "cx_sweep_begin: partitioned sweeps are implemented for dim == 1 only in this build");
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_sweep_begin: previous sweep not ended");
     CX_REQUIRE(h, !h->halo_state, CX_ERR_STATE, "cx_sweep_begin: the handle is configured for state halos (cx_halo_configure_state): use cx_sweep + cx_halo_state_exchange");
-    CX_REQUIRE(h, h->cfg.schedule != CX_SCHED_CHAIN_SCAN && h->cfg.schedule != CX_SCHED_TREE, CX_ERR_UNSUPPORTED, "cx_sweep_begin: the chain-scan and tree schedules are not partitioned in this build");
+    CX_REQUIRE(h, h->cfg.schedule != CX_SCHED_CHAIN_SCAN && h->cfg.schedule != CX_SCHED_TREE && h->cfg.schedule != CX_SCHED_REFERENCE, CX_ERR_UNSUPPORTED, "cx_sweep_begin: the chain-scan, tree and reference-order schedules are not partitioned in this build");
     cx::launch_halo_export(h, h->d_f2v, h->stream);
     CX_HIP(h, hipGetLastError());
     h->in_sweep = true;

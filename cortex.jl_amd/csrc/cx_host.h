@@ -152,5 +152,19 @@ void tree_sweep(cx_handle *h);           // every stage of the plan on the handl
 void tree_graph_drop(cx_handle *h);        // CX_SCHED_TREE: the stages of cx_tree_plan.h on the device (rebuilt when the set of observed variables changed)
 void sweep_main(cx_handle *h, bool skip_ghosts);
 void sweep_finish(cx_handle *h);
+// ---- cx_api_msg.hip -------------------------------------------------------------------------------------------------
+int32_t ensure_prod_store(cx_handle *h);   // the product store holds every registered ProductOfMessages node (graphs that captured its address are dropped when it moves)
+// ---- cx_api_ref.hip: CX_SCHED_REFERENCE -----------------------------------------------------------------------------
+int32_t ref_build(cx_handle *h);
+void ref_free(cx_handle *h);
+void ref_graphs_drop(cx_handle *h);
+void ref_on_set(cx_handle *h, int64_t n, const int64_t *edges, int32_t direction);
+void ref_on_seed(cx_handle *h, int32_t direction);
+void ref_on_batch(cx_handle *h, const cx_item *items, int64_t n);
+int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n);
+int32_t ref_sweep_all(cx_handle *h, int32_t n_sweeps);
+int64_t ref_state_bytes(cx_handle *h);
+void ref_state_write(cx_handle *h, char *out);
+bool ref_state_read(cx_handle *h, const char *in, int64_t bytes);
 
 }  // namespace cxh

@@ -3,6 +3,7 @@
 // (tests/hostlogic.py).  The product does not link this file: the .hip translation units include the same headers.
 //
 //   cxh_plan64_*   the work plan of the chain-scan schedule for dim 64 (cx_chain64_plan.h)
+//   cxh_ref_*      CX_SCHED_REFERENCE: the default resolver's wiring, the shadow of the readiness state, the recorded and levelled calls (cx_refsched.h)
 //   cxh_flat_*     cx_graph_create's flattening (cx_flatten.h) and CX_SCHED_CHAIN_SCAN's chain decomposition (cx_chains.h) over a
 //                  plain struct with cx_handle's host fields
 #include <cstdio>
@@ -13,6 +14,7 @@
 #include "cx_chains.h"
 #include "cx_halo_plan.h"
 #include "cx_tree_plan.h"
+#include "cx_refsched.h"
 
 using cx::plan64::Plan;
 
@@ -98,6 +100,10 @@ struct HostGraph {                       // the host fields of cx_handle that cx
     cx::chains::Out co;
     cx::treeplan::Out to;
     cx::treeplan::HP hp;
+    cx::refsched::Wiring rw;
+    cx::refsched::State rs;
+    cx::refsched::Call rcall;
+    cx::refsched::Plan rplan;
     std::string err;
 };
 
@@ -155,6 +161,90 @@ int32_t cxh_flat_tree_hp(void *p, char *err, int32_t errlen) {
     return rc;
 }
 
+// ---- CX_SCHED_REFERENCE (cx_refsched.h) ----------------------------------------------------------------------------------------
+int32_t cxh_ref_build(void *p, char *err, int32_t errlen) {
+    HostGraph *g = (HostGraph *)p;
+    std::string e;
+    int32_t rc;
+    try { rc = cx::refsched::build_wiring(g, g->rw, e); if (rc == CX_OK) cx::refsched::init_state(g->rw, g->rs); }
+    catch (const std::exception &x) { rc = CX_ERR_INVALID_ARGUMENT; e = x.what(); }
+    if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", e.c_str());
+    return rc;
+}
+
+static int64_t href_edge(const HostGraph *g, int64_t var_id, int64_t fac_id) {
+    auto it = std::lower_bound(g->var_ids.begin(), g->var_ids.end(), var_id);
+    if (it == g->var_ids.end() || *it != var_id) return -1;
+    const int64_t v = it - g->var_ids.begin();
+    auto b = g->edge_fac_id.begin() + g->var_off[v], e = g->edge_fac_id.begin() + g->var_off[v + 1];
+    auto jt = std::lower_bound(b, e, fac_id);
+    return (jt == e || *jt != fac_id) ? -1 : (int64_t)(jt - g->edge_fac_id.begin());
+}
+
+// set_value! on message signals: direction CX_TO_FACTOR / CX_TO_VARIABLE
+int32_t cxh_ref_set(void *p, int32_t direction, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids) {
+    HostGraph *g = (HostGraph *)p;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t e = href_edge(g, variable_ids[i], factor_ids[i]);
+        if (e < 0) return CX_ERR_NOT_FOUND;
+        cx::refsched::set_value(g->rw, g->rs, direction == CX_TO_FACTOR ? g->rw.sig_v2f(e) : g->rw.sig_f2v(e));
+    }
+    return CX_OK;
+}
+
+// one update_marginals!(ids) on the shadow; returns the number of executions (or a negative status), leaves the call for cxh_ref_trace / cxh_ref_level
+int64_t cxh_ref_update(void *p, int64_t n, const int64_t *variable_ids) {
+    HostGraph *g = (HostGraph *)p;
+    std::vector<int32_t> req((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        auto it = std::lower_bound(g->var_ids.begin(), g->var_ids.end(), variable_ids[i]);
+        if (it == g->var_ids.end() || *it != variable_ids[i]) return CX_ERR_NOT_FOUND;
+        req[i] = (int32_t)(it - g->var_ids.begin());
+    }
+    (void)cx::refsched::update_marginals(g->rw, g->rs, req.data(), n, g->rcall);
+    return (int64_t)g->rcall.order.size();
+}
+
+// the executions of the last call as rows {kind (CX_ITEM_*), variable id, factor id, range lo, range hi, round}
+void cxh_ref_trace(const void *p, int64_t *out6) {
+    const HostGraph *g = (const HostGraph *)p;
+    const auto &W = g->rw;
+    for (size_t i = 0; i < g->rcall.order.size(); i++) {
+        const int64_t s = g->rcall.order[i];
+        int64_t *o = out6 + 6 * i;
+        o[0] = o[1] = o[2] = o[3] = o[4] = 0; o[5] = g->rcall.round_of[i];
+        if (s < 2 * W.ne) {
+            const int64_t e = s < W.ne ? s : s - W.ne;
+            o[0] = s < W.ne ? CX_ITEM_MESSAGE_TO_FACTOR : CX_ITEM_MESSAGE_TO_VARIABLE; o[1] = g->var_ids[g->edge_var[e]]; o[2] = g->edge_fac_id[e];
+        } else if (s < 2 * W.ne + W.nv) { o[0] = CX_ITEM_INDIVIDUAL_MARGINAL; o[1] = g->var_ids[s - 2 * W.ne]; }
+        else { const auto &pr = W.prods[s - 2 * W.ne - W.nv]; o[0] = CX_ITEM_PRODUCT_OF_MESSAGES; o[1] = g->var_ids[pr.var]; o[3] = pr.lo; o[4] = pr.hi; }
+    }
+}
+
+// the last call levelled into stages of device items (segment-tree node i lives at index i of the product store)
+int32_t cxh_ref_level(void *p, char *err, int32_t errlen) {
+    HostGraph *g = (HostGraph *)p;
+    std::string e;
+    int32_t rc;
+    try { rc = cx::refsched::level(g, g->rw, g->rcall, [](int64_t i) { return i; }, g->rplan, e); }
+    catch (const std::exception &x) { rc = CX_ERR_INVALID_ARGUMENT; e = x.what(); }
+    if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", e.c_str());
+    return rc;
+}
+
+// what: 0 signals 1 dependencies 2 segment-tree nodes 3 state fingerprint (low 63 bits) 4 passes of the last call
+int64_t cxh_ref_scalar(const void *p, int32_t what) {
+    const HostGraph *g = (const HostGraph *)p;
+    switch (what) {
+    case 0: return g->rw.nsig;
+    case 1: return (int64_t)g->rw.dep.size();
+    case 2: return (int64_t)g->rw.prods.size();
+    case 3: return (int64_t)(g->rs.hash & 0x7fffffffffffffffull);
+    case 4: return g->rcall.rounds;
+    }
+    return -1;
+}
+
 // deep halo: layers by variable id (others 0), then the send list as slots; fills trim_lo / trim_hi / own and quiet runs
 int32_t cxh_flat_halo(void *p, int64_t n, const int64_t *variable_ids, const int32_t *layer, int32_t depth, int64_t n_send, const int32_t *send_slots) {
     HostGraph *g = (HostGraph *)p;
@@ -176,6 +266,7 @@ int32_t cxh_flat_halo(void *p, int64_t n, const int64_t *variable_ids, const int
 //   60 tree items (5 per item) 61 tree stage offsets 62 tree k-ary entries 63 their stage offsets 64 partner 65 slot_kary 66 kary_slot
 //   70.. heavy-path plan: 70 items 71 stage offsets 72 k-ary entries 73 their offsets 74 pos_var 75 skip0 76 skip1_up 77 skip1_down 78 link_pos 79 from 80 to
 //        81 head_fwd 82 head_bwd 83 pos_off 84 link_off 85 steps
+//   90 reference plan items (5 per item) 91 its stage offsets 92 its source lists 93 dep_off 94 dep 95 intermediate flags 96 signal flags 97 the last call's executions (signal numbers)
 //   40 pos_var 41 skip0 42 skip1 43 link_pos 44 from 45 to 46 head_fwd 47 head_bwd 48 tab_fwd 49 tab_bwd 50 trim_lo 51 trim_hi
 int64_t cxh_flat_array(const void *p, int32_t which, void *out) {
     const HostGraph *g = (const HostGraph *)p;
@@ -198,6 +289,8 @@ int64_t cxh_flat_array(const void *p, int32_t which, void *out) {
     case 74: return ints(g->hp.pos_var); case 75: return ints(g->hp.skip0); case 76: return ints(g->hp.skip1_up); case 77: return ints(g->hp.skip1_down);
     case 78: return ints(g->hp.link_pos); case 79: return ints(g->hp.from); case 80: return ints(g->hp.to); case 81: return ints(g->hp.head_fwd);
     case 82: return ints(g->hp.head_bwd); case 83: return ints(g->hp.pos_off); case 84: return ints(g->hp.link_off); case 85: return ints(g->hp.steps);
+    case 90: return ints(g->rplan.rec); case 91: return ints(g->rplan.stage_off); case 92: return ints(g->rplan.list); case 93: return ints(g->rw.dep_off); case 94: return ints(g->rw.dep);
+    case 95: return ints(g->rw.dep_inter); case 96: return ints(g->rs.flags); case 97: return ints(g->rcall.order);
     }
     return -1;
 }

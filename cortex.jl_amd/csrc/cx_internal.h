@@ -219,6 +219,10 @@ struct cx_handle {
     bool alt_two_back = false;       // after a two-sweep launch d_f2v_alt holds time t, not t+1 (see normalize_alt in cx_api_sweep.hip)
     double2 *d_f2v_tmp = nullptr;
 
+    // CX_SCHED_REFERENCE (cx_refsched.h, cx_api_ref.hip): wiring + shadow readiness state + plans (opaque); the list of the plan being launched
+    void *ref = nullptr;
+    int32_t *d_ref_list = nullptr;
+
     // variational families (cx_vmp.hip): opaque state
     void *vmp = nullptr;
 

@@ -349,7 +349,12 @@ __global__ __launch_bounds__(kBlock) void k_halo_import(const int32_t *__restric
 // a message out of a factor with more than two edges as a batch item (cx_kary_core.h): not a kind of the public interface —
 // cx_update_batch refuses kinds it does not know and routes such messages itself
 constexpr int kItemKaryEntry = 32;
-struct KaryTab { const int32_t *slot; const double *coef, *qb; };
+struct KaryTab { const int32_t *slot; const double *coef, *qb; const int32_t *list; };
+// items of the reference-order plans (cx_refsched.h) for the signals of variables of degree > 5, whose dependencies are segment-tree
+// nodes (dependencies.jl:90-173): the value is the sum — the reference's `reduce(product, get_value.(deps))` in natural form — of the
+// `hi` sources list[lo ..): an entry >= 0 is a factor→variable slot, ~entry a node of the product store.  What the reference's rule
+// call read, node by node — a node may lag behind its leaves on a graph with loops, and the reference reads the node.
+constexpr int kItemSumToFactor = 64, kItemSumToProduct = 65, kItemSumToMarginal = 66;
 template <int MODE>
 __device__ __forceinline__ void batch_item(int k, int idx, int v, int lo, int hi, const int32_t *__restrict__ vbase,
                                            const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
@@ -359,6 +364,11 @@ __device__ __forceinline__ void batch_item(int k, int idx, int v, int lo, int hi
                                            double2 *__restrict__ prod, double *__restrict__ joint, const KaryTab kt) {
     if (k == kItemKaryEntry) {            // internal (the tree schedule's stage lists): index = entry of the k-ary table
         kary_item(idx, kt.slot, kt.coef, kt.qb, v2f, f2v);
+    } else if (k >= kItemSumToFactor) {   // internal (reference-order plans)
+        double2 acc = zero2();
+        for (int j = 0; j < hi; j++) { const int s = kt.list[lo + j]; acc = add2(acc, s >= 0 ? f2v[s] : prod[~s]); }
+        if (k == kItemSumToMarginal) marg[v] = nat_marg ? acc : to_moment(acc);
+        else if (!__builtin_isnan(acc.y)) { if (k == kItemSumToFactor) v2f[idx] = acc; else prod[idx] = acc; }
     } else if (k == CX_ITEM_MESSAGE_TO_FACTOR) {
         m2f_one(idx, v, vbase, vdeg, vinfo, f2v, v2f);
     } else if (k == CX_ITEM_MESSAGE_TO_VARIABLE) {
@@ -436,8 +446,7 @@ __global__ __launch_bounds__(kRunBlock) void k_batch_run(const int64_t *__restri
                                                          double2 *__restrict__ marg, int nat_marg, double2 *__restrict__ prod, double *__restrict__ joint,
                                                          const KaryTab kt) {
     for (int st = s0; st < s1; st++) {
-        const int64_t i = stage_off[st] + threadIdx.x;
-        if (i < stage_off[st + 1])
+        for (int64_t i = stage_off[st] + threadIdx.x; i < stage_off[st + 1]; i += kRunBlock)      // (the tree schedule folds stages of at most kRunBlock items: one trip)
             batch_item<MODE>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg,
                              nat_marg, prod, joint, kt);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -459,7 +468,7 @@ __global__ __launch_bounds__(64) void k_batch_small(SmallBatch recs, int n, cons
     if (i >= n) return;
     const __attribute__((address_space(4))) int32_t *rec = (const __attribute__((address_space(4))) int32_t *)__builtin_amdgcn_kernarg_segment_ptr();
     batch_item<MODE>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg,
-                     nat_marg, prod, joint, KaryTab{nullptr, nullptr, nullptr});
+                     nat_marg, prod, joint, KaryTab{nullptr, nullptr, nullptr, nullptr});
     (void)recs;
 }
 
@@ -673,7 +682,7 @@ void launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n) {
     const int nb = (int)((n + kBlock - 1) / kBlock);
     prof_begin(h, CX_KERNEL_BATCH);
     const int mode = rule_mode(h), nat = h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0;
-    const KaryTab kt{h->d_kary_slot, h->d_kary_coef, h->d_kary_qb};
+    const KaryTab kt{h->d_kary_slot, h->d_kary_coef, h->d_kary_qb, h->d_ref_list};
 #define CX_B(M, PA, PB) hipLaunchKernelGGL(k_batch<M>, dim3(nb), dim3(kBlock), 0, h->stream, n, d_rec, h->d_vbase, h->d_var_deg, h->d_vinfo, \
                                            h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint, kt)
     if (mode == kRuleLinear) CX_B(kRuleLinear, h->d_a, h->d_b);
@@ -687,7 +696,7 @@ void launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n) {
 void launch_batch_run(cx_handle *h, const int32_t *d_rec, const int64_t *d_stage_off, int s0, int s1) {
     if (s1 <= s0) return;
     const int mode = rule_mode(h), nat = h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0;
-    const KaryTab kt{h->d_kary_slot, h->d_kary_coef, h->d_kary_qb};
+    const KaryTab kt{h->d_kary_slot, h->d_kary_coef, h->d_kary_qb, h->d_ref_list};
 #define CX_B(M, PA, PB) hipLaunchKernelGGL(k_batch_run<M>, dim3(1), dim3(kRunBlock), 0, h->stream, d_stage_off, s0, s1, d_rec, h->d_vbase, h->d_var_deg, h->d_vinfo, \
                                            h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint, kt)
     if (mode == kRuleLinear) CX_B(kRuleLinear, h->d_a, h->d_b);

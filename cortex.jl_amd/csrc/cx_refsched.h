@@ -1,0 +1,408 @@
+// cx_refsched.h — the GPU-free part of CX_SCHED_REFERENCE: ONE cx_sweep on ANY graph — loops included — is what ONE
+// update_marginals! of the reference leaves there.
+//
+// On a graph with cycles the reference's call is a sequential pass that always reads the newest values
+// (/root/reference/src/inference_engine.jl:575-608: forward / reverse passes over the requested variables;
+// /root/reference/src/signal.jl:466-490: per marginal a depth-first walk through the dependencies flagged intermediate, a pending
+// signal computed the moment it is met).  WHICH signals are computed, and in which order, is decided by the readiness nibbles alone
+// (/root/reference/src/signal.jl:141-154,232-253,339-356,668-730) — never by a value.  So the order of a call can be found without
+// computing anything: this header keeps a shadow of every signal's readiness state, wired as the default resolver wires it
+// (/root/reference/src/dependencies.jl:17-173), runs the reference's scheduler on the shadow and RECORDS the executions; the recorded
+// list is then levelled — an execution's stage is one more than the latest stage of (a) the executions of this call whose result it
+// reads, (b) the executions that read the value it overwrites, (c) its own previous execution — and the stages are replayed on the
+// device as item lists, the machinery CX_SCHED_TREE has (cx_api_sweep.hip).  Every value an item reads is then exactly the value the
+// reference's rule call read, and the results are the reference's up to the rounding of the natural-form arithmetic.
+//
+// The shadow is driven by whatever changes a value through the ABI: cx_set_messages / cx_seed_messages (the user's set_value!),
+// cx_update_batch (a plug-in's process!) and the sweeps themselves.
+//
+// Signals, by number:   [0, ne)            MessageToFactor of CSR edge e        (inference_signal.jl:29-32)
+//                       [ne, 2 ne)         MessageToVariable of CSR edge e      (:45-48)
+//                       [2 ne, 2 ne + nv)  IndividualMarginal of variable v     (:78-80)
+//                       [2 ne + nv, nsig)  ProductOfMessages(variable, range)   (:62-66), the segment-tree nodes of variables of degree > 5
+// Pure host C++ over any struct H with cx_handle's host fields (cx_flatten.h); tests/test_refsched.py runs it against the restated
+// reference engine (oracle/cortex_ref.c), also under -fsanitize=address,undefined.
+#pragma once
+
+#include <algorithm>
+#include <cstring>
+
+#include "cx_flatten.h"
+
+namespace cx {
+namespace refsched {
+
+using flat::fail_;
+
+constexpr uint8_t kPot = 1, kPend = 2, kComputed = 4;          // SignalProps (signal.jl:47-60) + "value !== UndefValue()"
+constexpr uint64_t kInter = 0x1, kWeak = 0x2, kComp = 0x4, kFresh = 0x8;      // signal.jl:507-510
+constexpr uint64_t kAllWeak = 0x2222222222222222ull, kAllComp = 0x4444444444444444ull, kAllFresh = 0x8888888888888888ull, kAllPass = 0x1111111111111111ull;
+
+struct Prod { int32_t var, lo, hi; };      // local variable, 1-based inclusive range over its factors in ascending id order (the variant's `range`)
+
+struct Wiring {
+    int64_t ne = 0, nv = 0, nsig = 0;
+    std::vector<int64_t> dep_off, lis_off, chunk_off;      // [nsig + 1]
+    std::vector<int32_t> dep;                              // dependencies in the resolver's order (add_dependency! appends)
+    std::vector<uint8_t> dep_inter;                        // 1: flagged intermediate
+    std::vector<int32_t> lis;                              // listeners (every dependency of the default wiring listens: listenmask all true)
+    std::vector<uint8_t> lis_idx;                          // position of this signal in the listener's dependency list (notify_listener!: first match)
+    std::vector<Prod> prods;                               // signal 2 ne + nv + i
+    std::vector<uint8_t> no_rule;                          // per MessageToVariable signal (index e): 1 = the device has no rule for this message
+    int64_t sig_v2f(int64_t e) const { return e; }
+    int64_t sig_f2v(int64_t e) const { return ne + e; }
+    int64_t sig_marg(int64_t v) const { return 2 * ne + v; }
+    int64_t sig_prod(int64_t i) const { return 2 * ne + nv + i; }
+};
+
+struct State {
+    std::vector<uint64_t> chunks;       // 4 bits per dependency, 16 per word (SignalDependenciesProps, signal.jl:36-45)
+    std::vector<uint8_t> flags;         // kPot | kPend | kComputed per signal
+    uint64_t hash = 0;                  // incremental (Zobrist) fingerprint of chunks + flags: equal states have equal fingerprints
+};
+
+inline uint64_t mix64(uint64_t x) {
+    x += 0x9e3779b97f4a7c15ull; x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull; x = (x ^ (x >> 27)) * 0x94d049bb133111ebull; return x ^ (x >> 31);
+}
+inline uint64_t zob_chunk(int64_t c, uint64_t value) { return mix64(value ^ mix64((uint64_t)c * 2 + 1)); }
+inline uint64_t zob_flag(int64_t s, uint8_t f) { return mix64((uint64_t)f ^ mix64((uint64_t)s * 2)); }
+
+// ---- the default resolver's wiring (dependencies.jl:5-173), emitted as (signal, dependency, intermediate) in add_dependency! order ----
+template <class H, class Emit>
+void wire(const H *h, const std::vector<int32_t> &efac, const std::vector<int32_t> &foff, const std::vector<int32_t> &fedge, std::vector<Prod> *prods,
+          Emit &&emit) {
+    const int64_t ne = h->ne, nv = h->nv, nf = h->nf;
+    // resolve_factor_dependencies!, dependencies.jl:17-31: every message out of a factor depends on the messages INTO it from its other
+    // variables, in the order of the factor's variables (ascending id)
+    for (int64_t f = 0; f < nf; f++)
+        for (int32_t k1 = foff[f]; k1 < foff[f + 1]; k1++)
+            for (int32_t k2 = foff[f]; k2 < foff[f + 1]; k2++)
+                if (k1 != k2) emit(ne + fedge[k1], (int64_t)fedge[k2], 0);
+    auto has_listeners = [&](int64_t e) { return foff[efac[e] + 1] - foff[efac[e]] >= 2; };      // isempty(get_listeners(msg_to_factor)), :73,107,117,149,159
+    int64_t next_prod = 2 * ne + nv;
+    // form_segment_tree_dependency!, dependencies.jl:128-173, over the 0-based half-open range [lo, hi) of the variable's edges
+    struct Rec {
+        const H *h; int64_t ne; std::vector<Prod> *prods; int64_t *next_prod; Emit &emit; decltype(has_listeners) &hl;
+        int64_t tree(int32_t v, int32_t lo, int32_t hi) {
+            const int32_t e0 = h->var_off[v];
+            if (hi - lo == 1) return ne + e0 + lo;
+            const int32_t mid = lo + (hi - lo) / 2;
+            const int64_t left = tree(v, lo, mid), right = tree(v, mid, hi);
+            cross(v, lo, mid, right); cross(v, mid, hi, left);
+            const int64_t inter = (*next_prod)++;
+            if (prods) prods->push_back(Prod{v, lo + 1, hi});
+            emit(inter, left, 1); emit(inter, right, 1);
+            return inter;
+        }
+        void cross(int32_t v, int32_t lo, int32_t hi, int64_t other) {
+            const int32_t e0 = h->var_off[v];
+            for (int32_t k = lo; k < hi; k++) if (hl(e0 + k)) emit((int64_t)(e0 + k), other, 1);
+        }
+    } rec{h, ne, prods, &next_prod, emit, has_listeners};
+    // resolve_variable_dependencies!, dependencies.jl:33-126
+    for (int64_t v = 0; v < nv; v++) {
+        const int32_t e0 = h->var_off[v], n = h->var_off[v + 1] - e0;
+        const int64_t marg = 2 * ne + v;
+        if (n == 0) continue;
+        if (n < 2) { emit(marg, ne + e0, 1); continue; }
+        if (n <= 5) {
+            for (int32_t k = 0; k < n; k++) {
+                emit(marg, ne + e0 + k, 1);
+                if (has_listeners(e0 + k))
+                    for (int32_t j = 0; j < n; j++) if (j != k) emit((int64_t)(e0 + k), ne + e0 + j, 1);
+            }
+            continue;
+        }
+        const int32_t mid = n / 2;
+        const int64_t left = rec.tree((int32_t)v, 0, mid), right = rec.tree((int32_t)v, mid, n);
+        rec.cross((int32_t)v, 0, mid, right); rec.cross((int32_t)v, mid, n, left);
+        emit(marg, left, 1); emit(marg, right, 1);
+    }
+}
+
+template <class H>
+int32_t build_wiring(const H *h, Wiring &W, std::string &err) {
+    const int64_t ne = h->ne, nv = h->nv, nf = h->nf;
+    W = Wiring();
+    W.ne = ne; W.nv = nv;
+    std::vector<int32_t> efac(ne), foff(nf + 1, 0), fedge(ne);
+    for (int64_t e = 0; e < ne; e++) {
+        auto it = std::lower_bound(h->fac_ids.begin(), h->fac_ids.end(), h->edge_fac_id[e]);
+        if (it == h->fac_ids.end() || *it != h->edge_fac_id[e]) return fail_(err, CX_ERR_STATE, "reference schedule: edge names an unknown factor");
+        efac[e] = (int32_t)(it - h->fac_ids.begin());
+        foff[efac[e] + 1]++;
+    }
+    for (int64_t f = 0; f < nf; f++) foff[f + 1] += foff[f];
+    {   // edges of one factor in ascending variable order (the CSR edge order is (variable, factor) ascending)
+        std::vector<int32_t> fill(foff.begin(), foff.end() - 1);
+        for (int64_t e = 0; e < ne; e++) fedge[fill[efac[e]]++] = (int32_t)e;
+    }
+    // pass 1: count; the segment-tree nodes get their numbers in creation order
+    std::vector<Prod> prods;
+    std::vector<int64_t> cnt;
+    {
+        int64_t nprod = 0;
+        for (int64_t v = 0; v < nv; v++) { const int32_t n = h->var_off[v + 1] - h->var_off[v]; if (n > 5) nprod += n - 2; }      // a binary tree over n leaves under two roots
+        W.nsig = 2 * ne + nv + nprod;
+        if (W.nsig >= (int64_t)0x7fffffff) return fail_(err, CX_ERR_UNSUPPORTED, "reference schedule: more than 2^31 signals");
+        cnt.assign(W.nsig + 1, 0);
+        wire(h, efac, foff, fedge, &prods, [&](int64_t s, int64_t, int) { cnt[s + 1]++; });
+        if ((int64_t)prods.size() != nprod) return fail_(err, CX_ERR_STATE, "reference schedule: segment-tree node count");
+    }
+    W.prods = std::move(prods);
+    W.dep_off.assign(W.nsig + 1, 0);
+    for (int64_t s = 0; s < W.nsig; s++) {
+        if (cnt[s + 1] > 255) return fail_(err, CX_ERR_UNSUPPORTED, "reference schedule: a signal with more than 255 dependencies");
+        W.dep_off[s + 1] = W.dep_off[s] + cnt[s + 1];
+    }
+    const int64_t nd = W.dep_off[W.nsig];
+    W.dep.assign(nd, -1); W.dep_inter.assign(nd, 0);
+    std::vector<int64_t> lcnt(W.nsig + 1, 0);
+    {   // pass 2: fill
+        std::vector<int64_t> fill(W.dep_off.begin(), W.dep_off.end() - 1);
+        wire(h, efac, foff, fedge, nullptr, [&](int64_t s, int64_t d, int inter) {
+            const int64_t p = fill[s]++;
+            W.dep[p] = (int32_t)d; W.dep_inter[p] = (uint8_t)inter;
+            lcnt[d + 1]++;
+        });
+    }
+    W.lis_off.assign(W.nsig + 1, 0);
+    for (int64_t s = 0; s < W.nsig; s++) W.lis_off[s + 1] = W.lis_off[s] + lcnt[s + 1];
+    W.lis.assign(nd, -1); W.lis_idx.assign(nd, 0);
+    {
+        std::vector<int64_t> fill(W.lis_off.begin(), W.lis_off.end() - 1);
+        for (int64_t s = 0; s < W.nsig; s++)
+            for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) {
+                const int64_t q = fill[W.dep[p]]++;
+                W.lis[q] = (int32_t)s; W.lis_idx[q] = (uint8_t)(p - W.dep_off[s]);
+            }
+    }
+    W.chunk_off.assign(W.nsig + 1, 0);
+    for (int64_t s = 0; s < W.nsig; s++) {
+        const int64_t n = W.dep_off[s + 1] - W.dep_off[s];
+        W.chunk_off[s + 1] = W.chunk_off[s] + std::max<int64_t>(1, (n + 15) / 16);      // a SignalDependenciesProps always owns one chunk (signal.jl:36-45)
+    }
+    // messages the device cannot compute: out of a factor that has no rule here and other variables (the reference's processor would
+    // call the user's rule; an opaque factor has none — inference_engine.jl:358 error(...))
+    W.no_rule.assign(ne, 0);
+    for (int64_t e = 0; e < ne; e++) {
+        const int32_t f = efac[e], deg = foff[f + 1] - foff[f];
+        if (deg >= 2 && h->fac_kind[f] == CX_FACTOR_OPAQUE) W.no_rule[e] = 1;
+    }
+    return CX_OK;
+}
+
+inline void init_state(const Wiring &W, State &S) {
+    S.chunks.assign(W.chunk_off[W.nsig], 0);
+    S.flags.assign(W.nsig, 0);
+    for (int64_t s = 0; s < W.nsig; s++)
+        for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++)
+            if (W.dep_inter[p]) { const int64_t i = p - W.dep_off[s]; S.chunks[W.chunk_off[s] + (i >> 4)] |= kInter << ((i & 15) << 2); }
+    S.hash = 0;
+    for (int64_t c = 0; c < (int64_t)S.chunks.size(); c++) S.hash ^= zob_chunk(c, S.chunks[c]);
+    for (int64_t s = 0; s < W.nsig; s++) S.hash ^= zob_flag(s, 0);
+}
+
+inline void put_chunk(State &S, int64_t c, uint64_t value) {
+    const uint64_t old = S.chunks[c];
+    if (old == value) return;
+    S.hash ^= zob_chunk(c, old) ^ zob_chunk(c, value);
+    S.chunks[c] = value;
+}
+inline void put_flags(State &S, int64_t s, uint8_t f) {
+    const uint8_t old = S.flags[s];
+    if (old == f) return;
+    S.hash ^= zob_flag(s, old) ^ zob_flag(s, f);
+    S.flags[s] = f;
+}
+
+// set_value!, signal.jl:232-253 (+ notify_listener!, :339-356)
+inline void set_value(const Wiring &W, State &S, int64_t s) {
+    for (int64_t c = W.chunk_off[s]; c < W.chunk_off[s + 1]; c++) put_chunk(S, c, S.chunks[c] & ~kAllFresh);      // unset_all_dependencies_fresh!, :653-655
+    put_flags(S, s, kComputed);                                                                                // props = (false, false)
+    for (int64_t q = W.lis_off[s]; q < W.lis_off[s + 1]; q++) {
+        const int64_t l = W.lis[q], i = W.lis_idx[q];
+        put_flags(S, l, (uint8_t)((S.flags[l] & kComputed) | kPot));                                           // listening: potentially pending, not pending
+        const int64_t c = W.chunk_off[l] + (i >> 4);
+        put_chunk(S, c, S.chunks[c] | ((kFresh | kComp) << ((i & 15) << 2)));
+    }
+}
+
+// is_meeting_pending_criteria, signal.jl:668-730: every dependency Computed & (Weak | Fresh), chunk-parallel, the last chunk padded with ones
+inline bool meets_pending_criteria(const Wiring &W, const State &S, int64_t s) {
+    const int64_t n = W.dep_off[s + 1] - W.dep_off[s];
+    if (n == 0) return false;
+    const int64_t c0 = W.chunk_off[s], nc = W.chunk_off[s + 1] - c0;
+    for (int64_t c = 0; c + 1 < nc; c++) {
+        const uint64_t ch = S.chunks[c0 + c];
+        if ((((ch & kAllComp) >> 2) & (((ch & kAllWeak) >> 1) | ((ch & kAllFresh) >> 3))) != kAllPass) return false;
+    }
+    const int off = (int)(((n - 1) & 15) << 2);
+    const uint64_t fill = off + 4 >= 64 ? 0 : (~0ull << (off + 4));       // Julia's UInt64 << 64 is 0
+    const uint64_t ch = S.chunks[c0 + nc - 1] | fill;
+    return (((ch & kAllComp) >> 2) & (((ch & kAllWeak) >> 1) | ((ch & kAllFresh) >> 3))) == kAllPass;
+}
+
+// is_pending, signal.jl:141-154: the cached answer, or a lazy evaluation when potentially pending
+inline bool is_pending(const Wiring &W, State &S, int64_t s) {
+    const uint8_t f = S.flags[s];
+    if (f & kPend) return true;
+    if (f & kPot) {
+        const bool p = meets_pending_criteria(W, S, s);
+        put_flags(S, s, (uint8_t)((f & kComputed) | (p ? kPend : 0)));
+        return p;
+    }
+    return false;
+}
+
+// ---- update_marginals!, inference_engine.jl:559-632, on the shadow: records the executions instead of computing ---------------------
+struct Call {
+    std::vector<int32_t> order;         // signals in execution order
+    std::vector<int32_t> round_of;      // the pass each execution belongs to (0-based; the final marginal round is the last)
+    int64_t rounds = 0;
+};
+
+struct Runner {
+    const Wiring &W; State &S; Call &out; int32_t round = 0; int32_t bad = -1;
+    bool f(int64_t d) {                 // the closure of process_inference_request, inference_engine.jl:512-525
+        if (!is_pending(W, S, d)) return false;
+        if (d >= W.ne && d < 2 * W.ne && W.no_rule[d - W.ne] && bad < 0) bad = (int32_t)d;
+        out.order.push_back((int32_t)d); out.round_of.push_back(round);
+        set_value(W, S, d);             // compute! = rule + set_value!, signal.jl:392-410
+        return true;
+    }
+    bool process_dependencies(int64_t s) {      // signal.jl:466-490, retry = true
+        bool any = false;
+        for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) {
+            const int64_t d = W.dep[p];
+            bool processed = f(d);
+            if (!processed && W.dep_inter[p]) {
+                const bool sub = process_dependencies(d);
+                if (sub) processed = f(d);
+                any = any || sub;
+            }
+            any = any || processed;
+        }
+        return any;
+    }
+};
+
+// req: local variable numbers in request order.  Returns -1, or the MessageToVariable signal the device has no rule for.
+inline int32_t update_marginals(const Wiring &W, State &S, const int32_t *req, int64_t n, Call &out) {
+    out = Call();
+    // request_inference_for, inference_engine.jl:298-323 (no linked signals under the default wiring)
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t m = W.sig_marg(req[i]);
+        for (int64_t p = W.dep_off[m]; p < W.dep_off[m + 1]; p++) { const int64_t d = W.dep[p]; put_flags(S, d, (uint8_t)((S.flags[d] & kComputed) | kPot)); }
+    }
+    std::vector<uint8_t> ready(n, 0);
+    Runner R{W, S, out};
+    bool cont = true, reverse = false;
+    while (cont) {
+        cont = false;
+        for (int64_t k = 0; k < n; k++) {
+            const int64_t i = reverse ? n - 1 - k : k;
+            if (ready[i]) continue;
+            const int64_t m = W.sig_marg(req[i]);
+            const bool did = R.process_dependencies(m);
+            if (is_pending(W, S, m)) ready[i] = 1;
+            cont = cont || did;
+        }
+        reverse = !reverse;
+        R.round++;
+    }
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t m = W.sig_marg(req[i]);
+        if (is_pending(W, S, m)) { out.order.push_back((int32_t)m); out.round_of.push_back(R.round); set_value(W, S, m); }
+    }
+    out.rounds = R.round + 1;
+    return R.bad;
+}
+
+// ---- the recorded executions as stages of device items -------------------------------------------------------------------------------
+// internal item kinds of the reference plans (cx_kernels.hip: batch_item): the value is the SUM of a list of sources — the
+// dependencies in the reference's order, exactly what its rule call folds (`reduce(product, get_value.(deps))` in natural form) — for
+// the signals of variables of degree > 5, whose dependencies are segment-tree nodes: a list entry >= 0 is a factor→variable slot,
+// ~entry the index of a node in the product store.  rec = {kind, destination, variable, first list entry, entries}
+constexpr int32_t kItemSumToFactor = 64, kItemSumToProduct = 65, kItemSumToMarginal = 66;
+
+struct Plan {
+    std::vector<int32_t> rec;            // 5 per item, by stage
+    std::vector<int64_t> stage_off;
+    std::vector<int32_t> list;           // sources of the list items
+    int64_t n_exec = 0, n_messages = 0, n_marginals = 0, n_products = 0, rounds = 0;
+};
+
+// prod_slot(i): the index of segment-tree node i in the handle's product store (the caller registers the nodes)
+template <class H, class ProdSlot>
+int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slot, Plan &P, std::string &err) {
+    const int64_t ne = W.ne, nv = W.nv, n = (int64_t)call.order.size();
+    P = Plan();
+    P.n_exec = n; P.rounds = call.rounds;
+    std::vector<int32_t> w_stage(W.nsig, 0), r_stage(W.nsig, 0), stage(n, 0);
+    int32_t n_stages = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t s = call.order[i];
+        int32_t st = std::max(w_stage[s], r_stage[s]) + 1;
+        for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) st = std::max(st, w_stage[W.dep[p]] + 1);
+        stage[i] = st; w_stage[s] = st;
+        for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) r_stage[W.dep[p]] = std::max(r_stage[W.dep[p]], st);
+        n_stages = std::max(n_stages, st);
+    }
+    P.stage_off.assign(n_stages + 1, 0);
+    for (int64_t i = 0; i < n; i++) P.stage_off[stage[i]]++;
+    for (int32_t s = 0; s < n_stages; s++) P.stage_off[s + 1] += P.stage_off[s];
+    P.rec.assign(5 * n, 0);
+    std::vector<int64_t> fill(P.stage_off.begin(), P.stage_off.end() - 1);
+    auto source = [&](int64_t d) -> int32_t {       // a dependency of a list item as a list entry
+        if (d >= ne && d < 2 * ne) return flat::slot_of_edge_t(h, d - ne);
+        return ~(int32_t)prod_slot(d - 2 * ne - nv);
+    };
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t s = call.order[i];
+        int32_t *r = &P.rec[5 * fill[stage[i] - 1]++];
+        if (s < ne) {                                    // MessageToFactor
+            const int32_t v = h->edge_var[s], deg = h->var_off[v + 1] - h->var_off[v], slot = flat::slot_of_edge_t(h, s);
+            P.n_messages++;
+            if (deg <= 5) { r[0] = CX_ITEM_MESSAGE_TO_FACTOR; r[1] = slot; r[2] = v; }
+            else {
+                r[0] = kItemSumToFactor; r[1] = slot; r[2] = v; r[3] = (int32_t)P.list.size(); r[4] = (int32_t)(W.dep_off[s + 1] - W.dep_off[s]);
+                for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) P.list.push_back(source(W.dep[p]));
+            }
+        } else if (s < 2 * ne) {                         // MessageToVariable
+            const int64_t e = s - ne;
+            const int32_t slot = flat::slot_of_edge_t(h, e);
+            P.n_messages++;
+            if (!h->slot_kary.empty() && h->slot_kary[slot] >= 0) { r[0] = 32; r[1] = h->slot_kary[slot]; }      // kItemKaryEntry
+            else if (h->partner[slot] >= 0) { r[0] = CX_ITEM_MESSAGE_TO_VARIABLE; r[1] = slot; r[2] = h->edge_var[e]; }
+            else return fail_(err, CX_ERR_UNSUPPORTED, "reference schedule: the message from factor " + std::to_string(h->edge_fac_id[e]) + " to variable " +
+                                                           std::to_string(h->var_ids[h->edge_var[e]]) + " is pending, and the factor has no rule on the device "
+                                                           "(an opaque factor of two or more variables: the reference's processor would raise, inference_engine.jl:358)");
+        } else if (s < 2 * ne + nv) {                    // IndividualMarginal
+            const int32_t v = (int32_t)(s - 2 * ne), deg = h->var_off[v + 1] - h->var_off[v];
+            P.n_marginals++;
+            if (deg <= 5) { r[0] = CX_ITEM_INDIVIDUAL_MARGINAL; r[1] = v; r[2] = v; }
+            else {
+                r[0] = kItemSumToMarginal; r[1] = v; r[2] = v; r[3] = (int32_t)P.list.size(); r[4] = (int32_t)(W.dep_off[s + 1] - W.dep_off[s]);
+                for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) P.list.push_back(source(W.dep[p]));
+            }
+        } else {                                         // ProductOfMessages
+            const int64_t pi = s - 2 * ne - nv;
+            P.n_products++;
+            r[0] = kItemSumToProduct; r[1] = (int32_t)prod_slot(pi); r[2] = W.prods[pi].var; r[3] = (int32_t)P.list.size(); r[4] = (int32_t)(W.dep_off[s + 1] - W.dep_off[s]);
+            for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) P.list.push_back(source(W.dep[p]));
+        }
+    }
+    return CX_OK;
+}
+
+// the signal of a batch item / a message as the shadow numbers it: -1 when there is none (a ProductOfMessages range that is not a node of
+// the variable's segment tree)
+inline int64_t find_prod(const Wiring &W, int32_t var, int32_t lo, int32_t hi) {
+    for (int64_t i = 0; i < (int64_t)W.prods.size(); i++)      // (hubs are rare; a map would pay only for graphs of many of them)
+        if (W.prods[i].var == var && W.prods[i].lo == lo && W.prods[i].hi == hi) return W.sig_prod(i);
+    return -1;
+}
+
+}  // namespace refsched
+}  // namespace cx

@@ -186,6 +186,31 @@ class DeviceGraph:
     def sweep(self, n: int = 1):
         self._check(self.lib.cx_sweep(self.h, int(n)))
 
+    def sweep_for(self, variable_ids):
+        """cx_sweep_for: ONE update_marginals!(engine, variable_ids) under CX_SCHED_REFERENCE, the ids in the caller's order"""
+        v = _i64(np.atleast_1d(variable_ids))
+        self._check(self.lib.cx_sweep_for(self.h, len(v), _p(v, C.c_int64)))
+
+    def ref_plan_stats(self) -> dict:
+        out = (C.c_int64 * 8)()
+        self._check(self.lib.cx_ref_plan_stats(self.h, out))
+        keys = ("stages", "launches", "executions", "messages", "rounds", "plans", "hits", "misses")
+        return dict(zip(keys, (int(x) for x in out)))
+
+    def ref_trace(self):
+        """cx_ref_trace: the executions of the last reference-order call as (kind, variable_id, factor_id, lo, hi) tuples"""
+        n = C.c_int64()
+        self._check(self.lib.cx_ref_trace(self.h, 0, None, C.byref(n)))
+        items = (L.Item * max(1, n.value))()
+        self._check(self.lib.cx_ref_trace(self.h, n.value, items, C.byref(n)))
+        out = []
+        for it in items[:n.value]:
+            if it.kind == L.ITEM_PRODUCT_OF_MESSAGES:
+                out.append((it.kind, int(it.variable_id), 0, int(it.factor_id) >> 32, int(it.factor_id) & 0xffffffff))
+            else:
+                out.append((it.kind, int(it.variable_id), int(it.factor_id), 0, 0))
+        return out
+
     def sweep_begin(self):
         self._check(self.lib.cx_sweep_begin(self.h))
 

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CX_ABI_VERSION 2   /* 2: cx_config.reserved became sweeps_per_launch (validated), five new item / factor kinds, state blobs "CXSTATE2" */
+#define CX_ABI_VERSION 3   /* 3: CX_SCHED_REFERENCE, cx_sweep_for, cx_ref_plan_stats, cx_ref_trace, cx_set_damping.  2: cx_config.reserved became sweeps_per_launch (validated), five new item / factor kinds, state blobs "CXSTATE2" */
 
 /* status codes */
 #define CX_OK 0
@@ -143,6 +143,22 @@ extern "C" {
                                  component, counted in variables and factors).  A cycle among the non-observed variables
                                  is refused (CX_ERR_UNSUPPORTED).  Lazy like the reference: nothing into observed
                                  variables.  dim 1 (Gaussian and natural-pair families), 2, 3, 4 and 64 (5 .. 63 with it).  */
+#define CX_SCHED_REFERENCE 4  /* ANY graph, loops included: one cx_sweep / cx_sweep_for = the reference's one update_marginals! —
+                                 the same signals computed in the same ORDER, each from exactly the values the reference's rule call
+                                 read (a sequential pass that always reads the newest values, inference_engine.jl:575-608,
+                                 signal.jl:466-490: "Gauss-Seidel" in requested-variable order x neighbour order).  The library keeps a
+                                 shadow of every signal's readiness nibbles, wired as DefaultDependencyResolver wires them
+                                 (dependencies.jl:17-173, signal.jl:141-154,232-253,668-730) and driven by cx_set_messages /
+                                 cx_seed_messages (the user's set_value!), cx_update_batch (a plug-in's process!) and the sweeps; a call
+                                 runs the reference's scheduler on the shadow, records the executions, levels them (an execution's stage
+                                 follows every execution whose result it reads, every reader of the value it overwrites, and its own
+                                 previous one) and replays the stages as item lists in ONE graph launch.  Plans are kept per (readiness
+                                 state at the start of the call, request): the steady state of "set the priors, call" replays a standing
+                                 plan.  Lazy like the reference: a call computes what is pending for the requested marginals, nothing
+                                 else; priors have to be re-set before a call to be fresh, exactly as there.  On a forest it is the tree
+                                 schedule with requests for some of the variables.  dim 1 (Gaussian and natural-pair families), factors
+                                 of any arity the rules have, variables of any degree (degree > 5: the segment-tree nodes of
+                                 dependencies.jl:90-173 are computed, stored and read one by one, as the reference does).  Not partitioned. */
 
 
 typedef struct cx_handle cx_handle;
@@ -153,7 +169,7 @@ typedef struct cx_config {
     int32_t dim;           /* message dimension d: 1 (scalar), 2, 3, 4 (registers); 64 is the MFMA path; 5 .. 63 run ON the dim 64 path,
                               embedded block-diagonally (x, u) with u a unit random walk nobody observes: exact results for the d x d
                               blocks, payloads of d and d + d*d doubles as for any d, at the cost of dim 64 whatever d is           */
-    int32_t schedule;      /* CX_SCHED_*: dim 1 all three; dim 2..4 CX_SCHED_FUSED or CX_SCHED_CHAIN_SCAN; dim 64 CX_SCHED_FUSED */
+    int32_t schedule;      /* CX_SCHED_*: dim 1 all five; dim 2..4 and 64 (5 .. 63 with it) CX_SCHED_FUSED, CX_SCHED_CHAIN_SCAN or CX_SCHED_TREE */
     int32_t compute_marginals_in_sweep; /* 1: every sweep also refreshes all marginals (update_marginals!).
                                            2 (CX_SCHED_CHAIN_SCAN, dim 2..4; elsewhere the same as 1): on demand — a sweep leaves
                                            the chain's forward and backward sums in the order of its walks, and the pass that
@@ -275,6 +291,18 @@ int32_t cx_get_products(cx_handle *h, int64_t n, const int64_t *variable_ids, co
 int32_t cx_get_joint_marginals(cx_handle *h, int64_t n, const int64_t *factor_ids, double *out);
 /* n_sweeps passes of the configured device schedule over the whole graph (asynchronous) */
 int32_t cx_sweep(cx_handle *h, int32_t n_sweeps);
+/* CX_SCHED_REFERENCE: ONE update_marginals!(engine, variable_ids) (src/inference_engine.jl:559-632; request_inference_for :298-323) for
+ * the named variables in the caller's order — only what is pending for those marginals is computed (cx_sweep requests every variable
+ * that is neither observed nor a stand-in, in ascending id order).  Other schedules: CX_ERR_UNSUPPORTED (they compute every message). */
+int32_t cx_sweep_for(cx_handle *h, int64_t n, const int64_t *variable_ids);
+/* the plan the last reference-order call replayed: out8 = { stages, kernel launches, executions (signals computed), of which messages,
+ * passes of the reference's loop (the final marginal round included), plans kept, calls that replayed a kept plan, calls that had to
+ * run the scheduler }.  Zeros before the first call and for other schedules. */
+int32_t cx_ref_plan_stats(const cx_handle *h, int64_t *out8);
+/* the executions of the last reference-order call in the reference's order — what a `trace = true` engine records
+ * (src/inference_engine.jl:650-862: TracedInferenceExecution.signal), as items (kind, variable_id, factor_id | CX_ITEM_RANGE).
+ * *n_executions = their number; out (may be NULL) receives the first `capacity` of them. */
+int32_t cx_ref_trace(const cx_handle *h, int64_t capacity, cx_item *out, int64_t *n_executions);
 /* max over directed messages of |Δmean|, |Δvariance| between the last two sweeps (host-synchronous) */
 int32_t cx_residual(cx_handle *h, double *out_max_abs_delta);
 /* sweep until cx_residual over `check_every` sweeps is <= tol, or max_sweeps have run (stopping rule for loopy graphs; the

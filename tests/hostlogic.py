@@ -82,6 +82,7 @@ _ARR = {"var_ids": 0, "var_off": 1, "edge_var": 2, "edge_fac_id": 3, "vbase": 4,
         "pos_var": 40, "skip0": 41, "skip1": 42, "link_pos": 43, "from": 44, "to": 45, "head_fwd": 46, "head_bwd": 47, "tab_fwd": 48, "tab_bwd": 49,
         "trim_lo": 50, "trim_hi": 51, "hp_rec": 70, "hp_stage_off": 71, "hp_kary": 72, "hp_kary_off": 73, "hp_pos_var": 74, "hp_skip0": 75, "hp_skip1_up": 76, "hp_skip1_down": 77,
         "hp_link_pos": 78, "hp_from": 79, "hp_to": 80, "hp_head_fwd": 81, "hp_head_bwd": 82, "hp_pos_off": 83, "hp_link_off": 84, "hp_steps": 85,
+        "ref_rec": 90, "ref_stage_off": 91, "ref_list": 92, "ref_dep_off": 93, "ref_dep": 94, "ref_dep_inter": 95, "ref_flags": 96, "ref_order": 97,
         "tree_rec": 60, "tree_stage_off": 61, "tree_kary": 62, "tree_kary_off": 63, "partner": 64, "slot_kary_all": 65,
         "kary_slot_all": 66}
 _SCA = {"nv": 0, "nf": 1, "ne": 2, "nslots": 3, "nslices": 4, "n_messages_per_sweep": 5, "any_linear": 6, "n_kary": 7, "big_start": 8, "npos_linked": 9,
@@ -112,6 +113,17 @@ class FlatGraph:
             L.cxh_flat_tree_hp.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
             L.cxh_flat_halo.restype = C.c_int32
             L.cxh_flat_halo.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
+            L.cxh_ref_build.restype = C.c_int32
+            L.cxh_ref_build.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+            L.cxh_ref_set.restype = C.c_int32
+            L.cxh_ref_set.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
+            L.cxh_ref_update.restype = C.c_int64
+            L.cxh_ref_update.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+            L.cxh_ref_trace.argtypes = [C.c_void_p, C.c_void_p]
+            L.cxh_ref_level.restype = C.c_int32
+            L.cxh_ref_level.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+            L.cxh_ref_scalar.restype = C.c_int64
+            L.cxh_ref_scalar.argtypes = [C.c_void_p, C.c_int32]
             L._flat_ready = True
         self.L = L
         ev = np.ascontiguousarray(edge_var, dtype=np.int64); ef = np.ascontiguousarray(edge_fac, dtype=np.int64)
@@ -166,3 +178,32 @@ class FlatGraph:
         v = np.ascontiguousarray(layer_var, dtype=np.int64); l = np.ascontiguousarray(layer, dtype=np.int32)
         ss = np.ascontiguousarray(send_slots, dtype=np.int32)
         return int(self.L.cxh_flat_halo(self.p, len(v), v.ctypes.data, l.ctypes.data, int(depth), len(ss), ss.ctypes.data))
+
+    # ---- CX_SCHED_REFERENCE (cx_refsched.h): wiring, shadow of the readiness state, recorded and levelled calls --------------------
+    def ref_build(self):
+        err = C.create_string_buffer(512)
+        rc = int(self.L.cxh_ref_build(self.p, err, 512))
+        return rc, err.value.decode()
+
+    def ref_set(self, direction, variable_ids, factor_ids):
+        v = np.ascontiguousarray(variable_ids, dtype=np.int64); f = np.ascontiguousarray(factor_ids, dtype=np.int64)
+        rc = int(self.L.cxh_ref_set(self.p, int(direction), len(v), v.ctypes.data, f.ctypes.data))
+        assert rc == 0, rc
+
+    def ref_update(self, variable_ids):
+        """one update_marginals!(ids) on the shadow: rows {kind, variable id, factor id, lo, hi, round} in execution order"""
+        v = np.ascontiguousarray(variable_ids, dtype=np.int64)
+        n = int(self.L.cxh_ref_update(self.p, len(v), v.ctypes.data))
+        assert n >= 0, n
+        out = np.zeros((n, 6), dtype=np.int64)
+        if n:
+            self.L.cxh_ref_trace(self.p, out.ctypes.data)
+        return out
+
+    def ref_level(self):
+        err = C.create_string_buffer(512)
+        rc = int(self.L.cxh_ref_level(self.p, err, 512))
+        return rc, err.value.decode()
+
+    def ref_scalar(self, what):
+        return int(self.L.cxh_ref_scalar(self.p, {"signals": 0, "dependencies": 1, "products": 2, "hash": 3, "rounds": 4}[what]))

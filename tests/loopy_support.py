@@ -80,8 +80,8 @@ class HostBackend:
 class HipBackend:
     """HipProcessor: values on the device, rule calls as launches through the C ABI"""
 
-    def __init__(self, mode):
-        self.proc = cx.HipProcessor(mode=mode)
+    def __init__(self, mode, schedule=None):
+        self.proc = cx.HipProcessor(mode=mode) if schedule is None else cx.HipProcessor(mode=mode, schedule=schedule)
         self.log = self.proc.execution_log
 
     def bind(self, engine, model):

@@ -1,0 +1,213 @@
+"""-m gpu: CX_SCHED_REFERENCE — ONE cx_sweep on a LOOPY graph is ONE update_marginals! of the reference, call by call.
+
+The device replays the order the reference's scheduler takes (found on a shadow of the readiness nibbles, csrc/cx_refsched.h; the
+CPU twin tests/test_refsched.py pins that order against oracle/cortex_ref.c signal by signal and executes the levelled stages in
+numpy) as stages of items in one graph launch.  Here: the values the device leaves after every call — every message in both
+directions, every marginal — against the restated engine (<= 1e-9: natural-form against moment-form arithmetic), the execution trace
+the library reports against the engine's, the plan cache, partial requests, a plug-in driving the same handle, and the checkpoint."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cortex.jl_amd as cx
+from cortex.jl_amd import _lib as L
+from oracle import exact, ref
+from tests.helpers import assert_close, engine_oracle_from_model, random_loopy_model
+from tests.loopy_support import pairwise_edges
+
+pytestmark = pytest.mark.gpu
+SEED_VARIANCE = 1e6
+
+
+def _models():
+    rnd, _ = random_loopy_model(11, 1, nv=60, extra=25)
+    hubs, _ = random_loopy_model(5, 1, nv=40, extra=70)
+    return {"grid8x9": cx.synth.gaussian_grid(8, 9, seed=5), "grid48x40": cx.synth.gaussian_grid(48, 40, seed=1), "random": rnd, "hubs": hubs}
+
+
+def _oracle_trace(E):
+    kinds = {ref.VAR_MSG_TO_FACTOR: L.ITEM_MESSAGE_TO_FACTOR, ref.VAR_MSG_TO_VARIABLE: L.ITEM_MESSAGE_TO_VARIABLE, ref.VAR_MARGINAL: L.ITEM_INDIVIDUAL_MARGINAL,
+             ref.VAR_PRODUCT: L.ITEM_PRODUCT_OF_MESSAGES}
+    out = []
+    for _r, _v, s, _b, _a in E.trace():
+        k, v, f, lo, hi = E.variant(s)
+        out.append((kinds[k], v, f if k in (ref.VAR_MSG_TO_FACTOR, ref.VAR_MSG_TO_VARIABLE) else 0, lo if k == ref.VAR_PRODUCT else 0, hi if k == ref.VAR_PRODUCT else 0))
+    return out
+
+
+def _set_priors(dev, E, model):
+    E.set_messages_to_variable(model.prior_var, model.prior_fac, model.prior_mean, model.prior_variance)
+    dev.set_messages(model.prior_var, model.prior_fac, L.TO_VARIABLE, L.FORM_MOMENT, np.stack([model.prior_mean, model.prior_variance], axis=1))
+
+
+def _compare(dev, E, model, request, what, rtol=1e-9):
+    for to_variable, direction in ((True, L.TO_VARIABLE), (False, L.TO_FACTOR)):
+        tags, a, b = E.get_messages(model.edge_var, model.edge_fac, to_variable)
+        got = dev.get_messages(model.edge_var, model.edge_fac, direction)
+        und = tags == ref.UNDEF
+        name = "f2v" if to_variable else "v2f"
+        assert np.array_equal(np.isnan(got[:, 1]), und), f"{what}: the same {name} messages are defined"
+        assert_close(got[~und, 0], a[~und], rtol, f"{what} {name} mean")
+        ok = ~und & (tags != ref.REAL)
+        assert_close(got[ok, 1], b[ok], rtol, f"{what} {name} variance")
+    tags, em, ev = E.get_marginals(request)
+    marg = dev.get_marginals(request)
+    und = tags == ref.UNDEF
+    assert np.array_equal(np.isnan(marg[:, 1]), und), f"{what}: the same marginals are defined"
+    assert_close(marg[~und, 0], em[~und], rtol, f"{what} marginal mean")
+    assert_close(marg[~und, 1], ev[~und], rtol, f"{what} marginal variance")
+
+
+def _start(model):
+    E = engine_oracle_from_model(model, trace=True)
+    dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(model, dev)
+    pv, pf = pairwise_edges(model)
+    E.set_messages_to_variable(pv, pf, np.zeros(len(pv)), np.full(len(pv), SEED_VARIANCE))
+    dev.seed_messages(L.TO_VARIABLE, 0.0, SEED_VARIANCE)
+    return E, dev
+
+
+@pytest.mark.parametrize("name", ["grid8x9", "grid48x40", "random", "hubs"])
+def test_one_sweep_on_a_loopy_graph_is_one_update_marginals_of_the_reference(hip_lib, name):
+    model = _models()[name]
+    E, dev = _start(model)
+    for call in range(5):
+        if call:
+            _set_priors(dev, E, model)
+        dev.sweep(1)
+        E.update_marginals(model.x_ids)
+        assert dev.ref_trace() == _oracle_trace(E), f"{name} call {call + 1}: the executions, in order"
+        _compare(dev, E, model, model.x_ids, f"{name} call {call + 1}")
+    st = dev.ref_plan_stats()
+    assert st["executions"] == len(E.trace()) and st["stages"] >= 3 and st["launches"] <= st["stages"]
+    assert st["hits"] + st["misses"] == 5
+    if name.startswith("grid"):
+        assert st["hits"] >= 3, "from the second call on the readiness state before a call repeats: a standing plan is replayed"
+    dev.close()
+
+
+def test_the_sweep_differs_from_a_jacobi_sweep_and_shares_its_fixed_point(hip_lib):
+    """what the item asks for in one sentence: the fused schedule's sweep is NOT the reference's call (it reads old values), the
+    reference-order schedule's is; both reach the same messages, and the exact posterior means"""
+    model = _models()["grid8x9"]
+    E, dev = _start(model)
+    jac = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(model, jac, seed_variance=SEED_VARIANCE)
+    dev.sweep(1); jac.sweep(1); E.update_marginals(model.x_ids)
+    pv, pf = pairwise_edges(model)
+    a, b = dev.get_messages(pv, pf, L.TO_VARIABLE), jac.get_messages(pv, pf, L.TO_VARIABLE)
+    assert np.max(np.abs(a[:, 0] - b[:, 0])) > 1e-3, "after ONE sweep the two schedules hold different messages"
+    for _ in range(250):
+        _set_priors(dev, E, model)
+        dev.sweep(1)
+    jac.sweep(500)
+    a, b = dev.get_messages(pv, pf, L.TO_VARIABLE), jac.get_messages(pv, pf, L.TO_VARIABLE)
+    assert_close(a, b, 1e-9, "the common fixed point")
+    me = exact.grid_posterior_mean(8, 9, model.meta["y"], model.meta["r"], model.meta["qh"], model.meta["qv"])
+    assert_close(dev.get_marginals(model.x_ids)[:, 0], me, 1e-8, "converged means vs the sparse solve")
+    assert dev.ref_plan_stats()["plans"] <= 4
+    dev.close(); jac.close()
+
+
+def test_partial_requests_in_the_callers_order(hip_lib):
+    model = _models()["grid8x9"]
+    E, dev = _start(model)
+    rng = np.random.default_rng(1)
+    for call in range(4):
+        if call:
+            _set_priors(dev, E, model)
+        request = rng.permutation(model.x_ids)[: 20 + 10 * call]
+        dev.sweep_for(request)
+        E.update_marginals(request)
+        assert dev.ref_trace() == _oracle_trace(E)
+        _compare(dev, E, model, request, f"partial request {call + 1}")
+    dev.close()
+
+
+@pytest.mark.parametrize("T", [1, 3, 200])
+def test_the_reference_state_space_model(hip_lib, T):
+    """test/inference_engine_tests.jl:379-488: one call is the Kalman smoother; a second call finds nothing pending"""
+    model = cx.synth.ssm_chain(T, seed=4, random_variances=True)
+    E = engine_oracle_from_model(model, trace=True)
+    dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(model, dev)
+    dev.sweep(1)
+    E.update_marginals(model.x_ids)
+    assert dev.ref_trace() == _oracle_trace(E)
+    _compare(dev, E, model, model.x_ids, f"chain T={T}")
+    xm, xv = exact.ssm_chain_posterior(model.data_y, model.meta["r"], model.meta["q"])
+    marg = dev.get_marginals(model.x_ids)
+    assert_close(marg[:, 0], xm, 1e-9, "smoother mean"); assert_close(marg[:, 1], xv, 1e-9, "smoother variance")
+    assert dev.ref_plan_stats()["executions"] == 5 * T - 4 + T
+    dev.sweep(1)
+    assert dev.ref_plan_stats()["executions"] == 0
+    # new data for one observation: the reference recomputes what depends on it and is requested — here too
+    y0 = model.data_y[:1] + 1.0
+    dev.set_messages(model.data_var[:1], model.data_fac[:1], L.TO_FACTOR, L.FORM_POINT, y0)
+    E.set_messages_to_factor(model.data_var[:1], model.data_fac[:1], y0, tag=ref.REAL)
+    dev.sweep(1)
+    E.update_marginals(model.x_ids)
+    assert dev.ref_trace() == _oracle_trace(E)
+    _compare(dev, E, model, model.x_ids, f"chain T={T}, new datum")
+    dev.close()
+
+
+def test_a_plugin_driving_the_same_handle_moves_the_shadow(hip_lib):
+    """per-signal process! calls through cx_update_batch are set_value!s on the shadow too: after a call run signal by signal by the host
+    scheduler, a cx_sweep finds nothing pending; with the priors re-set it computes exactly what the reference's next call computes"""
+    from tests.loopy_support import HipBackend, run_calls
+
+    model = _models()["grid8x9"]
+    b = HipBackend("per_signal", schedule=L.SCHED_REFERENCE)
+    executed = run_calls(model, b, n_calls=2)
+    dev = b.proc.dev
+    dev.sweep(1)
+    assert dev.ref_plan_stats()["executions"] == 0
+    dev.set_messages(model.prior_var, model.prior_fac, L.TO_VARIABLE, L.FORM_MOMENT, np.stack([model.prior_mean, model.prior_variance], axis=1))
+    dev.sweep(1)
+    assert dev.ref_plan_stats()["executions"] == executed[1]
+
+
+def test_checkpoint_carries_the_readiness_state(hip_lib):
+    model = _models()["hubs"]
+    E, dev = _start(model)
+    for call in range(2):
+        if call:
+            _set_priors(dev, E, model)
+        dev.sweep(1); E.update_marginals(model.x_ids)
+    blob = dev.export_state()
+    other = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(model, other)
+    other.import_state(blob)
+    for d in (dev, other):
+        d.set_messages(model.prior_var, model.prior_fac, L.TO_VARIABLE, L.FORM_MOMENT, np.stack([model.prior_mean, model.prior_variance], axis=1))
+        d.sweep(1)
+    E.set_messages_to_variable(model.prior_var, model.prior_fac, model.prior_mean, model.prior_variance)
+    E.update_marginals(model.x_ids)
+    assert other.ref_trace() == dev.ref_trace() == _oracle_trace(E)
+    assert np.array_equal(other.get_marginals(model.x_ids), dev.get_marginals(model.x_ids))
+    _compare(other, E, model, model.x_ids, "after the import")
+    dev.close(); other.close()
+
+
+def test_refusals(hip_lib):
+    model = _models()["grid8x9"]
+    dev = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(model, dev, seed_variance=SEED_VARIANCE)
+    with pytest.raises(cx.CortexHipError) as ei:
+        dev.sweep_for(model.x_ids[:3])
+    assert ei.value.code == L.ERR_UNSUPPORTED and "CX_SCHED_REFERENCE" in ei.value.message
+    dev.close()
+    with pytest.raises(cx.CortexHipError) as ei:
+        cx.DeviceGraph(schedule=L.SCHED_REFERENCE, dim=4)
+    assert ei.value.code == L.ERR_UNSUPPORTED
+    dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(model, dev)
+    with pytest.raises(cx.CortexHipError):
+        dev.sweep_for([10 ** 9])
+    with pytest.raises(cx.CortexHipError) as ei:
+        dev.halo_configure_state([], [], [], [])
+    assert ei.value.code == L.ERR_UNSUPPORTED
+    dev.close()

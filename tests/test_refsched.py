@@ -1,0 +1,265 @@
+"""CPU: CX_SCHED_REFERENCE's host logic (cortex.jl_amd/csrc/cx_refsched.h, compiled by g++ into libcortex_hostlogic.so) against the
+restated reference engine (oracle/cortex_ref.c).
+
+(1) ORDER: the shadow scheduler's executions equal the restated engine's trace, signal by signal, over consecutive calls on loopy
+    graphs, trees and chains, for full, partial and reversed requests, with data and priors set in between — bit-exact, as the tier
+    asks of schedule / indexing work.
+(2) LEVELLING: the recorded call, cut into stages, is executed here in numpy with every stage's items reading the values the stage
+    STARTED with (items of a stage run concurrently on the device): no item may read or overwrite what another item of its stage
+    writes, and the values after the last stage equal the restated engine's (moment-form arithmetic, the reference's operation order)
+    — every message and every marginal.
+The same file runs under -fsanitize=address,undefined (tests/test_hostlogic.py collects it with CXH_LIB set)."""
+import numpy as np
+import pytest
+
+import cortex.jl_amd as cx
+from cortex.jl_amd import _lib as L
+from oracle import ref
+from tests.helpers import assert_close, engine_oracle_from_model, random_loopy_model
+from tests.hostlogic import FlatGraph
+
+SEED_VARIANCE = 1e6
+K2F, K2V, KMARG, KPROD, KKARY = L.ITEM_MESSAGE_TO_FACTOR, L.ITEM_MESSAGE_TO_VARIABLE, L.ITEM_INDIVIDUAL_MARGINAL, L.ITEM_PRODUCT_OF_MESSAGES, 32
+KSUM2F, KSUM2P, KSUM2M = 64, 65, 66
+
+
+def _flat(model):
+    g = FlatGraph(model.edge_var, model.edge_fac, model.factor_ids, model.factor_kind, model.factor_var, schedule=L.SCHED_REFERENCE)
+    assert g.status == 0, g.error
+    rc, err = g.ref_build()
+    assert rc == 0, err
+    return g
+
+
+def _oracle_rows(E):
+    rows = []
+    for _r, _v, s, _b, _a in E.trace():
+        k, v, f, lo, hi = E.variant(s)
+        kind = {ref.VAR_MSG_TO_FACTOR: K2F, ref.VAR_MSG_TO_VARIABLE: K2V, ref.VAR_MARGINAL: KMARG, ref.VAR_PRODUCT: KPROD}[k]
+        rows.append((kind, v, f if kind in (K2F, K2V) else 0, lo if kind == KPROD else 0, hi if kind == KPROD else 0))
+    return rows
+
+
+class NumpyDevice:
+    """the device's message store in natural form + the items of cx_kernels.hip: batch_item, executed stage by stage"""
+
+    def __init__(self, g, model):
+        self.g = g
+        self.partner, self.vbase, self.var_off, self.vinfo = g.arr("partner"), g.arr("vbase"), g.arr("var_off"), g.arr("vinfo")
+        self.q = g.arr("q")
+        ns = g.scalar("nslots")
+        self.f2v = np.full((ns, 2), np.nan); self.v2f = np.full((ns, 2), np.nan)
+        self.marg = np.full((g.scalar("nv"), 2), np.nan)
+        self.prod = np.full((max(1, g.ref_scalar("products")), 2), np.nan)
+        self.var_ids, self.edge_var, self.edge_fac = g.arr("var_ids"), g.arr("edge_var"), g.arr("edge_fac_id")
+        self.slot = {}
+        for e in range(len(self.edge_var)):
+            v = self.edge_var[e]
+            self.slot[(int(self.var_ids[v]), int(self.edge_fac[e]))] = int(self.vbase[v] + 256 * (e - self.var_off[v])) if (self.vinfo[v] & 0x0f) != 0x0f else int(self.vbase[v] + e - self.var_off[v])
+
+    def set(self, buf, v, f, mean, variance):
+        getattr(self, buf)[self.slot[(int(v), int(f))]] = (mean / variance, 1.0 / variance)
+
+    def run(self, rec, stage_off, lists):
+        for s in range(len(stage_off) - 1):
+            items = rec[5 * stage_off[s]:5 * stage_off[s + 1]].reshape(-1, 5)
+            reads, writes, new = set(), set(), []
+            for k, idx, v, lo, hi in items:
+                if k == K2F:
+                    deg = self.var_off[v + 1] - self.var_off[v]
+                    src = [("f2v", int(self.vbase[v] + 256 * j)) for j in range(deg)]
+                    src = [t for t in src if t[1] != idx]
+                    dst = ("v2f", int(idx))
+                elif k == K2V:
+                    src, dst = [("v2f", int(self.partner[idx]))], ("f2v", int(idx))
+                elif k == KMARG:
+                    deg = self.var_off[v + 1] - self.var_off[v]
+                    src, dst = [("f2v", int(self.vbase[v] + 256 * j)) for j in range(deg)], ("marg", int(v))
+                elif k in (KSUM2F, KSUM2P, KSUM2M):
+                    src = [("f2v", int(t)) if t >= 0 else ("prod", int(~t)) for t in lists[lo:lo + hi]]
+                    dst = ({KSUM2F: "v2f", KSUM2P: "prod", KSUM2M: "marg"}[int(k)], int(idx))
+                else:
+                    raise AssertionError(f"unexpected item kind {k}")
+                vals = np.array([getattr(self, b)[i] for b, i in src])
+                assert not np.any(np.isnan(vals)), f"stage {s}: an item of kind {k} reads an undefined value"
+                if k == K2V:
+                    xi, w = vals[0]
+                    qq = self.q[idx]
+                    out = (xi, np.inf) if False else ((xi / w) / (1.0 / w + qq), 1.0 / (1.0 / w + qq)) if np.isfinite(w) else (xi / qq, 1.0 / qq)
+                else:
+                    out = tuple(vals.sum(axis=0))
+                reads.update(src); new.append((dst, out))
+                assert dst not in writes, f"stage {s}: two items write {dst}"
+                writes.add(dst)
+            assert not (reads & writes), f"stage {s}: an item reads what another item of the same stage writes: {sorted(reads & writes)[:3]}"
+            for (b, i), out in new:
+                getattr(self, b)[i] = out
+
+    def moment(self, buf, idx):
+        a = getattr(self, buf)[idx]
+        point = np.isinf(a[:, 1])              # a datum is stored as (y, +inf)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return np.where(point, a[:, 0], a[:, 0] / a[:, 1]), np.where(point, 0.0, 1.0 / a[:, 1])
+
+
+def _check_values(dev, E, model, request, what):
+    slots = np.array([dev.slot[(int(v), int(f))] for v, f in zip(model.edge_var, model.edge_fac)])
+    for to_variable, buf in ((True, "f2v"), (False, "v2f")):
+        tags, a, b = E.get_messages(model.edge_var, model.edge_fac, to_variable)
+        m, s = dev.moment(buf, slots)
+        und = tags == ref.UNDEF
+        # (data are point masses: variance 0 on the oracle's side, infinite precision here)
+        assert np.array_equal(np.isnan(s), und), f"{what}: the same {buf} messages are defined"
+        assert_close(m[~und], a[~und], 1e-10, f"{what} {buf} mean")
+        ok = ~und & (tags != ref.REAL)
+        assert_close(s[ok], b[ok], 1e-10, f"{what} {buf} variance")
+    tags, em, ev = E.get_marginals(request)
+    vi = np.searchsorted(dev.var_ids, request)
+    m, s = dev.moment("marg", vi)
+    und = tags == ref.UNDEF
+    assert np.array_equal(np.isnan(s), und), f"{what}: the same marginals are defined"
+    assert_close(m[~und], em[~und], 1e-10, f"{what} marginal mean")
+    assert_close(s[~und], ev[~und], 1e-10, f"{what} marginal variance")
+
+
+def _models():
+    rnd, _ = random_loopy_model(11, 1, nv=60, extra=25)
+    hubs, _ = random_loopy_model(5, 1, nv=40, extra=70)           # degrees up to ~12: segment trees over the CSR tail too
+    return {"grid8x9": cx.synth.gaussian_grid(8, 9, seed=5), "grid17x23": cx.synth.gaussian_grid(17, 23, seed=2), "random": rnd, "hubs": hubs}
+
+
+def _seed(g, E, dev, model):
+    pw = set(int(f) for f, k in zip(model.factor_ids, model.factor_kind) if k == 1)
+    keep = np.array([int(f) in pw for f in model.edge_fac])
+    pv, pf = model.edge_var[keep], model.edge_fac[keep]
+    E.set_messages_to_variable(pv, pf, np.zeros(len(pv)), np.full(len(pv), SEED_VARIANCE))
+    g.ref_set(L.TO_VARIABLE, pv, pf)
+    for v, f in zip(pv, pf):
+        dev.set("f2v", v, f, 0.0, SEED_VARIANCE)
+
+
+def _set_priors(g, E, dev, model):
+    E.set_messages_to_variable(model.prior_var, model.prior_fac, model.prior_mean, model.prior_variance)
+    g.ref_set(L.TO_VARIABLE, model.prior_var, model.prior_fac)
+    for v, f, m, s in zip(model.prior_var, model.prior_fac, model.prior_mean, model.prior_variance):
+        dev.set("f2v", v, f, m, s)
+
+
+@pytest.mark.parametrize("name", ["grid8x9", "grid17x23", "random", "hubs"])
+def test_order_and_levelled_values_on_loopy_graphs(name):
+    model = _models()[name]
+    g = _flat(model)
+    E = engine_oracle_from_model(model, trace=True)
+    dev = NumpyDevice(g, model)
+    _seed(g, E, dev, model)
+    _set_priors(g, E, dev, model)          # engine_oracle_from_model set them on its side already: once more is the same state
+    hashes = []
+    rng = np.random.default_rng(3)
+    for call in range(6):
+        if call:
+            _set_priors(g, E, dev, model)
+        request = model.x_ids if call < 4 else rng.permutation(model.x_ids)[: len(model.x_ids) // 2]
+        hashes.append(g.ref_scalar("hash"))
+        rows = g.ref_update(request)
+        E.update_marginals(request)
+        assert [tuple(r[:5]) for r in rows.tolist()] == _oracle_rows(E), f"{name} call {call + 1}: execution order"
+        assert rows[-1, 5] < g.ref_scalar("rounds")
+        rc, err = g.ref_level()
+        assert rc == 0, err
+        rec, off, lists = g.arr("ref_rec"), g.arr("ref_stage_off"), g.arr("ref_list")
+        assert off[-1] == len(rows) and len(rec) == 5 * len(rows)
+        dev.run(rec, off, lists)
+        _check_values(dev, E, model, request, f"{name} call {call + 1}")
+    if name.startswith("grid"):
+        assert hashes[2] == hashes[3], "on a grid the readiness state before a call repeats from the second call on: the plan is reused"
+    assert hashes[0] != hashes[1]
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 40])
+def test_the_reference_state_space_model(T):
+    """test/inference_engine_tests.jl:379-488: one call = the forward and the backward pass; 5T - 4 messages + T marginals"""
+    model = cx.synth.ssm_chain(T, seed=4, random_variances=True)
+    g = _flat(model)
+    E = engine_oracle_from_model(model, trace=True)
+    dev = NumpyDevice(g, model)
+    g.ref_set(L.TO_FACTOR, model.data_var, model.data_fac)
+    for v, f, y in zip(model.data_var, model.data_fac, model.data_y):
+        dev.v2f[dev.slot[(int(v), int(f))]] = (y, np.inf)
+    for call in range(2):
+        rows = g.ref_update(model.x_ids)
+        E.update_marginals(model.x_ids)
+        assert [tuple(r[:5]) for r in rows.tolist()] == _oracle_rows(E)
+        if call == 0:
+            assert len(rows) == 5 * T - 4 + T
+            rc, err = g.ref_level()
+            assert rc == 0, err
+            off = g.arr("ref_stage_off")
+            dev.run(g.arr("ref_rec"), off, g.arr("ref_list"))
+            _check_values(dev, E, model, model.x_ids, f"chain T={T}")
+            if T > 2:
+                assert len(off) - 1 <= 4 * T, "stages grow with the depth of the dependency chains, not with the number of messages"
+        else:
+            assert len(rows) == 0, "a second call without new data computes nothing (lazy)"
+
+
+def test_trees_partial_requests_compute_only_what_they_need():
+    model, _ = random_loopy_model(9, 1, nv=60, extra=-1)          # the spanning tree alone
+    g = _flat(model)
+    E = engine_oracle_from_model(model, trace=True)
+    dev = NumpyDevice(g, model)
+    _set_priors(g, E, dev, model)
+    first = model.x_ids[:3]
+    rows = g.ref_update(first)
+    E.update_marginals(first)
+    assert [tuple(r[:5]) for r in rows.tolist()] == _oracle_rows(E)
+    n_first = len(rows)
+    rc, err = g.ref_level()
+    assert rc == 0, err
+    dev.run(g.arr("ref_rec"), g.arr("ref_stage_off"), g.arr("ref_list"))
+    _check_values(dev, E, model, first, "tree, three marginals")
+    rows = g.ref_update(model.x_ids[::-1])
+    E.update_marginals(model.x_ids[::-1])
+    assert [tuple(r[:5]) for r in rows.tolist()] == _oracle_rows(E)
+    assert 0 < n_first < n_first + len(rows)
+    # (a request for three variables of a tree computes what is pending for THEM: the messages next to the leaves; their marginals stay
+    # undefined until a request walks the rest of the tree — the reference's laziness, reproduced, not repaired)
+    rc, err = g.ref_level()
+    assert rc == 0, err
+    dev.run(g.arr("ref_rec"), g.arr("ref_stage_off"), g.arr("ref_list"))
+    _check_values(dev, E, model, model.x_ids[::-1], "tree, the rest in reverse order")
+
+
+def test_wiring_equals_the_restated_resolver():
+    """dependency lists, in order, with the intermediate flags: dependencies.jl:17-173 on a graph with hubs"""
+    model = _models()["hubs"]
+    g = _flat(model)
+    E = engine_oracle_from_model(model)
+    dep_off, dep, inter = g.arr("ref_dep_off"), g.arr("ref_dep"), g.arr("ref_dep_inter")
+    ne, nv = g.scalar("ne"), g.scalar("nv")
+    var_ids, edge_var, edge_fac = g.arr("var_ids"), g.arr("edge_var"), g.arr("edge_fac_id")
+    rows = g.ref_update([])          # nothing requested, nothing computed
+    assert len(rows) == 0
+
+    def key_of(s):
+        if s < ne:
+            return (ref.VAR_MSG_TO_FACTOR, int(var_ids[edge_var[s]]), int(edge_fac[s]))
+        if s < 2 * ne:
+            return (ref.VAR_MSG_TO_VARIABLE, int(var_ids[edge_var[s - ne]]), int(edge_fac[s - ne]))
+        if s < 2 * ne + nv:
+            return (ref.VAR_MARGINAL, int(var_ids[s - 2 * ne]), 0)
+        return None
+
+    def okey(sig):
+        k, v, f, lo, hi = E.variant(sig)
+        return (k, v, f if k in (ref.VAR_MSG_TO_FACTOR, ref.VAR_MSG_TO_VARIABLE) else 0) if k != ref.VAR_PRODUCT else None
+
+    checked = 0
+    for e in range(ne):
+        v, f = int(var_ids[edge_var[e]]), int(edge_fac[e])
+        for s, osig in ((e, E.message_to_factor(v, f)), (ne + e, E.message_to_variable(v, f))):
+            mine = [key_of(int(d)) for d in dep[dep_off[s]:dep_off[s + 1]]]
+            theirs = [okey(d) for d in E.dependencies(osig)]
+            assert mine == theirs, (v, f)
+            checked += len(mine)
+    assert checked > 0 and g.ref_scalar("products") > 0
+    assert g.ref_scalar("dependencies") == len(dep) and set(np.unique(inter)) <= {0, 1}
