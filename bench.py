@@ -383,7 +383,49 @@ def config_parity(device: int = 0) -> dict:
                 "(test/inference_engine_tests.jl:593-1147), pinned call by call against the restated engine",
                 "sample": f"n={n} states, 6 iterations (states, then both precisions), every marginal after every call"}
 
-    for key, fn in (("C3", lambda: flooding(4, 2000, 8, 0)), ("C5", c5_fixed_point),
+    def reference_order(n=320, calls=3):
+        """CX_SCHED_REFERENCE against the restated reference engine, call by call: the executions in order, every message of both
+        directions, every marginal (the full-size check, two calls at 1415 x 1415: tests/test_gpu_reference_schedule.py)"""
+        from oracle import ref
+        from tests.helpers import engine_oracle_from_model
+        model = cx.synth.gaussian_grid(n, n, seed=77)
+        E = engine_oracle_from_model(model, trace=True)
+        dev = cx.DeviceGraph(device=device, schedule=L.SCHED_REFERENCE)
+        cx.synth.load_into_device(model, dev, seed_variance=1e6)
+        pw = model.factor_kind[np.searchsorted(model.factor_ids, model.edge_fac)] == 1
+        E.set_messages_to_variable(model.edge_var[pw], model.edge_fac[pw], np.zeros(pw.sum()), np.full(pw.sum(), 1e6))
+        kinds = {ref.VAR_MSG_TO_FACTOR: L.ITEM_MESSAGE_TO_FACTOR, ref.VAR_MSG_TO_VARIABLE: L.ITEM_MESSAGE_TO_VARIABLE, ref.VAR_MARGINAL: L.ITEM_INDIVIDUAL_MARGINAL}
+        worst, same_order = 0.0, True
+        for call in range(calls):
+            if call:
+                E.set_messages_to_variable(model.prior_var, model.prior_fac, model.prior_mean, model.prior_variance)
+                dev.set_messages(model.prior_var, model.prior_fac, L.TO_VARIABLE, L.FORM_MOMENT, np.stack([model.prior_mean, model.prior_variance], axis=1))
+            dev.sweep(1)
+            E.update_marginals(model.x_ids)
+            if call == calls - 1:      # the engine's trace, signal by signal (a Python loop over ~1e6 executions: once)
+                want = []
+                for _r, _v, s, _b, _a in E.trace():
+                    k, v, f, _lo, _hi = E.variant(s)
+                    want.append((kinds[k], v, f if k != ref.VAR_MARGINAL else 0, 0, 0))
+                same_order = dev.ref_trace() == want
+            for to_variable, direction in ((True, L.TO_VARIABLE), (False, L.TO_FACTOR)):
+                tags, a, b = E.get_messages(model.edge_var, model.edge_fac, to_variable)
+                got = dev.get_messages(model.edge_var, model.edge_fac, direction)
+                und = tags == ref.UNDEF
+                if not np.array_equal(np.isnan(got[:, 1]), und):
+                    worst = float("inf")
+                else:
+                    worst = max(worst, _rel_err(got[~und, 0], a[~und]), _rel_err(got[~und, 1], b[~und]))
+            _t, em, ev = E.get_marginals(model.x_ids)
+            marg = dev.get_marginals(model.x_ids)
+            worst = max(worst, _rel_err(marg[:, 0], em), _rel_err(marg[:, 1], ev))
+        dev.close()
+        return {"max_rel_err": worst if same_order else float("inf"), "tolerance": 1e-9, "execution_order_identical": bool(same_order),
+                "checker": "oracle/cortex_ref.c: the reference's InferenceEngine restated (Signals, readiness nibbles, default resolver, update_marginals!) with the "
+                           "reference's own moment-form rules (test/inference_engine_tests.jl:385-432)",
+                "sample": f"{n}x{n} grid, {calls} consecutive calls with the priors re-set in between: the execution trace of the last call, every message of both directions and every marginal after every call"}
+
+    for key, fn in (("C3", lambda: flooding(4, 2000, 8, 0)), ("C5", c5_fixed_point), ("C4-reference", reference_order),
                     ("VMP structured", lambda: vmp_family("structured", L.FAMILY_VMP_STRUCTURED)),
                     ("VMP mean_field", lambda: vmp_family("mean_field", L.FAMILY_VMP_MEAN_FIELD))):
         try:
@@ -409,6 +451,9 @@ def other_configs(parity=None) -> list:
                      ("C3-scan", lambda: bc.mv_scan(4, 1_000_000, 30, check=hooks.get("C3-scan"))[0]),
                      ("C5", lambda: bc.mv(64, 100_000, 12)), ("C5-scan", lambda: bc.mv64_scan(100_000, 8, check=hooks.get("C5-scan"))[0]),
                      ("VMP", lambda: bc.vmp()),
+                     # the headline graph under the reference's OWN order: one cx_sweep = one update_marginals! (sequential, newest values):
+                     # stage count, ms per call, calls to the fixed point beside the fused schedule's sweeps
+                     ("C4-reference", lambda: bc.reference_order(1415)),
                      # not a BASELINE config: the tree schedule (one sweep = the reference's one-call result on any forest), on a tree small
                      # enough to generate in a second
                      ("tree", lambda: bc.tree(n_factors=30_000, steps=20)),
@@ -859,6 +904,8 @@ def run_rank(args):
                     traffic_src = tr.get("source")
                 elif tr.get("kernel") == dom_name:
                     traffic_src = "REFUSED: profiles/traffic_latest.json was measured on another version of the kernel's sources (tools/profile_round.sh)"
+                    print("[bench] STALE PROFILE: profiles/traffic_latest.json was measured on another version of cx_kernels.hip — the headline's roofline falls back "
+                          "to algorithmic bytes until tools/profile_round.sh is re-run and its summary copied into profiles/", file=sys.stderr, flush=True)
             except Exception:
                 pass
         achieved_alg = alg_bytes / (avg_ms * 1e-3) / 1e9

@@ -61,10 +61,10 @@ inline int32_t ensure_stage(cx_handle *h, int64_t bytes) {
 }
 
 // (variable_id, factor_id) -> edge index; edges are sorted by (variable, factor)
+inline int64_t find_var(const cx_handle *h, int64_t var_id);
 inline int64_t find_edge(const cx_handle *h, int64_t var_id, int64_t fac_id) {
-    auto it = std::lower_bound(h->var_ids.begin(), h->var_ids.end(), var_id);
-    if (it == h->var_ids.end() || *it != var_id) return -1;
-    int64_t v = it - h->var_ids.begin();
+    const int64_t v = find_var(h, var_id);
+    if (v < 0) return -1;
     auto b = h->edge_fac_id.begin() + h->var_off[v], e = h->edge_fac_id.begin() + h->var_off[v + 1];
     auto jt = std::lower_bound(b, e, fac_id);
     if (jt == e || *jt != fac_id) return -1;
@@ -72,6 +72,8 @@ inline int64_t find_edge(const cx_handle *h, int64_t var_id, int64_t fac_id) {
 }
 
 inline int64_t find_var(const cx_handle *h, int64_t var_id) {
+    // ids handed out by one counter (BipartiteFactorGraphs add_variable!) are often 1, 2, 3, ...: look there first
+    if (var_id >= 1 && var_id <= (int64_t)h->var_ids.size() && h->var_ids[var_id - 1] == var_id) return var_id - 1;
     auto it = std::lower_bound(h->var_ids.begin(), h->var_ids.end(), var_id);
     if (it == h->var_ids.end() || *it != var_id) return -1;
     return it - h->var_ids.begin();

@@ -803,7 +803,7 @@ void chain64_stats(const cx_handle *h, int64_t *out8) {
     for (int i = 0; i < 8; i++) out8[i] = 0;
     if (!c) return;
     out8[0] = c->K0; out8[1] = c->fan; out8[2] = c->levels; out8[3] = c->n_pot; out8[4] = c->n_compositions; out8[5] = c->n_rules;
-    for (const auto &L : c->launches) out8[6] += L.kind == 0 ? 1 : L.steps;
+    out8[6] = (int64_t)c->launches.size() + (c->n_aux > 0 ? 1 : 0);      // kernel launches per sweep: a walk loops over its steps INSIDE one launch (chain64_run); + k_side64
     out8[7] = c->bytes;
 }
 

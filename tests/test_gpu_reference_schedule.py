@@ -211,3 +211,35 @@ def test_refusals(hip_lib):
         dev.halo_configure_state([], [], [], [])
     assert ei.value.code == L.ERR_UNSUPPORTED
     dev.close()
+
+
+def test_config_c4_full_size_two_calls(hip_lib):
+    """BASELINE config C4 itself (1415 x 1415, 10,005,465 edges) under the reference's order: two consecutive calls against the restated
+    engine at full size — 16,006,480 message executions + 2,002,225 marginals per call; every marginal, 400,000 sampled messages of
+    each direction.  (The engine restatement takes ~30 s to wire 22 M signals and ~2 s per call on one core.)"""
+    n = 1415
+    model = cx.synth.gaussian_grid(n, n, seed=1234)
+    E = engine_oracle_from_model(model)
+    dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(model, dev, seed_variance=SEED_VARIANCE)
+    pv, pf = pairwise_edges(model)
+    E.set_messages_to_variable(pv, pf, np.zeros(len(pv)), np.full(len(pv), SEED_VARIANCE))
+    pick = np.random.default_rng(0).choice(len(pv), 400_000, replace=False)
+    for call in range(2):
+        if call:
+            _set_priors(dev, E, model)
+        c0 = E.counters()
+        dev.sweep(1)
+        E.update_marginals(model.x_ids)
+        st = dev.ref_plan_stats()
+        c1 = E.counters()
+        assert st["messages"] == c1[0] - c0[0] == 16_006_480 and st["executions"] - st["messages"] == c1[1] - c0[1] == n * n
+        for to_variable, direction in ((True, L.TO_VARIABLE), (False, L.TO_FACTOR)):
+            _tags, a, b = E.get_messages(pv[pick], pf[pick], to_variable)
+            got = dev.get_messages(pv[pick], pf[pick], direction)
+            assert_close(got[:, 0], a, 1e-9, f"C4 call {call + 1} message mean"); assert_close(got[:, 1], b, 1e-9, f"C4 call {call + 1} message variance")
+        _t, em, ev = E.get_marginals(model.x_ids)
+        marg = dev.get_marginals(model.x_ids)
+        assert_close(marg[:, 0], em, 1e-9, f"C4 call {call + 1} marginal mean"); assert_close(marg[:, 1], ev, 1e-9, f"C4 call {call + 1} marginal variance")
+    assert 5_000 < st["stages"] < 6_500
+    dev.close()

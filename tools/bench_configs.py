@@ -31,7 +31,7 @@ def counter_traffic(kernel_substr):
     from importlib import import_module
     sha = import_module("cortex.jl_amd.build").sources_sha16
     subs = [kernel_substr] if isinstance(kernel_substr, str) else list(kernel_substr)
-    best = None
+    best, stale = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_configs_rocprof.json")) + glob.glob(os.path.join(ROOT, "profiles", "r*_vmp_rocprof.json"))):
         try:
             d = json.load(open(f))
@@ -39,10 +39,18 @@ def counter_traffic(kernel_substr):
             continue
         hit = {k: v for k, v in d.get("traffic", {}).items() if any(x in k for x in subs)}
         # a figure measured on another version of the kernel is no figure: the summary stores a hash of the kernel's sources
-        if not hit or any(v.get("sources_sha16") != sha(k) for k, v in hit.items()):
+        if not hit:
+            continue
+        if any(v.get("sources_sha16") != sha(k) for k, v in hit.items()):
+            stale = os.path.relpath(f, ROOT)
             continue
         # several kernels (one launch of each per sweep): their sum; `launches_per_sweep` when a kernel runs more than once
         best = (sum(v["hbm_bytes_per_launch"] * v.get("launches_per_sweep", 1) for v in hit.values()), os.path.relpath(f, ROOT))
+    if best is None and stale is not None:
+        # LOUD: a row of the driver's line is about to lose its counter-based fraction because the kernel changed after the last profile
+        print(f"[bench] STALE PROFILE: the counter traffic of {subs} in {stale} was measured on another version of the kernel's sources — "
+              f"its roofline row gets frac = null until tools/profile_configs.sh (profile_vmp.sh) is re-run and the summary copied into profiles/",
+              file=sys.stderr, flush=True)
     return best
 
 
@@ -362,10 +370,84 @@ def tree_mv(d=4, n_spine=200_000):
                        "sample": f"{len(ids)} marginals"}}
 
 
+def reference_order(n=1415, calls_timed=5, tol=1e-9, max_calls=400, check=None, fixed_point=True):
+    """C4 under CX_SCHED_REFERENCE: ONE cx_sweep = ONE update_marginals! of the reference on the loopy grid (the same executions in the
+    same order, csrc/cx_refsched.h).  Reported: the plan (stages, launches, executions), the host's one-off cost of finding it, ms per
+    call when a standing plan is replayed, and how many calls / fused sweeps it takes until no message moves by more than `tol` —
+    the sequential pass reads new values and needs fewer iterations, each of which costs thousands of dependent stages."""
+    model = cx.synth.gaussian_grid(n, n, seed=1234)
+    prior = np.stack([model.prior_mean, model.prior_variance], axis=1)
+    dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+    t0 = time.perf_counter()
+    cx.synth.load_into_device(model, dev, seed_variance=1e6)
+    t_load = time.perf_counter() - t0
+    plan_s = []
+    for _ in range(2):          # the first call starts from the seeded state, the second from the state every later call starts from
+        t0 = time.perf_counter()
+        dev.sweep(1); dev.sync()
+        plan_s.append(time.perf_counter() - t0)
+        dev.set_messages(model.prior_var, model.prior_fac, L.TO_VARIABLE, L.FORM_MOMENT, prior)
+    t_call, t_set = [], []
+    for _ in range(calls_timed):
+        dev.sync()
+        t0 = time.perf_counter()
+        dev.sweep(1); dev.sync()
+        t_call.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        dev.set_messages(model.prior_var, model.prior_fac, L.TO_VARIABLE, L.FORM_MOMENT, prior)
+        t_set.append(time.perf_counter() - t0)
+    st = dev.ref_plan_stats()
+    parity = check(dev, model) if check else None
+    out = {"config": "C4-reference", "workload": f"{n}x{n} Gaussian grid ({len(model.edge_var)} edges), CX_SCHED_REFERENCE: one cx_sweep = one update_marginals! of the reference (sequential order, newest values)",
+           "ms_per_call": float(np.median(t_call)) * 1e3, "plan": st, "executions_per_call": st["executions"], "messages_per_s": st["messages"] / float(np.median(t_call)),
+           "host": {"graph_upload_and_wiring_s": t_load, "first_two_calls_s_scheduler_levelling_upload_capture": plan_s,
+                    "re_setting_the_priors_s_per_call": float(np.median(t_set))},
+           "roofline": roofline("hbm", st["messages"] * 32 / float(np.median(t_call)) / 1e9, HBM_PEAK_GBS, "GB/s", None,
+                                kernel="k_batch / k_batch_run, one launch per stage or run of thin stages",
+                                basis="algorithmic bytes (32 B per message, SURVEY §8d) / call time", frac_algorithmic=st["messages"] * 32 / float(np.median(t_call)) / 1e9 / HBM_PEAK_GBS,
+                                frac_note="a latency-bound schedule by construction: the reference's order is sequential, its dependency depth is the stage count",
+                                bound_detail=f"{st['stages']} dependent stages in {st['launches']} launches (≈ {float(np.median(t_call)) / max(st['stages'], 1) * 1e6:.2f} us per stage)")}
+    if parity:
+        out["parity"] = parity
+    if fixed_point:
+        # calls until no message moves by more than tol (cx_residual between consecutive calls), beside the fused schedule's sweeps
+        fresh = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+        cx.synth.load_into_device(model, fresh, seed_variance=1e6)
+        fresh.residual()
+        calls, res = 0, float("inf")
+        while calls < max_calls and not res <= tol:
+            if calls:
+                fresh.set_messages(model.prior_var, model.prior_fac, L.TO_VARIABLE, L.FORM_MOMENT, prior)
+            fresh.sweep(1)
+            calls += 1
+            res = fresh.residual()
+        fused = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+        cx.synth.load_into_device(model, fused, seed_variance=1e6)
+        fused.residual()
+        sweeps, resf = 0, float("inf")
+        while sweeps < 4 * max_calls and not resf <= tol:
+            fused.sweep(1)
+            sweeps += 1
+            resf = fused.residual()
+        dtf = timed(fused, lambda: fused.sweep(1), 20, 2)
+        ids = model.x_ids[:: max(len(model.x_ids) // 200_000, 1)]
+        a, b = fresh.get_marginals(ids), fused.get_marginals(ids)
+        out["to_the_fixed_point"] = {"tolerance_max_abs_change_of_a_message": tol, "reference_order_calls": calls, "fused_sweeps": sweeps,
+                                     "reference_order_ms": calls * out["ms_per_call"], "fused_ms": sweeps * dtf * 1e3, "fused_ms_per_sweep": dtf * 1e3,
+                                     "marginals_agree_to": float(np.nanmax(np.abs(a - b) / np.maximum(np.abs(b), np.median(np.abs(b)))))}
+        fresh.close(); fused.close()
+    dev.close()
+    return out
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c2", "c3", "c5"]
     torch.cuda.init()
     for w in which:
+        if w.startswith("reference"):                    # reference | reference:300 (grid side)
+            parts = w.split(":")                           # reference:1415:nofp skips the iteration to the fixed point
+            print(json.dumps(reference_order(n=int(parts[1]) if len(parts) > 1 else 1415, fixed_point="nofp" not in parts)), flush=True)
+            continue
         if w.startswith("vmp"):
             for r in vmp(only=w[4:] or None):          # vmp | vmp_structured | vmp_mean_field
                 print(json.dumps(r), flush=True)
