@@ -73,6 +73,7 @@ SIGNATURES = {
     "cx_get_joint_marginals": (_i32, [_vp, _i64, _pi64, _pd]),
     "cx_sweep": (_i32, [_vp, _i32]),
     "cx_sweep_for": (_i32, [_vp, _i64, _pi64]),
+    "cx_set_damping": (_i32, [_vp, _dbl]),
     "cx_ref_plan_stats": (_i32, [_vp, _pi64]),
     "cx_ref_trace": (_i32, [_vp, _i64, C.POINTER(Item), _pi64]),
     "cx_residual": (_i32, [_vp, _pd]),

@@ -550,6 +550,23 @@ int32_t cx_chain_plan_stats(const cx_handle *h, int64_t *out8) {
     return CX_OK;
 }
 
+// Damped message passing: loopy Gaussian BP outside the walk-summable regime can oscillate; mixing every new factor→variable message
+// with the one it replaces is the usual remedy.  The reference has no such knob (its rules are the user's: a user damps inside the
+// rule); here the rules are the library's, so the knob is too.
+int32_t cx_set_damping(cx_handle *h, double lambda) {
+    CX_NOT_VMP(h, "cx_set_damping");
+    CX_REQUIRE(h, h, CX_ERR_INVALID_ARGUMENT, "null handle");
+    CX_REQUIRE(h, lambda >= 0.0 && lambda < 1.0, CX_ERR_INVALID_ARGUMENT, "cx_set_damping: 0 <= lambda < 1");
+    CX_REQUIRE(h, lambda == 0.0 || h->cfg.schedule == CX_SCHED_FUSED || h->cfg.schedule == CX_SCHED_FLOODING, CX_ERR_UNSUPPORTED,
+               "cx_set_damping: the fused and flooding schedules iterate to a fixed point and can be damped; the chain-scan, tree and reference-order schedules are exact or sequential passes");
+    CX_REQUIRE(h, lambda == 0.0 || (h->cfg.dim >= 1 && h->cfg.dim <= 4), CX_ERR_UNSUPPORTED, "cx_set_damping: dim 1 to 4");
+    CX_REQUIRE(h, lambda == 0.0 || h->halo_state || (h->send_slots.empty() && h->recv_slots.empty()), CX_ERR_UNSUPPORTED,
+               "cx_set_damping: not with per-sweep message halos (cx_halo_configure); state halos (cx_halo_configure_state) run plain sweeps and are damped like them");
+    CX_HIP(h, hipStreamSynchronize(h->stream));
+    h->damping = lambda;
+    return CX_OK;
+}
+
 int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
     CX_NOT_VMP(h, "cx_sweep");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep: no graph");
@@ -576,7 +593,7 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
     // pairs of sweeps as ONE launch each (cx_tiles.hip), when the schedule and the graph allow it
     // (opt-in: measured SLOWER than single sweeps on MI355X, see DESIGN.md §4c — kept as a tested experiment, not the default)
     const bool want_pairs = n_sweeps >= 2 && h->cfg.schedule == CX_SCHED_FUSED && h->cfg.sweeps_per_launch == 2 &&
-                            h->cfg.family == CX_FAMILY_GAUSSIAN && h->cfg.materialize_messages_to_factor == 0 && h->n_kary == 0 && tiled_env_enabled();
+                            h->cfg.family == CX_FAMILY_GAUSSIAN && h->cfg.materialize_messages_to_factor == 0 && h->n_kary == 0 && h->damping == 0.0 && tiled_env_enabled();
     if (want_pairs && h->tiles_state == 0) {
         std::string why;
         if (!cx::tiles_build(h, why)) h->tiles_state = -1;
@@ -635,6 +652,7 @@ int32_t cx_sweep_begin(cx_handle *h) {
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep_begin: no graph");
     CX_REQUIRE(h, h->cfg.dim == 1, CX_ERR_UNSUPPORTED, "cx_sweep_begin: partitioned sweeps are implemented for dim == 1 only in this build");
     CX_REQUIRE(h, !h->in_sweep, CX_ERR_STATE, "cx_sweep_begin: previous sweep not ended");
+    CX_REQUIRE(h, h->damping == 0.0, CX_ERR_UNSUPPORTED, "cx_sweep_begin: damped sweeps (cx_set_damping) are not split into begin / main / end");
     CX_REQUIRE(h, !h->halo_state, CX_ERR_STATE, "cx_sweep_begin: the handle is configured for state halos (cx_halo_configure_state): use cx_sweep + cx_halo_state_exchange");
     CX_REQUIRE(h, h->cfg.schedule != CX_SCHED_CHAIN_SCAN && h->cfg.schedule != CX_SCHED_TREE && h->cfg.schedule != CX_SCHED_REFERENCE, CX_ERR_UNSUPPORTED, "cx_sweep_begin: the chain-scan, tree and reference-order schedules are not partitioned in this build");
     cx::launch_halo_export(h, h->d_f2v, h->stream);

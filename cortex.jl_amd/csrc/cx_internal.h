@@ -190,6 +190,7 @@ struct cx_handle {
     bool ipc_fused = false;          // cx_halo_ipc_set_fused: push and unpack of an exchange as ONE launch (every neighbour pushes from another device)
     int ipc_quiet_lo = 1, ipc_quiet_hi = 0;   // the longest run of owned-only slices none of whose variables WRITES a message of the send list
                                               // (cx_halo_ipc_batch: that run of the last sweep is computed after the push); empty: none
+    double damping = 0.0;            // cx_set_damping: new = (1 - damping) rule + damping old (fused and flooding sweeps)
     bool in_sweep = false;
     bool v2f_stale = false;          // fused schedule without materialisation: v2f must be recomputed before use
     int mv_max_deg = 0;              // dim 2..4: widest slice of the graph (0: not computed yet)

@@ -28,7 +28,8 @@ namespace cx {
 namespace {
 
 __global__ __launch_bounds__(kBlock) void k_factor_kary(int nrows, const int32_t *__restrict__ kslot, const double *__restrict__ kcoef,
-                                                        const double *__restrict__ kqb, const double2 *__restrict__ v2f, double2 *__restrict__ f2v) {
+                                                        const double *__restrict__ kqb, const double2 *__restrict__ v2f, double2 *__restrict__ f2v,
+                                                        const double2 *__restrict__ prev, double lam) {
     const int t = blockIdx.x * kBlock + threadIdx.x, row = t >> 3, e = t & 7;
     if (row >= nrows) return;                                   // whole groups of eight leave together
     const int slot = kslot[t];
@@ -49,7 +50,12 @@ __global__ __launch_bounds__(kBlock) void k_factor_kary(int nrows, const int32_t
     if (slot < 0) return;
     const double mean = (kqb[2 * row + 1] - sm) / c, var = (kqb[2 * row] + sv) / (c * c);
     if (__builtin_isnan(mean) || __builtin_isnan(var)) return;  // a dependency is undefined: the signal is not pending
-    f2v[slot] = kary_natural(mean, var);
+    double2 r = kary_natural(mean, var);
+    if (lam != 0.0) {                                           // cx_set_damping: against the message this one replaces
+        const double2 old = prev[slot];
+        if (!__builtin_isnan(old.y)) r = make_double2((1.0 - lam) * r.x + lam * old.x, (1.0 - lam) * r.y + lam * old.y);
+    }
+    f2v[slot] = r;
 }
 
 // cx_update_batch: MessageToVariable items of such factors, one thread per item (entry = 8 * row + edge position)
@@ -121,7 +127,7 @@ void launch_kary(cx_handle *h, const double2 *v2f, double2 *f2v_out) {
     if (h->n_kary == 0) return;
     const int64_t threads = 8 * h->n_kary;
     hipLaunchKernelGGL(k_factor_kary, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, (int)h->n_kary, h->d_kary_slot,
-                       h->d_kary_coef, h->d_kary_qb, v2f, f2v_out);
+                       h->d_kary_coef, h->d_kary_qb, v2f, f2v_out, (const double2 *)h->d_f2v, h->damping);      // d_f2v: the sweep's input buffer (flooding: in place)
 }
 
 void launch_kary_link_params(cx_handle *h, int64_t link_lo, int64_t nlinks, double *a, double *b) {

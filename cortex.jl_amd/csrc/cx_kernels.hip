@@ -89,6 +89,12 @@ __device__ __forceinline__ double2 factor_rule(double2 m, double q, double a, do
     return o;
 }
 
+// damping (cx_set_damping): new = (1 - lambda) rule + lambda old, in natural form; an old value that is undefined does not damp
+__device__ __forceinline__ double2 damped(double2 r, double2 old, double lam) {
+    if (__builtin_isnan(old.y)) return r;
+    return make_double2((1.0 - lam) * r.x + lam * old.x, (1.0 - lam) * r.y + lam * old.y);
+}
+
 __device__ __forceinline__ double2 to_moment(double2 nat) {
     double var = 1.0 / nat.y;
     return make_double2(nat.x * var, var);
@@ -102,10 +108,11 @@ __device__ __forceinline__ double2 to_moment(double2 nat) {
 //          grid-like graphs)
 constexpr int kPackPartner16 = 1, kPackQLow = 2;
 constexpr int16_t kNoPartner16 = -32768;
-template <int MODE, bool STORE_V2F, bool PUSH, int PACK = 0>
+template <int MODE, bool STORE_V2F, bool PUSH, int PACK = 0, bool DAMP = false>
 __device__ __forceinline__ void emit(int slot, double2 o, const int32_t *__restrict__ partner, const double *__restrict__ sq,
                                      const double *__restrict__ sa, const double *__restrict__ sb, double2 *__restrict__ f2v_out,
-                                     double2 *__restrict__ v2f, int nt_out = 0, const int16_t *__restrict__ partner16 = nullptr) {
+                                     double2 *__restrict__ v2f, int nt_out = 0, const int16_t *__restrict__ partner16 = nullptr,
+                                     const double2 *__restrict__ prev = nullptr, double lam = 0.0) {
     if (__builtin_isnan(o.y)) return;  // a dependency is undefined: the signal is not pending, keep stored values
     if (STORE_V2F) v2f[slot] = o;
     if (PUSH) {
@@ -113,7 +120,8 @@ __device__ __forceinline__ void emit(int slot, double2 o, const int32_t *__restr
         if (PACK & kPackPartner16) { const int dlt = partner16[slot]; p = dlt == kNoPartner16 ? -1 : slot + dlt; }
         else p = partner[slot];
         if (p >= 0) {
-            const double2 r = factor_rule<MODE>(o, sq[(PACK & kPackQLow) ? (p < slot ? p : slot) : slot], MODE == kRuleLinear ? sa[slot] : 1.0, MODE == kRuleLinear ? sb[slot] : 0.0);
+            double2 r = factor_rule<MODE>(o, sq[(PACK & kPackQLow) ? (p < slot ? p : slot) : slot], MODE == kRuleLinear ? sa[slot] : 1.0, MODE == kRuleLinear ? sb[slot] : 0.0);
+            if (DAMP && !__builtin_isnan(r.y)) r = damped(r, prev[p], lam);      // the message this one replaces: the receiving slot in the sweep's input buffer
             if (MODE != kRuleBernoulli || !__builtin_isnan(r.y)) { if (nt_out) store_stream(&f2v_out[p], r); else f2v_out[p] = r; }
         }
     }
@@ -135,20 +143,27 @@ __device__ __forceinline__ void emit(int slot, double2 o, const int32_t *__restr
 // MAXW: the widest slice of the graph rounded up to 5 or 8 (a 2-D grid with one observation per variable has degree 5): the incoming and
 // the outgoing messages of a variable live in 2 x MAXW register pairs, and with five instead of eight the kernel fits 64 registers —
 // eight waves per SIMD instead of six.
-template <int MODE, bool STORE_V2F, bool PUSH, int PACK = 0, int MAXW = kSmallDeg>
+// nt: bit 0 nontemporal scatter stores, bit 1 nontemporal message loads, bit 2 nontemporal marginal stores (chosen by footprint: launchers)
+// (Round 5, measured on the 1/8 strip of C4 and removed again: workgroups of 128 / 64 threads — a quarter-slice each, to spread a launch
+// of 4.5 workgroups per compute unit more evenly: 10.15 / 10.98 us against 10.02; the partner differences and q loaded at the top of
+// the kernel beside the messages, one or two round trips to memory fewer per wave: 11.1 - 11.6 us against 10.0, and 63 - 66 against 56
+// on the whole grid.  profiles/r05_strip.md.)
+constexpr int kNtOut = 1, kNtIn = 2, kNtMarg = 4;
+template <int MODE, bool STORE_V2F, bool PUSH, int PACK = 0, int MAXW = kSmallDeg, bool DAMP = false>
 __global__ __launch_bounds__(kBlock) void k_sweep(int nv, const int32_t *__restrict__ slice_off, const uint8_t *__restrict__ vinfo,
                                                   const int32_t *__restrict__ partner, const double *__restrict__ sq,
                                                   const double *__restrict__ sa, const double *__restrict__ sb,
                                                   const double2 *__restrict__ f2v_in, double2 *__restrict__ f2v_out,
                                                   double2 *__restrict__ v2f, double2 *__restrict__ marg, int write_marg,
-                                                  int skip_ghosts, int nt_out, int slice_lo, int slice_hi, int excl_lo, int excl_hi,
-                                                  const int16_t *__restrict__ partner16) {
+                                                  int skip_ghosts, int nt, int slice_lo, int slice_hi, int excl_lo, int excl_hi,
+                                                  const int16_t *__restrict__ partner16, double lam) {
     // the slice -> XCD mapping stays the same from sweep to sweep (a strip's messages largely live in the L2s between sweeps:
     // launching only the active slice range re-deals the slices over the XCDs and measured 10 % SLOWER); idle slices exit here.
     // [excl_lo, excl_hi]: slices another launch of the same sweep covers (the owned interior, run beside the halo exchange)
     const int s = xcd_slab(blockIdx.x, gridDim.x);
     if (s < slice_lo || s > slice_hi || (s >= excl_lo && s <= excl_hi)) return;
     const int tid = threadIdx.x;
+    const int nt_out = nt & kNtOut;
     const int v = (s << kSliceShift) + tid;
     const int off = slice_off[s];
     const int W = (slice_off[s + 1] - off) >> kSliceShift;  // slice width: workgroup-uniform
@@ -164,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep(int nv, const int32_t *__restr
     for (int k = 0; k < MAXW; k++) {
         in[k] = zero2();
         if (k < W) {  // uniform branch
-            double2 x = load_stream(&f2v_in[base + k * kBlock]);
+            double2 x = (nt & kNtIn) ? load_stream(&f2v_in[base + k * kBlock]) : f2v_in[base + k * kBlock];
             if (k < deg) in[k] = x;
         }
     }
@@ -177,7 +192,10 @@ __global__ __launch_bounds__(kBlock) void k_sweep(int nv, const int32_t *__restr
 #pragma unroll
     for (int k = MAXW - 1; k >= 0; k--) { out[k] = add2(out[k], acc); acc = add2(acc, in[k]); }
 
-    if (write_marg) store_stream(&marg[v], write_marg == 2 ? total : to_moment(total));   // 2: natural-parameter marginals
+    if (write_marg) {                                    // 2: natural-parameter marginals
+        const double2 mg = write_marg == 2 ? total : to_moment(total);
+        if (nt & kNtMarg) store_stream(&marg[v], mg); else marg[v] = mg;
+    }
 
     // a variable with <2 factors has no dependencies on its message to the factor (dependencies.jl:48-55): never
     // computed; observed variables keep the data the caller set.  Their stored message still feeds the factor.
@@ -185,12 +203,12 @@ __global__ __launch_bounds__(kBlock) void k_sweep(int nv, const int32_t *__restr
     if (!fixed) {
 #pragma unroll
         for (int k = 0; k < MAXW; k++)
-            if (k < deg) emit<MODE, STORE_V2F, PUSH, PACK>(base + k * kBlock, out[k], partner, sq, sa, sb, f2v_out, v2f, nt_out, partner16);
+            if (k < deg) emit<MODE, STORE_V2F, PUSH, PACK, DAMP>(base + k * kBlock, out[k], partner, sq, sa, sb, f2v_out, v2f, nt_out, partner16, f2v_in, lam);
     } else if (PUSH) {
         // separate path (not a select on the message) so that out[] never has its address taken
 #pragma unroll
         for (int k = 0; k < MAXW; k++)
-            if (k < deg) emit<MODE, false, true, PACK>(base + k * kBlock, v2f[base + k * kBlock], partner, sq, sa, sb, f2v_out, v2f, 0, partner16);
+            if (k < deg) emit<MODE, false, true, PACK, DAMP>(base + k * kBlock, v2f[base + k * kBlock], partner, sq, sa, sb, f2v_out, v2f, 0, partner16, f2v_in, lam);
     }
 }
 
@@ -201,14 +219,15 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_factor_to_var(int nslots, const int32_t *__restrict__ partner,
                                                           const double *__restrict__ q, const double *__restrict__ pa,
                                                           const double *__restrict__ pb, const double2 *__restrict__ v2f,
-                                                          double2 *__restrict__ f2v) {
+                                                          double2 *__restrict__ f2v, double lam) {
     const int e = xcd_slab(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     if (e >= nslots) return;
     const int p = partner[e];
     if (p < 0) return;
     const double2 m = v2f[p];
     if (__builtin_isnan(m.y)) return;  // dependency not computed: not pending, keep the old value
-    const double2 r = factor_rule<MODE>(m, q[e], MODE == kRuleLinear ? pa[e] : 1.0, MODE == kRuleLinear ? pb[e] : 0.0);
+    double2 r = factor_rule<MODE>(m, q[e], MODE == kRuleLinear ? pa[e] : 1.0, MODE == kRuleLinear ? pb[e] : 0.0);
+    if (lam != 0.0 && !__builtin_isnan(r.y)) r = damped(r, f2v[e], lam);
     if (MODE != kRuleBernoulli || !__builtin_isnan(r.y)) f2v[e] = r;
 }
 
@@ -273,14 +292,15 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_push_slots(const int32_t *__restrict__ slots, int64_t n, const int32_t *__restrict__ partner,
                                                        const double *__restrict__ sq, const double *__restrict__ sa,
                                                        const double *__restrict__ sb, const double2 *__restrict__ v2f,
-                                                       double2 *__restrict__ f2v_out) {
+                                                       double2 *__restrict__ f2v_out, const double2 *__restrict__ prev, double lam) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const int e = slots[i], p = partner[e];
     if (p < 0) return;
     const double2 o = v2f[e];
     if (__builtin_isnan(o.y)) return;
-    const double2 r = factor_rule<MODE>(o, sq[e], MODE == kRuleLinear ? sa[e] : 1.0, MODE == kRuleLinear ? sb[e] : 0.0);
+    double2 r = factor_rule<MODE>(o, sq[e], MODE == kRuleLinear ? sa[e] : 1.0, MODE == kRuleLinear ? sb[e] : 0.0);
+    if (lam != 0.0 && prev && !__builtin_isnan(r.y)) r = damped(r, prev[p], lam);
     if (MODE != kRuleBernoulli || !__builtin_isnan(r.y)) f2v_out[p] = r;
 }
 
@@ -559,6 +579,17 @@ static inline int nt_scatter(const cx_handle *h) {
     return (h->nslots * (int64_t)sizeof(double2) <= (int64_t)40 << 20) ? 1 : 0;
 }
 
+// load / store policies of the fused sweep by footprint (CX_NT_FLAGS=<bits> forces: 1 scatter stores, 2 message loads, 4 marginal stores)
+static inline int nt_flags(const cx_handle *h) {
+    static const int forced = [] { const char *e = std::getenv("CX_NT_FLAGS"); return e ? std::atoi(e) : -1; }();
+    if (forced >= 0) return forced & 7;
+    // message loads: nontemporal always (C4: 86.3 -> 67.5 us; the 1/8 strip: 11.9 -> 10.0).  Marginal stores: nontemporal on the whole grid
+    // (C4: 60.5 -> 55.8), plain on a strip whose buffers the caches hold (9.68 - 9.79 against 9.99 - 10.02, three runs each): the
+    // inverse of the scatter stores' rule
+    const int out = nt_scatter(h);
+    return out | kNtIn | (out ? 0 : kNtMarg);
+}
+
 static inline int rule_mode(const cx_handle *h) {
     return h->cfg.family == CX_FAMILY_NATURAL2 ? kRuleBernoulli : (h->any_linear ? kRuleLinear : kRuleAdditive);
 }
@@ -572,9 +603,11 @@ static void launch_sweep_t(cx_handle *h, const double2 *f2v_in, double2 *f2v_out
     // CX_PACK=0 in the environment: the unpacked kernel (A/B); otherwise the packed form wherever the graph allows it (additive
     // Gaussian factors, every partner within 32 k slots) — bit-identical results: the same values travel, fewer bytes
     static const bool pack_on = [] { const char *e = std::getenv("CX_PACK"); return !(e && e[0] == '0'); }();
-#define CX_SWEEP_ARGS dim3((unsigned)h->nslices), dim3(kBlock), 0, h->stream, (int)h->nv, h->d_slice_off, h->d_vinfo, h->d_partner, sq, h->d_sa, \
+    const int nt = nt_flags(h);
+#define CX_SWEEP_TAIL 0, h->stream, (int)h->nv, h->d_slice_off, h->d_vinfo, h->d_partner, sq, h->d_sa, \
                       h->d_sb, f2v_in, f2v_out, h->d_v2f, h->d_marg, write_marg ? (h->cfg.family == CX_FAMILY_NATURAL2 ? 2 : 1) : 0,             \
-                      skip_ghosts ? 1 : 0, nt_scatter(h), lo, hi, xlo, xhi, h->d_partner16
+                      skip_ghosts ? 1 : 0, nt, lo, hi, xlo, xhi, h->d_partner16, h->damping
+#define CX_SWEEP_ARGS dim3((unsigned)h->nslices), dim3(kBlock), CX_SWEEP_TAIL
     // the widest slice, once per graph (CX_MAXW8=1: the eight-message instance for every graph, A/B)
     if (h->sweep_max_w == 0) {
         int w = 1;
@@ -583,12 +616,15 @@ static void launch_sweep_t(cx_handle *h, const double2 *f2v_in, double2 *f2v_out
     }
     static const bool force8 = [] { const char *e = std::getenv("CX_MAXW8"); return e && e[0] == '1'; }();
     const bool w5 = h->sweep_max_w <= 5 && !force8;
-    if (PUSH && LINEAR == kRuleAdditive && pack_on && h->d_partner16) {
+    if (PUSH && h->damping != 0.0) {      // damped sweeps: the general instance, with one more gather (the message each result replaces)
+        hipLaunchKernelGGL((k_sweep<LINEAR, STORE, PUSH, 0, kSmallDeg, true>), CX_SWEEP_ARGS);
+    } else if (PUSH && LINEAR == kRuleAdditive && pack_on && h->d_partner16) {
         if (w5) hipLaunchKernelGGL((k_sweep<LINEAR, STORE, PUSH, kPackPartner16 | kPackQLow, 5>), CX_SWEEP_ARGS);
         else hipLaunchKernelGGL((k_sweep<LINEAR, STORE, PUSH, kPackPartner16 | kPackQLow, kSmallDeg>), CX_SWEEP_ARGS);
     } else
         hipLaunchKernelGGL((k_sweep<LINEAR, STORE, PUSH, 0, kSmallDeg>), CX_SWEEP_ARGS);
 #undef CX_SWEEP_ARGS
+#undef CX_SWEEP_TAIL
 }
 
 void launch_fused(cx_handle *h, const double2 *f2v_in, double2 *f2v_out, bool write_marg, bool store_v2f, bool skip_ghosts) {
@@ -627,17 +663,20 @@ void launch_factor_to_var(cx_handle *h, const double2 *v2f, double2 *f2v) {
     prof_begin(h, CX_KERNEL_FACTOR_TO_VAR);
     const int mode = rule_mode(h);
     if (mode == kRuleLinear)
-        hipLaunchKernelGGL(k_factor_to_var<kRuleLinear>, dim3(nb), dim3(kBlock), 0, h->stream, n, h->d_partner, h->d_q, h->d_a, h->d_b, v2f, f2v);
+        hipLaunchKernelGGL(k_factor_to_var<kRuleLinear>, dim3(nb), dim3(kBlock), 0, h->stream, n, h->d_partner, h->d_q, h->d_a, h->d_b, v2f, f2v, h->damping);
     else if (mode == kRuleBernoulli)
         hipLaunchKernelGGL(k_factor_to_var<kRuleBernoulli>, dim3(nb), dim3(kBlock), 0, h->stream, n, h->d_partner, h->d_q,
-                           (const double *)nullptr, (const double *)nullptr, v2f, f2v);
+                           (const double *)nullptr, (const double *)nullptr, v2f, f2v, h->damping);
     else
         hipLaunchKernelGGL(k_factor_to_var<kRuleAdditive>, dim3(nb), dim3(kBlock), 0, h->stream, n, h->d_partner, h->d_q,
-                           (const double *)nullptr, (const double *)nullptr, v2f, f2v);
+                           (const double *)nullptr, (const double *)nullptr, v2f, f2v, h->damping);
     prof_end(h);
 }
 
 void launch_push_slots(cx_handle *h, const int32_t *d_slots, int64_t n, double2 *f2v_out, int kernel_id) {
+    // the big variables' part of a fused sweep (f2v_out is the sweep's output buffer, d_f2v its input): damped like the rest of it;
+    // the halo's pushes are not sweeps of their own (message halos refuse damping)
+    const double2 *prev = (kernel_id == CX_KERNEL_BIG_VAR && h->damping != 0.0) ? h->d_f2v : nullptr;
     if (n == 0) return;
     const double *sq = h->any_linear ? h->d_sq : h->d_q;
     const int nb = (int)((n + kBlock - 1) / kBlock);
@@ -645,13 +684,13 @@ void launch_push_slots(cx_handle *h, const int32_t *d_slots, int64_t n, double2 
     const int mode = rule_mode(h);
     if (mode == kRuleLinear)
         hipLaunchKernelGGL(k_push_slots<kRuleLinear>, dim3(nb), dim3(kBlock), 0, h->stream, d_slots, n, h->d_partner, sq, h->d_sa, h->d_sb,
-                           h->d_v2f, f2v_out);
+                           h->d_v2f, f2v_out, prev, h->damping);
     else if (mode == kRuleBernoulli)
         hipLaunchKernelGGL(k_push_slots<kRuleBernoulli>, dim3(nb), dim3(kBlock), 0, h->stream, d_slots, n, h->d_partner, sq,
-                           (const double *)nullptr, (const double *)nullptr, h->d_v2f, f2v_out);
+                           (const double *)nullptr, (const double *)nullptr, h->d_v2f, f2v_out, prev, h->damping);
     else
         hipLaunchKernelGGL(k_push_slots<kRuleAdditive>, dim3(nb), dim3(kBlock), 0, h->stream, d_slots, n, h->d_partner, sq,
-                           (const double *)nullptr, (const double *)nullptr, h->d_v2f, f2v_out);
+                           (const double *)nullptr, (const double *)nullptr, h->d_v2f, f2v_out, prev, h->damping);
     prof_end(h);
 }
 

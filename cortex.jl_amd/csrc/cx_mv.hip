@@ -45,13 +45,16 @@ constexpr int kTabLds = 8;   // parameter-set/direction pairs kept in LDS (3 d*d
 // scratch for d = 4 — the instance exists so that such graphs run, not to be fast).  A state-space chain has degree 3: three incoming messages instead of four
 // are 28 registers less for d = 4 — 168 VGPRs, THREE waves per SIMD instead of two (no scratch), which is what this kernel's
 // load / compute lock-step was short of.
-template <int D, int DEG, bool NT_LOADS>
-__global__ __launch_bounds__(kBlock, DEG == 3 ? 3 : DEG == 4 ? 2 : 1) void k_sweep_mv(int nv, int64_t nslots, const int32_t *__restrict__ slice_off,
+// DAMP (cx_set_damping): a result is mixed with the message it replaces — the receiving slot in the sweep's input buffer — in natural
+// form, (1 - lambda) rule + lambda old: a convex combination of positive definite precisions is positive definite.  Instances of their
+// own (one more gather and its registers), launched only while a damping factor is set.
+template <int D, int DEG, bool NT_LOADS, bool DAMP = false>
+__global__ __launch_bounds__(kBlock, DAMP ? 1 : DEG == 3 ? 3 : DEG == 4 ? 2 : 1) void k_sweep_mv(int nv, int64_t nslots, const int32_t *__restrict__ slice_off,
                                                      const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
                                                      const int32_t *__restrict__ spdir, const double *__restrict__ ptab, int ntab,
                                                      const double *__restrict__ f2v_in, double *__restrict__ f2v_out,
                                                      const double *__restrict__ v2f, double *__restrict__ marg, int write_marg,
-                                                     int observed_only) {
+                                                     int observed_only, double lam) {
     __shared__ double tab_s[kTabLds * 3 * D * D];
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
@@ -114,7 +117,16 @@ __global__ __launch_bounds__(kBlock, DEG == 3 ? 3 : DEG == 4 ? 2 : 1) void k_swe
                 if (j < deg && j != k) msg_add<D>(o, in[j]);
         }
         if (__builtin_isnan(o.lam[0])) continue;
-        const Msg<D> r = pd < nt ? mv_rule<D>(o, tab_s + pd * 3 * D * D) : mv_rule<D>(o, ptab + (int64_t)pd * 3 * D * D);
+        Msg<D> r = pd < nt ? mv_rule<D>(o, tab_s + pd * 3 * D * D) : mv_rule<D>(o, ptab + (int64_t)pd * 3 * D * D);
+        if (DAMP && !__builtin_isnan(r.lam[0])) {
+            const Msg<D> old = slot_load<D>(f2v_in, p);
+            if (!__builtin_isnan(old.lam[0])) {
+#pragma unroll
+                for (int i = 0; i < D; i++) r.eta[i] = (1.0 - lam) * r.eta[i] + lam * old.eta[i];
+#pragma unroll
+                for (int i = 0; i < D * (D + 1) / 2; i++) r.lam[i] = (1.0 - lam) * r.lam[i] + lam * old.lam[i];
+            }
+        }
         if (!__builtin_isnan(r.lam[0])) slot_store<D>(f2v_out, p, r);
     }
 }
@@ -223,11 +235,15 @@ void mv_launch_sweep(cx_handle *h, bool write_marg, int observed_only, double *f
     static const bool force4 = [] { const char *e = getenv("CX_MV_DEG4"); return e && e[0] == '1'; }();
     const bool deg3 = h->mv_max_deg <= 3 && !force4, deg8 = h->mv_max_deg > 4;
 #define CX_MV_ARGS g, b, 0, h->stream, (int)h->nv, h->nslots, h->d_slice_off, h->d_vinfo, h->d_partner, h->d_spdir, h->d_ptab, (int)(2 * h->ptab_sets), \
-                   h->d_mv_f2v, f2v_out, h->d_mv_v2f, h->d_mv_marg, (write_marg && !observed_only) ? 1 : 0, observed_only
+                   h->d_mv_f2v, f2v_out, h->d_mv_v2f, h->d_mv_marg, (write_marg && !observed_only) ? 1 : 0, observed_only, h->damping
     // CX_MV_NT=0/1: nontemporal loads of the incoming messages off / on (A/B; default on: every message is read once per sweep)
     static const bool nt = [] { const char *e = getenv("CX_MV_NT"); return !(e && e[0] == '0'); }();
+    // messages out of observed variables and other constant senders (observed_only passes) are functions of the data alone: never damped
+    const bool damp = h->damping != 0.0 && !observed_only;
 #define CX_MV(DD)                                                                      \
-    if (deg8) hipLaunchKernelGGL((k_sweep_mv<DD, 8, true>), CX_MV_ARGS);               \
+    if (damp && deg8) hipLaunchKernelGGL((k_sweep_mv<DD, 8, true, true>), CX_MV_ARGS); \
+    else if (damp) hipLaunchKernelGGL((k_sweep_mv<DD, 4, true, true>), CX_MV_ARGS);    \
+    else if (deg8) hipLaunchKernelGGL((k_sweep_mv<DD, 8, true>), CX_MV_ARGS);          \
     else if (deg3 && nt) hipLaunchKernelGGL((k_sweep_mv<DD, 3, true>), CX_MV_ARGS);    \
     else if (deg3) hipLaunchKernelGGL((k_sweep_mv<DD, 3, false>), CX_MV_ARGS);         \
     else if (nt) hipLaunchKernelGGL((k_sweep_mv<DD, 4, true>), CX_MV_ARGS);            \

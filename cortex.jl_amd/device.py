@@ -186,6 +186,10 @@ class DeviceGraph:
     def sweep(self, n: int = 1):
         self._check(self.lib.cx_sweep(self.h, int(n)))
 
+    def set_damping(self, lam: float):
+        """cx_set_damping: new = (1 - lam) rule + lam old for every factor→variable message of a fused / flooding sweep"""
+        self._check(self.lib.cx_set_damping(self.h, float(lam)))
+
     def sweep_for(self, variable_ids):
         """cx_sweep_for: ONE update_marginals!(engine, variable_ids) under CX_SCHED_REFERENCE, the ids in the caller's order"""
         v = _i64(np.atleast_1d(variable_ids))

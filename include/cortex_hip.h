@@ -291,6 +291,13 @@ int32_t cx_get_products(cx_handle *h, int64_t n, const int64_t *variable_ids, co
 int32_t cx_get_joint_marginals(cx_handle *h, int64_t n, const int64_t *factor_ids, double *out);
 /* n_sweeps passes of the configured device schedule over the whole graph (asynchronous) */
 int32_t cx_sweep(cx_handle *h, int32_t n_sweeps);
+/* Damping for the schedules that iterate to a fixed point (CX_SCHED_FUSED, CX_SCHED_FLOODING; dim 1 - 4): every factor→variable message a
+ * sweep computes is stored as (1 - lambda) x rule + lambda x the message it replaces, in natural parameters (an undefined old message does
+ * not damp).  0 <= lambda < 1, 0 (the default) = off: the sweeps are then bit for bit what they were.  The fixed point is unchanged; loopy
+ * Gaussian BP that oscillates outside the walk-summable regime converges under enough damping.  The reference has no counterpart: its rules
+ * are the user's code, a user damps inside them.  Not with per-sweep message halos (cx_halo_configure); state halos are damped like the
+ * plain sweeps they run. */
+int32_t cx_set_damping(cx_handle *h, double lambda);
 /* CX_SCHED_REFERENCE: ONE update_marginals!(engine, variable_ids) (src/inference_engine.jl:559-632; request_inference_for :298-323) for
  * the named variables in the caller's order — only what is pending for those marginals is computed (cx_sweep requests every variable
  * that is neither observed nor a stand-in, in ascending id order).  Other schedules: CX_ERR_UNSUPPORTED (they compute every message). */

@@ -54,6 +54,9 @@ def main():
                          "overlap = cx_halo_ipc_exchange_sweep; early = cx_halo_ipc_batch (the next exchange pushed inside the last sweep of a batch)")
     ap.add_argument("--batch", type=int, default=0, help="sweeps per cx_sweep call (default: depth)")
     ap.add_argument("--no-trim", action="store_true", help="run every redundant row in every sweep (no cx_halo_set_layers)")
+    ap.add_argument("--blocks", default="", help="RxC: cut the grid into R x C rectangular blocks (R * C = --world) instead of row strips and hold block "
+                                                 "--block r,c (partition.by_assignment_deep on the whole model: no exchange modes, timing of the sweeps only)")
+    ap.add_argument("--block", default="0,1")
     a = ap.parse_args()
     torch.cuda.init()
     N = a.grid
@@ -69,7 +72,18 @@ def main():
     whole_us = (time.perf_counter() - t0) / 1000 * 1e6
     whole.close()
     for depth in a.depth:
-        part = partition.grid_rows_deep(N, N, a.rank, a.world, depth, seed=1234)
+        if a.blocks:
+            R_, C_ = (int(x) for x in a.blocks.lower().split("x"))
+            br, bc = (int(x) for x in a.block.split(","))
+            assert R_ * C_ == a.world and not a.exchange
+            rb, cb = np.linspace(0, N, R_ + 1).astype(np.int64), np.linspace(0, N, C_ + 1).astype(np.int64)
+
+            def owner(ids):
+                i, j = (np.asarray(ids) - 1) // N, (np.asarray(ids) - 1) % N
+                return (np.searchsorted(rb, i, side="right") - 1) * C_ + (np.searchsorted(cb, j, side="right") - 1)
+            part = partition.by_assignment_deep(cx.synth.gaussian_grid(N, N, seed=1234), owner, br * C_ + bc, a.world, depth)
+        else:
+            part = partition.grid_rows_deep(N, N, a.rank, a.world, depth, seed=1234)
         if a.no_trim:
             part.layer_var = part.layer = None
         dev = cx.DeviceGraph(schedule=L.SCHED_FUSED)
@@ -114,7 +128,9 @@ def main():
             best = (wall, devt) if best is None or wall < best[0] else best
         rows_owned = len(part.owned_x) // N
         rows_held = st["n_variables"] // N
-        print(json.dumps({"strip": f"rank {a.rank} of {a.world}, {rows_owned} owned rows + 2 x {depth} redundant ({rows_held} rows held incl. stand-ins)",
+        print(json.dumps({"strip": (f"block {a.block} of a {a.blocks} cut, {len(part.owned_x)} owned variables, {st['n_variables']} held incl. stand-ins" if a.blocks else
+                                    f"rank {a.rank} of {a.world}, {rows_owned} owned rows + 2 x {depth} redundant ({rows_held} rows held incl. stand-ins)"),
+                          "owned_variables": int(len(part.owned_x)), "held_variables": int(st["n_variables"]),
                           "depth": depth, "exchange": (("IPC push, owned part of sweep 1, unpack, rest: one stream" if (a.overlap_exchange or a.ipc_form == "overlap") else "IPC, next exchange pushed inside the last sweep of a batch, unpacked after the owned part of the first" if a.ipc_form == "early" else "IPC push + flag, ONE launch" if a.ipc_form == "one" else "IPC push + flag, two launches") if a.ipc else "overlapped with the owned part of the first sweep" if a.overlap_exchange else "RCCL, serial on the compute stream") if a.exchange else False, "us_per_sweep_wall": best[0], "us_per_sweep_device": best[1],
                           "whole_grid_us_per_sweep": whole_us, "ideal_us": whole_us / a.world,
                           "ratio_to_ideal": best[0] / (whole_us / a.world), "speedup_if_all_ranks_like_this": whole_us / best[0],
