@@ -598,9 +598,11 @@ __device__ __forceinline__ void marg_store(double *__restrict__ marg, int64_t, i
 // from alpha + gamma in k_mvc_marg_out).  flags & 2: alpha_l / beta_l also go to their SELL slots f2v[to_slot[l]] / f2v[from_slot[l]].
 // PF (round 4): the walks fetch the NEXT step's side information, head flag and table index while the current step's rule runs — and
 // the first step's before the tile carry is composed; a step of the plain form is a memory round trip, then the rule, then the
-// stores, at the two waves per SIMD a chain of 1e6 links fills (the registers are held to two waves per SIMD then, not four).
+// stores, at the two waves per SIMD a chain of 1e6 links fills.  (The plain form, PF = false, is kept for CX_MVC_PREFETCH=0 A/B runs;
+// until round 5 it was held to 128 registers — four waves per SIMD — and carried 112 B of scratch for d = 4; a chain of 1e6 links
+// fills two waves per SIMD whatever the register count, so both forms now take what they need: 202 / 168 registers, no scratch.)
 template <int D, bool GT, bool PF>
-__global__ __launch_bounds__(kBlock, PF ? 2 : 4) void k_mvc_apply(MvcArgs A, int K, const double *__restrict__ excl, double *__restrict__ f2v,
+__global__ __launch_bounds__(kBlock, 2) void k_mvc_apply(MvcArgs A, int K, const double *__restrict__ excl, double *__restrict__ f2v,
                                                                double *__restrict__ marg, int flags) {
     constexpr int E = CMap<D>::ND + 1;
     using M = CMap<D>;
