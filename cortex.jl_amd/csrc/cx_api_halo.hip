@@ -129,6 +129,13 @@ int32_t cx_halo_set_layers(cx_handle *h, int64_t n, const int64_t *variable_ids,
         }
         cx::haloplan::layers(h, lay, depth);      // cx_halo_plan.h (GPU-free: also built and tested on the CPU under sanitizers)
         h->sweeps_since_exchange = 0;
+        // the quiet run of cx_halo_ipc_batch (the slices of the last sweep that may run AFTER the early push) is a function of the owned-only
+        // slices set just now: an IPC block that already stands gets it recomputed, so that no stale range survives new layers
+        // (cx_halo_configure_state drops the block itself, and with it the range)
+        if (h->d_ipc_block) {
+            h->ipc_quiet_lo = 1; h->ipc_quiet_hi = 0;
+            if (h->cfg.dim == 1) cx::haloplan::quiet_run(h);
+        }
         return CX_OK;
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_halo_set_layers: host allocation failed"); }
 }

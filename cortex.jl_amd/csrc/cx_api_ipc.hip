@@ -187,7 +187,7 @@ void ipc_destroy(cx_handle *h) {
     h->ipc_conn.clear();
     if (h->d_ipc_block) (void)hipFree(h->d_ipc_block);
     if (h->d_ipc_local) (void)hipFree(h->d_ipc_local);
-    h->d_ipc_block = nullptr; h->d_ipc_local = nullptr; h->ipc_area_bytes = 0; h->ipc_epoch = h->ipc_pushed = 0;
+    h->d_ipc_block = nullptr; h->d_ipc_local = nullptr; h->ipc_area_bytes = 0; h->ipc_epoch = h->ipc_pushed = 0; h->ipc_quiet_lo = 1; h->ipc_quiet_hi = 0;
 }
 
 }  // namespace cx

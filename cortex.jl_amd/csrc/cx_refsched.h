@@ -20,8 +20,8 @@
 //                       [ne, 2 ne)         MessageToVariable of CSR edge e      (:45-48)
 //                       [2 ne, 2 ne + nv)  IndividualMarginal of variable v     (:78-80)
 //                       [2 ne + nv, nsig)  ProductOfMessages(variable, range)   (:62-66), the segment-tree nodes of variables of degree > 5
-// Pure host C++ over any struct H with cx_handle's host fields (cx_flatten.h); tests/test_refsched.py runs it against the restated
-// reference engine (oracle/cortex_ref.c), also under -fsanitize=address,undefined.
+// Pure host C++ over any struct H with cx_handle's host fields (cx_flatten.h); tests/test_refsched.py runs it against the test suite's
+// restated reference engine, execution by execution, also under -fsanitize=address,undefined.
 #pragma once
 
 #include <algorithm>

@@ -365,7 +365,7 @@ int32_t build_hp(const H *h, HP &out, std::string &err) {
         out.stage_off.push_back((int64_t)out.rec.size() / 5);
         out.kary_off.push_back((int64_t)out.kary.size());
         out.steps.push_back(0); out.steps.push_back((int32_t)out.stage_off.size() - 2);
-        out.launches += 1 + (curk.empty() || cur.empty() ? 0 : 1);
+        out.launches += 1;      // one launch per item stage: its k-ary entries ride in the same record list (cx_api_sweep.hip: build_tree, kind 32)
         cur.clear(); curk.clear();
         return true;
     };

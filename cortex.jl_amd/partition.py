@@ -847,8 +847,13 @@ _MV_TABLES = {}
 
 
 def _mv_rule_tables(A, Q, forward):
-    """(P, B, C) of x_out = A x_in + N(0, Q) for the receiving end (csrc/cx_mv_core.h: mv_rule_tables), cached per matrix pair"""
-    key = (A.ctypes.data, Q.ctypes.data, A.shape, bool(forward), float(A[0, 0]), float(Q[0, 0]), float(A[-1, -1]), float(Q[-1, -1]))
+    """(P, B, C) of x_out = A x_in + N(0, Q) for the receiving end (csrc/cx_mv_core.h: mv_rule_tables), cached per matrix pair.
+    The key is the matrices' CONTENT (a digest of their bytes): an address can be recycled by a temporary that holds another matrix with
+    the same corner entries, and a stale (P, B, C) would be a silently wrong boundary message of a d = 64 block exchange."""
+    import hashlib
+
+    A, Q = np.ascontiguousarray(A, dtype=np.float64), np.ascontiguousarray(Q, dtype=np.float64)
+    key = (hashlib.blake2b(A.tobytes() + Q.tobytes(), digest_size=16).digest(), A.shape, bool(forward))
     tab = _MV_TABLES.get(key)
     if tab is None:
         Qi = np.linalg.inv(Q)

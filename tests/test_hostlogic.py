@@ -251,9 +251,10 @@ def _run_under_asan(lib, select, files=None):
 def test_host_logic_under_address_and_ub_sanitizers():
     from cortex.jl_amd import build as B
 
-    # this file and the plan of the tree schedule (tests/test_tree_plan.py: cx_tree_plan.h over forests, cycles, observed cuts)
+    # this file, the plan of the tree schedule (tests/test_tree_plan.py: cx_tree_plan.h over forests, cycles, observed cuts) and the
+    # reference-order schedule's wiring, shadow scheduler and levelling (tests/test_refsched.py: cx_refsched.h on loopy graphs with hubs)
     out = _run_under_asan(B.build_hostlogic(asan=True), "not sanitizers and not reintroduced",
-                          [os.path.abspath(__file__), os.path.join(ROOT, "tests", "test_tree_plan.py")])
+                          [os.path.abspath(__file__), os.path.join(ROOT, "tests", "test_tree_plan.py"), os.path.join(ROOT, "tests", "test_refsched.py")])
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr
 
