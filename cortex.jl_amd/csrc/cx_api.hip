@@ -15,7 +15,7 @@ using namespace cxh;
 namespace cxh {
 
 void dev_free_all(cx_handle *h) {
-    void *ptrs[] = {h->d_slice_off, h->d_partner, h->d_vbase, h->d_var_deg, h->d_big, h->d_big_slots, h->d_big_tmp,
+    void *ptrs[] = {h->d_slice_off, h->d_partner, h->d_vbase, h->d_var_deg, h->d_big, h->d_big_slots, h->d_big_slot_var, h->d_big_tmp,
                     h->d_vinfo, h->d_q, h->d_a, h->d_b, h->d_sq, h->d_sa, h->d_sb, h->d_f2v, h->d_v2f, h->d_marg,
                     h->d_f2v_alt, h->d_prev, h->d_scratch, h->d_send_slots, h->d_recv_slots, h->d_send_vars,
                     h->ext_halo_buffers ? nullptr : (void *)h->d_send_buf, h->ext_halo_buffers ? nullptr : (void *)h->d_recv_buf,
@@ -41,7 +41,7 @@ void dev_free_all(cx_handle *h) {
     h->d_chain_pos_var = h->d_chain_skip0 = h->d_chain_skip1 = h->d_chain_link_pos = h->d_chain_from = h->d_chain_to = nullptr;
     h->d_chain_head_fwd = h->d_chain_head_bwd = nullptr; h->d_chain_side = nullptr; h->d_chain_totals = nullptr; h->chains_dirty = true; h->tree_dirty = true;
     h->d_chain_tab_fwd = h->d_chain_tab_bwd = nullptr; h->d_mvc_side = h->d_mvc_totals = nullptr; h->d_mvc_side_l = h->d_mvc_alpha = h->d_mvc_gamma = h->d_mvc_prefix = h->d_mvc_wave_carry = h->d_mvc_block = nullptr;
-    h->d_slice_off = h->d_partner = h->d_vbase = h->d_var_deg = h->d_big = h->d_big_slots = nullptr;
+    h->d_slice_off = h->d_partner = h->d_vbase = h->d_var_deg = h->d_big = h->d_big_slots = h->d_big_slot_var = nullptr;
     h->d_big_tmp = nullptr; h->d_vinfo = nullptr;
     h->d_q = h->d_a = h->d_b = h->d_sq = h->d_sa = h->d_sb = nullptr;
     h->d_f2v = h->d_v2f = h->d_marg = h->d_f2v_alt = h->d_prev = nullptr;
@@ -284,6 +284,12 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
         CX_TRY(dev_upload(h, &h->d_vinfo, h->vinfo));
         CX_TRY(dev_upload(h, &h->d_big, h->big_vars));
         CX_TRY(dev_upload(h, &h->d_big_slots, h->big_slots));
+        if (mv && !h->big_vars.empty()) {
+            std::vector<int32_t> sv;
+            sv.reserve(h->big_slots.size());
+            for (int32_t v : h->big_vars) sv.insert(sv.end(), (size_t)var_deg[v], v);
+            CX_TRY(dev_upload(h, &h->d_big_slot_var, sv));
+        }
         CX_TRY(dev_alloc(h, &h->d_big_tmp, big_total));
         CX_TRY(dev_alloc(h, &h->d_scratch, 4096));
         if (mv) {

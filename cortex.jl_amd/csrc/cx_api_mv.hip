@@ -630,6 +630,7 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
         } else {
             if (h->observed_passes_due > 0) { cx::mv_launch_sweep(h, false, 1); h->observed_passes_due--; }
             cx::mv_launch_sweep(h, h->cfg.compute_marginals_in_sweep != 0, 0);
+            cx::mv_launch_big(h, h->cfg.compute_marginals_in_sweep != 0);      // variables of degree > 8 (none on most graphs: no launch)
         }
         std::swap(h->d_mv_f2v, h->d_mv_f2v_alt);
         h->sweeps_done++;

@@ -96,8 +96,11 @@ int32_t flatten(H *h, int64_t n_edges, const int64_t *edge_var, const int64_t *e
         slots += var_deg[v];
         CX_FLAT_REQUIRE(slots < (int64_t)0x7fffff00, CX_ERR_UNSUPPORTED, "cx_graph_create: slot space exceeds 2^31");
     }
-    h->nslots = slots;
     const int64_t big_total = slots - h->big_start;
+    // dim 2..4 store a message as 16-byte pairs, block-major over blocks of 256 slots (cx_mv_core.h): the CSR tail of the variables of
+    // degree > 8 ends on a whole block
+    if (h->cfg.dim > 1 && !h->big_vars.empty()) slots = (slots + kBlock - 1) / kBlock * kBlock;
+    h->nslots = slots;
     // ---- factors ------------------------------------------------------------------------------------------------
     std::vector<int64_t> ford(n_factors);
     std::iota(ford.begin(), ford.end(), 0);
@@ -132,18 +135,16 @@ int32_t flatten(H *h, int64_t n_edges, const int64_t *edge_var, const int64_t *e
     std::vector<int32_t> spdir;
     if (mv) {
         spdir.assign(slots, 0);
-        if (!h->big_vars.empty())
-            return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_create: dim > 1 handles variables of degree <= 8 only; variable " +
-                        std::to_string(h->var_ids[h->big_vars[0]]) + " has more");
         // dim 2..4: a variable's incoming messages live in registers (k_sweep_mv<D, DEG>: DEG = 3, 4 or 8 by the graph's widest
-        // variable); dim 64: a rule sums at most three sources itself (k_rule64w) — a sender of degree 5 .. 8 has its other messages summed
-        // into its stored variable→factor message first (k_v2f64; flooding and tree schedules, batch items); the chain-scan plans sum the
-        // side information of such a path variable into one message of their own first (k_side64, cx_mv64chain.hip).
-        const int max_deg = 8;
-        for (int64_t v = 0; v < nv; v++)
-            if (var_deg[v] > max_deg)
-                return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_create: dim " + std::to_string(h->cfg.dim) + " handles variables of degree <= " + std::to_string(max_deg) +
-                            " in this build; variable " + std::to_string(h->var_ids[v]) + " has degree " + std::to_string(var_deg[v]));
+        // variable); variables of degree > 8 live in the CSR tail like the scalar ones (round 5: k_big_mv, cx_mv.hip; fused and tree
+        // schedules, batch items — the reference's resolver takes any degree, src/dependencies.jl:90-173).  dim 64: a rule sums at most
+        // three sources itself (k_rule64w) — a sender of degree 5 .. 8 has its other messages summed into its stored variable→factor
+        // message first (k_v2f64; flooding and tree schedules, batch items); the chain-scan plans sum the side information of such a
+        // path variable into one message of their own first (k_side64, cx_mv64chain.hip).
+        if (!h->big_vars.empty() && (h->cfg.dim == 64 || h->cfg.schedule == CX_SCHED_CHAIN_SCAN))
+            return fail_(err, CX_ERR_UNSUPPORTED, std::string("cx_graph_create: ") + (h->cfg.dim == 64 ? "dim 64 (and 5 .. 63 with it)" : "the chain-scan schedule for dim > 1") +
+                        " handles variables of degree <= 8; variable " + std::to_string(h->var_ids[h->big_vars[0]]) + " has degree " +
+                        std::to_string(var_deg[h->big_vars[0]]) + (h->cfg.dim == 64 ? "" : " (the fused and tree schedules take any degree)"));
     }
     std::vector<double> q(mv ? 1 : slots, 0.0), a, b, sq, sa, sb;
     h->any_linear = false;

@@ -51,7 +51,7 @@ struct cx_handle {
 
     // ---- device buffers ----
     int32_t *d_slice_off = nullptr, *d_partner = nullptr, *d_vbase = nullptr, *d_var_deg = nullptr;
-    int32_t *d_big = nullptr, *d_big_slots = nullptr;
+    int32_t *d_big = nullptr, *d_big_slots = nullptr, *d_big_slot_var = nullptr;      // (dim 2..4: the variable of every slot of the CSR tail)
     double2 *d_big_tmp = nullptr;   // prefix scratch of the big-variable kernel, one entry per big slot
     int32_t big_start = 0;          // first slot of the big-variable CSR tail
     uint8_t *d_vinfo = nullptr;
@@ -282,6 +282,7 @@ void launch_tiled2(cx_handle *h, const double2 *f2v_in, double2 *f2v_out, bool w
 // multivariate (cx_mv.hip)
 void mv_launch_sweep(cx_handle *h, bool write_marg, int only, double *f2v_out = nullptr);   // only: 0 regular, 1 observed variables, 2 other fixed senders (degree 1, stand-ins)
 void mv_launch_v2f(cx_handle *h, const int32_t *d_slots, const int32_t *d_vars, int64_t n, const double *f2v);
+void mv_launch_big(cx_handle *h, bool write_marg, double *f2v_out = nullptr);     // the variables of degree > 8 of a fused sweep (dim 2..4)
 void mv_launch_scatter(cx_handle *h, double *dst, int64_t stride, int nc, int ncs, const int32_t *d_idx, const double *d_val, int64_t n);
 void mv_launch_gather(cx_handle *h, const double *src, int64_t stride, int nc, int ncs, const int32_t *d_idx, double *d_val, int64_t n);
 void mv_launch_seed(cx_handle *h, double *buf, double eta, double lam);

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kBlock, DAMP ? 1 : DEG == 3 ? 3 : DEG == 4 ? 2 : 1)
     // variable→factor message goes through the rule (the chain scan's leaf pass; the regular sweep handles them itself)
     const bool is_fixed = (info & kGhost) || deg < 2;
     // observed_only == 3: both kinds of constant senders in one pass (what the chain scan's leaf pass launches)
-    const bool active = v < nv && (observed_only == 3 ? ((info & kClamped) || (is_fixed && deg > 0))
+    const bool active = v < nv && deg != kBigDeg && (observed_only == 3 ? ((info & kClamped) || (is_fixed && deg > 0))
                                    : observed_only == 2 ? (!(info & kClamped) && is_fixed && deg > 0)
                                                         : (((info & kClamped) != 0) == (observed_only != 0)));
     const int base = off + tid;
@@ -135,18 +135,58 @@ __global__ __launch_bounds__(kBlock, DAMP ? 1 : DEG == 3 ? 3 : DEG == 4 ? 2 : 1)
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_v2f_mv(int64_t n, int64_t nslots, const int32_t *__restrict__ slots,
                                                    const int32_t *__restrict__ vars, const int32_t *__restrict__ vbase,
-                                                   const uint8_t *__restrict__ vinfo, const double *__restrict__ f2v,
+                                                   const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ vdeg, const double *__restrict__ f2v,
                                                    double *__restrict__ v2f) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const int slot = slots[i], v = vars[i];
-    const int info = vinfo[v], deg = info & kDegMask;
+    const int info = vinfo[v], deg = vdeg[v], stride = (info & kDegMask) == kBigDeg ? 1 : kBlock;
     if (deg < 2 || (info & (kClamped | kGhost))) return;
     const int b = vbase[v];
     Msg<D> o = msg_zero<D>();
     for (int j = 0; j < deg; j++)
-        if (b + j * kBlock != slot) msg_add<D>(o, slot_load<D>(f2v, b + j * kBlock));
+        if (b + j * stride != slot) msg_add<D>(o, slot_load<D>(f2v, b + j * stride));
     if (!__builtin_isnan(o.lam[0])) slot_store<D>(v2f, slot, o);
+}
+
+// Variables of degree > 8 (the CSR tail of the slot space; round 5): one thread per slot of such a variable — the variable→factor message
+// of the slot (the sum of the variable's other incoming messages, in slot order), through the factor rule into the partner's slot of
+// the sweep's output buffer; the thread of a variable's first slot also writes its marginal.  The reference wires such a variable
+// through a segment tree of ProductOfMessages nodes (src/dependencies.jl:90-173: O(log degree) inputs per message); here every slot
+// sums the others itself — O(degree^2) loads per hub and sweep out of the caches, which is what a hub of some hundreds of neighbours
+// costs without a second kernel and a scratch array (the scalar path has the wave scans: k_big_var_to_factor).
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_big_mv(int64_t n, const int32_t *__restrict__ slots, const int32_t *__restrict__ slot_var,
+                                                   const int32_t *__restrict__ vbase, const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
+                                                   const int32_t *__restrict__ partner, const int32_t *__restrict__ spdir, const double *__restrict__ ptab,
+                                                   const double *__restrict__ f2v_in, double *__restrict__ f2v_out, const double *__restrict__ v2f,
+                                                   double *__restrict__ marg, int write_marg, double lam) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int slot = slots[i], v = slot_var[i], info = vinfo[v], deg = vdeg[v], b = vbase[v];
+    Msg<D> o = msg_zero<D>();
+    for (int j = 0; j < deg; j++)
+        if (b + j != slot) msg_add<D>(o, slot_load<D>(f2v_in, b + j));
+    if (write_marg && slot == b) {
+        Msg<D> total = o;
+        msg_add<D>(total, slot_load<D>(f2v_in, slot));
+        slot_store_nt<D>(marg, v, __builtin_isnan(total.lam[0]) ? msg_all_nan<D>() : mv_to_moment<D>(total));
+    }
+    if (info & (kClamped | kGhost)) o = slot_load<D>(v2f, slot);      // an observed variable sends its data
+    const int p = partner[slot], pd = spdir[slot];
+    if (p < 0 || pd < 0 || __builtin_isnan(o.lam[0])) return;
+    Msg<D> r = mv_rule<D>(o, ptab + (int64_t)pd * 3 * D * D);
+    if (__builtin_isnan(r.lam[0])) return;
+    if (lam != 0.0) {
+        const Msg<D> old = slot_load<D>(f2v_in, p);
+        if (!__builtin_isnan(old.lam[0])) {
+#pragma unroll
+            for (int c = 0; c < D; c++) r.eta[c] = (1.0 - lam) * r.eta[c] + lam * old.eta[c];
+#pragma unroll
+            for (int c = 0; c < D * (D + 1) / 2; c++) r.lam[c] = (1.0 - lam) * r.lam[c] + lam * old.lam[c];
+        }
+    }
+    slot_store<D>(f2v_out, p, r);
 }
 
 // host staging <-> device.  ncs > 0: a MESSAGE buffer (block-major pairs, ncs stored doubles per slot: cx_mv_core.h);
@@ -256,10 +296,24 @@ void mv_launch_sweep(cx_handle *h, bool write_marg, int observed_only, double *f
     if (!observed_only) prof_e(h);
 }
 
+// the variables of degree > 8 of a fused sweep (after the sliced part: same input and output buffers)
+void mv_launch_big(cx_handle *h, bool write_marg, double *f2v_out) {
+    const int64_t n = (int64_t)h->big_slots.size();
+    if (n == 0) return;
+    if (!f2v_out) f2v_out = h->d_mv_f2v_alt;
+    const dim3 g((unsigned)((n + kBlock - 1) / kBlock)), b(kBlock);
+#define CX_MV(DD) hipLaunchKernelGGL((k_big_mv<DD>), g, b, 0, h->stream, n, h->d_big_slots, h->d_big_slot_var, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, \
+                                     h->d_spdir, h->d_ptab, h->d_mv_f2v, f2v_out, h->d_mv_v2f, h->d_mv_marg, write_marg ? 1 : 0, h->damping)
+    if (h->cfg.dim == 2) CX_MV(2);
+    else if (h->cfg.dim == 3) CX_MV(3);
+    else CX_MV(4);
+#undef CX_MV
+}
+
 void mv_launch_v2f(cx_handle *h, const int32_t *d_slots, const int32_t *d_vars, int64_t n, const double *f2v) {
     if (n == 0) return;
     const dim3 g((unsigned)((n + kBlock - 1) / kBlock)), b(kBlock);
-#define CX_MV(DD) hipLaunchKernelGGL((k_v2f_mv<DD>), g, b, 0, h->stream, n, h->nslots, d_slots, d_vars, h->d_vbase, h->d_vinfo, f2v, h->d_mv_v2f)
+#define CX_MV(DD) hipLaunchKernelGGL((k_v2f_mv<DD>), g, b, 0, h->stream, n, h->nslots, d_slots, d_vars, h->d_vbase, h->d_vinfo, h->d_var_deg, f2v, h->d_mv_v2f)
     if (h->cfg.dim == 2) CX_MV(2);
     else if (h->cfg.dim == 3) CX_MV(3);
     else CX_MV(4);

@@ -23,16 +23,17 @@ namespace cx {
 // rec: 5 int32 per item — kind, index (slot of the signal's edge | local variable | place in the product table), local variable, rule table
 // of the sending slot (ProductOfMessages: first message of the range, 1-based), 0 (ProductOfMessages: last message of the range)
 template <int D>
-__device__ __forceinline__ void batch_item_mv(int kind, int idx, int v, int tab, int hi, const int32_t *__restrict__ vbase, const uint8_t *__restrict__ vinfo,
+__device__ __forceinline__ void batch_item_mv(int kind, int idx, int v, int tab, int hi, const int32_t *__restrict__ vbase, const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ vdeg,
                                               const int32_t *__restrict__ partner, const double *__restrict__ ptab, double *__restrict__ f2v,
                                               double *__restrict__ v2f, double *__restrict__ marg, double *__restrict__ prod) {
-    const int info = vinfo[v], deg = info & kDegMask, b = vbase[v];
+    // (a variable of degree > 8 lives in the CSR tail: consecutive slots; the others in their slice, a slot every 256)
+    const int info = vinfo[v], deg = vdeg[v], b = vbase[v], st = (info & kDegMask) == kBigDeg ? 1 : kBlock;
     if (kind == CX_ITEM_MESSAGE_TO_FACTOR) {
         // variables of degree 1, observed variables and stand-ins have no dependencies: their message is what the caller stored
         if (deg < 2 || (info & (kClamped | kGhost))) return;
         Msg<D> o = msg_zero<D>();
         for (int j = 0; j < deg; j++)
-            if (b + j * kBlock != idx) msg_add<D>(o, slot_load<D>(f2v, b + j * kBlock));
+            if (b + j * st != idx) msg_add<D>(o, slot_load<D>(f2v, b + j * st));
         if (!__builtin_isnan(o.lam[0])) slot_store<D>(v2f, idx, o);
     } else if (kind == CX_ITEM_MESSAGE_TO_VARIABLE) {
         const int p = partner[idx];
@@ -43,42 +44,42 @@ __device__ __forceinline__ void batch_item_mv(int kind, int idx, int v, int tab,
         if (!__builtin_isnan(r.lam[0])) slot_store<D>(f2v, idx, r);
     } else if (kind == CX_ITEM_INDIVIDUAL_MARGINAL) {
         Msg<D> total = msg_zero<D>();
-        for (int j = 0; j < deg; j++) msg_add<D>(total, slot_load<D>(f2v, b + j * kBlock));
+        for (int j = 0; j < deg; j++) msg_add<D>(total, slot_load<D>(f2v, b + j * st));
         const bool ok = deg > 0 && !__builtin_isnan(total.lam[0]);
         slot_store<D>(marg, v, ok ? mv_to_moment<D>(total) : msg_all_nan<D>());
     } else if (kind == CX_ITEM_PRODUCT_OF_MESSAGES) {
         Msg<D> acc = msg_zero<D>();
-        for (int j = tab - 1; j < hi; j++) msg_add<D>(acc, slot_load<D>(f2v, b + j * kBlock));
+        for (int j = tab - 1; j < hi; j++) msg_add<D>(acc, slot_load<D>(f2v, b + j * st));
         if (!__builtin_isnan(acc.lam[0])) slot_store<D>(prod, idx, acc);      // a dependency is undefined: not pending, the stored value stays
     }
 }
 
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_batch_mv(int64_t n, const int32_t *__restrict__ rec, int64_t nslots, int nv, const int32_t *__restrict__ vbase,
-                                                     const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
+                                                     const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ vdeg, const int32_t *__restrict__ partner,
                                                      const double *__restrict__ ptab, double *__restrict__ f2v, double *__restrict__ v2f,
                                                      double *__restrict__ marg, double *__restrict__ prod) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    batch_item_mv<D>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vinfo, partner, ptab, f2v, v2f, marg, prod);
+    batch_item_mv<D>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vinfo, vdeg, partner, ptab, f2v, v2f, marg, prod);
 }
 
 // at most kSmallBatch items: the records are the first kernel argument (cx_kernels.hip: k_batch_small)
 template <int D>
 __global__ __launch_bounds__(64) void k_batch_mv_small(SmallBatch recs, int n, const int32_t *__restrict__ vbase, const uint8_t *__restrict__ vinfo,
-                                                       const int32_t *__restrict__ partner, const double *__restrict__ ptab, double *__restrict__ f2v,
+                                                       const int32_t *__restrict__ vdeg, const int32_t *__restrict__ partner, const double *__restrict__ ptab, double *__restrict__ f2v,
                                                        double *__restrict__ v2f, double *__restrict__ marg, double *__restrict__ prod) {
     const int i = threadIdx.x;
     if (i >= n) return;
     const __attribute__((address_space(4))) int32_t *rec = (const __attribute__((address_space(4))) int32_t *)__builtin_amdgcn_kernarg_segment_ptr();
-    batch_item_mv<D>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vinfo, partner, ptab, f2v, v2f, marg, prod);
+    batch_item_mv<D>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vinfo, vdeg, partner, ptab, f2v, v2f, marg, prod);
     (void)recs;
 }
 
 void mv_launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n) {
     if (n == 0) return;
     const dim3 g((unsigned)((n + kBlock - 1) / kBlock)), b(kBlock);
-#define CX_MVB(DD) hipLaunchKernelGGL((k_batch_mv<DD>), g, b, 0, h->stream, n, d_rec, h->nslots, (int)h->nv, h->d_vbase, h->d_vinfo, h->d_partner, \
+#define CX_MVB(DD) hipLaunchKernelGGL((k_batch_mv<DD>), g, b, 0, h->stream, n, d_rec, h->nslots, (int)h->nv, h->d_vbase, h->d_vinfo, h->d_var_deg, h->d_partner, \
                                       h->d_ptab, h->d_mv_f2v, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prod)
     if (h->cfg.dim == 2) CX_MVB(2);
     else if (h->cfg.dim == 3) CX_MVB(3);
@@ -88,7 +89,7 @@ void mv_launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n) {
 
 void mv_launch_batch_small(cx_handle *h, const SmallBatch &recs, int n) {
     if (n == 0) return;
-#define CX_MVB(DD) hipLaunchKernelGGL((k_batch_mv_small<DD>), dim3(1), dim3(64), 0, h->stream, recs, n, h->d_vbase, h->d_vinfo, h->d_partner, h->d_ptab, \
+#define CX_MVB(DD) hipLaunchKernelGGL((k_batch_mv_small<DD>), dim3(1), dim3(64), 0, h->stream, recs, n, h->d_vbase, h->d_vinfo, h->d_var_deg, h->d_partner, h->d_ptab, \
                                       h->d_mv_f2v, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prod)
     if (h->cfg.dim == 2) CX_MVB(2);
     else if (h->cfg.dim == 3) CX_MVB(3);

@@ -388,7 +388,7 @@ def test_d_dimensional_chain_through_the_plugin(hip_lib, d, n, mode, tol):
         assert_close(got.mean, m, tol, f"f2v mean edge {e}", scale_by="max"); assert_close(got.covariance, S, tol, f"f2v covariance edge {e}", scale_by="max")
 
 
-@pytest.mark.parametrize("d,children,mode", [(4, 5, "per_signal"), (3, 7, "wavefront"), (64, 5, "per_signal")])
+@pytest.mark.parametrize("d,children,mode", [(4, 5, "per_signal"), (3, 7, "wavefront"), (64, 5, "per_signal"), (4, 100, "wavefront"), (2, 12, "per_signal")])
 def test_a_d_dimensional_hub_through_the_plugin(hip_lib, d, children, mode):
     """a state with `children` child states, everybody observed: the hub has degree children + 1 > 5, so the reference's default
     resolver hangs its messages and its marginal off a segment tree of ProductOfMessages signals (src/dependencies.jl:90-173).  The host

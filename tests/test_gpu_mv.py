@@ -412,10 +412,11 @@ def test_mv_tree_with_degree_4_variables(hip_lib, monkeypatch, d, form, b):
     assert_close(marg[:, d:].reshape(n, d, d), ecov, 1e-8, "tree marginal covariance vs the joint solve")
 
 
-@pytest.mark.parametrize("d,b", [(2, 3), (3, 5), (4, 4), (4, 6)])
+@pytest.mark.parametrize("d,b", [(2, 3), (3, 5), (4, 4), (4, 6), (4, 7), (2, 12), (3, 9), (4, 17)])
 def test_mv_tree_with_variables_of_degree_up_to_eight(hip_lib, d, b):
     """dim 2..4: more than four edges per variable (the reference's resolver takes any degree, src/dependencies.jl:60-125): the sweep
-    keeps up to eight incoming messages in registers (k_sweep_mv<D, 8>).  Per sweep against the numpy restatement, then the joint solve."""
+    keeps up to eight incoming messages in registers (k_sweep_mv<D, 8>); b >= 7 (round 5): inner states of degree b + 2 > 8 live in the
+    CSR tail of the slot space and get their messages from k_big_mv.  Per sweep against the numpy restatement, then the joint solve."""
     n = 1 + b + b * b
     model, emean, ecov = _branching_lgssm(n, d, seed=6 + b, b=b)
     dev = _dev(model)

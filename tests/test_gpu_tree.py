@@ -280,7 +280,7 @@ def test_a_large_bushy_tree_one_sweep(hip_lib):
     assert_close(a, b, 1e-9, "marginals vs the fused schedule at its fixed point")
 
 
-@pytest.mark.parametrize("d,b,n", [(2, 2, 31), (3, 4, 85), (4, 3, 121), (4, 6, 259)])
+@pytest.mark.parametrize("d,b,n", [(2, 2, 31), (3, 4, 85), (4, 3, 121), (4, 6, 259), (4, 11, 133), (2, 30, 31)])
 def test_d_dimensional_trees_one_sweep(hip_lib, d, b, n):
     """dim 2..4: a tree of states with b children each (degree b + 2 <= 8), every state observed through a likelihood factor: one sweep of
     the tree schedule == the joint solve == the fused schedule at its fixed point, message by message"""
