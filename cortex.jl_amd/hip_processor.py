@@ -12,6 +12,11 @@ Modes:
                 signal: a wavefront there would be a Jacobi step the reference never takes.
   "sweep"       update_marginals! runs `n_sweeps` passes of the device schedule over the whole graph (cx_sweep) and
                 marks the requested marginals computed.  The benchmarked path.
+  "reference"   update_marginals!(engine, ids) is ONE cx_sweep_for(ids) under CX_SCHED_REFERENCE: the library replays what the
+                reference's scheduler would do for exactly this request — the same signals in the same order, each from the values
+                the reference's rule call would read, loops included — as one graph launch; plans are kept per readiness state, so
+                a repeated call (new data, same request) costs one launch.  The readiness bits live in the library's shadow
+                (csrc/cx_refsched.h); the host marks the requested marginals computed.  Scalar messages.
 """
 from __future__ import annotations
 
@@ -240,8 +245,12 @@ class HipProcessor(AbstractInferenceRequestProcessor):
                  factor_rule: Callable = default_factor_rule, family: str = "gaussian", dim: int = 1):
         """dim: the dimension of every variable (1: scalars; 2, 3, 4: small matrices in registers; 64: the MFMA path).  With
         dim > 1 the factors are MvGaussianLinear, data are length-d arrays and messages MvNormalMeanCovariance."""
-        if mode not in ("per_signal", "wavefront", "sweep"):
+        if mode not in ("per_signal", "wavefront", "sweep", "reference"):
             raise ValueError(f"unknown mode {mode!r}")
+        if mode == "reference":
+            if dim != 1:
+                raise ValueError("mode 'reference' (CX_SCHED_REFERENCE) is implemented for scalar messages")
+            schedule = L.SCHED_REFERENCE
         if family not in ("gaussian", "beta"):
             raise ValueError(f"unknown family {family!r}")
         if dim != 1 and family != "gaussian":
@@ -384,6 +393,13 @@ class HipProcessor(AbstractInferenceRequestProcessor):
     def update_marginals(self, engine, ids) -> bool:
         if self.mode == "per_signal":
             return False                       # the generic scheduler drives process! one signal at a time
+        if self.mode == "reference":
+            self.dev.sweep_for(list(ids))      # ONE update_marginals! of the reference, replayed on the device (also computes the requested marginals)
+            self.launches += 1
+            for vid in ids:
+                m = get_variable_marginal(engine.get_variable(vid))
+                _host_set_value(m, HipValue(self, m.variant))
+            return True
         if self.mode == "sweep":
             self.dev.sweep(self.n_sweeps)
             self.refresh_marginals(ids)        # marginals of the messages the last sweep produced

@@ -326,6 +326,38 @@ def test_config_c1_T1000_through_the_plugin(hip_lib, mode):
         assert proc.launches <= 2 * n + 4
 
 
+def test_config_c1_through_the_plugin_in_reference_mode(hip_lib):
+    """mode "reference": update_marginals! = ONE cx_sweep_for under CX_SCHED_REFERENCE — the reference's own executions (what a trace = true
+    engine records, signal by signal) replayed on the device in one launch; a second call with new data replays the standing plan"""
+    from cortex.jl_amd import _lib as L
+
+    n = 1000
+    proc = cx.HipProcessor(mode="reference")
+    engine, x, mean, var, dataset = _run(n, proc)
+    em, ev = exact.ssm_chain_posterior(dataset, 1.0, 1.0)
+    assert_close(mean, em, 1e-9, "C1 marginal mean vs exact smoother")
+    assert_close(var, ev, 1e-9, "C1 marginal variance vs exact smoother")
+    engine_cpu = _run(n, SSMBeliefPropagationProcessor())[0]
+    order_cpu = [e.signal.variant for r in engine_cpu.get_trace().inference_requests[0].rounds for e in r.executions]
+    kinds = {V.MessageToFactor: L.ITEM_MESSAGE_TO_FACTOR, V.MessageToVariable: L.ITEM_MESSAGE_TO_VARIABLE, V.IndividualMarginal: L.ITEM_INDIVIDUAL_MARGINAL}
+    want = [(kinds[type(v)], int(v.variable_id), int(getattr(v, "factor_id", 0) or 0), 0, 0) for v in order_cpu]
+    assert proc.dev.ref_trace() == want, "the library's execution trace == the host scheduler's with the CPU processor"
+    st = proc.dev.ref_plan_stats()
+    assert proc.launches == 1 and st["executions"] == 5 * n - 4 + n and st["launches"] < st["stages"]
+    # new data, same request: the readiness state before the call is the one the second plan was made for from then on
+    rng = np.random.default_rng(9)
+    for it in range(3):
+        ys = [float(2 * i + rng.standard_normal()) for i in range(1, n + 1)]
+        for i in range(n):
+            proc.set_value(engine.get_connection_message_to_factor(engine.get_variable_ids()[n + i], engine.get_factor_ids()[i]), ys[i])
+        update_marginals(engine, x)
+        got = np.array([[get_value(get_variable_marginal(engine.get_variable(v))).mean, get_value(get_variable_marginal(engine.get_variable(v))).variance] for v in x[::97]])
+        em, ev = exact.ssm_chain_posterior(ys, 1.0, 1.0)
+        assert_close(got[:, 0], em[::97], 1e-9, f"new data {it}: mean"); assert_close(got[:, 1], ev[::97], 1e-9, f"new data {it}: variance")
+    st = proc.dev.ref_plan_stats()
+    assert st["hits"] >= 1 and st["plans"] <= 3
+
+
 # ------------------------------------------------------------------------------------------------ dim > 1 behind the plug-in
 def _make_mv_ssm(n, d, processor, A, Q, R, trace=True):
     """the graph of make_ssm_model (test/inference_engine_tests.jl:436-462) with d-dimensional variables and linear-Gaussian

@@ -231,9 +231,12 @@ def test_error_paths_leave_nothing_out_of_bounds():
     assert hub(4).status == L.OK                                           # degree 7: dim 2..4 keep up to eight messages in registers
     assert hub(64).status == L.OK                                          # degree 7 at dim 64: the other messages are summed before the rule (k_v2f64)
     hub_v9, hub_f9 = np.r_[wide.edge_var, np.full(7, wide.x_ids[0])], np.r_[wide.edge_fac, 9000 + np.arange(7)]
-    big9 = FlatGraph(hub_v9, hub_f9, np.r_[wide.factor_ids, 9000 + np.arange(7)], np.r_[wide.factor_kind, np.zeros(7, np.int32)], np.r_[wide.factor_var, np.zeros(7)],
-                     edge_role=np.r_[wide.edge_role, np.zeros(7, np.int32)], dim=4)
-    assert big9.status == L.ERR_UNSUPPORTED and "degree <= 8" in big9.error
+    big9 = lambda dim, schedule=1: FlatGraph(hub_v9, hub_f9, np.r_[wide.factor_ids, 9000 + np.arange(7)], np.r_[wide.factor_kind, np.zeros(7, np.int32)],
+                                             np.r_[wide.factor_var, np.zeros(7)], edge_role=np.r_[wide.edge_role, np.zeros(7, np.int32)], dim=dim, schedule=schedule)
+    g9 = big9(4)                                                           # degree 9 at dim 2..4 (round 5): the CSR tail, whole blocks of 256 slots
+    assert g9.status == L.OK and len(g9.arr("big_vars")) == 1 and g9.scalar("nslots") % 256 == 0 and g9.scalar("nslots") >= g9.scalar("big_start") + 9
+    for refused in (big9(64), big9(4, L.SCHED_CHAIN_SCAN)):
+        assert refused.status == L.ERR_UNSUPPORTED and "degree <= 8" in refused.error
     k = cx.synth.kary_model(2, seed=1, k_choices=(3,))
     norole = FlatGraph(k.edge_var, k.edge_fac, k.factor_ids, k.factor_kind, k.factor_var)
     assert norole.status == L.ERR_INVALID_ARGUMENT and "edge roles" in norole.error
