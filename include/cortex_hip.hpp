@@ -104,6 +104,17 @@ class Handle {
     void update_batch(const std::vector<cx_item> &items) { check(cx_update_batch(h_, items.data(), (int64_t)items.size())); }
     void update_batch_async(const std::vector<cx_item> &items) { check(cx_update_batch_async(h_, items.data(), (int64_t)items.size())); }
     void sweep(int32_t n = 1) { check(cx_sweep(h_, n)); }
+    // CX_SCHED_REFERENCE: ONE update_marginals!(engine, variable_ids) — the named variables in the caller's order, only what is pending for them
+    void sweep_for(const std::vector<int64_t> &variable_ids) { check(cx_sweep_for(h_, (int64_t)variable_ids.size(), variable_ids.data())); }
+    std::array<int64_t, 8> ref_plan_stats() const { std::array<int64_t, 8> o{}; check(cx_ref_plan_stats(h_, o.data())); return o; }      // stages, launches, executions, messages, passes, plans, hits, misses
+    std::vector<cx_item> ref_trace() const {       // the executions of the last reference-order call, in the reference's order
+        int64_t n = 0;
+        check(cx_ref_trace(h_, 0, nullptr, &n));
+        std::vector<cx_item> out((size_t)n);
+        if (n) check(cx_ref_trace(h_, n, out.data(), &n));
+        return out;
+    }
+    void set_damping(double lambda) { check(cx_set_damping(h_, lambda)); }      // fused / flooding sweeps: new = (1 - lambda) rule + lambda old
     double residual() { double r = 0; check(cx_residual(h_, &r)); return r; }
     std::array<int64_t, 4> message_health() { std::array<int64_t, 4> o{}; check(cx_message_health(h_, o.data())); return o; }      // defined, undefined, negative precision, non-finite
     std::pair<int32_t, double> sweep_until(double tol, int32_t max_sweeps, int32_t check_every = 10) {

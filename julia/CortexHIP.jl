@@ -20,6 +20,7 @@ end
 
 mutable struct HipProcessor <: Cortex.AbstractInferenceRequestProcessor
     handle::Ptr{Cvoid}
+    schedule::Int              # CX_SCHED_* the handle was created with
     dim::Int                   # 1: scalar messages; 2 .. 64: d-dimensional linear-Gaussian messages (2, 3, 4 in registers, 64 on the matrix cores, 5 .. 63 embedded in the dim 64 path)
     queue::Vector{CxItem}
     signals::Vector{Cortex.InferenceSignal}
@@ -27,14 +28,18 @@ end
 
 check(h, rc) = rc == 0 ? nothing : error(unsafe_string(ccall((:cx_last_error, lib), Cstring, (Ptr{Cvoid},), h)))
 
-# schedule: 0 flooding, 1 fused (default), 2 chain scan (paths: one cx_sweep = one update_marginals!), 3 tree (any forest: the same)
+# schedule: 0 flooding, 1 fused (default), 2 chain scan (paths: one cx_sweep = one update_marginals!), 3 tree (any forest: the same),
+#           4 REFERENCE ORDER (ABI 3; dim 1): ANY graph, loops included — update_marginals!(engine, ids) below becomes ONE cx_sweep_for(ids):
+#           the signals Cortex.jl's own scheduler would compute for exactly this request, in its order, each from the values its rule
+#           call would read (the library keeps a shadow of the readiness nibbles, driven by set_datum! / set_message! / process! / the
+#           calls themselves), replayed as one graph launch; lazy like the reference (priors are re-set before a call to be fresh)
 # marginals: 1 every sweep writes every marginal; 2 (chain scan, dim 2 .. 4) on demand — formed when get_marginals asks
 function HipProcessor(; device = 0, dim = 1, schedule = 1, marginals = 1)
     cfg = Ref(CxConfig(sizeof(CxConfig), device, dim, schedule, marginals, 0, 0, 0))
     out = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:cx_create, lib), Int32, (Ref{CxConfig}, Ref{Ptr{Cvoid}}), cfg, out)
     rc == 0 || error(unsafe_string(ccall((:cx_last_error, lib), Cstring, (Ptr{Cvoid},), C_NULL)))
-    p = HipProcessor(out[], dim, CxItem[], Cortex.InferenceSignal[])
+    p = HipProcessor(out[], schedule, dim, CxItem[], Cortex.InferenceSignal[])
     finalizer(q -> ccall((:cx_destroy, lib), Int32, (Ptr{Cvoid},), q.handle), p)
     return p
 end
@@ -94,10 +99,27 @@ function flush!(p::HipProcessor)
 end
 struct HipValue end                           # the payload stays in HBM; read it back with cx_get_messages / cx_get_marginals
 
-# whole-sweep mode
+# where the user calls set_value!(message_to_variable(x, prior), NormalMeanVariance(m, v)) (priors, seeds; dim == 1)
+function set_message!(p::HipProcessor, signal::Cortex.InferenceSignal, mean, variance)
+    v = Cortex.get_variant(signal)
+    dir = v isa Cortex.InferenceSignalVariants.MessageToFactor ? 1 : 2                  # CX_TO_FACTOR / CX_TO_VARIABLE
+    check(p.handle, ccall((:cx_set_messages, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Int32, Int32, Ptr{Float64}),
+                          p.handle, 1, Int64[v.variable_id], Int64[v.factor_id], dir, 0, Float64[mean, variance]))           # CX_FORM_MOMENT
+    Cortex.set_value!(signal, (mean = mean, variance = variance))
+end
+
+# damping of the fused / flooding sweeps (ABI 3): new = (1 - lambda) rule + lambda old; 0 = off
+set_damping!(p::HipProcessor, lambda) = check(p.handle, ccall((:cx_set_damping, lib), Int32, (Ptr{Cvoid}, Float64), p.handle, lambda))
+
+# whole-call mode.  Under schedule 4 the request is honoured as the reference honours it — the named variables, in the caller's order,
+# only what is pending for them (src/inference_engine.jl:298-323,559-632): cx_sweep_for.  The other schedules compute every message.
 function Cortex.update_marginals!(engine::Cortex.InferenceEngine{M,D,HipProcessor}, ids::Union{AbstractVector,Tuple}) where {M,D}
     p = Cortex.get_inference_request_processor(engine)
-    check(p.handle, ccall((:cx_sweep, lib), Int32, (Ptr{Cvoid}, Int32), p.handle, 1))
+    if p.schedule == 4
+        check(p.handle, ccall((:cx_sweep_for, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}), p.handle, length(ids), collect(Int64, ids)))
+    else
+        check(p.handle, ccall((:cx_sweep, lib), Int32, (Ptr{Cvoid}, Int32), p.handle, 1))
+    end
     d = p.dim
     out = Matrix{Float64}(undef, d == 1 ? 2 : d + d * d, length(ids))           # per marginal: mean[d] then covariance[d*d]
     check(p.handle, ccall((:cx_get_marginals, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Float64}),
@@ -172,6 +194,21 @@ set_factor_coefficients!(p, variable_ids::Vector{Int64}, factor_ids::Vector{Int6
                           p.handle, length(a), variable_ids, factor_ids, a))
 
 # the plan of the dim 64 chain-scan schedule: (links per block, fan, levels, potentials, compositions, rules, launches, device bytes)
+# schedule 4: the executions of the last call in the reference's order — what a `trace = true` engine records as
+# TracedInferenceExecution.signal (src/inference_engine.jl:650-862) — as (kind, variable_id, factor_id | range) items
+function reference_trace(p)
+    n = Ref{Int64}(0)
+    check(p.handle, ccall((:cx_ref_trace, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{CxItem}, Ref{Int64}), p.handle, 0, C_NULL, n))
+    items = Vector{CxItem}(undef, n[])
+    check(p.handle, ccall((:cx_ref_trace, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{CxItem}, Ref{Int64}), p.handle, n[], items, n))
+    return items
+end
+function reference_plan_stats(p)       # stages, launches, executions, messages, passes, plans kept, calls that replayed a plan, calls that ran the scheduler
+    out = zeros(Int64, 8)
+    check(p.handle, ccall((:cx_ref_plan_stats, lib), Int32, (Ptr{Cvoid}, Ptr{Int64}), p.handle, out))
+    return out
+end
+
 function tree_plan_stats(p)            # CX_SCHED_TREE (schedule = 3): depth, stages, items, k-ary entries, components, up, down, marginals
     out = zeros(Int64, 8)
     check(p.handle, ccall((:cx_tree_plan_stats, lib), Int32, (Ptr{Cvoid}, Ptr{Int64}), p.handle, out))
