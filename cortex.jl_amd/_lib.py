@@ -61,6 +61,7 @@ SIGNATURES = {
     "cx_graph_stats": (_i32, [_vp, C.POINTER(Stats)]),
     "cx_tile_stats": (_i32, [_vp, _pi64, _pd, _pi64]),
     "cx_set_factor_coefficients": (_i32, [_vp, _i64, _pi64, _pi64, _pd]),
+    "cx_set_factor_edge_sets": (_i32, [_vp, _i64, _pi64, _pi64, _pi64]),
     "cx_edge_index": (_i32, [_vp, _i64, _pi64, _pi64, _pi64]),
     "cx_payload_doubles": (_i64, [_i32, _i32]),
     "cx_set_messages": (_i32, [_vp, _i64, _pi64, _pi64, _i32, _i32, _pd]),

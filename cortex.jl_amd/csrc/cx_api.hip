@@ -228,6 +228,7 @@ int32_t cx_set_factor_matrices(cx_handle *h, int64_t parameter_set, const double
         if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) { int32_t rc0 = mv_ensure_chain_msgs(h); if (rc0 != CX_OK) return rc0; }   // under the old tables
         // the messages out of observed variables, N(A y, Q), are cached in both Jacobi buffers: new (A, Q) invalidates them
         h->observed_passes_due = 2;
+        h->kary_dirty = true;             // dim 2..4 factors of more than two variables read the raw (A, Q)
         h->point64_dirty = true;
         h->chain_side_dirty = true;
         return upload_ptab(h);

@@ -485,6 +485,7 @@ int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
         CX_REQUIRE(h, !h->psets[i].empty(), CX_ERR_STATE, "cx_update_batch: parameter set " + std::to_string(i) + " was never set (cx_set_factor_matrices)");
     int32_t rc = mv_ensure_chain_msgs(h);
     if (rc != CX_OK) return rc;
+    if ((rc = cx::kary_upload(h)) != CX_OK) return rc;
     const bool d64 = h->cfg.dim == 64;
     std::vector<int32_t> rec, v2f_slots, v2f_vars, point_slots, rule_rec, slot_var, prod_rec;
     if (d64) {
@@ -505,6 +506,11 @@ int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
             if (e < 0) return fail(h, CX_ERR_NOT_FOUND, "no connection between variable " + std::to_string(it.variable_id) + " and factor " + std::to_string(it.factor_id));
             idx = cx::slot_of_edge(h, e); var = h->edge_var[e];
             const int32_t p = h->partner[idx];
+            if (!d64 && it.kind == CX_ITEM_MESSAGE_TO_VARIABLE && !h->slot_kary.empty() && h->slot_kary[idx] >= 0) {
+                // a message out of a factor of more than two variables: from the stored messages of the factor's other edges (cx_kary_mv_core.h)
+                rec[5 * i] = 32; rec[5 * i + 1] = h->slot_kary[idx]; rec[5 * i + 2] = (int32_t)var;
+                continue;
+            }
             if (it.kind == CX_ITEM_MESSAGE_TO_VARIABLE && p >= 0) tab = h->spdir[p];      // the rule table of the SENDING slot (unmasked: any message can be asked for)
             if (d64) {
                 if (it.kind == CX_ITEM_MESSAGE_TO_FACTOR) { v2f_slots.push_back((int32_t)idx); v2f_vars.push_back((int32_t)var); continue; }
@@ -595,6 +601,7 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
     for (int64_t i = 0; i <= h->max_pset; i++)
         CX_REQUIRE(h, !h->psets[i].empty(), CX_ERR_STATE, "cx_sweep: parameter set " + std::to_string(i) + " was never set (cx_set_factor_matrices)");
     if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) return mv_chain_sweep(h, n_sweeps);
+    { const int32_t rck = cx::kary_upload(h); if (rck != CX_OK) return rck; }      // factors of more than two variables: their table and matrices
     if (h->cfg.schedule == CX_SCHED_TREE) {
         // dim 2..4 on a forest (cx_tree_plan.h): the stages' items through k_batch_mv, in place in the one message buffer; the items
         // carry the rule table of the sending slot as the plan found it (the plan is rebuilt when a variable becomes observed)
@@ -631,6 +638,7 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
             if (h->observed_passes_due > 0) { cx::mv_launch_sweep(h, false, 1); h->observed_passes_due--; }
             cx::mv_launch_sweep(h, h->cfg.compute_marginals_in_sweep != 0, 0);
             cx::mv_launch_big(h, h->cfg.compute_marginals_in_sweep != 0);      // variables of degree > 8 (none on most graphs: no launch)
+            cx::mv_launch_kary(h);                                             // factors of more than two variables (the same)
         }
         std::swap(h->d_mv_f2v, h->d_mv_f2v_alt);
         h->sweeps_done++;

@@ -58,6 +58,7 @@ uint64_t graph_fingerprint(const cx_handle *h) {
     f = fnv1a(f, h->spdir.data(), h->spdir.size() * 4);
     for (const auto &ps : h->psets) { const uint64_t n = ps.size(); f = fnv1a(f, &n, 8); f = fnv1a(f, ps.data(), ps.size() * 8); }
     if (h->n_kary) { f = fnv1a(f, h->kary_slot.data(), h->kary_slot.size() * 4); f = fnv1a(f, h->kary_coef.data(), h->kary_coef.size() * 8); }
+    if (h->n_kary && h->cfg.dim > 1) f = fnv1a(f, h->kary_pset.data(), h->kary_pset.size() * 4);
     if (h->user_dim) { const int32_t u = h->user_dim; f = fnv1a(f, &u, 4); }      // dim 5 .. 63 embedded in 64: the real block's size is part of the model
     return f;
 }

@@ -132,7 +132,7 @@ int32_t build_tree(cx_handle *h) {
         // when it needs fewer launches than the level schedule's 2 x depth + 1 — chains with side branches, not bushy trees.
         // CX_TREE_HP=0 / 1: never / whenever the graph allows (A/B, tests).
         h->tree_hp = false;
-        const bool hp_mv = h->cfg.dim >= 2 && h->cfg.dim <= 4 && h->big_vars.empty();      // (dim 2 .. 4: the scans of cx_mvchain.hip per light depth; their side sums take degree <= 8: a graph with a hub runs level by level)
+        const bool hp_mv = h->cfg.dim >= 2 && h->cfg.dim <= 4 && h->big_vars.empty() && h->n_kary == 0;      // (dim 2 .. 4: the scans of cx_mvchain.hip per light depth; their side sums take degree <= 8: a graph with a hub runs level by level)
         const bool hp64 = h->cfg.dim == 64;                          // (dim 64: a plan of compositions and walks per light depth, cx_mv64chain.hip)
         cx::chain64_tree_free(h);
         h->tree_c64_up.clear(); h->tree_c64_final.clear();

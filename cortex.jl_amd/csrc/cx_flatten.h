@@ -116,7 +116,7 @@ int32_t flatten(H *h, int64_t n_edges, const int64_t *edge_var, const int64_t *e
     }
     h->nf = n_factors;
     h->lin_out_is_second.assign(n_factors, 0); h->fac_edges.clear();
-    h->n_kary = 0; h->kary_slot.clear(); h->kary_coef.clear(); h->kary_qb.clear(); h->slot_kary.clear(); h->kary_dirty = true;
+    h->n_kary = 0; h->kary_slot.clear(); h->kary_coef.clear(); h->kary_qb.clear(); h->slot_kary.clear(); h->kary_pset.clear(); h->kary_dirty = true;
     std::vector<int32_t> edge_fix(ne);      // local factor number per CSR edge
     for (int64_t e = 0; e < ne; e++) {
         auto it = std::lower_bound(h->fac_ids.begin(), h->fac_ids.end(), h->edge_fac_id[e]);
@@ -174,13 +174,18 @@ int32_t flatten(H *h, int64_t n_edges, const int64_t *edge_var, const int64_t *e
             // more than two edges (cx_kary.hip): every edge's message reads all the others' (dependencies.jl:17-31).  Entry order: the OUT
             // edge, then the IN edges by ascending variable id; coefficients start at a_i = 1 (cx_set_factor_coefficients)
             const std::string who = "cx_graph_create: CX_FACTOR_GAUSS_LINEAR_N (factor id " + std::to_string(h->fac_ids[f]) + ")";
-            if (mv) return fail_(err, CX_ERR_UNSUPPORTED, who + " needs dim == 1");
+            // dim 2..4 (round 5): x_out = A_1 x_1 + ... + A_k x_k + N(0, Q); params[0] names the parameter set whose Q is the noise and whose A is
+            // every input's matrix until cx_set_factor_edge_sets says otherwise (cx_kary_mv_core.h)
+            if (mv && h->cfg.dim == 64) return fail_(err, CX_ERR_UNSUPPORTED, who + ": dim 64 (and 5 .. 63 with it) takes factors of two variables");
             if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) return fail_(err, CX_ERR_UNSUPPORTED, who + ": a factor of three or more variables is not a link of a chain (use the tree, the fused or the flooding schedule)");
             if (deg < 3 || deg > 7) return fail_(err, CX_ERR_UNSUPPORTED, who + " takes 2 to 6 inputs and one output (3 to 7 edges), not " + std::to_string(deg) + " edges");
-            if (!(p[0] >= 0.0)) return fail_(err, CX_ERR_INVALID_ARGUMENT, who + ": the variance q must be >= 0");
+            if (!mv && !(p[0] >= 0.0)) return fail_(err, CX_ERR_INVALID_ARGUMENT, who + ": the variance q must be >= 0");
+            if (mv && (p[0] < 0 || (double)(int64_t)p[0] != p[0])) return fail_(err, CX_ERR_INVALID_ARGUMENT, who + ": params[0] must be a parameter-set index");
+            if (mv) h->max_pset = std::max<int64_t>(h->max_pset, (int64_t)p[0]);
             if (!edge_role) return fail_(err, CX_ERR_INVALID_ARGUMENT, who + " needs edge roles (one CX_ROLE_OUT, the rest CX_ROLE_IN)");
             const size_t row = (size_t)h->n_kary++;
             h->kary_slot.resize(8 * (row + 1), -1); h->kary_coef.resize(8 * (row + 1), 0.0);
+            h->kary_pset.resize(8 * (row + 1), mv ? (int32_t)p[0] : -1);
             h->kary_qb.push_back(p[0]); h->kary_qb.push_back(p[1]);
             if (h->slot_kary.empty()) h->slot_kary.assign(slots, -1);
             int n_in = 0, n_out = 0;

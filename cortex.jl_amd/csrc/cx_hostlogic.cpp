@@ -90,7 +90,7 @@ struct HostGraph {                       // the host fields of cx_handle that cx
     bool any_linear = false;
     int32_t big_start = 0;
     int64_t n_kary = 0;
-    std::vector<int32_t> kary_slot, slot_kary;
+    std::vector<int32_t> kary_slot, slot_kary, kary_pset;
     std::vector<double> kary_coef, kary_qb;
     bool kary_dirty = true;
     // deep halo (cx_halo_plan.h)

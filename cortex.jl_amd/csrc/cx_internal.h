@@ -77,6 +77,10 @@ struct cx_handle {
     // ascending variable id); coefficient c_e = +1 (OUT) / -a_i (IN); their slots have partner -1 (no pairwise rule touches them)
     int64_t n_kary = 0;
     std::vector<int32_t> kary_slot, slot_kary;      // [8 n_kary] slot per entry (-1 padding); [nslots] entry of a slot, -1 otherwise
+    std::vector<int32_t> kary_pset;                 // dim 2..4 (cx_kary_mv.hip): [8 n_kary] parameter set of the entry — an IN entry's A, the OUT entry's Q
+    int32_t *d_kary_pset = nullptr, *d_kary_v2f_slots = nullptr, *d_kary_v2f_vars = nullptr;
+    double *d_kary_aq = nullptr;                    // [sets][2][d * d]: A | Q raw
+    int64_t n_kary_v2f = 0, kary_aq_sets = 0;
     std::vector<double> kary_coef, kary_qb;         // [8 n_kary] c_e; [2 n_kary] q, b
     int32_t *d_kary_slot = nullptr, *d_slot_kary = nullptr;
     double *d_kary_coef = nullptr, *d_kary_qb = nullptr;
@@ -270,6 +274,10 @@ void kary_free(cx_handle *h);
 void launch_kary(cx_handle *h, const double2 *v2f, double2 *f2v_out);
 void launch_kary_items(cx_handle *h, const int32_t *d_entries, int64_t n);
 void launch_kary_link_params(cx_handle *h, int64_t link_lo, int64_t nlinks, double *a, double *b);
+// the same factors for dim 2..4 (cx_kary_mv.hip)
+int32_t kary_mv_upload(cx_handle *h);
+void kary_mv_free(cx_handle *h);
+void mv_launch_kary(cx_handle *h, double *f2v_out = nullptr);
 void launch_residual(cx_handle *h, const double2 *cur, const double2 *prev, int64_t n, double *d_out);
 void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_form, bool chain_v2f);
 void launch_chain_totals(cx_handle *h, double2 *f2v, bool fused_leaves, int64_t *ntiles_out);

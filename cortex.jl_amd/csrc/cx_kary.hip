@@ -98,6 +98,7 @@ __global__ void k_kary_link_params(int n, const int32_t *__restrict__ from, cons
 }  // namespace
 
 int32_t kary_upload(cx_handle *h) {
+    if (h->cfg.dim > 1) return kary_mv_upload(h);
     if (h->n_kary == 0 || !h->kary_dirty) return CX_OK;
     using namespace cxh;
     int32_t rc;
@@ -117,9 +118,10 @@ int32_t kary_upload(cx_handle *h) {
 }
 
 void kary_free(cx_handle *h) {
+    kary_mv_free(h);
     for (void *p : {(void *)h->d_kary_slot, (void *)h->d_kary_coef, (void *)h->d_kary_qb, (void *)h->d_slot_kary}) if (p) (void)hipFree(p);
     h->d_kary_slot = h->d_slot_kary = nullptr; h->d_kary_coef = h->d_kary_qb = nullptr;
-    h->n_kary = 0; h->kary_slot.clear(); h->kary_coef.clear(); h->kary_qb.clear(); h->slot_kary.clear(); h->kary_dirty = true;
+    h->n_kary = 0; h->kary_slot.clear(); h->kary_coef.clear(); h->kary_qb.clear(); h->slot_kary.clear(); h->kary_pset.clear(); h->kary_dirty = true;
 }
 
 // all factor→variable messages of the k-ary factors from the stored variable→factor messages

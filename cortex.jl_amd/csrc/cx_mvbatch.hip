@@ -17,6 +17,7 @@
 
 #include "cx_internal.h"
 #include "cx_mv_core.h"
+#include "cx_kary_mv_core.h"
 
 namespace cx {
 
@@ -25,7 +26,8 @@ namespace cx {
 template <int D>
 __device__ __forceinline__ void batch_item_mv(int kind, int idx, int v, int tab, int hi, const int32_t *__restrict__ vbase, const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ vdeg,
                                               const int32_t *__restrict__ partner, const double *__restrict__ ptab, double *__restrict__ f2v,
-                                              double *__restrict__ v2f, double *__restrict__ marg, double *__restrict__ prod) {
+                                              double *__restrict__ v2f, double *__restrict__ marg, double *__restrict__ prod, const KaryMvTab kt) {
+    if (kind == 32) { kary_item_mv<D>(idx, kt, v2f, f2v, nullptr, 0.0); return; }      // a message out of a factor of more than two variables (index = entry of its table)
     // (a variable of degree > 8 lives in the CSR tail: consecutive slots; the others in their slice, a slot every 256)
     const int info = vinfo[v], deg = vdeg[v], b = vbase[v], st = (info & kDegMask) == kBigDeg ? 1 : kBlock;
     if (kind == CX_ITEM_MESSAGE_TO_FACTOR) {
@@ -58,21 +60,21 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void k_batch_mv(int64_t n, const int32_t *__restrict__ rec, int64_t nslots, int nv, const int32_t *__restrict__ vbase,
                                                      const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ vdeg, const int32_t *__restrict__ partner,
                                                      const double *__restrict__ ptab, double *__restrict__ f2v, double *__restrict__ v2f,
-                                                     double *__restrict__ marg, double *__restrict__ prod) {
+                                                     double *__restrict__ marg, double *__restrict__ prod, const KaryMvTab kt) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    batch_item_mv<D>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vinfo, vdeg, partner, ptab, f2v, v2f, marg, prod);
+    batch_item_mv<D>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vinfo, vdeg, partner, ptab, f2v, v2f, marg, prod, kt);
 }
 
 // at most kSmallBatch items: the records are the first kernel argument (cx_kernels.hip: k_batch_small)
 template <int D>
 __global__ __launch_bounds__(64) void k_batch_mv_small(SmallBatch recs, int n, const int32_t *__restrict__ vbase, const uint8_t *__restrict__ vinfo,
                                                        const int32_t *__restrict__ vdeg, const int32_t *__restrict__ partner, const double *__restrict__ ptab, double *__restrict__ f2v,
-                                                       double *__restrict__ v2f, double *__restrict__ marg, double *__restrict__ prod) {
+                                                       double *__restrict__ v2f, double *__restrict__ marg, double *__restrict__ prod, const KaryMvTab kt) {
     const int i = threadIdx.x;
     if (i >= n) return;
     const __attribute__((address_space(4))) int32_t *rec = (const __attribute__((address_space(4))) int32_t *)__builtin_amdgcn_kernarg_segment_ptr();
-    batch_item_mv<D>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vinfo, vdeg, partner, ptab, f2v, v2f, marg, prod);
+    batch_item_mv<D>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vinfo, vdeg, partner, ptab, f2v, v2f, marg, prod, kt);
     (void)recs;
 }
 
@@ -80,7 +82,8 @@ void mv_launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n) {
     if (n == 0) return;
     const dim3 g((unsigned)((n + kBlock - 1) / kBlock)), b(kBlock);
 #define CX_MVB(DD) hipLaunchKernelGGL((k_batch_mv<DD>), g, b, 0, h->stream, n, d_rec, h->nslots, (int)h->nv, h->d_vbase, h->d_vinfo, h->d_var_deg, h->d_partner, \
-                                      h->d_ptab, h->d_mv_f2v, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prod)
+                                      h->d_ptab, h->d_mv_f2v, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prod, kt)
+    const KaryMvTab kt{h->d_kary_slot, h->d_kary_pset, h->d_kary_aq};
     if (h->cfg.dim == 2) CX_MVB(2);
     else if (h->cfg.dim == 3) CX_MVB(3);
     else CX_MVB(4);
@@ -90,7 +93,8 @@ void mv_launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n) {
 void mv_launch_batch_small(cx_handle *h, const SmallBatch &recs, int n) {
     if (n == 0) return;
 #define CX_MVB(DD) hipLaunchKernelGGL((k_batch_mv_small<DD>), dim3(1), dim3(64), 0, h->stream, recs, n, h->d_vbase, h->d_vinfo, h->d_var_deg, h->d_partner, h->d_ptab, \
-                                      h->d_mv_f2v, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prod)
+                                      h->d_mv_f2v, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prod, kt)
+    const KaryMvTab kt{h->d_kary_slot, h->d_kary_pset, h->d_kary_aq};
     if (h->cfg.dim == 2) CX_MVB(2);
     else if (h->cfg.dim == 3) CX_MVB(3);
     else CX_MVB(4);

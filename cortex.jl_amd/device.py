@@ -84,6 +84,11 @@ class DeviceGraph:
             raise ValueError(f"A and Q must be {self.dim}x{self.dim}")
         self._check(self.lib.cx_set_factor_matrices(self.h, int(parameter_set), _p(A, C.c_double), _p(Q, C.c_double)))
 
+    def set_factor_edge_sets(self, variable_ids, factor_ids, parameter_sets):
+        """cx_set_factor_edge_sets: dim 2..4, the A_i of ROLE_IN edges of CX_FACTOR_GAUSS_LINEAR_N factors by parameter set"""
+        v, f, s = _i64(np.atleast_1d(variable_ids)), _i64(np.atleast_1d(factor_ids)), _i64(np.atleast_1d(parameter_sets))
+        self._check(self.lib.cx_set_factor_edge_sets(self.h, len(v), _p(v, C.c_int64), _p(f, C.c_int64), _p(s, C.c_int64)))
+
     def stats(self) -> dict:
         s = L.Stats()
         self._check(self.lib.cx_graph_stats(self.h, C.byref(s)))

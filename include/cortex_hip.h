@@ -95,7 +95,9 @@ extern "C" {
                                        the message to the other is Beta(1 + r, 2 - r) = natural (r, 1 - r): the :bernoulli
                                        factor of test/inference_engine_tests.jl:250-262.  Without a datum the reference's rule
                                        is error(...): the message stays undefined */
-#define CX_FACTOR_GAUSS_LINEAR_N 5   /* dim == 1, 3 to 7 edges: x_out = a_1 x_1 + ... + a_k x_k + b + N(0, q), k = 2..6 inputs; params = {q, b};
+#define CX_FACTOR_GAUSS_LINEAR_N 5   /* 3 to 7 edges.  dim 2, 3, 4 (ABI 3): x_out = A_1 x_1 + ... + A_k x_k + N(0, Q), params = {parameter set}: its Q is the noise, its A
+                                        every input's matrix unless cx_set_factor_edge_sets names another set for an edge; fused and tree schedules,
+                                        batch items.  dim == 1: x_out = a_1 x_1 + ... + a_k x_k + b + N(0, q), k = 2..6 inputs; params = {q, b};
                                         exactly one CX_ROLE_OUT edge, the others CX_ROLE_IN; a_i = 1 unless cx_set_factor_coefficients says
                                         otherwise.  Every factor→variable message of the factor reads ALL its other variable→factor
                                         messages (src/dependencies.jl:17-31).  Flooding and fused schedules; not under partitions. */
@@ -229,6 +231,9 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
 int32_t cx_set_factor_matrices(cx_handle *h, int64_t parameter_set, const double *A, const double *Q);
 /* a_i of ROLE_IN edges of CX_FACTOR_GAUSS_LINEAR_N factors (finite, non-zero; default 1).  Takes effect at the next sweep. */
 int32_t cx_set_factor_coefficients(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, const double *a);
+/* dim 2, 3, 4: x_out = A_1 x_1 + ... + A_k x_k + N(0, Q) for a CX_FACTOR_GAUSS_LINEAR_N factor: the factor's params[0] names the parameter set
+ * whose Q is the noise and whose A is every input's matrix; this call gives the CX_ROLE_IN edge (variable, factor) the A of another set. */
+int32_t cx_set_factor_edge_sets(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, const int64_t *parameter_sets);
 int32_t cx_graph_stats(const cx_handle *h, cx_stats *out);
 /* the tiles of the two-sweep launches (cx_config.sweeps_per_launch): how many, how many variables a tile loads per variable it
  * owns (its two-hop ring), LDS bytes per workgroup; all 0 while no tiles exist (not built yet, or the graph cannot be tiled) */
