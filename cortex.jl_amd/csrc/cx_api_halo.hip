@@ -13,7 +13,7 @@ static inline int64_t halo_doubles(const cx_handle *h) { return h->cfg.dim == 1 
 
 int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const int64_t *sf, int64_t n_recv,
                           const int64_t *rv, const int64_t *rf) {
-    CX_REQUIRE(h, !h || h->n_kary == 0, CX_ERR_UNSUPPORTED, "halo configuration: partitions are implemented for unary and pairwise factors (this graph has CX_FACTOR_GAUSS_LINEAR_N factors)");
+    CX_REQUIRE(h, !h || h->n_kary == 0, CX_ERR_UNSUPPORTED, "cx_halo_configure: per-sweep message halos are implemented for unary and pairwise factors (this graph has CX_FACTOR_GAUSS_LINEAR_N factors: use state halos, cx_halo_configure_state)");
     CX_NOT_VMP(h, "cx_halo_configure");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_configure: no graph");
     CX_REQUIRE(h, h->cfg.schedule != CX_SCHED_REFERENCE, CX_ERR_UNSUPPORTED, "cx_halo_configure: the reference-order schedule is sequential by definition and is not partitioned");
@@ -64,7 +64,10 @@ int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const
 // (the error of the frozen outer edge advances one row per sweep).
 int32_t cx_halo_configure_state(cx_handle *h, int64_t n_send, const int64_t *sv, const int64_t *sf, int64_t n_recv,
                                 const int64_t *rv, const int64_t *rf) {
-    CX_REQUIRE(h, !h || h->n_kary == 0, CX_ERR_UNSUPPORTED, "halo configuration: partitions are implemented for unary and pairwise factors (this graph has CX_FACTOR_GAUSS_LINEAR_N factors)");
+    // (round 5) graphs with factors of more than two variables are cut like any other under STATE halos: the exchanged state is the
+    // factor→variable messages of the redundant variables whatever factor sent them, and a cut factor keeps all its variables on every
+    // rank that holds one of them within the halo (cortex.jl_amd/partition.py: by_assignment_deep).  The per-sweep message halo
+    // (cx_halo_configure) still takes unary and pairwise factors only: its import pushes a ghost's message through ONE partner edge.
     CX_NOT_VMP(h, "cx_halo_configure_state");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_halo_configure_state: no graph");
     CX_REQUIRE(h, h->cfg.schedule != CX_SCHED_CHAIN_SCAN && h->cfg.schedule != CX_SCHED_REFERENCE, CX_ERR_UNSUPPORTED,

@@ -217,10 +217,17 @@ def by_assignment_deep(model: synth.Model, owner_of_variable, rank: int, world: 
     fs, vx = ef[order], vix[order]
     first = np.flatnonzero(np.r_[True, fs[1:] != fs[:-1]])
     counts = np.diff(np.r_[first, len(fs)])
-    if np.any(counts > 2):
-        raise ValueError("by_assignment_deep handles unary and pairwise factors")
-    two = first[counts == 2]
-    a, b = vx[two], vx[two + 1]
+    # variables are adjacent when they share a factor: the two ends of a pairwise factor, every pair of a factor of more variables
+    # (round 5: CX_FACTOR_GAUSS_LINEAR_N — a cut factor then keeps ALL its variables on every rank that holds one of them within the
+    # halo, the ones beyond it as stand-ins)
+    a_list, b_list = [], []
+    for k in np.unique(counts[counts >= 2]):
+        st = first[counts == k]
+        for i in range(int(k)):
+            for j in range(i + 1, int(k)):
+                a_list.append(vx[st + i]); b_list.append(vx[st + j])
+    a = np.concatenate(a_list) if a_list else np.zeros(0, np.int64)
+    b = np.concatenate(b_list) if b_list else np.zeros(0, np.int64)
     A = sp.coo_matrix((np.ones(2 * len(a), np.int8), (np.r_[a, b], np.r_[b, a])), shape=(nv, nv)).tocsr()
 
     def layers(r):
@@ -271,6 +278,12 @@ def by_assignment_deep(model: synth.Model, owner_of_variable, rank: int, world: 
                         factor_var=np.asarray(model.factor_var)[keep_f], x_ids=x_loc, data_var=dv, data_fac=df, data_y=dy,
                         prior_var=pv, prior_fac=pf, prior_mean=pm, prior_variance=pvv, meta=dict(model.meta),
                         dim=model.dim, edge_role=loc_role, psets=dict(model.psets))
+
+    if "coef_var" in local.meta:      # per-edge coefficients of factors of more than two variables (synth.kary_model): the local edges' only
+        cvv, cff, caa = (np.asarray(local.meta[k]) for k in ("coef_var", "coef_fac", "coef"))
+        have = set(zip(loc_var.tolist(), loc_fac.tolist()))
+        m = np.array([(int(v), int(f)) in have for v, f in zip(cvv, cff)], dtype=bool) if len(cvv) else np.zeros(0, bool)
+        local.meta["coef_var"], local.meta["coef_fac"], local.meta["coef"] = cvv[m], cff[m], caa[m]
 
     def edges_of(mask_v):
         m = mask_v[vix]

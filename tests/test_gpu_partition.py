@@ -748,3 +748,52 @@ def test_a_batch_of_d_dimensional_chains_dealt_to_ranks(hip_lib):
         assert_close(dev.get_marginals(sub.x_ids), np.array([ref[int(v)] for v in sub.x_ids]), 1e-9, f"rank {r}: marginals vs the single handle",
                      scale_by="max")      # (most covariance entries are ~ 0: the median is no scale)
         dev.close()
+
+
+@pytest.mark.parametrize("seed,world,depth,n_factors", [(0, 2, 1, 30), (1, 3, 2, 60), (2, 4, 3, 150), (3, 4, 1, 600)])
+def test_deep_partition_of_graphs_with_factors_of_more_than_two_variables(hip_lib, seed, world, depth, n_factors):
+    """(round 5) loopy models of CX_FACTOR_GAUSS_LINEAR_N factors (3 - 7 edges) under state halos: a cut factor keeps all its variables
+    on every rank that holds one of them within the halo; owned messages and marginals bit-identical to the un-partitioned sweeps"""
+    import torch
+
+    whole_model = cx.synth.kary_model(n_factors, seed=40 + seed, tree=False)
+    used = np.unique(whole_model.edge_var)
+    owner_map = np.random.default_rng(seed).integers(0, world, int(used.max()) + 1)
+    owner = lambda ids: owner_map[np.asarray(ids, np.int64)]      # noqa: E731
+    sweeps = 3 * depth + 2
+    whole = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(whole_model, whole, seed_variance=1e6)
+    whole.sweep(sweeps)
+    ld = LoopbackDist(world, torch)
+    devs, parts, errors = [None] * world, [None] * world, []
+
+    def run(rank):
+        try:
+            ld.bind(rank)
+            part = partition.by_assignment_deep(whole_model, owner, rank, world, depth)
+            dev = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+            cx.synth.load_into_device(part.model, dev, seed_variance=1e6)
+            ex = partition.DeepHaloExchange(partition.DeviceStateSweeper(dev, part, torch, torch.device("cuda", 0)), part, ld)
+            ex.sweep(sweeps)
+            dev.sync()
+            devs[rank], parts[rank] = dev, part
+        except Exception as e:  # pragma: no cover
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    checked = 0
+    for rank in range(world):
+        part = parts[rank]
+        if len(part.owned_x) == 0:
+            continue
+        own = np.isin(part.model.edge_var, part.owned_x)
+        ev, ef = part.model.edge_var[own], part.model.edge_fac[own]
+        assert np.array_equal(devs[rank].get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL), whole.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL), equal_nan=True)
+        assert np.array_equal(devs[rank].get_marginals(part.owned_x), whole.get_marginals(part.owned_x), equal_nan=True)
+        checked += len(ev)
+    assert checked > 0
