@@ -284,6 +284,11 @@ def by_assignment_deep(model: synth.Model, owner_of_variable, rank: int, world: 
         have = set(zip(loc_var.tolist(), loc_fac.tolist()))
         m = np.array([(int(v), int(f)) in have for v, f in zip(cvv, cff)], dtype=bool) if len(cvv) else np.zeros(0, bool)
         local.meta["coef_var"], local.meta["coef_fac"], local.meta["coef"] = cvv[m], cff[m], caa[m]
+        if "kary_ids" in local.meta:      # the per-factor rows of synth.kary_model's meta, for the factors this rank holds
+            kk = np.isin(np.asarray(local.meta["kary_ids"]), keep_fac)
+            for key in ("kary_ids", "q", "b", "out_var"):
+                local.meta[key] = np.asarray(local.meta[key])[kk]
+            local.meta["fac_vars"] = [fv for fv, keep in zip(local.meta["fac_vars"], kk) if keep]
 
     def edges_of(mask_v):
         m = mask_v[vix]

@@ -5,7 +5,18 @@ from oracle import ref
 
 
 def flood_oracle_from_model(model, seed_variance=None):
-    """FloodGraph (oracle/bp_flood.c) loaded with the model's data, mirroring synth.load_into_device."""
+    """FloodGraph (oracle/bp_flood.c) loaded with the model's data, mirroring synth.load_into_device; a synth.kary_model (factors of
+    more than two variables) gets the k-ary checker (oracle/bp_kary.c)."""
+    if model.meta.get("kind") == "kary":
+        g = ref.KaryFloodGraph(model)
+        if len(model.prior_var):
+            g.set_message_to_variable(model.prior_var, model.prior_fac, model.prior_mean, model.prior_variance)
+        if len(model.data_var):
+            g.set_data(model.data_var, model.data_fac, model.data_y)
+        if seed_variance is not None:
+            und = np.isnan(g.f2v_v) & g.kary_edge
+            g.f2v_m[und], g.f2v_v[und] = 0.0, seed_variance
+        return g
     g = ref.FloodGraph(model.edge_var, model.edge_fac, model.factor_ids, model.factor_var)
     if len(model.data_var):
         g.set_data(model.data_var, model.data_fac, model.data_y)

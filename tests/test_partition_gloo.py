@@ -246,6 +246,56 @@ def test_generic_deep_partition_of_random_sparse_graphs(seed, world, depth):
             assert np.array_equal(getattr(sw.g, name)[own], getattr(g, name)[e], equal_nan=True), name
 
 
+@pytest.mark.parametrize("seed,world,depth,n_factors", [(0, 2, 1, 40), (1, 3, 2, 120), (2, 4, 1, 500)])
+def test_deep_partition_of_graphs_with_factors_of_more_than_two_variables(seed, world, depth, n_factors):
+    """(round 5) loopy models of linear-Gaussian factors of 3 - 7 variables cut with a deep halo: a cut factor keeps all its variables
+    on every rank that holds one of them within the halo.  In-process exchange, the k-ary CPU checker as the sweeper: owned messages
+    and marginals bit-identical to the single-process sweeps."""
+    from tests._dist_worker import OracleStateSweeper
+
+    whole = cx.synth.kary_model(n_factors, seed=60 + seed, tree=False)
+    used = np.unique(whole.edge_var)
+    owner_map = np.random.default_rng(seed).integers(0, world, int(used.max()) + 1)
+    owner = lambda ids: owner_map[np.asarray(ids, np.int64)]      # noqa: E731
+    parts = [partition.by_assignment_deep(whole, owner, r, world, depth) for r in range(world)]
+    assert np.array_equal(np.sort(np.concatenate([p.owned_x for p in parts])), np.sort(whole.x_ids))
+    for p in parts:      # a kept factor of more than two variables keeps every edge
+        for f in p.model.factor_ids[p.model.factor_kind == 5]:
+            assert (p.model.edge_fac == f).sum() == (whole.edge_fac == f).sum()
+    sws = [OracleStateSweeper(p, 1e3) for p in parts]
+    sweeps = 3 * depth + 2
+    for k in range(sweeps):
+        if k % depth == 0:
+            for sw in sws:
+                sw.pack()
+            for r, p in enumerate(parts):
+                for peer in p.peers:
+                    back = [pp for pp in parts[peer.rank].peers if pp.rank == r][0]
+                    sws[peer.rank].recv[back.recv] = sws[r].send[peer.send]
+            for sw in sws:
+                sw.unpack()
+        for sw in sws:
+            sw.sweep()
+    g = flood_oracle_from_model(whole, 1e3)
+    g.sweep(sweeps)
+    gm, gv = g.marginals()
+    checked = 0
+    for p, sw in zip(parts, sws):
+        if len(p.owned_x) == 0:
+            continue
+        m, v = sw.g.marginals()
+        li = np.searchsorted(sw.g.var_ids, p.owned_x); wi = np.searchsorted(g.var_ids, p.owned_x)
+        assert np.array_equal(m[li], gm[wi], equal_nan=True) and np.array_equal(v[li], gv[wi], equal_nan=True)
+        own = np.isin(sw.g.edge_var, p.owned_x)
+        e = g.edge_index(sw.g.edge_var[own], sw.g.edge_fac[own])
+        for name in ("f2v_m", "f2v_v"):
+            assert np.array_equal(getattr(sw.g, name)[own], getattr(g, name)[e], equal_nan=True), name
+        checked += int(own.sum())
+    assert checked > 0
+    if n_factors >= 500:      # (the small models are so well connected that a halo of depth 2 holds everything: the large one is really cut)
+        assert any(p.model.n_edges < whole.n_edges for p in parts)
+
+
 @pytest.mark.parametrize("depth", [2, 0])
 def test_gloo_partitioned_convergence_with_the_residual_all_reduce(tmp_path, depth):
     """partition.converge over gloo: three ranks — deep halo (depth 2) or one message halo per sweep (depth 0, the
