@@ -16,6 +16,7 @@ from typing import List, Tuple
 import os
 import numpy as np
 
+from . import _lib as L
 from . import synth
 
 
@@ -831,6 +832,57 @@ class HaloExchange:
 
 
 # ---- chain-scan partition (contiguous time blocks + one composed map per block) ------------------------------
+class TreeRegionExchange:
+    """A FOREST cut at its variables, every rank under an EXACT local schedule (CX_SCHED_TREE; round 5).
+
+    `by_assignment` gives every rank its variables, every factor that touches one of them and, for a cut factor, the far variable as a
+    degree-1 stand-in.  A stand-in's message into the cut factor has no dependencies on this rank (a variable of degree 1,
+    src/dependencies.jl:48-55): it is whatever was stored — here, what the owning rank computed.  One round = one exact local sweep
+    (every message of the piece from final local inputs), then the boundary variables' messages into the cut factors travel and become
+    the stand-ins' messages.  After r rounds every message that depends on at most r regions is exact; on a forest the rounds stop
+    changing anything after (regions on the longest path of the region tree) rounds, at the exact posterior — which is what the
+    un-partitioned tree schedule computes in one sweep.  The boundary is one message per cut factor and direction, staged through the
+    host (a few messages per round).  `dist`: torch.distributed (gloo / nccl with CPU tensors) or anything with its P2P surface."""
+
+    def __init__(self, dev, part: Partition, dist, torch):
+        self.dev, self.part, self.dist, self.torch = dev, part, dist, torch
+        self.width = int(dev.lib.cx_payload_doubles(dev.dim, L.FORM_NATURAL))
+        self.send = torch.zeros((max(len(part.send_var), 1), self.width), dtype=torch.float64)
+        self.recv = torch.full((max(len(part.recv_var), 1), self.width), float("nan"), dtype=torch.float64)
+        self.rounds = 0
+
+    def round(self) -> bool:
+        """one exact local sweep + one exchange; True when an imported message changed"""
+        dev, part, dist, torch = self.dev, self.part, self.dist, self.torch
+        dev.sweep(1)
+        n_s, n_r = len(part.send_var), len(part.recv_var)
+        if n_s:
+            self.send[:n_s] = torch.from_numpy(dev.get_messages(part.send_var, part.send_fac, L.TO_FACTOR, L.FORM_NATURAL)[:, :self.width])
+        before = self.recv.clone()
+        ops = []
+        for p in part.peers:
+            ops.append(dist.P2POp(dist.isend, self.send[p.send], p.rank))
+            ops.append(dist.P2POp(dist.irecv, self.recv[p.recv], p.rank))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        changed = not bool(torch.equal(torch.nan_to_num(before, nan=0.12345), torch.nan_to_num(self.recv, nan=0.12345)))
+        if n_r and changed:
+            dev.set_messages(part.recv_var, part.recv_fac, L.TO_FACTOR, L.FORM_NATURAL, self.recv[:n_r].numpy())
+        self.rounds += 1
+        return changed
+
+    def solve(self, max_rounds: int = 64) -> int:
+        """rounds until no rank imports anything new (agreed by an all-gather of one flag per rank), then one last local sweep"""
+        torch, dist = self.torch, self.dist
+        for _ in range(max_rounds):
+            mine = torch.tensor([1.0 if self.round() else 0.0], dtype=torch.float64)
+            flags = [torch.zeros(1, dtype=torch.float64) for _ in range(self.part.world)]
+            dist.all_gather(flags, mine)
+            if not any(float(f[0]) for f in flags):
+                return self.rounds
+        raise RuntimeError(f"TreeRegionExchange: the boundary messages still moved after {max_rounds} rounds (is the graph a forest?)")
+
+
 def _lin_apply(M, m):
     """the projective-linear map (e f g A B C; D = 1) of csrc/cx_chain.hip applied to a natural-form message (xi, w)"""
     e, f, g, A, B, Cc = M

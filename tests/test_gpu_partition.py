@@ -797,3 +797,56 @@ def test_deep_partition_of_graphs_with_factors_of_more_than_two_variables(hip_li
         assert np.array_equal(devs[rank].get_marginals(part.owned_x), whole.get_marginals(part.owned_x), equal_nan=True)
         checked += len(ev)
     assert checked > 0
+
+
+@pytest.mark.parametrize("seed,world,nv", [(0, 2, 40), (1, 3, 200), (2, 4, 1500)])
+def test_a_forest_cut_at_its_variables_under_the_tree_schedule(hip_lib, seed, world, nv):
+    """(round 5) partition.TreeRegionExchange: a random tree, a random variable→rank map (regions in many pieces), every rank under
+    CX_SCHED_TREE — rounds of [exact local sweep, the boundary messages travel] until nothing imported changes; the owned marginals and
+    messages are then the un-partitioned tree schedule's one-sweep result, i.e. the exact posterior"""
+    import torch
+    from tests.helpers import random_loopy_model
+
+    whole_model, _ = random_loopy_model(seed, world, nv=nv, extra=-1)          # the spanning tree alone
+    rng = np.random.default_rng(seed)
+    # contiguous id blocks with a few strays: regions of several pieces, region paths of several hops
+    owner_map = np.minimum((np.arange(nv) * world) // nv, world - 1)
+    stray = rng.choice(nv, nv // 10, replace=False)
+    owner_map[stray] = rng.integers(0, world, len(stray))
+    owner = lambda ids: owner_map[np.asarray(ids, np.int64) - 1]      # noqa: E731
+    whole = cx.DeviceGraph(schedule=L.SCHED_TREE)
+    cx.synth.load_into_device(whole_model, whole)
+    whole.sweep(1)
+    ld = LoopbackDist(world, torch)
+    devs, parts, rounds, errors = [None] * world, [None] * world, [0] * world, []
+
+    def run(rank):
+        try:
+            ld.bind(rank)
+            part = partition.by_assignment(whole_model, owner, rank, world)
+            dev = cx.DeviceGraph(schedule=L.SCHED_TREE)
+            cx.synth.load_into_device(part.model, dev)
+            ex = partition.TreeRegionExchange(dev, part, ld, torch)
+            rounds[rank] = ex.solve(max_rounds=nv)
+            devs[rank], parts[rank] = dev, part
+        except Exception as e:  # pragma: no cover
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert len(set(rounds)) == 1 and 2 <= rounds[0] <= nv, rounds
+    for rank in range(world):
+        part = parts[rank]
+        if len(part.owned_x) == 0:
+            continue
+        got, want = devs[rank].get_marginals(part.owned_x), whole.get_marginals(part.owned_x)
+        assert not np.any(np.isnan(got))
+        assert_close(got, want, 1e-11, f"rank {rank}: owned marginals vs the un-partitioned tree schedule", scale_by="max")
+        own = np.isin(part.model.edge_var, part.owned_x)
+        ev, ef = part.model.edge_var[own], part.model.edge_fac[own]
+        assert_close(devs[rank].get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL), whole.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL), 1e-11,
+                     f"rank {rank}: messages into owned variables", scale_by="max")
