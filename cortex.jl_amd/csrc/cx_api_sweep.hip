@@ -572,7 +572,7 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_sweep: no graph");
     CX_REQUIRE(h, n_sweeps >= 0, CX_ERR_INVALID_ARGUMENT, "cx_sweep: n_sweeps < 0");
     if (h->cfg.dim > 1) return mv_sweep(h, n_sweeps);
-    CX_REQUIRE(h, h->halo_state || h->chain_partition || (h->recv_slots.empty() && h->send_slots.empty()), CX_ERR_STATE,
+    CX_REQUIRE(h, h->halo_state || h->chain_partition || h->cfg.schedule == CX_SCHED_TREE || (h->recv_slots.empty() && h->send_slots.empty()), CX_ERR_STATE,
                "cx_sweep: this handle holds a partition (halo configured): use cx_sweep_begin / _main / _end");
     if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) { int32_t rc = build_chains(h); if (rc != CX_OK) return rc; }
     { int32_t rc = cx::kary_upload(h); if (rc != CX_OK) return rc; }      // coefficients set since the last sweep
@@ -581,7 +581,9 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
         return ref_sweep_all(h, n_sweeps);
     }
     if (h->cfg.schedule == CX_SCHED_TREE) {
-        CX_REQUIRE(h, h->recv_slots.empty() && h->send_slots.empty(), CX_ERR_UNSUPPORTED, "cx_sweep: the tree schedule is not partitioned in this build");
+        // (round 5) a forest cut at its variables: cx_halo_configure marks the far variables of the cut factors as stand-ins — constants hanging
+        // off their factors, like observed variables — and the CALLER moves the boundary between exact local sweeps: the stand-ins' messages
+        // with cx_set_messages, the boundary variables' with cx_get_messages (cortex.jl_amd/partition.py: TreeRegionExchange)
         int32_t rc = build_tree(h);
         if (rc != CX_OK) return rc;
         for (int32_t s = 0; s < n_sweeps; s++) { tree_sweep(h); h->sweeps_done++; }

@@ -136,8 +136,11 @@ def grid_rows_deep(n_rows: int, n_cols: int, rank: int, world: int, depth: int, 
     return _grid_cut_deep(n_rows, n_cols, _row_bounds(n_rows, world), rank, depth, seed)
 
 
-def by_assignment(model: synth.Model, owner_of_variable, rank: int, world: int) -> Partition:
+def by_assignment(model: synth.Model, owner_of_variable, rank: int, world: int, one_stand_in_per_cut_factor: bool = False) -> Partition:
     """Generic vertex partition: `owner_of_variable(ids) -> ranks` assigns every variable to a rank.
+    one_stand_in_per_cut_factor: a far variable that touches several cut factors of this rank appears once PER FACTOR, under fresh ids
+    above every id of the model — each copy a degree-1 stand-in, as the library's halo lists want them (on a graph where the far
+    variable would otherwise sit between two of this rank's pieces as a free variable of degree 2: TreeRegionExchange).
     Rank r keeps its variables, every factor touching one of them and, for pairwise factors whose other variable lives
     elsewhere, that variable as a degree-1 ghost.  Exports / imports are ordered by (peer, factor id), which both sides
     of a cut compute identically, so the k-th exported message of rank a towards rank b is the k-th imported message of
@@ -186,8 +189,21 @@ def by_assignment(model: synth.Model, owner_of_variable, rank: int, world: int) 
                         factor_var=np.asarray(model.factor_var)[keep_f], x_ids=x_own, data_var=dv, data_fac=df, data_y=dy,
                         prior_var=pv, prior_fac=pf, prior_mean=pm, prior_variance=pvv, meta=dict(model.meta),
                         dim=model.dim, edge_role=loc_role, psets=dict(model.psets))
+    if one_stand_in_per_cut_factor:
+        base = int(max(ev.max(), ef.max(), fid.max())) + 1
+        n_a, n_b = int(cut_a.sum()), int(cut_b.sum())
+        fresh_a, fresh_b = base + np.arange(n_a, dtype=np.int64), base + n_a + np.arange(n_b, dtype=np.int64)
+        # loc_var is [unary, inner a, inner b, cut_a own, cut_a ghost, cut_b ghost, cut_b own]: rename the two ghost runs
+        n0 = len(keep_unary) + 2 * int(inner.sum())
+        loc_var = loc_var.copy()
+        loc_var[n0 + n_a:n0 + 2 * n_a] = fresh_a
+        loc_var[n0 + 2 * n_a:n0 + 2 * n_a + n_b] = fresh_b
+        local.edge_var = loc_var
+        gh_of_cut_a, gh_of_cut_b = fresh_a, fresh_b
+    else:
+        gh_of_cut_a, gh_of_cut_b = b_v[cut_a], a_v[cut_b]
     # halo lists grouped by peer, ordered by factor id within a peer
-    my_v = np.concatenate([a_v[cut_a], b_v[cut_b]]); gh_v = np.concatenate([b_v[cut_a], a_v[cut_b]])
+    my_v = np.concatenate([a_v[cut_a], b_v[cut_b]]); gh_v = np.concatenate([gh_of_cut_a, gh_of_cut_b])
     cf = np.concatenate([f2[cut_a], f2[cut_b]]); peer = np.concatenate([b_o[cut_a], a_o[cut_b]])
     o = np.lexsort((cf, peer))
     my_v, gh_v, cf, peer = my_v[o], gh_v[o], cf[o], peer[o]
@@ -846,6 +862,9 @@ class TreeRegionExchange:
 
     def __init__(self, dev, part: Partition, dist, torch):
         self.dev, self.part, self.dist, self.torch = dev, part, dist, torch
+        # the far variables of the cut factors are stand-ins (cx_halo_configure flags them): constants hanging off their factors for the tree
+        # plan — level by level or over heavy paths — exactly like observed variables; what they send is what this class stores there
+        dev.halo_configure(part.send_var, part.send_fac, part.recv_var, part.recv_fac)
         self.width = int(dev.lib.cx_payload_doubles(dev.dim, L.FORM_NATURAL))
         self.send = torch.zeros((max(len(part.send_var), 1), self.width), dtype=torch.float64)
         self.recv = torch.full((max(len(part.recv_var), 1), self.width), float("nan"), dtype=torch.float64)
