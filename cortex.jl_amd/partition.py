@@ -876,6 +876,9 @@ class TreeRegionExchange:
         dev.sweep(1)
         n_s, n_r = len(part.send_var), len(part.recv_var)
         if n_s:
+            # the boundary variables' messages INTO the cut factors: nobody on this rank listens to them (the factor's other variable is a
+            # stand-in), so the lazy tree plan does not compute them — the exchange asks for them, as items over the sweep's final messages
+            dev.update_batch([L.ITEM_MESSAGE_TO_FACTOR] * n_s, part.send_var, part.send_fac)
             self.send[:n_s] = torch.from_numpy(dev.get_messages(part.send_var, part.send_fac, L.TO_FACTOR, L.FORM_NATURAL)[:, :self.width])
         before = self.recv.clone()
         ops = []
