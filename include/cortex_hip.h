@@ -100,7 +100,8 @@ extern "C" {
                                         batch items.  dim == 1: x_out = a_1 x_1 + ... + a_k x_k + b + N(0, q), k = 2..6 inputs; params = {q, b};
                                         exactly one CX_ROLE_OUT edge, the others CX_ROLE_IN; a_i = 1 unless cx_set_factor_coefficients says
                                         otherwise.  Every factor→variable message of the factor reads ALL its other variable→factor
-                                        messages (src/dependencies.jl:17-31).  Flooding and fused schedules; not under partitions. */
+                                        messages (src/dependencies.jl:17-31).  Flooding, fused, tree and reference-order schedules; under partitions
+                                        with state halos (cx_halo_configure_state), not with per-sweep message halos. */
 #define CX_NPARAM 4                 /* doubles per factor in factor_params */
 
 /* edge roles for directed factors (Connection.label :out/:in, model_engine.jl:182) */

@@ -243,3 +243,42 @@ def test_config_c4_full_size_two_calls(hip_lib):
         assert_close(marg[:, 0], em, 1e-9, f"C4 call {call + 1} marginal mean"); assert_close(marg[:, 1], ev, 1e-9, f"C4 call {call + 1} marginal variance")
     assert 5_000 < st["stages"] < 6_500
     dev.close()
+
+
+@pytest.mark.parametrize("n", [1, 5, 6, 9, 33, 100, 3000])
+def test_the_reference_beta_bernoulli_known_answer(hip_lib, n):
+    """The reference's conjugate known answer (test/inference_engine_tests.jl:241-377): update_marginals!(engine, p) on the star of n
+    Bernoulli factors leaves Beta(1 + Σ, 1 + n − Σ).  Under CX_SCHED_REFERENCE the device runs exactly the executions the reference
+    runs — the n messages, the segment tree's ProductOfMessages nodes (n > 5) one by one from their stored children, the marginal —
+    and the answer is exact (small integers in f64)."""
+    rng = np.random.default_rng(n)
+    data = rng.random(n) < 0.5
+    p = 1
+    o = 2 * np.arange(1, n + 1)          # ids as make_beta_bernoulli_model hands them out: o_i, f_i alternate (:311-327)
+    f = o + 1
+    dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE, family=L.FAMILY_NATURAL2)
+    dev.graph_create(np.concatenate([np.full(n, p), o]), np.concatenate([f, f]), f, np.full(n, L.FACTOR_BERNOULLI, np.int32), np.ones(n))
+    dev.set_messages(o, f, L.TO_FACTOR, L.FORM_POINT, data.astype(float))
+    dev.sweep_for([p])
+    nat = dev.get_marginals([p])[0]
+    assert (1.0 + nat[0], 1.0 + nat[1]) == (1.0 + data.sum(), 1.0 + n - data.sum())
+    st = dev.ref_plan_stats()
+    assert st["executions"] == n + (n - 2 if n > 5 else 0) + 1 and st["messages"] == n
+    if n <= 100:
+        E = ref.Engine(ref.P_BETA_BERNOULLI, trace=True)
+        assert E.add_variable() == p
+        for i in range(n):
+            assert (E.add_variable(), E.add_factor(ref.F_BERNOULLI)) == (o[i], f[i])
+            E.add_edge(p, int(f[i])); E.add_edge(int(o[i]), int(f[i]))
+        E.finalize()
+        for i in range(n):
+            E.set_value(E.message_to_factor(int(o[i]), int(f[i])), bool(data[i]))
+        E.update_marginals([p])
+        assert dev.ref_trace() == _oracle_trace(E)
+        if n > 5:       # a node of the tree reads back as the product of its range
+            lo, hi = 1, n // 2
+            node = dev.get_products([p], [lo], [hi], L.FORM_NATURAL)[0]
+            assert (node[0], node[1]) == (data[:hi].sum(), (~data[:hi]).sum())
+    dev.sweep_for([p])
+    assert dev.ref_plan_stats()["executions"] == 0       # nothing is pending: lazy
+    dev.close()

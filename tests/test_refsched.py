@@ -263,3 +263,38 @@ def test_wiring_equals_the_restated_resolver():
             checked += len(mine)
     assert checked > 0 and g.ref_scalar("products") > 0
     assert g.ref_scalar("dependencies") == len(dep) and set(np.unique(inter)) <= {0, 1}
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 6, 7, 8, 9, 33, 100])
+def test_the_reference_beta_bernoulli_model(n):
+    """test/inference_engine_tests.jl:241-377: a star of n Bernoulli factors around p; for n > 5 the marginal hangs off a segment tree of
+    ProductOfMessages nodes (dependencies.jl:90-173).  The shadow scheduler's executions for update_marginals!(engine, p) — messages,
+    tree nodes in the resolver's creation order, marginal — equal the restated engine's trace"""
+    rng = np.random.default_rng(n)
+    data = rng.random(n) < 0.5
+    E = ref.Engine(ref.P_BETA_BERNOULLI, trace=True)
+    p = E.add_variable()
+    o, f = [], []
+    for _ in range(n):
+        oi, fi = E.add_variable(), E.add_factor(ref.F_BERNOULLI)
+        o.append(oi); f.append(fi)
+        E.add_edge(p, fi); E.add_edge(oi, fi)
+    E.finalize()
+    for i in range(n):
+        E.set_value(E.message_to_factor(o[i], f[i]), bool(data[i]))
+    g = FlatGraph(np.concatenate([np.full(n, p), o]), np.concatenate([f, f]), f, np.full(n, L.FACTOR_BERNOULLI, np.int32), np.ones(n),
+                  schedule=L.SCHED_REFERENCE, family=L.FAMILY_NATURAL2)
+    assert g.status == 0, g.error
+    rc, err = g.ref_build()
+    assert rc == 0, err
+    assert g.ref_scalar("products") == (n - 2 if n > 5 else 0)
+    g.ref_set(L.TO_FACTOR, o, f)
+    rows = g.ref_update([p])
+    E.update_marginals([p])
+    assert [tuple(r[:5]) for r in rows.tolist()] == _oracle_rows(E)
+    assert len(rows) == n + (n - 2 if n > 5 else 0) + 1
+    rc, err = g.ref_level()
+    assert rc == 0, err
+    off = g.arr("ref_stage_off")
+    assert len(off) - 1 <= 2 + max(1, int(np.ceil(np.log2(max(n, 2))))) + 1, "messages, then the tree level by level, then the marginal"
+    assert len(g.ref_update([p])) == 0
