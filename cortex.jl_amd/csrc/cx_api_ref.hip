@@ -36,6 +36,7 @@ struct RefSched {
     int64_t hits = 0, misses = 0;
     uint64_t tick = 0;
     int last = -1;
+    bool touched = false;                       // a value was set or a call ran: the wiring can no longer be replaced (cx_graph_wire)
     int max_entries = 4, run_max = 1024;      // C4, ms per call: every stage a launch 57.6, runs of stages <= 1024 items 52.8, <= 4096 items 102 (one workgroup is slow on a wide stage)
 };
 
@@ -49,6 +50,7 @@ void entry_free(cx_handle *h, PlanEntry &e) {
 }
 
 rs::State &writable(RefSched *R) {
+    R->touched = true;
     if (R->S.use_count() > 1) R->S = std::make_shared<rs::State>(*R->S);      // a cached plan still names this state as its result
     return *R->S;
 }
@@ -231,6 +233,7 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n) {
             R->misses++;
         } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "reference schedule: host allocation failed"); }
     } else R->hits++;
+    R->touched = true;
     PlanEntry &e = R->cache[hit];
     e.last_used = ++R->tick;
     R->last = hit;
@@ -297,6 +300,53 @@ int32_t cx_sweep_for(cx_handle *h, int64_t n, const int64_t *variable_ids) {
         }
         return ref_sweep(h, req.data(), n);
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_sweep_for: host allocation failed"); }
+}
+
+// A user resolver's wiring in place of the default one (src/dependencies.jl:1-15; add_dependency!, src/signal.jl:286-337): the i-th triple
+// is add_dependency!(signals[i], dependencies[i]; weak, intermediate, listen) — see cx_refsched.h: build_user_wiring for what may depend
+// on what.  Replaces the whole wiring; before the first value is set.
+int32_t cx_graph_wire(cx_handle *h, int64_t n, const cx_item *signals, const cx_item *dependencies, const int32_t *flags) {
+    CX_NOT_VMP(h, "cx_graph_wire");
+    CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_graph_wire: no graph");
+    CX_REQUIRE(h, h->cfg.schedule == CX_SCHED_REFERENCE, CX_ERR_UNSUPPORTED, "cx_graph_wire: a dependency wiring is what CX_SCHED_REFERENCE runs the reference's scheduler on; the other schedules are fixed orders");
+    CX_REQUIRE(h, n >= 0 && (n == 0 || (signals && dependencies && flags)), CX_ERR_INVALID_ARGUMENT, "cx_graph_wire: null argument");
+    RefSched *R = ref_of(h);
+    CX_REQUIRE(h, R && !R->touched, CX_ERR_STATE, "cx_graph_wire: the wiring is fixed once a value has been set or a call has run (wire right after cx_graph_create, as the reference wires at engine construction)");
+    try {
+        auto number = [&](const cx_item &it, int64_t *out) -> int32_t {
+            if (it.kind == CX_ITEM_INDIVIDUAL_MARGINAL) {
+                const int64_t v = find_var(h, it.variable_id);
+                if (v < 0) return fail(h, CX_ERR_NOT_FOUND, "cx_graph_wire: unknown variable id " + std::to_string(it.variable_id));
+                *out = R->W.sig_marg(v);
+                return CX_OK;
+            }
+            if (it.kind != CX_ITEM_MESSAGE_TO_FACTOR && it.kind != CX_ITEM_MESSAGE_TO_VARIABLE)
+                return fail(h, CX_ERR_UNSUPPORTED, "cx_graph_wire: signals are MessageToFactor, MessageToVariable and IndividualMarginal (kind " + std::to_string(it.kind) + ")");
+            const int64_t e = find_edge(h, it.variable_id, it.factor_id);
+            if (e < 0) return fail(h, CX_ERR_NOT_FOUND, "cx_graph_wire: no connection between variable " + std::to_string(it.variable_id) + " and factor " + std::to_string(it.factor_id));
+            *out = it.kind == CX_ITEM_MESSAGE_TO_FACTOR ? R->W.sig_v2f(e) : R->W.sig_f2v(e);
+            return CX_OK;
+        };
+        std::vector<int64_t> s((size_t)n), d((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            int32_t rc = number(signals[i], &s[i]);
+            if (rc == CX_OK) rc = number(dependencies[i], &d[i]);
+            if (rc != CX_OK) return rc;
+            if (flags[i] & ~7) return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_graph_wire: flags are CX_WIRE_WEAK | CX_WIRE_INTERMEDIATE | CX_WIRE_NO_LISTEN");
+        }
+        rs::Wiring W;
+        std::string err;
+        const int32_t rc = rs::build_user_wiring(h, n, s.data(), d.data(), flags, W, err);
+        if (rc != CX_OK) return fail(h, rc, err);
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        for (auto &e : R->cache) entry_free(h, e);
+        R->cache.clear(); R->last = -1;
+        R->W = std::move(W);
+        R->prod_slot.clear();
+        R->S = std::make_shared<rs::State>();
+        rs::init_state(R->W, *R->S);
+        return CX_OK;
+    } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_graph_wire: host allocation failed"); }
 }
 
 int32_t cx_ref_plan_stats(const cx_handle *hc, int64_t *out8) {

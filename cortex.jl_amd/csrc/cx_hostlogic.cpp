@@ -181,6 +181,33 @@ static int64_t href_edge(const HostGraph *g, int64_t var_id, int64_t fac_id) {
     return (jt == e || *jt != fac_id) ? -1 : (int64_t)(jt - g->edge_fac_id.begin());
 }
 
+// a user wiring: triples (signal, dependency, flags), signals as (kind CX_ITEM_*, variable id, factor id) rows of three int64
+int32_t cxh_ref_wire(void *p, int64_t n, const int64_t *sig3, const int64_t *dep3, const int32_t *flags, char *err, int32_t errlen) {
+    HostGraph *g = (HostGraph *)p;
+    std::string e;
+    int32_t rc = CX_OK;
+    std::vector<int64_t> s((size_t)n), d((size_t)n);
+    auto number = [&](const int64_t *t, int64_t *out) {
+        if (t[0] == CX_ITEM_INDIVIDUAL_MARGINAL) {
+            auto it = std::lower_bound(g->var_ids.begin(), g->var_ids.end(), t[1]);
+            if (it == g->var_ids.end() || *it != t[1]) return false;
+            *out = 2 * g->ne + (it - g->var_ids.begin());
+            return true;
+        }
+        const int64_t ed = href_edge(g, t[1], t[2]);
+        if (ed < 0) return false;
+        *out = t[0] == CX_ITEM_MESSAGE_TO_FACTOR ? ed : g->ne + ed;
+        return true;
+    };
+    for (int64_t i = 0; i < n && rc == CX_OK; i++) if (!number(sig3 + 3 * i, &s[i]) || !number(dep3 + 3 * i, &d[i])) rc = CX_ERR_NOT_FOUND;
+    if (rc == CX_OK) {
+        try { rc = cx::refsched::build_user_wiring(g, n, s.data(), d.data(), flags, g->rw, e); if (rc == CX_OK) cx::refsched::init_state(g->rw, g->rs); }
+        catch (const std::exception &x) { rc = CX_ERR_INVALID_ARGUMENT; e = x.what(); }
+    }
+    if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", e.c_str());
+    return rc;
+}
+
 // set_value! on message signals: direction CX_TO_FACTOR / CX_TO_VARIABLE
 int32_t cxh_ref_set(void *p, int32_t direction, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids) {
     HostGraph *g = (HostGraph *)p;

@@ -45,8 +45,11 @@ struct Wiring {
     std::vector<int64_t> dep_off, lis_off, chunk_off;      // [nsig + 1]
     std::vector<int32_t> dep;                              // dependencies in the resolver's order (add_dependency! appends)
     std::vector<uint8_t> dep_inter;                        // 1: flagged intermediate
-    std::vector<int32_t> lis;                              // listeners (every dependency of the default wiring listens: listenmask all true)
+    std::vector<uint8_t> dep_weak;                         // 1: flagged weak (a user wiring, cx_graph_wire; the default resolver sets none)
+    std::vector<int32_t> lis;                              // listeners
     std::vector<uint8_t> lis_idx;                          // position of this signal in the listener's dependency list (notify_listener!: first match)
+    std::vector<uint8_t> lis_listen;                       // listenmask (add_dependency!(...; listen)): 1 everywhere under the default wiring
+    bool custom = false;                                   // a user wiring (cx_graph_wire): products of messages are "sum of the dependency list" items
     std::vector<Prod> prods;                               // signal 2 ne + nv + i
     std::vector<uint8_t> no_rule;                          // per MessageToVariable signal (index e): 1 = the device has no rule for this message
     int64_t sig_v2f(int64_t e) const { return e; }
@@ -120,6 +123,27 @@ void wire(const H *h, const std::vector<int32_t> &efac, const std::vector<int32_
     }
 }
 
+// listeners (in add_dependency! order over the whole wiring) and chunk offsets from the dependency lists; lis_listen[q] must have been
+// sized; a caller with per-dependency listen flags passes them as `listen_of_dep`
+inline void finish_wiring(Wiring &W, const std::vector<uint8_t> *listen_of_dep = nullptr) {
+    std::vector<int64_t> lcnt(W.nsig + 1, 0);
+    for (int64_t p = 0; p < (int64_t)W.dep.size(); p++) lcnt[W.dep[p] + 1]++;
+    W.lis_off.assign(W.nsig + 1, 0);
+    for (int64_t s = 0; s < W.nsig; s++) W.lis_off[s + 1] = W.lis_off[s] + lcnt[s + 1];
+    std::vector<int64_t> fill(W.lis_off.begin(), W.lis_off.end() - 1);
+    for (int64_t s = 0; s < W.nsig; s++)
+        for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) {
+            const int64_t q = fill[W.dep[p]]++;
+            W.lis[q] = (int32_t)s; W.lis_idx[q] = (uint8_t)(p - W.dep_off[s]);
+            if (listen_of_dep) W.lis_listen[q] = (*listen_of_dep)[p];
+        }
+    W.chunk_off.assign(W.nsig + 1, 0);
+    for (int64_t s = 0; s < W.nsig; s++) {
+        const int64_t n = W.dep_off[s + 1] - W.dep_off[s];
+        W.chunk_off[s + 1] = W.chunk_off[s] + std::max<int64_t>(1, (n + 15) / 16);      // a SignalDependenciesProps always owns one chunk (signal.jl:36-45)
+    }
+}
+
 template <class H>
 int32_t build_wiring(const H *h, Wiring &W, std::string &err) {
     const int64_t ne = h->ne, nv = h->nv, nf = h->nf;
@@ -156,32 +180,16 @@ int32_t build_wiring(const H *h, Wiring &W, std::string &err) {
         W.dep_off[s + 1] = W.dep_off[s] + cnt[s + 1];
     }
     const int64_t nd = W.dep_off[W.nsig];
-    W.dep.assign(nd, -1); W.dep_inter.assign(nd, 0);
-    std::vector<int64_t> lcnt(W.nsig + 1, 0);
+    W.dep.assign(nd, -1); W.dep_inter.assign(nd, 0); W.dep_weak.assign(nd, 0);
     {   // pass 2: fill
         std::vector<int64_t> fill(W.dep_off.begin(), W.dep_off.end() - 1);
         wire(h, efac, foff, fedge, nullptr, [&](int64_t s, int64_t d, int inter) {
             const int64_t p = fill[s]++;
             W.dep[p] = (int32_t)d; W.dep_inter[p] = (uint8_t)inter;
-            lcnt[d + 1]++;
         });
     }
-    W.lis_off.assign(W.nsig + 1, 0);
-    for (int64_t s = 0; s < W.nsig; s++) W.lis_off[s + 1] = W.lis_off[s] + lcnt[s + 1];
-    W.lis.assign(nd, -1); W.lis_idx.assign(nd, 0);
-    {
-        std::vector<int64_t> fill(W.lis_off.begin(), W.lis_off.end() - 1);
-        for (int64_t s = 0; s < W.nsig; s++)
-            for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) {
-                const int64_t q = fill[W.dep[p]]++;
-                W.lis[q] = (int32_t)s; W.lis_idx[q] = (uint8_t)(p - W.dep_off[s]);
-            }
-    }
-    W.chunk_off.assign(W.nsig + 1, 0);
-    for (int64_t s = 0; s < W.nsig; s++) {
-        const int64_t n = W.dep_off[s + 1] - W.dep_off[s];
-        W.chunk_off[s + 1] = W.chunk_off[s] + std::max<int64_t>(1, (n + 15) / 16);      // a SignalDependenciesProps always owns one chunk (signal.jl:36-45)
-    }
+    W.lis.assign(nd, -1); W.lis_idx.assign(nd, 0); W.lis_listen.assign(nd, 1);
+    finish_wiring(W);
     // messages the device cannot compute: out of a factor that has no rule here and other variables (the reference's processor would
     // call the user's rule; an opaque factor has none — inference_engine.jl:358 error(...))
     W.no_rule.assign(ne, 0);
@@ -192,12 +200,102 @@ int32_t build_wiring(const H *h, Wiring &W, std::string &err) {
     return CX_OK;
 }
 
+// ---- a user wiring (cx_graph_wire): the reference's add_dependency!(signal, dependency; weak, listen, intermediate), signal.jl:286-337,
+// call by call, in place of the default resolver's (a user resolver, dependencies.jl:1-15).  Signals: messages of both directions and
+// marginals; the RULES stay the sum-product ones, so a wiring may choose WHICH of a signal's natural inputs it waits for, in which order
+// and how (a filter that wires no backward messages, weak edges that use a stored value without waiting for a fresh one, ...):
+//   MessageToFactor(v, f)   depends on MessageToVariable(v, f'), f' != f        value = product of its dependency list
+//   IndividualMarginal(v)   depends on MessageToVariable(v, f')                 value = product of its dependency list
+//   MessageToVariable(v, f) depends on MessageToFactor(v', f), v' != v          value = the factor's rule on the stored messages of the
+//                                                                               factor's other edges (all of them, listed or not)
+// flags: bit 0 weak, bit 1 intermediate, bit 2 "do not listen".  Self-dependencies are skipped as add_dependency! skips them;
+// a signal may not list a dependency twice.  sig / dep: signal numbers (Wiring::sig_*), in call order.
+constexpr int32_t kWireWeak = 1, kWireIntermediate = 2, kWireNoListen = 4;
+
+template <class H>
+int32_t build_user_wiring(const H *h, int64_t n, const int64_t *sig, const int64_t *dep, const int32_t *flags, Wiring &W, std::string &err) {
+    const int64_t ne = h->ne, nv = h->nv;
+    W = Wiring();
+    W.ne = ne; W.nv = nv; W.nsig = 2 * ne + nv; W.custom = true;
+    std::vector<int32_t> efac(ne);
+    for (int64_t e = 0; e < ne; e++) {
+        auto it = std::lower_bound(h->fac_ids.begin(), h->fac_ids.end(), h->edge_fac_id[e]);
+        if (it == h->fac_ids.end() || *it != h->edge_fac_id[e]) return fail_(err, CX_ERR_STATE, "cx_graph_wire: edge names an unknown factor");
+        efac[e] = (int32_t)(it - h->fac_ids.begin());
+    }
+    auto var_of = [&](int64_t s) -> int64_t { return s < ne ? h->edge_var[s] : (s < 2 * ne ? h->edge_var[s - ne] : s - 2 * ne); };
+    std::vector<int64_t> cnt(W.nsig + 1, 0);
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t s = sig[i], d = dep[i];
+        if (s < 0 || s >= W.nsig || d < 0 || d >= W.nsig) return fail_(err, CX_ERR_INVALID_ARGUMENT, "cx_graph_wire: unknown signal");
+        if (s == d) continue;                                                    // signal.jl:295
+        if (s < ne || s >= 2 * ne) {                                             // MessageToFactor / marginal <- MessageToVariable of the same variable
+            if (!(d >= ne && d < 2 * ne) || var_of(d) != var_of(s) || (s < ne && d - ne == s))
+                return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_wire: a MessageToFactor / IndividualMarginal signal takes MessageToVariable signals of its own variable (other factors) as "
+                                                      "dependencies — its value is their product; other inputs would need a rule the device does not have");
+        } else {                                                                 // MessageToVariable <- MessageToFactor of the same factor, another variable
+            if (!(d < ne) || efac[d] != efac[s - ne] || d == s - ne)
+                return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_wire: a MessageToVariable signal takes MessageToFactor signals of its factor's other variables as dependencies");
+        }
+        cnt[s + 1]++;
+    }
+    W.dep_off.assign(W.nsig + 1, 0);
+    for (int64_t s = 0; s < W.nsig; s++) {
+        if (cnt[s + 1] > 255) return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_wire: a signal with more than 255 dependencies");
+        W.dep_off[s + 1] = W.dep_off[s] + cnt[s + 1];
+    }
+    const int64_t nd = W.dep_off[W.nsig];
+    W.dep.assign(nd, -1); W.dep_inter.assign(nd, 0); W.dep_weak.assign(nd, 0);
+    std::vector<uint8_t> listen(nd, 1);
+    std::vector<int64_t> fill(W.dep_off.begin(), W.dep_off.end() - 1);
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t s = sig[i], d = dep[i];
+        if (s == d) continue;
+        for (int64_t p = W.dep_off[s]; p < fill[s]; p++)
+            if (W.dep[p] == d) return fail_(err, CX_ERR_INVALID_ARGUMENT, "cx_graph_wire: a signal lists a dependency twice");
+        const int64_t p = fill[s]++;
+        W.dep[p] = (int32_t)d;
+        W.dep_weak[p] = (flags[i] & kWireWeak) ? 1 : 0; W.dep_inter[p] = (flags[i] & kWireIntermediate) ? 1 : 0; listen[p] = (flags[i] & kWireNoListen) ? 0 : 1;
+    }
+    W.lis.assign(nd, -1); W.lis_idx.assign(nd, 0); W.lis_listen.assign(nd, 1);
+    finish_wiring(W, &listen);
+    {   // process_dependencies! (signal.jl:466-490) descends through intermediate dependencies without a visited set: a cycle of them is an
+        // endless recursion in the reference (a stack overflow), so such a wiring is refused here.  Three-colour depth-first search.
+        std::vector<uint8_t> colour(W.nsig, 0);
+        std::vector<std::pair<int32_t, int64_t>> stack;
+        for (int64_t r = 0; r < W.nsig; r++) {
+            if (colour[r]) continue;
+            colour[r] = 1; stack.emplace_back((int32_t)r, W.dep_off[r]);
+            while (!stack.empty()) {
+                auto &top = stack.back();
+                const int32_t s = top.first;
+                if (top.second == W.dep_off[s + 1]) { colour[s] = 2; stack.pop_back(); continue; }
+                const int64_t p = top.second++;
+                if (!W.dep_inter[p]) continue;
+                const int32_t d = W.dep[p];
+                if (colour[d] == 1) return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_wire: the intermediate dependencies form a cycle: process_dependencies! (src/signal.jl:466-490) would never return");
+                if (colour[d] == 0) { colour[d] = 1; stack.emplace_back(d, W.dep_off[d]); }
+            }
+        }
+    }
+    W.no_rule.assign(ne, 0);
+    {
+        std::vector<int32_t> fdeg(h->nf, 0);
+        for (int64_t e = 0; e < ne; e++) fdeg[efac[e]]++;
+        for (int64_t e = 0; e < ne; e++) if (fdeg[efac[e]] >= 2 && h->fac_kind[efac[e]] == CX_FACTOR_OPAQUE) W.no_rule[e] = 1;
+    }
+    return CX_OK;
+}
+
 inline void init_state(const Wiring &W, State &S) {
     S.chunks.assign(W.chunk_off[W.nsig], 0);
     S.flags.assign(W.nsig, 0);
     for (int64_t s = 0; s < W.nsig; s++)
         for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++)
-            if (W.dep_inter[p]) { const int64_t i = p - W.dep_off[s]; S.chunks[W.chunk_off[s] + (i >> 4)] |= kInter << ((i & 15) << 2); }
+            if (W.dep_inter[p] || W.dep_weak[p]) {
+                const int64_t i = p - W.dep_off[s];
+                S.chunks[W.chunk_off[s] + (i >> 4)] |= ((W.dep_inter[p] ? kInter : 0) | (W.dep_weak[p] ? kWeak : 0)) << ((i & 15) << 2);
+            }
     S.hash = 0;
     for (int64_t c = 0; c < (int64_t)S.chunks.size(); c++) S.hash ^= zob_chunk(c, S.chunks[c]);
     for (int64_t s = 0; s < W.nsig; s++) S.hash ^= zob_flag(s, 0);
@@ -222,7 +320,7 @@ inline void set_value(const Wiring &W, State &S, int64_t s) {
     put_flags(S, s, kComputed);                                                                                // props = (false, false)
     for (int64_t q = W.lis_off[s]; q < W.lis_off[s + 1]; q++) {
         const int64_t l = W.lis[q], i = W.lis_idx[q];
-        put_flags(S, l, (uint8_t)((S.flags[l] & kComputed) | kPot));                                           // listening: potentially pending, not pending
+        if (W.lis_listen[q]) put_flags(S, l, (uint8_t)((S.flags[l] & kComputed) | kPot));                      // listening: potentially pending, not pending
         const int64_t c = W.chunk_off[l] + (i >> 4);
         put_chunk(S, c, S.chunks[c] | ((kFresh | kComp) << ((i & 15) << 2)));
     }
@@ -364,7 +462,7 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
         if (s < ne) {                                    // MessageToFactor
             const int32_t v = h->edge_var[s], deg = h->var_off[v + 1] - h->var_off[v], slot = flat::slot_of_edge_t(h, s);
             P.n_messages++;
-            if (deg <= 5) { r[0] = CX_ITEM_MESSAGE_TO_FACTOR; r[1] = slot; r[2] = v; }
+            if (deg <= 5 && !W.custom) { r[0] = CX_ITEM_MESSAGE_TO_FACTOR; r[1] = slot; r[2] = v; }
             else {
                 r[0] = kItemSumToFactor; r[1] = slot; r[2] = v; r[3] = (int32_t)P.list.size(); r[4] = (int32_t)(W.dep_off[s + 1] - W.dep_off[s]);
                 for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) P.list.push_back(source(W.dep[p]));
@@ -381,7 +479,7 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
         } else if (s < 2 * ne + nv) {                    // IndividualMarginal
             const int32_t v = (int32_t)(s - 2 * ne), deg = h->var_off[v + 1] - h->var_off[v];
             P.n_marginals++;
-            if (deg <= 5) { r[0] = CX_ITEM_INDIVIDUAL_MARGINAL; r[1] = v; r[2] = v; }
+            if (deg <= 5 && !W.custom) { r[0] = CX_ITEM_INDIVIDUAL_MARGINAL; r[1] = v; r[2] = v; }
             else {
                 r[0] = kItemSumToMarginal; r[1] = v; r[2] = v; r[3] = (int32_t)P.list.size(); r[4] = (int32_t)(W.dep_off[s + 1] - W.dep_off[s]);
                 for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) P.list.push_back(source(W.dep[p]));

@@ -200,6 +200,15 @@ class DeviceGraph:
         v = _i64(np.atleast_1d(variable_ids))
         self._check(self.lib.cx_sweep_for(self.h, len(v), _p(v, C.c_int64)))
 
+    def graph_wire(self, signals, dependencies, flags):
+        """cx_graph_wire: add_dependency!(signal, dependency; flags) triple by triple; a signal is (kind, variable_id, factor_id)"""
+        n = len(signals)
+        sig, dep = (L.Item * max(n, 1))(), (L.Item * max(n, 1))()
+        for i, ((k, v, f), (k2, v2, f2)) in enumerate(zip(signals, dependencies)):
+            sig[i] = L.Item(int(k), 0, int(v), int(f)); dep[i] = L.Item(int(k2), 0, int(v2), int(f2))
+        fl = np.ascontiguousarray(flags, dtype=np.int32)
+        self._check(self.lib.cx_graph_wire(self.h, n, sig, dep, _p(fl, C.c_int32) if n else None))
+
     def ref_plan_stats(self) -> dict:
         out = (C.c_int64 * 8)()
         self._check(self.lib.cx_ref_plan_stats(self.h, out))

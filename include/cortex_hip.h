@@ -308,6 +308,20 @@ int32_t cx_set_damping(cx_handle *h, double lambda);
  * the named variables in the caller's order — only what is pending for those marginals is computed (cx_sweep requests every variable
  * that is neither observed nor a stand-in, in ascending id order).  Other schedules: CX_ERR_UNSUPPORTED (they compute every message). */
 int32_t cx_sweep_for(cx_handle *h, int64_t n, const int64_t *variable_ids);
+/* CX_SCHED_REFERENCE: a user resolver's dependency wiring in place of DefaultDependencyResolver's (src/dependencies.jl:1-15): the i-th triple is
+ * add_dependency!(signals[i], dependencies[i]; weak, intermediate, listen) (src/signal.jl:286-337), in call order (= dependency order per
+ * signal).  Signals are named like batch items: CX_ITEM_MESSAGE_TO_FACTOR / CX_ITEM_MESSAGE_TO_VARIABLE (variable_id, factor_id),
+ * CX_ITEM_INDIVIDUAL_MARGINAL (variable_id).  The RULES stay the sum-product ones, so a wiring chooses which of a signal's natural inputs it
+ * waits for, in which order and how: a MessageToFactor / IndividualMarginal depends on MessageToVariable signals of its own variable (its
+ * value is the product of exactly its dependency list, in list order), a MessageToVariable on MessageToFactor signals of its factor's other
+ * variables (its value is the factor's rule on the stored messages of the factor's other edges).  Anything else — a message that depends on
+ * a marginal, as the variational resolvers of test/inference_engine_tests.jl:597-629 wire — needs a rule the device does not have:
+ * CX_ERR_UNSUPPORTED (the two variational families exist as fused calls: cx_update_marginals).  Replaces the whole wiring (n == 0: none);
+ * allowed until the first value is set or the first call runs, as the reference wires at engine construction. */
+#define CX_WIRE_WEAK 1          /* add_dependency!(...; weak = true): the dependency need only be computed, not fresh (src/signal.jl:36-45) */
+#define CX_WIRE_INTERMEDIATE 2  /* intermediate = true: process_dependencies! descends through it (src/signal.jl:466-490) */
+#define CX_WIRE_NO_LISTEN 4     /* listen = false: the dependency's set_value! does not make the signal potentially pending */
+int32_t cx_graph_wire(cx_handle *h, int64_t n, const cx_item *signals, const cx_item *dependencies, const int32_t *flags);
 /* the plan the last reference-order call replayed: out8 = { stages, kernel launches, executions (signals computed), of which messages,
  * passes of the reference's loop (the final marginal round included), plans kept, calls that replayed a kept plan, calls that had to
  * run the scheduler }.  Zeros before the first call and for other schedules. */

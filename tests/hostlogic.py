@@ -115,6 +115,8 @@ class FlatGraph:
             L.cxh_flat_halo.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
             L.cxh_ref_build.restype = C.c_int32
             L.cxh_ref_build.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+            L.cxh_ref_wire.restype = C.c_int32
+            L.cxh_ref_wire.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int32]
             L.cxh_ref_set.restype = C.c_int32
             L.cxh_ref_set.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
             L.cxh_ref_update.restype = C.c_int64
@@ -183,6 +185,14 @@ class FlatGraph:
     def ref_build(self):
         err = C.create_string_buffer(512)
         rc = int(self.L.cxh_ref_build(self.p, err, 512))
+        return rc, err.value.decode()
+
+    def ref_wire(self, signals, dependencies, flags):
+        """a user wiring: add_dependency!(signal, dependency; flags) triple by triple; a signal is (kind, variable id, factor id)"""
+        a = np.ascontiguousarray(np.asarray(signals, dtype=np.int64).reshape(-1, 3)); b = np.ascontiguousarray(np.asarray(dependencies, dtype=np.int64).reshape(-1, 3))
+        fl = np.ascontiguousarray(flags, dtype=np.int32)
+        err = C.create_string_buffer(512)
+        rc = int(self.L.cxh_ref_wire(self.p, len(fl), a.ctypes.data, b.ctypes.data, fl.ctypes.data, err, 512))
         return rc, err.value.decode()
 
     def ref_set(self, direction, variable_ids, factor_ids):

@@ -282,3 +282,113 @@ def test_the_reference_beta_bernoulli_known_answer(hip_lib, n):
     dev.sweep_for([p])
     assert dev.ref_plan_stats()["executions"] == 0       # nothing is pending: lazy
     dev.close()
+
+
+# ---- cx_graph_wire: a user resolver's wiring in place of the default one ---------------------------------------------------------------
+def _default_triples(model):
+    """the default resolver's add_dependency! calls of a model of degree <= 5, as (signal, dependency) keys (kind, variable, factor)"""
+    E0 = engine_oracle_from_model(model)
+    kinds = {ref.VAR_MSG_TO_FACTOR: L.ITEM_MESSAGE_TO_FACTOR, ref.VAR_MSG_TO_VARIABLE: L.ITEM_MESSAGE_TO_VARIABLE, ref.VAR_MARGINAL: L.ITEM_INDIVIDUAL_MARGINAL}
+
+    def key(sig):
+        k, v, f, _lo, _hi = E0.variant(sig)
+        return (kinds[k], int(v), int(f) if k != ref.VAR_MARGINAL else 0)
+    out = []
+    for v, f in zip(model.edge_var, model.edge_fac):
+        for sig in (E0.message_to_factor(int(v), int(f)), E0.message_to_variable(int(v), int(f))):
+            out += [(key(sig), key(d)) for d in E0.dependencies(sig)]
+    for v in model.x_ids:
+        out += [(key(E0.marginal(int(v))), key(d)) for d in E0.dependencies(E0.marginal(int(v)))]
+    return out
+
+
+def _engine_with_wiring(model, triples):
+    n_nodes = int(max(model.edge_var.max(), model.factor_ids.max()))
+    kind = np.zeros(n_nodes, dtype=np.int32); fkind = np.zeros(n_nodes, dtype=np.int32); p0 = np.ones(n_nodes)
+    kind[np.unique(model.edge_var) - 1] = 1; kind[model.factor_ids - 1] = 2
+    fkind[model.factor_ids - 1] = np.where(model.factor_kind == 1, ref.F_GAUSS_ADD, ref.F_OPAQUE)
+    p0[model.factor_ids - 1] = np.asarray(model.factor_var).reshape(len(model.factor_ids), -1)[:, 0]
+    E = ref.Engine(ref.P_SSM_BP, True)
+    E.bulk_build(kind, fkind, p0, model.edge_var, model.edge_fac)
+    E.finalize(resolve_dependencies=False)
+    sig_of = lambda k: E.marginal(k[1]) if k[0] == L.ITEM_INDIVIDUAL_MARGINAL else (E.message_to_factor(k[1], k[2]) if k[0] == L.ITEM_MESSAGE_TO_FACTOR else E.message_to_variable(k[1], k[2]))      # noqa: E731
+    for s, d, fl in triples:
+        E.add_dependency(sig_of(s), sig_of(d), weak=bool(fl & 1), intermediate=bool(fl & 2), listen=not (fl & 4))
+    return E
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_user_wiring_with_random_flags_on_a_loopy_grid(hip_lib, seed):
+    """cx_graph_wire: the default wiring of a grid with random weak / intermediate / listen flags, a tenth of the product dependencies
+    dropped, in a shuffled add_dependency! order — the device against the restated engine under the same calls: trace, messages, marginals"""
+    rng = np.random.default_rng(seed)
+    model = cx.synth.gaussian_grid(9, 8, seed=6)
+    triples = []
+    for s, d in _default_triples(model):
+        if s[0] != L.ITEM_MESSAGE_TO_VARIABLE and rng.random() < 0.1:
+            continue
+        fl = (L.WIRE_WEAK if rng.random() < 0.3 else 0) | (L.WIRE_INTERMEDIATE if s[0] != L.ITEM_MESSAGE_TO_VARIABLE and rng.random() < 0.6 else 0) | (L.WIRE_NO_LISTEN if rng.random() < 0.1 else 0)
+        triples.append((s, d, fl))
+    triples = [triples[i] for i in rng.permutation(len(triples))]
+    E = _engine_with_wiring(model, triples)
+    dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+    dev.graph_create(model.edge_var, model.edge_fac, model.factor_ids, model.factor_kind, model.factor_var)
+    dev.graph_wire([s for s, _d, _f in triples], [d for _s, d, _f in triples], [f for _s, _d, f in triples])
+    pv, pf = pairwise_edges(model)
+    E.set_messages_to_variable(pv, pf, np.zeros(len(pv)), np.full(len(pv), SEED_VARIANCE))
+    dev.seed_messages(L.TO_VARIABLE, 0.0, SEED_VARIANCE)
+    for call in range(5):
+        _set_priors(dev, E, model)
+        request = model.x_ids if call % 2 == 0 else rng.permutation(model.x_ids)[:30]
+        dev.sweep_for(request)
+        E.update_marginals(request)
+        assert dev.ref_trace() == _oracle_trace(E), f"call {call + 1}: the executions, in order"
+        _compare(dev, E, model, request, f"user wiring, call {call + 1}")
+    with pytest.raises(cx.CortexHipError) as ei:
+        dev.graph_wire([], [], [])
+    assert ei.value.code == L.ERR_STATE          # the wiring is fixed once values exist
+    dev.close()
+
+
+def test_a_filter_wiring_computes_the_kalman_filter(hip_lib):
+    """a user resolver that wires the forward messages of the state-space model only: one call is the Kalman FILTER"""
+    T = 400
+    model = cx.synth.ssm_chain(T, seed=8, random_variances=True)
+    x, y, lik, tr = model.x_ids, model.data_var, model.factor_ids[:T], model.factor_ids[T:]
+    F, V, M, I = L.ITEM_MESSAGE_TO_FACTOR, L.ITEM_MESSAGE_TO_VARIABLE, L.ITEM_INDIVIDUAL_MARGINAL, L.WIRE_INTERMEDIATE
+    triples = []
+    for t in range(T):
+        triples.append(((V, int(x[t]), int(lik[t])), (F, int(y[t]), int(lik[t])), 0))
+        triples.append(((M, int(x[t]), 0), (V, int(x[t]), int(lik[t])), I))
+        if t > 0:
+            triples.append(((M, int(x[t]), 0), (V, int(x[t]), int(tr[t - 1])), I))
+            triples.append(((V, int(x[t]), int(tr[t - 1])), (F, int(x[t - 1]), int(tr[t - 1])), 0))
+        if t + 1 < T:
+            triples.append(((F, int(x[t]), int(tr[t])), (V, int(x[t]), int(lik[t])), I))
+            if t > 0:
+                triples.append(((F, int(x[t]), int(tr[t])), (V, int(x[t]), int(tr[t - 1])), I))
+    dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+    dev.graph_create(model.edge_var, model.edge_fac, model.factor_ids, model.factor_kind, model.factor_var)
+    dev.graph_wire([s for s, _d, _f in triples], [d for _s, d, _f in triples], [f for _s, _d, f in triples])
+    dev.set_messages(model.data_var, model.data_fac, L.TO_FACTOR, L.FORM_POINT, model.data_y)
+    dev.sweep_for(x)
+    assert dev.ref_plan_stats()["executions"] == T + 2 * (T - 1) + T
+    r, q = model.meta["r"], model.meta["q"]
+    m, v = model.data_y[0], r[0]
+    fm, fv = [m], [v]
+    for t in range(1, T):
+        pvar = v + q[t - 1]
+        k = pvar / (pvar + r[t])
+        m, v = m + k * (model.data_y[t] - m), (1 - k) * pvar
+        fm.append(m); fv.append(v)
+    marg = dev.get_marginals(x)
+    assert_close(marg[:, 0], np.array(fm), 1e-9, "filtered means"); assert_close(marg[:, 1], np.array(fv), 1e-9, "filtered variances")
+    em, ev = exact.ssm_chain_posterior(model.data_y, r, q)
+    assert np.max(np.abs(marg[:-1, 1] - ev[:-1])) > 1e-3, "a filter is not the smoother (the last state is where they meet)"
+    assert_close(marg[-1:], np.array([[em[-1], ev[-1]]]), 1e-9, "the last state: filter == smoother")
+    with pytest.raises(cx.CortexHipError) as ei:      # a message that depends on a marginal: a rule the device does not have
+        fresh = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+        fresh.graph_create(model.edge_var, model.edge_fac, model.factor_ids, model.factor_kind, model.factor_var)
+        fresh.graph_wire([(V, int(x[1]), int(tr[0]))], [(M, int(x[0]), 0)], [L.WIRE_WEAK])
+    assert ei.value.code == L.ERR_UNSUPPORTED
+    dev.close()

@@ -298,3 +298,145 @@ def test_the_reference_beta_bernoulli_model(n):
     off = g.arr("ref_stage_off")
     assert len(off) - 1 <= 2 + max(1, int(np.ceil(np.log2(max(n, 2))))) + 1, "messages, then the tree level by level, then the marginal"
     assert len(g.ref_update([p])) == 0
+
+
+# ---- user wirings (cx_graph_wire): add_dependency!(signal, dependency; weak, listen, intermediate) triple by triple -----------------------
+def _key(E, sig):
+    k, v, f, _lo, _hi = E.variant(sig)
+    return ({ref.VAR_MSG_TO_FACTOR: K2F, ref.VAR_MSG_TO_VARIABLE: K2V, ref.VAR_MARGINAL: KMARG}[k], int(v), int(f) if k != ref.VAR_MARGINAL else 0)
+
+
+def _oracle_signal(E, key):
+    k, v, f = key
+    return E.marginal(v) if k == KMARG else (E.message_to_factor(v, f) if k == K2F else E.message_to_variable(v, f))
+
+
+def _wire_both(model, triples):
+    """the same add_dependency! calls into the restated engine (built without the default resolver) and into the shadow"""
+    n_nodes = int(max(model.edge_var.max(), model.factor_ids.max()))
+    kind = np.zeros(n_nodes, dtype=np.int32); fkind = np.zeros(n_nodes, dtype=np.int32); p0 = np.ones(n_nodes)
+    kind[np.unique(model.edge_var) - 1] = 1; kind[model.factor_ids - 1] = 2
+    fkind[model.factor_ids - 1] = np.where(model.factor_kind == 1, ref.F_GAUSS_ADD, ref.F_OPAQUE)
+    p0[model.factor_ids - 1] = np.asarray(model.factor_var).reshape(len(model.factor_ids), -1)[:, 0]
+    E = ref.Engine(ref.P_SSM_BP, True)
+    E.bulk_build(kind, fkind, p0, model.edge_var, model.edge_fac)
+    E.finalize(resolve_dependencies=False)
+    for s, d, fl in triples:
+        E.add_dependency(_oracle_signal(E, s), _oracle_signal(E, d), weak=bool(fl & 1), intermediate=bool(fl & 2), listen=not (fl & 4))
+    g = FlatGraph(model.edge_var, model.edge_fac, model.factor_ids, model.factor_kind, model.factor_var, schedule=L.SCHED_REFERENCE)
+    assert g.status == 0, g.error
+    rc, err = g.ref_build()
+    assert rc == 0, err
+    rc, err = g.ref_wire([s for s, _d, _f in triples], [d for _s, d, _f in triples], [f for _s, _d, f in triples])
+    assert rc == 0, err
+    return E, g
+
+
+def test_a_filter_wiring_on_the_state_space_model():
+    """a user resolver that wires the FORWARD messages only: update_marginals! then computes the Kalman FILTER (every marginal conditions
+    on the data up to its own time), not the smoother the default wiring gives; same executions as the restated engine under the same
+    add_dependency! calls, values by the levelled plan == the restated engine's == a textbook Kalman filter"""
+    T = 30
+    model = cx.synth.ssm_chain(T, seed=8, random_variances=True)
+    x, y, lik, tr = model.x_ids, model.data_var, model.factor_ids[:T], model.factor_ids[T:]
+    INTER = L.WIRE_INTERMEDIATE
+    triples = []
+    for t in range(T):
+        triples.append(((K2V, int(x[t]), int(lik[t])), (K2F, int(y[t]), int(lik[t])), 0))                  # lik_t→x_t  <-  y_t→lik_t
+        triples.append(((KMARG, int(x[t]), 0), (K2V, int(x[t]), int(lik[t])), INTER))
+        if t > 0:
+            triples.append(((KMARG, int(x[t]), 0), (K2V, int(x[t]), int(tr[t - 1])), INTER))
+            triples.append(((K2V, int(x[t]), int(tr[t - 1])), (K2F, int(x[t - 1]), int(tr[t - 1])), 0))    # tr_{t-1}→x_t  <-  x_{t-1}→tr_{t-1}
+        if t + 1 < T:
+            triples.append(((K2F, int(x[t]), int(tr[t])), (K2V, int(x[t]), int(lik[t])), INTER))           # x_t→tr_t  <-  lik_t→x_t, tr_{t-1}→x_t
+            if t > 0:
+                triples.append(((K2F, int(x[t]), int(tr[t])), (K2V, int(x[t]), int(tr[t - 1])), INTER))
+    E, g = _wire_both(model, triples)
+    dev = NumpyDevice(g, model)
+    E.set_messages_to_factor(model.data_var, model.data_fac, model.data_y, tag=ref.REAL)
+    g.ref_set(L.TO_FACTOR, model.data_var, model.data_fac)
+    for v, f, yy in zip(model.data_var, model.data_fac, model.data_y):
+        dev.v2f[dev.slot[(int(v), int(f))]] = (yy, np.inf)
+    rows = g.ref_update(x)
+    E.update_marginals(x)
+    assert [tuple(r[:5]) for r in rows.tolist()] == _oracle_rows(E)
+    assert len(rows) == T + 2 * (T - 1) + T          # likelihood messages, forward chain, marginals: no backward message is ever computed
+    rc, err = g.ref_level()
+    assert rc == 0, err
+    dev.run(g.arr("ref_rec"), g.arr("ref_stage_off"), g.arr("ref_list"))
+    _check_values(dev, E, model, x, "filter wiring")
+    # textbook Kalman filter: vague start, y_t = x_t + N(0, r_t), x_{t+1} = x_t + N(0, q_t)
+    r, q = model.meta["r"], model.meta["q"]
+    m, v = model.data_y[0], r[0]
+    fm, fv = [m], [v]
+    for t in range(1, T):
+        pv = v + q[t - 1]
+        k = pv / (pv + r[t])
+        m, v = m + k * (model.data_y[t] - m), (1 - k) * pv
+        fm.append(m); fv.append(v)
+    gm, gv = dev.moment("marg", np.searchsorted(dev.var_ids, x))
+    assert_close(gm, np.array(fm), 1e-10, "filtered means"); assert_close(gv, np.array(fv), 1e-10, "filtered variances")
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_random_flags_and_dropped_dependencies_on_a_loopy_grid(seed):
+    """the default wiring of a grid with random weak / intermediate / listen flags and a tenth of the product dependencies dropped, in a
+    shuffled add_dependency! order: the shadow scheduler and the restated engine execute the same signals in the same order over six calls
+    with data re-set in between, and the levelled plan leaves the engine's values"""
+    rng = np.random.default_rng(seed)
+    model = cx.synth.gaussian_grid(6, 7, seed=4)
+    E0 = engine_oracle_from_model(model)
+    triples = []
+    for v, f in zip(model.edge_var, model.edge_fac):
+        for sig in (E0.message_to_factor(int(v), int(f)), E0.message_to_variable(int(v), int(f))):
+            for d in E0.dependencies(sig):
+                triples.append((_key(E0, sig), _key(E0, d)))
+    for v in model.x_ids:
+        for d in E0.dependencies(E0.marginal(int(v))):
+            triples.append((_key(E0, E0.marginal(int(v))), _key(E0, d)))
+    out = []
+    for s, d in triples:
+        if s[0] != K2V and rng.random() < 0.1:
+            continue                                              # a product that leaves one of its natural inputs out
+        # (intermediate flags on the dependencies of products only, as the default resolver places them: flagged on the factor side too they
+        # close cycles on a loopy graph, which process_dependencies! never leaves — refused at wiring time, see the last test)
+        fl = (L.WIRE_WEAK if rng.random() < 0.3 else 0) | (L.WIRE_INTERMEDIATE if s[0] != K2V and rng.random() < 0.6 else 0) | (L.WIRE_NO_LISTEN if rng.random() < 0.1 else 0)
+        out.append((s, d, fl))
+    order = rng.permutation(len(out))
+    triples = [out[i] for i in order]
+    E, g = _wire_both(model, triples)
+    dev = NumpyDevice(g, model)
+    _seed(g, E, dev, model)
+    for call in range(6):
+        _set_priors(g, E, dev, model)
+        request = model.x_ids if call % 2 == 0 else rng.permutation(model.x_ids)[:20]
+        rows = g.ref_update(request)
+        E.update_marginals(request)
+        assert [tuple(r[:5]) for r in rows.tolist()] == _oracle_rows(E), f"seed {seed} call {call + 1}: execution order"
+        rc, err = g.ref_level()
+        assert rc == 0, err
+        dev.run(g.arr("ref_rec"), g.arr("ref_stage_off"), g.arr("ref_list"))
+        _check_values(dev, E, model, request, f"seed {seed} call {call + 1}")
+
+
+def test_wirings_the_device_has_no_rule_for_are_refused():
+    model = cx.synth.gaussian_grid(3, 3, seed=1)
+    g = _flat(model)
+    v, f = int(model.edge_var[-1]), int(model.edge_fac[-1])
+    other = int(model.x_ids[0]) if int(model.x_ids[0]) != v else int(model.x_ids[1])
+    for s, d, what in (((K2V, v, f), (KMARG, other, 0), "a message that depends on a marginal (a variational wiring)"),
+                       ((K2F, v, f), (K2V, v, f), "a MessageToFactor that depends on the message of its own edge"),
+                       ((KMARG, v, 0), (K2F, v, f), "a marginal that depends on a MessageToFactor")):
+        rc, err = g.ref_wire([s], [d], [0])
+        assert rc == L.ERR_UNSUPPORTED and "cx_graph_wire" in err, what
+    rc, err = g.ref_wire([(KMARG, v, 0), (KMARG, v, 0)], [(K2V, v, f), (K2V, v, f)], [0, 0])
+    assert rc == L.ERR_INVALID_ARGUMENT and "twice" in err
+    # intermediate flags all the way round a loop of the grid: process_dependencies! would recurse for ever
+    E0 = engine_oracle_from_model(model)
+    sig, dep = [], []
+    for vv, ff in zip(model.edge_var, model.edge_fac):
+        for s in (E0.message_to_factor(int(vv), int(ff)), E0.message_to_variable(int(vv), int(ff))):
+            for d in E0.dependencies(s):
+                sig.append(_key(E0, s)); dep.append(_key(E0, d))
+    rc, err = g.ref_wire(sig, dep, [L.WIRE_INTERMEDIATE] * len(sig))
+    assert rc == L.ERR_UNSUPPORTED and "cycle" in err
