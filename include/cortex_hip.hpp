@@ -114,6 +114,11 @@ class Handle {
         if (n) check(cx_ref_trace(h_, n, out.data(), &n));
         return out;
     }
+    // a user resolver's wiring: one triple per add_dependency!(signal, dependency; flags) (CX_WIRE_*), right after graph_create
+    void graph_wire(const std::vector<cx_item> &signals, const std::vector<cx_item> &dependencies, const std::vector<int32_t> &flags) {
+        need(dependencies.size(), signals.size(), "graph_wire dependencies"); need(flags.size(), signals.size(), "graph_wire flags");
+        check(cx_graph_wire(h_, (int64_t)signals.size(), signals.data(), dependencies.data(), flags.data()));
+    }
     void set_damping(double lambda) { check(cx_set_damping(h_, lambda)); }      // fused / flooding sweeps: new = (1 - lambda) rule + lambda old
     double residual() { double r = 0; check(cx_residual(h_, &r)); return r; }
     std::array<int64_t, 4> message_health() { std::array<int64_t, 4> o{}; check(cx_message_health(h_, o.data())); return o; }      // defined, undefined, negative precision, non-finite

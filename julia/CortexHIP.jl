@@ -194,6 +194,13 @@ set_factor_coefficients!(p, variable_ids::Vector{Int64}, factor_ids::Vector{Int6
                           p.handle, length(a), variable_ids, factor_ids, a))
 
 # the plan of the dim 64 chain-scan schedule: (links per block, fan, levels, potentials, compositions, rules, launches, device bytes)
+# schedule 4: a user resolver's wiring instead of the default one — one (signal, dependency, flags) triple per
+# add_dependency!(signal, dependency; weak, intermediate, listen) the resolver would issue (flags: 1 weak, 2 intermediate, 4 listen = false);
+# signals as CxItem (kind 1 MessageToFactor / 2 MessageToVariable with (variable_id, factor_id); 4 IndividualMarginal with variable_id).
+# Right after upload!, before any value is set.
+wire!(p::HipProcessor, signals::Vector{CxItem}, dependencies::Vector{CxItem}, flags::Vector{Int32}) =
+    check(p.handle, ccall((:cx_graph_wire, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{CxItem}, Ptr{CxItem}, Ptr{Int32}), p.handle, length(flags), signals, dependencies, flags))
+
 # schedule 4: the executions of the last call in the reference's order — what a `trace = true` engine records as
 # TracedInferenceExecution.signal (src/inference_engine.jl:650-862) — as (kind, variable_id, factor_id | range) items
 function reference_trace(p)
