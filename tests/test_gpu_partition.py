@@ -64,7 +64,11 @@ class LoopbackDist:
         works = []
         for o in ops:
             if o.op == self.isend:
-                self.torch.cuda.synchronize()  # the pack kernel has finished
+                if o.tensor.is_cuda:
+                    # the pack kernel has finished.  (Not for host tensors: a device-wide wait while ANOTHER rank thread is capturing its
+                    # tree plan into a HIP graph is refused by the runtime — thread-local capture mode does not cover hipDeviceSynchronize.
+                    # Ranks are processes in the product; threads are this file's rehearsal.)
+                    self.torch.cuda.synchronize()
                 with self.cv:
                     self.box.setdefault((me, o.peer), []).append(o.tensor.clone())  # FIFO: a rank may run a sweep ahead
                     self.cv.notify_all()
