@@ -7,6 +7,7 @@ from . import _lib
 from ._lib import CortexHipError
 from .device import DeviceGraph
 from . import synth
+from . import wiring
 from .signal import (Signal, UndefValue, UndefVariant, add_dependency, compute, get_dependencies, get_listeners,
                      get_value, get_variant, is_computed, is_pending, isa_variant, process_dependencies, set_value,
                      set_variant)

@@ -24,7 +24,7 @@ ROLE_OUT, ROLE_IN, ROLE_PRECISION = 0, 1, 2
 SCHED_FLOODING, SCHED_FUSED, SCHED_CHAIN_SCAN, SCHED_TREE, SCHED_REFERENCE = 0, 1, 2, 3, 4
 FAMILY_GAUSSIAN, FAMILY_NATURAL2, FAMILY_VMP_MEAN_FIELD, FAMILY_VMP_STRUCTURED = 0, 1, 2, 3
 VMP_ALL_NORMAL, VMP_ALL_PRECISION = -1, -2
-WIRE_WEAK, WIRE_INTERMEDIATE, WIRE_NO_LISTEN = 1, 2, 4
+WIRE_WEAK, WIRE_INTERMEDIATE, WIRE_NO_LISTEN, WIRE_DEFAULT_VARIABLE, WIRE_LINK = 1, 2, 4, 8, 16
 KERNEL_VAR_TO_FACTOR, KERNEL_FACTOR_TO_VAR, KERNEL_FUSED, KERNEL_BATCH, KERNEL_BIG_VAR = 0, 1, 2, 3, 4
 KERNEL_HALO_BEGIN, KERNEL_HALO_END, KERNEL_TILED = 5, 6, 7
 KERNEL_COUNT = 8

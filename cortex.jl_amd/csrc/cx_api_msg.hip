@@ -238,6 +238,12 @@ int32_t ensure_prod_store(cx_handle *h) {
     if (before && h->d_prod != before) { tree_graph_drop(h); ref_graphs_drop(h); }      // captured launches hold the store's address by value
     return rc;
 }
+int32_t ensure_joint_store(cx_handle *h) {
+    const double *before = h->d_joint;
+    const int32_t rc = grow_store(h, &h->d_joint, &h->joint_cap, (int64_t)h->joint_index.size(), 6);
+    if (before && h->d_joint != before) { tree_graph_drop(h); ref_graphs_drop(h); }
+    return rc;
+}
 }  // namespace cxh
 }  // extern "C++"
 
@@ -321,7 +327,7 @@ static int32_t update_batch(cx_handle *h, const cx_item *items, int64_t n) {
         }
         int32_t rc = ensure_prod_store(h);
         if (rc != CX_OK) return rc;
-        rc = grow_store(h, &h->d_joint, &h->joint_cap, (int64_t)h->joint_index.size(), 6);
+        rc = ensure_joint_store(h);
         if (rc != CX_OK) return rc;
         rc = ensure_v2f(h);
         if (rc != CX_OK) return rc;

@@ -33,11 +33,13 @@ struct RefSched {
     std::shared_ptr<rs::State> S;               // copy-on-write: a cache hit adopts the entry's post state without copying it
     std::vector<PlanEntry> cache;
     std::vector<int32_t> prod_slot;             // segment-tree node -> index in the handle's product store
+    std::vector<int32_t> joint_slot;            // factor -> index in the handle's joint store (-1: its joint marginal is not wired)
     int64_t hits = 0, misses = 0;
     uint64_t tick = 0;
     int last = -1;
     bool touched = false;                       // a value was set or a call ran: the wiring can no longer be replaced (cx_graph_wire)
-    int max_entries = 4, run_max = 1024;      // C4, ms per call: every stage a launch 57.6, runs of stages <= 1024 items 52.8, <= 4096 items 102 (one workgroup is slow on a wide stage)
+    int64_t max_bytes = (int64_t)2 << 30;       // plans kept: at most max_entries and at most this much device memory (the one in use always stays)
+    int max_entries = 16, run_max = 1024;      // C4, ms per call: every stage a launch 57.6, runs of stages <= 1024 items 52.8, <= 4096 items 102 (one workgroup is slow on a wide stage)
 };
 
 RefSched *ref_of(cx_handle *h) { return (RefSched *)h->ref; }
@@ -117,6 +119,28 @@ void ref_graphs_drop(cx_handle *h) {
     for (auto &e : R->cache) if (e.exec) { (void)hipGraphExecDestroy(e.exec); e.exec = nullptr; }
 }
 
+// the segment-tree nodes of the variables of degree > 5 live in the handle's product store, under the keys cx_update_batch's
+// ProductOfMessages items and cx_get_products use; the wired joint marginals in the joint store, under the keys of cx_get_joint_marginals
+static int32_t register_stores(cx_handle *h, RefSched *R) {
+    R->prod_slot.resize(R->W.prods.size());
+    for (size_t i = 0; i < R->W.prods.size(); i++) {
+        const auto &p = R->W.prods[i];
+        auto key = std::make_tuple(p.var, p.lo, p.hi);
+        auto it = h->prod_index.find(key);
+        if (it == h->prod_index.end()) it = h->prod_index.emplace(key, (int32_t)h->prod_index.size()).first;
+        R->prod_slot[i] = it->second;
+    }
+    R->joint_slot.assign(R->W.jrule.size(), -1);
+    for (size_t f = 0; f < R->W.jrule.size(); f++) {
+        if (!R->W.jrule[f]) continue;
+        auto it = h->joint_index.find((int32_t)f);
+        if (it == h->joint_index.end()) it = h->joint_index.emplace((int32_t)f, (int32_t)h->joint_index.size()).first;
+        R->joint_slot[f] = it->second;
+    }
+    { const int32_t rp = ensure_prod_store(h); if (rp != CX_OK) return rp; }
+    return ensure_joint_store(h);
+}
+
 // the wiring and the shadow state, built with the graph (everything starts as UndefValue(): nothing computed, nothing fresh)
 int32_t ref_build(cx_handle *h) {
     if (h->ref) return CX_OK;
@@ -126,18 +150,9 @@ int32_t ref_build(cx_handle *h) {
     if (rc != CX_OK) return fail(h, rc, err);
     R->S = std::make_shared<rs::State>();
     rs::init_state(R->W, *R->S);
-    // the segment-tree nodes of the variables of degree > 5 live in the handle's product store, under the keys cx_update_batch's
-    // ProductOfMessages items and cx_get_products use
-    R->prod_slot.resize(R->W.prods.size());
-    for (size_t i = 0; i < R->W.prods.size(); i++) {
-        const auto &p = R->W.prods[i];
-        auto key = std::make_tuple(p.var, p.lo, p.hi);
-        auto it = h->prod_index.find(key);
-        if (it == h->prod_index.end()) it = h->prod_index.emplace(key, (int32_t)h->prod_index.size()).first;
-        R->prod_slot[i] = it->second;
-    }
-    { const int32_t rp = ensure_prod_store(h); if (rp != CX_OK) return rp; }
+    { const int32_t rp = register_stores(h, R.get()); if (rp != CX_OK) return rp; }
     if (const char *v = std::getenv("CX_REF_CACHE")) R->max_entries = std::max(1, std::atoi(v));
+    if (const char *v = std::getenv("CX_REF_CACHE_MB")) R->max_bytes = std::max<int64_t>(1, std::atoll(v)) << 20;
     if (const char *v = std::getenv("CX_REF_RUN_MAX")) R->run_max = std::max(0, std::atoi(v));
     h->ref = R.release();
     return CX_OK;
@@ -149,6 +164,49 @@ void ref_on_set(cx_handle *h, int64_t n, const int64_t *edges, int32_t direction
     if (!R || n == 0) return;
     rs::State &S = writable(R);
     for (int64_t i = 0; i < n; i++) rs::set_value(R->W, S, direction == CX_TO_FACTOR ? R->W.sig_v2f(edges[i]) : R->W.sig_f2v(edges[i]));
+}
+
+// set_value! of marginal signals (cx_set_marginals under a user wiring): local variable numbers
+void ref_on_set_marginals(cx_handle *h, int64_t n, const int32_t *vars) {
+    RefSched *R = ref_of(h);
+    if (!R || n == 0) return;
+    rs::State &S = writable(R);
+    for (int64_t i = 0; i < n; i++) rs::set_value(R->W, S, R->W.sig_marg(vars[i]));
+}
+
+// cx_set_marginals on a reference-order handle: the user's set_value!(get_variable_marginal(...), value) — the initial q's and the data of
+// a variational wiring (test/inference_engine_tests.jl:717-736).  Store: (mean, variance) of a Normal variable, (shape, scale) of a precision.
+int32_t ref_set_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, int32_t form, const double *payload) {
+    RefSched *R = ref_of(h);
+    CX_REQUIRE(h, R && h->cfg.dim == 1, CX_ERR_STATE, "cx_set_marginals: no reference-order wiring");
+    CX_REQUIRE(h, form == CX_FORM_POINT || form == CX_FORM_MOMENT || form == CX_FORM_MEAN_PRECISION || form == CX_FORM_GAMMA, CX_ERR_INVALID_ARGUMENT, "cx_set_marginals: bad form");
+    try {
+        std::vector<int32_t> vars((size_t)n);
+        std::vector<double2> val((size_t)n);
+        const int64_t stride = form == CX_FORM_POINT ? 1 : 2;
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t v = find_var(h, variable_ids[i]);
+            if (v < 0) return fail(h, CX_ERR_NOT_FOUND, "unknown variable id " + std::to_string(variable_ids[i]));
+            const bool gamma = !h->var_gamma.empty() && h->var_gamma[v];
+            if (gamma != (form == CX_FORM_GAMMA))
+                return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_set_marginals: variable " + std::to_string(variable_ids[i]) + (gamma ? " is a precision (CX_FORM_GAMMA)" : " is a Normal variable (CX_FORM_POINT, CX_FORM_MOMENT or CX_FORM_MEAN_PRECISION)"));
+            const double *p = payload + i * stride;
+            vars[i] = (int32_t)v;
+            val[i] = form == CX_FORM_POINT ? make_double2(p[0], 0.0) : form == CX_FORM_MEAN_PRECISION ? make_double2(p[0], 1.0 / p[1]) : make_double2(p[0], p[1]);
+        }
+        const int64_t bytes_idx = ((n * 4 + 15) / 16) * 16;
+        const int32_t rc = ensure_stage(h, bytes_idx + n * 16);
+        if (rc != CX_OK) return rc;
+        int32_t *d_idx = (int32_t *)h->d_stage;
+        double2 *d_val = (double2 *)((char *)h->d_stage + bytes_idx);
+        CX_HIP(h, hipMemcpyAsync(d_idx, vars.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+        CX_HIP(h, hipMemcpyAsync(d_val, val.data(), (size_t)n * 16, hipMemcpyHostToDevice, h->stream));
+        cx::launch_scatter(h, h->d_marg, d_idx, d_val, n);
+        CX_HIP(h, hipGetLastError());
+        CX_HIP(h, hipStreamSynchronize(h->stream));      // the staging vectors die here
+        ref_on_set_marginals(h, n, vars.data());
+        return CX_OK;
+    } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_set_marginals: host allocation failed"); }
 }
 
 // cx_seed_messages: every message of `direction` that a rule computes (its slot has a partner or sits in a factor of more edges) and
@@ -205,9 +263,11 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n) {
             (void)bad;      // reported by level() with the message's ids
             rs::Plan P;
             std::string err;
-            const int32_t rc = rs::level(h, R->W, call, [&](int64_t i) { return R->prod_slot[i]; }, P, err);
+            const int32_t rc = rs::level(h, R->W, call, [&](int64_t i) { return R->prod_slot[i]; }, [&](int64_t f) { return R->joint_slot[f]; }, P, err);
             if (rc != CX_OK) return fail(h, rc, err);
-            if ((int)R->cache.size() >= R->max_entries) {      // least recently used out
+            const int64_t incoming = (int64_t)(P.rec.size() + P.list.size()) * 4 + (int64_t)P.stage_off.size() * 8;
+            auto kept_bytes = [&] { int64_t b = 0; for (auto &c : R->cache) b += c.device_bytes; return b; };
+            while (!R->cache.empty() && ((int)R->cache.size() >= R->max_entries || kept_bytes() + incoming > R->max_bytes)) {      // least recently used out
                 size_t lru = 0;
                 for (size_t i = 1; i < R->cache.size(); i++) if (R->cache[i].last_used < R->cache[lru].last_used) lru = i;
                 CX_HIP(h, hipStreamSynchronize(h->stream));
@@ -320,8 +380,14 @@ int32_t cx_graph_wire(cx_handle *h, int64_t n, const cx_item *signals, const cx_
                 *out = R->W.sig_marg(v);
                 return CX_OK;
             }
+            if (it.kind == CX_ITEM_JOINT_MARGINAL) {
+                auto ft = std::lower_bound(h->fac_ids.begin(), h->fac_ids.end(), it.factor_id);
+                if (ft == h->fac_ids.end() || *ft != it.factor_id) return fail(h, CX_ERR_NOT_FOUND, "cx_graph_wire: unknown factor id " + std::to_string(it.factor_id));
+                *out = 2 * h->ne + h->nv + (ft - h->fac_ids.begin());      // (Wiring::sig_joint of the wiring being built)
+                return CX_OK;
+            }
             if (it.kind != CX_ITEM_MESSAGE_TO_FACTOR && it.kind != CX_ITEM_MESSAGE_TO_VARIABLE)
-                return fail(h, CX_ERR_UNSUPPORTED, "cx_graph_wire: signals are MessageToFactor, MessageToVariable and IndividualMarginal (kind " + std::to_string(it.kind) + ")");
+                return fail(h, CX_ERR_UNSUPPORTED, "cx_graph_wire: signals are MessageToFactor, MessageToVariable, IndividualMarginal and JointMarginal (kind " + std::to_string(it.kind) + ")");
             const int64_t e = find_edge(h, it.variable_id, it.factor_id);
             if (e < 0) return fail(h, CX_ERR_NOT_FOUND, "cx_graph_wire: no connection between variable " + std::to_string(it.variable_id) + " and factor " + std::to_string(it.factor_id));
             *out = it.kind == CX_ITEM_MESSAGE_TO_FACTOR ? R->W.sig_v2f(e) : R->W.sig_f2v(e);
@@ -329,10 +395,11 @@ int32_t cx_graph_wire(cx_handle *h, int64_t n, const cx_item *signals, const cx_
         };
         std::vector<int64_t> s((size_t)n), d((size_t)n);
         for (int64_t i = 0; i < n; i++) {
+            if (flags[i] & ~31) return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_graph_wire: flags are CX_WIRE_WEAK | CX_WIRE_INTERMEDIATE | CX_WIRE_NO_LISTEN, or CX_WIRE_DEFAULT_VARIABLE, or CX_WIRE_LINK");
             int32_t rc = number(signals[i], &s[i]);
-            if (rc == CX_OK) rc = number(dependencies[i], &d[i]);
+            d[i] = s[i];
+            if (rc == CX_OK && !(flags[i] & CX_WIRE_DEFAULT_VARIABLE)) rc = number(dependencies[i], &d[i]);
             if (rc != CX_OK) return rc;
-            if (flags[i] & ~7) return fail(h, CX_ERR_INVALID_ARGUMENT, "cx_graph_wire: flags are CX_WIRE_WEAK | CX_WIRE_INTERMEDIATE | CX_WIRE_NO_LISTEN");
         }
         rs::Wiring W;
         std::string err;
@@ -342,10 +409,9 @@ int32_t cx_graph_wire(cx_handle *h, int64_t n, const cx_item *signals, const cx_
         for (auto &e : R->cache) entry_free(h, e);
         R->cache.clear(); R->last = -1;
         R->W = std::move(W);
-        R->prod_slot.clear();
         R->S = std::make_shared<rs::State>();
         rs::init_state(R->W, *R->S);
-        return CX_OK;
+        return register_stores(h, R);
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_graph_wire: host allocation failed"); }
 }
 
@@ -380,8 +446,10 @@ int32_t cx_ref_trace(const cx_handle *hc, int64_t capacity, cx_item *out, int64_
             it.variable_id = h->var_ids[h->edge_var[ed]]; it.factor_id = h->edge_fac_id[ed];
         } else if (s < 2 * ne + nv) {
             it.kind = CX_ITEM_INDIVIDUAL_MARGINAL; it.variable_id = h->var_ids[s - 2 * ne];
+        } else if (R->W.is_joint(s)) {
+            it.kind = CX_ITEM_JOINT_MARGINAL; it.factor_id = h->fac_ids[s - R->W.sig_joint(0)];
         } else {
-            const auto &p = R->W.prods[s - 2 * ne - nv];
+            const auto &p = R->W.prods[s - R->W.sig_prod(0)];
             it.kind = CX_ITEM_PRODUCT_OF_MESSAGES; it.variable_id = h->var_ids[p.var]; it.factor_id = CX_ITEM_RANGE(p.lo, p.hi);
         }
         out[i] = it;

@@ -9,9 +9,12 @@ extern "C" {
 // ---- variational families (cx_vmp.hip) --------------------------------------------------------------------------------
 int32_t cx_set_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, int32_t form, const double *payload) {
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_set_marginals: no graph");
-    CX_REQUIRE(h, is_vmp(h), CX_ERR_UNSUPPORTED, "cx_set_marginals: only the variational families keep settable marginals (sum-product marginals are products of messages: cx_set_messages)");
+    CX_REQUIRE(h, is_vmp(h) || (h->ref && h->cfg.dim == 1), CX_ERR_UNSUPPORTED,
+               "cx_set_marginals: the variational families and the reference-order schedule (a wiring whose messages depend on marginals) keep settable marginals; elsewhere a marginal is the "
+               "product of the messages: cx_set_messages");
     if (n == 0) return CX_OK;
     CX_REQUIRE(h, n > 0 && variable_ids && payload, CX_ERR_INVALID_ARGUMENT, "cx_set_marginals: null argument");
+    if (!is_vmp(h)) return ref_set_marginals(h, n, variable_ids, form, payload);
     return cx::vmp_set_marginals(h, n, variable_ids, form, payload);
 }
 
@@ -75,6 +78,8 @@ std::vector<StatePart> state_parts(cx_handle *h) {
         if (h->ref) {      // CX_SCHED_REFERENCE: the segment-tree nodes are values the next call may read; the shadow decides what it computes
             parts.push_back({6, h->d_prod, (int64_t)h->prod_index.size() * 16});
             parts.push_back({7, nullptr, ref_state_bytes(h)});
+            // the joint marginals of a user wiring (cx_graph_wire) are values too: the messages to the precisions read them
+            if (!h->joint_index.empty()) parts.push_back({8, h->d_joint, (int64_t)h->joint_index.size() * 48});
         }
     } else {
         const int64_t nc = h->nc, ncs = h->ncs;

@@ -116,6 +116,7 @@ int32_t flatten(H *h, int64_t n_edges, const int64_t *edge_var, const int64_t *e
     }
     h->nf = n_factors;
     h->lin_out_is_second.assign(n_factors, 0); h->fac_edges.clear();
+    h->np_role.clear(); h->var_gamma.clear();
     h->n_kary = 0; h->kary_slot.clear(); h->kary_coef.clear(); h->kary_qb.clear(); h->slot_kary.clear(); h->kary_pset.clear(); h->kary_dirty = true;
     std::vector<int32_t> edge_fix(ne);      // local factor number per CSR edge
     for (int64_t e = 0; e < ne; e++) {
@@ -168,6 +169,26 @@ int32_t flatten(H *h, int64_t n_edges, const int64_t *edge_var, const int64_t *e
             if (deg != 2) return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_create: CX_FACTOR_BERNOULLI needs exactly 2 edges (factor id " + std::to_string(h->fac_ids[f]) + ")");
             const int32_t b1 = slot_of_edge_t(h, fedge[foff[f]]), b2 = slot_of_edge_t(h, fedge[foff[f] + 1]);
             h->partner[b1] = b2; h->partner[b2] = b1;
+            continue;
+        }
+        if (kind == CX_FACTOR_NORMAL_PRECISION) {
+            // out ~ N(in, 1 / precision) with a Gamma-distributed precision: no sum-product rule — its messages are computed by the variational
+            // rules a user wiring selects (cx_graph_wire; cx_refsched.h: kRule*), so only the reference-order schedule can run it.  (The fused
+            // calls of the two test models of the reference are the CX_FAMILY_VMP_* handles, cx_vmp.hip.)
+            const std::string who = "cx_graph_create: CX_FACTOR_NORMAL_PRECISION (factor id " + std::to_string(h->fac_ids[f]) + ")";
+            if (mv || h->cfg.schedule != CX_SCHED_REFERENCE)
+                return fail_(err, CX_ERR_UNSUPPORTED, who + " has variational rules only: CX_SCHED_REFERENCE with a user wiring (cx_graph_wire, dim 1), or the CX_FAMILY_VMP_* families");
+            if (deg != 3 || !edge_role) return fail_(err, CX_ERR_INVALID_ARGUMENT, who + " needs three edges with roles CX_ROLE_OUT, CX_ROLE_IN, CX_ROLE_PRECISION");
+            if (h->np_role.empty()) { h->np_role.assign(ne, -1); h->var_gamma.assign(h->nv, 0); }
+            int seen = 0;
+            for (int32_t k = 0; k < deg; k++) {
+                const int32_t e = fedge[foff[f] + k], role = edge_role[ord[e]];
+                if (role < CX_ROLE_OUT || role > CX_ROLE_PRECISION || (seen & (1 << role)))
+                    return fail_(err, CX_ERR_INVALID_ARGUMENT, who + " needs three edges with roles CX_ROLE_OUT, CX_ROLE_IN, CX_ROLE_PRECISION, one each");
+                seen |= 1 << role;
+                h->np_role[e] = (int8_t)role;
+                if (role == CX_ROLE_PRECISION) h->var_gamma[h->edge_var[e]] = 1;
+            }
             continue;
         }
         if (kind == CX_FACTOR_GAUSS_LINEAR_N) {
@@ -240,6 +261,11 @@ int32_t flatten(H *h, int64_t n_edges, const int64_t *edge_var, const int64_t *e
     if (h->any_linear)
         for (int64_t s = 0; s < slots; s++)
             if (h->partner[s] >= 0) { sq[s] = q[h->partner[s]]; sa[s] = a[h->partner[s]]; sb[s] = b[h->partner[s]]; }
+    // a precision variable is Gamma-distributed wherever it appears: the precision of its factors, or on opaque factors (a prior the caller sets)
+    for (int64_t e = 0; e < ne && !h->var_gamma.empty(); e++)
+        if (h->var_gamma[h->edge_var[e]] && h->np_role[e] != CX_ROLE_PRECISION && h->fac_kind[edge_fix[e]] != CX_FACTOR_OPAQUE)
+            return fail_(err, CX_ERR_INVALID_ARGUMENT, "cx_graph_create: variable " + std::to_string(h->var_ids[h->edge_var[e]]) + " is the precision of a CX_FACTOR_NORMAL_PRECISION factor "
+                         "(Gamma-distributed) and a Normal variable of factor " + std::to_string(h->edge_fac_id[e]));
     // messages with >=1 dependency and >=1 listener (the metric's unit): both directions of every 2-edge Gaussian
     // factor, minus variable→factor messages of degree-1 variables (no dependencies, dependencies.jl:48-55)
     int64_t m = 0;

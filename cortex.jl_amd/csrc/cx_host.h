@@ -155,6 +155,9 @@ void tree_graph_drop(cx_handle *h);        // CX_SCHED_TREE: the stages of cx_tr
 void sweep_main(cx_handle *h, bool skip_ghosts);
 void sweep_finish(cx_handle *h);
 // ---- cx_api_msg.hip -------------------------------------------------------------------------------------------------
+int32_t ref_set_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, int32_t form, const double *payload);   // cx_api_ref.hip
+void ref_on_set_marginals(cx_handle *h, int64_t n, const int32_t *vars);
+int32_t ensure_joint_store(cx_handle *h);  // the same for the joint-marginal store (registered factors: cx_handle::joint_index)
 int32_t ensure_prod_store(cx_handle *h);   // the product store holds every registered ProductOfMessages node (graphs that captured its address are dropped when it moves)
 // ---- cx_api_ref.hip: CX_SCHED_REFERENCE -----------------------------------------------------------------------------
 int32_t ref_build(cx_handle *h);

@@ -85,7 +85,8 @@ struct HostGraph {                       // the host fields of cx_handle that cx
     std::vector<int64_t> var_ids, fac_ids, edge_fac_id;
     std::vector<int32_t> fac_kind, var_off, edge_var, vbase, slice_off, partner, big_vars, big_slots, fac_edges, spdir;
     std::vector<double> fac_params;
-    std::vector<uint8_t> vinfo, lin_out_is_second;
+    std::vector<uint8_t> vinfo, lin_out_is_second, var_gamma;
+    std::vector<int8_t> np_role;
     int64_t n_messages_per_sweep = 0, max_pset = -1;
     bool any_linear = false;
     int32_t big_start = 0;
@@ -188,6 +189,12 @@ int32_t cxh_ref_wire(void *p, int64_t n, const int64_t *sig3, const int64_t *dep
     int32_t rc = CX_OK;
     std::vector<int64_t> s((size_t)n), d((size_t)n);
     auto number = [&](const int64_t *t, int64_t *out) {
+        if (t[0] == CX_ITEM_JOINT_MARGINAL) {
+            auto it = std::lower_bound(g->fac_ids.begin(), g->fac_ids.end(), t[2]);
+            if (it == g->fac_ids.end() || *it != t[2]) return false;
+            *out = 2 * g->ne + g->nv + (it - g->fac_ids.begin());
+            return true;
+        }
         if (t[0] == CX_ITEM_INDIVIDUAL_MARGINAL) {
             auto it = std::lower_bound(g->var_ids.begin(), g->var_ids.end(), t[1]);
             if (it == g->var_ids.end() || *it != t[1]) return false;
@@ -199,7 +206,11 @@ int32_t cxh_ref_wire(void *p, int64_t n, const int64_t *sig3, const int64_t *dep
         *out = t[0] == CX_ITEM_MESSAGE_TO_FACTOR ? ed : g->ne + ed;
         return true;
     };
-    for (int64_t i = 0; i < n && rc == CX_OK; i++) if (!number(sig3 + 3 * i, &s[i]) || !number(dep3 + 3 * i, &d[i])) rc = CX_ERR_NOT_FOUND;
+    for (int64_t i = 0; i < n && rc == CX_OK; i++) {
+        if (!number(sig3 + 3 * i, &s[i])) rc = CX_ERR_NOT_FOUND;
+        d[i] = s[i];
+        if (rc == CX_OK && !(flags[i] & cx::refsched::kWireDefaultVariable) && !number(dep3 + 3 * i, &d[i])) rc = CX_ERR_NOT_FOUND;
+    }
     if (rc == CX_OK) {
         try { rc = cx::refsched::build_user_wiring(g, n, s.data(), d.data(), flags, g->rw, e); if (rc == CX_OK) cx::refsched::init_state(g->rw, g->rs); }
         catch (const std::exception &x) { rc = CX_ERR_INVALID_ARGUMENT; e = x.what(); }
@@ -215,6 +226,17 @@ int32_t cxh_ref_set(void *p, int32_t direction, int64_t n, const int64_t *variab
         const int64_t e = href_edge(g, variable_ids[i], factor_ids[i]);
         if (e < 0) return CX_ERR_NOT_FOUND;
         cx::refsched::set_value(g->rw, g->rs, direction == CX_TO_FACTOR ? g->rw.sig_v2f(e) : g->rw.sig_f2v(e));
+    }
+    return CX_OK;
+}
+
+// set_value! on marginal signals
+int32_t cxh_ref_set_marginals(void *p, int64_t n, const int64_t *variable_ids) {
+    HostGraph *g = (HostGraph *)p;
+    for (int64_t i = 0; i < n; i++) {
+        auto it = std::lower_bound(g->var_ids.begin(), g->var_ids.end(), variable_ids[i]);
+        if (it == g->var_ids.end() || *it != variable_ids[i]) return CX_ERR_NOT_FOUND;
+        cx::refsched::set_value(g->rw, g->rs, g->rw.sig_marg(it - g->var_ids.begin()));
     }
     return CX_OK;
 }
@@ -244,7 +266,8 @@ void cxh_ref_trace(const void *p, int64_t *out6) {
             const int64_t e = s < W.ne ? s : s - W.ne;
             o[0] = s < W.ne ? CX_ITEM_MESSAGE_TO_FACTOR : CX_ITEM_MESSAGE_TO_VARIABLE; o[1] = g->var_ids[g->edge_var[e]]; o[2] = g->edge_fac_id[e];
         } else if (s < 2 * W.ne + W.nv) { o[0] = CX_ITEM_INDIVIDUAL_MARGINAL; o[1] = g->var_ids[s - 2 * W.ne]; }
-        else { const auto &pr = W.prods[s - 2 * W.ne - W.nv]; o[0] = CX_ITEM_PRODUCT_OF_MESSAGES; o[1] = g->var_ids[pr.var]; o[3] = pr.lo; o[4] = pr.hi; }
+        else if (W.is_joint(s)) { o[0] = CX_ITEM_JOINT_MARGINAL; o[2] = g->fac_ids[s - W.sig_joint(0)]; }
+        else { const auto &pr = W.prods[s - W.sig_prod(0)]; o[0] = CX_ITEM_PRODUCT_OF_MESSAGES; o[1] = g->var_ids[pr.var]; o[3] = pr.lo; o[4] = pr.hi; }
     }
 }
 
@@ -253,7 +276,7 @@ int32_t cxh_ref_level(void *p, char *err, int32_t errlen) {
     HostGraph *g = (HostGraph *)p;
     std::string e;
     int32_t rc;
-    try { rc = cx::refsched::level(g, g->rw, g->rcall, [](int64_t i) { return i; }, g->rplan, e); }
+    try { rc = cx::refsched::level(g, g->rw, g->rcall, [](int64_t i) { return i; }, [](int64_t f) { return f; }, g->rplan, e); }
     catch (const std::exception &x) { rc = CX_ERR_INVALID_ARGUMENT; e = x.what(); }
     if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", e.c_str());
     return rc;

@@ -206,6 +206,8 @@ struct cx_handle {
     std::map<std::tuple<int32_t, int32_t, int32_t>, int32_t> prod_index;
     std::map<int32_t, int32_t> joint_index;
     std::vector<uint8_t> lin_out_is_second;   // per factor (GAUSS_LINEAR): the OUT edge is the edge of the higher variable id
+    std::vector<int8_t> np_role;              // per CSR edge: the role on a CX_FACTOR_NORMAL_PRECISION factor, -1 elsewhere (empty: no such factor)
+    std::vector<uint8_t> var_gamma;           // per variable: 1 = the precision of such factors, Gamma-distributed (marginal stored as (shape, scale))
     std::vector<int32_t> fac_edges;           // [2 nf] CSR edges of each (≤ 2-edge) factor, built on first use
     double2 *d_prod = nullptr;
     double *d_joint = nullptr;

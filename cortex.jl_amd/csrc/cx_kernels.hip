@@ -375,6 +375,50 @@ struct KaryTab { const int32_t *slot; const double *coef, *qb; const int32_t *li
 // `hi` sources list[lo ..): an entry >= 0 is a factor→variable slot, ~entry a node of the product store.  What the reference's rule
 // call read, node by node — a node may lag behind its leaves on a graph with loops, and the reference reads the node.
 constexpr int kItemSumToFactor = 64, kItemSumToProduct = 65, kItemSumToMarginal = 66;
+// ... and the variational rules of a CX_FACTOR_NORMAL_PRECISION factor (out ~ N(in, 1 / precision), precision ~ Gamma) that a user wiring
+// selects (cx_refsched.h: kRule*; the reference's test rules, test/inference_engine_tests.jl:647-689, 939-1030).  Marginals are read from
+// the marginal store: (mean, variance) of a Normal variable ((datum, 0) when observed), (shape, scale) of a precision — 72 stores the
+// latter from the natural-parameter sum (shape - 1, rate).  A message to a precision is Gamma(3/2, 2 / spread) = natural (1/2, spread / 2).
+constexpr int kItemMfNormal = 67, kItemMfGamma = 68, kItemStNormal = 69, kItemVmpJoint = 70, kItemStGamma = 71, kItemSumToGammaMarginal = 72;
+__device__ __forceinline__ void vmp_item(int k, int idx, int lo, const int32_t *__restrict__ list, double2 *__restrict__ f2v, const double2 *__restrict__ v2f,
+                                         const double2 *__restrict__ marg, double *__restrict__ joint) {
+    const double inf = __builtin_inf();
+    if (k == kItemMfNormal) {                 // N(E[other], E[precision])                                                        (:654-664)
+        const double2 a = marg[list[lo]], g = marg[list[lo + 1]];
+        const double eg = g.x * g.y;
+        if (!__builtin_isnan(a.x) && !__builtin_isnan(eg)) f2v[idx] = make_double2(a.x * eg, eg);
+    } else if (k == kItemMfGamma) {           // Gamma(3/2, 2 / (var a + var b + (E a - E b)^2))                                  (:666-684)
+        const double2 a = marg[list[lo]], b = marg[list[lo + 1]];
+        const double d = a.x - b.x, spread = a.y + b.y + d * d;
+        if (!__builtin_isnan(spread)) f2v[idx] = make_double2(0.5, 0.5 * spread);
+    } else if (k == kItemStNormal) {          // N(mean m, 1 / (var m + 1 / E[precision])), m the other Normal variable's message    (:1004-1010)
+        const double2 m = v2f[list[lo]], g = marg[list[lo + 1]];
+        const double eg = g.x * g.y;
+        if (__builtin_isnan(m.y) || __builtin_isnan(m.x) || __builtin_isnan(eg)) return;
+        const double mean = m.y == inf ? m.x : m.x / m.y, var = m.y == inf ? 0.0 : 1.0 / m.y;
+        const double w = 1.0 / (var + 1.0 / eg);
+        f2v[idx] = make_double2(mean * w, w);
+    } else if (k == kItemVmpJoint) {          // the 2-d Gaussian with precision [[w1 + E, -E], [-E, w2 + E]] and potential (xi1, xi2)  (:939-967)
+        const double2 m1 = v2f[list[lo]], m2 = v2f[list[lo + 1]], g = marg[list[lo + 2]];
+        const double eg = g.x * g.y;
+        if (__builtin_isnan(m1.y) || __builtin_isnan(m1.x) || __builtin_isnan(m2.y) || __builtin_isnan(m2.x) || __builtin_isnan(eg)) return;
+        double mu1, mu2, v11, v12, v22;
+        if (m1.y == inf && m2.y == inf) { mu1 = m1.x; mu2 = m2.x; v11 = v12 = v22 = 0.0; }
+        else if (m1.y == inf) { mu1 = m1.x; v11 = v12 = 0.0; v22 = 1.0 / (m2.y + eg); mu2 = v22 * (m2.x + eg * mu1); }
+        else if (m2.y == inf) { mu2 = m2.x; v22 = v12 = 0.0; v11 = 1.0 / (m1.y + eg); mu1 = v11 * (m1.x + eg * mu2); }
+        else {
+            const double a = m1.y + eg, c = m2.y + eg, idet = 1.0 / (a * c - eg * eg);
+            v11 = c * idet; v12 = eg * idet; v22 = a * idet;
+            mu1 = v11 * m1.x + v12 * m2.x; mu2 = v12 * m1.x + v22 * m2.x;
+        }
+        double *o = joint + 6 * (int64_t)idx;
+        o[0] = mu1; o[1] = mu2; o[2] = v11; o[3] = v12; o[4] = v12; o[5] = v22;
+    } else {                                  // kItemStGamma: Gamma(3/2, 2 / (V11 - 2 V12 + V22 + (m1 - m2)^2)) from the joint          (:1011-1016)
+        const double *o = joint + 6 * (int64_t)list[lo];
+        const double d = o[0] - o[1], spread = o[2] - o[3] - o[4] + o[5] + d * d;
+        if (!__builtin_isnan(spread)) f2v[idx] = make_double2(0.5, 0.5 * spread);
+    }
+}
 template <int MODE>
 __device__ __forceinline__ void batch_item(int k, int idx, int v, int lo, int hi, const int32_t *__restrict__ vbase,
                                            const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
@@ -384,10 +428,13 @@ __device__ __forceinline__ void batch_item(int k, int idx, int v, int lo, int hi
                                            double2 *__restrict__ prod, double *__restrict__ joint, const KaryTab kt) {
     if (k == kItemKaryEntry) {            // internal (the tree schedule's stage lists): index = entry of the k-ary table
         kary_item(idx, kt.slot, kt.coef, kt.qb, v2f, f2v);
+    } else if (k >= kItemMfNormal && k <= kItemStGamma) {
+        vmp_item(k, idx, lo, kt.list, f2v, v2f, marg, joint);
     } else if (k >= kItemSumToFactor) {   // internal (reference-order plans)
         double2 acc = zero2();
         for (int j = 0; j < hi; j++) { const int s = kt.list[lo + j]; acc = add2(acc, s >= 0 ? f2v[s] : prod[~s]); }
         if (k == kItemSumToMarginal) marg[v] = nat_marg ? acc : to_moment(acc);
+        else if (k == kItemSumToGammaMarginal) marg[v] = make_double2(acc.x + 1.0, 1.0 / acc.y);
         else if (!__builtin_isnan(acc.y)) { if (k == kItemSumToFactor) v2f[idx] = acc; else prod[idx] = acc; }
     } else if (k == CX_ITEM_MESSAGE_TO_FACTOR) {
         m2f_one(idx, v, vbase, vdeg, vinfo, f2v, v2f);

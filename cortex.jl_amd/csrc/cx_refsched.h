@@ -19,7 +19,8 @@
 // Signals, by number:   [0, ne)            MessageToFactor of CSR edge e        (inference_signal.jl:29-32)
 //                       [ne, 2 ne)         MessageToVariable of CSR edge e      (:45-48)
 //                       [2 ne, 2 ne + nv)  IndividualMarginal of variable v     (:78-80)
-//                       [2 ne + nv, nsig)  ProductOfMessages(variable, range)   (:62-66), the segment-tree nodes of variables of degree > 5
+//                       [.., + nj)         JointMarginal(factor)                (:93-96), user wirings only (nj = factors, else 0)
+//                       [.., nsig)         ProductOfMessages(variable, range)   (:62-66), the segment-tree nodes of variables of degree > 5
 // Pure host C++ over any struct H with cx_handle's host fields (cx_flatten.h); tests/test_refsched.py runs it against the test suite's
 // restated reference engine, execution by execution, also under -fsanitize=address,undefined.
 #pragma once
@@ -40,22 +41,43 @@ constexpr uint64_t kAllWeak = 0x2222222222222222ull, kAllComp = 0x44444444444444
 
 struct Prod { int32_t var, lo, hi; };      // local variable, 1-based inclusive range over its factors in ascending id order (the variant's `range`)
 
+// what computes a MessageToVariable signal (Wiring::vrule).  The sum-product rule of the factor reads the stored messages of the factor's
+// other edges; the variational rules of a CX_FACTOR_NORMAL_PRECISION factor (out ~ N(in, 1 / precision)) read exactly their dependency
+// list, which is also how they are told apart — the reference's user rule dispatches on the dependencies it is handed the same way
+// (test/inference_engine_tests.jl:647-689, 969-1030):
+//   kRuleMfNormal   to a Normal variable <- {marginal(other Normal), marginal(precision)}:  N(E[other], E[precision])                    (:654-664)
+//   kRuleMfGamma    to the precision     <- {marginal(out), marginal(in)}:  Gamma(3/2, 2 / (var out + var in + (E out - E in)^2))        (:666-684)
+//   kRuleStNormal   to a Normal variable <- {MessageToFactor(other Normal), marginal(precision)}:  N(mean m, 1 / (var m + 1 / E[precision]))  (:1004-1010)
+//   kRuleStGamma    to the precision     <- {JointMarginal(factor)}:  Gamma(3/2, 2 / (V11 - 2 V12 + V22 + (m1 - m2)^2))                 (:1011-1016)
+// and a JointMarginal(factor) <- {MessageToFactor(out), MessageToFactor(in), marginal(precision)} is the 2-d Gaussian of :939-967.
+constexpr uint8_t kRuleBP = 0, kRuleNone = 1, kRuleMfNormal = 2, kRuleMfGamma = 3, kRuleStNormal = 4, kRuleStGamma = 5;
+
 struct Wiring {
-    int64_t ne = 0, nv = 0, nsig = 0;
+    int64_t ne = 0, nv = 0, nj = 0, nsig = 0;
     std::vector<int64_t> dep_off, lis_off, chunk_off;      // [nsig + 1]
     std::vector<int32_t> dep;                              // dependencies in the resolver's order (add_dependency! appends)
     std::vector<uint8_t> dep_inter;                        // 1: flagged intermediate
     std::vector<uint8_t> dep_weak;                         // 1: flagged weak (a user wiring, cx_graph_wire; the default resolver sets none)
     std::vector<int32_t> lis;                              // listeners
-    std::vector<uint8_t> lis_idx;                          // position of this signal in the listener's dependency list (notify_listener!: first match)
+    std::vector<int32_t> lis_idx;                          // position of this signal in the listener's dependency list (notify_listener!: first match)
     std::vector<uint8_t> lis_listen;                       // listenmask (add_dependency!(...; listen)): 1 everywhere under the default wiring
     bool custom = false;                                   // a user wiring (cx_graph_wire): products of messages are "sum of the dependency list" items
-    std::vector<Prod> prods;                               // signal 2 ne + nv + i
-    std::vector<uint8_t> no_rule;                          // per MessageToVariable signal (index e): 1 = the device has no rule for this message
+    std::vector<Prod> prods;                               // signal 2 ne + nv + nj + i
+    std::vector<uint8_t> vrule;                            // per MessageToVariable signal (index e): kRule*
+    std::vector<uint8_t> jrule;                            // per JointMarginal signal (index f): 1 = wired as the variational joint of a NORMAL_PRECISION factor
+    std::vector<int64_t> link_off;                         // [nv + 1]: link_signal_to_variable! (model_engine.jl:64-71), in link order; empty = none
+    std::vector<int32_t> link;
+    std::vector<int32_t> efac, foff, fedge;                // local factor of every CSR edge; the edges of a factor in ascending variable order
     int64_t sig_v2f(int64_t e) const { return e; }
     int64_t sig_f2v(int64_t e) const { return ne + e; }
     int64_t sig_marg(int64_t v) const { return 2 * ne + v; }
-    int64_t sig_prod(int64_t i) const { return 2 * ne + nv + i; }
+    int64_t sig_joint(int64_t f) const { return 2 * ne + nv + f; }
+    int64_t sig_prod(int64_t i) const { return 2 * ne + nv + nj + i; }
+    bool is_v2f(int64_t s) const { return s < ne; }
+    bool is_f2v(int64_t s) const { return s >= ne && s < 2 * ne; }
+    bool is_marg(int64_t s) const { return s >= 2 * ne && s < 2 * ne + nv; }
+    bool is_joint(int64_t s) const { return s >= 2 * ne + nv && s < 2 * ne + nv + nj; }
+    bool is_prod(int64_t s) const { return s >= 2 * ne + nv + nj; }
 };
 
 struct State {
@@ -71,6 +93,49 @@ inline uint64_t zob_chunk(int64_t c, uint64_t value) { return mix64(value ^ mix6
 inline uint64_t zob_flag(int64_t s, uint8_t f) { return mix64((uint64_t)f ^ mix64((uint64_t)s * 2)); }
 
 // ---- the default resolver's wiring (dependencies.jl:5-173), emitted as (signal, dependency, intermediate) in add_dependency! order ----
+// resolve_variable_dependencies! (dependencies.jl:33-126) with form_segment_tree_dependency! (:128-173) for ONE variable.  hl(e): does the
+// MessageToFactor of edge e have listeners at this point — the reference asks get_listeners while it wires (:73,107,117,149,159), so under a
+// user wiring the answer depends on what was wired before
+template <class H, class Emit, class HasL>
+struct VarWirer {
+    const H *h; int64_t ne; std::vector<Prod> *prods; int64_t *next_prod; Emit &emit; HasL &hl;
+    VarWirer(const H *h_, std::vector<Prod> *p, int64_t *np, Emit &e, HasL &l) : h(h_), ne(h_->ne), prods(p), next_prod(np), emit(e), hl(l) {}
+    // over the 0-based half-open range [lo, hi) of the variable's edges
+    int64_t tree(int32_t v, int32_t lo, int32_t hi) {
+        const int32_t e0 = h->var_off[v];
+        if (hi - lo == 1) return ne + e0 + lo;
+        const int32_t mid = lo + (hi - lo) / 2;
+        const int64_t left = tree(v, lo, mid), right = tree(v, mid, hi);
+        cross(v, lo, mid, right); cross(v, mid, hi, left);
+        const int64_t inter = (*next_prod)++;
+        if (prods) prods->push_back(Prod{v, lo + 1, hi});
+        emit(inter, left, 1); emit(inter, right, 1);
+        return inter;
+    }
+    void cross(int32_t v, int32_t lo, int32_t hi, int64_t other) {
+        const int32_t e0 = h->var_off[v];
+        for (int32_t k = lo; k < hi; k++) if (hl(e0 + k)) emit((int64_t)(e0 + k), other, 1);
+    }
+    void variable(int64_t v) {
+        const int32_t e0 = h->var_off[v], n = h->var_off[v + 1] - e0;
+        const int64_t marg = 2 * ne + v;
+        if (n == 0) return;
+        if (n < 2) { emit(marg, ne + e0, 1); return; }
+        if (n <= 5) {
+            for (int32_t k = 0; k < n; k++) {
+                emit(marg, ne + e0 + k, 1);
+                if (hl(e0 + k))
+                    for (int32_t j = 0; j < n; j++) if (j != k) emit((int64_t)(e0 + k), ne + e0 + j, 1);
+            }
+            return;
+        }
+        const int32_t mid = n / 2;
+        const int64_t left = tree((int32_t)v, 0, mid), right = tree((int32_t)v, mid, n);
+        cross((int32_t)v, 0, mid, right); cross((int32_t)v, mid, n, left);
+        emit(marg, left, 1); emit(marg, right, 1);
+    }
+};
+
 template <class H, class Emit>
 void wire(const H *h, const std::vector<int32_t> &efac, const std::vector<int32_t> &foff, const std::vector<int32_t> &fedge, std::vector<Prod> *prods,
           Emit &&emit) {
@@ -81,46 +146,27 @@ void wire(const H *h, const std::vector<int32_t> &efac, const std::vector<int32_
         for (int32_t k1 = foff[f]; k1 < foff[f + 1]; k1++)
             for (int32_t k2 = foff[f]; k2 < foff[f + 1]; k2++)
                 if (k1 != k2) emit(ne + fedge[k1], (int64_t)fedge[k2], 0);
-    auto has_listeners = [&](int64_t e) { return foff[efac[e] + 1] - foff[efac[e]] >= 2; };      // isempty(get_listeners(msg_to_factor)), :73,107,117,149,159
+    auto has_listeners = [&](int64_t e) { return foff[efac[e] + 1] - foff[efac[e]] >= 2; };      // someone listens: a factor of two or more variables
     int64_t next_prod = 2 * ne + nv;
-    // form_segment_tree_dependency!, dependencies.jl:128-173, over the 0-based half-open range [lo, hi) of the variable's edges
-    struct Rec {
-        const H *h; int64_t ne; std::vector<Prod> *prods; int64_t *next_prod; Emit &emit; decltype(has_listeners) &hl;
-        int64_t tree(int32_t v, int32_t lo, int32_t hi) {
-            const int32_t e0 = h->var_off[v];
-            if (hi - lo == 1) return ne + e0 + lo;
-            const int32_t mid = lo + (hi - lo) / 2;
-            const int64_t left = tree(v, lo, mid), right = tree(v, mid, hi);
-            cross(v, lo, mid, right); cross(v, mid, hi, left);
-            const int64_t inter = (*next_prod)++;
-            if (prods) prods->push_back(Prod{v, lo + 1, hi});
-            emit(inter, left, 1); emit(inter, right, 1);
-            return inter;
-        }
-        void cross(int32_t v, int32_t lo, int32_t hi, int64_t other) {
-            const int32_t e0 = h->var_off[v];
-            for (int32_t k = lo; k < hi; k++) if (hl(e0 + k)) emit((int64_t)(e0 + k), other, 1);
-        }
-    } rec{h, ne, prods, &next_prod, emit, has_listeners};
-    // resolve_variable_dependencies!, dependencies.jl:33-126
-    for (int64_t v = 0; v < nv; v++) {
-        const int32_t e0 = h->var_off[v], n = h->var_off[v + 1] - e0;
-        const int64_t marg = 2 * ne + v;
-        if (n == 0) continue;
-        if (n < 2) { emit(marg, ne + e0, 1); continue; }
-        if (n <= 5) {
-            for (int32_t k = 0; k < n; k++) {
-                emit(marg, ne + e0 + k, 1);
-                if (has_listeners(e0 + k))
-                    for (int32_t j = 0; j < n; j++) if (j != k) emit((int64_t)(e0 + k), ne + e0 + j, 1);
-            }
-            continue;
-        }
-        const int32_t mid = n / 2;
-        const int64_t left = rec.tree((int32_t)v, 0, mid), right = rec.tree((int32_t)v, mid, n);
-        rec.cross((int32_t)v, 0, mid, right); rec.cross((int32_t)v, mid, n, left);
-        emit(marg, left, 1); emit(marg, right, 1);
+    VarWirer<H, Emit, decltype(has_listeners)> vw(h, prods, &next_prod, emit, has_listeners);
+    for (int64_t v = 0; v < nv; v++) vw.variable(v);
+}
+
+// the factor side of the graph as CSR (edges of one factor in ascending variable order: the CSR edge order is (variable, factor) ascending)
+template <class H>
+int32_t factor_csr(const H *h, Wiring &W, std::string &err, const char *who) {
+    const int64_t ne = h->ne, nf = h->nf;
+    W.efac.assign(ne, 0); W.foff.assign(nf + 1, 0); W.fedge.assign(ne, 0);
+    for (int64_t e = 0; e < ne; e++) {
+        auto it = std::lower_bound(h->fac_ids.begin(), h->fac_ids.end(), h->edge_fac_id[e]);
+        if (it == h->fac_ids.end() || *it != h->edge_fac_id[e]) return fail_(err, CX_ERR_STATE, std::string(who) + ": edge names an unknown factor");
+        W.efac[e] = (int32_t)(it - h->fac_ids.begin());
+        W.foff[W.efac[e] + 1]++;
     }
+    for (int64_t f = 0; f < nf; f++) W.foff[f + 1] += W.foff[f];
+    std::vector<int32_t> fill(W.foff.begin(), W.foff.end() - 1);
+    for (int64_t e = 0; e < ne; e++) W.fedge[fill[W.efac[e]]++] = (int32_t)e;
+    return CX_OK;
 }
 
 // listeners (in add_dependency! order over the whole wiring) and chunk offsets from the dependency lists; lis_listen[q] must have been
@@ -134,7 +180,7 @@ inline void finish_wiring(Wiring &W, const std::vector<uint8_t> *listen_of_dep =
     for (int64_t s = 0; s < W.nsig; s++)
         for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) {
             const int64_t q = fill[W.dep[p]]++;
-            W.lis[q] = (int32_t)s; W.lis_idx[q] = (uint8_t)(p - W.dep_off[s]);
+            W.lis[q] = (int32_t)s; W.lis_idx[q] = (int32_t)(p - W.dep_off[s]);
             if (listen_of_dep) W.lis_listen[q] = (*listen_of_dep)[p];
         }
     W.chunk_off.assign(W.nsig + 1, 0);
@@ -146,21 +192,11 @@ inline void finish_wiring(Wiring &W, const std::vector<uint8_t> *listen_of_dep =
 
 template <class H>
 int32_t build_wiring(const H *h, Wiring &W, std::string &err) {
-    const int64_t ne = h->ne, nv = h->nv, nf = h->nf;
+    const int64_t ne = h->ne, nv = h->nv;
     W = Wiring();
     W.ne = ne; W.nv = nv;
-    std::vector<int32_t> efac(ne), foff(nf + 1, 0), fedge(ne);
-    for (int64_t e = 0; e < ne; e++) {
-        auto it = std::lower_bound(h->fac_ids.begin(), h->fac_ids.end(), h->edge_fac_id[e]);
-        if (it == h->fac_ids.end() || *it != h->edge_fac_id[e]) return fail_(err, CX_ERR_STATE, "reference schedule: edge names an unknown factor");
-        efac[e] = (int32_t)(it - h->fac_ids.begin());
-        foff[efac[e] + 1]++;
-    }
-    for (int64_t f = 0; f < nf; f++) foff[f + 1] += foff[f];
-    {   // edges of one factor in ascending variable order (the CSR edge order is (variable, factor) ascending)
-        std::vector<int32_t> fill(foff.begin(), foff.end() - 1);
-        for (int64_t e = 0; e < ne; e++) fedge[fill[efac[e]]++] = (int32_t)e;
-    }
+    { const int32_t rc = factor_csr(h, W, err, "reference schedule"); if (rc != CX_OK) return rc; }
+    const std::vector<int32_t> &efac = W.efac, &foff = W.foff, &fedge = W.fedge;
     // pass 1: count; the segment-tree nodes get their numbers in creation order
     std::vector<Prod> prods;
     std::vector<int64_t> cnt;
@@ -175,10 +211,7 @@ int32_t build_wiring(const H *h, Wiring &W, std::string &err) {
     }
     W.prods = std::move(prods);
     W.dep_off.assign(W.nsig + 1, 0);
-    for (int64_t s = 0; s < W.nsig; s++) {
-        if (cnt[s + 1] > 255) return fail_(err, CX_ERR_UNSUPPORTED, "reference schedule: a signal with more than 255 dependencies");
-        W.dep_off[s + 1] = W.dep_off[s] + cnt[s + 1];
-    }
+    for (int64_t s = 0; s < W.nsig; s++) W.dep_off[s + 1] = W.dep_off[s] + cnt[s + 1];
     const int64_t nd = W.dep_off[W.nsig];
     W.dep.assign(nd, -1); W.dep_inter.assign(nd, 0); W.dep_weak.assign(nd, 0);
     {   // pass 2: fill
@@ -190,75 +223,190 @@ int32_t build_wiring(const H *h, Wiring &W, std::string &err) {
     }
     W.lis.assign(nd, -1); W.lis_idx.assign(nd, 0); W.lis_listen.assign(nd, 1);
     finish_wiring(W);
-    // messages the device cannot compute: out of a factor that has no rule here and other variables (the reference's processor would
-    // call the user's rule; an opaque factor has none — inference_engine.jl:358 error(...))
-    W.no_rule.assign(ne, 0);
+    // messages the device cannot compute: out of a factor that has no sum-product rule here and other variables (the reference's processor
+    // would call the user's rule; an opaque factor has none — inference_engine.jl:358 error(...); a CX_FACTOR_NORMAL_PRECISION factor has
+    // variational rules only, which the default wiring does not feed)
+    W.vrule.assign(ne, kRuleBP);
     for (int64_t e = 0; e < ne; e++) {
         const int32_t f = efac[e], deg = foff[f + 1] - foff[f];
-        if (deg >= 2 && h->fac_kind[f] == CX_FACTOR_OPAQUE) W.no_rule[e] = 1;
+        if (deg >= 2 && (h->fac_kind[f] == CX_FACTOR_OPAQUE || h->fac_kind[f] == CX_FACTOR_NORMAL_PRECISION)) W.vrule[e] = kRuleNone;
     }
     return CX_OK;
 }
 
 // ---- a user wiring (cx_graph_wire): the reference's add_dependency!(signal, dependency; weak, listen, intermediate), signal.jl:286-337,
-// call by call, in place of the default resolver's (a user resolver, dependencies.jl:1-15).  Signals: messages of both directions and
-// marginals; the RULES stay the sum-product ones, so a wiring may choose WHICH of a signal's natural inputs it waits for, in which order
-// and how (a filter that wires no backward messages, weak edges that use a stored value without waiting for a fresh one, ...):
-//   MessageToFactor(v, f)   depends on MessageToVariable(v, f'), f' != f        value = product of its dependency list
-//   IndividualMarginal(v)   depends on MessageToVariable(v, f')                 value = product of its dependency list
-//   MessageToVariable(v, f) depends on MessageToFactor(v', f), v' != v          value = the factor's rule on the stored messages of the
+// call by call, in place of the default resolver's (a user resolver, dependencies.jl:1-15).  Signals: messages of both directions,
+// marginals and the joint marginals of factors.  What a signal may depend on follows from what computes it on the device:
+//   MessageToFactor(v, f)   <- MessageToVariable(v, f'), f' != f                its value = the product of its dependency list
+//   IndividualMarginal(v)   <- MessageToVariable(v, f')                         its value = the product of its dependency list
+//   MessageToVariable(v, f) <- MessageToFactor(v', f), v' != v                  the factor's sum-product rule on the stored messages of the
 //                                                                               factor's other edges (all of them, listed or not)
-// flags: bit 0 weak, bit 1 intermediate, bit 2 "do not listen".  Self-dependencies are skipped as add_dependency! skips them;
-// a signal may not list a dependency twice.  sig / dep: signal numbers (Wiring::sig_*), in call order.
-constexpr int32_t kWireWeak = 1, kWireIntermediate = 2, kWireNoListen = 4;
+//   MessageToVariable / JointMarginal of a CX_FACTOR_NORMAL_PRECISION factor    the variational rules, chosen by the dependency list (kRule* above)
+// flags: bit 0 weak, bit 1 intermediate, bit 2 "do not listen"; bit 3: signal = IndividualMarginal(v), the dependency is ignored — the
+// DEFAULT resolver's resolve_variable_dependencies!(v) at this point of the call order (a user resolver that delegates the variable side,
+// test/inference_engine_tests.jl:812-814; it asks which MessageToFactor signals have listeners by now); bit 4: signal = JointMarginal(f),
+// dependency = IndividualMarginal(v): link_signal_to_variable!(v, signal) (model_engine.jl:64-71).  Self-dependencies are skipped as
+// add_dependency! skips them; a signal may not list a dependency twice.  sig / dep: signal numbers (Wiring::sig_*, joint marginals
+// numbered 2 ne + nv + f), in call order.
+constexpr int32_t kWireWeak = 1, kWireIntermediate = 2, kWireNoListen = 4, kWireDefaultVariable = 8, kWireLink = 16;
 
 template <class H>
 int32_t build_user_wiring(const H *h, int64_t n, const int64_t *sig, const int64_t *dep, const int32_t *flags, Wiring &W, std::string &err) {
-    const int64_t ne = h->ne, nv = h->nv;
+    const int64_t ne = h->ne, nv = h->nv, nf = h->nf;
     W = Wiring();
-    W.ne = ne; W.nv = nv; W.nsig = 2 * ne + nv; W.custom = true;
-    std::vector<int32_t> efac(ne);
-    for (int64_t e = 0; e < ne; e++) {
-        auto it = std::lower_bound(h->fac_ids.begin(), h->fac_ids.end(), h->edge_fac_id[e]);
-        if (it == h->fac_ids.end() || *it != h->edge_fac_id[e]) return fail_(err, CX_ERR_STATE, "cx_graph_wire: edge names an unknown factor");
-        efac[e] = (int32_t)(it - h->fac_ids.begin());
-    }
+    W.ne = ne; W.nv = nv; W.nj = nf; W.custom = true;
+    { const int32_t rc = factor_csr(h, W, err, "cx_graph_wire"); if (rc != CX_OK) return rc; }
+    const std::vector<int32_t> &efac = W.efac;
+    const int64_t n_named = 2 * ne + nv + nf;      // what a caller can name; the segment-tree nodes come after
     auto var_of = [&](int64_t s) -> int64_t { return s < ne ? h->edge_var[s] : (s < 2 * ne ? h->edge_var[s - ne] : s - 2 * ne); };
-    std::vector<int64_t> cnt(W.nsig + 1, 0);
     for (int64_t i = 0; i < n; i++) {
         const int64_t s = sig[i], d = dep[i];
-        if (s < 0 || s >= W.nsig || d < 0 || d >= W.nsig) return fail_(err, CX_ERR_INVALID_ARGUMENT, "cx_graph_wire: unknown signal");
-        if (s == d) continue;                                                    // signal.jl:295
-        if (s < ne || s >= 2 * ne) {                                             // MessageToFactor / marginal <- MessageToVariable of the same variable
-            if (!(d >= ne && d < 2 * ne) || var_of(d) != var_of(s) || (s < ne && d - ne == s))
-                return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_wire: a MessageToFactor / IndividualMarginal signal takes MessageToVariable signals of its own variable (other factors) as "
-                                                      "dependencies — its value is their product; other inputs would need a rule the device does not have");
-        } else {                                                                 // MessageToVariable <- MessageToFactor of the same factor, another variable
-            if (!(d < ne) || efac[d] != efac[s - ne] || d == s - ne)
-                return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_wire: a MessageToVariable signal takes MessageToFactor signals of its factor's other variables as dependencies");
+        if (s < 0 || s >= n_named) return fail_(err, CX_ERR_INVALID_ARGUMENT, "cx_graph_wire: unknown signal");
+        if (flags[i] & kWireDefaultVariable) {
+            if (!W.is_marg(s)) return fail_(err, CX_ERR_INVALID_ARGUMENT, "cx_graph_wire: CX_WIRE_DEFAULT_VARIABLE names the variable by its IndividualMarginal signal");
+            continue;
         }
-        cnt[s + 1]++;
+        if (d < 0 || d >= n_named) return fail_(err, CX_ERR_INVALID_ARGUMENT, "cx_graph_wire: unknown signal");
+        if (flags[i] & kWireLink) {
+            if (!W.is_marg(d)) return fail_(err, CX_ERR_INVALID_ARGUMENT, "cx_graph_wire: CX_WIRE_LINK names the variable by its IndividualMarginal signal");
+            continue;
+        }
     }
+    // the calls, replayed twice (count, fill): dependencies in call order, the default variable wiring where the caller asked for it
+    std::vector<int32_t> nlis;
+    std::vector<Prod> prods;
+    auto replay = [&](auto &&emit, std::vector<Prod> *pr) {
+        nlis.assign(n_named, 0);
+        int64_t next_prod = n_named;
+        auto counted = [&](int64_t s, int64_t d, int fl) { if (d < n_named) nlis[d]++; emit(s, d, fl); };
+        auto hl = [&](int64_t e) { return nlis[e] > 0; };
+        auto from_default = [&](int64_t s, int64_t d, int inter) { counted(s, d, inter ? kWireIntermediate : 0); };
+        VarWirer<H, decltype(from_default), decltype(hl)> vw(h, pr, &next_prod, from_default, hl);
+        for (int64_t i = 0; i < n; i++) {
+            if (flags[i] & kWireLink) continue;
+            if (flags[i] & kWireDefaultVariable) { vw.variable(sig[i] - 2 * ne); continue; }
+            if (sig[i] == dep[i]) continue;                                      // signal.jl:295
+            counted(sig[i], dep[i], flags[i]);
+        }
+        return next_prod;
+    };
+    std::vector<int64_t> cnt(n_named + 1, 0);
+    W.nsig = replay([&](int64_t s, int64_t, int) { if (s + 2 > (int64_t)cnt.size()) cnt.resize(s + 2, 0); cnt[s + 1]++; }, &prods);
+    if (W.nsig >= (int64_t)0x7fffffff) return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_wire: more than 2^31 signals");
+    cnt.resize(W.nsig + 1, 0);
+    W.prods = std::move(prods);
     W.dep_off.assign(W.nsig + 1, 0);
-    for (int64_t s = 0; s < W.nsig; s++) {
-        if (cnt[s + 1] > 255) return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_wire: a signal with more than 255 dependencies");
-        W.dep_off[s + 1] = W.dep_off[s] + cnt[s + 1];
-    }
+    for (int64_t s = 0; s < W.nsig; s++) W.dep_off[s + 1] = W.dep_off[s] + cnt[s + 1];
     const int64_t nd = W.dep_off[W.nsig];
     W.dep.assign(nd, -1); W.dep_inter.assign(nd, 0); W.dep_weak.assign(nd, 0);
     std::vector<uint8_t> listen(nd, 1);
-    std::vector<int64_t> fill(W.dep_off.begin(), W.dep_off.end() - 1);
-    for (int64_t i = 0; i < n; i++) {
-        const int64_t s = sig[i], d = dep[i];
-        if (s == d) continue;
-        for (int64_t p = W.dep_off[s]; p < fill[s]; p++)
-            if (W.dep[p] == d) return fail_(err, CX_ERR_INVALID_ARGUMENT, "cx_graph_wire: a signal lists a dependency twice");
-        const int64_t p = fill[s]++;
-        W.dep[p] = (int32_t)d;
-        W.dep_weak[p] = (flags[i] & kWireWeak) ? 1 : 0; W.dep_inter[p] = (flags[i] & kWireIntermediate) ? 1 : 0; listen[p] = (flags[i] & kWireNoListen) ? 0 : 1;
+    {
+        std::vector<int64_t> fill(W.dep_off.begin(), W.dep_off.end() - 1);
+        (void)replay([&](int64_t s, int64_t d, int fl) {
+            const int64_t p = fill[s]++;
+            W.dep[p] = (int32_t)d;
+            W.dep_weak[p] = (fl & kWireWeak) ? 1 : 0; W.dep_inter[p] = (fl & kWireIntermediate) ? 1 : 0; listen[p] = (fl & kWireNoListen) ? 0 : 1;
+        }, nullptr);
+    }
+    {   // a dependency listed twice: notify_listener! (signal.jl:339-356) would only ever refresh the first
+        std::vector<int32_t> tmp;
+        for (int64_t s = 0; s < W.nsig; s++) {
+            const int64_t lo = W.dep_off[s], hi = W.dep_off[s + 1];
+            if (hi - lo < 2) continue;
+            tmp.assign(W.dep.begin() + lo, W.dep.begin() + hi);
+            std::sort(tmp.begin(), tmp.end());
+            if (std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end()) return fail_(err, CX_ERR_INVALID_ARGUMENT, "cx_graph_wire: a signal lists a dependency twice");
+        }
     }
     W.lis.assign(nd, -1); W.lis_idx.assign(nd, 0); W.lis_listen.assign(nd, 1);
     finish_wiring(W, &listen);
+    {   // linked signals per variable, in link order
+        std::vector<int64_t> lc(nv + 1, 0);
+        bool any = false;
+        for (int64_t i = 0; i < n; i++) if (flags[i] & kWireLink) { lc[dep[i] - 2 * ne + 1]++; any = true; }
+        if (any) {
+            W.link_off.assign(nv + 1, 0);
+            for (int64_t v = 0; v < nv; v++) W.link_off[v + 1] = W.link_off[v] + lc[v + 1];
+            W.link.assign(W.link_off[nv], -1);
+            std::vector<int64_t> fill(W.link_off.begin(), W.link_off.end() - 1);
+            for (int64_t i = 0; i < n; i++) if (flags[i] & kWireLink) W.link[fill[dep[i] - 2 * ne]++] = (int32_t)sig[i];
+        }
+    }
+    // ---- what computes each signal: the dependency lists must be ones a device rule can serve -----------------------------------------
+    const bool np = !h->np_role.empty();
+    W.vrule.assign(ne, kRuleBP); W.jrule.assign(nf, 0);
+    for (int64_t s = 0; s < W.nsig; s++) {
+        const int64_t lo = W.dep_off[s], hi = W.dep_off[s + 1], nd_s = hi - lo;
+        if (W.is_v2f(s) || W.is_marg(s) || W.is_prod(s)) {
+            const int64_t v = W.is_prod(s) ? W.prods[s - W.sig_prod(0)].var : var_of(s);
+            for (int64_t p = lo; p < hi; p++) {
+                const int64_t d = W.dep[p];
+                const bool ok = (W.is_f2v(d) && var_of(d) == v && !(W.is_v2f(s) && d - ne == s)) || (W.is_prod(d) && W.prods[d - W.sig_prod(0)].var == v);
+                if (!ok) return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_wire: a MessageToFactor / IndividualMarginal signal takes MessageToVariable signals of its own variable (other factors) as "
+                                                               "dependencies — its value is their product; other inputs would need a rule the device does not have");
+            }
+            continue;
+        }
+        if (W.is_f2v(s)) {
+            const int64_t e = s - ne;
+            const int32_t f = efac[e], deg = W.foff[f + 1] - W.foff[f], kind = h->fac_kind[f];
+            if (kind != CX_FACTOR_NORMAL_PRECISION) {
+                for (int64_t p = lo; p < hi; p++) {
+                    const int64_t d = W.dep[p];
+                    if (!(W.is_v2f(d) && efac[d] == f && d != e))
+                        return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_wire: a MessageToVariable signal of a sum-product factor takes MessageToFactor signals of its factor's other variables as "
+                                                              "dependencies (messages that depend on marginals: the variational rules of CX_FACTOR_NORMAL_PRECISION factors)");
+                }
+                if (deg >= 2 && kind == CX_FACTOR_OPAQUE) W.vrule[e] = kRuleNone;
+                continue;
+            }
+            // out ~ N(in, 1 / precision): the two other edges of the factor, by role
+            W.vrule[e] = kRuleNone;
+            if (nd_s == 0) continue;
+            if (!np) return fail_(err, CX_ERR_STATE, "cx_graph_wire: a CX_FACTOR_NORMAL_PRECISION factor without edge roles");
+            const int role = h->np_role[e];
+            int64_t e_other = -1, e_other2 = -1, e_prec = -1;      // the Normal edges other than e (one, or two when e is the precision), the precision edge
+            for (int32_t k = W.foff[f]; k < W.foff[f + 1]; k++) {
+                const int32_t e2 = W.fedge[k];
+                if (e2 == e) continue;
+                if (h->np_role[e2] == CX_ROLE_PRECISION) e_prec = e2; else if (e_other < 0) e_other = e2; else e_other2 = e2;
+            }
+            auto has = [&](int64_t d) { for (int64_t p = lo; p < hi; p++) if (W.dep[p] == d) return true; return false; };
+            const std::string who = "cx_graph_wire: the message from factor " + std::to_string(h->edge_fac_id[e]) + " to variable " + std::to_string(h->var_ids[h->edge_var[e]]);
+            if (role != CX_ROLE_PRECISION) {
+                if (nd_s == 2 && has(W.sig_marg(h->edge_var[e_other])) && has(W.sig_marg(h->edge_var[e_prec]))) W.vrule[e] = kRuleMfNormal;
+                else if (nd_s == 2 && has(W.sig_v2f(e_other)) && has(W.sig_marg(h->edge_var[e_prec]))) W.vrule[e] = kRuleStNormal;
+                else return fail_(err, CX_ERR_UNSUPPORTED, who + ": a message to a Normal variable of a CX_FACTOR_NORMAL_PRECISION factor depends on the precision's marginal and on either the "
+                                                                 "other Normal variable's marginal (mean field) or its MessageToFactor (structured)");
+            } else {
+                if (nd_s == 2 && has(W.sig_marg(h->edge_var[e_other])) && has(W.sig_marg(h->edge_var[e_other2]))) W.vrule[e] = kRuleMfGamma;
+                else if (nd_s == 1 && has(W.sig_joint(f))) W.vrule[e] = kRuleStGamma;
+                else return fail_(err, CX_ERR_UNSUPPORTED, who + ": a message to the precision of a CX_FACTOR_NORMAL_PRECISION factor depends on the marginals of the factor's two Normal "
+                                                                 "variables (mean field) or on the factor's JointMarginal (structured)");
+            }
+            continue;
+        }
+        // JointMarginal(f)
+        if (nd_s == 0) continue;
+        const int64_t f = s - W.sig_joint(0);
+        int64_t e_a = -1, e_b = -1, e_prec = -1;
+        if (h->fac_kind[f] == CX_FACTOR_NORMAL_PRECISION && np)
+            for (int32_t k = W.foff[f]; k < W.foff[f + 1]; k++) {
+                const int32_t e2 = W.fedge[k];
+                if (h->np_role[e2] == CX_ROLE_PRECISION) e_prec = e2; else if (e_a < 0) e_a = e2; else e_b = e2;
+            }
+        bool ok = e_a >= 0 && e_b >= 0 && e_prec >= 0 && nd_s == 3;
+        if (ok) {
+            int seen = 0;
+            for (int64_t p = lo; p < hi; p++) seen |= W.dep[p] == W.sig_v2f(e_a) ? 1 : W.dep[p] == W.sig_v2f(e_b) ? 2 : W.dep[p] == W.sig_marg(h->edge_var[e_prec]) ? 4 : 8;
+            ok = seen == 7;
+        }
+        if (!ok) return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_wire: the JointMarginal of factor " + std::to_string(h->fac_ids[f]) + " must be that of a CX_FACTOR_NORMAL_PRECISION factor and depend on "
+                                                       "the two MessageToFactor signals of its Normal variables and on its precision's marginal (test/inference_engine_tests.jl:939-967)");
+        W.jrule[f] = 1;
+    }
+    // a linked signal must be one this wiring computes
+    for (int32_t ls : W.link) if (!W.is_joint(ls)) return fail_(err, CX_ERR_UNSUPPORTED, "cx_graph_wire: CX_WIRE_LINK links JointMarginal signals");
     {   // process_dependencies! (signal.jl:466-490) descends through intermediate dependencies without a visited set: a cycle of them is an
         // endless recursion in the reference (a stack overflow), so such a wiring is refused here.  Three-colour depth-first search.
         std::vector<uint8_t> colour(W.nsig, 0);
@@ -277,12 +425,6 @@ int32_t build_user_wiring(const H *h, int64_t n, const int64_t *sig, const int64
                 if (colour[d] == 0) { colour[d] = 1; stack.emplace_back(d, W.dep_off[d]); }
             }
         }
-    }
-    W.no_rule.assign(ne, 0);
-    {
-        std::vector<int32_t> fdeg(h->nf, 0);
-        for (int64_t e = 0; e < ne; e++) fdeg[efac[e]]++;
-        for (int64_t e = 0; e < ne; e++) if (fdeg[efac[e]] >= 2 && h->fac_kind[efac[e]] == CX_FACTOR_OPAQUE) W.no_rule[e] = 1;
     }
     return CX_OK;
 }
@@ -364,7 +506,7 @@ struct Runner {
     const Wiring &W; State &S; Call &out; int32_t round = 0; int32_t bad = -1;
     bool f(int64_t d) {                 // the closure of process_inference_request, inference_engine.jl:512-525
         if (!is_pending(W, S, d)) return false;
-        if (d >= W.ne && d < 2 * W.ne && W.no_rule[d - W.ne] && bad < 0) bad = (int32_t)d;
+        if (W.is_f2v(d) && W.vrule[d - W.ne] == kRuleNone && bad < 0) bad = (int32_t)d;
         out.order.push_back((int32_t)d); out.round_of.push_back(round);
         set_value(W, S, d);             // compute! = rule + set_value!, signal.jl:392-410
         return true;
@@ -388,10 +530,13 @@ struct Runner {
 // req: local variable numbers in request order.  Returns -1, or the MessageToVariable signal the device has no rule for.
 inline int32_t update_marginals(const Wiring &W, State &S, const int32_t *req, int64_t n, Call &out) {
     out = Call();
-    // request_inference_for, inference_engine.jl:298-323 (no linked signals under the default wiring)
+    // request_inference_for, inference_engine.jl:298-323: the dependencies of the marginal and the variable's linked signals become
+    // potentially pending
+    const bool links = !W.link_off.empty();
     for (int64_t i = 0; i < n; i++) {
         const int64_t m = W.sig_marg(req[i]);
         for (int64_t p = W.dep_off[m]; p < W.dep_off[m + 1]; p++) { const int64_t d = W.dep[p]; put_flags(S, d, (uint8_t)((S.flags[d] & kComputed) | kPot)); }
+        if (links) for (int64_t q = W.link_off[req[i]]; q < W.link_off[req[i] + 1]; q++) { const int64_t l = W.link[q]; put_flags(S, l, (uint8_t)((S.flags[l] & kComputed) | kPot)); }
     }
     std::vector<uint8_t> ready(n, 0);
     Runner R{W, S, out};
@@ -409,42 +554,64 @@ inline int32_t update_marginals(const Wiring &W, State &S, const int32_t *req, i
         reverse = !reverse;
         R.round++;
     }
+    // the final round, :610-628: per requested variable its marginal, then its linked signals, each if pending
     for (int64_t i = 0; i < n; i++) {
         const int64_t m = W.sig_marg(req[i]);
         if (is_pending(W, S, m)) { out.order.push_back((int32_t)m); out.round_of.push_back(R.round); set_value(W, S, m); }
+        if (links)
+            for (int64_t q = W.link_off[req[i]]; q < W.link_off[req[i] + 1]; q++) {
+                const int64_t l = W.link[q];
+                if (is_pending(W, S, l)) { out.order.push_back((int32_t)l); out.round_of.push_back(R.round); set_value(W, S, l); }
+            }
     }
     out.rounds = R.round + 1;
     return R.bad;
 }
 
 // ---- the recorded executions as stages of device items -------------------------------------------------------------------------------
-// internal item kinds of the reference plans (cx_kernels.hip: batch_item): the value is the SUM of a list of sources — the
+// internal item kinds of the reference plans (cx_kernels.hip: batch_item).  64-66, 72: the value is the SUM of a list of sources — the
 // dependencies in the reference's order, exactly what its rule call folds (`reduce(product, get_value.(deps))` in natural form) — for
-// the signals of variables of degree > 5, whose dependencies are segment-tree nodes: a list entry >= 0 is a factor→variable slot,
-// ~entry the index of a node in the product store.  rec = {kind, destination, variable, first list entry, entries}
-constexpr int32_t kItemSumToFactor = 64, kItemSumToProduct = 65, kItemSumToMarginal = 66;
+// the signals of variables of degree > 5, whose dependencies are segment-tree nodes, and for every product under a user wiring: a list
+// entry >= 0 is a factor→variable slot, ~entry the index of a node in the product store.  rec = {kind, destination, variable, first list
+// entry, entries}.  72: the marginal of a precision variable, stored as Gamma(shape, scale).  67-71: the variational rules (kRule*) of a
+// CX_FACTOR_NORMAL_PRECISION factor; list entries: marginal = local variable, message = slot, joint = index in the joint store
+//   67 {slot, variable, [marginal other, marginal precision]}     68 {slot, variable, [marginal a, marginal b]}
+//   69 {slot, variable, [message slot other, marginal precision]} 70 {joint index, -, [message slot a, message slot b, marginal precision]}   (a, b by ascending variable id)
+//   71 {slot, variable, [joint index]}
+constexpr int32_t kItemSumToFactor = 64, kItemSumToProduct = 65, kItemSumToMarginal = 66, kItemMfNormal = 67, kItemMfGamma = 68, kItemStNormal = 69,
+                  kItemVmpJoint = 70, kItemStGamma = 71, kItemSumToGammaMarginal = 72;
 
 struct Plan {
     std::vector<int32_t> rec;            // 5 per item, by stage
     std::vector<int64_t> stage_off;
     std::vector<int32_t> list;           // sources of the list items
-    int64_t n_exec = 0, n_messages = 0, n_marginals = 0, n_products = 0, rounds = 0;
+    int64_t n_exec = 0, n_messages = 0, n_marginals = 0, n_products = 0, n_joints = 0, rounds = 0;
 };
 
-// prod_slot(i): the index of segment-tree node i in the handle's product store (the caller registers the nodes)
-template <class H, class ProdSlot>
-int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slot, Plan &P, std::string &err) {
-    const int64_t ne = W.ne, nv = W.nv, n = (int64_t)call.order.size();
+// prod_slot(i): the index of segment-tree node i in the handle's product store; joint_slot(f): of factor f's joint marginal in the joint
+// store (the caller registers both)
+template <class H, class ProdSlot, class JointSlot>
+int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slot, JointSlot &&joint_slot, Plan &P, std::string &err) {
+    const int64_t ne = W.ne, n = (int64_t)call.order.size();
     P = Plan();
     P.n_exec = n; P.rounds = call.rounds;
     std::vector<int32_t> w_stage(W.nsig, 0), r_stage(W.nsig, 0), stage(n, 0);
     int32_t n_stages = 0;
+    // what an execution reads beyond its dependency list: a sum-product rule reads the stored messages of ALL the factor's other edges
+    auto unlisted_reads = [&](int64_t s, auto &&fn) {
+        if (!W.is_f2v(s) || W.vrule[s - ne] != kRuleBP) return;
+        const int32_t f = W.efac[s - ne];
+        if (W.foff[f + 1] - W.foff[f] <= 2 && !W.custom) return;      // (pairwise, default wiring: the other edge is the dependency)
+        for (int32_t k = W.foff[f]; k < W.foff[f + 1]; k++) if (W.fedge[k] != s - ne) fn((int64_t)W.fedge[k]);
+    };
     for (int64_t i = 0; i < n; i++) {
         const int64_t s = call.order[i];
         int32_t st = std::max(w_stage[s], r_stage[s]) + 1;
         for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) st = std::max(st, w_stage[W.dep[p]] + 1);
+        unlisted_reads(s, [&](int64_t d) { st = std::max(st, w_stage[d] + 1); });
         stage[i] = st; w_stage[s] = st;
         for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) r_stage[W.dep[p]] = std::max(r_stage[W.dep[p]], st);
+        unlisted_reads(s, [&](int64_t d) { r_stage[d] = std::max(r_stage[d], st); });
         n_stages = std::max(n_stages, st);
     }
     P.stage_off.assign(n_stages + 1, 0);
@@ -453,42 +620,69 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
     P.rec.assign(5 * n, 0);
     std::vector<int64_t> fill(P.stage_off.begin(), P.stage_off.end() - 1);
     auto source = [&](int64_t d) -> int32_t {       // a dependency of a list item as a list entry
-        if (d >= ne && d < 2 * ne) return flat::slot_of_edge_t(h, d - ne);
-        return ~(int32_t)prod_slot(d - 2 * ne - nv);
+        if (W.is_f2v(d)) return flat::slot_of_edge_t(h, d - ne);
+        return ~(int32_t)prod_slot(d - W.sig_prod(0));
     };
+    const bool gammas = !h->var_gamma.empty();
     for (int64_t i = 0; i < n; i++) {
         const int64_t s = call.order[i];
         int32_t *r = &P.rec[5 * fill[stage[i] - 1]++];
-        if (s < ne) {                                    // MessageToFactor
+        auto list_of_deps = [&]() {
+            r[3] = (int32_t)P.list.size(); r[4] = (int32_t)(W.dep_off[s + 1] - W.dep_off[s]);
+            for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) P.list.push_back(source(W.dep[p]));
+        };
+        if (W.is_v2f(s)) {                               // MessageToFactor
             const int32_t v = h->edge_var[s], deg = h->var_off[v + 1] - h->var_off[v], slot = flat::slot_of_edge_t(h, s);
             P.n_messages++;
             if (deg <= 5 && !W.custom) { r[0] = CX_ITEM_MESSAGE_TO_FACTOR; r[1] = slot; r[2] = v; }
-            else {
-                r[0] = kItemSumToFactor; r[1] = slot; r[2] = v; r[3] = (int32_t)P.list.size(); r[4] = (int32_t)(W.dep_off[s + 1] - W.dep_off[s]);
-                for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) P.list.push_back(source(W.dep[p]));
-            }
-        } else if (s < 2 * ne) {                         // MessageToVariable
+            else { r[0] = kItemSumToFactor; r[1] = slot; r[2] = v; list_of_deps(); }
+        } else if (W.is_f2v(s)) {                        // MessageToVariable
             const int64_t e = s - ne;
-            const int32_t slot = flat::slot_of_edge_t(h, e);
+            const int32_t slot = flat::slot_of_edge_t(h, e), v = h->edge_var[e];
+            const uint8_t rule = W.vrule[e];
             P.n_messages++;
-            if (!h->slot_kary.empty() && h->slot_kary[slot] >= 0) { r[0] = 32; r[1] = h->slot_kary[slot]; }      // kItemKaryEntry
-            else if (h->partner[slot] >= 0) { r[0] = CX_ITEM_MESSAGE_TO_VARIABLE; r[1] = slot; r[2] = h->edge_var[e]; }
-            else return fail_(err, CX_ERR_UNSUPPORTED, "reference schedule: the message from factor " + std::to_string(h->edge_fac_id[e]) + " to variable " +
-                                                           std::to_string(h->var_ids[h->edge_var[e]]) + " is pending, and the factor has no rule on the device "
-                                                           "(an opaque factor of two or more variables: the reference's processor would raise, inference_engine.jl:358)");
-        } else if (s < 2 * ne + nv) {                    // IndividualMarginal
-            const int32_t v = (int32_t)(s - 2 * ne), deg = h->var_off[v + 1] - h->var_off[v];
-            P.n_marginals++;
-            if (deg <= 5 && !W.custom) { r[0] = CX_ITEM_INDIVIDUAL_MARGINAL; r[1] = v; r[2] = v; }
-            else {
-                r[0] = kItemSumToMarginal; r[1] = v; r[2] = v; r[3] = (int32_t)P.list.size(); r[4] = (int32_t)(W.dep_off[s + 1] - W.dep_off[s]);
-                for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) P.list.push_back(source(W.dep[p]));
+            if (rule >= kRuleMfNormal) {
+                // the variational rules read exactly their dependencies; entries in a fixed order, whatever order the wiring listed them in
+                const int32_t f = W.efac[e];
+                int32_t e_other = -1, e_other2 = -1, e_prec = -1;
+                for (int32_t k = W.foff[f]; k < W.foff[f + 1]; k++) {
+                    const int32_t e2 = W.fedge[k];
+                    if (e2 == e) continue;
+                    if (h->np_role[e2] == CX_ROLE_PRECISION) e_prec = e2; else if (e_other < 0) e_other = e2; else e_other2 = e2;
+                }
+                r[1] = slot; r[2] = v; r[3] = (int32_t)P.list.size();
+                if (rule == kRuleMfNormal) { r[0] = kItemMfNormal; r[4] = 2; P.list.push_back(h->edge_var[e_other]); P.list.push_back(h->edge_var[e_prec]); }
+                else if (rule == kRuleMfGamma) { r[0] = kItemMfGamma; r[4] = 2; P.list.push_back(h->edge_var[e_other]); P.list.push_back(h->edge_var[e_other2]); }
+                else if (rule == kRuleStNormal) { r[0] = kItemStNormal; r[4] = 2; P.list.push_back(flat::slot_of_edge_t(h, e_other)); P.list.push_back(h->edge_var[e_prec]); }
+                else { r[0] = kItemStGamma; r[4] = 1; P.list.push_back((int32_t)joint_slot(f)); }
             }
+            else if (rule == kRuleBP && !h->slot_kary.empty() && h->slot_kary[slot] >= 0) { r[0] = 32; r[1] = h->slot_kary[slot]; }      // kItemKaryEntry
+            else if (rule == kRuleBP && h->partner[slot] >= 0) { r[0] = CX_ITEM_MESSAGE_TO_VARIABLE; r[1] = slot; r[2] = v; }
+            else return fail_(err, CX_ERR_UNSUPPORTED, "reference schedule: the message from factor " + std::to_string(h->edge_fac_id[e]) + " to variable " +
+                                                           std::to_string(h->var_ids[v]) + " is pending, and the factor has no rule on the device for it "
+                                                           "(an opaque factor of two or more variables: the reference's processor would raise, inference_engine.jl:358; "
+                                                           "a CX_FACTOR_NORMAL_PRECISION factor: wire its variational dependencies, cx_graph_wire)");
+        } else if (W.is_marg(s)) {                       // IndividualMarginal
+            const int32_t v = (int32_t)(s - 2 * ne), deg = h->var_off[v + 1] - h->var_off[v];
+            const bool gamma = gammas && h->var_gamma[v];
+            P.n_marginals++;
+            if (deg <= 5 && !W.custom && !gamma) { r[0] = CX_ITEM_INDIVIDUAL_MARGINAL; r[1] = v; r[2] = v; }
+            else { r[0] = gamma ? kItemSumToGammaMarginal : kItemSumToMarginal; r[1] = v; r[2] = v; list_of_deps(); }
+        } else if (W.is_joint(s)) {                      // JointMarginal of a NORMAL_PRECISION factor
+            const int64_t f = s - W.sig_joint(0);
+            if (!W.jrule[f]) return fail_(err, CX_ERR_UNSUPPORTED, "reference schedule: a JointMarginal without a rule is pending");
+            int32_t e_a = -1, e_b = -1, e_prec = -1;
+            for (int32_t k = W.foff[f]; k < W.foff[f + 1]; k++) {
+                const int32_t e2 = W.fedge[k];
+                if (h->np_role[e2] == CX_ROLE_PRECISION) e_prec = e2; else if (e_a < 0) e_a = e2; else e_b = e2;
+            }
+            P.n_joints++;
+            r[0] = kItemVmpJoint; r[1] = (int32_t)joint_slot(f); r[3] = (int32_t)P.list.size(); r[4] = 3;
+            P.list.push_back(flat::slot_of_edge_t(h, e_a)); P.list.push_back(flat::slot_of_edge_t(h, e_b)); P.list.push_back(h->edge_var[e_prec]);
         } else {                                         // ProductOfMessages
-            const int64_t pi = s - 2 * ne - nv;
+            const int64_t pi = s - W.sig_prod(0);
             P.n_products++;
-            r[0] = kItemSumToProduct; r[1] = (int32_t)prod_slot(pi); r[2] = W.prods[pi].var; r[3] = (int32_t)P.list.size(); r[4] = (int32_t)(W.dep_off[s + 1] - W.dep_off[s]);
-            for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) P.list.push_back(source(W.dep[p]));
+            r[0] = kItemSumToProduct; r[1] = (int32_t)prod_slot(pi); r[2] = W.prods[pi].var; list_of_deps();
         }
     }
     return CX_OK;

@@ -202,12 +202,21 @@ class DeviceGraph:
 
     def graph_wire(self, signals, dependencies, flags):
         """cx_graph_wire: add_dependency!(signal, dependency; flags) triple by triple; a signal is (kind, variable_id, factor_id)"""
-        n = len(signals)
-        sig, dep = (L.Item * max(n, 1))(), (L.Item * max(n, 1))()
-        for i, ((k, v, f), (k2, v2, f2)) in enumerate(zip(signals, dependencies)):
-            sig[i] = L.Item(int(k), 0, int(v), int(f)); dep[i] = L.Item(int(k2), 0, int(v2), int(f2))
+        item = np.dtype([("kind", "<i4"), ("reserved", "<i4"), ("variable_id", "<i8"), ("factor_id", "<i8")])      # cx_item
+        assert item.itemsize == C.sizeof(L.Item)
+
+        def items(rows):
+            rows = np.asarray(rows, dtype=np.int64).reshape(-1, 3)
+            out = np.zeros(max(len(rows), 1), dtype=item)
+            out["kind"][:len(rows)] = rows[:, 0]; out["variable_id"][:len(rows)] = rows[:, 1]; out["factor_id"][:len(rows)] = rows[:, 2]
+            return out
+
+        sig, dep = items(signals), items(dependencies)
         fl = np.ascontiguousarray(flags, dtype=np.int32)
-        self._check(self.lib.cx_graph_wire(self.h, n, sig, dep, _p(fl, C.c_int32) if n else None))
+        n = len(fl)
+        if len(np.asarray(signals).reshape(-1, 3)) != n or len(np.asarray(dependencies).reshape(-1, 3)) != n:
+            raise ValueError("graph_wire: signals, dependencies and flags must have one row per triple")
+        self._check(self.lib.cx_graph_wire(self.h, n, sig.ctypes.data_as(C.POINTER(L.Item)), dep.ctypes.data_as(C.POINTER(L.Item)), _p(fl, C.c_int32) if n else None))
 
     def ref_plan_stats(self) -> dict:
         out = (C.c_int64 * 8)()

@@ -88,9 +88,10 @@ extern "C" {
 #define CX_FACTOR_GAUSS_ADDITIVE 1  /* 2 edges: x_b = x_a + N(0, q)            params = {q}                */
 #define CX_FACTOR_GAUSS_LINEAR 2    /* 2 edges: x_out = a*x_in + b + N(0, q)   params = {q, a, b}          */
                                     /* dim>1:   x_out = A x_in + N(0, Q)       params via cx_set_factor_matrices */
-#define CX_FACTOR_NORMAL_PRECISION 3 /* 3 edges (variational families): x_out ~ N(x_in, 1 / precision); roles OUT, IN,
-                                       PRECISION — the :likelihood and :transition factors of
-                                       test/inference_engine_tests.jl:691-715 */
+#define CX_FACTOR_NORMAL_PRECISION 3 /* 3 edges: x_out ~ N(x_in, 1 / precision); roles OUT, IN, PRECISION — the :likelihood and
+                                       :transition factors of test/inference_engine_tests.jl:691-715.  Variational rules only: the
+                                       CX_FAMILY_VMP_* families, or CX_FAMILY_GAUSSIAN under CX_SCHED_REFERENCE with a user wiring
+                                       (cx_graph_wire, ABI 3) */
 #define CX_FACTOR_BERNOULLI 4        /* CX_FAMILY_NATURAL2, 2 edges: one variable carries an observed Bool r (a CX_FORM_POINT datum),
                                        the message to the other is Beta(1 + r, 2 - r) = natural (r, 1 - r): the :bernoulli
                                        factor of test/inference_engine_tests.jl:250-262.  Without a datum the reference's rule
@@ -265,7 +266,10 @@ int32_t cx_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
  *                       updated before, every precision of a transition factor (degree > 5) precedes the first state in the list and
  *                       every other requested precision was updated since the states last were; CX_ERR_UNSUPPORTED otherwise (the
  *                       reference then interleaves per variable).  Asynchronous on the handle's stream.
- * cx_get_marginals    : (mean, precision) for Normal variables ((datum, +inf) when observed), (shape, scale) for precisions. */
+ * cx_get_marginals    : (mean, precision) for Normal variables ((datum, +inf) when observed), (shape, scale) for precisions.
+ * cx_set_marginals also serves CX_SCHED_REFERENCE handles (dim 1) whose wiring makes messages depend on marginals (cx_graph_wire): the
+ * same forms; there cx_get_marginals returns (mean, variance) for Normal variables — the Gaussian family's form — and (shape, scale) for
+ * precisions. */
 #define CX_VMP_ALL_NORMAL (-1)
 #define CX_VMP_ALL_PRECISION (-2)
 int32_t cx_set_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, int32_t form, const double *payload);
@@ -311,16 +315,38 @@ int32_t cx_sweep_for(cx_handle *h, int64_t n, const int64_t *variable_ids);
 /* CX_SCHED_REFERENCE: a user resolver's dependency wiring in place of DefaultDependencyResolver's (src/dependencies.jl:1-15): the i-th triple is
  * add_dependency!(signals[i], dependencies[i]; weak, intermediate, listen) (src/signal.jl:286-337), in call order (= dependency order per
  * signal).  Signals are named like batch items: CX_ITEM_MESSAGE_TO_FACTOR / CX_ITEM_MESSAGE_TO_VARIABLE (variable_id, factor_id),
- * CX_ITEM_INDIVIDUAL_MARGINAL (variable_id).  The RULES stay the sum-product ones, so a wiring chooses which of a signal's natural inputs it
- * waits for, in which order and how: a MessageToFactor / IndividualMarginal depends on MessageToVariable signals of its own variable (its
- * value is the product of exactly its dependency list, in list order), a MessageToVariable on MessageToFactor signals of its factor's other
- * variables (its value is the factor's rule on the stored messages of the factor's other edges).  Anything else — a message that depends on
- * a marginal, as the variational resolvers of test/inference_engine_tests.jl:597-629 wire — needs a rule the device does not have:
- * CX_ERR_UNSUPPORTED (the two variational families exist as fused calls: cx_update_marginals).  Replaces the whole wiring (n == 0: none);
- * allowed until the first value is set or the first call runs, as the reference wires at engine construction. */
+ * CX_ITEM_INDIVIDUAL_MARGINAL (variable_id), CX_ITEM_JOINT_MARGINAL (factor_id).  The scheduler runs on whatever is wired; the VALUES come
+ * from the device's rules, so a dependency list must be one a rule can serve:
+ *   - a MessageToFactor / IndividualMarginal depends on MessageToVariable signals of its own variable: its value is the product of exactly
+ *     its dependency list, in list order (a dropped dependency is left out of the product);
+ *   - a MessageToVariable of a sum-product factor (additive, linear, linear-N) depends on MessageToFactor signals of its factor's other
+ *     variables: its value is the factor's rule on the stored messages of the factor's other edges;
+ *   - the messages of a CX_FACTOR_NORMAL_PRECISION factor (out ~ N(in, 1 / precision), precision Gamma-distributed) depend on MARGINALS — the
+ *     variational rules of the reference's test processors (test/inference_engine_tests.jl:647-689, 939-1030), chosen by the dependency list as
+ *     those rules choose:   to out / in     <- marginal(in / out), marginal(precision)              N(E[other], E[precision])
+ *                           to precision    <- marginal(out), marginal(in)                          Gamma(3/2, 2 / (var out + var in + (E out - E in)^2))
+ *                           to out / in     <- MessageToFactor(in / out), marginal(precision)       N(mean m, 1 / (var m + 1 / E[precision]))
+ *                           JointMarginal   <- MessageToFactor(out), MessageToFactor(in), marginal(precision)    the 2-d Gaussian of :939-967
+ *                           to precision    <- JointMarginal(factor)                                Gamma(3/2, 2 / (V11 - 2 V12 + V22 + (m1 - m2)^2))
+ *     Such factors exist under this schedule only.  A variable on a CX_ROLE_PRECISION edge is Gamma-distributed everywhere: its messages are the
+ *     natural pairs (shape - 1, rate) (CX_FORM_NATURAL; a prior is an opaque factor's message), its marginal is kept and returned as
+ *     (shape, scale); Normal variables as (mean, variance).  Initial marginals and data: cx_set_marginals (CX_FORM_GAMMA; CX_FORM_MOMENT /
+ *     CX_FORM_MEAN_PRECISION; CX_FORM_POINT = an observed value, variance 0), the user's set_value! on the marginal signal.
+ * Anything else is CX_ERR_UNSUPPORTED, as are intermediate flags that close a cycle (process_dependencies! would never return) and a
+ * dependency listed twice.  Two flags stand for calls other than add_dependency!:
+ *   CX_WIRE_DEFAULT_VARIABLE  signals[i] = IndividualMarginal(v), dependencies[i] ignored: resolve_variable_dependencies!(
+ *                             DefaultDependencyResolver(), engine, v) at this point of the call order (src/dependencies.jl:33-126: all-pairs up to
+ *                             degree 5, a segment tree of ProductOfMessages above; a MessageToFactor is wired only if something listens to it by now)
+ *   CX_WIRE_LINK              signals[i] = JointMarginal(f), dependencies[i] = IndividualMarginal(v): link_signal_to_variable!(v, signal)
+ *                             (src/model_engine.jl:64-71): requested and computed with v's marginal (src/inference_engine.jl:313-315, 617-625)
+ * Replaces the whole wiring (n == 0: none); allowed until the first value is set or the first call runs, as the reference wires at engine
+ * construction.  The two fused families (cx_update_marginals) remain the fast path for the reference's two test models; this entry point runs
+ * them, and any other wiring of these rules on any graph, call by call as the reference's scheduler would — mixed requests included. */
 #define CX_WIRE_WEAK 1          /* add_dependency!(...; weak = true): the dependency need only be computed, not fresh (src/signal.jl:36-45) */
 #define CX_WIRE_INTERMEDIATE 2  /* intermediate = true: process_dependencies! descends through it (src/signal.jl:466-490) */
 #define CX_WIRE_NO_LISTEN 4     /* listen = false: the dependency's set_value! does not make the signal potentially pending */
+#define CX_WIRE_DEFAULT_VARIABLE 8
+#define CX_WIRE_LINK 16
 int32_t cx_graph_wire(cx_handle *h, int64_t n, const cx_item *signals, const cx_item *dependencies, const int32_t *flags);
 /* the plan the last reference-order call replayed: out8 = { stages, kernel launches, executions (signals computed), of which messages,
  * passes of the reference's loop (the final marginal round included), plans kept, calls that replayed a kept plan, calls that had to

@@ -119,6 +119,8 @@ class FlatGraph:
             L.cxh_ref_wire.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int32]
             L.cxh_ref_set.restype = C.c_int32
             L.cxh_ref_set.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
+            L.cxh_ref_set_marginals.restype = C.c_int32
+            L.cxh_ref_set_marginals.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
             L.cxh_ref_update.restype = C.c_int64
             L.cxh_ref_update.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
             L.cxh_ref_trace.argtypes = [C.c_void_p, C.c_void_p]
@@ -198,6 +200,11 @@ class FlatGraph:
     def ref_set(self, direction, variable_ids, factor_ids):
         v = np.ascontiguousarray(variable_ids, dtype=np.int64); f = np.ascontiguousarray(factor_ids, dtype=np.int64)
         rc = int(self.L.cxh_ref_set(self.p, int(direction), len(v), v.ctypes.data, f.ctypes.data))
+        assert rc == 0, rc
+
+    def ref_set_marginals(self, variable_ids):
+        v = np.ascontiguousarray(variable_ids, dtype=np.int64)
+        rc = int(self.L.cxh_ref_set_marginals(self.p, len(v), v.ctypes.data))
         assert rc == 0, rc
 
     def ref_update(self, variable_ids):
