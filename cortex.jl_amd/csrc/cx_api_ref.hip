@@ -16,9 +16,9 @@ namespace {
 
 struct PlanEntry {
     uint64_t key = 0, req_key = 0;
-    int32_t *d_rec = nullptr, *d_list = nullptr;
+    int32_t *d_rec = nullptr, *d_list = nullptr, *d_wide_rec = nullptr;
     int64_t *d_stage_off = nullptr;
-    std::vector<int64_t> stage_off;
+    std::vector<int64_t> stage_off, wide_off;
     hipGraphExec_t exec = nullptr;
     bool graph_failed = false;
     std::shared_ptr<const rs::State> post;      // the readiness state the call leaves
@@ -46,8 +46,8 @@ RefSched *ref_of(cx_handle *h) { return (RefSched *)h->ref; }
 
 void entry_free(cx_handle *h, PlanEntry &e) {
     if (e.exec) { (void)hipGraphExecDestroy(e.exec); e.exec = nullptr; }
-    for (void *p : {(void *)e.d_rec, (void *)e.d_list, (void *)e.d_stage_off}) if (p) (void)hipFree(p);
-    e.d_rec = e.d_list = nullptr; e.d_stage_off = nullptr;
+    for (void *p : {(void *)e.d_rec, (void *)e.d_list, (void *)e.d_stage_off, (void *)e.d_wide_rec}) if (p) (void)hipFree(p);
+    e.d_rec = e.d_list = e.d_wide_rec = nullptr; e.d_stage_off = nullptr;
     h->device_bytes -= e.device_bytes; e.device_bytes = 0;
 }
 
@@ -63,12 +63,14 @@ int64_t issue(cx_handle *h, RefSched *R, const PlanEntry &e, bool count_only) {
     const size_t ns = e.stage_off.empty() ? 0 : e.stage_off.size() - 1;
     int64_t launches = 0;
     if (!count_only) h->d_ref_list = e.d_list;
+    auto wide_at = [&](size_t s) { return e.wide_off.empty() ? (int64_t)0 : e.wide_off[s + 1] - e.wide_off[s]; };
     for (size_t s = 0; s < ns;) {
         size_t t = s;
-        while (t < ns && e.stage_off[t + 1] - e.stage_off[t] <= R->run_max) t++;
+        while (t < ns && e.stage_off[t + 1] - e.stage_off[t] <= R->run_max && wide_at(t) == 0) t++;
         if (t >= s + 2) { if (!count_only) cx::launch_batch_run(h, e.d_rec, e.d_stage_off, (int)s, (int)t); launches++; s = t; continue; }
-        const int64_t n = e.stage_off[s + 1] - e.stage_off[s];
+        const int64_t n = e.stage_off[s + 1] - e.stage_off[s], nw = wide_at(s);
         if (n > 0) { if (!count_only) cx::launch_batch(h, e.d_rec + 5 * e.stage_off[s], n); launches++; }
+        if (nw > 0) { if (!count_only) cx::launch_wide_sum(h, e.d_wide_rec + 5 * e.wide_off[s], nw); launches++; }      // (independent of the stage's other items)
         s++;
     }
     return launches;
@@ -265,7 +267,7 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n) {
             std::string err;
             const int32_t rc = rs::level(h, R->W, call, [&](int64_t i) { return R->prod_slot[i]; }, [&](int64_t f) { return R->joint_slot[f]; }, P, err);
             if (rc != CX_OK) return fail(h, rc, err);
-            const int64_t incoming = (int64_t)(P.rec.size() + P.list.size()) * 4 + (int64_t)P.stage_off.size() * 8;
+            const int64_t incoming = (int64_t)(P.rec.size() + P.list.size() + P.wide_rec.size()) * 4 + (int64_t)P.stage_off.size() * 8;
             auto kept_bytes = [&] { int64_t b = 0; for (auto &c : R->cache) b += c.device_bytes; return b; };
             while (!R->cache.empty() && ((int)R->cache.size() >= R->max_entries || kept_bytes() + incoming > R->max_bytes)) {      // least recently used out
                 size_t lru = 0;
@@ -276,11 +278,12 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n) {
             }
             PlanEntry e;
             e.key = key; e.req_key = rk;
-            e.stage_off = P.stage_off;
+            e.stage_off = P.stage_off; e.wide_off = P.wide_off;
             e.n_messages = P.n_messages; e.n_marginals = P.n_marginals; e.n_products = P.n_products; e.rounds = P.rounds; e.list_entries = (int64_t)P.list.size();
             const int64_t before = h->device_bytes;
             int32_t rc2;
-            if ((rc2 = dev_upload(h, &e.d_rec, P.rec)) != CX_OK || (rc2 = dev_upload(h, &e.d_list, P.list)) != CX_OK || (rc2 = dev_upload(h, &e.d_stage_off, P.stage_off)) != CX_OK) {
+            if ((rc2 = dev_upload(h, &e.d_rec, P.rec)) != CX_OK || (rc2 = dev_upload(h, &e.d_list, P.list)) != CX_OK || (rc2 = dev_upload(h, &e.d_stage_off, P.stage_off)) != CX_OK ||
+                (rc2 = dev_upload(h, &e.d_wide_rec, P.wide_rec)) != CX_OK) {
                 e.device_bytes = h->device_bytes - before; entry_free(h, e); return rc2;
             }
             e.device_bytes = h->device_bytes - before;

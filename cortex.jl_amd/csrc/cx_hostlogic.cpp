@@ -276,7 +276,8 @@ int32_t cxh_ref_level(void *p, char *err, int32_t errlen) {
     HostGraph *g = (HostGraph *)p;
     std::string e;
     int32_t rc;
-    try { rc = cx::refsched::level(g, g->rw, g->rcall, [](int64_t i) { return i; }, [](int64_t f) { return f; }, g->rplan, e); }
+    const char *wl = std::getenv("CXH_REF_WIDE_LIST");      // (tests: a low threshold sends small lists down the wide path)
+    try { rc = cx::refsched::level(g, g->rw, g->rcall, [](int64_t i) { return i; }, [](int64_t f) { return f; }, g->rplan, e, wl ? std::atoll(wl) : cx::refsched::kWideList); }
     catch (const std::exception &x) { rc = CX_ERR_INVALID_ARGUMENT; e = x.what(); }
     if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", e.c_str());
     return rc;
@@ -341,6 +342,7 @@ int64_t cxh_flat_array(const void *p, int32_t which, void *out) {
     case 82: return ints(g->hp.head_bwd); case 83: return ints(g->hp.pos_off); case 84: return ints(g->hp.link_off); case 85: return ints(g->hp.steps);
     case 90: return ints(g->rplan.rec); case 91: return ints(g->rplan.stage_off); case 92: return ints(g->rplan.list); case 93: return ints(g->rw.dep_off); case 94: return ints(g->rw.dep);
     case 95: return ints(g->rw.dep_inter); case 96: return ints(g->rs.flags); case 97: return ints(g->rcall.order);
+    case 98: return ints(g->rplan.wide_rec); case 99: return ints(g->rplan.wide_off);
     }
     return -1;
 }

@@ -522,6 +522,28 @@ __global__ __launch_bounds__(kRunBlock) void k_batch_run(const int64_t *__restri
     }
 }
 
+// A list item of thousands of sources (cx_refsched.h: kWideList — the flat product a mean-field wiring makes of a precision's marginal):
+// one workgroup per item, a strided partial sum per thread, the partials folded in a fixed tree (wavefront shuffles, then shared memory):
+// deterministic, and a different association than the reference's left fold — a rounding-level difference.
+__global__ __launch_bounds__(1024) void k_wide_sum(const int32_t *__restrict__ rec, const int32_t *__restrict__ list, const double2 *__restrict__ f2v,
+                                                   double2 *__restrict__ v2f, double2 *__restrict__ marg, int nat_marg, double2 *__restrict__ prod) {
+    __shared__ double2 part[16];
+    const int32_t *r = rec + 5 * (int64_t)blockIdx.x;
+    const int k = r[0], idx = r[1], v = r[2], lo = r[3], hi = r[4];
+    double2 acc = zero2();
+    for (int j = threadIdx.x; j < hi; j += 1024) { const int s = list[lo + j]; acc = add2(acc, s >= 0 ? f2v[s] : prod[~s]); }
+    for (int off = 32; off > 0; off >>= 1) { acc.x += __shfl_down(acc.x, off, 64); acc.y += __shfl_down(acc.y, off, 64); }
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double2 t = part[0];
+        for (int w = 1; w < 16; w++) t = add2(t, part[w]);
+        if (k == kItemSumToMarginal) marg[v] = nat_marg ? t : to_moment(t);
+        else if (k == kItemSumToGammaMarginal) marg[v] = make_double2(t.x + 1.0, 1.0 / t.y);
+        else if (!__builtin_isnan(t.y)) { if (k == kItemSumToFactor) v2f[idx] = t; else prod[idx] = t; }
+    }
+}
+
 // A batch of at most kSmallBatch items travels IN the kernel arguments: no staging copy, nothing for the host to wait for before
 // it reuses its buffer — the launch is all a per-signal `process!` or a wavefront of a few signals costs.  The records are the
 // first parameter, i.e. the start of the kernarg segment, which every thread reads like any other constant memory.
@@ -789,6 +811,12 @@ void launch_batch_run(cx_handle *h, const int32_t *d_rec, const int64_t *d_stage
     else if (mode == kRuleBernoulli) CX_B(kRuleBernoulli, (const double *)nullptr, (const double *)nullptr);
     else CX_B(kRuleAdditive, (const double *)nullptr, (const double *)nullptr);
 #undef CX_B
+}
+
+void launch_wide_sum(cx_handle *h, const int32_t *d_rec, int64_t n) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_wide_sum, dim3((unsigned)n), dim3(1024), 0, h->stream, d_rec, h->d_ref_list, h->d_f2v, h->d_v2f, h->d_marg,
+                       h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0, h->d_prod);
 }
 
 void launch_batch_small(cx_handle *h, const SmallBatch &recs, int n) {

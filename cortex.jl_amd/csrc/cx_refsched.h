@@ -581,9 +581,15 @@ inline int32_t update_marginals(const Wiring &W, State &S, const int32_t *req, i
 constexpr int32_t kItemSumToFactor = 64, kItemSumToProduct = 65, kItemSumToMarginal = 66, kItemMfNormal = 67, kItemMfGamma = 68, kItemStNormal = 69,
                   kItemVmpJoint = 70, kItemStGamma = 71, kItemSumToGammaMarginal = 72;
 
+// a list item of more than kWideList sources (a flat product over a hub's messages: the marginal of a precision under a mean-field wiring
+// lists every factor) leaves the stage's thread-per-item launch: one workgroup sums it (cx_kernels.hip: k_wide_sum)
+constexpr int64_t kWideList = 1024;
+
 struct Plan {
     std::vector<int32_t> rec;            // 5 per item, by stage
     std::vector<int64_t> stage_off;
+    std::vector<int32_t> wide_rec;       // the wide list items, 5 per item, by stage
+    std::vector<int64_t> wide_off;       // [stages + 1]
     std::vector<int32_t> list;           // sources of the list items
     int64_t n_exec = 0, n_messages = 0, n_marginals = 0, n_products = 0, n_joints = 0, rounds = 0;
 };
@@ -591,7 +597,7 @@ struct Plan {
 // prod_slot(i): the index of segment-tree node i in the handle's product store; joint_slot(f): of factor f's joint marginal in the joint
 // store (the caller registers both)
 template <class H, class ProdSlot, class JointSlot>
-int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slot, JointSlot &&joint_slot, Plan &P, std::string &err) {
+int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slot, JointSlot &&joint_slot, Plan &P, std::string &err, int64_t wide_list = kWideList) {
     const int64_t ne = W.ne, n = (int64_t)call.order.size();
     P = Plan();
     P.n_exec = n; P.rounds = call.rounds;
@@ -614,11 +620,14 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
         unlisted_reads(s, [&](int64_t d) { r_stage[d] = std::max(r_stage[d], st); });
         n_stages = std::max(n_stages, st);
     }
-    P.stage_off.assign(n_stages + 1, 0);
-    for (int64_t i = 0; i < n; i++) P.stage_off[stage[i]]++;
-    for (int32_t s = 0; s < n_stages; s++) P.stage_off[s + 1] += P.stage_off[s];
-    P.rec.assign(5 * n, 0);
-    std::vector<int64_t> fill(P.stage_off.begin(), P.stage_off.end() - 1);
+    // (only products — MessageToFactor, marginals, segment-tree nodes — can be wide: the rules read at most three sources)
+    auto is_wide = [&](int64_t s) { return !W.is_f2v(s) && !W.is_joint(s) && W.dep_off[s + 1] - W.dep_off[s] > wide_list; };
+    P.stage_off.assign(n_stages + 1, 0); P.wide_off.assign(n_stages + 1, 0);
+    int64_t n_wide = 0;
+    for (int64_t i = 0; i < n; i++) { if (is_wide(call.order[i])) { P.wide_off[stage[i]]++; n_wide++; } else P.stage_off[stage[i]]++; }
+    for (int32_t s = 0; s < n_stages; s++) { P.stage_off[s + 1] += P.stage_off[s]; P.wide_off[s + 1] += P.wide_off[s]; }
+    P.rec.assign(5 * (n - n_wide), 0); P.wide_rec.assign(5 * n_wide, 0);
+    std::vector<int64_t> fill(P.stage_off.begin(), P.stage_off.end() - 1), wfill(P.wide_off.begin(), P.wide_off.end() - 1);
     auto source = [&](int64_t d) -> int32_t {       // a dependency of a list item as a list entry
         if (W.is_f2v(d)) return flat::slot_of_edge_t(h, d - ne);
         return ~(int32_t)prod_slot(d - W.sig_prod(0));
@@ -626,7 +635,7 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
     const bool gammas = !h->var_gamma.empty();
     for (int64_t i = 0; i < n; i++) {
         const int64_t s = call.order[i];
-        int32_t *r = &P.rec[5 * fill[stage[i] - 1]++];
+        int32_t *r = is_wide(s) ? &P.wide_rec[5 * wfill[stage[i] - 1]++] : &P.rec[5 * fill[stage[i] - 1]++];
         auto list_of_deps = [&]() {
             r[3] = (int32_t)P.list.size(); r[4] = (int32_t)(W.dep_off[s + 1] - W.dep_off[s]);
             for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) P.list.push_back(source(W.dep[p]));

@@ -163,7 +163,7 @@ function upload!(p::HipVmpProcessor, engine::Cortex.InferenceEngine, role_of)
 end
 
 # where the tests call set_value!(get_variable_marginal(...), value): form 1 = datum, 3 = (mean, precision), 4 = Gamma(shape, scale)
-function set_marginal!(p::HipVmpProcessor, variable_id, form, payload::Vector{Float64})
+function set_marginal!(p, variable_id, form, payload::Vector{Float64})      # HipVmpProcessor, or a HipProcessor of schedule 4 with a wiring whose messages depend on marginals
     check(p.handle, ccall((:cx_set_marginals, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}, Int32, Ptr{Float64}),
                           p.handle, 1, Int64[variable_id], form, payload))
 end
@@ -193,11 +193,13 @@ set_factor_coefficients!(p, variable_ids::Vector{Int64}, factor_ids::Vector{Int6
     check(p.handle, ccall((:cx_set_factor_coefficients, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}),
                           p.handle, length(a), variable_ids, factor_ids, a))
 
-# the plan of the dim 64 chain-scan schedule: (links per block, fan, levels, potentials, compositions, rules, launches, device bytes)
 # schedule 4: a user resolver's wiring instead of the default one — one (signal, dependency, flags) triple per
-# add_dependency!(signal, dependency; weak, intermediate, listen) the resolver would issue (flags: 1 weak, 2 intermediate, 4 listen = false);
-# signals as CxItem (kind 1 MessageToFactor / 2 MessageToVariable with (variable_id, factor_id); 4 IndividualMarginal with variable_id).
-# Right after upload!, before any value is set.
+# add_dependency!(signal, dependency; weak, intermediate, listen) the resolver would issue (flags: 1 weak, 2 intermediate, 4 listen = false;
+# 8: signal = IndividualMarginal(v), run DefaultDependencyResolver's resolve_variable_dependencies!(v) here; 16: signal = JointMarginal(f),
+# dependency = IndividualMarginal(v): link_signal_to_variable!(v, signal)).  Signals as CxItem: kind 1 MessageToFactor / 2 MessageToVariable
+# with (variable_id, factor_id); 4 IndividualMarginal with variable_id; 16 JointMarginal with factor_id.  Messages that depend on marginals
+# are served for CX_FACTOR_NORMAL_PRECISION (= 3) factors: the rules of test/inference_engine_tests.jl:647-689, 939-1030; the initial
+# marginals and the data then go through cx_set_marginals (set_marginal! below takes any handle: pass the HipProcessor's).  Right after upload!, before any value is set.
 wire!(p::HipProcessor, signals::Vector{CxItem}, dependencies::Vector{CxItem}, flags::Vector{Int32}) =
     check(p.handle, ccall((:cx_graph_wire, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{CxItem}, Ptr{CxItem}, Ptr{Int32}), p.handle, length(flags), signals, dependencies, flags))
 
@@ -234,6 +236,7 @@ function tree_heavy_path_stats(p)      # light depths, paths, variables on no pa
     return out
 end
 
+# the plan of the dim 64 chain-scan schedule: (links per block, fan, levels, potentials, compositions, rules, launches, device bytes)
 function chain_plan_stats(p)
     out = zeros(Int64, 8)
     check(p.handle, ccall((:cx_chain_plan_stats, lib), Int32, (Ptr{Cvoid}, Ptr{Int64}), p.handle, out))

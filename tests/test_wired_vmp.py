@@ -57,6 +57,18 @@ def test_mean_field_wiring_call_by_call(n):
     assert sum(len(r) for _i, r, _m in got) > 0
 
 
+def test_long_dependency_lists_leave_the_thread_per_item_launch(monkeypatch):
+    """a list item of more sources than cx_refsched.h: kWideList is summed by a workgroup of its own (k_wide_sum): here with the threshold
+    lowered to 8, so that the flat marginals of the two precisions (19 / 20 messages) take that path — same executions, same values"""
+    monkeypatch.setenv("CXH_REF_WIDE_LIST", "8")
+    data = vs.dataset(20, seed=7)
+    _, want = _run(ws.TracedOracleBackend(vs.mean_field_rule), "mean_field", data, 2)
+    be = ws.ShadowBackend()
+    _, got = _run(be, "mean_field", data, 2)
+    _compare(got, want, 1e-11, "mean field n=20, wide lists")
+    assert be.last_wide > 0
+
+
 @pytest.mark.parametrize("n", [4, 5, 7, 12, 33])
 def test_structured_wiring_call_by_call_with_the_mixed_request(n):
     """StructuredResolver (:816-897): the default variable wiring (segment trees above degree 5: n - 1 > 5), mean-field likelihoods, joint

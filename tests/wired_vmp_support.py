@@ -186,16 +186,21 @@ class ShadowBackend(WiringRecorder):
         rc, err = self.g.ref_level()
         assert rc == 0, err
         rec, off, lists = self.g.arr("ref_rec"), self.g.arr("ref_stage_off"), self.g.arr("ref_list")
-        self.last_stages = len(off) - 1
-        self.run(rec, off, lists)
+        wrec, woff = self.g.arr("ref_wide_rec"), self.g.arr("ref_wide_off")      # list items of many sources travel apart (k_wide_sum): same stage, same meaning
+        self.last_stages, self.last_wide = len(off) - 1, len(wrec) // 5
+        self.run(rec, off, lists, wrec, woff)
 
     def trace_rows(self):
         return self.last_rows
 
-    def run(self, rec, stage_off, lists):
+    def run(self, rec, stage_off, lists, wide_rec=(), wide_off=()):
         """cx_kernels.hip: batch_item for the kinds a wired plan holds; asserts that no item of a stage reads what another one writes"""
         for s in range(len(stage_off) - 1):
             items = rec[5 * stage_off[s]:5 * stage_off[s + 1]].reshape(-1, 5)
+            if len(wide_off):
+                wide = np.asarray(wide_rec[5 * wide_off[s]:5 * wide_off[s + 1]]).reshape(-1, 5)
+                assert all(int(k) in (64, 65, 66, 72) for k in wide[:, 0])
+                items = np.concatenate([items, wide])
             reads, writes, new = set(), set(), []
             for k, idx, v, lo, hi in items:
                 k, idx, lo, hi = int(k), int(idx), int(lo), int(hi)
