@@ -255,9 +255,11 @@ def test_host_logic_under_address_and_ub_sanitizers():
     from cortex.jl_amd import build as B
 
     # this file, the plan of the tree schedule (tests/test_tree_plan.py: cx_tree_plan.h over forests, cycles, observed cuts) and the
-    # reference-order schedule's wiring, shadow scheduler and levelling (tests/test_refsched.py: cx_refsched.h on loopy graphs with hubs)
+    # reference-order schedule's wiring, shadow scheduler and levelling (tests/test_refsched.py: cx_refsched.h on loopy graphs with hubs;
+    # tests/test_wired_vmp.py: user wirings with marginal-dependent messages, joint marginals, linked signals, wide lists)
     out = _run_under_asan(B.build_hostlogic(asan=True), "not sanitizers and not reintroduced",
-                          [os.path.abspath(__file__), os.path.join(ROOT, "tests", "test_tree_plan.py"), os.path.join(ROOT, "tests", "test_refsched.py")])
+                          [os.path.abspath(__file__), os.path.join(ROOT, "tests", "test_tree_plan.py"), os.path.join(ROOT, "tests", "test_refsched.py"),
+                           os.path.join(ROOT, "tests", "test_wired_vmp.py")])
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr
 
