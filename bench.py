@@ -451,6 +451,8 @@ def other_configs(parity=None) -> list:
                      ("C3-scan", lambda: bc.mv_scan(4, 1_000_000, 30, check=hooks.get("C3-scan"))[0]),
                      ("C5", lambda: bc.mv(64, 100_000, 12)), ("C5-scan", lambda: bc.mv64_scan(100_000, 8, check=hooks.get("C5-scan"))[0]),
                      ("VMP", lambda: bc.vmp()),
+                     # the same structured model as a user wiring under the reference-order schedule (cx_graph_wire): replayed plans per call
+                     ("VMP-wired", lambda: bc.vmp_wired(100_000)),
                      # the headline graph under the reference's OWN order: one cx_sweep = one update_marginals! (sequential, newest values):
                      # stage count, ms per call, calls to the fixed point beside the fused schedule's sweeps
                      ("C4-reference", lambda: bc.reference_order(1415)),

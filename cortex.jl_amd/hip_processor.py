@@ -17,6 +17,11 @@ Modes:
                 the reference's rule call would read, loops included — as one graph launch; plans are kept per readiness state, so
                 a repeated call (new data, same request) costs one launch.  The readiness bits live in the library's shadow
                 (csrc/cx_refsched.h); the host marks the requested marginals computed.  Scalar messages.
+                With a USER resolver (anything but DefaultDependencyResolver) the engine's signals carry that resolver's
+                add_dependency! calls when the processor is attached: they are read back (wiring.from_engine) and become the device's
+                wiring (cx_graph_wire) — weak / intermediate / listen flags, joint marginals and linked signals included; factors with a
+                NormalPrecisionFactor functional form get the variational rules their dependency lists select, marginals are then
+                settable (set_value on a marginal signal: Gamma, NormalMeanPrecision, NormalMeanVariance, a number = observed).
 """
 from __future__ import annotations
 
@@ -30,6 +35,7 @@ from . import _lib as L
 from .device import DeviceGraph
 from .inference_engine import (AbstractInferenceRequestProcessor, InferenceEngine, request_inference_for,
                                scan_inference_request)
+from .dependencies import DefaultDependencyResolver
 from .inference_signal import InferenceSignalVariants as V
 from .model_engine import get_factor_functional_form, get_variable_marginal
 from .signal import Signal, is_pending, set_value as _host_set_value
@@ -98,6 +104,8 @@ def default_factor_rule(factor) -> Tuple[int, Tuple[float, ...]]:
         return L.FACTOR_GAUSS_LINEAR, (ff.variance, ff.a, ff.b)
     if isinstance(ff, MvGaussianLinear):
         return L.FACTOR_GAUSS_LINEAR, ff          # dim > 1: attach() turns the (A, Q) object into a parameter-set index
+    if type(ff).__name__ == "NormalPrecisionFactor":      # (defined below) out ~ N(mean, 1 / precision): variational rules, mode "reference" + a user resolver
+        return L.FACTOR_NORMAL_PRECISION, ()
     return L.FACTOR_OPAQUE, ()
 
 
@@ -272,8 +280,18 @@ class HipProcessor(AbstractInferenceRequestProcessor):
         self.engine = engine
         ev, ef, role, fids, kinds, params = [], [], [], [], [], []
         psets = {}                             # id(functional_form) -> parameter-set index (dim > 1)
+        self.gamma_variables = set()           # precisions of NormalPrecisionFactor factors: their marginals are Gamma(shape, scale)
         for f in engine.get_factor_ids():
             kind, p = self.factor_rule(engine.get_factor(f))
+            if kind == L.FACTOR_NORMAL_PRECISION:
+                if self.mode != "reference":
+                    raise NotImplementedError("a NormalPrecisionFactor has variational rules only: HipProcessor(mode='reference') with a resolver that wires them, or HipVmpProcessor")
+                fids.append(f); kinds.append(kind); params.append((0.0,) * L.NPARAM)
+                for v, r in _normal_precision_roles(engine, f):
+                    ev.append(v); ef.append(f); role.append(r)
+                    if r == L.ROLE_PRECISION:
+                        self.gamma_variables.add(v)
+                continue
             if isinstance(p, MvGaussianLinear):
                 if self.dim == 1:
                     raise TypeError("MvGaussianLinear factors need HipProcessor(dim=d)")
@@ -290,6 +308,12 @@ class HipProcessor(AbstractInferenceRequestProcessor):
         if not ev:
             return
         self.dev.graph_create(ev, ef, fids, kinds, np.asarray(params, dtype=np.float64), edge_role=role)
+        if self.mode == "reference" and type(engine.dependency_resolver) is not DefaultDependencyResolver:
+            # a user resolver ran over the engine (dependencies.jl:1-15): its add_dependency! calls, read back from the signals, become the
+            # device's wiring (cx_graph_wire) — the device then schedules exactly what the host engine would
+            from . import wiring
+            t = wiring.from_engine(engine)
+            self.dev.graph_wire(t.signals, t.dependencies, t.flags)
 
     # ---- data injection: set_value! on a message signal, mirrored to the device ---------------------------------
     def set_value(self, signal: Signal, value):
@@ -298,8 +322,23 @@ class HipProcessor(AbstractInferenceRequestProcessor):
             direction = L.TO_FACTOR
         elif isinstance(variant, V.MessageToVariable):
             direction = L.TO_VARIABLE
+        elif isinstance(variant, V.IndividualMarginal) and self.mode == "reference" and self.dim == 1:
+            # set_value!(get_variable_marginal(...), value): the initial q's and the data of a wiring whose messages depend on marginals
+            vid = variant.variable_id
+            if isinstance(value, Gamma):
+                self.dev.set_marginals([vid], L.FORM_GAMMA, [value.shape, value.scale])
+            elif isinstance(value, NormalMeanPrecision):
+                self.dev.set_marginals([vid], L.FORM_MEAN_PRECISION, [value.mean, value.precision])
+            elif isinstance(value, NormalMeanVariance):
+                self.dev.set_marginals([vid], L.FORM_MOMENT, [value.mean, value.variance])
+            elif isinstance(value, (bool, int, float, np.floating)):
+                self.dev.set_marginals([vid], L.FORM_POINT, [float(value)])
+            else:
+                raise TypeError(f"HipProcessor.set_value: no device form for a marginal of type {type(value).__name__}")
+            _host_set_value(signal, value)
+            return
         else:
-            raise TypeError("HipProcessor.set_value: only message signals carry device payloads")
+            raise TypeError("HipProcessor.set_value: message signals carry device payloads (marginals too in mode 'reference')")
         if self.dim > 1:
             d = self.dim
             if isinstance(value, MvNormalMeanCovariance):
@@ -314,6 +353,10 @@ class HipProcessor(AbstractInferenceRequestProcessor):
             self.dev.set_messages([variant.variable_id], [variant.factor_id], direction, L.FORM_POINT, [float(value)])
         elif isinstance(value, Beta):
             self.dev.set_messages([variant.variable_id], [variant.factor_id], direction, L.FORM_NATURAL, [value.a - 1.0, value.b - 1.0])
+        elif isinstance(value, Gamma):         # a message to a precision (a prior): natural pair (shape - 1, rate)
+            self.dev.set_messages([variant.variable_id], [variant.factor_id], direction, L.FORM_NATURAL, [value.shape - 1.0, 1.0 / value.scale])
+        elif isinstance(value, NormalMeanPrecision):
+            self.dev.set_messages([variant.variable_id], [variant.factor_id], direction, L.FORM_NATURAL, [value.mean * value.precision, value.precision])
         else:
             self.dev.set_messages([variant.variable_id], [variant.factor_id], direction, L.FORM_MOMENT,
                                   [float(value.mean), float(value.variance)])
@@ -326,6 +369,8 @@ class HipProcessor(AbstractInferenceRequestProcessor):
             return mean[0], cov[0]
         if isinstance(variant, V.IndividualMarginal):
             m = self.dev.get_marginals([variant.variable_id])[0]
+            if variant.variable_id in getattr(self, "gamma_variables", ()):
+                return Gamma(float(m[0]), float(m[1]))
         elif isinstance(variant, V.MessageToVariable):
             m = self.dev.get_messages([variant.variable_id], [variant.factor_id], L.TO_VARIABLE, form)[0]
         elif isinstance(variant, V.MessageToFactor):
@@ -449,6 +494,19 @@ class NormalPrecisionFactor:
     test/inference_engine_tests.jl:691-715.  `roles` maps a connected variable's *name* to its role
     ("out" | "mean" | "precision"); with two variables of one name (x_i, x_{i+1}) the lower id is the mean."""
     roles: Tuple[Tuple[str, str], ...]
+
+
+def _normal_precision_roles(engine, f):
+    """(variable id, CX_ROLE_*) of a NormalPrecisionFactor's three variables, ascending ids; with two variables of one name the lower id is the mean"""
+    roles = dict(get_factor_functional_form(engine.get_factor(f)).roles)
+    seen_mean, out = False, []
+    for v in engine.get_connected_variable_ids(f):
+        r = roles[str(engine.get_variable(v).name).lstrip(":")]
+        if r == "both":
+            r = "out" if seen_mean else "mean"
+            seen_mean = True
+        out.append((v, {"out": L.ROLE_OUT, "mean": L.ROLE_IN, "precision": L.ROLE_PRECISION}[r]))
+    return out
 
 
 class HipVmpValue:

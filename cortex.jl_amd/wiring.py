@@ -106,3 +106,68 @@ def structured(edge_var, edge_fac, edge_role, clustered_factors, prior_factors=(
     s3 = _rows(L.ITEM_INDIVIDUAL_MARGINAL, vars_, 0)
     return Triples(np.concatenate([s1, s2, s3]), np.concatenate([d1, d2, s3]),
                    np.concatenate([f1, f2, np.full(len(vars_), L.WIRE_DEFAULT_VARIABLE, dtype=np.int32)]))
+
+
+def from_engine(engine) -> Triples:
+    """The wiring of a constructed InferenceEngine (host mirror of the reference's API) as cx_graph_wire triples: whatever
+    AbstractDependencyResolver ran over the engine (/root/reference/src/dependencies.jl:5-15), its add_dependency! calls are read back
+    from the signals — per signal the dependencies in their order with their weak / intermediate bits (SignalDependenciesProps) and the
+    listen bit (the dependency's listenmask), per variable the linked signals in link order.  A variable whose signals hang off
+    ProductOfMessages nodes was wired by the default resolver's segment tree (those nodes cannot be named from outside): it is exported as
+    CX_WIRE_DEFAULT_VARIABLE.  Factor side first, so that the default variable wiring finds the listeners it asks for."""
+    from .inference_signal import InferenceSignalVariants as V
+    from .model_engine import get_variable_linked_signals, get_variable_marginal
+    from .signal import IS_INTERMEDIATE, IS_WEAK
+
+    sig, dep, flags = [], [], []
+
+    def name(s):
+        v = s.variant
+        if isinstance(v, V.MessageToFactor):
+            return (L.ITEM_MESSAGE_TO_FACTOR, v.variable_id, v.factor_id)
+        if isinstance(v, V.MessageToVariable):
+            return (L.ITEM_MESSAGE_TO_VARIABLE, v.variable_id, v.factor_id)
+        if isinstance(v, V.IndividualMarginal):
+            return (L.ITEM_INDIVIDUAL_MARGINAL, v.variable_id, 0)
+        if isinstance(v, V.JointMarginal):
+            return (L.ITEM_JOINT_MARGINAL, 0, v.factor_id)
+        raise TypeError(f"cx_graph_wire cannot name a signal of variant {v!r}")
+
+    joints, seen_joint = [], set()
+
+    def export(s):
+        me = name(s)
+        for i, d in enumerate(s.dependencies):
+            if isinstance(d.variant, V.JointMarginal) and id(d) not in seen_joint:
+                seen_joint.add(id(d)); joints.append(d)
+            fl = (L.WIRE_WEAK if s.dependencies_props.get(i, IS_WEAK) else 0) | (L.WIRE_INTERMEDIATE if s.dependencies_props.get(i, IS_INTERMEDIATE) else 0)
+            k = next(j for j, l in enumerate(d.listeners) if l is s)      # add_dependency! pushes listener and listenmask together
+            if not d.listenmask[k]:
+                fl |= L.WIRE_NO_LISTEN
+            sig.append(me); dep.append(name(d)); flags.append(fl)
+
+    var_ids = list(engine.get_variable_ids())
+    for f in engine.get_factor_ids():
+        for v in engine.get_connected_variable_ids(f):
+            export(engine.get_connection_message_to_variable(v, f))
+    for v in var_ids:      # joint marginals reachable only through a link
+        for ls in get_variable_linked_signals(engine.get_variable(v)):
+            if isinstance(ls.variant, V.JointMarginal) and id(ls) not in seen_joint:
+                seen_joint.add(id(ls)); joints.append(ls)
+    done = 0
+    while done < len(joints):      # (a joint may depend on another joint: the structured resolver wires clusters to each other)
+        export(joints[done]); done += 1
+    for v in var_ids:
+        variable = engine.get_variable(v)
+        marg = get_variable_marginal(variable)
+        own = [marg] + [engine.get_connection_message_to_factor(v, f) for f in engine.get_connected_factor_ids(v)]
+        if any(isinstance(d.variant, V.ProductOfMessages) for s in own for d in s.dependencies):
+            sig.append(name(marg)); dep.append(name(marg)); flags.append(L.WIRE_DEFAULT_VARIABLE)
+        else:
+            for s in own:
+                export(s)
+        for ls in get_variable_linked_signals(variable):
+            sig.append(name(ls)); dep.append(name(marg)); flags.append(L.WIRE_LINK)
+    while done < len(joints):
+        export(joints[done]); done += 1
+    return Triples(np.asarray(sig, dtype=np.int64).reshape(-1, 3), np.asarray(dep, dtype=np.int64).reshape(-1, 3), np.asarray(flags, dtype=np.int32))

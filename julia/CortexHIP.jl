@@ -203,6 +203,56 @@ set_factor_coefficients!(p, variable_ids::Vector{Int64}, factor_ids::Vector{Int6
 wire!(p::HipProcessor, signals::Vector{CxItem}, dependencies::Vector{CxItem}, flags::Vector{Int32}) =
     check(p.handle, ccall((:cx_graph_wire, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{CxItem}, Ptr{CxItem}, Ptr{Int32}), p.handle, length(flags), signals, dependencies, flags))
 
+# schedule 4 with a USER resolver: the engine was constructed with it, so its add_dependency! calls are on the signals — read them back
+# (dependencies in order, weak / intermediate nibbles, the dependency's listenmask, the variables' linked signals) and hand them over.
+# A variable whose signals hang off ProductOfMessages nodes was wired by the default resolver's segment tree: flag 8.  Factor side first.
+# (cortex.jl_amd/wiring.py: from_engine is the same walk over the Python host mirror, exercised by tests/test_gpu_wired_vmp.py.)
+function wire_from_engine!(p::HipProcessor, engine::Cortex.InferenceEngine)
+    V = Cortex.InferenceSignalVariants
+    sig, dep, flags = CxItem[], CxItem[], Int32[]
+    name(s) = let v = Cortex.get_variant(s)
+        v isa V.MessageToFactor ? CxItem(1, 0, v.variable_id, v.factor_id) :
+        v isa V.MessageToVariable ? CxItem(2, 0, v.variable_id, v.factor_id) :
+        v isa V.IndividualMarginal ? CxItem(4, 0, v.variable_id, 0) :
+        v isa V.JointMarginal ? CxItem(16, 0, 0, v.factor_id) : error("cx_graph_wire cannot name a signal of variant $(v)")
+    end
+    joints, seen = Cortex.InferenceSignal[], Set{UInt}()
+    note(d) = (Cortex.get_variant(d) isa V.JointMarginal && !(objectid(d) in seen)) && (push!(seen, objectid(d)); push!(joints, d))
+    function export_signal(s)
+        for (i, d) in enumerate(Cortex.get_dependencies(s))
+            note(d)
+            fl = Int32(0)
+            Cortex.is_dependency_weak(s.dependencies_props, i) && (fl |= Int32(1))
+            Cortex.is_dependency_intermediate(s.dependencies_props, i) && (fl |= Int32(2))
+            d.listenmask[findfirst(l -> l === s, Cortex.get_listeners(d))] || (fl |= Int32(4))
+            push!(sig, name(s)); push!(dep, name(d)); push!(flags, fl)
+        end
+    end
+    for f in Cortex.get_factor_ids(engine), v in Cortex.get_connected_variable_ids(engine, f)
+        export_signal(Cortex.get_connection_message_to_variable(engine, v, f))
+    end
+    for v in Cortex.get_variable_ids(engine), ls in Cortex.get_variable_linked_signals(Cortex.get_variable(engine, v))
+        note(ls)
+    end
+    done = 0
+    while done < length(joints); done += 1; export_signal(joints[done]); end
+    for v in Cortex.get_variable_ids(engine)
+        variable = Cortex.get_variable(engine, v)
+        marg = Cortex.get_variable_marginal(variable)
+        own = vcat([marg], [Cortex.get_connection_message_to_factor(engine, v, f) for f in Cortex.get_connected_factor_ids(engine, v)])
+        if any(Cortex.get_variant(d) isa V.ProductOfMessages for s in own for d in Cortex.get_dependencies(s))
+            push!(sig, name(marg)); push!(dep, name(marg)); push!(flags, Int32(8))
+        else
+            foreach(export_signal, own)
+        end
+        for ls in Cortex.get_variable_linked_signals(variable)
+            push!(sig, name(ls)); push!(dep, name(marg)); push!(flags, Int32(16))
+        end
+    end
+    while done < length(joints); done += 1; export_signal(joints[done]); end
+    wire!(p, sig, dep, flags)
+end
+
 # schedule 4: the executions of the last call in the reference's order — what a `trace = true` engine records as
 # TracedInferenceExecution.signal (src/inference_engine.jl:650-862) — as (kind, variable_id, factor_id | range) items
 function reference_trace(p)

@@ -69,6 +69,24 @@ def test_the_tree_model_on_the_device_is_dense_coordinate_ascent(hip_lib):
     assert st["hits"] >= 14 and st["misses"] <= 6, st      # two standing plans in the steady state
 
 
+@pytest.mark.parametrize("kind,n", [("mean_field", 12), ("structured", 5), ("structured", 12)])
+def test_a_users_resolver_through_the_plugin(hip_lib, kind, n):
+    """the drop-in boundary for a USER resolver: the model engine, the transcribed resolver and HipProcessor(mode = "reference") go into
+    InferenceEngine as they would in the reference; the resolver wires the HOST engine's signals, the processor reads that wiring back
+    and hands it to the device.  Every update_marginals! of the reference's experiment equals the restated engine: executions and marginals."""
+    data = vs.dataset(n, seed=13)
+    rule = vs.mean_field_rule if kind == "mean_field" else vs.structured_rule
+    _, want = _run(ws.TracedOracleBackend(rule), kind, data, 3)
+    _, got = _run(ws.PluginBackend(), kind, data, 3)
+    _compare(got, want, 1e-9, f"plug-in, {kind} n={n}")
+
+
+def test_the_tree_model_through_the_plugin(hip_lib):
+    _, want = _run_tree(ws.TracedOracleBackend(vs.structured_rule), 25, 1, 3)
+    _, got = _run_tree(ws.PluginBackend(), 25, 1, 3)
+    _compare(got, want, 1e-9, "plug-in, tree K=25")
+
+
 def _wired_ssm(model, kind):
     dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
     nf = len(model.factor_ids)

@@ -110,6 +110,19 @@ def test_the_vectorised_wirings_are_the_resolvers_calls(kind, n):
     _compare(got, oracle, 1e-10, f"{kind} n={n}: array wiring vs the restated engine")
 
 
+@pytest.mark.parametrize("kind,n", [("mean_field", 9), ("structured", 5), ("structured", 14)])
+def test_a_wiring_read_back_from_the_host_engine(kind, n):
+    """cortex.jl_amd.wiring.from_engine: the resolvers run on the host mirror of the reference's API (as a user's resolver would), the
+    triples are read back from the signals' dependency lists, nibbles, listen masks and linked signals — and drive the shadow scheduler to
+    the restated engine's executions and values"""
+    data = vs.dataset(n, seed=5)
+    be = ws.ShadowBackend()
+    be.vectorised = "from_engine"
+    _, got = _run(be, kind, data, 2)
+    _, oracle = _run(ws.TracedOracleBackend(vs.mean_field_rule if kind == "mean_field" else vs.structured_rule), kind, data, 2)
+    _compare(got, oracle, 1e-10, f"{kind} n={n}: wiring read back from the host engine")
+
+
 def test_structured_wiring_reaches_the_references_own_assertions():
     """the facts the reference asserts (:1142-1143): both precisions recovered above 90 after 100 iterations on 100 points with true
     precisions 100 — here 40 iterations of the by-class calls on the shadow + numpy items (values only; the order is pinned above)"""

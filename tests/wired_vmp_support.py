@@ -93,6 +93,19 @@ class WiringRecorder:
     def resolve(self, factor_resolver, variable_resolver):
         """resolve_dependencies!, dependencies.jl:5-15: factors first, then variables, each in ascending id order"""
         self._index()
+        if self.vectorised == "from_engine":
+            # the resolvers run on the HOST mirror of the reference's API; the wiring is read back from its signals (what HipProcessor.attach does)
+            mirror = vs.MirrorBackend(rule=None)
+            ids = {}
+            for i in range(1, self.next_id):
+                ids[i] = mirror.add_variable(self.names[i]) if i in self.names else mirror.add_factor(self.forms[i])
+                assert ids[i] == i, "the mirror hands out the same ids"
+            for v, f in self.edges:
+                mirror.add_edge(v, f)
+            mirror.resolve(factor_resolver, variable_resolver)
+            t = cx.wiring.from_engine(mirror.engine)
+            self.sig, self.dep, self.flags = t.signals, t.dependencies, t.flags
+            return self.wired()
         if self.vectorised:
             ev, ef, role, _fids, _kinds = self.graph_arrays()
             priors = [f for f, form in self.forms.items() if form == "prior"]
@@ -297,7 +310,9 @@ def to_natural(value):
 
 
 def _set_prior(be, v, f, value):
-    if isinstance(be, vs.OracleBackend):
+    if hasattr(be, "set_prior"):
+        be.set_prior(v, f, value)
+    elif isinstance(be, vs.OracleBackend):
         be.E.set_value_ex(be.E.message_to_variable(v, f), value[0], value[1])
     else:
         be.set_message_to_variable(v, f, to_natural(value))
@@ -417,3 +432,62 @@ class DenseTreeVMP:
             cnt[g] += 1
             rate[g] += 0.5 * (self.Sigma[j, j] + (d - self.mu[j]) ** 2)
         self.op = [(a0 + 0.5 * c, 1.0 / (rate0 + r)) for c, r in zip(cnt, rate)]
+
+
+# ---- the plug-in: the host mirror of the reference's API with HipProcessor(mode = "reference") -------------------------------------------
+class PluginBackend(vs.MirrorBackend):
+    """What a user of the reference does, on the product's host mirror: build the model engine, pass THEIR resolver and the HIP processor
+    to InferenceEngine, set values, call update_marginals.  The resolver runs on the host engine's signals; HipProcessor.attach reads the
+    wiring back (cortex.jl_amd.wiring.from_engine) and hands it to the device (cx_graph_wire); every update_marginals! is then one
+    cx_sweep_for.  Values travel as the processor's value types."""
+
+    ROLES = {"likelihood": (("y", "out"), ("x", "mean"), ("obsnoise", "precision")), "transition": (("x", "both"), ("ssnoise", "precision"))}
+
+    def __init__(self):
+        from cortex.jl_amd import hip_processor as hp
+        self.hp = hp
+        super().__init__(rule=None)
+        self.forms = {}
+
+    def add_factor(self, form):
+        ff = self.hp.NormalPrecisionFactor(roles=self.ROLES[form]) if form in self.ROLES else form
+        f = self.graph.add_factor(self.cx.Factor(functional_form=ff))
+        self.forms[f] = form
+        return f
+
+    def factor_form(self, f): return self.forms[f]
+
+    def resolve(self, factor_resolver, variable_resolver):
+        cx, be = self.cx, self
+
+        class Resolver(cx.AbstractDependencyResolver):
+            def resolve_factor_dependencies(self, engine, factor_id):
+                be.engine = engine
+                factor_resolver(be, factor_id)
+
+            def resolve_variable_dependencies(self, engine, variable_id):
+                be.engine = engine
+                if variable_resolver is None:
+                    cx.DefaultDependencyResolver().resolve_variable_dependencies(engine, variable_id)
+                else:
+                    variable_resolver(be, variable_id)
+
+        self.processor = self.hp.HipProcessor(mode="reference")
+        self.engine = cx.InferenceEngine(model_engine=self.graph, dependency_resolver=Resolver(), inference_request_processor=self.processor)
+
+    def _value(self, value):
+        tag, p = value
+        return float(p[0]) if tag == ref.REAL else self.hp.NormalMeanPrecision(p[0], p[1]) if tag == ref.NORMAL_MP else self.hp.Gamma(p[0], p[1])
+
+    def set_marginal(self, v, value): self.processor.set_value(self.marginal(v), self._value(value))
+    def set_message_to_variable(self, v, f, natural): raise NotImplementedError
+    def set_prior(self, v, f, value): self.processor.set_value(self.message_to_variable(v, f), self._value(value))
+
+    def get_marginal(self, v):
+        m = self.processor.read(self.marginal(v).variant)
+        if isinstance(m, self.hp.Gamma):
+            return (ref.GAMMA, [m.shape, m.scale])
+        return (ref.NORMAL_MP, [m.mean, 1.0 / m.variance])
+
+    def trace_rows(self):
+        return [(k, 0 if k == KJOINT else v, f if k in (K2F, K2V, KJOINT) else 0, lo, hi) for k, v, f, lo, hi in self.processor.dev.ref_trace()]

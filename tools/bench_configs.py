@@ -281,6 +281,66 @@ def vmp(n=1_000_000, only=None):
     return out
 
 
+def vmp_wired(n=100_000, iterations=3):
+    """The structured variational model of the reference's tests as a WIRING (cx_graph_wire under CX_SCHED_REFERENCE: the resolver's
+    add_dependency! calls as triples, the rules chosen by the dependency lists) next to the fused family handle that hard-wires the same
+    model: per-call times of the replayed plans, what the host pays once, and the agreement of every marginal after `iterations` by-class
+    iterations.  (Call-by-call identity with the restated engine, mixed requests included: tests/test_gpu_wired_vmp.py.)"""
+    import time
+    model = cx.synth.vmp_ssm(n, seed=1234)
+    nf = len(model.factor_ids)
+    t0 = time.perf_counter()
+    t = cx.wiring.structured(model.edge_var, model.edge_fac, model.edge_role, clustered_factors=model.factor_ids[model.n:])
+    dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+    dev.graph_create(model.edge_var, model.edge_fac, model.factor_ids, np.full(nf, L.FACTOR_NORMAL_PRECISION, dtype=np.int32), np.zeros(nf), edge_role=model.edge_role)
+    dev.graph_wire(t.signals, t.dependencies, t.flags)
+    wire_s = time.perf_counter() - t0
+    dev.set_marginals([model.ssnoise, model.obsnoise], L.FORM_GAMMA, [1.0, 1.0, 1.0, 1.0])
+    dev.set_marginals(model.x_ids, L.FORM_MEAN_PRECISION, np.tile([0.0, 1.0], model.n))
+    dev.set_marginals(model.y_ids, L.FORM_POINT, model.data_y)
+    fused = cx.DeviceGraph(family=L.FAMILY_VMP_STRUCTURED, schedule=L.SCHED_CHAIN_SCAN)
+    cx.synth.load_vmp_into_device(model, fused)
+    calls = (("states", model.x_ids, L.VMP_ALL_NORMAL), ("ssnoise", [model.ssnoise], [model.ssnoise]), ("obsnoise", [model.obsnoise], [model.obsnoise]))
+    t0 = time.perf_counter()
+    for _ in range(iterations):
+        for _name, ids, fids in calls:
+            dev.sweep_for(ids); fused.update_marginals(fids)
+    dev.sync()
+    first_s = time.perf_counter() - t0
+    xa, xb = dev.get_marginals(model.x_ids), fused.get_marginals(model.x_ids)
+    ga, gb = dev.get_marginals([model.ssnoise, model.obsnoise]), fused.get_marginals([model.ssnoise, model.obsnoise])
+    err = max(float(np.max(np.abs(xa[:, 0] - xb[:, 0]) / np.maximum(np.abs(xb[:, 0]), 1e-3))), float(np.max(np.abs(1.0 / xa[:, 1] - xb[:, 1]) / xb[:, 1])),
+              float(np.max(np.abs(ga - gb) / np.abs(gb))))
+    per_call, plans = {}, {}
+    for i, (name, ids, _f) in enumerate(calls):
+        best = None
+        for _rep in range(3):
+            for _n2, ids2, _f2 in calls[:i]:
+                dev.sweep_for(ids2)
+            dev.sync(); t0 = time.perf_counter(); dev.sweep_for(ids); dev.sync()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            st = dev.ref_plan_stats()
+            for _n2, ids2, _f2 in calls[i + 1:]:
+                dev.sweep_for(ids2)
+        per_call[name] = best * 1e3
+        plans[name] = {k: st[k] for k in ("stages", "launches", "executions", "messages", "rounds")}
+    st = dev.ref_plan_stats()
+    dtf = timed(fused, lambda: [fused.update_marginals(f) for _n, _i, f in calls], 20, 5)
+    execs = sum(p["executions"] for p in plans.values())
+    total_ms = sum(per_call.values())
+    return {"config": "VMP-wired", "workload": f"structured VMP as a user wiring (cx_graph_wire, {len(t.flags)} add_dependency! triples), SSM with unknown precisions, n={n} states",
+            "ms_per_call": per_call, "ms_per_iteration": total_ms, "plans": plans, "executions_per_iteration": execs, "executions_per_s": execs / (total_ms * 1e-3),
+            "host_once": {"triples_and_wiring_s": wire_s, "first_iterations_s": first_s, "plans_kept": st["plans"], "calls_that_ran_the_scheduler": st["misses"]},
+            "fused_family_ms_per_iteration": dtf * 1e3,
+            "roofline": {"bound": "hbm", "achieved": execs * 32 / (total_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                         "frac_algorithmic": execs * 32 / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "basis": "algorithmic bytes (32 B per execution, SURVEY §8d) / time of the three calls",
+                         "frac_note": "the states' call is the reference's forward / backward chain: 2 n dependent stages inside one workgroup, a latency chain by construction; "
+                                      "the precisions' calls are wide and shallow", "kernel": "k_batch_run / k_batch over the plan's stages"},
+            "parity": {"max_rel_err": err, "tolerance": 1e-9, "checker": "the fused family handle on the same device (cx_update_marginals; itself pinned call by call against oracle/vmp.py and the "
+                       "restated engine), every state mean, state precision and both Gamma marginals", "sample": f"after {iterations} by-class iterations, n={n}"}}
+
+
 def vmp_traffic(family):
     """HBM bytes of one iteration of a variational family from the newest profiles/r*_vmp_rocprof.json (tools/profile_vmp.sh) whose
     kernel sources are the current ones; None otherwise"""
@@ -447,6 +507,9 @@ if __name__ == "__main__":
         if w.startswith("reference"):                    # reference | reference:300 (grid side)
             parts = w.split(":")                           # reference:1415:nofp skips the iteration to the fixed point
             print(json.dumps(reference_order(n=int(parts[1]) if len(parts) > 1 else 1415, fixed_point="nofp" not in parts)), flush=True)
+            continue
+        if w.startswith("vmpwired"):                     # vmpwired | vmpwired:1000000
+            print(json.dumps(vmp_wired(int(w.split(":")[1]) if ":" in w else 100_000)), flush=True)
             continue
         if w.startswith("vmp"):
             for r in vmp(only=w[4:] or None):          # vmp | vmp_structured | vmp_mean_field
