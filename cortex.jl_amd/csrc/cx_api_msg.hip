@@ -80,6 +80,7 @@ int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
                 for (int64_t i = 0; i < n; i++)
                     if (!(h->vinfo[vars[i]] & cx::kClamped)) { h->vinfo[vars[i]] |= cx::kClamped; newly = true; }
                 if (newly) {
+                    h->vinfo_epoch++;
                     h->chains_dirty = true; h->tree_dirty = true; h->offchain_marg_dirty = true;
                     CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
                 }

@@ -4,6 +4,8 @@
 // (readiness state at the start of the call, request), so the steady state of an iteration — set the priors, call, set the priors,
 // call — replays a standing plan and costs the host a hash lookup.
 
+#include <chrono>
+#include <cstdio>
 #include <memory>
 
 #include "cx_host.h"
@@ -16,11 +18,12 @@ namespace {
 
 struct PlanEntry {
     uint64_t key = 0, req_key = 0;
-    int32_t *d_rec = nullptr, *d_list = nullptr, *d_wide_rec = nullptr;
+    int32_t *d_rec = nullptr, *d_list = nullptr, *d_wide_rec = nullptr, *d_flat = nullptr;
     int64_t *d_stage_off = nullptr;
     std::vector<int64_t> stage_off, wide_off;
     hipGraphExec_t exec = nullptr;
     bool graph_failed = false;
+    bool cluster = false;                       // every stage in ONE launch of an XCD-resident cluster (cx_kernels.hip: k_ref_cluster)
     std::shared_ptr<const rs::State> post;      // the readiness state the call leaves
     std::vector<int32_t> order;                 // the executions, in the reference's order (cx_ref_trace)
     int64_t n_messages = 0, n_marginals = 0, n_products = 0, rounds = 0, launches = 0, list_entries = 0;
@@ -31,14 +34,23 @@ struct PlanEntry {
 struct RefSched {
     rs::Wiring W;
     std::shared_ptr<rs::State> S;               // copy-on-write: a cache hit adopts the entry's post state without copying it
+    std::shared_ptr<rs::State> spare;           // the private copy the last call displaced: the next writer copies INTO it (at C4 a state is 200 MB — freeing one and
+                                                // allocating the next cost 17 ms per call)
     std::vector<PlanEntry> cache;
     std::vector<int32_t> prod_slot;             // segment-tree node -> index in the handle's product store
     std::vector<int32_t> joint_slot;            // factor -> index in the handle's joint store (-1: its joint marginal is not wired)
+    std::vector<int32_t> all_req;               // the request of a plain cx_sweep (every variable that is neither observed nor a stand-in) and its key,
+    uint64_t all_key = 0, all_epoch = ~0ull;    // kept while the observed flags stand (2 M ids at C4: 12 ms of host time per call to rebuild and hash)
     int64_t hits = 0, misses = 0;
     uint64_t tick = 0;
     int last = -1;
     bool touched = false;                       // a value was set or a call ran: the wiring can no longer be replaced (cx_graph_wire)
-    int64_t max_bytes = (int64_t)2 << 30;       // plans kept: at most max_entries and at most this much device memory (the one in use always stays)
+    void *d_ctl = nullptr;                      // the cluster's control block (64 B)
+    int n_cu = 0;                               // compute units = workgroups of a cluster launch
+    bool cluster_on = true;                     // CX_REF_CLUSTER=0: plain launches (A/B); also off after a cluster wait timed out
+    int64_t cluster_max_items = 65536;          // a stage wider than this is a launch of its own on the whole chip
+    int64_t cluster_min_items = 128;            // per stage, on average: below that the stages are chains and one workgroup's own barrier is as good
+    int64_t max_bytes = (int64_t)4 << 30;       // plans kept: at most max_entries and at most this much device memory (the one in use always stays)
     int max_entries = 16, run_max = 1024;      // C4, ms per call: every stage a launch 57.6, runs of stages <= 1024 items 52.8, <= 4096 items 102 (one workgroup is slow on a wide stage)
 };
 
@@ -46,14 +58,58 @@ RefSched *ref_of(cx_handle *h) { return (RefSched *)h->ref; }
 
 void entry_free(cx_handle *h, PlanEntry &e) {
     if (e.exec) { (void)hipGraphExecDestroy(e.exec); e.exec = nullptr; }
-    for (void *p : {(void *)e.d_rec, (void *)e.d_list, (void *)e.d_stage_off, (void *)e.d_wide_rec}) if (p) (void)hipFree(p);
-    e.d_rec = e.d_list = e.d_wide_rec = nullptr; e.d_stage_off = nullptr;
+    for (void *p : {(void *)e.d_rec, (void *)e.d_list, (void *)e.d_stage_off, (void *)e.d_wide_rec, (void *)e.d_flat}) if (p) (void)hipFree(p);
+    e.d_rec = e.d_list = e.d_wide_rec = e.d_flat = nullptr; e.d_stage_off = nullptr;
     h->device_bytes -= e.device_bytes; e.device_bytes = 0;
+}
+
+// The records of a plan with everything the graph's tables would answer already filled in (cx_kernels.hip: FlatRec — kind | n << 8,
+// destination, variable, five sources): what the XCD-resident cluster runs, so that an item's chain of dependent loads is its values and
+// nothing else.  Items that do not fit (more than five sources, rules of factors with more than two edges, variational rules) point back
+// at their ordinary record.
+void flat_records(const cx_handle *h, const rs::Plan &P, std::vector<int32_t> &flat) {
+    constexpr int32_t kSumToFactor = 1, kSumToMarginal = 2, kSumToGamma = 3, kSumToProduct = 4, kRule = 5, kGeneric = 6, kCheckObserved = 0x80;
+    const int64_t n = (int64_t)P.rec.size() / 5;
+    flat.assign((size_t)8 * n, 0);
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t *r = &P.rec[5 * i];
+        int32_t *o = &flat[8 * i];
+        o[0] = kGeneric; o[1] = (int32_t)i;
+        const int32_t kind = r[0];
+        if (kind == CX_ITEM_MESSAGE_TO_FACTOR || kind == CX_ITEM_INDIVIDUAL_MARGINAL) {
+            const int32_t v = r[2], deg = h->var_off[v + 1] - h->var_off[v], b = h->vbase[v];
+            const int32_t stride = ((h->vinfo[v] & cx::kDegMask) == cx::kBigDeg) ? 1 : cx::kBlock;
+            if (kind == CX_ITEM_INDIVIDUAL_MARGINAL) {
+                if (deg < 1 || deg > 5) continue;
+                o[0] = kSumToMarginal | (deg << 8); o[1] = v; o[2] = v;
+                for (int32_t j = 0; j < deg; j++) o[3 + j] = b + j * stride;
+            } else {
+                if (deg < 2 || deg > 6) continue;
+                const int32_t k = (r[1] - b) / stride;
+                int32_t m = 0;
+                for (int32_t j = 0; j < deg; j++) if (j != k) o[3 + m++] = b + j * stride;      // ascending: the reference's fold over the other messages
+                o[0] = kSumToFactor | kCheckObserved | (m << 8); o[1] = r[1]; o[2] = v;
+            }
+        } else if (kind == CX_ITEM_MESSAGE_TO_VARIABLE) {
+            const int32_t p = h->partner[r[1]];
+            if (p < 0) continue;
+            o[0] = kRule | (1 << 8); o[1] = r[1]; o[2] = r[2]; o[3] = p;
+        } else if ((kind == rs::kItemSumToFactor || kind == rs::kItemSumToMarginal || kind == rs::kItemSumToProduct || kind == rs::kItemSumToGammaMarginal) && r[4] >= 1 && r[4] <= 5) {
+            o[0] = (kind == rs::kItemSumToFactor ? kSumToFactor : kind == rs::kItemSumToMarginal ? kSumToMarginal : kind == rs::kItemSumToProduct ? kSumToProduct : kSumToGamma) | (r[4] << 8);
+            o[1] = r[1]; o[2] = r[2];
+            for (int32_t j = 0; j < r[4]; j++) o[3 + j] = P.list[r[3] + j];
+        }
+    }
 }
 
 rs::State &writable(RefSched *R) {
     R->touched = true;
-    if (R->S.use_count() > 1) R->S = std::make_shared<rs::State>(*R->S);      // a cached plan still names this state as its result
+    if (R->S.use_count() > 1) {      // a cached plan still names this state as its result
+        std::shared_ptr<rs::State> n = (R->spare && R->spare.use_count() == 1) ? std::move(R->spare) : std::make_shared<rs::State>();
+        R->spare.reset();
+        *n = *R->S;                  // (vector assignment: the spare's storage is reused)
+        R->S = std::move(n);
+    }
     return *R->S;
 }
 
@@ -76,7 +132,35 @@ int64_t issue(cx_handle *h, RefSched *R, const PlanEntry &e, bool count_only) {
     return launches;
 }
 
-void run_entry(cx_handle *h, RefSched *R, PlanEntry &e) {
+int32_t run_entry(cx_handle *h, RefSched *R, PlanEntry &e) {
+    if (e.cluster && R->cluster_on && !h->profiling) {
+        h->d_ref_list = e.d_list;
+        // stages wider than the whole chip is (the first two of a grid's plan: every prior's message at once) leave as ordinary launches
+        // on all eight XCDs; the runs of stages between them go to the cluster, one launch per run
+        const int64_t ns = (int64_t)e.stage_off.size() - 1;
+        e.launches = 0;
+        for (int64_t s = 0; s < ns;) {
+            const int64_t w = e.stage_off[s + 1] - e.stage_off[s];
+            e.launches++;
+            if (w > R->cluster_max_items) { cx::launch_batch(h, e.d_rec + 5 * e.stage_off[s], w); s++; continue; }
+            int64_t t = s;
+            while (t < ns && e.stage_off[t + 1] - e.stage_off[t] <= R->cluster_max_items) t++;
+            cx::launch_ref_cluster(h, R->d_ctl, R->n_cu, e.d_flat, e.d_rec, e.d_stage_off + s, (int)(t - s));
+            // the members' waits are bounded; a call whose cluster gave up has computed part of its stages and cannot be repeated (the items
+            // overwrite their inputs' neighbours in place): it fails, loudly, and the handle goes back to plain launches
+            unsigned ctl[16] = {0};
+            CX_HIP(h, hipGetLastError());
+            CX_HIP(h, hipMemcpyAsync(ctl, R->d_ctl, sizeof(ctl), hipMemcpyDeviceToHost, h->stream));
+            CX_HIP(h, hipStreamSynchronize(h->stream));
+            if (ctl[4] || ctl[1] == 0) {
+                R->cluster_on = false;
+                return fail(h, CX_ERR_DEVICE, "reference schedule: a barrier of the XCD-resident cluster timed out (" + std::to_string(ctl[1]) + " member workgroups of " + std::to_string(ctl[0]) +
+                                              " registered); the call is incomplete — restore a checkpoint or set the messages again; further calls use plain launches");
+            }
+            s = t;
+        }
+        return CX_OK;
+    }
     static const bool graphs = [] { const char *v = std::getenv("CX_REF_GRAPH"); return !(v && v[0] == '0'); }();
     if (graphs && !e.graph_failed && !h->profiling && !e.exec && e.launches > 1) {
         hipError_t er = hipSuccess;
@@ -95,11 +179,12 @@ void run_entry(cx_handle *h, RefSched *R, PlanEntry &e) {
         if (er != hipSuccess || !e.exec) { (void)hipGetLastError(); e.exec = nullptr; e.graph_failed = true; }
     }
     if (e.exec && !h->profiling) {
-        if (hipGraphLaunch(e.exec, h->stream) == hipSuccess) return;
+        if (hipGraphLaunch(e.exec, h->stream) == hipSuccess) return CX_OK;
         (void)hipGetLastError();
         (void)hipGraphExecDestroy(e.exec); e.exec = nullptr; e.graph_failed = true;
     }
     (void)issue(h, R, e, false);
+    return CX_OK;
 }
 
 }  // namespace
@@ -110,6 +195,7 @@ void ref_free(cx_handle *h) {
     RefSched *R = ref_of(h);
     if (!R) return;
     for (auto &e : R->cache) entry_free(h, e);
+    if (R->d_ctl) (void)hipFree(R->d_ctl);
     delete R;
     h->ref = nullptr; h->d_ref_list = nullptr;
 }
@@ -154,6 +240,13 @@ int32_t ref_build(cx_handle *h) {
     rs::init_state(R->W, *R->S);
     { const int32_t rp = register_stores(h, R.get()); if (rp != CX_OK) return rp; }
     if (const char *v = std::getenv("CX_REF_CACHE")) R->max_entries = std::max(1, std::atoi(v));
+    if (const char *v = std::getenv("CX_REF_CLUSTER")) R->cluster_on = !(v[0] == '0');
+    if (const char *v = std::getenv("CX_REF_CLUSTER_MIN")) R->cluster_min_items = std::max<int64_t>(0, std::atoll(v));
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) R->n_cu = cus;
+        if (R->n_cu <= 0 || hipMalloc(&R->d_ctl, 64) != hipSuccess) { (void)hipGetLastError(); R->d_ctl = nullptr; R->cluster_on = false; }
+    }
     if (const char *v = std::getenv("CX_REF_CACHE_MB")) R->max_bytes = std::max<int64_t>(1, std::atoll(v)) << 20;
     if (const char *v = std::getenv("CX_REF_RUN_MAX")) R->run_max = std::max(0, std::atoi(v));
     h->ref = R.release();
@@ -247,12 +340,17 @@ void ref_on_batch(cx_handle *h, const cx_item *items, int64_t n) {
     }
 }
 
-// ONE update_marginals!(engine, request): req = local variable numbers in request order
-int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n) {
-    RefSched *R = ref_of(h);
-    CX_REQUIRE(h, R, CX_ERR_STATE, "reference schedule: no wiring (cx_graph_create builds it)");
+static uint64_t request_key(const int32_t *req, int64_t n) {
     uint64_t rk = rs::mix64((uint64_t)n);
     for (int64_t i = 0; i < n; i++) rk = rs::mix64(rk ^ (uint64_t)(uint32_t)req[i]);
+    return rk;
+}
+
+// ONE update_marginals!(engine, request): req = local variable numbers in request order; key: request_key(req, n) when the caller has it
+int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n, const uint64_t *key_known) {
+    RefSched *R = ref_of(h);
+    CX_REQUIRE(h, R, CX_ERR_STATE, "reference schedule: no wiring (cx_graph_create builds it)");
+    const uint64_t rk = key_known ? *key_known : request_key(req, n);
     const uint64_t key = R->S->hash;
     int hit = -1;
     for (size_t i = 0; i < R->cache.size(); i++) if (R->cache[i].key == key && R->cache[i].req_key == rk) { hit = (int)i; break; }
@@ -267,7 +365,7 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n) {
             std::string err;
             const int32_t rc = rs::level(h, R->W, call, [&](int64_t i) { return R->prod_slot[i]; }, [&](int64_t f) { return R->joint_slot[f]; }, P, err);
             if (rc != CX_OK) return fail(h, rc, err);
-            const int64_t incoming = (int64_t)(P.rec.size() + P.list.size() + P.wide_rec.size()) * 4 + (int64_t)P.stage_off.size() * 8;
+            const int64_t incoming = (int64_t)(P.rec.size() + P.list.size() + P.wide_rec.size() + P.rec.size() / 5 * 8) * 4 + (int64_t)P.stage_off.size() * 8;
             auto kept_bytes = [&] { int64_t b = 0; for (auto &c : R->cache) b += c.device_bytes; return b; };
             while (!R->cache.empty() && ((int)R->cache.size() >= R->max_entries || kept_bytes() + incoming > R->max_bytes)) {      // least recently used out
                 size_t lru = 0;
@@ -280,10 +378,17 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n) {
             e.key = key; e.req_key = rk;
             e.stage_off = P.stage_off; e.wide_off = P.wide_off;
             e.n_messages = P.n_messages; e.n_marginals = P.n_marginals; e.n_products = P.n_products; e.rounds = P.rounds; e.list_entries = (int64_t)P.list.size();
+            {   // wide and deep: the cluster; chains of thin stages stay with one workgroup's runs (k_batch_run), short plans with plain launches
+                const int64_t ns = (int64_t)P.stage_off.size() - 1, items = ns > 0 ? P.stage_off[ns] : 0;
+                e.cluster = R->d_ctl && R->cluster_on && P.wide_rec.empty() && ns >= 8 && items >= R->cluster_min_items * ns && h->nslots * 16 < ((int64_t)1 << 31) &&
+                            h->nv * 16 < ((int64_t)1 << 31) && (int64_t)h->prod_index.size() * 16 < ((int64_t)1 << 31);
+            }
+            std::vector<int32_t> flat;
+            if (e.cluster) flat_records(h, P, flat);
             const int64_t before = h->device_bytes;
             int32_t rc2;
             if ((rc2 = dev_upload(h, &e.d_rec, P.rec)) != CX_OK || (rc2 = dev_upload(h, &e.d_list, P.list)) != CX_OK || (rc2 = dev_upload(h, &e.d_stage_off, P.stage_off)) != CX_OK ||
-                (rc2 = dev_upload(h, &e.d_wide_rec, P.wide_rec)) != CX_OK) {
+                (rc2 = dev_upload(h, &e.d_wide_rec, P.wide_rec)) != CX_OK || (e.cluster && (rc2 = dev_upload(h, &e.d_flat, flat)) != CX_OK)) {
                 e.device_bytes = h->device_bytes - before; entry_free(h, e); return rc2;
             }
             e.device_bytes = h->device_bytes - before;
@@ -291,19 +396,28 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n) {
             e.post = T;
             e.order = std::move(call.order);
             e.launches = issue(h, R, e, true);
+            if (e.cluster) e.launches = 1;
             R->cache.push_back(std::move(e));
             hit = (int)R->cache.size() - 1;
             R->misses++;
         } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "reference schedule: host allocation failed"); }
     } else R->hits++;
+    static const bool timing = std::getenv("CX_REF_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     R->touched = true;
     PlanEntry &e = R->cache[hit];
     e.last_used = ++R->tick;
     R->last = hit;
     { const int32_t rc = cx::kary_upload(h); if (rc != CX_OK) return rc; }
-    run_entry(h, R, e);
+    { const int32_t rc = run_entry(h, R, e); if (rc != CX_OK) return rc; }
     CX_HIP(h, hipGetLastError());
+    const auto t1 = std::chrono::steady_clock::now();
+    if (R->S.use_count() == 1 && R->S != e.post) R->spare = std::move(R->S);      // nobody else holds the state this call started from: its storage serves the next writer
     R->S = std::const_pointer_cast<rs::State>(e.post);      // shared: the next writer copies
+    if (timing) {
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ref] run %.3f ms, adopt state %.3f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
+    }
     h->sweeps_done++;
     h->v2f_stale = false;
     return CX_OK;
@@ -311,9 +425,15 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n) {
 
 // the request of a plain cx_sweep: every variable that is neither observed nor a stand-in, ascending id
 int32_t ref_sweep_all(cx_handle *h, int32_t n_sweeps) {
-    std::vector<int32_t> req;
-    for (int64_t v = 0; v < h->nv; v++) if (!(h->vinfo[v] & (cx::kClamped | cx::kGhost))) req.push_back((int32_t)v);
-    for (int32_t s = 0; s < n_sweeps; s++) { const int32_t rc = ref_sweep(h, req.data(), (int64_t)req.size()); if (rc != CX_OK) return rc; }
+    RefSched *R = ref_of(h);
+    CX_REQUIRE(h, R, CX_ERR_STATE, "reference schedule: no wiring (cx_graph_create builds it)");
+    if (R->all_epoch != h->vinfo_epoch) {
+        R->all_req.clear();
+        for (int64_t v = 0; v < h->nv; v++) if (!(h->vinfo[v] & (cx::kClamped | cx::kGhost))) R->all_req.push_back((int32_t)v);
+        R->all_key = request_key(R->all_req.data(), (int64_t)R->all_req.size());
+        R->all_epoch = h->vinfo_epoch;
+    }
+    for (int32_t s = 0; s < n_sweeps; s++) { const int32_t rc = ref_sweep(h, R->all_req.data(), (int64_t)R->all_req.size(), &R->all_key); if (rc != CX_OK) return rc; }
     return CX_OK;
 }
 
@@ -361,7 +481,7 @@ int32_t cx_sweep_for(cx_handle *h, int64_t n, const int64_t *variable_ids) {
             if (v < 0) return fail(h, CX_ERR_NOT_FOUND, "unknown variable id " + std::to_string(variable_ids[i]));
             req[i] = (int32_t)v;
         }
-        return ref_sweep(h, req.data(), n);
+        return ref_sweep(h, req.data(), n, nullptr);
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_sweep_for: host allocation failed"); }
 }
 

@@ -174,7 +174,7 @@ int32_t cx_state_import(cx_handle *h, const void *buf, int64_t bytes) {
     o = (const char *)buf + sizeof hd;
     for (auto &p : parts) {
         o += sizeof(StateSection);
-        if (p.id == 1) std::memcpy(h->vinfo.data(), o, (size_t)p.bytes);
+        if (p.id == 1) { std::memcpy(h->vinfo.data(), o, (size_t)p.bytes); h->vinfo_epoch++; }
         if (p.bytes && p.dev) CX_HIP(h, hipMemcpy(p.dev, o, (size_t)p.bytes, hipMemcpyHostToDevice));
         else if (p.bytes && p.id == 7) CX_REQUIRE(h, ref_state_read(h, o, p.bytes), CX_ERR_INVALID_ARGUMENT, "cx_state_import: the readiness section does not fit this handle's wiring");
         o += p.bytes;

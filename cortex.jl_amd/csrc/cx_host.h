@@ -166,7 +166,7 @@ void ref_graphs_drop(cx_handle *h);
 void ref_on_set(cx_handle *h, int64_t n, const int64_t *edges, int32_t direction);
 void ref_on_seed(cx_handle *h, int32_t direction);
 void ref_on_batch(cx_handle *h, const cx_item *items, int64_t n);
-int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n);
+int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n, const uint64_t *key_known = nullptr);
 int32_t ref_sweep_all(cx_handle *h, int32_t n_sweeps);
 int64_t ref_state_bytes(cx_handle *h);
 void ref_state_write(cx_handle *h, char *out);

@@ -195,6 +195,7 @@ struct cx_handle {
     int ipc_quiet_lo = 1, ipc_quiet_hi = 0;   // the longest run of owned-only slices none of whose variables WRITES a message of the send list
                                               // (cx_halo_ipc_batch: that run of the last sweep is computed after the push); empty: none
     double damping = 0.0;            // cx_set_damping: new = (1 - damping) rule + damping old (fused and flooding sweeps)
+    uint64_t vinfo_epoch = 0;        // bumped whenever the observed flags of vinfo change (a cached "every free variable" request is then stale)
     bool in_sweep = false;
     bool v2f_stale = false;          // fused schedule without materialisation: v2f must be recomputed before use
     int mv_max_deg = 0;              // dim 2..4: widest slice of the graph (0: not computed yet)
@@ -263,6 +264,7 @@ void launch_push_slots(cx_handle *h, const int32_t *d_slots, int64_t n, double2 
 void launch_halo_export(cx_handle *h, const double2 *f2v, hipStream_t stream);
 void launch_halo_import(cx_handle *h, double2 *f2v_out, bool push);
 void launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n);
+void launch_ref_cluster(cx_handle *h, void *d_ctl, int n_workgroups, const int32_t *d_flat, const int32_t *d_rec, const int64_t *d_stage_off, int n_stages);   // all stages behind single-XCD barriers; ctl[4] != 0 afterwards: a wait timed out
 void launch_wide_sum(cx_handle *h, const int32_t *d_rec, int64_t n);   // reference plans: list items of more than cx::refsched::kWideList sources, a workgroup each
 void launch_batch_run(cx_handle *h, const int32_t *d_rec, const int64_t *d_stage_off, int s0, int s1);   // consecutive thin stages (<= 1024 items each) in one launch
 constexpr int kSmallBatch = 48;                        // items whose records (5 int32 each) ride in the kernel arguments

@@ -305,6 +305,7 @@ __global__ __launch_bounds__(kBlock) void k_push_slots(const int32_t *__restrict
 }
 
 // variable→factor for one slot of variable v (sequential sums in the order of the sweep kernel)
+template <bool COH = false>
 __device__ __forceinline__ void m2f_one(int slot, int v, const int32_t *vbase, const int32_t *vdeg, const uint8_t *vinfo,
                                         const double2 *f2v, double2 *v2f) {
     const int info = vinfo[v];
@@ -314,8 +315,8 @@ __device__ __forceinline__ void m2f_one(int slot, int v, const int32_t *vbase, c
     const int b = vbase[v];
     const int k = (slot - b) / stride;
     double2 pre = zero2(), suf = zero2();
-    for (int j = 0; j < k; j++) pre = add2(pre, f2v[b + j * stride]);
-    for (int j = deg - 1; j > k; j--) suf = add2(suf, f2v[b + j * stride]);
+    for (int j = 0; j < k; j++) pre = add2(pre, ld2<COH>(f2v, b + j * stride));
+    for (int j = deg - 1; j > k; j--) suf = add2(suf, ld2<COH>(f2v, b + j * stride));
     const double2 o = add2(pre, suf);
     if (!__builtin_isnan(o.y)) v2f[slot] = o;
 }
@@ -380,26 +381,27 @@ constexpr int kItemSumToFactor = 64, kItemSumToProduct = 65, kItemSumToMarginal 
 // the marginal store: (mean, variance) of a Normal variable ((datum, 0) when observed), (shape, scale) of a precision — 72 stores the
 // latter from the natural-parameter sum (shape - 1, rate).  A message to a precision is Gamma(3/2, 2 / spread) = natural (1/2, spread / 2).
 constexpr int kItemMfNormal = 67, kItemMfGamma = 68, kItemStNormal = 69, kItemVmpJoint = 70, kItemStGamma = 71, kItemSumToGammaMarginal = 72;
+template <bool COH>
 __device__ __forceinline__ void vmp_item(int k, int idx, int lo, const int32_t *__restrict__ list, double2 *__restrict__ f2v, const double2 *__restrict__ v2f,
                                          const double2 *__restrict__ marg, double *__restrict__ joint) {
     const double inf = __builtin_inf();
     if (k == kItemMfNormal) {                 // N(E[other], E[precision])                                                        (:654-664)
-        const double2 a = marg[list[lo]], g = marg[list[lo + 1]];
+        const double2 a = ld2<COH>(marg, list[lo]), g = ld2<COH>(marg, list[lo + 1]);
         const double eg = g.x * g.y;
         if (!__builtin_isnan(a.x) && !__builtin_isnan(eg)) f2v[idx] = make_double2(a.x * eg, eg);
     } else if (k == kItemMfGamma) {           // Gamma(3/2, 2 / (var a + var b + (E a - E b)^2))                                  (:666-684)
-        const double2 a = marg[list[lo]], b = marg[list[lo + 1]];
+        const double2 a = ld2<COH>(marg, list[lo]), b = ld2<COH>(marg, list[lo + 1]);
         const double d = a.x - b.x, spread = a.y + b.y + d * d;
         if (!__builtin_isnan(spread)) f2v[idx] = make_double2(0.5, 0.5 * spread);
     } else if (k == kItemStNormal) {          // N(mean m, 1 / (var m + 1 / E[precision])), m the other Normal variable's message    (:1004-1010)
-        const double2 m = v2f[list[lo]], g = marg[list[lo + 1]];
+        const double2 m = ld2<COH>(v2f, list[lo]), g = ld2<COH>(marg, list[lo + 1]);
         const double eg = g.x * g.y;
         if (__builtin_isnan(m.y) || __builtin_isnan(m.x) || __builtin_isnan(eg)) return;
         const double mean = m.y == inf ? m.x : m.x / m.y, var = m.y == inf ? 0.0 : 1.0 / m.y;
         const double w = 1.0 / (var + 1.0 / eg);
         f2v[idx] = make_double2(mean * w, w);
     } else if (k == kItemVmpJoint) {          // the 2-d Gaussian with precision [[w1 + E, -E], [-E, w2 + E]] and potential (xi1, xi2)  (:939-967)
-        const double2 m1 = v2f[list[lo]], m2 = v2f[list[lo + 1]], g = marg[list[lo + 2]];
+        const double2 m1 = ld2<COH>(v2f, list[lo]), m2 = ld2<COH>(v2f, list[lo + 1]), g = ld2<COH>(marg, list[lo + 2]);
         const double eg = g.x * g.y;
         if (__builtin_isnan(m1.y) || __builtin_isnan(m1.x) || __builtin_isnan(m2.y) || __builtin_isnan(m2.x) || __builtin_isnan(eg)) return;
         double mu1, mu2, v11, v12, v22;
@@ -414,12 +416,13 @@ __device__ __forceinline__ void vmp_item(int k, int idx, int lo, const int32_t *
         double *o = joint + 6 * (int64_t)idx;
         o[0] = mu1; o[1] = mu2; o[2] = v11; o[3] = v12; o[4] = v12; o[5] = v22;
     } else {                                  // kItemStGamma: Gamma(3/2, 2 / (V11 - 2 V12 + V22 + (m1 - m2)^2)) from the joint          (:1011-1016)
-        const double *o = joint + 6 * (int64_t)list[lo];
-        const double d = o[0] - o[1], spread = o[2] - o[3] - o[4] + o[5] + d * d;
+        const int jb = 6 * list[lo];
+        const double o0 = ld1<COH>(joint, jb), o1 = ld1<COH>(joint, jb + 1), o2 = ld1<COH>(joint, jb + 2), o3 = ld1<COH>(joint, jb + 3), o4 = ld1<COH>(joint, jb + 4), o5 = ld1<COH>(joint, jb + 5);
+        const double d = o0 - o1, spread = o2 - o3 - o4 + o5 + d * d;
         if (!__builtin_isnan(spread)) f2v[idx] = make_double2(0.5, 0.5 * spread);
     }
 }
-template <int MODE>
+template <int MODE, bool COH = false>
 __device__ __forceinline__ void batch_item(int k, int idx, int v, int lo, int hi, const int32_t *__restrict__ vbase,
                                            const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
                                            const int32_t *__restrict__ partner, const double *__restrict__ q,
@@ -427,21 +430,21 @@ __device__ __forceinline__ void batch_item(int k, int idx, int v, int lo, int hi
                                            double2 *__restrict__ f2v, double2 *__restrict__ v2f, double2 *__restrict__ marg, int nat_marg,
                                            double2 *__restrict__ prod, double *__restrict__ joint, const KaryTab kt) {
     if (k == kItemKaryEntry) {            // internal (the tree schedule's stage lists): index = entry of the k-ary table
-        kary_item(idx, kt.slot, kt.coef, kt.qb, v2f, f2v);
+        kary_item<COH>(idx, kt.slot, kt.coef, kt.qb, v2f, f2v);
     } else if (k >= kItemMfNormal && k <= kItemStGamma) {
-        vmp_item(k, idx, lo, kt.list, f2v, v2f, marg, joint);
+        vmp_item<COH>(k, idx, lo, kt.list, f2v, v2f, marg, joint);
     } else if (k >= kItemSumToFactor) {   // internal (reference-order plans)
         double2 acc = zero2();
-        for (int j = 0; j < hi; j++) { const int s = kt.list[lo + j]; acc = add2(acc, s >= 0 ? f2v[s] : prod[~s]); }
+        for (int j = 0; j < hi; j++) { const int s = kt.list[lo + j]; acc = add2(acc, s >= 0 ? ld2<COH>(f2v, s) : ld2<COH>(prod, ~s)); }
         if (k == kItemSumToMarginal) marg[v] = nat_marg ? acc : to_moment(acc);
         else if (k == kItemSumToGammaMarginal) marg[v] = make_double2(acc.x + 1.0, 1.0 / acc.y);
         else if (!__builtin_isnan(acc.y)) { if (k == kItemSumToFactor) v2f[idx] = acc; else prod[idx] = acc; }
     } else if (k == CX_ITEM_MESSAGE_TO_FACTOR) {
-        m2f_one(idx, v, vbase, vdeg, vinfo, f2v, v2f);
+        m2f_one<COH>(idx, v, vbase, vdeg, vinfo, f2v, v2f);
     } else if (k == CX_ITEM_MESSAGE_TO_VARIABLE) {
         const int p = partner[idx];
         if (p < 0) return;
-        const double2 m = v2f[p];
+        const double2 m = ld2<COH>(v2f, p);
         if (__builtin_isnan(m.y)) return;
         const double2 r = factor_rule<MODE>(m, q[idx], MODE == kRuleLinear ? pa[idx] : 1.0, MODE == kRuleLinear ? pb[idx] : 0.0);
         if (MODE != kRuleBernoulli || !__builtin_isnan(r.y)) f2v[idx] = r;
@@ -450,18 +453,18 @@ __device__ __forceinline__ void batch_item(int k, int idx, int v, int lo, int hi
         const int stride = ((vinfo[v] & kDegMask) == kBigDeg) ? 1 : kBlock;
         const int b = vbase[v];
         double2 acc = zero2();
-        for (int j = 0; j < deg; j++) acc = add2(acc, f2v[b + j * stride]);
+        for (int j = 0; j < deg; j++) acc = add2(acc, ld2<COH>(f2v, b + j * stride));
         marg[v] = (deg > 0) ? (nat_marg ? acc : to_moment(acc)) : nan2();
     } else if (k == CX_ITEM_PRODUCT_OF_MESSAGES) {
         const int stride = ((vinfo[v] & kDegMask) == kBigDeg) ? 1 : kBlock;
         const int b = vbase[v];
         double2 acc = zero2();
-        for (int j = lo - 1; j < hi; j++) acc = add2(acc, f2v[b + j * stride]);
+        for (int j = lo - 1; j < hi; j++) acc = add2(acc, ld2<COH>(f2v, b + j * stride));
         if (!__builtin_isnan(acc.y)) prod[idx] = acc;     // a dependency is undefined: not pending, keep the stored value
     } else if (k == CX_ITEM_JOINT_MARGINAL) {
         if (MODE == kRuleBernoulli) return;
         const int s_out = v, s_in = lo;
-        const double2 m_in = v2f[s_in], m_out = v2f[s_out];
+        const double2 m_in = ld2<COH>(v2f, s_in), m_out = ld2<COH>(v2f, s_out);
         double *o = joint + 6 * (int64_t)idx;
         if (__builtin_isnan(m_in.y) || __builtin_isnan(m_out.y)) return;
         const double a = MODE == kRuleLinear ? pa[s_out] : 1.0, b = MODE == kRuleLinear ? pb[s_out] : 0.0, iq = 1.0 / q[s_out];
@@ -519,6 +522,186 @@ __global__ __launch_bounds__(kRunBlock) void k_batch_run(const int64_t *__restri
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+// ---- an XCD-resident cluster: the stages of a reference-order plan behind barriers that never leave one L2 -------------------------------
+// A reference-order call on a loopy graph is thousands of DEPENDENT stages of a few thousand items (C4: 5,659 stages, 18 M items).  As
+// launches a stage costs ≈ 9 us (launch latency + three dependent memory round trips); a device-wide barrier costs 19 us and more, because
+// the eight XCDs keep separate L2s and an agent-scope release / acquire writes them back and invalidates them (profiles/r04_grid_barrier.txt).
+// The workgroups of ONE XCD share one L2: a store is written through the compute unit's vector cache to it, a load that bypasses the vector
+// cache (ld2<true>: a 16-byte buffer load with scope bit sc1) reads from it, and nothing is written back or invalidated in between — a barrier among them is one
+// counter in that L2: 0.75 us bare, 1.5 us with every thread passing a value to a thread of another workgroup (tools/lab/xcd_barrier.hip,
+// profiles/r05_xcd_barrier.txt: 32 workgroups x 1,024 threads, no wrong value in 2,000 rounds).  So ONE launch of (compute units) workgroups:
+// those that find themselves on XCD 0 (hardware XCC_ID) form the cluster — 32 x 1,024 threads, an eighth of the chip, which is more than
+// a stage is wide — the others leave at once; the members take the plan's stages one after the other, items dealt in runs of 1,024, with
+// that barrier in between.  Values are loaded coherently (batch_item<MODE, true>), plan records and graph constants as always.  Every wait
+// is bounded: a member that gives up raises a flag that all members see and the host checks (cx_api_ref.hip: the call then fails loudly).
+struct ClusterCtl { unsigned registered, members, rank_next, arrive, abort_, xcd_plus_1, pad[10]; };      // 64 B, zeroed before every launch
+
+__device__ __forceinline__ unsigned hw_xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(v));      // HW_REG_XCC_ID
+    return v & 7u;
+}
+__device__ __forceinline__ bool cluster_wait(unsigned *p, unsigned target, unsigned *abort_) {
+    for (unsigned spins = 0;; spins++) {
+        if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        if (spins > (1u << 24)) { __hip_atomic_store(abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }      // seconds
+        if ((spins & 63u) == 63u && __hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    }
+}
+constexpr int kClusterBlock = 1024;
+// What a member does per stage is a chain of dependent round trips to the L2: stage table -> record -> graph tables (degree, base slot,
+// partner) -> values -> store -> barrier.  The first three are known when the plan is made, so the cluster runs FLAT records (cx_api_ref.hip:
+// flat_records, 8 ints): kind | n << 8, destination, variable, five sources resolved to slots (>= 0: a factor→variable slot — the
+// variable→factor slot for a rule —, ~index: a node of the product store).  All sources of an item are loaded together (a source that is
+// not there reads past the end of the buffer: zero, no traffic), and a thread fetches its record of the NEXT stage before it waits at the
+// barrier: value loads -> store -> barrier is what is left on the chain.  kFlatGeneric: the item's ordinary record (five ints at index
+// `destination`) through batch_item — rules of factors with more than two edges, the variational rules, sums of more than five sources.
+constexpr int kFlatSumToFactor = 1, kFlatSumToMarginal = 2, kFlatSumToGamma = 3, kFlatSumToProduct = 4, kFlatRule = 5, kFlatGeneric = 6;
+constexpr int kFlatCheckObserved = 0x80;      // MessageToFactor of the compact form: not recomputed for an observed / stand-in variable (m2f_one)
+struct FlatRec { int32_t k, dst, v, s[5]; };
+
+template <int MODE>
+__device__ __forceinline__ void flat_item(const FlatRec r, const int32_t *__restrict__ rec, const int32_t *__restrict__ vbase, const int32_t *__restrict__ vdeg,
+                                          const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner, const double *__restrict__ q,
+                                          const double *__restrict__ pa, const double *__restrict__ pb, double2 *f2v, double2 *v2f, double2 *marg, int nat_marg,
+                                          double2 *prod, double *joint, const KaryTab kt) {
+    const int kind = r.k & 0x7f, n = r.k >> 8;
+    if (kind == kFlatGeneric) {
+        const int32_t *g = rec + 5 * (int64_t)r.dst;
+        batch_item<MODE, true>(g[0], g[1], g[2], g[3], g[4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+        return;
+    }
+    if (kind == kFlatRule) {
+        const double2 m = ld2<true>(v2f, r.s[0]);
+        const double qq = q[r.dst], a = MODE == kRuleLinear ? pa[r.dst] : 1.0, b = MODE == kRuleLinear ? pb[r.dst] : 0.0;
+        if (__builtin_isnan(m.y)) return;
+        const double2 o = factor_rule<MODE>(m, qq, a, b);
+        if (MODE != kRuleBernoulli || !__builtin_isnan(o.y)) f2v[r.dst] = o;
+        return;
+    }
+    const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)f2v, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)prod, 0, 0x7fffffff, 0x00020000);
+    const int info = (r.k & kFlatCheckObserved) ? vinfo[r.v] : 0;
+    cx_d2v val[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int sj = r.s[j];
+        const bool on = j < n;
+        // (an offset of -1 is past the end of the 2 GiB window: the load returns zero and moves nothing)
+        const cx_d2v a = __builtin_bit_cast(cx_d2v, __builtin_amdgcn_raw_buffer_load_b128(rf, (on && sj >= 0) ? sj * 16 : -1, 0, 16));
+        const cx_d2v b = __builtin_bit_cast(cx_d2v, __builtin_amdgcn_raw_buffer_load_b128(rp, (on && sj < 0) ? (~sj) * 16 : -1, 0, 16));
+        val[j] = a + b;
+    }
+    double2 acc = zero2();      // left to right, like the reference's fold
+#pragma unroll
+    for (int j = 0; j < 5; j++) if (j < n) acc = make_double2(acc.x + val[j][0], acc.y + val[j][1]);
+    if (kind == kFlatSumToMarginal) marg[r.dst] = nat_marg ? acc : to_moment(acc);
+    else if (kind == kFlatSumToGamma) marg[r.dst] = make_double2(acc.x + 1.0, 1.0 / acc.y);
+    else if (!__builtin_isnan(acc.y) && !(info & (kClamped | kGhost))) { if (kind == kFlatSumToFactor) v2f[r.dst] = acc; else prod[r.dst] = acc; }
+}
+
+__device__ __forceinline__ FlatRec flat_load(const int32_t *__restrict__ flat, int64_t i) {
+    const int4 a = *(const int4 *)(flat + 8 * i), b = *(const int4 *)(flat + 8 * i + 4);
+    FlatRec r;
+    r.k = a.x; r.dst = a.y; r.v = a.z; r.s[0] = a.w; r.s[1] = b.x; r.s[2] = b.y; r.s[3] = b.z; r.s[4] = b.w;
+    return r;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, unsigned G, const int64_t *__restrict__ stage_off, int n_stages,
+                                                               const int32_t *__restrict__ flat, const int32_t *__restrict__ rec, const int32_t *__restrict__ vbase,
+                                                               const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
+                                                               const double *__restrict__ q, const double *__restrict__ pa, const double *__restrict__ pb, double2 *f2v,
+                                                               double2 *v2f, double2 *marg, int nat_marg, double2 *prod, double *joint, const KaryTab kt, int dry) {
+    __shared__ unsigned rank_s, members_s, ok_s, mine_s;
+    if (threadIdx.x == 0) {      // the cluster's XCD is the one of the first workgroup to ask (whatever the partition mode numbers it)
+        const unsigned me = hw_xcc_id() + 1u;
+        unsigned expected = 0u;
+        const bool won = __hip_atomic_compare_exchange_strong(&c->xcd_plus_1, &expected, me, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mine_s = (won || expected == me) ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool mine = mine_s != 0;
+    if (threadIdx.x == 0) {
+        rank_s = mine ? __hip_atomic_fetch_add(&c->rank_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (mine) __hip_atomic_fetch_add(&c->members, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&c->registered, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok_s = 1u;
+        if (mine) {      // once every workgroup of the launch has said where it runs, the membership is final
+            ok_s = cluster_wait(&c->registered, G, &c->abort_) ? 1u : 0u;
+            members_s = __hip_atomic_load(&c->members, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (!mine || !ok_s) return;
+    // Roles.  A stage is rarely wider than a few thousand items, and what a member waits for most is memory it has never touched: the plan's
+    // records (hundreds of MB, read once) and values last written many stages ago.  So half of the cluster's workgroups are HELPERS: they
+    // take no part in the barriers and store nothing; helper j runs ahead of the members through the stages s = j (mod H), loads their
+    // records (help >= 1) and the lines of their sources (help >= 2) — into the L2 the members read from — and never lets anybody wait.
+    const int help = (dry >> 1) & 3, ahead_arg = (dry >> 8) & 0xff, members_arg = (dry >> 16) & 0xff;
+    const int64_t all = members_s, P = help && all >= 4 ? (members_arg && members_arg < all ? members_arg : all / 2) : all, H = all - P;
+    if ((int64_t)rank_s >= P) {
+        const int64_t hj = (int64_t)rank_s - P;
+        const int ahead = ahead_arg ? ahead_arg : (help >= 2 ? 4 : 12);      // stages: the L2 is 4 MB, a stage's sources up to 1 MB of lines, its records 32 B an item
+        unsigned sink = 0;
+        for (int64_t s = 2 + hj; s < n_stages; s += H) {
+            if (threadIdx.x == 0) {
+                unsigned okh = 1u;
+                for (unsigned spins = 0;; spins++) {
+                    const int64_t cur = __hip_atomic_load(&c->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (unsigned)P;
+                    if (s <= cur + ahead) break;
+                    if (spins > (1u << 24) || ((spins & 63u) == 63u && __hip_atomic_load(&c->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { okh = 0u; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                ok_s = okh;
+            }
+            __syncthreads();
+            if (!ok_s) return;
+            for (int64_t i = stage_off[s] + threadIdx.x; i < stage_off[s + 1]; i += kClusterBlock) {
+                const FlatRec r = flat_load(flat, i);
+                sink ^= (unsigned)r.k ^ (unsigned)r.dst;
+                if (help >= 2) {
+                    const int kind = r.k & 0x7f, n = r.k >> 8;
+                    if (kind == kFlatRule) sink ^= (unsigned)__double_as_longlong(ld2<true>(v2f, r.s[0]).y);
+                    else if (kind != kFlatGeneric)
+                        for (int j = 0; j < 5; j++) if (j < n) sink ^= (unsigned)__double_as_longlong((r.s[j] >= 0 ? ld2<true>(f2v, r.s[j]) : ld2<true>(prod, ~r.s[j])).y);
+                }
+            }
+            __syncthreads();
+        }
+        if (sink == 0x9e3779b9u) c->pad[0] = sink;      // (keeps the loads)
+        return;
+    }
+    const int64_t first = (int64_t)rank_s * kClusterBlock + threadIdx.x, step = P * kClusterBlock;
+    int64_t lo = stage_off[0], hi = stage_off[1];
+    FlatRec cur{};
+    bool have = lo + first < hi;
+    if (have) cur = flat_load(flat, lo + first);
+    for (int st = 0; st < n_stages; st++) {
+        // the next stage's bounds and this thread's first record of it: plan constants, on their way while this stage's values are loaded
+        const int64_t nlo = hi, nhi = st + 1 < n_stages ? stage_off[st + 2] : hi;
+        const bool nhave = st + 1 < n_stages && nlo + first < nhi;
+        FlatRec nxt{};
+        if (nhave && !(dry & 8)) nxt = flat_load(flat, nlo + first);      // (bit 3, CX_REF_CLUSTER_DRY=2: not even the records — the bare barriers)
+        if (!(dry & 1)) {      // (CX_REF_CLUSTER_DRY=1: the plan's skeleton — records and barriers, no item — for timing what a stage costs before it computes)
+            if (have) flat_item<MODE>(cur, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+            for (int64_t i = lo + first + step; i < hi; i += step)      // (a stage wider than the cluster)
+                flat_item<MODE>(flat_load(flat, i), rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+        }
+        if (st + 1 == n_stages) break;
+        // the barrier: this thread's stores have reached the L2, the workgroup has arrived, one thread reports and waits for the others
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(&c->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok_s = cluster_wait(&c->arrive, (unsigned)((st + 1) * P), &c->abort_) ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!ok_s) return;
+        lo = nlo; hi = nhi; have = nhave; cur = nxt;
     }
 }
 
@@ -807,6 +990,27 @@ void launch_batch_run(cx_handle *h, const int32_t *d_rec, const int64_t *d_stage
     const KaryTab kt{h->d_kary_slot, h->d_kary_coef, h->d_kary_qb, h->d_ref_list};
 #define CX_B(M, PA, PB) hipLaunchKernelGGL(k_batch_run<M>, dim3(1), dim3(kRunBlock), 0, h->stream, d_stage_off, s0, s1, d_rec, h->d_vbase, h->d_var_deg, h->d_vinfo, \
                                            h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint, kt)
+    if (mode == kRuleLinear) CX_B(kRuleLinear, h->d_a, h->d_b);
+    else if (mode == kRuleBernoulli) CX_B(kRuleBernoulli, (const double *)nullptr, (const double *)nullptr);
+    else CX_B(kRuleAdditive, (const double *)nullptr, (const double *)nullptr);
+#undef CX_B
+}
+
+// every stage of a reference-order plan in ONE launch of an XCD-resident cluster; d_ctl: 64 bytes the launch may scribble on (zeroed here)
+void launch_ref_cluster(cx_handle *h, void *d_ctl, int n_workgroups, const int32_t *d_flat, const int32_t *d_rec, const int64_t *d_stage_off, int n_stages) {
+    if (n_stages <= 0) return;
+    (void)hipMemsetAsync(d_ctl, 0, sizeof(ClusterCtl), h->stream);
+    const int mode = rule_mode(h), nat = h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0;
+    const KaryTab kt{h->d_kary_slot, h->d_kary_coef, h->d_kary_qb, h->d_ref_list};
+    // bit 0: CX_REF_CLUSTER_DRY=1; bits 1..: CX_REF_CLUSTER_HELP = 0 no helpers, 1 helpers load records, 2 (default) records and source lines
+    static const int dry = [] {
+        const char *e = std::getenv("CX_REF_CLUSTER_DRY"), *hp = std::getenv("CX_REF_CLUSTER_HELP");
+        const char *ah = std::getenv("CX_REF_CLUSTER_AHEAD"), *mb = std::getenv("CX_REF_CLUSTER_MEMBERS");      // A/B: stages the helpers run ahead, member workgroups
+        return ((e && (e[0] == '1' || e[0] == '2')) ? 1 : 0) | ((hp ? std::max(0, std::min(2, std::atoi(hp))) : 2) << 1) | ((e && e[0] == '2') ? 8 : 0) |
+               ((ah ? std::max(0, std::min(255, std::atoi(ah))) : 0) << 8) | ((mb ? std::max(0, std::min(255, std::atoi(mb))) : 0) << 16);
+    }();
+#define CX_B(M, PA, PB) hipLaunchKernelGGL(k_ref_cluster<M>, dim3(n_workgroups), dim3(kClusterBlock), 0, h->stream, (ClusterCtl *)d_ctl, (unsigned)n_workgroups, d_stage_off, n_stages, \
+                                           d_flat, d_rec, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint, kt, dry)
     if (mode == kRuleLinear) CX_B(kRuleLinear, h->d_a, h->d_b);
     else if (mode == kRuleBernoulli) CX_B(kRuleBernoulli, (const double *)nullptr, (const double *)nullptr);
     else CX_B(kRuleAdditive, (const double *)nullptr, (const double *)nullptr);
