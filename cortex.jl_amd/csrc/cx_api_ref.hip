@@ -51,7 +51,7 @@ struct RefSched {
     int64_t cluster_max_items = 65536;          // a stage wider than this is a launch of its own on the whole chip
     int64_t cluster_min_items = 128;            // per stage, on average: below that the stages are chains and one workgroup's own barrier is as good
     int64_t max_bytes = (int64_t)4 << 30;       // plans kept: at most max_entries and at most this much device memory (the one in use always stays)
-    int max_entries = 16, run_max = 1024;      // C4, ms per call: every stage a launch 57.6, runs of stages <= 1024 items 52.8, <= 4096 items 102 (one workgroup is slow on a wide stage)
+    int max_entries = 16, run_max = 1024;      // C4 as launches, ms per call: every stage a launch 57.6, runs of stages <= 1024 items 52.8, <= 4096 items 102 (one workgroup is slow on a wide stage)
 };
 
 RefSched *ref_of(cx_handle *h) { return (RefSched *)h->ref; }

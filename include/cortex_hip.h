@@ -156,7 +156,10 @@ extern "C" {
                                  cx_seed_messages (the user's set_value!), cx_update_batch (a plug-in's process!) and the sweeps; a call
                                  runs the reference's scheduler on the shadow, records the executions, levels them (an execution's stage
                                  follows every execution whose result it reads, every reader of the value it overwrites, and its own
-                                 previous one) and replays the stages as item lists in ONE graph launch.  Plans are kept per (readiness
+                                 previous one) and replays the stages as item lists in ONE launch: an XCD-resident cluster — the
+                                 workgroups of one XCD behind barriers that stay in that XCD's L2 — for plans of wide stages (such a call
+                                 returns when it has finished: the host checks that no barrier timed out), a HIP graph of stage launches
+                                 for chains of thin ones (asynchronous).  Plans are kept per (readiness
                                  state at the start of the call, request): the steady state of "set the priors, call" replays a standing
                                  plan.  Lazy like the reference: a call computes what is pending for the requested marginals, nothing
                                  else; priors have to be re-set before a call to be fresh, exactly as there.  On a forest it is the tree

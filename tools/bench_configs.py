@@ -463,7 +463,8 @@ def reference_order(n=1415, calls_timed=5, tol=1e-9, max_calls=400, check=None, 
            "host": {"graph_upload_and_wiring_s": t_load, "first_two_calls_s_scheduler_levelling_upload_capture": plan_s,
                     "re_setting_the_priors_s_per_call": float(np.median(t_set))},
            "roofline": roofline("hbm", st["messages"] * 32 / float(np.median(t_call)) / 1e9, HBM_PEAK_GBS, "GB/s", None,
-                                kernel="k_batch / k_batch_run, one launch per stage or run of thin stages",
+                                kernel="k_ref_cluster: the plan's stages behind single-XCD barriers in one launch (stages wider than 65,536 items: k_batch on the whole chip); "
+                                       "CX_REF_CLUSTER=0: k_batch / k_batch_run, one launch per stage or run of thin stages",
                                 basis="algorithmic bytes (32 B per message, SURVEY §8d) / call time", frac_algorithmic=st["messages"] * 32 / float(np.median(t_call)) / 1e9 / HBM_PEAK_GBS,
                                 frac_note="a latency-bound schedule by construction: the reference's order is sequential, its dependency depth is the stage count",
                                 bound_detail=f"{st['stages']} dependent stages in {st['launches']} launches (≈ {float(np.median(t_call)) / max(st['stages'], 1) * 1e6:.2f} us per stage)")}
