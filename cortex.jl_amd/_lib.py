@@ -76,6 +76,7 @@ SIGNATURES = {
     "cx_sweep": (_i32, [_vp, _i32]),
     "cx_sweep_for": (_i32, [_vp, _i64, _pi64]),
     "cx_set_damping": (_i32, [_vp, _dbl]),
+    "cx_cluster_stats": (_i32, [_vp, _pi64]),
     "cx_graph_wire": (_i32, [_vp, _i64, C.POINTER(Item), C.POINTER(Item), _pi32]),
     "cx_ref_plan_stats": (_i32, [_vp, _pi64]),
     "cx_ref_trace": (_i32, [_vp, _i64, C.POINTER(Item), _pi64]),

@@ -617,7 +617,7 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
         // dim 64 over heavy paths: the plans' device records follow the base pointers (host copies: before, never inside, the capture of
         // the sweep's launches)
         if (!h->tree_c64.empty() && (rc = cx::chain64_tree_resolve(h)) != CX_OK) return rc;
-        for (int32_t s = 0; s < n_sweeps; s++) { tree_sweep(h); h->sweeps_done++; }
+        for (int32_t s = 0; s < n_sweeps; s++) { const int32_t rt = tree_sweep(h); if (rt != CX_OK) return rt; h->sweeps_done++; }
         CX_HIP(h, hipGetLastError());
         return CX_OK;
     }

@@ -45,11 +45,6 @@ struct RefSched {
     uint64_t tick = 0;
     int last = -1;
     bool touched = false;                       // a value was set or a call ran: the wiring can no longer be replaced (cx_graph_wire)
-    void *d_ctl = nullptr;                      // the cluster's control block (64 B)
-    int n_cu = 0;                               // compute units = workgroups of a cluster launch
-    bool cluster_on = true;                     // CX_REF_CLUSTER=0: plain launches (A/B); also off after a cluster wait timed out
-    int64_t cluster_max_items = 65536;          // a stage wider than this is a launch of its own on the whole chip
-    int64_t cluster_min_items = 128;            // per stage, on average: below that the stages are chains and one workgroup's own barrier is as good
     int64_t max_bytes = (int64_t)4 << 30;       // plans kept: at most max_entries and at most this much device memory (the one in use always stays)
     int max_entries = 16, run_max = 1024;      // C4 as launches, ms per call: every stage a launch 57.6, runs of stages <= 1024 items 52.8, <= 4096 items 102 (one workgroup is slow on a wide stage)
 };
@@ -61,45 +56,6 @@ void entry_free(cx_handle *h, PlanEntry &e) {
     for (void *p : {(void *)e.d_rec, (void *)e.d_list, (void *)e.d_stage_off, (void *)e.d_wide_rec, (void *)e.d_flat}) if (p) (void)hipFree(p);
     e.d_rec = e.d_list = e.d_wide_rec = e.d_flat = nullptr; e.d_stage_off = nullptr;
     h->device_bytes -= e.device_bytes; e.device_bytes = 0;
-}
-
-// The records of a plan with everything the graph's tables would answer already filled in (cx_kernels.hip: FlatRec — kind | n << 8,
-// destination, variable, five sources): what the XCD-resident cluster runs, so that an item's chain of dependent loads is its values and
-// nothing else.  Items that do not fit (more than five sources, rules of factors with more than two edges, variational rules) point back
-// at their ordinary record.
-void flat_records(const cx_handle *h, const rs::Plan &P, std::vector<int32_t> &flat) {
-    constexpr int32_t kSumToFactor = 1, kSumToMarginal = 2, kSumToGamma = 3, kSumToProduct = 4, kRule = 5, kGeneric = 6, kCheckObserved = 0x80;
-    const int64_t n = (int64_t)P.rec.size() / 5;
-    flat.assign((size_t)8 * n, 0);
-    for (int64_t i = 0; i < n; i++) {
-        const int32_t *r = &P.rec[5 * i];
-        int32_t *o = &flat[8 * i];
-        o[0] = kGeneric; o[1] = (int32_t)i;
-        const int32_t kind = r[0];
-        if (kind == CX_ITEM_MESSAGE_TO_FACTOR || kind == CX_ITEM_INDIVIDUAL_MARGINAL) {
-            const int32_t v = r[2], deg = h->var_off[v + 1] - h->var_off[v], b = h->vbase[v];
-            const int32_t stride = ((h->vinfo[v] & cx::kDegMask) == cx::kBigDeg) ? 1 : cx::kBlock;
-            if (kind == CX_ITEM_INDIVIDUAL_MARGINAL) {
-                if (deg < 1 || deg > 5) continue;
-                o[0] = kSumToMarginal | (deg << 8); o[1] = v; o[2] = v;
-                for (int32_t j = 0; j < deg; j++) o[3 + j] = b + j * stride;
-            } else {
-                if (deg < 2 || deg > 6) continue;
-                const int32_t k = (r[1] - b) / stride;
-                int32_t m = 0;
-                for (int32_t j = 0; j < deg; j++) if (j != k) o[3 + m++] = b + j * stride;      // ascending: the reference's fold over the other messages
-                o[0] = kSumToFactor | kCheckObserved | (m << 8); o[1] = r[1]; o[2] = v;
-            }
-        } else if (kind == CX_ITEM_MESSAGE_TO_VARIABLE) {
-            const int32_t p = h->partner[r[1]];
-            if (p < 0) continue;
-            o[0] = kRule | (1 << 8); o[1] = r[1]; o[2] = r[2]; o[3] = p;
-        } else if ((kind == rs::kItemSumToFactor || kind == rs::kItemSumToMarginal || kind == rs::kItemSumToProduct || kind == rs::kItemSumToGammaMarginal) && r[4] >= 1 && r[4] <= 5) {
-            o[0] = (kind == rs::kItemSumToFactor ? kSumToFactor : kind == rs::kItemSumToMarginal ? kSumToMarginal : kind == rs::kItemSumToProduct ? kSumToProduct : kSumToGamma) | (r[4] << 8);
-            o[1] = r[1]; o[2] = r[2];
-            for (int32_t j = 0; j < r[4]; j++) o[3 + j] = P.list[r[3] + j];
-        }
-    }
 }
 
 rs::State &writable(RefSched *R) {
@@ -133,33 +89,9 @@ int64_t issue(cx_handle *h, RefSched *R, const PlanEntry &e, bool count_only) {
 }
 
 int32_t run_entry(cx_handle *h, RefSched *R, PlanEntry &e) {
-    if (e.cluster && R->cluster_on && !h->profiling) {
+    if (e.cluster && h->cluster_state > 0 && !h->profiling) {
         h->d_ref_list = e.d_list;
-        // stages wider than the whole chip is (the first two of a grid's plan: every prior's message at once) leave as ordinary launches
-        // on all eight XCDs; the runs of stages between them go to the cluster, one launch per run
-        const int64_t ns = (int64_t)e.stage_off.size() - 1;
-        e.launches = 0;
-        for (int64_t s = 0; s < ns;) {
-            const int64_t w = e.stage_off[s + 1] - e.stage_off[s];
-            e.launches++;
-            if (w > R->cluster_max_items) { cx::launch_batch(h, e.d_rec + 5 * e.stage_off[s], w); s++; continue; }
-            int64_t t = s;
-            while (t < ns && e.stage_off[t + 1] - e.stage_off[t] <= R->cluster_max_items) t++;
-            cx::launch_ref_cluster(h, R->d_ctl, R->n_cu, e.d_flat, e.d_rec, e.d_stage_off + s, (int)(t - s));
-            // the members' waits are bounded; a call whose cluster gave up has computed part of its stages and cannot be repeated (the items
-            // overwrite their inputs' neighbours in place): it fails, loudly, and the handle goes back to plain launches
-            unsigned ctl[16] = {0};
-            CX_HIP(h, hipGetLastError());
-            CX_HIP(h, hipMemcpyAsync(ctl, R->d_ctl, sizeof(ctl), hipMemcpyDeviceToHost, h->stream));
-            CX_HIP(h, hipStreamSynchronize(h->stream));
-            if (ctl[4] || ctl[1] == 0) {
-                R->cluster_on = false;
-                return fail(h, CX_ERR_DEVICE, "reference schedule: a barrier of the XCD-resident cluster timed out (" + std::to_string(ctl[1]) + " member workgroups of " + std::to_string(ctl[0]) +
-                                              " registered); the call is incomplete — restore a checkpoint or set the messages again; further calls use plain launches");
-            }
-            s = t;
-        }
-        return CX_OK;
+        return cluster_run(h, e.d_flat, e.d_rec, e.d_stage_off, e.stage_off, (int64_t)e.stage_off.size() - 1, &e.launches);
     }
     static const bool graphs = [] { const char *v = std::getenv("CX_REF_GRAPH"); return !(v && v[0] == '0'); }();
     if (graphs && !e.graph_failed && !h->profiling && !e.exec && e.launches > 1) {
@@ -191,11 +123,112 @@ int32_t run_entry(cx_handle *h, RefSched *R, PlanEntry &e) {
 
 namespace cxh {
 
+// The records of a plan with everything the graph's tables would answer already filled in (cx_kernels.hip: FlatRec — kind | n << 8,
+// destination, variable, five sources): what the XCD-resident cluster runs, so that an item's chain of dependent loads is its values and
+// nothing else.  Items that do not fit (more than five sources, rules of factors with more than two edges, variational rules) point back
+// at their ordinary record.
+void flat_records(const cx_handle *h, const std::vector<int32_t> &rec, const std::vector<int32_t> &list, std::vector<int32_t> &flat) {
+    constexpr int32_t kSumToFactor = 1, kSumToMarginal = 2, kSumToGamma = 3, kSumToProduct = 4, kRule = 5, kGeneric = 6, kCheckObserved = 0x80;
+    const int64_t n = (int64_t)rec.size() / 5;
+    flat.assign((size_t)8 * n, 0);
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t *r = &rec[5 * i];
+        int32_t *o = &flat[8 * i];
+        o[0] = kGeneric; o[1] = (int32_t)i;
+        const int32_t kind = r[0];
+        if (kind == CX_ITEM_MESSAGE_TO_FACTOR || kind == CX_ITEM_INDIVIDUAL_MARGINAL) {
+            const int32_t v = r[2], deg = h->var_off[v + 1] - h->var_off[v], b = h->vbase[v];
+            const int32_t stride = ((h->vinfo[v] & cx::kDegMask) == cx::kBigDeg) ? 1 : cx::kBlock;
+            if (kind == CX_ITEM_INDIVIDUAL_MARGINAL) {
+                if (deg < 1 || deg > 5) continue;
+                o[0] = kSumToMarginal | (deg << 8); o[1] = v; o[2] = v;
+                for (int32_t j = 0; j < deg; j++) o[3 + j] = b + j * stride;
+            } else {
+                if (deg < 2 || deg > 6) continue;
+                const int32_t k = (r[1] - b) / stride;
+                int32_t m = 0;
+                for (int32_t j = 0; j < deg; j++) if (j != k) o[3 + m++] = b + j * stride;      // ascending: the reference's fold over the other messages
+                o[0] = kSumToFactor | kCheckObserved | (m << 8); o[1] = r[1]; o[2] = v;
+            }
+        } else if (kind == CX_ITEM_MESSAGE_TO_VARIABLE) {
+            const int32_t p = h->partner[r[1]];
+            if (p < 0) continue;
+            o[0] = kRule | (1 << 8); o[1] = r[1]; o[2] = r[2]; o[3] = p;
+        } else if ((kind == rs::kItemSumToFactor || kind == rs::kItemSumToMarginal || kind == rs::kItemSumToProduct || kind == rs::kItemSumToGammaMarginal) && r[4] >= 1 && r[4] <= 5) {
+            o[0] = (kind == rs::kItemSumToFactor ? kSumToFactor : kind == rs::kItemSumToMarginal ? kSumToMarginal : kind == rs::kItemSumToProduct ? kSumToProduct : kSumToGamma) | (r[4] << 8);
+            o[1] = r[1]; o[2] = r[2];
+            for (int32_t j = 0; j < r[4]; j++) o[3 + j] = list[r[3] + j];
+        }
+    }
+}
+
+
+bool cluster_prepare(cx_handle *h) {
+    if (h->cluster_state != 0) return h->cluster_state > 0;
+    h->cluster_state = -1;
+    if (const char *v = std::getenv("CX_REF_CLUSTER")) if (v[0] == '0') return false;
+    if (const char *v = std::getenv("CX_REF_CLUSTER_MIN")) h->cluster_min_items = std::max<int64_t>(0, std::atoll(v));
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); return false; }
+    if (hipMalloc(&h->d_cluster_ctl, 64) != hipSuccess) { (void)hipGetLastError(); h->d_cluster_ctl = nullptr; return false; }
+    h->cluster_cu = cus;
+    h->cluster_state = 1;
+    return true;
+}
+
+bool cluster_fits(const cx_handle *h, const std::vector<int64_t> &stage_off, int64_t ns) {
+    if (h->cluster_state <= 0 || ns < 8 || (int64_t)stage_off.size() < ns + 1) return false;
+    const int64_t items = stage_off[ns] - stage_off[0];
+    const int64_t two_gib = (int64_t)1 << 31;
+    if (items < h->cluster_min_items * ns || h->nslots * 16 >= two_gib || h->nv * 16 >= two_gib || (int64_t)h->prod_index.size() * 16 >= two_gib) return false;
+    // the cluster is an eighth of the chip: it wins on stages it takes in one pass (≈ 4 us against ≈ 6.5 us for a launch) and loses on wider
+    // ones, which leave as launches — and every switch between the two is a launch and a wait for the device (≈ 25 us).  Estimated both ways.
+    // As launches, consecutive stages of at most 1,024 items fold into one launch of one workgroup (k_batch_run: ≈ 1 us a stage).
+    int64_t narrow = 0, wide = 0, segments = 0, thin = 0, thin_runs = 0;
+    bool in_seg = false, in_run = false;
+    for (int64_t s = 0; s < ns; s++) {
+        const int64_t w = stage_off[s + 1] - stage_off[s];
+        const bool nar = w <= h->cluster_max_items, th = w <= 1024;
+        if (nar) { narrow++; if (!in_seg) segments++; } else wide++;
+        if (th) { thin++; if (!in_run) thin_runs++; }
+        in_seg = nar; in_run = th;
+    }
+    const double as_launches = 6.5 * (double)(ns - thin) + 6.5 * (double)thin_runs + 1.0 * (double)thin;
+    const double on_cluster = 4.0 * (double)narrow + 6.5 * (double)wide + 25.0 * (double)segments;
+    return narrow >= 8 && on_cluster < 0.8 * as_launches;
+}
+
+int32_t cluster_run(cx_handle *h, const int32_t *d_flat, const int32_t *d_rec, const int64_t *d_stage_off, const std::vector<int64_t> &stage_off, int64_t ns, int64_t *launches) {
+    // stages wider than the whole chip is (the first two of a grid's plan: every prior's message at once) leave as ordinary launches
+    // on all eight XCDs; the runs of stages between them go to the cluster, one launch per run
+    if (launches) *launches = 0;
+    for (int64_t s = 0; s < ns;) {
+        const int64_t w = stage_off[s + 1] - stage_off[s];
+        if (launches) ++*launches;
+        if (w > h->cluster_max_items) { cx::launch_batch(h, d_rec + 5 * stage_off[s], w); s++; continue; }
+        int64_t t = s;
+        while (t < ns && stage_off[t + 1] - stage_off[t] <= h->cluster_max_items) t++;
+        cx::launch_ref_cluster(h, h->d_cluster_ctl, h->cluster_cu, d_flat, d_rec, d_stage_off + s, (int)(t - s));
+        // the members' waits are bounded; a call whose cluster gave up has computed part of its stages and cannot be repeated (the items
+        // overwrite their inputs' neighbours in place): it fails, loudly, and the handle goes back to plain launches
+        unsigned ctl[16] = {0};
+        CX_HIP(h, hipGetLastError());
+        CX_HIP(h, hipMemcpyAsync(ctl, h->d_cluster_ctl, sizeof(ctl), hipMemcpyDeviceToHost, h->stream));
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        if (ctl[4] || ctl[1] == 0) {
+            h->cluster_state = -1;
+            return fail(h, CX_ERR_DEVICE, "a barrier of the XCD-resident cluster timed out (" + std::to_string(ctl[1]) + " member workgroups of " + std::to_string(ctl[0]) +
+                                          " registered); the call is incomplete — restore a checkpoint or set the messages again; further calls use plain launches");
+        }
+        s = t;
+    }
+    return CX_OK;
+}
+
 void ref_free(cx_handle *h) {
     RefSched *R = ref_of(h);
     if (!R) return;
     for (auto &e : R->cache) entry_free(h, e);
-    if (R->d_ctl) (void)hipFree(R->d_ctl);
     delete R;
     h->ref = nullptr; h->d_ref_list = nullptr;
 }
@@ -240,13 +273,7 @@ int32_t ref_build(cx_handle *h) {
     rs::init_state(R->W, *R->S);
     { const int32_t rp = register_stores(h, R.get()); if (rp != CX_OK) return rp; }
     if (const char *v = std::getenv("CX_REF_CACHE")) R->max_entries = std::max(1, std::atoi(v));
-    if (const char *v = std::getenv("CX_REF_CLUSTER")) R->cluster_on = !(v[0] == '0');
-    if (const char *v = std::getenv("CX_REF_CLUSTER_MIN")) R->cluster_min_items = std::max<int64_t>(0, std::atoll(v));
-    {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) R->n_cu = cus;
-        if (R->n_cu <= 0 || hipMalloc(&R->d_ctl, 64) != hipSuccess) { (void)hipGetLastError(); R->d_ctl = nullptr; R->cluster_on = false; }
-    }
+    (void)cluster_prepare(h);
     if (const char *v = std::getenv("CX_REF_CACHE_MB")) R->max_bytes = std::max<int64_t>(1, std::atoll(v)) << 20;
     if (const char *v = std::getenv("CX_REF_RUN_MAX")) R->run_max = std::max(0, std::atoi(v));
     h->ref = R.release();
@@ -378,13 +405,10 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n, const uint64_t *k
             e.key = key; e.req_key = rk;
             e.stage_off = P.stage_off; e.wide_off = P.wide_off;
             e.n_messages = P.n_messages; e.n_marginals = P.n_marginals; e.n_products = P.n_products; e.rounds = P.rounds; e.list_entries = (int64_t)P.list.size();
-            {   // wide and deep: the cluster; chains of thin stages stay with one workgroup's runs (k_batch_run), short plans with plain launches
-                const int64_t ns = (int64_t)P.stage_off.size() - 1, items = ns > 0 ? P.stage_off[ns] : 0;
-                e.cluster = R->d_ctl && R->cluster_on && P.wide_rec.empty() && ns >= 8 && items >= R->cluster_min_items * ns && h->nslots * 16 < ((int64_t)1 << 31) &&
-                            h->nv * 16 < ((int64_t)1 << 31) && (int64_t)h->prod_index.size() * 16 < ((int64_t)1 << 31);
-            }
+            // wide and deep: the cluster; chains of thin stages stay with one workgroup's runs (k_batch_run), short plans with plain launches
+            e.cluster = P.wide_rec.empty() && cluster_fits(h, P.stage_off, (int64_t)P.stage_off.size() - 1);
             std::vector<int32_t> flat;
-            if (e.cluster) flat_records(h, P, flat);
+            if (e.cluster) flat_records(h, P.rec, P.list, flat);
             const int64_t before = h->device_bytes;
             int32_t rc2;
             if ((rc2 = dev_upload(h, &e.d_rec, P.rec)) != CX_OK || (rc2 = dev_upload(h, &e.d_list, P.list)) != CX_OK || (rc2 = dev_upload(h, &e.d_stage_off, P.stage_off)) != CX_OK ||
@@ -547,6 +571,15 @@ int32_t cx_ref_plan_stats(const cx_handle *hc, int64_t *out8) {
     const PlanEntry &e = R->cache[R->last];
     out8[0] = e.stage_off.empty() ? 0 : (int64_t)e.stage_off.size() - 1; out8[1] = e.launches; out8[2] = (int64_t)e.order.size(); out8[3] = e.n_messages;
     out8[4] = e.rounds; out8[5] = (int64_t)R->cache.size(); out8[6] = R->hits; out8[7] = R->misses;
+    return CX_OK;
+}
+
+int32_t cx_cluster_stats(const cx_handle *hc, int64_t *out4) {
+    cx_handle *h = const_cast<cx_handle *>(hc);
+    CX_REQUIRE(h, h && out4, CX_ERR_INVALID_ARGUMENT, "cx_cluster_stats: null argument");
+    RefSched *R = ref_of(h);
+    out4[0] = h->cluster_state; out4[1] = h->cluster_cu; out4[2] = 0;
+    out4[3] = (R && R->last >= 0 && R->last < (int)R->cache.size() && R->cache[R->last].cluster && h->cluster_state > 0) ? 1 : 0;
     return CX_OK;
 }
 

@@ -288,6 +288,10 @@ int32_t build_tree(cx_handle *h) {
             off.push_back((int64_t)rec.size() / 5);
         }
         if (!rec.empty() && (rc2 = dev_upload(h, &h->d_tree_rec, rec)) != CX_OK) return rc2;
+        // (The XCD-resident cluster of the reference-order plans — cx_kernels.hip: k_ref_cluster — was tried on these level plans too and
+        // taken out again: a tree's levels are thin next to the roots, where one workgroup's runs cost 1 us a stage, and one huge level of
+        // leaves, which wants the whole chip; the 1.09 M-edge forest took 1.24 ms on the cluster against 0.63 as launches, and no forest of
+        // tools/bench_configs.py or the tests has the many stages of 1 - 16 k items the cluster wins on.)
         if (h->d_tree_stage_off) { (void)hipFree(h->d_tree_stage_off); h->d_tree_stage_off = nullptr; }
         if ((rc2 = dev_upload(h, &h->d_tree_stage_off, off)) != CX_OK) return rc2;
         CX_HIP(h, hipStreamSynchronize(h->stream));
@@ -364,7 +368,7 @@ static void tree_issue(cx_handle *h) {
 // stream — and a sweep is one hipGraphLaunch on the caller's stream.  Measured on the 1.09 M-edge forest of tools/bench_configs.py
 // (206 launches): the sweep was bound by the host's launch rate.  CX_TREE_GRAPH=0: plain launches (A/B); a refused capture or
 // instantiation also falls back to them, for good.
-void tree_sweep(cx_handle *h) {
+int32_t tree_sweep(cx_handle *h) {
     static const bool graphs = [] { const char *e = std::getenv("CX_TREE_GRAPH"); return !(e && e[0] == '0'); }();
     if (graphs && !h->tree_graph_failed && !h->profiling && !h->tree_exec) {
         hipError_t e = hipSuccess;
@@ -383,12 +387,13 @@ void tree_sweep(cx_handle *h) {
         if (e != hipSuccess || !h->tree_exec) { (void)hipGetLastError(); h->tree_exec = nullptr; h->tree_graph_failed = true; }
     }
     if (h->tree_exec && !h->profiling) {
-        if (hipGraphLaunch(h->tree_exec, h->stream) == hipSuccess) return;
+        if (hipGraphLaunch(h->tree_exec, h->stream) == hipSuccess) return CX_OK;
         (void)hipGetLastError();
         tree_graph_drop(h);
         h->tree_graph_failed = true;
     }
     tree_issue(h);
+    return CX_OK;
 }
 
 // ---- the sweep ----------------------------------------------------------------------------------------------------
@@ -586,7 +591,7 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
         // with cx_set_messages, the boundary variables' with cx_get_messages (cortex.jl_amd/partition.py: TreeRegionExchange)
         int32_t rc = build_tree(h);
         if (rc != CX_OK) return rc;
-        for (int32_t s = 0; s < n_sweeps; s++) { tree_sweep(h); h->sweeps_done++; }
+        for (int32_t s = 0; s < n_sweeps; s++) { const int32_t rt = tree_sweep(h); if (rt != CX_OK) return rt; h->sweeps_done++; }
         h->v2f_stale = false;            // every variable→factor message somebody reads was stored by its stage
         CX_HIP(h, hipGetLastError());
         return CX_OK;

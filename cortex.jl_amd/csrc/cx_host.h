@@ -150,7 +150,7 @@ int32_t normalize_alt(cx_handle *h);
 int32_t ensure_v2f(cx_handle *h);
 int32_t build_chains(cx_handle *h);
 int32_t build_tree(cx_handle *h);
-void tree_sweep(cx_handle *h);           // every stage of the plan on the handle's stream (one graph launch when the runtime allows it)
+int32_t tree_sweep(cx_handle *h);        // every stage of the plan on the handle's stream (one graph launch, or an XCD-resident cluster for scalar plans of wide stages)
 void tree_graph_drop(cx_handle *h);        // CX_SCHED_TREE: the stages of cx_tree_plan.h on the device (rebuilt when the set of observed variables changed)
 void sweep_main(cx_handle *h, bool skip_ghosts);
 void sweep_finish(cx_handle *h);
@@ -166,6 +166,13 @@ void ref_graphs_drop(cx_handle *h);
 void ref_on_set(cx_handle *h, int64_t n, const int64_t *edges, int32_t direction);
 void ref_on_seed(cx_handle *h, int32_t direction);
 void ref_on_batch(cx_handle *h, const cx_item *items, int64_t n);
+// the XCD-resident cluster (cx_api_ref.hip)
+bool cluster_prepare(cx_handle *h);                                        // control block + compute-unit count + environment switches; false: use launches
+bool cluster_fits(const cx_handle *h, const std::vector<int64_t> &stage_off, int64_t n_stages);      // wide and deep enough, arrays below 2 GiB
+void flat_records(const cx_handle *h, const std::vector<int32_t> &rec, const std::vector<int32_t> &list, std::vector<int32_t> &flat);
+// stages [0, n_stages) of a plan (host copy of the offsets: stage_off) — runs of stages on the cluster, stages wider than the chip as launches;
+// synchronous; *launches (may be NULL) counts them.  An error: a barrier timed out, the plan ran in part
+int32_t cluster_run(cx_handle *h, const int32_t *d_flat, const int32_t *d_rec, const int64_t *d_stage_off, const std::vector<int64_t> &stage_off, int64_t n_stages, int64_t *launches);
 int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n, const uint64_t *key_known = nullptr);
 int32_t ref_sweep_all(cx_handle *h, int32_t n_sweeps);
 int64_t ref_state_bytes(cx_handle *h);

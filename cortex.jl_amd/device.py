@@ -218,6 +218,13 @@ class DeviceGraph:
             raise ValueError("graph_wire: signals, dependencies and flags must have one row per triple")
         self._check(self.lib.cx_graph_wire(self.h, n, sig.ctypes.data_as(C.POINTER(L.Item)), dep.ctypes.data_as(C.POINTER(L.Item)), _p(fl, C.c_int32) if n else None))
 
+    def cluster_stats(self) -> dict:
+        """cx_cluster_stats: the XCD-resident cluster — state (1 ready, 0 not prepared, -1 off), workgroups per launch, whether the last
+        reference-order call ran on it"""
+        out = (C.c_int64 * 4)()
+        self._check(self.lib.cx_cluster_stats(self.h, out))
+        return {"state": int(out[0]), "workgroups": int(out[1]), "last_reference_call": bool(out[3])}
+
     def ref_plan_stats(self) -> dict:
         out = (C.c_int64 * 8)()
         self._check(self.lib.cx_ref_plan_stats(self.h, out))

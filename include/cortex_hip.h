@@ -355,6 +355,11 @@ int32_t cx_graph_wire(cx_handle *h, int64_t n, const cx_item *signals, const cx_
  * passes of the reference's loop (the final marginal round included), plans kept, calls that replayed a kept plan, calls that had to
  * run the scheduler }.  Zeros before the first call and for other schedules. */
 int32_t cx_ref_plan_stats(const cx_handle *h, int64_t *out8);
+/* the XCD-resident cluster (reference-order plans of many dependent stages of 1 - 16 k items — calls on loopy graphs — run as ONE launch
+ * of the workgroups of one XCD behind barriers that stay in that XCD's L2): out4 = { 1 ready / 0 not prepared / -1 off
+ * (CX_REF_CLUSTER=0, or a barrier once timed out), workgroups per launch (compute units), 0 (reserved), 1 when the last reference-order
+ * call ran on it }. */
+int32_t cx_cluster_stats(const cx_handle *h, int64_t *out4);
 /* the executions of the last reference-order call in the reference's order — what a `trace = true` engine records
  * (src/inference_engine.jl:650-862: TracedInferenceExecution.signal), as items (kind, variable_id, factor_id | CX_ITEM_RANGE).
  * *n_executions = their number; out (may be NULL) receives the first `capacity` of them. */

@@ -1,0 +1,74 @@
+"""-m gpu: the XCD-resident cluster (cx_kernels.hip: k_ref_cluster) against the same plans run as launches.
+
+Reference-order plans of many dependent stages of 1 - 16 k items — a call on a large loopy grid — run as ONE launch of the workgroups of one XCD behind barriers that stay in that XCD's L2, with values loaded past the vector cache, flat
+records and helper workgroups that load ahead.  The plan and its items are the same either way; what is pinned here is that the cluster
+computes what the launches compute (the sums of a compact MessageToFactor item are associated left to right on the cluster, prefix + suffix
+as launches: equal to rounding), on the paths that choose it by themselves, and that the parity tests of the other files therefore cover it."""
+import os
+
+import numpy as np
+import pytest
+
+import cortex.jl_amd as cx
+from cortex.jl_amd import _lib as L
+from tests.helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(make):
+    """the same handle twice: on the cluster, and with CX_REF_CLUSTER=0 (read when the handle prepares its cluster)"""
+    a = make()
+    os.environ["CX_REF_CLUSTER"] = "0"
+    try:
+        b = make()
+    finally:
+        del os.environ["CX_REF_CLUSTER"]
+    return a, b
+
+
+def test_a_reference_order_call_on_a_grid_runs_on_the_cluster(hip_lib):
+    model = cx.synth.gaussian_grid(1200, 1300, seed=3)      # stages of a median ~ 1,400 items: wider than one workgroup's run, narrower than the cluster
+    prior = np.stack([model.prior_mean, model.prior_variance], axis=1)
+
+    def make():
+        dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+        cx.synth.load_into_device(model, dev, seed_variance=1e6)
+        return dev
+
+    a, b = _pair(make)
+    for call in range(3):
+        for dev in (a, b):
+            dev.sweep(1)
+        assert a.ref_trace() == b.ref_trace()
+        sa, sb = a.cluster_stats(), b.cluster_stats()
+        assert sa["state"] == 1 and sa["last_reference_call"] and sa["workgroups"] >= 32, sa
+        assert sb["state"] == -1 and not sb["last_reference_call"], sb
+        assert a.ref_plan_stats()["launches"] <= 4 < b.ref_plan_stats()["launches"]      # (the two stages that hold every prior at once leave as launches either way)
+        for direction in (L.TO_VARIABLE, L.TO_FACTOR):
+            ma, mb = a.get_messages(model.edge_var, model.edge_fac, direction, L.FORM_NATURAL), b.get_messages(model.edge_var, model.edge_fac, direction, L.FORM_NATURAL)
+            assert np.array_equal(np.isnan(ma), np.isnan(mb))
+            ok = ~np.isnan(ma)
+            assert_close(ma[ok], mb[ok], 1e-12, f"call {call}: messages, direction {direction}", scale_by="max")
+        assert_close(a.get_marginals(model.x_ids), b.get_marginals(model.x_ids), 1e-12, f"call {call}: marginals", scale_by="max")
+        for dev in (a, b):
+            dev.set_messages(model.prior_var, model.prior_fac, L.TO_VARIABLE, L.FORM_MOMENT, prior)
+
+
+def test_a_small_grid_stays_with_one_workgroups_runs(hip_lib):
+    """stages of at most 1,024 items fold into runs of one workgroup with its own barrier (≈ 1 us a stage): cheaper than the cluster's"""
+    model = cx.synth.gaussian_grid(100, 110, seed=3)
+    dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(model, dev, seed_variance=1e6)
+    dev.sweep(1)
+    assert dev.cluster_stats()["state"] == 1 and not dev.cluster_stats()["last_reference_call"]
+
+
+def test_plans_of_thin_stages_and_short_plans_stay_with_launches(hip_lib):
+    chain = cx.synth.ssm_chain(400, seed=1)
+    dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(chain, dev)
+    dev.sweep_for(chain.x_ids)
+    st = dev.cluster_stats()
+    assert st["state"] == 1 and not st["last_reference_call"], st      # 800 stages of a few items: one workgroup's own barrier (k_batch_run)
+    assert dev.ref_plan_stats()["launches"] == 1

@@ -337,7 +337,7 @@ def vmp_wired(n=100_000, iterations=3):
                          "frac_algorithmic": execs * 32 / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "basis": "algorithmic bytes (32 B per execution, SURVEY §8d) / time of the three calls",
                          "frac_note": "the states' call is the reference's forward / backward chain: 2 n dependent stages inside one workgroup, a latency chain by construction; "
                                       "the precisions' calls are wide and shallow", "kernel": "k_batch_run / k_batch over the plan's stages"},
-            "parity": {"max_rel_err": err, "tolerance": 1e-9, "checker": "the fused family handle on the same device (cx_update_marginals; itself pinned call by call against oracle/vmp.py and the "
+            "parity": {"max_rel_err": err, "tolerance": 1e-9, "checker": "the fused family handle on the same device (cx_update_marginals; itself pinned call by call against the test suite's array form of the reference's calls and the "
                        "restated engine), every state mean, state precision and both Gamma marginals", "sample": f"after {iterations} by-class iterations, n={n}"}}
 
 
