@@ -134,28 +134,28 @@ void flat_records(const cx_handle *h, const std::vector<int32_t> &rec, const std
     for (int64_t i = 0; i < n; i++) {
         const int32_t *r = &rec[5 * i];
         int32_t *o = &flat[8 * i];
-        o[0] = kGeneric; o[1] = (int32_t)i;
-        const int32_t kind = r[0];
+        const int32_t pair = r[0] & (rs::kRecLeads | rs::kRecFollows), kind = r[0] & rs::kRecKindMask;      // (the pair flags travel in the flat kind too)
+        o[0] = kGeneric | pair; o[1] = (int32_t)i;
         if (kind == CX_ITEM_MESSAGE_TO_FACTOR || kind == CX_ITEM_INDIVIDUAL_MARGINAL) {
             const int32_t v = r[2], deg = h->var_off[v + 1] - h->var_off[v], b = h->vbase[v];
             const int32_t stride = ((h->vinfo[v] & cx::kDegMask) == cx::kBigDeg) ? 1 : cx::kBlock;
             if (kind == CX_ITEM_INDIVIDUAL_MARGINAL) {
                 if (deg < 1 || deg > 5) continue;
-                o[0] = kSumToMarginal | (deg << 8); o[1] = v; o[2] = v;
+                o[0] = kSumToMarginal | (deg << 8) | pair; o[1] = v; o[2] = v;
                 for (int32_t j = 0; j < deg; j++) o[3 + j] = b + j * stride;
             } else {
                 if (deg < 2 || deg > 6) continue;
                 const int32_t k = (r[1] - b) / stride;
                 int32_t m = 0;
                 for (int32_t j = 0; j < deg; j++) if (j != k) o[3 + m++] = b + j * stride;      // ascending: the reference's fold over the other messages
-                o[0] = kSumToFactor | kCheckObserved | (m << 8); o[1] = r[1]; o[2] = v;
+                o[0] = kSumToFactor | kCheckObserved | (m << 8) | pair; o[1] = r[1]; o[2] = v;
             }
         } else if (kind == CX_ITEM_MESSAGE_TO_VARIABLE) {
             const int32_t p = h->partner[r[1]];
             if (p < 0) continue;
-            o[0] = kRule | (1 << 8); o[1] = r[1]; o[2] = r[2]; o[3] = p;
+            o[0] = kRule | (1 << 8) | pair; o[1] = r[1]; o[2] = r[2]; o[3] = p;
         } else if ((kind == rs::kItemSumToFactor || kind == rs::kItemSumToMarginal || kind == rs::kItemSumToProduct || kind == rs::kItemSumToGammaMarginal) && r[4] >= 1 && r[4] <= 5) {
-            o[0] = (kind == rs::kItemSumToFactor ? kSumToFactor : kind == rs::kItemSumToMarginal ? kSumToMarginal : kind == rs::kItemSumToProduct ? kSumToProduct : kSumToGamma) | (r[4] << 8);
+            o[0] = (kind == rs::kItemSumToFactor ? kSumToFactor : kind == rs::kItemSumToMarginal ? kSumToMarginal : kind == rs::kItemSumToProduct ? kSumToProduct : kSumToGamma) | (r[4] << 8) | pair;
             o[1] = r[1]; o[2] = r[2];
             for (int32_t j = 0; j < r[4]; j++) o[3 + j] = list[r[3] + j];
         }

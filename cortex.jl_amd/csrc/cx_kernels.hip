@@ -376,6 +376,9 @@ struct KaryTab { const int32_t *slot; const double *coef, *qb; const int32_t *li
 // `hi` sources list[lo ..): an entry >= 0 is a factor→variable slot, ~entry a node of the product store.  What the reference's rule
 // call read, node by node — a node may lag behind its leaves on a graph with loops, and the reference reads the node.
 constexpr int kItemSumToFactor = 64, kItemSumToProduct = 65, kItemSumToMarginal = 66;
+// a record that LEADS is followed in its stage's list by a record that FOLLOWS: one thread computes the first, waits for its store, and
+// computes the second — a MessageToFactor and the MessageToVariable that reads it, levelled as one item (cx_refsched.h: kRecLeads)
+constexpr int kRecLeads = 0x40000000, kRecFollows = 0x20000000, kRecKindMask = 0x0fffffff;
 // ... and the variational rules of a CX_FACTOR_NORMAL_PRECISION factor (out ~ N(in, 1 / precision), precision ~ Gamma) that a user wiring
 // selects (cx_refsched.h: kRule*; the reference's test rules, test/inference_engine_tests.jl:647-689, 939-1030).  Marginals are read from
 // the marginal store: (mean, variance) of a Normal variable ((datum, 0) when observed), (shape, scale) of a precision — 72 stores the
@@ -499,8 +502,15 @@ __global__ __launch_bounds__(kBlock) void k_batch(int64_t n, const int32_t *__re
                                                   double2 *__restrict__ prod, double *__restrict__ joint, const KaryTab kt) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    batch_item<MODE>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg,
+    const int k0 = rec[5 * i];
+    if (k0 & kRecFollows) return;
+    batch_item<MODE>(k0 & kRecKindMask, rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg,
                      nat_marg, prod, joint, kt);
+    if (k0 & kRecLeads) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the leader's store has been written through before the follower loads it
+        batch_item<MODE>(rec[5 * i + 5] & kRecKindMask, rec[5 * i + 6], rec[5 * i + 7], rec[5 * i + 8], rec[5 * i + 9], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f,
+                         marg, nat_marg, prod, joint, kt);
+    }
 }
 
 // A RUN of consecutive thin stages of the tree schedule (each at most kRunBlock items) in ONE launch of ONE workgroup: the stages of a
@@ -516,9 +526,17 @@ __global__ __launch_bounds__(kRunBlock) void k_batch_run(const int64_t *__restri
                                                          double2 *__restrict__ marg, int nat_marg, double2 *__restrict__ prod, double *__restrict__ joint,
                                                          const KaryTab kt) {
     for (int st = s0; st < s1; st++) {
-        for (int64_t i = stage_off[st] + threadIdx.x; i < stage_off[st + 1]; i += kRunBlock)      // (the tree schedule folds stages of at most kRunBlock items: one trip)
-            batch_item<MODE>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg,
+        for (int64_t i = stage_off[st] + threadIdx.x; i < stage_off[st + 1]; i += kRunBlock) {      // (the tree schedule folds stages of at most kRunBlock items: one trip)
+            const int k0 = rec[5 * i];
+            if (k0 & kRecFollows) continue;
+            batch_item<MODE>(k0 & kRecKindMask, rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg,
                              nat_marg, prod, joint, kt);
+            if (k0 & kRecLeads) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                batch_item<MODE>(rec[5 * i + 5] & kRecKindMask, rec[5 * i + 6], rec[5 * i + 7], rec[5 * i + 8], rec[5 * i + 9], vbase, vdeg, vinfo, partner, q, pa, pb, f2v,
+                                 v2f, marg, nat_marg, prod, joint, kt);
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -568,10 +586,10 @@ __device__ __forceinline__ void flat_item(const FlatRec r, const int32_t *__rest
                                           const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner, const double *__restrict__ q,
                                           const double *__restrict__ pa, const double *__restrict__ pb, double2 *f2v, double2 *v2f, double2 *marg, int nat_marg,
                                           double2 *prod, double *joint, const KaryTab kt) {
-    const int kind = r.k & 0x7f, n = r.k >> 8;
+    const int kind = r.k & 0x7f, n = (r.k >> 8) & 0xff;
     if (kind == kFlatGeneric) {
         const int32_t *g = rec + 5 * (int64_t)r.dst;
-        batch_item<MODE, true>(g[0], g[1], g[2], g[3], g[4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+        batch_item<MODE, true>(g[0] & kRecKindMask, g[1], g[2], g[3], g[4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
         return;
     }
     if (kind == kFlatRule) {
@@ -664,7 +682,7 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
                 const FlatRec r = flat_load(flat, i);
                 sink ^= (unsigned)r.k ^ (unsigned)r.dst;
                 if (help >= 2) {
-                    const int kind = r.k & 0x7f, n = r.k >> 8;
+                    const int kind = r.k & 0x7f, n = (r.k >> 8) & 0xff;
                     if (kind == kFlatRule) sink ^= (unsigned)__double_as_longlong(ld2<true>(v2f, r.s[0]).y);
                     else if (kind != kFlatGeneric)
                         for (int j = 0; j < 5; j++) if (j < n) sink ^= (unsigned)__double_as_longlong((r.s[j] >= 0 ? ld2<true>(f2v, r.s[j]) : ld2<true>(prod, ~r.s[j])).y);
@@ -687,9 +705,22 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
         FlatRec nxt{};
         if (nhave && !(dry & 8)) nxt = flat_load(flat, nlo + first);      // (bit 3, CX_REF_CLUSTER_DRY=2: not even the records — the bare barriers)
         if (!(dry & 1)) {      // (CX_REF_CLUSTER_DRY=1: the plan's skeleton — records and barriers, no item — for timing what a stage costs before it computes)
-            if (have) flat_item<MODE>(cur, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
-            for (int64_t i = lo + first + step; i < hi; i += step)      // (a stage wider than the cluster)
-                flat_item<MODE>(flat_load(flat, i), rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+            if (have && !(cur.k & kRecFollows)) {
+                flat_item<MODE>(cur, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+                if (cur.k & kRecLeads) {      // the record behind it: the message that reads this one, by the same thread, once the store has reached the L2
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    flat_item<MODE>(flat_load(flat, lo + first + 1), rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+                }
+            }
+            for (int64_t i = lo + first + step; i < hi; i += step) {      // (a stage wider than the cluster)
+                const FlatRec r = flat_load(flat, i);
+                if (r.k & kRecFollows) continue;
+                flat_item<MODE>(r, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+                if (r.k & kRecLeads) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    flat_item<MODE>(flat_load(flat, i + 1), rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+                }
+            }
         }
         if (st + 1 == n_stages) break;
         // the barrier: this thread's stores have reached the L2, the workgroup has arrived, one thread reports and waits for the others

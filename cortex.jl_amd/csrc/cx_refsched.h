@@ -26,6 +26,7 @@
 #pragma once
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "cx_flatten.h"
@@ -585,6 +586,15 @@ constexpr int32_t kItemSumToFactor = 64, kItemSumToProduct = 65, kItemSumToMargi
 // lists every factor) leaves the stage's thread-per-item launch: one workgroup sums it (cx_kernels.hip: k_wide_sum)
 constexpr int64_t kWideList = 1024;
 
+// Two executions as ONE item of a stage.  On a chain or a grid the reference's order alternates MessageToFactor(x, f) and
+// MessageToVariable(y, f): the second reads the first and nothing else that this call computes, so its stage would be the first's plus
+// one — half of a plan's depth is such pairs.  The pair is levelled as one item instead: the same thread computes the first, waits for its
+// store, and computes the second (cx_kernels.hip: the record that LEADS is followed, in the stage's list, by the record that FOLLOWS; the
+// follower's own thread skips it).  The reference's order is kept (the second still comes after the first) and every value read is the one
+// the reference's rule call read; a pair is only formed when no earlier execution of the call reads or writes the second's slot in that
+// stage or later.
+constexpr int32_t kRecLeads = 0x40000000, kRecFollows = 0x20000000, kRecKindMask = 0x0fffffff;
+
 struct Plan {
     std::vector<int32_t> rec;            // 5 per item, by stage
     std::vector<int64_t> stage_off;
@@ -602,7 +612,25 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
     P = Plan();
     P.n_exec = n; P.rounds = call.rounds;
     std::vector<int32_t> w_stage(W.nsig, 0), r_stage(W.nsig, 0), stage(n, 0);
+    std::vector<int32_t> w_exec(W.nsig, -1), follower(n, -1);      // the execution that last wrote a signal in this call; the execution fused behind one
+    std::vector<uint8_t> follows(n, 0);
     int32_t n_stages = 0;
+    auto is_wide = [&](int64_t s) { return !W.is_f2v(s) && !W.is_joint(s) && W.dep_off[s + 1] - W.dep_off[s] > wide_list; };
+    // the MessageToFactor signal a MessageToVariable execution can be fused behind: the one message its rule reads (a pairwise sum-product
+    // factor; the structured variational rule, which reads one message and the precision's marginal); -1: none
+    auto pair_source = [&](int64_t s) -> int64_t {
+        if (!W.is_f2v(s)) return -1;
+        const int64_t e = s - ne;
+        const int32_t f = W.efac[e];
+        if (W.vrule[e] == kRuleBP) {
+            if (W.foff[f + 1] - W.foff[f] != 2 || h->partner[flat::slot_of_edge_t(h, e)] < 0) return -1;
+            return W.fedge[W.foff[f]] == e ? W.fedge[W.foff[f] + 1] : W.fedge[W.foff[f]];
+        }
+        if (W.vrule[e] == kRuleStNormal)
+            for (int32_t k = W.foff[f]; k < W.foff[f + 1]; k++) { const int32_t e2 = W.fedge[k]; if (e2 != e && h->np_role[e2] != CX_ROLE_PRECISION) return e2; }
+        return -1;
+    };
+    static const bool fuse_pairs = [] { const char *e = std::getenv("CX_REF_FUSE_PAIRS"); return !(e && e[0] == '0'); }();      // (A/B)
     // what an execution reads beyond its dependency list: a sum-product rule reads the stored messages of ALL the factor's other edges
     auto unlisted_reads = [&](int64_t s, auto &&fn) {
         if (!W.is_f2v(s) || W.vrule[s - ne] != kRuleBP) return;
@@ -613,15 +641,26 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
     for (int64_t i = 0; i < n; i++) {
         const int64_t s = call.order[i];
         int32_t st = std::max(w_stage[s], r_stage[s]) + 1;
-        for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) st = std::max(st, w_stage[W.dep[p]] + 1);
-        unlisted_reads(s, [&](int64_t d) { st = std::max(st, w_stage[d] + 1); });
-        stage[i] = st; w_stage[s] = st;
+        const int64_t src = fuse_pairs ? pair_source(s) : -1;
+        if (src >= 0 && w_exec[src] >= 0 && follower[w_exec[src]] < 0 && !is_wide(src)) {
+            // behind the execution that wrote the message it reads, in that execution's stage — if nothing of this call reads or writes the
+            // destination there or later, and every other dependency was written before
+            const int32_t j = w_exec[src], sy = stage[j];
+            bool ok = std::max(w_stage[s], r_stage[s]) < sy;
+            for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1] && ok; p++) if (W.dep[p] != src) ok = w_stage[W.dep[p]] < sy;
+            if (ok) { st = sy; follower[j] = (int32_t)i; follows[i] = 1; }
+        }
+        if (!follows[i]) {
+            for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) st = std::max(st, w_stage[W.dep[p]] + 1);
+            unlisted_reads(s, [&](int64_t d) { st = std::max(st, w_stage[d] + 1); });
+        }
+        stage[i] = st; w_stage[s] = st; w_exec[s] = (int32_t)i;
         for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) r_stage[W.dep[p]] = std::max(r_stage[W.dep[p]], st);
+        if (src >= 0) r_stage[src] = std::max(r_stage[src], st);      // (a rule reads its message whether the wiring lists it or not)
         unlisted_reads(s, [&](int64_t d) { r_stage[d] = std::max(r_stage[d], st); });
         n_stages = std::max(n_stages, st);
     }
     // (only products — MessageToFactor, marginals, segment-tree nodes — can be wide: the rules read at most three sources)
-    auto is_wide = [&](int64_t s) { return !W.is_f2v(s) && !W.is_joint(s) && W.dep_off[s + 1] - W.dep_off[s] > wide_list; };
     P.stage_off.assign(n_stages + 1, 0); P.wide_off.assign(n_stages + 1, 0);
     int64_t n_wide = 0;
     for (int64_t i = 0; i < n; i++) { if (is_wide(call.order[i])) { P.wide_off[stage[i]]++; n_wide++; } else P.stage_off[stage[i]]++; }
@@ -633,7 +672,12 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
         return ~(int32_t)prod_slot(d - W.sig_prod(0));
     };
     const bool gammas = !h->var_gamma.empty();
-    for (int64_t i = 0; i < n; i++) {
+    // in execution order, a follower right behind its leader (both fill the same stage's list, one after the other)
+    std::vector<int32_t> emit_order;
+    emit_order.reserve(n);
+    for (int64_t i = 0; i < n; i++) { if (follows[i]) continue; emit_order.push_back((int32_t)i); if (follower[i] >= 0) emit_order.push_back(follower[i]); }
+    for (int64_t q = 0; q < n; q++) {
+        const int64_t i = emit_order[q];
         const int64_t s = call.order[i];
         int32_t *r = is_wide(s) ? &P.wide_rec[5 * wfill[stage[i] - 1]++] : &P.rec[5 * fill[stage[i] - 1]++];
         auto list_of_deps = [&]() {
@@ -693,6 +737,8 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
             P.n_products++;
             r[0] = kItemSumToProduct; r[1] = (int32_t)prod_slot(pi); r[2] = W.prods[pi].var; list_of_deps();
         }
+        if (follower[i] >= 0) r[0] |= kRecLeads;
+        if (follows[i]) r[0] |= kRecFollows;
     }
     return CX_OK;
 }

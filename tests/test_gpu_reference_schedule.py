@@ -241,7 +241,7 @@ def test_config_c4_full_size_two_calls(hip_lib):
         _t, em, ev = E.get_marginals(model.x_ids)
         marg = dev.get_marginals(model.x_ids)
         assert_close(marg[:, 0], em, 1e-9, f"C4 call {call + 1} marginal mean"); assert_close(marg[:, 1], ev, 1e-9, f"C4 call {call + 1} marginal variance")
-    assert 5_000 < st["stages"] < 6_500
+    assert 2_500 < st["stages"] < 3_300      # (≈ 2 N: a MessageToFactor and the MessageToVariable that reads it share a stage; ≈ 4 N with CX_REF_FUSE_PAIRS=0)
     dev.close()
 
 

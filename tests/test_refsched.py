@@ -61,10 +61,14 @@ class NumpyDevice:
         getattr(self, buf)[self.slot[(int(v), int(f))]] = (mean / variance, 1.0 / variance)
 
     def run(self, rec, stage_off, lists):
+        LEADS, FOLLOWS, MASK = 0x40000000, 0x20000000, 0x0fffffff      # cx_refsched.h: a record that leads is followed by one the same thread computes behind it
         for s in range(len(stage_off) - 1):
             items = rec[5 * stage_off[s]:5 * stage_off[s + 1]].reshape(-1, 5)
             reads, writes, new = set(), set(), []
+            leader_out = None                 # (destination, value) of the leader the next record follows
             for k, idx, v, lo, hi in items:
+                flags, k = int(k) & ~MASK, int(k) & MASK
+                assert bool(flags & FOLLOWS) == (leader_out is not None), f"stage {s}: a follower without its leader (or a leader without its follower)"
                 if k == K2F:
                     deg = self.var_off[v + 1] - self.var_off[v]
                     src = [("f2v", int(self.vbase[v] + 256 * j)) for j in range(deg)]
@@ -80,17 +84,26 @@ class NumpyDevice:
                     dst = ({KSUM2F: "v2f", KSUM2P: "prod", KSUM2M: "marg"}[int(k)], int(idx))
                 else:
                     raise AssertionError(f"unexpected item kind {k}")
-                vals = np.array([getattr(self, b)[i] for b, i in src])
+
+                def value(b, i):
+                    if leader_out is not None and leader_out[0] == (b, i):
+                        return leader_out[1]          # the follower reads what its leader just stored
+                    return getattr(self, b)[i]
+                vals = np.array([value(b, i) for b, i in src])
                 assert not np.any(np.isnan(vals)), f"stage {s}: an item of kind {k} reads an undefined value"
                 if k == K2V:
                     xi, w = vals[0]
                     qq = self.q[idx]
-                    out = (xi, np.inf) if False else ((xi / w) / (1.0 / w + qq), 1.0 / (1.0 / w + qq)) if np.isfinite(w) else (xi / qq, 1.0 / qq)
+                    out = ((xi / w) / (1.0 / w + qq), 1.0 / (1.0 / w + qq)) if np.isfinite(w) else (xi / qq, 1.0 / qq)
                 else:
                     out = tuple(vals.sum(axis=0))
-                reads.update(src); new.append((dst, out))
+                if flags & FOLLOWS:
+                    assert leader_out[0] in src, f"stage {s}: a follower that does not read its leader"
+                reads.update(t for t in src if leader_out is None or t != leader_out[0]); new.append((dst, out))
                 assert dst not in writes, f"stage {s}: two items write {dst}"
                 writes.add(dst)
+                leader_out = (dst, out) if flags & LEADS else None
+            assert leader_out is None
             assert not (reads & writes), f"stage {s}: an item reads what another item of the same stage writes: {sorted(reads & writes)[:3]}"
             for (b, i), out in new:
                 getattr(self, b)[i] = out

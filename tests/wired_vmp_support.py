@@ -207,7 +207,9 @@ class ShadowBackend(WiringRecorder):
         return self.last_rows
 
     def run(self, rec, stage_off, lists, wide_rec=(), wide_off=()):
-        """cx_kernels.hip: batch_item for the kinds a wired plan holds; asserts that no item of a stage reads what another one writes"""
+        """cx_kernels.hip: batch_item for the kinds a wired plan holds; asserts that no item of a stage reads what another one writes.  A record
+        that LEADS is followed by one the same thread computes behind it (cx_refsched.h: kRecLeads): the follower reads its leader's result"""
+        LEADS, FOLLOWS, MASK = 0x40000000, 0x20000000, 0x0fffffff
         for s in range(len(stage_off) - 1):
             items = rec[5 * stage_off[s]:5 * stage_off[s + 1]].reshape(-1, 5)
             if len(wide_off):
@@ -215,13 +217,20 @@ class ShadowBackend(WiringRecorder):
                 assert all(int(k) in (64, 65, 66, 72) for k in wide[:, 0])
                 items = np.concatenate([items, wide])
             reads, writes, new = set(), set(), []
+            leader_out = None
             for k, idx, v, lo, hi in items:
-                k, idx, lo, hi = int(k), int(idx), int(lo), int(hi)
+                flags, k, idx, lo, hi = int(k) & ~MASK, int(k) & MASK, int(idx), int(lo), int(hi)
+                assert bool(flags & FOLLOWS) == (leader_out is not None), f"stage {s}: a follower without its leader"
                 ls = [int(t) for t in lists[lo:lo + hi]]
+
+                def val(b, i):
+                    if leader_out is not None and leader_out[0] == (b, i):
+                        return np.asarray(leader_out[1], dtype=np.float64)
+                    return getattr(self, b)[i]
                 if k in (64, 65, 66, 72):
                     src = [("f2v", t) if t >= 0 else ("prod", ~t) for t in ls]
                     dst = ({64: "v2f", 65: "prod", 66: "marg", 72: "marg"}[k], idx)
-                    acc = np.array([getattr(self, b)[i] for b, i in src]).sum(axis=0)
+                    acc = np.array([val(b, i) for b, i in src]).sum(axis=0)
                     out = (acc[0] / acc[1], 1.0 / acc[1]) if k == 66 else (acc[0] + 1.0, 1.0 / acc[1]) if k == 72 else tuple(acc)
                 elif k == 67:
                     src, dst = [("marg", ls[0]), ("marg", ls[1])], ("f2v", idx)
@@ -233,7 +242,7 @@ class ShadowBackend(WiringRecorder):
                     out = (0.5, 0.5 * (a[1] + b[1] + (a[0] - b[0]) ** 2))
                 elif k == 69:
                     src, dst = [("v2f", ls[0]), ("marg", ls[1])], ("f2v", idx)
-                    m, eg = self.v2f[ls[0]], self.marg[ls[1]][0] * self.marg[ls[1]][1]
+                    m, eg = val("v2f", ls[0]), self.marg[ls[1]][0] * self.marg[ls[1]][1]
                     w = 1.0 / (1.0 / m[1] + 1.0 / eg)
                     out = (m[0] / m[1] * w, w)
                 elif k == 70:
@@ -250,10 +259,14 @@ class ShadowBackend(WiringRecorder):
                 else:
                     raise AssertionError(f"unexpected item kind {k} in a wired plan")
                 for b, i in src:
-                    assert not np.any(np.isnan(getattr(self, b)[i])), f"stage {s}: an item of kind {k} reads an undefined {b}[{i}]"
-                reads.update(src); new.append((dst, out))
+                    assert not np.any(np.isnan(val(b, i))), f"stage {s}: an item of kind {k} reads an undefined {b}[{i}]"
+                if flags & FOLLOWS:
+                    assert leader_out[0] in src, f"stage {s}: a follower that does not read its leader"
+                reads.update(t for t in src if leader_out is None or t != leader_out[0]); new.append((dst, out))
                 assert dst not in writes, f"stage {s}: two items write {dst}"
                 writes.add(dst)
+                leader_out = (dst, out) if flags & LEADS else None
+            assert leader_out is None
             assert not (reads & writes), f"stage {s}: an item reads what another item of the same stage writes: {sorted(reads & writes)[:3]}"
             for (b, i), out in new:
                 getattr(self, b)[i] = out
