@@ -581,11 +581,12 @@ constexpr int kFlatSumToFactor = 1, kFlatSumToMarginal = 2, kFlatSumToGamma = 3,
 constexpr int kFlatCheckObserved = 0x80;      // MessageToFactor of the compact form: not recomputed for an observed / stand-in variable (m2f_one)
 struct FlatRec { int32_t k, dst, v, s[5]; };
 
+// fwd (may be NULL): where a kFlatSumToFactor item leaves the message it stored (fwd->y NaN: it stored nothing) — its follower's input
 template <int MODE>
 __device__ __forceinline__ void flat_item(const FlatRec r, const int32_t *__restrict__ rec, const int32_t *__restrict__ vbase, const int32_t *__restrict__ vdeg,
                                           const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner, const double *__restrict__ q,
                                           const double *__restrict__ pa, const double *__restrict__ pb, double2 *f2v, double2 *v2f, double2 *marg, int nat_marg,
-                                          double2 *prod, double *joint, const KaryTab kt) {
+                                          double2 *prod, double *joint, const KaryTab kt, double2 *fwd = nullptr) {
     const int kind = r.k & 0x7f, n = (r.k >> 8) & 0xff;
     if (kind == kFlatGeneric) {
         const int32_t *g = rec + 5 * (int64_t)r.dst;
@@ -618,7 +619,32 @@ __device__ __forceinline__ void flat_item(const FlatRec r, const int32_t *__rest
     for (int j = 0; j < 5; j++) if (j < n) acc = make_double2(acc.x + val[j][0], acc.y + val[j][1]);
     if (kind == kFlatSumToMarginal) marg[r.dst] = nat_marg ? acc : to_moment(acc);
     else if (kind == kFlatSumToGamma) marg[r.dst] = make_double2(acc.x + 1.0, 1.0 / acc.y);
-    else if (!__builtin_isnan(acc.y) && !(info & (kClamped | kGhost))) { if (kind == kFlatSumToFactor) v2f[r.dst] = acc; else prod[r.dst] = acc; }
+    else if (!__builtin_isnan(acc.y) && !(info & (kClamped | kGhost))) {
+        if (kind == kFlatSumToFactor) { v2f[r.dst] = acc; if (fwd) *fwd = acc; }
+        else prod[r.dst] = acc;
+    }
+}
+
+// a leader and the record behind it (cx_refsched.h: kRecLeads).  The common pair — a MessageToFactor sum and the rule of the message that reads
+// it — passes the message on in a register: the follower does not wait for the leader's store.  Any other pair: the store first, then the follower.
+template <int MODE>
+__device__ __forceinline__ void flat_pair(const FlatRec lead, const FlatRec fol, const int32_t *__restrict__ rec, const int32_t *__restrict__ vbase,
+                                          const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
+                                          const double *__restrict__ q, const double *__restrict__ pa, const double *__restrict__ pb, double2 *f2v, double2 *v2f,
+                                          double2 *marg, int nat_marg, double2 *prod, double *joint, const KaryTab kt, bool forward) {
+    if (forward && (lead.k & 0x7f) == kFlatSumToFactor && (fol.k & 0x7f) == kFlatRule && fol.s[0] == lead.dst) {
+        const double qq = q[fol.dst], a = MODE == kRuleLinear ? pa[fol.dst] : 1.0, b = MODE == kRuleLinear ? pb[fol.dst] : 0.0;
+        double2 m = nan2();
+        flat_item<MODE>(lead, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, &m);
+        if (__builtin_isnan(m.y)) m = ld2<true>(v2f, fol.s[0]);      // the leader stored nothing (an observed variable, an undefined input): what is stored there
+        if (__builtin_isnan(m.y)) return;
+        const double2 o = factor_rule<MODE>(m, qq, a, b);
+        if (MODE != kRuleBernoulli || !__builtin_isnan(o.y)) f2v[fol.dst] = o;
+        return;
+    }
+    flat_item<MODE>(lead, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flat_item<MODE>(fol, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
 }
 
 __device__ __forceinline__ FlatRec flat_load(const int32_t *__restrict__ flat, int64_t i) {
@@ -706,20 +732,14 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
         if (nhave && !(dry & 8)) nxt = flat_load(flat, nlo + first);      // (bit 3, CX_REF_CLUSTER_DRY=2: not even the records — the bare barriers)
         if (!(dry & 1)) {      // (CX_REF_CLUSTER_DRY=1: the plan's skeleton — records and barriers, no item — for timing what a stage costs before it computes)
             if (have && !(cur.k & kRecFollows)) {
-                flat_item<MODE>(cur, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
-                if (cur.k & kRecLeads) {      // the record behind it: the message that reads this one, by the same thread, once the store has reached the L2
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    flat_item<MODE>(flat_load(flat, lo + first + 1), rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
-                }
+                if (cur.k & kRecLeads) flat_pair<MODE>(cur, flat_load(flat, lo + first + 1), rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, !(dry & 16));
+                else flat_item<MODE>(cur, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
             }
             for (int64_t i = lo + first + step; i < hi; i += step) {      // (a stage wider than the cluster)
                 const FlatRec r = flat_load(flat, i);
                 if (r.k & kRecFollows) continue;
-                flat_item<MODE>(r, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
-                if (r.k & kRecLeads) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    flat_item<MODE>(flat_load(flat, i + 1), rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
-                }
+                if (r.k & kRecLeads) flat_pair<MODE>(r, flat_load(flat, i + 1), rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, !(dry & 16));
+                else flat_item<MODE>(r, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
             }
         }
         if (st + 1 == n_stages) break;
@@ -1037,7 +1057,8 @@ void launch_ref_cluster(cx_handle *h, void *d_ctl, int n_workgroups, const int32
     static const int dry = [] {
         const char *e = std::getenv("CX_REF_CLUSTER_DRY"), *hp = std::getenv("CX_REF_CLUSTER_HELP");
         const char *ah = std::getenv("CX_REF_CLUSTER_AHEAD"), *mb = std::getenv("CX_REF_CLUSTER_MEMBERS");      // A/B: stages the helpers run ahead, member workgroups
-        return ((e && (e[0] == '1' || e[0] == '2')) ? 1 : 0) | ((hp ? std::max(0, std::min(2, std::atoi(hp))) : 2) << 1) | ((e && e[0] == '2') ? 8 : 0) |
+        const char *fw = std::getenv("CX_REF_PAIR_FWD");      // 0: a follower always waits for its leader's store (A/B)
+        return ((e && (e[0] == '1' || e[0] == '2')) ? 1 : 0) | ((hp ? std::max(0, std::min(2, std::atoi(hp))) : 2) << 1) | ((e && e[0] == '2') ? 8 : 0) | ((fw && fw[0] == '0') ? 16 : 0) |
                ((ah ? std::max(0, std::min(255, std::atoi(ah))) : 0) << 8) | ((mb ? std::max(0, std::min(255, std::atoi(mb))) : 0) << 16);
     }();
 #define CX_B(M, PA, PB) hipLaunchKernelGGL(k_ref_cluster<M>, dim3(n_workgroups), dim3(kClusterBlock), 0, h->stream, (ClusterCtl *)d_ctl, (unsigned)n_workgroups, d_stage_off, n_stages, \
