@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void k_push_slots(const int32_t *__restrict
 // variable→factor for one slot of variable v (sequential sums in the order of the sweep kernel)
 template <bool COH = false>
 __device__ __forceinline__ void m2f_one(int slot, int v, const int32_t *vbase, const int32_t *vdeg, const uint8_t *vinfo,
-                                        const double2 *f2v, double2 *v2f) {
+                                        const double2 *f2v, double2 *v2f, double2 *fwd = nullptr) {
     const int info = vinfo[v];
     const int deg = vdeg[v];
     if (deg < 2 || (info & (kClamped | kGhost))) return;
@@ -318,7 +318,7 @@ __device__ __forceinline__ void m2f_one(int slot, int v, const int32_t *vbase, c
     for (int j = 0; j < k; j++) pre = add2(pre, ld2<COH>(f2v, b + j * stride));
     for (int j = deg - 1; j > k; j--) suf = add2(suf, ld2<COH>(f2v, b + j * stride));
     const double2 o = add2(pre, suf);
-    if (!__builtin_isnan(o.y)) v2f[slot] = o;
+    if (!__builtin_isnan(o.y)) { v2f[slot] = o; if (fwd) *fwd = o; }
 }
 
 // halo export: variable→factor of the exported slots, computed straight into the send buffer (and into v2f)
@@ -431,7 +431,7 @@ __device__ __forceinline__ void batch_item(int k, int idx, int v, int lo, int hi
                                            const int32_t *__restrict__ partner, const double *__restrict__ q,
                                            const double *__restrict__ pa, const double *__restrict__ pb,
                                            double2 *__restrict__ f2v, double2 *__restrict__ v2f, double2 *__restrict__ marg, int nat_marg,
-                                           double2 *__restrict__ prod, double *__restrict__ joint, const KaryTab kt) {
+                                           double2 *__restrict__ prod, double *__restrict__ joint, const KaryTab kt, double2 *fwd = nullptr) {
     if (k == kItemKaryEntry) {            // internal (the tree schedule's stage lists): index = entry of the k-ary table
         kary_item<COH>(idx, kt.slot, kt.coef, kt.qb, v2f, f2v);
     } else if (k >= kItemMfNormal && k <= kItemStGamma) {
@@ -441,9 +441,9 @@ __device__ __forceinline__ void batch_item(int k, int idx, int v, int lo, int hi
         for (int j = 0; j < hi; j++) { const int s = kt.list[lo + j]; acc = add2(acc, s >= 0 ? ld2<COH>(f2v, s) : ld2<COH>(prod, ~s)); }
         if (k == kItemSumToMarginal) marg[v] = nat_marg ? acc : to_moment(acc);
         else if (k == kItemSumToGammaMarginal) marg[v] = make_double2(acc.x + 1.0, 1.0 / acc.y);
-        else if (!__builtin_isnan(acc.y)) { if (k == kItemSumToFactor) v2f[idx] = acc; else prod[idx] = acc; }
+        else if (!__builtin_isnan(acc.y)) { if (k == kItemSumToFactor) { v2f[idx] = acc; if (fwd) *fwd = acc; } else prod[idx] = acc; }
     } else if (k == CX_ITEM_MESSAGE_TO_FACTOR) {
-        m2f_one<COH>(idx, v, vbase, vdeg, vinfo, f2v, v2f);
+        m2f_one<COH>(idx, v, vbase, vdeg, vinfo, f2v, v2f, fwd);
     } else if (k == CX_ITEM_MESSAGE_TO_VARIABLE) {
         const int p = partner[idx];
         if (p < 0) return;
@@ -493,6 +493,31 @@ __device__ __forceinline__ void batch_item(int k, int idx, int v, int lo, int hi
     }
 }
 
+
+// a record that leads and the record behind it, by one thread (cx_refsched.h: kRecLeads).  A MessageToFactor and the pairwise rule that reads
+// it pass the message on in a register; any other pair stores first (the follower then loads what the leader has written through)
+template <int MODE>
+__device__ __forceinline__ void batch_pair(const int32_t *__restrict__ lead, const int32_t *__restrict__ fol, const int32_t *__restrict__ vbase,
+                                           const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
+                                           const double *__restrict__ q, const double *__restrict__ pa, const double *__restrict__ pb, double2 *__restrict__ f2v,
+                                           double2 *__restrict__ v2f, double2 *__restrict__ marg, int nat_marg, double2 *__restrict__ prod, double *__restrict__ joint,
+                                           const KaryTab kt) {
+    const int kl = lead[0] & kRecKindMask, kf = fol[0] & kRecKindMask, fidx = fol[1];
+    if ((kl == CX_ITEM_MESSAGE_TO_FACTOR || kl == kItemSumToFactor) && kf == CX_ITEM_MESSAGE_TO_VARIABLE && partner[fidx] == lead[1]) {
+        const double qq = q[fidx], a = MODE == kRuleLinear ? pa[fidx] : 1.0, b = MODE == kRuleLinear ? pb[fidx] : 0.0;
+        double2 m = nan2();
+        batch_item<MODE>(kl, lead[1], lead[2], lead[3], lead[4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, &m);
+        if (__builtin_isnan(m.y)) m = v2f[lead[1]];      // the leader stored nothing (an observed variable, an undefined input): what is stored there
+        if (__builtin_isnan(m.y)) return;
+        const double2 r = factor_rule<MODE>(m, qq, a, b);
+        if (MODE != kRuleBernoulli || !__builtin_isnan(r.y)) f2v[fidx] = r;
+        return;
+    }
+    batch_item<MODE>(kl, lead[1], lead[2], lead[3], lead[4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the leader's store has been written through before the follower loads it
+    batch_item<MODE>(kf, fol[1], fol[2], fol[3], fol[4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_batch(int64_t n, const int32_t *__restrict__ rec, const int32_t *__restrict__ vbase,
                                                   const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
@@ -504,13 +529,8 @@ __global__ __launch_bounds__(kBlock) void k_batch(int64_t n, const int32_t *__re
     if (i >= n) return;
     const int k0 = rec[5 * i];
     if (k0 & kRecFollows) return;
-    batch_item<MODE>(k0 & kRecKindMask, rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg,
-                     nat_marg, prod, joint, kt);
-    if (k0 & kRecLeads) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the leader's store has been written through before the follower loads it
-        batch_item<MODE>(rec[5 * i + 5] & kRecKindMask, rec[5 * i + 6], rec[5 * i + 7], rec[5 * i + 8], rec[5 * i + 9], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f,
-                         marg, nat_marg, prod, joint, kt);
-    }
+    if (k0 & kRecLeads) batch_pair<MODE>(rec + 5 * i, rec + 5 * i + 5, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+    else batch_item<MODE>(k0, rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
 }
 
 // A RUN of consecutive thin stages of the tree schedule (each at most kRunBlock items) in ONE launch of ONE workgroup: the stages of a
@@ -529,13 +549,8 @@ __global__ __launch_bounds__(kRunBlock) void k_batch_run(const int64_t *__restri
         for (int64_t i = stage_off[st] + threadIdx.x; i < stage_off[st + 1]; i += kRunBlock) {      // (the tree schedule folds stages of at most kRunBlock items: one trip)
             const int k0 = rec[5 * i];
             if (k0 & kRecFollows) continue;
-            batch_item<MODE>(k0 & kRecKindMask, rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg,
-                             nat_marg, prod, joint, kt);
-            if (k0 & kRecLeads) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                batch_item<MODE>(rec[5 * i + 5] & kRecKindMask, rec[5 * i + 6], rec[5 * i + 7], rec[5 * i + 8], rec[5 * i + 9], vbase, vdeg, vinfo, partner, q, pa, pb, f2v,
-                                 v2f, marg, nat_marg, prod, joint, kt);
-            }
+            if (k0 & kRecLeads) batch_pair<MODE>(rec + 5 * i, rec + 5 * i + 5, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+            else batch_item<MODE>(k0, rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
