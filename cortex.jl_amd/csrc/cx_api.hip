@@ -28,6 +28,7 @@ void dev_free_all(cx_handle *h) {
     tree_graph_drop(h); h->tree_graph_failed = false;
     if (h->d_cluster_ctl) { (void)hipFree(h->d_cluster_ctl); h->d_cluster_ctl = nullptr; }
     h->cluster_state = 0;
+    h->set_memos.clear();
     ref_free(h);
     cx::chain64_free(h);
     cx::chain64_tree_free(h);

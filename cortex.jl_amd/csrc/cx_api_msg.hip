@@ -56,9 +56,44 @@ int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
     }
     if (h->cfg.dim > 1) { try { return mv_set_messages(h, n, variable_ids, factor_ids, direction, form, payload); } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_set_messages: host allocation failed"); } }
     try {
-        std::vector<int32_t> idx, vars;
-        int32_t rc = stage_slots(h, n, variable_ids, factor_ids, idx, &vars);
-        if (rc != CX_OK) return rc;
+        // a long list is usually the list of the call before (an iteration's priors, a stream's data): its translation is kept
+        std::vector<int32_t> idx_local, vars_local;
+        const std::vector<int32_t> *idx_p = &idx_local, *vars_p = &vars_local;
+        const std::vector<int64_t> *edges_p = nullptr;
+        uint64_t set_key = 0;
+        constexpr int64_t kMemoMin = 4096;
+        if (n >= kMemoMin) {
+            uint64_t k = 0x9e3779b97f4a7c15ull ^ (uint64_t)n ^ ((uint64_t)direction << 56);
+            for (int64_t i = 0; i < n; i++) { k ^= (uint64_t)variable_ids[i] * 0xff51afd7ed558ccdull; k = (k << 23 | k >> 41) + (uint64_t)factor_ids[i] * 0xc4ceb9fe1a85ec53ull; }
+            k |= 1;
+            cx_handle::SetMemo *m = nullptr;
+            for (auto &c : h->set_memos)
+                if (c.key == k && c.direction == direction && (int64_t)c.var_ids.size() == n && std::memcmp(c.var_ids.data(), variable_ids, (size_t)n * 8) == 0 &&
+                    std::memcmp(c.fac_ids.data(), factor_ids, (size_t)n * 8) == 0) { m = &c; break; }
+            if (!m) {
+                cx_handle::SetMemo c;
+                c.key = k; c.direction = direction;
+                int32_t rc0 = stage_slots(h, n, variable_ids, factor_ids, c.idx, &c.vars);
+                if (rc0 != CX_OK) return rc0;
+                c.edges.resize((size_t)n);
+                for (int64_t i = 0; i < n; i++) c.edges[i] = find_edge(h, variable_ids[i], factor_ids[i]);
+                c.var_ids.assign(variable_ids, variable_ids + n); c.fac_ids.assign(factor_ids, factor_ids + n);
+                if (h->set_memos.size() >= 2) {      // the least recently used one goes
+                    size_t lru = 0;
+                    for (size_t j = 1; j < h->set_memos.size(); j++) if (h->set_memos[j].used < h->set_memos[lru].used) lru = j;
+                    h->set_memos.erase(h->set_memos.begin() + lru);
+                }
+                h->set_memos.push_back(std::move(c));
+                m = &h->set_memos.back();
+            }
+            m->used = ++h->set_memo_tick;
+            idx_p = &m->idx; vars_p = &m->vars; edges_p = &m->edges; set_key = k;
+        } else {
+            int32_t rc0 = stage_slots(h, n, variable_ids, factor_ids, idx_local, &vars_local);
+            if (rc0 != CX_OK) return rc0;
+        }
+        const std::vector<int32_t> &idx = *idx_p, &vars = *vars_p;
+        int32_t rc = CX_OK;
         const int64_t stride = form == CX_FORM_POINT ? 1 : 2;
         std::vector<double2> val(n);
         for (int64_t i = 0; i < n; i++) to_natural(form, payload + i * stride, &val[i]);
@@ -92,9 +127,12 @@ int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
         CX_HIP(h, hipGetLastError());
         CX_HIP(h, hipStreamSynchronize(h->stream));  // host staging vectors die here
         if (h->ref) {      // CX_SCHED_REFERENCE: the user's set_value! on the shadow of the readiness state, in list order
-            std::vector<int64_t> edges((size_t)n);
-            for (int64_t i = 0; i < n; i++) edges[i] = find_edge(h, variable_ids[i], factor_ids[i]);
-            ref_on_set(h, n, edges.data(), direction);
+            if (edges_p) ref_on_set(h, n, edges_p->data(), direction, set_key);
+            else {
+                std::vector<int64_t> edges((size_t)n);
+                for (int64_t i = 0; i < n; i++) edges[i] = find_edge(h, variable_ids[i], factor_ids[i]);
+                ref_on_set(h, n, edges.data(), direction, 0);
+            }
         }
         return CX_OK;
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_set_messages: host allocation failed"); }

@@ -39,6 +39,10 @@ struct RefSched {
     std::vector<PlanEntry> cache;
     std::vector<int32_t> prod_slot;             // segment-tree node -> index in the handle's product store
     std::vector<int32_t> joint_slot;            // factor -> index in the handle's joint store (-1: its joint marginal is not wired)
+    // the user's set_value! loop over a list cx_set_messages knows (set_key): the state it leads to, per state it started from — an iteration
+    // that re-sets its 2 M priors walks 2 M signals and copies a 200 MB state otherwise, every time, to arrive where it arrived before
+    struct SetTrans { uint64_t pre = 0, set_key = 0, used = 0; std::shared_ptr<const rs::State> post; };
+    std::vector<SetTrans> set_trans;
     std::vector<int32_t> all_req;               // the request of a plain cx_sweep (every variable that is neither observed nor a stand-in) and its key,
     uint64_t all_key = 0, all_epoch = ~0ull;    // kept while the observed flags stand (2 M ids at C4: 12 ms of host time per call to rebuild and hash)
     int64_t hits = 0, misses = 0;
@@ -281,11 +285,29 @@ int32_t ref_build(cx_handle *h) {
 }
 
 // set_value! of message signals through the ABI (cx_set_messages): edges as CSR indices
-void ref_on_set(cx_handle *h, int64_t n, const int64_t *edges, int32_t direction) {
+void ref_on_set(cx_handle *h, int64_t n, const int64_t *edges, int32_t direction, uint64_t set_key) {
     RefSched *R = ref_of(h);
     if (!R || n == 0) return;
+    const uint64_t pre = R->S->hash;
+    if (set_key)
+        for (auto &t : R->set_trans)
+            if (t.pre == pre && t.set_key == set_key) {      // the same list from the same state: the same state
+                t.used = ++R->tick;
+                R->touched = true;
+                if (R->S.use_count() == 1 && R->S != t.post) R->spare = std::move(R->S);
+                R->S = std::const_pointer_cast<rs::State>(t.post);
+                return;
+            }
     rs::State &S = writable(R);
     for (int64_t i = 0; i < n; i++) rs::set_value(R->W, S, direction == CX_TO_FACTOR ? R->W.sig_v2f(edges[i]) : R->W.sig_f2v(edges[i]));
+    if (set_key) {
+        if (R->set_trans.size() >= 3) {
+            size_t lru = 0;
+            for (size_t j = 1; j < R->set_trans.size(); j++) if (R->set_trans[j].used < R->set_trans[lru].used) lru = j;
+            R->set_trans.erase(R->set_trans.begin() + lru);
+        }
+        R->set_trans.push_back(RefSched::SetTrans{pre, set_key, ++R->tick, R->S});      // (shared from now on: the next writer copies)
+    }
 }
 
 // set_value! of marginal signals (cx_set_marginals under a user wiring): local variable numbers
@@ -554,7 +576,7 @@ int32_t cx_graph_wire(cx_handle *h, int64_t n, const cx_item *signals, const cx_
         if (rc != CX_OK) return fail(h, rc, err);
         CX_HIP(h, hipStreamSynchronize(h->stream));
         for (auto &e : R->cache) entry_free(h, e);
-        R->cache.clear(); R->last = -1;
+        R->cache.clear(); R->last = -1; R->set_trans.clear();
         R->W = std::move(W);
         R->S = std::make_shared<rs::State>();
         rs::init_state(R->W, *R->S);

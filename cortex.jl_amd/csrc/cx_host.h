@@ -163,7 +163,7 @@ int32_t ensure_prod_store(cx_handle *h);   // the product store holds every regi
 int32_t ref_build(cx_handle *h);
 void ref_free(cx_handle *h);
 void ref_graphs_drop(cx_handle *h);
-void ref_on_set(cx_handle *h, int64_t n, const int64_t *edges, int32_t direction);
+void ref_on_set(cx_handle *h, int64_t n, const int64_t *edges, int32_t direction, uint64_t set_key = 0);      // set_key != 0: the list is one cx_set_messages keeps (the state it leads to is kept too)
 void ref_on_seed(cx_handle *h, int32_t direction);
 void ref_on_batch(cx_handle *h, const cx_item *items, int64_t n);
 // the XCD-resident cluster (cx_api_ref.hip)

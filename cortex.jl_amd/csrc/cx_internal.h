@@ -195,6 +195,11 @@ struct cx_handle {
     int ipc_quiet_lo = 1, ipc_quiet_hi = 0;   // the longest run of owned-only slices none of whose variables WRITES a message of the send list
                                               // (cx_halo_ipc_batch: that run of the last sweep is computed after the push); empty: none
     double damping = 0.0;            // cx_set_damping: new = (1 - damping) rule + damping old (fused and flooding sweeps)
+    // cx_set_messages of a long list the caller repeats (an iteration re-sets its priors before every call): ids -> slots / variables / edges,
+    // kept for the last lists (the ids themselves are kept and compared: a hash alone would be trusted with the device's memory)
+    struct SetMemo { uint64_t key = 0, used = 0; int32_t direction = 0; std::vector<int64_t> var_ids, fac_ids, edges; std::vector<int32_t> idx, vars; };
+    std::vector<SetMemo> set_memos;
+    uint64_t set_memo_tick = 0;
     uint64_t vinfo_epoch = 0;        // bumped whenever the observed flags of vinfo change (a cached "every free variable" request is then stale)
     bool in_sweep = false;
     bool v2f_stale = false;          // fused schedule without materialisation: v2f must be recomputed before use

@@ -88,6 +88,29 @@ def test_one_sweep_on_a_loopy_graph_is_one_update_marginals_of_the_reference(hip
     dev.close()
 
 
+def test_a_long_list_of_priors_re_set_every_call_is_translated_once(hip_lib):
+    """cx_set_messages keeps the translation of a list of 4,096 ids or more (ids -> slots, variables, edges) and, under this schedule, the
+    readiness state the list leads to from the state it started from: an iteration "set the priors, call" on 70 x 72 = 5,040 variables —
+    with NEW prior values every time, the same list in another order once, and a shorter list once — against the restated engine, call by
+    call: the executions in order, every message, every marginal"""
+    model = cx.synth.gaussian_grid(70, 72, seed=4)
+    E, dev = _start(model)
+    rng = np.random.default_rng(0)
+    n = len(model.prior_var)
+    for call in range(7):
+        if call:
+            order = rng.permutation(n) if call == 4 else np.arange(n)
+            keep = order[: n - 500] if call == 5 else order
+            mean, var = model.prior_mean + 0.1 * call, model.prior_variance * (1.0 + 0.2 * call)
+            E.set_messages_to_variable(model.prior_var[keep], model.prior_fac[keep], mean[keep], var[keep])
+            dev.set_messages(model.prior_var[keep], model.prior_fac[keep], L.TO_VARIABLE, L.FORM_MOMENT, np.stack([mean[keep], var[keep]], axis=1))
+        dev.sweep(1)
+        E.update_marginals(model.x_ids)
+        assert dev.ref_trace() == _oracle_trace(E), f"call {call + 1}: the executions, in order"
+        _compare(dev, E, model, model.x_ids, f"call {call + 1}")
+    dev.close()
+
+
 def test_the_sweep_differs_from_a_jacobi_sweep_and_shares_its_fixed_point(hip_lib):
     """what the item asks for in one sentence: the fused schedule's sweep is NOT the reference's call (it reads old values), the
     reference-order schedule's is; both reach the same messages, and the exact posterior means"""
