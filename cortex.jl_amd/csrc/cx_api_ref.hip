@@ -43,6 +43,9 @@ struct RefSched {
     // that re-sets its 2 M priors walks 2 M signals and copies a 200 MB state otherwise, every time, to arrive where it arrived before
     struct SetTrans { uint64_t pre = 0, set_key = 0, used = 0; std::shared_ptr<const rs::State> post; };
     std::vector<SetTrans> set_trans;
+    std::vector<int64_t> last_ids;              // the id list of the last long cx_sweep_for, its request and key (a repeated request is compared, not translated again)
+    std::vector<int32_t> last_req;
+    uint64_t last_key = 0;
     std::vector<int32_t> all_req;               // the request of a plain cx_sweep (every variable that is neither observed nor a stand-in) and its key,
     uint64_t all_key = 0, all_epoch = ~0ull;    // kept while the observed flags stand (2 M ids at C4: 12 ms of host time per call to rebuild and hash)
     int64_t hits = 0, misses = 0;
@@ -521,11 +524,20 @@ int32_t cx_sweep_for(cx_handle *h, int64_t n, const int64_t *variable_ids) {
                "messages those marginals need, level by level); the other schedules compute every message: cx_sweep");
     CX_REQUIRE(h, n >= 0 && (n == 0 || variable_ids), CX_ERR_INVALID_ARGUMENT, "cx_sweep_for: null argument");
     try {
+        RefSched *R = ref_of(h);
+        if (R && n >= 4096 && (int64_t)R->last_ids.size() == n && std::memcmp(R->last_ids.data(), variable_ids, (size_t)n * 8) == 0)
+            return ref_sweep(h, R->last_req.data(), n, &R->last_key);
         std::vector<int32_t> req((size_t)n);
         for (int64_t i = 0; i < n; i++) {
             const int64_t v = find_var(h, variable_ids[i]);
             if (v < 0) return fail(h, CX_ERR_NOT_FOUND, "unknown variable id " + std::to_string(variable_ids[i]));
             req[i] = (int32_t)v;
+        }
+        if (R && n >= 4096) {
+            R->last_ids.assign(variable_ids, variable_ids + n);
+            R->last_key = request_key(req.data(), n);
+            R->last_req = req;
+            return ref_sweep(h, R->last_req.data(), n, &R->last_key);
         }
         return ref_sweep(h, req.data(), n, nullptr);
     } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_sweep_for: host allocation failed"); }
