@@ -19,6 +19,7 @@ namespace {
 struct PlanEntry {
     uint64_t key = 0, req_key = 0;
     int32_t *d_rec = nullptr, *d_list = nullptr, *d_wide_rec = nullptr, *d_flat = nullptr;
+    double *d_wide_partial = nullptr;           // 64 pairs of scratch per wide item of the widest stage (k_wide_sum)
     int64_t *d_stage_off = nullptr;
     std::vector<int64_t> stage_off, wide_off;
     hipGraphExec_t exec = nullptr;
@@ -60,8 +61,8 @@ RefSched *ref_of(cx_handle *h) { return (RefSched *)h->ref; }
 
 void entry_free(cx_handle *h, PlanEntry &e) {
     if (e.exec) { (void)hipGraphExecDestroy(e.exec); e.exec = nullptr; }
-    for (void *p : {(void *)e.d_rec, (void *)e.d_list, (void *)e.d_stage_off, (void *)e.d_wide_rec, (void *)e.d_flat}) if (p) (void)hipFree(p);
-    e.d_rec = e.d_list = e.d_wide_rec = e.d_flat = nullptr; e.d_stage_off = nullptr;
+    for (void *p : {(void *)e.d_rec, (void *)e.d_list, (void *)e.d_stage_off, (void *)e.d_wide_rec, (void *)e.d_flat, (void *)e.d_wide_partial}) if (p) (void)hipFree(p);
+    e.d_rec = e.d_list = e.d_wide_rec = e.d_flat = nullptr; e.d_stage_off = nullptr; e.d_wide_partial = nullptr;
     h->device_bytes -= e.device_bytes; e.device_bytes = 0;
 }
 
@@ -89,7 +90,7 @@ int64_t issue(cx_handle *h, RefSched *R, const PlanEntry &e, bool count_only) {
         if (t >= s + 2) { if (!count_only) cx::launch_batch_run(h, e.d_rec, e.d_stage_off, (int)s, (int)t); launches++; s = t; continue; }
         const int64_t n = e.stage_off[s + 1] - e.stage_off[s], nw = wide_at(s);
         if (n > 0) { if (!count_only) cx::launch_batch(h, e.d_rec + 5 * e.stage_off[s], n); launches++; }
-        if (nw > 0) { if (!count_only) cx::launch_wide_sum(h, e.d_wide_rec + 5 * e.wide_off[s], nw); launches++; }      // (independent of the stage's other items)
+        if (nw > 0) { if (!count_only) cx::launch_wide_sum(h, e.d_wide_rec + 5 * e.wide_off[s], nw, e.d_wide_partial); launches += 2; }      // (independent of the stage's other items)
         s++;
     }
     return launches;
@@ -437,7 +438,8 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n, const uint64_t *k
             const int64_t before = h->device_bytes;
             int32_t rc2;
             if ((rc2 = dev_upload(h, &e.d_rec, P.rec)) != CX_OK || (rc2 = dev_upload(h, &e.d_list, P.list)) != CX_OK || (rc2 = dev_upload(h, &e.d_stage_off, P.stage_off)) != CX_OK ||
-                (rc2 = dev_upload(h, &e.d_wide_rec, P.wide_rec)) != CX_OK || (e.cluster && (rc2 = dev_upload(h, &e.d_flat, flat)) != CX_OK)) {
+                (rc2 = dev_upload(h, &e.d_wide_rec, P.wide_rec)) != CX_OK || (e.cluster && (rc2 = dev_upload(h, &e.d_flat, flat)) != CX_OK) ||
+                (!P.wide_rec.empty() && (rc2 = dev_alloc(h, &e.d_wide_partial, (int64_t)(P.wide_rec.size() / 5) * 64 * 2)) != CX_OK)) {
                 e.device_bytes = h->device_bytes - before; entry_free(h, e); return rc2;
             }
             e.device_bytes = h->device_bytes - before;

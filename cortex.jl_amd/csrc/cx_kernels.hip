@@ -772,25 +772,39 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
 }
 
 // A list item of thousands of sources (cx_refsched.h: kWideList — the flat product a mean-field wiring makes of a precision's marginal):
-// one workgroup per item, a strided partial sum per thread, the partials folded in a fixed tree (wavefront shuffles, then shared memory):
-// deterministic, and a different association than the reference's left fold — a rounding-level difference.
+// a strided partial sum per thread, the partials folded in a fixed tree (wavefront shuffles, then shared memory), the workgroups' partials
+// in order: deterministic, and a different association than the reference's left fold — a rounding-level difference.
+// grid (items, kWideParts): part p of an item sums the sources p, p + kWideParts, ... of its list in strides of the workgroup — a list of 10^6
+// sources is 64 workgroups' work, not one's (0.83 ms for one workgroup) — and leaves ONE partial; k_wide_finish folds an item's partials
+// in order and stores the result
+constexpr int kWideParts = 64;
 __global__ __launch_bounds__(1024) void k_wide_sum(const int32_t *__restrict__ rec, const int32_t *__restrict__ list, const double2 *__restrict__ f2v,
-                                                   double2 *__restrict__ v2f, double2 *__restrict__ marg, int nat_marg, double2 *__restrict__ prod) {
+                                                   const double2 *__restrict__ prod, double2 *__restrict__ partial) {
     __shared__ double2 part[16];
     const int32_t *r = rec + 5 * (int64_t)blockIdx.x;
-    const int k = r[0], idx = r[1], v = r[2], lo = r[3], hi = r[4];
+    const int lo = r[3], hi = r[4];
     double2 acc = zero2();
-    for (int j = threadIdx.x; j < hi; j += 1024) { const int s = list[lo + j]; acc = add2(acc, s >= 0 ? f2v[s] : prod[~s]); }
+    for (int j = blockIdx.y * 1024 + threadIdx.x; j < hi; j += 1024 * kWideParts) { const int s = list[lo + j]; acc = add2(acc, s >= 0 ? f2v[s] : prod[~s]); }
     for (int off = 32; off > 0; off >>= 1) { acc.x += __shfl_down(acc.x, off, 64); acc.y += __shfl_down(acc.y, off, 64); }
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
         double2 t = part[0];
         for (int w = 1; w < 16; w++) t = add2(t, part[w]);
-        if (k == kItemSumToMarginal) marg[v] = nat_marg ? t : to_moment(t);
-        else if (k == kItemSumToGammaMarginal) marg[v] = make_double2(t.x + 1.0, 1.0 / t.y);
-        else if (!__builtin_isnan(t.y)) { if (k == kItemSumToFactor) v2f[idx] = t; else prod[idx] = t; }
+        partial[(int64_t)blockIdx.x * kWideParts + blockIdx.y] = t;
     }
+}
+__global__ __launch_bounds__(64) void k_wide_finish(const int32_t *__restrict__ rec, int n, const double2 *__restrict__ partial, double2 *__restrict__ v2f,
+                                                    double2 *__restrict__ marg, int nat_marg, double2 *__restrict__ prod) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t *r = rec + 5 * (int64_t)i;
+    const int k = r[0], idx = r[1], v = r[2];
+    double2 t = partial[(int64_t)i * kWideParts];
+    for (int p = 1; p < kWideParts; p++) t = add2(t, partial[(int64_t)i * kWideParts + p]);
+    if (k == kItemSumToMarginal) marg[v] = nat_marg ? t : to_moment(t);
+    else if (k == kItemSumToGammaMarginal) marg[v] = make_double2(t.x + 1.0, 1.0 / t.y);
+    else if (!__builtin_isnan(t.y)) { if (k == kItemSumToFactor) v2f[idx] = t; else prod[idx] = t; }
 }
 
 // A batch of at most kSmallBatch items travels IN the kernel arguments: no staging copy, nothing for the host to wait for before
@@ -1084,9 +1098,11 @@ void launch_ref_cluster(cx_handle *h, void *d_ctl, int n_workgroups, const int32
 #undef CX_B
 }
 
-void launch_wide_sum(cx_handle *h, const int32_t *d_rec, int64_t n) {
+// d_partial: n x 64 pairs of scratch (cx_api_ref.hip keeps one per plan that has wide items)
+void launch_wide_sum(cx_handle *h, const int32_t *d_rec, int64_t n, void *d_partial) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_wide_sum, dim3((unsigned)n), dim3(1024), 0, h->stream, d_rec, h->d_ref_list, h->d_f2v, h->d_v2f, h->d_marg,
+    hipLaunchKernelGGL(k_wide_sum, dim3((unsigned)n, kWideParts), dim3(1024), 0, h->stream, d_rec, h->d_ref_list, h->d_f2v, h->d_prod, (double2 *)d_partial);
+    hipLaunchKernelGGL(k_wide_finish, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, d_rec, (int)n, (const double2 *)d_partial, h->d_v2f, h->d_marg,
                        h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0, h->d_prod);
 }
 
