@@ -24,7 +24,7 @@ struct PlanEntry {
     std::vector<int64_t> stage_off, wide_off;
     hipGraphExec_t exec = nullptr;
     bool graph_failed = false;
-    bool cluster = false;                       // every stage in ONE launch of an XCD-resident cluster (cx_kernels.hip: k_ref_cluster)
+    bool cluster = false;                       // every stage in ONE launch of an XCD-resident cluster (cx_batch.hip: k_ref_cluster)
     std::shared_ptr<const rs::State> post;      // the readiness state the call leaves
     std::vector<int32_t> order;                 // the executions, in the reference's order (cx_ref_trace)
     int64_t n_messages = 0, n_marginals = 0, n_products = 0, rounds = 0, launches = 0, list_entries = 0;
@@ -131,7 +131,7 @@ int32_t run_entry(cx_handle *h, RefSched *R, PlanEntry &e) {
 
 namespace cxh {
 
-// The records of a plan with everything the graph's tables would answer already filled in (cx_kernels.hip: FlatRec — kind | n << 8,
+// The records of a plan with everything the graph's tables would answer already filled in (cx_batch.hip: FlatRec — kind | n << 8,
 // destination, variable, five sources): what the XCD-resident cluster runs, so that an item's chain of dependent loads is its values and
 // nothing else.  Items that do not fit (more than five sources, rules of factors with more than two edges, variational rules) point back
 // at their ordinary record.

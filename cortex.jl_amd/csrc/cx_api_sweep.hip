@@ -241,7 +241,7 @@ int32_t build_tree(cx_handle *h) {
             }
         }
         if (!h->tree_hp) std::memset(h->tree_hp_stats, 0, sizeof h->tree_hp_stats);
-        // a stage's messages out of factors with more than two edges ride in the same list as its other items (cx_kernels.hip:
+        // a stage's messages out of factors with more than two edges ride in the same list as its other items (cx_batch.hip:
         // kItemKaryEntry): one launch per stage
         std::vector<int32_t> rec;
         std::vector<int64_t> off(1, 0), koff(plan.kary_off.size(), 0);
@@ -288,7 +288,7 @@ int32_t build_tree(cx_handle *h) {
             off.push_back((int64_t)rec.size() / 5);
         }
         if (!rec.empty() && (rc2 = dev_upload(h, &h->d_tree_rec, rec)) != CX_OK) return rc2;
-        // (The XCD-resident cluster of the reference-order plans — cx_kernels.hip: k_ref_cluster — was tried on these level plans too and
+        // (The XCD-resident cluster of the reference-order plans — cx_batch.hip: k_ref_cluster — was tried on these level plans too and
         // taken out again: a tree's levels are thin next to the roots, where one workgroup's runs cost 1 us a stage, and one huge level of
         // leaves, which wants the whole chip; the 1.09 M-edge forest took 1.24 ms on the cluster against 0.63 as launches, and no forest of
         // tools/bench_configs.py or the tests has the many stages of 1 - 16 k items the cluster wins on.)
@@ -353,7 +353,7 @@ static void tree_issue(cx_handle *h) {
             s++; continue;
         }
         if (h->cfg.dim > 1) { if (n > 0) cx::mv_launch_batch(h, h->d_tree_rec + 5 * h->tree_stage_off[s], n); s++; continue; }
-        // dim 1: consecutive thin stages (the levels next to the roots) leave as ONE launch of one workgroup (cx_kernels.hip: k_batch_run)
+        // dim 1: consecutive thin stages (the levels next to the roots) leave as ONE launch of one workgroup (cx_batch.hip: k_batch_run)
         size_t e = s;
         while (runs && e < ns && h->tree_stage_off[e + 1] - h->tree_stage_off[e] <= 1024) e++;
         if (e >= s + 2) { cx::launch_batch_run(h, h->d_tree_rec, h->d_tree_stage_off, (int)s, (int)e); s = e; continue; }

@@ -1,0 +1,557 @@
+// cx_batch.hip — scalar (dim 1) work as ITEMS: the batched boundary of the plug-in (cx_update_batch: one thread per enqueued signal), the
+// stage plans of the tree and reference-order schedules (a launch per stage, runs of thin stages in one workgroup), the XCD-resident
+// cluster that takes a whole reference-order plan in one launch, and the workgroup sums of long dependency lists.  The sweeps are
+// cx_kernels.hip; what both share is cx_scalar_core.h.
+#include <algorithm>
+#include <cstdlib>
+
+#include "cx_scalar_core.h"
+
+namespace cx {
+
+// ------------------------------------------------------------------------------------------------
+// Batched mode: one thread per enqueued signal (the processor's `process!` override flushes a batch of
+// mutually independent pending signals; inference_engine.jl:528-537 is the precedent for collecting).
+// ------------------------------------------------------------------------------------------------
+// Item record (5 int32): kind, index, var, lo, hi.
+//   MESSAGE_TO_FACTOR / MESSAGE_TO_VARIABLE: index = slot, var = local variable
+//   INDIVIDUAL_MARGINAL:                     index = var = local variable
+//   PRODUCT_OF_MESSAGES (compute_product_of_messages!, inference_engine.jl:439-449; the segment-tree intermediates of
+//                        dependencies.jl:128-173): index = node in the product store, var = local variable, [lo, hi] = 1-based
+//                        inclusive range over the variable's neighbours (ascending factor id); value = product of those
+//                        factor→variable messages (natural form: their sum, left to right like the reference's fold)
+//   JOINT_MARGINAL (compute_joint_marginal!, :469-477): index = node in the joint store, var = slot of the factor's edge whose
+//                        rule parameters describe x_out = a x_in + b + N(0, q) (the OUT edge; either edge of an additive
+//                        factor), lo = slot of the other edge, hi = 1 when the OUT edge's variable has the LOWER id (output
+//                        order is ascending variable id).  Value: the 2-d Gaussian proportional to factor x the two
+//                        variable→factor messages, as mean[2] + covariance[4].
+// a message out of a factor with more than two edges as a batch item (cx_kary_core.h): not a kind of the public interface —
+// cx_update_batch refuses kinds it does not know and routes such messages itself
+constexpr int kItemKaryEntry = 32;
+struct KaryTab { const int32_t *slot; const double *coef, *qb; const int32_t *list; };
+// items of the reference-order plans (cx_refsched.h) for the signals of variables of degree > 5, whose dependencies are segment-tree
+// nodes (dependencies.jl:90-173): the value is the sum — the reference's `reduce(product, get_value.(deps))` in natural form — of the
+// `hi` sources list[lo ..): an entry >= 0 is a factor→variable slot, ~entry a node of the product store.  What the reference's rule
+// call read, node by node — a node may lag behind its leaves on a graph with loops, and the reference reads the node.
+constexpr int kItemSumToFactor = 64, kItemSumToProduct = 65, kItemSumToMarginal = 66;
+// a record that LEADS is followed in its stage's list by a record that FOLLOWS: one thread computes the first, waits for its store, and
+// computes the second — a MessageToFactor and the MessageToVariable that reads it, levelled as one item (cx_refsched.h: kRecLeads)
+constexpr int kRecLeads = 0x40000000, kRecFollows = 0x20000000, kRecKindMask = 0x0fffffff;
+// ... and the variational rules of a CX_FACTOR_NORMAL_PRECISION factor (out ~ N(in, 1 / precision), precision ~ Gamma) that a user wiring
+// selects (cx_refsched.h: kRule*; the reference's test rules, test/inference_engine_tests.jl:647-689, 939-1030).  Marginals are read from
+// the marginal store: (mean, variance) of a Normal variable ((datum, 0) when observed), (shape, scale) of a precision — 72 stores the
+// latter from the natural-parameter sum (shape - 1, rate).  A message to a precision is Gamma(3/2, 2 / spread) = natural (1/2, spread / 2).
+constexpr int kItemMfNormal = 67, kItemMfGamma = 68, kItemStNormal = 69, kItemVmpJoint = 70, kItemStGamma = 71, kItemSumToGammaMarginal = 72;
+template <bool COH>
+__device__ __forceinline__ void vmp_item(int k, int idx, int lo, const int32_t *__restrict__ list, double2 *__restrict__ f2v, const double2 *__restrict__ v2f,
+                                         const double2 *__restrict__ marg, double *__restrict__ joint) {
+    const double inf = __builtin_inf();
+    if (k == kItemMfNormal) {                 // N(E[other], E[precision])                                                        (:654-664)
+        const double2 a = ld2<COH>(marg, list[lo]), g = ld2<COH>(marg, list[lo + 1]);
+        const double eg = g.x * g.y;
+        if (!__builtin_isnan(a.x) && !__builtin_isnan(eg)) f2v[idx] = make_double2(a.x * eg, eg);
+    } else if (k == kItemMfGamma) {           // Gamma(3/2, 2 / (var a + var b + (E a - E b)^2))                                  (:666-684)
+        const double2 a = ld2<COH>(marg, list[lo]), b = ld2<COH>(marg, list[lo + 1]);
+        const double d = a.x - b.x, spread = a.y + b.y + d * d;
+        if (!__builtin_isnan(spread)) f2v[idx] = make_double2(0.5, 0.5 * spread);
+    } else if (k == kItemStNormal) {          // N(mean m, 1 / (var m + 1 / E[precision])), m the other Normal variable's message    (:1004-1010)
+        const double2 m = ld2<COH>(v2f, list[lo]), g = ld2<COH>(marg, list[lo + 1]);
+        const double eg = g.x * g.y;
+        if (__builtin_isnan(m.y) || __builtin_isnan(m.x) || __builtin_isnan(eg)) return;
+        const double mean = m.y == inf ? m.x : m.x / m.y, var = m.y == inf ? 0.0 : 1.0 / m.y;
+        const double w = 1.0 / (var + 1.0 / eg);
+        f2v[idx] = make_double2(mean * w, w);
+    } else if (k == kItemVmpJoint) {          // the 2-d Gaussian with precision [[w1 + E, -E], [-E, w2 + E]] and potential (xi1, xi2)  (:939-967)
+        const double2 m1 = ld2<COH>(v2f, list[lo]), m2 = ld2<COH>(v2f, list[lo + 1]), g = ld2<COH>(marg, list[lo + 2]);
+        const double eg = g.x * g.y;
+        if (__builtin_isnan(m1.y) || __builtin_isnan(m1.x) || __builtin_isnan(m2.y) || __builtin_isnan(m2.x) || __builtin_isnan(eg)) return;
+        double mu1, mu2, v11, v12, v22;
+        if (m1.y == inf && m2.y == inf) { mu1 = m1.x; mu2 = m2.x; v11 = v12 = v22 = 0.0; }
+        else if (m1.y == inf) { mu1 = m1.x; v11 = v12 = 0.0; v22 = 1.0 / (m2.y + eg); mu2 = v22 * (m2.x + eg * mu1); }
+        else if (m2.y == inf) { mu2 = m2.x; v22 = v12 = 0.0; v11 = 1.0 / (m1.y + eg); mu1 = v11 * (m1.x + eg * mu2); }
+        else {
+            const double a = m1.y + eg, c = m2.y + eg, idet = 1.0 / (a * c - eg * eg);
+            v11 = c * idet; v12 = eg * idet; v22 = a * idet;
+            mu1 = v11 * m1.x + v12 * m2.x; mu2 = v12 * m1.x + v22 * m2.x;
+        }
+        double *o = joint + 6 * (int64_t)idx;
+        o[0] = mu1; o[1] = mu2; o[2] = v11; o[3] = v12; o[4] = v12; o[5] = v22;
+    } else {                                  // kItemStGamma: Gamma(3/2, 2 / (V11 - 2 V12 + V22 + (m1 - m2)^2)) from the joint          (:1011-1016)
+        const int jb = 6 * list[lo];
+        const double o0 = ld1<COH>(joint, jb), o1 = ld1<COH>(joint, jb + 1), o2 = ld1<COH>(joint, jb + 2), o3 = ld1<COH>(joint, jb + 3), o4 = ld1<COH>(joint, jb + 4), o5 = ld1<COH>(joint, jb + 5);
+        const double d = o0 - o1, spread = o2 - o3 - o4 + o5 + d * d;
+        if (!__builtin_isnan(spread)) f2v[idx] = make_double2(0.5, 0.5 * spread);
+    }
+}
+template <int MODE, bool COH = false>
+__device__ __forceinline__ void batch_item(int k, int idx, int v, int lo, int hi, const int32_t *__restrict__ vbase,
+                                           const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
+                                           const int32_t *__restrict__ partner, const double *__restrict__ q,
+                                           const double *__restrict__ pa, const double *__restrict__ pb,
+                                           double2 *__restrict__ f2v, double2 *__restrict__ v2f, double2 *__restrict__ marg, int nat_marg,
+                                           double2 *__restrict__ prod, double *__restrict__ joint, const KaryTab kt, double2 *fwd = nullptr) {
+    if (k == kItemKaryEntry) {            // internal (the tree schedule's stage lists): index = entry of the k-ary table
+        kary_item<COH>(idx, kt.slot, kt.coef, kt.qb, v2f, f2v);
+    } else if (k >= kItemMfNormal && k <= kItemStGamma) {
+        vmp_item<COH>(k, idx, lo, kt.list, f2v, v2f, marg, joint);
+    } else if (k >= kItemSumToFactor) {   // internal (reference-order plans)
+        double2 acc = zero2();
+        for (int j = 0; j < hi; j++) { const int s = kt.list[lo + j]; acc = add2(acc, s >= 0 ? ld2<COH>(f2v, s) : ld2<COH>(prod, ~s)); }
+        if (k == kItemSumToMarginal) marg[v] = nat_marg ? acc : to_moment(acc);
+        else if (k == kItemSumToGammaMarginal) marg[v] = make_double2(acc.x + 1.0, 1.0 / acc.y);
+        else if (!__builtin_isnan(acc.y)) { if (k == kItemSumToFactor) { v2f[idx] = acc; if (fwd) *fwd = acc; } else prod[idx] = acc; }
+    } else if (k == CX_ITEM_MESSAGE_TO_FACTOR) {
+        m2f_one<COH>(idx, v, vbase, vdeg, vinfo, f2v, v2f, fwd);
+    } else if (k == CX_ITEM_MESSAGE_TO_VARIABLE) {
+        const int p = partner[idx];
+        if (p < 0) return;
+        const double2 m = ld2<COH>(v2f, p);
+        if (__builtin_isnan(m.y)) return;
+        const double2 r = factor_rule<MODE>(m, q[idx], MODE == kRuleLinear ? pa[idx] : 1.0, MODE == kRuleLinear ? pb[idx] : 0.0);
+        if (MODE != kRuleBernoulli || !__builtin_isnan(r.y)) f2v[idx] = r;
+    } else if (k == CX_ITEM_INDIVIDUAL_MARGINAL) {
+        const int deg = vdeg[v];
+        const int stride = ((vinfo[v] & kDegMask) == kBigDeg) ? 1 : kBlock;
+        const int b = vbase[v];
+        double2 acc = zero2();
+        for (int j = 0; j < deg; j++) acc = add2(acc, ld2<COH>(f2v, b + j * stride));
+        marg[v] = (deg > 0) ? (nat_marg ? acc : to_moment(acc)) : nan2();
+    } else if (k == CX_ITEM_PRODUCT_OF_MESSAGES) {
+        const int stride = ((vinfo[v] & kDegMask) == kBigDeg) ? 1 : kBlock;
+        const int b = vbase[v];
+        double2 acc = zero2();
+        for (int j = lo - 1; j < hi; j++) acc = add2(acc, ld2<COH>(f2v, b + j * stride));
+        if (!__builtin_isnan(acc.y)) prod[idx] = acc;     // a dependency is undefined: not pending, keep the stored value
+    } else if (k == CX_ITEM_JOINT_MARGINAL) {
+        if (MODE == kRuleBernoulli) return;
+        const int s_out = v, s_in = lo;
+        const double2 m_in = ld2<COH>(v2f, s_in), m_out = ld2<COH>(v2f, s_out);
+        double *o = joint + 6 * (int64_t)idx;
+        if (__builtin_isnan(m_in.y) || __builtin_isnan(m_out.y)) return;
+        const double a = MODE == kRuleLinear ? pa[s_out] : 1.0, b = MODE == kRuleLinear ? pb[s_out] : 0.0, iq = 1.0 / q[s_out];
+        double mi, mo, cii, cio, coo;
+        const double inf = __builtin_inf();
+        if (m_in.y == inf && m_out.y == inf) { mi = m_in.x; mo = m_out.x; cii = cio = coo = 0.0; }
+        else if (m_in.y == inf) {          // x_in observed: x_out | x_in
+            mi = m_in.x; cii = cio = 0.0;
+            coo = 1.0 / (m_out.y + iq); mo = coo * (m_out.x + (a * mi + b) * iq);
+        } else if (m_out.y == inf) {       // x_out observed
+            mo = m_out.x; coo = cio = 0.0;
+            cii = 1.0 / (m_in.y + a * a * iq); mi = cii * (m_in.x + a * (mo - b) * iq);
+        } else {
+            // precision [[w_in + a²/q, -a/q], [-a/q, w_out + 1/q]], potential [xi_in - a b/q, xi_out + b/q]
+            const double l11 = m_in.y + a * a * iq, l12 = -a * iq, l22 = m_out.y + iq;
+            const double e1 = m_in.x - a * b * iq, e2 = m_out.x + b * iq;
+            const double idet = 1.0 / (l11 * l22 - l12 * l12);
+            cii = l22 * idet; cio = -l12 * idet; coo = l11 * idet;
+            mi = cii * e1 + cio * e2; mo = cio * e1 + coo * e2;
+        }
+        if (hi) { o[0] = mo; o[1] = mi; o[2] = coo; o[3] = cio; o[4] = cio; o[5] = cii; }
+        else    { o[0] = mi; o[1] = mo; o[2] = cii; o[3] = cio; o[4] = cio; o[5] = coo; }
+    }
+}
+
+
+// a record that leads and the record behind it, by one thread (cx_refsched.h: kRecLeads).  A MessageToFactor and the pairwise rule that reads
+// it pass the message on in a register; any other pair stores first (the follower then loads what the leader has written through)
+template <int MODE>
+__device__ __forceinline__ void batch_pair(const int32_t *__restrict__ lead, const int32_t *__restrict__ fol, const int32_t *__restrict__ vbase,
+                                           const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
+                                           const double *__restrict__ q, const double *__restrict__ pa, const double *__restrict__ pb, double2 *__restrict__ f2v,
+                                           double2 *__restrict__ v2f, double2 *__restrict__ marg, int nat_marg, double2 *__restrict__ prod, double *__restrict__ joint,
+                                           const KaryTab kt) {
+    const int kl = lead[0] & kRecKindMask, kf = fol[0] & kRecKindMask, fidx = fol[1];
+    if ((kl == CX_ITEM_MESSAGE_TO_FACTOR || kl == kItemSumToFactor) && kf == CX_ITEM_MESSAGE_TO_VARIABLE && partner[fidx] == lead[1]) {
+        const double qq = q[fidx], a = MODE == kRuleLinear ? pa[fidx] : 1.0, b = MODE == kRuleLinear ? pb[fidx] : 0.0;
+        double2 m = nan2();
+        batch_item<MODE>(kl, lead[1], lead[2], lead[3], lead[4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, &m);
+        if (__builtin_isnan(m.y)) m = v2f[lead[1]];      // the leader stored nothing (an observed variable, an undefined input): what is stored there
+        if (__builtin_isnan(m.y)) return;
+        const double2 r = factor_rule<MODE>(m, qq, a, b);
+        if (MODE != kRuleBernoulli || !__builtin_isnan(r.y)) f2v[fidx] = r;
+        return;
+    }
+    batch_item<MODE>(kl, lead[1], lead[2], lead[3], lead[4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the leader's store has been written through before the follower loads it
+    batch_item<MODE>(kf, fol[1], fol[2], fol[3], fol[4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_batch(int64_t n, const int32_t *__restrict__ rec, const int32_t *__restrict__ vbase,
+                                                  const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
+                                                  const int32_t *__restrict__ partner, const double *__restrict__ q,
+                                                  const double *__restrict__ pa, const double *__restrict__ pb,
+                                                  double2 *__restrict__ f2v, double2 *__restrict__ v2f, double2 *__restrict__ marg, int nat_marg,
+                                                  double2 *__restrict__ prod, double *__restrict__ joint, const KaryTab kt) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int k0 = rec[5 * i];
+    if (k0 & kRecFollows) return;
+    if (k0 & kRecLeads) batch_pair<MODE>(rec + 5 * i, rec + 5 * i + 5, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+    else batch_item<MODE>(k0, rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+}
+
+// A RUN of consecutive thin stages of the tree schedule (each at most kRunBlock items) in ONE launch of ONE workgroup: the stages of a
+// run depend on each other, so the workgroup takes them one after the other with a barrier (and a workgroup-scope fence: the threads of
+// a workgroup share their compute unit's vector cache) in between — instead of a launch of ≈ 5 us per stage of a few items.  The thin
+// stages are the levels next to the roots, on the way up and again on the way down.
+constexpr int kRunBlock = 1024;
+template <int MODE>
+__global__ __launch_bounds__(kRunBlock) void k_batch_run(const int64_t *__restrict__ stage_off, int s0, int s1, const int32_t *__restrict__ rec,
+                                                         const int32_t *__restrict__ vbase, const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
+                                                         const int32_t *__restrict__ partner, const double *__restrict__ q, const double *__restrict__ pa,
+                                                         const double *__restrict__ pb, double2 *__restrict__ f2v, double2 *__restrict__ v2f,
+                                                         double2 *__restrict__ marg, int nat_marg, double2 *__restrict__ prod, double *__restrict__ joint,
+                                                         const KaryTab kt) {
+    for (int st = s0; st < s1; st++) {
+        for (int64_t i = stage_off[st] + threadIdx.x; i < stage_off[st + 1]; i += kRunBlock) {      // (the tree schedule folds stages of at most kRunBlock items: one trip)
+            const int k0 = rec[5 * i];
+            if (k0 & kRecFollows) continue;
+            if (k0 & kRecLeads) batch_pair<MODE>(rec + 5 * i, rec + 5 * i + 5, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+            else batch_item<MODE>(k0, rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+// ---- an XCD-resident cluster: the stages of a reference-order plan behind barriers that never leave one L2 -------------------------------
+// A reference-order call on a loopy graph is thousands of DEPENDENT stages of a few thousand items (C4: 5,659 stages, 18 M items).  As
+// launches a stage costs ≈ 9 us (launch latency + three dependent memory round trips); a device-wide barrier costs 19 us and more, because
+// the eight XCDs keep separate L2s and an agent-scope release / acquire writes them back and invalidates them (profiles/r04_grid_barrier.txt).
+// The workgroups of ONE XCD share one L2: a store is written through the compute unit's vector cache to it, a load that bypasses the vector
+// cache (ld2<true>: a 16-byte buffer load with scope bit sc1) reads from it, and nothing is written back or invalidated in between — a barrier among them is one
+// counter in that L2: 0.75 us bare, 1.5 us with every thread passing a value to a thread of another workgroup (tools/lab/xcd_barrier.hip,
+// profiles/r05_xcd_barrier.txt: 32 workgroups x 1,024 threads, no wrong value in 2,000 rounds).  So ONE launch of (compute units) workgroups:
+// those that find themselves on XCD 0 (hardware XCC_ID) form the cluster — 32 x 1,024 threads, an eighth of the chip, which is more than
+// a stage is wide — the others leave at once; the members take the plan's stages one after the other, items dealt in runs of 1,024, with
+// that barrier in between.  Values are loaded coherently (batch_item<MODE, true>), plan records and graph constants as always.  Every wait
+// is bounded: a member that gives up raises a flag that all members see and the host checks (cx_api_ref.hip: the call then fails loudly).
+struct ClusterCtl { unsigned registered, members, rank_next, arrive, abort_, xcd_plus_1, pad[10]; };      // 64 B, zeroed before every launch
+
+__device__ __forceinline__ unsigned hw_xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(v));      // HW_REG_XCC_ID
+    return v & 7u;
+}
+__device__ __forceinline__ bool cluster_wait(unsigned *p, unsigned target, unsigned *abort_) {
+    for (unsigned spins = 0;; spins++) {
+        if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        if (spins > (1u << 24)) { __hip_atomic_store(abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }      // seconds
+        if ((spins & 63u) == 63u && __hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    }
+}
+constexpr int kClusterBlock = 1024;
+// What a member does per stage is a chain of dependent round trips to the L2: stage table -> record -> graph tables (degree, base slot,
+// partner) -> values -> store -> barrier.  The first three are known when the plan is made, so the cluster runs FLAT records (cx_api_ref.hip:
+// flat_records, 8 ints): kind | n << 8, destination, variable, five sources resolved to slots (>= 0: a factor→variable slot — the
+// variable→factor slot for a rule —, ~index: a node of the product store).  All sources of an item are loaded together (a source that is
+// not there reads past the end of the buffer: zero, no traffic), and a thread fetches its record of the NEXT stage before it waits at the
+// barrier: value loads -> store -> barrier is what is left on the chain.  kFlatGeneric: the item's ordinary record (five ints at index
+// `destination`) through batch_item — rules of factors with more than two edges, the variational rules, sums of more than five sources.
+constexpr int kFlatSumToFactor = 1, kFlatSumToMarginal = 2, kFlatSumToGamma = 3, kFlatSumToProduct = 4, kFlatRule = 5, kFlatGeneric = 6;
+constexpr int kFlatCheckObserved = 0x80;      // MessageToFactor of the compact form: not recomputed for an observed / stand-in variable (m2f_one)
+struct FlatRec { int32_t k, dst, v, s[5]; };
+
+// fwd (may be NULL): where a kFlatSumToFactor item leaves the message it stored (fwd->y NaN: it stored nothing) — its follower's input
+template <int MODE>
+__device__ __forceinline__ void flat_item(const FlatRec r, const int32_t *__restrict__ rec, const int32_t *__restrict__ vbase, const int32_t *__restrict__ vdeg,
+                                          const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner, const double *__restrict__ q,
+                                          const double *__restrict__ pa, const double *__restrict__ pb, double2 *f2v, double2 *v2f, double2 *marg, int nat_marg,
+                                          double2 *prod, double *joint, const KaryTab kt, double2 *fwd = nullptr) {
+    const int kind = r.k & 0x7f, n = (r.k >> 8) & 0xff;
+    if (kind == kFlatGeneric) {
+        const int32_t *g = rec + 5 * (int64_t)r.dst;
+        batch_item<MODE, true>(g[0] & kRecKindMask, g[1], g[2], g[3], g[4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+        return;
+    }
+    if (kind == kFlatRule) {
+        const double2 m = ld2<true>(v2f, r.s[0]);
+        const double qq = q[r.dst], a = MODE == kRuleLinear ? pa[r.dst] : 1.0, b = MODE == kRuleLinear ? pb[r.dst] : 0.0;
+        if (__builtin_isnan(m.y)) return;
+        const double2 o = factor_rule<MODE>(m, qq, a, b);
+        if (MODE != kRuleBernoulli || !__builtin_isnan(o.y)) f2v[r.dst] = o;
+        return;
+    }
+    const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)f2v, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)prod, 0, 0x7fffffff, 0x00020000);
+    const int info = (r.k & kFlatCheckObserved) ? vinfo[r.v] : 0;
+    cx_d2v val[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int sj = r.s[j];
+        const bool on = j < n;
+        // (an offset of -1 is past the end of the 2 GiB window: the load returns zero and moves nothing)
+        const cx_d2v a = __builtin_bit_cast(cx_d2v, __builtin_amdgcn_raw_buffer_load_b128(rf, (on && sj >= 0) ? sj * 16 : -1, 0, 16));
+        const cx_d2v b = __builtin_bit_cast(cx_d2v, __builtin_amdgcn_raw_buffer_load_b128(rp, (on && sj < 0) ? (~sj) * 16 : -1, 0, 16));
+        val[j] = a + b;
+    }
+    double2 acc = zero2();      // left to right, like the reference's fold
+#pragma unroll
+    for (int j = 0; j < 5; j++) if (j < n) acc = make_double2(acc.x + val[j][0], acc.y + val[j][1]);
+    if (kind == kFlatSumToMarginal) marg[r.dst] = nat_marg ? acc : to_moment(acc);
+    else if (kind == kFlatSumToGamma) marg[r.dst] = make_double2(acc.x + 1.0, 1.0 / acc.y);
+    else if (!__builtin_isnan(acc.y) && !(info & (kClamped | kGhost))) {
+        if (kind == kFlatSumToFactor) { v2f[r.dst] = acc; if (fwd) *fwd = acc; }
+        else prod[r.dst] = acc;
+    }
+}
+
+// a leader and the record behind it (cx_refsched.h: kRecLeads).  The common pair — a MessageToFactor sum and the rule of the message that reads
+// it — passes the message on in a register: the follower does not wait for the leader's store.  Any other pair: the store first, then the follower.
+template <int MODE>
+__device__ __forceinline__ void flat_pair(const FlatRec lead, const FlatRec fol, const int32_t *__restrict__ rec, const int32_t *__restrict__ vbase,
+                                          const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
+                                          const double *__restrict__ q, const double *__restrict__ pa, const double *__restrict__ pb, double2 *f2v, double2 *v2f,
+                                          double2 *marg, int nat_marg, double2 *prod, double *joint, const KaryTab kt, bool forward) {
+    if (forward && (lead.k & 0x7f) == kFlatSumToFactor && (fol.k & 0x7f) == kFlatRule && fol.s[0] == lead.dst) {
+        const double qq = q[fol.dst], a = MODE == kRuleLinear ? pa[fol.dst] : 1.0, b = MODE == kRuleLinear ? pb[fol.dst] : 0.0;
+        double2 m = nan2();
+        flat_item<MODE>(lead, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, &m);
+        if (__builtin_isnan(m.y)) m = ld2<true>(v2f, fol.s[0]);      // the leader stored nothing (an observed variable, an undefined input): what is stored there
+        if (__builtin_isnan(m.y)) return;
+        const double2 o = factor_rule<MODE>(m, qq, a, b);
+        if (MODE != kRuleBernoulli || !__builtin_isnan(o.y)) f2v[fol.dst] = o;
+        return;
+    }
+    flat_item<MODE>(lead, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flat_item<MODE>(fol, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+}
+
+__device__ __forceinline__ FlatRec flat_load(const int32_t *__restrict__ flat, int64_t i) {
+    const int4 a = *(const int4 *)(flat + 8 * i), b = *(const int4 *)(flat + 8 * i + 4);
+    FlatRec r;
+    r.k = a.x; r.dst = a.y; r.v = a.z; r.s[0] = a.w; r.s[1] = b.x; r.s[2] = b.y; r.s[3] = b.z; r.s[4] = b.w;
+    return r;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, unsigned G, const int64_t *__restrict__ stage_off, int n_stages,
+                                                               const int32_t *__restrict__ flat, const int32_t *__restrict__ rec, const int32_t *__restrict__ vbase,
+                                                               const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
+                                                               const double *__restrict__ q, const double *__restrict__ pa, const double *__restrict__ pb, double2 *f2v,
+                                                               double2 *v2f, double2 *marg, int nat_marg, double2 *prod, double *joint, const KaryTab kt, int dry) {
+    __shared__ unsigned rank_s, members_s, ok_s, mine_s;
+    if (threadIdx.x == 0) {      // the cluster's XCD is the one of the first workgroup to ask (whatever the partition mode numbers it)
+        const unsigned me = hw_xcc_id() + 1u;
+        unsigned expected = 0u;
+        const bool won = __hip_atomic_compare_exchange_strong(&c->xcd_plus_1, &expected, me, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mine_s = (won || expected == me) ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool mine = mine_s != 0;
+    if (threadIdx.x == 0) {
+        rank_s = mine ? __hip_atomic_fetch_add(&c->rank_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (mine) __hip_atomic_fetch_add(&c->members, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&c->registered, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok_s = 1u;
+        if (mine) {      // once every workgroup of the launch has said where it runs, the membership is final
+            ok_s = cluster_wait(&c->registered, G, &c->abort_) ? 1u : 0u;
+            members_s = __hip_atomic_load(&c->members, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (!mine || !ok_s) return;
+    // Roles.  A stage is rarely wider than a few thousand items, and what a member waits for most is memory it has never touched: the plan's
+    // records (hundreds of MB, read once) and values last written many stages ago.  So half of the cluster's workgroups are HELPERS: they
+    // take no part in the barriers and store nothing; helper j runs ahead of the members through the stages s = j (mod H), loads their
+    // records (help >= 1) and the lines of their sources (help >= 2) — into the L2 the members read from — and never lets anybody wait.
+    const int help = (dry >> 1) & 3, ahead_arg = (dry >> 8) & 0xff, members_arg = (dry >> 16) & 0xff;
+    const int64_t all = members_s, P = help && all >= 4 ? (members_arg && members_arg < all ? members_arg : all / 2) : all, H = all - P;
+    if ((int64_t)rank_s >= P) {
+        const int64_t hj = (int64_t)rank_s - P;
+        const int ahead = ahead_arg ? ahead_arg : (help >= 2 ? 4 : 12);      // stages: the L2 is 4 MB, a stage's sources up to 1 MB of lines, its records 32 B an item
+        unsigned sink = 0;
+        for (int64_t s = 2 + hj; s < n_stages; s += H) {
+            if (threadIdx.x == 0) {
+                unsigned okh = 1u;
+                for (unsigned spins = 0;; spins++) {
+                    const int64_t cur = __hip_atomic_load(&c->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (unsigned)P;
+                    if (s <= cur + ahead) break;
+                    if (spins > (1u << 24) || ((spins & 63u) == 63u && __hip_atomic_load(&c->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { okh = 0u; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                ok_s = okh;
+            }
+            __syncthreads();
+            if (!ok_s) return;
+            for (int64_t i = stage_off[s] + threadIdx.x; i < stage_off[s + 1]; i += kClusterBlock) {
+                const FlatRec r = flat_load(flat, i);
+                sink ^= (unsigned)r.k ^ (unsigned)r.dst;
+                if (help >= 2) {
+                    const int kind = r.k & 0x7f, n = (r.k >> 8) & 0xff;
+                    if (kind == kFlatRule) sink ^= (unsigned)__double_as_longlong(ld2<true>(v2f, r.s[0]).y);
+                    else if (kind != kFlatGeneric)
+                        for (int j = 0; j < 5; j++) if (j < n) sink ^= (unsigned)__double_as_longlong((r.s[j] >= 0 ? ld2<true>(f2v, r.s[j]) : ld2<true>(prod, ~r.s[j])).y);
+                }
+            }
+            __syncthreads();
+        }
+        if (sink == 0x9e3779b9u) c->pad[0] = sink;      // (keeps the loads)
+        return;
+    }
+    const int64_t first = (int64_t)rank_s * kClusterBlock + threadIdx.x, step = P * kClusterBlock;
+    int64_t lo = stage_off[0], hi = stage_off[1];
+    FlatRec cur{};
+    bool have = lo + first < hi;
+    if (have) cur = flat_load(flat, lo + first);
+    for (int st = 0; st < n_stages; st++) {
+        // the next stage's bounds and this thread's first record of it: plan constants, on their way while this stage's values are loaded
+        const int64_t nlo = hi, nhi = st + 1 < n_stages ? stage_off[st + 2] : hi;
+        const bool nhave = st + 1 < n_stages && nlo + first < nhi;
+        FlatRec nxt{};
+        if (nhave && !(dry & 8)) nxt = flat_load(flat, nlo + first);      // (bit 3, CX_REF_CLUSTER_DRY=2: not even the records — the bare barriers)
+        if (!(dry & 1)) {      // (CX_REF_CLUSTER_DRY=1: the plan's skeleton — records and barriers, no item — for timing what a stage costs before it computes)
+            if (have && !(cur.k & kRecFollows)) {
+                if (cur.k & kRecLeads) flat_pair<MODE>(cur, flat_load(flat, lo + first + 1), rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, !(dry & 16));
+                else flat_item<MODE>(cur, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+            }
+            for (int64_t i = lo + first + step; i < hi; i += step) {      // (a stage wider than the cluster)
+                const FlatRec r = flat_load(flat, i);
+                if (r.k & kRecFollows) continue;
+                if (r.k & kRecLeads) flat_pair<MODE>(r, flat_load(flat, i + 1), rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, !(dry & 16));
+                else flat_item<MODE>(r, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+            }
+        }
+        if (st + 1 == n_stages) break;
+        // the barrier: this thread's stores have reached the L2, the workgroup has arrived, one thread reports and waits for the others
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(&c->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok_s = cluster_wait(&c->arrive, (unsigned)((st + 1) * P), &c->abort_) ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!ok_s) return;
+        lo = nlo; hi = nhi; have = nhave; cur = nxt;
+    }
+}
+
+// A list item of thousands of sources (cx_refsched.h: kWideList — the flat product a mean-field wiring makes of a precision's marginal):
+// a strided partial sum per thread, the partials folded in a fixed tree (wavefront shuffles, then shared memory), the workgroups' partials
+// in order: deterministic, and a different association than the reference's left fold — a rounding-level difference.
+// grid (items, kWideParts): part p of an item sums the sources p, p + kWideParts, ... of its list in strides of the workgroup — a list of 10^6
+// sources is 64 workgroups' work, not one's (0.83 ms for one workgroup) — and leaves ONE partial; k_wide_finish folds an item's partials
+// in order and stores the result
+constexpr int kWideParts = 64;
+__global__ __launch_bounds__(1024) void k_wide_sum(const int32_t *__restrict__ rec, const int32_t *__restrict__ list, const double2 *__restrict__ f2v,
+                                                   const double2 *__restrict__ prod, double2 *__restrict__ partial) {
+    __shared__ double2 part[16];
+    const int32_t *r = rec + 5 * (int64_t)blockIdx.x;
+    const int lo = r[3], hi = r[4];
+    double2 acc = zero2();
+    for (int j = blockIdx.y * 1024 + threadIdx.x; j < hi; j += 1024 * kWideParts) { const int s = list[lo + j]; acc = add2(acc, s >= 0 ? f2v[s] : prod[~s]); }
+    for (int off = 32; off > 0; off >>= 1) { acc.x += __shfl_down(acc.x, off, 64); acc.y += __shfl_down(acc.y, off, 64); }
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double2 t = part[0];
+        for (int w = 1; w < 16; w++) t = add2(t, part[w]);
+        partial[(int64_t)blockIdx.x * kWideParts + blockIdx.y] = t;
+    }
+}
+__global__ __launch_bounds__(64) void k_wide_finish(const int32_t *__restrict__ rec, int n, const double2 *__restrict__ partial, double2 *__restrict__ v2f,
+                                                    double2 *__restrict__ marg, int nat_marg, double2 *__restrict__ prod) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t *r = rec + 5 * (int64_t)i;
+    const int k = r[0], idx = r[1], v = r[2];
+    double2 t = partial[(int64_t)i * kWideParts];
+    for (int p = 1; p < kWideParts; p++) t = add2(t, partial[(int64_t)i * kWideParts + p]);
+    if (k == kItemSumToMarginal) marg[v] = nat_marg ? t : to_moment(t);
+    else if (k == kItemSumToGammaMarginal) marg[v] = make_double2(t.x + 1.0, 1.0 / t.y);
+    else if (!__builtin_isnan(t.y)) { if (k == kItemSumToFactor) v2f[idx] = t; else prod[idx] = t; }
+}
+
+// A batch of at most kSmallBatch items travels IN the kernel arguments: no staging copy, nothing for the host to wait for before
+// it reuses its buffer — the launch is all a per-signal `process!` or a wavefront of a few signals costs.  The records are the
+// first parameter, i.e. the start of the kernarg segment, which every thread reads like any other constant memory.
+template <int MODE>
+__global__ __launch_bounds__(64) void k_batch_small(SmallBatch recs, int n, const int32_t *__restrict__ vbase, const int32_t *__restrict__ vdeg,
+                                                    const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
+                                                    const double *__restrict__ q, const double *__restrict__ pa, const double *__restrict__ pb,
+                                                    double2 *__restrict__ f2v, double2 *__restrict__ v2f, double2 *__restrict__ marg, int nat_marg,
+                                                    double2 *__restrict__ prod, double *__restrict__ joint) {
+    const int i = threadIdx.x;
+    if (i >= n) return;
+    const __attribute__((address_space(4))) int32_t *rec = (const __attribute__((address_space(4))) int32_t *)__builtin_amdgcn_kernarg_segment_ptr();
+    batch_item<MODE>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg,
+                     nat_marg, prod, joint, KaryTab{nullptr, nullptr, nullptr, nullptr});
+    (void)recs;
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+void launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n) {
+    if (n == 0) return;
+    const int nb = (int)((n + kBlock - 1) / kBlock);
+    prof_begin(h, CX_KERNEL_BATCH);
+    const int mode = rule_mode(h), nat = h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0;
+    const KaryTab kt{h->d_kary_slot, h->d_kary_coef, h->d_kary_qb, h->d_ref_list};
+#define CX_B(M, PA, PB) hipLaunchKernelGGL(k_batch<M>, dim3(nb), dim3(kBlock), 0, h->stream, n, d_rec, h->d_vbase, h->d_var_deg, h->d_vinfo, \
+                                           h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint, kt)
+    if (mode == kRuleLinear) CX_B(kRuleLinear, h->d_a, h->d_b);
+    else if (mode == kRuleBernoulli) CX_B(kRuleBernoulli, (const double *)nullptr, (const double *)nullptr);
+    else CX_B(kRuleAdditive, (const double *)nullptr, (const double *)nullptr);
+#undef CX_B
+    prof_end(h);
+}
+
+// stages [s0, s1) of a device-resident stage table, each of at most kRunBlock items, in one launch (cx_api_sweep.hip: the tree schedule)
+void launch_batch_run(cx_handle *h, const int32_t *d_rec, const int64_t *d_stage_off, int s0, int s1) {
+    if (s1 <= s0) return;
+    const int mode = rule_mode(h), nat = h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0;
+    const KaryTab kt{h->d_kary_slot, h->d_kary_coef, h->d_kary_qb, h->d_ref_list};
+#define CX_B(M, PA, PB) hipLaunchKernelGGL(k_batch_run<M>, dim3(1), dim3(kRunBlock), 0, h->stream, d_stage_off, s0, s1, d_rec, h->d_vbase, h->d_var_deg, h->d_vinfo, \
+                                           h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint, kt)
+    if (mode == kRuleLinear) CX_B(kRuleLinear, h->d_a, h->d_b);
+    else if (mode == kRuleBernoulli) CX_B(kRuleBernoulli, (const double *)nullptr, (const double *)nullptr);
+    else CX_B(kRuleAdditive, (const double *)nullptr, (const double *)nullptr);
+#undef CX_B
+}
+
+// every stage of a reference-order plan in ONE launch of an XCD-resident cluster; d_ctl: 64 bytes the launch may scribble on (zeroed here)
+void launch_ref_cluster(cx_handle *h, void *d_ctl, int n_workgroups, const int32_t *d_flat, const int32_t *d_rec, const int64_t *d_stage_off, int n_stages) {
+    if (n_stages <= 0) return;
+    (void)hipMemsetAsync(d_ctl, 0, sizeof(ClusterCtl), h->stream);
+    const int mode = rule_mode(h), nat = h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0;
+    const KaryTab kt{h->d_kary_slot, h->d_kary_coef, h->d_kary_qb, h->d_ref_list};
+    // bit 0: CX_REF_CLUSTER_DRY=1; bits 1..: CX_REF_CLUSTER_HELP = 0 no helpers, 1 helpers load records, 2 (default) records and source lines
+    static const int dry = [] {
+        const char *e = std::getenv("CX_REF_CLUSTER_DRY"), *hp = std::getenv("CX_REF_CLUSTER_HELP");
+        const char *ah = std::getenv("CX_REF_CLUSTER_AHEAD"), *mb = std::getenv("CX_REF_CLUSTER_MEMBERS");      // A/B: stages the helpers run ahead, member workgroups
+        const char *fw = std::getenv("CX_REF_PAIR_FWD");      // 0: a follower always waits for its leader's store (A/B)
+        return ((e && (e[0] == '1' || e[0] == '2')) ? 1 : 0) | ((hp ? std::max(0, std::min(2, std::atoi(hp))) : 2) << 1) | ((e && e[0] == '2') ? 8 : 0) | ((fw && fw[0] == '0') ? 16 : 0) |
+               ((ah ? std::max(0, std::min(255, std::atoi(ah))) : 0) << 8) | ((mb ? std::max(0, std::min(255, std::atoi(mb))) : 0) << 16);
+    }();
+#define CX_B(M, PA, PB) hipLaunchKernelGGL(k_ref_cluster<M>, dim3(n_workgroups), dim3(kClusterBlock), 0, h->stream, (ClusterCtl *)d_ctl, (unsigned)n_workgroups, d_stage_off, n_stages, \
+                                           d_flat, d_rec, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint, kt, dry)
+    if (mode == kRuleLinear) CX_B(kRuleLinear, h->d_a, h->d_b);
+    else if (mode == kRuleBernoulli) CX_B(kRuleBernoulli, (const double *)nullptr, (const double *)nullptr);
+    else CX_B(kRuleAdditive, (const double *)nullptr, (const double *)nullptr);
+#undef CX_B
+}
+
+// d_partial: n x 64 pairs of scratch (cx_api_ref.hip keeps one per plan that has wide items)
+void launch_wide_sum(cx_handle *h, const int32_t *d_rec, int64_t n, void *d_partial) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_wide_sum, dim3((unsigned)n, kWideParts), dim3(1024), 0, h->stream, d_rec, h->d_ref_list, h->d_f2v, h->d_prod, (double2 *)d_partial);
+    hipLaunchKernelGGL(k_wide_finish, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, d_rec, (int)n, (const double2 *)d_partial, h->d_v2f, h->d_marg,
+                       h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0, h->d_prod);
+}
+
+void launch_batch_small(cx_handle *h, const SmallBatch &recs, int n) {
+    if (n == 0) return;
+    prof_begin(h, CX_KERNEL_BATCH);
+    const int mode = rule_mode(h), nat = h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0;
+#define CX_B(M, PA, PB) hipLaunchKernelGGL(k_batch_small<M>, dim3(1), dim3(64), 0, h->stream, recs, n, h->d_vbase, h->d_var_deg, h->d_vinfo, \
+                                           h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint)
+    if (mode == kRuleLinear) CX_B(kRuleLinear, h->d_a, h->d_b);
+    else if (mode == kRuleBernoulli) CX_B(kRuleBernoulli, (const double *)nullptr, (const double *)nullptr);
+    else CX_B(kRuleAdditive, (const double *)nullptr, (const double *)nullptr);
+#undef CX_B
+    prof_end(h);
+}
+
+}  // namespace cx

@@ -232,7 +232,7 @@ struct cx_handle {
     bool alt_two_back = false;       // after a two-sweep launch d_f2v_alt holds time t, not t+1 (see normalize_alt in cx_api_sweep.hip)
     double2 *d_f2v_tmp = nullptr;
 
-    // the XCD-resident cluster (cx_kernels.hip: k_ref_cluster; cx_api_ref.hip: cluster_prepare / cluster_run): stage plans of wide stages in ONE launch
+    // the XCD-resident cluster (cx_batch.hip: k_ref_cluster; cx_api_ref.hip: cluster_prepare / cluster_run): stage plans of wide stages in ONE launch
     void *d_cluster_ctl = nullptr;   // 64 B the launch scribbles on
     int cluster_cu = 0;              // compute units = workgroups of a cluster launch
     int cluster_state = 0;           // 0 not prepared, 1 ready, -1 off (CX_REF_CLUSTER=0, no memory, or a barrier once timed out)

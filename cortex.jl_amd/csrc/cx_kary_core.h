@@ -1,5 +1,5 @@
 // cx_kary_core.h — one factor→variable message of a factor with more than two edges, by ONE thread (entry = 8 * row + edge position in
-// the k-ary table of cx_kary.hip): shared by k_kary_items (cx_kary.hip) and the batch kernels (cx_kernels.hip), where such a message
+// the k-ary table of cx_kary.hip): shared by k_kary_items (cx_kary.hip) and the batch kernels (cx_batch.hip), where such a message
 // is an item like any other of a stage of the tree schedule — one launch per stage instead of two.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -20,7 +20,7 @@ __device__ __forceinline__ double2 kary_natural(double mean, double var) {
     return make_double2(mean * w, w);
 }
 
-// A value another workgroup of the SAME XCD may have stored since this kernel began (the XCD-resident cluster of cx_kernels.hip:
+// A value another workgroup of the SAME XCD may have stored since this kernel began (the XCD-resident cluster of cx_batch.hip:
 // k_ref_cluster): read from the XCD's L2, past the compute unit's vector cache — a buffer load with the scope bit sc1 (aux = 16), 16 bytes
 // at once and counted by the compiler like any load, so several are in flight together (an 8-byte atomic load at agent scope is the same
 // policy at about half the rate).  COH = false: an ordinary load.  base: wave-uniform; the array must stay below 2 GiB.

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void k_batch_mv(int64_t n, const int32_t *_
     batch_item_mv<D>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vinfo, vdeg, partner, ptab, f2v, v2f, marg, prod, kt);
 }
 
-// at most kSmallBatch items: the records are the first kernel argument (cx_kernels.hip: k_batch_small)
+// at most kSmallBatch items: the records are the first kernel argument (cx_batch.hip: k_batch_small)
 template <int D>
 __global__ __launch_bounds__(64) void k_batch_mv_small(SmallBatch recs, int n, const int32_t *__restrict__ vbase, const uint8_t *__restrict__ vinfo,
                                                        const int32_t *__restrict__ vdeg, const int32_t *__restrict__ partner, const double *__restrict__ ptab, double *__restrict__ f2v,

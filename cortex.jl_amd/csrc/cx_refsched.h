@@ -570,7 +570,7 @@ inline int32_t update_marginals(const Wiring &W, State &S, const int32_t *req, i
 }
 
 // ---- the recorded executions as stages of device items -------------------------------------------------------------------------------
-// internal item kinds of the reference plans (cx_kernels.hip: batch_item).  64-66, 72: the value is the SUM of a list of sources — the
+// internal item kinds of the reference plans (cx_batch.hip: batch_item).  64-66, 72: the value is the SUM of a list of sources — the
 // dependencies in the reference's order, exactly what its rule call folds (`reduce(product, get_value.(deps))` in natural form) — for
 // the signals of variables of degree > 5, whose dependencies are segment-tree nodes, and for every product under a user wiring: a list
 // entry >= 0 is a factor→variable slot, ~entry the index of a node in the product store.  rec = {kind, destination, variable, first list
@@ -583,13 +583,13 @@ constexpr int32_t kItemSumToFactor = 64, kItemSumToProduct = 65, kItemSumToMargi
                   kItemVmpJoint = 70, kItemStGamma = 71, kItemSumToGammaMarginal = 72;
 
 // a list item of more than kWideList sources (a flat product over a hub's messages: the marginal of a precision under a mean-field wiring
-// lists every factor) leaves the stage's thread-per-item launch: one workgroup sums it (cx_kernels.hip: k_wide_sum)
+// lists every factor) leaves the stage's thread-per-item launch: one workgroup sums it (cx_batch.hip: k_wide_sum)
 constexpr int64_t kWideList = 1024;
 
 // Two executions as ONE item of a stage.  On a chain or a grid the reference's order alternates MessageToFactor(x, f) and
 // MessageToVariable(y, f): the second reads the first and nothing else that this call computes, so its stage would be the first's plus
 // one — half of a plan's depth is such pairs.  The pair is levelled as one item instead: the same thread computes the first, waits for its
-// store, and computes the second (cx_kernels.hip: the record that LEADS is followed, in the stage's list, by the record that FOLLOWS; the
+// store, and computes the second (cx_batch.hip: the record that LEADS is followed, in the stage's list, by the record that FOLLOWS; the
 // follower's own thread skips it).  The reference's order is kept (the second still comes after the first) and every value read is the one
 // the reference's rule call read; a pair is only formed when no earlier execution of the call reads or writes the second's slot in that
 // stage or later.

@@ -9,7 +9,7 @@
 //   down     stages from level 0 to the last but one: the nodes of a level send to their children
 //   last     the marginal of every non-observed variable
 // A stage is a list of batch items (5 int32 each: kind, slot, variable, rule table (dim > 1), 0 — what cx_update_batch stages,
-// cx_kernels.hip / cx_mvbatch.hip) plus,
+// cx_batch.hip / cx_mvbatch.hip) plus,
 // for factors with more than two edges, a list of entries of the k-ary table (cx_kary.hip).  Items of a stage are independent.
 // Lazy like the reference: no message into an observed variable or a stand-in, no variable→factor message towards a factor whose
 // other variables are all observed, nothing out of a variable of degree 1 (its stored message has no dependencies,

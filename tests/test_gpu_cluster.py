@@ -1,4 +1,4 @@
-"""-m gpu: the XCD-resident cluster (cx_kernels.hip: k_ref_cluster) against the same plans run as launches.
+"""-m gpu: the XCD-resident cluster (cx_batch.hip: k_ref_cluster) against the same plans run as launches.
 
 Reference-order plans of many dependent stages of 1 - 16 k items — a call on a large loopy grid — run as ONE launch of the workgroups of one XCD behind barriers that stay in that XCD's L2, with values loaded past the vector cache, flat
 records and helper workgroups that load ahead.  The plan and its items are the same either way; what is pinned here is that the cluster

@@ -41,7 +41,7 @@ def _oracle_rows(E):
 
 
 class NumpyDevice:
-    """the device's message store in natural form + the items of cx_kernels.hip: batch_item, executed stage by stage"""
+    """the device's message store in natural form + the items of cx_batch.hip: batch_item, executed stage by stage"""
 
     def __init__(self, g, model):
         self.g = g

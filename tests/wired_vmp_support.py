@@ -5,7 +5,7 @@ back-end protocol.  `WiringRecorder` is a third back-end: it RECORDS the resolve
 cx_graph_wire triples.  Two executors sit behind it:
 
   * ShadowBackend — the GPU-free host logic (cx_refsched.h built for the CPU, tests/hostlogic.py): the scheduler's executions per call,
-    levelled into stages, and the stages executed by a numpy restatement of the device items (cx_kernels.hip: batch_item / vmp_item)
+    levelled into stages, and the stages executed by a numpy restatement of the device items (cx_batch.hip: batch_item / vmp_item)
   * DeviceBackend — the product: DeviceGraph(schedule = CX_SCHED_REFERENCE) + graph_wire + set_marginals + sweep_for
 
 Both are compared call by call with OracleBackend (oracle/cortex_ref.c driven by the transcribed rules)."""
@@ -207,7 +207,7 @@ class ShadowBackend(WiringRecorder):
         return self.last_rows
 
     def run(self, rec, stage_off, lists, wide_rec=(), wide_off=()):
-        """cx_kernels.hip: batch_item for the kinds a wired plan holds; asserts that no item of a stage reads what another one writes.  A record
+        """cx_batch.hip: batch_item for the kinds a wired plan holds; asserts that no item of a stage reads what another one writes.  A record
         that LEADS is followed by one the same thread computes behind it (cx_refsched.h: kRecLeads): the follower reads its leader's result"""
         LEADS, FOLLOWS, MASK = 0x40000000, 0x20000000, 0x0fffffff
         for s in range(len(stage_off) - 1):

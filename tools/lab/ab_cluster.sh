@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the XCD-resident cluster (cx_kernels.hip: k_ref_cluster) on the C4 reference-order plan (1415 x 1415 grid: 5,659 stages, 18.0 M items):
+# A/B of the XCD-resident cluster (cx_batch.hip: k_ref_cluster) on the C4 reference-order plan (1415 x 1415 grid: 5,659 stages, 18.0 M items):
 # ms per replayed call (wall clock, device synchronised).  CX_REF_CLUSTER=0: plain launches (a HIP graph of k_batch / k_batch_run);
 # CX_REF_CLUSTER_HELP: 0 every workgroup of the XCD a member, 1 half of them helpers that load the plan's records ahead of the members,
 # 2 (default) records and the lines of the items' sources; CX_REF_CLUSTER_DRY: 1 records and barriers but no item, 2 the bare barriers.
