@@ -171,6 +171,20 @@ __device__ __forceinline__ void batch_pair(const int32_t *__restrict__ lead, con
         if (MODE != kRuleBernoulli || !__builtin_isnan(r.y)) f2v[fidx] = r;
         return;
     }
+    if ((kl == CX_ITEM_MESSAGE_TO_FACTOR || kl == kItemSumToFactor) && kf == kItemStNormal && kt.list[fol[3]] == lead[1]) {
+        // the structured variational rule behind the message it reads (a chain of a wired model): N(mean m, 1 / (var m + 1 / E[precision]))
+        const double2 g = marg[kt.list[fol[3] + 1]];
+        double2 m = nan2();
+        batch_item<MODE>(kl, lead[1], lead[2], lead[3], lead[4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, &m);
+        if (__builtin_isnan(m.y)) m = v2f[lead[1]];
+        const double eg = g.x * g.y;
+        if (__builtin_isnan(m.y) || __builtin_isnan(m.x) || __builtin_isnan(eg)) return;
+        const double inf = __builtin_inf();
+        const double mean = m.y == inf ? m.x : m.x / m.y, var = m.y == inf ? 0.0 : 1.0 / m.y;
+        const double w = 1.0 / (var + 1.0 / eg);
+        f2v[fidx] = make_double2(mean * w, w);
+        return;
+    }
     batch_item<MODE>(kl, lead[1], lead[2], lead[3], lead[4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the leader's store has been written through before the follower loads it
     batch_item<MODE>(kf, fol[1], fol[2], fol[3], fol[4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
