@@ -104,10 +104,11 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
         return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: the variational families need dim == 1");
     if (config->family == CX_FAMILY_NATURAL2 && (config->dim != 1 || config->schedule == CX_SCHED_CHAIN_SCAN))
         return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: CX_FAMILY_NATURAL2 needs dim == 1 and the flooding, fused, tree or reference schedule");
-    if (config->schedule == CX_SCHED_REFERENCE && (config->dim != 1 || is_vmp))
-        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: CX_SCHED_REFERENCE replays the reference's execution order for scalar messages (dim == 1, Gaussian or natural-pair family)");
-    if (config->dim > 1 && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN && config->schedule != CX_SCHED_TREE)
-        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: dim > 1 runs the fused, the chain-scan and the tree schedule");
+    if (config->schedule == CX_SCHED_REFERENCE && ((config->dim != 1 && (config->dim < 2 || config->dim > 4)) || user_dim || is_vmp))
+        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: CX_SCHED_REFERENCE replays the reference's execution order for dim 1 (Gaussian or natural-pair family) and dim 2, 3, 4");
+    if (config->dim > 1 && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN && config->schedule != CX_SCHED_TREE &&
+        !(config->schedule == CX_SCHED_REFERENCE && config->dim <= 4))
+        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: dim > 1 runs the fused, the chain-scan and the tree schedule (dim 2, 3, 4 also the reference-order schedule)");
     if (config->schedule != CX_SCHED_FLOODING && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN && config->schedule != CX_SCHED_TREE && config->schedule != CX_SCHED_REFERENCE)
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: unknown schedule");
     if (config->schedule == CX_SCHED_TREE && config->family == CX_FAMILY_VMP_MEAN_FIELD)
@@ -307,6 +308,7 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
             CX_HIP(h, hipMemsetAsync(h->d_mv_v2f, 0xff, (size_t)(ncs * slots) * 8, h->stream));
             if (h->cfg.dim != 64) CX_HIP(h, hipMemsetAsync(h->d_mv_marg, 0xff, (size_t)(ncs * h->nslices * cx::kBlock) * 8, h->stream));
             CX_HIP(h, hipStreamSynchronize(h->stream));
+            if (h->cfg.schedule == CX_SCHED_REFERENCE) CX_TRY(ref_build(h));      // dim 2 .. 4: the same wiring and shadow, the stages through k_batch_mv
             h->has_graph = true;
             return upload_ptab(h);
         }

@@ -196,6 +196,7 @@ int32_t cx_seed_messages(cx_handle *h, int32_t direction, double mean, double va
             cx::mv_launch_seed(h, h->d_mv_f2v_alt, mean / variance, 1.0 / variance);
         }
         CX_HIP(h, hipGetLastError());
+        try { ref_on_seed(h, direction); } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_seed_messages: host allocation failed"); }
         return CX_OK;
     }
     double2 v = make_double2(mean / variance, 1.0 / variance);

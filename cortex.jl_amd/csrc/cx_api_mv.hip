@@ -161,6 +161,11 @@ int32_t mv_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
     }
     CX_HIP(h, hipGetLastError());
     CX_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->ref) {      // CX_SCHED_REFERENCE: the user's set_value! on the shadow of the readiness state, in list order
+        std::vector<int64_t> edges((size_t)n);
+        for (int64_t i = 0; i < n; i++) edges[i] = find_edge(h, variable_ids[i], factor_ids[i]);
+        ref_on_set(h, n, edges.data(), direction, 0);
+    }
     return CX_OK;
 }
 
@@ -215,7 +220,9 @@ int32_t mv_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
     int32_t rc = stage_slots(h, n, variable_ids, factor_ids, idx, &vars);
     if (rc != CX_OK) return rc;
     if ((rc = mv_ensure_chain_msgs(h)) != CX_OK) return rc;
-    if (direction == CX_TO_FACTOR) { rc = mv_refresh_v2f(h, idx, vars); if (rc != CX_OK) return rc; }
+    // (the reference-order schedule STORES its variable→factor messages — each is a signal with its own place in the order — where the
+    // sweeps that keep them in registers recompute them for the reader)
+    if (direction == CX_TO_FACTOR && h->cfg.schedule != CX_SCHED_REFERENCE) { rc = mv_refresh_v2f(h, idx, vars); if (rc != CX_OK) return rc; }
     return mv_get(h, direction == CX_TO_FACTOR ? h->d_mv_v2f : h->d_mv_f2v, h->nslots, idx, form, false, out);
 }
 
@@ -568,6 +575,7 @@ int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
         std::memcpy(sb.r, rec.data(), (size_t)(5 * n) * 4);
         cx::mv_launch_batch_small(h, sb, (int)n);
         CX_HIP(h, hipGetLastError());
+        ref_on_batch(h, items, n);
         return CX_OK;
     }
     if (!d64) {
@@ -593,14 +601,21 @@ int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
     }
     CX_HIP(h, hipGetLastError());
     CX_HIP(h, hipStreamSynchronize(h->stream));      // synchronous: the host sets readiness bits next (signal.jl:232-253)
+    ref_on_batch(h, items, n);
+    return CX_OK;
+}
+
+int32_t mv_check_psets(cx_handle *h) {
+    CX_REQUIRE(h, (int64_t)h->psets.size() > h->max_pset, CX_ERR_STATE, "cx_sweep: a factor names a parameter set that was never set (cx_set_factor_matrices)");
+    for (int64_t i = 0; i <= h->max_pset; i++)
+        CX_REQUIRE(h, !h->psets[i].empty(), CX_ERR_STATE, "cx_sweep: parameter set " + std::to_string(i) + " was never set (cx_set_factor_matrices)");
     return CX_OK;
 }
 
 int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
-    CX_REQUIRE(h, (int64_t)h->psets.size() > h->max_pset, CX_ERR_STATE, "cx_sweep: a factor names a parameter set that was never set (cx_set_factor_matrices)");
-    for (int64_t i = 0; i <= h->max_pset; i++)
-        CX_REQUIRE(h, !h->psets[i].empty(), CX_ERR_STATE, "cx_sweep: parameter set " + std::to_string(i) + " was never set (cx_set_factor_matrices)");
+    { const int32_t rp = mv_check_psets(h); if (rp != CX_OK) return rp; }
     if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) return mv_chain_sweep(h, n_sweeps);
+    if (h->cfg.schedule == CX_SCHED_REFERENCE) return ref_sweep_all(h, n_sweeps);      // (dim 2 .. 4: cx_api_ref.hip)
     { const int32_t rck = cx::kary_upload(h); if (rck != CX_OK) return rck; }      // factors of more than two variables: their table and matrices
     if (h->cfg.schedule == CX_SCHED_TREE) {
         // dim 2..4 on a forest (cx_tree_plan.h): the stages' items through k_batch_mv, in place in the one message buffer; the items

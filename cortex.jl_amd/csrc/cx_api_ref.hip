@@ -83,6 +83,13 @@ int64_t issue(cx_handle *h, RefSched *R, const PlanEntry &e, bool count_only) {
     const size_t ns = e.stage_off.empty() ? 0 : e.stage_off.size() - 1;
     int64_t launches = 0;
     if (!count_only) h->d_ref_list = e.d_list;
+    if (h->cfg.dim > 1) {      // dim 2 .. 4: a launch of k_batch_mv per stage (no runs, no cluster: cx_mvbatch.hip)
+        for (size_t s = 0; s < ns; s++) {
+            const int64_t n = e.stage_off[s + 1] - e.stage_off[s];
+            if (n > 0) { if (!count_only) cx::mv_launch_batch(h, e.d_rec + 5 * e.stage_off[s], n); launches++; }
+        }
+        return launches;
+    }
     auto wide_at = [&](size_t s) { return e.wide_off.empty() ? (int64_t)0 : e.wide_off[s + 1] - e.wide_off[s]; };
     for (size_t s = 0; s < ns;) {
         size_t t = s;
@@ -185,7 +192,7 @@ bool cluster_prepare(cx_handle *h) {
 }
 
 bool cluster_fits(const cx_handle *h, const std::vector<int64_t> &stage_off, int64_t ns) {
-    if (h->cluster_state <= 0 || ns < 8 || (int64_t)stage_off.size() < ns + 1) return false;
+    if (h->cluster_state <= 0 || h->cfg.dim != 1 || ns < 8 || (int64_t)stage_off.size() < ns + 1) return false;
     const int64_t items = stage_off[ns] - stage_off[0];
     const int64_t two_gib = (int64_t)1 << 31;
     if (items < h->cluster_min_items * ns || h->nslots * 16 >= two_gib || h->nv * 16 >= two_gib || (int64_t)h->prod_index.size() * 16 >= two_gib) return false;
@@ -365,7 +372,8 @@ void ref_on_seed(cx_handle *h, int32_t direction) {
     rs::State &S = writable(R);
     for (int64_t e = 0; e < h->ne; e++) {
         const int32_t slot = cx::slot_of_edge(h, e);
-        if (h->partner[slot] < 0 && (h->slot_kary.empty() || h->slot_kary[slot] < 0)) continue;
+        // (dim 2 .. 4: the seeding kernel gives a value to the messages of pairwise factors only, cx_mv.hip: k_mv_seed)
+        if (h->partner[slot] < 0 && (h->cfg.dim > 1 || h->slot_kary.empty() || h->slot_kary[slot] < 0)) continue;
         const int64_t s = direction == CX_TO_FACTOR ? R->W.sig_v2f(e) : R->W.sig_f2v(e);
         if (!(S.flags[s] & rs::kComputed)) rs::set_value(R->W, S, s);
     }
@@ -525,6 +533,7 @@ int32_t cx_sweep_for(cx_handle *h, int64_t n, const int64_t *variable_ids) {
                "cx_sweep_for: a request for some variables, in the caller's order, is served by CX_SCHED_REFERENCE (on a forest it computes exactly the "
                "messages those marginals need, level by level); the other schedules compute every message: cx_sweep");
     CX_REQUIRE(h, n >= 0 && (n == 0 || variable_ids), CX_ERR_INVALID_ARGUMENT, "cx_sweep_for: null argument");
+    if (h->cfg.dim > 1) { const int32_t rp = mv_check_psets(h); if (rp != CX_OK) return rp; }
     try {
         RefSched *R = ref_of(h);
         if (R && n >= 4096 && (int64_t)R->last_ids.size() == n && std::memcmp(R->last_ids.data(), variable_ids, (size_t)n * 8) == 0)
@@ -552,6 +561,7 @@ int32_t cx_graph_wire(cx_handle *h, int64_t n, const cx_item *signals, const cx_
     CX_NOT_VMP(h, "cx_graph_wire");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_graph_wire: no graph");
     CX_REQUIRE(h, h->cfg.schedule == CX_SCHED_REFERENCE, CX_ERR_UNSUPPORTED, "cx_graph_wire: a dependency wiring is what CX_SCHED_REFERENCE runs the reference's scheduler on; the other schedules are fixed orders");
+    CX_REQUIRE(h, h->cfg.dim == 1, CX_ERR_UNSUPPORTED, "cx_graph_wire: user wirings run as sums of dependency lists, which are items of the scalar kernels (dim == 1)");
     CX_REQUIRE(h, n >= 0 && (n == 0 || (signals && dependencies && flags)), CX_ERR_INVALID_ARGUMENT, "cx_graph_wire: null argument");
     RefSched *R = ref_of(h);
     CX_REQUIRE(h, R && !R->touched, CX_ERR_STATE, "cx_graph_wire: the wiring is fixed once a value has been set or a call has run (wire right after cx_graph_create, as the reference wires at engine construction)");

@@ -139,6 +139,7 @@ int32_t mv_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
                         int32_t form, double *out);
 int32_t mv_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, double *out);
 int32_t mv_sweep(cx_handle *h, int32_t n_sweeps);
+int32_t mv_check_psets(cx_handle *h);         // every parameter set a factor names has been set
 int32_t mv_residual(cx_handle *h, double *out);
 int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n);
 int32_t mv_chain_block_maps(cx_handle *h, double *fwd, double *bwd, double *side_first, double *side_last, int64_t *first_variable_id,

@@ -630,7 +630,11 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
             for (int32_t k = W.foff[f]; k < W.foff[f + 1]; k++) { const int32_t e2 = W.fedge[k]; if (e2 != e && h->np_role[e2] != CX_ROLE_PRECISION) return e2; }
         return -1;
     };
-    static const bool fuse_pairs = [] { const char *e = std::getenv("CX_REF_FUSE_PAIRS"); return !(e && e[0] == '0'); }();      // (A/B)
+    // dim 2 .. 4 (cx_mvbatch.hip: k_batch_mv): the compact items only — records {kind, slot | variable, variable, rule table of the sending
+    // slot} —, so variables of degree <= 5 under the default wiring, and no pairs (that kernel takes one record per thread)
+    const bool mv = h->cfg.dim > 1;
+    static const bool fuse_env = [] { const char *e = std::getenv("CX_REF_FUSE_PAIRS"); return !(e && e[0] == '0'); }();      // (A/B)
+    const bool fuse_pairs = fuse_env && !mv;
     // what an execution reads beyond its dependency list: a sum-product rule reads the stored messages of ALL the factor's other edges
     auto unlisted_reads = [&](int64_t s, auto &&fn) {
         if (!W.is_f2v(s) || W.vrule[s - ne] != kRuleBP) return;
@@ -688,6 +692,8 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
             const int32_t v = h->edge_var[s], deg = h->var_off[v + 1] - h->var_off[v], slot = flat::slot_of_edge_t(h, s);
             P.n_messages++;
             if (deg <= 5 && !W.custom) { r[0] = CX_ITEM_MESSAGE_TO_FACTOR; r[1] = slot; r[2] = v; }
+            else if (mv) return fail_(err, CX_ERR_UNSUPPORTED, "reference schedule, dim > 1: variable " + std::to_string(h->var_ids[v]) + " has degree " + std::to_string(deg) +
+                                                                " — the segment-tree signals of degrees above 5 are items of the scalar kernels only");
             else { r[0] = kItemSumToFactor; r[1] = slot; r[2] = v; list_of_deps(); }
         } else if (W.is_f2v(s)) {                        // MessageToVariable
             const int64_t e = s - ne;
@@ -709,8 +715,12 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
                 else if (rule == kRuleStNormal) { r[0] = kItemStNormal; r[4] = 2; P.list.push_back(flat::slot_of_edge_t(h, e_other)); P.list.push_back(h->edge_var[e_prec]); }
                 else { r[0] = kItemStGamma; r[4] = 1; P.list.push_back((int32_t)joint_slot(f)); }
             }
-            else if (rule == kRuleBP && !h->slot_kary.empty() && h->slot_kary[slot] >= 0) { r[0] = 32; r[1] = h->slot_kary[slot]; }      // kItemKaryEntry
-            else if (rule == kRuleBP && h->partner[slot] >= 0) { r[0] = CX_ITEM_MESSAGE_TO_VARIABLE; r[1] = slot; r[2] = v; }
+            else if (rule == kRuleBP && !h->slot_kary.empty() && h->slot_kary[slot] >= 0) {
+                if (mv) return fail_(err, CX_ERR_UNSUPPORTED, "reference schedule, dim > 1: factors of more than two variables are replayed for scalar messages only (factor " +
+                                                              std::to_string(h->edge_fac_id[e]) + ")");
+                r[0] = 32; r[1] = h->slot_kary[slot];      // kItemKaryEntry
+            }
+            else if (rule == kRuleBP && h->partner[slot] >= 0) { r[0] = CX_ITEM_MESSAGE_TO_VARIABLE; r[1] = slot; r[2] = v; if (mv) r[3] = h->spdir[h->partner[slot]]; }
             else return fail_(err, CX_ERR_UNSUPPORTED, "reference schedule: the message from factor " + std::to_string(h->edge_fac_id[e]) + " to variable " +
                                                            std::to_string(h->var_ids[v]) + " is pending, and the factor has no rule on the device for it "
                                                            "(an opaque factor of two or more variables: the reference's processor would raise, inference_engine.jl:358; "
@@ -720,6 +730,8 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
             const bool gamma = gammas && h->var_gamma[v];
             P.n_marginals++;
             if (deg <= 5 && !W.custom && !gamma) { r[0] = CX_ITEM_INDIVIDUAL_MARGINAL; r[1] = v; r[2] = v; }
+            else if (mv) return fail_(err, CX_ERR_UNSUPPORTED, "reference schedule, dim > 1: variable " + std::to_string(h->var_ids[v]) + " has degree " + std::to_string(deg) +
+                                                                " — the segment-tree signals of degrees above 5 are items of the scalar kernels only");
             else { r[0] = gamma ? kItemSumToGammaMarginal : kItemSumToMarginal; r[1] = v; r[2] = v; list_of_deps(); }
         } else if (W.is_joint(s)) {                      // JointMarginal of a NORMAL_PRECISION factor
             const int64_t f = s - W.sig_joint(0);

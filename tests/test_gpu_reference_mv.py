@@ -1,0 +1,169 @@
+"""-m gpu: CX_SCHED_REFERENCE for d-dimensional messages (dim 2, 3, 4): one cx_sweep / cx_sweep_for is the reference's one
+update_marginals! on ANY graph of pairwise linear-Gaussian factors, loops included.
+
+The reference has no d-dimensional rule (parity unpinned for d > 1); what CAN be pinned is the ORDER — the scheduler never
+looks at a value, so the restated engine (oracle/cortex_ref.c) run on the scalar twin of a graph records exactly the executions the
+reference would make on the d-dimensional one — and the VALUES those executions leave when each is computed, in that order, from the
+newest stored values with the d-dimensional rules of oracle/mv.py (the numpy restatement the flooding sweeps are checked against).  On a
+chain that is the exact smoother, checked against the chain-scan schedule and the block-tridiagonal solve as well."""
+import numpy as np
+import pytest
+
+import cortex.jl_amd as cx
+from cortex.jl_amd import _lib as L
+from oracle import ref
+from oracle.mv import MvFlood, product
+from tests.helpers import assert_close, engine_oracle_from_model
+
+pytestmark = pytest.mark.gpu
+SEED_VARIANCE = 50.0
+
+
+def loopy_lgssm(T, d, seed, skips=(3,)):
+    """lgssm_chain plus transition-like factors x_t -> x_{t + s}: every state on cycles, degrees <= 5"""
+    m = cx.synth.lgssm_chain(T, d=d, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    x = m.x_ids
+    nxt = int(m.factor_ids.max()) + 1
+    ev, ef, role, fids = [m.edge_var], [m.edge_fac], [m.edge_role], [m.factor_ids]
+    for s in skips:
+        f = np.arange(nxt, nxt + T - s, dtype=np.int64); nxt += T - s
+        ev += [x[:-s], x[s:]]; ef += [f, f]
+        role += [np.full(T - s, L.ROLE_IN, np.int32), np.full(T - s, L.ROLE_OUT, np.int32)]
+        fids.append(f)
+    A2 = 0.6 * np.linalg.qr(rng.standard_normal((d, d)))[0]
+    psets = dict(m.psets); psets[2] = (A2, 0.4 * np.eye(d))
+    n_new = sum(len(f) for f in fids[1:])
+    return cx.synth.Model(edge_var=np.concatenate(ev), edge_fac=np.concatenate(ef), factor_ids=np.concatenate(fids),
+                          factor_kind=np.full(len(m.factor_ids) + n_new, L.FACTOR_GAUSS_LINEAR, dtype=np.int32),
+                          factor_var=np.concatenate([m.factor_var, np.full(n_new, 2.0)]), x_ids=x, data_var=m.data_var, data_fac=m.data_fac,
+                          data_y=m.data_y, dim=d, edge_role=np.concatenate(role), psets=psets, meta=dict(m.meta, kind="loopy_lgssm"))
+
+
+def scalar_twin(model):
+    """the same bipartite graph with scalar additive factors and scalar data: what the restated engine schedules"""
+    return cx.synth.Model(edge_var=model.edge_var, edge_fac=model.edge_fac, factor_ids=model.factor_ids,
+                          factor_kind=np.ones(len(model.factor_ids), np.int32), factor_var=np.ones(len(model.factor_ids)), x_ids=model.x_ids,
+                          data_var=model.data_var, data_fac=model.data_fac, data_y=np.asarray(model.data_y)[:, 0])
+
+
+class MvSequential(MvFlood):
+    """oracle/mv.py's rules, one execution at a time in a given order (each from the newest stored values)"""
+
+    def execute(self, kind, var, fac):
+        g = self.g
+        if kind == L.ITEM_INDIVIDUAL_MARGINAL:
+            return
+        e = int(g.edge_index([var], [fac])[0])
+        if kind == L.ITEM_MESSAGE_TO_VARIABLE:
+            r = self._rule(e)
+            assert r is not None, "the reference computes a signal only when its dependencies are computed"
+            self.f2v[e] = r
+        else:
+            v = int(np.searchsorted(g.var_ids, var))
+            acc = None
+            for o in range(int(g.var_off[v]), int(g.var_off[v + 1])):
+                if o != e:
+                    assert self.f2v[o] is not None
+                    acc = self.f2v[o] if acc is None else product(acc, self.f2v[o])
+            self.v2f[e] = acc
+
+
+def _oracle_rows(E):
+    kinds = {ref.VAR_MSG_TO_FACTOR: L.ITEM_MESSAGE_TO_FACTOR, ref.VAR_MSG_TO_VARIABLE: L.ITEM_MESSAGE_TO_VARIABLE, ref.VAR_MARGINAL: L.ITEM_INDIVIDUAL_MARGINAL}
+    rows = []
+    for _r, _v, s, _b, _a in E.trace():
+        k, v, f, _lo, _hi = E.variant(s)
+        rows.append((kinds[k], v, f if kinds[k] != L.ITEM_INDIVIDUAL_MARGINAL else 0, 0, 0))
+    return rows
+
+
+@pytest.mark.parametrize("d,T,skips", [(2, 12, (3,)), (3, 20, (2,)), (4, 30, (5,))])
+def test_one_call_on_a_loopy_d_dimensional_graph(hip_lib, d, T, skips):
+    model = loopy_lgssm(T, d, seed=10 + d, skips=skips)
+    twin = scalar_twin(model)
+    E = engine_oracle_from_model(twin, trace=True)
+    seq = MvSequential(model)
+    dev = cx.DeviceGraph(dim=d, schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(model, dev, seed_variance=SEED_VARIANCE)
+    # the seeding a user of the reference does by hand on a loopy graph: every message out of a pairwise factor that is still undefined
+    E.set_messages_to_variable(twin.edge_var, twin.edge_fac, np.zeros(len(twin.edge_var)), np.full(len(twin.edge_var), SEED_VARIANCE))
+    for e in range(seq.g.ne):
+        seq.f2v[e] = (np.zeros(d), SEED_VARIANCE * np.eye(d))
+    for call in range(3):
+        if call:      # new data: the likelihood messages become pending again, and everything downstream of them
+            y = np.asarray(model.data_y) + 0.1 * call
+            dev.set_messages(model.data_var, model.data_fac, L.TO_FACTOR, L.FORM_POINT, y)
+            E.set_messages_to_factor(twin.data_var, twin.data_fac, y[:, 0], tag=ref.REAL)
+            for e, row in zip(seq.g.edge_index(model.data_var, model.data_fac), y):
+                seq.point[int(e)] = row
+        dev.sweep_for(model.x_ids)
+        E.update_marginals(twin.x_ids)
+        rows = _oracle_rows(E)
+        assert dev.ref_trace() == rows, f"d={d} call {call + 1}: the executions, in the reference's order"
+        for k, v, f, _lo, _hi in rows:
+            seq.execute(k, v, f)
+        # every message of both directions, every requested marginal
+        g = seq.g
+        for direction, store in ((L.TO_VARIABLE, seq.f2v), (L.TO_FACTOR, seq.v2f)):
+            got = dev.get_messages(g.edge_var, g.edge_fac, direction)
+            for e in range(g.ne):
+                if store[e] is None or e in seq.point:
+                    continue
+                assert_close(got[e, :d], store[e][0], 1e-8, f"d={d} call {call + 1} direction {direction} edge {e}: mean", scale_by="max")
+                assert_close(got[e, d:].reshape(d, d), store[e][1], 1e-8, f"d={d} call {call + 1} direction {direction} edge {e}: covariance", scale_by="max")
+        marg = dev.get_marginals(model.x_ids)
+        for i, xv in enumerate(model.x_ids):
+            mm, SS = seq.marginal(int(np.searchsorted(g.var_ids, xv)))
+            assert_close(marg[i, :d], mm, 1e-8, f"d={d} call {call + 1}: marginal mean of {xv}", scale_by="max")
+            assert_close(marg[i, d:].reshape(d, d), SS, 1e-8, f"d={d} call {call + 1}: marginal covariance of {xv}", scale_by="max")
+    st = dev.ref_plan_stats()
+    assert st["hits"] + st["misses"] == 3 and st["executions"] == len(rows)
+
+
+@pytest.mark.parametrize("d", [2, 4])
+def test_one_call_on_a_chain_is_the_exact_smoother(hip_lib, d):
+    """no seeding, one call: 5 T - 4 messages in the reference's forward / backward order + T marginals == the chain-scan schedule's sweep
+    and the block-tridiagonal posterior"""
+    from oracle.exact import lgssm_posterior
+    T = 60
+    model = cx.synth.lgssm_chain(T, d=d, seed=3)
+    dev = cx.DeviceGraph(dim=d, schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(model, dev)
+    dev.sweep(1)
+    st = dev.ref_plan_stats()
+    assert st["messages"] == 5 * T - 4 and st["executions"] == 6 * T - 4
+    scan = cx.DeviceGraph(dim=d, schedule=L.SCHED_CHAIN_SCAN)
+    cx.synth.load_into_device(model, scan)
+    scan.sweep(1)
+    a, b = dev.get_marginals(model.x_ids), scan.get_marginals(model.x_ids)
+    assert_close(a, b, 1e-9, "reference order vs chain scan", scale_by="max")
+    means, covs = lgssm_posterior(np.asarray(model.data_y), model.meta["A"], model.meta["Q"], model.meta["R"])
+    assert_close(a[:, :d], means, 1e-8, "means vs the block-tridiagonal solve", scale_by="max")
+    assert_close(a[:, d:].reshape(T, d, d), covs, 1e-8, "covariances vs the block-tridiagonal solve", scale_by="max")
+    # a lazy request in the caller's order, and a checkpoint that carries the shadow
+    dev.set_messages(model.data_var, model.data_fac, L.TO_FACTOR, L.FORM_POINT, np.asarray(model.data_y) + 1.0)
+    blob = dev.export_state()
+    other = cx.DeviceGraph(dim=d, schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(model, other)
+    other.import_state(blob)
+    for h in (dev, other):
+        h.sweep_for(model.x_ids[::-1][:7])
+    assert dev.ref_trace() == other.ref_trace() and len(dev.ref_trace()) > 7
+    assert np.array_equal(dev.get_marginals(model.x_ids[-7:]), other.get_marginals(model.x_ids[-7:]))
+
+
+def test_refusals_for_dim_above_one(hip_lib):
+    with pytest.raises(cx.CortexHipError, match="dim 1 .* and dim 2, 3, 4"):
+        cx.DeviceGraph(dim=64, schedule=L.SCHED_REFERENCE)
+    model = cx.synth.lgssm_chain(8, d=2, seed=1)
+    dev = cx.DeviceGraph(dim=2, schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(model, dev)
+    with pytest.raises(cx.CortexHipError, match="scalar kernels"):
+        dev.graph_wire([], [], [])
+    # a variable of degree 6: its signals hang off segment-tree nodes, which only the scalar item kernels sum
+    hub = loopy_lgssm(20, 2, seed=2, skips=(2, 3, 5))
+    dev = cx.DeviceGraph(dim=2, schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(hub, dev, seed_variance=SEED_VARIANCE)
+    with pytest.raises(cx.CortexHipError, match="degree"):
+        dev.sweep(1)
