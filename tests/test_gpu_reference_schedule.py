@@ -224,7 +224,7 @@ def test_refusals(hip_lib):
     assert ei.value.code == L.ERR_UNSUPPORTED and "CX_SCHED_REFERENCE" in ei.value.message
     dev.close()
     with pytest.raises(cx.CortexHipError) as ei:
-        cx.DeviceGraph(schedule=L.SCHED_REFERENCE, dim=4)
+        cx.DeviceGraph(schedule=L.SCHED_REFERENCE, dim=64)      # (dim 2, 3, 4: tests/test_gpu_reference_mv.py)
     assert ei.value.code == L.ERR_UNSUPPORTED
     dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
     cx.synth.load_into_device(model, dev)
