@@ -380,7 +380,7 @@ def _make_mv_ssm(n, d, processor, A, Q, R, trace=True):
 
 
 @pytest.mark.parametrize("d,n,mode,tol", [(4, 50, "per_signal", 1e-9), (4, 50, "wavefront", 1e-9), (2, 7, "per_signal", 1e-9),
-                                          (64, 6, "per_signal", 1e-8), (64, 6, "wavefront", 1e-8)])
+                                          (64, 6, "per_signal", 1e-8), (64, 6, "wavefront", 1e-8), (4, 50, "reference", 1e-9), (3, 9, "reference", 1e-9)])
 def test_d_dimensional_chain_through_the_plugin(hip_lib, d, n, mode, tol):
     """dim > 1 behind the plug-in boundary.  The host mirror's scheduler (readiness bits and all) drives the device
     one signal (or one wavefront) at a time through cx_update_batch; execution order == the same scheduler on the same graph shape
@@ -405,6 +405,11 @@ def test_d_dimensional_chain_through_the_plugin(hip_lib, d, n, mode, tol):
     order_cpu = [e.signal.variant for r in engine_cpu.get_trace().inference_requests[0].rounds for e in r.executions]
     if mode == "per_signal":
         assert proc.execution_log == order_cpu and proc.launches == 5 * n - 4 + n
+    elif mode == "reference":      # ONE cx_sweep_for: the library's own trace is the host scheduler's order
+        from cortex.jl_amd import _lib as L
+        kinds = {V.MessageToFactor: L.ITEM_MESSAGE_TO_FACTOR, V.MessageToVariable: L.ITEM_MESSAGE_TO_VARIABLE, V.IndividualMarginal: L.ITEM_INDIVIDUAL_MARGINAL}
+        assert proc.dev.ref_trace() == [(kinds[type(v)], int(v.variable_id), int(getattr(v, "factor_id", 0) or 0), 0, 0) for v in order_cpu]
+        assert proc.launches == 1
     else:
         assert sorted(map(repr, proc.execution_log)) == sorted(map(repr, order_cpu)) and proc.launches <= 2 * n + 4
     # messages into the latent variables vs the numpy restatement at its fixed point (ids coincide: same construction order)

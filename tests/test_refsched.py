@@ -453,3 +453,46 @@ def test_wirings_the_device_has_no_rule_for_are_refused():
                 sig.append(_key(E0, s)); dep.append(_key(E0, d))
     rc, err = g.ref_wire(sig, dep, [L.WIRE_INTERMEDIATE] * len(sig))
     assert rc == L.ERR_UNSUPPORTED and "cycle" in err
+
+
+def test_plans_for_d_dimensional_messages():
+    """dim 2 .. 4 (cx_mvbatch.hip: k_batch_mv takes the compact records only): the same executions as for scalar messages on the same graph,
+    no pairs, the rule table of the sending slot in every MessageToVariable record; variables of degree above 5 are refused"""
+    T = 9
+    x = np.arange(1, T + 1); y = x + T; lik = x + 2 * T; tr = np.arange(3 * T + 1, 4 * T)
+    skip = np.arange(4 * T, 4 * T + T - 3)
+    ev = np.concatenate([y, x, x[:-1], x[1:], x[:-3], x[3:]]); ef = np.concatenate([lik, lik, tr, tr, skip, skip])
+    role = np.concatenate([np.zeros(T), np.ones(T), np.ones(T - 1), np.zeros(T - 1), np.ones(T - 3), np.zeros(T - 3)]).astype(np.int32)
+    fids = np.concatenate([lik, tr, skip])
+    traces = {}
+    for dim in (1, 3):
+        kinds = np.full(len(fids), 1 if dim == 1 else 2, np.int32)      # additive (scalar) / linear with a parameter set (dim > 1)
+        g = FlatGraph(ev, ef, fids, kinds, np.ones(len(fids)) if dim == 1 else np.zeros(len(fids)), edge_role=role, dim=dim, schedule=L.SCHED_REFERENCE)
+        assert g.status == 0, g.error
+        rc, err = g.ref_build(); assert rc == 0, err
+        g.ref_set(L.TO_FACTOR, y, lik)
+        g.ref_set(L.TO_VARIABLE, ev, ef)
+        rows = g.ref_update(x)
+        traces[dim] = [tuple(int(t) for t in r[:3]) for r in rows]
+        rc, err = g.ref_level(); assert rc == 0, err
+        rec = g.arr("ref_rec").reshape(-1, 5)
+        if dim > 1:
+            assert not np.any(rec[:, 0] & 0x60000000), "no leader / follower flags: that kernel takes one record per thread"
+            assert set(rec[:, 0].tolist()) <= {K2F, K2V, KMARG}
+            spdir, partner = g.arr("spdir"), g.arr("partner")
+            m2v = rec[rec[:, 0] == K2V]
+            assert np.array_equal(m2v[:, 3], spdir[partner[m2v[:, 1]]])
+        else:
+            assert np.any(rec[:, 0] & 0x40000000)
+    assert traces[1] == traces[3], "the order never depends on what a message is"
+    # one more skip link per state: degree 7
+    skip2 = np.arange(5 * T, 5 * T + T - 2)
+    ev2 = np.concatenate([ev, x[:-2], x[2:]]); ef2 = np.concatenate([ef, skip2, skip2]); role2 = np.concatenate([role, np.ones(T - 2, np.int32), np.zeros(T - 2, np.int32)])
+    fids2 = np.concatenate([fids, skip2])
+    g = FlatGraph(ev2, ef2, fids2, np.full(len(fids2), 2, np.int32), np.zeros(len(fids2)), edge_role=role2, dim=2, schedule=L.SCHED_REFERENCE)
+    assert g.status == 0, g.error
+    rc, err = g.ref_build(); assert rc == 0, err
+    g.ref_set(L.TO_FACTOR, y, lik); g.ref_set(L.TO_VARIABLE, ev2, ef2)
+    g.ref_update(x)
+    rc, err = g.ref_level()
+    assert rc != 0 and "degree" in err
