@@ -185,7 +185,7 @@ bool cluster_prepare(cx_handle *h) {
     if (const char *v = std::getenv("CX_REF_CLUSTER_MIN")) h->cluster_min_items = std::max<int64_t>(0, std::atoll(v));
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); return false; }
-    if (hipMalloc(&h->d_cluster_ctl, 64) != hipSuccess) { (void)hipGetLastError(); h->d_cluster_ctl = nullptr; return false; }
+    if (hipMalloc(&h->d_cluster_ctl, 512) != hipSuccess) { (void)hipGetLastError(); h->d_cluster_ctl = nullptr; return false; }
     h->cluster_cu = cus;
     h->cluster_state = 1;
     return true;
@@ -226,7 +226,7 @@ int32_t cluster_run(cx_handle *h, const int32_t *d_flat, const int32_t *d_rec, c
         cx::launch_ref_cluster(h, h->d_cluster_ctl, h->cluster_cu, d_flat, d_rec, d_stage_off + s, (int)(t - s));
         // the members' waits are bounded; a call whose cluster gave up has computed part of its stages and cannot be repeated (the items
         // overwrite their inputs' neighbours in place): it fails, loudly, and the handle goes back to plain launches
-        unsigned ctl[16] = {0};
+        unsigned ctl[128] = {0};
         CX_HIP(h, hipGetLastError());
         CX_HIP(h, hipMemcpyAsync(ctl, h->d_cluster_ctl, sizeof(ctl), hipMemcpyDeviceToHost, h->stream));
         CX_HIP(h, hipStreamSynchronize(h->stream));
@@ -234,6 +234,15 @@ int32_t cluster_run(cx_handle *h, const int32_t *d_flat, const int32_t *d_rec, c
             h->cluster_state = -1;
             return fail(h, CX_ERR_DEVICE, "a barrier of the XCD-resident cluster timed out (" + std::to_string(ctl[1]) + " member workgroups of " + std::to_string(ctl[0]) +
                                           " registered); the call is incomplete — restore a checkpoint or set the messages again; further calls use plain launches");
+        }
+        if (std::getenv("CX_REF_CLUSTER_TIME")) {      // member 0's clock (10 ns ticks): issue, memory, workgroup, cluster, release
+            unsigned long long tk[5]; std::memcpy(tk, ctl + 64, sizeof(tk));
+            std::fprintf(stderr, "[cluster %lld stages] us per stage: issue %.3f memory %.3f workgroup %.3f cluster %.3f release %.3f\n", (long long)(t - s),
+                         tk[0] * 0.01 / (t - s), tk[1] * 0.01 / (t - s), tk[2] * 0.01 / (t - s), tk[3] * 0.01 / (t - s), tk[4] * 0.01 / (t - s));
+            unsigned long long wk[16]; std::memcpy(wk, ctl + 80, sizeof(wk));
+            std::fprintf(stderr, "  member 0's wavefronts, release to acknowledged stores:");
+            for (int j = 0; j < 16; j++) std::fprintf(stderr, " %.2f", wk[j] * 0.01 / (t - s));
+            std::fprintf(stderr, "\n");
         }
         s = t;
     }

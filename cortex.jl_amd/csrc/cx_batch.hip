@@ -242,7 +242,10 @@ __global__ __launch_bounds__(kRunBlock) void k_batch_run(const int64_t *__restri
 // a stage is wide — the others leave at once; the members take the plan's stages one after the other, items dealt in runs of 1,024, with
 // that barrier in between.  Values are loaded coherently (batch_item<MODE, true>), plan records and graph constants as always.  Every wait
 // is bounded: a member that gives up raises a flag that all members see and the host checks (cx_api_ref.hip: the call then fails loudly).
-struct ClusterCtl { unsigned registered, members, rank_next, arrive, abort_, xcd_plus_1, pad[10]; };      // 64 B, zeroed before every launch
+// 512 B, zeroed before every launch: the barrier's line; `progress` (the stage the members are in, what the helpers poll — on a line of its own,
+// so that they do not queue behind the barrier's atomics); `ticks` (CX_REF_CLUSTER_TIME=1: where member 0 spent the call, in 10 ns)
+struct ClusterCtl { unsigned registered, members, rank_next, arrive, abort_, xcd_plus_1, pad[26]; unsigned progress, pad2[31]; unsigned long long ticks[8], wave_ticks[16]; unsigned pad3[16]; };
+static_assert(sizeof(ClusterCtl) == 512, "cx_api_ref.hip allocates and reads back 512 bytes");
 
 __device__ __forceinline__ unsigned hw_xcc_id() {
     unsigned v;
@@ -341,6 +344,54 @@ __device__ __forceinline__ FlatRec flat_load(const int32_t *__restrict__ flat, i
     return r;
 }
 
+// A helper's pass over one stage (help = 3): what a member will wait for, touched ahead of it so that it waits for the XCD's L2 and not for
+// memory — the records, the value lines of every source, a rule's constants, an observed-flag byte.  Nothing here depends on anything but the
+// record, so a thread takes four records at a time and has all their lines in flight together (one word of each line is enough; a load
+// that is not wanted points past the end of its buffer: zero, no traffic).
+template <int MODE>
+__device__ __forceinline__ unsigned help_stage(const int32_t *__restrict__ flat, int64_t lo, int64_t hi, const double2 *f2v, const double2 *v2f, const double2 *prod,
+                                               const double *q, const double *pa, const double *pb, const uint8_t *vinfo) {
+    const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)f2v, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)v2f, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)prod, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)q, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(MODE == kRuleLinear ? pa : q), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(MODE == kRuleLinear ? pb : q), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void *)vinfo, 0, 0x7fffffff, 0x00020000);
+    constexpr int U = 4;
+    unsigned sink = 0;
+    for (int64_t base = lo + threadIdx.x; base < hi; base += U * kClusterBlock) {
+        FlatRec r[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t i = base + (int64_t)u * kClusterBlock;
+            r[u] = flat_load(flat, i < hi ? i : base);
+            if (i >= hi) r[u].k = 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int kind = r[u].k & 0x7f, n = (r[u].k >> 8) & 0xff;
+            const bool rule = kind == kFlatRule, sum = kind >= kFlatSumToFactor && kind <= kFlatSumToProduct;
+            // (a follower's message comes to it in a register: cx_batch.hip flat_pair)
+            sink ^= (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rv, rule && !(r[u].k & kRecFollows) ? r[u].s[0] * 16 + 8 : -1, 0, 16);
+            sink ^= (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rq, rule ? r[u].dst * 8 : -1, 0, 16);
+            if (MODE == kRuleLinear) {
+                sink ^= (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ra, rule ? r[u].dst * 8 : -1, 0, 16);
+                sink ^= (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rb, rule ? r[u].dst * 8 : -1, 0, 16);
+            }
+            sink ^= (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ri, (r[u].k & kFlatCheckObserved) && kind != kFlatGeneric ? (r[u].v & ~3) : -1, 0, 16);
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const int sj = r[u].s[j];
+                const bool on = sum && j < n;
+                sink ^= (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rf, (on && sj >= 0) ? sj * 16 + 8 : -1, 0, 16);
+                sink ^= (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rp, (on && sj < 0) ? (~sj) * 16 + 8 : -1, 0, 16);
+            }
+        }
+    }
+    return sink;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, unsigned G, const int64_t *__restrict__ stage_off, int n_stages,
                                                                const int32_t *__restrict__ flat, const int32_t *__restrict__ rec, const int32_t *__restrict__ vbase,
@@ -376,13 +427,13 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
     const int64_t all = members_s, P = help && all >= 4 ? (members_arg && members_arg < all ? members_arg : all / 2) : all, H = all - P;
     if ((int64_t)rank_s >= P) {
         const int64_t hj = (int64_t)rank_s - P;
-        const int ahead = ahead_arg ? ahead_arg : (help >= 2 ? 4 : 12);      // stages: the L2 is 4 MB, a stage's sources up to 1 MB of lines, its records 32 B an item
+        const int ahead = ahead_arg ? ahead_arg : (help >= 3 ? 10 : help >= 2 ? 4 : 12);      // stages: the L2 is 4 MB, a stage's sources up to 1 MB of lines, its records 32 B an item
         unsigned sink = 0;
         for (int64_t s = 2 + hj; s < n_stages; s += H) {
             if (threadIdx.x == 0) {
                 unsigned okh = 1u;
                 for (unsigned spins = 0;; spins++) {
-                    const int64_t cur = __hip_atomic_load(&c->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (unsigned)P;
+                    const int64_t cur = __hip_atomic_load(&c->progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (s <= cur + ahead) break;
                     if (spins > (1u << 24) || ((spins & 63u) == 63u && __hip_atomic_load(&c->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { okh = 0u; break; }
                     __builtin_amdgcn_s_sleep(2);
@@ -391,6 +442,7 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
             }
             __syncthreads();
             if (!ok_s) return;
+            if (help >= 3) { sink ^= help_stage<MODE>(flat, stage_off[s], stage_off[s + 1], f2v, v2f, prod, q, pa, pb, vinfo); __syncthreads(); continue; }
             for (int64_t i = stage_off[s] + threadIdx.x; i < stage_off[s + 1]; i += kClusterBlock) {
                 const FlatRec r = flat_load(flat, i);
                 sink ^= (unsigned)r.k ^ (unsigned)r.dst;
@@ -406,20 +458,29 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
         if (sink == 0x9e3779b9u) c->pad[0] = sink;      // (keeps the loads)
         return;
     }
-    const int64_t first = (int64_t)rank_s * kClusterBlock + threadIdx.x, step = P * kClusterBlock;
+    // records are dealt a wavefront at a time, the members' FIRST wavefronts before anybody's second: a stage is rarely as wide as the cluster, and
+    // the wavefronts that share a SIMD take turns at issuing (measured: each 0.3 us behind the one before it)
+    const int64_t first = ((int64_t)(threadIdx.x >> 6) * P + rank_s) * 64 + (threadIdx.x & 63), step = P * kClusterBlock;
     int64_t lo = stage_off[0], hi = stage_off[1];
-    FlatRec cur{};
+    FlatRec cur{}, cur2{};      // this thread's record of the stage and the one behind it (a leader's follower)
     bool have = lo + first < hi;
     if (have) cur = flat_load(flat, lo + first);
+    if (lo + first + 1 < hi) cur2 = flat_load(flat, lo + first + 1);
+    int64_t nhi = n_stages > 1 ? stage_off[2] : hi;
+    const bool timed = (dry & 32) && rank_s == 0 && threadIdx.x == 0;
+    const bool wtimed = (dry & 32) && rank_s == 0 && (threadIdx.x & 63) == 0;      // each wavefront of member 0: from the barrier's release to its stores' acknowledgement
+    unsigned long long tk[5] = {0, 0, 0, 0, 0}, t0 = timed ? wall_clock64() : 0, wt = 0, w0 = wtimed ? wall_clock64() : 0;
     for (int st = 0; st < n_stages; st++) {
-        // the next stage's bounds and this thread's first record of it: plan constants, on their way while this stage's values are loaded
-        const int64_t nlo = hi, nhi = st + 1 < n_stages ? stage_off[st + 2] : hi;
+        // the next stage's bounds (fetched a stage earlier still) and this thread's first record of it: plan constants, on their way while this
+        // stage's values are loaded
+        const int64_t nlo = hi, nnhi = st + 2 < n_stages ? stage_off[st + 3] : nhi;
         const bool nhave = st + 1 < n_stages && nlo + first < nhi;
-        FlatRec nxt{};
-        if (nhave && !(dry & 8)) nxt = flat_load(flat, nlo + first);      // (bit 3, CX_REF_CLUSTER_DRY=2: not even the records — the bare barriers)
+        FlatRec nxt{}, nxt2{};
+        if (nhave && !(dry & 8)) nxt = flat_load(flat, nlo + first);
+        if (st + 1 < n_stages && nlo + first + 1 < nhi && !(dry & 8)) nxt2 = flat_load(flat, nlo + first + 1);      // (bit 3, CX_REF_CLUSTER_DRY=2: not even the records — the bare barriers)
         if (!(dry & 1)) {      // (CX_REF_CLUSTER_DRY=1: the plan's skeleton — records and barriers, no item — for timing what a stage costs before it computes)
             if (have && !(cur.k & kRecFollows)) {
-                if (cur.k & kRecLeads) flat_pair<MODE>(cur, flat_load(flat, lo + first + 1), rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, !(dry & 16));
+                if (cur.k & kRecLeads) flat_pair<MODE>(cur, cur2, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, !(dry & 16));
                 else flat_item<MODE>(cur, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
             }
             for (int64_t i = lo + first + step; i < hi; i += step) {      // (a stage wider than the cluster)
@@ -430,17 +491,27 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
             }
         }
         if (st + 1 == n_stages) break;
+        if (timed) { const unsigned long long t = wall_clock64(); tk[0] += t - t0; t0 = t; }      // items issued (and what the compiler made them wait for)
         // the barrier: this thread's stores have reached the L2, the workgroup has arrived, one thread reports and waits for the others
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (timed) { const unsigned long long t = wall_clock64(); tk[1] += t - t0; t0 = t; }      // loads returned, stores acknowledged
+        if (wtimed) wt += wall_clock64() - w0;
         __syncthreads();
+        if (timed) { const unsigned long long t = wall_clock64(); tk[2] += t - t0; t0 = t; }      // the workgroup's other wavefronts
         if (threadIdx.x == 0) {
             __hip_atomic_fetch_add(&c->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok_s = cluster_wait(&c->arrive, (unsigned)((st + 1) * P), &c->abort_) ? 1u : 0u;
+            if (rank_s == 0) __hip_atomic_store(&c->progress, (unsigned)(st + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (timed) { const unsigned long long t = wall_clock64(); tk[3] += t - t0; t0 = t; }      // the other workgroups
         __syncthreads();
         if (!ok_s) return;
-        lo = nlo; hi = nhi; have = nhave; cur = nxt;
+        if (timed) { const unsigned long long t = wall_clock64(); tk[4] += t - t0; t0 = t; }
+        if (wtimed) w0 = wall_clock64();
+        lo = nlo; hi = nhi; nhi = nnhi; have = nhave; cur = nxt; cur2 = nxt2;
     }
+    if (timed) for (int j = 0; j < 5; j++) c->ticks[j] = tk[j];
+    if (wtimed) c->wave_ticks[threadIdx.x >> 6] = wt;
 }
 
 // A list item of thousands of sources (cx_refsched.h: kWideList — the flat product a mean-field wiring makes of a precision's marginal):
@@ -525,18 +596,18 @@ void launch_batch_run(cx_handle *h, const int32_t *d_rec, const int64_t *d_stage
 #undef CX_B
 }
 
-// every stage of a reference-order plan in ONE launch of an XCD-resident cluster; d_ctl: 64 bytes the launch may scribble on (zeroed here)
+// every stage of a reference-order plan in ONE launch of an XCD-resident cluster; d_ctl: 512 bytes the launch may scribble on (zeroed here)
 void launch_ref_cluster(cx_handle *h, void *d_ctl, int n_workgroups, const int32_t *d_flat, const int32_t *d_rec, const int64_t *d_stage_off, int n_stages) {
     if (n_stages <= 0) return;
     (void)hipMemsetAsync(d_ctl, 0, sizeof(ClusterCtl), h->stream);
     const int mode = rule_mode(h), nat = h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0;
     const KaryTab kt{h->d_kary_slot, h->d_kary_coef, h->d_kary_qb, h->d_ref_list};
-    // bit 0: CX_REF_CLUSTER_DRY=1; bits 1..: CX_REF_CLUSTER_HELP = 0 no helpers, 1 helpers load records, 2 (default) records and source lines
+    // bit 0: CX_REF_CLUSTER_DRY=1; bits 1..: CX_REF_CLUSTER_HELP = 0 no helpers, 1 helpers load records, 2 records and source lines, 3 (default) those and the rules' constants, four records in flight per thread
     static const int dry = [] {
         const char *e = std::getenv("CX_REF_CLUSTER_DRY"), *hp = std::getenv("CX_REF_CLUSTER_HELP");
         const char *ah = std::getenv("CX_REF_CLUSTER_AHEAD"), *mb = std::getenv("CX_REF_CLUSTER_MEMBERS");      // A/B: stages the helpers run ahead, member workgroups
-        const char *fw = std::getenv("CX_REF_PAIR_FWD");      // 0: a follower always waits for its leader's store (A/B)
-        return ((e && (e[0] == '1' || e[0] == '2')) ? 1 : 0) | ((hp ? std::max(0, std::min(2, std::atoi(hp))) : 2) << 1) | ((e && e[0] == '2') ? 8 : 0) | ((fw && fw[0] == '0') ? 16 : 0) |
+        const char *fw = std::getenv("CX_REF_PAIR_FWD"), *tm = std::getenv("CX_REF_CLUSTER_TIME");      // 0: a follower always waits for its leader's store (A/B); 1: member 0's clock
+        return ((e && (e[0] == '1' || e[0] == '2')) ? 1 : 0) | ((hp ? std::max(0, std::min(3, std::atoi(hp))) : 3) << 1) | ((e && e[0] == '2') ? 8 : 0) | ((fw && fw[0] == '0') ? 16 : 0) | ((tm && tm[0] == '1') ? 32 : 0) |
                ((ah ? std::max(0, std::min(255, std::atoi(ah))) : 0) << 8) | ((mb ? std::max(0, std::min(255, std::atoi(mb))) : 0) << 16);
     }();
 #define CX_B(M, PA, PB) hipLaunchKernelGGL(k_ref_cluster<M>, dim3(n_workgroups), dim3(kClusterBlock), 0, h->stream, (ClusterCtl *)d_ctl, (unsigned)n_workgroups, d_stage_off, n_stages, \
