@@ -293,7 +293,9 @@ __device__ __forceinline__ void flat_item(const FlatRec r, const int32_t *__rest
     }
     const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)f2v, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)prod, 0, 0x7fffffff, 0x00020000);
-    const int info = (r.k & kFlatCheckObserved) ? vinfo[r.v] : 0;
+    // (a buffer load like the values', not a branch on a byte that has to arrive first: one round trip to the L2 for all of them)
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void *)vinfo, 0, 0x7fffffff, 0x00020000);
+    const int info = __builtin_amdgcn_raw_buffer_load_b8(ri, (r.k & kFlatCheckObserved) ? r.v : -1, 0, 0);
     cx_d2v val[5];
 #pragma unroll
     for (int j = 0; j < 5; j++) {
@@ -471,13 +473,10 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
     const bool wtimed = (dry & 32) && rank_s == 0 && (threadIdx.x & 63) == 0;      // each wavefront of member 0: from the barrier's release to its stores' acknowledgement
     unsigned long long tk[5] = {0, 0, 0, 0, 0}, t0 = timed ? wall_clock64() : 0, wt = 0, w0 = wtimed ? wall_clock64() : 0;
     for (int st = 0; st < n_stages; st++) {
-        // the next stage's bounds (fetched a stage earlier still) and this thread's first record of it: plan constants, on their way while this
-        // stage's values are loaded
+        // the next stage's bounds (fetched a stage earlier still); this thread's first record of it is asked for once this stage's items are done:
+        // plan constants, on their way while the stores are acknowledged and the others arrive
         const int64_t nlo = hi, nnhi = st + 2 < n_stages ? stage_off[st + 3] : nhi;
         const bool nhave = st + 1 < n_stages && nlo + first < nhi;
-        FlatRec nxt{}, nxt2{};
-        if (nhave && !(dry & 8)) nxt = flat_load(flat, nlo + first);
-        if (st + 1 < n_stages && nlo + first + 1 < nhi && !(dry & 8)) nxt2 = flat_load(flat, nlo + first + 1);      // (bit 3, CX_REF_CLUSTER_DRY=2: not even the records — the bare barriers)
         if (!(dry & 1)) {      // (CX_REF_CLUSTER_DRY=1: the plan's skeleton — records and barriers, no item — for timing what a stage costs before it computes)
             if (have && !(cur.k & kRecFollows)) {
                 if (cur.k & kRecLeads) flat_pair<MODE>(cur, cur2, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, !(dry & 16));
@@ -491,6 +490,12 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
             }
         }
         if (st + 1 == n_stages) break;
+        // (after the items, not before: the hardware counts loads in order, and a record asked for first would be waited for first —
+        // a round trip to the L2 before the stage's values are even asked for)
+        asm volatile("" ::: "memory");
+        FlatRec nxt{}, nxt2{};
+        if (nhave && !(dry & 8)) nxt = flat_load(flat, nlo + first);      // (bit 3, CX_REF_CLUSTER_DRY=2: not even the records — the bare barriers)
+        if (nlo + first + 1 < nhi && !(dry & 8)) nxt2 = flat_load(flat, nlo + first + 1);
         if (timed) { const unsigned long long t = wall_clock64(); tk[0] += t - t0; t0 = t; }      // items issued (and what the compiler made them wait for)
         // the barrier: this thread's stores have reached the L2, the workgroup has arrived, one thread reports and waits for the others
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
