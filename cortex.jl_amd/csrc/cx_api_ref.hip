@@ -196,7 +196,7 @@ bool cluster_fits(const cx_handle *h, const std::vector<int64_t> &stage_off, int
     const int64_t items = stage_off[ns] - stage_off[0];
     const int64_t two_gib = (int64_t)1 << 31;
     if (items < h->cluster_min_items * ns || h->nslots * 16 >= two_gib || h->nv * 16 >= two_gib || (int64_t)h->prod_index.size() * 16 >= two_gib) return false;
-    // the cluster is an eighth of the chip: it wins on stages it takes in one pass (≈ 4 us against ≈ 6.5 us for a launch) and loses on wider
+    // the cluster is an eighth of the chip: it wins on stages it takes in one pass (≈ 3 us against ≈ 6.5 us for a launch) and loses on wider
     // ones, which leave as launches — and every switch between the two is a launch and a wait for the device (≈ 25 us).  Estimated both ways.
     // As launches, consecutive stages of at most 1,024 items fold into one launch of one workgroup (k_batch_run: ≈ 1 us a stage).
     int64_t narrow = 0, wide = 0, segments = 0, thin = 0, thin_runs = 0;
@@ -209,7 +209,7 @@ bool cluster_fits(const cx_handle *h, const std::vector<int64_t> &stage_off, int
         in_seg = nar; in_run = th;
     }
     const double as_launches = 6.5 * (double)(ns - thin) + 6.5 * (double)thin_runs + 1.0 * (double)thin;
-    const double on_cluster = 4.0 * (double)narrow + 6.5 * (double)wide + 25.0 * (double)segments;
+    const double on_cluster = 3.0 * (double)narrow + 6.5 * (double)wide + 25.0 * (double)segments;
     return narrow >= 8 && on_cluster < 0.8 * as_launches;
 }
 
