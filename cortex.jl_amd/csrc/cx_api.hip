@@ -178,7 +178,7 @@ static int32_t upload_ptab(cx_handle *h) {
     // The tree schedule's stages are captured into a HIP graph with the table pointers baked in by value (cx_api_sweep.hip:
     // tree_sweep): the tables are rewritten IN PLACE while their size holds, and a graph captured over a table that has to move is
     // dropped before the old allocation goes (the next sweep captures again).
-    if (h->d_ptab && h->ptab_sets < nsets) { tree_graph_drop(h); (void)hipFree(h->d_ptab); h->d_ptab = nullptr; }
+    if (h->d_ptab && h->ptab_sets < nsets) { tree_graph_drop(h); ref_graphs_drop(h); (void)hipFree(h->d_ptab); h->d_ptab = nullptr; }      // (the reference-order plans' graphs too: cx_api_ref.hip)
     if (!h->d_ptab) { int32_t rc = dev_alloc(h, &h->d_ptab, (int64_t)(per * nsets)); if (rc != CX_OK) return rc; h->ptab_sets = nsets; }
     CX_HIP(h, hipMemcpy(h->d_ptab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
     h->pot64_fresh = false;

@@ -566,6 +566,7 @@ int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
         if (h->d_mv_prod) {
             CX_HIP(h, hipMemcpyAsync(bigger, h->d_mv_prod, (size_t)(h->mv_prod_cap * per) * 8, hipMemcpyDeviceToDevice, h->stream));
             CX_HIP(h, hipStreamSynchronize(h->stream));
+            tree_graph_drop(h); ref_graphs_drop(h);      // captured launches hold the table's address by value
             (void)hipFree(h->d_mv_prod);
         }
         h->d_mv_prod = bigger; h->mv_prod_cap = cap;

@@ -44,7 +44,7 @@ int32_t kary_mv_upload(cx_handle *h) {
     const size_t per = (size_t)2 * d * d, nsets = h->psets.size();
     std::vector<double> aq(per * std::max<size_t>(nsets, 1), 0.0);
     for (size_t i = 0; i < nsets; i++) if (!h->psets[i].empty()) std::memcpy(&aq[per * i], h->psets[i].data(), per * 8);
-    if (h->d_kary_aq && h->kary_aq_sets < (int64_t)nsets) { tree_graph_drop(h); (void)hipFree(h->d_kary_aq); h->d_kary_aq = nullptr; }      // (captured launches hold the address)
+    if (h->d_kary_aq && h->kary_aq_sets < (int64_t)nsets) { tree_graph_drop(h); ref_graphs_drop(h); (void)hipFree(h->d_kary_aq); h->d_kary_aq = nullptr; }      // (captured launches hold the address)
     if (!h->d_kary_aq) { if ((rc = dev_alloc(h, &h->d_kary_aq, (int64_t)aq.size())) != CX_OK) return rc; h->kary_aq_sets = (int64_t)nsets; }
     CX_HIP(h, hipMemcpy(h->d_kary_aq, aq.data(), aq.size() * 8, hipMemcpyHostToDevice));
     CX_HIP(h, hipMemcpy(h->d_kary_pset, h->kary_pset.data(), h->kary_pset.size() * 4, hipMemcpyHostToDevice));

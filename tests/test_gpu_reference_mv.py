@@ -167,3 +167,44 @@ def test_refusals_for_dim_above_one(hip_lib):
     cx.synth.load_into_device(hub, dev, seed_variance=SEED_VARIANCE)
     with pytest.raises(cx.CortexHipError, match="degree"):
         dev.sweep(1)
+
+
+@pytest.mark.parametrize("d", [3])
+def test_new_rule_matrices_under_a_standing_reference_plan(hip_lib, d):
+    """cx_set_factor_matrices between calls (the parameter-learning flow): a replayed plan is a captured HIP graph with the rule tables'
+    address baked in; the tables are rewritten in place while their size holds, and when one more parameter set makes them move, the
+    plans' graphs are dropped with the old allocation — the next call equals a fresh handle's under the new (A, Q)."""
+    import copy
+
+    T = 40
+    model = cx.synth.lgssm_chain(T, d=d, seed=5)
+    y = np.asarray(model.data_y)
+    rng = np.random.default_rng(3)
+    A_new = 0.6 * np.linalg.qr(rng.standard_normal((d, d)))[0]
+
+    def call(h):
+        h.set_messages(model.data_var, model.data_fac, L.TO_FACTOR, L.FORM_POINT, y)
+        h.sweep(1)
+        return h.get_marginals(model.x_ids)
+
+    dev = cx.DeviceGraph(dim=d, schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(model, dev)
+    first = [call(dev) for _ in range(4)][-1]
+    assert dev.ref_plan_stats()["hits"] >= 2, "the test needs a replayed plan"
+    assert not np.any(np.isnan(first))
+    nsets = len(model.psets)
+    dev.set_factor_matrices(nsets, np.eye(d), np.eye(d))            # one more set: the tables move
+    dev.set_factor_matrices(0, A_new, 0.5 * np.eye(d))
+    hits = dev.ref_plan_stats()["hits"]
+    got = call(dev)
+    assert dev.ref_plan_stats()["hits"] == hits + 1, "the same plan, replayed over the new tables"
+    changed = copy.copy(model)
+    changed.psets = dict(model.psets); changed.psets[0] = (A_new, 0.5 * np.eye(d))
+    fresh = cx.DeviceGraph(dim=d, schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(changed, fresh)
+    want = call(fresh)
+    assert np.max(np.abs(first - want)) > 1e-3, "the two parameter sets must give different posteriors for this test to mean anything"
+    assert_close(got, want, 1e-10, "marginals after new matrices vs a fresh handle", scale_by="max")
+    dev.set_factor_matrices(0, *model.psets[0])                     # same size: in place
+    assert_close(call(dev), first, 1e-10, "back to the first parameters", scale_by="max")
+    dev.close(); fresh.close()
