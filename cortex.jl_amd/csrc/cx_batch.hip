@@ -216,7 +216,13 @@ __global__ __launch_bounds__(kRunBlock) void k_batch_run(const int64_t *__restri
                                                          const int32_t *__restrict__ partner, const double *__restrict__ q, const double *__restrict__ pa,
                                                          const double *__restrict__ pb, double2 *__restrict__ f2v, double2 *__restrict__ v2f,
                                                          double2 *__restrict__ marg, int nat_marg, double2 *__restrict__ prod, double *__restrict__ joint,
-                                                         const KaryTab kt) {
+                                                         const KaryTab kt, unsigned long long *ticks) {
+    // (ticks: CX_RUN_TIME=1, thread 0's clock in 10 ns — items, the release fence, the barrier — added up over every launch of the process.
+    // Measured on the wired variational chain: items 2.4 – 2.6 us a stage, fence 0.04, barrier 0.03; a wavefront that touched the records and
+    // list entries three stages ahead, and records loaded whole instead of kind first: 2.35 – 2.4, i.e. nothing — a stage is its chain of
+    // value loads, arithmetic and stores, not its plan constants.  Both taken out again.)
+    unsigned long long tk[3] = {0, 0, 0}, t0 = ticks && threadIdx.x == 0 ? wall_clock64() : 0;
+    const bool timed = ticks && threadIdx.x == 0;
     for (int st = s0; st < s1; st++) {
         for (int64_t i = stage_off[st] + threadIdx.x; i < stage_off[st + 1]; i += kRunBlock) {      // (the tree schedule folds stages of at most kRunBlock items: one trip)
             const int k0 = rec[5 * i];
@@ -224,10 +230,14 @@ __global__ __launch_bounds__(kRunBlock) void k_batch_run(const int64_t *__restri
             if (k0 & kRecLeads) batch_pair<MODE>(rec + 5 * i, rec + 5 * i + 5, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
             else batch_item<MODE>(k0, rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
         }
+        if (timed) { const unsigned long long t = wall_clock64(); tk[0] += t - t0; t0 = t; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (timed) { const unsigned long long t = wall_clock64(); tk[1] += t - t0; t0 = t; }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (timed) { const unsigned long long t = wall_clock64(); tk[2] += t - t0; t0 = t; }
     }
+    if (timed) { for (int j = 0; j < 3; j++) atomicAdd(ticks + j, tk[j]); atomicAdd(ticks + 3, (unsigned long long)(s1 - s0)); }
 }
 
 // ---- an XCD-resident cluster: the stages of a reference-order plan behind barriers that never leave one L2 -------------------------------
@@ -593,8 +603,22 @@ void launch_batch_run(cx_handle *h, const int32_t *d_rec, const int64_t *d_stage
     if (s1 <= s0) return;
     const int mode = rule_mode(h), nat = h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0;
     const KaryTab kt{h->d_kary_slot, h->d_kary_coef, h->d_kary_qb, h->d_ref_list};
+    static unsigned long long *d_ticks = [] {      // CX_RUN_TIME=1: printed when the process ends
+        unsigned long long *p = nullptr;
+        const char *e = std::getenv("CX_RUN_TIME");
+        if (e && e[0] == '1' && hipMalloc(&p, 64) == hipSuccess) {
+            (void)hipMemset(p, 0, 64);
+            static unsigned long long *keep; keep = p;
+            std::atexit([] {
+                unsigned long long t[4] = {0, 0, 0, 0};
+                if (hipMemcpy(t, keep, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess && t[3])
+                    std::fprintf(stderr, "[k_batch_run %llu stages] us per stage: items %.3f release %.3f barrier %.3f\n", t[3], t[0] * 0.01 / t[3], t[1] * 0.01 / t[3], t[2] * 0.01 / t[3]);
+            });
+        }
+        return p;
+    }();
 #define CX_B(M, PA, PB) hipLaunchKernelGGL(k_batch_run<M>, dim3(1), dim3(kRunBlock), 0, h->stream, d_stage_off, s0, s1, d_rec, h->d_vbase, h->d_var_deg, h->d_vinfo, \
-                                           h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint, kt)
+                                           h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint, kt, d_ticks)
     if (mode == kRuleLinear) CX_B(kRuleLinear, h->d_a, h->d_b);
     else if (mode == kRuleBernoulli) CX_B(kRuleBernoulli, (const double *)nullptr, (const double *)nullptr);
     else CX_B(kRuleAdditive, (const double *)nullptr, (const double *)nullptr);
