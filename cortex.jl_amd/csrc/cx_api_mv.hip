@@ -485,6 +485,28 @@ int32_t mv_ensure_chain_msgs(cx_handle *h) {
 // MFMA rule on a stored variable→factor message (k_rule64w with the "stored input" flag), the point-mass rule (k_point64);
 // marginals of dim 64 are computed from the stored messages when they are read (cx_get_marginals), so a marginal item only
 // checks its variable.
+
+// the ProductOfMessages table grows with the signals that name it (whole blocks of 256 entries; new entries read as UndefValue()):
+// cx_update_batch's items and the segment-tree nodes of a reference-order wiring (cx_api_ref.hip: register_stores)
+int32_t mv_ensure_prod_store(cx_handle *h) {
+    if ((int64_t)h->prod_index.size() <= h->mv_prod_cap) return CX_OK;
+    const bool d64 = h->cfg.dim == 64;
+    const int64_t cap = std::max<int64_t>(2 * h->mv_prod_cap, (((int64_t)h->prod_index.size() + 255) / 256) * 256);
+    const int64_t per = d64 ? h->nc : h->ncs;
+    double *bigger = nullptr;
+    int32_t rc;
+    if ((rc = dev_alloc(h, &bigger, cap * per)) != CX_OK) return rc;
+    CX_HIP(h, hipMemsetAsync(bigger, 0xff, (size_t)(cap * per) * 8, h->stream));
+    if (h->d_mv_prod) {
+        CX_HIP(h, hipMemcpyAsync(bigger, h->d_mv_prod, (size_t)(h->mv_prod_cap * per) * 8, hipMemcpyDeviceToDevice, h->stream));
+        CX_HIP(h, hipStreamSynchronize(h->stream));
+        tree_graph_drop(h); ref_graphs_drop(h);      // captured launches hold the table's address by value
+        (void)hipFree(h->d_mv_prod);
+    }
+    h->d_mv_prod = bigger; h->mv_prod_cap = cap;
+    return CX_OK;
+}
+
 int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
     h->pot64_fresh = false;
     CX_REQUIRE(h, (int64_t)h->psets.size() > h->max_pset, CX_ERR_STATE, "cx_update_batch: a factor names a parameter set that was never set (cx_set_factor_matrices)");
@@ -556,21 +578,7 @@ int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
         }
         rec[5 * i] = it.kind; rec[5 * i + 1] = (int32_t)idx; rec[5 * i + 2] = (int32_t)var; rec[5 * i + 3] = (int32_t)tab;
     }
-    // the ProductOfMessages table grows with the signals that name it (whole blocks of 256 entries; new entries read as UndefValue())
-    if ((int64_t)h->prod_index.size() > h->mv_prod_cap) {
-        const int64_t cap = std::max<int64_t>(2 * h->mv_prod_cap, (((int64_t)h->prod_index.size() + 255) / 256) * 256);
-        const int64_t per = d64 ? h->nc : h->ncs;
-        double *bigger = nullptr;
-        if ((rc = dev_alloc(h, &bigger, cap * per)) != CX_OK) return rc;
-        CX_HIP(h, hipMemsetAsync(bigger, 0xff, (size_t)(cap * per) * 8, h->stream));
-        if (h->d_mv_prod) {
-            CX_HIP(h, hipMemcpyAsync(bigger, h->d_mv_prod, (size_t)(h->mv_prod_cap * per) * 8, hipMemcpyDeviceToDevice, h->stream));
-            CX_HIP(h, hipStreamSynchronize(h->stream));
-            tree_graph_drop(h); ref_graphs_drop(h);      // captured launches hold the table's address by value
-            (void)hipFree(h->d_mv_prod);
-        }
-        h->d_mv_prod = bigger; h->mv_prod_cap = cap;
-    }
+    if ((rc = mv_ensure_prod_store(h)) != CX_OK) return rc;
     if (!d64 && n <= cx::kSmallBatch) {          // records in the kernel arguments, no wait (cx_api_msg.hip: cx_update_batch)
         cx::SmallBatch sb{};
         std::memcpy(sb.r, rec.data(), (size_t)(5 * n) * 4);

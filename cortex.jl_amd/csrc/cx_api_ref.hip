@@ -282,6 +282,7 @@ static int32_t register_stores(cx_handle *h, RefSched *R) {
         if (it == h->joint_index.end()) it = h->joint_index.emplace((int32_t)f, (int32_t)h->joint_index.size()).first;
         R->joint_slot[f] = it->second;
     }
+    if (h->cfg.dim > 1) return mv_ensure_prod_store(h);      // (no joint marginals, no variational rules: cx_graph_wire refuses dim > 1)
     { const int32_t rp = ensure_prod_store(h); if (rp != CX_OK) return rp; }
     return ensure_joint_store(h);
 }

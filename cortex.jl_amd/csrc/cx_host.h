@@ -142,6 +142,7 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps);
 int32_t mv_check_psets(cx_handle *h);         // every parameter set a factor names has been set
 int32_t mv_residual(cx_handle *h, double *out);
 int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n);
+int32_t mv_ensure_prod_store(cx_handle *h);     // room in the dim > 1 product table for every key of prod_index
 int32_t mv_chain_block_maps(cx_handle *h, double *fwd, double *bwd, double *side_first, double *side_last, int64_t *first_variable_id,
                             int64_t *last_variable_id, int64_t *n_links);
 int32_t mv_ensure_marginals(cx_handle *h);    // chain scan, dim 2..4, marginals on demand: form them from the last sweep's alpha and gamma

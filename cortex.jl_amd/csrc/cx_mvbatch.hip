@@ -10,6 +10,9 @@
 //                        intermediate signals the reference's default resolver creates for a variable of degree > 5
 //                        (src/dependencies.jl:90-173); stored (natural form) in a table of its own, read back by cx_get_products.  The
 //                        other items never read it: they fold the messages themselves, as the scalar items do
+// ... and, internal to the reference-order plans (cx_refsched.h: kItemSumTo*), the signals of a variable of degree > 5 under the default
+// resolver, whose dependencies are segment-tree nodes: kinds 64 (MessageToFactor), 65 (ProductOfMessages), 66 (IndividualMarginal) are the sum
+// of `hi` sources list[tab ..) in the reference's order — an entry >= 0 a factor→variable slot, ~entry a node of the product table.
 // A batch holds mutually independent signals (the host's scheduler guarantees it: one wavefront of pending signals), so the items
 // of a launch never read what another item of the same launch writes.  A result with an undefined dependency (NaN) is not stored:
 // the signal was not pending.
@@ -26,8 +29,16 @@ namespace cx {
 template <int D>
 __device__ __forceinline__ void batch_item_mv(int kind, int idx, int v, int tab, int hi, const int32_t *__restrict__ vbase, const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ vdeg,
                                               const int32_t *__restrict__ partner, const double *__restrict__ ptab, double *__restrict__ f2v,
-                                              double *__restrict__ v2f, double *__restrict__ marg, double *__restrict__ prod, const KaryMvTab kt) {
+                                              double *__restrict__ v2f, double *__restrict__ marg, double *__restrict__ prod, const KaryMvTab kt, const int32_t *__restrict__ list) {
     if (kind == 32) { kary_item_mv<D>(idx, kt, v2f, f2v, nullptr, 0.0); return; }      // a message out of a factor of more than two variables (index = entry of its table)
+    if (kind >= 64 && kind <= 66) {      // (a node may lag behind its leaves on a graph with loops, and the reference reads the node)
+        Msg<D> acc = msg_zero<D>();
+        for (int j = 0; j < hi; j++) { const int s = list[tab + j]; msg_add<D>(acc, s >= 0 ? slot_load<D>(f2v, s) : slot_load<D>(prod, ~s)); }
+        const bool ok = hi > 0 && !__builtin_isnan(acc.lam[0]);
+        if (kind == 66) slot_store<D>(marg, v, ok ? mv_to_moment<D>(acc) : msg_all_nan<D>());
+        else if (ok) slot_store<D>(kind == 64 ? v2f : prod, idx, acc);
+        return;
+    }
     // (a variable of degree > 8 lives in the CSR tail: consecutive slots; the others in their slice, a slot every 256)
     const int info = vinfo[v], deg = vdeg[v], b = vbase[v], st = (info & kDegMask) == kBigDeg ? 1 : kBlock;
     if (kind == CX_ITEM_MESSAGE_TO_FACTOR) {
@@ -60,21 +71,21 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void k_batch_mv(int64_t n, const int32_t *__restrict__ rec, int64_t nslots, int nv, const int32_t *__restrict__ vbase,
                                                      const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ vdeg, const int32_t *__restrict__ partner,
                                                      const double *__restrict__ ptab, double *__restrict__ f2v, double *__restrict__ v2f,
-                                                     double *__restrict__ marg, double *__restrict__ prod, const KaryMvTab kt) {
+                                                     double *__restrict__ marg, double *__restrict__ prod, const KaryMvTab kt, const int32_t *__restrict__ list) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    batch_item_mv<D>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vinfo, vdeg, partner, ptab, f2v, v2f, marg, prod, kt);
+    batch_item_mv<D>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vinfo, vdeg, partner, ptab, f2v, v2f, marg, prod, kt, list);
 }
 
 // at most kSmallBatch items: the records are the first kernel argument (cx_batch.hip: k_batch_small)
 template <int D>
 __global__ __launch_bounds__(64) void k_batch_mv_small(SmallBatch recs, int n, const int32_t *__restrict__ vbase, const uint8_t *__restrict__ vinfo,
                                                        const int32_t *__restrict__ vdeg, const int32_t *__restrict__ partner, const double *__restrict__ ptab, double *__restrict__ f2v,
-                                                       double *__restrict__ v2f, double *__restrict__ marg, double *__restrict__ prod, const KaryMvTab kt) {
+                                                       double *__restrict__ v2f, double *__restrict__ marg, double *__restrict__ prod, const KaryMvTab kt, const int32_t *__restrict__ list) {
     const int i = threadIdx.x;
     if (i >= n) return;
     const __attribute__((address_space(4))) int32_t *rec = (const __attribute__((address_space(4))) int32_t *)__builtin_amdgcn_kernarg_segment_ptr();
-    batch_item_mv<D>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vinfo, vdeg, partner, ptab, f2v, v2f, marg, prod, kt);
+    batch_item_mv<D>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vinfo, vdeg, partner, ptab, f2v, v2f, marg, prod, kt, list);
     (void)recs;
 }
 
@@ -82,7 +93,7 @@ void mv_launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n) {
     if (n == 0) return;
     const dim3 g((unsigned)((n + kBlock - 1) / kBlock)), b(kBlock);
 #define CX_MVB(DD) hipLaunchKernelGGL((k_batch_mv<DD>), g, b, 0, h->stream, n, d_rec, h->nslots, (int)h->nv, h->d_vbase, h->d_vinfo, h->d_var_deg, h->d_partner, \
-                                      h->d_ptab, h->d_mv_f2v, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prod, kt)
+                                      h->d_ptab, h->d_mv_f2v, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prod, kt, h->d_ref_list)
     const KaryMvTab kt{h->d_kary_slot, h->d_kary_pset, h->d_kary_aq};
     if (h->cfg.dim == 2) CX_MVB(2);
     else if (h->cfg.dim == 3) CX_MVB(3);
@@ -93,7 +104,7 @@ void mv_launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n) {
 void mv_launch_batch_small(cx_handle *h, const SmallBatch &recs, int n) {
     if (n == 0) return;
 #define CX_MVB(DD) hipLaunchKernelGGL((k_batch_mv_small<DD>), dim3(1), dim3(64), 0, h->stream, recs, n, h->d_vbase, h->d_vinfo, h->d_var_deg, h->d_partner, h->d_ptab, \
-                                      h->d_mv_f2v, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prod, kt)
+                                      h->d_mv_f2v, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prod, kt, h->d_ref_list)
     const KaryMvTab kt{h->d_kary_slot, h->d_kary_pset, h->d_kary_aq};
     if (h->cfg.dim == 2) CX_MVB(2);
     else if (h->cfg.dim == 3) CX_MVB(3);

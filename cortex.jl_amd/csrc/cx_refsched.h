@@ -630,8 +630,9 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
             for (int32_t k = W.foff[f]; k < W.foff[f + 1]; k++) { const int32_t e2 = W.fedge[k]; if (e2 != e && h->np_role[e2] != CX_ROLE_PRECISION) return e2; }
         return -1;
     };
-    // dim 2 .. 4 (cx_mvbatch.hip: k_batch_mv): the compact items only — records {kind, slot | variable, variable, rule table of the sending
-    // slot} —, so variables of degree <= 5 under the default wiring, and no pairs (that kernel takes one record per thread)
+    // dim 2 .. 4 (cx_mvbatch.hip: k_batch_mv): the compact items — records {kind, slot | variable, variable, rule table of the sending
+    // slot} — and the list sums of the segment-tree signals (degrees above 5); the default wiring only, and no pairs (that kernel takes one
+    // record per thread)
     const bool mv = h->cfg.dim > 1;
     static const bool fuse_env = [] { const char *e = std::getenv("CX_REF_FUSE_PAIRS"); return !(e && e[0] == '0'); }();      // (A/B)
     const bool fuse_pairs = fuse_env && !mv;
@@ -669,6 +670,7 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
     int64_t n_wide = 0;
     for (int64_t i = 0; i < n; i++) { if (is_wide(call.order[i])) { P.wide_off[stage[i]]++; n_wide++; } else P.stage_off[stage[i]]++; }
     for (int32_t s = 0; s < n_stages; s++) { P.stage_off[s + 1] += P.stage_off[s]; P.wide_off[s + 1] += P.wide_off[s]; }
+    if (mv && n_wide) return fail_(err, CX_ERR_UNSUPPORTED, "reference schedule, dim > 1: a product of more than 1,024 sources is summed by a workgroup for scalar messages only");
     P.rec.assign(5 * (n - n_wide), 0); P.wide_rec.assign(5 * n_wide, 0);
     std::vector<int64_t> fill(P.stage_off.begin(), P.stage_off.end() - 1), wfill(P.wide_off.begin(), P.wide_off.end() - 1);
     auto source = [&](int64_t d) -> int32_t {       // a dependency of a list item as a list entry
@@ -692,8 +694,6 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
             const int32_t v = h->edge_var[s], deg = h->var_off[v + 1] - h->var_off[v], slot = flat::slot_of_edge_t(h, s);
             P.n_messages++;
             if (deg <= 5 && !W.custom) { r[0] = CX_ITEM_MESSAGE_TO_FACTOR; r[1] = slot; r[2] = v; }
-            else if (mv) return fail_(err, CX_ERR_UNSUPPORTED, "reference schedule, dim > 1: variable " + std::to_string(h->var_ids[v]) + " has degree " + std::to_string(deg) +
-                                                                " — the segment-tree signals of degrees above 5 are items of the scalar kernels only");
             else { r[0] = kItemSumToFactor; r[1] = slot; r[2] = v; list_of_deps(); }
         } else if (W.is_f2v(s)) {                        // MessageToVariable
             const int64_t e = s - ne;
@@ -730,8 +730,6 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
             const bool gamma = gammas && h->var_gamma[v];
             P.n_marginals++;
             if (deg <= 5 && !W.custom && !gamma) { r[0] = CX_ITEM_INDIVIDUAL_MARGINAL; r[1] = v; r[2] = v; }
-            else if (mv) return fail_(err, CX_ERR_UNSUPPORTED, "reference schedule, dim > 1: variable " + std::to_string(h->var_ids[v]) + " has degree " + std::to_string(deg) +
-                                                                " — the segment-tree signals of degrees above 5 are items of the scalar kernels only");
             else { r[0] = gamma ? kItemSumToGammaMarginal : kItemSumToMarginal; r[1] = v; r[2] = v; list_of_deps(); }
         } else if (W.is_joint(s)) {                      // JointMarginal of a NORMAL_PRECISION factor
             const int64_t f = s - W.sig_joint(0);

@@ -6,6 +6,7 @@ import pytest
 
 import cortex.jl_amd as cx
 from cortex.jl_amd import InferenceSignalVariants as V
+from cortex.jl_amd import _lib as L
 from cortex.jl_amd import get_value, get_variable_marginal, update_marginals
 from oracle import exact, ref
 from tests.helpers import assert_close
@@ -425,7 +426,8 @@ def test_d_dimensional_chain_through_the_plugin(hip_lib, d, n, mode, tol):
         assert_close(got.mean, m, tol, f"f2v mean edge {e}", scale_by="max"); assert_close(got.covariance, S, tol, f"f2v covariance edge {e}", scale_by="max")
 
 
-@pytest.mark.parametrize("d,children,mode", [(4, 5, "per_signal"), (3, 7, "wavefront"), (64, 5, "per_signal"), (4, 100, "wavefront"), (2, 12, "per_signal")])
+@pytest.mark.parametrize("d,children,mode", [(4, 5, "per_signal"), (3, 7, "wavefront"), (64, 5, "per_signal"), (4, 100, "wavefront"), (2, 12, "per_signal"),
+                                             (4, 100, "reference"), (2, 12, "reference")])
 def test_a_d_dimensional_hub_through_the_plugin(hip_lib, d, children, mode):
     """a state with `children` child states, everybody observed: the hub has degree children + 1 > 5, so the reference's default
     resolver hangs its messages and its marginal off a segment tree of ProductOfMessages signals (src/dependencies.jl:90-173).  The host
@@ -452,7 +454,10 @@ def test_a_d_dimensional_hub_through_the_plugin(hip_lib, d, children, mode):
     for i in range(n):
         proc.set_value(engine.get_connection_message_to_factor(y[i], lik[i]), data[i])
     update_marginals(engine, x)
-    assert any(isinstance(v, V.ProductOfMessages) for v in proc.execution_log), "the segment tree's nodes were processed on the device"
+    if mode == "reference":      # ONE cx_sweep_for: the call's executions are the device's (cx_ref_trace), the segment tree's nodes among them
+        assert proc.launches == 1 and any(r[0] == L.ITEM_PRODUCT_OF_MESSAGES for r in proc.dev.ref_trace())
+    else:
+        assert any(isinstance(v, V.ProductOfMessages) for v in proc.execution_log), "the segment tree's nodes were processed on the device"
     vals = [get_value(get_variable_marginal(engine.get_variable(v))) for v in x]
     # joint solve
     Qi, Ri = np.linalg.inv(Q), np.linalg.inv(R)
@@ -466,6 +471,10 @@ def test_a_d_dimensional_hub_through_the_plugin(hip_lib, d, children, mode):
     assert_close(np.stack([v.mean for v in vals]), mean, 1e-8, f"d={d} {mode}: marginal means vs the joint solve", scale_by="max")
     assert_close(np.stack([v.covariance for v in vals]), np.stack([S[i*d:(i+1)*d, i*d:(i+1)*d] for i in range(n)]), 1e-8,
                  f"d={d} {mode}: marginal covariances vs the joint solve", scale_by="max")
+    if mode == "reference":
+        _k, var, _f, lo, hi = next(r for r in proc.dev.ref_trace() if r[0] == L.ITEM_PRODUCT_OF_MESSAGES)
+        assert np.all(np.isfinite(proc.dev.get_products([var], [lo], [hi])))
+        return
     # a product node reads back as the product of its range
     node = next(v for v in proc.execution_log if isinstance(v, V.ProductOfMessages))
     got = proc.read(node)

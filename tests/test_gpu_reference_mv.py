@@ -161,12 +161,6 @@ def test_refusals_for_dim_above_one(hip_lib):
     cx.synth.load_into_device(model, dev)
     with pytest.raises(cx.CortexHipError, match="scalar kernels"):
         dev.graph_wire([], [], [])
-    # a variable of degree 6: its signals hang off segment-tree nodes, which only the scalar item kernels sum
-    hub = loopy_lgssm(20, 2, seed=2, skips=(2, 3, 5))
-    dev = cx.DeviceGraph(dim=2, schedule=L.SCHED_REFERENCE)
-    cx.synth.load_into_device(hub, dev, seed_variance=SEED_VARIANCE)
-    with pytest.raises(cx.CortexHipError, match="degree"):
-        dev.sweep(1)
 
 
 @pytest.mark.parametrize("d", [3])
@@ -208,3 +202,92 @@ def test_new_rule_matrices_under_a_standing_reference_plan(hip_lib, d):
     dev.set_factor_matrices(0, *model.psets[0])                     # same size: in place
     assert_close(call(dev), first, 1e-10, "back to the first parameters", scale_by="max")
     dev.close(); fresh.close()
+
+
+class MvBySignal(MvFlood):
+    """oracle/mv.py's rules, one execution of the restated engine at a time, every product folded over the signal's OWN dependency list
+    (E.dependencies): for a variable of degree above 5 those are segment-tree nodes, which may lag behind their leaves on a graph with loops"""
+
+    def __init__(self, model, E):
+        super().__init__(model)
+        self.E, self.prod = E, {}
+
+    def value_of(self, s):
+        k, v, f, lo, hi = self.E.variant(s)
+        if k == ref.VAR_MSG_TO_VARIABLE:
+            return self.f2v[int(self.g.edge_index([v], [f])[0])]
+        assert k == ref.VAR_PRODUCT
+        return self.prod.get((v, lo, hi))
+
+    def execute_signal(self, s):
+        k, v, f, lo, hi = self.E.variant(s)
+        if k == ref.VAR_MSG_TO_VARIABLE:
+            e = int(self.g.edge_index([v], [f])[0])
+            r = self._rule(e)
+            assert r is not None
+            self.f2v[e] = r
+            return
+        acc = None
+        for d in self.E.dependencies(s):
+            val = self.value_of(d)
+            assert val is not None, "the reference computes a signal only when its dependencies are computed"
+            acc = val if acc is None else product(acc, val)
+        if k == ref.VAR_MSG_TO_FACTOR:
+            self.v2f[int(self.g.edge_index([v], [f])[0])] = acc
+        elif k == ref.VAR_PRODUCT:
+            self.prod[(v, lo, hi)] = acc
+        else:
+            self.marg = getattr(self, "marg", {})
+            self.marg[v] = acc
+
+
+@pytest.mark.parametrize("d,T,skips", [(2, 16, (2, 3, 5)), (3, 14, (2, 3, 4))])
+def test_one_call_with_variables_of_degree_above_five(hip_lib, d, T, skips):
+    """three skip links per state: interior states have degree 9 — their messages and marginals hang off segment-tree nodes
+    (dependencies.jl:90-173), list sums of k_batch_mv; executions, every message, every node and every marginal against the restated
+    engine's order executed with d-dimensional arithmetic, three calls"""
+    from tests.test_gpu_reference_schedule import _oracle_trace
+
+    model = loopy_lgssm(T, d, seed=20 + d, skips=skips)
+    twin = scalar_twin(model)
+    E = engine_oracle_from_model(twin, trace=True)
+    seq = MvBySignal(model, E)
+    g = seq.g
+    assert int(np.max(np.diff(g.var_off))) >= 7
+    dev = cx.DeviceGraph(dim=d, schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(model, dev, seed_variance=SEED_VARIANCE)
+    E.set_messages_to_variable(twin.edge_var, twin.edge_fac, np.zeros(len(twin.edge_var)), np.full(len(twin.edge_var), SEED_VARIANCE))
+    for e in range(g.ne):
+        seq.f2v[e] = (np.zeros(d), SEED_VARIANCE * np.eye(d))
+    for call in range(3):
+        if call:
+            y = np.asarray(model.data_y) + 0.1 * call
+            dev.set_messages(model.data_var, model.data_fac, L.TO_FACTOR, L.FORM_POINT, y)
+            E.set_messages_to_factor(twin.data_var, twin.data_fac, y[:, 0], tag=ref.REAL)
+            for e, row in zip(g.edge_index(model.data_var, model.data_fac), y):
+                seq.point[int(e)] = row
+        dev.sweep_for(model.x_ids)
+        E.update_marginals(twin.x_ids)
+        assert dev.ref_trace() == _oracle_trace(E), f"d={d} call {call + 1}: the executions, in the reference's order"
+        order = [s for _r, _v, s, _b, _a in E.trace()]
+        assert any(E.variant(s)[0] == ref.VAR_PRODUCT for s in order)
+        for s in order:
+            seq.execute_signal(s)
+        for direction, store in ((L.TO_VARIABLE, seq.f2v), (L.TO_FACTOR, seq.v2f)):
+            got = dev.get_messages(g.edge_var, g.edge_fac, direction)
+            for e in range(g.ne):
+                if store[e] is None or e in seq.point:
+                    continue
+                assert_close(got[e, :d], store[e][0], 1e-8, f"d={d} call {call + 1} direction {direction} edge {e}: mean", scale_by="max")
+                assert_close(got[e, d:].reshape(d, d), store[e][1], 1e-8, f"d={d} call {call + 1} direction {direction} edge {e}: covariance", scale_by="max")
+        marg = dev.get_marginals(model.x_ids)
+        for i, xv in enumerate(model.x_ids):
+            mm, SS = seq.marg[int(xv)]
+            assert_close(marg[i, :d], mm, 1e-8, f"d={d} call {call + 1}: marginal mean of {xv}", scale_by="max")
+            assert_close(marg[i, d:].reshape(d, d), SS, 1e-8, f"d={d} call {call + 1}: marginal covariance of {xv}", scale_by="max")
+        keys = sorted(seq.prod)
+        got = dev.get_products([k[0] for k in keys], [k[1] for k in keys], [k[2] for k in keys])
+        for row, k in zip(got, keys):
+            mm, SS = seq.prod[k]
+            assert_close(row[:d], mm, 1e-8, f"d={d} call {call + 1}: node {k} mean", scale_by="max")
+            assert_close(row[d:].reshape(d, d), SS, 1e-8, f"d={d} call {call + 1}: node {k} covariance", scale_by="max")

@@ -457,7 +457,7 @@ def test_wirings_the_device_has_no_rule_for_are_refused():
 
 def test_plans_for_d_dimensional_messages():
     """dim 2 .. 4 (cx_mvbatch.hip: k_batch_mv takes the compact records only): the same executions as for scalar messages on the same graph,
-    no pairs, the rule table of the sending slot in every MessageToVariable record; variables of degree above 5 are refused"""
+    no pairs, the rule table of the sending slot in every MessageToVariable record; variables of degree above 5 as list sums"""
     T = 9
     x = np.arange(1, T + 1); y = x + T; lik = x + 2 * T; tr = np.arange(3 * T + 1, 4 * T)
     skip = np.arange(4 * T, 4 * T + T - 3)
@@ -489,10 +489,26 @@ def test_plans_for_d_dimensional_messages():
     skip2 = np.arange(5 * T, 5 * T + T - 2)
     ev2 = np.concatenate([ev, x[:-2], x[2:]]); ef2 = np.concatenate([ef, skip2, skip2]); role2 = np.concatenate([role, np.ones(T - 2, np.int32), np.zeros(T - 2, np.int32)])
     fids2 = np.concatenate([fids, skip2])
-    g = FlatGraph(ev2, ef2, fids2, np.full(len(fids2), 2, np.int32), np.zeros(len(fids2)), edge_role=role2, dim=2, schedule=L.SCHED_REFERENCE)
-    assert g.status == 0, g.error
-    rc, err = g.ref_build(); assert rc == 0, err
-    g.ref_set(L.TO_FACTOR, y, lik); g.ref_set(L.TO_VARIABLE, ev2, ef2)
-    g.ref_update(x)
-    rc, err = g.ref_level()
-    assert rc != 0 and "degree" in err
+    # ... whose signals hang off segment-tree nodes: list sums (64 MessageToFactor, 65 ProductOfMessages, 66 IndividualMarginal), the same
+    # records as for scalar messages but for the pairs
+    hub = {}
+    for dim in (1, 2):
+        g = FlatGraph(ev2, ef2, fids2, np.full(len(fids2), 1 if dim == 1 else 2, np.int32), np.ones(len(fids2)) if dim == 1 else np.zeros(len(fids2)), edge_role=role2, dim=dim,
+                      schedule=L.SCHED_REFERENCE)
+        assert g.status == 0, g.error
+        rc, err = g.ref_build(); assert rc == 0, err
+        g.ref_set(L.TO_FACTOR, y, lik); g.ref_set(L.TO_VARIABLE, ev2, ef2)
+        rows = g.ref_update(x)
+        rc, err = g.ref_level(); assert rc == 0, err
+        rec, lst = g.arr("ref_rec").reshape(-1, 5).copy(), g.arr("ref_list").copy()
+        hub[dim] = ([tuple(int(t) for t in r[:3]) for r in rows], rec, lst)
+    assert hub[1][0] == hub[2][0]
+    rec = hub[2][1]
+    assert not np.any(rec[:, 0] & 0x60000000)
+    assert {64, 65, 66} <= set(rec[:, 0].tolist()) <= {K2F, K2V, KMARG, 64, 65, 66}
+    sums = rec[rec[:, 0] >= 64]
+    assert np.all(sums[:, 4] >= 1) and np.all(sums[:, 3] + sums[:, 4] <= len(hub[2][2]))
+    # the same multiset of list items (kind, destination, the sources in order) as the scalar plan's
+    def items(rec, lst):
+        return sorted((int(r[0] & 0x0fffffff), int(r[1]), tuple(int(t) for t in lst[r[3]:r[3] + r[4]])) for r in rec if (r[0] & 0x0fffffff) >= 64)
+    assert items(rec, hub[2][2]) == items(hub[1][1], hub[1][2])
