@@ -716,9 +716,7 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
                 else { r[0] = kItemStGamma; r[4] = 1; P.list.push_back((int32_t)joint_slot(f)); }
             }
             else if (rule == kRuleBP && !h->slot_kary.empty() && h->slot_kary[slot] >= 0) {
-                if (mv) return fail_(err, CX_ERR_UNSUPPORTED, "reference schedule, dim > 1: factors of more than two variables are replayed for scalar messages only (factor " +
-                                                              std::to_string(h->edge_fac_id[e]) + ")");
-                r[0] = 32; r[1] = h->slot_kary[slot];      // kItemKaryEntry
+                r[0] = 32; r[1] = h->slot_kary[slot];      // kItemKaryEntry (cx_kary_core.h; dim 2 .. 4: cx_kary_mv_core.h)
             }
             else if (rule == kRuleBP && h->partner[slot] >= 0) { r[0] = CX_ITEM_MESSAGE_TO_VARIABLE; r[1] = slot; r[2] = v; if (mv) r[3] = h->spdir[h->partner[slot]]; }
             else return fail_(err, CX_ERR_UNSUPPORTED, "reference schedule: the message from factor " + std::to_string(h->edge_fac_id[e]) + " to variable " +

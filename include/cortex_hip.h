@@ -163,8 +163,8 @@ extern "C" {
                                  state at the start of the call, request): the steady state of "set the priors, call" replays a standing
                                  plan.  Lazy like the reference: a call computes what is pending for the requested marginals, nothing
                                  else; priors have to be re-set before a call to be fresh, exactly as there.  On a forest it is the tree
-                                 schedule with requests for some of the variables.  dim 2, 3, 4 (ABI 3): pairwise linear-Gaussian factors,
-                                 variables of any degree, the default wiring (the stages run through the batched d-dimensional items;
+                                 schedule with requests for some of the variables.  dim 2, 3, 4 (ABI 3): linear-Gaussian factors of two to seven
+                                 variables, variables of any degree, the default wiring (the stages run through the batched d-dimensional items;
                                  variable→factor messages are stored signals there, not recomputed for a reader).  dim 1 (Gaussian and natural-pair families), factors
                                  of any arity the rules have, variables of any degree (degree > 5: the segment-tree nodes of
                                  dependencies.jl:90-173 are computed, stored and read one by one, as the reference does).  Not partitioned. */

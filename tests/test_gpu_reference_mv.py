@@ -291,3 +291,38 @@ def test_one_call_with_variables_of_degree_above_five(hip_lib, d, T, skips):
             mm, SS = seq.prod[k]
             assert_close(row[:d], mm, 1e-8, f"d={d} call {call + 1}: node {k} mean", scale_by="max")
             assert_close(row[d:].reshape(d, d), SS, 1e-8, f"d={d} call {call + 1}: node {k} covariance", scale_by="max")
+
+
+@pytest.mark.parametrize("d,n_factors,seed", [(2, 6, 2), (4, 15, 3)])
+def test_factors_of_three_to_seven_variables(hip_lib, d, n_factors, seed):
+    """x_out = A_1 x_1 + ... + A_k x_k + N(0, Q) with up to six inputs on a tree: the message out of such a factor is one item (the entry of the
+    factor's table, cx_kary_mv_core.h) that reads the stored messages of ALL the factor's other edges.  One call from the priors is the
+    exact posterior (a dense joint solve), the executions are those of the scalar handle on the same graph (the order never depends on
+    what a message is; the scalar plans are pinned against the restated engine), and a second call after new priors replays"""
+    from tests.test_gpu_kary_mv import _kary_tree, _load
+
+    model, prior, facs, fid, sets, mean, cov = _kary_tree(n_factors, d, seed, k_choices=(2, 3, 5, 6))
+    n = len(model.x_ids)
+    dev = _load(model, prior, facs, fid, sets, L.SCHED_REFERENCE)
+    dev.sweep(1)
+    marg = dev.get_marginals(model.x_ids)
+    assert not np.any(np.isnan(marg))
+    assert_close(marg[:, :d], mean, 1e-8, "marginal mean vs the joint solve", scale_by="max")
+    assert_close(marg[:, d:].reshape(n, d, d), cov, 1e-8, "marginal covariance vs the joint solve", scale_by="max")
+    trace = dev.ref_trace()
+    # the scalar handle on the same bipartite graph
+    twin = cx.synth.Model(edge_var=model.edge_var, edge_fac=model.edge_fac, factor_ids=model.factor_ids, factor_kind=model.factor_kind,
+                          factor_var=np.ones(len(model.factor_ids)), x_ids=model.x_ids, edge_role=model.edge_role)
+    sc = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(twin, sc)
+    sc.set_messages(model.x_ids, model.x_ids + n, L.TO_VARIABLE, L.FORM_NATURAL, np.ones((n, 2)))
+    sc.sweep(1)
+    assert trace == sc.ref_trace() and len(trace) > 3 * n
+    # new priors: pending again, the same plan
+    eta, W = prior
+    for _ in range(2):
+        dev.set_messages(model.x_ids, model.x_ids + n, L.TO_VARIABLE, L.FORM_NATURAL, np.concatenate([eta, W.reshape(n, d * d)], axis=1))
+        dev.sweep(1)
+    assert dev.ref_plan_stats()["hits"] >= 1
+    assert_close(dev.get_marginals(model.x_ids), marg, 1e-10, "the same priors again", scale_by="max")
+    dev.close(); sc.close()
