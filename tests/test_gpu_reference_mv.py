@@ -326,3 +326,88 @@ def test_factors_of_three_to_seven_variables(hip_lib, d, n_factors, seed):
     assert dev.ref_plan_stats()["hits"] >= 1
     assert_close(dev.get_marginals(model.x_ids), marg, 1e-10, "the same priors again", scale_by="max")
     dev.close(); sc.close()
+
+
+def test_factors_of_several_variables_on_a_cycle(hip_lib):
+    """two factors of four variables that share two of them (x2 - F1 - x3 - F2 - x2 is a cycle), every variable with a prior: three calls with
+    new priors in between; the executions are the scalar handle's, and every message of both directions equals those executions carried
+    out one at a time in numpy (the moment-form formulas of csrc/cx_kary_mv_core.h on the NEWEST stored messages of the other edges)"""
+    d = 2
+    rng = np.random.default_rng(4)
+    sets = {s: (0.7 * np.linalg.qr(rng.standard_normal((d, d)))[0], (0.3 + 0.1 * s) * np.eye(d) + 0.05) for s in range(3)}
+    n = 6
+    x = np.arange(1, n + 1, dtype=np.int64); unary = x + n; F = np.array([2 * n + 1, 2 * n + 2], np.int64)
+    members = {int(F[0]): (4, [1, 2, 3]), int(F[1]): (5, [2, 3, 6])}      # factor: (out, inputs)
+    eset = {(1, int(F[0])): 0, (2, int(F[0])): 1, (3, int(F[0])): 2, (2, int(F[1])): 2, (3, int(F[1])): 0, (6, int(F[1])): 1}
+    qset = {int(F[0]): 0, int(F[1]): 1}
+    ev, ef, role = list(x), list(unary), [L.ROLE_OUT] * n
+    for f, (out, ins) in members.items():
+        ev.append(out); ef.append(f); role.append(L.ROLE_OUT)
+        for i in ins:
+            ev.append(i); ef.append(f); role.append(L.ROLE_IN)
+    ev, ef = np.array(ev, np.int64), np.array(ef, np.int64)
+    kinds = np.concatenate([np.zeros(n, np.int32), np.full(2, L.FACTOR_GAUSS_LINEAR_N, np.int32)])
+    model = cx.synth.Model(edge_var=ev, edge_fac=ef, factor_ids=np.concatenate([unary, F]), factor_kind=kinds,
+                           factor_var=np.concatenate([np.zeros(n), [qset[int(F[0])], qset[int(F[1])]]]).astype(float), x_ids=x, dim=d,
+                           edge_role=np.array(role, np.int32), psets=sets)
+    twin = cx.synth.Model(edge_var=ev, edge_fac=ef, factor_ids=model.factor_ids, factor_kind=kinds, factor_var=np.ones(n + 2), x_ids=x, edge_role=model.edge_role)
+    dev, sc = cx.DeviceGraph(dim=d, schedule=L.SCHED_REFERENCE), cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(model, dev); cx.synth.load_into_device(twin, sc)
+    kv = [v for (v, f) in eset]; kf = [f for (v, f) in eset]
+    dev.set_factor_edge_sets(kv, kf, [eset[k] for k in eset])
+    # the seeds a user of the reference sets by hand on a loopy graph: every message out of the two factors
+    big = ev >= 0
+    big[:n] = False
+    seed = np.concatenate([np.zeros(d), (1e-3 * np.eye(d)).reshape(-1)])
+    dev.set_messages(ev[big], ef[big], L.TO_VARIABLE, L.FORM_NATURAL, np.tile(seed, (int(big.sum()), 1)))
+    sc.set_messages(ev[big], ef[big], L.TO_VARIABLE, L.FORM_NATURAL, np.tile([0.0, 1e-3], (int(big.sum()), 1)))
+    f2v = {(int(v), int(f)): (np.zeros(d), 1e-3 * np.eye(d)) for v, f in zip(ev[big], ef[big])}      # natural (eta, Lambda)
+    v2f = {}
+
+    def moment(nat):
+        V = np.linalg.inv(nat[1])
+        return V @ nat[0], V
+
+    def execute(kind, v, f):
+        if kind == L.ITEM_MESSAGE_TO_FACTOR:
+            others = [f2v[(v, g)] for g in ef[ev == v] if int(g) != f]
+            v2f[(v, f)] = (sum(o[0] for o in others), sum(o[1] for o in others))
+        elif kind == L.ITEM_MESSAGE_TO_VARIABLE:
+            out, ins = members[f]
+            A = {i: sets[eset[(i, f)]][0] for i in ins}
+            Q = sets[qset[f]][1]
+            m = {i: moment(v2f[(i, f)]) for i in [out] + ins if i != v}
+            if v == out:
+                mu, S = sum(A[i] @ m[i][0] for i in ins), Q + sum(A[i] @ m[i][1] @ A[i].T for i in ins)
+                Si = np.linalg.inv(S)
+                f2v[(v, f)] = (Si @ mu, Si)
+            else:
+                mu = m[out][0] - sum(A[i] @ m[i][0] for i in ins if i != v)
+                S = m[out][1] + Q + sum(A[i] @ m[i][1] @ A[i].T for i in ins if i != v)
+                Si = np.linalg.inv(S)
+                f2v[(v, f)] = (A[v].T @ Si @ mu, A[v].T @ Si @ A[v])
+
+    for call in range(3):
+        W = np.stack([np.eye(d) * rng.uniform(0.5, 2.0) + 0.1 for _ in range(n)]); eta = rng.standard_normal((n, d))
+        dev.set_messages(x, unary, L.TO_VARIABLE, L.FORM_NATURAL, np.concatenate([eta, W.reshape(n, d * d)], axis=1))
+        sc.set_messages(x, unary, L.TO_VARIABLE, L.FORM_NATURAL, np.ones((n, 2)))
+        for i in range(n):
+            f2v[(int(x[i]), int(unary[i]))] = (eta[i], W[i])
+        dev.sweep(1); sc.sweep(1)
+        trace = dev.ref_trace()
+        assert trace == sc.ref_trace() and sum(1 for r in trace if r[0] == L.ITEM_MESSAGE_TO_VARIABLE) >= 8
+        for k, v, f, _lo, _hi in trace:
+            execute(k, int(v), int(f))
+        for direction, store in ((L.TO_VARIABLE, f2v), (L.TO_FACTOR, v2f)):
+            keys = sorted(store)
+            got = dev.get_messages([k[0] for k in keys], [k[1] for k in keys], direction, L.FORM_NATURAL)
+            for row, k in zip(got, keys):
+                assert_close(row[:d], store[k][0], 1e-8, f"call {call + 1} direction {direction} {k}: eta", scale_by="max")
+                assert_close(row[d:].reshape(d, d), store[k][1], 1e-8, f"call {call + 1} direction {direction} {k}: Lambda", scale_by="max")
+        marg = dev.get_marginals(x)
+        for i in range(n):
+            tot = [f2v[(int(x[i]), int(g))] for g in ef[ev == x[i]]]
+            mm, VV = moment((sum(t[0] for t in tot), sum(t[1] for t in tot)))
+            assert_close(marg[i, :d], mm, 1e-8, f"call {call + 1}: marginal mean of x{i + 1}", scale_by="max")
+            assert_close(marg[i, d:].reshape(d, d), VV, 1e-8, f"call {call + 1}: marginal covariance of x{i + 1}", scale_by="max")
+    dev.close(); sc.close()
