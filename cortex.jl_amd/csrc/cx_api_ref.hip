@@ -83,10 +83,15 @@ int64_t issue(cx_handle *h, RefSched *R, const PlanEntry &e, bool count_only) {
     const size_t ns = e.stage_off.empty() ? 0 : e.stage_off.size() - 1;
     int64_t launches = 0;
     if (!count_only) h->d_ref_list = e.d_list;
-    if (h->cfg.dim > 1) {      // dim 2 .. 4: a launch of k_batch_mv per stage (no runs, no cluster: cx_mvbatch.hip)
-        for (size_t s = 0; s < ns; s++) {
+    if (h->cfg.dim > 1) {      // dim 2 .. 4 (cx_mvbatch.hip): runs of thin stages as one launch of one workgroup, the others a launch of k_batch_mv each; no cluster
+        const int64_t thin = std::min<int64_t>(R->run_max, cx::mv_run_block());
+        for (size_t s = 0; s < ns;) {
+            size_t t = s;
+            while (t < ns && e.stage_off[t + 1] - e.stage_off[t] <= thin) t++;
+            if (t >= s + 2) { if (!count_only) cx::mv_launch_batch_run(h, e.d_rec, e.d_stage_off, (int)s, (int)t); launches++; s = t; continue; }
             const int64_t n = e.stage_off[s + 1] - e.stage_off[s];
             if (n > 0) { if (!count_only) cx::mv_launch_batch(h, e.d_rec + 5 * e.stage_off[s], n); launches++; }
+            s++;
         }
         return launches;
     }

@@ -311,6 +311,8 @@ void mv_launch_scatter(cx_handle *h, double *dst, int64_t stride, int nc, int nc
 void mv_launch_gather(cx_handle *h, const double *src, int64_t stride, int nc, int ncs, const int32_t *d_idx, double *d_val, int64_t n);
 void mv_launch_seed(cx_handle *h, double *buf, double eta, double lam);
 void mv_launch_batch_small(cx_handle *h, const SmallBatch &recs, int n);
+void mv_launch_batch_run(cx_handle *h, const int32_t *d_rec, const int64_t *d_stage_off, int s0, int s1);   // stages [s0, s1), each at most mv_run_block() items, one workgroup
+int mv_run_block();
 void mv_launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n);   // cx_mvbatch.hip: 5 int32 per item (kind, index, variable, rule table, 0)
 void mv_launch_residual(cx_handle *h, const double *cur, const double *prev, int64_t n, double *d_out);
 bool spd_inverse(int d, const double *S, double *out);

@@ -89,6 +89,37 @@ __global__ __launch_bounds__(64) void k_batch_mv_small(SmallBatch recs, int n, c
     (void)recs;
 }
 
+// A run of consecutive thin stages of a plan (each at most kMvRunBlock items) in ONE launch of one workgroup, a barrier between the stages
+// instead of a kernel boundary (cx_batch.hip: k_batch_run, for d-dimensional messages): the stages of a reference-order plan on a chain
+// or a small loopy graph are a few items each, and a launch apiece is 6 us of latency per stage.
+constexpr int kMvRunBlock = 256;
+template <int D>
+__global__ __launch_bounds__(kMvRunBlock) void k_batch_mv_run(const int64_t *__restrict__ stage_off, int s0, int s1, const int32_t *__restrict__ rec, const int32_t *__restrict__ vbase,
+                                                              const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ vdeg, const int32_t *__restrict__ partner,
+                                                              const double *__restrict__ ptab, double *__restrict__ f2v, double *__restrict__ v2f, double *__restrict__ marg,
+                                                              double *__restrict__ prod, const KaryMvTab kt, const int32_t *__restrict__ list) {
+    for (int st = s0; st < s1; st++) {
+        for (int64_t i = stage_off[st] + threadIdx.x; i < stage_off[st + 1]; i += kMvRunBlock)
+            batch_item_mv<D>(rec[5 * i], rec[5 * i + 1], rec[5 * i + 2], rec[5 * i + 3], rec[5 * i + 4], vbase, vinfo, vdeg, partner, ptab, f2v, v2f, marg, prod, kt, list);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+int mv_run_block() { return kMvRunBlock; }
+
+void mv_launch_batch_run(cx_handle *h, const int32_t *d_rec, const int64_t *d_stage_off, int s0, int s1) {
+    if (s1 <= s0) return;
+#define CX_MVB(DD) hipLaunchKernelGGL((k_batch_mv_run<DD>), dim3(1), dim3(kMvRunBlock), 0, h->stream, d_stage_off, s0, s1, d_rec, h->d_vbase, h->d_vinfo, h->d_var_deg, h->d_partner, \
+                                      h->d_ptab, h->d_mv_f2v, h->d_mv_v2f, h->d_mv_marg, h->d_mv_prod, kt, h->d_ref_list)
+    const KaryMvTab kt{h->d_kary_slot, h->d_kary_pset, h->d_kary_aq};
+    if (h->cfg.dim == 2) CX_MVB(2);
+    else if (h->cfg.dim == 3) CX_MVB(3);
+    else CX_MVB(4);
+#undef CX_MVB
+}
+
 void mv_launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n) {
     if (n == 0) return;
     const dim3 g((unsigned)((n + kBlock - 1) / kBlock)), b(kBlock);
