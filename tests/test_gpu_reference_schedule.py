@@ -149,6 +149,23 @@ def test_partial_requests_in_the_callers_order(hip_lib):
     dev.close()
 
 
+def test_empty_and_repeated_requests(hip_lib):
+    """update_marginals!(engine, ids) walks ids as given (src/inference_engine.jl:559-632): nothing for an empty list, and a variable named
+    twice is processed where it stands first — the second mention finds its marginal computed"""
+    model = _models()["grid8x9"]
+    E, dev = _start(model)
+    x = model.x_ids
+    for request in ([], [x[5], x[5]], [x[40], x[7], x[40], x[7], x[8]], list(x) + list(x[:5])):
+        _set_priors(dev, E, model)
+        request = np.asarray(request, dtype=np.int64)
+        dev.sweep_for(request)
+        E.update_marginals(request)
+        assert dev.ref_trace() == _oracle_trace(E), f"request {request[:6]}"
+        if len(request):
+            _compare(dev, E, model, np.unique(request), f"request of {len(request)} ids")
+    dev.close()
+
+
 @pytest.mark.parametrize("T", [1, 3, 200])
 def test_the_reference_state_space_model(hip_lib, T):
     """test/inference_engine_tests.jl:379-488: one call is the Kalman smoother; a second call finds nothing pending"""
