@@ -35,7 +35,7 @@
 
 namespace {
 
-constexpr int kChunk = 4096;      // factors per first-level reduction workgroup
+constexpr int kChunk = 1024;      // factors per first-level reduction workgroup: four per thread of k_rate_sum, all their loads in flight together
 constexpr double kInfD = std::numeric_limits<double>::infinity();
 
 struct Vmp {
@@ -60,12 +60,12 @@ struct Vmp {
     double *n_mean = nullptr, *n_prec = nullptr, *n_mean_alt = nullptr, *n_prec_alt = nullptr;
     uint8_t *d_observed = nullptr, *d_mask = nullptr;
     double *g_shape = nullptr, *g_scale = nullptr, *g_mean = nullptr, *g_new = nullptr;   // g_new: [2][nG] staged (shape, scale)
-    int32_t *d_f_out = nullptr, *d_f_mean = nullptr, *d_f_gamma = nullptr, *d_f_pos = nullptr;
+    int32_t *d_f_out = nullptr, *d_f_mean = nullptr, *d_f_gamma = nullptr, *d_f_order = nullptr;      // (order: the factors sorted by precision variable)
     int32_t *d_nb_off = nullptr, *d_nb_other = nullptr, *d_nb_gamma = nullptr;            // mean field: CSR per Normal variable
     int32_t *d_chunk_begin = nullptr, *d_chunk_end = nullptr, *d_g_chunk_off = nullptr, *d_g_deg = nullptr;
     int32_t *d_req = nullptr;                                                               // requested Gamma indices
     std::vector<int32_t> req_on_device;                                                     // ... as last uploaded
-    double *d_rate = nullptr, *d_partial = nullptr;
+    double *d_partial = nullptr;
     // structured: inner scalar handle over the Normal variables
     cx_handle *chain = nullptr;
     int32_t *d_slot_out = nullptr, *d_slot_mean = nullptr;   // slot (inner handle) of the factor's OUT / IN edge
@@ -142,16 +142,12 @@ __global__ __launch_bounds__(256) void k_mf_normal(int n, const int32_t *__restr
     prec_out[i] = w;
 }
 
-// rate = 1 / scale of the Gamma(3/2, .) message of every factor towards its precision variable, written in Gamma-sorted order
+// rate = 1 / scale of the Gamma(3/2, .) message of a factor towards its precision variable
 template <bool STRUCTURED>
-__global__ __launch_bounds__(256) void k_rate(int nf, const int32_t *__restrict__ f_out, const int32_t *__restrict__ f_mean,
-                                              const int32_t *__restrict__ f_gamma, const int32_t *__restrict__ f_pos,
-                                              const double *__restrict__ n_mean, const double *__restrict__ n_prec,
-                                              const uint8_t *__restrict__ observed, const double *__restrict__ g_mean,
-                                              const int32_t *__restrict__ slot_out, const int32_t *__restrict__ slot_mean,
-                                              const double2 *__restrict__ v2f, double *__restrict__ rate) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= nf) return;
+__device__ __forceinline__ double rate_of(int f, const int32_t *__restrict__ f_out, const int32_t *__restrict__ f_mean, const int32_t *__restrict__ f_gamma,
+                                          const double *__restrict__ n_mean, const double *__restrict__ n_prec, const uint8_t *__restrict__ observed,
+                                          const double *__restrict__ g_mean, const int32_t *__restrict__ slot_out, const int32_t *__restrict__ slot_mean,
+                                          const double2 *__restrict__ v2f) {
     const int a = f_out[f], b = f_mean[f];
     double spread;
     if (STRUCTURED && !observed[a] && !observed[b]) {
@@ -170,7 +166,7 @@ __global__ __launch_bounds__(256) void k_rate(int nf, const int32_t *__restrict_
         const double dm = n_mean[a] - n_mean[b];
         spread = va + vb + dm * dm;                                     // :666-684, :990-995
     }
-    rate[f_pos[f]] = 0.5 * spread;     // Gamma(3/2, 2 / spread): rate = spread / 2
+    return 0.5 * spread;     // Gamma(3/2, 2 / spread): rate = spread / 2
 }
 
 __device__ __forceinline__ double block_sum(double v, double *sh) {
@@ -184,18 +180,36 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
     return r;   // valid in thread 0
 }
 
-__global__ __launch_bounds__(256) void k_reduce_chunks(const int32_t *__restrict__ chunk_begin, const int32_t *__restrict__ chunk_end,
-                                                       const double *__restrict__ rate, double *__restrict__ partial) {
+// The rates of a chunk of factors — consecutive in the order sorted by precision variable, never spanning two of them — and their sum, in
+// one kernel: the rates themselves are nobody's to read (until round 5 they were stored, 8 B a factor, and summed by a kernel of their own:
+// 7 us and 32 MB of an iteration at n = 1e6).  A thread takes the chunk's factors t, t + 256, t + 512, t + 768 and adds them in that order,
+// the workgroup folds its threads in a fixed tree: the sum does not depend on the launch.
+// Measured and NOT kept: the workgroup that finishes last (a counter behind __threadfence()) also finishing the precision variables, to
+// save k_gamma_finish's launch (4.6 us) — every workgroup's agent-scope release writes back and invalidates its XCD's L2, and this kernel
+// went from 16.2 to 72 us (13.2 to 54 for the mean-field family): profiles/r05_vmp_rocprof.md holds the kept form.
+template <bool STRUCTURED>
+__global__ __launch_bounds__(256) void k_rate_sum(const int32_t *__restrict__ chunk_begin, const int32_t *__restrict__ chunk_end, const int32_t *__restrict__ order,
+                                                  const int32_t *__restrict__ f_out, const int32_t *__restrict__ f_mean, const int32_t *__restrict__ f_gamma,
+                                                  const double *__restrict__ n_mean, const double *__restrict__ n_prec, const uint8_t *__restrict__ observed,
+                                                  const double *__restrict__ g_mean, const int32_t *__restrict__ slot_out, const int32_t *__restrict__ slot_mean,
+                                                  const double2 *__restrict__ v2f, double *__restrict__ partial) {
     __shared__ double sh[4];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, lo = chunk_begin[c], hi = chunk_end[c];
+    double r[kChunk / 256];
+#pragma unroll
+    for (int u = 0; u < kChunk / 256; u++) {
+        const int i = lo + threadIdx.x + 256 * u;
+        r[u] = i < hi ? rate_of<STRUCTURED>(order[i], f_out, f_mean, f_gamma, n_mean, n_prec, observed, g_mean, slot_out, slot_mean, v2f) : 0.0;
+    }
     double acc = 0.0;
-    for (int i = chunk_begin[c] + threadIdx.x; i < chunk_end[c]; i += blockDim.x) acc += rate[i];
+#pragma unroll
+    for (int u = 0; u < kChunk / 256; u++) acc += r[u];
     const double s = block_sum(acc, sh);
     if (threadIdx.x == 0) partial[c] = s;
 }
 
 // one workgroup per requested Gamma variable: sum its chunk partials and store (shape, scale, mean).  Every reader of the OLD
-// means in this round (k_mf_normal, k_rate) was launched before this kernel on the same stream, so the Jacobi round needs no
+// means in this round (k_mf_normal, k_rate_sum) was launched before this kernel on the same stream, so the Jacobi round needs no
 // staging copy and no commit launch of its own.
 __global__ __launch_bounds__(256) void k_gamma_finish(const int32_t *__restrict__ req, const int32_t *__restrict__ g_chunk_off,
                                                       const int32_t *__restrict__ g_deg, const double *__restrict__ partial,
@@ -331,10 +345,9 @@ int32_t vmp_graph_create(cx_handle *h, int64_t ne, const int64_t *edge_var, cons
             s->f_out[f] = s->var_local[e_out[f]]; s->f_mean[f] = s->var_local[e_mean[f]]; s->f_gamma[f] = s->var_local[e_prec[f]];
         }
         // factors sorted by Gamma variable (stable: ascending factor id inside), cut into chunks that never span two variables
-        std::vector<int32_t> order(nf), pos(nf);
+        std::vector<int32_t> order(nf);
         std::iota(order.begin(), order.end(), 0);
         std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return s->f_gamma[a] < s->f_gamma[b]; });
-        for (int64_t k = 0; k < nf; k++) pos[order[k]] = (int32_t)k;
         s->g_deg.assign(s->nG, 0);
         for (int64_t f = 0; f < nf; f++) s->g_deg[s->f_gamma[f]]++;
         std::vector<int32_t> chunk_begin, chunk_end;
@@ -357,10 +370,10 @@ int32_t vmp_graph_create(cx_handle *h, int64_t ne, const int64_t *edge_var, cons
         int32_t rc;
 #define TRY(x) do { rc = (x); if (rc != CX_OK) return rc; } while (0)
         TRY(up(h, s, &s->d_f_out, s->f_out)); TRY(up(h, s, &s->d_f_mean, s->f_mean)); TRY(up(h, s, &s->d_f_gamma, s->f_gamma));
-        TRY(up(h, s, &s->d_f_pos, pos));
+        TRY(up(h, s, &s->d_f_order, order));
         TRY(up(h, s, &s->d_chunk_begin, chunk_begin)); TRY(up(h, s, &s->d_chunk_end, chunk_end));
         TRY(up(h, s, &s->d_g_chunk_off, s->g_chunk_off)); TRY(up(h, s, &s->d_g_deg, s->g_deg));
-        TRY(alloc(h, s, &s->d_rate, nf)); TRY(alloc(h, s, &s->d_partial, s->nChunks));
+        TRY(alloc(h, s, &s->d_partial, s->nChunks));
         TRY(alloc(h, s, &s->n_mean, s->nN)); TRY(alloc(h, s, &s->n_prec, s->nN));
         TRY(alloc(h, s, &s->n_mean_alt, s->nN)); TRY(alloc(h, s, &s->n_prec_alt, s->nN));
         TRY(alloc(h, s, &s->d_observed, s->nN)); TRY(alloc(h, s, &s->d_mask, s->nN));
@@ -625,12 +638,11 @@ int32_t vmp_update_marginals(cx_handle *h, int64_t n, const int64_t *ids) {
                 s->req_on_device = req;
             }
             if (s->structured)
-                hipLaunchKernelGGL(k_rate<true>, dim3(blocks(s->nF)), dim3(256), 0, h->stream, (int)s->nF, s->d_f_out, s->d_f_mean, s->d_f_gamma, s->d_f_pos,
-                                   s->n_mean, s->n_prec, s->d_observed, s->g_mean, s->d_slot_out, s->d_slot_mean, s->chain->d_v2f, s->d_rate);
+                hipLaunchKernelGGL(k_rate_sum<true>, dim3((unsigned)s->nChunks), dim3(256), 0, h->stream, s->d_chunk_begin, s->d_chunk_end, s->d_f_order, s->d_f_out, s->d_f_mean,
+                                   s->d_f_gamma, s->n_mean, s->n_prec, s->d_observed, s->g_mean, s->d_slot_out, s->d_slot_mean, s->chain->d_v2f, s->d_partial);
             else
-                hipLaunchKernelGGL(k_rate<false>, dim3(blocks(s->nF)), dim3(256), 0, h->stream, (int)s->nF, s->d_f_out, s->d_f_mean, s->d_f_gamma, s->d_f_pos,
-                                   s->n_mean, s->n_prec, s->d_observed, s->g_mean, (const int32_t *)nullptr, (const int32_t *)nullptr, (const double2 *)nullptr, s->d_rate);
-            hipLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)s->nChunks), dim3(256), 0, h->stream, s->d_chunk_begin, s->d_chunk_end, s->d_rate, s->d_partial);
+                hipLaunchKernelGGL(k_rate_sum<false>, dim3((unsigned)s->nChunks), dim3(256), 0, h->stream, s->d_chunk_begin, s->d_chunk_end, s->d_f_order, s->d_f_out, s->d_f_mean,
+                                   s->d_f_gamma, s->n_mean, s->n_prec, s->d_observed, s->g_mean, (const int32_t *)nullptr, (const int32_t *)nullptr, (const double2 *)nullptr, s->d_partial);
             hipLaunchKernelGGL(k_gamma_finish, dim3((unsigned)req.size()), dim3(256), 0, h->stream, s->d_req, s->d_g_chunk_off, s->d_g_deg, s->d_partial,
                                s->g_shape, s->g_scale, s->g_mean);
         }
