@@ -79,6 +79,7 @@ rs::State &writable(RefSched *R) {
 
 // the stages of a plan on the handle's stream: runs of stages of at most run_max items as ONE launch of one workgroup (a barrier
 // between the stages instead of a kernel boundary), the wide ones a launch each
+static bool flat_runs() { static const bool on = [] { const char *v = std::getenv("CX_REF_FLAT_RUNS"); return !(v && v[0] == '0'); }(); return on; }      // (A/B: 0 = runs on the ordinary records)
 int64_t issue(cx_handle *h, RefSched *R, const PlanEntry &e, bool count_only) {
     const size_t ns = e.stage_off.empty() ? 0 : e.stage_off.size() - 1;
     int64_t launches = 0;
@@ -99,7 +100,10 @@ int64_t issue(cx_handle *h, RefSched *R, const PlanEntry &e, bool count_only) {
     for (size_t s = 0; s < ns;) {
         size_t t = s;
         while (t < ns && e.stage_off[t + 1] - e.stage_off[t] <= R->run_max && wide_at(t) == 0) t++;
-        if (t >= s + 2) { if (!count_only) cx::launch_batch_run(h, e.d_rec, e.d_stage_off, (int)s, (int)t); launches++; s = t; continue; }
+        if (t >= s + 2) {
+            if (!count_only) { if (e.d_flat && flat_runs()) cx::launch_flat_run(h, e.d_flat, e.d_rec, e.d_stage_off, (int)s, (int)t); else cx::launch_batch_run(h, e.d_rec, e.d_stage_off, (int)s, (int)t); }
+            launches++; s = t; continue;
+        }
         const int64_t n = e.stage_off[s + 1] - e.stage_off[s], nw = wide_at(s);
         if (n > 0) { if (!count_only) cx::launch_batch(h, e.d_rec + 5 * e.stage_off[s], n); launches++; }
         if (nw > 0) { if (!count_only) cx::launch_wide_sum(h, e.d_wide_rec + 5 * e.wide_off[s], nw, e.d_wide_partial); launches += 2; }      // (independent of the stage's other items)
@@ -148,7 +152,7 @@ namespace cxh {
 // nothing else.  Items that do not fit (more than five sources, rules of factors with more than two edges, variational rules) point back
 // at their ordinary record.
 void flat_records(const cx_handle *h, const std::vector<int32_t> &rec, const std::vector<int32_t> &list, std::vector<int32_t> &flat) {
-    constexpr int32_t kSumToFactor = 1, kSumToMarginal = 2, kSumToGamma = 3, kSumToProduct = 4, kRule = 5, kGeneric = 6, kCheckObserved = 0x80;
+    constexpr int32_t kSumToFactor = 1, kSumToMarginal = 2, kSumToGamma = 3, kSumToProduct = 4, kRule = 5, kGeneric = 6, kVmp = 7, kCheckObserved = 0x80;
     const int64_t n = (int64_t)rec.size() / 5;
     flat.assign((size_t)8 * n, 0);
     for (int64_t i = 0; i < n; i++) {
@@ -177,6 +181,9 @@ void flat_records(const cx_handle *h, const std::vector<int32_t> &rec, const std
         } else if ((kind == rs::kItemSumToFactor || kind == rs::kItemSumToMarginal || kind == rs::kItemSumToProduct || kind == rs::kItemSumToGammaMarginal) && r[4] >= 1 && r[4] <= 5) {
             o[0] = (kind == rs::kItemSumToFactor ? kSumToFactor : kind == rs::kItemSumToMarginal ? kSumToMarginal : kind == rs::kItemSumToProduct ? kSumToProduct : kSumToGamma) | (r[4] << 8) | pair;
             o[1] = r[1]; o[2] = r[2];
+            for (int32_t j = 0; j < r[4]; j++) o[3 + j] = list[r[3] + j];
+        } else if (kind >= rs::kItemMfNormal && kind <= rs::kItemStGamma && r[4] >= 1 && r[4] <= 3) {      // a variational rule: which one in the count field
+            o[0] = kVmp | ((kind - rs::kItemMfNormal) << 8) | pair; o[1] = r[1]; o[2] = r[2];
             for (int32_t j = 0; j < r[4]; j++) o[3 + j] = list[r[3] + j];
         }
     }
@@ -456,12 +463,16 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n, const uint64_t *k
             e.n_messages = P.n_messages; e.n_marginals = P.n_marginals; e.n_products = P.n_products; e.rounds = P.rounds; e.list_entries = (int64_t)P.list.size();
             // wide and deep: the cluster; chains of thin stages stay with one workgroup's runs (k_batch_run), short plans with plain launches
             e.cluster = P.wide_rec.empty() && cluster_fits(h, P.stage_off, (int64_t)P.stage_off.size() - 1);
+            // flat records: the cluster's, and the runs of thin stages' (k_flat_run) — items that load through 2 GiB buffer windows
+            const int64_t two_gib = (int64_t)1 << 31;
+            const bool want_flat = e.cluster || (h->cfg.dim == 1 && flat_runs() && h->nslots * 16 < two_gib && h->nv * 16 < two_gib && (int64_t)h->prod_index.size() * 16 < two_gib &&
+                                                 (int64_t)h->joint_index.size() * 48 < two_gib);
             std::vector<int32_t> flat;
-            if (e.cluster) flat_records(h, P.rec, P.list, flat);
+            if (want_flat) flat_records(h, P.rec, P.list, flat);
             const int64_t before = h->device_bytes;
             int32_t rc2;
             if ((rc2 = dev_upload(h, &e.d_rec, P.rec)) != CX_OK || (rc2 = dev_upload(h, &e.d_list, P.list)) != CX_OK || (rc2 = dev_upload(h, &e.d_stage_off, P.stage_off)) != CX_OK ||
-                (rc2 = dev_upload(h, &e.d_wide_rec, P.wide_rec)) != CX_OK || (e.cluster && (rc2 = dev_upload(h, &e.d_flat, flat)) != CX_OK) ||
+                (rc2 = dev_upload(h, &e.d_wide_rec, P.wide_rec)) != CX_OK || (want_flat && (rc2 = dev_upload(h, &e.d_flat, flat)) != CX_OK) ||
                 (!P.wide_rec.empty() && (rc2 = dev_alloc(h, &e.d_wide_partial, (int64_t)(P.wide_rec.size() / 5) * 64 * 2)) != CX_OK)) {
                 e.device_bytes = h->device_bytes - before; entry_free(h, e); return rc2;
             }

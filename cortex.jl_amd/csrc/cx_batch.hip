@@ -43,26 +43,26 @@ constexpr int kRecLeads = 0x40000000, kRecFollows = 0x20000000, kRecKindMask = 0
 // latter from the natural-parameter sum (shape - 1, rate).  A message to a precision is Gamma(3/2, 2 / spread) = natural (1/2, spread / 2).
 constexpr int kItemMfNormal = 67, kItemMfGamma = 68, kItemStNormal = 69, kItemVmpJoint = 70, kItemStGamma = 71, kItemSumToGammaMarginal = 72;
 template <bool COH>
-__device__ __forceinline__ void vmp_item(int k, int idx, int lo, const int32_t *__restrict__ list, double2 *__restrict__ f2v, const double2 *__restrict__ v2f,
-                                         const double2 *__restrict__ marg, double *__restrict__ joint) {
+__device__ __forceinline__ void vmp_item(int k, int idx, int s0, int s1, int s2, double2 *__restrict__ f2v, const double2 *__restrict__ v2f,
+                                         const double2 *__restrict__ marg, double *__restrict__ joint) {      // (s0 .. s2: the record's list entries)
     const double inf = __builtin_inf();
     if (k == kItemMfNormal) {                 // N(E[other], E[precision])                                                        (:654-664)
-        const double2 a = ld2<COH>(marg, list[lo]), g = ld2<COH>(marg, list[lo + 1]);
+        const double2 a = ld2<COH>(marg, s0), g = ld2<COH>(marg, s1);
         const double eg = g.x * g.y;
         if (!__builtin_isnan(a.x) && !__builtin_isnan(eg)) f2v[idx] = make_double2(a.x * eg, eg);
     } else if (k == kItemMfGamma) {           // Gamma(3/2, 2 / (var a + var b + (E a - E b)^2))                                  (:666-684)
-        const double2 a = ld2<COH>(marg, list[lo]), b = ld2<COH>(marg, list[lo + 1]);
+        const double2 a = ld2<COH>(marg, s0), b = ld2<COH>(marg, s1);
         const double d = a.x - b.x, spread = a.y + b.y + d * d;
         if (!__builtin_isnan(spread)) f2v[idx] = make_double2(0.5, 0.5 * spread);
     } else if (k == kItemStNormal) {          // N(mean m, 1 / (var m + 1 / E[precision])), m the other Normal variable's message    (:1004-1010)
-        const double2 m = ld2<COH>(v2f, list[lo]), g = ld2<COH>(marg, list[lo + 1]);
+        const double2 m = ld2<COH>(v2f, s0), g = ld2<COH>(marg, s1);
         const double eg = g.x * g.y;
         if (__builtin_isnan(m.y) || __builtin_isnan(m.x) || __builtin_isnan(eg)) return;
         const double mean = m.y == inf ? m.x : m.x / m.y, var = m.y == inf ? 0.0 : 1.0 / m.y;
         const double w = 1.0 / (var + 1.0 / eg);
         f2v[idx] = make_double2(mean * w, w);
     } else if (k == kItemVmpJoint) {          // the 2-d Gaussian with precision [[w1 + E, -E], [-E, w2 + E]] and potential (xi1, xi2)  (:939-967)
-        const double2 m1 = ld2<COH>(v2f, list[lo]), m2 = ld2<COH>(v2f, list[lo + 1]), g = ld2<COH>(marg, list[lo + 2]);
+        const double2 m1 = ld2<COH>(v2f, s0), m2 = ld2<COH>(v2f, s1), g = ld2<COH>(marg, s2);
         const double eg = g.x * g.y;
         if (__builtin_isnan(m1.y) || __builtin_isnan(m1.x) || __builtin_isnan(m2.y) || __builtin_isnan(m2.x) || __builtin_isnan(eg)) return;
         double mu1, mu2, v11, v12, v22;
@@ -77,7 +77,7 @@ __device__ __forceinline__ void vmp_item(int k, int idx, int lo, const int32_t *
         double *o = joint + 6 * (int64_t)idx;
         o[0] = mu1; o[1] = mu2; o[2] = v11; o[3] = v12; o[4] = v12; o[5] = v22;
     } else {                                  // kItemStGamma: Gamma(3/2, 2 / (V11 - 2 V12 + V22 + (m1 - m2)^2)) from the joint          (:1011-1016)
-        const int jb = 6 * list[lo];
+        const int jb = 6 * s0;
         const double o0 = ld1<COH>(joint, jb), o1 = ld1<COH>(joint, jb + 1), o2 = ld1<COH>(joint, jb + 2), o3 = ld1<COH>(joint, jb + 3), o4 = ld1<COH>(joint, jb + 4), o5 = ld1<COH>(joint, jb + 5);
         const double d = o0 - o1, spread = o2 - o3 - o4 + o5 + d * d;
         if (!__builtin_isnan(spread)) f2v[idx] = make_double2(0.5, 0.5 * spread);
@@ -93,7 +93,7 @@ __device__ __forceinline__ void batch_item(int k, int idx, int v, int lo, int hi
     if (k == kItemKaryEntry) {            // internal (the tree schedule's stage lists): index = entry of the k-ary table
         kary_item<COH>(idx, kt.slot, kt.coef, kt.qb, v2f, f2v);
     } else if (k >= kItemMfNormal && k <= kItemStGamma) {
-        vmp_item<COH>(k, idx, lo, kt.list, f2v, v2f, marg, joint);
+        vmp_item<COH>(k, idx, kt.list[lo], hi > 1 ? kt.list[lo + 1] : 0, hi > 2 ? kt.list[lo + 2] : 0, f2v, v2f, marg, joint);
     } else if (k >= kItemSumToFactor) {   // internal (reference-order plans)
         double2 acc = zero2();
         for (int j = 0; j < hi; j++) { const int s = kt.list[lo + j]; acc = add2(acc, s >= 0 ? ld2<COH>(f2v, s) : ld2<COH>(prod, ~s)); }
@@ -278,6 +278,7 @@ constexpr int kClusterBlock = 1024;
 // barrier: value loads -> store -> barrier is what is left on the chain.  kFlatGeneric: the item's ordinary record (five ints at index
 // `destination`) through batch_item — rules of factors with more than two edges, the variational rules, sums of more than five sources.
 constexpr int kFlatSumToFactor = 1, kFlatSumToMarginal = 2, kFlatSumToGamma = 3, kFlatSumToProduct = 4, kFlatRule = 5, kFlatGeneric = 6;
+constexpr int kFlatVmp = 7;      // a variational rule (kItemMfNormal + n, n in the count field), its list entries in s[0 .. 2]
 constexpr int kFlatCheckObserved = 0x80;      // MessageToFactor of the compact form: not recomputed for an observed / stand-in variable (m2f_one)
 struct FlatRec { int32_t k, dst, v, s[5]; };
 
@@ -293,6 +294,7 @@ __device__ __forceinline__ void flat_item(const FlatRec r, const int32_t *__rest
         batch_item<MODE, true>(g[0] & kRecKindMask, g[1], g[2], g[3], g[4], vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
         return;
     }
+    if (kind == kFlatVmp) { vmp_item<true>(kItemMfNormal + n, r.dst, r.s[0], r.s[1], r.s[2], f2v, v2f, marg, joint); return; }
     if (kind == kFlatRule) {
         const double2 m = ld2<true>(v2f, r.s[0]);
         const double qq = q[r.dst], a = MODE == kRuleLinear ? pa[r.dst] : 1.0, b = MODE == kRuleLinear ? pb[r.dst] : 0.0;
@@ -342,6 +344,20 @@ __device__ __forceinline__ void flat_pair(const FlatRec lead, const FlatRec fol,
         if (__builtin_isnan(m.y)) return;
         const double2 o = factor_rule<MODE>(m, qq, a, b);
         if (MODE != kRuleBernoulli || !__builtin_isnan(o.y)) f2v[fol.dst] = o;
+        return;
+    }
+    if (forward && (lead.k & 0x7f) == kFlatSumToFactor && (fol.k & 0x7f) == kFlatVmp && ((fol.k >> 8) & 0xff) == kItemStNormal - kItemMfNormal && fol.s[0] == lead.dst) {
+        // the structured variational rule behind the message it reads (a chain of a wired model): N(mean m, 1 / (var m + 1 / E[precision]))
+        const double2 g = ld2<true>(marg, fol.s[1]);
+        double2 m = nan2();
+        flat_item<MODE>(lead, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, &m);
+        if (__builtin_isnan(m.y)) m = ld2<true>(v2f, fol.s[0]);
+        const double eg = g.x * g.y;
+        if (__builtin_isnan(m.y) || __builtin_isnan(m.x) || __builtin_isnan(eg)) return;
+        const double inf = __builtin_inf();
+        const double mean = m.y == inf ? m.x : m.x / m.y, var = m.y == inf ? 0.0 : 1.0 / m.y;
+        const double w = 1.0 / (var + 1.0 / eg);
+        f2v[fol.dst] = make_double2(mean * w, w);
         return;
     }
     flat_item<MODE>(lead, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
@@ -461,7 +477,7 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
                 if (help >= 2) {
                     const int kind = r.k & 0x7f, n = (r.k >> 8) & 0xff;
                     if (kind == kFlatRule) sink ^= (unsigned)__double_as_longlong(ld2<true>(v2f, r.s[0]).y);
-                    else if (kind != kFlatGeneric)
+                    else if (kind != kFlatGeneric && kind != kFlatVmp)
                         for (int j = 0; j < 5; j++) if (j < n) sink ^= (unsigned)__double_as_longlong((r.s[j] >= 0 ? ld2<true>(f2v, r.s[j]) : ld2<true>(prod, ~r.s[j])).y);
                 }
             }
@@ -527,6 +543,44 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
     }
     if (timed) for (int j = 0; j < 5; j++) c->ticks[j] = tk[j];
     if (wtimed) c->wave_ticks[threadIdx.x >> 6] = wt;
+}
+
+// A run of consecutive thin stages of a reference-order plan in ONE launch of ONE workgroup (k_batch_run's job) on FLAT records.  What a
+// stage of such a run costs is a chain of dependent loads — stage table, record, list entries, graph tables, values — and a hand-off
+// through memory inside one workgroup is only 0.16 – 0.19 us (tools/lab/wg_handoff.hip: store, barrier, load; 0.15 more for every index
+// that has to come from memory first), so the plan's constants are taken off the chain: a thread holds its flat record (sources resolved) and
+// the one behind it, and asks for the next stage's pair before this stage's barrier.  Stages of at most kRunBlock items.
+template <int MODE>
+__global__ __launch_bounds__(kRunBlock) void k_flat_run(const int64_t *__restrict__ stage_off, int s0, int s1, const int32_t *__restrict__ flat, const int32_t *__restrict__ rec,
+                                                        const int32_t *__restrict__ vbase, const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
+                                                        const int32_t *__restrict__ partner, const double *__restrict__ q, const double *__restrict__ pa,
+                                                        const double *__restrict__ pb, double2 *f2v, double2 *v2f, double2 *marg, int nat_marg, double2 *prod, double *joint,
+                                                        const KaryTab kt) {
+    // item i of a stage goes to lane i / 16 of wavefront i mod 16: the few items of a thin stage are of different kinds, and one wavefront would
+    // take their branches — each a round of loads — one after the other
+    const int me = (threadIdx.x >> 6) + (kRunBlock / 64) * (threadIdx.x & 63);
+    int64_t lo = stage_off[s0], hi = stage_off[s0 + 1], nhi = s0 + 2 <= s1 ? stage_off[s0 + 2] : hi;
+    FlatRec cur{}, cur2{};
+    bool have = lo + me < hi;
+    if (have) cur = flat_load(flat, lo + me);
+    if (lo + me + 1 < hi) cur2 = flat_load(flat, lo + me + 1);
+    for (int st = s0; st < s1; st++) {
+        const int64_t nlo = hi, nnhi = st + 3 <= s1 ? stage_off[st + 3] : nhi;
+        if (have && !(cur.k & kRecFollows)) {
+            if (cur.k & kRecLeads) flat_pair<MODE>(cur, cur2, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, true);
+            else flat_item<MODE>(cur, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+        }
+        if (st + 1 == s1) break;
+        asm volatile("" ::: "memory");      // (the next records after the items: the hardware counts loads in order)
+        const bool nhave = nlo + me < nhi;
+        FlatRec nxt{}, nxt2{};
+        if (nhave) nxt = flat_load(flat, nlo + me);
+        if (nlo + me + 1 < nhi) nxt2 = flat_load(flat, nlo + me + 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        lo = nlo; hi = nhi; nhi = nnhi; have = nhave; cur = nxt; cur2 = nxt2;
+    }
 }
 
 // A list item of thousands of sources (cx_refsched.h: kWideList — the flat product a mean-field wiring makes of a precision's marginal):
@@ -619,6 +673,19 @@ void launch_batch_run(cx_handle *h, const int32_t *d_rec, const int64_t *d_stage
     }();
 #define CX_B(M, PA, PB) hipLaunchKernelGGL(k_batch_run<M>, dim3(1), dim3(kRunBlock), 0, h->stream, d_stage_off, s0, s1, d_rec, h->d_vbase, h->d_var_deg, h->d_vinfo, \
                                            h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint, kt, d_ticks)
+    if (mode == kRuleLinear) CX_B(kRuleLinear, h->d_a, h->d_b);
+    else if (mode == kRuleBernoulli) CX_B(kRuleBernoulli, (const double *)nullptr, (const double *)nullptr);
+    else CX_B(kRuleAdditive, (const double *)nullptr, (const double *)nullptr);
+#undef CX_B
+}
+
+// the same run on the plan's flat records (cx_api_ref.hip: flat_records)
+void launch_flat_run(cx_handle *h, const int32_t *d_flat, const int32_t *d_rec, const int64_t *d_stage_off, int s0, int s1) {
+    if (s1 <= s0) return;
+    const int mode = rule_mode(h), nat = h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0;
+    const KaryTab kt{h->d_kary_slot, h->d_kary_coef, h->d_kary_qb, h->d_ref_list};
+#define CX_B(M, PA, PB) hipLaunchKernelGGL(k_flat_run<M>, dim3(1), dim3(kRunBlock), 0, h->stream, d_stage_off, s0, s1, d_flat, d_rec, h->d_vbase, h->d_var_deg, h->d_vinfo, \
+                                           h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint, kt)
     if (mode == kRuleLinear) CX_B(kRuleLinear, h->d_a, h->d_b);
     else if (mode == kRuleBernoulli) CX_B(kRuleBernoulli, (const double *)nullptr, (const double *)nullptr);
     else CX_B(kRuleAdditive, (const double *)nullptr, (const double *)nullptr);
