@@ -312,7 +312,7 @@ int32_t ref_build(cx_handle *h) {
     if (const char *v = std::getenv("CX_REF_CACHE")) R->max_entries = std::max(1, std::atoi(v));
     (void)cluster_prepare(h);
     if (const char *v = std::getenv("CX_REF_CACHE_MB")) R->max_bytes = std::max<int64_t>(1, std::atoll(v)) << 20;
-    if (const char *v = std::getenv("CX_REF_RUN_MAX")) R->run_max = std::max(0, std::atoi(v));
+    if (const char *v = std::getenv("CX_REF_RUN_MAX")) R->run_max = std::min(1024, std::max(0, std::atoi(v)));      // (k_flat_run: a stage is one pass of 1,024 threads)
     h->ref = R.release();
     return CX_OK;
 }
