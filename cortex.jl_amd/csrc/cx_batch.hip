@@ -553,36 +553,53 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
 // (Measured on top and not kept: the next record asked for BEFORE the items, so that a stage does not begin by waiting for the last one's
 // stores to be acknowledged — loads and stores come back in issue order — 1.51 against 1.37 ms on the 1,001-stage wired chain; the last
 // wavefront touching the records six stages ahead: nothing, 1.37.)
+// The records travel through LDS: loads and stores come back in the order they were issued, so a thread that asked for its next record
+// after its stores began the next stage by waiting for those stores' acknowledgement (0.3 us), and one that asked before its items made its
+// values wait for the record.  The LAST wavefront stores nothing: it fetches the next stage's records into the other half of a double buffer
+// while the fifteen others work, and after the barrier everybody reads its record from LDS (another counter).  Per stage on the 1,001-stage
+// wired chain: 2.06 us (k_batch_run) -> 1.63 (flat records) -> 1.31 (one item per wavefront) -> see DESIGN.md §4c for this form.
+constexpr int kRunItemWaves = kRunBlock / 64 - 1;
 template <int MODE>
 __global__ __launch_bounds__(kRunBlock) void k_flat_run(const int64_t *__restrict__ stage_off, int s0, int s1, const int32_t *__restrict__ flat, const int32_t *__restrict__ rec,
                                                         const int32_t *__restrict__ vbase, const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
                                                         const int32_t *__restrict__ partner, const double *__restrict__ q, const double *__restrict__ pa,
                                                         const double *__restrict__ pb, double2 *f2v, double2 *v2f, double2 *marg, int nat_marg, double2 *prod, double *joint,
                                                         const KaryTab kt) {
-    // item i of a stage goes to lane i / 16 of wavefront i mod 16: the few items of a thin stage are of different kinds, and one wavefront would
+    __shared__ int4 rb[2][kRunBlock][2];      // 64 KB: the records of this stage and of the next
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool loader = wave == kRunItemWaves;
+    // item i of a stage goes to lane i / 15 of wavefront i mod 15: the few items of a thin stage are of different kinds, and one wavefront would
     // take their branches — each a round of loads — one after the other
-    const int me = (threadIdx.x >> 6) + (kRunBlock / 64) * (threadIdx.x & 63);
+    const int me = wave + kRunItemWaves * lane;
+    const int4 *flat4 = (const int4 *)flat;
     int64_t lo = stage_off[s0], hi = stage_off[s0 + 1], nhi = s0 + 2 <= s1 ? stage_off[s0 + 2] : hi;
-    FlatRec cur{}, cur2{};
-    bool have = lo + me < hi;
-    if (have) cur = flat_load(flat, lo + me);
-    if (lo + me + 1 < hi) cur2 = flat_load(flat, lo + me + 1);
+    if (loader)
+        for (int64_t i = lane; i < hi - lo; i += 64) { rb[0][i][0] = flat4[2 * (lo + i)]; rb[0][i][1] = flat4[2 * (lo + i) + 1]; }
+    __syncthreads();
+    auto record = [&](int p, int64_t i) {
+        const int4 a = rb[p][i][0], b = rb[p][i][1];
+        FlatRec r;
+        r.k = a.x; r.dst = a.y; r.v = a.z; r.s[0] = a.w; r.s[1] = b.x; r.s[2] = b.y; r.s[3] = b.z; r.s[4] = b.w;
+        return r;
+    };
     for (int st = s0; st < s1; st++) {
-        const int64_t nlo = hi, nnhi = st + 3 <= s1 ? stage_off[st + 3] : nhi;
-        if (have && !(cur.k & kRecFollows)) {
-            if (cur.k & kRecLeads) flat_pair<MODE>(cur, cur2, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, true);
-            else flat_item<MODE>(cur, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+        const int p = (st - s0) & 1;
+        const int64_t nlo = hi, nnhi = st + 3 <= s1 ? stage_off[st + 3] : nhi, W = hi - lo;
+        if (loader) {
+            if (st + 1 < s1)
+                for (int64_t i = lane; i < nhi - nlo; i += 64) { rb[p ^ 1][i][0] = flat4[2 * (nlo + i)]; rb[p ^ 1][i][1] = flat4[2 * (nlo + i) + 1]; }
+        } else {
+            for (int64_t i = me; i < W; i += kRunItemWaves * 64) {
+                const FlatRec cur = record(p, i);
+                if (cur.k & kRecFollows) continue;
+                if (cur.k & kRecLeads) flat_pair<MODE>(cur, record(p, i + 1), rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, true);
+                else flat_item<MODE>(cur, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+            }
         }
-        if (st + 1 == s1) break;
-        asm volatile("" ::: "memory");      // (the next records after the items: the hardware counts loads in order)
-        const bool nhave = nlo + me < nhi;
-        FlatRec nxt{}, nxt2{};
-        if (nhave) nxt = flat_load(flat, nlo + me);
-        if (nlo + me + 1 < nhi) nxt2 = flat_load(flat, nlo + me + 1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        lo = nlo; hi = nhi; nhi = nnhi; have = nhave; cur = nxt; cur2 = nxt2;
+        lo = nlo; hi = nhi; nhi = nnhi;
     }
 }
 

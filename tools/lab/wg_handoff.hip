@@ -11,7 +11,8 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 
-template <int MODE>      // 0 plain loads, 1 sc1 loads, 2 LDS, 3 plain + index from memory, 4 plain, and the workgroup waits for the store's acknowledgement
+template <int MODE>      // 0 plain loads, 1 sc1 loads, 2 LDS, 3 plain + index from memory, 4 plain, and the workgroup waits for the store's acknowledgement,
+                         // 5 plain, and four dependent f64 divisions on the value (a variational rule's arithmetic)
 __global__ __launch_bounds__(1024) void k_chain(double *buf, const int *idx, int n, int R, double *out) {
     __shared__ double lds[2][1024];
     const int t = threadIdx.x;
@@ -20,6 +21,7 @@ __global__ __launch_bounds__(1024) void k_chain(double *buf, const int *idx, int
         double *cur = buf + (size_t)(r & 1) * 1024;
         if (t < n) {
             if (MODE == 2) lds[r & 1][t] = x * 1.0000001 + 0.5;
+            else if (MODE == 5) { const double a = 1.0 / x, b = 1.0 / (a + 0.25), c = b / (x + 1.0), d = 1.0 / (c + 1.0); cur[t] = d + x * 1e-9; }
             else cur[t] = x * 1.0000001 + 0.5;
         }
         if (MODE == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -43,11 +45,11 @@ int main() {
     CK(hipMalloc(&buf, 2 * 1024 * 8)); CK(hipMalloc(&out, 1024 * 8)); CK(hipMalloc(&idx, (size_t)R * 1024 * 4));
     int *h = (int *)malloc((size_t)R * 1024 * 4);
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    const char *names[] = {"plain load", "sc1 load", "through LDS", "plain load, index from memory first", "plain load, store acknowledged before the barrier"};
+    const char *names[] = {"plain load", "sc1 load", "through LDS", "plain load, index from memory first", "plain load, store acknowledged before the barrier", "plain load, four dependent f64 divisions"};
     for (int n : {8, 64, 1024}) {
         for (size_t i = 0; i < (size_t)R * 1024; i++) h[i] = (int)((i % 1024 + 1) % n);
         CK(hipMemcpy(idx, h, (size_t)R * 1024 * 4, hipMemcpyHostToDevice));
-        for (int mode = 0; mode < 5; mode++) {
+        for (int mode = 0; mode < 6; mode++) {
             float best = 1e30f;
             double first = 0;
             for (int rep = 0; rep < 3; rep++) {
@@ -58,7 +60,8 @@ int main() {
                     case 1: hipLaunchKernelGGL(k_chain<1>, dim3(1), dim3(1024), 0, 0, buf, idx, n, R, out); break;
                     case 2: hipLaunchKernelGGL(k_chain<2>, dim3(1), dim3(1024), 0, 0, buf, idx, n, R, out); break;
                     case 3: hipLaunchKernelGGL(k_chain<3>, dim3(1), dim3(1024), 0, 0, buf, idx, n, R, out); break;
-                    default: hipLaunchKernelGGL(k_chain<4>, dim3(1), dim3(1024), 0, 0, buf, idx, n, R, out); break;
+                    case 4: hipLaunchKernelGGL(k_chain<4>, dim3(1), dim3(1024), 0, 0, buf, idx, n, R, out); break;
+                    default: hipLaunchKernelGGL(k_chain<5>, dim3(1), dim3(1024), 0, 0, buf, idx, n, R, out); break;
                 }
                 CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
                 float ms; CK(hipEventElapsedTime(&ms, a, b));
