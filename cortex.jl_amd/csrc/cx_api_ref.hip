@@ -5,6 +5,7 @@
 // call — replays a standing plan and costs the host a hash lookup.
 
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <memory>
 
@@ -155,7 +156,10 @@ void flat_records(const cx_handle *h, const std::vector<int32_t> &rec, const std
     constexpr int32_t kSumToFactor = 1, kSumToMarginal = 2, kSumToGamma = 3, kSumToProduct = 4, kRule = 5, kGeneric = 6, kVmp = 7, kCheckObserved = 0x80;
     const int64_t n = (int64_t)rec.size() / 5;
     flat.assign((size_t)8 * n, 0);
-    for (int64_t i = 0; i < n; i++) {
+    // (a record depends on nothing but itself: large plans are resolved by several threads — 18 M records: 0.2 s on one)
+    const int64_t n_threads = n < (1 << 20) ? 1 : std::max<int64_t>(1, std::min<int64_t>(16, (int64_t)std::thread::hardware_concurrency()));
+    auto work = [&](int64_t i0, int64_t i1) {
+    for (int64_t i = i0; i < i1; i++) {
         const int32_t *r = &rec[5 * i];
         int32_t *o = &flat[8 * i];
         const int32_t pair = r[0] & (rs::kRecLeads | rs::kRecFollows), kind = r[0] & rs::kRecKindMask;      // (the pair flags travel in the flat kind too)
@@ -187,6 +191,11 @@ void flat_records(const cx_handle *h, const std::vector<int32_t> &rec, const std
             for (int32_t j = 0; j < r[4]; j++) o[3 + j] = list[r[3] + j];
         }
     }
+    };
+    if (n_threads == 1) { work(0, n); return; }
+    std::vector<std::thread> pool;
+    for (int64_t t = 0; t < n_threads; t++) pool.emplace_back(work, n * t / n_threads, n * (t + 1) / n_threads);
+    for (auto &th : pool) th.join();
 }
 
 
@@ -440,14 +449,18 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n, const uint64_t *k
     if (hit < 0) {
         try {
             // the scheduler runs on a copy: a call the device cannot replay leaves the shadow where it was
+            static const bool timing_b = std::getenv("CX_REF_TIMING") != nullptr;
+            const auto b0 = std::chrono::steady_clock::now();
             auto T = std::make_shared<rs::State>(*R->S);
             rs::Call call;
             const int32_t bad = rs::update_marginals(R->W, *T, req, n, call);
+            const auto b1 = std::chrono::steady_clock::now();
             (void)bad;      // reported by level() with the message's ids
             rs::Plan P;
             std::string err;
             const int32_t rc = rs::level(h, R->W, call, [&](int64_t i) { return R->prod_slot[i]; }, [&](int64_t f) { return R->joint_slot[f]; }, P, err);
             if (rc != CX_OK) return fail(h, rc, err);
+            const auto b2 = std::chrono::steady_clock::now();
             const int64_t incoming = (int64_t)(P.rec.size() + P.list.size() + P.wide_rec.size() + P.rec.size() / 5 * 8) * 4 + (int64_t)P.stage_off.size() * 8;
             auto kept_bytes = [&] { int64_t b = 0; for (auto &c : R->cache) b += c.device_bytes; return b; };
             while (!R->cache.empty() && ((int)R->cache.size() >= R->max_entries || kept_bytes() + incoming > R->max_bytes)) {      // least recently used out
@@ -469,6 +482,7 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n, const uint64_t *k
                                                  (int64_t)h->joint_index.size() * 48 < two_gib);
             std::vector<int32_t> flat;
             if (want_flat) flat_records(h, P.rec, P.list, flat);
+            const auto b3 = std::chrono::steady_clock::now();
             const int64_t before = h->device_bytes;
             int32_t rc2;
             if ((rc2 = dev_upload(h, &e.d_rec, P.rec)) != CX_OK || (rc2 = dev_upload(h, &e.d_list, P.list)) != CX_OK || (rc2 = dev_upload(h, &e.d_stage_off, P.stage_off)) != CX_OK ||
@@ -478,6 +492,12 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n, const uint64_t *k
             }
             e.device_bytes = h->device_bytes - before;
             CX_HIP(h, hipStreamSynchronize(h->stream));      // the plan's host vectors die here
+            if (timing_b) {
+                const auto b4 = std::chrono::steady_clock::now();
+                auto ms = [](auto x, auto y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
+                fprintf(stderr, "[ref] new plan (%lld executions): scheduler %.1f ms, levelling %.1f ms, flat records %.1f ms, upload %.1f ms\n", (long long)call.order.size(),
+                        ms(b0, b1), ms(b1, b2), ms(b2, b3), ms(b3, b4));
+            }
             e.post = T;
             e.order = std::move(call.order);
             e.launches = issue(h, R, e, true);
