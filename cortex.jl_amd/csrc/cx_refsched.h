@@ -645,6 +645,13 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
     };
     for (int64_t i = 0; i < n; i++) {
         const int64_t s = call.order[i];
+        // (the executions wander over tables of tens of millions of signals: what the ones to come will read is asked for ahead)
+        if (i + 24 < n) { const int64_t a = call.order[i + 24]; __builtin_prefetch(&W.dep_off[a]); __builtin_prefetch(&w_stage[a]); __builtin_prefetch(&r_stage[a]); }
+        if (i + 12 < n) { const int64_t a = call.order[i + 12]; __builtin_prefetch(&W.dep[W.dep_off[a]]); }
+        if (i + 6 < n) {
+            const int64_t a = call.order[i + 6];
+            for (int64_t p = W.dep_off[a]; p < W.dep_off[a + 1] && p < W.dep_off[a] + 6; p++) { __builtin_prefetch(&w_stage[W.dep[p]]); __builtin_prefetch(&r_stage[W.dep[p]]); }
+        }
         int32_t st = std::max(w_stage[s], r_stage[s]) + 1;
         const int64_t src = fuse_pairs ? pair_source(s) : -1;
         if (src >= 0 && w_exec[src] >= 0 && follower[w_exec[src]] < 0 && !is_wide(src)) {
