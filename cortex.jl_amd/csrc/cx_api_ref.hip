@@ -5,6 +5,7 @@
 // call — replays a standing plan and costs the host a hash lookup.
 
 #include <chrono>
+#include <mutex>
 #include <thread>
 #include <cstdio>
 #include <memory>
@@ -238,6 +239,11 @@ int32_t cluster_run(cx_handle *h, const int32_t *d_flat, const int32_t *d_rec, c
     // stages wider than the whole chip is (the first two of a grid's plan: every prior's message at once) leave as ordinary launches
     // on all eight XCDs; the runs of stages between them go to the cluster, one launch per run
     if (launches) *launches = 0;
+    // one cluster at a time per process: two launches that each hold part of one XCD's compute units would wait for each other's workgroups
+    // to become resident until both time out (handles driven from different threads; another PROCESS's cluster can still do that: both
+    // calls then fail loudly after their bounded waits and their handles go back to launches)
+    static std::mutex one_cluster;
+    std::lock_guard<std::mutex> hold(one_cluster);
     for (int64_t s = 0; s < ns;) {
         const int64_t w = stage_off[s + 1] - stage_off[s];
         if (launches) ++*launches;

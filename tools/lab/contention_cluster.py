@@ -25,6 +25,22 @@ if len(sys.argv) > 1 and sys.argv[1] == "tenant":
     print(json.dumps({"tenant_sweeps": n}), flush=True)
     sys.exit(0)
 
+if len(sys.argv) > 1 and sys.argv[1] == "tenant_ref":      # a second user of the cluster: reference-order calls of its own
+    model = cx.synth.gaussian_grid(1000, 1000, seed=2)
+    prior = np.stack([model.prior_mean, model.prior_variance], axis=1)
+    dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(model, dev, seed_variance=1e6)
+    t_end = time.time() + float(sys.argv[2])
+    n = failed = 0
+    while time.time() < t_end:
+        dev.set_messages(model.prior_var, model.prior_fac, L.TO_VARIABLE, L.FORM_MOMENT, prior)
+        try:
+            dev.sweep(1); dev.sync(); n += 1
+        except cx.CortexHipError:
+            failed += 1
+    print(json.dumps({"tenant_reference_calls": n, "tenant_failed": failed, "tenant_cluster_state": dev.cluster_stats()["state"]}), flush=True)
+    sys.exit(0)
+
 side, calls = 1415, 40
 model = cx.synth.gaussian_grid(side, side, seed=1)
 prior = np.stack([model.prior_mean, model.prior_variance], axis=1)
@@ -49,7 +65,7 @@ def run(n):
 
 run(4)
 alone, f0 = run(calls)
-child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "tenant", "25"], stdout=subprocess.PIPE, text=True)
+child = subprocess.Popen([sys.executable, os.path.abspath(__file__), os.environ.get("TENANT", "tenant"), "25"], stdout=subprocess.PIPE, text=True)
 time.sleep(12.0)      # the tenant imports, builds its grid and starts sweeping
 shared, f1 = run(calls)
 out, _ = child.communicate(timeout=120)
