@@ -55,6 +55,31 @@ def test_a_reference_order_call_on_a_grid_runs_on_the_cluster(hip_lib):
             dev.set_messages(model.prior_var, model.prior_fac, L.TO_VARIABLE, L.FORM_MOMENT, prior)
 
 
+def test_two_cluster_handles_agree_in_every_bit(hip_lib):
+    """the same plan on two handles: whichever XCD and workgroups a launch lands on, the arithmetic per execution is the same, so every stored
+    value agrees bit for bit after every call — a value read before its writer's store had reached the L2 would show here (the long form:
+    tools/lab/soak_cluster.py, 150 calls at C4)"""
+    model = cx.synth.gaussian_grid(900, 1000, seed=5)
+    prior = np.stack([model.prior_mean, model.prior_variance], axis=1)
+    devs = []
+    for _ in range(2):
+        dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+        cx.synth.load_into_device(model, dev, seed_variance=1e6)
+        devs.append(dev)
+    for call in range(6):
+        for dev in devs:
+            dev.set_messages(model.prior_var, model.prior_fac, L.TO_VARIABLE, L.FORM_MOMENT, prior)
+            dev.sweep(1)
+        assert all(d.cluster_stats()["last_reference_call"] for d in devs)
+        a, b = (d.get_marginals(model.x_ids) for d in devs)
+        assert np.array_equal(a, b), f"call {call}: marginals"
+        for direction in (L.TO_VARIABLE, L.TO_FACTOR):
+            ma, mb = (d.get_messages(model.edge_var, model.edge_fac, direction, L.FORM_NATURAL) for d in devs)
+            assert np.array_equal(ma, mb, equal_nan=True), f"call {call}: messages, direction {direction}"
+    for d in devs:
+        d.close()
+
+
 def test_a_small_grid_stays_with_one_workgroups_runs(hip_lib):
     """stages of at most 1,024 items fold into runs of one workgroup with its own barrier (≈ 1 us a stage): cheaper than the cluster's"""
     model = cx.synth.gaussian_grid(100, 110, seed=3)
