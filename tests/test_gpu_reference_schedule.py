@@ -134,6 +134,24 @@ def test_the_sweep_differs_from_a_jacobi_sweep_and_shares_its_fixed_point(hip_li
     dev.close(); jac.close()
 
 
+def test_a_grid_of_runs_and_launches_against_the_engine(hip_lib):
+    """a 230 x 240 grid: its plan's stages run from a pair to ~1,100 records — runs of thin stages on flat records in one workgroup
+    (cx_batch.hip: k_flat_run; between 960 and 1,024 records the fifteen item wavefronts take a second pass) next to stages that leave as
+    launches; three calls, executions and every message and marginal against the restated engine"""
+    model = cx.synth.gaussian_grid(230, 240, seed=7)
+    E, dev = _start(model)
+    for call in range(3):
+        if call:
+            _set_priors(dev, E, model)
+        dev.sweep(1)
+        E.update_marginals(model.x_ids)
+        assert dev.ref_trace() == _oracle_trace(E), f"call {call + 1}: the executions"
+        _compare(dev, E, model, model.x_ids, f"230 x 240 call {call + 1}")
+    st = dev.ref_plan_stats()
+    assert 1 < st["launches"] < st["stages"] and not dev.cluster_stats()["last_reference_call"], st
+    dev.close()
+
+
 def test_partial_requests_in_the_callers_order(hip_lib):
     model = _models()["grid8x9"]
     E, dev = _start(model)
