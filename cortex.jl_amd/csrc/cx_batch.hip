@@ -558,6 +558,8 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
 // values wait for the record.  The LAST wavefront stores nothing: it fetches the next stage's records into the other half of a double buffer
 // while the fifteen others work, and after the barrier everybody reads its record from LDS (another counter).  Per stage on the 1,001-stage
 // wired chain: 2.06 us (k_batch_run) -> 1.63 (flat records) -> 1.31 (one item per wavefront) -> see DESIGN.md §4c for this form.
+// (Measured on top and not kept: even stages on wavefronts 0 .. 6 and odd stages on 7 .. 13, so that a stage's loads do not queue behind the
+// last one's store acknowledgements: 1.22 against 1.14 ms, 158 against 119 – 138 ms at n = 1e5.)
 constexpr int kRunItemWaves = kRunBlock / 64 - 1;
 template <int MODE>
 __global__ __launch_bounds__(kRunBlock) void k_flat_run(const int64_t *__restrict__ stage_off, int s0, int s1, const int32_t *__restrict__ flat, const int32_t *__restrict__ rec,
