@@ -39,6 +39,70 @@ __global__ __launch_bounds__(1024) void k_chain(double *buf, const int *idx, int
     if (t < n) out[t] = x;
 }
 
+// What a stage of k_flat_run does, piece by piece (FEAT bits): 1 the value through five 16-byte sc1 buffer loads + five that point past the
+// buffer, 2 a byte buffer load (the observed flag) with them, 4 the record from LDS (four ds_read_b128), 8 two stores (a sum, then a rule's
+// result with four dependent divisions), 16 the stage's bounds from memory (a scalar load), 32 item t on wavefront t mod 15 (one lane each)
+// instead of consecutive lanes
+typedef double __attribute__((ext_vector_type(2))) d2v;
+template <int FEAT>
+__global__ __launch_bounds__(1024) void k_stage(double *buf, double *buf2, const unsigned char *flags, const long *bounds, int n, int R, double *out) {
+    __shared__ int4 recs[1024][2];
+    const int tid = threadIdx.x;
+    const int t = (FEAT & 32) ? ((tid >> 6) < 15 ? (tid >> 6) + 15 * (tid & 63) : 1 << 20) : tid;
+    if (tid < 1024) { recs[tid][0] = make_int4(tid, (tid + 1) % n, (tid + 2) % n, (tid + 3) % n); recs[tid][1] = make_int4((tid + 4) % n, (tid + 5) % n, 0, 0); }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)buf, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)flags, 0, 0x7fffffff, 0x00020000);
+    double x = 1.0 + tid;
+    for (int r = 0; r < R; r++) {
+        long hi = n;
+        if (FEAT & 16) hi = bounds[r];
+        if (t < hi) {
+            int s[5] = {(t + 1) % n, (t + 2) % n, (t + 3) % n, (t + 4) % n, (t + 5) % n};
+            if (FEAT & 4) { const int4 a = recs[t][0], b = recs[t][1]; s[0] = a.y; s[1] = a.z; s[2] = a.w; s[3] = b.x; s[4] = b.y; }
+            double acc = 0.0;
+            const int base = (r & 1) * 2048 * 16;
+            if (FEAT & 1) {
+                d2v v[5];
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    const d2v a = __builtin_bit_cast(d2v, __builtin_amdgcn_raw_buffer_load_b128(rf, base + s[j] * 16, 0, 16));
+                    const d2v b = __builtin_bit_cast(d2v, __builtin_amdgcn_raw_buffer_load_b128(rf, -1, 0, 16));
+                    v[j] = a + b;
+                }
+                for (int j = 0; j < 5; j++) acc += v[j][0];
+            } else acc = buf[base / 8 + s[0] * 2];
+            if (FEAT & 2) acc += (double)__builtin_amdgcn_raw_buffer_load_b8(rg, t, 0, 0);
+            const int nb = ((r + 1) & 1) * 2048 * 2;
+            if (FEAT & 8) {
+                buf2[nb + 2 * t] = acc;
+                const double a = 1.0 / (acc + 2.0), b = 1.0 / (a + 0.25), c = b / (acc + 3.0), d = 1.0 / (c + 1.0);
+                buf[nb + 2 * t] = d + 1e-9 * acc; buf[nb + 2 * t + 1] = a;
+            } else buf[nb + 2 * t] = acc * 1e-3 + 0.5;
+            x = acc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    if (tid < n) out[tid] = x;
+}
+
+template <int FEAT>
+static float run_stage(double *buf, double *buf2, unsigned char *flags, long *bounds, int n, int R, double *out) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+        CK(hipMemset(buf, 0, 2 * 2048 * 16));
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL(k_stage<FEAT>, dim3(1), dim3(1024), 0, 0, buf, buf2, flags, bounds, n, R, out);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    return 1e3f * best / R;
+}
+
 int main() {
     const int R = 20000;
     double *buf, *out; int *idx;
@@ -70,6 +134,23 @@ int main() {
             }
             printf("n = %4d  %-52s %7.3f us per round   (x0 = %.6f)\n", n, names[mode], 1e3 * best / R, first);
         }
+    }
+    {
+        const int R2 = 20000, n = 7;
+        double *b1, *b2, *o; unsigned char *fl; long *bd;
+        CK(hipMalloc(&b1, 2 * 2048 * 16)); CK(hipMalloc(&b2, 2 * 2048 * 16)); CK(hipMalloc(&o, 1024 * 8)); CK(hipMalloc(&fl, 4096)); CK(hipMalloc(&bd, (size_t)R2 * 8));
+        CK(hipMemset(fl, 0, 4096));
+        long *hb = (long *)malloc((size_t)R2 * 8);
+        for (int i = 0; i < R2; i++) hb[i] = n;
+        CK(hipMemcpy(bd, hb, (size_t)R2 * 8, hipMemcpyHostToDevice));
+        printf("\na stage of %d items, features added one by one (us per round):\n", n);
+        printf("  plain load, one store                                   %7.3f\n", run_stage<0>(b1, b2, fl, bd, n, R2, o));
+        printf("  + five sc1 buffer loads (and five past the end)         %7.3f\n", run_stage<1>(b1, b2, fl, bd, n, R2, o));
+        printf("  + the flag byte                                         %7.3f\n", run_stage<3>(b1, b2, fl, bd, n, R2, o));
+        printf("  + the record from LDS                                   %7.3f\n", run_stage<7>(b1, b2, fl, bd, n, R2, o));
+        printf("  + two stores, four divisions between them               %7.3f\n", run_stage<15>(b1, b2, fl, bd, n, R2, o));
+        printf("  + the stage's bounds from memory                        %7.3f\n", run_stage<31>(b1, b2, fl, bd, n, R2, o));
+        printf("  + one item per wavefront                                %7.3f\n", run_stage<63>(b1, b2, fl, bd, n, R2, o));
     }
     return 0;
 }
