@@ -101,7 +101,8 @@ int64_t issue(cx_handle *h, RefSched *R, const PlanEntry &e, bool count_only) {
     auto wide_at = [&](size_t s) { return e.wide_off.empty() ? (int64_t)0 : e.wide_off[s + 1] - e.wide_off[s]; };
     for (size_t s = 0; s < ns;) {
         size_t t = s;
-        while (t < ns && e.stage_off[t + 1] - e.stage_off[t] <= R->run_max && wide_at(t) == 0) t++;
+        const int64_t thin_max = e.d_flat && flat_runs() ? std::min<int64_t>(R->run_max, cx::flat_run_max()) : R->run_max;
+        while (t < ns && e.stage_off[t + 1] - e.stage_off[t] <= thin_max && wide_at(t) == 0) t++;
         if (t >= s + 2) {
             if (!count_only) { if (e.d_flat && flat_runs()) cx::launch_flat_run(h, e.d_flat, e.d_rec, e.d_stage_off, (int)s, (int)t); else cx::launch_batch_run(h, e.d_rec, e.d_stage_off, (int)s, (int)t); }
             launches++; s = t; continue;
@@ -153,7 +154,7 @@ namespace cxh {
 // destination, variable, five sources): what the XCD-resident cluster runs, so that an item's chain of dependent loads is its values and
 // nothing else.  Items that do not fit (more than five sources, rules of factors with more than two edges, variational rules) point back
 // at their ordinary record.
-void flat_records(const cx_handle *h, const std::vector<int32_t> &rec, const std::vector<int32_t> &list, std::vector<int32_t> &flat) {
+void flat_records(const cx_handle *h, const std::vector<int32_t> &rec, const std::vector<int32_t> &list, const std::vector<int64_t> &stage_off, std::vector<int32_t> &flat) {
     constexpr int32_t kSumToFactor = 1, kSumToMarginal = 2, kSumToGamma = 3, kSumToProduct = 4, kRule = 5, kGeneric = 6, kVmp = 7, kCheckObserved = 0x80;
     const int64_t n = (int64_t)rec.size() / 5;
     flat.assign((size_t)8 * n, 0);
@@ -193,10 +194,39 @@ void flat_records(const cx_handle *h, const std::vector<int32_t> &rec, const std
         }
     }
     };
-    if (n_threads == 1) { work(0, n); return; }
-    std::vector<std::thread> pool;
-    for (int64_t t = 0; t < n_threads; t++) pool.emplace_back(work, n * t / n_threads, n * (t + 1) / n_threads);
-    for (auto &th : pool) th.join();
+    if (n_threads == 1) work(0, n);
+    else {
+        std::vector<std::thread> pool;
+        for (int64_t t = 0; t < n_threads; t++) pool.emplace_back(work, n * t / n_threads, n * (t + 1) / n_threads);
+        for (auto &th : pool) th.join();
+    }
+    // A stage of at most 64 records (a chain's, a small graph's): its units — a record, or a leader and its follower — sorted by kind, the
+    // first record of every kind flagged (cx_batch.hip: kFlatGroupStart; k_flat_run gives each kind a wavefront of its own).  The order of
+    // the items of a stage is free: they are independent.
+    constexpr int32_t kGroupStart = 0x10000000;
+    struct Unit { uint64_t key; int32_t first, count; };
+    std::vector<Unit> units;
+    std::vector<int32_t> tmp;
+    for (size_t st = 0; st + 1 < stage_off.size(); st++) {
+        const int64_t lo = stage_off[st], W = stage_off[st + 1] - lo;
+        if (W < 2 || W > 64) continue;
+        units.clear();
+        for (int64_t i = 0; i < W;) {
+            const int32_t *o = &flat[8 * (lo + i)];
+            const bool leads = (o[0] & rs::kRecLeads) && i + 1 < W;
+            auto kind_of = [](int32_t k) { return (uint32_t)((k & 0x7f) == kVmp ? (k & 0xffff) : (k & 0xff)); };      // (a variational rule's name is in the count field)
+            const uint64_t k0 = kind_of(o[0]), k1 = leads ? kind_of(flat[8 * (lo + i + 1)]) : 0;
+            units.push_back({(k0 << 16) | k1, (int32_t)i, leads ? 2 : 1});
+            i += leads ? 2 : 1;
+        }
+        std::stable_sort(units.begin(), units.end(), [](const Unit &a, const Unit &b) { return a.key < b.key; });
+        tmp.assign(flat.begin() + 8 * lo, flat.begin() + 8 * (lo + W));
+        int64_t w = 0;
+        for (size_t u = 0; u < units.size(); u++) {
+            for (int32_t c = 0; c < units[u].count; c++, w++) std::copy(tmp.begin() + 8 * (units[u].first + c), tmp.begin() + 8 * (units[u].first + c) + 8, flat.begin() + 8 * (lo + w));
+            if (u == 0 || units[u].key != units[u - 1].key) flat[8 * (lo + w - units[u].count)] |= kGroupStart;
+        }
+    }
 }
 
 
@@ -487,7 +517,7 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n, const uint64_t *k
             const bool want_flat = e.cluster || (h->cfg.dim == 1 && flat_runs() && h->nslots * 16 < two_gib && h->nv * 16 < two_gib && (int64_t)h->prod_index.size() * 16 < two_gib &&
                                                  (int64_t)h->joint_index.size() * 48 < two_gib);
             std::vector<int32_t> flat;
-            if (want_flat) flat_records(h, P.rec, P.list, flat);
+            if (want_flat) flat_records(h, P.rec, P.list, P.stage_off, flat);
             const auto b3 = std::chrono::steady_clock::now();
             const int64_t before = h->device_bytes;
             int32_t rc2;

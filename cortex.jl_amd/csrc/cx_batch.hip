@@ -560,42 +560,70 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
 // wired chain: 2.06 us (k_batch_run) -> 1.63 (flat records) -> 1.31 (one item per wavefront) -> see DESIGN.md §4c for this form.
 // (Measured on top and not kept: even stages on wavefronts 0 .. 6 and odd stages on 7 .. 13, so that a stage's loads do not queue behind the
 // last one's store acknowledgements: 1.22 against 1.14 ms, 158 against 119 – 138 ms at n = 1e5.)
-constexpr int kRunItemWaves = kRunBlock / 64 - 1;
+constexpr int kRunItemWaves = kRunBlock / 64 - 1, kFlatRunMax = kRunItemWaves * 64;      // 15 wavefronts of items: stages of at most 960 records
+// (cx_api_ref.hip: flat_records) the first record of a group of one kind in a stage of at most 64 records, which are sorted by kind
+constexpr int kFlatGroupStart = 0x10000000;
 template <int MODE>
 __global__ __launch_bounds__(kRunBlock) void k_flat_run(const int64_t *__restrict__ stage_off, int s0, int s1, const int32_t *__restrict__ flat, const int32_t *__restrict__ rec,
                                                         const int32_t *__restrict__ vbase, const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
                                                         const int32_t *__restrict__ partner, const double *__restrict__ q, const double *__restrict__ pa,
                                                         const double *__restrict__ pb, double2 *f2v, double2 *v2f, double2 *marg, int nat_marg, double2 *prod, double *joint,
-                                                        const KaryTab kt) {
-    __shared__ int4 rb[2][kRunBlock][2];      // 64 KB: the records of this stage and of the next
+                                                        const KaryTab kt, int by_kind) {
+    __shared__ int4 rb[2][kFlatRunMax][2];      // 60 KB: the records of this stage and of the next, where their threads look for them
+    __shared__ int grouped_s[2];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool loader = wave == kRunItemWaves;
-    // item i of a stage goes to lane i / 15 of wavefront i mod 15: the few items of a thin stage are of different kinds, and one wavefront would
-    // take their branches — each a round of loads — one after the other
-    const int me = wave + kRunItemWaves * lane;
     const int4 *flat4 = (const int4 *)flat;
+    // WHERE a record goes decides who runs it: thread t takes the record in slot t.  A stage of at most 64 records, sorted by kind when the plan
+    // was made: one wavefront per kind (a wavefront takes the branches of its lanes one after the other — a round of loads each — and every
+    // wavefront that loads at all costs its load instructions: tools/lab/wg_handoff.hip), a pair's follower next to its leader.  Any other
+    // stage: record j in lane j / 15 of wavefront j mod 15.
+    auto place = [&](int p, int64_t from, int64_t W) {
+        const int4 zero = make_int4(0, 0, 0, 0);
+        for (int c = 0; c < kRunItemWaves; c++) rb[p][c * 64 + lane][0] = zero;      // (kind 0: nothing to do)
+        if (W <= 64) {
+            int4 a = zero, b = zero;
+            if (lane < W) { a = flat4[2 * (from + lane)]; b = flat4[2 * (from + lane) + 1]; }
+            const unsigned long long starts = __ballot(lane < W && (a.x & kFlatGroupStart));
+            const bool ok = by_kind && (starts & 1ull) && __popcll(starts) <= kRunItemWaves;
+            int slot = (lane % kRunItemWaves) * 64 + lane / kRunItemWaves;
+            if (ok) {
+                const unsigned long long below = starts & ((2ull << lane) - 1ull);
+                slot = (__popcll(below) - 1) * 64 + (lane - (63 - __clzll((long long)below)));
+            }
+            if (lane < W) { rb[p][slot][0] = a; rb[p][slot][1] = b; }
+            if (lane == 0) grouped_s[p] = ok ? 1 : 0;
+        } else {
+            for (int64_t j = lane; j < W; j += 64) {
+                const int slot = (int)(j % kRunItemWaves) * 64 + (int)(j / kRunItemWaves);
+                rb[p][slot][0] = flat4[2 * (from + j)]; rb[p][slot][1] = flat4[2 * (from + j) + 1];
+            }
+            if (lane == 0) grouped_s[p] = 0;
+        }
+    };
     int64_t lo = stage_off[s0], hi = stage_off[s0 + 1], nhi = s0 + 2 <= s1 ? stage_off[s0 + 2] : hi;
-    if (loader)
-        for (int64_t i = lane; i < hi - lo; i += 64) { rb[0][i][0] = flat4[2 * (lo + i)]; rb[0][i][1] = flat4[2 * (lo + i) + 1]; }
+    if (loader) place(0, lo, hi - lo);
     __syncthreads();
-    auto record = [&](int p, int64_t i) {
-        const int4 a = rb[p][i][0], b = rb[p][i][1];
+    auto record = [&](int p, int slot) {
+        const int4 a = rb[p][slot][0], b = rb[p][slot][1];
         FlatRec r;
         r.k = a.x; r.dst = a.y; r.v = a.z; r.s[0] = a.w; r.s[1] = b.x; r.s[2] = b.y; r.s[3] = b.z; r.s[4] = b.w;
         return r;
     };
     for (int st = s0; st < s1; st++) {
         const int p = (st - s0) & 1;
-        const int64_t nlo = hi, nnhi = st + 3 <= s1 ? stage_off[st + 3] : nhi, W = hi - lo;
+        const int64_t nlo = hi, nnhi = st + 3 <= s1 ? stage_off[st + 3] : nhi;
         if (loader) {
-            if (st + 1 < s1)
-                for (int64_t i = lane; i < nhi - nlo; i += 64) { rb[p ^ 1][i][0] = flat4[2 * (nlo + i)]; rb[p ^ 1][i][1] = flat4[2 * (nlo + i) + 1]; }
+            if (st + 1 < s1) place(p ^ 1, nlo, nhi - nlo);
         } else {
-            for (int64_t i = me; i < W; i += kRunItemWaves * 64) {
-                const FlatRec cur = record(p, i);
-                if (cur.k & kRecFollows) continue;
-                if (cur.k & kRecLeads) flat_pair<MODE>(cur, record(p, i + 1), rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, true);
-                else flat_item<MODE>(cur, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
+            const FlatRec cur = record(p, threadIdx.x);
+            if ((cur.k & 0x7f) && !(cur.k & kRecFollows)) {
+                if (cur.k & kRecLeads) {
+                    // the follower: the next slot of the same wavefront (sorted by kind), or record j + 1 of the dealt order
+                    const int j1 = lane * kRunItemWaves + wave + 1;
+                    const int fs = grouped_s[p] ? (int)threadIdx.x + 1 : (j1 % kRunItemWaves) * 64 + j1 / kRunItemWaves;
+                    flat_pair<MODE>(cur, record(p, fs), rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, true);
+                } else flat_item<MODE>(cur, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -604,6 +632,8 @@ __global__ __launch_bounds__(kRunBlock) void k_flat_run(const int64_t *__restric
         lo = nlo; hi = nhi; nhi = nnhi;
     }
 }
+
+int flat_run_max() { return kFlatRunMax; }
 
 // A list item of thousands of sources (cx_refsched.h: kWideList — the flat product a mean-field wiring makes of a precision's marginal):
 // a strided partial sum per thread, the partials folded in a fixed tree (wavefront shuffles, then shared memory), the workgroups' partials
@@ -704,10 +734,11 @@ void launch_batch_run(cx_handle *h, const int32_t *d_rec, const int64_t *d_stage
 // the same run on the plan's flat records (cx_api_ref.hip: flat_records)
 void launch_flat_run(cx_handle *h, const int32_t *d_flat, const int32_t *d_rec, const int64_t *d_stage_off, int s0, int s1) {
     if (s1 <= s0) return;
+    static const int by_kind = [] { const char *e = std::getenv("CX_FLAT_RUN_BY_KIND"); return e && e[0] == '0' ? 0 : 1; }();      // (A/B: 0 = every stage dealt)
     const int mode = rule_mode(h), nat = h->cfg.family == CX_FAMILY_NATURAL2 ? 1 : 0;
     const KaryTab kt{h->d_kary_slot, h->d_kary_coef, h->d_kary_qb, h->d_ref_list};
 #define CX_B(M, PA, PB) hipLaunchKernelGGL(k_flat_run<M>, dim3(1), dim3(kRunBlock), 0, h->stream, d_stage_off, s0, s1, d_flat, d_rec, h->d_vbase, h->d_var_deg, h->d_vinfo, \
-                                           h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint, kt)
+                                           h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint, kt, by_kind)
     if (mode == kRuleLinear) CX_B(kRuleLinear, h->d_a, h->d_b);
     else if (mode == kRuleBernoulli) CX_B(kRuleBernoulli, (const double *)nullptr, (const double *)nullptr);
     else CX_B(kRuleAdditive, (const double *)nullptr, (const double *)nullptr);

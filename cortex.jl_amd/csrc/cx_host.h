@@ -171,7 +171,7 @@ void ref_on_batch(cx_handle *h, const cx_item *items, int64_t n);
 // the XCD-resident cluster (cx_api_ref.hip)
 bool cluster_prepare(cx_handle *h);                                        // control block + compute-unit count + environment switches; false: use launches
 bool cluster_fits(const cx_handle *h, const std::vector<int64_t> &stage_off, int64_t n_stages);      // wide and deep enough, arrays below 2 GiB
-void flat_records(const cx_handle *h, const std::vector<int32_t> &rec, const std::vector<int32_t> &list, std::vector<int32_t> &flat);
+void flat_records(const cx_handle *h, const std::vector<int32_t> &rec, const std::vector<int32_t> &list, const std::vector<int64_t> &stage_off, std::vector<int32_t> &flat);
 // stages [0, n_stages) of a plan (host copy of the offsets: stage_off) — runs of stages on the cluster, stages wider than the chip as launches;
 // synchronous; *launches (may be NULL) counts them.  An error: a barrier timed out, the plan ran in part
 int32_t cluster_run(cx_handle *h, const int32_t *d_flat, const int32_t *d_rec, const int64_t *d_stage_off, const std::vector<int64_t> &stage_off, int64_t n_stages, int64_t *launches);

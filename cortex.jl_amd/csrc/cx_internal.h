@@ -275,7 +275,8 @@ void launch_push_slots(cx_handle *h, const int32_t *d_slots, int64_t n, double2 
 void launch_halo_export(cx_handle *h, const double2 *f2v, hipStream_t stream);
 void launch_halo_import(cx_handle *h, double2 *f2v_out, bool push);
 void launch_batch(cx_handle *h, const int32_t *d_rec, int64_t n);
-void launch_flat_run(cx_handle *h, const int32_t *d_flat, const int32_t *d_rec, const int64_t *d_stage_off, int s0, int s1);   // launch_batch_run on flat records
+void launch_flat_run(cx_handle *h, const int32_t *d_flat, const int32_t *d_rec, const int64_t *d_stage_off, int s0, int s1);
+int flat_run_max();      // stages of at most this many records   // launch_batch_run on flat records
 void launch_ref_cluster(cx_handle *h, void *d_ctl, int n_workgroups, const int32_t *d_flat, const int32_t *d_rec, const int64_t *d_stage_off, int n_stages);   // all stages behind single-XCD barriers; ctl[4] != 0 afterwards: a wait timed out
 void launch_wide_sum(cx_handle *h, const int32_t *d_rec, int64_t n, void *d_partial);   // reference plans: list items of more than cx::refsched::kWideList sources, a workgroup each
 void launch_batch_run(cx_handle *h, const int32_t *d_rec, const int64_t *d_stage_off, int s0, int s1);   // consecutive thin stages (<= 1024 items each) in one launch
