@@ -200,16 +200,17 @@ void flat_records(const cx_handle *h, const std::vector<int32_t> &rec, const std
         for (int64_t t = 0; t < n_threads; t++) pool.emplace_back(work, n * t / n_threads, n * (t + 1) / n_threads);
         for (auto &th : pool) th.join();
     }
-    // A stage of at most 64 records (a chain's, a small graph's): its units — a record, or a leader and its follower — sorted by kind, the
-    // first record of every kind flagged (cx_batch.hip: kFlatGroupStart; k_flat_run gives each kind a wavefront of its own).  The order of
-    // the items of a stage is free: they are independent.
+    // A stage that a run of one workgroup can take (cx_batch.hip: k_flat_run, at most 960 records): its units — a record, or a leader and its
+    // follower — sorted by kind, the first record of every kind flagged (kFlatGroupStart: with at most 64 records each kind gets a wavefront
+    // of its own; with more, a wavefront takes a consecutive run of them, mostly of one kind).  The order of the items of a stage is free:
+    // they are independent.
     constexpr int32_t kGroupStart = 0x10000000;
     struct Unit { uint64_t key; int32_t first, count; };
     std::vector<Unit> units;
     std::vector<int32_t> tmp;
     for (size_t st = 0; st + 1 < stage_off.size(); st++) {
         const int64_t lo = stage_off[st], W = stage_off[st + 1] - lo;
-        if (W < 2 || W > 64) continue;
+        if (W < 2 || W > cx::flat_run_max()) continue;      // (group starts matter to the kernel up to 64 records; the order up to a run's widest stage)
         units.clear();
         for (int64_t i = 0; i < W;) {
             const int32_t *o = &flat[8 * (lo + i)];

@@ -574,10 +574,10 @@ __global__ __launch_bounds__(kRunBlock) void k_flat_run(const int64_t *__restric
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool loader = wave == kRunItemWaves;
     const int4 *flat4 = (const int4 *)flat;
-    // WHERE a record goes decides who runs it: thread t takes the record in slot t.  A stage of at most 64 records, sorted by kind when the plan
-    // was made: one wavefront per kind (a wavefront takes the branches of its lanes one after the other — a round of loads each — and every
-    // wavefront that loads at all costs its load instructions: tools/lab/wg_handoff.hip), a pair's follower next to its leader.  Any other
-    // stage: record j in lane j / 15 of wavefront j mod 15.
+    // WHERE a record goes decides who runs it: thread t takes the record in slot t.  The records of a stage are sorted by kind when the plan is
+    // made.  At most 64 of them: one wavefront per kind (a wavefront takes the branches of its lanes one after the other — a round of loads
+    // each — and every wavefront that loads at all costs its load instructions: tools/lab/wg_handoff.hip), a pair's follower next to its
+    // leader.  More: consecutive runs of ceil(W / 15) records, a run per wavefront (mostly of one kind, all fifteen busy).
     auto place = [&](int p, int64_t from, int64_t W) {
         const int4 zero = make_int4(0, 0, 0, 0);
         for (int c = 0; c < kRunItemWaves; c++) rb[p][c * 64 + lane][0] = zero;      // (kind 0: nothing to do)
@@ -586,19 +586,21 @@ __global__ __launch_bounds__(kRunBlock) void k_flat_run(const int64_t *__restric
             if (lane < W) { a = flat4[2 * (from + lane)]; b = flat4[2 * (from + lane) + 1]; }
             const unsigned long long starts = __ballot(lane < W && (a.x & kFlatGroupStart));
             const bool ok = by_kind && (starts & 1ull) && __popcll(starts) <= kRunItemWaves;
-            int slot = (lane % kRunItemWaves) * 64 + lane / kRunItemWaves;
+            const int c = by_kind ? (int)((W + kRunItemWaves - 1) / kRunItemWaves) : 0;      // (0: the old dealing, record j in lane j / 15 of wavefront j mod 15)
+            int slot = c ? (lane / c) * 64 + lane % c : (lane % kRunItemWaves) * 64 + lane / kRunItemWaves;
             if (ok) {
                 const unsigned long long below = starts & ((2ull << lane) - 1ull);
                 slot = (__popcll(below) - 1) * 64 + (lane - (63 - __clzll((long long)below)));
             }
             if (lane < W) { rb[p][slot][0] = a; rb[p][slot][1] = b; }
-            if (lane == 0) grouped_s[p] = ok ? 1 : 0;
+            if (lane == 0) grouped_s[p] = ok ? 1 : c << 1;
         } else {
+            const int c = by_kind ? (int)((W + kRunItemWaves - 1) / kRunItemWaves) : 0;
             for (int64_t j = lane; j < W; j += 64) {
-                const int slot = (int)(j % kRunItemWaves) * 64 + (int)(j / kRunItemWaves);
+                const int slot = c ? (int)(j / c) * 64 + (int)(j % c) : (int)(j % kRunItemWaves) * 64 + (int)(j / kRunItemWaves);
                 rb[p][slot][0] = flat4[2 * (from + j)]; rb[p][slot][1] = flat4[2 * (from + j) + 1];
             }
-            if (lane == 0) grouped_s[p] = 0;
+            if (lane == 0) grouped_s[p] = c << 1;
         }
     };
     int64_t lo = stage_off[s0], hi = stage_off[s0 + 1], nhi = s0 + 2 <= s1 ? stage_off[s0 + 2] : hi;
@@ -619,9 +621,10 @@ __global__ __launch_bounds__(kRunBlock) void k_flat_run(const int64_t *__restric
             const FlatRec cur = record(p, threadIdx.x);
             if ((cur.k & 0x7f) && !(cur.k & kRecFollows)) {
                 if (cur.k & kRecLeads) {
-                    // the follower: the next slot of the same wavefront (sorted by kind), or record j + 1 of the dealt order
-                    const int j1 = lane * kRunItemWaves + wave + 1;
-                    const int fs = grouped_s[p] ? (int)threadIdx.x + 1 : (j1 % kRunItemWaves) * 64 + j1 / kRunItemWaves;
+                    // the follower: the next slot of the same wavefront (a wavefront per kind), or where record j + 1 was put
+                    const int g = grouped_s[p], c = g >> 1;
+                    const int j1 = c ? wave * c + lane + 1 : lane * kRunItemWaves + wave + 1;
+                    const int fs = g == 1 ? (int)threadIdx.x + 1 : c ? (j1 / c) * 64 + j1 % c : (j1 % kRunItemWaves) * 64 + j1 / kRunItemWaves;
                     flat_pair<MODE>(cur, record(p, fs), rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt, true);
                 } else flat_item<MODE>(cur, rec, vbase, vdeg, vinfo, partner, q, pa, pb, f2v, v2f, marg, nat_marg, prod, joint, kt);
             }
