@@ -49,7 +49,7 @@ __device__ __forceinline__ void batch_item_mv(int kind, int idx, int v, int tab,
             if (b + j * st != idx) msg_add<D>(o, slot_load<D>(f2v, b + j * st));
         if (!__builtin_isnan(o.lam[0])) slot_store<D>(v2f, idx, o);
     } else if (kind == CX_ITEM_MESSAGE_TO_VARIABLE) {
-        const int p = partner[idx];
+        const int p = hi > 0 ? hi - 1 : partner[idx];       // (a reference-order plan's record names the sending slot: cx_refsched.h)
         if (p < 0) return;                                  // an opaque factor's message is the caller's to set
         const Msg<D> in = slot_load<D>(v2f, p);
         if (__builtin_isnan(in.lam[0])) return;

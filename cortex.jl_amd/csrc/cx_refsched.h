@@ -725,7 +725,7 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
             else if (rule == kRuleBP && !h->slot_kary.empty() && h->slot_kary[slot] >= 0) {
                 r[0] = 32; r[1] = h->slot_kary[slot];      // kItemKaryEntry (cx_kary_core.h; dim 2 .. 4: cx_kary_mv_core.h)
             }
-            else if (rule == kRuleBP && h->partner[slot] >= 0) { r[0] = CX_ITEM_MESSAGE_TO_VARIABLE; r[1] = slot; r[2] = v; if (mv) r[3] = h->spdir[h->partner[slot]]; }
+            else if (rule == kRuleBP && h->partner[slot] >= 0) { r[0] = CX_ITEM_MESSAGE_TO_VARIABLE; r[1] = slot; r[2] = v; if (mv) { r[3] = h->spdir[h->partner[slot]]; r[4] = h->partner[slot] + 1; } }      // (dim > 1: the rule table of the sending slot, and the sending slot itself + 1 — one look-up less on the chain)
             else return fail_(err, CX_ERR_UNSUPPORTED, "reference schedule: the message from factor " + std::to_string(h->edge_fac_id[e]) + " to variable " +
                                                            std::to_string(h->var_ids[v]) + " is pending, and the factor has no rule on the device for it "
                                                            "(an opaque factor of two or more variables: the reference's processor would raise, inference_engine.jl:358; "
