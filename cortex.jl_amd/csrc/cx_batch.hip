@@ -530,8 +530,16 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
         __syncthreads();
         if (timed) { const unsigned long long t = wall_clock64(); tk[2] += t - t0; t0 = t; }      // the workgroup's other wavefronts
         if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(&c->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok_s = cluster_wait(&c->arrive, (unsigned)((st + 1) * P), &c->abort_) ? 1u : 0u;
+            // the last to arrive writes a word on a line of its own and the others poll that word, not the counter the arrivals are still
+            // adding to (8.2 – 8.4 against 8.3 – 8.8 ms per call at C4, three pairs of runs; CX_REF_CLUSTER_RELEASE=0: everybody polls the counter)
+            if ((dry >> 27) & 1) {
+                const unsigned before = __hip_atomic_fetch_add(&c->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (before + 1u == (unsigned)((st + 1) * P)) { __hip_atomic_store(&c->pad3[0], (unsigned)(st + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok_s = 1u; }
+                else ok_s = cluster_wait(&c->pad3[0], (unsigned)(st + 1), &c->abort_) ? 1u : 0u;
+            } else {
+                __hip_atomic_fetch_add(&c->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok_s = cluster_wait(&c->arrive, (unsigned)((st + 1) * P), &c->abort_) ? 1u : 0u;
+            }
             if (rank_s == 0) __hip_atomic_store(&c->progress, (unsigned)(st + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (timed) { const unsigned long long t = wall_clock64(); tk[3] += t - t0; t0 = t; }      // the other workgroups
@@ -758,9 +766,10 @@ void launch_ref_cluster(cx_handle *h, void *d_ctl, int n_workgroups, const int32
     static const int dry = [] {
         const char *e = std::getenv("CX_REF_CLUSTER_DRY"), *hp = std::getenv("CX_REF_CLUSTER_HELP");
         const char *ah = std::getenv("CX_REF_CLUSTER_AHEAD"), *mb = std::getenv("CX_REF_CLUSTER_MEMBERS");      // A/B: stages the helpers run ahead, member workgroups
-        const char *fw = std::getenv("CX_REF_PAIR_FWD"), *tm = std::getenv("CX_REF_CLUSTER_TIME");      // 0: a follower always waits for its leader's store (A/B); 1: member 0's clock
+        const char *fw = std::getenv("CX_REF_PAIR_FWD"), *tm = std::getenv("CX_REF_CLUSTER_TIME");
+        const char *rl = std::getenv("CX_REF_CLUSTER_RELEASE");      // 0: a follower always waits for its leader's store (A/B); 1: member 0's clock
         return ((e && (e[0] == '1' || e[0] == '2')) ? 1 : 0) | ((hp ? std::max(0, std::min(3, std::atoi(hp))) : 3) << 1) | ((e && e[0] == '2') ? 8 : 0) | ((fw && fw[0] == '0') ? 16 : 0) | ((tm && tm[0] == '1') ? 32 : 0) |
-               ((ah ? std::max(0, std::min(255, std::atoi(ah))) : 0) << 8) | ((mb ? std::max(0, std::min(255, std::atoi(mb))) : 0) << 16);
+               ((ah ? std::max(0, std::min(255, std::atoi(ah))) : 0) << 8) | ((mb ? std::max(0, std::min(255, std::atoi(mb))) : 0) << 16) | ((rl && rl[0] == '0') ? 0 : (1 << 27));
     }();
 #define CX_B(M, PA, PB) hipLaunchKernelGGL(k_ref_cluster<M>, dim3(n_workgroups), dim3(kClusterBlock), 0, h->stream, (ClusterCtl *)d_ctl, (unsigned)n_workgroups, d_stage_off, n_stages, \
                                            d_flat, d_rec, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint, kt, dry)
