@@ -448,11 +448,11 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
     __syncthreads();
     if (!mine || !ok_s) return;
     // Roles.  A stage is rarely wider than a few thousand items, and what a member waits for most is memory it has never touched: the plan's
-    // records (hundreds of MB, read once) and values last written many stages ago.  So half of the cluster's workgroups are HELPERS: they
+    // records (hundreds of MB, read once) and values last written many stages ago.  So three eighths of the cluster's workgroups are HELPERS: they
     // take no part in the barriers and store nothing; helper j runs ahead of the members through the stages s = j (mod H), loads their
     // records (help >= 1) and the lines of their sources (help >= 2) — into the L2 the members read from — and never lets anybody wait.
     const int help = (dry >> 1) & 3, ahead_arg = (dry >> 8) & 0xff, members_arg = (dry >> 16) & 0xff;
-    const int64_t all = members_s, P = help && all >= 4 ? (members_arg && members_arg < all ? members_arg : all / 2) : all, H = all - P;
+    const int64_t all = members_s, P = help && all >= 4 ? (members_arg && members_arg < all ? members_arg : all * 5 / 8) : all, H = all - P;      // (20 of 32: 7.9 – 8.1 against 8.0 – 8.4 ms for 16 in four pairs of runs; 24 and more: the helpers fall behind)
     if ((int64_t)rank_s >= P) {
         const int64_t hj = (int64_t)rank_s - P;
         const int ahead = ahead_arg ? ahead_arg : (help >= 3 ? 10 : help >= 2 ? 4 : 12);      // stages: the L2 is 4 MB, a stage's sources up to 1 MB of lines, its records 32 B an item
