@@ -425,6 +425,29 @@ def config_parity(device: int = 0) -> dict:
                            "reference's own moment-form rules (test/inference_engine_tests.jl:385-432)",
                 "sample": f"{n}x{n} grid, {calls} consecutive calls with the priors re-set in between: the execution trace of the last call, every message of both directions and every marginal after every call"}
 
+    def tree_exact(dev, model):           # the tree schedule's one sweep against a sparse direct solve of the joint Gaussian, on a sample
+        ids = model.x_ids[:: max(len(model.x_ids) // 300, 1)]
+        _i, em, ev = exact.kary_posterior_sparse(model, ids)
+        marg = dev.get_marginals(ids)
+        return {"max_rel_err": max(_rel_err(marg[:, 0], em), _rel_err(marg[:, 1], ev)), "tolerance": 1e-9,
+                "checker": "oracle/exact.py: sparse LU of the joint precision (every mean; variances by unit-vector solves)",
+                "sample": f"{len(ids)} of {len(model.x_ids)} marginals, one sweep"}
+
+    def vmp_wired_check(xs, gm, model, iterations):
+        """the wired model's marginals after `iterations` by-class iterations against oracle/vmp.py run the same calls at the same size"""
+        from oracle import vmp
+        arr = vmp.StructuredVMP(model.data_y)
+        for _ in range(iterations):
+            for which in (["x"], ["ssnoise"], ["obsnoise"]):
+                arr.update(which)
+        # the wired handle reports states in moment form (mean, variance); the array form holds (mean, precision)
+        got = np.concatenate([xs[:, 0], 1.0 / xs[:, 1], gm[0], gm[1]])
+        want = np.concatenate([arr.xm, arr.xw, arr.ss, arr.obs])
+        err = float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-3)))
+        return {"max_rel_err": err, "tolerance": 1e-9, "checker": "oracle/vmp.py: the array form of the reference's update_marginals! on its structured variational SSM "
+                "(test/inference_engine_tests.jl:807-1147), pinned call by call against the restated engine",
+                "sample": f"n={len(xs)} states, {iterations} iterations by class, every state mean and precision and both Gamma marginals"}
+
     for key, fn in (("C3", lambda: flooding(4, 2000, 8, 0)), ("C5", c5_fixed_point), ("C4-reference", reference_order),
                     ("VMP structured", lambda: vmp_family("structured", L.FAMILY_VMP_STRUCTURED)),
                     ("VMP mean_field", lambda: vmp_family("mean_field", L.FAMILY_VMP_MEAN_FIELD))):
@@ -432,7 +455,7 @@ def config_parity(device: int = 0) -> dict:
             rows[key] = fn()
         except Exception as e:
             rows[key] = {"error": f"{type(e).__name__}: {e}"}
-    return {"hooks": {"C2": c2, "C3-scan": c3_scan, "C5-scan": c5_scan}, "standalone": rows}
+    return {"hooks": {"C2": c2, "C3-scan": c3_scan, "C5-scan": c5_scan, "tree": tree_exact, "VMP-wired": vmp_wired_check}, "standalone": rows}
 
 
 def other_configs(parity=None) -> list:
@@ -452,16 +475,16 @@ def other_configs(parity=None) -> list:
                      ("C5", lambda: bc.mv(64, 100_000, 12)), ("C5-scan", lambda: bc.mv64_scan(100_000, 8, check=hooks.get("C5-scan"))[0]),
                      ("VMP", lambda: bc.vmp()),
                      # the same structured model as a user wiring under the reference-order schedule (cx_graph_wire): replayed plans per call
-                     ("VMP-wired", lambda: bc.vmp_wired(100_000)),
+                     ("VMP-wired", lambda: bc.vmp_wired(100_000, check=hooks.get("VMP-wired"))),
                      # the headline graph under the reference's OWN order: one cx_sweep = one update_marginals! (sequential, newest values):
                      # stage count, ms per call, calls to the fixed point beside the fused schedule's sweeps
                      ("C4-reference", lambda: bc.reference_order(1415)),
                      # not a BASELINE config: the tree schedule (one sweep = the reference's one-call result on any forest), on a tree small
                      # enough to generate in a second
-                     ("tree", lambda: bc.tree(n_factors=30_000, steps=20)),
+                     ("tree", lambda: bc.tree(n_factors=30_000, steps=20, check=hooks.get("tree"))),
                      # the same schedule where the level-by-level form would take two launches per level: long paths with side branches and
                      # factors of 2..6 variables (scalar; heavy paths through factors of any arity), and a d = 4 chain with a latent layer
-                     ("tree-deep", lambda: bc.tree(n_factors=20_000, steps=20, shape="deep")),
+                     ("tree-deep", lambda: bc.tree(n_factors=20_000, steps=20, shape="deep", check=hooks.get("tree"))),
                      ("tree-mv", lambda: bc.tree_mv(d=4, n_spine=50_000))):
         try:
             r = fn()
@@ -507,7 +530,109 @@ def cpu_config_table(seed: int):
     for r in rows:
         print(json.dumps(r), flush=True)
 
+HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "details")
+HEADLINE_MAX_BYTES = 4096
 
+
+def _strict(x):
+    """JSON has no NaN / Infinity tokens: non-finite floats become null (a failed check keeps its `ok: false`), numpy scalars become
+    Python's, long floats are cut to 6 significant digits (the side file keeps them whole)"""
+    if isinstance(x, dict):
+        return {str(k): _strict(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_strict(v) for v in x]
+    if isinstance(x, (bool, np.bool_)):
+        return bool(x)
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        return float(f"{x:.6g}") if np.isfinite(x) else None
+    return x
+
+
+def headline_line(full: dict, details_path=None) -> str:
+    """The ONE line the driver reads: the contract's keys, `roofline`, `cpu_baseline`, `parity` and the path of the side file that
+    holds everything else (other configs, every timed region, the long notes).  Strict JSON, under 4 KB, whatever `full` holds."""
+    ro = full.get("roofline") or {}
+    cb = full.get("cpu_baseline")
+    pa = full.get("parity")
+    cfg = full.get("config") or {}
+    line = {k: full.get(k) for k in HEADLINE_KEYS[:12]}
+    line["config"] = {k: cfg[k] for k in ("workload", "schedule", "partition", "seed", "halo_depth") if k in cfg}
+    line["roofline"] = {k: ro.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "basis", "avg_kernel_ms",
+                                                 "payload_bytes_per_launch", "frac_payload", "survey_convention_bytes_per_launch",
+                                                 "frac_survey_convention") if k in ro}
+    if cb is not None:
+        line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+        fa = cb.get("flooding_all_cores")
+        if fa:
+            line["cpu_baseline"]["flooding_all_cores"] = {k: fa.get(k) for k in ("value", "cores")}
+    if pa is not None:
+        line["parity"] = {k: pa.get(k) for k in ("ok", "max_rel_err_marginals", "max_rel_err_messages", "tolerance", "sweeps", "sample", "checker") if k in pa}
+    oc = full.get("other_configs")
+    if oc:
+        # a digest only: config name, its time, its fraction, whether its check passed — the rows themselves are in the side file
+        line["other_configs_digest"] = [[r.get("config"), r.get("ms_per_sweep", r.get("ms_per_iteration", r.get("ms_per_call"))),
+                                         (r.get("roofline") or {}).get("frac"), (r.get("parity") or r.get("self_check") or {}).get("ok")]
+                                        if "error" not in r else [r.get("config"), "error"] for r in oc]
+    for k in ("weak_scaling", "halo_check"):
+        if k in full:
+            w = full[k]
+            line[k] = {kk: w.get(kk) for kk in ("value", "unit", "ms_per_step")} if isinstance(w, dict) else w
+    line["details"] = details_path
+    line = _strict(line)
+
+    def dump():
+        return json.dumps(line, allow_nan=False, separators=(",", ":"))
+
+    def clip(d, key, n):
+        if isinstance(d.get(key), str) and len(d[key]) > n:
+            d[key] = d[key][: n - 1] + "…"
+
+    text = dump()
+    if len(text.encode()) >= HEADLINE_MAX_BYTES:          # long free-text fields are the only thing that can grow: cut them, in this order
+        for d, key, n in ((line["config"], "schedule", 200), (line.get("parity") or {}, "checker", 120), (line.get("cpu_baseline") or {}, "sample", 160),
+                          (line["config"], "workload", 240), (line["roofline"], "basis", 120), (line.get("parity") or {}, "sample", 100)):
+            clip(d, key, n)
+            text = dump()
+            if len(text.encode()) < HEADLINE_MAX_BYTES:
+                break
+    if len(text.encode()) >= HEADLINE_MAX_BYTES:
+        line.pop("other_configs_digest", None)
+        text = dump()
+    assert len(text.encode()) < HEADLINE_MAX_BYTES, len(text.encode())
+    return text
+
+
+def write_details(full: dict, world: int) -> str:
+    """everything measured in this run, whole: gpurun_out/bench_details_n<N>.json (relative path returned), and on stderr"""
+    rel = os.path.join("gpurun_out", f"bench_details_n{world}.json")
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, rel), "w") as f:
+            json.dump(_strict_keep(full), f, indent=1)
+    except OSError as e:                                  # a read-only checkout must not cost the headline
+        print(f"[bench] could not write {rel}: {e}", file=sys.stderr)
+        rel = None
+    print("[bench] details: " + json.dumps(_strict_keep(full)), file=sys.stderr, flush=True)
+    return rel
+
+
+def _strict_keep(x):
+    """as _strict, floats kept whole"""
+    if isinstance(x, dict):
+        return {str(k): _strict_keep(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_strict_keep(v) for v in x]
+    if isinstance(x, (bool, np.bool_)):
+        return bool(x)
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    if isinstance(x, (float, np.floating)):
+        return float(x) if np.isfinite(x) else None
+    return x
 
 
 def _watchdog(seconds: float):
@@ -911,7 +1036,12 @@ def run_rank(args):
             except Exception:
                 pass
         achieved_alg = alg_bytes / (avg_ms * 1e-3) / 1e9
-        achieved = (traffic / (avg_ms * 1e-3) / 1e9) if traffic else achieved_alg
+        # payload: stored factor→variable messages read (one per edge), those written (one per directed pairwise update pair) and the
+        # marginals, 16 B each — x steps per launch for the two-sweep kernel; the flooding schedule also stores variable→factor messages
+        payload_bytes = 16.0 * (st["n_edges"] + w.local_updates_per_step / 2 + st["n_variables"]) * max(steps_per_launch, 1.0)
+        if args.schedule != "fused" or args.materialize:
+            payload_bytes = 16.0 * (st["n_edges"] + w.local_updates_per_step + st["n_variables"]) * steps_per_launch
+        achieved = (traffic / (avg_ms * 1e-3) / 1e9) if traffic else payload_bytes / (avg_ms * 1e-3) / 1e9
         strong = args.scaling == "strong"
         out = {
             "metric": "edge-message updates/sec per sweep, 10M-edge Gaussian grid",
@@ -938,16 +1068,18 @@ def run_rank(args):
                          # 6.29 TB/s a pure HBM copy reaches; `frac` prices it against the 8 TB/s spec, `frac_of_measured_copy` against that copy
                          "bound_detail": "L2-fabric traffic incl. Infinity-Cache hits (memory system, not HBM alone)",
                          "frac_of_measured_copy": achieved / HBM_COPY_GBS, "measured_copy_peak": HBM_COPY_GBS,
-                         "basis": ("counter traffic (FETCH_SIZE x2 + WRITE_SIZE at the L2-fabric side, Infinity-Cache hits included) / avg launch duration"
-                                   if traffic else "algorithmic bytes / avg launch duration (no counter traffic on file for this kernel)"),
+                         "basis": ("counter bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/) / avg launch duration (events on the library's stream)"
+                                   if traffic else "payload bytes / avg launch duration (no counter traffic on file for this kernel)"),
                          "traffic_source": traffic_src,
                          "avg_kernel_ms": avg_ms,
                          "avg_kernel_basis": "device time of the median timed region (events on the library's stream) / launches",
                          "sampled_kernel_ms": sampled_ms, "sampled_launches": dom_n,
-                         "algorithmic_bytes_per_launch": alg_bytes, "achieved_algorithmic": achieved_alg,
-                         "frac_algorithmic": achieved_alg / HBM_PEAK_GBS,
-                         "frac_algorithmic_note": "SURVEY §8d convention (32 B per directed update); the fused kernel never stores "
-                                                  "variable→factor messages, so it moves fewer bytes than this convention counts",
+                         # what the fused schedule MUST move per launch: every stored message read once (16 B), every message out of a
+                         # pairwise factor and every marginal written once; index and parameter arrays are not payload
+                         "payload_bytes_per_launch": payload_bytes, "frac_payload": payload_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         # SURVEY §8d's convention (32 B per directed update: payload read + written, variable→factor messages included);
+                         # the fused kernel keeps those in registers, so this convention counts bytes that never move and can exceed 1
+                         "survey_convention_bytes_per_launch": alg_bytes, "frac_survey_convention": achieved_alg / HBM_PEAK_GBS,
                          "all_kernels_sampled_ms": {k: v[0] / v[1] for k, v in kern.items()}},
             # computed inside the same kernel, not counted in `value`; a two-sweep launch writes them once (its second sweep's)
             "marginals_per_s": total_variables * args.steps / elapsed / (2.0 if dom_id == L.KERNEL_TILED else 1.0),
@@ -963,7 +1095,9 @@ def run_rank(args):
         if world == 1 and not args.no_other_configs and not args.self_halo:
             w.close()                                  # free the headline grid before the other configs allocate theirs
             out["other_configs"] = other_configs(config_parity(local_rank) if not args.no_cpu_baseline else None)
-        print(json.dumps(out), flush=True)
+        # ONE compact line on stdout, printed last; everything else to the side file and to stderr
+        sys.stderr.flush()
+        print(headline_line(out, write_details(out, world)), flush=True)
     dog.cancel()
     if dist is not None:
         dist.barrier()

@@ -186,3 +186,56 @@ def lgssm_posterior_longdouble(y, A, Q, R):
         X = _ld_solve(P, np.concatenate([I, (hl[t] + hr[t] - h[t])[:, None]], axis=1))
         cov[t] = X[:, :d].astype(np.float64); mean[t] = X[:, d].astype(np.float64)
     return mean, cov
+
+
+def kary_posterior_sparse(model, sample_ids=None):
+    """Exact posterior of a synth.kary_model / synth.tree_model (linear-Gaussian factors x_out = sum_i a_i x_i + b + N(0, q) of any
+    arity, unary priors, point-mass data) at sizes a dense inverse does not reach: the joint precision J = sum of prior precisions +
+    sum_f c_f c_f' / q_f assembled sparse (observed variables conditioned on their data), one sparse LU, the mean of every free
+    variable and the variance of `sample_ids` (default: all) from one solve per sampled unit vector.  Returns (ids, mean, variance)
+    over the sample.  Same mathematics as tests/kary_support.dense_posterior, which pins it on small models."""
+    import scipy.sparse as sp
+    from scipy.sparse.linalg import splu
+
+    meta = model.meta
+    used = np.asarray(meta["used"], dtype=np.int64)
+    obs = {int(v): float(y) for v, y in zip(model.data_var, model.data_y)}
+    is_obs = np.zeros(int(used.max()) + 2, dtype=bool)
+    if obs:
+        is_obs[np.fromiter(obs.keys(), dtype=np.int64)] = True
+    free = used[~is_obs[used]]
+    pos = np.full(int(used.max()) + 2, -1, dtype=np.int64)
+    pos[free] = np.arange(len(free))
+    n = len(free)
+    rows, cols, vals = [pos[np.asarray(model.prior_var)]], [pos[np.asarray(model.prior_var)]], [1.0 / np.asarray(model.prior_variance)]
+    h = np.zeros(n)
+    np.add.at(h, pos[np.asarray(model.prior_var)], np.asarray(model.prior_mean) / np.asarray(model.prior_variance))
+    cv, cf, ca = (meta["all_coef_var"], meta["all_coef_fac"], meta["all_coef"]) if "all_coef" in meta else (meta["coef_var"], meta["coef_fac"], meta["coef"])
+    coef = {(int(v), int(f)): float(a) for v, f, a in zip(cv, cf, ca)}
+    r_, c_, v_ = [], [], []
+    for fi, fid in enumerate(meta["kary_ids"]):
+        vs = meta["fac_vars"][fi]
+        out = int(meta["out_var"][fi])
+        c = {v: (1.0 if v == out else -coef[(v, int(fid))]) for v in vs}
+        b, q = float(meta["b"][fi]), float(meta["q"][fi])
+        rhs = b - sum(c[v] * obs[v] for v in vs if v in obs)
+        fv = [v for v in vs if v not in obs]
+        for a in fv:
+            h[pos[a]] += c[a] * rhs / q
+            for bb in fv:
+                r_.append(pos[a]); c_.append(pos[bb]); v_.append(c[a] * c[bb] / q)
+    rows.append(np.asarray(r_, dtype=np.int64)); cols.append(np.asarray(c_, dtype=np.int64)); vals.append(np.asarray(v_))
+    J = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsc()
+    lu = splu(J)
+    mean = lu.solve(h)
+    ids = free if sample_ids is None else np.asarray(sample_ids, dtype=np.int64)
+    p = pos[ids]
+    if np.any(p < 0):
+        raise ValueError("a sampled variable is observed or does not occur in the model")
+    var = np.empty(len(ids))
+    for lo in range(0, len(ids), 256):                   # unit vectors in blocks: n x 256 doubles at a time
+        blk = p[lo:lo + 256]
+        E = np.zeros((n, len(blk)))
+        E[blk, np.arange(len(blk))] = 1.0
+        var[lo:lo + 256] = lu.solve(E)[blk, np.arange(len(blk))]
+    return ids, mean[p], var

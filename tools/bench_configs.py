@@ -103,7 +103,7 @@ def c2(check=None):
             # two launches at their fixed cost: the sweep is LAUNCH-LATENCY bound, far from the HBM roofline it is priced against
             "roofline": roofline("hbm", achieved, HBM_PEAK_GBS, "GB/s", tr[0] if tr else None, limited_by="launch latency (2 kernels per sweep)",
                                  basis="counter traffic of the sweep's kernels / sweep time" if tr else "algorithmic bytes / sweep time",
-                                 traffic_source=tr[1] if tr else None, algorithmic_bytes_per_sweep=alg, frac_algorithmic=alg / dt / 1e9 / HBM_PEAK_GBS),
+                                 traffic_source=tr[1] if tr else None, algorithmic_bytes_per_sweep=alg, frac_survey_convention=alg / dt / 1e9 / HBM_PEAK_GBS),
             "flooding": {"ms_per_sweep": dtf * 1e3, "updates_per_sweep": nf, "updates_per_s": nf / dtf, "algorithmic_GBps": nf * 32 / dtf / 1e9},
             **({"parity": parity} if parity else {})}
 
@@ -147,8 +147,8 @@ def mv(d, T, steps):
         out["roofline"] = roofline("hbm", achieved, HBM_PEAK_GBS, "GB/s", tr[0] if tr else None, kernel=f"k_sweep_mv<{d}>", avg_kernel_ms=kern_s * 1e3,
                                    basis="counter traffic / avg launch duration" if tr else "algorithmic bytes / avg launch duration",
                                    traffic_source=tr[1] if tr else None, algorithmic_bytes_per_launch=alg,
-                                   frac_algorithmic=alg / kern_s / 1e9 / HBM_PEAK_GBS,
-                                   frac_algorithmic_note="SURVEY §8d convention: 2 x 160 B per update over ALL directed updates; the kernel skips the constant "
+                                   frac_survey_convention=alg / kern_s / 1e9 / HBM_PEAK_GBS,
+                                   survey_convention_note="SURVEY §8d convention: 2 x 160 B per update over ALL directed updates; the kernel skips the constant "
                                                          "messages out of observed variables and stores packed-symmetric 112 B, so it moves fewer bytes")
     return out
 
@@ -208,7 +208,7 @@ def mv_scan(d, T, steps, ks=(None,), check=None):
                     "roofline": roofline("hbm", achieved, HBM_PEAK_GBS, "GB/s", tr[0] if tr else None, kernel="k_mvc_totals + k_mvc_apply + k_mvc_marg_out",
                                          basis="counter traffic of the sweep's three launches / sweep time" if tr else "algorithmic bytes / sweep time",
                                          traffic_source=tr[1] if tr else None, algorithmic_bytes_per_sweep=alg,
-                                         frac_algorithmic=alg / dt / 1e9 / HBM_PEAK_GBS),
+                                         frac_survey_convention=alg / dt / 1e9 / HBM_PEAK_GBS),
                     **({"parity": parity} if parity else {}), **({"marginals_on_demand": lazy} if lazy else {})})
     os.environ.pop("CX_MVC_K", None)
     return out
@@ -281,7 +281,7 @@ def vmp(n=1_000_000, only=None):
     return out
 
 
-def vmp_wired(n=100_000, iterations=3):
+def vmp_wired(n=100_000, iterations=3, check=None):
     """The structured variational model of the reference's tests as a WIRING (cx_graph_wire under CX_SCHED_REFERENCE: the resolver's
     add_dependency! calls as triples, the rules chosen by the dependency lists) next to the fused family handle that hard-wires the same
     model: per-call times of the replayed plans, what the host pays once, and the agreement of every marginal after `iterations` by-class
@@ -334,11 +334,13 @@ def vmp_wired(n=100_000, iterations=3):
             "host_once": {"triples_and_wiring_s": wire_s, "first_iterations_s": first_s, "plans_kept": st["plans"], "calls_that_ran_the_scheduler": st["misses"]},
             "fused_family_ms_per_iteration": dtf * 1e3,
             "roofline": {"bound": "hbm", "achieved": execs * 32 / (total_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                         "frac_algorithmic": execs * 32 / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "basis": "algorithmic bytes (32 B per execution, SURVEY §8d) / time of the three calls",
+                         "frac_survey_convention": execs * 32 / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "basis": "algorithmic bytes (32 B per execution, SURVEY §8d) / time of the three calls",
                          "frac_note": "the states' call is the reference's forward / backward chain: 2 n dependent stages inside one workgroup, a latency chain by construction; "
                                       "the precisions' calls are wide and shallow", "kernel": "k_batch_run / k_batch over the plan's stages"},
-            "parity": {"max_rel_err": err, "tolerance": 1e-9, "checker": "the fused family handle on the same device (cx_update_marginals; itself pinned call by call against the test suite's array form of the reference's calls and the "
-                       "restated engine), every state mean, state precision and both Gamma marginals", "sample": f"after {iterations} by-class iterations, n={n}"}}
+            # device against device: NOT parity (bench.py's hook adds the `parity` object: the CPU checker's array form at this size)
+            "self_check": {"max_rel_err": err, "tolerance": 1e-9, "ok": bool(err <= 1e-9), "checker": "the fused family handle on the same device (cx_update_marginals), every state mean, "
+                           "state precision and both Gamma marginals", "sample": f"after {iterations} by-class iterations, n={n}"},
+            **({"parity": check(xa, ga, model, iterations)} if check else {})}
 
 
 def vmp_traffic(family):
@@ -359,7 +361,7 @@ def vmp_traffic(family):
     return best
 
 
-def tree(n_factors=200_000, steps=20, shape="random"):
+def tree(n_factors=200_000, steps=20, shape="random", check=None):
     """the tree schedule (CX_SCHED_TREE): ONE sweep on a forest = the reference's one update_marginals! there, level by level.  Not a
     BASELINE config: a bushy tree with factors of 2..6 variables and ~10^6 edges, timed per exact sweep, beside the number of fused
     sweeps the fixed-point schedule needs for the same result on the same graph."""
@@ -386,12 +388,13 @@ def tree(n_factors=200_000, steps=20, shape="random"):
             "roofline": roofline("hbm", n_msgs * 32 / dt / 1e9, HBM_PEAK_GBS, "GB/s", None,
                                  kernel="k_chain_* scans of the heavy paths + k_batch item stages" if hp["launches"] else "k_batch, one launch per stage",
                                  basis="algorithmic bytes (32 B per message, SURVEY §8d) / sweep time",
-                                 frac_algorithmic=n_msgs * 32 / dt / 1e9 / HBM_PEAK_GBS,
-                                 frac_note="a latency-bound schedule: the fraction of HBM on algorithmic bytes is frac_algorithmic, no counter traffic was collected",
+                                 frac_survey_convention=n_msgs * 32 / dt / 1e9 / HBM_PEAK_GBS,
+                                 frac_note="a latency-bound schedule: the fraction of HBM on SURVEY §8d's byte convention is frac_survey_convention, no counter traffic was collected",
                                  bound_detail=f"not a bandwidth-bound schedule: {launches} dependent launches (≈ {dt / max(launches, 1) * 1e6:.1f} us "
                                               "each at this size): the time is the number of dependent launches x per-kernel time"),
-            "parity": {"max_rel_err_marginals": err, "ok": bool(err < 1e-9), "checker": "the fused schedule at its fixed point on the same device (the tree "
-                       "schedule against a dense solve: tests/test_gpu_tree.py)", "sample": f"{len(ids)} marginals"}}
+            "self_check": {"max_rel_err_marginals": err, "ok": bool(err < 1e-9), "checker": "the fused schedule at its fixed point on the same device",
+                           "sample": f"{len(ids)} marginals"},
+            **({"parity": check(dev, model)} if check else {})}
 
 
 def tree_mv(d=4, n_spine=200_000):
@@ -424,10 +427,11 @@ def tree_mv(d=4, n_spine=200_000):
             "ms_per_sweep": dt * 1e3, "plan": st, "heavy_paths": hp, "launches_per_sweep": hp["launches"] or st["stages"], "messages_per_sweep": n_msgs, "messages_per_s": n_msgs / dt,
             "level_schedule_on_a_tenth": {"ms_per_sweep": dtl * 1e3, "stages": lv.tree_plan_stats()["stages"]},
             "roofline": roofline("hbm", n_msgs * 2 * S / dt / 1e9, HBM_PEAK_GBS, "GB/s", None, kernel="k_mvc_* scans of the heavy paths + k_batch_mv item stages" if d <= 4 else "k_compose64p / k_walk64b plans of the heavy paths + k_rule64w item stages",
-                                 basis=f"algorithmic bytes ({2 * S} B per message, SURVEY §8d) / sweep time", frac_algorithmic=n_msgs * 2 * S / dt / 1e9 / HBM_PEAK_GBS,
-                                 frac_note="a latency-bound schedule: the fraction of HBM on algorithmic bytes is frac_algorithmic, no counter traffic was collected"),
-            "parity": {"max_rel_err_marginals": err, "ok": bool(err < 1e-8), "checker": "the level schedule on the same device, a tenth of the model (joint solves: tests/test_gpu_tree.py)",
-                       "sample": f"{len(ids)} marginals"}}
+                                 basis=f"algorithmic bytes ({2 * S} B per message, SURVEY §8d) / sweep time", frac_survey_convention=n_msgs * 2 * S / dt / 1e9 / HBM_PEAK_GBS,
+                                 frac_note="a latency-bound schedule: the fraction of HBM on SURVEY §8d's byte convention is frac_survey_convention, no counter traffic was collected"),
+            # device against device (the joint solves of this schedule: tests/test_gpu_tree.py); not a parity claim
+            "self_check": {"max_rel_err_marginals": err, "ok": bool(err < 1e-8), "checker": "the level schedule on the same device, a tenth of the model",
+                           "sample": f"{len(ids)} marginals"}}
 
 
 def reference_order(n=1415, calls_timed=5, tol=1e-9, max_calls=400, check=None, fixed_point=True):
@@ -465,7 +469,7 @@ def reference_order(n=1415, calls_timed=5, tol=1e-9, max_calls=400, check=None, 
            "roofline": roofline("hbm", st["messages"] * 32 / float(np.median(t_call)) / 1e9, HBM_PEAK_GBS, "GB/s", None,
                                 kernel="k_ref_cluster: the plan's stages behind single-XCD barriers in one launch (stages wider than 65,536 items: k_batch on the whole chip); "
                                        "CX_REF_CLUSTER=0: k_batch / k_batch_run, one launch per stage or run of thin stages",
-                                basis="algorithmic bytes (32 B per message, SURVEY §8d) / call time", frac_algorithmic=st["messages"] * 32 / float(np.median(t_call)) / 1e9 / HBM_PEAK_GBS,
+                                basis="algorithmic bytes (32 B per message, SURVEY §8d) / call time", frac_survey_convention=st["messages"] * 32 / float(np.median(t_call)) / 1e9 / HBM_PEAK_GBS,
                                 frac_note="a latency-bound schedule by construction: the reference's order is sequential, its dependency depth is the stage count",
                                 bound_detail=f"{st['stages']} dependent stages in {st['launches']} launches (≈ {float(np.median(t_call)) / max(st['stages'], 1) * 1e6:.2f} us per stage)")}
     if parity:
