@@ -51,8 +51,6 @@ def parse(argv=None):
                     help="per-launch hipEvent pairs in the extra, untimed sampling region (every n-th launch)")
     ap.add_argument("--grid", type=int, default=1415, help="N: the N x N grid (1415 -> 10,005,465 edges)")
     ap.add_argument("--schedule", choices=["flooding", "fused"], default=os.environ.get("CX_BENCH_SCHEDULE", "fused"))
-    ap.add_argument("--sweeps-per-launch", type=int, default=1, choices=[1, 2],
-                    help="2: the two-sweeps-per-launch experiment (cx_tiles.hip; bit-identical, measured slower: DESIGN.md §4c)")
     ap.add_argument("--materialize", action="store_true", help="also store every variable→factor message each sweep")
     ap.add_argument("--halo", choices=["ipc", "rccl", "torch"], default=os.environ.get("CX_HALO", "ipc"),
                     help="N > 1: the exchange pushed by the library into the neighbours' IPC-mapped receive areas (default; audited, "
@@ -661,7 +659,7 @@ class Workload:
         self.args, self.scaling, self.world, self.rank = args, scaling, world, rank
         schedule = L.SCHED_FUSED if args.schedule == "fused" else L.SCHED_FLOODING
         self.dev = dev = cx.DeviceGraph(device=local_rank, schedule=schedule, marginals_in_sweep=True,
-                                        materialize_messages_to_factor=args.materialize, sweeps_per_launch=args.sweeps_per_launch)
+                                        materialize_messages_to_factor=args.materialize)
         dev.set_stream(torch.cuda.current_stream().cuda_stream)
         self.halo_kind, self.halo_tensors, self.part, self.exchange, self.ipc = None, None, None, None, None
         red_dev = "cuda" if backend == "nccl" else "cpu"
@@ -956,7 +954,7 @@ def run_rank(args):
     dev.sync()
     dev.profile_enable(False)
     kern = {}
-    for k in (L.KERNEL_TILED, L.KERNEL_FUSED, L.KERNEL_VAR_TO_FACTOR, L.KERNEL_FACTOR_TO_VAR, L.KERNEL_HALO_BEGIN, L.KERNEL_HALO_END):
+    for k in (L.KERNEL_FUSED, L.KERNEL_VAR_TO_FACTOR, L.KERNEL_FACTOR_TO_VAR, L.KERNEL_HALO_BEGIN, L.KERNEL_HALO_END):
         ms, n = dev.profile_read(k)
         if n:
             kern[dev.kernel_name(k)] = (ms, n, k)
@@ -1005,9 +1003,8 @@ def run_rank(args):
             dom_name, (dom_ms, dom_n, dom_id) = max(kern.items(), key=lambda kv: kv[1][0])
         else:
             dom_name, (dom_ms, dom_n, dom_id) = "k_sweep<fused>", (0.0, 0, L.KERNEL_FUSED)
-        tiles = dev.tile_stats()
-        # launches per step: the two-sweep kernel covers two steps per launch; the flooding schedule needs two launches per step
-        steps_per_launch = 2.0 if dom_id == L.KERNEL_TILED else (1.0 if args.schedule == "fused" else 0.5)
+        # launches per step: the flooding schedule needs two launches per step
+        steps_per_launch = 1.0 if args.schedule == "fused" else 0.5
         # algorithmic bytes per launch: §8d's 32 B per directed message update x the updates one launch performs
         upd_per_launch = w.local_updates_per_step * steps_per_launch
         alg_bytes = upd_per_launch * BYTES_PER_UPDATE
@@ -1037,7 +1034,7 @@ def run_rank(args):
                 pass
         achieved_alg = alg_bytes / (avg_ms * 1e-3) / 1e9
         # payload: stored factor→variable messages read (one per edge), those written (one per directed pairwise update pair) and the
-        # marginals, 16 B each — x steps per launch for the two-sweep kernel; the flooding schedule also stores variable→factor messages
+        # marginals, 16 B each; the flooding schedule also stores variable→factor messages
         payload_bytes = 16.0 * (st["n_edges"] + w.local_updates_per_step / 2 + st["n_variables"]) * max(steps_per_launch, 1.0)
         if args.schedule != "fused" or args.materialize:
             payload_bytes = 16.0 * (st["n_edges"] + w.local_updates_per_step + st["n_variables"]) * steps_per_launch
@@ -1053,9 +1050,7 @@ def run_rank(args):
                                     f"C4 weak scaling: one {N}x{N} strip per GPU of a {N * world}x{N} grid; rank 0 holds") +
                                    f" {st['n_edges']} bipartite edges, {w.updates_per_step} owned directed message updates + "
                                    f"{w.owned_variables} marginals per sweep; whole job {int(total_updates_per_step)} updates per sweep",
-                       "schedule": args.schedule + (f", two sweeps per launch ({tiles['n_tiles']} tiles, {tiles['variables_loaded_per_owned']:.2f} variables "
-                                                    f"loaded per owned one, {tiles['lds_bytes_per_workgroup']} B LDS per workgroup; marginals written by the "
-                                                    f"second sweep of each launch)" if dom_id == L.KERNEL_TILED else "") +
+                       "schedule": args.schedule +
                                    ("" if w.halo_kind is None else f" + {w.halo_kind}"),
                        "partition": f"{world} row blocks", "seed": args.seed,
                        **({"halo_depth": args.halo_depth, "halo_depth_trials_ms_per_sweep": depth_trials} if depth_trials else {})},
@@ -1081,8 +1076,8 @@ def run_rank(args):
                          # the fused kernel keeps those in registers, so this convention counts bytes that never move and can exceed 1
                          "survey_convention_bytes_per_launch": alg_bytes, "frac_survey_convention": achieved_alg / HBM_PEAK_GBS,
                          "all_kernels_sampled_ms": {k: v[0] / v[1] for k, v in kern.items()}},
-            # computed inside the same kernel, not counted in `value`; a two-sweep launch writes them once (its second sweep's)
-            "marginals_per_s": total_variables * args.steps / elapsed / (2.0 if dom_id == L.KERNEL_TILED else 1.0),
+            # computed inside the same kernel, not counted in `value`
+            "marginals_per_s": total_variables * args.steps / elapsed,
             "max_message_change_over_run": res,
         }
         if halo_check is not None:

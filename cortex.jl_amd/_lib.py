@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CORTEX_HIP_LIB", os.path.join(HERE, "libcortex_hip.so"))  # override: A/B builds of the same ABI
 
 # mirrors of the #defines in include/cortex_hip.h
-ABI_VERSION = 3
+ABI_VERSION = 4
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NOT_FOUND, ERR_UNSUPPORTED, ERR_STATE, ERR_DEVICE, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY = (
     -1, -2, -3, -4, -5, -6, -7)
@@ -26,14 +26,14 @@ FAMILY_GAUSSIAN, FAMILY_NATURAL2, FAMILY_VMP_MEAN_FIELD, FAMILY_VMP_STRUCTURED =
 VMP_ALL_NORMAL, VMP_ALL_PRECISION = -1, -2
 WIRE_WEAK, WIRE_INTERMEDIATE, WIRE_NO_LISTEN, WIRE_DEFAULT_VARIABLE, WIRE_LINK = 1, 2, 4, 8, 16
 KERNEL_VAR_TO_FACTOR, KERNEL_FACTOR_TO_VAR, KERNEL_FUSED, KERNEL_BATCH, KERNEL_BIG_VAR = 0, 1, 2, 3, 4
-KERNEL_HALO_BEGIN, KERNEL_HALO_END, KERNEL_TILED = 5, 6, 7
+KERNEL_HALO_BEGIN, KERNEL_HALO_END = 5, 6
 KERNEL_COUNT = 8
 
 
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("dim", C.c_int32), ("schedule", C.c_int32),
                 ("compute_marginals_in_sweep", C.c_int32), ("materialize_messages_to_factor", C.c_int32),
-                ("family", C.c_int32), ("sweeps_per_launch", C.c_int32)]
+                ("family", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Item(C.Structure):
@@ -60,7 +60,6 @@ SIGNATURES = {
     "cx_graph_create": (_i32, [_vp, _i64, _pi64, _pi64, _pi32, _i64, _pi64, _pi32, _pd]),
     "cx_set_factor_matrices": (_i32, [_vp, _i64, _pd, _pd]),
     "cx_graph_stats": (_i32, [_vp, C.POINTER(Stats)]),
-    "cx_tile_stats": (_i32, [_vp, _pi64, _pd, _pi64]),
     "cx_set_factor_coefficients": (_i32, [_vp, _i64, _pi64, _pi64, _pd]),
     "cx_set_factor_edge_sets": (_i32, [_vp, _i64, _pi64, _pi64, _pi64]),
     "cx_edge_index": (_i32, [_vp, _i64, _pi64, _pi64, _pi64]),

@@ -14,12 +14,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcortex_hip.so")
 SOURCES = ["cx_api.hip", "cx_api_mv.hip", "cx_api_msg.hip", "cx_api_sweep.hip", "cx_api_halo.hip", "cx_api_ipc.hip", "cx_api_state.hip", "cx_api_ref.hip", "cx_health.hip", "cx_kernels.hip", "cx_batch.hip", "cx_kary.hip", "cx_kary_mv.hip", "cx_chain.hip", "cx_mv.hip", "cx_mvchain.hip", "cx_mv64chain.hip", "cx_mvbatch.hip", "cx_mv64.hip", "cx_mv64w.hip", "cx_comm.hip", "cx_vmp.hip"]
-# Two sweeps per launch (cx_tiles.hip: temporal blocking in LDS) is bit-identical and measured 1.8 - 2x SLOWER than two single sweeps
-# (HISTORY.md): kept as source and as a test, built only on request — CX_BUILD_TILED2=1 python -m cortex.jl_amd.build --force
-if os.environ.get("CX_BUILD_TILED2"):
-    SOURCES.append("cx_tiles.hip")
-# every header a source may include: a change in any of them rebuilds everything (cx_mv64w_core.h and cx_tiling.h were missing
-# from this list for a while — an edit there alone left the library as it was)
+# every header a source may include: a change in any of them rebuilds everything
 HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(ROOT, "include", "cortex_hip.h")]
 
 
@@ -74,8 +69,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     dbg = ["-gline-tables-only"] if os.environ.get("CX_BUILD_DEBUG") else []      # line numbers in host backtraces (rocgdb)
-    tiled = ["-DCX_WITH_TILED2=1"] if os.environ.get("CX_BUILD_TILED2") else []
-    flags = dbg + tiled + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+    flags = dbg + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-I/opt/rocm/include"]
     hdr_t = max(os.path.getmtime(h) for h in HEADERS)
 

@@ -33,9 +33,6 @@ void dev_free_all(cx_handle *h) {
     cx::chain64_free(h);
     cx::chain64_tree_free(h);
     cx::kary_free(h);
-    cx::tiles_free(h);
-    if (h->d_f2v_tmp) (void)hipFree(h->d_f2v_tmp);
-    h->d_f2v_tmp = nullptr; h->alt_two_back = false;
     if (h->d_prod) (void)hipFree(h->d_prod);
     if (h->d_joint) (void)hipFree(h->d_joint);
     h->d_prod = nullptr; h->d_joint = nullptr; h->prod_cap = h->joint_cap = 0; h->prod_index.clear(); h->joint_index.clear();
@@ -79,7 +76,6 @@ const char *cx_kernel_name(int32_t k) {
     case CX_KERNEL_BIG_VAR: return "k_big_var_to_factor";
     case CX_KERNEL_HALO_BEGIN: return "k_halo_export";
     case CX_KERNEL_HALO_END: return "k_halo_import";
-    case CX_KERNEL_TILED: return "k_sweep2<two sweeps per launch>";
     }
     return "";
 }
@@ -114,8 +110,8 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
     if (config->schedule == CX_SCHED_TREE && config->family == CX_FAMILY_VMP_MEAN_FIELD)
         return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: the mean-field family has no inner sweep to schedule (flooding, fused or chain-scan are accepted and ignored; "
                                                  "the tree schedule is the structured family's, for state variables that form a forest)");
-    if (config->sweeps_per_launch < 0 || config->sweeps_per_launch > 2)
-        return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: sweeps_per_launch must be 0 (automatic), 1 or 2");
+    if (config->reserved != 0 && config->reserved != 1)
+        return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: cx_config.reserved must be 0 (ABI 2 - 3 called it sweeps_per_launch; the two-sweep launch, measured slower, was removed in ABI 4)");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -350,13 +346,6 @@ int32_t cx_graph_stats(const cx_handle *h, cx_stats *out) {
 }
 
 // tiles of the two-sweep launches (built on the first cx_sweep(n >= 2) of a fused scalar handle)
-int32_t cx_tile_stats(const cx_handle *h, int64_t *n_tiles, double *variables_loaded_per_owned, int64_t *lds_bytes_per_workgroup) {
-    if (!h) return CX_ERR_INVALID_ARGUMENT;
-    if (n_tiles) *n_tiles = h->tiles_state > 0 ? h->n_tiles : 0;
-    if (variables_loaded_per_owned) *variables_loaded_per_owned = h->tiles_state > 0 ? h->tile_redundancy : 0.0;
-    if (lds_bytes_per_workgroup) *lds_bytes_per_workgroup = h->tiles_state > 0 ? h->tile_lds : 0;
-    return CX_OK;
-}
 
 int32_t cx_edge_index(const cx_handle *hc, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, int64_t *out_edge) {
     cx_handle *h = const_cast<cx_handle *>(hc);

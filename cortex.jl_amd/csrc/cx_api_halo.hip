@@ -36,7 +36,7 @@ int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const
         for (int32_t v : recv_vars) h->vinfo[v] |= cx::kGhost;
         h->halo_state = false;
         h->chains_dirty = true; h->tree_dirty = true;
-        CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
+        CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
         cx::ipc_destroy(h);          // the receive areas are sized by the halo lists
         for (void *p : {(void *)h->d_send_slots, (void *)h->d_recv_slots, (void *)h->d_send_vars}) if (p) (void)hipFree(p);
         if (!h->ext_halo_buffers) { if (h->d_send_buf) (void)hipFree(h->d_send_buf); if (h->d_recv_buf) (void)hipFree(h->d_recv_buf); }
@@ -82,7 +82,7 @@ int32_t cx_halo_configure_state(cx_handle *h, int64_t n_send, const int64_t *sv,
         if (rc != CX_OK) return rc;
         if (std::any_of(h->vinfo.begin(), h->vinfo.end(), [](uint8_t b) { return (b & cx::kGhost) != 0; })) {
             for (uint8_t &b : h->vinfo) b &= (uint8_t)~cx::kGhost;
-            CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
+            CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
         }
         cx::ipc_destroy(h);          // the receive areas are sized by the halo lists
         for (void *p : {(void *)h->d_send_slots, (void *)h->d_recv_slots, (void *)h->d_send_vars}) if (p) (void)hipFree(p);

@@ -389,7 +389,7 @@ int32_t cx_halo_ipc_exchange_sweep(cx_handle *h, int32_t n_sweeps) {
     CX_REQUIRE(h, h && h->has_graph && h->halo_state && h->d_ipc_block, CX_ERR_STATE, "cx_halo_ipc_exchange_sweep: call cx_halo_ipc_alloc first");
     CX_REQUIRE(h, n_sweeps >= 1, CX_ERR_INVALID_ARGUMENT, "cx_halo_ipc_exchange_sweep: n_sweeps < 1");
     const bool split = h->cfg.dim == 1 && h->cfg.schedule == CX_SCHED_FUSED && h->halo_depth > 0 && h->big_vars.empty() && h->n_kary == 0 && !h->peers.empty() &&
-                       h->own_slice_hi >= h->own_slice_lo && h->cfg.sweeps_per_launch != 2;
+                       h->own_slice_hi >= h->own_slice_lo;
     if (!split) {
         const int32_t rc = cx_halo_ipc_exchange(h);
         return rc != CX_OK ? rc : cx_sweep(h, n_sweeps);
@@ -407,7 +407,6 @@ int32_t cx_halo_ipc_exchange_sweep(cx_handle *h, int32_t n_sweeps) {
     sweep_main(h, false);
     h->run_excl_lo = 1; h->run_excl_hi = 0; h->run_slice0 = 0; h->run_nslices = 0;
     sweep_finish(h);
-    h->alt_two_back = false;
     h->sweeps_since_exchange = 1;
     CX_HIP(h, hipGetLastError());
     return n_sweeps > 1 ? cx_sweep(h, n_sweeps - 1) : CX_OK;
@@ -427,7 +426,7 @@ int32_t cx_halo_ipc_batch(cx_handle *h, int32_t n_sweeps) {
     CX_REQUIRE(h, h && h->has_graph && h->halo_state && h->d_ipc_block, CX_ERR_STATE, std::string(who) + ": call cx_halo_ipc_alloc first");
     CX_REQUIRE(h, n_sweeps >= 1, CX_ERR_INVALID_ARGUMENT, std::string(who) + ": n_sweeps < 1");
     const bool split = h->cfg.dim == 1 && h->cfg.schedule == CX_SCHED_FUSED && h->halo_depth > 0 && h->big_vars.empty() && h->n_kary == 0 && !h->peers.empty() &&
-                       h->own_slice_hi >= h->own_slice_lo && h->cfg.sweeps_per_launch != 2 && h->ipc_quiet_hi >= h->ipc_quiet_lo &&
+                       h->own_slice_hi >= h->own_slice_lo && h->ipc_quiet_hi >= h->ipc_quiet_lo &&
                        h->cfg.materialize_messages_to_factor == 0 && n_sweeps >= 2 && n_sweeps <= h->halo_depth;
     if (!split) return cx_halo_ipc_exchange_sweep(h, n_sweeps);
     int32_t rc;
@@ -448,7 +447,6 @@ int32_t cx_halo_ipc_batch(cx_handle *h, int32_t n_sweeps) {
     sweep_main(h, false);
     reset();
     sweep_finish(h);
-    h->alt_two_back = false;
     h->sweeps_since_exchange = 1;
     // ---- sweeps 2 .. n - 1 ---------------------------------------------------------------------------------------------------------
     if (n_sweeps > 2 && (rc = cx_sweep(h, n_sweeps - 2)) != CX_OK) return rc;
@@ -468,7 +466,6 @@ int32_t cx_halo_ipc_batch(cx_handle *h, int32_t n_sweeps) {
     sweep_main(h, false);
     reset();
     sweep_finish(h);
-    h->alt_two_back = false;
     h->sweeps_since_exchange++;
     CX_HIP(h, hipGetLastError());
     return CX_OK;

@@ -117,7 +117,7 @@ int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
                 if (newly) {
                     h->vinfo_epoch++;
                     h->chains_dirty = true; h->tree_dirty = true; h->offchain_marg_dirty = true;
-                    CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
+                    CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
                 }
             }
         } else {

@@ -89,7 +89,7 @@ int32_t mv64_set_messages(cx_handle *h, int64_t n, const std::vector<int32_t> &i
         for (int64_t i = 0; i < n; i++)
             if (!(h->vinfo[vars[i]] & cx::kClamped)) { h->vinfo[vars[i]] |= cx::kClamped; newly = true; }
         if (newly) {     // the work lists depend on WHICH variables are observed, not on their data
-            CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
+            CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
             h->work64_dirty = true;
             h->chains_dirty = true; h->tree_dirty = true;      // a newly observed variable leaves the chains
         }
@@ -151,7 +151,7 @@ int32_t mv_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
                 if (!(h->vinfo[vars[i]] & cx::kClamped)) { h->vinfo[vars[i]] |= cx::kClamped; newly = true; }
             if (newly) {
                 h->chains_dirty = true; h->tree_dirty = true;      // a newly observed variable leaves the chains
-                CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream)); h->tile_info_dirty = true;
+                CX_HIP(h, hipMemcpyAsync(h->d_vinfo, h->vinfo.data(), (size_t)h->nv, hipMemcpyHostToDevice, h->stream));
                 h->spdir_dirty = true;
             }
         }

@@ -113,7 +113,6 @@ int32_t cx_state_export(cx_handle *h, void *buf, int64_t bytes) {
     (void)cx_state_bytes(h, &need);
     CX_REQUIRE(h, buf && bytes >= need, CX_ERR_INVALID_ARGUMENT, "cx_state_export: buffer smaller than cx_state_bytes");
     CX_HIP(h, hipSetDevice(h->cfg.device));
-    { int32_t rc = normalize_alt(h); if (rc != CX_OK) return rc; }   // the blob holds the buffers of time n and n - 1
     if (h->cfg.dim > 1) { int32_t rc = mv_ensure_chain_msgs(h); if (rc != CX_OK) return rc; }
     CX_HIP(h, hipStreamSynchronize(h->stream));
     auto parts = state_parts(h);
@@ -183,7 +182,7 @@ int32_t cx_state_import(cx_handle *h, const void *buf, int64_t bytes) {
     h->sweeps_done = hd.sweeps_done;
     h->v2f_stale = (hd.v2f_stale & 1) != 0;
     h->offchain_marg_dirty = (hd.v2f_stale & 2) != 0;     // the marginals themselves travelled in section 5
-    h->alt_two_back = false; h->tile_info_dirty = true; h->chain_msgs_stale = false; h->mvc_marg_pending = false;     // (the imported marginals are final)
+    h->chain_msgs_stale = false; h->mvc_marg_pending = false;     // (the imported marginals are final)
     h->spdir_dirty = h->work64_dirty = h->point64_dirty = h->chains_dirty = true; h->tree_dirty = true;   // derived from the observed flags
     if (h->d_prev) { (void)hipFree(h->d_prev); h->d_prev = nullptr; }               // residual snapshots restart
     if (h->d_mv_prev) { (void)hipFree(h->d_mv_prev); h->d_mv_prev = nullptr; }

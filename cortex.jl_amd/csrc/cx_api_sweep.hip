@@ -11,27 +11,8 @@ namespace cxh {
 
 // In the fused schedule without materialisation the variable→factor messages of the last sweep exist only as
 // "leave-one-out of the sweep's input buffer", which is retained in d_f2v_alt: recompute them on demand.
-// After a two-sweep launch (cx_tiles.hip) the retained buffer d_f2v_alt holds time t while d_f2v holds t+2: the buffer of
-// time t+1 — the input of the last sweep, which is what variable→factor messages and checkpoints are defined from — never
-// existed.  Regenerate it with one plain sweep from time t into a third buffer and make that the retained buffer.
-int32_t normalize_alt(cx_handle *h) {
-    if (!h->alt_two_back) return CX_OK;
-    if (!h->d_f2v_tmp) { int32_t rc = dev_alloc(h, &h->d_f2v_tmp, h->nslots); if (rc != CX_OK) return rc; }
-    // slots no sweep writes (priors of unary factors, padding) are equal in every buffer: start from a copy
-    CX_HIP(h, hipMemcpyAsync(h->d_f2v_tmp, h->d_f2v_alt, (size_t)h->nslots * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
-    const bool prof = h->profiling;
-    h->profiling = false;
-    cx::launch_fused(h, h->d_f2v_alt, h->d_f2v_tmp, false, false, false);
-    h->profiling = prof;
-    CX_HIP(h, hipGetLastError());
-    std::swap(h->d_f2v_alt, h->d_f2v_tmp);
-    h->alt_two_back = false;
-    return CX_OK;
-}
-
 int32_t ensure_v2f(cx_handle *h) {
     if (!h->v2f_stale) return CX_OK;
-    { int32_t rc = normalize_alt(h); if (rc != CX_OK) return rc; }
     const double2 *src = h->d_f2v_alt ? h->d_f2v_alt : h->d_f2v;
     cx::launch_var_to_factor(h, src, false);
     cx::launch_big_var_to_factor(h, src, false);
@@ -451,24 +432,6 @@ void sweep_finish(cx_handle *h) {
 
 }  // namespace cxh
 
-#ifndef CX_WITH_TILED2
-// cx_tiles.hip is not part of the default build (two sweeps per launch: bit-identical, measured slower — HISTORY.md; built with
-// CX_BUILD_TILED2=1): cx_config.sweeps_per_launch = 2 then runs single sweeps, exactly as it does for a graph the tiler refuses
-namespace cx {
-bool tiles_build(cx_handle *, std::string &why) { why = "two sweeps per launch is not built into this library (CX_BUILD_TILED2)"; return false; }
-bool tiles_prepare_kernel(cx_handle *) { return false; }
-void tiles_free(cx_handle *) {}
-void launch_tiled2(cx_handle *, const double2 *, double2 *, bool) {}
-}  // namespace cx
-#endif
-
-// CX_TILED=0 in the environment turns the two-sweep launches off (A/B measurements)
-static bool tiled_env_enabled() {
-    static const int on = [] { const char *e = std::getenv("CX_TILED"); return (e && e[0] == '0') ? 0 : 1; }();
-    return on != 0;
-}
-
-
 // ---- chain-scan partitions: the composed maps of a time block -------------------------------------------
 // Host copy of cx_chain.hip's map algebra (projective-linear maps on (xi, w, 1), D normalised to 1)
 namespace {
@@ -597,25 +560,6 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
         return CX_OK;
     }
     int32_t s = 0;
-    // pairs of sweeps as ONE launch each (cx_tiles.hip), when the schedule and the graph allow it
-    // (opt-in: measured SLOWER than single sweeps on MI355X, see DESIGN.md §4c — kept as a tested experiment, not the default)
-    const bool want_pairs = n_sweeps >= 2 && h->cfg.schedule == CX_SCHED_FUSED && h->cfg.sweeps_per_launch == 2 &&
-                            h->cfg.family == CX_FAMILY_GAUSSIAN && h->cfg.materialize_messages_to_factor == 0 && h->n_kary == 0 && h->damping == 0.0 && tiled_env_enabled();
-    if (want_pairs && h->tiles_state == 0) {
-        std::string why;
-        if (!cx::tiles_build(h, why)) h->tiles_state = -1;
-        else if (!cx::tiles_prepare_kernel(h)) { cx::tiles_free(h); h->tiles_state = -1; }
-    }
-    if (want_pairs && h->tiles_state > 0) {
-        const bool marg = h->cfg.compute_marginals_in_sweep != 0;
-        for (; s + 2 <= n_sweeps; s += 2) {
-            cx::launch_tiled2(h, h->d_f2v, h->d_f2v_alt, marg);
-            std::swap(h->d_f2v, h->d_f2v_alt);     // d_f2v: time t+2; d_f2v_alt: time t
-            h->alt_two_back = true;
-            h->v2f_stale = true;
-            h->sweeps_done += 2;
-        }
-    }
     for (; s < n_sweeps; s++) {
         h->run_slice0 = 0; h->run_nslices = 0;
         if (h->halo_state && h->halo_depth > 0 && h->cfg.schedule == CX_SCHED_FUSED && h->big_vars.empty()) {
@@ -623,7 +567,7 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
             const int L = h->halo_depth - j + 1;                                       // layers that have to run
             if (h->trim_hi[L] >= h->trim_lo[L]) { h->run_slice0 = h->trim_lo[L]; h->run_nslices = h->trim_hi[L] - h->trim_lo[L] + 1; }
         }
-        sweep_main(h, false); sweep_finish(h); h->alt_two_back = false;
+        sweep_main(h, false); sweep_finish(h);
         h->run_slice0 = 0; h->run_nslices = 0;
         h->sweeps_since_exchange++;
     }

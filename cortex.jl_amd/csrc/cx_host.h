@@ -148,7 +148,6 @@ int32_t mv_chain_block_maps(cx_handle *h, double *fwd, double *bwd, double *side
 int32_t mv_ensure_marginals(cx_handle *h);    // chain scan, dim 2..4, marginals on demand: form them from the last sweep's alpha and gamma
 int32_t mv_ensure_chain_msgs(cx_handle *h);   // chain scan, dim 2..4: materialise the chain messages in d_mv_f2v (every reader of it calls this)
 // ---- cx_api_sweep.hip -----------------------------------------------------------------------------------------------
-int32_t normalize_alt(cx_handle *h);
 int32_t ensure_v2f(cx_handle *h);
 int32_t build_chains(cx_handle *h);
 int32_t build_tree(cx_handle *h);

@@ -221,16 +221,6 @@ struct cx_handle {
     double *d_mv_prod = nullptr;         // dim > 1: the ProductOfMessages table (natural form; dim 2..4 in the messages' pair form, dim 64 one row of 4,160 doubles each)
     int64_t mv_prod_cap = 0;             // entries it holds (a multiple of 256)
 
-    // two sweeps per launch (cx_tiles.hip): tile tables built once per graph
-    int tiles_state = 0;             // 0: not built yet, 1: ready, -1: this graph is outside the tiled kernel
-    void *d_tile_hdr = nullptr, *d_tile_recs = nullptr, *d_tile_pl = nullptr, *d_tile_var = nullptr, *d_tile_info = nullptr;
-    int32_t n_tiles = 0, tile_max_slots = 0, tile_pl_stride = 0, tile_max_deg = 8, tile_grid = 256;
-    int64_t n_tile_recs = 0;
-    bool tile_info_dirty = true;     // d_vinfo changed since the tiles' copy of the observed / stand-in flags was refreshed
-    int64_t tile_lds = 0;
-    double tile_redundancy = 0.0;    // (own + ring) variables loaded per own variable
-    bool alt_two_back = false;       // after a two-sweep launch d_f2v_alt holds time t, not t+1 (see normalize_alt in cx_api_sweep.hip)
-    double2 *d_f2v_tmp = nullptr;
 
     // the XCD-resident cluster (cx_batch.hip: k_ref_cluster; cx_api_ref.hip: cluster_prepare / cluster_run): stage plans of wide stages in ONE launch
     void *d_cluster_ctl = nullptr;   // 512 B the launch scribbles on (cx_batch.hip: ClusterCtl)
@@ -300,11 +290,6 @@ void launch_residual(cx_handle *h, const double2 *cur, const double2 *prev, int6
 void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_form, bool chain_v2f);
 void launch_chain_totals(cx_handle *h, double2 *f2v, bool fused_leaves, int64_t *ntiles_out);
 void launch_chain_scan_range(cx_handle *h, double2 *f2v, int64_t pos_lo, int64_t npos, int64_t link_lo, int64_t nlinks, const int32_t *skip1, bool final);
-// two sweeps per launch (cx_tiles.hip)
-bool tiles_build(cx_handle *h, std::string &why);
-bool tiles_prepare_kernel(cx_handle *h);
-void tiles_free(cx_handle *h);
-void launch_tiled2(cx_handle *h, const double2 *f2v_in, double2 *f2v_out, bool write_marg);
 // multivariate (cx_mv.hip)
 void mv_launch_sweep(cx_handle *h, bool write_marg, int only, double *f2v_out = nullptr);   // only: 0 regular, 1 observed variables, 2 other fixed senders (degree 1, stand-ins)
 void mv_launch_v2f(cx_handle *h, const int32_t *d_slots, const int32_t *d_vars, int64_t n, const double *f2v);

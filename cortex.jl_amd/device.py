@@ -26,11 +26,11 @@ def _p(a, ct):
 
 class DeviceGraph:
     def __init__(self, device: int = 0, dim: int = 1, schedule: int = L.SCHED_FUSED, marginals_in_sweep: bool = True,
-                 materialize_messages_to_factor: bool = False, family: int = L.FAMILY_GAUSSIAN, sweeps_per_launch: int = 0):
+                 materialize_messages_to_factor: bool = False, family: int = L.FAMILY_GAUSSIAN):
         self.lib = L.load()
         self._batch_raw = None
         cfg = L.Config(C.sizeof(L.Config), device, dim, schedule, int(marginals_in_sweep),      # True/1: every sweep; 2: on demand (chain scan, dim 2..4)
-                       int(materialize_messages_to_factor), int(family), int(sweeps_per_launch))
+                       int(materialize_messages_to_factor), int(family), 0)
         h = C.c_void_p()
         rc = self.lib.cx_create(C.byref(cfg), C.byref(h))
         if rc != L.OK:
@@ -93,11 +93,6 @@ class DeviceGraph:
         s = L.Stats()
         self._check(self.lib.cx_graph_stats(self.h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in L.Stats._fields_}
-
-    def tile_stats(self) -> dict:
-        n, r, b = C.c_int64(), C.c_double(), C.c_int64()
-        self._check(self.lib.cx_tile_stats(self.h, C.byref(n), C.byref(r), C.byref(b)))
-        return {"n_tiles": n.value, "variables_loaded_per_owned": r.value, "lds_bytes_per_workgroup": b.value}
 
     def tree_plan_stats(self):
         """cx_tree_plan_stats: the stages of the tree schedule's last sweep (zeros before it and for other schedules)"""

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CX_ABI_VERSION 3   /* 3: CX_SCHED_REFERENCE, cx_sweep_for, cx_ref_plan_stats, cx_ref_trace, cx_set_damping.  2: cx_config.reserved became sweeps_per_launch (validated), five new item / factor kinds, state blobs "CXSTATE2" */
+#define CX_ABI_VERSION 4   /* 4: cx_config.sweeps_per_launch -> reserved, cx_tile_stats and CX_KERNEL_TILED removed.  3: CX_SCHED_REFERENCE, cx_sweep_for, cx_ref_plan_stats, cx_ref_trace, cx_set_damping.  2: cx_config.reserved became sweeps_per_launch (validated), five new item / factor kinds, state blobs "CXSTATE2" */
 
 /* status codes */
 #define CX_OK 0
@@ -191,12 +191,8 @@ typedef struct cx_config {
                                                input buffer when cx_get_messages / cx_update_batch asks for them;
                                                1: every sweep also stores them */
     int32_t family;        /* CX_FAMILY_*: what a scalar (dim == 1) message's two numbers mean */
-    int32_t sweeps_per_launch; /* CX_SCHED_FUSED, dim == 1.  0 or 1: one launch per sweep (the default and the measured optimum).
-                                  2: cx_sweep(n >= 2) runs pairs of sweeps as ONE launch that keeps the intermediate time step in
-                                  LDS (cx_tiles.hip) — bit-identical results and half the launches, but on MI355X slower than two
-                                  single sweeps (the tiles' ring loads are 16-byte pieces of 128-byte lines): an
-                                  experiment kept under test, not a recommendation.  Graphs it cannot tile run single sweeps.  The
-                                  marginals of a two-sweep launch are those of its second sweep. */
+    int32_t reserved;      /* 0 (1 is accepted).  ABI 2 - 3: sweeps_per_launch — the two-sweeps-per-launch kernel (temporal blocking in
+                              LDS; bit-identical, measured 1.8 - 2x slower than two single sweeps, HISTORY.md) was removed in ABI 4 */
 } cx_config;
 
 typedef struct cx_item {
@@ -242,9 +238,6 @@ int32_t cx_set_factor_coefficients(cx_handle *h, int64_t n, const int64_t *varia
  * whose Q is the noise and whose A is every input's matrix; this call gives the CX_ROLE_IN edge (variable, factor) the A of another set. */
 int32_t cx_set_factor_edge_sets(cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids, const int64_t *parameter_sets);
 int32_t cx_graph_stats(const cx_handle *h, cx_stats *out);
-/* the tiles of the two-sweep launches (cx_config.sweeps_per_launch): how many, how many variables a tile loads per variable it
- * owns (its two-hop ring), LDS bytes per workgroup; all 0 while no tiles exist (not built yet, or the graph cannot be tiled) */
-int32_t cx_tile_stats(const cx_handle *h, int64_t *n_tiles, double *variables_loaded_per_owned, int64_t *lds_bytes_per_workgroup);
 /* position of Connection (variable_id, factor_id) in the flattened edge table (sorted by variable, factor) */
 int32_t cx_edge_index(const cx_handle *h, int64_t n, const int64_t *variable_ids, const int64_t *factor_ids,
                       int64_t *out_edge);
@@ -552,7 +545,7 @@ int32_t cx_state_import(cx_handle *h, const void *buf, int64_t bytes);  /* valid
 #define CX_KERNEL_BIG_VAR 4
 #define CX_KERNEL_HALO_BEGIN 5
 #define CX_KERNEL_HALO_END 6
-#define CX_KERNEL_TILED 7      /* two sweeps per launch (cx_config.sweeps_per_launch) */
+/* 7: unused since ABI 4 (was the two-sweeps-per-launch kernel) */
 #define CX_KERNEL_COUNT 8
 /* hipEvent pairs around kernel launches on the handle's stream: on == 1 every launch, on == n > 1 every n-th
  * launch of each kernel (events are barrier packets; a stride keeps the other launches back to back), 0 off */

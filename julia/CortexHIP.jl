@@ -12,7 +12,7 @@ const lib = "libcortex_hip.so"
 
 struct CxConfig            # mirrors cx_config
     struct_size::Int32; device::Int32; dim::Int32; schedule::Int32
-    compute_marginals_in_sweep::Int32; materialize_messages_to_factor::Int32; family::Int32; sweeps_per_launch::Int32
+    compute_marginals_in_sweep::Int32; materialize_messages_to_factor::Int32; family::Int32; reserved::Int32
 end
 struct CxItem              # mirrors cx_item
     kind::Int32; reserved::Int32; variable_id::Int64; factor_id::Int64
