@@ -21,6 +21,9 @@ int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const
     // not messages); every other dim > 1 partition uses state halos (cx_halo_configure_state)
     const bool mv_chain_block = ((h->cfg.dim >= 2 && h->cfg.dim <= 4) || h->cfg.dim == 64) && h->cfg.schedule == CX_SCHED_CHAIN_SCAN;
     CX_REQUIRE(h, h->cfg.dim == 1 || mv_chain_block, CX_ERR_UNSUPPORTED, "cx_halo_configure: message halos are implemented for dim == 1 (dim > 1: cx_halo_configure_state, or a chain-scan time block)");
+    // the same exclusion as cx_set_damping's, whichever call comes first (empty lists take a halo away and are always accepted)
+    CX_REQUIRE(h, h->damping == 0.0 || (n_send == 0 && n_recv == 0), CX_ERR_UNSUPPORTED,
+               "cx_halo_configure: per-sweep message halos are not damped (cx_set_damping is in force: set it to 0 first, or use state halos, cx_halo_configure_state)");
     CX_REQUIRE(h, n_send >= 0 && n_recv >= 0, CX_ERR_INVALID_ARGUMENT, "cx_halo_configure: negative count");
     CX_REQUIRE(h, (n_send == 0 || (sv && sf)) && (n_recv == 0 || (rv && rf)), CX_ERR_INVALID_ARGUMENT, "cx_halo_configure: null argument");
     try {

@@ -238,6 +238,11 @@ bool cluster_prepare(cx_handle *h) {
     if (const char *v = std::getenv("CX_REF_CLUSTER_MIN")) h->cluster_min_items = std::max<int64_t>(0, std::atoll(v));
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); return false; }
+    // the cluster rests on gfx942 / gfx950 specifics (XCC_ID in hwreg 20, s_waitcnt vmcnt(0) as a store acknowledgement, one L2 per XCD that serves sc1
+    // loads of plain stores): any other device keeps plain launches
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && std::strncmp(prop.gcnArchName, "gfx942", 6) != 0) return false;
     if (hipMalloc(&h->d_cluster_ctl, 512) != hipSuccess) { (void)hipGetLastError(); h->d_cluster_ctl = nullptr; return false; }
     h->cluster_cu = cus;
     h->cluster_state = 1;
@@ -278,20 +283,35 @@ int32_t cluster_run(cx_handle *h, const int32_t *d_flat, const int32_t *d_rec, c
     for (int64_t s = 0; s < ns;) {
         const int64_t w = stage_off[s + 1] - stage_off[s];
         if (launches) ++*launches;
-        if (w > h->cluster_max_items) { cx::launch_batch(h, d_rec + 5 * stage_off[s], w); s++; continue; }
+        // (cluster_state < 0: an earlier run of THIS call timed out and was finished on launches — so is the rest of the call)
+        if (w > h->cluster_max_items || h->cluster_state <= 0) { if (w > 0) cx::launch_batch(h, d_rec + 5 * stage_off[s], w); s++; continue; }
         int64_t t = s;
         while (t < ns && stage_off[t + 1] - stage_off[t] <= h->cluster_max_items) t++;
         cx::launch_ref_cluster(h, h->d_cluster_ctl, h->cluster_cu, d_flat, d_rec, d_stage_off + s, (int)(t - s));
-        // the members' waits are bounded; a call whose cluster gave up has computed part of its stages and cannot be repeated (the items
-        // overwrite their inputs' neighbours in place): it fails, loudly, and the handle goes back to plain launches
+        // The members' waits are bounded in time.  A run whose cluster gave up has computed its first stages and part of one more; the
+        // items of one stage never read each other's outputs (rs::level's invariant: a reader of a value and its next writer are in
+        // different stages), so a partly executed stage can be executed again, and a stage is complete exactly when all P members have
+        // arrived at its barrier (their stores acknowledged first): the run resumes at stage arrive / P as plain launches — from its
+        // first stage when the membership itself was never settled — and the handle stays with launches from then on.
         unsigned ctl[128] = {0};
         CX_HIP(h, hipGetLastError());
         CX_HIP(h, hipMemcpyAsync(ctl, h->d_cluster_ctl, sizeof(ctl), hipMemcpyDeviceToHost, h->stream));
         CX_HIP(h, hipStreamSynchronize(h->stream));
         if (ctl[4] || ctl[1] == 0) {
             h->cluster_state = -1;
-            return fail(h, CX_ERR_DEVICE, "a barrier of the XCD-resident cluster timed out (" + std::to_string(ctl[1]) + " member workgroups of " + std::to_string(ctl[0]) +
-                                          " registered); the call is incomplete — restore a checkpoint or set the messages again; further calls use plain launches");
+            h->cluster_recoveries++;
+            const int64_t P = ctl[7], done = P > 0 ? std::min<int64_t>((int64_t)ctl[3] / P, t - s) : 0;
+            h->cluster_note = "a barrier of the XCD-resident cluster timed out (" + std::to_string(ctl[1]) + " member workgroups of " + std::to_string(ctl[0]) + " registered, " +
+                              std::to_string(done) + " of " + std::to_string(t - s) + " stages complete); the call was finished on plain launches, as are all further calls of this handle";
+            if (std::getenv("CX_REF_CLUSTER_VERBOSE")) std::fprintf(stderr, "[cortex_hip] %s\n", h->cluster_note.c_str());
+            for (int64_t x = s + done; x < t; x++) {
+                const int64_t wx = stage_off[x + 1] - stage_off[x];
+                if (wx > 0) cx::launch_batch(h, d_rec + 5 * stage_off[x], wx);
+                if (launches) ++*launches;
+            }
+            CX_HIP(h, hipGetLastError());
+            s = t;
+            continue;
         }
         if (std::getenv("CX_REF_CLUSTER_TIME")) {      // member 0's clock (10 ns ticks): issue, memory, workgroup, cluster, release
             unsigned long long tk[5]; std::memcpy(tk, ctl + 64, sizeof(tk));
@@ -594,9 +614,19 @@ void ref_state_write(cx_handle *h, char *out) {
 bool ref_state_read(cx_handle *h, const char *in, int64_t bytes) {
     RefSched *R = ref_of(h);
     if (!R || bytes != ref_state_bytes(h)) return false;
-    auto T = std::make_shared<rs::State>(*R->S);
+    auto T = std::make_shared<rs::State>();
+    rs::init_state(R->W, *T);            // the static Intermediate / Weak bits are the WIRING's (add_dependency! kwargs), never the blob's
     std::memcpy(T->flags.data(), in + 8, T->flags.size());
-    std::memcpy(T->chunks.data(), in + 8 + T->flags.size(), 8 * T->chunks.size());
+    const char *cw = in + 8 + T->flags.size();
+    constexpr uint64_t kDynamic = rs::kAllComp | rs::kAllFresh, kStatic = ~kDynamic;
+    for (size_t c = 0; c < T->chunks.size(); c++) {
+        uint64_t w;
+        std::memcpy(&w, cw + 8 * c, 8);
+        // a blob of the right size written under ANOTHER wiring would change which dependencies count as weak: refuse it
+        if ((w & kStatic) != (T->chunks[c] & kStatic)) return false;
+        T->chunks[c] |= w & kDynamic;
+    }
+    R->touched = true;                   // the imported readiness is state: a later cx_graph_wire must not silently throw it away
     // the fingerprint is recomputed, not trusted
     T->hash = 0;
     for (int64_t c = 0; c < (int64_t)T->chunks.size(); c++) T->hash ^= rs::zob_chunk(c, T->chunks[c]);
@@ -707,7 +737,7 @@ int32_t cx_cluster_stats(const cx_handle *hc, int64_t *out4) {
     cx_handle *h = const_cast<cx_handle *>(hc);
     CX_REQUIRE(h, h && out4, CX_ERR_INVALID_ARGUMENT, "cx_cluster_stats: null argument");
     RefSched *R = ref_of(h);
-    out4[0] = h->cluster_state; out4[1] = h->cluster_cu; out4[2] = 0;
+    out4[0] = h->cluster_state; out4[1] = h->cluster_cu; out4[2] = h->cluster_recoveries;
     out4[3] = (R && R->last >= 0 && R->last < (int)R->cache.size() && R->cache[R->last].cluster && h->cluster_state > 0) ? 1 : 0;
     return CX_OK;
 }

@@ -257,16 +257,27 @@ __global__ __launch_bounds__(kRunBlock) void k_batch_run(const int64_t *__restri
 struct ClusterCtl { unsigned registered, members, rank_next, arrive, abort_, xcd_plus_1, pad[26]; unsigned progress, pad2[31]; unsigned long long ticks[8], wave_ticks[16]; unsigned pad3[16]; };
 static_assert(sizeof(ClusterCtl) == 512, "cx_api_ref.hip allocates and reads back 512 bytes");
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "k_ref_cluster: hwreg(20) is XCC_ID, s_waitcnt vmcnt(0) acknowledges stores and one XCD's L2 serves sc1 loads of plain stores on gfx942 / gfx950 only"
+#endif
 __device__ __forceinline__ unsigned hw_xcc_id() {
     unsigned v;
     asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(v));      // HW_REG_XCC_ID
     return v & 7u;
 }
-__device__ __forceinline__ bool cluster_wait(unsigned *p, unsigned target, unsigned *abort_) {
+// Every wait is bounded by TIME, not by a poll count: `limit` ticks of the constant 100 MHz clock (wall_clock64; cx_api_ref.hip passes 1.5 s,
+// CX_REF_CLUSTER_TIMEOUT_MS changes it) — a bound that is known to sit under the driver's compute-lockup timeout whatever the contention.
+// The clock is read every 64th poll (the first reading starts the wait's own clock: a wait that is satisfied at once never reads it).
+__device__ __forceinline__ bool cluster_wait(unsigned *p, unsigned target, unsigned *abort_, unsigned long long limit) {
+    unsigned long long t0 = 0;
     for (unsigned spins = 0;; spins++) {
         if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
-        if (spins > (1u << 24)) { __hip_atomic_store(abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }      // seconds
-        if ((spins & 63u) == 63u && __hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+        if ((spins & 63u) == 63u) {
+            if (__hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+            const unsigned long long now = wall_clock64();
+            if (!t0) t0 = now;
+            else if (now - t0 > limit) { __hip_atomic_store(abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+        }
     }
 }
 constexpr int kClusterBlock = 1024;
@@ -425,7 +436,8 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
                                                                const int32_t *__restrict__ flat, const int32_t *__restrict__ rec, const int32_t *__restrict__ vbase,
                                                                const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo, const int32_t *__restrict__ partner,
                                                                const double *__restrict__ q, const double *__restrict__ pa, const double *__restrict__ pb, double2 *f2v,
-                                                               double2 *v2f, double2 *marg, int nat_marg, double2 *prod, double *joint, const KaryTab kt, int dry) {
+                                                               double2 *v2f, double2 *marg, int nat_marg, double2 *prod, double *joint, const KaryTab kt, int dry,
+                                                               unsigned long long wait_limit, int fault_stage) {
     __shared__ unsigned rank_s, members_s, ok_s, mine_s;
     if (threadIdx.x == 0) {      // the cluster's XCD is the one of the first workgroup to ask (whatever the partition mode numbers it)
         const unsigned me = hw_xcc_id() + 1u;
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
         __hip_atomic_fetch_add(&c->registered, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok_s = 1u;
         if (mine) {      // once every workgroup of the launch has said where it runs, the membership is final
-            ok_s = cluster_wait(&c->registered, G, &c->abort_) ? 1u : 0u;
+            ok_s = cluster_wait(&c->registered, G, &c->abort_, wait_limit) ? 1u : 0u;
             members_s = __hip_atomic_load(&c->members, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -452,7 +464,9 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
     // take no part in the barriers and store nothing; helper j runs ahead of the members through the stages s = j (mod H), loads their
     // records (help >= 1) and the lines of their sources (help >= 2) — into the L2 the members read from — and never lets anybody wait.
     const int help = (dry >> 1) & 3, ahead_arg = (dry >> 8) & 0xff, members_arg = (dry >> 16) & 0xff;
-    const int64_t all = members_s, P = help && all >= 4 ? (members_arg && members_arg < all ? members_arg : all * 5 / 8) : all, H = all - P;      // (20 of 32: 7.9 – 8.1 against 8.0 – 8.4 ms for 16 in four pairs of runs; 24 and more: the helpers fall behind)
+    const int64_t all = members_s, P = help && all >= 4 ? (members_arg && members_arg < all ? members_arg : all * 5 / 8) : all, H = all - P;
+    // (what the host needs to find the first incomplete stage after a wait that timed out: arrive / P, cx_api_ref.hip: cluster_run)
+    if (rank_s == 0 && threadIdx.x == 0) __hip_atomic_store(&c->pad[1], (unsigned)P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (20 of 32: 7.9 – 8.1 against 8.0 – 8.4 ms for 16 in four pairs of runs; 24 and more: the helpers fall behind)
     if ((int64_t)rank_s >= P) {
         const int64_t hj = (int64_t)rank_s - P;
         const int ahead = ahead_arg ? ahead_arg : (help >= 3 ? 10 : help >= 2 ? 4 : 12);      // stages: the L2 is 4 MB, a stage's sources up to 1 MB of lines, its records 32 B an item
@@ -460,10 +474,15 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
         for (int64_t s = 2 + hj; s < n_stages; s += H) {
             if (threadIdx.x == 0) {
                 unsigned okh = 1u;
+                unsigned long long t0 = 0;
                 for (unsigned spins = 0;; spins++) {
                     const int64_t cur = __hip_atomic_load(&c->progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (s <= cur + ahead) break;
-                    if (spins > (1u << 24) || ((spins & 63u) == 63u && __hip_atomic_load(&c->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { okh = 0u; break; }
+                    if ((spins & 63u) == 63u) {      // (a helper never raises the flag: it only stops helping when the members have stopped or its own wait is too long)
+                        if (__hip_atomic_load(&c->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { okh = 0u; break; }
+                        const unsigned long long now = wall_clock64();
+                        if (!t0) t0 = now; else if (now - t0 > wait_limit) { okh = 0u; break; }
+                    }
                     __builtin_amdgcn_s_sleep(2);
                 }
                 ok_s = okh;
@@ -529,16 +548,19 @@ __global__ __launch_bounds__(kClusterBlock) void k_ref_cluster(ClusterCtl *c, un
         if (wtimed) wt += wall_clock64() - w0;
         __syncthreads();
         if (timed) { const unsigned long long t = wall_clock64(); tk[2] += t - t0; t0 = t; }      // the workgroup's other wavefronts
+        // (fault injection, CX_REF_CLUSTER_FAULT=<stage>: the member of rank 1 never arrives at this stage's barrier — what a workgroup
+        // that was never resident, or died, looks like to the others; tests/test_gpu_cluster.py)
+        if (fault_stage > 0 && st + 1 == fault_stage && rank_s == 1) return;
         if (threadIdx.x == 0) {
             // the last to arrive writes a word on a line of its own and the others poll that word, not the counter the arrivals are still
             // adding to (8.2 – 8.4 against 8.3 – 8.8 ms per call at C4, three pairs of runs; CX_REF_CLUSTER_RELEASE=0: everybody polls the counter)
             if ((dry >> 27) & 1) {
                 const unsigned before = __hip_atomic_fetch_add(&c->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (before + 1u == (unsigned)((st + 1) * P)) { __hip_atomic_store(&c->pad3[0], (unsigned)(st + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok_s = 1u; }
-                else ok_s = cluster_wait(&c->pad3[0], (unsigned)(st + 1), &c->abort_) ? 1u : 0u;
+                else ok_s = cluster_wait(&c->pad3[0], (unsigned)(st + 1), &c->abort_, wait_limit) ? 1u : 0u;
             } else {
                 __hip_atomic_fetch_add(&c->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok_s = cluster_wait(&c->arrive, (unsigned)((st + 1) * P), &c->abort_) ? 1u : 0u;
+                ok_s = cluster_wait(&c->arrive, (unsigned)((st + 1) * P), &c->abort_, wait_limit) ? 1u : 0u;
             }
             if (rank_s == 0) __hip_atomic_store(&c->progress, (unsigned)(st + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -771,8 +793,15 @@ void launch_ref_cluster(cx_handle *h, void *d_ctl, int n_workgroups, const int32
         return ((e && (e[0] == '1' || e[0] == '2')) ? 1 : 0) | ((hp ? std::max(0, std::min(3, std::atoi(hp))) : 3) << 1) | ((e && e[0] == '2') ? 8 : 0) | ((fw && fw[0] == '0') ? 16 : 0) | ((tm && tm[0] == '1') ? 32 : 0) |
                ((ah ? std::max(0, std::min(255, std::atoi(ah))) : 0) << 8) | ((mb ? std::max(0, std::min(255, std::atoi(mb))) : 0) << 16) | ((rl && rl[0] == '0') ? 0 : (1 << 27));
     }();
+    // the bound of every wait in ticks of the 100 MHz clock (read per launch: a test shortens it), and the fault-injection stage (1-based, 0: none)
+    double ms = 1500.0;
+    if (const char *e = std::getenv("CX_REF_CLUSTER_TIMEOUT_MS")) ms = std::max(1.0, std::min(20000.0, std::atof(e)));
+    const unsigned long long wait_limit = (unsigned long long)(ms * 1e5);
+    int fault_stage = 0;
+    if (const char *e = std::getenv("CX_REF_CLUSTER_FAULT")) fault_stage = std::max(0, std::atoi(e));
 #define CX_B(M, PA, PB) hipLaunchKernelGGL(k_ref_cluster<M>, dim3(n_workgroups), dim3(kClusterBlock), 0, h->stream, (ClusterCtl *)d_ctl, (unsigned)n_workgroups, d_stage_off, n_stages, \
-                                           d_flat, d_rec, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint, kt, dry)
+                                           d_flat, d_rec, h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_partner, h->d_q, PA, PB, h->d_f2v, h->d_v2f, h->d_marg, nat, h->d_prod, h->d_joint, kt, dry, \
+                                           wait_limit, fault_stage)
     if (mode == kRuleLinear) CX_B(kRuleLinear, h->d_a, h->d_b);
     else if (mode == kRuleBernoulli) CX_B(kRuleBernoulli, (const double *)nullptr, (const double *)nullptr);
     else CX_B(kRuleAdditive, (const double *)nullptr, (const double *)nullptr);

@@ -225,7 +225,9 @@ struct cx_handle {
     // the XCD-resident cluster (cx_batch.hip: k_ref_cluster; cx_api_ref.hip: cluster_prepare / cluster_run): stage plans of wide stages in ONE launch
     void *d_cluster_ctl = nullptr;   // 512 B the launch scribbles on (cx_batch.hip: ClusterCtl)
     int cluster_cu = 0;              // compute units = workgroups of a cluster launch
-    int cluster_state = 0;           // 0 not prepared, 1 ready, -1 off (CX_REF_CLUSTER=0, no memory, or a barrier once timed out)
+    int cluster_state = 0;           // 0 not prepared, 1 ready, -1 off (CX_REF_CLUSTER=0, no memory, another architecture, or a barrier once timed out)
+    int64_t cluster_recoveries = 0;  // calls whose cluster gave up at a barrier and that were finished on plain launches (cx_cluster_stats)
+    std::string cluster_note;        // what happened, for cx_last_error's reader
     int64_t cluster_max_items = 16384, cluster_min_items = 128;      // a stage wider than max (one pass of the members) is a launch of its own on the whole chip; plans of fewer than min items per stage are chains
 
     // CX_SCHED_REFERENCE (cx_refsched.h, cx_api_ref.hip): wiring + shadow readiness state + plans (opaque); the list of the plan being launched

@@ -214,11 +214,11 @@ class DeviceGraph:
         self._check(self.lib.cx_graph_wire(self.h, n, sig.ctypes.data_as(C.POINTER(L.Item)), dep.ctypes.data_as(C.POINTER(L.Item)), _p(fl, C.c_int32) if n else None))
 
     def cluster_stats(self) -> dict:
-        """cx_cluster_stats: the XCD-resident cluster — state (1 ready, 0 not prepared, -1 off), workgroups per launch, whether the last
-        reference-order call ran on it"""
+        """cx_cluster_stats: the XCD-resident cluster — state (1 ready, 0 not prepared, -1 off), workgroups per launch, calls that were
+        finished on plain launches after a barrier of the cluster timed out, whether the last reference-order call ran on it"""
         out = (C.c_int64 * 4)()
         self._check(self.lib.cx_cluster_stats(self.h, out))
-        return {"state": int(out[0]), "workgroups": int(out[1]), "last_reference_call": bool(out[3])}
+        return {"state": int(out[0]), "workgroups": int(out[1]), "recovered_calls": int(out[2]), "last_reference_call": bool(out[3])}
 
     def ref_plan_stats(self) -> dict:
         out = (C.c_int64 * 8)()

@@ -352,8 +352,10 @@ int32_t cx_graph_wire(cx_handle *h, int64_t n, const cx_item *signals, const cx_
 int32_t cx_ref_plan_stats(const cx_handle *h, int64_t *out8);
 /* the XCD-resident cluster (reference-order plans of many dependent stages of 1 - 16 k items — calls on loopy graphs — run as ONE launch
  * of the workgroups of one XCD behind barriers that stay in that XCD's L2): out4 = { 1 ready / 0 not prepared / -1 off
- * (CX_REF_CLUSTER=0, or a barrier once timed out), workgroups per launch (compute units), 0 (reserved), 1 when the last reference-order
- * call ran on it }. */
+ * (CX_REF_CLUSTER=0, a device that is neither gfx942 nor gfx950, or a barrier once timed out), workgroups per launch (compute units),
+ * calls RECOVERED (every wait of the cluster is bounded in time — 1.5 s, CX_REF_CLUSTER_TIMEOUT_MS; a call whose cluster gives up is
+ * finished from its first incomplete stage on plain launches, returns CX_OK with the same results, and the handle stays with launches),
+ * 1 when the last reference-order call ran on the cluster }. */
 int32_t cx_cluster_stats(const cx_handle *h, int64_t *out4);
 /* the executions of the last reference-order call in the reference's order — what a `trace = true` engine records
  * (src/inference_engine.jl:650-862: TracedInferenceExecution.signal), as items (kind, variable_id, factor_id | CX_ITEM_RANGE).

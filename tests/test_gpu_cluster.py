@@ -97,3 +97,48 @@ def test_plans_of_thin_stages_and_short_plans_stay_with_launches(hip_lib):
     st = dev.cluster_stats()
     assert st["state"] == 1 and not st["last_reference_call"], st      # 800 stages of a few items: one workgroup's own barrier (k_batch_run)
     assert dev.ref_plan_stats()["launches"] == 1
+
+
+@pytest.mark.parametrize("fault_stage", [1, 700])
+def test_a_member_that_never_arrives_is_survived(hip_lib, monkeypatch, fault_stage):
+    """Fault injection: one member workgroup skips its arrival at one barrier — what a workgroup that never became resident
+    (a CU mask, a restricted queue, a third tenant's long kernels) looks like to the others.  Every wait of the cluster is bounded in TIME
+    (shortened here), the host finds the first incomplete stage from the arrival counter and finishes the call on plain launches from
+    there: the call succeeds with the launches' results, the handle reports one recovered call and stays with launches."""
+    model = cx.synth.gaussian_grid(1200, 1300, seed=3)
+    prior = np.stack([model.prior_mean, model.prior_variance], axis=1)
+
+    def make():
+        dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+        cx.synth.load_into_device(model, dev, seed_variance=1e6)
+        return dev
+
+    a, b = _pair(make)
+    for dev in (a, b):          # a first, undisturbed call (it also finds the plan)
+        dev.sweep(1)
+        dev.set_messages(model.prior_var, model.prior_fac, L.TO_VARIABLE, L.FORM_MOMENT, prior)
+    assert a.cluster_stats()["state"] == 1 and a.cluster_stats()["last_reference_call"]
+    monkeypatch.setenv("CX_REF_CLUSTER_FAULT", str(fault_stage))
+    monkeypatch.setenv("CX_REF_CLUSTER_TIMEOUT_MS", "50")
+    import time
+    t0 = time.perf_counter()
+    a.sweep(1)                  # does NOT raise
+    a.sync()
+    dt = time.perf_counter() - t0
+    monkeypatch.delenv("CX_REF_CLUSTER_FAULT")
+    b.sweep(1)
+    st = a.cluster_stats()
+    assert st["state"] == -1 and st["recovered_calls"] == 1, st
+    assert dt < 5.0, f"the bounded waits took {dt:.2f} s"
+    for call in range(2):       # the faulted call, then one more on the handle that went back to launches
+        assert a.ref_trace() == b.ref_trace()
+        for direction in (L.TO_VARIABLE, L.TO_FACTOR):
+            ma, mb = a.get_messages(model.edge_var, model.edge_fac, direction, L.FORM_NATURAL), b.get_messages(model.edge_var, model.edge_fac, direction, L.FORM_NATURAL)
+            assert np.array_equal(np.isnan(ma), np.isnan(mb))
+            ok = ~np.isnan(ma)
+            assert_close(ma[ok], mb[ok], 1e-12, f"call {call}: messages, direction {direction}", scale_by="max")
+        assert_close(a.get_marginals(model.x_ids), b.get_marginals(model.x_ids), 1e-12, f"call {call}: marginals", scale_by="max")
+        for dev in (a, b):
+            dev.set_messages(model.prior_var, model.prior_fac, L.TO_VARIABLE, L.FORM_MOMENT, prior)
+            dev.sweep(1)
+    assert a.cluster_stats()["recovered_calls"] == 1 and not a.cluster_stats()["last_reference_call"]

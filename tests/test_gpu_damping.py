@@ -163,3 +163,32 @@ def test_refusals(hip_lib):
             dev.set_damping(bad)
         assert ei.value.code == L.ERR_INVALID_ARGUMENT
     dev.close()
+
+
+def test_message_halos_and_damping_exclude_each_other_in_either_order(hip_lib):
+    """ cx_set_damping refuses a handle with per-sweep message halos; cx_halo_configure must refuse a damped handle too"""
+    from cortex.jl_amd import partition
+    part = partition.grid_rows(12, 10, 0, 2, seed=3)
+    a = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(part.model, a, seed_variance=1e6)
+    a.halo_configure(part.send_var, part.send_fac, part.recv_var, part.recv_fac)
+    with pytest.raises(cx.CortexHipError) as ei:
+        a.set_damping(0.5)
+    assert ei.value.code == L.ERR_UNSUPPORTED
+    b = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(part.model, b, seed_variance=1e6)
+    b.set_damping(0.5)
+    with pytest.raises(cx.CortexHipError, match="not damped") as ei:
+        b.halo_configure(part.send_var, part.send_fac, part.recv_var, part.recv_fac)
+    assert ei.value.code == L.ERR_UNSUPPORTED
+    b.halo_configure([], [], [], [])          # taking a halo away is always possible
+    b.set_damping(0.0)
+    b.halo_configure(part.send_var, part.send_fac, part.recv_var, part.recv_fac)
+    # state halos run plain sweeps and are damped like them
+    c = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    deep = partition.grid_rows_deep(12, 10, 0, 2, 2, seed=3)
+    cx.synth.load_into_device(deep.model, c, seed_variance=1e6)
+    c.set_damping(0.3)
+    c.halo_configure_state(deep.send_var, deep.send_fac, deep.recv_var, deep.recv_fac)
+    for d in (a, b, c):
+        d.close()

@@ -149,6 +149,44 @@ def test_a_wired_handle_round_trips_through_a_checkpoint(hip_lib):
         assert np.array_equal(p, q)
 
 
+def test_an_imported_readiness_state_is_state_and_keeps_the_wirings_own_flags(hip_lib):
+    """ a checkpoint's readiness section carries the dynamic Computed / Fresh bits only: the Intermediate / Weak bits are the
+    wiring's, so a blob written under another wiring is refused instead of changing which dependencies count as weak; and an import counts
+    as "a value was set": a cx_graph_wire after it is refused instead of silently throwing the imported readiness away."""
+    model = cx.synth.vmp_ssm(12, seed=4)
+    a = _wired_ssm(model, "structured")
+    a.sweep_for(model.x_ids)
+    blob = a.export_state()
+    nf = len(model.factor_ids)
+
+    def fresh():
+        d = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+        d.graph_create(model.edge_var, model.edge_fac, model.factor_ids, np.full(nf, L.FACTOR_NORMAL_PRECISION, dtype=np.int32), np.zeros(nf), edge_role=model.edge_role)
+        return d
+    t = cx.wiring.structured(model.edge_var, model.edge_fac, model.edge_role, clustered_factors=model.factor_ids[model.n:])
+    b = fresh()
+    b.graph_wire(t.signals, t.dependencies, t.flags)
+    b.import_state(blob)
+    with pytest.raises(cx.CortexHipError, match="wiring is fixed"):
+        b.graph_wire(t.signals, t.dependencies, t.flags)
+    # the same triples with every weak dependency made strong: the same sizes, other static bits
+    c = fresh()
+    strong = np.asarray(t.flags).copy() & ~np.int32(L.WIRE_WEAK)
+    assert np.any(strong != np.asarray(t.flags))
+    try:
+        c.graph_wire(t.signals, t.dependencies, strong)
+    except cx.CortexHipError:
+        return                  # (a wiring no rule serves is refused at wiring time: nothing to import into)
+    with pytest.raises(cx.CortexHipError, match="does not fit this handle's wiring"):
+        c.import_state(blob)
+    # ... and another resolver's wiring (other dependency lists)
+    d = fresh()
+    m = cx.wiring.mean_field(model.edge_var, model.edge_fac, model.edge_role)
+    d.graph_wire(m.signals, m.dependencies, m.flags)
+    with pytest.raises(cx.CortexHipError):
+        d.import_state(blob)
+
+
 def test_refusals_on_the_device(hip_lib):
     model = cx.synth.vmp_ssm(6, seed=1)
     nf = len(model.factor_ids)
