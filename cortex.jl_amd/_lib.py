@@ -110,6 +110,7 @@ SIGNATURES = {
     "cx_halo_ipc_set_timeout": (_i32, [_vp, C.c_double]),
     "cx_chain_block_maps": (_i32, [_vp, _pd, _pd, _pd, _pd, _pi64, _pi64, _pi64]),
     "cx_chain_plan_stats": (_i32, [_vp, _pi64]),
+    "cx_chain_scan_stats": (_i32, [_vp, _pi64]),
     "cx_tree_plan_stats": (_i32, [_vp, _pi64]),
     "cx_tree_heavy_path_stats": (_i32, [_vp, _pi64]),
     "cx_set_marginals": (_i32, [_vp, _i64, _pi64, _i32, _pd]),

@@ -31,6 +31,7 @@ void dev_free_all(cx_handle *h) {
     h->set_memos.clear();
     ref_free(h);
     cx::chain64_free(h);
+    cx::chain_onepass_free(h);
     cx::chain64_tree_free(h);
     cx::kary_free(h);
     if (h->d_prod) (void)hipFree(h->d_prod);

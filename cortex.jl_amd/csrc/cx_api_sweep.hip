@@ -518,6 +518,12 @@ int32_t cx_chain_plan_stats(const cx_handle *h, int64_t *out8) {
     return CX_OK;
 }
 
+int32_t cx_chain_scan_stats(const cx_handle *h, int64_t *out4) {
+    if (!h || !out4) return CX_ERR_INVALID_ARGUMENT;
+    out4[0] = h->chain_onepass_state; out4[1] = h->chain_onepass_launches; out4[2] = 0; out4[3] = 0;
+    return CX_OK;
+}
+
 // Damped message passing: loopy Gaussian BP outside the walk-summable regime can oscillate; mixing every new factor→variable message
 // with the one it replaces is the usual remedy.  The reference has no such knob (its rules are the user's: a user damps inside the
 // rule); here the rules are the library's, so the knob is too.

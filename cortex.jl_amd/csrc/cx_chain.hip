@@ -17,7 +17,11 @@
 // Path boundaries are handled by a segmented scan (head flags).  The arithmetic is re-associated relative to the
 // sequential schedule: results agree to rounding (tests hold 1e-9), not bitwise.
 
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 
 #include "cx_internal.h"
 
@@ -405,6 +409,298 @@ __global__ __launch_bounds__(2 * T) void k_chain_run_apply(ChainArgs A, const Li
     }
 }
 
+
+// ---- ONE launch (round 6): the two kernels above merged behind per-tile flags ("single-pass scan with decoupled look-back") ---------------
+// k_chain_run_totals ends where k_chain_run_apply begins only because a workgroup's carry is made of OTHER workgroups' tile totals: a
+// kernel boundary used as a device-wide barrier, ≈ 5.7 us of a 21 us sweep at C2, plus every thread's prefix written out and read back
+// (run_excl: 14 MB at C2).  Here a workgroup publishes its two tile totals (64 bytes each, write-through stores, then a flag), keeps its
+// runs' prefixes in registers, and composes the totals of the tiles before it as they appear: nobody waits for anything but data.
+//   * Publishing comes BEFORE any wait, so the launch makes progress whenever every workgroup is or becomes resident; the launcher takes
+//     this path only when the whole grid fits the device at once (occupancy x compute units), and every wait is bounded in time: a
+//     workgroup that gives up raises a word in host memory (chain_abort), nobody stores a result, and the next call that waits for the
+//     stream fails loudly and switches the handle back to the two launches (a chain-scan sweep is exact whatever it starts from: repeat it).
+//   * Totals cross XCDs: written through (sc0 sc1), read past the caches (sc0 sc1), each 16-byte piece carrying the launch's tag beside its
+//     value (below) — no flag, no fence: an agent-scope release / acquire would write back and invalidate the XCD's whole L2 under the
+//     other workgroups' loads, and a flag is a second round trip through the memory the XCDs share.
+//   * The epoch the tag is made of lives on the device and is moved on inside the launch (by the last workgroup past its look-back,
+//     counted by `done`), so a captured graph replays.
+constexpr int kOnepassMaxTiles = 2048;
+constexpr int kTotalPieces = 8;        // 16-byte pieces per published total (seven used): records are 128 bytes apart
+struct OnepassCtl { unsigned epoch, done, pad[14]; };
+typedef unsigned int cx_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long cx_u64;
+// A published total is seven pieces (value, value XOR tag), the tag a 64-bit pattern of the launch's epoch: a reader that finds the
+// relation in all seven has the values of THIS launch — no flag, so no second round trip through the memory the XCDs share, and no
+// assumption that a 16-byte store is seen whole (a piece torn at any granularity fails the relation; pieces of an earlier launch carry
+// another tag).
+__device__ __forceinline__ cx_u64 epoch_tag(unsigned epoch) { return ((cx_u64)(epoch + 1u) * 0x9E3779B97F4A7C15ull) | 1ull; }
+__device__ __forceinline__ void store_piece(double2 *p, double v, cx_u64 tag) {
+    const cx_u64 b = (cx_u64)__double_as_longlong(v), c = b ^ tag;
+    cx_u32x4 r;
+    r[0] = (unsigned)b; r[1] = (unsigned)(b >> 32); r[2] = (unsigned)c; r[3] = (unsigned)(c >> 32);
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(r) : "memory");      // written through (system scope)
+}
+__device__ __forceinline__ void publish_total(double2 *p, const Lin &t, cx_u64 tag) {
+    store_piece(p, t.e, tag); store_piece(p + 1, t.f, tag); store_piece(p + 2, t.g, tag); store_piece(p + 3, t.A, tag);
+    store_piece(p + 4, t.B, tag); store_piece(p + 5, t.C, tag); store_piece(p + 6, (double)t.seg, tag);
+}
+// one look at a published total, past the caches: true when all seven pieces carry this launch's tag
+__device__ __forceinline__ bool read_total(const double2 *p, cx_u64 tag, Lin &t) {
+    cx_u32x4 r[7];
+    asm volatile("global_load_dwordx4 %0, %7, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %1, %7, off offset:16 sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %7, off offset:32 sc0 sc1\n\t"
+                 "global_load_dwordx4 %3, %7, off offset:48 sc0 sc1\n\t"
+                 "global_load_dwordx4 %4, %7, off offset:64 sc0 sc1\n\t"
+                 "global_load_dwordx4 %5, %7, off offset:80 sc0 sc1\n\t"
+                 "global_load_dwordx4 %6, %7, off offset:96 sc0 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6])
+                 : "v"(p)
+                 : "memory");
+    double v[7];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const cx_u64 b = (cx_u64)r[i][0] | ((cx_u64)r[i][1] << 32), c = (cx_u64)r[i][2] | ((cx_u64)r[i][3] << 32);
+        ok = ok && ((b ^ c) == tag);
+        v[i] = __longlong_as_double((long long)b);
+    }
+    t.e = v[0]; t.f = v[1]; t.g = v[2]; t.A = v[3]; t.B = v[4]; t.C = v[5]; t.seg = (int)v[6];
+    return ok;
+}
+// false: gave up (time) or somebody else did
+__device__ __forceinline__ bool wait_total(const double2 *p, cx_u64 tag, Lin &t, const unsigned *abort_word, unsigned long long limit) {
+    unsigned long long t0 = 0;
+    for (unsigned spins = 0;; spins++) {
+        if (read_total(p, tag, t)) return true;
+        if ((spins & 15u) == 15u) {
+            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return false;
+            const unsigned long long now = wall_clock64();      // 100 MHz
+            if (!t0) t0 = now; else if (now - t0 > limit) return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <int K, int T, bool MARG>
+__global__ __launch_bounds__(2 * T) void k_chain_onepass(ChainArgs A, double2 *__restrict__ totals64, OnepassCtl *__restrict__ ctl, unsigned *__restrict__ abort_word,
+                                                         unsigned long long wait_limit_and_fault, double2 *__restrict__ f2v, double2 *__restrict__ marg, int marg_form,
+                                                         double2 *__restrict__ chain_v2f, double *__restrict__ split_mean, double *__restrict__ split_prec,
+                                                         const bool store_msgs, unsigned long long *__restrict__ stamps) {
+    constexpr int kRunTile = K * T;
+    const int half = threadIdx.x / T, tid = threadIdx.x % T, dir = half == 0 ? 1 : -1, ntiles = gridDim.x;
+    const int pos = half == 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;       // this block's place in the direction's scan order
+    const int lane = tid & 63, wid = tid >> 6;
+    __shared__ Lin wave_tot[2][T / 64];
+    __shared__ double2 msg_s[MARG ? 2 : 1][MARG ? kRunTile : 1];
+    __shared__ double2 seam[2];
+    // (CX_CHAIN_ONEPASS_STAMPS=1, lab: where a workgroup's time goes — the 100 MHz clock at six points, thread 0)
+#define CX_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+    CX_STAMP(0);
+    double2 *tot_dir = totals64 + (size_t)half * kOnepassMaxTiles * kTotalPieces;
+    __shared__ unsigned epoch_s;
+    if (threadIdx.x == 0) epoch_s = __hip_atomic_load(&ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (needed after the first barrier: behind the links' loads)
+    const unsigned long long wait_limit = wait_limit_and_fault & ~(1ull << 63);
+    // 1. this thread's run, composed in order; the prefix of the runs before it within the tile stays in registers
+    LinkIn in[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) in[k] = load_link_in(A, run_link<K, T>(A, blockIdx.x, tid * K + k, dir), dir);
+    Lin t = lin_identity();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if (in[k].link < 0) continue;
+        const Lin m = lin_of_link(in[k].u, in[k].q, in[k].a, in[k].b, in[k].seg);
+        t = k == 0 ? m : lin_compose(t, m);
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        Lin o = lin_shfl_up(t, d);
+        if (lane >= d) t = lin_compose(o, t);
+    }
+    if (lane == 63) wave_tot[half][wid] = t;
+    __syncthreads();
+    Lin ex = lin_shfl_up(t, 1);
+    if (lane == 0) ex = lin_identity();
+    if (wid > 0) {
+        Lin carry = wave_tot[half][0];
+        for (int w = 1; w < wid; w++) carry = lin_compose(carry, wave_tot[half][w]);
+        ex = lin_compose(carry, ex);
+    }
+    CX_STAMP(1);
+    // 2. the tile's total goes out before anything is waited for
+    if (tid == 0) {
+        Lin tot = wave_tot[half][0];
+        for (int w = 1; w < T / 64; w++) tot = lin_compose(tot, wave_tot[half][w]);
+        if (!((wait_limit_and_fault >> 63) && half == 0 && pos == 0)) publish_total(tot_dir + (size_t)pos * kTotalPieces, tot, epoch_tag(epoch_s));
+    }
+    __syncthreads();      // (wave_tot is reused below)
+    CX_STAMP(2);
+    // 3. the carry: the totals of the tiles before this one, thread t the run [t per, (t + 1) per) of them as they are published
+    const int per = (pos + T - 1) / T;
+    const cx_u64 tag = epoch_tag(epoch_s);
+    bool ok = true;
+    if (per > 0 && wid * 64 * per < pos) {
+        const int b = tid * per, e = min(b + per, pos);
+        Lin c = lin_identity();
+        for (int j = b; j < e; j++) {
+            Lin x;
+            if (!wait_total(tot_dir + (size_t)j * kTotalPieces, tag, x, abort_word, wait_limit)) { ok = false; break; }
+            c = j == b ? x : lin_compose(c, x);
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            Lin o = lin_shfl_up(c, d);
+            if (lane >= d) c = lin_compose(o, c);
+        }
+        if (lane == 63) wave_tot[half][wid] = c;
+    } else if (lane == 63) wave_tot[half][wid] = lin_identity();
+    if (__syncthreads_or(ok ? 0 : 1)) {      // somebody gave up: say so where the host looks, store nothing (the sweep is repeated on two launches)
+        if (threadIdx.x == 0) __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    if (tid == 0) {
+        Lin c = wave_tot[half][0];
+        for (int w = 1; w < T / 64; w++) c = lin_compose(c, wave_tot[half][w]);
+        seam[half] = make_double2(c.g, c.B);      // the carry applied to the empty message
+    }
+    // this workgroup has read every total it will read: it says so now and looks at the answer when its own work is done — the last one
+    // to have said so moves the epoch on for the next launch (or replay of a captured graph)
+    unsigned arrived = 0;
+    if (threadIdx.x == 0) arrived = __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    CX_STAMP(3);
+    // 4. the walk, as k_chain_run_apply's
+    __syncthreads();      // (seam)
+    const int lo = blockIdx.x * kRunTile;
+    double2 m = lin_apply(ex, seam[half]);
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int l = in[k].link;
+        if (l < 0) continue;
+        if (in[k].seg) m = make_double2(0.0, 0.0);
+        const double2 v = make_double2(m.x + in[k].u.x, m.y + in[k].u.y);
+        const double s = 1.0 / (in[k].a * in[k].a + in[k].q * v.y);
+        m = make_double2((in[k].a * v.x + in[k].b * v.y) * s, v.y * s);
+        if (MARG) msg_s[half][l - lo] = m;
+        else if (!__builtin_isnan(m.y)) f2v[in[k].recv] = m;
+    }
+    if (MARG) {
+        __syncthreads();
+        const double2 seam_alpha = seam[0], seam_beta = seam[1];
+        const int cnt = min(kRunTile, A.nlinks - lo);
+        for (int j = threadIdx.x; j < cnt; j += 2 * T) {
+            const int l = lo + j, p = A.link_pos[l];
+            const double2 sd = A.side[p], be = msg_s[1][j];
+            if (store_msgs) {
+                const double2 al = msg_s[0][j];
+                if (!__builtin_isnan(al.y)) f2v[A.to_slot[l]] = al;
+                if (!__builtin_isnan(be.y)) f2v[A.from_slot[l]] = be;
+            }
+            double2 lx = sd;
+            if (!A.head_fwd[l]) { const double2 al = j > 0 ? msg_s[0][j - 1] : seam_alpha; lx.x += al.x; lx.y += al.y; }
+            const double2 tt = make_double2(lx.x + be.x, lx.y + be.y);
+            if (marg_form == 3) { const int v = A.pos_var[p]; split_mean[v] = tt.x / tt.y; split_prec[v] = tt.y; }
+            else marg[A.pos_var[p]] = marg_form == 2 ? tt : chain_to_moment(tt);
+            const double2 s1 = A.side[p + 1], al1 = msg_s[0][j];
+            if (A.head_bwd[l]) {
+                const double2 u = make_double2(s1.x + al1.x, s1.y + al1.y);
+                if (marg_form == 3) { const int v = A.pos_var[p + 1]; split_mean[v] = u.x / u.y; split_prec[v] = u.y; }
+                else marg[A.pos_var[p + 1]] = marg_form == 2 ? u : chain_to_moment(u);
+            }
+            if (chain_v2f) {
+                if (!__builtin_isnan(lx.y)) chain_v2f[A.from_slot[l]] = lx;
+                double2 rx = s1;
+                if (!A.head_bwd[l]) { const double2 bn = j + 1 < cnt ? msg_s[1][j + 1] : seam_beta; rx.x += bn.x; rx.y += bn.y; }
+                if (!__builtin_isnan(rx.y)) chain_v2f[A.to_slot[l]] = rx;
+            }
+        }
+    }
+    CX_STAMP(4);
+    if (threadIdx.x == 0 && arrived == (unsigned)ntiles) {
+        __hip_atomic_store(&ctl->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->epoch, epoch_s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    CX_STAMP(5);
+#undef CX_STAMP
+}
+
+// the one-launch form is taken when it is on (CX_CHAIN_ONEPASS != 0, no wait of it ever timed out on this handle), the grid is within the
+// flags' table and ALL its workgroups are resident at once on this device
+template <int K, int T>
+static bool onepass_ready(cx_handle *h, int ntiles) {
+    if (h->chain_onepass_state < 0 || ntiles > kOnepassMaxTiles || ntiles < 1) return false;
+    if (h->chain_onepass_state == 0) {
+        h->chain_onepass_state = -1;
+        if (const char *e = getenv("CX_CHAIN_ONEPASS")) if (e[0] == '0') return false;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); return false; }
+        // 2 x kOnepassMaxTiles totals of 128 bytes, the control block behind them; the abort word in host memory the device can write
+        void *d = nullptr;
+        const size_t bytes = (size_t)2 * kOnepassMaxTiles * kTotalPieces * 16 + sizeof(OnepassCtl);
+        if (hipMalloc(&d, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipMemset(d, 0, bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d); return false; }
+        void *hw = nullptr;
+        if (hipHostMalloc(&hw, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d); return false; }
+        std::memset(hw, 0, 64);
+        void *dw = nullptr;
+        if (hipHostGetDevicePointer(&dw, hw, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d); (void)hipHostFree(hw); return false; }
+        h->d_chain_onepass = d; h->chain_abort_host = (volatile unsigned *)hw; h->d_chain_abort = dw;
+        h->chain_onepass_cus = cus;
+        h->chain_onepass_state = 1;
+    }
+    // resident workgroups of each instance (the marginal form holds 32 KB of LDS more)
+    static int per_cu[2] = {0, 0};
+    if (!per_cu[0]) {
+        int a = 0, b = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_chain_onepass<K, T, true>, 2 * T, 0) != hipSuccess) { (void)hipGetLastError(); a = 0; }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_chain_onepass<K, T, false>, 2 * T, 0) != hipSuccess) { (void)hipGetLastError(); b = 0; }
+        per_cu[0] = std::max(a, 0) + 1; per_cu[1] = std::max(b, 0) + 1;      // (+ 1: 0 means "not asked yet")
+    }
+    const int fit = (std::min(per_cu[0], per_cu[1]) - 1) * h->chain_onepass_cus;
+    return ntiles <= fit;
+}
+
+template <int K, int T>
+static void launch_onepass(cx_handle *h, const ChainArgs &A, int ntiles, double2 *f2v, int marg_form, bool chain_v2f) {
+    double2 *totals64 = (double2 *)h->d_chain_onepass;
+    OnepassCtl *ctl = (OnepassCtl *)((char *)h->d_chain_onepass + (size_t)2 * kOnepassMaxTiles * kTotalPieces * 16);
+    // every wait's bound in ticks of the 100 MHz clock (0.5 s; read per launch: a test shortens it) and the fault injection of that test
+    // (CX_CHAIN_ONEPASS_FAULT=1: the first tile of the forward scan never publishes its total)
+    const char *e = getenv("CX_CHAIN_ONEPASS_TIMEOUT_MS"), *ef = getenv("CX_CHAIN_ONEPASS_FAULT");
+    const unsigned long long limit = (unsigned long long)((e ? std::max(1.0, std::min(20000.0, atof(e))) : 500.0) * 1e5) | (ef && ef[0] == '1' ? 1ull << 63 : 0ull);
+    const bool store = !(h->chain_msgs_unread && marg_form == 3 && chain_v2f);
+    double2 *v2f = chain_v2f ? h->d_v2f : nullptr;
+    const dim3 g(ntiles), b(2 * T);
+    static const bool want_stamps = [] { const char *v = getenv("CX_CHAIN_ONEPASS_STAMPS"); return v && v[0] == '1'; }();
+    unsigned long long *stamps = nullptr;
+    if (want_stamps && hipMalloc((void **)&stamps, (size_t)ntiles * 64) != hipSuccess) { (void)hipGetLastError(); stamps = nullptr; }
+    if (marg_form) hipLaunchKernelGGL((k_chain_onepass<K, T, true>), g, b, 0, h->stream, A, totals64, ctl, (unsigned *)h->d_chain_abort, limit, f2v, h->d_marg, marg_form, v2f, h->d_split_mean, h->d_split_prec, store, stamps);
+    else hipLaunchKernelGGL((k_chain_onepass<K, T, false>), g, b, 0, h->stream, A, totals64, ctl, (unsigned *)h->d_chain_abort, limit, f2v, h->d_marg, 0, (double2 *)nullptr, (double *)nullptr, (double *)nullptr, true, stamps);
+    h->chain_onepass_launches++;
+    if (stamps) {      // lab: per phase, the earliest, median and latest workgroup, in us after the first workgroup started
+        std::vector<unsigned long long> st((size_t)ntiles * 8);
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(stamps);
+        unsigned long long t0 = ~0ull;
+        for (int i = 0; i < ntiles; i++) t0 = std::min(t0, st[(size_t)i * 8]);
+        static const char *names[6] = {"start", "runs composed", "total published", "carry composed", "results stored", "end"};
+        for (int ph = 0; ph < 6; ph++) {
+            std::vector<double> v;
+            for (int i = 0; i < ntiles; i++) v.push_back((double)(st[(size_t)i * 8 + ph] - t0) * 0.01);
+            std::sort(v.begin(), v.end());
+            fprintf(stderr, "[onepass %d tiles] %-16s min %7.2f  median %7.2f  max %7.2f us\n", ntiles, names[ph], v.front(), v[v.size() / 2], v.back());
+        }
+    }
+}
+
+void chain_onepass_free(cx_handle *h) {
+    if (h->d_chain_onepass) (void)hipFree(h->d_chain_onepass);
+    if (h->chain_abort_host) (void)hipHostFree((void *)h->chain_abort_host);
+    h->d_chain_onepass = nullptr; h->chain_abort_host = nullptr; h->d_chain_abort = nullptr;
+    if (h->chain_onepass_state > 0) h->chain_onepass_state = 0;
+}
+
 // the shape of a tile: K links per thread, T threads per direction (CX_CHAIN_SHAPE picks among the instances: lab switch)
 constexpr int kRunTileLinks = 512;        // every instance below has K * T = 512 or a multiple of it
 static int chain_shape() {
@@ -422,7 +718,8 @@ static void launch_run_totals(cx_handle *h, const ChainArgs &A, int *ntiles_out)
 
 template <int K, int T>
 static void launch_run_scan(cx_handle *h, const ChainArgs &A, double2 *f2v, int marg_form, bool chain_v2f) {
-    int ntiles = 0;
+    int ntiles = (A.nlinks + K * T - 1) / (K * T);
+    if (onepass_ready<K, T>(h, ntiles)) { launch_onepass<K, T>(h, A, ntiles, f2v, marg_form, chain_v2f); return; }
     launch_run_totals<K, T>(h, A, &ntiles);
     Lin *totals = (Lin *)h->d_chain_totals, *run_excl = totals + (size_t)2 * (ntiles + 1);
     const dim3 g(ntiles), b(2 * T);

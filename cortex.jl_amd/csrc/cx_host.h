@@ -18,6 +18,20 @@ namespace cxh {
 
 inline thread_local std::string g_create_error;
 
+// The one-launch chain scan (cx_chain.hip: k_chain_onepass) raises a word in mapped host memory when one of its bounded waits times out
+// (a workgroup of the launch never became resident: CU mask, another tenant's persistent kernel).  Whoever checks a HIP call next
+// finds it: the call fails, the handle uses the two-launch scan from then on.  A chain-scan sweep is exact whatever state it starts
+// from, so the caller repeats the sweep.
+constexpr const char *kChainAbortMessage = "the one-launch chain scan timed out waiting for a workgroup that never became resident; the last chain-scan sweep "
+                                           "stored nothing — call cx_sweep again (this handle now uses the two-launch scan)";
+template <class H>
+inline bool chain_abort_take(H *h) {
+    if (!h || !h->chain_abort_host || !*h->chain_abort_host) return false;
+    *const_cast<volatile unsigned *>(h->chain_abort_host) = 0;
+    const_cast<cx_handle *>(static_cast<const cx_handle *>(h))->chain_onepass_state = -1;
+    return true;
+}
+inline bool chain_abort_take(std::nullptr_t) { return false; }
 inline int32_t fail(cx_handle *h, int32_t code, const std::string &msg) {
     if (h) h->err = msg; else g_create_error = msg;
     return code;
@@ -29,6 +43,8 @@ inline int32_t fail(cx_handle *h, int32_t code, const std::string &msg) {
         if (e_ != hipSuccess)                                                                    \
             return cxh::fail(h, e_ == hipErrorOutOfMemory ? CX_ERR_OUT_OF_MEMORY : CX_ERR_DEVICE, \
                              std::string(#call) + ": " + hipGetErrorString(e_));                 \
+        if (cxh::chain_abort_take(h))                                                            \
+            return cxh::fail(h, CX_ERR_DEVICE, cxh::kChainAbortMessage);                         \
     } while (0)
 
 #define CX_REQUIRE(h, cond, code, msg) \

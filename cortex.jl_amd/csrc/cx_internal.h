@@ -155,6 +155,12 @@ struct cx_handle {
     uint8_t *d_chain_head_fwd = nullptr, *d_chain_head_bwd = nullptr;
     double2 *d_chain_side = nullptr;
     void *d_chain_totals = nullptr;
+    // the chain scan as ONE launch (cx_chain.hip: k_chain_onepass): tile totals + flags on the device, the word in mapped host memory that a
+    // workgroup raises when a wait of it times out (checked by every CX_HIP of the host: the call that finds it fails, the handle goes back to two launches)
+    void *d_chain_onepass = nullptr, *d_chain_abort = nullptr;
+    volatile unsigned *chain_abort_host = nullptr;
+    int chain_onepass_state = 0, chain_onepass_cus = 0;      // 0 not prepared, 1 ready, -1 off (CX_CHAIN_ONEPASS=0, no memory, or a wait once timed out)
+    int64_t chain_onepass_launches = 0;
     // dim 2..4 (cx_mvchain.hip): rule-table index of each link's two messages, side sums [nc][npos], tile totals of the map scan
     int32_t *d_chain_tab_fwd = nullptr, *d_chain_tab_bwd = nullptr;
     double *d_mvc_side = nullptr, *d_mvc_totals = nullptr;
@@ -318,6 +324,7 @@ void mv64_rows_gather(cx_handle *h, const double *src, const int32_t *d_idx, dou
 void mv64_set_point(cx_handle *h, double *dst, const int32_t *d_idx, const double *d_y, int64_t n);
 bool mv_rule_tables(int d, const double *A, const double *Q, double *out);
 size_t chain_total_bytes(int64_t nlinks);
+void chain_onepass_free(cx_handle *h);
 // chain scan for dim 2..4 (cx_mvchain.hip)
 int mvc_links_per_thread(int64_t nlinks);
 size_t mvc_prefix_doubles(int dim, int64_t nlinks, int K);

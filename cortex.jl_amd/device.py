@@ -114,6 +114,12 @@ class DeviceGraph:
         keys = ("links_per_block", "fan", "levels", "potentials", "compositions", "rules", "launches", "device_bytes")
         return dict(zip(keys, (int(x) for x in out)))
 
+    def chain_scan_stats(self):
+        """cx_chain_scan_stats: the scalar chain scan as one launch — state (1 ready, 0 not prepared, -1 off) and how many such launches ran"""
+        out = (C.c_int64 * 4)()
+        self._check(self.lib.cx_chain_scan_stats(self.h, out))
+        return {"state": int(out[0]), "launches": int(out[1])}
+
     def edge_index(self, variable_ids, factor_ids):
         v, f = _i64(np.atleast_1d(variable_ids)), _i64(np.atleast_1d(factor_ids))
         out = np.zeros(len(v), dtype=np.int64)

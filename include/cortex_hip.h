@@ -350,6 +350,13 @@ int32_t cx_graph_wire(cx_handle *h, int64_t n, const cx_item *signals, const cx_
  * passes of the reference's loop (the final marginal round included), plans kept, calls that replayed a kept plan, calls that had to
  * run the scheduler }.  Zeros before the first call and for other schedules. */
 int32_t cx_ref_plan_stats(const cx_handle *h, int64_t *out8);
+/* the scalar chain scan as ONE launch (CX_SCHED_CHAIN_SCAN, the scans of CX_SCHED_TREE's heavy paths, the variational families' state
+ * pass): a single-pass scan whose workgroups publish their tile totals behind flags instead of ending a kernel (csrc/cx_chain.hip:
+ * k_chain_onepass).  Taken when the whole grid is resident at once; every wait is bounded in time (0.5 s, CX_CHAIN_ONEPASS_TIMEOUT_MS) —
+ * a launch whose wait times out stores NOTHING, the next call that checks the device returns CX_ERR_DEVICE, the handle goes back to the
+ * two-launch scan and the caller repeats the sweep (a chain-scan sweep is exact whatever it starts from).  CX_CHAIN_ONEPASS=0 turns it off.
+ * out4 = { 1 ready / 0 not prepared / -1 off, launches of the one-launch form so far, 0, 0 }. */
+int32_t cx_chain_scan_stats(const cx_handle *h, int64_t *out4);
 /* the XCD-resident cluster (reference-order plans of many dependent stages of 1 - 16 k items — calls on loopy graphs — run as ONE launch
  * of the workgroups of one XCD behind barriers that stay in that XCD's L2): out4 = { 1 ready / 0 not prepared / -1 off
  * (CX_REF_CLUSTER=0, a device that is neither gfx942 nor gfx950, or a barrier once timed out), workgroups per launch (compute units),

@@ -106,6 +106,7 @@ class Handle {
     void sweep(int32_t n = 1) { check(cx_sweep(h_, n)); }
     // CX_SCHED_REFERENCE: ONE update_marginals!(engine, variable_ids) — the named variables in the caller's order, only what is pending for them
     void sweep_for(const std::vector<int64_t> &variable_ids) { check(cx_sweep_for(h_, (int64_t)variable_ids.size(), variable_ids.data())); }
+    std::array<int64_t, 4> chain_scan_stats() const { std::array<int64_t, 4> o{}; check(cx_chain_scan_stats(h_, o.data())); return o; }      // state, one-launch scans so far, 0, 0
     std::array<int64_t, 8> ref_plan_stats() const { std::array<int64_t, 8> o{}; check(cx_ref_plan_stats(h_, o.data())); return o; }      // stages, launches, executions, messages, passes, plans, hits, misses
     std::vector<cx_item> ref_trace() const {       // the executions of the last reference-order call, in the reference's order
         int64_t n = 0;

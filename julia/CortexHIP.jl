@@ -293,6 +293,13 @@ function chain_plan_stats(p)
     out
 end
 
+# the scalar chain scan as one launch: (1 ready / 0 not prepared / -1 off, launches of that form, 0, 0)
+function chain_scan_stats(p)
+    out = zeros(Int64, 4)
+    check(p.handle, ccall((:cx_chain_scan_stats, lib), Int32, (Ptr{Cvoid}, Ptr{Int64}), p.handle, out))
+    out
+end
+
 load_state!(p, path) = (buf = read(path); check(p.handle, ccall((:cx_state_import, lib), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int64), p.handle, buf, length(buf))))
 
 # deep halo: `exchange_every` plain sweeps between two state exchanges issued by the library over RCCL

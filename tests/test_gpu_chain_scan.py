@@ -266,3 +266,54 @@ def test_chain_scan_sees_data_changes_between_sweeps(hip_lib):
     assert_close(marg[:, 0], xm, 1e-9, "posterior mean after new data")
     assert_close(marg[:, 1], xv, 1e-9, "posterior variance after new data")
     assert not np.allclose(marg[:, 0], first[:, 0])
+
+
+@pytest.mark.parametrize("T", [1500, 70001, 250001])
+def test_the_one_launch_scan_equals_the_two_launch_scan(hip_lib, monkeypatch, T):
+    """(round 6) the chain scan as ONE launch (tile totals published behind flags, csrc/cx_chain.hip: k_chain_onepass) against the two
+    launches it replaces (CX_CHAIN_ONEPASS=0, read when a handle first scans): the same compositions in the same order — equal to a few
+    units in the last place (two kernels, two sets of fused multiply-adds) —, sweep after sweep (the epoch moves on inside the launch)."""
+    model = cx.synth.ssm_chain(T, seed=T + 1, random_variances=True)
+    a = cx.DeviceGraph(schedule=L.SCHED_CHAIN_SCAN)
+    cx.synth.load_into_device(model, a)
+    monkeypatch.setenv("CX_CHAIN_ONEPASS", "0")
+    b = cx.DeviceGraph(schedule=L.SCHED_CHAIN_SCAN)
+    cx.synth.load_into_device(model, b)
+    b.sweep(1)
+    monkeypatch.delenv("CX_CHAIN_ONEPASS")
+    tr = model.factor_ids[T:]
+    for sweep in range(4):
+        a.sweep(1)
+        if sweep:
+            b.sweep(1)
+        np.testing.assert_allclose(a.get_marginals(model.x_ids), b.get_marginals(model.x_ids), rtol=1e-13, atol=0, err_msg=f"sweep {sweep}")
+        for vs in (model.x_ids[:-1], model.x_ids[1:]):
+            np.testing.assert_allclose(a.get_messages(vs, tr, L.TO_VARIABLE, L.FORM_NATURAL), b.get_messages(vs, tr, L.TO_VARIABLE, L.FORM_NATURAL), rtol=1e-13, atol=1e-300)
+    sa, sb = a.chain_scan_stats(), b.chain_scan_stats()
+    assert sa["state"] == 1 and sa["launches"] == 4, sa
+    assert sb["state"] == -1 and sb["launches"] == 0, sb
+
+
+def test_a_one_launch_scan_whose_wait_times_out_fails_loudly_and_the_sweep_can_be_repeated(hip_lib, monkeypatch):
+    """fault injection: the first tile never publishes its forward total (what a workgroup that never becomes resident looks like).  The
+    waits are bounded in time; nobody stores anything; the next call that looks at the device returns CX_ERR_DEVICE; the handle goes
+    back to two launches, and repeating the sweep gives the exact result."""
+    T = 9000
+    model = cx.synth.ssm_chain(T, seed=5, random_variances=True)
+    dev = cx.DeviceGraph(schedule=L.SCHED_CHAIN_SCAN)
+    cx.synth.load_into_device(model, dev)
+    monkeypatch.setenv("CX_CHAIN_ONEPASS_FAULT", "1")
+    monkeypatch.setenv("CX_CHAIN_ONEPASS_TIMEOUT_MS", "20")
+    with pytest.raises(cx.CortexHipError, match="one-launch chain scan timed out") as ei:
+        dev.sweep(1)
+        dev.sync()
+        dev.get_marginals(model.x_ids)
+    assert ei.value.code == L.ERR_DEVICE
+    monkeypatch.delenv("CX_CHAIN_ONEPASS_FAULT")
+    assert dev.chain_scan_stats()["state"] == -1
+    dev.sweep(1)
+    marg = dev.get_marginals(model.x_ids)
+    xm, xv = exact.ssm_chain_posterior(model.data_y, model.meta["r"], model.meta["q"])
+    assert_close(marg[:, 0], xm, 1e-9, "marginal mean after the repeated sweep")
+    assert_close(marg[:, 1], xv, 1e-9, "marginal variance after the repeated sweep")
+    assert dev.chain_scan_stats()["launches"] == 1
