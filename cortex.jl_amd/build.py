@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcortex_hip.so")
-SOURCES = ["cx_api.hip", "cx_api_mv.hip", "cx_api_msg.hip", "cx_api_sweep.hip", "cx_api_halo.hip", "cx_api_ipc.hip", "cx_api_state.hip", "cx_api_ref.hip", "cx_health.hip", "cx_kernels.hip", "cx_batch.hip", "cx_kary.hip", "cx_kary_mv.hip", "cx_chain.hip", "cx_mv.hip", "cx_mvchain.hip", "cx_mv64chain.hip", "cx_mvbatch.hip", "cx_mv64.hip", "cx_mv64w.hip", "cx_comm.hip", "cx_vmp.hip"]
+SOURCES = ["cx_api.hip", "cx_api_mv.hip", "cx_api_msg.hip", "cx_api_sweep.hip", "cx_api_halo.hip", "cx_api_ipc.hip", "cx_api_state.hip", "cx_api_ref.hip", "cx_health.hip", "cx_kernels.hip", "cx_batch.hip", "cx_kary.hip", "cx_kary_mv.hip", "cx_chain.hip", "cx_planscan.hip", "cx_mv.hip", "cx_mvchain.hip", "cx_mv64chain.hip", "cx_mvbatch.hip", "cx_mv64.hip", "cx_mv64w.hip", "cx_comm.hip", "cx_vmp.hip"]
 # every header a source may include: a change in any of them rebuilds everything
 HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(ROOT, "include", "cortex_hip.h")]
 
@@ -21,7 +21,7 @@ HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith("
 # which sources a kernel's code comes from: a counter-traffic figure kept under profiles/ is only as good as the kernel it was
 # measured on, so the summaries store a hash of these files and bench.py refuses a figure whose kernel has changed since
 KERNEL_SOURCES = (("k_sweep_mv", ("cx_mv.hip", "cx_mv_core.h")), ("k_mvc_", ("cx_mvchain.hip", "cx_mv_core.h")),
-                  ("k_chain_", ("cx_chain.hip",)), ("k_rule64w", ("cx_mv64w.hip", "cx_mv64w_core.h")), ("k_compose64", ("cx_mv64chain.hip", "cx_mv64w_core.h")), ("k_walk64b", ("cx_mv64chain.hip", "cx_mv64w_core.h")), ("k_rule64", ("cx_mv64.hip",)),
+                  ("k_chain_", ("cx_chain.hip", "cx_lin.h")), ("k_pscan_", ("cx_planscan.hip", "cx_lin.h")), ("k_rule64w", ("cx_mv64w.hip", "cx_mv64w_core.h")), ("k_compose64", ("cx_mv64chain.hip", "cx_mv64w_core.h")), ("k_walk64b", ("cx_mv64chain.hip", "cx_mv64w_core.h")), ("k_rule64", ("cx_mv64.hip",)),
                   ("k_sweep", ("cx_kernels.hip", "cx_scalar_core.h")), ("k_batch", ("cx_batch.hip", "cx_scalar_core.h")), ("k_ref_cluster", ("cx_batch.hip", "cx_scalar_core.h")), ("k_mf_", ("cx_vmp.hip",)), ("k_rate", ("cx_vmp.hip",)), ("k_gamma", ("cx_vmp.hip",)),
                   ("k_set_q", ("cx_vmp.hip",)), ("k_pull", ("cx_vmp.hip",)), ("k_reduce", ("cx_vmp.hip",)))
 

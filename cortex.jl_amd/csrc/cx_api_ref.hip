@@ -24,6 +24,13 @@ struct PlanEntry {
     double *d_wide_partial = nullptr;           // 64 pairs of scratch per wide item of the widest stage (k_wide_sum)
     int64_t *d_stage_off = nullptr;
     std::vector<int64_t> stage_off, wide_off;
+    // chains of pairs that run as scans (cx_refsched.h: ScanStep; cx_planscan.hip): the links' arrays, the steps, the first step of every stage (-1: none)
+    std::vector<rs::ScanStep> scans;
+    std::vector<int32_t> scan_at;
+    int32_t *d_sl_lead_dst = nullptr, *d_sl_lead_var = nullptr, *d_sl_fol_dst = nullptr, *d_sl_prec = nullptr, *d_sl_src_off = nullptr, *d_sl_src = nullptr;
+    uint8_t *d_sl_head = nullptr;
+    void *d_scan_scratch = nullptr;
+    int64_t n_chain_exec = 0;
     hipGraphExec_t exec = nullptr;
     bool graph_failed = false;
     bool cluster = false;                       // every stage in ONE launch of an XCD-resident cluster (cx_batch.hip: k_ref_cluster)
@@ -63,8 +70,10 @@ RefSched *ref_of(cx_handle *h) { return (RefSched *)h->ref; }
 
 void entry_free(cx_handle *h, PlanEntry &e) {
     if (e.exec) { (void)hipGraphExecDestroy(e.exec); e.exec = nullptr; }
-    for (void *p : {(void *)e.d_rec, (void *)e.d_list, (void *)e.d_stage_off, (void *)e.d_wide_rec, (void *)e.d_flat, (void *)e.d_wide_partial}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)e.d_rec, (void *)e.d_list, (void *)e.d_stage_off, (void *)e.d_wide_rec, (void *)e.d_flat, (void *)e.d_wide_partial, (void *)e.d_sl_lead_dst, (void *)e.d_sl_lead_var,
+                    (void *)e.d_sl_fol_dst, (void *)e.d_sl_prec, (void *)e.d_sl_src_off, (void *)e.d_sl_src, (void *)e.d_sl_head, e.d_scan_scratch}) if (p) (void)hipFree(p);
     e.d_rec = e.d_list = e.d_wide_rec = e.d_flat = nullptr; e.d_stage_off = nullptr; e.d_wide_partial = nullptr;
+    e.d_sl_lead_dst = e.d_sl_lead_var = e.d_sl_fol_dst = e.d_sl_prec = e.d_sl_src_off = e.d_sl_src = nullptr; e.d_sl_head = nullptr; e.d_scan_scratch = nullptr;
     h->device_bytes -= e.device_bytes; e.device_bytes = 0;
 }
 
@@ -99,10 +108,19 @@ int64_t issue(cx_handle *h, RefSched *R, const PlanEntry &e, bool count_only) {
         return launches;
     }
     auto wide_at = [&](size_t s) { return e.wide_off.empty() ? (int64_t)0 : e.wide_off[s + 1] - e.wide_off[s]; };
+    // the scan steps of a stage (chains of pairs, cx_planscan.hip): beside the stage's items — they read nothing those write and the other way round
+    auto scans_of = [&](size_t s) {
+        if (e.scan_at.empty() || e.scan_at[s] < 0) return;
+        for (size_t k = (size_t)e.scan_at[s]; k < e.scans.size() && e.scans[k].stage == (int32_t)s + 1; k++) {
+            if (!count_only) cx::launch_plan_scan(h, e.d_sl_lead_dst, e.d_sl_lead_var, e.d_sl_fol_dst, e.d_sl_prec, e.d_sl_src_off, e.d_sl_src, e.d_sl_head, e.scans[k].lo, e.scans[k].hi, e.d_scan_scratch);
+            launches += 2;
+        }
+    };
+    auto has_scan = [&](size_t s) { return !e.scan_at.empty() && e.scan_at[s] >= 0; };
     for (size_t s = 0; s < ns;) {
         size_t t = s;
         const int64_t thin_max = e.d_flat && flat_runs() ? std::min<int64_t>(R->run_max, cx::flat_run_max()) : R->run_max;
-        while (t < ns && e.stage_off[t + 1] - e.stage_off[t] <= thin_max && wide_at(t) == 0) t++;
+        while (t < ns && e.stage_off[t + 1] - e.stage_off[t] <= thin_max && wide_at(t) == 0 && !has_scan(t)) t++;
         if (t >= s + 2) {
             if (!count_only) { if (e.d_flat && flat_runs()) cx::launch_flat_run(h, e.d_flat, e.d_rec, e.d_stage_off, (int)s, (int)t); else cx::launch_batch_run(h, e.d_rec, e.d_stage_off, (int)s, (int)t); }
             launches++; s = t; continue;
@@ -110,6 +128,7 @@ int64_t issue(cx_handle *h, RefSched *R, const PlanEntry &e, bool count_only) {
         const int64_t n = e.stage_off[s + 1] - e.stage_off[s], nw = wide_at(s);
         if (n > 0) { if (!count_only) cx::launch_batch(h, e.d_rec + 5 * e.stage_off[s], n); launches++; }
         if (nw > 0) { if (!count_only) cx::launch_wide_sum(h, e.d_wide_rec + 5 * e.wide_off[s], nw, e.d_wide_partial); launches += 2; }      // (independent of the stage's other items)
+        scans_of(s);
         s++;
     }
     return launches;
@@ -532,7 +551,12 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n, const uint64_t *k
             e.stage_off = P.stage_off; e.wide_off = P.wide_off;
             e.n_messages = P.n_messages; e.n_marginals = P.n_marginals; e.n_products = P.n_products; e.rounds = P.rounds; e.list_entries = (int64_t)P.list.size();
             // wide and deep: the cluster; chains of thin stages stay with one workgroup's runs (k_batch_run), short plans with plain launches
-            e.cluster = P.wide_rec.empty() && cluster_fits(h, P.stage_off, (int64_t)P.stage_off.size() - 1);
+            e.cluster = P.wide_rec.empty() && P.scans.empty() && cluster_fits(h, P.stage_off, (int64_t)P.stage_off.size() - 1);
+            e.scans = P.scans; e.n_chain_exec = P.n_chain_exec;
+            if (!P.scans.empty()) {
+                e.scan_at.assign(P.stage_off.size() - 1, -1);
+                for (size_t k = P.scans.size(); k-- > 0;) e.scan_at[P.scans[k].stage - 1] = (int32_t)k;
+            }
             // flat records: the cluster's, and the runs of thin stages' (k_flat_run) — items that load through 2 GiB buffer windows
             const int64_t two_gib = (int64_t)1 << 31;
             const bool want_flat = e.cluster || (h->cfg.dim == 1 && flat_runs() && h->nslots * 16 < two_gib && h->nv * 16 < two_gib && (int64_t)h->prod_index.size() * 16 < two_gib &&
@@ -546,6 +570,18 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n, const uint64_t *k
                 (rc2 = dev_upload(h, &e.d_wide_rec, P.wide_rec)) != CX_OK || (want_flat && (rc2 = dev_upload(h, &e.d_flat, flat)) != CX_OK) ||
                 (!P.wide_rec.empty() && (rc2 = dev_alloc(h, &e.d_wide_partial, (int64_t)(P.wide_rec.size() / 5) * 64 * 2)) != CX_OK)) {
                 e.device_bytes = h->device_bytes - before; entry_free(h, e); return rc2;
+            }
+            if (!P.scans.empty()) {
+                int64_t widest = 0;
+                for (auto &sc : P.scans) widest = std::max(widest, sc.hi - sc.lo);
+                char *scratch = nullptr;
+                if ((rc2 = dev_upload(h, &e.d_sl_lead_dst, P.sl_lead_dst)) != CX_OK || (rc2 = dev_upload(h, &e.d_sl_lead_var, P.sl_lead_var)) != CX_OK ||
+                    (rc2 = dev_upload(h, &e.d_sl_fol_dst, P.sl_fol_dst)) != CX_OK || (rc2 = dev_upload(h, &e.d_sl_prec, P.sl_prec)) != CX_OK ||
+                    (rc2 = dev_upload(h, &e.d_sl_src_off, P.sl_src_off)) != CX_OK || (rc2 = dev_upload(h, &e.d_sl_src, P.sl_src)) != CX_OK ||
+                    (rc2 = dev_upload(h, &e.d_sl_head, P.sl_head)) != CX_OK || (rc2 = dev_alloc(h, &scratch, cx::plan_scan_scratch_bytes(widest))) != CX_OK) {
+                    e.d_scan_scratch = scratch; e.device_bytes = h->device_bytes - before; entry_free(h, e); return rc2;
+                }
+                e.d_scan_scratch = scratch;
             }
             e.device_bytes = h->device_bytes - before;
             CX_HIP(h, hipStreamSynchronize(h->stream));      // the plan's host vectors die here

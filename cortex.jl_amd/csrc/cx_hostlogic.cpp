@@ -317,6 +317,7 @@ int32_t cxh_flat_halo(void *p, int64_t n, const int64_t *variable_ids, const int
 //   60 tree items (5 per item) 61 tree stage offsets 62 tree k-ary entries 63 their stage offsets 64 partner 65 slot_kary 66 kary_slot
 //   70.. heavy-path plan: 70 items 71 stage offsets 72 k-ary entries 73 their offsets 74 pos_var 75 skip0 76 skip1_up 77 skip1_down 78 link_pos 79 from 80 to
 //        81 head_fwd 82 head_bwd 83 pos_off 84 link_off 85 steps
+//   100 the plan's scan steps (stage, first link, end) 101 .. 107 the links: leader slot, leader variable, follower slot, precision variable, source offsets, sources, heads
 //   90 reference plan items (5 per item) 91 its stage offsets 92 its source lists 93 dep_off 94 dep 95 intermediate flags 96 signal flags 97 the last call's executions (signal numbers)
 //   40 pos_var 41 skip0 42 skip1 43 link_pos 44 from 45 to 46 head_fwd 47 head_bwd 48 tab_fwd 49 tab_bwd 50 trim_lo 51 trim_hi
 int64_t cxh_flat_array(const void *p, int32_t which, void *out) {
@@ -343,6 +344,10 @@ int64_t cxh_flat_array(const void *p, int32_t which, void *out) {
     case 90: return ints(g->rplan.rec); case 91: return ints(g->rplan.stage_off); case 92: return ints(g->rplan.list); case 93: return ints(g->rw.dep_off); case 94: return ints(g->rw.dep);
     case 95: return ints(g->rw.dep_inter); case 96: return ints(g->rs.flags); case 97: return ints(g->rcall.order);
     case 98: return ints(g->rplan.wide_rec); case 99: return ints(g->rplan.wide_off);
+    case 100: { if (out) for (size_t i = 0; i < g->rplan.scans.size(); i++) { ((int64_t *)out)[3 * i] = g->rplan.scans[i].stage; ((int64_t *)out)[3 * i + 1] = g->rplan.scans[i].lo; ((int64_t *)out)[3 * i + 2] = g->rplan.scans[i].hi; }
+                return (int64_t)g->rplan.scans.size() * 3; }
+    case 101: return ints(g->rplan.sl_lead_dst); case 102: return ints(g->rplan.sl_lead_var); case 103: return ints(g->rplan.sl_fol_dst); case 104: return ints(g->rplan.sl_prec);
+    case 105: return ints(g->rplan.sl_src_off); case 106: return ints(g->rplan.sl_src); case 107: return ints(g->rplan.sl_head);
     }
     return -1;
 }

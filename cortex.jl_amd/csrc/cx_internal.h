@@ -325,6 +325,11 @@ void mv64_set_point(cx_handle *h, double *dst, const int32_t *d_idx, const doubl
 bool mv_rule_tables(int d, const double *A, const double *Q, double *out);
 size_t chain_total_bytes(int64_t nlinks);
 void chain_onepass_free(cx_handle *h);
+// chains inside reference-order plans as scans (cx_planscan.hip)
+int64_t plan_scan_scratch_bytes(int64_t nlinks);
+int64_t plan_scan_max_links();
+void launch_plan_scan(cx_handle *h, const int32_t *lead_dst, const int32_t *lead_var, const int32_t *fol_dst, const int32_t *prec, const int32_t *src_off,
+                      const int32_t *src, const uint8_t *head, int64_t lo, int64_t hi, void *scratch);
 // chain scan for dim 2..4 (cx_mvchain.hip)
 int mvc_links_per_thread(int64_t nlinks);
 size_t mvc_prefix_doubles(int dim, int64_t nlinks, int K);

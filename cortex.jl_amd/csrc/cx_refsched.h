@@ -595,6 +595,18 @@ constexpr int64_t kWideList = 1024;
 // stage or later.
 constexpr int32_t kRecLeads = 0x40000000, kRecFollows = 0x20000000, kRecKindMask = 0x0fffffff;
 
+// A path inside a plan as ONE step (round 6).  On a state-space model the reference's call is a forward and a backward chain of pairs —
+// MessageToFactor(x_t, f_t) then MessageToVariable(x_t+1, f_t), each pair reading the one before it — and levelling gives every pair a
+// stage of its own: the wired variational SSM of the reference's tests at n = 10^5 is 100,001 stages of two pairs and a handful of
+// dependants, 1.1 us each.  But a pair is a projective-linear map of its incoming message (cx_chain.hip), so a chain of pairs whose
+// OTHER inputs are settled before it starts is a prefix scan.  level() finds such chains (kChainMin pairs or more), checks that nothing
+// of the call stands between their executions (below), gives ALL their executions the stage of the first pair, levels everything
+// else again around them, and hands the chains to the caller as scan steps: links in chain order with the list of settled sources
+// each leader adds to the message that travels.  The executions, their order and the values they read are the reference's; only the
+// association of the arithmetic differs (a scan composes maps where the sequence applies them one by one: equal to rounding).
+struct ScanStep { int32_t stage; int64_t lo, hi; };      // beside the items of stage `stage` (1-based): links [lo, hi)
+constexpr int64_t kChainMin = 128;
+constexpr int64_t kScanStepMaxLinks = (int64_t)2048 * 1024;      // cx_planscan.hip: every workgroup of a step composes the totals of the tiles before it
 struct Plan {
     std::vector<int32_t> rec;            // 5 per item, by stage
     std::vector<int64_t> stage_off;
@@ -602,12 +614,20 @@ struct Plan {
     std::vector<int64_t> wide_off;       // [stages + 1]
     std::vector<int32_t> list;           // sources of the list items
     int64_t n_exec = 0, n_messages = 0, n_marginals = 0, n_products = 0, n_joints = 0, rounds = 0;
+    // the chains that run as scans: per link the leader's MessageToFactor slot and variable, the follower's MessageToVariable slot, the
+    // precision variable whose marginal the follower's rule reads (-1: the sum-product rule of a pairwise factor), the first link of a chain,
+    // and the leader's settled sources (a factor→variable slot, or ~index of a node of the product store) in the reference's fold order
+    std::vector<ScanStep> scans;
+    std::vector<int32_t> sl_lead_dst, sl_lead_var, sl_fol_dst, sl_prec, sl_src_off, sl_src;
+    std::vector<uint8_t> sl_head;
+    int64_t n_chain_exec = 0;            // executions that run inside scan steps (not in `rec`)
 };
 
 // prod_slot(i): the index of segment-tree node i in the handle's product store; joint_slot(f): of factor f's joint marginal in the joint
 // store (the caller registers both)
 template <class H, class ProdSlot, class JointSlot>
-int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slot, JointSlot &&joint_slot, Plan &P, std::string &err, int64_t wide_list = kWideList) {
+int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slot, JointSlot &&joint_slot, Plan &P, std::string &err, int64_t wide_list = kWideList,
+              int64_t chain_min = -1) {
     const int64_t ne = W.ne, n = (int64_t)call.order.size();
     P = Plan();
     P.n_exec = n; P.rounds = call.rounds;
@@ -615,6 +635,7 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
     std::vector<int32_t> w_exec(W.nsig, -1), follower(n, -1);      // the execution that last wrote a signal in this call; the execution fused behind one
     std::vector<uint8_t> follows(n, 0);
     int32_t n_stages = 0;
+    if (chain_min < 0) { const char *e = std::getenv("CX_REF_CHAIN_MIN"); chain_min = e ? std::atoll(e) : kChainMin; }      // (0: no chains as scans — A/B, tests)
     auto is_wide = [&](int64_t s) { return !W.is_f2v(s) && !W.is_joint(s) && W.dep_off[s + 1] - W.dep_off[s] > wide_list; };
     // the MessageToFactor signal a MessageToVariable execution can be fused behind: the one message its rule reads (a pairwise sum-product
     // factor; the structured variational rule, which reads one message and the precision's marginal); -1: none
@@ -636,6 +657,11 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
     const bool mv = h->cfg.dim > 1;
     static const bool fuse_env = [] { const char *e = std::getenv("CX_REF_FUSE_PAIRS"); return !(e && e[0] == '0'); }();      // (A/B)
     const bool fuse_pairs = fuse_env && !mv;
+    // chains as scans: scalar Gaussian messages (the map algebra of cx_chain.hip), plans of a size whose bookkeeping (three ints per execution) is cheap
+    const bool contract = fuse_pairs && chain_min > 0 && n >= 2 * chain_min && n <= ((int64_t)1 << 23) && h->cfg.family != CX_FAMILY_NATURAL2;
+    std::vector<int32_t> prev_w, prev_r, cpred, leader_of, member;      // member[i] >= 0: execution i runs inside a scan step of that stage (second pass)
+    if (contract) { prev_w.assign(n, 0); prev_r.assign(n, 0); cpred.assign(n, -1); leader_of.assign(n, -1); }
+    bool second_pass = false;
     // what an execution reads beyond its dependency list: a sum-product rule reads the stored messages of ALL the factor's other edges
     auto unlisted_reads = [&](int64_t s, auto &&fn) {
         if (!W.is_f2v(s) || W.vrule[s - ne] != kRuleBP) return;
@@ -643,6 +669,10 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
         if (W.foff[f + 1] - W.foff[f] <= 2 && !W.custom) return;      // (pairwise, default wiring: the other edge is the dependency)
         for (int32_t k = W.foff[f]; k < W.foff[f + 1]; k++) if (W.fedge[k] != s - ne) fn((int64_t)W.fedge[k]);
     };
+    auto run_pass = [&]() {
+    std::fill(w_stage.begin(), w_stage.end(), 0); std::fill(r_stage.begin(), r_stage.end(), 0); std::fill(stage.begin(), stage.end(), 0);
+    std::fill(w_exec.begin(), w_exec.end(), -1); std::fill(follower.begin(), follower.end(), -1); std::fill(follows.begin(), follows.end(), 0);
+    n_stages = 0;
     for (int64_t i = 0; i < n; i++) {
         const int64_t s = call.order[i];
         // (the executions wander over tables of tens of millions of signals: what the ones to come will read is asked for ahead)
@@ -652,6 +682,16 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
             const int64_t a = call.order[i + 6];
             for (int64_t p = W.dep_off[a]; p < W.dep_off[a + 1] && p < W.dep_off[a] + 6; p++) { __builtin_prefetch(&w_stage[W.dep[p]]); __builtin_prefetch(&r_stage[W.dep[p]]); }
         }
+        if (second_pass && member[i] >= 0) {      // inside a scan step: every execution of the chain at the stage of its first pair
+            const int32_t stm = member[i];
+            const int64_t srcm = pair_source(s);
+            stage[i] = stm; w_stage[s] = stm; w_exec[s] = (int32_t)i;
+            for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) r_stage[W.dep[p]] = std::max(r_stage[W.dep[p]], stm);
+            if (srcm >= 0) r_stage[srcm] = std::max(r_stage[srcm], stm);
+            n_stages = std::max(n_stages, stm);
+            continue;
+        }
+        if (contract && !second_pass) { prev_w[i] = w_stage[s]; prev_r[i] = r_stage[s]; }
         int32_t st = std::max(w_stage[s], r_stage[s]) + 1;
         const int64_t src = fuse_pairs ? pair_source(s) : -1;
         if (src >= 0 && w_exec[src] >= 0 && follower[w_exec[src]] < 0 && !is_wide(src)) {
@@ -660,11 +700,17 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
             const int32_t j = w_exec[src], sy = stage[j];
             bool ok = std::max(w_stage[s], r_stage[s]) < sy;
             for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1] && ok; p++) if (W.dep[p] != src) ok = w_stage[W.dep[p]] < sy;
-            if (ok) { st = sy; follower[j] = (int32_t)i; follows[i] = 1; }
+            if (ok) { st = sy; follower[j] = (int32_t)i; follows[i] = 1; if (contract && !second_pass) leader_of[i] = j; }
         }
         if (!follows[i]) {
             for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) st = std::max(st, w_stage[W.dep[p]] + 1);
             unlisted_reads(s, [&](int64_t d) { st = std::max(st, w_stage[d] + 1); });
+            // (chains) a MessageToFactor whose stage is set by ONE message a fused pair of this call stored: that pair comes before it in a chain
+            if (contract && !second_pass && W.is_v2f(s))
+                for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) {
+                    const int32_t k = w_exec[W.dep[p]];
+                    if (k >= 0 && follows[k] && stage[k] == st - 1) cpred[i] = cpred[i] == -1 ? k : -2;
+                }
         }
         stage[i] = st; w_stage[s] = st; w_exec[s] = (int32_t)i;
         for (int64_t p = W.dep_off[s]; p < W.dep_off[s + 1]; p++) r_stage[W.dep[p]] = std::max(r_stage[W.dep[p]], st);
@@ -672,13 +718,101 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
         unlisted_reads(s, [&](int64_t d) { r_stage[d] = std::max(r_stage[d], st); });
         n_stages = std::max(n_stages, st);
     }
+    };
+    run_pass();
+    // ---- chains of pairs as scan steps --------------------------------------------------------------------------------------------------
+    struct ChainRun { int32_t stage; std::vector<int32_t> leaders; };
+    std::vector<ChainRun> chain_runs;
+    if (contract) {
+        const std::vector<int32_t> w_final(w_stage);      // the stage of the LAST write of every signal in this call
+        std::vector<int32_t> succ(n, -1), predp(n, -1);
+        for (int64_t j = 0; j < n; j++) {
+            if (follower[j] < 0 || cpred[j] < 0) continue;
+            const int32_t lp = leader_of[cpred[j]];
+            if (lp >= 0 && succ[lp] < 0) { succ[lp] = (int32_t)j; predp[j] = lp; }
+        }
+        member.assign(n, -1);
+        for (int64_t j0 = 0; j0 < n; j0++) {
+            if (follower[j0] < 0 || predp[j0] >= 0) continue;
+            std::vector<int32_t> c;
+            for (int32_t j = (int32_t)j0; j >= 0; j = succ[j]) c.push_back(j);
+            if ((int64_t)c.size() < chain_min || (int64_t)c.size() > kScanStepMaxLinks) continue;
+            // Nothing of the call may stand between the chain's executions: what they read from outside is last written before the first
+            // pair's stage (so no execution that depends on the chain feeds it), and what they overwrite was last read and written before
+            // it (so nobody waits for the OLD value while the chain runs ahead).  Then every other execution either comes before the
+            // chain or can come after ALL of it.
+            const int32_t s0 = stage[c[0]];
+            bool ok = true;
+            for (size_t t = 0; t < c.size() && ok; t++) {
+                const int32_t Lx = c[t], Fx = follower[Lx];
+                const int64_t sL = call.order[Lx], sF = call.order[Fx], chain_in = t ? (int64_t)call.order[follower[c[t - 1]]] : -1;
+                ok = prev_w[Lx] < s0 && prev_r[Lx] < s0 && prev_w[Fx] < s0 && prev_r[Fx] < s0 && !is_wide(sL);
+                // (the slot must take part in the sum: the leader of an observed variable stores nothing — not a link)
+                ok = ok && !(h->vinfo[h->edge_var[sL]] & (cx::kClamped | cx::kGhost));
+                for (int64_t p = W.dep_off[sL]; p < W.dep_off[sL + 1] && ok; p++) if (W.dep[p] != chain_in) ok = w_final[W.dep[p]] < s0;
+                for (int64_t p = W.dep_off[sF]; p < W.dep_off[sF + 1] && ok; p++) if (W.dep[p] != sL) ok = w_final[W.dep[p]] < s0;
+                if (ok && t) {      // the message that travels must be a listed source of the next leader
+                    bool listed = false;
+                    for (int64_t p = W.dep_off[sL]; p < W.dep_off[sL + 1]; p++) listed = listed || W.dep[p] == chain_in;
+                    ok = listed;
+                }
+            }
+            if (!ok) continue;
+            for (int32_t Lx : c) { member[Lx] = s0; member[follower[Lx]] = s0; }
+            chain_runs.push_back(ChainRun{s0, std::move(c)});
+        }
+        if (!chain_runs.empty()) {
+            // the pairs keep their records' order; everything else is levelled again around the chains
+            std::vector<int32_t> fol1(follower);
+            second_pass = true;
+            run_pass();
+            for (auto &cr : chain_runs) for (int32_t Lx : cr.leaders) { follower[Lx] = -1; (void)fol1; }
+            // stages that the chains' executions left empty disappear
+            std::vector<int32_t> used(n_stages + 1, 0), remap(n_stages + 1, 0);
+            for (int64_t i = 0; i < n; i++) used[stage[i]] = 1;
+            int32_t m = 0;
+            for (int32_t st = 1; st <= n_stages; st++) if (used[st]) remap[st] = ++m;
+            for (int64_t i = 0; i < n; i++) stage[i] = remap[stage[i]];
+            for (auto &cr : chain_runs) cr.stage = remap[cr.stage];
+            n_stages = m;
+            // the links, by stage and chain
+            std::stable_sort(chain_runs.begin(), chain_runs.end(), [](const ChainRun &x, const ChainRun &y) { return x.stage < y.stage; });
+            P.sl_src_off.push_back(0);
+            for (auto &cr : chain_runs) {
+                if (P.scans.empty() || P.scans.back().stage != cr.stage || P.scans.back().hi - P.scans.back().lo + (int64_t)cr.leaders.size() > kScanStepMaxLinks) P.scans.push_back(ScanStep{cr.stage, (int64_t)P.sl_head.size(), (int64_t)P.sl_head.size()});
+                for (size_t t = 0; t < cr.leaders.size(); t++) {
+                    const int32_t Lx = cr.leaders[t], Fx = fol1[Lx];
+                    const int64_t sL = call.order[Lx], sF = call.order[Fx], eF = sF - ne, chain_in = t ? (int64_t)call.order[fol1[cr.leaders[t - 1]]] : -1;
+                    P.sl_lead_dst.push_back(flat::slot_of_edge_t(h, sL)); P.sl_lead_var.push_back(h->edge_var[sL]);
+                    P.sl_fol_dst.push_back(flat::slot_of_edge_t(h, eF));
+                    int32_t prec = -1;
+                    if (W.vrule[eF] == kRuleStNormal) {
+                        const int32_t f = W.efac[eF];
+                        for (int32_t k = W.foff[f]; k < W.foff[f + 1]; k++) if (h->np_role[W.fedge[k]] == CX_ROLE_PRECISION) prec = h->edge_var[W.fedge[k]];
+                    }
+                    P.sl_prec.push_back(prec);
+                    P.sl_head.push_back(t == 0 ? 1 : 0);
+                    for (int64_t p = W.dep_off[sL]; p < W.dep_off[sL + 1]; p++) {
+                        const int64_t d = W.dep[p];
+                        if (d == chain_in) continue;
+                        P.sl_src.push_back(W.is_f2v(d) ? flat::slot_of_edge_t(h, d - ne) : ~(int32_t)prod_slot(d - W.sig_prod(0)));
+                    }
+                    P.sl_src_off.push_back((int32_t)P.sl_src.size());
+                    P.n_messages += 2; P.n_chain_exec += 2;
+                }
+                P.scans.back().hi = (int64_t)P.sl_head.size();
+            }
+        } else member.clear();
+    }
+    const bool have_chains = !chain_runs.empty();
+    auto in_chain = [&](int64_t i) { return have_chains && member[i] >= 0; };
     // (only products — MessageToFactor, marginals, segment-tree nodes — can be wide: the rules read at most three sources)
     P.stage_off.assign(n_stages + 1, 0); P.wide_off.assign(n_stages + 1, 0);
     int64_t n_wide = 0;
-    for (int64_t i = 0; i < n; i++) { if (is_wide(call.order[i])) { P.wide_off[stage[i]]++; n_wide++; } else P.stage_off[stage[i]]++; }
+    for (int64_t i = 0; i < n; i++) { if (in_chain(i)) continue; if (is_wide(call.order[i])) { P.wide_off[stage[i]]++; n_wide++; } else P.stage_off[stage[i]]++; }
     for (int32_t s = 0; s < n_stages; s++) { P.stage_off[s + 1] += P.stage_off[s]; P.wide_off[s + 1] += P.wide_off[s]; }
     if (mv && n_wide) return fail_(err, CX_ERR_UNSUPPORTED, "reference schedule, dim > 1: a product of more than 1,024 sources is summed by a workgroup for scalar messages only");
-    P.rec.assign(5 * (n - n_wide), 0); P.wide_rec.assign(5 * n_wide, 0);
+    P.rec.assign(5 * (n - n_wide - P.n_chain_exec), 0); P.wide_rec.assign(5 * n_wide, 0);
     std::vector<int64_t> fill(P.stage_off.begin(), P.stage_off.end() - 1), wfill(P.wide_off.begin(), P.wide_off.end() - 1);
     auto source = [&](int64_t d) -> int32_t {       // a dependency of a list item as a list entry
         if (W.is_f2v(d)) return flat::slot_of_edge_t(h, d - ne);
@@ -688,8 +822,8 @@ int32_t level(const H *h, const Wiring &W, const Call &call, ProdSlot &&prod_slo
     // in execution order, a follower right behind its leader (both fill the same stage's list, one after the other)
     std::vector<int32_t> emit_order;
     emit_order.reserve(n);
-    for (int64_t i = 0; i < n; i++) { if (follows[i]) continue; emit_order.push_back((int32_t)i); if (follower[i] >= 0) emit_order.push_back(follower[i]); }
-    for (int64_t q = 0; q < n; q++) {
+    for (int64_t i = 0; i < n; i++) { if (follows[i] || in_chain(i)) continue; emit_order.push_back((int32_t)i); if (follower[i] >= 0) emit_order.push_back(follower[i]); }
+    for (int64_t q = 0; q < (int64_t)emit_order.size(); q++) {
         const int64_t i = emit_order[q];
         const int64_t s = call.order[i];
         int32_t *r = is_wide(s) ? &P.wide_rec[5 * wfill[stage[i] - 1]++] : &P.rec[5 * fill[stage[i] - 1]++];

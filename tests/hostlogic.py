@@ -83,6 +83,7 @@ _ARR = {"var_ids": 0, "var_off": 1, "edge_var": 2, "edge_fac_id": 3, "vbase": 4,
         "trim_lo": 50, "trim_hi": 51, "hp_rec": 70, "hp_stage_off": 71, "hp_kary": 72, "hp_kary_off": 73, "hp_pos_var": 74, "hp_skip0": 75, "hp_skip1_up": 76, "hp_skip1_down": 77,
         "hp_link_pos": 78, "hp_from": 79, "hp_to": 80, "hp_head_fwd": 81, "hp_head_bwd": 82, "hp_pos_off": 83, "hp_link_off": 84, "hp_steps": 85,
         "ref_rec": 90, "ref_stage_off": 91, "ref_list": 92, "ref_dep_off": 93, "ref_dep": 94, "ref_dep_inter": 95, "ref_flags": 96, "ref_order": 97, "ref_wide_rec": 98, "ref_wide_off": 99,
+        "ref_scans": 100, "ref_sl_lead_dst": 101, "ref_sl_lead_var": 102, "ref_sl_fol_dst": 103, "ref_sl_prec": 104, "ref_sl_src_off": 105, "ref_sl_src": 106, "ref_sl_head": 107,
         "tree_rec": 60, "tree_stage_off": 61, "tree_kary": 62, "tree_kary_off": 63, "partner": 64, "slot_kary_all": 65,
         "kary_slot_all": 66}
 _SCA = {"nv": 0, "nf": 1, "ne": 2, "nslots": 3, "nslices": 4, "n_messages_per_sweep": 5, "any_linear": 6, "n_kary": 7, "big_start": 8, "npos_linked": 9,

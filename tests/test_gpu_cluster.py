@@ -89,14 +89,22 @@ def test_a_small_grid_stays_with_one_workgroups_runs(hip_lib):
     assert dev.cluster_stats()["state"] == 1 and not dev.cluster_stats()["last_reference_call"]
 
 
-def test_plans_of_thin_stages_and_short_plans_stay_with_launches(hip_lib):
+def test_plans_of_thin_stages_and_short_plans_stay_with_launches(hip_lib, monkeypatch):
+    monkeypatch.setenv("CX_REF_CHAIN_MIN", "0")      # (the chains of this plan as stages, not as the scan steps of round 6: tests/test_gpu_reference_schedule.py)
     chain = cx.synth.ssm_chain(400, seed=1)
     dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
     cx.synth.load_into_device(chain, dev)
     dev.sweep_for(chain.x_ids)
     st = dev.cluster_stats()
-    assert st["state"] == 1 and not st["last_reference_call"], st      # 800 stages of a few items: one workgroup's own barrier (k_batch_run)
+    assert st["state"] == 1 and not st["last_reference_call"], st      # 400 stages of a few items: one workgroup's own barrier (k_batch_run)
     assert dev.ref_plan_stats()["launches"] == 1
+    monkeypatch.delenv("CX_REF_CHAIN_MIN")
+    scans = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
+    cx.synth.load_into_device(chain, scans)
+    scans.sweep_for(chain.x_ids)
+    st = scans.ref_plan_stats()
+    assert st["stages"] <= 4 and st["launches"] <= 6, st              # the same call with its two chains as scan steps
+    assert_close(scans.get_marginals(chain.x_ids), dev.get_marginals(chain.x_ids), 1e-10, "chains as scan steps == chains as stages", scale_by="max")
 
 
 @pytest.mark.parametrize("fault_stage", [1, 700])

@@ -344,7 +344,8 @@ def test_config_c1_through_the_plugin_in_reference_mode(hip_lib):
     want = [(kinds[type(v)], int(v.variable_id), int(getattr(v, "factor_id", 0) or 0), 0, 0) for v in order_cpu]
     assert proc.dev.ref_trace() == want, "the library's execution trace == the host scheduler's with the CPU processor"
     st = proc.dev.ref_plan_stats()
-    assert proc.launches == 1 and st["executions"] == 5 * n - 4 + n and st["launches"] < st["stages"]
+    # (round 6) the forward and the backward pass are chains of pairs: two scan steps beside a handful of stages, not 1,001 stages
+    assert proc.launches == 1 and st["executions"] == 5 * n - 4 + n and st["stages"] <= 4 and st["launches"] <= 6, st
     # new data, same request: the readiness state before the call is the one the second plan was made for from then on
     rng = np.random.default_rng(9)
     for it in range(3):

@@ -46,6 +46,24 @@ def test_structured_wiring_on_the_device_with_the_mixed_request(hip_lib, n):
     np.testing.assert_allclose(jm[:, 1], xs[1:, 0], rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("n,chain_min", [(12, 3), (33, 3), (100, 8), (300, None)])
+def test_structured_wiring_with_its_chains_as_scan_steps(hip_lib, monkeypatch, n, chain_min):
+    """(round 6) the states' call of the structured wiring is the reference's forward / backward pass: two chains of pairs whose follower is
+    the structured rule N(mean m, 1 / (var m + 1 / E[precision])).  They run as prefix scans (cx_planscan.hip) inside the reference-order
+    plan — the executions the library reports and every marginal after every call stay the restated engine's, the mixed request included;
+    the plan of the states' call is a handful of stages instead of n."""
+    if chain_min is not None:
+        monkeypatch.setenv("CX_REF_CHAIN_MIN", str(chain_min))      # (read when a plan is levelled; the default is 128 pairs)
+    iters = 3
+    data = vs.dataset(n, seed=21)
+    _, want = _run(ws.TracedOracleBackend(vs.structured_rule), "structured", data, iters)
+    be = ws.DeviceBackend()
+    _, got = _run(be, "structured", data, iters)
+    _compare(got, want, 1e-9, f"structured n={n}, chains as scans")
+    st = be.dev.ref_plan_stats()      # the last call of the experiment: the states together with both precisions
+    assert st["executions"] >= 4 * (n - 1) and st["stages"] <= 40, st
+
+
 @pytest.mark.parametrize("K,seed", [(6, 0), (25, 1), (200, 2)])
 def test_a_tree_of_means_with_grouped_precisions_on_the_device(hip_lib, K, seed):
     _, want = _run_tree(ws.TracedOracleBackend(vs.structured_rule), K, seed, 4)

@@ -60,11 +60,45 @@ class NumpyDevice:
     def set(self, buf, v, f, mean, variance):
         getattr(self, buf)[self.slot[(int(v), int(f))]] = (mean / variance, 1.0 / variance)
 
+    def scan_links(self, s, reads, writes, new):
+        """the scan steps of stage s (cx_refsched.h: ScanStep; cx_planscan.hip runs them as prefix scans): link by link, in chain order — the
+        leader's sum over its settled sources and the message the pair before it stored, then the follower's rule"""
+        g = self.g
+        scans = g.arr("ref_scans").reshape(-1, 3)
+        if not len(scans):
+            return 0
+        ld, lv, fd, pr, so, sr, hd = (g.arr("ref_sl_" + k) for k in ("lead_dst", "lead_var", "fol_dst", "prec", "src_off", "src", "head"))
+        n = 0
+        for st, lo, hi in scans:
+            if st != s + 1:
+                continue
+            m = None
+            for l in range(lo, hi):
+                assert pr[l] < 0, "this runner holds the sum-product rules only"
+                if hd[l]:
+                    m = np.zeros(2)
+                else:
+                    assert m is not None
+                src = [("f2v", int(t)) if t >= 0 else ("prod", int(~t)) for t in sr[so[l]:so[l + 1]]]
+                vals = np.array([getattr(self, b)[i] for b, i in src]).reshape(-1, 2)
+                assert not np.any(np.isnan(vals)), f"stage {s}: a link's settled source is undefined"
+                v = m + vals.sum(axis=0)
+                qq = self.q[fd[l]]
+                m = np.array([(v[0] / v[1]) / (1.0 / v[1] + qq), 1.0 / (1.0 / v[1] + qq)])
+                reads.update(src)
+                for dst, out in ((("v2f", int(ld[l])), tuple(v)), (("f2v", int(fd[l])), tuple(m))):
+                    assert dst not in writes, f"stage {s}: a link writes {dst} twice"
+                    writes.add(dst); new.append((dst, out))
+                n += 2
+        return n
+
     def run(self, rec, stage_off, lists):
         LEADS, FOLLOWS, MASK = 0x40000000, 0x20000000, 0x0fffffff      # cx_refsched.h: a record that leads is followed by one the same thread computes behind it
+        self.chain_executions = 0
         for s in range(len(stage_off) - 1):
             items = rec[5 * stage_off[s]:5 * stage_off[s + 1]].reshape(-1, 5)
             reads, writes, new = set(), set(), []
+            self.chain_executions += self.scan_links(s, reads, writes, new)
             leader_out = None                 # (destination, value) of the leader the next record follows
             for k, idx, v, lo, hi in items:
                 flags, k = int(k) & ~MASK, int(k) & MASK
@@ -180,8 +214,8 @@ def test_order_and_levelled_values_on_loopy_graphs(name):
         rc, err = g.ref_level()
         assert rc == 0, err
         rec, off, lists = g.arr("ref_rec"), g.arr("ref_stage_off"), g.arr("ref_list")
-        assert off[-1] == len(rows) and len(rec) == 5 * len(rows)
         dev.run(rec, off, lists)
+        assert off[-1] + dev.chain_executions == len(rows) and len(rec) == 5 * off[-1]
         _check_values(dev, E, model, request, f"{name} call {call + 1}")
     if name.startswith("grid"):
         assert hashes[2] == hashes[3], "on a grid the readiness state before a call repeats from the second call on: the plan is reused"
@@ -213,6 +247,65 @@ def test_the_reference_state_space_model(T):
                 assert len(off) - 1 <= 4 * T, "stages grow with the depth of the dependency chains, not with the number of messages"
         else:
             assert len(rows) == 0, "a second call without new data computes nothing (lazy)"
+
+
+@pytest.mark.parametrize("T,chain_min", [(40, 8), (300, 128), (300, 16), (1000, 128)])
+def test_the_chains_of_a_state_space_model_run_as_scan_steps(monkeypatch, T, chain_min):
+    """(round 6) the forward and the backward pass of the reference's call on a state-space model are two chains of pairs: level() hands
+    them out as scan steps (every execution of a chain at the stage of its first pair), everything else is levelled around them — a
+    handful of stages instead of T —, and the values are the engine's"""
+    monkeypatch.setenv("CX_REF_CHAIN_MIN", str(chain_min))
+    model = cx.synth.ssm_chain(T, seed=T, random_variances=True)
+    g = _flat(model)
+    E = engine_oracle_from_model(model, trace=True)
+    dev = NumpyDevice(g, model)
+    g.ref_set(L.TO_FACTOR, model.data_var, model.data_fac)
+    for v, f, y in zip(model.data_var, model.data_fac, model.data_y):
+        dev.v2f[dev.slot[(int(v), int(f))]] = (y, np.inf)
+    rows = g.ref_update(model.x_ids)
+    E.update_marginals(model.x_ids)
+    assert [tuple(r[:5]) for r in rows.tolist()] == _oracle_rows(E)
+    rc, err = g.ref_level()
+    assert rc == 0, err
+    off, scans = g.arr("ref_stage_off"), g.arr("ref_scans").reshape(-1, 3)
+    dev.run(g.arr("ref_rec"), off, g.arr("ref_list"))
+    _check_values(dev, E, model, model.x_ids, f"chain T={T} as scans")
+    assert len(scans) >= 1 and len(off) - 1 <= 8, (scans, len(off) - 1)
+    assert dev.chain_executions >= 4 * (T - 1) - 8 and off[-1] + dev.chain_executions == len(rows)
+    assert int(g.arr("ref_sl_head").sum()) == 2, "two chains: the forward and the backward pass"
+    monkeypatch.setenv("CX_REF_CHAIN_MIN", "0")
+    rc, err = g.ref_level()
+    assert rc == 0 and len(g.arr("ref_scans")) == 0 and len(g.arr("ref_stage_off")) - 1 >= T - 1
+
+
+@pytest.mark.parametrize("name", ["grid8x9", "grid17x23", "random", "hubs"])
+def test_chains_found_inside_loopy_plans_keep_the_engines_values(monkeypatch, name):
+    """the same with a threshold of three pairs on graphs with loops, where chains of pairs run along rows between executions that read
+    and overwrite their neighbours: whatever level() accepts as a scan step must leave the engine's values, call after call"""
+    monkeypatch.setenv("CX_REF_CHAIN_MIN", "3")
+    model = _models()[name]
+    g = _flat(model)
+    E = engine_oracle_from_model(model, trace=True)
+    dev = NumpyDevice(g, model)
+    _seed(g, E, dev, model)
+    _set_priors(g, E, dev, model)
+    found = 0
+    rng = np.random.default_rng(4)
+    for call in range(5):
+        if call:
+            _set_priors(g, E, dev, model)
+        request = model.x_ids if call < 3 else rng.permutation(model.x_ids)[: len(model.x_ids) // 2]
+        rows = g.ref_update(request)
+        E.update_marginals(request)
+        assert [tuple(r[:5]) for r in rows.tolist()] == _oracle_rows(E)
+        rc, err = g.ref_level()
+        assert rc == 0, err
+        off = g.arr("ref_stage_off")
+        dev.run(g.arr("ref_rec"), off, g.arr("ref_list"))
+        assert off[-1] + dev.chain_executions == len(rows)
+        found += dev.chain_executions
+        _check_values(dev, E, model, request, f"{name} call {call + 1} with chains as scans")
+    print(f"{name}: {found} executions ran inside scan steps")      # (on these graphs level() mostly refuses: a chain's neighbours are rewritten within the call)
 
 
 def test_trees_partial_requests_compute_only_what_they_need():
