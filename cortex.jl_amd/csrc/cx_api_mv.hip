@@ -271,8 +271,9 @@ int32_t build_work64(cx_handle *h) {
         // order), rule-table index, destination slot, flags
         int32_t others[3] = {-1, -1, -1};
         int n_others = 0;
+        const int32_t stride = cx::slot_stride(h, v);      // (a variable of degree > 8 lives in the CSR tail: consecutive slots)
         for (int32_t j = 0; j < deg; j++) {
-            const int32_t sj = h->vbase[v] + j * cx::kBlock;
+            const int32_t sj = h->vbase[v] + j * stride;
             if (sj != s && n_others < 3) others[n_others++] = sj;
         }
         if (deg > 4) {      // more than three other messages: k_v2f64 sums them into the stored variable→factor message, the rule reads that
@@ -555,7 +556,7 @@ int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
             }
         } else if (it.kind == CX_ITEM_PRODUCT_OF_MESSAGES) {
             // ProductOfMessages(variable_id, range, ...), inference_signal.jl:62-66 (the range travels in factor_id): what the reference's
-            // default resolver creates for a variable of degree > 5 (src/dependencies.jl:90-173) — dim > 1 takes degrees up to 8
+            // default resolver creates for a variable of degree > 5 (src/dependencies.jl:90-173)
             var = find_var(h, it.variable_id);
             if (var < 0) return fail(h, CX_ERR_NOT_FOUND, "unknown variable id " + std::to_string(it.variable_id));
             const int64_t lo = (int64_t)((uint64_t)it.factor_id >> 32), hi = (int64_t)((uint64_t)it.factor_id & 0xffffffffu);
@@ -568,8 +569,8 @@ int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
             if (pit == h->prod_index.end()) pit = h->prod_index.emplace(key, (int32_t)h->prod_index.size()).first;
             idx = pit->second; tab = lo;
             if (d64) {
-                prod_rec.insert(prod_rec.end(), {(int32_t)idx, (int32_t)(hi - lo + 1)});
-                for (int64_t j = lo - 1; j < lo - 1 + 8; j++) prod_rec.push_back(j < hi ? h->vbase[var] + (int32_t)j * cx::kBlock : -1);
+                const int32_t stride = cx::slot_stride(h, (int32_t)var);
+                prod_rec.insert(prod_rec.end(), {(int32_t)idx, (int32_t)(hi - lo + 1), h->vbase[var] + (int32_t)(lo - 1) * stride, stride});
                 continue;
             }
             rec[5 * i + 4] = (int32_t)hi;
@@ -592,12 +593,12 @@ int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
         CX_HIP(h, hipMemcpyAsync(h->d_stage, rec.data(), 5 * n * 4, hipMemcpyHostToDevice, h->stream));
         cx::mv_launch_batch(h, (const int32_t *)h->d_stage, n);
     } else {
-        const int64_t n1 = (int64_t)v2f_slots.size(), n2 = (int64_t)point_slots.size(), n3 = (int64_t)rule_rec.size() / 8, n4 = (int64_t)prod_rec.size() / 10;
-        if ((rc = ensure_stage(h, (2 * n1 + n2 + 8 * n3 + 10 * n4 + 4) * 4)) != CX_OK) return rc;
+        const int64_t n1 = (int64_t)v2f_slots.size(), n2 = (int64_t)point_slots.size(), n3 = (int64_t)rule_rec.size() / 8, n4 = (int64_t)prod_rec.size() / 4;
+        if ((rc = ensure_stage(h, (2 * n1 + n2 + 8 * n3 + 4 * n4 + 4) * 4)) != CX_OK) return rc;
         int32_t *d = (int32_t *)h->d_stage;
         int32_t *d_s = d, *d_v = d + n1, *d_p = d + 2 * n1, *d_r = d + 2 * n1 + n2, *d_q = d + 2 * n1 + n2 + 8 * n3;
         if (n4) {
-            CX_HIP(h, hipMemcpyAsync(d_q, prod_rec.data(), n4 * 40, hipMemcpyHostToDevice, h->stream));
+            CX_HIP(h, hipMemcpyAsync(d_q, prod_rec.data(), n4 * 16, hipMemcpyHostToDevice, h->stream));
             cx::mv64_launch_range_sums(h, (int)n4, d_q, h->d_mv_f2v, h->d_mv_prod);
         }
         if (n1) { CX_HIP(h, hipMemcpyAsync(d_s, v2f_slots.data(), n1 * 4, hipMemcpyHostToDevice, h->stream)); CX_HIP(h, hipMemcpyAsync(d_v, v2f_vars.data(), n1 * 4, hipMemcpyHostToDevice, h->stream)); }
@@ -658,6 +659,7 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
         if (h->cfg.dim == 64) {
             cx::mv64_launch_v2f(h, (int)h->n_pre64, h->d_pre64_slots, h->d_pre64_vars, h->d_mv_f2v);      // senders of degree 5 .. 8
             cx::mv64_launch_rule(h, (int)h->n_rule64, h->d_rule64_rec, h->d_mv_f2v, h->d_mv_f2v_alt, CX_KERNEL_FUSED);
+            cx::mv64_launch_damp(h, (int)h->n_rule64, h->d_rule64_rec, h->d_mv_f2v, h->d_mv_f2v_alt, h->damping);
         } else {
             if (h->observed_passes_due > 0) { cx::mv_launch_sweep(h, false, 1); h->observed_passes_due--; }
             cx::mv_launch_sweep(h, h->cfg.compute_marginals_in_sweep != 0, 0);

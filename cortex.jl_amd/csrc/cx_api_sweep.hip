@@ -245,11 +245,12 @@ int32_t build_tree(cx_handle *h) {
                     const int32_t deg = h->var_off[u + 1] - h->var_off[u];
                     int32_t others[3] = {-1, -1, -1};
                     int n_others = 0;
+                    const int32_t stride = cx::slot_stride(h, u);
                     for (int32_t j = 0; j < deg; j++) {
-                        const int32_t sj = h->vbase[u] + j * cx::kBlock;
+                        const int32_t sj = h->vbase[u] + j * stride;
                         if (sj != sl && n_others < 3) others[n_others++] = sj;
                     }
-                    if (deg > 4) {      // a sender of degree 5 .. 8: its other messages (final by now) are summed by k_v2f64 first, the rule reads the sum
+                    if (deg > 4) {      // a sender of degree 5 or more: its other messages (final by now) are summed by k_v2f64 first, the rule reads the sum
                         pre_s.push_back(sl); pre_v.push_back(u);
                         rec.insert(rec.end(), {sl, -1, -1, -1, h->spdir[sl], dst, 1, 0});
                     } else
@@ -533,7 +534,7 @@ int32_t cx_set_damping(cx_handle *h, double lambda) {
     CX_REQUIRE(h, lambda >= 0.0 && lambda < 1.0, CX_ERR_INVALID_ARGUMENT, "cx_set_damping: 0 <= lambda < 1");
     CX_REQUIRE(h, lambda == 0.0 || h->cfg.schedule == CX_SCHED_FUSED || h->cfg.schedule == CX_SCHED_FLOODING, CX_ERR_UNSUPPORTED,
                "cx_set_damping: the fused and flooding schedules iterate to a fixed point and can be damped; the chain-scan, tree and reference-order schedules are exact or sequential passes");
-    CX_REQUIRE(h, lambda == 0.0 || (h->cfg.dim >= 1 && h->cfg.dim <= 4), CX_ERR_UNSUPPORTED, "cx_set_damping: dim 1 to 4");
+    // (round 6: dim 64, and 5 .. 63 embedded in it, too: the rule's output mixed with the message it replaces, cx_mv64.hip: k_damp64)
     CX_REQUIRE(h, lambda == 0.0 || h->halo_state || (h->send_slots.empty() && h->recv_slots.empty()), CX_ERR_UNSUPPORTED,
                "cx_set_damping: not with per-sweep message halos (cx_halo_configure); state halos (cx_halo_configure_state) run plain sweeps and are damped like them");
     CX_HIP(h, hipStreamSynchronize(h->stream));

@@ -139,13 +139,14 @@ int32_t flatten(H *h, int64_t n_edges, const int64_t *edge_var, const int64_t *e
         // dim 2..4: a variable's incoming messages live in registers (k_sweep_mv<D, DEG>: DEG = 3, 4 or 8 by the graph's widest
         // variable); variables of degree > 8 live in the CSR tail like the scalar ones (round 5: k_big_mv, cx_mv.hip; fused and tree
         // schedules, batch items — the reference's resolver takes any degree, src/dependencies.jl:90-173).  dim 64: a rule sums at most
-        // three sources itself (k_rule64w) — a sender of degree 5 .. 8 has its other messages summed into its stored variable→factor
+        // three sources itself (k_rule64w) — a sender of degree 5 or more has its other messages summed into its stored variable→factor
         // message first (k_v2f64; flooding and tree schedules, batch items); the chain-scan plans sum the side information of such a
         // path variable into one message of their own first (k_side64, cx_mv64chain.hip).
-        if (!h->big_vars.empty() && (h->cfg.dim == 64 || h->cfg.schedule == CX_SCHED_CHAIN_SCAN))
-            return fail_(err, CX_ERR_UNSUPPORTED, std::string("cx_graph_create: ") + (h->cfg.dim == 64 ? "dim 64 (and 5 .. 63 with it)" : "the chain-scan schedule for dim > 1") +
-                        " handles variables of degree <= 8; variable " + std::to_string(h->var_ids[h->big_vars[0]]) + " has degree " +
-                        std::to_string(var_deg[h->big_vars[0]]) + (h->cfg.dim == 64 ? "" : " (the fused and tree schedules take any degree)"));
+        // (round 6) dim 64 takes any degree too: a variable of degree > 8 lives in the CSR tail (consecutive slots), k_v2f64 and the marginal
+        // kernel walk its slots by the variable's own degree and stride
+        if (!h->big_vars.empty() && h->cfg.schedule == CX_SCHED_CHAIN_SCAN)
+            return fail_(err, CX_ERR_UNSUPPORTED, std::string("cx_graph_create: the chain-scan schedule for dim > 1 handles variables of degree <= 8; variable ") +
+                        std::to_string(h->var_ids[h->big_vars[0]]) + " has degree " + std::to_string(var_deg[h->big_vars[0]]) + " (the fused and tree schedules take any degree)");
     }
     std::vector<double> q(mv ? 1 : slots, 0.0), a, b, sq, sa, sb;
     h->any_linear = false;

@@ -258,6 +258,8 @@ struct cx_handle {
 namespace cx {
 
 // slot of CSR edge e (host)
+// the distance between two consecutive slots of variable v: 1 in the CSR tail (degree > 8), 256 in a slice
+inline int32_t slot_stride(const cx_handle *h, int32_t v) { return ((h->vinfo[v] & kDegMask) == kBigDeg) ? 1 : kBlock; }
 inline int32_t slot_of_edge(const cx_handle *h, int64_t e) {
     const int32_t v = h->edge_var[e];
     const int32_t k = (int32_t)(e - h->var_off[v]);
@@ -317,7 +319,8 @@ void mv64w_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const doub
 void mv64_launch_marginals(cx_handle *h, int n, const int32_t *d_vars, const double *f2v, double *out);
 void mv64_launch_point(cx_handle *h, int nwork, const int32_t *d_slots, double *out_a, double *out_b);
 void mv64_launch_v2f(cx_handle *h, int n, const int32_t *d_slots, const int32_t *d_vars, const double *f2v);
-void mv64_launch_range_sums(cx_handle *h, int n, const int32_t *d_rec10, const double *f2v, double *out);      // rec: destination row, n sources, 8 source slots
+void mv64_launch_damp(cx_handle *h, int n, const int32_t *d_rec, const double *old, double *out, double lam);
+void mv64_launch_range_sums(cx_handle *h, int n, const int32_t *d_rec4, const double *f2v, double *out);      // rec: destination row, n sources, first slot, slot stride
 void mv64_launch_seed(cx_handle *h, double *buf, double eta, double lam);
 void mv64_rows_scatter(cx_handle *h, double *dst, const int32_t *d_idx, const double *d_val, int64_t n);
 void mv64_rows_gather(cx_handle *h, const double *src, const int32_t *d_idx, double *d_val, int64_t n);

@@ -159,7 +159,7 @@ static_assert((kD + 16) * kLd <= (kD + 1) * kLd + 4 * 16 * kLdw + kD, "fifth til
 // — one scalar round trip instead of the chain work list → vinfo / vbase / spdir / partner → loads.
 template <int MODE>
 __global__ __launch_bounds__(kBlock, 2) void k_rule64(int nwork, const int32_t *__restrict__ work_rec, const int32_t *__restrict__ work_vars,
-                                                      const int32_t *__restrict__ vbase, const uint8_t *__restrict__ vinfo,
+                                                      const int32_t *__restrict__ vbase, const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
                                                       const double *__restrict__ ptab,
                                                       const double *__restrict__ f2v_in, const double *__restrict__ v2f,
                                                       double *__restrict__ out) {
@@ -217,16 +217,16 @@ __global__ __launch_bounds__(kBlock, 2) void k_rule64(int nwork, const int32_t *
         }
     } else {
         const int v = work_vars[w];
-        const int deg = vinfo[v] & kDegMask;
+        const int info = vinfo[v];
+        const bool big = (info & kDegMask) == kBigDeg;      // degree > 8: consecutive slots in the CSR tail, the degree in vdeg
+        const int deg = big ? vdeg[v] : (info & kDegMask), stride = big ? 1 : kBlock;
         const int base = vbase[v];
         double acc[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[i] = 0.0;
         double ea = 0.0;
-#pragma unroll 4
-        for (int j = 0; j < 8; j++) {      // (degree <= 8: the SELL width)
-            if (j >= deg) break;
-            const double *src = f2v_in + (int64_t)(base + j * kBlock) * kMsg;
+        for (int j = 0; j < deg; j++) {
+            const double *src = f2v_in + (int64_t)(base + j * stride) * kMsg;
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[i] += src[kD + tid + kBlock * i];
             if (tid < kD) ea += src[tid];
@@ -539,37 +539,50 @@ __global__ __launch_bounds__(kBlock) void k_point64(int nwork, const int32_t *__
 
 // variable→factor message of a listed slot, on demand: the sum of the variable's other incoming messages
 __global__ __launch_bounds__(kBlock) void k_v2f64(int n, const int32_t *__restrict__ slots, const int32_t *__restrict__ vars,
-                                                  const int32_t *__restrict__ vbase, const uint8_t *__restrict__ vinfo,
+                                                  const int32_t *__restrict__ vbase, const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
                                                   const double *__restrict__ f2v, double *__restrict__ v2f) {
     const int w = blockIdx.x;
     if (w >= n) return;
     const int slot = slots[w], v = vars[w];
-    const int info = vinfo[v], deg = info & kDegMask;
+    const int info = vinfo[v];
+    const bool big = (info & kDegMask) == kBigDeg;          // degree > 8: consecutive slots in the CSR tail
+    const int deg = big ? vdeg[v] : (info & kDegMask), stride = big ? 1 : kBlock;
     if (deg < 2 || (info & (kClamped | kGhost))) return;
     const int base = vbase[v];
     for (int e = threadIdx.x; e < kMsg; e += kBlock) {
         double acc = 0.0;
         for (int j = 0; j < deg; j++) {
-            const int sj = base + j * kBlock;
+            const int sj = base + j * stride;
             if (sj != slot) acc += f2v[(int64_t)sj * kMsg + e];
         }
         v2f[(int64_t)slot * kMsg + e] = acc;
     }
 }
 
-// ProductOfMessages of dim 64: the sum of up to eight messages of a variable into a row of the product table; nothing is stored when one
+// ProductOfMessages of dim 64: the sum of a range of a variable's messages into a row of the product table; nothing is stored when one
 // of them is undefined (the signal is not pending)
 __global__ __launch_bounds__(kBlock) void k_range_sum64(int n, const int32_t *__restrict__ rec, const double *__restrict__ f2v, double *__restrict__ out) {
     const int w = blockIdx.x;
     if (w >= n) return;
-    const int32_t *r = rec + 10 * (int64_t)w;
-    const int dst = r[0], ns = r[1];
-    for (int j = 0; j < ns; j++) if (__builtin_isnan(f2v[(int64_t)r[2 + j] * kMsg + kD])) return;      // (whole messages are NaN together)
+    const int32_t *r = rec + 4 * (int64_t)w;      // {row of the product table, messages, first slot, slot stride (1 in the CSR tail, 256 in a slice)}
+    const int dst = r[0], ns = r[1], first = r[2], stride = r[3];
+    for (int j = 0; j < ns; j++) if (__builtin_isnan(f2v[(int64_t)(first + j * stride) * kMsg + kD])) return;      // (whole messages are NaN together)
     for (int e = threadIdx.x; e < kMsg; e += kBlock) {
         double acc = 0.0;
-        for (int j = 0; j < ns; j++) acc += f2v[(int64_t)r[2 + j] * kMsg + e];
+        for (int j = 0; j < ns; j++) acc += f2v[(int64_t)(first + j * stride) * kMsg + e];
         out[(int64_t)dst * kMsg + e] = acc;
     }
+}
+
+// damping (cx_set_damping) of a flooding sweep of dim 64: every message a rule record has just written into `out` becomes
+// (1 - lambda) out + lambda old in natural form, `old` the message it replaces in the sweep's input buffer; an old message that is
+// undefined does not damp (cx_scalar_core.h: damped).  One workgroup per rule record, after the rule launch.
+__global__ __launch_bounds__(kBlock) void k_damp64(int n, const int32_t *__restrict__ rec, const double *__restrict__ old, double *__restrict__ out, double lam) {
+    const int w = blockIdx.x;
+    if (w >= n) return;
+    const int64_t dst = (int64_t)rec[8 * (int64_t)w + 5] * kMsg;
+    if (__builtin_isnan(old[dst + kD]) || __builtin_isnan(out[dst + kD])) return;      // (whole messages are NaN together)
+    for (int e = threadIdx.x; e < kMsg; e += kBlock) out[dst + e] = (1.0 - lam) * out[dst + e] + lam * old[dst + e];
 }
 
 __global__ void k_fill64(double *__restrict__ buf, int64_t nslots, double eta, double lam, const int32_t *__restrict__ partner) {
@@ -630,7 +643,7 @@ void mv64_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const doubl
     if (wave_form && !classic)
         mv64w_launch_rule(h, nwork, d_rec, f2v_in, f2v_out);
     else if (classic)
-        hipLaunchKernelGGL((k_rule64<0>), dim3(nwork), dim3(kBlock), 0, h->stream, nwork, d_rec, (const int32_t *)nullptr, h->d_vbase, h->d_vinfo,
+        hipLaunchKernelGGL((k_rule64<0>), dim3(nwork), dim3(kBlock), 0, h->stream, nwork, d_rec, (const int32_t *)nullptr, h->d_vbase, h->d_var_deg, h->d_vinfo,
                            h->d_ptab, f2v_in, h->d_mv_v2f, f2v_out);
     else
         hipLaunchKernelGGL(k_rule64s, dim3(nwork), dim3(kBlock), 0, h->stream, nwork, d_rec, h->d_ptab, f2v_in, h->d_mv_v2f, f2v_out);
@@ -640,7 +653,7 @@ void mv64_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const doubl
 void mv64_launch_marginals(cx_handle *h, int n, const int32_t *d_vars, const double *f2v, double *out) {
     if (n == 0) return;
     hipLaunchKernelGGL((k_rule64<1>), dim3(n), dim3(kBlock), 0, h->stream, n, (const int32_t *)nullptr, d_vars,
-                       h->d_vbase, h->d_vinfo, h->d_ptab, f2v, h->d_mv_v2f, out);
+                       h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_ptab, f2v, h->d_mv_v2f, out);
 }
 
 void mv64_launch_point(cx_handle *h, int nwork, const int32_t *d_slots, double *out_a, double *out_b) {
@@ -651,12 +664,17 @@ void mv64_launch_point(cx_handle *h, int nwork, const int32_t *d_slots, double *
 
 void mv64_launch_v2f(cx_handle *h, int n, const int32_t *d_slots, const int32_t *d_vars, const double *f2v) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_v2f64, dim3(n), dim3(kBlock), 0, h->stream, n, d_slots, d_vars, h->d_vbase, h->d_vinfo, f2v, h->d_mv_v2f);
+    hipLaunchKernelGGL(k_v2f64, dim3(n), dim3(kBlock), 0, h->stream, n, d_slots, d_vars, h->d_vbase, h->d_var_deg, h->d_vinfo, f2v, h->d_mv_v2f);
 }
 
-void mv64_launch_range_sums(cx_handle *h, int n, const int32_t *d_rec10, const double *f2v, double *out) {
+void mv64_launch_range_sums(cx_handle *h, int n, const int32_t *d_rec4, const double *f2v, double *out) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_range_sum64, dim3(n), dim3(kBlock), 0, h->stream, n, d_rec10, f2v, out);
+    hipLaunchKernelGGL(k_range_sum64, dim3(n), dim3(kBlock), 0, h->stream, n, d_rec4, f2v, out);
+}
+
+void mv64_launch_damp(cx_handle *h, int n, const int32_t *d_rec, const double *old, double *out, double lam) {
+    if (n == 0 || lam == 0.0) return;
+    hipLaunchKernelGGL(k_damp64, dim3(n), dim3(kBlock), 0, h->stream, n, d_rec, old, out, lam);
 }
 
 void mv64_launch_seed(cx_handle *h, double *buf, double eta, double lam) {

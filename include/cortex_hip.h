@@ -291,8 +291,7 @@ int32_t cx_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, d
 int32_t cx_update_batch(cx_handle *h, const cx_item *items, int64_t n);
 int32_t cx_update_batch_async(cx_handle *h, const cx_item *items, int64_t n);
 /* values of the intermediates cx_update_batch keeps on the device: ProductOfMessages nodes (2 doubles each — dim > 1: a message
- * payload of d + d * d doubles each; the reference's default resolver creates them for variables of degree > 5, which dim > 1 takes up
- * to degree 8 — `form` CX_FORM_MOMENT or CX_FORM_NATURAL) and JointMarginal nodes (dim 1) (6 doubles each: mean[2], covariance[4] row-major, variables in
+ * payload of d + d * d doubles each; the reference's default resolver creates them for variables of degree > 5; any degree — `form` CX_FORM_MOMENT or CX_FORM_NATURAL) and JointMarginal nodes (dim 1) (6 doubles each: mean[2], covariance[4] row-major, variables in
  * ascending id order).  A node never computed reads as NaN (UndefValue()). */
 int32_t cx_get_products(cx_handle *h, int64_t n, const int64_t *variable_ids, const int32_t *range_lo, const int32_t *range_hi,
                         int32_t form, double *out);

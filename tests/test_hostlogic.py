@@ -235,7 +235,9 @@ def test_error_paths_leave_nothing_out_of_bounds():
                                              np.r_[wide.factor_var, np.zeros(7)], edge_role=np.r_[wide.edge_role, np.zeros(7, np.int32)], dim=dim, schedule=schedule)
     g9 = big9(4)                                                           # degree 9 at dim 2..4 (round 5): the CSR tail, whole blocks of 256 slots
     assert g9.status == L.OK and len(g9.arr("big_vars")) == 1 and g9.scalar("nslots") % 256 == 0 and g9.scalar("nslots") >= g9.scalar("big_start") + 9
-    for refused in (big9(64), big9(4, L.SCHED_CHAIN_SCAN)):
+    g64 = big9(64)                                                         # (round 6) dim 64 too: k_v2f64 and the marginal kernel walk the tail by degree and stride
+    assert g64.status == L.OK and len(g64.arr("big_vars")) == 1
+    for refused in (big9(64, L.SCHED_CHAIN_SCAN), big9(4, L.SCHED_CHAIN_SCAN)):
         assert refused.status == L.ERR_UNSUPPORTED and "degree <= 8" in refused.error
     k = cx.synth.kary_model(2, seed=1, k_choices=(3,))
     norole = FlatGraph(k.edge_var, k.edge_fac, k.factor_ids, k.factor_kind, k.factor_var)
