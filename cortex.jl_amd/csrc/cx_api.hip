@@ -101,11 +101,11 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
         return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: the variational families need dim == 1");
     if (config->family == CX_FAMILY_NATURAL2 && (config->dim != 1 || config->schedule == CX_SCHED_CHAIN_SCAN))
         return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: CX_FAMILY_NATURAL2 needs dim == 1 and the flooding, fused, tree or reference schedule");
-    if (config->schedule == CX_SCHED_REFERENCE && ((config->dim != 1 && (config->dim < 2 || config->dim > 4)) || user_dim || is_vmp))
-        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: CX_SCHED_REFERENCE replays the reference's execution order for dim 1 (Gaussian or natural-pair family) and dim 2, 3, 4");
-    if (config->dim > 1 && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN && config->schedule != CX_SCHED_TREE &&
-        !(config->schedule == CX_SCHED_REFERENCE && config->dim <= 4))
-        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: dim > 1 runs the fused, the chain-scan and the tree schedule (dim 2, 3, 4 also the reference-order schedule)");
+    // (round 6: the reference-order schedule for dim 64 too — and 5 .. 63 inside it: the stages through k_v2f64 / k_rule64w, cx_api_ref.hip)
+    if (config->schedule == CX_SCHED_REFERENCE && is_vmp)
+        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: CX_SCHED_REFERENCE replays the reference's execution order for the Gaussian and natural-pair families (the variational rules run under it as a wiring: cx_graph_wire)");
+    if (config->dim > 1 && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN && config->schedule != CX_SCHED_TREE && config->schedule != CX_SCHED_REFERENCE)
+        return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: dim > 1 runs the fused, the chain-scan, the tree and the reference-order schedule");
     if (config->schedule != CX_SCHED_FLOODING && config->schedule != CX_SCHED_FUSED && config->schedule != CX_SCHED_CHAIN_SCAN && config->schedule != CX_SCHED_TREE && config->schedule != CX_SCHED_REFERENCE)
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: unknown schedule");
     if (config->schedule == CX_SCHED_TREE && config->family == CX_FAMILY_VMP_MEAN_FIELD)

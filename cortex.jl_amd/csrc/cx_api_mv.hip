@@ -127,7 +127,15 @@ int32_t mv_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
     std::vector<int32_t> idx, vars;
     int32_t rc = stage_slots(h, n, variable_ids, factor_ids, idx, &vars);
     if (rc != CX_OK) return rc;
-    if (d == 64) return mv64_set_messages(h, n, idx, vars, direction, form, payload);
+    if (d == 64) {
+        rc = mv64_set_messages(h, n, idx, vars, direction, form, payload);
+        if (rc == CX_OK && h->ref) {      // CX_SCHED_REFERENCE: the user's set_value! on the shadow of the readiness state, in list order
+            std::vector<int64_t> edges((size_t)n);
+            for (int64_t i = 0; i < n; i++) edges[i] = find_edge(h, variable_ids[i], factor_ids[i]);
+            ref_on_set(h, n, edges.data(), direction, 0);
+        }
+        return rc;
+    }
     const int64_t stride = form == CX_FORM_POINT ? d : d + d * d;
     std::vector<double> val((size_t)n * nc);
     for (int64_t i = 0; i < n; i++)

@@ -31,6 +31,11 @@ struct PlanEntry {
     uint8_t *d_sl_head = nullptr;
     void *d_scan_scratch = nullptr;
     int64_t n_chain_exec = 0;
+    // dim 64: a stage is up to four launches of the kernels a dim 64 sweep is made of — sums of a range of a variable's messages into the
+    // product table (k_range_sum64), variable→factor sums (k_v2f64), the messages out of observed variables (k_point64), the MFMA rule on
+    // a stored variable→factor message (k_rule64w) — over these lists, by stage
+    int32_t *d64_prod = nullptr, *d64_v2f_slot = nullptr, *d64_v2f_var = nullptr, *d64_point = nullptr, *d64_rule = nullptr;
+    std::vector<int64_t> off64_prod, off64_v2f, off64_point, off64_rule;
     hipGraphExec_t exec = nullptr;
     bool graph_failed = false;
     bool cluster = false;                       // every stage in ONE launch of an XCD-resident cluster (cx_batch.hip: k_ref_cluster)
@@ -71,7 +76,9 @@ RefSched *ref_of(cx_handle *h) { return (RefSched *)h->ref; }
 void entry_free(cx_handle *h, PlanEntry &e) {
     if (e.exec) { (void)hipGraphExecDestroy(e.exec); e.exec = nullptr; }
     for (void *p : {(void *)e.d_rec, (void *)e.d_list, (void *)e.d_stage_off, (void *)e.d_wide_rec, (void *)e.d_flat, (void *)e.d_wide_partial, (void *)e.d_sl_lead_dst, (void *)e.d_sl_lead_var,
-                    (void *)e.d_sl_fol_dst, (void *)e.d_sl_prec, (void *)e.d_sl_src_off, (void *)e.d_sl_src, (void *)e.d_sl_head, e.d_scan_scratch}) if (p) (void)hipFree(p);
+                    (void *)e.d_sl_fol_dst, (void *)e.d_sl_prec, (void *)e.d_sl_src_off, (void *)e.d_sl_src, (void *)e.d_sl_head, e.d_scan_scratch,
+                    (void *)e.d64_prod, (void *)e.d64_v2f_slot, (void *)e.d64_v2f_var, (void *)e.d64_point, (void *)e.d64_rule}) if (p) (void)hipFree(p);
+    e.d64_prod = e.d64_v2f_slot = e.d64_v2f_var = e.d64_point = e.d64_rule = nullptr;
     e.d_rec = e.d_list = e.d_wide_rec = e.d_flat = nullptr; e.d_stage_off = nullptr; e.d_wide_partial = nullptr;
     e.d_sl_lead_dst = e.d_sl_lead_var = e.d_sl_fol_dst = e.d_sl_prec = e.d_sl_src_off = e.d_sl_src = nullptr; e.d_sl_head = nullptr; e.d_scan_scratch = nullptr;
     h->device_bytes -= e.device_bytes; e.device_bytes = 0;
@@ -95,6 +102,19 @@ int64_t issue(cx_handle *h, RefSched *R, const PlanEntry &e, bool count_only) {
     const size_t ns = e.stage_off.empty() ? 0 : e.stage_off.size() - 1;
     int64_t launches = 0;
     if (!count_only) h->d_ref_list = e.d_list;
+    if (h->cfg.dim == 64) {      // the stage's items sorted into the kernels of a dim 64 sweep (lists made with the plan: plan64)
+        for (size_t s = 0; s < ns; s++) {
+            const int64_t np = e.off64_prod[s + 1] - e.off64_prod[s], nf = e.off64_v2f[s + 1] - e.off64_v2f[s], npt = e.off64_point[s + 1] - e.off64_point[s], nr = e.off64_rule[s + 1] - e.off64_rule[s];
+            if (!count_only) {
+                cx::mv64_launch_range_sums(h, (int)np, e.d64_prod + 4 * e.off64_prod[s], h->d_mv_f2v, h->d_mv_prod);
+                cx::mv64_launch_v2f(h, (int)nf, e.d64_v2f_slot + e.off64_v2f[s], e.d64_v2f_var + e.off64_v2f[s], h->d_mv_f2v);
+                cx::mv64_launch_point(h, (int)npt, e.d64_point + e.off64_point[s], h->d_mv_f2v, h->d_mv_f2v);
+                cx::mv64_launch_rule(h, (int)nr, e.d64_rule + 8 * e.off64_rule[s], h->d_mv_f2v, h->d_mv_f2v, CX_KERNEL_BATCH);
+            }
+            launches += (np > 0) + (nf > 0) + (npt > 0) + (nr > 0);
+        }
+        return launches;
+    }
     if (h->cfg.dim > 1) {      // dim 2 .. 4 (cx_mvbatch.hip): runs of thin stages as one launch of one workgroup, the others a launch of k_batch_mv each; no cluster
         const int64_t thin = std::min<int64_t>(R->run_max, cx::mv_run_block());
         for (size_t s = 0; s < ns;) {
@@ -508,6 +528,48 @@ void ref_on_batch(cx_handle *h, const cx_item *items, int64_t n) {
     }
 }
 
+// dim 64: the levelled records of a plan as the lists its stages launch (PlanEntry: d64_*).  What an execution computes does not depend
+// on HOW the reference's rule would have folded it: a MessageToFactor is the sum of the variable's other stored messages (k_v2f64; the
+// segment-tree nodes a variable of degree > 5 hangs it off hold partial sums of the same messages), a ProductOfMessages node the sum of
+// its range (k_range_sum64), a MessageToVariable the rule on the sender's stored variable→factor message — or on its datum —, and a
+// marginal is formed from the stored messages when it is read (cx_get_marginals), like under every other dim 64 schedule.
+static int32_t plan64(cx_handle *h, RefSched *R, const rs::Plan &P, PlanEntry &e) {
+    const size_t ns = P.stage_off.size() - 1;
+    std::vector<int32_t> prod, v2f_s, v2f_v, point, rule, slot_var(h->nslots, -1), node_of(h->prod_index.size(), -1);
+    for (int64_t ed = 0; ed < h->ne; ed++) slot_var[cx::slot_of_edge(h, ed)] = h->edge_var[ed];
+    for (size_t i = 0; i < R->prod_slot.size(); i++) if (R->prod_slot[i] >= 0 && R->prod_slot[i] < (int32_t)node_of.size()) node_of[R->prod_slot[i]] = (int32_t)i;
+    e.off64_prod.assign(1, 0); e.off64_v2f.assign(1, 0); e.off64_point.assign(1, 0); e.off64_rule.assign(1, 0);
+    for (size_t st = 0; st < ns; st++) {
+        for (int64_t i = P.stage_off[st]; i < P.stage_off[st + 1]; i++) {
+            const int32_t *r = &P.rec[5 * i];
+            const int32_t kind = r[0] & rs::kRecKindMask;
+            if (kind == CX_ITEM_MESSAGE_TO_FACTOR || kind == rs::kItemSumToFactor) { v2f_s.push_back(r[1]); v2f_v.push_back(r[2]); }
+            else if (kind == CX_ITEM_MESSAGE_TO_VARIABLE) {
+                const int32_t dst = r[1], p = h->partner[dst];
+                if (p < 0) continue;
+                if (h->vinfo[slot_var[p]] & cx::kClamped) {
+                    if (h->vinfo[r[2]] & cx::kClamped) return fail(h, CX_ERR_UNSUPPORTED, "reference schedule, dim 64: a message between two observed variables is not computed");
+                    point.push_back(p);
+                } else rule.insert(rule.end(), {p, -1, -1, -1, h->spdir[p], dst, 1, 0});      // flag 1: the stored variable→factor message of slot p is the input
+            } else if (kind == rs::kItemSumToProduct) {
+                const int32_t pi = r[1] >= 0 && r[1] < (int32_t)node_of.size() ? node_of[r[1]] : -1;
+                if (pi < 0) return fail(h, CX_ERR_STATE, "reference schedule, dim 64: a segment-tree node without a row in the product table");
+                const auto &pr = R->W.prods[pi];
+                const int32_t stride = cx::slot_stride(h, pr.var);
+                prod.insert(prod.end(), {r[1], pr.hi - pr.lo + 1, h->vbase[pr.var] + (pr.lo - 1) * stride, stride});
+            } else if (kind == CX_ITEM_INDIVIDUAL_MARGINAL || kind == rs::kItemSumToMarginal) {
+                continue;      // formed when read
+            } else return fail(h, CX_ERR_UNSUPPORTED, "reference schedule, dim 64: item kind " + std::to_string(kind) + " has no dim 64 kernel (factors of more than two variables are dim 2 .. 4)");
+        }
+        e.off64_prod.push_back((int64_t)prod.size() / 4); e.off64_v2f.push_back((int64_t)v2f_s.size());
+        e.off64_point.push_back((int64_t)point.size()); e.off64_rule.push_back((int64_t)rule.size() / 8);
+    }
+    int32_t rc;
+    if ((rc = dev_upload(h, &e.d64_prod, prod)) != CX_OK || (rc = dev_upload(h, &e.d64_v2f_slot, v2f_s)) != CX_OK || (rc = dev_upload(h, &e.d64_v2f_var, v2f_v)) != CX_OK ||
+        (rc = dev_upload(h, &e.d64_point, point)) != CX_OK || (rc = dev_upload(h, &e.d64_rule, rule)) != CX_OK) return rc;
+    return CX_OK;
+}
+
 static uint64_t request_key(const int32_t *req, int64_t n) {
     uint64_t rk = rs::mix64((uint64_t)n);
     for (int64_t i = 0; i < n; i++) rk = rs::mix64(rk ^ (uint64_t)(uint32_t)req[i]);
@@ -571,6 +633,7 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n, const uint64_t *k
                 (!P.wide_rec.empty() && (rc2 = dev_alloc(h, &e.d_wide_partial, (int64_t)(P.wide_rec.size() / 5) * 64 * 2)) != CX_OK)) {
                 e.device_bytes = h->device_bytes - before; entry_free(h, e); return rc2;
             }
+            if (h->cfg.dim == 64 && (rc2 = plan64(h, R, P, e)) != CX_OK) { e.device_bytes = h->device_bytes - before; entry_free(h, e); return rc2; }
             if (!P.scans.empty()) {
                 int64_t widest = 0;
                 for (auto &sc : P.scans) widest = std::max(widest, sc.hi - sc.lo);
@@ -618,6 +681,7 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n, const uint64_t *k
     }
     h->sweeps_done++;
     h->v2f_stale = false;
+    if (h->cfg.dim == 64) { h->point64_dirty = true; h->pot64_fresh = false; }      // (as after a batch: a sweep of another schedule recomputes its constants)
     return CX_OK;
 }
 

@@ -256,8 +256,6 @@ class HipProcessor(AbstractInferenceRequestProcessor):
         if mode not in ("per_signal", "wavefront", "sweep", "reference"):
             raise ValueError(f"unknown mode {mode!r}")
         if mode == "reference":
-            if dim not in (1, 2, 3, 4):
-                raise ValueError("mode 'reference' (CX_SCHED_REFERENCE) is implemented for dim 1 and dim 2, 3, 4")
             schedule = L.SCHED_REFERENCE
         if family not in ("gaussian", "beta"):
             raise ValueError(f"unknown family {family!r}")

@@ -429,7 +429,7 @@ def test_d_dimensional_chain_through_the_plugin(hip_lib, d, n, mode, tol):
 
 @pytest.mark.parametrize("d,children,mode", [(4, 5, "per_signal"), (3, 7, "wavefront"), (64, 5, "per_signal"), (4, 100, "wavefront"), (2, 12, "per_signal"),
                                              (4, 100, "reference"), (2, 12, "reference"),
-                                             (64, 40, "wavefront"), (64, 11, "per_signal"), (16, 9, "wavefront")])      # (round 6) dim 64 — and 5 .. 63 inside it — at any degree
+                                             (64, 40, "wavefront"), (64, 11, "per_signal"), (16, 9, "wavefront"), (64, 40, "reference")])      # (round 6) dim 64 — and 5 .. 63 inside it — at any degree
 def test_a_d_dimensional_hub_through_the_plugin(hip_lib, d, children, mode):
     """a state with `children` child states, everybody observed: the hub has degree children + 1 > 5, so the reference's default
     resolver hangs its messages and its marginal off a segment tree of ProductOfMessages signals (src/dependencies.jl:90-173).  The host
