@@ -26,6 +26,7 @@ void dev_free_all(cx_handle *h) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     h->d_tree_rec = h->d_tree_kary = nullptr; h->d_tree_skip1_down = nullptr; h->d_tree_a = h->d_tree_b = nullptr; h->d_pre64_slots = h->d_pre64_vars = h->d_tree_pre_slots = h->d_tree_pre_vars = nullptr; h->n_pre64 = 0; h->tree_hp = false; h->tree_dirty = true; h->d_partner16 = nullptr; h->d_mvc_var_link = nullptr; h->d_tree_stage_off = nullptr;
     tree_graph_drop(h); h->tree_graph_failed = false;
+    batch_graph_drop(h);
     if (h->d_cluster_ctl) { (void)hipFree(h->d_cluster_ctl); h->d_cluster_ctl = nullptr; }
     h->cluster_state = 0;
     h->set_memos.clear();

@@ -134,6 +134,7 @@ int32_t cx_halo_set_layers(cx_handle *h, int64_t n, const int64_t *variable_ids,
             lay[v] = layer[i];
         }
         cx::haloplan::layers(h, lay, depth);      // cx_halo_plan.h (GPU-free: also built and tested on the CPU under sanitizers)
+        batch_graph_drop(h);                      // (a captured batch holds the old layers' slice ranges)
         h->sweeps_since_exchange = 0;
         // the quiet run of cx_halo_ipc_batch (the slices of the last sweep that may run AFTER the early push) is a function of the owned-only
         // slices set just now: an IPC block that already stands gets it recomputed, so that no stale range survives new layers

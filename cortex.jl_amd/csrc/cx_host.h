@@ -168,6 +168,7 @@ int32_t ensure_v2f(cx_handle *h);
 int32_t build_chains(cx_handle *h);
 int32_t build_tree(cx_handle *h);
 int32_t tree_sweep(cx_handle *h);        // every stage of the plan on the handle's stream (one graph launch, or an XCD-resident cluster for scalar plans of wide stages)
+void batch_graph_drop(cx_handle *h);       // the captured sweeps of a deep-halo batch (cx_api_sweep.hip: cx_sweep)
 void tree_graph_drop(cx_handle *h);        // CX_SCHED_TREE: the stages of cx_tree_plan.h on the device (rebuilt when the set of observed variables changed)
 void sweep_main(cx_handle *h, bool skip_ghosts);
 void sweep_finish(cx_handle *h);

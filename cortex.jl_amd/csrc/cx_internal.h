@@ -155,6 +155,12 @@ struct cx_handle {
     uint8_t *d_chain_head_fwd = nullptr, *d_chain_head_bwd = nullptr;
     double2 *d_chain_side = nullptr;
     void *d_chain_totals = nullptr;
+    // the sweeps between two exchanges of a deep-halo partition as ONE graph launch (cx_api_sweep.hip: cx_sweep): the same (first sweep after
+    // the exchange, sweeps, buffers) seen a second time is captured, from then on replayed; two slots (an odd batch alternates its buffers)
+    struct BatchGraph { uint64_t key = 0; hipGraphExec_t exec = nullptr; int seen = 0; bool failed = false; };
+    BatchGraph batch_graph[2];
+    uint64_t batch_epoch = 1;        // moved on by whatever a captured batch bakes in (layers, damping, the graph itself): cxh::batch_graph_drop
+    int64_t batch_graph_launches = 0;
     // the chain scan as ONE launch (cx_chain.hip: k_chain_onepass): tile totals + flags on the device, the word in mapped host memory that a
     // workgroup raises when a wait of it times out (checked by every CX_HIP of the host: the call that finds it fails, the handle goes back to two launches)
     void *d_chain_onepass = nullptr, *d_chain_abort = nullptr;

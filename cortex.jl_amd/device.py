@@ -118,7 +118,7 @@ class DeviceGraph:
         """cx_chain_scan_stats: the scalar chain scan as one launch — state (1 ready, 0 not prepared, -1 off) and how many such launches ran"""
         out = (C.c_int64 * 4)()
         self._check(self.lib.cx_chain_scan_stats(self.h, out))
-        return {"state": int(out[0]), "launches": int(out[1])}
+        return {"state": int(out[0]), "launches": int(out[1]), "halo_batch_graph_launches": int(out[2])}
 
     def edge_index(self, variable_ids, factor_ids):
         v, f = _i64(np.atleast_1d(variable_ids)), _i64(np.atleast_1d(factor_ids))

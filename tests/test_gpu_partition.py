@@ -300,6 +300,36 @@ def test_deep_halo_exchange_issued_by_the_library(hip_lib, rows, cols, depth, sw
     assert np.array_equal(dev.get_marginals(m.x_ids), plain.get_marginals(m.x_ids), equal_nan=True)
 
 
+@pytest.mark.parametrize("depth", [8, 7, 16])
+def test_the_sweeps_between_two_exchanges_replay_as_one_graph_launch(hip_lib, monkeypatch, depth):
+    """(round 6) a deep-halo batch — `depth` trimmed sweeps between two exchanges — asked for a second time is captured and from then on
+    replayed as ONE graph launch (cx_sweep; an odd depth alternates between two graphs: the buffers swap roles).  Bit-identical to the
+    plain launches (CX_HALO_GRAPH=0) and to the un-partitioned handle, batch after batch."""
+    rows, cols, batches = 64, 256, 7
+    part = partition.deep_self(rows, cols, depth, seed=8)
+    m = part.model
+
+    def run():
+        dev = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+        cx.synth.load_into_device(m, dev, seed_variance=1e6)
+        ex = partition.DeepHaloRccl(dev, part, overlap=False)
+        ex.sweep(batches * depth)
+        return dev
+    a = run()
+    monkeypatch.setenv("CX_HALO_GRAPH", "0")
+    b = run()
+    monkeypatch.delenv("CX_HALO_GRAPH")
+    plain = cx.DeviceGraph(schedule=L.SCHED_FUSED)
+    cx.synth.load_into_device(m, plain, seed_variance=1e6)
+    plain.sweep(batches * depth)
+    ga, gb = a.chain_scan_stats()["halo_batch_graph_launches"], b.chain_scan_stats()["halo_batch_graph_launches"]
+    assert gb == 0 and ga >= batches - (2 if depth % 2 == 0 else 4), (ga, gb)
+    for dev in (a, b):
+        assert np.array_equal(dev.get_messages(m.edge_var, m.edge_fac, L.TO_VARIABLE, L.FORM_NATURAL),
+                              plain.get_messages(m.edge_var, m.edge_fac, L.TO_VARIABLE, L.FORM_NATURAL), equal_nan=True)
+        assert np.array_equal(dev.get_marginals(m.x_ids), plain.get_marginals(m.x_ids), equal_nan=True)
+
+
 @pytest.mark.parametrize("world,depth,sweeps", [(5, 8, 19), (8, 16, 35)])
 def test_config_c4_full_size_deep_halo(hip_lib, world, depth, sweeps):
     """BASELINE config C4 at full size: the 1415 x 1415 grid (10,005,465 edges) cut into row blocks with a deep halo, one
