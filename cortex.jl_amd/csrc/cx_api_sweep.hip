@@ -574,11 +574,13 @@ int32_t cx_sweep(cx_handle *h, int32_t n_sweeps) {
     }
     int32_t s = 0;
     // The sweeps between two exchanges of a deep-halo partition (cx_halo_configure_state + layers): 12 .. 32 launches of 10 us whose slice
-    // ranges repeat batch after batch.  The second time the same batch is asked for it is captured, from then on ONE graph launch (measured on
-    // the 1/8 strip of C4 in round 4: - 4 % per sweep).  What a batch bakes in is in its key (first sweep after the exchange, sweeps, the two
-    // buffers, batch_epoch); the host state the sweeps leave is applied by the same code either way.
+    // ranges repeat batch after batch.  CX_HALO_GRAPH=1: the second time the same batch is asked for it is captured, from then on ONE graph
+    // launch.  OFF by default: on the 1/8 strip of C4 (depth 16) the replayed graph measured 10.10 - 10.25 us per sweep against 9.90 - 9.92
+    // for the plain launches, 11.74 against 11.18 with the exchange (profiles/r06_strip.md) — back-to-back launches from one thread already
+    // overlap their launch latency, and a graph's kernel nodes are dispatched no closer together.  What a batch bakes in is in its key
+    // (first sweep after the exchange, sweeps, the two buffers, batch_epoch); the host state the sweeps leave is applied by the same code.
     const char *bg_env = std::getenv("CX_HALO_GRAPH");      // (read per call: a test runs both forms in one process)
-    const bool batch_graphs = !(bg_env && bg_env[0] == '0');
+    const bool batch_graphs = bg_env && bg_env[0] == '1';
     cx_handle::BatchGraph *bg = nullptr;
     bool capturing = false;
     hipStream_t user_stream = h->stream;

@@ -356,7 +356,7 @@ int32_t cx_ref_plan_stats(const cx_handle *h, int64_t *out8);
  * two-launch scan and the caller repeats the sweep (a chain-scan sweep is exact whatever it starts from).  CX_CHAIN_ONEPASS=0 turns it off.
  * out4 = { 1 ready / 0 not prepared / -1 off, launches of the one-launch form so far, G, 0 } — G counts another kind of fused launch: the
  * sweeps between two exchanges of a deep-halo partition (cx_halo_configure_state + cx_halo_set_layers) replayed as ONE graph launch once
- * the same batch has been asked for twice (CX_HALO_GRAPH=0: always plain launches). */
+ * the same batch has been asked for twice — with CX_HALO_GRAPH=1 only: measured 2 - 5 % slower than the plain launches on MI355X, off by default. */
 int32_t cx_chain_scan_stats(const cx_handle *h, int64_t *out4);
 /* the XCD-resident cluster (reference-order plans of many dependent stages of 1 - 16 k items — calls on loopy graphs — run as ONE launch
  * of the workgroups of one XCD behind barriers that stay in that XCD's L2): out4 = { 1 ready / 0 not prepared / -1 off

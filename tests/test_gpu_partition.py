@@ -302,9 +302,10 @@ def test_deep_halo_exchange_issued_by_the_library(hip_lib, rows, cols, depth, sw
 
 @pytest.mark.parametrize("depth", [8, 7, 16])
 def test_the_sweeps_between_two_exchanges_replay_as_one_graph_launch(hip_lib, monkeypatch, depth):
-    """(round 6) a deep-halo batch — `depth` trimmed sweeps between two exchanges — asked for a second time is captured and from then on
-    replayed as ONE graph launch (cx_sweep; an odd depth alternates between two graphs: the buffers swap roles).  Bit-identical to the
-    plain launches (CX_HALO_GRAPH=0) and to the un-partitioned handle, batch after batch."""
+    """(round 6, CX_HALO_GRAPH=1: measured slower than plain launches and off by default, kept under test) a deep-halo batch — `depth`
+    trimmed sweeps between two exchanges — asked for a second time is captured and from then on replayed as ONE graph launch (cx_sweep; an
+    odd depth alternates between two graphs: the buffers swap roles).  Bit-identical to the plain launches and to the un-partitioned
+    handle, batch after batch."""
     rows, cols, batches = 64, 256, 7
     part = partition.deep_self(rows, cols, depth, seed=8)
     m = part.model
@@ -315,10 +316,10 @@ def test_the_sweeps_between_two_exchanges_replay_as_one_graph_launch(hip_lib, mo
         ex = partition.DeepHaloRccl(dev, part, overlap=False)
         ex.sweep(batches * depth)
         return dev
+    monkeypatch.setenv("CX_HALO_GRAPH", "1")
     a = run()
-    monkeypatch.setenv("CX_HALO_GRAPH", "0")
-    b = run()
     monkeypatch.delenv("CX_HALO_GRAPH")
+    b = run()
     plain = cx.DeviceGraph(schedule=L.SCHED_FUSED)
     cx.synth.load_into_device(m, plain, seed_variance=1e6)
     plain.sweep(batches * depth)
