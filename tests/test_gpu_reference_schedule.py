@@ -258,8 +258,9 @@ def test_refusals(hip_lib):
         dev.sweep_for(model.x_ids[:3])
     assert ei.value.code == L.ERR_UNSUPPORTED and "CX_SCHED_REFERENCE" in ei.value.message
     dev.close()
+    cx.DeviceGraph(schedule=L.SCHED_REFERENCE, dim=64).close()      # (round 6: accepted — dim 2, 3, 4 and 64: tests/test_gpu_reference_mv.py)
     with pytest.raises(cx.CortexHipError) as ei:
-        cx.DeviceGraph(schedule=L.SCHED_REFERENCE, dim=64)      # (dim 2, 3, 4: tests/test_gpu_reference_mv.py)
+        cx.DeviceGraph(schedule=L.SCHED_REFERENCE, family=L.FAMILY_VMP_STRUCTURED)      # the variational rules run under it as a wiring
     assert ei.value.code == L.ERR_UNSUPPORTED
     dev = cx.DeviceGraph(schedule=L.SCHED_REFERENCE)
     cx.synth.load_into_device(model, dev)
