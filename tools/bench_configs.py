@@ -94,14 +94,16 @@ def c2(check=None):
     fl.sweep(3)
     dtf = timed(fl, lambda: fl.sweep(1), 200, 20)
     nf = fl.stats()["n_messages_per_sweep"]
-    tr = counter_traffic(["k_chain_run_totals", "k_chain_run_apply"])   # the steady-state launches of one sweep (245 tiles: no scan-of-totals kernel)
+    one = dev.chain_scan_stats()["launches"] > 0      # (round 6) the scan as ONE launch: k_chain_onepass
+    tr = counter_traffic(["k_chain_onepass"] if one else ["k_chain_run_totals", "k_chain_run_apply"])   # the steady-state launches of one sweep
     alg = (5 * T - 4) * 32
     achieved = (tr[0] if tr else alg) / dt / 1e9
     return {"config": "C2", "workload": f"scalar chain T={T} ({st['n_edges']} edges), chain-scan schedule: exact forward/backward in one sweep",
             "ms_per_sweep": dt * 1e3, "reference_updates_per_sweep": 5 * T - 4, "updates_per_s": (5 * T - 4) / dt,
             "algorithmic_GBps": alg / dt / 1e9,
             # two launches at their fixed cost: the sweep is LAUNCH-LATENCY bound, far from the HBM roofline it is priced against
-            "roofline": roofline("hbm", achieved, HBM_PEAK_GBS, "GB/s", tr[0] if tr else None, limited_by="launch latency (2 kernels per sweep)",
+            "roofline": roofline("hbm", achieved, HBM_PEAK_GBS, "GB/s", tr[0] if tr else None, limited_by="one launch: the links' dependent loads and the look-back's trips to memory" if one else "launch latency (2 kernels per sweep)",
+                                 kernel="k_chain_onepass" if one else "k_chain_run_totals + k_chain_run_apply",
                                  basis="counter traffic of the sweep's kernels / sweep time" if tr else "algorithmic bytes / sweep time",
                                  traffic_source=tr[1] if tr else None, algorithmic_bytes_per_sweep=alg, frac_survey_convention=alg / dt / 1e9 / HBM_PEAK_GBS),
             "flooding": {"ms_per_sweep": dtf * 1e3, "updates_per_sweep": nf, "updates_per_s": nf / dtf, "algorithmic_GBps": nf * 32 / dtf / 1e9},
