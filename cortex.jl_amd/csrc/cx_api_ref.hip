@@ -774,7 +774,9 @@ int32_t cx_graph_wire(cx_handle *h, int64_t n, const cx_item *signals, const cx_
     CX_NOT_VMP(h, "cx_graph_wire");
     CX_REQUIRE(h, h && h->has_graph, CX_ERR_STATE, "cx_graph_wire: no graph");
     CX_REQUIRE(h, h->cfg.schedule == CX_SCHED_REFERENCE, CX_ERR_UNSUPPORTED, "cx_graph_wire: a dependency wiring is what CX_SCHED_REFERENCE runs the reference's scheduler on; the other schedules are fixed orders");
-    CX_REQUIRE(h, h->cfg.dim == 1, CX_ERR_UNSUPPORTED, "cx_graph_wire: user wirings run as sums of dependency lists, which are items of the scalar kernels (dim == 1)");
+    // (round 6) dim 2 .. 4 too: a MessageToFactor / marginal under a user wiring is the sum of ITS dependency list, an item k_batch_mv has
+    // (the segment-tree signals use it); dim 64 forms marginals from ALL stored messages when they are read, which a wiring may not list
+    CX_REQUIRE(h, h->cfg.dim >= 1 && h->cfg.dim <= 4, CX_ERR_UNSUPPORTED, "cx_graph_wire: user wirings run as sums of dependency lists: dim 1 (all rules) and dim 2, 3, 4 (sum-product rules)");
     CX_REQUIRE(h, n >= 0 && (n == 0 || (signals && dependencies && flags)), CX_ERR_INVALID_ARGUMENT, "cx_graph_wire: null argument");
     RefSched *R = ref_of(h);
     CX_REQUIRE(h, R && !R->touched, CX_ERR_STATE, "cx_graph_wire: the wiring is fixed once a value has been set or a call has run (wire right after cx_graph_create, as the reference wires at engine construction)");

@@ -338,7 +338,9 @@ int32_t cx_sweep_for(cx_handle *h, int64_t n, const int64_t *variable_ids);
  *                             (src/model_engine.jl:64-71): requested and computed with v's marginal (src/inference_engine.jl:313-315, 617-625)
  * Replaces the whole wiring (n == 0: none); allowed until the first value is set or the first call runs, as the reference wires at engine
  * construction.  The two fused families (cx_update_marginals) remain the fast path for the reference's two test models; this entry point runs
- * them, and any other wiring of these rules on any graph, call by call as the reference's scheduler would — mixed requests included. */
+ * them, and any other wiring of these rules on any graph, call by call as the reference's scheduler would — mixed requests included.
+ * dim 1: all of the above.  dim 2, 3, 4 (ABI 4): wirings of the sum-product rules (a MessageToFactor / marginal is the sum of ITS dependency
+ * list); dim 64 forms marginals from all stored messages when they are read and refuses wirings. */
 #define CX_WIRE_WEAK 1          /* add_dependency!(...; weak = true): the dependency need only be computed, not fresh (src/signal.jl:36-45) */
 #define CX_WIRE_INTERMEDIATE 2  /* intermediate = true: process_dependencies! descends through it (src/signal.jl:466-490) */
 #define CX_WIRE_NO_LISTEN 4     /* listen = false: the dependency's set_value! does not make the signal potentially pending */

@@ -158,8 +158,13 @@ def test_refusals_for_dim_above_one(hip_lib):
     model = cx.synth.lgssm_chain(8, d=2, seed=1)
     dev = cx.DeviceGraph(dim=2, schedule=L.SCHED_REFERENCE)
     cx.synth.load_into_device(model, dev)
-    with pytest.raises(cx.CortexHipError, match="scalar kernels"):
+    with pytest.raises(cx.CortexHipError, match="wiring is fixed"):  # (round 6: dim 2 .. 4 take user wirings — right after cx_graph_create, like dim 1)
         dev.graph_wire([], [], [])
+    d64 = cx.DeviceGraph(dim=64, schedule=L.SCHED_REFERENCE)
+    m64 = cx.synth.lgssm_chain(4, d=64, seed=1)
+    cx.synth.load_into_device(m64, d64)
+    with pytest.raises(cx.CortexHipError, match="dim 2, 3, 4"):
+        d64.graph_wire([], [], [])
 
 
 @pytest.mark.parametrize("d", [3])
@@ -410,3 +415,51 @@ def test_factors_of_several_variables_on_a_cycle(hip_lib):
             assert_close(marg[i, :d], mm, 1e-8, f"call {call + 1}: marginal mean of x{i + 1}", scale_by="max")
             assert_close(marg[i, d:].reshape(d, d), VV, 1e-8, f"call {call + 1}: marginal covariance of x{i + 1}", scale_by="max")
     dev.close(); sc.close()
+
+
+@pytest.mark.parametrize("d", [2, 4])
+def test_a_filter_wiring_of_a_d_dimensional_state_space_model(hip_lib, d):
+    """(round 6) cx_graph_wire for dim 2 .. 4: a user resolver that wires the forward messages only — one call is the Kalman FILTER
+    of the linear-Gaussian state-space model (numpy, textbook form), not the smoother; the marginals are sums of the wiring's own
+    dependency lists (the backward messages are never computed and never read)"""
+    T = 150
+    model = cx.synth.lgssm_chain(T, d=d, seed=6)
+    A, Q, Rm = model.meta["A"], model.meta["Q"], model.meta["R"]
+    x, y = model.x_ids, model.data_var
+    lik, tr = model.data_fac, np.setdiff1d(model.factor_ids, model.data_fac)
+    assert len(lik) == T and len(tr) == T - 1
+    F, V, M, I = L.ITEM_MESSAGE_TO_FACTOR, L.ITEM_MESSAGE_TO_VARIABLE, L.ITEM_INDIVIDUAL_MARGINAL, L.WIRE_INTERMEDIATE
+    triples = []
+    for t in range(T):
+        triples.append(((V, int(x[t]), int(lik[t])), (F, int(y[t]), int(lik[t])), 0))
+        triples.append(((M, int(x[t]), 0), (V, int(x[t]), int(lik[t])), I))
+        if t > 0:
+            triples.append(((M, int(x[t]), 0), (V, int(x[t]), int(tr[t - 1])), I))
+            triples.append(((V, int(x[t]), int(tr[t - 1])), (F, int(x[t - 1]), int(tr[t - 1])), 0))
+        if t + 1 < T:
+            triples.append(((F, int(x[t]), int(tr[t])), (V, int(x[t]), int(lik[t])), I))
+            if t > 0:
+                triples.append(((F, int(x[t]), int(tr[t])), (V, int(x[t]), int(tr[t - 1])), I))
+    dev = cx.DeviceGraph(dim=d, schedule=L.SCHED_REFERENCE)
+    for k, (Ak, Qk) in model.psets.items():
+        dev.set_factor_matrices(k, Ak, Qk)
+    dev.graph_create(model.edge_var, model.edge_fac, model.factor_ids, model.factor_kind, model.factor_var, edge_role=model.edge_role)
+    dev.graph_wire([s for s, _d, _f in triples], [dd for _s, dd, _f in triples], [f for _s, _d, f in triples])
+    dev.set_messages(model.data_var, model.data_fac, L.TO_FACTOR, L.FORM_POINT, model.data_y)
+    dev.sweep_for(x)
+    assert dev.ref_plan_stats()["executions"] == T + 2 * (T - 1) + T
+    Y = np.asarray(model.data_y)
+    m, P = Y[0].copy(), Rm.copy()
+    fm, fP = [m], [P]
+    for t in range(1, T):
+        mp, Pp = A @ m, A @ P @ A.T + Q
+        K = Pp @ np.linalg.inv(Pp + Rm)
+        m, P = mp + K @ (Y[t] - mp), (np.eye(d) - K) @ Pp
+        fm.append(m); fP.append(P)
+    marg = dev.get_marginals(x)
+    assert_close(marg[:, :d], np.array(fm), 1e-8, "filtered means", scale_by="max")
+    assert_close(marg[:, d:].reshape(T, d, d), np.array(fP), 1e-8, "filtered covariances", scale_by="max")
+    from oracle.exact import lgssm_posterior
+    sm, sP = lgssm_posterior(Y, A, Q, Rm)
+    assert np.max(np.abs(marg[:-1, d:].reshape(T - 1, d, d) - sP[:-1])) > 1e-4, "a filter is not the smoother"
+    assert_close(marg[-1, :d], sm[-1], 1e-8, "the last state: filter == smoother", scale_by="max")
