@@ -446,7 +446,18 @@ def config_parity(device: int = 0) -> dict:
                 "(test/inference_engine_tests.jl:807-1147), pinned call by call against the restated engine",
                 "sample": f"n={len(xs)} states, {iterations} iterations by class, every state mean and precision and both Gamma marginals"}
 
-    for key, fn in (("C3", lambda: flooding(4, 2000, 8, 0)), ("C5", c5_fixed_point), ("C4-reference", reference_order),
+    def tiles_fixed_point(d=16, T=48):      # a native-tile dim swept to its fixed point on a short chain against the exact smoother
+        model = cx.synth.lgssm_chain(T, d=d, seed=23)
+        dev = cx.DeviceGraph(device=device, dim=d, schedule=L.SCHED_FUSED)
+        cx.synth.load_into_device(model, dev, seed_variance=1e6)
+        dev.sweep(T + 2)
+        em, ecov = exact.lgssm_posterior(model.data_y, model.meta["A"], model.meta["Q"], model.meta["R"])
+        marg = dev.get_marginals(model.x_ids)
+        dev.close()
+        return {"max_rel_err": max(_rel_err(marg[:, :d], em), _rel_err(marg[:, d:].reshape(T, d, d), ecov)), "tolerance": 1e-6,
+                "checker": "oracle/exact.py: block-tridiagonal posterior", "sample": f"d={d}, T={T} chain swept to its fixed point ({T + 2} sweeps), all marginals"}
+
+    for key, fn in (("C3", lambda: flooding(4, 2000, 8, 0)), ("C5", c5_fixed_point), ("d=16 native tiles", tiles_fixed_point), ("C4-reference", reference_order),
                     ("VMP structured", lambda: vmp_family("structured", L.FAMILY_VMP_STRUCTURED)),
                     ("VMP mean_field", lambda: vmp_family("mean_field", L.FAMILY_VMP_MEAN_FIELD))):
         try:
@@ -470,7 +481,10 @@ def other_configs(parity=None) -> list:
     rows = []
     for name, fn in (("C2", lambda: bc.c2(check=hooks.get("C2"))), ("C3", lambda: bc.mv(4, 1_000_000, 30)),
                      ("C3-scan", lambda: bc.mv_scan(4, 1_000_000, 30, check=hooks.get("C3-scan"))[0]),
-                     ("C5", lambda: bc.mv(64, 100_000, 12)), ("C5-scan", lambda: bc.mv64_scan(100_000, 8, check=hooks.get("C5-scan"))[0]),
+                     ("C5", lambda: bc.mv(64, 100_000, 12)),
+                     # (round 6) d = 16 in its native tile size beside the embedding in 64 x 64 that every d in 5 .. 63 ran in until round 5
+                     ("d=16 native tiles", lambda: bc.mv_tiles(16, 100_000, 20)),
+                     ("C5-scan", lambda: bc.mv64_scan(100_000, 8, check=hooks.get("C5-scan"))[0]),
                      ("VMP", lambda: bc.vmp()),
                      # the same structured model as a user wiring under the reference-order schedule (cx_graph_wire): replayed plans per call
                      ("VMP-wired", lambda: bc.vmp_wired(100_000, check=hooks.get("VMP-wired"))),

@@ -33,6 +33,8 @@ void dev_free_all(cx_handle *h) {
     ref_free(h);
     cx::chain64_free(h);
     cx::chain_onepass_free(h);
+    for (void *p : {(void *)h->d_marg64_sums, (void *)h->d_marg64_tab, (void *)h->d_marg64_rec}) if (p) (void)hipFree(p);
+    h->d_marg64_sums = h->d_marg64_tab = nullptr; h->d_marg64_rec = nullptr; h->marg64_cap = 0;
     cx::chain64_tree_free(h);
     cx::kary_free(h);
     if (h->d_prod) (void)hipFree(h->d_prod);
@@ -89,12 +91,21 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: config is NULL or struct_size mismatch");
     if (config->dim < 1 || config->dim > 64)
         return fail(nullptr, CX_ERR_UNSUPPORTED, "cx_create: this build implements dim 1 .. 64");
-    // dim 5 .. 63 run on the dim 64 path, embedded: x -> (x, u) with u a 64 - d dimensional unit random walk observed nowhere — every
-    // rule matrix, message and datum block-diagonal (real block, identity block), so the real block of every result is exact and the
-    // identity block keeps every joint positive definite.  The price is the arithmetic of dim 64 whatever d is.
-    const int user_dim = (config->dim > 4 && config->dim < 64) ? config->dim : 0;
+    // dim 5 .. 64 run on the matrix-core path in 1 x 1, 2 x 2 or 4 x 4 tiles of 16 (cx_const.h: is_mfma_dim): internal dim 16, 32 or 64,
+    // the smallest that holds the user's (round 6; until then always 64: a d = 8 message moved 64 x its bytes).  A dim in between is
+    // embedded: x -> (x, u) with u a unit random walk observed nowhere — every rule matrix, message and datum block-diagonal (real block,
+    // identity block), so the real block of every result is exact and the identity block keeps every joint positive definite.  The
+    // chain-scan and tree schedules' plans are written for 4 x 4 tiles: they keep 64.  CX_MFMA_DIM=64 forces 64 everywhere (A/B).
     cx_config padded;
-    if (user_dim) { padded = *config; padded.dim = 64; config = &padded; }
+    int user_dim = 0;
+    if (config->dim > 4) {
+        int internal = 64;
+        const char *force = std::getenv("CX_MFMA_DIM");
+        if ((config->schedule == CX_SCHED_FUSED || config->schedule == CX_SCHED_REFERENCE) && !(force && std::atoi(force) == 64))
+            internal = config->dim <= 16 ? 16 : config->dim <= 32 ? 32 : 64;
+        user_dim = config->dim != internal ? config->dim : 0;
+        padded = *config; padded.dim = internal; config = &padded;
+    }
     const bool is_vmp = config->family == CX_FAMILY_VMP_MEAN_FIELD || config->family == CX_FAMILY_VMP_STRUCTURED;
     if (config->family != CX_FAMILY_GAUSSIAN && config->family != CX_FAMILY_NATURAL2 && !is_vmp)
         return fail(nullptr, CX_ERR_INVALID_ARGUMENT, "cx_create: unknown family");
@@ -125,7 +136,7 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
     if (!h) return fail(nullptr, CX_ERR_OUT_OF_MEMORY, "cx_create: host allocation failed");
     h->cfg = *config;
     h->user_dim = user_dim;
-    h->nc = config->dim == 1 ? 2 : (config->dim == 64 ? 64 + 64 * 64 : config->dim + config->dim * (config->dim + 1) / 2);
+    h->nc = config->dim == 1 ? 2 : (cx::is_mfma_dim(config->dim) ? config->dim + config->dim * config->dim : config->dim + config->dim * (config->dim + 1) / 2);
     h->ncs = (config->dim >= 2 && config->dim <= 4) ? 2 * ((h->nc + 1) / 2) : h->nc;
     h->stream = nullptr;  // default stream until cx_set_stream
     *out = h;
@@ -180,7 +191,7 @@ static int32_t upload_ptab(cx_handle *h) {
     if (!h->d_ptab) { int32_t rc = dev_alloc(h, &h->d_ptab, (int64_t)(per * nsets)); if (rc != CX_OK) return rc; h->ptab_sets = nsets; }
     CX_HIP(h, hipMemcpy(h->d_ptab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
     h->pot64_fresh = false;
-    if (d == 64) {   // the wave-per-message rule kernel reads B transposed (tile rows are its contraction index)
+    if (cx::is_mfma_dim(d)) {   // the wave-per-message rule kernel reads B transposed (tile rows are its contraction index)
         const size_t dd = (size_t)d * d;
         std::vector<double> bt(2 * (size_t)nsets * dd);
         for (int64_t t = 0; t < 2 * nsets; t++) {
@@ -300,11 +311,11 @@ int32_t cx_graph_create(cx_handle *h, int64_t n_edges, const int64_t *edge_var, 
             h->spdir = spdir; h->spdir_dirty = true;
             CX_TRY(dev_upload(h, &h->d_spdir, spdir));
             CX_TRY(dev_alloc(h, &h->d_mv_f2v, ncs * slots)); CX_TRY(dev_alloc(h, &h->d_mv_f2v_alt, ncs * slots));
-            CX_TRY(dev_alloc(h, &h->d_mv_v2f, ncs * slots)); CX_TRY(dev_alloc(h, &h->d_mv_marg, h->cfg.dim == 64 ? 1 : ncs * h->nslices * cx::kBlock));      // pair form by variable, whole 256-blocks
+            CX_TRY(dev_alloc(h, &h->d_mv_v2f, ncs * slots)); CX_TRY(dev_alloc(h, &h->d_mv_marg, cx::is_mfma_dim(h->cfg.dim) ? 1 : ncs * h->nslices * cx::kBlock));      // pair form by variable, whole 256-blocks
             CX_HIP(h, hipMemsetAsync(h->d_mv_f2v, 0xff, (size_t)(ncs * slots) * 8, h->stream));
             CX_HIP(h, hipMemsetAsync(h->d_mv_f2v_alt, 0xff, (size_t)(ncs * slots) * 8, h->stream));
             CX_HIP(h, hipMemsetAsync(h->d_mv_v2f, 0xff, (size_t)(ncs * slots) * 8, h->stream));
-            if (h->cfg.dim != 64) CX_HIP(h, hipMemsetAsync(h->d_mv_marg, 0xff, (size_t)(ncs * h->nslices * cx::kBlock) * 8, h->stream));
+            if (!cx::is_mfma_dim(h->cfg.dim)) CX_HIP(h, hipMemsetAsync(h->d_mv_marg, 0xff, (size_t)(ncs * h->nslices * cx::kBlock) * 8, h->stream));
             CX_HIP(h, hipStreamSynchronize(h->stream));
             if (h->cfg.schedule == CX_SCHED_REFERENCE) CX_TRY(ref_build(h));      // dim 2 .. 4: the same wiring and shadow, the stages through k_batch_mv
             h->has_graph = true;

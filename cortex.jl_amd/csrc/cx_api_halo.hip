@@ -19,7 +19,7 @@ int32_t cx_halo_configure(cx_handle *h, int64_t n_send, const int64_t *sv, const
     CX_REQUIRE(h, h->cfg.schedule != CX_SCHED_REFERENCE, CX_ERR_UNSUPPORTED, "cx_halo_configure: the reference-order schedule is sequential by definition and is not partitioned");
     // dim 2..4 and 64 under the chain-scan schedule: the lists only name the stand-ins of a time block (cx_chain_block_maps exchanges maps,
     // not messages); every other dim > 1 partition uses state halos (cx_halo_configure_state)
-    const bool mv_chain_block = ((h->cfg.dim >= 2 && h->cfg.dim <= 4) || h->cfg.dim == 64) && h->cfg.schedule == CX_SCHED_CHAIN_SCAN;
+    const bool mv_chain_block = ((h->cfg.dim >= 2 && h->cfg.dim <= 4) || cx::is_mfma_dim(h->cfg.dim)) && h->cfg.schedule == CX_SCHED_CHAIN_SCAN;
     CX_REQUIRE(h, h->cfg.dim == 1 || mv_chain_block, CX_ERR_UNSUPPORTED, "cx_halo_configure: message halos are implemented for dim == 1 (dim > 1: cx_halo_configure_state, or a chain-scan time block)");
     // the same exclusion as cx_set_damping's, whichever call comes first (empty lists take a halo away and are always accepted)
     CX_REQUIRE(h, h->damping == 0.0 || (n_send == 0 && n_recv == 0), CX_ERR_UNSUPPORTED,
@@ -107,13 +107,13 @@ int32_t cx_halo_configure_state(cx_handle *h, int64_t n_send, const int64_t *sv,
 static void state_pack(cx_handle *h) {
     const int64_t n = (int64_t)h->send_slots.size();
     if (h->cfg.dim == 1) cx::launch_gather(h, h->d_f2v, h->d_send_slots, h->d_send_buf, n);
-    else if (h->cfg.dim == 64) cx::mv64_rows_gather(h, h->d_mv_f2v, h->d_send_slots, (double *)h->d_send_buf, n);
+    else if (cx::is_mfma_dim(h->cfg.dim)) cx::mv64_rows_gather(h, h->d_mv_f2v, h->d_send_slots, (double *)h->d_send_buf, n);
     else cx::mv_launch_gather(h, h->d_mv_f2v, h->nslots, h->nc, h->ncs, h->d_send_slots, (double *)h->d_send_buf, n);
 }
 static void state_unpack(cx_handle *h) {
     const int64_t n = (int64_t)h->recv_slots.size();
     if (h->cfg.dim == 1) cx::launch_scatter(h, h->d_f2v, h->d_recv_slots, h->d_recv_buf, n);
-    else if (h->cfg.dim == 64) cx::mv64_rows_scatter(h, h->d_mv_f2v, h->d_recv_slots, (const double *)h->d_recv_buf, n);
+    else if (cx::is_mfma_dim(h->cfg.dim)) cx::mv64_rows_scatter(h, h->d_mv_f2v, h->d_recv_slots, (const double *)h->d_recv_buf, n);
     else cx::mv_launch_scatter(h, h->d_mv_f2v, h->nslots, h->nc, h->ncs, h->d_recv_slots, (const double *)h->d_recv_buf, n);
 }
 

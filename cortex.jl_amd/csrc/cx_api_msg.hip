@@ -9,11 +9,10 @@ using namespace cxh;
 
 extern "C" {
 
-// ---- dim 5 .. 63 embedded in dim 64 (cx_create): payloads in, block-diagonal with an identity block; results out, their real block ----
+// ---- a dim embedded in the next tile size (16, 32, 64; cx_create): payloads in, block-diagonal with an identity block; results out, their real block ----
 namespace {
 // vector[u] (+ matrix[u][u]) -> vector[64] (+ matrix[64][64] = blockdiag(matrix, I)); a NaN matrix (UndefValue) stays all NaN
-void pad_payload(int u, bool with_matrix, const double *in, double *out) {
-    const int d = 64;
+void pad_payload(int u, int d, bool with_matrix, const double *in, double *out) {
     for (int k = 0; k < d; k++) out[k] = k < u ? in[k] : 0.0;
     if (!with_matrix) return;
     bool undef = false;
@@ -23,8 +22,7 @@ void pad_payload(int u, bool with_matrix, const double *in, double *out) {
             out[d + r * d + c] = undef ? std::numeric_limits<double>::quiet_NaN() : (r < u && c < u) ? in[u + r * u + c] : (r == c ? 1.0 : 0.0);
     if (undef) for (int k = 0; k < d; k++) out[k] = std::numeric_limits<double>::quiet_NaN();
 }
-void unpad_payload(int u, const double *in, double *out) {
-    const int d = 64;
+void unpad_payload(int u, int d, const double *in, double *out) {
     for (int k = 0; k < u; k++) out[k] = in[k];
     for (int r = 0; r < u; r++) for (int c = 0; c < u; c++) out[u + r * u + c] = in[d + r * d + c];
 }
@@ -46,11 +44,11 @@ int32_t cx_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
     CX_REQUIRE(h, n > 0 && variable_ids && factor_ids && payload, CX_ERR_INVALID_ARGUMENT, "cx_set_messages: null argument");
     if (h->user_dim) {
         try {
-            const int u = h->user_dim, d = 64;
+            const int u = h->user_dim, d = h->cfg.dim;
             const bool mat = form != CX_FORM_POINT;
             const size_t si = mat ? (size_t)u + (size_t)u * u : (size_t)u, so = mat ? (size_t)d + (size_t)d * d : (size_t)d;
             std::vector<double> big((size_t)n * so);
-            for (int64_t i = 0; i < n; i++) pad_payload(u, mat, payload + (size_t)i * si, &big[(size_t)i * so]);
+            for (int64_t i = 0; i < n; i++) pad_payload(u, d, mat, payload + (size_t)i * si, &big[(size_t)i * so]);
             return mv_set_messages(h, n, variable_ids, factor_ids, direction, form, big.data());
         } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_set_messages: host allocation failed"); }
     }
@@ -149,12 +147,12 @@ int32_t cx_get_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
     CX_REQUIRE(h, n > 0 && variable_ids && factor_ids && out, CX_ERR_INVALID_ARGUMENT, "cx_get_messages: null argument");
     if (h->user_dim) {
         try {
-            const int u = h->user_dim, d = 64;
+            const int u = h->user_dim, d = h->cfg.dim;
             const size_t so = (size_t)u + (size_t)u * u, sb = (size_t)d + (size_t)d * d;
             std::vector<double> big((size_t)n * sb);
             const int32_t rc = mv_get_messages(h, n, variable_ids, factor_ids, direction, form, big.data());
             if (rc != CX_OK) return rc;
-            for (int64_t i = 0; i < n; i++) unpad_payload(u, &big[(size_t)i * sb], out + (size_t)i * so);
+            for (int64_t i = 0; i < n; i++) unpad_payload(u, d, &big[(size_t)i * sb], out + (size_t)i * so);
             return CX_OK;
         } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_get_messages: host allocation failed"); }
     }
@@ -187,7 +185,7 @@ int32_t cx_seed_messages(cx_handle *h, int32_t direction, double mean, double va
     CX_REQUIRE(h, variance > 0.0, CX_ERR_INVALID_ARGUMENT, "cx_seed_messages: variance must be > 0");
     if (h->cfg.dim > 1) {
         CX_REQUIRE(h, direction == CX_TO_VARIABLE, CX_ERR_UNSUPPORTED, "cx_seed_messages: dim > 1 seeds factor→variable messages only");
-        if (h->cfg.dim == 64) {
+        if (cx::is_mfma_dim(h->cfg.dim)) {
             h->pot64_fresh = false;
             cx::mv64_launch_seed(h, h->d_mv_f2v, mean / variance, 1.0 / variance);
             cx::mv64_launch_seed(h, h->d_mv_f2v_alt, mean / variance, 1.0 / variance);
@@ -220,12 +218,12 @@ int32_t cx_get_marginals(cx_handle *h, int64_t n, const int64_t *variable_ids, d
     if (is_vmp(h)) return cx::vmp_get_marginals(h, n, variable_ids, out);
     if (h->user_dim) {
         try {
-            const int u = h->user_dim, d = 64;
+            const int u = h->user_dim, d = h->cfg.dim;
             const size_t so = (size_t)u + (size_t)u * u, sb = (size_t)d + (size_t)d * d;
             std::vector<double> big((size_t)n * sb);
             const int32_t rc = mv_get_marginals(h, n, variable_ids, big.data());
             if (rc != CX_OK) return rc;
-            for (int64_t i = 0; i < n; i++) unpad_payload(u, &big[(size_t)i * sb], out + (size_t)i * so);
+            for (int64_t i = 0; i < n; i++) unpad_payload(u, d, &big[(size_t)i * sb], out + (size_t)i * so);
             return CX_OK;
         } catch (const std::bad_alloc &) { return fail(h, CX_ERR_OUT_OF_MEMORY, "cx_get_marginals: host allocation failed"); }
     }
@@ -443,7 +441,7 @@ int32_t cx_get_products(cx_handle *h, int64_t n, const int64_t *variable_ids, co
             const int32_t rc = mv_get(h, h->d_mv_prod, h->mv_prod_cap, idx, form, false, rows.data());
             if (rc != CX_OK) return rc;
             for (size_t k = 0; k < idx.size(); k++) {
-                if (h->user_dim) unpad_payload(u, &rows[k * sb], out + (size_t)where[k] * so);
+                if (h->user_dim) unpad_payload(u, d, &rows[k * sb], out + (size_t)where[k] * so);
                 else std::memcpy(out + (size_t)where[k] * so, &rows[k * sb], sb * 8);
             }
             return CX_OK;

@@ -62,7 +62,7 @@ int32_t mv_refresh_v2f(cx_handle *h, const std::vector<int32_t> &slots, const st
     CX_HIP(h, hipMemcpyAsync(d_v, vars.data(), n * 4, hipMemcpyHostToDevice, h->stream));
     // fused schedule: the input buffer of the last sweep; chain scan: the one buffer there is (its messages are the fixed point)
     const double *src = (h->sweeps_done > 0 && h->cfg.schedule != CX_SCHED_CHAIN_SCAN && h->cfg.schedule != CX_SCHED_TREE) ? h->d_mv_f2v_alt : h->d_mv_f2v;
-    if (h->cfg.dim == 64) cx::mv64_launch_v2f(h, (int)n, d_s, d_v, src);
+    if (cx::is_mfma_dim(h->cfg.dim)) cx::mv64_launch_v2f(h, (int)n, d_s, d_v, src);
     else cx::mv_launch_v2f(h, d_s, d_v, n, src);
     CX_HIP(h, hipGetLastError());
     CX_HIP(h, hipStreamSynchronize(h->stream));
@@ -71,7 +71,7 @@ int32_t mv_refresh_v2f(cx_handle *h, const std::vector<int32_t> &slots, const st
 
 int32_t mv64_set_messages(cx_handle *h, int64_t n, const std::vector<int32_t> &idx, const std::vector<int32_t> &vars, int32_t direction,
                           int32_t form, const double *payload) {
-    const int d = 64, nc = h->nc;
+    const int d = h->cfg.dim, nc = h->nc;
     const int64_t bytes_idx = ((n * 4 + 15) / 16) * 16;
     int32_t rc;
     // (a partition's time block: the messages that enter it at its two ends are the only ones the fresh potentials do not depend on)
@@ -127,7 +127,7 @@ int32_t mv_set_messages(cx_handle *h, int64_t n, const int64_t *variable_ids, co
     std::vector<int32_t> idx, vars;
     int32_t rc = stage_slots(h, n, variable_ids, factor_ids, idx, &vars);
     if (rc != CX_OK) return rc;
-    if (d == 64) {
+    if (cx::is_mfma_dim(d)) {
         rc = mv64_set_messages(h, n, idx, vars, direction, form, payload);
         if (rc == CX_OK && h->ref) {      // CX_SCHED_REFERENCE: the user's set_value! on the shadow of the readiness state, in list order
             std::vector<int64_t> edges((size_t)n);
@@ -187,7 +187,7 @@ int32_t mv_get(cx_handle *h, const double *src, int64_t stride, const std::vecto
     int32_t *d_idx = (int32_t *)h->d_stage;
     double *d_val = (double *)((char *)h->d_stage + bytes_idx);
     CX_HIP(h, hipMemcpyAsync(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice, h->stream));
-    if (d == 64) {
+    if (cx::is_mfma_dim(d)) {
         if (already_moment) {
             // idx = variables: computed on demand.  A marginal the kernel cannot form (an incoming message undefined, a total precision
             // that is not positive definite) is not stored: the staging rows start as UndefValue()
@@ -327,7 +327,7 @@ static int32_t mv_chain_sweep(cx_handle *h, int32_t n_sweeps) {
     CX_REQUIRE(h, h->chain_covers_all, CX_ERR_UNSUPPORTED,
                "cx_sweep: the chain-scan schedule for dim > 1 needs every non-observed variable on a chain (a non-observed variable of degree 1 "
                "or a stand-in reads messages the scan does not produce): use the fused schedule for this graph");
-    if (h->cfg.dim == 64) {
+    if (cx::is_mfma_dim(h->cfg.dim)) {
         // dim 64 (cx_mv64chain.hip): the messages out of observed variables are constants (k_point64, once per change of data or rule
         // tables); a sweep composes the blocks' potentials and walks every path in both directions, writing the exact messages into
         // the ONE message buffer.  Marginals of dim 64 are formed from the stored messages when they are read.
@@ -372,13 +372,13 @@ static int32_t mv_chain_sweep(cx_handle *h, int32_t n_sweeps) {
 //     f(eta, Lambda) = ( c + B (Lambda + P)^-1 (eta + h),  C - B (Lambda + P)^-1 B' );   sides: eta[d] | Lambda packed upper.
 int32_t mv_chain_block_maps(cx_handle *h, double *fwd, double *bwd, double *side_first, double *side_last, int64_t *first_variable_id,
                             int64_t *last_variable_id, int64_t *n_links) {
-    CX_REQUIRE(h, h->cfg.dim <= 4 || h->cfg.dim == 64, CX_ERR_UNSUPPORTED, "cx_chain_block_maps: dim 1..4 and 64");
+    CX_REQUIRE(h, h->cfg.dim <= 4 || cx::is_mfma_dim(h->cfg.dim), CX_ERR_UNSUPPORTED, "cx_chain_block_maps: dim 1..4 and 64");
     CX_REQUIRE(h, (int64_t)h->psets.size() > h->max_pset, CX_ERR_STATE, "cx_chain_block_maps: a parameter set was never set (cx_set_factor_matrices)");
     int32_t rc = build_chains(h);
     if (rc != CX_OK) return rc;
     CX_REQUIRE(h, h->chain_nlinks >= 1 && h->chain_nlinks == h->chain_npos - 1, CX_ERR_UNSUPPORTED,
                "cx_chain_block_maps: the non-observed variables of this handle must form ONE path of at least two variables (a time block of a chain)");
-    if (h->cfg.dim == 64) {
+    if (cx::is_mfma_dim(h->cfg.dim)) {
         // dim 64 (round 4): the plan of cx_chain64_plan.h with a root — the compose launches leave the ONE potential of the block's two
         // end variables; forwards it is the map (P + side_first, B, C, h + side_first, c), backwards (C + side_last, B', P, c + side_last, h)
         // (the same convention as dim 2..4: a direction's map includes the side information of the end it is entered at)
@@ -499,7 +499,7 @@ int32_t mv_ensure_chain_msgs(cx_handle *h) {
 // cx_update_batch's items and the segment-tree nodes of a reference-order wiring (cx_api_ref.hip: register_stores)
 int32_t mv_ensure_prod_store(cx_handle *h) {
     if ((int64_t)h->prod_index.size() <= h->mv_prod_cap) return CX_OK;
-    const bool d64 = h->cfg.dim == 64;
+    const bool d64 = cx::is_mfma_dim(h->cfg.dim);
     const int64_t cap = std::max<int64_t>(2 * h->mv_prod_cap, (((int64_t)h->prod_index.size() + 255) / 256) * 256);
     const int64_t per = d64 ? h->nc : h->ncs;
     double *bigger = nullptr;
@@ -524,7 +524,7 @@ int32_t mv_update_batch(cx_handle *h, const cx_item *items, int64_t n) {
     int32_t rc = mv_ensure_chain_msgs(h);
     if (rc != CX_OK) return rc;
     if ((rc = cx::kary_upload(h)) != CX_OK) return rc;
-    const bool d64 = h->cfg.dim == 64;
+    const bool d64 = cx::is_mfma_dim(h->cfg.dim);
     std::vector<int32_t> rec, v2f_slots, v2f_vars, point_slots, rule_rec, slot_var, prod_rec;
     if (d64) {
         slot_var.assign(h->nslots, -1);
@@ -640,7 +640,7 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
         // carry the rule table of the sending slot as the plan found it (the plan is rebuilt when a variable becomes observed)
         int32_t rc = build_tree(h);
         if (rc != CX_OK) return rc;
-        if (h->cfg.dim == 64) {       // the constant messages out of observed variables (as the other dim 64 schedules do)
+        if (cx::is_mfma_dim(h->cfg.dim)) {       // the constant messages out of observed variables (as the other dim 64 schedules do)
             if ((rc = build_work64(h)) != CX_OK) return rc;
             if (h->point64_dirty) {
                 cx::mv64_launch_point(h, (int)h->n_point64, h->d_point64_slots, h->d_mv_f2v, h->d_mv_f2v_alt);
@@ -654,7 +654,7 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
         CX_HIP(h, hipGetLastError());
         return CX_OK;
     }
-    if (h->cfg.dim == 64) {
+    if (cx::is_mfma_dim(h->cfg.dim)) {
         int32_t rc = build_work64(h);
         if (rc != CX_OK) return rc;
         if (h->point64_dirty) {   // messages out of observed variables are constant: computed once, into both buffers
@@ -662,9 +662,9 @@ int32_t mv_sweep(cx_handle *h, int32_t n_sweeps) {
             h->point64_dirty = false;
         }
     }
-    if (h->cfg.dim != 64) { int32_t rc = mv_refresh_spdir(h); if (rc != CX_OK) return rc; }
+    if (!cx::is_mfma_dim(h->cfg.dim)) { int32_t rc = mv_refresh_spdir(h); if (rc != CX_OK) return rc; }
     for (int32_t s = 0; s < n_sweeps; s++) {
-        if (h->cfg.dim == 64) {
+        if (cx::is_mfma_dim(h->cfg.dim)) {
             cx::mv64_launch_v2f(h, (int)h->n_pre64, h->d_pre64_slots, h->d_pre64_vars, h->d_mv_f2v);      // senders of degree 5 .. 8
             cx::mv64_launch_rule(h, (int)h->n_rule64, h->d_rule64_rec, h->d_mv_f2v, h->d_mv_f2v_alt, CX_KERNEL_FUSED);
             cx::mv64_launch_damp(h, (int)h->n_rule64, h->d_rule64_rec, h->d_mv_f2v, h->d_mv_f2v_alt, h->damping);

@@ -102,7 +102,7 @@ int64_t issue(cx_handle *h, RefSched *R, const PlanEntry &e, bool count_only) {
     const size_t ns = e.stage_off.empty() ? 0 : e.stage_off.size() - 1;
     int64_t launches = 0;
     if (!count_only) h->d_ref_list = e.d_list;
-    if (h->cfg.dim == 64) {      // the stage's items sorted into the kernels of a dim 64 sweep (lists made with the plan: plan64)
+    if (cx::is_mfma_dim(h->cfg.dim)) {      // the stage's items sorted into the kernels of a dim 64 sweep (lists made with the plan: plan64)
         for (size_t s = 0; s < ns; s++) {
             const int64_t np = e.off64_prod[s + 1] - e.off64_prod[s], nf = e.off64_v2f[s + 1] - e.off64_v2f[s], npt = e.off64_point[s + 1] - e.off64_point[s], nr = e.off64_rule[s + 1] - e.off64_rule[s];
             if (!count_only) {
@@ -633,7 +633,7 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n, const uint64_t *k
                 (!P.wide_rec.empty() && (rc2 = dev_alloc(h, &e.d_wide_partial, (int64_t)(P.wide_rec.size() / 5) * 64 * 2)) != CX_OK)) {
                 e.device_bytes = h->device_bytes - before; entry_free(h, e); return rc2;
             }
-            if (h->cfg.dim == 64 && (rc2 = plan64(h, R, P, e)) != CX_OK) { e.device_bytes = h->device_bytes - before; entry_free(h, e); return rc2; }
+            if (cx::is_mfma_dim(h->cfg.dim) && (rc2 = plan64(h, R, P, e)) != CX_OK) { e.device_bytes = h->device_bytes - before; entry_free(h, e); return rc2; }
             if (!P.scans.empty()) {
                 int64_t widest = 0;
                 for (auto &sc : P.scans) widest = std::max(widest, sc.hi - sc.lo);
@@ -681,7 +681,7 @@ int32_t ref_sweep(cx_handle *h, const int32_t *req, int64_t n, const uint64_t *k
     }
     h->sweeps_done++;
     h->v2f_stale = false;
-    if (h->cfg.dim == 64) { h->point64_dirty = true; h->pot64_fresh = false; }      // (as after a batch: a sweep of another schedule recomputes its constants)
+    if (cx::is_mfma_dim(h->cfg.dim)) { h->point64_dirty = true; h->pot64_fresh = false; }      // (as after a batch: a sweep of another schedule recomputes its constants)
     return CX_OK;
 }
 

@@ -86,7 +86,7 @@ std::vector<StatePart> state_parts(cx_handle *h) {
         parts.push_back({2, h->d_mv_f2v, ncs * slots * 8});
         parts.push_back({3, h->d_mv_f2v_alt, ncs * slots * 8});
         parts.push_back({4, h->d_mv_v2f, ncs * slots * 8});
-        if (h->cfg.dim != 64) parts.push_back({5, h->d_mv_marg, ncs * h->nslices * cx::kBlock * 8});
+        if (!cx::is_mfma_dim(h->cfg.dim)) parts.push_back({5, h->d_mv_marg, ncs * h->nslices * cx::kBlock * 8});
         if (h->ref) parts.push_back({7, nullptr, ref_state_bytes(h)});      // CX_SCHED_REFERENCE, dim 2 .. 4: the shadow decides what the next call computes
     }
     return parts;

@@ -57,7 +57,7 @@ int32_t build_chains(cx_handle *h) {
         if ((rc = dev_upload(h, &h->d_chain_to, to)) != CX_OK) return rc;
         if ((rc = dev_upload(h, &h->d_chain_head_fwd, head_fwd)) != CX_OK) return rc;
         if ((rc = dev_upload(h, &h->d_chain_head_bwd, head_bwd)) != CX_OK) return rc;
-        if (h->cfg.dim == 64) {
+        if (cx::is_mfma_dim(h->cfg.dim)) {
             // wide messages: a plan of compositions and walks (cx_chain64_plan.h) instead of the per-thread scan of dim 2..4
             h->d_chain_side = nullptr; h->d_chain_totals = nullptr;
             if ((rc = cx::chain64_build(h, pos_var, skip0, skip1, link_pos, from, to, head_fwd, head_bwd, tab_fwd, tab_bwd)) != CX_OK) return rc;
@@ -119,7 +119,7 @@ int32_t build_tree(cx_handle *h) {
         // CX_TREE_HP=0 / 1: never / whenever the graph allows (A/B, tests).
         h->tree_hp = false;
         const bool hp_mv = h->cfg.dim >= 2 && h->cfg.dim <= 4 && h->big_vars.empty() && h->n_kary == 0;      // (dim 2 .. 4: the scans of cx_mvchain.hip per light depth; their side sums take degree <= 8: a graph with a hub runs level by level)
-        const bool hp64 = h->cfg.dim == 64;                          // (dim 64: a plan of compositions and walks per light depth, cx_mv64chain.hip)
+        const bool hp64 = cx::is_mfma_dim(h->cfg.dim);                          // (dim 64: a plan of compositions and walks per light depth, cx_mv64chain.hip)
         cx::chain64_tree_free(h);
         h->tree_c64_up.clear(); h->tree_c64_final.clear();
         if ((h->cfg.dim == 1 && h->cfg.family != CX_FAMILY_NATURAL2) || hp_mv || hp64) {
@@ -232,7 +232,7 @@ int32_t build_tree(cx_handle *h) {
         std::vector<int32_t> rec;
         std::vector<int64_t> off(1, 0), koff(plan.kary_off.size(), 0);
         rec.reserve(plan.rec.size() + 5 * plan.kary.size());
-        if (h->cfg.dim == 64) {
+        if (cx::is_mfma_dim(h->cfg.dim)) {
             // dim 64: a factor→variable message is ONE rule record of cx_mv64w.hip — the sending slot, the other slots of the sending
             // variable (the rule sums them itself: no stored variable→factor message), the rule table, the destination — so only the
             // plan's factor→variable items become work; messages out of observed variables are constants (k_point64 at data injection),
@@ -300,11 +300,11 @@ static void tree_issue(cx_handle *h) {
         // variables' marginals is left out then.)
         for (size_t i = 0; i + 1 < h->tree_hp_steps.size(); i += 2) {
             const int32_t kind = h->tree_hp_steps[i], idx = h->tree_hp_steps[i + 1];
-            if (kind == 0 && h->cfg.dim == 64) {      // a stage of dim 64: one launch of the rule kernel over its records (marginals are formed when read)
+            if (kind == 0 && cx::is_mfma_dim(h->cfg.dim)) {      // a stage of dim 64: one launch of the rule kernel over its records (marginals are formed when read)
                 const int64_t n = h->tree_stage_off[idx + 1] - h->tree_stage_off[idx], np = h->tree_pre_off[idx + 1] - h->tree_pre_off[idx];
                 if (np > 0) cx::mv64_launch_v2f(h, (int)np, h->d_tree_pre_slots + h->tree_pre_off[idx], h->d_tree_pre_vars + h->tree_pre_off[idx], h->d_mv_f2v);
                 if (n > 0) cx::mv64_launch_rule(h, (int)n, h->d_tree_rec + 8 * h->tree_stage_off[idx], h->d_mv_f2v, h->d_mv_f2v, CX_KERNEL_BATCH);
-            } else if (h->cfg.dim == 64) {
+            } else if (cx::is_mfma_dim(h->cfg.dim)) {
                 const int32_t pi = (kind == 1 ? h->tree_c64_up : h->tree_c64_final)[idx];
                 if (pi >= 0) (void)cx::chain64_tree_sweep(h, pi);
             } else if (kind == 0) {
@@ -328,12 +328,12 @@ static void tree_issue(cx_handle *h) {
         return;
     }
     size_t ns = h->tree_stage_off.empty() ? 0 : h->tree_stage_off.size() - 1;
-    if (ns > 0 && h->cfg.compute_marginals_in_sweep == 0 && h->cfg.dim != 64) ns--;      // the last stage is the marginals (the flag is fixed per handle)
+    if (ns > 0 && h->cfg.compute_marginals_in_sweep == 0 && !cx::is_mfma_dim(h->cfg.dim)) ns--;      // the last stage is the marginals (the flag is fixed per handle)
     // CX_TREE_RUNS=0: every stage a launch of its own (A/B)
     static const bool runs = [] { const char *e = std::getenv("CX_TREE_RUNS"); return !(e && e[0] == '0'); }();
     for (size_t s = 0; s < ns;) {
         const int64_t n = h->tree_stage_off[s + 1] - h->tree_stage_off[s], nk = h->tree_kary_off[s + 1] - h->tree_kary_off[s];
-        if (h->cfg.dim == 64) {
+        if (cx::is_mfma_dim(h->cfg.dim)) {
             const int64_t np = h->tree_pre_off[s + 1] - h->tree_pre_off[s];
             if (np > 0) cx::mv64_launch_v2f(h, (int)np, h->d_tree_pre_slots + h->tree_pre_off[s], h->d_tree_pre_vars + h->tree_pre_off[s], h->d_mv_f2v);
             if (n > 0) cx::mv64_launch_rule(h, (int)n, h->d_tree_rec + 8 * h->tree_stage_off[s], h->d_mv_f2v, h->d_mv_f2v, CX_KERNEL_BATCH);

@@ -15,4 +15,10 @@ constexpr uint8_t kBigDeg = 0x0f;
 constexpr uint8_t kGhost = 0x40;     // degree-1 stand-in for a variable owned by another rank (halo import)
 constexpr uint8_t kClamped = 0x80;   // observed variable: its messages are data, never recomputed
 
+// The dimensions whose messages are message-major records eta[d] | Lambda[d][d] worked on by the f64 matrix cores, a wave per message,
+// in 16 x 16 accumulator tiles (cx_mv64w.hip): 1 x 1, 2 x 2 or 4 x 4 tiles.  User dims 5 .. 63 run inside the smallest of them that
+// holds them (padded with an unobserved unit random walk; cx_api.hip: cx_create) under the fused and reference-order schedules; the
+// chain-scan and tree schedules have their plans written for 4 x 4 tiles and keep 64.
+constexpr bool is_mfma_dim(int d) { return d == 16 || d == 32 || d == 64; }
+
 }  // namespace cx

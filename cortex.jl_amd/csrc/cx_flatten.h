@@ -198,7 +198,7 @@ int32_t flatten(H *h, int64_t n_edges, const int64_t *edge_var, const int64_t *e
             const std::string who = "cx_graph_create: CX_FACTOR_GAUSS_LINEAR_N (factor id " + std::to_string(h->fac_ids[f]) + ")";
             // dim 2..4 (round 5): x_out = A_1 x_1 + ... + A_k x_k + N(0, Q); params[0] names the parameter set whose Q is the noise and whose A is
             // every input's matrix until cx_set_factor_edge_sets says otherwise (cx_kary_mv_core.h)
-            if (mv && h->cfg.dim == 64) return fail_(err, CX_ERR_UNSUPPORTED, who + ": dim 64 (and 5 .. 63 with it) takes factors of two variables");
+            if (mv && cx::is_mfma_dim(h->cfg.dim)) return fail_(err, CX_ERR_UNSUPPORTED, who + ": dim 64 (and 5 .. 63 with it) takes factors of two variables");
             if (h->cfg.schedule == CX_SCHED_CHAIN_SCAN) return fail_(err, CX_ERR_UNSUPPORTED, who + ": a factor of three or more variables is not a link of a chain (use the tree, the fused or the flooding schedule)");
             if (deg < 3 || deg > 7) return fail_(err, CX_ERR_UNSUPPORTED, who + " takes 2 to 6 inputs and one output (3 to 7 edges), not " + std::to_string(deg) + " edges");
             if (!mv && !(p[0] >= 0.0)) return fail_(err, CX_ERR_INVALID_ARGUMENT, who + ": the variance q must be >= 0");

@@ -96,6 +96,10 @@ struct cx_handle {
     int observed_passes_due = 2;                   // sweeps that still have to write the messages out of observed variables
     double *d_ptab = nullptr;                      // [2*npsets][3][d*d]: (P, B, C) triples
     double *d_zero_msg = nullptr;                  // d = 64: one message of zeros (what an absent source reads)
+    // dim 16 / 32: the marginal read-out's scratch (sums of the listed variables' messages + their rule records) and identity table
+    double *d_marg64_sums = nullptr, *d_marg64_tab = nullptr;
+    int32_t *d_marg64_rec = nullptr;
+    int64_t marg64_cap = 0;
     double *d_ptab_bt = nullptr;                   // d = 64: [2*npsets][d*d], the transposes of the B tables (cx_mv64w.hip)
     int64_t ptab_sets = 0, ptab_bt_sets = 0, max_pset = -1;     // parameter sets the device tables have room for (rewritten in place while that holds)
     double *d_mv_f2v = nullptr, *d_mv_f2v_alt = nullptr, *d_mv_v2f = nullptr, *d_mv_marg = nullptr, *d_mv_prev = nullptr;
@@ -323,6 +327,7 @@ bool spd_inverse(int d, const double *S, double *out);
 void mv64_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const double *f2v_in, double *f2v_out, int kernel_id);
 void mv64w_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const double *f2v_in, double *f2v_out);   // cx_mv64w.hip
 void mv64_launch_marginals(cx_handle *h, int n, const int32_t *d_vars, const double *f2v, double *out);
+void mv64w_launch_marginal_rule(cx_handle *h, int n, const int32_t *d_rec, const double *ident_tab, const double *ident_bt, const double *sums, double *out);
 void mv64_launch_point(cx_handle *h, int nwork, const int32_t *d_slots, double *out_a, double *out_b);
 void mv64_launch_v2f(cx_handle *h, int n, const int32_t *d_slots, const int32_t *d_vars, const double *f2v);
 void mv64_launch_damp(cx_handle *h, int n, const int32_t *d_rec, const double *old, double *out, double lam);

@@ -20,6 +20,8 @@
 
 #include <cstdlib>
 
+#include <cstdio>
+#include <vector>
 #include "cx_internal.h"
 
 namespace cx {
@@ -512,35 +514,37 @@ __global__ __launch_bounds__(kBlock, 3) void k_rule64s(int nwork, const int32_t 
 }
 
 // observed senders: Lambda_out = C, eta_out = B y  (one workgroup per message; pure streaming)
-__global__ __launch_bounds__(kBlock) void k_point64(int nwork, const int32_t *__restrict__ work_slots, const int32_t *__restrict__ partner,
+__global__ __launch_bounds__(kBlock) void k_point64(const int kd, int nwork, const int32_t *__restrict__ work_slots, const int32_t *__restrict__ partner,
                                                     const int32_t *__restrict__ spdir, const double *__restrict__ ptab,
                                                     const double *__restrict__ v2f, double *__restrict__ out_a, double *__restrict__ out_b) {
-    __shared__ double y[kD];
+    const int km = kd + kd * kd;      // doubles per message record: eta[kd] | Lambda[kd][kd]
+    __shared__ double y[64];
     const int w = blockIdx.x;
     if (w >= nwork) return;
     const int slot = work_slots[w], tid = threadIdx.x;
-    const double *tab = ptab + (int64_t)spdir[slot] * 3 * kD * kD;
-    if (tid < kD) y[tid] = v2f[(int64_t)slot * kMsg + tid];
+    const double *tab = ptab + (int64_t)spdir[slot] * 3 * kd * kd;
+    if (tid < kd) y[tid] = v2f[(int64_t)slot * km + tid];
     __syncthreads();
     if (__builtin_isnan(y[0])) return;
-    const int64_t dst = (int64_t)partner[slot] * kMsg;
-    for (int e = tid; e < kD * kD; e += kBlock) {
-        const double c = tab[2 * kD * kD + e];
-        out_a[dst + kD + e] = c;
-        out_b[dst + kD + e] = c;
+    const int64_t dst = (int64_t)partner[slot] * km;
+    for (int e = tid; e < kd * kd; e += kBlock) {
+        const double c = tab[2 * kd * kd + e];
+        out_a[dst + kd + e] = c;
+        out_b[dst + kd + e] = c;
     }
-    if (tid < kD) {
+    if (tid < kd) {
         double s = 0.0;
-        for (int k = 0; k < kD; k++) s += tab[kD * kD + tid * kD + k] * y[k];
+        for (int k = 0; k < kd; k++) s += tab[kd * kd + tid * kd + k] * y[k];
         out_a[dst + tid] = s;
         out_b[dst + tid] = s;
     }
 }
 
 // variable→factor message of a listed slot, on demand: the sum of the variable's other incoming messages
-__global__ __launch_bounds__(kBlock) void k_v2f64(int n, const int32_t *__restrict__ slots, const int32_t *__restrict__ vars,
+__global__ __launch_bounds__(kBlock) void k_v2f64(const int kd, int n, const int32_t *__restrict__ slots, const int32_t *__restrict__ vars,
                                                   const int32_t *__restrict__ vbase, const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo,
                                                   const double *__restrict__ f2v, double *__restrict__ v2f) {
+    const int km = kd + kd * kd;      // doubles per message record: eta[kd] | Lambda[kd][kd]
     const int w = blockIdx.x;
     if (w >= n) return;
     const int slot = slots[w], v = vars[w];
@@ -549,81 +553,114 @@ __global__ __launch_bounds__(kBlock) void k_v2f64(int n, const int32_t *__restri
     const int deg = big ? vdeg[v] : (info & kDegMask), stride = big ? 1 : kBlock;
     if (deg < 2 || (info & (kClamped | kGhost))) return;
     const int base = vbase[v];
-    for (int e = threadIdx.x; e < kMsg; e += kBlock) {
+    for (int e = threadIdx.x; e < km; e += kBlock) {
         double acc = 0.0;
         for (int j = 0; j < deg; j++) {
             const int sj = base + j * stride;
-            if (sj != slot) acc += f2v[(int64_t)sj * kMsg + e];
+            if (sj != slot) acc += f2v[(int64_t)sj * km + e];
         }
-        v2f[(int64_t)slot * kMsg + e] = acc;
+        v2f[(int64_t)slot * km + e] = acc;
     }
 }
 
 // ProductOfMessages of dim 64: the sum of a range of a variable's messages into a row of the product table; nothing is stored when one
 // of them is undefined (the signal is not pending)
-__global__ __launch_bounds__(kBlock) void k_range_sum64(int n, const int32_t *__restrict__ rec, const double *__restrict__ f2v, double *__restrict__ out) {
+__global__ __launch_bounds__(kBlock) void k_range_sum64(const int kd, int n, const int32_t *__restrict__ rec, const double *__restrict__ f2v, double *__restrict__ out) {
+    const int km = kd + kd * kd;      // doubles per message record: eta[kd] | Lambda[kd][kd]
     const int w = blockIdx.x;
     if (w >= n) return;
     const int32_t *r = rec + 4 * (int64_t)w;      // {row of the product table, messages, first slot, slot stride (1 in the CSR tail, 256 in a slice)}
     const int dst = r[0], ns = r[1], first = r[2], stride = r[3];
-    for (int j = 0; j < ns; j++) if (__builtin_isnan(f2v[(int64_t)(first + j * stride) * kMsg + kD])) return;      // (whole messages are NaN together)
-    for (int e = threadIdx.x; e < kMsg; e += kBlock) {
+    for (int j = 0; j < ns; j++) if (__builtin_isnan(f2v[(int64_t)(first + j * stride) * km + kd])) return;      // (whole messages are NaN together)
+    for (int e = threadIdx.x; e < km; e += kBlock) {
         double acc = 0.0;
-        for (int j = 0; j < ns; j++) acc += f2v[(int64_t)(first + j * stride) * kMsg + e];
-        out[(int64_t)dst * kMsg + e] = acc;
+        for (int j = 0; j < ns; j++) acc += f2v[(int64_t)(first + j * stride) * km + e];
+        out[(int64_t)dst * km + e] = acc;
     }
 }
 
 // damping (cx_set_damping) of a flooding sweep of dim 64: every message a rule record has just written into `out` becomes
 // (1 - lambda) out + lambda old in natural form, `old` the message it replaces in the sweep's input buffer; an old message that is
 // undefined does not damp (cx_scalar_core.h: damped).  One workgroup per rule record, after the rule launch.
-__global__ __launch_bounds__(kBlock) void k_damp64(int n, const int32_t *__restrict__ rec, const double *__restrict__ old, double *__restrict__ out, double lam) {
+__global__ __launch_bounds__(kBlock) void k_damp64(const int kd, int n, const int32_t *__restrict__ rec, const double *__restrict__ old, double *__restrict__ out, double lam) {
+    const int km = kd + kd * kd;      // doubles per message record: eta[kd] | Lambda[kd][kd]
     const int w = blockIdx.x;
     if (w >= n) return;
-    const int64_t dst = (int64_t)rec[8 * (int64_t)w + 5] * kMsg;
-    if (__builtin_isnan(old[dst + kD]) || __builtin_isnan(out[dst + kD])) return;      // (whole messages are NaN together)
-    for (int e = threadIdx.x; e < kMsg; e += kBlock) out[dst + e] = (1.0 - lam) * out[dst + e] + lam * old[dst + e];
+    const int64_t dst = (int64_t)rec[8 * (int64_t)w + 5] * km;
+    if (__builtin_isnan(old[dst + kd]) || __builtin_isnan(out[dst + kd])) return;      // (whole messages are NaN together)
+    for (int e = threadIdx.x; e < km; e += kBlock) out[dst + e] = (1.0 - lam) * out[dst + e] + lam * old[dst + e];
 }
 
-__global__ void k_fill64(double *__restrict__ buf, int64_t nslots, double eta, double lam, const int32_t *__restrict__ partner) {
+__global__ void k_fill64(const int kd, double *__restrict__ buf, int64_t nslots, double eta, double lam, const int32_t *__restrict__ partner) {
+    const int km = kd + kd * kd;      // doubles per message record: eta[kd] | Lambda[kd][kd]
     const int64_t s = blockIdx.x;
     if (s >= nslots || partner[s] < 0) return;
-    if (!__builtin_isnan(buf[s * kMsg + kD])) return;
-    for (int e = threadIdx.x; e < kMsg; e += blockDim.x) {
+    if (!__builtin_isnan(buf[s * km + kd])) return;
+    for (int e = threadIdx.x; e < km; e += blockDim.x) {
         double v = eta;
-        if (e >= kD) { const int q = e - kD; v = ((q >> 6) == (q & 63)) ? lam : 0.0; }
-        buf[s * kMsg + e] = v;
+        if (e >= kd) { const int q = e - kd; v = (q / kd == q % kd) ? lam : 0.0; }
+        buf[s * km + e] = v;
     }
 }
 
 // row-wise staging helpers for the message-major layout
-__global__ void k_rows_scatter(double *__restrict__ dst, const int32_t *__restrict__ idx, const double *__restrict__ val, int64_t n) {
+__global__ void k_rows_scatter(const int kd, double *__restrict__ dst, const int32_t *__restrict__ idx, const double *__restrict__ val, int64_t n) {
+    const int km = kd + kd * kd;      // doubles per message record: eta[kd] | Lambda[kd][kd]
     const int64_t i = blockIdx.x;
     if (i >= n) return;
-    for (int e = threadIdx.x; e < kMsg; e += blockDim.x) dst[(int64_t)idx[i] * kMsg + e] = val[i * kMsg + e];
+    for (int e = threadIdx.x; e < km; e += blockDim.x) dst[(int64_t)idx[i] * km + e] = val[i * km + e];
 }
-__global__ void k_rows_gather(const double *__restrict__ src, const int32_t *__restrict__ idx, double *__restrict__ val, int64_t n) {
+__global__ void k_rows_gather(const int kd, const double *__restrict__ src, const int32_t *__restrict__ idx, double *__restrict__ val, int64_t n) {
+    const int km = kd + kd * kd;      // doubles per message record: eta[kd] | Lambda[kd][kd]
     const int64_t i = blockIdx.x;
     if (i >= n) return;
-    for (int e = threadIdx.x; e < kMsg; e += blockDim.x) val[i * kMsg + e] = src[(int64_t)idx[i] * kMsg + e];
+    for (int e = threadIdx.x; e < km; e += blockDim.x) val[i * km + e] = src[(int64_t)idx[i] * km + e];
 }
 // observed data: eta = y, Lambda[0][0] = +inf marks the point mass (the rest of the slot is never read)
-__global__ void k_set_point64(double *__restrict__ dst, const int32_t *__restrict__ idx, const double *__restrict__ y, int64_t n) {
+__global__ void k_set_point64(const int kd, double *__restrict__ dst, const int32_t *__restrict__ idx, const double *__restrict__ y, int64_t n) {
+    const int km = kd + kd * kd;      // doubles per message record: eta[kd] | Lambda[kd][kd]
     const int64_t i = blockIdx.x;
     if (i >= n) return;
-    if (threadIdx.x < kD) dst[(int64_t)idx[i] * kMsg + threadIdx.x] = y[i * kD + threadIdx.x];
-    if (threadIdx.x == kD) dst[(int64_t)idx[i] * kMsg + kD] = __builtin_inf();
+    if (threadIdx.x < kd) dst[(int64_t)idx[i] * km + threadIdx.x] = y[i * kd + threadIdx.x];
+    if (threadIdx.x == kd) dst[(int64_t)idx[i] * km + kd] = __builtin_inf();
+}
+
+// marginals of dim 16 / 32 (the wave kernel forms them: cx_mv64w.hip): sums[w] = the sum of EVERY incoming message of variable vars[w]
+// (NaN if one is undefined); the rule records that read them, {-, w, -1, -1, table 0, destination row w, 0, 0}, are made on the host
+// (written here by thread 0 as eight int stores, hipcc 7.2 merged them into two 16-byte stores and LOST the two -1: the first store went
+// out with whatever v2, v3 held — the loop counter — and the rule kernel read a third source at slot 512)
+__global__ __launch_bounds__(kBlock) void k_sum_all64(const int kd, int n, const int32_t *__restrict__ vars, const int32_t *__restrict__ vbase,
+                                                      const int32_t *__restrict__ vdeg, const uint8_t *__restrict__ vinfo, const double *__restrict__ f2v,
+                                                      double *__restrict__ sums) {
+    const int km = kd + kd * kd;
+    const int w = blockIdx.x;
+    if (w >= n) return;
+    const int v = vars[w], info = vinfo[v];
+    const bool big = (info & kDegMask) == kBigDeg;
+    const int deg = big ? vdeg[v] : (info & kDegMask), stride = big ? 1 : kBlock, base = vbase[v];
+    for (int e = threadIdx.x; e < km; e += kBlock) {
+        double acc = deg > 0 ? 0.0 : __builtin_nan("");
+        for (int j = 0; j < deg; j++) acc += f2v[(int64_t)(base + j * stride) * km + e];
+        sums[(int64_t)w * km + e] = acc;
+    }
+}
+// (mean | minus covariance) -> (mean | covariance), in place
+__global__ void k_negate_cov64(const int kd, double *__restrict__ rows, int64_t n) {
+    const int km = kd + kd * kd;
+    const int64_t i = blockIdx.x;
+    if (i >= n) return;
+    for (int e = kd + threadIdx.x; e < km; e += blockDim.x) rows[i * km + e] = -rows[i * km + e];
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
 void mv64_rows_scatter(cx_handle *h, double *dst, const int32_t *d_idx, const double *d_val, int64_t n) {
-    if (n) hipLaunchKernelGGL(k_rows_scatter, dim3((unsigned)n), dim3(256), 0, h->stream, dst, d_idx, d_val, n);
+    if (n) hipLaunchKernelGGL(k_rows_scatter, dim3((unsigned)n), dim3(256), 0, h->stream, h->cfg.dim, dst, d_idx, d_val, n);
 }
 void mv64_rows_gather(cx_handle *h, const double *src, const int32_t *d_idx, double *d_val, int64_t n) {
-    if (n) hipLaunchKernelGGL(k_rows_gather, dim3((unsigned)n), dim3(256), 0, h->stream, src, d_idx, d_val, n);
+    if (n) hipLaunchKernelGGL(k_rows_gather, dim3((unsigned)n), dim3(256), 0, h->stream, h->cfg.dim, src, d_idx, d_val, n);
 }
 void mv64_set_point(cx_handle *h, double *dst, const int32_t *d_idx, const double *d_y, int64_t n) {
-    if (n) hipLaunchKernelGGL(k_set_point64, dim3((unsigned)n), dim3(128), 0, h->stream, dst, d_idx, d_y, n);
+    if (n) hipLaunchKernelGGL(k_set_point64, dim3((unsigned)n), dim3(128), 0, h->stream, h->cfg.dim, dst, d_idx, d_y, n);
 }
 
 void mv64_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const double *f2v_in, double *f2v_out, int kernel_id) {
@@ -639,8 +676,8 @@ void mv64_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const doubl
     // default: the wave-per-message form (cx_mv64w.hip, 5.1 ms per C5 sweep); CX_RULE64=g selects the workgroup-per-message
     // form below (8.8 ms).  Read per launch so that a test can switch forms inside one process.
     const char *form_env = getenv("CX_RULE64");
-    const int wave_form = (form_env && form_env[0] == 'g') ? 0 : 1;
-    if (wave_form && !classic)
+    const int wave_form = (form_env && form_env[0] == 'g' && h->cfg.dim == kD) ? 0 : 1;      // (the workgroup forms are written for 64)
+    if (wave_form && (!classic || h->cfg.dim != kD))
         mv64w_launch_rule(h, nwork, d_rec, f2v_in, f2v_out);
     else if (classic)
         hipLaunchKernelGGL((k_rule64<0>), dim3(nwork), dim3(kBlock), 0, h->stream, nwork, d_rec, (const int32_t *)nullptr, h->d_vbase, h->d_var_deg, h->d_vinfo,
@@ -652,33 +689,58 @@ void mv64_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const doubl
 
 void mv64_launch_marginals(cx_handle *h, int n, const int32_t *d_vars, const double *f2v, double *out) {
     if (n == 0) return;
+    if (h->cfg.dim != kD) {
+        // dim 16 / 32: the sum of a variable's messages through the wave kernel's rule with P = 0, B = I, C = 0: eta_out = M^-1 eta (the
+        // mean), Lambda_out = -M^-1; scratch (sums + records) and the identity table live with the handle
+        const int kd = h->cfg.dim, km = kd + kd * kd;
+        if (h->marg64_cap < n) {
+            if (h->d_marg64_sums) (void)hipFree(h->d_marg64_sums);
+            if (h->d_marg64_rec) (void)hipFree(h->d_marg64_rec);
+            h->d_marg64_sums = nullptr; h->d_marg64_rec = nullptr; h->marg64_cap = 0;
+            if (hipMalloc((void **)&h->d_marg64_sums, (size_t)n * km * 8) != hipSuccess || hipMalloc((void **)&h->d_marg64_rec, (size_t)n * 32) != hipSuccess) { (void)hipGetLastError(); return; }      // (the rows stay UndefValue())
+            h->marg64_cap = n;
+            std::vector<int32_t> rec((size_t)n * 8, 0);
+            for (int w = 0; w < n; w++) { rec[8 * (size_t)w + 1] = w; rec[8 * (size_t)w + 2] = -1; rec[8 * (size_t)w + 3] = -1; rec[8 * (size_t)w + 5] = w; }
+            if (hipMemcpy(h->d_marg64_rec, rec.data(), rec.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); h->marg64_cap = 0; return; }
+        }
+        if (!h->d_marg64_tab) {
+            std::vector<double> tab((size_t)4 * kd * kd, 0.0);      // P = 0 | B = I | C = 0 | B' = I
+            for (int r = 0; r < kd; r++) { tab[(size_t)kd * kd + (size_t)r * kd + r] = 1.0; tab[(size_t)3 * kd * kd + (size_t)r * kd + r] = 1.0; }
+            if (hipMalloc((void **)&h->d_marg64_tab, tab.size() * 8) != hipSuccess) { (void)hipGetLastError(); h->d_marg64_tab = nullptr; return; }
+            (void)hipMemcpy(h->d_marg64_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice);
+        }
+        hipLaunchKernelGGL(k_sum_all64, dim3(n), dim3(kBlock), 0, h->stream, kd, n, d_vars, h->d_vbase, h->d_var_deg, h->d_vinfo, f2v, h->d_marg64_sums);
+        mv64w_launch_marginal_rule(h, n, h->d_marg64_rec, h->d_marg64_tab, h->d_marg64_tab + (size_t)3 * kd * kd, h->d_marg64_sums, out);
+        hipLaunchKernelGGL(k_negate_cov64, dim3(n), dim3(256), 0, h->stream, kd, out, (int64_t)n);
+        return;
+    }
     hipLaunchKernelGGL((k_rule64<1>), dim3(n), dim3(kBlock), 0, h->stream, n, (const int32_t *)nullptr, d_vars,
                        h->d_vbase, h->d_var_deg, h->d_vinfo, h->d_ptab, f2v, h->d_mv_v2f, out);
 }
 
 void mv64_launch_point(cx_handle *h, int nwork, const int32_t *d_slots, double *out_a, double *out_b) {
     if (nwork == 0) return;
-    hipLaunchKernelGGL(k_point64, dim3(nwork), dim3(kBlock), 0, h->stream, nwork, d_slots, h->d_partner, h->d_spdir, h->d_ptab,
+    hipLaunchKernelGGL(k_point64, dim3(nwork), dim3(kBlock), 0, h->stream, h->cfg.dim, nwork, d_slots, h->d_partner, h->d_spdir, h->d_ptab,
                        h->d_mv_v2f, out_a, out_b);
 }
 
 void mv64_launch_v2f(cx_handle *h, int n, const int32_t *d_slots, const int32_t *d_vars, const double *f2v) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_v2f64, dim3(n), dim3(kBlock), 0, h->stream, n, d_slots, d_vars, h->d_vbase, h->d_var_deg, h->d_vinfo, f2v, h->d_mv_v2f);
+    hipLaunchKernelGGL(k_v2f64, dim3(n), dim3(kBlock), 0, h->stream, h->cfg.dim, n, d_slots, d_vars, h->d_vbase, h->d_var_deg, h->d_vinfo, f2v, h->d_mv_v2f);
 }
 
 void mv64_launch_range_sums(cx_handle *h, int n, const int32_t *d_rec4, const double *f2v, double *out) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_range_sum64, dim3(n), dim3(kBlock), 0, h->stream, n, d_rec4, f2v, out);
+    hipLaunchKernelGGL(k_range_sum64, dim3(n), dim3(kBlock), 0, h->stream, h->cfg.dim, n, d_rec4, f2v, out);
 }
 
 void mv64_launch_damp(cx_handle *h, int n, const int32_t *d_rec, const double *old, double *out, double lam) {
     if (n == 0 || lam == 0.0) return;
-    hipLaunchKernelGGL(k_damp64, dim3(n), dim3(kBlock), 0, h->stream, n, d_rec, old, out, lam);
+    hipLaunchKernelGGL(k_damp64, dim3(n), dim3(kBlock), 0, h->stream, h->cfg.dim, n, d_rec, old, out, lam);
 }
 
 void mv64_launch_seed(cx_handle *h, double *buf, double eta, double lam) {
-    hipLaunchKernelGGL(k_fill64, dim3((unsigned)h->nslots), dim3(256), 0, h->stream, buf, h->nslots, eta, lam, h->d_partner);
+    hipLaunchKernelGGL(k_fill64, dim3((unsigned)h->nslots), dim3(256), 0, h->stream, h->cfg.dim, buf, h->nslots, eta, lam, h->d_partner);
 }
 
 }  // namespace cx

@@ -1,4 +1,4 @@
-// cx_mv64w.hip — the d = 64 factor→variable rule with ONE WAVE PER MESSAGE and the matrices resident in registers.
+// cx_mv64w.hip — the d = 64 (round 6: also 16 and 32) factor→variable rule with ONE WAVE PER MESSAGE and the matrices resident in registers.
 //
 // Why: in the workgroup-per-message form (cx_mv64.hip, k_rule64s) the f64 vector pipe carries as many SIMD
 // cycles as its 584 matrix instructions — 77 % of them the 4 x 4 pivot factorisations that all four waves repeat — and the
@@ -43,42 +43,56 @@ using namespace w64;
 //   factorisation   M upper tiles (80) + the column-layout temporaries of diag_factor (~100); V_k go to LDS (2 KB each)
 //   solve           U off-diagonal (48) + Yt column blocks as they are finished (<= 160) + one V tile / negated U tile (16)
 //   Gram + store    Yt (160) + one G tile, one C tile; every G tile leaves for HBM as soon as its 16 instructions are done
-template <int WAVES_PER_SIMD>
+template <int WAVES_PER_SIMD, int NT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES_PER_SIMD, WAVES_PER_SIMD)))
 void k_rule64w(int nwork, const int32_t *__restrict__ work_rec, const double *__restrict__ ptab, const double *__restrict__ btab,
                const double *__restrict__ zero_msg, const double *__restrict__ f2v_in, const double *__restrict__ v2f,
                double *__restrict__ out) {
+    constexpr int KD = 16 * NT, KM = KD + KD * KD;      // (round 6) NT x NT tiles of 16: d = 16, 32, 64; a record is eta[KD] | Lambda[KD][KD]
     __shared__ double S[16 * kLdT];
-    __shared__ double Vs[4][16 * kLdT];
+    __shared__ double Vs[NT][16 * kLdT];
     const int w = blockIdx.x;
     if (w >= nwork) return;
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
     const int32_t *rec = work_rec + 8 * (int64_t)w;
     const int slot = rec[0], s0 = rec[1], s1 = rec[2], s2 = rec[3], dst_slot = rec[5], flags = rec[6];
-    const double *tab = ptab + (int64_t)rec[4] * 3 * kD * kD;
-    const double *bt = btab + (int64_t)rec[4] * kD * kD;
+    const double *tab = ptab + (int64_t)rec[4] * 3 * KD * KD;
+    const double *bt = btab + (int64_t)rec[4] * KD * KD;
     const bool fixed = (flags & kFlagFixed) != 0;
     // an absent source reads a message of zeros: a "load or skip" choice per element — even a wave-uniform one — makes hipcc
     // branch around every load and wait for it alone (336 dependent round trips per message in the first version of this kernel)
-    const double *src0 = fixed ? v2f + (int64_t)slot * kMsg : (s0 >= 0 ? f2v_in + (int64_t)s0 * kMsg : zero_msg);
-    const double *src1 = (!fixed && s1 >= 0) ? f2v_in + (int64_t)s1 * kMsg : zero_msg;
+    const double *src0 = fixed ? v2f + (int64_t)slot * KM : (s0 >= 0 ? f2v_in + (int64_t)s0 * KM : zero_msg);
+    const double *src1 = (!fixed && s1 >= 0) ? f2v_in + (int64_t)s1 * KM : zero_msg;
     const bool has2 = !fixed && s2 >= 0;
-    const double *src2 = has2 ? f2v_in + (int64_t)s2 * kMsg : zero_msg;
+    const double *src2 = has2 ? f2v_in + (int64_t)s2 * KM : zero_msg;
 
-    (void)rule64w_apply<false>((gcdp)tab, (gcdp)bt, (gcdp)(tab + 2 * kD * kD), nullptr, nullptr, (gcdp)src0, (gcdp)src1, (gcdp)src2, has2,
-                               (gdp)(out + (int64_t)dst_slot * kMsg), S, Vs, lane, g, c);
+    (void)rule64w_apply<false, false, NT>((gcdp)tab, (gcdp)bt, (gcdp)(tab + 2 * KD * KD), nullptr, nullptr, (gcdp)src0, (gcdp)src1, (gcdp)src2, has2,
+                                          (gdp)(out + (int64_t)dst_slot * KM), S, Vs, lane, g, c);
 }
 
-void mv64w_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const double *f2v_in, double *f2v_out) {
+// the launch for the handle's tile count; the tables and the stored variable→factor messages may be given (the marginal read-out of
+// dim 16 / 32 runs the rule on a table of its own: P = 0, B = I, C = 0 gives (M^-1 eta, -M^-1))
+static void launch_rule_tiles(cx_handle *h, int nwork, const int32_t *d_rec, const double *ptab, const double *btab, const double *f2v_in, const double *v2f, double *out) {
     static const int one = [] { const char *e = getenv("CX_RULE64_WAVES"); return (e && e[0] == '1') ? 1 : 0; }();
     // (holding back the odd wave slot of every SIMD's first pair by half a message, so that the two waves would not run their
     // vector and matrix phases in lockstep, was measured in tools/ab_c5.py: no difference at 2, 3, 4 or 6 x 8k cycles)
-    if (one)
-        hipLaunchKernelGGL(k_rule64w<1>, dim3(nwork), dim3(64), 0, h->stream, nwork, d_rec, h->d_ptab, h->d_ptab_bt, h->d_zero_msg, f2v_in,
-                           h->d_mv_v2f, f2v_out);
-    else
-        hipLaunchKernelGGL(k_rule64w<2>, dim3(nwork), dim3(64), 0, h->stream, nwork, d_rec, h->d_ptab, h->d_ptab_bt, h->d_zero_msg, f2v_in,
-                           h->d_mv_v2f, f2v_out);
+    // 1 x 1 and 2 x 2 tiles hold their matrices in a few registers: four waves per SIMD (128 registers: the diagonal tile's column arrays)
+#define CX_R(W, N) hipLaunchKernelGGL((k_rule64w<W, N>), dim3(nwork), dim3(64), 0, h->stream, nwork, d_rec, ptab, btab, h->d_zero_msg, f2v_in, v2f, out)
+    if (h->cfg.dim == 16) CX_R(4, 1);
+    else if (h->cfg.dim == 32) CX_R(4, 2);
+    else if (one) CX_R(1, 4);
+    else CX_R(2, 4);
+#undef CX_R
+}
+
+void mv64w_launch_rule(cx_handle *h, int nwork, const int32_t *d_rec, const double *f2v_in, double *f2v_out) {
+    launch_rule_tiles(h, nwork, d_rec, h->d_ptab, h->d_ptab_bt, f2v_in, h->d_mv_v2f, f2v_out);
+}
+
+// marginals of dim 16 / 32 (dim 64: k_rule64<1>, cx_mv64.hip): `sums` holds the sum of every incoming message of the w-th listed
+// variable (k_sum_all64), `d_rec` one record per variable {-, w, -1, -1, 0, w, 0, 0}; out[w] = (mean | MINUS the covariance)
+void mv64w_launch_marginal_rule(cx_handle *h, int n, const int32_t *d_rec, const double *ident_tab, const double *ident_bt, const double *sums, double *out) {
+    if (n) launch_rule_tiles(h, n, d_rec, ident_tab, ident_bt, sums, sums, out);
 }
 
 }  // namespace cx

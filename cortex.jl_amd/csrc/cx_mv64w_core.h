@@ -51,8 +51,10 @@ __device__ __forceinline__ d4 tts(const d4 &T, const d4 &S, d4 acc) {
 
 __device__ __forceinline__ d4 neg(const d4 &T) { return d4{-T[0], -T[1], -T[2], -T[3]}; }
 
-// index of the upper tile (a, b), a <= b, in a 10-entry array
-__device__ __forceinline__ constexpr int ut(int a, int b) { return a * 4 - a * (a - 1) / 2 + (b - a); }
+// index of the upper tile (a, b), a <= b, among the NT (NT + 1) / 2 upper tiles of a matrix of NT x NT tiles (4 x 4: a 10-entry array)
+template <int NT>
+__device__ __forceinline__ constexpr int utn(int a, int b) { return a * NT - a * (a - 1) / 2 + (b - a); }
+__device__ __forceinline__ constexpr int ut(int a, int b) { return utn<4>(a, b); }
 
 // acc += (lane I of this lane's 16-lane row).row_val * mul — v_fmac_f64 with the DPP control row_newbcast (gfx90a and later: the only
 // DPP control 64-bit vector instructions take).  A VGPR written by a vector instruction needs two wait states before a DPP read
@@ -137,7 +139,9 @@ __device__ __forceinline__ int tile_off(int tr, int tc, int r, int g, int c) { r
 // lane but the one offset, which is what a kernel that LOOPS over rules needs to stay under 256 registers (with pointers hipcc
 // keeps a 64-bit address or a 32-bit offset per tile row that is out of reach of the 13-bit immediate, hoists them out of the
 // loop and spills: cx_mv64chain.hip).  Reads past the end of a buffer return zero; nothing relies on that.
-__device__ __forceinline__ constexpr int tile_const(int a, int b, int r) { return (16 * a + 4 * r) * kD + 16 * b; }
+template <int NT>
+__device__ __forceinline__ constexpr int tile_const_n(int a, int b, int r) { return (16 * a + 4 * r) * (16 * NT) + 16 * b; }
+__device__ __forceinline__ constexpr int tile_const(int a, int b, int r) { return tile_const_n<4>(a, b, r); }
 struct PtrAcc {
     gdp p;
     __device__ __forceinline__ double ld(int lane_part, int cst) const { return p[lane_part + cst]; }
@@ -181,14 +185,17 @@ __device__ __forceinline__ BufAcc buf_of(gcdp p) { return BufAcc{__builtin_amdgc
 // ZS (optional): 64 doubles of LDS private to this wave.  With it z = U^-T eta_in waits there between its solve and its use (eta_out =
 // Yt' z) instead of in 32 registers across the matrix solve — what the loops of cx_mv64chain.hip need to stay under 256 registers at two
 // waves per SIMD without spilling (over the limit hipcc also un-clusters the loads: one memory round trip per load).
-template <bool AFFINE, bool Z_IN_LDS, bool CHUNKED, class A>
+// NT (round 6): the matrices are NT x NT tiles of 16 — d = 16, 32 or 64; a message record is eta[16 NT] | Lambda[16 NT][16 NT].
+template <bool AFFINE, bool Z_IN_LDS, bool CHUNKED, class A, int NT = 4>
 __device__ __forceinline__ bool rule64_body(const A tabP, const A bt, const A tabC, const A hv, const A cv, const A src0, const A src1, const A src2, const bool has2,
                                             const A dst, double *S, double (*Vs)[16 * kLdT], const int lane, const int g, const int c, double *ZS = nullptr) {
     W64_STAMP_INIT;
     (void)lane;
-    const int mo = g * kD + c;          // the per-lane part of every matrix access
+    static_assert(!CHUNKED || NT == 4, "the chunked operand loads are written for 4 x 4 tiles");
+    constexpr int KD = 16 * NT, NU = NT * (NT + 1) / 2;      // the dimension; upper tiles
+    const int mo = g * KD + c;          // the per-lane part of every matrix access
     // ---- M = P + sum of the other incoming Lambdas (ascending neighbour order), upper tiles only ------------------------------
-    d4 M[10];
+    d4 M[NU];
     if constexpr (CHUNKED) {
         // a kernel that loops over rules: four tiles' worth of operands in flight at a time, each sum pinned where it is made.
         // Left to itself hipcc, at 256 registers, falls back to its minimum-pressure schedule for this block: one memory round trip
@@ -205,7 +212,7 @@ __device__ __forceinline__ bool rule64_body(const A tabP, const A bt, const A ta
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int o = tile_const(a, b, r);
-                        M[t][r] = tabP.ld(mo, o); X0[t - t0][r] = src0.ld(mo, kD + o); X1[t - t0][r] = src1.ld(mo, kD + o);
+                        M[t][r] = tabP.ld(mo, o); X0[t - t0][r] = src0.ld(mo, KD + o); X1[t - t0][r] = src1.ld(mo, KD + o);
                     }
                 }
             // (the loads above are written first and the additions after them: under register pressure hipcc keeps source order)
@@ -229,7 +236,7 @@ __device__ __forceinline__ bool rule64_body(const A tabP, const A bt, const A ta
                         const int t = ut(a, b);
                         if (t < t0 || t >= t0 + 5) continue;
 #pragma unroll
-                        for (int r = 0; r < 4; r++) X2[t - t0][r] = src2.ld(mo, kD + tile_const(a, b, r));
+                        for (int r = 0; r < 4; r++) X2[t - t0][r] = src2.ld(mo, KD + tile_const(a, b, r));
                     }
 #pragma unroll
                 for (int t = t0; t < t0 + 5; t++)
@@ -243,21 +250,21 @@ __device__ __forceinline__ bool rule64_body(const A tabP, const A bt, const A ta
         }
     } else {
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int a = 0; a < NT; a++)
 #pragma unroll
-        for (int b = a; b < 4; b++)
+        for (int b = a; b < NT; b++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int o = tile_const(a, b, r);
-                M[ut(a, b)][r] = (tabP.ld(mo, o) + src0.ld(mo, kD + o)) + src1.ld(mo, kD + o);
+                const int o = tile_const_n<NT>(a, b, r);
+                M[utn<NT>(a, b)][r] = (tabP.ld(mo, o) + src0.ld(mo, KD + o)) + src1.ld(mo, KD + o);
             }
     if (has2) {      // a third source (a sender of degree 4) is rare: ONE branch around the whole block of loads
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+        for (int a = 0; a < NT; a++)
 #pragma unroll
-            for (int b = a; b < 4; b++)
+            for (int b = a; b < NT; b++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) M[ut(a, b)][r] += src2.ld(mo, kD + tile_const(a, b, r));
+                for (int r = 0; r < 4; r++) M[utn<NT>(a, b)][r] += src2.ld(mo, KD + tile_const_n<NT>(a, b, r));
     }
     }
     // a dependency is undefined (whole messages are NaN together): the signal is not pending
@@ -266,18 +273,18 @@ __device__ __forceinline__ bool rule64_body(const A tabP, const A bt, const A ta
 
     // ---- blocked upper Cholesky, NB = 16: off-diagonal tiles of M become U, V_k = U_kk^-1 goes to LDS -------------------------
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const d4 Vk = diag_factor(M[ut(k, k)], S, g, c);
+    for (int k = 0; k < NT; k++) {
+        const d4 Vk = diag_factor(M[utn<NT>(k, k)], S, g, c);
         W64_STAMP(1);
 #pragma unroll
         for (int r = 0; r < 4; r++) Vs[k][(g + 4 * r) * kLdT + c] = Vk[r];
 #pragma unroll
-        for (int j = k + 1; j < 4; j++) M[ut(k, j)] = tts(Vk, M[ut(k, j)], d4{0.0, 0.0, 0.0, 0.0});        // U[k][j] = V_k' M[k][j]
+        for (int j = k + 1; j < NT; j++) M[utn<NT>(k, j)] = tts(Vk, M[utn<NT>(k, j)], d4{0.0, 0.0, 0.0, 0.0});        // U[k][j] = V_k' M[k][j]
 #pragma unroll
-        for (int i = k + 1; i < 4; i++) {
-            const d4 nu = neg(M[ut(k, i)]);
+        for (int i = k + 1; i < NT; i++) {
+            const d4 nu = neg(M[utn<NT>(k, i)]);
 #pragma unroll
-            for (int j = i; j < 4; j++) M[ut(i, j)] = tts(nu, M[ut(k, j)], M[ut(i, j)]);                       // M[i][j] -= U[k][i]' U[k][j]
+            for (int j = i; j < NT; j++) M[utn<NT>(i, j)] = tts(nu, M[utn<NT>(k, j)], M[utn<NT>(i, j)]);                       // M[i][j] -= U[k][i]' U[k][j]
         }
         W64_STAMP(2);
     }
@@ -287,9 +294,9 @@ __device__ __forceinline__ bool rule64_body(const A tabP, const A bt, const A ta
     //      instructions, on tiles that are 15/16 zeros).  Two vector layouts: RV — lane (g, c) holds x[g + 4 r] in register r
     //      (indexed like tile rows); CV — lane (g, c) holds y[c] (indexed like tile columns).  T' x for a tile T: four FMAs per lane
     //      and a sum over the four lane groups gives CV; CV -> RV is four lane reads. -----------------------------------------------
-    double zrv[4][4];
+    double zrv[NT][4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < NT; j++) {
         double wcv = src0.ld(c, 16 * j) + src1.ld(c, 16 * j);
         if (has2) wcv += src2.ld(c, 16 * j);
         if (AFFINE) wcv += hv.ld(c, 16 * j);
@@ -297,7 +304,7 @@ __device__ __forceinline__ bool rule64_body(const A tabP, const A bt, const A ta
         for (int k = 0; k < j; k++) {
             double p = 0.0;
 #pragma unroll
-            for (int r = 0; r < 4; r++) p += M[ut(k, j)][r] * zrv[k][r];
+            for (int r = 0; r < 4; r++) p += M[utn<NT>(k, j)][r] * zrv[k][r];
             wcv -= sum_groups(p);                                                      // eta_j - sum_k U[k][j]' z_k
         }
         double p = 0.0;
@@ -308,60 +315,60 @@ __device__ __forceinline__ bool rule64_body(const A tabP, const A bt, const A ta
         for (int r = 0; r < 4; r++) zrv[j][r] = cv_to_rv(zcv, g, r);
         if (Z_IN_LDS && g == 0) ZS[16 * j + c] = zcv;
     }
-    const bool z_undefined = __builtin_isnan(bcast(zrv[3][0], 0));
+    const bool z_undefined = __builtin_isnan(bcast(zrv[NT - 1][0], 0));
 
     W64_STAMP(3);
     // ---- Yt = U^-T B', one block COLUMN at a time (forward substitution over its four row blocks) ------------------------------
-    d4 Y[4][4];
+    d4 Y[NT][NT];
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
+    for (int b = 0; b < NT; b++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < NT; j++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) Y[j][b][r] = bt.ld(mo, tile_const(j, b, r));
+            for (int r = 0; r < 4; r++) Y[j][b][r] = bt.ld(mo, tile_const_n<NT>(j, b, r));
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NT; j++) {
             d4 Vj;
 #pragma unroll
             for (int r = 0; r < 4; r++) Vj[r] = Vs[j][(g + 4 * r) * kLdT + c];
             Y[j][b] = tts(Vj, Y[j][b], d4{0.0, 0.0, 0.0, 0.0});                                                  // Yt[j] = V_j' R[j]
 #pragma unroll
-            for (int jj = j + 1; jj < 4; jj++) Y[jj][b] = tts(neg(M[ut(j, jj)]), Y[j][b], Y[jj][b]);           // R[jj] -= U[j][jj]' Yt[j]
+            for (int jj = j + 1; jj < NT; jj++) Y[jj][b] = tts(neg(M[utn<NT>(j, jj)]), Y[j][b], Y[jj][b]);           // R[jj] -= U[j][jj]' Yt[j]
         }
     }
     // not positive definite somewhere: NaN everywhere downstream — leave the old message
-    if (__builtin_isnan(bcast(Y[3][0][0], 0)) || z_undefined) return false;
+    if (__builtin_isnan(bcast(Y[NT - 1][0][0], 0)) || z_undefined) return false;
     W64_STAMP(4);
 
     // ---- Gram tile by tile: G[a][b] = sum_j Yt[j][a]' Yt[j][b];  Lambda_out = C - G (C symmetric: the lower tiles are the
     //      transposes of the same differences, turned through LDS);  eta_out = Yt' z on the vector pipe ---------------------------
 #pragma unroll
-    for (int a = 0; a < 4; a++) {
+    for (int a = 0; a < NT; a++) {
 #pragma unroll
-        for (int b = a; b < 4; b++) {
+        for (int b = a; b < NT; b++) {
             d4 Ct;
 #pragma unroll
-            for (int r = 0; r < 4; r++) Ct[r] = tabC.ld(mo, tile_const(a, b, r));
+            for (int r = 0; r < 4; r++) Ct[r] = tabC.ld(mo, tile_const_n<NT>(a, b, r));
             d4 G = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int j = 0; j < 4; j++) G = tts(Y[j][a], Y[j][b], G);
+            for (int j = 0; j < NT; j++) G = tts(Y[j][a], Y[j][b], G);
             d4 D;
 #pragma unroll
             for (int r = 0; r < 4; r++) D[r] = Ct[r] - G[r];
 #pragma unroll
-            for (int r = 0; r < 4; r++) dst.st(mo, kD + tile_const(a, b, r), D[r]);
+            for (int r = 0; r < 4; r++) dst.st(mo, KD + tile_const_n<NT>(a, b, r), D[r]);
             if (b > a) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the previous tile's reads have returned
 #pragma unroll
                 for (int r = 0; r < 4; r++) S[(g + 4 * r) * kLdT + c] = D[r];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int r = 0; r < 4; r++) dst.st(mo, kD + tile_const(b, a, r), S[c * kLdT + g + 4 * r]);
+                for (int r = 0; r < 4; r++) dst.st(mo, KD + tile_const_n<NT>(b, a, r), S[c * kLdT + g + 4 * r]);
             }
         }
         double p = 0.0;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < NT; j++)
 #pragma unroll
             for (int r = 0; r < 4; r++) p += Y[j][a][r] * (Z_IN_LDS ? ZS[16 * j + g + 4 * r] : zrv[j][r]);
         double ecv = sum_groups(p);                                                    // (Yt' z)[16 a + c]
@@ -375,10 +382,10 @@ __device__ __forceinline__ bool rule64_body(const A tabP, const A bt, const A ta
 
 
 // the rule on plain pointers (k_rule64w, k_step64)
-template <bool AFFINE, bool Z_IN_LDS = false>
+template <bool AFFINE, bool Z_IN_LDS = false, int NT = 4>
 __device__ __forceinline__ bool rule64w_apply(gcdp tabP, gcdp bt, gcdp tabC, gcdp hv, gcdp cv, gcdp src0, gcdp src1, gcdp src2, const bool has2, gdp dst,
                                               double *S, double (*Vs)[16 * kLdT], const int lane, const int g, const int c, double *ZS = nullptr) {
-    return rule64_body<AFFINE, Z_IN_LDS, false, PtrAcc>(acc_of(tabP), acc_of(bt), acc_of(tabC), acc_of(hv), acc_of(cv), acc_of(src0), acc_of(src1), acc_of(src2), has2,
+    return rule64_body<AFFINE, Z_IN_LDS, false, PtrAcc, NT>(acc_of(tabP), acc_of(bt), acc_of(tabC), acc_of(hv), acc_of(cv), acc_of(src0), acc_of(src1), acc_of(src2), has2,
                                                  acc_of((gcdp)dst), S, Vs, lane, g, c, ZS);
 }
 // the rule on buffer descriptors (the walks that loop inside a kernel: cx_mv64chain.hip)

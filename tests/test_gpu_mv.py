@@ -446,16 +446,21 @@ def test_mv_tree_with_variables_of_degree_up_to_eight(hip_lib, d, b):
     assert not np.all(np.isnan(vm))
 
 
-# ------------------------------------------------------------------------------- dim 5 .. 63: embedded in the dim 64 path
+# ------------------------------------------------------------------------------- dim 5 .. 63: in 1 x 1, 2 x 2 or 4 x 4 tiles of 16
 
-@pytest.mark.parametrize("d", [5, 6, 16, 33, 63])
+@pytest.mark.parametrize("d", [5, 6, 16, 20, 32, 33, 63])
 def test_dimensions_between_4_and_64_run_embedded_in_the_mfma_path(hip_lib, d):
-    """cfg.dim of 5 .. 63 (a constant-velocity model has d = 6, ...): the handle runs as dim 64 with every rule matrix, message and
-    datum block-diagonal (real block, identity block) — payloads stay d and d + d*d doubles.  Per sweep against the numpy restatement in
-    dimension d, then the block-tridiagonal solve; the chain-scan schedule gives the same marginals in ONE sweep."""
+    """cfg.dim of 5 .. 63 (a constant-velocity model has d = 6, ...): the handle runs on the matrix-core path in the smallest of 16, 32,
+    64 that holds d (round 6; the chain-scan schedule: always 64), every rule matrix, message and datum block-diagonal (real block, identity
+    block) where d is in between — payloads stay d and d + d*d doubles.  Per sweep against the numpy restatement in dimension d, then the
+    block-tridiagonal solve; the chain-scan schedule gives the same marginals in ONE sweep."""
     T = 7
     model = cx.synth.lgssm_chain(T, d=d, seed=30 + d)
     dev = _dev(model)
+    # the storage is the tile size's: a message record is eta[nd] | Lambda[nd][nd]
+    nd = 16 if d <= 16 else 32 if d <= 32 else 64
+    st = dev.stats()
+    assert st["device_bytes"] < 3.3 * st["n_slots"] * (nd + nd * nd) * 8 + (2 << 20), (d, nd, st)
     o = MvFlood(model)
     g = o.g
     xs_set = set(np.searchsorted(g.var_ids, model.x_ids).tolist())
@@ -525,3 +530,33 @@ def test_product_of_messages_items_for_variables_of_degree_above_five(hip_lib, d
     assert np.all(np.isnan(mom[1]))
     with pytest.raises(cx.CortexHipError, match="outside 1:"):
         dev.update_batch([L.ITEM_PRODUCT_OF_MESSAGES], [root], [L.item_range(1, deg + 1)])
+
+
+@pytest.mark.parametrize("d", [8, 16, 24, 32])
+def test_native_tiles_equal_the_embedding_in_64(hip_lib, monkeypatch, d):
+    """(round 6) the same model in its native tile size (1 x 1 or 2 x 2 tiles of 16) and embedded in 4 x 4 tiles (CX_MFMA_DIM=64, the only
+    form until round 5): every message after every sweep and every marginal agree to rounding; the native handle holds (nd + nd^2) /
+    (64 + 64^2) of the bytes"""
+    T = 12
+    model = cx.synth.lgssm_chain(T, d=d, seed=70 + d)
+    a = _dev(model)
+    monkeypatch.setenv("CX_MFMA_DIM", "64")
+    b = _dev(model)
+    monkeypatch.delenv("CX_MFMA_DIM")
+    nd = 16 if d <= 16 else 32
+    sa, sb = a.stats(), b.stats()
+    assert sa["n_slots"] == sb["n_slots"] and sa["device_bytes"] < sb["device_bytes"] * 1.35 * (nd + nd * nd) / (64 + 64 * 64) + (2 << 20), (sa, sb)
+    xs = set(int(v) for v in model.x_ids)
+    keep = np.array([int(v) in xs for v in model.edge_var])
+    ev, ef = model.edge_var[keep], model.edge_fac[keep]
+    for sweep in range(T + 2):
+        a.sweep(1); b.sweep(1)
+        ma, mb = a.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL), b.get_messages(ev, ef, L.TO_VARIABLE, L.FORM_NATURAL)
+        assert np.array_equal(np.isnan(ma), np.isnan(mb)), f"sweep {sweep}"
+        ok = ~np.isnan(ma)
+        assert_close(ma[ok], mb[ok], 1e-9, f"d={d} sweep {sweep}: messages, native tiles vs embedded")
+    assert_close(a.get_marginals(model.x_ids), b.get_marginals(model.x_ids), 1e-9, f"d={d}: marginals, native tiles vs embedded")
+    em, ecov = exact.lgssm_posterior(model.data_y, model.meta["A"], model.meta["Q"], model.meta["R"])
+    marg = a.get_marginals(model.x_ids)
+    assert_close(marg[:, :d], em, 1e-8, f"d={d}: marginal mean vs block-tridiagonal solve")
+    assert_close(marg[:, d:].reshape(T, d, d), ecov, 1e-8, f"d={d}: marginal covariance vs block-tridiagonal solve")
