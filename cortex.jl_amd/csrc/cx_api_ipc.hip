@@ -69,7 +69,11 @@ constexpr int kIpcBlock = 1024, kIpcItems = 4;   // few, fat workgroups: the com
 // What travels is 16-byte UNITS: a scalar message is one (its double2), a message of dim 2 - 4 is ncp of them — the pairs of its
 // block-major storage form (cx_mv_core.h: slot_offset; pair q of slot s is unit ((s >> 8) ncp + q) 256 + (s & 255) of the buffer).
 // Unit u of a halo list is pair u % ncp of its message u / ncp; send / receive offsets and counts are in units.
-__device__ __forceinline__ int64_t ipc_unit(int32_t slot, int q, int ncp) { return ((int64_t)(slot >> 8) * ncp + q) * 256 + (slot & 255); }
+// (round 6) the matrix-core dims (16, 32, 64) store a message as one record of nc doubles: unit q of slot s is unit s nc / 2 + q; the
+// launchers say so with a NEGATIVE unit count
+__device__ __forceinline__ int64_t ipc_unit(int32_t slot, int q, int ncp) {
+    return ncp < 0 ? (int64_t)slot * (-ncp) + q : ((int64_t)(slot >> 8) * ncp + q) * 256 + (slot & 255);
+}
 
 __device__ __forceinline__ void ipc_push_block(int64_t block, unsigned int nblocks, const double2 *__restrict__ f2v, const int32_t *__restrict__ send_slots,
                                                int64_t n, int ncp, const PushArgs &a, unsigned long long epoch, unsigned int *__restrict__ done) {
@@ -80,8 +84,9 @@ __device__ __forceinline__ void ipc_push_block(int64_t block, unsigned int nbloc
 #pragma unroll
     for (int k = 0; k < kIpcItems; k++) {
         const int64_t i = base + k * kIpcBlock;
-        const unsigned int u = (unsigned int)i, mi = ncp == 1 ? u : u / (unsigned int)ncp;
-        q[k] = ncp == 1 ? 0 : (int)(u - mi * (unsigned int)ncp);
+        const unsigned int an = (unsigned int)(ncp < 0 ? -ncp : ncp);
+        const unsigned int u = (unsigned int)i, mi = an == 1 ? u : u / an;
+        q[k] = an == 1 ? 0 : (int)(u - mi * an);
         slot[k] = i < n ? send_slots[mi] : -1;
     }
 #pragma unroll
@@ -117,8 +122,9 @@ __device__ __forceinline__ void ipc_unpack_block(int64_t block, double2 *__restr
 #pragma unroll
     for (int k = 0; k < kIpcItems; k++) {                    // while thread 0 waits
         const int64_t i = base + k * kIpcBlock;
-        const unsigned int u = (unsigned int)i, mi = ncp == 1 ? u : u / (unsigned int)ncp;
-        q[k] = ncp == 1 ? 0 : (int)(u - mi * (unsigned int)ncp);
+        const unsigned int an = (unsigned int)(ncp < 0 ? -ncp : ncp);
+        const unsigned int u = (unsigned int)i, mi = an == 1 ? u : u / an;
+        q[k] = an == 1 ? 0 : (int)(u - mi * an);
         slot[k] = i < n ? recv_slots[mi] : -1;
     }
     if (threadIdx.x == 0) {
@@ -179,6 +185,8 @@ namespace cx {
 
 // 16-byte units per message (scalar: 1; dim 2 - 4: the pairs of the storage form) and the buffer they live in
 static inline int ipc_ncp(const cx_handle *h) { return h->cfg.dim == 1 ? 1 : (int)(h->ncs / 2); }
+// what the kernels are told: negative for the message-major records of the matrix-core dims (ipc_unit)
+static inline int ipc_ncp_signed(const cx_handle *h) { return is_mfma_dim(h->cfg.dim) ? -ipc_ncp(h) : ipc_ncp(h); }
 static inline double2 *ipc_messages(cx_handle *h) { return h->cfg.dim == 1 ? (double2 *)h->d_f2v : (double2 *)h->d_mv_f2v; }
 
 void ipc_destroy(cx_handle *h) {
@@ -196,7 +204,7 @@ extern "C" {
 
 int32_t cx_halo_ipc_alloc(cx_handle *h, void *handle64, void **local_base, int64_t *area_bytes) {
     CX_REQUIRE(h, h && h->has_graph && h->halo_state, CX_ERR_STATE, "cx_halo_ipc_alloc: call cx_halo_configure_state first");
-    CX_REQUIRE(h, h->cfg.dim >= 1 && h->cfg.dim <= 4, CX_ERR_UNSUPPORTED, "cx_halo_ipc_alloc: dim 1 - 4; dim 64 partitions exchange through cx_halo_state_exchange");
+    // (round 6: the matrix-core dims too — a message record travels as nc / 2 units)
     CX_REQUIRE(h, handle64 && local_base && area_bytes, CX_ERR_INVALID_ARGUMENT, "cx_halo_ipc_alloc: null argument");
     CX_REQUIRE(h, !h->peers.empty() && (int)h->peers.size() <= kMaxPeers, CX_ERR_STATE, "cx_halo_ipc_alloc: call cx_halo_peers first (1 to 8 neighbours)");
     CX_REQUIRE(h, (int64_t)std::max(h->send_slots.size(), h->recv_slots.size()) * cx::ipc_ncp(h) < (1ll << 31), CX_ERR_UNSUPPORTED,
@@ -303,7 +311,7 @@ static int32_t ipc_push(cx_handle *h, const char *who, const double2 *src = null
     const int64_t ns = (int64_t)h->send_slots.size() * ncp;
     // the push runs even with nothing to send: its last workgroup raises the flags the neighbours wait for
     hipLaunchKernelGGL(k_ipc_push, dim3((unsigned)std::max<int64_t>((ns + kIpcBlock * kIpcItems - 1) / (kIpcBlock * kIpcItems), 1)), dim3(kIpcBlock), 0, h->stream,
-                       src ? src : (const double2 *)cx::ipc_messages(h), (const int32_t *)h->d_send_slots, ns, ncp, a, epoch, (unsigned int *)h->d_ipc_local);
+                       src ? src : (const double2 *)cx::ipc_messages(h), (const int32_t *)h->d_send_slots, ns, cx::ipc_ncp_signed(h), a, epoch, (unsigned int *)h->d_ipc_local);
     h->ipc_pushed = (int64_t)epoch;
     CX_HIP(h, hipGetLastError());
     return CX_OK;
@@ -324,7 +332,7 @@ static int32_t ipc_unpack(cx_handle *h, const char *who) {
     const double2 *area = (const double2 *)((char *)h->d_ipc_block + kFlagBytes + (int64_t)par * h->ipc_area_bytes);
     const unsigned long long limit = (unsigned long long)(h->ipc_timeout_s * 1e8);       // wall_clock64: 100 MHz
     hipLaunchKernelGGL(k_ipc_unpack, dim3((unsigned)std::max<int64_t>((nr + kIpcBlock * kIpcItems - 1) / (kIpcBlock * kIpcItems), 1)), dim3(kIpcBlock), 0, h->stream,
-                       cx::ipc_messages(h), (const int32_t *)h->d_recv_slots, area, nr, ncp, w, epoch, limit, (int *)h->d_ipc_local + 1);
+                       cx::ipc_messages(h), (const int32_t *)h->d_recv_slots, area, nr, cx::ipc_ncp_signed(h), w, epoch, limit, (int *)h->d_ipc_local + 1);
     h->ipc_epoch = (int64_t)epoch;
     h->sweeps_since_exchange = 0;
     CX_HIP(h, hipGetLastError());
@@ -369,7 +377,7 @@ int32_t cx_halo_ipc_exchange(cx_handle *h) {
     const unsigned int n_push = (unsigned)std::max<int64_t>((ns + per - 1) / per, 1), n_unpack = (unsigned)std::max<int64_t>((nr + per - 1) / per, 1);
     const double2 *area = (const double2 *)((char *)h->d_ipc_block + kFlagBytes + (int64_t)par * h->ipc_area_bytes);
     const unsigned long long limit = (unsigned long long)(h->ipc_timeout_s * 1e8);       // wall_clock64: 100 MHz
-    hipLaunchKernelGGL(k_ipc_exchange, dim3(n_push + n_unpack), dim3(kIpcBlock), 0, h->stream, cx::ipc_messages(h), (const int32_t *)h->d_send_slots, ns, ncp, a,
+    hipLaunchKernelGGL(k_ipc_exchange, dim3(n_push + n_unpack), dim3(kIpcBlock), 0, h->stream, cx::ipc_messages(h), (const int32_t *)h->d_send_slots, ns, cx::ipc_ncp_signed(h), a,
                        n_push, (unsigned int *)h->d_ipc_local, (const int32_t *)h->d_recv_slots, area, nr, w, epoch, limit, (int *)h->d_ipc_local + 1);
     h->ipc_epoch = h->ipc_pushed = (int64_t)epoch;
     h->sweeps_since_exchange = 0;
