@@ -483,7 +483,7 @@ def other_configs(parity=None) -> list:
                      ("C3-scan", lambda: bc.mv_scan(4, 1_000_000, 30, check=hooks.get("C3-scan"))[0]),
                      ("C5", lambda: bc.mv(64, 100_000, 12)),
                      # (round 6) d = 16 in its native tile size beside the embedding in 64 x 64 that every d in 5 .. 63 ran in until round 5
-                     ("d=16 native tiles", lambda: bc.mv_tiles(16, 100_000, 20)),
+                     ("d=16 native tiles", lambda: bc.mv_tiles(16, 100_000, 20, embedded_T=20_000)),
                      ("C5-scan", lambda: bc.mv64_scan(100_000, 8, check=hooks.get("C5-scan"))[0]),
                      ("VMP", lambda: bc.vmp()),
                      # the same structured model as a user wiring under the reference-order schedule (cx_graph_wire): replayed plans per call
