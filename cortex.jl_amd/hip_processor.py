@@ -38,7 +38,7 @@ from .inference_engine import (AbstractInferenceRequestProcessor, InferenceEngin
 from .dependencies import DefaultDependencyResolver
 from .inference_signal import InferenceSignalVariants as V
 from .model_engine import get_factor_functional_form, get_variable_marginal
-from .signal import Signal, is_pending, set_value as _host_set_value
+from .signal import ALL_FRESH, _M64, Signal, is_pending, set_value as _host_set_value
 
 
 @dataclass(frozen=True)
@@ -443,12 +443,26 @@ class HipProcessor(AbstractInferenceRequestProcessor):
             key = (id(engine), len(ids), ids[0] if len(ids) else None, ids[-1] if len(ids) else None)
             kept = getattr(self, "_ref_request", None)
             if kept is None or kept[0] != key or kept[1] != list(ids):
-                kept = (key, list(ids), np.ascontiguousarray(ids, dtype=np.int64), [get_variable_marginal(engine.get_variable(vid)) for vid in ids])
+                margs = [get_variable_marginal(engine.get_variable(vid)) for vid in ids]
+                kept = (key, list(ids), np.ascontiguousarray(ids, dtype=np.int64), margs, [HipValue(self, m.variant) for m in margs])
                 self._ref_request = kept
             self.dev.sweep_for(kept[2])
             self.launches += 1
-            for m in kept[3]:
-                _host_set_value(m, HipValue(self, m.variant))
+            # set_value!(marginal, handle) per requested marginal (signal.jl:232-253), spelt out: the handle object is kept and only
+            # forgets what it read last time; a marginal that somebody listens to goes through the general function
+            fresh_mask = ~ALL_FRESH & _M64
+            for m, hv in zip(kept[3], kept[4]):
+                if m.listeners:
+                    hv._cache = None
+                    _host_set_value(m, hv)
+                    continue
+                hv._cache = None
+                m.value = hv
+                ch = m.dependencies_props.chunks
+                for c in range(len(ch)):
+                    ch[c] &= fresh_mask
+                m.is_potentially_pending = False
+                m._is_pending = False
             return True
         if self.mode == "sweep":
             self.dev.sweep(self.n_sweeps)
