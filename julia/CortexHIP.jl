@@ -29,7 +29,7 @@ end
 check(h, rc) = rc == 0 ? nothing : error(unsafe_string(ccall((:cx_last_error, lib), Cstring, (Ptr{Cvoid},), h)))
 
 # schedule: 0 flooding, 1 fused (default), 2 chain scan (paths: one cx_sweep = one update_marginals!), 3 tree (any forest: the same),
-#           4 REFERENCE ORDER (ABI 3; dim 1 - 4): ANY graph, loops included — update_marginals!(engine, ids) below becomes ONE cx_sweep_for(ids):
+#           4 REFERENCE ORDER (ABI 3; every dim since ABI 4): ANY graph, loops included — update_marginals!(engine, ids) below becomes ONE cx_sweep_for(ids):
 #           the signals Cortex.jl's own scheduler would compute for exactly this request, in its order, each from the values its rule
 #           call would read (the library keeps a shadow of the readiness nibbles, driven by set_datum! / set_message! / process! / the
 #           calls themselves), replayed as one graph launch; lazy like the reference (priors are re-set before a call to be fresh)
@@ -290,6 +290,14 @@ end
 function chain_plan_stats(p)
     out = zeros(Int64, 8)
     check(p.handle, ccall((:cx_chain_plan_stats, lib), Int32, (Ptr{Cvoid}, Ptr{Int64}), p.handle, out))
+    out
+end
+
+# the XCD-resident cluster of reference-order plans: (1 ready / 0 not prepared / -1 off, workgroups per launch, calls finished on plain
+# launches after a barrier of the cluster timed out — such a call still returns its results —, 1 when the last call ran on it)
+function cluster_stats(p)
+    out = zeros(Int64, 4)
+    check(p.handle, ccall((:cx_cluster_stats, lib), Int32, (Ptr{Cvoid}, Ptr{Int64}), p.handle, out))
     out
 end
 
