@@ -44,7 +44,9 @@ int32_t build_chains(cx_handle *h) {
         h->d_chain_tab_fwd = h->d_chain_tab_bwd = nullptr; h->d_mvc_side = h->d_mvc_totals = nullptr;
         h->d_mvc_side_l = h->d_mvc_alpha = h->d_mvc_gamma = h->d_mvc_prefix = h->d_mvc_wave_carry = h->d_mvc_block = nullptr; h->d_mvc_var_link = nullptr;
         h->chain_npos = (int64_t)pos_var.size(); h->chain_nlinks = (int64_t)link_pos.size();
-        h->chain_side_dirty = true;
+        h->chain_side_dirty = true; h->chain_linkpar_dirty = true;
+        h->chain_pos0 = link_pos.empty() ? -1 : link_pos[0];      // one path: positions follow the links
+        for (size_t l = 0; l < link_pos.size() && h->chain_pos0 >= 0; l++) if (link_pos[l] != h->chain_pos0 + (int64_t)l) h->chain_pos0 = -1;
         int64_t n_readers = 0;   // variables that read factor→variable messages: everything but observed variables and ghosts
         for (int64_t v = 0; v < nv; v++) n_readers += (h->vinfo[v] & (cx::kClamped | cx::kGhost)) ? 0 : 1;
         h->chain_covers_all = n_readers == h->chain_npos;

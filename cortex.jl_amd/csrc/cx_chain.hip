@@ -79,6 +79,15 @@ __global__ __launch_bounds__(kBlock) void k_chain_side(int npos, const int32_t *
 // Direction dir = +1: link l maps α at position l to α at position l+1 (uses side[l], parameters of to_slot[l]).
 // Direction dir = -1: links are visited in reverse order; link l maps β at position l+1 to β at position l
 // (uses side[l+1], parameters of from_slot[l]).  `pos_of_link[l]` is the chain position of the link's left end.
+// The receiving slot's rule parameters copied into link order, one array each per direction (round 6): q[to_slot[l]] is a load behind a
+// load, and in a launch that is a chain of five trips to memory every one of them shows (k_chain_onepass).  Arrays, not records: a
+// thread owns K CONSECUTIVE links, so its K values of one array are one or two 16-byte loads.
+struct LinkPar {
+    const double *q, *a, *b;      // (a, b null on a graph without linear factors)
+    const int32_t *recv_seg;      // receiving slot | (first link of its path in this direction) << 31
+    const int32_t *g;             // slot_q's precision index (-1: q as stored), null without one
+};
+
 struct ChainArgs {
     int nlinks;
     const int32_t *link_pos;     // position of the left variable of link l
@@ -91,6 +100,8 @@ struct ChainArgs {
     const double *gm;
     const double2 *side;
     const int32_t *pos_var;      // variable at a chain position (for the marginals k_chain_apply<.., true> writes)
+    int pos0;                    // >= 0: link_pos[l] == pos0 + l for every link (one path): a side sum's address needs no load
+    LinkPar par[2];              // the rule parameters in LINK order, forward / backward (k_chain_linkpar); par[0].q null: not made
 };
 
 // Tiles are blocks of K * T consecutive links in BOTH directions (K links per thread, T threads per direction): the tile at position p
@@ -121,17 +132,84 @@ __device__ __forceinline__ int run_link(const ChainArgs &A, int block, int j, in
     return dir > 0 ? lo + j : hi - 1 - j;
 }
 
+__device__ __forceinline__ int chain_pos(const ChainArgs &A, int l) { return A.pos0 >= 0 ? A.pos0 + l : A.link_pos[l]; }
+
 __device__ __forceinline__ LinkIn load_link_in(const ChainArgs &A, int l, int dir) {
     LinkIn in;
     in.link = l;
     if (l < 0) { in.u = make_double2(0.0, 0.0); in.q = 0.0; in.a = 1.0; in.b = 0.0; in.recv = -1; in.seg = 0; return in; }
+    in.u = A.side[chain_pos(A, l) + (dir > 0 ? 0 : 1)];
+    if (A.par[0].q) {
+        const LinkPar &P = A.par[dir > 0 ? 0 : 1];
+        const int rs = P.recv_seg[l], g = P.g ? P.g[l] : -1;
+        in.recv = rs & 0x7fffffff; in.seg = rs < 0 ? 1 : 0;
+        in.q = g >= 0 ? 1.0 / A.gm[g] : P.q[l];
+        in.a = P.a ? P.a[l] : 1.0; in.b = P.b ? P.b[l] : 0.0;
+        return in;
+    }
     in.recv = dir > 0 ? A.to_slot[l] : A.from_slot[l];
-    in.u = A.side[A.link_pos[l] + (dir > 0 ? 0 : 1)];
     in.seg = dir > 0 ? A.head_fwd[l] : A.head_bwd[l];
     in.q = slot_q(A.q, A.qg, A.gm, in.recv);
     in.a = A.a ? A.a[in.recv] : 1.0;
     in.b = A.b ? A.b[in.recv] : 0.0;
     return in;
+}
+
+// a thread's run of K links in scan order.  With link-ordered parameters and one path the run is K consecutive entries of every array
+// (ascending in memory; the backward scan reads them in reverse): indexed from one base, so the compiler forms 16-byte loads.
+template <int K, int T>
+__device__ __forceinline__ void load_run(const ChainArgs &A, int block, int tid, int dir, LinkIn (&in)[K]) {
+    const int lo = block * (K * T), hi = min(lo + K * T, A.nlinks), j0 = tid * K;
+    if (A.par[0].q && A.pos0 >= 0 && hi - lo == K * T) {      // a whole tile: the run's base is a multiple of K in both directions
+        const LinkPar &P = A.par[dir > 0 ? 0 : 1];
+        const int base = dir > 0 ? lo + j0 : hi - j0 - K;
+        const double2 *side = A.side + A.pos0 + base + (dir > 0 ? 0 : 1);
+        const double *pq = (const double *)__builtin_assume_aligned(P.q + base, 8 * K), *pa = P.a ? (const double *)__builtin_assume_aligned(P.a + base, 8 * K) : nullptr,
+                     *pb = P.b ? (const double *)__builtin_assume_aligned(P.b + base, 8 * K) : nullptr;
+        const int32_t *prs = (const int32_t *)__builtin_assume_aligned(P.recv_seg + base, 4 * K), *pg = P.g ? (const int32_t *)__builtin_assume_aligned(P.g + base, 4 * K) : nullptr;
+        double2 u[K]; double q[K], a[K], b[K]; int rs[K], g[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) { u[k] = side[k]; q[k] = pq[k]; rs[k] = prs[k]; }
+        if (pa) {
+#pragma unroll
+            for (int k = 0; k < K; k++) { a[k] = pa[k]; b[k] = pb[k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; k++) { a[k] = 1.0; b[k] = 0.0; }
+        }
+        if (pg) {
+#pragma unroll
+            for (int k = 0; k < K; k++) g[k] = pg[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; k++) g[k] = -1;
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int kk = dir > 0 ? k : K - 1 - k;
+            in[k].link = base + kk; in[k].u = u[kk]; in[k].a = a[kk]; in[k].b = b[kk];
+            in[k].recv = rs[kk] & 0x7fffffff; in[k].seg = rs[kk] < 0 ? 1 : 0;
+            in[k].q = g[kk] >= 0 ? 1.0 / A.gm[g[kk]] : q[kk];
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) in[k] = load_link_in(A, run_link<K, T>(A, block, j0 + k, dir), dir);
+}
+
+__global__ __launch_bounds__(kBlock) void k_chain_linkpar(int nlinks, const int32_t *__restrict__ from_slot, const int32_t *__restrict__ to_slot,
+                                                          const uint8_t *__restrict__ head_fwd, const uint8_t *__restrict__ head_bwd, const double *__restrict__ q,
+                                                          const double *__restrict__ a, const double *__restrict__ b, const int32_t *__restrict__ qg,
+                                                          int stride, double *__restrict__ oq, double *__restrict__ oa, double *__restrict__ ob,
+                                                          int32_t *__restrict__ ors, int32_t *__restrict__ og) {
+    // (output arrays: forward half at [0, nlinks), backward half at [stride, stride + nlinks))
+    const int l = blockIdx.x * kBlock + threadIdx.x;
+    if (l >= nlinks) return;
+    const int t = to_slot[l], f = from_slot[l];
+    oq[l] = q[t]; oq[stride + l] = q[f];
+    if (a) { oa[l] = a[t]; oa[stride + l] = a[f]; ob[l] = b[t]; ob[stride + l] = b[f]; }
+    ors[l] = t | (head_fwd[l] ? (int)0x80000000 : 0); ors[stride + l] = f | (head_bwd[l] ? (int)0x80000000 : 0);
+    if (qg) { og[l] = qg[t]; og[stride + l] = qg[f]; }
 }
 
 // workgroup-wide inclusive scan of kTile links; returns this thread's kItems inclusive prefixes and the tile total
@@ -172,8 +250,7 @@ __global__ __launch_bounds__(2 * T) void k_chain_run_totals(ChainArgs A, Lin *__
     const int lane = tid & 63, wid = tid >> 6;
     __shared__ Lin wave_tot[2][T / 64];
     LinkIn in[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) in[k] = load_link_in(A, run_link<K, T>(A, blockIdx.x, tid * K + k, dir), dir);
+    load_run<K, T>(A, blockIdx.x, tid, dir, in);
     Lin t = lin_identity();
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -274,8 +351,7 @@ __global__ __launch_bounds__(2 * T) void k_chain_run_apply(ChainArgs A, const Li
     __shared__ double2 seam[2];                                       // the message that enters the tile: [0] alpha from the left, [1] beta from the right
     // this thread's run and its prefix within the tile: issued before the carry is worked out
     LinkIn in[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) in[k] = load_link_in(A, run_link<K, T>(A, blockIdx.x, tid * K + k, dir), dir);
+    load_run<K, T>(A, blockIdx.x, tid, dir, in);
     const Lin ex = run_excl[((size_t)half * ntiles + pos) * T + tid];
     if (OWN_CARRY) {
         // totals[0 .. pos) precede this tile in its direction: thread t composes the run [t * per, (t + 1) * per) of them in order
@@ -320,7 +396,7 @@ __global__ __launch_bounds__(2 * T) void k_chain_run_apply(ChainArgs A, const Li
         const double2 seam_alpha = seam[0], seam_beta = seam[1];
         const int cnt = min(kRunTile, A.nlinks - lo);
         for (int j = threadIdx.x; j < cnt; j += 2 * T) {
-            const int l = lo + j, p = A.link_pos[l];
+            const int l = lo + j, p = chain_pos(A, l);
             const double2 sd = A.side[p], be = msg_s[1][j];
             if (store_msgs) {
                 const double2 al = msg_s[0][j];
@@ -364,15 +440,15 @@ __global__ __launch_bounds__(2 * T) void k_chain_run_apply(ChainArgs A, const Li
 //   * Totals cross XCDs: written through (sc0 sc1), read past the caches (sc0 sc1), each 16-byte piece carrying the launch's tag beside its
 //     value (below) — no flag, no fence: an agent-scope release / acquire would write back and invalidate the XCD's whole L2 under the
 //     other workgroups' loads, and a flag is a second round trip through the memory the XCDs share.
-//   * The epoch the tag is made of lives on the device and is moved on inside the launch (by the last workgroup past its look-back,
-//     counted by `done`), so a captured graph replays.
+//   * The epoch the tag is made of lives on the device and is moved on inside the launch (by workgroup 0 when it is past its look-back:
+//     it has then seen every other workgroup's total, i.e. every workgroup has read the word), so a captured graph replays.
 constexpr int kOnepassMaxTiles = 2048;
-constexpr int kTotalPieces = 8;        // 16-byte pieces per published total (seven used): records are 128 bytes apart
+constexpr int kTotalPieces = 8;        // 16-byte pieces per published total: records are 128 bytes apart
 struct OnepassCtl { unsigned epoch, done, pad[14]; };
 typedef unsigned int cx_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long cx_u64;
-// A published total is seven pieces (value, value XOR tag), the tag a 64-bit pattern of the launch's epoch: a reader that finds the
-// relation in all seven has the values of THIS launch — no flag, so no second round trip through the memory the XCDs share, and no
+// A published total is eight pieces (value, value XOR tag), the tag a 64-bit pattern of the launch's epoch: a reader that finds the
+// relation in all eight has the values of THIS launch — no flag, so no second round trip through the memory the XCDs share, and no
 // assumption that a 16-byte store is seen whole (a piece torn at any granularity fails the relation; pieces of an earlier launch carry
 // another tag).
 __device__ __forceinline__ cx_u64 epoch_tag(unsigned epoch) { return ((cx_u64)(epoch + 1u) * 0x9E3779B97F4A7C15ull) | 1ull; }
@@ -382,59 +458,68 @@ __device__ __forceinline__ void store_piece(double2 *p, double v, cx_u64 tag) {
     r[0] = (unsigned)b; r[1] = (unsigned)(b >> 32); r[2] = (unsigned)c; r[3] = (unsigned)(c >> 32);
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(r) : "memory");      // written through (system scope)
 }
-__device__ __forceinline__ void publish_total(double2 *p, const Lin &t, cx_u64 tag) {
+__device__ __forceinline__ void publish_total(double2 *p, const LinP &t, cx_u64 tag) {
     store_piece(p, t.e, tag); store_piece(p + 1, t.f, tag); store_piece(p + 2, t.g, tag); store_piece(p + 3, t.A, tag);
-    store_piece(p + 4, t.B, tag); store_piece(p + 5, t.C, tag); store_piece(p + 6, (double)t.seg, tag);
+    store_piece(p + 4, t.B, tag); store_piece(p + 5, t.C, tag); store_piece(p + 6, t.D, tag); store_piece(p + 7, (double)t.seg, tag);
 }
-// one look at a published total, past the caches: true when all seven pieces carry this launch's tag
-__device__ __forceinline__ bool read_total(const double2 *p, cx_u64 tag, Lin &t) {
-    cx_u32x4 r[7];
-    asm volatile("global_load_dwordx4 %0, %7, off sc0 sc1\n\t"
-                 "global_load_dwordx4 %1, %7, off offset:16 sc0 sc1\n\t"
-                 "global_load_dwordx4 %2, %7, off offset:32 sc0 sc1\n\t"
-                 "global_load_dwordx4 %3, %7, off offset:48 sc0 sc1\n\t"
-                 "global_load_dwordx4 %4, %7, off offset:64 sc0 sc1\n\t"
-                 "global_load_dwordx4 %5, %7, off offset:80 sc0 sc1\n\t"
-                 "global_load_dwordx4 %6, %7, off offset:96 sc0 sc1\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6])
-                 : "v"(p)
-                 : "memory");
-    double v[7];
-    bool ok = true;
+// A wave fetches the totals its 64 threads compose: lane l asks for piece l & 7 of the total of thread (l >> 3) + 8 i, i = 0 .. 7 — the
+// eight pieces of a total are ONE 128-byte request (a thread reading its own total piece by piece made eight, and the 245 tiles of C2
+// 480 k of them per round on 490 lines) — past the caches, again until every piece carries this launch's tag; the values go through
+// LDS to the thread that composes them.  `first`: index of the total of the wave's first thread; `stride`: between two threads' totals;
+// `limit`: totals exist below it.  false: gave up (time) or somebody else did.
+__device__ __forceinline__ bool stage_totals(const double2 *tot, int first, int stride, int limit, cx_u64 tag, double (*out)[8] /* LDS, the wave's 64 rows */,
+                                             int lane, const unsigned *abort_word, unsigned long long wait_limit) {
+    const int piece = lane & 7;
+    unsigned pending = 0;      // bit i: the i-th request of this lane is still to be answered with the tag
+    const double2 *src[8];
 #pragma unroll
-    for (int i = 0; i < 7; i++) {
-        const cx_u64 b = (cx_u64)r[i][0] | ((cx_u64)r[i][1] << 32), c = (cx_u64)r[i][2] | ((cx_u64)r[i][3] << 32);
-        ok = ok && ((b ^ c) == tag);
-        v[i] = __longlong_as_double((long long)b);
+    for (int i = 0; i < 8; i++) {
+        const int j = first + (i * 8 + (lane >> 3)) * stride;
+        src[i] = tot + (size_t)j * kTotalPieces + piece;
+        if (j < limit) pending |= 1u << i;
     }
-    t.e = v[0]; t.f = v[1]; t.g = v[2]; t.A = v[3]; t.B = v[4]; t.C = v[5]; t.seg = (int)v[6];
-    return ok;
-}
-// false: gave up (time) or somebody else did
-__device__ __forceinline__ bool wait_total(const double2 *p, cx_u64 tag, Lin &t, const unsigned *abort_word, unsigned long long limit) {
     unsigned long long t0 = 0;
     for (unsigned spins = 0;; spins++) {
-        if (read_total(p, tag, t)) return true;
+        cx_u32x4 r[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (pending & (1u << i)) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(r[i]) : "v"(src[i]) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (!(pending & (1u << i))) continue;
+            const cx_u64 b = (cx_u64)r[i][0] | ((cx_u64)r[i][1] << 32), c = (cx_u64)r[i][2] | ((cx_u64)r[i][3] << 32);
+            if ((b ^ c) == tag) { out[i * 8 + (lane >> 3)][piece] = __longlong_as_double((long long)b); pending &= ~(1u << i); }
+        }
+        if (!__any(pending != 0)) return true;
         if ((spins & 15u) == 15u) {
             if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return false;
             const unsigned long long now = wall_clock64();      // 100 MHz
-            if (!t0) t0 = now; else if (now - t0 > limit) return false;
+            if (!t0) t0 = now; else if (now - t0 > wait_limit) return false;
         }
         __builtin_amdgcn_s_sleep(1);
     }
+}
+
+// results nobody reads again inside the launch: stored nontemporal on request, so that they do not push the links' parameters out of the L2s
+typedef double cx_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void out_store(double2 *p, double2 v, bool nt) {
+    if (nt) { cx_d2v t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, (cx_d2v *)p); }
+    else *p = v;
 }
 
 template <int K, int T, bool MARG>
 __global__ __launch_bounds__(2 * T) void k_chain_onepass(ChainArgs A, double2 *__restrict__ totals64, OnepassCtl *__restrict__ ctl, unsigned *__restrict__ abort_word,
                                                          unsigned long long wait_limit_and_fault, double2 *__restrict__ f2v, double2 *__restrict__ marg, int marg_form,
                                                          double2 *__restrict__ chain_v2f, double *__restrict__ split_mean, double *__restrict__ split_prec,
-                                                         const bool store_msgs, unsigned long long *__restrict__ stamps) {
+                                                         const bool store_msgs, const bool nt, unsigned long long *__restrict__ stamps) {
     constexpr int kRunTile = K * T;
+    constexpr int kOut = MARG ? (kRunTile + 2 * T - 1) / (2 * T) : 1;      // links per thread of the marginal phase
     const int half = threadIdx.x / T, tid = threadIdx.x % T, dir = half == 0 ? 1 : -1, ntiles = gridDim.x;
     const int pos = half == 0 ? blockIdx.x : ntiles - 1 - blockIdx.x;       // this block's place in the direction's scan order
     const int lane = tid & 63, wid = tid >> 6;
-    __shared__ Lin wave_tot[2][T / 64];
+    __shared__ LinP wave_tot[2][T / 64], wave_run[2][T / 64];      // the look-back's and the runs' wave totals
+    __shared__ double tot_s[2][T][8];                              // the published totals a wave has fetched, a row per composing thread
     __shared__ double2 msg_s[MARG ? 2 : 1][MARG ? kRunTile : 1];
     __shared__ double2 seam[2];
     // (CX_CHAIN_ONEPASS_STAMPS=1, lab: where a workgroup's time goes — the 100 MHz clock at six points, thread 0)
@@ -446,122 +531,138 @@ __global__ __launch_bounds__(2 * T) void k_chain_onepass(ChainArgs A, double2 *_
     const unsigned long long wait_limit = wait_limit_and_fault & ~(1ull << 63);
     // 1. this thread's run, composed in order; the prefix of the runs before it within the tile stays in registers
     LinkIn in[K];
+    load_run<K, T>(A, blockIdx.x, tid, dir, in);
+    // what the marginal phase reads besides the messages is asked for NOW, so that nothing but stores is left behind the look-back
+    const int lo = blockIdx.x * kRunTile, cnt = min(kRunTile, A.nlinks - lo);
+    double2 o_sd[kOut], o_s1[kOut];
+    int o_to[kOut], o_from[kOut], o_v0[kOut], o_v1[kOut], o_heads[kOut];
+    if (MARG) {
 #pragma unroll
-    for (int k = 0; k < K; k++) in[k] = load_link_in(A, run_link<K, T>(A, blockIdx.x, tid * K + k, dir), dir);
-    Lin t = lin_identity();
+        for (int i = 0; i < kOut; i++) {
+            const int j = threadIdx.x + i * 2 * T;
+            o_heads[i] = -1;
+            if (j < cnt) {
+                const int l = lo + j, p = chain_pos(A, l);
+                o_sd[i] = A.side[p]; o_s1[i] = A.side[p + 1];
+                o_to[i] = A.to_slot[l]; o_from[i] = A.from_slot[l];
+                o_v0[i] = A.pos_var[p]; o_v1[i] = A.pos_var[p + 1];
+                o_heads[i] = (A.head_fwd[l] ? 1 : 0) | (A.head_bwd[l] ? 2 : 0);
+            }
+        }
+    }
+    LinP t = linp_identity();
 #pragma unroll
     for (int k = 0; k < K; k++) {
         if (in[k].link < 0) continue;
-        const Lin m = lin_of_link(in[k].u, in[k].q, in[k].a, in[k].b, in[k].seg);
-        t = k == 0 ? m : lin_compose(t, m);
+        const LinP m = linp_of_link(in[k].u, in[k].q, in[k].a, in[k].b, in[k].seg);
+        t = k == 0 ? m : linp_compose(t, m);
     }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        Lin o = lin_shfl_up(t, d);
-        if (lane >= d) t = lin_compose(o, t);
-    }
-    if (lane == 63) wave_tot[half][wid] = t;
+    t = linp_wave_scan(t, lane);
+    if (lane == 63) wave_run[half][wid] = t;
+    const LinP ex = linp_wave_prev(t, lane);      // the runs before this one within the wave
     __syncthreads();
-    Lin ex = lin_shfl_up(t, 1);
-    if (lane == 0) ex = lin_identity();
-    if (wid > 0) {
-        Lin carry = wave_tot[half][0];
-        for (int w = 1; w < wid; w++) carry = lin_compose(carry, wave_tot[half][w]);
-        ex = lin_compose(carry, ex);
-    }
     CX_STAMP(1);
     // 2. the tile's total goes out before anything is waited for
     if (tid == 0) {
-        Lin tot = wave_tot[half][0];
-        for (int w = 1; w < T / 64; w++) tot = lin_compose(tot, wave_tot[half][w]);
+        LinP tot = wave_run[half][0];
+        for (int w = 1; w < T / 64; w++) tot = linp_compose(tot, wave_run[half][w]);
         if (!((wait_limit_and_fault >> 63) && half == 0 && pos == 0)) publish_total(tot_dir + (size_t)pos * kTotalPieces, tot, epoch_tag(epoch_s));
     }
-    __syncthreads();      // (wave_tot is reused below)
+    __syncthreads();      // (nobody polls before the workgroup's own totals are on their way: early polls only crowd the memory the XCDs share)
     CX_STAMP(2);
     // 3. the carry: the totals of the tiles before this one, thread t the run [t per, (t + 1) per) of them as they are published
     const int per = (pos + T - 1) / T;
     const cx_u64 tag = epoch_tag(epoch_s);
     bool ok = true;
     if (per > 0 && wid * 64 * per < pos) {
-        const int b = tid * per, e = min(b + per, pos);
-        Lin c = lin_identity();
-        for (int j = b; j < e; j++) {
-            Lin x;
-            if (!wait_total(tot_dir + (size_t)j * kTotalPieces, tag, x, abort_word, wait_limit)) { ok = false; break; }
-            c = j == b ? x : lin_compose(c, x);
+        LinP c = linp_identity();
+        for (int r = 0; r < per; r++) {      // round r: thread t's total t per + r
+            if (!stage_totals(tot_dir, wid * 64 * per + r, per, pos, tag, &tot_s[half][wid * 64], lane, abort_word, wait_limit)) { ok = false; break; }
+            if (tid * per + r < pos) {
+                const double *v = tot_s[half][tid];
+                const LinP x{v[0], v[1], v[2], v[3], v[4], v[5], v[6], (int)v[7]};
+                c = r == 0 ? x : linp_compose(c, x);
+            }
         }
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            Lin o = lin_shfl_up(c, d);
-            if (lane >= d) c = lin_compose(o, c);
-        }
+        CX_STAMP(7);
+        c = linp_wave_scan(c, lane);
         if (lane == 63) wave_tot[half][wid] = c;
-    } else if (lane == 63) wave_tot[half][wid] = lin_identity();
+    } else if (lane == 63) wave_tot[half][wid] = linp_identity();
     if (__syncthreads_or(ok ? 0 : 1)) {      // somebody gave up: say so where the host looks, store nothing (the sweep is repeated on two launches)
         if (threadIdx.x == 0) __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
-    if (tid == 0) {
-        Lin c = wave_tot[half][0];
-        for (int w = 1; w < T / 64; w++) c = lin_compose(c, wave_tot[half][w]);
-        seam[half] = make_double2(c.g, c.B);      // the carry applied to the empty message
-    }
-    // this workgroup has read every total it will read: it says so now and looks at the answer when its own work is done — the last one
-    // to have said so moves the epoch on for the next launch (or replay of a captured graph)
-    unsigned arrived = 0;
-    if (threadIdx.x == 0) arrived = __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    CX_STAMP(3);
-    // 4. the walk, as k_chain_run_apply's
-    __syncthreads();      // (seam)
-    const int lo = blockIdx.x * kRunTile;
-    double2 m = lin_apply(ex, seam[half]);
+    CX_STAMP(6);
+    // the message that enters this thread's run: the empty message through the tile's carry (the look-back's wave totals), the waves
+    // before this one, the runs before this one — applied to a message kept as (x, w) / d: no composition, no division
+    MsgP mp{0.0, 0.0, 1.0};
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        const int l = in[k].link;
-        if (l < 0) continue;
-        if (in[k].seg) m = make_double2(0.0, 0.0);
-        const double2 v = make_double2(m.x + in[k].u.x, m.y + in[k].u.y);
-        const double s = 1.0 / (in[k].a * in[k].a + in[k].q * v.y);
-        m = make_double2((in[k].a * v.x + in[k].b * v.y) * s, v.y * s);
-        if (MARG) msg_s[half][l - lo] = m;
-        else if (!__builtin_isnan(m.y)) f2v[in[k].recv] = m;
+    for (int w = 0; w < T / 64; w++) mp = linp_apply_p(wave_tot[half][w], mp);
+    const MsgP tile_in = mp;      // (what enters the tile: the marginal phase reads it as `seam`; its division waits until the walk is on its way)
+    for (int w = 0; w < wid; w++) mp = linp_apply_p(wave_run[half][w], mp);
+    mp = linp_apply_p(ex, mp);
+    CX_STAMP(3);
+    // 4. the walk, as k_chain_run_apply's, with the message kept as (x, w) / d: the divisions leave the chain of dependent operations
+    {
+        const int sh0 = -__builtin_amdgcn_frexp_exp(mp.d);
+        double mx = __builtin_ldexp(mp.x, sh0), mw = __builtin_ldexp(mp.w, sh0), md = __builtin_ldexp(mp.d, sh0);
+        double ox[K], ow[K], od[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (in[k].link < 0) continue;
+            if (in[k].seg) { mx = 0.0; mw = 0.0; md = 1.0; }
+            const double vx = mx + in[k].u.x * md, vw = mw + in[k].u.y * md;
+            double nd = in[k].a * in[k].a * md + in[k].q * vw, nx = in[k].a * vx + in[k].b * vw, nw = vw;
+            const int sh = -__builtin_amdgcn_frexp_exp(nd);
+            mx = ox[k] = __builtin_ldexp(nx, sh); mw = ow[k] = __builtin_ldexp(nw, sh); md = od[k] = __builtin_ldexp(nd, sh);
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int l = in[k].link;
+            if (l < 0) continue;
+            const double inv = 1.0 / od[k];
+            const double2 r = make_double2(ox[k] * inv, ow[k] * inv);
+            if (MARG) msg_s[half][l - lo] = r;
+            else if (!__builtin_isnan(r.y)) out_store(&f2v[in[k].recv], r, nt);
+        }
     }
+    if (tid == 0) { const double inv = 1.0 / tile_in.d; seam[half] = make_double2(tile_in.x * inv, tile_in.w * inv); }
     if (MARG) {
-        __syncthreads();
+        __syncthreads();      // (msg_s, seam)
         const double2 seam_alpha = seam[0], seam_beta = seam[1];
-        const int cnt = min(kRunTile, A.nlinks - lo);
-        for (int j = threadIdx.x; j < cnt; j += 2 * T) {
-            const int l = lo + j, p = A.link_pos[l];
-            const double2 sd = A.side[p], be = msg_s[1][j];
+#pragma unroll
+        for (int i = 0; i < kOut; i++) {
+            const int j = threadIdx.x + i * 2 * T;
+            if (o_heads[i] < 0) continue;
+            const bool hf = o_heads[i] & 1, hb = o_heads[i] & 2;
+            const double2 sd = o_sd[i], be = msg_s[MARG ? 1 : 0][j], al1 = msg_s[0][j];
             if (store_msgs) {
-                const double2 al = msg_s[0][j];
-                if (!__builtin_isnan(al.y)) f2v[A.to_slot[l]] = al;
-                if (!__builtin_isnan(be.y)) f2v[A.from_slot[l]] = be;
+                if (!__builtin_isnan(al1.y)) out_store(&f2v[o_to[i]], al1, nt);
+                if (!__builtin_isnan(be.y)) out_store(&f2v[o_from[i]], be, nt);
             }
             double2 lx = sd;
-            if (!A.head_fwd[l]) { const double2 al = j > 0 ? msg_s[0][j - 1] : seam_alpha; lx.x += al.x; lx.y += al.y; }
+            if (!hf) { const double2 al = j > 0 ? msg_s[0][j - 1] : seam_alpha; lx.x += al.x; lx.y += al.y; }
             const double2 tt = make_double2(lx.x + be.x, lx.y + be.y);
-            if (marg_form == 3) { const int v = A.pos_var[p]; split_mean[v] = tt.x / tt.y; split_prec[v] = tt.y; }
-            else marg[A.pos_var[p]] = marg_form == 2 ? tt : chain_to_moment(tt);
-            const double2 s1 = A.side[p + 1], al1 = msg_s[0][j];
-            if (A.head_bwd[l]) {
+            if (marg_form == 3) { split_mean[o_v0[i]] = tt.x / tt.y; split_prec[o_v0[i]] = tt.y; }
+            else out_store(&marg[o_v0[i]], marg_form == 2 ? tt : chain_to_moment(tt), nt);
+            const double2 s1 = o_s1[i];
+            if (hb) {
                 const double2 u = make_double2(s1.x + al1.x, s1.y + al1.y);
-                if (marg_form == 3) { const int v = A.pos_var[p + 1]; split_mean[v] = u.x / u.y; split_prec[v] = u.y; }
-                else marg[A.pos_var[p + 1]] = marg_form == 2 ? u : chain_to_moment(u);
+                if (marg_form == 3) { split_mean[o_v1[i]] = u.x / u.y; split_prec[o_v1[i]] = u.y; }
+                else out_store(&marg[o_v1[i]], marg_form == 2 ? u : chain_to_moment(u), nt);
             }
             if (chain_v2f) {
-                if (!__builtin_isnan(lx.y)) chain_v2f[A.from_slot[l]] = lx;
+                if (!__builtin_isnan(lx.y)) out_store(&chain_v2f[o_from[i]], lx, nt);
                 double2 rx = s1;
-                if (!A.head_bwd[l]) { const double2 bn = j + 1 < cnt ? msg_s[1][j + 1] : seam_beta; rx.x += bn.x; rx.y += bn.y; }
-                if (!__builtin_isnan(rx.y)) chain_v2f[A.to_slot[l]] = rx;
+                if (!hb) { const double2 bn = j + 1 < cnt ? msg_s[MARG ? 1 : 0][j + 1] : seam_beta; rx.x += bn.x; rx.y += bn.y; }
+                if (!__builtin_isnan(rx.y)) out_store(&chain_v2f[o_to[i]], rx, nt);
             }
         }
     }
     CX_STAMP(4);
-    if (threadIdx.x == 0 && arrived == (unsigned)ntiles) {
-        __hip_atomic_store(&ctl->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ctl->epoch, epoch_s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // The epoch moves on for the next launch (or replay of a captured graph): by workgroup 0, which is past its look-back, so every other
+    // workgroup has published — with the tag of the epoch it read at its start: nobody will read the word again in this launch.
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&ctl->epoch, epoch_s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     CX_STAMP(5);
 #undef CX_STAMP
 }
@@ -613,11 +714,16 @@ static void launch_onepass(cx_handle *h, const ChainArgs &A, int ntiles, double2
     const bool store = !(h->chain_msgs_unread && marg_form == 3 && chain_v2f);
     double2 *v2f = chain_v2f ? h->d_v2f : nullptr;
     const dim3 g(ntiles), b(2 * T);
+    // results stored nontemporal (C2: 18.0 -> 16.9 us: the links' parameters stay in the L2s from sweep to sweep) when the sweep's own
+    // caller reads them next, not another kernel of the same iteration (CX_CHAIN_NT=0: never, lab)
+    static const bool nt_on = [] { const char *v = getenv("CX_CHAIN_NT"); return !(v && v[0] == '0'); }();
+    const bool nt = nt_on && (marg_form == 1 || marg_form == 2);
     static const bool want_stamps = [] { const char *v = getenv("CX_CHAIN_ONEPASS_STAMPS"); return v && v[0] == '1'; }();
     unsigned long long *stamps = nullptr;
     if (want_stamps && hipMalloc((void **)&stamps, (size_t)ntiles * 64) != hipSuccess) { (void)hipGetLastError(); stamps = nullptr; }
-    if (marg_form) hipLaunchKernelGGL((k_chain_onepass<K, T, true>), g, b, 0, h->stream, A, totals64, ctl, (unsigned *)h->d_chain_abort, limit, f2v, h->d_marg, marg_form, v2f, h->d_split_mean, h->d_split_prec, store, stamps);
-    else hipLaunchKernelGGL((k_chain_onepass<K, T, false>), g, b, 0, h->stream, A, totals64, ctl, (unsigned *)h->d_chain_abort, limit, f2v, h->d_marg, 0, (double2 *)nullptr, (double *)nullptr, (double *)nullptr, true, stamps);
+    if (stamps) (void)hipMemsetAsync(stamps, 0, (size_t)ntiles * 64, h->stream);
+    if (marg_form) hipLaunchKernelGGL((k_chain_onepass<K, T, true>), g, b, 0, h->stream, A, totals64, ctl, (unsigned *)h->d_chain_abort, limit, f2v, h->d_marg, marg_form, v2f, h->d_split_mean, h->d_split_prec, store, nt, stamps);
+    else hipLaunchKernelGGL((k_chain_onepass<K, T, false>), g, b, 0, h->stream, A, totals64, ctl, (unsigned *)h->d_chain_abort, limit, f2v, h->d_marg, 0, (double2 *)nullptr, (double *)nullptr, (double *)nullptr, true, nt, stamps);
     h->chain_onepass_launches++;
     if (stamps) {      // lab: per phase, the earliest, median and latest workgroup, in us after the first workgroup started
         std::vector<unsigned long long> st((size_t)ntiles * 8);
@@ -626,10 +732,11 @@ static void launch_onepass(cx_handle *h, const ChainArgs &A, int ntiles, double2
         (void)hipFree(stamps);
         unsigned long long t0 = ~0ull;
         for (int i = 0; i < ntiles; i++) t0 = std::min(t0, st[(size_t)i * 8]);
-        static const char *names[6] = {"start", "runs composed", "total published", "carry composed", "results stored", "end"};
-        for (int ph = 0; ph < 6; ph++) {
+        static const char *names[8] = {"start", "runs composed", "total published", "carry composed", "results stored", "end", "all totals scanned", "wave 0 has its totals"};
+        for (int ph = 0; ph < 8; ph++) {
             std::vector<double> v;
-            for (int i = 0; i < ntiles; i++) v.push_back((double)(st[(size_t)i * 8 + ph] - t0) * 0.01);
+            for (int i = 0; i < ntiles; i++) if (st[(size_t)i * 8 + ph]) v.push_back((double)(st[(size_t)i * 8 + ph] - t0) * 0.01);
+            if (v.empty()) continue;
             std::sort(v.begin(), v.end());
             fprintf(stderr, "[onepass %d tiles] %-16s min %7.2f  median %7.2f  max %7.2f us\n", ntiles, names[ph], v.front(), v[v.size() / 2], v.back());
         }
@@ -641,6 +748,8 @@ void chain_onepass_free(cx_handle *h) {
     if (h->chain_abort_host) (void)hipHostFree((void *)h->chain_abort_host);
     h->d_chain_onepass = nullptr; h->chain_abort_host = nullptr; h->d_chain_abort = nullptr;
     if (h->chain_onepass_state > 0) h->chain_onepass_state = 0;
+    if (h->d_chain_linkpar) (void)hipFree(h->d_chain_linkpar);
+    h->d_chain_linkpar = nullptr; h->chain_linkpar_cap = 0; h->chain_linkpar_dirty = true;
 }
 
 // the shape of a tile: K links per thread, T threads per direction (CX_CHAIN_SHAPE picks among the instances: lab switch)
@@ -695,7 +804,36 @@ static void launch_chain_side(cx_handle *h, double2 *f2v, bool fused_leaves) {
 
 static ChainArgs chain_args(cx_handle *h) {
     return ChainArgs{(int)h->chain_nlinks, h->d_chain_link_pos, h->d_chain_from, h->d_chain_to, h->d_chain_head_fwd, h->d_chain_head_bwd,
-                     h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_q_gamma, h->d_q_gmean, h->d_chain_side, h->d_chain_pos_var};
+                     h->d_q, h->any_linear ? h->d_a : nullptr, h->any_linear ? h->d_b : nullptr, h->d_q_gamma, h->d_q_gmean, h->d_chain_side, h->d_chain_pos_var,
+                     h->chain_pos0, {LinkPar{nullptr, nullptr, nullptr, nullptr, nullptr}, LinkPar{nullptr, nullptr, nullptr, nullptr, nullptr}}};
+}
+
+// the rule parameters in link order: made when the chains are (re)built or another precision index is installed — the tables they are
+// copied from do not change between those (a scalar graph's q, a, b are set at creation; q through the index is read at its source)
+static bool chain_linkpar(cx_handle *h, ChainArgs &A) {
+    static const bool on = [] { const char *e = getenv("CX_CHAIN_LINKPAR"); return !(e && e[0] == '0'); }();
+    if (!on) return false;
+    const int64_t n = h->chain_nlinks, ns = (n + 7) / 8 * 8, n2 = 2 * ns;      // (the backward half starts at a multiple of eight entries: 16-byte loads)
+    if (h->chain_linkpar_dirty || !h->d_chain_linkpar || h->chain_linkpar_qg != (const void *)h->d_q_gamma) {
+        if (h->chain_linkpar_cap < n) {
+            if (h->d_chain_linkpar) (void)hipFree(h->d_chain_linkpar);
+            h->d_chain_linkpar = nullptr; h->chain_linkpar_cap = 0;
+            if (hipMalloc(&h->d_chain_linkpar, (size_t)n2 * (3 * 8 + 2 * 4)) != hipSuccess) { (void)hipGetLastError(); h->d_chain_linkpar = nullptr; return false; }
+            h->chain_linkpar_cap = n;
+        }
+    }
+    const int64_t cs = (h->chain_linkpar_cap + 7) / 8 * 8;
+    double *oq = (double *)h->d_chain_linkpar, *oa = oq + 2 * cs, *ob = oa + 2 * cs;
+    int32_t *ors = (int32_t *)(ob + 2 * cs), *og = ors + 2 * cs;
+    const bool lin = h->any_linear, idx = h->d_q_gamma != nullptr;
+    if (h->chain_linkpar_dirty || h->chain_linkpar_qg != (const void *)h->d_q_gamma) {
+        hipLaunchKernelGGL(k_chain_linkpar, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, (int)n, h->d_chain_from, h->d_chain_to, h->d_chain_head_fwd,
+                           h->d_chain_head_bwd, h->d_q, lin ? h->d_a : nullptr, lin ? h->d_b : nullptr, h->d_q_gamma, (int)ns, oq, oa, ob, ors, og);
+        h->chain_linkpar_dirty = false; h->chain_linkpar_qg = (const void *)h->d_q_gamma;
+    }
+    A.par[0] = LinkPar{oq, lin ? oa : nullptr, lin ? ob : nullptr, ors, idx ? og : nullptr};
+    A.par[1] = LinkPar{oq + ns, lin ? oa + ns : nullptr, lin ? ob + ns : nullptr, ors + ns, idx ? og + ns : nullptr};
+    return true;
 }
 
 // CX_CHAIN_SHAPE, measured on one box (C2 / structured family, us per sweep / iteration): 1 = <4, 256>: 21.0 / 119.7 (the default);
@@ -720,7 +858,8 @@ void launch_chain_scan(cx_handle *h, double2 *f2v, bool fused_leaves, int marg_f
     // import, a new q table), not on every sweep.
     if (!fused_leaves || h->chain_side_dirty) launch_chain_side(h, f2v, fused_leaves);
     h->chain_side_dirty = false;
-    const ChainArgs A = chain_args(h);
+    ChainArgs A = chain_args(h);
+    (void)chain_linkpar(h, A);
 #define CX_CALL(K, T) launch_run_scan<K, T>(h, A, f2v, marg_form, chain_v2f)
     CX_CHAIN_SHAPES(CX_CALL)
 #undef CX_CALL
@@ -739,7 +878,7 @@ void launch_chain_scan_range(cx_handle *h, double2 *f2v, int64_t pos_lo, int64_t
                        h->d_v2f, f2v, h->d_chain_side + pos_lo);
     // the link arrays start at this depth's first link; positions stay global (link_pos, side and pos_var are indexed by them)
     const ChainArgs A{(int)nlinks, h->d_chain_link_pos + link_lo, h->d_chain_from + link_lo, h->d_chain_to + link_lo, h->d_chain_head_fwd + link_lo,
-                      h->d_chain_head_bwd + link_lo, h->d_q, pa, pb, h->d_q_gamma, h->d_q_gmean, h->d_chain_side, h->d_chain_pos_var};
+                      h->d_chain_head_bwd + link_lo, h->d_q, pa, pb, h->d_q_gamma, h->d_q_gmean, h->d_chain_side, h->d_chain_pos_var, -1, {LinkPar{nullptr, nullptr, nullptr, nullptr, nullptr}, LinkPar{nullptr, nullptr, nullptr, nullptr, nullptr}}};
     const int form = final ? (h->cfg.family == CX_FAMILY_NATURAL2 ? 2 : 1) : 0;
 #define CX_CALL(K, T) launch_run_scan<K, T>(h, A, f2v, form, final)
     CX_CHAIN_SHAPES(CX_CALL)

@@ -169,6 +169,8 @@ struct cx_handle {
     // workgroup raises when a wait of it times out (checked by every CX_HIP of the host: the call that finds it fails, the handle goes back to two launches)
     void *d_chain_onepass = nullptr, *d_chain_abort = nullptr;
     volatile unsigned *chain_abort_host = nullptr;
+    // the chain links' rule parameters in link order (cx_chain.hip: k_chain_linkpar); chain_pos0 >= 0: link l's left end is position chain_pos0 + l
+    void *d_chain_linkpar = nullptr; int64_t chain_linkpar_cap = 0; bool chain_linkpar_dirty = true; const void *chain_linkpar_qg = nullptr; int chain_pos0 = -1;
     int chain_onepass_state = 0, chain_onepass_cus = 0;      // 0 not prepared, 1 ready, -1 off (CX_CHAIN_ONEPASS=0, no memory, or a wait once timed out)
     int64_t chain_onepass_launches = 0;
     // dim 2..4 (cx_mvchain.hip): rule-table index of each link's two messages, side sums [nc][npos], tile totals of the map scan
