@@ -508,8 +508,10 @@ __device__ __forceinline__ void out_store(double2 *p, double2 v, bool nt) {
     else *p = v;
 }
 
-template <int K, int T, bool MARG>
-__global__ __launch_bounds__(2 * T) void k_chain_onepass(ChainArgs A, double2 *__restrict__ totals64, OnepassCtl *__restrict__ ctl, unsigned *__restrict__ abort_word,
+// WIDE: held to 128 registers (two workgroups of 512 per compute unit: grids of up to twice the compute units stay resident) by
+// loading what the marginal phase reads where it reads it
+template <int K, int T, bool MARG, bool WIDE>
+__global__ __launch_bounds__(2 * T, WIDE ? 4 : 2) void k_chain_onepass(ChainArgs A, double2 *__restrict__ totals64, OnepassCtl *__restrict__ ctl, unsigned *__restrict__ abort_word,
                                                          unsigned long long wait_limit_and_fault, double2 *__restrict__ f2v, double2 *__restrict__ marg, int marg_form,
                                                          double2 *__restrict__ chain_v2f, double *__restrict__ split_mean, double *__restrict__ split_prec,
                                                          const bool store_msgs, const bool nt, unsigned long long *__restrict__ stamps) {
@@ -536,19 +538,20 @@ __global__ __launch_bounds__(2 * T) void k_chain_onepass(ChainArgs A, double2 *_
     const int lo = blockIdx.x * kRunTile, cnt = min(kRunTile, A.nlinks - lo);
     double2 o_sd[kOut], o_s1[kOut];
     int o_to[kOut], o_from[kOut], o_v0[kOut], o_v1[kOut], o_heads[kOut];
-    if (MARG) {
-#pragma unroll
-        for (int i = 0; i < kOut; i++) {
-            const int j = threadIdx.x + i * 2 * T;
-            o_heads[i] = -1;
-            if (j < cnt) {
-                const int l = lo + j, p = chain_pos(A, l);
-                o_sd[i] = A.side[p]; o_s1[i] = A.side[p + 1];
-                o_to[i] = A.to_slot[l]; o_from[i] = A.from_slot[l];
-                o_v0[i] = A.pos_var[p]; o_v1[i] = A.pos_var[p + 1];
-                o_heads[i] = (A.head_fwd[l] ? 1 : 0) | (A.head_bwd[l] ? 2 : 0);
-            }
+    auto load_out = [&](int i) {
+        const int j = threadIdx.x + i * 2 * T;
+        o_heads[i] = -1;
+        if (j < cnt) {
+            const int l = lo + j, p = chain_pos(A, l);
+            o_sd[i] = A.side[p]; o_s1[i] = A.side[p + 1];
+            o_to[i] = A.to_slot[l]; o_from[i] = A.from_slot[l];
+            o_v0[i] = A.pos_var[p]; o_v1[i] = A.pos_var[p + 1];
+            o_heads[i] = (A.head_fwd[l] ? 1 : 0) | (A.head_bwd[l] ? 2 : 0);
         }
+    };
+    if (MARG && !WIDE) {
+#pragma unroll
+        for (int i = 0; i < kOut; i++) load_out(i);
     }
     LinP t = linp_identity();
 #pragma unroll
@@ -633,6 +636,7 @@ __global__ __launch_bounds__(2 * T) void k_chain_onepass(ChainArgs A, double2 *_
 #pragma unroll
         for (int i = 0; i < kOut; i++) {
             const int j = threadIdx.x + i * 2 * T;
+            if (WIDE) load_out(i);
             if (o_heads[i] < 0) continue;
             const bool hf = o_heads[i] & 1, hb = o_heads[i] & 2;
             const double2 sd = o_sd[i], be = msg_s[MARG ? 1 : 0][j], al1 = msg_s[0][j];
@@ -670,7 +674,8 @@ __global__ __launch_bounds__(2 * T) void k_chain_onepass(ChainArgs A, double2 *_
 // the one-launch form is taken when it is on (CX_CHAIN_ONEPASS != 0, no wait of it ever timed out on this handle), the grid is within the
 // flags' table and ALL its workgroups are resident at once on this device
 template <int K, int T>
-static bool onepass_ready(cx_handle *h, int ntiles) {
+static bool onepass_ready(cx_handle *h, int ntiles, bool *wide) {
+    *wide = false;
     if (h->chain_onepass_state < 0 || ntiles > kOnepassMaxTiles || ntiles < 1) return false;
     if (h->chain_onepass_state == 0) {
         h->chain_onepass_state = -1;
@@ -691,19 +696,22 @@ static bool onepass_ready(cx_handle *h, int ntiles) {
         h->chain_onepass_cus = cus;
         h->chain_onepass_state = 1;
     }
-    // resident workgroups of each instance (the marginal form holds 32 KB of LDS more)
+    // resident workgroups of each instance (the marginal form holds 32 KB of LDS more; the wide instances hold fewer registers): the
+    // narrow pair when the grid fits it, the wide pair otherwise
     static int per_cu[2] = {0, 0};
     if (!per_cu[0]) {
-        int a = 0, b = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_chain_onepass<K, T, true>, 2 * T, 0) != hipSuccess) { (void)hipGetLastError(); a = 0; }
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_chain_onepass<K, T, false>, 2 * T, 0) != hipSuccess) { (void)hipGetLastError(); b = 0; }
-        per_cu[0] = std::max(a, 0) + 1; per_cu[1] = std::max(b, 0) + 1;      // (+ 1: 0 means "not asked yet")
+        int a = 0, b = 0, c = 0, d = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_chain_onepass<K, T, true, false>, 2 * T, 0) != hipSuccess) { (void)hipGetLastError(); a = 0; }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_chain_onepass<K, T, false, false>, 2 * T, 0) != hipSuccess) { (void)hipGetLastError(); b = 0; }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, k_chain_onepass<K, T, true, true>, 2 * T, 0) != hipSuccess) { (void)hipGetLastError(); c = 0; }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, k_chain_onepass<K, T, false, true>, 2 * T, 0) != hipSuccess) { (void)hipGetLastError(); d = 0; }
+        per_cu[0] = std::max(std::min(a, b), 0) + 1; per_cu[1] = std::max(std::min(c, d), 0) + 1;      // (+ 1: 0 means "not asked yet")
     }
-    const int fit = (std::min(per_cu[0], per_cu[1]) - 1) * h->chain_onepass_cus;
-    return ntiles <= fit;
+    *wide = ntiles > (per_cu[0] - 1) * h->chain_onepass_cus;
+    return ntiles <= (std::max(per_cu[0], per_cu[1]) - 1) * h->chain_onepass_cus;
 }
 
-template <int K, int T>
+template <int K, int T, bool WIDE>
 static void launch_onepass(cx_handle *h, const ChainArgs &A, int ntiles, double2 *f2v, int marg_form, bool chain_v2f) {
     double2 *totals64 = (double2 *)h->d_chain_onepass;
     OnepassCtl *ctl = (OnepassCtl *)((char *)h->d_chain_onepass + (size_t)2 * kOnepassMaxTiles * kTotalPieces * 16);
@@ -722,8 +730,8 @@ static void launch_onepass(cx_handle *h, const ChainArgs &A, int ntiles, double2
     unsigned long long *stamps = nullptr;
     if (want_stamps && hipMalloc((void **)&stamps, (size_t)ntiles * 64) != hipSuccess) { (void)hipGetLastError(); stamps = nullptr; }
     if (stamps) (void)hipMemsetAsync(stamps, 0, (size_t)ntiles * 64, h->stream);
-    if (marg_form) hipLaunchKernelGGL((k_chain_onepass<K, T, true>), g, b, 0, h->stream, A, totals64, ctl, (unsigned *)h->d_chain_abort, limit, f2v, h->d_marg, marg_form, v2f, h->d_split_mean, h->d_split_prec, store, nt, stamps);
-    else hipLaunchKernelGGL((k_chain_onepass<K, T, false>), g, b, 0, h->stream, A, totals64, ctl, (unsigned *)h->d_chain_abort, limit, f2v, h->d_marg, 0, (double2 *)nullptr, (double *)nullptr, (double *)nullptr, true, nt, stamps);
+    if (marg_form) hipLaunchKernelGGL((k_chain_onepass<K, T, true, WIDE>), g, b, 0, h->stream, A, totals64, ctl, (unsigned *)h->d_chain_abort, limit, f2v, h->d_marg, marg_form, v2f, h->d_split_mean, h->d_split_prec, store, nt, stamps);
+    else hipLaunchKernelGGL((k_chain_onepass<K, T, false, WIDE>), g, b, 0, h->stream, A, totals64, ctl, (unsigned *)h->d_chain_abort, limit, f2v, h->d_marg, 0, (double2 *)nullptr, (double *)nullptr, (double *)nullptr, true, nt, stamps);
     h->chain_onepass_launches++;
     if (stamps) {      // lab: per phase, the earliest, median and latest workgroup, in us after the first workgroup started
         std::vector<unsigned long long> st((size_t)ntiles * 8);
@@ -770,7 +778,12 @@ static void launch_run_totals(cx_handle *h, const ChainArgs &A, int *ntiles_out)
 template <int K, int T>
 static void launch_run_scan(cx_handle *h, const ChainArgs &A, double2 *f2v, int marg_form, bool chain_v2f) {
     int ntiles = (A.nlinks + K * T - 1) / (K * T);
-    if (onepass_ready<K, T>(h, ntiles)) { launch_onepass<K, T>(h, A, ntiles, f2v, marg_form, chain_v2f); return; }
+    bool wide = false;
+    if (onepass_ready<K, T>(h, ntiles, &wide)) {
+        if (wide) launch_onepass<K, T, true>(h, A, ntiles, f2v, marg_form, chain_v2f);
+        else launch_onepass<K, T, false>(h, A, ntiles, f2v, marg_form, chain_v2f);
+        return;
+    }
     launch_run_totals<K, T>(h, A, &ntiles);
     Lin *totals = (Lin *)h->d_chain_totals, *run_excl = totals + (size_t)2 * (ntiles + 1);
     const dim3 g(ntiles), b(2 * T);

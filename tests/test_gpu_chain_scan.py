@@ -268,11 +268,12 @@ def test_chain_scan_sees_data_changes_between_sweeps(hip_lib):
     assert not np.allclose(marg[:, 0], first[:, 0])
 
 
-@pytest.mark.parametrize("T", [1500, 70001, 250001])
+@pytest.mark.parametrize("T", [1500, 70001, 250001, 400001])
 def test_the_one_launch_scan_equals_the_two_launch_scan(hip_lib, monkeypatch, T):
-    """(round 6) the chain scan as ONE launch (tile totals published behind flags, csrc/cx_chain.hip: k_chain_onepass) against the two
-    launches it replaces (CX_CHAIN_ONEPASS=0, read when a handle first scans): the same compositions in the same order — equal to a few
-    units in the last place (two kernels, two sets of fused multiply-adds) —, sweep after sweep (the epoch moves on inside the launch)."""
+    """(round 6) the chain scan as ONE launch (tile totals published with the launch's tag, csrc/cx_chain.hip: k_chain_onepass) against
+    the two launches it replaces (CX_CHAIN_ONEPASS=0, read when a handle first scans): the same maps composed in the same order, the one
+    launch without divisions (entries scaled by powers of two) — equal to a few units in the last place —, sweep after sweep (the epoch
+    moves on inside the launch).  T = 400,001 is 391 tiles: more than one workgroup per compute unit, the instance held to 128 registers."""
     model = cx.synth.ssm_chain(T, seed=T + 1, random_variances=True)
     a = cx.DeviceGraph(schedule=L.SCHED_CHAIN_SCAN)
     cx.synth.load_into_device(model, a)
