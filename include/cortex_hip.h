@@ -354,8 +354,8 @@ int32_t cx_graph_wire(cx_handle *h, int64_t n, const cx_item *signals, const cx_
  * run the scheduler }.  Zeros before the first call and for other schedules. */
 int32_t cx_ref_plan_stats(const cx_handle *h, int64_t *out8);
 /* the scalar chain scan as ONE launch (CX_SCHED_CHAIN_SCAN, the scans of CX_SCHED_TREE's heavy paths, the variational families' state
- * pass): a single-pass scan whose workgroups publish their tile totals behind flags instead of ending a kernel (csrc/cx_chain.hip:
- * k_chain_onepass).  Taken when the whole grid is resident at once; every wait is bounded in time (0.5 s, CX_CHAIN_ONEPASS_TIMEOUT_MS) —
+ * pass): a single-pass scan whose workgroups publish their tile totals under the launch's tag instead of ending a kernel
+ * (csrc/cx_chain.hip: k_chain_onepass).  Taken when the whole grid is resident at once (up to twice the compute units' count of tiles); every wait is bounded in time (0.5 s, CX_CHAIN_ONEPASS_TIMEOUT_MS) —
  * a launch whose wait times out stores NOTHING, the next call that checks the device returns CX_ERR_DEVICE, the handle goes back to the
  * two-launch scan and the caller repeats the sweep (a chain-scan sweep is exact whatever it starts from).  CX_CHAIN_ONEPASS=0 turns it off.
  * out4 = { 1 ready / 0 not prepared / -1 off, launches of the one-launch form so far, G, 0 } — G counts another kind of fused launch: the
