@@ -444,7 +444,7 @@ __global__ __launch_bounds__(2 * T) void k_chain_run_apply(ChainArgs A, const Li
 //     it has then seen every other workgroup's total, i.e. every workgroup has read the word), so a captured graph replays.
 constexpr int kOnepassMaxTiles = 2048;
 constexpr int kTotalPieces = 8;        // 16-byte pieces per published total: records are 128 bytes apart
-struct OnepassCtl { unsigned epoch, done, pad[14]; };
+struct OnepassCtl { unsigned epoch, pad[15]; };
 typedef unsigned int cx_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long cx_u64;
 // A published total is eight pieces (value, value XOR tag), the tag a 64-bit pattern of the launch's epoch: a reader that finds the
@@ -602,6 +602,7 @@ __global__ __launch_bounds__(2 * T, WIDE ? 4 : 2) void k_chain_onepass(ChainArgs
 #pragma unroll
     for (int w = 0; w < T / 64; w++) mp = linp_apply_p(wave_tot[half][w], mp);
     const MsgP tile_in = mp;      // (what enters the tile: the marginal phase reads it as `seam`; its division waits until the walk is on its way)
+    mp = msgp_rescale(mp);        // (every few maps the triple goes back to d in [0.5, 1): a map's entries are bounded by nothing but its own D)
     for (int w = 0; w < wid; w++) mp = linp_apply_p(wave_run[half][w], mp);
     mp = linp_apply_p(ex, mp);
     CX_STAMP(3);
@@ -693,6 +694,7 @@ static bool onepass_ready(cx_handle *h, int ntiles, bool *wide) {
         void *dw = nullptr;
         if (hipHostGetDevicePointer(&dw, hw, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d); (void)hipHostFree(hw); return false; }
         h->d_chain_onepass = d; h->chain_abort_host = (volatile unsigned *)hw; h->d_chain_abort = dw;
+        h->device_bytes += (int64_t)bytes;
         h->chain_onepass_cus = cus;
         h->chain_onepass_state = 1;
     }
@@ -833,6 +835,7 @@ static bool chain_linkpar(cx_handle *h, ChainArgs &A) {
             h->d_chain_linkpar = nullptr; h->chain_linkpar_cap = 0;
             if (hipMalloc(&h->d_chain_linkpar, (size_t)n2 * (3 * 8 + 2 * 4)) != hipSuccess) { (void)hipGetLastError(); h->d_chain_linkpar = nullptr; return false; }
             h->chain_linkpar_cap = n;
+            h->device_bytes += n2 * (3 * 8 + 2 * 4);
         }
     }
     const int64_t cs = (h->chain_linkpar_cap + 7) / 8 * 8;

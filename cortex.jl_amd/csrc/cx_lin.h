@@ -146,6 +146,11 @@ __device__ __forceinline__ MsgP linp_apply_p(const LinP &p, const MsgP &m) {
     return MsgP{p.e * m.x + p.f * m.w + p.g * m.d, p.A * m.w + p.B * m.d, p.C * m.w + p.D * m.d};
 }
 
+__device__ __forceinline__ MsgP msgp_rescale(const MsgP &m) {
+    const int k = -__builtin_amdgcn_frexp_exp(m.d);
+    return MsgP{__builtin_ldexp(m.x, k), __builtin_ldexp(m.w, k), __builtin_ldexp(m.d, k)};
+}
+
 __device__ __forceinline__ double2 linp_apply(const LinP &p, double2 m) {
     if (p.seg) { const double inv = 1.0 / p.D; return make_double2(p.g * inv, p.B * inv); }
     const double inv = 1.0 / (p.C * m.y + p.D);

@@ -52,6 +52,39 @@ def ssm_chain_posterior(y, r, q):
     return tridiag_posterior(diag, off, y / r)
 
 
+def ssm_chain_posterior_decimal(y, r, q, digits=50):
+    """ssm_chain_posterior in `digits`-digit decimal arithmetic: the float64 solve above loses what 1 / r + 1 / q loses when the variances
+    span many decades (1.9e-6 of the mean at twelve decades and T = 70,001; tools/lab/c2_dynamic_range.py).  Mean by elimination, variances
+    from the two one-sided recursions (the diagonal of the inverse of a tridiagonal matrix)."""
+    from decimal import Decimal, getcontext
+
+    getcontext().prec = digits
+    T = len(y)
+    one = Decimal(1)
+    rr = [Decimal(float(x)) for x in np.broadcast_to(np.asarray(r, dtype=np.float64), (T,))]
+    qq = [Decimal(float(x)) for x in np.broadcast_to(np.asarray(q, dtype=np.float64), (max(T - 1, 0),))]
+    diag = [one / x for x in rr]
+    for i in range(T - 1):
+        w = one / qq[i]
+        diag[i] += w
+        diag[i + 1] += w
+    off = [-one / x for x in qq]
+    b = [Decimal(float(y[i])) / rr[i] for i in range(T)]
+    d = diag[:]
+    for i in range(1, T):
+        m = off[i - 1] / d[i - 1]
+        d[i] -= m * off[i - 1]
+        b[i] -= m * b[i - 1]
+    x = [Decimal(0)] * T
+    x[-1] = b[-1] / d[-1]
+    for i in range(T - 2, -1, -1):
+        x[i] = (b[i] - off[i] * x[i + 1]) / d[i]
+    e = diag[:]
+    for i in range(T - 2, -1, -1):
+        e[i] -= off[i] * off[i] / e[i + 1]
+    return np.array([float(v) for v in x]), np.array([float(one / (d[i] + e[i] - diag[i])) for i in range(T)])
+
+
 def grid_precision(n_rows, n_cols, r, qh, qv):
     """Sparse precision of the grid model: unary y_i ~ N(x_i, r_i) and pairwise
     difference factors x_i - x_j ~ N(0, q_ij).  qh[i, j] couples (i, j)-(i, j+1); qv[i, j]
