@@ -95,14 +95,14 @@ int32_t cx_create(const cx_config *config, cx_handle **out) {
     // the smallest that holds the user's (round 6; until then always 64: a d = 8 message moved 64 x its bytes).  A dim in between is
     // embedded: x -> (x, u) with u a unit random walk observed nowhere — every rule matrix, message and datum block-diagonal (real block,
     // identity block), so the real block of every result is exact and the identity block keeps every joint positive definite.  The
-    // chain-scan and tree schedules' plans are written for 4 x 4 tiles: they keep 64.  CX_MFMA_DIM=64 forces 64 everywhere (A/B).
+    // chain-scan and tree schedules run the same plans on kernels of their own for 1 x 1 and 2 x 2 tiles (cx_mv64chain.hip: k_compose_nt,
+    // k_walk_nt).  CX_MFMA_DIM=64 forces 64 everywhere (A/B; a chain cut into time blocks: cx_chain_block_maps exchanges 64 x 64 potentials).
     cx_config padded;
     int user_dim = 0;
     if (config->dim > 4) {
         int internal = 64;
         const char *force = std::getenv("CX_MFMA_DIM");
-        if ((config->schedule == CX_SCHED_FUSED || config->schedule == CX_SCHED_REFERENCE) && !(force && std::atoi(force) == 64))
-            internal = config->dim <= 16 ? 16 : config->dim <= 32 ? 32 : 64;
+        if (!(force && std::atoi(force) == 64)) internal = config->dim <= 16 ? 16 : config->dim <= 32 ? 32 : 64;
         user_dim = config->dim != internal ? config->dim : 0;
         padded = *config; padded.dim = internal; config = &padded;
     }

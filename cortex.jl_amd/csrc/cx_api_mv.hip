@@ -372,7 +372,8 @@ static int32_t mv_chain_sweep(cx_handle *h, int32_t n_sweeps) {
 //     f(eta, Lambda) = ( c + B (Lambda + P)^-1 (eta + h),  C - B (Lambda + P)^-1 B' );   sides: eta[d] | Lambda packed upper.
 int32_t mv_chain_block_maps(cx_handle *h, double *fwd, double *bwd, double *side_first, double *side_last, int64_t *first_variable_id,
                             int64_t *last_variable_id, int64_t *n_links) {
-    CX_REQUIRE(h, h->cfg.dim <= 4 || cx::is_mfma_dim(h->cfg.dim), CX_ERR_UNSUPPORTED, "cx_chain_block_maps: dim 1..4 and 64");
+    CX_REQUIRE(h, h->cfg.dim <= 4 || (h->cfg.dim == 64 && !h->user_dim), CX_ERR_UNSUPPORTED,
+               "cx_chain_block_maps: dim 1 .. 4 and 64 (the maps of a block on the matrix-core path are 64 x 64 potentials: a smaller dim has to be embedded by the caller)");
     CX_REQUIRE(h, (int64_t)h->psets.size() > h->max_pset, CX_ERR_STATE, "cx_chain_block_maps: a parameter set was never set (cx_set_factor_matrices)");
     int32_t rc = build_chains(h);
     if (rc != CX_OK) return rc;

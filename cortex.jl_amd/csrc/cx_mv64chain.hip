@@ -525,6 +525,201 @@ struct Chain64 {
     int32_t side_ends[6] = {-1, -1, -1, -1, -1, -1};      // side slots of path 0's first / last position
 };
 
+// ---- 1 x 1 and 2 x 2 tiles (round 6: d = 5 .. 32 in their native size under the chain-scan and tree schedules too) ---------------------
+// The same plan, the same records, the same algebra — on matrices of NT x NT tiles of 16 with NT = 1, 2, where a whole composition fits
+// ONE wave's registers (18 tiles at NT = 2) and nothing has to be split, staged or streamed: P1, M (in C1's place), Y1 (in B1's place),
+// Y2 and the new B stay in registers over a job's children.  A composition of 1 x 1 tiles is 24 matrix instructions behind one
+// diagonal tile's pivot chain: these kernels are bound by that chain's latency, not by the matrix pipe (as k_rule64w<4, 1> is).
+template <int NT, bool AFFINE>
+__global__ __launch_bounds__(64) void k_walk_nt(int njobs, const DJob *__restrict__ jobs, const DStep *__restrict__ steps) {
+    __shared__ double S[16 * kLdT];
+    __shared__ double Vs[NT][16 * kLdT];
+    const int w = blockIdx.x;
+    if (w >= njobs) return;
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int first = as_const(jobs)[w].first, n = as_const(jobs)[w].n;
+    for (int s = 0; s < n; s++) {
+        const auto *st = as_const(steps) + (first + s);
+        if (!rule64w_apply<AFFINE, false, NT>(st->P, st->Bt, st->C, st->h, st->c, st->src[0], st->src[1], st->src[2], st->has2 != 0, st->dst, S, Vs, lane, g, c)) break;
+        // the next step reads what this one stored (its entering message): the stores have to have left the wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(64) void k_compose_nt(int njobs, const DJob *__restrict__ jobs, const DChild *__restrict__ children) {
+    constexpr int KD = 16 * NT, NU = NT * (NT + 1) / 2;
+    __shared__ double S[16 * kLdT];
+    __shared__ double Vs[NT][16 * kLdT];
+    const int w = blockIdx.x;
+    if (w >= njobs) return;
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15, mo = g * KD + c;
+    const int first = as_const(jobs)[w].first, n = as_const(jobs)[w].n;
+    gdp out = as_const(jobs)[w].out;
+    // the running potential: P1 and C1 as upper tiles, B1[i][j] = tile (row block i: the joint's side, column block j: the far end's)
+    d4 P1[NU], C1[NU], B1[NT][NT];
+    double h1[NT], c1[NT];      // element 16 j + c in every lane group
+    {
+        const auto *ch = as_const(children) + first;
+        const PtrAcc P = acc_of(ch->P), B = acc_of(ch->B), C = acc_of(ch->C), hh = acc_of(ch->h), cc = acc_of(ch->c);
+#pragma unroll
+        for (int a = 0; a < NT; a++) {
+#pragma unroll
+            for (int b = 0; b < NT; b++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int o = tile_const_n<NT>(a, b, r);
+                    B1[a][b][r] = B.ld(mo, o);
+                    if (b >= a) { P1[utn<NT>(a, b)][r] = P.ld(mo, o); C1[utn<NT>(a, b)][r] = C.ld(mo, o); }
+                }
+            h1[a] = hh.ld(c, 16 * a); c1[a] = cc.ld(c, 16 * a);
+        }
+    }
+    for (int k = 1; k < n; k++) {
+        const auto *ch = as_const(children) + (first + k);
+        const PtrAcc P2 = acc_of(ch->P), Bt2 = acc_of(ch->Bt), C2 = acc_of(ch->C), h2 = acc_of(ch->h), c2 = acc_of(ch->c);
+        const int nside = (int)ch->nside;
+        // the joint: M = C1 + P2 + the sides' Lambdas (in C1's registers), gv = c1 + h2 + the sides' etas
+        double gv[NT];
+#pragma unroll
+        for (int a = 0; a < NT; a++) {
+#pragma unroll
+            for (int b = a; b < NT; b++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) C1[utn<NT>(a, b)][r] += P2.ld(mo, tile_const_n<NT>(a, b, r));
+            gv[a] = c1[a] + h2.ld(c, 16 * a);
+        }
+        for (int sd = 0; sd < nside; sd++) {      // (uniform; side messages are whole records eta[KD] | Lambda[KD][KD])
+            const PtrAcc sm = acc_of(ch->side[sd]);
+#pragma unroll
+            for (int a = 0; a < NT; a++) {
+#pragma unroll
+                for (int b = a; b < NT; b++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) C1[utn<NT>(a, b)][r] += sm.ld(mo, KD + tile_const_n<NT>(a, b, r));
+                gv[a] += sm.ld(c, 16 * a);
+            }
+        }
+        // M = U'U: off-diagonal tiles of C1 become U, V_k = U_kk^-1 goes to LDS
+#pragma unroll
+        for (int kk = 0; kk < NT; kk++) {
+            const d4 Vk = diag_factor(C1[utn<NT>(kk, kk)], S, g, c);
+#pragma unroll
+            for (int r = 0; r < 4; r++) Vs[kk][(g + 4 * r) * kLdT + c] = Vk[r];
+#pragma unroll
+            for (int j = kk + 1; j < NT; j++) C1[utn<NT>(kk, j)] = tts(Vk, C1[utn<NT>(kk, j)], d4{0.0, 0.0, 0.0, 0.0});
+#pragma unroll
+            for (int i = kk + 1; i < NT; i++) {
+                const d4 nu = neg(C1[utn<NT>(kk, i)]);
+#pragma unroll
+                for (int j = i; j < NT; j++) C1[utn<NT>(i, j)] = tts(nu, C1[utn<NT>(kk, j)], C1[utn<NT>(i, j)]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // z = U^-T gv on the vector pipe (as in rule64_body)
+        double zrv[NT][4];
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            double wcv = gv[j];
+#pragma unroll
+            for (int kk = 0; kk < j; kk++) {
+                double p = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) p += C1[utn<NT>(kk, j)][r] * zrv[kk][r];
+                wcv -= sum_groups(p);
+            }
+            double p = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) p += Vs[j][(g + 4 * r) * kLdT + c] * cv_to_rv(wcv, g, r);
+            const double zcv = sum_groups(p);
+#pragma unroll
+            for (int r = 0; r < 4; r++) zrv[j][r] = cv_to_rv(zcv, g, r);
+        }
+        // Y1 = U^-T B1 (in B1's registers), Y2 = U^-T B2'
+        d4 Y2[NT][NT];
+#pragma unroll
+        for (int a = 0; a < NT; a++)
+#pragma unroll
+            for (int b = 0; b < NT; b++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) Y2[a][b][r] = Bt2.ld(mo, tile_const_n<NT>(a, b, r));
+#pragma unroll
+        for (int b = 0; b < NT; b++)
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                d4 Vj;
+#pragma unroll
+                for (int r = 0; r < 4; r++) Vj[r] = Vs[j][(g + 4 * r) * kLdT + c];
+                B1[j][b] = tts(Vj, B1[j][b], d4{0.0, 0.0, 0.0, 0.0});
+                Y2[j][b] = tts(Vj, Y2[j][b], d4{0.0, 0.0, 0.0, 0.0});
+#pragma unroll
+                for (int jj = j + 1; jj < NT; jj++) {
+                    const d4 nu = neg(C1[utn<NT>(j, jj)]);
+                    B1[jj][b] = tts(nu, B1[j][b], B1[jj][b]);
+                    Y2[jj][b] = tts(nu, Y2[j][b], Y2[jj][b]);
+                }
+            }
+        // P1 -= Y1'Y1, h1 += Y1'z;  C1 = C2 - Y2'Y2, c1 = c2 + Y2'z;  B1 = Y2'Y1
+        d4 Bn[NT][NT];
+#pragma unroll
+        for (int a = 0; a < NT; a++) {
+#pragma unroll
+            for (int b = 0; b < NT; b++) {
+                d4 G = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int j = 0; j < NT; j++) G = tts(Y2[j][a], B1[j][b], G);
+                Bn[a][b] = G;
+            }
+#pragma unroll
+            for (int b = a; b < NT; b++) {
+                d4 G1 = d4{0.0, 0.0, 0.0, 0.0}, G2 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int j = 0; j < NT; j++) { G1 = tts(B1[j][a], B1[j][b], G1); G2 = tts(Y2[j][a], Y2[j][b], G2); }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    P1[utn<NT>(a, b)][r] -= G1[r];
+                    C1[utn<NT>(a, b)][r] = C2.ld(mo, tile_const_n<NT>(a, b, r)) - G2[r];
+                }
+            }
+            double p1 = 0.0, p2 = 0.0;
+#pragma unroll
+            for (int j = 0; j < NT; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) { p1 += B1[j][a][r] * zrv[j][r]; p2 += Y2[j][a][r] * zrv[j][r]; }
+            h1[a] += sum_groups(p1);
+            c1[a] = c2.ld(c, 16 * a) + sum_groups(p2);
+        }
+#pragma unroll
+        for (int a = 0; a < NT; a++)
+#pragma unroll
+            for (int b = 0; b < NT; b++) B1[a][b] = Bn[a][b];
+    }
+    // the record: P | B | B' | C (row-major; P and C: their upper tiles) | h | c
+    const PtrAcc oP = acc_of((gcdp)out), oB = acc_of((gcdp)(out + KD * KD)), oBt = acc_of((gcdp)(out + 2 * KD * KD)), oC = acc_of((gcdp)(out + 3 * KD * KD)),
+                 ohc = acc_of((gcdp)(out + 4 * KD * KD));
+#pragma unroll
+    for (int a = 0; a < NT; a++) {
+#pragma unroll
+        for (int b = 0; b < NT; b++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int o = tile_const_n<NT>(a, b, r);
+                oB.st(mo, o, B1[a][b][r]);
+                if (b >= a) { oP.st(mo, o, P1[utn<NT>(a, b)][r]); oC.st(mo, o, C1[utn<NT>(a, b)][r]); }
+            }
+            // B' tile (b, a) is this tile transposed: through LDS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 4; r++) S[(g + 4 * r) * kLdT + c] = B1[a][b][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 4; r++) oBt.st(mo, tile_const_n<NT>(b, a, r), S[c * kLdT + g + 4 * r]);
+        }
+        if (g == 0) { ohc.st(c, 16 * a, h1[a]); ohc.st(c, KD + 16 * a, c1[a]); }
+    }
+}
+
 static void chain64_drop(cx_handle *h, Chain64 *c) {
     if (!c) return;
     for (void *p : {(void *)c->d_jobs, (void *)c->d_children, (void *)c->d_steps, (void *)c->d_pot, (void *)c->d_ent, (void *)c->d_ring, (void *)c->d_aux, (void *)c->d_aux_src}) if (p) (void)hipFree(p);
@@ -533,17 +728,17 @@ static void chain64_drop(cx_handle *h, Chain64 *c) {
 }
 
 // the side information of a position with three or more side slots, summed: one workgroup per arena message
-__global__ __launch_bounds__(256) void k_side64(int n, const int32_t *__restrict__ src, const double *__restrict__ f2v, double *__restrict__ aux) {
+__global__ __launch_bounds__(256) void k_side64(int n, int msg, const int32_t *__restrict__ src, const double *__restrict__ f2v, double *__restrict__ aux) {
     const int w = blockIdx.x;
     if (w >= n) return;
     int s[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) s[j] = src[8 * w + j];
-    for (int e = threadIdx.x; e < kMsg; e += 256) {
+    for (int e = threadIdx.x; e < msg; e += 256) {
         double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) if (s[j] >= 0) acc += f2v[(int64_t)s[j] * kMsg + e];
-        aux[(int64_t)w * kMsg + e] = acc;
+        for (int j = 0; j < 8; j++) if (s[j] >= 0) acc += f2v[(int64_t)s[j] * msg + e];
+        aux[(int64_t)w * msg + e] = acc;
     }
 }
 
@@ -620,7 +815,7 @@ static int32_t chain64_make(cx_handle *h, Chain64 **out, bool root, const std::v
     int ncu = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, h->cfg.device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
     p64::Input in;
-    in.d = 64; in.npos = npos; in.nlinks = nlinks;
+    in.d = h->cfg.dim; in.npos = npos; in.nlinks = nlinks;      // (16, 32 or 64: cx_const.h is_mfma_dim)
     in.link_pos = link_pos.data(); in.from = from.data(); in.to = to.data(); in.tab_fwd = tab_fwd.data(); in.tab_bwd = tab_bwd.data();
     in.head_fwd = head_fwd.data(); in.head_bwd = head_bwd.data(); in.side = side.data(); in.side_aux = side_aux.data();
     in.K0 = env_int("CX_MVC64_K", 0);            // links per level-0 block (default: one block per SIMD)
@@ -661,10 +856,10 @@ static int32_t chain64_make(cx_handle *h, Chain64 **out, bool root, const std::v
     if ((rc = cxh::dev_alloc(h, &c->d_steps, (int64_t)c->steps.size())) != CX_OK) return rc;
     if ((rc = cxh::dev_alloc(h, &c->d_pot, plan.n_pot * plan.pot)) != CX_OK) return rc;
     if ((rc = cxh::dev_alloc(h, &c->d_ent, plan.n_ent * plan.msg)) != CX_OK) return rc;
-    if (plan.n_pot > 0 && (rc = cxh::dev_alloc(h, &c->d_ring, (int64_t)widest_compose * 16 * kTileD)) != CX_OK) return rc;
+    if (plan.n_pot > 0 && h->cfg.dim == kD && (rc = cxh::dev_alloc(h, &c->d_ring, (int64_t)widest_compose * 16 * kTileD)) != CX_OK) return rc;      // (the pair of waves' hand-over)
     c->n_aux = (int64_t)aux_src.size() / 8;
     if (c->n_aux > 0) {
-        if ((rc = cxh::dev_alloc(h, &c->d_aux, c->n_aux * (int64_t)kMsg)) != CX_OK) return rc;
+        if ((rc = cxh::dev_alloc(h, &c->d_aux, c->n_aux * plan.msg)) != CX_OK) return rc;
         if ((rc = cxh::dev_upload(h, &c->d_aux_src, aux_src)) != CX_OK) return rc;
         CX_HIP(h, hipStreamSynchronize(h->stream));      // (aux_src is a local)
     }
@@ -747,13 +942,19 @@ static int32_t chain64_run(cx_handle *h, Chain64 *c, bool skip_compose) {
     }
     std::vector<unsigned long long> hs(st_n);
 #endif
-    if (c->n_aux > 0) hipLaunchKernelGGL(k_side64, dim3((unsigned)c->n_aux), dim3(256), 0, h->stream, (int)c->n_aux, c->d_aux_src, h->d_mv_f2v, c->d_aux);
+    const int dim = h->cfg.dim;
+    if (c->n_aux > 0) hipLaunchKernelGGL(k_side64, dim3((unsigned)c->n_aux), dim3(256), 0, h->stream, (int)c->n_aux, dim + dim * dim, c->d_aux_src, h->d_mv_f2v, c->d_aux);
     for (const auto &L : c->launches) {
 #ifdef CX_C64_STAMPS
         (void)hipMemsetAsync(d_st, 0, st_n * 8, h->stream);
 #endif
         if (L.kind == 0 && skip_compose) continue;
-        if (L.kind == 0) {
+        if (dim != kD) {      // 1 x 1 / 2 x 2 tiles: one wave per job, whatever the launch
+            const bool two = dim == 32;
+            if (L.kind == 0) { if (two) hipLaunchKernelGGL(k_compose_nt<2>, dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_children); else hipLaunchKernelGGL(k_compose_nt<1>, dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_children); }
+            else if (L.kind == 1) { if (two) hipLaunchKernelGGL((k_walk_nt<2, true>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps); else hipLaunchKernelGGL((k_walk_nt<1, true>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps); }
+            else { if (two) hipLaunchKernelGGL((k_walk_nt<2, false>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps); else hipLaunchKernelGGL((k_walk_nt<1, false>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps); }
+        } else if (L.kind == 0) {
             hipLaunchKernelGGL(k_compose64p, dim3(L.n), dim3(128), 0, h->stream, L.n, c->d_jobs + L.first, c->d_children, c->d_ring);
         } else if (L.kind == 1) {          // few jobs: a wave alone on its SIMD
             hipLaunchKernelGGL((k_walk64b<1, true>), dim3(L.n), dim3(64), 0, h->stream, L.n, c->d_jobs + L.first, c->d_steps);
@@ -783,6 +984,7 @@ static int32_t chain64_run(cx_handle *h, Chain64 *c, bool skip_compose) {
 int32_t chain64_block_potential(cx_handle *h, double *pot, int32_t *side_first3, int32_t *side_last3, bool *no_root) {
     Chain64 *c = (Chain64 *)h->chain64;
     if (!c) return cxh::fail(h, CX_ERR_STATE, "chain-scan schedule, dim 64: no plan");
+    if (h->cfg.dim != kD) return cxh::fail(h, CX_ERR_UNSUPPORTED, "cx_chain_block_maps: time blocks of a chain on the matrix-core path are exchanged as 64 x 64 potentials (dim 64)");
     *no_root = c->n_roots < 1;
     if (*no_root) return CX_OK;
     if (c->n_roots != 1) return cxh::fail(h, CX_ERR_UNSUPPORTED, "cx_chain_block_maps: the non-observed variables of this handle must form ONE path (a time block of a chain)");
