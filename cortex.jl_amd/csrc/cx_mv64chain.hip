@@ -820,7 +820,9 @@ static int32_t chain64_make(cx_handle *h, Chain64 **out, bool root, const std::v
     in.head_fwd = head_fwd.data(); in.head_bwd = head_bwd.data(); in.side = side.data(); in.side_aux = side_aux.data();
     in.K0 = env_int("CX_MVC64_K", 0);            // links per level-0 block (default: one block per SIMD)
     in.fan = std::max(2, env_int("CX_MVC64_FAN", 2));      // binary tree: the shortest dependent chain above level 0 (fan 2 / 4 / 8: 14.19 / 14.37 / 15.08 ms on C5)
-    in.lanes = 4 * (int64_t)ncu;                 // a composition is one wave per SIMD
+    // a composition of 4 x 4 tiles is one wave per SIMD (a pair of waves per two SIMDs); the small-tile kernels run three (1 x 1: four in
+    // the walks) or two (2 x 2) waves per SIMD, and their time is a wave's chain of dependent pivots: more, shorter blocks
+    in.lanes = 4 * (int64_t)ncu * (h->cfg.dim == 16 ? env_int("CX_MVC_NT_WAVES", 3) : h->cfg.dim == 32 ? env_int("CX_MVC_NT_WAVES", 2) : 1);
     in.root = root;                              // a time block hands its whole potential to the other blocks
     p64::Plan plan;
     try { plan = p64::build(in); }

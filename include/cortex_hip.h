@@ -176,8 +176,8 @@ typedef struct cx_config {
     int32_t struct_size;   /* sizeof(cx_config), for forward compatibility */
     int32_t device;        /* HIP device ordinal */
     int32_t dim;           /* message dimension d: 1 (scalar), 2, 3, 4 (registers); 5 .. 64 run on the f64 matrix cores, a wave per message, in
-                              1 x 1, 2 x 2 or 4 x 4 accumulator tiles of 16: the smallest of 16, 32, 64 that holds d under CX_SCHED_FUSED and
-                              CX_SCHED_REFERENCE (ABI 4), always 64 under CX_SCHED_CHAIN_SCAN and CX_SCHED_TREE.  A d in between is embedded
+                              1 x 1, 2 x 2 or 4 x 4 accumulator tiles of 16: the smallest of 16, 32, 64 that holds d, under every schedule
+                              (ABI 4; cx_chain_block_maps: dim 1 .. 4 and 64 only).  A d in between is embedded
                               block-diagonally (x, u) with u a unit random walk nobody observes: exact results for the d x d blocks,
                               payloads of d and d + d*d doubles as for any d, at the cost of the tile size                          */
     int32_t schedule;      /* CX_SCHED_*: dim 1 all five; dim 2 .. 64: CX_SCHED_FUSED, CX_SCHED_CHAIN_SCAN, CX_SCHED_TREE, CX_SCHED_REFERENCE */

@@ -190,6 +190,20 @@ def mv_tiles(d=16, T=100_000, steps=20, embedded_T=None):
         rows[name] = {"states": Tn, "ms_per_sweep": dt * 1e3, "kernel_ms": ms / max(n, 1), "ns_per_message": dt * 1e9 / (2 * (Tn - 1)),
                       "device_bytes": st["device_bytes"], "bytes_per_slot": st["device_bytes"] / st["n_slots"]}
         dev.close()
+    # the same two forms under the chain-scan schedule: ONE exact sweep (the smoother at every state)
+    for name, env, Tn in (("native", None, T), ("embedded_in_64", "64", embedded_T or T)):
+        model = cx.synth.lgssm_chain(Tn, d=d, seed=1234)
+        if env:
+            os.environ["CX_MFMA_DIM"] = env
+        try:
+            dev = cx.DeviceGraph(dim=d, schedule=L.SCHED_CHAIN_SCAN)
+        finally:
+            os.environ.pop("CX_MFMA_DIM", None)
+        cx.synth.load_into_device(model, dev)
+        dev.sweep(2)
+        dt = timed(dev, lambda: dev.sweep(1), 4, 1)
+        rows[name]["chain_scan"] = {"ms_per_exact_sweep": dt * 1e3, "ns_per_state": dt * 1e9 / Tn, "plan": dev.chain_plan_stats()}
+        dev.close()
     nmsg = 2 * (T - 1)
     kern_s = rows["native"]["kernel_ms"] * 1e-3
     tf = nmsg * mfma * 2048 / kern_s / 1e12
@@ -197,6 +211,7 @@ def mv_tiles(d=16, T=100_000, steps=20, embedded_T=None):
     return {"config": f"d={d} native tiles", "workload": f"d={d} linear-Gaussian chain T={T}, fused flooding sweep, {nt} x {nt} tiles of 16 (the embedding in 4 x 4 tiles beside it)",
             "ms_per_sweep": rows["native"]["ms_per_sweep"], "native": rows["native"], "embedded_in_64": rows["embedded_in_64"],
             "speedup_over_embedding": rows["embedded_in_64"]["ns_per_message"] / rows["native"]["ns_per_message"],
+            "chain_scan_speedup_over_embedding": rows["embedded_in_64"]["chain_scan"]["ns_per_state"] / rows["native"]["chain_scan"]["ns_per_state"],
             "bytes_ratio": rows["native"]["bytes_per_slot"] / rows["embedded_in_64"]["bytes_per_slot"], "bytes_ratio_of_records": (nd + nd * nd) / (64 + 64 * 64),
             "roofline": roofline("hbm", nmsg * 2 * payload / kern_s / 1e9, HBM_PEAK_GBS, "GB/s", None, kernel=f"k_rule64w<4, {nt}>", avg_kernel_ms=kern_s * 1e3,
                                  basis=f"record bytes ({2 * payload} B per message: read + written) / avg launch duration; no counter traffic collected",
