@@ -21,7 +21,7 @@ end
 mutable struct HipProcessor <: Cortex.AbstractInferenceRequestProcessor
     handle::Ptr{Cvoid}
     schedule::Int              # CX_SCHED_* the handle was created with
-    dim::Int                   # 1: scalar messages; 2 .. 64: d-dimensional linear-Gaussian messages (2, 3, 4 in registers; 5 .. 64 on the matrix cores in tiles of 16: the smallest of 16, 32, 64 that holds d — 64 under the chain-scan and tree schedules)
+    dim::Int                   # 1: scalar messages; 2 .. 64: d-dimensional linear-Gaussian messages (2, 3, 4 in registers; 5 .. 64 on the matrix cores in tiles of 16: the smallest of 16, 32, 64 that holds d, under every schedule)
     queue::Vector{CxItem}
     signals::Vector{Cortex.InferenceSignal}
 end
