@@ -10,7 +10,6 @@
 namespace cx {
 namespace {
 
-constexpr int kD64 = 64, kMsg64 = kD64 + kD64 * kD64;      // dim 64: eta[64] | Lambda[64][64] per slot (cx_mv64w_core.h)
 
 // counters: 0 defined, 1 undefined (UndefValue), 2 a negative precision (dim > 1: a negative diagonal entry of Lambda), 3 non-finite
 __device__ __forceinline__ void tally(unsigned long long *c, bool undef, bool neg, bool nonfin) {
@@ -43,17 +42,18 @@ __global__ void k_health_mv(int64_t n, const int32_t *__restrict__ slots, const 
     tally(c, undef, neg, nonfin);
 }
 
-// dim 64: one wave per message
-__global__ __launch_bounds__(64) void k_health64(int64_t n, const int32_t *__restrict__ slots, const double *__restrict__ f2v, unsigned long long *__restrict__ c) {
+// the matrix-core dims (16, 32, 64): one wave per message record eta[kd] | Lambda[kd][kd]
+__global__ __launch_bounds__(64) void k_health64(int kd, int64_t n, const int32_t *__restrict__ slots, const double *__restrict__ f2v, unsigned long long *__restrict__ c) {
     const int64_t w = blockIdx.x;
     if (w >= n) return;
-    const double *m = f2v + (int64_t)slots[w] * kMsg64;
+    const int km = kd + kd * kd;
+    const double *m = f2v + (int64_t)slots[w] * km;
     int undef = 0, neg = 0, nonfin = 0;
-    for (int e = threadIdx.x; e < kMsg64; e += 64) {
+    for (int e = threadIdx.x; e < km; e += 64) {
         const double x = m[e];
         undef |= __builtin_isnan(x);
         nonfin |= __builtin_isinf(x);
-        if (e >= kD64 && (e - kD64) / kD64 == (e - kD64) % kD64) neg |= x < 0.0;
+        if (e >= kd && (e - kd) / kd == (e - kd) % kd) neg |= x < 0.0;
     }
     undef = __any(undef); neg = __any(neg); nonfin = __any(nonfin);
     if (threadIdx.x == 0) tally(c, undef != 0, neg != 0, nonfin != 0);
@@ -90,7 +90,7 @@ extern "C" int32_t cx_message_health(cx_handle *h, int64_t *out4) {
         else if (h->cfg.dim == 2) hipLaunchKernelGGL(cx::k_health_mv<2>, g, b, 0, h->stream, n, d_s, (const double *)h->d_mv_f2v, d_c);
         else if (h->cfg.dim == 3) hipLaunchKernelGGL(cx::k_health_mv<3>, g, b, 0, h->stream, n, d_s, (const double *)h->d_mv_f2v, d_c);
         else if (h->cfg.dim == 4) hipLaunchKernelGGL(cx::k_health_mv<4>, g, b, 0, h->stream, n, d_s, (const double *)h->d_mv_f2v, d_c);
-        else hipLaunchKernelGGL(cx::k_health64, dim3((unsigned)n), dim3(64), 0, h->stream, n, d_s, (const double *)h->d_mv_f2v, d_c);
+        else hipLaunchKernelGGL(cx::k_health64, dim3((unsigned)n), dim3(64), 0, h->stream, h->cfg.dim, n, d_s, (const double *)h->d_mv_f2v, d_c);
         unsigned long long c[4];
         CX_HIP(h, hipMemcpyAsync(c, d_c, 32, hipMemcpyDeviceToHost, h->stream));
         CX_HIP(h, hipStreamSynchronize(h->stream));

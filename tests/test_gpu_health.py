@@ -44,7 +44,7 @@ def test_loopy_grid_after_seeding(hip_lib):
     assert dev.message_health() == {"defined": n, "undefined": 0, "negative_precision": 0, "non_finite": 0}
 
 
-@pytest.mark.parametrize("d,T,schedule", [(4, 300, L.SCHED_CHAIN_SCAN), (2, 50, L.SCHED_TREE), (64, 12, L.SCHED_CHAIN_SCAN), (6, 9, L.SCHED_TREE)])
+@pytest.mark.parametrize("d,T,schedule", [(4, 300, L.SCHED_CHAIN_SCAN), (2, 50, L.SCHED_TREE), (64, 12, L.SCHED_CHAIN_SCAN), (6, 9, L.SCHED_TREE), (16, 9, L.SCHED_TREE), (20, 12, L.SCHED_CHAIN_SCAN)])
 def test_d_dimensional_messages(hip_lib, d, T, schedule):
     m = cx.synth.lgssm_chain(T, d=d, seed=4)
     dev = cx.DeviceGraph(dim=d, schedule=schedule)

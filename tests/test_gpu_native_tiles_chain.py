@@ -91,3 +91,58 @@ def test_the_tree_schedule_over_heavy_paths_at_native_tiles(hip_lib, d):
     fused = _solve(model, L.SCHED_FUSED, sweeps=2 * n + 8)
     ids = model.x_ids
     assert_close(_marginals(tree, ids), _marginals(fused, ids), 1e-8, f"d={d}: tree schedule vs the fused fixed point")
+
+
+@pytest.mark.parametrize("d", [16, 24])
+def test_new_data_and_new_rule_matrices_between_sweeps(hip_lib, monkeypatch, d):
+    import dataclasses
+
+    monkeypatch.setenv("CX_MVC64_K", "3")
+    T = 50
+    model = cx.synth.lgssm_chain(T, d=d, seed=41)
+    dev = _solve(model, sweeps=2)
+
+    def check(m, what):
+        em, ecov = exact.lgssm_posterior(m.data_y, m.meta["A"], m.meta["Q"], m.meta["R"])
+        marg = _marginals(dev, m.x_ids)
+        assert_close(marg[:, :d], em, 1e-9, what + ", means")
+        assert_close(marg[:, d:].reshape(T, d, d), ecov, 1e-9, what + ", covariances")
+
+    y2 = model.data_y + 0.5
+    dev.set_messages(model.data_var, model.data_fac, L.TO_FACTOR, L.FORM_POINT, y2)
+    dev.sweep(1)
+    check(dataclasses.replace(model, data_y=y2), "after new data")
+    R2 = 2.5 * model.meta["R"]
+    dev.set_factor_matrices(1, np.eye(d), R2)
+    dev.sweep(1)
+    m2 = dataclasses.replace(model, data_y=y2, meta={**model.meta, "R": R2})
+    check(m2, "after a new likelihood covariance")
+    A2 = 0.9 * model.meta["A"]
+    dev.set_factor_matrices(0, A2, model.meta["Q"])
+    dev.sweep(1)
+    check(dataclasses.replace(m2, meta={**m2.meta, "A": A2}), "after a new transition matrix")
+
+
+@pytest.mark.parametrize("d", [16, 32])
+def test_disjoint_chains_and_isolated_variables(hip_lib, monkeypatch, d):
+    """several components — chains of 1 (an isolated variable: no link), 2, 30 and 7 states: nothing is carried across a path boundary"""
+    monkeypatch.setenv("CX_MVC64_K", "2")
+    monkeypatch.setenv("CX_MVC64_FAN", "3")
+    A = cx.synth.lgssm_chain(2, d=d, seed=50).meta["A"]          # one parameter set for all components
+    parts = [cx.synth.lgssm_chain(T, d=d, seed=50 + T, A=A) for T in (1, 2, 30, 1, 7)]
+    model = cx.synth.concat_models(parts)
+    dev = _solve(model)
+    for part, (n, off) in zip(parts, model.meta["parts"]):
+        em, ecov = exact.lgssm_posterior(part.data_y, part.meta["A"], part.meta["Q"], part.meta["R"])
+        marg = dev.get_marginals(part.x_ids + off)
+        assert_close(marg[:, :d], em, 1e-9, f"component of {n} states, means")
+        assert_close(marg[:, d:].reshape(n, d, d), ecov, 1e-9, f"component of {n} states, covariances")
+
+
+def test_time_blocks_are_refused_below_64(hip_lib):
+    """cx_chain_block_maps exchanges 64 x 64 potentials: a chain of d = 16 has to be embedded by the caller (CX_MFMA_DIM=64)"""
+    model = cx.synth.lgssm_chain(12, d=16, seed=1)
+    dev = _solve(model)
+    with pytest.raises(cx.CortexHipError) as e:
+        dev.chain_block_maps()
+    assert e.value.code == L.ERR_UNSUPPORTED
