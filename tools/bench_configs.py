@@ -66,12 +66,14 @@ def roofline(bound, achieved, peak, unit, traffic, **extra):
     return r
 
 
-def timed(dev, fn, steps, warmup, reps=3):
-    """seconds per call of fn: the MEDIAN of `reps` batches of `steps` calls.  One batch is not enough in a process that has torn down
+def timed(dev, fn, steps, warmup, reps=None):
+    """seconds per call of fn: the MEDIAN of `reps` batches of `steps` calls (3; CX_BENCH_REPS=1 under the profilers, whose summaries count
+    launches per iteration).  One batch is not enough in a process that has torn down
     another handle shortly before: one of the first batches of the next handle then holds a stall of ~ 70 ms whatever the kernels are
     (tools/lab/tiles_after_c5.py: 3.4 - 3.8 ms per sweep in ONE batch of 20 around a 0.40 ms kernel, 0.33 before and after; a bare HIP
     program that creates and destroys streams, memory and events does not show it: tools/lab/teardown_stall.hip) — the d = 16 row of
     bench.py came out at 4.3 ms behind the C5 row that way."""
+    reps = reps or int(os.environ.get("CX_BENCH_REPS", "3"))
     for _ in range(warmup):
         fn()
     dev.sync()

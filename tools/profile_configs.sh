@@ -8,6 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_configs_$TAG
 mkdir -p $O
 export TMPDIR=/tmp
+export CX_BENCH_REPS=1      # one batch per row: the summaries count launches per iteration
 cd /tmp
 B="python3 $R/tools/bench_configs.py c2 c3 c3scan c5"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B > $O/trace.log 2>&1 || { tail -5 $O/trace.log; exit 1; }

@@ -6,6 +6,7 @@ set -o pipefail
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
+export CX_BENCH_REPS=1      # one batch per row: the summaries count launches per iteration
 mkdir -p $R/gpurun_out/profiles_$TAG
 for fam in structured mean_field; do
   O=$R/gpurun_out/prof_vmp_${fam}_$TAG
