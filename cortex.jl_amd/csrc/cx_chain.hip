@@ -428,11 +428,11 @@ __global__ __launch_bounds__(2 * T) void k_chain_run_apply(ChainArgs A, const Li
 }
 
 
-// ---- ONE launch (round 6): the two kernels above merged behind per-tile flags ("single-pass scan with decoupled look-back") ---------------
+// ---- ONE launch (round 6): the two kernels above merged ("single-pass scan with decoupled look-back", the totals tagged, not flagged) ------
 // k_chain_run_totals ends where k_chain_run_apply begins only because a workgroup's carry is made of OTHER workgroups' tile totals: a
 // kernel boundary used as a device-wide barrier, ≈ 5.7 us of a 21 us sweep at C2, plus every thread's prefix written out and read back
-// (run_excl: 14 MB at C2).  Here a workgroup publishes its two tile totals (64 bytes each, write-through stores, then a flag), keeps its
-// runs' prefixes in registers, and composes the totals of the tiles before it as they appear: nobody waits for anything but data.
+// (run_excl: 14 MB at C2).  Here a workgroup publishes its two tile totals (128 bytes each, write-through stores), keeps its runs'
+// prefixes in registers, and composes the totals of the tiles before it as they appear: nobody waits for anything but data.
 //   * Publishing comes BEFORE any wait, so the launch makes progress whenever every workgroup is or becomes resident; the launcher takes
 //     this path only when the whole grid fits the device at once (occupancy x compute units), and every wait is bounded in time: a
 //     workgroup that gives up raises a word in host memory (chain_abort), nobody stores a result, and the next call that waits for the
@@ -440,6 +440,8 @@ __global__ __launch_bounds__(2 * T) void k_chain_run_apply(ChainArgs A, const Li
 //   * Totals cross XCDs: written through (sc0 sc1), read past the caches (sc0 sc1), each 16-byte piece carrying the launch's tag beside its
 //     value (below) — no flag, no fence: an agent-scope release / acquire would write back and invalidate the XCD's whole L2 under the
 //     other workgroups' loads, and a flag is a second round trip through the memory the XCDs share.
+//   * A wave fetches the totals its 64 threads compose with eight lanes per total — one 128-byte request each (stage_totals); the maps are
+//     kept up to scale (cx_lin.h: LinP), so a composition has no division, and the wave scans run on DPP row shifts and broadcasts.
 //   * The epoch the tag is made of lives on the device and is moved on inside the launch (by workgroup 0 when it is past its look-back:
 //     it has then seen every other workgroup's total, i.e. every workgroup has read the word), so a captured graph replays.
 constexpr int kOnepassMaxTiles = 2048;
@@ -673,7 +675,7 @@ __global__ __launch_bounds__(2 * T, WIDE ? 4 : 2) void k_chain_onepass(ChainArgs
 }
 
 // the one-launch form is taken when it is on (CX_CHAIN_ONEPASS != 0, no wait of it ever timed out on this handle), the grid is within the
-// flags' table and ALL its workgroups are resident at once on this device
+// totals' table and ALL its workgroups are resident at once on this device
 template <int K, int T>
 static bool onepass_ready(cx_handle *h, int ntiles, bool *wide) {
     *wide = false;
