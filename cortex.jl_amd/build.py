@@ -41,8 +41,26 @@ def sources_sha16(kernel_name: str) -> str:
     h = hashlib.sha256()
     for f in files:
         h.update(f.encode())
-        h.update(open(os.path.join(CSRC, f), "rb").read())
+        h.update(_code_only(open(os.path.join(CSRC, f), "rb").read().decode("utf-8", "replace")).encode())
     return h.hexdigest()[:16]
+
+
+def _code_only(text: str) -> str:
+    """the source without comments and blank lines: a profile stays valid over an edit that changes no code"""
+    import re
+
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    out = []
+    for line in text.splitlines():
+        i = line.find("//")
+        while i >= 0 and line.count('"', 0, i) % 2:      # (inside a string literal: the next one)
+            i = line.find("//", i + 2)
+        if i >= 0:
+            line = line[:i]
+        line = line.rstrip()
+        if line.strip():
+            out.append(line)
+    return "\n".join(out)
 
 
 def _hipcc() -> str:
