@@ -431,6 +431,25 @@ def vmp_traffic(family):
     return best
 
 
+def _tree_traffic(row, n_factors):
+    """counter bytes of one exact tree sweep from profiles/r*_tree_traffic.json (tools/profile_tree.sh), when they were taken on this
+    version of the item and scan kernels and on the same forest"""
+    import glob
+    from importlib import import_module
+    sha = import_module("cortex.jl_amd.build").sources_sha16
+    want = sha("k_batch") + sha("k_chain_")
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_tree_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        r = d.get("rows", {}).get(row, {})
+        if r.get("sources_sha16") == want and r.get("hbm_bytes_per_sweep") and d.get("n_factors", {}).get(row) == n_factors:
+            best = (float(r["hbm_bytes_per_sweep"]), os.path.relpath(f, ROOT))
+    return best
+
+
 def tree(n_factors=200_000, steps=20, shape="random", check=None):
     """the tree schedule (CX_SCHED_TREE): ONE sweep on a forest = the reference's one update_marginals! there, level by level.  Not a
     BASELINE config: a bushy tree with factors of 2..6 variables and ~10^6 edges, timed per exact sweep, beside the number of fused
@@ -452,14 +471,16 @@ def tree(n_factors=200_000, steps=20, shape="random", check=None):
     a, b = dev.get_marginals(ids), fused.get_marginals(ids)
     err = float(np.nanmax(np.abs(a - b) / np.maximum(np.abs(b), np.median(np.abs(b)))))
     n_msgs = st["messages_up"] + st["messages_down"]
+    tt = _tree_traffic("tree" if shape == "random" else f"tree-{shape}", n_factors)
     return {"config": "tree" if shape == "random" else f"tree-{shape}", "workload": f"scalar Gaussian forest, {n_factors} factors of 2..6 variables + a prior per variable ({len(model.edge_var)} edges, shape {shape})",
             "ms_per_sweep": dt * 1e3, "plan": st, "heavy_paths": hp, "launches_per_sweep": launches, "messages_per_sweep": n_msgs, "messages_per_s": n_msgs / dt,
             "fused_schedule": {"ms_per_sweep": dtf * 1e3, "sweeps_to_the_same_result": need, "ms_to_the_same_result": need * dtf * 1e3},
-            "roofline": roofline("hbm", n_msgs * 32 / dt / 1e9, HBM_PEAK_GBS, "GB/s", None,
+            "roofline": roofline("hbm", (tt[0] if tt else n_msgs * 32) / dt / 1e9, HBM_PEAK_GBS, "GB/s", tt[0] if tt else None,
                                  kernel="k_chain_* scans of the heavy paths + k_batch item stages" if hp["launches"] else "k_batch, one launch per stage",
-                                 basis="algorithmic bytes (32 B per message, SURVEY §8d) / sweep time",
+                                 basis=(f"counter bytes per sweep (FETCH_SIZE x2 + WRITE_SIZE over all launches of a sweep, {tt[1]}) / sweep time" if tt
+                                        else "algorithmic bytes (32 B per message, SURVEY §8d) / sweep time"),
                                  frac_survey_convention=n_msgs * 32 / dt / 1e9 / HBM_PEAK_GBS,
-                                 frac_note="a latency-bound schedule: the fraction of HBM on SURVEY §8d's byte convention is frac_survey_convention, no counter traffic was collected",
+                                 frac_note="a latency-bound schedule" + ("" if tt else ": the fraction of HBM on SURVEY §8d's byte convention is frac_survey_convention, no counter traffic on file for these sources and this forest"),
                                  bound_detail=f"not a bandwidth-bound schedule: {launches} dependent launches (≈ {dt / max(launches, 1) * 1e6:.1f} us "
                                               "each at this size): the time is the number of dependent launches x per-kernel time"),
             "self_check": {"max_rel_err_marginals": err, "ok": bool(err < 1e-9), "checker": "the fused schedule at its fixed point on the same device",
