@@ -111,7 +111,13 @@ __device__ __forceinline__ d4 diag_factor(const d4 &T, double *__restrict__ S, i
     double m[16], aw[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) { m[i] = S[i * kLdT + c]; aw[i] = 0.0; }
+#ifdef CX_W64_PRIO      // lab (tools/lab/w64_phases.hip): the pivot chain at a raised wave priority — see there for what it bought
+    __builtin_amdgcn_s_setprio(CX_W64_PRIO);
+#endif
     diag_steps(m, aw, c, std::make_integer_sequence<int, 16>{});
+#ifdef CX_W64_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (dbg_u && g == 0) {
 #pragma unroll
         for (int i = 0; i < 16; i++) dbg_u[i * 16 + c] = m[i];

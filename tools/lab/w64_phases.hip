@@ -33,8 +33,8 @@ int main(int argc, char **argv) {
     for (int rep = 0; rep < 3; rep++) {
         CK(hipMemset(stamps, 0, (size_t)nwork * 64));
         CK(hipEventRecord(e0));
-        if (waves == 1) hipLaunchKernelGGL(cx::k_rule64w<1, 4>, dim3(nwork), dim3(64), 0, 0, nwork, rec, d_tab, d_bt, zero, f2v, f2v, out);
-        else hipLaunchKernelGGL(cx::k_rule64w<2, 4>, dim3(nwork), dim3(64), 0, 0, nwork, rec, d_tab, d_bt, zero, f2v, f2v, out);
+        if (waves == 1) hipLaunchKernelGGL((cx::k_rule64w<1, 4>), dim3(nwork), dim3(64), 0, 0, nwork, rec, d_tab, d_bt, zero, f2v, f2v, out);
+        else hipLaunchKernelGGL((cx::k_rule64w<2, 4>), dim3(nwork), dim3(64), 0, 0, nwork, rec, d_tab, d_bt, zero, f2v, f2v, out);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         CK(hipMemcpy(hs.data(), stamps, (size_t)nwork * 64, hipMemcpyDeviceToHost));
