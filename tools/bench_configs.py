@@ -135,7 +135,7 @@ def mv(d, T, steps):
            "ms_per_sweep": dt * 1e3, "kernel_ms": ms / max(n, 1), "updates_per_sweep": upd, "updates_per_s": upd / dt,
            "algorithmic_GBps": upd * 2 * payload / dt / 1e9, "payload_bytes": payload}
     kern_s = ms / max(n, 1) / 1e3
-    tr = counter_traffic("k_rule64" if d == 64 else f"k_sweep_mv<{d},")
+    tr = counter_traffic("k_rule64w<2, 4>" if d == 64 else f"k_sweep_mv<{d},")
     alg = upd * 2 * payload
     if d == 64:
         # v_mfma_f64_16x16x4_f64 per factor→variable message, 2*16*16*4 flop each: 384 in the wave-per-message kernel
@@ -165,7 +165,7 @@ def mv(d, T, steps):
     return out
 
 
-def mv_tiles(d=16, T=100_000, steps=20, embedded_T=None):
+def mv_tiles(d=16, T=100_000, steps=20, embedded_T=None, native_only=False):
     """(round 6) a d-dimensional chain on the matrix-core path in its NATIVE tile size (d <= 16: one 16 x 16 tile, d <= 32: 2 x 2) beside the
     same kind of model embedded in 4 x 4 tiles (CX_MFMA_DIM=64: the only form until round 5; `embedded_T` states, default T — the embedding
     of T = 10^5 holds 40 GB): ms per fused sweep, ns per message, bytes per slot, MFMA rate.  The wave-per-message rule issues
@@ -174,7 +174,7 @@ def mv_tiles(d=16, T=100_000, steps=20, embedded_T=None):
     nt = nd // 16
     mfma = 4 * nt ** 3 + 2 * nt * nt * (nt + 1)
     rows = {}
-    for name, env, Tn in (("native", None, T), ("embedded_in_64", "64", embedded_T or T)):
+    for name, env, Tn in (("native", None, T), ("embedded_in_64", "64", embedded_T or T))[:1 if native_only else 2]:
         model = cx.synth.lgssm_chain(Tn, d=d, seed=1234)
         if env:
             os.environ["CX_MFMA_DIM"] = env
@@ -192,6 +192,8 @@ def mv_tiles(d=16, T=100_000, steps=20, embedded_T=None):
         rows[name] = {"states": Tn, "ms_per_sweep": dt * 1e3, "kernel_ms": ms / max(n, 1), "ns_per_message": dt * 1e9 / (2 * (Tn - 1)),
                       "device_bytes": st["device_bytes"], "bytes_per_slot": st["device_bytes"] / st["n_slots"]}
         dev.close()
+    if native_only:      # (under the profilers: the native kernel's launches alone)
+        return {"config": f"d={d} native tiles", "native": rows["native"]}
     # the same two forms under the chain-scan schedule: ONE exact sweep (the smoother at every state)
     for name, env, Tn in (("native", None, T), ("embedded_in_64", "64", embedded_T or T)):
         model = cx.synth.lgssm_chain(Tn, d=d, seed=1234)
@@ -208,6 +210,7 @@ def mv_tiles(d=16, T=100_000, steps=20, embedded_T=None):
         dev.close()
     nmsg = 2 * (T - 1)
     kern_s = rows["native"]["kernel_ms"] * 1e-3
+    tr = counter_traffic(f"k_rule64w<4, {nt}>") if T == 100_000 else None      # (profiled at this size: tools/profile_configs.sh)
     tf = nmsg * mfma * 2048 / kern_s / 1e12
     payload = (nd + nd * nd) * 8
     return {"config": f"d={d} native tiles", "workload": f"d={d} linear-Gaussian chain T={T}, fused flooding sweep, {nt} x {nt} tiles of 16 (the embedding in 4 x 4 tiles beside it)",
@@ -215,8 +218,8 @@ def mv_tiles(d=16, T=100_000, steps=20, embedded_T=None):
             "speedup_over_embedding": rows["embedded_in_64"]["ns_per_message"] / rows["native"]["ns_per_message"],
             "chain_scan_speedup_over_embedding": rows["embedded_in_64"]["chain_scan"]["ns_per_state"] / rows["native"]["chain_scan"]["ns_per_state"],
             "bytes_ratio": rows["native"]["bytes_per_slot"] / rows["embedded_in_64"]["bytes_per_slot"], "bytes_ratio_of_records": (nd + nd * nd) / (64 + 64 * 64),
-            "roofline": roofline("hbm", nmsg * 2 * payload / kern_s / 1e9, HBM_PEAK_GBS, "GB/s", None, kernel=f"k_rule64w<4, {nt}>", avg_kernel_ms=kern_s * 1e3,
-                                 basis=f"record bytes ({2 * payload} B per message: read + written) / avg launch duration; no counter traffic collected",
+            "roofline": roofline("hbm", (tr[0] if tr else nmsg * 2 * payload) / kern_s / 1e9, HBM_PEAK_GBS, "GB/s", tr[0] if tr else None, kernel=f"k_rule64w<4, {nt}>", avg_kernel_ms=kern_s * 1e3,
+                                 basis=(f"counter bytes per launch ({tr[1]}) / avg launch duration" if tr else f"record bytes ({2 * payload} B per message: read + written) / avg launch duration; no counter traffic on file"),
                                  mfma_per_message=mfma, mfma_TFLOPs=tf, frac_of_f64_matrix_peak=tf / F64_MATRIX_PEAK_TF,
                                  frac_survey_convention=nmsg * 2 * payload / kern_s / 1e9 / HBM_PEAK_GBS,
                                  bound_detail=f"a message of {nt} x {nt} tiles is {payload} B and {mfma} matrix instructions behind {16 * nt} dependent pivot steps: "
@@ -617,6 +620,9 @@ if __name__ == "__main__":
             continue
         if w.startswith("tree"):                         # tree | tree:deep
             print(json.dumps(tree(shape=w.split(":")[1] if ":" in w else "random")), flush=True)
+            continue
+        if w.startswith("tilesn"):                       # tilesn:16 — the native kernel's sweeps alone (the profilers' form)
+            print(json.dumps(mv_tiles(int(w.split(":")[1]) if ":" in w else 16, native_only=True)), flush=True)
             continue
         if w.startswith("tiles"):                        # tiles | tiles:8 | tiles:32 (the user's dim)
             print(json.dumps(mv_tiles(int(w.split(":")[1]) if ":" in w else 16)), flush=True)

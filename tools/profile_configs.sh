@@ -10,7 +10,7 @@ mkdir -p $O
 export TMPDIR=/tmp
 export CX_BENCH_REPS=1      # one batch per row: the summaries count launches per iteration
 cd /tmp
-B="python3 $R/tools/bench_configs.py c2 c3 c3scan c5"
+B="python3 $R/tools/bench_configs.py c2 c3 c3scan c5 tilesn:16"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B > $O/trace.log 2>&1 || { tail -5 $O/trace.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B > $O/fetch.log 2>&1 || { tail -5 $O/fetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $B > $O/write.log 2>&1 || { tail -5 $O/write.log; exit 1; }

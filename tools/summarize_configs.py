@@ -48,11 +48,11 @@ def main():
     res = {"tag": a.tag, "kernels": {}, "traffic": {}}
     lines = [f"# rocprofv3 summary: configs C2 / C3 / C5 ({a.tag})", "",
              "`tools/profile_configs.sh`: `rocprofv3 --kernel-trace --stats`, then `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes, "
-             "each over `python3 tools/bench_configs.py c2 c3 c5`.  HBM bytes = FETCH_SIZE x 1024 x 2 (gfx950 counts 64 B per 128-B request: "
+             "each over `python3 tools/bench_configs.py c2 c3 c3scan c5 tilesn:16`.  HBM bytes = FETCH_SIZE x 1024 x 2 (gfx950 counts 64 B per 128-B request: "
              "MI355X_MICROARCH.md §HBM; x2.000 measured for 4/8/16 B-per-lane streams, profiles/r01_rocprof.md) + WRITE_SIZE x 1024, "
              "at the L2-fabric side (Infinity-Cache hits included).", "",
              "| kernel | calls | avg us | median us | HBM read MB / launch | HBM write MB / launch | GB/s at the median |", "|---|---|---|---|---|---|---|"]
-    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1]))[:16]:
+    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1]))[:20]:
         res["kernels"][k] = {"calls": len(v), "avg_us": sum(v) / len(v), "median_us": med(v)}
         rd = med(fetch[k]) * 1024 * 2 if k in fetch else None
         wr = med(write[k]) * 1024 if k in write else None
@@ -75,7 +75,7 @@ def main():
             util = pm["SQ_VALU_MFMA_BUSY_CYCLES"] / (pm["GRBM_GUI_ACTIVE"] / 8 * 256 * 4)
             pm["mfma_util"] = util
             lines += ["", f"MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CU x 4 SIMD) = **{util:.3f}**"]
-        k64 = [k for k in dur if "k_rule64" in k]
+        k64 = [k for k in dur if "k_rule64w<2, 4>" in k] or [k for k in dur if "k_rule64" in k]      # (C5's: the d = 16 row runs k_rule64w<4, 1>)
         if "SQ_INSTS_MFMA" in pm and k64:
             t = med(dur[k64[0]]) * 1e-6
             tf = pm["SQ_INSTS_MFMA"] * 2048 / t / 1e12
