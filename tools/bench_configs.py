@@ -105,7 +105,7 @@ def c2(check=None):
     dtf = timed(fl, lambda: fl.sweep(1), 200, 20)
     nf = fl.stats()["n_messages_per_sweep"]
     one = dev.chain_scan_stats()["launches"] > 0      # (round 6) the scan as ONE launch: k_chain_onepass
-    tr = counter_traffic(["k_chain_onepass"] if one else ["k_chain_run_totals", "k_chain_run_apply"])   # the steady-state launches of one sweep
+    tr = counter_traffic(["k_chain_onepass<4, 256, true"] if one else ["k_chain_run_totals", "k_chain_run_apply"])      # (the instance that also writes the marginals: every sweep but a handle's first)   # the steady-state launches of one sweep
     alg = (5 * T - 4) * 32
     achieved = (tr[0] if tr else alg) / dt / 1e9
     return {"config": "C2", "workload": f"scalar chain T={T} ({st['n_edges']} edges), chain-scan schedule: exact forward/backward in one sweep",
