@@ -223,7 +223,7 @@ def test_checkpoint_round_trip_under_the_chain_schedule(hip_lib):
     assert_close(other.get_marginals(model.x_ids), want, 1e-12, "a sweep after the import")
 
 
-@pytest.mark.parametrize("d,sensors,T", [(64, 3, 9), (64, 6, 7), (6, 4, 30)])
+@pytest.mark.parametrize("d,sensors,T", [(64, 3, 9), (64, 6, 7), (6, 4, 30), (16, 6, 7), (24, 3, 9), (32, 5, 12)])
 def test_chain_variables_of_degree_up_to_eight(hip_lib, d, sensors, T):
     """a chain whose states are observed by several sensors each (degree 2 + sensors, up to 8): a rule or a joint of the plan sums three
     sources — the side information of such a position is summed into one message first (k_side64) — ONE sweep == the joint solve"""
